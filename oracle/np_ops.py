@@ -1,0 +1,196 @@
+"""float64 NumPy restatement of every primitive on the TwinGAN hot path (oracle, test-only).
+
+PARITY UNPINNED -- see ``oracle/__init__.py``.  All tensors are NHWC, weights HWIO
+``[kh, kw, Cin, Cout]`` exactly as the reference's TF variables.  Each function cites the
+reference lines (relative to /root/reference) it restates.
+"""
+import numpy as np
+
+F64 = np.float64
+
+
+def get_num_channels(stage, max_num_channels=256):
+  """nets/pggan_utils.py:369-372 (python-2 integer division)."""
+  return min(1024 // (2 ** stage), max_num_channels)
+
+
+# --------------------------------------------------------------------------------------------
+# conv / fc  (tf.contrib.layers.conv2d -> tf.nn.conv2d, called at nets/pggan_utils.py:316-320)
+# --------------------------------------------------------------------------------------------
+def same_pads(k):
+  """TF 'SAME', stride 1: total pad k-1, low side gets floor((k-1)/2)."""
+  lo = (k - 1) // 2
+  return lo, (k - 1) - lo
+
+
+def conv2d(x, w, padding='SAME'):
+  """Stride-1 cross-correlation, NHWC x HWIO.  nets/pggan_utils.py:95-97 (stride 1, SAME, k=3)."""
+  x = np.asarray(x, F64)
+  w = np.asarray(w, F64)
+  n, h, ww, cin = x.shape
+  kh, kw, cin2, cout = w.shape
+  assert cin == cin2
+  if padding == 'SAME':
+    (pt, pb), (pl, pr) = same_pads(kh), same_pads(kw)
+  else:
+    pt = pb = pl = pr = 0
+  xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+  ho = xp.shape[1] - kh + 1
+  wo = xp.shape[2] - kw + 1
+  y = np.zeros((n, ho, wo, cout), F64)
+  for i in range(kh):
+    for j in range(kw):
+      y += np.einsum('nhwc,co->nhwo', xp[:, i:i + ho, j:j + wo, :], w[i, j])
+  return y
+
+
+def conv2d_bwd_data(gy, w, in_hw, padding='SAME'):
+  """d conv2d / d x  (TF Conv2DBackpropInput)."""
+  gy = np.asarray(gy, F64)
+  w = np.asarray(w, F64)
+  kh, kw, cin, cout = w.shape
+  n, ho, wo, _ = gy.shape
+  h, ww = in_hw
+  if padding == 'SAME':
+    (pt, pb), (pl, pr) = same_pads(kh), same_pads(kw)
+  else:
+    pt = pb = pl = pr = 0
+  gxp = np.zeros((n, h + pt + pb, ww + pl + pr, cin), F64)
+  for i in range(kh):
+    for j in range(kw):
+      gxp[:, i:i + ho, j:j + wo, :] += np.einsum('nhwo,co->nhwc', gy, w[i, j])
+  return gxp[:, pt:pt + h, pl:pl + ww, :]
+
+
+def conv2d_bwd_weight(x, gy, ksize, padding='SAME'):
+  """d conv2d / d w  (TF Conv2DBackpropFilter)."""
+  x = np.asarray(x, F64)
+  gy = np.asarray(gy, F64)
+  kh, kw = ksize
+  n, ho, wo, cout = gy.shape
+  cin = x.shape[3]
+  if padding == 'SAME':
+    (pt, pb), (pl, pr) = same_pads(kh), same_pads(kw)
+  else:
+    pt = pb = pl = pr = 0
+  xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+  gw = np.zeros((kh, kw, cin, cout), F64)
+  for i in range(kh):
+    for j in range(kw):
+      gw[i, j] = np.einsum('nhwc,nhwo->co', xp[:, i:i + ho, j:j + wo, :], gy)
+  return gw
+
+
+def fully_connected(x, w, b=None):
+  """layers.fully_connected, nets/pggan_utils.py:323-327; weights [in, out]."""
+  y = np.asarray(x, F64) @ np.asarray(w, F64)
+  if b is not None:
+    y = y + np.asarray(b, F64)
+  return y
+
+
+# --------------------------------------------------------------------------------------------
+# pointwise / normalisation
+# --------------------------------------------------------------------------------------------
+def leaky_relu(x, alpha=0.2):
+  """util_misc.py:68-86: tf.maximum(alpha * x, x)."""
+  x = np.asarray(x, F64)
+  return np.maximum(alpha * x, x)
+
+
+def pixel_norm(x, eps=1e-6):
+  """nets/pggan_utils.py:330-331: x / sqrt(mean_C(x^2) + eps)."""
+  x = np.asarray(x, F64)
+  return x / np.sqrt(np.mean(np.square(x), axis=3, keepdims=True) + eps)
+
+
+def instance_norm(x, gamma, beta, eps=1e-6):
+  """libs/instance_norm.py:131-135: tf.nn.moments over (H,W) (biased variance), then
+  tf.nn.batch_normalization: inv = rsqrt(var+eps)*gamma ; y = x*inv + (beta - mean*inv)."""
+  x = np.asarray(x, F64)
+  mean = x.mean(axis=(1, 2), keepdims=True)
+  var = np.mean(np.square(x - mean), axis=(1, 2), keepdims=True)
+  inv = 1.0 / np.sqrt(var + eps) * np.asarray(gamma, F64)
+  return x * inv + (np.asarray(beta, F64) - mean * inv)
+
+
+def batch_norm_train(x, gamma, beta, eps=1e-3):
+  """libs/batch_norm.py:430,464-470 (training mode, no renorm): batch moments over (N,H,W),
+  epsilon = max(1e-3, 1.001e-5) (libs/batch_norm.py:48,464-468)."""
+  x = np.asarray(x, F64)
+  mean = x.mean(axis=(0, 1, 2), keepdims=True)
+  var = np.mean(np.square(x - mean), axis=(0, 1, 2), keepdims=True)
+  inv = 1.0 / np.sqrt(var + eps) * np.asarray(gamma, F64)
+  return x * inv + (np.asarray(beta, F64) - mean * inv)
+
+
+def bias_add(x, b):
+  return np.asarray(x, F64) + np.asarray(b, F64)
+
+
+def upsample2x(x):
+  """nets/pggan_utils.py:349-350: tf.image.resize_nearest_neighbor to (2h, 2w): out[i,j]=in[i//2,j//2]."""
+  x = np.asarray(x, F64)
+  return np.repeat(np.repeat(x, 2, axis=1), 2, axis=2)
+
+
+def avg_pool2(x):
+  """nets/pggan.py:274,306,436,468: tf.nn.avg_pool 2x2 stride 2 VALID."""
+  x = np.asarray(x, F64)
+  n, h, w, c = x.shape
+  return x.reshape(n, h // 2, 2, w // 2, 2, c).mean(axis=(2, 4))
+
+
+def lerp(new, old, alpha):
+  """nets/pggan.py:205,314,475: new * alpha + (1 - alpha) * old."""
+  return np.asarray(new, F64) * alpha + (1.0 - alpha) * np.asarray(old, F64)
+
+
+def minibatch_state_concat(x, eps=1e-8):
+  """nets/pggan_utils.py:353-366: sqrt(biased var over batch + eps) -> mean over everything ->
+  one scalar tiled to [N,4,4,1] and concatenated on C (4x4 is hard-coded in the reference)."""
+  x = np.asarray(x, F64)
+  mean = x.mean(axis=0, keepdims=True)
+  std = np.sqrt(np.mean(np.square(x - mean), axis=0, keepdims=True) + eps)
+  val = std.mean()
+  tile = np.full((x.shape[0], 4, 4, 1), val, F64)
+  return np.concatenate([x, tile], axis=3)
+
+
+# --------------------------------------------------------------------------------------------
+# losses (twingan.py:451-505, image_generation.py:318-439)
+# --------------------------------------------------------------------------------------------
+def absolute_difference(labels, predictions, weight=1.0):
+  """tf.losses.absolute_difference with scalar weight: mean(|p - l|) * w."""
+  return np.mean(np.abs(np.asarray(predictions, F64) - np.asarray(labels, F64))) * weight
+
+
+def wgan_d_loss(fake_pred, real_pred):
+  """image_generation.py:350: mean D(fake) - mean D(real)."""
+  return np.mean(fake_pred) - np.mean(real_pred)
+
+
+def wgan_g_loss(fake_pred):
+  """image_generation.py:333: -mean D(fake)."""
+  return -np.mean(fake_pred)
+
+
+def gradient_penalty(interp_grad, lam=10.0):
+  """image_generation.py:431-436: slopes = sqrt(sum_{h,w,c} g^2) (no eps); mean((slopes-1)^2)*lambda."""
+  g = np.asarray(interp_grad, F64)
+  slopes = np.sqrt(np.sum(np.square(g), axis=(1, 2, 3)))
+  return np.mean(np.square(slopes - 1.0)) * lam
+
+
+# --------------------------------------------------------------------------------------------
+# optimiser (model/model_inheritor.py:537-542 -> tf.train.AdamOptimizer)
+# --------------------------------------------------------------------------------------------
+def adam_step(theta, g, m, v, t, lr=1e-4, beta1=0.5, beta2=0.99, eps=1e-8):
+  """TF-1.x Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; theta -= lr_t*m/(sqrt(v)+eps).
+  ``t`` is the 1-based count of applies (shared by G and D: image_generation.py:554-561)."""
+  theta, g, m, v = (np.asarray(a, F64) for a in (theta, g, m, v))
+  lr_t = lr * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+  m = beta1 * m + (1.0 - beta1) * g
+  v = beta2 * v + (1.0 - beta2) * g * g
+  theta = theta - lr_t * m / (np.sqrt(v) + eps)
+  return theta, m, v

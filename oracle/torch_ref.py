@@ -1,0 +1,471 @@
+"""torch-CPU restatement of the TwinGAN training graph (oracle, test-only; also the timed CPU baseline).
+
+PARITY UNPINNED -- see ``oracle/__init__.py``.  Stock ``torch.nn.functional`` ops only; autograd
+supplies the reference gradients (incl. the WGAN-GP double backward).  Works in float32 or float64
+(dtype follows the parameters).  Public tensors are NHWC; parameters are keyed by the reference's
+TF variable names with TF layouts (conv HWIO, fc [in, out]).
+
+Restated files (all relative to /root/reference): nets/pggan.py, nets/pggan_utils.py,
+libs/instance_norm.py, util_misc.py:68-86, twingan.py:146-521,820-891,
+image_generation.py:318-439,543-662,1001-1006, model/model_inheritor.py:537-542,
+deployment/model_deploy.py:242-315.
+"""
+import math
+from dataclasses import dataclass, field
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class Config:
+  """The flags that shape the hot path (defaults = BASELINE.json / SURVEY.md section 8d)."""
+  hw: int = 256                      # train_image_size
+  max_ch: int = 256                  # pggan_max_num_channels            (nets/pggan.py:51-53)
+  norm: str = 'instance_norm'        # generator_norm_type               (nets/pggan.py:24)
+  do_pixel_norm: bool = True         # nets/pggan.py:34-38
+  use_unet: bool = True              # twingan.py:53-56
+  is_growing: bool = False           # image_generation.py:69-72
+  alpha_grow: float = 0.0
+  loss: str = 'wgan_gp'              # loss_architecture                 (image_generation.py:81-83)
+  gp_lambda: float = 10.0            # image_generation.py:92-95
+  gan_weight: float = 1.0            # image_generation.py:84-86
+  drift: float = 0.0                 # wgan_drift_loss_weight            (image_generation.py:96-98)
+  l_cyc: float = 1.0                 # twingan.py:73-76
+  l_content: float = 0.1             # twingan.py:80-82
+  do_l_cyc_gan: bool = True          # twingan.py:77-79
+  lr: float = 1e-4                   # docs/training.md:24-25
+  beta1: float = 0.5
+  beta2: float = 0.99
+  adam_eps: float = 1e-8
+  in_eps: float = 1e-6               # libs/instance_norm.py:37
+  pn_eps: float = 1e-6               # nets/pggan_utils.py:330
+  lrelu: float = 0.2                 # util_misc.py:68
+
+
+def get_num_channels(stage, max_num_channels=256):
+  """nets/pggan_utils.py:369-372 (py2 integer division)."""
+  return min(1024 // (2 ** stage), max_num_channels)
+
+
+def max_stage_of(hw):
+  """nets/pggan.py:126,218,425."""
+  return int(math.log2(hw)) - 2
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter construction (names: SURVEY.md Appendix C; init: nets/pggan_utils.py:56,93, pggan.py:364-368)
+# ------------------------------------------------------------------------------------------------
+def _conv_p(P, g, scope, k, cin, cout, norm_domains, bias, dtype, std=0.02):
+  if std == 'he':                    # test-only: O(1) activations so parity errors are visible
+    std = math.sqrt(2.0 / (k * k * cin))
+  P[scope + '/weights'] = torch.randn(k, k, cin, cout, generator=g, dtype=torch.float32).to(dtype) * std
+  if bias:
+    P[scope + '/biases'] = torch.zeros(cout, dtype=dtype)
+  for d in norm_domains:
+    P[scope + '/InstanceNorm/gamma_' + d] = torch.ones(cout, dtype=dtype)
+    P[scope + '/InstanceNorm/beta_' + d] = torch.zeros(cout, dtype=dtype)
+
+
+def encoder_param_specs(top, hw, max_ch, growing=False):
+  """[(scope, k, cin, cout)] for nets/pggan.py:403-479 (also the D skeleton, :242-315)."""
+  ms = max_stage_of(hw)
+  specs = []
+  if growing:
+    specs.append(('%s/from_rgb_%dx%d/Conv' % (top, hw // 2, hw // 2), 1, 3, get_num_channels(ms - 1, max_ch)))
+  c = get_num_channels(ms, max_ch)
+  specs.append(('%s/from_rgb_%dx%d/Conv' % (top, hw, hw), 1, 3, c))
+  for stage in range(ms, 0, -1):
+    cur = hw // (2 ** (ms - stage))
+    nc = get_num_channels(stage - 1, max_ch)
+    blk = '%s/encoder_block_%dx%dx%d' % (top, cur, cur, nc)
+    specs.append((blk + '/Conv', 3, c, c))
+    specs.append((blk + '/Conv_1', 3, c, nc))
+    c = nc
+  return specs
+
+
+def generator_param_specs(top, hw, max_ch, use_unet, growing=False):
+  """[(scope, k, cin, cout)] for nets/pggan.py:93-211 with a [B,4,4,C] source."""
+  ms = max_stage_of(hw)
+  specs = []
+  c = get_num_channels(0, max_ch)
+  blk = '%s/block_4x4x%d' % (top, c)
+  specs.append((blk + '/Conv', 3, c, c))      # source channels == ch(0) in TwinGAN
+  specs.append((blk + '/Conv_1', 3, c, c))
+  for stage in range(1, ms + 1):
+    cur = 2 ** (stage + 2)
+    oc = get_num_channels(stage, max_ch)
+    if stage == ms and growing:
+      specs.append(('%s/generator_to_rgb_%dx%d/Conv' % (top, cur // 2, cur // 2), 1, c, 3))
+    cin = c + (get_num_channels(stage - 1, max_ch) if use_unet else 0)
+    blk = '%s/block_%dx%dx%d' % (top, cur, cur, oc)
+    specs.append((blk + '/Conv', 3, cin, oc))
+    specs.append((blk + '/Conv_1', 3, oc, oc))
+    c = oc
+  specs.append(('%s/generator_to_rgb_%dx%d/Conv' % (top, hw, hw), 1, c, 3))
+  return specs
+
+
+def discriminator_tail_specs(top, max_ch):
+  blk = '%s/before_fc_1x1x%d' % (top, max_ch)
+  return [(blk + '/Conv', 3, max_ch + 1, max_ch), (blk + '/Conv_1', 4, max_ch, max_ch)]
+
+
+def init_params(cfg, seed=0, dtype=torch.float32, std=0.02):
+  """All TwinGAN variables for one progressive stage (twingan.py:105-110 scopes).  ``std=0.02`` is the
+  reference initialiser; ``std='he'`` is a test-only variant (also randomises biases / gamma / beta)."""
+  g = torch.Generator().manual_seed(seed)
+  P = {}
+  for s in encoder_param_specs('encoder_content', cfg.hw, cfg.max_ch, cfg.is_growing):
+    _conv_p(P, g, s[0], s[1], s[2], s[3], ('s', 't') if cfg.norm == 'instance_norm' else (), False, dtype, std)
+  for s in generator_param_specs('generator', cfg.hw, cfg.max_ch, cfg.use_unet, cfg.is_growing):
+    _conv_p(P, g, s[0], s[1], s[2], s[3], ('s', 't') if cfg.norm == 'instance_norm' else (), False, dtype, std)
+  for top in ('discriminator_s', 'discriminator_t'):
+    for s in encoder_param_specs(top, cfg.hw, cfg.max_ch, cfg.is_growing) + discriminator_tail_specs(top, cfg.max_ch):
+      _conv_p(P, g, s[0], s[1], s[2], s[3], (), True, dtype, std)
+    P[top + '/prediction/fully_connected/weights'] = \
+        torch.randn(cfg.max_ch, 1, generator=g, dtype=torch.float32).to(dtype) * \
+        (math.sqrt(1.0 / cfg.max_ch) if std == 'he' else 0.02)
+    P[top + '/prediction/fully_connected/biases'] = torch.zeros(1, dtype=dtype)
+  if std == 'he':
+    for k in sorted(P):
+      if k.endswith('/biases') or '/beta_' in k:
+        P[k] = (torch.randn(P[k].shape, generator=g, dtype=torch.float32) * 0.1).to(dtype)
+      elif '/gamma_' in k:
+        P[k] = (1.0 + torch.randn(P[k].shape, generator=g, dtype=torch.float32) * 0.1).to(dtype)
+  return P
+
+
+def generator_var_names(P):
+  """twingan.py:526-527: G step trains encoder_content, encoder_style, generator."""
+  return sorted(k for k in P if k.startswith(('encoder_content/', 'encoder_style/', 'generator/')))
+
+
+def discriminator_var_names(P):
+  """image_generation.py:484-485: every scope starting with 'discriminator'."""
+  return sorted(k for k in P if k.startswith('discriminator'))
+
+
+# ------------------------------------------------------------------------------------------------
+# primitives
+# ------------------------------------------------------------------------------------------------
+def conv2d(x, w, padding):
+  """NHWC x HWIO stride-1 conv via F.conv2d (TF SAME pads (k-1)//2 low, k//2 high)."""
+  kh, kw = w.shape[0], w.shape[1]
+  xc = x.permute(0, 3, 1, 2)
+  if padding == 'SAME':
+    pl, ph = (kh - 1) // 2, kh // 2
+    if pl != ph:
+      xc = F.pad(xc, ((kw - 1) // 2, kw // 2, pl, ph))
+      pad = 0
+    else:
+      pad = pl
+  else:
+    pad = 0
+  y = F.conv2d(xc, w.permute(3, 2, 0, 1), padding=pad)
+  return y.permute(0, 2, 3, 1)
+
+
+def leaky_relu(x, alpha=0.2):
+  return torch.maximum(alpha * x, x)             # util_misc.py:86
+
+
+def pixel_norm(x, eps=1e-6):
+  return x / torch.sqrt(torch.mean(x * x, dim=3, keepdim=True) + eps)   # pggan_utils.py:330-331
+
+
+def instance_norm(x, gamma, beta, eps=1e-6):
+  mean = x.mean(dim=(1, 2), keepdim=True)        # libs/instance_norm.py:131
+  var = ((x - mean) ** 2).mean(dim=(1, 2), keepdim=True)
+  inv = torch.rsqrt(var + eps) * gamma           # tf.nn.batch_normalization form, :134
+  return x * inv + (beta - mean * inv)
+
+
+def upsample2x(x):
+  return x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)      # pggan_utils.py:349-350
+
+
+def avg_pool2(x):
+  n, h, w, c = x.shape
+  return x.reshape(n, h // 2, 2, w // 2, 2, c).mean(dim=(2, 4))          # tf.nn.avg_pool 2x2 s2 VALID
+
+
+def minibatch_state_concat(x):
+  eps = 1e-8 if x.dtype in (torch.float32, torch.float64) else 1e-6      # pggan_utils.py:359
+  mean = x.mean(dim=0, keepdim=True)
+  std = torch.sqrt(((x - mean) ** 2).mean(dim=0, keepdim=True) + eps)
+  val = std.mean()
+  tile = val.reshape(1, 1, 1, 1).expand(x.shape[0], 4, 4, 1)
+  return torch.cat([x, tile], dim=3)
+
+
+# ------------------------------------------------------------------------------------------------
+# layers = arg-scoped conv (nets/pggan_utils.py:54-127,236-245): conv -> norm -> act, then pixel-norm
+# ------------------------------------------------------------------------------------------------
+def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=True):
+  """Generator/encoder conv: no bias (a normalizer is set), per-domain instance norm,
+  LeakyReLU, optional pixel norm (nets/pggan.py:78-81,387-391)."""
+  y = conv2d(x, P[scope + '/weights'], padding)
+  if cfg.norm == 'instance_norm':
+    y = instance_norm(y, P[scope + '/InstanceNorm/gamma_' + domain], P[scope + '/InstanceNorm/beta_' + domain],
+                      cfg.in_eps)
+  elif cfg.norm not in ('none', None):
+    raise NotImplementedError(cfg.norm)
+  if act:
+    y = leaky_relu(y, cfg.lrelu)
+  if pixnorm and cfg.do_pixel_norm:
+    y = pixel_norm(y, cfg.pn_eps)
+  return y
+
+
+def d_conv(P, scope, x, cfg, k=3, padding='SAME'):
+  """Discriminator conv: bias, no norm, LeakyReLU (nets/pggan_utils.py:116; slim bias rule)."""
+  y = conv2d(x, P[scope + '/weights'], padding) + P[scope + '/biases']
+  return leaky_relu(y, cfg.lrelu)
+
+
+# ------------------------------------------------------------------------------------------------
+# networks
+# ------------------------------------------------------------------------------------------------
+def encoder(P, x, domain, cfg, top='encoder_content'):
+  """nets/pggan.py:403-479 (encoder_before_classification).  Returns (net, end_points)."""
+  hw = x.shape[1]
+  ms = max_stage_of(hw)
+  ep = {'source': x}
+  shr = None
+  if cfg.is_growing:
+    shr = avg_pool2(x)
+    name = 'from_rgb_%dx%d' % (hw // 2, hw // 2)
+    shr = ge_conv(P, '%s/%s/Conv' % (top, name), shr, domain, cfg, k=1)
+    ep[name] = shr
+  name = 'from_rgb_%dx%d' % (hw, hw)
+  net = ge_conv(P, '%s/%s/Conv' % (top, name), x, domain, cfg, k=1)
+  ep[name] = net
+  for stage in range(ms, 0, -1):
+    nc = get_num_channels(stage - 1, cfg.max_ch)
+    cur = hw // (2 ** (ms - stage))
+    name = 'encoder_block_%dx%dx%d' % (cur, cur, nc)
+    net = ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg)
+    net = ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg)
+    ep[name] = net
+    cur //= 2
+    net = avg_pool2(net)
+    ep['downsample_to_%dx%dx%d' % (cur, cur, nc)] = net
+    if stage == ms and cfg.is_growing:
+      net = net * cfg.alpha_grow + (1 - cfg.alpha_grow) * shr
+      ep['encoder_block_interpolated_%dx%dx%d' % (cur, cur, nc)] = net
+  ep['before_classification'] = net
+  return net, ep
+
+
+def _concat_unet(layer, unet_ep, max_ch):
+  """nets/pggan_utils.py:281-298."""
+  if unet_ep is None:
+    return layer
+  hw = layer.shape[1]
+  nc = get_num_channels(max_stage_of(hw) - 1, max_ch)
+  name = 'encoder_block_interpolated_%dx%dx%d' % (hw, hw, nc)
+  if name not in unet_ep:
+    name = 'encoder_block_%dx%dx%d' % (hw, hw, nc)
+  if name not in unet_ep:
+    raise ValueError('%s not in unet_end_points' % name)
+  return torch.cat((layer, unet_ep[name]), dim=3)
+
+
+def generator(P, source, domain, cfg, unet_ep=None, top='generator'):
+  """nets/pggan.py:93-211 with a [B,4,4,C] source (TwinGAN mode).  Returns (output, end_points)."""
+  ms = max_stage_of(cfg.hw)
+  ep = {'source': source}
+  net = source
+  before_growth = None
+  hw = 4
+  for stage in range(0, ms + 1):
+    hw = 2 ** (stage + 2)
+    oc = get_num_channels(stage, cfg.max_ch)
+    name = 'block_%dx%dx%d' % (hw, hw, oc)
+    if hw == 4:
+      assert source.shape[1] == 4 and source.shape[2] == 4
+      net = ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg)
+      net = ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg)
+    else:
+      if stage == ms and cfg.is_growing:
+        rgb = 'generator_to_rgb_%dx%d' % (hw // 2, hw // 2)
+        before_growth = ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=1, act=False, pixnorm=False)
+        before_growth = upsample2x(before_growth)
+        ep[rgb] = before_growth
+      net = upsample2x(net)
+      net = _concat_unet(net, unet_ep, cfg.max_ch)
+      net = ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg)
+      net = ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg)
+    ep[name] = net
+  rgb = 'generator_to_rgb_%dx%d' % (hw, hw)
+  to_rgb = ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=1, act=False, pixnorm=False)
+  if cfg.is_growing:
+    out = to_rgb * cfg.alpha_grow + (1 - cfg.alpha_grow) * before_growth
+  else:
+    out = to_rgb
+  ep['output'] = out
+  return out, ep
+
+
+def discriminator(P, x, cfg, top):
+  """nets/pggan.py:242-376.  Returns (prediction [B,1], end_points)."""
+  hw = x.shape[1]
+  ms = max_stage_of(hw)
+  ep = {}
+  shr = None
+  if cfg.is_growing:
+    shr = avg_pool2(x)
+    name = 'from_rgb_%dx%d' % (hw // 2, hw // 2)
+    shr = d_conv(P, '%s/%s/Conv' % (top, name), shr, cfg, k=1)
+    ep[name] = shr
+  name = 'from_rgb_%dx%d' % (hw, hw)
+  net = d_conv(P, '%s/%s/Conv' % (top, name), x, cfg, k=1)
+  ep[name] = net
+  for stage in range(ms, 0, -1):
+    nc = get_num_channels(stage - 1, cfg.max_ch)
+    cur = hw // (2 ** (ms - stage))
+    name = 'encoder_block_%dx%dx%d' % (cur, cur, nc)
+    net = d_conv(P, '%s/%s/Conv' % (top, name), net, cfg)
+    net = d_conv(P, '%s/%s/Conv_1' % (top, name), net, cfg)
+    ep[name] = net
+    net = avg_pool2(net)
+    if stage == ms and cfg.is_growing:
+      net = net * cfg.alpha_grow + (1 - cfg.alpha_grow) * shr
+  blk = '%s/before_fc_1x1x%d' % (top, cfg.max_ch)
+  net = minibatch_state_concat(net)
+  net = d_conv(P, blk + '/Conv', net, cfg, k=3, padding='SAME')
+  net = d_conv(P, blk + '/Conv_1', net, cfg, k=4, padding='VALID')
+  ep['before_fc'] = net
+  feat = net.reshape(net.shape[0], -1)
+  pred = feat @ P[top + '/prediction/fully_connected/weights'] + P[top + '/prediction/fully_connected/biases']
+  ep['prediction'] = pred
+  return pred, ep
+
+
+def growing_image(img, alpha):
+  """image_generation.py:1001-1006."""
+  return alpha * img + (1 - alpha) * upsample2x(avg_pool2(img))
+
+
+# ------------------------------------------------------------------------------------------------
+# the per-clone graph and its losses (twingan.py:146-521)
+# ------------------------------------------------------------------------------------------------
+def forward_generators(P, sources, targets, cfg):
+  """twingan.py:198-288: E(s), E(t), the four generator passes, and the two re-encodes."""
+  es, es_ep = encoder(P, sources, 's', cfg)
+  et, et_ep = encoder(P, targets, 't', cfg)
+  unet = cfg.use_unet
+  s_prime, _ = generator(P, et, 's', cfg, et_ep if unet else None)      # target content -> source domain
+  s_cycle, _ = generator(P, es, 's', cfg, es_ep if unet else None)
+  t_prime, _ = generator(P, es, 't', cfg, es_ep if unet else None)
+  t_cycle, _ = generator(P, et, 't', cfg, et_ep if unet else None)
+  return dict(es=es, et=et, s_prime=s_prime, s_cycle=s_cycle, t_prime=t_prime, t_cycle=t_cycle)
+
+
+def generator_loss(P, sources, targets, cfg):
+  """Sum of GENERATOR_LOSSES (twingan.py:464-505; image_generation.py:331-337)."""
+  assert cfg.loss in ('wgan_gp', 'wgan')
+  if cfg.is_growing:
+    sources, targets = growing_image(sources, cfg.alpha_grow), growing_image(targets, cfg.alpha_grow)
+  o = forward_generators(P, sources, targets, cfg)
+  e_tp, _ = encoder(P, o['t_prime'], 't', cfg)
+  e_sp, _ = encoder(P, o['s_prime'], 's', cfg)
+  terms = {}
+  for d, orig, prime, cyc, enc_orig, enc_opp_prime in (
+      ('s', sources, o['s_prime'], o['s_cycle'], o['es'], e_tp),
+      ('t', targets, o['t_prime'], o['t_cycle'], o['et'], e_sp)):
+    top = 'discriminator_' + d
+    terms['l_cyc_' + d] = (orig - cyc).abs().mean() * cfg.l_cyc
+    if cfg.hw >= 64 and cfg.do_l_cyc_gan:
+      pc, _ = discriminator(P, cyc, cfg, top)
+      terms['generator_fool_loss_cycle_' + d] = -pc.mean() * cfg.gan_weight
+    pp, _ = discriminator(P, prime, cfg, top)
+    terms['generator_fool_loss_prime_' + d] = -pp.mean() * cfg.gan_weight
+    if cfg.l_content:
+      terms['l_content_' + d] = (enc_orig - enc_opp_prime).abs().mean() * cfg.l_content
+  return sum(terms.values()), terms
+
+
+def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t):
+  """Sum of DISCRIMINATOR_LOSSES (image_generation.py:348-379,414-439).  ``gp_alpha_*`` are the
+  per-sample U[0,1) draws, shape [B,1,1,1].  E/G run without grad: only D variables are in the
+  var_list (image_generation.py:605-610)."""
+  assert cfg.loss in ('wgan_gp', 'wgan')
+  if cfg.is_growing:
+    sources, targets = growing_image(sources, cfg.alpha_grow), growing_image(targets, cfg.alpha_grow)
+  with torch.no_grad():
+    o = forward_generators(P, sources, targets, cfg)
+  terms = {}
+  for d, real, prime, cyc, a in (('s', sources, o['s_prime'], o['s_cycle'], gp_alpha_s),
+                                 ('t', targets, o['t_prime'], o['t_cycle'], gp_alpha_t)):
+    top = 'discriminator_' + d
+    pr, _ = discriminator(P, real, cfg, top)
+    if cfg.hw >= 64 and cfg.do_l_cyc_gan:
+      pc, _ = discriminator(P, cyc, cfg, top)
+      terms['discriminator_loss_cycle_' + d] = (pc.mean() - pr.mean()) * cfg.gan_weight
+    pp, _ = discriminator(P, prime, cfg, top)
+    terms['discriminator_loss_prime_' + d] = (pp.mean() - pr.mean()) * cfg.gan_weight
+    if cfg.drift:
+      terms['discriminator_drift_loss_prime_' + d] = cfg.drift * (pr ** 2).mean()
+    if cfg.loss == 'wgan_gp':
+      interp = (real + a * (prime - real)).detach().requires_grad_(True)
+      pi, _ = discriminator(P, interp, cfg, top)
+      gi, = torch.autograd.grad(pi.sum(), interp, create_graph=True)     # tf.gradients(pred, interp)
+      slopes = torch.sqrt((gi ** 2).sum(dim=(1, 2, 3)))
+      terms['discriminator_gradient_penalty_prime_' + d] = ((slopes - 1.0) ** 2).mean() * cfg.gp_lambda
+  return sum(terms.values()), terms
+
+
+# ------------------------------------------------------------------------------------------------
+# optimisation (image_generation.py:587-662; TF Adam)
+# ------------------------------------------------------------------------------------------------
+class AdamState:
+  """One tf.train.AdamOptimizer shared by G and D (image_generation.py:554-561): a single pair of
+  beta-power accumulators that advances on every apply."""
+
+  def __init__(self, P, cfg):
+    self.m = {k: torch.zeros_like(v) for k, v in P.items()}
+    self.v = {k: torch.zeros_like(v) for k, v in P.items()}
+    self.t = 0
+    self.cfg = cfg
+
+  def apply(self, P, grads):
+    c = self.cfg
+    self.t += 1
+    lr_t = c.lr * math.sqrt(1.0 - c.beta2 ** self.t) / (1.0 - c.beta1 ** self.t)
+    with torch.no_grad():
+      for k, g in grads.items():
+        self.m[k].mul_(c.beta1).add_(g, alpha=1 - c.beta1)
+        self.v[k].mul_(c.beta2).addcmul_(g, g, value=1 - c.beta2)
+        P[k].sub_(lr_t * self.m[k] / (self.v[k].sqrt() + c.adam_eps))
+
+
+def grads_of(loss, P, names):
+  ps = [P[k] for k in names]
+  gs = torch.autograd.grad(loss, ps, allow_unused=True)
+  return {k: (g if g is not None else torch.zeros_like(P[k])) for k, g in zip(names, gs)}
+
+
+def train_step(P, opt, sources, targets, cfg, gp_alpha_s, gp_alpha_t, counter, literal_schedule=False):
+  """One ``session.run(train_op)`` (image_generation.py:640-652): counter % n_critic == 0 -> apply G
+  grads, else D grads.  ``literal_schedule`` also computes the un-applied gradient set, as the
+  reference graph does (image_generation.py:631-639)."""
+  for v in P.values():
+    v.requires_grad_(True)
+  g_names, d_names = generator_var_names(P), discriminator_var_names(P)
+  is_g = (counter % 2 == 0)
+  out = {}
+  if is_g or literal_schedule:
+    gl, _ = generator_loss(P, sources, targets, cfg)
+    gg = grads_of(gl, P, g_names)
+    out['g_loss'] = float(gl.detach())
+  if (not is_g) or literal_schedule:
+    dl, _ = discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t)
+    dg = grads_of(dl, P, d_names)
+    out['d_loss'] = float(dl.detach())
+  for v in P.values():
+    v.requires_grad_(False)
+  opt.apply(P, gg if is_g else dg)
+  return out
