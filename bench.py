@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py -- TwinGAN G+D training images/sec at the 256x256 final progressive stage on MI355X.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1: one rank per GPU under
+torch.distributed.run, RCCL).  One "step" = one full G+D step = one generator/encoder apply + one
+discriminator apply (n_critic = 2, image_generation.py:640-652) over one synthetic batch of
+``--batch`` (source, target) pairs per GPU, inputs resident in HBM.  value = pairs/sec over all ranks.
+
+Extra objects on the JSON line (rank 0, N = 1): ``roofline`` for the dominant kernel family (HIP
+events around every launch in a separate instrumented pass of the same step) and ``cpu_baseline``
+(the torch-CPU oracle timed on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0              # HBM3E spec (6.3 TB/s achievable)
+GFLOP_PER_PAIR_256 = 335.0         # conv+FC MACs*2 of one G+D step at 256x256
+
+
+def parse():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=6)
+  ap.add_argument('--warmup', type=int, default=2)
+  ap.add_argument('--batch', type=int, default=16, help='pairs per GPU (BASELINE config: 16)')
+  ap.add_argument('--hw', type=int, default=256)
+  ap.add_argument('--max-ch', type=int, default=256)
+  ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+  ap.add_argument('--no-roofline', action='store_true')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--cpu-batch', type=int, default=1)
+  return ap.parse_args()
+
+
+def synthetic_batch(batch, hw, dtype, device, rank):
+  """a_source ~ U[0,1) seed 1234 (CelebA-shaped), b_source ~ U[0,1) seed 4321 (Getchu-shaped)."""
+  ga = torch.Generator().manual_seed(1234 + rank)
+  gb = torch.Generator().manual_seed(4321 + rank)
+  a = torch.rand(batch, hw, hw, 3, generator=ga).to(device).to(dtype).contiguous()
+  b = torch.rand(batch, hw, hw, 3, generator=gb).to(device).to(dtype).contiguous()
+  return a, b
+
+
+def one_step(tr, a, b):
+  tr.run(a, b)      # generator / encoder apply   (n_critic_counter % 2 == 0)
+  tr.run(a, b)      # discriminator apply (GP alphas drawn on device)
+
+
+def roofline_pass(tr, a, b, steps=2):
+  """Re-runs the same step with HIP events around every kernel launch (on the launch stream) and
+  aggregates per kernel family."""
+  from twingan_amd import _lib
+  rec = []
+  _lib.profiler = rec
+  for _ in range(steps):
+    one_step(tr, a, b)
+  torch.cuda.synchronize()
+  _lib.profiler = None
+  fam = {}
+  for name, tag, fl, by, e0, e1 in rec:
+    ms = e0.elapsed_time(e1)
+    key = name if not tag else '%s[%s]' % (name, tag.split(':')[0] + ':' + tag.split(':')[1] if ':' in tag else tag)
+    f = fam.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+    f['ms'] += ms
+    f['flops'] += fl
+    f['bytes'] += by
+    f['launches'] += 1
+  total_ms = sum(f['ms'] for f in fam.values())
+  top = sorted(fam.items(), key=lambda kv: -kv[1]['ms'])
+  detail = []
+  for k, f in top[:12]:
+    detail.append(dict(kernel=k, share=round(f['ms'] / total_ms, 4), launches=f['launches'] // steps,
+                       avg_us=round(1e3 * f['ms'] / f['launches'], 2),
+                       tflops=round(f['flops'] / (f['ms'] * 1e-3) / 1e12, 2) if f['ms'] else 0.0,
+                       gbs=round(f['bytes'] / (f['ms'] * 1e-3) / 1e9, 1) if f['ms'] else 0.0))
+  k, f = top[0]
+  is_conv = 'conv2d' in k
+  if is_conv:
+    achieved = f['flops'] / (f['ms'] * 1e-3) / 1e12
+    roof = dict(bound='mfma', achieved=round(achieved, 2), peak=BF16_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                frac=round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), traffic=None)
+  else:
+    achieved = f['bytes'] / (f['ms'] * 1e-3) / 1e9
+    roof = dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None)
+  roof['kernel'] = k
+  roof['avg_launch_us'] = round(1e3 * f['ms'] / f['launches'], 2)
+  roof['hbm_algorithmic_gbs'] = round(f['bytes'] / (f['ms'] * 1e-3) / 1e9, 1)
+  roof['kernel_time_ms_per_step'] = round(total_ms / steps, 3)
+  roof['families'] = detail
+  return roof
+
+
+def cpu_baseline(args):
+  """torch-CPU oracle (kind 'port': the TF-1.8 reference cannot run here) on a bounded sample:
+  one G+D step (efficient schedule) at the bench resolution with a reduced batch."""
+  from oracle import torch_ref as R
+  cores = os.cpu_count() or 1
+  torch.set_num_threads(cores)
+  rcfg = R.Config(hw=args.hw, max_ch=args.max_ch)
+  P = R.init_params(rcfg, seed=0)
+  opt = R.AdamState(P, rcfg)
+  g = torch.Generator().manual_seed(1234)
+  bsz = args.cpu_batch
+  s, t = torch.rand(bsz, args.hw, args.hw, 3, generator=g), torch.rand(bsz, args.hw, args.hw, 3, generator=g)
+  al = torch.rand(bsz, 1, 1, 1, generator=g)
+  t0 = time.time()
+  R.train_step(P, opt, s, t, rcfg, al, al, counter=0)
+  R.train_step(P, opt, s, t, rcfg, al, al, counter=1)
+  dt = time.time() - t0
+  return dict(value=round(bsz / dt, 4), unit='images/sec', cores=cores, kind='port',
+              sample='1 G+D step, batch %d at %dx%d, fp32 torch-CPU oracle, efficient schedule, %.1f s' % (
+                  bsz, args.hw, args.hw, dt))
+
+
+def main():
+  args = parse()
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+  else:
+    torch.cuda.set_device(0)
+  device = torch.device('cuda', local_rank if world > 1 else 0)
+
+  from twingan_amd import Config
+  from twingan_amd.twingan import Trainer
+  cfg = Config(hw=args.hw, max_ch=args.max_ch, precision=args.precision)
+  tr = Trainer(cfg, device=device, seed=0, world_size=world)
+  dtype = torch.bfloat16 if args.precision == 'bf16' else torch.float32
+  a, b = synthetic_batch(args.batch, args.hw, dtype, device, rank)
+
+  for _ in range(args.warmup):
+    one_step(tr, a, b)
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    one_step(tr, a, b)
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+
+  ms_per_step = 1e3 * elapsed / args.steps
+  value = args.batch * world * args.steps / elapsed
+  out = {
+      'metric': 'training images/sec (G+D step) at 256x256 final stage' if args.hw == 256 else
+                'training images/sec (G+D step) at %dx%d' % (args.hw, args.hw),
+      'value': round(value, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+      'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+      'dtype': args.precision, 'data': 'synthetic',
+      'config': {'workload': 'TwinGAN %dx%d final stage (configs[3]): E/G/2xD max_ch %d, UNet + per-domain '
+                             'instance norm + pixel norm, WGAN-GP, Adam; 1 step = G apply + D apply' % (
+                                 args.hw, args.hw, args.max_ch),
+                 'global_batch': args.batch * world, 'batch_per_gpu': args.batch, 'parallelism': 'dp%d' % world,
+                 'gflop_per_pair_model': GFLOP_PER_PAIR_256 if args.hw == 256 else None},
+  }
+  if args.hw == 256:
+    tf = value * GFLOP_PER_PAIR_256 / 1e3 / world
+    out['step_mfma_frac'] = round(tf / BF16_MFMA_PEAK_TFLOPS, 4)       # whole-step fraction of the conv roofline
+  if rank == 0 and world == 1:
+    if not args.no_roofline:
+      out['roofline'] = roofline_pass(tr, a, b)
+    if not args.no_cpu_baseline:
+      del tr
+      torch.cuda.empty_cache()
+      out['cpu_baseline'] = cpu_baseline(args)
+  if rank == 0:
+    print(json.dumps(out))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

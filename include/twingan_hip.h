@@ -1,0 +1,209 @@
+/*
+ * twingan_hip.h -- C ABI of libtwingan_hip.so: the MI355X (gfx950) kernels behind the TwinGAN
+ * G+D training hot path.
+ *
+ * The reference (jerryli27/TwinGAN) has no FFI: its "operator API" for this path is the Python op
+ * facade libs/ops.py:28-40 + nets/pggan_utils.py maybe_* helpers, which dispatch to stock TF-1.8
+ * kernels.  Each entry point below names the reference call site (file:line under /root/reference)
+ * whose TF kernel(s) it replaces.  twingan_amd/_lib.py is the ctypes binding; INTEGRATION.md shows
+ * the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - all activation tensors are NHWC, C-contiguous, 16-byte aligned base pointers;
+ *   - `dtype` selects the activation storage type: TG_F32 or TG_BF16; accumulation is always fp32;
+ *   - conv weights are TF HWIO [kh][kw][cin][cout] fp32 ("master") unless a parameter says "packed";
+ *   - the caller owns all memory; the library never allocates device memory and never synchronises;
+ *     kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream);
+ *   - return value: 0 = success, negative TG_E* = failure; tg_last_error() returns a thread-local
+ *     message.  Nothing is enqueued when an error is returned.
+ */
+#ifndef TWINGAN_HIP_H_
+#define TWINGAN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TG_F32 0
+#define TG_BF16 1
+
+#define TG_OK 0
+#define TG_EINVAL (-1)   /* bad shape / dtype / flag combination */
+#define TG_EALIGN (-2)   /* pointer or channel count not aligned as required */
+#define TG_ELAUNCH (-3)  /* hipLaunchKernel reported an error */
+#define TG_ENOSUP (-4)   /* combination not implemented by the selected algorithm */
+
+/* Conv algorithm selector */
+#define TG_ALGO_DIRECT 0 /* one thread per output, any shape, f32 or bf16 activations */
+#define TG_ALGO_MFMA 1   /* LDS-tiled implicit GEMM on v_mfma_f32_32x32x16_bf16, bf16 activations only */
+
+/* Epilogue / prologue flags */
+#define TG_EPI_BIAS 1
+#define TG_EPI_LRELU 2
+
+int tg_version(void);
+const char* tg_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution: stride 1, kh,kw <= 4, arbitrary zero padding (pad_t/pad_l on the low side; the
+ * high side follows from hout/wout).  Replaces tf.contrib.layers.conv2d -> Conv2D /
+ * Conv2DBackpropInput / Conv2DBackpropFilter at nets/pggan_utils.py:316-320 (every E/G/D conv in
+ * nets/pggan.py) and the 4x4 VALID convs at nets/pggan.py:153,330,495.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t n, hin, win, cin;   /* input  [n,hin,win,cin]  (cin = physical channels)           */
+  int32_t hout, wout, cout;   /* output [n,hout,wout,cout]                                   */
+  int32_t kh, kw, pad_t, pad_l;
+  int32_t dtype;              /* TG_F32 | TG_BF16 (activations x, y, gy, gx)                 */
+  int32_t algo;               /* TG_ALGO_*                                                   */
+  int32_t epilogue;           /* TG_EPI_* bits (forward only)                                */
+  float lrelu_alpha;          /* util_misc.py:68 (0.2)                                       */
+} TgConvDesc;
+
+/* y = epilogue(conv(x, w)).  DIRECT: w = fp32 HWIO master (rounded to bf16 on read when dtype is
+ * bf16).  MFMA: w = bf16 pack from tg_conv2d_pack_weights(mode 0).  bias: fp32 [cout] or NULL. */
+int tg_conv2d_fwd(const TgConvDesc* d, const void* x, const void* w, const float* bias, void* y, void* stream);
+
+/* gx = d conv / d x applied to gy (Conv2DBackpropInput).  `d` is the FORWARD descriptor.
+ * DIRECT: w = fp32 HWIO master.  MFMA: w = bf16 pack from tg_conv2d_pack_weights(mode 1). */
+int tg_conv2d_bwd_data(const TgConvDesc* d, const void* gy, const void* w, void* gx, void* stream);
+
+/* gw (fp32 HWIO) = d conv / d w (Conv2DBackpropFilter), `d` is the FORWARD descriptor.
+ * workspace: tg_conv2d_bwd_weight_workspace(d) bytes (split-K partial slabs; may be 0/NULL).
+ * accumulate != 0 adds into gw instead of overwriting it. */
+size_t tg_conv2d_bwd_weight_workspace(const TgConvDesc* d);
+int tg_conv2d_bwd_weight(const TgConvDesc* d, const void* x, const void* gy, float* gw, int accumulate,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* bf16 K-contiguous weight packs for the MFMA kernels, from the fp32 HWIO master (`d` = forward
+ * descriptor; a kxk VALID conv on a kxk input is packed as the equivalent dense 1x1 over k*k*cin).
+ * mode 0 (forward):  out[co][tap][ci]        = w[tap][ci][co]
+ * mode 1 (bwd data): out[ci][tap'][co]       = w[ntaps-1-tap'][ci][co]   (180-degree rotated taps)
+ * rows (first index) are padded to a multiple of 64 and the innermost index to a multiple of 16,
+ * zero filled.  tg_conv2d_pack_elems returns the element count of the pack. */
+size_t tg_conv2d_pack_elems(const TgConvDesc* d, int mode);
+int tg_conv2d_pack_weights(const TgConvDesc* d, const float* w_hwio, int mode, void* out_bf16, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 1x1 convs with a 3-channel side (fromRGB 3->C, toRGB C->3): pure-bandwidth VALU kernels.
+ * nets/pggan.py:233-240,395-399 (from_rgb), :176-178,198-200 (to_rgb).  w = fp32 [cin][cout].
+ * y = epilogue(x @ w).  bwd_data of one is the forward of the other with w transposed (wt != 0
+ * reads w as [cout][cin]).  bwd_weight: gw[cin][cout] = sum_pixels x^T gy.
+ * ------------------------------------------------------------------------------------------- */
+int tg_pointwise_conv_fwd(const void* x, const float* w, const float* bias, void* y, int64_t npix, int cin, int cout,
+                          int wt, int epilogue, float lrelu_alpha, int dtype, void* stream);
+int tg_pointwise_conv_bwd_weight(const void* x, const void* gy, float* gw, int64_t npix, int cin, int cout,
+                                 int accumulate, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Instance norm (+ LeakyReLU + pixel norm), libs/instance_norm.py:131-135, util_misc.py:68-86,
+ * nets/pggan_utils.py:330-331.  Layer order: conv -> norm -> act -> pixel-norm (pggan.py:78-81).
+ * ------------------------------------------------------------------------------------------- */
+/* mean[n*c], rstd[n*c] (fp32) over (h,w) of y[n,h,w,c]; biased variance, rstd = rsqrt(var+eps). */
+int tg_instance_norm_stats(const void* y, float* mean, float* rstd, int n, int h, int w, int c, float eps, int dtype,
+                           void* stream);
+/* z = pixnorm(lrelu((y-mean)*rstd*gamma + beta)); flags: bit0 lrelu, bit1 pixel-norm.
+ * gamma/beta fp32 [c].  pn_scale (fp32 [n*h*w], may be NULL unless pixel-norm) receives
+ * 1/sqrt(mean_c(a^2)+pn_eps) for the backward. */
+int tg_norm_act_fwd(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                    void* z, float* pn_scale, int n, int h, int w, int c, int flags, float lrelu_alpha, float pn_eps,
+                    int dtype, void* stream);
+/* Backward of tg_norm_act_fwd.  Inputs: gz, y (raw conv output), pn_scale, mean, rstd, gamma, beta.
+ * Outputs: gy (same dtype), ggamma[c], gbeta[c] (fp32, may be NULL; accumulate != 0 adds).
+ * sums: fp32 scratch [2*n*c] (zeroed by the call). */
+int tg_norm_act_bwd(const void* gz, const void* y, const float* pn_scale, const float* mean, const float* rstd,
+                    const float* gamma, const float* beta, void* gy, float* ggamma, float* gbeta, float* sums, int n,
+                    int h, int w, int c, int flags, float lrelu_alpha, int accumulate, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Discriminator pointwise: bias + LeakyReLU (nets/pggan_utils.py:116; slim BiasAdd) and pieces
+ * of its (double) backward.
+ * ------------------------------------------------------------------------------------------- */
+/* z = lrelu(y + bias) (bias may be NULL; alpha = 1 disables the activation) */
+int tg_bias_lrelu_fwd(const void* y, const float* bias, void* z, int64_t npix, int c, float alpha, int dtype,
+                      void* stream);
+/* gy = gz * (z > 0 ? 1 : alpha)   (also its own double backward wrt gz) */
+int tg_lrelu_bwd(const void* gz, const void* z, void* gy, int64_t numel, float alpha, int dtype, void* stream);
+/* out[c] (fp32) = sum over pixels of g[pix][c]  (BiasAddGrad) */
+int tg_channel_sum(const void* g, float* out, int64_t npix, int c, int accumulate, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Resampling / concat / fade-in.
+ * ------------------------------------------------------------------------------------------- */
+/* out[n,2h,2w,c0+c1] = concat(nearest_up2(x0[n,h,w,c0]), x1[n,2h,2w,c1]); c1 == 0 -> plain upsample.
+ * nets/pggan_utils.py:349-350 + :281-298 (generator features first). */
+int tg_upsample2x_concat_fwd(const void* x0, const void* x1, void* out, int n, int h, int w, int c0, int c1, int dtype,
+                             void* stream);
+/* g0[n,h,w,c0] = 2x2 sum of gout[..., :c0];  g1 = gout[..., c0:]  (either may be NULL to skip) */
+int tg_upsample2x_concat_bwd(const void* gout, void* g0, void* g1, int n, int h, int w, int c0, int c1, int dtype,
+                             void* stream);
+/* tf.nn.avg_pool 2x2 s2 VALID (nets/pggan.py:274,306,436,468): y[n,h/2,w/2,c]; scale=0.25.
+ * With scale=1 it is the 2x2 sum (upsample backward). */
+int tg_pool2x2_fwd(const void* x, void* y, int n, int h, int w, int c, float scale, int dtype, void* stream);
+/* gx[n,h,w,c] = scale * gy[n,h/2,w/2,c] replicated 2x2 (avg-pool backward with scale .25; plain upsample with 1) */
+int tg_pool2x2_bwd(const void* gy, void* gx, int n, int h, int w, int c, float scale, int dtype, void* stream);
+/* out = a*x + b*y (y may be NULL).  Fade-in lerp nets/pggan.py:205,314,475; image_generation.py:1006. */
+int tg_axpby(const void* x, const void* y, void* out, int64_t numel, float a, float b, int dtype, void* stream);
+/* out[b,...] = x[b,...] + alpha[b] * (y[b,...] - x[b,...])   (WGAN-GP interpolates, image_generation.py:424) */
+int tg_sample_lerp(const void* x, const void* y, const float* alpha, void* out, int batch, int64_t per_sample,
+                   int dtype, void* stream);
+/* out[b,...] = coef[b] * x[b,...] * scalar[0]   (coef fp32 [batch], scalar fp32 device pointer or NULL) */
+int tg_sample_scale(const void* x, const float* coef, const float* scalar, void* out, int batch, int64_t per_sample,
+                    int dtype, void* stream);
+/* out[i] = value * (scalar ? scalar[0] : 1)   (broadcast of a device scalar, e.g. d mean / d x) */
+int tg_fill_scaled(void* out, const float* scalar, float value, int64_t numel, int dtype, void* stream);
+int tg_cast(const void* src, void* dst, int64_t numel, int src_dtype, int dst_dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Minibatch stddev, nets/pggan_utils.py:353-366.  x[n, p] with p = h*w*c (4*4*C).
+ * out[n,h,w,cpad]: channels [0,c) copy x, channel c = the statistic, (c, cpad) = 0 so that the
+ * following 3x3 conv sees a 16-byte aligned channel count.  stat: fp32 [1].
+ * ------------------------------------------------------------------------------------------- */
+int tg_mbstd_fwd(const void* x, void* out, float* stat, int n, int hw, int c, int cpad, float eps, int dtype,
+                 void* stream);
+/* gx = gout[..., :c] + d stat/d x * sum(gout[..., c]) */
+int tg_mbstd_bwd(const void* gout, const void* x, void* gx, int n, int hw, int c, int cpad, float eps, int dtype,
+                 void* stream);
+/* double backward: given v = grad wrt gx, returns ggout (grad wrt gout) and gx2 (grad wrt x). */
+int tg_mbstd_bwd_bwd(const void* v, const void* gout, const void* x, void* ggout, void* gx2, int n, int hw, int c,
+                     int cpad, float eps, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Small dense layers (layers.fully_connected, nets/pggan_utils.py:323-327; pggan.py:365-370):
+ * C[m,n] = op(A)[m,k] @ op(B)[k,n] (+ bias[n]); A,B,C fp32 row-major; ta/tb transpose flags.
+ * ------------------------------------------------------------------------------------------- */
+int tg_small_gemm(const float* a, const float* b, const float* bias, float* c, int m, int n, int k, int ta, int tb,
+                  int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Loss reductions (twingan.py:464,502; image_generation.py:333,350,431-433).  Outputs fp32.
+ * ------------------------------------------------------------------------------------------- */
+/* out[0] (+)= scale * sum(x) */
+int tg_sum(const void* x, float* out, int64_t numel, float scale, int accumulate, int dtype, void* stream);
+/* out[0] (+)= scale * sum|a-b| */
+int tg_abs_diff_sum(const void* a, const void* b, float* out, int64_t numel, float scale, int accumulate, int dtype,
+                    void* stream);
+/* ga = gscale[0]*scale*sign(a-b), gb = -ga  (either may be NULL) */
+int tg_abs_diff_bwd(const void* a, const void* b, const float* gscale, void* ga, void* gb, int64_t numel, float scale,
+                    int dtype, void* stream);
+/* out[b] = sum over the sample of x^2 */
+int tg_sample_sumsq(const void* x, float* out, int batch, int64_t per_sample, int dtype, void* stream);
+/* WGAN-GP scalar tail: loss[0] = lambda*mean_b (sqrt(ss[b])-1)^2 ; coef[b] = lambda*2*(sqrt(ss)-1)/(sqrt(ss)*batch) */
+int tg_gp_penalty(const float* sumsq, float* loss, float* coef, int batch, float lambda, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Adam, TF-1.x form (model/model_inheritor.py:537-542): theta -= lr_t * m / (sqrt(v) + eps) with
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller.  Flat fp32 buffers of `numel`
+ * elements; grad_scale multiplies g first (1/loss_scale).  theta_bf16 (may be NULL) receives the
+ * rounded copy of the updated parameters (cast-on-read shadow, deployment/model_deploy.py:146-183).
+ * ------------------------------------------------------------------------------------------- */
+int tg_adam_step(float* theta, const float* grad, float* m, float* v, void* theta_bf16, int64_t numel, float lr_t,
+                 float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TWINGAN_HIP_H_ */

@@ -1,0 +1,178 @@
+"""GPU parity of the full networks, losses, gradients (incl. the WGAN-GP double backward) and the
+alternating Adam step against the torch-CPU oracle on identical seeded inputs and weights.
+
+fp32 path (direct kernels): network outputs rel-L2 <= 1e-5 / max|d| <= 1e-4, gradients rel-L2 <= 1e-4.
+bf16 path (MFMA kernels, fp32 master weights): outputs rel-L2 <= 2e-2, gradients rel-L2 <= 6e-2
+(deep stacks of bf16 layers; per-primitive bounds are in test_gpu_ops.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import torch_ref as R       # noqa: E402  (checker only)
+
+
+def rel_l2(a, b):
+  a = a.detach().double().cpu().numpy()
+  b = b.detach().double().cpu().numpy()
+  assert a.shape == b.shape, (a.shape, b.shape)
+  return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def make(cfg_kw, precision, seed=0, batch=3):
+  from twingan_amd import Config
+  from twingan_amd.twingan import Trainer
+  cfg = Config(precision=precision, **cfg_kw)
+  rcfg = R.Config(hw=cfg.hw, max_ch=cfg.max_ch, is_growing=cfg.is_growing, alpha_grow=cfg.alpha_grow,
+                  use_unet=cfg.use_unet)
+  Pref = R.init_params(rcfg, seed=seed, dtype=torch.float64, std='he')
+  tr = Trainer(cfg, device='cuda:0', seed=seed)
+  tr.store.load_state_dict({k: v.float() for k, v in Pref.items()})
+  Pref = {k: v.float().double() for k, v in Pref.items()}          # identical fp32-representable weights
+  g = torch.Generator().manual_seed(1234 + seed)
+  s = torch.rand(batch, cfg.hw, cfg.hw, 3, generator=g)
+  t = torch.rand(batch, cfg.hw, cfg.hw, 3, generator=g)
+  a_s, a_t = torch.rand(batch, generator=g), torch.rand(batch, generator=g)
+  adt = torch.bfloat16 if precision == 'bf16' else torch.float32
+  if precision == 'bf16':
+    s, t = s.to(adt).float(), t.to(adt).float()
+  dev = dict(s=s.to('cuda:0').to(adt).contiguous(), t=t.to('cuda:0').to(adt).contiguous(), a_s=a_s.to('cuda:0'),
+             a_t=a_t.to('cuda:0'))
+  ref = dict(s=s.double(), t=t.double(), a_s=a_s.double().reshape(-1, 1, 1, 1), a_t=a_t.double().reshape(-1, 1, 1, 1))
+  return cfg, rcfg, tr, Pref, dev, ref
+
+
+def test_param_schema_matches_oracle():
+  cfg, rcfg, tr, Pref, _, _ = make(dict(hw=16, max_ch=32), 'fp32')
+  sd = tr.store.state_dict()
+  assert set(sd) == set(Pref)
+  for k in sd:
+    assert tuple(sd[k].shape) == tuple(Pref[k].shape), k
+  assert tr.P['discriminator_s/before_fc_1x1x32/Conv/weights'].shape == (3, 3, 40, 32)     # physical (padded) view
+
+
+@pytest.mark.parametrize('growing', [False, True])
+def test_networks_fp32_forward(growing):
+  from twingan_amd import pggan
+  kw = dict(hw=32, max_ch=32, is_growing=growing, alpha_grow=0.3 if growing else 0.0)
+  cfg, rcfg, tr, Pref, dev, ref = make(kw, 'fp32')
+  with torch.no_grad():
+    net, ep = pggan.encoder_before_classification(tr.P, dev['s'], 's', cfg)
+    rnet, rep = R.encoder(Pref, ref['s'], 's', rcfg)
+    assert set(ep) == set(rep)
+    for k in rep:
+      e = rel_l2(ep[k], rep[k])
+      assert e < 1e-5, ('encoder', k, e)
+    out, gep = pggan.generator(tr.P, net, 't', cfg, ep)
+    rout, rgep = R.generator(Pref, rnet, 't', rcfg, rep)
+    assert set(k for k in gep if k != 'alpha_grow') == set(rgep)
+    assert rel_l2(out, rout) < 1e-5
+    assert float((out.double().cpu() - rout).abs().max()) < 1e-4
+    pred, dep = pggan.discriminator(tr.P, out, cfg, 'discriminator_t')
+    rpred, _ = R.discriminator(Pref, rout, rcfg, 'discriminator_t')
+    assert rel_l2(pred, rpred) < 1e-5
+    assert pred.shape == (3, 1)
+
+
+def _grads_close(tr, Pref, names, tol, what):
+  gd = tr.store.grad_dict()
+  num = den = 0.0
+  worst = (0.0, None)
+  for k in names:
+    a = gd[k].double().cpu().numpy()
+    b = Pref[k].grad.numpy() if Pref[k].grad is not None else np.zeros_like(a)
+    num += np.sum((a - b) ** 2)
+    den += np.sum(b ** 2)
+    e = np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-12)
+    if e > worst[0] and np.linalg.norm(b) > 1e-6:
+      worst = (e, k)
+  tot = np.sqrt(num / (den + 1e-30))
+  assert tot < tol, '%s grads rel-L2 %.3e (worst %s %.3e)' % (what, tot, worst[1], worst[0])
+
+
+@pytest.mark.parametrize('precision,hw,max_ch', [('fp32', 16, 16), ('fp32', 64, 8), ('bf16', 32, 32)])
+def test_losses_and_gradients(precision, hw, max_ch):
+  from twingan_amd import twingan as T
+  cfg, rcfg, tr, Pref, dev, ref = make(dict(hw=hw, max_ch=max_ch), precision, seed=2, batch=2)
+  ftol, gtol = (1e-4, 2e-4) if precision == 'fp32' else (3e-2, 6e-2)
+  for v in Pref.values():
+    v.requires_grad_(True)
+  # ---- generator loss
+  tr.store.zero_grad('g')
+  tr._set_requires_grad(g=True, d=False)
+  gl, gterms = T.generator_loss(tr.P, dev['s'], dev['t'], cfg)
+  rgl, rterms = R.generator_loss(Pref, ref['s'], ref['t'], rcfg)
+  assert set(gterms) == set(rterms)
+  for k in rterms:
+    assert abs(gterms[k].item() - rterms[k].item()) < ftol * max(1.0, abs(rterms[k].item())) + (
+        0 if precision == 'fp32' else 2e-2), (k, gterms[k].item(), rterms[k].item())
+  gl.backward()
+  rgl.backward()
+  gptr = tr.store.grad['g'].data_ptr()
+  assert tr.P['generator/block_4x4x%d/Conv/weights' % max_ch].grad.data_ptr() >= gptr     # flat buffer still in place
+  _grads_close(tr, Pref, tr.store.names('g'), gtol, 'generator')
+  for v in Pref.values():
+    v.grad = None
+  # ---- discriminator loss (WGAN-GP double backward)
+  tr.store.zero_grad('d')
+  tr._set_requires_grad(g=False, d=True)
+  dl, dterms = T.discriminator_loss(tr.P, dev['s'], dev['t'], cfg, dev['a_s'], dev['a_t'])
+  rdl, rdterms = R.discriminator_loss(Pref, ref['s'], ref['t'], rcfg, ref['a_s'], ref['a_t'])
+  assert set(dterms) == set(rdterms)
+  for k in rdterms:
+    assert abs(dterms[k].item() - rdterms[k].item()) < ftol * max(1.0, abs(rdterms[k].item())) + (
+        0 if precision == 'fp32' else 5e-2 * abs(rdterms[k].item()) + 2e-2), (k, dterms[k].item(), rdterms[k].item())
+  dl.backward()
+  rdl.backward()
+  _grads_close(tr, Pref, tr.store.names('d'), gtol, 'discriminator')
+
+
+def test_alternating_train_steps_match_oracle():
+  """Four session.run equivalents (G, D, G, D) with the shared Adam counter (image_generation.py:640-652)."""
+  cfg, rcfg, tr, Pref, dev, ref = make(dict(hw=16, max_ch=16), 'fp32', seed=3, batch=2)
+  opt = R.AdamState(Pref, rcfg)
+  for i in range(4):
+    tr.run(dev['s'], dev['t'], dev['a_s'], dev['a_t'])
+    R.train_step(Pref, opt, ref['s'], ref['t'], rcfg, ref['a_s'], ref['a_t'], counter=i)
+  assert tr.adam_t == opt.t == 4 and tr.global_step == 2 and tr.n_critic_counter == 4
+  sd = tr.store.state_dict()
+  # Adam's first steps move every weight by ~lr regardless of gradient scale, so compare the UPDATE
+  upd_err = []
+  num = den = 0.0
+  P0 = R.init_params(rcfg, seed=3, dtype=torch.float64, std='he')
+  for k in sd:
+    d_dev = sd[k].double().cpu() - P0[k].float().double()
+    d_ref = Pref[k].detach() - P0[k].float().double()
+    num += float(((d_dev - d_ref) ** 2).sum())
+    den += float((d_ref ** 2).sum())
+    if float(d_ref.abs().max()) > 0:
+      upd_err.append(float((d_dev - d_ref).norm() / (d_ref.norm() + 1e-30)))
+  # Adam's first steps are sign-like, so a handful of near-zero gradients may flip; bound the aggregate
+  assert np.sqrt(num / den) < 5e-2, np.sqrt(num / den)
+  assert np.median(upd_err) < 1e-2, np.median(upd_err)
+
+
+def test_full_size_properties_256_bf16():
+  """BASELINE config (256x256, max_ch 256) through size-independent properties: shapes, finiteness,
+  instance-norm statistics of a generator block, pixel-norm unit RMS, D linearity of the GP ones-vector."""
+  from twingan_amd import Config, pggan
+  from twingan_amd.twingan import Trainer
+  cfg = Config(hw=256, max_ch=256, precision='bf16')
+  tr = Trainer(cfg, device='cuda:0', seed=0)
+  g = torch.Generator().manual_seed(5)
+  s = torch.rand(2, 256, 256, 3, generator=g).to('cuda:0').to(torch.bfloat16)
+  with torch.no_grad():
+    net, ep = pggan.encoder_before_classification(tr.P, s, 's', cfg)
+    assert net.shape == (2, 4, 4, 256)
+    assert ep['encoder_block_256x256x32'].shape == (2, 256, 256, 32)
+    rms = ep['encoder_block_128x128x64'].float().pow(2).mean(dim=3)
+    assert float((rms - 1).abs().max()) < 0.05                                  # pixel norm => unit RMS over C
+    out, _ = pggan.generator(tr.P, net, 't', cfg, ep)
+    assert out.shape == (2, 256, 256, 3) and bool(torch.isfinite(out.float()).all())
+    m = out.float().mean(dim=(1, 2))
+    v = out.float().var(dim=(1, 2), unbiased=False)
+    assert float(m.abs().max()) < 0.05 and float((v - 1).abs().max()) < 0.1     # to_rgb is instance-normalised
+    pred, _ = pggan.discriminator(tr.P, out, cfg, 'discriminator_s')
+    assert pred.shape == (2, 1) and bool(torch.isfinite(pred).all())

@@ -1,0 +1,445 @@
+"""GPU parity: every HIP operator (through the C ABI) against the oracle on the same seeded inputs.
+
+Tolerances: fp32 kernels vs the float64 oracle: rel-L2 <= 2e-5 (single primitive);
+bf16 kernels vs the oracle evaluated on the same bf16-rounded inputs: rel-L2 <= 1e-2 forward,
+3e-2 gradients; MFMA bf16 kernels vs the direct bf16 kernels (same rounding, different summation
+order): rel-L2 <= 2e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import np_ops as N          # noqa: E402  (checker only)
+from oracle import torch_ref as R       # noqa: E402
+
+F32_TOL = 2e-5
+BF16_FWD_TOL = 1e-2
+BF16_GRAD_TOL = 3e-2
+MFMA_VS_DIRECT_TOL = 2e-3
+
+
+def dev():
+  return torch.device('cuda:0')
+
+
+def rel_l2(a, b):
+  a = np.asarray(a, np.float64)
+  b = np.asarray(b, np.float64)
+  assert a.shape == b.shape, (a.shape, b.shape)
+  return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def to_dev(a, dtype=torch.float32):
+  return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev()).to(dtype).contiguous()
+
+
+def host(t):
+  return t.detach().float().cpu().numpy().astype(np.float64)
+
+
+def bf16_round(a):
+  return torch.from_numpy(np.asarray(a, np.float32)).to(torch.bfloat16).float().numpy().astype(np.float64)
+
+
+def tol_for(dtype, grad=False):
+  if dtype == torch.float32:
+    return F32_TOL
+  return BF16_GRAD_TOL if grad else BF16_FWD_TOL
+
+
+@pytest.fixture(scope='module')
+def ops():
+  from twingan_amd import ops as _ops
+  return _ops
+
+
+# ---------------------------------------------------------------------------------------------- conv
+CONV_CASES = [
+    # n, h, w, cin, cout, k, padding
+    (2, 6, 6, 5, 7, 3, 'SAME'),
+    (1, 9, 5, 3, 4, 3, 'SAME'),
+    (2, 5, 5, 4, 6, 1, 'SAME'),
+    (3, 4, 4, 5, 6, 4, 'VALID'),
+    (2, 7, 7, 3, 5, 4, 'VALID'),
+    (2, 8, 8, 16, 16, 3, 'SAME'),
+]
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,k,padding', CONV_CASES)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv_direct_vs_oracle(ops, n, h, w, cin, cout, k, padding, dtype):
+  rng = np.random.RandomState(1)
+  x = rng.randn(n, h, w, cin)
+  wt = rng.randn(k, k, cin, cout) / np.sqrt(k * k * cin)
+  b = rng.randn(cout) * 0.1
+  if dtype == torch.bfloat16:
+    x, wr = bf16_round(x), bf16_round(wt)
+  else:
+    wr = wt
+  import twingan_amd.ops as O
+  saved = O._mfma_ok
+  O._mfma_ok = lambda *a: False          # force the direct algorithm
+  try:
+    xd = to_dev(x, dtype).requires_grad_(True)
+    wd = to_dev(wt).requires_grad_(True)
+    bd = to_dev(b).requires_grad_(True)
+    y = ops.conv2d(xd, wd, bd, k, padding, lrelu=True)
+    ref = N.leaky_relu(N.conv2d(x, wr, padding) + b)
+    assert rel_l2(host(y), ref) < tol_for(dtype)
+    gy = rng.randn(*ref.shape)
+    if dtype == torch.bfloat16:
+      gy = bf16_round(gy)
+    y.backward(to_dev(gy, dtype))
+    gpre = gy * np.where(ref > 0, 1.0, 0.2)
+    if dtype == torch.bfloat16:
+      gpre = bf16_round(gpre)
+    assert rel_l2(host(xd.grad), N.conv2d_bwd_data(gpre, wr, (h, w), padding)) < tol_for(dtype, True)
+    assert rel_l2(host(wd.grad), N.conv2d_bwd_weight(x, gpre, (k, k), padding)) < tol_for(dtype, True)
+    assert rel_l2(host(bd.grad), gpre.sum(axis=(0, 1, 2))) < tol_for(dtype, True)
+  finally:
+    O._mfma_ok = saved
+
+
+MFMA_CASES = [
+    # n, h, w, cin, cout, k, padding    (model layer shapes at reduced extent + ragged tiles)
+    (2, 16, 16, 16, 16, 3, 'SAME'),
+    (2, 16, 16, 16, 32, 3, 'SAME'),
+    (1, 32, 32, 32, 64, 3, 'SAME'),
+    (2, 8, 8, 64, 128, 3, 'SAME'),
+    (2, 8, 8, 128, 256, 3, 'SAME'),
+    (3, 4, 4, 256, 256, 3, 'SAME'),
+    (2, 8, 8, 512, 256, 3, 'SAME'),
+    (1, 16, 16, 256, 64, 3, 'SAME'),
+    (1, 32, 32, 64, 16, 3, 'SAME'),
+    (5, 4, 4, 264, 256, 3, 'SAME'),      # D tail conv after minibatch-stddev padding
+    (5, 4, 4, 64, 64, 4, 'VALID'),       # dense rewrite of the 4x4 VALID conv
+    (16, 4, 4, 256, 256, 4, 'VALID'),
+    (1, 20, 12, 24, 40, 3, 'SAME'),      # ragged spatial tiles, channels not multiples of 16/32
+    (3, 10, 18, 8, 8, 3, 'SAME'),
+    (2, 12, 12, 32, 48, 1, 'SAME'),      # generic 1x1
+    (1, 40, 24, 16, 16, 3, 'SAME'),
+]
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,k,padding', MFMA_CASES)
+def test_conv_mfma_vs_direct_and_oracle(ops, n, h, w, cin, cout, k, padding):
+  import twingan_amd.ops as O
+  rng = np.random.RandomState(2)
+  x = bf16_round(rng.randn(n, h, w, cin))
+  wt = rng.randn(k, k, cin, cout) / np.sqrt(k * k * cin)
+  b = rng.randn(cout) * 0.1
+  spec = O.ConvSpec(k, padding)
+  assert O._mfma_ok(torch.bfloat16, cin, cout, spec, h, w)
+  res = {}
+  for algo in ('mfma', 'direct'):
+    saved = O._mfma_ok
+    if algo == 'direct':
+      O._mfma_ok = lambda *a: False
+    try:
+      xd = to_dev(x, torch.bfloat16).requires_grad_(True)
+      wd = to_dev(wt).requires_grad_(True)
+      bd = to_dev(b).requires_grad_(True)
+      y = ops.conv2d(xd, wd, bd, k, padding, lrelu=True)
+      gy = bf16_round(np.random.RandomState(3).randn(*y.shape))
+      y.backward(to_dev(gy, torch.bfloat16))
+      res[algo] = (host(y), host(xd.grad), host(wd.grad), host(bd.grad))
+    finally:
+      O._mfma_ok = saved
+  names = ('y', 'gx', 'gw', 'gb')
+  for i, nm in enumerate(names):
+    e = rel_l2(res['mfma'][i], res['direct'][i])
+    assert e < MFMA_VS_DIRECT_TOL, '%s mfma vs direct rel-L2 %.3e' % (nm, e)
+  ref = N.leaky_relu(N.conv2d(x, bf16_round(wt), padding) + b)
+  assert rel_l2(res['mfma'][0], ref) < BF16_FWD_TOL
+
+
+def test_conv_mfma_transpose_detecting(ops):
+  """A = identity-like weights with an ASYMMETRIC pattern catch swapped rows/cols or flipped taps."""
+  cin = cout = 32
+  x = np.zeros((1, 8, 8, cin))
+  x[0, 2, 5, 3] = 1.0
+  x[0, 6, 1, 17] = 2.0
+  w = np.zeros((3, 3, cin, cout))
+  w[0, 2, 3, 9] = 1.0        # tap (dy=-1, dx=+1): out[y, x] += in[y-1, x+1]
+  w[2, 1, 17, 30] = 0.5      # tap (dy=+1, dx=0)
+  y = ops.conv2d(to_dev(x, torch.bfloat16), to_dev(w), None, 3, 'SAME')
+  ref = N.conv2d(x, w)
+  assert np.array_equal(host(y), ref)
+  assert host(y)[0, 3, 4, 9] == 1.0 and host(y)[0, 5, 1, 30] == 1.0
+
+
+def test_conv_double_backward_matches_oracle(ops):
+  """Second-order path used by WGAN-GP: d/dw of ||d conv / d x||^2."""
+  rng = np.random.RandomState(4)
+  x = rng.randn(2, 6, 6, 4)
+  w = rng.randn(3, 3, 4, 5) * 0.3
+  xd = to_dev(x).requires_grad_(True)
+  wd = to_dev(w).requires_grad_(True)
+  y = ops.conv2d(xd, wd, None, 3, 'SAME', lrelu=True)
+  gx, = torch.autograd.grad(y, xd, grad_outputs=torch.ones_like(y), create_graph=True)
+  pen = ops.gradient_penalty(gx.contiguous(), 10.0)
+  pen.backward()
+  xt = torch.from_numpy(x).requires_grad_(True)
+  wt = torch.from_numpy(w).requires_grad_(True)
+  yt = R.leaky_relu(R.conv2d(xt, wt, 'SAME'))
+  gxt, = torch.autograd.grad(yt.sum(), xt, create_graph=True)
+  pt = ((torch.sqrt((gxt ** 2).sum(dim=(1, 2, 3))) - 1) ** 2).mean() * 10.0
+  pt.backward()
+  assert abs(pen.item() - pt.item()) < 1e-4 * abs(pt.item())
+  assert rel_l2(host(wd.grad), wt.grad.numpy()) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- rgb 1x1
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('cin,cout', [(3, 16), (3, 256), (16, 3), (256, 3), (3, 12), (20, 3)])
+def test_pointwise_conv(ops, dtype, cin, cout):
+  rng = np.random.RandomState(5)
+  x = rng.randn(3, 7, 5, cin)
+  w = rng.randn(1, 1, cin, cout) / np.sqrt(cin)
+  b = rng.randn(cout) * 0.1
+  if dtype == torch.bfloat16:
+    x, wr = bf16_round(x), bf16_round(w)
+  else:
+    wr = w
+  xd, wd, bd = to_dev(x, dtype).requires_grad_(True), to_dev(w).requires_grad_(True), to_dev(b).requires_grad_(True)
+  y = ops.pointwise_conv(xd, wd, bd, lrelu=True)
+  ref = N.leaky_relu(x @ wr[0, 0] + b)
+  assert rel_l2(host(y), ref) < tol_for(dtype)
+  gy = rng.randn(*ref.shape)
+  if dtype == torch.bfloat16:
+    gy = bf16_round(gy)
+  y.backward(to_dev(gy, dtype))
+  gpre = gy * np.where(ref > 0, 1.0, 0.2)
+  if dtype == torch.bfloat16:
+    gpre = bf16_round(gpre)
+  assert rel_l2(host(xd.grad), gpre @ wr[0, 0].T) < tol_for(dtype, True)
+  assert rel_l2(host(wd.grad)[0, 0], np.einsum('nhwc,nhwo->co', x, gpre)) < tol_for(dtype, True)
+  assert rel_l2(host(bd.grad), gpre.sum(axis=(0, 1, 2))) < tol_for(dtype, True)
+
+
+# ---------------------------------------------------------------------------------------------- norm_act
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('n,h,w,c,lrelu,pn', [(2, 8, 8, 16, True, True), (3, 4, 4, 256, True, True),
+                                              (2, 16, 16, 32, True, False), (2, 8, 8, 3, False, False),
+                                              (1, 32, 32, 64, True, True), (2, 5, 7, 8, True, True)])
+def test_norm_act(ops, dtype, n, h, w, c, lrelu, pn):
+  rng = np.random.RandomState(6)
+  y = rng.randn(n, h, w, c) * 1.5 + 0.7
+  gamma = 1.0 + 0.2 * rng.randn(c)
+  beta = 0.1 * rng.randn(c)
+  gz = rng.randn(n, h, w, c)
+  if dtype == torch.bfloat16:
+    y, gz = bf16_round(y), bf16_round(gz)
+  yd = to_dev(y, dtype).requires_grad_(True)
+  gd, bd = to_dev(gamma).requires_grad_(True), to_dev(beta).requires_grad_(True)
+  z = ops.norm_act(yd, gd, bd, lrelu=lrelu, pixel_norm=pn)
+  z.backward(to_dev(gz, dtype))
+  yt = torch.from_numpy(y).requires_grad_(True)
+  gt = torch.from_numpy(gamma).requires_grad_(True)
+  bt = torch.from_numpy(beta).requires_grad_(True)
+  zt = R.instance_norm(yt, gt, bt)
+  if lrelu:
+    zt = R.leaky_relu(zt)
+  if pn:
+    zt = R.pixel_norm(zt)
+  zt.backward(torch.from_numpy(gz))
+  assert rel_l2(host(z), zt.detach().numpy()) < tol_for(dtype)
+  assert rel_l2(host(yd.grad), yt.grad.numpy()) < tol_for(dtype, True)
+  assert rel_l2(host(gd.grad), gt.grad.numpy()) < tol_for(dtype, True)
+  assert rel_l2(host(bd.grad), bt.grad.numpy()) < tol_for(dtype, True)
+
+
+def test_instance_norm_large_mean_is_stable(ops):
+  """Shifted-sum statistics: a large common offset must not destroy the variance in fp32."""
+  rng = np.random.RandomState(7)
+  y = rng.randn(1, 64, 64, 8) * 0.01 + 100.0
+  z = ops.norm_act(to_dev(y), to_dev(np.ones(8)), to_dev(np.zeros(8)), lrelu=False, pixel_norm=False)
+  ref = N.instance_norm(np.asarray(to_dev(y).cpu().numpy(), np.float64), 1.0, 0.0)
+  assert rel_l2(host(z), ref) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------- resampling
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('c0,c1', [(8, 8), (16, 0), (3, 0), (256, 256), (5, 3)])
+def test_upsample_concat(ops, dtype, c0, c1):
+  rng = np.random.RandomState(8)
+  x0 = rng.randn(2, 3, 5, c0)
+  x1 = rng.randn(2, 6, 10, c1) if c1 else None
+  if dtype == torch.bfloat16:
+    x0 = bf16_round(x0)
+    x1 = bf16_round(x1) if c1 else None
+  a = to_dev(x0, dtype).requires_grad_(True)
+  b = to_dev(x1, dtype).requires_grad_(True) if c1 else None
+  out = ops.upsample2x_concat(a, b)
+  ref = N.upsample2x(x0)
+  if c1:
+    ref = np.concatenate([ref, x1], axis=3)
+  assert np.array_equal(host(out), ref)
+  go = rng.randn(*ref.shape)
+  if dtype == torch.bfloat16:
+    go = bf16_round(go)
+  out.backward(to_dev(go, dtype))
+  g0 = go[..., :c0].reshape(2, 3, 2, 5, 2, c0).sum(axis=(2, 4))
+  assert rel_l2(host(a.grad), g0) < tol_for(dtype)
+  if c1:
+    assert np.array_equal(host(b.grad), go[..., c0:])
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('c', [16, 3, 256])
+def test_avg_pool_and_double_backward(ops, dtype, c):
+  rng = np.random.RandomState(9)
+  x = rng.randn(2, 6, 8, c)
+  if dtype == torch.bfloat16:
+    x = bf16_round(x)
+  xd = to_dev(x, dtype).requires_grad_(True)
+  y = ops.avg_pool2(xd)
+  assert rel_l2(host(y), N.avg_pool2(x)) < tol_for(dtype)
+  gy = rng.randn(*y.shape)
+  if dtype == torch.bfloat16:
+    gy = bf16_round(gy)
+  gyd = to_dev(gy, dtype).requires_grad_(True)
+  gx, = torch.autograd.grad(y, xd, grad_outputs=gyd, create_graph=True)
+  assert rel_l2(host(gx), N.upsample2x(gy) * 0.25) < tol_for(dtype)
+  v = rng.randn(*x.shape)
+  if dtype == torch.bfloat16:
+    v = bf16_round(v)
+  ggy, = torch.autograd.grad(gx, gyd, grad_outputs=to_dev(v, dtype))
+  assert rel_l2(host(ggy), N.avg_pool2(v)) < tol_for(dtype)       # adjoint of the adjoint
+
+
+def test_lerp_and_cast(ops):
+  rng = np.random.RandomState(10)
+  a, b = rng.randn(2, 4, 4, 6), rng.randn(2, 4, 4, 6)
+  ad, bd = to_dev(a).requires_grad_(True), to_dev(b).requires_grad_(True)
+  out = ops.lerp(ad, bd, 0.3)
+  assert rel_l2(host(out), N.lerp(a, b, 0.3)) < F32_TOL
+  out.backward(torch.ones_like(out))
+  assert rel_l2(host(ad.grad), np.full(a.shape, 0.3)) < F32_TOL
+  assert rel_l2(host(bd.grad), np.full(a.shape, 0.7)) < F32_TOL
+  c = ops.cast(to_dev(a), torch.bfloat16)
+  assert c.dtype == torch.bfloat16 and np.array_equal(host(c), bf16_round(a))
+
+
+# ---------------------------------------------------------------------------------------------- mbstd
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('n,c', [(5, 8), (16, 256), (3, 32)])
+def test_mbstd_fwd_bwd_bwdbwd(ops, dtype, n, c):
+  from twingan_amd.params import mbstd_cpad
+  rng = np.random.RandomState(11)
+  x = rng.randn(n, 4, 4, c)
+  if dtype == torch.bfloat16:
+    x = bf16_round(x)
+  cpad = mbstd_cpad(c)
+  xd = to_dev(x, dtype).requires_grad_(True)
+  out = ops.minibatch_state_concat(xd, cpad)
+  assert out.shape == (n, 4, 4, cpad)
+  eps = 1e-8 if dtype == torch.float32 else 1e-6
+  ref = N.minibatch_state_concat(x, eps)
+  assert rel_l2(host(out)[..., :c + 1], ref) < tol_for(dtype)
+  assert np.all(host(out)[..., c + 1:] == 0)
+  # first + second order vs torch autograd on the oracle
+  go = rng.randn(n, 4, 4, cpad)
+  v = rng.randn(n, 4, 4, c)
+  if dtype == torch.bfloat16:
+    go, v = bf16_round(go), bf16_round(v)
+  god = to_dev(go, dtype).requires_grad_(True)
+  gx, = torch.autograd.grad(out, xd, grad_outputs=god, create_graph=True)
+  ggo, gx2 = torch.autograd.grad(gx, [god, xd], grad_outputs=to_dev(v, dtype))
+
+  xt = torch.from_numpy(x).requires_grad_(True)
+  got = torch.from_numpy(go[..., :c + 1].copy()).requires_grad_(True)
+  mean = xt.mean(dim=0, keepdim=True)
+  std = torch.sqrt(((xt - mean) ** 2).mean(dim=0, keepdim=True) + eps)
+  outt = torch.cat([xt, std.mean().reshape(1, 1, 1, 1).expand(n, 4, 4, 1)], dim=3)
+  gxt, = torch.autograd.grad(outt, xt, grad_outputs=got, create_graph=True)
+  ggot, gx2t = torch.autograd.grad(gxt, [got, xt], grad_outputs=torch.from_numpy(v))
+  gtol = tol_for(dtype, True)
+  assert rel_l2(host(gx), gxt.detach().numpy()) < gtol
+  assert rel_l2(host(ggo)[..., :c + 1], ggot.numpy()) < gtol
+  assert rel_l2(host(gx2), gx2t.numpy()) < (gtol if dtype == torch.float32 else 0.1)
+
+
+# ---------------------------------------------------------------------------------------------- dense, losses
+def test_fully_connected_and_grads(ops):
+  rng = np.random.RandomState(12)
+  x, w, b = rng.randn(6, 40), rng.randn(40, 3), rng.randn(3)
+  xd, wd, bd = to_dev(x).requires_grad_(True), to_dev(w).requires_grad_(True), to_dev(b).requires_grad_(True)
+  y = ops.fully_connected(xd, wd, bd)
+  assert rel_l2(host(y), N.fully_connected(x, w, b)) < F32_TOL
+  g = rng.randn(6, 3)
+  gx, = torch.autograd.grad(y, xd, grad_outputs=to_dev(g), create_graph=True)
+  assert rel_l2(host(gx), g @ w.T) < F32_TOL
+  v = rng.randn(6, 40)
+  (gx * to_dev(v)).sum().backward()            # d/dw of <v, g w^T> = v^T g
+  assert rel_l2(host(wd.grad), v.T @ g) < F32_TOL
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_losses(ops, dtype):
+  rng = np.random.RandomState(13)
+  a, b = rng.rand(2, 8, 8, 3), rng.rand(2, 8, 8, 3)
+  if dtype == torch.bfloat16:
+    a, b = bf16_round(a), bf16_round(b)
+  ad, bd = to_dev(a, dtype).requires_grad_(True), to_dev(b, dtype).requires_grad_(True)
+  l1 = ops.abs_diff_mean(ad, bd, 0.1)
+  assert abs(l1.item() - N.absolute_difference(a, b, 0.1)) < 1e-6
+  (l1 * 3.0).backward()
+  assert rel_l2(host(ad.grad), 0.3 * np.sign(a - b) / a.size) < tol_for(dtype)
+  assert rel_l2(host(bd.grad), -0.3 * np.sign(a - b) / a.size) < tol_for(dtype)
+  p = rng.randn(7, 1)
+  pd = to_dev(p).requires_grad_(True)
+  m = ops.mean(pd, -1.0)
+  assert abs(m.item() - N.wgan_g_loss(p)) < 1e-6
+  m.backward()
+  assert rel_l2(host(pd.grad), np.full(p.shape, -1.0 / 7)) < F32_TOL
+  g = rng.randn(4, 8, 8, 3) * 0.05
+  if dtype == torch.bfloat16:
+    g = bf16_round(g)
+  gd = to_dev(g, dtype).requires_grad_(True)
+  gp = ops.gradient_penalty(gd, 10.0)
+  assert abs(gp.item() - N.gradient_penalty(g, 10.0)) < 1e-4 * N.gradient_penalty(g, 10.0)
+  gp.backward()
+  gt = torch.from_numpy(g).requires_grad_(True)
+  (((torch.sqrt((gt ** 2).sum(dim=(1, 2, 3))) - 1) ** 2).mean() * 10.0).backward()
+  assert rel_l2(host(gd.grad), gt.grad.numpy()) < tol_for(dtype, True)
+
+
+def test_gp_unit_linear_critic_is_zero(ops):
+  w = np.random.RandomState(14).randn(4, 4, 3)
+  w /= np.linalg.norm(w)
+  g = np.tile(w[None], (5, 1, 1, 1))
+  assert ops.gradient_penalty(to_dev(g), 10.0).item() < 1e-10
+
+
+def test_sample_lerp(ops):
+  rng = np.random.RandomState(15)
+  x, y, a = rng.rand(4, 8, 8, 3), rng.rand(4, 8, 8, 3), rng.rand(4)
+  out = ops.sample_lerp(to_dev(x), to_dev(y), to_dev(a))
+  assert rel_l2(host(out), x + a[:, None, None, None] * (y - x)) < F32_TOL
+
+
+def test_adam_kernel_tf_semantics():
+  from twingan_amd._lib import call
+  rng = np.random.RandomState(16)
+  th, g = rng.randn(1000), rng.randn(1000)
+  m, v = np.zeros(1000), np.zeros(1000)
+  thd, md, vd = to_dev(th), to_dev(m), to_dev(v)
+  for t in (1, 2, 3):
+    g = rng.randn(1000)
+    lr_t = 1e-4 * np.sqrt(1 - 0.99 ** t) / (1 - 0.5 ** t)
+    call('tg_adam_step', thd.data_ptr(), to_dev(g).data_ptr(), md.data_ptr(), vd.data_ptr(), None, 1000, float(lr_t),
+         0.5, 0.99, 1e-8, 1.0, torch.cuda.current_stream().cuda_stream)
+    th, m, v = N.adam_step(th, g, m, v, t)
+  assert rel_l2(host(thd), th) < 1e-6
+  assert rel_l2(host(md), m) < 1e-5 and rel_l2(host(vd), v) < 1e-5
+
+
+def test_errors_are_loud(ops):
+  from twingan_amd._lib import TgError
+  with pytest.raises(TgError):
+    ops.conv2d(torch.zeros(1, 4, 4, 4), torch.zeros(3, 3, 4, 4))          # CPU tensors: no fallback
+  with pytest.raises(TgError):
+    ops.pointwise_conv(to_dev(np.zeros((1, 2, 2, 8))), to_dev(np.zeros((1, 1, 8, 8))))

@@ -1,0 +1,154 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/twingan_hip.h declares,
+the ctypes signatures cover the header, the host-side mirror (parameter schema, channel schedule,
+padding rules, step schedule) agrees with the oracle, and the product path refuses to run without
+a GPU (no CPU fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+  src = open(os.path.join(ROOT, 'include', 'twingan_hip.h')).read()
+  src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+  return sorted(set(re.findall(r'\b(tg_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+  import ctypes
+  from twingan_amd import _lib
+  assert os.path.exists(_lib.LIB_PATH), 'build first: python -c "import __graft_entry__ as g; g.build()"'
+  lib = ctypes.CDLL(_lib.LIB_PATH)
+  syms = header_symbols()
+  assert len(syms) >= 30
+  for s in syms:
+    assert hasattr(lib, s), 'missing export %s' % s
+
+
+def test_ctypes_signatures_cover_header():
+  from twingan_amd import _lib
+  assert sorted(_lib.SIGNATURES) == header_symbols()
+  lib = _lib.load()
+  assert lib.tg_version() >= 100
+  assert lib.tg_last_error() is not None
+
+
+def test_conv_desc_layout_matches_header():
+  import ctypes
+  from twingan_amd._lib import TgConvDesc
+  assert ctypes.sizeof(TgConvDesc) == 15 * 4      # 14 int32 + 1 float, no padding
+
+
+def test_invalid_descriptor_is_rejected_without_gpu():
+  """Argument validation happens before any launch, so it can be exercised on a CPU-only box."""
+  import ctypes
+  from twingan_amd import _lib
+  lib = _lib.load()
+  d = _lib.TgConvDesc()
+  d.n, d.hin, d.win, d.cin, d.hout, d.wout, d.cout = 1, 4, 4, 8, 9, 4, 8      # hout inconsistent with stride 1
+  d.kh = d.kw = 3
+  d.pad_t = d.pad_l = 1
+  rc = lib.tg_conv2d_fwd(ctypes.byref(d), 16, 16, None, 16, None)
+  assert rc == -1 and b'inconsistent' in lib.tg_last_error()
+  d.hout = 4
+  d.kh = 5
+  assert lib.tg_conv2d_fwd(ctypes.byref(d), 16, 16, None, 16, None) == -1
+  assert lib.tg_pointwise_conv_fwd(16, 16, None, 16, 10, 8, 8, 0, 0, 0.2, 0, None) == -4     # TG_ENOSUP
+
+
+def test_pack_sizes():
+  import ctypes
+  from twingan_amd import _lib
+  lib = _lib.load()
+  d = _lib.TgConvDesc()
+  d.n, d.hin, d.win, d.cin, d.hout, d.wout, d.cout = 16, 4, 4, 264, 4, 4, 256
+  d.kh = d.kw = 3
+  d.pad_t = d.pad_l = 1
+  assert lib.tg_conv2d_pack_elems(ctypes.byref(d), 0) == 256 * 9 * 272          # rows pad 64, inner pad 16
+  assert lib.tg_conv2d_pack_elems(ctypes.byref(d), 1) == 320 * 9 * 256
+  d.cin, d.kh, d.kw, d.pad_t, d.pad_l, d.hout, d.wout = 256, 4, 4, 0, 0, 1, 1     # 4x4 VALID on 4x4 -> dense 4096
+  assert lib.tg_conv2d_pack_elems(ctypes.byref(d), 0) == 256 * 4096
+  assert lib.tg_conv2d_pack_elems(ctypes.byref(d), 1) == 4096 * 256
+
+
+def test_no_cpu_fallback():
+  from twingan_amd import ops
+  from twingan_amd._lib import TgError
+  with pytest.raises(TgError):
+    ops.conv2d(torch.zeros(1, 4, 4, 8), torch.zeros(3, 3, 8, 8))
+  with pytest.raises(TgError):
+    ops.norm_act(torch.zeros(1, 4, 4, 8), torch.ones(8), torch.zeros(8))
+  with pytest.raises(TgError):
+    ops.abs_diff_mean(torch.zeros(4), torch.zeros(4))
+
+
+def test_product_does_not_import_oracle():
+  for dirpath, _, files in os.walk(os.path.join(ROOT, 'twingan_amd')):
+    for f in files:
+      if f.endswith('.py'):
+        src = open(os.path.join(dirpath, f)).read()
+        assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f
+
+
+def test_channel_schedule_and_padding_rules():
+  from twingan_amd.ops import ConvSpec
+  from twingan_amd.params import get_num_channels, max_stage_of, mbstd_cpad
+  assert [get_num_channels(s) for s in range(8)] == [256, 256, 256, 128, 64, 32, 16, 8]
+  assert max_stage_of(4) == 0 and max_stage_of(256) == 6
+  assert mbstd_cpad(256) == 264 and mbstd_cpad(8) == 16 and mbstd_cpad(32) == 40
+  s = ConvSpec(3)
+  assert (s.pad_t, s.out_hw(7, 5)) == (1, (7, 5))
+  s = ConvSpec(4, 'VALID')
+  assert (s.pad_t, s.out_hw(4, 4)) == (0, (1, 1))
+  s = ConvSpec(4, 'SAME')
+  assert s.pad_t == 1                               # TF SAME with even k: low side gets floor((k-1)/2)
+
+
+@pytest.mark.parametrize('hw,max_ch,growing', [(256, 256, False), (64, 256, False), (16, 32, True), (4, 16, False)])
+def test_param_schema_matches_oracle(hw, max_ch, growing):
+  from oracle import torch_ref as R
+  from twingan_amd import Config
+  from twingan_amd.params import ParamStore, declare_twingan
+  cfg = Config(hw=hw, max_ch=max_ch, is_growing=growing, alpha_grow=0.5)
+  store = declare_twingan(ParamStore('cpu'), cfg).build(seed=0)
+  ref = R.init_params(R.Config(hw=hw, max_ch=max_ch, is_growing=growing, alpha_grow=0.5))
+  sd = store.state_dict()
+  assert set(sd) == set(ref)
+  for k in ref:
+    assert tuple(sd[k].shape) == tuple(ref[k].shape), k
+  assert set(store.names('g')) == set(R.generator_var_names(ref))
+  assert set(store.names('d')) == set(R.discriminator_var_names(ref))
+  if hw == 256:
+    assert store.numel('g') == sum(ref[k].numel() for k in R.generator_var_names(ref))
+    assert store.numel('d') == 2 * 4590097
+  # init semantics: gamma 1, beta / biases 0, weights ~ N(0, 0.02), physical padding rows zero
+  any_w = sd['generator/block_4x4x%d/Conv/weights' % min(256, max_ch)]
+  assert 0.015 < float(any_w.std()) < 0.025
+  tail = store['discriminator_s/before_fc_1x1x%d/Conv/weights' % max_ch]
+  assert float(tail[:, :, max_ch + 1:, :].abs().max()) == 0.0
+  # state-dict round trip with missing variables (pggan_runner.py:136-146 ignore_missing_vars)
+  partial = {k: v for k, v in sd.items() if 'from_rgb' not in k}
+  store.load_state_dict(partial, strict=False)
+  with pytest.raises(KeyError):
+    store.load_state_dict(partial, strict=True)
+  # every variable's gradient is a view into the group's flat gradient buffer
+  for k in store.names():
+    g = store.specs[k]['group']
+    base = store.grad[g]
+    assert base.data_ptr() <= store[k].grad.data_ptr() < base.data_ptr() + base.numel() * 4
+
+
+def test_step_schedule_counters():
+  """n_critic alternation and counters (image_generation.py:640-652) without touching the GPU."""
+  from twingan_amd import Config
+  from twingan_amd.twingan import Trainer
+  tr = Trainer(Config(hw=8, max_ch=8), device='cpu')
+  calls = []
+  tr.g_step = lambda s, t: calls.append('g')
+  tr.d_step = lambda s, t, a=None, b=None: calls.append('d')
+  for _ in range(5):
+    tr.run(None, None)
+  assert calls == ['g', 'd', 'g', 'd', 'g'] and tr.global_step == 3 and tr.n_critic_counter == 5

@@ -1,0 +1,117 @@
+"""ctypes binding of libtwingan_hip.so (include/twingan_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a kernel call returns
+an error, this module raises.  (``oracle/`` is test infrastructure and is never imported here.)
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+TG_F32, TG_BF16 = 0, 1
+TG_ALGO_DIRECT, TG_ALGO_MFMA = 0, 1
+TG_EPI_BIAS, TG_EPI_LRELU = 1, 2
+NF_LRELU, NF_PIXNORM = 1, 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libtwingan_hip.so')
+
+
+class TgError(RuntimeError):
+  pass
+
+
+class TgConvDesc(Structure):
+  _fields_ = [(k, c_int32) for k in ('n', 'hin', 'win', 'cin', 'hout', 'wout', 'cout', 'kh', 'kw', 'pad_t', 'pad_l',
+                                     'dtype', 'algo', 'epilogue')] + [('lrelu_alpha', c_float)]
+
+
+_P = c_void_p
+_FP = c_void_p      # float* passed as raw address
+_D = POINTER(TgConvDesc)
+
+# name -> (restype, argtypes).  Mirrors include/twingan_hip.h one to one.
+SIGNATURES = {
+    'tg_version': (c_int, []),
+    'tg_last_error': (c_char_p, []),
+    'tg_conv2d_fwd': (c_int, [_D, _P, _P, _FP, _P, _P]),
+    'tg_conv2d_bwd_data': (c_int, [_D, _P, _P, _P, _P]),
+    'tg_conv2d_bwd_weight_workspace': (c_size_t, [_D]),
+    'tg_conv2d_bwd_weight': (c_int, [_D, _P, _P, _FP, c_int, _P, c_size_t, _P]),
+    'tg_conv2d_pack_elems': (c_size_t, [_D, c_int]),
+    'tg_conv2d_pack_weights': (c_int, [_D, _FP, c_int, _P, _P]),
+    'tg_pointwise_conv_fwd': (c_int, [_P, _FP, _FP, _P, c_int64, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    'tg_pointwise_conv_bwd_weight': (c_int, [_P, _P, _FP, c_int64, c_int, c_int, c_int, c_int, _P]),
+    'tg_instance_norm_stats': (c_int, [_P, _FP, _FP, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    'tg_norm_act_fwd': (c_int, [_P, _FP, _FP, _FP, _FP, _P, _FP, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
+                                c_int, _P]),
+    'tg_norm_act_bwd': (c_int, [_P, _P, _FP, _FP, _FP, _FP, _FP, _P, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int,
+                                c_float, c_int, c_int, _P]),
+    'tg_bias_lrelu_fwd': (c_int, [_P, _FP, _P, c_int64, c_int, c_float, c_int, _P]),
+    'tg_lrelu_bwd': (c_int, [_P, _P, _P, c_int64, c_float, c_int, _P]),
+    'tg_channel_sum': (c_int, [_P, _FP, c_int64, c_int, c_int, c_int, _P]),
+    'tg_upsample2x_concat_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'tg_upsample2x_concat_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'tg_pool2x2_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    'tg_pool2x2_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    'tg_axpby': (c_int, [_P, _P, _P, c_int64, c_float, c_float, c_int, _P]),
+    'tg_sample_lerp': (c_int, [_P, _P, _FP, _P, c_int, c_int64, c_int, _P]),
+    'tg_sample_scale': (c_int, [_P, _FP, _FP, _P, c_int, c_int64, c_int, _P]),
+    'tg_fill_scaled': (c_int, [_P, _FP, c_float, c_int64, c_int, _P]),
+    'tg_cast': (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
+    'tg_mbstd_fwd': (c_int, [_P, _P, _FP, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    'tg_mbstd_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    'tg_mbstd_bwd_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    'tg_small_gemm': (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'tg_sum': (c_int, [_P, _FP, c_int64, c_float, c_int, c_int, _P]),
+    'tg_abs_diff_sum': (c_int, [_P, _P, _FP, c_int64, c_float, c_int, c_int, _P]),
+    'tg_abs_diff_bwd': (c_int, [_P, _P, _FP, _P, _P, c_int64, c_float, c_int, _P]),
+    'tg_sample_sumsq': (c_int, [_P, _FP, c_int, c_int64, c_int, _P]),
+    'tg_gp_penalty': (c_int, [_FP, _FP, _FP, c_int, c_float, _P]),
+    'tg_adam_step': (c_int, [_FP, _FP, _FP, _FP, _P, c_int64, c_float, c_float, c_float, c_float, c_float, _P]),
+}
+
+_lib = None
+
+
+def load():
+  """Loads (once) and returns the ctypes handle.  Raises TgError if the library was not built."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise TgError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                  '(make -C twingan_amd/csrc). There is no CPU fallback.' % LIB_PATH)
+  lib = ctypes.CDLL(LIB_PATH)
+  for name, (res, args) in SIGNATURES.items():
+    fn = getattr(lib, name)       # AttributeError if a declared symbol is missing
+    fn.restype = res
+    fn.argtypes = args
+  _lib = lib
+  return lib
+
+
+# Optional per-launch profiler used by bench.py's roofline pass: when set to a list, every call is
+# bracketed by HIP events on torch's current stream (the stream the kernels are enqueued on) and
+# (name, tag, flops, bytes, start_event, end_event) is appended.
+profiler = None
+
+
+def call(name, *args, work=None):
+  """Calls an int-returning entry point and raises TgError(tg_last_error()) on failure.
+  ``work`` = (tag, algorithmic flops, algorithmic bytes) of this launch, for the roofline pass."""
+  lib = load()
+  if profiler is not None:
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = getattr(lib, name)(*args)
+    e1.record()
+    if callable(work):
+      work = work()
+    tag, fl, by = work if work is not None else ('', 0, 0)
+    profiler.append((name, tag, fl, by, e0, e1))
+  else:
+    rc = getattr(lib, name)(*args)
+  if rc != 0:
+    raise TgError('%s failed (%d): %s' % (name, rc, lib.tg_last_error().decode()))
+  return rc

@@ -1,0 +1,29 @@
+"""The reference flags that shape the hot path, as one dataclass (the reference scatters them over
+tf.flags in nets/pggan.py:24-59, image_generation.py:50-121, twingan.py:39-88,
+model/model_inheritor.py:41-304)."""
+from dataclasses import dataclass
+
+
+@dataclass
+class Config:
+  hw: int = 256                       # --train_image_size (pggan_runner.py:136-150)
+  max_ch: int = 256                   # --pggan_max_num_channels           nets/pggan.py:51-53
+  generator_norm_type: str = 'instance_norm'   # nets/pggan.py:24 (north-star config)
+  do_pixel_norm: bool = True          # nets/pggan.py:34-38
+  use_unet: bool = True               # twingan.py:53-56
+  is_growing: bool = False            # image_generation.py:69-72
+  alpha_grow: float = 0.0             # twingan.py:833-835
+  loss_architecture: str = 'wgan_gp'  # image_generation.py:81-83
+  gradient_penalty_lambda: float = 10.0   # image_generation.py:92-95
+  gan_weight: float = 1.0             # image_generation.py:84-86
+  wgan_drift_loss_weight: float = 0.0     # image_generation.py:96-98
+  l_cyc_weight: float = 1.0           # twingan.py:73-76
+  l_content_weight: float = 0.1       # twingan.py:80-82
+  do_l_cyc_gan: bool = True           # twingan.py:77-79
+  n_critic: int = 2                   # image_generation.py:87-90
+  learning_rate: float = 1e-4         # docs/training.md:24-25
+  adam_beta1: float = 0.5
+  adam_beta2: float = 0.99
+  opt_epsilon: float = 1e-8
+  precision: str = 'bf16'             # 'bf16': bf16 activations + MFMA convs, fp32 master weights; 'fp32': exact path
+  loss_scale: float = 1.0             # --mix_precision_loss_scale (model_inheritor.py:568-570); bf16 needs none

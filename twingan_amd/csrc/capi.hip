@@ -1,0 +1,76 @@
+// extern "C" entry points that dispatch between algorithms, plus error plumbing.
+#include "tg_common.h"
+
+static thread_local char tg_err[512] = "";
+
+void tg_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(tg_err, sizeof(tg_err), fmt, ap);
+  va_end(ap);
+}
+
+int tg_conv2d_fwd_direct(const TgConvDesc*, const void*, const void*, const float*, void*, hipStream_t);
+int tg_conv2d_bwd_data_direct(const TgConvDesc*, const void*, const void*, void*, hipStream_t);
+int tg_conv2d_bwd_weight_direct(const TgConvDesc*, const void*, const void*, float*, int, hipStream_t);
+int tg_conv2d_fwd_mfma(const TgConvDesc*, const void*, const void*, const float*, void*, hipStream_t);
+int tg_conv2d_bwd_data_mfma(const TgConvDesc*, const void*, const void*, void*, hipStream_t);
+size_t tg_conv2d_bwd_weight_workspace_mfma(const TgConvDesc*);
+int tg_conv2d_bwd_weight_mfma(const TgConvDesc*, const void*, const void*, float*, int, void*, size_t, hipStream_t);
+
+static int check_desc(const char* who, const TgConvDesc* d) {
+  TG_CHECK(d != nullptr, TG_EINVAL, "%s: null descriptor", who);
+  TG_CHECK(d->n > 0 && d->hin > 0 && d->win > 0 && d->cin > 0 && d->hout > 0 && d->wout > 0 && d->cout > 0, TG_EINVAL,
+           "%s: non-positive dimension", who);
+  TG_CHECK(d->kh >= 1 && d->kh <= 4 && d->kw >= 1 && d->kw <= 4, TG_EINVAL, "%s: kernel %dx%d out of range", who, d->kh,
+           d->kw);
+  TG_CHECK(d->pad_t >= 0 && d->pad_t < d->kh && d->pad_l >= 0 && d->pad_l < d->kw, TG_EINVAL, "%s: bad padding", who);
+  // stride 1: the high-side padding implied by hout must be within the kernel
+  const int pb = d->hout + d->kh - 1 - d->hin - d->pad_t, pr = d->wout + d->kw - 1 - d->win - d->pad_l;
+  TG_CHECK(pb >= 0 && pb < d->kh && pr >= 0 && pr < d->kw, TG_EINVAL, "%s: output size %dx%d inconsistent with input", who,
+           d->hout, d->wout);
+  TG_CHECK(d->dtype == TG_F32 || d->dtype == TG_BF16, TG_EINVAL, "%s: dtype %d", who, d->dtype);
+  TG_CHECK(d->algo == TG_ALGO_DIRECT || d->algo == TG_ALGO_MFMA, TG_EINVAL, "%s: algo %d", who, d->algo);
+  return TG_OK;
+}
+
+extern "C" {
+
+int tg_version(void) { return 100; }
+const char* tg_last_error(void) { return tg_err; }
+
+int tg_conv2d_fwd(const TgConvDesc* d, const void* x, const void* w, const float* bias, void* y, void* stream) {
+  int rc = check_desc("tg_conv2d_fwd", d);
+  if (rc) return rc;
+  TG_CHECK(x && w && y, TG_EINVAL, "tg_conv2d_fwd: null pointer");
+  TG_CHECK(tg_aligned16(x) && tg_aligned16(w) && tg_aligned16(y), TG_EALIGN, "tg_conv2d_fwd: pointers must be 16 B aligned");
+  if (d->algo == TG_ALGO_MFMA) return tg_conv2d_fwd_mfma(d, x, w, bias, y, (hipStream_t)stream);
+  return tg_conv2d_fwd_direct(d, x, w, bias, y, (hipStream_t)stream);
+}
+
+int tg_conv2d_bwd_data(const TgConvDesc* d, const void* gy, const void* w, void* gx, void* stream) {
+  int rc = check_desc("tg_conv2d_bwd_data", d);
+  if (rc) return rc;
+  TG_CHECK(gy && w && gx, TG_EINVAL, "tg_conv2d_bwd_data: null pointer");
+  TG_CHECK(tg_aligned16(gy) && tg_aligned16(w) && tg_aligned16(gx), TG_EALIGN,
+           "tg_conv2d_bwd_data: pointers must be 16 B aligned");
+  if (d->algo == TG_ALGO_MFMA) return tg_conv2d_bwd_data_mfma(d, gy, w, gx, (hipStream_t)stream);
+  return tg_conv2d_bwd_data_direct(d, gy, w, gx, (hipStream_t)stream);
+}
+
+size_t tg_conv2d_bwd_weight_workspace(const TgConvDesc* d) {
+  if (!d || d->algo != TG_ALGO_MFMA) return 0;
+  return tg_conv2d_bwd_weight_workspace_mfma(d);
+}
+
+int tg_conv2d_bwd_weight(const TgConvDesc* d, const void* x, const void* gy, float* gw, int accumulate, void* ws,
+                         size_t ws_bytes, void* stream) {
+  int rc = check_desc("tg_conv2d_bwd_weight", d);
+  if (rc) return rc;
+  TG_CHECK(x && gy && gw, TG_EINVAL, "tg_conv2d_bwd_weight: null pointer");
+  TG_CHECK(tg_aligned16(x) && tg_aligned16(gy), TG_EALIGN, "tg_conv2d_bwd_weight: pointers must be 16 B aligned");
+  if (d->algo == TG_ALGO_MFMA) return tg_conv2d_bwd_weight_mfma(d, x, gy, gw, accumulate, ws, ws_bytes, (hipStream_t)stream);
+  return tg_conv2d_bwd_weight_direct(d, x, gy, gw, accumulate, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,545 @@
+// LDS-tiled implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_32x32x16_bf16),
+// bf16 activations / fp32 accumulate, NHWC.
+//
+//   forward / backward-data : conv_fwd_mfma   (backward-data = forward over gy with the rotated,
+//                                              transposed weight pack and pad' = k-1-pad)
+//   backward-weight         : conv_wgrad_mfma (split-K over pixel tiles -> fp32 slabs -> reduce)
+//
+// Tiling (both kernels): a workgroup of 4 waves owns BM = 128 output pixels arranged as
+// TI images x TH rows x TW cols (powers of two, TW*TH*TI = 128) and stages the input *halo* tile
+// [TI][TH+kh-1][TW+kw-1][KC channels] in LDS once per channel chunk; every tap of the filter then
+// reads its shifted window from LDS, so HBM/L2 sees each input element ~once (+halo overlap)
+// instead of kh*kw times.  LDS rows are padded to an odd number of 16-byte slots so that the
+// 16-byte fragment reads of a wave are bank-conflict free (MI355X_MICROARCH.md, LDS table).
+//
+// MFMA operand roles are swapped (A = weights, B = pixels) so the accumulator of a lane holds
+// 4 consecutive output channels of one pixel per register quad -> 8-byte bf16x4 NHWC stores.
+//
+// Reference call sites replaced: tf.contrib.layers.conv2d at nets/pggan_utils.py:316-320 and
+// its TF gradients (Conv2DBackpropInput / Conv2DBackpropFilter).
+#include "tg_common.h"
+
+namespace {
+
+struct Geom {
+  int n, hin, win, cin;        // physical input
+  int hout, wout, cout;        // physical output
+  int cin_pad;                 // channels in the weight pack (multiple of 16)
+  int pad_t, pad_l;
+  int tw_log2, th_log2, ti_log2;
+  int tiles_x, tiles_y, tiles_img;   // tiles per row / per column / image groups
+  int epilogue;
+  float alpha;
+};
+
+extern __shared__ __attribute__((aligned(16))) unsigned char tg_smem[];
+
+constexpr int MAXA = 6;   // max 16-byte A-tile vectors per thread per chunk
+
+__device__ __forceinline__ bf16x8 zero8() {
+  bf16x8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = (bf16)0.f;
+  return z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward (and backward-data) kernel
+// ------------------------------------------------------------------------------------------------
+template <int KH, int KW, int KC, int BN>
+__global__ __launch_bounds__(256) void conv_fwd_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp,
+                                                     const float* __restrict__ bias, bf16* __restrict__ y,
+                                                     const Geom g) {
+  constexpr int NT = KH * KW;
+  constexpr int VPP = KC / 8;                 // 16-byte vectors per pixel per chunk
+  constexpr int PS_A = KC * 2 + 16;           // LDS bytes per halo pixel (odd # of 16 B slots)
+  constexpr int RS_B = NT * KC * 2 + 16;      // LDS bytes per weight row
+  constexpr int NTILE = BN / 32;
+  constexpr int BVEC = BN * NT * VPP;         // B-tile vectors per chunk
+  constexpr int BSLOTS = (BVEC + 255) / 256;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int TW = 1 << g.tw_log2, TH = 1 << g.th_log2, TI = 1 << g.ti_log2;
+  const int HWX = TW + KW - 1, HH = TH + KH - 1;
+  const int halo_px = TI * HH * HWX;
+  unsigned char* sA = tg_smem;
+  unsigned char* sB = tg_smem + ((halo_px * PS_A + 15) & ~15);
+
+  // tile origin
+  int t = blockIdx.x;
+  const int tx = t % g.tiles_x;
+  t /= g.tiles_x;
+  const int ty = t % g.tiles_y;
+  const int tim = t / g.tiles_y;
+  const int ox0 = tx << g.tw_log2, oy0 = ty << g.th_log2, img0 = tim << g.ti_log2;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- fixed A-tile slots of this thread -------------------------------------------------------
+  int a_goff[MAXA];    // element offset of channel 0 of the slot's pixel (+part*8), or -1
+  int a_loff[MAXA];    // LDS byte offset, or -1 when the slot does not exist
+  int a_part[MAXA];
+  const int avec = halo_px * VPP;
+#pragma unroll
+  for (int s = 0; s < MAXA; ++s) {
+    const int v = tid + s * 256;
+    a_goff[s] = -1;
+    a_loff[s] = -1;
+    a_part[s] = 0;
+    if (v < avec) {
+      const int px = v / VPP, part = v - px * VPP;
+      const int hx = px % HWX;
+      const int r = px / HWX;
+      const int hy = r % HH;
+      const int im = r / HH;
+      const int iy = oy0 + hy - g.pad_t, ix = ox0 + hx - g.pad_l, in_ = img0 + im;
+      a_loff[s] = px * PS_A + part * 16;
+      a_part[s] = part * 8;
+      if (iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win && in_ < g.n)
+        a_goff[s] = ((in_ * g.hin + iy) * g.win + ix) * g.cin + part * 8;
+    }
+  }
+
+  // ---- this lane's pixel (B operand / output column) -------------------------------------------
+  const int m = wid * 32 + (lane & 31);
+  const int mx = m & (TW - 1), my = (m >> g.tw_log2) & (TH - 1), mi = m >> (g.tw_log2 + g.th_log2);
+  const int kgrp = lane >> 5;
+  const int a_base = ((mi * HH + my) * HWX + mx) * PS_A + kgrp * 16;
+  const int b_base = (lane & 31) * RS_B + kgrp * 16;
+
+  f32x16 acc[NTILE];
+#pragma unroll
+  for (int i = 0; i < NTILE; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+  const int wrow = NT * g.cin_pad;    // elements per packed weight row
+  for (int c0 = 0; c0 < g.cin_pad; c0 += KC) {
+    if (c0) __syncthreads();
+    // A halo tile
+#pragma unroll
+    for (int s = 0; s < MAXA; ++s) {
+      if (a_loff[s] >= 0) {
+        bf16x8 v = zero8();
+        if (a_goff[s] >= 0 && c0 + a_part[s] + 8 <= g.cin) v = *reinterpret_cast<const bf16x8*>(x + a_goff[s] + c0);
+        *reinterpret_cast<bf16x8*>(sA + a_loff[s]) = v;
+      }
+    }
+    // B (weight) tile: rows n0..n0+BN, all taps, channels c0..c0+KC
+#pragma unroll
+    for (int s = 0; s < BSLOTS; ++s) {
+      const int v = tid + s * 256;
+      if (v < BVEC) {
+        const int row = v / (NT * VPP);
+        const int rem = v - row * (NT * VPP);
+        const int tap = rem / VPP, part = rem - tap * VPP;
+        const bf16x8 w8 = *reinterpret_cast<const bf16x8*>(wp + (size_t)(n0 + row) * wrow + tap * g.cin_pad + c0 + part * 8);
+        *reinterpret_cast<bf16x8*>(sB + row * RS_B + (tap * KC + part * 8) * 2) = w8;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ky = 0; ky < KH; ++ky) {
+#pragma unroll
+      for (int kx = 0; kx < KW; ++kx) {
+        const int a_tap = a_base + (ky * HWX + kx) * PS_A;
+        const int tap = ky * KW + kx;
+#pragma unroll
+        for (int kk = 0; kk < KC / 16; ++kk) {
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sA + a_tap + kk * 32);
+#pragma unroll
+          for (int nt = 0; nt < NTILE; ++nt) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sB + b_base + nt * 32 * RS_B + (tap * KC + kk * 16) * 2);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[nt], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: lane holds pixel m, channels n0 + nt*32 + 8*q + 4*kgrp + {0..3} ----------------
+  const int oy = oy0 + my, ox = ox0 + mx, on = img0 + mi;
+  if (oy < g.hout && ox < g.wout && on < g.n) {
+    bf16* yp = y + ((size_t)(on * g.hout + oy) * g.wout + ox) * g.cout;
+#pragma unroll
+    for (int nt = 0; nt < NTILE; ++nt) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ch = n0 + nt * 32 + q * 8 + kgrp * 4;
+        if (ch < g.cout) {
+          bf16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v = acc[nt][q * 4 + j];
+            if (g.epilogue & TG_EPI_BIAS) v += bias[ch + j];
+            if (g.epilogue & TG_EPI_LRELU) v = lrelu_f(v, g.alpha);
+            o[j] = (bf16)v;
+          }
+          *reinterpret_cast<bf16x4*>(yp + ch) = o;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward-weight kernel.  Block = (k-slice of pixel tiles, 32-wide ci tile, 32-wide co tile).
+// The 4 waves split the 128 pixels of each tile (K dimension) and keep one 32x32 fp32
+// accumulator per tap; at the end they are summed through LDS and written to this k-slice's slab
+// [tap][cin][cout]; conv_wgrad_reduce sums the slabs into the HWIO gradient.
+// D[m = ci][n = co] += sum_pix X[pix + tap][ci] * GY[pix][co]
+// ------------------------------------------------------------------------------------------------
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void conv_wgrad_mfma(const bf16* __restrict__ x, const bf16* __restrict__ gy,
+                                                       float* __restrict__ slab, const Geom g, int n_co_tiles,
+                                                       int tiles_per_block, int total_tiles) {
+  constexpr int NT = KH * KW;
+  constexpr int PS_X = 32 * 2 + 16;   // 32 input channels per halo pixel
+  constexpr int PS_G = 32 * 2 + 16;   // 32 output channels per pixel
+  constexpr int MAXX = 5;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int TW = 1 << g.tw_log2, TH = 1 << g.th_log2, TI = 1 << g.ti_log2;
+  const int HWX = TW + KW - 1, HH = TH + KH - 1;
+  const int halo_px = TI * HH * HWX;
+  unsigned char* sX = tg_smem;
+  unsigned char* sG = tg_smem + ((halo_px * PS_X + 15) & ~15);
+
+  const int ci_tile = blockIdx.y / n_co_tiles, co_tile = blockIdx.y - ci_tile * n_co_tiles;
+  const int ci0 = ci_tile * 32, co0 = co_tile * 32;
+
+  // fixed halo decomposition of this thread's X slots (tile independent)
+  int x_loff[MAXX], x_hy[MAXX], x_hx[MAXX], x_im[MAXX], x_ch[MAXX];
+  const int xvec = halo_px * 4;
+#pragma unroll
+  for (int s = 0; s < MAXX; ++s) {
+    const int v = tid + s * 256;
+    x_loff[s] = -1;
+    x_hy[s] = x_hx[s] = x_im[s] = x_ch[s] = 0;
+    if (v < xvec) {
+      const int px = v >> 2, part = v & 3;
+      x_hx[s] = px % HWX;
+      const int r = px / HWX;
+      x_hy[s] = r % HH;
+      x_im[s] = r / HH;
+      x_ch[s] = ci0 + part * 8;
+      x_loff[s] = px * PS_X + part * 16;
+    }
+  }
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+  const int kgrp = lane >> 5, idx = lane & 31;
+  const int tile_begin = blockIdx.x * tiles_per_block;
+  int tile_end = tile_begin + tiles_per_block;
+  if (tile_end > total_tiles) tile_end = total_tiles;
+
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    int t = tile;
+    const int tx = t % g.tiles_x;
+    t /= g.tiles_x;
+    const int ty = t % g.tiles_y;
+    const int tim = t / g.tiles_y;
+    const int ox0 = tx << g.tw_log2, oy0 = ty << g.th_log2, img0 = tim << g.ti_log2;
+    if (tile != tile_begin) __syncthreads();
+    // X halo tile (32 channels from ci0)
+#pragma unroll
+    for (int s = 0; s < MAXX; ++s) {
+      if (x_loff[s] >= 0) {
+        const int iy = oy0 + x_hy[s] - g.pad_t, ix = ox0 + x_hx[s] - g.pad_l, in_ = img0 + x_im[s];
+        bf16x8 v = zero8();
+        if (iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win && in_ < g.n && x_ch[s] + 8 <= g.cin)
+          v = *reinterpret_cast<const bf16x8*>(x + ((size_t)(in_ * g.hin + iy) * g.win + ix) * g.cin + x_ch[s]);
+        *reinterpret_cast<bf16x8*>(sX + x_loff[s]) = v;
+      }
+    }
+    // GY tile: 128 pixels x 32 channels from co0 (2 vectors per thread)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int v = tid + s * 256;
+      const int pm = v >> 2, part = v & 3;
+      const int px_ = pm & (TW - 1), py_ = (pm >> g.tw_log2) & (TH - 1), pi_ = pm >> (g.tw_log2 + g.th_log2);
+      const int oy = oy0 + py_, ox = ox0 + px_, on = img0 + pi_;
+      bf16x8 w8 = zero8();
+      if (oy < g.hout && ox < g.wout && on < g.n && co0 + part * 8 + 8 <= g.cout)
+        w8 = *reinterpret_cast<const bf16x8*>(gy + ((size_t)(on * g.hout + oy) * g.wout + ox) * g.cout + co0 + part * 8);
+      *reinterpret_cast<bf16x8*>(sG + pm * PS_G + part * 16) = w8;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      // this lane's 8 reduction pixels of the k-step
+      const int m0 = wid * 32 + ks * 16 + kgrp * 8;
+      bf16x8 gf;
+      int xoff[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int mj = m0 + j;
+        gf[j] = *reinterpret_cast<const bf16*>(sG + mj * PS_G + idx * 2);
+        const int jx = mj & (TW - 1), jy = (mj >> g.tw_log2) & (TH - 1), ji = mj >> (g.tw_log2 + g.th_log2);
+        xoff[j] = ((ji * HH + jy) * HWX + jx) * PS_X + idx * 2;
+      }
+#pragma unroll
+      for (int ky = 0; ky < KH; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+          const int tapoff = (ky * HWX + kx) * PS_X;
+          bf16x8 xf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xf[j] = *reinterpret_cast<const bf16*>(sX + xoff[j] + tapoff);
+          acc[ky * KW + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, gf, acc[ky * KW + kx], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- cross-wave reduction through LDS, one tap at a time; write the slab ----------------------
+  float* red = reinterpret_cast<float*>(tg_smem);    // [4 waves][16 regs][64 lanes]
+  float* out = slab + (size_t)blockIdx.x * NT * g.cin * g.cout;
+#pragma unroll
+  for (int tap = 0; tap < NT; ++tap) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wid * 16 + r) * 64 + lane] = acc[tap][r];
+    __syncthreads();
+    // thread -> (lane' = tid & 63, regs (tid >> 6) * 4 .. +3)
+    const int l2 = tid & 63, rq = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = rq * 4 + j;
+      const float sum = red[(0 * 16 + r) * 64 + l2] + red[(1 * 16 + r) * 64 + l2] + red[(2 * 16 + r) * 64 + l2] +
+                        red[(3 * 16 + r) * 64 + l2];
+      const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * (l2 >> 5);
+      const int co = co0 + (l2 & 31);
+      if (ci < g.cin && co < g.cout) out[((size_t)tap * g.cin + ci) * g.cout + co] = sum;
+    }
+  }
+}
+
+__global__ void conv_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ gw, int64_t nw, int nslices,
+                                  int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = accumulate ? gw[i] : 0.f;
+    for (int k = 0; k < nslices; ++k) s += slab[(size_t)k * nw + i];
+    gw[i] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------
+// mode 0: out[co][tap][ci] = w[tap][ci][co];  mode 1: out[ci][tap'][co] = w[NT-1-tap'][ci][co]
+__global__ void pack_weights(const float* __restrict__ w, bf16* __restrict__ out, int nt, int cin, int cout, int rows,
+                             int rows_pad, int inner, int inner_pad, int mode) {
+  const int64_t total = (int64_t)rows_pad * nt * inner_pad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % inner_pad);
+    int64_t r = i / inner_pad;
+    const int tap = (int)(r % nt);
+    const int row = (int)(r / nt);
+    float v = 0.f;
+    if (row < rows && k < inner) {
+      if (mode == 0)
+        v = w[((int64_t)tap * cin + k) * cout + row];
+      else
+        v = w[((int64_t)(nt - 1 - tap) * cin + row) * cout + k];
+    }
+    out[i] = (bf16)v;
+  }
+}
+
+inline int ilog2(int v) {
+  int r = 0;
+  while ((1 << r) < v) ++r;
+  return r;
+}
+
+// choose the 128-pixel tile shape for an output of hout x wout
+void pick_tile(int hout, int wout, Geom* g) {
+  int tw = 1 << ilog2(wout);
+  if (tw > 16) tw = 16;
+  int th = 1 << ilog2(hout);
+  if (th > 128 / tw) th = 128 / tw;
+  const int ti = 128 / (tw * th);
+  g->tw_log2 = ilog2(tw);
+  g->th_log2 = ilog2(th);
+  g->ti_log2 = ilog2(ti);
+  g->tiles_x = (wout + tw - 1) / tw;
+  g->tiles_y = (hout + th - 1) / th;
+}
+
+int fill_geom(const char* who, int n, int hin, int win, int cin, int hout, int wout, int cout, int kh, int kw, int pad_t,
+              int pad_l, Geom* g) {
+  TG_CHECK(cin % 8 == 0 && cout % 8 == 0, TG_EALIGN, "%s(mfma): cin (%d) and cout (%d) must be multiples of 8", who, cin,
+           cout);
+  TG_CHECK((kh == 1 && kw == 1) || (kh == 3 && kw == 3), TG_ENOSUP, "%s(mfma): kernel %dx%d not supported", who, kh, kw);
+  g->n = n; g->hin = hin; g->win = win; g->cin = cin;
+  g->hout = hout; g->wout = wout; g->cout = cout;
+  g->cin_pad = (cin + 15) / 16 * 16;
+  g->pad_t = pad_t; g->pad_l = pad_l;
+  pick_tile(hout, wout, g);
+  const int ti = 1 << g->ti_log2;
+  g->tiles_img = (n + ti - 1) / ti;
+  g->epilogue = 0;
+  g->alpha = 1.f;
+  return TG_OK;
+}
+
+template <int KH, int KW, int KC, int BN>
+int launch_fwd(const Geom& g, const bf16* x, const bf16* wp, const float* bias, bf16* y, hipStream_t s) {
+  const int TW = 1 << g.tw_log2, TH = 1 << g.th_log2, TI = 1 << g.ti_log2;
+  const int halo_px = TI * (TH + KH - 1) * (TW + KW - 1);
+  TG_CHECK(halo_px * (KC / 8) <= 256 * MAXA, TG_ENOSUP, "conv(mfma): halo tile too large (%d px)", halo_px);
+  const size_t lds = ((size_t)(halo_px * (KC * 2 + 16) + 15) & ~(size_t)15) + (size_t)BN * (KH * KW * KC * 2 + 16);
+  TG_CHECK(lds <= 64 * 1024, TG_ENOSUP, "conv(mfma): LDS %zu > 64 KiB", lds);
+  dim3 grid(g.tiles_x * g.tiles_y * g.tiles_img, (g.cout + BN - 1) / BN);
+  hipLaunchKernelGGL((conv_fwd_mfma<KH, KW, KC, BN>), grid, dim3(256), lds, s, x, wp, bias, y, g);
+  TG_LAUNCH_CHECK("conv_fwd_mfma");
+  return TG_OK;
+}
+
+template <int KH, int KW>
+int dispatch_fwd(const Geom& g, const bf16* x, const bf16* wp, const float* bias, bf16* y, hipStream_t s) {
+  const bool wide = g.cout > 32;
+  if constexpr (KH == 1) {
+    if (g.cin_pad % 64 == 0)
+    return wide ? launch_fwd<KH, KW, 64, 64>(g, x, wp, bias, y, s) : launch_fwd<KH, KW, 64, 32>(g, x, wp, bias, y, s);
+  }
+  if (g.cin_pad % 32 == 0) {
+    return wide ? launch_fwd<KH, KW, 32, 64>(g, x, wp, bias, y, s) : launch_fwd<KH, KW, 32, 32>(g, x, wp, bias, y, s);
+  }
+  return wide ? launch_fwd<KH, KW, 16, 64>(g, x, wp, bias, y, s) : launch_fwd<KH, KW, 16, 32>(g, x, wp, bias, y, s);
+}
+
+}  // namespace
+
+// Rewrites "k x k VALID on a k x k input" (1x1 output) as a 1x1 conv over k*k*cin channels: with NHWC
+// activations and HWIO weights both reshapes are free (nets/pggan.py:330-331,495).
+static bool as_dense(const TgConvDesc* d, TgConvDesc* o) {
+  if (d->hout == 1 && d->wout == 1 && d->hin == d->kh && d->win == d->kw && d->pad_t == 0 && d->pad_l == 0 &&
+      (d->kh > 1 || d->kw > 1)) {
+    *o = *d;
+    o->cin = d->cin * d->kh * d->kw;
+    o->hin = o->win = 1;
+    o->kh = o->kw = 1;
+    return true;
+  }
+  return false;
+}
+
+static void pack_dims(const TgConvDesc* d0, int mode, int* nt, int* cin, int* cout, int* rows, int* rows_pad,
+                      int* inner, int* inner_pad) {
+  TgConvDesc dd;
+  const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
+  *nt = d->kh * d->kw;
+  *cin = d->cin;
+  *cout = d->cout;
+  *rows = mode == 0 ? d->cout : d->cin;
+  *inner = mode == 0 ? d->cin : d->cout;
+  *rows_pad = (*rows + 63) / 64 * 64;      // a BN=64 block never reads past the pack
+  *inner_pad = (*inner + 15) / 16 * 16;
+}
+
+size_t tg_conv2d_pack_elems(const TgConvDesc* d, int mode) {
+  int nt, cin, cout, rows, rows_pad, inner, inner_pad;
+  pack_dims(d, mode, &nt, &cin, &cout, &rows, &rows_pad, &inner, &inner_pad);
+  return (size_t)rows_pad * nt * inner_pad;
+}
+
+int tg_conv2d_pack_weights(const TgConvDesc* d, const float* w, int mode, void* out, void* stream) {
+  TG_CHECK(mode == 0 || mode == 1, TG_EINVAL, "tg_conv2d_pack_weights: mode %d", mode);
+  int nt, cin, cout, rows, rows_pad, inner, inner_pad;
+  pack_dims(d, mode, &nt, &cin, &cout, &rows, &rows_pad, &inner, &inner_pad);
+  const int64_t total = (int64_t)rows_pad * nt * inner_pad;
+  hipLaunchKernelGGL(pack_weights, dim3(tg_grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16*)out, nt,
+                     cin, cout, rows, rows_pad, inner, inner_pad, mode);
+  TG_LAUNCH_CHECK("tg_conv2d_pack_weights");
+  return TG_OK;
+}
+
+int tg_conv2d_fwd_mfma(const TgConvDesc* d0, const void* x, const void* wp, const float* bias, void* y, hipStream_t s) {
+  TgConvDesc dd;
+  const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
+  TG_CHECK(d->dtype == TG_BF16, TG_ENOSUP, "tg_conv2d_fwd(mfma): bf16 activations only");
+  Geom g;
+  int rc = fill_geom("tg_conv2d_fwd", d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->kw, d->pad_t,
+                     d->pad_l, &g);
+  if (rc) return rc;
+  g.epilogue = d->epilogue;
+  g.alpha = d->lrelu_alpha;
+  TG_CHECK(!(d->epilogue & TG_EPI_BIAS) || bias, TG_EINVAL, "tg_conv2d_fwd: bias epilogue without bias pointer");
+  if (d->kh == 1) return dispatch_fwd<1, 1>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
+  return dispatch_fwd<3, 3>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
+}
+
+int tg_conv2d_bwd_data_mfma(const TgConvDesc* d0, const void* gy, const void* wp, void* gx, hipStream_t s) {
+  TgConvDesc dd;
+  const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
+  TG_CHECK(d->dtype == TG_BF16, TG_ENOSUP, "tg_conv2d_bwd_data(mfma): bf16 activations only");
+  Geom g;   // a forward conv over gy: in = (hout,wout,cout), out = (hin,win,cin), pad' = k-1-pad
+  int rc = fill_geom("tg_conv2d_bwd_data", d->n, d->hout, d->wout, d->cout, d->hin, d->win, d->cin, d->kh, d->kw,
+                     d->kh - 1 - d->pad_t, d->kw - 1 - d->pad_l, &g);
+  if (rc) return rc;
+  if (d->kh == 1) return dispatch_fwd<1, 1>(g, (const bf16*)gy, (const bf16*)wp, nullptr, (bf16*)gx, s);
+  return dispatch_fwd<3, 3>(g, (const bf16*)gy, (const bf16*)wp, nullptr, (bf16*)gx, s);
+}
+
+static void wgrad_split(const Geom& g, int* n_ci, int* n_co, int* nslices, int* tiles_per_block, int* total_tiles) {
+  *n_ci = (g.cin + 31) / 32;
+  *n_co = (g.cout + 31) / 32;
+  *total_tiles = g.tiles_x * g.tiles_y * g.tiles_img;
+  int want = 1024 / (*n_ci * *n_co);          // aim for ~1024 workgroups (4 per CU)
+  if (want < 1) want = 1;
+  if (want > *total_tiles) want = *total_tiles;
+  *tiles_per_block = (*total_tiles + want - 1) / want;
+  *nslices = (*total_tiles + *tiles_per_block - 1) / *tiles_per_block;
+}
+
+size_t tg_conv2d_bwd_weight_workspace_mfma(const TgConvDesc* d0) {
+  TgConvDesc dd;
+  const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
+  Geom g;
+  if (fill_geom("tg_conv2d_bwd_weight", d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->kw, d->pad_t,
+                d->pad_l, &g))
+    return 0;
+  int n_ci, n_co, nslices, tpb, total;
+  wgrad_split(g, &n_ci, &n_co, &nslices, &tpb, &total);
+  return (size_t)nslices * d->kh * d->kw * d->cin * d->cout * sizeof(float);
+}
+
+int tg_conv2d_bwd_weight_mfma(const TgConvDesc* d0, const void* x, const void* gy, float* gw, int accumulate, void* ws,
+                              size_t ws_bytes, hipStream_t s) {
+  TgConvDesc dd;
+  const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
+  TG_CHECK(d->dtype == TG_BF16, TG_ENOSUP, "tg_conv2d_bwd_weight(mfma): bf16 activations only");
+  Geom g;
+  int rc = fill_geom("tg_conv2d_bwd_weight", d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->kw,
+                     d->pad_t, d->pad_l, &g);
+  if (rc) return rc;
+  int n_ci, n_co, nslices, tpb, total;
+  wgrad_split(g, &n_ci, &n_co, &nslices, &tpb, &total);
+  const int64_t nw = (int64_t)d->kh * d->kw * d->cin * d->cout;
+  TG_CHECK(ws && ws_bytes >= (size_t)nslices * nw * sizeof(float), TG_EINVAL,
+           "tg_conv2d_bwd_weight(mfma): workspace too small (%zu < %zu)", ws_bytes, (size_t)nslices * nw * sizeof(float));
+  const int TW = 1 << g.tw_log2, TH = 1 << g.th_log2, TI = 1 << g.ti_log2;
+  const int halo_px = TI * (TH + d->kh - 1) * (TW + d->kw - 1);
+  TG_CHECK(halo_px * 4 <= 256 * 5, TG_ENOSUP, "conv_wgrad(mfma): halo tile too large (%d px)", halo_px);
+  size_t lds = ((size_t)(halo_px * 80 + 15) & ~(size_t)15) + 128 * 80;
+  if (lds < 4 * 16 * 64 * sizeof(float)) lds = 4 * 16 * 64 * sizeof(float);
+  TG_CHECK(lds <= 64 * 1024, TG_ENOSUP, "conv_wgrad(mfma): LDS %zu > 64 KiB", lds);
+  dim3 grid(nslices, n_ci * n_co);
+  if (d->kh == 1)
+    hipLaunchKernelGGL((conv_wgrad_mfma<1, 1>), grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g,
+                       n_co, tpb, total);
+  else
+    hipLaunchKernelGGL((conv_wgrad_mfma<3, 3>), grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g,
+                       n_co, tpb, total);
+  TG_LAUNCH_CHECK("conv_wgrad_mfma");
+  hipLaunchKernelGGL(conv_wgrad_reduce, dim3(tg_grid_for(nw, 256)), dim3(256), 0, s, (const float*)ws, gw, nw, nslices,
+                     accumulate);
+  TG_LAUNCH_CHECK("conv_wgrad_reduce");
+  return TG_OK;
+}

@@ -1,0 +1,420 @@
+// Instance norm statistics, the fused (instance-norm affine + LeakyReLU + pixel-norm) forward and
+// backward, and per-channel sums (BiasAddGrad).  NHWC, fp32 or bf16 storage, fp32 math.
+//
+// Reference: libs/instance_norm.py:131-135 (tf.nn.moments over H,W + tf.nn.batch_normalization),
+// util_misc.py:68-86 (LeakyReLU), nets/pggan_utils.py:330-331 (pixel norm); layer order
+// conv -> norm -> act -> pixel-norm (nets/pggan.py:78-81).
+//
+// Thread mapping everywhere: one thread owns one V-wide channel vector of one pixel; the C/V
+// threads of a pixel are adjacent lanes of one wave, so the per-pixel channel reduction of pixel
+// norm is a butterfly shuffle inside the wave.
+#include "tg_common.h"
+
+namespace {
+
+#define NF_LRELU 1
+#define NF_PIXNORM 2
+
+template <typename T, int V>
+struct VecIO {
+  __device__ static __forceinline__ void load(const T* p, float* o) {
+    if constexpr (V == 1) {
+      o[0] = ld(p);
+    } else {
+      Vec16<T> v = ldv(p);
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = v.get(j);
+    }
+  }
+  __device__ static __forceinline__ void store(T* p, const float* o) {
+    if constexpr (V == 1) {
+      st(p, o[0]);
+    } else {
+      Vec16<T> v;
+#pragma unroll
+      for (int j = 0; j < V; ++j) v.set(j, o[j]);
+      stv(p, v);
+    }
+  }
+};
+
+// group-wide (g lanes, power of two <= 64) butterfly sum
+__device__ __forceinline__ float group_sum(float v, int g) {
+  for (int o = g >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// statistics: shifted sums  S1 = sum(y - K), S2 = sum((y-K)^2) with K = y[n,0,0,c]  (stable in fp32)
+// accumulated into mean[] / rstd[] (pre-zeroed), finalised in place.
+// grid = (chunks, n).  block = 256 threads = (256/cv pixel lanes) x (cv vectors)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int V>
+__global__ void in_stats_partial(const T* __restrict__ y, float* __restrict__ s1, float* __restrict__ s2, int hw, int c,
+                                 int px_per_block) {
+  extern __shared__ float sh[];   // [2][c]
+  const int cv = c / V;
+  const int lanes = blockDim.x / cv;
+  const int v = threadIdx.x % cv, pl = threadIdx.x / cv;
+  const int n = blockIdx.y;
+  for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) sh[i] = 0.f;
+  __syncthreads();
+  const T* base = y + (int64_t)n * hw * c;
+  float k[V], a1[V], a2[V];
+  VecIO<T, V>::load(base + v * V, k);
+#pragma unroll
+  for (int j = 0; j < V; ++j) a1[j] = a2[j] = 0.f;
+  const int p0 = blockIdx.x * px_per_block;
+  const int p1 = min(p0 + px_per_block, hw);
+  if (pl < lanes) {
+    for (int p = p0 + pl; p < p1; p += lanes) {
+      float x[V];
+      VecIO<T, V>::load(base + (int64_t)p * c + v * V, x);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float d = x[j] - k[j];
+        a1[j] += d;
+        a2[j] = fmaf(d, d, a2[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      atomicAdd(&sh[v * V + j], a1[j]);
+      atomicAdd(&sh[c + v * V + j], a2[j]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < c; i += blockDim.x) {
+    atomicAdd(s1 + (int64_t)n * c + i, sh[i]);
+    atomicAdd(s2 + (int64_t)n * c + i, sh[c + i]);
+  }
+}
+
+template <typename T>
+__global__ void in_stats_final(const T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int n, int hw,
+                               int c, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * c) return;
+  const int in_ = i / c, ch = i - in_ * c;
+  const float k = ld(y + (int64_t)in_ * hw * c + ch);
+  const float inv = 1.f / (float)hw;
+  const float m1 = mean[i] * inv, m2 = rstd[i] * inv;
+  float var = m2 - m1 * m1;
+  var = var < 0.f ? 0.f : var;
+  mean[i] = k + m1;
+  rstd[i] = rsqrtf(var + eps);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward:  u = (y - mean) * rstd * gamma + beta ; a = lrelu(u) ; z = a * s, s = rsqrt(mean_c a^2 + eps)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int V>
+__global__ void norm_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, T* __restrict__ z, float* __restrict__ pn_scale,
+                                    int64_t npix, int hw, int c, int flags, float alpha, float pn_eps) {
+  const int cv = c / V;
+  const int64_t total = npix * cv;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // total is padded up to a multiple of the stride step so that all lanes of a pixel group stay converged
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int v = (int)(i % cv);
+    const int64_t p = i / cv;
+    const int n = (int)(p / hw);
+    float x[V];
+    VecIO<T, V>::load(y + p * c + v * V, x);
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const int ch = v * V + j;
+      const float r = rstd[n * c + ch] * gamma[ch];
+      float u = x[j] * r + (beta[ch] - mean[n * c + ch] * r);      // tf.nn.batch_normalization form
+      if (flags & NF_LRELU) u = lrelu_f(u, alpha);
+      x[j] = u;
+      ss = fmaf(u, u, ss);
+    }
+    if (flags & NF_PIXNORM) {
+      ss = group_sum(ss, cv);
+      const float s = rsqrtf(ss / (float)c + pn_eps);
+#pragma unroll
+      for (int j = 0; j < V; ++j) x[j] *= s;
+      if (pn_scale && v == 0) pn_scale[p] = s;
+    }
+    VecIO<T, V>::store(z + p * c + v * V, x);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward pass 1: gu = d loss / d u (pre-activation), written to gy (temporary);
+//                  sums[n][c][0] += gu, sums[n][c][1] += gu * yhat
+// ------------------------------------------------------------------------------------------------
+template <typename T, int V>
+__global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restrict__ y, const float* __restrict__ pn_scale,
+                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ gu_out,
+                                     float* __restrict__ sums, int hw, int c, int flags, float alpha, int px_per_block) {
+  extern __shared__ float sh[];   // [2][c]
+  const int cv = c / V;
+  const int lanes = blockDim.x / cv;
+  const int v = threadIdx.x % cv, pl = threadIdx.x / cv;
+  const int n = blockIdx.y;
+  for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) sh[i] = 0.f;
+  __syncthreads();
+  float mu[V], rs[V], ga[V], be[V], a1[V], a2[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int ch = v * V + j;
+    mu[j] = mean[n * c + ch];
+    rs[j] = rstd[n * c + ch];
+    ga[j] = gamma[ch];
+    be[j] = beta[ch];
+    a1[j] = a2[j] = 0.f;
+  }
+  const int p0 = blockIdx.x * px_per_block;
+  const int p1 = min(p0 + px_per_block, hw);
+  // every lane of a pixel group iterates the same number of times (pl is uniform within a group)
+  if (pl < lanes) {
+    for (int p = p0 + pl; p < p1; p += lanes) {
+      const int64_t gp = (int64_t)n * hw + p;
+      float g[V], x[V], yh[V], u[V];
+      VecIO<T, V>::load(gz + gp * c + v * V, g);
+      VecIO<T, V>::load(y + gp * c + v * V, x);
+      float dot = 0.f;
+      const float s = (flags & NF_PIXNORM) ? pn_scale[gp] : 1.f;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        yh[j] = (x[j] - mu[j]) * rs[j];
+        u[j] = yh[j] * ga[j] + be[j];
+        const float a = (flags & NF_LRELU) ? lrelu_f(u[j], alpha) : u[j];
+        dot = fmaf(g[j], a * s, dot);          // gz . z
+        x[j] = a * s;                          // z
+      }
+      if (flags & NF_PIXNORM) {
+        dot = group_sum(dot, cv) / (float)c;
+#pragma unroll
+        for (int j = 0; j < V; ++j) g[j] = s * (g[j] - x[j] * dot);     // d/da
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        if (flags & NF_LRELU) g[j] *= (u[j] > 0.f ? 1.f : alpha);
+        const float gr = rnd<T>(g[j]);      // what pass 2 will read back
+        a1[j] += gr;
+        a2[j] = fmaf(gr, yh[j], a2[j]);
+      }
+      VecIO<T, V>::store(gu_out + gp * c + v * V, g);
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      atomicAdd(&sh[v * V + j], a1[j]);
+      atomicAdd(&sh[c + v * V + j], a2[j]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < c; i += blockDim.x) {
+    atomicAdd(sums + ((int64_t)n * c + i) * 2 + 0, sh[i]);
+    atomicAdd(sums + ((int64_t)n * c + i) * 2 + 1, sh[c + i]);
+  }
+}
+
+// backward pass 2: gy = gamma*rstd * (gu - S1/hw - yhat * S2/hw)   (in place over gu)
+template <typename T, int V>
+__global__ void norm_act_bwd2_kernel(T* __restrict__ gy, const T* __restrict__ y, const float* __restrict__ mean,
+                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                     const float* __restrict__ sums, int64_t npix, int hw, int c) {
+  const int cv = c / V;
+  const int64_t total = npix * cv;
+  const float inv = 1.f / (float)hw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int v = (int)(i % cv);
+    const int64_t p = i / cv;
+    const int n = (int)(p / hw);
+    float g[V], x[V];
+    VecIO<T, V>::load(gy + p * c + v * V, g);
+    VecIO<T, V>::load(y + p * c + v * V, x);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const int ch = v * V + j;
+      const float r = rstd[n * c + ch];
+      const float yh = (x[j] - mean[n * c + ch]) * r;
+      const float s1 = sums[((int64_t)n * c + ch) * 2] * inv, s2 = sums[((int64_t)n * c + ch) * 2 + 1] * inv;
+      g[j] = gamma[ch] * r * (g[j] - s1 - yh * s2);
+    }
+    VecIO<T, V>::store(gy + p * c + v * V, g);
+  }
+}
+
+__global__ void norm_param_grads(const float* __restrict__ sums, float* __restrict__ ggamma, float* __restrict__ gbeta,
+                                 int n, int c, int accumulate) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  float sb = 0.f, sg = 0.f;
+  for (int i = 0; i < n; ++i) {
+    sb += sums[((int64_t)i * c + ch) * 2];
+    sg += sums[((int64_t)i * c + ch) * 2 + 1];
+  }
+  if (ggamma) ggamma[ch] = (accumulate ? ggamma[ch] : 0.f) + sg;
+  if (gbeta) gbeta[ch] = (accumulate ? gbeta[ch] : 0.f) + sb;
+}
+
+// out[c] += sum_p g[p][c]
+template <typename T, int V>
+__global__ void channel_sum_kernel(const T* __restrict__ g, float* __restrict__ out, int64_t npix, int c) {
+  extern __shared__ float sh[];   // [c]
+  const int cv = c / V;
+  const int lanes = blockDim.x / cv;
+  const int v = threadIdx.x % cv, pl = threadIdx.x / cv;
+  for (int i = threadIdx.x; i < c; i += blockDim.x) sh[i] = 0.f;
+  __syncthreads();
+  float a[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) a[j] = 0.f;
+  if (pl < lanes) {
+    for (int64_t p = (int64_t)blockIdx.x * lanes + pl; p < npix; p += (int64_t)gridDim.x * lanes) {
+      float x[V];
+      VecIO<T, V>::load(g + p * c + v * V, x);
+#pragma unroll
+      for (int j = 0; j < V; ++j) a[j] += x[j];
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) atomicAdd(&sh[v * V + j], a[j]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < c; i += blockDim.x) atomicAdd(out + i, sh[i]);
+}
+
+// largest power of two <= 64 check for the pixel-norm group reduction
+inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+template <typename T>
+int pick_v(int c) {
+  constexpr int V = Vec16<T>::N;
+  return (c % V == 0 && c / V <= 256) ? V : 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tg_instance_norm_stats(const void* y, float* mean, float* rstd, int n, int h, int w, int c, float eps, int dtype,
+                           void* stream) {
+  TG_CHECK(y && mean && rstd && n > 0 && h > 0 && w > 0 && c > 0, TG_EINVAL, "tg_instance_norm_stats: bad arguments");
+  TG_CHECK(c <= 256 * 8, TG_ENOSUP, "tg_instance_norm_stats: c=%d too large", c);
+  hipStream_t s = (hipStream_t)stream;
+  const int hw = h * w;
+  if (hipMemsetAsync(mean, 0, (size_t)n * c * sizeof(float), s) != hipSuccess ||
+      hipMemsetAsync(rstd, 0, (size_t)n * c * sizeof(float), s) != hipSuccess) {
+    tg_set_error("tg_instance_norm_stats: memset failed");
+    return TG_ELAUNCH;
+  }
+  int chunks = (1024 + n - 1) / n;                      // ~1024 blocks in total
+  int ppb = (hw + chunks - 1) / chunks;
+  if (ppb < 64) ppb = 64;
+  chunks = (hw + ppb - 1) / ppb;
+  TG_DISPATCH_DTYPE(dtype, "tg_instance_norm_stats", {
+    const int V = pick_v<T>(c);
+    TG_CHECK(c / V <= 256, TG_ENOSUP, "tg_instance_norm_stats: c=%d not supported", c);
+    const size_t lds = 2 * (size_t)c * sizeof(float);
+    if (V == 1)
+      hipLaunchKernelGGL((in_stats_partial<T, 1>), dim3(chunks, n), dim3(256), lds, s, (const T*)y, mean, rstd, hw, c, ppb);
+    else
+      hipLaunchKernelGGL((in_stats_partial<T, Vec16<T>::N>), dim3(chunks, n), dim3(256), lds, s, (const T*)y, mean, rstd,
+                         hw, c, ppb);
+    hipLaunchKernelGGL(in_stats_final<T>, dim3((n * c + 255) / 256), dim3(256), 0, s, (const T*)y, mean, rstd, n, hw, c,
+                       eps);
+  });
+  TG_LAUNCH_CHECK("tg_instance_norm_stats");
+  return TG_OK;
+}
+
+int tg_norm_act_fwd(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta, void* z,
+                    float* pn_scale, int n, int h, int w, int c, int flags, float alpha, float pn_eps, int dtype,
+                    void* stream) {
+  TG_CHECK(y && mean && rstd && gamma && beta && z && n > 0 && h > 0 && w > 0 && c > 0, TG_EINVAL,
+           "tg_norm_act_fwd: bad arguments");
+  const int64_t npix = (int64_t)n * h * w;
+  TG_DISPATCH_DTYPE(dtype, "tg_norm_act_fwd", {
+    constexpr int VN = Vec16<T>::N;
+    const bool vec = (c % VN == 0) && pow2(c / VN) && c / VN <= 64;
+    if (flags & NF_PIXNORM) {
+      TG_CHECK(vec, TG_ENOSUP, "tg_norm_act_fwd: pixel norm needs c (%d) = %d * 2^k <= %d", c, VN, 64 * VN);
+      TG_CHECK(pn_scale, TG_EINVAL, "tg_norm_act_fwd: pixel norm needs pn_scale");
+    }
+    if (vec) {
+      // grid stride must be a multiple of the group size so pixel groups stay in one wave: 256 % (c/VN) == 0 holds
+      hipLaunchKernelGGL((norm_act_fwd_kernel<T, VN>), dim3(tg_grid_for(npix * (c / VN), 256)), dim3(256), 0,
+                         (hipStream_t)stream, (const T*)y, mean, rstd, gamma, beta, (T*)z, pn_scale, npix, h * w, c, flags,
+                         alpha, pn_eps);
+    } else {
+      hipLaunchKernelGGL((norm_act_fwd_kernel<T, 1>), dim3(tg_grid_for(npix * c, 256)), dim3(256), 0, (hipStream_t)stream,
+                         (const T*)y, mean, rstd, gamma, beta, (T*)z, pn_scale, npix, h * w, c, flags, alpha, pn_eps);
+    }
+  });
+  TG_LAUNCH_CHECK("tg_norm_act_fwd");
+  return TG_OK;
+}
+
+int tg_norm_act_bwd(const void* gz, const void* y, const float* pn_scale, const float* mean, const float* rstd,
+                    const float* gamma, const float* beta, void* gy, float* ggamma, float* gbeta, float* sums, int n, int h,
+                    int w, int c, int flags, float alpha, int accumulate, int dtype, void* stream) {
+  TG_CHECK(gz && y && mean && rstd && gamma && beta && gy && sums && n > 0 && h > 0 && w > 0 && c > 0, TG_EINVAL,
+           "tg_norm_act_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int hw = h * w;
+  const int64_t npix = (int64_t)n * hw;
+  if (hipMemsetAsync(sums, 0, (size_t)n * c * 2 * sizeof(float), s) != hipSuccess) {
+    tg_set_error("tg_norm_act_bwd: memset failed");
+    return TG_ELAUNCH;
+  }
+  int chunks = (1024 + n - 1) / n;
+  int ppb = (hw + chunks - 1) / chunks;
+  if (ppb < 64) ppb = 64;
+  chunks = (hw + ppb - 1) / ppb;
+  TG_DISPATCH_DTYPE(dtype, "tg_norm_act_bwd", {
+    constexpr int VN = Vec16<T>::N;
+    const bool vec = (c % VN == 0) && pow2(c / VN) && c / VN <= 64;
+    const size_t lds = 2 * (size_t)c * sizeof(float);
+    if (flags & NF_PIXNORM) {
+      TG_CHECK(vec && pn_scale, TG_ENOSUP, "tg_norm_act_bwd: pixel norm needs c (%d) = %d * 2^k and pn_scale", c, VN);
+    }
+    if (vec) {
+      hipLaunchKernelGGL((norm_act_bwd1_kernel<T, VN>), dim3(chunks, n), dim3(256), lds, s, (const T*)gz, (const T*)y,
+                         pn_scale, mean, rstd, gamma, beta, (T*)gy, sums, hw, c, flags, alpha, ppb);
+      hipLaunchKernelGGL((norm_act_bwd2_kernel<T, VN>), dim3(tg_grid_for(npix * (c / VN), 256)), dim3(256), 0, s, (T*)gy,
+                         (const T*)y, mean, rstd, gamma, sums, npix, hw, c);
+    } else {
+      TG_CHECK(c <= 256, TG_ENOSUP, "tg_norm_act_bwd: scalar path needs c <= 256 (got %d)", c);
+      hipLaunchKernelGGL((norm_act_bwd1_kernel<T, 1>), dim3(chunks, n), dim3(256), lds, s, (const T*)gz, (const T*)y,
+                         pn_scale, mean, rstd, gamma, beta, (T*)gy, sums, hw, c, flags, alpha, ppb);
+      hipLaunchKernelGGL((norm_act_bwd2_kernel<T, 1>), dim3(tg_grid_for(npix * c, 256)), dim3(256), 0, s, (T*)gy,
+                         (const T*)y, mean, rstd, gamma, sums, npix, hw, c);
+    }
+  });
+  if (ggamma || gbeta)
+    hipLaunchKernelGGL(norm_param_grads, dim3((c + 255) / 256), dim3(256), 0, s, sums, ggamma, gbeta, n, c, accumulate);
+  TG_LAUNCH_CHECK("tg_norm_act_bwd");
+  return TG_OK;
+}
+
+int tg_channel_sum(const void* g, float* out, int64_t npix, int c, int accumulate, int dtype, void* stream) {
+  TG_CHECK(g && out && npix > 0 && c > 0, TG_EINVAL, "tg_channel_sum: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate && hipMemsetAsync(out, 0, (size_t)c * sizeof(float), s) != hipSuccess) {
+    tg_set_error("tg_channel_sum: memset failed");
+    return TG_ELAUNCH;
+  }
+  TG_DISPATCH_DTYPE(dtype, "tg_channel_sum", {
+    const int V = pick_v<T>(c);
+    TG_CHECK(c / V <= 256, TG_ENOSUP, "tg_channel_sum: c=%d not supported", c);
+    const int lanes = 256 / (c / V);
+    const int blocks = tg_grid_for(npix, lanes * 8, 1024);
+    const size_t lds = (size_t)c * sizeof(float);
+    if (V == 1)
+      hipLaunchKernelGGL((channel_sum_kernel<T, 1>), dim3(blocks), dim3(256), lds, s, (const T*)g, out, npix, c);
+    else
+      hipLaunchKernelGGL((channel_sum_kernel<T, Vec16<T>::N>), dim3(blocks), dim3(256), lds, s, (const T*)g, out, npix, c);
+  });
+  TG_LAUNCH_CHECK("tg_channel_sum");
+  return TG_OK;
+}
+
+}  // extern "C"

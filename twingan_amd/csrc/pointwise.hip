@@ -1,0 +1,597 @@
+// Bandwidth-bound pointwise / resampling kernels of the TwinGAN hot path (NHWC, fp32 or bf16
+// storage, fp32 math, 16-byte vector accesses wherever the channel count allows).
+#include "tg_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// generic vectorised elementwise driver: f(i, vec...) over numel elements
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void axpby_kernel(const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ out, int64_t numel, float a,
+                             float b) {
+  constexpr int V = Vec16<T>::N;
+  const int64_t nvec = numel / V;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    Vec16<T> vx = ldv(x + i * V), vo;
+    if (y) {
+      Vec16<T> vy = ldv(y + i * V);
+#pragma unroll
+      for (int j = 0; j < V; ++j) vo.set(j, a * vx.get(j) + b * vy.get(j));
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) vo.set(j, a * vx.get(j));
+    }
+    stv(out + i * V, vo);
+  }
+  for (int64_t i = nvec * V + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride)
+    st(out + i, a * ld(x + i) + (y ? b * ld(y + i) : 0.f));
+}
+
+template <typename T>
+__global__ void lrelu_bwd_kernel(const T* __restrict__ gz, const T* __restrict__ z, T* __restrict__ gy, int64_t numel,
+                                 float alpha) {
+  constexpr int V = Vec16<T>::N;
+  const int64_t nvec = numel / V;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    Vec16<T> vg = ldv(gz + i * V), vz = ldv(z + i * V), vo;
+#pragma unroll
+    for (int j = 0; j < V; ++j) vo.set(j, vg.get(j) * (vz.get(j) > 0.f ? 1.f : alpha));
+    stv(gy + i * V, vo);
+  }
+  for (int64_t i = nvec * V + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride)
+    st(gy + i, ld(gz + i) * (ld(z + i) > 0.f ? 1.f : alpha));
+}
+
+template <typename T>
+__global__ void bias_lrelu_kernel(const T* __restrict__ y, const float* __restrict__ bias, T* __restrict__ z,
+                                  int64_t numel, int c, float alpha) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  constexpr int V = Vec16<T>::N;
+  if (c % V == 0) {
+    const int64_t nvec = numel / V;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+      const int ch = (int)((i * V) % c);
+      Vec16<T> vy = ldv(y + i * V), vo;
+#pragma unroll
+      for (int j = 0; j < V; ++j) vo.set(j, lrelu_f(vy.get(j) + (bias ? bias[ch + j] : 0.f), alpha));
+      stv(z + i * V, vo);
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride)
+      st(z + i, lrelu_f(ld(y + i) + (bias ? bias[i % c] : 0.f), alpha));
+  }
+}
+
+template <typename T>
+__global__ void fill_scaled_kernel(T* __restrict__ out, const float* __restrict__ scalar, float value, int64_t numel) {
+  const float v = value * (scalar ? scalar[0] : 1.f);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x)
+    st(out + i, v);
+}
+
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, int64_t numel) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) st(d + i, ld(s + i));
+}
+
+// out[b, :] = x + alpha[b] * (y - x)
+template <typename T>
+__global__ void sample_lerp_kernel(const T* __restrict__ x, const T* __restrict__ y, const float* __restrict__ alpha,
+                                   T* __restrict__ out, int64_t per, int64_t numel) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) {
+    const float a = alpha[i / per], vx = ld(x + i);
+    st(out + i, vx + a * (ld(y + i) - vx));
+  }
+}
+
+template <typename T>
+__global__ void sample_scale_kernel(const T* __restrict__ x, const float* __restrict__ coef,
+                                    const float* __restrict__ scalar, T* __restrict__ out, int64_t per, int64_t numel) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float sc = scalar ? scalar[0] : 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride)
+    st(out + i, ld(x + i) * coef[i / per] * sc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2x nearest upsample (+ channel concat), its backward; 2x2 pool and its backward.
+// One thread per 16-byte channel vector of one OUTPUT pixel (scalar path when c % V != 0).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int V>
+__global__ void upsample_concat_fwd_kernel(const T* __restrict__ x0, const T* __restrict__ x1, T* __restrict__ out, int n,
+                                           int h, int w, int c0, int c1) {
+  const int c = c0 + c1, cv = c / V, c0v = c0 / V;
+  const int64_t total = (int64_t)n * (2 * h) * (2 * w) * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int v = (int)(i % cv);
+    int64_t p = i / cv;
+    const int ox = (int)(p % (2 * w));
+    p /= 2 * w;
+    const int oy = (int)(p % (2 * h));
+    const int in_ = (int)(p / (2 * h));
+    const T* src = (v < c0v) ? x0 + (((int64_t)in_ * h + (oy >> 1)) * w + (ox >> 1)) * c0 + v * V
+                             : x1 + (((int64_t)in_ * 2 * h + oy) * (2 * w) + ox) * c1 + (v - c0v) * V;
+    T* dst = out + (((int64_t)in_ * 2 * h + oy) * (2 * w) + ox) * c + v * V;
+    if (V == 1)
+      *dst = *src;
+    else
+      stv(dst, ldv(src));
+  }
+}
+
+template <typename T, int V>
+__global__ void upsample_concat_bwd_kernel(const T* __restrict__ go, T* __restrict__ g0, T* __restrict__ g1, int n, int h,
+                                           int w, int c0, int c1) {
+  // g0: one thread per (input pixel, vector) sums its 2x2 block; g1: copy of the tail channels.
+  const int c = c0 + c1, c0v = c0 / V, c1v = c1 / V;
+  const int64_t t0 = g0 ? (int64_t)n * h * w * c0v : 0;
+  const int64_t t1 = g1 ? (int64_t)n * 4 * h * w * c1v : 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < t0 + t1; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < t0) {
+      const int v = (int)(i % c0v);
+      int64_t p = i / c0v;
+      const int x = (int)(p % w);
+      p /= w;
+      const int y = (int)(p % h);
+      const int in_ = (int)(p / h);
+      float acc[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const T* src = go + (((int64_t)in_ * 2 * h + 2 * y + dy) * (2 * w) + 2 * x + dx) * c + v * V;
+          if (V == 1) {
+            acc[0] += ld(src);
+          } else {
+            Vec16<T> s = ldv(src);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] += s.get(j);
+          }
+        }
+      T* dst = g0 + (((int64_t)in_ * h + y) * w + x) * c0 + v * V;
+      if (V == 1) {
+        st(dst, acc[0]);
+      } else {
+        Vec16<T> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) o.set(j, acc[j]);
+        stv(dst, o);
+      }
+    } else {
+      const int64_t k = i - t0;
+      const int v = (int)(k % c1v);
+      const int64_t p = k / c1v;      // output pixel linear index
+      const T* src = go + p * c + c0 + v * V;
+      T* dst = g1 + p * c1 + v * V;
+      if (V == 1)
+        *dst = *src;
+      else
+        stv(dst, ldv(src));
+    }
+  }
+}
+
+template <typename T, int V>
+__global__ void pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c, float scale) {
+  const int cv = c / V, ho = h / 2, wo = w / 2;
+  const int64_t total = (int64_t)n * ho * wo * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int v = (int)(i % cv);
+    int64_t p = i / cv;
+    const int ox = (int)(p % wo);
+    p /= wo;
+    const int oy = (int)(p % ho);
+    const int in_ = (int)(p / ho);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const T* src = x + (((int64_t)in_ * h + 2 * oy + dy) * w + 2 * ox + dx) * c + v * V;
+        if (V == 1) {
+          acc[0] += ld(src);
+        } else {
+          Vec16<T> s = ldv(src);
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc[j] += s.get(j);
+        }
+      }
+    T* dst = y + (((int64_t)in_ * ho + oy) * wo + ox) * c + v * V;
+    if (V == 1) {
+      st(dst, acc[0] * scale);
+    } else {
+      Vec16<T> o;
+#pragma unroll
+      for (int j = 0; j < V; ++j) o.set(j, acc[j] * scale);
+      stv(dst, o);
+    }
+  }
+}
+
+template <typename T, int V>
+__global__ void pool_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, int n, int h, int w, int c, float scale) {
+  const int cv = c / V, ho = h / 2, wo = w / 2;
+  const int64_t total = (int64_t)n * h * w * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int v = (int)(i % cv);
+    int64_t p = i / cv;
+    const int x = (int)(p % w);
+    p /= w;
+    const int y = (int)(p % h);
+    const int in_ = (int)(p / h);
+    T* dst = gx + (((int64_t)in_ * h + y) * w + x) * c + v * V;
+    if ((y >> 1) >= ho || (x >> 1) >= wo) {   // odd trailing row/col (VALID pooling drops it)
+      if (V == 1) {
+        st(dst, 0.f);
+      } else {
+        Vec16<T> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) o.set(j, 0.f);
+        stv(dst, o);
+      }
+      continue;
+    }
+    const T* src = gy + (((int64_t)in_ * ho + (y >> 1)) * wo + (x >> 1)) * c + v * V;
+    if (V == 1) {
+      st(dst, ld(src) * scale);
+    } else {
+      Vec16<T> s = ldv(src), o;
+#pragma unroll
+      for (int j = 0; j < V; ++j) o.set(j, s.get(j) * scale);
+      stv(dst, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1x1 convs with a tiny (<= 4) channel count on one side.
+// ------------------------------------------------------------------------------------------------
+// small-in: y[p, co] = sum_{ci<cin} x[p,ci] * w[ci,co]; thread = (pixel, V-vector of co)
+template <typename T, int V>
+__global__ void pw_small_in_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                   T* __restrict__ y, int64_t npix, int cin, int cout, int wt, int epi, float alpha) {
+  extern __shared__ float sw[];   // [cin][cout] (+ bias[cout])
+  for (int i = threadIdx.x; i < cin * cout; i += blockDim.x) {
+    const int ci = i / cout, co = i - ci * cout;
+    sw[i] = rnd<T>(wt ? w[co * cin + ci] : w[i]);
+  }
+  for (int i = threadIdx.x; i < cout; i += blockDim.x) sw[cin * cout + i] = (epi & TG_EPI_BIAS) ? bias[i] : 0.f;
+  __syncthreads();
+  const int cv = cout / V;
+  const int64_t total = npix * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int v = (int)(i % cv);
+    const int64_t p = i / cv;
+    float xin[4];
+    for (int ci = 0; ci < cin; ++ci) xin[ci] = ld(x + p * cin + ci);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float a = 0.f;
+      for (int ci = 0; ci < cin; ++ci) a = fmaf(xin[ci], sw[ci * cout + v * V + j], a);
+      a += sw[cin * cout + v * V + j];
+      if (epi & TG_EPI_LRELU) a = lrelu_f(a, alpha);
+      acc[j] = a;
+    }
+    T* dst = y + p * cout + v * V;
+    if (V == 1) {
+      st(dst, acc[0]);
+    } else {
+      Vec16<T> o;
+#pragma unroll
+      for (int j = 0; j < V; ++j) o.set(j, acc[j]);
+      stv(dst, o);
+    }
+  }
+}
+
+// small-out: y[p, co<cout<=4] = sum_ci x[p,ci] * w[ci,co]; thread = pixel, loops over V-vectors of ci
+template <typename T, int V>
+__global__ void pw_small_out_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                    T* __restrict__ y, int64_t npix, int cin, int cout, int wt, int epi, float alpha) {
+  extern __shared__ float sw[];   // [cout][cin]  (transposed for contiguous reads) + bias
+  for (int i = threadIdx.x; i < cin * cout; i += blockDim.x) {
+    const int co = i / cin, ci = i - co * cin;
+    sw[i] = rnd<T>(wt ? w[co * cin + ci] : w[ci * cout + co]);
+  }
+  for (int i = threadIdx.x; i < cout; i += blockDim.x) sw[cin * cout + i] = (epi & TG_EPI_BIAS) ? bias[i] : 0.f;
+  __syncthreads();
+  const int civ = cin / V;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int v = 0; v < civ; ++v) {
+      float xv[V];
+      if (V == 1) {
+        xv[0] = ld(x + p * cin + v);
+      } else {
+        Vec16<T> s = ldv(x + p * cin + v * V);
+#pragma unroll
+        for (int j = 0; j < V; ++j) xv[j] = s.get(j);
+      }
+      for (int co = 0; co < cout; ++co)
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[co] = fmaf(xv[j], sw[co * cin + v * V + j], acc[co]);
+    }
+    for (int co = 0; co < cout; ++co) {
+      float a = acc[co] + sw[cin * cout + co];
+      if (epi & TG_EPI_LRELU) a = lrelu_f(a, alpha);
+      st(y + p * cout + co, a);
+    }
+  }
+}
+
+// out[s*os + c*oc] += sum_p small[p, s] * big[p, c];   thread = (pixel lane, V-vector of big channels)
+template <typename T, int V>
+__global__ void pw_wgrad_kernel(const T* __restrict__ small, const T* __restrict__ big, float* __restrict__ out,
+                                int64_t npix, int ns, int cb, int os, int oc) {
+  extern __shared__ float sacc[];   // [ns][cb]
+  for (int i = threadIdx.x; i < ns * cb; i += blockDim.x) sacc[i] = 0.f;
+  __syncthreads();
+  const int cv = cb / V;
+  const int lanes = blockDim.x / cv;           // pixel lanes per block
+  const int v = threadIdx.x % cv, pl = threadIdx.x / cv;
+  float acc[4][V];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[s][j] = 0.f;
+  if (pl < lanes) {
+    for (int64_t p = (int64_t)blockIdx.x * lanes + pl; p < npix; p += (int64_t)gridDim.x * lanes) {
+      float bv[V];
+      if (V == 1) {
+        bv[0] = ld(big + p * cb + v);
+      } else {
+        Vec16<T> s = ldv(big + p * cb + v * V);
+#pragma unroll
+        for (int j = 0; j < V; ++j) bv[j] = s.get(j);
+      }
+      for (int s = 0; s < ns; ++s) {
+        const float sv = ld(small + p * ns + s);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[s][j] = fmaf(sv, bv[j], acc[s][j]);
+      }
+    }
+    for (int s = 0; s < ns; ++s)
+#pragma unroll
+      for (int j = 0; j < V; ++j) atomicAdd(&sacc[s * cb + v * V + j], acc[s][j]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ns * cb; i += blockDim.x) {
+    const int s = i / cb, c = i - s * cb;
+    atomicAdd(out + (int64_t)s * os + (int64_t)c * oc, sacc[i]);
+  }
+}
+
+template <typename T>
+int launch_pw_fwd(const T* x, const float* w, const float* bias, T* y, int64_t npix, int cin, int cout, int wt, int epi,
+                  float alpha, hipStream_t s) {
+  constexpr int V = Vec16<T>::N;
+  const size_t lds = (size_t)(cin * cout + cout) * sizeof(float);
+  if (cin <= 4) {
+    if (cout % V == 0)
+      hipLaunchKernelGGL((pw_small_in_kernel<T, V>), dim3(tg_grid_for(npix * (cout / V), 256)), dim3(256), lds, s, x, w,
+                         bias, y, npix, cin, cout, wt, epi, alpha);
+    else
+      hipLaunchKernelGGL((pw_small_in_kernel<T, 1>), dim3(tg_grid_for(npix * cout, 256)), dim3(256), lds, s, x, w, bias, y,
+                         npix, cin, cout, wt, epi, alpha);
+  } else {
+    if (cin % V == 0)
+      hipLaunchKernelGGL((pw_small_out_kernel<T, V>), dim3(tg_grid_for(npix, 256)), dim3(256), lds, s, x, w, bias, y, npix,
+                         cin, cout, wt, epi, alpha);
+    else
+      hipLaunchKernelGGL((pw_small_out_kernel<T, 1>), dim3(tg_grid_for(npix, 256)), dim3(256), lds, s, x, w, bias, y, npix,
+                         cin, cout, wt, epi, alpha);
+  }
+  return TG_OK;
+}
+
+template <typename T>
+int launch_pw_wgrad(const T* x, const T* gy, float* gw, int64_t npix, int cin, int cout, hipStream_t s) {
+  constexpr int V = Vec16<T>::N;
+  // small side = the <=4-channel tensor
+  const bool small_in = cin <= 4;
+  const T* small = small_in ? x : gy;
+  const T* big = small_in ? gy : x;
+  const int ns = small_in ? cin : cout, cb = small_in ? cout : cin;
+  const int os = small_in ? cout : 1, oc = small_in ? 1 : cout;   // gw[ci][co] index strides
+  const size_t lds = (size_t)ns * cb * sizeof(float);
+  const int blocks = tg_grid_for(npix, 64, 1024);
+  if (cb % V == 0 && cb / V <= 256)
+    hipLaunchKernelGGL((pw_wgrad_kernel<T, V>), dim3(blocks), dim3(256), lds, s, small, big, gw, npix, ns, cb, os, oc);
+  else
+    hipLaunchKernelGGL((pw_wgrad_kernel<T, 1>), dim3(blocks), dim3(256), lds, s, small, big, gw, npix, ns, cb, os, oc);
+  return TG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tg_axpby(const void* x, const void* y, void* out, int64_t numel, float a, float b, int dtype, void* stream) {
+  TG_CHECK(x && out && numel >= 0, TG_EINVAL, "tg_axpby: bad arguments");
+  if (numel == 0) return TG_OK;
+  TG_DISPATCH_DTYPE(dtype, "tg_axpby", {
+    hipLaunchKernelGGL(axpby_kernel<T>, dim3(tg_grid_for(numel / Vec16<T>::N + 1, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)x, (const T*)y, (T*)out, numel, a, b);
+  });
+  TG_LAUNCH_CHECK("tg_axpby");
+  return TG_OK;
+}
+
+int tg_lrelu_bwd(const void* gz, const void* z, void* gy, int64_t numel, float alpha, int dtype, void* stream) {
+  TG_CHECK(gz && z && gy && numel >= 0, TG_EINVAL, "tg_lrelu_bwd: bad arguments");
+  if (numel == 0) return TG_OK;
+  TG_DISPATCH_DTYPE(dtype, "tg_lrelu_bwd", {
+    hipLaunchKernelGGL(lrelu_bwd_kernel<T>, dim3(tg_grid_for(numel / Vec16<T>::N + 1, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)gz, (const T*)z, (T*)gy, numel, alpha);
+  });
+  TG_LAUNCH_CHECK("tg_lrelu_bwd");
+  return TG_OK;
+}
+
+int tg_bias_lrelu_fwd(const void* y, const float* bias, void* z, int64_t npix, int c, float alpha, int dtype,
+                      void* stream) {
+  TG_CHECK(y && z && npix > 0 && c > 0, TG_EINVAL, "tg_bias_lrelu_fwd: bad arguments");
+  const int64_t numel = npix * c;
+  TG_DISPATCH_DTYPE(dtype, "tg_bias_lrelu_fwd", {
+    hipLaunchKernelGGL(bias_lrelu_kernel<T>, dim3(tg_grid_for(numel / Vec16<T>::N + 1, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)y, bias, (T*)z, numel, c, alpha);
+  });
+  TG_LAUNCH_CHECK("tg_bias_lrelu_fwd");
+  return TG_OK;
+}
+
+int tg_fill_scaled(void* out, const float* scalar, float value, int64_t numel, int dtype, void* stream) {
+  TG_CHECK(out && numel >= 0, TG_EINVAL, "tg_fill_scaled: bad arguments");
+  if (numel == 0) return TG_OK;
+  TG_DISPATCH_DTYPE(dtype, "tg_fill_scaled", {
+    hipLaunchKernelGGL(fill_scaled_kernel<T>, dim3(tg_grid_for(numel, 256)), dim3(256), 0, (hipStream_t)stream, (T*)out,
+                       scalar, value, numel);
+  });
+  TG_LAUNCH_CHECK("tg_fill_scaled");
+  return TG_OK;
+}
+
+int tg_cast(const void* src, void* dst, int64_t numel, int sd, int dd, void* stream) {
+  TG_CHECK(src && dst && numel >= 0, TG_EINVAL, "tg_cast: bad arguments");
+  if (numel == 0) return TG_OK;
+  const dim3 grid(tg_grid_for(numel, 256)), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (sd == TG_F32 && dd == TG_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16>), grid, blk, 0, s, (const float*)src, (bf16*)dst, numel);
+  else if (sd == TG_BF16 && dd == TG_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16, float>), grid, blk, 0, s, (const bf16*)src, (float*)dst, numel);
+  else if (sd == TG_F32 && dd == TG_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), grid, blk, 0, s, (const float*)src, (float*)dst, numel);
+  else if (sd == TG_BF16 && dd == TG_BF16)
+    hipLaunchKernelGGL((cast_kernel<bf16, bf16>), grid, blk, 0, s, (const bf16*)src, (bf16*)dst, numel);
+  else {
+    tg_set_error("tg_cast: unsupported dtypes %d -> %d", sd, dd);
+    return TG_EINVAL;
+  }
+  TG_LAUNCH_CHECK("tg_cast");
+  return TG_OK;
+}
+
+int tg_sample_lerp(const void* x, const void* y, const float* alpha, void* out, int batch, int64_t per, int dtype,
+                   void* stream) {
+  TG_CHECK(x && y && alpha && out && batch > 0 && per > 0, TG_EINVAL, "tg_sample_lerp: bad arguments");
+  TG_DISPATCH_DTYPE(dtype, "tg_sample_lerp", {
+    hipLaunchKernelGGL(sample_lerp_kernel<T>, dim3(tg_grid_for(batch * per, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)x, (const T*)y, alpha, (T*)out, per, batch * per);
+  });
+  TG_LAUNCH_CHECK("tg_sample_lerp");
+  return TG_OK;
+}
+
+int tg_sample_scale(const void* x, const float* coef, const float* scalar, void* out, int batch, int64_t per, int dtype,
+                    void* stream) {
+  TG_CHECK(x && coef && out && batch > 0 && per > 0, TG_EINVAL, "tg_sample_scale: bad arguments");
+  TG_DISPATCH_DTYPE(dtype, "tg_sample_scale", {
+    hipLaunchKernelGGL(sample_scale_kernel<T>, dim3(tg_grid_for(batch * per, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)x, coef, scalar, (T*)out, per, batch * per);
+  });
+  TG_LAUNCH_CHECK("tg_sample_scale");
+  return TG_OK;
+}
+
+#define TG_SPATIAL_LAUNCH(KERNEL, VECOK, TOTAL_VEC, TOTAL_SCALAR, ...)                                                 \
+  TG_DISPATCH_DTYPE(dtype, #KERNEL, {                                                                                  \
+    constexpr int V = Vec16<T>::N;                                                                                     \
+    if (VECOK(V))                                                                                                      \
+      hipLaunchKernelGGL((KERNEL<T, V>), dim3(tg_grid_for(TOTAL_VEC(V), 256)), dim3(256), 0, (hipStream_t)stream,      \
+                         __VA_ARGS__);                                                                                 \
+    else                                                                                                               \
+      hipLaunchKernelGGL((KERNEL<T, 1>), dim3(tg_grid_for(TOTAL_SCALAR, 256)), dim3(256), 0, (hipStream_t)stream,      \
+                         __VA_ARGS__);                                                                                 \
+  })
+
+int tg_upsample2x_concat_fwd(const void* x0, const void* x1, void* out, int n, int h, int w, int c0, int c1, int dtype,
+                             void* stream) {
+  TG_CHECK(x0 && out && n > 0 && h > 0 && w > 0 && c0 > 0 && c1 >= 0 && (c1 == 0 || x1), TG_EINVAL,
+           "tg_upsample2x_concat_fwd: bad arguments");
+#define VOK(V) (c0 % V == 0 && c1 % V == 0)
+#define TV(V) ((int64_t)n * 4 * h * w * ((c0 + c1) / V))
+  TG_SPATIAL_LAUNCH(upsample_concat_fwd_kernel, VOK, TV, (int64_t)n * 4 * h * w * (c0 + c1), (const T*)x0, (const T*)x1,
+                    (T*)out, n, h, w, c0, c1);
+#undef VOK
+#undef TV
+  TG_LAUNCH_CHECK("tg_upsample2x_concat_fwd");
+  return TG_OK;
+}
+
+int tg_upsample2x_concat_bwd(const void* gout, void* g0, void* g1, int n, int h, int w, int c0, int c1, int dtype,
+                             void* stream) {
+  TG_CHECK(gout && n > 0 && h > 0 && w > 0 && c0 > 0 && c1 >= 0, TG_EINVAL, "tg_upsample2x_concat_bwd: bad arguments");
+  if (c1 == 0) g1 = nullptr;
+  if (!g0 && !g1) return TG_OK;
+#define VOK(V) (c0 % V == 0 && c1 % V == 0)
+#define TV(V) ((int64_t)n * h * w * (c0 / V) + (int64_t)n * 4 * h * w * (c1 / V))
+  TG_SPATIAL_LAUNCH(upsample_concat_bwd_kernel, VOK, TV, (int64_t)n * h * w * c0 + (int64_t)n * 4 * h * w * c1,
+                    (const T*)gout, (T*)g0, (T*)g1, n, h, w, c0, c1);
+#undef VOK
+#undef TV
+  TG_LAUNCH_CHECK("tg_upsample2x_concat_bwd");
+  return TG_OK;
+}
+
+int tg_pool2x2_fwd(const void* x, void* y, int n, int h, int w, int c, float scale, int dtype, void* stream) {
+  TG_CHECK(x && y && n > 0 && h > 1 && w > 1 && c > 0, TG_EINVAL, "tg_pool2x2_fwd: bad arguments");
+#define VOK(V) (c % V == 0)
+#define TV(V) ((int64_t)n * (h / 2) * (w / 2) * (c / V))
+  TG_SPATIAL_LAUNCH(pool_fwd_kernel, VOK, TV, (int64_t)n * (h / 2) * (w / 2) * c, (const T*)x, (T*)y, n, h, w, c, scale);
+#undef VOK
+#undef TV
+  TG_LAUNCH_CHECK("tg_pool2x2_fwd");
+  return TG_OK;
+}
+
+int tg_pool2x2_bwd(const void* gy, void* gx, int n, int h, int w, int c, float scale, int dtype, void* stream) {
+  TG_CHECK(gy && gx && n > 0 && h > 1 && w > 1 && c > 0, TG_EINVAL, "tg_pool2x2_bwd: bad arguments");
+#define VOK(V) (c % V == 0)
+#define TV(V) ((int64_t)n * h * w * (c / V))
+  TG_SPATIAL_LAUNCH(pool_bwd_kernel, VOK, TV, (int64_t)n * h * w * c, (const T*)gy, (T*)gx, n, h, w, c, scale);
+#undef VOK
+#undef TV
+  TG_LAUNCH_CHECK("tg_pool2x2_bwd");
+  return TG_OK;
+}
+
+int tg_pointwise_conv_fwd(const void* x, const float* w, const float* bias, void* y, int64_t npix, int cin, int cout,
+                          int wt, int epilogue, float alpha, int dtype, void* stream) {
+  TG_CHECK(x && w && y && npix > 0 && cin > 0 && cout > 0, TG_EINVAL, "tg_pointwise_conv_fwd: bad arguments");
+  TG_CHECK(cin <= 4 || cout <= 4, TG_ENOSUP, "tg_pointwise_conv_fwd: one of cin (%d) / cout (%d) must be <= 4", cin, cout);
+  TG_CHECK((size_t)(cin * cout + cout) * sizeof(float) <= 48 * 1024, TG_ENOSUP, "tg_pointwise_conv_fwd: weights too large");
+  TG_CHECK(!(epilogue & TG_EPI_BIAS) || bias, TG_EINVAL, "tg_pointwise_conv_fwd: bias epilogue without bias");
+  TG_DISPATCH_DTYPE(dtype, "tg_pointwise_conv_fwd", {
+    launch_pw_fwd<T>((const T*)x, w, bias, (T*)y, npix, cin, cout, wt, epilogue, alpha, (hipStream_t)stream);
+  });
+  TG_LAUNCH_CHECK("tg_pointwise_conv_fwd");
+  return TG_OK;
+}
+
+int tg_pointwise_conv_bwd_weight(const void* x, const void* gy, float* gw, int64_t npix, int cin, int cout, int accumulate,
+                                 int dtype, void* stream) {
+  TG_CHECK(x && gy && gw && npix > 0 && cin > 0 && cout > 0, TG_EINVAL, "tg_pointwise_conv_bwd_weight: bad arguments");
+  TG_CHECK(cin <= 4 || cout <= 4, TG_ENOSUP, "tg_pointwise_conv_bwd_weight: one of cin/cout must be <= 4");
+  if (!accumulate && hipMemsetAsync(gw, 0, (size_t)cin * cout * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+    tg_set_error("tg_pointwise_conv_bwd_weight: memset failed");
+    return TG_ELAUNCH;
+  }
+  TG_DISPATCH_DTYPE(dtype, "tg_pointwise_conv_bwd_weight", {
+    launch_pw_wgrad<T>((const T*)x, (const T*)gy, gw, npix, cin, cout, (hipStream_t)stream);
+  });
+  TG_LAUNCH_CHECK("tg_pointwise_conv_bwd_weight");
+  return TG_OK;
+}
+
+}  // extern "C"

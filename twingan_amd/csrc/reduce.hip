@@ -1,0 +1,357 @@
+// Minibatch-stddev (forward, backward, double backward), loss reductions, WGAN-GP tail, the small
+// dense layer and the fused Adam step.
+#include "tg_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Minibatch stddev, nets/pggan_utils.py:353-366.  x[n][p], p = hw*c.  Single workgroup: the tensor
+// is [B,4,4,C] (64 K elements at B=16, C=256).
+//   stat = mean_p sqrt(var_n(x[:,p]) + eps)          (biased variance over the batch)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void mbstd_fwd_kernel(const T* __restrict__ x, T* __restrict__ out,
+                                                         float* __restrict__ stat, int n, int hw, int c, int cpad,
+                                                         float eps) {
+  __shared__ float red[16];
+  const int P = hw * c;
+  float acc = 0.f;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    float mu = 0.f;
+    for (int i = 0; i < n; ++i) mu += ld(x + (int64_t)i * P + p);
+    mu /= (float)n;
+    float var = 0.f;
+    for (int i = 0; i < n; ++i) {
+      const float d = ld(x + (int64_t)i * P + p) - mu;
+      var = fmaf(d, d, var);
+    }
+    acc += sqrtf(var / (float)n + eps);
+  }
+  const float val = block_sum(acc, red) / (float)P;
+  if (threadIdx.x == 0 && stat) stat[0] = val;
+  const int64_t total = (int64_t)n * hw * cpad;
+  for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
+    const int ch = (int)(i % cpad);
+    const int64_t px = i / cpad;
+    float v = 0.f;
+    if (ch < c)
+      v = ld(x + px * c + ch);
+    else if (ch == c)
+      v = val;
+    st(out + i, v);
+  }
+}
+
+// gx[n][p] = gout[n][hw][ch<c] + G * (x - mu_p) / (N * sigma_p * P),  G = sum over (n,hw) of gout[..., c]
+template <typename T>
+__global__ __launch_bounds__(1024) void mbstd_bwd_kernel(const T* __restrict__ gout, const T* __restrict__ x,
+                                                         T* __restrict__ gx, int n, int hw, int c, int cpad, float eps) {
+  __shared__ float red[16];
+  const int P = hw * c;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n * hw; i += blockDim.x) acc += ld(gout + (int64_t)i * cpad + c);
+  const float G = block_sum(acc, red);
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    float mu = 0.f;
+    for (int i = 0; i < n; ++i) mu += ld(x + (int64_t)i * P + p);
+    mu /= (float)n;
+    float var = 0.f;
+    for (int i = 0; i < n; ++i) {
+      const float d = ld(x + (int64_t)i * P + p) - mu;
+      var = fmaf(d, d, var);
+    }
+    const float sigma = sqrtf(var / (float)n + eps);
+    const float k = G / ((float)n * sigma * (float)P);
+    const int px = p / c, ch = p - px * c;
+    for (int i = 0; i < n; ++i) {
+      const float d = ld(x + (int64_t)i * P + p) - mu;
+      st(gx + (int64_t)i * P + p, ld(gout + ((int64_t)i * hw + px) * cpad + ch) + k * d);
+    }
+  }
+}
+
+// Double backward.  With c_n = x_n - mu, sigma = sqrt(mean c^2 + eps), gx_n = gpass_n + G c_n /(N sigma P):
+//   d/dG      : T = sum_{n,p} v_np c_np / (N sigma_p P)  -> ggout[..., c] = T for every (n,hw); ggout[..., <c] = v
+//   d/dx_mp   : (G/(N P)) * [ (v_m - mean_n v)/sigma - (sum_n v_n c_n) c_m / (N sigma^3) ]
+template <typename T>
+__global__ __launch_bounds__(1024) void mbstd_bwd_bwd_kernel(const T* __restrict__ v, const T* __restrict__ gout,
+                                                             const T* __restrict__ x, T* __restrict__ ggout,
+                                                             T* __restrict__ gx2, int n, int hw, int c, int cpad,
+                                                             float eps) {
+  __shared__ float red[16];
+  const int P = hw * c;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n * hw; i += blockDim.x) acc += ld(gout + (int64_t)i * cpad + c);
+  const float G = block_sum(acc, red);
+  float tacc = 0.f;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    float mu = 0.f, vm = 0.f;
+    for (int i = 0; i < n; ++i) {
+      mu += ld(x + (int64_t)i * P + p);
+      vm += ld(v + (int64_t)i * P + p);
+    }
+    mu /= (float)n;
+    vm /= (float)n;
+    float var = 0.f, vc = 0.f;
+    for (int i = 0; i < n; ++i) {
+      const float d = ld(x + (int64_t)i * P + p) - mu;
+      var = fmaf(d, d, var);
+      vc = fmaf(ld(v + (int64_t)i * P + p), d, vc);
+    }
+    const float sigma = sqrtf(var / (float)n + eps);
+    tacc += vc / ((float)n * sigma * (float)P);
+    if (gx2) {
+      const float k = G / ((float)n * (float)P);
+      for (int i = 0; i < n; ++i) {
+        const float d = ld(x + (int64_t)i * P + p) - mu;
+        const float vi = ld(v + (int64_t)i * P + p);
+        st(gx2 + (int64_t)i * P + p, k * ((vi - vm) / sigma - vc * d / ((float)n * sigma * sigma * sigma)));
+      }
+    }
+  }
+  const float Tt = block_sum(tacc, red);
+  if (ggout) {
+    const int64_t total = (int64_t)n * hw * cpad;
+    for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
+      const int ch = (int)(i % cpad);
+      const int64_t px = i / cpad;
+      float o = 0.f;
+      if (ch < c)
+        o = ld(v + px * c + ch);
+      else if (ch == c)
+        o = Tt;
+      st(ggout + i, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// reductions
+// ------------------------------------------------------------------------------------------------
+template <typename T, int MODE>   // MODE 0: sum(x)  1: sum|x-y|
+__global__ void sum_kernel(const T* __restrict__ x, const T* __restrict__ y, float* __restrict__ out, int64_t numel,
+                           float scale) {
+  __shared__ float red[8];
+  constexpr int V = Vec16<T>::N;
+  const int64_t nvec = numel / V, stride = (int64_t)gridDim.x * blockDim.x;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    Vec16<T> a = ldv(x + i * V);
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc += a.get(j);
+    } else {
+      Vec16<T> b = ldv(y + i * V);
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc += fabsf(a.get(j) - b.get(j));
+    }
+  }
+  for (int64_t i = nvec * V + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride)
+    acc += MODE == 0 ? ld(x + i) : fabsf(ld(x + i) - ld(y + i));
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0) atomicAdd(out, tot * scale);
+}
+
+template <typename T>
+__global__ void abs_diff_bwd_kernel(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ gscale,
+                                    T* __restrict__ ga, T* __restrict__ gb, int64_t numel, float scale) {
+  const float g = (gscale ? gscale[0] : 1.f) * scale;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
+    const float d = ld(a + i) - ld(b + i);
+    const float s = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+    if (ga) st(ga + i, s);
+    if (gb) st(gb + i, -s);
+  }
+}
+
+// out[b] = sum over sample b of x^2;  grid = (chunks, batch), out pre-zeroed
+template <typename T>
+__global__ void sample_sumsq_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t per) {
+  __shared__ float red[8];
+  constexpr int V = Vec16<T>::N;
+  const T* base = x + (int64_t)blockIdx.y * per;
+  const int64_t nvec = per / V, stride = (int64_t)gridDim.x * blockDim.x;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    Vec16<T> a = ldv(base + i * V);
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc = fmaf(a.get(j), a.get(j), acc);
+  }
+  for (int64_t i = nvec * V + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += stride) {
+    const float a = ld(base + i);
+    acc = fmaf(a, a, acc);
+  }
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0) atomicAdd(out + blockIdx.y, tot);
+}
+
+// image_generation.py:431-436
+__global__ void gp_penalty_kernel(const float* __restrict__ ss, float* __restrict__ loss, float* __restrict__ coef,
+                                  int batch, float lambda) {
+  __shared__ float red[8];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < batch; b += blockDim.x) {
+    const float slope = sqrtf(ss[b]);
+    const float d = slope - 1.f;
+    acc += d * d;
+    if (coef) coef[b] = slope > 0.f ? lambda * 2.f * d / (slope * (float)batch) : 0.f;
+  }
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0 && loss) loss[0] = lambda * tot / (float)batch;
+}
+
+// C[m,n] (+)= op(A)[m,k] @ op(B)[k,n] + bias[n]; one thread per output element
+__global__ void small_gemm_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias,
+                                  float* __restrict__ c, int m, int n, int k, int ta, int tb, int accumulate) {
+  const int64_t total = (int64_t)m * n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % n), row = (int)(i / n);
+    float acc = 0.f;
+    for (int kk = 0; kk < k; ++kk) {
+      const float av = ta ? a[(int64_t)kk * m + row] : a[(int64_t)row * k + kk];
+      const float bv = tb ? b[(int64_t)col * k + kk] : b[(int64_t)kk * n + col];
+      acc = fmaf(av, bv, acc);
+    }
+    if (bias) acc += bias[col];
+    c[i] = (accumulate ? c[i] : 0.f) + acc;
+  }
+}
+
+// TF-1.x Adam (model/model_inheritor.py:537-542): epsilon OUTSIDE the bias-corrected sqrt.
+__global__ void adam_kernel(float* __restrict__ th, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, bf16* __restrict__ shadow, int64_t numel, float lr_t, float b1, float b2,
+                            float eps, float gscale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float t = th[i] - lr_t * mi / (sqrtf(vi) + eps);
+    m[i] = mi;
+    v[i] = vi;
+    th[i] = t;
+    if (shadow) shadow[i] = (bf16)t;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tg_mbstd_fwd(const void* x, void* out, float* stat, int n, int hw, int c, int cpad, float eps, int dtype,
+                 void* stream) {
+  TG_CHECK(x && out && n > 0 && hw > 0 && c > 0 && cpad > c, TG_EINVAL, "tg_mbstd_fwd: bad arguments (cpad must exceed c)");
+  TG_DISPATCH_DTYPE(dtype, "tg_mbstd_fwd", {
+    hipLaunchKernelGGL(mbstd_fwd_kernel<T>, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const T*)x, (T*)out, stat, n, hw,
+                       c, cpad, eps);
+  });
+  TG_LAUNCH_CHECK("tg_mbstd_fwd");
+  return TG_OK;
+}
+
+int tg_mbstd_bwd(const void* gout, const void* x, void* gx, int n, int hw, int c, int cpad, float eps, int dtype,
+                 void* stream) {
+  TG_CHECK(gout && x && gx && n > 0 && hw > 0 && c > 0 && cpad > c, TG_EINVAL, "tg_mbstd_bwd: bad arguments");
+  TG_DISPATCH_DTYPE(dtype, "tg_mbstd_bwd", {
+    hipLaunchKernelGGL(mbstd_bwd_kernel<T>, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const T*)gout, (const T*)x,
+                       (T*)gx, n, hw, c, cpad, eps);
+  });
+  TG_LAUNCH_CHECK("tg_mbstd_bwd");
+  return TG_OK;
+}
+
+int tg_mbstd_bwd_bwd(const void* v, const void* gout, const void* x, void* ggout, void* gx2, int n, int hw, int c, int cpad,
+                     float eps, int dtype, void* stream) {
+  TG_CHECK(v && gout && x && n > 0 && hw > 0 && c > 0 && cpad > c, TG_EINVAL, "tg_mbstd_bwd_bwd: bad arguments");
+  TG_DISPATCH_DTYPE(dtype, "tg_mbstd_bwd_bwd", {
+    hipLaunchKernelGGL(mbstd_bwd_bwd_kernel<T>, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const T*)v, (const T*)gout,
+                       (const T*)x, (T*)ggout, (T*)gx2, n, hw, c, cpad, eps);
+  });
+  TG_LAUNCH_CHECK("tg_mbstd_bwd_bwd");
+  return TG_OK;
+}
+
+static int zero_unless(float* p, size_t bytes, int accumulate, hipStream_t s, const char* who) {
+  if (!accumulate && hipMemsetAsync(p, 0, bytes, s) != hipSuccess) {
+    tg_set_error("%s: memset failed", who);
+    return TG_ELAUNCH;
+  }
+  return TG_OK;
+}
+
+int tg_sum(const void* x, float* out, int64_t numel, float scale, int accumulate, int dtype, void* stream) {
+  TG_CHECK(x && out && numel > 0, TG_EINVAL, "tg_sum: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = zero_unless(out, sizeof(float), accumulate, s, "tg_sum");
+  if (rc) return rc;
+  TG_DISPATCH_DTYPE(dtype, "tg_sum", {
+    hipLaunchKernelGGL((sum_kernel<T, 0>), dim3(tg_grid_for(numel / Vec16<T>::N + 1, 256, 1024)), dim3(256), 0, s,
+                       (const T*)x, (const T*)nullptr, out, numel, scale);
+  });
+  TG_LAUNCH_CHECK("tg_sum");
+  return TG_OK;
+}
+
+int tg_abs_diff_sum(const void* a, const void* b, float* out, int64_t numel, float scale, int accumulate, int dtype,
+                    void* stream) {
+  TG_CHECK(a && b && out && numel > 0, TG_EINVAL, "tg_abs_diff_sum: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = zero_unless(out, sizeof(float), accumulate, s, "tg_abs_diff_sum");
+  if (rc) return rc;
+  TG_DISPATCH_DTYPE(dtype, "tg_abs_diff_sum", {
+    hipLaunchKernelGGL((sum_kernel<T, 1>), dim3(tg_grid_for(numel / Vec16<T>::N + 1, 256, 1024)), dim3(256), 0, s,
+                       (const T*)a, (const T*)b, out, numel, scale);
+  });
+  TG_LAUNCH_CHECK("tg_abs_diff_sum");
+  return TG_OK;
+}
+
+int tg_abs_diff_bwd(const void* a, const void* b, const float* gscale, void* ga, void* gb, int64_t numel, float scale,
+                    int dtype, void* stream) {
+  TG_CHECK(a && b && numel > 0 && (ga || gb), TG_EINVAL, "tg_abs_diff_bwd: bad arguments");
+  TG_DISPATCH_DTYPE(dtype, "tg_abs_diff_bwd", {
+    hipLaunchKernelGGL(abs_diff_bwd_kernel<T>, dim3(tg_grid_for(numel, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)a, (const T*)b, gscale, (T*)ga, (T*)gb, numel, scale);
+  });
+  TG_LAUNCH_CHECK("tg_abs_diff_bwd");
+  return TG_OK;
+}
+
+int tg_sample_sumsq(const void* x, float* out, int batch, int64_t per, int dtype, void* stream) {
+  TG_CHECK(x && out && batch > 0 && per > 0, TG_EINVAL, "tg_sample_sumsq: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = zero_unless(out, (size_t)batch * sizeof(float), 0, s, "tg_sample_sumsq");
+  if (rc) return rc;
+  TG_DISPATCH_DTYPE(dtype, "tg_sample_sumsq", {
+    const int chunks = tg_grid_for(per / Vec16<T>::N + 1, 256, 64);
+    hipLaunchKernelGGL(sample_sumsq_kernel<T>, dim3(chunks, batch), dim3(256), 0, s, (const T*)x, out, per);
+  });
+  TG_LAUNCH_CHECK("tg_sample_sumsq");
+  return TG_OK;
+}
+
+int tg_gp_penalty(const float* sumsq, float* loss, float* coef, int batch, float lambda, void* stream) {
+  TG_CHECK(sumsq && batch > 0, TG_EINVAL, "tg_gp_penalty: bad arguments");
+  hipLaunchKernelGGL(gp_penalty_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sumsq, loss, coef, batch, lambda);
+  TG_LAUNCH_CHECK("tg_gp_penalty");
+  return TG_OK;
+}
+
+int tg_small_gemm(const float* a, const float* b, const float* bias, float* c, int m, int n, int k, int ta, int tb,
+                  int accumulate, void* stream) {
+  TG_CHECK(a && b && c && m > 0 && n > 0 && k > 0, TG_EINVAL, "tg_small_gemm: bad arguments");
+  hipLaunchKernelGGL(small_gemm_kernel, dim3(tg_grid_for((int64_t)m * n, 256)), dim3(256), 0, (hipStream_t)stream, a, b,
+                     bias, c, m, n, k, ta, tb, accumulate);
+  TG_LAUNCH_CHECK("tg_small_gemm");
+  return TG_OK;
+}
+
+int tg_adam_step(float* theta, const float* grad, float* m, float* v, void* theta_bf16, int64_t numel, float lr_t,
+                 float beta1, float beta2, float eps, float grad_scale, void* stream) {
+  TG_CHECK(theta && grad && m && v && numel > 0, TG_EINVAL, "tg_adam_step: bad arguments");
+  hipLaunchKernelGGL(adam_kernel, dim3(tg_grid_for(numel, 256)), dim3(256), 0, (hipStream_t)stream, theta, grad, m, v,
+                     (bf16*)theta_bf16, numel, lr_t, beta1, beta2, eps, grad_scale);
+  TG_LAUNCH_CHECK("tg_adam_step");
+  return TG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+// Shared device/host helpers for libtwingan_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/twingan_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define TG_WAVE 64
+
+// ---- error plumbing -------------------------------------------------------------------------
+void tg_set_error(const char* fmt, ...);
+
+#define TG_CHECK(cond, code, ...)  \
+  do {                             \
+    if (!(cond)) {                 \
+      tg_set_error(__VA_ARGS__);   \
+      return (code);               \
+    }                              \
+  } while (0)
+
+#define TG_LAUNCH_CHECK(name)                                                     \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) {                                                      \
+      tg_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));        \
+      return TG_ELAUNCH;                                                          \
+    }                                                                             \
+  } while (0)
+
+static inline bool tg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- scalar load/store by storage type ------------------------------------------------------
+template <typename T> __device__ __forceinline__ float ld(const T* p);
+template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld<bf16>(const bf16* p) { return (float)*p; }
+template <typename T> __device__ __forceinline__ void st(T* p, float v);
+template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st<bf16>(bf16* p, float v) { *p = (bf16)v; }
+
+// round-trip through the storage type (so fp32 math sees what a bf16 store would keep)
+template <typename T> __device__ __forceinline__ float rnd(float v);
+template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
+template <> __device__ __forceinline__ float rnd<bf16>(float v) { return (float)(bf16)v; }
+
+// ---- 16-byte vectors of the storage type ----------------------------------------------------
+template <typename T> struct Vec16;   // 16 bytes worth of T
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  f32x4 v;
+  __device__ __forceinline__ float get(int i) const { return v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <> struct Vec16<bf16> {
+  static constexpr int N = 8;
+  bf16x8 v;
+  __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16)x; }
+};
+template <typename T> __device__ __forceinline__ Vec16<T> ldv(const T* p) {
+  return *reinterpret_cast<const Vec16<T>*>(p);
+}
+template <typename T> __device__ __forceinline__ void stv(T* p, const Vec16<T>& v) {
+  *reinterpret_cast<Vec16<T>*>(p) = v;
+}
+
+// ---- reductions -----------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum; result valid in every thread.  `red` = __shared__ float[>= blockDim/64].
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += red[i];
+  return r;
+}
+
+__device__ __forceinline__ float lrelu_f(float x, float a) { return fmaxf(a * x, x); }
+
+static inline int tg_grid_for(int64_t work, int block, int max_blocks = 256 * 16) {
+  int64_t g = (work + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > max_blocks) g = max_blocks;
+  return (int)g;
+}
+
+// dtype dispatch helper
+#define TG_DISPATCH_DTYPE(dtype, NAME, ...)                 \
+  do {                                                      \
+    if ((dtype) == TG_F32) {                                \
+      using T = float;                                      \
+      __VA_ARGS__                                           \
+    } else if ((dtype) == TG_BF16) {                        \
+      using T = bf16;                                       \
+      __VA_ARGS__                                           \
+    } else {                                                \
+      tg_set_error("%s: unsupported dtype %d", NAME, dtype); \
+      return TG_EINVAL;                                     \
+    }                                                       \
+  } while (0)

@@ -1,0 +1,694 @@
+"""Autograd operators over the HIP kernels of libtwingan_hip.so.
+
+This is the MI355X counterpart of the reference's op facade (libs/ops.py:28-40 and the stock TF
+ops used by nets/pggan_utils.py): every function here enqueues hand-written gfx950 kernels through
+the C ABI (include/twingan_hip.h) on torch's current HIP stream.  torch supplies device memory,
+streams and the autograd tape only.  Every backward is itself built from these operators, so
+second-order gradients (WGAN-GP, image_generation.py:414-439) flow through the same kernels.
+
+All activations are NHWC contiguous tensors (fp32 or bf16); conv weights are fp32 HWIO masters.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (NF_LRELU, NF_PIXNORM, TG_ALGO_DIRECT, TG_ALGO_MFMA, TG_BF16, TG_EPI_BIAS, TG_EPI_LRELU, TG_F32,
+                   TgConvDesc, call)
+
+LRELU_ALPHA = 0.2    # util_misc.py:68
+
+
+def _dt(t):
+  if t.dtype == torch.bfloat16:
+    return TG_BF16
+  if t.dtype == torch.float32:
+    return TG_F32
+  raise _lib.TgError('unsupported tensor dtype %s' % t.dtype)
+
+
+def _stream():
+  return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+  return None if t is None else t.data_ptr()
+
+
+def _chk(*ts):
+  for t in ts:
+    if t is not None:
+      if not t.is_cuda:
+        raise _lib.TgError('twingan_amd ops need CUDA/HIP tensors (no CPU fallback)')
+      if not t.is_contiguous():
+        raise _lib.TgError('twingan_amd ops need contiguous NHWC tensors')
+
+
+# ------------------------------------------------------------------------------------------------
+# weight-pack cache for the MFMA kernels
+# ------------------------------------------------------------------------------------------------
+class PackCache:
+  """bf16 K-contiguous packs (tg_conv2d_pack_weights) of registered master weights.  A pack is
+  rebuilt in place (same device address, graph-capture friendly) when ``version`` has moved since it
+  was made -- the optimiser bumps ``version`` after every apply."""
+  version = 0
+  _registered = set()
+  _packs = {}
+
+  @classmethod
+  def register(cls, w):
+    cls._registered.add(w.data_ptr())
+
+  @classmethod
+  def clear(cls):
+    cls._registered.clear()
+    cls._packs.clear()
+
+  @classmethod
+  def get(cls, w, desc, mode):
+    n = _lib.load().tg_conv2d_pack_elems(ctypes.byref(desc), mode)
+    key = (w.data_ptr(), mode, n)
+    cached = w.data_ptr() in cls._registered
+    ent = cls._packs.get(key) if cached else None
+    if ent is not None and ent[0] == cls.version:
+      return ent[1]
+    buf = ent[1] if ent is not None else torch.empty(n, dtype=torch.bfloat16, device=w.device)
+    call('tg_conv2d_pack_weights', ctypes.byref(desc), _p(w), mode, _p(buf), _stream())
+    if cached:
+      cls._packs[key] = (cls.version, buf)
+    return buf
+
+
+class ConvSpec:
+  """Static description of one stride-1 conv (TF SAME / VALID padding rules)."""
+  __slots__ = ('kh', 'kw', 'pad_t', 'pad_l', 'valid', 'epilogue', 'alpha')
+
+  def __init__(self, k, padding='SAME', epilogue=0, alpha=LRELU_ALPHA):
+    self.kh = self.kw = k
+    self.valid = padding == 'VALID'
+    self.pad_t = self.pad_l = 0 if self.valid else (k - 1) // 2      # TF SAME: low side gets floor((k-1)/2)
+    self.epilogue = epilogue
+    self.alpha = alpha
+
+  def out_hw(self, h, w):
+    return (h - self.kh + 1, w - self.kw + 1) if self.valid else (h, w)
+
+
+def _mfma_ok(dtype, cin, cout, spec, hin, win):
+  if dtype != torch.bfloat16 or cin % 8 or cout % 8:
+    return False
+  if spec.kh == 1 or spec.kh == 3:
+    return True
+  return spec.valid and hin == spec.kh and win == spec.kw     # k x k VALID on k x k input -> dense
+
+
+def _esize(t):
+  return 2 if t.dtype == torch.bfloat16 else 4
+
+
+def _conv_work(d, tag, es):
+  """Algorithmic work of one conv launch: MACs*2 and compulsory bytes (input + output + weights once)."""
+  flops = 2 * d.n * d.hout * d.wout * d.cout * d.kh * d.kw * d.cin
+  by = es * d.n * (d.hin * d.win * d.cin + d.hout * d.wout * d.cout) + es * d.kh * d.kw * d.cin * d.cout
+  algo = 'mfma' if d.algo == TG_ALGO_MFMA else 'direct'
+  return ('%s:%s:k%d:c%d>%d:hw%d' % (tag, algo, d.kh, d.cin, d.cout, d.hout), flops, by)
+
+
+def _desc(x_shape, cout, spec, dtype, epilogue):
+  n, h, w, cin = x_shape
+  ho, wo = spec.out_hw(h, w)
+  d = TgConvDesc()
+  d.n, d.hin, d.win, d.cin = n, h, w, cin
+  d.hout, d.wout, d.cout = ho, wo, cout
+  d.kh, d.kw, d.pad_t, d.pad_l = spec.kh, spec.kw, spec.pad_t, spec.pad_l
+  d.dtype = TG_BF16 if dtype == torch.bfloat16 else TG_F32
+  d.algo = TG_ALGO_MFMA if _mfma_ok(dtype, cin, cout, spec, h, w) else TG_ALGO_DIRECT
+  d.epilogue = epilogue
+  d.lrelu_alpha = spec.alpha
+  return d
+
+
+# ------------------------------------------------------------------------------------------------
+# raw (non-autograd) kernel wrappers
+# ------------------------------------------------------------------------------------------------
+def conv_fwd_raw(x, w, bias, spec, epilogue):
+  _chk(x, w, bias)
+  d = _desc(x.shape, w.shape[3], spec, x.dtype, epilogue)
+  y = torch.empty((d.n, d.hout, d.wout, d.cout), dtype=x.dtype, device=x.device)
+  wk = PackCache.get(w, d, 0) if d.algo == TG_ALGO_MFMA else w
+  call('tg_conv2d_fwd', ctypes.byref(d), _p(x), _p(wk), _p(bias), _p(y), _stream(),
+       work=lambda: _conv_work(d, 'fwd', _esize(x)))
+  return y
+
+
+def conv_bwd_data_raw(gy, w, x_shape, spec):
+  _chk(gy, w)
+  d = _desc(x_shape, w.shape[3], spec, gy.dtype, 0)
+  gx = torch.empty(tuple(x_shape), dtype=gy.dtype, device=gy.device)
+  wk = PackCache.get(w, d, 1) if d.algo == TG_ALGO_MFMA else w
+  call('tg_conv2d_bwd_data', ctypes.byref(d), _p(gy), _p(wk), _p(gx), _stream(),
+       work=lambda: _conv_work(d, 'dgrad', _esize(gy)))
+  return gx
+
+
+def conv_bwd_weight_raw(x, gy, spec):
+  _chk(x, gy)
+  d = _desc(x.shape, gy.shape[3], spec, x.dtype, 0)
+  gw = torch.empty((spec.kh, spec.kw, x.shape[3], gy.shape[3]), dtype=torch.float32, device=x.device)
+  nbytes = _lib.load().tg_conv2d_bwd_weight_workspace(ctypes.byref(d))
+  ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device) if nbytes else None
+  call('tg_conv2d_bwd_weight', ctypes.byref(d), _p(x), _p(gy), _p(gw), 0, _p(ws), nbytes, _stream(),
+       work=lambda: _conv_work(d, 'wgrad', _esize(x)))
+  return gw
+
+
+def lrelu_bwd_raw(g, z, alpha):
+  _chk(g, z)
+  out = torch.empty_like(g)
+  call('tg_lrelu_bwd', _p(g), _p(z), _p(out), g.numel(), alpha, _dt(g), _stream())
+  return out
+
+
+def channel_sum_raw(g):
+  _chk(g)
+  c = g.shape[-1]
+  out = torch.empty(c, dtype=torch.float32, device=g.device)
+  call('tg_channel_sum', _p(g), _p(out), g.numel() // c, c, 0, _dt(g), _stream())
+  return out
+
+
+def sample_lerp(x, y, alpha):
+  """x + alpha[b] * (y - x)  -- WGAN-GP interpolates (image_generation.py:424).  No autograd."""
+  _chk(x, y, alpha)
+  out = torch.empty_like(x)
+  b = x.shape[0]
+  call('tg_sample_lerp', _p(x), _p(y), _p(alpha), _p(out), b, x.numel() // b, _dt(x), _stream())
+  return out
+
+
+def fill(shape, value, dtype, device, scalar=None):
+  out = torch.empty(shape, dtype=dtype, device=device)
+  call('tg_fill_scaled', _p(out), _p(scalar), float(value), out.numel(), _dt(out), _stream())
+  return out
+
+
+def cast_raw(x, dtype):
+  _chk(x)
+  out = torch.empty(x.shape, dtype=dtype, device=x.device)
+  call('tg_cast', _p(x), _p(out), x.numel(), _dt(x), _dt(out), _stream())
+  return out
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution  (layers.conv2d, nets/pggan_utils.py:316-320)
+# ------------------------------------------------------------------------------------------------
+class Conv2dFn(torch.autograd.Function):
+  """z = epilogue(conv(x, w) [+ bias]) with epilogue in {none, bias, bias+lrelu, lrelu}."""
+
+  @staticmethod
+  def forward(ctx, x, w, bias, spec, epilogue):
+    z = conv_fwd_raw(x, w, bias, spec, epilogue)
+    ctx.spec, ctx.epilogue = spec, epilogue
+    ctx.save_for_backward(x, w, z if (epilogue & TG_EPI_LRELU) else None)
+    return z
+
+  @staticmethod
+  def backward(ctx, gz):
+    x, w, z = ctx.saved_tensors
+    spec = ctx.spec
+    gz = gz.contiguous()
+    g = LReluBwdFn.apply(gz, z, spec.alpha) if (ctx.epilogue & TG_EPI_LRELU) else gz
+    gx = ConvBwdDataFn.apply(g, w, tuple(x.shape), spec) if ctx.needs_input_grad[0] else None
+    gw = ConvBwdWeightFn.apply(x, g, spec) if ctx.needs_input_grad[1] else None
+    gb = ChannelSumFn.apply(g) if ((ctx.epilogue & TG_EPI_BIAS) and ctx.needs_input_grad[2]) else None
+    return gx, gw, gb, None, None
+
+
+class ConvBwdDataFn(torch.autograd.Function):
+  """gx = conv^T(gy, w)  (Conv2DBackpropInput); differentiable in gy and w."""
+
+  @staticmethod
+  def forward(ctx, gy, w, x_shape, spec):
+    ctx.spec, ctx.x_shape = spec, x_shape
+    ctx.save_for_backward(gy, w)
+    return conv_bwd_data_raw(gy, w, x_shape, spec)
+
+  @staticmethod
+  def backward(ctx, v):
+    gy, w = ctx.saved_tensors
+    v = v.contiguous()
+    ggy = Conv2dFn.apply(v, w, None, ctx.spec, 0) if ctx.needs_input_grad[0] else None
+    gw = ConvBwdWeightFn.apply(v, gy, ctx.spec) if ctx.needs_input_grad[1] else None
+    return ggy, gw, None, None
+
+
+class ConvBwdWeightFn(torch.autograd.Function):
+  """gw = x^T * gy  (Conv2DBackpropFilter), fp32 HWIO.  Third-order terms are not needed by any
+  TwinGAN loss, so this node is a leaf of the double-backward graph."""
+
+  @staticmethod
+  def forward(ctx, x, gy, spec):
+    return conv_bwd_weight_raw(x, gy, spec)
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, v):
+    raise NotImplementedError('third-order gradient through conv backward-weight')
+
+
+class LReluBwdFn(torch.autograd.Function):
+  """g * (z > 0 ? 1 : alpha); linear in g (its own double backward), zero gradient wrt z."""
+
+  @staticmethod
+  def forward(ctx, g, z, alpha):
+    ctx.alpha = alpha
+    ctx.save_for_backward(z)
+    return lrelu_bwd_raw(g, z, alpha)
+
+  @staticmethod
+  def backward(ctx, v):
+    z, = ctx.saved_tensors
+    return LReluBwdFn.apply(v.contiguous(), z, ctx.alpha), None, None
+
+
+class ChannelSumFn(torch.autograd.Function):
+  """BiasAddGrad: sum over pixels -> fp32 [C]."""
+
+  @staticmethod
+  def forward(ctx, g):
+    return channel_sum_raw(g)
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, v):
+    raise NotImplementedError('gradient through a bias gradient')
+
+
+def conv2d(x, w, bias=None, k=3, padding='SAME', lrelu=False, alpha=LRELU_ALPHA):
+  """Stride-1 conv, optional fused bias and LeakyReLU (discriminator layers)."""
+  spec = ConvSpec(k, padding, 0, alpha)
+  epi = (TG_EPI_BIAS if bias is not None else 0) | (TG_EPI_LRELU if lrelu else 0)
+  return Conv2dFn.apply(x, w, bias, spec, epi)
+
+
+# ------------------------------------------------------------------------------------------------
+# 1x1 convs with a 3-channel side: fromRGB / toRGB (nets/pggan.py:176-178,198-200,233-240,395-399)
+# ------------------------------------------------------------------------------------------------
+def _pw_fwd_raw(x, w, bias, wt, epilogue, alpha):
+  _chk(x, w, bias)
+  cin = x.shape[-1]
+  cout = w.shape[0] if wt else w.shape[1]
+  assert (w.shape[1] if wt else w.shape[0]) == cin, (w.shape, cin, wt)
+  y = torch.empty(x.shape[:-1] + (cout,), dtype=x.dtype, device=x.device)
+  call('tg_pointwise_conv_fwd', _p(x), _p(w), _p(bias), _p(y), x.numel() // cin, cin, cout, int(wt), epilogue, alpha,
+       _dt(x), _stream())
+  return y
+
+
+class PointwiseConvFn(torch.autograd.Function):
+  """z = epilogue(x @ W [+ b]) with W = w (wt=False) or w^T (wt=True); w is fp32 [a, b]."""
+
+  @staticmethod
+  def forward(ctx, x, w, bias, wt, epilogue, alpha):
+    z = _pw_fwd_raw(x, w, bias, wt, epilogue, alpha)
+    ctx.wt, ctx.epilogue, ctx.alpha = wt, epilogue, alpha
+    ctx.save_for_backward(x, w, z if (epilogue & TG_EPI_LRELU) else None)
+    return z
+
+  @staticmethod
+  def backward(ctx, gz):
+    x, w, z = ctx.saved_tensors
+    gz = gz.contiguous()
+    g = LReluBwdFn.apply(gz, z, ctx.alpha) if (ctx.epilogue & TG_EPI_LRELU) else gz
+    gx = PointwiseConvFn.apply(g, w, None, not ctx.wt, 0, ctx.alpha) if ctx.needs_input_grad[0] else None
+    gw = None
+    if ctx.needs_input_grad[1]:
+      # y = x @ W: dW = x^T g.  With wt the stored tensor is W^T, so dw = g^T x.
+      gw = PointwiseWgradFn.apply(g, x) if ctx.wt else PointwiseWgradFn.apply(x, g)
+    gb = ChannelSumFn.apply(g) if ((ctx.epilogue & TG_EPI_BIAS) and ctx.needs_input_grad[2]) else None
+    return gx, gw, gb, None, None, None
+
+
+class PointwiseWgradFn(torch.autograd.Function):
+  """a^T b over pixels -> fp32 [ca, cb] (one of ca, cb <= 4)."""
+
+  @staticmethod
+  def forward(ctx, a, b):
+    _chk(a, b)
+    ca, cb = a.shape[-1], b.shape[-1]
+    out = torch.empty((ca, cb), dtype=torch.float32, device=a.device)
+    call('tg_pointwise_conv_bwd_weight', _p(a), _p(b), _p(out), a.numel() // ca, ca, cb, 0, _dt(a), _stream())
+    return out
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, v):
+    raise NotImplementedError('third-order gradient through pointwise weight gradient')
+
+
+def pointwise_conv(x, w_hwio, bias=None, lrelu=False, alpha=LRELU_ALPHA):
+  """1x1 conv with w [1,1,cin,cout] where cin <= 4 or cout <= 4."""
+  w2 = w_hwio.view(w_hwio.shape[2], w_hwio.shape[3])
+  epi = (TG_EPI_BIAS if bias is not None else 0) | (TG_EPI_LRELU if lrelu else 0)
+  return PointwiseConvFn.apply(x, w2, bias, False, epi, alpha)
+
+
+# ------------------------------------------------------------------------------------------------
+# instance norm + LeakyReLU + pixel norm (generator / encoder layers)
+# ------------------------------------------------------------------------------------------------
+class NormActFn(torch.autograd.Function):
+  """z = pixel_norm(lrelu(instance_norm(y; gamma, beta))) -- libs/instance_norm.py:131-135,
+  util_misc.py:86, nets/pggan_utils.py:330-331.  First-order only (E/G never sit under the
+  gradient penalty)."""
+
+  @staticmethod
+  def forward(ctx, y, gamma, beta, flags, in_eps, pn_eps, alpha):
+    _chk(y, gamma, beta)
+    n, h, w, c = y.shape
+    mean = torch.empty(n * c, dtype=torch.float32, device=y.device)
+    rstd = torch.empty(n * c, dtype=torch.float32, device=y.device)
+    call('tg_instance_norm_stats', _p(y), _p(mean), _p(rstd), n, h, w, c, in_eps, _dt(y), _stream(),
+         work=('in_stats', 0, y.numel() * _esize(y)))
+    z = torch.empty_like(y)
+    s = torch.empty(n * h * w, dtype=torch.float32, device=y.device) if (flags & NF_PIXNORM) else None
+    call('tg_norm_act_fwd', _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(z), _p(s), n, h, w, c, flags, alpha,
+         pn_eps, _dt(y), _stream(), work=('norm_act_fwd', 0, 2 * y.numel() * _esize(y)))
+    ctx.flags, ctx.alpha = flags, alpha
+    ctx.save_for_backward(y, mean, rstd, gamma, beta, s)
+    return z
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, gz):
+    y, mean, rstd, gamma, beta, s = ctx.saved_tensors
+    gz = gz.contiguous()
+    n, h, w, c = y.shape
+    gy = torch.empty_like(y)
+    gg = torch.empty(c, dtype=torch.float32, device=y.device)
+    gb = torch.empty(c, dtype=torch.float32, device=y.device)
+    sums = torch.empty(2 * n * c, dtype=torch.float32, device=y.device)
+    call('tg_norm_act_bwd', _p(gz), _p(y), _p(s), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(gy), _p(gg), _p(gb),
+         _p(sums), n, h, w, c, ctx.flags, ctx.alpha, 0, _dt(y), _stream(),
+         work=('norm_act_bwd', 0, 3 * y.numel() * _esize(y)))
+    return gy, gg, gb, None, None, None, None
+
+
+def norm_act(y, gamma, beta, lrelu=True, pixel_norm=True, in_eps=1e-6, pn_eps=1e-6, alpha=LRELU_ALPHA):
+  flags = (NF_LRELU if lrelu else 0) | (NF_PIXNORM if pixel_norm else 0)
+  return NormActFn.apply(y, gamma, beta, flags, in_eps, pn_eps, alpha)
+
+
+# ------------------------------------------------------------------------------------------------
+# resampling / concat / fade-in
+# ------------------------------------------------------------------------------------------------
+class UpsampleConcatFn(torch.autograd.Function):
+  """concat(nearest_up2(x0), x1) on C (nets/pggan_utils.py:349-350, 281-298)."""
+
+  @staticmethod
+  def forward(ctx, x0, x1):
+    _chk(x0, x1)
+    n, h, w, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[3]
+    out = torch.empty((n, 2 * h, 2 * w, c0 + c1), dtype=x0.dtype, device=x0.device)
+    call('tg_upsample2x_concat_fwd', _p(x0), _p(x1), _p(out), n, h, w, c0, c1, _dt(x0), _stream())
+    ctx.dims = (n, h, w, c0, c1)
+    return out
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, go):
+    n, h, w, c0, c1 = ctx.dims
+    go = go.contiguous()
+    g0 = torch.empty((n, h, w, c0), dtype=go.dtype, device=go.device) if ctx.needs_input_grad[0] else None
+    g1 = torch.empty((n, 2 * h, 2 * w, c1), dtype=go.dtype, device=go.device) \
+        if (c1 and ctx.needs_input_grad[1]) else None
+    call('tg_upsample2x_concat_bwd', _p(go), _p(g0), _p(g1), n, h, w, c0, c1, _dt(go), _stream())
+    return g0, g1
+
+
+def upsample2x_concat(x0, x1=None):
+  return UpsampleConcatFn.apply(x0, x1)
+
+
+class Pool2Fn(torch.autograd.Function):
+  """scale * (2x2 block sum), stride 2 (avg-pool with scale .25)."""
+
+  @staticmethod
+  def forward(ctx, x, scale):
+    _chk(x)
+    n, h, w, c = x.shape
+    y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+    call('tg_pool2x2_fwd', _p(x), _p(y), n, h, w, c, scale, _dt(x), _stream())
+    ctx.scale, ctx.hw = scale, (h, w)
+    return y
+
+  @staticmethod
+  def backward(ctx, gy):
+    return Pool2BwdFn.apply(gy.contiguous(), ctx.scale, ctx.hw), None
+
+
+class Pool2BwdFn(torch.autograd.Function):
+  """scale * gy replicated 2x2 (adjoint of Pool2Fn; also the plain upsample with scale 1)."""
+
+  @staticmethod
+  def forward(ctx, gy, scale, hw):
+    _chk(gy)
+    n, _, _, c = gy.shape
+    gx = torch.empty((n, hw[0], hw[1], c), dtype=gy.dtype, device=gy.device)
+    call('tg_pool2x2_bwd', _p(gy), _p(gx), n, hw[0], hw[1], c, scale, _dt(gy), _stream())
+    ctx.scale = scale
+    return gx
+
+  @staticmethod
+  def backward(ctx, v):
+    return Pool2Fn.apply(v.contiguous(), ctx.scale), None, None
+
+
+def avg_pool2(x):
+  return Pool2Fn.apply(x, 0.25)
+
+
+class AxpbyFn(torch.autograd.Function):
+  """a*x + b*y (fade-in lerp, nets/pggan.py:205,314,475)."""
+
+  @staticmethod
+  def forward(ctx, x, y, a, b):
+    _chk(x, y)
+    out = torch.empty_like(x)
+    call('tg_axpby', _p(x), _p(y), _p(out), x.numel(), a, b, _dt(x), _stream())
+    ctx.a, ctx.b, ctx.has_y = a, b, y is not None
+    return out
+
+  @staticmethod
+  def backward(ctx, g):
+    g = g.contiguous()
+    gx = AxpbyFn.apply(g, None, ctx.a, 0.0) if ctx.needs_input_grad[0] else None
+    gy = AxpbyFn.apply(g, None, ctx.b, 0.0) if (ctx.has_y and ctx.needs_input_grad[1]) else None
+    return gx, gy, None, None
+
+
+def lerp(new, old, alpha):
+  """new * alpha + (1 - alpha) * old."""
+  return AxpbyFn.apply(new, old, float(alpha), float(1.0 - alpha))
+
+
+class CastFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x, dtype):
+    ctx.src = x.dtype
+    return cast_raw(x, dtype)
+
+  @staticmethod
+  def backward(ctx, g):
+    return CastFn.apply(g.contiguous(), ctx.src), None
+
+
+def cast(x, dtype):
+  return x if x.dtype == dtype else CastFn.apply(x, dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# minibatch stddev (nets/pggan_utils.py:353-366)
+# ------------------------------------------------------------------------------------------------
+def _mbstd_eps(dtype):
+  return 1e-8 if dtype == torch.float32 else 1e-6      # pggan_utils.py:359
+
+
+class MbstdFn(torch.autograd.Function):
+  """[n,h,w,c] -> [n,h,w,cpad]: x, the batch-stddev statistic in channel c, zeros above."""
+
+  @staticmethod
+  def forward(ctx, x, cpad):
+    _chk(x)
+    n, h, w, c = x.shape
+    out = torch.empty((n, h, w, cpad), dtype=x.dtype, device=x.device)
+    call('tg_mbstd_fwd', _p(x), _p(out), None, n, h * w, c, cpad, _mbstd_eps(x.dtype), _dt(x), _stream())
+    ctx.cpad = cpad
+    ctx.save_for_backward(x)
+    return out
+
+  @staticmethod
+  def backward(ctx, gout):
+    x, = ctx.saved_tensors
+    return MbstdBwdFn.apply(gout.contiguous(), x, ctx.cpad), None
+
+
+class MbstdBwdFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, gout, x, cpad):
+    n, h, w, c = x.shape
+    gx = torch.empty_like(x)
+    call('tg_mbstd_bwd', _p(gout), _p(x), _p(gx), n, h * w, c, cpad, _mbstd_eps(x.dtype), _dt(x), _stream())
+    ctx.cpad = cpad
+    ctx.save_for_backward(gout, x)
+    return gx
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, v):
+    gout, x = ctx.saved_tensors
+    v = v.contiguous()
+    n, h, w, c = x.shape
+    ggout = torch.empty_like(gout) if ctx.needs_input_grad[0] else None
+    gx2 = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+    call('tg_mbstd_bwd_bwd', _p(v), _p(gout), _p(x), _p(ggout), _p(gx2), n, h * w, c, ctx.cpad, _mbstd_eps(x.dtype),
+         _dt(x), _stream())
+    return ggout, gx2, None
+
+
+def minibatch_state_concat(x, cpad):
+  return MbstdFn.apply(x, cpad)
+
+
+# ------------------------------------------------------------------------------------------------
+# small dense layer (layers.fully_connected, nets/pggan_utils.py:323-327)
+# ------------------------------------------------------------------------------------------------
+class GemmFn(torch.autograd.Function):
+  """c = op(a) @ op(b), fp32 row-major; fully differentiable (every gradient is another GemmFn)."""
+
+  @staticmethod
+  def forward(ctx, a, b, ta, tb):
+    _chk(a, b)
+    m = a.shape[1] if ta else a.shape[0]
+    k = a.shape[0] if ta else a.shape[1]
+    n = b.shape[0] if tb else b.shape[1]
+    assert (b.shape[1] if tb else b.shape[0]) == k
+    c = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    call('tg_small_gemm', _p(a), _p(b), None, _p(c), m, n, k, int(ta), int(tb), 0, _stream())
+    ctx.ta, ctx.tb = ta, tb
+    ctx.save_for_backward(a, b)
+    return c
+
+  @staticmethod
+  def backward(ctx, g):
+    a, b = ctx.saved_tensors
+    g = g.contiguous()
+    ta, tb = ctx.ta, ctx.tb
+    ga = gb = None
+    if ctx.needs_input_grad[0]:
+      ga = GemmFn.apply(b, g, tb, True) if ta else GemmFn.apply(g, b, False, not tb)
+    if ctx.needs_input_grad[1]:
+      gb = GemmFn.apply(g, a, True, ta) if tb else GemmFn.apply(a, g, not ta, False)
+    return ga, gb, None, None
+
+
+class AddRowBiasFn(torch.autograd.Function):
+  """x[m,n] + b[n] for fp32 2-D tensors (tiny: the [B,1] prediction)."""
+
+  @staticmethod
+  def forward(ctx, x, b):
+    _chk(x, b)
+    out = torch.empty_like(x)
+    call('tg_bias_lrelu_fwd', _p(x), _p(b), _p(out), x.shape[0], x.shape[1], 1.0, TG_F32, _stream())
+    return out
+
+  @staticmethod
+  def backward(ctx, g):
+    g = g.contiguous()
+    return g, (ChannelSumFn.apply(g) if ctx.needs_input_grad[1] else None)
+
+
+def fully_connected(x, w, b):
+  """x [B,K] (any dtype) @ w [K,N] + b -> fp32 [B,N]."""
+  y = GemmFn.apply(cast(x, torch.float32), w, False, False)
+  return AddRowBiasFn.apply(y, b) if b is not None else y
+
+
+# ------------------------------------------------------------------------------------------------
+# losses (twingan.py:464,502; image_generation.py:333,350,431-436)
+# ------------------------------------------------------------------------------------------------
+class MeanFn(torch.autograd.Function):
+  """mean(x) * weight -> fp32 [1]."""
+
+  @staticmethod
+  def forward(ctx, x, weight):
+    _chk(x)
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    call('tg_sum', _p(x), _p(out), x.numel(), weight / x.numel(), 0, _dt(x), _stream())
+    ctx.meta = (x.shape, x.dtype, weight / x.numel())
+    return out
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, g):
+    shape, dtype, k = ctx.meta
+    return fill(shape, k, dtype, g.device, scalar=g.contiguous()), None
+
+
+class AbsDiffMeanFn(torch.autograd.Function):
+  """weight * mean|a - b| (tf.losses.absolute_difference) -> fp32 [1]."""
+
+  @staticmethod
+  def forward(ctx, a, b, weight):
+    _chk(a, b)
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    call('tg_abs_diff_sum', _p(a), _p(b), _p(out), a.numel(), weight / a.numel(), 0, _dt(a), _stream())
+    ctx.k = weight / a.numel()
+    ctx.save_for_backward(a, b)
+    return out
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, g):
+    a, b = ctx.saved_tensors
+    ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+    gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+    call('tg_abs_diff_bwd', _p(a), _p(b), _p(g.contiguous()), _p(ga), _p(gb), a.numel(), ctx.k, _dt(a), _stream())
+    return ga, gb, None
+
+
+class GradPenaltyFn(torch.autograd.Function):
+  """lambda * mean_b (||g_b||_2 - 1)^2 (image_generation.py:431-436) -> fp32 [1]."""
+
+  @staticmethod
+  def forward(ctx, g, lam):
+    _chk(g)
+    b = g.shape[0]
+    ss = torch.empty(b, dtype=torch.float32, device=g.device)
+    call('tg_sample_sumsq', _p(g), _p(ss), b, g.numel() // b, _dt(g), _stream())
+    loss = torch.empty(1, dtype=torch.float32, device=g.device)
+    coef = torch.empty(b, dtype=torch.float32, device=g.device)
+    call('tg_gp_penalty', _p(ss), _p(loss), _p(coef), b, lam, _stream())
+    ctx.save_for_backward(g, coef)
+    return loss
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, gl):
+    g, coef = ctx.saved_tensors
+    out = torch.empty_like(g)
+    b = g.shape[0]
+    call('tg_sample_scale', _p(g), _p(coef), _p(gl.contiguous()), _p(out), b, g.numel() // b, _dt(g), _stream())
+    return out, None
+
+
+def mean(x, weight=1.0):
+  return MeanFn.apply(x, float(weight))
+
+
+def abs_diff_mean(a, b, weight=1.0):
+  return AbsDiffMeanFn.apply(a, b, float(weight))
+
+
+def gradient_penalty(g, lam):
+  return GradPenaltyFn.apply(g, float(lam))

@@ -1,0 +1,190 @@
+"""Parameter store: every variable of one optimiser group lives in ONE flat fp32 HBM buffer (plus
+flat grad / Adam m / Adam v buffers), so a step needs one fused Adam launch and one RCCL all-reduce
+per group instead of one per variable (the reference applies Adam and tf.add_n per variable:
+model/model_inheritor.py:537-542, deployment/model_deploy.py:473-503).
+
+Variables are addressed by the reference's TF names and keep TF layouts
+(conv HWIO, fc [in, out]) so reference checkpoints map 1:1.  A variable may have a *physical*
+shape larger than its logical one (the D tail conv sees the minibatch-stddev tensor padded to a
+multiple of 8 channels); the padding rows are zero and stay zero under Adam.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from .ops import PackCache
+
+ALIGN = 64   # elements; keeps every variable 256-byte aligned inside the flat buffer
+
+
+def get_num_channels(stage, max_num_channels=256):
+  """nets/pggan_utils.py:369-372 (python-2 integer division)."""
+  return min(1024 // (2 ** stage), max_num_channels)
+
+
+def max_stage_of(hw):
+  """nets/pggan.py:126,218,425."""
+  return int(math.log2(hw)) - 2
+
+
+def mbstd_cpad(c):
+  """Physical channel count of the minibatch-stddev output (c + 1 rounded up to a multiple of 8)."""
+  return (c + 1 + 7) // 8 * 8
+
+
+class ParamStore:
+  GROUPS = ('g', 'd')    # g: encoder_content + generator (twingan.py:526-527); d: discriminator_* (image_generation.py:484-485)
+
+  def __init__(self, device):
+    self.device = torch.device(device)
+    self.specs = OrderedDict()      # name -> dict(shape, phys, group, kind)
+    self.P = {}                     # name -> physical leaf tensor (requires_grad)
+    self.flat = {}
+    self.grad = {}
+    self.m = {}
+    self.v = {}
+    self.offsets = {}
+
+  # ---- declaration ----------------------------------------------------------------------------
+  def add(self, name, shape, group, kind, phys=None):
+    assert name not in self.specs, name
+    self.specs[name] = dict(shape=tuple(shape), phys=tuple(phys or shape), group=group, kind=kind)
+
+  def add_conv(self, scope, k, cin, cout, group, bias, norm_domains, phys_cin=None):
+    self.add(scope + '/weights', (k, k, cin, cout), group, 'conv_w', (k, k, phys_cin or cin, cout))
+    if bias:
+      self.add(scope + '/biases', (cout,), group, 'bias')
+    for d in norm_domains:
+      self.add('%s/InstanceNorm/gamma_%s' % (scope, d), (cout,), group, 'gamma')
+      self.add('%s/InstanceNorm/beta_%s' % (scope, d), (cout,), group, 'beta')
+
+  # ---- allocation -----------------------------------------------------------------------------
+  def build(self, seed=0):
+    sizes = {g: 0 for g in self.GROUPS}
+    for name, s in self.specs.items():
+      n = int(math.prod(s['phys']))
+      self.offsets[name] = sizes[s['group']]
+      sizes[s['group']] += (n + ALIGN - 1) // ALIGN * ALIGN
+    for g in self.GROUPS:
+      n = max(sizes[g], ALIGN)
+      self.flat[g] = torch.zeros(n, dtype=torch.float32, device=self.device)
+      self.grad[g] = torch.zeros(n, dtype=torch.float32, device=self.device)
+      self.m[g] = torch.zeros(n, dtype=torch.float32, device=self.device)
+      self.v[g] = torch.zeros(n, dtype=torch.float32, device=self.device)
+    gen = torch.Generator().manual_seed(seed)
+    for name, s in self.specs.items():
+      g, off, n = s['group'], self.offsets[name], int(math.prod(s['phys']))
+      p = self.flat[g][off:off + n].view(s['phys'])
+      self._init(p, s, gen)
+      p.requires_grad_(True)
+      p.grad = self.grad[g][off:off + n].view(s['phys'])
+      self.P[name] = p
+      if s['kind'] == 'conv_w':
+        PackCache.register(p)
+    PackCache.version += 1
+    return self
+
+  def _init(self, p, s, gen):
+    """weights ~ N(0, 0.02) (nets/pggan_utils.py:56,93; pggan.py:364-368), biases/beta 0, gamma 1."""
+    with torch.no_grad():
+      if s['kind'] in ('conv_w', 'fc_w'):
+        p.zero_()
+        w = torch.randn(s['shape'], generator=gen, dtype=torch.float32) * 0.02
+        self._logical(p, s).copy_(w.to(p.device))
+      elif s['kind'] == 'gamma':
+        p.fill_(1.0)
+      else:
+        p.zero_()
+
+  @staticmethod
+  def _logical(p, s):
+    if s['phys'] == s['shape']:
+      return p
+    return p[tuple(slice(0, d) for d in s['shape'])]
+
+  # ---- access ---------------------------------------------------------------------------------
+  def __getitem__(self, name):
+    return self.P[name]
+
+  def __contains__(self, name):
+    return name in self.P
+
+  def names(self, group=None):
+    return [k for k, s in self.specs.items() if group is None or s['group'] == group]
+
+  def state_dict(self):
+    """Logical (reference-shaped) copies keyed by TF variable names."""
+    return {k: self._logical(self.P[k].detach(), s).clone() for k, s in self.specs.items()}
+
+  def grad_dict(self):
+    return {k: self._logical(self.P[k].grad, s).clone() for k, s in self.specs.items()}
+
+  def load_state_dict(self, sd, strict=True):
+    """``ignore_missing_vars`` semantics of pggan_runner.py:136-146 when strict is False."""
+    with torch.no_grad():
+      for k, s in self.specs.items():
+        if k not in sd:
+          if strict:
+            raise KeyError(k)
+          continue
+        src = torch.as_tensor(sd[k]).to(device=self.device, dtype=torch.float32)
+        assert tuple(src.shape) == s['shape'], (k, tuple(src.shape), s['shape'])
+        self.P[k].zero_() if s['phys'] != s['shape'] else None
+        self._logical(self.P[k], s).copy_(src)
+    PackCache.version += 1
+
+  def zero_grad(self, group):
+    self.grad[group].zero_()
+
+  def numel(self, group):
+    return sum(int(math.prod(s['shape'])) for s in self.specs.values() if s['group'] == group)
+
+
+def declare_twingan(store, cfg):
+  """All TwinGAN variables of one progressive stage (scopes twingan.py:105-110; layer lists
+  SURVEY.md Appendix A; nets/pggan.py:93-211,242-376,403-479)."""
+  hw, mc = cfg.hw, cfg.max_ch
+  ms = max_stage_of(hw)
+  nd = ('s', 't') if cfg.generator_norm_type == 'instance_norm' else ()
+
+  def enc_skeleton(top, group, bias, norm_domains):
+    if cfg.is_growing:
+      store.add_conv('%s/from_rgb_%dx%d/Conv' % (top, hw // 2, hw // 2), 1, 3, get_num_channels(ms - 1, mc), group, bias,
+                     norm_domains)
+    c = get_num_channels(ms, mc)
+    store.add_conv('%s/from_rgb_%dx%d/Conv' % (top, hw, hw), 1, 3, c, group, bias, norm_domains)
+    for stage in range(ms, 0, -1):
+      cur = hw // (2 ** (ms - stage))
+      nc = get_num_channels(stage - 1, mc)
+      blk = '%s/encoder_block_%dx%dx%d' % (top, cur, cur, nc)
+      store.add_conv(blk + '/Conv', 3, c, c, group, bias, norm_domains)
+      store.add_conv(blk + '/Conv_1', 3, c, nc, group, bias, norm_domains)
+      c = nc
+
+  enc_skeleton('encoder_content', 'g', False, nd)
+  # generator
+  c = get_num_channels(0, mc)
+  blk = 'generator/block_4x4x%d' % c
+  store.add_conv(blk + '/Conv', 3, c, c, 'g', False, nd)
+  store.add_conv(blk + '/Conv_1', 3, c, c, 'g', False, nd)
+  for stage in range(1, ms + 1):
+    cur = 2 ** (stage + 2)
+    oc = get_num_channels(stage, mc)
+    if stage == ms and cfg.is_growing:
+      store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (cur // 2, cur // 2), 1, c, 3, 'g', False, nd)
+    cin = c + (get_num_channels(stage - 1, mc) if cfg.use_unet else 0)
+    blk = 'generator/block_%dx%dx%d' % (cur, cur, oc)
+    store.add_conv(blk + '/Conv', 3, cin, oc, 'g', False, nd)
+    store.add_conv(blk + '/Conv_1', 3, oc, oc, 'g', False, nd)
+    c = oc
+  store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (hw, hw), 1, c, 3, 'g', False, nd)
+  # discriminators
+  for top in ('discriminator_s', 'discriminator_t'):
+    enc_skeleton(top, 'd', True, ())
+    blk = '%s/before_fc_1x1x%d' % (top, mc)
+    store.add_conv(blk + '/Conv', 3, mc + 1, mc, 'd', True, (), phys_cin=mbstd_cpad(mc))
+    store.add_conv(blk + '/Conv_1', 4, mc, mc, 'd', True, ())
+    store.add(top + '/prediction/fully_connected/weights', (mc, 1), 'd', 'fc_w')
+    store.add(top + '/prediction/fully_connected/biases', (1,), 'd', 'bias')
+  return store

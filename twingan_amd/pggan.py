@@ -1,0 +1,184 @@
+"""PGGAN-style encoder / generator / discriminator on the gfx950 kernels.
+
+Mirror of the reference network functions (nets/pggan.py) and layer helpers (nets/pggan_utils.py):
+same function names, same end-point names, same variable names, same layer order
+(conv -> norm -> LeakyReLU -> pixel-norm for G/E; conv + bias -> LeakyReLU for D).  What differs is
+the execution: every layer is one or two fused HIP kernels (twingan_amd/ops.py) instead of 6-10
+stock TF ops, and per-domain normaliser parameters are selected by ``domain`` ('s' | 't') instead of
+a TF variable-scope postfix (conditional_layer_var_scope_postfix, nets/pggan_utils.py:102-113).
+
+Network functions return ``(output, end_points)`` like the reference.  Tensors are NHWC.
+"""
+from . import ops
+from .params import get_num_channels, max_stage_of, mbstd_cpad
+
+
+# ------------------------------------------------------------------------------------------------
+# layer helpers (nets/pggan_utils.py)
+# ------------------------------------------------------------------------------------------------
+def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pixel_norm=True):
+  """maybe_pixel_norm(maybe_equalized_conv2d(...)) for the generator / encoder arg-scope
+  (nets/pggan_utils.py:86-98,236-245): conv without bias, per-domain instance norm, LeakyReLU(0.2),
+  then pixel norm (nets/pggan.py:78-81)."""
+  w = P[scope + '/weights']
+  if k == 1 and (w.shape[2] <= 4 or w.shape[3] <= 4):
+    y = ops.pointwise_conv(x, w)
+  else:
+    y = ops.conv2d(x, w, None, k, padding)
+  if cfg.generator_norm_type == 'instance_norm':
+    return ops.norm_act(y, P['%s/InstanceNorm/gamma_%s' % (scope, domain)],
+                        P['%s/InstanceNorm/beta_%s' % (scope, domain)], lrelu=activation,
+                        pixel_norm=pixel_norm and cfg.do_pixel_norm)
+  raise NotImplementedError('generator_norm_type=%s (only instance_norm is on the MI355X hot path)' %
+                            cfg.generator_norm_type)
+
+
+def _d_conv(P, scope, x, k=3, padding='SAME'):
+  """Discriminator arg-scope (nets/pggan_utils.py:116-127): conv + bias, no norm, LeakyReLU(0.2),
+  fused into the conv epilogue."""
+  w = P[scope + '/weights']
+  b = P[scope + '/biases']
+  if k == 1 and (w.shape[2] <= 4 or w.shape[3] <= 4):
+    return ops.pointwise_conv(x, w, b, lrelu=True)
+  return ops.conv2d(x, w, b, k, padding, lrelu=True)
+
+
+def resize_twice_as_big(x):
+  """nets/pggan_utils.py:349-350."""
+  return ops.upsample2x_concat(x, None)
+
+
+def maybe_concat_unet_layer(layer_hw, unet_end_points, max_ch):
+  """nets/pggan_utils.py:281-298: pick the encoder end-point to concatenate at resolution hw."""
+  if unet_end_points is None:
+    return None
+  num_channels = get_num_channels(max_stage_of(layer_hw) - 1, max_ch)
+  name = 'encoder_block_interpolated_%dx%dx%d' % (layer_hw, layer_hw, num_channels)
+  if name not in unet_end_points:
+    name = 'encoder_block_%dx%dx%d' % (layer_hw, layer_hw, num_channels)
+  if name not in unet_end_points:
+    raise ValueError('%s not in unet_end_points' % name)
+  return unet_end_points[name]
+
+
+# ------------------------------------------------------------------------------------------------
+# encoder (nets/pggan.py:382-479)
+# ------------------------------------------------------------------------------------------------
+def encoder_before_classification(P, source, domain, cfg, top='encoder_content'):
+  hw = source.shape[1]
+  max_stage = max_stage_of(hw)
+  assert max_stage >= 0
+  end_points = {'source': source}
+  shrinked = None
+  if cfg.is_growing:
+    shrinked = ops.avg_pool2(source)
+    name = 'from_rgb_%dx%d' % (hw // 2, hw // 2)
+    shrinked = _ge_conv(P, '%s/%s/Conv' % (top, name), shrinked, domain, cfg, k=1)
+    end_points[name] = shrinked
+  name = 'from_rgb_%dx%d' % (hw, hw)
+  net = _ge_conv(P, '%s/%s/Conv' % (top, name), source, domain, cfg, k=1)
+  end_points[name] = net
+  for stage in range(max_stage, 0, -1):
+    num_channels = get_num_channels(stage - 1, cfg.max_ch)
+    current_hw = hw // (2 ** (max_stage - stage))
+    name = 'encoder_block_%dx%dx%d' % (current_hw, current_hw, num_channels)
+    net = _ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg)
+    net = _ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg)
+    end_points[name] = net
+    current_hw //= 2
+    net = ops.avg_pool2(net)
+    end_points['downsample_to_%dx%dx%d' % (current_hw, current_hw, num_channels)] = net
+    if stage == max_stage and cfg.is_growing:
+      net = ops.lerp(net, shrinked, cfg.alpha_grow)
+      end_points['encoder_block_interpolated_%dx%dx%d' % (current_hw, current_hw, num_channels)] = net
+  end_points['before_classification'] = net
+  return net, end_points
+
+
+# ------------------------------------------------------------------------------------------------
+# generator (nets/pggan.py:69-211), TwinGAN mode: source is the encoder's [B,4,4,C] content tensor
+# ------------------------------------------------------------------------------------------------
+def generator(P, source, domain, cfg, unet_end_points=None, top='generator'):
+  max_stage = max_stage_of(cfg.hw)
+  assert source.shape[1] == 4 and source.shape[2] == 4, 'TwinGAN generator expects a 4x4 content tensor'
+  end_points = {'source': source}
+  net = source
+  net_before_growth = None
+  hw = 4
+  for stage in range(0, max_stage + 1):
+    hw = 2 ** (stage + 2)
+    output_channels = get_num_channels(stage, cfg.max_ch)
+    name = 'block_%dx%dx%d' % (hw, hw, output_channels)
+    if hw == 4:
+      net = _ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg)
+      net = _ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg)
+    else:
+      if stage == max_stage and cfg.is_growing:
+        rgb = 'generator_to_rgb_%dx%d' % (hw // 2, hw // 2)
+        net_before_growth = _ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=1, activation=False,
+                                     pixel_norm=False)
+        net_before_growth = resize_twice_as_big(net_before_growth)
+        end_points[rgb] = net_before_growth
+      # generator_three_layer_block: upsample -> concat(UNet) -> conv -> conv  (pggan.py:69-83)
+      net = ops.upsample2x_concat(net, maybe_concat_unet_layer(hw, unet_end_points, cfg.max_ch))
+      net = _ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg)
+      net = _ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg)
+    end_points[name] = net
+  rgb = 'generator_to_rgb_%dx%d' % (hw, hw)
+  # to_rgb: activation None, normaliser still applied, no pixel norm (pggan.py:192-200)
+  to_rgb = _ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=1, activation=False, pixel_norm=False)
+  if cfg.is_growing:
+    output = ops.lerp(to_rgb, net_before_growth, cfg.alpha_grow)
+    end_points['alpha_grow'] = cfg.alpha_grow
+  else:
+    output = to_rgb
+  end_points['output'] = output
+  return output, end_points
+
+
+# ------------------------------------------------------------------------------------------------
+# discriminator (nets/pggan.py:217-376)
+# ------------------------------------------------------------------------------------------------
+def discriminator_before_fc(P, source, cfg, top):
+  hw = source.shape[1]
+  max_stage = max_stage_of(hw)
+  assert max_stage >= 0
+  end_points = {}
+  shrinked = None
+  if cfg.is_growing:
+    shrinked = ops.avg_pool2(source)
+    name = 'from_rgb_%dx%d' % (hw // 2, hw // 2)
+    shrinked = _d_conv(P, '%s/%s/Conv' % (top, name), shrinked, k=1)
+    end_points[name] = shrinked
+  name = 'from_rgb_%dx%d' % (hw, hw)
+  net = _d_conv(P, '%s/%s/Conv' % (top, name), source, k=1)
+  end_points[name] = net
+  for stage in range(max_stage, 0, -1):
+    num_channels = get_num_channels(stage - 1, cfg.max_ch)
+    current_hw = hw // (2 ** (max_stage - stage))
+    name = 'encoder_block_%dx%dx%d' % (current_hw, current_hw, num_channels)
+    net = _d_conv(P, '%s/%s/Conv' % (top, name), net)
+    net = _d_conv(P, '%s/%s/Conv_1' % (top, name), net)
+    end_points[name] = net
+    current_hw //= 2
+    net = ops.avg_pool2(net)
+    end_points['downsample_to_%dx%dx%d' % (current_hw, current_hw, num_channels)] = net
+    if stage == max_stage and cfg.is_growing:
+      net = ops.lerp(net, shrinked, cfg.alpha_grow)
+      end_points['encoder_block_interpolated_%dx%dx%d' % (current_hw, current_hw, num_channels)] = net
+  blk = 'before_fc_1x1x%d' % cfg.max_ch
+  net = ops.minibatch_state_concat(net, mbstd_cpad(net.shape[3]))      # pggan_utils.py:353-366
+  net = _d_conv(P, '%s/%s/Conv' % (top, blk), net, k=3, padding='SAME')
+  net = _d_conv(P, '%s/%s/Conv_1' % (top, blk), net, k=4, padding='VALID')
+  end_points[blk] = net
+  end_points['before_fc'] = net
+  return net, end_points
+
+
+def discriminator(P, source, cfg, top):
+  net, end_points = discriminator_before_fc(P, source, cfg, top)
+  feat = net.reshape(net.shape[0], -1)                                 # tf.squeeze(net, (1, 2))
+  pred = ops.fully_connected(feat, P[top + '/prediction/fully_connected/weights'],
+                             P[top + '/prediction/fully_connected/biases'])
+  end_points['prediction'] = pred
+  return pred, end_points

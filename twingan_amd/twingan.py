@@ -1,0 +1,177 @@
+"""TwinGAN training graph, losses and the alternating G/D step on MI355X.
+
+Mirrors twingan.GanModel._clone_fn / add_loss (twingan.py:146-521), image_generation.add_gan_loss /
+_add_wgan_gp_loss / _add_optimization (image_generation.py:318-439,587-662), the Adam of
+model/model_inheritor.py:537-542 and the data-parallel clone reduction of
+deployment/model_deploy.py:242-315,473-503 -- with two deliberate scheduling differences:
+
+  * only the gradient set that is applied is computed (the reference graph computes both every
+    session.run -- its own note at image_generation.py:631-639);
+  * one process per GPU; the per-variable tf.add_n over clones becomes ONE sum all-reduce (RCCL over
+    xGMI) of the group's flat gradient buffer, with the loss pre-divided by the world size
+    (model_deploy.py:265-268).
+"""
+import ctypes
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import ops, pggan
+from ._lib import call
+from .ops import PackCache
+from .params import ParamStore, declare_twingan
+
+
+def act_dtype(cfg):
+  return torch.bfloat16 if cfg.precision == 'bf16' else torch.float32
+
+
+def get_growing_image(img, alpha):
+  """image_generation.py:1001-1006: alpha * img + (1 - alpha) * up(avgpool(img))."""
+  low = ops.upsample2x_concat(ops.avg_pool2(img), None)
+  return ops.lerp(img, low, alpha)
+
+
+def forward_generators(P, sources, targets, cfg):
+  """twingan.py:198-269: E(s), E(t) and the four generator passes (shared conv weights, per-domain
+  norm parameters, UNet skips from the encoder whose content is decoded)."""
+  es, es_ep = pggan.encoder_before_classification(P, sources, 's', cfg)
+  et, et_ep = pggan.encoder_before_classification(P, targets, 't', cfg)
+  u = cfg.use_unet
+  s_prime, _ = pggan.generator(P, et, 's', cfg, et_ep if u else None)     # target content -> source domain
+  s_cycle, _ = pggan.generator(P, es, 's', cfg, es_ep if u else None)
+  t_prime, _ = pggan.generator(P, es, 't', cfg, es_ep if u else None)
+  t_cycle, _ = pggan.generator(P, et, 't', cfg, et_ep if u else None)
+  return dict(es=es, et=et, s_prime=s_prime, s_cycle=s_cycle, t_prime=t_prime, t_cycle=t_cycle)
+
+
+def generator_loss(P, sources, targets, cfg):
+  """GENERATOR_LOSSES (twingan.py:464-505; image_generation.py:331-337).  Returns (total [1], terms)."""
+  assert cfg.loss_architecture in ('wgan_gp', 'wgan'), cfg.loss_architecture
+  if cfg.is_growing:
+    sources, targets = get_growing_image(sources, cfg.alpha_grow), get_growing_image(targets, cfg.alpha_grow)
+  o = forward_generators(P, sources, targets, cfg)
+  e_tp, _ = pggan.encoder_before_classification(P, o['t_prime'], 't', cfg)       # twingan.py:275-288
+  e_sp, _ = pggan.encoder_before_classification(P, o['s_prime'], 's', cfg)
+  terms = {}
+  for d, orig, prime, cyc, enc_orig, enc_opp_prime in (
+      ('s', sources, o['s_prime'], o['s_cycle'], o['es'], e_tp),
+      ('t', targets, o['t_prime'], o['t_cycle'], o['et'], e_sp)):
+    top = 'discriminator_' + d
+    terms['l_cyc_' + d] = ops.abs_diff_mean(orig, cyc, cfg.l_cyc_weight)
+    if cfg.hw >= 64 and cfg.do_l_cyc_gan:
+      pc, _ = pggan.discriminator(P, cyc, cfg, top)
+      terms['generator_fool_loss_cycle_' + d] = ops.mean(pc, -cfg.gan_weight)
+    pp, _ = pggan.discriminator(P, prime, cfg, top)
+    terms['generator_fool_loss_prime_' + d] = ops.mean(pp, -cfg.gan_weight)
+    if cfg.l_content_weight:
+      terms['l_content_' + d] = ops.abs_diff_mean(enc_orig, enc_opp_prime, cfg.l_content_weight)
+  total = None
+  for v in terms.values():
+    total = v if total is None else total + v
+  return total, terms
+
+
+def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t):
+  """DISCRIMINATOR_LOSSES (image_generation.py:348-379,414-439).  gp_alpha_*: fp32 [B] U[0,1) draws.
+  E/G run without a tape: only discriminator variables are in the var_list (image_generation.py:605-610)."""
+  assert cfg.loss_architecture in ('wgan_gp', 'wgan'), cfg.loss_architecture
+  with torch.no_grad():
+    if cfg.is_growing:
+      sources, targets = get_growing_image(sources, cfg.alpha_grow), get_growing_image(targets, cfg.alpha_grow)
+    o = forward_generators(P, sources, targets, cfg)
+  terms = {}
+  for d, real, prime, cyc, a in (('s', sources, o['s_prime'], o['s_cycle'], gp_alpha_s),
+                                 ('t', targets, o['t_prime'], o['t_cycle'], gp_alpha_t)):
+    top = 'discriminator_' + d
+    pr, _ = pggan.discriminator(P, real, cfg, top)
+    mean_real = ops.mean(pr, cfg.gan_weight)
+    if cfg.hw >= 64 and cfg.do_l_cyc_gan:
+      pc, _ = pggan.discriminator(P, cyc, cfg, top)
+      terms['discriminator_loss_cycle_' + d] = ops.mean(pc, cfg.gan_weight) - mean_real
+    pp, _ = pggan.discriminator(P, prime, cfg, top)
+    terms['discriminator_loss_prime_' + d] = ops.mean(pp, cfg.gan_weight) - mean_real
+    if cfg.wgan_drift_loss_weight:
+      raise NotImplementedError('wgan_drift_loss_weight (image_generation.py:360-367) is off in every BASELINE config')
+    if cfg.loss_architecture == 'wgan_gp':
+      interp = ops.sample_lerp(real, prime, a).requires_grad_(True)               # image_generation.py:420-424
+      pi, _ = pggan.discriminator(P, interp, cfg, top)
+      ones = ops.fill(pi.shape, 1.0, pi.dtype, pi.device)
+      gi, = torch.autograd.grad(pi, interp, grad_outputs=ones, create_graph=True)  # tf.gradients(pred, interp)
+      terms['discriminator_gradient_penalty_prime_' + d] = ops.gradient_penalty(gi.contiguous(),
+                                                                                cfg.gradient_penalty_lambda)
+  total = None
+  for v in terms.values():
+    total = v if total is None else total + v
+  return total, terms
+
+
+class Trainer:
+  """One data-parallel clone: parameters, Adam state and the alternating step."""
+
+  def __init__(self, cfg, device='cuda', seed=0, world_size=1, process_group=None):
+    self.cfg = cfg
+    self.device = torch.device(device)
+    self.world = world_size
+    self.pg = process_group
+    self.store = declare_twingan(ParamStore(self.device), cfg).build(seed)
+    self.P = self.store.P
+    self.n_critic_counter = 0       # image_generation.py:622-623
+    self.global_step = 0            # advanced on G runs only (image_generation.py:648-652)
+    self.adam_t = 0                 # one shared optimizer: beta powers advance on every apply (:554-561)
+
+  # ---- optimiser --------------------------------------------------------------------------------
+  def _allreduce(self, group):
+    """deployment/model_deploy.py:473-503 (tf.add_n over clones) as one RCCL sum all-reduce."""
+    if self.world > 1:
+      dist.all_reduce(self.store.grad[group], op=dist.ReduceOp.SUM, group=self.pg)
+
+  def _adam(self, group):
+    c = self.cfg
+    self.adam_t += 1
+    lr_t = c.learning_rate * math.sqrt(1.0 - c.adam_beta2 ** self.adam_t) / (1.0 - c.adam_beta1 ** self.adam_t)
+    s = self.store
+    call('tg_adam_step', s.flat[group].data_ptr(), s.grad[group].data_ptr(), s.m[group].data_ptr(),
+         s.v[group].data_ptr(), None, s.flat[group].numel(), lr_t, c.adam_beta1, c.adam_beta2, c.opt_epsilon,
+         1.0 / c.loss_scale, torch.cuda.current_stream().cuda_stream)
+    PackCache.version += 1
+
+  # ---- steps ------------------------------------------------------------------------------------
+  def g_step(self, sources, targets):
+    self.store.zero_grad('g')
+    self._set_requires_grad(g=True, d=False)
+    loss, terms = generator_loss(self.P, sources, targets, self.cfg)
+    (loss * (self.cfg.loss_scale / self.world)).backward()          # model_deploy.py:265-268,308-313
+    self._allreduce('g')
+    self._adam('g')
+    return loss.detach(), terms
+
+  def d_step(self, sources, targets, gp_alpha_s=None, gp_alpha_t=None):
+    b = sources.shape[0]
+    if gp_alpha_s is None:
+      gp_alpha_s = torch.rand(b, dtype=torch.float32, device=self.device)
+    if gp_alpha_t is None:
+      gp_alpha_t = torch.rand(b, dtype=torch.float32, device=self.device)
+    self.store.zero_grad('d')
+    self._set_requires_grad(g=False, d=True)
+    loss, terms = discriminator_loss(self.P, sources, targets, self.cfg, gp_alpha_s, gp_alpha_t)
+    (loss * (self.cfg.loss_scale / self.world)).backward()
+    self._allreduce('d')
+    self._adam('d')
+    return loss.detach(), terms
+
+  def run(self, sources, targets, gp_alpha_s=None, gp_alpha_t=None):
+    """One ``session.run(train_op)`` of the reference (image_generation.py:640-652):
+    n_critic_counter % n_critic == 0 -> generator/encoder apply, else discriminator apply."""
+    if self.n_critic_counter % self.cfg.n_critic == 0:
+      out = self.g_step(sources, targets)
+      self.global_step += 1
+    else:
+      out = self.d_step(sources, targets, gp_alpha_s, gp_alpha_t)
+    self.n_critic_counter += 1
+    return out
+
+  def _set_requires_grad(self, g, d):
+    for name, s in self.store.specs.items():
+      self.P[name].requires_grad_(g if s['group'] == 'g' else d)
