@@ -1,0 +1,156 @@
+"""Golden fixtures (tests/golden/*.npz, written by tools/make_golden.py from the float64 oracle).
+
+CPU (not gpu): the oracle still reproduces its frozen vectors (float64 NumPy primitives exactly, the
+torch-CPU float32 graph within fp32 round-off) -- guards the checker against silent drift.
+GPU: the HIP path (fp32 direct kernels; bf16 MFMA kernels with a looser bound) hits the same vectors
+through the C ABI.  Tolerances: fp32 outputs rel-L2 <= 1e-5, losses 1e-4 relative, gradients rel-L2
+<= 3e-3 (the fp32 torch-CPU oracle itself is 1e-3 from the fp64 vectors at 64x64); bf16 outputs rel-L2 <= 3e-2, gradients <= 8e-2.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ops as N          # checker only
+from oracle import torch_ref as R
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+MODELS = {'twingan_hw16_c8': dict(hw=16, max_ch=8), 'twingan_hw64_c8': dict(hw=64, max_ch=8),
+          'twingan_hw16_c8_growing': dict(hw=16, max_ch=8, is_growing=True, alpha_grow=0.3)}
+
+
+def load(name):
+  return dict(np.load(os.path.join(GOLD, name + '.npz')))
+
+
+def rel_l2(a, b):
+  a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+  assert a.shape == b.shape, (a.shape, b.shape)
+  return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU: oracle vs its frozen vectors
+# ------------------------------------------------------------------------------------------------
+def test_numpy_oracle_reproduces_primitive_fixtures():
+  g = load('primitives')
+  for tag, k, pad, hw in (('c3', 3, 'SAME', 8), ('c1', 1, 'SAME', 8), ('c4', 4, 'VALID', 4), ('rgb', 1, 'SAME', 8)):
+    assert rel_l2(N.conv2d(g[tag + '_x'], g[tag + '_w'], pad), g[tag + '_y']) < 1e-14
+    assert rel_l2(N.conv2d_bwd_data(g[tag + '_gy'], g[tag + '_w'], (hw, hw), pad), g[tag + '_gx']) < 1e-14
+    assert rel_l2(N.conv2d_bwd_weight(g[tag + '_x'], g[tag + '_gy'], (k, k), pad), g[tag + '_gw']) < 1e-14
+  z = N.pixel_norm(N.leaky_relu(N.instance_norm(g['na_x'], g['na_gamma'], g['na_beta'])))
+  assert rel_l2(z, g['na_z']) < 1e-14
+  assert rel_l2(N.minibatch_state_concat(g['mb_x']), g['mb_y']) < 1e-14
+  assert abs(N.absolute_difference(g['l_a'], g['l_b'], 0.7) - float(g['l_abs'])) < 1e-15
+  assert abs(N.gradient_penalty(g['gp_g'], 10.0) - float(g['gp'])) < 1e-12
+  th, m, v = g['adam_theta0'].copy(), np.zeros(64), np.zeros(64)
+  for t in range(3):
+    th, m, v = N.adam_step(th, g['adam_g'][t], m, v, t + 1)
+  assert rel_l2(th, g['adam_theta3']) < 1e-15
+
+
+@pytest.mark.parametrize('name', sorted(MODELS))
+def test_torch_oracle_fp32_reproduces_model_fixtures(name):
+  g = load(name)
+  kw = MODELS[name]
+  cfg = R.Config(**kw)
+  P = {k[len('param/'):]: torch.from_numpy(v).float() for k, v in g.items() if k.startswith('param/')}
+  s, t = torch.from_numpy(g['in/sources']).float(), torch.from_numpy(g['in/targets']).float()
+  with torch.no_grad():
+    o = R.forward_generators(P, s, t, cfg)
+  for k in ('es', 's_prime', 't_prime', 's_cycle', 't_cycle'):
+    assert rel_l2(o[k].numpy(), g['fwd/' + k]) < 2e-5, k
+  for v in P.values():
+    v.requires_grad_(True)
+  a_s = torch.from_numpy(g['in/gp_alpha_s']).float().reshape(-1, 1, 1, 1)
+  a_t = torch.from_numpy(g['in/gp_alpha_t']).float().reshape(-1, 1, 1, 1)
+  dl, terms = R.discriminator_loss(P, s, t, cfg, a_s, a_t)
+  assert abs(float(dl) - float(g['loss/d_total'])) < 1e-4 * max(1.0, abs(float(g['loss/d_total'])))
+  for k, v in terms.items():
+    assert abs(float(v) - float(g['loss/d/' + k])) < 1e-4 * max(1.0, abs(float(g['loss/d/' + k]))), k
+  grads = R.grads_of(dl, P, R.discriminator_var_names(P))
+  num = sum(float(((grads[k].double().numpy() - g['grad/' + k]) ** 2).sum()) for k in grads)
+  den = sum(float((g['grad/' + k] ** 2).sum()) for k in grads)
+  assert (num / den) ** 0.5 < 3e-3      # fp32 round-off through the GP double backward (1e-3 at 64x64)
+
+
+def test_cycle_gan_term_only_from_64():
+  """twingan.py:466: the fixtures themselves encode the rule."""
+  assert not any('cycle' in k for k in load('twingan_hw16_c8') if k.startswith('loss/d/'))
+  assert any('cycle' in k for k in load('twingan_hw64_c8') if k.startswith('loss/d/'))
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU: HIP path vs the frozen vectors
+# ------------------------------------------------------------------------------------------------
+def _dev(a, dtype=torch.float32):
+  return torch.from_numpy(np.ascontiguousarray(a)).float().to('cuda:0').to(dtype).contiguous()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_gpu_primitives_hit_golden(dtype):
+  from twingan_amd import ops
+  g = load('primitives')
+  tol = 1e-5 if dtype == torch.float32 else 1.5e-2
+  for tag, k, pad in (('c3', 3, 'SAME'), ('c1', 1, 'SAME'), ('c4', 4, 'VALID')):
+    x, w = _dev(g[tag + '_x'], dtype).requires_grad_(True), _dev(g[tag + '_w']).requires_grad_(True)
+    y = ops.conv2d(x, w, None, k, pad)
+    assert rel_l2(y.detach().float().cpu().numpy(), g[tag + '_y']) < tol, tag
+    y.backward(_dev(g[tag + '_gy'], dtype))
+    assert rel_l2(x.grad.float().cpu().numpy(), g[tag + '_gx']) < tol, tag
+    assert rel_l2(w.grad.cpu().numpy(), g[tag + '_gw']) < tol, tag
+  x, w = _dev(g['rgb_x'], dtype), _dev(g['rgb_w'])
+  assert rel_l2(ops.pointwise_conv(x, w).float().cpu().numpy(), g['rgb_y']) < tol
+  z = ops.norm_act(_dev(g['na_x'], dtype), _dev(g['na_gamma']), _dev(g['na_beta']))
+  assert rel_l2(z.float().cpu().numpy(), g['na_z']) < (1e-5 if dtype == torch.float32 else 1e-2)
+  z = ops.norm_act(_dev(g['na_x'], dtype), _dev(g['na_gamma']), _dev(g['na_beta']), lrelu=False, pixel_norm=False)
+  assert rel_l2(z.float().cpu().numpy(), g['na_z_rgb']) < (1e-5 if dtype == torch.float32 else 1e-2)
+  up = ops.upsample2x_concat(_dev(g['rs_x'], dtype))
+  assert rel_l2(up.float().cpu().numpy(), g['rs_up']) < (1e-7 if dtype == torch.float32 else 4e-3)
+  if dtype == torch.float32:
+    mb = ops.minibatch_state_concat(_dev(g['mb_x']), 24)
+    assert rel_l2(mb[..., :17].cpu().numpy(), g['mb_y']) < 1e-6
+    assert float(mb[..., 17:].abs().max()) == 0.0
+    la = ops.abs_diff_mean(_dev(g['l_a']), _dev(g['l_b']), 0.7)
+    assert abs(la.item() - float(g['l_abs'])) < 1e-6
+    gp = ops.gradient_penalty(_dev(g['gp_g']), 10.0)
+    assert abs(gp.item() - float(g['gp'])) < 1e-5 * float(g['gp'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,precision', [('twingan_hw16_c8', 'fp32'), ('twingan_hw64_c8', 'fp32'),
+                                            ('twingan_hw16_c8_growing', 'fp32'), ('twingan_hw64_c8', 'bf16')])
+def test_gpu_model_hits_golden(name, precision):
+  from twingan_amd import Config
+  from twingan_amd import twingan as T
+  g = load(name)
+  cfg = Config(precision=precision, **MODELS[name])
+  tr = T.Trainer(cfg, device='cuda:0', seed=0)
+  tr.store.load_state_dict({k[len('param/'):]: torch.from_numpy(v).float() for k, v in g.items()
+                            if k.startswith('param/')})
+  adt = torch.bfloat16 if precision == 'bf16' else torch.float32
+  s, t = _dev(g['in/sources'], adt), _dev(g['in/targets'], adt)
+  a_s, a_t = _dev(g['in/gp_alpha_s']), _dev(g['in/gp_alpha_t'])
+  otol, ltol, gtol = (1e-5, 1e-4, 3e-3) if precision == 'fp32' else (3e-2, 5e-2, 8e-2)
+  with torch.no_grad():
+    o = T.forward_generators(tr.P, s, t, cfg)
+  for k in ('es', 's_prime', 't_prime', 's_cycle', 't_cycle'):
+    assert rel_l2(o[k].float().cpu().numpy(), g['fwd/' + k]) < otol, k
+  for group, fn, args in (('g', T.generator_loss, (s, t, cfg)), ('d', T.discriminator_loss, (s, t, cfg, a_s, a_t))):
+    tr.store.zero_grad(group)
+    tr._set_requires_grad(g=group == 'g', d=group == 'd')
+    loss, terms = fn(tr.P, *args)
+    want = float(g['loss/%s_total' % group])
+    assert abs(loss.item() - want) < ltol * max(1.0, abs(want)) + (0.0 if precision == 'fp32' else 5e-2), (group, loss.item(), want)
+    if precision == 'fp32':
+      for k, v in terms.items():
+        w = float(g['loss/%s/%s' % (group, k)])
+        assert abs(v.item() - w) < ltol * max(1.0, abs(w)), (k, v.item(), w)
+    loss.backward()
+    gd = tr.store.grad_dict()
+    names = tr.store.names(group)
+    num = sum(float(((gd[k].double().cpu().numpy() - g['grad/' + k]) ** 2).sum()) for k in names)
+    den = sum(float((g['grad/' + k] ** 2).sum()) for k in names)
+    assert (num / den) ** 0.5 < gtol, (group, (num / den) ** 0.5)

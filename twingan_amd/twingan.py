@@ -15,10 +15,10 @@ import ctypes
 import math
 
 import torch
-import torch.distributed as dist
 
 from . import ops, pggan
 from ._lib import call
+from .dp import GradReducer, loss_scale_for_clones
 from .ops import PackCache
 from .params import ParamStore, declare_twingan
 
@@ -114,7 +114,7 @@ class Trainer:
     self.cfg = cfg
     self.device = torch.device(device)
     self.world = world_size
-    self.pg = process_group
+    self.reducer = GradReducer(world_size, process_group)
     self.store = declare_twingan(ParamStore(self.device), cfg).build(seed)
     self.P = self.store.P
     self.n_critic_counter = 0       # image_generation.py:622-623
@@ -123,9 +123,8 @@ class Trainer:
 
   # ---- optimiser --------------------------------------------------------------------------------
   def _allreduce(self, group):
-    """deployment/model_deploy.py:473-503 (tf.add_n over clones) as one RCCL sum all-reduce."""
-    if self.world > 1:
-      dist.all_reduce(self.store.grad[group], op=dist.ReduceOp.SUM, group=self.pg)
+    """deployment/model_deploy.py:473-503 (tf.add_n over clones) as bucketed RCCL sum all-reduces."""
+    self.reducer.allreduce(self.store.grad[group])
 
   def _adam(self, group):
     c = self.cfg
@@ -142,7 +141,7 @@ class Trainer:
     self.store.zero_grad('g')
     self._set_requires_grad(g=True, d=False)
     loss, terms = generator_loss(self.P, sources, targets, self.cfg)
-    (loss * (self.cfg.loss_scale / self.world)).backward()          # model_deploy.py:265-268,308-313
+    (loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)).backward()          # model_deploy.py:265-268,308-313
     self._allreduce('g')
     self._adam('g')
     return loss.detach(), terms
@@ -156,7 +155,7 @@ class Trainer:
     self.store.zero_grad('d')
     self._set_requires_grad(g=False, d=True)
     loss, terms = discriminator_loss(self.P, sources, targets, self.cfg, gp_alpha_s, gp_alpha_t)
-    (loss * (self.cfg.loss_scale / self.world)).backward()
+    (loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)).backward()
     self._allreduce('d')
     self._adam('d')
     return loss.detach(), terms
