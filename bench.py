@@ -37,9 +37,12 @@ def parse():
   ap.add_argument('--hw', type=int, default=256)
   ap.add_argument('--max-ch', type=int, default=256)
   ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+  ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
   ap.add_argument('--no-roofline', action='store_true')
   ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--cpu-batch', type=int, default=1)
+  ap.add_argument('--cpu-batch', type=int, default=2)
+  ap.add_argument('--cpu-threads', type=int, default=0, help='0 = min(host cores, 32)')
+  ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
   return ap.parse_args()
 
 
@@ -62,11 +65,14 @@ def roofline_pass(tr, a, b, steps=2):
   aggregates per kernel family."""
   from twingan_amd import _lib
   rec = []
+  graph_mode, tr.use_graph = tr.use_graph, False        # per-launch events need eager launches
+  one_step(tr, a, b)
   _lib.profiler = rec
   for _ in range(steps):
     one_step(tr, a, b)
   torch.cuda.synchronize()
   _lib.profiler = None
+  tr.use_graph = graph_mode
   fam = {}
   for name, tag, fl, by, e0, e1 in rec:
     ms = e0.elapsed_time(e1)
@@ -85,8 +91,9 @@ def roofline_pass(tr, a, b, steps=2):
                        tflops=round(f['flops'] / (f['ms'] * 1e-3) / 1e12, 2) if f['ms'] else 0.0,
                        gbs=round(f['bytes'] / (f['ms'] * 1e-3) / 1e9, 1) if f['ms'] else 0.0))
   k, f = top[0]
-  is_conv = 'conv2d' in k
-  if is_conv:
+  # the family is MFMA-bound when its algorithmic intensity exceeds the bf16 ridge (2.5 PF / 8 TB/s = 312 FLOP/B)
+  intensity = f['flops'] / max(f['bytes'], 1.0)
+  if f['flops'] and intensity > 1e3 * BF16_MFMA_PEAK_TFLOPS / HBM_PEAK_GBS:
     achieved = f['flops'] / (f['ms'] * 1e-3) / 1e12
     roof = dict(bound='mfma', achieved=round(achieved, 2), peak=BF16_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                 frac=round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), traffic=None)
@@ -94,6 +101,7 @@ def roofline_pass(tr, a, b, steps=2):
     achieved = f['bytes'] / (f['ms'] * 1e-3) / 1e9
     roof = dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                 frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None)
+  roof['intensity_flop_per_byte'] = round(intensity, 1)
   roof['kernel'] = k
   roof['avg_launch_us'] = round(1e3 * f['ms'] / f['launches'], 2)
   roof['hbm_algorithmic_gbs'] = round(f['bytes'] / (f['ms'] * 1e-3) / 1e9, 1)
@@ -103,10 +111,27 @@ def roofline_pass(tr, a, b, steps=2):
 
 
 def cpu_baseline(args):
+  """Runs cpu_baseline_child in a subprocess with a hard time limit so the bench line is always printed."""
+  import subprocess
+  cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--hw', str(args.hw), '--max-ch',
+         str(args.max_ch), '--cpu-batch', str(args.cpu_batch), '--cpu-threads', str(args.cpu_threads)]
+  try:
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    if line:
+      return json.loads(line[-1])
+    return dict(value=None, unit='images/sec', cores=0, kind='port', sample='failed: ' + out.stderr[-200:])
+  except subprocess.TimeoutExpired:
+    return dict(value=None, unit='images/sec', cores=0, kind='port', sample='timed out after 240 s')
+
+
+def cpu_baseline_child(args):
   """torch-CPU oracle (kind 'port': the TF-1.8 reference cannot run here) on a bounded sample:
-  one G+D step (efficient schedule) at the bench resolution with a reduced batch."""
+  one G+D step (efficient schedule) at the bench resolution with a reduced batch, after one untimed
+  warm-up G+D step.  Threads are capped: intra-op parallelism of these small convs stops scaling
+  long before the host's core count."""
   from oracle import torch_ref as R
-  cores = os.cpu_count() or 1
+  cores = args.cpu_threads or min(os.cpu_count() or 1, 32)
   torch.set_num_threads(cores)
   rcfg = R.Config(hw=args.hw, max_ch=args.max_ch)
   P = R.init_params(rcfg, seed=0)
@@ -115,17 +140,25 @@ def cpu_baseline(args):
   bsz = args.cpu_batch
   s, t = torch.rand(bsz, args.hw, args.hw, 3, generator=g), torch.rand(bsz, args.hw, args.hw, 3, generator=g)
   al = torch.rand(bsz, 1, 1, 1, generator=g)
-  t0 = time.time()
   R.train_step(P, opt, s, t, rcfg, al, al, counter=0)
   R.train_step(P, opt, s, t, rcfg, al, al, counter=1)
-  dt = time.time() - t0
-  return dict(value=round(bsz / dt, 4), unit='images/sec', cores=cores, kind='port',
-              sample='1 G+D step, batch %d at %dx%d, fp32 torch-CPU oracle, efficient schedule, %.1f s' % (
-                  bsz, args.hw, args.hw, dt))
+  reps, t0 = 0, time.time()
+  while True:
+    R.train_step(P, opt, s, t, rcfg, al, al, counter=0)
+    R.train_step(P, opt, s, t, rcfg, al, al, counter=1)
+    reps += 1
+    dt = time.time() - t0
+    if dt > 10.0 or reps >= 8:
+      break
+  print(json.dumps(dict(value=round(bsz * reps / dt, 4), unit='images/sec', cores=cores, kind='port',
+                        sample='%d G+D step(s), batch %d at %dx%d, fp32 torch-CPU oracle (oracle/torch_ref.py), efficient '
+                               'schedule, %d threads, %.1f s' % (reps, bsz, args.hw, args.hw, cores, dt))))
 
 
 def main():
   args = parse()
+  if args.cpu_baseline_only:
+    return cpu_baseline_child(args)
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -141,7 +174,7 @@ def main():
   from twingan_amd import Config
   from twingan_amd.twingan import Trainer
   cfg = Config(hw=args.hw, max_ch=args.max_ch, precision=args.precision)
-  tr = Trainer(cfg, device=device, seed=0, world_size=world)
+  tr = Trainer(cfg, device=device, seed=0, world_size=world, use_graph=not args.no_graph)
   dtype = torch.bfloat16 if args.precision == 'bf16' else torch.float32
   a, b = synthetic_batch(args.batch, args.hw, dtype, device, rank)
 
@@ -176,6 +209,7 @@ def main():
                              'instance norm + pixel norm, WGAN-GP, Adam; 1 step = G apply + D apply' % (
                                  args.hw, args.hw, args.max_ch),
                  'global_batch': args.batch * world, 'batch_per_gpu': args.batch, 'parallelism': 'dp%d' % world,
+                 'launch': 'eager' if args.no_graph else 'hipGraph replay',
                  'gflop_per_pair_model': GFLOP_PER_PAIR_256 if args.hw == 256 else None},
   }
   if args.hw == 256:

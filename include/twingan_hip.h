@@ -199,9 +199,13 @@ int tg_gp_penalty(const float* sumsq, float* loss, float* coef, int batch, float
  * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller.  Flat fp32 buffers of `numel`
  * elements; grad_scale multiplies g first (1/loss_scale).  theta_bf16 (may be NULL) receives the
  * rounded copy of the updated parameters (cast-on-read shadow, deployment/model_deploy.py:146-183).
+ * lr_t_dev (may be NULL): device fp32 [1] that overrides lr_t -- lets a captured hipGraph replay the
+ * step with a fresh bias-corrected rate.  tg_adam_tick advances the shared optimiser step counter on
+ * the device (one counter for G and D applies, image_generation.py:554-561) and writes that rate.
  * ------------------------------------------------------------------------------------------- */
 int tg_adam_step(float* theta, const float* grad, float* m, float* v, void* theta_bf16, int64_t numel, float lr_t,
-                 float beta1, float beta2, float eps, float grad_scale, void* stream);
+                 const float* lr_t_dev, float beta1, float beta2, float eps, float grad_scale, void* stream);
+int tg_adam_tick(int64_t* step_dev, float* lr_t_dev, float lr, float beta1, float beta2, void* stream);
 
 #ifdef __cplusplus
 }

@@ -270,6 +270,9 @@ def test_upsample_concat(ops, dtype, c0, c1):
   if dtype == torch.bfloat16:
     x0 = bf16_round(x0)
     x1 = bf16_round(x1) if c1 else None
+  else:                                   # exact-copy check: start from fp32-representable values
+    x0 = x0.astype(np.float32).astype(np.float64)
+    x1 = x1.astype(np.float32).astype(np.float64) if c1 else None
   a = to_dev(x0, dtype).requires_grad_(True)
   b = to_dev(x1, dtype).requires_grad_(True) if c1 else None
   out = ops.upsample2x_concat(a, b)
@@ -278,8 +281,7 @@ def test_upsample_concat(ops, dtype, c0, c1):
     ref = np.concatenate([ref, x1], axis=3)
   assert np.array_equal(host(out), ref)
   go = rng.randn(*ref.shape)
-  if dtype == torch.bfloat16:
-    go = bf16_round(go)
+  go = bf16_round(go) if dtype == torch.bfloat16 else go.astype(np.float32).astype(np.float64)
   out.backward(to_dev(go, dtype))
   g0 = go[..., :c0].reshape(2, 3, 2, 5, 2, c0).sum(axis=(2, 4))
   assert rel_l2(host(a.grad), g0) < tol_for(dtype)
@@ -431,10 +433,31 @@ def test_adam_kernel_tf_semantics():
     g = rng.randn(1000)
     lr_t = 1e-4 * np.sqrt(1 - 0.99 ** t) / (1 - 0.5 ** t)
     call('tg_adam_step', thd.data_ptr(), to_dev(g).data_ptr(), md.data_ptr(), vd.data_ptr(), None, 1000, float(lr_t),
-         0.5, 0.99, 1e-8, 1.0, torch.cuda.current_stream().cuda_stream)
+         None, 0.5, 0.99, 1e-8, 1.0, torch.cuda.current_stream().cuda_stream)
     th, m, v = N.adam_step(th, g, m, v, t)
   assert rel_l2(host(thd), th) < 1e-6
   assert rel_l2(host(md), m) < 1e-5 and rel_l2(host(vd), v) < 1e-5
+
+
+def test_adam_device_tick_matches_host_schedule():
+  """tg_adam_tick: the shared step counter and bias-corrected rate kept on the device (graph replay)."""
+  from twingan_amd._lib import call
+  rng = np.random.RandomState(17)
+  th = rng.randn(512)
+  m, v = np.zeros(512), np.zeros(512)
+  thd, md, vd = to_dev(th), to_dev(m), to_dev(v)
+  step = torch.zeros(1, dtype=torch.int64, device='cuda:0')
+  lr_t = torch.zeros(1, dtype=torch.float32, device='cuda:0')
+  st = torch.cuda.current_stream().cuda_stream
+  for t in (1, 2, 3, 4):
+    g = rng.randn(512)
+    call('tg_adam_tick', step.data_ptr(), lr_t.data_ptr(), 1e-4, 0.5, 0.99, st)
+    call('tg_adam_step', thd.data_ptr(), to_dev(g).data_ptr(), md.data_ptr(), vd.data_ptr(), None, 512, 0.0,
+         lr_t.data_ptr(), 0.5, 0.99, 1e-8, 1.0, st)
+    th, m, v = N.adam_step(th, g, m, v, t)
+    assert int(step.item()) == t
+    assert abs(lr_t.item() - 1e-4 * np.sqrt(1 - 0.99 ** t) / (1 - 0.5 ** t)) < 1e-10
+  assert rel_l2(host(thd), th) < 1e-6
 
 
 def test_errors_are_loud(ops):

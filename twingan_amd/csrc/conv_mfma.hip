@@ -319,12 +319,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma(const bf16* __restrict__ 
   }
 }
 
-__global__ void conv_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ gw, int64_t nw, int nslices,
-                                  int accumulate) {
+// gw[i] += sum over this block row's share of the k-slices (grid.y slice groups; gw pre-zeroed unless
+// accumulating).  One fp32 atomic per element per slice group.
+__global__ void conv_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ gw, int64_t nw, int nslices) {
+  const int per = (nslices + gridDim.y - 1) / gridDim.y;
+  const int k0 = blockIdx.y * per;
+  const int k1 = min(nslices, k0 + per);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (int64_t)gridDim.x * blockDim.x) {
-    float s = accumulate ? gw[i] : 0.f;
-    for (int k = 0; k < nslices; ++k) s += slab[(size_t)k * nw + i];
-    gw[i] = s;
+    float s0 = 0.f, s1 = 0.f;
+    int k = k0;
+    for (; k + 1 < k1; k += 2) {
+      s0 += slab[(size_t)k * nw + i];
+      s1 += slab[(size_t)(k + 1) * nw + i];
+    }
+    if (k < k1) s0 += slab[(size_t)k * nw + i];
+    if (k1 > k0) atomicAdd(gw + i, s0 + s1);
   }
 }
 
@@ -491,7 +500,7 @@ static void wgrad_split(const Geom& g, int* n_ci, int* n_co, int* nslices, int* 
   *n_ci = (g.cin + 31) / 32;
   *n_co = (g.cout + 31) / 32;
   *total_tiles = g.tiles_x * g.tiles_y * g.tiles_img;
-  int want = 1024 / (*n_ci * *n_co);          // aim for ~1024 workgroups (4 per CU)
+  int want = 768 / (*n_ci * *n_co);           // aim for one resident wave of workgroups (3 per CU at 152 VGPRs)
   if (want < 1) want = 1;
   if (want > *total_tiles) want = *total_tiles;
   *tiles_per_block = (*total_tiles + want - 1) / want;
@@ -538,8 +547,16 @@ int tg_conv2d_bwd_weight_mfma(const TgConvDesc* d0, const void* x, const void* g
     hipLaunchKernelGGL((conv_wgrad_mfma<3, 3>), grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g,
                        n_co, tpb, total);
   TG_LAUNCH_CHECK("conv_wgrad_mfma");
-  hipLaunchKernelGGL(conv_wgrad_reduce, dim3(tg_grid_for(nw, 256)), dim3(256), 0, s, (const float*)ws, gw, nw, nslices,
-                     accumulate);
+  if (!accumulate && hipMemsetAsync(gw, 0, (size_t)nw * sizeof(float), s) != hipSuccess) {
+    tg_set_error("tg_conv2d_bwd_weight(mfma): memset failed");
+    return TG_ELAUNCH;
+  }
+  // spread the slice loop over grid.y so that small weights (9 blocks of elements) still fill the chip
+  const int gx = tg_grid_for(nw, 256);
+  int gy_ = (1024 + gx - 1) / gx;
+  if (gy_ > nslices) gy_ = nslices;
+  if (gy_ < 1) gy_ = 1;
+  hipLaunchKernelGGL(conv_wgrad_reduce, dim3(gx, gy_), dim3(256), 0, s, (const float*)ws, gw, nw, nslices);
   TG_LAUNCH_CHECK("conv_wgrad_reduce");
   return TG_OK;
 }

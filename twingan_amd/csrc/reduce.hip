@@ -219,8 +219,9 @@ __global__ void small_gemm_kernel(const float* __restrict__ a, const float* __re
 
 // TF-1.x Adam (model/model_inheritor.py:537-542): epsilon OUTSIDE the bias-corrected sqrt.
 __global__ void adam_kernel(float* __restrict__ th, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, bf16* __restrict__ shadow, int64_t numel, float lr_t, float b1, float b2,
-                            float eps, float gscale) {
+                            float* __restrict__ v, bf16* __restrict__ shadow, int64_t numel, float lr_t,
+                            const float* __restrict__ lr_t_dev, float b1, float b2, float eps, float gscale) {
+  if (lr_t_dev) lr_t = lr_t_dev[0];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * gscale;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -230,6 +231,15 @@ __global__ void adam_kernel(float* __restrict__ th, const float* __restrict__ g,
     v[i] = vi;
     th[i] = t;
     if (shadow) shadow[i] = (bf16)t;
+  }
+}
+
+// One thread: t = ++step; lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t)   (tf.train.AdamOptimizer._prepare/_apply_dense)
+__global__ void adam_tick_kernel(int64_t* step, float* lr_t, float lr, float b1, float b2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int64_t t = step[0] + 1;
+    step[0] = t;
+    lr_t[0] = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
   }
 }
 
@@ -346,11 +356,18 @@ int tg_small_gemm(const float* a, const float* b, const float* bias, float* c, i
 }
 
 int tg_adam_step(float* theta, const float* grad, float* m, float* v, void* theta_bf16, int64_t numel, float lr_t,
-                 float beta1, float beta2, float eps, float grad_scale, void* stream) {
+                 const float* lr_t_dev, float beta1, float beta2, float eps, float grad_scale, void* stream) {
   TG_CHECK(theta && grad && m && v && numel > 0, TG_EINVAL, "tg_adam_step: bad arguments");
   hipLaunchKernelGGL(adam_kernel, dim3(tg_grid_for(numel, 256)), dim3(256), 0, (hipStream_t)stream, theta, grad, m, v,
-                     (bf16*)theta_bf16, numel, lr_t, beta1, beta2, eps, grad_scale);
+                     (bf16*)theta_bf16, numel, lr_t, lr_t_dev, beta1, beta2, eps, grad_scale);
   TG_LAUNCH_CHECK("tg_adam_step");
+  return TG_OK;
+}
+
+int tg_adam_tick(int64_t* step_dev, float* lr_t_dev, float lr, float beta1, float beta2, void* stream) {
+  TG_CHECK(step_dev && lr_t_dev, TG_EINVAL, "tg_adam_tick: null pointer");
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev, lr_t_dev, lr, beta1, beta2);
+  TG_LAUNCH_CHECK("tg_adam_tick");
   return TG_OK;
 }
 

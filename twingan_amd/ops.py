@@ -48,21 +48,29 @@ def _chk(*ts):
 # weight-pack cache for the MFMA kernels
 # ------------------------------------------------------------------------------------------------
 class PackCache:
-  """bf16 K-contiguous packs (tg_conv2d_pack_weights) of registered master weights.  A pack is
-  rebuilt in place (same device address, graph-capture friendly) when ``version`` has moved since it
-  was made -- the optimiser bumps ``version`` after every apply."""
+  """bf16 K-contiguous packs (tg_conv2d_pack_weights) of registered master weights.
+
+  Lazy mode (tests, eager steps): a pack is rebuilt in place (same device address) at its next use
+  when ``version`` has moved since it was made.  Explicit mode (the trainer, and the only mode that
+  is safe under hipGraph capture): the optimiser calls ``refresh(weights)`` right after every apply,
+  which re-packs every existing pack of those weights and stamps it current, so a captured step
+  contains its own pack launches and never depends on cache state."""
   version = 0
-  _registered = set()
-  _packs = {}
+  _registered = {}     # data_ptr -> weight tensor
+  _packs = {}          # (data_ptr, mode, elems) -> [version, buffer, descriptor copy]
 
   @classmethod
   def register(cls, w):
-    cls._registered.add(w.data_ptr())
+    cls._registered[w.data_ptr()] = w
 
   @classmethod
   def clear(cls):
     cls._registered.clear()
     cls._packs.clear()
+
+  @classmethod
+  def _pack(cls, w, desc, mode, buf):
+    call('tg_conv2d_pack_weights', ctypes.byref(desc), _p(w), mode, _p(buf), _stream())
 
   @classmethod
   def get(cls, w, desc, mode):
@@ -73,10 +81,24 @@ class PackCache:
     if ent is not None and ent[0] == cls.version:
       return ent[1]
     buf = ent[1] if ent is not None else torch.empty(n, dtype=torch.bfloat16, device=w.device)
-    call('tg_conv2d_pack_weights', ctypes.byref(desc), _p(w), mode, _p(buf), _stream())
+    cls._pack(w, desc, mode, buf)
     if cached:
-      cls._packs[key] = (cls.version, buf)
+      dcopy = TgConvDesc()
+      ctypes.pointer(dcopy)[0] = desc
+      cls._packs[key] = [cls.version, buf, dcopy]
     return buf
+
+  @classmethod
+  def refresh(cls, weights):
+    """Re-packs (in place) every existing pack of ``weights`` and marks it current."""
+    ptrs = {w.data_ptr() for w in weights}
+    n = 0
+    for (ptr, mode, _), ent in cls._packs.items():
+      if ptr in ptrs:
+        cls._pack(cls._registered[ptr], ent[2], mode, ent[1])
+        ent[0] = cls.version
+        n += 1
+    return n
 
 
 class ConvSpec:

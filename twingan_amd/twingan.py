@@ -108,9 +108,17 @@ def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t):
 
 
 class Trainer:
-  """One data-parallel clone: parameters, Adam state and the alternating step."""
+  """One data-parallel clone: parameters, Adam state and the alternating step.
 
-  def __init__(self, cfg, device='cuda', seed=0, world_size=1, process_group=None):
+  ``run`` is one ``session.run(train_op)`` of the reference.  With ``use_graph=True`` the two step kinds
+  (generator/encoder apply, discriminator apply) are captured once as hipGraphs over static input
+  buffers and replayed: the ~4-5 k kernel launches of a step then cost one graph launch on the host
+  instead of a Python/ctypes round trip each.  Everything a replay needs lives on the device: the
+  shared Adam step counter and bias-corrected rate (tg_adam_tick), the WGAN-GP alphas (device RNG),
+  the weight packs (rebuilt by the captured optimiser tail).
+  """
+
+  def __init__(self, cfg, device='cuda', seed=0, world_size=1, process_group=None, use_graph=False):
     self.cfg = cfg
     self.device = torch.device(device)
     self.world = world_size
@@ -120,6 +128,13 @@ class Trainer:
     self.n_critic_counter = 0       # image_generation.py:622-623
     self.global_step = 0            # advanced on G runs only (image_generation.py:648-652)
     self.adam_t = 0                 # one shared optimizer: beta powers advance on every apply (:554-561)
+    self._adam_step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+    self._lr_t_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
+    self._group_weights = {g: [self.P[k] for k, s in self.store.specs.items() if s['group'] == g and s['kind'] == 'conv_w']
+                           for g in self.store.GROUPS}
+    self.use_graph = use_graph
+    self._graphs = None
+    self._static = None
 
   # ---- optimiser --------------------------------------------------------------------------------
   def _allreduce(self, group):
@@ -127,26 +142,28 @@ class Trainer:
     self.reducer.allreduce(self.store.grad[group])
 
   def _adam(self, group):
+    """tf.train.AdamOptimizer apply (model/model_inheritor.py:537-542) on the group's flat buffers, then
+    refresh the bf16 weight packs of the convs that just moved."""
     c = self.cfg
     self.adam_t += 1
-    lr_t = c.learning_rate * math.sqrt(1.0 - c.adam_beta2 ** self.adam_t) / (1.0 - c.adam_beta1 ** self.adam_t)
     s = self.store
+    st = torch.cuda.current_stream().cuda_stream
+    call('tg_adam_tick', self._adam_step_dev.data_ptr(), self._lr_t_dev.data_ptr(), c.learning_rate, c.adam_beta1,
+         c.adam_beta2, st)
     call('tg_adam_step', s.flat[group].data_ptr(), s.grad[group].data_ptr(), s.m[group].data_ptr(),
-         s.v[group].data_ptr(), None, s.flat[group].numel(), lr_t, c.adam_beta1, c.adam_beta2, c.opt_epsilon,
-         1.0 / c.loss_scale, torch.cuda.current_stream().cuda_stream)
-    PackCache.version += 1
+         s.v[group].data_ptr(), None, s.flat[group].numel(), 0.0, self._lr_t_dev.data_ptr(), c.adam_beta1,
+         c.adam_beta2, c.opt_epsilon, 1.0 / c.loss_scale, st)
+    PackCache.refresh(self._group_weights[group])
 
   # ---- steps ------------------------------------------------------------------------------------
-  def g_step(self, sources, targets):
+  def _g_grads(self, sources, targets):
     self.store.zero_grad('g')
     self._set_requires_grad(g=True, d=False)
     loss, terms = generator_loss(self.P, sources, targets, self.cfg)
-    (loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)).backward()          # model_deploy.py:265-268,308-313
-    self._allreduce('g')
-    self._adam('g')
-    return loss.detach(), terms
+    (loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)).backward()     # model_deploy.py:265-268,308-313
+    return loss.detach(), {k: v.detach() for k, v in terms.items()}
 
-  def d_step(self, sources, targets, gp_alpha_s=None, gp_alpha_t=None):
+  def _d_grads(self, sources, targets, gp_alpha_s=None, gp_alpha_t=None):
     b = sources.shape[0]
     if gp_alpha_s is None:
       gp_alpha_s = torch.rand(b, dtype=torch.float32, device=self.device)
@@ -156,18 +173,80 @@ class Trainer:
     self._set_requires_grad(g=False, d=True)
     loss, terms = discriminator_loss(self.P, sources, targets, self.cfg, gp_alpha_s, gp_alpha_t)
     (loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)).backward()
+    return loss.detach(), {k: v.detach() for k, v in terms.items()}
+
+  def g_step(self, sources, targets):
+    out = self._g_grads(sources, targets)
+    self._allreduce('g')
+    self._adam('g')
+    return out
+
+  def d_step(self, sources, targets, gp_alpha_s=None, gp_alpha_t=None):
+    out = self._d_grads(sources, targets, gp_alpha_s, gp_alpha_t)
     self._allreduce('d')
     self._adam('d')
-    return loss.detach(), terms
+    return out
+
+  # ---- hipGraph capture ---------------------------------------------------------------------------
+  def _capture(self, sources, targets):
+    """Captures {grads, apply} x {g, d}.  Gradient graphs and apply graphs are separate so that the
+    clone all-reduce (RCCL) runs between them, outside any capture."""
+    self._static = dict(s=sources.clone(), t=targets.clone())
+    st = self._static
+    side = torch.cuda.Stream(device=self.device)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                 # eager warm-up (real runs): allocates every pack once
+      for _ in range(2 * self.cfg.n_critic):      # whole n_critic cycles, so the caller's G/D phase is unchanged
+        if self.n_critic_counter % self.cfg.n_critic == 0:
+          self.g_step(st['s'], st['t'])
+          self.global_step += 1
+        else:
+          self.d_step(st['s'], st['t'])
+        self.n_critic_counter += 1
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize(self.device)
+    graphs, outs = {}, {}
+    pool = None
+    for kind, fn in (('g', self._g_grads), ('d', self._d_grads)):
+      gr = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(gr, pool=pool):
+        outs[kind] = fn(st['s'], st['t'])
+      pool = gr.pool()
+      ga = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(ga, pool=pool):
+        self._adam(kind)
+      graphs[kind] = (gr, ga)
+    self.adam_t -= 2                              # the two captured (not executed) applies
+    self._graphs, self._outs = graphs, outs
+
+  def _run_graph(self, kind, sources, targets):
+    if self._graphs is None:
+      self._capture(sources, targets)
+    st = self._static
+    if sources.data_ptr() != st['s'].data_ptr():
+      st['s'].copy_(sources)
+    if targets.data_ptr() != st['t'].data_ptr():
+      st['t'].copy_(targets)
+    gr, ga = self._graphs[kind]
+    gr.replay()
+    self._allreduce(kind)
+    ga.replay()
+    self.adam_t += 1
+    return self._outs[kind]
 
   def run(self, sources, targets, gp_alpha_s=None, gp_alpha_t=None):
     """One ``session.run(train_op)`` of the reference (image_generation.py:640-652):
     n_critic_counter % n_critic == 0 -> generator/encoder apply, else discriminator apply."""
-    if self.n_critic_counter % self.cfg.n_critic == 0:
+    is_g = self.n_critic_counter % self.cfg.n_critic == 0
+    if self.use_graph:
+      assert gp_alpha_s is None and gp_alpha_t is None, 'graph mode draws the GP alphas on the device'
+      out = self._run_graph('g' if is_g else 'd', sources, targets)
+    elif is_g:
       out = self.g_step(sources, targets)
-      self.global_step += 1
     else:
       out = self.d_step(sources, targets, gp_alpha_s, gp_alpha_t)
+    if is_g:
+      self.global_step += 1
     self.n_critic_counter += 1
     return out
 
