@@ -39,6 +39,7 @@ extern "C" {
 /* Conv algorithm selector */
 #define TG_ALGO_DIRECT 0 /* one thread per output, any shape, f32 or bf16 activations */
 #define TG_ALGO_MFMA 1   /* LDS-tiled implicit GEMM on v_mfma_f32_32x32x16_bf16, bf16 activations only */
+#define TG_ALGO_MFMA_V1 2 /* same weight packs, forces the first-generation MFMA kernels (A/B benchmarking) */
 
 /* Epilogue / prologue flags */
 #define TG_EPI_BIAS 1

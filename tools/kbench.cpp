@@ -1,0 +1,220 @@
+// kbench -- per-layer conv benchmark + on-device cross-check through the C ABI (no Python).
+//
+//   tools/kbench [filter] [--algo A] [--iters N] [--batch B] [--nocheck]
+//
+// For every conv of the 256x256 TwinGAN stage (E/D skeleton + G with UNet concat, SURVEY.md
+// Appendix A) runs forward / backward-data / backward-weight with the MFMA kernels, checks each
+// against the direct kernels (validated against the oracle by tests/test_gpu_ops.py) at a reduced
+// batch, and times the full batch with HIP events.  Build: make -C twingan_amd/csrc kbench
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../include/twingan_hip.h"
+
+#define HC(x)                                                                      \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess) {                                                        \
+      fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      exit(2);                                                                     \
+    }                                                                              \
+  } while (0)
+#define TC(x)                                                               \
+  do {                                                                      \
+    int r_ = (x);                                                           \
+    if (r_) {                                                               \
+      fprintf(stderr, "%s:%d %s -> %d: %s\n", __FILE__, __LINE__, #x, r_, tg_last_error()); \
+      exit(3);                                                              \
+    }                                                                       \
+  } while (0)
+
+struct Case {
+  const char* name;
+  int hw, cin, cout, k;
+};
+
+static uint16_t f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7fff + ((u >> 16) & 1);
+  return (uint16_t)(u >> 16);
+}
+static float bf2f(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static uint32_t rng_state = 12345;
+static float frand() {
+  rng_state = rng_state * 1664525u + 1013904223u;
+  return ((rng_state >> 8) & 0xffff) / 32768.0f - 1.0f;
+}
+
+static void* dev_bf16_random(size_t n, float scale) {
+  std::vector<uint16_t> h(n);
+  for (size_t i = 0; i < n; ++i) h[i] = f2bf(frand() * scale);
+  void* d;
+  HC(hipMalloc(&d, n * 2 + 64));
+  HC(hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice));
+  return d;
+}
+static float* dev_f32_random(size_t n, float scale) {
+  std::vector<float> h(n);
+  for (size_t i = 0; i < n; ++i) h[i] = frand() * scale;
+  float* d;
+  HC(hipMalloc(&d, n * 4 + 64));
+  HC(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+  return d;
+}
+static double rel_l2_bf16(const void* a, const void* b, size_t n) {
+  std::vector<uint16_t> ha(n), hb(n);
+  HC(hipMemcpy(ha.data(), a, n * 2, hipMemcpyDeviceToHost));
+  HC(hipMemcpy(hb.data(), b, n * 2, hipMemcpyDeviceToHost));
+  double num = 0, den = 0;
+  for (size_t i = 0; i < n; ++i) {
+    double x = bf2f(ha[i]), y = bf2f(hb[i]);
+    num += (x - y) * (x - y);
+    den += y * y;
+  }
+  return sqrt(num / (den + 1e-30));
+}
+static double rel_l2_f32(const float* a, const float* b, size_t n) {
+  std::vector<float> ha(n), hb(n);
+  HC(hipMemcpy(ha.data(), a, n * 4, hipMemcpyDeviceToHost));
+  HC(hipMemcpy(hb.data(), b, n * 4, hipMemcpyDeviceToHost));
+  double num = 0, den = 0;
+  for (size_t i = 0; i < n; ++i) {
+    double x = ha[i], y = hb[i];
+    num += (x - y) * (x - y);
+    den += y * y;
+  }
+  return sqrt(num / (den + 1e-30));
+}
+
+static TgConvDesc mk(int n, int hw, int cin, int cout, int k, int algo, int epi) {
+  TgConvDesc d;
+  memset(&d, 0, sizeof(d));
+  d.n = n; d.hin = d.win = hw; d.cin = cin;
+  d.hout = d.wout = hw; d.cout = cout;
+  d.kh = d.kw = k;
+  d.pad_t = d.pad_l = (k - 1) / 2;
+  d.dtype = TG_BF16;
+  d.algo = algo;
+  d.epilogue = epi;
+  d.lrelu_alpha = 0.2f;
+  return d;
+}
+
+template <typename F>
+static float time_us(F f, int iters) {
+  hipEvent_t e0, e1;
+  HC(hipEventCreate(&e0));
+  HC(hipEventCreate(&e1));
+  f();
+  f();
+  HC(hipDeviceSynchronize());
+  HC(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) f();
+  HC(hipEventRecord(e1, 0));
+  HC(hipEventSynchronize(e1));
+  float ms;
+  HC(hipEventElapsedTime(&ms, e0, e1));
+  HC(hipEventDestroy(e0));
+  HC(hipEventDestroy(e1));
+  return 1e3f * ms / iters;
+}
+
+int main(int argc, char** argv) {
+  const char* filter = nullptr;
+  int algo = TG_ALGO_MFMA, iters = 20, batch = 16, check = 1;
+  for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "--algo")) algo = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--iters")) iters = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--batch")) batch = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--nocheck")) check = 0;
+    else filter = argv[i];
+  }
+  std::vector<Case> cases = {
+      {"E256a", 256, 16, 16, 3},  {"E256b", 256, 16, 32, 3},  {"E128a", 128, 32, 32, 3},  {"E128b", 128, 32, 64, 3},
+      {"E64a", 64, 64, 64, 3},    {"E64b", 64, 64, 128, 3},   {"E32a", 32, 128, 128, 3},  {"E32b", 32, 128, 256, 3},
+      {"E16", 16, 256, 256, 3},   {"E8", 8, 256, 256, 3},     {"D4", 4, 264, 256, 3},     {"G4", 4, 256, 256, 3},
+      {"G8a", 8, 512, 256, 3},    {"G16a", 16, 512, 256, 3},  {"G32a", 32, 512, 128, 3},  {"G32b", 32, 128, 128, 3},
+      {"G64a", 64, 256, 64, 3},   {"G128a", 128, 128, 32, 3}, {"G256a", 256, 64, 16, 3},
+  };
+  printf("%-7s %-5s %4s %4s>%-4s | %9s %8s %8s %9s\n", "case", "op", "hw", "cin", "cout", "us", "GB/s", "TF/s", "relL2");
+  for (const Case& c : cases) {
+    if (filter && !strstr(c.name, filter)) continue;
+    const size_t px = (size_t)batch * c.hw * c.hw;
+    void* x = dev_bf16_random(px * c.cin, 1.0f);
+    void* gy = dev_bf16_random(px * c.cout, 1.0f);
+    float* w = dev_f32_random((size_t)c.k * c.k * c.cin * c.cout, sqrtf(2.0f / (c.k * c.k * c.cin)));
+    float* bias = dev_f32_random(c.cout, 0.1f);
+    void *y, *y2, *gx, *gx2;
+    HC(hipMalloc(&y, px * c.cout * 2));
+    HC(hipMalloc(&y2, px * c.cout * 2));
+    HC(hipMalloc(&gx, px * c.cin * 2));
+    HC(hipMalloc(&gx2, px * c.cin * 2));
+    const size_t nw = (size_t)c.k * c.k * c.cin * c.cout;
+    float *gw, *gw2;
+    HC(hipMalloc(&gw, nw * 4));
+    HC(hipMalloc(&gw2, nw * 4));
+    TgConvDesc d = mk(batch, c.hw, c.cin, c.cout, c.k, algo, TG_EPI_BIAS | TG_EPI_LRELU);
+    TgConvDesc d0 = d;
+    d0.epilogue = 0;
+    void *p0, *p1;
+    HC(hipMalloc(&p0, tg_conv2d_pack_elems(&d, 0) * 2 + 64));
+    HC(hipMalloc(&p1, tg_conv2d_pack_elems(&d, 1) * 2 + 64));
+    TC(tg_conv2d_pack_weights(&d, w, 0, p0, nullptr));
+    TC(tg_conv2d_pack_weights(&d, w, 1, p1, nullptr));
+    const size_t wsb = tg_conv2d_bwd_weight_workspace(&d);
+    void* ws = nullptr;
+    if (wsb) HC(hipMalloc(&ws, wsb));
+    // ---- correctness at batch nchk against the direct kernels
+    double e_f = -1, e_d = -1, e_w = -1;
+    if (check) {
+      const int nchk = batch < 2 ? batch : 2;
+      TgConvDesc dm = mk(nchk, c.hw, c.cin, c.cout, c.k, algo, TG_EPI_BIAS | TG_EPI_LRELU);
+      TgConvDesc dr = mk(nchk, c.hw, c.cin, c.cout, c.k, TG_ALGO_DIRECT, TG_EPI_BIAS | TG_EPI_LRELU);
+      const size_t pc = (size_t)nchk * c.hw * c.hw;
+      TC(tg_conv2d_fwd(&dm, x, p0, bias, y, nullptr));
+      TC(tg_conv2d_fwd(&dr, x, w, bias, y2, nullptr));
+      e_f = rel_l2_bf16(y, y2, pc * c.cout);
+      TC(tg_conv2d_bwd_data(&dm, gy, p1, gx, nullptr));
+      TC(tg_conv2d_bwd_data(&dr, gy, w, gx2, nullptr));
+      e_d = rel_l2_bf16(gx, gx2, pc * c.cin);
+      void* wsc = nullptr;
+      const size_t wc = tg_conv2d_bwd_weight_workspace(&dm);
+      if (wc) HC(hipMalloc(&wsc, wc));
+      TC(tg_conv2d_bwd_weight(&dm, x, gy, gw, 0, wsc, wc, nullptr));
+      TC(tg_conv2d_bwd_weight(&dr, x, gy, gw2, 0, nullptr, 0, nullptr));
+      e_w = rel_l2_f32(gw, gw2, nw);
+      if (wsc) HC(hipFree(wsc));
+    }
+    // ---- timing at the full batch
+    const double flops = 2.0 * px * c.cout * c.k * c.k * c.cin;
+    const double bytes = 2.0 * px * (c.cin + c.cout) + 2.0 * nw;
+    float t;
+    t = time_us([&] { TC(tg_conv2d_fwd(&d, x, p0, bias, y, nullptr)); }, iters);
+    printf("%-7s %-5s %4d %4d>%-4d | %9.1f %8.0f %8.1f %9.2e\n", c.name, "fwd", c.hw, c.cin, c.cout, t, bytes / t * 1e-3,
+           flops / t * 1e-6, e_f);
+    t = time_us([&] { TC(tg_conv2d_bwd_data(&d0, gy, p1, gx, nullptr)); }, iters);
+    printf("%-7s %-5s %4d %4d>%-4d | %9.1f %8.0f %8.1f %9.2e\n", c.name, "dgrad", c.hw, c.cin, c.cout, t, bytes / t * 1e-3,
+           flops / t * 1e-6, e_d);
+    t = time_us([&] { TC(tg_conv2d_bwd_weight(&d0, x, gy, gw, 0, ws, wsb, nullptr)); }, iters);
+    printf("%-7s %-5s %4d %4d>%-4d | %9.1f %8.0f %8.1f %9.2e\n", c.name, "wgrad", c.hw, c.cin, c.cout, t, bytes / t * 1e-3,
+           flops / t * 1e-6, e_w);
+    fflush(stdout);
+    HC(hipFree(x)); HC(hipFree(gy)); HC(hipFree(w)); HC(hipFree(bias)); HC(hipFree(y)); HC(hipFree(y2));
+    HC(hipFree(gx)); HC(hipFree(gx2)); HC(hipFree(gw)); HC(hipFree(gw2)); HC(hipFree(p0)); HC(hipFree(p1));
+    if (ws) HC(hipFree(ws));
+  }
+  return 0;
+}

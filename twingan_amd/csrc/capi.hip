@@ -30,7 +30,8 @@ static int check_desc(const char* who, const TgConvDesc* d) {
   TG_CHECK(pb >= 0 && pb < d->kh && pr >= 0 && pr < d->kw, TG_EINVAL, "%s: output size %dx%d inconsistent with input", who,
            d->hout, d->wout);
   TG_CHECK(d->dtype == TG_F32 || d->dtype == TG_BF16, TG_EINVAL, "%s: dtype %d", who, d->dtype);
-  TG_CHECK(d->algo == TG_ALGO_DIRECT || d->algo == TG_ALGO_MFMA, TG_EINVAL, "%s: algo %d", who, d->algo);
+  TG_CHECK(d->algo == TG_ALGO_DIRECT || d->algo == TG_ALGO_MFMA || d->algo == TG_ALGO_MFMA_V1, TG_EINVAL, "%s: algo %d", who,
+           d->algo);
   return TG_OK;
 }
 
@@ -44,7 +45,7 @@ int tg_conv2d_fwd(const TgConvDesc* d, const void* x, const void* w, const float
   if (rc) return rc;
   TG_CHECK(x && w && y, TG_EINVAL, "tg_conv2d_fwd: null pointer");
   TG_CHECK(tg_aligned16(x) && tg_aligned16(w) && tg_aligned16(y), TG_EALIGN, "tg_conv2d_fwd: pointers must be 16 B aligned");
-  if (d->algo == TG_ALGO_MFMA) return tg_conv2d_fwd_mfma(d, x, w, bias, y, (hipStream_t)stream);
+  if (d->algo != TG_ALGO_DIRECT) return tg_conv2d_fwd_mfma(d, x, w, bias, y, (hipStream_t)stream);
   return tg_conv2d_fwd_direct(d, x, w, bias, y, (hipStream_t)stream);
 }
 
@@ -54,12 +55,12 @@ int tg_conv2d_bwd_data(const TgConvDesc* d, const void* gy, const void* w, void*
   TG_CHECK(gy && w && gx, TG_EINVAL, "tg_conv2d_bwd_data: null pointer");
   TG_CHECK(tg_aligned16(gy) && tg_aligned16(w) && tg_aligned16(gx), TG_EALIGN,
            "tg_conv2d_bwd_data: pointers must be 16 B aligned");
-  if (d->algo == TG_ALGO_MFMA) return tg_conv2d_bwd_data_mfma(d, gy, w, gx, (hipStream_t)stream);
+  if (d->algo != TG_ALGO_DIRECT) return tg_conv2d_bwd_data_mfma(d, gy, w, gx, (hipStream_t)stream);
   return tg_conv2d_bwd_data_direct(d, gy, w, gx, (hipStream_t)stream);
 }
 
 size_t tg_conv2d_bwd_weight_workspace(const TgConvDesc* d) {
-  if (!d || d->algo != TG_ALGO_MFMA) return 0;
+  if (!d || d->algo == TG_ALGO_DIRECT) return 0;
   return tg_conv2d_bwd_weight_workspace_mfma(d);
 }
 
@@ -69,7 +70,7 @@ int tg_conv2d_bwd_weight(const TgConvDesc* d, const void* x, const void* gy, flo
   if (rc) return rc;
   TG_CHECK(x && gy && gw, TG_EINVAL, "tg_conv2d_bwd_weight: null pointer");
   TG_CHECK(tg_aligned16(x) && tg_aligned16(gy), TG_EALIGN, "tg_conv2d_bwd_weight: pointers must be 16 B aligned");
-  if (d->algo == TG_ALGO_MFMA) return tg_conv2d_bwd_weight_mfma(d, x, gy, gw, accumulate, ws, ws_bytes, (hipStream_t)stream);
+  if (d->algo != TG_ALGO_DIRECT) return tg_conv2d_bwd_weight_mfma(d, x, gy, gw, accumulate, ws, ws_bytes, (hipStream_t)stream);
   return tg_conv2d_bwd_weight_direct(d, x, gy, gw, accumulate, (hipStream_t)stream);
 }
 

@@ -1,0 +1,290 @@
+// conv_tile: implicit-GEMM stride-1 SAME convolution (3x3 or 1x1) for feature maps of 16x16 and
+// up, bf16 NHWC, fp32 accumulate on v_mfma_f32_32x32x16_bf16.  Forward and backward-data (the
+// latter = this kernel over gy with the 180-degree rotated, transposed weight pack).
+//
+// Why a second kernel next to conv_mfma.hip: the first MFMA kernel spends ~1500 of its ~1650
+// instructions per 128-pixel tile on runtime div/mod address arithmetic and is VALU-bound at
+// 2 TB/s on the thin 128x128 / 256x256 layers.  Here every tile dimension is a compile-time
+// constant, so halo / tap offsets fold into instruction immediates:
+//
+//   workgroup = 4 waves, output tile = (8*MT) rows x 16 cols of ONE image (MT = 1 or 2);
+//   wave w owns MT sub-tiles of 2 rows x 16 cols = 32 pixels = the N dimension of one MFMA;
+//   A operand = weights (32 output channels = M), B operand = pixels, so a lane's accumulator
+//   holds 4 consecutive output channels of its pixel per register quad; lanes l and l+32 swap
+//   quads (v_permlane32_swap) to own 16 consecutive channels -> 16-byte NHWC stores;
+//   input halo tile [(8*MT+2)][18][KC] and weight tile [BN][taps*KC] live in LDS, both with one
+//   16-byte pad per row so 16-byte fragment reads spread over all banks;
+//   the next K chunk's global loads are issued before the current chunk's MFMAs (register
+//   prefetch), written to LDS after them.
+//
+// Reference call sites replaced: tf.contrib.layers.conv2d at nets/pggan_utils.py:316-320 (every
+// E/G/D conv of nets/pggan.py at 16x16 and above) and its Conv2DBackpropInput gradient.
+#include "tg_common.h"
+
+namespace {
+
+struct TileGeom {
+  int n, h, w, cin, cout;      // SAME conv: input and output are both [n,h,w,*]
+  int cin_pad;                 // channels per tap in the weight pack (multiple of 16)
+  int pad;                     // low-side zero padding (forward: (k-1)/2; backward-data: k-1-(k-1)/2)
+  int tiles_x, tiles_y;        // tiles per image row / column
+  int nblk;                    // tiles_x * tiles_y * n
+  int epilogue;
+  float alpha;
+};
+
+extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+// Buffer resources: out-of-range offsets read as zero / drop the store, so image borders, unused
+// staging slots and partial channel blocks need no exec-mask branches (offset OOB = "masked off").
+constexpr unsigned OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ bf16x8 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  bf16x2 v;
+  v[0] = (bf16)lo;
+  v[1] = (bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+
+template <int KH, int KC, int BN, int MT>
+__global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
+                                                        const float* __restrict__ bias, bf16* __restrict__ y,
+                                                        const TileGeom g) {
+  constexpr int KW = KH, NT = KH * KW;
+  constexpr int TW = 16, TH = 8 * MT;
+  constexpr int HWX = TW + KW - 1, HH = TH + KH - 1;
+  constexpr int VPP = KC / 8;                       // 16-byte vectors per pixel per chunk
+  constexpr int PS_A = KC * 2 + 16;                 // LDS bytes per halo pixel
+  constexpr int RS_B = NT * KC * 2 + 16;            // LDS bytes per weight row
+  constexpr int AVEC = HH * HWX * VPP;              // halo vectors per chunk
+  constexpr int ASLOTS = (AVEC + 255) / 256;
+  constexpr int BVEC = BN * NT * VPP;
+  constexpr int BSLOTS = (BVEC + 255) / 256;
+  constexpr int NTILE = BN / 32;
+  constexpr int A_BYTES = (HH * HWX * PS_A + 15) & ~15;
+
+  unsigned char* sA = tile_smem;
+  unsigned char* sB = tile_smem + A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+
+  // ---- XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous tile range
+  int t = blockIdx.x;
+  if ((g.nblk & 7) == 0) t = (t & 7) * (g.nblk >> 3) + (t >> 3);
+  const int tx = t % g.tiles_x;
+  t /= g.tiles_x;
+  const int ty = t % g.tiles_y;
+  const int img = t / g.tiles_y;
+  const int ox0 = tx * TW, oy0 = ty * TH;
+  const int n0 = blockIdx.y * BN;
+  const size_t img_elems = (size_t)g.h * g.w * g.cin;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (size_t)img * img_elems, (unsigned)(img_elems * 2));
+  const int wrow = NT * g.cin_pad;
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(wp + (size_t)n0 * wrow, (unsigned)((size_t)BN * wrow * 2));
+
+  // ---- per-thread staging slots (compile-time trip counts, constant divisors); byte offsets
+  unsigned a_goff[ASLOTS];     // inside the image at chunk 0, or OOB (zero fill: border / unused slot)
+  int a_loff[ASLOTS];
+#pragma unroll
+  for (int s = 0; s < ASLOTS; ++s) {
+    const int v = tid + s * 256;
+    const int px = v / VPP, part = v % VPP;
+    const int hy = px / HWX, hx = px % HWX;
+    const int iy = oy0 + hy - g.pad, ix = ox0 + hx - g.pad;
+    a_loff[s] = px * PS_A + part * 16;
+    const bool ok = (v < AVEC) && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
+    a_goff[s] = ok ? (unsigned)(((iy * g.w + ix) * g.cin + part * 8) * 2) : OOB;
+  }
+  unsigned b_goff[BSLOTS];
+  int b_loff[BSLOTS];
+#pragma unroll
+  for (int s = 0; s < BSLOTS; ++s) {
+    const int v = tid + s * 256;
+    const int row = v / (NT * VPP), rem = v % (NT * VPP);
+    const int tap = rem / VPP, part = rem % VPP;
+    b_goff[s] = (v < BVEC) ? (unsigned)((row * wrow + tap * g.cin_pad + part * 8) * 2) : OOB;
+    b_loff[s] = row * RS_B + (tap * KC + part * 8) * 2;
+  }
+
+  // ---- this lane's operand addresses
+  const int kgrp = lane >> 5, l31 = lane & 31;
+  // B operand (pixels): sub-tile mt of wave wid = rows (wid*MT + mt)*2 + (l31 >> 4), col l31 & 15
+  const int a_base = (((wid * MT) * 2 + (l31 >> 4)) * HWX + (l31 & 15)) * PS_A + kgrp * 16;
+  const int b_base = l31 * RS_B + kgrp * 16;
+
+  f32x16 acc[MT][NTILE];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int i = 0; i < NTILE; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[m][i][j] = 0.f;
+
+  // NOTE: a cin that is not a multiple of 16 (the 264-channel minibatch-stddev tensor) makes the last
+  // chunk read 8 channels of the NEXT pixel; the weight pack is zero there, so they contribute 0.
+  bf16x8 ra[ASLOTS], rb[BSLOTS];
+  auto load_chunk = [&](int c0) {
+#pragma unroll
+    for (int s = 0; s < ASLOTS; ++s) ra[s] = buf_load16(rx, a_goff[s] + (unsigned)(c0 * 2));
+#pragma unroll
+    for (int s = 0; s < BSLOTS; ++s) rb[s] = buf_load16(rw, b_goff[s] + (unsigned)(c0 * 2));
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int s = 0; s < ASLOTS; ++s)
+      if (s < ASLOTS - 1 || tid + s * 256 < AVEC) *reinterpret_cast<bf16x8*>(sA + a_loff[s]) = ra[s];
+#pragma unroll
+    for (int s = 0; s < BSLOTS; ++s)
+      if (s < BSLOTS - 1 || tid + s * 256 < BVEC) *reinterpret_cast<bf16x8*>(sB + b_loff[s]) = rb[s];
+  };
+
+  load_chunk(0);
+  for (int c0 = 0; c0 < g.cin_pad; c0 += KC) {
+    if (c0) __syncthreads();             // everyone is done reading the previous chunk
+    store_chunk();
+    __syncthreads();
+    if (c0 + KC < g.cin_pad) load_chunk(c0 + KC);     // in flight during the MFMAs below
+#pragma unroll
+    for (int ky = 0; ky < KH; ++ky) {
+#pragma unroll
+      for (int kx = 0; kx < KW; ++kx) {
+#pragma unroll
+        for (int kk = 0; kk < KC / 16; ++kk) {
+          bf16x8 xf[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            xf[m] = *reinterpret_cast<const bf16x8*>(sA + a_base + ((m * 2 + ky) * HWX + kx) * PS_A + kk * 32);
+#pragma unroll
+          for (int nt = 0; nt < NTILE; ++nt) {
+            const bf16x8 wf =
+                *reinterpret_cast<const bf16x8*>(sB + b_base + nt * 32 * RS_B + ((ky * KW + kx) * KC + kk * 16) * 2);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[m], acc[m][nt], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue.  acc[m][nt][4q + j] = channel n0 + nt*32 + 8q + 4*kgrp + j of this lane's pixel.
+  // After the half-wave swap the low lane (kgrp 0) owns channels [0,16) of the 32-block, the high lane
+  // [16,32), each as two 16-byte vectors.
+  const size_t out_img = (size_t)g.h * g.w * g.cout;
+  const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + (size_t)img * out_img, (unsigned)(out_img * 2));
+  const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, (g.epilogue & TG_EPI_BIAS) ? (unsigned)(g.cout * 4) : 0u);
+#pragma unroll
+  for (int nt = 0; nt < NTILE; ++nt) {
+    f32x4 bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)      // OOB (channel >= cout, or no bias) reads 0
+      bq[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                             rbias, (unsigned)((n0 + nt * 32 + q * 8 + kgrp * 4) * 4), 0, 0));
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int oy = oy0 + (wid * MT + m) * 2 + (l31 >> 4), ox = ox0 + (l31 & 15);
+      unsigned p[4][2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float a = acc[m][nt][q * 4 + j] + bq[q][j];
+          if (g.epilogue & TG_EPI_LRELU) a = lrelu_f(a, g.alpha);
+          v[j] = a;
+        }
+        p[q][0] = pack_bf16x2(v[0], v[1]);
+        p[q][1] = pack_bf16x2(v[2], v[3]);
+      }
+      // swap: (p[0], p[2]) and (p[1], p[3]); vdst[hi half] <-> src[lo half]
+      u32x4 o0, o1;
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        auto r02 = __builtin_amdgcn_permlane32_swap(p[0][d], p[2][d], false, false);
+        auto r13 = __builtin_amdgcn_permlane32_swap(p[1][d], p[3][d], false, false);
+        // low lane: r02 = (own q0 [ch 0-3], partner q0 [ch 4-7]); high lane: (partner q2 [16-19], own q2 [20-23])
+        o0[d] = r02[0];
+        o0[2 + d] = r02[1];
+        o1[d] = r13[0];
+        o1[2 + d] = r13[1];
+      }
+      const int ch0 = n0 + nt * 32 + kgrp * 16;
+      const unsigned off = (unsigned)(((oy * g.w + ox) * g.cout + ch0) * 2);
+      __builtin_amdgcn_raw_buffer_store_b128(o0, ry, (ch0 + 8 <= g.cout) ? off : OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(o1, ry, (ch0 + 16 <= g.cout) ? off + 16 : OOB, 0, 0);
+    }
+  }
+}
+
+template <int KH, int KC, int BN, int MT>
+int launch_tile(const TileGeom& g0, const bf16* x, const bf16* wp, const float* bias, bf16* y, hipStream_t s) {
+  TileGeom g = g0;
+  constexpr int TH = 8 * MT, HWX = 16 + KH - 1, HH = TH + KH - 1;
+  g.tiles_x = g.w / 16;
+  g.tiles_y = g.h / TH;
+  g.nblk = g.tiles_x * g.tiles_y * g.n;
+  const size_t lds = (size_t)((HH * HWX * (KC * 2 + 16) + 15) & ~15) + (size_t)BN * (KH * KH * KC * 2 + 16);
+  TG_CHECK(lds <= 160 * 1024, TG_ENOSUP, "conv_tile: LDS %zu too large", lds);
+  auto kern = conv_tile_kernel<KH, KC, BN, MT>;
+  if (lds > 64 * 1024) {
+    static bool raised = false;      // per instantiation
+    if (!raised) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+          hipSuccess) {
+        tg_set_error("conv_tile: cannot raise dynamic LDS to %zu", lds);
+        return TG_ELAUNCH;
+      }
+      raised = true;
+    }
+  }
+  dim3 grid(g.nblk, (g.cout + BN - 1) / BN);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, wp, bias, y, g);
+  TG_LAUNCH_CHECK("conv_tile");
+  return TG_OK;
+}
+
+template <int KH>
+int dispatch_tile(const TileGeom& g, const bf16* x, const bf16* wp, const float* bias, bf16* y, hipStream_t s) {
+  const bool wide = g.cout > 32;
+  const int tiles1 = (g.w / 16) * (g.h / 8) * g.n * ((g.cout + (wide ? 63 : 31)) / (wide ? 64 : 32));
+  // two sub-tiles per wave (256-pixel workgroup tile) halve the weight staging per pixel; use them
+  // when that still leaves >= 2 workgroups per CU and the map is tall enough
+  const bool mt2 = (g.h % 16 == 0) && tiles1 >= 2 * 2 * 256 && g.cin_pad >= 64;
+  if (g.cin_pad % 32 == 0) {
+    if (wide) return mt2 ? launch_tile<KH, 32, 64, 2>(g, x, wp, bias, y, s) : launch_tile<KH, 32, 64, 1>(g, x, wp, bias, y, s);
+    return mt2 ? launch_tile<KH, 32, 32, 2>(g, x, wp, bias, y, s) : launch_tile<KH, 32, 32, 1>(g, x, wp, bias, y, s);
+  }
+  if (wide) return launch_tile<KH, 16, 64, 1>(g, x, wp, bias, y, s);
+  return launch_tile<KH, 16, 32, 1>(g, x, wp, bias, y, s);
+}
+
+}  // namespace
+
+// Shapes this kernel takes: square-kernel 1x1 / 3x3, stride 1, SAME, h % 8 == 0, w % 16 == 0.
+bool tg_conv_tile_supported(int h, int w, int hout, int wout, int kh, int kw, int pad_t, int pad_l) {
+  if (kh != kw || (kh != 1 && kh != 3)) return false;
+  if (h != hout || w != wout) return false;
+  if (pad_t != pad_l) return false;
+  return (h % 8 == 0) && (w % 16 == 0);
+}
+
+int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int epilogue, float alpha, const void* x,
+                     const void* wp, const float* bias, void* y, hipStream_t s) {
+  TileGeom g;
+  g.n = n; g.h = h; g.w = w; g.cin = cin; g.cout = cout;
+  g.cin_pad = (cin + 15) / 16 * 16;
+  g.pad = pad;
+  g.tiles_x = g.tiles_y = g.nblk = 0;
+  g.epilogue = epilogue;
+  g.alpha = alpha;
+  if (k == 1) return dispatch_tile<1>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
+  return dispatch_tile<3>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
+}
