@@ -520,9 +520,20 @@ static void wgrad_split(const Geom& g, int* n_ci, int* n_co, int* nslices, int* 
   *nslices = (*total_tiles + *tiles_per_block - 1) / *tiles_per_block;
 }
 
+bool tg_wgrad_tile_supported(int h, int w, int hout, int wout, int kh, int kw, int pad_t, int pad_l);
+size_t tg_wgrad_tile_workspace(int n, int h, int w, int cin, int cout);
+int tg_wgrad_tile_run(int n, int h, int w, int cin, int cout, const void* x, const void* gy, float* gw, int accumulate,
+                      void* ws, size_t ws_bytes, hipStream_t s);
+
+static bool use_wgrad_tile(const TgConvDesc* d) {
+  return d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 &&
+         tg_wgrad_tile_supported(d->hin, d->win, d->hout, d->wout, d->kh, d->kw, d->pad_t, d->pad_l);
+}
+
 size_t tg_conv2d_bwd_weight_workspace_mfma(const TgConvDesc* d0) {
   TgConvDesc dd;
   const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
+  if (use_wgrad_tile(d)) return tg_wgrad_tile_workspace(d->n, d->hin, d->win, d->cin, d->cout);
   Geom g;
   if (fill_geom("tg_conv2d_bwd_weight", d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->kw, d->pad_t,
                 d->pad_l, &g))
@@ -537,6 +548,7 @@ int tg_conv2d_bwd_weight_mfma(const TgConvDesc* d0, const void* x, const void* g
   TgConvDesc dd;
   const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
   TG_CHECK(d->dtype == TG_BF16, TG_ENOSUP, "tg_conv2d_bwd_weight(mfma): bf16 activations only");
+  if (use_wgrad_tile(d)) return tg_wgrad_tile_run(d->n, d->hin, d->win, d->cin, d->cout, x, gy, gw, accumulate, ws, ws_bytes, s);
   Geom g;
   int rc = fill_geom("tg_conv2d_bwd_weight", d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->kw,
                      d->pad_t, d->pad_l, &g);

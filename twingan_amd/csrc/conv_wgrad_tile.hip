@@ -1,0 +1,252 @@
+// conv_wgrad_tile: 3x3 SAME backward-weight for feature maps of 16x16 and up, bf16 NHWC inputs,
+// fp32 HWIO output.   gw[tap][ci][co] = sum over pixels of x[pix + tap][ci] * gy[pix][co]
+//
+// The reduction (K) dimension of this GEMM is the PIXEL axis, while both operands are stored
+// channel-contiguous (NHWC): every MFMA fragment needs 8 consecutive pixels of one channel.  gfx950's
+// LDS transpose read does exactly that: ds_read_b64_tr_b16 takes, per 16-lane group, sixteen 8-byte
+// row addresses R[s][0..3] and returns to lane i the column R[(i>>2)+4j][i&3], j = 0..3 (measured with
+// tools/probes/ds_read_tr.hip).  With lane s pointing at (pixel p0 + (s>>2), channels c0 + 4*(s&3)..)
+// lane i receives channel c0+i of pixels p0..p0+3: two reads build one v_mfma_f32_32x32x16_bf16
+// operand (8 pixels x 32 channels per half-wave) with no VALU work and no bank conflicts (a half-wave
+// reads 4 consecutive 64-byte pixels = all 64 banks once).
+//
+//   workgroup = 4 waves; owns one (32 ci x 32 co) block of the weight and a contiguous range of
+//   (8 rows x 16 cols) pixel tiles; per tile the x halo [10][18][32 ch] and gy [8][16][32 ch] are
+//   staged in LDS (64 B per pixel, dense); wave w reduces rows 2w, 2w+1 (two 16-pixel K steps) into
+//   9 per-tap 32x32 fp32 accumulators; the next tile's global loads are in flight during the MFMAs.
+//   At the end the 4 waves are summed through LDS and the valid [cin x cout] part is written to this
+//   workgroup's fp32 slab; conv_wgrad_tile_reduce sums the slabs into gw.
+//
+// Reference call site replaced: the Conv2DBackpropFilter gradient of tf.contrib.layers.conv2d
+// (nets/pggan_utils.py:316-320).
+#include "tg_common.h"
+
+namespace {
+
+struct WgGeom {
+  int n, h, w, cin, cout;
+  int tiles_x, tiles_y, total_tiles;
+  int n_co_blk;                 // number of 32-wide co blocks (blockIdx.y = ci_blk * n_co_blk + co_blk)
+  int tiles_per_wg;
+};
+
+extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+constexpr unsigned WOOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// 8 consecutive pixels (stride 64 B) of this lane's channel: two transpose reads
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * 64));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gy,
+                                                              float* __restrict__ slab, const WgGeom g) {
+  constexpr int TW = 16, TH = 8, HWX = 18, HH = 10, NT = 9;
+  constexpr int PS = 64;                            // LDS bytes per pixel (32 channels, dense)
+  constexpr int XVEC = HH * HWX * 4, XSLOTS = (XVEC + 255) / 256;      // 720 -> 3
+  constexpr int GSLOTS = (TH * TW * 4) / 256;                          // 512 -> 2
+  constexpr int X_BYTES = HH * HWX * PS;                               // 11520
+  constexpr int G_BYTES = TH * TW * PS;                                // 8192
+
+  unsigned char* sX = wg_smem;
+  unsigned char* sG = wg_smem + X_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int ci_blk = blockIdx.y / g.n_co_blk, co_blk = blockIdx.y - ci_blk * g.n_co_blk;
+  const int ci0 = ci_blk * 32, co0 = co_blk * 32;
+
+  // ---- staging slots: tile-independent LDS offsets and intra-tile pixel coordinates
+  int x_loff[XSLOTS], x_hy[XSLOTS], x_hx[XSLOTS], x_ch[XSLOTS];
+#pragma unroll
+  for (int s = 0; s < XSLOTS; ++s) {
+    const int v = tid + s * 256;
+    const int px = v >> 2, part = v & 3;
+    x_hy[s] = px / HWX;
+    x_hx[s] = px % HWX;
+    x_ch[s] = (v < XVEC && ci0 + part * 8 + 8 <= g.cin) ? (ci0 + part * 8) : -1;     // -1: zero fill
+    x_loff[s] = px * PS + part * 16;
+  }
+  int g_loff[GSLOTS], g_py[GSLOTS], g_px[GSLOTS], g_ch[GSLOTS];
+#pragma unroll
+  for (int s = 0; s < GSLOTS; ++s) {
+    const int v = tid + s * 256;
+    const int px = v >> 2, part = v & 3;
+    g_py[s] = px >> 4;
+    g_px[s] = px & 15;
+    g_ch[s] = (co0 + part * 8 + 8 <= g.cout) ? (co0 + part * 8) : -1;
+    g_loff[s] = px * PS + part * 16;
+  }
+
+  // ---- fragment addresses.  16-lane group gq = lane >> 4: channel half c0 = 16*(gq & 1), K half
+  // kg = gq >> 1 (pixels kg*8 .. kg*8+7 of the 16-pixel K step); lane t = lane & 15 points at
+  // pixel +(t >> 2), channels c0 + 4*(t & 3).
+  const int gq = lane >> 4, t16 = lane & 15;
+  const int frag_off = ((gq >> 1) * 8 + (t16 >> 2)) * PS + ((gq & 1) * 16 + (t16 & 3) * 4) * 2;
+  // wave wid reduces tile rows 2*wid (K step 0) and 2*wid + 1 (K step 1)
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+  const size_t ximg = (size_t)g.h * g.w * g.cin, gimg = (size_t)g.h * g.w * g.cout;
+  const int tile_begin = blockIdx.x * g.tiles_per_wg;
+  int tile_end = tile_begin + g.tiles_per_wg;
+  if (tile_end > g.total_tiles) tile_end = g.total_tiles;
+
+  bf16x8 rx[XSLOTS], rg[GSLOTS];
+  auto load_tile = [&](int tile) {
+    int t = tile;
+    const int tx = t % g.tiles_x;
+    t /= g.tiles_x;
+    const int ty = t % g.tiles_y;
+    const int img = t / g.tiles_y;
+    const int ox0 = tx * TW, oy0 = ty * TH;
+    const __amdgpu_buffer_rsrc_t bx = wg_rsrc(x + (size_t)img * ximg, (unsigned)(ximg * 2));
+    const __amdgpu_buffer_rsrc_t bg = wg_rsrc(gy + (size_t)img * gimg, (unsigned)(gimg * 2));
+#pragma unroll
+    for (int s = 0; s < XSLOTS; ++s) {
+      const int iy = oy0 + x_hy[s] - 1, ix = ox0 + x_hx[s] - 1;
+      const bool ok = x_ch[s] >= 0 && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
+      const unsigned off = ok ? (unsigned)(((iy * g.w + ix) * g.cin + x_ch[s]) * 2) : WOOB;
+      rx[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bx, off, 0, 0));
+    }
+#pragma unroll
+    for (int s = 0; s < GSLOTS; ++s) {
+      const unsigned off =
+          g_ch[s] >= 0 ? (unsigned)((((oy0 + g_py[s]) * g.w + ox0 + g_px[s]) * g.cout + g_ch[s]) * 2) : WOOB;
+      rg[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bg, off, 0, 0));
+    }
+  };
+
+  if (tile_begin < tile_end) load_tile(tile_begin);
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    if (tile != tile_begin) __syncthreads();          // all fragment reads of the previous tile are done
+#pragma unroll
+    for (int s = 0; s < XSLOTS; ++s)
+      if (s < XSLOTS - 1 || tid + s * 256 < XVEC) *reinterpret_cast<bf16x8*>(sX + x_loff[s]) = rx[s];
+#pragma unroll
+    for (int s = 0; s < GSLOTS; ++s) *reinterpret_cast<bf16x8*>(sG + g_loff[s]) = rg[s];
+    __syncthreads();
+    if (tile + 1 < tile_end) load_tile(tile + 1);     // in flight during the MFMAs
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int row = wid * 2 + ks;
+      const bf16x8 gf = tr_frag(sG + (row * TW) * PS + frag_off);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const bf16x8 xf = tr_frag(sX + ((row + ky) * HWX + kx) * PS + frag_off);
+          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, gf, acc[ky * 3 + kx], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- cross-wave reduction through LDS, one tap at a time; write the valid part of the slab.
+  // acc[tap][r]: ci = ci0 + (r & 3) + 8*(r >> 2) + 4*(lane >> 5), co = co0 + (lane & 31)
+  float* red = reinterpret_cast<float*>(wg_smem);    // [4 waves][16 regs][64 lanes] = 16 KiB
+  float* out = slab + (size_t)blockIdx.x * NT * g.cin * g.cout;
+#pragma unroll
+  for (int tap = 0; tap < NT; ++tap) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wid * 16 + r) * 64 + lane] = acc[tap][r];
+    __syncthreads();
+    const int l2 = tid & 63, rq = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = rq * 4 + j;
+      const float sum = red[(0 * 16 + r) * 64 + l2] + red[(1 * 16 + r) * 64 + l2] + red[(2 * 16 + r) * 64 + l2] +
+                        red[(3 * 16 + r) * 64 + l2];
+      const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * (l2 >> 5);
+      const int co = co0 + (l2 & 31);
+      if (ci < g.cin && co < g.cout) out[((size_t)tap * g.cin + ci) * g.cout + co] = sum;
+    }
+  }
+}
+
+// gw[i] (+)= sum over slices; grid.y slice groups, one fp32 atomic per element per group (gw pre-zeroed
+// unless accumulating)
+__global__ void conv_wgrad_tile_reduce(const float* __restrict__ slab, float* __restrict__ gw, int64_t nw, int nslices) {
+  const int per = (nslices + gridDim.y - 1) / gridDim.y;
+  const int k0 = blockIdx.y * per;
+  const int k1 = min(nslices, k0 + per);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (int64_t)gridDim.x * blockDim.x) {
+    float s0 = 0.f, s1 = 0.f;
+    int k = k0;
+    for (; k + 1 < k1; k += 2) {
+      s0 += slab[(size_t)k * nw + i];
+      s1 += slab[(size_t)(k + 1) * nw + i];
+    }
+    if (k < k1) s0 += slab[(size_t)k * nw + i];
+    if (k1 > k0) atomicAdd(gw + i, s0 + s1);
+  }
+}
+
+void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices) {
+  g->n = n; g->h = h; g->w = w; g->cin = cin; g->cout = cout;
+  g->tiles_x = w / 16;
+  g->tiles_y = h / 8;
+  g->total_tiles = g->tiles_x * g->tiles_y * n;
+  const int n_ci = (cin + 31) / 32;
+  g->n_co_blk = (cout + 31) / 32;
+  int want = 512 / (n_ci * g->n_co_blk);      // ~2 workgroups per CU in total
+  if (want < 1) want = 1;
+  if (want > g->total_tiles) want = g->total_tiles;
+  g->tiles_per_wg = (g->total_tiles + want - 1) / want;
+  *nslices = (g->total_tiles + g->tiles_per_wg - 1) / g->tiles_per_wg;
+}
+
+}  // namespace
+
+bool tg_wgrad_tile_supported(int h, int w, int hout, int wout, int kh, int kw, int pad_t, int pad_l) {
+  return kh == 3 && kw == 3 && pad_t == 1 && pad_l == 1 && h == hout && w == wout && (h % 8 == 0) && (w % 16 == 0);
+}
+
+size_t tg_wgrad_tile_workspace(int n, int h, int w, int cin, int cout) {
+  WgGeom g;
+  int nslices;
+  wg_split(n, h, w, cin, cout, &g, &nslices);
+  return (size_t)nslices * 9 * cin * cout * sizeof(float);
+}
+
+int tg_wgrad_tile_run(int n, int h, int w, int cin, int cout, const void* x, const void* gy, float* gw, int accumulate,
+                      void* ws, size_t ws_bytes, hipStream_t s) {
+  WgGeom g;
+  int nslices;
+  wg_split(n, h, w, cin, cout, &g, &nslices);
+  const int64_t nw = (int64_t)9 * cin * cout;
+  TG_CHECK(ws && ws_bytes >= (size_t)nslices * nw * sizeof(float), TG_EINVAL,
+           "tg_conv2d_bwd_weight(tile): workspace too small (%zu < %zu)", ws_bytes, (size_t)nslices * nw * sizeof(float));
+  const int n_ci = (cin + 31) / 32;
+  const size_t lds = 10 * 18 * 64 + 8 * 16 * 64;      // 19712 >= the 16 KiB reduction scratch
+  hipLaunchKernelGGL(conv_wgrad_tile_kernel, dim3(nslices, n_ci * g.n_co_blk), dim3(256), lds, s, (const bf16*)x,
+                     (const bf16*)gy, (float*)ws, g);
+  TG_LAUNCH_CHECK("conv_wgrad_tile");
+  if (!accumulate && hipMemsetAsync(gw, 0, (size_t)nw * sizeof(float), s) != hipSuccess) {
+    tg_set_error("tg_conv2d_bwd_weight(tile): memset failed");
+    return TG_ELAUNCH;
+  }
+  const int gx = tg_grid_for(nw, 256);
+  int gy_ = (1024 + gx - 1) / gx;
+  if (gy_ > nslices) gy_ = nslices;
+  if (gy_ < 1) gy_ = 1;
+  hipLaunchKernelGGL(conv_wgrad_tile_reduce, dim3(gx, gy_), dim3(256), 0, s, (const float*)ws, gw, nw, nslices);
+  TG_LAUNCH_CHECK("conv_wgrad_tile_reduce");
+  return TG_OK;
+}
