@@ -138,7 +138,11 @@ def test_gpu_model_hits_golden(name, precision):
   with torch.no_grad():
     o = T.forward_generators(tr.P, s, t, cfg)
   for k in ('es', 's_prime', 't_prime', 's_cycle', 't_cycle'):
-    assert rel_l2(o[k].float().cpu().numpy(), g['fwd/' + k]) < otol, k
+    # bf16 at 8 channels: the fp64 oracle with bf16 storage rounding (tools/bf16_sensitivity.py) predicts rel-L2
+    # 0.038 for the encoder output and 0.12-0.20 for the generator outputs (instance-normalised to_rgb); the
+    # kernels measure 0.039 / 0.18.  Tight bf16 bounds live in the per-primitive tests.
+    tol = otol if precision == 'fp32' else (0.06 if k == 'es' else 0.3)
+    assert rel_l2(o[k].float().cpu().numpy(), g['fwd/' + k]) < tol, k
   for group, fn, args in (('g', T.generator_loss, (s, t, cfg)), ('d', T.discriminator_loss, (s, t, cfg, a_s, a_t))):
     tr.store.zero_grad(group)
     tr._set_requires_grad(g=group == 'g', d=group == 'd')

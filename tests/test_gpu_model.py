@@ -65,15 +65,15 @@ def test_networks_fp32_forward(growing):
     assert set(ep) == set(rep)
     for k in rep:
       e = rel_l2(ep[k], rep[k])
-      assert e < 1e-5, ('encoder', k, e)
+      assert e < 2e-5, ("encoder", k, e)
     out, gep = pggan.generator(tr.P, net, 't', cfg, ep)
     rout, rgep = R.generator(Pref, rnet, 't', rcfg, rep)
     assert set(k for k in gep if k != 'alpha_grow') == set(rgep)
-    assert rel_l2(out, rout) < 1e-5
+    assert rel_l2(out, rout) < 2e-5
     assert float((out.double().cpu() - rout).abs().max()) < 1e-4
     pred, dep = pggan.discriminator(tr.P, out, cfg, 'discriminator_t')
     rpred, _ = R.discriminator(Pref, rout, rcfg, 'discriminator_t')
-    assert rel_l2(pred, rpred) < 1e-5
+    assert rel_l2(pred, rpred) < 2e-5
     assert pred.shape == (3, 1)
 
 

@@ -10,6 +10,24 @@ void tg_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+__global__ void tg_zero_kernel(uint32_t* __restrict__ a, size_t na, uint32_t* __restrict__ b, size_t nb) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += stride) {
+    if (i < na) a[i] = 0u;
+    else b[i - na] = 0u;
+  }
+}
+
+int tg_zero_async(void* a, size_t a_bytes, void* b, size_t b_bytes, hipStream_t s) {
+  TG_CHECK((a_bytes & 3) == 0 && (b_bytes & 3) == 0, TG_EALIGN, "tg_zero_async: sizes must be multiples of 4");
+  const size_t na = a ? a_bytes / 4 : 0, nb = b ? b_bytes / 4 : 0;
+  if (na + nb == 0) return TG_OK;
+  hipLaunchKernelGGL(tg_zero_kernel, dim3(tg_grid_for((int64_t)(na + nb), 256, 1024)), dim3(256), 0, s, (uint32_t*)a, na,
+                     (uint32_t*)b, nb);
+  TG_LAUNCH_CHECK("tg_zero_async");
+  return TG_OK;
+}
+
 int tg_conv2d_fwd_direct(const TgConvDesc*, const void*, const void*, const float*, void*, hipStream_t);
 int tg_conv2d_bwd_data_direct(const TgConvDesc*, const void*, const void*, void*, hipStream_t);
 int tg_conv2d_bwd_weight_direct(const TgConvDesc*, const void*, const void*, float*, int, hipStream_t);

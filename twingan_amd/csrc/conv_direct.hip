@@ -123,10 +123,8 @@ int tg_conv2d_bwd_weight_direct(const TgConvDesc* d, const void* x, const void* 
   const int64_t nw = (int64_t)d->kh * d->kw * d->cin * d->cout;
   const int64_t npix = (int64_t)d->n * d->hout * d->wout;
   if (!accumulate) {
-    if (hipMemsetAsync(gw, 0, nw * sizeof(float), s) != hipSuccess) {
-      tg_set_error("tg_conv2d_bwd_weight: memset failed");
-      return TG_ELAUNCH;
-    }
+    int rc = tg_zero_async(gw, nw * sizeof(float), nullptr, 0, s);
+    if (rc) return rc;
   }
   const int pix_per_chunk = 2048;
   const int gy_chunks = (int)((npix + pix_per_chunk - 1) / pix_per_chunk);

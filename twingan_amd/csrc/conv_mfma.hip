@@ -319,24 +319,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma(const bf16* __restrict__ 
   }
 }
 
-// gw[i] += sum over this block row's share of the k-slices (grid.y slice groups; gw pre-zeroed unless
-// accumulating).  One fp32 atomic per element per slice group.
-__global__ void conv_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ gw, int64_t nw, int nslices) {
-  const int per = (nslices + gridDim.y - 1) / gridDim.y;
-  const int k0 = blockIdx.y * per;
-  const int k1 = min(nslices, k0 + per);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (int64_t)gridDim.x * blockDim.x) {
-    float s0 = 0.f, s1 = 0.f;
-    int k = k0;
-    for (; k + 1 < k1; k += 2) {
-      s0 += slab[(size_t)k * nw + i];
-      s1 += slab[(size_t)(k + 1) * nw + i];
-    }
-    if (k < k1) s0 += slab[(size_t)k * nw + i];
-    if (k1 > k0) atomicAdd(gw + i, s0 + s1);
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------------
@@ -525,6 +507,8 @@ size_t tg_wgrad_tile_workspace(int n, int h, int w, int cin, int cout);
 int tg_wgrad_tile_run(int n, int h, int w, int cin, int cout, const void* x, const void* gy, float* gw, int accumulate,
                       void* ws, size_t ws_bytes, hipStream_t s);
 
+int tg_wgrad_slab_reduce(const float* slab, float* gw, int64_t nw, int nslices, int accumulate, hipStream_t s);
+
 static bool use_wgrad_tile(const TgConvDesc* d) {
   return d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 &&
          tg_wgrad_tile_supported(d->hin, d->win, d->hout, d->wout, d->kh, d->kw, d->pad_t, d->pad_l);
@@ -572,16 +556,5 @@ int tg_conv2d_bwd_weight_mfma(const TgConvDesc* d0, const void* x, const void* g
     hipLaunchKernelGGL((conv_wgrad_mfma<3, 3>), grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g,
                        n_co, tpb, total);
   TG_LAUNCH_CHECK("conv_wgrad_mfma");
-  if (!accumulate && hipMemsetAsync(gw, 0, (size_t)nw * sizeof(float), s) != hipSuccess) {
-    tg_set_error("tg_conv2d_bwd_weight(mfma): memset failed");
-    return TG_ELAUNCH;
-  }
-  // spread the slice loop over grid.y so that small weights (9 blocks of elements) still fill the chip
-  const int gx = tg_grid_for(nw, 256);
-  int gy_ = (1024 + gx - 1) / gx;
-  if (gy_ > nslices) gy_ = nslices;
-  if (gy_ < 1) gy_ = 1;
-  hipLaunchKernelGGL(conv_wgrad_reduce, dim3(gx, gy_), dim3(256), 0, s, (const float*)ws, gw, nw, nslices);
-  TG_LAUNCH_CHECK("conv_wgrad_reduce");
-  return TG_OK;
+  return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
 }

@@ -15,7 +15,7 @@
 //   staged in LDS (64 B per pixel, dense); wave w reduces rows 2w, 2w+1 (two 16-pixel K steps) into
 //   9 per-tap 32x32 fp32 accumulators; the next tile's global loads are in flight during the MFMAs.
 //   At the end the 4 waves are summed through LDS and the valid [cin x cout] part is written to this
-//   workgroup's fp32 slab; conv_wgrad_tile_reduce sums the slabs into gw.
+//   workgroup's fp32 slab; conv_wgrad_slab_reduce sums the slabs into gw.
 //
 // Reference call site replaced: the Conv2DBackpropFilter gradient of tf.contrib.layers.conv2d
 // (nets/pggan_utils.py:316-320).
@@ -180,21 +180,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   }
 }
 
-// gw[i] (+)= sum over slices; grid.y slice groups, one fp32 atomic per element per group (gw pre-zeroed
-// unless accumulating)
-__global__ void conv_wgrad_tile_reduce(const float* __restrict__ slab, float* __restrict__ gw, int64_t nw, int nslices) {
-  const int per = (nslices + gridDim.y - 1) / gridDim.y;
-  const int k0 = blockIdx.y * per;
-  const int k1 = min(nslices, k0 + per);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (int64_t)gridDim.x * blockDim.x) {
-    float s0 = 0.f, s1 = 0.f;
-    int k = k0;
-    for (; k + 1 < k1; k += 2) {
+// gw[i] (+)= sum over the k-slices of slab[k][i].  A workgroup owns 16 consecutive elements; its 256 threads
+// are 16 slice groups x 16 elements, summed through LDS: no atomics, no pre-zeroing, deterministic.
+__global__ __launch_bounds__(256) void conv_wgrad_slab_reduce(const float* __restrict__ slab, float* __restrict__ gw,
+                                                              int64_t nw, int nslices, int accumulate) {
+  __shared__ float part[16][17];
+  const int e = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blockIdx.x * 16 + e;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < nw) {
+    int k = sg;
+    for (; k + 16 < nslices; k += 32) {
       s0 += slab[(size_t)k * nw + i];
-      s1 += slab[(size_t)(k + 1) * nw + i];
+      s1 += slab[(size_t)(k + 16) * nw + i];
     }
-    if (k < k1) s0 += slab[(size_t)k * nw + i];
-    if (k1 > k0) atomicAdd(gw + i, s0 + s1);
+    if (k < nslices) s0 += slab[(size_t)k * nw + i];
+  }
+  part[sg][e] = s0 + s1;
+  __syncthreads();
+  if (threadIdx.x < 16 && i < nw) {
+    float t = accumulate ? gw[i] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += part[j][e];
+    gw[i] = t;
   }
 }
 
@@ -213,6 +221,8 @@ void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices) {
 }
 
 }  // namespace
+
+int tg_wgrad_slab_reduce(const float* slab, float* gw, int64_t nw, int nslices, int accumulate, hipStream_t s);
 
 bool tg_wgrad_tile_supported(int h, int w, int hout, int wout, int kh, int kw, int pad_t, int pad_l) {
   return kh == 3 && kw == 3 && pad_t == 1 && pad_l == 1 && h == hout && w == wout && (h % 8 == 0) && (w % 16 == 0);
@@ -238,15 +248,12 @@ int tg_wgrad_tile_run(int n, int h, int w, int cin, int cout, const void* x, con
   hipLaunchKernelGGL(conv_wgrad_tile_kernel, dim3(nslices, n_ci * g.n_co_blk), dim3(256), lds, s, (const bf16*)x,
                      (const bf16*)gy, (float*)ws, g);
   TG_LAUNCH_CHECK("conv_wgrad_tile");
-  if (!accumulate && hipMemsetAsync(gw, 0, (size_t)nw * sizeof(float), s) != hipSuccess) {
-    tg_set_error("tg_conv2d_bwd_weight(tile): memset failed");
-    return TG_ELAUNCH;
-  }
-  const int gx = tg_grid_for(nw, 256);
-  int gy_ = (1024 + gx - 1) / gx;
-  if (gy_ > nslices) gy_ = nslices;
-  if (gy_ < 1) gy_ = 1;
-  hipLaunchKernelGGL(conv_wgrad_tile_reduce, dim3(gx, gy_), dim3(256), 0, s, (const float*)ws, gw, nw, nslices);
-  TG_LAUNCH_CHECK("conv_wgrad_tile_reduce");
+  return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
+}
+
+int tg_wgrad_slab_reduce(const float* slab, float* gw, int64_t nw, int nslices, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(conv_wgrad_slab_reduce, dim3((unsigned)((nw + 15) / 16)), dim3(256), 0, s, slab, gw, nw, nslices,
+                     accumulate);
+  TG_LAUNCH_CHECK("conv_wgrad_slab_reduce");
   return TG_OK;
 }

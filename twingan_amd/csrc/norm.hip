@@ -301,10 +301,9 @@ int tg_instance_norm_stats(const void* y, float* mean, float* rstd, int n, int h
   TG_CHECK(c <= 256 * 8, TG_ENOSUP, "tg_instance_norm_stats: c=%d too large", c);
   hipStream_t s = (hipStream_t)stream;
   const int hw = h * w;
-  if (hipMemsetAsync(mean, 0, (size_t)n * c * sizeof(float), s) != hipSuccess ||
-      hipMemsetAsync(rstd, 0, (size_t)n * c * sizeof(float), s) != hipSuccess) {
-    tg_set_error("tg_instance_norm_stats: memset failed");
-    return TG_ELAUNCH;
+  {
+    int rc = tg_zero_async(mean, (size_t)n * c * sizeof(float), rstd, (size_t)n * c * sizeof(float), s);
+    if (rc) return rc;
   }
   int chunks = (1024 + n - 1) / n;                      // ~1024 blocks in total
   int ppb = (hw + chunks - 1) / chunks;
@@ -361,9 +360,9 @@ int tg_norm_act_bwd(const void* gz, const void* y, const float* pn_scale, const 
   hipStream_t s = (hipStream_t)stream;
   const int hw = h * w;
   const int64_t npix = (int64_t)n * hw;
-  if (hipMemsetAsync(sums, 0, (size_t)n * c * 2 * sizeof(float), s) != hipSuccess) {
-    tg_set_error("tg_norm_act_bwd: memset failed");
-    return TG_ELAUNCH;
+  {
+    int rc = tg_zero_async(sums, (size_t)n * c * 2 * sizeof(float), nullptr, 0, s);
+    if (rc) return rc;
   }
   int chunks = (1024 + n - 1) / n;
   int ppb = (hw + chunks - 1) / chunks;
@@ -398,9 +397,9 @@ int tg_norm_act_bwd(const void* gz, const void* y, const float* pn_scale, const 
 int tg_channel_sum(const void* g, float* out, int64_t npix, int c, int accumulate, int dtype, void* stream) {
   TG_CHECK(g && out && npix > 0 && c > 0, TG_EINVAL, "tg_channel_sum: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  if (!accumulate && hipMemsetAsync(out, 0, (size_t)c * sizeof(float), s) != hipSuccess) {
-    tg_set_error("tg_channel_sum: memset failed");
-    return TG_ELAUNCH;
+  if (!accumulate) {
+    int rc = tg_zero_async(out, (size_t)c * sizeof(float), nullptr, 0, s);
+    if (rc) return rc;
   }
   TG_DISPATCH_DTYPE(dtype, "tg_channel_sum", {
     const int V = pick_v<T>(c);

@@ -583,9 +583,9 @@ int tg_pointwise_conv_bwd_weight(const void* x, const void* gy, float* gw, int64
                                  int dtype, void* stream) {
   TG_CHECK(x && gy && gw && npix > 0 && cin > 0 && cout > 0, TG_EINVAL, "tg_pointwise_conv_bwd_weight: bad arguments");
   TG_CHECK(cin <= 4 || cout <= 4, TG_ENOSUP, "tg_pointwise_conv_bwd_weight: one of cin/cout must be <= 4");
-  if (!accumulate && hipMemsetAsync(gw, 0, (size_t)cin * cout * sizeof(float), (hipStream_t)stream) != hipSuccess) {
-    tg_set_error("tg_pointwise_conv_bwd_weight: memset failed");
-    return TG_ELAUNCH;
+  if (!accumulate) {
+    int rc = tg_zero_async(gw, (size_t)cin * cout * sizeof(float), nullptr, 0, (hipStream_t)stream);
+    if (rc) return rc;
   }
   TG_DISPATCH_DTYPE(dtype, "tg_pointwise_conv_bwd_weight", {
     launch_pw_wgrad<T>((const T*)x, (const T*)gy, gw, npix, cin, cout, (hipStream_t)stream);

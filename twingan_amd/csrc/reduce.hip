@@ -281,10 +281,7 @@ int tg_mbstd_bwd_bwd(const void* v, const void* gout, const void* x, void* ggout
 }
 
 static int zero_unless(float* p, size_t bytes, int accumulate, hipStream_t s, const char* who) {
-  if (!accumulate && hipMemsetAsync(p, 0, bytes, s) != hipSuccess) {
-    tg_set_error("%s: memset failed", who);
-    return TG_ELAUNCH;
-  }
+  if (!accumulate) return tg_zero_async(p, bytes, nullptr, 0, s);
   return TG_OK;
 }
 

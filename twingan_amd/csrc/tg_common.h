@@ -36,6 +36,11 @@ void tg_set_error(const char* fmt, ...);
     }                                                                             \
   } while (0)
 
+// Zero-fills up to two fp32-aligned device buffers with ONE kernel launch on `s`.  Used instead of
+// hipMemsetAsync everywhere: memset nodes captured into a hipGraph were observed to run out of order with
+// the kernels that accumulate into the buffer (ROCm 7.2), corrupting replayed steps.
+int tg_zero_async(void* a, size_t a_bytes, void* b, size_t b_bytes, hipStream_t s);
+
 static inline bool tg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- scalar load/store by storage type ------------------------------------------------------
