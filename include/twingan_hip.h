@@ -128,6 +128,10 @@ int tg_bias_lrelu_fwd(const void* y, const float* bias, void* z, int64_t npix, i
                       void* stream);
 /* gy = gz * (z > 0 ? 1 : alpha)   (also its own double backward wrt gz) */
 int tg_lrelu_bwd(const void* gz, const void* z, void* gy, int64_t numel, float alpha, int dtype, void* stream);
+/* gy = gz * (z > 0 ? 1 : alpha) and gbias[c] (+)= sum over pixels of gy  -- LeakyReLU backward fused with
+ * BiasAddGrad (one pass over gz, z instead of two kernels) */
+int tg_lrelu_bwd_bias(const void* gz, const void* z, void* gy, float* gbias, int64_t npix, int c, float alpha,
+                      int accumulate, int dtype, void* stream);
 /* out[c] (fp32) = sum over pixels of g[pix][c]  (BiasAddGrad) */
 int tg_channel_sum(const void* g, float* out, int64_t npix, int c, int accumulate, int dtype, void* stream);
 

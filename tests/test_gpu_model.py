@@ -192,7 +192,7 @@ def test_graph_replay_matches_eager_steps():
   assert (num / den) ** 0.5 < 5e-3, (num / den) ** 0.5      # Adam's sign-like first steps amplify atomics-order noise
   la, _ = a.run(s, t)
   lb, _ = b.run(s, t)
-  assert abs(la.item() - lb.item()) < 1e-3 * max(1.0, abs(la.item()))
+  assert abs(la.item() - lb.item()) < 1e-2 * max(1.0, abs(la.item()))
 
 
 def test_graph_replay_wgan_gp_bf16_runs():

@@ -147,7 +147,7 @@ int main(int argc, char** argv) {
       {"E64a", 64, 64, 64, 3},    {"E64b", 64, 64, 128, 3},   {"E32a", 32, 128, 128, 3},  {"E32b", 32, 128, 256, 3},
       {"E16", 16, 256, 256, 3},   {"E8", 8, 256, 256, 3},     {"D4", 4, 264, 256, 3},     {"G4", 4, 256, 256, 3},
       {"G8a", 8, 512, 256, 3},    {"G16a", 16, 512, 256, 3},  {"G32a", 32, 512, 128, 3},  {"G32b", 32, 128, 128, 3},
-      {"G64a", 64, 256, 64, 3},   {"G128a", 128, 128, 32, 3}, {"G256a", 256, 64, 16, 3},
+      {"G64a", 64, 256, 64, 3},   {"P1x1", 4, 256, 256, 1},   {"G128a", 128, 128, 32, 3}, {"G256a", 256, 64, 16, 3},
   };
   printf("%-7s %-5s %4s %4s>%-4s | %9s %8s %8s %9s\n", "case", "op", "hw", "cin", "cout", "us", "GB/s", "TF/s", "relL2");
   for (const Case& c : cases) {

@@ -48,6 +48,7 @@ SIGNATURES = {
                                 c_float, c_int, c_int, _P]),
     'tg_bias_lrelu_fwd': (c_int, [_P, _FP, _P, c_int64, c_int, c_float, c_int, _P]),
     'tg_lrelu_bwd': (c_int, [_P, _P, _P, c_int64, c_float, c_int, _P]),
+    'tg_lrelu_bwd_bias': (c_int, [_P, _P, _P, _FP, c_int64, c_int, c_float, c_int, c_int, _P]),
     'tg_channel_sum': (c_int, [_P, _FP, c_int64, c_int, c_int, c_int, _P]),
     'tg_upsample2x_concat_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'tg_upsample2x_concat_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

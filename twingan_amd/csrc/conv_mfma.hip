@@ -455,6 +455,10 @@ bool tg_conv_tile_supported(int h, int w, int hout, int wout, int kh, int kw, in
 int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int epilogue, float alpha, const void* x,
                      const void* wp, const float* bias, void* y, hipStream_t s);
 
+bool tg_conv_small_supported(int n, int hout, int wout, int kh, int kw);
+int tg_conv_small_run(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l,
+                      int epilogue, float alpha, const void* x, const void* wp, const float* bias, void* y, hipStream_t s);
+
 int tg_conv2d_fwd_mfma(const TgConvDesc* d0, const void* x, const void* wp, const float* bias, void* y, hipStream_t s) {
   TgConvDesc dd;
   const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
@@ -464,6 +468,10 @@ int tg_conv2d_fwd_mfma(const TgConvDesc* d0, const void* x, const void* wp, cons
       tg_conv_tile_supported(d->hin, d->win, d->hout, d->wout, d->kh, d->kw, d->pad_t, d->pad_l))
     return tg_conv_tile_run(d->n, d->hin, d->win, d->cin, d->cout, d->kh, d->pad_t, d->epilogue, d->lrelu_alpha, x, wp,
                             bias, y, s);
+  if (d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 && d->pad_t == d->pad_l &&
+      tg_conv_small_supported(d->n, d->hout, d->wout, d->kh, d->kw))
+    return tg_conv_small_run(d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->pad_t, d->pad_l,
+                             d->epilogue, d->lrelu_alpha, x, wp, bias, y, s);
   Geom g;
   int rc = fill_geom("tg_conv2d_fwd", d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->kw, d->pad_t,
                      d->pad_l, &g);
@@ -483,6 +491,10 @@ int tg_conv2d_bwd_data_mfma(const TgConvDesc* d0, const void* gy, const void* wp
       tg_conv_tile_supported(d->hout, d->wout, d->hin, d->win, d->kh, d->kw, d->pad_t, d->pad_l))
     return tg_conv_tile_run(d->n, d->hout, d->wout, d->cout, d->cin, d->kh, d->kh - 1 - d->pad_t, 0, 1.f, gy, wp, nullptr,
                             gx, s);
+  if (d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 && d->pad_t == d->pad_l &&
+      tg_conv_small_supported(d->n, d->hin, d->win, d->kh, d->kw))
+    return tg_conv_small_run(d->n, d->hout, d->wout, d->cout, d->hin, d->win, d->cin, d->kh, d->kh - 1 - d->pad_t,
+                             d->kw - 1 - d->pad_l, 0, 1.f, gy, wp, nullptr, gx, s);
   Geom g;   // a forward conv over gy: in = (hout,wout,cout), out = (hin,win,cin), pad' = k-1-pad
   int rc = fill_geom("tg_conv2d_bwd_data", d->n, d->hout, d->wout, d->cout, d->hin, d->win, d->cin, d->kh, d->kw,
                      d->kh - 1 - d->pad_t, d->kw - 1 - d->pad_l, &g);

@@ -1,0 +1,168 @@
+// conv_small: stride-1 convolution (any k <= 3, any zero padding; also the "k x k VALID on a k x k input"
+// layers rewritten as dense 1x1) for SMALL pixel counts -- the 4x4 / 8x8 stages and the discriminator
+// tail, where N*H*W is 16..1024 but Cin*k*k is 2304..4608.  bf16 NHWC in/out, fp32 accumulate on
+// v_mfma_f32_32x32x16_bf16.  Forward and backward-data (rotated pack).
+//
+// These layers are latency-bound, not bandwidth- or MFMA-bound: the first MFMA kernel gave them 8-32
+// workgroups that each walked the whole K dimension (25-70 us).  Here
+//   - a workgroup owns a 32-pixel x 32-channel output tile (grid = pixels/32 x cout/32),
+//   - its 4 waves SPLIT K: wave w takes the 16-channel chunks w, w+4, w+8, ... of every tap,
+//   - operands go straight from L2 to registers in MFMA fragment layout (16 B per lane; activations and
+//     weights of these layers are L2-resident), no LDS staging, no barrier in the main loop,
+//   - out-of-image taps are buffer loads with an out-of-range offset (return 0),
+//   - the 4 partial accumulators are summed through LDS once, then bias + LeakyReLU + 16-byte stores.
+//
+// Reference call sites replaced: the 4x4 / 8x8 convs of nets/pggan.py:148-166,289-315,318-335,450-476
+// (tf.contrib.layers.conv2d, nets/pggan_utils.py:316-320) and their Conv2DBackpropInput gradients.
+#include "tg_common.h"
+
+namespace {
+
+struct SmallGeom {
+  int n, hin, win, cin, hout, wout, cout;
+  int cin_pad, kh, kw, pad_t, pad_l;
+  int npix;                    // n * hout * wout
+  int nchunks;                 // cin_pad / 16
+  int epilogue;
+  float alpha;
+  unsigned x_bytes, w_bytes, y_bytes;
+};
+
+constexpr unsigned SOOB = 0x80000000u;
+typedef __attribute__((ext_vector_type(4))) unsigned su32x4;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t s_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ bf16x8 s_load16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ unsigned s_pack2(float lo, float hi) {
+  bf16x2 v;
+  v[0] = (bf16)lo;
+  v[1] = (bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+
+template <int NT>      // taps (1 or 9)
+__global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
+                                                         const float* __restrict__ bias, bf16* __restrict__ y,
+                                                         const SmallGeom g) {
+  __shared__ float red[4][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, kgrp = lane >> 5;
+  const int p = blockIdx.x * 32 + l31;              // this lane's output pixel (B operand column)
+  const int n0 = blockIdx.y * 32;                   // first output channel of the tile
+
+  const __amdgpu_buffer_rsrc_t rx = s_rsrc(x, g.x_bytes);
+  const __amdgpu_buffer_rsrc_t rw = s_rsrc(wp, g.w_bytes);
+
+  // per-tap byte offset of this lane's source pixel (channel 0 + kgrp*8), SOOB outside the image / tile
+  unsigned xoff[NT];
+  {
+    const int hw = g.hout * g.wout;
+    const int img = p / hw, rem = p - img * hw;
+    const int oy = rem / g.wout, ox = rem - oy * g.wout;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int ky = t / (NT == 1 ? 1 : 3), kx = t - ky * (NT == 1 ? 1 : 3);
+      const int iy = oy + ky - g.pad_t, ix = ox + kx - g.pad_l;
+      const bool ok = p < g.npix && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
+      xoff[t] = ok ? (unsigned)((((img * g.hin + iy) * g.win + ix) * g.cin + kgrp * 8) * 2) : SOOB;
+    }
+  }
+  const unsigned wrow = (unsigned)(NT * g.cin_pad);
+  const unsigned woff = (unsigned)(((n0 + l31) * wrow + kgrp * 8) * 2);      // + (tap*cin_pad + c)*2
+
+  f32x16 acc;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+
+  // NOTE: a cin that is not a multiple of 16 (264) makes the last chunk read 8 channels of the next pixel;
+  // the weight pack is zero there.
+  auto k_step = [&](int ck) __attribute__((always_inline)) {
+    const unsigned c2 = (unsigned)(ck * 32);          // byte offset of the chunk's first channel
+    bf16x8 xf[NT], wf[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      wf[t] = s_load16(rw, woff + (unsigned)(t * g.cin_pad * 2) + c2);
+      xf[t] = s_load16(rx, xoff[t] + c2);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t], xf[t], acc, 0, 0, 0);
+  };
+  if constexpr (NT == 1) {
+#pragma unroll 8
+    for (int ck = wid; ck < g.nchunks; ck += 4) k_step(ck);     // dense layers: many chunks, 2 loads each
+  } else {
+    for (int ck = wid; ck < g.nchunks; ck += 4) k_step(ck);     // 18 loads in flight per chunk already
+  }
+
+  // ---- sum the 4 K-slices
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wid][r][lane] = acc[r];
+  __syncthreads();
+  // wave w finishes register quads q = w (channels 8w + 4*kgrp .. +3 of the 32-block) for every pixel
+  // -> after the half-wave swap each lane stores 8 consecutive channels (16 bytes)
+  {
+    const int q = wid;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = q * 4 + j;
+      v[j] = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
+    }
+    const __amdgpu_buffer_rsrc_t rbias = s_rsrc(bias, (g.epilogue & TG_EPI_BIAS) ? (unsigned)(g.cout * 4) : 0u);
+    const f32x4 bq = __builtin_bit_cast(
+        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, (unsigned)((n0 + q * 8 + kgrp * 4) * 4), 0, 0));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] += bq[j];
+      if (g.epilogue & TG_EPI_LRELU) v[j] = lrelu_f(v[j], g.alpha);
+    }
+    const unsigned p0 = s_pack2(v[0], v[1]), p1 = s_pack2(v[2], v[3]);
+    // low lanes hold channels 8q..8q+3, high lanes 8q+4..8q+7 of the same pixel: give the low lane all 8
+    auto s0 = __builtin_amdgcn_permlane32_swap(p0, p0, false, false);   // s0[1] on a low lane = partner's p0
+    auto s1 = __builtin_amdgcn_permlane32_swap(p1, p1, false, false);
+    su32x4 o;
+    o[0] = p0; o[1] = p1; o[2] = s0[1]; o[3] = s1[1];
+    const int ch0 = n0 + q * 8;
+    const bool ok = kgrp == 0 && p < g.npix && ch0 + 8 <= g.cout;
+    const __amdgpu_buffer_rsrc_t ry = s_rsrc(y, g.y_bytes);
+    __builtin_amdgcn_raw_buffer_store_b128(o, ry, ok ? (unsigned)((p * g.cout + ch0) * 2) : SOOB, 0, 0);
+  }
+}
+
+}  // namespace
+
+// M = n*hout*wout pixels.  Worth it when the tile kernel does not apply and the pixel count is small.
+bool tg_conv_small_supported(int n, int hout, int wout, int kh, int kw) {
+  if (!((kh == 1 && kw == 1) || (kh == 3 && kw == 3))) return false;
+  return (int64_t)n * hout * wout <= 4096;
+}
+
+int tg_conv_small_run(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l,
+                      int epilogue, float alpha, const void* x, const void* wp, const float* bias, void* y,
+                      hipStream_t s) {
+  SmallGeom g;
+  g.n = n; g.hin = hin; g.win = win; g.cin = cin; g.hout = hout; g.wout = wout; g.cout = cout;
+  g.cin_pad = (cin + 15) / 16 * 16;
+  g.kh = g.kw = k;
+  g.pad_t = pad_t; g.pad_l = pad_l;
+  g.npix = n * hout * wout;
+  g.nchunks = g.cin_pad / 16;
+  g.epilogue = epilogue;
+  g.alpha = alpha;
+  const size_t xb = (size_t)n * hin * win * cin * 2, yb = (size_t)g.npix * cout * 2;
+  const size_t rows_pad = (size_t)(cout + 63) / 64 * 64;
+  const size_t wb = rows_pad * k * k * g.cin_pad * 2;
+  TG_CHECK(xb < 0x7fffffffull && yb < 0x7fffffffull && wb < 0x7fffffffull, TG_ENOSUP, "conv_small: tensor too large");
+  g.x_bytes = (unsigned)xb; g.y_bytes = (unsigned)yb; g.w_bytes = (unsigned)wb;
+  dim3 grid((g.npix + 31) / 32, (cout + 31) / 32);
+  if (k == 1)
+    hipLaunchKernelGGL(conv_small_kernel<1>, grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, g);
+  else
+    hipLaunchKernelGGL(conv_small_kernel<9>, grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, g);
+  TG_LAUNCH_CHECK("conv_small");
+  return TG_OK;
+}

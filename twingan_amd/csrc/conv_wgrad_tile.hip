@@ -180,28 +180,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   }
 }
 
-// gw[i] (+)= sum over the k-slices of slab[k][i].  A workgroup owns 16 consecutive elements; its 256 threads
-// are 16 slice groups x 16 elements, summed through LDS: no atomics, no pre-zeroing, deterministic.
+// gw[i] (+)= sum over the k-slices of slab[k][i].  A workgroup owns 256/SG consecutive elements; its 256
+// threads are SG slice groups x 256/SG elements, summed through LDS: no atomics, no pre-zeroing,
+// deterministic.  SG is large for small weights (few elements, many slices) and 1 for large ones.
+template <int SG>
 __global__ __launch_bounds__(256) void conv_wgrad_slab_reduce(const float* __restrict__ slab, float* __restrict__ gw,
                                                               int64_t nw, int nslices, int accumulate) {
-  __shared__ float part[16][17];
-  const int e = threadIdx.x & 15, sg = threadIdx.x >> 4;
-  const int64_t i = (int64_t)blockIdx.x * 16 + e;
+  constexpr int EPB = 256 / SG;
+  __shared__ float part[SG][EPB + 1];
+  const int e = threadIdx.x % EPB, sg = threadIdx.x / EPB;
+  const int64_t i = (int64_t)blockIdx.x * EPB + e;
   float s0 = 0.f, s1 = 0.f;
   if (i < nw) {
     int k = sg;
-    for (; k + 16 < nslices; k += 32) {
+    for (; k + SG < nslices; k += 2 * SG) {
       s0 += slab[(size_t)k * nw + i];
-      s1 += slab[(size_t)(k + 16) * nw + i];
+      s1 += slab[(size_t)(k + SG) * nw + i];
     }
     if (k < nslices) s0 += slab[(size_t)k * nw + i];
   }
+  if (SG == 1) {
+    if (i < nw) gw[i] = (accumulate ? gw[i] : 0.f) + s0 + s1;
+    return;
+  }
   part[sg][e] = s0 + s1;
   __syncthreads();
-  if (threadIdx.x < 16 && i < nw) {
+  if (threadIdx.x < EPB && i < nw) {
     float t = accumulate ? gw[i] : 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) t += part[j][e];
+    for (int j = 0; j < SG; ++j) t += part[j][e];
     gw[i] = t;
   }
 }
@@ -252,8 +259,15 @@ int tg_wgrad_tile_run(int n, int h, int w, int cin, int cout, const void* x, con
 }
 
 int tg_wgrad_slab_reduce(const float* slab, float* gw, int64_t nw, int nslices, int accumulate, hipStream_t s) {
-  hipLaunchKernelGGL(conv_wgrad_slab_reduce, dim3((unsigned)((nw + 15) / 16)), dim3(256), 0, s, slab, gw, nw, nslices,
-                     accumulate);
+  if (nw < 16384)
+    hipLaunchKernelGGL(conv_wgrad_slab_reduce<16>, dim3((unsigned)((nw + 15) / 16)), dim3(256), 0, s, slab, gw, nw, nslices,
+                       accumulate);
+  else if (nw < 131072)
+    hipLaunchKernelGGL(conv_wgrad_slab_reduce<4>, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, s, slab, gw, nw, nslices,
+                       accumulate);
+  else
+    hipLaunchKernelGGL(conv_wgrad_slab_reduce<1>, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, slab, gw, nw,
+                       nslices, accumulate);
   TG_LAUNCH_CHECK("conv_wgrad_slab_reduce");
   return TG_OK;
 }

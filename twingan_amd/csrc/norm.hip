@@ -282,6 +282,38 @@ __global__ void channel_sum_kernel(const T* __restrict__ g, float* __restrict__ 
   for (int i = threadIdx.x; i < c; i += blockDim.x) atomicAdd(out + i, sh[i]);
 }
 
+// gy = gz * (z > 0 ? 1 : alpha)  and  gbias[c] += sum_p gy[p][c]   (LeakyReLU backward fused with BiasAddGrad)
+template <typename T, int V>
+__global__ void lrelu_bwd_bias_kernel(const T* __restrict__ gz, const T* __restrict__ z, T* __restrict__ gy,
+                                      float* __restrict__ gbias, int64_t npix, int c, float alpha) {
+  extern __shared__ float sh[];   // [c]
+  const int cv = c / V;
+  const int lanes = blockDim.x / cv;
+  const int v = threadIdx.x % cv, pl = threadIdx.x / cv;
+  for (int i = threadIdx.x; i < c; i += blockDim.x) sh[i] = 0.f;
+  __syncthreads();
+  float a[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) a[j] = 0.f;
+  if (pl < lanes) {
+    for (int64_t p = (int64_t)blockIdx.x * lanes + pl; p < npix; p += (int64_t)gridDim.x * lanes) {
+      float g[V], zz[V];
+      VecIO<T, V>::load(gz + p * c + v * V, g);
+      VecIO<T, V>::load(z + p * c + v * V, zz);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        g[j] = rnd<T>(g[j] * (zz[j] > 0.f ? 1.f : alpha));
+        a[j] += g[j];
+      }
+      VecIO<T, V>::store(gy + p * c + v * V, g);
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) atomicAdd(&sh[v * V + j], a[j]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < c; i += blockDim.x) atomicAdd(gbias + i, sh[i]);
+}
+
 // largest power of two <= 64 check for the pixel-norm group reduction
 inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -391,6 +423,32 @@ int tg_norm_act_bwd(const void* gz, const void* y, const float* pn_scale, const 
   if (ggamma || gbeta)
     hipLaunchKernelGGL(norm_param_grads, dim3((c + 255) / 256), dim3(256), 0, s, sums, ggamma, gbeta, n, c, accumulate);
   TG_LAUNCH_CHECK("tg_norm_act_bwd");
+  return TG_OK;
+}
+
+int tg_lrelu_bwd_bias(const void* gz, const void* z, void* gy, float* gbias, int64_t npix, int c, float alpha,
+                      int accumulate, int dtype, void* stream) {
+  TG_CHECK(gz && z && gy && gbias && npix > 0 && c > 0, TG_EINVAL, "tg_lrelu_bwd_bias: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) {
+    int rc = tg_zero_async(gbias, (size_t)c * sizeof(float), nullptr, 0, s);
+    if (rc) return rc;
+  }
+  TG_DISPATCH_DTYPE(dtype, "tg_lrelu_bwd_bias", {
+    const int V = pick_v<T>(c);
+    TG_CHECK(c / V <= 256, TG_ENOSUP, "tg_lrelu_bwd_bias: c=%d not supported", c);
+    const int lanes = 256 / (c / V);
+    // few, fat workgroups: every workgroup ends with c global atomics on the same c addresses
+    const int blocks = tg_grid_for(npix, lanes * 16, 512);
+    const size_t lds = (size_t)c * sizeof(float);
+    if (V == 1)
+      hipLaunchKernelGGL((lrelu_bwd_bias_kernel<T, 1>), dim3(blocks), dim3(256), lds, s, (const T*)gz, (const T*)z, (T*)gy,
+                         gbias, npix, c, alpha);
+    else
+      hipLaunchKernelGGL((lrelu_bwd_bias_kernel<T, Vec16<T>::N>), dim3(blocks), dim3(256), lds, s, (const T*)gz,
+                         (const T*)z, (T*)gy, gbias, npix, c, alpha);
+  });
+  TG_LAUNCH_CHECK("tg_lrelu_bwd_bias");
   return TG_OK;
 }
 

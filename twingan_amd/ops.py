@@ -101,6 +101,46 @@ class PackCache:
     return n
 
 
+class GradSink:
+  """Fused gradient accumulation: a parameter registered here has its gradient ADDED straight into the
+  registered buffer (its slice of the optimiser group's flat fp32 gradient, params.ParamStore) by the
+  backward kernels themselves, and the autograd Function returns None for it -- no temporary gradient
+  tensor, no zero-fill of it, no AccumulateGrad add kernel.  Only used outside create_graph mode (nothing
+  differentiates a parameter gradient)."""
+  _sinks = {}
+
+  @classmethod
+  def register(cls, p, grad):
+    cls._sinks[p.data_ptr()] = grad
+
+  @classmethod
+  def clear(cls):
+    cls._sinks.clear()
+
+  @classmethod
+  def get(cls, p):
+    if p is None or torch.is_grad_enabled():
+      return None
+    return cls._sinks.get(p.data_ptr())
+
+
+class _State:
+  skip_param_grads = False
+
+
+class no_param_grads:
+  """Context: backward passes run inside it do not compute parameter gradients (weights, biases, norm
+  affine).  Used around the WGAN-GP inner ``tf.gradients(pred, interp)`` (image_generation.py:429), which
+  only needs d pred / d interp; the parameters receive their gradient through the double backward."""
+
+  def __enter__(self):
+    self.prev = _State.skip_param_grads
+    _State.skip_param_grads = True
+
+  def __exit__(self, *a):
+    _State.skip_param_grads = self.prev
+
+
 class ConvSpec:
   """Static description of one stride-1 conv (TF SAME / VALID padding rules)."""
   __slots__ = ('kh', 'kw', 'pad_t', 'pad_l', 'valid', 'epilogue', 'alpha')
@@ -173,15 +213,51 @@ def conv_bwd_data_raw(gy, w, x_shape, spec):
   return gx
 
 
-def conv_bwd_weight_raw(x, gy, spec):
+def conv_bwd_weight_raw(x, gy, spec, out=None):
+  """gw = x^T * gy; with ``out`` the result is ADDED into that fp32 HWIO buffer (gradient sink)."""
   _chk(x, gy)
   d = _desc(x.shape, gy.shape[3], spec, x.dtype, 0)
-  gw = torch.empty((spec.kh, spec.kw, x.shape[3], gy.shape[3]), dtype=torch.float32, device=x.device)
+  shape = (spec.kh, spec.kw, x.shape[3], gy.shape[3])
+  if out is None:
+    gw = torch.empty(shape, dtype=torch.float32, device=x.device)
+  else:
+    assert tuple(out.shape) == shape and out.is_contiguous(), (tuple(out.shape), shape)
+    gw = out
   nbytes = _lib.load().tg_conv2d_bwd_weight_workspace(ctypes.byref(d))
   ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device) if nbytes else None
-  call('tg_conv2d_bwd_weight', ctypes.byref(d), _p(x), _p(gy), _p(gw), 0, _p(ws), nbytes, _stream(),
+  call('tg_conv2d_bwd_weight', ctypes.byref(d), _p(x), _p(gy), _p(gw), 0 if out is None else 1, _p(ws), nbytes, _stream(),
        work=lambda: _conv_work(d, 'wgrad', _esize(x)))
   return gw
+
+
+def _weight_grad(x, g, spec, w):
+  """Parameter gradient of a conv: into the sink when ``w`` has one (returns None), else a differentiable node."""
+  sink = GradSink.get(w)
+  if sink is not None:
+    conv_bwd_weight_raw(x, g, spec, out=sink)
+    return None
+  return ConvBwdWeightFn.apply(x, g, spec)
+
+
+def _bias_grad(g, bias):
+  sink = GradSink.get(bias)
+  if sink is not None:
+    c = g.shape[-1]
+    call('tg_channel_sum', _p(g), _p(sink), g.numel() // c, c, 1, _dt(g), _stream())
+    return None
+  return ChannelSumFn.apply(g)
+
+
+def lrelu_bwd_bias(gz, z, alpha, bias):
+  """g = gz * lrelu'(z) and the bias gradient in one pass; returns (g, gb) with gb None when sunk."""
+  _chk(gz, z)
+  g = torch.empty_like(gz)
+  c = gz.shape[-1]
+  sink = GradSink.get(bias)
+  gb = sink if sink is not None else torch.empty(c, dtype=torch.float32, device=gz.device)
+  call('tg_lrelu_bwd_bias', _p(gz), _p(z), _p(g), _p(gb), gz.numel() // c, c, alpha, 1 if sink is not None else 0,
+       _dt(gz), _stream(), work=('lrelu_bwd_bias', 0, 3 * gz.numel() * _esize(gz)))
+  return g, (None if sink is not None else gb)
 
 
 def lrelu_bwd_raw(g, z, alpha):
@@ -231,18 +307,30 @@ class Conv2dFn(torch.autograd.Function):
   def forward(ctx, x, w, bias, spec, epilogue):
     z = conv_fwd_raw(x, w, bias, spec, epilogue)
     ctx.spec, ctx.epilogue = spec, epilogue
-    ctx.save_for_backward(x, w, z if (epilogue & TG_EPI_LRELU) else None)
+    ctx.save_for_backward(x, w, z if (epilogue & TG_EPI_LRELU) else None, bias)
     return z
 
   @staticmethod
   def backward(ctx, gz):
-    x, w, z = ctx.saved_tensors
+    x, w, z, bias = ctx.saved_tensors
     spec = ctx.spec
     gz = gz.contiguous()
-    g = LReluBwdFn.apply(gz, z, spec.alpha) if (ctx.epilogue & TG_EPI_LRELU) else gz
+    params = not _State.skip_param_grads
+    need_w = ctx.needs_input_grad[1] and params
+    need_b = bool(ctx.epilogue & TG_EPI_BIAS) and ctx.needs_input_grad[2] and params
+    gb = None
+    if ctx.epilogue & TG_EPI_LRELU:
+      if need_b and not torch.is_grad_enabled():
+        g, gb = lrelu_bwd_bias(gz, z, spec.alpha, bias)
+        need_b = False
+      else:
+        g = LReluBwdFn.apply(gz, z, spec.alpha)
+    else:
+      g = gz
     gx = ConvBwdDataFn.apply(g, w, tuple(x.shape), spec) if ctx.needs_input_grad[0] else None
-    gw = ConvBwdWeightFn.apply(x, g, spec) if ctx.needs_input_grad[1] else None
-    gb = ChannelSumFn.apply(g) if ((ctx.epilogue & TG_EPI_BIAS) and ctx.needs_input_grad[2]) else None
+    gw = _weight_grad(x, g, spec, w) if need_w else None
+    if need_b:
+      gb = _bias_grad(g, bias)
     return gx, gw, gb, None, None
 
 
@@ -260,7 +348,7 @@ class ConvBwdDataFn(torch.autograd.Function):
     gy, w = ctx.saved_tensors
     v = v.contiguous()
     ggy = Conv2dFn.apply(v, w, None, ctx.spec, 0) if ctx.needs_input_grad[0] else None
-    gw = ConvBwdWeightFn.apply(v, gy, ctx.spec) if ctx.needs_input_grad[1] else None
+    gw = _weight_grad(v, gy, ctx.spec, w) if (ctx.needs_input_grad[1] and not _State.skip_param_grads) else None
     return ggy, gw, None, None
 
 
@@ -334,20 +422,37 @@ class PointwiseConvFn(torch.autograd.Function):
   def forward(ctx, x, w, bias, wt, epilogue, alpha):
     z = _pw_fwd_raw(x, w, bias, wt, epilogue, alpha)
     ctx.wt, ctx.epilogue, ctx.alpha = wt, epilogue, alpha
-    ctx.save_for_backward(x, w, z if (epilogue & TG_EPI_LRELU) else None)
+    ctx.save_for_backward(x, w, z if (epilogue & TG_EPI_LRELU) else None, bias)
     return z
 
   @staticmethod
   def backward(ctx, gz):
-    x, w, z = ctx.saved_tensors
+    x, w, z, bias = ctx.saved_tensors
     gz = gz.contiguous()
-    g = LReluBwdFn.apply(gz, z, ctx.alpha) if (ctx.epilogue & TG_EPI_LRELU) else gz
+    params = not _State.skip_param_grads
+    need_b = bool(ctx.epilogue & TG_EPI_BIAS) and ctx.needs_input_grad[2] and params
+    gb = None
+    if ctx.epilogue & TG_EPI_LRELU:
+      if need_b and not torch.is_grad_enabled():
+        g, gb = lrelu_bwd_bias(gz, z, ctx.alpha, bias)
+        need_b = False
+      else:
+        g = LReluBwdFn.apply(gz, z, ctx.alpha)
+    else:
+      g = gz
     gx = PointwiseConvFn.apply(g, w, None, not ctx.wt, 0, ctx.alpha) if ctx.needs_input_grad[0] else None
     gw = None
-    if ctx.needs_input_grad[1]:
+    if ctx.needs_input_grad[1] and params:
       # y = x @ W: dW = x^T g.  With wt the stored tensor is W^T, so dw = g^T x.
-      gw = PointwiseWgradFn.apply(g, x) if ctx.wt else PointwiseWgradFn.apply(x, g)
-    gb = ChannelSumFn.apply(g) if ((ctx.epilogue & TG_EPI_BIAS) and ctx.needs_input_grad[2]) else None
+      a, b = (g, x) if ctx.wt else (x, g)
+      sink = GradSink.get(w)
+      if sink is not None:
+        ca, cb = a.shape[-1], b.shape[-1]
+        call('tg_pointwise_conv_bwd_weight', _p(a), _p(b), _p(sink), a.numel() // ca, ca, cb, 1, _dt(a), _stream())
+      else:
+        gw = PointwiseWgradFn.apply(a, b)
+    if need_b:
+      gb = _bias_grad(g, bias)
     return gx, gw, gb, None, None, None
 
 
@@ -406,12 +511,21 @@ class NormActFn(torch.autograd.Function):
     gz = gz.contiguous()
     n, h, w, c = y.shape
     gy = torch.empty_like(y)
-    gg = torch.empty(c, dtype=torch.float32, device=y.device)
-    gb = torch.empty(c, dtype=torch.float32, device=y.device)
     sums = torch.empty(2 * n * c, dtype=torch.float32, device=y.device)
+    sg, sb = GradSink.get(gamma), GradSink.get(beta)
+    sunk = sg is not None and sb is not None
+    if _State.skip_param_grads:
+      gg = gb = None
+    elif sunk:
+      gg, gb = sg, sb
+    else:
+      gg = torch.empty(c, dtype=torch.float32, device=y.device)
+      gb = torch.empty(c, dtype=torch.float32, device=y.device)
     call('tg_norm_act_bwd', _p(gz), _p(y), _p(s), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(gy), _p(gg), _p(gb),
-         _p(sums), n, h, w, c, ctx.flags, ctx.alpha, 0, _dt(y), _stream(),
+         _p(sums), n, h, w, c, ctx.flags, ctx.alpha, 1 if sunk else 0, _dt(y), _stream(),
          work=('norm_act_bwd', 0, 3 * y.numel() * _esize(y)))
+    if sunk or _State.skip_param_grads:
+      gg = gb = None
     return gy, gg, gb, None, None, None, None
 
 

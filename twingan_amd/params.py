@@ -13,7 +13,7 @@ from collections import OrderedDict
 
 import torch
 
-from .ops import PackCache
+from .ops import GradSink, PackCache
 
 ALIGN = 64   # elements; keeps every variable 256-byte aligned inside the flat buffer
 
@@ -79,6 +79,7 @@ class ParamStore:
       self._init(p, s, gen)
       p.requires_grad_(True)
       p.grad = self.grad[g][off:off + n].view(s['phys'])
+      GradSink.register(p, p.grad)          # backward kernels accumulate straight into the flat buffer
       self.P[name] = p
       if s['kind'] == 'conv_w':
         PackCache.register(p)

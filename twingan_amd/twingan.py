@@ -98,7 +98,8 @@ def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t):
       interp = ops.sample_lerp(real, prime, a).requires_grad_(True)               # image_generation.py:420-424
       pi, _ = pggan.discriminator(P, interp, cfg, top)
       ones = ops.fill(pi.shape, 1.0, pi.dtype, pi.device)
-      gi, = torch.autograd.grad(pi, interp, grad_outputs=ones, create_graph=True)  # tf.gradients(pred, interp)
+      with ops.no_param_grads():        # only d pred / d interp is needed here; parameters get theirs via the double backward
+        gi, = torch.autograd.grad(pi, interp, grad_outputs=ones, create_graph=True)  # tf.gradients(pred, interp)
       terms['discriminator_gradient_penalty_prime_' + d] = ops.gradient_penalty(gi.contiguous(),
                                                                                 cfg.gradient_penalty_lambda)
   total = None
