@@ -44,6 +44,30 @@ __device__ __forceinline__ float group_sum(float v, int g) {
   return v;
 }
 
+// Adds this thread's V per-channel partials into sh[base + v*V + j].  Threads of a wave that own the same
+// channel vector (v = tid % cv) are first summed with an xor butterfly over the pixel-lane bits, so that only
+// cv lanes per wave touch LDS (instead of 64 lanes fighting over cv*V addresses).
+template <int V>
+__device__ __forceinline__ void wave_channel_accumulate(float (&a)[V], float* sh, int base, int cv, int v, bool active) {
+  if (cv <= 64 && (cv & (cv - 1)) == 0) {
+    if (!active) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) a[j] = 0.f;
+    }
+    for (int o = cv; o < 64; o <<= 1) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) a[j] += __shfl_xor(a[j], o, 64);
+    }
+    if ((int)(threadIdx.x & 63) < cv) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) atomicAdd(&sh[base + v * V + j], a[j]);
+    }
+  } else if (active) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) atomicAdd(&sh[base + v * V + j], a[j]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // statistics: shifted sums  S1 = sum(y - K), S2 = sum((y-K)^2) with K = y[n,0,0,c]  (stable in fp32)
 // accumulated into mean[] / rstd[] (pre-zeroed), finalised in place.
@@ -77,12 +101,9 @@ __global__ void in_stats_partial(const T* __restrict__ y, float* __restrict__ s1
         a2[j] = fmaf(d, d, a2[j]);
       }
     }
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-      atomicAdd(&sh[v * V + j], a1[j]);
-      atomicAdd(&sh[c + v * V + j], a2[j]);
-    }
   }
+  wave_channel_accumulate<V>(a1, sh, 0, cv, v, pl < lanes);
+  wave_channel_accumulate<V>(a2, sh, c, cv, v, pl < lanes);
   __syncthreads();
   for (int i = threadIdx.x; i < c; i += blockDim.x) {
     atomicAdd(s1 + (int64_t)n * c + i, sh[i]);
@@ -203,12 +224,9 @@ __global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restri
       }
       VecIO<T, V>::store(gu_out + gp * c + v * V, g);
     }
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-      atomicAdd(&sh[v * V + j], a1[j]);
-      atomicAdd(&sh[c + v * V + j], a2[j]);
-    }
   }
+  wave_channel_accumulate<V>(a1, sh, 0, cv, v, pl < lanes);
+  wave_channel_accumulate<V>(a2, sh, c, cv, v, pl < lanes);
   __syncthreads();
   for (int i = threadIdx.x; i < c; i += blockDim.x) {
     atomicAdd(sums + ((int64_t)n * c + i) * 2 + 0, sh[i]);
@@ -275,9 +293,8 @@ __global__ void channel_sum_kernel(const T* __restrict__ g, float* __restrict__ 
 #pragma unroll
       for (int j = 0; j < V; ++j) a[j] += x[j];
     }
-#pragma unroll
-    for (int j = 0; j < V; ++j) atomicAdd(&sh[v * V + j], a[j]);
   }
+  wave_channel_accumulate<V>(a, sh, 0, cv, v, pl < lanes);
   __syncthreads();
   for (int i = threadIdx.x; i < c; i += blockDim.x) atomicAdd(out + i, sh[i]);
 }
@@ -307,9 +324,8 @@ __global__ void lrelu_bwd_bias_kernel(const T* __restrict__ gz, const T* __restr
       }
       VecIO<T, V>::store(gy + p * c + v * V, g);
     }
-#pragma unroll
-    for (int j = 0; j < V; ++j) atomicAdd(&sh[v * V + j], a[j]);
   }
+  wave_channel_accumulate<V>(a, sh, 0, cv, v, pl < lanes);
   __syncthreads();
   for (int i = threadIdx.x; i < c; i += blockDim.x) atomicAdd(gbias + i, sh[i]);
 }
