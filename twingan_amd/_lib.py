@@ -42,10 +42,10 @@ SIGNATURES = {
     'tg_pointwise_conv_fwd': (c_int, [_P, _FP, _FP, _P, c_int64, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     'tg_pointwise_conv_bwd_weight': (c_int, [_P, _P, _FP, c_int64, c_int, c_int, c_int, c_int, _P]),
     'tg_instance_norm_stats': (c_int, [_P, _FP, _FP, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
-    'tg_norm_act_fwd': (c_int, [_P, _FP, _FP, _FP, _FP, _P, _FP, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
-                                c_int, _P]),
-    'tg_norm_act_bwd': (c_int, [_P, _P, _FP, _FP, _FP, _FP, _FP, _P, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int,
-                                c_float, c_int, c_int, _P]),
+    'tg_norm_act_fwd': (c_int, [_P, _FP, _FP, _FP, _FP, _FP, _FP, c_int, _P, _FP, c_int, c_int, c_int, c_int, c_int,
+                                c_float, c_float, c_int, _P]),
+    'tg_norm_act_bwd': (c_int, [_P, _P, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, _P, _FP, _FP, _FP, _FP, _FP, c_int,
+                                c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
     'tg_bias_lrelu_fwd': (c_int, [_P, _FP, _P, c_int64, c_int, c_float, c_int, _P]),
     'tg_lrelu_bwd': (c_int, [_P, _P, _P, c_int64, c_float, c_int, _P]),
     'tg_lrelu_bwd_bias': (c_int, [_P, _P, _P, _FP, c_int64, c_int, c_float, c_int, c_int, _P]),
@@ -59,9 +59,9 @@ SIGNATURES = {
     'tg_sample_scale': (c_int, [_P, _FP, _FP, _P, c_int, c_int64, c_int, _P]),
     'tg_fill_scaled': (c_int, [_P, _FP, c_float, c_int64, c_int, _P]),
     'tg_cast': (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
-    'tg_mbstd_fwd': (c_int, [_P, _P, _FP, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
-    'tg_mbstd_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
-    'tg_mbstd_bwd_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    'tg_mbstd_fwd': (c_int, [_P, _P, _FP, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    'tg_mbstd_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    'tg_mbstd_bwd_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     'tg_small_gemm': (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'tg_sum': (c_int, [_P, _FP, c_int64, c_float, c_int, c_int, _P]),
     'tg_abs_diff_sum': (c_int, [_P, _P, _FP, c_int64, c_float, c_int, c_int, _P]),

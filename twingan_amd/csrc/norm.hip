@@ -132,8 +132,10 @@ __global__ void in_stats_final(const T* __restrict__ y, float* __restrict__ mean
 template <typename T, int V>
 __global__ void norm_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, T* __restrict__ z, float* __restrict__ pn_scale,
-                                    int64_t npix, int hw, int c, int flags, float alpha, float pn_eps) {
+                                    const float* __restrict__ beta, const float* __restrict__ gamma2,
+                                    const float* __restrict__ beta2, int split, T* __restrict__ z,
+                                    float* __restrict__ pn_scale, int64_t npix, int hw, int c, int flags, float alpha,
+                                    float pn_eps) {
   const int cv = c / V;
   const int64_t total = npix * cv;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -144,12 +146,14 @@ __global__ void norm_act_fwd_kernel(const T* __restrict__ y, const float* __rest
     const int n = (int)(p / hw);
     float x[V];
     VecIO<T, V>::load(y + p * c + v * V, x);
+    const float* ga = n < split ? gamma : gamma2;      // per-domain affine parameters (images >= split: 2nd domain)
+    const float* be = n < split ? beta : beta2;
     float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       const int ch = v * V + j;
-      const float r = rstd[n * c + ch] * gamma[ch];
-      float u = x[j] * r + (beta[ch] - mean[n * c + ch] * r);      // tf.nn.batch_normalization form
+      const float r = rstd[n * c + ch] * ga[ch];
+      float u = x[j] * r + (be[ch] - mean[n * c + ch] * r);      // tf.nn.batch_normalization form
       if (flags & NF_LRELU) u = lrelu_f(u, alpha);
       x[j] = u;
       ss = fmaf(u, u, ss);
@@ -172,8 +176,10 @@ __global__ void norm_act_fwd_kernel(const T* __restrict__ y, const float* __rest
 template <typename T, int V>
 __global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restrict__ y, const float* __restrict__ pn_scale,
                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                     const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ gu_out,
-                                     float* __restrict__ sums, int hw, int c, int flags, float alpha, int px_per_block) {
+                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ gamma2, const float* __restrict__ beta2, int split,
+                                     T* __restrict__ gu_out, float* __restrict__ sums, int hw, int c, int flags,
+                                     float alpha, int px_per_block) {
   extern __shared__ float sh[];   // [2][c]
   const int cv = c / V;
   const int lanes = blockDim.x / cv;
@@ -187,8 +193,8 @@ __global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restri
     const int ch = v * V + j;
     mu[j] = mean[n * c + ch];
     rs[j] = rstd[n * c + ch];
-    ga[j] = gamma[ch];
-    be[j] = beta[ch];
+    ga[j] = (n < split ? gamma : gamma2)[ch];
+    be[j] = (n < split ? beta : beta2)[ch];
     a1[j] = a2[j] = 0.f;
   }
   const int p0 = blockIdx.x * px_per_block;
@@ -238,7 +244,8 @@ __global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restri
 template <typename T, int V>
 __global__ void norm_act_bwd2_kernel(T* __restrict__ gy, const T* __restrict__ y, const float* __restrict__ mean,
                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                     const float* __restrict__ sums, int64_t npix, int hw, int c) {
+                                     const float* __restrict__ gamma2, int split, const float* __restrict__ sums,
+                                     int64_t npix, int hw, int c) {
   const int cv = c / V;
   const int64_t total = npix * cv;
   const float inv = 1.f / (float)hw;
@@ -255,23 +262,28 @@ __global__ void norm_act_bwd2_kernel(T* __restrict__ gy, const T* __restrict__ y
       const float r = rstd[n * c + ch];
       const float yh = (x[j] - mean[n * c + ch]) * r;
       const float s1 = sums[((int64_t)n * c + ch) * 2] * inv, s2 = sums[((int64_t)n * c + ch) * 2 + 1] * inv;
-      g[j] = gamma[ch] * r * (g[j] - s1 - yh * s2);
+      g[j] = (n < split ? gamma : gamma2)[ch] * r * (g[j] - s1 - yh * s2);
     }
     VecIO<T, V>::store(gy + p * c + v * V, g);
   }
 }
 
+// images [i0, i1) -> (ggamma, gbeta); blockIdx.y selects the domain half
 __global__ void norm_param_grads(const float* __restrict__ sums, float* __restrict__ ggamma, float* __restrict__ gbeta,
-                                 int n, int c, int accumulate) {
+                                 float* __restrict__ ggamma2, float* __restrict__ gbeta2, int split, int n, int c,
+                                 int accumulate) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
+  const int i0 = blockIdx.y ? split : 0, i1 = blockIdx.y ? n : split;
+  float* gg = blockIdx.y ? ggamma2 : ggamma;
+  float* gb = blockIdx.y ? gbeta2 : gbeta;
   float sb = 0.f, sg = 0.f;
-  for (int i = 0; i < n; ++i) {
+  for (int i = i0; i < i1; ++i) {
     sb += sums[((int64_t)i * c + ch) * 2];
     sg += sums[((int64_t)i * c + ch) * 2 + 1];
   }
-  if (ggamma) ggamma[ch] = (accumulate ? ggamma[ch] : 0.f) + sg;
-  if (gbeta) gbeta[ch] = (accumulate ? gbeta[ch] : 0.f) + sb;
+  if (gg) gg[ch] = (accumulate ? gg[ch] : 0.f) + sg;
+  if (gb) gb[ch] = (accumulate ? gb[ch] : 0.f) + sb;
 }
 
 // out[c] += sum_p g[p][c]
@@ -373,11 +385,13 @@ int tg_instance_norm_stats(const void* y, float* mean, float* rstd, int n, int h
   return TG_OK;
 }
 
-int tg_norm_act_fwd(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta, void* z,
-                    float* pn_scale, int n, int h, int w, int c, int flags, float alpha, float pn_eps, int dtype,
-                    void* stream) {
+int tg_norm_act_fwd(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                    const float* gamma2, const float* beta2, int split, void* z, float* pn_scale, int n, int h, int w, int c,
+                    int flags, float alpha, float pn_eps, int dtype, void* stream) {
   TG_CHECK(y && mean && rstd && gamma && beta && z && n > 0 && h > 0 && w > 0 && c > 0, TG_EINVAL,
            "tg_norm_act_fwd: bad arguments");
+  if (!gamma2 || !beta2) split = n;
+  TG_CHECK(split >= 0 && split <= n, TG_EINVAL, "tg_norm_act_fwd: split %d outside [0, %d]", split, n);
   const int64_t npix = (int64_t)n * h * w;
   TG_DISPATCH_DTYPE(dtype, "tg_norm_act_fwd", {
     constexpr int VN = Vec16<T>::N;
@@ -389,11 +403,12 @@ int tg_norm_act_fwd(const void* y, const float* mean, const float* rstd, const f
     if (vec) {
       // grid stride must be a multiple of the group size so pixel groups stay in one wave: 256 % (c/VN) == 0 holds
       hipLaunchKernelGGL((norm_act_fwd_kernel<T, VN>), dim3(tg_grid_for(npix * (c / VN), 256)), dim3(256), 0,
-                         (hipStream_t)stream, (const T*)y, mean, rstd, gamma, beta, (T*)z, pn_scale, npix, h * w, c, flags,
-                         alpha, pn_eps);
+                         (hipStream_t)stream, (const T*)y, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)z, pn_scale, npix,
+                         h * w, c, flags, alpha, pn_eps);
     } else {
       hipLaunchKernelGGL((norm_act_fwd_kernel<T, 1>), dim3(tg_grid_for(npix * c, 256)), dim3(256), 0, (hipStream_t)stream,
-                         (const T*)y, mean, rstd, gamma, beta, (T*)z, pn_scale, npix, h * w, c, flags, alpha, pn_eps);
+                         (const T*)y, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)z, pn_scale, npix, h * w, c, flags,
+                         alpha, pn_eps);
     }
   });
   TG_LAUNCH_CHECK("tg_norm_act_fwd");
@@ -401,10 +416,13 @@ int tg_norm_act_fwd(const void* y, const float* mean, const float* rstd, const f
 }
 
 int tg_norm_act_bwd(const void* gz, const void* y, const float* pn_scale, const float* mean, const float* rstd,
-                    const float* gamma, const float* beta, void* gy, float* ggamma, float* gbeta, float* sums, int n, int h,
-                    int w, int c, int flags, float alpha, int accumulate, int dtype, void* stream) {
+                    const float* gamma, const float* beta, const float* gamma2, const float* beta2, int split, void* gy,
+                    float* ggamma, float* gbeta, float* ggamma2, float* gbeta2, float* sums, int n, int h, int w, int c,
+                    int flags, float alpha, int accumulate, int dtype, void* stream) {
   TG_CHECK(gz && y && mean && rstd && gamma && beta && gy && sums && n > 0 && h > 0 && w > 0 && c > 0, TG_EINVAL,
            "tg_norm_act_bwd: bad arguments");
+  if (!gamma2 || !beta2) split = n;
+  TG_CHECK(split >= 0 && split <= n, TG_EINVAL, "tg_norm_act_bwd: split %d outside [0, %d]", split, n);
   hipStream_t s = (hipStream_t)stream;
   const int hw = h * w;
   const int64_t npix = (int64_t)n * hw;
@@ -425,19 +443,20 @@ int tg_norm_act_bwd(const void* gz, const void* y, const float* pn_scale, const 
     }
     if (vec) {
       hipLaunchKernelGGL((norm_act_bwd1_kernel<T, VN>), dim3(chunks, n), dim3(256), lds, s, (const T*)gz, (const T*)y,
-                         pn_scale, mean, rstd, gamma, beta, (T*)gy, sums, hw, c, flags, alpha, ppb);
+                         pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)gy, sums, hw, c, flags, alpha, ppb);
       hipLaunchKernelGGL((norm_act_bwd2_kernel<T, VN>), dim3(tg_grid_for(npix * (c / VN), 256)), dim3(256), 0, s, (T*)gy,
-                         (const T*)y, mean, rstd, gamma, sums, npix, hw, c);
+                         (const T*)y, mean, rstd, gamma, gamma2, split, sums, npix, hw, c);
     } else {
       TG_CHECK(c <= 256, TG_ENOSUP, "tg_norm_act_bwd: scalar path needs c <= 256 (got %d)", c);
       hipLaunchKernelGGL((norm_act_bwd1_kernel<T, 1>), dim3(chunks, n), dim3(256), lds, s, (const T*)gz, (const T*)y,
-                         pn_scale, mean, rstd, gamma, beta, (T*)gy, sums, hw, c, flags, alpha, ppb);
+                         pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)gy, sums, hw, c, flags, alpha, ppb);
       hipLaunchKernelGGL((norm_act_bwd2_kernel<T, 1>), dim3(tg_grid_for(npix * c, 256)), dim3(256), 0, s, (T*)gy,
-                         (const T*)y, mean, rstd, gamma, sums, npix, hw, c);
+                         (const T*)y, mean, rstd, gamma, gamma2, split, sums, npix, hw, c);
     }
   });
-  if (ggamma || gbeta)
-    hipLaunchKernelGGL(norm_param_grads, dim3((c + 255) / 256), dim3(256), 0, s, sums, ggamma, gbeta, n, c, accumulate);
+  if (ggamma || gbeta || ggamma2 || gbeta2)
+    hipLaunchKernelGGL(norm_param_grads, dim3((c + 255) / 256, split < n ? 2 : 1), dim3(256), 0, s, sums, ggamma, gbeta,
+                       ggamma2, gbeta2, split, n, c, accumulate);
   TG_LAUNCH_CHECK("tg_norm_act_bwd");
   return TG_OK;
 }

@@ -15,6 +15,11 @@ __global__ __launch_bounds__(1024) void mbstd_fwd_kernel(const T* __restrict__ x
                                                          float eps) {
   __shared__ float red[16];
   const int P = hw * c;
+  // one workgroup per statistic group of n images (blockIdx.x): the reference computes the statistic per
+  // discriminator call; several calls batched along N keep their own statistic
+  x += (int64_t)blockIdx.x * n * P;
+  out += (int64_t)blockIdx.x * n * hw * cpad;
+  if (stat) stat += blockIdx.x;
   float acc = 0.f;
   for (int p = threadIdx.x; p < P; p += blockDim.x) {
     float mu = 0.f;
@@ -48,6 +53,9 @@ __global__ __launch_bounds__(1024) void mbstd_bwd_kernel(const T* __restrict__ g
                                                          T* __restrict__ gx, int n, int hw, int c, int cpad, float eps) {
   __shared__ float red[16];
   const int P = hw * c;
+  gout += (int64_t)blockIdx.x * n * hw * cpad;
+  x += (int64_t)blockIdx.x * n * P;
+  gx += (int64_t)blockIdx.x * n * P;
   float acc = 0.f;
   for (int i = threadIdx.x; i < n * hw; i += blockDim.x) acc += ld(gout + (int64_t)i * cpad + c);
   const float G = block_sum(acc, red);
@@ -80,6 +88,11 @@ __global__ __launch_bounds__(1024) void mbstd_bwd_bwd_kernel(const T* __restrict
                                                              float eps) {
   __shared__ float red[16];
   const int P = hw * c;
+  v += (int64_t)blockIdx.x * n * P;
+  gout += (int64_t)blockIdx.x * n * hw * cpad;
+  x += (int64_t)blockIdx.x * n * P;
+  if (ggout) ggout += (int64_t)blockIdx.x * n * hw * cpad;
+  if (gx2) gx2 += (int64_t)blockIdx.x * n * P;
   float acc = 0.f;
   for (int i = threadIdx.x; i < n * hw; i += blockDim.x) acc += ld(gout + (int64_t)i * cpad + c);
   const float G = block_sum(acc, red);
@@ -247,34 +260,37 @@ __global__ void adam_tick_kernel(int64_t* step, float* lr_t, float lr, float b1,
 
 extern "C" {
 
-int tg_mbstd_fwd(const void* x, void* out, float* stat, int n, int hw, int c, int cpad, float eps, int dtype,
+int tg_mbstd_fwd(const void* x, void* out, float* stat, int n, int groups, int hw, int c, int cpad, float eps, int dtype,
                  void* stream) {
   TG_CHECK(x && out && n > 0 && hw > 0 && c > 0 && cpad > c, TG_EINVAL, "tg_mbstd_fwd: bad arguments (cpad must exceed c)");
+  TG_CHECK(groups > 0 && n % groups == 0, TG_EINVAL, "tg_mbstd_fwd: n (%d) not divisible by groups (%d)", n, groups);
   TG_DISPATCH_DTYPE(dtype, "tg_mbstd_fwd", {
-    hipLaunchKernelGGL(mbstd_fwd_kernel<T>, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const T*)x, (T*)out, stat, n, hw,
-                       c, cpad, eps);
+    hipLaunchKernelGGL(mbstd_fwd_kernel<T>, dim3(groups), dim3(1024), 0, (hipStream_t)stream, (const T*)x, (T*)out, stat,
+                       n / groups, hw, c, cpad, eps);
   });
   TG_LAUNCH_CHECK("tg_mbstd_fwd");
   return TG_OK;
 }
 
-int tg_mbstd_bwd(const void* gout, const void* x, void* gx, int n, int hw, int c, int cpad, float eps, int dtype,
-                 void* stream) {
+int tg_mbstd_bwd(const void* gout, const void* x, void* gx, int n, int groups, int hw, int c, int cpad, float eps,
+                 int dtype, void* stream) {
   TG_CHECK(gout && x && gx && n > 0 && hw > 0 && c > 0 && cpad > c, TG_EINVAL, "tg_mbstd_bwd: bad arguments");
+  TG_CHECK(groups > 0 && n % groups == 0, TG_EINVAL, "tg_mbstd_bwd: n (%d) not divisible by groups (%d)", n, groups);
   TG_DISPATCH_DTYPE(dtype, "tg_mbstd_bwd", {
-    hipLaunchKernelGGL(mbstd_bwd_kernel<T>, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const T*)gout, (const T*)x,
-                       (T*)gx, n, hw, c, cpad, eps);
+    hipLaunchKernelGGL(mbstd_bwd_kernel<T>, dim3(groups), dim3(1024), 0, (hipStream_t)stream, (const T*)gout, (const T*)x,
+                       (T*)gx, n / groups, hw, c, cpad, eps);
   });
   TG_LAUNCH_CHECK("tg_mbstd_bwd");
   return TG_OK;
 }
 
-int tg_mbstd_bwd_bwd(const void* v, const void* gout, const void* x, void* ggout, void* gx2, int n, int hw, int c, int cpad,
-                     float eps, int dtype, void* stream) {
+int tg_mbstd_bwd_bwd(const void* v, const void* gout, const void* x, void* ggout, void* gx2, int n, int groups, int hw, int c,
+                     int cpad, float eps, int dtype, void* stream) {
   TG_CHECK(v && gout && x && n > 0 && hw > 0 && c > 0 && cpad > c, TG_EINVAL, "tg_mbstd_bwd_bwd: bad arguments");
+  TG_CHECK(groups > 0 && n % groups == 0, TG_EINVAL, "tg_mbstd_bwd_bwd: n (%d) not divisible by groups (%d)", n, groups);
   TG_DISPATCH_DTYPE(dtype, "tg_mbstd_bwd_bwd", {
-    hipLaunchKernelGGL(mbstd_bwd_bwd_kernel<T>, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const T*)v, (const T*)gout,
-                       (const T*)x, (T*)ggout, (T*)gx2, n, hw, c, cpad, eps);
+    hipLaunchKernelGGL(mbstd_bwd_bwd_kernel<T>, dim3(groups), dim3(1024), 0, (hipStream_t)stream, (const T*)v,
+                       (const T*)gout, (const T*)x, (T*)ggout, (T*)gx2, n / groups, hw, c, cpad, eps);
   });
   TG_LAUNCH_CHECK("tg_mbstd_bwd_bwd");
   return TG_OK;

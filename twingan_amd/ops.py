@@ -486,52 +486,56 @@ def pointwise_conv(x, w_hwio, bias=None, lrelu=False, alpha=LRELU_ALPHA):
 class NormActFn(torch.autograd.Function):
   """z = pixel_norm(lrelu(instance_norm(y; gamma, beta))) -- libs/instance_norm.py:131-135,
   util_misc.py:86, nets/pggan_utils.py:330-331.  First-order only (E/G never sit under the
-  gradient penalty)."""
+  gradient penalty).  With (gamma2, beta2, split) images [split, n) use the second domain's parameters."""
 
   @staticmethod
-  def forward(ctx, y, gamma, beta, flags, in_eps, pn_eps, alpha):
-    _chk(y, gamma, beta)
+  def forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha):
+    _chk(y, gamma, beta, gamma2, beta2)
     n, h, w, c = y.shape
+    split = n if gamma2 is None else int(split)
     mean = torch.empty(n * c, dtype=torch.float32, device=y.device)
     rstd = torch.empty(n * c, dtype=torch.float32, device=y.device)
     call('tg_instance_norm_stats', _p(y), _p(mean), _p(rstd), n, h, w, c, in_eps, _dt(y), _stream(),
          work=('in_stats', 0, y.numel() * _esize(y)))
     z = torch.empty_like(y)
     s = torch.empty(n * h * w, dtype=torch.float32, device=y.device) if (flags & NF_PIXNORM) else None
-    call('tg_norm_act_fwd', _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(z), _p(s), n, h, w, c, flags, alpha,
-         pn_eps, _dt(y), _stream(), work=('norm_act_fwd', 0, 2 * y.numel() * _esize(y)))
-    ctx.flags, ctx.alpha = flags, alpha
-    ctx.save_for_backward(y, mean, rstd, gamma, beta, s)
+    call('tg_norm_act_fwd', _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(gamma2), _p(beta2), split, _p(z), _p(s),
+         n, h, w, c, flags, alpha, pn_eps, _dt(y), _stream(), work=('norm_act_fwd', 0, 2 * y.numel() * _esize(y)))
+    ctx.flags, ctx.alpha, ctx.split = flags, alpha, split
+    ctx.save_for_backward(y, mean, rstd, gamma, beta, gamma2, beta2, s)
     return z
 
   @staticmethod
   @torch.autograd.function.once_differentiable
   def backward(ctx, gz):
-    y, mean, rstd, gamma, beta, s = ctx.saved_tensors
+    y, mean, rstd, gamma, beta, gamma2, beta2, s = ctx.saved_tensors
     gz = gz.contiguous()
     n, h, w, c = y.shape
     gy = torch.empty_like(y)
     sums = torch.empty(2 * n * c, dtype=torch.float32, device=y.device)
-    sg, sb = GradSink.get(gamma), GradSink.get(beta)
-    sunk = sg is not None and sb is not None
+    two = gamma2 is not None
+    params = [gamma, beta] + ([gamma2, beta2] if two else [])
+    sinks = [GradSink.get(q) for q in params]
+    sunk = all(t is not None for t in sinks)
     if _State.skip_param_grads:
-      gg = gb = None
+      outs = [None] * 4
     elif sunk:
-      gg, gb = sg, sb
+      outs = sinks + [None] * (4 - len(sinks))
     else:
-      gg = torch.empty(c, dtype=torch.float32, device=y.device)
-      gb = torch.empty(c, dtype=torch.float32, device=y.device)
-    call('tg_norm_act_bwd', _p(gz), _p(y), _p(s), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(gy), _p(gg), _p(gb),
-         _p(sums), n, h, w, c, ctx.flags, ctx.alpha, 1 if sunk else 0, _dt(y), _stream(),
+      outs = [torch.empty(c, dtype=torch.float32, device=y.device) for _ in params] + [None] * (4 - len(params))
+    call('tg_norm_act_bwd', _p(gz), _p(y), _p(s), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(gamma2), _p(beta2),
+         ctx.split, _p(gy), _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), _p(sums), n, h, w, c, ctx.flags, ctx.alpha,
+         1 if (sunk and not _State.skip_param_grads) else 0, _dt(y), _stream(),
          work=('norm_act_bwd', 0, 3 * y.numel() * _esize(y)))
     if sunk or _State.skip_param_grads:
-      gg = gb = None
-    return gy, gg, gb, None, None, None, None
+      outs = [None] * 4
+    return gy, outs[0], outs[1], outs[2], outs[3], None, None, None, None, None
 
 
-def norm_act(y, gamma, beta, lrelu=True, pixel_norm=True, in_eps=1e-6, pn_eps=1e-6, alpha=LRELU_ALPHA):
+def norm_act(y, gamma, beta, lrelu=True, pixel_norm=True, in_eps=1e-6, pn_eps=1e-6, alpha=LRELU_ALPHA, gamma2=None,
+             beta2=None, split=None):
   flags = (NF_LRELU if lrelu else 0) | (NF_PIXNORM if pixel_norm else 0)
-  return NormActFn.apply(y, gamma, beta, flags, in_eps, pn_eps, alpha)
+  return NormActFn.apply(y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -651,31 +655,32 @@ def _mbstd_eps(dtype):
 
 
 class MbstdFn(torch.autograd.Function):
-  """[n,h,w,c] -> [n,h,w,cpad]: x, the batch-stddev statistic in channel c, zeros above."""
+  """[n,h,w,c] -> [n,h,w,cpad]: x, the batch-stddev statistic in channel c, zeros above.  ``groups``
+  consecutive sub-batches (discriminator calls batched along N) each keep their own statistic."""
 
   @staticmethod
-  def forward(ctx, x, cpad):
+  def forward(ctx, x, cpad, groups):
     _chk(x)
     n, h, w, c = x.shape
     out = torch.empty((n, h, w, cpad), dtype=x.dtype, device=x.device)
-    call('tg_mbstd_fwd', _p(x), _p(out), None, n, h * w, c, cpad, _mbstd_eps(x.dtype), _dt(x), _stream())
-    ctx.cpad = cpad
+    call('tg_mbstd_fwd', _p(x), _p(out), None, n, groups, h * w, c, cpad, _mbstd_eps(x.dtype), _dt(x), _stream())
+    ctx.cpad, ctx.groups = cpad, groups
     ctx.save_for_backward(x)
     return out
 
   @staticmethod
   def backward(ctx, gout):
     x, = ctx.saved_tensors
-    return MbstdBwdFn.apply(gout.contiguous(), x, ctx.cpad), None
+    return MbstdBwdFn.apply(gout.contiguous(), x, ctx.cpad, ctx.groups), None, None
 
 
 class MbstdBwdFn(torch.autograd.Function):
   @staticmethod
-  def forward(ctx, gout, x, cpad):
+  def forward(ctx, gout, x, cpad, groups):
     n, h, w, c = x.shape
     gx = torch.empty_like(x)
-    call('tg_mbstd_bwd', _p(gout), _p(x), _p(gx), n, h * w, c, cpad, _mbstd_eps(x.dtype), _dt(x), _stream())
-    ctx.cpad = cpad
+    call('tg_mbstd_bwd', _p(gout), _p(x), _p(gx), n, groups, h * w, c, cpad, _mbstd_eps(x.dtype), _dt(x), _stream())
+    ctx.cpad, ctx.groups = cpad, groups
     ctx.save_for_backward(gout, x)
     return gx
 
@@ -687,13 +692,13 @@ class MbstdBwdFn(torch.autograd.Function):
     n, h, w, c = x.shape
     ggout = torch.empty_like(gout) if ctx.needs_input_grad[0] else None
     gx2 = torch.empty_like(x) if ctx.needs_input_grad[1] else None
-    call('tg_mbstd_bwd_bwd', _p(v), _p(gout), _p(x), _p(ggout), _p(gx2), n, h * w, c, ctx.cpad, _mbstd_eps(x.dtype),
-         _dt(x), _stream())
-    return ggout, gx2, None
+    call('tg_mbstd_bwd_bwd', _p(v), _p(gout), _p(x), _p(ggout), _p(gx2), n, ctx.groups, h * w, c, ctx.cpad,
+         _mbstd_eps(x.dtype), _dt(x), _stream())
+    return ggout, gx2, None, None
 
 
-def minibatch_state_concat(x, cpad):
-  return MbstdFn.apply(x, cpad)
+def minibatch_state_concat(x, cpad, groups=1):
+  return MbstdFn.apply(x, cpad, int(groups))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -19,13 +19,20 @@ from .params import get_num_channels, max_stage_of, mbstd_cpad
 def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pixel_norm=True):
   """maybe_pixel_norm(maybe_equalized_conv2d(...)) for the generator / encoder arg-scope
   (nets/pggan_utils.py:86-98,236-245): conv without bias, per-domain instance norm, LeakyReLU(0.2),
-  then pixel norm (nets/pggan.py:78-81)."""
+  then pixel norm (nets/pggan.py:78-81).  ``domain`` is 's' | 't', or (d0, d1, split): the batch holds
+  ``split`` images of domain d0 followed by images of domain d1 (two reference passes as one launch)."""
   w = P[scope + '/weights']
   if k == 1 and (w.shape[2] <= 4 or w.shape[3] <= 4):
     y = ops.pointwise_conv(x, w)
   else:
     y = ops.conv2d(x, w, None, k, padding)
   if cfg.generator_norm_type == 'instance_norm':
+    if isinstance(domain, tuple):
+      d0, d1, split = domain
+      return ops.norm_act(y, P['%s/InstanceNorm/gamma_%s' % (scope, d0)], P['%s/InstanceNorm/beta_%s' % (scope, d0)],
+                          lrelu=activation, pixel_norm=pixel_norm and cfg.do_pixel_norm,
+                          gamma2=P['%s/InstanceNorm/gamma_%s' % (scope, d1)],
+                          beta2=P['%s/InstanceNorm/beta_%s' % (scope, d1)], split=split)
     return ops.norm_act(y, P['%s/InstanceNorm/gamma_%s' % (scope, domain)],
                         P['%s/InstanceNorm/beta_%s' % (scope, domain)], lrelu=activation,
                         pixel_norm=pixel_norm and cfg.do_pixel_norm)
@@ -139,7 +146,7 @@ def generator(P, source, domain, cfg, unet_end_points=None, top='generator'):
 # ------------------------------------------------------------------------------------------------
 # discriminator (nets/pggan.py:217-376)
 # ------------------------------------------------------------------------------------------------
-def discriminator_before_fc(P, source, cfg, top):
+def discriminator_before_fc(P, source, cfg, top, groups=1):
   hw = source.shape[1]
   max_stage = max_stage_of(hw)
   assert max_stage >= 0
@@ -167,7 +174,7 @@ def discriminator_before_fc(P, source, cfg, top):
       net = ops.lerp(net, shrinked, cfg.alpha_grow)
       end_points['encoder_block_interpolated_%dx%dx%d' % (current_hw, current_hw, num_channels)] = net
   blk = 'before_fc_1x1x%d' % cfg.max_ch
-  net = ops.minibatch_state_concat(net, mbstd_cpad(net.shape[3]))      # pggan_utils.py:353-366
+  net = ops.minibatch_state_concat(net, mbstd_cpad(net.shape[3]), groups)      # pggan_utils.py:353-366
   net = _d_conv(P, '%s/%s/Conv' % (top, blk), net, k=3, padding='SAME')
   net = _d_conv(P, '%s/%s/Conv_1' % (top, blk), net, k=4, padding='VALID')
   end_points[blk] = net
@@ -175,8 +182,10 @@ def discriminator_before_fc(P, source, cfg, top):
   return net, end_points
 
 
-def discriminator(P, source, cfg, top):
-  net, end_points = discriminator_before_fc(P, source, cfg, top)
+def discriminator(P, source, cfg, top, groups=1):
+  """``groups`` > 1: ``source`` is that many discriminator calls batched along N (each keeps its own
+  minibatch-stddev statistic, as separate reference calls would)."""
+  net, end_points = discriminator_before_fc(P, source, cfg, top, groups)
   feat = net.reshape(net.shape[0], -1)                                 # tf.squeeze(net, (1, 2))
   pred = ops.fully_connected(feat, P[top + '/prediction/fully_connected/weights'],
                              P[top + '/prediction/fully_connected/biases'])

@@ -33,16 +33,31 @@ def get_growing_image(img, alpha):
   return ops.lerp(img, low, alpha)
 
 
+def _skip_names(ep):
+  return [k for k in ep if k.startswith('encoder_block_')]
+
+
 def forward_generators(P, sources, targets, cfg):
-  """twingan.py:198-269: E(s), E(t) and the four generator passes (shared conv weights, per-domain
-  norm parameters, UNet skips from the encoder whose content is decoded)."""
-  es, es_ep = pggan.encoder_before_classification(P, sources, 's', cfg)
-  et, et_ep = pggan.encoder_before_classification(P, targets, 't', cfg)
-  u = cfg.use_unet
-  s_prime, _ = pggan.generator(P, et, 's', cfg, et_ep if u else None)     # target content -> source domain
-  s_cycle, _ = pggan.generator(P, es, 's', cfg, es_ep if u else None)
-  t_prime, _ = pggan.generator(P, es, 't', cfg, es_ep if u else None)
-  t_cycle, _ = pggan.generator(P, et, 't', cfg, et_ep if u else None)
+  """twingan.py:198-269: E(s), E(t) and the four generator passes (shared conv weights, per-domain norm
+  parameters, UNet skips from the encoder whose content is decoded).
+
+  The reference builds six separate towers; here passes that share conv weights run as ONE batch along N --
+  E([s; t]) with domains (s, t), and G([E(t); E(s); E(s); E(t)]) with domains (s, s, t, t) = s', s_cyc, t', t_cyc --
+  because the low-resolution layers cannot fill 256 CUs with 16 images (instance-norm statistics are per image
+  and the norm kernels pick gamma/beta per image, so the results are those of the separate passes)."""
+  b = sources.shape[0]
+  x = torch.cat([sources, targets], dim=0)
+  e, ep = pggan.encoder_before_classification(P, x, ('s', 't', b), cfg)
+  es, et = e.chunk(2)
+  content = torch.cat([et, es, es, et], dim=0)
+  unet = None
+  if cfg.use_unet:
+    unet = {}
+    for k in _skip_names(ep):
+      vs, vt = ep[k].chunk(2)
+      unet[k] = torch.cat([vt, vs, vs, vt], dim=0)
+  out, _ = pggan.generator(P, content, ('s', 't', 2 * b), cfg, unet)
+  s_prime, s_cycle, t_prime, t_cycle = out.chunk(4)
   return dict(es=es, et=et, s_prime=s_prime, s_cycle=s_cycle, t_prime=t_prime, t_cycle=t_cycle)
 
 
@@ -51,20 +66,25 @@ def generator_loss(P, sources, targets, cfg):
   assert cfg.loss_architecture in ('wgan_gp', 'wgan'), cfg.loss_architecture
   if cfg.is_growing:
     sources, targets = get_growing_image(sources, cfg.alpha_grow), get_growing_image(targets, cfg.alpha_grow)
+  b = sources.shape[0]
   o = forward_generators(P, sources, targets, cfg)
-  e_tp, _ = pggan.encoder_before_classification(P, o['t_prime'], 't', cfg)       # twingan.py:275-288
-  e_sp, _ = pggan.encoder_before_classification(P, o['s_prime'], 's', cfg)
+  # re-encode s' in domain s and t' in domain t as one batch (twingan.py:275-288)
+  e2, _ = pggan.encoder_before_classification(P, torch.cat([o['s_prime'], o['t_prime']], dim=0), ('s', 't', b), cfg)
+  e_sp, e_tp = e2.chunk(2)
+  cyc_gan = cfg.hw >= 64 and cfg.do_l_cyc_gan
   terms = {}
   for d, orig, prime, cyc, enc_orig, enc_opp_prime in (
       ('s', sources, o['s_prime'], o['s_cycle'], o['es'], e_tp),
       ('t', targets, o['t_prime'], o['t_cycle'], o['et'], e_sp)):
     top = 'discriminator_' + d
     terms['l_cyc_' + d] = ops.abs_diff_mean(orig, cyc, cfg.l_cyc_weight)
-    if cfg.hw >= 64 and cfg.do_l_cyc_gan:
-      pc, _ = pggan.discriminator(P, cyc, cfg, top)
-      terms['generator_fool_loss_cycle_' + d] = ops.mean(pc, -cfg.gan_weight)
-    pp, _ = pggan.discriminator(P, prime, cfg, top)
-    terms['generator_fool_loss_prime_' + d] = ops.mean(pp, -cfg.gan_weight)
+    if cyc_gan:      # D(cyc) and D(prime) of one domain share weights: one batch, two minibatch-stddev groups
+      pred, _ = pggan.discriminator(P, torch.cat([cyc, prime], dim=0), cfg, top, groups=2)
+      pc, pp = pred.chunk(2)
+      terms['generator_fool_loss_cycle_' + d] = ops.mean(pc.contiguous(), -cfg.gan_weight)
+    else:
+      pp, _ = pggan.discriminator(P, prime, cfg, top)
+    terms['generator_fool_loss_prime_' + d] = ops.mean(pp.contiguous(), -cfg.gan_weight)
     if cfg.l_content_weight:
       terms['l_content_' + d] = ops.abs_diff_mean(enc_orig, enc_opp_prime, cfg.l_content_weight)
   total = None
@@ -81,16 +101,21 @@ def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t):
     if cfg.is_growing:
       sources, targets = get_growing_image(sources, cfg.alpha_grow), get_growing_image(targets, cfg.alpha_grow)
     o = forward_generators(P, sources, targets, cfg)
+  cyc_gan = cfg.hw >= 64 and cfg.do_l_cyc_gan
   terms = {}
   for d, real, prime, cyc, a in (('s', sources, o['s_prime'], o['s_cycle'], gp_alpha_s),
                                  ('t', targets, o['t_prime'], o['t_cycle'], gp_alpha_t)):
     top = 'discriminator_' + d
-    pr, _ = pggan.discriminator(P, real, cfg, top)
+    # D(real), D(cyc), D(prime) of one domain share weights: one batch, one minibatch-stddev group per call
+    if cyc_gan:
+      pred, _ = pggan.discriminator(P, torch.cat([real, cyc, prime], dim=0), cfg, top, groups=3)
+      pr, pc, pp = (t.contiguous() for t in pred.chunk(3))
+    else:
+      pred, _ = pggan.discriminator(P, torch.cat([real, prime], dim=0), cfg, top, groups=2)
+      pr, pp = (t.contiguous() for t in pred.chunk(2))
     mean_real = ops.mean(pr, cfg.gan_weight)
-    if cfg.hw >= 64 and cfg.do_l_cyc_gan:
-      pc, _ = pggan.discriminator(P, cyc, cfg, top)
+    if cyc_gan:
       terms['discriminator_loss_cycle_' + d] = ops.mean(pc, cfg.gan_weight) - mean_real
-    pp, _ = pggan.discriminator(P, prime, cfg, top)
     terms['discriminator_loss_prime_' + d] = ops.mean(pp, cfg.gan_weight) - mean_real
     if cfg.wgan_drift_loss_weight:
       raise NotImplementedError('wgan_drift_loss_weight (image_generation.py:360-367) is off in every BASELINE config')
