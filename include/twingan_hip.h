@@ -141,13 +141,17 @@ int tg_channel_sum(const void* g, float* out, int64_t npix, int c, int accumulat
 /* ---------------------------------------------------------------------------------------------
  * Resampling / concat / fade-in.
  * ------------------------------------------------------------------------------------------- */
-/* out[n,2h,2w,c0+c1] = concat(nearest_up2(x0[n,h,w,c0]), x1[n,2h,2w,c1]); c1 == 0 -> plain upsample.
- * nets/pggan_utils.py:349-350 + :281-298 (generator features first). */
-int tg_upsample2x_concat_fwd(const void* x0, const void* x1, void* out, int n, int h, int w, int c0, int c1, int dtype,
-                             void* stream);
-/* g0[n,h,w,c0] = 2x2 sum of gout[..., :c0];  g1 = gout[..., c0:]  (either may be NULL to skip) */
-int tg_upsample2x_concat_bwd(const void* gout, void* g0, void* g1, int n, int h, int w, int c0, int c1, int dtype,
-                             void* stream);
+/* out[n,2h,2w,c0+c1] = concat(nearest_up2(x0[n,h,w,c0]), x1[n',2h,2w,c1]); c1 == 0 -> plain upsample.
+ * nets/pggan_utils.py:349-350 + :281-298 (generator features first).
+ * gsz == 0: n' = n, image i reads skip image i.  gsz > 0: the n images are n/gsz (<= 4) groups of gsz; output
+ * group k reads skip group (perm >> 8k) & 0xff -- the four generator passes batched along N read the UNet skips
+ * of the two encoder passes without materialising copies (TwinGAN: perm = E(t), E(s), E(s), E(t)). */
+int tg_upsample2x_concat_fwd(const void* x0, const void* x1, void* out, int n, int h, int w, int c0, int c1, int gsz,
+                             unsigned perm, int dtype, void* stream);
+/* g0[n,h,w,c0] = 2x2 sum of gout[..., :c0];  g1[n',...] = gout[..., c0:] summed over the output groups that read
+ * the skip image (either may be NULL to skip) */
+int tg_upsample2x_concat_bwd(const void* gout, void* g0, void* g1, int n, int h, int w, int c0, int c1, int gsz,
+                             unsigned perm, int dtype, void* stream);
 /* tf.nn.avg_pool 2x2 s2 VALID (nets/pggan.py:274,306,436,468): y[n,h/2,w/2,c]; scale=0.25.
  * With scale=1 it is the 2x2 sum (upsample backward). */
 int tg_pool2x2_fwd(const void* x, void* y, int n, int h, int w, int c, float scale, int dtype, void* stream);

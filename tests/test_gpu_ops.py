@@ -514,3 +514,23 @@ def test_mbstd_groups_equal_separate_calls(ops):
     oi.backward(go[2 * g:2 * g + 2].contiguous())
     assert rel_l2(host(out[2 * g:2 * g + 2]), host(oi)) < 1e-6
     assert rel_l2(host(x.grad[2 * g:2 * g + 2]), host(xi.grad)) < 1e-5
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_upsample_concat_group_permutation(ops, dtype):
+  """Four generator passes batched along N read the skips of the [s; t] encoder batch as groups (t, s, s, t)."""
+  rng = np.random.RandomState(23)
+  gsz, perm = 2, (1, 0, 0, 1)
+  x0 = to_dev(bf16_round(rng.randn(8, 3, 4, 8)), dtype).requires_grad_(True)
+  x1 = to_dev(bf16_round(rng.randn(4, 6, 8, 16)), dtype).requires_grad_(True)
+  out = ops.upsample2x_concat(x0, x1, gsz, perm)
+  go = to_dev(bf16_round(rng.randn(8, 6, 8, 24)), dtype)
+  out.backward(go)
+  a = x0.detach().clone().requires_grad_(True)
+  b = x1.detach().clone().requires_grad_(True)
+  bs, bt = b[:2], b[2:]
+  ref = ops.upsample2x_concat(a, torch.cat([bt, bs, bs, bt], dim=0).contiguous())
+  ref.backward(go)
+  assert np.array_equal(host(out), host(ref))
+  assert rel_l2(host(x0.grad), host(a.grad)) < 1e-6
+  assert rel_l2(host(x1.grad), host(b.grad)) < (1e-6 if dtype == torch.float32 else 1e-2)

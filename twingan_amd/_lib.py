@@ -50,8 +50,8 @@ SIGNATURES = {
     'tg_lrelu_bwd': (c_int, [_P, _P, _P, c_int64, c_float, c_int, _P]),
     'tg_lrelu_bwd_bias': (c_int, [_P, _P, _P, _FP, c_int64, c_int, c_float, c_int, c_int, _P]),
     'tg_channel_sum': (c_int, [_P, _FP, c_int64, c_int, c_int, c_int, _P]),
-    'tg_upsample2x_concat_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
-    'tg_upsample2x_concat_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'tg_upsample2x_concat_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint, c_int, _P]),
+    'tg_upsample2x_concat_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint, c_int, _P]),
     'tg_pool2x2_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     'tg_pool2x2_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     'tg_axpby': (c_int, [_P, _P, _P, c_int64, c_float, c_float, c_int, _P]),

@@ -104,7 +104,7 @@ __global__ void sample_scale_kernel(const T* __restrict__ x, const float* __rest
 // ------------------------------------------------------------------------------------------------
 template <typename T, int V>
 __global__ void upsample_concat_fwd_kernel(const T* __restrict__ x0, const T* __restrict__ x1, T* __restrict__ out, int n,
-                                           int h, int w, int c0, int c1) {
+                                           int h, int w, int c0, int c1, int gsz, unsigned perm) {
   const int c = c0 + c1, cv = c / V, c0v = c0 / V;
   const int64_t total = (int64_t)n * (2 * h) * (2 * w) * cv;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -114,8 +114,10 @@ __global__ void upsample_concat_fwd_kernel(const T* __restrict__ x0, const T* __
     p /= 2 * w;
     const int oy = (int)(p % (2 * h));
     const int in_ = (int)(p / (2 * h));
+    // skip source image: identity, or group permutation (out group k of gsz images reads x1 group perm[k])
+    const int i1 = gsz ? (int)((perm >> (8 * (in_ / gsz))) & 0xffu) * gsz + in_ % gsz : in_;
     const T* src = (v < c0v) ? x0 + (((int64_t)in_ * h + (oy >> 1)) * w + (ox >> 1)) * c0 + v * V
-                             : x1 + (((int64_t)in_ * 2 * h + oy) * (2 * w) + ox) * c1 + (v - c0v) * V;
+                             : x1 + (((int64_t)i1 * 2 * h + oy) * (2 * w) + ox) * c1 + (v - c0v) * V;
     T* dst = out + (((int64_t)in_ * 2 * h + oy) * (2 * w) + ox) * c + v * V;
     if (V == 1)
       *dst = *src;
@@ -126,11 +128,12 @@ __global__ void upsample_concat_fwd_kernel(const T* __restrict__ x0, const T* __
 
 template <typename T, int V>
 __global__ void upsample_concat_bwd_kernel(const T* __restrict__ go, T* __restrict__ g0, T* __restrict__ g1, int n, int h,
-                                           int w, int c0, int c1) {
-  // g0: one thread per (input pixel, vector) sums its 2x2 block; g1: copy of the tail channels.
+                                           int w, int c0, int c1, int gsz, unsigned perm, int n1) {
+  // g0: one thread per (input pixel, vector) sums its 2x2 block; g1: copy of the tail channels (summed over
+  // the output groups that read the same skip image when a group permutation is in use).
   const int c = c0 + c1, c0v = c0 / V, c1v = c1 / V;
   const int64_t t0 = g0 ? (int64_t)n * h * w * c0v : 0;
-  const int64_t t1 = g1 ? (int64_t)n * 4 * h * w * c1v : 0;
+  const int64_t t1 = g1 ? (int64_t)n1 * 4 * h * w * c1v : 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < t0 + t1; i += (int64_t)gridDim.x * blockDim.x) {
     if (i < t0) {
       const int v = (int)(i % c0v);
@@ -167,13 +170,42 @@ __global__ void upsample_concat_bwd_kernel(const T* __restrict__ go, T* __restri
     } else {
       const int64_t k = i - t0;
       const int v = (int)(k % c1v);
-      const int64_t p = k / c1v;      // output pixel linear index
-      const T* src = go + p * c + c0 + v * V;
+      const int64_t p = k / c1v;      // skip-tensor pixel linear index (image-major)
       T* dst = g1 + p * c1 + v * V;
-      if (V == 1)
-        *dst = *src;
-      else
-        stv(dst, ldv(src));
+      if (!gsz) {
+        const T* src = go + p * c + c0 + v * V;
+        if (V == 1)
+          *dst = *src;
+        else
+          stv(dst, ldv(src));
+      } else {
+        const int64_t ipx = (int64_t)4 * h * w;
+        const int j = (int)(p / ipx);                 // skip image
+        const int64_t q = p - (int64_t)j * ipx;
+        const int sg = j / gsz, jj = j - sg * gsz;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        for (int og = 0; og < n / gsz; ++og) {
+          if ((int)((perm >> (8 * og)) & 0xffu) != sg) continue;
+          const T* src = go + (((int64_t)(og * gsz + jj)) * ipx + q) * c + c0 + v * V;
+          if (V == 1) {
+            acc[0] += ld(src);
+          } else {
+            Vec16<T> sv = ldv(src);
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += sv.get(e);
+          }
+        }
+        if (V == 1) {
+          st(dst, acc[0]);
+        } else {
+          Vec16<T> o;
+#pragma unroll
+          for (int e = 0; e < V; ++e) o.set(e, acc[e]);
+          stv(dst, o);
+        }
+      }
     }
   }
 }
@@ -267,8 +299,46 @@ __global__ void pw_small_in_kernel(const T* __restrict__ x, const float* __restr
   for (int i = threadIdx.x; i < cout; i += blockDim.x) sw[cin * cout + i] = (epi & TG_EPI_BIAS) ? bias[i] : 0.f;
   __syncthreads();
   const int cv = cout / V;
+  const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  if (cv <= 256 && (cv & (cv - 1)) == 0) {
+    // fast path (cv divides the thread count): a thread keeps ONE channel vector for its whole life, so its
+    // cin x V weights and biases sit in registers and the pixel loop has no division and no LDS traffic
+    const int v = (int)(gtid % cv);
+    float wr[4][V], br[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      br[j] = sw[cin * cout + v * V + j];
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) wr[ci][j] = ci < cin ? sw[ci * cout + v * V + j] : 0.f;
+    }
+    const int64_t pstride = nthreads / cv;
+    for (int64_t p = gtid / cv; p < npix; p += pstride) {
+      float xin[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int ci = 0; ci < cin; ++ci) xin[ci] = ld(x + p * cin + ci);
+      float acc[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float a = br[j];
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) a = fmaf(xin[ci], wr[ci][j], a);
+        if (epi & TG_EPI_LRELU) a = lrelu_f(a, alpha);
+        acc[j] = a;
+      }
+      T* dst = y + p * cout + v * V;
+      if (V == 1) {
+        st(dst, acc[0]);
+      } else {
+        Vec16<T> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) o.set(j, acc[j]);
+        stv(dst, o);
+      }
+    }
+    return;
+  }
   const int64_t total = npix * cv;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = gtid; i < total; i += nthreads) {
     const int v = (int)(i % cv);
     const int64_t p = i / cv;
     float xin[4];
@@ -360,6 +430,21 @@ __global__ void pw_wgrad_kernel(const T* __restrict__ small, const T* __restrict
         for (int j = 0; j < V; ++j) acc[s][j] = fmaf(sv, bv[j], acc[s][j]);
       }
     }
+  }
+  if (cv <= 64 && (cv & (cv - 1)) == 0) {
+    // sum the pixel lanes of a wave that own the same channel vector first: cv lanes per wave touch LDS
+    for (int o = cv; o < 64; o <<= 1) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[s][j] += __shfl_xor(acc[s][j], o, 64);
+    }
+    if ((int)(threadIdx.x & 63) < cv) {
+      for (int s = 0; s < ns; ++s)
+#pragma unroll
+        for (int j = 0; j < V; ++j) atomicAdd(&sacc[s * cb + v * V + j], acc[s][j]);
+    }
+  } else if (pl < lanes) {
     for (int s = 0; s < ns; ++s)
 #pragma unroll
       for (int j = 0; j < V; ++j) atomicAdd(&sacc[s * cb + v * V + j], acc[s][j]);
@@ -515,29 +600,49 @@ int tg_sample_scale(const void* x, const float* coef, const float* scalar, void*
                          __VA_ARGS__);                                                                                 \
   })
 
-int tg_upsample2x_concat_fwd(const void* x0, const void* x1, void* out, int n, int h, int w, int c0, int c1, int dtype,
-                             void* stream) {
+static int check_perm(const char* who, int n, int gsz, unsigned perm, int* n1) {
+  *n1 = n;
+  if (!gsz) return TG_OK;
+  TG_CHECK(gsz > 0 && n % gsz == 0 && n / gsz <= 4, TG_EINVAL, "%s: n (%d) must be 1..4 groups of gsz (%d)", who, n, gsz);
+  int mx = 0;
+  for (int k = 0; k < n / gsz; ++k) {
+    const int v = (int)((perm >> (8 * k)) & 0xffu);
+    if (v > mx) mx = v;
+  }
+  TG_CHECK(mx < 4, TG_EINVAL, "%s: permutation entry %d out of range", who, mx);
+  *n1 = (mx + 1) * gsz;
+  return TG_OK;
+}
+
+int tg_upsample2x_concat_fwd(const void* x0, const void* x1, void* out, int n, int h, int w, int c0, int c1, int gsz,
+                             unsigned perm, int dtype, void* stream) {
   TG_CHECK(x0 && out && n > 0 && h > 0 && w > 0 && c0 > 0 && c1 >= 0 && (c1 == 0 || x1), TG_EINVAL,
            "tg_upsample2x_concat_fwd: bad arguments");
+  int n1;
+  int rc = check_perm("tg_upsample2x_concat_fwd", n, gsz, perm, &n1);
+  if (rc) return rc;
 #define VOK(V) (c0 % V == 0 && c1 % V == 0)
 #define TV(V) ((int64_t)n * 4 * h * w * ((c0 + c1) / V))
   TG_SPATIAL_LAUNCH(upsample_concat_fwd_kernel, VOK, TV, (int64_t)n * 4 * h * w * (c0 + c1), (const T*)x0, (const T*)x1,
-                    (T*)out, n, h, w, c0, c1);
+                    (T*)out, n, h, w, c0, c1, gsz, perm);
 #undef VOK
 #undef TV
   TG_LAUNCH_CHECK("tg_upsample2x_concat_fwd");
   return TG_OK;
 }
 
-int tg_upsample2x_concat_bwd(const void* gout, void* g0, void* g1, int n, int h, int w, int c0, int c1, int dtype,
-                             void* stream) {
+int tg_upsample2x_concat_bwd(const void* gout, void* g0, void* g1, int n, int h, int w, int c0, int c1, int gsz,
+                             unsigned perm, int dtype, void* stream) {
   TG_CHECK(gout && n > 0 && h > 0 && w > 0 && c0 > 0 && c1 >= 0, TG_EINVAL, "tg_upsample2x_concat_bwd: bad arguments");
   if (c1 == 0) g1 = nullptr;
   if (!g0 && !g1) return TG_OK;
+  int n1;
+  int rc = check_perm("tg_upsample2x_concat_bwd", n, gsz, perm, &n1);
+  if (rc) return rc;
 #define VOK(V) (c0 % V == 0 && c1 % V == 0)
-#define TV(V) ((int64_t)n * h * w * (c0 / V) + (int64_t)n * 4 * h * w * (c1 / V))
-  TG_SPATIAL_LAUNCH(upsample_concat_bwd_kernel, VOK, TV, (int64_t)n * h * w * c0 + (int64_t)n * 4 * h * w * c1,
-                    (const T*)gout, (T*)g0, (T*)g1, n, h, w, c0, c1);
+#define TV(V) ((int64_t)n * h * w * (c0 / V) + (int64_t)n1 * 4 * h * w * (c1 / V))
+  TG_SPATIAL_LAUNCH(upsample_concat_bwd_kernel, VOK, TV, (int64_t)n * h * w * c0 + (int64_t)n1 * 4 * h * w * c1,
+                    (const T*)gout, (T*)g0, (T*)g1, n, h, w, c0, c1, gsz, perm, n1);
 #undef VOK
 #undef TV
   TG_LAUNCH_CHECK("tg_upsample2x_concat_bwd");

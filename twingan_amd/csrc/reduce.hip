@@ -21,29 +21,72 @@ __global__ __launch_bounds__(1024) void mbstd_fwd_kernel(const T* __restrict__ x
   out += (int64_t)blockIdx.x * n * hw * cpad;
   if (stat) stat += blockIdx.x;
   float acc = 0.f;
-  for (int p = threadIdx.x; p < P; p += blockDim.x) {
-    float mu = 0.f;
-    for (int i = 0; i < n; ++i) mu += ld(x + (int64_t)i * P + p);
-    mu /= (float)n;
-    float var = 0.f;
-    for (int i = 0; i < n; ++i) {
-      const float d = ld(x + (int64_t)i * P + p) - mu;
-      var = fmaf(d, d, var);
+  constexpr int V = Vec16<T>::N;
+  if (P % V == 0 && n <= 32) {
+    // 16-byte loads: a thread owns V consecutive positions and keeps the n samples' vectors in flight together
+    for (int p = threadIdx.x * V; p < P; p += blockDim.x * V) {
+      float mu[V], var[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) mu[j] = var[j] = 0.f;
+      for (int i = 0; i < n; ++i) {
+        const Vec16<T> xv = ldv(x + (int64_t)i * P + p);
+#pragma unroll
+        for (int j = 0; j < V; ++j) mu[j] += xv.get(j);
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) mu[j] /= (float)n;
+      for (int i = 0; i < n; ++i) {
+        const Vec16<T> xv = ldv(x + (int64_t)i * P + p);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const float d = xv.get(j) - mu[j];
+          var[j] = fmaf(d, d, var[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc += sqrtf(var[j] / (float)n + eps);
     }
-    acc += sqrtf(var / (float)n + eps);
+  } else {
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+      float mu = 0.f;
+      for (int i = 0; i < n; ++i) mu += ld(x + (int64_t)i * P + p);
+      mu /= (float)n;
+      float var = 0.f;
+      for (int i = 0; i < n; ++i) {
+        const float d = ld(x + (int64_t)i * P + p) - mu;
+        var = fmaf(d, d, var);
+      }
+      acc += sqrtf(var / (float)n + eps);
+    }
   }
   const float val = block_sum(acc, red) / (float)P;
   if (threadIdx.x == 0 && stat) stat[0] = val;
   const int64_t total = (int64_t)n * hw * cpad;
-  for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
-    const int ch = (int)(i % cpad);
-    const int64_t px = i / cpad;
-    float v = 0.f;
-    if (ch < c)
-      v = ld(x + px * c + ch);
-    else if (ch == c)
-      v = val;
-    st(out + i, v);
+  if (c % V == 0 && cpad % V == 0) {
+    const int cvp = cpad / V;
+    for (int64_t i = threadIdx.x; i < total / V; i += blockDim.x) {
+      const int cb = (int)(i % cvp) * V;
+      const int64_t px = i / cvp;
+      Vec16<T> o;
+      if (cb < c) {
+        o = ldv(x + px * c + cb);
+      } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) o.set(j, (cb + j == c) ? val : 0.f);
+      }
+      stv(out + px * cpad + cb, o);
+    }
+  } else {
+    for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
+      const int ch = (int)(i % cpad);
+      const int64_t px = i / cpad;
+      float v = 0.f;
+      if (ch < c)
+        v = ld(x + px * c + ch);
+      else if (ch == c)
+        v = val;
+      st(out + i, v);
+    }
   }
 }
 
@@ -59,6 +102,41 @@ __global__ __launch_bounds__(1024) void mbstd_bwd_kernel(const T* __restrict__ g
   float acc = 0.f;
   for (int i = threadIdx.x; i < n * hw; i += blockDim.x) acc += ld(gout + (int64_t)i * cpad + c);
   const float G = block_sum(acc, red);
+  constexpr int V = Vec16<T>::N;
+  if (c % V == 0 && cpad % V == 0 && n <= 32) {
+    for (int p = threadIdx.x * V; p < P; p += blockDim.x * V) {
+      float mu[V], var[V], k[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) mu[j] = var[j] = 0.f;
+      for (int i = 0; i < n; ++i) {
+        const Vec16<T> xv = ldv(x + (int64_t)i * P + p);
+#pragma unroll
+        for (int j = 0; j < V; ++j) mu[j] += xv.get(j);
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) mu[j] /= (float)n;
+      for (int i = 0; i < n; ++i) {
+        const Vec16<T> xv = ldv(x + (int64_t)i * P + p);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const float d = xv.get(j) - mu[j];
+          var[j] = fmaf(d, d, var[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) k[j] = G / ((float)n * sqrtf(var[j] / (float)n + eps) * (float)P);
+      const int px = p / c, ch = p - px * c;
+      for (int i = 0; i < n; ++i) {
+        const Vec16<T> xv = ldv(x + (int64_t)i * P + p);
+        const Vec16<T> gv = ldv(gout + ((int64_t)i * hw + px) * cpad + ch);
+        Vec16<T> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) o.set(j, gv.get(j) + k[j] * (xv.get(j) - mu[j]));
+        stv(gx + (int64_t)i * P + p, o);
+      }
+    }
+    return;
+  }
   for (int p = threadIdx.x; p < P; p += blockDim.x) {
     float mu = 0.f;
     for (int i = 0; i < n; ++i) mu += ld(x + (int64_t)i * P + p);

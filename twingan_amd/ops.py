@@ -541,33 +541,45 @@ def norm_act(y, gamma, beta, lrelu=True, pixel_norm=True, in_eps=1e-6, pn_eps=1e
 # ------------------------------------------------------------------------------------------------
 # resampling / concat / fade-in
 # ------------------------------------------------------------------------------------------------
+def _pack_perm(perm):
+  v = 0
+  for k, g in enumerate(perm):
+    v |= (int(g) & 0xff) << (8 * k)
+  return v
+
+
 class UpsampleConcatFn(torch.autograd.Function):
-  """concat(nearest_up2(x0), x1) on C (nets/pggan_utils.py:349-350, 281-298)."""
+  """concat(nearest_up2(x0), x1) on C (nets/pggan_utils.py:349-350, 281-298).  With (gsz, perm) output group k
+  (gsz images) reads skip group perm[k] of x1 -- several generator passes batched along N share the encoder's
+  skip tensors without copies."""
 
   @staticmethod
-  def forward(ctx, x0, x1):
+  def forward(ctx, x0, x1, gsz, perm):
     _chk(x0, x1)
     n, h, w, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[3]
+    if gsz:
+      assert x1 is not None and n % gsz == 0 and len(perm) == n // gsz and x1.shape[0] == (max(perm) + 1) * gsz
     out = torch.empty((n, 2 * h, 2 * w, c0 + c1), dtype=x0.dtype, device=x0.device)
-    call('tg_upsample2x_concat_fwd', _p(x0), _p(x1), _p(out), n, h, w, c0, c1, _dt(x0), _stream())
-    ctx.dims = (n, h, w, c0, c1)
+    pk = _pack_perm(perm) if gsz else 0
+    call('tg_upsample2x_concat_fwd', _p(x0), _p(x1), _p(out), n, h, w, c0, c1, gsz, pk, _dt(x0), _stream())
+    ctx.dims = (n, h, w, c0, c1, gsz, pk, 0 if x1 is None else x1.shape[0])
     return out
 
   @staticmethod
   @torch.autograd.function.once_differentiable
   def backward(ctx, go):
-    n, h, w, c0, c1 = ctx.dims
+    n, h, w, c0, c1, gsz, pk, n1 = ctx.dims
     go = go.contiguous()
     g0 = torch.empty((n, h, w, c0), dtype=go.dtype, device=go.device) if ctx.needs_input_grad[0] else None
-    g1 = torch.empty((n, 2 * h, 2 * w, c1), dtype=go.dtype, device=go.device) \
+    g1 = torch.empty((n1, 2 * h, 2 * w, c1), dtype=go.dtype, device=go.device) \
         if (c1 and ctx.needs_input_grad[1]) else None
-    call('tg_upsample2x_concat_bwd', _p(go), _p(g0), _p(g1), n, h, w, c0, c1, _dt(go), _stream())
-    return g0, g1
+    call('tg_upsample2x_concat_bwd', _p(go), _p(g0), _p(g1), n, h, w, c0, c1, gsz, pk, _dt(go), _stream())
+    return g0, g1, None, None
 
 
-def upsample2x_concat(x0, x1=None):
-  return UpsampleConcatFn.apply(x0, x1)
+def upsample2x_concat(x0, x1=None, gsz=0, perm=()):
+  return UpsampleConcatFn.apply(x0, x1, int(gsz), tuple(perm))
 
 
 class Pool2Fn(torch.autograd.Function):

@@ -105,7 +105,7 @@ def encoder_before_classification(P, source, domain, cfg, top='encoder_content')
 # ------------------------------------------------------------------------------------------------
 # generator (nets/pggan.py:69-211), TwinGAN mode: source is the encoder's [B,4,4,C] content tensor
 # ------------------------------------------------------------------------------------------------
-def generator(P, source, domain, cfg, unet_end_points=None, top='generator'):
+def generator(P, source, domain, cfg, unet_end_points=None, top='generator', unet_groups=None):
   max_stage = max_stage_of(cfg.hw)
   assert source.shape[1] == 4 and source.shape[2] == 4, 'TwinGAN generator expects a 4x4 content tensor'
   end_points = {'source': source}
@@ -127,7 +127,12 @@ def generator(P, source, domain, cfg, unet_end_points=None, top='generator'):
         net_before_growth = resize_twice_as_big(net_before_growth)
         end_points[rgb] = net_before_growth
       # generator_three_layer_block: upsample -> concat(UNet) -> conv -> conv  (pggan.py:69-83)
-      net = ops.upsample2x_concat(net, maybe_concat_unet_layer(hw, unet_end_points, cfg.max_ch))
+      # unet_groups = (gsz, perm): batched passes read the skip tensors of the encoder batch by group permutation
+      skip = maybe_concat_unet_layer(hw, unet_end_points, cfg.max_ch)
+      if skip is not None and unet_groups is not None:
+        net = ops.upsample2x_concat(net, skip, unet_groups[0], unet_groups[1])
+      else:
+        net = ops.upsample2x_concat(net, skip)
       net = _ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg)
       net = _ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg)
     end_points[name] = net

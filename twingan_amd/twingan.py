@@ -33,10 +33,6 @@ def get_growing_image(img, alpha):
   return ops.lerp(img, low, alpha)
 
 
-def _skip_names(ep):
-  return [k for k in ep if k.startswith('encoder_block_')]
-
-
 def forward_generators(P, sources, targets, cfg):
   """twingan.py:198-269: E(s), E(t) and the four generator passes (shared conv weights, per-domain norm
   parameters, UNet skips from the encoder whose content is decoded).
@@ -50,13 +46,9 @@ def forward_generators(P, sources, targets, cfg):
   e, ep = pggan.encoder_before_classification(P, x, ('s', 't', b), cfg)
   es, et = e.chunk(2)
   content = torch.cat([et, es, es, et], dim=0)
-  unet = None
-  if cfg.use_unet:
-    unet = {}
-    for k in _skip_names(ep):
-      vs, vt = ep[k].chunk(2)
-      unet[k] = torch.cat([vt, vs, vs, vt], dim=0)
-  out, _ = pggan.generator(P, content, ('s', 't', 2 * b), cfg, unet)
+  # UNet skips: generator group k reads encoder group (t, s, s, t)[k] of the [s; t] encoder batch -- no copies
+  out, _ = pggan.generator(P, content, ('s', 't', 2 * b), cfg, ep if cfg.use_unet else None,
+                           unet_groups=(b, (1, 0, 0, 1)))
   s_prime, s_cycle, t_prime, t_cycle = out.chunk(4)
   return dict(es=es, et=et, s_prime=s_prime, s_cycle=s_cycle, t_prime=t_prime, t_cycle=t_cycle)
 
