@@ -61,8 +61,10 @@ def one_step(tr, a, b):
 
 
 def roofline_pass(tr, a, b, steps=2):
-  """Re-runs the same step with HIP events around every kernel launch (on the launch stream) and
-  aggregates per kernel family."""
+  """Re-runs the same step eagerly with HIP events around every kernel launch (on the launch stream) and
+  aggregates (1) per entry point ("families") and (2) per exact layer shape.  The reported roofline is that of
+  the single most expensive layer shape: algorithmic bytes (or flops) of one launch / its average duration,
+  against the HBM (or dense bf16 MFMA) peak, whichever bounds that shape (intensity vs the 312 FLOP/B ridge)."""
   from twingan_amd import _lib
   rec = []
   graph_mode, tr.use_graph = tr.use_graph, False        # per-launch events need eager launches
@@ -73,27 +75,34 @@ def roofline_pass(tr, a, b, steps=2):
   torch.cuda.synchronize()
   _lib.profiler = None
   tr.use_graph = graph_mode
-  fam = {}
-  for name, tag, fl, by, e0, e1 in rec:
+  ridge = 1e3 * BF16_MFMA_PEAK_TFLOPS / HBM_PEAK_GBS
+  fam, shapes = {}, {}
+  t_total = t_min_total = 0.0
+  for name, tag, fl, by, e0, e1, kname in rec:
     ms = e0.elapsed_time(e1)
-    key = name if not tag else '%s[%s]' % (name, tag.split(':')[0] + ':' + tag.split(':')[1] if ':' in tag else tag)
-    f = fam.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-    f['ms'] += ms
-    f['flops'] += fl
-    f['bytes'] += by
-    f['launches'] += 1
-  total_ms = sum(f['ms'] for f in fam.values())
-  top = sorted(fam.items(), key=lambda kv: -kv[1]['ms'])
-  detail = []
-  for k, f in top[:12]:
-    detail.append(dict(kernel=k, share=round(f['ms'] / total_ms, 4), launches=f['launches'] // steps,
-                       avg_us=round(1e3 * f['ms'] / f['launches'], 2),
-                       tflops=round(f['flops'] / (f['ms'] * 1e-3) / 1e12, 2) if f['ms'] else 0.0,
-                       gbs=round(f['bytes'] / (f['ms'] * 1e-3) / 1e9, 1) if f['ms'] else 0.0))
-  k, f = top[0]
-  # the family is MFMA-bound when its algorithmic intensity exceeds the bf16 ridge (2.5 PF / 8 TB/s = 312 FLOP/B)
+    t_total += ms
+    if fl or by:      # the launch's own lower bound at the two peaks
+      t_min_total += max(fl / (BF16_MFMA_PEAK_TFLOPS * 1e12), by / (HBM_PEAK_GBS * 1e9)) * 1e3
+    # family = the kernel symbol the dispatch selected (what rocprofv3 reports), else the entry point
+    fkey = kname if kname else name
+    for key, table in ((fkey, fam), ('%s[%s]' % (name, tag) if tag else name, shapes)):
+      f = table.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+      f['ms'] += ms
+      f['flops'] += fl
+      f['bytes'] += by
+      f['launches'] += 1
+
+  def row(k, f):
+    return dict(kernel=k, share=round(f['ms'] / t_total, 4), launches=f['launches'] // steps,
+                avg_us=round(1e3 * f['ms'] / f['launches'], 2),
+                tflops=round(f['flops'] / (f['ms'] * 1e-3) / 1e12, 2) if f['ms'] else 0.0,
+                gbs=round(f['bytes'] / (f['ms'] * 1e-3) / 1e9, 1) if f['ms'] else 0.0)
+
+  top_shapes = sorted(((k, f) for k, f in shapes.items() if f['bytes']), key=lambda kv: -kv[1]['ms'])
+  # the dominant KERNEL (all its launches in the step): achieved = its algorithmic bytes (flops) / its time
+  k, f = sorted(((kk, ff) for kk, ff in fam.items() if ff['bytes']), key=lambda kv: -kv[1]['ms'])[0]
   intensity = f['flops'] / max(f['bytes'], 1.0)
-  if f['flops'] and intensity > 1e3 * BF16_MFMA_PEAK_TFLOPS / HBM_PEAK_GBS:
+  if f['flops'] and intensity > ridge:
     achieved = f['flops'] / (f['ms'] * 1e-3) / 1e12
     roof = dict(bound='mfma', achieved=round(achieved, 2), peak=BF16_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                 frac=round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), traffic=None)
@@ -101,12 +110,41 @@ def roofline_pass(tr, a, b, steps=2):
     achieved = f['bytes'] / (f['ms'] * 1e-3) / 1e9
     roof = dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                 frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None)
-  roof['intensity_flop_per_byte'] = round(intensity, 1)
   roof['kernel'] = k
+  roof['intensity_flop_per_byte'] = round(intensity, 1)
   roof['avg_launch_us'] = round(1e3 * f['ms'] / f['launches'], 2)
-  roof['hbm_algorithmic_gbs'] = round(f['bytes'] / (f['ms'] * 1e-3) / 1e9, 1)
-  roof['kernel_time_ms_per_step'] = round(total_ms / steps, 3)
-  roof['families'] = detail
+  roof['algorithmic_bytes_per_launch'] = int(f['bytes'] / f['launches'])
+  roof['algorithmic_flops_per_launch'] = int(f['flops'] / f['launches'])
+  # measured HBM traffic of this kernel from the PMC passes (tools/pmc_traffic.sh -> profiles/r01_pmc_traffic.json):
+  # PMC runs are per layer shape, so the sample(s) taken on this kernel symbol are listed with their shapes;
+  # `traffic` is the measured HBM bytes per launch of the first sample (compare with its algorithmic bytes).
+  pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+  if os.path.exists(pmc):
+    try:
+      import re
+
+      def sym(n):      # mangled or plain kernel name -> "base<a,b,c>"
+        m = re.search(r'(conv_\w+?_kernel|conv_\w+_mfma)', n)
+        if not m:
+          return n
+        targs = re.findall(r'Li(\d+)E', n)
+        return m.group(1) + ('<%s>' % ','.join(targs) if targs else '')
+      samples = [dict(shape=e['shape'], hbm_bytes_per_launch=e['hbm_bytes_per_launch'],
+                      algorithmic_bytes_per_launch=e['algorithmic_bytes_per_launch'],
+                      traffic_over_algorithmic=e['traffic_over_algorithmic'])
+                 for e in json.load(open(pmc)).get('kernels', []) if sym(e.get('kernel', '')) == k]
+      if samples:
+        roof['traffic'] = samples[0]['hbm_bytes_per_launch']
+        roof['traffic_samples'] = samples
+        roof['traffic_source'] = ('profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, '
+                                  'FETCH_SIZE x2 (gfx950), per launch of the listed layer shape')
+    except Exception:
+      pass
+  roof['kernel_time_ms_per_step'] = round(t_total / steps, 3)
+  # whole step against the two peaks: sum over launches of max(flops/MFMA peak, bytes/HBM peak) / measured time
+  roof['step_roofline_frac'] = round(t_min_total / t_total, 4)
+  roof['top_shapes'] = [row(kk, ff) for kk, ff in top_shapes[:8]]
+  roof['families'] = [row(kk, ff) for kk, ff in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])[:12]]
   return roof
 
 

@@ -47,6 +47,9 @@ extern "C" {
 
 int tg_version(void);
 const char* tg_last_error(void);
+/* name of the kernel variant the last conv dispatch on this thread selected (e.g. "conv_tile_kernel<3,32,64,1>");
+ * lets host-side timing be attributed to the kernel symbols rocprofv3 reports */
+const char* tg_last_kernel(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution: stride 1, kh,kw <= 4, arbitrary zero padding (pad_t/pad_l on the low side; the
@@ -114,11 +117,13 @@ int tg_instance_norm_stats(const void* y, float* mean, float* rstd, int n, int h
 int tg_norm_act_fwd(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
                     const float* gamma2, const float* beta2, int split, void* z, float* pn_scale, int n, int h, int w, int c,
                     int flags, float lrelu_alpha, float pn_eps, int dtype, void* stream);
-/* Backward of tg_norm_act_fwd.  Inputs: gz, y (raw conv output), pn_scale, mean, rstd, gamma, beta (+ 2nd domain).
+/* Backward of tg_norm_act_fwd.  Inputs: gz [n,h,w,c] and/or gz_pooled [n,h/2,w/2,c] (either may be NULL; the
+ * layer-output gradient is gz + 0.25 * upsample(gz_pooled): the tf.nn.avg_pool that follows an encoder block,
+ * nets/pggan.py:436,468, is folded in), y (raw conv output), pn_scale, mean, rstd, gamma, beta (+ 2nd domain).
  * Outputs: gy (same dtype), ggamma[c], gbeta[c] (+ ggamma2, gbeta2 for images >= split) (fp32, may be NULL;
  * accumulate != 0 adds).  sums: fp32 scratch [2*n*c] (zeroed by the call). */
-int tg_norm_act_bwd(const void* gz, const void* y, const float* pn_scale, const float* mean, const float* rstd,
-                    const float* gamma, const float* beta, const float* gamma2, const float* beta2, int split, void* gy,
+int tg_norm_act_bwd(const void* gz, const void* gz_pooled, const void* y, const float* pn_scale, const float* mean,
+                    const float* rstd, const float* gamma, const float* beta, const float* gamma2, const float* beta2, int split, void* gy,
                     float* ggamma, float* gbeta, float* ggamma2, float* gbeta2, float* sums, int n, int h, int w, int c,
                     int flags, float lrelu_alpha, int accumulate, int dtype, void* stream);
 
@@ -135,6 +140,11 @@ int tg_lrelu_bwd(const void* gz, const void* z, void* gy, int64_t numel, float a
  * BiasAddGrad (one pass over gz, z instead of two kernels) */
 int tg_lrelu_bwd_bias(const void* gz, const void* z, void* gy, float* gbias, int64_t npix, int c, float alpha,
                       int accumulate, int dtype, void* stream);
+/* Same with the 2x2 average pool that follows a discriminator block (nets/pggan.py:274,306) folded in: the
+ * incoming gradient is gz [n,h,w,c] (may be NULL) + 0.25 * upsample(gz_pooled [n,h/2,w/2,c]) (may be NULL);
+ * gbias may be NULL (no bias gradient wanted). */
+int tg_lrelu_pool_bwd(const void* gz, const void* gz_pooled, const void* z, void* gy, float* gbias, int n, int h, int w,
+                      int c, float alpha, int accumulate, int dtype, void* stream);
 /* out[c] (fp32) = sum over pixels of g[pix][c]  (BiasAddGrad) */
 int tg_channel_sum(const void* g, float* out, int64_t npix, int c, int accumulate, int dtype, void* stream);
 

@@ -534,3 +534,65 @@ def test_upsample_concat_group_permutation(ops, dtype):
   assert np.array_equal(host(out), host(ref))
   assert rel_l2(host(x0.grad), host(a.grad)) < 1e-6
   assert rel_l2(host(x1.grad), host(b.grad)) < (1e-6 if dtype == torch.float32 else 1e-2)
+
+
+# ---------------------------------------------------------------------------------------------- fused pooling
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv_pool_fused_backward_equals_composition(ops, dtype):
+  """conv + bias + LeakyReLU followed by tf.nn.avg_pool (nets/pggan.py:304-306): the fused op's backward (pool folded
+  into the LeakyReLU / bias-gradient kernel) against conv2d -> avg_pool2, with and without the pre-pool output used."""
+  rng = np.random.RandomState(31)
+  x0 = bf16_round(rng.randn(2, 8, 16, 16))
+  w0 = rng.randn(3, 3, 16, 16) / 12.0
+  b0 = rng.randn(16) * 0.1
+  gp = bf16_round(rng.randn(2, 4, 8, 16))
+  gf = bf16_round(rng.randn(2, 8, 16, 16))
+  for use_full in (False, True):
+    res = []
+    for fused in (True, False):
+      x = to_dev(x0, dtype).requires_grad_(True)
+      w = to_dev(w0).requires_grad_(True)
+      b = to_dev(b0).requires_grad_(True)
+      if fused:
+        z, zp = ops.conv2d(x, w, b, 3, 'SAME', lrelu=True, pool=True)
+      else:
+        z = ops.conv2d(x, w, b, 3, 'SAME', lrelu=True)
+        zp = ops.avg_pool2(z)
+      outs, grads = [zp], [to_dev(gp, dtype)]
+      if use_full:
+        outs.append(z)
+        grads.append(to_dev(gf, dtype))
+      torch.autograd.backward(outs, grads)
+      res.append((host(zp), host(x.grad), host(w.grad), host(b.grad)))
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for i, nm in enumerate(('zp', 'gx', 'gw', 'gb')):
+      assert rel_l2(res[0][i], res[1][i]) < tol, (use_full, nm, rel_l2(res[0][i], res[1][i]))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_norm_act_pool_fused_backward_equals_composition(ops, dtype):
+  """Last layer of an encoder block + avg_pool (nets/pggan.py:466-468) with the UNet skip also consuming z."""
+  rng = np.random.RandomState(32)
+  y0 = bf16_round(rng.randn(3, 8, 8, 16) * 1.5 + 0.3)
+  ga0, be0 = 1 + 0.1 * rng.randn(16), 0.1 * rng.randn(16)
+  gp = bf16_round(rng.randn(3, 4, 4, 16))
+  gf = bf16_round(rng.randn(3, 8, 8, 16))
+  for use_full in (False, True):
+    res = []
+    for fused in (True, False):
+      y = to_dev(y0, dtype).requires_grad_(True)
+      ga, be = to_dev(ga0).requires_grad_(True), to_dev(be0).requires_grad_(True)
+      if fused:
+        z, zp = ops.norm_act(y, ga, be, pool=True)
+      else:
+        z = ops.norm_act(y, ga, be)
+        zp = ops.avg_pool2(z)
+      outs, grads = [zp], [to_dev(gp, dtype)]
+      if use_full:
+        outs.append(z)
+        grads.append(to_dev(gf, dtype))
+      torch.autograd.backward(outs, grads)
+      res.append((host(zp), host(y.grad), host(ga.grad), host(be.grad)))
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for i, nm in enumerate(('zp', 'gy', 'ggamma', 'gbeta')):
+      assert rel_l2(res[0][i], res[1][i]) < tol, (use_full, nm, rel_l2(res[0][i], res[1][i]))

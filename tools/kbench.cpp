@@ -134,12 +134,14 @@ static float time_us(F f, int iters) {
 
 int main(int argc, char** argv) {
   const char* filter = nullptr;
+  const char* only_op = nullptr;      // --op fwd|dgrad|wgrad: time just that op (PMC runs)
   int algo = TG_ALGO_MFMA, iters = 20, batch = 16, check = 1;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--algo")) algo = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--iters")) iters = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--batch")) batch = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--nocheck")) check = 0;
+    else if (!strcmp(argv[i], "--op")) only_op = argv[++i];
     else filter = argv[i];
   }
   std::vector<Case> cases = {
@@ -180,7 +182,7 @@ int main(int argc, char** argv) {
     // ---- correctness at batch nchk against the direct kernels
     double e_f = -1, e_d = -1, e_w = -1;
     if (check) {
-      const int nchk = batch < 2 ? batch : 2;
+      const int nchk = batch < 8 ? batch : 8;      // enough tiles to reach the multi-tile (weight-resident) variants
       TgConvDesc dm = mk(nchk, c.hw, c.cin, c.cout, c.k, algo, TG_EPI_BIAS | TG_EPI_LRELU);
       TgConvDesc dr = mk(nchk, c.hw, c.cin, c.cout, c.k, TG_ALGO_DIRECT, TG_EPI_BIAS | TG_EPI_LRELU);
       const size_t pc = (size_t)nchk * c.hw * c.hw;
@@ -202,15 +204,21 @@ int main(int argc, char** argv) {
     const double flops = 2.0 * px * c.cout * c.k * c.k * c.cin;
     const double bytes = 2.0 * px * (c.cin + c.cout) + 2.0 * nw;
     float t;
+    if (!only_op || !strcmp(only_op, "fwd")) {
     t = time_us([&] { TC(tg_conv2d_fwd(&d, x, p0, bias, y, nullptr)); }, iters);
     printf("%-7s %-5s %4d %4d>%-4d | %9.1f %8.0f %8.1f %9.2e\n", c.name, "fwd", c.hw, c.cin, c.cout, t, bytes / t * 1e-3,
            flops / t * 1e-6, e_f);
+    }
+    if (!only_op || !strcmp(only_op, "dgrad")) {
     t = time_us([&] { TC(tg_conv2d_bwd_data(&d0, gy, p1, gx, nullptr)); }, iters);
     printf("%-7s %-5s %4d %4d>%-4d | %9.1f %8.0f %8.1f %9.2e\n", c.name, "dgrad", c.hw, c.cin, c.cout, t, bytes / t * 1e-3,
            flops / t * 1e-6, e_d);
+    }
+    if (!only_op || !strcmp(only_op, "wgrad")) {
     t = time_us([&] { TC(tg_conv2d_bwd_weight(&d0, x, gy, gw, 0, ws, wsb, nullptr)); }, iters);
     printf("%-7s %-5s %4d %4d>%-4d | %9.1f %8.0f %8.1f %9.2e\n", c.name, "wgrad", c.hw, c.cin, c.cout, t, bytes / t * 1e-3,
            flops / t * 1e-6, e_w);
+    }
     fflush(stdout);
     HC(hipFree(x)); HC(hipFree(gy)); HC(hipFree(w)); HC(hipFree(bias)); HC(hipFree(y)); HC(hipFree(y2));
     HC(hipFree(gx)); HC(hipFree(gx2)); HC(hipFree(gw)); HC(hipFree(gw2)); HC(hipFree(p0)); HC(hipFree(p1));

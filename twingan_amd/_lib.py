@@ -33,6 +33,7 @@ _D = POINTER(TgConvDesc)
 SIGNATURES = {
     'tg_version': (c_int, []),
     'tg_last_error': (c_char_p, []),
+    'tg_last_kernel': (c_char_p, []),
     'tg_conv2d_fwd': (c_int, [_D, _P, _P, _FP, _P, _P]),
     'tg_conv2d_bwd_data': (c_int, [_D, _P, _P, _P, _P]),
     'tg_conv2d_bwd_weight_workspace': (c_size_t, [_D]),
@@ -44,11 +45,12 @@ SIGNATURES = {
     'tg_instance_norm_stats': (c_int, [_P, _FP, _FP, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     'tg_norm_act_fwd': (c_int, [_P, _FP, _FP, _FP, _FP, _FP, _FP, c_int, _P, _FP, c_int, c_int, c_int, c_int, c_int,
                                 c_float, c_float, c_int, _P]),
-    'tg_norm_act_bwd': (c_int, [_P, _P, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, _P, _FP, _FP, _FP, _FP, _FP, c_int,
+    'tg_norm_act_bwd': (c_int, [_P, _P, _P, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, _P, _FP, _FP, _FP, _FP, _FP, c_int,
                                 c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
     'tg_bias_lrelu_fwd': (c_int, [_P, _FP, _P, c_int64, c_int, c_float, c_int, _P]),
     'tg_lrelu_bwd': (c_int, [_P, _P, _P, c_int64, c_float, c_int, _P]),
     'tg_lrelu_bwd_bias': (c_int, [_P, _P, _P, _FP, c_int64, c_int, c_float, c_int, c_int, _P]),
+    'tg_lrelu_pool_bwd': (c_int, [_P, _P, _P, _P, _FP, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
     'tg_channel_sum': (c_int, [_P, _FP, c_int64, c_int, c_int, c_int, _P]),
     'tg_upsample2x_concat_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint, c_int, _P]),
     'tg_upsample2x_concat_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint, c_int, _P]),
@@ -111,7 +113,8 @@ def call(name, *args, work=None):
     if callable(work):
       work = work()
     tag, fl, by = work if work is not None else ('', 0, 0)
-    profiler.append((name, tag, fl, by, e0, e1))
+    kname = lib.tg_last_kernel().decode() if name.startswith('tg_conv2d') else ''
+    profiler.append((name, tag, fl, by, e0, e1, kname))
   else:
     rc = getattr(lib, name)(*args)
   if rc != 0:

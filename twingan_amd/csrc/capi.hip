@@ -3,6 +3,15 @@
 
 static thread_local char tg_err[512] = "";
 
+static thread_local char tg_kname[96] = "";
+
+void tg_note_kernel(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(tg_kname, sizeof(tg_kname), fmt, ap);
+  va_end(ap);
+}
+
 void tg_set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -57,6 +66,7 @@ extern "C" {
 
 int tg_version(void) { return 100; }
 const char* tg_last_error(void) { return tg_err; }
+const char* tg_last_kernel(void) { return tg_kname; }
 
 int tg_conv2d_fwd(const TgConvDesc* d, const void* x, const void* w, const float* bias, void* y, void* stream) {
   int rc = check_desc("tg_conv2d_fwd", d);

@@ -100,6 +100,7 @@ int tg_conv2d_fwd_direct(const TgConvDesc* d, const void* x, const void* w, cons
                          hipStream_t s) {
   const int64_t total = (int64_t)d->n * d->hout * d->wout * d->cout;
   const int grid = tg_grid_for(total, 256, 256 * 64);
+  tg_note_kernel("conv_fwd_direct");
   TG_DISPATCH_DTYPE(d->dtype, "tg_conv2d_fwd", {
     hipLaunchKernelGGL(conv_fwd_direct<T>, dim3(grid), dim3(256), 0, s, (const T*)x, (const float*)w, bias, (T*)y, *d);
   });
@@ -110,6 +111,7 @@ int tg_conv2d_fwd_direct(const TgConvDesc* d, const void* x, const void* w, cons
 int tg_conv2d_bwd_data_direct(const TgConvDesc* d, const void* gy, const void* w, void* gx, hipStream_t s) {
   const int64_t total = (int64_t)d->n * d->hin * d->win * d->cin;
   const int grid = tg_grid_for(total, 256, 256 * 64);
+  tg_note_kernel("conv_bwd_data_direct");
   TG_DISPATCH_DTYPE(d->dtype, "tg_conv2d_bwd_data", {
     hipLaunchKernelGGL(conv_bwd_data_direct<T>, dim3(grid), dim3(256), 0, s, (const T*)gy, (const float*)w, (T*)gx,
                        *d);
@@ -126,6 +128,7 @@ int tg_conv2d_bwd_weight_direct(const TgConvDesc* d, const void* x, const void* 
     int rc = tg_zero_async(gw, nw * sizeof(float), nullptr, 0, s);
     if (rc) return rc;
   }
+  tg_note_kernel("conv_bwd_weight_direct");
   const int pix_per_chunk = 2048;
   const int gy_chunks = (int)((npix + pix_per_chunk - 1) / pix_per_chunk);
   const int gx = tg_grid_for(nw, 256, 4096);

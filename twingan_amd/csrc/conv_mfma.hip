@@ -387,6 +387,7 @@ int launch_fwd(const Geom& g, const bf16* x, const bf16* wp, const float* bias, 
   const size_t lds = ((size_t)(halo_px * (KC * 2 + 16) + 15) & ~(size_t)15) + (size_t)BN * (KH * KW * KC * 2 + 16);
   TG_CHECK(lds <= 64 * 1024, TG_ENOSUP, "conv(mfma): LDS %zu > 64 KiB", lds);
   dim3 grid(g.tiles_x * g.tiles_y * g.tiles_img, (g.cout + BN - 1) / BN);
+  tg_note_kernel("conv_fwd_mfma<%d,%d,%d,%d>", KH, KW, KC, BN);
   hipLaunchKernelGGL((conv_fwd_mfma<KH, KW, KC, BN>), grid, dim3(256), lds, s, x, wp, bias, y, g);
   TG_LAUNCH_CHECK("conv_fwd_mfma");
   return TG_OK;
@@ -561,6 +562,7 @@ int tg_conv2d_bwd_weight_mfma(const TgConvDesc* d0, const void* x, const void* g
   if (lds < 4 * 16 * 64 * sizeof(float)) lds = 4 * 16 * 64 * sizeof(float);
   TG_CHECK(lds <= 64 * 1024, TG_ENOSUP, "conv_wgrad(mfma): LDS %zu > 64 KiB", lds);
   dim3 grid(nslices, n_ci * n_co);
+  tg_note_kernel("conv_wgrad_mfma<%d,%d>", d->kh, d->kw);
   if (d->kh == 1)
     hipLaunchKernelGGL((conv_wgrad_mfma<1, 1>), grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g,
                        n_co, tpb, total);

@@ -44,22 +44,24 @@ __device__ __forceinline__ unsigned s_pack2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, v);
 }
 
-template <int NT>      // taps (1 or 9)
+template <int NT, int MT>      // taps (1 or 9); 32-pixel column blocks per workgroup (weight fragment reuse)
 __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                          const float* __restrict__ bias, bf16* __restrict__ y,
                                                          const SmallGeom g) {
   __shared__ float red[4][16][64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, kgrp = lane >> 5;
-  const int p = blockIdx.x * 32 + l31;              // this lane's output pixel (B operand column)
+  const int pbase = blockIdx.x * 32 * MT + l31;     // this lane's output pixel of column block 0 (B operand column)
   const int n0 = blockIdx.y * 32;                   // first output channel of the tile
 
   const __amdgpu_buffer_rsrc_t rx = s_rsrc(x, g.x_bytes);
   const __amdgpu_buffer_rsrc_t rw = s_rsrc(wp, g.w_bytes);
 
   // per-tap byte offset of this lane's source pixel (channel 0 + kgrp*8), SOOB outside the image / tile
-  unsigned xoff[NT];
-  {
+  unsigned xoff[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int p = pbase + m * 32;
     const int hw = g.hout * g.wout;
     const int img = p / hw, rem = p - img * hw;
     const int oy = rem / g.wout, ox = rem - oy * g.wout;
@@ -68,28 +70,33 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict_
       const int ky = t / (NT == 1 ? 1 : 3), kx = t - ky * (NT == 1 ? 1 : 3);
       const int iy = oy + ky - g.pad_t, ix = ox + kx - g.pad_l;
       const bool ok = p < g.npix && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
-      xoff[t] = ok ? (unsigned)((((img * g.hin + iy) * g.win + ix) * g.cin + kgrp * 8) * 2) : SOOB;
+      xoff[m][t] = ok ? (unsigned)((((img * g.hin + iy) * g.win + ix) * g.cin + kgrp * 8) * 2) : SOOB;
     }
   }
   const unsigned wrow = (unsigned)(NT * g.cin_pad);
   const unsigned woff = (unsigned)(((n0 + l31) * wrow + kgrp * 8) * 2);      // + (tap*cin_pad + c)*2
 
-  f32x16 acc;
+  f32x16 acc[MT];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[m][j] = 0.f;
 
   // NOTE: a cin that is not a multiple of 16 (264) makes the last chunk read 8 channels of the next pixel;
   // the weight pack is zero there.
   auto k_step = [&](int ck) __attribute__((always_inline)) {
     const unsigned c2 = (unsigned)(ck * 32);          // byte offset of the chunk's first channel
-    bf16x8 xf[NT], wf[NT];
+    bf16x8 wf[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      wf[t] = s_load16(rw, woff + (unsigned)(t * g.cin_pad * 2) + c2);
-      xf[t] = s_load16(rx, xoff[t] + c2);
+    for (int t = 0; t < NT; ++t) wf[t] = s_load16(rw, woff + (unsigned)(t * g.cin_pad * 2) + c2);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      bf16x8 xf[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) xf[t] = s_load16(rx, xoff[m][t] + c2);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t], xf[t], acc[m], 0, 0, 0);
     }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t], xf[t], acc, 0, 0, 0);
   };
   if constexpr (NT == 1) {
 #pragma unroll 8
@@ -98,26 +105,25 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict_
     for (int ck = wid; ck < g.nchunks; ck += 4) k_step(ck);     // 18 loads in flight per chunk already
   }
 
-  // ---- sum the 4 K-slices
-#pragma unroll
-  for (int r = 0; r < 16; ++r) red[wid][r][lane] = acc[r];
-  __syncthreads();
+  // ---- sum the 4 K-slices, one column block at a time
+  const __amdgpu_buffer_rsrc_t rbias = s_rsrc(bias, (g.epilogue & TG_EPI_BIAS) ? (unsigned)(g.cout * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t ry = s_rsrc(y, g.y_bytes);
   // wave w finishes register quads q = w (channels 8w + 4*kgrp .. +3 of the 32-block) for every pixel
   // -> after the half-wave swap each lane stores 8 consecutive channels (16 bytes)
-  {
-    const int q = wid;
+  const int q = wid;
+  const f32x4 bq = __builtin_bit_cast(
+      f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, (unsigned)((n0 + q * 8 + kgrp * 4) * 4), 0, 0));
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    if (m) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wid][r][lane] = acc[m][r];
+    __syncthreads();
     float v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int r = q * 4 + j;
-      v[j] = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
-    }
-    const __amdgpu_buffer_rsrc_t rbias = s_rsrc(bias, (g.epilogue & TG_EPI_BIAS) ? (unsigned)(g.cout * 4) : 0u);
-    const f32x4 bq = __builtin_bit_cast(
-        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, (unsigned)((n0 + q * 8 + kgrp * 4) * 4), 0, 0));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      v[j] += bq[j];
+      v[j] = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane] + bq[j];
       if (g.epilogue & TG_EPI_LRELU) v[j] = lrelu_f(v[j], g.alpha);
     }
     const unsigned p0 = s_pack2(v[0], v[1]), p1 = s_pack2(v[2], v[3]);
@@ -127,8 +133,8 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict_
     su32x4 o;
     o[0] = p0; o[1] = p1; o[2] = s0[1]; o[3] = s1[1];
     const int ch0 = n0 + q * 8;
+    const int p = pbase + m * 32;
     const bool ok = kgrp == 0 && p < g.npix && ch0 + 8 <= g.cout;
-    const __amdgpu_buffer_rsrc_t ry = s_rsrc(y, g.y_bytes);
     __builtin_amdgcn_raw_buffer_store_b128(o, ry, ok ? (unsigned)((p * g.cout + ch0) * 2) : SOOB, 0, 0);
   }
 }
@@ -158,11 +164,20 @@ int tg_conv_small_run(int n, int hin, int win, int cin, int hout, int wout, int 
   const size_t wb = rows_pad * k * k * g.cin_pad * 2;
   TG_CHECK(xb < 0x7fffffffull && yb < 0x7fffffffull && wb < 0x7fffffffull, TG_ENOSUP, "conv_small: tensor too large");
   g.x_bytes = (unsigned)xb; g.y_bytes = (unsigned)yb; g.w_bytes = (unsigned)wb;
-  dim3 grid((g.npix + 31) / 32, (cout + 31) / 32);
-  if (k == 1)
-    hipLaunchKernelGGL(conv_small_kernel<1>, grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, g);
-  else
-    hipLaunchKernelGGL(conv_small_kernel<9>, grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, g);
+  // more pixel columns per workgroup once there are enough pixels to keep >= 256 workgroups: each weight
+  // fragment then feeds MT MFMAs (the weights are the bulk of the L2 traffic of these layers)
+  const int ny = (cout + 31) / 32;
+  const int mt = (g.npix / 128) * ny >= 256 ? 4 : ((g.npix / 64) * ny >= 256 ? 2 : 1);
+  dim3 grid((g.npix + 32 * mt - 1) / (32 * mt), ny);
+#define TG_SMALL_LAUNCH(NT_, MT_)                             \
+  tg_note_kernel("conv_small_kernel<%d,%d>", NT_, MT_); \
+  hipLaunchKernelGGL((conv_small_kernel<NT_, MT_>), grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, g)
+  if (k == 1) {
+    if (mt == 4) { TG_SMALL_LAUNCH(1, 4); } else if (mt == 2) { TG_SMALL_LAUNCH(1, 2); } else { TG_SMALL_LAUNCH(1, 1); }
+  } else {
+    if (mt == 4) { TG_SMALL_LAUNCH(9, 4); } else if (mt == 2) { TG_SMALL_LAUNCH(9, 2); } else { TG_SMALL_LAUNCH(9, 1); }
+  }
+#undef TG_SMALL_LAUNCH
   TG_LAUNCH_CHECK("conv_small");
   return TG_OK;
 }

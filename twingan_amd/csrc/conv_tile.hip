@@ -29,6 +29,7 @@ struct TileGeom {
   int pad;                     // low-side zero padding (forward: (k-1)/2; backward-data: k-1-(k-1)/2)
   int tiles_x, tiles_y;        // tiles per image row / column
   int nblk;                    // tiles_x * tiles_y * n
+  int tiles_per_wg;            // weight-resident variant: consecutive tiles per workgroup
   int epilogue;
   float alpha;
 };
@@ -224,6 +225,208 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Weight-resident variant for the THIN layers (cin_pad <= 64, i.e. NCH <= 2 chunks of 32 channels, or one of
+// 16): with K = 9*cin that small, re-staging the workgroup's [BN x 9*cin] weight slice for every 128-pixel
+// tile costs more L2->LDS traffic than the activations themselves (16 k tiles x 37 KB at 128x128).  Here a
+// workgroup stages its weight slice ONCE and walks `tiles_per_wg` consecutive tiles, so per tile it only moves
+// the input halo; the next tile's halo loads are in flight during the MFMAs of the current one.
+// ------------------------------------------------------------------------------------------------
+template <int KH, int KC, int BN, int NCH>
+__global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
+                                                             const float* __restrict__ bias, bf16* __restrict__ y,
+                                                             const TileGeom g) {
+  constexpr int KW = KH, NT = KH * KW;
+  constexpr int TW = 16, TH = 8;
+  constexpr int HWX = TW + KW - 1, HH = TH + KH - 1;
+  constexpr int VPP = KC / 8;
+  constexpr int PS_A = KC * 2 + 16;
+  constexpr int RS_B = NT * KC * 2 + 16;
+  constexpr int AVEC = HH * HWX * VPP;
+  constexpr int ASLOTS = (AVEC + 255) / 256;
+  constexpr int BVEC = BN * NT * VPP;
+  constexpr int BSLOTS = (BVEC + 255) / 256;
+  constexpr int NTILE = BN / 32;
+  constexpr int A_BYTES = (HH * HWX * PS_A + 15) & ~15;
+  constexpr int B_BYTES = BN * RS_B;
+
+  unsigned char* sA = tile_smem;
+  unsigned char* sB = tile_smem + A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n0 = blockIdx.y * BN;
+  const int wrow = NT * g.cin_pad;
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(wp + (size_t)n0 * wrow, (unsigned)((size_t)BN * wrow * 2));
+
+  // ---- stage the whole weight slice (all chunks) once
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    bf16x8 rb[BSLOTS];
+#pragma unroll
+    for (int s = 0; s < BSLOTS; ++s) {
+      const int v = tid + s * 256;
+      const int row = v / (NT * VPP), rem = v % (NT * VPP);
+      const int tap = rem / VPP, part = rem % VPP;
+      const unsigned off = (v < BVEC) ? (unsigned)((row * wrow + tap * g.cin_pad + ch * KC + part * 8) * 2) : OOB;
+      rb[s] = buf_load16(rw, off);
+    }
+#pragma unroll
+    for (int s = 0; s < BSLOTS; ++s) {
+      const int v = tid + s * 256;
+      const int row = v / (NT * VPP), rem = v % (NT * VPP);
+      const int tap = rem / VPP, part = rem % VPP;
+      if (s < BSLOTS - 1 || v < BVEC)
+        *reinterpret_cast<bf16x8*>(sB + ch * B_BYTES + row * RS_B + (tap * KC + part * 8) * 2) = rb[s];
+    }
+  }
+
+  // ---- tile-independent slot geometry
+  int a_hy[ASLOTS], a_hx[ASLOTS], a_loff[ASLOTS];
+#pragma unroll
+  for (int s = 0; s < ASLOTS; ++s) {
+    const int v = tid + s * 256;
+    const int px = v / VPP, part = v % VPP;
+    a_hy[s] = (v < AVEC) ? px / HWX : -100000;      // unused slot: never in range
+    a_hx[s] = px % HWX;
+    a_loff[s] = px * PS_A + part * 16;
+  }
+  const int kgrp = lane >> 5, l31 = lane & 31;
+  const int a_base = ((wid * 2 + (l31 >> 4)) * HWX + (l31 & 15)) * PS_A + kgrp * 16;
+  const int b_base = l31 * RS_B + kgrp * 16;
+
+  // XCD-aware order of workgroups, then consecutive tiles inside a workgroup
+  int wg = blockIdx.x;
+  const int nwg = gridDim.x;
+  if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
+  const int t_begin = wg * g.tiles_per_wg;
+  int t_end = t_begin + g.tiles_per_wg;
+  if (t_end > g.nblk) t_end = g.nblk;
+  const size_t img_elems = (size_t)g.h * g.w * g.cin;
+  const size_t out_img = (size_t)g.h * g.w * g.cout;
+
+  bf16x8 ra[ASLOTS];
+  // loads chunk `ch` of tile `t` into ra
+  auto load_a = [&](int t, int ch) {
+    const int tx = t % g.tiles_x;
+    const int r = t / g.tiles_x;
+    const int ty = r % g.tiles_y;
+    const int img = r / g.tiles_y;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (size_t)img * img_elems, (unsigned)(img_elems * 2));
+#pragma unroll
+    for (int s = 0; s < ASLOTS; ++s) {
+      const int iy = ty * TH + a_hy[s] - g.pad, ix = tx * TW + a_hx[s] - g.pad;
+      const bool ok = iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
+      const int part8 = ((tid + s * 256) % VPP) * 8;
+      ra[s] = buf_load16(rx, ok ? (unsigned)(((iy * g.w + ix) * g.cin + part8 + ch * KC) * 2) : OOB);
+    }
+  };
+
+  const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, (g.epilogue & TG_EPI_BIAS) ? (unsigned)(g.cout * 4) : 0u);
+  f32x4 bq[NTILE][4];
+#pragma unroll
+  for (int nt = 0; nt < NTILE; ++nt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      bq[nt][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 rbias, (unsigned)((n0 + nt * 32 + q * 8 + kgrp * 4) * 4), 0, 0));
+
+  if (t_begin < t_end) load_a(t_begin, 0);
+  bool first = true;
+  for (int t = t_begin; t < t_end; ++t) {
+    f32x16 acc[NTILE];
+#pragma unroll
+    for (int i = 0; i < NTILE; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      if (!first) __syncthreads();          // everyone finished reading the previous halo chunk
+      first = false;
+#pragma unroll
+      for (int s = 0; s < ASLOTS; ++s)
+        if (s < ASLOTS - 1 || tid + s * 256 < AVEC) *reinterpret_cast<bf16x8*>(sA + a_loff[s]) = ra[s];
+      __syncthreads();                      // (the first one also covers the weight staging)
+      if (ch + 1 < NCH) load_a(t, ch + 1);
+      else if (t + 1 < t_end) load_a(t + 1, 0);
+#pragma unroll
+      for (int ky = 0; ky < KH; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+#pragma unroll
+          for (int kk = 0; kk < KC / 16; ++kk) {
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sA + a_base + (ky * HWX + kx) * PS_A + kk * 32);
+#pragma unroll
+            for (int nt = 0; nt < NTILE; ++nt) {
+              const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sB + ch * B_BYTES + b_base + nt * 32 * RS_B +
+                                                                 ((ky * KW + kx) * KC + kk * 16) * 2);
+              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[nt], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    // ---- epilogue of tile t
+    const int tx = t % g.tiles_x;
+    const int r = t / g.tiles_x;
+    const int ty = r % g.tiles_y;
+    const int img = r / g.tiles_y;
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + (size_t)img * out_img, (unsigned)(out_img * 2));
+    const int oy = ty * TH + wid * 2 + (l31 >> 4), ox = tx * TW + (l31 & 15);
+#pragma unroll
+    for (int nt = 0; nt < NTILE; ++nt) {
+      unsigned p[4][2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float a = acc[nt][q * 4 + j] + bq[nt][q][j];
+          if (g.epilogue & TG_EPI_LRELU) a = lrelu_f(a, g.alpha);
+          v[j] = a;
+        }
+        p[q][0] = pack_bf16x2(v[0], v[1]);
+        p[q][1] = pack_bf16x2(v[2], v[3]);
+      }
+      u32x4 o0, o1;
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        auto r02 = __builtin_amdgcn_permlane32_swap(p[0][d], p[2][d], false, false);
+        auto r13 = __builtin_amdgcn_permlane32_swap(p[1][d], p[3][d], false, false);
+        o0[d] = r02[0];
+        o0[2 + d] = r02[1];
+        o1[d] = r13[0];
+        o1[2 + d] = r13[1];
+      }
+      const int ch0 = n0 + nt * 32 + kgrp * 16;
+      const unsigned off = (unsigned)(((oy * g.w + ox) * g.cout + ch0) * 2);
+      __builtin_amdgcn_raw_buffer_store_b128(o0, ry, (ch0 + 8 <= g.cout) ? off : OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(o1, ry, (ch0 + 16 <= g.cout) ? off + 16 : OOB, 0, 0);
+    }
+  }
+}
+
+template <int KH, int KC, int BN, int NCH>
+int launch_tile_wres(const TileGeom& g0, const bf16* x, const bf16* wp, const float* bias, bf16* y, hipStream_t s) {
+  TileGeom g = g0;
+  constexpr int HWX = 16 + KH - 1, HH = 8 + KH - 1;
+  g.tiles_x = g.w / 16;
+  g.tiles_y = g.h / 8;
+  g.nblk = g.tiles_x * g.tiles_y * g.n;
+  const int ny = (g.cout + BN - 1) / BN;
+  int tpw = g.nblk * ny / (256 * 4);          // aim for ~4 workgroups per CU over the whole grid
+  if (tpw < 1) tpw = 1;
+  if (tpw > 16) tpw = 16;
+  g.tiles_per_wg = tpw;
+  const int nwg = (g.nblk + tpw - 1) / tpw;
+  const size_t lds = (size_t)((HH * HWX * (KC * 2 + 16) + 15) & ~15) + (size_t)NCH * BN * (KH * KH * KC * 2 + 16);
+  TG_CHECK(lds <= 64 * 1024, TG_ENOSUP, "conv_tile(wres): LDS %zu too large", lds);
+  tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d>", KH, KC, BN, NCH);
+  hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH>), dim3(nwg, ny), dim3(256), lds, s, x, wp, bias, y, g);
+  TG_LAUNCH_CHECK("conv_tile_wres");
+  return TG_OK;
+}
+
 template <int KH, int KC, int BN, int MT>
 int launch_tile(const TileGeom& g0, const bf16* x, const bf16* wp, const float* bias, bf16* y, hipStream_t s) {
   TileGeom g = g0;
@@ -246,6 +449,7 @@ int launch_tile(const TileGeom& g0, const bf16* x, const bf16* wp, const float* 
     }
   }
   dim3 grid(g.nblk, (g.cout + BN - 1) / BN);
+  tg_note_kernel("conv_tile_kernel<%d,%d,%d,%d>", KH, KC, BN, MT);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, wp, bias, y, g);
   TG_LAUNCH_CHECK("conv_tile");
   return TG_OK;
@@ -258,6 +462,11 @@ int dispatch_tile(const TileGeom& g, const bf16* x, const bf16* wp, const float*
   // two sub-tiles per wave (256-pixel workgroup tile) halve the weight staging per pixel; use them
   // when that still leaves >= 2 workgroups per CU and the map is tall enough
   const bool mt2 = (g.h % 16 == 0) && tiles1 >= 2 * 2 * 256 && g.cin_pad >= 64;
+  // thin layers with many tiles: weights resident in LDS, several tiles per workgroup
+  if (tiles1 >= 2048) {
+    if (g.cin_pad == 16) return wide ? launch_tile_wres<KH, 16, 64, 1>(g, x, wp, bias, y, s) : launch_tile_wres<KH, 16, 32, 1>(g, x, wp, bias, y, s);
+    if (g.cin_pad == 32) return wide ? launch_tile_wres<KH, 32, 64, 1>(g, x, wp, bias, y, s) : launch_tile_wres<KH, 32, 32, 1>(g, x, wp, bias, y, s);
+  }
   if (g.cin_pad % 32 == 0) {
     if (wide) return mt2 ? launch_tile<KH, 32, 64, 2>(g, x, wp, bias, y, s) : launch_tile<KH, 32, 64, 1>(g, x, wp, bias, y, s);
     return mt2 ? launch_tile<KH, 32, 32, 2>(g, x, wp, bias, y, s) : launch_tile<KH, 32, 32, 1>(g, x, wp, bias, y, s);

@@ -26,7 +26,8 @@ namespace {
 struct WgGeom {
   int n, h, w, cin, cout;
   int tiles_x, tiles_y, total_tiles;
-  int n_co_blk;                 // number of 32-wide co blocks (blockIdx.y = ci_blk * n_co_blk + co_blk)
+  int n_co_blk;                 // number of 32-wide co blocks (pair = ci_blk * n_co_blk + co_blk)
+  int n_pairs, nslices;
   int tiles_per_wg;
 };
 
@@ -64,7 +65,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   unsigned char* sG = wg_smem + X_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int ci_blk = blockIdx.y / g.n_co_blk, co_blk = blockIdx.y - ci_blk * g.n_co_blk;
+  // 1-D grid over (pixel slice, channel pair).  A 64-byte half of a 128-byte x line belongs to ONE ci block, so
+  // the two ci blocks that share a line must read it at the same time on the same XCD (same L2) or HBM serves
+  // it twice (PMC: 1.9x the algorithmic bytes before this mapping).  Workgroup b runs on XCD b % 8, hence
+  // id = (slice / 8) * 8 * npairs + pair * 8 + slice % 8.
+  int slice, pair;
+  {
+    const int id = blockIdx.x, npairs = g.n_pairs;
+    if ((g.nslices & 7) == 0) {
+      const int hi = id / (8 * npairs), rem = id - hi * 8 * npairs;
+      pair = rem >> 3;
+      slice = hi * 8 + (rem & 7);
+    } else {
+      pair = id % npairs;
+      slice = id / npairs;
+    }
+  }
+  const int ci_blk = pair / g.n_co_blk, co_blk = pair - ci_blk * g.n_co_blk;
   const int ci0 = ci_blk * 32, co0 = co_blk * 32;
 
   // ---- staging slots: tile-independent LDS offsets and intra-tile pixel coordinates
@@ -103,7 +120,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
   const size_t ximg = (size_t)g.h * g.w * g.cin, gimg = (size_t)g.h * g.w * g.cout;
-  const int tile_begin = blockIdx.x * g.tiles_per_wg;
+  const int tile_begin = slice * g.tiles_per_wg;
   int tile_end = tile_begin + g.tiles_per_wg;
   if (tile_end > g.total_tiles) tile_end = g.total_tiles;
 
@@ -160,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   // ---- cross-wave reduction through LDS, one tap at a time; write the valid part of the slab.
   // acc[tap][r]: ci = ci0 + (r & 3) + 8*(r >> 2) + 4*(lane >> 5), co = co0 + (lane & 31)
   float* red = reinterpret_cast<float*>(wg_smem);    // [4 waves][16 regs][64 lanes] = 16 KiB
-  float* out = slab + (size_t)blockIdx.x * NT * g.cin * g.cout;
+  float* out = slab + (size_t)slice * NT * g.cin * g.cout;
 #pragma unroll
   for (int tap = 0; tap < NT; ++tap) {
     __syncthreads();
@@ -225,6 +242,8 @@ void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices) {
   if (want > g->total_tiles) want = g->total_tiles;
   g->tiles_per_wg = (g->total_tiles + want - 1) / want;
   *nslices = (g->total_tiles + g->tiles_per_wg - 1) / g->tiles_per_wg;
+  g->n_pairs = n_ci * g->n_co_blk;
+  g->nslices = *nslices;
 }
 
 }  // namespace
@@ -252,7 +271,8 @@ int tg_wgrad_tile_run(int n, int h, int w, int cin, int cout, const void* x, con
            "tg_conv2d_bwd_weight(tile): workspace too small (%zu < %zu)", ws_bytes, (size_t)nslices * nw * sizeof(float));
   const int n_ci = (cin + 31) / 32;
   const size_t lds = 10 * 18 * 64 + 8 * 16 * 64;      // 19712 >= the 16 KiB reduction scratch
-  hipLaunchKernelGGL(conv_wgrad_tile_kernel, dim3(nslices, n_ci * g.n_co_blk), dim3(256), lds, s, (const bf16*)x,
+  tg_note_kernel("conv_wgrad_tile_kernel");
+  hipLaunchKernelGGL(conv_wgrad_tile_kernel, dim3(nslices * n_ci * g.n_co_blk), dim3(256), lds, s, (const bf16*)x,
                      (const bf16*)gy, (float*)ws, g);
   TG_LAUNCH_CHECK("conv_wgrad_tile");
   return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);

@@ -38,6 +38,31 @@ struct VecIO {
   }
 };
 
+// Incoming layer-output gradient of pixel (n, p) = gz[n,p] (may be NULL) + scale * gzp[n, y/2, x/2] (may be NULL):
+// the 2x2 average pool that follows a layer is folded into the layer's backward instead of materialising
+// the upsampled pooled gradient (and the sum with the UNet-skip gradient) in HBM.
+template <typename T, int V>
+__device__ __forceinline__ void load_grad(const T* gz, const T* gzp, int n, int p, int hw, int wdim, int c, int v,
+                                          float pool_scale, float* g) {
+  if (gz) {
+    VecIO<T, V>::load(gz + ((int64_t)n * hw + p) * c + v * V, g);
+  } else {
+#pragma unroll
+    for (int j = 0; j < V; ++j) g[j] = 0.f;
+  }
+  if (gzp) {
+    // wdim / hw are powers of two for every progressive stage: shifts instead of runtime divisions
+    const bool p2 = (wdim & (wdim - 1)) == 0;
+    const int yy = p2 ? (p >> (31 - __builtin_clz(wdim))) : p / wdim, xx = p - yy * wdim;
+    const int hp = p2 ? ((hw >> (31 - __builtin_clz(wdim))) >> 1) : hw / wdim / 2;
+    const int64_t pp = ((int64_t)n * hp + (yy >> 1)) * (wdim >> 1) + (xx >> 1);
+    float q[V];
+    VecIO<T, V>::load(gzp + pp * c + v * V, q);
+#pragma unroll
+    for (int j = 0; j < V; ++j) g[j] = fmaf(pool_scale, q[j], g[j]);
+  }
+}
+
 // group-wide (g lanes, power of two <= 64) butterfly sum
 __device__ __forceinline__ float group_sum(float v, int g) {
   for (int o = g >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -174,7 +199,8 @@ __global__ void norm_act_fwd_kernel(const T* __restrict__ y, const float* __rest
 //                  sums[n][c][0] += gu, sums[n][c][1] += gu * yhat
 // ------------------------------------------------------------------------------------------------
 template <typename T, int V>
-__global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restrict__ y, const float* __restrict__ pn_scale,
+__global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restrict__ gzp, int wdim,
+                                     const T* __restrict__ y, const float* __restrict__ pn_scale,
                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                      const float* __restrict__ gamma2, const float* __restrict__ beta2, int split,
@@ -204,7 +230,7 @@ __global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restri
     for (int p = p0 + pl; p < p1; p += lanes) {
       const int64_t gp = (int64_t)n * hw + p;
       float g[V], x[V], yh[V], u[V];
-      VecIO<T, V>::load(gz + gp * c + v * V, g);
+      load_grad<T, V>(gz, gzp, n, p, hw, wdim, c, v, 0.25f, g);
       VecIO<T, V>::load(y + gp * c + v * V, x);
       float dot = 0.f;
       const float s = (flags & NF_PIXNORM) ? pn_scale[gp] : 1.f;
@@ -313,8 +339,9 @@ __global__ void channel_sum_kernel(const T* __restrict__ g, float* __restrict__ 
 
 // gy = gz * (z > 0 ? 1 : alpha)  and  gbias[c] += sum_p gy[p][c]   (LeakyReLU backward fused with BiasAddGrad)
 template <typename T, int V>
-__global__ void lrelu_bwd_bias_kernel(const T* __restrict__ gz, const T* __restrict__ z, T* __restrict__ gy,
-                                      float* __restrict__ gbias, int64_t npix, int c, float alpha) {
+__global__ void lrelu_bwd_bias_kernel(const T* __restrict__ gz, const T* __restrict__ gzp, int hw, int wdim,
+                                      const T* __restrict__ z, T* __restrict__ gy, float* __restrict__ gbias,
+                                      int64_t npix, int c, float alpha) {
   extern __shared__ float sh[];   // [c]
   const int cv = c / V;
   const int lanes = blockDim.x / cv;
@@ -327,7 +354,12 @@ __global__ void lrelu_bwd_bias_kernel(const T* __restrict__ gz, const T* __restr
   if (pl < lanes) {
     for (int64_t p = (int64_t)blockIdx.x * lanes + pl; p < npix; p += (int64_t)gridDim.x * lanes) {
       float g[V], zz[V];
-      VecIO<T, V>::load(gz + p * c + v * V, g);
+      if (gzp) {
+        const int n = ((hw & (hw - 1)) == 0) ? (int)(p >> (31 - __builtin_clz(hw))) : (int)(p / hw);
+        load_grad<T, V>(gz, gzp, n, (int)(p - (int64_t)n * hw), hw, wdim, c, v, 0.25f, g);
+      } else {
+        VecIO<T, V>::load(gz + p * c + v * V, g);
+      }
       VecIO<T, V>::load(z + p * c + v * V, zz);
 #pragma unroll
       for (int j = 0; j < V; ++j) {
@@ -337,6 +369,7 @@ __global__ void lrelu_bwd_bias_kernel(const T* __restrict__ gz, const T* __restr
       VecIO<T, V>::store(gy + p * c + v * V, g);
     }
   }
+  if (!gbias) return;
   wave_channel_accumulate<V>(a, sh, 0, cv, v, pl < lanes);
   __syncthreads();
   for (int i = threadIdx.x; i < c; i += blockDim.x) atomicAdd(gbias + i, sh[i]);
@@ -415,12 +448,14 @@ int tg_norm_act_fwd(const void* y, const float* mean, const float* rstd, const f
   return TG_OK;
 }
 
-int tg_norm_act_bwd(const void* gz, const void* y, const float* pn_scale, const float* mean, const float* rstd,
+int tg_norm_act_bwd(const void* gz, const void* gz_pooled, const void* y, const float* pn_scale, const float* mean,
+                    const float* rstd,
                     const float* gamma, const float* beta, const float* gamma2, const float* beta2, int split, void* gy,
                     float* ggamma, float* gbeta, float* ggamma2, float* gbeta2, float* sums, int n, int h, int w, int c,
                     int flags, float alpha, int accumulate, int dtype, void* stream) {
-  TG_CHECK(gz && y && mean && rstd && gamma && beta && gy && sums && n > 0 && h > 0 && w > 0 && c > 0, TG_EINVAL,
-           "tg_norm_act_bwd: bad arguments");
+  TG_CHECK((gz || gz_pooled) && y && mean && rstd && gamma && beta && gy && sums && n > 0 && h > 0 && w > 0 && c > 0,
+           TG_EINVAL, "tg_norm_act_bwd: bad arguments");
+  TG_CHECK(!gz_pooled || (h % 2 == 0 && w % 2 == 0), TG_EINVAL, "tg_norm_act_bwd: pooled gradient needs even h, w");
   if (!gamma2 || !beta2) split = n;
   TG_CHECK(split >= 0 && split <= n, TG_EINVAL, "tg_norm_act_bwd: split %d outside [0, %d]", split, n);
   hipStream_t s = (hipStream_t)stream;
@@ -442,14 +477,14 @@ int tg_norm_act_bwd(const void* gz, const void* y, const float* pn_scale, const 
       TG_CHECK(vec && pn_scale, TG_ENOSUP, "tg_norm_act_bwd: pixel norm needs c (%d) = %d * 2^k and pn_scale", c, VN);
     }
     if (vec) {
-      hipLaunchKernelGGL((norm_act_bwd1_kernel<T, VN>), dim3(chunks, n), dim3(256), lds, s, (const T*)gz, (const T*)y,
-                         pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)gy, sums, hw, c, flags, alpha, ppb);
+      hipLaunchKernelGGL((norm_act_bwd1_kernel<T, VN>), dim3(chunks, n), dim3(256), lds, s, (const T*)gz,
+                         (const T*)gz_pooled, w, (const T*)y, pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)gy, sums, hw, c, flags, alpha, ppb);
       hipLaunchKernelGGL((norm_act_bwd2_kernel<T, VN>), dim3(tg_grid_for(npix * (c / VN), 256)), dim3(256), 0, s, (T*)gy,
                          (const T*)y, mean, rstd, gamma, gamma2, split, sums, npix, hw, c);
     } else {
       TG_CHECK(c <= 256, TG_ENOSUP, "tg_norm_act_bwd: scalar path needs c <= 256 (got %d)", c);
-      hipLaunchKernelGGL((norm_act_bwd1_kernel<T, 1>), dim3(chunks, n), dim3(256), lds, s, (const T*)gz, (const T*)y,
-                         pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)gy, sums, hw, c, flags, alpha, ppb);
+      hipLaunchKernelGGL((norm_act_bwd1_kernel<T, 1>), dim3(chunks, n), dim3(256), lds, s, (const T*)gz,
+                         (const T*)gz_pooled, w, (const T*)y, pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)gy, sums, hw, c, flags, alpha, ppb);
       hipLaunchKernelGGL((norm_act_bwd2_kernel<T, 1>), dim3(tg_grid_for(npix * c, 256)), dim3(256), 0, s, (T*)gy,
                          (const T*)y, mean, rstd, gamma, gamma2, split, sums, npix, hw, c);
     }
@@ -461,30 +496,50 @@ int tg_norm_act_bwd(const void* gz, const void* y, const float* pn_scale, const 
   return TG_OK;
 }
 
-int tg_lrelu_bwd_bias(const void* gz, const void* z, void* gy, float* gbias, int64_t npix, int c, float alpha,
-                      int accumulate, int dtype, void* stream) {
-  TG_CHECK(gz && z && gy && gbias && npix > 0 && c > 0, TG_EINVAL, "tg_lrelu_bwd_bias: bad arguments");
-  hipStream_t s = (hipStream_t)stream;
-  if (!accumulate) {
+static int lrelu_bwd_launch(const char* who, const void* gz, const void* gzp, int hw, int wdim, const void* z, void* gy,
+                            float* gbias, int64_t npix, int c, float alpha, int accumulate, int dtype, hipStream_t s) {
+  if (gbias && !accumulate) {
     int rc = tg_zero_async(gbias, (size_t)c * sizeof(float), nullptr, 0, s);
     if (rc) return rc;
   }
-  TG_DISPATCH_DTYPE(dtype, "tg_lrelu_bwd_bias", {
+  TG_DISPATCH_DTYPE(dtype, who, {
     const int V = pick_v<T>(c);
-    TG_CHECK(c / V <= 256, TG_ENOSUP, "tg_lrelu_bwd_bias: c=%d not supported", c);
+    TG_CHECK(c / V <= 256, TG_ENOSUP, "%s: c=%d not supported", who, c);
     const int lanes = 256 / (c / V);
-    // few, fat workgroups: every workgroup ends with c global atomics on the same c addresses
-    const int blocks = tg_grid_for(npix, lanes * 16, 512);
+    // few, fat workgroups when a bias gradient is produced: every workgroup ends with c global atomics
+    const int blocks = gbias ? tg_grid_for(npix, lanes * 16, 512) : tg_grid_for(npix, lanes * 4, 2048);
     const size_t lds = (size_t)c * sizeof(float);
     if (V == 1)
-      hipLaunchKernelGGL((lrelu_bwd_bias_kernel<T, 1>), dim3(blocks), dim3(256), lds, s, (const T*)gz, (const T*)z, (T*)gy,
-                         gbias, npix, c, alpha);
+      hipLaunchKernelGGL((lrelu_bwd_bias_kernel<T, 1>), dim3(blocks), dim3(256), lds, s, (const T*)gz, (const T*)gzp, hw,
+                         wdim, (const T*)z, (T*)gy, gbias, npix, c, alpha);
     else
       hipLaunchKernelGGL((lrelu_bwd_bias_kernel<T, Vec16<T>::N>), dim3(blocks), dim3(256), lds, s, (const T*)gz,
-                         (const T*)z, (T*)gy, gbias, npix, c, alpha);
+                         (const T*)gzp, hw, wdim, (const T*)z, (T*)gy, gbias, npix, c, alpha);
   });
-  TG_LAUNCH_CHECK("tg_lrelu_bwd_bias");
+  hipError_t e__ = hipGetLastError();
+  if (e__ != hipSuccess) {
+    tg_set_error("%s: launch failed: %s", who, hipGetErrorString(e__));
+    return TG_ELAUNCH;
+  }
   return TG_OK;
+}
+
+int tg_lrelu_bwd_bias(const void* gz, const void* z, void* gy, float* gbias, int64_t npix, int c, float alpha,
+                      int accumulate, int dtype, void* stream) {
+  TG_CHECK(gz && z && gy && gbias && npix > 0 && c > 0, TG_EINVAL, "tg_lrelu_bwd_bias: bad arguments");
+  return lrelu_bwd_launch("tg_lrelu_bwd_bias", gz, nullptr, 1, 1, z, gy, gbias, npix, c, alpha, accumulate, dtype,
+                          (hipStream_t)stream);
+}
+
+int tg_lrelu_pool_bwd(const void* gz, const void* gz_pooled, const void* z, void* gy, float* gbias, int n, int h, int w,
+                      int c, float alpha, int accumulate, int dtype, void* stream) {
+  TG_CHECK((gz || gz_pooled) && z && gy && n > 0 && h > 0 && w > 0 && c > 0, TG_EINVAL, "tg_lrelu_pool_bwd: bad arguments");
+  TG_CHECK(!gz_pooled || (h % 2 == 0 && w % 2 == 0), TG_EINVAL, "tg_lrelu_pool_bwd: pooled gradient needs even h, w");
+  if (!gz_pooled)
+    return lrelu_bwd_launch("tg_lrelu_pool_bwd", gz, nullptr, 1, 1, z, gy, gbias, (int64_t)n * h * w, c, alpha, accumulate,
+                            dtype, (hipStream_t)stream);
+  return lrelu_bwd_launch("tg_lrelu_pool_bwd", gz, gz_pooled, h * w, w, z, gy, gbias, (int64_t)n * h * w, c, alpha,
+                          accumulate, dtype, (hipStream_t)stream);
 }
 
 int tg_channel_sum(const void* g, float* out, int64_t npix, int c, int accumulate, int dtype, void* stream) {

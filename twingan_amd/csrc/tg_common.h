@@ -36,6 +36,10 @@ void tg_set_error(const char* fmt, ...);
     }                                                                             \
   } while (0)
 
+// Records the name of the kernel variant a dispatch picked (thread-local; read back with tg_last_kernel()), so
+// that host-side per-launch timing can be attributed to the same kernel symbols rocprofv3 reports.
+void tg_note_kernel(const char* fmt, ...);
+
 // Zero-fills up to two fp32-aligned device buffers with ONE kernel launch on `s`.  Used instead of
 // hipMemsetAsync everywhere: memset nodes captured into a hipGraph were observed to run out of order with
 // the kernels that accumulate into the buffer (ROCm 7.2), corrupting replayed steps.

@@ -173,7 +173,7 @@ def _conv_work(d, tag, es):
   flops = 2 * d.n * d.hout * d.wout * d.cout * d.kh * d.kw * d.cin
   by = es * d.n * (d.hin * d.win * d.cin + d.hout * d.wout * d.cout) + es * d.kh * d.kw * d.cin * d.cout
   algo = 'mfma' if d.algo == TG_ALGO_MFMA else 'direct'
-  return ('%s:%s:k%d:c%d>%d:hw%d' % (tag, algo, d.kh, d.cin, d.cout, d.hout), flops, by)
+  return ('%s:%s:k%d:c%d>%d:hw%d:n%d' % (tag, algo, d.kh, d.cin, d.cout, d.hout, d.n), flops, by)
 
 
 def _desc(x_shape, cout, spec, dtype, epilogue):
@@ -248,15 +248,18 @@ def _bias_grad(g, bias):
   return ChannelSumFn.apply(g)
 
 
-def lrelu_bwd_bias(gz, z, alpha, bias):
-  """g = gz * lrelu'(z) and the bias gradient in one pass; returns (g, gb) with gb None when sunk."""
-  _chk(gz, z)
-  g = torch.empty_like(gz)
-  c = gz.shape[-1]
-  sink = GradSink.get(bias)
-  gb = sink if sink is not None else torch.empty(c, dtype=torch.float32, device=gz.device)
-  call('tg_lrelu_bwd_bias', _p(gz), _p(z), _p(g), _p(gb), gz.numel() // c, c, alpha, 1 if sink is not None else 0,
-       _dt(gz), _stream(), work=('lrelu_bwd_bias', 0, 3 * gz.numel() * _esize(gz)))
+def lrelu_pool_bwd(gz, gzp, z, alpha, bias, want_bias):
+  """g = (gz + 0.25 * upsample2(gzp)) * lrelu'(z), optionally with the bias gradient, in one pass.
+  Returns (g, gb) with gb None when it was added into the bias' gradient sink (or not wanted)."""
+  _chk(gz, gzp, z)
+  g = torch.empty_like(z)
+  n, h, w, c = z.shape
+  sink = GradSink.get(bias) if want_bias else None
+  gb = None
+  if want_bias:
+    gb = sink if sink is not None else torch.empty(c, dtype=torch.float32, device=z.device)
+  call('tg_lrelu_pool_bwd', _p(gz), _p(gzp), _p(z), _p(g), _p(gb), n, h, w, c, alpha, 1 if sink is not None else 0,
+       _dt(z), _stream(), work=('lrelu_pool_bwd', 0, int((2 + (gz is not None) + 0.25 * (gzp is not None)) * z.numel()) * _esize(z)))
   return g, (None if sink is not None else gb)
 
 
@@ -297,9 +300,42 @@ def cast_raw(x, dtype):
   return out
 
 
+
+
 # ------------------------------------------------------------------------------------------------
 # convolution  (layers.conv2d, nets/pggan_utils.py:316-320)
 # ------------------------------------------------------------------------------------------------
+def _conv_backward(ctx, gz, gzp=None):
+  """Shared backward of Conv2dFn / Conv2dPoolFn.  ``gzp``: gradient of the 2x2-average-pooled output."""
+  x, w, z, bias = ctx.saved_tensors
+  spec = ctx.spec
+  params = not _State.skip_param_grads
+  need_w = ctx.needs_input_grad[1] and params
+  need_b = bool(ctx.epilogue & TG_EPI_BIAS) and ctx.needs_input_grad[2] and params
+  gb = None
+  gz = gz.contiguous() if gz is not None else None
+  gzp = gzp.contiguous() if gzp is not None else None
+  fused = (ctx.epilogue & TG_EPI_LRELU) and not torch.is_grad_enabled()
+  if gzp is not None and not fused:
+    # differentiable composition (create_graph) or no activation: materialise the upsampled pooled gradient
+    up = Pool2BwdFn.apply(gzp, 0.25, (z.shape[1], z.shape[2]) if z is not None else ctx.out_hw)
+    gz = up if gz is None else gz + up
+    gzp = None
+  if ctx.epilogue & TG_EPI_LRELU:
+    if fused and (need_b or gzp is not None):
+      g, gb = lrelu_pool_bwd(gz, gzp, z, spec.alpha, bias if need_b else None, need_b)
+      need_b = False
+    else:
+      g = LReluBwdFn.apply(gz, z, spec.alpha)
+  else:
+    g = gz
+  gx = ConvBwdDataFn.apply(g, w, tuple(x.shape), spec) if ctx.needs_input_grad[0] else None
+  gw = _weight_grad(x, g, spec, w) if need_w else None
+  if need_b:
+    gb = _bias_grad(g, bias)
+  return gx, gw, gb, None, None
+
+
 class Conv2dFn(torch.autograd.Function):
   """z = epilogue(conv(x, w) [+ bias]) with epilogue in {none, bias, bias+lrelu, lrelu}."""
 
@@ -307,31 +343,37 @@ class Conv2dFn(torch.autograd.Function):
   def forward(ctx, x, w, bias, spec, epilogue):
     z = conv_fwd_raw(x, w, bias, spec, epilogue)
     ctx.spec, ctx.epilogue = spec, epilogue
+    ctx.out_hw = (z.shape[1], z.shape[2])
     ctx.save_for_backward(x, w, z if (epilogue & TG_EPI_LRELU) else None, bias)
     return z
 
   @staticmethod
   def backward(ctx, gz):
-    x, w, z, bias = ctx.saved_tensors
-    spec = ctx.spec
-    gz = gz.contiguous()
-    params = not _State.skip_param_grads
-    need_w = ctx.needs_input_grad[1] and params
-    need_b = bool(ctx.epilogue & TG_EPI_BIAS) and ctx.needs_input_grad[2] and params
-    gb = None
-    if ctx.epilogue & TG_EPI_LRELU:
-      if need_b and not torch.is_grad_enabled():
-        g, gb = lrelu_bwd_bias(gz, z, spec.alpha, bias)
-        need_b = False
-      else:
-        g = LReluBwdFn.apply(gz, z, spec.alpha)
-    else:
-      g = gz
-    gx = ConvBwdDataFn.apply(g, w, tuple(x.shape), spec) if ctx.needs_input_grad[0] else None
-    gw = _weight_grad(x, g, spec, w) if need_w else None
-    if need_b:
-      gb = _bias_grad(g, bias)
-    return gx, gw, gb, None, None
+    return _conv_backward(ctx, gz)
+
+
+class Conv2dPoolFn(torch.autograd.Function):
+  """(z, avg_pool2(z)) with z = epilogue(conv(x, w) [+ bias]) -- the last conv of a discriminator block and
+  the tf.nn.avg_pool after it (nets/pggan.py:304-306).  Outside create_graph mode the backward folds the
+  pool's gradient into the LeakyReLU / bias-gradient kernel instead of upsampling it through HBM."""
+
+  @staticmethod
+  def forward(ctx, x, w, bias, spec, epilogue):
+    z = conv_fwd_raw(x, w, bias, spec, epilogue)
+    n, h, ww, c = z.shape
+    zp = torch.empty((n, h // 2, ww // 2, c), dtype=z.dtype, device=z.device)
+    call('tg_pool2x2_fwd', _p(z), _p(zp), n, h, ww, c, 0.25, _dt(z), _stream())
+    ctx.spec, ctx.epilogue = spec, epilogue
+    ctx.out_hw = (h, ww)
+    ctx.set_materialize_grads(False)
+    ctx.save_for_backward(x, w, z if (epilogue & TG_EPI_LRELU) else None, bias)
+    return z, zp
+
+  @staticmethod
+  def backward(ctx, gz, gzp):
+    if gz is None and gzp is None:
+      return None, None, None, None, None
+    return _conv_backward(ctx, gz, gzp)
 
 
 class ConvBwdDataFn(torch.autograd.Function):
@@ -394,10 +436,13 @@ class ChannelSumFn(torch.autograd.Function):
     raise NotImplementedError('gradient through a bias gradient')
 
 
-def conv2d(x, w, bias=None, k=3, padding='SAME', lrelu=False, alpha=LRELU_ALPHA):
-  """Stride-1 conv, optional fused bias and LeakyReLU (discriminator layers)."""
+def conv2d(x, w, bias=None, k=3, padding='SAME', lrelu=False, alpha=LRELU_ALPHA, pool=False):
+  """Stride-1 conv, optional fused bias and LeakyReLU (discriminator layers).  ``pool``: also return the
+  2x2 average-pooled output -> (z, z_pooled)."""
   spec = ConvSpec(k, padding, 0, alpha)
   epi = (TG_EPI_BIAS if bias is not None else 0) | (TG_EPI_LRELU if lrelu else 0)
+  if pool:
+    return Conv2dPoolFn.apply(x, w, bias, spec, epi)
   return Conv2dFn.apply(x, w, bias, spec, epi)
 
 
@@ -434,7 +479,8 @@ class PointwiseConvFn(torch.autograd.Function):
     gb = None
     if ctx.epilogue & TG_EPI_LRELU:
       if need_b and not torch.is_grad_enabled():
-        g, gb = lrelu_bwd_bias(gz, z, ctx.alpha, bias)
+        g, gb = lrelu_pool_bwd(gz, None, z.reshape(-1, 1, 1, z.shape[-1]) if z.dim() != 4 else z, ctx.alpha, bias, True)
+        g = g.reshape(gz.shape)
         need_b = False
       else:
         g = LReluBwdFn.apply(gz, z, ctx.alpha)
@@ -483,6 +529,50 @@ def pointwise_conv(x, w_hwio, bias=None, lrelu=False, alpha=LRELU_ALPHA):
 # ------------------------------------------------------------------------------------------------
 # instance norm + LeakyReLU + pixel norm (generator / encoder layers)
 # ------------------------------------------------------------------------------------------------
+def _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha):
+  _chk(y, gamma, beta, gamma2, beta2)
+  n, h, w, c = y.shape
+  split = n if gamma2 is None else int(split)
+  mean = torch.empty(n * c, dtype=torch.float32, device=y.device)
+  rstd = torch.empty(n * c, dtype=torch.float32, device=y.device)
+  call('tg_instance_norm_stats', _p(y), _p(mean), _p(rstd), n, h, w, c, in_eps, _dt(y), _stream(),
+       work=('in_stats', 0, y.numel() * _esize(y)))
+  z = torch.empty_like(y)
+  s = torch.empty(n * h * w, dtype=torch.float32, device=y.device) if (flags & NF_PIXNORM) else None
+  call('tg_norm_act_fwd', _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(gamma2), _p(beta2), split, _p(z), _p(s),
+       n, h, w, c, flags, alpha, pn_eps, _dt(y), _stream(), work=('norm_act_fwd', 0, 2 * y.numel() * _esize(y)))
+  ctx.flags, ctx.alpha, ctx.split = flags, alpha, split
+  ctx.save_for_backward(y, mean, rstd, gamma, beta, gamma2, beta2, s)
+  return z
+
+
+def _norm_act_backward(ctx, gz, gzp=None):
+  y, mean, rstd, gamma, beta, gamma2, beta2, s = ctx.saved_tensors
+  gz = gz.contiguous() if gz is not None else None
+  gzp = gzp.contiguous() if gzp is not None else None
+  n, h, w, c = y.shape
+  gy = torch.empty_like(y)
+  sums = torch.empty(2 * n * c, dtype=torch.float32, device=y.device)
+  two = gamma2 is not None
+  params = [gamma, beta] + ([gamma2, beta2] if two else [])
+  sinks = [GradSink.get(q) for q in params]
+  sunk = all(t is not None for t in sinks)
+  if _State.skip_param_grads:
+    outs = [None] * 4
+  elif sunk:
+    outs = sinks + [None] * (4 - len(sinks))
+  else:
+    outs = [torch.empty(c, dtype=torch.float32, device=y.device) for _ in params] + [None] * (4 - len(params))
+  passes = 3 + (0.25 if gzp is not None else 0) - (0 if gz is not None else 1)
+  call('tg_norm_act_bwd', _p(gz), _p(gzp), _p(y), _p(s), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(gamma2), _p(beta2),
+       ctx.split, _p(gy), _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), _p(sums), n, h, w, c, ctx.flags, ctx.alpha,
+       1 if (sunk and not _State.skip_param_grads) else 0, _dt(y), _stream(),
+       work=('norm_act_bwd', 0, int(passes * y.numel()) * _esize(y)))
+  if sunk or _State.skip_param_grads:
+    outs = [None] * 4
+  return gy, outs[0], outs[1], outs[2], outs[3], None, None, None, None, None
+
+
 class NormActFn(torch.autograd.Function):
   """z = pixel_norm(lrelu(instance_norm(y; gamma, beta))) -- libs/instance_norm.py:131-135,
   util_misc.py:86, nets/pggan_utils.py:330-331.  First-order only (E/G never sit under the
@@ -490,52 +580,42 @@ class NormActFn(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha):
-    _chk(y, gamma, beta, gamma2, beta2)
-    n, h, w, c = y.shape
-    split = n if gamma2 is None else int(split)
-    mean = torch.empty(n * c, dtype=torch.float32, device=y.device)
-    rstd = torch.empty(n * c, dtype=torch.float32, device=y.device)
-    call('tg_instance_norm_stats', _p(y), _p(mean), _p(rstd), n, h, w, c, in_eps, _dt(y), _stream(),
-         work=('in_stats', 0, y.numel() * _esize(y)))
-    z = torch.empty_like(y)
-    s = torch.empty(n * h * w, dtype=torch.float32, device=y.device) if (flags & NF_PIXNORM) else None
-    call('tg_norm_act_fwd', _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(gamma2), _p(beta2), split, _p(z), _p(s),
-         n, h, w, c, flags, alpha, pn_eps, _dt(y), _stream(), work=('norm_act_fwd', 0, 2 * y.numel() * _esize(y)))
-    ctx.flags, ctx.alpha, ctx.split = flags, alpha, split
-    ctx.save_for_backward(y, mean, rstd, gamma, beta, gamma2, beta2, s)
-    return z
+    return _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha)
 
   @staticmethod
   @torch.autograd.function.once_differentiable
   def backward(ctx, gz):
-    y, mean, rstd, gamma, beta, gamma2, beta2, s = ctx.saved_tensors
-    gz = gz.contiguous()
-    n, h, w, c = y.shape
-    gy = torch.empty_like(y)
-    sums = torch.empty(2 * n * c, dtype=torch.float32, device=y.device)
-    two = gamma2 is not None
-    params = [gamma, beta] + ([gamma2, beta2] if two else [])
-    sinks = [GradSink.get(q) for q in params]
-    sunk = all(t is not None for t in sinks)
-    if _State.skip_param_grads:
-      outs = [None] * 4
-    elif sunk:
-      outs = sinks + [None] * (4 - len(sinks))
-    else:
-      outs = [torch.empty(c, dtype=torch.float32, device=y.device) for _ in params] + [None] * (4 - len(params))
-    call('tg_norm_act_bwd', _p(gz), _p(y), _p(s), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(gamma2), _p(beta2),
-         ctx.split, _p(gy), _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), _p(sums), n, h, w, c, ctx.flags, ctx.alpha,
-         1 if (sunk and not _State.skip_param_grads) else 0, _dt(y), _stream(),
-         work=('norm_act_bwd', 0, 3 * y.numel() * _esize(y)))
-    if sunk or _State.skip_param_grads:
-      outs = [None] * 4
-    return gy, outs[0], outs[1], outs[2], outs[3], None, None, None, None, None
+    return _norm_act_backward(ctx, gz)
+
+
+class NormActPoolFn(torch.autograd.Function):
+  """(z, avg_pool2(z)) for the last layer of an encoder block (nets/pggan.py:466-468): z is the UNet skip
+  end-point, the pooled tensor feeds the next block.  The backward takes both gradients and folds the pool
+  (and the sum of the two) into the normalisation backward kernel."""
+
+  @staticmethod
+  def forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha):
+    z = _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha)
+    n, h, w, c = z.shape
+    zp = torch.empty((n, h // 2, w // 2, c), dtype=z.dtype, device=z.device)
+    call('tg_pool2x2_fwd', _p(z), _p(zp), n, h, w, c, 0.25, _dt(z), _stream())
+    ctx.set_materialize_grads(False)
+    return z, zp
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, gz, gzp):
+    if gz is None and gzp is None:
+      return (None,) * 10
+    return _norm_act_backward(ctx, gz, gzp)
 
 
 def norm_act(y, gamma, beta, lrelu=True, pixel_norm=True, in_eps=1e-6, pn_eps=1e-6, alpha=LRELU_ALPHA, gamma2=None,
-             beta2=None, split=None):
+             beta2=None, split=None, pool=False):
+  """``pool``: also return the 2x2 average-pooled output -> (z, z_pooled)."""
   flags = (NF_LRELU if lrelu else 0) | (NF_PIXNORM if pixel_norm else 0)
-  return NormActFn.apply(y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha)
+  fn = NormActPoolFn if pool else NormActFn
+  return fn.apply(y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -16,7 +16,7 @@ from .params import get_num_channels, max_stage_of, mbstd_cpad
 # ------------------------------------------------------------------------------------------------
 # layer helpers (nets/pggan_utils.py)
 # ------------------------------------------------------------------------------------------------
-def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pixel_norm=True):
+def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pixel_norm=True, pool=False):
   """maybe_pixel_norm(maybe_equalized_conv2d(...)) for the generator / encoder arg-scope
   (nets/pggan_utils.py:86-98,236-245): conv without bias, per-domain instance norm, LeakyReLU(0.2),
   then pixel norm (nets/pggan.py:78-81).  ``domain`` is 's' | 't', or (d0, d1, split): the batch holds
@@ -32,22 +32,22 @@ def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pix
       return ops.norm_act(y, P['%s/InstanceNorm/gamma_%s' % (scope, d0)], P['%s/InstanceNorm/beta_%s' % (scope, d0)],
                           lrelu=activation, pixel_norm=pixel_norm and cfg.do_pixel_norm,
                           gamma2=P['%s/InstanceNorm/gamma_%s' % (scope, d1)],
-                          beta2=P['%s/InstanceNorm/beta_%s' % (scope, d1)], split=split)
+                          beta2=P['%s/InstanceNorm/beta_%s' % (scope, d1)], split=split, pool=pool)
     return ops.norm_act(y, P['%s/InstanceNorm/gamma_%s' % (scope, domain)],
                         P['%s/InstanceNorm/beta_%s' % (scope, domain)], lrelu=activation,
-                        pixel_norm=pixel_norm and cfg.do_pixel_norm)
+                        pixel_norm=pixel_norm and cfg.do_pixel_norm, pool=pool)
   raise NotImplementedError('generator_norm_type=%s (only instance_norm is on the MI355X hot path)' %
                             cfg.generator_norm_type)
 
 
-def _d_conv(P, scope, x, k=3, padding='SAME'):
+def _d_conv(P, scope, x, k=3, padding='SAME', pool=False):
   """Discriminator arg-scope (nets/pggan_utils.py:116-127): conv + bias, no norm, LeakyReLU(0.2),
   fused into the conv epilogue."""
   w = P[scope + '/weights']
   b = P[scope + '/biases']
   if k == 1 and (w.shape[2] <= 4 or w.shape[3] <= 4):
     return ops.pointwise_conv(x, w, b, lrelu=True)
-  return ops.conv2d(x, w, b, k, padding, lrelu=True)
+  return ops.conv2d(x, w, b, k, padding, lrelu=True, pool=pool)
 
 
 def resize_twice_as_big(x):
@@ -90,10 +90,9 @@ def encoder_before_classification(P, source, domain, cfg, top='encoder_content')
     current_hw = hw // (2 ** (max_stage - stage))
     name = 'encoder_block_%dx%dx%d' % (current_hw, current_hw, num_channels)
     net = _ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg)
-    net = _ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg)
-    end_points[name] = net
+    # last layer of the block + tf.nn.avg_pool (nets/pggan.py:466-468) as one op: (skip end-point, pooled)
+    end_points[name], net = _ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg, pool=True)
     current_hw //= 2
-    net = ops.avg_pool2(net)
     end_points['downsample_to_%dx%dx%d' % (current_hw, current_hw, num_channels)] = net
     if stage == max_stage and cfg.is_growing:
       net = ops.lerp(net, shrinked, cfg.alpha_grow)
@@ -170,10 +169,8 @@ def discriminator_before_fc(P, source, cfg, top, groups=1):
     current_hw = hw // (2 ** (max_stage - stage))
     name = 'encoder_block_%dx%dx%d' % (current_hw, current_hw, num_channels)
     net = _d_conv(P, '%s/%s/Conv' % (top, name), net)
-    net = _d_conv(P, '%s/%s/Conv_1' % (top, name), net)
-    end_points[name] = net
+    end_points[name], net = _d_conv(P, '%s/%s/Conv_1' % (top, name), net, pool=True)      # conv + avg_pool (pggan.py:304-306)
     current_hw //= 2
-    net = ops.avg_pool2(net)
     end_points['downsample_to_%dx%dx%d' % (current_hw, current_hw, num_channels)] = net
     if stage == max_stage and cfg.is_growing:
       net = ops.lerp(net, shrinked, cfg.alpha_grow)
