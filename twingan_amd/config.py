@@ -26,4 +26,5 @@ class Config:
   adam_beta2: float = 0.99
   opt_epsilon: float = 1e-8
   precision: str = 'bf16'             # 'bf16': bf16 activations + MFMA convs, fp32 master weights; 'fp32': exact path
+  domain_streams: bool = True         # run the two (independent) discriminators on two HIP streams
   loss_scale: float = 1.0             # --mix_precision_loss_scale (model_inheritor.py:568-570); bf16 needs none

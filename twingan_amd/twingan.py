@@ -23,6 +23,46 @@ from .ops import PackCache
 from .params import ParamStore, declare_twingan
 
 
+class _DomainStreams:
+  """The two discriminators (discriminator_s / discriminator_t) are independent networks: their passes --
+  forward, backward and the WGAN-GP double backward -- are enqueued on two HIP streams so the many small
+  (launch- and latency-bound) kernels of the 4x4..32x32 stages of one overlap with the other.  Autograd runs
+  every backward node on the stream its forward ran on, so the backward overlaps the same way; both forks and
+  the join are stream-wait edges, which hipGraph capture records as graph dependencies."""
+  _pool = {}
+
+  def __init__(self, device, enabled):
+    self.enabled = enabled and torch.cuda.is_available()
+    if self.enabled:
+      key = torch.device(device).index
+      if key not in self._pool:
+        self._pool[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+      self.side = self._pool[key]
+      self.main = torch.cuda.current_stream(device)
+      for st in self.side:
+        st.wait_stream(self.main)
+
+  def domain(self, i):
+    import contextlib
+    return torch.cuda.stream(self.side[i]) if self.enabled else contextlib.nullcontext()
+
+  def join(self):
+    if self.enabled:
+      for st in self.side:
+        self.main.wait_stream(st)
+
+  @classmethod
+  def join_all(cls, device):
+    """The current stream waits for the domain streams.  Needed after ``backward()``: parameter gradients are
+    accumulated into the flat buffers by the backward kernels themselves (ops.GradSink), on the stream of
+    the forward op, and autograd only joins streams of gradients it accumulates itself."""
+    key = torch.device(device).index
+    if key in cls._pool:
+      main = torch.cuda.current_stream(device)
+      for st in cls._pool[key]:
+        main.wait_stream(st)
+
+
 def act_dtype(cfg):
   return torch.bfloat16 if cfg.precision == 'bf16' else torch.float32
 
@@ -65,20 +105,23 @@ def generator_loss(P, sources, targets, cfg):
   e_sp, e_tp = e2.chunk(2)
   cyc_gan = cfg.hw >= 64 and cfg.do_l_cyc_gan
   terms = {}
-  for d, orig, prime, cyc, enc_orig, enc_opp_prime in (
+  streams = _DomainStreams(sources.device, cfg.domain_streams)
+  for i, (d, orig, prime, cyc, enc_orig, enc_opp_prime) in enumerate((
       ('s', sources, o['s_prime'], o['s_cycle'], o['es'], e_tp),
-      ('t', targets, o['t_prime'], o['t_cycle'], o['et'], e_sp)):
+      ('t', targets, o['t_prime'], o['t_cycle'], o['et'], e_sp))):
     top = 'discriminator_' + d
-    terms['l_cyc_' + d] = ops.abs_diff_mean(orig, cyc, cfg.l_cyc_weight)
-    if cyc_gan:      # D(cyc) and D(prime) of one domain share weights: one batch, two minibatch-stddev groups
-      pred, _ = pggan.discriminator(P, torch.cat([cyc, prime], dim=0), cfg, top, groups=2)
-      pc, pp = pred.chunk(2)
-      terms['generator_fool_loss_cycle_' + d] = ops.mean(pc.contiguous(), -cfg.gan_weight)
-    else:
-      pp, _ = pggan.discriminator(P, prime, cfg, top)
-    terms['generator_fool_loss_prime_' + d] = ops.mean(pp.contiguous(), -cfg.gan_weight)
-    if cfg.l_content_weight:
-      terms['l_content_' + d] = ops.abs_diff_mean(enc_orig, enc_opp_prime, cfg.l_content_weight)
+    with streams.domain(i):
+      terms['l_cyc_' + d] = ops.abs_diff_mean(orig, cyc, cfg.l_cyc_weight)
+      if cyc_gan:      # D(cyc) and D(prime) of one domain share weights: one batch, two minibatch-stddev groups
+        pred, _ = pggan.discriminator(P, torch.cat([cyc, prime], dim=0), cfg, top, groups=2)
+        pc, pp = pred.chunk(2)
+        terms['generator_fool_loss_cycle_' + d] = ops.mean(pc.contiguous(), -cfg.gan_weight)
+      else:
+        pp, _ = pggan.discriminator(P, prime, cfg, top)
+      terms['generator_fool_loss_prime_' + d] = ops.mean(pp.contiguous(), -cfg.gan_weight)
+      if cfg.l_content_weight:
+        terms['l_content_' + d] = ops.abs_diff_mean(enc_orig, enc_opp_prime, cfg.l_content_weight)
+  streams.join()
   total = None
   for v in terms.values():
     total = v if total is None else total + v
@@ -95,9 +138,22 @@ def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t):
     o = forward_generators(P, sources, targets, cfg)
   cyc_gan = cfg.hw >= 64 and cfg.do_l_cyc_gan
   terms = {}
-  for d, real, prime, cyc, a in (('s', sources, o['s_prime'], o['s_cycle'], gp_alpha_s),
-                                 ('t', targets, o['t_prime'], o['t_cycle'], gp_alpha_t)):
+  streams = _DomainStreams(sources.device, cfg.domain_streams)
+  for i, (d, real, prime, cyc, a) in enumerate((('s', sources, o['s_prime'], o['s_cycle'], gp_alpha_s),
+                                                ('t', targets, o['t_prime'], o['t_cycle'], gp_alpha_t))):
     top = 'discriminator_' + d
+    with streams.domain(i):
+      _d_domain_terms(P, cfg, terms, d, top, real, prime, cyc, a, cyc_gan)
+  streams.join()
+  total = None
+  for v in terms.values():
+    total = v if total is None else total + v
+  return total, terms
+
+
+def _d_domain_terms(P, cfg, terms, d, top, real, prime, cyc, a, cyc_gan):
+  """One domain's DISCRIMINATOR_LOSSES (the body of the loop in image_generation.py:348-379,414-439)."""
+  if True:
     # D(real), D(cyc), D(prime) of one domain share weights: one batch, one minibatch-stddev group per call
     if cyc_gan:
       pred, _ = pggan.discriminator(P, torch.cat([real, cyc, prime], dim=0), cfg, top, groups=3)
@@ -119,10 +175,6 @@ def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t):
         gi, = torch.autograd.grad(pi, interp, grad_outputs=ones, create_graph=True)  # tf.gradients(pred, interp)
       terms['discriminator_gradient_penalty_prime_' + d] = ops.gradient_penalty(gi.contiguous(),
                                                                                 cfg.gradient_penalty_lambda)
-  total = None
-  for v in terms.values():
-    total = v if total is None else total + v
-  return total, terms
 
 
 class Trainer:
@@ -179,6 +231,7 @@ class Trainer:
     self._set_requires_grad(g=True, d=False)
     loss, terms = generator_loss(self.P, sources, targets, self.cfg)
     (loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)).backward()     # model_deploy.py:265-268,308-313
+    _DomainStreams.join_all(self.device)
     return loss.detach(), {k: v.detach() for k, v in terms.items()}
 
   def _d_grads(self, sources, targets, gp_alpha_s=None, gp_alpha_t=None):
@@ -191,6 +244,7 @@ class Trainer:
     self._set_requires_grad(g=False, d=True)
     loss, terms = discriminator_loss(self.P, sources, targets, self.cfg, gp_alpha_s, gp_alpha_t)
     (loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)).backward()
+    _DomainStreams.join_all(self.device)
     return loss.detach(), {k: v.detach() for k, v in terms.items()}
 
   def g_step(self, sources, targets):
