@@ -198,8 +198,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
 }
 
 // gw[i] (+)= sum over the k-slices of slab[k][i].  A workgroup owns 256/SG consecutive elements; its 256
-// threads are SG slice groups x 256/SG elements, summed through LDS: no atomics, no pre-zeroing,
-// deterministic.  SG is large for small weights (few elements, many slices) and 1 for large ones.
+// threads are SG slice groups x 256/SG elements, summed through LDS: no pre-zeroing; one
+// atomic per element only when accumulating into an existing gradient (several streams may feed one sink).  SG is large for small weights (few elements, many slices) and 1 for large ones.
 template <int SG>
 __global__ __launch_bounds__(256) void conv_wgrad_slab_reduce(const float* __restrict__ slab, float* __restrict__ gw,
                                                               int64_t nw, int nslices, int accumulate) {
@@ -217,16 +217,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_slab_reduce(const float* __res
     if (k < nslices) s0 += slab[(size_t)k * nw + i];
   }
   if (SG == 1) {
-    if (i < nw) gw[i] = (accumulate ? gw[i] : 0.f) + s0 + s1;
+    if (i < nw) {
+      if (accumulate) atomicAdd(gw + i, s0 + s1);      // sinks may be fed from several streams at once
+      else gw[i] = s0 + s1;
+    }
     return;
   }
   part[sg][e] = s0 + s1;
   __syncthreads();
   if (threadIdx.x < EPB && i < nw) {
-    float t = accumulate ? gw[i] : 0.f;
+    float t = 0.f;
 #pragma unroll
     for (int j = 0; j < SG; ++j) t += part[j][e];
-    gw[i] = t;
+    if (accumulate) atomicAdd(gw + i, t);              // sinks may be fed from several streams at once
+    else gw[i] = t;
   }
 }
 

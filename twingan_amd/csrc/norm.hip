@@ -308,8 +308,14 @@ __global__ void norm_param_grads(const float* __restrict__ sums, float* __restri
     sb += sums[((int64_t)i * c + ch) * 2];
     sg += sums[((int64_t)i * c + ch) * 2 + 1];
   }
-  if (gg) gg[ch] = (accumulate ? gg[ch] : 0.f) + sg;
-  if (gb) gb[ch] = (accumulate ? gb[ch] : 0.f) + sb;
+  if (gg) {
+    if (accumulate) atomicAdd(gg + ch, sg);
+    else gg[ch] = sg;
+  }
+  if (gb) {
+    if (accumulate) atomicAdd(gb + ch, sb);
+    else gb[ch] = sb;
+  }
 }
 
 // out[c] += sum_p g[p][c]

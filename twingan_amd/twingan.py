@@ -31,12 +31,14 @@ class _DomainStreams:
   the join are stream-wait edges, which hipGraph capture records as graph dependencies."""
   _pool = {}
 
+  NSTREAMS = 2      # measured: 2 streams 676 img/s, 4 streams (GP passes on their own) 615-623
+
   def __init__(self, device, enabled):
     self.enabled = enabled and torch.cuda.is_available()
     if self.enabled:
       key = torch.device(device).index
       if key not in self._pool:
-        self._pool[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        self._pool[key] = tuple(torch.cuda.Stream(device=device) for _ in range(self.NSTREAMS))
       self.side = self._pool[key]
       self.main = torch.cuda.current_stream(device)
       for st in self.side:
@@ -100,15 +102,12 @@ def generator_loss(P, sources, targets, cfg):
     sources, targets = get_growing_image(sources, cfg.alpha_grow), get_growing_image(targets, cfg.alpha_grow)
   b = sources.shape[0]
   o = forward_generators(P, sources, targets, cfg)
-  # re-encode s' in domain s and t' in domain t as one batch (twingan.py:275-288)
-  e2, _ = pggan.encoder_before_classification(P, torch.cat([o['s_prime'], o['t_prime']], dim=0), ('s', 't', b), cfg)
-  e_sp, e_tp = e2.chunk(2)
   cyc_gan = cfg.hw >= 64 and cfg.do_l_cyc_gan
   terms = {}
+  # fork: the two discriminators run on their own streams while the main stream re-encodes s' / t'
   streams = _DomainStreams(sources.device, cfg.domain_streams)
-  for i, (d, orig, prime, cyc, enc_orig, enc_opp_prime) in enumerate((
-      ('s', sources, o['s_prime'], o['s_cycle'], o['es'], e_tp),
-      ('t', targets, o['t_prime'], o['t_cycle'], o['et'], e_sp))):
+  for i, (d, orig, prime, cyc) in enumerate((('s', sources, o['s_prime'], o['s_cycle']),
+                                             ('t', targets, o['t_prime'], o['t_cycle']))):
     top = 'discriminator_' + d
     with streams.domain(i):
       terms['l_cyc_' + d] = ops.abs_diff_mean(orig, cyc, cfg.l_cyc_weight)
@@ -119,8 +118,12 @@ def generator_loss(P, sources, targets, cfg):
       else:
         pp, _ = pggan.discriminator(P, prime, cfg, top)
       terms['generator_fool_loss_prime_' + d] = ops.mean(pp.contiguous(), -cfg.gan_weight)
-      if cfg.l_content_weight:
-        terms['l_content_' + d] = ops.abs_diff_mean(enc_orig, enc_opp_prime, cfg.l_content_weight)
+  # re-encode s' in domain s and t' in domain t as one batch (twingan.py:275-288)
+  e2, _ = pggan.encoder_before_classification(P, torch.cat([o['s_prime'], o['t_prime']], dim=0), ('s', 't', b), cfg)
+  e_sp, e_tp = e2.chunk(2)
+  if cfg.l_content_weight:
+    terms['l_content_s'] = ops.abs_diff_mean(o['es'], e_tp, cfg.l_content_weight)
+    terms['l_content_t'] = ops.abs_diff_mean(o['et'], e_sp, cfg.l_content_weight)
   streams.join()
   total = None
   for v in terms.values():
@@ -144,6 +147,8 @@ def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t):
     top = 'discriminator_' + d
     with streams.domain(i):
       _d_domain_terms(P, cfg, terms, d, top, real, prime, cyc, a, cyc_gan)
+      if cfg.loss_architecture == 'wgan_gp':
+        _d_domain_gp(P, cfg, terms, d, top, real, prime, a)
   streams.join()
   total = None
   for v in terms.values():
@@ -167,14 +172,16 @@ def _d_domain_terms(P, cfg, terms, d, top, real, prime, cyc, a, cyc_gan):
     terms['discriminator_loss_prime_' + d] = ops.mean(pp, cfg.gan_weight) - mean_real
     if cfg.wgan_drift_loss_weight:
       raise NotImplementedError('wgan_drift_loss_weight (image_generation.py:360-367) is off in every BASELINE config')
-    if cfg.loss_architecture == 'wgan_gp':
-      interp = ops.sample_lerp(real, prime, a).requires_grad_(True)               # image_generation.py:420-424
-      pi, _ = pggan.discriminator(P, interp, cfg, top)
-      ones = ops.fill(pi.shape, 1.0, pi.dtype, pi.device)
-      with ops.no_param_grads():        # only d pred / d interp is needed here; parameters get theirs via the double backward
-        gi, = torch.autograd.grad(pi, interp, grad_outputs=ones, create_graph=True)  # tf.gradients(pred, interp)
-      terms['discriminator_gradient_penalty_prime_' + d] = ops.gradient_penalty(gi.contiguous(),
-                                                                                cfg.gradient_penalty_lambda)
+
+
+def _d_domain_gp(P, cfg, terms, d, top, real, prime, a):
+  """WGAN-GP term of one domain (image_generation.py:414-439)."""
+  interp = ops.sample_lerp(real, prime, a).requires_grad_(True)               # image_generation.py:420-424
+  pi, _ = pggan.discriminator(P, interp, cfg, top)
+  ones = ops.fill(pi.shape, 1.0, pi.dtype, pi.device)
+  with ops.no_param_grads():        # only d pred / d interp is needed here; parameters get theirs via the double backward
+    gi, = torch.autograd.grad(pi, interp, grad_outputs=ones, create_graph=True)  # tf.gradients(pred, interp)
+  terms['discriminator_gradient_penalty_prime_' + d] = ops.gradient_penalty(gi.contiguous(), cfg.gradient_penalty_lambda)
 
 
 class Trainer:
