@@ -143,7 +143,7 @@ def roofline_pass(tr, a, b, steps=2):
   roof['kernel_time_ms_per_step'] = round(t_total / steps, 3)
   # whole step against the two peaks: sum over launches of max(flops/MFMA peak, bytes/HBM peak) / measured time
   roof['step_roofline_frac'] = round(t_min_total / t_total, 4)
-  roof['top_shapes'] = [row(kk, ff) for kk, ff in top_shapes[:8]]
+  roof['top_shapes'] = [row(kk, ff) for kk, ff in top_shapes[:48]]
   roof['families'] = [row(kk, ff) for kk, ff in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])[:12]]
   return roof
 
@@ -247,7 +247,7 @@ def main():
                              'instance norm + pixel norm, WGAN-GP, Adam; 1 step = G apply + D apply' % (
                                  args.hw, args.hw, args.max_ch),
                  'global_batch': args.batch * world, 'batch_per_gpu': args.batch, 'parallelism': 'dp%d' % world,
-                 'launch': 'eager' if args.no_graph else 'hipGraph replay',
+                 'launch': 'hipGraph replay' if tr.use_graph else 'eager',
                  'gflop_per_pair_model': GFLOP_PER_PAIR_256 if args.hw == 256 else None},
   }
   if args.hw == 256:

@@ -286,13 +286,16 @@ class Trainer:
     torch.cuda.synchronize(self.device)
     graphs, outs = {}, {}
     pool = None
+    # with a process group alive, its watchdog thread issues event queries while we capture: only this
+    # thread's unsafe calls may invalidate the capture
+    mode = 'thread_local' if self.world > 1 else 'global'
     for kind, fn in (('g', self._g_grads), ('d', self._d_grads)):
       gr = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(gr, pool=pool):
+      with torch.cuda.graph(gr, pool=pool, capture_error_mode=mode):
         outs[kind] = fn(st['s'], st['t'])
       pool = gr.pool()
       ga = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(ga, pool=pool):
+      with torch.cuda.graph(ga, pool=pool, capture_error_mode=mode):
         self._adam(kind)
       graphs[kind] = (gr, ga)
     self.adam_t -= 2                              # the two captured (not executed) applies
@@ -300,7 +303,15 @@ class Trainer:
 
   def _run_graph(self, kind, sources, targets):
     if self._graphs is None:
-      self._capture(sources, targets)
+      try:
+        self._capture(sources, targets)
+      except Exception as e:      # keep training: eager launches are the same kernels, only the host cost differs
+        import warnings
+        warnings.warn('hipGraph capture failed (%s: %s); falling back to eager launches' % (type(e).__name__, e))
+        torch.cuda.synchronize(self.device)
+        self.use_graph, self._graphs = False, None
+        self.adam_t = int(self._adam_step_dev.item())
+        return self.g_step(sources, targets) if kind == 'g' else self.d_step(sources, targets)
     st = self._static
     if sources.data_ptr() != st['s'].data_ptr():
       st['s'].copy_(sources)
