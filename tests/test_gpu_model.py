@@ -236,3 +236,68 @@ def test_full_size_properties_256_bf16():
     assert float(m.abs().max()) < 0.05 and float((v - 1).abs().max()) < 0.1     # to_rgb is instance-normalised
     pred, _ = pggan.discriminator(tr.P, out, cfg, 'discriminator_s')
     assert pred.shape == (2, 1) and bool(torch.isfinite(pred).all())
+
+
+def _dp_worker(rank, world, port, q, use_graph):
+  import os
+  import torch.distributed as dist
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  torch.cuda.set_device(0)
+  dist.init_process_group('gloo', rank=rank, world_size=world)      # both ranks share the box's single GPU
+  try:
+    from twingan_amd import Config
+    from twingan_amd.twingan import Trainer
+    cfg = Config(hw=32, max_ch=16, precision='fp32', loss_architecture='wgan')
+    g = torch.Generator().manual_seed(50 + rank)                     # every clone draws its own batch
+    s = torch.rand(2, 32, 32, 3, generator=g).to('cuda:0')
+    t = torch.rand(2, 32, 32, 3, generator=g).to('cuda:0')
+    tr = Trainer(cfg, device='cuda:0', seed=7, world_size=world, use_graph=use_graph)
+    for _ in range(6):
+      tr.run(s, t)
+    torch.cuda.synchronize()
+    q.put((rank, tr.store.flat['g'].cpu().numpy(), tr.store.flat['d'].cpu().numpy(), tr.use_graph))
+    dist.barrier()
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_data_parallel_two_clones_one_gpu(use_graph):
+  """Two clones (processes) on the one GPU of the test box, gloo instead of RCCL: exercises the Trainer's DP
+  path -- loss / num_clones, all-reduce of the flat gradient buffers between the gradient and apply graphs,
+  graph capture with a process group alive.  Both clones must end with identical parameters, different from a
+  single clone's (deployment/model_deploy.py:242-315,473-503)."""
+  import socket
+  import torch.multiprocessing as mp
+  sk = socket.socket()
+  sk.bind(('127.0.0.1', 0))
+  port = sk.getsockname()[1]
+  sk.close()
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, use_graph)) for r in range(2)]
+  for p in procs:
+    p.start()
+  got = dict()
+  for _ in range(2):
+    r, fg, fd, graphed = q.get(timeout=600)
+    got[r] = (fg, fd, graphed)
+  for p in procs:
+    p.join(timeout=600)
+    assert p.exitcode == 0
+  for i in (0, 1):
+    a, b = got[0][i], got[1][i]
+    assert np.abs(a - b).max() <= 1e-6 * max(1.0, np.abs(a).max()), 'clones diverged'
+  assert got[0][2] == use_graph, 'graph capture fell back to eager'
+  # single clone on clone 0's batch moves differently
+  from twingan_amd import Config
+  from twingan_amd.twingan import Trainer
+  cfg = Config(hw=32, max_ch=16, precision='fp32', loss_architecture='wgan')
+  g = torch.Generator().manual_seed(50)
+  s = torch.rand(2, 32, 32, 3, generator=g).to('cuda:0')
+  t = torch.rand(2, 32, 32, 3, generator=g).to('cuda:0')
+  tr = Trainer(cfg, device='cuda:0', seed=7)
+  for _ in range(6):
+    tr.run(s, t)
+  assert np.abs(tr.store.flat['g'].cpu().numpy() - got[0][0]).max() > 1e-6
