@@ -213,6 +213,17 @@ int tg_abs_diff_sum(const void* a, const void* b, float* out, int64_t numel, flo
 /* ga = gscale[0]*scale*sign(a-b), gb = -ga  (either may be NULL) */
 int tg_abs_diff_bwd(const void* a, const void* b, const float* gscale, void* ga, void* gb, int64_t numel, float scale,
                     int dtype, void* stream);
+/* Prediction losses on the fp32 [B,1] discriminator outputs (image_generation.py:331-400):
+ * out[0] (+)= scale * sum_i f(x_i) with mode 0: x (WGAN means), 1: relu(a + b*x) (hinge), 2: sigmoid cross
+ * entropy against label a (tf.losses.sigmoid_cross_entropy: max(x,0) - x*a + log(1+exp(-|x|))), 3: x^2 (drift
+ * term :360-367).  bwd: gx_i = gscale[0] * scale * f'(x_i)  (gscale may be NULL = 1). */
+int tg_pred_loss_fwd(const float* x, float* out, int n, int mode, float a, float b, float scale, int accumulate,
+                     void* stream);
+int tg_pred_loss_bwd(const float* x, const float* gscale, float* gx, int n, int mode, float a, float b, float scale,
+                     void* stream);
+/* out[0] = variance over every element, from sum[0] = sum(x) and sample_sumsq[batch] (DRAGAN's "std",
+ * image_generation.py:445, which is tf.nn.moments(...)[1]) */
+int tg_var_from_sums(const float* sum, const float* sample_sumsq, float* out, int batch, int64_t numel, void* stream);
 /* out[b] = sum over the sample of x^2 */
 int tg_sample_sumsq(const void* x, float* out, int batch, int64_t per_sample, int dtype, void* stream);
 /* WGAN-GP scalar tail: loss[0] = lambda*mean_b (sqrt(ss[b])-1)^2 ; coef[b] = lambda*2*(sqrt(ss)-1)/(sqrt(ss)*batch) */

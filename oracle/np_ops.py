@@ -175,6 +175,31 @@ def wgan_g_loss(fake_pred):
   return -np.mean(fake_pred)
 
 
+def sigmoid_cross_entropy(labels, logits, weight=1.0):
+  """tf.losses.sigmoid_cross_entropy (mean over elements) * weight, in TF's stable form
+  max(x,0) - x*z + log(1 + exp(-|x|))  (image_generation.py:340-344,383-394)."""
+  x, z = np.asarray(logits, F64), np.asarray(labels, F64)
+  return np.mean(np.maximum(x, 0.0) - x * z + np.log1p(np.exp(-np.abs(x)))) * weight
+
+
+def hinge_d_loss(fake_pred, real_pred):
+  """image_generation.py:373-375: mean relu(1 + D(fake)) + mean relu(1 - D(real))."""
+  f, r = np.asarray(fake_pred, F64), np.asarray(real_pred, F64)
+  return np.mean(np.maximum(1.0 + f, 0.0)) + np.mean(np.maximum(1.0 - r, 0.0))
+
+
+def drift_loss(real_pred, weight):
+  """image_generation.py:360-367: w * mean(D(real)^2)."""
+  return weight * np.mean(np.square(np.asarray(real_pred, F64)))
+
+
+def dragan_perturbed_batch(minibatch, noise):
+  """image_generation.py:441-449 (get_perturbed_batch): x + 0.5 * VARIANCE(all elements of x) * U(-1,1) -- the
+  reference names it std but takes tf.nn.moments(...)[1], the variance.  ``noise`` = the U(-1,1) draw."""
+  x = np.asarray(minibatch, F64)
+  return x + 0.5 * np.var(x) * np.asarray(noise, F64)
+
+
 def gradient_penalty(interp_grad, lam=10.0):
   """image_generation.py:431-436: slopes = sqrt(sum_{h,w,c} g^2) (no eps); mean((slopes-1)^2)*lambda."""
   g = np.asarray(interp_grad, F64)

@@ -364,9 +364,30 @@ def forward_generators(P, sources, targets, cfg):
   return dict(es=es, et=et, s_prime=s_prime, s_cycle=s_cycle, t_prime=t_prime, t_cycle=t_cycle)
 
 
+LOSSES = ('wgan_gp', 'wgan', 'hinge', 'gan', 'dragan')
+
+
+def _fool_loss(pred, cfg):
+  """image_generation.py:331-344: -mean D(fake) for wgan / wgan_gp / hinge, sigmoid-xent against ones otherwise."""
+  if cfg.loss in ('wgan_gp', 'wgan', 'hinge'):
+    return -pred.mean() * cfg.gan_weight
+  return F.binary_cross_entropy_with_logits(pred, torch.ones_like(pred)) * cfg.gan_weight
+
+
+def _real_fake_losses(terms, name, pf, pr, cfg):
+  """The real/fake part of the discriminator loss (image_generation.py:348-357,370-394)."""
+  if cfg.loss in ('wgan_gp', 'wgan'):
+    terms['discriminator_loss' + name] = (pf.mean() - pr.mean()) * cfg.gan_weight
+  elif cfg.loss == 'hinge':
+    terms['discriminator_loss' + name] = (F.relu(1 + pf).mean() + F.relu(1 - pr).mean()) * cfg.gan_weight
+  else:
+    terms['discriminator_fake_loss' + name] = F.binary_cross_entropy_with_logits(pf, torch.zeros_like(pf)) * cfg.gan_weight
+    terms['discriminator_real_loss' + name] = F.binary_cross_entropy_with_logits(pr, torch.ones_like(pr)) * cfg.gan_weight
+
+
 def generator_loss(P, sources, targets, cfg):
-  """Sum of GENERATOR_LOSSES (twingan.py:464-505; image_generation.py:331-337)."""
-  assert cfg.loss in ('wgan_gp', 'wgan')
+  """Sum of GENERATOR_LOSSES (twingan.py:464-505; image_generation.py:331-344)."""
+  assert cfg.loss in LOSSES
   if cfg.is_growing:
     sources, targets = growing_image(sources, cfg.alpha_grow), growing_image(targets, cfg.alpha_grow)
   o = forward_generators(P, sources, targets, cfg)
@@ -380,37 +401,42 @@ def generator_loss(P, sources, targets, cfg):
     terms['l_cyc_' + d] = (orig - cyc).abs().mean() * cfg.l_cyc
     if cfg.hw >= 64 and cfg.do_l_cyc_gan:
       pc, _ = discriminator(P, cyc, cfg, top)
-      terms['generator_fool_loss_cycle_' + d] = -pc.mean() * cfg.gan_weight
+      terms['generator_fool_loss_cycle_' + d] = _fool_loss(pc, cfg)
     pp, _ = discriminator(P, prime, cfg, top)
-    terms['generator_fool_loss_prime_' + d] = -pp.mean() * cfg.gan_weight
+    terms['generator_fool_loss_prime_' + d] = _fool_loss(pp, cfg)
     if cfg.l_content:
       terms['l_content_' + d] = (enc_orig - enc_opp_prime).abs().mean() * cfg.l_content
   return sum(terms.values()), terms
 
 
-def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t):
-  """Sum of DISCRIMINATOR_LOSSES (image_generation.py:348-379,414-439).  ``gp_alpha_*`` are the
-  per-sample U[0,1) draws, shape [B,1,1,1].  E/G run without grad: only D variables are in the
-  var_list (image_generation.py:605-610)."""
-  assert cfg.loss in ('wgan_gp', 'wgan')
+def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t, dragan_noise_s=None, dragan_noise_t=None):
+  """Sum of DISCRIMINATOR_LOSSES (image_generation.py:348-412,414-476).  ``gp_alpha_*`` are the
+  per-sample U[0,1) draws, shape [B,1,1,1]; ``dragan_noise_*`` the U(-1,1) draws of get_perturbed_batch
+  (image shape).  E/G run without grad: only D variables are in the var_list (image_generation.py:605-610)."""
+  assert cfg.loss in LOSSES
   if cfg.is_growing:
     sources, targets = growing_image(sources, cfg.alpha_grow), growing_image(targets, cfg.alpha_grow)
   with torch.no_grad():
     o = forward_generators(P, sources, targets, cfg)
   terms = {}
-  for d, real, prime, cyc, a in (('s', sources, o['s_prime'], o['s_cycle'], gp_alpha_s),
-                                 ('t', targets, o['t_prime'], o['t_cycle'], gp_alpha_t)):
+  for d, real, prime, cyc, a, noise in (('s', sources, o['s_prime'], o['s_cycle'], gp_alpha_s, dragan_noise_s),
+                                        ('t', targets, o['t_prime'], o['t_cycle'], gp_alpha_t, dragan_noise_t)):
     top = 'discriminator_' + d
     pr, _ = discriminator(P, real, cfg, top)
-    if cfg.hw >= 64 and cfg.do_l_cyc_gan:
+    if cfg.hw >= 64 and cfg.do_l_cyc_gan:                 # only_real_fake_loss=True (twingan.py:466-474)
       pc, _ = discriminator(P, cyc, cfg, top)
-      terms['discriminator_loss_cycle_' + d] = (pc.mean() - pr.mean()) * cfg.gan_weight
+      _real_fake_losses(terms, '_cycle_' + d, pc, pr, cfg)
     pp, _ = discriminator(P, prime, cfg, top)
-    terms['discriminator_loss_prime_' + d] = (pp.mean() - pr.mean()) * cfg.gan_weight
-    if cfg.drift:
+    _real_fake_losses(terms, '_prime_' + d, pp, pr, cfg)
+    if cfg.drift and cfg.loss in ('wgan_gp', 'wgan'):     # image_generation.py:360-367
       terms['discriminator_drift_loss_prime_' + d] = cfg.drift * (pr ** 2).mean()
-    if cfg.loss == 'wgan_gp':
+    interp = None
+    if cfg.loss == 'wgan_gp':                             # image_generation.py:414-439
       interp = (real + a * (prime - real)).detach().requires_grad_(True)
+    elif cfg.loss == 'dragan':                            # image_generation.py:441-476
+      perturbed = real + 0.5 * real.var(unbiased=False) * noise
+      interp = (real + a * (perturbed - real)).detach().requires_grad_(True)
+    if interp is not None:
       pi, _ = discriminator(P, interp, cfg, top)
       gi, = torch.autograd.grad(pi.sum(), interp, create_graph=True)     # tf.gradients(pred, interp)
       slopes = torch.sqrt((gi ** 2).sum(dim=(1, 2, 3)))

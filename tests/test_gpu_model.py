@@ -301,3 +301,48 @@ def test_data_parallel_two_clones_one_gpu(use_graph):
   for _ in range(6):
     tr.run(s, t)
   assert np.abs(tr.store.flat['g'].cpu().numpy() - got[0][0]).max() > 1e-6
+
+
+@pytest.mark.parametrize('loss,drift', [('hinge', 0.0), ('gan', 0.0), ('dragan', 0.0), ('wgan', 0.001)])
+def test_loss_architectures_match_oracle(loss, drift):
+  """--loss_architecture hinge / gan / dragan and the WGAN drift term (image_generation.py:331-400,441-476)."""
+  from twingan_amd import Config
+  from twingan_amd import twingan as T
+  from twingan_amd.twingan import Trainer
+  cfg = Config(hw=16, max_ch=16, precision='fp32', loss_architecture=loss, wgan_drift_loss_weight=drift,
+               gradient_penalty_lambda=0.25 if loss == 'dragan' else 10.0)
+  rcfg = R.Config(hw=16, max_ch=16, loss=loss, drift=drift, gp_lambda=cfg.gradient_penalty_lambda)
+  Pref = R.init_params(rcfg, seed=6, dtype=torch.float64, std='he')
+  tr = Trainer(cfg, device='cuda:0', seed=6)
+  tr.store.load_state_dict({k: v.float() for k, v in Pref.items()})
+  Pref = {k: v.float().double().requires_grad_(True) for k, v in Pref.items()}
+  g = torch.Generator().manual_seed(77)
+  s, t = torch.rand(2, 16, 16, 3, generator=g), torch.rand(2, 16, 16, 3, generator=g)
+  a_s, a_t = torch.rand(2, generator=g), torch.rand(2, generator=g)
+  n_s, n_t = torch.rand(2, 16, 16, 3, generator=g) * 2 - 1, torch.rand(2, 16, 16, 3, generator=g) * 2 - 1
+  dev = lambda x: x.to('cuda:0').contiguous()
+  # generator side
+  tr.store.zero_grad('g')
+  tr._set_requires_grad(g=True, d=False)
+  gl, gterms = T.generator_loss(tr.P, dev(s), dev(t), cfg)
+  rgl, rgterms = R.generator_loss(Pref, s.double(), t.double(), rcfg)
+  assert set(gterms) == set(rgterms)
+  for k in rgterms:
+    assert abs(gterms[k].item() - rgterms[k].item()) < 1e-4 * max(1.0, abs(rgterms[k].item())), k
+  gl.backward()
+  rgl.backward()
+  _grads_close(tr, Pref, tr.store.names('g'), 8e-2, 'generator')
+  for v in Pref.values():
+    v.grad = None
+  # discriminator side
+  tr.store.zero_grad('d')
+  tr._set_requires_grad(g=False, d=True)
+  dl, dterms = T.discriminator_loss(tr.P, dev(s), dev(t), cfg, dev(a_s), dev(a_t), dev(n_s), dev(n_t))
+  rdl, rdterms = R.discriminator_loss(Pref, s.double(), t.double(), rcfg, a_s.double().reshape(-1, 1, 1, 1),
+                                      a_t.double().reshape(-1, 1, 1, 1), n_s.double(), n_t.double())
+  assert set(dterms) == set(rdterms), (sorted(dterms), sorted(rdterms))
+  for k in rdterms:
+    assert abs(dterms[k].item() - rdterms[k].item()) < 1e-4 * max(1.0, abs(rdterms[k].item())), (k, dterms[k].item(), rdterms[k].item())
+  dl.backward()
+  rdl.backward()
+  _grads_close(tr, Pref, tr.store.names('d'), 8e-2, 'discriminator')

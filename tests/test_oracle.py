@@ -308,3 +308,43 @@ def test_train_step_alternates():
   assert all(torch.equal(P[k], P1[k]) for k in gk)
   assert any(not torch.equal(P[k], P1[k]) for k in dk)
   assert opt.t == 2                                           # shared beta-power counter
+
+
+def test_gan_loss_variants_np_vs_torch():
+  """image_generation.py:331-400,441-449: sigmoid cross entropy (gan / dragan), hinge, drift, perturbed batch."""
+  import torch.nn.functional as F
+  rng = np.random.RandomState(40)
+  pf, pr = rng.randn(6, 1) * 2, rng.randn(6, 1) * 2
+  t = lambda a: torch.from_numpy(a)
+  assert abs(N.sigmoid_cross_entropy(np.ones_like(pf), pf, 0.7) -
+             float(F.binary_cross_entropy_with_logits(t(pf), torch.ones(6, 1, dtype=torch.float64)) * 0.7)) < 1e-12
+  assert abs(N.sigmoid_cross_entropy(np.zeros_like(pf), pf) -
+             float(F.binary_cross_entropy_with_logits(t(pf), torch.zeros(6, 1, dtype=torch.float64)))) < 1e-12
+  assert abs(N.hinge_d_loss(pf, pr) - float(F.relu(1 + t(pf)).mean() + F.relu(1 - t(pr)).mean())) < 1e-12
+  assert abs(N.drift_loss(pr, 0.001) - 0.001 * float((t(pr) ** 2).mean())) < 1e-15
+  # known answers: xent at logit 0 is log 2 either way; hinge of a perfect critic is 0
+  assert abs(N.sigmoid_cross_entropy(np.ones(3), np.zeros(3)) - np.log(2)) < 1e-15
+  assert N.hinge_d_loss(np.full(4, -2.0), np.full(4, 2.0)) == 0.0
+  x, noise = rng.rand(2, 4, 4, 3), rng.rand(2, 4, 4, 3) * 2 - 1
+  assert np.allclose(N.dragan_perturbed_batch(x, noise), x + 0.5 * x.var() * noise)
+
+
+@pytest.mark.parametrize('loss', ['hinge', 'gan', 'dragan'])
+def test_loss_architectures_run_and_differentiate(loss):
+  cfg = R.Config(hw=16, max_ch=8, loss=loss, drift=0.0)
+  P = R.init_params(cfg, seed=1, dtype=torch.float64, std='he')
+  g = torch.Generator().manual_seed(3)
+  s, t_ = torch.rand(2, 16, 16, 3, generator=g).double(), torch.rand(2, 16, 16, 3, generator=g).double()
+  a = torch.rand(2, 1, 1, 1, generator=g).double()
+  noise = torch.rand(2, 16, 16, 3, generator=g).double() * 2 - 1
+  for v in P.values():
+    v.requires_grad_(True)
+  gl, gt = R.generator_loss(P, s, t_, cfg)
+  dl, dt = R.discriminator_loss(P, s, t_, cfg, a, a, noise, noise)
+  if loss == 'hinge':
+    assert set(dt) == {'discriminator_loss_prime_s', 'discriminator_loss_prime_t'}
+  else:
+    assert 'discriminator_fake_loss_prime_s' in dt and 'discriminator_real_loss_prime_t' in dt
+    assert ('discriminator_gradient_penalty_prime_s' in dt) == (loss == 'dragan')
+  grads = R.grads_of(dl, P, R.discriminator_var_names(P))
+  assert all(torch.isfinite(v).all() for v in grads.values())

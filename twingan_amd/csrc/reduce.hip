@@ -291,6 +291,52 @@ __global__ void gp_penalty_kernel(const float* __restrict__ ss, float* __restric
   if (threadIdx.x == 0 && loss) loss[0] = lambda * tot / (float)batch;
 }
 
+// Prediction losses on the tiny fp32 [B,1] discriminator outputs (image_generation.py:331-400).
+//   mode 0: x                      (WGAN means)
+//   mode 1: relu(a + b*x)          (hinge: a = 1, b = +1 for fakes / -1 for reals)
+//   mode 2: sigmoid cross entropy against label a in {0,1}: max(x,0) - x*a + log(1 + exp(-|x|))
+//   mode 3: x^2                    (WGAN drift term)
+__device__ __forceinline__ float pred_loss_f(float x, int mode, float a, float b) {
+  if (mode == 1) return fmaxf(a + b * x, 0.f);
+  if (mode == 2) return fmaxf(x, 0.f) - x * a + log1pf(expf(-fabsf(x)));
+  if (mode == 3) return x * x;
+  return x;
+}
+__device__ __forceinline__ float pred_loss_df(float x, int mode, float a, float b) {
+  if (mode == 1) return (a + b * x) > 0.f ? b : 0.f;
+  if (mode == 2) return 1.f / (1.f + expf(-x)) - a;       // sigmoid(x) - label
+  if (mode == 3) return 2.f * x;
+  return 1.f;
+}
+__global__ void pred_loss_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int n, int mode, float a,
+                                     float b, float scale, int accumulate) {
+  __shared__ float red[8];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += pred_loss_f(x[i], mode, a, b);
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + scale * tot;
+}
+__global__ void pred_loss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gscale, float* __restrict__ gx,
+                                     int n, int mode, float a, float b, float scale) {
+  const float g = (gscale ? gscale[0] : 1.f) * scale;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    gx[i] = g * pred_loss_df(x[i], mode, a, b);
+}
+
+// out[0] = E[x^2] - E[x]^2 from sum = s1[0] and the per-sample sums of squares ss[batch]  (DRAGAN,
+// image_generation.py:445: the VARIANCE over every element of the minibatch)
+__global__ void var_from_sums_kernel(const float* __restrict__ s1, const float* __restrict__ ss, float* __restrict__ out,
+                                     int batch, float inv_numel) {
+  __shared__ float red[8];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < batch; i += blockDim.x) acc += ss[i];
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    const float m = s1[0] * inv_numel;
+    out[0] = fmaxf(tot * inv_numel - m * m, 0.f);
+  }
+}
+
 // C[m,n] (+)= op(A)[m,k] @ op(B)[k,n] + bias[n]; one thread per output element
 __global__ void small_gemm_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias,
                                   float* __restrict__ c, int m, int n, int k, int ta, int tb, int accumulate) {
@@ -434,6 +480,32 @@ int tg_gp_penalty(const float* sumsq, float* loss, float* coef, int batch, float
   TG_CHECK(sumsq && batch > 0, TG_EINVAL, "tg_gp_penalty: bad arguments");
   hipLaunchKernelGGL(gp_penalty_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sumsq, loss, coef, batch, lambda);
   TG_LAUNCH_CHECK("tg_gp_penalty");
+  return TG_OK;
+}
+
+int tg_pred_loss_fwd(const float* x, float* out, int n, int mode, float a, float b, float scale, int accumulate,
+                     void* stream) {
+  TG_CHECK(x && out && n > 0 && mode >= 0 && mode <= 3, TG_EINVAL, "tg_pred_loss_fwd: bad arguments");
+  hipLaunchKernelGGL(pred_loss_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, out, n, mode, a, b, scale,
+                     accumulate);
+  TG_LAUNCH_CHECK("tg_pred_loss_fwd");
+  return TG_OK;
+}
+
+int tg_pred_loss_bwd(const float* x, const float* gscale, float* gx, int n, int mode, float a, float b, float scale,
+                     void* stream) {
+  TG_CHECK(x && gx && n > 0 && mode >= 0 && mode <= 3, TG_EINVAL, "tg_pred_loss_bwd: bad arguments");
+  hipLaunchKernelGGL(pred_loss_bwd_kernel, dim3(tg_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, gscale, gx, n,
+                     mode, a, b, scale);
+  TG_LAUNCH_CHECK("tg_pred_loss_bwd");
+  return TG_OK;
+}
+
+int tg_var_from_sums(const float* sum, const float* sample_sumsq, float* out, int batch, int64_t numel, void* stream) {
+  TG_CHECK(sum && sample_sumsq && out && batch > 0 && numel > 0, TG_EINVAL, "tg_var_from_sums: bad arguments");
+  hipLaunchKernelGGL(var_from_sums_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sum, sample_sumsq, out, batch,
+                     1.0f / (float)numel);
+  TG_LAUNCH_CHECK("tg_var_from_sums");
   return TG_OK;
 }
 

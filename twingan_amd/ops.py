@@ -915,6 +915,72 @@ class GradPenaltyFn(torch.autograd.Function):
     return out, None
 
 
+class PredLossFn(torch.autograd.Function):
+  """weight * mean_i f(x_i) over the fp32 discriminator predictions; f by ``mode`` (0 identity, 1 relu(a + b x),
+  2 sigmoid cross entropy against label a, 3 square) -- image_generation.py:331-400.  First order."""
+
+  @staticmethod
+  def forward(ctx, x, mode, a, b, weight):
+    _chk(x)
+    assert x.dtype == torch.float32
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    k = weight / x.numel()
+    call('tg_pred_loss_fwd', _p(x), _p(out), x.numel(), mode, a, b, k, 0, _stream())
+    ctx.meta = (mode, a, b, k)
+    ctx.save_for_backward(x)
+    return out
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, g):
+    x, = ctx.saved_tensors
+    mode, a, b, k = ctx.meta
+    gx = torch.empty_like(x)
+    call('tg_pred_loss_bwd', _p(x), _p(g.contiguous()), _p(gx), x.numel(), mode, a, b, k, _stream())
+    return gx, None, None, None, None
+
+
+def hinge_mean(x, a, b, weight=1.0):
+  """weight * mean(relu(a + b*x))."""
+  return PredLossFn.apply(x.contiguous(), 1, float(a), float(b), float(weight))
+
+
+def sigmoid_xent_mean(x, label, weight=1.0):
+  """tf.losses.sigmoid_cross_entropy(label * ones, x) * weight."""
+  return PredLossFn.apply(x.contiguous(), 2, float(label), 0.0, float(weight))
+
+
+def square_mean(x, weight=1.0):
+  return PredLossFn.apply(x.contiguous(), 3, 0.0, 0.0, float(weight))
+
+
+def batch_variance(x):
+  """Variance over every element of the minibatch as a device fp32 [1] (no autograd): DRAGAN's noise scale."""
+  _chk(x)
+  b = x.shape[0]
+  s1 = torch.empty(1, dtype=torch.float32, device=x.device)
+  ss = torch.empty(b, dtype=torch.float32, device=x.device)
+  out = torch.empty(1, dtype=torch.float32, device=x.device)
+  call('tg_sum', _p(x), _p(s1), x.numel(), 1.0, 0, _dt(x), _stream())
+  call('tg_sample_sumsq', _p(x), _p(ss), b, x.numel() // b, _dt(x), _stream())
+  call('tg_var_from_sums', _p(s1), _p(ss), _p(out), b, x.numel(), _stream())
+  return out
+
+
+def dragan_interpolates(real, noise, alpha):
+  """real + alpha[b] * (perturbed - real) with perturbed = real + 0.5 * Var(real) * noise
+  (image_generation.py:441-449,455-460).  No autograd (the interpolates are a leaf)."""
+  _chk(real, noise, alpha)
+  var = batch_variance(real)
+  b = real.shape[0]
+  delta = torch.empty_like(real)
+  half = (alpha * 0.5).contiguous()
+  call('tg_sample_scale', _p(noise), _p(half), _p(var), _p(delta), b, real.numel() // b, _dt(real), _stream())
+  out = torch.empty_like(real)
+  call('tg_axpby', _p(real), _p(delta), _p(out), real.numel(), 1.0, 1.0, _dt(real), _stream())
+  return out
+
+
 def mean(x, weight=1.0):
   return MeanFn.apply(x, float(weight))
 

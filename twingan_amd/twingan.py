@@ -65,6 +65,31 @@ class _DomainStreams:
         main.wait_stream(st)
 
 
+LOSSES = ('wgan_gp', 'wgan', 'hinge', 'gan', 'dragan')      # --loss_architecture, image_generation.py:81-83
+
+
+def _fool_loss(pred, cfg):
+  """image_generation.py:331-344."""
+  pred = pred.contiguous()
+  if cfg.loss_architecture in ('wgan_gp', 'wgan', 'hinge'):
+    return ops.mean(pred, -cfg.gan_weight)
+  return ops.sigmoid_xent_mean(pred, 1.0, cfg.gan_weight)
+
+
+def _real_fake_losses(terms, name, pf, pr, cfg, mean_real=None):
+  """image_generation.py:348-357 (wgan), :370-379 (hinge), :380-394 (gan / dragan)."""
+  la = cfg.loss_architecture
+  if la in ('wgan_gp', 'wgan'):
+    mr = mean_real if mean_real is not None else ops.mean(pr, cfg.gan_weight)
+    terms['discriminator_loss' + name] = ops.mean(pf, cfg.gan_weight) - mr
+  elif la == 'hinge':
+    terms['discriminator_loss' + name] = ops.hinge_mean(pf, 1.0, 1.0, cfg.gan_weight) + \
+        ops.hinge_mean(pr, 1.0, -1.0, cfg.gan_weight)
+  else:
+    terms['discriminator_fake_loss' + name] = ops.sigmoid_xent_mean(pf, 0.0, cfg.gan_weight)
+    terms['discriminator_real_loss' + name] = ops.sigmoid_xent_mean(pr, 1.0, cfg.gan_weight)
+
+
 def act_dtype(cfg):
   return torch.bfloat16 if cfg.precision == 'bf16' else torch.float32
 
@@ -97,7 +122,7 @@ def forward_generators(P, sources, targets, cfg):
 
 def generator_loss(P, sources, targets, cfg):
   """GENERATOR_LOSSES (twingan.py:464-505; image_generation.py:331-337).  Returns (total [1], terms)."""
-  assert cfg.loss_architecture in ('wgan_gp', 'wgan'), cfg.loss_architecture
+  assert cfg.loss_architecture in LOSSES, cfg.loss_architecture
   if cfg.is_growing:
     sources, targets = get_growing_image(sources, cfg.alpha_grow), get_growing_image(targets, cfg.alpha_grow)
   b = sources.shape[0]
@@ -114,10 +139,10 @@ def generator_loss(P, sources, targets, cfg):
       if cyc_gan:      # D(cyc) and D(prime) of one domain share weights: one batch, two minibatch-stddev groups
         pred, _ = pggan.discriminator(P, torch.cat([cyc, prime], dim=0), cfg, top, groups=2)
         pc, pp = pred.chunk(2)
-        terms['generator_fool_loss_cycle_' + d] = ops.mean(pc.contiguous(), -cfg.gan_weight)
+        terms['generator_fool_loss_cycle_' + d] = _fool_loss(pc, cfg)
       else:
         pp, _ = pggan.discriminator(P, prime, cfg, top)
-      terms['generator_fool_loss_prime_' + d] = ops.mean(pp.contiguous(), -cfg.gan_weight)
+      terms['generator_fool_loss_prime_' + d] = _fool_loss(pp, cfg)
   # re-encode s' in domain s and t' in domain t as one batch (twingan.py:275-288)
   e2, _ = pggan.encoder_before_classification(P, torch.cat([o['s_prime'], o['t_prime']], dim=0), ('s', 't', b), cfg)
   e_sp, e_tp = e2.chunk(2)
@@ -131,10 +156,11 @@ def generator_loss(P, sources, targets, cfg):
   return total, terms
 
 
-def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t):
-  """DISCRIMINATOR_LOSSES (image_generation.py:348-379,414-439).  gp_alpha_*: fp32 [B] U[0,1) draws.
+def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t, dragan_noise_s=None, dragan_noise_t=None):
+  """DISCRIMINATOR_LOSSES (image_generation.py:348-412,414-476).  gp_alpha_*: fp32 [B] U[0,1) draws;
+  dragan_noise_*: the U(-1,1) draws of get_perturbed_batch (image shaped; drawn on the device when None).
   E/G run without a tape: only discriminator variables are in the var_list (image_generation.py:605-610)."""
-  assert cfg.loss_architecture in ('wgan_gp', 'wgan'), cfg.loss_architecture
+  assert cfg.loss_architecture in LOSSES, cfg.loss_architecture
   with torch.no_grad():
     if cfg.is_growing:
       sources, targets = get_growing_image(sources, cfg.alpha_grow), get_growing_image(targets, cfg.alpha_grow)
@@ -142,13 +168,14 @@ def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t):
   cyc_gan = cfg.hw >= 64 and cfg.do_l_cyc_gan
   terms = {}
   streams = _DomainStreams(sources.device, cfg.domain_streams)
-  for i, (d, real, prime, cyc, a) in enumerate((('s', sources, o['s_prime'], o['s_cycle'], gp_alpha_s),
-                                                ('t', targets, o['t_prime'], o['t_cycle'], gp_alpha_t))):
+  for i, (d, real, prime, cyc, a, noise) in enumerate((
+      ('s', sources, o['s_prime'], o['s_cycle'], gp_alpha_s, dragan_noise_s),
+      ('t', targets, o['t_prime'], o['t_cycle'], gp_alpha_t, dragan_noise_t))):
     top = 'discriminator_' + d
     with streams.domain(i):
       _d_domain_terms(P, cfg, terms, d, top, real, prime, cyc, a, cyc_gan)
-      if cfg.loss_architecture == 'wgan_gp':
-        _d_domain_gp(P, cfg, terms, d, top, real, prime, a)
+      if cfg.loss_architecture in ('wgan_gp', 'dragan'):
+        _d_domain_gp(P, cfg, terms, d, top, real, prime, a, noise)
   streams.join()
   total = None
   for v in terms.values():
@@ -166,17 +193,24 @@ def _d_domain_terms(P, cfg, terms, d, top, real, prime, cyc, a, cyc_gan):
     else:
       pred, _ = pggan.discriminator(P, torch.cat([real, prime], dim=0), cfg, top, groups=2)
       pr, pp = (t.contiguous() for t in pred.chunk(2))
-    mean_real = ops.mean(pr, cfg.gan_weight)
-    if cyc_gan:
-      terms['discriminator_loss_cycle_' + d] = ops.mean(pc, cfg.gan_weight) - mean_real
-    terms['discriminator_loss_prime_' + d] = ops.mean(pp, cfg.gan_weight) - mean_real
-    if cfg.wgan_drift_loss_weight:
-      raise NotImplementedError('wgan_drift_loss_weight (image_generation.py:360-367) is off in every BASELINE config')
+    wgan = cfg.loss_architecture in ('wgan_gp', 'wgan')
+    mean_real = ops.mean(pr, cfg.gan_weight) if wgan else None
+    if cyc_gan:                                             # only_real_fake_loss=True (twingan.py:466-474)
+      _real_fake_losses(terms, '_cycle_' + d, pc, pr, cfg, mean_real)
+    _real_fake_losses(terms, '_prime_' + d, pp, pr, cfg, mean_real)
+    if cfg.wgan_drift_loss_weight and wgan:                 # image_generation.py:360-367
+      terms['discriminator_drift_loss_prime_' + d] = ops.square_mean(pr, cfg.wgan_drift_loss_weight)
 
 
-def _d_domain_gp(P, cfg, terms, d, top, real, prime, a):
-  """WGAN-GP term of one domain (image_generation.py:414-439)."""
-  interp = ops.sample_lerp(real, prime, a).requires_grad_(True)               # image_generation.py:420-424
+def _d_domain_gp(P, cfg, terms, d, top, real, prime, a, noise=None):
+  """Gradient penalty of one domain: WGAN-GP on real..fake interpolates (image_generation.py:414-439) or DRAGAN
+  on real..perturbed-real ones (:441-476)."""
+  if cfg.loss_architecture == 'dragan':
+    if noise is None:
+      noise = (torch.rand(real.shape, dtype=torch.float32, device=real.device) * 2.0 - 1.0).to(real.dtype)
+    interp = ops.dragan_interpolates(real, noise.contiguous(), a).requires_grad_(True)
+  else:
+    interp = ops.sample_lerp(real, prime, a).requires_grad_(True)             # image_generation.py:420-424
   pi, _ = pggan.discriminator(P, interp, cfg, top)
   ones = ops.fill(pi.shape, 1.0, pi.dtype, pi.device)
   with ops.no_param_grads():        # only d pred / d interp is needed here; parameters get theirs via the double backward
