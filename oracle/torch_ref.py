@@ -41,6 +41,7 @@ class Config:
   in_eps: float = 1e-6               # libs/instance_norm.py:37
   pn_eps: float = 1e-6               # nets/pggan_utils.py:330
   lrelu: float = 0.2                 # util_misc.py:68
+  bn_state: object = None            # dict collecting the BatchNorm moving statistics when set
 
 
 def get_num_channels(stage, max_num_channels=256):
@@ -56,15 +57,20 @@ def max_stage_of(hw):
 # ------------------------------------------------------------------------------------------------
 # parameter construction (names: SURVEY.md Appendix C; init: nets/pggan_utils.py:56,93, pggan.py:364-368)
 # ------------------------------------------------------------------------------------------------
-def _conv_p(P, g, scope, k, cin, cout, norm_domains, bias, dtype, std=0.02):
+NORM_SCOPE = {'instance_norm': 'InstanceNorm', 'batch_norm': 'BatchNorm'}      # libs/instance_norm.py:66, batch_norm.py:80
+BN_EPS = 1e-3       # libs/batch_norm.py:48 (max(epsilon, 1.001e-5), :464-468)
+BN_DECAY = 0.999    # libs/batch_norm.py:45
+
+
+def _conv_p(P, g, scope, k, cin, cout, norm_domains, bias, dtype, std=0.02, norm_scope='InstanceNorm'):
   if std == 'he':                    # test-only: O(1) activations so parity errors are visible
     std = math.sqrt(2.0 / (k * k * cin))
   P[scope + '/weights'] = torch.randn(k, k, cin, cout, generator=g, dtype=torch.float32).to(dtype) * std
   if bias:
     P[scope + '/biases'] = torch.zeros(cout, dtype=dtype)
   for d in norm_domains:
-    P[scope + '/InstanceNorm/gamma_' + d] = torch.ones(cout, dtype=dtype)
-    P[scope + '/InstanceNorm/beta_' + d] = torch.zeros(cout, dtype=dtype)
+    P['%s/%s/gamma_%s' % (scope, norm_scope, d)] = torch.ones(cout, dtype=dtype)
+    P['%s/%s/beta_%s' % (scope, norm_scope, d)] = torch.zeros(cout, dtype=dtype)
 
 
 def encoder_param_specs(top, hw, max_ch, growing=False):
@@ -118,9 +124,11 @@ def init_params(cfg, seed=0, dtype=torch.float32, std=0.02):
   g = torch.Generator().manual_seed(seed)
   P = {}
   for s in encoder_param_specs('encoder_content', cfg.hw, cfg.max_ch, cfg.is_growing):
-    _conv_p(P, g, s[0], s[1], s[2], s[3], ('s', 't') if cfg.norm == 'instance_norm' else (), False, dtype, std)
+    _conv_p(P, g, s[0], s[1], s[2], s[3], ('s', 't') if cfg.norm in NORM_SCOPE else (), False, dtype, std,
+            NORM_SCOPE.get(cfg.norm, ''))
   for s in generator_param_specs('generator', cfg.hw, cfg.max_ch, cfg.use_unet, cfg.is_growing):
-    _conv_p(P, g, s[0], s[1], s[2], s[3], ('s', 't') if cfg.norm == 'instance_norm' else (), False, dtype, std)
+    _conv_p(P, g, s[0], s[1], s[2], s[3], ('s', 't') if cfg.norm in NORM_SCOPE else (), False, dtype, std,
+            NORM_SCOPE.get(cfg.norm, ''))
   for top in ('discriminator_s', 'discriminator_t'):
     for s in encoder_param_specs(top, cfg.hw, cfg.max_ch, cfg.is_growing) + discriminator_tail_specs(top, cfg.max_ch):
       _conv_p(P, g, s[0], s[1], s[2], s[3], (), True, dtype, std)
@@ -182,6 +190,20 @@ def instance_norm(x, gamma, beta, eps=1e-6):
   return x * inv + (beta - mean * inv)
 
 
+def batch_norm_train(x, gamma, beta, eps=BN_EPS):
+  """libs/batch_norm.py:430,464-470 (training mode, no renorm): biased moments over (N,H,W),
+  tf.nn.batch_normalization form.  Returns (y, batch mean, batch variance)."""
+  mean = x.mean(dim=(0, 1, 2), keepdim=True)
+  var = ((x - mean) ** 2).mean(dim=(0, 1, 2), keepdim=True)
+  inv = torch.rsqrt(var + eps) * gamma
+  return x * inv + (beta - mean * inv), mean.reshape(-1), var.reshape(-1)
+
+
+def moving_average_update(moving, value, decay=BN_DECAY):
+  """moving_averages.assign_moving_average(zero_debias=False), libs/batch_norm.py:283-300."""
+  return moving - (1.0 - decay) * (moving - value)
+
+
 def upsample2x(x):
   return x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)      # pggan_utils.py:349-350
 
@@ -210,6 +232,13 @@ def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=Tru
   if cfg.norm == 'instance_norm':
     y = instance_norm(y, P[scope + '/InstanceNorm/gamma_' + domain], P[scope + '/InstanceNorm/beta_' + domain],
                       cfg.in_eps)
+  elif cfg.norm == 'batch_norm':       # the reference's default generator_norm_type (nets/pggan.py:24)
+    y, bm, bv = batch_norm_train(y, P[scope + '/BatchNorm/gamma_' + domain], P[scope + '/BatchNorm/beta_' + domain])
+    if cfg.bn_state is not None:       # moving statistics per domain postfix (libs/batch_norm.py:184-196)
+      for nm, val, init in (('moving_mean_', bm, 0.0), ('moving_variance_', bv, 1.0)):
+        key = scope + '/BatchNorm/' + nm + domain
+        cur = cfg.bn_state.get(key, torch.full_like(val, init))
+        cfg.bn_state[key] = moving_average_update(cur, val.detach())
   elif cfg.norm not in ('none', None):
     raise NotImplementedError(cfg.norm)
   if act:

@@ -346,3 +346,36 @@ def test_loss_architectures_match_oracle(loss, drift):
   dl.backward()
   rdl.backward()
   _grads_close(tr, Pref, tr.store.names('d'), 8e-2, 'discriminator')
+
+
+def test_batch_norm_generator_matches_oracle():
+  """generator_norm_type=batch_norm -- the reference's default (nets/pggan.py:24; libs/batch_norm.py): per-pass batch
+  statistics even though the passes are batched along N here, per-domain gamma/beta and moving statistics."""
+  from twingan_amd import Config
+  from twingan_amd import twingan as T
+  from twingan_amd.twingan import Trainer
+  cfg = Config(hw=16, max_ch=16, precision='fp32', generator_norm_type='batch_norm')
+  state = {}
+  rcfg = R.Config(hw=16, max_ch=16, norm='batch_norm', bn_state=state)
+  Pref = R.init_params(rcfg, seed=8, dtype=torch.float64, std='he')
+  tr = Trainer(cfg, device='cuda:0', seed=8)
+  assert set(tr.store.state_dict()) == set(Pref)
+  tr.store.load_state_dict({k: v.float() for k, v in Pref.items()})
+  Pref = {k: v.float().double().requires_grad_(True) for k, v in Pref.items()}
+  g = torch.Generator().manual_seed(78)
+  s, t = torch.rand(3, 16, 16, 3, generator=g), torch.rand(3, 16, 16, 3, generator=g)
+  dev = lambda x: x.to('cuda:0').contiguous()
+  tr.store.zero_grad('g')
+  tr._set_requires_grad(g=True, d=False)
+  gl, gterms = T.generator_loss(tr.P, dev(s), dev(t), cfg)
+  rgl, rgterms = R.generator_loss(Pref, s.double(), t.double(), rcfg)
+  for k in rgterms:
+    assert abs(gterms[k].item() - rgterms[k].item()) < 1e-4 * max(1.0, abs(rgterms[k].item())), k
+  gl.backward()
+  rgl.backward()
+  _grads_close(tr, Pref, tr.store.names('g'), 8e-2, 'generator(batch_norm)')
+  # moving statistics: same set of variables, same values (each pass = one assign_moving_average)
+  assert set(tr.store.state) == set(state)
+  for k, v in state.items():
+    a = tr.store.state[k].double().cpu().numpy()
+    assert np.abs(a - v.numpy()).max() < 1e-5 * max(1.0, np.abs(v.numpy()).max()), k

@@ -348,3 +348,19 @@ def test_loss_architectures_run_and_differentiate(loss):
     assert ('discriminator_gradient_penalty_prime_s' in dt) == (loss == 'dragan')
   grads = R.grads_of(dl, P, R.discriminator_var_names(P))
   assert all(torch.isfinite(v).all() for v in grads.values())
+
+
+def test_batch_norm_np_vs_torch_and_moving_average():
+  """libs/batch_norm.py:430,464-470 (training-mode moments over N,H,W; eps 1e-3) and :283-300 (moving average)."""
+  rng = np.random.RandomState(41)
+  x = rng.randn(3, 4, 4, 8) * 2 + 1
+  ga, be = 1 + 0.1 * rng.randn(8), 0.1 * rng.randn(8)
+  y, m, v = R.batch_norm_train(torch.from_numpy(x), torch.from_numpy(ga), torch.from_numpy(be))
+  assert np.allclose(y.numpy(), N.batch_norm_train(x, ga, be), atol=1e-12)
+  assert np.allclose(m.numpy(), x.mean(axis=(0, 1, 2))) and np.allclose(v.numpy(), x.var(axis=(0, 1, 2)))
+  mm = R.moving_average_update(torch.zeros(8, dtype=torch.float64), m)
+  assert np.allclose(mm.numpy(), 0.001 * x.mean(axis=(0, 1, 2)))
+  # a per-channel constant input normalises to beta
+  c = np.tile(np.arange(8.0), (2, 3, 3, 1))
+  yc, _, _ = R.batch_norm_train(torch.from_numpy(c), torch.from_numpy(ga), torch.from_numpy(be))
+  assert np.allclose(yc.numpy(), np.broadcast_to(be, c.shape), atol=1e-9)

@@ -529,7 +529,20 @@ def pointwise_conv(x, w_hwio, bias=None, lrelu=False, alpha=LRELU_ALPHA):
 # ------------------------------------------------------------------------------------------------
 # instance norm + LeakyReLU + pixel norm (generator / encoder layers)
 # ------------------------------------------------------------------------------------------------
-def _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha):
+def _ema_update(mean, rstd, n, c, split, eps, ema):
+  """BatchNorm moving statistics (libs/batch_norm.py:283-300): one assign_moving_average per batched pass
+  (= per statistic group), into the pass' domain variables.  ema = (decay, [(moving_mean, moving_var) per domain])."""
+  decay, pairs = ema
+  with torch.no_grad():
+    m = mean.view(n, c)
+    v = rstd.view(n, c).pow(-2) - eps
+    for gi in range(n):
+      mm, mv = pairs[0 if gi < split else 1]
+      mm.sub_((mm - m[gi]) * (1.0 - decay))
+      mv.sub_((mv - v[gi]) * (1.0 - decay))
+
+
+def _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema=None):
   _chk(y, gamma, beta, gamma2, beta2)
   n, h, w, c = y.shape
   split = n if gamma2 is None else int(split)
@@ -537,6 +550,8 @@ def _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, 
   rstd = torch.empty(n * c, dtype=torch.float32, device=y.device)
   call('tg_instance_norm_stats', _p(y), _p(mean), _p(rstd), n, h, w, c, in_eps, _dt(y), _stream(),
        work=('in_stats', 0, y.numel() * _esize(y)))
+  if ema is not None:
+    _ema_update(mean, rstd, n, c, split, in_eps, ema)
   z = torch.empty_like(y)
   s = torch.empty(n * h * w, dtype=torch.float32, device=y.device) if (flags & NF_PIXNORM) else None
   call('tg_norm_act_fwd', _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(gamma2), _p(beta2), split, _p(z), _p(s),
@@ -579,13 +594,13 @@ class NormActFn(torch.autograd.Function):
   gradient penalty).  With (gamma2, beta2, split) images [split, n) use the second domain's parameters."""
 
   @staticmethod
-  def forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha):
-    return _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha)
+  def forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema):
+    return _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema)
 
   @staticmethod
   @torch.autograd.function.once_differentiable
   def backward(ctx, gz):
-    return _norm_act_backward(ctx, gz)
+    return _norm_act_backward(ctx, gz) + (None,)
 
 
 class NormActPoolFn(torch.autograd.Function):
@@ -594,8 +609,8 @@ class NormActPoolFn(torch.autograd.Function):
   (and the sum of the two) into the normalisation backward kernel."""
 
   @staticmethod
-  def forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha):
-    z = _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha)
+  def forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema):
+    z = _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema)
     n, h, w, c = z.shape
     zp = torch.empty((n, h // 2, w // 2, c), dtype=z.dtype, device=z.device)
     call('tg_pool2x2_fwd', _p(z), _p(zp), n, h, w, c, 0.25, _dt(z), _stream())
@@ -606,16 +621,18 @@ class NormActPoolFn(torch.autograd.Function):
   @torch.autograd.function.once_differentiable
   def backward(ctx, gz, gzp):
     if gz is None and gzp is None:
-      return (None,) * 10
-    return _norm_act_backward(ctx, gz, gzp)
+      return (None,) * 11
+    return _norm_act_backward(ctx, gz, gzp) + (None,)
 
 
 def norm_act(y, gamma, beta, lrelu=True, pixel_norm=True, in_eps=1e-6, pn_eps=1e-6, alpha=LRELU_ALPHA, gamma2=None,
-             beta2=None, split=None, pool=False):
-  """``pool``: also return the 2x2 average-pooled output -> (z, z_pooled)."""
+             beta2=None, split=None, pool=False, ema=None):
+  """Statistics are per leading index of ``y`` (instance norm: one image; batch norm: the caller passes the view
+  [passes, B*H, W, C] so that each batched pass is one statistic group).  ``pool``: also return the 2x2
+  average-pooled output -> (z, z_pooled).  ``ema``: (decay, [(moving_mean, moving_var) per domain]) to update."""
   flags = (NF_LRELU if lrelu else 0) | (NF_PIXNORM if pixel_norm else 0)
   fn = NormActPoolFn if pool else NormActFn
-  return fn.apply(y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha)
+  return fn.apply(y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema)
 
 
 # ------------------------------------------------------------------------------------------------

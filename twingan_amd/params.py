@@ -33,31 +33,41 @@ def mbstd_cpad(c):
   return (c + 1 + 7) // 8 * 8
 
 
+class _ParamDict(dict):
+  """name -> parameter tensor; ``state`` holds the non-trainable variables (BatchNorm moving statistics)."""
+  state = None
+
+
 class ParamStore:
   GROUPS = ('g', 'd')    # g: encoder_content + generator (twingan.py:526-527); d: discriminator_* (image_generation.py:484-485)
 
   def __init__(self, device):
     self.device = torch.device(device)
     self.specs = OrderedDict()      # name -> dict(shape, phys, group, kind)
-    self.P = {}                     # name -> physical leaf tensor (requires_grad)
+    self.P = _ParamDict()           # name -> physical leaf tensor (requires_grad)
     self.flat = {}
     self.grad = {}
     self.m = {}
     self.v = {}
     self.offsets = {}
+    self.state_specs = OrderedDict()   # name -> (numel, init value): non-trainable variables
+    self.state = {}
 
   # ---- declaration ----------------------------------------------------------------------------
   def add(self, name, shape, group, kind, phys=None):
     assert name not in self.specs, name
     self.specs[name] = dict(shape=tuple(shape), phys=tuple(phys or shape), group=group, kind=kind)
 
-  def add_conv(self, scope, k, cin, cout, group, bias, norm_domains, phys_cin=None):
+  def add_conv(self, scope, k, cin, cout, group, bias, norm_domains, phys_cin=None, norm_scope='InstanceNorm'):
     self.add(scope + '/weights', (k, k, cin, cout), group, 'conv_w', (k, k, phys_cin or cin, cout))
     if bias:
       self.add(scope + '/biases', (cout,), group, 'bias')
     for d in norm_domains:
-      self.add('%s/InstanceNorm/gamma_%s' % (scope, d), (cout,), group, 'gamma')
-      self.add('%s/InstanceNorm/beta_%s' % (scope, d), (cout,), group, 'beta')
+      self.add('%s/%s/gamma_%s' % (scope, norm_scope, d), (cout,), group, 'gamma')
+      self.add('%s/%s/beta_%s' % (scope, norm_scope, d), (cout,), group, 'beta')
+      if norm_scope == 'BatchNorm':      # non-trainable moving statistics (libs/batch_norm.py:184-196)
+        self.state_specs['%s/BatchNorm/moving_mean_%s' % (scope, d)] = (cout, 0.0)
+        self.state_specs['%s/BatchNorm/moving_variance_%s' % (scope, d)] = (cout, 1.0)
 
   # ---- allocation -----------------------------------------------------------------------------
   def build(self, seed=0):
@@ -83,6 +93,9 @@ class ParamStore:
       self.P[name] = p
       if s['kind'] == 'conv_w':
         PackCache.register(p)
+    for name, (n, init) in self.state_specs.items():
+      self.state[name] = torch.full((n,), init, dtype=torch.float32, device=self.device)
+    self.P.state = self.state
     PackCache.version += 1
     return self
 
@@ -149,39 +162,43 @@ def declare_twingan(store, cfg):
   SURVEY.md Appendix A; nets/pggan.py:93-211,242-376,403-479)."""
   hw, mc = cfg.hw, cfg.max_ch
   ms = max_stage_of(hw)
-  nd = ('s', 't') if cfg.generator_norm_type == 'instance_norm' else ()
+  NORM_SCOPE = {'instance_norm': 'InstanceNorm', 'batch_norm': 'BatchNorm'}
+  if cfg.generator_norm_type not in NORM_SCOPE:
+    raise NotImplementedError('generator_norm_type=%s' % cfg.generator_norm_type)
+  nd = ('s', 't')
+  ns = NORM_SCOPE[cfg.generator_norm_type]
 
   def enc_skeleton(top, group, bias, norm_domains):
     if cfg.is_growing:
       store.add_conv('%s/from_rgb_%dx%d/Conv' % (top, hw // 2, hw // 2), 1, 3, get_num_channels(ms - 1, mc), group, bias,
-                     norm_domains)
+                     norm_domains, norm_scope=ns)
     c = get_num_channels(ms, mc)
-    store.add_conv('%s/from_rgb_%dx%d/Conv' % (top, hw, hw), 1, 3, c, group, bias, norm_domains)
+    store.add_conv('%s/from_rgb_%dx%d/Conv' % (top, hw, hw), 1, 3, c, group, bias, norm_domains, norm_scope=ns)
     for stage in range(ms, 0, -1):
       cur = hw // (2 ** (ms - stage))
       nc = get_num_channels(stage - 1, mc)
       blk = '%s/encoder_block_%dx%dx%d' % (top, cur, cur, nc)
-      store.add_conv(blk + '/Conv', 3, c, c, group, bias, norm_domains)
-      store.add_conv(blk + '/Conv_1', 3, c, nc, group, bias, norm_domains)
+      store.add_conv(blk + '/Conv', 3, c, c, group, bias, norm_domains, norm_scope=ns)
+      store.add_conv(blk + '/Conv_1', 3, c, nc, group, bias, norm_domains, norm_scope=ns)
       c = nc
 
   enc_skeleton('encoder_content', 'g', False, nd)
   # generator
   c = get_num_channels(0, mc)
   blk = 'generator/block_4x4x%d' % c
-  store.add_conv(blk + '/Conv', 3, c, c, 'g', False, nd)
-  store.add_conv(blk + '/Conv_1', 3, c, c, 'g', False, nd)
+  store.add_conv(blk + '/Conv', 3, c, c, 'g', False, nd, norm_scope=ns)
+  store.add_conv(blk + '/Conv_1', 3, c, c, 'g', False, nd, norm_scope=ns)
   for stage in range(1, ms + 1):
     cur = 2 ** (stage + 2)
     oc = get_num_channels(stage, mc)
     if stage == ms and cfg.is_growing:
-      store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (cur // 2, cur // 2), 1, c, 3, 'g', False, nd)
+      store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (cur // 2, cur // 2), 1, c, 3, 'g', False, nd, norm_scope=ns)
     cin = c + (get_num_channels(stage - 1, mc) if cfg.use_unet else 0)
     blk = 'generator/block_%dx%dx%d' % (cur, cur, oc)
-    store.add_conv(blk + '/Conv', 3, cin, oc, 'g', False, nd)
-    store.add_conv(blk + '/Conv_1', 3, oc, oc, 'g', False, nd)
+    store.add_conv(blk + '/Conv', 3, cin, oc, 'g', False, nd, norm_scope=ns)
+    store.add_conv(blk + '/Conv_1', 3, oc, oc, 'g', False, nd, norm_scope=ns)
     c = oc
-  store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (hw, hw), 1, c, 3, 'g', False, nd)
+  store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (hw, hw), 1, c, 3, 'g', False, nd, norm_scope=ns)
   # discriminators
   for top in ('discriminator_s', 'discriminator_t'):
     enc_skeleton(top, 'd', True, ())

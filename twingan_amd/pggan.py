@@ -26,18 +26,38 @@ def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pix
     y = ops.pointwise_conv(x, w)
   else:
     y = ops.conv2d(x, w, None, k, padding)
-  if cfg.generator_norm_type == 'instance_norm':
-    if isinstance(domain, tuple):
-      d0, d1, split = domain
-      return ops.norm_act(y, P['%s/InstanceNorm/gamma_%s' % (scope, d0)], P['%s/InstanceNorm/beta_%s' % (scope, d0)],
-                          lrelu=activation, pixel_norm=pixel_norm and cfg.do_pixel_norm,
-                          gamma2=P['%s/InstanceNorm/gamma_%s' % (scope, d1)],
-                          beta2=P['%s/InstanceNorm/beta_%s' % (scope, d1)], split=split, pool=pool)
-    return ops.norm_act(y, P['%s/InstanceNorm/gamma_%s' % (scope, domain)],
-                        P['%s/InstanceNorm/beta_%s' % (scope, domain)], lrelu=activation,
-                        pixel_norm=pixel_norm and cfg.do_pixel_norm, pool=pool)
-  raise NotImplementedError('generator_norm_type=%s (only instance_norm is on the MI355X hot path)' %
-                            cfg.generator_norm_type)
+  nt = cfg.generator_norm_type
+  if nt not in ('instance_norm', 'batch_norm'):
+    raise NotImplementedError('generator_norm_type=%s (instance_norm and batch_norm are built)' % nt)
+  ns = 'InstanceNorm' if nt == 'instance_norm' else 'BatchNorm'
+  if isinstance(domain, tuple):
+    d0, d1, split = domain[:3]
+    passes = domain[3] if len(domain) > 3 else 2
+  else:
+    d0, d1, split, passes = domain, None, None, 1
+  g0, b0 = P['%s/%s/gamma_%s' % (scope, ns, d0)], P['%s/%s/beta_%s' % (scope, ns, d0)]
+  g1 = P['%s/%s/gamma_%s' % (scope, ns, d1)] if d1 else None
+  b1 = P['%s/%s/beta_%s' % (scope, ns, d1)] if d1 else None
+  pn = pixel_norm and cfg.do_pixel_norm
+  if nt == 'instance_norm':
+    return ops.norm_act(y, g0, b0, lrelu=activation, pixel_norm=pn, gamma2=g1, beta2=b1, split=split, pool=pool)
+  # batch norm (libs/batch_norm.py:42-326, training mode): moments over (N,H,W) of ONE reference pass.  Each of
+  # the `passes` batched along N is a statistic group: the [passes, B*H, W, C] view turns the per-image
+  # kernels into per-pass ones (pixel norm and pooling are per pixel / per 2x2 block, which the view preserves).
+  n, h, w, c = y.shape
+  assert n % passes == 0 and (split is None or (split * passes) % n == 0)
+  yv = y.view(passes, (n // passes) * h, w, c)
+  st = P.state if hasattr(P, 'state') else None
+  ema = None
+  if st is not None:
+    pairs = [(st['%s/BatchNorm/moving_mean_%s' % (scope, d)], st['%s/BatchNorm/moving_variance_%s' % (scope, d)])
+             for d in ((d0, d1) if d1 else (d0,))]
+    ema = (0.999, pairs)
+  out = ops.norm_act(yv, g0, b0, lrelu=activation, pixel_norm=pn, in_eps=1e-3, gamma2=g1, beta2=b1,
+                     split=None if split is None else split * passes // n, pool=pool, ema=ema)
+  if pool:
+    return out[0].view(n, h, w, c), out[1].view(n, h // 2, w // 2, c)
+  return out.view(n, h, w, c)
 
 
 def _d_conv(P, scope, x, k=3, padding='SAME', pool=False):

@@ -110,11 +110,11 @@ def forward_generators(P, sources, targets, cfg):
   and the norm kernels pick gamma/beta per image, so the results are those of the separate passes)."""
   b = sources.shape[0]
   x = torch.cat([sources, targets], dim=0)
-  e, ep = pggan.encoder_before_classification(P, x, ('s', 't', b), cfg)
+  e, ep = pggan.encoder_before_classification(P, x, ('s', 't', b, 2), cfg)
   es, et = e.chunk(2)
   content = torch.cat([et, es, es, et], dim=0)
   # UNet skips: generator group k reads encoder group (t, s, s, t)[k] of the [s; t] encoder batch -- no copies
-  out, _ = pggan.generator(P, content, ('s', 't', 2 * b), cfg, ep if cfg.use_unet else None,
+  out, _ = pggan.generator(P, content, ('s', 't', 2 * b, 4), cfg, ep if cfg.use_unet else None,
                            unet_groups=(b, (1, 0, 0, 1)))
   s_prime, s_cycle, t_prime, t_cycle = out.chunk(4)
   return dict(es=es, et=et, s_prime=s_prime, s_cycle=s_cycle, t_prime=t_prime, t_cycle=t_cycle)
@@ -144,7 +144,7 @@ def generator_loss(P, sources, targets, cfg):
         pp, _ = pggan.discriminator(P, prime, cfg, top)
       terms['generator_fool_loss_prime_' + d] = _fool_loss(pp, cfg)
   # re-encode s' in domain s and t' in domain t as one batch (twingan.py:275-288)
-  e2, _ = pggan.encoder_before_classification(P, torch.cat([o['s_prime'], o['t_prime']], dim=0), ('s', 't', b), cfg)
+  e2, _ = pggan.encoder_before_classification(P, torch.cat([o['s_prime'], o['t_prime']], dim=0), ('s', 't', b, 2), cfg)
   e_sp, e_tp = e2.chunk(2)
   if cfg.l_content_weight:
     terms['l_content_s'] = ops.abs_diff_mean(o['es'], e_tp, cfg.l_content_weight)
