@@ -152,3 +152,32 @@ def test_step_schedule_counters():
   for _ in range(5):
     tr.run(None, None)
   assert calls == ['g', 'd', 'g', 'd', 'g'] and tr.global_step == 3 and tr.n_critic_counter == 5
+
+
+def test_stage_schedule_matches_pggan_runner():
+  """pggan_runner.py:90-109: stage names, growing/stable alternation, steps = images / batch, last stage open-ended."""
+  from twingan_amd.runner import LAST_STAGE_STEPS, alpha_grow, stage_schedule
+  sch = stage_schedule(4, 32, {4: 16, 8: 16, 16: 8, 32: 8}, 300000)
+  assert [s[0] for s in sch] == ['4', '4to8', '8', '8to16', '16', '16to32', '32']
+  assert [s[2] for s in sch] == [False, True, False, True, False, True, False]
+  assert sch[0][4] == 18750 and sch[3][4] == 37500 and sch[-1][4] == LAST_STAGE_STEPS and sch[-2][4] == 37500
+  full = stage_schedule()
+  assert len(full) == 13 and full[-1][:3] == ('256', 256, False) and full[-2][0] == '128to256'
+  assert alpha_grow(0, 100) == 0.0 and alpha_grow(50, 100) == 0.5
+
+
+def test_warm_start_ignores_missing_and_reshaped_vars():
+  """ignore_missing_vars semantics (pggan_runner.py:136-146): shared blocks are copied, the new resolution's layers
+  (and the from_rgb / to_rgb of the new size) keep their fresh initialisation."""
+  from twingan_amd import Config
+  from twingan_amd.params import ParamStore, declare_twingan
+  from twingan_amd.runner import warm_start
+  prev = declare_twingan(ParamStore('cpu'), Config(hw=8, max_ch=8)).build(seed=1)
+  class T:      # the part of Trainer that warm_start touches
+    store = declare_twingan(ParamStore('cpu'), Config(hw=16, max_ch=8, is_growing=True)).build(seed=2)
+  loaded = warm_start(T, prev.state_dict())
+  assert 'generator/block_8x8x8/Conv/weights' in loaded and 'encoder_content/from_rgb_8x8/Conv/weights' in loaded
+  assert 'generator/block_16x16x8/Conv/weights' not in loaded
+  a, b = prev.state_dict(), T.store.state_dict()
+  assert torch.equal(a['generator/block_8x8x8/Conv/weights'], b['generator/block_8x8x8/Conv/weights'])
+  assert torch.equal(a['generator/generator_to_rgb_8x8/Conv/weights'], b['generator/generator_to_rgb_8x8/Conv/weights'])
