@@ -42,6 +42,8 @@ class Config:
   pn_eps: float = 1e-6               # nets/pggan_utils.py:330
   lrelu: float = 0.2                 # util_misc.py:68
   bn_state: object = None            # dict collecting the BatchNorm moving statistics when set
+  equalized: bool = False            # equalized_learning_rate           (nets/pggan.py:40; pggan_utils.py:236-254)
+  res_block: bool = False            # use_res_block                     (nets/pggan.py:44; pggan_utils.py:257-264,334-342)
 
 
 def get_num_channels(stage, max_num_channels=256):
@@ -113,6 +115,25 @@ def generator_param_specs(top, hw, max_ch, use_unet, growing=False):
   return specs
 
 
+def shortcut_specs(specs, hw, max_ch, use_unet=False):
+  """[(scope, 1, cin, cout)] of the 1x1 'shortcut' convs --use_res_block adds where a block changes the channel
+  count (nets/pggan_utils.py:334-342): from_rgb blocks (3 -> C), encoder / discriminator two-layer blocks (block
+  input vs out_channels) and generator three-layer blocks (upsampled [+ UNet concat] input vs out_channels)."""
+  out = []
+  for scope, k, cin, cout in specs:
+    blk, leaf = scope.rsplit('/', 1)
+    name = blk.rsplit('/', 1)[1]
+    if name.startswith('from_rgb_') and cin != cout:
+      out.append((blk + '/shortcut', 1, cin, cout))
+    elif name.startswith('encoder_block_') and leaf == 'Conv':
+      nc = int(name.rsplit('x', 1)[1])
+      if cin != nc:
+        out.append((blk + '/shortcut', 1, cin, nc))
+    elif name.startswith('block_') and leaf == 'Conv' and not name.startswith('block_4x4x') and cin != cout:
+      out.append((blk + '/shortcut', 1, cin, cout))
+  return out
+
+
 def discriminator_tail_specs(top, max_ch):
   blk = '%s/before_fc_1x1x%d' % (top, max_ch)
   return [(blk + '/Conv', 3, max_ch + 1, max_ch), (blk + '/Conv_1', 4, max_ch, max_ch)]
@@ -120,9 +141,13 @@ def discriminator_tail_specs(top, max_ch):
 
 def init_params(cfg, seed=0, dtype=torch.float32, std=0.02):
   """All TwinGAN variables for one progressive stage (twingan.py:105-110 scopes).  ``std=0.02`` is the
-  reference initialiser; ``std='he'`` is a test-only variant (also randomises biases / gamma / beta)."""
+  reference initialiser (1.0 with equalized_learning_rate, nets/pggan_utils.py:82-84, pggan.py:364); ``std='he'``
+  is a test-only variant (also randomises biases / gamma / beta)."""
   g = torch.Generator().manual_seed(seed)
   P = {}
+  he = std == 'he'
+  if cfg.equalized:
+    std = 1.0
   for s in encoder_param_specs('encoder_content', cfg.hw, cfg.max_ch, cfg.is_growing):
     _conv_p(P, g, s[0], s[1], s[2], s[3], ('s', 't') if cfg.norm in NORM_SCOPE else (), False, dtype, std,
             NORM_SCOPE.get(cfg.norm, ''))
@@ -134,9 +159,16 @@ def init_params(cfg, seed=0, dtype=torch.float32, std=0.02):
       _conv_p(P, g, s[0], s[1], s[2], s[3], (), True, dtype, std)
     P[top + '/prediction/fully_connected/weights'] = \
         torch.randn(cfg.max_ch, 1, generator=g, dtype=torch.float32).to(dtype) * \
-        (math.sqrt(1.0 / cfg.max_ch) if std == 'he' else 0.02)
+        (math.sqrt(1.0 / cfg.max_ch) if std == 'he' else std)
     P[top + '/prediction/fully_connected/biases'] = torch.zeros(1, dtype=dtype)
-  if std == 'he':
+  if cfg.res_block:      # after everything else so the other variables keep their seeded values
+    ge = encoder_param_specs('encoder_content', cfg.hw, cfg.max_ch, cfg.is_growing) + \
+        generator_param_specs('generator', cfg.hw, cfg.max_ch, cfg.use_unet, cfg.is_growing)
+    dd = [sp for top in ('discriminator_s', 'discriminator_t')
+          for sp in encoder_param_specs(top, cfg.hw, cfg.max_ch, cfg.is_growing)]
+    for sp in shortcut_specs(ge, cfg.hw, cfg.max_ch) + shortcut_specs(dd, cfg.hw, cfg.max_ch):
+      _conv_p(P, g, sp[0], 1, sp[2], sp[3], (), True, dtype, std)
+  if he:
     for k in sorted(P):
       if k.endswith('/biases') or '/beta_' in k:
         P[k] = (torch.randn(P[k].shape, generator=g, dtype=torch.float32) * 0.1).to(dtype)
@@ -225,10 +257,29 @@ def minibatch_state_concat(x):
 # ------------------------------------------------------------------------------------------------
 # layers = arg-scoped conv (nets/pggan_utils.py:54-127,236-245): conv -> norm -> act, then pixel-norm
 # ------------------------------------------------------------------------------------------------
+def equalize(x, cfg, k):
+  """maybe_equalized_conv2d / maybe_equalized_fc (nets/pggan_utils.py:236-254): the INPUT is scaled by
+  sqrt(2 / (in_ch * k^2)) (k = 1 for the fully connected layer)."""
+  if not cfg.equalized:
+    return x
+  return x * math.sqrt(2.0 / (x.shape[-1] * k * k))
+
+
+def resblock(P, blk, input_layer, out_channels, conv_out, cfg):
+  """maybe_resblock (nets/pggan_utils.py:257-264,334-342): identity, or a 1x1 'shortcut' conv (+bias, no norm, no
+  activation) when the channel count changes, added to the block's conv output."""
+  if not cfg.res_block:
+    return conv_out
+  if input_layer.shape[-1] == out_channels:
+    return input_layer + conv_out
+  sc = conv2d(equalize(input_layer, cfg, 1), P[blk + '/shortcut/weights'], 'SAME') + P[blk + '/shortcut/biases']
+  return sc + conv_out
+
+
 def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=True):
   """Generator/encoder conv: no bias (a normalizer is set), per-domain instance norm,
   LeakyReLU, optional pixel norm (nets/pggan.py:78-81,387-391)."""
-  y = conv2d(x, P[scope + '/weights'], padding)
+  y = conv2d(equalize(x, cfg, k), P[scope + '/weights'], padding)
   if cfg.norm == 'instance_norm':
     y = instance_norm(y, P[scope + '/InstanceNorm/gamma_' + domain], P[scope + '/InstanceNorm/beta_' + domain],
                       cfg.in_eps)
@@ -250,7 +301,7 @@ def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=Tru
 
 def d_conv(P, scope, x, cfg, k=3, padding='SAME'):
   """Discriminator conv: bias, no norm, LeakyReLU (nets/pggan_utils.py:116; slim bias rule)."""
-  y = conv2d(x, P[scope + '/weights'], padding) + P[scope + '/biases']
+  y = conv2d(equalize(x, cfg, k), P[scope + '/weights'], padding) + P[scope + '/biases']
   return leaky_relu(y, cfg.lrelu)
 
 
@@ -266,17 +317,22 @@ def encoder(P, x, domain, cfg, top='encoder_content'):
   if cfg.is_growing:
     shr = avg_pool2(x)
     name = 'from_rgb_%dx%d' % (hw // 2, hw // 2)
+    pooled = shr
     shr = ge_conv(P, '%s/%s/Conv' % (top, name), shr, domain, cfg, k=1)
+    shr = resblock(P, '%s/%s' % (top, name), pooled, shr.shape[-1], shr, cfg)
     ep[name] = shr
   name = 'from_rgb_%dx%d' % (hw, hw)
   net = ge_conv(P, '%s/%s/Conv' % (top, name), x, domain, cfg, k=1)
+  net = resblock(P, '%s/%s' % (top, name), x, net.shape[-1], net, cfg)
   ep[name] = net
   for stage in range(ms, 0, -1):
     nc = get_num_channels(stage - 1, cfg.max_ch)
     cur = hw // (2 ** (ms - stage))
     name = 'encoder_block_%dx%dx%d' % (cur, cur, nc)
+    blk_in = net
     net = ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg)
     net = ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg)
+    net = resblock(P, '%s/%s' % (top, name), blk_in, nc, net, cfg)
     ep[name] = net
     cur //= 2
     net = avg_pool2(net)
@@ -325,8 +381,10 @@ def generator(P, source, domain, cfg, unet_ep=None, top='generator'):
         ep[rgb] = before_growth
       net = upsample2x(net)
       net = _concat_unet(net, unet_ep, cfg.max_ch)
+      blk_in = net
       net = ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg)
       net = ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg)
+      net = resblock(P, '%s/%s' % (top, name), blk_in, oc, net, cfg)
     ep[name] = net
   rgb = 'generator_to_rgb_%dx%d' % (hw, hw)
   to_rgb = ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=1, act=False, pixnorm=False)
@@ -347,17 +405,22 @@ def discriminator(P, x, cfg, top):
   if cfg.is_growing:
     shr = avg_pool2(x)
     name = 'from_rgb_%dx%d' % (hw // 2, hw // 2)
+    pooled = shr
     shr = d_conv(P, '%s/%s/Conv' % (top, name), shr, cfg, k=1)
+    shr = resblock(P, '%s/%s' % (top, name), pooled, shr.shape[-1], shr, cfg)
     ep[name] = shr
   name = 'from_rgb_%dx%d' % (hw, hw)
   net = d_conv(P, '%s/%s/Conv' % (top, name), x, cfg, k=1)
+  net = resblock(P, '%s/%s' % (top, name), x, net.shape[-1], net, cfg)
   ep[name] = net
   for stage in range(ms, 0, -1):
     nc = get_num_channels(stage - 1, cfg.max_ch)
     cur = hw // (2 ** (ms - stage))
     name = 'encoder_block_%dx%dx%d' % (cur, cur, nc)
+    blk_in = net
     net = d_conv(P, '%s/%s/Conv' % (top, name), net, cfg)
     net = d_conv(P, '%s/%s/Conv_1' % (top, name), net, cfg)
+    net = resblock(P, '%s/%s' % (top, name), blk_in, nc, net, cfg)
     ep[name] = net
     net = avg_pool2(net)
     if stage == ms and cfg.is_growing:
@@ -368,7 +431,8 @@ def discriminator(P, x, cfg, top):
   net = d_conv(P, blk + '/Conv_1', net, cfg, k=4, padding='VALID')
   ep['before_fc'] = net
   feat = net.reshape(net.shape[0], -1)
-  pred = feat @ P[top + '/prediction/fully_connected/weights'] + P[top + '/prediction/fully_connected/biases']
+  pred = equalize(feat, cfg, 1) @ P[top + '/prediction/fully_connected/weights'] + \
+      P[top + '/prediction/fully_connected/biases']
   ep['prediction'] = pred
   return pred, ep
 

@@ -27,7 +27,7 @@ def make(cfg_kw, precision, seed=0, batch=3):
   from twingan_amd.twingan import Trainer
   cfg = Config(precision=precision, **cfg_kw)
   rcfg = R.Config(hw=cfg.hw, max_ch=cfg.max_ch, is_growing=cfg.is_growing, alpha_grow=cfg.alpha_grow,
-                  use_unet=cfg.use_unet)
+                  use_unet=cfg.use_unet, equalized=cfg.equalized_learning_rate, res_block=cfg.use_res_block)
   Pref = R.init_params(rcfg, seed=seed, dtype=torch.float64, std='he')
   tr = Trainer(cfg, device='cuda:0', seed=seed)
   tr.store.load_state_dict({k: v.float() for k, v in Pref.items()})
@@ -143,6 +143,70 @@ def test_losses_and_gradients(precision, hw, max_ch):
   dl.backward()
   rdl.backward()
   _grads_close(tr, Pref, tr.store.names('d'), gtol, 'discriminator', min_cos)
+
+
+@pytest.mark.parametrize('equalized,res_block,growing', [(True, False, False), (False, True, False), (True, True, True)])
+def test_equalized_lr_and_res_block(equalized, res_block, growing):
+  """--equalized_learning_rate (input scaling, N(0,1) weights; nets/pggan_utils.py:82-84,236-254) and --use_res_block
+  (identity / 1x1 'shortcut' residuals; :257-264,334-342): schema, forward, losses and gradients vs the oracle,
+  including the WGAN-GP double backward through the scaled / residual layers."""
+  from twingan_amd import pggan
+  from twingan_amd import twingan as T
+  kw = dict(hw=32, max_ch=16, equalized_learning_rate=equalized, use_res_block=res_block, is_growing=growing,
+            alpha_grow=0.4 if growing else 0.0)
+  cfg, rcfg, tr, Pref, dev, ref = make(kw, 'fp32', seed=5, batch=2)
+  assert set(tr.store.state_dict()) == set(Pref)
+  if res_block:
+    assert 'generator/block_8x8x16/shortcut/weights' in Pref and 'discriminator_s/from_rgb_32x32/shortcut/biases' in Pref
+  with torch.no_grad():
+    net, ep = pggan.encoder_before_classification(tr.P, dev['s'], 's', cfg)
+    rnet, rep = R.encoder(Pref, ref['s'], 's', rcfg)
+    for k in rep:
+      assert rel_l2(ep[k], rep[k]) < 2e-5, k
+    out, _ = pggan.generator(tr.P, net, 't', cfg, ep)
+    rout, _ = R.generator(Pref, rnet, 't', rcfg, rep)
+    assert rel_l2(out, rout) < 2e-5
+    pred, _ = pggan.discriminator(tr.P, out, cfg, 'discriminator_t')
+    rpred, _ = R.discriminator(Pref, rout, rcfg, 'discriminator_t')
+    assert rel_l2(pred, rpred) < 2e-5
+  for v in Pref.values():
+    v.requires_grad_(True)
+  tr.store.zero_grad('g')
+  tr._set_requires_grad(g=True, d=False)
+  gl, gterms = T.generator_loss(tr.P, dev['s'], dev['t'], cfg)
+  rgl, rterms = R.generator_loss(Pref, ref['s'], ref['t'], rcfg)
+  for k in rterms:
+    assert abs(gterms[k].item() - rterms[k].item()) < 1e-4 * max(1.0, abs(rterms[k].item())), k
+  gl.backward()
+  rgl.backward()
+  _grads_close(tr, Pref, tr.store.names('g'), 8e-2, 'generator')
+  for v in Pref.values():
+    v.grad = None
+  tr.store.zero_grad('d')
+  tr._set_requires_grad(g=False, d=True)
+  dl, dterms = T.discriminator_loss(tr.P, dev['s'], dev['t'], cfg, dev['a_s'], dev['a_t'])
+  rdl, rdterms = R.discriminator_loss(Pref, ref['s'], ref['t'], rcfg, ref['a_s'], ref['a_t'])
+  for k in rdterms:
+    assert abs(dterms[k].item() - rdterms[k].item()) < 1e-4 * max(1.0, abs(rdterms[k].item())), k
+  dl.backward()
+  rdl.backward()
+  _grads_close(tr, Pref, tr.store.names('d'), 8e-2, 'discriminator')
+
+
+def test_equalized_res_block_bf16_graph_step_runs():
+  """The same options on the production path (bf16 MFMA kernels, hipGraph): finite losses, parameters move."""
+  from twingan_amd import Config
+  from twingan_amd.twingan import Trainer
+  cfg = Config(hw=32, max_ch=32, equalized_learning_rate=True, use_res_block=True)
+  tr = Trainer(cfg, device='cuda:0', seed=1, use_graph=True)
+  g = torch.Generator().manual_seed(3)
+  s = torch.rand(4, 32, 32, 3, generator=g).to('cuda:0').bfloat16()
+  t = torch.rand(4, 32, 32, 3, generator=g).to('cuda:0').bfloat16()
+  before = tr.store.flat['g'].clone()
+  for _ in range(6):
+    loss, terms = tr.run(s, t)
+    assert np.isfinite(float(loss)) and all(np.isfinite(float(v)) for v in terms.values())
+  assert float((tr.store.flat['g'] - before).abs().max()) > 0
 
 
 def test_alternating_train_steps_match_oracle():

@@ -11,6 +11,8 @@ class Config:
   generator_norm_type: str = 'instance_norm'   # nets/pggan.py:24 (north-star config)
   do_pixel_norm: bool = True          # nets/pggan.py:34-38
   use_unet: bool = True               # twingan.py:53-56
+  equalized_learning_rate: bool = False   # nets/pggan.py:39-41; nets/pggan_utils.py:82-84,236-254
+  use_res_block: bool = False         # nets/pggan.py:43-46; nets/pggan_utils.py:257-264,334-342
   is_growing: bool = False            # image_generation.py:69-72
   alpha_grow: float = 0.0             # twingan.py:833-835
   loss_architecture: str = 'wgan_gp'  # image_generation.py:81-83

@@ -736,6 +736,16 @@ class AxpbyFn(torch.autograd.Function):
     return gx, gy, None, None
 
 
+def scale(x, a):
+  """a * x (the input scaling of maybe_equalized_conv2d / maybe_equalized_fc, nets/pggan_utils.py:236-254)."""
+  return AxpbyFn.apply(x, None, float(a), 0.0)
+
+
+def add(x, y):
+  """x + y (residual shortcut, nets/pggan_utils.py:261)."""
+  return AxpbyFn.apply(x, y, 1.0, 1.0)
+
+
 def lerp(new, old, alpha):
   """new * alpha + (1 - alpha) * old."""
   return AxpbyFn.apply(new, old, float(alpha), float(1.0 - alpha))

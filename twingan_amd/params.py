@@ -52,6 +52,7 @@ class ParamStore:
     self.offsets = {}
     self.state_specs = OrderedDict()   # name -> (numel, init value): non-trainable variables
     self.state = {}
+    self.weights_init_stddev = 0.02    # 1.0 under equalized_learning_rate (nets/pggan_utils.py:82-84, pggan.py:364)
 
   # ---- declaration ----------------------------------------------------------------------------
   def add(self, name, shape, group, kind, phys=None):
@@ -100,11 +101,12 @@ class ParamStore:
     return self
 
   def _init(self, p, s, gen):
-    """weights ~ N(0, 0.02) (nets/pggan_utils.py:56,93; pggan.py:364-368), biases/beta 0, gamma 1."""
+    """weights ~ N(0, 0.02) (nets/pggan_utils.py:56,93; pggan.py:364-368; N(0,1) when equalized), biases/beta 0,
+    gamma 1."""
     with torch.no_grad():
       if s['kind'] in ('conv_w', 'fc_w'):
         p.zero_()
-        w = torch.randn(s['shape'], generator=gen, dtype=torch.float32) * 0.02
+        w = torch.randn(s['shape'], generator=gen, dtype=torch.float32) * self.weights_init_stddev
         self._logical(p, s).copy_(w.to(p.device))
       elif s['kind'] == 'gamma':
         p.fill_(1.0)
@@ -167,19 +169,30 @@ def declare_twingan(store, cfg):
     raise NotImplementedError('generator_norm_type=%s' % cfg.generator_norm_type)
   nd = ('s', 't')
   ns = NORM_SCOPE[cfg.generator_norm_type]
+  if cfg.equalized_learning_rate:
+    store.weights_init_stddev = 1.0
+
+  def shortcut(blk, cin, cout, group):
+    """--use_res_block: 1x1 'shortcut' conv (+bias, no norm) where a block changes the channel count
+    (nets/pggan_utils.py:334-342)."""
+    if cfg.use_res_block and cin != cout:
+      store.add_conv(blk + '/shortcut', 1, cin, cout, group, True, ())
 
   def enc_skeleton(top, group, bias, norm_domains):
     if cfg.is_growing:
       store.add_conv('%s/from_rgb_%dx%d/Conv' % (top, hw // 2, hw // 2), 1, 3, get_num_channels(ms - 1, mc), group, bias,
                      norm_domains, norm_scope=ns)
+      shortcut('%s/from_rgb_%dx%d' % (top, hw // 2, hw // 2), 3, get_num_channels(ms - 1, mc), group)
     c = get_num_channels(ms, mc)
     store.add_conv('%s/from_rgb_%dx%d/Conv' % (top, hw, hw), 1, 3, c, group, bias, norm_domains, norm_scope=ns)
+    shortcut('%s/from_rgb_%dx%d' % (top, hw, hw), 3, c, group)
     for stage in range(ms, 0, -1):
       cur = hw // (2 ** (ms - stage))
       nc = get_num_channels(stage - 1, mc)
       blk = '%s/encoder_block_%dx%dx%d' % (top, cur, cur, nc)
       store.add_conv(blk + '/Conv', 3, c, c, group, bias, norm_domains, norm_scope=ns)
       store.add_conv(blk + '/Conv_1', 3, c, nc, group, bias, norm_domains, norm_scope=ns)
+      shortcut(blk, c, nc, group)
       c = nc
 
   enc_skeleton('encoder_content', 'g', False, nd)
@@ -197,6 +210,7 @@ def declare_twingan(store, cfg):
     blk = 'generator/block_%dx%dx%d' % (cur, cur, oc)
     store.add_conv(blk + '/Conv', 3, cin, oc, 'g', False, nd, norm_scope=ns)
     store.add_conv(blk + '/Conv_1', 3, oc, oc, 'g', False, nd, norm_scope=ns)
+    shortcut(blk, cin, oc, 'g')
     c = oc
   store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (hw, hw), 1, c, 3, 'g', False, nd, norm_scope=ns)
   # discriminators

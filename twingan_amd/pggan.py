@@ -9,6 +9,8 @@ a TF variable-scope postfix (conditional_layer_var_scope_postfix, nets/pggan_uti
 
 Network functions return ``(output, end_points)`` like the reference.  Tensors are NHWC.
 """
+import math
+
 from . import ops
 from .params import get_num_channels, max_stage_of, mbstd_cpad
 
@@ -16,12 +18,38 @@ from .params import get_num_channels, max_stage_of, mbstd_cpad
 # ------------------------------------------------------------------------------------------------
 # layer helpers (nets/pggan_utils.py)
 # ------------------------------------------------------------------------------------------------
+def _equalize(x, cfg, k, in_ch=None):
+  """maybe_equalized_conv2d / maybe_equalized_fc (nets/pggan_utils.py:236-254): with --equalized_learning_rate the
+  layer INPUT is scaled by sqrt(2 / (in_ch * k^2)); weights are then N(0,1)-initialised (params.declare_twingan)."""
+  if not cfg.equalized_learning_rate:
+    return x
+  return ops.scale(x, math.sqrt(2.0 / ((in_ch or x.shape[-1]) * k * k)))
+
+
+def _conv_any(x, w, bias, k):
+  if k == 1 and (w.shape[2] <= 4 or w.shape[3] <= 4):
+    return ops.pointwise_conv(x, w, bias)
+  return ops.conv2d(x, w, bias, k, 'SAME')
+
+
+def maybe_resblock(P, blk, input_layer, out_channels, conv2d_out, cfg):
+  """nets/pggan_utils.py:257-264,334-342: ``shortcut + conv2d_out`` with the shortcut = the block input, or a 1x1
+  conv of it (scope 'shortcut', bias, no normaliser, no activation) when the channel count changes."""
+  if not cfg.use_res_block:
+    return conv2d_out
+  if input_layer.shape[-1] == out_channels:
+    return ops.add(input_layer, conv2d_out)
+  sc = _conv_any(_equalize(input_layer, cfg, 1), P[blk + '/shortcut/weights'], P[blk + '/shortcut/biases'], 1)
+  return ops.add(sc, conv2d_out)
+
+
 def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pixel_norm=True, pool=False):
   """maybe_pixel_norm(maybe_equalized_conv2d(...)) for the generator / encoder arg-scope
   (nets/pggan_utils.py:86-98,236-245): conv without bias, per-domain instance norm, LeakyReLU(0.2),
   then pixel norm (nets/pggan.py:78-81).  ``domain`` is 's' | 't', or (d0, d1, split): the batch holds
   ``split`` images of domain d0 followed by images of domain d1 (two reference passes as one launch)."""
   w = P[scope + '/weights']
+  x = _equalize(x, cfg, k)
   if k == 1 and (w.shape[2] <= 4 or w.shape[3] <= 4):
     y = ops.pointwise_conv(x, w)
   else:
@@ -60,11 +88,12 @@ def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pix
   return out.view(n, h, w, c)
 
 
-def _d_conv(P, scope, x, k=3, padding='SAME', pool=False):
+def _d_conv(P, scope, x, cfg, k=3, padding='SAME', pool=False, in_ch=None):
   """Discriminator arg-scope (nets/pggan_utils.py:116-127): conv + bias, no norm, LeakyReLU(0.2),
   fused into the conv epilogue."""
   w = P[scope + '/weights']
   b = P[scope + '/biases']
+  x = _equalize(x, cfg, k, in_ch)      # in_ch: logical channel count when x is channel-padded (minibatch stddev)
   if k == 1 and (w.shape[2] <= 4 or w.shape[3] <= 4):
     return ops.pointwise_conv(x, w, b, lrelu=True)
   return ops.conv2d(x, w, b, k, padding, lrelu=True, pool=pool)
@@ -98,20 +127,28 @@ def encoder_before_classification(P, source, domain, cfg, top='encoder_content')
   end_points = {'source': source}
   shrinked = None
   if cfg.is_growing:
-    shrinked = ops.avg_pool2(source)
+    pooled = ops.avg_pool2(source)
     name = 'from_rgb_%dx%d' % (hw // 2, hw // 2)
-    shrinked = _ge_conv(P, '%s/%s/Conv' % (top, name), shrinked, domain, cfg, k=1)
+    shrinked = _ge_conv(P, '%s/%s/Conv' % (top, name), pooled, domain, cfg, k=1)
+    shrinked = maybe_resblock(P, '%s/%s' % (top, name), pooled, shrinked.shape[-1], shrinked, cfg)
     end_points[name] = shrinked
   name = 'from_rgb_%dx%d' % (hw, hw)
   net = _ge_conv(P, '%s/%s/Conv' % (top, name), source, domain, cfg, k=1)
+  net = maybe_resblock(P, '%s/%s' % (top, name), source, net.shape[-1], net, cfg)
   end_points[name] = net
   for stage in range(max_stage, 0, -1):
     num_channels = get_num_channels(stage - 1, cfg.max_ch)
     current_hw = hw // (2 ** (max_stage - stage))
     name = 'encoder_block_%dx%dx%d' % (current_hw, current_hw, num_channels)
+    block_in = net
     net = _ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg)
-    # last layer of the block + tf.nn.avg_pool (nets/pggan.py:466-468) as one op: (skip end-point, pooled)
-    end_points[name], net = _ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg, pool=True)
+    if cfg.use_res_block:
+      net = _ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg)
+      end_points[name] = maybe_resblock(P, '%s/%s' % (top, name), block_in, num_channels, net, cfg)
+      net = ops.avg_pool2(end_points[name])
+    else:
+      # last layer of the block + tf.nn.avg_pool (nets/pggan.py:466-468) as one op: (skip end-point, pooled)
+      end_points[name], net = _ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg, pool=True)
     current_hw //= 2
     end_points['downsample_to_%dx%dx%d' % (current_hw, current_hw, num_channels)] = net
     if stage == max_stage and cfg.is_growing:
@@ -152,8 +189,10 @@ def generator(P, source, domain, cfg, unet_end_points=None, top='generator', une
         net = ops.upsample2x_concat(net, skip, unet_groups[0], unet_groups[1])
       else:
         net = ops.upsample2x_concat(net, skip)
+      block_in = net
       net = _ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg)
       net = _ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg)
+      net = maybe_resblock(P, '%s/%s' % (top, name), block_in, output_channels, net, cfg)
     end_points[name] = net
   rgb = 'generator_to_rgb_%dx%d' % (hw, hw)
   # to_rgb: activation None, normaliser still applied, no pixel norm (pggan.py:192-200)
@@ -177,19 +216,27 @@ def discriminator_before_fc(P, source, cfg, top, groups=1):
   end_points = {}
   shrinked = None
   if cfg.is_growing:
-    shrinked = ops.avg_pool2(source)
+    pooled = ops.avg_pool2(source)
     name = 'from_rgb_%dx%d' % (hw // 2, hw // 2)
-    shrinked = _d_conv(P, '%s/%s/Conv' % (top, name), shrinked, k=1)
+    shrinked = _d_conv(P, '%s/%s/Conv' % (top, name), pooled, cfg, k=1)
+    shrinked = maybe_resblock(P, '%s/%s' % (top, name), pooled, shrinked.shape[-1], shrinked, cfg)
     end_points[name] = shrinked
   name = 'from_rgb_%dx%d' % (hw, hw)
-  net = _d_conv(P, '%s/%s/Conv' % (top, name), source, k=1)
+  net = _d_conv(P, '%s/%s/Conv' % (top, name), source, cfg, k=1)
+  net = maybe_resblock(P, '%s/%s' % (top, name), source, net.shape[-1], net, cfg)
   end_points[name] = net
   for stage in range(max_stage, 0, -1):
     num_channels = get_num_channels(stage - 1, cfg.max_ch)
     current_hw = hw // (2 ** (max_stage - stage))
     name = 'encoder_block_%dx%dx%d' % (current_hw, current_hw, num_channels)
-    net = _d_conv(P, '%s/%s/Conv' % (top, name), net)
-    end_points[name], net = _d_conv(P, '%s/%s/Conv_1' % (top, name), net, pool=True)      # conv + avg_pool (pggan.py:304-306)
+    block_in = net
+    net = _d_conv(P, '%s/%s/Conv' % (top, name), net, cfg)
+    if cfg.use_res_block:
+      net = _d_conv(P, '%s/%s/Conv_1' % (top, name), net, cfg)
+      end_points[name] = maybe_resblock(P, '%s/%s' % (top, name), block_in, num_channels, net, cfg)
+      net = ops.avg_pool2(end_points[name])
+    else:
+      end_points[name], net = _d_conv(P, '%s/%s/Conv_1' % (top, name), net, cfg, pool=True)   # conv + avg_pool (pggan.py:304-306)
     current_hw //= 2
     end_points['downsample_to_%dx%dx%d' % (current_hw, current_hw, num_channels)] = net
     if stage == max_stage and cfg.is_growing:
@@ -197,8 +244,8 @@ def discriminator_before_fc(P, source, cfg, top, groups=1):
       end_points['encoder_block_interpolated_%dx%dx%d' % (current_hw, current_hw, num_channels)] = net
   blk = 'before_fc_1x1x%d' % cfg.max_ch
   net = ops.minibatch_state_concat(net, mbstd_cpad(net.shape[3]), groups)      # pggan_utils.py:353-366
-  net = _d_conv(P, '%s/%s/Conv' % (top, blk), net, k=3, padding='SAME')
-  net = _d_conv(P, '%s/%s/Conv_1' % (top, blk), net, k=4, padding='VALID')
+  net = _d_conv(P, '%s/%s/Conv' % (top, blk), net, cfg, k=3, padding='SAME', in_ch=cfg.max_ch + 1)
+  net = _d_conv(P, '%s/%s/Conv_1' % (top, blk), net, cfg, k=4, padding='VALID')
   end_points[blk] = net
   end_points['before_fc'] = net
   return net, end_points
@@ -209,7 +256,7 @@ def discriminator(P, source, cfg, top, groups=1):
   minibatch-stddev statistic, as separate reference calls would)."""
   net, end_points = discriminator_before_fc(P, source, cfg, top, groups)
   feat = net.reshape(net.shape[0], -1)                                 # tf.squeeze(net, (1, 2))
-  pred = ops.fully_connected(feat, P[top + '/prediction/fully_connected/weights'],
+  pred = ops.fully_connected(_equalize(feat, cfg, 1), P[top + '/prediction/fully_connected/weights'],
                              P[top + '/prediction/fully_connected/biases'])
   end_points['prediction'] = pred
   return pred, end_points
