@@ -144,6 +144,9 @@ def roofline_pass(tr, a, b, steps=2):
   # whole step against the two peaks: sum over launches of max(flops/MFMA peak, bytes/HBM peak) / measured time
   roof['step_roofline_frac'] = round(t_min_total / t_total, 4)
   roof['top_shapes'] = [row(kk, ff) for kk, ff in top_shapes[:48]]
+  if os.environ.get('TG_DUMP_SHAPES'):      # full per-shape table for kernel work (not part of the bench line)
+    with open(os.environ['TG_DUMP_SHAPES'], 'w') as fh:
+      json.dump([row(kk, ff) for kk, ff in top_shapes], fh, indent=0)
   roof['families'] = [row(kk, ff) for kk, ff in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])[:12]]
   return roof
 

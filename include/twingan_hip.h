@@ -91,6 +91,15 @@ int tg_conv2d_bwd_weight(const TgConvDesc* d, const void* x, const void* gy, flo
 size_t tg_conv2d_pack_elems(const TgConvDesc* d, int mode);
 int tg_conv2d_pack_weights(const TgConvDesc* d, const float* w_hwio, int mode, void* out_bf16, void* stream);
 
+/* All packs of an optimiser group in ONE launch (the step re-packs ~60 weights after every Adam apply; one
+ * launch per pack is launch-latency bound).  The caller builds a job table in HOST memory with
+ * tg_pack_table_fill (job j of njobs; *total_blocks accumulates the grid size, start it at 0), copies its
+ * tg_pack_table_bytes(njobs) bytes to the device once, and calls tg_conv2d_pack_weights_multi every step. */
+size_t tg_pack_table_bytes(int njobs);
+int tg_pack_table_fill(const TgConvDesc* d, const float* w_hwio, int mode, void* out_bf16, int job, void* table_host,
+                       int32_t* total_blocks);
+int tg_conv2d_pack_weights_multi(const void* table_device, int njobs, int total_blocks, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * 1x1 convs with a 3-channel side (fromRGB 3->C, toRGB C->3): pure-bandwidth VALU kernels.
  * nets/pggan.py:233-240,395-399 (from_rgb), :176-178,198-200 (to_rgb).  w = fp32 [cin][cout].

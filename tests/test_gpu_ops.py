@@ -596,3 +596,32 @@ def test_norm_act_pool_fused_backward_equals_composition(ops, dtype):
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     for i, nm in enumerate(('zp', 'gy', 'ggamma', 'gbeta')):
       assert rel_l2(res[0][i], res[1][i]) < tol, (use_full, nm, rel_l2(res[0][i], res[1][i]))
+
+
+def test_multi_tensor_pack_matches_single_packs():
+  """PackCache.refresh (one tg_conv2d_pack_weights_multi launch) == one tg_conv2d_pack_weights per pack."""
+  from twingan_amd.ops import PackCache
+  PackCache.clear()
+  g = torch.Generator().manual_seed(5)
+  ws = [torch.randn(3, 3, ci, co, generator=g).to(dev()) for ci, co in ((16, 32), (40, 16), (64, 64))]
+  ws.append(torch.randn(4, 4, 32, 32, generator=g).to(dev()))
+  for w in ws:
+    PackCache.register(w)
+  packs = []
+  for w in ws:
+    k = w.shape[0]
+    x = torch.randn(2, 16 if k == 3 else 4, 16 if k == 3 else 4, w.shape[2], generator=g).to(dev()).bfloat16()
+    spec = ops.ConvSpec(k, 'SAME' if k == 3 else 'VALID')
+    d = ops._desc(x.shape, w.shape[3], spec, x.dtype, 0)
+    for mode in (0, 1):
+      packs.append((w, mode, PackCache.get(w, d, mode)))
+  want = [p.clone() for _, _, p in packs]
+  with torch.no_grad():
+    for w in ws:
+      w.mul_(2.0)
+  PackCache.version += 1
+  assert PackCache.refresh(ws) == len(packs)
+  torch.cuda.synchronize()
+  for (w, mode, p), ref in zip(packs, want):
+    assert torch.equal(p.float(), (ref.float() * 2.0)), (tuple(w.shape), mode)
+  PackCache.clear()

@@ -40,6 +40,9 @@ SIGNATURES = {
     'tg_conv2d_bwd_weight': (c_int, [_D, _P, _P, _FP, c_int, _P, c_size_t, _P]),
     'tg_conv2d_pack_elems': (c_size_t, [_D, c_int]),
     'tg_conv2d_pack_weights': (c_int, [_D, _FP, c_int, _P, _P]),
+    'tg_pack_table_bytes': (c_size_t, [c_int]),
+    'tg_pack_table_fill': (c_int, [_D, _FP, c_int, _P, c_int, _P, POINTER(c_int32)]),
+    'tg_conv2d_pack_weights_multi': (c_int, [_P, c_int, c_int, _P]),
     'tg_pointwise_conv_fwd': (c_int, [_P, _FP, _FP, _P, c_int64, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     'tg_pointwise_conv_bwd_weight': (c_int, [_P, _P, _FP, c_int64, c_int, c_int, c_int, c_int, _P]),
     'tg_instance_norm_stats': (c_int, [_P, _FP, _FP, c_int, c_int, c_int, c_int, c_float, c_int, _P]),

@@ -452,6 +452,72 @@ int tg_conv2d_pack_weights(const TgConvDesc* d, const float* w, int mode, void* 
   return TG_OK;
 }
 
+// ---- multi-tensor pack: one launch for every pack of an optimiser group
+namespace {
+struct PackJob {
+  const float* w;
+  bf16* out;
+  int nt, cin, cout, rows, rows_pad, inner, inner_pad, mode;
+  int block_begin, block_end;      // this job's slice of the grid (PACK_EPB elements per block)
+};
+constexpr int PACK_EPB = 2048;
+
+__global__ __launch_bounds__(256) void pack_weights_multi(const PackJob* __restrict__ jobs, int njobs) {
+  // binary search: the job whose [block_begin, block_end) holds this block (uniform -> scalar loads)
+  int lo = 0, hi = njobs - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (b >= jobs[mid].block_end) lo = mid + 1;
+    else hi = mid;
+  }
+  const PackJob j = jobs[lo];
+  const int64_t total = (int64_t)j.rows_pad * j.nt * j.inner_pad;
+  const int64_t i0 = (int64_t)(b - j.block_begin) * PACK_EPB;
+#pragma unroll 2
+  for (int e = threadIdx.x; e < PACK_EPB; e += 256) {
+    const int64_t i = i0 + e;
+    if (i >= total) break;
+    const int k = (int)(i % j.inner_pad);
+    const int64_t r = i / j.inner_pad;
+    const int tap = (int)(r % j.nt);
+    const int row = (int)(r / j.nt);
+    float v = 0.f;
+    if (row < j.rows && k < j.inner)
+      v = j.mode == 0 ? j.w[((int64_t)tap * j.cin + k) * j.cout + row]
+                      : j.w[((int64_t)(j.nt - 1 - tap) * j.cin + row) * j.cout + k];
+    j.out[i] = (bf16)v;
+  }
+}
+}  // namespace
+
+size_t tg_pack_table_bytes(int njobs) { return (size_t)(njobs > 0 ? njobs : 0) * sizeof(PackJob); }
+
+int tg_pack_table_fill(const TgConvDesc* d, const float* w, int mode, void* out, int job, void* table_host,
+                       int32_t* total_blocks) {
+  TG_CHECK(d && w && out && table_host && total_blocks && job >= 0, TG_EINVAL, "tg_pack_table_fill: bad arguments");
+  TG_CHECK(mode == 0 || mode == 1, TG_EINVAL, "tg_pack_table_fill: mode %d", mode);
+  PackJob j;
+  j.w = w;
+  j.out = (bf16*)out;
+  j.mode = mode;
+  pack_dims(d, mode, &j.nt, &j.cin, &j.cout, &j.rows, &j.rows_pad, &j.inner, &j.inner_pad);
+  const int64_t total = (int64_t)j.rows_pad * j.nt * j.inner_pad;
+  j.block_begin = *total_blocks;
+  j.block_end = j.block_begin + (int)((total + PACK_EPB - 1) / PACK_EPB);
+  *total_blocks = j.block_end;
+  ((PackJob*)table_host)[job] = j;
+  return TG_OK;
+}
+
+int tg_conv2d_pack_weights_multi(const void* table_device, int njobs, int total_blocks, void* stream) {
+  TG_CHECK(table_device && njobs > 0 && total_blocks > 0, TG_EINVAL, "tg_conv2d_pack_weights_multi: bad arguments");
+  hipLaunchKernelGGL(pack_weights_multi, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const PackJob*)table_device, njobs);
+  TG_LAUNCH_CHECK("tg_conv2d_pack_weights_multi");
+  return TG_OK;
+}
+
 bool tg_conv_tile_supported(int h, int w, int hout, int wout, int kh, int kw, int pad_t, int pad_l);
 int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int epilogue, float alpha, const void* x,
                      const void* wp, const float* bias, void* y, hipStream_t s);

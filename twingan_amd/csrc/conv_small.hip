@@ -44,7 +44,7 @@ __device__ __forceinline__ unsigned s_pack2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, v);
 }
 
-template <int NT, int MT>      // taps (1 or 9); 32-pixel column blocks per workgroup (weight fragment reuse)
+template <int NT, int MT, int U>      // taps (1 or 9); 32-pixel column blocks per workgroup; chunks per load group
 __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                          const float* __restrict__ bias, bf16* __restrict__ y,
                                                          const SmallGeom g) {
@@ -84,25 +84,68 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict_
 
   // NOTE: a cin that is not a multiple of 16 (264) makes the last chunk read 8 channels of the next pixel;
   // the weight pack is zero there.
-  auto k_step = [&](int ck) __attribute__((always_inline)) {
-    const unsigned c2 = (unsigned)(ck * 32);          // byte offset of the chunk's first channel
-    bf16x8 wf[NT];
+  //
+  // K loop: wave w owns the chunk groups w, w+4, ... (a group = U consecutive 16-channel chunks).  The
+  // fragments of group i+1 are requested before the MFMAs of group i run (two register stages), and a
+  // scheduling barrier keeps the compiler from sinking those loads back between the MFMAs -- left alone
+  // it keeps 2-4 loads in flight and the kernel runs at one L2 latency per load.
+  struct Stage {
+    bf16x8 w[U][NT];
+    bf16x8 x[U][MT][NT];
+  };
+  const int ngroups = (g.nchunks + U - 1) / U;
+  auto load = [&](Stage& st, int grp) __attribute__((always_inline)) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) wf[t] = s_load16(rw, woff + (unsigned)(t * g.cin_pad * 2) + c2);
+    for (int u = 0; u < U; ++u) {
+      const int ck = grp * U + u;
+      const bool in = ck < g.nchunks;                 // chunks past the end read zeros
+      const unsigned c2 = (unsigned)(ck * 32);        // byte offset of the chunk's first channel
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      bf16x8 xf[NT];
+      for (int t = 0; t < NT; ++t) st.w[u][t] = s_load16(rw, in ? woff + (unsigned)(t * g.cin_pad * 2) + c2 : SOOB);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) xf[t] = s_load16(rx, xoff[m][t] + c2);
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t], xf[t], acc[m], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) st.x[u][m][t] = s_load16(rx, in ? xoff[m][t] + c2 : SOOB);
     }
   };
-  if constexpr (NT == 1) {
-#pragma unroll 8
-    for (int ck = wid; ck < g.nchunks; ck += 4) k_step(ck);     // dense layers: many chunks, 2 loads each
+  auto compute = [&](const Stage& st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st.w[u][t], st.x[u][m][t], acc[m], 0, 0, 0);
+  };
+  constexpr bool DB = (1 + MT) * NT * U <= 27;      // two stages fit the register file
+  if constexpr (DB) {
+    Stage sa, sb;
+    int grp = wid;
+    if (grp < ngroups) {
+      load(sa, grp);
+      while (true) {
+        if (grp + 4 < ngroups) load(sb, grp + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(sa);
+        __builtin_amdgcn_sched_barrier(0);
+        grp += 4;
+        if (grp >= ngroups) break;
+        if (grp + 4 < ngroups) load(sa, grp + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(sb);
+        __builtin_amdgcn_sched_barrier(0);
+        grp += 4;
+        if (grp >= ngroups) break;
+      }
+    }
   } else {
-    for (int ck = wid; ck < g.nchunks; ck += 4) k_step(ck);     // 18 loads in flight per chunk already
+    Stage sa;
+    for (int grp = wid; grp < ngroups; grp += 4) {
+      load(sa, grp);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(sa);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
   // ---- sum the 4 K-slices, one column block at a time
@@ -171,7 +214,7 @@ int tg_conv_small_run(int n, int hin, int win, int cin, int hout, int wout, int 
   dim3 grid((g.npix + 32 * mt - 1) / (32 * mt), ny);
 #define TG_SMALL_LAUNCH(NT_, MT_)                             \
   tg_note_kernel("conv_small_kernel<%d,%d>", NT_, MT_); \
-  hipLaunchKernelGGL((conv_small_kernel<NT_, MT_>), grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, g)
+  hipLaunchKernelGGL((conv_small_kernel<NT_, MT_, (NT_ == 1 ? 8 / MT_ : 1)>), grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, g)
   if (k == 1) {
     if (mt == 4) { TG_SMALL_LAUNCH(1, 4); } else if (mt == 2) { TG_SMALL_LAUNCH(1, 2); } else { TG_SMALL_LAUNCH(1, 1); }
   } else {

@@ -20,6 +20,7 @@
 // Reference call site replaced: the Conv2DBackpropFilter gradient of tf.contrib.layers.conv2d
 // (nets/pggan_utils.py:316-320).
 #include "tg_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -52,6 +53,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
+template <bool ATOMIC>
 __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gy,
                                                               float* __restrict__ slab, const WgGeom g) {
   constexpr int TW = 16, TH = 8, HWX = 18, HH = 10, NT = 9;
@@ -84,25 +86,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   const int ci_blk = pair / g.n_co_blk, co_blk = pair - ci_blk * g.n_co_blk;
   const int ci0 = ci_blk * 32, co0 = co_blk * 32;
 
-  // ---- staging slots: tile-independent LDS offsets and intra-tile pixel coordinates
-  int x_loff[XSLOTS], x_hy[XSLOTS], x_hx[XSLOTS], x_ch[XSLOTS];
+  // ---- staging slots: everything that does not depend on the tile is folded into per-slot constants, so a
+  // tile's 5 global addresses cost one add, two range compares and a select each (written branch-free: left
+  // to itself the compiler branches around every load and drains vmcnt inside the branch).
+  int x_loff[XSLOTS], x_hy1[XSLOTS], x_hx1[XSLOTS], x_rel[XSLOTS];
+  bool x_use[XSLOTS];
 #pragma unroll
   for (int s = 0; s < XSLOTS; ++s) {
     const int v = tid + s * 256;
     const int px = v >> 2, part = v & 3;
-    x_hy[s] = px / HWX;
-    x_hx[s] = px % HWX;
-    x_ch[s] = (v < XVEC && ci0 + part * 8 + 8 <= g.cin) ? (ci0 + part * 8) : -1;     // -1: zero fill
+    x_hy1[s] = px / HWX - 1;
+    x_hx1[s] = px % HWX - 1;
+    x_use[s] = v < XVEC && ci0 + part * 8 + 8 <= g.cin;                    // else zero fill
+    x_rel[s] = ((x_hy1[s] * g.w + x_hx1[s]) * g.cin + ci0 + part * 8) * 2;   // bytes from the tile's first pixel
     x_loff[s] = px * PS + part * 16;
   }
-  int g_loff[GSLOTS], g_py[GSLOTS], g_px[GSLOTS], g_ch[GSLOTS];
+  int g_loff[GSLOTS];
+  unsigned g_rel[GSLOTS];
 #pragma unroll
   for (int s = 0; s < GSLOTS; ++s) {
     const int v = tid + s * 256;
     const int px = v >> 2, part = v & 3;
-    g_py[s] = px >> 4;
-    g_px[s] = px & 15;
-    g_ch[s] = (co0 + part * 8 + 8 <= g.cout) ? (co0 + part * 8) : -1;
+    const bool use = co0 + part * 8 + 8 <= g.cout;
+    g_rel[s] = use ? (unsigned)((((px >> 4) * g.w + (px & 15)) * g.cout + co0 + part * 8) * 2) : WOOB;
     g_loff[s] = px * PS + part * 16;
   }
 
@@ -124,9 +130,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   int tile_end = tile_begin + g.tiles_per_wg;
   if (tile_end > g.total_tiles) tile_end = g.total_tiles;
 
-  bf16x8 rx[XSLOTS], rg[GSLOTS];
-  auto load_tile = [&](int tile) {
-    int t = tile;
+  // Two register stages (tiles t+1 and t+2 in flight while tile t is reduced) and two LDS buffers (one
+  // barrier per tile: tile t+1 is written to the other buffer while slower waves still read tile t).
+  // With a single stage the loads had only one tile's MFMAs (~0.4 us) to land and every tile exposed
+  // most of an HBM round trip.
+  struct Stage {
+    bf16x8 rx[XSLOTS], rg[GSLOTS];
+  };
+  auto load_tile = [&](Stage& st, int tile) __attribute__((always_inline)) {
+    const unsigned live = tile < tile_end;      // past the end: every lane out of range -> a tile of zeros
+    int t = live ? tile : tile_begin;
     const int tx = t % g.tiles_x;
     t /= g.tiles_x;
     const int ty = t % g.tiles_y;
@@ -134,50 +147,66 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
     const int ox0 = tx * TW, oy0 = ty * TH;
     const __amdgpu_buffer_rsrc_t bx = wg_rsrc(x + (size_t)img * ximg, (unsigned)(ximg * 2));
     const __amdgpu_buffer_rsrc_t bg = wg_rsrc(gy + (size_t)img * gimg, (unsigned)(gimg * 2));
+    const int xbase = (oy0 * g.w + ox0) * g.cin * 2;
+    const unsigned gbase = (unsigned)((oy0 * g.w + ox0) * g.cout * 2);
 #pragma unroll
     for (int s = 0; s < XSLOTS; ++s) {
-      const int iy = oy0 + x_hy[s] - 1, ix = ox0 + x_hx[s] - 1;
-      const bool ok = x_ch[s] >= 0 && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
-      const unsigned off = ok ? (unsigned)(((iy * g.w + ix) * g.cin + x_ch[s]) * 2) : WOOB;
-      rx[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bx, off, 0, 0));
+      const unsigned ok = live & (unsigned)x_use[s] & (unsigned)((unsigned)(oy0 + x_hy1[s]) < (unsigned)g.h) &
+                          (unsigned)((unsigned)(ox0 + x_hx1[s]) < (unsigned)g.w);
+      const unsigned off = ok ? (unsigned)(xbase + x_rel[s]) : WOOB;
+      st.rx[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bx, off, 0, 0));
     }
 #pragma unroll
-    for (int s = 0; s < GSLOTS; ++s) {
-      const unsigned off =
-          g_ch[s] >= 0 ? (unsigned)((((oy0 + g_py[s]) * g.w + ox0 + g_px[s]) * g.cout + g_ch[s]) * 2) : WOOB;
-      rg[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bg, off, 0, 0));
-    }
+    for (int s = 0; s < GSLOTS; ++s)      // g_rel = WOOB (bit 31) stays out of range after adding gbase < 2^31
+      st.rg[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bg, live ? gbase + g_rel[s] : WOOB, 0, 0));
   };
-
-  if (tile_begin < tile_end) load_tile(tile_begin);
-  for (int tile = tile_begin; tile < tile_end; ++tile) {
-    if (tile != tile_begin) __syncthreads();          // all fragment reads of the previous tile are done
+  auto stage_to_lds = [&](const Stage& st, unsigned char* bX, unsigned char* bG) __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < XSLOTS; ++s)
-      if (s < XSLOTS - 1 || tid + s * 256 < XVEC) *reinterpret_cast<bf16x8*>(sX + x_loff[s]) = rx[s];
+      if (s < XSLOTS - 1 || tid + s * 256 < XVEC) *reinterpret_cast<bf16x8*>(bX + x_loff[s]) = st.rx[s];
 #pragma unroll
-    for (int s = 0; s < GSLOTS; ++s) *reinterpret_cast<bf16x8*>(sG + g_loff[s]) = rg[s];
-    __syncthreads();
-    if (tile + 1 < tile_end) load_tile(tile + 1);     // in flight during the MFMAs
+    for (int s = 0; s < GSLOTS; ++s) *reinterpret_cast<bf16x8*>(bG + g_loff[s]) = st.rg[s];
+  };
+  auto reduce_tile = [&](const unsigned char* bX, const unsigned char* bG) __attribute__((always_inline)) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int row = wid * 2 + ks;
-      const bf16x8 gf = tr_frag(sG + (row * TW) * PS + frag_off);
+      const bf16x8 gf = tr_frag(bG + (row * TW) * PS + frag_off);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const bf16x8 xf = tr_frag(sX + ((row + ky) * HWX + kx) * PS + frag_off);
+          const bf16x8 xf = tr_frag(bX + ((row + ky) * HWX + kx) * PS + frag_off);
           acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, gf, acc[ky * 3 + kx], 0, 0, 0);
         }
       }
     }
+  };
+
+  unsigned char* sX1 = wg_smem + X_BYTES + G_BYTES;
+  unsigned char* sG1 = sX1 + X_BYTES;
+  // Two tiles per trip, no branches inside: a workgroup with an odd tile count reduces one all-zero tile.
+  Stage sa, sb;
+  load_tile(sa, tile_begin);
+  load_tile(sb, tile_begin + 1);
+  for (int tile = tile_begin; tile < tile_end; tile += 2) {
+    stage_to_lds(sa, sX, sG);
+    __syncthreads();
+    load_tile(sa, tile + 2);
+    reduce_tile(sX, sG);
+    stage_to_lds(sb, sX1, sG1);
+    __syncthreads();
+    load_tile(sb, tile + 3);
+    reduce_tile(sX1, sG1);
   }
 
   // ---- cross-wave reduction through LDS, one tap at a time; write the valid part of the slab.
   // acc[tap][r]: ci = ci0 + (r & 3) + 8*(r >> 2) + 4*(lane >> 5), co = co0 + (lane & 31)
   float* red = reinterpret_cast<float*>(wg_smem);    // [4 waves][16 regs][64 lanes] = 16 KiB
-  float* out = slab + (size_t)slice * NT * g.cin * g.cout;
+  // ATOMIC: `slab` is the gradient itself and every workgroup adds its partial sums into it (one
+  // global_atomic_add_f32 per element, 64 consecutive floats per wave instruction) -- no slab round trip
+  // through HBM and no second launch.
+  float* out = ATOMIC ? slab : slab + (size_t)slice * NT * g.cin * g.cout;
 #pragma unroll
   for (int tap = 0; tap < NT; ++tap) {
     __syncthreads();
@@ -192,7 +221,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
                         red[(3 * 16 + r) * 64 + l2];
       const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * (l2 >> 5);
       const int co = co0 + (l2 & 31);
-      if (ci < g.cin && co < g.cout) out[((size_t)tap * g.cin + ci) * g.cout + co] = sum;
+      if (ci < g.cin && co < g.cout) {
+        if (ATOMIC) atomicAdd(out + ((size_t)tap * g.cin + ci) * g.cout + co, sum);
+        else out[((size_t)tap * g.cin + ci) * g.cout + co] = sum;
+      }
     }
   }
 }
@@ -241,7 +273,13 @@ void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices) {
   g->total_tiles = g->tiles_x * g->tiles_y * n;
   const int n_ci = (cin + 31) / 32;
   g->n_co_blk = (cout + 31) / 32;
-  int want = 512 / (n_ci * g->n_co_blk);      // ~2 workgroups per CU in total
+  // ~2 workgroups per CU in total; 1 per CU when that leaves a workgroup fewer than 8 tiles: every workgroup
+  // costs one slab write + read (9*32*32 floats), which then outweighs its share of the input traffic
+  // (kbench, 128x128x32 n16: 24.2 -> 20.6 us; 256x256x16 n48 prefers 512: 70 vs 85 us).
+  const int pairs = n_ci * g->n_co_blk;
+  int want = 512 / pairs;
+  if (want < 1) want = 1;
+  if ((g->total_tiles + want - 1) / want < 8) want = 256 / pairs;
   if (want < 1) want = 1;
   if (want > g->total_tiles) want = g->total_tiles;
   g->tiles_per_wg = (g->total_tiles + want - 1) / want;
@@ -274,9 +312,20 @@ int tg_wgrad_tile_run(int n, int h, int w, int cin, int cout, const void* x, con
   TG_CHECK(ws && ws_bytes >= (size_t)nslices * nw * sizeof(float), TG_EINVAL,
            "tg_conv2d_bwd_weight(tile): workspace too small (%zu < %zu)", ws_bytes, (size_t)nslices * nw * sizeof(float));
   const int n_ci = (cin + 31) / 32;
-  const size_t lds = 10 * 18 * 64 + 8 * 16 * 64;      // 19712 >= the 16 KiB reduction scratch
+  const size_t lds = 2 * (10 * 18 * 64 + 8 * 16 * 64);      // two tile buffers of 19712 B; the first doubles as the 16 KiB reduction scratch
   tg_note_kernel("conv_wgrad_tile_kernel");
-  hipLaunchKernelGGL(conv_wgrad_tile_kernel, dim3(nslices * n_ci * g.n_co_blk), dim3(256), lds, s, (const bf16*)x,
+  static const int atomic_mode = getenv("TG_WGRAD_ATOMIC") ? atoi(getenv("TG_WGRAD_ATOMIC")) : 0;
+  if (atomic_mode) {
+    if (!accumulate) {
+      int rc = tg_zero_async(gw, (size_t)nw * sizeof(float), nullptr, 0, s);
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL(conv_wgrad_tile_kernel<true>, dim3(nslices * n_ci * g.n_co_blk), dim3(256), lds, s, (const bf16*)x,
+                       (const bf16*)gy, gw, g);
+    TG_LAUNCH_CHECK("conv_wgrad_tile");
+    return TG_OK;
+  }
+  hipLaunchKernelGGL(conv_wgrad_tile_kernel<false>, dim3(nslices * n_ci * g.n_co_blk), dim3(256), lds, s, (const bf16*)x,
                      (const bf16*)gy, (float*)ws, g);
   TG_LAUNCH_CHECK("conv_wgrad_tile");
   return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);

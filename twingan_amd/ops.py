@@ -67,6 +67,7 @@ class PackCache:
   def clear(cls):
     cls._registered.clear()
     cls._packs.clear()
+    cls._tables.clear()
 
   @classmethod
   def _pack(cls, w, desc, mode, buf):
@@ -88,17 +89,33 @@ class PackCache:
       cls._packs[key] = [cls.version, buf, dcopy]
     return buf
 
+  _tables = {}         # (weight ptrs, pack keys) -> (device job table, njobs, total blocks)
+
   @classmethod
   def refresh(cls, weights):
-    """Re-packs (in place) every existing pack of ``weights`` and marks it current."""
+    """Re-packs (in place) every existing pack of ``weights`` in ONE launch (tg_conv2d_pack_weights_multi) and
+    marks them current.  The job table is built (and copied to the device) the first time a given set of packs is
+    refreshed -- in the trainer that happens during the eager warm-up runs, before any graph capture."""
     ptrs = {w.data_ptr() for w in weights}
-    n = 0
-    for (ptr, mode, _), ent in cls._packs.items():
-      if ptr in ptrs:
-        cls._pack(cls._registered[ptr], ent[2], mode, ent[1])
-        ent[0] = cls.version
-        n += 1
-    return n
+    keys = tuple(k for k in cls._packs if k[0] in ptrs)
+    if not keys:
+      return 0
+    tkey = (tuple(sorted(ptrs)), keys)
+    tab = cls._tables.get(tkey)
+    if tab is None:
+      lib = _lib.load()
+      host = ctypes.create_string_buffer(lib.tg_pack_table_bytes(len(keys)))
+      blocks = ctypes.c_int32(0)
+      for j, k in enumerate(keys):
+        ent = cls._packs[k]
+        call('tg_pack_table_fill', ctypes.byref(ent[2]), _p(cls._registered[k[0]]), k[1], _p(ent[1]), j,
+             ctypes.addressof(host), ctypes.byref(blocks))
+      dev = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(cls._packs[keys[0]][1].device)
+      tab = cls._tables[tkey] = (dev, len(keys), blocks.value)
+    call('tg_conv2d_pack_weights_multi', _p(tab[0]), tab[1], tab[2], _stream())
+    for k in keys:
+      cls._packs[k][0] = cls.version
+    return len(keys)
 
 
 class GradSink:
@@ -166,6 +183,10 @@ def _mfma_ok(dtype, cin, cout, spec, hin, win):
 
 def _esize(t):
   return 2 if t.dtype == torch.bfloat16 else 4
+
+
+def _shape_tag(t):
+  return ':c%d:hw%d:n%d' % (t.shape[-1], t.shape[-2], t.shape[0]) if t.dim() == 4 else ':numel%d' % t.numel()
 
 
 def _conv_work(d, tag, es):
@@ -259,14 +280,15 @@ def lrelu_pool_bwd(gz, gzp, z, alpha, bias, want_bias):
   if want_bias:
     gb = sink if sink is not None else torch.empty(c, dtype=torch.float32, device=z.device)
   call('tg_lrelu_pool_bwd', _p(gz), _p(gzp), _p(z), _p(g), _p(gb), n, h, w, c, alpha, 1 if sink is not None else 0,
-       _dt(z), _stream(), work=('lrelu_pool_bwd', 0, int((2 + (gz is not None) + 0.25 * (gzp is not None)) * z.numel()) * _esize(z)))
+       _dt(z), _stream(), work=('lrelu_pool_bwd' + _shape_tag(z), 0, int((2 + (gz is not None) + 0.25 * (gzp is not None)) * z.numel()) * _esize(z)))
   return g, (None if sink is not None else gb)
 
 
 def lrelu_bwd_raw(g, z, alpha):
   _chk(g, z)
   out = torch.empty_like(g)
-  call('tg_lrelu_bwd', _p(g), _p(z), _p(out), g.numel(), alpha, _dt(g), _stream())
+  call('tg_lrelu_bwd', _p(g), _p(z), _p(out), g.numel(), alpha, _dt(g), _stream(),
+       work=('lrelu_bwd' + _shape_tag(z), 0, 3 * z.numel() * _esize(z)))
   return out
 
 
@@ -362,7 +384,8 @@ class Conv2dPoolFn(torch.autograd.Function):
     z = conv_fwd_raw(x, w, bias, spec, epilogue)
     n, h, ww, c = z.shape
     zp = torch.empty((n, h // 2, ww // 2, c), dtype=z.dtype, device=z.device)
-    call('tg_pool2x2_fwd', _p(z), _p(zp), n, h, ww, c, 0.25, _dt(z), _stream())
+    call('tg_pool2x2_fwd', _p(z), _p(zp), n, h, ww, c, 0.25, _dt(z), _stream(),
+         work=('pool_fwd' + _shape_tag(z), 0, int(1.25 * z.numel()) * _esize(z)))
     ctx.spec, ctx.epilogue = spec, epilogue
     ctx.out_hw = (h, ww)
     ctx.set_materialize_grads(False)
@@ -549,13 +572,13 @@ def _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, 
   mean = torch.empty(n * c, dtype=torch.float32, device=y.device)
   rstd = torch.empty(n * c, dtype=torch.float32, device=y.device)
   call('tg_instance_norm_stats', _p(y), _p(mean), _p(rstd), n, h, w, c, in_eps, _dt(y), _stream(),
-       work=('in_stats', 0, y.numel() * _esize(y)))
+       work=('in_stats' + _shape_tag(y), 0, y.numel() * _esize(y)))
   if ema is not None:
     _ema_update(mean, rstd, n, c, split, in_eps, ema)
   z = torch.empty_like(y)
   s = torch.empty(n * h * w, dtype=torch.float32, device=y.device) if (flags & NF_PIXNORM) else None
   call('tg_norm_act_fwd', _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(gamma2), _p(beta2), split, _p(z), _p(s),
-       n, h, w, c, flags, alpha, pn_eps, _dt(y), _stream(), work=('norm_act_fwd', 0, 2 * y.numel() * _esize(y)))
+       n, h, w, c, flags, alpha, pn_eps, _dt(y), _stream(), work=('norm_act_fwd' + _shape_tag(y), 0, 2 * y.numel() * _esize(y)))
   ctx.flags, ctx.alpha, ctx.split = flags, alpha, split
   ctx.save_for_backward(y, mean, rstd, gamma, beta, gamma2, beta2, s)
   return z
@@ -582,7 +605,7 @@ def _norm_act_backward(ctx, gz, gzp=None):
   call('tg_norm_act_bwd', _p(gz), _p(gzp), _p(y), _p(s), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(gamma2), _p(beta2),
        ctx.split, _p(gy), _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), _p(sums), n, h, w, c, ctx.flags, ctx.alpha,
        1 if (sunk and not _State.skip_param_grads) else 0, _dt(y), _stream(),
-       work=('norm_act_bwd', 0, int(passes * y.numel()) * _esize(y)))
+       work=('norm_act_bwd' + _shape_tag(y), 0, int(passes * y.numel()) * _esize(y)))
   if sunk or _State.skip_param_grads:
     outs = [None] * 4
   return gy, outs[0], outs[1], outs[2], outs[3], None, None, None, None, None
@@ -613,7 +636,8 @@ class NormActPoolFn(torch.autograd.Function):
     z = _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema)
     n, h, w, c = z.shape
     zp = torch.empty((n, h // 2, w // 2, c), dtype=z.dtype, device=z.device)
-    call('tg_pool2x2_fwd', _p(z), _p(zp), n, h, w, c, 0.25, _dt(z), _stream())
+    call('tg_pool2x2_fwd', _p(z), _p(zp), n, h, w, c, 0.25, _dt(z), _stream(),
+         work=('pool_fwd' + _shape_tag(z), 0, int(1.25 * z.numel()) * _esize(z)))
     ctx.set_materialize_grads(False)
     return z, zp
 
@@ -659,7 +683,8 @@ class UpsampleConcatFn(torch.autograd.Function):
       assert x1 is not None and n % gsz == 0 and len(perm) == n // gsz and x1.shape[0] == (max(perm) + 1) * gsz
     out = torch.empty((n, 2 * h, 2 * w, c0 + c1), dtype=x0.dtype, device=x0.device)
     pk = _pack_perm(perm) if gsz else 0
-    call('tg_upsample2x_concat_fwd', _p(x0), _p(x1), _p(out), n, h, w, c0, c1, gsz, pk, _dt(x0), _stream())
+    call('tg_upsample2x_concat_fwd', _p(x0), _p(x1), _p(out), n, h, w, c0, c1, gsz, pk, _dt(x0), _stream(),
+         work=('upcat_fwd' + _shape_tag(out), 0, (x0.numel() + (x1.numel() if x1 is not None else 0) + out.numel()) * _esize(out)))
     ctx.dims = (n, h, w, c0, c1, gsz, pk, 0 if x1 is None else x1.shape[0])
     return out
 
@@ -671,7 +696,8 @@ class UpsampleConcatFn(torch.autograd.Function):
     g0 = torch.empty((n, h, w, c0), dtype=go.dtype, device=go.device) if ctx.needs_input_grad[0] else None
     g1 = torch.empty((n1, 2 * h, 2 * w, c1), dtype=go.dtype, device=go.device) \
         if (c1 and ctx.needs_input_grad[1]) else None
-    call('tg_upsample2x_concat_bwd', _p(go), _p(g0), _p(g1), n, h, w, c0, c1, gsz, pk, _dt(go), _stream())
+    call('tg_upsample2x_concat_bwd', _p(go), _p(g0), _p(g1), n, h, w, c0, c1, gsz, pk, _dt(go), _stream(),
+         work=('upcat_bwd' + _shape_tag(go), 0, (go.numel() + g0.numel() + (g1.numel() if g1 is not None else 0)) * _esize(go)))
     return g0, g1, None, None
 
 
