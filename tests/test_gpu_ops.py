@@ -598,7 +598,7 @@ def test_norm_act_pool_fused_backward_equals_composition(ops, dtype):
       assert rel_l2(res[0][i], res[1][i]) < tol, (use_full, nm, rel_l2(res[0][i], res[1][i]))
 
 
-def test_multi_tensor_pack_matches_single_packs():
+def test_multi_tensor_pack_matches_single_packs(ops):
   """PackCache.refresh (one tg_conv2d_pack_weights_multi launch) == one tg_conv2d_pack_weights per pack."""
   from twingan_amd.ops import PackCache
   PackCache.clear()

@@ -46,6 +46,10 @@ SIGNATURES = {
     'tg_pointwise_conv_fwd': (c_int, [_P, _FP, _FP, _P, c_int64, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     'tg_pointwise_conv_bwd_weight': (c_int, [_P, _P, _FP, c_int64, c_int, c_int, c_int, c_int, _P]),
     'tg_instance_norm_stats': (c_int, [_P, _FP, _FP, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    'tg_norm_chunks': (c_int, [c_int, c_int, c_int]),
+    'tg_instance_norm_partials': (c_int, [_P, _FP, c_int, c_int, c_int, c_int, c_int, _P]),
+    'tg_norm_act_fwd_partials': (c_int, [_P, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, _P, _FP, c_int, c_int, c_int, c_int,
+                                         c_int, c_float, c_float, c_float, c_int, _P]),
     'tg_norm_act_fwd': (c_int, [_P, _FP, _FP, _FP, _FP, _FP, _FP, c_int, _P, _FP, c_int, c_int, c_int, c_int, c_int,
                                 c_float, c_float, c_int, _P]),
     'tg_norm_act_bwd': (c_int, [_P, _P, _P, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, _P, _FP, _FP, _FP, _FP, _FP, c_int,

@@ -98,7 +98,8 @@ __device__ __forceinline__ void wave_channel_accumulate(float (&a)[V], float* sh
 // accumulated into mean[] / rstd[] (pre-zeroed), finalised in place.
 // grid = (chunks, n).  block = 256 threads = (256/cv pixel lanes) x (cv vectors)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int V>
+// PART: write this block's sums to part[n][chunk][2][c] (s1 = part) instead of atomically adding into s1 / s2
+template <typename T, int V, bool PART = false>
 __global__ void in_stats_partial(const T* __restrict__ y, float* __restrict__ s1, float* __restrict__ s2, int hw, int c,
                                  int px_per_block) {
   extern __shared__ float sh[];   // [2][c]
@@ -130,10 +131,31 @@ __global__ void in_stats_partial(const T* __restrict__ y, float* __restrict__ s1
   wave_channel_accumulate<V>(a1, sh, 0, cv, v, pl < lanes);
   wave_channel_accumulate<V>(a2, sh, c, cv, v, pl < lanes);
   __syncthreads();
+  if (PART) {
+    float* out = s1 + ((int64_t)n * gridDim.x + blockIdx.x) * 2 * c;
+    for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) out[i] = sh[i];
+    return;
+  }
   for (int i = threadIdx.x; i < c; i += blockDim.x) {
     atomicAdd(s1 + (int64_t)n * c + i, sh[i]);
     atomicAdd(s2 + (int64_t)n * c + i, sh[c + i]);
   }
+}
+
+// sh[0..2c) = sum over the chunks of part[n][chunk][0..2c)  (every thread of the block; ends with a barrier)
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int n, int chunks, int c, float* sh) {
+  for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) {
+    const float* p = part + (int64_t)n * chunks * 2 * c + i;
+    float a = 0.f, b = 0.f;
+    int k = 0;
+    for (; k + 1 < chunks; k += 2) {
+      a += p[(int64_t)k * 2 * c];
+      b += p[(int64_t)(k + 1) * 2 * c];
+    }
+    if (k < chunks) a += p[(int64_t)k * 2 * c];
+    sh[i] = a + b;
+  }
+  __syncthreads();
 }
 
 template <typename T>
@@ -191,6 +213,79 @@ __global__ void norm_act_fwd_kernel(const T* __restrict__ y, const float* __rest
       if (pn_scale && v == 0) pn_scale[p] = s;
     }
     VecIO<T, V>::store(z + p * c + v * V, x);
+  }
+}
+
+// Same forward with the statistics finalised in the prologue from the partial sums of in_stats_partial<PART>
+// (no separate finalise launch, no zero fill, no atomics).  grid = (chunks2, n): a block stays inside one image.
+// Block (0, n) also writes mean / rstd of its image for the backward and the moving averages.
+template <typename T, int V>
+__global__ void norm_act_fwd_part_kernel(const T* __restrict__ y, const float* __restrict__ part, int chunks,
+                                         float* __restrict__ mean, float* __restrict__ rstd,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         const float* __restrict__ gamma2, const float* __restrict__ beta2, int split,
+                                         T* __restrict__ z, float* __restrict__ pn_scale, int hw, int c, int flags,
+                                         float alpha, float in_eps, float pn_eps, int px_per_block) {
+  extern __shared__ float sh[];   // [2][c]: sums, then (scale, shift)
+  const int cv = c / V;
+  const int lanes = blockDim.x / cv;
+  const int v = threadIdx.x % cv, pl = threadIdx.x / cv;
+  const int n = blockIdx.y;
+  reduce_partials(part, n, chunks, c, sh);
+  const float* ga = n < split ? gamma : gamma2;
+  const float* be = n < split ? beta : beta2;
+  const float inv = 1.f / (float)hw;
+  float m_[8], r_[8];      // c <= 2048: at most 8 channels per thread
+  int cnt = 0;
+  for (int i = threadIdx.x; i < c; i += blockDim.x, ++cnt) {
+    const float k = ld(y + (int64_t)n * hw * c + i);
+    const float m1 = sh[i] * inv, m2 = sh[c + i] * inv;
+    float var = m2 - m1 * m1;
+    var = var < 0.f ? 0.f : var;
+    m_[cnt] = k + m1;
+    r_[cnt] = rsqrtf(var + in_eps);
+  }
+  __syncthreads();
+  cnt = 0;
+  for (int i = threadIdx.x; i < c; i += blockDim.x, ++cnt) {
+    if (blockIdx.x == 0) {
+      mean[n * c + i] = m_[cnt];
+      rstd[n * c + i] = r_[cnt];
+    }
+    const float r = r_[cnt] * ga[i];
+    sh[i] = r;                                  // u = y * scale + shift (tf.nn.batch_normalization form)
+    sh[c + i] = be[i] - m_[cnt] * r;
+  }
+  __syncthreads();
+  float sc[V], sf[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    sc[j] = sh[v * V + j];
+    sf[j] = sh[c + v * V + j];
+  }
+  const int p0 = blockIdx.x * px_per_block;
+  const int p1 = min(p0 + px_per_block, hw);
+  if (pl >= lanes) return;
+  for (int p = p0 + pl; p < p1; p += lanes) {      // pl is uniform within a pixel group: groups stay converged
+    const int64_t gp = (int64_t)n * hw + p;
+    float x[V];
+    VecIO<T, V>::load(y + gp * c + v * V, x);
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float u = x[j] * sc[j] + sf[j];
+      if (flags & NF_LRELU) u = lrelu_f(u, alpha);
+      x[j] = u;
+      ss = fmaf(u, u, ss);
+    }
+    if (flags & NF_PIXNORM) {
+      ss = group_sum(ss, cv);
+      const float q = rsqrtf(ss / (float)c + pn_eps);
+#pragma unroll
+      for (int j = 0; j < V; ++j) x[j] *= q;
+      if (pn_scale && v == 0) pn_scale[gp] = q;
+    }
+    VecIO<T, V>::store(z + gp * c + v * V, x);
   }
 }
 
@@ -260,53 +355,75 @@ __global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restri
   wave_channel_accumulate<V>(a1, sh, 0, cv, v, pl < lanes);
   wave_channel_accumulate<V>(a2, sh, c, cv, v, pl < lanes);
   __syncthreads();
-  for (int i = threadIdx.x; i < c; i += blockDim.x) {
-    atomicAdd(sums + ((int64_t)n * c + i) * 2 + 0, sh[i]);
-    atomicAdd(sums + ((int64_t)n * c + i) * 2 + 1, sh[c + i]);
-  }
+  // this block's partial sums: sums[n][chunk][0..c) = S1, [c..2c) = S2 (no zero fill, no atomics)
+  float* out = sums + ((int64_t)n * gridDim.x + blockIdx.x) * 2 * c;
+  for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) out[i] = sh[i];
 }
 
-// backward pass 2: gy = gamma*rstd * (gu - S1/hw - yhat * S2/hw)   (in place over gu)
+// backward pass 2: gy = gamma*rstd * (gu - S1/hw - yhat * S2/hw)   (in place over gu).  grid = (chunks2, n); the
+// prologue sums the image's partial S1 / S2; with `sink` block (0, n) adds them into the parameter gradients.
 template <typename T, int V>
-__global__ void norm_act_bwd2_kernel(T* __restrict__ gy, const T* __restrict__ y, const float* __restrict__ mean,
-                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                     const float* __restrict__ gamma2, int split, const float* __restrict__ sums,
-                                     int64_t npix, int hw, int c) {
+__global__ void norm_act_bwd2_part_kernel(T* __restrict__ gy, const T* __restrict__ y, const float* __restrict__ mean,
+                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                          const float* __restrict__ gamma2, int split, const float* __restrict__ part,
+                                          int chunks, float* __restrict__ ggamma, float* __restrict__ gbeta,
+                                          float* __restrict__ ggamma2, float* __restrict__ gbeta2, int sink, int hw,
+                                          int c, int px_per_block) {
+  extern __shared__ float sh[];   // [2][c]
   const int cv = c / V;
-  const int64_t total = npix * cv;
+  const int lanes = blockDim.x / cv;
+  const int v = threadIdx.x % cv, pl = threadIdx.x / cv;
+  const int n = blockIdx.y;
+  reduce_partials(part, n, chunks, c, sh);
+  if (sink && blockIdx.x == 0) {
+    float* gg = n < split ? ggamma : ggamma2;
+    float* gb = n < split ? gbeta : gbeta2;
+    for (int i = threadIdx.x; i < c; i += blockDim.x) {
+      if (gb) atomicAdd(gb + i, sh[i]);
+      if (gg) atomicAdd(gg + i, sh[c + i]);
+    }
+  }
   const float inv = 1.f / (float)hw;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int v = (int)(i % cv);
-    const int64_t p = i / cv;
-    const int n = (int)(p / hw);
+  float mu[V], rs[V], gr[V], s1[V], s2[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int ch = v * V + j;
+    mu[j] = mean[n * c + ch];
+    rs[j] = rstd[n * c + ch];
+    gr[j] = (n < split ? gamma : gamma2)[ch] * rs[j];
+    s1[j] = sh[ch] * inv;
+    s2[j] = sh[c + ch] * inv;
+  }
+  const int p0 = blockIdx.x * px_per_block;
+  const int p1 = min(p0 + px_per_block, hw);
+  if (pl >= lanes) return;
+  for (int p = p0 + pl; p < p1; p += lanes) {
+    const int64_t gp = (int64_t)n * hw + p;
     float g[V], x[V];
-    VecIO<T, V>::load(gy + p * c + v * V, g);
-    VecIO<T, V>::load(y + p * c + v * V, x);
+    VecIO<T, V>::load(gy + gp * c + v * V, g);
+    VecIO<T, V>::load(y + gp * c + v * V, x);
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      const int ch = v * V + j;
-      const float r = rstd[n * c + ch];
-      const float yh = (x[j] - mean[n * c + ch]) * r;
-      const float s1 = sums[((int64_t)n * c + ch) * 2] * inv, s2 = sums[((int64_t)n * c + ch) * 2 + 1] * inv;
-      g[j] = (n < split ? gamma : gamma2)[ch] * r * (g[j] - s1 - yh * s2);
+      const float yh = (x[j] - mu[j]) * rs[j];
+      g[j] = gr[j] * (g[j] - s1[j] - yh * s2[j]);
     }
-    VecIO<T, V>::store(gy + p * c + v * V, g);
+    VecIO<T, V>::store(gy + gp * c + v * V, g);
   }
 }
 
 // images [i0, i1) -> (ggamma, gbeta); blockIdx.y selects the domain half
-__global__ void norm_param_grads(const float* __restrict__ sums, float* __restrict__ ggamma, float* __restrict__ gbeta,
-                                 float* __restrict__ ggamma2, float* __restrict__ gbeta2, int split, int n, int c,
-                                 int accumulate) {
+__global__ void norm_param_grads(const float* __restrict__ part, int chunks, float* __restrict__ ggamma,
+                                 float* __restrict__ gbeta, float* __restrict__ ggamma2, float* __restrict__ gbeta2,
+                                 int split, int n, int c, int accumulate) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
   const int i0 = blockIdx.y ? split : 0, i1 = blockIdx.y ? n : split;
   float* gg = blockIdx.y ? ggamma2 : ggamma;
   float* gb = blockIdx.y ? gbeta2 : gbeta;
   float sb = 0.f, sg = 0.f;
-  for (int i = i0; i < i1; ++i) {
-    sb += sums[((int64_t)i * c + ch) * 2];
-    sg += sums[((int64_t)i * c + ch) * 2 + 1];
+  for (int64_t k = (int64_t)i0 * chunks; k < (int64_t)i1 * chunks; ++k) {      // part[n][chunk][2][c]
+    sb += part[k * 2 * c + ch];
+    sg += part[k * 2 * c + c + ch];
   }
   if (gg) {
     if (accumulate) atomicAdd(gg + ch, sg);
@@ -392,7 +509,84 @@ int pick_v(int c) {
 
 }  // namespace
 
+// pixel range of one statistics / reduction block: ~1024 blocks in total, at least 64 pixels each
+static void norm_chunks(int n, int hw, int* chunks, int* ppb) {
+  int ch = (1024 + n - 1) / n;
+  int pp = (hw + ch - 1) / ch;
+  if (pp < 64) pp = 64;
+  *ppb = pp;
+  *chunks = (hw + pp - 1) / pp;
+}
+
 extern "C" {
+
+int tg_norm_chunks(int n, int h, int w) {
+  int chunks, ppb;
+  if (n <= 0 || h <= 0 || w <= 0) return 0;
+  norm_chunks(n, h * w, &chunks, &ppb);
+  return chunks;
+}
+
+int tg_instance_norm_partials(const void* y, float* partials, int n, int h, int w, int c, int dtype, void* stream) {
+  TG_CHECK(y && partials && n > 0 && h > 0 && w > 0 && c > 0, TG_EINVAL, "tg_instance_norm_partials: bad arguments");
+  TG_CHECK(c <= 256 * 8, TG_ENOSUP, "tg_instance_norm_partials: c=%d too large", c);
+  hipStream_t s = (hipStream_t)stream;
+  const int hw = h * w;
+  int chunks, ppb;
+  norm_chunks(n, hw, &chunks, &ppb);
+  TG_DISPATCH_DTYPE(dtype, "tg_instance_norm_partials", {
+    const int V = pick_v<T>(c);
+    TG_CHECK(c / V <= 256, TG_ENOSUP, "tg_instance_norm_partials: c=%d not supported", c);
+    const size_t lds = 2 * (size_t)c * sizeof(float);
+    if (V == 1)
+      hipLaunchKernelGGL((in_stats_partial<T, 1, true>), dim3(chunks, n), dim3(256), lds, s, (const T*)y, partials, nullptr,
+                         hw, c, ppb);
+    else
+      hipLaunchKernelGGL((in_stats_partial<T, Vec16<T>::N, true>), dim3(chunks, n), dim3(256), lds, s, (const T*)y,
+                         partials, nullptr, hw, c, ppb);
+  });
+  TG_LAUNCH_CHECK("tg_instance_norm_partials");
+  return TG_OK;
+}
+
+int tg_norm_act_fwd_partials(const void* y, const float* partials, float* mean, float* rstd, const float* gamma,
+                             const float* beta, const float* gamma2, const float* beta2, int split, void* z,
+                             float* pn_scale, int n, int h, int w, int c, int flags, float alpha, float in_eps,
+                             float pn_eps, int dtype, void* stream) {
+  TG_CHECK(y && partials && mean && rstd && gamma && beta && z && n > 0 && h > 0 && w > 0 && c > 0, TG_EINVAL,
+           "tg_norm_act_fwd_partials: bad arguments");
+  TG_CHECK(c <= 256 * 8, TG_ENOSUP, "tg_norm_act_fwd_partials: c=%d too large", c);
+  if (!gamma2 || !beta2) split = n;
+  TG_CHECK(split >= 0 && split <= n, TG_EINVAL, "tg_norm_act_fwd_partials: split %d outside [0, %d]", split, n);
+  const int hw = h * w;
+  int chunks, ppb_s;
+  norm_chunks(n, hw, &chunks, &ppb_s);
+  int chunks2 = (2048 + n - 1) / n;                    // ~2048 blocks for the streaming pass
+  int ppb = (hw + chunks2 - 1) / chunks2;
+  if (ppb < 64) ppb = 64;
+  chunks2 = (hw + ppb - 1) / ppb;
+  const size_t lds = 2 * (size_t)c * sizeof(float);
+  TG_DISPATCH_DTYPE(dtype, "tg_norm_act_fwd_partials", {
+    constexpr int VN = Vec16<T>::N;
+    const bool vec = (c % VN == 0) && pow2(c / VN) && c / VN <= 64;
+    if (flags & NF_PIXNORM) {
+      TG_CHECK(vec, TG_ENOSUP, "tg_norm_act_fwd_partials: pixel norm needs c (%d) = %d * 2^k <= %d", c, VN, 64 * VN);
+      TG_CHECK(pn_scale, TG_EINVAL, "tg_norm_act_fwd_partials: pixel norm needs pn_scale");
+    }
+    if (vec) {
+      hipLaunchKernelGGL((norm_act_fwd_part_kernel<T, VN>), dim3(chunks2, n), dim3(256), lds, (hipStream_t)stream,
+                         (const T*)y, partials, chunks, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)z, pn_scale, hw,
+                         c, flags, alpha, in_eps, pn_eps, ppb);
+    } else {
+      TG_CHECK(c <= 256, TG_ENOSUP, "tg_norm_act_fwd_partials: scalar path needs c <= 256 (got %d)", c);
+      hipLaunchKernelGGL((norm_act_fwd_part_kernel<T, 1>), dim3(chunks2, n), dim3(256), lds, (hipStream_t)stream,
+                         (const T*)y, partials, chunks, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)z, pn_scale, hw,
+                         c, flags, alpha, in_eps, pn_eps, ppb);
+    }
+  });
+  TG_LAUNCH_CHECK("tg_norm_act_fwd_partials");
+  return TG_OK;
+}
 
 int tg_instance_norm_stats(const void* y, float* mean, float* rstd, int n, int h, int w, int c, float eps, int dtype,
                            void* stream) {
@@ -467,37 +661,37 @@ int tg_norm_act_bwd(const void* gz, const void* gz_pooled, const void* y, const 
   hipStream_t s = (hipStream_t)stream;
   const int hw = h * w;
   const int64_t npix = (int64_t)n * hw;
-  {
-    int rc = tg_zero_async(sums, (size_t)n * c * 2 * sizeof(float), nullptr, 0, s);
-    if (rc) return rc;
-  }
-  int chunks = (1024 + n - 1) / n;
-  int ppb = (hw + chunks - 1) / chunks;
-  if (ppb < 64) ppb = 64;
-  chunks = (hw + ppb - 1) / ppb;
+  int chunks, ppb;
+  norm_chunks(n, hw, &chunks, &ppb);
+  int chunks2 = (2048 + n - 1) / n;
+  int ppb2 = (hw + chunks2 - 1) / chunks2;
+  if (ppb2 < 64) ppb2 = 64;
+  chunks2 = (hw + ppb2 - 1) / ppb2;
+  const bool want_params = ggamma || gbeta || ggamma2 || gbeta2;
+  const int sink = (want_params && accumulate) ? 1 : 0;      // block (0, n) of pass 2 adds the image's sums
+  const size_t lds = 2 * (size_t)c * sizeof(float);
   TG_DISPATCH_DTYPE(dtype, "tg_norm_act_bwd", {
     constexpr int VN = Vec16<T>::N;
     const bool vec = (c % VN == 0) && pow2(c / VN) && c / VN <= 64;
-    const size_t lds = 2 * (size_t)c * sizeof(float);
     if (flags & NF_PIXNORM) {
       TG_CHECK(vec && pn_scale, TG_ENOSUP, "tg_norm_act_bwd: pixel norm needs c (%d) = %d * 2^k and pn_scale", c, VN);
     }
     if (vec) {
       hipLaunchKernelGGL((norm_act_bwd1_kernel<T, VN>), dim3(chunks, n), dim3(256), lds, s, (const T*)gz,
                          (const T*)gz_pooled, w, (const T*)y, pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)gy, sums, hw, c, flags, alpha, ppb);
-      hipLaunchKernelGGL((norm_act_bwd2_kernel<T, VN>), dim3(tg_grid_for(npix * (c / VN), 256)), dim3(256), 0, s, (T*)gy,
-                         (const T*)y, mean, rstd, gamma, gamma2, split, sums, npix, hw, c);
+      hipLaunchKernelGGL((norm_act_bwd2_part_kernel<T, VN>), dim3(chunks2, n), dim3(256), lds, s, (T*)gy, (const T*)y, mean,
+                         rstd, gamma, gamma2, split, sums, chunks, ggamma, gbeta, ggamma2, gbeta2, sink, hw, c, ppb2);
     } else {
       TG_CHECK(c <= 256, TG_ENOSUP, "tg_norm_act_bwd: scalar path needs c <= 256 (got %d)", c);
       hipLaunchKernelGGL((norm_act_bwd1_kernel<T, 1>), dim3(chunks, n), dim3(256), lds, s, (const T*)gz,
                          (const T*)gz_pooled, w, (const T*)y, pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)gy, sums, hw, c, flags, alpha, ppb);
-      hipLaunchKernelGGL((norm_act_bwd2_kernel<T, 1>), dim3(tg_grid_for(npix * c, 256)), dim3(256), 0, s, (T*)gy,
-                         (const T*)y, mean, rstd, gamma, gamma2, split, sums, npix, hw, c);
+      hipLaunchKernelGGL((norm_act_bwd2_part_kernel<T, 1>), dim3(chunks2, n), dim3(256), lds, s, (T*)gy, (const T*)y, mean,
+                         rstd, gamma, gamma2, split, sums, chunks, ggamma, gbeta, ggamma2, gbeta2, sink, hw, c, ppb2);
     }
   });
-  if (ggamma || gbeta || ggamma2 || gbeta2)
-    hipLaunchKernelGGL(norm_param_grads, dim3((c + 255) / 256, split < n ? 2 : 1), dim3(256), 0, s, sums, ggamma, gbeta,
-                       ggamma2, gbeta2, split, n, c, accumulate);
+  if (want_params && !sink)
+    hipLaunchKernelGGL(norm_param_grads, dim3((c + 255) / 256, split < n ? 2 : 1), dim3(256), 0, s, sums, chunks, ggamma,
+                       gbeta, ggamma2, gbeta2, split, n, c, 0);
   TG_LAUNCH_CHECK("tg_norm_act_bwd");
   return TG_OK;
 }

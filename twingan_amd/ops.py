@@ -571,14 +571,17 @@ def _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, 
   split = n if gamma2 is None else int(split)
   mean = torch.empty(n * c, dtype=torch.float32, device=y.device)
   rstd = torch.empty(n * c, dtype=torch.float32, device=y.device)
-  call('tg_instance_norm_stats', _p(y), _p(mean), _p(rstd), n, h, w, c, in_eps, _dt(y), _stream(),
+  chunks = _lib.load().tg_norm_chunks(n, h, w)
+  part = torch.empty(n * chunks * 2 * c, dtype=torch.float32, device=y.device)
+  call('tg_instance_norm_partials', _p(y), _p(part), n, h, w, c, _dt(y), _stream(),
        work=('in_stats' + _shape_tag(y), 0, y.numel() * _esize(y)))
-  if ema is not None:
-    _ema_update(mean, rstd, n, c, split, in_eps, ema)
   z = torch.empty_like(y)
   s = torch.empty(n * h * w, dtype=torch.float32, device=y.device) if (flags & NF_PIXNORM) else None
-  call('tg_norm_act_fwd', _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(gamma2), _p(beta2), split, _p(z), _p(s),
-       n, h, w, c, flags, alpha, pn_eps, _dt(y), _stream(), work=('norm_act_fwd' + _shape_tag(y), 0, 2 * y.numel() * _esize(y)))
+  call('tg_norm_act_fwd_partials', _p(y), _p(part), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(gamma2), _p(beta2), split,
+       _p(z), _p(s), n, h, w, c, flags, alpha, in_eps, pn_eps, _dt(y), _stream(),
+       work=('norm_act_fwd' + _shape_tag(y), 0, 2 * y.numel() * _esize(y)))
+  if ema is not None:
+    _ema_update(mean, rstd, n, c, split, in_eps, ema)
   ctx.flags, ctx.alpha, ctx.split = flags, alpha, split
   ctx.save_for_backward(y, mean, rstd, gamma, beta, gamma2, beta2, s)
   return z
@@ -590,7 +593,7 @@ def _norm_act_backward(ctx, gz, gzp=None):
   gzp = gzp.contiguous() if gzp is not None else None
   n, h, w, c = y.shape
   gy = torch.empty_like(y)
-  sums = torch.empty(2 * n * c, dtype=torch.float32, device=y.device)
+  sums = torch.empty(n * _lib.load().tg_norm_chunks(n, h, w) * 2 * c, dtype=torch.float32, device=y.device)
   two = gamma2 is not None
   params = [gamma, beta] + ([gamma2, beta2] if two else [])
   sinks = [GradSink.get(q) for q in params]
