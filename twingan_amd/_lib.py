@@ -14,6 +14,8 @@ NF_LRELU, NF_PIXNORM = 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtwingan_hip.so')
+if os.environ.get('TG_LIB_PATH'):      # kernel A/B runs (tools/ab.sh): an alternative build of the same ABI
+  LIB_PATH = os.environ['TG_LIB_PATH']
 
 
 class TgError(RuntimeError):

@@ -117,14 +117,24 @@ __global__ void in_stats_partial(const T* __restrict__ y, float* __restrict__ s1
   const int p0 = blockIdx.x * px_per_block;
   const int p1 = min(p0 + px_per_block, hw);
   if (pl < lanes) {
-    for (int p = p0 + pl; p < p1; p += lanes) {
-      float x[V];
-      VecIO<T, V>::load(base + (int64_t)p * c + v * V, x);
+    constexpr int U = 4;      // pixels in flight per thread
+    for (int pb = p0 + pl; pb < p1; pb += lanes * U) {
+      float x[U][V];
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        const float d = x[j] - k[j];
-        a1[j] += d;
-        a2[j] = fmaf(d, d, a2[j]);
+      for (int u = 0; u < U; ++u) {
+        const int p = min(pb + u * lanes, p1 - 1);
+        VecIO<T, V>::load(base + (int64_t)p * c + v * V, x[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (pb + u * lanes < p1) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            const float d = x[u][j] - k[j];
+            a1[j] += d;
+            a2[j] = fmaf(d, d, a2[j]);
+          }
+        }
       }
     }
   }
@@ -266,26 +276,35 @@ __global__ void norm_act_fwd_part_kernel(const T* __restrict__ y, const float* _
   const int p0 = blockIdx.x * px_per_block;
   const int p1 = min(p0 + px_per_block, hw);
   if (pl >= lanes) return;
-  for (int p = p0 + pl; p < p1; p += lanes) {      // pl is uniform within a pixel group: groups stay converged
-    const int64_t gp = (int64_t)n * hw + p;
-    float x[V];
-    VecIO<T, V>::load(y + gp * c + v * V, x);
-    float ss = 0.f;
+  constexpr int U = 4;      // pixels in flight per thread
+  for (int pb = p0 + pl; pb < p1; pb += lanes * U) {      // pl is uniform within a pixel group: groups stay converged
+    float x[U][V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-      float u = x[j] * sc[j] + sf[j];
-      if (flags & NF_LRELU) u = lrelu_f(u, alpha);
-      x[j] = u;
-      ss = fmaf(u, u, ss);
+    for (int u = 0; u < U; ++u) {
+      const int p = min(pb + u * lanes, p1 - 1);
+      VecIO<T, V>::load(y + ((int64_t)n * hw + p) * c + v * V, x[u]);
     }
-    if (flags & NF_PIXNORM) {
-      ss = group_sum(ss, cv);
-      const float q = rsqrtf(ss / (float)c + pn_eps);
 #pragma unroll
-      for (int j = 0; j < V; ++j) x[j] *= q;
-      if (pn_scale && v == 0) pn_scale[gp] = q;
+    for (int u = 0; u < U; ++u) {
+      const int p = pb + u * lanes;
+      const int64_t gp = (int64_t)n * hw + p;
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float t = x[u][j] * sc[j] + sf[j];
+        if (flags & NF_LRELU) t = lrelu_f(t, alpha);
+        x[u][j] = t;
+        ss = fmaf(t, t, ss);
+      }
+      if (flags & NF_PIXNORM) {
+        ss = group_sum(ss, cv);
+        const float q = rsqrtf(ss / (float)c + pn_eps);
+#pragma unroll
+        for (int j = 0; j < V; ++j) x[u][j] *= q;
+        if (pn_scale && v == 0 && p < p1) pn_scale[gp] = q;
+      }
+      if (p < p1) VecIO<T, V>::store(z + gp * c + v * V, x[u]);
     }
-    VecIO<T, V>::store(z + gp * c + v * V, x);
   }
 }
 
@@ -322,34 +341,49 @@ __global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restri
   const int p1 = min(p0 + px_per_block, hw);
   // every lane of a pixel group iterates the same number of times (pl is uniform within a group)
   if (pl < lanes) {
-    for (int p = p0 + pl; p < p1; p += lanes) {
-      const int64_t gp = (int64_t)n * hw + p;
-      float g[V], x[V], yh[V], u[V];
-      load_grad<T, V>(gz, gzp, n, p, hw, wdim, c, v, 0.25f, g);
-      VecIO<T, V>::load(y + gp * c + v * V, x);
-      float dot = 0.f;
-      const float s = (flags & NF_PIXNORM) ? pn_scale[gp] : 1.f;
+    constexpr int U = 2;      // pixels in flight per thread (3 loads each)
+    for (int pb = p0 + pl; pb < p1; pb += lanes * U) {
+      float gq[U][V], xq[U][V], sq[U];
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        yh[j] = (x[j] - mu[j]) * rs[j];
-        u[j] = yh[j] * ga[j] + be[j];
-        const float a = (flags & NF_LRELU) ? lrelu_f(u[j], alpha) : u[j];
-        dot = fmaf(g[j], a * s, dot);          // gz . z
-        x[j] = a * s;                          // z
-      }
-      if (flags & NF_PIXNORM) {
-        dot = group_sum(dot, cv) / (float)c;
-#pragma unroll
-        for (int j = 0; j < V; ++j) g[j] = s * (g[j] - x[j] * dot);     // d/da
+      for (int q = 0; q < U; ++q) {
+        const int p = min(pb + q * lanes, p1 - 1);
+        const int64_t gp = (int64_t)n * hw + p;
+        load_grad<T, V>(gz, gzp, n, p, hw, wdim, c, v, 0.25f, gq[q]);
+        VecIO<T, V>::load(y + gp * c + v * V, xq[q]);
+        sq[q] = (flags & NF_PIXNORM) ? pn_scale[gp] : 1.f;
       }
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        if (flags & NF_LRELU) g[j] *= (u[j] > 0.f ? 1.f : alpha);
-        const float gr = rnd<T>(g[j]);      // what pass 2 will read back
-        a1[j] += gr;
-        a2[j] = fmaf(gr, yh[j], a2[j]);
+      for (int q = 0; q < U; ++q) {
+        const int p = pb + q * lanes;
+        const bool live = p < p1;
+        const int64_t gp = (int64_t)n * hw + p;
+        float yh[V], u[V];
+        float (&g)[V] = gq[q];
+        float (&x)[V] = xq[q];
+        const float s = sq[q];
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          yh[j] = (x[j] - mu[j]) * rs[j];
+          u[j] = yh[j] * ga[j] + be[j];
+          const float a = (flags & NF_LRELU) ? lrelu_f(u[j], alpha) : u[j];
+          dot = fmaf(g[j], a * s, dot);          // gz . z
+          x[j] = a * s;                          // z
+        }
+        if (flags & NF_PIXNORM) {
+          dot = group_sum(dot, cv) / (float)c;
+#pragma unroll
+          for (int j = 0; j < V; ++j) g[j] = s * (g[j] - x[j] * dot);     // d/da
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          if (flags & NF_LRELU) g[j] *= (u[j] > 0.f ? 1.f : alpha);
+          const float gr = live ? rnd<T>(g[j]) : 0.f;      // what pass 2 will read back
+          a1[j] += gr;
+          a2[j] = fmaf(gr, yh[j], a2[j]);
+        }
+        if (live) VecIO<T, V>::store(gu_out + gp * c + v * V, g);
       }
-      VecIO<T, V>::store(gu_out + gp * c + v * V, g);
     }
   }
   wave_channel_accumulate<V>(a1, sh, 0, cv, v, pl < lanes);
@@ -397,17 +431,27 @@ __global__ void norm_act_bwd2_part_kernel(T* __restrict__ gy, const T* __restric
   const int p0 = blockIdx.x * px_per_block;
   const int p1 = min(p0 + px_per_block, hw);
   if (pl >= lanes) return;
-  for (int p = p0 + pl; p < p1; p += lanes) {
-    const int64_t gp = (int64_t)n * hw + p;
-    float g[V], x[V];
-    VecIO<T, V>::load(gy + gp * c + v * V, g);
-    VecIO<T, V>::load(y + gp * c + v * V, x);
+  constexpr int U = 4;      // pixels in flight per thread
+  for (int pb = p0 + pl; pb < p1; pb += lanes * U) {
+    float g[U][V], x[U][V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-      const float yh = (x[j] - mu[j]) * rs[j];
-      g[j] = gr[j] * (g[j] - s1[j] - yh * s2[j]);
+    for (int u = 0; u < U; ++u) {
+      const int64_t gp = (int64_t)n * hw + min(pb + u * lanes, p1 - 1);
+      VecIO<T, V>::load(gy + gp * c + v * V, g[u]);
+      VecIO<T, V>::load(y + gp * c + v * V, x[u]);
     }
-    VecIO<T, V>::store(gy + gp * c + v * V, g);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = pb + u * lanes;
+      if (p < p1) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const float yh = (x[u][j] - mu[j]) * rs[j];
+          g[u][j] = gr[j] * (g[u][j] - s1[j] - yh * s2[j]);
+        }
+        VecIO<T, V>::store(gy + ((int64_t)n * hw + p) * c + v * V, g[u]);
+      }
+    }
   }
 }
 
@@ -466,6 +510,7 @@ __global__ void lrelu_bwd_bias_kernel(const T* __restrict__ gz, const T* __restr
                                       const T* __restrict__ z, T* __restrict__ gy, float* __restrict__ gbias,
                                       int64_t npix, int c, float alpha) {
   extern __shared__ float sh[];   // [c]
+  constexpr int U = 4;            // pixels in flight per thread: a streaming pass needs >= 64 KB outstanding per CU
   const int cv = c / V;
   const int lanes = blockDim.x / cv;
   const int v = threadIdx.x % cv, pl = threadIdx.x / cv;
@@ -475,21 +520,35 @@ __global__ void lrelu_bwd_bias_kernel(const T* __restrict__ gz, const T* __restr
 #pragma unroll
   for (int j = 0; j < V; ++j) a[j] = 0.f;
   if (pl < lanes) {
-    for (int64_t p = (int64_t)blockIdx.x * lanes + pl; p < npix; p += (int64_t)gridDim.x * lanes) {
-      float g[V], zz[V];
-      if (gzp) {
-        const int n = ((hw & (hw - 1)) == 0) ? (int)(p >> (31 - __builtin_clz(hw))) : (int)(p / hw);
-        load_grad<T, V>(gz, gzp, n, (int)(p - (int64_t)n * hw), hw, wdim, c, v, 0.25f, g);
-      } else {
-        VecIO<T, V>::load(gz + p * c + v * V, g);
-      }
-      VecIO<T, V>::load(z + p * c + v * V, zz);
+    const int64_t stride = (int64_t)gridDim.x * lanes;
+    const int hw_shift = ((hw & (hw - 1)) == 0) ? 31 - __builtin_clz(hw) : -1;
+    for (int64_t pb = (int64_t)blockIdx.x * lanes + pl; pb < npix; pb += stride * U) {
+      float g[U][V], zz[U][V];
+      // all loads first (addresses clamped instead of predicated: no branches between the loads)
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        g[j] = rnd<T>(g[j] * (zz[j] > 0.f ? 1.f : alpha));
-        a[j] += g[j];
+      for (int u = 0; u < U; ++u) {
+        int64_t p = pb + u * stride;
+        p = p < npix ? p : npix - 1;
+        if (gzp) {
+          const int n = hw_shift >= 0 ? (int)(p >> hw_shift) : (int)(p / hw);
+          load_grad<T, V>(gz, gzp, n, (int)(p - (int64_t)n * hw), hw, wdim, c, v, 0.25f, g[u]);
+        } else {
+          VecIO<T, V>::load(gz + p * c + v * V, g[u]);
+        }
+        VecIO<T, V>::load(z + p * c + v * V, zz[u]);
       }
-      VecIO<T, V>::store(gy + p * c + v * V, g);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t p = pb + u * stride;
+        if (p < npix) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            g[u][j] = rnd<T>(g[u][j] * (zz[u][j] > 0.f ? 1.f : alpha));
+            a[j] += g[u][j];
+          }
+          VecIO<T, V>::store(gy + p * c + v * V, g[u]);
+        }
+      }
     }
   }
   if (!gbias) return;
@@ -707,7 +766,7 @@ static int lrelu_bwd_launch(const char* who, const void* gz, const void* gzp, in
     TG_CHECK(c / V <= 256, TG_ENOSUP, "%s: c=%d not supported", who, c);
     const int lanes = 256 / (c / V);
     // few, fat workgroups when a bias gradient is produced: every workgroup ends with c global atomics
-    const int blocks = gbias ? tg_grid_for(npix, lanes * 16, 512) : tg_grid_for(npix, lanes * 4, 2048);
+    const int blocks = gbias ? tg_grid_for(npix, lanes * 16, 1024) : tg_grid_for(npix, lanes * 4, 2048);
     const size_t lds = (size_t)c * sizeof(float);
     if (V == 1)
       hipLaunchKernelGGL((lrelu_bwd_bias_kernel<T, 1>), dim3(blocks), dim3(256), lds, s, (const T*)gz, (const T*)gzp, hw,
