@@ -123,9 +123,11 @@ int tg_instance_norm_stats(const void* y, float* mean, float* rstd, int n, int h
  * nets/pggan_utils.py:102-113): when gamma2/beta2 are non-NULL, images [0, split) use gamma/beta and images
  * [split, n) use gamma2/beta2, so the source- and target-domain passes of one network run as ONE batch.
  * pn_scale (fp32 [n*h*w], may be NULL unless pixel-norm) receives 1/sqrt(mean_c(a^2)+pn_eps) for the backward. */
+/* per_image_params != 0: gamma / beta are [n][c] -- one row per image (batch renorm: every pass batched along n has
+ * its own r*gamma, d*gamma+beta); gamma2 / beta2 / split are then ignored. */
 int tg_norm_act_fwd(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                    const float* gamma2, const float* beta2, int split, void* z, float* pn_scale, int n, int h, int w, int c,
-                    int flags, float lrelu_alpha, float pn_eps, int dtype, void* stream);
+                    const float* gamma2, const float* beta2, int split, int per_image_params, void* z, float* pn_scale,
+                    int n, int h, int w, int c, int flags, float lrelu_alpha, float pn_eps, int dtype, void* stream);
 /* The same forward as two launches instead of four (no zero fill, no atomics, no finalise kernel):
  * tg_instance_norm_partials writes per-block shifted sums to partials (fp32 [n * tg_norm_chunks(n,h,w) * 2 * c]);
  * tg_norm_act_fwd_partials finalises mean / rstd from them in its prologue, WRITES mean[n*c] / rstd[n*c] (for the
@@ -140,11 +142,11 @@ int tg_norm_act_fwd_partials(const void* y, const float* partials, float* mean, 
  * layer-output gradient is gz + 0.25 * upsample(gz_pooled): the tf.nn.avg_pool that follows an encoder block,
  * nets/pggan.py:436,468, is folded in), y (raw conv output), pn_scale, mean, rstd, gamma, beta (+ 2nd domain).
  * Outputs: gy (same dtype), ggamma[c], gbeta[c] (+ ggamma2, gbeta2 for images >= split) (fp32, may be NULL;
- * accumulate != 0 adds).  sums: fp32 scratch [n * tg_norm_chunks(n,h,w) * 2 * c] (per-block partial sums). */
+ * accumulate != 0 adds; with per_image_params ggamma / gbeta are [n][c] and written).  sums: fp32 scratch [n * tg_norm_chunks(n,h,w) * 2 * c] (per-block partial sums). */
 int tg_norm_act_bwd(const void* gz, const void* gz_pooled, const void* y, const float* pn_scale, const float* mean,
                     const float* rstd, const float* gamma, const float* beta, const float* gamma2, const float* beta2, int split, void* gy,
-                    float* ggamma, float* gbeta, float* ggamma2, float* gbeta2, float* sums, int n, int h, int w, int c,
-                    int flags, float lrelu_alpha, int accumulate, int dtype, void* stream);
+                    int per_image_params, float* ggamma, float* gbeta, float* ggamma2, float* gbeta2, float* sums, int n,
+                    int h, int w, int c, int flags, float lrelu_alpha, int accumulate, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Discriminator pointwise: bias + LeakyReLU (nets/pggan_utils.py:116; slim BiasAdd) and pieces

@@ -41,7 +41,8 @@ class Config:
   in_eps: float = 1e-6               # libs/instance_norm.py:37
   pn_eps: float = 1e-6               # nets/pggan_utils.py:330
   lrelu: float = 0.2                 # util_misc.py:68
-  bn_state: object = None            # dict collecting the BatchNorm moving statistics when set
+  bn_state: object = None            # dict collecting the BatchNorm moving (and renorm) statistics when set
+  global_step: int = 0               # batch renorm clipping schedule (nets/pggan_utils.py:207-223)
   equalized: bool = False            # equalized_learning_rate           (nets/pggan.py:40; pggan_utils.py:236-254)
   res_block: bool = False            # use_res_block                     (nets/pggan.py:44; pggan_utils.py:257-264,334-342)
 
@@ -59,7 +60,7 @@ def max_stage_of(hw):
 # ------------------------------------------------------------------------------------------------
 # parameter construction (names: SURVEY.md Appendix C; init: nets/pggan_utils.py:56,93, pggan.py:364-368)
 # ------------------------------------------------------------------------------------------------
-NORM_SCOPE = {'instance_norm': 'InstanceNorm', 'batch_norm': 'BatchNorm'}      # libs/instance_norm.py:66, batch_norm.py:80
+NORM_SCOPE = {'instance_norm': 'InstanceNorm', 'batch_norm': 'BatchNorm', 'batch_renorm': 'BatchNorm'}      # libs/instance_norm.py:66, batch_norm.py:80
 BN_EPS = 1e-3       # libs/batch_norm.py:48 (max(epsilon, 1.001e-5), :464-468)
 BN_DECAY = 0.999    # libs/batch_norm.py:45
 
@@ -231,6 +232,53 @@ def batch_norm_train(x, gamma, beta, eps=BN_EPS):
   return x * inv + (beta - mean * inv), mean.reshape(-1), var.reshape(-1)
 
 
+RENORM_MOMENTUM = 0.99                                     # libs/batch_norm.py:62; pggan_utils.py:163 sets decay the same
+RENORM_BOUNDARIES = (10000, 20000, 30000)                  # nets/pggan_utils.py:43-47
+RENORM_RMAX, RENORM_RMIN, RENORM_DMAX = (1.1, 1.5, 2.0, 4.0), (0.9, 0.66, 0.5, 0.25), (0.1, 0.3, 0.5, 1.0)
+
+
+def renorm_clipping(global_step):
+  """get_renorm_clipping_params (nets/pggan_utils.py:207-223): tf.train.piecewise_constant of the global step."""
+  i = sum(1 for b in RENORM_BOUNDARIES if global_step > b)
+  return dict(rmax=RENORM_RMAX[i], rmin=RENORM_RMIN[i], dmax=RENORM_DMAX[i])
+
+
+def batch_renorm_train(x, gamma, beta, state, key, postfix, clipping, eps=BN_EPS, momentum=RENORM_MOMENTUM):
+  """conditional_batch_norm(renorm=True, is_training=True): _batch_norm_aux + _renorm_correction_and_moments
+  (libs/batch_norm.py:329-470).  ``state`` holds renorm_mean / renorm_mean_weight / renorm_stddev /
+  renorm_stddev_weight / moving_mean / moving_variance under ``key + name + postfix`` (zero / one initialised,
+  libs/batch_norm.py:184-246) and is updated in place."""
+  mean = x.mean(dim=(0, 1, 2))
+  var = x.var(dim=(0, 1, 2), unbiased=False)
+  c = x.shape[-1]
+
+  def get(name, shape, init):
+    k = key + name + postfix
+    if k not in state:
+      state[k] = torch.full(shape, init, dtype=x.dtype)
+    return k
+
+  k_rm, k_rmw = get('renorm_mean', (c,), 0.0), get('renorm_mean_weight', (1,), 0.0)
+  k_rs, k_rsw = get('renorm_stddev', (c,), 0.0), get('renorm_stddev_weight', (1,), 0.0)
+  k_mm, k_mv = get('moving_mean', (c,), 0.0), get('moving_variance', (c,), 1.0)
+  with torch.no_grad():
+    stddev = torch.sqrt(var + eps)
+    mixed_mean = state[k_rm] + (1.0 - state[k_rmw]) * mean
+    mixed_std = state[k_rs] + (1.0 - state[k_rsw]) * stddev
+    r = (stddev / mixed_std).clamp(clipping['rmin'], clipping['rmax'])          # stop_gradient (:443-444)
+    d = ((mean - mixed_mean) / mixed_std).clamp(-clipping['dmax'], clipping['dmax'])
+    state[k_rm] = state[k_rm] * momentum + mean * (1 - momentum)
+    state[k_rmw] = state[k_rmw] * momentum + (1 - momentum)
+    state[k_rs] = state[k_rs] * momentum + stddev * (1 - momentum)
+    state[k_rsw] = state[k_rsw] * momentum + (1 - momentum)
+    new_mean = state[k_rm] / state[k_rmw]
+    new_std = state[k_rs] / state[k_rsw]
+    state[k_mm] = state[k_mm] * momentum + new_mean * (1 - momentum)
+    state[k_mv] = state[k_mv] * momentum + (new_std * new_std - eps) * (1 - momentum)
+  scale, offset = r * gamma, d * gamma + beta                                    # _compose_transforms (:431-437)
+  return (x - mean) * torch.rsqrt(var + eps) * scale + offset
+
+
 def moving_average_update(moving, value, decay=BN_DECAY):
   """moving_averages.assign_moving_average(zero_debias=False), libs/batch_norm.py:283-300."""
   return moving - (1.0 - decay) * (moving - value)
@@ -290,6 +338,9 @@ def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=Tru
         key = scope + '/BatchNorm/' + nm + domain
         cur = cfg.bn_state.get(key, torch.full_like(val, init))
         cfg.bn_state[key] = moving_average_update(cur, val.detach())
+  elif cfg.norm == 'batch_renorm':     # the configuration of docs/training.md:17
+    y = batch_renorm_train(y, P[scope + '/BatchNorm/gamma_' + domain], P[scope + '/BatchNorm/beta_' + domain],
+                           cfg.bn_state, scope + '/BatchNorm/', '_' + domain, renorm_clipping(cfg.global_step))
   elif cfg.norm not in ('none', None):
     raise NotImplementedError(cfg.norm)
   if act:

@@ -443,3 +443,44 @@ def test_batch_norm_generator_matches_oracle():
   for k, v in state.items():
     a = tr.store.state[k].double().cpu().numpy()
     assert np.abs(a - v.numpy()).max() < 1e-5 * max(1.0, np.abs(v.numpy()).max()), k
+
+
+@pytest.mark.parametrize('global_step', [0, 25000])
+def test_batch_renorm_generator_matches_oracle(global_step):
+  """generator_norm_type=batch_renorm -- the configuration the reference's training guide uses (docs/training.md:17;
+  libs/batch_norm.py:209-246,329-470): r / d corrections from the renorm statistics (stop-gradient, clipped by the
+  global-step schedule), renorm + moving statistics updated per pass in call order.  Two consecutive generator-loss
+  evaluations so the second one sees non-trivial renorm state."""
+  from twingan_amd import Config
+  from twingan_amd import twingan as T
+  from twingan_amd.twingan import Trainer
+  cfg = Config(hw=16, max_ch=16, precision='fp32', generator_norm_type='batch_renorm')
+  state = {}
+  rcfg = R.Config(hw=16, max_ch=16, norm='batch_renorm', bn_state=state, global_step=global_step)
+  Pref = R.init_params(rcfg, seed=8, dtype=torch.float64, std='he')
+  tr = Trainer(cfg, device='cuda:0', seed=8)
+  tr.global_step = global_step
+  tr._set_renorm_clipping()
+  assert set(tr.store.state_dict()) == set(Pref)
+  tr.store.load_state_dict({k: v.float() for k, v in Pref.items()})
+  Pref = {k: v.float().double().requires_grad_(True) for k, v in Pref.items()}
+  g = torch.Generator().manual_seed(78)
+  dev = lambda x: x.to('cuda:0').contiguous()
+  for it in range(2):
+    s, t = torch.rand(3, 16, 16, 3, generator=g), torch.rand(3, 16, 16, 3, generator=g)
+    for v in Pref.values():
+      v.grad = None
+    tr.store.zero_grad('g')
+    tr._set_requires_grad(g=True, d=False)
+    gl, gterms = T.generator_loss(tr.P, dev(s), dev(t), cfg)
+    rgl, rgterms = R.generator_loss(Pref, s.double(), t.double(), rcfg)
+    for k in rgterms:
+      assert abs(gterms[k].item() - rgterms[k].item()) < 2e-4 * max(1.0, abs(rgterms[k].item())), (it, k)
+    gl.backward()
+    rgl.backward()
+    _grads_close(tr, Pref, tr.store.names('g'), 8e-2, 'generator(batch_renorm, run %d)' % it)
+  renorm_state = {k: v for k, v in tr.store.state.items() if not k.startswith('renorm/')}
+  assert set(renorm_state) == set(state)
+  for k, v in state.items():
+    a = renorm_state[k].double().cpu().numpy()
+    assert np.abs(a - v.numpy()).max() < 2e-5 * max(1.0, np.abs(v.numpy()).max()), k

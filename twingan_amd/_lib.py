@@ -52,10 +52,10 @@ SIGNATURES = {
     'tg_instance_norm_partials': (c_int, [_P, _FP, c_int, c_int, c_int, c_int, c_int, _P]),
     'tg_norm_act_fwd_partials': (c_int, [_P, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, _P, _FP, c_int, c_int, c_int, c_int,
                                          c_int, c_float, c_float, c_float, c_int, _P]),
-    'tg_norm_act_fwd': (c_int, [_P, _FP, _FP, _FP, _FP, _FP, _FP, c_int, _P, _FP, c_int, c_int, c_int, c_int, c_int,
+    'tg_norm_act_fwd': (c_int, [_P, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, _P, _FP, c_int, c_int, c_int, c_int, c_int,
                                 c_float, c_float, c_int, _P]),
-    'tg_norm_act_bwd': (c_int, [_P, _P, _P, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, _P, _FP, _FP, _FP, _FP, _FP, c_int,
-                                c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
+    'tg_norm_act_bwd': (c_int, [_P, _P, _P, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, _P, c_int, _FP, _FP, _FP, _FP, _FP,
+                                c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
     'tg_bias_lrelu_fwd': (c_int, [_P, _FP, _P, c_int64, c_int, c_float, c_int, _P]),
     'tg_lrelu_bwd': (c_int, [_P, _P, _P, c_int64, c_float, c_int, _P]),
     'tg_lrelu_bwd_bias': (c_int, [_P, _P, _P, _FP, c_int64, c_int, c_float, c_int, c_int, _P]),

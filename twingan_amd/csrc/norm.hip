@@ -190,7 +190,7 @@ template <typename T, int V>
 __global__ void norm_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, const float* __restrict__ gamma2,
-                                    const float* __restrict__ beta2, int split, T* __restrict__ z,
+                                    const float* __restrict__ beta2, int split, int pstride, T* __restrict__ z,
                                     float* __restrict__ pn_scale, int64_t npix, int hw, int c, int flags, float alpha,
                                     float pn_eps) {
   const int cv = c / V;
@@ -203,8 +203,9 @@ __global__ void norm_act_fwd_kernel(const T* __restrict__ y, const float* __rest
     const int n = (int)(p / hw);
     float x[V];
     VecIO<T, V>::load(y + p * c + v * V, x);
-    const float* ga = n < split ? gamma : gamma2;      // per-domain affine parameters (images >= split: 2nd domain)
-    const float* be = n < split ? beta : beta2;
+    // per-domain affine parameters (images >= split: 2nd domain), or one parameter row per image (pstride = c)
+    const float* ga = pstride ? gamma + (int64_t)n * pstride : (n < split ? gamma : gamma2);
+    const float* be = pstride ? beta + (int64_t)n * pstride : (n < split ? beta : beta2);
     float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
@@ -318,8 +319,8 @@ __global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restri
                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                      const float* __restrict__ gamma2, const float* __restrict__ beta2, int split,
-                                     T* __restrict__ gu_out, float* __restrict__ sums, int hw, int c, int flags,
-                                     float alpha, int px_per_block) {
+                                     int pstride, T* __restrict__ gu_out, float* __restrict__ sums, int hw, int c,
+                                     int flags, float alpha, int px_per_block) {
   extern __shared__ float sh[];   // [2][c]
   const int cv = c / V;
   const int lanes = blockDim.x / cv;
@@ -333,8 +334,8 @@ __global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restri
     const int ch = v * V + j;
     mu[j] = mean[n * c + ch];
     rs[j] = rstd[n * c + ch];
-    ga[j] = (n < split ? gamma : gamma2)[ch];
-    be[j] = (n < split ? beta : beta2)[ch];
+    ga[j] = pstride ? gamma[(int64_t)n * pstride + ch] : (n < split ? gamma : gamma2)[ch];
+    be[j] = pstride ? beta[(int64_t)n * pstride + ch] : (n < split ? beta : beta2)[ch];
     a1[j] = a2[j] = 0.f;
   }
   const int p0 = blockIdx.x * px_per_block;
@@ -399,17 +400,22 @@ __global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restri
 template <typename T, int V>
 __global__ void norm_act_bwd2_part_kernel(T* __restrict__ gy, const T* __restrict__ y, const float* __restrict__ mean,
                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                          const float* __restrict__ gamma2, int split, const float* __restrict__ part,
-                                          int chunks, float* __restrict__ ggamma, float* __restrict__ gbeta,
-                                          float* __restrict__ ggamma2, float* __restrict__ gbeta2, int sink, int hw,
-                                          int c, int px_per_block) {
+                                          const float* __restrict__ gamma2, int split, int pstride,
+                                          const float* __restrict__ part, int chunks, float* __restrict__ ggamma,
+                                          float* __restrict__ gbeta, float* __restrict__ ggamma2,
+                                          float* __restrict__ gbeta2, int sink, int hw, int c, int px_per_block) {
   extern __shared__ float sh[];   // [2][c]
   const int cv = c / V;
   const int lanes = blockDim.x / cv;
   const int v = threadIdx.x % cv, pl = threadIdx.x / cv;
   const int n = blockIdx.y;
   reduce_partials(part, n, chunks, c, sh);
-  if (sink && blockIdx.x == 0) {
+  if (pstride && blockIdx.x == 0) {      // one parameter row per image: its gradient row is this image's sums
+    for (int i = threadIdx.x; i < c; i += blockDim.x) {
+      if (gbeta) gbeta[(int64_t)n * pstride + i] = sh[i];
+      if (ggamma) ggamma[(int64_t)n * pstride + i] = sh[c + i];
+    }
+  } else if (sink && blockIdx.x == 0) {
     float* gg = n < split ? ggamma : ggamma2;
     float* gb = n < split ? gbeta : gbeta2;
     for (int i = threadIdx.x; i < c; i += blockDim.x) {
@@ -424,7 +430,7 @@ __global__ void norm_act_bwd2_part_kernel(T* __restrict__ gy, const T* __restric
     const int ch = v * V + j;
     mu[j] = mean[n * c + ch];
     rs[j] = rstd[n * c + ch];
-    gr[j] = (n < split ? gamma : gamma2)[ch] * rs[j];
+    gr[j] = (pstride ? gamma[(int64_t)n * pstride + ch] : (n < split ? gamma : gamma2)[ch]) * rs[j];
     s1[j] = sh[ch] * inv;
     s2[j] = sh[c + ch] * inv;
   }
@@ -678,8 +684,9 @@ int tg_instance_norm_stats(const void* y, float* mean, float* rstd, int n, int h
 }
 
 int tg_norm_act_fwd(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                    const float* gamma2, const float* beta2, int split, void* z, float* pn_scale, int n, int h, int w, int c,
-                    int flags, float alpha, float pn_eps, int dtype, void* stream) {
+                    const float* gamma2, const float* beta2, int split, int per_image_params, void* z, float* pn_scale,
+                    int n, int h, int w, int c, int flags, float alpha, float pn_eps, int dtype, void* stream) {
+  const int pstride = per_image_params ? c : 0;
   TG_CHECK(y && mean && rstd && gamma && beta && z && n > 0 && h > 0 && w > 0 && c > 0, TG_EINVAL,
            "tg_norm_act_fwd: bad arguments");
   if (!gamma2 || !beta2) split = n;
@@ -695,12 +702,12 @@ int tg_norm_act_fwd(const void* y, const float* mean, const float* rstd, const f
     if (vec) {
       // grid stride must be a multiple of the group size so pixel groups stay in one wave: 256 % (c/VN) == 0 holds
       hipLaunchKernelGGL((norm_act_fwd_kernel<T, VN>), dim3(tg_grid_for(npix * (c / VN), 256)), dim3(256), 0,
-                         (hipStream_t)stream, (const T*)y, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)z, pn_scale, npix,
-                         h * w, c, flags, alpha, pn_eps);
+                         (hipStream_t)stream, (const T*)y, mean, rstd, gamma, beta, gamma2, beta2, split, pstride, (T*)z,
+                         pn_scale, npix, h * w, c, flags, alpha, pn_eps);
     } else {
       hipLaunchKernelGGL((norm_act_fwd_kernel<T, 1>), dim3(tg_grid_for(npix * c, 256)), dim3(256), 0, (hipStream_t)stream,
-                         (const T*)y, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)z, pn_scale, npix, h * w, c, flags,
-                         alpha, pn_eps);
+                         (const T*)y, mean, rstd, gamma, beta, gamma2, beta2, split, pstride, (T*)z, pn_scale, npix, h * w,
+                         c, flags, alpha, pn_eps);
     }
   });
   TG_LAUNCH_CHECK("tg_norm_act_fwd");
@@ -710,8 +717,9 @@ int tg_norm_act_fwd(const void* y, const float* mean, const float* rstd, const f
 int tg_norm_act_bwd(const void* gz, const void* gz_pooled, const void* y, const float* pn_scale, const float* mean,
                     const float* rstd,
                     const float* gamma, const float* beta, const float* gamma2, const float* beta2, int split, void* gy,
-                    float* ggamma, float* gbeta, float* ggamma2, float* gbeta2, float* sums, int n, int h, int w, int c,
-                    int flags, float alpha, int accumulate, int dtype, void* stream) {
+                    int per_image_params, float* ggamma, float* gbeta, float* ggamma2, float* gbeta2, float* sums, int n,
+                    int h, int w, int c, int flags, float alpha, int accumulate, int dtype, void* stream) {
+  const int pstride = per_image_params ? c : 0;
   TG_CHECK((gz || gz_pooled) && y && mean && rstd && gamma && beta && gy && sums && n > 0 && h > 0 && w > 0 && c > 0,
            TG_EINVAL, "tg_norm_act_bwd: bad arguments");
   TG_CHECK(!gz_pooled || (h % 2 == 0 && w % 2 == 0), TG_EINVAL, "tg_norm_act_bwd: pooled gradient needs even h, w");
@@ -727,6 +735,7 @@ int tg_norm_act_bwd(const void* gz, const void* gz_pooled, const void* y, const 
   if (ppb2 < 64) ppb2 = 64;
   chunks2 = (hw + ppb2 - 1) / ppb2;
   const bool want_params = ggamma || gbeta || ggamma2 || gbeta2;
+  TG_CHECK(!pstride || !accumulate, TG_EINVAL, "tg_norm_act_bwd: per-image parameter gradients are written, not added");
   const int sink = (want_params && accumulate) ? 1 : 0;      // block (0, n) of pass 2 adds the image's sums
   const size_t lds = 2 * (size_t)c * sizeof(float);
   TG_DISPATCH_DTYPE(dtype, "tg_norm_act_bwd", {
@@ -737,18 +746,18 @@ int tg_norm_act_bwd(const void* gz, const void* gz_pooled, const void* y, const 
     }
     if (vec) {
       hipLaunchKernelGGL((norm_act_bwd1_kernel<T, VN>), dim3(chunks, n), dim3(256), lds, s, (const T*)gz,
-                         (const T*)gz_pooled, w, (const T*)y, pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)gy, sums, hw, c, flags, alpha, ppb);
+                         (const T*)gz_pooled, w, (const T*)y, pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split, pstride, (T*)gy, sums, hw, c, flags, alpha, ppb);
       hipLaunchKernelGGL((norm_act_bwd2_part_kernel<T, VN>), dim3(chunks2, n), dim3(256), lds, s, (T*)gy, (const T*)y, mean,
-                         rstd, gamma, gamma2, split, sums, chunks, ggamma, gbeta, ggamma2, gbeta2, sink, hw, c, ppb2);
+                         rstd, gamma, gamma2, split, pstride, sums, chunks, ggamma, gbeta, ggamma2, gbeta2, sink, hw, c, ppb2);
     } else {
       TG_CHECK(c <= 256, TG_ENOSUP, "tg_norm_act_bwd: scalar path needs c <= 256 (got %d)", c);
       hipLaunchKernelGGL((norm_act_bwd1_kernel<T, 1>), dim3(chunks, n), dim3(256), lds, s, (const T*)gz,
-                         (const T*)gz_pooled, w, (const T*)y, pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)gy, sums, hw, c, flags, alpha, ppb);
+                         (const T*)gz_pooled, w, (const T*)y, pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split, pstride, (T*)gy, sums, hw, c, flags, alpha, ppb);
       hipLaunchKernelGGL((norm_act_bwd2_part_kernel<T, 1>), dim3(chunks2, n), dim3(256), lds, s, (T*)gy, (const T*)y, mean,
-                         rstd, gamma, gamma2, split, sums, chunks, ggamma, gbeta, ggamma2, gbeta2, sink, hw, c, ppb2);
+                         rstd, gamma, gamma2, split, pstride, sums, chunks, ggamma, gbeta, ggamma2, gbeta2, sink, hw, c, ppb2);
     }
   });
-  if (want_params && !sink)
+  if (want_params && !sink && !pstride)
     hipLaunchKernelGGL(norm_param_grads, dim3((c + 255) / 256, split < n ? 2 : 1), dim3(256), 0, s, sums, chunks, ggamma,
                        gbeta, ggamma2, gbeta2, split, n, c, 0);
   TG_LAUNCH_CHECK("tg_norm_act_bwd");

@@ -354,6 +354,30 @@ __global__ void small_gemm_kernel(const float* __restrict__ a, const float* __re
   }
 }
 
+// Same GEMM with one WAVE per output element (lanes split K, butterfly sum): the discriminator's fully connected
+// layer is [B,256] x [256,1] -- a thread per output walks K = 256 as one dependent chain (18 us).
+__global__ void small_gemm_wave_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                       const float* __restrict__ bias, float* __restrict__ c, int m, int n, int k, int ta,
+                                       int tb, int accumulate) {
+  const int64_t total = (int64_t)m * n;
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i = w0; i < total; i += nw) {
+    const int col = (int)(i % n), row = (int)(i / n);
+    float acc = 0.f;
+    for (int kk = lane; kk < k; kk += 64) {
+      const float av = ta ? a[(int64_t)kk * m + row] : a[(int64_t)row * k + kk];
+      const float bv = tb ? b[(int64_t)col * k + kk] : b[(int64_t)kk * n + col];
+      acc = fmaf(av, bv, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      if (bias) acc += bias[col];
+      c[i] = (accumulate ? c[i] : 0.f) + acc;
+    }
+  }
+}
+
 // TF-1.x Adam (model/model_inheritor.py:537-542): epsilon OUTSIDE the bias-corrected sqrt.
 __global__ void adam_kernel(float* __restrict__ th, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, bf16* __restrict__ shadow, int64_t numel, float lr_t,
@@ -512,8 +536,12 @@ int tg_var_from_sums(const float* sum, const float* sample_sumsq, float* out, in
 int tg_small_gemm(const float* a, const float* b, const float* bias, float* c, int m, int n, int k, int ta, int tb,
                   int accumulate, void* stream) {
   TG_CHECK(a && b && c && m > 0 && n > 0 && k > 0, TG_EINVAL, "tg_small_gemm: bad arguments");
-  hipLaunchKernelGGL(small_gemm_kernel, dim3(tg_grid_for((int64_t)m * n, 256)), dim3(256), 0, (hipStream_t)stream, a, b,
-                     bias, c, m, n, k, ta, tb, accumulate);
+  if (k >= 32 && (int64_t)m * n <= 4096)
+    hipLaunchKernelGGL(small_gemm_wave_kernel, dim3(tg_grid_for((int64_t)m * n * 64, 256)), dim3(256), 0,
+                       (hipStream_t)stream, a, b, bias, c, m, n, k, ta, tb, accumulate);
+  else
+    hipLaunchKernelGGL(small_gemm_kernel, dim3(tg_grid_for((int64_t)m * n, 256)), dim3(256), 0, (hipStream_t)stream, a, b,
+                       bias, c, m, n, k, ta, tb, accumulate);
   TG_LAUNCH_CHECK("tg_small_gemm");
   return TG_OK;
 }

@@ -565,24 +565,42 @@ def _ema_update(mean, rstd, n, c, split, eps, ema):
       mv.sub_((mv - v[gi]) * (1.0 - decay))
 
 
-def _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema=None):
+def instance_stats(y, eps):
+  """(mean, rstd), fp32 [n*c], of y[n,h,w,c] over (h,w): biased variance, rstd = rsqrt(var + eps).  No autograd."""
+  _chk(y)
+  n, h, w, c = y.shape
+  mean = torch.empty(n * c, dtype=torch.float32, device=y.device)
+  rstd = torch.empty(n * c, dtype=torch.float32, device=y.device)
+  call('tg_instance_norm_stats', _p(y), _p(mean), _p(rstd), n, h, w, c, eps, _dt(y), _stream(),
+       work=('in_stats' + _shape_tag(y), 0, y.numel() * _esize(y)))
+  return mean, rstd
+
+
+def _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema=None, stats=None):
   _chk(y, gamma, beta, gamma2, beta2)
   n, h, w, c = y.shape
   split = n if gamma2 is None else int(split)
-  mean = torch.empty(n * c, dtype=torch.float32, device=y.device)
-  rstd = torch.empty(n * c, dtype=torch.float32, device=y.device)
-  chunks = _lib.load().tg_norm_chunks(n, h, w)
-  part = torch.empty(n * chunks * 2 * c, dtype=torch.float32, device=y.device)
-  call('tg_instance_norm_partials', _p(y), _p(part), n, h, w, c, _dt(y), _stream(),
-       work=('in_stats' + _shape_tag(y), 0, y.numel() * _esize(y)))
+  per_image = gamma.dim() == 2          # [n, c] parameter rows (batch renorm): statistics come from the caller
   z = torch.empty_like(y)
   s = torch.empty(n * h * w, dtype=torch.float32, device=y.device) if (flags & NF_PIXNORM) else None
-  call('tg_norm_act_fwd_partials', _p(y), _p(part), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(gamma2), _p(beta2), split,
-       _p(z), _p(s), n, h, w, c, flags, alpha, in_eps, pn_eps, _dt(y), _stream(),
-       work=('norm_act_fwd' + _shape_tag(y), 0, 2 * y.numel() * _esize(y)))
-  if ema is not None:
-    _ema_update(mean, rstd, n, c, split, in_eps, ema)
-  ctx.flags, ctx.alpha, ctx.split = flags, alpha, split
+  if per_image:
+    assert stats is not None and tuple(gamma.shape) == (n, c) and tuple(beta.shape) == (n, c) and gamma2 is None
+    mean, rstd = stats
+    call('tg_norm_act_fwd', _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), 0, 0, split, 1, _p(z), _p(s), n, h, w, c,
+         flags, alpha, pn_eps, _dt(y), _stream(), work=('norm_act_fwd' + _shape_tag(y), 0, 2 * y.numel() * _esize(y)))
+  else:
+    mean = torch.empty(n * c, dtype=torch.float32, device=y.device)
+    rstd = torch.empty(n * c, dtype=torch.float32, device=y.device)
+    chunks = _lib.load().tg_norm_chunks(n, h, w)
+    part = torch.empty(n * chunks * 2 * c, dtype=torch.float32, device=y.device)
+    call('tg_instance_norm_partials', _p(y), _p(part), n, h, w, c, _dt(y), _stream(),
+         work=('in_stats' + _shape_tag(y), 0, y.numel() * _esize(y)))
+    call('tg_norm_act_fwd_partials', _p(y), _p(part), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(gamma2), _p(beta2), split,
+         _p(z), _p(s), n, h, w, c, flags, alpha, in_eps, pn_eps, _dt(y), _stream(),
+         work=('norm_act_fwd' + _shape_tag(y), 0, 2 * y.numel() * _esize(y)))
+    if ema is not None:
+      _ema_update(mean, rstd, n, c, split, in_eps, ema)
+  ctx.flags, ctx.alpha, ctx.split, ctx.per_image = flags, alpha, split, per_image
   ctx.save_for_backward(y, mean, rstd, gamma, beta, gamma2, beta2, s)
   return z
 
@@ -596,22 +614,26 @@ def _norm_act_backward(ctx, gz, gzp=None):
   sums = torch.empty(n * _lib.load().tg_norm_chunks(n, h, w) * 2 * c, dtype=torch.float32, device=y.device)
   two = gamma2 is not None
   params = [gamma, beta] + ([gamma2, beta2] if two else [])
-  sinks = [GradSink.get(q) for q in params]
+  per_image = ctx.per_image
+  sinks = [None if per_image else GradSink.get(q) for q in params]
   sunk = all(t is not None for t in sinks)
   if _State.skip_param_grads:
     outs = [None] * 4
+  elif per_image:
+    outs = [torch.empty((n, c), dtype=torch.float32, device=y.device) for _ in params] + [None, None]
   elif sunk:
     outs = sinks + [None] * (4 - len(sinks))
   else:
     outs = [torch.empty(c, dtype=torch.float32, device=y.device) for _ in params] + [None] * (4 - len(params))
   passes = 3 + (0.25 if gzp is not None else 0) - (0 if gz is not None else 1)
   call('tg_norm_act_bwd', _p(gz), _p(gzp), _p(y), _p(s), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(gamma2), _p(beta2),
-       ctx.split, _p(gy), _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), _p(sums), n, h, w, c, ctx.flags, ctx.alpha,
+       ctx.split, _p(gy), 1 if per_image else 0, _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), _p(sums), n, h, w, c,
+       ctx.flags, ctx.alpha,
        1 if (sunk and not _State.skip_param_grads) else 0, _dt(y), _stream(),
        work=('norm_act_bwd' + _shape_tag(y), 0, int(passes * y.numel()) * _esize(y)))
   if sunk or _State.skip_param_grads:
     outs = [None] * 4
-  return gy, outs[0], outs[1], outs[2], outs[3], None, None, None, None, None
+  return gy, outs[0], outs[1], outs[2], outs[3], None, None, None, None, None, None
 
 
 class NormActFn(torch.autograd.Function):
@@ -620,8 +642,8 @@ class NormActFn(torch.autograd.Function):
   gradient penalty).  With (gamma2, beta2, split) images [split, n) use the second domain's parameters."""
 
   @staticmethod
-  def forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema):
-    return _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema)
+  def forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema, stats):
+    return _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema, stats)
 
   @staticmethod
   @torch.autograd.function.once_differentiable
@@ -635,8 +657,8 @@ class NormActPoolFn(torch.autograd.Function):
   (and the sum of the two) into the normalisation backward kernel."""
 
   @staticmethod
-  def forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema):
-    z = _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema)
+  def forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema, stats):
+    z = _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema, stats)
     n, h, w, c = z.shape
     zp = torch.empty((n, h // 2, w // 2, c), dtype=z.dtype, device=z.device)
     call('tg_pool2x2_fwd', _p(z), _p(zp), n, h, w, c, 0.25, _dt(z), _stream(),
@@ -648,18 +670,20 @@ class NormActPoolFn(torch.autograd.Function):
   @torch.autograd.function.once_differentiable
   def backward(ctx, gz, gzp):
     if gz is None and gzp is None:
-      return (None,) * 11
+      return (None,) * 12
     return _norm_act_backward(ctx, gz, gzp) + (None,)
 
 
 def norm_act(y, gamma, beta, lrelu=True, pixel_norm=True, in_eps=1e-6, pn_eps=1e-6, alpha=LRELU_ALPHA, gamma2=None,
-             beta2=None, split=None, pool=False, ema=None):
+             beta2=None, split=None, pool=False, ema=None, stats=None):
   """Statistics are per leading index of ``y`` (instance norm: one image; batch norm: the caller passes the view
   [passes, B*H, W, C] so that each batched pass is one statistic group).  ``pool``: also return the 2x2
-  average-pooled output -> (z, z_pooled).  ``ema``: (decay, [(moving_mean, moving_var) per domain]) to update."""
+  average-pooled output -> (z, z_pooled).  ``ema``: (decay, [(moving_mean, moving_var) per domain]) to update.
+  Batch renorm: ``gamma`` / ``beta`` are [n, c] (one effective r*gamma, d*gamma+beta row per statistic group,
+  ordinary differentiable tensors) and ``stats`` = instance_stats(y, eps) computed by the caller."""
   flags = (NF_LRELU if lrelu else 0) | (NF_PIXNORM if pixel_norm else 0)
   fn = NormActPoolFn if pool else NormActFn
-  return fn.apply(y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema)
+  return fn.apply(y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema, stats)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -53,6 +53,7 @@ class ParamStore:
     self.state_specs = OrderedDict()   # name -> (numel, init value): non-trainable variables
     self.state = {}
     self.weights_init_stddev = 0.02    # 1.0 under equalized_learning_rate (nets/pggan_utils.py:82-84, pggan.py:364)
+    self.renorm = False                # generator_norm_type=batch_renorm: extra non-trainable renorm_* variables
 
   # ---- declaration ----------------------------------------------------------------------------
   def add(self, name, shape, group, kind, phys=None):
@@ -69,6 +70,11 @@ class ParamStore:
       if norm_scope == 'BatchNorm':      # non-trainable moving statistics (libs/batch_norm.py:184-196)
         self.state_specs['%s/BatchNorm/moving_mean_%s' % (scope, d)] = (cout, 0.0)
         self.state_specs['%s/BatchNorm/moving_variance_%s' % (scope, d)] = (cout, 1.0)
+        if self.renorm:                  # batch renorm training statistics (libs/batch_norm.py:209-246), zero-initialised
+          self.state_specs['%s/BatchNorm/renorm_mean_%s' % (scope, d)] = (cout, 0.0)
+          self.state_specs['%s/BatchNorm/renorm_mean_weight_%s' % (scope, d)] = (1, 0.0)
+          self.state_specs['%s/BatchNorm/renorm_stddev_%s' % (scope, d)] = (cout, 0.0)
+          self.state_specs['%s/BatchNorm/renorm_stddev_weight_%s' % (scope, d)] = (1, 0.0)
 
   # ---- allocation -----------------------------------------------------------------------------
   def build(self, seed=0):
@@ -96,6 +102,9 @@ class ParamStore:
         PackCache.register(p)
     for name, (n, init) in self.state_specs.items():
       self.state[name] = torch.full((n,), init, dtype=torch.float32, device=self.device)
+    if self.renorm:      # clipping bounds of the current global step (nets/pggan_utils.py:207-223), set by the trainer
+      for k, v in (('renorm/rmax', 1.1), ('renorm/rmin', 0.9), ('renorm/dmax', 0.1)):
+        self.state[k] = torch.full((1,), v, dtype=torch.float32, device=self.device)
     self.P.state = self.state
     PackCache.version += 1
     return self
@@ -164,7 +173,8 @@ def declare_twingan(store, cfg):
   SURVEY.md Appendix A; nets/pggan.py:93-211,242-376,403-479)."""
   hw, mc = cfg.hw, cfg.max_ch
   ms = max_stage_of(hw)
-  NORM_SCOPE = {'instance_norm': 'InstanceNorm', 'batch_norm': 'BatchNorm'}
+  NORM_SCOPE = {'instance_norm': 'InstanceNorm', 'batch_norm': 'BatchNorm', 'batch_renorm': 'BatchNorm'}
+  store.renorm = cfg.generator_norm_type == 'batch_renorm'
   if cfg.generator_norm_type not in NORM_SCOPE:
     raise NotImplementedError('generator_norm_type=%s' % cfg.generator_norm_type)
   nd = ('s', 't')

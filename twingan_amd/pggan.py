@@ -55,8 +55,8 @@ def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pix
   else:
     y = ops.conv2d(x, w, None, k, padding)
   nt = cfg.generator_norm_type
-  if nt not in ('instance_norm', 'batch_norm'):
-    raise NotImplementedError('generator_norm_type=%s (instance_norm and batch_norm are built)' % nt)
+  if nt not in ('instance_norm', 'batch_norm', 'batch_renorm'):
+    raise NotImplementedError('generator_norm_type=%s (instance_norm, batch_norm and batch_renorm are built)' % nt)
   ns = 'InstanceNorm' if nt == 'instance_norm' else 'BatchNorm'
   if isinstance(domain, tuple):
     d0, d1, split = domain[:3]
@@ -76,6 +76,12 @@ def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pix
   assert n % passes == 0 and (split is None or (split * passes) % n == 0)
   yv = y.view(passes, (n // passes) * h, w, c)
   st = P.state if hasattr(P, 'state') else None
+  if nt == 'batch_renorm':
+    out = _batch_renorm(P, scope, yv, (d0, d1, None if split is None else split * passes // n, passes), activation, pn,
+                        pool)
+    if pool:
+      return out[0].view(n, h, w, c), out[1].view(n, h // 2, w // 2, c)
+    return out.view(n, h, w, c)
   ema = None
   if st is not None:
     pairs = [(st['%s/BatchNorm/moving_mean_%s' % (scope, d)], st['%s/BatchNorm/moving_variance_%s' % (scope, d)])
@@ -86,6 +92,54 @@ def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pix
   if pool:
     return out[0].view(n, h, w, c), out[1].view(n, h // 2, w // 2, c)
   return out.view(n, h, w, c)
+
+
+BN_EPS = 1e-3            # libs/batch_norm.py:48
+RENORM_MOMENTUM = 0.99   # libs/batch_norm.py:62; the moving averages use the same decay (nets/pggan_utils.py:163)
+
+
+def _batch_renorm(P, scope, yv, domain, activation, pn, pool):
+  """conditional_batch_norm(renorm=True) in training mode (libs/batch_norm.py:209-246,329-470), for yv =
+  [passes, B*H, W, C] where pass i belongs to domain d0 (i < split) or d1.  Per pass, in call order:
+    stddev = sqrt(var + eps);  r = clip(stddev / mixed_stddev),  d = clip((mean - mixed_mean) / mixed_stddev)
+    with mixed_x = renorm_x + (1 - renorm_x_weight) * batch_x  (pre-update values, stop-gradient),
+    out = x_hat * (r * gamma) + (d * gamma + beta);  then renorm_mean / renorm_stddev (+ weights) and the moving
+    mean / variance (of the unbiased renorm values) are updated with momentum 0.99.
+  The reference applies the passes' update ops in unspecified order within one session.run; here (and in the
+  oracle) passes update the state sequentially.  The per-channel state arithmetic is a handful of tiny tensor ops;
+  the normalisation itself is the fused kernel with one parameter row per pass."""
+  import torch
+  d0, d1, split, passes = domain
+  st = P.state
+  mean, rstd = ops.instance_stats(yv, BN_EPS)
+  c = yv.shape[3]
+  mean_p, rstd_p = mean.view(passes, c), rstd.view(passes, c)
+  rmax, rmin, dmax = st['renorm/rmax'], st['renorm/rmin'], st['renorm/dmax']
+  g_rows, b_rows = [], []
+  m = RENORM_MOMENTUM
+  for i in range(passes):
+    d = d0 if (split is None or i < split) else d1
+    pre = '%s/BatchNorm/' % scope
+    gamma, beta = P[pre + 'gamma_' + d], P[pre + 'beta_' + d]
+    with torch.no_grad():
+      bmean, stddev = mean_p[i], 1.0 / rstd_p[i]
+      rm, rmw = st[pre + 'renorm_mean_' + d], st[pre + 'renorm_mean_weight_' + d]
+      rs, rsw = st[pre + 'renorm_stddev_' + d], st[pre + 'renorm_stddev_weight_' + d]
+      mixed_mean = rm + (1.0 - rmw) * bmean
+      mixed_std = rs + (1.0 - rsw) * stddev
+      r = torch.minimum(torch.maximum(stddev / mixed_std, rmin), rmax)
+      dd = torch.minimum(torch.maximum((bmean - mixed_mean) / mixed_std, -dmax), dmax)
+      rm.mul_(m).add_(bmean, alpha=1.0 - m)
+      rmw.mul_(m).add_(1.0 - m)
+      rs.mul_(m).add_(stddev, alpha=1.0 - m)
+      rsw.mul_(m).add_(1.0 - m)
+      new_mean, new_std = rm / rmw, rs / rsw
+      st[pre + 'moving_mean_' + d].mul_(m).add_(new_mean, alpha=1.0 - m)
+      st[pre + 'moving_variance_' + d].mul_(m).add_(new_std * new_std - BN_EPS, alpha=1.0 - m)
+    g_rows.append(r * gamma)
+    b_rows.append(dd * gamma + beta)
+  return ops.norm_act(yv, torch.stack(g_rows), torch.stack(b_rows), lrelu=activation, pixel_norm=pn, in_eps=BN_EPS,
+                      pool=pool, stats=(mean, rstd))
 
 
 def _d_conv(P, scope, x, cfg, k=3, padding='SAME', pool=False, in_ch=None):

@@ -218,6 +218,16 @@ def _d_domain_gp(P, cfg, terms, d, top, real, prime, a, noise=None):
   terms['discriminator_gradient_penalty_prime_' + d] = ops.gradient_penalty(gi.contiguous(), cfg.gradient_penalty_lambda)
 
 
+BATCH_RENORM_BOUNDARIES = (10000, 20000, 30000)                      # nets/pggan_utils.py:43-47
+BATCH_RENORM_RMAX, BATCH_RENORM_RMIN, BATCH_RENORM_DMAX = (1.1, 1.5, 2.0, 4.0), (0.9, 0.66, 0.5, 0.25), (0.1, 0.3, 0.5, 1.0)
+
+
+def renorm_clipping(global_step):
+  """tf.train.piecewise_constant over BATCH_RENORM_BOUNDARIES: value i while step <= boundary i, the last one after."""
+  i = sum(1 for b in BATCH_RENORM_BOUNDARIES if global_step > b)
+  return BATCH_RENORM_RMAX[i], BATCH_RENORM_RMIN[i], BATCH_RENORM_DMAX[i]
+
+
 class Trainer:
   """One data-parallel clone: parameters, Adam state and the alternating step.
 
@@ -362,6 +372,8 @@ class Trainer:
     """One ``session.run(train_op)`` of the reference (image_generation.py:640-652):
     n_critic_counter % n_critic == 0 -> generator/encoder apply, else discriminator apply."""
     is_g = self.n_critic_counter % self.cfg.n_critic == 0
+    if self.cfg.generator_norm_type == 'batch_renorm':
+      self._set_renorm_clipping()
     if self.use_graph:
       assert gp_alpha_s is None and gp_alpha_t is None, 'graph mode draws the GP alphas on the device'
       out = self._run_graph('g' if is_g else 'd', sources, targets)
@@ -373,6 +385,17 @@ class Trainer:
       self.global_step += 1
     self.n_critic_counter += 1
     return out
+
+  def _set_renorm_clipping(self):
+    """get_renorm_clipping_params (nets/pggan_utils.py:40-50,207-223): rmax / rmin / dmax are piecewise constant in the
+    global step.  They live in device scalars so a captured graph picks up the current values."""
+    rmax, rmin, dmax = renorm_clipping(self.global_step)
+    if getattr(self, '_renorm_clip', None) != (rmax, rmin, dmax):
+      self._renorm_clip = (rmax, rmin, dmax)
+      st = self.store.state
+      st['renorm/rmax'].fill_(rmax)
+      st['renorm/rmin'].fill_(rmin)
+      st['renorm/dmax'].fill_(dmax)
 
   def _set_requires_grad(self, g, d):
     for name, s in self.store.specs.items():
