@@ -43,6 +43,11 @@ class Config:
   lrelu: float = 0.2                 # util_misc.py:68
   bn_state: object = None            # dict collecting the BatchNorm moving (and renorm) statistics when set
   global_step: int = 0               # batch renorm clipping schedule (nets/pggan_utils.py:207-223)
+  spectral_norm: bool = False        # nets/pggan.py:28-30 (discriminator convs; libs/sn.py:38-101)
+  sn_state: object = None            # dict scope -> u [1, cout] (libs/sn.py:56-57); updated by end_run()
+  sn_cache: object = None            # per-run normalised kernels: every use in a run sees the pre-run u
+  do_self_attention: bool = False    # image_generation.py:62-64
+  self_attention_hw: int = 64        # image_generation.py:65-67
   equalized: bool = False            # equalized_learning_rate           (nets/pggan.py:40; pggan_utils.py:236-254)
   res_block: bool = False            # use_res_block                     (nets/pggan.py:44; pggan_utils.py:257-264,334-342)
 
@@ -162,6 +167,25 @@ def init_params(cfg, seed=0, dtype=torch.float32, std=0.02):
         torch.randn(cfg.max_ch, 1, generator=g, dtype=torch.float32).to(dtype) * \
         (math.sqrt(1.0 / cfg.max_ch) if std == 'he' else std)
     P[top + '/prediction/fully_connected/biases'] = torch.zeros(1, dtype=dtype)
+  if cfg.do_self_attention:      # libs/self_attention.py:24-70 under each network's arg-scope; sa_gamma starts at 0
+    ms = max_stage_of(cfg.hw)
+    nd = ('s', 't') if cfg.norm in NORM_SCOPE else ()
+
+    def att(top, hw_, c_, name_c, bias, domains):
+      if hw_ != cfg.self_attention_hw:
+        return
+      sc = '%s/self_attention_%dx%dx%d' % (top, hw_, hw_, name_c)
+      for nm, co in (('sa_f', c_ // 8), ('sa_g', c_ // 8), ('sa_h', c_)):
+        _conv_p(P, g, '%s/%s' % (sc, nm), 1, c_, co, domains, bias, dtype, std, NORM_SCOPE.get(cfg.norm, ''))
+      P[sc + '/sa_gamma'] = torch.zeros(1, dtype=dtype)
+
+    for top, bias, domains in (('encoder_content', False, nd), ('discriminator_s', True, ()), ('discriminator_t', True, ())):
+      c = get_num_channels(ms, cfg.max_ch)
+      for stage in range(ms, 0, -1):
+        att(top, cfg.hw // (2 ** (ms - stage)), c, get_num_channels(stage - 1, cfg.max_ch), bias, domains)
+        c = get_num_channels(stage - 1, cfg.max_ch)
+    for stage in range(0, ms + 1):
+      att('generator', 2 ** (stage + 2), get_num_channels(stage, cfg.max_ch), get_num_channels(stage, cfg.max_ch), False, nd)
   if cfg.res_block:      # after everything else so the other variables keep their seeded values
     ge = encoder_param_specs('encoder_content', cfg.hw, cfg.max_ch, cfg.is_growing) + \
         generator_param_specs('generator', cfg.hw, cfg.max_ch, cfg.use_unet, cfg.is_growing)
@@ -175,6 +199,8 @@ def init_params(cfg, seed=0, dtype=torch.float32, std=0.02):
         P[k] = (torch.randn(P[k].shape, generator=g, dtype=torch.float32) * 0.1).to(dtype)
       elif '/gamma_' in k:
         P[k] = (1.0 + torch.randn(P[k].shape, generator=g, dtype=torch.float32) * 0.1).to(dtype)
+      elif k.endswith('/sa_gamma'):
+        P[k] = (0.5 + torch.randn(P[k].shape, generator=g, dtype=torch.float32) * 0.1).to(dtype)
   return P
 
 
@@ -320,14 +346,90 @@ def resblock(P, blk, input_layer, out_channels, conv_out, cfg):
     return conv_out
   if input_layer.shape[-1] == out_channels:
     return input_layer + conv_out
-  sc = conv2d(equalize(input_layer, cfg, 1), P[blk + '/shortcut/weights'], 'SAME') + P[blk + '/shortcut/biases']
+  w = spectral_normed_weight(P, blk + '/shortcut', cfg) if blk.startswith('discriminator') else P[blk + '/shortcut/weights']
+  sc = conv2d(equalize(input_layer, cfg, 1), w, 'SAME') + P[blk + '/shortcut/biases']
   return sc + conv_out
 
 
-def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=True):
+def l2_normalize(x):
+  """tf.nn.l2_normalize over all elements (epsilon 1e-12 under the square root's argument)."""
+  return x / x.pow(2).sum().clamp_min(1e-12).sqrt()
+
+
+def spectral_normed_weight(P, scope, cfg):
+  """libs/sn.py:38-101 with num_iters=1: v = l2n(u W^T), u' = l2n(v W), sigma = v W u'^T, W_bar = W / sigma; the
+  gradient flows through v, u' and sigma.  The reference assigns u at every use of W in unspecified order within a
+  session.run; this restatement fixes the schedule "every use in a run reads the pre-run u" (see end_run)."""
+  w = P[scope + '/weights']
+  if not cfg.spectral_norm:
+    return w
+  if cfg.sn_cache is None:
+    cfg.sn_cache = {}
+  if scope in cfg.sn_cache:
+    return cfg.sn_cache[scope][0]
+  u = cfg.sn_state[scope + '/u'].to(w.dtype)
+  w2 = w.reshape(-1, w.shape[-1])
+  v = l2_normalize(u @ w2.t())
+  u1 = l2_normalize(v @ w2)
+  sigma = (v @ w2 @ u1.t()).reshape(())
+  w_bar = (w2 / sigma).reshape(w.shape)
+  cfg.sn_cache[scope] = (w_bar, u1.detach())
+  return w_bar
+
+
+def end_run(cfg):
+  """The tf.assign(u, u_final) of libs/sn.py:84-86 for every kernel used in this run."""
+  if cfg.sn_cache:
+    for scope, (_, u1) in cfg.sn_cache.items():
+      cfg.sn_state[scope + '/u'] = u1.clone()
+    cfg.sn_cache.clear()
+
+
+def init_sn_state(P, seed=0):
+  """u ~ truncated normal [1, cout] for every discriminator conv kernel (libs/sn.py:56-57); the attention convs and
+  the fully connected layer are not spectrally normed (libs/self_attention.py:33-58; libs/ops.py:37-40)."""
+  g = torch.Generator().manual_seed(seed)
+  st = {}
+  for k in sorted(P):
+    if k.startswith('discriminator') and k.endswith('/weights') and P[k].dim() == 4 and '/self_attention_' not in k:
+      t = torch.empty(1, P[k].shape[-1], dtype=torch.float32)
+      torch.nn.init.trunc_normal_(t, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=g)
+      st[k[:-len('/weights')] + '/u'] = t.double()
+  return st
+
+
+def self_attention(P, sc, layer, domain, cfg, is_discriminator):
+  """libs/self_attention.py:24-70."""
+  n, hh, ww, c = layer.shape
+  outs = []
+  for nm in ('sa_f', 'sa_g', 'sa_h'):
+    scope = '%s/%s' % (sc, nm)
+    if is_discriminator:
+      y = conv2d(layer, P[scope + '/weights'], 'SAME') + P[scope + '/biases']
+    else:
+      y = ge_conv(P, scope, layer, domain, cfg, k=1, act=False, pixnorm=False, equalized=False)
+    outs.append(torch.tanh(y) if nm != 'sa_h' else y)
+  f, g, h = outs
+  npos = hh * ww
+  s_ = torch.bmm(f.reshape(n, npos, -1), g.reshape(n, npos, -1).transpose(1, 2))
+  beta = torch.softmax(s_, dim=-1)
+  o = torch.bmm(beta, h.reshape(n, npos, c)).reshape(layer.shape)
+  return P[sc + '/sa_gamma'] * o + layer
+
+
+def maybe_self_attention(P, top, hw, name_c, net, ep, domain, cfg, is_discriminator=False):
+  """nets/pggan_utils.py:301-308."""
+  if cfg.do_self_attention and hw == cfg.self_attention_hw:
+    name = 'self_attention_%dx%dx%d' % (hw, hw, name_c)
+    net = self_attention(P, '%s/%s' % (top, name), net, domain, cfg, is_discriminator)
+    ep[name] = net
+  return net
+
+
+def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=True, equalized=True):
   """Generator/encoder conv: no bias (a normalizer is set), per-domain instance norm,
   LeakyReLU, optional pixel norm (nets/pggan.py:78-81,387-391)."""
-  y = conv2d(equalize(x, cfg, k), P[scope + '/weights'], padding)
+  y = conv2d(equalize(x, cfg, k) if equalized else x, P[scope + '/weights'], padding)
   if cfg.norm == 'instance_norm':
     y = instance_norm(y, P[scope + '/InstanceNorm/gamma_' + domain], P[scope + '/InstanceNorm/beta_' + domain],
                       cfg.in_eps)
@@ -352,7 +454,7 @@ def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=Tru
 
 def d_conv(P, scope, x, cfg, k=3, padding='SAME'):
   """Discriminator conv: bias, no norm, LeakyReLU (nets/pggan_utils.py:116; slim bias rule)."""
-  y = conv2d(equalize(x, cfg, k), P[scope + '/weights'], padding) + P[scope + '/biases']
+  y = conv2d(equalize(x, cfg, k), spectral_normed_weight(P, scope, cfg), padding) + P[scope + '/biases']
   return leaky_relu(y, cfg.lrelu)
 
 
@@ -379,6 +481,7 @@ def encoder(P, x, domain, cfg, top='encoder_content'):
   for stage in range(ms, 0, -1):
     nc = get_num_channels(stage - 1, cfg.max_ch)
     cur = hw // (2 ** (ms - stage))
+    net = maybe_self_attention(P, top, cur, nc, net, ep, domain, cfg)
     name = 'encoder_block_%dx%dx%d' % (cur, cur, nc)
     blk_in = net
     net = ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg)
@@ -437,6 +540,7 @@ def generator(P, source, domain, cfg, unet_ep=None, top='generator'):
       net = ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg)
       net = resblock(P, '%s/%s' % (top, name), blk_in, oc, net, cfg)
     ep[name] = net
+    net = maybe_self_attention(P, top, hw, oc, net, ep, domain, cfg)      # nets/pggan.py:188-190
   rgb = 'generator_to_rgb_%dx%d' % (hw, hw)
   to_rgb = ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=1, act=False, pixnorm=False)
   if cfg.is_growing:
@@ -467,6 +571,7 @@ def discriminator(P, x, cfg, top):
   for stage in range(ms, 0, -1):
     nc = get_num_channels(stage - 1, cfg.max_ch)
     cur = hw // (2 ** (ms - stage))
+    net = maybe_self_attention(P, top, cur, nc, net, ep, None, cfg, True)   # nets/pggan.py:294-296
     name = 'encoder_block_%dx%dx%d' % (cur, cur, nc)
     blk_in = net
     net = d_conv(P, '%s/%s/Conv' % (top, name), net, cfg)

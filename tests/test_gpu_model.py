@@ -27,7 +27,9 @@ def make(cfg_kw, precision, seed=0, batch=3):
   from twingan_amd.twingan import Trainer
   cfg = Config(precision=precision, **cfg_kw)
   rcfg = R.Config(hw=cfg.hw, max_ch=cfg.max_ch, is_growing=cfg.is_growing, alpha_grow=cfg.alpha_grow,
-                  use_unet=cfg.use_unet, equalized=cfg.equalized_learning_rate, res_block=cfg.use_res_block)
+                  use_unet=cfg.use_unet, equalized=cfg.equalized_learning_rate, res_block=cfg.use_res_block,
+                  spectral_norm=cfg.spectral_norm, do_self_attention=cfg.do_self_attention,
+                  self_attention_hw=cfg.self_attention_hw, loss=cfg.loss_architecture)
   Pref = R.init_params(rcfg, seed=seed, dtype=torch.float64, std='he')
   tr = Trainer(cfg, device='cuda:0', seed=seed)
   tr.store.load_state_dict({k: v.float() for k, v in Pref.items()})
@@ -484,3 +486,67 @@ def test_batch_renorm_generator_matches_oracle(global_step):
   for k, v in state.items():
     a = renorm_state[k].double().cpu().numpy()
     assert np.abs(a - v.numpy()).max() < 2e-5 * max(1.0, np.abs(v.numpy()).max()), k
+
+
+@pytest.mark.parametrize('loss', ['hinge', 'wgan_gp'])
+def test_spectral_norm_and_self_attention(loss):
+  """SURVEY config 4: --spectral_norm on the discriminator convs (libs/sn.py:38-101, gradient through sigma, u assigned
+  once per run) and --do_self_attention in E / G / D (libs/self_attention.py:24-70), against the oracle: losses,
+  gradients (under wgan_gp also the double backward through the normalised kernels and the attention), and the
+  power-iteration state after each run."""
+  from twingan_amd import pggan
+  from twingan_amd import twingan as T
+  kw = dict(hw=32, max_ch=32, spectral_norm=True, do_self_attention=True, self_attention_hw=16, loss_architecture=loss)
+  cfg, rcfg, tr, Pref, dev, ref = make(kw, 'fp32', seed=6, batch=2)
+  assert set(tr.store.state_dict()) == set(Pref)
+  rcfg.sn_state = R.init_sn_state(Pref, seed=3)
+  assert set(rcfg.sn_state) == set(tr.store.state)
+  for k, v in rcfg.sn_state.items():
+    tr.store.state[k].copy_(v.float())
+    rcfg.sn_state[k] = v.float().double()
+  for v in Pref.values():
+    v.requires_grad_(True)
+  for it in range(2):
+    for v in Pref.values():
+      v.grad = None
+    tr.store.zero_grad('g')
+    tr._set_requires_grad(g=True, d=False)
+    gl, gterms = T.generator_loss(tr.P, dev['s'], dev['t'], cfg)
+    rgl, rterms = R.generator_loss(Pref, ref['s'], ref['t'], rcfg)
+    for k in rterms:
+      assert abs(gterms[k].item() - rterms[k].item()) < 1e-4 * max(1.0, abs(rterms[k].item())), (it, k)
+    gl.backward()
+    rgl.backward()
+    pggan.end_run(tr.P)
+    R.end_run(rcfg)
+    _grads_close(tr, Pref, tr.store.names('g'), 8e-2, 'generator run %d' % it)
+    for v in Pref.values():
+      v.grad = None
+    tr.store.zero_grad('d')
+    tr._set_requires_grad(g=False, d=True)
+    dl, dterms = T.discriminator_loss(tr.P, dev['s'], dev['t'], cfg, dev['a_s'], dev['a_t'])
+    rdl, rdterms = R.discriminator_loss(Pref, ref['s'], ref['t'], rcfg, ref['a_s'], ref['a_t'])
+    for k in rdterms:
+      assert abs(dterms[k].item() - rdterms[k].item()) < 1e-4 * max(1.0, abs(rdterms[k].item())), (it, k)
+    dl.backward()
+    rdl.backward()
+    pggan.end_run(tr.P)
+    R.end_run(rcfg)
+    _grads_close(tr, Pref, tr.store.names('d'), 8e-2, 'discriminator run %d' % it)
+    for k, v in rcfg.sn_state.items():
+      assert rel_l2(tr.store.state[k], v) < 1e-4, (it, k)
+
+
+def test_spectral_norm_attention_bf16_graph_step_runs():
+  from twingan_amd import Config
+  from twingan_amd.twingan import Trainer
+  cfg = Config(hw=32, max_ch=64, spectral_norm=True, do_self_attention=True, self_attention_hw=16, loss_architecture='hinge')
+  tr = Trainer(cfg, device='cuda:0', seed=1, use_graph=True)
+  g = torch.Generator().manual_seed(3)
+  s = torch.rand(4, 32, 32, 3, generator=g).to('cuda:0').bfloat16()
+  t = torch.rand(4, 32, 32, 3, generator=g).to('cuda:0').bfloat16()
+  u0 = tr.store.state['discriminator_s/from_rgb_32x32/Conv/u'].clone()
+  for _ in range(6):
+    loss, terms = tr.run(s, t)
+    assert np.isfinite(float(loss)) and all(np.isfinite(float(v)) for v in terms.values())
+  assert float((tr.store.state['discriminator_s/from_rgb_32x32/Conv/u'] - u0).abs().max()) > 0

@@ -13,6 +13,10 @@ class Config:
   use_unet: bool = True               # twingan.py:53-56
   equalized_learning_rate: bool = False   # nets/pggan.py:39-41; nets/pggan_utils.py:82-84,236-254
   use_res_block: bool = False         # nets/pggan.py:43-46; nets/pggan_utils.py:257-264,334-342
+  spectral_norm: bool = False         # nets/pggan.py:28-30; libs/sn.py:38-101 (discriminator convs)
+  spectral_norm_in_non_discriminator: bool = False   # nets/pggan.py:31-33
+  do_self_attention: bool = False     # image_generation.py:62-64; libs/self_attention.py:24-70
+  self_attention_hw: int = 64         # image_generation.py:65-67
   is_growing: bool = False            # image_generation.py:69-72
   alpha_grow: float = 0.0             # twingan.py:833-835
   loss_architecture: str = 'wgan_gp'  # image_generation.py:81-83

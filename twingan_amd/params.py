@@ -101,7 +101,13 @@ class ParamStore:
       if s['kind'] == 'conv_w':
         PackCache.register(p)
     for name, (n, init) in self.state_specs.items():
-      self.state[name] = torch.full((n,), init, dtype=torch.float32, device=self.device)
+      if init == 'trunc_normal':      # tf.truncated_normal_initializer(): N(0,1) redrawn outside 2 sigma
+        t = torch.empty(n, dtype=torch.float32)
+        torch.nn.init.trunc_normal_(t, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=gen)
+        self.state[name] = t.to(self.device)
+      else:
+        self.state[name] = torch.full((n,) if isinstance(n, int) else tuple(n), init, dtype=torch.float32,
+                                      device=self.device)
     if self.renorm:      # clipping bounds of the current global step (nets/pggan_utils.py:207-223), set by the trainer
       for k, v in (('renorm/rmax', 1.1), ('renorm/rmin', 0.9), ('renorm/dmax', 0.1)):
         self.state[k] = torch.full((1,), v, dtype=torch.float32, device=self.device)
@@ -182,6 +188,30 @@ def declare_twingan(store, cfg):
   if cfg.equalized_learning_rate:
     store.weights_init_stddev = 1.0
 
+  def sn_state(scope, cout, is_disc):
+    """--spectral_norm: the power-iteration vector 'u' [1, cout] of a conv (libs/sn.py:56-57, truncated normal)."""
+    if cfg.spectral_norm and (is_disc or cfg.spectral_norm_in_non_discriminator):
+      store.state_specs[scope + '/u'] = ((1, cout), 'trunc_normal')
+
+  _add_conv = store.add_conv
+
+  def add_conv(scope, k, cin, cout, group, bias, norm_domains, **kw):
+    _add_conv(scope, k, cin, cout, group, bias, norm_domains, **kw)
+    sn_state(scope, cout, group == 'd')
+
+  store.add_conv = add_conv
+
+  def attention(top, hw_, c_, name_c, group, bias, norm_domains):
+    """--do_self_attention: sa_f / sa_g (c -> c/8), sa_h (c -> c) 1x1 convs under the scope's arg-scope (normaliser
+    in G/E, bias in D) and the scalar sa_gamma (libs/self_attention.py:24-70; nets/pggan_utils.py:301-308).  They go
+    through libs.sn.convolution with do_spec_norm False: never spectrally normed."""
+    if not (cfg.do_self_attention and hw_ == cfg.self_attention_hw):
+      return
+    sc = '%s/self_attention_%dx%dx%d' % (top, hw_, hw_, name_c)
+    for nm, co in (('sa_f', c_ // 8), ('sa_g', c_ // 8), ('sa_h', c_)):
+      _add_conv('%s/%s' % (sc, nm), 1, c_, co, group, bias, norm_domains, norm_scope=ns)
+    store.add(sc + '/sa_gamma', (1,), group, 'beta')
+
   def shortcut(blk, cin, cout, group):
     """--use_res_block: 1x1 'shortcut' conv (+bias, no norm) where a block changes the channel count
     (nets/pggan_utils.py:334-342)."""
@@ -199,6 +229,7 @@ def declare_twingan(store, cfg):
     for stage in range(ms, 0, -1):
       cur = hw // (2 ** (ms - stage))
       nc = get_num_channels(stage - 1, mc)
+      attention(top, cur, c, nc, group, bias, norm_domains)
       blk = '%s/encoder_block_%dx%dx%d' % (top, cur, cur, nc)
       store.add_conv(blk + '/Conv', 3, c, c, group, bias, norm_domains, norm_scope=ns)
       store.add_conv(blk + '/Conv_1', 3, c, nc, group, bias, norm_domains, norm_scope=ns)
@@ -211,6 +242,7 @@ def declare_twingan(store, cfg):
   blk = 'generator/block_4x4x%d' % c
   store.add_conv(blk + '/Conv', 3, c, c, 'g', False, nd, norm_scope=ns)
   store.add_conv(blk + '/Conv_1', 3, c, c, 'g', False, nd, norm_scope=ns)
+  attention('generator', 4, c, c, 'g', False, nd)
   for stage in range(1, ms + 1):
     cur = 2 ** (stage + 2)
     oc = get_num_channels(stage, mc)
@@ -221,6 +253,7 @@ def declare_twingan(store, cfg):
     store.add_conv(blk + '/Conv', 3, cin, oc, 'g', False, nd, norm_scope=ns)
     store.add_conv(blk + '/Conv_1', 3, oc, oc, 'g', False, nd, norm_scope=ns)
     shortcut(blk, cin, oc, 'g')
+    attention('generator', cur, oc, oc, 'g', False, nd)
     c = oc
   store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (hw, hw), 1, c, 3, 'g', False, nd, norm_scope=ns)
   # discriminators
@@ -231,4 +264,5 @@ def declare_twingan(store, cfg):
     store.add_conv(blk + '/Conv_1', 4, mc, mc, 'd', True, ())
     store.add(top + '/prediction/fully_connected/weights', (mc, 1), 'd', 'fc_w')
     store.add(top + '/prediction/fully_connected/biases', (1,), 'd', 'bias')
+  store.add_conv = _add_conv
   return store

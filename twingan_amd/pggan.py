@@ -26,30 +26,109 @@ def _equalize(x, cfg, k, in_ch=None):
   return ops.scale(x, math.sqrt(2.0 / ((in_ch or x.shape[-1]) * k * k)))
 
 
+def _l2_normalize(x):
+  """tf.nn.l2_normalize over all elements: x / sqrt(max(sum(x^2), 1e-12))."""
+  return x / x.pow(2).sum().clamp_min(1e-12).sqrt()
+
+
+def _sn(P, scope, cfg, is_discriminator):
+  """The conv kernel of ``scope``, spectrally normalised when --spectral_norm applies to it
+  (nets/pggan_utils.py:316-320; libs/sn.py:38-101): one power iteration from the persistent vector u,
+      v = l2n(u W^T),  u' = l2n(v W),  sigma = v W u'^T,  W_bar = W / sigma      (W = kernel as [k*k*cin, cout])
+  with the gradient flowing through sigma, v and u' (the reference does not stop it).  The reference re-runs the
+  iteration and assigns u at EVERY use of the kernel inside one session.run, in unspecified order; here every use in
+  a run sees the pre-run u (one valid schedule of those unordered assigns) and u is assigned once, by end_run().
+  The iteration is a few matrix-vector products on the fp32 master weight: plain tensor ops, differentiable twice."""
+  w = P[scope + '/weights']
+  if not (cfg.spectral_norm and (is_discriminator or cfg.spectral_norm_in_non_discriminator)):
+    return w
+  cache = P.__dict__.setdefault('sn_cache', {})
+  if scope in cache:
+    return cache[scope]
+  u = P.state[scope + '/u']
+  w2 = w.reshape(-1, w.shape[-1])
+  v = _l2_normalize(u @ w2.t())
+  u1 = _l2_normalize(v @ w2)
+  sigma = (v @ w2 @ u1.t()).reshape(())
+  w_bar = (w2 / sigma).reshape(w.shape)
+  P.__dict__.setdefault('sn_pending', {})[scope + '/u'] = u1.detach()
+  cache[scope] = w_bar
+  return w_bar
+
+
+def end_run(P):
+  """End of one session.run equivalent: assign the power-iteration vectors (libs/sn.py:84-86) and drop the
+  per-run normalised kernels."""
+  pending = P.__dict__.get('sn_pending')
+  if pending:
+    for k, v in pending.items():
+      P.state[k].copy_(v)
+    pending.clear()
+  cache = P.__dict__.get('sn_cache')
+  if cache:
+    cache.clear()
+
+
+def self_attention_layer(P, sc, layer, domain, cfg, is_discriminator):
+  """libs/self_attention.py:24-70 (SAGAN): f, g = tanh(conv1x1 -> c/8), h = conv1x1 -> c under the scope's arg-scope
+  (bias in D; the generator normaliser, no bias, in G / E -- nets/pggan_utils.py:86-98), s = f g^T over the h*w
+  positions, beta = softmax(s), o = beta h, y = sa_gamma * o + layer.  The two batched matrix products run on the
+  library GEMM and the softmax on the framework kernel (config-5-only path; a fused MFMA attention kernel is the
+  next step for it); everything is differentiable twice (the discriminator sits under the gradient penalty)."""
+  import torch
+  n, hh, ww, c = layer.shape
+  outs = []
+  for nm in ('sa_f', 'sa_g', 'sa_h'):
+    scope = '%s/%s' % (sc, nm)
+    if is_discriminator:
+      w, b = P[scope + '/weights'], P[scope + '/biases']
+      y = ops.conv2d(layer, w, b, 1, 'SAME')      # libs.sn.convolution directly: no equalized-lr input scaling
+    else:
+      y = _ge_conv(P, scope, layer, domain, cfg, k=1, activation=False, pixel_norm=False, equalize=False)
+    outs.append(torch.tanh(y) if nm != 'sa_h' else y)
+  f, g, h = outs
+  npos = hh * ww
+  s = torch.bmm(f.reshape(n, npos, -1), g.reshape(n, npos, -1).transpose(1, 2))
+  beta = torch.softmax(s.float(), dim=-1).to(s.dtype)
+  o = torch.bmm(beta, h.reshape(n, npos, c)).reshape(layer.shape)
+  return P[sc + '/sa_gamma'].to(layer.dtype) * o + layer
+
+
+def maybe_add_self_attention(P, top, hw, name_channels, net, end_points, domain, cfg, is_discriminator=False):
+  """nets/pggan_utils.py:301-308."""
+  if cfg.do_self_attention and hw == cfg.self_attention_hw:
+    name = 'self_attention_%dx%dx%d' % (hw, hw, name_channels)
+    net = self_attention_layer(P, '%s/%s' % (top, name), net, domain, cfg, is_discriminator)
+    end_points[name] = net
+  return net
+
+
 def _conv_any(x, w, bias, k):
   if k == 1 and (w.shape[2] <= 4 or w.shape[3] <= 4):
     return ops.pointwise_conv(x, w, bias)
   return ops.conv2d(x, w, bias, k, 'SAME')
 
 
-def maybe_resblock(P, blk, input_layer, out_channels, conv2d_out, cfg):
+def maybe_resblock(P, blk, input_layer, out_channels, conv2d_out, cfg, is_discriminator=False):
   """nets/pggan_utils.py:257-264,334-342: ``shortcut + conv2d_out`` with the shortcut = the block input, or a 1x1
   conv of it (scope 'shortcut', bias, no normaliser, no activation) when the channel count changes."""
   if not cfg.use_res_block:
     return conv2d_out
   if input_layer.shape[-1] == out_channels:
     return ops.add(input_layer, conv2d_out)
-  sc = _conv_any(_equalize(input_layer, cfg, 1), P[blk + '/shortcut/weights'], P[blk + '/shortcut/biases'], 1)
+  sc = _conv_any(_equalize(input_layer, cfg, 1), _sn(P, blk + '/shortcut', cfg, is_discriminator),
+                 P[blk + '/shortcut/biases'], 1)
   return ops.add(sc, conv2d_out)
 
 
-def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pixel_norm=True, pool=False):
+def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pixel_norm=True, pool=False, equalize=True):
   """maybe_pixel_norm(maybe_equalized_conv2d(...)) for the generator / encoder arg-scope
   (nets/pggan_utils.py:86-98,236-245): conv without bias, per-domain instance norm, LeakyReLU(0.2),
   then pixel norm (nets/pggan.py:78-81).  ``domain`` is 's' | 't', or (d0, d1, split): the batch holds
   ``split`` images of domain d0 followed by images of domain d1 (two reference passes as one launch)."""
-  w = P[scope + '/weights']
-  x = _equalize(x, cfg, k)
+  w = _sn(P, scope, cfg, False)
+  if equalize:
+    x = _equalize(x, cfg, k)
   if k == 1 and (w.shape[2] <= 4 or w.shape[3] <= 4):
     y = ops.pointwise_conv(x, w)
   else:
@@ -145,7 +224,7 @@ def _batch_renorm(P, scope, yv, domain, activation, pn, pool):
 def _d_conv(P, scope, x, cfg, k=3, padding='SAME', pool=False, in_ch=None):
   """Discriminator arg-scope (nets/pggan_utils.py:116-127): conv + bias, no norm, LeakyReLU(0.2),
   fused into the conv epilogue."""
-  w = P[scope + '/weights']
+  w = _sn(P, scope, cfg, True)
   b = P[scope + '/biases']
   x = _equalize(x, cfg, k, in_ch)      # in_ch: logical channel count when x is channel-padded (minibatch stddev)
   if k == 1 and (w.shape[2] <= 4 or w.shape[3] <= 4):
@@ -193,6 +272,7 @@ def encoder_before_classification(P, source, domain, cfg, top='encoder_content')
   for stage in range(max_stage, 0, -1):
     num_channels = get_num_channels(stage - 1, cfg.max_ch)
     current_hw = hw // (2 ** (max_stage - stage))
+    net = maybe_add_self_attention(P, top, current_hw, num_channels, net, end_points, domain, cfg)
     name = 'encoder_block_%dx%dx%d' % (current_hw, current_hw, num_channels)
     block_in = net
     net = _ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg)
@@ -248,6 +328,7 @@ def generator(P, source, domain, cfg, unet_end_points=None, top='generator', une
       net = _ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg)
       net = maybe_resblock(P, '%s/%s' % (top, name), block_in, output_channels, net, cfg)
     end_points[name] = net
+    net = maybe_add_self_attention(P, top, hw, output_channels, net, end_points, domain, cfg)      # pggan.py:188-190
   rgb = 'generator_to_rgb_%dx%d' % (hw, hw)
   # to_rgb: activation None, normaliser still applied, no pixel norm (pggan.py:192-200)
   to_rgb = _ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=1, activation=False, pixel_norm=False)
@@ -273,21 +354,22 @@ def discriminator_before_fc(P, source, cfg, top, groups=1):
     pooled = ops.avg_pool2(source)
     name = 'from_rgb_%dx%d' % (hw // 2, hw // 2)
     shrinked = _d_conv(P, '%s/%s/Conv' % (top, name), pooled, cfg, k=1)
-    shrinked = maybe_resblock(P, '%s/%s' % (top, name), pooled, shrinked.shape[-1], shrinked, cfg)
+    shrinked = maybe_resblock(P, '%s/%s' % (top, name), pooled, shrinked.shape[-1], shrinked, cfg, True)
     end_points[name] = shrinked
   name = 'from_rgb_%dx%d' % (hw, hw)
   net = _d_conv(P, '%s/%s/Conv' % (top, name), source, cfg, k=1)
-  net = maybe_resblock(P, '%s/%s' % (top, name), source, net.shape[-1], net, cfg)
+  net = maybe_resblock(P, '%s/%s' % (top, name), source, net.shape[-1], net, cfg, True)
   end_points[name] = net
   for stage in range(max_stage, 0, -1):
     num_channels = get_num_channels(stage - 1, cfg.max_ch)
     current_hw = hw // (2 ** (max_stage - stage))
+    net = maybe_add_self_attention(P, top, current_hw, num_channels, net, end_points, None, cfg, True)   # pggan.py:294-296
     name = 'encoder_block_%dx%dx%d' % (current_hw, current_hw, num_channels)
     block_in = net
     net = _d_conv(P, '%s/%s/Conv' % (top, name), net, cfg)
     if cfg.use_res_block:
       net = _d_conv(P, '%s/%s/Conv_1' % (top, name), net, cfg)
-      end_points[name] = maybe_resblock(P, '%s/%s' % (top, name), block_in, num_channels, net, cfg)
+      end_points[name] = maybe_resblock(P, '%s/%s' % (top, name), block_in, num_channels, net, cfg, True)
       net = ops.avg_pool2(end_points[name])
     else:
       end_points[name], net = _d_conv(P, '%s/%s/Conv_1' % (top, name), net, cfg, pool=True)   # conv + avg_pool (pggan.py:304-306)

@@ -14,6 +14,8 @@ deployment/model_deploy.py:242-315,473-503 -- with two deliberate scheduling dif
 import ctypes
 import math
 
+import dataclasses
+
 import torch
 
 from . import ops, pggan
@@ -240,6 +242,9 @@ class Trainer:
   """
 
   def __init__(self, cfg, device='cuda', seed=0, world_size=1, process_group=None, use_graph=False):
+    if cfg.spectral_norm and cfg.domain_streams:
+      # the per-run normalised kernels (pggan._sn) are shared by every use of a discriminator: keep them on one stream
+      cfg = dataclasses.replace(cfg, domain_streams=False)
     self.cfg = cfg
     self.device = torch.device(device)
     self.world = world_size
@@ -283,6 +288,7 @@ class Trainer:
     loss, terms = generator_loss(self.P, sources, targets, self.cfg)
     (loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)).backward()     # model_deploy.py:265-268,308-313
     _DomainStreams.join_all(self.device)
+    pggan.end_run(self.P)
     return loss.detach(), {k: v.detach() for k, v in terms.items()}
 
   def _d_grads(self, sources, targets, gp_alpha_s=None, gp_alpha_t=None):
@@ -296,6 +302,7 @@ class Trainer:
     loss, terms = discriminator_loss(self.P, sources, targets, self.cfg, gp_alpha_s, gp_alpha_t)
     (loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)).backward()
     _DomainStreams.join_all(self.device)
+    pggan.end_run(self.P)
     return loss.detach(), {k: v.detach() for k, v in terms.items()}
 
   def g_step(self, sources, targets):
