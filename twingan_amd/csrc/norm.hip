@@ -310,17 +310,44 @@ __global__ void norm_act_fwd_part_kernel(const T* __restrict__ y, const float* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward pass 1: gu = d loss / d u (pre-activation), written to gy (temporary);
-//                  sums[n][c][0] += gu, sums[n][c][1] += gu * yhat
+// backward.  gu = d loss / d u (u = pre-activation) of one pixel from (gz, y): recomputed by BOTH passes instead
+// of being written by pass 1 and read back by pass 2 (5 tensor passes instead of 6).
+//   in: g = gz, x = y, s = pixel-norm scale;  out: g = gu, yh = yhat
 // ------------------------------------------------------------------------------------------------
+template <int V>
+__device__ __forceinline__ void norm_act_gu(float (&g)[V], float (&x)[V], float s, const float (&mu)[V],
+                                            const float (&rs)[V], const float (&ga)[V], const float (&be)[V], int flags,
+                                            float alpha, int cv, int c, float (&yh)[V]) {
+  float u[V];
+  float dot = 0.f;
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    yh[j] = (x[j] - mu[j]) * rs[j];
+    u[j] = yh[j] * ga[j] + be[j];
+    const float a = (flags & NF_LRELU) ? lrelu_f(u[j], alpha) : u[j];
+    dot = fmaf(g[j], a * s, dot);          // gz . z
+    x[j] = a * s;                          // z
+  }
+  if (flags & NF_PIXNORM) {
+    dot = group_sum(dot, cv) / (float)c;
+#pragma unroll
+    for (int j = 0; j < V; ++j) g[j] = s * (g[j] - x[j] * dot);     // d/da
+  }
+  if (flags & NF_LRELU) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) g[j] *= (u[j] > 0.f ? 1.f : alpha);
+  }
+}
+
+// backward pass 1: partial sums  sums[n][chunk][0..c) = sum gu,  [c..2c) = sum gu * yhat
 template <typename T, int V>
 __global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restrict__ gzp, int wdim,
                                      const T* __restrict__ y, const float* __restrict__ pn_scale,
                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                      const float* __restrict__ gamma2, const float* __restrict__ beta2, int split,
-                                     int pstride, T* __restrict__ gu_out, float* __restrict__ sums, int hw, int c,
-                                     int flags, float alpha, int px_per_block) {
+                                     int pstride, float* __restrict__ sums, int hw, int c, int flags, float alpha,
+                                     int px_per_block) {
   extern __shared__ float sh[];   // [2][c]
   const int cv = c / V;
   const int lanes = blockDim.x / cv;
@@ -355,35 +382,15 @@ __global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restri
       }
 #pragma unroll
       for (int q = 0; q < U; ++q) {
-        const int p = pb + q * lanes;
-        const bool live = p < p1;
-        const int64_t gp = (int64_t)n * hw + p;
-        float yh[V], u[V];
-        float (&g)[V] = gq[q];
-        float (&x)[V] = xq[q];
-        const float s = sq[q];
-        float dot = 0.f;
+        const bool live = pb + q * lanes < p1;
+        float yh[V];
+        norm_act_gu<V>(gq[q], xq[q], sq[q], mu, rs, ga, be, flags, alpha, cv, c, yh);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-          yh[j] = (x[j] - mu[j]) * rs[j];
-          u[j] = yh[j] * ga[j] + be[j];
-          const float a = (flags & NF_LRELU) ? lrelu_f(u[j], alpha) : u[j];
-          dot = fmaf(g[j], a * s, dot);          // gz . z
-          x[j] = a * s;                          // z
-        }
-        if (flags & NF_PIXNORM) {
-          dot = group_sum(dot, cv) / (float)c;
-#pragma unroll
-          for (int j = 0; j < V; ++j) g[j] = s * (g[j] - x[j] * dot);     // d/da
-        }
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-          if (flags & NF_LRELU) g[j] *= (u[j] > 0.f ? 1.f : alpha);
-          const float gr = live ? rnd<T>(g[j]) : 0.f;      // what pass 2 will read back
+          const float gr = live ? gq[q][j] : 0.f;
           a1[j] += gr;
           a2[j] = fmaf(gr, yh[j], a2[j]);
         }
-        if (live) VecIO<T, V>::store(gu_out + gp * c + v * V, g);
       }
     }
   }
@@ -395,15 +402,18 @@ __global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restri
   for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) out[i] = sh[i];
 }
 
-// backward pass 2: gy = gamma*rstd * (gu - S1/hw - yhat * S2/hw)   (in place over gu).  grid = (chunks2, n); the
-// prologue sums the image's partial S1 / S2; with `sink` block (0, n) adds them into the parameter gradients.
+// backward pass 2: gy = gamma*rstd * (gu - S1/hw - yhat * S2/hw).  grid = (chunks2, n); the prologue sums the
+// image's partial S1 / S2; with `sink` block (0, n) adds them into the parameter gradients.
 template <typename T, int V>
-__global__ void norm_act_bwd2_part_kernel(T* __restrict__ gy, const T* __restrict__ y, const float* __restrict__ mean,
-                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                          const float* __restrict__ gamma2, int split, int pstride,
-                                          const float* __restrict__ part, int chunks, float* __restrict__ ggamma,
-                                          float* __restrict__ gbeta, float* __restrict__ ggamma2,
-                                          float* __restrict__ gbeta2, int sink, int hw, int c, int px_per_block) {
+__global__ void norm_act_bwd2_part_kernel(const T* __restrict__ gz, const T* __restrict__ gzp, int wdim,
+                                          const T* __restrict__ y, const float* __restrict__ pn_scale,
+                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                          const float* __restrict__ gamma2, const float* __restrict__ beta2, int split,
+                                          int pstride, T* __restrict__ gy, const float* __restrict__ part, int chunks,
+                                          float* __restrict__ ggamma, float* __restrict__ gbeta,
+                                          float* __restrict__ ggamma2, float* __restrict__ gbeta2, int sink, int hw, int c,
+                                          int flags, float alpha, int px_per_block) {
   extern __shared__ float sh[];   // [2][c]
   const int cv = c / V;
   const int lanes = blockDim.x / cv;
@@ -424,39 +434,39 @@ __global__ void norm_act_bwd2_part_kernel(T* __restrict__ gy, const T* __restric
     }
   }
   const float inv = 1.f / (float)hw;
-  float mu[V], rs[V], gr[V], s1[V], s2[V];
+  float mu[V], rs[V], ga[V], be[V], s1[V], s2[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) {
     const int ch = v * V + j;
     mu[j] = mean[n * c + ch];
     rs[j] = rstd[n * c + ch];
-    gr[j] = (pstride ? gamma[(int64_t)n * pstride + ch] : (n < split ? gamma : gamma2)[ch]) * rs[j];
+    ga[j] = pstride ? gamma[(int64_t)n * pstride + ch] : (n < split ? gamma : gamma2)[ch];
+    be[j] = pstride ? beta[(int64_t)n * pstride + ch] : (n < split ? beta : beta2)[ch];
     s1[j] = sh[ch] * inv;
     s2[j] = sh[c + ch] * inv;
   }
   const int p0 = blockIdx.x * px_per_block;
   const int p1 = min(p0 + px_per_block, hw);
   if (pl >= lanes) return;
-  constexpr int U = 4;      // pixels in flight per thread
+  constexpr int U = 2;      // pixels in flight per thread (3 loads each)
   for (int pb = p0 + pl; pb < p1; pb += lanes * U) {
-    float g[U][V], x[U][V];
+    float gq[U][V], xq[U][V], sq[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t gp = (int64_t)n * hw + min(pb + u * lanes, p1 - 1);
-      VecIO<T, V>::load(gy + gp * c + v * V, g[u]);
-      VecIO<T, V>::load(y + gp * c + v * V, x[u]);
+    for (int q = 0; q < U; ++q) {
+      const int p = min(pb + q * lanes, p1 - 1);
+      const int64_t gp = (int64_t)n * hw + p;
+      load_grad<T, V>(gz, gzp, n, p, hw, wdim, c, v, 0.25f, gq[q]);
+      VecIO<T, V>::load(y + gp * c + v * V, xq[q]);
+      sq[q] = (flags & NF_PIXNORM) ? pn_scale[gp] : 1.f;
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int p = pb + u * lanes;
-      if (p < p1) {
+    for (int q = 0; q < U; ++q) {
+      const int p = pb + q * lanes;
+      float yh[V];
+      norm_act_gu<V>(gq[q], xq[q], sq[q], mu, rs, ga, be, flags, alpha, cv, c, yh);
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-          const float yh = (x[u][j] - mu[j]) * rs[j];
-          g[u][j] = gr[j] * (g[u][j] - s1[j] - yh * s2[j]);
-        }
-        VecIO<T, V>::store(gy + ((int64_t)n * hw + p) * c + v * V, g[u]);
-      }
+      for (int j = 0; j < V; ++j) gq[q][j] = ga[j] * rs[j] * (gq[q][j] - s1[j] - yh[j] * s2[j]);
+      if (p < p1) VecIO<T, V>::store(gy + ((int64_t)n * hw + p) * c + v * V, gq[q]);
     }
   }
 }
@@ -746,15 +756,17 @@ int tg_norm_act_bwd(const void* gz, const void* gz_pooled, const void* y, const 
     }
     if (vec) {
       hipLaunchKernelGGL((norm_act_bwd1_kernel<T, VN>), dim3(chunks, n), dim3(256), lds, s, (const T*)gz,
-                         (const T*)gz_pooled, w, (const T*)y, pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split, pstride, (T*)gy, sums, hw, c, flags, alpha, ppb);
-      hipLaunchKernelGGL((norm_act_bwd2_part_kernel<T, VN>), dim3(chunks2, n), dim3(256), lds, s, (T*)gy, (const T*)y, mean,
-                         rstd, gamma, gamma2, split, pstride, sums, chunks, ggamma, gbeta, ggamma2, gbeta2, sink, hw, c, ppb2);
+                         (const T*)gz_pooled, w, (const T*)y, pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split, pstride, sums, hw, c, flags, alpha, ppb);
+      hipLaunchKernelGGL((norm_act_bwd2_part_kernel<T, VN>), dim3(chunks2, n), dim3(256), lds, s, (const T*)gz,
+                         (const T*)gz_pooled, w, (const T*)y, pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split,
+                         pstride, (T*)gy, sums, chunks, ggamma, gbeta, ggamma2, gbeta2, sink, hw, c, flags, alpha, ppb2);
     } else {
       TG_CHECK(c <= 256, TG_ENOSUP, "tg_norm_act_bwd: scalar path needs c <= 256 (got %d)", c);
       hipLaunchKernelGGL((norm_act_bwd1_kernel<T, 1>), dim3(chunks, n), dim3(256), lds, s, (const T*)gz,
-                         (const T*)gz_pooled, w, (const T*)y, pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split, pstride, (T*)gy, sums, hw, c, flags, alpha, ppb);
-      hipLaunchKernelGGL((norm_act_bwd2_part_kernel<T, 1>), dim3(chunks2, n), dim3(256), lds, s, (T*)gy, (const T*)y, mean,
-                         rstd, gamma, gamma2, split, pstride, sums, chunks, ggamma, gbeta, ggamma2, gbeta2, sink, hw, c, ppb2);
+                         (const T*)gz_pooled, w, (const T*)y, pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split, pstride, sums, hw, c, flags, alpha, ppb);
+      hipLaunchKernelGGL((norm_act_bwd2_part_kernel<T, 1>), dim3(chunks2, n), dim3(256), lds, s, (const T*)gz,
+                         (const T*)gz_pooled, w, (const T*)y, pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split,
+                         pstride, (T*)gy, sums, chunks, ggamma, gbeta, ggamma2, gbeta2, sink, hw, c, flags, alpha, ppb2);
     }
   });
   if (want_params && !sink && !pstride)
