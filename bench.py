@@ -133,6 +133,7 @@ def roofline_pass(tr, a, b, steps=2):
                       algorithmic_bytes_per_launch=e['algorithmic_bytes_per_launch'],
                       traffic_over_algorithmic=e['traffic_over_algorithmic'])
                  for e in json.load(open(pmc)).get('kernels', []) if sym(e.get('kernel', '')) == k]
+      samples.sort(key=lambda e: -e['algorithmic_bytes_per_launch'])
       if samples:
         roof['traffic'] = samples[0]['hbm_bytes_per_launch']
         roof['traffic_samples'] = samples

@@ -9,7 +9,7 @@ import os
 import re
 import sys
 
-CASES = {'G256a': (256, 64, 16), 'E256a': (256, 16, 16), 'G32a': (32, 512, 128), 'E32b': (32, 128, 256)}
+CASES = {'G256a': (256, 64, 16), 'E256a': (256, 16, 16), 'E128a': (128, 32, 32), 'G32a': (32, 512, 128), 'E32b': (32, 128, 256)}
 
 
 def main(root):

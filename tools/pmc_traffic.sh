@@ -7,7 +7,7 @@ REPO=$PWD
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc
 cd /tmp
-for spec in "G256a fwd 64" "G256a wgrad 64" "G256a dgrad 64" "E256a fwd 32" "G32a fwd 64" "E32b fwd 32"; do
+for spec in "G256a fwd 64" "G256a wgrad 64" "G256a dgrad 64" "E256a fwd 32" "E256a wgrad 48" "E128a wgrad 16" "G32a fwd 64" "E32b fwd 32"; do
   set -- $spec
   for ctr in FETCH_SIZE WRITE_SIZE; do
     out=$REPO/gpurun_out/pmc/$1_$2_n$3_$ctr
