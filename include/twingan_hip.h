@@ -131,13 +131,14 @@ int tg_norm_act_fwd(const void* y, const float* mean, const float* rstd, const f
 /* The same forward as two launches instead of four (no zero fill, no atomics, no finalise kernel):
  * tg_instance_norm_partials writes per-block shifted sums to partials (fp32 [n * tg_norm_chunks(n,h,w) * 2 * c]);
  * tg_norm_act_fwd_partials finalises mean / rstd from them in its prologue, WRITES mean[n*c] / rstd[n*c] (for the
- * backward and the BatchNorm moving averages) and applies the affine + LeakyReLU + pixel norm. */
+ * backward and the BatchNorm moving averages) and applies the affine + LeakyReLU + pixel norm.  z_pooled (may be NULL):
+ * also receives the 2x2 average pool of z, [n, h/2, w/2, c] (tf.nn.avg_pool after an encoder block, pggan.py:466-468). */
 int tg_norm_chunks(int n, int h, int w);
 int tg_instance_norm_partials(const void* y, float* partials, int n, int h, int w, int c, int dtype, void* stream);
 int tg_norm_act_fwd_partials(const void* y, const float* partials, float* mean, float* rstd, const float* gamma,
                              const float* beta, const float* gamma2, const float* beta2, int split, void* z,
-                             float* pn_scale, int n, int h, int w, int c, int flags, float lrelu_alpha, float in_eps,
-                             float pn_eps, int dtype, void* stream);
+                             void* z_pooled, float* pn_scale, int n, int h, int w, int c, int flags, float lrelu_alpha,
+                             float in_eps, float pn_eps, int dtype, void* stream);
 /* Backward of tg_norm_act_fwd.  Inputs: gz [n,h,w,c] and/or gz_pooled [n,h/2,w/2,c] (either may be NULL; the
  * layer-output gradient is gz + 0.25 * upsample(gz_pooled): the tf.nn.avg_pool that follows an encoder block,
  * nets/pggan.py:436,468, is folded in), y (raw conv output), pn_scale, mean, rstd, gamma, beta (+ 2nd domain).

@@ -50,7 +50,7 @@ SIGNATURES = {
     'tg_instance_norm_stats': (c_int, [_P, _FP, _FP, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     'tg_norm_chunks': (c_int, [c_int, c_int, c_int]),
     'tg_instance_norm_partials': (c_int, [_P, _FP, c_int, c_int, c_int, c_int, c_int, _P]),
-    'tg_norm_act_fwd_partials': (c_int, [_P, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, _P, _FP, c_int, c_int, c_int, c_int,
+    'tg_norm_act_fwd_partials': (c_int, [_P, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, _P, _P, _FP, c_int, c_int, c_int, c_int,
                                          c_int, c_float, c_float, c_float, c_int, _P]),
     'tg_norm_act_fwd': (c_int, [_P, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, _P, _FP, c_int, c_int, c_int, c_int, c_int,
                                 c_float, c_float, c_int, _P]),

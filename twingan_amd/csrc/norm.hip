@@ -230,13 +230,17 @@ __global__ void norm_act_fwd_kernel(const T* __restrict__ y, const float* __rest
 // Same forward with the statistics finalised in the prologue from the partial sums of in_stats_partial<PART>
 // (no separate finalise launch, no zero fill, no atomics).  grid = (chunks2, n): a block stays inside one image.
 // Block (0, n) also writes mean / rstd of its image for the backward and the moving averages.
-template <typename T, int V>
+// POOL: the 4 pixels a thread keeps in flight are one 2x2 block and the thread also writes their average to zp
+// [n, h/2, w/2, c] (the tf.nn.avg_pool after an encoder block, nets/pggan.py:466-468) -- px_per_block then counts
+// 2x2 blocks and wdim is the row length.
+template <typename T, int V, bool POOL = false>
 __global__ void norm_act_fwd_part_kernel(const T* __restrict__ y, const float* __restrict__ part, int chunks,
                                          float* __restrict__ mean, float* __restrict__ rstd,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                          const float* __restrict__ gamma2, const float* __restrict__ beta2, int split,
-                                         T* __restrict__ z, float* __restrict__ pn_scale, int hw, int c, int flags,
-                                         float alpha, float in_eps, float pn_eps, int px_per_block) {
+                                         T* __restrict__ z, T* __restrict__ zp, int wdim, float* __restrict__ pn_scale,
+                                         int hw, int c, int flags, float alpha, float in_eps, float pn_eps,
+                                         int px_per_block) {
   extern __shared__ float sh[];   // [2][c]: sums, then (scale, shift)
   const int cv = c / V;
   const int lanes = blockDim.x / cv;
@@ -274,21 +278,32 @@ __global__ void norm_act_fwd_part_kernel(const T* __restrict__ y, const float* _
     sc[j] = sh[v * V + j];
     sf[j] = sh[c + v * V + j];
   }
-  const int p0 = blockIdx.x * px_per_block;
-  const int p1 = min(p0 + px_per_block, hw);
-  if (pl >= lanes) return;
   constexpr int U = 4;      // pixels in flight per thread
-  for (int pb = p0 + pl; pb < p1; pb += lanes * U) {      // pl is uniform within a pixel group: groups stay converged
+  const int nunits = POOL ? hw / 4 : hw;      // 2x2 blocks or pixels of this image
+  const int p0 = blockIdx.x * px_per_block;
+  const int p1 = min(p0 + px_per_block, nunits);
+  if (pl >= lanes) return;
+  const int wq = wdim >> 1;
+  for (int pb = p0 + pl; pb < p1; pb += lanes * (POOL ? 1 : U)) {      // pl is uniform within a pixel group: groups stay converged
     float x[U][V];
+    int px[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int p = min(pb + u * lanes, p1 - 1);
-      VecIO<T, V>::load(y + ((int64_t)n * hw + p) * c + v * V, x[u]);
+      if (POOL) {
+        const int qy = pb / wq, qx = pb - qy * wq;
+        px[u] = (2 * qy + (u >> 1)) * wdim + 2 * qx + (u & 1);
+      } else {
+        px[u] = min(pb + u * lanes, p1 - 1);
+      }
+      VecIO<T, V>::load(y + ((int64_t)n * hw + px[u]) * c + v * V, x[u]);
     }
+    float pooled[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) pooled[j] = 0.f;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int p = pb + u * lanes;
-      const int64_t gp = (int64_t)n * hw + p;
+      const bool live = POOL || pb + u * lanes < p1;
+      const int64_t gp = (int64_t)n * hw + px[u];
       float ss = 0.f;
 #pragma unroll
       for (int j = 0; j < V; ++j) {
@@ -302,9 +317,18 @@ __global__ void norm_act_fwd_part_kernel(const T* __restrict__ y, const float* _
         const float q = rsqrtf(ss / (float)c + pn_eps);
 #pragma unroll
         for (int j = 0; j < V; ++j) x[u][j] *= q;
-        if (pn_scale && v == 0 && p < p1) pn_scale[gp] = q;
+        if (pn_scale && v == 0 && live) pn_scale[gp] = q;
       }
-      if (p < p1) VecIO<T, V>::store(z + gp * c + v * V, x[u]);
+      if (live) VecIO<T, V>::store(z + gp * c + v * V, x[u]);
+      if (POOL) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) pooled[j] += rnd<T>(x[u][j]);      // the pool reads the stored (rounded) z
+      }
+    }
+    if (POOL) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) pooled[j] *= 0.25f;
+      VecIO<T, V>::store(zp + ((int64_t)n * (hw / 4) + pb) * c + v * V, pooled);
     }
   }
 }
@@ -626,8 +650,9 @@ int tg_instance_norm_partials(const void* y, float* partials, int n, int h, int 
 
 int tg_norm_act_fwd_partials(const void* y, const float* partials, float* mean, float* rstd, const float* gamma,
                              const float* beta, const float* gamma2, const float* beta2, int split, void* z,
-                             float* pn_scale, int n, int h, int w, int c, int flags, float alpha, float in_eps,
-                             float pn_eps, int dtype, void* stream) {
+                             void* z_pooled, float* pn_scale, int n, int h, int w, int c, int flags, float alpha,
+                             float in_eps, float pn_eps, int dtype, void* stream) {
+  TG_CHECK(!z_pooled || (h % 2 == 0 && w % 2 == 0), TG_EINVAL, "tg_norm_act_fwd_partials: pooled output needs even h, w");
   TG_CHECK(y && partials && mean && rstd && gamma && beta && z && n > 0 && h > 0 && w > 0 && c > 0, TG_EINVAL,
            "tg_norm_act_fwd_partials: bad arguments");
   TG_CHECK(c <= 256 * 8, TG_ENOSUP, "tg_norm_act_fwd_partials: c=%d too large", c);
@@ -636,10 +661,11 @@ int tg_norm_act_fwd_partials(const void* y, const float* partials, float* mean, 
   const int hw = h * w;
   int chunks, ppb_s;
   norm_chunks(n, hw, &chunks, &ppb_s);
+  const int units = z_pooled ? hw / 4 : hw;            // the pooled variant walks 2x2 blocks (4 pixels each)
   int chunks2 = (2048 + n - 1) / n;                    // ~2048 blocks for the streaming pass
-  int ppb = (hw + chunks2 - 1) / chunks2;
-  if (ppb < 64) ppb = 64;
-  chunks2 = (hw + ppb - 1) / ppb;
+  int ppb = (units + chunks2 - 1) / chunks2;
+  if (ppb < (z_pooled ? 16 : 64)) ppb = z_pooled ? 16 : 64;
+  chunks2 = (units + ppb - 1) / ppb;
   const size_t lds = 2 * (size_t)c * sizeof(float);
   TG_DISPATCH_DTYPE(dtype, "tg_norm_act_fwd_partials", {
     constexpr int VN = Vec16<T>::N;
@@ -648,15 +674,24 @@ int tg_norm_act_fwd_partials(const void* y, const float* partials, float* mean, 
       TG_CHECK(vec, TG_ENOSUP, "tg_norm_act_fwd_partials: pixel norm needs c (%d) = %d * 2^k <= %d", c, VN, 64 * VN);
       TG_CHECK(pn_scale, TG_EINVAL, "tg_norm_act_fwd_partials: pixel norm needs pn_scale");
     }
-    if (vec) {
+    if (vec && z_pooled) {
+      hipLaunchKernelGGL((norm_act_fwd_part_kernel<T, VN, true>), dim3(chunks2, n), dim3(256), lds, (hipStream_t)stream,
+                         (const T*)y, partials, chunks, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)z, (T*)z_pooled,
+                         w, pn_scale, hw, c, flags, alpha, in_eps, pn_eps, ppb);
+    } else if (vec) {
       hipLaunchKernelGGL((norm_act_fwd_part_kernel<T, VN>), dim3(chunks2, n), dim3(256), lds, (hipStream_t)stream,
-                         (const T*)y, partials, chunks, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)z, pn_scale, hw,
-                         c, flags, alpha, in_eps, pn_eps, ppb);
+                         (const T*)y, partials, chunks, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)z, (T*)nullptr,
+                         w, pn_scale, hw, c, flags, alpha, in_eps, pn_eps, ppb);
     } else {
       TG_CHECK(c <= 256, TG_ENOSUP, "tg_norm_act_fwd_partials: scalar path needs c <= 256 (got %d)", c);
-      hipLaunchKernelGGL((norm_act_fwd_part_kernel<T, 1>), dim3(chunks2, n), dim3(256), lds, (hipStream_t)stream,
-                         (const T*)y, partials, chunks, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)z, pn_scale, hw,
-                         c, flags, alpha, in_eps, pn_eps, ppb);
+      if (z_pooled)
+        hipLaunchKernelGGL((norm_act_fwd_part_kernel<T, 1, true>), dim3(chunks2, n), dim3(256), lds, (hipStream_t)stream,
+                           (const T*)y, partials, chunks, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)z,
+                           (T*)z_pooled, w, pn_scale, hw, c, flags, alpha, in_eps, pn_eps, ppb);
+      else
+        hipLaunchKernelGGL((norm_act_fwd_part_kernel<T, 1>), dim3(chunks2, n), dim3(256), lds, (hipStream_t)stream,
+                           (const T*)y, partials, chunks, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)z,
+                           (T*)nullptr, w, pn_scale, hw, c, flags, alpha, in_eps, pn_eps, ppb);
     }
   });
   TG_LAUNCH_CHECK("tg_norm_act_fwd_partials");

@@ -576,7 +576,8 @@ def instance_stats(y, eps):
   return mean, rstd
 
 
-def _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema=None, stats=None):
+def _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema=None, stats=None,
+                      zp=None):
   _chk(y, gamma, beta, gamma2, beta2)
   n, h, w, c = y.shape
   split = n if gamma2 is None else int(split)
@@ -596,8 +597,8 @@ def _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, 
     call('tg_instance_norm_partials', _p(y), _p(part), n, h, w, c, _dt(y), _stream(),
          work=('in_stats' + _shape_tag(y), 0, y.numel() * _esize(y)))
     call('tg_norm_act_fwd_partials', _p(y), _p(part), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(gamma2), _p(beta2), split,
-         _p(z), _p(s), n, h, w, c, flags, alpha, in_eps, pn_eps, _dt(y), _stream(),
-         work=('norm_act_fwd' + _shape_tag(y), 0, 2 * y.numel() * _esize(y)))
+         _p(z), _p(zp), _p(s), n, h, w, c, flags, alpha, in_eps, pn_eps, _dt(y), _stream(),
+         work=('norm_act_fwd' + _shape_tag(y), 0, int((2 + (0.25 if zp is not None else 0)) * y.numel()) * _esize(y)))
     if ema is not None:
       _ema_update(mean, rstd, n, c, split, in_eps, ema)
   ctx.flags, ctx.alpha, ctx.split, ctx.per_image = flags, alpha, split, per_image
@@ -658,11 +659,14 @@ class NormActPoolFn(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema, stats):
-    z = _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema, stats)
-    n, h, w, c = z.shape
-    zp = torch.empty((n, h // 2, w // 2, c), dtype=z.dtype, device=z.device)
-    call('tg_pool2x2_fwd', _p(z), _p(zp), n, h, w, c, 0.25, _dt(z), _stream(),
-         work=('pool_fwd' + _shape_tag(z), 0, int(1.25 * z.numel()) * _esize(z)))
+    n, h, w, c = y.shape
+    zp = torch.empty((n, h // 2, w // 2, c), dtype=y.dtype, device=y.device)
+    fused = gamma.dim() == 1      # the partial-sums forward writes the pooled tensor itself
+    z = _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema, stats,
+                          zp if fused else None)
+    if not fused:
+      call('tg_pool2x2_fwd', _p(z), _p(zp), n, h, w, c, 0.25, _dt(z), _stream(),
+           work=('pool_fwd' + _shape_tag(z), 0, int(1.25 * z.numel()) * _esize(z)))
     ctx.set_materialize_grads(False)
     return z, zp
 
