@@ -53,15 +53,20 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <bool ATOMIC>
+// TW = 16: a tile is 8 rows x 16 cols of one image (maps of 16x16 and up).  TW = 8: the 8x8 maps -- a tile is TWO
+// whole images, K step ks = image ks of the pair, and the two 8-pixel halves of a K step are rows 2w and 2w+1.
+template <int TW>
 __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gy,
                                                               float* __restrict__ slab, const WgGeom g) {
-  constexpr int TW = 16, TH = 8, HWX = 18, HH = 10, NT = 9;
+  constexpr bool ATOMIC = false;
+  constexpr int TH = 8, HWX = TW + 2, HH = 10, NT = 9;
+  constexpr int IPT = 16 / TW;                      // images per tile
   constexpr int PS = 64;                            // LDS bytes per pixel (32 channels, dense)
-  constexpr int XVEC = HH * HWX * 4, XSLOTS = (XVEC + 255) / 256;      // 720 -> 3
-  constexpr int GSLOTS = (TH * TW * 4) / 256;                          // 512 -> 2
-  constexpr int X_BYTES = HH * HWX * PS;                               // 11520
-  constexpr int G_BYTES = TH * TW * PS;                                // 8192
+  constexpr int XPX = IPT * HH * HWX;               // halo pixels per tile: 180 / 200
+  constexpr int XVEC = XPX * 4, XSLOTS = (XVEC + 255) / 256;           // 720 -> 3, 800 -> 4
+  constexpr int GSLOTS = (128 * 4) / 256;                              // 128 output pixels per tile -> 2
+  constexpr int X_BYTES = XPX * PS;                                    // 11520 / 12800
+  constexpr int G_BYTES = 128 * PS;                                    // 8192
 
   unsigned char* sX = wg_smem;
   unsigned char* sG = wg_smem + X_BYTES;
@@ -95,10 +100,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   for (int s = 0; s < XSLOTS; ++s) {
     const int v = tid + s * 256;
     const int px = v >> 2, part = v & 3;
-    x_hy1[s] = px / HWX - 1;
-    x_hx1[s] = px % HWX - 1;
+    const int sub = px / (HH * HWX), rem = px - sub * (HH * HWX);          // image of the tile (TW = 8), pixel in its halo
+    x_hy1[s] = rem / HWX - 1;
+    x_hx1[s] = rem % HWX - 1;
     x_use[s] = v < XVEC && ci0 + part * 8 + 8 <= g.cin;                    // else zero fill
-    x_rel[s] = ((x_hy1[s] * g.w + x_hx1[s]) * g.cin + ci0 + part * 8) * 2;   // bytes from the tile's first pixel
+    // bytes from the tile's first pixel (TW = 8: from the first pixel of the pair's first image)
+    x_rel[s] = (((sub * g.h + x_hy1[s]) * g.w + x_hx1[s]) * g.cin + ci0 + part * 8) * 2;
     x_loff[s] = px * PS + part * 16;
   }
   int g_loff[GSLOTS];
@@ -108,7 +115,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
     const int v = tid + s * 256;
     const int px = v >> 2, part = v & 3;
     const bool use = co0 + part * 8 + 8 <= g.cout;
-    g_rel[s] = use ? (unsigned)((((px >> 4) * g.w + (px & 15)) * g.cout + co0 + part * 8) * 2) : WOOB;
+    // TW = 16: pixel (px >> 4, px & 15) of the tile; TW = 8: pixel px & 63 of image px >> 6 (rows are contiguous)
+    g_rel[s] = use ? (unsigned)(((TW == 16 ? (px >> 4) * g.w + (px & 15) : px) * g.cout + co0 + part * 8) * 2) : WOOB;
     g_loff[s] = px * PS + part * 16;
   }
 
@@ -117,7 +125,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   // pixel +(t >> 2), channels c0 + 4*(t & 3).
   const int gq = lane >> 4, t16 = lane & 15;
   const int frag_off = ((gq >> 1) * 8 + (t16 >> 2)) * PS + ((gq & 1) * 16 + (t16 & 3) * 4) * 2;
-  // wave wid reduces tile rows 2*wid (K step 0) and 2*wid + 1 (K step 1)
+  // x: the second 8-pixel half of a K step is 8 pixels on (TW = 16) or the next halo row (TW = 8)
+  const int frag_off_x = ((gq >> 1) * (TW == 16 ? 8 : HWX) + (t16 >> 2)) * PS + ((gq & 1) * 16 + (t16 & 3) * 4) * 2;
+  // TW = 16: wave wid reduces tile rows 2*wid (K step 0) and 2*wid + 1 (K step 1)
 
   f32x16 acc[NT];
 #pragma unroll
@@ -140,13 +150,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   auto load_tile = [&](Stage& st, int tile) __attribute__((always_inline)) {
     const unsigned live = tile < tile_end;      // past the end: every lane out of range -> a tile of zeros
     int t = live ? tile : tile_begin;
-    const int tx = t % g.tiles_x;
-    t /= g.tiles_x;
-    const int ty = t % g.tiles_y;
-    const int img = t / g.tiles_y;
-    const int ox0 = tx * TW, oy0 = ty * TH;
-    const __amdgpu_buffer_rsrc_t bx = wg_rsrc(x + (size_t)img * ximg, (unsigned)(ximg * 2));
-    const __amdgpu_buffer_rsrc_t bg = wg_rsrc(gy + (size_t)img * gimg, (unsigned)(gimg * 2));
+    int img, ox0, oy0, nimg;
+    if constexpr (TW == 16) {
+      const int tx = t % g.tiles_x;
+      t /= g.tiles_x;
+      const int ty = t % g.tiles_y;
+      img = t / g.tiles_y;
+      ox0 = tx * TW;
+      oy0 = ty * TH;
+      nimg = 1;
+    } else {
+      img = t * 2;                              // the pair (2t, 2t+1); an odd batch ends with a half-empty tile:
+      ox0 = oy0 = 0;                            // the buffer resource then covers one image, the other reads zeros
+      nimg = img + 1 < g.n ? 2 : 1;
+    }
+    const __amdgpu_buffer_rsrc_t bx = wg_rsrc(x + (size_t)img * ximg, (unsigned)(ximg * 2 * nimg));
+    const __amdgpu_buffer_rsrc_t bg = wg_rsrc(gy + (size_t)img * gimg, (unsigned)(gimg * 2 * nimg));
     const int xbase = (oy0 * g.w + ox0) * g.cin * 2;
     const unsigned gbase = (unsigned)((oy0 * g.w + ox0) * g.cout * 2);
 #pragma unroll
@@ -170,13 +189,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   auto reduce_tile = [&](const unsigned char* bX, const unsigned char* bG) __attribute__((always_inline)) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const int row = wid * 2 + ks;
-      const bf16x8 gf = tr_frag(bG + (row * TW) * PS + frag_off);
+      // first pixel of this wave's K step in the gy tile / (for tap 0,0) in the halo tile
+      const int gpx = TW == 16 ? (wid * 2 + ks) * 16 : ks * 64 + wid * 16;
+      const int xpx = TW == 16 ? (wid * 2 + ks) * HWX : ks * (HH * HWX) + wid * 2 * HWX;
+      const bf16x8 gf = tr_frag(bG + gpx * PS + frag_off);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const bf16x8 xf = tr_frag(bX + ((row + ky) * HWX + kx) * PS + frag_off);
+          const bf16x8 xf = tr_frag(bX + (xpx + ky * HWX + kx) * PS + frag_off_x);
           acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, gf, acc[ky * 3 + kx], 0, 0, 0);
         }
       }
@@ -268,9 +289,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_slab_reduce(const float* __res
 
 void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices) {
   g->n = n; g->h = h; g->w = w; g->cin = cin; g->cout = cout;
-  g->tiles_x = w / 16;
-  g->tiles_y = h / 8;
-  g->total_tiles = g->tiles_x * g->tiles_y * n;
+  if (w == 8) {      // 8x8 maps: a tile is a pair of images
+    g->tiles_x = g->tiles_y = 1;
+    g->total_tiles = (n + 1) / 2;
+  } else {
+    g->tiles_x = w / 16;
+    g->tiles_y = h / 8;
+    g->total_tiles = g->tiles_x * g->tiles_y * n;
+  }
   const int n_ci = (cin + 31) / 32;
   g->n_co_blk = (cout + 31) / 32;
   // ~2 workgroups per CU in total; 1 per CU when that leaves a workgroup fewer than 8 tiles: every workgroup
@@ -293,7 +319,8 @@ void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices) {
 int tg_wgrad_slab_reduce(const float* slab, float* gw, int64_t nw, int nslices, int accumulate, hipStream_t s);
 
 bool tg_wgrad_tile_supported(int h, int w, int hout, int wout, int kh, int kw, int pad_t, int pad_l) {
-  return kh == 3 && kw == 3 && pad_t == 1 && pad_l == 1 && h == hout && w == wout && (h % 8 == 0) && (w % 16 == 0);
+  return kh == 3 && kw == 3 && pad_t == 1 && pad_l == 1 && h == hout && w == wout &&
+         (((h % 8 == 0) && (w % 16 == 0)) || (h == 8 && w == 8));
 }
 
 size_t tg_wgrad_tile_workspace(int n, int h, int w, int cin, int cout) {
@@ -314,19 +341,13 @@ int tg_wgrad_tile_run(int n, int h, int w, int cin, int cout, const void* x, con
   const int n_ci = (cin + 31) / 32;
   const size_t lds = 2 * (10 * 18 * 64 + 8 * 16 * 64);      // two tile buffers of 19712 B; the first doubles as the 16 KiB reduction scratch
   tg_note_kernel("conv_wgrad_tile_kernel");
-  static const int atomic_mode = getenv("TG_WGRAD_ATOMIC") ? atoi(getenv("TG_WGRAD_ATOMIC")) : 0;
-  if (atomic_mode) {
-    if (!accumulate) {
-      int rc = tg_zero_async(gw, (size_t)nw * sizeof(float), nullptr, 0, s);
-      if (rc) return rc;
-    }
-    hipLaunchKernelGGL(conv_wgrad_tile_kernel<true>, dim3(nslices * n_ci * g.n_co_blk), dim3(256), lds, s, (const bf16*)x,
-                       (const bf16*)gy, gw, g);
-    TG_LAUNCH_CHECK("conv_wgrad_tile");
-    return TG_OK;
-  }
-  hipLaunchKernelGGL(conv_wgrad_tile_kernel<false>, dim3(nslices * n_ci * g.n_co_blk), dim3(256), lds, s, (const bf16*)x,
-                     (const bf16*)gy, (float*)ws, g);
+  const size_t lds8 = 2 * (2 * 10 * 10 * 64 + 8 * 16 * 64);
+  if (w == 8)
+    hipLaunchKernelGGL(conv_wgrad_tile_kernel<8>, dim3(nslices * n_ci * g.n_co_blk), dim3(256), lds8, s, (const bf16*)x,
+                       (const bf16*)gy, (float*)ws, g);
+  else
+    hipLaunchKernelGGL(conv_wgrad_tile_kernel<16>, dim3(nslices * n_ci * g.n_co_blk), dim3(256), lds, s, (const bf16*)x,
+                       (const bf16*)gy, (float*)ws, g);
   TG_LAUNCH_CHECK("conv_wgrad_tile");
   return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
 }
