@@ -415,19 +415,32 @@ __global__ void pw_wgrad_kernel(const T* __restrict__ small, const T* __restrict
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[s][j] = 0.f;
   if (pl < lanes) {
-    for (int64_t p = (int64_t)blockIdx.x * lanes + pl; p < npix; p += (int64_t)gridDim.x * lanes) {
-      float bv[V];
-      if (V == 1) {
-        bv[0] = ld(big + p * cb + v);
-      } else {
-        Vec16<T> s = ldv(big + p * cb + v * V);
+    constexpr int U = 4;      // pixels in flight per thread
+    const int64_t stride = (int64_t)gridDim.x * lanes;
+    for (int64_t pb = (int64_t)blockIdx.x * lanes + pl; pb < npix; pb += stride * U) {
+      float bv[U][V], sv[U][4];
 #pragma unroll
-        for (int j = 0; j < V; ++j) bv[j] = s.get(j);
+      for (int u = 0; u < U; ++u) {
+        int64_t p = pb + u * stride;
+        p = p < npix ? p : npix - 1;      // clamped, not predicated: no branches between the loads
+        if (V == 1) {
+          bv[u][0] = ld(big + p * cb + v);
+        } else {
+          Vec16<T> t = ldv(big + p * cb + v * V);
+#pragma unroll
+          for (int j = 0; j < V; ++j) bv[u][j] = t.get(j);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sv[u][s] = s < ns ? ld(small + p * ns + s) : 0.f;
       }
-      for (int s = 0; s < ns; ++s) {
-        const float sv = ld(small + p * ns + s);
 #pragma unroll
-        for (int j = 0; j < V; ++j) acc[s][j] = fmaf(sv, bv[j], acc[s][j]);
+      for (int u = 0; u < U; ++u) {
+        if (pb + u * stride < npix) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[s][j] = fmaf(sv[u][s], bv[u][j], acc[s][j]);
+        }
       }
     }
   }

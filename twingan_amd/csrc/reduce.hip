@@ -4,6 +4,17 @@
 
 namespace {
 
+// The n (<= 16) samples of V consecutive positions, all requested before any is used: a runtime-length load/use
+// loop is one L2 round trip per sample (3 such loops made these single-workgroup kernels 20-90 us).
+constexpr int MB_NMAX = 16;
+template <typename T>
+__device__ __forceinline__ void mb_load_samples(const T* __restrict__ x, int n, int P, int p, Vec16<T> (&xv)[MB_NMAX]) {
+#pragma unroll
+  for (int i = 0; i < MB_NMAX; ++i) xv[i] = ldv(x + (int64_t)(i < n ? i : n - 1) * P + p);
+}
+
+
+
 // ------------------------------------------------------------------------------------------------
 // Minibatch stddev, nets/pggan_utils.py:353-366.  x[n][p], p = hw*c.  Single workgroup: the tensor
 // is [B,4,4,C] (64 K elements at B=16, C=256).
@@ -28,19 +39,41 @@ __global__ __launch_bounds__(1024) void mbstd_fwd_kernel(const T* __restrict__ x
       float mu[V], var[V];
 #pragma unroll
       for (int j = 0; j < V; ++j) mu[j] = var[j] = 0.f;
-      for (int i = 0; i < n; ++i) {
-        const Vec16<T> xv = ldv(x + (int64_t)i * P + p);
+      if (n <= MB_NMAX) {
+        Vec16<T> xs[MB_NMAX];
+        mb_load_samples<T>(x, n, P, p, xs);
 #pragma unroll
-        for (int j = 0; j < V; ++j) mu[j] += xv.get(j);
-      }
+        for (int i = 0; i < MB_NMAX; ++i)
+          if (i < n) {
 #pragma unroll
-      for (int j = 0; j < V; ++j) mu[j] /= (float)n;
-      for (int i = 0; i < n; ++i) {
-        const Vec16<T> xv = ldv(x + (int64_t)i * P + p);
+            for (int j = 0; j < V; ++j) mu[j] += xs[i].get(j);
+          }
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-          const float d = xv.get(j) - mu[j];
-          var[j] = fmaf(d, d, var[j]);
+        for (int j = 0; j < V; ++j) mu[j] /= (float)n;
+#pragma unroll
+        for (int i = 0; i < MB_NMAX; ++i)
+          if (i < n) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+              const float d = xs[i].get(j) - mu[j];
+              var[j] = fmaf(d, d, var[j]);
+            }
+          }
+      } else {
+        for (int i = 0; i < n; ++i) {
+          const Vec16<T> xv = ldv(x + (int64_t)i * P + p);
+#pragma unroll
+          for (int j = 0; j < V; ++j) mu[j] += xv.get(j);
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) mu[j] /= (float)n;
+        for (int i = 0; i < n; ++i) {
+          const Vec16<T> xv = ldv(x + (int64_t)i * P + p);
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            const float d = xv.get(j) - mu[j];
+            var[j] = fmaf(d, d, var[j]);
+          }
         }
       }
 #pragma unroll
@@ -103,6 +136,46 @@ __global__ __launch_bounds__(1024) void mbstd_bwd_kernel(const T* __restrict__ g
   for (int i = threadIdx.x; i < n * hw; i += blockDim.x) acc += ld(gout + (int64_t)i * cpad + c);
   const float G = block_sum(acc, red);
   constexpr int V = Vec16<T>::N;
+  if (c % V == 0 && cpad % V == 0 && n <= MB_NMAX) {
+    for (int p = threadIdx.x * V; p < P; p += blockDim.x * V) {
+      float mu[V], var[V], k[V];
+      Vec16<T> xs[MB_NMAX], gs[MB_NMAX];
+      const int px = p / c, ch = p - px * c;
+      mb_load_samples<T>(x, n, P, p, xs);
+#pragma unroll
+      for (int i = 0; i < MB_NMAX; ++i) gs[i] = ldv(gout + ((int64_t)(i < n ? i : n - 1) * hw + px) * cpad + ch);
+#pragma unroll
+      for (int j = 0; j < V; ++j) mu[j] = var[j] = 0.f;
+#pragma unroll
+      for (int i = 0; i < MB_NMAX; ++i)
+        if (i < n) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) mu[j] += xs[i].get(j);
+        }
+#pragma unroll
+      for (int j = 0; j < V; ++j) mu[j] /= (float)n;
+#pragma unroll
+      for (int i = 0; i < MB_NMAX; ++i)
+        if (i < n) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            const float d = xs[i].get(j) - mu[j];
+            var[j] = fmaf(d, d, var[j]);
+          }
+        }
+#pragma unroll
+      for (int j = 0; j < V; ++j) k[j] = G / ((float)n * sqrtf(var[j] / (float)n + eps) * (float)P);
+#pragma unroll
+      for (int i = 0; i < MB_NMAX; ++i)
+        if (i < n) {
+          Vec16<T> o;
+#pragma unroll
+          for (int j = 0; j < V; ++j) o.set(j, gs[i].get(j) + k[j] * (xs[i].get(j) - mu[j]));
+          stv(gx + (int64_t)i * P + p, o);
+        }
+    }
+    return;
+  }
   if (c % V == 0 && cpad % V == 0 && n <= 32) {
     for (int p = threadIdx.x * V; p < P; p += blockDim.x * V) {
       float mu[V], var[V], k[V];
@@ -175,7 +248,62 @@ __global__ __launch_bounds__(1024) void mbstd_bwd_bwd_kernel(const T* __restrict
   for (int i = threadIdx.x; i < n * hw; i += blockDim.x) acc += ld(gout + (int64_t)i * cpad + c);
   const float G = block_sum(acc, red);
   float tacc = 0.f;
-  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+  constexpr int V = Vec16<T>::N;
+  const bool fast = P % V == 0 && n <= MB_NMAX;
+  if (fast) {
+    for (int p = threadIdx.x * V; p < P; p += blockDim.x * V) {
+      Vec16<T> xs[MB_NMAX], vs[MB_NMAX];
+      mb_load_samples<T>(x, n, P, p, xs);
+      mb_load_samples<T>(v, n, P, p, vs);
+      float mu[V], vm[V], var[V], vc[V], sigma[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) mu[j] = vm[j] = var[j] = vc[j] = 0.f;
+#pragma unroll
+      for (int i = 0; i < MB_NMAX; ++i)
+        if (i < n) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            mu[j] += xs[i].get(j);
+            vm[j] += vs[i].get(j);
+          }
+        }
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        mu[j] /= (float)n;
+        vm[j] /= (float)n;
+      }
+#pragma unroll
+      for (int i = 0; i < MB_NMAX; ++i)
+        if (i < n) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            const float d = xs[i].get(j) - mu[j];
+            var[j] = fmaf(d, d, var[j]);
+            vc[j] = fmaf(vs[i].get(j), d, vc[j]);
+          }
+        }
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        sigma[j] = sqrtf(var[j] / (float)n + eps);
+        tacc += vc[j] / ((float)n * sigma[j] * (float)P);
+      }
+      if (gx2) {
+        const float k = G / ((float)n * (float)P);
+#pragma unroll
+        for (int i = 0; i < MB_NMAX; ++i)
+          if (i < n) {
+            Vec16<T> o;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+              const float d = xs[i].get(j) - mu[j];
+              o.set(j, k * ((vs[i].get(j) - vm[j]) / sigma[j] - vc[j] * d / ((float)n * sigma[j] * sigma[j] * sigma[j])));
+            }
+            stv(gx2 + (int64_t)i * P + p, o);
+          }
+      }
+    }
+  }
+  for (int p = threadIdx.x; p < P && !fast; p += blockDim.x) {
     float mu = 0.f, vm = 0.f;
     for (int i = 0; i < n; ++i) {
       mu += ld(x + (int64_t)i * P + p);
@@ -203,15 +331,31 @@ __global__ __launch_bounds__(1024) void mbstd_bwd_bwd_kernel(const T* __restrict
   const float Tt = block_sum(tacc, red);
   if (ggout) {
     const int64_t total = (int64_t)n * hw * cpad;
-    for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
-      const int ch = (int)(i % cpad);
-      const int64_t px = i / cpad;
-      float o = 0.f;
-      if (ch < c)
-        o = ld(v + px * c + ch);
-      else if (ch == c)
-        o = Tt;
-      st(ggout + i, o);
+    if (c % V == 0 && cpad % V == 0) {
+      const int cvp = cpad / V;
+      for (int64_t i = threadIdx.x; i < total / V; i += blockDim.x) {
+        const int cb = (int)(i % cvp) * V;
+        const int64_t px = i / cvp;
+        Vec16<T> o;
+        if (cb < c) {
+          o = ldv(v + px * c + cb);
+        } else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) o.set(j, (cb + j == c) ? Tt : 0.f);
+        }
+        stv(ggout + px * cpad + cb, o);
+      }
+    } else {
+      for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
+        const int ch = (int)(i % cpad);
+        const int64_t px = i / cpad;
+        float o = 0.f;
+        if (ch < c)
+          o = ld(v + px * c + ch);
+        else if (ch == c)
+          o = Tt;
+        st(ggout + i, o);
+      }
     }
   }
 }
