@@ -82,6 +82,21 @@ size_t tg_conv2d_bwd_weight_workspace(const TgConvDesc* d);
 int tg_conv2d_bwd_weight(const TgConvDesc* d, const void* x, const void* gy, float* gw, int accumulate,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* generator_three_layer_block's first conv (nets/pggan.py:69-78) with its input concat(nearest_up2(x0), x1)
+ * (resize_twice_as_big + maybe_concat_unet_layer, nets/pggan_utils.py:281-298,349-350) read straight from the two
+ * sources instead of from a materialised copy: y[n,h,w,cout] = conv3x3_same(concat(up2(x0 [n,h/2,w/2,c0]),
+ * x1 [n1,h,w,c1]), w) and its filter gradient gw[3][3][c0+c1][cout].  bf16 activations; w_pack = mode-0 pack of the
+ * ordinary [3,3,c0+c1,cout] kernel; (gsz, perm) as in tg_upsample2x_concat_fwd.  The input gradient is the ordinary
+ * tg_conv2d_bwd_data followed by tg_upsample2x_concat_bwd.  tg_conv2d_upcat_supported: h % 8 == 0, w % 16 == 0,
+ * c0 % 32 == 0, c1 % 32 == 0, cout % 8 == 0. */
+int tg_conv2d_upcat_supported(int h, int w, int c0, int c1, int cout);
+int tg_conv2d_upcat_fwd(const void* x0, const void* x1, const void* w_pack, void* y, int n, int h, int w, int c0, int c1,
+                        int cout, int gsz, unsigned perm, void* stream);
+size_t tg_conv2d_upcat_bwd_weight_workspace(int n, int h, int w, int c0, int c1, int cout);
+int tg_conv2d_upcat_bwd_weight(const void* x0, const void* x1, const void* gy, float* gw, int accumulate, void* workspace,
+                               size_t workspace_bytes, int n, int h, int w, int c0, int c1, int cout, int gsz,
+                               unsigned perm, void* stream);
+
 /* bf16 K-contiguous weight packs for the MFMA kernels, from the fp32 HWIO master (`d` = forward
  * descriptor; a kxk VALID conv on a kxk input is packed as the equivalent dense 1x1 over k*k*cin).
  * mode 0 (forward):  out[co][tap][ci]        = w[tap][ci][co]

@@ -625,3 +625,28 @@ def test_multi_tensor_pack_matches_single_packs(ops):
   for (w, mode, p), ref in zip(packs, want):
     assert torch.equal(p.float(), (ref.float() * 2.0)), (tuple(w.shape), mode)
   PackCache.clear()
+
+
+@pytest.mark.parametrize('n,h,c0,c1,cout,gsz,perm', [(2, 8, 32, 32, 16, 0, ()), (4, 16, 64, 64, 64, 1, (1, 0, 0, 1)),
+                                                        (2, 8, 64, 32, 128, 0, ())])
+def test_upcat_conv_matches_materialised_path(ops, n, h, c0, c1, cout, gsz, perm):
+  """conv3x3(concat(up2(x0), skip)) read from the two sources (tg_conv2d_upcat_fwd / _bwd_weight) == the same conv
+  over the materialised tg_upsample2x_concat_fwd tensor: output, both input gradients and the filter gradient."""
+  g = torch.Generator().manual_seed(11)
+  n1 = (max(perm) + 1) * gsz if gsz else n
+  x0 = torch.randn(n, h, h, c0, generator=g).to(dev()).bfloat16().requires_grad_(True)
+  x1 = torch.randn(n1, 2 * h, 2 * h, c1, generator=g).to(dev()).bfloat16().requires_grad_(True)
+  w = (torch.randn(3, 3, c0 + c1, cout, generator=g) * (2.0 / (9 * (c0 + c1))) ** 0.5).to(dev()).requires_grad_(True)
+  gy = torch.randn(n, 2 * h, 2 * h, cout, generator=g).to(dev()).bfloat16()
+  assert ops.upcat_conv_supported(x0, x1, w)
+  y_ref = ops.conv2d(ops.upsample2x_concat(x0, x1, gsz, perm), w, None, 3, 'SAME')
+  y_ref.backward(gy)
+  ref = [t.grad.clone() for t in (x0, x1, w)]
+  for t in (x0, x1, w):
+    t.grad = None
+  y = ops.upcat_conv(x0, x1, w, gsz, perm)
+  y.backward(gy)
+  assert rel_l2(host(y), host(y_ref)) < 1e-6           # same kernel arithmetic, same accumulation order per tile
+  assert rel_l2(host(x0.grad), host(ref[0])) < 1e-6
+  assert rel_l2(host(x1.grad), host(ref[1])) < 1e-6
+  assert rel_l2(host(w.grad), host(ref[2])) < 1e-5

@@ -5,7 +5,7 @@ an error, this module raises.  (``oracle/`` is test infrastructure and is never 
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint, c_void_p
 
 TG_F32, TG_BF16 = 0, 1
 TG_ALGO_DIRECT, TG_ALGO_MFMA = 0, 1
@@ -40,6 +40,11 @@ SIGNATURES = {
     'tg_conv2d_bwd_data': (c_int, [_D, _P, _P, _P, _P]),
     'tg_conv2d_bwd_weight_workspace': (c_size_t, [_D]),
     'tg_conv2d_bwd_weight': (c_int, [_D, _P, _P, _FP, c_int, _P, c_size_t, _P]),
+    'tg_conv2d_upcat_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    'tg_conv2d_upcat_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_uint, _P]),
+    'tg_conv2d_upcat_bwd_weight_workspace': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    'tg_conv2d_upcat_bwd_weight': (c_int, [_P, _P, _P, _FP, c_int, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int,
+                                           c_int, c_uint, _P]),
     'tg_conv2d_pack_elems': (c_size_t, [_D, c_int]),
     'tg_conv2d_pack_weights': (c_int, [_D, _FP, c_int, _P, _P]),
     'tg_pack_table_bytes': (c_size_t, [c_int]),

@@ -43,6 +43,13 @@ int tg_conv2d_bwd_weight_direct(const TgConvDesc*, const void*, const void*, flo
 int tg_conv2d_fwd_mfma(const TgConvDesc*, const void*, const void*, const float*, void*, hipStream_t);
 int tg_conv2d_bwd_data_mfma(const TgConvDesc*, const void*, const void*, void*, hipStream_t);
 size_t tg_conv2d_bwd_weight_workspace_mfma(const TgConvDesc*);
+bool tg_conv_tile_upcat_supported(int h, int w, int c0, int c1, int cout);
+int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, const void* x0,
+                           const void* x1, const void* wp, void* y, hipStream_t s);
+size_t tg_wgrad_tile_workspace(int n, int h, int w, int cin, int cout);
+int tg_wgrad_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, const void* x0,
+                            const void* x1, const void* gy, float* gw, int accumulate, void* ws, size_t ws_bytes,
+                            hipStream_t s);
 int tg_conv2d_bwd_weight_mfma(const TgConvDesc*, const void*, const void*, float*, int, void*, size_t, hipStream_t);
 
 static int check_desc(const char* who, const TgConvDesc* d) {
@@ -90,6 +97,42 @@ int tg_conv2d_bwd_data(const TgConvDesc* d, const void* gy, const void* w, void*
 size_t tg_conv2d_bwd_weight_workspace(const TgConvDesc* d) {
   if (!d || d->algo == TG_ALGO_DIRECT) return 0;
   return tg_conv2d_bwd_weight_workspace_mfma(d);
+}
+
+int tg_conv2d_upcat_supported(int h, int w, int c0, int c1, int cout) {
+  return tg_conv_tile_upcat_supported(h, w, c0, c1, cout) ? 1 : 0;
+}
+
+static int check_upcat(const char* who, int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm) {
+  TG_CHECK(n > 0 && tg_conv_tile_upcat_supported(h, w, c0, c1, cout), TG_ENOSUP,
+           "%s: needs h %% 8 == 0, w %% 16 == 0, c0 and c1 multiples of 32 (got %dx%d, %d+%d -> %d)", who, h, w, c0, c1, cout);
+  TG_CHECK(gsz >= 0 && (gsz == 0 || (n % gsz == 0 && n / gsz <= 4)), TG_EINVAL, "%s: bad skip groups (n %d, gsz %d)", who, n,
+           gsz);
+  (void)perm;
+  return TG_OK;
+}
+
+int tg_conv2d_upcat_fwd(const void* x0, const void* x1, const void* w_pack, void* y, int n, int h, int w, int c0, int c1,
+                        int cout, int gsz, unsigned perm, void* stream) {
+  TG_CHECK(x0 && x1 && w_pack && y, TG_EINVAL, "tg_conv2d_upcat_fwd: null pointer");
+  int rc = check_upcat("tg_conv2d_upcat_fwd", n, h, w, c0, c1, cout, gsz, perm);
+  if (rc) return rc;
+  return tg_conv_tile_upcat_run(n, h, w, c0, c1, cout, gsz, perm, x0, x1, w_pack, y, (hipStream_t)stream);
+}
+
+size_t tg_conv2d_upcat_bwd_weight_workspace(int n, int h, int w, int c0, int c1, int cout) {
+  if (n <= 0 || !tg_conv_tile_upcat_supported(h, w, c0, c1, cout)) return 0;
+  return tg_wgrad_tile_workspace(n, h, w, c0 + c1, cout);
+}
+
+int tg_conv2d_upcat_bwd_weight(const void* x0, const void* x1, const void* gy, float* gw, int accumulate, void* ws,
+                               size_t ws_bytes, int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm,
+                               void* stream) {
+  TG_CHECK(x0 && x1 && gy && gw, TG_EINVAL, "tg_conv2d_upcat_bwd_weight: null pointer");
+  int rc = check_upcat("tg_conv2d_upcat_bwd_weight", n, h, w, c0, c1, cout, gsz, perm);
+  if (rc) return rc;
+  return tg_wgrad_tile_upcat_run(n, h, w, c0, c1, cout, gsz, perm, x0, x1, gy, gw, accumulate, ws, ws_bytes,
+                                 (hipStream_t)stream);
 }
 
 int tg_conv2d_bwd_weight(const TgConvDesc* d, const void* x, const void* gy, float* gw, int accumulate, void* ws,

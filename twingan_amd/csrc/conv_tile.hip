@@ -32,6 +32,11 @@ struct TileGeom {
   int tiles_per_wg;            // weight-resident variant: consecutive tiles per workgroup
   int epilogue;
   float alpha;
+  // fused input concat(nearest_up2(x), x1) (UPCAT kernels): x is [n, h/2, w/2, c0], x1 is [n1, h, w, cin - c0];
+  // output image i reads skip image perm-group(i) (see tg_upsample2x_concat_fwd)
+  const bf16* x1;
+  int c0, gsz;
+  unsigned perm;
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
@@ -56,7 +61,10 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, v);
 }
 
-template <int KH, int KC, int BN, int MT>
+// UPCAT: the conv input is concat(nearest_up2(x), x1) on channels (generator_three_layer_block,
+// nets/pggan.py:69-76) read straight from the two sources -- K chunks below c0 come from the half-resolution
+// tensor, the rest from the skip tensor -- instead of from a materialised copy.
+template <int KH, int KC, int BN, int MT, bool UPCAT = false>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                         const float* __restrict__ bias, bf16* __restrict__ y,
                                                         const TileGeom g) {
@@ -87,13 +95,19 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
   const int img = t / g.tiles_y;
   const int ox0 = tx * TW, oy0 = ty * TH;
   const int n0 = blockIdx.y * BN;
-  const size_t img_elems = (size_t)g.h * g.w * g.cin;
+  const int c1 = g.cin - g.c0;
+  const size_t img_elems = UPCAT ? (size_t)(g.h / 2) * (g.w / 2) * g.c0 : (size_t)g.h * g.w * g.cin;
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (size_t)img * img_elems, (unsigned)(img_elems * 2));
+  const size_t img1_elems = (size_t)g.h * g.w * c1;
+  const int img1 = (UPCAT && g.gsz) ? (int)((g.perm >> (8 * (img / g.gsz))) & 0xffu) * g.gsz + img % g.gsz : img;
+  const __amdgpu_buffer_rsrc_t rx1 =
+      make_rsrc(UPCAT ? g.x1 + (size_t)img1 * img1_elems : x, UPCAT ? (unsigned)(img1_elems * 2) : 0u);
   const int wrow = NT * g.cin_pad;
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(wp + (size_t)n0 * wrow, (unsigned)((size_t)BN * wrow * 2));
 
   // ---- per-thread staging slots (compile-time trip counts, constant divisors); byte offsets
   unsigned a_goff[ASLOTS];     // inside the image at chunk 0, or OOB (zero fill: border / unused slot)
+  unsigned a_goff1[UPCAT ? ASLOTS : 1];      // UPCAT: the same pixel in the skip tensor
   int a_loff[ASLOTS];
 #pragma unroll
   for (int s = 0; s < ASLOTS; ++s) {
@@ -103,7 +117,12 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
     const int iy = oy0 + hy - g.pad, ix = ox0 + hx - g.pad;
     a_loff[s] = px * PS_A + part * 16;
     const bool ok = (v < AVEC) && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
-    a_goff[s] = ok ? (unsigned)(((iy * g.w + ix) * g.cin + part * 8) * 2) : OOB;
+    if constexpr (UPCAT) {
+      a_goff[s] = ok ? (unsigned)((((iy >> 1) * (g.w >> 1) + (ix >> 1)) * g.c0 + part * 8) * 2) : OOB;
+      a_goff1[s] = ok ? (unsigned)(((iy * g.w + ix) * c1 + part * 8) * 2) : OOB;
+    } else {
+      a_goff[s] = ok ? (unsigned)(((iy * g.w + ix) * g.cin + part * 8) * 2) : OOB;
+    }
   }
   unsigned b_goff[BSLOTS];
   int b_loff[BSLOTS];
@@ -134,8 +153,18 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
   // chunk read 8 channels of the NEXT pixel; the weight pack is zero there, so they contribute 0.
   bf16x8 ra[ASLOTS], rb[BSLOTS];
   auto load_chunk = [&](int c0) {
+    if constexpr (UPCAT) {
+      if (c0 < g.c0) {      // uniform: a chunk lies entirely in one source (c0 % KC == 0)
 #pragma unroll
-    for (int s = 0; s < ASLOTS; ++s) ra[s] = buf_load16(rx, a_goff[s] + (unsigned)(c0 * 2));
+        for (int s = 0; s < ASLOTS; ++s) ra[s] = buf_load16(rx, a_goff[s] + (unsigned)(c0 * 2));
+      } else {
+#pragma unroll
+        for (int s = 0; s < ASLOTS; ++s) ra[s] = buf_load16(rx1, a_goff1[s] + (unsigned)((c0 - g.c0) * 2));
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < ASLOTS; ++s) ra[s] = buf_load16(rx, a_goff[s] + (unsigned)(c0 * 2));
+    }
 #pragma unroll
     for (int s = 0; s < BSLOTS; ++s) rb[s] = buf_load16(rw, b_goff[s] + (unsigned)(c0 * 2));
   };
@@ -427,7 +456,7 @@ int launch_tile_wres(const TileGeom& g0, const bf16* x, const bf16* wp, const fl
   return TG_OK;
 }
 
-template <int KH, int KC, int BN, int MT>
+template <int KH, int KC, int BN, int MT, bool UPCAT = false>
 int launch_tile(const TileGeom& g0, const bf16* x, const bf16* wp, const float* bias, bf16* y, hipStream_t s) {
   TileGeom g = g0;
   constexpr int TH = 8 * MT, HWX = 16 + KH - 1, HH = TH + KH - 1;
@@ -436,7 +465,7 @@ int launch_tile(const TileGeom& g0, const bf16* x, const bf16* wp, const float* 
   g.nblk = g.tiles_x * g.tiles_y * g.n;
   const size_t lds = (size_t)((HH * HWX * (KC * 2 + 16) + 15) & ~15) + (size_t)BN * (KH * KH * KC * 2 + 16);
   TG_CHECK(lds <= 160 * 1024, TG_ENOSUP, "conv_tile: LDS %zu too large", lds);
-  auto kern = conv_tile_kernel<KH, KC, BN, MT>;
+  auto kern = conv_tile_kernel<KH, KC, BN, MT, UPCAT>;
   if (lds > 64 * 1024) {
     static bool raised = false;      // per instantiation
     if (!raised) {
@@ -449,10 +478,19 @@ int launch_tile(const TileGeom& g0, const bf16* x, const bf16* wp, const float* 
     }
   }
   dim3 grid(g.nblk, (g.cout + BN - 1) / BN);
-  tg_note_kernel("conv_tile_kernel<%d,%d,%d,%d>", KH, KC, BN, MT);
+  tg_note_kernel(UPCAT ? "conv_tile_kernel<%d,%d,%d,%d,upcat>" : "conv_tile_kernel<%d,%d,%d,%d>", KH, KC, BN, MT);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, wp, bias, y, g);
   TG_LAUNCH_CHECK("conv_tile");
   return TG_OK;
+}
+
+// forward over concat(nearest_up2(x), x1): 3x3, both channel counts multiples of 32
+int dispatch_tile_upcat(const TileGeom& g, const bf16* x, const bf16* wp, const float* bias, bf16* y, hipStream_t s) {
+  const bool wide = g.cout > 32;
+  const int tiles1 = (g.w / 16) * (g.h / 8) * g.n * ((g.cout + (wide ? 63 : 31)) / (wide ? 64 : 32));
+  const bool mt2 = (g.h % 16 == 0) && tiles1 >= 2 * 2 * 256;
+  if (wide) return mt2 ? launch_tile<3, 32, 64, 2, true>(g, x, wp, bias, y, s) : launch_tile<3, 32, 64, 1, true>(g, x, wp, bias, y, s);
+  return mt2 ? launch_tile<3, 32, 32, 2, true>(g, x, wp, bias, y, s) : launch_tile<3, 32, 32, 1, true>(g, x, wp, bias, y, s);
 }
 
 template <int KH>
@@ -494,6 +532,31 @@ int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int
   g.tiles_x = g.tiles_y = g.nblk = 0;
   g.epilogue = epilogue;
   g.alpha = alpha;
+  g.x1 = nullptr;
+  g.c0 = g.gsz = 0;
+  g.perm = 0;
   if (k == 1) return dispatch_tile<1>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
   return dispatch_tile<3>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
+}
+
+// y = conv3x3_same(concat(nearest_up2(x0 [n,h/2,w/2,c0]), x1 [n1,h,w,c1])) without materialising the concat.
+bool tg_conv_tile_upcat_supported(int h, int w, int c0, int c1, int cout) {
+  return (h % 8 == 0) && (w % 16 == 0) && c0 > 0 && c1 > 0 && c0 % 32 == 0 && c1 % 32 == 0 && cout % 8 == 0;
+}
+
+int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, const void* x0,
+                           const void* x1, const void* wp, void* y, hipStream_t s) {
+  TileGeom g;
+  g.n = n; g.h = h; g.w = w; g.cin = c0 + c1; g.cout = cout;
+  g.cin_pad = g.cin;
+  g.pad = 1;
+  g.tiles_x = g.tiles_y = g.nblk = 0;
+  g.tiles_per_wg = 0;
+  g.epilogue = 0;
+  g.alpha = 0.f;
+  g.x1 = (const bf16*)x1;
+  g.c0 = c0;
+  g.gsz = gsz;
+  g.perm = perm;
+  return dispatch_tile_upcat(g, (const bf16*)x0, (const bf16*)wp, nullptr, (bf16*)y, s);
 }

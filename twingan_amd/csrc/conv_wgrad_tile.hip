@@ -30,6 +30,11 @@ struct WgGeom {
   int n_co_blk;                 // number of 32-wide co blocks (pair = ci_blk * n_co_blk + co_blk)
   int n_pairs, nslices;
   int tiles_per_wg;
+  // fused input concat(nearest_up2(x), x1): x is [n, h/2, w/2, c0], x1 is [n1, h, w, cin - c0] (c0 = 0: plain input);
+  // image i reads skip image perm-group(i).  A 32-channel ci block lies entirely in one source (c0 % 32 == 0).
+  const bf16* x1;
+  int c0, gsz;
+  unsigned perm;
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
@@ -105,7 +110,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
     x_hx1[s] = rem % HWX - 1;
     x_use[s] = v < XVEC && ci0 + part * 8 + 8 <= g.cin;                    // else zero fill
     // bytes from the tile's first pixel (TW = 8: from the first pixel of the pair's first image)
-    x_rel[s] = (((sub * g.h + x_hy1[s]) * g.w + x_hx1[s]) * g.cin + ci0 + part * 8) * 2;
+    if (g.c0 == 0)
+      x_rel[s] = (((sub * g.h + x_hy1[s]) * g.w + x_hx1[s]) * g.cin + ci0 + part * 8) * 2;
+    else if (ci0 < g.c0)      // half-resolution source: (iy >> 1, ix >> 1); tile origins are even
+      x_rel[s] = (((x_hy1[s] >> 1) * (g.w >> 1) + (x_hx1[s] >> 1)) * g.c0 + ci0 + part * 8) * 2;
+    else                      // skip source
+      x_rel[s] = ((x_hy1[s] * g.w + x_hx1[s]) * (g.cin - g.c0) + ci0 - g.c0 + part * 8) * 2;
     x_loff[s] = px * PS + part * 16;
   }
   int g_loff[GSLOTS];
@@ -135,7 +145,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
-  const size_t ximg = (size_t)g.h * g.w * g.cin, gimg = (size_t)g.h * g.w * g.cout;
+  const bool from_up = g.c0 != 0 && ci0 < g.c0, from_skip = g.c0 != 0 && ci0 >= g.c0;
+  const int xc = from_up ? g.c0 : (from_skip ? g.cin - g.c0 : g.cin);      // channels per pixel of this block's source
+  const size_t ximg = from_up ? (size_t)(g.h >> 1) * (g.w >> 1) * xc : (size_t)g.h * g.w * xc;
+  const size_t gimg = (size_t)g.h * g.w * g.cout;
+  const bf16* xsrc = from_skip ? g.x1 : x;
   const int tile_begin = slice * g.tiles_per_wg;
   int tile_end = tile_begin + g.tiles_per_wg;
   if (tile_end > g.total_tiles) tile_end = g.total_tiles;
@@ -164,9 +178,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
       ox0 = oy0 = 0;                            // the buffer resource then covers one image, the other reads zeros
       nimg = img + 1 < g.n ? 2 : 1;
     }
-    const __amdgpu_buffer_rsrc_t bx = wg_rsrc(x + (size_t)img * ximg, (unsigned)(ximg * 2 * nimg));
+    const int ximg_i = (from_skip && g.gsz) ? (int)((g.perm >> (8 * (img / g.gsz))) & 0xffu) * g.gsz + img % g.gsz : img;
+    const __amdgpu_buffer_rsrc_t bx = wg_rsrc(xsrc + (size_t)ximg_i * ximg, (unsigned)(ximg * 2 * nimg));
     const __amdgpu_buffer_rsrc_t bg = wg_rsrc(gy + (size_t)img * gimg, (unsigned)(gimg * 2 * nimg));
-    const int xbase = (oy0 * g.w + ox0) * g.cin * 2;
+    const int xbase = from_up ? ((oy0 >> 1) * (g.w >> 1) + (ox0 >> 1)) * xc * 2 : (oy0 * g.w + ox0) * xc * 2;
     const unsigned gbase = (unsigned)((oy0 * g.w + ox0) * g.cout * 2);
 #pragma unroll
     for (int s = 0; s < XSLOTS; ++s) {
@@ -289,6 +304,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_slab_reduce(const float* __res
 
 void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices) {
   g->n = n; g->h = h; g->w = w; g->cin = cin; g->cout = cout;
+  g->x1 = nullptr;
+  g->c0 = g->gsz = 0;
+  g->perm = 0;
   if (w == 8) {      // 8x8 maps: a tile is a pair of images
     g->tiles_x = g->tiles_y = 1;
     g->total_tiles = (n + 1) / 2;
@@ -349,6 +367,30 @@ int tg_wgrad_tile_run(int n, int h, int w, int cin, int cout, const void* x, con
     hipLaunchKernelGGL(conv_wgrad_tile_kernel<16>, dim3(nslices * n_ci * g.n_co_blk), dim3(256), lds, s, (const bf16*)x,
                        (const bf16*)gy, (float*)ws, g);
   TG_LAUNCH_CHECK("conv_wgrad_tile");
+  return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
+}
+
+// gw = d/dw of conv3x3_same(concat(nearest_up2(x0), x1)) read from the two sources (see conv_tile.hip UPCAT)
+int tg_wgrad_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, const void* x0,
+                            const void* x1, const void* gy, float* gw, int accumulate, void* ws, size_t ws_bytes,
+                            hipStream_t s) {
+  WgGeom g;
+  int nslices;
+  const int cin = c0 + c1;
+  wg_split(n, h, w, cin, cout, &g, &nslices);
+  g.x1 = (const bf16*)x1;
+  g.c0 = c0;
+  g.gsz = gsz;
+  g.perm = perm;
+  const int64_t nw = (int64_t)9 * cin * cout;
+  TG_CHECK(ws && ws_bytes >= (size_t)nslices * nw * sizeof(float), TG_EINVAL,
+           "tg_conv2d_bwd_weight_upcat: workspace too small (%zu < %zu)", ws_bytes, (size_t)nslices * nw * sizeof(float));
+  const int n_ci = (cin + 31) / 32;
+  const size_t lds = 2 * (10 * 18 * 64 + 8 * 16 * 64);
+  tg_note_kernel("conv_wgrad_tile_kernel");
+  hipLaunchKernelGGL(conv_wgrad_tile_kernel<16>, dim3(nslices * n_ci * g.n_co_blk), dim3(256), lds, s, (const bf16*)x0,
+                     (const bf16*)gy, (float*)ws, g);
+  TG_LAUNCH_CHECK("conv_wgrad_tile(upcat)");
   return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
 }
 

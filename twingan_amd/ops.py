@@ -732,6 +732,71 @@ class UpsampleConcatFn(torch.autograd.Function):
     return g0, g1, None, None
 
 
+def upcat_conv_supported(x0, x1, w):
+  """Can conv3x3(concat(up2(x0), x1), w) run from the two sources without materialising the concat?"""
+  if x1 is None or x0.dtype != torch.bfloat16 or w.shape[0] != 3:
+    return False
+  return bool(_lib.load().tg_conv2d_upcat_supported(2 * x0.shape[1], 2 * x0.shape[2], x0.shape[3], x1.shape[3], w.shape[3]))
+
+
+class UpcatConvFn(torch.autograd.Function):
+  """y = conv3x3_same(concat(nearest_up2(x0), x1), w): the first conv of generator_three_layer_block
+  (nets/pggan.py:69-78) reading its input from the two source tensors (tg_conv2d_upcat_fwd / _bwd_weight); the
+  concatenated tensor is never written.  The input gradient is the ordinary backward-data over a temporary in concat
+  layout, split by tg_upsample2x_concat_bwd.  First-order only (the generator never sits under the gradient penalty)."""
+
+  @staticmethod
+  def forward(ctx, x0, x1, w, gsz, perm):
+    _chk(x0, x1, w)
+    n, h, ww, c0 = x0.shape
+    c1, cout = x1.shape[3], w.shape[3]
+    if gsz:
+      assert n % gsz == 0 and len(perm) == n // gsz and x1.shape[0] == (max(perm) + 1) * gsz
+    H, W = 2 * h, 2 * ww
+    spec = ConvSpec(3, 'SAME')
+    d = _desc((n, H, W, c0 + c1), cout, spec, x0.dtype, 0)
+    y = torch.empty((n, H, W, cout), dtype=x0.dtype, device=x0.device)
+    pk = _pack_perm(perm) if gsz else 0
+    call('tg_conv2d_upcat_fwd', _p(x0), _p(x1), _p(PackCache.get(w, d, 0)), _p(y), n, H, W, c0, c1, cout, gsz, pk, _stream(),
+         work=lambda: ('fwd:upcat:k3:c%d+%d>%d:hw%d:n%d' % (c0, c1, cout, H, n), 2 * n * H * W * cout * 9 * (c0 + c1),
+                       2 * (x0.numel() + x1.numel() + y.numel()) + 2 * w.numel()))
+    ctx.dims = (n, H, W, c0, c1, cout, gsz, pk, x1.shape[0])
+    ctx.spec = spec
+    ctx.save_for_backward(x0, x1, w)
+    return y
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, gy):
+    x0, x1, w = ctx.saved_tensors
+    n, H, W, c0, c1, cout, gsz, pk, n1 = ctx.dims
+    gy = gy.contiguous()
+    g0 = g1 = gw = None
+    if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+      gcat = conv_bwd_data_raw(gy, w, (n, H, W, c0 + c1), ctx.spec)
+      g0 = torch.empty_like(x0) if ctx.needs_input_grad[0] else None
+      g1 = torch.empty_like(x1) if ctx.needs_input_grad[1] else None
+      call('tg_upsample2x_concat_bwd', _p(gcat), _p(g0), _p(g1), n, H // 2, W // 2, c0, c1, gsz, pk, _dt(gcat), _stream(),
+           work=('upcat_bwd' + _shape_tag(gcat), 0, (gcat.numel() + x0.numel() + x1.numel()) * _esize(gcat)))
+    if ctx.needs_input_grad[2] and not _State.skip_param_grads:
+      sink = GradSink.get(w)
+      gw = sink if sink is not None else torch.empty(tuple(w.shape), dtype=torch.float32, device=gy.device)
+      lib = _lib.load()
+      nbytes = lib.tg_conv2d_upcat_bwd_weight_workspace(n, H, W, c0, c1, cout)
+      ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=gy.device)
+      call('tg_conv2d_upcat_bwd_weight', _p(x0), _p(x1), _p(gy), _p(gw), 1 if sink is not None else 0, _p(ws), nbytes,
+           n, H, W, c0, c1, cout, gsz, pk, _stream(),
+           work=lambda: ('wgrad:upcat:k3:c%d+%d>%d:hw%d:n%d' % (c0, c1, cout, H, n), 2 * n * H * W * cout * 9 * (c0 + c1),
+                         2 * (x0.numel() + x1.numel() + gy.numel()) + 4 * w.numel()))
+      if sink is not None:
+        gw = None
+    return g0, g1, gw, None, None
+
+
+def upcat_conv(x0, x1, w, gsz=0, perm=()):
+  return UpcatConvFn.apply(x0, x1, w, gsz, tuple(perm))
+
+
 def upsample2x_concat(x0, x1=None, gsz=0, perm=()):
   return UpsampleConcatFn.apply(x0, x1, int(gsz), tuple(perm))
 

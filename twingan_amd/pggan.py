@@ -121,18 +121,19 @@ def maybe_resblock(P, blk, input_layer, out_channels, conv2d_out, cfg, is_discri
   return ops.add(sc, conv2d_out)
 
 
-def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pixel_norm=True, pool=False, equalize=True):
+def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pixel_norm=True, pool=False, equalize=True,
+             upcat=None):
   """maybe_pixel_norm(maybe_equalized_conv2d(...)) for the generator / encoder arg-scope
   (nets/pggan_utils.py:86-98,236-245): conv without bias, per-domain instance norm, LeakyReLU(0.2),
   then pixel norm (nets/pggan.py:78-81).  ``domain`` is 's' | 't', or (d0, d1, split): the batch holds
   ``split`` images of domain d0 followed by images of domain d1 (two reference passes as one launch)."""
   w = _sn(P, scope, cfg, False)
-  if equalize:
-    x = _equalize(x, cfg, k)
-  if k == 1 and (w.shape[2] <= 4 or w.shape[3] <= 4):
-    y = ops.pointwise_conv(x, w)
+  if upcat is not None:      # x is None: the input is concat(up2(x0), skip), read from the two sources by the conv
+    y = ops.upcat_conv(upcat[0], upcat[1], w, upcat[2], upcat[3])
+  elif k == 1 and (w.shape[2] <= 4 or w.shape[3] <= 4):
+    y = ops.pointwise_conv(_equalize(x, cfg, k) if equalize else x, w)
   else:
-    y = ops.conv2d(x, w, None, k, padding)
+    y = ops.conv2d(_equalize(x, cfg, k) if equalize else x, w, None, k, padding)
   nt = cfg.generator_norm_type
   if nt not in ('instance_norm', 'batch_norm', 'batch_renorm'):
     raise NotImplementedError('generator_norm_type=%s (instance_norm, batch_norm and batch_renorm are built)' % nt)
@@ -319,12 +320,16 @@ def generator(P, source, domain, cfg, unet_end_points=None, top='generator', une
       # generator_three_layer_block: upsample -> concat(UNet) -> conv -> conv  (pggan.py:69-83)
       # unet_groups = (gsz, perm): batched passes read the skip tensors of the encoder batch by group permutation
       skip = maybe_concat_unet_layer(hw, unet_end_points, cfg.max_ch)
-      if skip is not None and unet_groups is not None:
-        net = ops.upsample2x_concat(net, skip, unet_groups[0], unet_groups[1])
+      gsz, perm = unet_groups if (skip is not None and unet_groups is not None) else (0, ())
+      w0 = P['%s/%s/Conv/weights' % (top, name)]
+      if not (cfg.use_res_block or cfg.equalized_learning_rate) and ops.upcat_conv_supported(net, skip, w0):
+        # resize_twice_as_big + maybe_concat_unet_layer + the block's first conv as one op: no concat tensor
+        block_in = None
+        net = _ge_conv(P, '%s/%s/Conv' % (top, name), None, domain, cfg, upcat=(net, skip, gsz, perm))
       else:
-        net = ops.upsample2x_concat(net, skip)
-      block_in = net
-      net = _ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg)
+        net = ops.upsample2x_concat(net, skip, gsz, perm)
+        block_in = net
+        net = _ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg)
       net = _ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg)
       net = maybe_resblock(P, '%s/%s' % (top, name), block_in, output_channels, net, cfg)
     end_points[name] = net
