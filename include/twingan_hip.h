@@ -82,6 +82,14 @@ size_t tg_conv2d_bwd_weight_workspace(const TgConvDesc* d);
 int tg_conv2d_bwd_weight(const TgConvDesc* d, const void* x, const void* gy, float* gw, int accumulate,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same filter gradient over TWO batches of one layer in one launch: gw (+)= wgrad(xa [d->n images], gya) +
+ * wgrad(xb [nb images], gyb) -- e.g. the batched real/fake/interpolate pass and the gradient-penalty double-backward
+ * term of a discriminator conv, or the two encoder passes of a generator step.  `d` describes batch a.
+ * tg_conv2d_bwd_weight2_workspace returns 0 when the layer is not eligible (then issue two ordinary calls). */
+size_t tg_conv2d_bwd_weight2_workspace(const TgConvDesc* d, int nb);
+int tg_conv2d_bwd_weight2(const TgConvDesc* d, int nb, const void* xa, const void* gya, const void* xb, const void* gyb,
+                          float* gw, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 /* generator_three_layer_block's first conv (nets/pggan.py:69-78) with its input concat(nearest_up2(x0), x1)
  * (resize_twice_as_big + maybe_concat_unet_layer, nets/pggan_utils.py:281-298,349-350) read straight from the two
  * sources instead of from a materialised copy: y[n,h,w,cout] = conv3x3_same(concat(up2(x0 [n,h/2,w/2,c0]),

@@ -650,3 +650,18 @@ def test_upcat_conv_matches_materialised_path(ops, n, h, c0, c1, cout, gsz, perm
   assert rel_l2(host(x0.grad), host(ref[0])) < 1e-6
   assert rel_l2(host(x1.grad), host(ref[1])) < 1e-6
   assert rel_l2(host(w.grad), host(ref[2])) < 1e-5
+
+
+@pytest.mark.parametrize('hw,cin,cout,na,nb', [(16, 64, 32, 2, 3), (8, 256, 64, 3, 2), (32, 16, 16, 1, 4)])
+def test_paired_filter_gradient_matches_two_launches(ops, hw, cin, cout, na, nb):
+  """tg_conv2d_bwd_weight2 (two batches of one layer in one launch) == two tg_conv2d_bwd_weight launches."""
+  g = torch.Generator().manual_seed(7)
+  mk = lambda n, c: torch.randn(n, hw, hw, c, generator=g).to(dev()).bfloat16()
+  xa, gya, xb, gyb = mk(na, cin), mk(na, cout), mk(nb, cin), mk(nb, cout)
+  spec = ops.ConvSpec(3, 'SAME')
+  ref = torch.zeros(3, 3, cin, cout, device=dev())
+  ops.conv_bwd_weight_raw(xa, gya, spec, out=ref)
+  ops.conv_bwd_weight_raw(xb, gyb, spec, out=ref)
+  out = torch.zeros_like(ref)
+  assert ops.conv_bwd_weight2_raw(xa, gya, xb, gyb, spec, out)
+  assert rel_l2(host(out), host(ref)) < 1e-5

@@ -43,6 +43,11 @@ int tg_conv2d_bwd_weight_direct(const TgConvDesc*, const void*, const void*, flo
 int tg_conv2d_fwd_mfma(const TgConvDesc*, const void*, const void*, const float*, void*, hipStream_t);
 int tg_conv2d_bwd_data_mfma(const TgConvDesc*, const void*, const void*, void*, hipStream_t);
 size_t tg_conv2d_bwd_weight_workspace_mfma(const TgConvDesc*);
+bool tg_conv2d_bwd_weight2_supported_mfma(const TgConvDesc* d);
+size_t tg_conv2d_bwd_weight2_workspace_mfma(const TgConvDesc* d, int nb);
+int tg_conv2d_bwd_weight2_mfma(const TgConvDesc* d, int nb, const void* xa, const void* gya, const void* xb, const void* gyb,
+                               float* gw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+
 bool tg_conv_tile_upcat_supported(int h, int w, int c0, int c1, int cout);
 int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, const void* x0,
                            const void* x1, const void* wp, void* y, hipStream_t s);
@@ -97,6 +102,23 @@ int tg_conv2d_bwd_data(const TgConvDesc* d, const void* gy, const void* w, void*
 size_t tg_conv2d_bwd_weight_workspace(const TgConvDesc* d) {
   if (!d || d->algo == TG_ALGO_DIRECT) return 0;
   return tg_conv2d_bwd_weight_workspace_mfma(d);
+}
+
+size_t tg_conv2d_bwd_weight2_workspace(const TgConvDesc* d, int nb) {
+  if (!d || nb <= 0 || check_desc("tg_conv2d_bwd_weight2_workspace", d) || d->algo == TG_ALGO_DIRECT ||
+      !tg_conv2d_bwd_weight2_supported_mfma(d))
+    return 0;
+  return tg_conv2d_bwd_weight2_workspace_mfma(d, nb);
+}
+
+int tg_conv2d_bwd_weight2(const TgConvDesc* d, int nb, const void* xa, const void* gya, const void* xb, const void* gyb,
+                          float* gw, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_desc("tg_conv2d_bwd_weight2", d);
+  if (rc) return rc;
+  TG_CHECK(xa && gya && xb && gyb && gw && nb > 0, TG_EINVAL, "tg_conv2d_bwd_weight2: bad arguments");
+  TG_CHECK(d->algo != TG_ALGO_DIRECT && tg_conv2d_bwd_weight2_supported_mfma(d), TG_ENOSUP,
+           "tg_conv2d_bwd_weight2: layer not taken by the tile kernel (query tg_conv2d_bwd_weight2_workspace first)");
+  return tg_conv2d_bwd_weight2_mfma(d, nb, xa, gya, xb, gyb, gw, accumulate, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int tg_conv2d_upcat_supported(int h, int w, int c0, int c1, int cout) {

@@ -593,6 +593,20 @@ static bool use_wgrad_tile(const TgConvDesc* d) {
          tg_wgrad_tile_supported(d->hin, d->win, d->hout, d->wout, d->kh, d->kw, d->pad_t, d->pad_l);
 }
 
+size_t tg_wgrad_tile_workspace2(int na, int nb, int h, int w, int cin, int cout);
+int tg_wgrad_tile_run2(int na, int nb, int h, int w, int cin, int cout, const void* xa, const void* gya, const void* xb,
+                       const void* gyb, float* gw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+
+// two batches (na, nb images) of one layer: supported when the tile kernel takes the layer
+bool tg_conv2d_bwd_weight2_supported_mfma(const TgConvDesc* d) { return d->dtype == TG_BF16 && use_wgrad_tile(d); }
+size_t tg_conv2d_bwd_weight2_workspace_mfma(const TgConvDesc* d, int nb) {
+  return tg_wgrad_tile_workspace2(d->n, nb, d->hin, d->win, d->cin, d->cout);
+}
+int tg_conv2d_bwd_weight2_mfma(const TgConvDesc* d, int nb, const void* xa, const void* gya, const void* xb, const void* gyb,
+                               float* gw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+  return tg_wgrad_tile_run2(d->n, nb, d->hin, d->win, d->cin, d->cout, xa, gya, xb, gyb, gw, accumulate, ws, ws_bytes, s);
+}
+
 size_t tg_conv2d_bwd_weight_workspace_mfma(const TgConvDesc* d0) {
   TgConvDesc dd;
   const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;

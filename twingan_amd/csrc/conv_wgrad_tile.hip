@@ -35,6 +35,12 @@ struct WgGeom {
   const bf16* x1;
   int c0, gsz;
   unsigned perm;
+  // second (x, gy) segment of the SAME layer (another batch whose gradient goes to the same weight): tiles
+  // [tiles_a, total_tiles) read it -- one launch instead of two (every launch costs ~15-20 us of ramp, slab write and
+  // reduction whatever its size).  tiles_a == total_tiles: no second segment.
+  const bf16* xb;
+  const bf16* gyb;
+  int nb, tiles_a;
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
@@ -164,6 +170,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   auto load_tile = [&](Stage& st, int tile) __attribute__((always_inline)) {
     const unsigned live = tile < tile_end;      // past the end: every lane out of range -> a tile of zeros
     int t = live ? tile : tile_begin;
+    const bool segb = t >= g.tiles_a;           // second (x, gy) pair
+    if (segb) t -= g.tiles_a;
+    const bf16* xs = segb ? g.xb : xsrc;
+    const bf16* gs = segb ? g.gyb : gy;
+    const int nseg = segb ? g.nb : g.n;
     int img, ox0, oy0, nimg;
     if constexpr (TW == 16) {
       const int tx = t % g.tiles_x;
@@ -176,11 +187,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
     } else {
       img = t * 2;                              // the pair (2t, 2t+1); an odd batch ends with a half-empty tile:
       ox0 = oy0 = 0;                            // the buffer resource then covers one image, the other reads zeros
-      nimg = img + 1 < g.n ? 2 : 1;
+      nimg = img + 1 < nseg ? 2 : 1;
     }
     const int ximg_i = (from_skip && g.gsz) ? (int)((g.perm >> (8 * (img / g.gsz))) & 0xffu) * g.gsz + img % g.gsz : img;
-    const __amdgpu_buffer_rsrc_t bx = wg_rsrc(xsrc + (size_t)ximg_i * ximg, (unsigned)(ximg * 2 * nimg));
-    const __amdgpu_buffer_rsrc_t bg = wg_rsrc(gy + (size_t)img * gimg, (unsigned)(gimg * 2 * nimg));
+    const __amdgpu_buffer_rsrc_t bx = wg_rsrc(xs + (size_t)ximg_i * ximg, (unsigned)(ximg * 2 * nimg));
+    const __amdgpu_buffer_rsrc_t bg = wg_rsrc(gs + (size_t)img * gimg, (unsigned)(gimg * 2 * nimg));
     const int xbase = from_up ? ((oy0 >> 1) * (g.w >> 1) + (ox0 >> 1)) * xc * 2 : (oy0 * g.w + ox0) * xc * 2;
     const unsigned gbase = (unsigned)((oy0 * g.w + ox0) * g.cout * 2);
 #pragma unroll
@@ -302,18 +313,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_slab_reduce(const float* __res
   }
 }
 
-void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices) {
+void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices, int nb = 0) {
   g->n = n; g->h = h; g->w = w; g->cin = cin; g->cout = cout;
   g->x1 = nullptr;
   g->c0 = g->gsz = 0;
   g->perm = 0;
+  g->xb = g->gyb = nullptr;
+  g->nb = nb;
   if (w == 8) {      // 8x8 maps: a tile is a pair of images
     g->tiles_x = g->tiles_y = 1;
-    g->total_tiles = (n + 1) / 2;
+    g->tiles_a = (n + 1) / 2;
+    g->total_tiles = g->tiles_a + (nb + 1) / 2;
   } else {
     g->tiles_x = w / 16;
     g->tiles_y = h / 8;
-    g->total_tiles = g->tiles_x * g->tiles_y * n;
+    g->tiles_a = g->tiles_x * g->tiles_y * n;
+    g->total_tiles = g->tiles_a + g->tiles_x * g->tiles_y * nb;
   }
   const int n_ci = (cin + 31) / 32;
   g->n_co_blk = (cout + 31) / 32;
@@ -367,6 +382,36 @@ int tg_wgrad_tile_run(int n, int h, int w, int cin, int cout, const void* x, con
     hipLaunchKernelGGL(conv_wgrad_tile_kernel<16>, dim3(nslices * n_ci * g.n_co_blk), dim3(256), lds, s, (const bf16*)x,
                        (const bf16*)gy, (float*)ws, g);
   TG_LAUNCH_CHECK("conv_wgrad_tile");
+  return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
+}
+
+size_t tg_wgrad_tile_workspace2(int na, int nb, int h, int w, int cin, int cout) {
+  WgGeom g;
+  int nslices;
+  wg_split(na, h, w, cin, cout, &g, &nslices, nb);
+  return (size_t)nslices * 9 * cin * cout * sizeof(float);
+}
+
+// gw (+)= wgrad(xa, gya) + wgrad(xb, gyb): two batches of the same layer in one launch
+int tg_wgrad_tile_run2(int na, int nb, int h, int w, int cin, int cout, const void* xa, const void* gya, const void* xb,
+                       const void* gyb, float* gw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+  WgGeom g;
+  int nslices;
+  wg_split(na, h, w, cin, cout, &g, &nslices, nb);
+  g.xb = (const bf16*)xb;
+  g.gyb = (const bf16*)gyb;
+  const int64_t nw = (int64_t)9 * cin * cout;
+  TG_CHECK(ws && ws_bytes >= (size_t)nslices * nw * sizeof(float), TG_EINVAL,
+           "tg_conv2d_bwd_weight2: workspace too small (%zu < %zu)", ws_bytes, (size_t)nslices * nw * sizeof(float));
+  const int n_ci = (cin + 31) / 32;
+  tg_note_kernel("conv_wgrad_tile_kernel");
+  if (w == 8)
+    hipLaunchKernelGGL(conv_wgrad_tile_kernel<8>, dim3(nslices * n_ci * g.n_co_blk), dim3(256),
+                       2 * (2 * 10 * 10 * 64 + 8 * 16 * 64), s, (const bf16*)xa, (const bf16*)gya, (float*)ws, g);
+  else
+    hipLaunchKernelGGL(conv_wgrad_tile_kernel<16>, dim3(nslices * n_ci * g.n_co_blk), dim3(256),
+                       2 * (10 * 18 * 64 + 8 * 16 * 64), s, (const bf16*)xa, (const bf16*)gya, (float*)ws, g);
+  TG_LAUNCH_CHECK("conv_wgrad_tile(2)");
   return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
 }
 

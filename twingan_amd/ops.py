@@ -133,12 +133,44 @@ class GradSink:
   @classmethod
   def clear(cls):
     cls._sinks.clear()
+    cls._held = {}
 
   @classmethod
   def get(cls, p):
     if p is None or torch.is_grad_enabled():
       return None
     return cls._sinks.get(p.data_ptr())
+
+  # Pairing of filter gradients: with ``pair`` on (the trainer), the first filter-gradient request of a weight in a
+  # backward pass is held back; when a second one for the same weight arrives (the batched real/fake/interpolate pass
+  # and the gradient-penalty double-backward term of a discriminator conv; the two encoder passes of a generator step)
+  # both run as ONE tg_conv2d_bwd_weight2 launch.  flush() issues the ones that stayed alone; it runs where gradients
+  # are consumed (Trainer before the all-reduce / Adam, ParamStore.grad_dict()).
+  pair = False
+  _held = {}      # weight data_ptr -> (x, gy, spec, sink)
+
+  @classmethod
+  def submit(cls, w, x, gy, spec, sink):
+    if not cls.pair:
+      conv_bwd_weight_raw(x, gy, spec, out=sink)
+      return
+    key = w.data_ptr()
+    first = cls._held.pop(key, None)
+    if first is None:
+      cls._held[key] = (x, gy, spec, sink)
+    elif not conv_bwd_weight2_raw(first[0], first[1], x, gy, spec, sink):
+      conv_bwd_weight_raw(first[0], first[1], first[2], out=sink)
+      conv_bwd_weight_raw(x, gy, spec, out=sink)
+
+  @classmethod
+  def flush(cls):
+    held, cls._held = cls._held, {}
+    cur = torch.cuda.current_stream() if held else None
+    for x, gy, spec, sink in held.values():
+      conv_bwd_weight_raw(x, gy, spec, out=sink)
+      x.record_stream(cur)       # may have been produced on a domain stream
+      gy.record_stream(cur)
+    return len(held)
 
 
 class _State:
@@ -251,11 +283,33 @@ def conv_bwd_weight_raw(x, gy, spec, out=None):
   return gw
 
 
+def conv_bwd_weight2_raw(xa, gya, xb, gyb, spec, out):
+  """out += wgrad(xa, gya) + wgrad(xb, gyb) in one launch; False when the layer is not eligible."""
+  _chk(xa, gya, xb, gyb)
+  if xa.shape[1:] != xb.shape[1:] or gya.shape[1:] != gyb.shape[1:] or xa.dtype != xb.dtype:
+    return False
+  d = _desc(xa.shape, gya.shape[3], spec, xa.dtype, 0)
+  nb = xb.shape[0]
+  nbytes = _lib.load().tg_conv2d_bwd_weight2_workspace(ctypes.byref(d), nb)
+  if not nbytes:
+    return False
+  ws = torch.empty(nbytes, dtype=torch.uint8, device=xa.device)
+  es = _esize(xa)
+
+  def work():
+    tag, fl, by = _conv_work(d, 'wgrad', es)
+    k = (d.n + nb) / d.n
+    return (tag.replace(':n%d' % d.n, ':n%d+%d' % (d.n, nb)), int(fl * k), int(by * k))
+  call('tg_conv2d_bwd_weight2', ctypes.byref(d), nb, _p(xa), _p(gya), _p(xb), _p(gyb), _p(out), 1, _p(ws), nbytes, _stream(),
+       work=work)
+  return True
+
+
 def _weight_grad(x, g, spec, w):
   """Parameter gradient of a conv: into the sink when ``w`` has one (returns None), else a differentiable node."""
   sink = GradSink.get(w)
   if sink is not None:
-    conv_bwd_weight_raw(x, g, spec, out=sink)
+    GradSink.submit(w, x, g, spec, sink)
     return None
   return ConvBwdWeightFn.apply(x, g, spec)
 

@@ -149,6 +149,7 @@ class ParamStore:
     return {k: self._logical(self.P[k].detach(), s).clone() for k, s in self.specs.items()}
 
   def grad_dict(self):
+    GradSink.flush()                             # filter gradients held back for pairing
     if self.device.type == 'cuda':
       torch.cuda.synchronize(self.device)      # gradient sinks are written by kernels on several streams
     return {k: self._logical(self.P[k].grad, s).clone() for k, s in self.specs.items()}

@@ -286,8 +286,13 @@ class Trainer:
     self.store.zero_grad('g')
     self._set_requires_grad(g=True, d=False)
     loss, terms = generator_loss(self.P, sources, targets, self.cfg)
-    (loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)).backward()     # model_deploy.py:265-268,308-313
+    ops.GradSink.pair = True
+    try:
+      (loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)).backward()     # model_deploy.py:265-268,308-313
+    finally:
+      ops.GradSink.pair = False
     _DomainStreams.join_all(self.device)
+    ops.GradSink.flush()
     pggan.end_run(self.P)
     return loss.detach(), {k: v.detach() for k, v in terms.items()}
 
@@ -300,8 +305,13 @@ class Trainer:
     self.store.zero_grad('d')
     self._set_requires_grad(g=False, d=True)
     loss, terms = discriminator_loss(self.P, sources, targets, self.cfg, gp_alpha_s, gp_alpha_t)
-    (loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)).backward()
+    ops.GradSink.pair = True
+    try:
+      (loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)).backward()
+    finally:
+      ops.GradSink.pair = False
     _DomainStreams.join_all(self.device)
+    ops.GradSink.flush()
     pggan.end_run(self.P)
     return loss.detach(), {k: v.detach() for k, v in terms.items()}
 
