@@ -74,6 +74,12 @@ int tg_conv2d_fwd(const TgConvDesc* d, const void* x, const void* w, const float
 /* gx = d conv / d x applied to gy (Conv2DBackpropInput).  `d` is the FORWARD descriptor.
  * DIRECT: w = fp32 HWIO master.  MFMA: w = bf16 pack from tg_conv2d_pack_weights(mode 1). */
 int tg_conv2d_bwd_data(const TgConvDesc* d, const void* gy, const void* w, void* gx, void* stream);
+/* The same with the LeakyReLU backward of the layer that PRODUCED this conv's input folded in:
+ * gx = bwd_data(gy) * (x_act > 0 ? 1 : d->lrelu_alpha), x_act = the forward input [n,hin,win,cin] (an activation
+ * output, so x_act > 0 iff its pre-activation was).  One epilogue read of x_act instead of a separate
+ * read-read-write pass (tf LeakyReluGrad after Conv2DBackpropInput). */
+int tg_conv2d_bwd_data_masked(const TgConvDesc* d, const void* gy, const void* w, const void* x_act, void* gx,
+                              void* stream);
 
 /* gw (fp32 HWIO) = d conv / d w (Conv2DBackpropFilter), `d` is the FORWARD descriptor.
  * workspace: tg_conv2d_bwd_weight_workspace(d) bytes (split-K partial slabs; may be 0/NULL).
@@ -89,6 +95,17 @@ int tg_conv2d_bwd_weight(const TgConvDesc* d, const void* x, const void* gy, flo
 size_t tg_conv2d_bwd_weight2_workspace(const TgConvDesc* d, int nb);
 int tg_conv2d_bwd_weight2(const TgConvDesc* d, int nb, const void* xa, const void* gya, const void* xb, const void* gyb,
                           float* gw, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Filter gradient AND bias gradient of a conv + bias layer from one read of gy: gbias[cout] += sum over pixels of gy
+ * (BiasAddGrad; always ADDS -- the caller zeroes).  The tile kernels get it from one extra MFMA per K step with an
+ * all-ones operand; other shapes fall back to tg_channel_sum. */
+int tg_conv2d_bwd_weight_bias(const TgConvDesc* d, const void* x, const void* gy, float* gw, float* gbias, int accumulate,
+                              void* workspace, size_t workspace_bytes, void* stream);
+/* bias_segs: bit 0 = batch a contributes to gbias, bit 1 = batch b (the gradient-penalty double-backward term of a
+ * layer carries no bias gradient). */
+int tg_conv2d_bwd_weight2_bias(const TgConvDesc* d, int nb, const void* xa, const void* gya, const void* xb,
+                               const void* gyb, float* gw, float* gbias, int bias_segs, int accumulate, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /* generator_three_layer_block's first conv (nets/pggan.py:69-78) with its input concat(nearest_up2(x0), x1)
  * (resize_twice_as_big + maybe_concat_unet_layer, nets/pggan_utils.py:281-298,349-350) read straight from the two

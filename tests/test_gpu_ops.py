@@ -665,3 +665,38 @@ def test_paired_filter_gradient_matches_two_launches(ops, hw, cin, cout, na, nb)
   out = torch.zeros_like(ref)
   assert ops.conv_bwd_weight2_raw(xa, gya, xb, gyb, spec, out)
   assert rel_l2(host(out), host(ref)) < 1e-5
+
+
+@pytest.mark.parametrize('dtype,hw,c1,c2', [(torch.bfloat16, 16, 32, 64), (torch.bfloat16, 32, 16, 16), (torch.float32, 8, 8, 8),
+                                            (torch.bfloat16, 8, 64, 32)])
+def test_lrelu_backward_folded_into_next_backward_data(ops, dtype, hw, c1, c2):
+  """conv+bias+lrelu -> conv+bias+lrelu: with fuse_input_lrelu the first layer's LeakyReLU backward runs in the second
+  layer's backward-data epilogue and its bias gradient in its own filter-gradient kernel (gradient sinks); all
+  gradients must match the unfused chain."""
+  g = torch.Generator().manual_seed(21)
+  x = torch.randn(3, hw, hw, 16, generator=g).to(dev()).to(dtype)
+  w1 = (torch.randn(3, 3, 16, c1, generator=g) * 0.1).to(dev())
+  b1 = (torch.randn(c1, generator=g) * 0.1).to(dev())
+  w2 = (torch.randn(3, 3, c1, c2, generator=g) * 0.1).to(dev())
+  b2 = (torch.randn(c2, generator=g) * 0.1).to(dev())
+  gy = torch.randn(3, hw, hw, c2, generator=g).to(dev()).to(dtype)
+  res = []
+  for fuse, sinks in ((False, False), (True, False), (True, True)):
+    ops.GradSink.clear()
+    ps = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+    xin = x.clone().requires_grad_(True)
+    bufs = [torch.zeros_like(p) for p in ps]
+    if sinks:
+      for p, b in zip(ps, bufs):
+        ops.GradSink.register(p, b)
+    z1 = ops.conv2d(xin, ps[0], ps[1], 3, 'SAME', lrelu=True)
+    z2 = ops.conv2d(z1, ps[2], ps[3], 3, 'SAME', lrelu=True, fuse_input_lrelu=fuse)
+    z2.backward(gy)
+    ops.GradSink.flush()
+    grads = [b if sinks else p.grad for p, b in zip(ps, bufs)]
+    res.append([host(xin.grad)] + [host(t) for t in grads])
+  ops.GradSink.clear()
+  tol = 1e-5 if dtype == torch.float32 else 2e-2      # bf16: the fused path rounds gx once instead of twice
+  for other in res[1:]:
+    for a, b in zip(other, res[0]):
+      assert rel_l2(a, b) < tol

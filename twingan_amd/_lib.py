@@ -38,10 +38,13 @@ SIGNATURES = {
     'tg_last_kernel': (c_char_p, []),
     'tg_conv2d_fwd': (c_int, [_D, _P, _P, _FP, _P, _P]),
     'tg_conv2d_bwd_data': (c_int, [_D, _P, _P, _P, _P]),
+    'tg_conv2d_bwd_data_masked': (c_int, [_D, _P, _P, _P, _P, _P]),
     'tg_conv2d_bwd_weight_workspace': (c_size_t, [_D]),
     'tg_conv2d_bwd_weight': (c_int, [_D, _P, _P, _FP, c_int, _P, c_size_t, _P]),
     'tg_conv2d_bwd_weight2_workspace': (c_size_t, [_D, c_int]),
     'tg_conv2d_bwd_weight2': (c_int, [_D, c_int, _P, _P, _P, _P, _FP, c_int, _P, c_size_t, _P]),
+    'tg_conv2d_bwd_weight_bias': (c_int, [_D, _P, _P, _FP, _FP, c_int, _P, c_size_t, _P]),
+    'tg_conv2d_bwd_weight2_bias': (c_int, [_D, c_int, _P, _P, _P, _P, _FP, _FP, c_int, c_int, _P, c_size_t, _P]),
     'tg_conv2d_upcat_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'tg_conv2d_upcat_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_uint, _P]),
     'tg_conv2d_upcat_bwd_weight_workspace': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),

@@ -41,12 +41,15 @@ int tg_conv2d_fwd_direct(const TgConvDesc*, const void*, const void*, const floa
 int tg_conv2d_bwd_data_direct(const TgConvDesc*, const void*, const void*, void*, hipStream_t);
 int tg_conv2d_bwd_weight_direct(const TgConvDesc*, const void*, const void*, float*, int, hipStream_t);
 int tg_conv2d_fwd_mfma(const TgConvDesc*, const void*, const void*, const float*, void*, hipStream_t);
-int tg_conv2d_bwd_data_mfma(const TgConvDesc*, const void*, const void*, void*, hipStream_t);
+int tg_conv2d_bwd_data_mfma(const TgConvDesc*, const void*, const void*, void*, hipStream_t, const void* mask = nullptr);
+bool tg_conv2d_bwd_data_mask_fusable_mfma(const TgConvDesc*);
 size_t tg_conv2d_bwd_weight_workspace_mfma(const TgConvDesc*);
 bool tg_conv2d_bwd_weight2_supported_mfma(const TgConvDesc* d);
 size_t tg_conv2d_bwd_weight2_workspace_mfma(const TgConvDesc* d, int nb);
 int tg_conv2d_bwd_weight2_mfma(const TgConvDesc* d, int nb, const void* xa, const void* gya, const void* xb, const void* gyb,
-                               float* gw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+                               float* gw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s, float* gbias = nullptr,
+                               int bias_segs = 3);
+bool tg_conv2d_bwd_weight_bias_fused_mfma(const TgConvDesc* d);
 
 bool tg_conv_tile_upcat_supported(int h, int w, int c0, int c1, int cout);
 int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, const void* x0,
@@ -55,7 +58,8 @@ size_t tg_wgrad_tile_workspace(int n, int h, int w, int cin, int cout);
 int tg_wgrad_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, const void* x0,
                             const void* x1, const void* gy, float* gw, int accumulate, void* ws, size_t ws_bytes,
                             hipStream_t s);
-int tg_conv2d_bwd_weight_mfma(const TgConvDesc*, const void*, const void*, float*, int, void*, size_t, hipStream_t);
+int tg_conv2d_bwd_weight_mfma(const TgConvDesc*, const void*, const void*, float*, int, void*, size_t, hipStream_t,
+                              float* gbias = nullptr);
 
 static int check_desc(const char* who, const TgConvDesc* d) {
   TG_CHECK(d != nullptr, TG_EINVAL, "%s: null descriptor", who);
@@ -97,6 +101,21 @@ int tg_conv2d_bwd_data(const TgConvDesc* d, const void* gy, const void* w, void*
            "tg_conv2d_bwd_data: pointers must be 16 B aligned");
   if (d->algo != TG_ALGO_DIRECT) return tg_conv2d_bwd_data_mfma(d, gy, w, gx, (hipStream_t)stream);
   return tg_conv2d_bwd_data_direct(d, gy, w, gx, (hipStream_t)stream);
+}
+
+int tg_conv2d_bwd_data_masked(const TgConvDesc* d, const void* gy, const void* w, const void* x_act, void* gx,
+                              void* stream) {
+  int rc = check_desc("tg_conv2d_bwd_data_masked", d);
+  if (rc) return rc;
+  TG_CHECK(gy && w && gx && x_act, TG_EINVAL, "tg_conv2d_bwd_data_masked: null pointer");
+  TG_CHECK(tg_aligned16(gy) && tg_aligned16(w) && tg_aligned16(gx) && tg_aligned16(x_act), TG_EALIGN,
+           "tg_conv2d_bwd_data_masked: pointers must be 16 B aligned");
+  if (d->algo != TG_ALGO_DIRECT && tg_conv2d_bwd_data_mask_fusable_mfma(d))
+    return tg_conv2d_bwd_data_mfma(d, gy, w, gx, (hipStream_t)stream, x_act);
+  // not fusable for this shape / algorithm: plain backward-data, then the mask in place
+  rc = tg_conv2d_bwd_data(d, gy, w, gx, stream);
+  if (rc) return rc;
+  return tg_lrelu_bwd(gx, x_act, gx, (int64_t)d->n * d->hin * d->win * d->cin, d->lrelu_alpha, d->dtype, stream);
 }
 
 size_t tg_conv2d_bwd_weight_workspace(const TgConvDesc* d) {
@@ -155,6 +174,36 @@ int tg_conv2d_upcat_bwd_weight(const void* x0, const void* x1, const void* gy, f
   if (rc) return rc;
   return tg_wgrad_tile_upcat_run(n, h, w, c0, c1, cout, gsz, perm, x0, x1, gy, gw, accumulate, ws, ws_bytes,
                                  (hipStream_t)stream);
+}
+
+// gbias += sum over pixels of gy, either inside the filter-gradient kernel (tile kernels) or by tg_channel_sum
+static int bias_fallback(const TgConvDesc* d, const void* gy, float* gbias, int nimg, void* stream) {
+  return tg_channel_sum(gy, gbias, (int64_t)nimg * d->hout * d->wout, d->cout, 1, d->dtype, stream);
+}
+
+int tg_conv2d_bwd_weight_bias(const TgConvDesc* d, const void* x, const void* gy, float* gw, float* gbias, int accumulate,
+                              void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_desc("tg_conv2d_bwd_weight_bias", d);
+  if (rc) return rc;
+  TG_CHECK(x && gy && gw && gbias, TG_EINVAL, "tg_conv2d_bwd_weight_bias: null pointer");
+  if (d->algo != TG_ALGO_DIRECT && tg_conv2d_bwd_weight_bias_fused_mfma(d))
+    return tg_conv2d_bwd_weight_mfma(d, x, gy, gw, accumulate, ws, ws_bytes, (hipStream_t)stream, gbias);
+  rc = tg_conv2d_bwd_weight(d, x, gy, gw, accumulate, ws, ws_bytes, stream);
+  if (rc) return rc;
+  return bias_fallback(d, gy, gbias, d->n, stream);
+}
+
+int tg_conv2d_bwd_weight2_bias(const TgConvDesc* d, int nb, const void* xa, const void* gya, const void* xb,
+                               const void* gyb, float* gw, float* gbias, int bias_segs, int accumulate, void* ws,
+                               size_t ws_bytes, void* stream) {
+  int rc = check_desc("tg_conv2d_bwd_weight2_bias", d);
+  if (rc) return rc;
+  TG_CHECK(xa && gya && xb && gyb && gw && gbias && nb > 0, TG_EINVAL, "tg_conv2d_bwd_weight2_bias: bad arguments");
+  TG_CHECK(d->algo != TG_ALGO_DIRECT && tg_conv2d_bwd_weight2_supported_mfma(d), TG_ENOSUP,
+           "tg_conv2d_bwd_weight2_bias: layer not taken by the tile kernel");
+  TG_CHECK(bias_segs >= 1 && bias_segs <= 3, TG_EINVAL, "tg_conv2d_bwd_weight2_bias: bias_segs %d", bias_segs);
+  return tg_conv2d_bwd_weight2_mfma(d, nb, xa, gya, xb, gyb, gw, accumulate, ws, ws_bytes, (hipStream_t)stream, gbias,
+                                    bias_segs);
 }
 
 int tg_conv2d_bwd_weight(const TgConvDesc* d, const void* x, const void* gy, float* gw, int accumulate, void* ws,

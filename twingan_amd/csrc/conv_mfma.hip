@@ -520,7 +520,7 @@ int tg_conv2d_pack_weights_multi(const void* table_device, int njobs, int total_
 
 bool tg_conv_tile_supported(int h, int w, int hout, int wout, int kh, int kw, int pad_t, int pad_l);
 int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int epilogue, float alpha, const void* x,
-                     const void* wp, const float* bias, void* y, hipStream_t s);
+                     const void* wp, const float* bias, void* y, hipStream_t s, const void* mask = nullptr);
 
 bool tg_conv_small_supported(int n, int hout, int wout, int kh, int kw);
 int tg_conv_small_run(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l,
@@ -550,14 +550,24 @@ int tg_conv2d_fwd_mfma(const TgConvDesc* d0, const void* x, const void* wp, cons
   return dispatch_fwd<3, 3>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
 }
 
-int tg_conv2d_bwd_data_mfma(const TgConvDesc* d0, const void* gy, const void* wp, void* gx, hipStream_t s) {
+// Can the LeakyReLU backward of the producer of x be folded into this backward-data's epilogue?
+bool tg_conv2d_bwd_data_mask_fusable_mfma(const TgConvDesc* d0) {
+  TgConvDesc dd;
+  const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
+  return d->dtype == TG_BF16 && d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 &&
+         tg_conv_tile_supported(d->hout, d->wout, d->hin, d->win, d->kh, d->kw, d->pad_t, d->pad_l);
+}
+
+int tg_conv2d_bwd_data_mfma(const TgConvDesc* d0, const void* gy, const void* wp, void* gx, hipStream_t s,
+                            const void* mask) {
   TgConvDesc dd;
   const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
   TG_CHECK(d->dtype == TG_BF16, TG_ENOSUP, "tg_conv2d_bwd_data(mfma): bf16 activations only");
+  TG_CHECK(!mask || tg_conv2d_bwd_data_mask_fusable_mfma(d0), TG_ENOSUP, "tg_conv2d_bwd_data(mfma): mask not fusable here");
   if (d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 &&
       tg_conv_tile_supported(d->hout, d->wout, d->hin, d->win, d->kh, d->kw, d->pad_t, d->pad_l))
-    return tg_conv_tile_run(d->n, d->hout, d->wout, d->cout, d->cin, d->kh, d->kh - 1 - d->pad_t, 0, 1.f, gy, wp, nullptr,
-                            gx, s);
+    return tg_conv_tile_run(d->n, d->hout, d->wout, d->cout, d->cin, d->kh, d->kh - 1 - d->pad_t, 0,
+                            mask ? d->lrelu_alpha : 1.f, gy, wp, nullptr, gx, s, mask);
   if (d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 && d->pad_t == d->pad_l &&
       tg_conv_small_supported(d->n, d->hin, d->win, d->kh, d->kw))
     return tg_conv_small_run(d->n, d->hout, d->wout, d->cout, d->hin, d->win, d->cin, d->kh, d->kh - 1 - d->pad_t,
@@ -584,7 +594,7 @@ static void wgrad_split(const Geom& g, int* n_ci, int* n_co, int* nslices, int* 
 bool tg_wgrad_tile_supported(int h, int w, int hout, int wout, int kh, int kw, int pad_t, int pad_l);
 size_t tg_wgrad_tile_workspace(int n, int h, int w, int cin, int cout);
 int tg_wgrad_tile_run(int n, int h, int w, int cin, int cout, const void* x, const void* gy, float* gw, int accumulate,
-                      void* ws, size_t ws_bytes, hipStream_t s);
+                      void* ws, size_t ws_bytes, hipStream_t s, float* gbias = nullptr);
 
 int tg_wgrad_slab_reduce(const float* slab, float* gw, int64_t nw, int nslices, int accumulate, hipStream_t s);
 
@@ -595,7 +605,8 @@ static bool use_wgrad_tile(const TgConvDesc* d) {
 
 size_t tg_wgrad_tile_workspace2(int na, int nb, int h, int w, int cin, int cout);
 int tg_wgrad_tile_run2(int na, int nb, int h, int w, int cin, int cout, const void* xa, const void* gya, const void* xb,
-                       const void* gyb, float* gw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+                       const void* gyb, float* gw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s,
+                       float* gbias = nullptr, int bias_segs = 3);
 
 // two batches (na, nb images) of one layer: supported when the tile kernel takes the layer
 bool tg_conv2d_bwd_weight2_supported_mfma(const TgConvDesc* d) { return d->dtype == TG_BF16 && use_wgrad_tile(d); }
@@ -603,8 +614,17 @@ size_t tg_conv2d_bwd_weight2_workspace_mfma(const TgConvDesc* d, int nb) {
   return tg_wgrad_tile_workspace2(d->n, nb, d->hin, d->win, d->cin, d->cout);
 }
 int tg_conv2d_bwd_weight2_mfma(const TgConvDesc* d, int nb, const void* xa, const void* gya, const void* xb, const void* gyb,
-                               float* gw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
-  return tg_wgrad_tile_run2(d->n, nb, d->hin, d->win, d->cin, d->cout, xa, gya, xb, gyb, gw, accumulate, ws, ws_bytes, s);
+                               float* gw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s, float* gbias,
+                               int bias_segs) {
+  return tg_wgrad_tile_run2(d->n, nb, d->hin, d->win, d->cin, d->cout, xa, gya, xb, gyb, gw, accumulate, ws, ws_bytes, s,
+                            gbias, bias_segs);
+}
+
+// does tg_conv2d_bwd_weight_mfma produce the bias gradient itself for this descriptor?
+bool tg_conv2d_bwd_weight_bias_fused_mfma(const TgConvDesc* d0) {
+  TgConvDesc dd;
+  const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
+  return d->dtype == TG_BF16 && use_wgrad_tile(d);
 }
 
 size_t tg_conv2d_bwd_weight_workspace_mfma(const TgConvDesc* d0) {
@@ -621,11 +641,13 @@ size_t tg_conv2d_bwd_weight_workspace_mfma(const TgConvDesc* d0) {
 }
 
 int tg_conv2d_bwd_weight_mfma(const TgConvDesc* d0, const void* x, const void* gy, float* gw, int accumulate, void* ws,
-                              size_t ws_bytes, hipStream_t s) {
+                              size_t ws_bytes, hipStream_t s, float* gbias) {
   TgConvDesc dd;
   const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
   TG_CHECK(d->dtype == TG_BF16, TG_ENOSUP, "tg_conv2d_bwd_weight(mfma): bf16 activations only");
-  if (use_wgrad_tile(d)) return tg_wgrad_tile_run(d->n, d->hin, d->win, d->cin, d->cout, x, gy, gw, accumulate, ws, ws_bytes, s);
+  TG_CHECK(!gbias || use_wgrad_tile(d), TG_ENOSUP, "tg_conv2d_bwd_weight(mfma): bias gradient not fused for this layer");
+  if (use_wgrad_tile(d))
+    return tg_wgrad_tile_run(d->n, d->hin, d->win, d->cin, d->cout, x, gy, gw, accumulate, ws, ws_bytes, s, gbias);
   Geom g;
   int rc = fill_geom("tg_conv2d_bwd_weight", d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->kw,
                      d->pad_t, d->pad_l, &g);

@@ -37,6 +37,10 @@ struct TileGeom {
   const bf16* x1;
   int c0, gsz;
   unsigned perm;
+  // backward-data with the LeakyReLU backward of the PRODUCER of this conv's input folded into the epilogue:
+  // out = acc * (mask > 0 ? 1 : alpha), mask = the forward input (= the producer's activation output), same shape as
+  // the output (NULL: plain)
+  const bf16* mask;
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
@@ -52,6 +56,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 }
 __device__ __forceinline__ bf16x8 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
+// LeakyReLU derivative of 4 consecutive bf16 activations (8 bytes at `off`): z > 0 ? 1 : alpha
+__device__ __forceinline__ void mask4(__amdgpu_buffer_rsrc_t r, unsigned off, float alpha, float (&f)[4]) {
+  const u32x2 z = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+  f[0] = (short)(z[0] & 0xffffu) > 0 ? 1.f : alpha;      // a positive bf16 is a positive int16 pattern
+  f[1] = (short)(z[0] >> 16) > 0 ? 1.f : alpha;
+  f[2] = (short)(z[1] & 0xffffu) > 0 ? 1.f : alpha;
+  f[3] = (short)(z[1] >> 16) > 0 ? 1.f : alpha;
 }
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
@@ -210,6 +223,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
   // [16,32), each as two 16-byte vectors.
   const size_t out_img = (size_t)g.h * g.w * g.cout;
   const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + (size_t)img * out_img, (unsigned)(out_img * 2));
+  const __amdgpu_buffer_rsrc_t rmask =
+      make_rsrc(g.mask ? g.mask + (size_t)img * out_img : y, g.mask ? (unsigned)(out_img * 2) : 0u);
   const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, (g.epilogue & TG_EPI_BIAS) ? (unsigned)(g.cout * 4) : 0u);
 #pragma unroll
   for (int nt = 0; nt < NTILE; ++nt) {
@@ -230,6 +245,13 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
           float a = acc[m][nt][q * 4 + j] + bq[q][j];
           if (g.epilogue & TG_EPI_LRELU) a = lrelu_f(a, g.alpha);
           v[j] = a;
+        }
+        if (g.mask) {      // uniform
+          const int chq = n0 + nt * 32 + q * 8 + kgrp * 4;
+          float f[4];
+          mask4(rmask, chq + 4 <= g.cout ? (unsigned)(((oy * g.w + ox) * g.cout + chq) * 2) : OOB, g.alpha, f);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] *= f[j];
         }
         p[q][0] = pack_bf16x2(v[0], v[1]);
         p[q][1] = pack_bf16x2(v[2], v[3]);
@@ -401,6 +423,8 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
     const int ty = r % g.tiles_y;
     const int img = r / g.tiles_y;
     const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + (size_t)img * out_img, (unsigned)(out_img * 2));
+    const __amdgpu_buffer_rsrc_t rmask =
+        make_rsrc(g.mask ? g.mask + (size_t)img * out_img : y, g.mask ? (unsigned)(out_img * 2) : 0u);
     const int oy = ty * TH + wid * 2 + (l31 >> 4), ox = tx * TW + (l31 & 15);
 #pragma unroll
     for (int nt = 0; nt < NTILE; ++nt) {
@@ -413,6 +437,13 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
           float a = acc[nt][q * 4 + j] + bq[nt][q][j];
           if (g.epilogue & TG_EPI_LRELU) a = lrelu_f(a, g.alpha);
           v[j] = a;
+        }
+        if (g.mask) {      // uniform
+          const int chq = n0 + nt * 32 + q * 8 + kgrp * 4;
+          float f[4];
+          mask4(rmask, chq + 4 <= g.cout ? (unsigned)(((oy * g.w + ox) * g.cout + chq) * 2) : OOB, g.alpha, f);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] *= f[j];
         }
         p[q][0] = pack_bf16x2(v[0], v[1]);
         p[q][1] = pack_bf16x2(v[2], v[3]);
@@ -524,7 +555,7 @@ bool tg_conv_tile_supported(int h, int w, int hout, int wout, int kh, int kw, in
 }
 
 int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int epilogue, float alpha, const void* x,
-                     const void* wp, const float* bias, void* y, hipStream_t s) {
+                     const void* wp, const float* bias, void* y, hipStream_t s, const void* mask) {
   TileGeom g;
   g.n = n; g.h = h; g.w = w; g.cin = cin; g.cout = cout;
   g.cin_pad = (cin + 15) / 16 * 16;
@@ -535,6 +566,7 @@ int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int
   g.x1 = nullptr;
   g.c0 = g.gsz = 0;
   g.perm = 0;
+  g.mask = (const bf16*)mask;
   if (k == 1) return dispatch_tile<1>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
   return dispatch_tile<3>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
 }
@@ -558,5 +590,6 @@ int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gs
   g.c0 = c0;
   g.gsz = gsz;
   g.perm = perm;
+  g.mask = nullptr;
   return dispatch_tile_upcat(g, (const bf16*)x0, (const bf16*)wp, nullptr, (bf16*)y, s);
 }

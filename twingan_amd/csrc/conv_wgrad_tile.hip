@@ -41,6 +41,10 @@ struct WgGeom {
   const bf16* xb;
   const bf16* gyb;
   int nb, tiles_a;
+  // BIAS kernels: gbias[co] += sum over all pixels of gy[.., co] (BiasAddGrad of the layer), by the ci-block-0
+  // workgroups: one more MFMA per K step with an all-ones A operand.
+  float* gbias;
+  int bias_segs;      // bit 0: segment a contributes to gbias, bit 1: segment b
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
@@ -66,7 +70,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
 
 // TW = 16: a tile is 8 rows x 16 cols of one image (maps of 16x16 and up).  TW = 8: the 8x8 maps -- a tile is TWO
 // whole images, K step ks = image ks of the pair, and the two 8-pixel halves of a K step are rows 2w and 2w+1.
-template <int TW>
+template <int TW, bool BIAS = false>
 __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gy,
                                                               float* __restrict__ slab, const WgGeom g) {
   constexpr bool ATOMIC = false;
@@ -150,6 +154,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  f32x16 accb;                 // BIAS: every row = the column sums of gy
+  bf16x8 ones;
+  if constexpr (BIAS) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) accb[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+  }
+  const bool do_bias = BIAS && ci_blk == 0;      // uniform
+  bool bias_a = false, bias_b = false, bias_0 = false, bias_1 = false;      // per register stage / per LDS buffer
 
   const bool from_up = g.c0 != 0 && ci0 < g.c0, from_skip = g.c0 != 0 && ci0 >= g.c0;
   const int xc = from_up ? g.c0 : (from_skip ? g.cin - g.c0 : g.cin);      // channels per pixel of this block's source
@@ -167,10 +181,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   struct Stage {
     bf16x8 rx[XSLOTS], rg[GSLOTS];
   };
-  auto load_tile = [&](Stage& st, int tile) __attribute__((always_inline)) {
+  auto load_tile = [&](Stage& st, int tile, bool& bias_on) __attribute__((always_inline)) {
     const unsigned live = tile < tile_end;      // past the end: every lane out of range -> a tile of zeros
     int t = live ? tile : tile_begin;
     const bool segb = t >= g.tiles_a;           // second (x, gy) pair
+    bias_on = do_bias && ((g.bias_segs >> (segb ? 1 : 0)) & 1);
     if (segb) t -= g.tiles_a;
     const bf16* xs = segb ? g.xb : xsrc;
     const bf16* gs = segb ? g.gyb : gy;
@@ -212,13 +227,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
 #pragma unroll
     for (int s = 0; s < GSLOTS; ++s) *reinterpret_cast<bf16x8*>(bG + g_loff[s]) = st.rg[s];
   };
-  auto reduce_tile = [&](const unsigned char* bX, const unsigned char* bG) __attribute__((always_inline)) {
+  auto reduce_tile = [&](const unsigned char* bX, const unsigned char* bG, bool bias_on) __attribute__((always_inline)) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       // first pixel of this wave's K step in the gy tile / (for tap 0,0) in the halo tile
       const int gpx = TW == 16 ? (wid * 2 + ks) * 16 : ks * 64 + wid * 16;
       const int xpx = TW == 16 ? (wid * 2 + ks) * HWX : ks * (HH * HWX) + wid * 2 * HWX;
       const bf16x8 gf = tr_frag(bG + gpx * PS + frag_off);
+      if constexpr (BIAS) {
+        if (bias_on) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, gf, accb, 0, 0, 0);
+      }
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
@@ -234,17 +252,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   unsigned char* sG1 = sX1 + X_BYTES;
   // Two tiles per trip, no branches inside: a workgroup with an odd tile count reduces one all-zero tile.
   Stage sa, sb;
-  load_tile(sa, tile_begin);
-  load_tile(sb, tile_begin + 1);
+  load_tile(sa, tile_begin, bias_a);
+  load_tile(sb, tile_begin + 1, bias_b);
   for (int tile = tile_begin; tile < tile_end; tile += 2) {
     stage_to_lds(sa, sX, sG);
+    bias_0 = bias_a;
     __syncthreads();
-    load_tile(sa, tile + 2);
-    reduce_tile(sX, sG);
+    load_tile(sa, tile + 2, bias_a);
+    reduce_tile(sX, sG, bias_0);
     stage_to_lds(sb, sX1, sG1);
+    bias_1 = bias_b;
     __syncthreads();
-    load_tile(sb, tile + 3);
-    reduce_tile(sX1, sG1);
+    load_tile(sb, tile + 3, bias_b);
+    reduce_tile(sX1, sG1, bias_1);
   }
 
   // ---- cross-wave reduction through LDS, one tap at a time; write the valid part of the slab.
@@ -272,6 +292,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
         if (ATOMIC) atomicAdd(out + ((size_t)tap * g.cin + ci) * g.cout + co, sum);
         else out[((size_t)tap * g.cin + ci) * g.cout + co] = sum;
       }
+    }
+  }
+  if constexpr (BIAS) {
+    if (do_bias) {      // accb[0] on lanes 0..31 = row 0 of the all-equal rows: column sum of co0 + lane
+      __syncthreads();
+      if (lane < 32) red[wid * 32 + lane] = accb[0];
+      __syncthreads();
+      if (tid < 32 && co0 + tid < g.cout) atomicAdd(g.gbias + co0 + tid, red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid]);
     }
   }
 }
@@ -320,6 +348,8 @@ void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices, i
   g->perm = 0;
   g->xb = g->gyb = nullptr;
   g->nb = nb;
+  g->gbias = nullptr;
+  g->bias_segs = 3;
   if (w == 8) {      // 8x8 maps: a tile is a pair of images
     g->tiles_x = g->tiles_y = 1;
     g->tiles_a = (n + 1) / 2;
@@ -364,10 +394,11 @@ size_t tg_wgrad_tile_workspace(int n, int h, int w, int cin, int cout) {
 }
 
 int tg_wgrad_tile_run(int n, int h, int w, int cin, int cout, const void* x, const void* gy, float* gw, int accumulate,
-                      void* ws, size_t ws_bytes, hipStream_t s) {
+                      void* ws, size_t ws_bytes, hipStream_t s, float* gbias) {
   WgGeom g;
   int nslices;
   wg_split(n, h, w, cin, cout, &g, &nslices);
+  g.gbias = gbias;
   const int64_t nw = (int64_t)9 * cin * cout;
   TG_CHECK(ws && ws_bytes >= (size_t)nslices * nw * sizeof(float), TG_EINVAL,
            "tg_conv2d_bwd_weight(tile): workspace too small (%zu < %zu)", ws_bytes, (size_t)nslices * nw * sizeof(float));
@@ -375,12 +406,15 @@ int tg_wgrad_tile_run(int n, int h, int w, int cin, int cout, const void* x, con
   const size_t lds = 2 * (10 * 18 * 64 + 8 * 16 * 64);      // two tile buffers of 19712 B; the first doubles as the 16 KiB reduction scratch
   tg_note_kernel("conv_wgrad_tile_kernel");
   const size_t lds8 = 2 * (2 * 10 * 10 * 64 + 8 * 16 * 64);
-  if (w == 8)
-    hipLaunchKernelGGL(conv_wgrad_tile_kernel<8>, dim3(nslices * n_ci * g.n_co_blk), dim3(256), lds8, s, (const bf16*)x,
-                       (const bf16*)gy, (float*)ws, g);
+  const dim3 grid(nslices * n_ci * g.n_co_blk);
+  if (w == 8 && gbias)
+    hipLaunchKernelGGL((conv_wgrad_tile_kernel<8, true>), grid, dim3(256), lds8, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g);
+  else if (w == 8)
+    hipLaunchKernelGGL((conv_wgrad_tile_kernel<8>), grid, dim3(256), lds8, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g);
+  else if (gbias)
+    hipLaunchKernelGGL((conv_wgrad_tile_kernel<16, true>), grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g);
   else
-    hipLaunchKernelGGL(conv_wgrad_tile_kernel<16>, dim3(nslices * n_ci * g.n_co_blk), dim3(256), lds, s, (const bf16*)x,
-                       (const bf16*)gy, (float*)ws, g);
+    hipLaunchKernelGGL((conv_wgrad_tile_kernel<16>), grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g);
   TG_LAUNCH_CHECK("conv_wgrad_tile");
   return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
 }
@@ -394,23 +428,30 @@ size_t tg_wgrad_tile_workspace2(int na, int nb, int h, int w, int cin, int cout)
 
 // gw (+)= wgrad(xa, gya) + wgrad(xb, gyb): two batches of the same layer in one launch
 int tg_wgrad_tile_run2(int na, int nb, int h, int w, int cin, int cout, const void* xa, const void* gya, const void* xb,
-                       const void* gyb, float* gw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+                       const void* gyb, float* gw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s, float* gbias,
+                       int bias_segs) {
   WgGeom g;
   int nslices;
   wg_split(na, h, w, cin, cout, &g, &nslices, nb);
   g.xb = (const bf16*)xb;
   g.gyb = (const bf16*)gyb;
+  g.gbias = gbias;
+  g.bias_segs = bias_segs;
   const int64_t nw = (int64_t)9 * cin * cout;
   TG_CHECK(ws && ws_bytes >= (size_t)nslices * nw * sizeof(float), TG_EINVAL,
            "tg_conv2d_bwd_weight2: workspace too small (%zu < %zu)", ws_bytes, (size_t)nslices * nw * sizeof(float));
   const int n_ci = (cin + 31) / 32;
   tg_note_kernel("conv_wgrad_tile_kernel");
-  if (w == 8)
-    hipLaunchKernelGGL(conv_wgrad_tile_kernel<8>, dim3(nslices * n_ci * g.n_co_blk), dim3(256),
-                       2 * (2 * 10 * 10 * 64 + 8 * 16 * 64), s, (const bf16*)xa, (const bf16*)gya, (float*)ws, g);
+  const dim3 grid(nslices * n_ci * g.n_co_blk);
+  const size_t l8 = 2 * (2 * 10 * 10 * 64 + 8 * 16 * 64), l16 = 2 * (10 * 18 * 64 + 8 * 16 * 64);
+  if (w == 8 && gbias)
+    hipLaunchKernelGGL((conv_wgrad_tile_kernel<8, true>), grid, dim3(256), l8, s, (const bf16*)xa, (const bf16*)gya, (float*)ws, g);
+  else if (w == 8)
+    hipLaunchKernelGGL((conv_wgrad_tile_kernel<8>), grid, dim3(256), l8, s, (const bf16*)xa, (const bf16*)gya, (float*)ws, g);
+  else if (gbias)
+    hipLaunchKernelGGL((conv_wgrad_tile_kernel<16, true>), grid, dim3(256), l16, s, (const bf16*)xa, (const bf16*)gya, (float*)ws, g);
   else
-    hipLaunchKernelGGL(conv_wgrad_tile_kernel<16>, dim3(nslices * n_ci * g.n_co_blk), dim3(256),
-                       2 * (10 * 18 * 64 + 8 * 16 * 64), s, (const bf16*)xa, (const bf16*)gya, (float*)ws, g);
+    hipLaunchKernelGGL((conv_wgrad_tile_kernel<16>), grid, dim3(256), l16, s, (const bf16*)xa, (const bf16*)gya, (float*)ws, g);
   TG_LAUNCH_CHECK("conv_wgrad_tile(2)");
   return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
 }
@@ -433,7 +474,7 @@ int tg_wgrad_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int g
   const int n_ci = (cin + 31) / 32;
   const size_t lds = 2 * (10 * 18 * 64 + 8 * 16 * 64);
   tg_note_kernel("conv_wgrad_tile_kernel");
-  hipLaunchKernelGGL(conv_wgrad_tile_kernel<16>, dim3(nslices * n_ci * g.n_co_blk), dim3(256), lds, s, (const bf16*)x0,
+  hipLaunchKernelGGL((conv_wgrad_tile_kernel<16>), dim3(nslices * n_ci * g.n_co_blk), dim3(256), lds, s, (const bf16*)x0,
                      (const bf16*)gy, (float*)ws, g);
   TG_LAUNCH_CHECK("conv_wgrad_tile(upcat)");
   return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);

@@ -147,27 +147,31 @@ class GradSink:
   # both run as ONE tg_conv2d_bwd_weight2 launch.  flush() issues the ones that stayed alone; it runs where gradients
   # are consumed (Trainer before the all-reduce / Adam, ParamStore.grad_dict()).
   pair = False
-  _held = {}      # weight data_ptr -> (x, gy, spec, sink)
+  _held = {}      # weight data_ptr -> (x, gy, spec, sink, bias_sink)
 
   @classmethod
-  def submit(cls, w, x, gy, spec, sink):
+  def submit(cls, w, x, gy, spec, sink, bias_sink=None):
+    """``bias_sink``: the layer's bias gradient buffer when it is to be produced from this read of gy."""
     if not cls.pair:
-      conv_bwd_weight_raw(x, gy, spec, out=sink)
+      conv_bwd_weight_raw(x, gy, spec, out=sink, gbias=bias_sink)
       return
     key = w.data_ptr()
     first = cls._held.pop(key, None)
     if first is None:
-      cls._held[key] = (x, gy, spec, sink)
-    elif not conv_bwd_weight2_raw(first[0], first[1], x, gy, spec, sink):
-      conv_bwd_weight_raw(first[0], first[1], first[2], out=sink)
-      conv_bwd_weight_raw(x, gy, spec, out=sink)
+      cls._held[key] = (x, gy, spec, sink, bias_sink)
+      return
+    gb = first[4] if first[4] is not None else bias_sink
+    segs = (1 if first[4] is not None else 0) | (2 if bias_sink is not None else 0)
+    if not conv_bwd_weight2_raw(first[0], first[1], x, gy, spec, sink, gb, segs):
+      conv_bwd_weight_raw(first[0], first[1], first[2], out=sink, gbias=first[4])
+      conv_bwd_weight_raw(x, gy, spec, out=sink, gbias=bias_sink)
 
   @classmethod
   def flush(cls):
     held, cls._held = cls._held, {}
     cur = torch.cuda.current_stream() if held else None
-    for x, gy, spec, sink in held.values():
-      conv_bwd_weight_raw(x, gy, spec, out=sink)
+    for x, gy, spec, sink, bias_sink in held.values():
+      conv_bwd_weight_raw(x, gy, spec, out=sink, gbias=bias_sink)
       x.record_stream(cur)       # may have been produced on a domain stream
       gy.record_stream(cur)
     return len(held)
@@ -266,8 +270,21 @@ def conv_bwd_data_raw(gy, w, x_shape, spec):
   return gx
 
 
-def conv_bwd_weight_raw(x, gy, spec, out=None):
-  """gw = x^T * gy; with ``out`` the result is ADDED into that fp32 HWIO buffer (gradient sink)."""
+def conv_bwd_data_masked_raw(gy, w, x_act, spec):
+  """gx = conv^T(gy, w) * (x_act > 0 ? 1 : alpha): backward-data with the LeakyReLU backward of the layer that produced
+  this conv's input ``x_act`` folded into the epilogue (tg_conv2d_bwd_data_masked)."""
+  _chk(gy, w, x_act)
+  d = _desc(x_act.shape, w.shape[3], spec, gy.dtype, 0)
+  gx = torch.empty_like(x_act)
+  wk = PackCache.get(w, d, 1) if d.algo == TG_ALGO_MFMA else w
+  call('tg_conv2d_bwd_data_masked', ctypes.byref(d), _p(gy), _p(wk), _p(x_act), _p(gx), _stream(),
+       work=lambda: _conv_work(d, 'dgrad', _esize(gy)))
+  return gx
+
+
+def conv_bwd_weight_raw(x, gy, spec, out=None, gbias=None):
+  """gw = x^T * gy; with ``out`` the result is ADDED into that fp32 HWIO buffer (gradient sink).  ``gbias``: fp32 [cout]
+  buffer that also receives += sum over pixels of gy (the layer's bias gradient, from the same read of gy)."""
   _chk(x, gy)
   d = _desc(x.shape, gy.shape[3], spec, x.dtype, 0)
   shape = (spec.kh, spec.kw, x.shape[3], gy.shape[3])
@@ -278,13 +295,18 @@ def conv_bwd_weight_raw(x, gy, spec, out=None):
     gw = out
   nbytes = _lib.load().tg_conv2d_bwd_weight_workspace(ctypes.byref(d))
   ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device) if nbytes else None
-  call('tg_conv2d_bwd_weight', ctypes.byref(d), _p(x), _p(gy), _p(gw), 0 if out is None else 1, _p(ws), nbytes, _stream(),
-       work=lambda: _conv_work(d, 'wgrad', _esize(x)))
+  if gbias is not None:
+    call('tg_conv2d_bwd_weight_bias', ctypes.byref(d), _p(x), _p(gy), _p(gw), _p(gbias), 0 if out is None else 1, _p(ws),
+         nbytes, _stream(), work=lambda: _conv_work(d, 'wgrad', _esize(x)))
+  else:
+    call('tg_conv2d_bwd_weight', ctypes.byref(d), _p(x), _p(gy), _p(gw), 0 if out is None else 1, _p(ws), nbytes, _stream(),
+         work=lambda: _conv_work(d, 'wgrad', _esize(x)))
   return gw
 
 
-def conv_bwd_weight2_raw(xa, gya, xb, gyb, spec, out):
-  """out += wgrad(xa, gya) + wgrad(xb, gyb) in one launch; False when the layer is not eligible."""
+def conv_bwd_weight2_raw(xa, gya, xb, gyb, spec, out, gbias=None, bias_segs=3):
+  """out += wgrad(xa, gya) + wgrad(xb, gyb) in one launch; False when the layer is not eligible.  ``gbias`` += the
+  pixel sums of gya (bias_segs bit 0) and / or gyb (bit 1)."""
   _chk(xa, gya, xb, gyb)
   if xa.shape[1:] != xb.shape[1:] or gya.shape[1:] != gyb.shape[1:] or xa.dtype != xb.dtype:
     return False
@@ -300,17 +322,23 @@ def conv_bwd_weight2_raw(xa, gya, xb, gyb, spec, out):
     tag, fl, by = _conv_work(d, 'wgrad', es)
     k = (d.n + nb) / d.n
     return (tag.replace(':n%d' % d.n, ':n%d+%d' % (d.n, nb)), int(fl * k), int(by * k))
-  call('tg_conv2d_bwd_weight2', ctypes.byref(d), nb, _p(xa), _p(gya), _p(xb), _p(gyb), _p(out), 1, _p(ws), nbytes, _stream(),
-       work=work)
+  if gbias is not None:
+    call('tg_conv2d_bwd_weight2_bias', ctypes.byref(d), nb, _p(xa), _p(gya), _p(xb), _p(gyb), _p(out), _p(gbias), bias_segs,
+         1, _p(ws), nbytes, _stream(), work=work)
+  else:
+    call('tg_conv2d_bwd_weight2', ctypes.byref(d), nb, _p(xa), _p(gya), _p(xb), _p(gyb), _p(out), 1, _p(ws), nbytes,
+         _stream(), work=work)
   return True
 
 
-def _weight_grad(x, g, spec, w):
-  """Parameter gradient of a conv: into the sink when ``w`` has one (returns None), else a differentiable node."""
+def _weight_grad(x, g, spec, w, bias_sink=None):
+  """Parameter gradient of a conv: into the sink when ``w`` has one (returns None), else a differentiable node.
+  ``bias_sink``: also add the bias gradient (pixel sums of g) into that buffer from the same kernel."""
   sink = GradSink.get(w)
   if sink is not None:
-    GradSink.submit(w, x, g, spec, sink)
+    GradSink.submit(w, x, g, spec, sink, bias_sink)
     return None
+  assert bias_sink is None
   return ConvBwdWeightFn.apply(x, g, spec)
 
 
@@ -392,12 +420,20 @@ def _conv_backward(ctx, gz, gzp=None):
   gz = gz.contiguous() if gz is not None else None
   gzp = gzp.contiguous() if gzp is not None else None
   fused = (ctx.epilogue & TG_EPI_LRELU) and not torch.is_grad_enabled()
+  # the (single) consumer of z is a conv whose backward-data applies this layer's LeakyReLU mask itself
+  premasked = fused and gzp is None and getattr(ctx, 'tg_premasked', False)
+  bias_sink = None
   if gzp is not None and not fused:
     # differentiable composition (create_graph) or no activation: materialise the upsampled pooled gradient
     up = Pool2BwdFn.apply(gzp, 0.25, (z.shape[1], z.shape[2]) if z is not None else ctx.out_hw)
     gz = up if gz is None else gz + up
     gzp = None
-  if ctx.epilogue & TG_EPI_LRELU:
+  if premasked:
+    g = gz
+    if need_b and need_w and GradSink.get(bias) is not None and GradSink.get(w) is not None:
+      bias_sink = GradSink.get(bias)      # the filter-gradient kernel sums g over pixels as well
+      need_b = False
+  elif ctx.epilogue & TG_EPI_LRELU:
     if fused and (need_b or gzp is not None):
       g, gb = lrelu_pool_bwd(gz, gzp, z, spec.alpha, bias if need_b else None, need_b)
       need_b = False
@@ -405,20 +441,25 @@ def _conv_backward(ctx, gz, gzp=None):
       g = LReluBwdFn.apply(gz, z, spec.alpha)
   else:
     g = gz
-  gx = ConvBwdDataFn.apply(g, w, tuple(x.shape), spec) if ctx.needs_input_grad[0] else None
-  gw = _weight_grad(x, g, spec, w) if need_w else None
+  gx = None
+  if ctx.needs_input_grad[0]:
+    if getattr(ctx, 'mask_input', False) and not torch.is_grad_enabled():
+      gx = conv_bwd_data_masked_raw(g, w, x, spec)      # x = the producer's LeakyReLU output
+    else:
+      gx = ConvBwdDataFn.apply(g, w, tuple(x.shape), spec)
+  gw = _weight_grad(x, g, spec, w, bias_sink) if need_w else None
   if need_b:
     gb = _bias_grad(g, bias)
-  return gx, gw, gb, None, None
+  return gx, gw, gb, None, None, None
 
 
 class Conv2dFn(torch.autograd.Function):
   """z = epilogue(conv(x, w) [+ bias]) with epilogue in {none, bias, bias+lrelu, lrelu}."""
 
   @staticmethod
-  def forward(ctx, x, w, bias, spec, epilogue):
+  def forward(ctx, x, w, bias, spec, epilogue, mask_input=False):
     z = conv_fwd_raw(x, w, bias, spec, epilogue)
-    ctx.spec, ctx.epilogue = spec, epilogue
+    ctx.spec, ctx.epilogue, ctx.mask_input = spec, epilogue, mask_input
     ctx.out_hw = (z.shape[1], z.shape[2])
     ctx.save_for_backward(x, w, z if (epilogue & TG_EPI_LRELU) else None, bias)
     return z
@@ -434,8 +475,9 @@ class Conv2dPoolFn(torch.autograd.Function):
   pool's gradient into the LeakyReLU / bias-gradient kernel instead of upsampling it through HBM."""
 
   @staticmethod
-  def forward(ctx, x, w, bias, spec, epilogue):
+  def forward(ctx, x, w, bias, spec, epilogue, mask_input=False):
     z = conv_fwd_raw(x, w, bias, spec, epilogue)
+    ctx.mask_input = mask_input
     n, h, ww, c = z.shape
     zp = torch.empty((n, h // 2, ww // 2, c), dtype=z.dtype, device=z.device)
     call('tg_pool2x2_fwd', _p(z), _p(zp), n, h, ww, c, 0.25, _dt(z), _stream(),
@@ -449,7 +491,7 @@ class Conv2dPoolFn(torch.autograd.Function):
   @staticmethod
   def backward(ctx, gz, gzp):
     if gz is None and gzp is None:
-      return None, None, None, None, None
+      return None, None, None, None, None, None
     return _conv_backward(ctx, gz, gzp)
 
 
@@ -466,7 +508,7 @@ class ConvBwdDataFn(torch.autograd.Function):
   def backward(ctx, v):
     gy, w = ctx.saved_tensors
     v = v.contiguous()
-    ggy = Conv2dFn.apply(v, w, None, ctx.spec, 0) if ctx.needs_input_grad[0] else None
+    ggy = Conv2dFn.apply(v, w, None, ctx.spec, 0, False) if ctx.needs_input_grad[0] else None
     gw = _weight_grad(v, gy, ctx.spec, w) if (ctx.needs_input_grad[1] and not _State.skip_param_grads) else None
     return ggy, gw, None, None
 
@@ -513,14 +555,30 @@ class ChannelSumFn(torch.autograd.Function):
     raise NotImplementedError('gradient through a bias gradient')
 
 
-def conv2d(x, w, bias=None, k=3, padding='SAME', lrelu=False, alpha=LRELU_ALPHA, pool=False):
+def _claim_input_lrelu(x, alpha):
+  """``x`` is the LeakyReLU output of a conv node and THIS conv is its only consumer: take over its LeakyReLU
+  backward (our backward-data applies the mask in its epilogue; the producer then skips its own mask pass)."""
+  node = x.grad_fn
+  if node is None or not getattr(node, 'tg_lrelu_out', False) or getattr(node, 'tg_lrelu_alpha', None) != alpha:
+    return False
+  node.tg_premasked = True
+  return True
+
+
+def conv2d(x, w, bias=None, k=3, padding='SAME', lrelu=False, alpha=LRELU_ALPHA, pool=False, fuse_input_lrelu=False):
   """Stride-1 conv, optional fused bias and LeakyReLU (discriminator layers).  ``pool``: also return the
-  2x2 average-pooled output -> (z, z_pooled)."""
+  2x2 average-pooled output -> (z, z_pooled).  ``fuse_input_lrelu``: the caller guarantees that ``x`` is consumed by
+  this conv only; when x is a conv node's LeakyReLU output, that layer's LeakyReLU backward moves into this conv's
+  backward-data epilogue (first-order backward passes only; create_graph passes keep the separate nodes)."""
   spec = ConvSpec(k, padding, 0, alpha)
   epi = (TG_EPI_BIAS if bias is not None else 0) | (TG_EPI_LRELU if lrelu else 0)
+  mask_input = bool(fuse_input_lrelu) and _claim_input_lrelu(x, alpha)
   if pool:
-    return Conv2dPoolFn.apply(x, w, bias, spec, epi)
-  return Conv2dFn.apply(x, w, bias, spec, epi)
+    return Conv2dPoolFn.apply(x, w, bias, spec, epi, mask_input)
+  z = Conv2dFn.apply(x, w, bias, spec, epi, mask_input)
+  if lrelu and z.grad_fn is not None:
+    z.grad_fn.tg_lrelu_out, z.grad_fn.tg_lrelu_alpha = True, alpha
+  return z
 
 
 # ------------------------------------------------------------------------------------------------
@@ -554,7 +612,9 @@ class PointwiseConvFn(torch.autograd.Function):
     params = not _State.skip_param_grads
     need_b = bool(ctx.epilogue & TG_EPI_BIAS) and ctx.needs_input_grad[2] and params
     gb = None
-    if ctx.epilogue & TG_EPI_LRELU:
+    if (ctx.epilogue & TG_EPI_LRELU) and getattr(ctx, 'tg_premasked', False) and not torch.is_grad_enabled():
+      g = gz      # the consumer conv's backward-data already applied this layer's LeakyReLU mask
+    elif ctx.epilogue & TG_EPI_LRELU:
       if need_b and not torch.is_grad_enabled():
         g, gb = lrelu_pool_bwd(gz, None, z.reshape(-1, 1, 1, z.shape[-1]) if z.dim() != 4 else z, ctx.alpha, bias, True)
         g = g.reshape(gz.shape)
@@ -600,7 +660,10 @@ def pointwise_conv(x, w_hwio, bias=None, lrelu=False, alpha=LRELU_ALPHA):
   """1x1 conv with w [1,1,cin,cout] where cin <= 4 or cout <= 4."""
   w2 = w_hwio.view(w_hwio.shape[2], w_hwio.shape[3])
   epi = (TG_EPI_BIAS if bias is not None else 0) | (TG_EPI_LRELU if lrelu else 0)
-  return PointwiseConvFn.apply(x, w2, bias, False, epi, alpha)
+  z = PointwiseConvFn.apply(x, w2, bias, False, epi, alpha)
+  if lrelu and z.grad_fn is not None:
+    z.grad_fn.tg_lrelu_out, z.grad_fn.tg_lrelu_alpha = True, alpha
+  return z
 
 
 # ------------------------------------------------------------------------------------------------

@@ -222,7 +222,7 @@ def _batch_renorm(P, scope, yv, domain, activation, pn, pool):
                       pool=pool, stats=(mean, rstd))
 
 
-def _d_conv(P, scope, x, cfg, k=3, padding='SAME', pool=False, in_ch=None):
+def _d_conv(P, scope, x, cfg, k=3, padding='SAME', pool=False, in_ch=None, sole_consumer=False):
   """Discriminator arg-scope (nets/pggan_utils.py:116-127): conv + bias, no norm, LeakyReLU(0.2),
   fused into the conv epilogue."""
   w = _sn(P, scope, cfg, True)
@@ -230,7 +230,10 @@ def _d_conv(P, scope, x, cfg, k=3, padding='SAME', pool=False, in_ch=None):
   x = _equalize(x, cfg, k, in_ch)      # in_ch: logical channel count when x is channel-padded (minibatch stddev)
   if k == 1 and (w.shape[2] <= 4 or w.shape[3] <= 4):
     return ops.pointwise_conv(x, w, b, lrelu=True)
-  return ops.conv2d(x, w, b, k, padding, lrelu=True, pool=pool)
+  # sole_consumer: nothing else reads x, so (when x is the previous conv's LeakyReLU output and no input scaling sits
+  # in between) that layer's LeakyReLU backward is folded into this conv's backward-data
+  fuse = sole_consumer and not cfg.equalized_learning_rate and not cfg.use_res_block
+  return ops.conv2d(x, w, b, k, padding, lrelu=True, pool=pool, fuse_input_lrelu=fuse)
 
 
 def resize_twice_as_big(x):
@@ -371,13 +374,13 @@ def discriminator_before_fc(P, source, cfg, top, groups=1):
     net = maybe_add_self_attention(P, top, current_hw, num_channels, net, end_points, None, cfg, True)   # pggan.py:294-296
     name = 'encoder_block_%dx%dx%d' % (current_hw, current_hw, num_channels)
     block_in = net
-    net = _d_conv(P, '%s/%s/Conv' % (top, name), net, cfg)
+    net = _d_conv(P, '%s/%s/Conv' % (top, name), net, cfg, sole_consumer=True)
     if cfg.use_res_block:
       net = _d_conv(P, '%s/%s/Conv_1' % (top, name), net, cfg)
       end_points[name] = maybe_resblock(P, '%s/%s' % (top, name), block_in, num_channels, net, cfg, True)
       net = ops.avg_pool2(end_points[name])
     else:
-      end_points[name], net = _d_conv(P, '%s/%s/Conv_1' % (top, name), net, cfg, pool=True)   # conv + avg_pool (pggan.py:304-306)
+      end_points[name], net = _d_conv(P, '%s/%s/Conv_1' % (top, name), net, cfg, pool=True, sole_consumer=True)   # conv + avg_pool (pggan.py:304-306)
     current_hw //= 2
     end_points['downsample_to_%dx%dx%d' % (current_hw, current_hw, num_channels)] = net
     if stage == max_stage and cfg.is_growing:
@@ -386,7 +389,7 @@ def discriminator_before_fc(P, source, cfg, top, groups=1):
   blk = 'before_fc_1x1x%d' % cfg.max_ch
   net = ops.minibatch_state_concat(net, mbstd_cpad(net.shape[3]), groups)      # pggan_utils.py:353-366
   net = _d_conv(P, '%s/%s/Conv' % (top, blk), net, cfg, k=3, padding='SAME', in_ch=cfg.max_ch + 1)
-  net = _d_conv(P, '%s/%s/Conv_1' % (top, blk), net, cfg, k=4, padding='VALID')
+  net = _d_conv(P, '%s/%s/Conv_1' % (top, blk), net, cfg, k=4, padding='VALID', sole_consumer=True)
   end_points[blk] = net
   end_points['before_fc'] = net
   return net, end_points
