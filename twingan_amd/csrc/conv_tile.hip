@@ -20,6 +20,7 @@
 // Reference call sites replaced: tf.contrib.layers.conv2d at nets/pggan_utils.py:316-320 (every
 // E/G/D conv of nets/pggan.py at 16x16 and above) and its Conv2DBackpropInput gradient.
 #include "tg_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -526,7 +527,9 @@ int dispatch_tile_upcat(const TileGeom& g, const bf16* x, const bf16* wp, const 
 
 template <int KH>
 int dispatch_tile(const TileGeom& g, const bf16* x, const bf16* wp, const float* bias, bf16* y, hipStream_t s) {
-  const bool wide = g.cout > 32;
+  // 64-channel blocks halve the pixel staging per output, but a grid under ~4 workgroups per CU wants 32-channel
+  // blocks (kbench 16x16x256 n16: 15.7 -> 10.6 us; 32x32x128 n48: 21.9 -> 20.2 us; above 1024 blocks 64 wins)
+  const bool wide = g.cout > 32 && (g.w / 16) * (g.h / 8) * g.n * ((g.cout + 63) / 64) >= 1024;
   const int tiles1 = (g.w / 16) * (g.h / 8) * g.n * ((g.cout + (wide ? 63 : 31)) / (wide ? 64 : 32));
   // two sub-tiles per wave (256-pixel workgroup tile) halve the weight staging per pixel; use them
   // when that still leaves >= 2 workgroups per CU and the map is tall enough
