@@ -463,6 +463,7 @@ struct PackJob {
 constexpr int PACK_EPB = 2048;
 
 __global__ __launch_bounds__(256) void pack_weights_multi(const PackJob* __restrict__ jobs, int njobs) {
+  __shared__ float tile[64][65];
   // binary search: the job whose [block_begin, block_end) holds this block (uniform -> scalar loads)
   int lo = 0, hi = njobs - 1;
   const int b = blockIdx.x;
@@ -472,6 +473,29 @@ __global__ __launch_bounds__(256) void pack_weights_multi(const PackJob* __restr
     else hi = mid;
   }
   const PackJob j = jobs[lo];
+  if (j.mode == 0) {
+    // out[co][tap][ci] = w[tap][ci][co]: a transpose per tap.  One block = one 64 (ci) x 64 (co) tile through LDS so
+    // that both the fp32 reads (along co) and the bf16 writes (along ci) are coalesced.
+    const int kt = (j.inner_pad + 63) / 64, rt = j.rows_pad / 64;
+    int t = b - j.block_begin;
+    const int k0 = (t % kt) * 64;
+    t /= kt;
+    const int r0 = (t % rt) * 64;
+    const int tap = t / rt;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+      const int ci = k0 + i, co = r0 + tx;
+      tile[i][tx] = (ci < j.cin && co < j.cout) ? j.w[((int64_t)tap * j.cin + ci) * j.cout + co] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+      const int co = r0 + i, ci = k0 + tx;
+      if (ci < j.inner_pad) j.out[((int64_t)co * j.nt + tap) * j.inner_pad + ci] = (bf16)tile[tx][i];
+    }
+    return;
+  }
   const int64_t total = (int64_t)j.rows_pad * j.nt * j.inner_pad;
   const int64_t i0 = (int64_t)(b - j.block_begin) * PACK_EPB;
 #pragma unroll 2
@@ -483,9 +507,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi(const PackJob* __restr
     const int tap = (int)(r % j.nt);
     const int row = (int)(r / j.nt);
     float v = 0.f;
-    if (row < j.rows && k < j.inner)
-      v = j.mode == 0 ? j.w[((int64_t)tap * j.cin + k) * j.cout + row]
-                      : j.w[((int64_t)(j.nt - 1 - tap) * j.cin + row) * j.cout + k];
+    if (row < j.rows && k < j.inner) v = j.w[((int64_t)(j.nt - 1 - tap) * j.cin + row) * j.cout + k];      // mode 1
     j.out[i] = (bf16)v;
   }
 }
@@ -504,7 +526,10 @@ int tg_pack_table_fill(const TgConvDesc* d, const float* w, int mode, void* out,
   pack_dims(d, mode, &j.nt, &j.cin, &j.cout, &j.rows, &j.rows_pad, &j.inner, &j.inner_pad);
   const int64_t total = (int64_t)j.rows_pad * j.nt * j.inner_pad;
   j.block_begin = *total_blocks;
-  j.block_end = j.block_begin + (int)((total + PACK_EPB - 1) / PACK_EPB);
+  if (mode == 0)      // one block per (tap, 64 rows, 64 inner) tile
+    j.block_end = j.block_begin + j.nt * (j.rows_pad / 64) * ((j.inner_pad + 63) / 64);
+  else
+    j.block_end = j.block_begin + (int)((total + PACK_EPB - 1) / PACK_EPB);
   *total_blocks = j.block_end;
   ((PackJob*)table_host)[job] = j;
   return TG_OK;
