@@ -92,6 +92,13 @@ def _real_fake_losses(terms, name, pf, pr, cfg, mean_real=None):
     terms['discriminator_real_loss' + name] = ops.sigmoid_xent_mean(pr, 1.0, cfg.gan_weight)
 
 
+def _sum_terms(terms):
+  """tf.add_n over the loss collection (model/model_inheritor.py): one stack + sum instead of a chain of adds (each
+  add is a launch forward and another one backward)."""
+  vals = list(terms.values())
+  return torch.stack([v.reshape(1) for v in vals]).sum(dim=0) if len(vals) > 1 else vals[0]
+
+
 def act_dtype(cfg):
   return torch.bfloat16 if cfg.precision == 'bf16' else torch.float32
 
@@ -152,10 +159,7 @@ def generator_loss(P, sources, targets, cfg):
     terms['l_content_s'] = ops.abs_diff_mean(o['es'], e_tp, cfg.l_content_weight)
     terms['l_content_t'] = ops.abs_diff_mean(o['et'], e_sp, cfg.l_content_weight)
   streams.join()
-  total = None
-  for v in terms.values():
-    total = v if total is None else total + v
-  return total, terms
+  return _sum_terms(terms), terms
 
 
 def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t, dragan_noise_s=None, dragan_noise_t=None):
@@ -179,10 +183,7 @@ def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t, dragan_
       if cfg.loss_architecture in ('wgan_gp', 'dragan'):
         _d_domain_gp(P, cfg, terms, d, top, real, prime, a, noise)
   streams.join()
-  total = None
-  for v in terms.values():
-    total = v if total is None else total + v
-  return total, terms
+  return _sum_terms(terms), terms
 
 
 def _d_domain_terms(P, cfg, terms, d, top, real, prime, cyc, a, cyc_gan):
