@@ -48,6 +48,9 @@ class Config:
   sn_cache: object = None            # per-run normalised kernels: every use in a run sees the pre-run u
   do_self_attention: bool = False    # image_generation.py:62-64
   self_attention_hw: int = 64        # image_generation.py:65-67
+  use_style_embedding: bool = False  # twingan.py:47-49
+  style_embed_size: int = 16         # twingan.py:50-51
+  style_noise: object = None         # the N(0,1) random_style_embed [B, E] of twingan.py:232-235 (drawn when None)
   equalized: bool = False            # equalized_learning_rate           (nets/pggan.py:40; pggan_utils.py:236-254)
   res_block: bool = False            # use_res_block                     (nets/pggan.py:44; pggan_utils.py:257-264,334-342)
 
@@ -179,13 +182,34 @@ def init_params(cfg, seed=0, dtype=torch.float32, std=0.02):
         _conv_p(P, g, '%s/%s' % (sc, nm), 1, c_, co, domains, bias, dtype, std, NORM_SCOPE.get(cfg.norm, ''))
       P[sc + '/sa_gamma'] = torch.zeros(1, dtype=dtype)
 
-    for top, bias, domains in (('encoder_content', False, nd), ('discriminator_s', True, ()), ('discriminator_t', True, ())):
+    tops = [('encoder_content', False, nd), ('discriminator_s', True, ()), ('discriminator_t', True, ())]
+    if cfg.use_style_embedding:
+      tops.append(('encoder_style', False, nd))
+    for top, bias, domains in tops:
       c = get_num_channels(ms, cfg.max_ch)
       for stage in range(ms, 0, -1):
         att(top, cfg.hw // (2 ** (ms - stage)), c, get_num_channels(stage - 1, cfg.max_ch), bias, domains)
         c = get_num_channels(stage - 1, cfg.max_ch)
     for stage in range(0, ms + 1):
       att('generator', 2 ** (stage + 2), get_num_channels(stage, cfg.max_ch), get_num_channels(stage, cfg.max_ch), False, nd)
+  if cfg.use_style_embedding:    # twingan.py:47-51: style encoder (pggan.encoder) + generator norms conditioned on its output
+    nd = ('s', 't')
+    for sp in encoder_param_specs('encoder_style', cfg.hw, cfg.max_ch, cfg.is_growing):
+      _conv_p(P, g, sp[0], sp[1], sp[2], sp[3], nd, False, dtype, std, NORM_SCOPE[cfg.norm])
+    blk = 'encoder_style/before_fc_1x1x%d' % cfg.max_ch
+    _conv_p(P, g, blk + '/Conv', 3, get_num_channels(0, cfg.max_ch), cfg.max_ch, nd, False, dtype, std, NORM_SCOPE[cfg.norm])
+    _conv_p(P, g, blk + '/Conv_1', 4, cfg.max_ch, cfg.max_ch, nd, False, dtype, std, NORM_SCOPE[cfg.norm])
+    P['encoder_style/prediction/fully_connected/weights'] = \
+        torch.randn(cfg.max_ch, cfg.style_embed_size, generator=g, dtype=torch.float32).to(dtype) * \
+        (math.sqrt(1.0 / cfg.max_ch) if he else std)
+    P['encoder_style/prediction/fully_connected/biases'] = torch.zeros(cfg.style_embed_size, dtype=dtype)
+    # generator: gamma_<d> / beta_<d> vectors become fully connected layers of the embedding (xavier uniform, zero bias)
+    E = cfg.style_embed_size
+    for k in [k for k in P if k.startswith('generator/') and ('/gamma_' in k or '/beta_' in k)]:
+      c = P.pop(k).shape[0]
+      lim = math.sqrt(6.0 / (E + c))
+      P[k + '/weights'] = ((torch.rand(E, c, generator=g, dtype=torch.float32) * 2 - 1) * lim).to(dtype)
+      P[k + '/biases'] = torch.zeros(c, dtype=dtype)
   if cfg.res_block:      # after everything else so the other variables keep their seeded values
     ge = encoder_param_specs('encoder_content', cfg.hw, cfg.max_ch, cfg.is_growing) + \
         generator_param_specs('generator', cfg.hw, cfg.max_ch, cfg.use_unet, cfg.is_growing)
@@ -398,7 +422,7 @@ def init_sn_state(P, seed=0):
   return st
 
 
-def self_attention(P, sc, layer, domain, cfg, is_discriminator):
+def self_attention(P, sc, layer, domain, cfg, is_discriminator, cond=None):
   """libs/self_attention.py:24-70."""
   n, hh, ww, c = layer.shape
   outs = []
@@ -407,7 +431,7 @@ def self_attention(P, sc, layer, domain, cfg, is_discriminator):
     if is_discriminator:
       y = conv2d(layer, P[scope + '/weights'], 'SAME') + P[scope + '/biases']
     else:
-      y = ge_conv(P, scope, layer, domain, cfg, k=1, act=False, pixnorm=False, equalized=False)
+      y = ge_conv(P, scope, layer, domain, cfg, k=1, act=False, pixnorm=False, equalized=False, cond=cond)
     outs.append(torch.tanh(y) if nm != 'sa_h' else y)
   f, g, h = outs
   npos = hh * ww
@@ -417,20 +441,26 @@ def self_attention(P, sc, layer, domain, cfg, is_discriminator):
   return P[sc + '/sa_gamma'] * o + layer
 
 
-def maybe_self_attention(P, top, hw, name_c, net, ep, domain, cfg, is_discriminator=False):
+def maybe_self_attention(P, top, hw, name_c, net, ep, domain, cfg, is_discriminator=False, cond=None):
   """nets/pggan_utils.py:301-308."""
   if cfg.do_self_attention and hw == cfg.self_attention_hw:
     name = 'self_attention_%dx%dx%d' % (hw, hw, name_c)
-    net = self_attention(P, '%s/%s' % (top, name), net, domain, cfg, is_discriminator)
+    net = self_attention(P, '%s/%s' % (top, name), net, domain, cfg, is_discriminator, cond)
     ep[name] = net
   return net
 
 
-def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=True, equalized=True):
+def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=True, equalized=True, cond=None):
   """Generator/encoder conv: no bias (a normalizer is set), per-domain instance norm,
   LeakyReLU, optional pixel norm (nets/pggan.py:78-81,387-391)."""
   y = conv2d(equalize(x, cfg, k) if equalized else x, P[scope + '/weights'], padding)
-  if cfg.norm == 'instance_norm':
+  if cfg.norm == 'instance_norm' and cond is not None:
+    # conditional parameters (libs/instance_norm.py:93-120): gamma = 1 + FC(cond), beta = FC(cond), one row per image
+    pre = scope + '/InstanceNorm/'
+    gamma = 1.0 + cond @ P[pre + 'gamma_%s/weights' % domain] + P[pre + 'gamma_%s/biases' % domain]
+    beta = cond @ P[pre + 'beta_%s/weights' % domain] + P[pre + 'beta_%s/biases' % domain]
+    y = instance_norm(y, gamma[:, None, None, :], beta[:, None, None, :], cfg.in_eps)
+  elif cfg.norm == 'instance_norm':
     y = instance_norm(y, P[scope + '/InstanceNorm/gamma_' + domain], P[scope + '/InstanceNorm/beta_' + domain],
                       cfg.in_eps)
   elif cfg.norm == 'batch_norm':       # the reference's default generator_norm_type (nets/pggan.py:24)
@@ -498,6 +528,20 @@ def encoder(P, x, domain, cfg, top='encoder_content'):
   return net, ep
 
 
+def encoder_full(P, x, domain, cfg, top='encoder_style'):
+  """nets/pggan.py:482-541 (pggan.encoder): encoder_before_classification, conv3x3 SAME, conv4x4 VALID (norm +
+  LeakyReLU, no pixel norm), squeeze, fully connected -> [B, output_dim]."""
+  net, ep = encoder(P, x, domain, cfg, top)
+  blk = '%s/before_fc_1x1x%d' % (top, cfg.max_ch)
+  net = ge_conv(P, blk + '/Conv', net, domain, cfg, pixnorm=False)
+  net = ge_conv(P, blk + '/Conv_1', net, domain, cfg, k=4, padding='VALID', pixnorm=False)
+  feat = net.reshape(net.shape[0], -1)
+  pred = equalize(feat, cfg, 1) @ P[top + '/prediction/fully_connected/weights'] + \
+      P[top + '/prediction/fully_connected/biases']
+  ep['prediction'] = pred
+  return pred, ep
+
+
 def _concat_unet(layer, unet_ep, max_ch):
   """nets/pggan_utils.py:281-298."""
   if unet_ep is None:
@@ -512,7 +556,7 @@ def _concat_unet(layer, unet_ep, max_ch):
   return torch.cat((layer, unet_ep[name]), dim=3)
 
 
-def generator(P, source, domain, cfg, unet_ep=None, top='generator'):
+def generator(P, source, domain, cfg, unet_ep=None, top='generator', cond=None):
   """nets/pggan.py:93-211 with a [B,4,4,C] source (TwinGAN mode).  Returns (output, end_points)."""
   ms = max_stage_of(cfg.hw)
   ep = {'source': source}
@@ -525,24 +569,24 @@ def generator(P, source, domain, cfg, unet_ep=None, top='generator'):
     name = 'block_%dx%dx%d' % (hw, hw, oc)
     if hw == 4:
       assert source.shape[1] == 4 and source.shape[2] == 4
-      net = ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg)
-      net = ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg)
+      net = ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg, cond=cond)
+      net = ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg, cond=cond)
     else:
       if stage == ms and cfg.is_growing:
         rgb = 'generator_to_rgb_%dx%d' % (hw // 2, hw // 2)
-        before_growth = ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=1, act=False, pixnorm=False)
+        before_growth = ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=1, act=False, pixnorm=False, cond=cond)
         before_growth = upsample2x(before_growth)
         ep[rgb] = before_growth
       net = upsample2x(net)
       net = _concat_unet(net, unet_ep, cfg.max_ch)
       blk_in = net
-      net = ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg)
-      net = ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg)
+      net = ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg, cond=cond)
+      net = ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg, cond=cond)
       net = resblock(P, '%s/%s' % (top, name), blk_in, oc, net, cfg)
     ep[name] = net
-    net = maybe_self_attention(P, top, hw, oc, net, ep, domain, cfg)      # nets/pggan.py:188-190
+    net = maybe_self_attention(P, top, hw, oc, net, ep, domain, cfg, cond=cond)      # nets/pggan.py:188-190
   rgb = 'generator_to_rgb_%dx%d' % (hw, hw)
-  to_rgb = ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=1, act=False, pixnorm=False)
+  to_rgb = ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=1, act=False, pixnorm=False, cond=cond)
   if cfg.is_growing:
     out = to_rgb * cfg.alpha_grow + (1 - cfg.alpha_grow) * before_growth
   else:
@@ -606,11 +650,16 @@ def forward_generators(P, sources, targets, cfg):
   es, es_ep = encoder(P, sources, 's', cfg)
   et, et_ep = encoder(P, targets, 't', cfg)
   unet = cfg.use_unet
-  s_prime, _ = generator(P, et, 's', cfg, et_ep if unet else None)      # target content -> source domain
-  s_cycle, _ = generator(P, es, 's', cfg, es_ep if unet else None)
-  t_prime, _ = generator(P, es, 't', cfg, es_ep if unet else None)
-  t_cycle, _ = generator(P, et, 't', cfg, et_ep if unet else None)
-  return dict(es=es, et=et, s_prime=s_prime, s_cycle=s_cycle, t_prime=t_prime, t_cycle=t_cycle)
+  rand = style_s = style_t = None
+  if cfg.use_style_embedding:      # twingan.py:201-235
+    style_s, _ = encoder_full(P, sources, 's', cfg)
+    style_t, _ = encoder_full(P, targets, 't', cfg)
+    rand = cfg.style_noise if cfg.style_noise is not None else torch.randn_like(style_s)
+  s_prime, _ = generator(P, et, 's', cfg, et_ep if unet else None, cond=rand)      # target content -> source domain
+  s_cycle, _ = generator(P, es, 's', cfg, es_ep if unet else None, cond=style_s)
+  t_prime, _ = generator(P, es, 't', cfg, es_ep if unet else None, cond=rand)
+  t_cycle, _ = generator(P, et, 't', cfg, et_ep if unet else None, cond=style_t)
+  return dict(es=es, et=et, s_prime=s_prime, s_cycle=s_cycle, t_prime=t_prime, t_cycle=t_cycle, random_style_embed=rand)
 
 
 LOSSES = ('wgan_gp', 'wgan', 'hinge', 'gan', 'dragan')
@@ -655,6 +704,9 @@ def generator_loss(P, sources, targets, cfg):
     terms['generator_fool_loss_prime_' + d] = _fool_loss(pp, cfg)
     if cfg.l_content:
       terms['l_content_' + d] = (enc_orig - enc_opp_prime).abs().mean() * cfg.l_content
+      if cfg.use_style_embedding:      # twingan.py:495-505: |random_style_embed - E_style(d_prime)|
+        st_prime, _ = encoder_full(P, prime, d, cfg)
+        terms['l_style_' + d] = (o['random_style_embed'] - st_prime).abs().mean() * cfg.l_content
   return sum(terms.values()), terms
 
 

@@ -29,7 +29,8 @@ def make(cfg_kw, precision, seed=0, batch=3):
   rcfg = R.Config(hw=cfg.hw, max_ch=cfg.max_ch, is_growing=cfg.is_growing, alpha_grow=cfg.alpha_grow,
                   use_unet=cfg.use_unet, equalized=cfg.equalized_learning_rate, res_block=cfg.use_res_block,
                   spectral_norm=cfg.spectral_norm, do_self_attention=cfg.do_self_attention,
-                  self_attention_hw=cfg.self_attention_hw, loss=cfg.loss_architecture)
+                  self_attention_hw=cfg.self_attention_hw, loss=cfg.loss_architecture,
+                  use_style_embedding=cfg.use_style_embedding, style_embed_size=cfg.style_embed_size)
   Pref = R.init_params(rcfg, seed=seed, dtype=torch.float64, std='he')
   tr = Trainer(cfg, device='cuda:0', seed=seed)
   tr.store.load_state_dict({k: v.float() for k, v in Pref.items()})
@@ -550,3 +551,53 @@ def test_spectral_norm_attention_bf16_graph_step_runs():
     loss, terms = tr.run(s, t)
     assert np.isfinite(float(loss)) and all(np.isfinite(float(v)) for v in terms.values())
   assert float((tr.store.state['discriminator_s/from_rgb_32x32/Conv/u'] - u0).abs().max()) > 0
+
+
+@pytest.mark.parametrize('attention', [False, True])
+def test_style_embedding_matches_oracle(attention):
+  """--use_style_embedding (twingan.py:47-51,201-288,495-505): the style encoder (pggan.encoder: classification head on
+  the encoder body), generator normalisers conditioned on the embedding (gamma = 1 + FC(e), beta = FC(e), one row per
+  image: random embedding for s' / t', the encoded style for the cycle images), and the style read-back losses."""
+  from twingan_amd import twingan as T
+  kw = dict(hw=16, max_ch=16, use_style_embedding=True, style_embed_size=8, do_self_attention=attention,
+            self_attention_hw=8)
+  cfg, rcfg, tr, Pref, dev, ref = make(kw, 'fp32', seed=9, batch=2)
+  assert set(tr.store.state_dict()) == set(Pref)
+  g = torch.Generator().manual_seed(5)
+  noise = torch.randn(2, 8, generator=g)
+  rcfg.style_noise = noise.double()
+  for v in Pref.values():
+    v.requires_grad_(True)
+  tr.store.zero_grad('g')
+  tr._set_requires_grad(g=True, d=False)
+  gl, gterms = T.generator_loss(tr.P, dev['s'], dev['t'], cfg, style_noise=noise.to('cuda:0'))
+  rgl, rterms = R.generator_loss(Pref, ref['s'], ref['t'], rcfg)
+  assert set(gterms) == set(rterms) and 'l_style_s' in rterms
+  for k in rterms:
+    assert abs(gterms[k].item() - rterms[k].item()) < 1e-4 * max(1.0, abs(rterms[k].item())), k
+  gl.backward()
+  rgl.backward()
+  _grads_close(tr, Pref, tr.store.names('g'), 8e-2, 'generator(style)')
+  # the discriminator step only needs the forward of the styled generators
+  tr.store.zero_grad('d')
+  tr._set_requires_grad(g=False, d=True)
+  dl, dterms = T.discriminator_loss(tr.P, dev['s'], dev['t'], cfg, dev['a_s'], dev['a_t'])
+  assert np.isfinite(float(dl))
+
+
+def test_style_embedding_bf16_graph_step_runs():
+  from twingan_amd import Config
+  from twingan_amd.twingan import Trainer
+  cfg = Config(hw=32, max_ch=32, use_style_embedding=True)
+  tr = Trainer(cfg, device='cuda:0', seed=1, use_graph=True)
+  g = torch.Generator().manual_seed(3)
+  s = torch.rand(4, 32, 32, 3, generator=g).to('cuda:0').bfloat16()
+  t = torch.rand(4, 32, 32, 3, generator=g).to('cuda:0').bfloat16()
+  # detach(): an autograd op on a parameter here would create its AccumulateGrad node on the default stream, and the
+  # captured backward would then synchronise with a stream that is not capturing (hipStreamEndCapture crashes)
+  before = tr.store.P['encoder_style/prediction/fully_connected/weights'].detach().clone()
+  for _ in range(6):
+    loss, terms = tr.run(s, t)
+    assert np.isfinite(float(loss)) and all(np.isfinite(float(v)) for v in terms.values())
+  after = tr.store.P['encoder_style/prediction/fully_connected/weights'].detach()
+  assert float((after - before).abs().max()) > 0

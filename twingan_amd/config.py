@@ -17,6 +17,8 @@ class Config:
   spectral_norm_in_non_discriminator: bool = False   # nets/pggan.py:31-33
   do_self_attention: bool = False     # image_generation.py:62-64; libs/self_attention.py:24-70
   self_attention_hw: int = 64         # image_generation.py:65-67
+  use_style_embedding: bool = False   # twingan.py:47-49: generator norm parameters conditioned on a style embedding
+  style_embed_size: int = 16          # twingan.py:50-51
   is_growing: bool = False            # image_generation.py:69-72
   alpha_grow: float = 0.0             # twingan.py:833-835
   loss_architecture: str = 'wgan_gp'  # image_generation.py:81-83

@@ -61,7 +61,15 @@ class PackCache:
 
   @classmethod
   def register(cls, w):
-    cls._registered[w.data_ptr()] = w
+    """(Re)registers a master weight.  Packs made for a previous tensor at the same address (an earlier ParamStore whose
+    memory the allocator handed out again) describe another shape and must not be refreshed from this one."""
+    ptr = w.data_ptr()
+    if ptr in cls._registered and cls._registered[ptr] is not w:
+      for k in [k for k in cls._packs if k[0] == ptr]:
+        del cls._packs[k]
+      for k in [k for k in cls._tables if ptr in k[0]]:
+        del cls._tables[k]
+    cls._registered[ptr] = w
 
   @classmethod
   def clear(cls):
@@ -129,6 +137,7 @@ class GradSink:
   @classmethod
   def register(cls, p, grad):
     cls._sinks[p.data_ptr()] = grad
+    cls._held.pop(p.data_ptr(), None)
 
   @classmethod
   def clear(cls):

@@ -60,11 +60,17 @@ class ParamStore:
     assert name not in self.specs, name
     self.specs[name] = dict(shape=tuple(shape), phys=tuple(phys or shape), group=group, kind=kind)
 
-  def add_conv(self, scope, k, cin, cout, group, bias, norm_domains, phys_cin=None, norm_scope='InstanceNorm'):
+  def add_conv(self, scope, k, cin, cout, group, bias, norm_domains, phys_cin=None, norm_scope='InstanceNorm',
+               cond_dim=0):
     self.add(scope + '/weights', (k, k, cin, cout), group, 'conv_w', (k, k, phys_cin or cin, cout))
     if bias:
       self.add(scope + '/biases', (cout,), group, 'bias')
     for d in norm_domains:
+      if cond_dim:      # gamma = 1 + FC(cond), beta = FC(cond)  (libs/instance_norm.py:93-120, batch_norm.py:34-38)
+        for nm in ('gamma', 'beta'):
+          self.add('%s/%s/%s_%s/weights' % (scope, norm_scope, nm, d), (cond_dim, cout), group, 'xavier_w')
+          self.add('%s/%s/%s_%s/biases' % (scope, norm_scope, nm, d), (cout,), group, 'bias')
+        continue
       self.add('%s/%s/gamma_%s' % (scope, norm_scope, d), (cout,), group, 'gamma')
       self.add('%s/%s/beta_%s' % (scope, norm_scope, d), (cout,), group, 'beta')
       if norm_scope == 'BatchNorm':      # non-trainable moving statistics (libs/batch_norm.py:184-196)
@@ -123,6 +129,9 @@ class ParamStore:
         p.zero_()
         w = torch.randn(s['shape'], generator=gen, dtype=torch.float32) * self.weights_init_stddev
         self._logical(p, s).copy_(w.to(p.device))
+      elif s['kind'] == 'xavier_w':      # layers.fully_connected default: xavier_initializer (uniform)
+        lim = math.sqrt(6.0 / (s['shape'][0] + s['shape'][1]))
+        p.copy_(((torch.rand(s['shape'], generator=gen, dtype=torch.float32) * 2.0 - 1.0) * lim).to(p.device))
       elif s['kind'] == 'gamma':
         p.fill_(1.0)
       else:
@@ -202,7 +211,7 @@ def declare_twingan(store, cfg):
 
   store.add_conv = add_conv
 
-  def attention(top, hw_, c_, name_c, group, bias, norm_domains):
+  def attention(top, hw_, c_, name_c, group, bias, norm_domains, **kw):
     """--do_self_attention: sa_f / sa_g (c -> c/8), sa_h (c -> c) 1x1 convs under the scope's arg-scope (normaliser
     in G/E, bias in D) and the scalar sa_gamma (libs/self_attention.py:24-70; nets/pggan_utils.py:301-308).  They go
     through libs.sn.convolution with do_spec_norm False: never spectrally normed."""
@@ -210,7 +219,7 @@ def declare_twingan(store, cfg):
       return
     sc = '%s/self_attention_%dx%dx%d' % (top, hw_, hw_, name_c)
     for nm, co in (('sa_f', c_ // 8), ('sa_g', c_ // 8), ('sa_h', c_)):
-      _add_conv('%s/%s' % (sc, nm), 1, c_, co, group, bias, norm_domains, norm_scope=ns)
+      _add_conv('%s/%s' % (sc, nm), 1, c_, co, group, bias, norm_domains, norm_scope=ns, **kw)
     store.add(sc + '/sa_gamma', (1,), group, 'beta')
 
   def shortcut(blk, cin, cout, group):
@@ -238,25 +247,36 @@ def declare_twingan(store, cfg):
       c = nc
 
   enc_skeleton('encoder_content', 'g', False, nd)
+  gen_kw = {}
+  if cfg.use_style_embedding:      # twingan.py:47-51,201-223: the style encoder (pggan.encoder) and conditional generator norms
+    if cfg.generator_norm_type != 'instance_norm':
+      raise NotImplementedError('use_style_embedding with generator_norm_type=%s' % cfg.generator_norm_type)
+    enc_skeleton('encoder_style', 'g', False, nd)
+    c0 = get_num_channels(0, mc)
+    store.add_conv('encoder_style/before_fc_1x1x%d/Conv' % mc, 3, c0, mc, 'g', False, nd, norm_scope=ns)
+    store.add_conv('encoder_style/before_fc_1x1x%d/Conv_1' % mc, 4, mc, mc, 'g', False, nd, norm_scope=ns)
+    store.add('encoder_style/prediction/fully_connected/weights', (mc, cfg.style_embed_size), 'g', 'fc_w')
+    store.add('encoder_style/prediction/fully_connected/biases', (cfg.style_embed_size,), 'g', 'bias')
+    gen_kw = dict(cond_dim=cfg.style_embed_size)
   # generator
   c = get_num_channels(0, mc)
   blk = 'generator/block_4x4x%d' % c
-  store.add_conv(blk + '/Conv', 3, c, c, 'g', False, nd, norm_scope=ns)
-  store.add_conv(blk + '/Conv_1', 3, c, c, 'g', False, nd, norm_scope=ns)
-  attention('generator', 4, c, c, 'g', False, nd)
+  store.add_conv(blk + '/Conv', 3, c, c, 'g', False, nd, norm_scope=ns, **gen_kw)
+  store.add_conv(blk + '/Conv_1', 3, c, c, 'g', False, nd, norm_scope=ns, **gen_kw)
+  attention('generator', 4, c, c, 'g', False, nd, **gen_kw)
   for stage in range(1, ms + 1):
     cur = 2 ** (stage + 2)
     oc = get_num_channels(stage, mc)
     if stage == ms and cfg.is_growing:
-      store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (cur // 2, cur // 2), 1, c, 3, 'g', False, nd, norm_scope=ns)
+      store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (cur // 2, cur // 2), 1, c, 3, 'g', False, nd, norm_scope=ns, **gen_kw)
     cin = c + (get_num_channels(stage - 1, mc) if cfg.use_unet else 0)
     blk = 'generator/block_%dx%dx%d' % (cur, cur, oc)
-    store.add_conv(blk + '/Conv', 3, cin, oc, 'g', False, nd, norm_scope=ns)
-    store.add_conv(blk + '/Conv_1', 3, oc, oc, 'g', False, nd, norm_scope=ns)
+    store.add_conv(blk + '/Conv', 3, cin, oc, 'g', False, nd, norm_scope=ns, **gen_kw)
+    store.add_conv(blk + '/Conv_1', 3, oc, oc, 'g', False, nd, norm_scope=ns, **gen_kw)
     shortcut(blk, cin, oc, 'g')
-    attention('generator', cur, oc, oc, 'g', False, nd)
+    attention('generator', cur, oc, oc, 'g', False, nd, **gen_kw)
     c = oc
-  store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (hw, hw), 1, c, 3, 'g', False, nd, norm_scope=ns)
+  store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (hw, hw), 1, c, 3, 'g', False, nd, norm_scope=ns, **gen_kw)
   # discriminators
   for top in ('discriminator_s', 'discriminator_t'):
     enc_skeleton(top, 'd', True, ())

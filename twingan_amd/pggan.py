@@ -69,7 +69,7 @@ def end_run(P):
     cache.clear()
 
 
-def self_attention_layer(P, sc, layer, domain, cfg, is_discriminator):
+def self_attention_layer(P, sc, layer, domain, cfg, is_discriminator, cond=None):
   """libs/self_attention.py:24-70 (SAGAN): f, g = tanh(conv1x1 -> c/8), h = conv1x1 -> c under the scope's arg-scope
   (bias in D; the generator normaliser, no bias, in G / E -- nets/pggan_utils.py:86-98), s = f g^T over the h*w
   positions, beta = softmax(s), o = beta h, y = sa_gamma * o + layer.  The two batched matrix products run on the
@@ -84,7 +84,7 @@ def self_attention_layer(P, sc, layer, domain, cfg, is_discriminator):
       w, b = P[scope + '/weights'], P[scope + '/biases']
       y = ops.conv2d(layer, w, b, 1, 'SAME')      # libs.sn.convolution directly: no equalized-lr input scaling
     else:
-      y = _ge_conv(P, scope, layer, domain, cfg, k=1, activation=False, pixel_norm=False, equalize=False)
+      y = _ge_conv(P, scope, layer, domain, cfg, k=1, activation=False, pixel_norm=False, equalize=False, cond=cond)
     outs.append(torch.tanh(y) if nm != 'sa_h' else y)
   f, g, h = outs
   npos = hh * ww
@@ -94,11 +94,11 @@ def self_attention_layer(P, sc, layer, domain, cfg, is_discriminator):
   return P[sc + '/sa_gamma'].to(layer.dtype) * o + layer
 
 
-def maybe_add_self_attention(P, top, hw, name_channels, net, end_points, domain, cfg, is_discriminator=False):
+def maybe_add_self_attention(P, top, hw, name_channels, net, end_points, domain, cfg, is_discriminator=False, cond=None):
   """nets/pggan_utils.py:301-308."""
   if cfg.do_self_attention and hw == cfg.self_attention_hw:
     name = 'self_attention_%dx%dx%d' % (hw, hw, name_channels)
-    net = self_attention_layer(P, '%s/%s' % (top, name), net, domain, cfg, is_discriminator)
+    net = self_attention_layer(P, '%s/%s' % (top, name), net, domain, cfg, is_discriminator, cond)
     end_points[name] = net
   return net
 
@@ -121,8 +121,24 @@ def maybe_resblock(P, blk, input_layer, out_channels, conv2d_out, cfg, is_discri
   return ops.add(sc, conv2d_out)
 
 
+def _cond_rows(P, scope, ns, cond, segments):
+  """Per-image normaliser parameters from a style embedding (libs/instance_norm.py:93-120; libs/batch_norm.py:34-38):
+  gamma = 1 + FC(cond; '<scope>/<norm>/gamma_<d>'), beta = FC(cond; '.../beta_<d>') with the FC of each image's domain.
+  ``segments``: [(domain, lo, hi)] over the batch.  Returns ([n, C], [n, C]) fp32, differentiable."""
+  import torch
+  gs, bs = [], []
+  for d, lo, hi in segments:
+    c = cond[lo:hi].contiguous()
+    pre = '%s/%s/' % (scope, ns)
+    gs.append(ops.fully_connected(c, P[pre + 'gamma_%s/weights' % d], P[pre + 'gamma_%s/biases' % d]) + 1.0)
+    bs.append(ops.fully_connected(c, P[pre + 'beta_%s/weights' % d], P[pre + 'beta_%s/biases' % d]))
+  if len(gs) == 1:
+    return gs[0], bs[0]
+  return torch.cat(gs), torch.cat(bs)
+
+
 def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pixel_norm=True, pool=False, equalize=True,
-             upcat=None):
+             upcat=None, cond=None):
   """maybe_pixel_norm(maybe_equalized_conv2d(...)) for the generator / encoder arg-scope
   (nets/pggan_utils.py:86-98,236-245): conv without bias, per-domain instance norm, LeakyReLU(0.2),
   then pixel norm (nets/pggan.py:78-81).  ``domain`` is 's' | 't', or (d0, d1, split): the batch holds
@@ -143,10 +159,16 @@ def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pix
     passes = domain[3] if len(domain) > 3 else 2
   else:
     d0, d1, split, passes = domain, None, None, 1
+  pn = pixel_norm and cfg.do_pixel_norm
+  if cond is not None:      # conditional instance norm: one parameter row per image (twingan.py:245-267)
+    assert nt == 'instance_norm'
+    n_ = y.shape[0]
+    segs = [(d0, 0, n_)] if d1 is None else [(d0, 0, split), (d1, split, n_)]
+    g_rows, b_rows = _cond_rows(P, scope, ns, cond, segs)
+    return ops.norm_act(y, g_rows, b_rows, lrelu=activation, pixel_norm=pn, pool=pool, stats=ops.instance_stats(y, 1e-6))
   g0, b0 = P['%s/%s/gamma_%s' % (scope, ns, d0)], P['%s/%s/beta_%s' % (scope, ns, d0)]
   g1 = P['%s/%s/gamma_%s' % (scope, ns, d1)] if d1 else None
   b1 = P['%s/%s/beta_%s' % (scope, ns, d1)] if d1 else None
-  pn = pixel_norm and cfg.do_pixel_norm
   if nt == 'instance_norm':
     return ops.norm_act(y, g0, b0, lrelu=activation, pixel_norm=pn, gamma2=g1, beta2=b1, split=split, pool=pool)
   # batch norm (libs/batch_norm.py:42-326, training mode): moments over (N,H,W) of ONE reference pass.  Each of
@@ -296,10 +318,34 @@ def encoder_before_classification(P, source, domain, cfg, top='encoder_content')
   return net, end_points
 
 
+def encoder_classification(P, net, domain, cfg, top):
+  """nets/pggan.py:482-507: conv3x3 SAME -> conv4x4 VALID (generator arg-scope: norm + LeakyReLU, no pixel norm) -> FC.
+  The 4x4 VALID output is 1x1, so its instance norm sees one pixel (variance 0): the layer outputs lrelu(beta), as in
+  the reference."""
+  blk = '%s/before_fc_1x1x%d' % (top, cfg.max_ch)
+  end_points = {}
+  net = _ge_conv(P, blk + '/Conv', net, domain, cfg, pixel_norm=False)
+  net = _ge_conv(P, blk + '/Conv_1', net, domain, cfg, k=4, padding='VALID', pixel_norm=False)
+  end_points['before_fc_1x1x%d' % cfg.max_ch] = net
+  feat = net.reshape(net.shape[0], -1)
+  pred = ops.fully_connected(_equalize(feat, cfg, 1), P[top + '/prediction/fully_connected/weights'],
+                             P[top + '/prediction/fully_connected/biases'])
+  end_points['prediction'] = pred
+  return pred, end_points
+
+
+def encoder(P, source, domain, cfg, top='encoder_style'):
+  """nets/pggan.py:510-541: the full encoder -> [B, output_dim] (the style encoder of twingan.py:201-223)."""
+  net, end_points = encoder_before_classification(P, source, domain, cfg, top)
+  pred, ep = encoder_classification(P, net, domain, cfg, top)
+  end_points.update(ep)
+  return pred, end_points
+
+
 # ------------------------------------------------------------------------------------------------
 # generator (nets/pggan.py:69-211), TwinGAN mode: source is the encoder's [B,4,4,C] content tensor
 # ------------------------------------------------------------------------------------------------
-def generator(P, source, domain, cfg, unet_end_points=None, top='generator', unet_groups=None):
+def generator(P, source, domain, cfg, unet_end_points=None, top='generator', unet_groups=None, cond=None):
   max_stage = max_stage_of(cfg.hw)
   assert source.shape[1] == 4 and source.shape[2] == 4, 'TwinGAN generator expects a 4x4 content tensor'
   end_points = {'source': source}
@@ -311,13 +357,13 @@ def generator(P, source, domain, cfg, unet_end_points=None, top='generator', une
     output_channels = get_num_channels(stage, cfg.max_ch)
     name = 'block_%dx%dx%d' % (hw, hw, output_channels)
     if hw == 4:
-      net = _ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg)
-      net = _ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg)
+      net = _ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg, cond=cond)
+      net = _ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg, cond=cond)
     else:
       if stage == max_stage and cfg.is_growing:
         rgb = 'generator_to_rgb_%dx%d' % (hw // 2, hw // 2)
         net_before_growth = _ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=1, activation=False,
-                                     pixel_norm=False)
+                                     pixel_norm=False, cond=cond)
         net_before_growth = resize_twice_as_big(net_before_growth)
         end_points[rgb] = net_before_growth
       # generator_three_layer_block: upsample -> concat(UNet) -> conv -> conv  (pggan.py:69-83)
@@ -328,18 +374,18 @@ def generator(P, source, domain, cfg, unet_end_points=None, top='generator', une
       if not (cfg.use_res_block or cfg.equalized_learning_rate) and ops.upcat_conv_supported(net, skip, w0):
         # resize_twice_as_big + maybe_concat_unet_layer + the block's first conv as one op: no concat tensor
         block_in = None
-        net = _ge_conv(P, '%s/%s/Conv' % (top, name), None, domain, cfg, upcat=(net, skip, gsz, perm))
+        net = _ge_conv(P, '%s/%s/Conv' % (top, name), None, domain, cfg, upcat=(net, skip, gsz, perm), cond=cond)
       else:
         net = ops.upsample2x_concat(net, skip, gsz, perm)
         block_in = net
-        net = _ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg)
-      net = _ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg)
+        net = _ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg, cond=cond)
+      net = _ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg, cond=cond)
       net = maybe_resblock(P, '%s/%s' % (top, name), block_in, output_channels, net, cfg)
     end_points[name] = net
-    net = maybe_add_self_attention(P, top, hw, output_channels, net, end_points, domain, cfg)      # pggan.py:188-190
+    net = maybe_add_self_attention(P, top, hw, output_channels, net, end_points, domain, cfg, cond=cond)      # pggan.py:188-190
   rgb = 'generator_to_rgb_%dx%d' % (hw, hw)
   # to_rgb: activation None, normaliser still applied, no pixel norm (pggan.py:192-200)
-  to_rgb = _ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=1, activation=False, pixel_norm=False)
+  to_rgb = _ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=1, activation=False, pixel_norm=False, cond=cond)
   if cfg.is_growing:
     output = ops.lerp(to_rgb, net_before_growth, cfg.alpha_grow)
     end_points['alpha_grow'] = cfg.alpha_grow

@@ -109,7 +109,7 @@ def get_growing_image(img, alpha):
   return ops.lerp(img, low, alpha)
 
 
-def forward_generators(P, sources, targets, cfg):
+def forward_generators(P, sources, targets, cfg, style_noise=None):
   """twingan.py:198-269: E(s), E(t) and the four generator passes (shared conv weights, per-domain norm
   parameters, UNet skips from the encoder whose content is decoded).
 
@@ -122,20 +122,29 @@ def forward_generators(P, sources, targets, cfg):
   e, ep = pggan.encoder_before_classification(P, x, ('s', 't', b, 2), cfg)
   es, et = e.chunk(2)
   content = torch.cat([et, es, es, et], dim=0)
+  cond = rand = None
+  if cfg.use_style_embedding:
+    # twingan.py:201-267: style encoder on s / t (one batch, domains s|t); s' and t' are generated with ONE random
+    # N(0,1) embedding, the cycle images with the encoded style of their own input
+    st, _ = pggan.encoder(P, x, ('s', 't', b, 2), cfg, 'encoder_style')
+    style_s, style_t = st.chunk(2)
+    rand = style_noise if style_noise is not None else torch.randn(b, cfg.style_embed_size, dtype=torch.float32,
+                                                                  device=x.device)
+    cond = torch.cat([rand, style_s, rand, style_t], dim=0)
   # UNet skips: generator group k reads encoder group (t, s, s, t)[k] of the [s; t] encoder batch -- no copies
   out, _ = pggan.generator(P, content, ('s', 't', 2 * b, 4), cfg, ep if cfg.use_unet else None,
-                           unet_groups=(b, (1, 0, 0, 1)))
+                           unet_groups=(b, (1, 0, 0, 1)), cond=cond)
   s_prime, s_cycle, t_prime, t_cycle = out.chunk(4)
-  return dict(es=es, et=et, s_prime=s_prime, s_cycle=s_cycle, t_prime=t_prime, t_cycle=t_cycle)
+  return dict(es=es, et=et, s_prime=s_prime, s_cycle=s_cycle, t_prime=t_prime, t_cycle=t_cycle, random_style_embed=rand)
 
 
-def generator_loss(P, sources, targets, cfg):
+def generator_loss(P, sources, targets, cfg, style_noise=None):
   """GENERATOR_LOSSES (twingan.py:464-505; image_generation.py:331-337).  Returns (total [1], terms)."""
   assert cfg.loss_architecture in LOSSES, cfg.loss_architecture
   if cfg.is_growing:
     sources, targets = get_growing_image(sources, cfg.alpha_grow), get_growing_image(targets, cfg.alpha_grow)
   b = sources.shape[0]
-  o = forward_generators(P, sources, targets, cfg)
+  o = forward_generators(P, sources, targets, cfg, style_noise)
   cyc_gan = cfg.hw >= 64 and cfg.do_l_cyc_gan
   terms = {}
   # fork: the two discriminators run on their own streams while the main stream re-encodes s' / t'
@@ -153,11 +162,17 @@ def generator_loss(P, sources, targets, cfg):
         pp, _ = pggan.discriminator(P, prime, cfg, top)
       terms['generator_fool_loss_prime_' + d] = _fool_loss(pp, cfg)
   # re-encode s' in domain s and t' in domain t as one batch (twingan.py:275-288)
-  e2, _ = pggan.encoder_before_classification(P, torch.cat([o['s_prime'], o['t_prime']], dim=0), ('s', 't', b, 2), cfg)
+  primes = torch.cat([o['s_prime'], o['t_prime']], dim=0)
+  e2, _ = pggan.encoder_before_classification(P, primes, ('s', 't', b, 2), cfg)
   e_sp, e_tp = e2.chunk(2)
   if cfg.l_content_weight:
     terms['l_content_s'] = ops.abs_diff_mean(o['es'], e_tp, cfg.l_content_weight)
     terms['l_content_t'] = ops.abs_diff_mean(o['et'], e_sp, cfg.l_content_weight)
+    if cfg.use_style_embedding:      # twingan.py:495-505: the style read back from s' / t' must be the random one
+      st2, _ = pggan.encoder(P, primes, ('s', 't', b, 2), cfg, 'encoder_style')
+      st_sp, st_tp = st2.chunk(2)
+      terms['l_style_s'] = ops.abs_diff_mean(o['random_style_embed'], st_sp.contiguous(), cfg.l_content_weight)
+      terms['l_style_t'] = ops.abs_diff_mean(o['random_style_embed'], st_tp.contiguous(), cfg.l_content_weight)
   streams.join()
   return _sum_terms(terms), terms
 
