@@ -181,3 +181,20 @@ def test_warm_start_ignores_missing_and_reshaped_vars():
   a, b = prev.state_dict(), T.store.state_dict()
   assert torch.equal(a['generator/block_8x8x8/Conv/weights'], b['generator/block_8x8x8/Conv/weights'])
   assert torch.equal(a['generator/generator_to_rgb_8x8/Conv/weights'], b['generator/generator_to_rgb_8x8/Conv/weights'])
+
+
+def test_state_dict_carries_non_trainable_variables():
+  """Moving / renorm statistics and spectral-norm vectors travel with state_dict(include_state=True) and back."""
+  from twingan_amd import Config
+  from twingan_amd.params import ParamStore, declare_twingan
+  cfg = Config(hw=8, max_ch=8, generator_norm_type='batch_renorm', spectral_norm=True)
+  a = declare_twingan(ParamStore('cpu'), cfg).build(seed=1)
+  b = declare_twingan(ParamStore('cpu'), cfg).build(seed=2)
+  k_bn = 'generator/block_4x4x8/Conv/BatchNorm/renorm_mean_s'
+  k_u = 'discriminator_s/from_rgb_8x8/Conv/u'
+  a.state[k_bn].fill_(0.25)
+  sd = a.state_dict(include_state=True)
+  assert k_bn in sd and k_u in sd and 'renorm/rmax' not in sd
+  assert k_bn not in a.state_dict()
+  b.load_state_dict(sd)
+  assert torch.equal(b.state[k_bn], a.state[k_bn]) and torch.equal(b.state[k_u], a.state[k_u])

@@ -153,9 +153,13 @@ class ParamStore:
   def names(self, group=None):
     return [k for k, s in self.specs.items() if group is None or s['group'] == group]
 
-  def state_dict(self):
-    """Logical (reference-shaped) copies keyed by TF variable names."""
-    return {k: self._logical(self.P[k].detach(), s).clone() for k, s in self.specs.items()}
+  def state_dict(self, include_state=False):
+    """Logical (reference-shaped) copies keyed by TF variable names.  ``include_state``: also the non-trainable
+    variables (BatchNorm moving / renorm statistics, spectral-norm u) -- what a TF checkpoint of the stage holds."""
+    sd = {k: self._logical(self.P[k].detach(), s).clone() for k, s in self.specs.items()}
+    if include_state:
+      sd.update({k: v.clone() for k, v in self.state.items() if k in self.state_specs})
+    return sd
 
   def grad_dict(self):
     GradSink.flush()                             # filter gradients held back for pairing
@@ -175,6 +179,9 @@ class ParamStore:
         assert tuple(src.shape) == s['shape'], (k, tuple(src.shape), s['shape'])
         self.P[k].zero_() if s['phys'] != s['shape'] else None
         self._logical(self.P[k], s).copy_(src)
+      for k in self.state_specs:      # non-trainable variables, when the dict carries them
+        if k in sd and tuple(torch.as_tensor(sd[k]).shape) == tuple(self.state[k].shape):
+          self.state[k].copy_(torch.as_tensor(sd[k]).to(device=self.device, dtype=torch.float32))
     PackCache.version += 1
 
   def zero_grad(self, group):

@@ -41,8 +41,10 @@ def warm_start(trainer, previous_state):
   """Loads every variable of ``previous_state`` (a ParamStore.state_dict()) that this stage also has and whose
   shape matches; the rest keep their fresh initialisation -- slim's assign_from_checkpoint_fn with
   ignore_missing_vars (model/model_inheritor.py:576-644).  Returns the names that were loaded."""
-  specs = trainer.store.specs
-  usable = {k: v for k, v in previous_state.items() if k in specs and tuple(v.shape) == specs[k]['shape']}
+  specs, state = trainer.store.specs, trainer.store.state
+  usable = {k: v for k, v in previous_state.items()
+            if (k in specs and tuple(v.shape) == specs[k]['shape']) or
+            (k in trainer.store.state_specs and tuple(v.shape) == tuple(state[k].shape))}
   trainer.store.load_state_dict(usable, strict=False)
   return sorted(usable)
 
@@ -67,7 +69,7 @@ def run_progressive(base_cfg, batch_fn, start_hw=4, max_hw=256, hw_to_batch_size
       for _ in range(cfg.n_critic):
         s, t = batch_fn(hw, bsz)
         tr.run(s, t)
-    state = tr.store.state_dict()
+    state = tr.store.state_dict(include_state=True)
     history.append(dict(stage=name, hw=hw, is_growing=growing, batch_size=bsz, steps=steps, warm_started=len(loaded)))
     if on_stage_end is not None:
       on_stage_end(name, tr)
