@@ -601,3 +601,38 @@ def test_style_embedding_bf16_graph_step_runs():
     assert np.isfinite(float(loss)) and all(np.isfinite(float(v)) for v in terms.values())
   after = tr.store.P['encoder_style/prediction/fully_connected/weights'].detach()
   assert float((after - before).abs().max()) > 0
+
+
+@pytest.mark.parametrize('hw,growing', [(64, False), (128, True), (512, False)])
+def test_full_width_stages_run(hw, growing):
+  """Every progressive stage of the reference schedule at its real channel widths (pggan_max_num_channels=256): the
+  kernel dispatch of each resolution (4x4 ... 512x512, 8 ... 256 channels) on the bf16 path.  At 64x64 the bf16 MFMA
+  losses are also checked against the fp32 direct kernels on the same weights and inputs."""
+  from twingan_amd import Config
+  from twingan_amd import twingan as T
+  from twingan_amd.twingan import Trainer
+  b = 2 if hw < 512 else 1
+  g = torch.Generator().manual_seed(hw)
+  s = torch.rand(b, hw, hw, 3, generator=g).to('cuda:0')
+  t = torch.rand(b, hw, hw, 3, generator=g).to('cuda:0')
+  a = torch.rand(b, generator=g).to('cuda:0')
+  kw = dict(hw=hw, max_ch=256, is_growing=growing, alpha_grow=0.3 if growing else 0.0)
+  tr = Trainer(Config(precision='bf16', **kw), device='cuda:0', seed=4)
+  for _ in range(2):
+    loss, terms = tr.run(s.bfloat16(), t.bfloat16())
+    assert np.isfinite(float(loss)) and all(np.isfinite(float(v)) for v in terms.values())
+  if hw == 64:
+    sd = tr.store.state_dict()
+    ref = Trainer(Config(precision='fp32', **kw), device='cuda:0', seed=4)
+    ref.store.load_state_dict(sd)
+    with torch.no_grad():
+      lb, tb = T.generator_loss(tr.P, s.bfloat16(), t.bfloat16(), tr.cfg)
+      lf, tf_ = T.generator_loss(ref.P, s, t, ref.cfg)
+    for k in tf_:
+      assert abs(float(tb[k]) - float(tf_[k])) < 5e-2 * max(1.0, abs(float(tf_[k]))), (k, float(tb[k]), float(tf_[k]))
+    tr._set_requires_grad(g=False, d=True)
+    ref._set_requires_grad(g=False, d=True)
+    lb, tb = T.discriminator_loss(tr.P, s.bfloat16(), t.bfloat16(), tr.cfg, a, a)
+    lf, tf_ = T.discriminator_loss(ref.P, s, t, ref.cfg, a, a)
+    for k in tf_:
+      assert abs(float(tb[k]) - float(tf_[k])) < 5e-2 * max(1.0, abs(float(tf_[k]))) + 2e-2, (k, float(tb[k]), float(tf_[k]))
