@@ -264,6 +264,11 @@ class Trainer:
     self.cfg = cfg
     self.device = torch.device(device)
     self.world = world_size
+    if world_size > 1 and self.device.type == 'cuda':
+      # every clone draws its own GP alphas / style noise (the reference's clones own their random ops,
+      # deployment/model_deploy.py:224-239); weights are initialised from the shared CPU seed below
+      rank = torch.distributed.get_rank(process_group) if torch.distributed.is_initialized() else 0
+      torch.cuda.manual_seed(1000003 * (seed + 1) + rank)
     self.reducer = GradReducer(world_size, process_group)
     self.store = declare_twingan(ParamStore(self.device), cfg).build(seed)
     self.P = self.store.P
