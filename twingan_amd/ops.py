@@ -9,6 +9,7 @@ second-order gradients (WGAN-GP, image_generation.py:414-439) flow through the s
 All activations are NHWC contiguous tensors (fp32 or bf16); conv weights are fp32 HWIO masters.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -136,7 +137,7 @@ class GradSink:
 
   @classmethod
   def register(cls, p, grad):
-    cls._sinks[p.data_ptr()] = grad
+    cls._sinks[p.data_ptr()] = (weakref.ref(p), grad)
     cls._held.pop(p.data_ptr(), None)
 
   @classmethod
@@ -148,7 +149,13 @@ class GradSink:
   def get(cls, p):
     if p is None or torch.is_grad_enabled():
       return None
-    return cls._sinks.get(p.data_ptr())
+    ent = cls._sinks.get(p.data_ptr())
+    if ent is None:
+      return None
+    if ent[0]() is None:       # the registered parameter is gone and the allocator handed its address out again
+      del cls._sinks[p.data_ptr()]
+      return None
+    return ent[1]              # p is the parameter or a view of it (its memory cannot be anything else while it lives)
 
   # Pairing of filter gradients: with ``pair`` on (the trainer), the first filter-gradient request of a weight in a
   # backward pass is held back; when a second one for the same weight arrives (the batched real/fake/interpolate pass
