@@ -17,7 +17,31 @@ from oracle import torch_ref as R
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 MODELS = {'twingan_hw16_c8': dict(hw=16, max_ch=8), 'twingan_hw64_c8': dict(hw=64, max_ch=8),
-          'twingan_hw16_c8_growing': dict(hw=16, max_ch=8, is_growing=True, alpha_grow=0.3)}
+          'twingan_hw16_c8_growing': dict(hw=16, max_ch=8, is_growing=True, alpha_grow=0.3),
+          'twingan_hw16_c8_hinge_eqlr_res': dict(hw=16, max_ch=8, loss='hinge', equalized=True, res_block=True),
+          'twingan_hw16_c8_batch_norm': dict(hw=16, max_ch=8, norm='batch_norm'),
+          'twingan_hw16_c8_style': dict(hw=16, max_ch=8, use_style_embedding=True, style_embed_size=8)}
+# oracle Config field -> product Config field where the names differ
+PRODUCT_FIELD = dict(loss='loss_architecture', equalized='equalized_learning_rate', res_block='use_res_block',
+                     norm='generator_norm_type')
+
+
+def product_kw(name):
+  return {PRODUCT_FIELD.get(k, k): v for k, v in MODELS[name].items()}
+
+
+def out_tol(name, k, tol):
+  """The style encoder ends in an instance norm over ONE pixel (4x4 VALID conv output): in the reference's
+  tf.nn.batch_normalization form x * inv + (beta - mean * inv), inv = gamma / sqrt(0 + 1e-6), the two ~1000 * x terms
+  cancel, which costs fp32 ~1e-3 of the embedding -- and of the cycle images generated from it."""
+  return 1e-2 if (name.endswith('_style') and 'cycle' in k) else tol
+
+
+def oracle_cfg(name, g):
+  cfg = R.Config(**MODELS[name])
+  if 'in/style_noise' in g:
+    cfg.style_noise = torch.from_numpy(g['in/style_noise']).float()
+  return cfg
 
 
 def load(name):
@@ -53,14 +77,13 @@ def test_numpy_oracle_reproduces_primitive_fixtures():
 @pytest.mark.parametrize('name', sorted(MODELS))
 def test_torch_oracle_fp32_reproduces_model_fixtures(name):
   g = load(name)
-  kw = MODELS[name]
-  cfg = R.Config(**kw)
+  cfg = oracle_cfg(name, g)
   P = {k[len('param/'):]: torch.from_numpy(v).float() for k, v in g.items() if k.startswith('param/')}
   s, t = torch.from_numpy(g['in/sources']).float(), torch.from_numpy(g['in/targets']).float()
   with torch.no_grad():
     o = R.forward_generators(P, s, t, cfg)
   for k in ('es', 's_prime', 't_prime', 's_cycle', 't_cycle'):
-    assert rel_l2(o[k].numpy(), g['fwd/' + k]) < 2e-5, k
+    assert rel_l2(o[k].numpy(), g['fwd/' + k]) < out_tol(name, k, 2e-5), k
   for v in P.values():
     v.requires_grad_(True)
   a_s = torch.from_numpy(g['in/gp_alpha_s']).float().reshape(-1, 1, 1, 1)
@@ -121,13 +144,16 @@ def test_gpu_primitives_hit_golden(dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name,precision', [('twingan_hw16_c8', 'fp32'), ('twingan_hw64_c8', 'fp32'),
-                                            ('twingan_hw16_c8_growing', 'fp32'), ('twingan_hw64_c8', 'bf16')])
+                                            ('twingan_hw16_c8_growing', 'fp32'), ('twingan_hw64_c8', 'bf16'),
+                                            ('twingan_hw16_c8_hinge_eqlr_res', 'fp32'),
+                                            ('twingan_hw16_c8_batch_norm', 'fp32'), ('twingan_hw16_c8_style', 'fp32')])
 def test_gpu_model_hits_golden(name, precision):
   from twingan_amd import Config
   from twingan_amd import twingan as T
   g = load(name)
-  cfg = Config(precision=precision, **MODELS[name])
+  cfg = Config(precision=precision, **product_kw(name))
   tr = T.Trainer(cfg, device='cuda:0', seed=0)
+  noise = _dev(g['in/style_noise']) if 'in/style_noise' in g else None
   tr.store.load_state_dict({k[len('param/'):]: torch.from_numpy(v).float() for k, v in g.items()
                             if k.startswith('param/')})
   adt = torch.bfloat16 if precision == 'bf16' else torch.float32
@@ -140,14 +166,14 @@ def test_gpu_model_hits_golden(name, precision):
   # bounds are the per-primitive ones.
   otol, ltol, gtol = (2e-5, 1e-4, 8e-2) if precision == 'fp32' else (5e-2, 5e-2, None)
   with torch.no_grad():
-    o = T.forward_generators(tr.P, s, t, cfg)
+    o = T.forward_generators(tr.P, s, t, cfg, noise)
   for k in ('es', 's_prime', 't_prime', 's_cycle', 't_cycle'):
     # bf16 at 8 channels: the fp64 oracle with bf16 storage rounding (tools/bf16_sensitivity.py) predicts rel-L2
     # 0.038 for the encoder output and 0.12-0.20 for the generator outputs (instance-normalised to_rgb); the
     # kernels measure 0.039 / 0.18.  Tight bf16 bounds live in the per-primitive tests.
-    tol = otol if precision == 'fp32' else (0.06 if k == 'es' else 0.3)
+    tol = out_tol(name, k, otol) if precision == 'fp32' else (0.06 if k == 'es' else 0.3)
     assert rel_l2(o[k].float().cpu().numpy(), g['fwd/' + k]) < tol, k
-  for group, fn, args in (('g', T.generator_loss, (s, t, cfg)), ('d', T.discriminator_loss, (s, t, cfg, a_s, a_t))):
+  for group, fn, args in (('g', T.generator_loss, (s, t, cfg, noise)), ('d', T.discriminator_loss, (s, t, cfg, a_s, a_t, None, None, noise))):
     tr.store.zero_grad(group)
     tr._set_requires_grad(g=group == 'g', d=group == 'd')
     loss, terms = fn(tr.P, *args)

@@ -67,8 +67,8 @@ def primitives():
   return d
 
 
-def model(hw, max_ch, batch, growing=False, alpha=0.0, seed=0):
-  cfg = R.Config(hw=hw, max_ch=max_ch, is_growing=growing, alpha_grow=alpha)
+def model(hw, max_ch, batch, growing=False, alpha=0.0, seed=0, **extra):
+  cfg = R.Config(hw=hw, max_ch=max_ch, is_growing=growing, alpha_grow=alpha, **extra)
   P = R.init_params(cfg, seed=seed, dtype=torch.float64, std='he')
   # round the parameters to fp32 so the GPU fp32 path starts from identical bits
   P = {k: v.float().double() for k, v in P.items()}
@@ -78,6 +78,9 @@ def model(hw, max_ch, batch, growing=False, alpha=0.0, seed=0):
   a_s = torch.rand(batch, generator=g).double()
   a_t = torch.rand(batch, generator=g).double()
   d = {'in/sources': s.numpy(), 'in/targets': t.numpy(), 'in/gp_alpha_s': a_s.numpy(), 'in/gp_alpha_t': a_t.numpy()}
+  if cfg.use_style_embedding:      # the random_style_embed draw of twingan.py:232-235 is an input of the fixture
+    cfg.style_noise = torch.randn(batch, cfg.style_embed_size, generator=g).double()
+    d['in/style_noise'] = cfg.style_noise.numpy()
   for k, v in P.items():
     d['param/' + k] = v.numpy()
   with torch.no_grad():
@@ -112,6 +115,12 @@ def main():
   np.savez_compressed(os.path.join(OUT, 'twingan_hw16_c8.npz'), **model(16, 8, 2))
   np.savez_compressed(os.path.join(OUT, 'twingan_hw64_c8.npz'), **model(64, 8, 2))
   np.savez_compressed(os.path.join(OUT, 'twingan_hw16_c8_growing.npz'), **model(16, 8, 2, growing=True, alpha=0.3))
+  # option rows of SURVEY 8(a): hinge loss + equalized lr + residual shortcuts; batch norm; style embedding
+  np.savez_compressed(os.path.join(OUT, 'twingan_hw16_c8_hinge_eqlr_res.npz'),
+                      **model(16, 8, 2, loss='hinge', equalized=True, res_block=True))
+  np.savez_compressed(os.path.join(OUT, 'twingan_hw16_c8_batch_norm.npz'), **model(16, 8, 2, norm='batch_norm'))
+  np.savez_compressed(os.path.join(OUT, 'twingan_hw16_c8_style.npz'),
+                      **model(16, 8, 2, use_style_embedding=True, style_embed_size=8))
   for f in sorted(os.listdir(OUT)):
     print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -177,7 +177,8 @@ def generator_loss(P, sources, targets, cfg, style_noise=None):
   return _sum_terms(terms), terms
 
 
-def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t, dragan_noise_s=None, dragan_noise_t=None):
+def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t, dragan_noise_s=None, dragan_noise_t=None,
+                       style_noise=None):
   """DISCRIMINATOR_LOSSES (image_generation.py:348-412,414-476).  gp_alpha_*: fp32 [B] U[0,1) draws;
   dragan_noise_*: the U(-1,1) draws of get_perturbed_batch (image shaped; drawn on the device when None).
   E/G run without a tape: only discriminator variables are in the var_list (image_generation.py:605-610)."""
@@ -185,7 +186,7 @@ def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t, dragan_
   with torch.no_grad():
     if cfg.is_growing:
       sources, targets = get_growing_image(sources, cfg.alpha_grow), get_growing_image(targets, cfg.alpha_grow)
-    o = forward_generators(P, sources, targets, cfg)
+    o = forward_generators(P, sources, targets, cfg, style_noise)
   cyc_gan = cfg.hw >= 64 and cfg.do_l_cyc_gan
   terms = {}
   streams = _DomainStreams(sources.device, cfg.domain_streams)
