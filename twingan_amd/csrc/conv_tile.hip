@@ -197,25 +197,32 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
     store_chunk();
     __syncthreads();
     if (c0 + KC < g.cin_pad) load_chunk(c0 + KC);     // in flight during the MFMAs below
+    // K steps of this chunk: (tap, 16-channel half).  The fragments of step s+1 are read from LDS before the MFMAs of
+    // step s are issued (two fragment sets; the scheduling barriers keep the compiler from moving the reads back next
+    // to their use), so an MFMA never waits a full LDS round trip for its operands.
+    constexpr int NSTEP = NT * (KC / 16);
+    bf16x8 xf[2][MT], wf[2][NTILE];
+    auto read_step = [&](int st, int buf) __attribute__((always_inline)) {
+      const int tap = st / (KC / 16), kk = st % (KC / 16);
+      const int ky = tap / KW, kx = tap % KW;
 #pragma unroll
-    for (int ky = 0; ky < KH; ++ky) {
+      for (int m = 0; m < MT; ++m)
+        xf[buf][m] = *reinterpret_cast<const bf16x8*>(sA + a_base + ((m * 2 + ky) * HWX + kx) * PS_A + kk * 32);
 #pragma unroll
-      for (int kx = 0; kx < KW; ++kx) {
+      for (int nt = 0; nt < NTILE; ++nt)
+        wf[buf][nt] = *reinterpret_cast<const bf16x8*>(sB + b_base + nt * 32 * RS_B + (tap * KC + kk * 16) * 2);
+    };
+    read_step(0, 0);
 #pragma unroll
-        for (int kk = 0; kk < KC / 16; ++kk) {
-          bf16x8 xf[MT];
+    for (int st = 0; st < NSTEP; ++st) {
+      if (st + 1 < NSTEP) read_step(st + 1, (st + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
-            xf[m] = *reinterpret_cast<const bf16x8*>(sA + a_base + ((m * 2 + ky) * HWX + kx) * PS_A + kk * 32);
+      for (int nt = 0; nt < NTILE; ++nt)
 #pragma unroll
-          for (int nt = 0; nt < NTILE; ++nt) {
-            const bf16x8 wf =
-                *reinterpret_cast<const bf16x8*>(sB + b_base + nt * 32 * RS_B + ((ky * KW + kx) * KC + kk * 16) * 2);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[m], acc[m][nt], 0, 0, 0);
-          }
-        }
-      }
+        for (int m = 0; m < MT; ++m)
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[st & 1][nt], xf[st & 1][m], acc[m][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
