@@ -1,0 +1,942 @@
+"""TEST INFRASTRUCTURE -- the `tensorflow` module tree of the shim (see core.py for what this is and is not).
+
+Each function restates the documented TF-1.8 behaviour of the op of the same name on float64 torch tensors; the
+non-obvious ones say which TF behaviour they follow."""
+import contextlib
+import functools
+import math
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import core
+from .core import (F64, STATE, Tensor, Variable, TensorShape, Dimension, raw, wrap, shape_list, float32, float16,
+                   float64, int32, int64, bool_)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# plain ops
+# ------------------------------------------------------------------------------------------------------------------
+def _axes(axis, ndim):
+  if axis is None:
+    return list(range(ndim))
+  if isinstance(axis, (int, np.integer, Dimension)):
+    axis = [int(axis)]
+  return [int(a) % ndim for a in axis]
+
+
+def constant(value, dtype=None, shape=None, name=None, verify_shape=False):
+  t = raw(value)
+  if dtype is not None and not dtype.is_floating and t.is_floating_point():
+    t = t.to(torch.int64)
+  if shape is not None:
+    t = t.expand(shape_list(shape)).clone() if t.dim() == 0 else t.reshape(shape_list(shape))
+  return Tensor(t, dtype, name)
+
+
+def convert_to_tensor(value, dtype=None, name=None, preferred_dtype=None):
+  if isinstance(value, Tensor):
+    return value
+  return constant(value, dtype=dtype, name=name)
+
+
+def cast(x, dtype, name=None):
+  t = raw(x)
+  if dtype.is_floating:
+    t = t.to(F64)
+  elif dtype == bool_:
+    t = t != 0
+  else:
+    t = t.to(torch.int64) if not t.is_floating_point() else torch.trunc(t).to(torch.int64)
+  return Tensor(t, dtype, name)
+
+
+def to_float(x, name=None):
+  return cast(x, float32)
+
+
+def identity(x, name=None):
+  x = convert_to_tensor(x)
+  return Tensor(x.t, x.dtype, name)
+
+
+def stop_gradient(x, name=None):
+  return wrap(raw(x).detach(), x)
+
+
+def reshape(x, shape, name=None):
+  return wrap(raw(x).reshape(shape_list(shape)), x)
+
+
+def expand_dims(x, axis=None, name=None, dim=None):
+  axis = dim if axis is None else axis
+  return wrap(raw(x).unsqueeze(int(axis)), x)
+
+
+def squeeze(x, axis=None, name=None, squeeze_dims=None):
+  axis = squeeze_dims if axis is None else axis
+  t = raw(x)
+  if axis is None:
+    return wrap(t.squeeze(), x)
+  for a in sorted(_axes(axis, t.dim()), reverse=True):
+    assert t.shape[a] == 1
+    t = t.squeeze(a)
+  return wrap(t, x)
+
+
+def concat(values, axis, name=None):
+  return wrap(torch.cat([raw(v) for v in values], dim=int(axis)), values[0])
+
+
+def stack(values, axis=0, name=None):
+  return wrap(torch.stack([raw(v) for v in values], dim=int(axis)), values[0] if isinstance(values[0], Tensor) else None)
+
+
+def transpose(x, perm=None, name=None):
+  t = raw(x)
+  return wrap(t.permute(*[int(p) for p in perm]) if perm is not None else t.t(), x)
+
+
+def tile(x, multiples, name=None):
+  return wrap(raw(x).repeat(*shape_list(multiples)), x)
+
+
+def pad(x, paddings, mode='CONSTANT', name=None, constant_values=0):
+  assert mode == 'CONSTANT'
+  flat = []
+  for lo, hi in reversed([tuple(p) for p in paddings]):
+    flat += [int(lo), int(hi)]
+  return wrap(F.pad(raw(x), flat, value=float(constant_values)), x)
+
+
+def shape(x, name=None, out_type=None):
+  return Tensor(torch.tensor(list(raw(x).shape), dtype=torch.int64), int32)
+
+
+def zeros_like(x, dtype=None, name=None):
+  return wrap(torch.zeros_like(raw(x)), x)
+
+
+def ones_like(x, dtype=None, name=None):
+  return wrap(torch.ones_like(raw(x)), x)
+
+
+def zeros(shape, dtype=float32, name=None):
+  return Tensor(torch.zeros(shape_list(shape), dtype=F64), dtype)
+
+
+def ones(shape, dtype=float32, name=None):
+  return Tensor(torch.ones(shape_list(shape), dtype=F64), dtype)
+
+
+def _unary(fn):
+  def op(x, name=None):
+    return wrap(fn(raw(x)), x, name=name)
+  return op
+
+
+def _binary(fn):
+  def op(x, y, name=None):
+    like = x if isinstance(x, Tensor) else y
+    return wrap(fn(raw(x), raw(y)), like, name=name)
+  return op
+
+
+sqrt, rsqrt, square, exp, log = map(_unary, (torch.sqrt, torch.rsqrt, torch.square, torch.exp, torch.log))
+negative, tanh, sigmoid, abs_ = map(_unary, (torch.neg, torch.tanh, torch.sigmoid, torch.abs))
+add, subtract, multiply, divide = map(_binary, (torch.add, torch.sub, torch.mul, torch.div))
+minimum, maximum, pow_ = map(_binary, (torch.minimum, torch.maximum, torch.pow))
+
+
+def add_n(inputs, name=None):
+  out = raw(inputs[0])
+  for v in inputs[1:]:
+    out = out + raw(v)
+  return wrap(out, inputs[0], name=name)
+
+
+def clip_by_value(x, lo, hi, name=None):
+  return wrap(torch.minimum(torch.maximum(raw(x), raw(lo)), raw(hi)), x)
+
+
+def where(cond, x=None, y=None, name=None):
+  return wrap(torch.where(raw(cond), raw(x), raw(y)), x)
+
+
+def _compare(fn):
+  def op(x, y, name=None):
+    return Tensor(fn(raw(x), raw(y)), bool_)
+  return op
+
+
+equal, not_equal, greater, less = map(_compare, (torch.eq, torch.ne, torch.gt, torch.lt))
+greater_equal, less_equal = map(_compare, (torch.ge, torch.le))
+
+
+def _reduce(fn):
+  def op(x, axis=None, keepdims=None, name=None, reduction_indices=None, keep_dims=None):
+    axis = reduction_indices if axis is None else axis
+    keep = bool(keepdims if keepdims is not None else keep_dims)
+    t = raw(x)
+    if t.dim() == 0:
+      return wrap(t, x, name=name)
+    return wrap(fn(t, dim=_axes(axis, t.dim()), keepdim=keep), x, name=name)
+  return op
+
+
+reduce_mean = _reduce(torch.mean)
+reduce_sum = _reduce(torch.sum)
+reduce_max = _reduce(torch.amax)
+reduce_min = _reduce(torch.amin)
+
+
+def matmul(a, b, transpose_a=False, transpose_b=False, name=None):
+  x, y = raw(a), raw(b)
+  if transpose_a:
+    x = x.transpose(-1, -2)
+  if transpose_b:
+    y = y.transpose(-1, -2)
+  return wrap(torch.matmul(x, y), a)
+
+
+def tensordot(a, b, axes, name=None):
+  if isinstance(axes, (int, np.integer)):
+    return wrap(torch.tensordot(raw(a), raw(b), dims=int(axes)), a)
+  return wrap(torch.tensordot(raw(a), raw(b), dims=([list(axes[0]), list(axes[1])])), a)
+
+
+# ---- random ops: every draw is logged so that the oracle can be fed the same numbers -----------------------------
+def _draw(kind, shape, name):
+  shape = shape_list(shape)
+  if kind == 'normal':
+    t = torch.randn(shape, dtype=F64, generator=STATE.gen)
+  else:
+    t = torch.rand(shape, dtype=F64, generator=STATE.gen)
+  STATE.random_log.append((name or kind, t))
+  return t
+
+
+def random_normal(shape, mean=0.0, stddev=1.0, dtype=float32, seed=None, name=None):
+  return Tensor(mean + stddev * _draw('normal', shape, name), dtype, name)
+
+
+def random_uniform(shape, minval=0, maxval=None, dtype=float32, seed=None, name=None):
+  maxval = 1.0 if maxval is None else maxval
+  return Tensor(minval + (maxval - minval) * _draw('uniform', shape, name), dtype, name)
+
+
+# ---- control flow / state ------------------------------------------------------------------------------------
+@contextlib.contextmanager
+def control_dependencies(deps):
+  yield
+
+
+@contextlib.contextmanager
+def _null_context(*a, **k):
+  yield
+
+
+class _Assign(Tensor):
+  """A deferred assignment (graph-mode `tf.assign` only runs when fetched): executed by run_update_ops()."""
+
+  def __init__(self, var, value_t):
+    Tensor.__init__(self, value_t, var.dtype, 'assign')
+    self.var = var
+
+  def run(self):
+    with torch.no_grad():
+      self.var.t.copy_(self.t.detach().reshape(self.var.t.shape))
+
+
+def assign(ref, value, validate_shape=None, use_locking=None, name=None):
+  a = _Assign(ref, raw(value))
+  STATE.deferred.append(a)
+  return a
+
+
+def assign_add(ref, value, use_locking=None, name=None):
+  return assign(ref, ref.t.detach() + raw(value))
+
+
+def assign_sub(ref, value, use_locking=None, name=None):
+  return assign(ref, ref.t.detach() - raw(value))
+
+
+def run_update_ops(ops=None):
+  """Executes the deferred assignments (all of them, or the ones reachable from `ops`) exactly once."""
+  todo = STATE.deferred if ops is None else [o for o in ops if isinstance(o, _Assign)]
+  for a in todo:
+    a.run()
+  STATE.deferred = [a for a in STATE.deferred if a not in todo]
+
+
+def group(*inputs, **kw):
+  return list(inputs)
+
+
+def no_op(name=None):
+  return None
+
+
+def cond(pred, true_fn=None, false_fn=None, name=None, fn1=None, fn2=None, strict=False):
+  true_fn, false_fn = true_fn or fn1, false_fn or fn2
+  p = bool(raw(pred).item()) if isinstance(pred, Tensor) else bool(pred)
+  return true_fn() if p else false_fn()
+
+
+def while_loop(cond_fn, body, loop_vars, **unused):
+  loop_vars = tuple(loop_vars)
+  while True:
+    c = cond_fn(*loop_vars)
+    c = bool(raw(c).item()) if isinstance(c, Tensor) else bool(c)
+    if not c:
+      return loop_vars
+    out = body(*loop_vars)
+    loop_vars = tuple(out) if isinstance(out, (tuple, list)) else (out,)
+
+
+def gradients(ys, xs, grad_ys=None, name=None, **unused):
+  ys = ys if isinstance(ys, (list, tuple)) else [ys]
+  xs_l = xs if isinstance(xs, (list, tuple)) else [xs]
+  total = sum(raw(y).sum() for y in ys)
+  gs = torch.autograd.grad(total, [raw(x) for x in xs_l], create_graph=True, allow_unused=True)
+  return [None if g is None else wrap(g, x) for g, x in zip(gs, xs_l)]
+
+
+def placeholder(dtype, shape=None, name=None):
+  return Tensor(torch.zeros(shape_list(shape), dtype=F64), dtype, name)
+
+
+def placeholder_with_default(input, shape, name=None):
+  return convert_to_tensor(input)
+
+
+# ---- nn ------------------------------------------------------------------------------------------------------
+def _same_pad(n, k, s):
+  out = -(-n // s)
+  total = max((out - 1) * s + k - n, 0)
+  return total // 2, total - total // 2
+
+
+def nn_conv2d(input, filter, strides, padding, use_cudnn_on_gpu=True, data_format='NHWC', dilations=None, name=None):
+  """tf.nn.conv2d, NHWC x HWIO; 'SAME' pads (total // 2) before and the rest after, as TF does."""
+  x = raw(input).permute(0, 3, 1, 2)
+  w = raw(filter).permute(3, 2, 0, 1)
+  sh, sw = int(strides[1]), int(strides[2])
+  if padding == 'SAME':
+    pt, pb = _same_pad(x.shape[2], w.shape[2], sh)
+    pl, pr = _same_pad(x.shape[3], w.shape[3], sw)
+    x = F.pad(x, [pl, pr, pt, pb])
+  else:
+    assert padding == 'VALID', padding
+  return wrap(F.conv2d(x, w, stride=(sh, sw)).permute(0, 2, 3, 1), input)
+
+
+def nn_avg_pool(value, ksize, strides, padding, data_format='NHWC', name=None):
+  assert padding == 'VALID'
+  x = raw(value).permute(0, 3, 1, 2)
+  y = F.avg_pool2d(x, (int(ksize[1]), int(ksize[2])), (int(strides[1]), int(strides[2])))
+  return wrap(y.permute(0, 2, 3, 1), value)
+
+
+def nn_bias_add(value, bias, data_format=None, name=None):
+  return wrap(raw(value) + raw(bias), value)
+
+
+def nn_moments(x, axes, shift=None, name=None, keep_dims=False, keepdims=None):
+  keep = bool(keepdims if keepdims is not None else keep_dims)
+  t = raw(x)
+  ax = _axes(axes, t.dim())
+  mean = t.mean(dim=ax, keepdim=True)
+  var = ((t - mean) ** 2).mean(dim=ax, keepdim=True)      # population variance of the centred values
+  if not keep:
+    for a in sorted(ax, reverse=True):
+      mean, var = mean.squeeze(a), var.squeeze(a)
+  return wrap(mean, x), wrap(var, x)
+
+
+def nn_batch_normalization(x, mean, variance, offset, scale, variance_epsilon, name=None):
+  inv = torch.rsqrt(raw(variance) + raw(variance_epsilon))
+  if scale is not None:
+    inv = inv * raw(scale)
+  shift = -raw(mean) * inv
+  if offset is not None:
+    shift = raw(offset) + shift
+  return wrap(raw(x) * inv + shift, x)
+
+
+def nn_l2_normalize(x, axis=None, epsilon=1e-12, name=None, dim=None):
+  axis = dim if axis is None else axis
+  t = raw(x)
+  ss = (t * t).sum(dim=_axes(axis, t.dim()), keepdim=True)
+  return wrap(t * torch.rsqrt(torch.clamp(ss, min=epsilon)), x)
+
+
+def nn_softmax(logits, axis=-1, name=None, dim=None):
+  axis = dim if dim is not None else axis
+  return wrap(torch.softmax(raw(logits), dim=int(axis)), logits)
+
+
+def nn_sigmoid_xent(_sentinel=None, labels=None, logits=None, name=None):
+  x, z = raw(logits), raw(labels)
+  return wrap(torch.clamp(x, min=0) - x * z + torch.log1p(torch.exp(-x.abs())), logits)
+
+
+def nn_leaky_relu(features, alpha=0.2, name=None):
+  t = raw(features)
+  return wrap(torch.maximum(alpha * t, t), features)
+
+
+def image_resize_nearest(images, size, align_corners=False, name=None):
+  """tf.image.resize_nearest_neighbor (align_corners=False): src index = floor(dst * in / out)."""
+  t = raw(images)
+  oh, ow = shape_list(size)
+  ih, iw = t.shape[1], t.shape[2]
+  ys = torch.clamp(torch.floor(torch.arange(oh, dtype=F64) * (ih / oh)).long(), max=ih - 1)
+  xs = torch.clamp(torch.floor(torch.arange(ow, dtype=F64) * (iw / ow)).long(), max=iw - 1)
+  return wrap(t[:, ys][:, :, xs], images)
+
+
+def image_resize_bilinear(images, size, align_corners=False, name=None):
+  """tf.image.resize_bilinear (TF1, align_corners=False): src = dst * in / out, no half-pixel offset."""
+  t = raw(images)
+  oh, ow = shape_list(size)
+  ih, iw = t.shape[1], t.shape[2]
+
+  def taps(o, i):
+    src = torch.arange(o, dtype=F64) * (i / o)
+    lo = torch.clamp(torch.floor(src).long(), max=i - 1)
+    hi = torch.clamp(lo + 1, max=i - 1)
+    return lo, hi, src - lo.to(F64)
+  y0, y1, fy = taps(oh, ih)
+  x0, x1, fx = taps(ow, iw)
+  fy = fy.view(1, oh, 1, 1)
+  fx = fx.view(1, 1, ow, 1)
+  top = t[:, y0][:, :, x0] * (1 - fx) + t[:, y0][:, :, x1] * fx
+  bot = t[:, y1][:, :, x0] * (1 - fx) + t[:, y1][:, :, x1] * fx
+  return wrap(top * (1 - fy) + bot * fy, images)
+
+
+# ---- tf.losses ---------------------------------------------------------------------------------------------------
+class Reduction(object):
+  NONE, SUM, MEAN = 'none', 'weighted_sum', 'weighted_mean'
+  SUM_OVER_BATCH_SIZE, SUM_OVER_NONZERO_WEIGHTS = 'weighted_sum_over_batch_size', 'weighted_sum_by_nonzero_weights'
+  SUM_BY_NONZERO_WEIGHTS = 'weighted_sum_by_nonzero_weights'
+
+
+def compute_weighted_loss(losses, weights=1.0, scope=None, loss_collection='losses',
+                          reduction=Reduction.SUM_BY_NONZERO_WEIGHTS):
+  """tf.losses.compute_weighted_loss: sum(losses * weights) / #(elements whose weight is not 0), 0 if there are none."""
+  assert reduction == Reduction.SUM_BY_NONZERO_WEIGHTS
+  l = raw(losses)
+  w = raw(weights) * torch.ones_like(l)
+  present = (w != 0).to(F64).sum()
+  total = (l * w).sum()
+  loss = torch.where(present > 0, total / torch.clamp(present, min=1.0), torch.zeros_like(total))
+  out = Tensor(loss, float32, (scope or 'weighted_loss') + '/value')
+  if loss_collection:
+    core.add_to_collection(loss_collection, out)
+  return out
+
+
+def absolute_difference(labels, predictions, weights=1.0, scope=None, loss_collection='losses',
+                        reduction=Reduction.SUM_BY_NONZERO_WEIGHTS):
+  losses = (raw(predictions) - raw(labels)).abs()
+  return compute_weighted_loss(Tensor(losses), weights, scope or 'absolute_difference', loss_collection, reduction)
+
+
+def sigmoid_cross_entropy(multi_class_labels, logits, weights=1.0, label_smoothing=0, scope=None,
+                          loss_collection='losses', reduction=Reduction.SUM_BY_NONZERO_WEIGHTS):
+  assert not label_smoothing
+  losses = nn_sigmoid_xent(labels=multi_class_labels, logits=logits)
+  return compute_weighted_loss(losses, weights, scope or 'sigmoid_cross_entropy_loss', loss_collection, reduction)
+
+
+def cosine_distance(labels, predictions, axis=None, weights=1.0, scope=None, loss_collection='losses',
+                    reduction=Reduction.SUM_BY_NONZERO_WEIGHTS, dim=None):
+  axis = dim if axis is None else axis
+  losses = 1 - (raw(predictions) * raw(labels)).sum(dim=int(axis), keepdim=True)
+  return compute_weighted_loss(Tensor(losses), weights, scope or 'cosine_distance_loss', loss_collection, reduction)
+
+
+def get_losses(scope=None, loss_collection='losses'):
+  return core.get_collection(loss_collection, scope)
+
+
+# ---- tf.train ----------------------------------------------------------------------------------------------------
+def get_global_step(graph=None):
+  return STATE.global_step
+
+
+def get_or_create_global_step(graph=None):
+  if STATE.global_step is None:
+    STATE.global_step = Variable('global_step', torch.zeros((), dtype=torch.int64), int64, False)
+  return STATE.global_step
+
+
+def piecewise_constant(x, boundaries, values, name=None):
+  """values[i] for the first i with x <= boundaries[i], else values[-1]."""
+  xv = float(raw(x).item())
+  for b, v in zip(boundaries, values):
+    if xv <= b:
+      return Tensor(torch.tensor(float(v), dtype=F64), float32, name)
+  return Tensor(torch.tensor(float(values[-1]), dtype=F64), float32, name)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# contrib.framework: arg_scope
+# ------------------------------------------------------------------------------------------------------------------
+_ARG_STACK = [{}]
+
+
+def _key(fn):
+  return getattr(fn, '_key_op', None) or (fn.__module__, fn.__name__)
+
+
+def add_arg_scope(func):
+  @functools.wraps(func)
+  def with_args(*args, **kwargs):
+    defaults = _ARG_STACK[-1].get(_key(with_args))
+    if defaults:
+      merged = dict(defaults)
+      merged.update(kwargs)
+      kwargs = merged
+    return func(*args, **kwargs)
+  with_args._key_op = (func.__module__, func.__name__)
+  return with_args
+
+
+@contextlib.contextmanager
+def arg_scope(list_ops_or_scope, **kwargs):
+  if isinstance(list_ops_or_scope, dict):
+    if kwargs:
+      raise ValueError('When attempting to re-use a scope by suppling a dictionary, kwargs must be empty.')
+    new = {k: dict(v) for k, v in list_ops_or_scope.items()}
+  else:
+    new = {k: dict(v) for k, v in _ARG_STACK[-1].items()}
+    for op in list_ops_or_scope:
+      if not hasattr(op, '_key_op'):
+        raise ValueError('%s is not decorated with @add_arg_scope' % (op,))
+      d = new.setdefault(_key(op), {})
+      d.update(kwargs)
+  _ARG_STACK.append(new)
+  try:
+    yield new
+  finally:
+    _ARG_STACK.pop()
+
+
+def has_arg_scope(func):
+  return hasattr(func, '_key_op')
+
+
+def model_variable(name, shape=None, dtype=float32, initializer=None, regularizer=None, trainable=True,
+                   collections=None, caching_device=None, device=None, partitioner=None, custom_getter=None,
+                   use_resource=None):
+  collections = list(collections or []) + ['variables', 'model_variables']
+  return core.get_variable(name, shape, dtype, initializer, regularizer, trainable, collections)
+
+
+def contrib_variable(name, shape=None, dtype=float32, initializer=None, regularizer=None, trainable=True,
+                     collections=None, **unused):
+  return core.get_variable(name, shape, dtype, initializer, regularizer, trainable, collections)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# contrib.layers
+# ------------------------------------------------------------------------------------------------------------------
+def _two(v):
+  if isinstance(v, (list, tuple)):
+    return [int(v[0]), int(v[1])]
+  return [int(v), int(v)]
+
+
+def get_variable_collections(variables_collections, name):
+  if isinstance(variables_collections, dict):
+    return variables_collections.get(name, None)
+  return variables_collections
+
+
+def collect_named_outputs(collections, alias, outputs):
+  return outputs
+
+
+def constant_value(value_or_tensor_or_var, dtype=None):
+  v = value_or_tensor_or_var
+  if isinstance(v, Tensor):
+    return v.t.item() if v.t.dim() == 0 and not isinstance(v, Variable) else None
+  return v
+
+
+def smart_cond(pred, fn1, fn2, name=None):
+  p = constant_value(pred)
+  if p is None:
+    p = bool(raw(pred).item())
+  return fn1() if p else fn2()
+
+
+def _apply_regularizer(regularizer, var):
+  if regularizer is not None:
+    r = regularizer(var)
+    if r is not None:
+      core.add_to_collection(core.GraphKeys.REGULARIZATION_LOSSES, r)
+
+
+@add_arg_scope
+def layers_convolution(inputs, num_outputs, kernel_size, stride=1, padding='SAME', data_format=None, rate=1,
+                       activation_fn='relu', normalizer_fn=None, normalizer_params=None,
+                       weights_initializer=None, weights_regularizer=None, biases_initializer=core.zeros_initializer(),
+                       biases_regularizer=None, reuse=None, variables_collections=None, outputs_collections=None,
+                       trainable=True, scope=None):
+  """tf.contrib.layers.conv2d: variables `weights` [kh, kw, in, out] and (only without a normalizer_fn) `biases`;
+  normalizer, then activation.  Default scope name 'Conv', uniquified like variable_scope(None, default_name)."""
+  assert rate == 1 and data_format in (None, 'NHWC')
+  with core.variable_scope(scope, 'Conv', [inputs], reuse=reuse) as sc:
+    inputs = convert_to_tensor(inputs)
+    kh, kw = _two(kernel_size)
+    cin = int(inputs.shape[-1])
+    w = core.get_variable('weights', [kh, kw, cin, int(num_outputs)], inputs.dtype.base_dtype,
+                          weights_initializer or core.glorot_uniform_initializer(), trainable=trainable,
+                          collections=get_variable_collections(variables_collections, 'weights'))
+    _apply_regularizer(weights_regularizer, w)
+    sh, sw = _two(stride)
+    out = nn_conv2d(inputs, w, [1, sh, sw, 1], padding)
+    if normalizer_fn is None and biases_initializer is not None:
+      b = core.get_variable('biases', [int(num_outputs)], inputs.dtype.base_dtype, biases_initializer,
+                            trainable=trainable, collections=get_variable_collections(variables_collections, 'biases'))
+      out = nn_bias_add(out, b)
+    if normalizer_fn is not None:
+      out = normalizer_fn(out, **(normalizer_params or {}))
+    if activation_fn == 'relu':      # the contrib default, tf.nn.relu
+      activation_fn = nn_relu
+    if activation_fn is not None:
+      out = activation_fn(out)
+    return out
+
+
+@add_arg_scope
+def layers_fully_connected(inputs, num_outputs, activation_fn='relu', normalizer_fn=None, normalizer_params=None,
+                           weights_initializer=None, weights_regularizer=None,
+                           biases_initializer=core.zeros_initializer(), biases_regularizer=None, reuse=None,
+                           variables_collections=None, outputs_collections=None, trainable=True, scope=None):
+  """tf.contrib.layers.fully_connected: `weights` [in, out] (+ `biases` without a normalizer_fn); acts on the last
+  axis.  Default scope name 'fully_connected'."""
+  with core.variable_scope(scope, 'fully_connected', [inputs], reuse=reuse) as sc:
+    inputs = convert_to_tensor(inputs)
+    cin = int(inputs.shape[-1])
+    w = core.get_variable('weights', [cin, int(num_outputs)], inputs.dtype.base_dtype,
+                          weights_initializer or core.glorot_uniform_initializer(), trainable=trainable,
+                          collections=get_variable_collections(variables_collections, 'weights'))
+    _apply_regularizer(weights_regularizer, w)
+    out = wrap(torch.matmul(raw(inputs), raw(w)), inputs)
+    if normalizer_fn is None and biases_initializer is not None:
+      b = core.get_variable('biases', [int(num_outputs)], inputs.dtype.base_dtype, biases_initializer,
+                            trainable=trainable, collections=get_variable_collections(variables_collections, 'biases'))
+      out = nn_bias_add(out, b)
+    if normalizer_fn is not None:
+      out = normalizer_fn(out, **(normalizer_params or {}))
+    if activation_fn == 'relu':      # the contrib default, tf.nn.relu
+      activation_fn = nn_relu
+    if activation_fn is not None:
+      out = activation_fn(out)
+    return out
+
+
+def nn_relu(features, name=None):
+  return wrap(torch.relu(raw(features)), features)
+
+
+def l2_regularizer(scale, scope=None):
+  def reg(weights):
+    return Tensor(float(scale) * 0.5 * (raw(weights) ** 2).sum(), float32, 'l2_regularizer')
+  return reg
+
+
+def _unsupported(name):
+  def fn(*a, **k):
+    raise NotImplementedError('tf shim: %s is not implemented' % name)
+  fn.__name__ = name.split('.')[-1]
+  fn.__module__ = 'tensorflow.contrib.layers.python.layers.layers'
+  return add_arg_scope(fn)
+
+
+# ---- tf.layers base classes (libs/sn.py subclasses them) ----------------------------------------------------------
+_RENAME = {'kernel': 'weights', 'bias': 'biases'}      # what layers._build_variable_getter({...}) does in contrib
+
+
+class _Layer(object):
+  """tf.layers.Layer as contrib.layers uses it: `apply` = build once inside the captured variable scope, then call."""
+
+  def __init__(self, trainable=True, name=None, dtype=None, activity_regularizer=None, _scope=None, _reuse=None,
+               **unused):
+    self.trainable, self.name, self.dtype = trainable, name, dtype or float32
+    self._scope, self._reuse, self.built = _scope, _reuse, False
+
+  def add_variable(self, name, shape, initializer=None, regularizer=None, trainable=True, dtype=None):
+    v = core.get_variable(_RENAME.get(name, name), shape, dtype or self.dtype, initializer,
+                          trainable=trainable and self.trainable)
+    _apply_regularizer(regularizer, v)
+    return v
+
+  def apply(self, inputs):
+    with core.variable_scope(self._scope, reuse=self._reuse):
+      if not self.built:
+        self.build(inputs.shape)
+        self.built = True
+      return self.call(inputs)
+
+  __call__ = apply
+
+
+class Convolution2D(_Layer):
+  rank = 2
+
+  def __init__(self, filters, kernel_size, strides=1, padding='valid', data_format='channels_last', dilation_rate=1,
+               activation=None, use_bias=True, kernel_initializer=None, bias_initializer=None, kernel_regularizer=None,
+               bias_regularizer=None, **kw):
+    _Layer.__init__(self, **kw)
+    assert data_format == 'channels_last' and _two(dilation_rate) == [1, 1]
+    self.filters, self.kernel_size, self.strides = int(filters), _two(kernel_size), _two(strides)
+    self.padding, self.data_format, self.activation, self.use_bias = padding, data_format, activation, bool(use_bias)
+    self.kernel_initializer, self.bias_initializer = kernel_initializer, bias_initializer
+    self.kernel_regularizer, self.bias_regularizer = kernel_regularizer, bias_regularizer
+    self.kernel = self.bias = None
+
+  def build(self, input_shape):
+    cin = int(input_shape[-1])
+    self.kernel = self.add_variable('kernel', self.kernel_size + [cin, self.filters], self.kernel_initializer,
+                                    self.kernel_regularizer)
+    if self.use_bias:
+      self.bias = self.add_variable('bias', [self.filters], self.bias_initializer, self.bias_regularizer)
+
+  def _convolution_op(self, inputs, kernel):
+    return nn_conv2d(inputs, kernel, [1] + self.strides + [1], self.padding.upper())
+
+  def call(self, inputs):
+    out = self._convolution_op(inputs, self.kernel)
+    if self.use_bias:
+      out = nn_bias_add(out, self.bias)
+    return self.activation(out) if self.activation is not None else out
+
+
+class Dense(_Layer):
+  def __init__(self, units, activation=None, use_bias=True, kernel_initializer=None, bias_initializer=None,
+               kernel_regularizer=None, bias_regularizer=None, **kw):
+    _Layer.__init__(self, **kw)
+    self.units, self.activation, self.use_bias = int(units), activation, bool(use_bias)
+    self.kernel_initializer, self.bias_initializer = kernel_initializer, bias_initializer
+    self.kernel_regularizer, self.bias_regularizer = kernel_regularizer, bias_regularizer
+    self.kernel = self.bias = None
+
+  def build(self, input_shape):
+    self.kernel = self.add_variable('kernel', [int(input_shape[-1]), self.units], self.kernel_initializer,
+                                    self.kernel_regularizer)
+    if self.use_bias:
+      self.bias = self.add_variable('bias', [self.units], self.bias_initializer, self.bias_regularizer)
+
+  def call(self, inputs):
+    out = wrap(torch.matmul(raw(inputs), raw(self.kernel)), inputs)
+    if self.use_bias:
+      out = nn_bias_add(out, self.bias)
+    return self.activation(out) if self.activation is not None else out
+
+
+def _not_a_layer(name):
+  class Unsupported(_Layer):
+    def __init__(self, *a, **k):
+      raise NotImplementedError('tf shim: %s' % name)
+  return Unsupported
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# module tree
+# ------------------------------------------------------------------------------------------------------------------
+class StubObject(object):
+  """Anything the hot path never really uses (summaries, savers, queues ...): absorbs calls and attribute access."""
+
+  def __init__(self, name):
+    object.__setattr__(self, '_name', name)
+
+  def __getattr__(self, k):
+    if k.startswith('__') and k.endswith('__'):
+      raise AttributeError(k)
+    return StubObject(self._name + '.' + k)
+
+  def __call__(self, *a, **k):
+    return StubObject(self._name + '()')
+
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *a):
+    return False
+
+  def __iter__(self):
+    return iter(())
+
+  def __repr__(self):
+    return '<stub %s>' % self._name
+
+
+class StubModule(types.ModuleType):
+  def __getattr__(self, k):
+    if k.startswith('__') and k.endswith('__'):
+      raise AttributeError(k)
+    v = sys.modules.get(self.__name__ + '.' + k) or StubObject(self.__name__ + '.' + k)
+    setattr(self, k, v)
+    return v
+
+
+def _module(name, **attrs):
+  m = StubModule(name)
+  m.__path__ = []      # a package: submodule imports go through the finder below
+  for k, v in attrs.items():
+    setattr(m, k, v)
+  return m
+
+
+def build_modules():
+  logging = _module('tensorflow.logging', INFO=20, WARN=30, ERROR=40, DEBUG=10,
+                    info=lambda *a, **k: None, warning=lambda *a, **k: None, warn=lambda *a, **k: None,
+                    error=lambda *a, **k: None, log_every_n=lambda *a, **k: None, log=lambda *a, **k: None,
+                    set_verbosity=lambda *a, **k: None)
+  nn = _module('tensorflow.nn', relu=nn_relu, leaky_relu=nn_leaky_relu, tanh=tanh, sigmoid=sigmoid,
+               softmax=nn_softmax, bias_add=nn_bias_add, avg_pool=nn_avg_pool, conv2d=nn_conv2d, moments=nn_moments,
+               batch_normalization=nn_batch_normalization, l2_normalize=nn_l2_normalize,
+               sigmoid_cross_entropy_with_logits=nn_sigmoid_xent)
+  image = _module('tensorflow.image', resize_nearest_neighbor=image_resize_nearest,
+                  resize_bilinear=image_resize_bilinear)
+  losses = _module('tensorflow.losses', compute_weighted_loss=compute_weighted_loss,
+                   absolute_difference=absolute_difference, sigmoid_cross_entropy=sigmoid_cross_entropy,
+                   cosine_distance=cosine_distance, get_losses=get_losses, Reduction=Reduction,
+                   get_regularization_losses=lambda scope=None: core.get_collection(
+                     core.GraphKeys.REGULARIZATION_LOSSES, scope))
+  train = _module('tensorflow.train', get_global_step=get_global_step,
+                  get_or_create_global_step=get_or_create_global_step, piecewise_constant=piecewise_constant)
+  app = _module('tensorflow.app', flags=core.flags)
+
+  conv2d = layers_convolution
+  fully_connected = layers_fully_connected
+  layers_impl = _module(
+    'tensorflow.contrib.layers.python.layers.layers', conv2d=conv2d, convolution=conv2d, convolution2d=conv2d,
+    fully_connected=fully_connected, conv2d_transpose=_unsupported('layers.conv2d_transpose'),
+    batch_norm=_unsupported('layers.batch_norm'), layer_norm=_unsupported('layers.layer_norm'),
+    instance_norm=_unsupported('layers.instance_norm'), l2_regularizer=l2_regularizer,
+    xavier_initializer=core.glorot_uniform_initializer, utils=None,
+    _build_variable_getter=lambda rename=None: None, _add_variable_to_collections=lambda *a, **k: None,
+    core_layers=_module('tensorflow.python.layers.core', Dense=Dense),
+    six=_module('six', integer_types=(int, np.integer)), nn=None)
+  utils = _module('tensorflow.contrib.layers.python.layers.utils', get_variable_collections=get_variable_collections,
+                  collect_named_outputs=collect_named_outputs, smart_cond=smart_cond, constant_value=constant_value,
+                  two_element_tuple=lambda v: tuple(_two(v)))
+  initializers = _module('tensorflow.contrib.layers.python.layers.initializers',
+                         xavier_initializer=core.glorot_uniform_initializer)
+  layers_impl.utils = utils
+  py_layers = _module('tensorflow.contrib.layers.python.layers', layers=layers_impl, utils=utils,
+                      initializers=initializers, batch_norm=layers_impl.batch_norm, convolution=conv2d,
+                      fully_connected=fully_connected)
+  py = _module('tensorflow.contrib.layers.python', layers=py_layers)
+  contrib_layers = _module(
+    'tensorflow.contrib.layers', conv2d=conv2d, convolution=conv2d, convolution2d=conv2d,
+    fully_connected=fully_connected, conv2d_transpose=layers_impl.conv2d_transpose, batch_norm=layers_impl.batch_norm,
+    layer_norm=layers_impl.layer_norm, instance_norm=layers_impl.instance_norm, l2_regularizer=l2_regularizer,
+    xavier_initializer=core.glorot_uniform_initializer, python=py)
+
+  fw_variables = _module('tensorflow.contrib.framework.python.ops.variables', model_variable=model_variable,
+                         variable=contrib_variable, get_or_create_global_step=get_or_create_global_step)
+  fw_ops = _module('tensorflow.contrib.framework.python.ops', add_arg_scope=add_arg_scope, arg_scope=arg_scope,
+                   variables=fw_variables, has_arg_scope=has_arg_scope)
+  fw_py = _module('tensorflow.contrib.framework.python', ops=fw_ops)
+  arg_scope_mod = arg_scope
+  framework = _module('tensorflow.contrib.framework', arg_scope=arg_scope, add_arg_scope=add_arg_scope,
+                      python=fw_py, model_variable=model_variable, get_or_create_global_step=get_or_create_global_step,
+                      get_variables=lambda scope=None, suffix=None, collection='variables': core.get_collection(
+                        collection, scope), get_model_variables=lambda scope=None, suffix=None: core.get_collection(
+                        'model_variables', scope))
+  slim = _module('tensorflow.contrib.slim', arg_scope=arg_scope, add_arg_scope=add_arg_scope, conv2d=conv2d,
+                 fully_connected=fully_connected, model_variable=model_variable,
+                 get_or_create_global_step=get_or_create_global_step, l2_regularizer=l2_regularizer,
+                 get_variables=framework.get_variables, get_model_variables=framework.get_model_variables)
+  contrib = _module('tensorflow.contrib', layers=contrib_layers, framework=framework, slim=slim)
+
+  py_fw_ops = _module('tensorflow.python.framework.ops', convert_to_tensor=convert_to_tensor,
+                      add_to_collections=core.add_to_collections, add_to_collection=core.add_to_collection,
+                      control_dependencies=control_dependencies, device=_null_context, colocate_with=_null_context,
+                      name_scope=core.name_scope, Tensor=Tensor, GraphKeys=core.GraphKeys)
+  array_ops = _module('tensorflow.python.ops.array_ops', constant=constant, identity=identity, reshape=reshape,
+                      shape=shape, stop_gradient=stop_gradient, ones_like=ones_like, zeros_like=zeros_like,
+                      expand_dims=expand_dims, squeeze=squeeze, concat=concat, transpose=transpose)
+  convolutional = _module('tensorflow.python.layers.convolutional', Convolution2D=Convolution2D, Conv2D=Convolution2D,
+                          Convolution1D=_not_a_layer('Convolution1D'), Convolution3D=_not_a_layer('Convolution3D'))
+  gen_math_ops = _module('tensorflow.python.ops.gen_math_ops', mat_mul=matmul)
+  context = _module('tensorflow.python.eager.context', executing_eagerly=lambda: False, in_eager_mode=lambda: False)
+
+  tf = _module(
+    'tensorflow', __version__='1.8.0-shim',
+    float16=float16, float32=float32, float64=float64, int32=int32, int64=int64, bool=bool_, DType=core.DType,
+    Tensor=Tensor, Variable=Variable, TensorShape=TensorShape, Dimension=Dimension,
+    constant=constant, convert_to_tensor=convert_to_tensor, cast=cast, to_float=to_float, identity=identity,
+    stop_gradient=stop_gradient, reshape=reshape, expand_dims=expand_dims, squeeze=squeeze, concat=concat, stack=stack,
+    transpose=transpose, tile=tile, pad=pad, shape=shape, zeros_like=zeros_like, ones_like=ones_like, zeros=zeros,
+    ones=ones, sqrt=sqrt, rsqrt=rsqrt, square=square, exp=exp, log=log, negative=negative, tanh=tanh, sigmoid=sigmoid,
+    abs=abs_, add=add, subtract=subtract, multiply=multiply, divide=divide, div=divide, minimum=minimum,
+    maximum=maximum, pow=pow_, add_n=add_n, clip_by_value=clip_by_value, where=where, equal=equal,
+    not_equal=not_equal, greater=greater, less=less, greater_equal=greater_equal, less_equal=less_equal,
+    reduce_mean=reduce_mean, reduce_sum=reduce_sum, reduce_max=reduce_max, reduce_min=reduce_min, matmul=matmul,
+    tensordot=tensordot, random_normal=random_normal, random_uniform=random_uniform,
+    control_dependencies=control_dependencies, device=_null_context, assign=assign, assign_add=assign_add,
+    assign_sub=assign_sub, group=group, no_op=no_op, cond=cond, while_loop=while_loop, gradients=gradients,
+    placeholder=placeholder, placeholder_with_default=placeholder_with_default,
+    variable_scope=core.variable_scope, name_scope=core.name_scope, get_variable=core.get_variable,
+    get_variable_scope=core.get_variable_scope, AUTO_REUSE=core.AUTO_REUSE, GraphKeys=core.GraphKeys,
+    add_to_collection=core.add_to_collection, add_to_collections=core.add_to_collections,
+    get_collection=core.get_collection, get_collection_ref=core.get_collection_ref,
+    zeros_initializer=core.zeros_initializer, ones_initializer=core.ones_initializer,
+    constant_initializer=core.constant_initializer, random_normal_initializer=core.random_normal_initializer,
+    truncated_normal_initializer=core.truncated_normal_initializer,
+    glorot_uniform_initializer=core.glorot_uniform_initializer,
+    executing_eagerly=lambda: False, flags=core.flags, app=app, logging=logging, nn=nn, image=image, losses=losses,
+    train=train, contrib=contrib,
+    global_variables=lambda scope=None: core.get_collection('variables', scope),
+    trainable_variables=lambda scope=None: core.get_collection('trainable_variables', scope),
+    model_variables=lambda scope=None: core.get_collection('model_variables', scope))
+
+  mods = {m.__name__: m for m in (
+    tf, logging, nn, image, losses, train, app, contrib, contrib_layers, py, py_layers, layers_impl, utils,
+    initializers, framework, fw_py, fw_ops, fw_variables, slim, py_fw_ops, array_ops, context, convolutional,
+    gen_math_ops)}
+  return mods
+
+
+class _StubFinder(object):
+  """Resolves every other `tensorflow.*` (and explicitly stubbed) import to an absorbing stub module."""
+
+  def __init__(self, prefixes):
+    self.prefixes = tuple(prefixes)
+
+  def find_spec(self, name, path=None, target=None):
+    import importlib.machinery
+    if name.startswith(self.prefixes) or name in self.prefixes:
+      return importlib.machinery.ModuleSpec(name, self, is_package=True)
+    return None
+
+  def create_module(self, spec):
+    m = StubModule(spec.name)
+    m.__path__ = []
+    return m
+
+  def exec_module(self, module):
+    pass
+
+
+def install(extra_stub_prefixes=()):
+  """Puts the shim's `tensorflow` into sys.modules.  Refuses to shadow a real TensorFlow."""
+  if 'tensorflow' in sys.modules and not isinstance(sys.modules['tensorflow'], StubModule):
+    raise RuntimeError('a real tensorflow is already imported')
+  mods = build_modules()
+  sys.modules.update(mods)
+  sys.meta_path.insert(0, _StubFinder(('tensorflow.',) + tuple(extra_stub_prefixes)))
+  return mods['tensorflow']

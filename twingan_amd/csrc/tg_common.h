@@ -1,5 +1,6 @@
 // Shared device/host helpers for libtwingan_hip.so (gfx950 only).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -101,6 +102,13 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 }
 
 __device__ __forceinline__ float lrelu_f(float x, float a) { return fmaxf(a * x, x); }
+
+// launch-heuristic experiments: TG_TUNE_<NAME>=<int> in the environment overrides `dflt` (read at every call, so
+// two hipGraph captures in one process can bake different settings); only tools/ab_env.py sets these
+static inline int tg_tune(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
 
 static inline int tg_grid_for(int64_t work, int block, int max_blocks = 256 * 16) {
   int64_t g = (work + block - 1) / block;
