@@ -23,7 +23,7 @@ BASE_FLAGS = dict(generator_network='pggan', is_growing=False, loss_architecture
                   use_gdrop=False, use_conditional_labels=False, do_encoder_distillation=False)
 
 
-def run(flags, sources, targets, global_step=0, seed=0, preset=None, want_grads=True):
+def run(flags, sources, targets, global_step=0, seed=0, preset=None, want_grads=True, eager_updates=False):
   """flags: reference flag name -> value.  sources / targets: float arrays [B, H, W, 3].  preset: variable values
   (reference name -> array) to use instead of the reference's initialisers."""
   tf = loader.install()
@@ -39,12 +39,21 @@ def run(flags, sources, targets, global_step=0, seed=0, preset=None, want_grads=
     setattr(F, k, v)
   core.STATE.reset(seed)
   core.STATE.preset = dict(preset or {})
+  core.STATE.eager_updates = bool(eager_updates)
   tfapi._ARG_STACK[:] = [{}]
   gs = tfapi.get_or_create_global_step()
   gs.t.fill_(int(global_step))
   S = core.Tensor(torch.tensor(np.asarray(sources, np.float64), requires_grad=True), core.float32, 'a_source')
   T = core.Tensor(torch.tensor(np.asarray(targets, np.float64), requires_grad=True), core.float32, 'b_source')
   networks = ref.GanModel._select_network(None)
+  if F.use_style_embedding:
+    # As written the reference cannot build this configuration: _clone_fn (twingan.py:203-205) forwards the
+    # `self_attention_hw` entry of the shared kwargs (twingan.py:846-847) to pggan.encoder, whose signature
+    # (nets/pggan.py:509-521) has no such parameter -> TypeError.  Pinned with that one keyword dropped, i.e. with
+    # the style encoder's attention resolution at encoder_before_classification's default.
+    style_fn = networks['encoder_style_network_fn']
+    networks['encoder_style_network_fn'] = lambda *a, **k: style_fn(
+      *a, **{kk: v for kk, v in k.items() if kk != 'self_attention_hw'})
   end_points = ref.GanModel._clone_fn(networks, None, None, data_batched={'a_source': S, 'b_source': T},
                                       is_training=True, global_step=gs)
 
@@ -81,3 +90,39 @@ def run(flags, sources, targets, global_step=0, seed=0, preset=None, want_grads=
   tfapi.run_update_ops()
   res['state_after'] = {k: v.t.detach().numpy().copy() for k, v in core.STATE.variables.items() if not v.trainable}
   return res
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# oracle Config <-> reference flags / names
+# ---------------------------------------------------------------------------------------------------------------
+GROW_STEPS = 1000      # max_number_of_steps used to express alpha_grow as a global step (grow_start_number_of_steps=0)
+
+
+def flags_of(cfg):
+  """The reference flags (twingan.py:40-92, image_generation.py:45-130, nets/pggan.py:24-60) an oracle Config sets."""
+  return dict(
+    train_image_size=cfg.hw, pggan_max_num_channels=cfg.max_ch, generator_norm_type=cfg.norm,
+    do_pixel_norm=cfg.do_pixel_norm, use_unet=cfg.use_unet, is_growing=cfg.is_growing,
+    max_number_of_steps=GROW_STEPS, grow_start_number_of_steps=0, loss_architecture=cfg.loss,
+    gradient_penalty_lambda=cfg.gp_lambda, gan_weight=cfg.gan_weight, wgan_drift_loss_weight=cfg.drift,
+    l_cyc_weight=cfg.l_cyc, l_content_weight=cfg.l_content, do_l_cyc_gan=cfg.do_l_cyc_gan,
+    spectral_norm=cfg.spectral_norm, do_self_attention=cfg.do_self_attention, self_attention_hw=cfg.self_attention_hw,
+    use_style_embedding=cfg.use_style_embedding, style_embed_size=cfg.style_embed_size,
+    equalized_learning_rate=cfg.equalized, use_res_block=cfg.res_block)
+
+
+def global_step_of(cfg):
+  """alpha_grow = (global_step - grow_start) / (max_steps - grow_start)  (twingan.py:834-836)."""
+  return int(round(cfg.alpha_grow * GROW_STEPS)) if cfg.is_growing else int(cfg.global_step)
+
+
+def term_name(ref_name):
+  """Reference loss-op name -> the oracle's / product's term name.  The reference builds the s-domain losses first
+  (twingan.py:453), so within one graph 'x' is the s term and the uniquified 'x_1' the t term."""
+  fixed = {'l_source_content_before_classification': 'l_content_s', 'l_target_content_before_classification': 'l_content_t',
+           'l_source_style_prediction': 'l_style_s', 'l_target_style_prediction': 'l_style_t'}
+  if ref_name in fixed:
+    return fixed[ref_name]
+  if ref_name.startswith('l_cyc_'):
+    return ref_name
+  return ref_name[:-2] + '_t' if ref_name.endswith('_1') else ref_name + '_s'

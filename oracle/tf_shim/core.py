@@ -369,6 +369,9 @@ class VariableScope(object):
   def reuse_variables(self):
     self.reuse = True
 
+  def set_partitioner(self, partitioner):
+    pass
+
 
 class State(object):
   def __init__(self, seed=0):
@@ -383,7 +386,8 @@ class State(object):
     self.random_log = []                # (op name, torch tensor) of every random op, in call order
     self.global_step = None
     self.preset = {}                    # full variable name -> numpy value used instead of the initializer
-    self.deferred = []                  # assign ops: (variable, value thunk) executed by run_update_ops()
+    self.deferred = []                  # assign ops waiting for run_update_ops()
+    self.eager_updates = False          # True: assign ops run where they are created (see tfapi._Assign.schedule)
 
 
 STATE = State()

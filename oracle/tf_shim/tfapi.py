@@ -209,23 +209,24 @@ def tensordot(a, b, axes, name=None):
 
 
 # ---- random ops: every draw is logged so that the oracle can be fed the same numbers -----------------------------
-def _draw(kind, shape, name):
+def _draw(kind, shape, name, scale, shift):
   shape = shape_list(shape)
   if kind == 'normal':
     t = torch.randn(shape, dtype=F64, generator=STATE.gen)
   else:
     t = torch.rand(shape, dtype=F64, generator=STATE.gen)
-  STATE.random_log.append((name or kind, t))
+  t = shift + scale * t
+  STATE.random_log.append((name or kind, t))      # the value the graph sees
   return t
 
 
 def random_normal(shape, mean=0.0, stddev=1.0, dtype=float32, seed=None, name=None):
-  return Tensor(mean + stddev * _draw('normal', shape, name), dtype, name)
+  return Tensor(_draw('normal', shape, name, stddev, mean), dtype, name)
 
 
 def random_uniform(shape, minval=0, maxval=None, dtype=float32, seed=None, name=None):
   maxval = 1.0 if maxval is None else maxval
-  return Tensor(minval + (maxval - minval) * _draw('uniform', shape, name), dtype, name)
+  return Tensor(_draw('uniform', shape, name, maxval - minval, minval), dtype, name)
 
 
 # ---- control flow / state ------------------------------------------------------------------------------------
@@ -246,15 +247,41 @@ class _Assign(Tensor):
     Tensor.__init__(self, value_t, var.dtype, 'assign')
     self.var = var
 
+  def schedule(self):
+    """Deferred to run_update_ops() -- or, with STATE.eager_updates, executed now: program order is one of the
+    schedules a TF executor may pick for update ops that have no dependencies between them."""
+    if getattr(STATE, 'eager_updates', False):
+      self.run()
+    else:
+      STATE.deferred.append(self)
+    return self
+
   def run(self):
     with torch.no_grad():
       self.var.t.copy_(self.t.detach().reshape(self.var.t.shape))
 
 
+class _MovingAverageAssign(_Assign):
+  """moving_averages.assign_moving_average: `variable -= (variable - value) * (1 - decay)`.  Its in-graph value is
+  computed from the variable as it is now; when it RUNS (run_update_ops) it reads the variable again, so that several
+  updates of one variable in a run compose sequentially, as separately scheduled assign_sub ops do."""
+
+  def __init__(self, var, value, decay):
+    self.value, self.decay = raw(value).detach(), float(decay)
+    _Assign.__init__(self, var, var.t.detach() - (var.t.detach() - self.value) * (1.0 - self.decay))
+
+  def run(self):
+    with torch.no_grad():
+      self.var.t.sub_((self.var.t - self.value.reshape(self.var.t.shape)) * (1.0 - self.decay))
+
+
+def assign_moving_average(variable, value, decay, zero_debias=True, name=None):
+  assert not zero_debias, 'tf shim: zero_debias moving averages are not implemented'
+  return _MovingAverageAssign(variable, value, decay).schedule()
+
+
 def assign(ref, value, validate_shape=None, use_locking=None, name=None):
-  a = _Assign(ref, raw(value))
-  STATE.deferred.append(a)
-  return a
+  return _Assign(ref, raw(value).detach().clone()).schedule()
 
 
 def assign_add(ref, value, use_locking=None, name=None):
@@ -872,6 +899,8 @@ def build_modules():
   convolutional = _module('tensorflow.python.layers.convolutional', Convolution2D=Convolution2D, Conv2D=Convolution2D,
                           Convolution1D=_not_a_layer('Convolution1D'), Convolution3D=_not_a_layer('Convolution3D'))
   gen_math_ops = _module('tensorflow.python.ops.gen_math_ops', mat_mul=matmul)
+  moving_averages = _module('tensorflow.python.training.moving_averages',
+                            assign_moving_average=assign_moving_average)
   context = _module('tensorflow.python.eager.context', executing_eagerly=lambda: False, in_eager_mode=lambda: False)
 
   tf = _module(
@@ -907,7 +936,7 @@ def build_modules():
   mods = {m.__name__: m for m in (
     tf, logging, nn, image, losses, train, app, contrib, contrib_layers, py, py_layers, layers_impl, utils,
     initializers, framework, fw_py, fw_ops, fw_variables, slim, py_fw_ops, array_ops, context, convolutional,
-    gen_math_ops)}
+    gen_math_ops, moving_averages)}
   return mods
 
 

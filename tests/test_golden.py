@@ -1,7 +1,13 @@
-"""Golden fixtures (tests/golden/*.npz, written by tools/make_golden.py from the float64 oracle).
+"""Golden fixtures (tests/golden/*.npz, written by tools/make_golden.py).
 
-CPU (not gpu): the oracle still reproduces its frozen vectors (float64 NumPy primitives exactly, the
-torch-CPU float32 graph within fp32 round-off) -- guards the checker against silent drift.
+The twingan_*.npz model fixtures are REFERENCE-generated: one G+D step of the reference's own graph code
+(/root/reference twingan.py, image_generation.py, nets/pggan*.py, libs/*) executed on the TensorFlow-API stand-in of
+oracle/tf_shim (oracle/ref_runner.py) -- weights, inputs, the reference's random draws, generated images, every loss
+term, every gradient.  primitives.npz holds single TensorFlow ops restated in float64 NumPy (oracle/np_ops.py).
+
+CPU (not gpu): the float64 oracle reproduces the reference's numbers to 1e-9 (this is what pins the oracle), the
+float32 oracle within fp32 round-off; where /root/reference is mounted the fixtures are re-derived from it and must
+come out bit-identical.
 GPU: the HIP path (fp32 direct kernels; bf16 MFMA kernels with a looser bound) hits the same vectors
 through the C ABI.  Tolerances: fp32 primitives rel-L2 <= 1e-5; fp32 whole-network outputs rel-L2 <= 2e-5, losses 1e-4
 relative, whole-model gradients rel-L2 <= 8e-2 (typically 2e-3; rare LeakyReLU-mask flips move them by 1-6 %); bf16 outputs rel-L2 <= 5e-2, losses 5e-2.
@@ -20,7 +26,10 @@ MODELS = {'twingan_hw16_c8': dict(hw=16, max_ch=8), 'twingan_hw64_c8': dict(hw=6
           'twingan_hw16_c8_growing': dict(hw=16, max_ch=8, is_growing=True, alpha_grow=0.3),
           'twingan_hw16_c8_hinge_eqlr_res': dict(hw=16, max_ch=8, loss='hinge', equalized=True, res_block=True),
           'twingan_hw16_c8_batch_norm': dict(hw=16, max_ch=8, norm='batch_norm'),
-          'twingan_hw16_c8_style': dict(hw=16, max_ch=8, use_style_embedding=True, style_embed_size=8)}
+          'twingan_hw16_c8_style': dict(hw=16, max_ch=8, use_style_embedding=True, style_embed_size=8),
+          'twingan_hw16_c8_dragan': dict(hw=16, max_ch=8, loss='dragan'),
+          'twingan_hw16_c16_sn_att': dict(hw=16, max_ch=16, spectral_norm=True, do_self_attention=True,
+                                          self_attention_hw=8)}
 # oracle Config field -> product Config field where the names differ
 PRODUCT_FIELD = dict(loss='loss_architecture', equalized='equalized_learning_rate', res_block='use_res_block',
                      norm='generator_norm_type')
@@ -37,11 +46,33 @@ def out_tol(name, k, tol):
   return 1e-2 if (name.endswith('_style') and 'cycle' in k) else tol
 
 
-def oracle_cfg(name, g):
+def oracle_cfg(name, g, dtype=torch.float32):
   cfg = R.Config(**MODELS[name])
   if 'in/style_noise' in g:
-    cfg.style_noise = torch.from_numpy(g['in/style_noise']).float()
+    cfg.style_noise = torch.from_numpy(g['in/style_noise']).to(dtype)
+  if cfg.spectral_norm:      # the power-iteration vectors are non-trainable variables of the fixture
+    cfg.sn_state = {k[len('param/'):]: torch.from_numpy(v).to(dtype) for k, v in g.items()
+                    if k.startswith('param/') and k.endswith('/u')}
+    cfg.sn_cache = {}
   return cfg
+
+
+def grown(s, t, cfg):
+  """The fixtures' end points are the reference's: at a growing stage its networks see the blended images
+  (twingan.py:828-841)."""
+  return (R.growing_image(s, cfg.alpha_grow), R.growing_image(t, cfg.alpha_grow)) if cfg.is_growing else (s, t)
+
+
+def oracle_inputs(g, dtype):
+  """(params, sources, targets, gp alphas, DRAGAN noise) of a model fixture as torch tensors of `dtype`."""
+  P = {k[len('param/'):]: torch.from_numpy(v).to(dtype) for k, v in g.items()
+       if k.startswith('param/') and not k.endswith('/u')}
+  s, t = torch.from_numpy(g['in/sources']).to(dtype), torch.from_numpy(g['in/targets']).to(dtype)
+  a_s = torch.from_numpy(g['in/gp_alpha_s']).to(dtype).reshape(-1, 1, 1, 1)
+  a_t = torch.from_numpy(g['in/gp_alpha_t']).to(dtype).reshape(-1, 1, 1, 1)
+  n_s = torch.from_numpy(g['in/dragan_noise_s']).to(dtype) if 'in/dragan_noise_s' in g else None
+  n_t = torch.from_numpy(g['in/dragan_noise_t']).to(dtype) if 'in/dragan_noise_t' in g else None
+  return P, s, t, a_s, a_t, n_s, n_t
 
 
 def load(name):
@@ -75,20 +106,71 @@ def test_numpy_oracle_reproduces_primitive_fixtures():
 
 
 @pytest.mark.parametrize('name', sorted(MODELS))
+def test_oracle_f64_matches_the_reference(name):
+  """THE PIN: every loss term and every gradient of the float64 oracle against the numbers the reference's own code
+  produced for the same weights, inputs and random draws."""
+  g = load(name)
+  cfg = oracle_cfg(name, g, torch.float64)
+  P, s, t, a_s, a_t, n_s, n_t = oracle_inputs(g, torch.float64)
+  with torch.no_grad():
+    o = R.forward_generators(P, *grown(s, t, cfg), cfg)
+    for k in ('es', 's_prime', 't_prime', 's_cycle', 't_cycle'):
+      assert np.abs(o[k].numpy() - g['fwd/' + k]).max() < 1e-9, k
+    assert np.abs(R.discriminator(P, grown(s, t, cfg)[0], cfg, 'discriminator_s')[0].numpy() - g['fwd/d_s_real']).max() < 1e-9
+  cfg.sn_cache = {}      # normalised kernels cached under no_grad carry no graph
+  for v in P.values():
+    v.requires_grad_(True)
+  gl, gterms = R.generator_loss(P, s, t, cfg)
+  dl, dterms = R.discriminator_loss(P, s, t, cfg, a_s, a_t, n_s, n_t)
+  for grp, total, terms in (('g', gl, gterms), ('d', dl, dterms)):
+    assert abs(float(total) - float(g['loss/%s_total' % grp])) < 1e-9
+    assert {'loss/%s/%s' % (grp, k) for k in terms} == {k for k in g if k.startswith('loss/%s/' % grp)}
+    for k, v in terms.items():
+      assert abs(float(v) - float(g['loss/%s/%s' % (grp, k)])) < 1e-9, k
+  grads = dict(R.grads_of(gl, P, R.generator_var_names(P)))
+  grads.update(R.grads_of(dl, P, R.discriminator_var_names(P)))
+  assert set(grads) == {k[len('grad/'):] for k in g if k.startswith('grad/')} == set(P)
+  scale = max(float(np.abs(g['grad/' + k]).max()) for k in grads)
+  for k, v in grads.items():
+    assert np.abs(v.detach().numpy() - g['grad/' + k]).max() < 1e-9 * scale, k
+  if cfg.spectral_norm:      # libs/sn.py:84-86: what the run leaves in u
+    R.end_run(cfg)
+    for k, v in cfg.sn_state.items():
+      assert np.abs(v.numpy() - g['state_after/' + k]).max() < 1e-12, k
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='the reference tree is only mounted in the build container')
+@pytest.mark.parametrize('name', ['twingan_hw16_c8', 'twingan_hw16_c16_sn_att'])
+def test_fixtures_are_what_the_reference_computes(name):
+  """Re-runs the reference's graph code (oracle/ref_runner.py) on the fixture's weights and inputs."""
+  from oracle import ref_runner
+  g = load(name)
+  cfg = R.Config(**MODELS[name])
+  preset = {k[len('param/'):]: v for k, v in g.items() if k.startswith('param/')}
+  ref = ref_runner.run(ref_runner.flags_of(cfg), g['in/sources'], g['in/targets'],
+                       global_step=ref_runner.global_step_of(cfg), seed=0, preset=preset)
+  assert set(ref['variables']) - {'global_step'} == set(preset)      # the reference creates exactly these variables
+  assert abs(ref['g_loss'] - float(g['loss/g_total'])) < 1e-12 and abs(ref['d_loss'] - float(g['loss/d_total'])) < 1e-12
+  for grp in 'gd':
+    for k, v in ref[grp + '_terms'].items():
+      assert abs(v - float(g['loss/%s/%s' % (grp, ref_runner.term_name(k))])) < 1e-12, k
+    for k, v in ref[grp + '_grads'].items():
+      if 'grad/' + k in g and (grp == 'd') == k.startswith('discriminator'):
+        assert np.abs(v - g['grad/' + k]).max() < 1e-12, k
+
+
+@pytest.mark.parametrize('name', sorted(MODELS))
 def test_torch_oracle_fp32_reproduces_model_fixtures(name):
   g = load(name)
   cfg = oracle_cfg(name, g)
-  P = {k[len('param/'):]: torch.from_numpy(v).float() for k, v in g.items() if k.startswith('param/')}
-  s, t = torch.from_numpy(g['in/sources']).float(), torch.from_numpy(g['in/targets']).float()
+  P, s, t, a_s, a_t, n_s, n_t = oracle_inputs(g, torch.float32)
   with torch.no_grad():
-    o = R.forward_generators(P, s, t, cfg)
+    o = R.forward_generators(P, *grown(s, t, cfg), cfg)
   for k in ('es', 's_prime', 't_prime', 's_cycle', 't_cycle'):
     assert rel_l2(o[k].numpy(), g['fwd/' + k]) < out_tol(name, k, 2e-5), k
   for v in P.values():
     v.requires_grad_(True)
-  a_s = torch.from_numpy(g['in/gp_alpha_s']).float().reshape(-1, 1, 1, 1)
-  a_t = torch.from_numpy(g['in/gp_alpha_t']).float().reshape(-1, 1, 1, 1)
-  dl, terms = R.discriminator_loss(P, s, t, cfg, a_s, a_t)
+  dl, terms = R.discriminator_loss(P, s, t, cfg, a_s, a_t, n_s, n_t)
   assert abs(float(dl) - float(g['loss/d_total'])) < 1e-4 * max(1.0, abs(float(g['loss/d_total'])))
   for k, v in terms.items():
     assert abs(float(v) - float(g['loss/d/' + k])) < 1e-4 * max(1.0, abs(float(g['loss/d/' + k]))), k
@@ -146,7 +228,8 @@ def test_gpu_primitives_hit_golden(dtype):
 @pytest.mark.parametrize('name,precision', [('twingan_hw16_c8', 'fp32'), ('twingan_hw64_c8', 'fp32'),
                                             ('twingan_hw16_c8_growing', 'fp32'), ('twingan_hw64_c8', 'bf16'),
                                             ('twingan_hw16_c8_hinge_eqlr_res', 'fp32'),
-                                            ('twingan_hw16_c8_batch_norm', 'fp32'), ('twingan_hw16_c8_style', 'fp32')])
+                                            ('twingan_hw16_c8_batch_norm', 'fp32'), ('twingan_hw16_c8_style', 'fp32'),
+                                            ('twingan_hw16_c8_dragan', 'fp32'), ('twingan_hw16_c16_sn_att', 'fp32')])
 def test_gpu_model_hits_golden(name, precision):
   from twingan_amd import Config
   from twingan_amd import twingan as T
@@ -159,6 +242,8 @@ def test_gpu_model_hits_golden(name, precision):
   adt = torch.bfloat16 if precision == 'bf16' else torch.float32
   s, t = _dev(g['in/sources'], adt), _dev(g['in/targets'], adt)
   a_s, a_t = _dev(g['in/gp_alpha_s']), _dev(g['in/gp_alpha_t'])
+  n_s = _dev(g['in/dragan_noise_s'], adt) if 'in/dragan_noise_s' in g else None
+  n_t = _dev(g['in/dragan_noise_t'], adt) if 'in/dragan_noise_t' in g else None
   # whole-model fp32 gradients: typically 2e-4..5e-3 from the fp64 vectors, but the graph has discontinuities
   # (LeakyReLU masks, L1 signs) and the fp32 statistics are summed with atomics in varying order, so a unit
   # sitting within ~1e-6 of zero occasionally flips and moves the encoder gradients by 1-6 % (measured: 5 of 40
@@ -166,14 +251,15 @@ def test_gpu_model_hits_golden(name, precision):
   # bounds are the per-primitive ones.
   otol, ltol, gtol = (2e-5, 1e-4, 8e-2) if precision == 'fp32' else (5e-2, 5e-2, None)
   with torch.no_grad():
-    o = T.forward_generators(tr.P, s, t, cfg, noise)
+    gs, gt = (T.get_growing_image(s, cfg.alpha_grow), T.get_growing_image(t, cfg.alpha_grow)) if cfg.is_growing else (s, t)
+    o = T.forward_generators(tr.P, gs, gt, cfg, noise)
   for k in ('es', 's_prime', 't_prime', 's_cycle', 't_cycle'):
     # bf16 at 8 channels: the fp64 oracle with bf16 storage rounding (tools/bf16_sensitivity.py) predicts rel-L2
     # 0.038 for the encoder output and 0.12-0.20 for the generator outputs (instance-normalised to_rgb); the
     # kernels measure 0.039 / 0.18.  Tight bf16 bounds live in the per-primitive tests.
     tol = out_tol(name, k, otol) if precision == 'fp32' else (0.06 if k == 'es' else 0.3)
     assert rel_l2(o[k].float().cpu().numpy(), g['fwd/' + k]) < tol, k
-  for group, fn, args in (('g', T.generator_loss, (s, t, cfg, noise)), ('d', T.discriminator_loss, (s, t, cfg, a_s, a_t, None, None, noise))):
+  for group, fn, args in (('g', T.generator_loss, (s, t, cfg, noise)), ('d', T.discriminator_loss, (s, t, cfg, a_s, a_t, n_s, n_t, noise))):
     tr.store.zero_grad(group)
     tr._set_requires_grad(g=group == 'g', d=group == 'd')
     loss, terms = fn(tr.P, *args)

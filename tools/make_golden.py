@@ -1,16 +1,19 @@
 #!/usr/bin/env python
-"""Generates tests/golden/*.npz: seeded input/output vectors of the TwinGAN hot path computed by the
-float64 oracle (oracle/np_ops.py for the primitives, oracle/torch_ref.py in float64 for whole
-networks, losses and gradients).
+"""Generates tests/golden/*.npz.
 
-The reference itself (Python-2 / TF-1.8) cannot be imported here and ships no golden
-vectors for this path, so these fixtures are *oracle-generated*: they freeze the restatement so that
-(a) the oracle cannot drift silently and (b) the GPU parity tests have committed vectors to hit.
-Parity stays "unpinned" in the sense of oracle/__init__.py.
+  * twingan_*.npz -- REFERENCE-generated: weights, inputs, random draws, generated images, every loss term and every
+    gradient of one G+D step, computed by the reference's own graph-building code (twingan.py / image_generation.py /
+    nets/pggan*.py / libs/* under /root/reference) executed on the TensorFlow-1.8 API stand-in of oracle/tf_shim
+    (TensorFlow itself is not installed here; see oracle/tf_shim/core.py for exactly what that does and does not
+    pin).  The float64 oracle must agree with those numbers to 1e-9 or nothing is written.
+  * primitives.npz -- oracle-generated (oracle/np_ops.py): single ops (conv + both gradients, norm, resampling,
+    minibatch stddev, losses, Adam) whose semantics are TensorFlow's, not the reference's.
 
+Needs /root/reference, i.e. runs in the build container only; the tests read the committed files.
 Run:  python tools/make_golden.py      (rewrites tests/golden/; deterministic)
 """
 import os
+import re
 import sys
 
 import numpy as np
@@ -68,59 +71,115 @@ def primitives():
 
 
 def model(hw, max_ch, batch, growing=False, alpha=0.0, seed=0, **extra):
+  """One model fixture, computed by the REFERENCE's own graph code (oracle/ref_runner.py: twingan.GanModel._clone_fn
+  and everything it calls, executed on the TF stand-in of oracle/tf_shim) from seeded weights and inputs.  The random
+  draws the reference makes (WGAN-GP / DRAGAN alphas, style noise) become inputs of the fixture.  Before anything is
+  written the float64 oracle is checked against the same numbers (1e-9): a fixture is never frozen from a
+  restatement that disagrees with the reference."""
+  from oracle import ref_runner
   cfg = R.Config(hw=hw, max_ch=max_ch, is_growing=growing, alpha_grow=alpha, **extra)
   P = R.init_params(cfg, seed=seed, dtype=torch.float64, std='he')
   # round the parameters to fp32 so the GPU fp32 path starts from identical bits
   P = {k: v.float().double() for k, v in P.items()}
+  state = {}
+  if cfg.spectral_norm:
+    state = {k: v.float().double() for k, v in R.init_sn_state(P, seed=seed + 1).items()}
   g = torch.Generator().manual_seed(1234)
   s = torch.rand(batch, hw, hw, 3, generator=g).double()
   t = torch.rand(batch, hw, hw, 3, generator=g).double()
-  a_s = torch.rand(batch, generator=g).double()
-  a_t = torch.rand(batch, generator=g).double()
-  d = {'in/sources': s.numpy(), 'in/targets': t.numpy(), 'in/gp_alpha_s': a_s.numpy(), 'in/gp_alpha_t': a_t.numpy()}
-  if cfg.use_style_embedding:      # the random_style_embed draw of twingan.py:232-235 is an input of the fixture
-    cfg.style_noise = torch.randn(batch, cfg.style_embed_size, generator=g).double()
-    d['in/style_noise'] = cfg.style_noise.numpy()
-  for k, v in P.items():
+  preset = {k: v.numpy() for k, v in list(P.items()) + list(state.items())}
+  ref = ref_runner.run(ref_runner.flags_of(cfg), s.numpy(), t.numpy(), global_step=ref_runner.global_step_of(cfg),
+                       seed=seed, preset=preset)
+  created = set(ref['variables']) - {'global_step'}
+  moving = {k for k in created if re.search(r'/(moving_mean|moving_variance)_[st]$', k)}      # oracle: cfg.bn_state
+  assert created - moving == set(preset), (sorted(created - moving - set(preset)), sorted(set(preset) - created))
+  draws = {}
+  for n, v in ref['random']:
+    draws.setdefault(n, []).append(v)
+  d = {'in/sources': s.numpy(), 'in/targets': t.numpy()}
+  a_s = a_t = noise_s = noise_t = None
+  if 'alpha' in draws:
+    d['in/gp_alpha_s'], d['in/gp_alpha_t'] = draws['alpha'][0].reshape(-1), draws['alpha'][1].reshape(-1)
+    a_s, a_t = (torch.from_numpy(x).reshape(-1, 1, 1, 1) for x in (d['in/gp_alpha_s'], d['in/gp_alpha_t']))
+  else:
+    d['in/gp_alpha_s'] = d['in/gp_alpha_t'] = np.zeros(batch)
+  if 'uniform' in draws:      # get_perturbed_batch, image_generation.py:441-449
+    d['in/dragan_noise_s'], d['in/dragan_noise_t'] = draws['uniform']
+    noise_s, noise_t = torch.from_numpy(draws['uniform'][0]), torch.from_numpy(draws['uniform'][1])
+  if cfg.use_style_embedding:      # the random_style_embed draw of twingan.py:232-235
+    d['in/style_noise'] = draws['random_style_embed'][0]
+    cfg.style_noise = torch.from_numpy(d['in/style_noise'])
+  for k, v in list(P.items()) + list(state.items()):
     d['param/' + k] = v.numpy()
-  with torch.no_grad():
-    o = R.forward_generators(P, s, t, cfg)
-    for k in ('es', 's_prime', 't_prime', 's_cycle', 't_cycle'):
-      d['fwd/' + k] = o[k].numpy()
-    d['fwd/d_s_real'] = R.discriminator(P, s, cfg, 'discriminator_s')[0].numpy()
-    d['fwd/d_t_prime'] = R.discriminator(P, o['t_prime'], cfg, 'discriminator_t')[0].numpy()
+  ep = ref['end_points']
+  d['fwd/es'] = ep['encoded_source_content_before_classification']
+  for k in ('s_prime', 't_prime', 's_cycle', 't_cycle'):
+    d['fwd/' + k] = ep[k + '_output']
+  d['fwd/d_s_real'] = ep['discriminator_real_s_prediction']
+  d['fwd/d_t_prime'] = ep['discriminator_t_prime_prediction']
+  d['loss/g_total'], d['loss/d_total'] = np.array(ref['g_loss']), np.array(ref['d_loss'])
+  for grp in 'gd':
+    for k, v in ref[grp + '_terms'].items():
+      d['loss/%s/%s' % (grp, ref_runner.term_name(k))] = np.array(v)
+  gnames, dnames = R.generator_var_names(P), R.discriminator_var_names(P)
+  for k in gnames:
+    d['grad/' + k] = ref['g_grads'].get(k, np.zeros(tuple(P[k].shape)))
+  for k in dnames:
+    d['grad/' + k] = ref['d_grads'].get(k, np.zeros(tuple(P[k].shape)))
+  for k in state:
+    d['state_after/' + k] = ref['state_after'][k]
+
+  # ---- the pin: the float64 oracle against the reference's numbers ------------------------------------------
+  if state:
+    cfg.sn_state, cfg.sn_cache = {k: v.clone() for k, v in state.items()}, {}
   for v in P.values():
     v.requires_grad_(True)
   gl, gterms = R.generator_loss(P, s, t, cfg)
-  gg = R.grads_of(gl, P, R.generator_var_names(P))
-  dl, dterms = R.discriminator_loss(P, s, t, cfg, a_s.reshape(-1, 1, 1, 1), a_t.reshape(-1, 1, 1, 1))
-  dg = R.grads_of(dl, P, R.discriminator_var_names(P))
-  d['loss/g_total'] = np.array(float(gl))
-  d['loss/d_total'] = np.array(float(dl))
-  for k, v in gterms.items():
-    d['loss/g/' + k] = np.array(float(v))
-  for k, v in dterms.items():
-    d['loss/d/' + k] = np.array(float(v))
-  for k, v in gg.items():
-    d['grad/' + k] = v.detach().numpy()
-  for k, v in dg.items():
-    d['grad/' + k] = v.detach().numpy()
+  gg = R.grads_of(gl, P, gnames)
+  dl, dterms = R.discriminator_loss(P, s, t, cfg, a_s, a_t, noise_s, noise_t)
+  dg = R.grads_of(dl, P, dnames)
+  worst = max(abs(float(gl) - ref['g_loss']), abs(float(dl) - ref['d_loss']))
+  for grp, terms in (('g', gterms), ('d', dterms)):
+    assert {'loss/%s/%s' % (grp, k) for k in terms} == {k for k in d if k.startswith('loss/%s/' % grp)}, grp
+    for k, v in terms.items():
+      worst = max(worst, abs(float(v) - float(d['loss/%s/%s' % (grp, k)])))
+  scale = max(float(np.abs(d['grad/' + k]).max()) for k in gnames + dnames)
+  for k, v in list(gg.items()) + list(dg.items()):
+    worst = max(worst, float(np.abs(v.detach().numpy() - d['grad/' + k]).max()) / scale)
+  if state:
+    R.end_run(cfg)
+    for k in state:
+      worst = max(worst, float(np.abs(cfg.sn_state[k].numpy() - d['state_after/' + k]).max()))
+  assert worst < 1e-9, 'oracle disagrees with the reference: %g' % worst
+  print('  oracle vs reference: max deviation %.1e (losses, loss terms, all gradients%s)'
+        % (worst, ', spectral-norm u' if state else ''))
   return d
+
+
+CASES = {      # fixture name -> (batch, oracle Config fields); tests/test_golden.py::MODELS mirrors the Config fields
+  # 16x16 (no cycle-GAN term, twingan.py:466) and 64x64 at 8 channels (cycle-GAN term on), plus a growing stage
+  'twingan_hw16_c8': (2, dict(hw=16, max_ch=8)),
+  'twingan_hw64_c8': (2, dict(hw=64, max_ch=8)),
+  'twingan_hw16_c8_growing': (2, dict(hw=16, max_ch=8, growing=True, alpha=0.3)),
+  # option rows of SURVEY 8(a)
+  'twingan_hw16_c8_hinge_eqlr_res': (2, dict(hw=16, max_ch=8, loss='hinge', equalized=True, res_block=True)),
+  'twingan_hw16_c8_batch_norm': (2, dict(hw=16, max_ch=8, norm='batch_norm')),
+  # batch 1: the reference's conditional instance norm multiplies [B,1,1,C] statistics by a [B,C] gamma without
+  # reshaping it (libs/instance_norm.py:100-135), which only broadcasts as intended for one image
+  'twingan_hw16_c8_style': (1, dict(hw=16, max_ch=8, use_style_embedding=True, style_embed_size=8)),
+  'twingan_hw16_c8_dragan': (2, dict(hw=16, max_ch=8, loss='dragan')),
+  'twingan_hw16_c16_sn_att': (2, dict(hw=16, max_ch=16, spectral_norm=True, do_self_attention=True,
+                                      self_attention_hw=8)),
+}
 
 
 def main():
   os.makedirs(OUT, exist_ok=True)
   np.savez_compressed(os.path.join(OUT, 'primitives.npz'), **primitives())
-  # 16x16 (no cycle-GAN term, twingan.py:466) and 64x64 at 8 channels (cycle-GAN term on), plus a growing stage
-  np.savez_compressed(os.path.join(OUT, 'twingan_hw16_c8.npz'), **model(16, 8, 2))
-  np.savez_compressed(os.path.join(OUT, 'twingan_hw64_c8.npz'), **model(64, 8, 2))
-  np.savez_compressed(os.path.join(OUT, 'twingan_hw16_c8_growing.npz'), **model(16, 8, 2, growing=True, alpha=0.3))
-  # option rows of SURVEY 8(a): hinge loss + equalized lr + residual shortcuts; batch norm; style embedding
-  np.savez_compressed(os.path.join(OUT, 'twingan_hw16_c8_hinge_eqlr_res.npz'),
-                      **model(16, 8, 2, loss='hinge', equalized=True, res_block=True))
-  np.savez_compressed(os.path.join(OUT, 'twingan_hw16_c8_batch_norm.npz'), **model(16, 8, 2, norm='batch_norm'))
-  np.savez_compressed(os.path.join(OUT, 'twingan_hw16_c8_style.npz'),
-                      **model(16, 8, 2, use_style_embedding=True, style_embed_size=8))
+  for name, (batch, kw) in CASES.items():
+    print(name)
+    kw = dict(kw)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **model(kw.pop('hw'), kw.pop('max_ch'), batch, **kw))
   for f in sorted(os.listdir(OUT)):
     print(f, os.path.getsize(os.path.join(OUT, f)))
 
