@@ -1,6 +1,7 @@
 """float64 NumPy restatement of every primitive on the TwinGAN hot path (oracle, test-only).
 
-PARITY UNPINNED -- see ``oracle/__init__.py``.  All tensors are NHWC, weights HWIO
+Parity status: these are TensorFlow-op semantics restated (not pinned by a TensorFlow run) -- see
+``oracle/__init__.py``.  All tensors are NHWC, weights HWIO
 ``[kh, kw, Cin, Cout]`` exactly as the reference's TF variables.  Each function cites the
 reference lines (relative to /root/reference) it restates.
 """

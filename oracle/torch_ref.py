@@ -1,6 +1,7 @@
 """torch-CPU restatement of the TwinGAN training graph (oracle, test-only; also the timed CPU baseline).
 
-PARITY UNPINNED -- see ``oracle/__init__.py``.  Stock ``torch.nn.functional`` ops only; autograd
+Parity status: PINNED against the reference's own graph code (oracle/ref_runner.py, tests/golden/twingan_*.npz;
+TensorFlow-op semantics restated) -- see ``oracle/__init__.py``.  Stock ``torch.nn.functional`` ops only; autograd
 supplies the reference gradients (incl. the WGAN-GP double backward).  Works in float32 or float64
 (dtype follows the parameters).  Public tensors are NHWC; parameters are keyed by the reference's
 TF variable names with TF layouts (conv HWIO, fc [in, out]).

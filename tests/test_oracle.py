@@ -1,6 +1,7 @@
 """Pins the oracle: float64 NumPy restatement <-> torch-CPU restatement, plus the analytic
-known-answer tests of SURVEY.md Appendix B.  (The reference holds no golden vectors for this path
-and cannot run here -- parity is otherwise unpinned; see oracle/__init__.py.)"""
+known-answer tests of SURVEY.md Appendix B.  (These cover the TensorFlow-op level, which no
+TensorFlow run pins here; the composition is pinned against the reference's own code by tests/test_golden.py --
+see oracle/__init__.py.)"""
 import math
 
 import numpy as np
