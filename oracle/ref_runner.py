@@ -126,3 +126,32 @@ def term_name(ref_name):
   if ref_name.startswith('l_cyc_'):
     return ref_name
   return ref_name[:-2] + '_t' if ref_name.endswith('_1') else ref_name + '_s'
+
+
+def run_stage_driver(start_hw, max_hw, hw_to_batch_size, num_images_per_resolution, train_dir='run'):
+  """Executes pggan_runner.main (/root/reference/pggan_runner.py:82-160) with an empty train_dir and a recording
+  stand-in for the per-stage program, and returns the flags it sets for every stage, in order."""
+  import os
+  tf = loader.install()
+  import pggan_runner as ref
+  F = tf.flags.FLAGS
+  F.start_hw, F.max_hw, F.hw_to_batch_size = start_hw, max_hw, repr(dict(hw_to_batch_size))
+  F.num_images_per_resolution, F.train_dir, F.is_training, F.do_export = num_images_per_resolution, train_dir, True, False
+  stages = []
+
+  class Recorder(object):
+    def main(self):
+      stages.append(dict(name=os.path.relpath(F.train_dir, train_dir), hw=int(F.train_image_size),
+                         is_growing=bool(F.is_growing), batch_size=int(F.batch_size),
+                         max_number_of_steps=int(F.max_number_of_steps),
+                         ignore_missing_vars=bool(F.ignore_missing_vars),
+                         checkpoint_path=(os.path.relpath(F.checkpoint_path, train_dir)
+                                          if 'checkpoint_path' in F and F.checkpoint_path else None)))
+  saved = ref.select_program
+  ref.select_program = lambda name: Recorder()
+  try:
+    F.checkpoint_path = None
+    ref.main(None)
+  finally:
+    ref.select_program = saved
+  return stages

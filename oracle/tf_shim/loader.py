@@ -22,7 +22,7 @@ from .core import Dimension
 
 REAL = ('nets', 'nets.pggan', 'nets.pggan_utils', 'libs', 'libs.ops', 'libs.batch_norm', 'libs.instance_norm',
         'libs.sn', 'libs.self_attention', 'libs.gdrop', 'util_misc', 'twingan', 'image_generation', 'model',
-        'model.model_inheritor')
+        'model.model_inheritor', 'pggan_runner')
 STUBS = ('datasets', 'preprocessing', 'deployment', 'util_io', 'nets.cyclegan', 'nets.cyclegan_dis',
          'nets.nets_factory', 'PIL', 'scipy.misc')
 
@@ -52,11 +52,14 @@ class _Py2Div(ast.NodeTransformer):
     return node
 
 
-def _to_py3(src, path):
+def _to_py3(src, path, top_level):
   with warnings.catch_warnings():
     warnings.simplefilter('ignore')
     from lib2to3 import refactor
-    tool = refactor.RefactoringTool(refactor.get_fixers_from_package('lib2to3.fixes'))
+    fixers = refactor.get_fixers_from_package('lib2to3.fixes')
+    if top_level:      # a sibling `import x` of a top-level script is already absolute
+      fixers = [f for f in fixers if f != 'lib2to3.fixes.fix_import']
+    tool = refactor.RefactoringTool(fixers)
     return str(tool.refactor_string(src if src.endswith('\n') else src + '\n', path))
 
 
@@ -92,7 +95,7 @@ class _ReferenceFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
     path = module.__spec__.origin
     with open(path) as fh:
       src = fh.read()
-    src3 = _to_py3(src, path)
+    src3 = _to_py3(src, path, '.' not in module.__name__)
     tree = ast.parse(src3, path)
     future_div = any(isinstance(n, ast.ImportFrom) and n.module == '__future__' and
                      any(a.name == 'division' for a in n.names) for n in tree.body)

@@ -842,7 +842,8 @@ def build_modules():
                    get_regularization_losses=lambda scope=None: core.get_collection(
                      core.GraphKeys.REGULARIZATION_LOSSES, scope))
   train = _module('tensorflow.train', get_global_step=get_global_step,
-                  get_or_create_global_step=get_or_create_global_step, piecewise_constant=piecewise_constant)
+                  get_or_create_global_step=get_or_create_global_step, piecewise_constant=piecewise_constant,
+                  latest_checkpoint=lambda checkpoint_dir, latest_filename=None: None)
   app = _module('tensorflow.app', flags=core.flags)
 
   conv2d = layers_convolution

@@ -166,6 +166,28 @@ def test_stage_schedule_matches_pggan_runner():
   assert alpha_grow(0, 100) == 0.0 and alpha_grow(50, 100) == 0.5
 
 
+def test_stage_schedule_matches_what_pggan_runner_sets():
+  """tests/golden/stage_driver.json = the per-stage flags pggan_runner.main itself set when it was executed by
+  oracle/ref_runner.run_stage_driver (tools/make_golden.py); where /root/reference is mounted it is run again."""
+  import json
+  import os
+  from twingan_amd.runner import stage_schedule
+  with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'stage_driver.json')) as fh:
+    cases = json.load(fh)
+  assert len(cases) >= 3
+  for c in cases:
+    table = {int(k): v for k, v in c['hw_to_batch_size'].items()}
+    mine = stage_schedule(c['start_hw'], c['max_hw'], table, c['num_images_per_resolution'])
+    ref = c['stages']
+    assert [(s['name'], s['hw'], s['is_growing'], s['batch_size'], s['max_number_of_steps']) for s in ref] == mine
+    # warm start: every stage restores from the previous one, ignoring missing variables exactly when growing
+    assert [s['checkpoint_path'] for s in ref] == [None] + [s['name'] for s in ref[:-1]]
+    assert all(s['ignore_missing_vars'] == s['is_growing'] for s in ref)
+    if os.path.isdir('/root/reference'):
+      from oracle import ref_runner
+      assert ref_runner.run_stage_driver(c['start_hw'], c['max_hw'], table, c['num_images_per_resolution']) == ref
+
+
 def test_warm_start_ignores_missing_and_reshaped_vars():
   """ignore_missing_vars semantics (pggan_runner.py:136-146): shared blocks are copied, the new resolution's layers
   (and the from_rgb / to_rgb of the new size) keep their fresh initialisation."""

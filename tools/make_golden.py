@@ -180,6 +180,17 @@ def main():
     print(name)
     kw = dict(kw)
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **model(kw.pop('hw'), kw.pop('max_ch'), batch, **kw))
+  # the progressive-growing stage driver (pggan_runner.py:82-160), executed the same way
+  import json
+  from oracle import ref_runner
+  drv = []
+  for args in ((4, 32, {4: 16, 8: 16, 16: 8, 32: 8}, 300000),
+               (4, 256, {4: 16, 8: 16, 16: 16, 32: 16, 64: 12, 128: 12, 256: 12, 512: 6}, 300000),
+               (8, 64, {8: 8, 16: 8, 32: 8, 64: 3}, 1000)):
+    drv.append(dict(start_hw=args[0], max_hw=args[1], hw_to_batch_size={str(k): v for k, v in args[2].items()},
+                    num_images_per_resolution=args[3], stages=ref_runner.run_stage_driver(*args)))
+  with open(os.path.join(OUT, 'stage_driver.json'), 'w') as fh:
+    json.dump(drv, fh, indent=1)
   for f in sorted(os.listdir(OUT)):
     print(f, os.path.getsize(os.path.join(OUT, f)))
 
