@@ -155,3 +155,74 @@ def run_stage_driver(start_hw, max_hw, hw_to_batch_size, num_images_per_resoluti
   finally:
     ref.select_program = saved
   return stages
+
+
+def run_clones(flags, batches, global_step=0, seed=0, preset=None):
+  """Data-parallel clones as the reference builds them (model/model_inheritor.py:1006-1045 -> deployment/
+  model_deploy.py): create_clones() calls GanModel._clone_fn once per clone (variables shared, one dequeued batch
+  each), optimize_clones() divides every clone's loss by num_clones and sums the per-variable gradients with
+  tf.add_n.  batches: [(sources, targets)] per clone.  Returns per-clone loss terms and random draws, the two total
+  losses and the summed gradients."""
+  tf = loader.install()
+  import twingan as ref
+  from deployment import model_deploy
+  F = tf.flags.FLAGS
+  if not hasattr(run, '_defaults'):
+    run._defaults = F.flag_values_dict()
+  for k, v in run._defaults.items():
+    setattr(F, k, v)
+  for k, v in dict(BASE_FLAGS, **flags).items():
+    setattr(F, k, v)
+  core.STATE.reset(seed)
+  core.STATE.preset = dict(preset or {})
+  tfapi._ARG_STACK[:] = [{}]
+  gs = tfapi.get_or_create_global_step()
+  gs.t.fill_(int(global_step))
+
+  class Queue(object):      # the prefetch queue of model_inheritor.py:1033-1034: one batch per dequeue()
+    def __init__(self):
+      self.i = 0
+
+    def dequeue(self):
+      s, t = batches[self.i]
+      self.i += 1
+      return [core.Tensor(torch.tensor(np.asarray(a, np.float64), requires_grad=True), core.float32) for a in (s, t)]
+
+  config = model_deploy.DeploymentConfig(num_clones=len(batches))
+  networks = ref.GanModel._select_network(None)
+  marks = [0]
+
+  def model_fn(*a, **k):
+    out = ref.GanModel._clone_fn(*a, **k)
+    marks.append(len(core.STATE.random_log))
+    return out
+  clones = model_deploy.create_clones(config, model_fn, args=[networks, Queue(), ['a_source', 'b_source']],
+                                      kwargs=dict(is_training=True, global_step=gs))
+  names = [k for k, v in core.STATE.variables.items() if v.trainable]
+  model = ref.GanModel.__new__(ref.GanModel)      # the variable selection of image_generation.py:487-501
+  var_lists = dict(g=model._get_generator_variables_to_train(), d=model._get_discriminator_variables_to_train())
+  model._check_trainable_vars(var_lists['g'], var_lists['d'])
+  res = dict(trainable=names, variables={k: v.t.detach().numpy().copy() for k, v in core.STATE.variables.items()},
+             clones=[])
+  for i, clone in enumerate(clones):
+    terms = {}
+    for grp, coll in (('g', ref.GENERATOR_LOSS_COLLECTION), ('d', ref.DISCRIMINATOR_LOSS_COLLECTION)):
+      out = {}
+      for l in core.get_collection(coll, clone.scope):
+        name = l.name[len(clone.scope):-len('/value:0')]
+        k, n = name, 0
+        while k in out:
+          n += 1
+          k = '%s_%d' % (name, n)
+        out[k] = float(l.t)
+      terms[grp] = out
+    res['clones'].append(dict(scope=clone.scope, g_terms=terms['g'], d_terms=terms['d'],
+                              random=[(n, t.numpy().copy()) for n, t in
+                                      core.STATE.random_log[marks[i]:marks[i + 1]]]))
+  opt = tfapi.Optimizer()
+  for grp, coll in (('g', ref.GENERATOR_LOSS_COLLECTION), ('d', ref.DISCRIMINATOR_LOSS_COLLECTION)):
+    total, gv = model_deploy.optimize_clones(clones, opt, gradient_scale=1.0, loss_collection=coll,
+                                             var_list=var_lists[grp])
+    res[grp + '_loss'] = float(total.t)
+    res[grp + '_grads'] = {v.op.name: g.t.detach().numpy().copy() for g, v in gv}
+  return res

@@ -385,6 +385,7 @@ class State(object):
     self.gen = torch.Generator().manual_seed(seed)
     self.random_log = []                # (op name, torch tensor) of every random op, in call order
     self.global_step = None
+    self.name_scope = ''
     self.preset = {}                    # full variable name -> numpy value used instead of the initializer
     self.deferred = []                  # assign ops waiting for run_update_ops()
     self.eager_updates = False          # True: assign ops run where they are created (see tfapi._Assign.schedule)
@@ -447,7 +448,21 @@ def get_variable_scope():
 
 @contextlib.contextmanager
 def name_scope(name=None, default_name=None, values=None):
-  yield (name or default_name or '')
+  """Only what the hot path needs of tf.name_scope: a prefix for the names of loss tensors (so that
+  tf.get_collection(collection, clone.scope) can pick one clone's losses, deployment/model_deploy.py:258) and the
+  'scope/' string it yields.  A name ending in '/' re-enters that scope verbatim."""
+  name = name or default_name or ''
+  if name.endswith('/'):
+    full = name
+  elif name:
+    full = STATE.name_scope + name + '/'
+  else:
+    full = STATE.name_scope
+  saved, STATE.name_scope = STATE.name_scope, full
+  try:
+    yield full
+  finally:
+    STATE.name_scope = saved
 
 
 def get_variable(name, shape=None, dtype=None, initializer=None, regularizer=None, trainable=True, collections=None,

@@ -22,8 +22,8 @@ from .core import Dimension
 
 REAL = ('nets', 'nets.pggan', 'nets.pggan_utils', 'libs', 'libs.ops', 'libs.batch_norm', 'libs.instance_norm',
         'libs.sn', 'libs.self_attention', 'libs.gdrop', 'util_misc', 'twingan', 'image_generation', 'model',
-        'model.model_inheritor', 'pggan_runner')
-STUBS = ('datasets', 'preprocessing', 'deployment', 'util_io', 'nets.cyclegan', 'nets.cyclegan_dis',
+        'model.model_inheritor', 'pggan_runner', 'deployment', 'deployment.model_deploy')
+STUBS = ('datasets', 'preprocessing', 'util_io', 'nets.cyclegan', 'nets.cyclegan_dis',
          'nets.nets_factory', 'PIL', 'scipy.misc')
 
 

@@ -463,7 +463,7 @@ def compute_weighted_loss(losses, weights=1.0, scope=None, loss_collection='loss
   present = (w != 0).to(F64).sum()
   total = (l * w).sum()
   loss = torch.where(present > 0, total / torch.clamp(present, min=1.0), torch.zeros_like(total))
-  out = Tensor(loss, float32, (scope or 'weighted_loss') + '/value')
+  out = Tensor(loss, float32, STATE.name_scope + (scope or 'weighted_loss') + '/value')
   if loss_collection:
     core.add_to_collection(loss_collection, out)
   return out
@@ -513,6 +513,19 @@ def piecewise_constant(x, boundaries, values, name=None):
   return Tensor(torch.tensor(float(values[-1]), dtype=F64), float32, name)
 
 
+class Optimizer(object):
+  """tf.train.Optimizer.compute_gradients only (what deployment/model_deploy.py:302-306 calls): d loss / d var for
+  every variable of var_list (default: the trainable variables), None where the loss does not depend on it."""
+
+  def __init__(self, *args, **kwargs):
+    self.args, self.kwargs = args, kwargs
+
+  def compute_gradients(self, loss, var_list=None, **unused):
+    var_list = list(var_list) if var_list is not None else core.get_collection(core.GraphKeys.TRAINABLE_VARIABLES)
+    gs = torch.autograd.grad(raw(loss), [v.t for v in var_list], allow_unused=True, retain_graph=True)
+    return [(None if g is None else Tensor(g, v.dtype, v.op.name + '/grad'), v) for g, v in zip(gs, var_list)]
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # contrib.framework: arg_scope
 # ------------------------------------------------------------------------------------------------------------------
@@ -560,6 +573,7 @@ def has_arg_scope(func):
   return hasattr(func, '_key_op')
 
 
+@add_arg_scope
 def model_variable(name, shape=None, dtype=float32, initializer=None, regularizer=None, trainable=True,
                    collections=None, caching_device=None, device=None, partitioner=None, custom_getter=None,
                    use_resource=None):
@@ -567,6 +581,7 @@ def model_variable(name, shape=None, dtype=float32, initializer=None, regularize
   return core.get_variable(name, shape, dtype, initializer, regularizer, trainable, collections)
 
 
+@add_arg_scope
 def contrib_variable(name, shape=None, dtype=float32, initializer=None, regularizer=None, trainable=True,
                      collections=None, **unused):
   return core.get_variable(name, shape, dtype, initializer, regularizer, trainable, collections)
@@ -843,7 +858,8 @@ def build_modules():
                      core.GraphKeys.REGULARIZATION_LOSSES, scope))
   train = _module('tensorflow.train', get_global_step=get_global_step,
                   get_or_create_global_step=get_or_create_global_step, piecewise_constant=piecewise_constant,
-                  latest_checkpoint=lambda checkpoint_dir, latest_filename=None: None)
+                  latest_checkpoint=lambda checkpoint_dir, latest_filename=None: None,
+                  Optimizer=Optimizer, GradientDescentOptimizer=Optimizer, AdamOptimizer=Optimizer)
   app = _module('tensorflow.app', flags=core.flags)
 
   conv2d = layers_convolution
@@ -887,7 +903,7 @@ def build_modules():
   slim = _module('tensorflow.contrib.slim', arg_scope=arg_scope, add_arg_scope=add_arg_scope, conv2d=conv2d,
                  fully_connected=fully_connected, model_variable=model_variable,
                  get_or_create_global_step=get_or_create_global_step, l2_regularizer=l2_regularizer,
-                 get_variables=framework.get_variables, get_model_variables=framework.get_model_variables)
+                 variable=contrib_variable, get_variables=framework.get_variables, get_model_variables=framework.get_model_variables)
   contrib = _module('tensorflow.contrib', layers=contrib_layers, framework=framework, slim=slim)
 
   py_fw_ops = _module('tensorflow.python.framework.ops', convert_to_tensor=convert_to_tensor,

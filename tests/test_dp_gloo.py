@@ -1,6 +1,8 @@
 """world_size-2 data-parallel checks on CPU (gloo): the clone reduction of
 deployment/model_deploy.py:242-315,473-503 as implemented by twingan_amd/dp.py over the flat gradient
-buffers of twingan_amd/params.py.  The oracle supplies each clone's gradients (checker only)."""
+buffers of twingan_amd/params.py.  The oracle supplies each clone's gradients (checker only); the expected result
+is the REFERENCE's: tests/golden/clones2_hw16_c8.npz holds what model_deploy.create_clones / optimize_clones produced
+for two clones of GanModel._clone_fn (oracle/ref_runner.run_clones, tools/make_golden.py)."""
 import os
 import socket
 
@@ -18,20 +20,26 @@ def _free_port():
   return p
 
 
-def _clone_grads(rank, world, hw=16, max_ch=8, batch=2):
-  """fp64 oracle gradients of clone ``rank``'s D loss, already scaled by 1/world."""
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'clones2_hw16_c8.npz')
+
+
+def _clone_grads(rank, world, hw=16, max_ch=8):
+  """fp64 oracle gradients of clone ``rank``'s D loss on the fixture's batch for that clone, scaled by the factor
+  the product applies to a clone's loss (loss_scale_for_clones)."""
+  import numpy as np
   from oracle import torch_ref as R
+  from twingan_amd.dp import loss_scale_for_clones
+  g = np.load(GOLD)
   rcfg = R.Config(hw=hw, max_ch=max_ch)
-  P = R.init_params(rcfg, seed=0, dtype=torch.float64, std='he')
-  g = torch.Generator().manual_seed(100 + rank)
-  s = torch.rand(batch, hw, hw, 3, generator=g, dtype=torch.float64)
-  t = torch.rand(batch, hw, hw, 3, generator=g, dtype=torch.float64)
-  a = torch.rand(batch, 1, 1, 1, generator=g, dtype=torch.float64)
+  P = {k[len('param/'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith('param/')}
+  s, t = torch.from_numpy(g['clone%d/sources' % rank]), torch.from_numpy(g['clone%d/targets' % rank])
+  a_s = torch.from_numpy(g['clone%d/gp_alpha_s' % rank]).reshape(-1, 1, 1, 1)
+  a_t = torch.from_numpy(g['clone%d/gp_alpha_t' % rank]).reshape(-1, 1, 1, 1)
   names = R.discriminator_var_names(P)
   for k in names:
     P[k].requires_grad_(True)
-  loss, _ = R.discriminator_loss(P, s, t, rcfg, a, a)
-  grads = torch.autograd.grad(loss / world, [P[k] for k in names])
+  loss, _ = R.discriminator_loss(P, s, t, rcfg, a_s, a_t)
+  grads = torch.autograd.grad(loss * loss_scale_for_clones(1.0, world), [P[k] for k in names])
   return dict(zip(names, grads))
 
 
@@ -75,13 +83,14 @@ def test_grad_reducer_sums_clone_gradients_world2():
   for p in procs:
     p.join(timeout=300)
     assert p.exitcode == 0
-  # expected: sum over clones of grad(loss_r / world) == grad of the mean clone loss
-  g0, g1 = _clone_grads(0, world), _clone_grads(1, world)
-  assert set(got) == set(g0)
-  for k in g0:
-    want = (g0[k] + g1[k]).numpy()
-    err = abs(got[k] - want).max()
-    assert err <= 1e-6 * max(1.0, abs(want).max()), (k, err)
+  # expected: what the reference's optimize_clones returned for these two clones (tf.add_n of grad(loss_r / 2))
+  import numpy as np
+  ref = np.load(GOLD)
+  want = {k[len('grad_d/'):]: ref[k] for k in ref.files if k.startswith('grad_d/')}
+  assert set(got) == set(want)
+  for k in want:
+    err = abs(got[k] - want[k]).max()
+    assert err <= 1e-6 * max(1.0, abs(want[k]).max()), (k, err)      # the product's buffers are fp32
 
 
 def test_bucket_bounds_cover_buffer():

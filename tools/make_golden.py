@@ -156,6 +156,49 @@ def model(hw, max_ch, batch, growing=False, alpha=0.0, seed=0, **extra):
   return d
 
 
+def clones(hw, max_ch, batch, n, seed=0):
+  """Data-parallel fixture: n clones built by deployment/model_deploy.create_clones around GanModel._clone_fn, losses
+  divided by n and gradients summed by optimize_clones (oracle/ref_runner.run_clones)."""
+  from oracle import ref_runner
+  cfg = R.Config(hw=hw, max_ch=max_ch)
+  P = {k: v.float().double() for k, v in R.init_params(cfg, seed=seed, dtype=torch.float64, std='he').items()}
+  g = torch.Generator().manual_seed(4321)
+  batches = [(torch.rand(batch, hw, hw, 3, generator=g).double(), torch.rand(batch, hw, hw, 3, generator=g).double())
+             for _ in range(n)]
+  ref = ref_runner.run_clones(ref_runner.flags_of(cfg), [(s.numpy(), t.numpy()) for s, t in batches], seed=seed,
+                              preset={k: v.numpy() for k, v in P.items()})
+  d = {'param/' + k: v.numpy() for k, v in P.items()}
+  d['loss/g_total'], d['loss/d_total'] = np.array(ref['g_loss']), np.array(ref['d_loss'])
+  gnames, dnames = R.generator_var_names(P), R.discriminator_var_names(P)
+  assert set(ref['g_grads']) == set(gnames) and set(ref['d_grads']) == set(dnames)      # image_generation.py:487-501
+  for k in gnames:
+    d['grad_g/' + k] = ref['g_grads'][k]
+  for k in dnames:
+    d['grad_d/' + k] = ref['d_grads'][k]
+  for v in P.values():
+    v.requires_grad_(True)
+  worst, tot = 0.0, dict(g=0.0, d=0.0)
+  acc = {k: 0.0 for k in P}
+  for i, ((s, t), c) in enumerate(zip(batches, ref['clones'])):
+    a = [x for nme, x in c['random'] if nme == 'alpha']
+    d['clone%d/sources' % i], d['clone%d/targets' % i] = s.numpy(), t.numpy()
+    d['clone%d/gp_alpha_s' % i], d['clone%d/gp_alpha_t' % i] = a[0].reshape(-1), a[1].reshape(-1)
+    gl, _ = R.generator_loss(P, s, t, cfg)
+    dl, _ = R.discriminator_loss(P, s, t, cfg, torch.from_numpy(a[0]), torch.from_numpy(a[1]))
+    tot['g'] += float(gl) / n
+    tot['d'] += float(dl) / n
+    for k, v in list(R.grads_of(gl / n, P, gnames).items()) + list(R.grads_of(dl / n, P, dnames).items()):
+      acc[k] = acc[k] + v
+  worst = max(abs(tot['g'] - ref['g_loss']), abs(tot['d'] - ref['d_loss']))
+  for k in gnames:
+    worst = max(worst, float(np.abs(acc[k].numpy() - d['grad_g/' + k]).max()))
+  for k in dnames:
+    worst = max(worst, float(np.abs(acc[k].numpy() - d['grad_d/' + k]).max()))
+  assert worst < 1e-9, worst
+  print('  %d clones, oracle vs reference (model_deploy): max deviation %.1e' % (n, worst))
+  return d
+
+
 CASES = {      # fixture name -> (batch, oracle Config fields); tests/test_golden.py::MODELS mirrors the Config fields
   # 16x16 (no cycle-GAN term, twingan.py:466) and 64x64 at 8 channels (cycle-GAN term on), plus a growing stage
   'twingan_hw16_c8': (2, dict(hw=16, max_ch=8)),
@@ -180,6 +223,7 @@ def main():
     print(name)
     kw = dict(kw)
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **model(kw.pop('hw'), kw.pop('max_ch'), batch, **kw))
+  np.savez_compressed(os.path.join(OUT, 'clones2_hw16_c8.npz'), **clones(16, 8, 2, 2))
   # the progressive-growing stage driver (pggan_runner.py:82-160), executed the same way
   import json
   from oracle import ref_runner
