@@ -151,7 +151,8 @@ def test_step_schedule_counters():
   tr.d_step = lambda s, t, a=None, b=None: calls.append('d')
   for _ in range(5):
     tr.run(None, None)
-  assert calls == ['g', 'd', 'g', 'd', 'g'] and tr.global_step == 3 and tr.n_critic_counter == 5
+  # global_step advances at the end of the run that completes a cycle (see Trainer._advance_counters)
+  assert calls == ['g', 'd', 'g', 'd', 'g'] and tr.global_step == 2 and tr.n_critic_counter == 5
 
 
 def test_stage_schedule_matches_pggan_runner():

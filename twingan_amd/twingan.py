@@ -274,7 +274,7 @@ class Trainer:
     self.store = declare_twingan(ParamStore(self.device), cfg).build(seed)
     self.P = self.store.P
     self.n_critic_counter = 0       # image_generation.py:622-623
-    self.global_step = 0            # advanced on G runs only (image_generation.py:648-652)
+    self.global_step = 0            # advanced once per n_critic cycle, see _advance_counters
     self.adam_t = 0                 # one shared optimizer: beta powers advance on every apply (:554-561)
     self._adam_step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
     self._lr_t_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
@@ -361,10 +361,9 @@ class Trainer:
       for _ in range(2 * self.cfg.n_critic):      # whole n_critic cycles, so the caller's G/D phase is unchanged
         if self.n_critic_counter % self.cfg.n_critic == 0:
           self.g_step(st['s'], st['t'])
-          self.global_step += 1
         else:
           self.d_step(st['s'], st['t'])
-        self.n_critic_counter += 1
+        self._advance_counters()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize(self.device)
     graphs, outs = {}, {}
@@ -420,10 +419,18 @@ class Trainer:
       out = self.g_step(sources, targets)
     else:
       out = self.d_step(sources, targets, gp_alpha_s, gp_alpha_t)
-    if is_g:
-      self.global_step += 1
-    self.n_critic_counter += 1
+    self._advance_counters()
     return out
+
+  def _advance_counters(self):
+    """image_generation.py:640-652: apply_gradients(global_step=n_critic_counter) adds 1 to the counter; the
+    predicate of `increase_global_step` is built under control_dependencies([grad_updates]) and reads the counter
+    through its (non-resource, hence live) variable value, i.e. AFTER that increment: global_step advances at the end
+    of the run that completes an n_critic cycle -- with n_critic = 2, at the end of every discriminator run, so both
+    runs of a G+D pair see the same global step (alpha_grow, renorm clipping)."""
+    self.n_critic_counter += 1
+    if self.n_critic_counter % self.cfg.n_critic == 0:
+      self.global_step += 1
 
   def _set_renorm_clipping(self):
     """get_renorm_clipping_params (nets/pggan_utils.py:40-50,207-223): rmax / rmin / dmax are piecewise constant in the
