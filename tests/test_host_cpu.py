@@ -141,6 +141,37 @@ def test_param_schema_matches_oracle(hw, max_ch, growing):
     assert base.data_ptr() <= store[k].grad.data_ptr() < base.data_ptr() + base.numel() * 4
 
 
+def test_variables_match_what_the_reference_creates():
+  """tests/golden/variable_schema.json: the variables twingan.GanModel._clone_fn created when the reference's own code
+  was executed (oracle/ref_runner.py, tools/make_golden.py) at full width -- names, shapes, trainable or not, and the
+  mean / std of what its initialisers drew.  The product must declare exactly those."""
+  import json
+  import os
+  from twingan_amd import Config
+  from twingan_amd.params import ParamStore, declare_twingan
+  from test_golden import PRODUCT_FIELD
+  with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'variable_schema.json')) as fh:
+    schema = json.load(fh)
+  assert len(schema) >= 4
+  for name, case in schema.items():
+    cfg = Config(**{PRODUCT_FIELD.get(k, k): v for k, v in case['config'].items()})
+    store = declare_twingan(ParamStore('cpu'), cfg).build(seed=0)
+    ref = case['variables']
+    train = {k: tuple(store.specs[k]['shape']) for k in store.specs}
+    state = {k: tuple(v.shape) for k, v in store.state.items() if not k.startswith('renorm/')}      # device scalars
+    assert train == {k: tuple(v['shape']) for k, v in ref.items() if v['trainable']}, name
+    want_state = {k: tuple(v['shape']) or (1,) for k, v in ref.items() if not v['trainable']}
+    assert {k: (v or (1,)) for k, v in state.items()} == want_state, name
+    sd = store.state_dict(include_state=True)
+    for k, v in ref.items():
+      got = sd[k].double()
+      if v['std'] == 0.0:                       # constant initialisers: zeros / ones
+        assert float((got - v['mean']).abs().max()) == 0.0, (name, k)
+      elif got.numel() >= 4096:                 # random initialisers: same distribution
+        assert abs(float(got.std()) - v['std']) < 0.08 * v['std'], (name, k, float(got.std()), v['std'])
+        assert abs(float(got.mean()) - v['mean']) < 0.1 * v['std'], (name, k)
+
+
 def test_step_schedule_counters():
   """n_critic alternation and counters (image_generation.py:640-652) without touching the GPU."""
   from twingan_amd import Config

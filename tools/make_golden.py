@@ -216,6 +216,15 @@ CASES = {      # fixture name -> (batch, oracle Config fields); tests/test_golde
 }
 
 
+SCHEMAS = {      # full-width configurations of BASELINE.json, run once through the reference just for its variables
+  'hw256_c256': dict(hw=256, max_ch=256),
+  'hw128_c256_growing': dict(hw=128, max_ch=256, is_growing=True, alpha_grow=0.5),
+  'hw64_c256_sn_att_bn': dict(hw=64, max_ch=256, norm='batch_renorm', spectral_norm=True, do_self_attention=True,
+                              self_attention_hw=32),
+  'hw32_c128_eqlr_res': dict(hw=32, max_ch=128, equalized=True, res_block=True),
+}
+
+
 def main():
   os.makedirs(OUT, exist_ok=True)
   np.savez_compressed(os.path.join(OUT, 'primitives.npz'), **primitives())
@@ -224,9 +233,22 @@ def main():
     kw = dict(kw)
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **model(kw.pop('hw'), kw.pop('max_ch'), batch, **kw))
   np.savez_compressed(os.path.join(OUT, 'clones2_hw16_c8.npz'), **clones(16, 8, 2, 2))
-  # the progressive-growing stage driver (pggan_runner.py:82-160), executed the same way
+  # the variables the reference creates at full width, with what its initialisers drew (names, shapes, statistics)
   import json
   from oracle import ref_runner
+  schema = {}
+  for name, kw in SCHEMAS.items():
+    cfg = R.Config(**kw)
+    r = np.random.RandomState(0)
+    ref = ref_runner.run(ref_runner.flags_of(cfg), r.rand(1, cfg.hw, cfg.hw, 3), r.rand(1, cfg.hw, cfg.hw, 3),
+                         global_step=ref_runner.global_step_of(cfg), want_grads=False)
+    schema[name] = dict(config=kw, variables={
+      k: dict(shape=list(v.shape), trainable=k in ref['trainable'], mean=float(v.mean()), std=float(v.std()))
+      for k, v in ref['variables'].items() if k != 'global_step'})
+    print('schema', name, len(schema[name]['variables']), 'variables')
+  with open(os.path.join(OUT, 'variable_schema.json'), 'w') as fh:
+    json.dump(schema, fh, indent=0, sort_keys=True)
+  # the progressive-growing stage driver (pggan_runner.py:82-160), executed the same way
   drv = []
   for args in ((4, 32, {4: 16, 8: 16, 16: 8, 32: 8}, 300000),
                (4, 256, {4: 16, 8: 16, 16: 16, 32: 16, 64: 12, 128: 12, 256: 12, 512: 6}, 300000),
