@@ -305,6 +305,67 @@ def test_full_size_properties_256_bf16():
     assert pred.shape == (2, 1) and bool(torch.isfinite(pred).all())
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_full_size_256_hits_the_reference(precision):
+  """BASELINE.json's headline configuration at FULL size (256x256, 256 channels, batch 2) against what the
+  reference's own code computed for it (tests/golden/full_hw256_c256.json, tools/make_golden.py --full: the graph of
+  twingan.GanModel._clone_fn executed on the TF stand-in): every loss term, probes of every generated image, and --
+  fp32 path -- the norm of every variable's gradient.  Weights and inputs are re-created from the fixture's seeds.
+  Tolerances: fp32 losses 2e-3 relative (to max(1, |x|)), image probes 5e-3 absolute, gradient norms 5 %
+  (10 % of the group's largest norm as the floor); bf16 losses 6e-2, probes 0.25 (8-bit mantissa through ~40 layers)."""
+  import json
+  import os
+  from twingan_amd import Config
+  from twingan_amd import twingan as T
+  with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'full_hw256_c256.json')) as fh:
+    fix = json.load(fh)
+  hw, batch = fix['config']['hw'], fix['batch']
+  rcfg = R.Config(**fix['config'])
+  P = R.init_params(rcfg, seed=fix['param_seed'], dtype=torch.float64, std='he')
+  cfg = Config(precision=precision, **fix['config'])
+  tr = T.Trainer(cfg, device='cuda:0', seed=0)
+  tr.store.load_state_dict({k: v.float() for k, v in P.items()})
+  del P
+  g = torch.Generator().manual_seed(fix['input_seed'])
+  adt = torch.bfloat16 if precision == 'bf16' else torch.float32
+  s = torch.rand(batch, hw, hw, 3, generator=g).to('cuda:0').to(adt)
+  t = torch.rand(batch, hw, hw, 3, generator=g).to('cuda:0').to(adt)
+  a_s = torch.tensor(fix['gp_alpha_s'], dtype=torch.float32, device='cuda:0')
+  a_t = torch.tensor(fix['gp_alpha_t'], dtype=torch.float32, device='cuda:0')
+  ltol, ptol = (2e-3, 5e-3) if precision == 'fp32' else (6e-2, 0.25)
+  step = hw // 4
+  with torch.no_grad():
+    o = T.forward_generators(tr.P, s, t, cfg)
+  for k in ('s_prime', 't_prime', 's_cycle', 't_cycle'):
+    want = torch.tensor(fix['probe'][k])
+    got = o[k][:, ::step, ::step, :].float().cpu()
+    assert float((got - want).abs().max()) < ptol, (k, float((got - want).abs().max()))
+  del o
+  for group, fn, args, terms_want, total in (
+      ('g', T.generator_loss, (s, t, cfg), fix['g_terms'], fix['g_total']),
+      ('d', T.discriminator_loss, (s, t, cfg, a_s, a_t), fix['d_terms'], fix['d_total'])):
+    tr.store.zero_grad(group)
+    tr._set_requires_grad(g=group == 'g', d=group == 'd')
+    loss, terms = fn(tr.P, *args)
+    assert set(terms) == set(terms_want), group
+    for k, v in terms.items():
+      assert abs(v.item() - terms_want[k]) < ltol * max(1.0, abs(terms_want[k])), (k, v.item(), terms_want[k])
+    assert abs(loss.item() - total) < ltol * max(1.0, abs(total)) * 2, (group, loss.item(), total)
+    if precision != 'fp32':
+      continue
+    loss.backward()
+    gd = tr.store.grad_dict()
+    names = tr.store.names(group)
+    floor = 0.1 * max(fix['grad_norm'][k] for k in names)
+    bad = []
+    for k in names:
+      got, want = float(gd[k].double().norm()), fix['grad_norm'][k]
+      if abs(got - want) > 0.05 * max(want, floor):
+        bad.append((k, got, want))
+    assert not bad, bad[:5]
+    del loss, terms, gd
+
+
 def _dp_worker(rank, world, port, q, use_graph):
   import os
   import torch.distributed as dist

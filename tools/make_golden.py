@@ -216,6 +216,38 @@ CASES = {      # fixture name -> (batch, oracle Config fields); tests/test_golde
 }
 
 
+def full_size(hw=256, max_ch=256, batch=2, seed=0):
+  """BASELINE.json's headline configuration (256x256, 256 channels) through the reference's own code, at full size.
+  The weights (71 MB) are not stored: they are `R.init_params(cfg, seed, float64, 'he')` rounded to fp32 and the inputs
+  come from a seeded generator, both re-created by the test; what is stored is what the reference computed -- every
+  loss term, the L2 norm of every variable's gradient, a probe of every generated image.  (Takes a few minutes and
+  ~20 GB: `python tools/make_golden.py --full`.)"""
+  from oracle import ref_runner
+  cfg = R.Config(hw=hw, max_ch=max_ch)
+  P = {k: v.float().double() for k, v in R.init_params(cfg, seed=seed, dtype=torch.float64, std='he').items()}
+  g = torch.Generator().manual_seed(1234)
+  s = torch.rand(batch, hw, hw, 3, generator=g).double()
+  t = torch.rand(batch, hw, hw, 3, generator=g).double()
+  ref = ref_runner.run(ref_runner.flags_of(cfg), s.numpy(), t.numpy(), seed=seed,
+                       preset={k: v.numpy() for k, v in P.items()})
+  assert set(ref['variables']) - {'global_step'} == set(P)
+  alphas = [v.reshape(-1).tolist() for n, v in ref['random'] if n == 'alpha']
+  out = dict(config=dict(hw=hw, max_ch=max_ch), batch=batch, param_seed=seed, input_seed=1234,
+             gp_alpha_s=alphas[0], gp_alpha_t=alphas[1], g_total=ref['g_loss'], d_total=ref['d_loss'],
+             g_terms={ref_runner.term_name(k): v for k, v in ref['g_terms'].items()},
+             d_terms={ref_runner.term_name(k): v for k, v in ref['d_terms'].items()})
+  gnames, dnames = R.generator_var_names(P), R.discriminator_var_names(P)
+  out['grad_norm'] = {k: float(np.linalg.norm(ref['g_grads'][k])) for k in gnames}
+  out['grad_norm'].update({k: float(np.linalg.norm(ref['d_grads'][k])) for k in dnames})
+  step = hw // 4
+  out['probe'] = {k: ref['end_points'][k + '_output'][:, ::step, ::step, :].tolist()
+                  for k in ('s_prime', 't_prime', 's_cycle', 't_cycle')}
+  out['probe']['d_real_s'] = ref['end_points']['discriminator_real_s_prediction'].reshape(-1).tolist()
+  out['probe']['d_t_prime'] = ref['end_points']['discriminator_t_prime_prediction'].reshape(-1).tolist()
+  out['probe']['es_abs_mean'] = float(np.abs(ref['end_points']['encoded_source_content_before_classification']).mean())
+  return out
+
+
 SCHEMAS = {      # full-width configurations of BASELINE.json, run once through the reference just for its variables
   'hw256_c256': dict(hw=256, max_ch=256),
   'hw128_c256_growing': dict(hw=128, max_ch=256, is_growing=True, alpha_grow=0.5),
@@ -262,4 +294,10 @@ def main():
 
 
 if __name__ == '__main__':
-  main()
+  if '--full' in sys.argv:      # only the full-size fixture (slow); the default run leaves it untouched
+    import json
+    with open(os.path.join(OUT, 'full_hw256_c256.json'), 'w') as fh:
+      json.dump(full_size(), fh, indent=0, sort_keys=True)
+    print('full_hw256_c256.json', os.path.getsize(os.path.join(OUT, 'full_hw256_c256.json')))
+  else:
+    main()
