@@ -311,8 +311,10 @@ def test_full_size_256_hits_the_reference(precision):
   reference's own code computed for it (tests/golden/full_hw256_c256.json, tools/make_golden.py --full: the graph of
   twingan.GanModel._clone_fn executed on the TF stand-in): every loss term, probes of every generated image, and --
   fp32 path -- the norm of every variable's gradient.  Weights and inputs are re-created from the fixture's seeds.
-  Tolerances: fp32 losses 2e-3 relative (to max(1, |x|)), image probes 5e-3 absolute, gradient norms 5 %
-  (10 % of the group's largest norm as the floor); bf16 losses 6e-2, probes 0.25 (8-bit mantissa through ~40 layers)."""
+  Measured (tools/full_size_report.py): fp32 path -- worst loss term 2.3e-6, worst probe 2.3e-5, gradient-norm ratios
+  0.9988..1.0015; bf16 path -- 7.5e-3, 0.17, ratios 0.75..1.18 with median 0.996.  Bounds: fp32 losses 2e-4 relative
+  (to max(1, |x|)), probes 1e-3, gradient norms 1 % (of max(norm, 1e-3 of the group's largest)); bf16 losses 3e-2,
+  probes 0.3, gradient-norm ratios 0.5..1.6 with the median within 3 %."""
   import json
   import os
   from twingan_amd import Config
@@ -332,7 +334,7 @@ def test_full_size_256_hits_the_reference(precision):
   t = torch.rand(batch, hw, hw, 3, generator=g).to('cuda:0').to(adt)
   a_s = torch.tensor(fix['gp_alpha_s'], dtype=torch.float32, device='cuda:0')
   a_t = torch.tensor(fix['gp_alpha_t'], dtype=torch.float32, device='cuda:0')
-  ltol, ptol = (2e-3, 5e-3) if precision == 'fp32' else (6e-2, 0.25)
+  ltol, ptol = (2e-4, 1e-3) if precision == 'fp32' else (3e-2, 0.3)
   step = hw // 4
   with torch.no_grad():
     o = T.forward_generators(tr.P, s, t, cfg)
@@ -351,17 +353,17 @@ def test_full_size_256_hits_the_reference(precision):
     for k, v in terms.items():
       assert abs(v.item() - terms_want[k]) < ltol * max(1.0, abs(terms_want[k])), (k, v.item(), terms_want[k])
     assert abs(loss.item() - total) < ltol * max(1.0, abs(total)) * 2, (group, loss.item(), total)
-    if precision != 'fp32':
-      continue
     loss.backward()
     gd = tr.store.grad_dict()
     names = tr.store.names(group)
-    floor = 0.1 * max(fix['grad_norm'][k] for k in names)
-    bad = []
-    for k in names:
-      got, want = float(gd[k].double().norm()), fix['grad_norm'][k]
-      if abs(got - want) > 0.05 * max(want, floor):
-        bad.append((k, got, want))
+    floor = 1e-3 * max(fix['grad_norm'][k] for k in names)
+    pairs = [(k, float(gd[k].double().norm()), fix['grad_norm'][k]) for k in names]
+    if precision == 'fp32':
+      bad = [p for p in pairs if abs(p[1] - p[2]) > 0.01 * max(p[2], floor)]
+    else:
+      ratios = [p[1] / p[2] for p in pairs if p[2] > floor]
+      bad = [p for p in pairs if p[2] > floor and not 0.5 < p[1] / p[2] < 1.6]
+      assert abs(float(np.median(ratios)) - 1.0) < 0.03, float(np.median(ratios))
     assert not bad, bad[:5]
     del loss, terms, gd
 
