@@ -226,3 +226,56 @@ def run_clones(flags, batches, global_step=0, seed=0, preset=None):
     res[grp + '_loss'] = float(total.t)
     res[grp + '_grads'] = {v.op.name: g.t.detach().numpy().copy() for g, v in gv}
   return res
+
+
+def run_training(flags, runs, seed=0, preset=None):
+  """`len(runs)` consecutive session.run(train_op) calls of the reference's training graph: clones
+  (model_deploy.create_clones around GanModel._clone_fn), learning rate and optimizer (model_inheritor.py:471-542),
+  and GanModel._add_optimization (image_generation.py:587-662: generator / discriminator gradients through
+  optimize_clones, the n_critic alternation under tf.cond, apply_gradients, the global-step increment).  The stand-in
+  is eager, so the graph is rebuilt for every run with all variables (incl. the optimizer's) reused, and every state
+  update executes where it is created -- the order the reference's control dependencies prescribe.
+  runs: [(sources, targets)].  Returns per-run losses / counters / random draws and the final variable values."""
+  tf = loader.install()
+  import twingan as ref
+  from deployment import model_deploy
+  F = tf.flags.FLAGS
+  if not hasattr(run, '_defaults'):
+    run._defaults = F.flag_values_dict()
+  for k, v in run._defaults.items():
+    setattr(F, k, v)
+  for k, v in dict(BASE_FLAGS, **flags).items():
+    setattr(F, k, v)
+  core.STATE.reset(seed)
+  core.STATE.preset = dict(preset or {})
+  core.STATE.eager_updates = True
+  gs = tfapi.get_or_create_global_step()
+  model = ref.GanModel.__new__(ref.GanModel)
+  networks = ref.GanModel._select_network(None)
+  config = model_deploy.DeploymentConfig(num_clones=1)
+  history = []
+  for i, (s, t) in enumerate(runs):
+    tfapi._ARG_STACK[:] = [{}]
+    core.STATE.scope_count = {}
+    core.STATE.scope_stack[0].reuse = True if i > 0 else None      # the same graph, built again
+    for k in list(core.STATE.collections):                       # per-run collections (losses, update ops ...)
+      if k not in ('variables', 'trainable_variables', 'model_variables'):
+        del core.STATE.collections[k]
+    mark = len(core.STATE.random_log)
+
+    class Queue(object):
+      def dequeue(self):
+        return [core.Tensor(torch.tensor(np.asarray(a, np.float64), requires_grad=True), core.float32) for a in (s, t)]
+    clones = model_deploy.create_clones(config, ref.GanModel._clone_fn, args=[networks, Queue(), ['a_source', 'b_source']],
+                                        kwargs=dict(is_training=True, global_step=gs))
+    update_ops = core.get_collection(core.GraphKeys.UPDATE_OPS, config.clone_scope(0))
+    before = dict(n_critic_counter=int(core.STATE.variables['n_critic_counter'].t) if i else 0, global_step=int(gs.t))
+    lr = model._configure_learning_rate(1000, gs)
+    optimizer = model._configure_optimizer(lr)
+    train = model._add_optimization(clones, optimizer, set(), update_ops, gs)
+    history.append(dict(
+      before, train_tensor=float(train.t), learning_rate=float(core.raw(lr)),
+      random=[(n, v.numpy().copy()) for n, v in core.STATE.random_log[mark:]],
+      n_critic_counter_after=int(core.STATE.variables['n_critic_counter'].t), global_step_after=int(gs.t)))
+  return dict(history=history,
+              variables={k: v.t.detach().numpy().copy() for k, v in core.STATE.variables.items()})

@@ -514,16 +514,82 @@ def piecewise_constant(x, boundaries, values, name=None):
 
 
 class Optimizer(object):
-  """tf.train.Optimizer.compute_gradients only (what deployment/model_deploy.py:302-306 calls): d loss / d var for
-  every variable of var_list (default: the trainable variables), None where the loss does not depend on it."""
+  """tf.train.Optimizer as the hot path uses it: compute_gradients (deployment/model_deploy.py:302-306) and
+  apply_gradients(grads_and_vars, global_step) (image_generation.py:550).  The base class is plain gradient descent."""
 
-  def __init__(self, *args, **kwargs):
-    self.args, self.kwargs = args, kwargs
+  def __init__(self, learning_rate=0.0, *args, **kwargs):
+    self._lr = learning_rate
 
   def compute_gradients(self, loss, var_list=None, **unused):
     var_list = list(var_list) if var_list is not None else core.get_collection(core.GraphKeys.TRAINABLE_VARIABLES)
     gs = torch.autograd.grad(raw(loss), [v.t for v in var_list], allow_unused=True, retain_graph=True)
     return [(None if g is None else Tensor(g, v.dtype, v.op.name + '/grad'), v) for g, v in zip(gs, var_list)]
+
+  def _slot(self, var, name, init):
+    """Optimizer state lives in the variable store (reference names: '<var>/Adam', '<var>/Adam_1', 'beta1_power',
+    'beta2_power'), so it persists when the graph is rebuilt for the next run."""
+    full = (var.op.name + '/' + name) if var is not None else name
+    if full not in STATE.variables:
+      STATE.variables[full] = Variable(full, init.detach().clone(), float32, False)
+    return STATE.variables[full]
+
+  def _apply(self, grad, var):
+    with torch.no_grad():
+      var.t.sub_(float(raw(self._lr)) * raw(grad).detach())
+
+  def _finish(self):
+    pass
+
+  def apply_gradients(self, grads_and_vars, global_step=None, name=None):
+    """Runs where it is created (program order): the update of every variable, the optimizer's own state, then
+    global_step += 1 -- the order tf.train.Optimizer.apply_gradients enforces with control dependencies."""
+    for g, v in grads_and_vars:
+      if g is not None:
+        self._apply(g, v)
+    self._finish()
+    if global_step is not None:
+      with torch.no_grad():
+        global_step.t.add_(1)
+    return Tensor(torch.tensor(True), bool_, name or 'apply_gradients')
+
+
+class AdamOptimizer(Optimizer):
+  """tf.train.AdamOptimizer (TF 1.8, training/adam.py): per variable m <- b1 m + (1-b1) g, v <- b2 v + (1-b2) g^2,
+  var <- var - lr_t m / (sqrt(v) + eps) with lr_t = lr sqrt(1 - b2^t) / (1 - b1^t); the powers b1^t, b2^t are ONE pair
+  of non-slot variables per optimizer object, multiplied by b1, b2 after each apply_gradients call."""
+
+  def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8, use_locking=False, name='Adam'):
+    Optimizer.__init__(self, learning_rate)
+    self._b1, self._b2, self._eps = float(beta1), float(beta2), float(epsilon)
+
+  def _powers(self):
+    return (self._slot(None, 'beta1_power', torch.tensor(self._b1, dtype=F64)),
+            self._slot(None, 'beta2_power', torch.tensor(self._b2, dtype=F64)))
+
+  def _apply(self, grad, var):
+    b1p, b2p = self._powers()
+    m = self._slot(var, 'Adam', torch.zeros_like(var.t))
+    v = self._slot(var, 'Adam_1', torch.zeros_like(var.t))
+    g = raw(grad).detach()
+    with torch.no_grad():
+      lr_t = float(raw(self._lr)) * torch.sqrt(1 - b2p.t) / (1 - b1p.t)
+      m.t.mul_(self._b1).add_((1 - self._b1) * g)
+      v.t.mul_(self._b2).add_((1 - self._b2) * g * g)
+      var.t.sub_(lr_t * m.t / (torch.sqrt(v.t) + self._eps))
+
+  def _finish(self):
+    b1p, b2p = self._powers()
+    with torch.no_grad():
+      b1p.t.mul_(self._b1)
+      b2p.t.mul_(self._b2)
+
+
+def floormod(x, y, name=None):
+  return wrap(torch.remainder(raw(x), raw(y)), x if isinstance(x, Tensor) else y)
+
+
+def global_norm(t_list, name=None):
+  return Tensor(torch.sqrt(sum((raw(t).detach() ** 2).sum() for t in t_list if t is not None)))
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -859,7 +925,7 @@ def build_modules():
   train = _module('tensorflow.train', get_global_step=get_global_step,
                   get_or_create_global_step=get_or_create_global_step, piecewise_constant=piecewise_constant,
                   latest_checkpoint=lambda checkpoint_dir, latest_filename=None: None,
-                  Optimizer=Optimizer, GradientDescentOptimizer=Optimizer, AdamOptimizer=Optimizer)
+                  Optimizer=Optimizer, GradientDescentOptimizer=Optimizer, AdamOptimizer=AdamOptimizer)
   app = _module('tensorflow.app', flags=core.flags)
 
   conv2d = layers_convolution
@@ -931,6 +997,7 @@ def build_modules():
     abs=abs_, add=add, subtract=subtract, multiply=multiply, divide=divide, div=divide, minimum=minimum,
     maximum=maximum, pow=pow_, add_n=add_n, clip_by_value=clip_by_value, where=where, equal=equal,
     not_equal=not_equal, greater=greater, less=less, greater_equal=greater_equal, less_equal=less_equal,
+    mod=floormod, floormod=floormod, global_norm=global_norm, IndexedSlices=type('IndexedSlices', (), {}),
     reduce_mean=reduce_mean, reduce_sum=reduce_sum, reduce_max=reduce_max, reduce_min=reduce_min, matmul=matmul,
     tensordot=tensordot, random_normal=random_normal, random_uniform=random_uniform,
     control_dependencies=control_dependencies, device=_null_context, assign=assign, assign_add=assign_add,

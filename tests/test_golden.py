@@ -180,6 +180,37 @@ def test_torch_oracle_fp32_reproduces_model_fixtures(name):
   assert (num / den) ** 0.5 < 3e-3      # fp32 round-off through the GP double backward (1e-3 at 64x64)
 
 
+def test_oracle_training_runs_match_the_reference():
+  """tests/golden/train4_hw16_c8.npz: four consecutive session.run(train_op) of the reference's training graph
+  (GanModel._add_optimization, image_generation.py:587-662, with Adam from the flags) -- the oracle's train_step must
+  leave every variable where the reference left it, and the product's host counters must move the same way."""
+  g = load('train4_hw16_c8')
+  cfg = R.Config(hw=16, max_ch=8, lr=float(g['meta/lr']), beta1=float(g['meta/beta1']), beta2=float(g['meta/beta2']),
+                 adam_eps=float(g['meta/eps']))
+  P = {k[len('param/'):]: torch.from_numpy(v).clone() for k, v in g.items() if k.startswith('param/')}      # updated in place
+  opt = R.AdamState(P, cfg)
+  from twingan_amd import Config
+  from twingan_amd.twingan import Trainer
+  tr = Trainer(Config(hw=8, max_ch=8), device='cpu')      # host-side counters only
+  tr.g_step = lambda s, t: None
+  tr.d_step = lambda s, t, a=None, b=None: None
+  for i in range(4):
+    before = (tr.n_critic_counter, tr.global_step)
+    tr.run(None, None)
+    assert list(g['run%d/counters' % i]) == [before[0], before[1], tr.n_critic_counter, tr.global_step], i
+    out = R.train_step(P, opt, torch.from_numpy(g['run%d/sources' % i]), torch.from_numpy(g['run%d/targets' % i]), cfg,
+                       torch.from_numpy(g['run%d/gp_alpha_s' % i]).reshape(-1, 1, 1, 1),
+                       torch.from_numpy(g['run%d/gp_alpha_t' % i]).reshape(-1, 1, 1, 1), i)
+    assert ('g_loss' in out) == (i % 2 == 0)                       # G apply on even runs, D apply on odd ones
+    if 'd_loss' in out:
+      assert abs(out['d_loss'] - float(g['run%d/d_loss' % i])) < 1e-9
+  for k, v in P.items():
+    assert np.abs(v.detach().numpy() - g['after/' + k]).max() < 1e-12, k
+  moved = max(np.abs(g['after/' + k] - g['param/' + k]).max() for k in P)
+  assert moved > 1e-3                                              # the runs really trained
+  assert abs(float(g['after_opt/beta1_power']) - cfg.beta1 ** 5) < 1e-15      # one shared pair of powers, 4 applies
+
+
 def test_cycle_gan_term_only_from_64():
   """twingan.py:466: the fixtures themselves encode the rule."""
   assert not any('cycle' in k for k in load('twingan_hw16_c8') if k.startswith('loss/d/'))
@@ -222,6 +253,36 @@ def test_gpu_primitives_hit_golden(dtype):
     assert abs(la.item() - float(g['l_abs'])) < 1e-6
     gp = ops.gradient_penalty(_dev(g['gp_g']), 10.0)
     assert abs(gp.item() - float(g['gp'])) < 1e-5 * float(g['gp'])
+
+
+@pytest.mark.gpu
+def test_gpu_training_runs_hit_the_reference():
+  """The HIP path (fp32, eager) through the four training runs of tests/golden/train4_hw16_c8.npz: same inputs and
+  alphas, Adam on the device; compares the UPDATE of every variable with the reference's (aggregate rel-L2 <= 5e-2,
+  median per variable <= 3e-2 -- Adam's first steps are sign-like, so a near-zero gradient may flip)."""
+  from twingan_amd import Config
+  from twingan_amd import twingan as T
+  g = load('train4_hw16_c8')
+  cfg = Config(hw=16, max_ch=8, precision='fp32', learning_rate=float(g['meta/lr']), adam_beta1=float(g['meta/beta1']),
+               adam_beta2=float(g['meta/beta2']), opt_epsilon=float(g['meta/eps']))
+  tr = T.Trainer(cfg, device='cuda:0', seed=0, use_graph=False)
+  tr.store.load_state_dict({k[len('param/'):]: torch.from_numpy(v).float() for k, v in g.items() if k.startswith('param/')})
+  for i in range(4):
+    tr.run(_dev(g['run%d/sources' % i]), _dev(g['run%d/targets' % i]), _dev(g['run%d/gp_alpha_s' % i]),
+           _dev(g['run%d/gp_alpha_t' % i]))
+    assert [tr.n_critic_counter, tr.global_step] == list(g['run%d/counters' % i][2:])
+  sd = tr.store.state_dict()
+  num = den = 0.0
+  per_var = []
+  for k in sd:
+    d_dev = sd[k].double().cpu().numpy() - g['param/' + k]
+    d_ref = g['after/' + k] - g['param/' + k]
+    num += float(((d_dev - d_ref) ** 2).sum())
+    den += float((d_ref ** 2).sum())
+    if np.abs(d_ref).max() > 0:
+      per_var.append(float(np.linalg.norm(d_dev - d_ref) / (np.linalg.norm(d_ref) + 1e-30)))
+  assert np.sqrt(num / den) < 5e-2, np.sqrt(num / den)
+  assert np.median(per_var) < 3e-2, np.median(per_var)
 
 
 @pytest.mark.gpu

@@ -216,6 +216,42 @@ CASES = {      # fixture name -> (batch, oracle Config fields); tests/test_golde
 }
 
 
+def training(hw=16, max_ch=8, batch=2, n_runs=4, seed=0):
+  """n_runs consecutive session.run(train_op) of the reference's training graph (oracle/ref_runner.run_training:
+  clones, Adam from the flags, GanModel._add_optimization with its n_critic alternation) from seeded weights: the
+  inputs / alphas of every run, the counters and losses it saw, and every variable afterwards."""
+  from oracle import ref_runner
+  cfg = R.Config(hw=hw, max_ch=max_ch, lr=1e-3)
+  P = {k: v.float().double() for k, v in R.init_params(cfg, seed=seed, dtype=torch.float64, std='he').items()}
+  g = torch.Generator().manual_seed(777)
+  runs = [(torch.rand(batch, hw, hw, 3, generator=g).double(), torch.rand(batch, hw, hw, 3, generator=g).double())
+          for _ in range(n_runs)]
+  flags = dict(ref_runner.flags_of(cfg), learning_rate=cfg.lr, learning_rate_decay_type='fixed', optimizer='adam',
+               adam_beta1=cfg.beta1, adam_beta2=cfg.beta2, opt_epsilon=cfg.adam_eps, n_critic=2)
+  ref = ref_runner.run_training(flags, [(s.numpy(), t.numpy()) for s, t in runs], seed=seed,
+                                preset={k: v.numpy() for k, v in P.items()})
+  d = {'param/' + k: v.numpy().copy() for k, v in P.items()}      # train_step below updates P in place
+  d['meta/lr'], d['meta/beta1'], d['meta/beta2'], d['meta/eps'] = (np.array(x) for x in (cfg.lr, cfg.beta1, cfg.beta2, cfg.adam_eps))
+  for k in P:
+    d['after/' + k] = ref['variables'][k]
+  for k in ('beta1_power', 'beta2_power'):
+    d['after_opt/' + k] = ref['variables'][k]
+  opt = R.AdamState(P, cfg)
+  for i, ((s, t), h) in enumerate(zip(runs, ref['history'])):
+    a = [v for n, v in h['random'] if n == 'alpha']
+    d['run%d/sources' % i], d['run%d/targets' % i] = s.numpy(), t.numpy()
+    d['run%d/gp_alpha_s' % i], d['run%d/gp_alpha_t' % i] = a[0].reshape(-1), a[1].reshape(-1)
+    d['run%d/counters' % i] = np.array([h['n_critic_counter'], h['global_step'], h['n_critic_counter_after'],
+                                        h['global_step_after']])
+    d['run%d/d_loss' % i] = np.array(h['train_tensor'])      # train_op = identity(discriminator_loss) for wgan
+    out = R.train_step(P, opt, s, t, cfg, torch.from_numpy(a[0]), torch.from_numpy(a[1]), i)
+    assert 'd_loss' not in out or abs(out['d_loss'] - h['train_tensor']) < 1e-9
+  worst = max(float(np.abs(P[k].detach().numpy() - d['after/' + k]).max()) for k in P)
+  assert worst < 1e-9, worst
+  print('  %d training runs, oracle vs reference: max parameter deviation %.1e' % (n_runs, worst))
+  return d
+
+
 def full_size(hw=256, max_ch=256, batch=2, seed=0):
   """BASELINE.json's headline configuration (256x256, 256 channels) through the reference's own code, at full size.
   The weights (71 MB) are not stored: they are `R.init_params(cfg, seed, float64, 'he')` rounded to fp32 and the inputs
@@ -265,6 +301,7 @@ def main():
     kw = dict(kw)
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **model(kw.pop('hw'), kw.pop('max_ch'), batch, **kw))
   np.savez_compressed(os.path.join(OUT, 'clones2_hw16_c8.npz'), **clones(16, 8, 2, 2))
+  np.savez_compressed(os.path.join(OUT, 'train4_hw16_c8.npz'), **training())
   # the variables the reference creates at full width, with what its initialisers drew (names, shapes, statistics)
   import json
   from oracle import ref_runner
