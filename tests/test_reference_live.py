@@ -1,0 +1,75 @@
+"""Live pin: where the reference tree is mounted (the build container) its own graph code is executed on the TensorFlow
+stand-in (oracle/ref_runner.py) for configurations beyond the frozen fixtures, and the float64 oracle must reproduce
+every loss term and every gradient.  Skipped on the GPU box, where /root/reference does not exist."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as R
+
+pytestmark = pytest.mark.skipif(not os.path.isdir('/root/reference'),
+                                reason='the reference tree is only mounted in the build container')
+
+CASES = {
+  'gan': dict(hw=64, max_ch=8, loss='gan'),                                   # cycle-GAN term on (twingan.py:466)
+  'wgan_drift': dict(hw=16, max_ch=8, loss='wgan', drift=0.001),
+  'hinge_64': dict(hw=64, max_ch=8, loss='hinge'),
+  'no_unet_no_pixel_norm': dict(hw=16, max_ch=8, use_unet=False, do_pixel_norm=False),
+  'no_cycle_gan_no_content': dict(hw=64, max_ch=8, do_l_cyc_gan=False, l_content=0.0),
+  'weights': dict(hw=16, max_ch=8, gan_weight=0.7, l_cyc=2.0, l_content=0.3, gp_lambda=5.0),
+  'eqlr': dict(hw=32, max_ch=16, equalized=True),
+  'res_block_growing': dict(hw=16, max_ch=8, res_block=True, is_growing=True, alpha_grow=0.6),
+  'batch_renorm_step0': dict(hw=16, max_ch=8, norm='batch_renorm'),
+  'sn_hinge': dict(hw=16, max_ch=8, spectral_norm=True, loss='hinge'),
+  'attention_in_generator': dict(hw=16, max_ch=16, do_self_attention=True, self_attention_hw=16),
+  'style_embed_6': dict(hw=16, max_ch=16, use_style_embedding=True, style_embed_size=6),
+}
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_oracle_matches_live_reference(name):
+  from oracle import ref_runner
+  cfg = R.Config(**CASES[name])
+  batch = 1 if cfg.use_style_embedding else 2      # see tools/make_golden.py::CASES on the style case
+  P = R.init_params(cfg, seed=11, dtype=torch.float64, std='he')
+  state = R.init_sn_state(P, seed=12) if cfg.spectral_norm else {}
+  rng = np.random.RandomState(13)
+  s, t = rng.rand(batch, cfg.hw, cfg.hw, 3), rng.rand(batch, cfg.hw, cfg.hw, 3)
+  preset = {k: v.numpy() for k, v in list(P.items()) + list(state.items())}
+  if cfg.norm == 'batch_renorm':
+    cfg.bn_state = {}      # the oracle applies the renorm state updates in program order: ask the stand-in for the same
+  ref = ref_runner.run(ref_runner.flags_of(cfg), s, t, global_step=ref_runner.global_step_of(cfg), seed=1, preset=preset,
+                       eager_updates=cfg.norm == 'batch_renorm')
+  created = {k for k in ref['variables'] if k != 'global_step' and '/moving_' not in k and '/renorm_' not in k}
+  assert created == set(preset)
+  draws = {}
+  for n, v in ref['random']:
+    draws.setdefault(n, []).append(torch.from_numpy(v))
+  a = draws.get('alpha', [None, None])
+  noise = draws.get('uniform', [None, None])
+  if cfg.use_style_embedding:
+    cfg.style_noise = draws['random_style_embed'][0]
+  if state:
+    cfg.sn_state, cfg.sn_cache = {k: v.clone() for k, v in state.items()}, {}
+  for v in P.values():
+    v.requires_grad_(True)
+  st, tt = torch.from_numpy(s), torch.from_numpy(t)
+  gl, gterms = R.generator_loss(P, st, tt, cfg)
+  if cfg.norm == 'batch_renorm':
+    cfg.bn_state = {}      # both losses belong to one reference run: the second oracle pass starts from the same state
+  dl, dterms = R.discriminator_loss(P, st, tt, cfg, a[0], a[1], noise[0], noise[1])
+  for grp, total, terms in (('g', gl, gterms), ('d', dl, dterms)):
+    want = {ref_runner.term_name(k): v for k, v in ref[grp + '_terms'].items()}
+    assert set(want) == set(terms), (grp, sorted(want), sorted(terms))
+    for k, v in terms.items():
+      assert abs(float(v) - want[k]) < 1e-9, (k, float(v), want[k])
+    assert abs(float(total) - ref[grp + '_loss']) < 1e-9
+  grads = dict(R.grads_of(gl, P, R.generator_var_names(P)))
+  grads.update(R.grads_of(dl, P, R.discriminator_var_names(P)))
+  scale = max(float(np.abs(v).max()) for v in list(ref['g_grads'].values()) + list(ref['d_grads'].values()))
+  for k, v in grads.items():
+    want = ref['d_grads' if k.startswith('discriminator') else 'g_grads'].get(k)
+    got = v.detach().numpy()
+    assert np.abs(got - (want if want is not None else 0.0)).max() < 1e-9 * scale, k
