@@ -27,7 +27,7 @@ for v in variants:
   trainers.append(tr)
 best = [1e9] * len(variants)
 tot = [0.0] * len(variants)
-ROUNDS, STEPS = 5, 10
+ROUNDS, STEPS = int(os.environ.get("AB_ROUNDS", 5)), 10
 for r in range(ROUNDS):
   for i, tr in enumerate(trainers):
     torch.cuda.synchronize()

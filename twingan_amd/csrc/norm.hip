@@ -610,16 +610,11 @@ int pick_v(int c) {
 
 // smallest pixel range worth a workgroup: small images are latency-bound (one dependent load round per trip), so
 // they get one trip per workgroup; larger ones amortise the prologue / partial-sum traffic over >= 64 pixels
-static inline int min_ppb(int hw) {
-  const int mode = tg_tune("TG_TUNE_NORM_PPB", 1);
-  if (mode == 0) return 64;
-  if (mode == 2) return hw <= 256 ? 16 : hw <= 1024 ? 32 : 64;
-  return hw <= 64 ? 16 : hw <= 256 ? 32 : 64;
-}
+static inline int min_ppb(int hw) { return hw <= 64 ? 16 : hw <= 256 ? 32 : 64; }
 
 // pixel range of one statistics / reduction block: ~1024 blocks in total
 static void norm_chunks(int n, int hw, int* chunks, int* ppb) {
-  int ch = (tg_tune("TG_TUNE_NORM_BLOCKS", 1024) + n - 1) / n;
+  int ch = (1024 + n - 1) / n;
   int pp = (hw + ch - 1) / ch;
   if (pp < min_ppb(hw)) pp = min_ppb(hw);
   *ppb = pp;
@@ -671,7 +666,7 @@ int tg_norm_act_fwd_partials(const void* y, const float* partials, float* mean, 
   int chunks, ppb_s;
   norm_chunks(n, hw, &chunks, &ppb_s);
   const int units = z_pooled ? hw / 4 : hw;            // the pooled variant walks 2x2 blocks (4 pixels each)
-  int chunks2 = (tg_tune("TG_TUNE_NORM_BLOCKS2", 2048) + n - 1) / n;                    // ~2048 blocks for the streaming pass
+  int chunks2 = (2048 + n - 1) / n;                    // ~2048 blocks for the streaming pass
   int ppb = (units + chunks2 - 1) / chunks2;
   const int floor_ppb = z_pooled ? 16 : min_ppb(hw);
   if (ppb < floor_ppb) ppb = floor_ppb;
@@ -785,7 +780,7 @@ int tg_norm_act_bwd(const void* gz, const void* gz_pooled, const void* y, const 
   const int64_t npix = (int64_t)n * hw;
   int chunks, ppb;
   norm_chunks(n, hw, &chunks, &ppb);
-  int chunks2 = (tg_tune("TG_TUNE_NORM_BLOCKS2", 2048) + n - 1) / n;
+  int chunks2 = (2048 + n - 1) / n;
   int ppb2 = (hw + chunks2 - 1) / chunks2;
   if (ppb2 < min_ppb(hw)) ppb2 = min_ppb(hw);
   chunks2 = (hw + ppb2 - 1) / ppb2;
@@ -832,8 +827,7 @@ static int lrelu_bwd_launch(const char* who, const void* gz, const void* gzp, in
     TG_CHECK(c / V <= 256, TG_ENOSUP, "%s: c=%d not supported", who, c);
     const int lanes = 256 / (c / V);
     // few, fat workgroups when a bias gradient is produced: every workgroup ends with c global atomics
-    const bool small = tg_tune("TG_TUNE_LRELU_SMALL", 0) && npix * c < (int64_t)tg_tune("TG_TUNE_LRELU_ELEMS", 4 << 20);
-    const int blocks = (gbias && !small) ? tg_grid_for(npix, lanes * 16, 1024) : tg_grid_for(npix, lanes * 4, 2048);
+    const int blocks = gbias ? tg_grid_for(npix, lanes * 16, 1024) : tg_grid_for(npix, lanes * 4, 2048);
     const size_t lds = (size_t)c * sizeof(float);
     if (V == 1)
       hipLaunchKernelGGL((lrelu_bwd_bias_kernel<T, 1>), dim3(blocks), dim3(256), lds, s, (const T*)gz, (const T*)gzp, hw,

@@ -104,7 +104,8 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 __device__ __forceinline__ float lrelu_f(float x, float a) { return fmaxf(a * x, x); }
 
 // launch-heuristic experiments: TG_TUNE_<NAME>=<int> in the environment overrides `dflt` (read at every call, so
-// two hipGraph captures in one process can bake different settings); only tools/ab_env.py sets these
+// two hipGraph captures in one process can bake different settings).  For tools/ab_env.py; no call site is left in
+// the tree when an experiment is over
 static inline int tg_tune(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;
