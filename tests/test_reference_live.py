@@ -22,6 +22,8 @@ CASES = {
   'eqlr': dict(hw=32, max_ch=16, equalized=True),
   'res_block_growing': dict(hw=16, max_ch=8, res_block=True, is_growing=True, alpha_grow=0.6),
   'batch_renorm_step0': dict(hw=16, max_ch=8, norm='batch_renorm'),
+  'batch_renorm_step25000': dict(hw=16, max_ch=8, norm='batch_renorm', global_step=25000),
+  'batch_norm': dict(hw=16, max_ch=8, norm='batch_norm'),
   'sn_hinge': dict(hw=16, max_ch=8, spectral_norm=True, loss='hinge'),
   'attention_in_generator': dict(hw=16, max_ch=16, do_self_attention=True, self_attention_hw=16),
   'style_embed_6': dict(hw=16, max_ch=16, use_style_embedding=True, style_embed_size=6),
@@ -38,10 +40,11 @@ def test_oracle_matches_live_reference(name):
   rng = np.random.RandomState(13)
   s, t = rng.rand(batch, cfg.hw, cfg.hw, 3), rng.rand(batch, cfg.hw, cfg.hw, 3)
   preset = {k: v.numpy() for k, v in list(P.items()) + list(state.items())}
-  if cfg.norm == 'batch_renorm':
-    cfg.bn_state = {}      # the oracle applies the renorm state updates in program order: ask the stand-in for the same
+  stateful = cfg.norm in ('batch_norm', 'batch_renorm')
+  if stateful:
+    cfg.bn_state = {}      # the oracle applies the moving-statistics updates in program order: ask the stand-in for the same
   ref = ref_runner.run(ref_runner.flags_of(cfg), s, t, global_step=ref_runner.global_step_of(cfg), seed=1, preset=preset,
-                       eager_updates=cfg.norm == 'batch_renorm')
+                       eager_updates=stateful)
   created = {k for k in ref['variables'] if k != 'global_step' and '/moving_' not in k and '/renorm_' not in k}
   assert created == set(preset)
   draws = {}
@@ -57,7 +60,14 @@ def test_oracle_matches_live_reference(name):
     v.requires_grad_(True)
   st, tt = torch.from_numpy(s), torch.from_numpy(t)
   gl, gterms = R.generator_loss(P, st, tt, cfg)
-  if cfg.norm == 'batch_renorm':
+  if stateful:
+    # one oracle generator pass = the eight encoder / generator applications of one reference run, in the same order:
+    # the moving (and renorm) statistics it leaves must be the ones the reference's update ops leave
+    # (libs/batch_norm.py:283-320,358-392; decay 0.999, renorm momentum 0.99)
+    after = {k: v for k, v in ref['state_after'].items() if k != 'global_step'}
+    assert set(after) == set(cfg.bn_state), sorted(set(after) ^ set(cfg.bn_state))[:6]
+    for k, v in after.items():
+      assert np.abs(cfg.bn_state[k].numpy().reshape(v.shape) - v).max() < 1e-12, k
     cfg.bn_state = {}      # both losses belong to one reference run: the second oracle pass starts from the same state
   dl, dterms = R.discriminator_loss(P, st, tt, cfg, a[0], a[1], noise[0], noise[1])
   for grp, total, terms in (('g', gl, gterms), ('d', dl, dterms)):
