@@ -40,6 +40,7 @@ def run(flags, sources, targets, global_step=0, seed=0, preset=None, want_grads=
   core.STATE.reset(seed)
   core.STATE.preset = dict(preset or {})
   core.STATE.eager_updates = bool(eager_updates)
+  core.STATE.placeholder_batch = int(np.asarray(sources).shape[0])
   tfapi._ARG_STACK[:] = [{}]
   gs = tfapi.get_or_create_global_step()
   gs.t.fill_(int(global_step))

@@ -386,6 +386,7 @@ class State(object):
     self.random_log = []                # (op name, torch tensor) of every random op, in call order
     self.global_step = None
     self.name_scope = ''
+    self.placeholder_batch = 1
     self.preset = {}                    # full variable name -> numpy value used instead of the initializer
     self.deferred = []                  # assign ops waiting for run_update_ops()
     self.eager_updates = False          # True: assign ops run where they are created (see tfapi._Assign.schedule)

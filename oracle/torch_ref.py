@@ -465,7 +465,16 @@ def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=Tru
     y = instance_norm(y, P[scope + '/InstanceNorm/gamma_' + domain], P[scope + '/InstanceNorm/beta_' + domain],
                       cfg.in_eps)
   elif cfg.norm == 'batch_norm':       # the reference's default generator_norm_type (nets/pggan.py:24)
-    y, bm, bv = batch_norm_train(y, P[scope + '/BatchNorm/gamma_' + domain], P[scope + '/BatchNorm/beta_' + domain])
+    if cond is not None:
+      # conditional batch norm (libs/batch_norm.py:82-85,152-159,403-424): the embedding is l2-normalised per row,
+      # gamma = 1 + FC, beta = FC, one row per image, broadcast as [B,1,1,C] against the BATCH statistics
+      cn = cond / cond.pow(2).sum(dim=1, keepdim=True).clamp_min(1e-12).sqrt()
+      pre = scope + '/BatchNorm/'
+      gamma = (1.0 + cn @ P[pre + 'gamma_%s/weights' % domain] + P[pre + 'gamma_%s/biases' % domain])[:, None, None, :]
+      beta = (cn @ P[pre + 'beta_%s/weights' % domain] + P[pre + 'beta_%s/biases' % domain])[:, None, None, :]
+    else:
+      gamma, beta = P[scope + '/BatchNorm/gamma_' + domain], P[scope + '/BatchNorm/beta_' + domain]
+    y, bm, bv = batch_norm_train(y, gamma, beta)
     if cfg.bn_state is not None:       # moving statistics per domain postfix (libs/batch_norm.py:184-196)
       for nm, val, init in (('moving_mean_', bm, 0.0), ('moving_variance_', bv, 1.0)):
         key = scope + '/BatchNorm/' + nm + domain

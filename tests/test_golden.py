@@ -27,6 +27,8 @@ MODELS = {'twingan_hw16_c8': dict(hw=16, max_ch=8), 'twingan_hw64_c8': dict(hw=6
           'twingan_hw16_c8_hinge_eqlr_res': dict(hw=16, max_ch=8, loss='hinge', equalized=True, res_block=True),
           'twingan_hw16_c8_batch_norm': dict(hw=16, max_ch=8, norm='batch_norm'),
           'twingan_hw16_c8_style': dict(hw=16, max_ch=8, use_style_embedding=True, style_embed_size=8),
+          'twingan_hw16_c8_style_bn': dict(hw=16, max_ch=8, use_style_embedding=True, style_embed_size=8,
+                                           norm='batch_norm'),
           'twingan_hw16_c8_dragan': dict(hw=16, max_ch=8, loss='dragan'),
           'twingan_hw16_c16_sn_att': dict(hw=16, max_ch=16, spectral_norm=True, do_self_attention=True,
                                           self_attention_hw=8)}
@@ -290,7 +292,8 @@ def test_gpu_training_runs_hit_the_reference():
                                             ('twingan_hw16_c8_growing', 'fp32'), ('twingan_hw64_c8', 'bf16'),
                                             ('twingan_hw16_c8_hinge_eqlr_res', 'fp32'),
                                             ('twingan_hw16_c8_batch_norm', 'fp32'), ('twingan_hw16_c8_style', 'fp32'),
-                                            ('twingan_hw16_c8_dragan', 'fp32'), ('twingan_hw16_c16_sn_att', 'fp32')])
+                                            ('twingan_hw16_c8_dragan', 'fp32'), ('twingan_hw16_c16_sn_att', 'fp32'),
+                                            ('twingan_hw16_c8_style_bn', 'fp32')])
 def test_gpu_model_hits_golden(name, precision):
   from twingan_amd import Config
   from twingan_amd import twingan as T

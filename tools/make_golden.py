@@ -210,6 +210,8 @@ CASES = {      # fixture name -> (batch, oracle Config fields); tests/test_golde
   # batch 1: the reference's conditional instance norm multiplies [B,1,1,C] statistics by a [B,C] gamma without
   # reshaping it (libs/instance_norm.py:100-135), which only broadcasts as intended for one image
   'twingan_hw16_c8_style': (1, dict(hw=16, max_ch=8, use_style_embedding=True, style_embed_size=8)),
+  # ... while its conditional BATCH norm (libs/batch_norm.py:403-424 reshapes the rows) works for any batch
+  'twingan_hw16_c8_style_bn': (2, dict(hw=16, max_ch=8, use_style_embedding=True, style_embed_size=8, norm='batch_norm')),
   'twingan_hw16_c8_dragan': (2, dict(hw=16, max_ch=8, loss='dragan')),
   'twingan_hw16_c16_sn_att': (2, dict(hw=16, max_ch=16, spectral_norm=True, do_self_attention=True,
                                       self_attention_hw=8)),

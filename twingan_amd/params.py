@@ -256,7 +256,7 @@ def declare_twingan(store, cfg):
   enc_skeleton('encoder_content', 'g', False, nd)
   gen_kw = {}
   if cfg.use_style_embedding:      # twingan.py:47-51,201-223: the style encoder (pggan.encoder) and conditional generator norms
-    if cfg.generator_norm_type != 'instance_norm':
+    if cfg.generator_norm_type not in ('instance_norm', 'batch_norm'):
       raise NotImplementedError('use_style_embedding with generator_norm_type=%s' % cfg.generator_norm_type)
     enc_skeleton('encoder_style', 'g', False, nd)
     c0 = get_num_channels(0, mc)

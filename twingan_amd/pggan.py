@@ -160,12 +160,15 @@ def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pix
   else:
     d0, d1, split, passes = domain, None, None, 1
   pn = pixel_norm and cfg.do_pixel_norm
-  if cond is not None:      # conditional instance norm: one parameter row per image (twingan.py:245-267)
-    assert nt == 'instance_norm'
+  if cond is not None:      # conditional norm: one parameter row per image (twingan.py:245-267)
     n_ = y.shape[0]
     segs = [(d0, 0, n_)] if d1 is None else [(d0, 0, split), (d1, split, n_)]
-    g_rows, b_rows = _cond_rows(P, scope, ns, cond, segs)
-    return ops.norm_act(y, g_rows, b_rows, lrelu=activation, pixel_norm=pn, pool=pool, stats=ops.instance_stats(y, 1e-6))
+    if nt == 'instance_norm':
+      g_rows, b_rows = _cond_rows(P, scope, ns, cond, segs)
+      return ops.norm_act(y, g_rows, b_rows, lrelu=activation, pixel_norm=pn, pool=pool, stats=ops.instance_stats(y, 1e-6))
+    if nt != 'batch_norm':
+      raise NotImplementedError('style embedding with generator_norm_type=%s' % nt)
+    return _cond_batch_norm(P, scope, y, cond, segs, passes, activation, pn, pool, cfg)
   g0, b0 = P['%s/%s/gamma_%s' % (scope, ns, d0)], P['%s/%s/beta_%s' % (scope, ns, d0)]
   g1 = P['%s/%s/gamma_%s' % (scope, ns, d1)] if d1 else None
   b1 = P['%s/%s/beta_%s' % (scope, ns, d1)] if d1 else None
@@ -194,6 +197,38 @@ def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pix
   if pool:
     return out[0].view(n, h, w, c), out[1].view(n, h // 2, w // 2, c)
   return out.view(n, h, w, c)
+
+
+def _cond_batch_norm(P, scope, y, cond, segs, passes, activation, pn, pool, cfg):
+  """conditional_batch_norm with a conditional layer (libs/batch_norm.py:82-85,152-159,403-470): the embedding is
+  l2-normalised per image, gamma = 1 + FC, beta = FC give one row per image, applied to activations normalised with
+  the statistics of the whole reference pass.  An option row, not on the headline path: the batch statistics and
+  their backward are the HIP normaliser (per-pass view, unit gamma, zero beta, no activation); the per-image affine,
+  LeakyReLU and pixel norm that follow are a framework composite, like the attention products."""
+  import torch
+  n, h, w, c = y.shape
+  cn = cond.float()
+  cn = cn / cn.pow(2).sum(dim=1, keepdim=True).clamp_min(1e-12).sqrt()
+  g_rows, b_rows = _cond_rows(P, scope, 'BatchNorm', cn, segs)
+  one = torch.ones(c, dtype=torch.float32, device=y.device)
+  zero = torch.zeros(c, dtype=torch.float32, device=y.device)
+  ema = None
+  st = P.state if hasattr(P, 'state') else None
+  if st is not None:
+    doms = [d for d, _, _ in segs]
+    ema = (0.999, [(st['%s/BatchNorm/moving_mean_%s' % (scope, d)], st['%s/BatchNorm/moving_variance_%s' % (scope, d)])
+                   for d in doms])
+  split_v = None if len(segs) == 1 else segs[0][2] * passes // n
+  yhat = ops.norm_act(y.view(passes, (n // passes) * h, w, c), one, zero, lrelu=False, pixel_norm=False, in_eps=BN_EPS,
+                      gamma2=one if split_v is not None else None, beta2=zero if split_v is not None else None,
+                      split=split_v, ema=ema).view(n, h, w, c)
+  z = yhat.float() * g_rows.view(n, 1, 1, c) + b_rows.view(n, 1, 1, c)
+  if activation:
+    z = torch.maximum(z * ops.LRELU_ALPHA, z)
+  if pn:
+    z = z * torch.rsqrt(z.pow(2).mean(dim=3, keepdim=True) + 1e-6)
+  z = z.to(y.dtype).contiguous()
+  return (z, ops.avg_pool2(z)) if pool else z
 
 
 BN_EPS = 1e-3            # libs/batch_norm.py:48
