@@ -292,6 +292,7 @@ SCHEMAS = {      # full-width configurations of BASELINE.json, run once through 
   'hw64_c256_sn_att_bn': dict(hw=64, max_ch=256, norm='batch_renorm', spectral_norm=True, do_self_attention=True,
                               self_attention_hw=32),
   'hw32_c128_eqlr_res': dict(hw=32, max_ch=128, equalized=True, res_block=True),
+  'hw32_c64_style_bn': dict(hw=32, max_ch=64, use_style_embedding=True, style_embed_size=16, norm='batch_norm'),
 }
 
 

@@ -70,9 +70,9 @@ class ParamStore:
         for nm in ('gamma', 'beta'):
           self.add('%s/%s/%s_%s/weights' % (scope, norm_scope, nm, d), (cond_dim, cout), group, 'xavier_w')
           self.add('%s/%s/%s_%s/biases' % (scope, norm_scope, nm, d), (cout,), group, 'bias')
-        continue
-      self.add('%s/%s/gamma_%s' % (scope, norm_scope, d), (cout,), group, 'gamma')
-      self.add('%s/%s/beta_%s' % (scope, norm_scope, d), (cout,), group, 'beta')
+      else:
+        self.add('%s/%s/gamma_%s' % (scope, norm_scope, d), (cout,), group, 'gamma')
+        self.add('%s/%s/beta_%s' % (scope, norm_scope, d), (cout,), group, 'beta')
       if norm_scope == 'BatchNorm':      # non-trainable moving statistics (libs/batch_norm.py:184-196)
         self.state_specs['%s/BatchNorm/moving_mean_%s' % (scope, d)] = (cout, 0.0)
         self.state_specs['%s/BatchNorm/moving_variance_%s' % (scope, d)] = (cout, 1.0)
