@@ -700,3 +700,29 @@ def test_lrelu_backward_folded_into_next_backward_data(ops, dtype, hw, c1, c2):
   for other in res[1:]:
     for a, b in zip(other, res[0]):
       assert rel_l2(a, b) < tol
+
+
+@pytest.mark.parametrize('dtype,hw,c1,c2', [(torch.bfloat16, 16, 32, 64), (torch.float32, 8, 8, 8), (torch.bfloat16, 32, 16, 16)])
+def test_lrelu_fold_under_create_graph_matches_unfused(ops, dtype, hw, c1, c2):
+  """Gradient-penalty shaped double backward through conv+bias+lrelu -> conv+bias+lrelu -> conv: with fuse_input_lrelu
+  the first backward runs MaskedDgradFn (mask in the backward-data epilogue) instead of LeakyReLU-backward + backward-
+  data nodes; the input gradient, the penalty and every parameter gradient of the penalty must match the unfused chain."""
+  g = torch.Generator().manual_seed(33)
+  x = torch.randn(2, hw, hw, 16, generator=g).to(dev()).to(dtype)
+  shapes = [(3, 3, 16, c1), (c1,), (3, 3, c1, c2), (c2,), (3, 3, c2, 16), (16,)]
+  ws = [(torch.randn(*s, generator=g) * (0.1 if len(s) == 4 else 0.05)).to(dev()) for s in shapes]
+  res = []
+  for fuse in (False, True):
+    ops.GradSink.clear()
+    ps = [t.clone().requires_grad_(True) for t in ws]
+    xin = x.clone().requires_grad_(True)
+    z1 = ops.conv2d(xin, ps[0], ps[1], 3, 'SAME', lrelu=True)
+    z2 = ops.conv2d(z1, ps[2], ps[3], 3, 'SAME', lrelu=True, fuse_input_lrelu=fuse)
+    z3 = ops.conv2d(z2, ps[4], ps[5], 3, 'SAME', lrelu=True, fuse_input_lrelu=fuse)
+    gx, = torch.autograd.grad(z3.float().sum(), xin, create_graph=True)
+    pen = ((gx.float().pow(2).sum(dim=(1, 2, 3)).sqrt() - 1.0) ** 2).mean()
+    grads = torch.autograd.grad(pen, [ps[0], ps[2], ps[4]])
+    res.append([host(gx.detach()), host(pen.detach().reshape(1))] + [host(t) for t in grads])
+  tol = 1e-5 if dtype == torch.float32 else 3e-2
+  for a, b in zip(res[1], res[0]):
+    assert rel_l2(a, b) < tol, (rel_l2(a, b))

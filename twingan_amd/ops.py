@@ -436,8 +436,9 @@ def _conv_backward(ctx, gz, gzp=None):
   gz = gz.contiguous() if gz is not None else None
   gzp = gzp.contiguous() if gzp is not None else None
   fused = (ctx.epilogue & TG_EPI_LRELU) and not torch.is_grad_enabled()
-  # the (single) consumer of z is a conv whose backward-data applies this layer's LeakyReLU mask itself
-  premasked = fused and gzp is None and getattr(ctx, 'tg_premasked', False)
+  # the (single) consumer of z is a conv whose backward-data applies this layer's LeakyReLU mask itself -- in
+  # first-order passes with the raw masked kernel, in create_graph passes with the differentiable MaskedDgradFn
+  premasked = bool(ctx.epilogue & TG_EPI_LRELU) and gzp is None and getattr(ctx, 'tg_premasked', False)
   bias_sink = None
   if gzp is not None and not fused:
     # differentiable composition (create_graph) or no activation: materialise the upsampled pooled gradient
@@ -459,8 +460,8 @@ def _conv_backward(ctx, gz, gzp=None):
     g = gz
   gx = None
   if ctx.needs_input_grad[0]:
-    if getattr(ctx, 'mask_input', False) and not torch.is_grad_enabled():
-      gx = conv_bwd_data_masked_raw(g, w, x, spec)      # x = the producer's LeakyReLU output
+    if getattr(ctx, 'mask_input', False):      # x = the producer's LeakyReLU output
+      gx = MaskedDgradFn.apply(g, w, x, spec) if torch.is_grad_enabled() else conv_bwd_data_masked_raw(g, w, x, spec)
     else:
       gx = ConvBwdDataFn.apply(g, w, tuple(x.shape), spec)
   gw = _weight_grad(x, g, spec, w, bias_sink) if need_w else None
@@ -529,6 +530,27 @@ class ConvBwdDataFn(torch.autograd.Function):
     return ggy, gw, None, None
 
 
+class MaskedDgradFn(torch.autograd.Function):
+  """gx = conv^T(gy, w) * mask(x_act), mask = (x_act > 0 ? 1 : alpha): backward-data with the LeakyReLU backward of the
+  layer that produced this conv's input folded into its epilogue, for create_graph passes (the gradient-penalty
+  first backward).  Linear in gy and in w, so its own backward is  v' = v * mask(x_act);  d/dgy = conv(v', w),
+  d/dw = x'^T-style filter gradient of (v', gy);  the mask is piecewise constant: no gradient to x_act."""
+
+  @staticmethod
+  def forward(ctx, gy, w, x_act, spec):
+    ctx.spec = spec
+    ctx.save_for_backward(gy, w, x_act)
+    return conv_bwd_data_masked_raw(gy, w, x_act, spec)
+
+  @staticmethod
+  def backward(ctx, v):
+    gy, w, x_act = ctx.saved_tensors
+    vm = LReluBwdFn.apply(v.contiguous(), x_act, ctx.spec.alpha)
+    ggy = Conv2dFn.apply(vm, w, None, ctx.spec, 0, False) if ctx.needs_input_grad[0] else None
+    gw = _weight_grad(vm, gy, ctx.spec, w) if (ctx.needs_input_grad[1] and not _State.skip_param_grads) else None
+    return ggy, gw, None, None
+
+
 class ConvBwdWeightFn(torch.autograd.Function):
   """gw = x^T * gy  (Conv2DBackpropFilter), fp32 HWIO.  Third-order terms are not needed by any
   TwinGAN loss, so this node is a leaf of the double-backward graph."""
@@ -585,7 +607,7 @@ def conv2d(x, w, bias=None, k=3, padding='SAME', lrelu=False, alpha=LRELU_ALPHA,
   """Stride-1 conv, optional fused bias and LeakyReLU (discriminator layers).  ``pool``: also return the
   2x2 average-pooled output -> (z, z_pooled).  ``fuse_input_lrelu``: the caller guarantees that ``x`` is consumed by
   this conv only; when x is a conv node's LeakyReLU output, that layer's LeakyReLU backward moves into this conv's
-  backward-data epilogue (first-order backward passes only; create_graph passes keep the separate nodes)."""
+  backward-data epilogue (raw kernel in first-order passes, the differentiable MaskedDgradFn in create_graph passes)."""
   spec = ConvSpec(k, padding, 0, alpha)
   epi = (TG_EPI_BIAS if bias is not None else 0) | (TG_EPI_LRELU if lrelu else 0)
   mask_input = bool(fuse_input_lrelu) and _claim_input_lrelu(x, alpha)
@@ -628,7 +650,7 @@ class PointwiseConvFn(torch.autograd.Function):
     params = not _State.skip_param_grads
     need_b = bool(ctx.epilogue & TG_EPI_BIAS) and ctx.needs_input_grad[2] and params
     gb = None
-    if (ctx.epilogue & TG_EPI_LRELU) and getattr(ctx, 'tg_premasked', False) and not torch.is_grad_enabled():
+    if (ctx.epilogue & TG_EPI_LRELU) and getattr(ctx, 'tg_premasked', False):
       g = gz      # the consumer conv's backward-data already applied this layer's LeakyReLU mask
     elif ctx.epilogue & TG_EPI_LRELU:
       if need_b and not torch.is_grad_enabled():
