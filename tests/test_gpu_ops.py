@@ -706,7 +706,8 @@ def test_lrelu_backward_folded_into_next_backward_data(ops, dtype, hw, c1, c2):
 def test_lrelu_fold_under_create_graph_matches_unfused(ops, dtype, hw, c1, c2):
   """Gradient-penalty shaped double backward through conv+bias+lrelu -> conv+bias+lrelu -> conv: with fuse_input_lrelu
   the first backward runs MaskedDgradFn (mask in the backward-data epilogue) instead of LeakyReLU-backward + backward-
-  data nodes; the input gradient, the penalty and every parameter gradient of the penalty must match the unfused chain."""
+  data nodes (and the pooled last layer one unpool+mask node); the input gradient, the penalty and every parameter
+  gradient of the penalty must match the unfused chain and a float64 torch reference."""
   g = torch.Generator().manual_seed(33)
   x = torch.randn(2, hw, hw, 16, generator=g).to(dev()).to(dtype)
   shapes = [(3, 3, 16, c1), (c1,), (3, 3, c1, c2), (c2,), (3, 3, c2, 16), (16,)]
@@ -718,7 +719,7 @@ def test_lrelu_fold_under_create_graph_matches_unfused(ops, dtype, hw, c1, c2):
     xin = x.clone().requires_grad_(True)
     z1 = ops.conv2d(xin, ps[0], ps[1], 3, 'SAME', lrelu=True)
     z2 = ops.conv2d(z1, ps[2], ps[3], 3, 'SAME', lrelu=True, fuse_input_lrelu=fuse)
-    z3 = ops.conv2d(z2, ps[4], ps[5], 3, 'SAME', lrelu=True, fuse_input_lrelu=fuse)
+    _, z3 = ops.conv2d(z2, ps[4], ps[5], 3, 'SAME', lrelu=True, fuse_input_lrelu=fuse, pool=True)      # block end: pooled
     gx, = torch.autograd.grad(z3.float().sum(), xin, create_graph=True)
     pen = ((gx.float().pow(2).sum(dim=(1, 2, 3)).sqrt() - 1.0) ** 2).mean()
     grads = torch.autograd.grad(pen, [ps[0], ps[2], ps[4]])
@@ -726,3 +727,19 @@ def test_lrelu_fold_under_create_graph_matches_unfused(ops, dtype, hw, c1, c2):
   tol = 1e-5 if dtype == torch.float32 else 3e-2
   for a, b in zip(res[1], res[0]):
     assert rel_l2(a, b) < tol, (rel_l2(a, b))
+  # independent reference: the same graph in float64 torch on the host
+  import torch.nn.functional as F
+  xr = x.double().cpu().requires_grad_(True)
+  pr = [t.double().cpu().requires_grad_(True) for t in ws]
+  def layer(a, w, b):
+    y = F.conv2d(a.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), b, padding=1).permute(0, 2, 3, 1)
+    return torch.maximum(y, 0.2 * y)
+  a3 = layer(layer(layer(xr, pr[0], pr[1]), pr[2], pr[3]), pr[4], pr[5])
+  z3r = F.avg_pool2d(a3.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+  gxr, = torch.autograd.grad(z3r.sum(), xr, create_graph=True)
+  penr = ((gxr.pow(2).sum(dim=(1, 2, 3)).sqrt() - 1.0) ** 2).mean()
+  gr = torch.autograd.grad(penr, [pr[0], pr[2], pr[4]])
+  want = [gxr.detach().numpy(), penr.detach().reshape(1).numpy()] + [t.numpy() for t in gr]
+  rtol = 1e-4 if dtype == torch.float32 else 6e-2
+  for a, b in zip(res[1], want):
+    assert rel_l2(a, b) < rtol, rel_l2(a, b)

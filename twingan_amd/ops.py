@@ -440,16 +440,23 @@ def _conv_backward(ctx, gz, gzp=None):
   # first-order passes with the raw masked kernel, in create_graph passes with the differentiable MaskedDgradFn
   premasked = bool(ctx.epilogue & TG_EPI_LRELU) and gzp is None and getattr(ctx, 'tg_premasked', False)
   bias_sink = None
+  pooled_lrelu = None
   if gzp is not None and not fused:
-    # differentiable composition (create_graph) or no activation: materialise the upsampled pooled gradient
-    up = Pool2BwdFn.apply(gzp, 0.25, (z.shape[1], z.shape[2]) if z is not None else ctx.out_hw)
-    gz = up if gz is None else gz + up
+    if gz is None and (ctx.epilogue & TG_EPI_LRELU):
+      # create_graph pass over a pooled LeakyReLU layer: unpool + mask in one differentiable node
+      pooled_lrelu = LReluPoolBwdFn.apply(gzp, z, spec.alpha)
+    else:
+      # differentiable composition or no activation: materialise the upsampled pooled gradient
+      up = Pool2BwdFn.apply(gzp, 0.25, (z.shape[1], z.shape[2]) if z is not None else ctx.out_hw)
+      gz = up if gz is None else gz + up
     gzp = None
   if premasked:
     g = gz
     if need_b and need_w and GradSink.get(bias) is not None and GradSink.get(w) is not None:
       bias_sink = GradSink.get(bias)      # the filter-gradient kernel sums g over pixels as well
       need_b = False
+  elif pooled_lrelu is not None:
+    g = pooled_lrelu
   elif ctx.epilogue & TG_EPI_LRELU:
     if fused and (need_b or gzp is not None):
       g, gb = lrelu_pool_bwd(gz, gzp, z, spec.alpha, bias if need_b else None, need_b)
@@ -578,6 +585,22 @@ class LReluBwdFn(torch.autograd.Function):
   def backward(ctx, v):
     z, = ctx.saved_tensors
     return LReluBwdFn.apply(v.contiguous(), z, ctx.alpha), None, None
+
+
+class LReluPoolBwdFn(torch.autograd.Function):
+  """g = 0.25 * upsample2(gzp) * (z > 0 ? 1 : alpha): the backward of avg_pool2(lrelu(.)) in one pass, differentiable
+  in gzp for create_graph passes (linear: d/dgzp = avg_pool2(v * mask(z)); the mask has no gradient)."""
+
+  @staticmethod
+  def forward(ctx, gzp, z, alpha):
+    ctx.alpha = alpha
+    ctx.save_for_backward(z)
+    return lrelu_pool_bwd(None, gzp.contiguous(), z, alpha, None, False)[0]
+
+  @staticmethod
+  def backward(ctx, v):
+    z, = ctx.saved_tensors
+    return Pool2Fn.apply(LReluBwdFn.apply(v.contiguous(), z, ctx.alpha), 0.25), None, None
 
 
 class ChannelSumFn(torch.autograd.Function):
