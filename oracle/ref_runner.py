@@ -109,7 +109,8 @@ def flags_of(cfg):
     l_cyc_weight=cfg.l_cyc, l_content_weight=cfg.l_content, do_l_cyc_gan=cfg.do_l_cyc_gan,
     spectral_norm=cfg.spectral_norm, do_self_attention=cfg.do_self_attention, self_attention_hw=cfg.self_attention_hw,
     use_style_embedding=cfg.use_style_embedding, style_embed_size=cfg.style_embed_size,
-    equalized_learning_rate=cfg.equalized, use_res_block=cfg.res_block)
+    equalized_learning_rate=cfg.equalized, use_res_block=cfg.res_block,
+    pggan_unet_max_concat_hw=getattr(cfg, 'unet_max_concat_hw', None))
 
 
 def global_step_of(cfg):

@@ -26,6 +26,7 @@ class Config:
   norm: str = 'instance_norm'        # generator_norm_type               (nets/pggan.py:24)
   do_pixel_norm: bool = True         # nets/pggan.py:34-38
   use_unet: bool = True              # twingan.py:53-56
+  unet_max_concat_hw: object = None  # pggan_unet_max_concat_hw (nets/pggan.py:57-59): no skip above this hw
   is_growing: bool = False           # image_generation.py:69-72
   alpha_grow: float = 0.0
   loss: str = 'wgan_gp'              # loss_architecture                 (image_generation.py:81-83)
@@ -103,7 +104,7 @@ def encoder_param_specs(top, hw, max_ch, growing=False):
   return specs
 
 
-def generator_param_specs(top, hw, max_ch, use_unet, growing=False):
+def generator_param_specs(top, hw, max_ch, use_unet, growing=False, unet_max_hw=None):
   """[(scope, k, cin, cout)] for nets/pggan.py:93-211 with a [B,4,4,C] source."""
   ms = max_stage_of(hw)
   specs = []
@@ -116,7 +117,7 @@ def generator_param_specs(top, hw, max_ch, use_unet, growing=False):
     oc = get_num_channels(stage, max_ch)
     if stage == ms and growing:
       specs.append(('%s/generator_to_rgb_%dx%d/Conv' % (top, cur // 2, cur // 2), 1, c, 3))
-    cin = c + (get_num_channels(stage - 1, max_ch) if use_unet else 0)
+    cin = c + (get_num_channels(stage - 1, max_ch) if (use_unet and not (unet_max_hw and cur > unet_max_hw)) else 0)
     blk = '%s/block_%dx%dx%d' % (top, cur, cur, oc)
     specs.append((blk + '/Conv', 3, cin, oc))
     specs.append((blk + '/Conv_1', 3, oc, oc))
@@ -161,7 +162,7 @@ def init_params(cfg, seed=0, dtype=torch.float32, std=0.02):
   for s in encoder_param_specs('encoder_content', cfg.hw, cfg.max_ch, cfg.is_growing):
     _conv_p(P, g, s[0], s[1], s[2], s[3], ('s', 't') if cfg.norm in NORM_SCOPE else (), False, dtype, std,
             NORM_SCOPE.get(cfg.norm, ''))
-  for s in generator_param_specs('generator', cfg.hw, cfg.max_ch, cfg.use_unet, cfg.is_growing):
+  for s in generator_param_specs('generator', cfg.hw, cfg.max_ch, cfg.use_unet, cfg.is_growing, cfg.unet_max_concat_hw):
     _conv_p(P, g, s[0], s[1], s[2], s[3], ('s', 't') if cfg.norm in NORM_SCOPE else (), False, dtype, std,
             NORM_SCOPE.get(cfg.norm, ''))
   for top in ('discriminator_s', 'discriminator_t'):
@@ -213,7 +214,7 @@ def init_params(cfg, seed=0, dtype=torch.float32, std=0.02):
       P[k + '/biases'] = torch.zeros(c, dtype=dtype)
   if cfg.res_block:      # after everything else so the other variables keep their seeded values
     ge = encoder_param_specs('encoder_content', cfg.hw, cfg.max_ch, cfg.is_growing) + \
-        generator_param_specs('generator', cfg.hw, cfg.max_ch, cfg.use_unet, cfg.is_growing)
+        generator_param_specs('generator', cfg.hw, cfg.max_ch, cfg.use_unet, cfg.is_growing, cfg.unet_max_concat_hw)
     dd = [sp for top in ('discriminator_s', 'discriminator_t')
           for sp in encoder_param_specs(top, cfg.hw, cfg.max_ch, cfg.is_growing)]
     for sp in shortcut_specs(ge, cfg.hw, cfg.max_ch) + shortcut_specs(dd, cfg.hw, cfg.max_ch):
@@ -552,11 +553,13 @@ def encoder_full(P, x, domain, cfg, top='encoder_style'):
   return pred, ep
 
 
-def _concat_unet(layer, unet_ep, max_ch):
+def _concat_unet(layer, unet_ep, max_ch, max_hw=None):
   """nets/pggan_utils.py:281-298."""
   if unet_ep is None:
     return layer
   hw = layer.shape[1]
+  if max_hw and hw > max_hw:      # pggan_unet_max_concat_hw (:287-289)
+    return layer
   nc = get_num_channels(max_stage_of(hw) - 1, max_ch)
   name = 'encoder_block_interpolated_%dx%dx%d' % (hw, hw, nc)
   if name not in unet_ep:
@@ -588,7 +591,7 @@ def generator(P, source, domain, cfg, unet_ep=None, top='generator', cond=None):
         before_growth = upsample2x(before_growth)
         ep[rgb] = before_growth
       net = upsample2x(net)
-      net = _concat_unet(net, unet_ep, cfg.max_ch)
+      net = _concat_unet(net, unet_ep, cfg.max_ch, cfg.unet_max_concat_hw)
       blk_in = net
       net = ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg, cond=cond)
       net = ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg, cond=cond)

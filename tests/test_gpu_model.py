@@ -30,7 +30,8 @@ def make(cfg_kw, precision, seed=0, batch=3):
                   use_unet=cfg.use_unet, equalized=cfg.equalized_learning_rate, res_block=cfg.use_res_block,
                   spectral_norm=cfg.spectral_norm, do_self_attention=cfg.do_self_attention,
                   self_attention_hw=cfg.self_attention_hw, loss=cfg.loss_architecture,
-                  use_style_embedding=cfg.use_style_embedding, style_embed_size=cfg.style_embed_size)
+                  use_style_embedding=cfg.use_style_embedding, style_embed_size=cfg.style_embed_size,
+                  unet_max_concat_hw=cfg.unet_max_concat_hw)
   Pref = R.init_params(rcfg, seed=seed, dtype=torch.float64, std='he')
   tr = Trainer(cfg, device='cuda:0', seed=seed)
   tr.store.load_state_dict({k: v.float() for k, v in Pref.items()})
@@ -279,6 +280,33 @@ def test_graph_replay_wgan_gp_bf16_runs():
   assert tr.adam_t == 10 and int(tr._adam_step_dev.item()) == 10
   assert float((tr.store.flat['d'] - p0).abs().max()) > 0
   assert bool(torch.isfinite(tr.store.flat['g']).all()) and bool(torch.isfinite(tr.store.flat['d']).all())
+
+
+def test_unet_max_concat_hw_matches_oracle():
+  """--pggan_unet_max_concat_hw (nets/pggan_utils.py:287-289): generator blocks above that resolution get no encoder
+  skip (and their first conv no skip channels); outputs and generator gradients against the oracle, fp32."""
+  cfg, rcfg, tr, Pref, dev, ref = make(dict(hw=32, max_ch=16, unet_max_concat_hw=8), 'fp32', seed=5, batch=2)
+  from twingan_amd import twingan as T
+  assert tr.P['generator/block_8x8x16/Conv/weights'].shape[2] == 32      # 16 + 16 skip channels
+  assert tr.P['generator/block_16x16x16/Conv/weights'].shape[2] == 16     # no skip above 8x8
+  with torch.no_grad():
+    o = T.forward_generators(tr.P, dev['s'], dev['t'], cfg)
+    oref = R.forward_generators(Pref, ref['s'], ref['t'], rcfg)
+  for k in ('s_prime', 't_cycle'):
+    assert rel_l2(o[k], oref[k]) < 2e-5, k
+  tr.store.zero_grad('g')
+  tr._set_requires_grad(g=True, d=False)
+  loss, _ = T.generator_loss(tr.P, dev['s'], dev['t'], cfg)
+  loss.backward()
+  for v in Pref.values():
+    v.requires_grad_(True)
+  lref, _ = R.generator_loss(Pref, ref['s'], ref['t'], rcfg)
+  assert abs(loss.item() - float(lref)) < 1e-4 * max(1.0, abs(float(lref)))
+  gref = R.grads_of(lref, Pref, R.generator_var_names(Pref))
+  gd = tr.store.grad_dict()
+  num = sum(float(((gd[k].double().cpu() - gref[k]) ** 2).sum()) for k in gref)
+  den = sum(float((gref[k] ** 2).sum()) for k in gref)
+  assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
 
 
 def test_full_size_properties_256_bf16():

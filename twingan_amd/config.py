@@ -11,6 +11,7 @@ class Config:
   generator_norm_type: str = 'instance_norm'   # nets/pggan.py:24: instance_norm (north star) | batch_norm | batch_renorm
   do_pixel_norm: bool = True          # nets/pggan.py:34-38
   use_unet: bool = True               # twingan.py:53-56
+  unet_max_concat_hw: object = None   # --pggan_unet_max_concat_hw (nets/pggan.py:57-59): no UNet skip above this hw
   equalized_learning_rate: bool = False   # nets/pggan.py:39-41; nets/pggan_utils.py:82-84,236-254
   use_res_block: bool = False         # nets/pggan.py:43-46; nets/pggan_utils.py:257-264,334-342
   spectral_norm: bool = False         # nets/pggan.py:28-30; libs/sn.py:38-101 (discriminator convs)

@@ -276,7 +276,8 @@ def declare_twingan(store, cfg):
     oc = get_num_channels(stage, mc)
     if stage == ms and cfg.is_growing:
       store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (cur // 2, cur // 2), 1, c, 3, 'g', False, nd, norm_scope=ns, **gen_kw)
-    cin = c + (get_num_channels(stage - 1, mc) if cfg.use_unet else 0)
+    skip = cfg.use_unet and not (cfg.unet_max_concat_hw and cur > cfg.unet_max_concat_hw)      # pggan_utils.py:287-289
+    cin = c + (get_num_channels(stage - 1, mc) if skip else 0)
     blk = 'generator/block_%dx%dx%d' % (cur, cur, oc)
     store.add_conv(blk + '/Conv', 3, cin, oc, 'g', False, nd, norm_scope=ns, **gen_kw)
     store.add_conv(blk + '/Conv_1', 3, oc, oc, 'g', False, nd, norm_scope=ns, **gen_kw)

@@ -298,9 +298,10 @@ def resize_twice_as_big(x):
   return ops.upsample2x_concat(x, None)
 
 
-def maybe_concat_unet_layer(layer_hw, unet_end_points, max_ch):
-  """nets/pggan_utils.py:281-298: pick the encoder end-point to concatenate at resolution hw."""
-  if unet_end_points is None:
+def maybe_concat_unet_layer(layer_hw, unet_end_points, max_ch, max_concat_hw=None):
+  """nets/pggan_utils.py:281-298: pick the encoder end-point to concatenate at resolution hw (none above
+  --pggan_unet_max_concat_hw)."""
+  if unet_end_points is None or (max_concat_hw and layer_hw > max_concat_hw):
     return None
   num_channels = get_num_channels(max_stage_of(layer_hw) - 1, max_ch)
   name = 'encoder_block_interpolated_%dx%dx%d' % (layer_hw, layer_hw, num_channels)
@@ -403,7 +404,7 @@ def generator(P, source, domain, cfg, unet_end_points=None, top='generator', une
         end_points[rgb] = net_before_growth
       # generator_three_layer_block: upsample -> concat(UNet) -> conv -> conv  (pggan.py:69-83)
       # unet_groups = (gsz, perm): batched passes read the skip tensors of the encoder batch by group permutation
-      skip = maybe_concat_unet_layer(hw, unet_end_points, cfg.max_ch)
+      skip = maybe_concat_unet_layer(hw, unet_end_points, cfg.max_ch, cfg.unet_max_concat_hw)
       gsz, perm = unet_groups if (skip is not None and unet_groups is not None) else (0, ())
       w0 = P['%s/%s/Conv/weights' % (top, name)]
       if not (cfg.use_res_block or cfg.equalized_learning_rate) and ops.upcat_conv_supported(net, skip, w0):
