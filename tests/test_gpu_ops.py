@@ -113,6 +113,8 @@ MFMA_CASES = [
     (2, 8, 8, 512, 256, 3, 'SAME'),
     (1, 16, 16, 256, 64, 3, 'SAME'),
     (1, 32, 32, 64, 16, 3, 'SAME'),
+    (2, 16, 16, 128, 128, 3, 'SAME'),
+    (2, 16, 32, 256, 256, 3, 'SAME'),
     (5, 4, 4, 264, 256, 3, 'SAME'),      # D tail conv after minibatch-stddev padding
     (5, 4, 4, 64, 64, 4, 'VALID'),       # dense rewrite of the 4x4 VALID conv
     (16, 4, 4, 256, 256, 4, 'VALID'),
