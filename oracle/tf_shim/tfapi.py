@@ -4,7 +4,6 @@ Each function restates the documented TF-1.8 behaviour of the op of the same nam
 non-obvious ones say which TF behaviour they follow."""
 import contextlib
 import functools
-import math
 import sys
 import types
 
@@ -964,7 +963,6 @@ def build_modules():
   fw_ops = _module('tensorflow.contrib.framework.python.ops', add_arg_scope=add_arg_scope, arg_scope=arg_scope,
                    variables=fw_variables, has_arg_scope=has_arg_scope)
   fw_py = _module('tensorflow.contrib.framework.python', ops=fw_ops)
-  arg_scope_mod = arg_scope
   framework = _module('tensorflow.contrib.framework', arg_scope=arg_scope, add_arg_scope=add_arg_scope,
                       python=fw_py, model_variable=model_variable, get_or_create_global_step=get_or_create_global_step,
                       get_variables=lambda scope=None, suffix=None, collection='variables': core.get_collection(

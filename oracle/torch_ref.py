@@ -12,7 +12,7 @@ image_generation.py:318-439,543-662,1001-1006, model/model_inheritor.py:537-542,
 deployment/model_deploy.py:242-315.
 """
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 
 import torch
 import torch.nn.functional as F

@@ -12,7 +12,6 @@ deployment/model_deploy.py:242-315,473-503 -- with two deliberate scheduling dif
     (model_deploy.py:265-268).
 """
 import ctypes
-import math
 
 import dataclasses
 
