@@ -110,7 +110,8 @@ def flags_of(cfg):
     spectral_norm=cfg.spectral_norm, do_self_attention=cfg.do_self_attention, self_attention_hw=cfg.self_attention_hw,
     use_style_embedding=cfg.use_style_embedding, style_embed_size=cfg.style_embed_size,
     equalized_learning_rate=cfg.equalized, use_res_block=cfg.res_block,
-    pggan_unet_max_concat_hw=getattr(cfg, 'unet_max_concat_hw', None))
+    pggan_unet_max_concat_hw=getattr(cfg, 'unet_max_concat_hw', None),
+    spectral_norm_in_non_discriminator=getattr(cfg, 'sn_non_disc', False))
 
 
 def global_step_of(cfg):

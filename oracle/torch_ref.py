@@ -46,6 +46,7 @@ class Config:
   bn_state: object = None            # dict collecting the BatchNorm moving (and renorm) statistics when set
   global_step: int = 0               # batch renorm clipping schedule (nets/pggan_utils.py:207-223)
   spectral_norm: bool = False        # nets/pggan.py:28-30 (discriminator convs; libs/sn.py:38-101)
+  sn_non_disc: bool = False          # spectral_norm_in_non_discriminator (nets/pggan.py:31-33): encoder / generator convs too
   sn_state: object = None            # dict scope -> u [1, cout] (libs/sn.py:56-57); updated by end_run()
   sn_cache: object = None            # per-run normalised kernels: every use in a run sees the pre-run u
   do_self_attention: bool = False    # image_generation.py:62-64
@@ -372,7 +373,7 @@ def resblock(P, blk, input_layer, out_channels, conv_out, cfg):
     return conv_out
   if input_layer.shape[-1] == out_channels:
     return input_layer + conv_out
-  w = spectral_normed_weight(P, blk + '/shortcut', cfg) if blk.startswith('discriminator') else P[blk + '/shortcut/weights']
+  w = spectral_normed_weight(P, blk + '/shortcut', cfg, blk.startswith('discriminator'))
   sc = conv2d(equalize(input_layer, cfg, 1), w, 'SAME') + P[blk + '/shortcut/biases']
   return sc + conv_out
 
@@ -382,12 +383,12 @@ def l2_normalize(x):
   return x / x.pow(2).sum().clamp_min(1e-12).sqrt()
 
 
-def spectral_normed_weight(P, scope, cfg):
+def spectral_normed_weight(P, scope, cfg, is_discriminator=True):
   """libs/sn.py:38-101 with num_iters=1: v = l2n(u W^T), u' = l2n(v W), sigma = v W u'^T, W_bar = W / sigma; the
   gradient flows through v, u' and sigma.  The reference assigns u at every use of W in unspecified order within a
   session.run; this restatement fixes the schedule "every use in a run reads the pre-run u" (see end_run)."""
   w = P[scope + '/weights']
-  if not cfg.spectral_norm:
+  if not (cfg.spectral_norm and (is_discriminator or cfg.sn_non_disc)):      # nets/pggan_utils.py:316-320
     return w
   if cfg.sn_cache is None:
     cfg.sn_cache = {}
@@ -411,13 +412,14 @@ def end_run(cfg):
     cfg.sn_cache.clear()
 
 
-def init_sn_state(P, seed=0):
+def init_sn_state(P, seed=0, non_disc=False):
   """u ~ truncated normal [1, cout] for every discriminator conv kernel (libs/sn.py:56-57); the attention convs and
   the fully connected layer are not spectrally normed (libs/self_attention.py:33-58; libs/ops.py:37-40)."""
   g = torch.Generator().manual_seed(seed)
   st = {}
   for k in sorted(P):
-    if k.startswith('discriminator') and k.endswith('/weights') and P[k].dim() == 4 and '/self_attention_' not in k:
+    if (non_disc or k.startswith('discriminator')) and k.endswith('/weights') and P[k].dim() == 4 and \
+        '/self_attention_' not in k:
       t = torch.empty(1, P[k].shape[-1], dtype=torch.float32)
       torch.nn.init.trunc_normal_(t, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=g)
       st[k[:-len('/weights')] + '/u'] = t.double()
@@ -433,7 +435,8 @@ def self_attention(P, sc, layer, domain, cfg, is_discriminator, cond=None):
     if is_discriminator:
       y = conv2d(layer, P[scope + '/weights'], 'SAME') + P[scope + '/biases']
     else:
-      y = ge_conv(P, scope, layer, domain, cfg, k=1, act=False, pixnorm=False, equalized=False, cond=cond)
+      y = ge_conv(P, scope, layer, domain, cfg, k=1, act=False, pixnorm=False, equalized=False, cond=cond,
+                  spectral=False)      # libs/self_attention.py:33-58 calls sn.convolution without do_spec_norm
     outs.append(torch.tanh(y) if nm != 'sa_h' else y)
   f, g, h = outs
   npos = hh * ww
@@ -452,10 +455,12 @@ def maybe_self_attention(P, top, hw, name_c, net, ep, domain, cfg, is_discrimina
   return net
 
 
-def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=True, equalized=True, cond=None):
+def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=True, equalized=True, cond=None,
+            spectral=True):
   """Generator/encoder conv: no bias (a normalizer is set), per-domain instance norm,
   LeakyReLU, optional pixel norm (nets/pggan.py:78-81,387-391)."""
-  y = conv2d(equalize(x, cfg, k) if equalized else x, P[scope + '/weights'], padding)
+  w = spectral_normed_weight(P, scope, cfg, False) if spectral else P[scope + '/weights']
+  y = conv2d(equalize(x, cfg, k) if equalized else x, w, padding)
   if cfg.norm == 'instance_norm' and cond is not None:
     # conditional parameters (libs/instance_norm.py:93-120): gamma = 1 + FC(cond), beta = FC(cond), one row per image
     pre = scope + '/InstanceNorm/'

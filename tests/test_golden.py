@@ -34,7 +34,7 @@ MODELS = {'twingan_hw16_c8': dict(hw=16, max_ch=8), 'twingan_hw64_c8': dict(hw=6
                                           self_attention_hw=8)}
 # oracle Config field -> product Config field where the names differ
 PRODUCT_FIELD = dict(loss='loss_architecture', equalized='equalized_learning_rate', res_block='use_res_block',
-                     norm='generator_norm_type')
+                     norm='generator_norm_type', sn_non_disc='spectral_norm_in_non_discriminator')
 
 
 def product_kw(name):

@@ -31,7 +31,7 @@ def make(cfg_kw, precision, seed=0, batch=3):
                   spectral_norm=cfg.spectral_norm, do_self_attention=cfg.do_self_attention,
                   self_attention_hw=cfg.self_attention_hw, loss=cfg.loss_architecture,
                   use_style_embedding=cfg.use_style_embedding, style_embed_size=cfg.style_embed_size,
-                  unet_max_concat_hw=cfg.unet_max_concat_hw)
+                  unet_max_concat_hw=cfg.unet_max_concat_hw, sn_non_disc=cfg.spectral_norm_in_non_discriminator)
   Pref = R.init_params(rcfg, seed=seed, dtype=torch.float64, std='he')
   tr = Trainer(cfg, device='cuda:0', seed=seed)
   tr.store.load_state_dict({k: v.float() for k, v in Pref.items()})
@@ -627,6 +627,38 @@ def test_spectral_norm_and_self_attention(loss):
     _grads_close(tr, Pref, tr.store.names('d'), 8e-2, 'discriminator run %d' % it)
     for k, v in rcfg.sn_state.items():
       assert rel_l2(tr.store.state[k], v) < 1e-4, (it, k)
+
+
+def test_spectral_norm_in_encoder_and_generator():
+  """--spectral_norm_in_non_discriminator (nets/pggan.py:31-33): the encoder / generator conv kernels (incl. from-RGB,
+  to-RGB and the residual shortcuts) are spectrally normalised too; generator loss terms, gradients through sigma and
+  the power-iteration vectors after the run, against the oracle (which is pinned against the reference for this flag:
+  tests/test_reference_live.py::sn_everywhere)."""
+  from twingan_amd import pggan
+  from twingan_amd import twingan as T
+  kw = dict(hw=16, max_ch=16, spectral_norm=True, spectral_norm_in_non_discriminator=True, use_res_block=True)
+  cfg, rcfg, tr, Pref, dev, ref = make(kw, 'fp32', seed=8, batch=2)
+  rcfg.sn_state = R.init_sn_state(Pref, seed=4, non_disc=True)
+  assert set(rcfg.sn_state) == set(tr.store.state), sorted(set(rcfg.sn_state) ^ set(tr.store.state))[:6]
+  assert any(k.startswith('generator/') for k in rcfg.sn_state) and any('/shortcut/u' in k for k in rcfg.sn_state)
+  for k, v in rcfg.sn_state.items():
+    tr.store.state[k].copy_(v.float())
+    rcfg.sn_state[k] = v.float().double()
+  for v in Pref.values():
+    v.requires_grad_(True)
+  tr.store.zero_grad('g')
+  tr._set_requires_grad(g=True, d=False)
+  gl, gterms = T.generator_loss(tr.P, dev['s'], dev['t'], cfg)
+  rgl, rterms = R.generator_loss(Pref, ref['s'], ref['t'], rcfg)
+  for k in rterms:
+    assert abs(gterms[k].item() - rterms[k].item()) < 1e-4 * max(1.0, abs(rterms[k].item())), k
+  gl.backward()
+  rgl.backward()
+  pggan.end_run(tr.P)
+  R.end_run(rcfg)
+  _grads_close(tr, Pref, tr.store.names('g'), 8e-2, 'generator run')
+  for k, v in rcfg.sn_state.items():
+    assert rel_l2(tr.store.state[k], v) < 1e-4, k
 
 
 def test_spectral_norm_attention_bf16_graph_step_runs():

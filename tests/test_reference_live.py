@@ -26,6 +26,7 @@ CASES = {
   'batch_renorm_step25000': dict(hw=16, max_ch=8, norm='batch_renorm', global_step=25000),
   'batch_norm': dict(hw=16, max_ch=8, norm='batch_norm'),
   'sn_hinge': dict(hw=16, max_ch=8, spectral_norm=True, loss='hinge'),
+  'sn_everywhere': dict(hw=16, max_ch=8, spectral_norm=True, sn_non_disc=True, res_block=True),
   'attention_in_generator': dict(hw=16, max_ch=16, do_self_attention=True, self_attention_hw=16),
   'style_embed_6': dict(hw=16, max_ch=16, use_style_embedding=True, style_embed_size=6),
   # conditional BATCH norm is the style configuration the reference can actually build for a batch > 1
@@ -39,7 +40,7 @@ def test_oracle_matches_live_reference(name):
   cfg = R.Config(**CASES[name])
   batch = 1 if (cfg.use_style_embedding and cfg.norm == 'instance_norm') else 2      # see tools/make_golden.py::CASES
   P = R.init_params(cfg, seed=11, dtype=torch.float64, std='he')
-  state = R.init_sn_state(P, seed=12) if cfg.spectral_norm else {}
+  state = R.init_sn_state(P, seed=12, non_disc=cfg.sn_non_disc) if cfg.spectral_norm else {}
   rng = np.random.RandomState(13)
   s, t = rng.rand(batch, cfg.hw, cfg.hw, 3), rng.rand(batch, cfg.hw, cfg.hw, 3)
   preset = {k: v.numpy() for k, v in list(P.items()) + list(state.items())}
