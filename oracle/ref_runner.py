@@ -111,7 +111,8 @@ def flags_of(cfg):
     use_style_embedding=cfg.use_style_embedding, style_embed_size=cfg.style_embed_size,
     equalized_learning_rate=cfg.equalized, use_res_block=cfg.res_block,
     pggan_unet_max_concat_hw=getattr(cfg, 'unet_max_concat_hw', None),
-    spectral_norm_in_non_discriminator=getattr(cfg, 'sn_non_disc', False))
+    spectral_norm_in_non_discriminator=getattr(cfg, 'sn_non_disc', False),
+    pggan_max_num_channels_dis=getattr(cfg, 'max_ch_dis', None))
 
 
 def global_step_of(cfg):

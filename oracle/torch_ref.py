@@ -23,6 +23,7 @@ class Config:
   """The flags that shape the hot path (defaults = BASELINE.json / SURVEY.md section 8d)."""
   hw: int = 256                      # train_image_size
   max_ch: int = 256                  # pggan_max_num_channels            (nets/pggan.py:51-53)
+  max_ch_dis: object = None          # pggan_max_num_channels_dis        (nets/pggan.py:54-56; pggan_utils.py:375-380)
   norm: str = 'instance_norm'        # generator_norm_type               (nets/pggan.py:24)
   do_pixel_norm: bool = True         # nets/pggan.py:34-38
   use_unet: bool = True              # twingan.py:53-56
@@ -166,12 +167,13 @@ def init_params(cfg, seed=0, dtype=torch.float32, std=0.02):
   for s in generator_param_specs('generator', cfg.hw, cfg.max_ch, cfg.use_unet, cfg.is_growing, cfg.unet_max_concat_hw):
     _conv_p(P, g, s[0], s[1], s[2], s[3], ('s', 't') if cfg.norm in NORM_SCOPE else (), False, dtype, std,
             NORM_SCOPE.get(cfg.norm, ''))
+  md = cfg.max_ch_dis or cfg.max_ch
   for top in ('discriminator_s', 'discriminator_t'):
-    for s in encoder_param_specs(top, cfg.hw, cfg.max_ch, cfg.is_growing) + discriminator_tail_specs(top, cfg.max_ch):
+    for s in encoder_param_specs(top, cfg.hw, md, cfg.is_growing) + discriminator_tail_specs(top, md):
       _conv_p(P, g, s[0], s[1], s[2], s[3], (), True, dtype, std)
     P[top + '/prediction/fully_connected/weights'] = \
-        torch.randn(cfg.max_ch, 1, generator=g, dtype=torch.float32).to(dtype) * \
-        (math.sqrt(1.0 / cfg.max_ch) if std == 'he' else std)
+        torch.randn(md, 1, generator=g, dtype=torch.float32).to(dtype) * \
+        (math.sqrt(1.0 / md) if std == 'he' else std)
     P[top + '/prediction/fully_connected/biases'] = torch.zeros(1, dtype=dtype)
   if cfg.do_self_attention:      # libs/self_attention.py:24-70 under each network's arg-scope; sa_gamma starts at 0
     ms = max_stage_of(cfg.hw)
@@ -189,10 +191,11 @@ def init_params(cfg, seed=0, dtype=torch.float32, std=0.02):
     if cfg.use_style_embedding:
       tops.append(('encoder_style', False, nd))
     for top, bias, domains in tops:
-      c = get_num_channels(ms, cfg.max_ch)
+      mt = md if top.startswith('discriminator') else cfg.max_ch
+      c = get_num_channels(ms, mt)
       for stage in range(ms, 0, -1):
-        att(top, cfg.hw // (2 ** (ms - stage)), c, get_num_channels(stage - 1, cfg.max_ch), bias, domains)
-        c = get_num_channels(stage - 1, cfg.max_ch)
+        att(top, cfg.hw // (2 ** (ms - stage)), c, get_num_channels(stage - 1, mt), bias, domains)
+        c = get_num_channels(stage - 1, mt)
     for stage in range(0, ms + 1):
       att('generator', 2 ** (stage + 2), get_num_channels(stage, cfg.max_ch), get_num_channels(stage, cfg.max_ch), False, nd)
   if cfg.use_style_embedding:    # twingan.py:47-51: style encoder (pggan.encoder) + generator norms conditioned on its output
@@ -217,8 +220,8 @@ def init_params(cfg, seed=0, dtype=torch.float32, std=0.02):
     ge = encoder_param_specs('encoder_content', cfg.hw, cfg.max_ch, cfg.is_growing) + \
         generator_param_specs('generator', cfg.hw, cfg.max_ch, cfg.use_unet, cfg.is_growing, cfg.unet_max_concat_hw)
     dd = [sp for top in ('discriminator_s', 'discriminator_t')
-          for sp in encoder_param_specs(top, cfg.hw, cfg.max_ch, cfg.is_growing)]
-    for sp in shortcut_specs(ge, cfg.hw, cfg.max_ch) + shortcut_specs(dd, cfg.hw, cfg.max_ch):
+          for sp in encoder_param_specs(top, cfg.hw, md, cfg.is_growing)]
+    for sp in shortcut_specs(ge, cfg.hw, cfg.max_ch) + shortcut_specs(dd, cfg.hw, md):
       _conv_p(P, g, sp[0], 1, sp[2], sp[3], (), True, dtype, std)
   if he:
     for k in sorted(P):
@@ -631,7 +634,7 @@ def discriminator(P, x, cfg, top):
   net = resblock(P, '%s/%s' % (top, name), x, net.shape[-1], net, cfg)
   ep[name] = net
   for stage in range(ms, 0, -1):
-    nc = get_num_channels(stage - 1, cfg.max_ch)
+    nc = get_num_channels(stage - 1, cfg.max_ch_dis or cfg.max_ch)
     cur = hw // (2 ** (ms - stage))
     net = maybe_self_attention(P, top, cur, nc, net, ep, None, cfg, True)   # nets/pggan.py:294-296
     name = 'encoder_block_%dx%dx%d' % (cur, cur, nc)
@@ -643,7 +646,7 @@ def discriminator(P, x, cfg, top):
     net = avg_pool2(net)
     if stage == ms and cfg.is_growing:
       net = net * cfg.alpha_grow + (1 - cfg.alpha_grow) * shr
-  blk = '%s/before_fc_1x1x%d' % (top, cfg.max_ch)
+  blk = '%s/before_fc_1x1x%d' % (top, cfg.max_ch_dis or cfg.max_ch)
   net = minibatch_state_concat(net)
   net = d_conv(P, blk + '/Conv', net, cfg, k=3, padding='SAME')
   net = d_conv(P, blk + '/Conv_1', net, cfg, k=4, padding='VALID')

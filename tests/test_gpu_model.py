@@ -31,7 +31,8 @@ def make(cfg_kw, precision, seed=0, batch=3):
                   spectral_norm=cfg.spectral_norm, do_self_attention=cfg.do_self_attention,
                   self_attention_hw=cfg.self_attention_hw, loss=cfg.loss_architecture,
                   use_style_embedding=cfg.use_style_embedding, style_embed_size=cfg.style_embed_size,
-                  unet_max_concat_hw=cfg.unet_max_concat_hw, sn_non_disc=cfg.spectral_norm_in_non_discriminator)
+                  unet_max_concat_hw=cfg.unet_max_concat_hw, sn_non_disc=cfg.spectral_norm_in_non_discriminator,
+                  max_ch_dis=cfg.max_ch_dis)
   Pref = R.init_params(rcfg, seed=seed, dtype=torch.float64, std='he')
   tr = Trainer(cfg, device='cuda:0', seed=seed)
   tr.store.load_state_dict({k: v.float() for k, v in Pref.items()})
@@ -307,6 +308,27 @@ def test_unet_max_concat_hw_matches_oracle():
   num = sum(float(((gd[k].double().cpu() - gref[k]) ** 2).sum()) for k in gref)
   den = sum(float((gref[k] ** 2).sum()) for k in gref)
   assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
+
+
+def test_discriminator_max_channels_matches_oracle():
+  """--pggan_max_num_channels_dis (nets/pggan.py:54-56; pggan_utils.py:375-380): the discriminators get their own channel
+  cap (schedule, before_fc scope name, minibatch-stddev pad, prediction FC); D loss terms and gradients incl. the
+  gradient penalty against the oracle (pinned against the reference for this flag: tests/test_reference_live.py)."""
+  cfg, rcfg, tr, Pref, dev, ref = make(dict(hw=32, max_ch=32, max_ch_dis=16), 'fp32', seed=9, batch=2)
+  from twingan_amd import twingan as T
+  assert 'discriminator_s/before_fc_1x1x16/Conv/weights' in tr.store.specs
+  assert tr.store.specs['discriminator_t/prediction/fully_connected/weights']['shape'] == (16, 1)
+  tr.store.zero_grad('d')
+  tr._set_requires_grad(g=False, d=True)
+  dl, dterms = T.discriminator_loss(tr.P, dev['s'], dev['t'], cfg, dev['a_s'], dev['a_t'])
+  for v in Pref.values():
+    v.requires_grad_(True)
+  rdl, rterms = R.discriminator_loss(Pref, ref['s'], ref['t'], rcfg, ref['a_s'], ref['a_t'])
+  for k in rterms:
+    assert abs(dterms[k].item() - rterms[k].item()) < 1e-4 * max(1.0, abs(rterms[k].item())), k
+  dl.backward()
+  rdl.backward()
+  _grads_close(tr, Pref, tr.store.names('d'), 8e-2, 'discriminator')
 
 
 def test_full_size_properties_256_bf16():

@@ -17,6 +17,7 @@ CASES = {
   'wgan_drift': dict(hw=16, max_ch=8, loss='wgan', drift=0.001),
   'hinge_64': dict(hw=64, max_ch=8, loss='hinge'),
   'no_unet_no_pixel_norm': dict(hw=16, max_ch=8, use_unet=False, do_pixel_norm=False),
+  'max_ch_dis': dict(hw=32, max_ch=16, max_ch_dis=8, do_self_attention=True, self_attention_hw=16, res_block=True),
   'unet_max_concat_hw': dict(hw=32, max_ch=16, unet_max_concat_hw=8),
   'no_cycle_gan_no_content': dict(hw=64, max_ch=8, do_l_cyc_gan=False, l_content=0.0),
   'weights': dict(hw=16, max_ch=8, gan_weight=0.7, l_cyc=2.0, l_content=0.3, gp_lambda=5.0),

@@ -294,6 +294,7 @@ SCHEMAS = {      # full-width configurations of BASELINE.json, run once through 
   'hw32_c128_eqlr_res': dict(hw=32, max_ch=128, equalized=True, res_block=True),
   'hw32_c64_style_bn': dict(hw=32, max_ch=64, use_style_embedding=True, style_embed_size=16, norm='batch_norm'),
   'hw64_c64_unet_max16': dict(hw=64, max_ch=64, unet_max_concat_hw=16),
+  'hw64_c64_dis32': dict(hw=64, max_ch=64, max_ch_dis=32, res_block=True),
   'hw32_c32_sn_everywhere_res': dict(hw=32, max_ch=16, spectral_norm=True, sn_non_disc=True, res_block=True),
 }
 

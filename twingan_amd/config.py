@@ -8,6 +8,7 @@ from dataclasses import dataclass
 class Config:
   hw: int = 256                       # --train_image_size (pggan_runner.py:136-150)
   max_ch: int = 256                   # --pggan_max_num_channels           nets/pggan.py:51-53
+  max_ch_dis: object = None           # --pggan_max_num_channels_dis (nets/pggan.py:54-56): discriminators only; None = max_ch
   generator_norm_type: str = 'instance_norm'   # nets/pggan.py:24: instance_norm (north star) | batch_norm | batch_renorm
   do_pixel_norm: bool = True          # nets/pggan.py:34-38
   use_unet: bool = True               # twingan.py:53-56

@@ -235,7 +235,7 @@ def declare_twingan(store, cfg):
     if cfg.use_res_block and cin != cout:
       store.add_conv(blk + '/shortcut', 1, cin, cout, group, True, ())
 
-  def enc_skeleton(top, group, bias, norm_domains):
+  def enc_skeleton(top, group, bias, norm_domains, mc=mc):
     if cfg.is_growing:
       store.add_conv('%s/from_rgb_%dx%d/Conv' % (top, hw // 2, hw // 2), 1, 3, get_num_channels(ms - 1, mc), group, bias,
                      norm_domains, norm_scope=ns)
@@ -287,11 +287,12 @@ def declare_twingan(store, cfg):
   store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (hw, hw), 1, c, 3, 'g', False, nd, norm_scope=ns, **gen_kw)
   # discriminators
   for top in ('discriminator_s', 'discriminator_t'):
-    enc_skeleton(top, 'd', True, ())
-    blk = '%s/before_fc_1x1x%d' % (top, mc)
-    store.add_conv(blk + '/Conv', 3, mc + 1, mc, 'd', True, (), phys_cin=mbstd_cpad(mc))
-    store.add_conv(blk + '/Conv_1', 4, mc, mc, 'd', True, ())
-    store.add(top + '/prediction/fully_connected/weights', (mc, 1), 'd', 'fc_w')
+    md = cfg.max_ch_dis or mc      # get_discriminator_max_num_channels (nets/pggan_utils.py:375-380)
+    enc_skeleton(top, 'd', True, (), md)
+    blk = '%s/before_fc_1x1x%d' % (top, md)
+    store.add_conv(blk + '/Conv', 3, md + 1, md, 'd', True, (), phys_cin=mbstd_cpad(md))
+    store.add_conv(blk + '/Conv_1', 4, md, md, 'd', True, ())
+    store.add(top + '/prediction/fully_connected/weights', (md, 1), 'd', 'fc_w')
     store.add(top + '/prediction/fully_connected/biases', (1,), 'd', 'bias')
   store.add_conv = _add_conv
   return store

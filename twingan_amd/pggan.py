@@ -438,6 +438,7 @@ def discriminator_before_fc(P, source, cfg, top, groups=1):
   hw = source.shape[1]
   max_stage = max_stage_of(hw)
   assert max_stage >= 0
+  max_ch = cfg.max_ch_dis or cfg.max_ch      # get_discriminator_max_num_channels (nets/pggan_utils.py:375-380)
   end_points = {}
   shrinked = None
   if cfg.is_growing:
@@ -451,7 +452,7 @@ def discriminator_before_fc(P, source, cfg, top, groups=1):
   net = maybe_resblock(P, '%s/%s' % (top, name), source, net.shape[-1], net, cfg, True)
   end_points[name] = net
   for stage in range(max_stage, 0, -1):
-    num_channels = get_num_channels(stage - 1, cfg.max_ch)
+    num_channels = get_num_channels(stage - 1, max_ch)
     current_hw = hw // (2 ** (max_stage - stage))
     net = maybe_add_self_attention(P, top, current_hw, num_channels, net, end_points, None, cfg, True)   # pggan.py:294-296
     name = 'encoder_block_%dx%dx%d' % (current_hw, current_hw, num_channels)
@@ -468,9 +469,9 @@ def discriminator_before_fc(P, source, cfg, top, groups=1):
     if stage == max_stage and cfg.is_growing:
       net = ops.lerp(net, shrinked, cfg.alpha_grow)
       end_points['encoder_block_interpolated_%dx%dx%d' % (current_hw, current_hw, num_channels)] = net
-  blk = 'before_fc_1x1x%d' % cfg.max_ch
+  blk = 'before_fc_1x1x%d' % max_ch
   net = ops.minibatch_state_concat(net, mbstd_cpad(net.shape[3]), groups)      # pggan_utils.py:353-366
-  net = _d_conv(P, '%s/%s/Conv' % (top, blk), net, cfg, k=3, padding='SAME', in_ch=cfg.max_ch + 1)
+  net = _d_conv(P, '%s/%s/Conv' % (top, blk), net, cfg, k=3, padding='SAME', in_ch=max_ch + 1)
   net = _d_conv(P, '%s/%s/Conv_1' % (top, blk), net, cfg, k=4, padding='VALID', sole_consumer=True)
   end_points[blk] = net
   end_points['before_fc'] = net
