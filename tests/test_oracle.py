@@ -365,3 +365,49 @@ def test_batch_norm_np_vs_torch_and_moving_average():
   c = np.tile(np.arange(8.0), (2, 3, 3, 1))
   yc, _, _ = R.batch_norm_train(torch.from_numpy(c), torch.from_numpy(ga), torch.from_numpy(be))
   assert np.allclose(yc.numpy(), np.broadcast_to(be, c.shape), atol=1e-9)
+
+
+def test_tf_stand_in_primitives_agree_with_numpy_restatement():
+  """The TensorFlow stand-in that executes the reference's source (oracle/tf_shim) and the float64 NumPy oracle
+  (oracle/np_ops.py) restate the same TensorFlow ops independently (torch vs hand-written NumPy loops): they must
+  agree to round-off -- conv2d (SAME / VALID, k = 1, 3, 4), avg_pool, nearest upsampling, moments + batch_normalization,
+  l2_normalize, tf.losses reductions, Adam."""
+  from oracle import np_ops as N
+  from oracle.tf_shim import core, tfapi
+  core.STATE.reset(0)
+  r = np.random.RandomState(11)
+  T = lambda a: core.Tensor(torch.tensor(np.asarray(a, np.float64)))
+  close = lambda a, b, tol=1e-12: np.abs(np.asarray(a) - np.asarray(b)).max() < tol
+  x = r.randn(2, 8, 8, 5)
+  for k, pad in ((1, 'SAME'), (3, 'SAME'), (4, 'VALID'), (4, 'SAME'), (3, 'VALID')):
+    w = r.randn(k, k, 5, 7)
+    if pad == 'SAME' and k == 4:
+      continue      # np_ops restates only the paddings the hot path uses
+    assert close(tfapi.nn_conv2d(T(x), T(w), [1, 1, 1, 1], pad).t.numpy(), N.conv2d(x, w, pad)), (k, pad)
+  assert close(tfapi.nn_avg_pool(T(x), (1, 2, 2, 1), (1, 2, 2, 1), 'VALID').t.numpy(), N.avg_pool2(x))
+  assert close(tfapi.image_resize_nearest(T(x), (16, 16)).t.numpy(), N.upsample2x(x))
+  gamma, beta = 1 + 0.1 * r.randn(5), 0.1 * r.randn(5)
+  mean, var = tfapi.nn_moments(T(x), [1, 2], keep_dims=True)
+  inorm = tfapi.nn_batch_normalization(T(x), mean, var, T(beta), T(gamma), 1e-6)
+  assert close(inorm.t.numpy(), N.instance_norm(x, gamma, beta))
+  mean, var = tfapi.nn_moments(T(x), [0, 1, 2])
+  bnorm = tfapi.nn_batch_normalization(T(x), mean, var, T(beta), T(gamma), 1e-3)
+  ref_bn = N.batch_norm_train(x, gamma, beta)
+  assert close(bnorm.t.numpy(), ref_bn[0] if isinstance(ref_bn, tuple) else ref_bn)
+  a, b = r.rand(2, 4, 4, 3), r.rand(2, 4, 4, 3)
+  assert abs(float(tfapi.absolute_difference(T(a), T(b), weights=0.7, loss_collection=None).t) -
+             N.absolute_difference(a, b, 0.7)) < 1e-14
+  logits, labels = r.randn(6, 1), np.ones((6, 1))
+  assert abs(float(tfapi.sigmoid_cross_entropy(T(labels), T(logits), weights=0.3, loss_collection=None).t) -
+             N.sigmoid_cross_entropy(labels, logits, 0.3)) < 1e-14
+  # Adam: three applies of the stand-in optimizer == three np_ops.adam_step with t = 1, 2, 3
+  theta0 = r.randn(9)
+  v = core.get_variable('adam_probe', [9], core.float32, core.constant_initializer(theta0))
+  opt = tfapi.AdamOptimizer(1e-3, beta1=0.5, beta2=0.99, epsilon=1e-8)
+  th, m, vv = theta0.copy(), np.zeros(9), np.zeros(9)
+  for t in range(1, 4):
+    g = r.randn(9)
+    opt.apply_gradients([(T(g), v)])
+    th, m, vv = N.adam_step(th, g, m, vv, t, lr=1e-3, beta1=0.5, beta2=0.99, eps=1e-8)
+    assert close(v.t.detach().numpy(), th, 1e-14), t
+  core.STATE.reset(0)
