@@ -28,6 +28,9 @@ HBM_PEAK_GBS = 8000.0              # HBM3E spec (6.3 TB/s achievable)
 GFLOP_PER_PAIR_256 = 335.0         # conv+FC MACs*2 of one G+D step at 256x256
 
 
+METRIC = 'training images/sec (G+D step) at 256\u00d7256 final stage, 1/2/4/8 MI355X'      # BASELINE.json's metric, verbatim
+
+
 def parse():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -242,8 +245,7 @@ def main():
   ms_per_step = 1e3 * elapsed / args.steps
   value = args.batch * world * args.steps / elapsed
   out = {
-      'metric': 'training images/sec (G+D step) at 256x256 final stage' if args.hw == 256 else
-                'training images/sec (G+D step) at %dx%d' % (args.hw, args.hw),
+      'metric': METRIC if args.hw == 256 else 'training images/sec (G+D step) at %dx%d' % (args.hw, args.hw),
       'value': round(value, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
       'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
       'dtype': args.precision, 'data': 'synthetic',

@@ -252,3 +252,36 @@ def test_state_dict_carries_non_trainable_variables():
   assert k_bn not in a.state_dict()
   b.load_state_dict(sd)
   assert torch.equal(b.state[k_bn], a.state[k_bn]) and torch.equal(b.state[k_u], a.state[k_u])
+
+
+def test_bench_line_contract():
+  """The JSON line bench.py printed for the final build of the round (profiles/r01_j_bench.json) carries every field of
+  the driver's contract, the metric of BASELINE.json, and a self-consistent roofline / cpu_baseline; the command line
+  takes --gpus / --steps / --warmup."""
+  import json
+  import os
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  with open(os.path.join(root, 'profiles', 'r01_j_bench.json')) as fh:
+    d = json.load(fh)
+  with open(os.path.join(root, 'BASELINE.json')) as fh:
+    base = json.load(fh)
+  for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+            'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+    assert k in d, k
+  sys.path.insert(0, root)
+  import bench
+  assert bench.METRIC == base['metric']      # the line's metric is BASELINE.json's, verbatim
+  assert d['unit'] == 'images/sec' and d['higher_is_better'] is True
+  assert d['n_gpus'] == 1 and d['scaling'] == 'weak' and d['dtype'] == 'bf16' and d['data'] == 'synthetic'
+  assert d['vs_baseline'] is None and not base['published']      # no published number for this metric
+  assert 'workload' in d['config'] and 'model' not in d['config']
+  assert abs(d['value'] - d['config']['global_batch'] / (d['ms_per_step'] * 1e-3)) < 0.01 * d['value']
+  r = d['roofline']
+  assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s') and r['peak'] in (8000.0, 2500.0)
+  assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and r['traffic'] is None or r['traffic'] > 0
+  c = d['cpu_baseline']
+  assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == d['unit'] and c['sample']
+  src = open(os.path.join(root, 'bench.py')).read()
+  for flag in ('--gpus', '--steps', '--warmup'):
+    assert "'%s'" % flag in src
