@@ -1,8 +1,11 @@
 #!/usr/bin/env python
 """bench.py -- TwinGAN G+D training images/sec at the 256x256 final progressive stage on MI355X.
 
-Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1: one rank per GPU under
-torch.distributed.run, RCCL).  One "step" = one full G+D step = one generator/encoder apply + one
+Contract: ``python bench.py --gpus N --steps K --warmup W``.  N>1: one rank per GPU over RCCL -- either the caller
+launches the ranks (``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...``: WORLD_SIZE is in the
+environment) or, called plainly, this script re-launches itself under torch.distributed.run with N ranks on
+127.0.0.1 (the reference's single-process ``--num_clones=N``, deployment/model_deploy.py:186-239, as one process
+per MI355X).  One "step" = one full G+D step = one generator/encoder apply + one
 discriminator apply (n_critic = 2, image_generation.py:640-652) over one synthetic batch of
 ``--batch`` (source, target) pairs per GPU, inputs resident in HBM.  value = pairs/sec over all ranks.
 
@@ -46,7 +49,61 @@ def parse():
   ap.add_argument('--cpu-batch', type=int, default=2)
   ap.add_argument('--cpu-threads', type=int, default=0, help='0 = min(host cores, 32)')
   ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
+  ap.add_argument('--overlap', default='auto', choices=['auto', 'on', 'off'],
+                  help='segmented backward + overlapped gradient all-reduce (auto: when N > 1)')
+  ap.add_argument('--launch-check', action='store_true',
+                  help='no kernels: bring up the N ranks, build the parameter store and time the per-segment gradient '
+                       'all-reduce schedule of a step (gloo on CPU when no GPU is visible) -- tests the launcher')
   return ap.parse_args()
+
+
+def _free_port():
+  import socket
+  sk = socket.socket()
+  sk.bind(('127.0.0.1', 0))
+  port = sk.getsockname()[1]
+  sk.close()
+  return port
+
+
+def spawn_ranks(n):
+  """``bench.py --gpus N`` without a launcher: re-run this command line as N ranks (torch.distributed.run, local
+  rendezvous on 127.0.0.1); rank 0 prints the JSON line, the exit code is the job's."""
+  import subprocess
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL needs it on this driver
+  env.setdefault('OMP_NUM_THREADS', '8')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+         '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+  return subprocess.call(cmd, env=env)
+
+
+def launch_check(args, world, rank, device):
+  """The data-parallel plumbing of a step without its kernels: per backward segment, the all-reduce of that segment's
+  range of the flat gradient buffer (dp.GradReducer over params.grad_phase ranges), then the sum is checked."""
+  from twingan_amd import Config
+  from twingan_amd.dp import GradReducer
+  from twingan_amd.params import ParamStore, declare_twingan
+  cfg = Config(hw=args.hw, max_ch=args.max_ch, precision=args.precision)
+  store = declare_twingan(ParamStore(device), cfg).build(0)
+  red = GradReducer(world, None)
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    for grp in store.GROUPS:
+      store.grad[grp].fill_(float(rank + 1))
+      for ph in sorted(store.phase_bounds[grp]):
+        lo, hi = store.phase_bounds[grp][ph]
+        red.start(store.grad[grp][lo:hi], n_buckets=1)
+      red.finish()
+      want = world * (world + 1) / 2.0
+      assert float(store.grad[grp].min()) == want and float(store.grad[grp].max()) == want, 'all-reduce sum is wrong'
+  if device.type == 'cuda':
+    torch.cuda.synchronize()
+  dist.barrier() if world > 1 else None
+  dt = time.perf_counter() - t0
+  return dict(ms_per_step=1e3 * dt / max(args.steps, 1),
+              grad_bytes={g: 4 * store.grad[g].numel() for g in store.GROUPS},
+              segments={g: {str(p): list(b) for p, b in store.phase_bounds[g].items()} for g in store.GROUPS})
 
 
 def synthetic_batch(batch, hw, dtype, device, rank):
@@ -195,8 +252,8 @@ def cpu_baseline_child(args):
     dt = time.time() - t0
     if dt > 10.0 or reps >= 8:
       break
-  print(json.dumps(dict(value=round(bsz * reps / dt, 4), unit='images/sec', cores=cores, kind='port',
-                        sample='%d G+D step(s), batch %d at %dx%d, fp32 torch-CPU oracle (oracle/torch_ref.py), efficient '
+  print(json.dumps(dict(value=round(bsz * reps / dt, 4), unit='images/sec', cores=cores, host_cores=os.cpu_count(),
+                        kind='port', sample='%d G+D step(s), batch %d at %dx%d, fp32 torch-CPU oracle (oracle/torch_ref.py), efficient '
                                'schedule, %d threads, %.1f s' % (reps, bsz, args.hw, args.hw, cores, dt))))
 
 
@@ -204,27 +261,68 @@ def main():
   args = parse()
   if args.cpu_baseline_only:
     return cpu_baseline_child(args)
+  if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+    sys.exit(spawn_ranks(args.gpus))
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  have_gpu = torch.cuda.is_available()
+  if not have_gpu and not args.launch_check:
+    raise SystemExit('bench.py needs a GPU (the HIP kernels have no CPU fallback); --launch-check tests the launcher')
+  backend = 'nccl' if have_gpu else 'gloo'
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-  else:
+    if have_gpu:
+      torch.cuda.set_device(local_rank)
+      dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    else:
+      dist.init_process_group(backend, rank=rank, world_size=world)
+  elif have_gpu:
     torch.cuda.set_device(0)
-  device = torch.device('cuda', local_rank if world > 1 else 0)
+  device = torch.device('cuda', local_rank if world > 1 else 0) if have_gpu else torch.device('cpu')
+  observed_world = dist.get_world_size() if world > 1 else 1
+
+  def base_line(value, ms_per_step, launch):
+    return {
+        'metric': METRIC if args.hw == 256 else 'training images/sec (G+D step) at %dx%d' % (args.hw, args.hw),
+        'value': value, 'unit': 'images/sec', 'n_gpus': observed_world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': args.precision, 'data': 'synthetic',
+        'config': {'workload': 'TwinGAN %dx%d final stage (configs[3]): E/G/2xD max_ch %d, UNet + per-domain '
+                               'instance norm + pixel norm, WGAN-GP, Adam; 1 step = G apply + D apply' % (
+                                   args.hw, args.hw, args.max_ch),
+                   'global_batch': args.batch * observed_world, 'batch_per_gpu': args.batch,
+                   'parallelism': 'dp%d' % observed_world, 'launch': launch,
+                   'collective': ('%s all-reduce, world %d' % ('RCCL' if backend == 'nccl' else backend, observed_world))
+                   if world > 1 else None,
+                   'gflop_per_pair_model': GFLOP_PER_PAIR_256 if args.hw == 256 else None},
+    }
+
+  if args.launch_check:
+    info = launch_check(args, world, rank, device)
+    out = base_line(None, round(info['ms_per_step'], 3), 'launch-check (no kernels)')
+    out['launch_check'] = info
+    if rank == 0:
+      print(json.dumps(out))
+    if world > 1:
+      dist.destroy_process_group()
+    return
 
   from twingan_amd import Config
   from twingan_amd.twingan import Trainer
   cfg = Config(hw=args.hw, max_ch=args.max_ch, precision=args.precision)
-  tr = Trainer(cfg, device=device, seed=0, world_size=world, use_graph=not args.no_graph)
+  overlap = None if args.overlap == 'auto' else args.overlap == 'on'
+  tr = Trainer(cfg, device=device, seed=0, world_size=world, use_graph=not args.no_graph, overlap=overlap)
   dtype = torch.bfloat16 if args.precision == 'bf16' else torch.float32
   a, b = synthetic_batch(args.batch, args.hw, dtype, device, rank)
 
-  for _ in range(args.warmup):
+  for _ in range(max(args.warmup, 1)):      # at least one: the first graph-mode step is the capture
     one_step(tr, a, b)
+  if not args.no_graph and not tr.use_graph:
+    # the timed region must be the hipGraph replay the line says it is: never time a silent eager fallback
+    sys.stderr.write('bench.py: hipGraph capture failed on rank %d (%s)\n' % (rank, tr.graph_fallback_reason))
+    sys.exit(3)
   torch.cuda.synchronize()
   if world > 1:
     dist.barrier()
@@ -244,18 +342,8 @@ def main():
 
   ms_per_step = 1e3 * elapsed / args.steps
   value = args.batch * world * args.steps / elapsed
-  out = {
-      'metric': METRIC if args.hw == 256 else 'training images/sec (G+D step) at %dx%d' % (args.hw, args.hw),
-      'value': round(value, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-      'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-      'dtype': args.precision, 'data': 'synthetic',
-      'config': {'workload': 'TwinGAN %dx%d final stage (configs[3]): E/G/2xD max_ch %d, UNet + per-domain '
-                             'instance norm + pixel norm, WGAN-GP, Adam; 1 step = G apply + D apply' % (
-                                 args.hw, args.hw, args.max_ch),
-                 'global_batch': args.batch * world, 'batch_per_gpu': args.batch, 'parallelism': 'dp%d' % world,
-                 'launch': 'hipGraph replay' if tr.use_graph else 'eager',
-                 'gflop_per_pair_model': GFLOP_PER_PAIR_256 if args.hw == 256 else None},
-  }
+  out = base_line(round(value, 3), round(ms_per_step, 3), 'hipGraph replay' if tr.use_graph else 'eager')
+  out['config']['backward_segments'] = {g: tr._nseg(g) for g in ('g', 'd')}
   if args.hw == 256:
     tf = value * GFLOP_PER_PAIR_256 / 1e3 / world
     out['step_mfma_frac'] = round(tf / BF16_MFMA_PEAK_TFLOPS, 4)       # whole-step fraction of the conv roofline
@@ -263,6 +351,7 @@ def main():
     if not args.no_roofline:
       out['roofline'] = roofline_pass(tr, a, b)
     if not args.no_cpu_baseline:
+      tr.close()
       del tr
       torch.cuda.empty_cache()
       out['cpu_baseline'] = cpu_baseline(args)

@@ -82,6 +82,70 @@ def conv2d_bwd_weight(x, gy, ksize, padding='SAME'):
   return gw
 
 
+def _tap_views(xp, kh, kw, ho, wo):
+  for i in range(kh):
+    for j in range(kw):
+      yield i, j, xp[:, i:i + ho, j:j + wo, :]
+
+
+def conv2d_gemm(x, w, padding='SAME'):
+  """conv2d() with every tap as one float64 BLAS product ([pixels, Cin] @ [Cin, Cout]) instead of an einsum loop:
+  the same sums, fast enough for the full-size layer shapes of tests/test_gpu_bench_shapes.py.  Held to conv2d() by
+  tests/test_oracle.py."""
+  x = np.asarray(x, F64)
+  w = np.asarray(w, F64)
+  n, h, ww, cin = x.shape
+  kh, kw, _, cout = w.shape
+  (pt, pb), (pl, pr) = (same_pads(kh), same_pads(kw)) if padding == 'SAME' else ((0, 0), (0, 0))
+  xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+  ho, wo = xp.shape[1] - kh + 1, xp.shape[2] - kw + 1
+  y = np.zeros((n * ho * wo, cout), F64)
+  for i, j, v in _tap_views(xp, kh, kw, ho, wo):
+    y += np.ascontiguousarray(v).reshape(-1, cin) @ w[i, j]
+  return y.reshape(n, ho, wo, cout)
+
+
+def conv2d_bwd_data_gemm(gy, w, in_hw, padding='SAME'):
+  """conv2d_bwd_data() as the correlation of the padded gradient with the 180-degree rotated, transposed kernel."""
+  gy = np.asarray(gy, F64)
+  w = np.asarray(w, F64)
+  kh, kw, cin, cout = w.shape
+  n, ho, wo, _ = gy.shape
+  h, ww = in_hw
+  (pt, pb), (pl, pr) = (same_pads(kh), same_pads(kw)) if padding == 'SAME' else ((0, 0), (0, 0))
+  # gx[y, x] = sum_{i,j} gy[y + pt - i, x + pl - j] w[i, j]^T: pad gy so that every index is in range
+  gp = np.pad(gy, ((0, 0), (kh - 1 - pt, h - ho + pt), (kw - 1 - pl, ww - wo + pl), (0, 0)))
+  gx = np.zeros((n * h * ww, cin), F64)
+  for i in range(kh):
+    for j in range(kw):
+      v = gp[:, kh - 1 - i:kh - 1 - i + h, kw - 1 - j:kw - 1 - j + ww, :]
+      gx += np.ascontiguousarray(v).reshape(-1, cout) @ w[i, j].T
+  return gx.reshape(n, h, ww, cin)
+
+
+def conv2d_bwd_weight_gemm(x, gy, ksize, padding='SAME', per_image=False):
+  """conv2d_bwd_weight() with one BLAS product per tap.  ``per_image``: [N, kh, kw, Cin, Cout], the per-image terms
+  whose sum over N is the filter gradient (any sub-batch / pair of segments is then a sum of slices)."""
+  x = np.asarray(x, F64)
+  gy = np.asarray(gy, F64)
+  kh, kw = ksize
+  n, ho, wo, cout = gy.shape
+  cin = x.shape[3]
+  (pt, pb), (pl, pr) = (same_pads(kh), same_pads(kw)) if padding == 'SAME' else ((0, 0), (0, 0))
+  xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+  if per_image:
+    gw = np.zeros((n, kh, kw, cin, cout), F64)
+    g2 = gy.reshape(n, ho * wo, cout)
+    for i, j, v in _tap_views(xp, kh, kw, ho, wo):
+      gw[:, i, j] = np.matmul(np.ascontiguousarray(v).reshape(n, ho * wo, cin).transpose(0, 2, 1), g2)
+    return gw
+  gw = np.zeros((kh, kw, cin, cout), F64)
+  g2 = gy.reshape(-1, cout)
+  for i, j, v in _tap_views(xp, kh, kw, ho, wo):
+    gw[i, j] = np.ascontiguousarray(v).reshape(-1, cin).T @ g2
+  return gw
+
+
 def fully_connected(x, w, b=None):
   """layers.fully_connected, nets/pggan_utils.py:323-327; weights [in, out]."""
   y = np.asarray(x, F64) @ np.asarray(w, F64)

@@ -1,0 +1,275 @@
+"""Every conv kernel variant one bench step dispatches, AT the bench's shapes (256x256 final stage, batch 16 per GPU
+as the trainer batches it: n = 16 / 32 / 48 / 64, two-segment filter gradients 48+16 / 32+32), through the C ABI,
+against the float64 oracle on the same bf16-rounded inputs -- plus the normalisation kernels at their bench shapes.
+
+tests/golden/bench_dispatch_shapes.json (tools/make_dispatch_shapes.py, from the per-shape table of bench.py's
+roofline pass) lists the (entry point, layer shape, n) triples; tests/golden/bench_dispatch_kernels.json holds the
+kernel symbol each one selected (tg_last_kernel) when the table was recorded, so a silent change of dispatch is a
+failure too (TG_RECORD_KERNELS=<path> re-records).
+
+Tolerances: bf16 outputs (forward, backward-data) rel-L2 <= 4e-3 vs the oracle (one bf16 rounding of the output is
+1.1e-3) on the first and last image of the batch, and <= 2e-3 vs the direct (one-thread-per-output) kernel over the
+WHOLE tensor; fp32 outputs (filter and bias gradients, fp32 accumulation of exact bf16 products) rel-L2 <= 1e-4 vs the
+oracle over the whole batch.  SURVEY.md 8c asks 1e-2 / 3e-2.
+"""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import np_ops as N          # noqa: E402  (checker only)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, 'golden', 'bench_dispatch_shapes.json')) as _fh:
+  LAYERS = json.load(_fh)['layers']
+KERNELS_PATH = os.path.join(HERE, 'golden', 'bench_dispatch_kernels.json')
+BF16_OUT_TOL, VS_DIRECT_TOL, F32_OUT_TOL = 4e-3, 2e-3, 1e-4
+NMAX = 64
+RECORDED = {}
+
+
+def rel_l2(a, b):
+  a = np.asarray(a, np.float64)
+  b = np.asarray(b, np.float64)
+  assert a.shape == b.shape, (a.shape, b.shape)
+  return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def host(t):
+  return t.detach().float().cpu().numpy().astype(np.float64)
+
+
+def last_kernel():
+  from twingan_amd import _lib
+  return _lib.load().tg_last_kernel().decode()
+
+
+def _note(key, ep, n, sym=None):
+  RECORDED.setdefault(key, {}).setdefault(ep, {})[n] = sym if sym is not None else last_kernel()
+
+
+def _rand_bf16(shape, seed):
+  g = torch.Generator(device='cuda').manual_seed(seed)
+  return torch.randn(shape, generator=g, device='cuda', dtype=torch.float32).to(torch.bfloat16).contiguous()
+
+
+class _Direct:
+  """Forces the direct (one thread per output) algorithm inside the block."""
+
+  def __enter__(self):
+    import twingan_amd.ops as O
+    self.O, self.saved = O, O._mfma_ok
+    O._mfma_ok = lambda *a: False
+
+  def __exit__(self, *a):
+    self.O._mfma_ok = self.saved
+
+
+@pytest.mark.parametrize('key', sorted(k for k in LAYERS if '+' not in k.split('>')[0]))
+def test_conv_variants_at_bench_shapes(key):
+  import twingan_amd.ops as O
+  from twingan_amd._lib import TG_EPI_BIAS, TG_EPI_LRELU
+  k, cin, cout, hw = (int(v) for v in re.match(r'k(\d):c(\d+)>(\d+):hw(\d+)', key).groups())
+  valid = k == 4
+  hin = 4 if valid else hw
+  spec = O.ConvSpec(k, 'VALID' if valid else 'SAME')
+  eps = LAYERS[key]
+  x = _rand_bf16((NMAX, hin, hin, cin), 1)
+  gy = _rand_bf16((NMAX, hw, hw, cout), 2)
+  g = torch.Generator().manual_seed(3)
+  w = (torch.randn(k, k, cin, cout, generator=g) / (k * k * cin) ** 0.5).to(torch.bfloat16).float().cuda().contiguous()
+  bias = (torch.randn(cout, generator=g) * 0.1).cuda()
+  wn, bn = host(w), host(bias)
+  pad = 'VALID' if valid else 'SAME'
+
+  # ---- forward: both epilogues (generator / encoder: none; discriminator: bias + LeakyReLU)
+  for n in (int(v) for v in eps.get('tg_conv2d_fwd', [])):
+    sel = sorted({0, n - 1})
+    xs = host(x[sel])
+    lin = N.conv2d_gemm(xs, wn, pad)
+    for epi, ref in ((0, lin), (TG_EPI_BIAS | TG_EPI_LRELU, N.leaky_relu(lin + bn))):
+      y = O.conv_fwd_raw(x[:n], w, bias if epi else None, spec, epi)
+      _note(key, 'tg_conv2d_fwd', str(n))
+      e = rel_l2(host(y[sel]), ref)
+      assert e < BF16_OUT_TOL, ('fwd', key, n, epi, e)
+      with _Direct():
+        yd = O.conv_fwd_raw(x[:n], w, bias if epi else None, spec, epi)
+      if epi == 0:      # with LeakyReLU a 1-ulp difference across zero is a 5x jump of the element: linear part only
+        e = rel_l2(host(y), host(yd))
+        assert e < VS_DIRECT_TOL, ('fwd vs direct', key, n, e)
+      del y, yd
+
+  # ---- backward-data, plain and with the producer's LeakyReLU mask in the epilogue
+  for ep in ('tg_conv2d_bwd_data', 'tg_conv2d_bwd_data_masked'):
+    for n in (int(v) for v in eps.get(ep, [])):
+      sel = sorted({0, n - 1})
+      ref = N.conv2d_bwd_data_gemm(host(gy[sel]), wn, (hin, hin), pad)
+      if ep.endswith('masked'):
+        gx = O.conv_bwd_data_masked_raw(gy[:n], w, x[:n], spec)
+        ref = ref * np.where(host(x[sel]) > 0, 1.0, 0.2)
+      else:
+        gx = O.conv_bwd_data_raw(gy[:n], w, (n, hin, hin, cin), spec)
+      _note(key, ep, str(n))
+      e = rel_l2(host(gx[sel]), ref)
+      assert e < BF16_OUT_TOL, (ep, key, n, e)
+      with _Direct():
+        gd = O.conv_bwd_data_raw(gy[:n], w, (n, hin, hin, cin), spec)
+        if ep.endswith('masked'):
+          gd = O.lrelu_bwd_raw(gd, x[:n], 0.2)
+      e = rel_l2(host(gx), host(gd))
+      # the direct kernel rounds once more before the mask: 2 roundings apart
+      assert e < (2 * VS_DIRECT_TOL if ep.endswith('masked') else VS_DIRECT_TOL), (ep + ' vs direct', key, n, e)
+      del gx, gd
+
+  # ---- filter gradients (fp32): single batch, with the bias gradient, two segments
+  wg_eps = [e for e in eps if 'bwd_weight' in e]
+  if wg_eps:
+    per = N.conv2d_bwd_weight_gemm(host(x), host(gy), (k, k), pad, per_image=True)      # [64, k, k, cin, cout]
+    bsum = host(gy).sum(axis=(1, 2))                                                       # [64, cout]
+    for ep in wg_eps:
+      for nn in eps[ep]:
+        parts = [int(v) for v in nn.split('+')]
+        n = sum(parts)
+        want_b = ep.endswith('_bias')
+        gb = torch.zeros(cout, dtype=torch.float32, device='cuda') if want_b else None
+        if len(parts) == 1:
+          gw = O.conv_bwd_weight_raw(x[:n], gy[:n], spec, gbias=gb)
+          _note(key, ep, nn)
+          bias_ref = bsum[:n].sum(0)
+        else:
+          a = parts[0]
+          gw = torch.zeros((k, k, cin, cout), dtype=torch.float32, device='cuda')
+          # the trainer's bias segments: only the batched pass (segment a) feeds the bias in a D step
+          ok = O.conv_bwd_weight2_raw(x[:a], gy[:a], x[a:n], gy[a:n], spec, gw, gb, 1 if want_b else 3)
+          assert ok, ('two-segment filter gradient refused', key, nn)
+          _note(key, ep, nn)
+          bias_ref = bsum[:a].sum(0)
+        e = rel_l2(host(gw), per[:n].sum(0))
+        assert e < F32_OUT_TOL, (ep, key, nn, e)
+        if want_b:
+          e = rel_l2(host(gb), bias_ref)
+          assert e < F32_OUT_TOL, (ep + ' bias', key, nn, e)
+        del gw
+
+
+@pytest.mark.parametrize('key', sorted(k for k in LAYERS if '+' in k.split('>')[0]))
+def test_upcat_conv_at_bench_shapes(key):
+  """conv3x3(concat(up2(x0), skip)) read from its two sources (generator_three_layer_block's first conv), forward and
+  filter gradient, with the trainer's skip-group permutation (four generator passes read two encoder passes)."""
+  import twingan_amd.ops as O
+  c0, c1, cout, hw = (int(v) for v in re.match(r'k3:c(\d+)\+(\d+)>(\d+):hw(\d+)', key).groups())
+  n, gsz, perm = NMAX, 16, (1, 0, 0, 1)
+  x0 = _rand_bf16((n, hw // 2, hw // 2, c0), 5)
+  x1 = _rand_bf16((2 * gsz, hw, hw, c1), 6)
+  gy = _rand_bf16((n, hw, hw, cout), 7)
+  g = torch.Generator().manual_seed(8)
+  w = (torch.randn(3, 3, c0 + c1, cout, generator=g) / (9 * (c0 + c1)) ** 0.5).to(torch.bfloat16).float().cuda()
+  w = w.contiguous().requires_grad_(True)
+  assert O.upcat_conv_supported(x0, x1, w)
+  x0.requires_grad_(True)
+  x1.requires_grad_(True)
+  y = O.upcat_conv(x0, x1, w, gsz, perm)
+  _note(key, 'tg_conv2d_upcat_fwd', str(n))
+  wn = host(w)
+
+  def cat_of(i):      # the materialised input of image i
+    up = np.repeat(np.repeat(host(x0[i:i + 1]), 2, axis=1), 2, axis=2)
+    return np.concatenate([up, host(x1[perm[i // gsz] * gsz + i % gsz][None])], axis=3)
+  for i in (0, gsz + 3, n - 1):
+    e = rel_l2(host(y[i:i + 1]), N.conv2d_gemm(cat_of(i), wn))
+    assert e < BF16_OUT_TOL, ('upcat fwd', key, i, e)
+  y.backward(gy)
+  _note(key, 'tg_conv2d_upcat_bwd_weight', str(n), 'conv_wgrad_tile_kernel')
+  gyn = host(gy)
+  ref = np.zeros_like(wn)
+  for i in range(n):
+    ref += N.conv2d_bwd_weight_gemm(cat_of(i), gyn[i:i + 1], (3, 3))
+  e = rel_l2(host(w.grad), ref)
+  assert e < F32_OUT_TOL, ('upcat wgrad', key, e)
+  # input gradients: backward-data over the concat layout, split into the two sources (skip groups summed: every
+  # encoder image is read by two generator passes)
+  gcat0 = N.conv2d_bwd_data_gemm(gyn[:1], wn, (hw, hw))
+  g0_ref = gcat0[..., :c0].reshape(1, hw // 2, 2, hw // 2, 2, c0).sum(axis=(2, 4))
+  e = rel_l2(host(x0.grad[:1]), g0_ref)
+  assert e < 2 * BF16_OUT_TOL, ('upcat gx0', key, e)
+  j = 5                                            # skip image 5 (group 0) is read by output groups 1 and 2
+  tot = sum(N.conv2d_bwd_data_gemm(gyn[i:i + 1], wn, (hw, hw))[..., c0:] for i in (gsz + j, 2 * gsz + j))
+  e = rel_l2(host(x1.grad[j:j + 1]), tot)
+  assert e < 2 * BF16_OUT_TOL, ('upcat gx1', key, e)
+
+
+NORM_SHAPES = [
+    # c, hw, n, pool    (encoder: [s; t] and [s'; t'] batches of 32 with the block-end avg-pool; generator: 4 passes = 64)
+    (16, 256, 32, False), (32, 256, 32, True), (64, 128, 32, True), (128, 64, 32, True), (256, 32, 32, True),
+    (256, 8, 32, True), (16, 256, 64, False), (32, 128, 64, False), (64, 64, 64, False), (128, 32, 64, False),
+    (256, 16, 64, False), (256, 4, 64, False),
+]
+
+
+@pytest.mark.parametrize('c,hw,n,pool', NORM_SHAPES)
+def test_norm_act_at_bench_shapes(c, hw, n, pool):
+  """instance norm (two domains along N) + LeakyReLU + pixel norm (+ the encoder's avg-pool), forward and backward, at
+  the bench's tensor shapes; the oracle (float64 autograd of the literal formulas) on the same bf16 inputs."""
+  import twingan_amd.ops as O
+  y = _rand_bf16((n, hw, hw, c), 11)
+  y = (y.float() * 0.7 + 0.3).to(torch.bfloat16).contiguous().requires_grad_(True)
+  g = torch.Generator().manual_seed(12)
+  par = [(torch.randn(c, generator=g) * s + o).cuda().requires_grad_(True) for s, o in ((0.2, 1.0), (0.2, 0.0)) * 2]
+  ga, be, ga2, be2 = par
+  split = n // 2
+  out = O.norm_act(y, ga, be, lrelu=True, pixel_norm=True, gamma2=ga2, beta2=be2, split=split, pool=pool)
+  z, zp = out if pool else (out, None)
+  gz = _rand_bf16(tuple(z.shape), 13)
+  gzp = _rand_bf16(tuple(zp.shape), 14) if pool else None
+  torch.autograd.backward([z, zp] if pool else [z], [gz, gzp] if pool else [gz])
+  want = [np.zeros(c) for _ in range(4)]
+  checked = (0, split - 1, split, n - 1)
+  for i in range(n):
+    yi = y[i:i + 1].detach().double().cpu().requires_grad_(True)
+    p = [t.detach().double().cpu().requires_grad_(True) for t in ((ga, be) if i < split else (ga2, be2))]
+    mean = yi.mean(dim=(1, 2), keepdim=True)
+    var = ((yi - mean) ** 2).mean(dim=(1, 2), keepdim=True)
+    u = (yi - mean) * torch.rsqrt(var + 1e-6) * p[0] + p[1]
+    a = torch.maximum(0.2 * u, u)
+    zr = a * torch.rsqrt((a * a).mean(dim=3, keepdim=True) + 1e-6)
+    outs, gouts = [zr], [gz[i:i + 1].double().cpu()]
+    if pool:
+      outs.append(zr.reshape(1, hw // 2, 2, hw // 2, 2, c).mean(dim=(2, 4)))
+      gouts.append(gzp[i:i + 1].double().cpu())
+    torch.autograd.backward(outs, gouts)
+    k = 0 if i < split else 2
+    want[k] += p[0].grad.numpy()
+    want[k + 1] += p[1].grad.numpy()
+    if i in checked:
+      assert rel_l2(host(z[i:i + 1]), zr.detach().numpy()) < 6e-3, ('z', i)
+      if pool:
+        assert rel_l2(host(zp[i:i + 1]), outs[1].detach().numpy()) < 6e-3, ('zp', i)
+      e = rel_l2(host(y.grad[i:i + 1]), yi.grad.numpy())
+      assert e < 1.5e-2, ('gy', i, e)
+  for t, wv, nm in zip(par, want, ('gamma', 'beta', 'gamma2', 'beta2')):
+    e = rel_l2(host(t.grad), wv)
+    assert e < 2e-3, (nm, e)      # fp32 sums of bf16-exact inputs; the bf16 rounding of z does not enter
+
+
+def test_dispatch_table_matches_recorded_kernels():
+  """Runs last in this file: every dispatch above must have selected the kernel symbol recorded in
+  tests/golden/bench_dispatch_kernels.json."""
+  if not RECORDED:
+    pytest.skip('the shape tests of this file did not run in this session')
+  dst = os.environ.get('TG_RECORD_KERNELS')
+  if dst:
+    with open(dst, 'w') as fh:
+      json.dump(RECORDED, fh, indent=1, sort_keys=True)
+    return
+  assert os.path.exists(KERNELS_PATH), 'record with TG_RECORD_KERNELS=tests/golden/bench_dispatch_kernels.json'
+  with open(KERNELS_PATH) as fh:
+    want = json.load(fh)
+  for key, eps in RECORDED.items():
+    for ep, by_n in eps.items():
+      for n, sym in by_n.items():
+        assert want.get(key, {}).get(ep, {}).get(n) == sym, (key, ep, n, sym, want.get(key, {}).get(ep, {}).get(n))

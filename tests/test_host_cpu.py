@@ -285,3 +285,97 @@ def test_bench_line_contract():
   src = open(os.path.join(root, 'bench.py')).read()
   for flag in ('--gpus', '--steps', '--warmup'):
     assert "'%s'" % flag in src
+
+
+def test_bench_gpus_n_spawns_n_ranks():
+  """`python bench.py --gpus 2` with no launcher in the environment starts 2 ranks itself (the reference's
+  one-process --num_clones=N, deployment/model_deploy.py:186-239, as one process per GPU).  --launch-check runs the
+  launcher, the process group (gloo here, RCCL on a GPU box) and the per-segment all-reduce schedule without kernels."""
+  import json
+  import subprocess
+  import sys
+  env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+  env['CUDA_VISIBLE_DEVICES'] = env['HIP_VISIBLE_DEVICES'] = ''      # a GPU box has one GPU: force the gloo path
+  out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--hw', '32',
+                        '--max-ch', '16', '--launch-check'], capture_output=True, text=True, timeout=600, env=env)
+  assert out.returncode == 0, out.stderr[-2000:]
+  lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, out.stdout      # rank 0 only
+  d = json.loads(lines[0])
+  assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['config']['global_batch'] == 32
+  assert 'world 2' in d['config']['collective'] and d['scaling'] == 'weak'
+  seg = d['launch_check']['segments']
+  assert len(seg['g']) >= 1 and len(seg['d']) >= 1
+
+
+def test_gradient_phases_are_contiguous_ranges():
+  """params.grad_phase: the flat gradient buffer is laid out segment by segment (what one backward segment completes is
+  one contiguous range = one all-reduce), the initial values do not depend on the layout, and growing stages / the
+  style encoder keep a single phase."""
+  from twingan_amd import Config
+  from twingan_amd.params import ParamStore, declare_twingan, grad_phase
+  cfg = Config(hw=128, max_ch=64)
+  st = declare_twingan(ParamStore('cpu'), cfg).build(seed=3)
+  assert sorted(st.phase_bounds['g']) == [0, 1, 2] and sorted(st.phase_bounds['d']) == [0, 1]
+  for g in ('g', 'd'):
+    b = [st.phase_bounds[g][p] for p in sorted(st.phase_bounds[g])]
+    assert b[0][0] == 0 and b[-1][1] == st.grad[g].numel()
+    assert all(x[1] == y[0] and x[0] % 64 == 0 for x, y in zip(b, b[1:]))
+    for k, s in st.specs.items():
+      if s['group'] == g:
+        lo, hi = st.phase_bounds[g][st.phase[k]]
+        assert lo <= st.offsets[k] < hi, k
+  assert grad_phase('generator/block_128x128x32/Conv/weights', cfg) == 0
+  assert grad_phase('encoder_content/encoder_block_32x32x64/Conv_1/InstanceNorm/gamma_s', cfg) == 1
+  assert grad_phase('encoder_content/encoder_block_64x64x64/Conv/weights', cfg) == 2
+  assert grad_phase('encoder_content/from_rgb_128x128/Conv/weights', cfg) == 2
+  assert grad_phase('discriminator_t/encoder_block_64x64x64/Conv/biases', cfg) == 1
+  assert grad_phase('discriminator_t/before_fc_1x1x64/Conv_1/weights', cfg) == 0
+  assert grad_phase('discriminator_s/prediction/fully_connected/weights', cfg) == 0
+  # same seed, layout switched off: identical values under every name
+  flat = declare_twingan(ParamStore('cpu'), cfg)
+  flat.phase_of = None
+  flat = flat.build(seed=3)
+  a, b = st.state_dict(), flat.state_dict()
+  assert all(torch.equal(a[k], b[k]) for k in a)
+  assert flat.offsets != st.offsets
+  one = declare_twingan(ParamStore('cpu'), Config(hw=64, max_ch=16, is_growing=True)).build(seed=0)
+  assert list(one.phase_bounds['g']) == [0] and list(one.phase_bounds['d']) == [0]
+
+
+def test_segmented_backward_equals_plain_backward():
+  """ops.Cuts: stopping the backward at detached leaves and resuming from their producers, segment by segment, leaves
+  the same parameter gradients as one loss.backward() (plain torch graph: the mechanism has no kernels of its own)."""
+  from twingan_amd.ops import Cuts
+  torch.manual_seed(0)
+  w = [torch.randn(6, 6, dtype=torch.float64, requires_grad=True) for _ in range(4)]
+  x = torch.randn(5, 6, dtype=torch.float64)
+
+  def net(cut):
+    h1 = torch.tanh(x @ w[0])                   # "high-resolution encoder"
+    h1c = Cuts.cut(h1, 2) if cut else h1        # inner cut: resumes in segment 2
+    h2 = torch.tanh(h1c @ w[1])                 # "low-resolution encoder"
+    skip = Cuts.cut(h1, 2) if cut else h1       # skip edge out of the high part
+    e = Cuts.cut(h2, 1) if cut else h2          # content edge
+    g = torch.tanh(e @ w[2]) + skip @ w[3]      # "generator"
+    return (g ** 2).sum() + 0.1 * (h2.detach() * e).sum()
+
+  net(False).backward()
+  want = [p.grad.clone() for p in w]
+  for p in w:
+    p.grad = None
+  Cuts.begin()
+  try:
+    net(True).backward()
+    assert w[2].grad is not None and w[0].grad is None and w[1].grad is None      # segment 0 stops at the cuts
+    for seg in (1, 2):
+      roots, grads = Cuts.roots(seg)
+      assert roots
+      torch.autograd.backward(roots, grads)
+      assert (w[1].grad is not None) and ((w[0].grad is not None) == (seg == 2))
+  finally:
+    Cuts.end()
+  for p, g in zip(w, want):
+    assert torch.allclose(p.grad, g, rtol=1e-12, atol=1e-14)
+  y = torch.ones(2, requires_grad=True)
+  assert Cuts.cut(y, 1) is y                    # inactive: the identity

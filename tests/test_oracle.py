@@ -411,3 +411,19 @@ def test_tf_stand_in_primitives_agree_with_numpy_restatement():
     th, m, vv = N.adam_step(th, g, m, vv, t, lr=1e-3, beta1=0.5, beta2=0.99, eps=1e-8)
     assert close(v.t.detach().numpy(), th, 1e-14), t
   core.STATE.reset(0)
+
+
+def test_gemm_forms_of_the_conv_oracle_equal_the_einsum_forms():
+  """np_ops.conv2d_gemm / conv2d_bwd_data_gemm / conv2d_bwd_weight_gemm (one BLAS product per tap; what the full-size
+  layer checks of tests/test_gpu_bench_shapes.py use) are the same sums as the einsum restatements above them."""
+  rng = np.random.RandomState(0)
+  for (n, h, w, ci, co, k, pad) in [(2, 6, 5, 3, 4, 3, 'SAME'), (3, 4, 4, 5, 6, 4, 'VALID'), (2, 7, 7, 3, 5, 4, 'SAME'),
+                                    (2, 5, 5, 4, 6, 1, 'SAME'), (2, 7, 6, 3, 5, 4, 'VALID')]:
+    x, wt = rng.randn(n, h, w, ci), rng.randn(k, k, ci, co)
+    y = N.conv2d(x, wt, pad)
+    assert np.allclose(y, N.conv2d_gemm(x, wt, pad), atol=1e-12)
+    gy = rng.randn(*y.shape)
+    assert np.allclose(N.conv2d_bwd_data(gy, wt, (h, w), pad), N.conv2d_bwd_data_gemm(gy, wt, (h, w), pad), atol=1e-12)
+    gw = N.conv2d_bwd_weight(x, gy, (k, k), pad)
+    assert np.allclose(gw, N.conv2d_bwd_weight_gemm(x, gy, (k, k), pad), atol=1e-12)
+    assert np.allclose(gw, N.conv2d_bwd_weight_gemm(x, gy, (k, k), pad, per_image=True).sum(0), atol=1e-12)

@@ -37,4 +37,6 @@ class Config:
   opt_epsilon: float = 1e-8
   precision: str = 'bf16'             # 'bf16': bf16 activations + MFMA convs, fp32 master weights; 'fp32': exact path
   domain_streams: bool = True         # run the two (independent) discriminators on two HIP streams
+  overlap_cut_hw: int = 32            # data-parallel runs: the backward is cut where the feature maps grow past this size and
+                                      # the all-reduce of the (large) lower-resolution gradients overlaps the rest of it
   loss_scale: float = 1.0             # --mix_precision_loss_scale (model_inheritor.py:568-570); bf16 needs none

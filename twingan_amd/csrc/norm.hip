@@ -69,28 +69,49 @@ __device__ __forceinline__ float group_sum(float v, int g) {
   return v;
 }
 
-// Adds this thread's V per-channel partials into sh[base + v*V + j].  Threads of a wave that own the same
-// channel vector (v = tid % cv) are first summed with an xor butterfly over the pixel-lane bits, so that only
-// cv lanes per wave touch LDS (instead of 64 lanes fighting over cv*V addresses).
+// sh[base + v*V + j] = sum over the block's threads that own channel vector v (v = tid % cv) of a[j], in a FIXED
+// order: threads of a wave are summed with an xor butterfly over the pixel-lane bits, the waves' results go to
+// per-wave LDS slots and are added in wave order (no float atomics: neither the statistics of the forward pass nor
+// anything else computed here depends on which wave arrives first).  Channel counts that are not a power of two
+// (<= 64 vectors) take per-thread slots summed in thread order.  Block-collective: contains barriers; blockDim = 256.
 template <int V>
 __device__ __forceinline__ void wave_channel_accumulate(float (&a)[V], float* sh, int base, int cv, int v, bool active) {
-  if (cv <= 64 && (cv & (cv - 1)) == 0) {
-    if (!active) {
+  __shared__ float scratch[256 * V];
+  const int tid = threadIdx.x;
+  if (!active) {
 #pragma unroll
-      for (int j = 0; j < V; ++j) a[j] = 0.f;
-    }
+    for (int j = 0; j < V; ++j) a[j] = 0.f;
+  }
+  if (cv <= 64 && (cv & (cv - 1)) == 0) {
     for (int o = cv; o < 64; o <<= 1) {
 #pragma unroll
       for (int j = 0; j < V; ++j) a[j] += __shfl_xor(a[j], o, 64);
     }
-    if ((int)(threadIdx.x & 63) < cv) {
+    const int wave = tid >> 6, lane = tid & 63;      // lane < cv: lane == v
+    if (lane < cv) {
 #pragma unroll
-      for (int j = 0; j < V; ++j) atomicAdd(&sh[base + v * V + j], a[j]);
+      for (int j = 0; j < V; ++j) scratch[(wave * cv + lane) * V + j] = a[j];
     }
-  } else if (active) {
+    __syncthreads();
+    const int nw = blockDim.x >> 6, span = cv * V;
+    for (int i = tid; i < span; i += blockDim.x) {
+      float t = 0.f;
+      for (int w = 0; w < nw; ++w) t += scratch[w * span + i];
+      sh[base + i] = t;
+    }
+  } else {
 #pragma unroll
-    for (int j = 0; j < V; ++j) atomicAdd(&sh[base + v * V + j], a[j]);
+    for (int j = 0; j < V; ++j) scratch[tid * V + j] = a[j];
+    __syncthreads();
+    const int lanes = blockDim.x / cv;               // thread (pl, v) = tid pl * cv + v
+    for (int i = tid; i < cv * V; i += blockDim.x) {
+      const int vv = i / V, j = i - vv * V;
+      float t = 0.f;
+      for (int pl = 0; pl < lanes; ++pl) t += scratch[(pl * cv + vv) * V + j];
+      sh[base + i] = t;
+    }
   }
+  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -452,9 +473,24 @@ __global__ void norm_act_bwd2_part_kernel(const T* __restrict__ gz, const T* __r
   } else if (sink && blockIdx.x == 0) {
     float* gg = n < split ? ggamma : ggamma2;
     float* gb = n < split ? gbeta : gbeta2;
-    for (int i = threadIdx.x; i < c; i += blockDim.x) {
-      if (gb) atomicAdd(gb + i, sh[i]);
-      if (gg) atomicAdd(gg + i, sh[c + i]);
+    if constexpr (sizeof(T) == 4) {
+      // exact-parity (fp32) path: the domain's first image sums the partials of all its images in image order and
+      // issues ONE add per parameter (launches that feed a sink are stream-ordered) -- the result does not depend on
+      // which image's block arrives first
+      const int i0 = n < split ? 0 : split, i1 = n < split ? split : (int)gridDim.y;
+      if (n == i0) {
+        for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) {
+          float t = 0.f;
+          for (int64_t k = (int64_t)i0 * chunks; k < (int64_t)i1 * chunks; ++k) t += part[k * 2 * c + i];
+          float* dst = i < c ? gb : gg;
+          if (dst) atomicAdd(dst + (i < c ? i : i - c), t);
+        }
+      }
+    } else {
+      for (int i = threadIdx.x; i < c; i += blockDim.x) {
+        if (gb) atomicAdd(gb + i, sh[i]);
+        if (gg) atomicAdd(gg + i, sh[c + i]);
+      }
     }
   }
   const float inv = 1.f / (float)hw;

@@ -5,8 +5,9 @@ deployment/model_deploy.py builds ``num_clones`` towers on one host, divides eve
 device (:473-503).  Here a clone is one process on one MI355X; because every variable of an
 optimiser group lives in ONE flat fp32 gradient buffer (params.ParamStore), the whole ``add_n``
 fan-in is a handful of large sum all-reduces (RCCL over xGMI when the backend is "nccl"; gloo on
-CPU in the tests).  Buckets are issued asynchronously so that the caller can keep enqueuing
-backward kernels / the other group's work while they are in flight, and waited for just before Adam.
+CPU in the tests).  Buckets are issued asynchronously -- the trainer calls start() once per backward
+segment, on the range of the flat buffer whose gradients that segment completed (params.grad_phase), and keeps
+enqueuing the next segment's backward kernels while the sum is in flight -- and waited for just before Adam.
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of the ~35 MB group buffer is
 per-link bound (~0.4 ms), so few large buckets beat many small ones -- the default is 2 buckets.
@@ -43,16 +44,18 @@ class GradReducer:
     self.n_buckets = n_buckets
     self._pending = []
 
-  def start(self, flat_grad):
-    """Enqueues the bucketed all-reduce (no-op for a single clone).  Returns the number of buckets."""
-    assert not self._pending, 'previous reduction not finished'
+  def start(self, flat_grad, n_buckets=None):
+    """Enqueues the bucketed all-reduce of ``flat_grad`` (a 1-D view of a flat gradient buffer; no-op for a single
+    clone) behind everything already enqueued on the current stream.  May be called several times before finish().
+    Returns the number of buckets issued."""
     if self.world <= 1:
       return 0
     if not dist.is_initialized():
       raise RuntimeError('world_size %d but torch.distributed is not initialised' % self.world)
-    for lo, hi in bucket_bounds(flat_grad.numel(), self.n_buckets):
+    bounds = bucket_bounds(flat_grad.numel(), n_buckets or self.n_buckets)
+    for lo, hi in bounds:
       self._pending.append(dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-    return len(self._pending)
+    return len(bounds)
 
   def finish(self):
     """Makes the reduced gradients visible to the stream Adam is enqueued on."""

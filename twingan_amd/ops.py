@@ -29,6 +29,8 @@ def _dt(t):
 
 
 def _stream():
+  """torch's current HIP stream of the current device; _chk() verifies that the tensors live on that device (a Trainer
+  on cuda:N enters ``torch.cuda.device(N)`` around every step)."""
   return torch.cuda.current_stream().cuda_stream
 
 
@@ -37,10 +39,16 @@ def _p(t):
 
 
 def _chk(*ts):
+  cur = None
   for t in ts:
     if t is not None:
       if not t.is_cuda:
         raise _lib.TgError('twingan_amd ops need CUDA/HIP tensors (no CPU fallback)')
+      if cur is None:
+        cur = torch.cuda.current_device()
+      if t.device.index != cur:
+        raise _lib.TgError('tensor on cuda:%d but the current device is cuda:%d: wrap the call in torch.cuda.device()'
+                           % (t.device.index, cur))
       if not t.is_contiguous():
         raise _lib.TgError('twingan_amd ops need contiguous NHWC tensors')
 
@@ -77,6 +85,17 @@ class PackCache:
     cls._registered.clear()
     cls._packs.clear()
     cls._tables.clear()
+
+  @classmethod
+  def unregister(cls, w):
+    """Forgets a master weight and its packs / job tables (ParamStore.close())."""
+    ptr = w.data_ptr()
+    if cls._registered.get(ptr) is w:
+      del cls._registered[ptr]
+      for k in [k for k in cls._packs if k[0] == ptr]:
+        del cls._packs[k]
+      for k in [k for k in cls._tables if ptr in k[0]]:
+        del cls._tables[k]
 
   @classmethod
   def _pack(cls, w, desc, mode, buf):
@@ -146,6 +165,13 @@ class GradSink:
     cls._held = {}
 
   @classmethod
+  def unregister(cls, p):
+    ent = cls._sinks.get(p.data_ptr())
+    if ent is not None and ent[0]() is p:
+      del cls._sinks[p.data_ptr()]
+      cls._held.pop(p.data_ptr(), None)
+
+  @classmethod
   def get(cls, p):
     if p is None or torch.is_grad_enabled():
       return None
@@ -183,14 +209,54 @@ class GradSink:
       conv_bwd_weight_raw(x, gy, spec, out=sink, gbias=bias_sink)
 
   @classmethod
-  def flush(cls):
-    held, cls._held = cls._held, {}
+  def flush(cls, only=None):
+    """Issues the held filter gradients.  ``only``: predicate on the weight's data_ptr -- the trainer flushes, at the
+    end of a backward segment, the weights whose gradient that segment completes and keeps the rest held for the
+    pair that a later segment brings."""
+    if only is None:
+      held, cls._held = cls._held, {}
+    else:
+      held = {k: v for k, v in cls._held.items() if only(k)}
+      for k in held:
+        del cls._held[k]
     cur = torch.cuda.current_stream() if held else None
     for x, gy, spec, sink, bias_sink in held.values():
       conv_bwd_weight_raw(x, gy, spec, out=sink, gbias=bias_sink)
       x.record_stream(cur)       # may have been produced on a domain stream
       gy.record_stream(cur)
     return len(held)
+
+
+class Cuts:
+  """Segmented backward for the overlapped clone all-reduce (deployment/model_deploy.py:473-503 sums the clones'
+  gradients after the whole backward; here the sum of the gradients a segment completes travels over xGMI while the
+  next segment runs).  While ``active``, ``cut(t, seg)`` replaces an activation by a detached leaf: the backward of
+  the loss stops there (segment 0), and segment ``seg`` later resumes from the producer ``t`` with the gradient the
+  leaf received.  Inactive (single clone, growing stages): cut() is the identity and the graph is the usual one."""
+  active = False
+  pairs = {}       # seg -> [(producer tensor, leaf)]
+
+  @classmethod
+  def begin(cls):
+    cls.active, cls.pairs = True, {}
+
+  @classmethod
+  def end(cls):
+    cls.active, cls.pairs = False, {}
+
+  @classmethod
+  def cut(cls, t, seg):
+    if not cls.active or not torch.is_grad_enabled() or not t.requires_grad:
+      return t
+    leaf = t.detach().requires_grad_(True)
+    cls.pairs.setdefault(seg, []).append((t, leaf))
+    return leaf
+
+  @classmethod
+  def roots(cls, seg):
+    """([producers], [their gradients]) of segment ``seg``; a leaf nothing consumed has no gradient and is dropped."""
+    prs = [(t, leaf.grad) for t, leaf in cls.pairs.get(seg, ()) if leaf.grad is not None]
+    return [t for t, _ in prs], [g for _, g in prs]
 
 
 class _State:

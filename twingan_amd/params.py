@@ -54,6 +54,9 @@ class ParamStore:
     self.state = {}
     self.weights_init_stddev = 0.02    # 1.0 under equalized_learning_rate (nets/pggan_utils.py:82-84, pggan.py:364)
     self.renorm = False                # generator_norm_type=batch_renorm: extra non-trainable renorm_* variables
+    self.phase_of = None               # name -> backward segment at whose end the gradient is final (grad_phase)
+    self.phase_bounds = {}             # group -> {phase: (lo, hi)} element range of each phase in the flat buffers
+    self.phase = {}                    # name -> phase
 
   # ---- declaration ----------------------------------------------------------------------------
   def add(self, name, shape, group, kind, phys=None):
@@ -84,11 +87,24 @@ class ParamStore:
 
   # ---- allocation -----------------------------------------------------------------------------
   def build(self, seed=0):
+    """Lays the variables out phase by phase (``phase_of``): the gradients that one backward segment completes are
+    one contiguous range of the group's flat buffer, so the clone all-reduce of that range (dp.GradReducer) can start
+    while the next segment is still running.  Initial values are drawn in declaration order whatever the layout."""
     sizes = {g: 0 for g in self.GROUPS}
-    for name, s in self.specs.items():
+    phase = {name: (int(self.phase_of(name)) if self.phase_of else 0) for name in self.specs}
+    order = sorted(self.specs, key=lambda k: phase[k])      # stable: declaration order inside a phase
+    marks = {g: {} for g in self.GROUPS}
+    for name in order:
+      s = self.specs[name]
       n = int(math.prod(s['phys']))
       self.offsets[name] = sizes[s['group']]
+      marks[s['group']].setdefault(phase[name], sizes[s['group']])
       sizes[s['group']] += (n + ALIGN - 1) // ALIGN * ALIGN
+    for g in self.GROUPS:
+      ids = sorted(marks[g]) or [0]
+      starts = [marks[g].get(p, 0) for p in ids]
+      self.phase_bounds[g] = dict(zip(ids, zip(starts, starts[1:] + [max(sizes[g], ALIGN)])))
+    self.phase = phase
     for g in self.GROUPS:
       n = max(sizes[g], ALIGN)
       self.flat[g] = torch.zeros(n, dtype=torch.float32, device=self.device)
@@ -187,14 +203,47 @@ class ParamStore:
   def zero_grad(self, group):
     self.grad[group].zero_()
 
+  def close(self):
+    """Drops this store's entries from the process-wide pack / gradient-sink registries (they hold strong references
+    to the parameter and gradient views): call when a stage's trainer is done (runner.run_progressive)."""
+    for p in self.P.values():
+      GradSink.unregister(p)
+      PackCache.unregister(p)
+
   def numel(self, group):
     return sum(int(math.prod(s['shape'])) for s in self.specs.values() if s['group'] == group)
+
+
+_HW_IN_NAME = __import__('re').compile(r'/(?:encoder_block|from_rgb|self_attention|block|generator_to_rgb)_(\d+)x\d+')
+
+
+def grad_phase(name, cfg):
+  """Backward segment (twingan.Trainer._grad_segments) at whose end the gradient of variable ``name`` is complete,
+  for the cut resolution ``cfg.overlap_cut_hw``:
+
+    generator step  0: generator/*  (re-encode pass, discriminators and the generator are differentiated first)
+                    1: encoder layers at <= cut_hw        2: encoder layers above cut_hw (their backward runs last)
+    discriminator   0: layers at <= cut_hw, the tail and the FC (gradient penalty passes + low-resolution part of the
+                       batched pass)                      1: layers above cut_hw
+
+  Growing stages and the style encoder keep everything in phase 0 (the trainer does not split those steps)."""
+  if cfg.is_growing or cfg.use_style_embedding or not cfg.overlap_cut_hw or cfg.hw <= cfg.overlap_cut_hw:
+    return 0
+  top = name.split('/', 1)[0]
+  if top == 'generator':
+    return 0
+  m = _HW_IN_NAME.search(name)
+  high = bool(m) and int(m.group(1)) > cfg.overlap_cut_hw
+  if top.startswith('encoder'):
+    return 2 if high else 1
+  return 1 if high else 0
 
 
 def declare_twingan(store, cfg):
   """All TwinGAN variables of one progressive stage (scopes twingan.py:105-110; layer lists
   SURVEY.md Appendix A; nets/pggan.py:93-211,242-376,403-479)."""
   hw, mc = cfg.hw, cfg.max_ch
+  store.phase_of = lambda name: grad_phase(name, cfg)
   ms = max_stage_of(hw)
   NORM_SCOPE = {'instance_norm': 'InstanceNorm', 'batch_norm': 'BatchNorm', 'batch_renorm': 'BatchNorm'}
   store.renorm = cfg.generator_norm_type == 'batch_renorm'

@@ -315,7 +315,10 @@ def maybe_concat_unet_layer(layer_hw, unet_end_points, max_ch, max_concat_hw=Non
 # ------------------------------------------------------------------------------------------------
 # encoder (nets/pggan.py:382-479)
 # ------------------------------------------------------------------------------------------------
-def encoder_before_classification(P, source, domain, cfg, top='encoder_content'):
+def encoder_before_classification(P, source, domain, cfg, top='encoder_content', cuts=None):
+  """``cuts`` = (low segment, high segment) of a segmented backward (ops.Cuts; no-ops unless the trainer opened one):
+  the UNet skip end-points become leaves, and so does the tensor entering the first block at cfg.overlap_cut_hw --
+  blocks above that resolution (whose backward runs last) resume in the high segment."""
   hw = source.shape[1]
   max_stage = max_stage_of(hw)
   assert max_stage >= 0
@@ -334,6 +337,8 @@ def encoder_before_classification(P, source, domain, cfg, top='encoder_content')
   for stage in range(max_stage, 0, -1):
     num_channels = get_num_channels(stage - 1, cfg.max_ch)
     current_hw = hw // (2 ** (max_stage - stage))
+    if cuts is not None and current_hw == cfg.overlap_cut_hw and current_hw < hw:
+      net = ops.Cuts.cut(net, cuts[1])
     net = maybe_add_self_attention(P, top, current_hw, num_channels, net, end_points, domain, cfg)
     name = 'encoder_block_%dx%dx%d' % (current_hw, current_hw, num_channels)
     block_in = net
@@ -345,6 +350,8 @@ def encoder_before_classification(P, source, domain, cfg, top='encoder_content')
     else:
       # last layer of the block + tf.nn.avg_pool (nets/pggan.py:466-468) as one op: (skip end-point, pooled)
       end_points[name], net = _ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg, pool=True)
+    if cuts is not None:      # the skip end-point is read by the generator only
+      end_points[name] = ops.Cuts.cut(end_points[name], cuts[1] if current_hw > cfg.overlap_cut_hw else cuts[0])
     current_hw //= 2
     end_points['downsample_to_%dx%dx%d' % (current_hw, current_hw, num_channels)] = net
     if stage == max_stage and cfg.is_growing:
@@ -434,7 +441,8 @@ def generator(P, source, domain, cfg, unet_end_points=None, top='generator', une
 # ------------------------------------------------------------------------------------------------
 # discriminator (nets/pggan.py:217-376)
 # ------------------------------------------------------------------------------------------------
-def discriminator_before_fc(P, source, cfg, top, groups=1):
+def discriminator_before_fc(P, source, cfg, top, groups=1, cut_seg=None):
+  """``cut_seg``: segment of a segmented backward (ops.Cuts) in which the blocks above cfg.overlap_cut_hw resume."""
   hw = source.shape[1]
   max_stage = max_stage_of(hw)
   assert max_stage >= 0
@@ -454,6 +462,8 @@ def discriminator_before_fc(P, source, cfg, top, groups=1):
   for stage in range(max_stage, 0, -1):
     num_channels = get_num_channels(stage - 1, max_ch)
     current_hw = hw // (2 ** (max_stage - stage))
+    if cut_seg is not None and current_hw == cfg.overlap_cut_hw and current_hw < hw:
+      net = ops.Cuts.cut(net, cut_seg)
     net = maybe_add_self_attention(P, top, current_hw, num_channels, net, end_points, None, cfg, True)   # pggan.py:294-296
     name = 'encoder_block_%dx%dx%d' % (current_hw, current_hw, num_channels)
     block_in = net
@@ -478,10 +488,10 @@ def discriminator_before_fc(P, source, cfg, top, groups=1):
   return net, end_points
 
 
-def discriminator(P, source, cfg, top, groups=1):
+def discriminator(P, source, cfg, top, groups=1, cut_seg=None):
   """``groups`` > 1: ``source`` is that many discriminator calls batched along N (each keeps its own
   minibatch-stddev statistic, as separate reference calls would)."""
-  net, end_points = discriminator_before_fc(P, source, cfg, top, groups)
+  net, end_points = discriminator_before_fc(P, source, cfg, top, groups, cut_seg)
   feat = net.reshape(net.shape[0], -1)                                 # tf.squeeze(net, (1, 2))
   pred = ops.fully_connected(_equalize(feat, cfg, 1), P[top + '/prediction/fully_connected/weights'],
                              P[top + '/prediction/fully_connected/biases'])

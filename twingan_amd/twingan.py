@@ -118,7 +118,10 @@ def forward_generators(P, sources, targets, cfg, style_noise=None):
   and the norm kernels pick gamma/beta per image, so the results are those of the separate passes)."""
   b = sources.shape[0]
   x = torch.cat([sources, targets], dim=0)
-  e, ep = pggan.encoder_before_classification(P, x, ('s', 't', b, 2), cfg)
+  # cuts (segmented backward of a data-parallel generator step, no-ops otherwise): every tensor this encoder pass
+  # hands to the generator / the losses becomes a leaf; its low-resolution half resumes in segment 1, the rest in 2
+  e, ep = pggan.encoder_before_classification(P, x, ('s', 't', b, 2), cfg, cuts=(1, 2))
+  e = ops.Cuts.cut(e, 1)
   es, et = e.chunk(2)
   content = torch.cat([et, es, es, et], dim=0)
   cond = rand = None
@@ -206,10 +209,10 @@ def _d_domain_terms(P, cfg, terms, d, top, real, prime, cyc, a, cyc_gan):
   if True:
     # D(real), D(cyc), D(prime) of one domain share weights: one batch, one minibatch-stddev group per call
     if cyc_gan:
-      pred, _ = pggan.discriminator(P, torch.cat([real, cyc, prime], dim=0), cfg, top, groups=3)
+      pred, _ = pggan.discriminator(P, torch.cat([real, cyc, prime], dim=0), cfg, top, groups=3, cut_seg=1)
       pr, pc, pp = (t.contiguous() for t in pred.chunk(3))
     else:
-      pred, _ = pggan.discriminator(P, torch.cat([real, prime], dim=0), cfg, top, groups=2)
+      pred, _ = pggan.discriminator(P, torch.cat([real, prime], dim=0), cfg, top, groups=2, cut_seg=1)
       pr, pp = (t.contiguous() for t in pred.chunk(2))
     wgan = cfg.loss_architecture in ('wgan_gp', 'wgan')
     mean_real = ops.mean(pr, cfg.gan_weight) if wgan else None
@@ -257,18 +260,24 @@ class Trainer:
   the weight packs (rebuilt by the captured optimiser tail).
   """
 
-  def __init__(self, cfg, device='cuda', seed=0, world_size=1, process_group=None, use_graph=False):
+  def __init__(self, cfg, device='cuda', seed=0, world_size=1, process_group=None, use_graph=False, overlap=None):
+    """``overlap``: cut the backward into segments and start the clone all-reduce of each segment's finished
+    gradients while the next one runs (None: whenever there is more than one clone; True forces the segmented
+    schedule for a single clone too -- same results, used by the tests)."""
     if cfg.spectral_norm and cfg.domain_streams:
       # the per-run normalised kernels (pggan._sn) are shared by every use of a discriminator: keep them on one stream
       cfg = dataclasses.replace(cfg, domain_streams=False)
     self.cfg = cfg
     self.device = torch.device(device)
+    if self.device.type == 'cuda' and self.device.index is None:
+      self.device = torch.device('cuda', torch.cuda.current_device())
     self.world = world_size
     if world_size > 1 and self.device.type == 'cuda':
       # every clone draws its own GP alphas / style noise (the reference's clones own their random ops,
       # deployment/model_deploy.py:224-239); weights are initialised from the shared CPU seed below
       rank = torch.distributed.get_rank(process_group) if torch.distributed.is_initialized() else 0
-      torch.cuda.manual_seed(1000003 * (seed + 1) + rank)
+      with torch.cuda.device(self.device):
+        torch.cuda.manual_seed(1000003 * (seed + 1) + rank)
     self.reducer = GradReducer(world_size, process_group)
     self.store = declare_twingan(ParamStore(self.device), cfg).build(seed)
     self.P = self.store.P
@@ -279,14 +288,38 @@ class Trainer:
     self._lr_t_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
     self._group_weights = {g: [self.P[k] for k, s in self.store.specs.items() if s['group'] == g and s['kind'] == 'conv_w']
                            for g in self.store.GROUPS}
+    # segmented backward (params.grad_phase): only where no autograd node is shared between segments -- the per-run
+    # spectrally normalised kernels are such nodes, growing stages / the style encoder add edges the cuts do not cover
+    want = (world_size > 1) if overlap is None else bool(overlap)
+    self.split = bool(want and not (cfg.is_growing or cfg.use_style_embedding or cfg.spectral_norm)
+                      and cfg.overlap_cut_hw and cfg.hw > cfg.overlap_cut_hw)
+    self._ptr_phase = {self.P[k].data_ptr(): ph for k, ph in self.store.phase.items()}
     self.use_graph = use_graph
+    self.graph_fallback_reason = None
     self._graphs = None
     self._static = None
 
+  def close(self):
+    """Releases the captured graphs and this trainer's entries in the pack / gradient-sink registries."""
+    self._graphs = self._static = None
+    self.store.close()
+
   # ---- optimiser --------------------------------------------------------------------------------
-  def _allreduce(self, group):
-    """deployment/model_deploy.py:473-503 (tf.add_n over clones) as bucketed RCCL sum all-reduces."""
-    self.reducer.allreduce(self.store.grad[group])
+  def _nseg(self, group):
+    return len(self.store.phase_bounds[group]) if self.split else 1
+
+  def _reduce_start(self, group, seg):
+    """deployment/model_deploy.py:473-503 (tf.add_n over clones) as RCCL sum all-reduces of the flat gradient buffer:
+    the range whose gradients backward segment ``seg`` completed is enqueued on the communication stream (which waits
+    for everything enqueued so far) and travels while the next segment runs; _reduce_finish() waits before Adam."""
+    if self.world <= 1:
+      return
+    g = self.store.grad[group]
+    if self._nseg(group) == 1:
+      self.reducer.start(g)
+    else:
+      lo, hi = self.store.phase_bounds[group][seg]
+      self.reducer.start(g[lo:hi], n_buckets=1)
 
   def _adam(self, group):
     """tf.train.AdamOptimizer apply (model/model_inheritor.py:537-542) on the group's flat buffers, then
@@ -299,87 +332,134 @@ class Trainer:
          c.adam_beta2, st)
     call('tg_adam_step', s.flat[group].data_ptr(), s.grad[group].data_ptr(), s.m[group].data_ptr(),
          s.v[group].data_ptr(), None, s.flat[group].numel(), 0.0, self._lr_t_dev.data_ptr(), c.adam_beta1,
-         c.adam_beta2, c.opt_epsilon, 1.0 / c.loss_scale, st)
+         c.adam_beta2, c.opt_epsilon, 1.0 / c.loss_scale, st,
+         work=('adam:numel%d' % s.flat[group].numel(), 0, 28 * s.flat[group].numel()))
     PackCache.refresh(self._group_weights[group])
 
   # ---- steps ------------------------------------------------------------------------------------
-  def _g_grads(self, sources, targets):
-    self.store.zero_grad('g')
-    self._set_requires_grad(g=True, d=False)
-    loss, terms = generator_loss(self.P, sources, targets, self.cfg)
-    ops.GradSink.pair = True
+  def _grad_segments(self, group, sources, targets, gp_alpha_s=None, gp_alpha_t=None):
+    """Generator over the backward segments of one step: forward + segment 0 (from the loss down to the cuts), then one
+    resumed backward per further segment (ops.Cuts).  Yields (segment, (loss, terms)) when the gradients of that
+    segment's phase (params.grad_phase) are final in the flat buffer -- the caller starts their all-reduce and asks
+    for the next segment.  A single segment (one clone, growing stages, ...) is the plain loss.backward()."""
+    nseg = self._nseg(group)
+    self.store.zero_grad(group)
+    self._set_requires_grad(g=group == 'g', d=group == 'd')
+    if nseg > 1:
+      ops.Cuts.begin()
     try:
-      (loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)).backward()     # model_deploy.py:265-268,308-313
+      if group == 'g':
+        loss, terms = generator_loss(self.P, sources, targets, self.cfg)
+      else:
+        b = sources.shape[0]
+        if gp_alpha_s is None:
+          gp_alpha_s = torch.rand(b, dtype=torch.float32, device=self.device)
+        if gp_alpha_t is None:
+          gp_alpha_t = torch.rand(b, dtype=torch.float32, device=self.device)
+        loss, terms = discriminator_loss(self.P, sources, targets, self.cfg, gp_alpha_s, gp_alpha_t)
+      out = (loss.detach(), {k: v.detach() for k, v in terms.items()})
+      scaled = loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)       # model_deploy.py:265-268,308-313
+      ops.GradSink.pair = True
+      for seg in range(nseg):
+        if seg == 0:
+          scaled.backward()
+        else:
+          roots, grads = ops.Cuts.roots(seg)
+          torch.autograd.backward(roots, grads)
+        _DomainStreams.join_all(self.device)
+        last = seg == nseg - 1
+        # filter gradients still waiting for a pair: issue those this segment completes, keep the others
+        ops.GradSink.flush(None if last else (lambda ptr, seg=seg: self._ptr_phase.get(ptr, 0) <= seg))
+        if last:
+          pggan.end_run(self.P)
+        yield seg, out
     finally:
       ops.GradSink.pair = False
-    _DomainStreams.join_all(self.device)
-    ops.GradSink.flush()
-    pggan.end_run(self.P)
-    return loss.detach(), {k: v.detach() for k, v in terms.items()}
+      if nseg > 1:
+        ops.Cuts.end()
 
-  def _d_grads(self, sources, targets, gp_alpha_s=None, gp_alpha_t=None):
-    b = sources.shape[0]
-    if gp_alpha_s is None:
-      gp_alpha_s = torch.rand(b, dtype=torch.float32, device=self.device)
-    if gp_alpha_t is None:
-      gp_alpha_t = torch.rand(b, dtype=torch.float32, device=self.device)
-    self.store.zero_grad('d')
-    self._set_requires_grad(g=False, d=True)
-    loss, terms = discriminator_loss(self.P, sources, targets, self.cfg, gp_alpha_s, gp_alpha_t)
-    ops.GradSink.pair = True
-    try:
-      (loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)).backward()
-    finally:
-      ops.GradSink.pair = False
-    _DomainStreams.join_all(self.device)
-    ops.GradSink.flush()
-    pggan.end_run(self.P)
-    return loss.detach(), {k: v.detach() for k, v in terms.items()}
+  def _step(self, group, sources, targets, gp_alpha_s=None, gp_alpha_t=None):
+    out = None
+    for seg, out in self._grad_segments(group, sources, targets, gp_alpha_s, gp_alpha_t):
+      self._reduce_start(group, seg)
+    self.reducer.finish()
+    self._adam(group)
+    return out
 
   def g_step(self, sources, targets):
-    out = self._g_grads(sources, targets)
-    self._allreduce('g')
-    self._adam('g')
-    return out
+    return self._step('g', sources, targets)
 
   def d_step(self, sources, targets, gp_alpha_s=None, gp_alpha_t=None):
-    out = self._d_grads(sources, targets, gp_alpha_s, gp_alpha_t)
-    self._allreduce('d')
-    self._adam('d')
-    return out
+    return self._step('d', sources, targets, gp_alpha_s, gp_alpha_t)
 
   # ---- hipGraph capture ---------------------------------------------------------------------------
+  def _snapshot(self):
+    """Everything a training run mutates: parameters, Adam moments and step, non-trainable state (BatchNorm moving /
+    renorm statistics, spectral-norm u), the host counters and the device RNG."""
+    s = self.store
+    return dict(flat={g: s.flat[g].clone() for g in s.GROUPS}, m={g: s.m[g].clone() for g in s.GROUPS},
+                v={g: s.v[g].clone() for g in s.GROUPS}, state={k: v.clone() for k, v in s.state.items()},
+                step=self._adam_step_dev.clone(), lr=self._lr_t_dev.clone(),
+                host=(self.n_critic_counter, self.global_step, self.adam_t), rng=torch.cuda.get_rng_state(self.device))
+
+  def _restore(self, snap):
+    s = self.store
+    with torch.no_grad():
+      for g in s.GROUPS:
+        s.flat[g].copy_(snap['flat'][g])
+        s.m[g].copy_(snap['m'][g])
+        s.v[g].copy_(snap['v'][g])
+        s.grad[g].zero_()
+      for k, v in snap['state'].items():
+        s.state[k].copy_(v)
+      self._adam_step_dev.copy_(snap['step'])
+      self._lr_t_dev.copy_(snap['lr'])
+    self.n_critic_counter, self.global_step, self.adam_t = snap['host']
+    torch.cuda.set_rng_state(snap['rng'], self.device)
+    for g in s.GROUPS:                      # the packs follow the restored masters
+      PackCache.refresh(self._group_weights[g])
+
   def _capture(self, sources, targets):
-    """Captures {grads, apply} x {g, d}.  Gradient graphs and apply graphs are separate so that the
-    clone all-reduce (RCCL) runs between them, outside any capture."""
+    """Captures, per step kind, one graph per backward segment and one for the apply: the clone all-reduces (RCCL)
+    run between them, outside any capture.  The eager warm-up (one real step of each kind: allocates every weight pack
+    and job table once) is undone afterwards, so graph mode and eager mode follow the same trajectory."""
     self._static = dict(s=sources.clone(), t=targets.clone())
     st = self._static
+    snap = self._snapshot()
     side = torch.cuda.Stream(device=self.device)
     side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):                 # eager warm-up (real runs): allocates every pack once
-      for _ in range(2 * self.cfg.n_critic):      # whole n_critic cycles, so the caller's G/D phase is unchanged
-        if self.n_critic_counter % self.cfg.n_critic == 0:
-          self.g_step(st['s'], st['t'])
-        else:
-          self.d_step(st['s'], st['t'])
-        self._advance_counters()
-    torch.cuda.current_stream().wait_stream(side)
+    try:
+      with torch.cuda.stream(side):
+        self.g_step(st['s'], st['t'])
+        self.d_step(st['s'], st['t'])
+      torch.cuda.current_stream().wait_stream(side)
+      torch.cuda.synchronize(self.device)
+    finally:
+      self._restore(snap)
     torch.cuda.synchronize(self.device)
     graphs, outs = {}, {}
     pool = None
     # with a process group alive, its watchdog thread issues event queries while we capture: only this
     # thread's unsafe calls may invalidate the capture
     mode = 'thread_local' if self.world > 1 else 'global'
-    for kind, fn in (('g', self._g_grads), ('d', self._d_grads)):
-      gr = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(gr, pool=pool, capture_error_mode=mode):
-        outs[kind] = fn(st['s'], st['t'])
-      pool = gr.pool()
+    adam_t = self.adam_t
+    for kind in ('g', 'd'):
+      segs = []
+      gen = self._grad_segments(kind, st['s'], st['t'])
+      try:
+        for _ in range(self._nseg(kind)):
+          gr = torch.cuda.CUDAGraph()
+          with torch.cuda.graph(gr, pool=pool, capture_error_mode=mode):
+            _, outs[kind] = next(gen)
+          pool = gr.pool()
+          segs.append(gr)
+      finally:
+        gen.close()
       ga = torch.cuda.CUDAGraph()
       with torch.cuda.graph(ga, pool=pool, capture_error_mode=mode):
         self._adam(kind)
-      graphs[kind] = (gr, ga)
-    self.adam_t -= 2                              # the two captured (not executed) applies
+      graphs[kind] = (segs, ga)
+    self.adam_t = adam_t                          # the captured (not executed) applies
     self._graphs, self._outs = graphs, outs
 
   def _run_graph(self, kind, sources, targets):
@@ -388,8 +468,16 @@ class Trainer:
         self._capture(sources, targets)
       except Exception as e:      # keep training: eager launches are the same kernels, only the host cost differs
         import warnings
-        warnings.warn('hipGraph capture failed (%s: %s); falling back to eager launches' % (type(e).__name__, e))
+        self.graph_fallback_reason = '%s: %s' % (type(e).__name__, e)
+        warnings.warn('hipGraph capture failed (%s); falling back to eager launches' % self.graph_fallback_reason)
         torch.cuda.synchronize(self.device)
+        # leave no half-issued step behind: held filter gradients, open cuts, forked side streams
+        ops.GradSink._held.clear()
+        ops.GradSink.pair = False
+        ops.Cuts.end()
+        _DomainStreams.join_all(self.device)
+        self.store.zero_grad('g')
+        self.store.zero_grad('d')
         self.use_graph, self._graphs = False, None
         self.adam_t = int(self._adam_step_dev.item())
         return self.g_step(sources, targets) if kind == 'g' else self.d_step(sources, targets)
@@ -398,9 +486,11 @@ class Trainer:
       st['s'].copy_(sources)
     if targets.data_ptr() != st['t'].data_ptr():
       st['t'].copy_(targets)
-    gr, ga = self._graphs[kind]
-    gr.replay()
-    self._allreduce(kind)
+    segs, ga = self._graphs[kind]
+    for seg, gr in enumerate(segs):
+      gr.replay()
+      self._reduce_start(kind, seg)
+    self.reducer.finish()
     ga.replay()
     self.adam_t += 1
     return self._outs[kind]
@@ -409,15 +499,18 @@ class Trainer:
     """One ``session.run(train_op)`` of the reference (image_generation.py:640-652):
     n_critic_counter % n_critic == 0 -> generator/encoder apply, else discriminator apply."""
     is_g = self.n_critic_counter % self.cfg.n_critic == 0
-    if self.cfg.generator_norm_type == 'batch_renorm':
-      self._set_renorm_clipping()
-    if self.use_graph:
-      assert gp_alpha_s is None and gp_alpha_t is None, 'graph mode draws the GP alphas on the device'
-      out = self._run_graph('g' if is_g else 'd', sources, targets)
-    elif is_g:
-      out = self.g_step(sources, targets)
-    else:
-      out = self.d_step(sources, targets, gp_alpha_s, gp_alpha_t)
+    import contextlib
+    # the kernels go to the current device's stream (ops._stream)
+    with (torch.cuda.device(self.device) if self.device.type == 'cuda' else contextlib.nullcontext()):
+      if self.cfg.generator_norm_type == 'batch_renorm':
+        self._set_renorm_clipping()
+      if self.use_graph:
+        assert gp_alpha_s is None and gp_alpha_t is None, 'graph mode draws the GP alphas on the device'
+        out = self._run_graph('g' if is_g else 'd', sources, targets)
+      elif is_g:
+        out = self.g_step(sources, targets)
+      else:
+        out = self.d_step(sources, targets, gp_alpha_s, gp_alpha_t)
     self._advance_counters()
     return out
 
