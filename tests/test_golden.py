@@ -10,7 +10,7 @@ float32 oracle within fp32 round-off; where /root/reference is mounted the fixtu
 come out bit-identical.
 GPU: the HIP path (fp32 direct kernels; bf16 MFMA kernels with a looser bound) hits the same vectors
 through the C ABI.  Tolerances: fp32 primitives rel-L2 <= 1e-5; fp32 whole-network outputs rel-L2 <= 2e-5, losses 1e-4
-relative, whole-model gradients rel-L2 <= 8e-2 (typically 2e-3; rare LeakyReLU-mask flips move them by 1-6 %); bf16 outputs rel-L2 <= 5e-2, losses 5e-2.
+relative, whole-model gradients rel-L2 <= 1e-2 (every variable of non-negligible norm <= 3e-2); bf16 outputs rel-L2 <= 5e-2, losses 5e-2.
 """
 import os
 
@@ -308,12 +308,11 @@ def test_gpu_model_hits_golden(name, precision):
   a_s, a_t = _dev(g['in/gp_alpha_s']), _dev(g['in/gp_alpha_t'])
   n_s = _dev(g['in/dragan_noise_s'], adt) if 'in/dragan_noise_s' in g else None
   n_t = _dev(g['in/dragan_noise_t'], adt) if 'in/dragan_noise_t' in g else None
-  # whole-model fp32 gradients: typically 2e-4..5e-3 from the fp64 vectors, but the graph has discontinuities
-  # (LeakyReLU masks, L1 signs) and the fp32 statistics are summed with atomics in varying order, so a unit
-  # sitting within ~1e-6 of zero occasionally flips and moves the encoder gradients by 1-6 % (measured: 5 of 40
-  # runs at 2.7e-2 on this case, tools/dbg_flaky.py; none with l_content_weight=0).  Hence 8e-2 here; the tight
-  # bounds are the per-primitive ones.
-  otol, ltol, gtol = (2e-5, 1e-4, 8e-2) if precision == 'fp32' else (5e-2, 5e-2, None)
+  # whole-model fp32 gradients: 1e-6 .. 5e-3 from the fp64 vectors (the 64x64 graph is ill-conditioned: the fp32
+  # torch oracle itself is 1e-3 from the fp64 one).  The graph has discontinuities (LeakyReLU masks, L1 signs), but
+  # every forward statistic is summed in a fixed order (norm.hip), so there is no run-to-run flip of a unit near
+  # zero any more (round 1: 5 of 40 runs at 2.7e-2, hence 8e-2 then).  Aggregate 1e-2, every variable 3e-2.
+  otol, ltol, gtol = (2e-5, 1e-4, 1e-2) if precision == 'fp32' else (5e-2, 5e-2, None)
   with torch.no_grad():
     gs, gt = (T.get_growing_image(s, cfg.alpha_grow), T.get_growing_image(t, cfg.alpha_grow)) if cfg.is_growing else (s, t)
     o = T.forward_generators(tr.P, gs, gt, cfg, noise)
@@ -344,3 +343,9 @@ def test_gpu_model_hits_golden(name, precision):
     num = sum(float(((gd[k].double().cpu().numpy() - g['grad/' + k]) ** 2).sum()) for k in names)
     den = sum(float((g['grad/' + k] ** 2).sum()) for k in names)
     assert (num / den) ** 0.5 < gtol, (group, (num / den) ** 0.5)
+    top = max(float(np.linalg.norm(g['grad/' + k])) for k in names)
+    for k in names:      # ... and no single variable hides in the aggregate
+      nb = float(np.linalg.norm(g['grad/' + k]))
+      if nb >= 1e-3 * top:
+        e = float(np.linalg.norm(gd[k].double().cpu().numpy() - g['grad/' + k])) / nb
+        assert e < 3 * gtol, (group, k, e)

@@ -82,6 +82,10 @@ def test_networks_fp32_forward(growing):
     assert pred.shape == (3, 1)
 
 
+FP32_GRAD_TOL = 5e-3         # whole-model fp32 gradients, aggregate rel-L2 over a group (measured 5e-7 .. 1.6e-3)
+FP32_VAR_GRAD_TOL = 2e-2     # ... and every single variable of non-negligible norm (measured <= 5.7e-3)
+
+
 def _grads_close(tr, Pref, names, tol, what, min_cos=None, var_tol=None):
   """Aggregate rel-L2 over the group <= tol, and -- ``var_tol`` -- every single variable whose reference gradient is
   not negligible (norm >= 1e-3 of the group's largest) within var_tol of it: a wrong gradient of one small tensor
@@ -116,15 +120,16 @@ def test_losses_and_gradients(precision, hw, max_ch):
   from twingan_amd import twingan as T
   cfg, rcfg, tr, Pref, dev, ref = make(dict(hw=hw, max_ch=max_ch), precision, seed=2, batch=2)
   # fp32: the fp32 torch-CPU oracle itself sits 1e-3 from the fp64 one at 64x64 (GP double backward, IN
-  # cancellations), and the fp32
-  # kernels (different summation orders, one-pass shifted statistics) 3-5e-3; on top, the atomics-ordered fp32
-  # statistics make a LeakyReLU unit within ~1e-6 of zero flip now and then, which moves the encoder gradients by
-  # 1-6 % (tools/dbg_flaky.py) -- so 8e-2.  bf16: this graph is chaotic under 2^-8 storage rounding -- the fp64 oracle
+  # cancellations); the fp32 kernels (other summation orders, one-pass shifted statistics) measure 1e-6 at 16x16 and
+  # 1.6e-3 (worst single variable 5.7e-3) at 64x64.  Every statistic of the forward pass is summed in a fixed order
+  # (norm.hip wave_channel_accumulate), so these figures are reproducible run to run -- round 1 needed 8e-2 because
+  # atomics-ordered statistics flipped a LeakyReLU unit near zero now and then.  bf16: this graph is chaotic under 2^-8 storage rounding -- the fp64 oracle
   # with bf16 rounding inserted at the same storage points (tools/bf16_sensitivity.py) moves the G
   # gradients by rel-L2 0.31 on this very case (0.21 from rounding the weights alone, 0.10 in fp16), and
   # the kernels reproduce that figure (0.32); per-primitive bf16 bounds are tight (test_gpu_ops.py).
   # So the whole-model bf16 check is directional: rel-L2 <= 0.5 and cosine >= 0.9.
-  ftol, gtol = (1e-4, 8e-2) if precision == 'fp32' else (3e-2, 0.5)
+  ftol, gtol = (1e-4, FP32_GRAD_TOL) if precision == 'fp32' else (3e-2, 0.5)
+  vtol = FP32_VAR_GRAD_TOL if precision == 'fp32' else None
   min_cos = None if precision == 'fp32' else 0.9
   for v in Pref.values():
     v.requires_grad_(True)
@@ -141,7 +146,7 @@ def test_losses_and_gradients(precision, hw, max_ch):
   rgl.backward()
   gptr = tr.store.grad['g'].data_ptr()
   assert tr.P['generator/block_4x4x%d/Conv/weights' % max_ch].grad.data_ptr() >= gptr     # flat buffer still in place
-  _grads_close(tr, Pref, tr.store.names('g'), gtol, 'generator', min_cos)
+  _grads_close(tr, Pref, tr.store.names('g'), gtol, 'generator', min_cos, vtol)
   for v in Pref.values():
     v.grad = None
   # ---- discriminator loss (WGAN-GP double backward)
@@ -155,7 +160,7 @@ def test_losses_and_gradients(precision, hw, max_ch):
         0 if precision == 'fp32' else 5e-2 * abs(rdterms[k].item()) + 2e-2), (k, dterms[k].item(), rdterms[k].item())
   dl.backward()
   rdl.backward()
-  _grads_close(tr, Pref, tr.store.names('d'), gtol, 'discriminator', min_cos)
+  _grads_close(tr, Pref, tr.store.names('d'), gtol, 'discriminator', min_cos, vtol)
 
 
 @pytest.mark.parametrize('equalized,res_block,growing', [(True, False, False), (False, True, False), (True, True, True)])
@@ -192,7 +197,7 @@ def test_equalized_lr_and_res_block(equalized, res_block, growing):
     assert abs(gterms[k].item() - rterms[k].item()) < 1e-4 * max(1.0, abs(rterms[k].item())), k
   gl.backward()
   rgl.backward()
-  _grads_close(tr, Pref, tr.store.names('g'), 8e-2, 'generator')
+  _grads_close(tr, Pref, tr.store.names('g'), FP32_GRAD_TOL, 'generator', var_tol=FP32_VAR_GRAD_TOL)
   for v in Pref.values():
     v.grad = None
   tr.store.zero_grad('d')
@@ -203,7 +208,7 @@ def test_equalized_lr_and_res_block(equalized, res_block, growing):
     assert abs(dterms[k].item() - rdterms[k].item()) < 1e-4 * max(1.0, abs(rdterms[k].item())), k
   dl.backward()
   rdl.backward()
-  _grads_close(tr, Pref, tr.store.names('d'), 8e-2, 'discriminator')
+  _grads_close(tr, Pref, tr.store.names('d'), FP32_GRAD_TOL, 'discriminator', var_tol=FP32_VAR_GRAD_TOL)
 
 
 def test_equalized_res_block_bf16_graph_step_runs():
@@ -384,7 +389,7 @@ def test_discriminator_max_channels_matches_oracle():
     assert abs(dterms[k].item() - rterms[k].item()) < 1e-4 * max(1.0, abs(rterms[k].item())), k
   dl.backward()
   rdl.backward()
-  _grads_close(tr, Pref, tr.store.names('d'), 8e-2, 'discriminator')
+  _grads_close(tr, Pref, tr.store.names('d'), FP32_GRAD_TOL, 'discriminator', var_tol=FP32_VAR_GRAD_TOL)
 
 
 def test_full_size_properties_256_bf16():
@@ -569,7 +574,7 @@ def test_loss_architectures_match_oracle(loss, drift):
     assert abs(gterms[k].item() - rgterms[k].item()) < 1e-4 * max(1.0, abs(rgterms[k].item())), k
   gl.backward()
   rgl.backward()
-  _grads_close(tr, Pref, tr.store.names('g'), 8e-2, 'generator')
+  _grads_close(tr, Pref, tr.store.names('g'), FP32_GRAD_TOL, 'generator', var_tol=FP32_VAR_GRAD_TOL)
   for v in Pref.values():
     v.grad = None
   # discriminator side
@@ -583,7 +588,7 @@ def test_loss_architectures_match_oracle(loss, drift):
     assert abs(dterms[k].item() - rdterms[k].item()) < 1e-4 * max(1.0, abs(rdterms[k].item())), (k, dterms[k].item(), rdterms[k].item())
   dl.backward()
   rdl.backward()
-  _grads_close(tr, Pref, tr.store.names('d'), 8e-2, 'discriminator')
+  _grads_close(tr, Pref, tr.store.names('d'), FP32_GRAD_TOL, 'discriminator', var_tol=FP32_VAR_GRAD_TOL)
 
 
 def test_batch_norm_generator_matches_oracle():
@@ -611,7 +616,7 @@ def test_batch_norm_generator_matches_oracle():
     assert abs(gterms[k].item() - rgterms[k].item()) < 1e-4 * max(1.0, abs(rgterms[k].item())), k
   gl.backward()
   rgl.backward()
-  _grads_close(tr, Pref, tr.store.names('g'), 8e-2, 'generator(batch_norm)')
+  _grads_close(tr, Pref, tr.store.names('g'), FP32_GRAD_TOL, 'generator(batch_norm, var_tol=FP32_VAR_GRAD_TOL)')
   # moving statistics: same set of variables, same values (each pass = one assign_moving_average)
   assert set(tr.store.state) == set(state)
   for k, v in state.items():
@@ -652,7 +657,7 @@ def test_batch_renorm_generator_matches_oracle(global_step):
       assert abs(gterms[k].item() - rgterms[k].item()) < 2e-4 * max(1.0, abs(rgterms[k].item())), (it, k)
     gl.backward()
     rgl.backward()
-    _grads_close(tr, Pref, tr.store.names('g'), 8e-2, 'generator(batch_renorm, run %d)' % it)
+    _grads_close(tr, Pref, tr.store.names('g'), FP32_GRAD_TOL, 'generator(batch_renorm, run %d, var_tol=FP32_VAR_GRAD_TOL)' % it)
   renorm_state = {k: v for k, v in tr.store.state.items() if not k.startswith('renorm/')}
   assert set(renorm_state) == set(state)
   for k, v in state.items():
@@ -691,7 +696,7 @@ def test_spectral_norm_and_self_attention(loss):
     rgl.backward()
     pggan.end_run(tr.P)
     R.end_run(rcfg)
-    _grads_close(tr, Pref, tr.store.names('g'), 8e-2, 'generator run %d' % it)
+    _grads_close(tr, Pref, tr.store.names('g'), FP32_GRAD_TOL, 'generator run %d' % it, var_tol=FP32_VAR_GRAD_TOL)
     for v in Pref.values():
       v.grad = None
     tr.store.zero_grad('d')
@@ -704,7 +709,7 @@ def test_spectral_norm_and_self_attention(loss):
     rdl.backward()
     pggan.end_run(tr.P)
     R.end_run(rcfg)
-    _grads_close(tr, Pref, tr.store.names('d'), 8e-2, 'discriminator run %d' % it)
+    _grads_close(tr, Pref, tr.store.names('d'), FP32_GRAD_TOL, 'discriminator run %d' % it, var_tol=FP32_VAR_GRAD_TOL)
     for k, v in rcfg.sn_state.items():
       assert rel_l2(tr.store.state[k], v) < 1e-4, (it, k)
 
@@ -736,7 +741,7 @@ def test_spectral_norm_in_encoder_and_generator():
   rgl.backward()
   pggan.end_run(tr.P)
   R.end_run(rcfg)
-  _grads_close(tr, Pref, tr.store.names('g'), 8e-2, 'generator run')
+  _grads_close(tr, Pref, tr.store.names('g'), FP32_GRAD_TOL, 'generator run', var_tol=FP32_VAR_GRAD_TOL)
   for k, v in rcfg.sn_state.items():
     assert rel_l2(tr.store.state[k], v) < 1e-4, k
 
@@ -780,7 +785,7 @@ def test_style_embedding_matches_oracle(attention):
     assert abs(gterms[k].item() - rterms[k].item()) < 1e-4 * max(1.0, abs(rterms[k].item())), k
   gl.backward()
   rgl.backward()
-  _grads_close(tr, Pref, tr.store.names('g'), 8e-2, 'generator(style)')
+  _grads_close(tr, Pref, tr.store.names('g'), FP32_GRAD_TOL, 'generator(style, var_tol=FP32_VAR_GRAD_TOL)')
   # the discriminator step only needs the forward of the styled generators
   tr.store.zero_grad('d')
   tr._set_requires_grad(g=False, d=True)

@@ -38,17 +38,24 @@ def bucket_bounds(numel, n_buckets, align=64):
 class GradReducer:
   """Sum all-reduce of one flat gradient buffer across clones, in ``n_buckets`` async pieces."""
 
-  def __init__(self, world_size=1, process_group=None, n_buckets=2):
+  def __init__(self, world_size=1, process_group=None, n_buckets=2, always=False):
+    """``always``: issue the collectives for a single clone too (tools/rccl_smoke.py: exercises RCCL and the
+    segment / all-reduce interleaving on a one-GPU box; a one-rank sum is the identity)."""
     self.world = int(world_size)
     self.pg = process_group
     self.n_buckets = n_buckets
+    self.always = always
     self._pending = []
+
+  @property
+  def active(self):
+    return self.world > 1 or self.always
 
   def start(self, flat_grad, n_buckets=None):
     """Enqueues the bucketed all-reduce of ``flat_grad`` (a 1-D view of a flat gradient buffer; no-op for a single
     clone) behind everything already enqueued on the current stream.  May be called several times before finish().
     Returns the number of buckets issued."""
-    if self.world <= 1:
+    if not self.active:
       return 0
     if not dist.is_initialized():
       raise RuntimeError('world_size %d but torch.distributed is not initialised' % self.world)

@@ -312,7 +312,7 @@ class Trainer:
     """deployment/model_deploy.py:473-503 (tf.add_n over clones) as RCCL sum all-reduces of the flat gradient buffer:
     the range whose gradients backward segment ``seg`` completed is enqueued on the communication stream (which waits
     for everything enqueued so far) and travels while the next segment runs; _reduce_finish() waits before Adam."""
-    if self.world <= 1:
+    if not self.reducer.active:
       return
     g = self.store.grad[group]
     if self._nseg(group) == 1:
@@ -441,7 +441,7 @@ class Trainer:
     pool = None
     # with a process group alive, its watchdog thread issues event queries while we capture: only this
     # thread's unsafe calls may invalidate the capture
-    mode = 'thread_local' if self.world > 1 else 'global'
+    mode = 'thread_local' if (self.world > 1 or torch.distributed.is_initialized()) else 'global'
     adam_t = self.adam_t
     for kind in ('g', 'd'):
       segs = []
