@@ -313,6 +313,13 @@ def test_gpu_model_hits_golden(name, precision):
   # every forward statistic is summed in a fixed order (norm.hip), so there is no run-to-run flip of a unit near
   # zero any more (round 1: 5 of 40 runs at 2.7e-2, hence 8e-2 then).  Aggregate 1e-2, every variable 3e-2.
   otol, ltol, gtol = (2e-5, 1e-4, 1e-2) if precision == 'fp32' else (5e-2, 5e-2, None)
+  vtol = 3 * gtol if gtol else None
+  if name.endswith('_style'):
+    # the style encoder's last layer is an instance norm over ONE pixel (out_tol above): its 1000 * x cancellation
+    # costs any fp32 evaluation 1e-3 of the embedding, which flips low-resolution LeakyReLU units of the cycle passes.
+    # Measured on this fixture: the plain fp32 torch oracle is 6.58e-2 (worst variable 0.50) from the float64
+    # vectors, the fp32 HIP path 6.58e-2 (tools/golden_grad_report.py) -- the bound is what fp32 can do here
+    gtol, vtol = 1e-1, None
   with torch.no_grad():
     gs, gt = (T.get_growing_image(s, cfg.alpha_grow), T.get_growing_image(t, cfg.alpha_grow)) if cfg.is_growing else (s, t)
     o = T.forward_generators(tr.P, gs, gt, cfg, noise)
@@ -344,8 +351,8 @@ def test_gpu_model_hits_golden(name, precision):
     den = sum(float((g['grad/' + k] ** 2).sum()) for k in names)
     assert (num / den) ** 0.5 < gtol, (group, (num / den) ** 0.5)
     top = max(float(np.linalg.norm(g['grad/' + k])) for k in names)
-    for k in names:      # ... and no single variable hides in the aggregate
+    for k in names if vtol else ():      # ... and no single variable hides in the aggregate
       nb = float(np.linalg.norm(g['grad/' + k]))
       if nb >= 1e-3 * top:
         e = float(np.linalg.norm(gd[k].double().cpu().numpy() - g['grad/' + k])) / nb
-        assert e < 3 * gtol, (group, k, e)
+        assert e < vtol, (group, k, e)

@@ -304,6 +304,239 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Thin layers (cin or cout = 16: the 256x256 blocks of E / D, the generator's last concat conv).  The 32 x 32
+// accumulator block of the kernel above is 75 % padding there (kbench: 16->16 and 16->32 at 256x256 take the same
+// 100 us -- bound by MFMA issue and per-tile overhead, not by HBM).  Here the block is 16 ci x CO co (CO = 16 | 32)
+// (one workgroup per 16 x 16 block of the weight) on v_mfma_f32_16x16x32_bf16: A = x^T [16 ci x 32 px], B = gy [32 px x 16 co], K = 32 pixels = the same two
+// transpose reads per operand.  LDS holds 16 channels per pixel (32 B; gy: CO * 2 B), the tile is 16 rows x 16 cols
+// (halo 18 x 18: 1.27x instead of 1.41x), wave w reduces row pairs (4w, 4w+1) and (4w+2, 4w+3) = 2 K steps per tile.
+// K index k = (group gq = lane >> 4, e = 0..7)  <->  pixel (row r + (e >> 2), col 4*gq + (e & 3)): a half-wave then
+// reads 8 consecutive pixels = 256 contiguous bytes per transpose read (conflict-free), same mapping for both operands.
+// Accumulators: 9 x f32x4 instead of 9 x f32x16 -> 4 workgroups per CU instead of 2.  A 32-channel cout runs as two
+// co blocks (a single workgroup with both, CO = 32, needs 214 VGPRs: 2 workgroups per CU, 112 vs 105 us in kbench).
+template <int CO, bool BIAS>
+__global__ __launch_bounds__(256, BIAS ? 3 : 4) void conv_wgrad_thin_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gy,
+                                                                 float* __restrict__ slab, const WgGeom g) {
+  constexpr int TH = 16, TW = 16, HWX = 18, HH = 18, NT = 9, NB = CO / 16;
+  constexpr int PSX = 32, PSG = CO * 2;
+  constexpr int XPX = HH * HWX;                                         // 324 halo pixels
+  constexpr int XVEC = XPX * 2, XSLOTS = (XVEC + 255) / 256;            // 648 16-byte vectors -> 3
+  constexpr int GVEC = 256 * (CO / 8), GSLOTS = GVEC / 256;             // 2 | 4
+  constexpr int X_BYTES = XPX * PSX;                                    // 10368
+  constexpr int G_BYTES = 256 * PSG;                                    // 8192 | 16384
+  typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int slice, pair;      // same XCD-aware (slice, ci block) mapping as conv_wgrad_tile_kernel
+  {
+    const int id = blockIdx.x, npairs = g.n_pairs;
+    if ((g.nslices & 7) == 0) {
+      const int hi = id / (8 * npairs), rem = id - hi * 8 * npairs;
+      pair = rem >> 3;
+      slice = hi * 8 + (rem & 7);
+    } else {
+      pair = id % npairs;
+      slice = id / npairs;
+    }
+  }
+  const int ci_blk = pair / g.n_co_blk, co_blk = pair - ci_blk * g.n_co_blk;
+  const int ci0 = ci_blk * 16, co0 = co_blk * CO;
+
+  int x_loff[XSLOTS], x_hy1[XSLOTS], x_hx1[XSLOTS], x_rel[XSLOTS];
+  bool x_use[XSLOTS];
+#pragma unroll
+  for (int s = 0; s < XSLOTS; ++s) {
+    const int v = tid + s * 256;
+    const int px = v >> 1, part = v & 1;
+    x_hy1[s] = px / HWX - 1;
+    x_hx1[s] = px % HWX - 1;
+    x_use[s] = v < XVEC;
+    if (g.c0 == 0)
+      x_rel[s] = ((x_hy1[s] * g.w + x_hx1[s]) * g.cin + ci0 + part * 8) * 2;
+    else if (ci0 < g.c0)      // half-resolution source: (iy >> 1, ix >> 1); tile origins are even
+      x_rel[s] = (((x_hy1[s] >> 1) * (g.w >> 1) + (x_hx1[s] >> 1)) * g.c0 + ci0 + part * 8) * 2;
+    else                      // skip source
+      x_rel[s] = ((x_hy1[s] * g.w + x_hx1[s]) * (g.cin - g.c0) + ci0 - g.c0 + part * 8) * 2;
+    x_loff[s] = px * PSX + part * 16;
+  }
+  int g_loff[GSLOTS];
+  unsigned g_rel[GSLOTS];
+#pragma unroll
+  for (int s = 0; s < GSLOTS; ++s) {
+    const int v = tid + s * 256;
+    const int px = v / (CO / 8), part = v % (CO / 8);
+    const bool use = co0 + part * 8 + 8 <= g.cout;
+    g_rel[s] = use ? (unsigned)((((px >> 4) * g.w + (px & 15)) * g.cout + co0 + part * 8) * 2) : WOOB;
+    g_loff[s] = px * PSG + part * 16;
+  }
+
+  // fragment addresses: group gq points at pixel col 4*gq + (t16 >> 2) of the K step's first row; the second
+  // transpose read is the same columns one row down
+  const int gq = lane >> 4, t16 = lane & 15;
+  const int fx = (gq * 4 + (t16 >> 2)) * PSX + (t16 & 3) * 8;
+  const int fg = (gq * 4 + (t16 >> 2)) * PSG + (t16 & 3) * 8;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto frag = [&](const unsigned char* p, int row_stride) __attribute__((always_inline)) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + row_stride));
+    s16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  f32x4 acc[NT][NB];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][b][j] = 0.f;
+  f32x4 accb[NB];
+  bf16x8 ones;
+  if constexpr (BIAS) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) accb[b][j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+  }
+  const bool do_bias = BIAS && ci_blk == 0;      // uniform
+  bool bias_a = false, bias_b = false, bias_0 = false, bias_1 = false;
+
+  const bool from_up = g.c0 != 0 && ci0 < g.c0, from_skip = g.c0 != 0 && ci0 >= g.c0;
+  const int xc = from_up ? g.c0 : (from_skip ? g.cin - g.c0 : g.cin);
+  const size_t ximg = from_up ? (size_t)(g.h >> 1) * (g.w >> 1) * xc : (size_t)g.h * g.w * xc;
+  const size_t gimg = (size_t)g.h * g.w * g.cout;
+  const bf16* xsrc = from_skip ? g.x1 : x;
+  const int tile_begin = slice * g.tiles_per_wg;
+  int tile_end = tile_begin + g.tiles_per_wg;
+  if (tile_end > g.total_tiles) tile_end = g.total_tiles;
+
+  struct Stage {
+    bf16x8 rx[XSLOTS], rg[GSLOTS];
+  };
+  auto load_tile = [&](Stage& st, int tile, bool& bias_on) __attribute__((always_inline)) {
+    const unsigned live = tile < tile_end;
+    int t = live ? tile : tile_begin;
+    const bool segb = t >= g.tiles_a;
+    bias_on = do_bias && ((g.bias_segs >> (segb ? 1 : 0)) & 1);
+    if (segb) t -= g.tiles_a;
+    const bf16* xs = segb ? g.xb : xsrc;
+    const bf16* gs = segb ? g.gyb : gy;
+    const int tx = t % g.tiles_x;
+    t /= g.tiles_x;
+    const int ty = t % g.tiles_y;
+    const int img = t / g.tiles_y;
+    const int ox0 = tx * TW, oy0 = ty * TH;
+    const int ximg_i = (from_skip && g.gsz) ? (int)((g.perm >> (8 * (img / g.gsz))) & 0xffu) * g.gsz + img % g.gsz : img;
+    const __amdgpu_buffer_rsrc_t bx = wg_rsrc(xs + (size_t)ximg_i * ximg, (unsigned)(ximg * 2));
+    const __amdgpu_buffer_rsrc_t bg = wg_rsrc(gs + (size_t)img * gimg, (unsigned)(gimg * 2));
+    const int xbase = from_up ? ((oy0 >> 1) * (g.w >> 1) + (ox0 >> 1)) * xc * 2 : (oy0 * g.w + ox0) * xc * 2;
+    const unsigned gbase = (unsigned)((oy0 * g.w + ox0) * g.cout * 2);
+#pragma unroll
+    for (int s = 0; s < XSLOTS; ++s) {
+      const unsigned ok = live & (unsigned)x_use[s] & (unsigned)((unsigned)(oy0 + x_hy1[s]) < (unsigned)g.h) &
+                          (unsigned)((unsigned)(ox0 + x_hx1[s]) < (unsigned)g.w);
+      const unsigned off = ok ? (unsigned)(xbase + x_rel[s]) : WOOB;
+      st.rx[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bx, off, 0, 0));
+    }
+#pragma unroll
+    for (int s = 0; s < GSLOTS; ++s)
+      st.rg[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bg, live ? gbase + g_rel[s] : WOOB, 0, 0));
+  };
+  auto stage_to_lds = [&](const Stage& st, unsigned char* bX, unsigned char* bG) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < XSLOTS; ++s)
+      if (s < XSLOTS - 1 || tid + s * 256 < XVEC) *reinterpret_cast<bf16x8*>(bX + x_loff[s]) = st.rx[s];
+#pragma unroll
+    for (int s = 0; s < GSLOTS; ++s) *reinterpret_cast<bf16x8*>(bG + g_loff[s]) = st.rg[s];
+  };
+  auto reduce_tile = [&](const unsigned char* bX, const unsigned char* bG, bool bias_on) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int r = wid * 4 + ks * 2;      // first output row of this K step
+      bf16x8 gf[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) gf[b] = frag(bG + r * 16 * PSG + fg + b * 32, 16 * PSG);
+      if constexpr (BIAS) {
+        if (bias_on) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) accb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, gf[b], accb[b], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const bf16x8 xf = frag(bX + ((r + ky) * HWX + kx) * PSX + fx, HWX * PSX);
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+            acc[ky * 3 + kx][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, gf[b], acc[ky * 3 + kx][b], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  unsigned char* sX = wg_smem;
+  unsigned char* sG = wg_smem + X_BYTES;
+  unsigned char* sX1 = wg_smem + X_BYTES + G_BYTES;
+  unsigned char* sG1 = sX1 + X_BYTES;
+  Stage sa, sb;
+  load_tile(sa, tile_begin, bias_a);
+  load_tile(sb, tile_begin + 1, bias_b);
+  for (int tile = tile_begin; tile < tile_end; tile += 2) {
+    stage_to_lds(sa, sX, sG);
+    bias_0 = bias_a;
+    __syncthreads();
+    load_tile(sa, tile + 2, bias_a);
+    reduce_tile(sX, sG, bias_0);
+    stage_to_lds(sb, sX1, sG1);
+    bias_1 = bias_b;
+    __syncthreads();
+    load_tile(sb, tile + 3, bias_b);
+    reduce_tile(sX1, sG1, bias_1);
+  }
+
+  // ---- cross-wave reduction through LDS, one co half at a time (4 waves x 36 regs x 64 lanes floats = 36 KiB), and
+  // the slab write.  acc[tap][b][r]: ci = ci0 + 4*(lane >> 4) + r, co = 16*b + (lane & 15)
+  float* red = reinterpret_cast<float*>(wg_smem);
+  constexpr int NR = NT * 4;                               // registers per lane and co half
+  float* out = slab + (size_t)slice * NT * g.cin * g.cout;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < NT; ++tap)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wid * NR + tap * 4 + r) * 64 + lane] = acc[tap][b][r];
+    __syncthreads();
+    for (int i = tid; i < NR * 64; i += 256) {
+      const int q = i >> 6, l2 = i & 63;
+      const float sum = red[(0 * NR + q) * 64 + l2] + red[(1 * NR + q) * 64 + l2] + red[(2 * NR + q) * 64 + l2] +
+                        red[(3 * NR + q) * 64 + l2];
+      const int r = q & 3, tap = q >> 2;
+      const int ci = ci0 + 4 * (l2 >> 4) + r, co = co0 + 16 * b + (l2 & 15);
+      if (co < g.cout) out[((size_t)tap * g.cin + ci) * g.cout + co] = sum;
+    }
+  }
+  if constexpr (BIAS) {
+    if (do_bias) {      // accb[b][0] on lanes 0..15 = row 0 of the all-equal rows: column sum of co 16*b + lane
+      __syncthreads();
+      if (lane < 16) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) red[wid * 32 + b * 16 + lane] = accb[b][0];
+      }
+      __syncthreads();
+      if (tid < CO && co0 + tid < g.cout) atomicAdd(g.gbias + co0 + tid, red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid]);
+    }
+  }
+}
+
 // gw[i] (+)= sum over the k-slices of slab[k][i].  A workgroup owns 256/SG consecutive elements; its 256
 // threads are SG slice groups x 256/SG elements, summed through LDS: no pre-zeroing; one
 // atomic per element only when accumulating into an existing gradient (several streams may feed one sink).  SG is large for small weights (few elements, many slices) and 1 for large ones.
@@ -314,15 +547,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_slab_reduce(const float* __res
   __shared__ float part[SG][EPB + 1];
   const int e = threadIdx.x % EPB, sg = threadIdx.x / EPB;
   const int64_t i = (int64_t)blockIdx.x * EPB + e;
-  float s0 = 0.f, s1 = 0.f;
+  // 8 independent partial sums in a fixed order: 8 loads in flight per thread (with 2 the kernel ran at one L2 round
+  // trip per pair of slices: 11.8 us for 1024 slabs of a 16 x 16 layer, rocprofv3) and a result that does not depend
+  // on timing
+  float a[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) a[u] = 0.f;
   if (i < nw) {
     int k = sg;
-    for (; k + SG < nslices; k += 2 * SG) {
-      s0 += slab[(size_t)k * nw + i];
-      s1 += slab[(size_t)(k + SG) * nw + i];
+    for (; k + 7 * SG < nslices; k += 8 * SG) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += slab[(size_t)(k + u * SG) * nw + i];
     }
-    if (k < nslices) s0 += slab[(size_t)k * nw + i];
+    for (; k < nslices; k += SG) a[0] += slab[(size_t)k * nw + i];
   }
+  const float s0 = (a[0] + a[1]) + (a[2] + a[3]), s1 = (a[4] + a[5]) + (a[6] + a[7]);
   if (SG == 1) {
     if (i < nw) {
       if (accumulate) atomicAdd(gw + i, s0 + s1);      // sinks may be fed from several streams at once
@@ -341,7 +580,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_slab_reduce(const float* __res
   }
 }
 
+bool wg_thin(int h, int w, int cin, int cout);
+
 void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices, int nb = 0) {
+  const bool thin = wg_thin(h, w, cin, cout);
   g->n = n; g->h = h; g->w = w; g->cin = cin; g->cout = cout;
   g->x1 = nullptr;
   g->c0 = g->gsz = 0;
@@ -356,19 +598,19 @@ void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices, i
     g->total_tiles = g->tiles_a + (nb + 1) / 2;
   } else {
     g->tiles_x = w / 16;
-    g->tiles_y = h / 8;
+    g->tiles_y = h / (thin ? 16 : 8);
     g->tiles_a = g->tiles_x * g->tiles_y * n;
     g->total_tiles = g->tiles_a + g->tiles_x * g->tiles_y * nb;
   }
-  const int n_ci = (cin + 31) / 32;
-  g->n_co_blk = (cout + 31) / 32;
+  const int n_ci = thin ? cin / 16 : (cin + 31) / 32;      // thin: 16-channel ci blocks, one co block (cout <= 32)
+  g->n_co_blk = thin ? (cout + 15) / 16 : (cout + 31) / 32;
   // ~2 workgroups per CU in total; 1 per CU when that leaves a workgroup fewer than 8 tiles: every workgroup
   // costs one slab write + read (9*32*32 floats), which then outweighs its share of the input traffic
   // (kbench, 128x128x32 n16: 24.2 -> 20.6 us; 256x256x16 n48 prefers 512: 70 vs 85 us).
   const int pairs = n_ci * g->n_co_blk;
-  int want = 512 / pairs;
+  int want = (thin ? 1024 : 512) / pairs;      // thin: 4 workgroups per CU fit
   if (want < 1) want = 1;
-  if ((g->total_tiles + want - 1) / want < 8) want = 256 / pairs;
+  if ((g->total_tiles + want - 1) / want < (thin ? 4 : 8)) want = 256 / pairs;
   if (want < 1) want = 1;
   if (want > g->total_tiles) want = g->total_tiles;
   g->tiles_per_wg = (g->total_tiles + want - 1) / want;
@@ -380,6 +622,24 @@ void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices, i
 }  // namespace
 
 int tg_wgrad_slab_reduce(const float* slab, float* gw, int64_t nw, int nslices, int accumulate, hipStream_t s);
+
+namespace {
+bool wg_thin(int h, int w, int cin, int cout) {
+  return h % 16 == 0 && w % 16 == 0 && h >= 64 && cin % 16 == 0 && cout % 8 == 0 && cout <= 32 && (cin == 16 || cout == 16);
+}
+
+// launches the thin kernel for geometry g (already split); false: not a thin layer
+bool wg_launch_thin(const WgGeom& g, const bf16* x, const bf16* gy, float* ws, int nslices, hipStream_t s) {
+  if (!wg_thin(g.h, g.w, g.cin, g.cout)) return false;
+  const dim3 grid(nslices * (g.cin / 16) * g.n_co_blk);
+  const bool bias = g.gbias != nullptr;
+  const size_t lds = 2 * (18 * 18 * 32 + 256 * 32);
+  tg_note_kernel(bias ? "conv_wgrad_thin_kernel<16,bias>" : "conv_wgrad_thin_kernel<16>");
+  if (bias) hipLaunchKernelGGL((conv_wgrad_thin_kernel<16, true>), grid, dim3(256), lds, s, x, gy, ws, g);
+  else hipLaunchKernelGGL((conv_wgrad_thin_kernel<16, false>), grid, dim3(256), lds, s, x, gy, ws, g);
+  return true;
+}
+}  // namespace
 
 bool tg_wgrad_tile_supported(int h, int w, int hout, int wout, int kh, int kw, int pad_t, int pad_l) {
   return kh == 3 && kw == 3 && pad_t == 1 && pad_l == 1 && h == hout && w == wout &&
@@ -402,6 +662,10 @@ int tg_wgrad_tile_run(int n, int h, int w, int cin, int cout, const void* x, con
   const int64_t nw = (int64_t)9 * cin * cout;
   TG_CHECK(ws && ws_bytes >= (size_t)nslices * nw * sizeof(float), TG_EINVAL,
            "tg_conv2d_bwd_weight(tile): workspace too small (%zu < %zu)", ws_bytes, (size_t)nslices * nw * sizeof(float));
+  if (wg_launch_thin(g, (const bf16*)x, (const bf16*)gy, (float*)ws, nslices, s)) {
+    TG_LAUNCH_CHECK("conv_wgrad_thin");
+    return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
+  }
   const int n_ci = (cin + 31) / 32;
   const size_t lds = 2 * (10 * 18 * 64 + 8 * 16 * 64);      // two tile buffers of 19712 B; the first doubles as the 16 KiB reduction scratch
   tg_note_kernel("conv_wgrad_tile_kernel");
@@ -440,6 +704,10 @@ int tg_wgrad_tile_run2(int na, int nb, int h, int w, int cin, int cout, const vo
   const int64_t nw = (int64_t)9 * cin * cout;
   TG_CHECK(ws && ws_bytes >= (size_t)nslices * nw * sizeof(float), TG_EINVAL,
            "tg_conv2d_bwd_weight2: workspace too small (%zu < %zu)", ws_bytes, (size_t)nslices * nw * sizeof(float));
+  if (wg_launch_thin(g, (const bf16*)xa, (const bf16*)gya, (float*)ws, nslices, s)) {
+    TG_LAUNCH_CHECK("conv_wgrad_thin(2)");
+    return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
+  }
   const int n_ci = (cin + 31) / 32;
   tg_note_kernel("conv_wgrad_tile_kernel");
   const dim3 grid(nslices * n_ci * g.n_co_blk);
@@ -471,6 +739,10 @@ int tg_wgrad_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int g
   const int64_t nw = (int64_t)9 * cin * cout;
   TG_CHECK(ws && ws_bytes >= (size_t)nslices * nw * sizeof(float), TG_EINVAL,
            "tg_conv2d_bwd_weight_upcat: workspace too small (%zu < %zu)", ws_bytes, (size_t)nslices * nw * sizeof(float));
+  if (wg_launch_thin(g, (const bf16*)x0, (const bf16*)gy, (float*)ws, nslices, s)) {
+    TG_LAUNCH_CHECK("conv_wgrad_thin(upcat)");
+    return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
+  }
   const int n_ci = (cin + 31) / 32;
   const size_t lds = 2 * (10 * 18 * 64 + 8 * 16 * 64);
   tg_note_kernel("conv_wgrad_tile_kernel");
