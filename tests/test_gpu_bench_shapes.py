@@ -184,7 +184,7 @@ def test_upcat_conv_at_bench_shapes(key):
     e = rel_l2(host(y[i:i + 1]), N.conv2d_gemm(cat_of(i), wn))
     assert e < BF16_OUT_TOL, ('upcat fwd', key, i, e)
   y.backward(gy)
-  _note(key, 'tg_conv2d_upcat_bwd_weight', str(n), 'conv_wgrad_tile_kernel')
+  _note(key, 'tg_conv2d_upcat_bwd_weight', str(n))      # the filter gradient is the last conv launch of the backward
   gyn = host(gy)
   ref = np.zeros_like(wn)
   for i in range(n):
