@@ -39,8 +39,10 @@ def parse():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=6)
   ap.add_argument('--warmup', type=int, default=2)
-  ap.add_argument('--batch', type=int, default=16, help='pairs per GPU (BASELINE config: 16)')
-  ap.add_argument('--hw', type=int, default=256)
+  ap.add_argument('--config', type=int, default=3, choices=[1, 2, 3],
+                  help="BASELINE.json configs[i]: 1 = 64x64 batch 64, 2 = 128x128 batch 32, 3 = 256x256 batch 16 per GPU (the metric's)")
+  ap.add_argument('--batch', type=int, default=None, help='pairs per GPU (default: the config\'s)')
+  ap.add_argument('--hw', type=int, default=None)
   ap.add_argument('--max-ch', type=int, default=256)
   ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
   ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
@@ -54,7 +56,11 @@ def parse():
   ap.add_argument('--launch-check', action='store_true',
                   help='no kernels: bring up the N ranks, build the parameter store and time the per-segment gradient '
                        'all-reduce schedule of a step (gloo on CPU when no GPU is visible) -- tests the launcher')
-  return ap.parse_args()
+  args = ap.parse_args()
+  hw, batch = {1: (64, 64), 2: (128, 32), 3: (256, 16)}[args.config]
+  args.hw = args.hw or hw
+  args.batch = args.batch or batch
+  return args
 
 
 def _free_port():
@@ -175,33 +181,37 @@ def roofline_pass(tr, a, b, steps=2):
   roof['avg_launch_us'] = round(1e3 * f['ms'] / f['launches'], 2)
   roof['algorithmic_bytes_per_launch'] = int(f['bytes'] / f['launches'])
   roof['algorithmic_flops_per_launch'] = int(f['flops'] / f['launches'])
-  # measured HBM traffic of this kernel from the PMC passes (tools/pmc_traffic.sh -> profiles/r01_pmc_traffic.json):
-  # PMC runs are per layer shape, so the sample(s) taken on this kernel symbol are listed with their shapes;
-  # `traffic` is the measured HBM bytes per launch of the first sample (compare with its algorithmic bytes).
-  pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-  if os.path.exists(pmc):
-    try:
-      import re
-
-      def sym(n):      # mangled or plain kernel name -> "base<a,b,c>"
-        m = re.search(r'(conv_\w+?_kernel|conv_\w+_mfma)', n)
-        if not m:
-          return n
-        targs = re.findall(r'Li(\d+)E', n)
-        return m.group(1) + ('<%s>' % ','.join(targs) if targs else '')
-      samples = [dict(shape=e['shape'], hbm_bytes_per_launch=e['hbm_bytes_per_launch'],
-                      algorithmic_bytes_per_launch=e['algorithmic_bytes_per_launch'],
-                      traffic_over_algorithmic=e['traffic_over_algorithmic'])
-                 for e in json.load(open(pmc)).get('kernels', []) if sym(e.get('kernel', '')) == k]
-      samples.sort(key=lambda e: -e['algorithmic_bytes_per_launch'])
-      if samples:
-        roof['traffic'] = samples[0]['hbm_bytes_per_launch']
-        roof['traffic_samples'] = samples
-        roof['traffic_source'] = ('profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, '
-                                  'FETCH_SIZE x2 (gfx950), per launch of the listed layer shape')
-    except Exception:
-      pass
+  # measured HBM traffic and MFMA utilisation from the PMC passes (tools/pmc_kernels.sh -> profiles/rNN_pmc.json):
+  # PMC runs are per layer shape, so the samples taken on a kernel symbol are listed with their shapes; `traffic` is
+  # the measured HBM bytes per launch of the largest sample of the dominant kernel (compare with its algorithmic bytes)
+  pmc_rows, pmc_src = load_pmc()
+  if pmc_rows:
+    def samples_of(sym):
+      rows = [e for e in pmc_rows if same_kernel(e.get('kernel', ''), sym)]
+      rows.sort(key=lambda e: -e['algorithmic_bytes_per_launch'])
+      return [{kk: e[kk] for kk in ('shape', 'hbm_bytes_per_launch', 'algorithmic_bytes_per_launch', 'traffic_over_algorithmic',
+                                    'mfma_util', 'mfma_flops_over_algorithmic') if kk in e} for e in rows]
+    samples = samples_of(k)
+    if samples:
+      roof['traffic'] = samples[0].get('hbm_bytes_per_launch')
+      roof['traffic_samples'] = samples
+      utils = [e['mfma_util'] for e in samples if 'mfma_util' in e]
+      if utils:
+        roof['mfma_util'] = max(utils)
+      roof['traffic_source'] = ('%s: rocprofv3 --pmc, one counter set per pass; FETCH_SIZE x2 (gfx950); mfma_util = '
+                                'SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), per launch of the listed layer shape'
+                                % pmc_src)
+    roof['pmc_by_kernel'] = {}
+    for kk in fam:
+      sm = samples_of(kk)
+      if sm:
+        roof['pmc_by_kernel'][kk] = dict(
+            mfma_util=[e['mfma_util'] for e in sm if 'mfma_util' in e],
+            traffic_over_algorithmic=[e['traffic_over_algorithmic'] for e in sm if 'traffic_over_algorithmic' in e],
+            shapes=[e['shape'] for e in sm])
   roof['kernel_time_ms_per_step'] = round(t_total / steps, 3)
+  roof['kernel_time_note'] = ('sum of per-launch HIP-event durations of an EAGER pass of the same step; it exceeds ms_per_step '
+                              'because the two discriminator streams overlap and eager launches add event overhead')
   # whole step against the two peaks: sum over launches of max(flops/MFMA peak, bytes/HBM peak) / measured time
   roof['step_roofline_frac'] = round(t_min_total / t_total, 4)
   roof['top_shapes'] = [row(kk, ff) for kk, ff in top_shapes[:48]]
@@ -210,6 +220,42 @@ def roofline_pass(tr, a, b, steps=2):
       json.dump([row(kk, ff) for kk, ff in top_shapes], fh, indent=0)
   roof['families'] = [row(kk, ff) for kk, ff in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])[:12]]
   return roof
+
+
+def kernel_key(name):
+  """(base symbol, numeric template arguments) of a kernel name in any spelling: the mangled symbol rocprofv3 reports
+  (..conv_tile_wres_kernelILi3ELi16ELi32ELi1EE..), its demangled form, or what tg_last_kernel() notes
+  ("conv_tile_kernel<3,32,64,2,upcat>").  Non-numeric arguments (bools, tags) are dropped."""
+  import re
+  m = re.search(r'(conv_\w+?_kernel|conv_\w+_mfma)', name)
+  if not m:
+    return name, ()
+  rest = name[m.end():]
+  if rest.startswith('I'):      # mangled template argument list
+    nums = re.findall(r'Li(\d+)E', rest.split('EEv')[0])
+  else:
+    t = re.match(r'<([^>]*)>', rest)
+    nums = [v.strip() for v in t.group(1).split(',') if v.strip().isdigit()] if t else []
+  return m.group(1), tuple(int(v) for v in nums)
+
+
+def same_kernel(a, b):
+  (ba, ta), (bb, tb) = kernel_key(a), kernel_key(b)
+  n = min(len(ta), len(tb))
+  return ba == bb and ta[:n] == tb[:n]
+
+
+def load_pmc():
+  """The committed PMC table of the newest round (profiles/rNN_pmc*.json, tools/pmc_kernels.sh)."""
+  import glob
+  files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc*.json')))
+  if not files:
+    return [], None
+  try:
+    rows = json.load(open(files[-1])).get('kernels', [])
+  except Exception:
+    return [], None
+  return rows, os.path.relpath(files[-1], ROOT)
 
 
 def cpu_baseline(args):
@@ -289,9 +335,9 @@ def main():
         'value': value, 'unit': 'images/sec', 'n_gpus': observed_world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.precision, 'data': 'synthetic',
-        'config': {'workload': 'TwinGAN %dx%d final stage (configs[3]): E/G/2xD max_ch %d, UNet + per-domain '
+        'config': {'workload': 'TwinGAN %dx%d stage, batch %d per GPU (configs[%d]): E/G/2xD max_ch %d, UNet + per-domain '
                                'instance norm + pixel norm, WGAN-GP, Adam; 1 step = G apply + D apply' % (
-                                   args.hw, args.hw, args.max_ch),
+                                   args.hw, args.hw, args.batch, args.config, args.max_ch),
                    'global_batch': args.batch * observed_world, 'batch_per_gpu': args.batch,
                    'parallelism': 'dp%d' % observed_world, 'launch': launch,
                    'collective': ('%s all-reduce, world %d' % ('RCCL' if backend == 'nccl' else backend, observed_world))

@@ -139,8 +139,9 @@ class PackCache:
         call('tg_pack_table_fill', ctypes.byref(ent[2]), _p(cls._registered[k[0]]), k[1], _p(ent[1]), j,
              ctypes.addressof(host), ctypes.byref(blocks))
       dev = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(cls._packs[keys[0]][1].device)
-      tab = cls._tables[tkey] = (dev, len(keys), blocks.value)
-    call('tg_conv2d_pack_weights_multi', _p(tab[0]), tab[1], tab[2], _stream())
+      nbytes = sum(_nb(cls._registered[k[0]]) for k in keys) + sum(_nb(cls._packs[k][1]) for k in keys)
+      tab = cls._tables[tkey] = (dev, len(keys), blocks.value, nbytes)
+    call('tg_conv2d_pack_weights_multi', _p(tab[0]), tab[1], tab[2], _stream(), work=('pack_multi:%d' % tab[1], 0, tab[3]))
     for k in keys:
       cls._packs[k][0] = cls.version
     return len(keys)
@@ -307,6 +308,11 @@ def _shape_tag(t):
   return ':c%d:hw%d:n%d' % (t.shape[-1], t.shape[-2], t.shape[0]) if t.dim() == 4 else ':numel%d' % t.numel()
 
 
+def _nb(*ts):
+  """Bytes of the given tensors (None skipped): the compulsory traffic of a streaming kernel that touches each once."""
+  return sum(t.numel() * t.element_size() for t in ts if t is not None)
+
+
 def _conv_work(d, tag, es):
   """Algorithmic work of one conv launch: MACs*2 and compulsory bytes (input + output + weights once)."""
   flops = 2 * d.n * d.hout * d.wout * d.cout * d.kh * d.kw * d.cin
@@ -359,8 +365,10 @@ def conv_bwd_data_masked_raw(gy, w, x_act, spec):
   d = _desc(x_act.shape, w.shape[3], spec, gy.dtype, 0)
   gx = torch.empty_like(x_act)
   wk = PackCache.get(w, d, 1) if d.algo == TG_ALGO_MFMA else w
-  call('tg_conv2d_bwd_data_masked', ctypes.byref(d), _p(gy), _p(wk), _p(x_act), _p(gx), _stream(),
-       work=lambda: _conv_work(d, 'dgrad', _esize(gy)))
+  def work():      # the mask is one more read of a tensor of the input's size
+    tag, fl, by = _conv_work(d, 'dgrad', _esize(gy))
+    return tag.replace('dgrad:', 'dgrad_masked:'), fl, by + _nb(x_act)
+  call('tg_conv2d_bwd_data_masked', ctypes.byref(d), _p(gy), _p(wk), _p(x_act), _p(gx), _stream(), work=work)
   return gx
 
 
@@ -428,7 +436,8 @@ def _bias_grad(g, bias):
   sink = GradSink.get(bias)
   if sink is not None:
     c = g.shape[-1]
-    call('tg_channel_sum', _p(g), _p(sink), g.numel() // c, c, 1, _dt(g), _stream())
+    call('tg_channel_sum', _p(g), _p(sink), g.numel() // c, c, 1, _dt(g), _stream(),
+         work=('channel_sum' + _shape_tag(g), 0, _nb(g)))
     return None
   return ChannelSumFn.apply(g)
 
@@ -460,7 +469,8 @@ def channel_sum_raw(g):
   _chk(g)
   c = g.shape[-1]
   out = torch.empty(c, dtype=torch.float32, device=g.device)
-  call('tg_channel_sum', _p(g), _p(out), g.numel() // c, c, 0, _dt(g), _stream())
+  call('tg_channel_sum', _p(g), _p(out), g.numel() // c, c, 0, _dt(g), _stream(),
+       work=('channel_sum' + _shape_tag(g), 0, _nb(g)))
   return out
 
 
@@ -469,20 +479,22 @@ def sample_lerp(x, y, alpha):
   _chk(x, y, alpha)
   out = torch.empty_like(x)
   b = x.shape[0]
-  call('tg_sample_lerp', _p(x), _p(y), _p(alpha), _p(out), b, x.numel() // b, _dt(x), _stream())
+  call('tg_sample_lerp', _p(x), _p(y), _p(alpha), _p(out), b, x.numel() // b, _dt(x), _stream(),
+       work=('sample_lerp' + _shape_tag(x), 0, _nb(x, y, out)))
   return out
 
 
 def fill(shape, value, dtype, device, scalar=None):
   out = torch.empty(shape, dtype=dtype, device=device)
-  call('tg_fill_scaled', _p(out), _p(scalar), float(value), out.numel(), _dt(out), _stream())
+  call('tg_fill_scaled', _p(out), _p(scalar), float(value), out.numel(), _dt(out), _stream(),
+       work=('fill:numel%d' % out.numel(), 0, _nb(out)))
   return out
 
 
 def cast_raw(x, dtype):
   _chk(x)
   out = torch.empty(x.shape, dtype=dtype, device=x.device)
-  call('tg_cast', _p(x), _p(out), x.numel(), _dt(x), _dt(out), _stream())
+  call('tg_cast', _p(x), _p(out), x.numel(), _dt(x), _dt(out), _stream(), work=('cast:numel%d' % x.numel(), 0, _nb(x, out)))
   return out
 
 
@@ -718,7 +730,7 @@ def _pw_fwd_raw(x, w, bias, wt, epilogue, alpha):
   assert (w.shape[1] if wt else w.shape[0]) == cin, (w.shape, cin, wt)
   y = torch.empty(x.shape[:-1] + (cout,), dtype=x.dtype, device=x.device)
   call('tg_pointwise_conv_fwd', _p(x), _p(w), _p(bias), _p(y), x.numel() // cin, cin, cout, int(wt), epilogue, alpha,
-       _dt(x), _stream())
+       _dt(x), _stream(), work=('pw_fwd:c%d>%d:px%d' % (cin, cout, x.numel() // cin), 2 * x.numel() * cout, _nb(x, y)))
   return y
 
 
@@ -758,7 +770,8 @@ class PointwiseConvFn(torch.autograd.Function):
       sink = GradSink.get(w)
       if sink is not None:
         ca, cb = a.shape[-1], b.shape[-1]
-        call('tg_pointwise_conv_bwd_weight', _p(a), _p(b), _p(sink), a.numel() // ca, ca, cb, 1, _dt(a), _stream())
+        call('tg_pointwise_conv_bwd_weight', _p(a), _p(b), _p(sink), a.numel() // ca, ca, cb, 1, _dt(a), _stream(),
+             work=('pw_wgrad:c%d>%d:px%d' % (ca, cb, a.numel() // ca), 2 * a.numel() * cb, _nb(a, b)))
       else:
         gw = PointwiseWgradFn.apply(a, b)
     if need_b:
@@ -774,7 +787,8 @@ class PointwiseWgradFn(torch.autograd.Function):
     _chk(a, b)
     ca, cb = a.shape[-1], b.shape[-1]
     out = torch.empty((ca, cb), dtype=torch.float32, device=a.device)
-    call('tg_pointwise_conv_bwd_weight', _p(a), _p(b), _p(out), a.numel() // ca, ca, cb, 0, _dt(a), _stream())
+    call('tg_pointwise_conv_bwd_weight', _p(a), _p(b), _p(out), a.numel() // ca, ca, cb, 0, _dt(a), _stream(),
+         work=('pw_wgrad:c%d>%d:px%d' % (ca, cb, a.numel() // ca), 2 * a.numel() * cb, _nb(a, b)))
     return out
 
   @staticmethod
@@ -1053,7 +1067,8 @@ class Pool2Fn(torch.autograd.Function):
     _chk(x)
     n, h, w, c = x.shape
     y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
-    call('tg_pool2x2_fwd', _p(x), _p(y), n, h, w, c, scale, _dt(x), _stream())
+    call('tg_pool2x2_fwd', _p(x), _p(y), n, h, w, c, scale, _dt(x), _stream(),
+         work=('pool_fwd' + _shape_tag(x), 0, _nb(x, y)))
     ctx.scale, ctx.hw = scale, (h, w)
     return y
 
@@ -1070,7 +1085,8 @@ class Pool2BwdFn(torch.autograd.Function):
     _chk(gy)
     n, _, _, c = gy.shape
     gx = torch.empty((n, hw[0], hw[1], c), dtype=gy.dtype, device=gy.device)
-    call('tg_pool2x2_bwd', _p(gy), _p(gx), n, hw[0], hw[1], c, scale, _dt(gy), _stream())
+    call('tg_pool2x2_bwd', _p(gy), _p(gx), n, hw[0], hw[1], c, scale, _dt(gy), _stream(),
+         work=('pool_bwd' + _shape_tag(gx), 0, _nb(gy, gx)))
     ctx.scale = scale
     return gx
 
@@ -1090,7 +1106,8 @@ class AxpbyFn(torch.autograd.Function):
   def forward(ctx, x, y, a, b):
     _chk(x, y)
     out = torch.empty_like(x)
-    call('tg_axpby', _p(x), _p(y), _p(out), x.numel(), a, b, _dt(x), _stream())
+    call('tg_axpby', _p(x), _p(y), _p(out), x.numel(), a, b, _dt(x), _stream(),
+         work=('axpby:numel%d' % x.numel(), 0, _nb(x, y, out)))
     ctx.a, ctx.b, ctx.has_y = a, b, y is not None
     return out
 
@@ -1148,7 +1165,8 @@ class MbstdFn(torch.autograd.Function):
     _chk(x)
     n, h, w, c = x.shape
     out = torch.empty((n, h, w, cpad), dtype=x.dtype, device=x.device)
-    call('tg_mbstd_fwd', _p(x), _p(out), None, n, groups, h * w, c, cpad, _mbstd_eps(x.dtype), _dt(x), _stream())
+    call('tg_mbstd_fwd', _p(x), _p(out), None, n, groups, h * w, c, cpad, _mbstd_eps(x.dtype), _dt(x), _stream(),
+         work=('mbstd_fwd' + _shape_tag(x), 0, _nb(x, out)))
     ctx.cpad, ctx.groups = cpad, groups
     ctx.save_for_backward(x)
     return out
@@ -1164,7 +1182,8 @@ class MbstdBwdFn(torch.autograd.Function):
   def forward(ctx, gout, x, cpad, groups):
     n, h, w, c = x.shape
     gx = torch.empty_like(x)
-    call('tg_mbstd_bwd', _p(gout), _p(x), _p(gx), n, groups, h * w, c, cpad, _mbstd_eps(x.dtype), _dt(x), _stream())
+    call('tg_mbstd_bwd', _p(gout), _p(x), _p(gx), n, groups, h * w, c, cpad, _mbstd_eps(x.dtype), _dt(x), _stream(),
+         work=('mbstd_bwd' + _shape_tag(x), 0, _nb(gout, x, gx)))
     ctx.cpad, ctx.groups = cpad, groups
     ctx.save_for_backward(gout, x)
     return gx
@@ -1178,7 +1197,7 @@ class MbstdBwdFn(torch.autograd.Function):
     ggout = torch.empty_like(gout) if ctx.needs_input_grad[0] else None
     gx2 = torch.empty_like(x) if ctx.needs_input_grad[1] else None
     call('tg_mbstd_bwd_bwd', _p(v), _p(gout), _p(x), _p(ggout), _p(gx2), n, ctx.groups, h * w, c, ctx.cpad,
-         _mbstd_eps(x.dtype), _dt(x), _stream())
+         _mbstd_eps(x.dtype), _dt(x), _stream(), work=('mbstd_bwd_bwd' + _shape_tag(x), 0, _nb(v, gout, x, ggout, gx2)))
     return ggout, gx2, None, None
 
 
@@ -1250,7 +1269,8 @@ class MeanFn(torch.autograd.Function):
   def forward(ctx, x, weight):
     _chk(x)
     out = torch.empty(1, dtype=torch.float32, device=x.device)
-    call('tg_sum', _p(x), _p(out), x.numel(), weight / x.numel(), 0, _dt(x), _stream())
+    call('tg_sum', _p(x), _p(out), x.numel(), weight / x.numel(), 0, _dt(x), _stream(),
+         work=('sum:numel%d' % x.numel(), 0, _nb(x)))
     ctx.meta = (x.shape, x.dtype, weight / x.numel())
     return out
 
@@ -1268,7 +1288,8 @@ class AbsDiffMeanFn(torch.autograd.Function):
   def forward(ctx, a, b, weight):
     _chk(a, b)
     out = torch.empty(1, dtype=torch.float32, device=a.device)
-    call('tg_abs_diff_sum', _p(a), _p(b), _p(out), a.numel(), weight / a.numel(), 0, _dt(a), _stream())
+    call('tg_abs_diff_sum', _p(a), _p(b), _p(out), a.numel(), weight / a.numel(), 0, _dt(a), _stream(),
+         work=('abs_diff_sum:numel%d' % a.numel(), 0, _nb(a, b)))
     ctx.k = weight / a.numel()
     ctx.save_for_backward(a, b)
     return out
@@ -1279,7 +1300,8 @@ class AbsDiffMeanFn(torch.autograd.Function):
     a, b = ctx.saved_tensors
     ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
     gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
-    call('tg_abs_diff_bwd', _p(a), _p(b), _p(g.contiguous()), _p(ga), _p(gb), a.numel(), ctx.k, _dt(a), _stream())
+    call('tg_abs_diff_bwd', _p(a), _p(b), _p(g.contiguous()), _p(ga), _p(gb), a.numel(), ctx.k, _dt(a), _stream(),
+         work=('abs_diff_bwd:numel%d' % a.numel(), 0, _nb(a, b, ga, gb)))
     return ga, gb, None
 
 
@@ -1291,7 +1313,8 @@ class GradPenaltyFn(torch.autograd.Function):
     _chk(g)
     b = g.shape[0]
     ss = torch.empty(b, dtype=torch.float32, device=g.device)
-    call('tg_sample_sumsq', _p(g), _p(ss), b, g.numel() // b, _dt(g), _stream())
+    call('tg_sample_sumsq', _p(g), _p(ss), b, g.numel() // b, _dt(g), _stream(),
+         work=('sample_sumsq:numel%d' % g.numel(), 0, _nb(g)))
     loss = torch.empty(1, dtype=torch.float32, device=g.device)
     coef = torch.empty(b, dtype=torch.float32, device=g.device)
     call('tg_gp_penalty', _p(ss), _p(loss), _p(coef), b, lam, _stream())
@@ -1304,7 +1327,8 @@ class GradPenaltyFn(torch.autograd.Function):
     g, coef = ctx.saved_tensors
     out = torch.empty_like(g)
     b = g.shape[0]
-    call('tg_sample_scale', _p(g), _p(coef), _p(gl.contiguous()), _p(out), b, g.numel() // b, _dt(g), _stream())
+    call('tg_sample_scale', _p(g), _p(coef), _p(gl.contiguous()), _p(out), b, g.numel() // b, _dt(g), _stream(),
+         work=('sample_scale:numel%d' % g.numel(), 0, _nb(g, out)))
     return out, None
 
 
