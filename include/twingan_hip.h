@@ -304,6 +304,23 @@ int tg_adam_step(float* theta, const float* grad, float* m, float* v, void* thet
                  const float* lr_t_dev, float beta1, float beta2, float eps, float grad_scale, void* stream);
 int tg_adam_tick(int64_t* step_dev, float* lr_t_dev, float lr, float beta1, float beta2, void* stream);
 
+/* -------------------------------------------------------------------------------------------
+ * Spectral normalisation of a conv kernel -- replaces libs/sn.py:38-101 (spectral_normed_weight: the tf.matmul /
+ * tf.nn.l2_normalize chain behind libs.sn.convolution, nets/pggan_utils.py:316-320, --spectral_norm).
+ * w: fp32 [k_rows = kh*kw*cin, cout] (the HWIO kernel flattened), u: fp32 [cout] persistent power-iteration vector.
+ *   fwd: v = l2n(u W^T) [k_rows], u_new = l2n(v W) [cout], sigma = v W u_new^T, w_bar = W / sigma;
+ *        stats = {sigma, |u W^T|} (fp32 [2], kept for the backward).  The caller assigns u <- u_new (libs/sn.py:84-86).
+ *   bwd: gw (+)= d L / d W for g_wbar = d L / d w_bar, the gradient flowing through sigma, v and u_new as in the
+ *        reference (no stop_gradient).
+ * ws: tg_spectral_norm_workspace(k_rows, cout) bytes of scratch.  cout <= 1024.
+ * ------------------------------------------------------------------------------------------- */
+size_t tg_spectral_norm_workspace(int k_rows, int cout);
+int tg_spectral_norm_fwd(const float* w, const float* u, float* w_bar, float* u_new, float* v, float* stats, int k_rows,
+                         int cout, void* ws, size_t ws_bytes, void* stream);
+int tg_spectral_norm_bwd(const float* g_wbar, const float* w, const float* u, const float* u_new, const float* v,
+                         const float* stats, float* gw, int accumulate, int k_rows, int cout, void* ws, size_t ws_bytes,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

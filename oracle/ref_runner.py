@@ -283,3 +283,60 @@ def run_training(flags, runs, seed=0, preset=None):
       n_critic_counter_after=int(core.STATE.variables['n_critic_counter'].t), global_step_after=int(gs.t)))
   return dict(history=history,
               variables={k: v.t.detach().numpy().copy() for k, v in core.STATE.variables.items()})
+
+
+def run_pggan(flags, targets, global_step=0, seed=0, preset=None, want_grads=True):
+  """BASELINE configs[0]: the plain PGGAN trainer -- image_generation.GanModel._clone_fn
+  (/root/reference/image_generation.py:194-316) with no generator input, i.e. pggan.generator drawing its own
+  tf.random_normal noise [B,1,1,C] (nets/pggan.py:86-153), one discriminator, add_gan_loss.  Returns the same kind of
+  record as run(): variables, random draws (the noise first), loss terms, gradients, end points."""
+  tf = loader.install()
+  import image_generation as ref
+  F = tf.flags.FLAGS
+  if not hasattr(run, '_defaults'):
+    run._defaults = F.flag_values_dict()
+  for k, v in run._defaults.items():
+    setattr(F, k, v)
+  base = {k: v for k, v in BASE_FLAGS.items() if k in run._defaults}      # twingan.py's own flags may not be defined
+  for k, v in dict(base, **flags).items():
+    if k not in run._defaults:
+      raise KeyError('the reference defines no flag %r' % k)
+    setattr(F, k, v)
+  core.STATE.reset(seed)
+  core.STATE.preset = dict(preset or {})
+  core.STATE.eager_updates = False
+  core.STATE.placeholder_batch = int(np.asarray(targets).shape[0])
+  tfapi._ARG_STACK[:] = [{}]
+  gs = tfapi.get_or_create_global_step()
+  gs.t.fill_(int(global_step))
+  T = core.Tensor(torch.tensor(np.asarray(targets, np.float64), requires_grad=True), core.float32, 'target')
+  networks = ref.GanModel._select_network(None)
+  # the image post-processing of the `custom_generated_targets` inference end point lives in the (stubbed, out of
+  # scope) preprocessing package: identity here -- it does not feed any loss
+  keep = ref.GanModel._post_process_image
+  ref.GanModel._post_process_image = staticmethod(lambda image: image)
+  try:
+    end_points = ref.GanModel._clone_fn(networks, None, None, data_batched={'target': T}, is_training=True, global_step=gs)
+  finally:
+    ref.GanModel._post_process_image = keep
+
+  def losses(coll):
+    return {l.name[:-len('/value:0')]: l for l in core.get_collection(coll)}
+  g_terms, d_terms = losses(ref.GENERATOR_LOSS_COLLECTION), losses(ref.DISCRIMINATOR_LOSS_COLLECTION)
+  res = dict(
+    variables={k: v.t.detach().numpy().copy() for k, v in core.STATE.variables.items()},
+    trainable=[k for k, v in core.STATE.variables.items() if v.trainable],
+    random=[(n, t.numpy().copy()) for n, t in core.STATE.random_log],
+    g_terms={k: float(v.t) for k, v in g_terms.items()}, d_terms={k: float(v.t) for k, v in d_terms.items()},
+    end_points={k: v.t.detach().numpy().copy() for k, v in end_points.items()
+                if isinstance(v, core.Tensor) and not k.startswith('custom_') and not k.endswith('_ph')})
+  res['g_loss'] = float(sum(v.t for v in g_terms.values()))
+  res['d_loss'] = float(sum(v.t for v in d_terms.values()))
+  if want_grads:
+    names = res['trainable']
+    leaves = [core.STATE.variables[k].t for k in names]
+    for tag, terms in (('g_grads', g_terms), ('d_grads', d_terms)):
+      total = sum(v.t for v in terms.values())
+      gr = torch.autograd.grad(total, leaves, allow_unused=True, retain_graph=True)
+      res[tag] = {k: g.numpy().copy() for k, g in zip(names, gr) if g is not None}
+  return res

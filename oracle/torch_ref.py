@@ -77,6 +77,12 @@ BN_EPS = 1e-3       # libs/batch_norm.py:48 (max(epsilon, 1.001e-5), :464-468)
 BN_DECAY = 0.999    # libs/batch_norm.py:45
 
 
+def _pf(domain):
+  """Variable-name postfix of a domain: '_s' / '_t' in TwinGAN, '' in the plain PGGAN trainer
+  (conditional_layer_var_scope_postfix, nets/pggan_utils.py:102-113)."""
+  return '_' + domain if domain else ''
+
+
 def _conv_p(P, g, scope, k, cin, cout, norm_domains, bias, dtype, std=0.02, norm_scope='InstanceNorm'):
   if std == 'he':                    # test-only: O(1) activations so parity errors are visible
     std = math.sqrt(2.0 / (k * k * cin))
@@ -84,8 +90,8 @@ def _conv_p(P, g, scope, k, cin, cout, norm_domains, bias, dtype, std=0.02, norm
   if bias:
     P[scope + '/biases'] = torch.zeros(cout, dtype=dtype)
   for d in norm_domains:
-    P['%s/%s/gamma_%s' % (scope, norm_scope, d)] = torch.ones(cout, dtype=dtype)
-    P['%s/%s/beta_%s' % (scope, norm_scope, d)] = torch.zeros(cout, dtype=dtype)
+    P['%s/%s/gamma%s' % (scope, norm_scope, _pf(d))] = torch.ones(cout, dtype=dtype)
+    P['%s/%s/beta%s' % (scope, norm_scope, _pf(d))] = torch.zeros(cout, dtype=dtype)
 
 
 def encoder_param_specs(top, hw, max_ch, growing=False):
@@ -467,11 +473,11 @@ def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=Tru
   if cfg.norm == 'instance_norm' and cond is not None:
     # conditional parameters (libs/instance_norm.py:93-120): gamma = 1 + FC(cond), beta = FC(cond), one row per image
     pre = scope + '/InstanceNorm/'
-    gamma = 1.0 + cond @ P[pre + 'gamma_%s/weights' % domain] + P[pre + 'gamma_%s/biases' % domain]
-    beta = cond @ P[pre + 'beta_%s/weights' % domain] + P[pre + 'beta_%s/biases' % domain]
+    gamma = 1.0 + cond @ P[pre + 'gamma%s/weights' % _pf(domain)] + P[pre + 'gamma%s/biases' % _pf(domain)]
+    beta = cond @ P[pre + 'beta%s/weights' % _pf(domain)] + P[pre + 'beta%s/biases' % _pf(domain)]
     y = instance_norm(y, gamma[:, None, None, :], beta[:, None, None, :], cfg.in_eps)
   elif cfg.norm == 'instance_norm':
-    y = instance_norm(y, P[scope + '/InstanceNorm/gamma_' + domain], P[scope + '/InstanceNorm/beta_' + domain],
+    y = instance_norm(y, P[scope + '/InstanceNorm/gamma' + _pf(domain)], P[scope + '/InstanceNorm/beta' + _pf(domain)],
                       cfg.in_eps)
   elif cfg.norm == 'batch_norm':       # the reference's default generator_norm_type (nets/pggan.py:24)
     if cond is not None:
@@ -479,19 +485,19 @@ def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=Tru
       # gamma = 1 + FC, beta = FC, one row per image, broadcast as [B,1,1,C] against the BATCH statistics
       cn = cond / cond.pow(2).sum(dim=1, keepdim=True).clamp_min(1e-12).sqrt()
       pre = scope + '/BatchNorm/'
-      gamma = (1.0 + cn @ P[pre + 'gamma_%s/weights' % domain] + P[pre + 'gamma_%s/biases' % domain])[:, None, None, :]
-      beta = (cn @ P[pre + 'beta_%s/weights' % domain] + P[pre + 'beta_%s/biases' % domain])[:, None, None, :]
+      gamma = (1.0 + cn @ P[pre + 'gamma%s/weights' % _pf(domain)] + P[pre + 'gamma%s/biases' % _pf(domain)])[:, None, None, :]
+      beta = (cn @ P[pre + 'beta%s/weights' % _pf(domain)] + P[pre + 'beta%s/biases' % _pf(domain)])[:, None, None, :]
     else:
-      gamma, beta = P[scope + '/BatchNorm/gamma_' + domain], P[scope + '/BatchNorm/beta_' + domain]
+      gamma, beta = P[scope + '/BatchNorm/gamma' + _pf(domain)], P[scope + '/BatchNorm/beta' + _pf(domain)]
     y, bm, bv = batch_norm_train(y, gamma, beta)
     if cfg.bn_state is not None:       # moving statistics per domain postfix (libs/batch_norm.py:184-196)
       for nm, val, init in (('moving_mean_', bm, 0.0), ('moving_variance_', bv, 1.0)):
-        key = scope + '/BatchNorm/' + nm + domain
+        key = scope + '/BatchNorm/' + nm.rstrip('_') + _pf(domain)
         cur = cfg.bn_state.get(key, torch.full_like(val, init))
         cfg.bn_state[key] = moving_average_update(cur, val.detach())
   elif cfg.norm == 'batch_renorm':     # the configuration of docs/training.md:17
-    y = batch_renorm_train(y, P[scope + '/BatchNorm/gamma_' + domain], P[scope + '/BatchNorm/beta_' + domain],
-                           cfg.bn_state, scope + '/BatchNorm/', '_' + domain, renorm_clipping(cfg.global_step))
+    y = batch_renorm_train(y, P[scope + '/BatchNorm/gamma' + _pf(domain)], P[scope + '/BatchNorm/beta' + _pf(domain)],
+                           cfg.bn_state, scope + '/BatchNorm/', _pf(domain), renorm_clipping(cfg.global_step))
   elif cfg.norm not in ('none', None):
     raise NotImplementedError(cfg.norm)
   if act:
@@ -589,8 +595,12 @@ def generator(P, source, domain, cfg, unet_ep=None, top='generator', cond=None):
     oc = get_num_channels(stage, cfg.max_ch)
     name = 'block_%dx%dx%d' % (hw, hw, oc)
     if hw == 4:
-      assert source.shape[1] == 4 and source.shape[2] == 4
-      net = ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg, cond=cond)
+      if source.shape[1] == 1 and source.shape[2] == 1:      # latent noise (nets/pggan.py:135-153): pad to 7x7, 4x4 VALID
+        net = F.pad(net, (0, 0, 3, 3, 3, 3))
+        net = ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg, k=4, padding='VALID', cond=cond)
+      else:
+        assert source.shape[1] == 4 and source.shape[2] == 4
+        net = ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg, cond=cond)
       net = ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg, cond=cond)
     else:
       if stage == ms and cfg.is_growing:
@@ -656,6 +666,72 @@ def discriminator(P, x, cfg, top):
       P[top + '/prediction/fully_connected/biases']
   ep['prediction'] = pred
   return pred, ep
+
+
+# ------------------------------------------------------------------------------------------------
+# the plain PGGAN trainer (image_generation.GanModel, image_generation.py:194-476) -- BASELINE configs[0]
+# ------------------------------------------------------------------------------------------------
+def init_pggan_params(cfg, seed=0, dtype=torch.float32, std=0.02):
+  """Scopes 'generator' (latent-noise input: block_4x4 Conv is 4x4 VALID over get_num_channels(1) channels) and
+  'discriminator'; normaliser variables without a domain postfix."""
+  g = torch.Generator().manual_seed(seed)
+  P = {}
+  he = std == 'he'
+  ns = NORM_SCOPE.get(cfg.norm, '')
+  nd = ('',) if cfg.norm in NORM_SCOPE else ()
+  specs = generator_param_specs('generator', cfg.hw, cfg.max_ch, False, cfg.is_growing)
+  c0 = get_num_channels(0, cfg.max_ch)
+  for sp in specs:
+    if sp[0] == 'generator/block_4x4x%d/Conv' % c0:
+      sp = (sp[0], 4, get_num_channels(1, cfg.max_ch), c0)
+    _conv_p(P, g, sp[0], sp[1], sp[2], sp[3], nd, False, dtype, std, ns)
+  md = cfg.max_ch_dis or cfg.max_ch
+  top = 'discriminator'
+  for sp in encoder_param_specs(top, cfg.hw, md, cfg.is_growing) + discriminator_tail_specs(top, md):
+    _conv_p(P, g, sp[0], sp[1], sp[2], sp[3], (), True, dtype, std)
+  P[top + '/prediction/fully_connected/weights'] = \
+      torch.randn(md, 1, generator=g, dtype=torch.float32).to(dtype) * (math.sqrt(1.0 / md) if he else std)
+  P[top + '/prediction/fully_connected/biases'] = torch.zeros(1, dtype=dtype)
+  if he:
+    for k in sorted(P):
+      if k.endswith('/biases') or k.endswith('/beta'):
+        P[k] = (torch.randn(P[k].shape, generator=g, dtype=torch.float32) * 0.1).to(dtype)
+      elif k.endswith('/gamma'):
+        P[k] = (1.0 + torch.randn(P[k].shape, generator=g, dtype=torch.float32) * 0.1).to(dtype)
+  return P
+
+
+def pggan_generator_loss(P, targets, cfg, noise):
+  """GENERATOR_LOSSES of image_generation.GanModel (add_gan_loss, :331-344).  Returns (total, terms)."""
+  fake, _ = generator(P, noise, '', cfg, None, 'generator')
+  pred, _ = discriminator(P, fake, cfg, 'discriminator')
+  terms = {'generator_fool_loss': _fool_loss(pred, cfg)}
+  return sum(terms.values()), terms
+
+
+def pggan_discriminator_loss(P, targets, cfg, noise, gp_alpha, dragan_noise=None):
+  """DISCRIMINATOR_LOSSES of image_generation.GanModel (:348-476); the generator runs without a tape."""
+  with torch.no_grad():
+    if cfg.is_growing:
+      targets = growing_image(targets, cfg.alpha_grow)
+    fake, _ = generator(P, noise, '', cfg, None, 'generator')
+  pr, _ = discriminator(P, targets, cfg, 'discriminator')
+  pf, _ = discriminator(P, fake, cfg, 'discriminator')
+  terms = {}
+  _real_fake_losses(terms, '', pf, pr, cfg)
+  if cfg.drift and cfg.loss in ('wgan_gp', 'wgan'):
+    terms['discriminator_drift_loss'] = cfg.drift * (pr ** 2).mean()
+  if cfg.loss in ('wgan_gp', 'dragan'):
+    if cfg.loss == 'dragan':
+      interp = targets + gp_alpha * (targets + 0.5 * targets.var(unbiased=False) * dragan_noise - targets)
+    else:
+      interp = targets + gp_alpha * (fake - targets)
+    interp = interp.detach().requires_grad_(True)
+    pi, _ = discriminator(P, interp, cfg, 'discriminator')
+    gi, = torch.autograd.grad(pi.sum(), interp, create_graph=True)
+    slopes = torch.sqrt((gi ** 2).sum(dim=(1, 2, 3)))
+    terms['discriminator_gradient_penalty'] = cfg.gp_lambda * ((slopes - 1.0) ** 2).mean()
+  return sum(terms.values()), terms
 
 
 def growing_image(img, alpha):

@@ -356,3 +356,97 @@ def test_gpu_model_hits_golden(name, precision):
       if nb >= 1e-3 * top:
         e = float(np.linalg.norm(gd[k].double().cpu().numpy() - g['grad/' + k])) / nb
         assert e < vtol, (group, k, e)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs[0]: the plain PGGAN trainer (image_generation.GanModel), reference-generated fixtures
+# ------------------------------------------------------------------------------------------------
+PGGAN_MODELS = {'pggan_hw4_c16': dict(hw=4, max_ch=16, norm='batch_norm'),
+                'pggan_hw8_c16_in': dict(hw=8, max_ch=16, norm='instance_norm'),
+                'pggan_hw8_c16_hinge_grow': dict(hw=8, max_ch=16, norm='batch_norm', loss='hinge', is_growing=True,
+                                                 alpha_grow=0.3)}
+
+
+def _pggan_inputs(g, dtype):
+  P = {k[len('param/'):]: torch.from_numpy(v).to(dtype) for k, v in g.items() if k.startswith('param/')}
+  t = torch.from_numpy(g['in/targets']).to(dtype)
+  noise = torch.from_numpy(g['in/noise']).to(dtype)
+  alpha = torch.from_numpy(g['in/gp_alpha']).to(dtype).reshape(-1, 1, 1, 1)
+  return P, t, noise, alpha
+
+
+@pytest.mark.parametrize('name', sorted(PGGAN_MODELS))
+def test_pggan_oracle_f64_matches_the_reference(name):
+  """THE PIN for configs[0]: the float64 oracle against what image_generation.GanModel._clone_fn computed
+  (oracle/ref_runner.run_pggan, tools/make_golden.py --pggan): generated images, every loss term, every gradient."""
+  g = load(name)
+  cfg = R.Config(use_unet=False, **PGGAN_MODELS[name])
+  P, t, noise, alpha = _pggan_inputs(g, torch.float64)
+  with torch.no_grad():
+    out, _ = R.generator(P, noise, '', cfg, None, 'generator')
+    assert np.abs(out.numpy() - g['fwd/generator_output']).max() < 1e-9
+  for v in P.values():
+    v.requires_grad_(True)
+  gl, gt = R.pggan_generator_loss(P, t, cfg, noise)
+  dl, dt = R.pggan_discriminator_loss(P, t, cfg, noise, alpha)
+  assert {'loss/g/' + k for k in gt} | {'loss/d/' + k for k in dt} == {k for k in g if k.startswith(('loss/g/', 'loss/d/'))}
+  for grp, terms in (('g', gt), ('d', dt)):
+    for k, v in terms.items():
+      assert abs(float(v) - float(g['loss/%s/%s' % (grp, k)])) < 1e-9, k
+  grads = dict(R.grads_of(gl, P, [k for k in P if k.startswith('generator')]))
+  grads.update(R.grads_of(dl, P, [k for k in P if k.startswith('discriminator')]))
+  assert set(grads) == {k[len('grad/'):] for k in g if k.startswith('grad/')}
+  scale = max(float(np.abs(g['grad/' + k]).max()) for k in grads)
+  for k, v in grads.items():
+    assert np.abs(v.detach().numpy() - g['grad/' + k]).max() < 1e-9 * scale, k
+
+
+@pytest.mark.parametrize('name', sorted(PGGAN_MODELS))
+def test_pggan_product_declares_the_reference_variables(name):
+  from twingan_amd import Config
+  from twingan_amd.params import ParamStore, declare_pggan
+  g = load(name)
+  st = declare_pggan(ParamStore('cpu'), Config(**product_kw_of(PGGAN_MODELS[name]))).build(0)
+  want = {k[len('param/'):]: v.shape for k, v in g.items() if k.startswith('param/')}
+  assert {k: tuple(s['shape']) for k, s in st.specs.items()} == {k: tuple(v) for k, v in want.items()}
+
+
+def product_kw_of(kw):
+  return {PRODUCT_FIELD.get(k, k): v for k, v in kw.items()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', sorted(PGGAN_MODELS))
+def test_gpu_pggan_trainer_hits_golden(name):
+  """The HIP path (fp32) of the plain PGGAN trainer -- latent noise through the 4x4 VALID first conv, one
+  discriminator, add_gan_loss -- against the reference-generated vectors: image, loss terms, every gradient."""
+  from twingan_amd import Config
+  from twingan_amd import image_generation as IG
+  g = load(name)
+  cfg = Config(precision='fp32', **product_kw_of(PGGAN_MODELS[name]))
+  tr = IG.PgganTrainer(cfg, device='cuda:0', seed=0)
+  tr.store.load_state_dict({k[len('param/'):]: torch.from_numpy(v).float() for k, v in g.items() if k.startswith('param/')})
+  t, noise, alpha = _dev(g['in/targets']), _dev(g['in/noise']), _dev(g['in/gp_alpha'])
+  with torch.no_grad():
+    out = IG.generate(tr.P, noise, cfg)
+  assert rel_l2(out.float().cpu().numpy(), g['fwd/generator_output']) < 2e-5
+  for group, fn, args in (('g', IG.generator_loss, (t, cfg, noise)), ('d', IG.discriminator_loss, (t, cfg, noise, alpha))):
+    tr.store.zero_grad(group)
+    tr._set_requires_grad(g=group == 'g', d=group == 'd')
+    loss, terms = fn(tr.P, *args)
+    for k, v in terms.items():
+      w = float(g['loss/%s/%s' % (group, k)])
+      assert abs(v.item() - w) < 1e-4 * max(1.0, abs(w)), (k, v.item(), w)
+    loss.backward()
+    gd = tr.store.grad_dict()
+    names = tr.store.names(group)
+    num = sum(float(((gd[k].double().cpu().numpy() - g['grad/' + k]) ** 2).sum()) for k in names)
+    den = sum(float((g['grad/' + k] ** 2).sum()) for k in names)
+    assert (num / den) ** 0.5 < 1e-2, (group, (num / den) ** 0.5)
+  # and the alternating step runs (device-drawn noise), eagerly and from the captured graphs
+  for use_graph in (False, True):
+    tr2 = IG.PgganTrainer(Config(precision='bf16', **product_kw_of(PGGAN_MODELS[name])), device='cuda:0', seed=1,
+                          use_graph=use_graph and not cfg.is_growing)
+    tb = t.to(torch.bfloat16)
+    losses = [tr2.run(None, tb)[0].item() for _ in range(4)]
+    assert all(np.isfinite(losses)), losses

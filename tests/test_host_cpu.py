@@ -54,7 +54,9 @@ def test_invalid_descriptor_is_rejected_without_gpu():
   rc = lib.tg_conv2d_fwd(ctypes.byref(d), 16, 16, None, 16, None)
   assert rc == -1 and b'inconsistent' in lib.tg_last_error()
   d.hout = 4
-  d.kh = 5
+  d.kh = 8                                    # direct kernels: up to 7x7 (to-RGB layers with the larger filter)
+  assert lib.tg_conv2d_fwd(ctypes.byref(d), 16, 16, None, 16, None) == -1
+  d.kh, d.algo = 5, 1                         # the MFMA kernels: 1x1, 3x3, dense 4x4 VALID
   assert lib.tg_conv2d_fwd(ctypes.byref(d), 16, 16, None, 16, None) == -1
   assert lib.tg_pointwise_conv_fwd(16, 16, None, 16, 10, 8, 8, 0, 0, 0.2, 0, None) == -4     # TG_ENOSUP
 

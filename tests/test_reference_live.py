@@ -88,3 +88,52 @@ def test_oracle_matches_live_reference(name):
     want = ref['d_grads' if k.startswith('discriminator') else 'g_grads'].get(k)
     got = v.detach().numpy()
     assert np.abs(got - (want if want is not None else 0.0)).max() < 1e-9 * scale, k
+
+
+PGGAN_CASES = {
+  'stage0_batch16': dict(hw=4, max_ch=32, norm='batch_norm'),                 # BASELINE configs[0]
+  'instance_norm_16': dict(hw=16, max_ch=8, norm='instance_norm'),
+  'gan_loss': dict(hw=8, max_ch=16, norm='batch_norm', loss='gan'),
+  'dragan': dict(hw=8, max_ch=8, norm='instance_norm', loss='dragan'),
+  'wgan_drift_growing': dict(hw=16, max_ch=8, norm='instance_norm', loss='wgan', drift=0.001, is_growing=True, alpha_grow=0.4),
+}
+
+
+@pytest.mark.parametrize('name', sorted(PGGAN_CASES))
+def test_pggan_oracle_matches_live_reference(name):
+  """The plain PGGAN trainer (image_generation.GanModel._clone_fn with the generator drawing its own latent noise:
+  BASELINE configs[0]) executed live; the float64 oracle reproduces every loss term and gradient."""
+  from oracle import ref_runner
+  cfg = R.Config(use_unet=False, **PGGAN_CASES[name])
+  batch = 16 if name == 'stage0_batch16' else 3
+  P = R.init_pggan_params(cfg, seed=21, dtype=torch.float64, std='he')
+  rng = np.random.RandomState(22)
+  t = rng.rand(batch, cfg.hw, cfg.hw, 3)
+  flags = dict(train_image_size=cfg.hw, pggan_max_num_channels=cfg.max_ch, generator_norm_type=cfg.norm,
+               loss_architecture=cfg.loss, wgan_drift_loss_weight=cfg.drift, is_growing=cfg.is_growing,
+               max_number_of_steps=ref_runner.GROW_STEPS, grow_start_number_of_steps=0)
+  ref = ref_runner.run_pggan(flags, t, global_step=ref_runner.global_step_of(cfg), seed=2,
+                             preset={k: v.numpy() for k, v in P.items()})
+  assert set(ref['trainable']) == set(P)
+  draws = {}
+  for n, v in ref['random']:
+    draws.setdefault(n, []).append(torch.from_numpy(v))
+  assert tuple(draws['normal'][0].shape) == (batch, 1, 1, R.get_num_channels(1, cfg.max_ch))      # get_noise_shape
+  noise = draws['normal'][0]
+  alpha = draws['alpha'][0] if 'alpha' in draws else None
+  dnoise = draws['uniform'][0] if 'uniform' in draws else None
+  for v in P.values():
+    v.requires_grad_(True)
+  tt = torch.from_numpy(t)
+  gl, gterms = R.pggan_generator_loss(P, tt, cfg, noise)
+  dl, dterms = R.pggan_discriminator_loss(P, tt, cfg, noise, alpha, dnoise)
+  for grp, terms in (('g', gterms), ('d', dterms)):
+    assert set(terms) == set(ref[grp + '_terms']), (sorted(terms), sorted(ref[grp + '_terms']))
+    for k, v in terms.items():
+      assert abs(float(v) - ref[grp + '_terms'][k]) < 1e-9, (k, float(v), ref[grp + '_terms'][k])
+  grads = dict(R.grads_of(gl, P, [k for k in P if k.startswith('generator')]))
+  grads.update(R.grads_of(dl, P, [k for k in P if k.startswith('discriminator')]))
+  scale = max(float(np.abs(v).max()) for v in list(ref['g_grads'].values()) + list(ref['d_grads'].values()))
+  for k, v in grads.items():
+    want = ref['d_grads' if k.startswith('discriminator') else 'g_grads'][k]
+    assert np.abs(v.detach().numpy() - want).max() < 1e-9 * scale, k

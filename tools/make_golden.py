@@ -299,6 +299,61 @@ SCHEMAS = {      # full-width configurations of BASELINE.json, run once through 
 }
 
 
+PGGAN_CASES = {      # BASELINE configs[0] (4x4 stage 0, batch 16) and an 8x8 stage; name -> (batch, oracle Config kwargs)
+    'pggan_hw4_c16': (16, dict(hw=4, max_ch=16, norm='batch_norm')),
+    'pggan_hw8_c16_in': (4, dict(hw=8, max_ch=16, norm='instance_norm')),
+    'pggan_hw8_c16_hinge_grow': (4, dict(hw=8, max_ch=16, norm='batch_norm', loss='hinge', is_growing=True, alpha_grow=0.3)),
+}
+
+
+def pggan_model(batch, seed=0, **kw):
+  """One fixture of the plain PGGAN trainer (image_generation.GanModel._clone_fn executed by
+  oracle/ref_runner.run_pggan): seeded weights and targets, the reference's own noise and GP-alpha draws, every loss
+  term, every gradient, the generated images.  Refuses to write unless the float64 oracle agrees to 1e-9."""
+  from oracle import ref_runner
+  cfg = R.Config(use_unet=False, **kw)
+  P = {k: v.float().double() for k, v in R.init_pggan_params(cfg, seed=seed, dtype=torch.float64, std='he').items()}
+  g = torch.Generator().manual_seed(4321)
+  t = torch.rand(batch, cfg.hw, cfg.hw, 3, generator=g).double()
+  flags = dict(train_image_size=cfg.hw, pggan_max_num_channels=cfg.max_ch, generator_norm_type=cfg.norm,
+               loss_architecture=cfg.loss, is_growing=cfg.is_growing, max_number_of_steps=ref_runner.GROW_STEPS,
+               grow_start_number_of_steps=0)
+  ref = ref_runner.run_pggan(flags, t.numpy(), global_step=ref_runner.global_step_of(cfg), seed=seed,
+                             preset={k: v.numpy() for k, v in P.items()})
+  assert set(ref['trainable']) == set(P), set(ref['trainable']) ^ set(P)
+  draws = {}
+  for n, v in ref['random']:
+    draws.setdefault(n, []).append(v)
+  noise = torch.from_numpy(draws['normal'][0])
+  alpha = torch.from_numpy(draws['alpha'][0]) if 'alpha' in draws else torch.zeros(batch, 1, 1, 1, dtype=torch.float64)
+  d = {'in/targets': t.numpy(), 'in/noise': noise.numpy(), 'in/gp_alpha': alpha.numpy().reshape(-1)}
+  for k, v in P.items():
+    d['param/' + k] = v.numpy()
+  d['fwd/generator_output'] = ref['end_points']['generator_output']
+  d['fwd/d_real'] = ref['end_points']['discriminator_real_prediction']
+  d['loss/g_total'], d['loss/d_total'] = np.array(ref['g_loss']), np.array(ref['d_loss'])
+  for grp in 'gd':
+    for k, v in ref[grp + '_terms'].items():
+      d['loss/%s/%s' % (grp, k)] = np.array(v)
+    for k, v in ref[grp + '_grads'].items():
+      if (grp == 'd') == k.startswith('discriminator'):
+        d['grad/' + k] = v
+  # the oracle must reproduce all of it
+  for v in P.values():
+    v.requires_grad_(True)
+  gl, gt = R.pggan_generator_loss(P, t, cfg, noise)
+  dl, dt = R.pggan_discriminator_loss(P, t, cfg, noise, alpha)
+  for k, v in list(gt.items()) + list(dt.items()):
+    grp = 'g' if k in gt else 'd'
+    assert abs(float(v) - float(d['loss/%s/%s' % (grp, k)])) < 1e-9, k
+  grads = dict(R.grads_of(gl, P, [k for k in P if k.startswith('generator')]))
+  grads.update(R.grads_of(dl, P, [k for k in P if k.startswith('discriminator')]))
+  scale = max(float(np.abs(d['grad/' + k]).max()) for k in grads)
+  for k, v in grads.items():
+    assert np.abs(v.numpy() - d['grad/' + k]).max() < 1e-9 * scale, k
+  return d
+
+
 def main():
   os.makedirs(OUT, exist_ok=True)
   np.savez_compressed(os.path.join(OUT, 'primitives.npz'), **primitives())
@@ -308,6 +363,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **model(kw.pop('hw'), kw.pop('max_ch'), batch, **kw))
   np.savez_compressed(os.path.join(OUT, 'clones2_hw16_c8.npz'), **clones(16, 8, 2, 2))
   np.savez_compressed(os.path.join(OUT, 'train4_hw16_c8.npz'), **training())
+  for name, (batch, kw) in PGGAN_CASES.items():
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **pggan_model(batch, **kw))
   # the variables the reference creates at full width, with what its initialisers drew (names, shapes, statistics)
   import json
   from oracle import ref_runner
@@ -337,7 +394,11 @@ def main():
 
 
 if __name__ == '__main__':
-  if '--full' in sys.argv:      # only the full-size fixture (slow); the default run leaves it untouched
+  if '--pggan' in sys.argv:      # only the plain-PGGAN fixtures
+    for name, (batch, kw) in PGGAN_CASES.items():
+      np.savez_compressed(os.path.join(OUT, name + '.npz'), **pggan_model(batch, **kw))
+      print(name, os.path.getsize(os.path.join(OUT, name + '.npz')))
+  elif '--full' in sys.argv:      # only the full-size fixture (slow); the default run leaves it untouched
     import json
     with open(os.path.join(OUT, 'full_hw256_c256.json'), 'w') as fh:
       json.dump(full_size(), fh, indent=0, sort_keys=True)

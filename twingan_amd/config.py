@@ -15,6 +15,7 @@ class Config:
   unet_max_concat_hw: object = None   # --pggan_unet_max_concat_hw (nets/pggan.py:57-59): no UNet skip above this hw
   equalized_learning_rate: bool = False   # nets/pggan.py:39-41; nets/pggan_utils.py:82-84,236-254
   use_res_block: bool = False         # nets/pggan.py:43-46; nets/pggan_utils.py:257-264,334-342
+  use_larger_filter_at_rgb_layer: bool = False   # nets/pggan.py:47-50: 7x7 (min(7, hw/2)) to-RGB kernels
   spectral_norm: bool = False         # nets/pggan.py:28-30; libs/sn.py:38-101 (discriminator convs)
   spectral_norm_in_non_discriminator: bool = False   # nets/pggan.py:31-33
   do_self_attention: bool = False     # image_generation.py:62-64; libs/self_attention.py:24-70

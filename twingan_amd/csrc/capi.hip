@@ -39,7 +39,9 @@ int tg_zero_async(void* a, size_t a_bytes, void* b, size_t b_bytes, hipStream_t 
 
 int tg_conv2d_fwd_direct(const TgConvDesc*, const void*, const void*, const float*, void*, hipStream_t);
 int tg_conv2d_bwd_data_direct(const TgConvDesc*, const void*, const void*, void*, hipStream_t);
-int tg_conv2d_bwd_weight_direct(const TgConvDesc*, const void*, const void*, float*, int, hipStream_t);
+int tg_conv2d_bwd_weight_direct(const TgConvDesc*, const void*, const void*, float*, int, hipStream_t, void* ws = nullptr,
+                                size_t ws_bytes = 0);
+size_t tg_conv2d_bwd_weight_workspace_direct(const TgConvDesc*);
 int tg_conv2d_fwd_mfma(const TgConvDesc*, const void*, const void*, const float*, void*, hipStream_t);
 int tg_conv2d_bwd_data_mfma(const TgConvDesc*, const void*, const void*, void*, hipStream_t, const void* mask = nullptr);
 bool tg_conv2d_bwd_data_mask_fusable_mfma(const TgConvDesc*);
@@ -65,8 +67,11 @@ static int check_desc(const char* who, const TgConvDesc* d) {
   TG_CHECK(d != nullptr, TG_EINVAL, "%s: null descriptor", who);
   TG_CHECK(d->n > 0 && d->hin > 0 && d->win > 0 && d->cin > 0 && d->hout > 0 && d->wout > 0 && d->cout > 0, TG_EINVAL,
            "%s: non-positive dimension", who);
-  TG_CHECK(d->kh >= 1 && d->kh <= 4 && d->kw >= 1 && d->kw <= 4, TG_EINVAL, "%s: kernel %dx%d out of range", who, d->kh,
-           d->kw);
+  // the MFMA kernels take 1x1, 3x3 and the dense 4x4 VALID; the direct kernels any size up to 7x7 (the 7x7 to-RGB
+  // layers of --use_larger_filter_at_rgb_layer, nets/pggan.py:172,194)
+  const int kmax = d->algo == TG_ALGO_DIRECT ? 7 : 4;
+  TG_CHECK(d->kh >= 1 && d->kh <= kmax && d->kw >= 1 && d->kw <= kmax, TG_EINVAL, "%s: kernel %dx%d out of range", who,
+           d->kh, d->kw);
   TG_CHECK(d->pad_t >= 0 && d->pad_t < d->kh && d->pad_l >= 0 && d->pad_l < d->kw, TG_EINVAL, "%s: bad padding", who);
   // stride 1: the high-side padding implied by hout must be within the kernel
   const int pb = d->hout + d->kh - 1 - d->hin - d->pad_t, pr = d->wout + d->kw - 1 - d->win - d->pad_l;
@@ -119,7 +124,8 @@ int tg_conv2d_bwd_data_masked(const TgConvDesc* d, const void* gy, const void* w
 }
 
 size_t tg_conv2d_bwd_weight_workspace(const TgConvDesc* d) {
-  if (!d || d->algo == TG_ALGO_DIRECT) return 0;
+  if (!d) return 0;
+  if (d->algo == TG_ALGO_DIRECT) return tg_conv2d_bwd_weight_workspace_direct(d);
   return tg_conv2d_bwd_weight_workspace_mfma(d);
 }
 
@@ -213,7 +219,7 @@ int tg_conv2d_bwd_weight(const TgConvDesc* d, const void* x, const void* gy, flo
   TG_CHECK(x && gy && gw, TG_EINVAL, "tg_conv2d_bwd_weight: null pointer");
   TG_CHECK(tg_aligned16(x) && tg_aligned16(gy), TG_EALIGN, "tg_conv2d_bwd_weight: pointers must be 16 B aligned");
   if (d->algo != TG_ALGO_DIRECT) return tg_conv2d_bwd_weight_mfma(d, x, gy, gw, accumulate, ws, ws_bytes, (hipStream_t)stream);
-  return tg_conv2d_bwd_weight_direct(d, x, gy, gw, accumulate, (hipStream_t)stream);
+  return tg_conv2d_bwd_weight_direct(d, x, gy, gw, accumulate, (hipStream_t)stream, ws, ws_bytes);
 }
 
 }  // extern "C"

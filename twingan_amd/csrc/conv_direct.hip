@@ -65,10 +65,12 @@ __global__ void conv_bwd_data_direct(const T* __restrict__ gy, const float* __re
   }
 }
 
-// gw[ky,kx,ci,co] += sum over a chunk of output pixels of x[.., ci] * gy[.., co]
+// gw[ky,kx,ci,co] += sum over a chunk of output pixels of x[.., ci] * gy[.., co].  With `slab` every pixel chunk
+// writes its partial result to slab[chunk][.] and the chunks are summed in order by the slab reduction (the exact-parity
+// path: no float atomics, the result does not depend on block timing); without workspace the chunks are added atomically.
 template <typename T>
 __global__ void conv_bwd_weight_direct(const T* __restrict__ x, const T* __restrict__ gy, float* __restrict__ gw,
-                                       TgConvDesc d, int pix_per_chunk) {
+                                       float* __restrict__ slab, TgConvDesc d, int pix_per_chunk) {
   const int64_t nw = (int64_t)d.kh * d.kw * d.cin * d.cout;
   const int64_t npix = (int64_t)d.n * d.hout * d.wout;
   const int64_t p0 = (int64_t)blockIdx.y * pix_per_chunk;
@@ -90,7 +92,8 @@ __global__ void conv_bwd_weight_direct(const T* __restrict__ x, const T* __restr
       if (iy < 0 || iy >= d.hin || ix < 0 || ix >= d.win) continue;
       acc = fmaf(ld(x + (((int64_t)n * d.hin + iy) * d.win + ix) * d.cin + ci), ld(gy + p * d.cout + co), acc);
     }
-    atomicAdd(gw + i, acc);
+    if (slab) slab[(size_t)blockIdx.y * nw + i] = acc;
+    else atomicAdd(gw + i, acc);
   }
 }
 
@@ -120,23 +123,35 @@ int tg_conv2d_bwd_data_direct(const TgConvDesc* d, const void* gy, const void* w
   return TG_OK;
 }
 
-int tg_conv2d_bwd_weight_direct(const TgConvDesc* d, const void* x, const void* gy, float* gw, int accumulate,
-                                hipStream_t s) {
+int tg_wgrad_slab_reduce(const float* slab, float* gw, int64_t nw, int nslices, int accumulate, hipStream_t s);
+
+static constexpr int DIRECT_PIX_PER_CHUNK = 2048;
+
+size_t tg_conv2d_bwd_weight_workspace_direct(const TgConvDesc* d) {
   const int64_t nw = (int64_t)d->kh * d->kw * d->cin * d->cout;
   const int64_t npix = (int64_t)d->n * d->hout * d->wout;
-  if (!accumulate) {
+  return (size_t)((npix + DIRECT_PIX_PER_CHUNK - 1) / DIRECT_PIX_PER_CHUNK) * nw * sizeof(float);
+}
+
+int tg_conv2d_bwd_weight_direct(const TgConvDesc* d, const void* x, const void* gy, float* gw, int accumulate,
+                                hipStream_t s, void* ws, size_t ws_bytes) {
+  const int64_t nw = (int64_t)d->kh * d->kw * d->cin * d->cout;
+  const int64_t npix = (int64_t)d->n * d->hout * d->wout;
+  float* slab = (ws && ws_bytes >= tg_conv2d_bwd_weight_workspace_direct(d)) ? (float*)ws : nullptr;
+  if (!accumulate && !slab) {
     int rc = tg_zero_async(gw, nw * sizeof(float), nullptr, 0, s);
     if (rc) return rc;
   }
   tg_note_kernel("conv_bwd_weight_direct");
-  const int pix_per_chunk = 2048;
+  const int pix_per_chunk = DIRECT_PIX_PER_CHUNK;
   const int gy_chunks = (int)((npix + pix_per_chunk - 1) / pix_per_chunk);
   const int gx = tg_grid_for(nw, 256, 4096);
   TG_CHECK(gy_chunks <= 65535, TG_EINVAL, "tg_conv2d_bwd_weight(direct): too many pixels (%lld)", (long long)npix);
   TG_DISPATCH_DTYPE(d->dtype, "tg_conv2d_bwd_weight", {
     hipLaunchKernelGGL(conv_bwd_weight_direct<T>, dim3(gx, gy_chunks), dim3(256), 0, s, (const T*)x, (const T*)gy, gw,
-                       *d, pix_per_chunk);
+                       slab, *d, pix_per_chunk);
   });
   TG_LAUNCH_CHECK("tg_conv2d_bwd_weight(direct)");
+  if (slab) return tg_wgrad_slab_reduce(slab, gw, nw, gy_chunks, accumulate, s);
   return TG_OK;
 }

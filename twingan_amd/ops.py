@@ -1206,6 +1206,51 @@ def minibatch_state_concat(x, cpad, groups=1):
 
 
 # ------------------------------------------------------------------------------------------------
+# spectral normalisation of a conv kernel (libs/sn.py:38-101)
+# ------------------------------------------------------------------------------------------------
+class SpectralNormFn(torch.autograd.Function):
+  """(w_bar, u_new) = one power iteration on the fp32 master kernel w [kh,kw,cin,cout] from the persistent vector u
+  [1,cout]: w_bar = w / sigma with sigma = v W u_new^T (tg_spectral_norm_fwd).  The backward (tg_spectral_norm_bwd) lets
+  the gradient flow through sigma, v and u_new like the reference's graph; it is first order -- the gradient-penalty
+  double backward reaches the master weight through w_bar, i.e. through ONE application of this node's backward."""
+
+  @staticmethod
+  def forward(ctx, w, u):
+    _chk(w, u)
+    cout = w.shape[-1]
+    k_rows = w.numel() // cout
+    w_bar, u_new = torch.empty_like(w), torch.empty_like(u)
+    v = torch.empty(k_rows, dtype=torch.float32, device=w.device)
+    stats = torch.empty(2, dtype=torch.float32, device=w.device)
+    nbytes = _lib.load().tg_spectral_norm_workspace(k_rows, cout)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    call('tg_spectral_norm_fwd', _p(w), _p(u), _p(w_bar), _p(u_new), _p(v), _p(stats), k_rows, cout, _p(ws), nbytes,
+         _stream(), work=('sn_fwd:k%d:c%d' % (k_rows, cout), 6 * w.numel(), 4 * _nb(w)))
+    ctx.dims = (k_rows, cout, nbytes)
+    ctx.save_for_backward(w, u, u_new, v, stats)
+    ctx.mark_non_differentiable(u_new)
+    return w_bar, u_new
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, g, _gu):
+    w, u, u_new, v, stats = ctx.saved_tensors
+    k_rows, cout, nbytes = ctx.dims
+    g = g.contiguous()
+    sink = None if _State.skip_param_grads else GradSink.get(w)
+    gw = sink if sink is not None else torch.empty_like(w)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    call('tg_spectral_norm_bwd', _p(g), _p(w), _p(u), _p(u_new), _p(v), _p(stats), _p(gw), 1 if sink is not None else 0,
+         k_rows, cout, _p(ws), nbytes, _stream(), work=('sn_bwd:k%d:c%d' % (k_rows, cout), 6 * w.numel(), 4 * _nb(w)))
+    return (None if sink is not None else gw), None
+
+
+def spectral_norm(w, u):
+  """-> (w_bar, u_new); see SpectralNormFn."""
+  return SpectralNormFn.apply(w, u.contiguous())
+
+
+# ------------------------------------------------------------------------------------------------
 # small dense layer (layers.fully_connected, nets/pggan_utils.py:323-327)
 # ------------------------------------------------------------------------------------------------
 class GemmFn(torch.autograd.Function):

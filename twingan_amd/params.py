@@ -68,22 +68,23 @@ class ParamStore:
     self.add(scope + '/weights', (k, k, cin, cout), group, 'conv_w', (k, k, phys_cin or cin, cout))
     if bias:
       self.add(scope + '/biases', (cout,), group, 'bias')
+    pf = lambda d: '_' + d if d else ''      # domain postfix of the normaliser variables ('' in the plain PGGAN trainer)
     for d in norm_domains:
       if cond_dim:      # gamma = 1 + FC(cond), beta = FC(cond)  (libs/instance_norm.py:93-120, batch_norm.py:34-38)
         for nm in ('gamma', 'beta'):
-          self.add('%s/%s/%s_%s/weights' % (scope, norm_scope, nm, d), (cond_dim, cout), group, 'xavier_w')
-          self.add('%s/%s/%s_%s/biases' % (scope, norm_scope, nm, d), (cout,), group, 'bias')
+          self.add('%s/%s/%s%s/weights' % (scope, norm_scope, nm, pf(d)), (cond_dim, cout), group, 'xavier_w')
+          self.add('%s/%s/%s%s/biases' % (scope, norm_scope, nm, pf(d)), (cout,), group, 'bias')
       else:
-        self.add('%s/%s/gamma_%s' % (scope, norm_scope, d), (cout,), group, 'gamma')
-        self.add('%s/%s/beta_%s' % (scope, norm_scope, d), (cout,), group, 'beta')
+        self.add('%s/%s/gamma%s' % (scope, norm_scope, pf(d)), (cout,), group, 'gamma')
+        self.add('%s/%s/beta%s' % (scope, norm_scope, pf(d)), (cout,), group, 'beta')
       if norm_scope == 'BatchNorm':      # non-trainable moving statistics (libs/batch_norm.py:184-196)
-        self.state_specs['%s/BatchNorm/moving_mean_%s' % (scope, d)] = (cout, 0.0)
-        self.state_specs['%s/BatchNorm/moving_variance_%s' % (scope, d)] = (cout, 1.0)
+        self.state_specs['%s/BatchNorm/moving_mean%s' % (scope, pf(d))] = (cout, 0.0)
+        self.state_specs['%s/BatchNorm/moving_variance%s' % (scope, pf(d))] = (cout, 1.0)
         if self.renorm:                  # batch renorm training statistics (libs/batch_norm.py:209-246), zero-initialised
-          self.state_specs['%s/BatchNorm/renorm_mean_%s' % (scope, d)] = (cout, 0.0)
-          self.state_specs['%s/BatchNorm/renorm_mean_weight_%s' % (scope, d)] = (1, 0.0)
-          self.state_specs['%s/BatchNorm/renorm_stddev_%s' % (scope, d)] = (cout, 0.0)
-          self.state_specs['%s/BatchNorm/renorm_stddev_weight_%s' % (scope, d)] = (1, 0.0)
+          self.state_specs['%s/BatchNorm/renorm_mean%s' % (scope, pf(d))] = (cout, 0.0)
+          self.state_specs['%s/BatchNorm/renorm_mean_weight%s' % (scope, pf(d))] = (1, 0.0)
+          self.state_specs['%s/BatchNorm/renorm_stddev%s' % (scope, pf(d))] = (cout, 0.0)
+          self.state_specs['%s/BatchNorm/renorm_stddev_weight%s' % (scope, pf(d))] = (1, 0.0)
 
   # ---- allocation -----------------------------------------------------------------------------
   def build(self, seed=0):
@@ -239,18 +240,26 @@ def grad_phase(name, cfg):
   return 1 if high else 0
 
 
-def declare_twingan(store, cfg):
+def declare_pggan(store, cfg):
+  """The plain PGGAN trainer's variables (image_generation.py:194-316: scopes 'generator' and 'discriminator', latent
+  noise input, no encoder, no domain postfix on the normaliser variables) -- BASELINE configs[0]."""
+  return declare_twingan(store, cfg, model='pggan')
+
+
+def declare_twingan(store, cfg, model='twingan'):
   """All TwinGAN variables of one progressive stage (scopes twingan.py:105-110; layer lists
-  SURVEY.md Appendix A; nets/pggan.py:93-211,242-376,403-479)."""
+  SURVEY.md Appendix A; nets/pggan.py:93-211,242-376,403-479).  ``model='pggan'``: see declare_pggan."""
   hw, mc = cfg.hw, cfg.max_ch
-  store.phase_of = lambda name: grad_phase(name, cfg)
+  pggan_model = model == 'pggan'
+  store.phase_of = (lambda name: 0) if pggan_model else (lambda name: grad_phase(name, cfg))
   ms = max_stage_of(hw)
   NORM_SCOPE = {'instance_norm': 'InstanceNorm', 'batch_norm': 'BatchNorm', 'batch_renorm': 'BatchNorm'}
   store.renorm = cfg.generator_norm_type == 'batch_renorm'
   if cfg.generator_norm_type not in NORM_SCOPE:
     raise NotImplementedError('generator_norm_type=%s' % cfg.generator_norm_type)
-  nd = ('s', 't')
+  nd = ('',) if pggan_model else ('s', 't')
   ns = NORM_SCOPE[cfg.generator_norm_type]
+  rk = min(7, hw // 2) if cfg.use_larger_filter_at_rgb_layer else 1      # nets/pggan.py:172-175,194-197
   if cfg.equalized_learning_rate:
     store.weights_init_stddev = 1.0
 
@@ -302,9 +311,10 @@ def declare_twingan(store, cfg):
       shortcut(blk, c, nc, group)
       c = nc
 
-  enc_skeleton('encoder_content', 'g', False, nd)
+  if not pggan_model:
+    enc_skeleton('encoder_content', 'g', False, nd)
   gen_kw = {}
-  if cfg.use_style_embedding:      # twingan.py:47-51,201-223: the style encoder (pggan.encoder) and conditional generator norms
+  if cfg.use_style_embedding and not pggan_model:      # twingan.py:47-51,201-223: the style encoder (pggan.encoder) and conditional generator norms
     if cfg.generator_norm_type not in ('instance_norm', 'batch_norm'):
       raise NotImplementedError('use_style_embedding with generator_norm_type=%s' % cfg.generator_norm_type)
     enc_skeleton('encoder_style', 'g', False, nd)
@@ -317,15 +327,19 @@ def declare_twingan(store, cfg):
   # generator
   c = get_num_channels(0, mc)
   blk = 'generator/block_4x4x%d' % c
-  store.add_conv(blk + '/Conv', 3, c, c, 'g', False, nd, norm_scope=ns, **gen_kw)
+  if pggan_model:      # latent noise [B,1,1,get_num_channels(1)] padded to 7x7, 4x4 VALID (nets/pggan.py:135-153)
+    store.add_conv(blk + '/Conv', 4, get_num_channels(1, mc), c, 'g', False, nd, norm_scope=ns)
+  else:
+    store.add_conv(blk + '/Conv', 3, c, c, 'g', False, nd, norm_scope=ns, **gen_kw)
   store.add_conv(blk + '/Conv_1', 3, c, c, 'g', False, nd, norm_scope=ns, **gen_kw)
   attention('generator', 4, c, c, 'g', False, nd, **gen_kw)
   for stage in range(1, ms + 1):
     cur = 2 ** (stage + 2)
     oc = get_num_channels(stage, mc)
     if stage == ms and cfg.is_growing:
-      store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (cur // 2, cur // 2), 1, c, 3, 'g', False, nd, norm_scope=ns, **gen_kw)
-    skip = cfg.use_unet and not (cfg.unet_max_concat_hw and cur > cfg.unet_max_concat_hw)      # pggan_utils.py:287-289
+      store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (cur // 2, cur // 2), rk, c, 3, 'g', False, nd, norm_scope=ns, **gen_kw)
+    skip = (cfg.use_unet and not pggan_model and
+            not (cfg.unet_max_concat_hw and cur > cfg.unet_max_concat_hw))      # pggan_utils.py:287-289
     cin = c + (get_num_channels(stage - 1, mc) if skip else 0)
     blk = 'generator/block_%dx%dx%d' % (cur, cur, oc)
     store.add_conv(blk + '/Conv', 3, cin, oc, 'g', False, nd, norm_scope=ns, **gen_kw)
@@ -333,9 +347,9 @@ def declare_twingan(store, cfg):
     shortcut(blk, cin, oc, 'g')
     attention('generator', cur, oc, oc, 'g', False, nd, **gen_kw)
     c = oc
-  store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (hw, hw), 1, c, 3, 'g', False, nd, norm_scope=ns, **gen_kw)
+  store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (hw, hw), rk, c, 3, 'g', False, nd, norm_scope=ns, **gen_kw)
   # discriminators
-  for top in ('discriminator_s', 'discriminator_t'):
+  for top in (('discriminator',) if pggan_model else ('discriminator_s', 'discriminator_t')):
     md = cfg.max_ch_dis or mc      # get_discriminator_max_num_channels (nets/pggan_utils.py:375-380)
     enc_skeleton(top, 'd', True, (), md)
     blk = '%s/before_fc_1x1x%d' % (top, md)

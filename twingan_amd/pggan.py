@@ -18,6 +18,12 @@ from .params import get_num_channels, max_stage_of, mbstd_cpad
 # ------------------------------------------------------------------------------------------------
 # layer helpers (nets/pggan_utils.py)
 # ------------------------------------------------------------------------------------------------
+def _pf(d):
+  """Variable-name postfix of a domain (conditional_layer_var_scope_postfix, nets/pggan_utils.py:102-113): '_s' / '_t' in
+  TwinGAN, nothing in the plain PGGAN trainer (image_generation.py)."""
+  return '_' + d if d else ''
+
+
 def _equalize(x, cfg, k, in_ch=None):
   """maybe_equalized_conv2d / maybe_equalized_fc (nets/pggan_utils.py:236-254): with --equalized_learning_rate the
   layer INPUT is scaled by sqrt(2 / (in_ch * k^2)); weights are then N(0,1)-initialised (params.declare_twingan)."""
@@ -38,7 +44,8 @@ def _sn(P, scope, cfg, is_discriminator):
   with the gradient flowing through sigma, v and u' (the reference does not stop it).  The reference re-runs the
   iteration and assigns u at EVERY use of the kernel inside one session.run, in unspecified order; here every use in
   a run sees the pre-run u (one valid schedule of those unordered assigns) and u is assigned once, by end_run().
-  The iteration is a few matrix-vector products on the fp32 master weight: plain tensor ops, differentiable twice."""
+  The iteration and its backward are the tg_spectral_norm_fwd / _bwd kernels on the fp32 master weight
+  (ops.SpectralNormFn)."""
   w = P[scope + '/weights']
   if not (cfg.spectral_norm and (is_discriminator or cfg.spectral_norm_in_non_discriminator)):
     return w
@@ -46,12 +53,8 @@ def _sn(P, scope, cfg, is_discriminator):
   if scope in cache:
     return cache[scope]
   u = P.state[scope + '/u']
-  w2 = w.reshape(-1, w.shape[-1])
-  v = _l2_normalize(u @ w2.t())
-  u1 = _l2_normalize(v @ w2)
-  sigma = (v @ w2 @ u1.t()).reshape(())
-  w_bar = (w2 / sigma).reshape(w.shape)
-  P.__dict__.setdefault('sn_pending', {})[scope + '/u'] = u1.detach()
+  w_bar, u1 = ops.spectral_norm(w, u)
+  P.__dict__.setdefault('sn_pending', {})[scope + '/u'] = u1
   cache[scope] = w_bar
   return w_bar
 
@@ -169,9 +172,9 @@ def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pix
     if nt != 'batch_norm':
       raise NotImplementedError('style embedding with generator_norm_type=%s' % nt)
     return _cond_batch_norm(P, scope, y, cond, segs, passes, activation, pn, pool, cfg)
-  g0, b0 = P['%s/%s/gamma_%s' % (scope, ns, d0)], P['%s/%s/beta_%s' % (scope, ns, d0)]
-  g1 = P['%s/%s/gamma_%s' % (scope, ns, d1)] if d1 else None
-  b1 = P['%s/%s/beta_%s' % (scope, ns, d1)] if d1 else None
+  g0, b0 = P['%s/%s/gamma%s' % (scope, ns, _pf(d0))], P['%s/%s/beta%s' % (scope, ns, _pf(d0))]
+  g1 = P['%s/%s/gamma%s' % (scope, ns, _pf(d1))] if d1 else None
+  b1 = P['%s/%s/beta%s' % (scope, ns, _pf(d1))] if d1 else None
   if nt == 'instance_norm':
     return ops.norm_act(y, g0, b0, lrelu=activation, pixel_norm=pn, gamma2=g1, beta2=b1, split=split, pool=pool)
   # batch norm (libs/batch_norm.py:42-326, training mode): moments over (N,H,W) of ONE reference pass.  Each of
@@ -189,7 +192,7 @@ def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pix
     return out.view(n, h, w, c)
   ema = None
   if st is not None:
-    pairs = [(st['%s/BatchNorm/moving_mean_%s' % (scope, d)], st['%s/BatchNorm/moving_variance_%s' % (scope, d)])
+    pairs = [(st['%s/BatchNorm/moving_mean%s' % (scope, _pf(d))], st['%s/BatchNorm/moving_variance%s' % (scope, _pf(d))])
              for d in ((d0, d1) if d1 else (d0,))]
     ema = (0.999, pairs)
   out = ops.norm_act(yv, g0, b0, lrelu=activation, pixel_norm=pn, in_eps=1e-3, gamma2=g1, beta2=b1,
@@ -216,7 +219,7 @@ def _cond_batch_norm(P, scope, y, cond, segs, passes, activation, pn, pool, cfg)
   st = P.state if hasattr(P, 'state') else None
   if st is not None:
     doms = [d for d, _, _ in segs]
-    ema = (0.999, [(st['%s/BatchNorm/moving_mean_%s' % (scope, d)], st['%s/BatchNorm/moving_variance_%s' % (scope, d)])
+    ema = (0.999, [(st['%s/BatchNorm/moving_mean%s' % (scope, _pf(d))], st['%s/BatchNorm/moving_variance%s' % (scope, _pf(d))])
                    for d in doms])
   split_v = None if len(segs) == 1 else segs[0][2] * passes // n
   yhat = ops.norm_act(y.view(passes, (n // passes) * h, w, c), one, zero, lrelu=False, pixel_norm=False, in_eps=BN_EPS,
@@ -257,11 +260,11 @@ def _batch_renorm(P, scope, yv, domain, activation, pn, pool):
   for i in range(passes):
     d = d0 if (split is None or i < split) else d1
     pre = '%s/BatchNorm/' % scope
-    gamma, beta = P[pre + 'gamma_' + d], P[pre + 'beta_' + d]
+    gamma, beta = P[pre + 'gamma' + _pf(d)], P[pre + 'beta' + _pf(d)]
     with torch.no_grad():
       bmean, stddev = mean_p[i], 1.0 / rstd_p[i]
-      rm, rmw = st[pre + 'renorm_mean_' + d], st[pre + 'renorm_mean_weight_' + d]
-      rs, rsw = st[pre + 'renorm_stddev_' + d], st[pre + 'renorm_stddev_weight_' + d]
+      rm, rmw = st[pre + 'renorm_mean' + _pf(d)], st[pre + 'renorm_mean_weight' + _pf(d)]
+      rs, rsw = st[pre + 'renorm_stddev' + _pf(d)], st[pre + 'renorm_stddev_weight' + _pf(d)]
       mixed_mean = rm + (1.0 - rmw) * bmean
       mixed_std = rs + (1.0 - rsw) * stddev
       r = torch.minimum(torch.maximum(stddev / mixed_std, rmin), rmax)
@@ -271,8 +274,8 @@ def _batch_renorm(P, scope, yv, domain, activation, pn, pool):
       rs.mul_(m).add_(stddev, alpha=1.0 - m)
       rsw.mul_(m).add_(1.0 - m)
       new_mean, new_std = rm / rmw, rs / rsw
-      st[pre + 'moving_mean_' + d].mul_(m).add_(new_mean, alpha=1.0 - m)
-      st[pre + 'moving_variance_' + d].mul_(m).add_(new_std * new_std - BN_EPS, alpha=1.0 - m)
+      st[pre + 'moving_mean' + _pf(d)].mul_(m).add_(new_mean, alpha=1.0 - m)
+      st[pre + 'moving_variance' + _pf(d)].mul_(m).add_(new_std * new_std - BN_EPS, alpha=1.0 - m)
     g_rows.append(r * gamma)
     b_rows.append(dd * gamma + beta)
   return ops.norm_act(yv, torch.stack(g_rows), torch.stack(b_rows), lrelu=activation, pixel_norm=pn, in_eps=BN_EPS,
@@ -388,9 +391,29 @@ def encoder(P, source, domain, cfg, top='encoder_style'):
 # ------------------------------------------------------------------------------------------------
 # generator (nets/pggan.py:69-211), TwinGAN mode: source is the encoder's [B,4,4,C] content tensor
 # ------------------------------------------------------------------------------------------------
+def rgb_kernel_size(cfg, hw):
+  """--use_larger_filter_at_rgb_layer (nets/pggan.py:172-175,194-197): to-RGB kernel min(7, hw / 2) instead of 1x1.
+  The reference computes it from the CURRENT block's hw for both the grown and the previous-resolution layer."""
+  return min(7, hw // 2) if cfg.use_larger_filter_at_rgb_layer else 1
+
+
+def get_noise_shape(batch_size=None, max_num_channels=256):
+  """nets/pggan.py:86-90: the latent noise of the plain PGGAN generator, [B, 1, 1, get_num_channels(1)]."""
+  return (batch_size, 1, 1, get_num_channels(1, max_num_channels))
+
+
 def generator(P, source, domain, cfg, unet_end_points=None, top='generator', unet_groups=None, cond=None):
+  """``source``: the encoder's [B,4,4,C] content tensor (TwinGAN), or latent noise [B,1,1,C] / [B,C] (plain PGGAN,
+  nets/pggan.py:135-153: zero-padded to 7x7 so that the block's first conv, 4x4 VALID, yields the 4x4 map)."""
+  import torch
   max_stage = max_stage_of(cfg.hw)
-  assert source.shape[1] == 4 and source.shape[2] == 4, 'TwinGAN generator expects a 4x4 content tensor'
+  if source.dim() == 2:
+    source = source.reshape(source.shape[0], 1, 1, source.shape[1])
+  noise_mode = source.shape[1] == 1 and source.shape[2] == 1
+  if noise_mode:
+    source = torch.nn.functional.pad(source, (0, 0, 3, 3, 3, 3)).contiguous()
+  else:
+    assert source.shape[1] == 4 and source.shape[2] == 4, 'the generator takes a 4x4 content tensor or 1x1 noise'
   end_points = {'source': source}
   net = source
   net_before_growth = None
@@ -400,13 +423,16 @@ def generator(P, source, domain, cfg, unet_end_points=None, top='generator', une
     output_channels = get_num_channels(stage, cfg.max_ch)
     name = 'block_%dx%dx%d' % (hw, hw, output_channels)
     if hw == 4:
-      net = _ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg, cond=cond)
+      if noise_mode:
+        net = _ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg, k=4, padding='VALID', cond=cond)
+      else:
+        net = _ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg, cond=cond)
       net = _ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg, cond=cond)
     else:
       if stage == max_stage and cfg.is_growing:
         rgb = 'generator_to_rgb_%dx%d' % (hw // 2, hw // 2)
-        net_before_growth = _ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=1, activation=False,
-                                     pixel_norm=False, cond=cond)
+        net_before_growth = _ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=rgb_kernel_size(cfg, hw),
+                                     activation=False, pixel_norm=False, cond=cond)
         net_before_growth = resize_twice_as_big(net_before_growth)
         end_points[rgb] = net_before_growth
       # generator_three_layer_block: upsample -> concat(UNet) -> conv -> conv  (pggan.py:69-83)
@@ -428,7 +454,8 @@ def generator(P, source, domain, cfg, unet_end_points=None, top='generator', une
     net = maybe_add_self_attention(P, top, hw, output_channels, net, end_points, domain, cfg, cond=cond)      # pggan.py:188-190
   rgb = 'generator_to_rgb_%dx%d' % (hw, hw)
   # to_rgb: activation None, normaliser still applied, no pixel norm (pggan.py:192-200)
-  to_rgb = _ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=1, activation=False, pixel_norm=False, cond=cond)
+  to_rgb = _ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=rgb_kernel_size(cfg, hw), activation=False,
+                    pixel_norm=False, cond=cond)
   if cfg.is_growing:
     output = ops.lerp(to_rgb, net_before_growth, cfg.alpha_grow)
     end_points['alpha_grow'] = cfg.alpha_grow

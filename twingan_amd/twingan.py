@@ -223,9 +223,9 @@ def _d_domain_terms(P, cfg, terms, d, top, real, prime, cyc, a, cyc_gan):
       terms['discriminator_drift_loss_prime_' + d] = ops.square_mean(pr, cfg.wgan_drift_loss_weight)
 
 
-def _d_domain_gp(P, cfg, terms, d, top, real, prime, a, noise=None):
+def _d_domain_gp(P, cfg, terms, d, top, real, prime, a, noise=None, name=None):
   """Gradient penalty of one domain: WGAN-GP on real..fake interpolates (image_generation.py:414-439) or DRAGAN
-  on real..perturbed-real ones (:441-476)."""
+  on real..perturbed-real ones (:441-476).  ``name``: the loss term's name (default: TwinGAN's per-domain one)."""
   if cfg.loss_architecture == 'dragan':
     if noise is None:
       noise = (torch.rand(real.shape, dtype=torch.float32, device=real.device) * 2.0 - 1.0).to(real.dtype)
@@ -236,7 +236,7 @@ def _d_domain_gp(P, cfg, terms, d, top, real, prime, a, noise=None):
   ones = ops.fill(pi.shape, 1.0, pi.dtype, pi.device)
   with ops.no_param_grads():        # only d pred / d interp is needed here; parameters get theirs via the double backward
     gi, = torch.autograd.grad(pi, interp, grad_outputs=ones, create_graph=True)  # tf.gradients(pred, interp)
-  terms['discriminator_gradient_penalty_prime_' + d] = ops.gradient_penalty(gi.contiguous(), cfg.gradient_penalty_lambda)
+  terms[name or 'discriminator_gradient_penalty_prime_' + d] = ops.gradient_penalty(gi.contiguous(), cfg.gradient_penalty_lambda)
 
 
 BATCH_RENORM_BOUNDARIES = (10000, 20000, 30000)                      # nets/pggan_utils.py:43-47
@@ -279,7 +279,7 @@ class Trainer:
       with torch.cuda.device(self.device):
         torch.cuda.manual_seed(1000003 * (seed + 1) + rank)
     self.reducer = GradReducer(world_size, process_group)
-    self.store = declare_twingan(ParamStore(self.device), cfg).build(seed)
+    self.store = self._declare(ParamStore(self.device), cfg).build(seed)
     self.P = self.store.P
     self.n_critic_counter = 0       # image_generation.py:622-623
     self.global_step = 0            # advanced once per n_critic cycle, see _advance_counters
@@ -349,14 +349,14 @@ class Trainer:
       ops.Cuts.begin()
     try:
       if group == 'g':
-        loss, terms = generator_loss(self.P, sources, targets, self.cfg)
+        loss, terms = self._generator_loss(sources, targets)
       else:
-        b = sources.shape[0]
+        b = targets.shape[0]
         if gp_alpha_s is None:
           gp_alpha_s = torch.rand(b, dtype=torch.float32, device=self.device)
         if gp_alpha_t is None:
           gp_alpha_t = torch.rand(b, dtype=torch.float32, device=self.device)
-        loss, terms = discriminator_loss(self.P, sources, targets, self.cfg, gp_alpha_s, gp_alpha_t)
+        loss, terms = self._discriminator_loss(sources, targets, gp_alpha_s, gp_alpha_t)
       out = (loss.detach(), {k: v.detach() for k, v in terms.items()})
       scaled = loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)       # model_deploy.py:265-268,308-313
       ops.GradSink.pair = True
@@ -377,6 +377,16 @@ class Trainer:
       ops.GradSink.pair = False
       if nseg > 1:
         ops.Cuts.end()
+
+  # the model: TwinGAN's two loss sums (subclasses swap them: image_generation.PgganTrainer)
+  def _declare(self, store, cfg):
+    return declare_twingan(store, cfg)
+
+  def _generator_loss(self, sources, targets):
+    return generator_loss(self.P, sources, targets, self.cfg)
+
+  def _discriminator_loss(self, sources, targets, gp_alpha_s, gp_alpha_t):
+    return discriminator_loss(self.P, sources, targets, self.cfg, gp_alpha_s, gp_alpha_t)
 
   def _step(self, group, sources, targets, gp_alpha_s=None, gp_alpha_t=None):
     out = None
@@ -423,7 +433,7 @@ class Trainer:
     """Captures, per step kind, one graph per backward segment and one for the apply: the clone all-reduces (RCCL)
     run between them, outside any capture.  The eager warm-up (one real step of each kind: allocates every weight pack
     and job table once) is undone afterwards, so graph mode and eager mode follow the same trajectory."""
-    self._static = dict(s=sources.clone(), t=targets.clone())
+    self._static = dict(s=None if sources is None else sources.clone(), t=targets.clone())
     st = self._static
     snap = self._snapshot()
     side = torch.cuda.Stream(device=self.device)
@@ -482,7 +492,7 @@ class Trainer:
         self.adam_t = int(self._adam_step_dev.item())
         return self.g_step(sources, targets) if kind == 'g' else self.d_step(sources, targets)
     st = self._static
-    if sources.data_ptr() != st['s'].data_ptr():
+    if sources is not None and sources.data_ptr() != st['s'].data_ptr():
       st['s'].copy_(sources)
     if targets.data_ptr() != st['t'].data_ptr():
       st['t'].copy_(targets)
