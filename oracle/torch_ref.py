@@ -168,11 +168,11 @@ def init_params(cfg, seed=0, dtype=torch.float32, std=0.02):
   if cfg.equalized:
     std = 1.0
   for s in encoder_param_specs('encoder_content', cfg.hw, cfg.max_ch, cfg.is_growing):
-    _conv_p(P, g, s[0], s[1], s[2], s[3], ('s', 't') if cfg.norm in NORM_SCOPE else (), False, dtype, std,
-            NORM_SCOPE.get(cfg.norm, ''))
+    _conv_p(P, g, s[0], s[1], s[2], s[3], ('s', 't') if cfg.norm in NORM_SCOPE else (), cfg.norm not in NORM_SCOPE, dtype,
+            std, NORM_SCOPE.get(cfg.norm, ''))      # no normaliser: slim's conv2d owns a bias instead
   for s in generator_param_specs('generator', cfg.hw, cfg.max_ch, cfg.use_unet, cfg.is_growing, cfg.unet_max_concat_hw):
-    _conv_p(P, g, s[0], s[1], s[2], s[3], ('s', 't') if cfg.norm in NORM_SCOPE else (), False, dtype, std,
-            NORM_SCOPE.get(cfg.norm, ''))
+    _conv_p(P, g, s[0], s[1], s[2], s[3], ('s', 't') if cfg.norm in NORM_SCOPE else (), cfg.norm not in NORM_SCOPE, dtype,
+            std, NORM_SCOPE.get(cfg.norm, ''))
   md = cfg.max_ch_dis or cfg.max_ch
   for top in ('discriminator_s', 'discriminator_t'):
     for s in encoder_param_specs(top, cfg.hw, md, cfg.is_growing) + discriminator_tail_specs(top, md):
@@ -498,7 +498,9 @@ def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=Tru
   elif cfg.norm == 'batch_renorm':     # the configuration of docs/training.md:17
     y = batch_renorm_train(y, P[scope + '/BatchNorm/gamma' + _pf(domain)], P[scope + '/BatchNorm/beta' + _pf(domain)],
                            cfg.bn_state, scope + '/BatchNorm/', _pf(domain), renorm_clipping(cfg.global_step))
-  elif cfg.norm not in ('none', None):
+  elif cfg.norm in ('none', None):      # nets/pggan_utils.py:198-200: normalizer_fn None -> slim's conv2d adds its bias
+    y = y + P[scope + '/biases']
+  else:
     raise NotImplementedError(cfg.norm)
   if act:
     y = leaky_relu(y, cfg.lrelu)

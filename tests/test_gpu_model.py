@@ -616,12 +616,46 @@ def test_batch_norm_generator_matches_oracle():
     assert abs(gterms[k].item() - rgterms[k].item()) < 1e-4 * max(1.0, abs(rgterms[k].item())), k
   gl.backward()
   rgl.backward()
-  _grads_close(tr, Pref, tr.store.names('g'), FP32_GRAD_TOL, 'generator(batch_norm, var_tol=FP32_VAR_GRAD_TOL)')
+  _grads_close(tr, Pref, tr.store.names('g'), FP32_GRAD_TOL, 'generator(batch_norm)', var_tol=FP32_VAR_GRAD_TOL)
   # moving statistics: same set of variables, same values (each pass = one assign_moving_average)
   assert set(tr.store.state) == set(state)
   for k, v in state.items():
     a = tr.store.state[k].double().cpu().numpy()
     assert np.abs(a - v.numpy()).max() < 1e-5 * max(1.0, np.abs(v.numpy()).max()), k
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_no_normaliser_generator_matches_oracle(precision):
+  """generator_norm_type=none (nets/pggan_utils.py:198-200): the encoder / generator convs own a bias, LeakyReLU runs in
+  the conv epilogue and the pixel norm is the fused kernel with constant statistics (ops.pixel_norm, NF_NOSTATS in
+  its backward).  Losses and gradients against the oracle (pinned live: test_reference_live 'no_normaliser')."""
+  from twingan_amd import Config
+  from twingan_amd import twingan as T
+  from twingan_amd.twingan import Trainer
+  cfg = Config(hw=16, max_ch=16, precision=precision, generator_norm_type='none')
+  rcfg = R.Config(hw=16, max_ch=16, norm='none')
+  Pref = R.init_params(rcfg, seed=9, dtype=torch.float64, std='he')
+  tr = Trainer(cfg, device='cuda:0', seed=9)
+  assert set(tr.store.state_dict()) == set(Pref) and 'generator/block_8x8x16/Conv/biases' in Pref
+  tr.store.load_state_dict({k: v.float() for k, v in Pref.items()})
+  Pref = {k: v.float().double().requires_grad_(True) for k, v in Pref.items()}
+  g = torch.Generator().manual_seed(79)
+  adt = torch.bfloat16 if precision == 'bf16' else torch.float32
+  s, t = (torch.rand(3, 16, 16, 3, generator=g).to(adt).float() for _ in range(2))
+  dev = lambda x: x.to('cuda:0').to(adt).contiguous()
+  tr.store.zero_grad('g')
+  tr._set_requires_grad(g=True, d=False)
+  gl, gterms = T.generator_loss(tr.P, dev(s), dev(t), cfg)
+  rgl, rgterms = R.generator_loss(Pref, s.double(), t.double(), rcfg)
+  tol = 1e-4 if precision == 'fp32' else 5e-2
+  for k in rgterms:
+    assert abs(gterms[k].item() - rgterms[k].item()) < tol * max(1.0, abs(rgterms[k].item())), k
+  gl.backward()
+  rgl.backward()
+  if precision == 'fp32':
+    _grads_close(tr, Pref, tr.store.names('g'), FP32_GRAD_TOL, 'generator(no normaliser)', var_tol=FP32_VAR_GRAD_TOL)
+  else:
+    _grads_close(tr, Pref, tr.store.names('g'), 0.5, 'generator(no normaliser, bf16)', min_cos=0.9)
 
 
 @pytest.mark.parametrize('global_step', [0, 25000])
@@ -657,7 +691,7 @@ def test_batch_renorm_generator_matches_oracle(global_step):
       assert abs(gterms[k].item() - rgterms[k].item()) < 2e-4 * max(1.0, abs(rgterms[k].item())), (it, k)
     gl.backward()
     rgl.backward()
-    _grads_close(tr, Pref, tr.store.names('g'), FP32_GRAD_TOL, 'generator(batch_renorm, run %d, var_tol=FP32_VAR_GRAD_TOL)' % it)
+    _grads_close(tr, Pref, tr.store.names('g'), FP32_GRAD_TOL, 'generator(batch_renorm, run %d)' % it, var_tol=FP32_VAR_GRAD_TOL)
   renorm_state = {k: v for k, v in tr.store.state.items() if not k.startswith('renorm/')}
   assert set(renorm_state) == set(state)
   for k, v in state.items():
@@ -785,7 +819,7 @@ def test_style_embedding_matches_oracle(attention):
     assert abs(gterms[k].item() - rterms[k].item()) < 1e-4 * max(1.0, abs(rterms[k].item())), k
   gl.backward()
   rgl.backward()
-  _grads_close(tr, Pref, tr.store.names('g'), FP32_GRAD_TOL, 'generator(style, var_tol=FP32_VAR_GRAD_TOL)')
+  _grads_close(tr, Pref, tr.store.names('g'), FP32_GRAD_TOL, 'generator(style)', var_tol=FP32_VAR_GRAD_TOL)
   # the discriminator step only needs the forward of the styled generators
   tr.store.zero_grad('d')
   tr._set_requires_grad(g=False, d=True)

@@ -745,3 +745,27 @@ def test_lrelu_fold_under_create_graph_matches_unfused(ops, dtype, hw, c1, c2):
   rtol = 1e-4 if dtype == torch.float32 else 6e-2
   for a, b in zip(res[1], want):
     assert rel_l2(a, b) < rtol, rel_l2(a, b)
+
+
+@pytest.mark.parametrize('k,cin,cout', [(3, 16, 32), (1, 3, 16), (4, 64, 64), (3, 264, 256), (3, 5, 7)])
+def test_spectral_norm_matches_oracle(ops, k, cin, cout):
+  """tg_spectral_norm_fwd / _bwd (libs/sn.py:38-101): w_bar, the next power-iteration vector, and d L / d w with the
+  gradient flowing through sigma, v and u' -- against float64 autograd of the literal formulas."""
+  rng = np.random.RandomState(6)
+  w = rng.randn(k, k, cin, cout) * 0.1
+  u = rng.randn(1, cout)
+  gq = rng.randn(k, k, cin, cout)
+  wd = to_dev(w).requires_grad_(True)
+  w_bar, u_new = ops.spectral_norm(wd, to_dev(u))
+  (w_bar * to_dev(gq)).sum().backward()
+  wt = torch.from_numpy(w).requires_grad_(True)
+  w2 = wt.reshape(-1, cout)
+  ut = torch.from_numpy(u)
+  v = R.l2_normalize(ut @ w2.t())
+  u1 = R.l2_normalize(v @ w2)
+  sigma = (v @ w2 @ u1.t()).reshape(())
+  ref = (w2 / sigma).reshape(wt.shape)
+  (ref * torch.from_numpy(gq)).sum().backward()
+  assert rel_l2(host(w_bar), ref.detach().numpy()) < F32_TOL
+  assert rel_l2(host(u_new), u1.detach().numpy()) < F32_TOL
+  assert rel_l2(host(wd.grad), wt.grad.numpy()) < 5 * F32_TOL

@@ -26,6 +26,7 @@ CASES = {
   'batch_renorm_step0': dict(hw=16, max_ch=8, norm='batch_renorm'),
   'batch_renorm_step25000': dict(hw=16, max_ch=8, norm='batch_renorm', global_step=25000),
   'batch_norm': dict(hw=16, max_ch=8, norm='batch_norm'),
+  'no_normaliser': dict(hw=16, max_ch=8, norm='none'),                        # convs with biases (nets/pggan_utils.py:198-200)
   'sn_hinge': dict(hw=16, max_ch=8, spectral_norm=True, loss='hinge'),
   'sn_everywhere': dict(hw=16, max_ch=8, spectral_norm=True, sn_non_disc=True, res_block=True),
   'attention_in_generator': dict(hw=16, max_ch=16, do_self_attention=True, self_attention_hw=16),

@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 TG_F32, TG_BF16 = 0, 1
 TG_ALGO_DIRECT, TG_ALGO_MFMA = 0, 1
 TG_EPI_BIAS, TG_EPI_LRELU = 1, 2
-NF_LRELU, NF_PIXNORM = 1, 2
+NF_LRELU, NF_PIXNORM, NF_NOSTATS = 1, 2, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtwingan_hip.so')

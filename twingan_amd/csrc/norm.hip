@@ -14,6 +14,7 @@ namespace {
 
 #define NF_LRELU 1
 #define NF_PIXNORM 2
+#define NF_NOSTATS 4      // mean / rstd are constants (no normaliser: pixel norm only): the backward drops the statistic terms
 
 template <typename T, int V>
 struct VecIO {
@@ -502,8 +503,8 @@ __global__ void norm_act_bwd2_part_kernel(const T* __restrict__ gz, const T* __r
     rs[j] = rstd[n * c + ch];
     ga[j] = pstride ? gamma[(int64_t)n * pstride + ch] : (n < split ? gamma : gamma2)[ch];
     be[j] = pstride ? beta[(int64_t)n * pstride + ch] : (n < split ? beta : beta2)[ch];
-    s1[j] = sh[ch] * inv;
-    s2[j] = sh[c + ch] * inv;
+    s1[j] = (flags & NF_NOSTATS) ? 0.f : sh[ch] * inv;
+    s2[j] = (flags & NF_NOSTATS) ? 0.f : sh[c + ch] * inv;
   }
   const int p0 = blockIdx.x * px_per_block;
   const int p1 = min(p0 + px_per_block, hw);

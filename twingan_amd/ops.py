@@ -14,7 +14,7 @@ import weakref
 import torch
 
 from . import _lib
-from ._lib import (NF_LRELU, NF_PIXNORM, TG_ALGO_DIRECT, TG_ALGO_MFMA, TG_BF16, TG_EPI_BIAS, TG_EPI_LRELU, TG_F32,
+from ._lib import (NF_LRELU, NF_NOSTATS, NF_PIXNORM, TG_ALGO_DIRECT, TG_ALGO_MFMA, TG_BF16, TG_EPI_BIAS, TG_EPI_LRELU, TG_F32,
                    TgConvDesc, call)
 
 LRELU_ALPHA = 0.2    # util_misc.py:68
@@ -934,6 +934,22 @@ class NormActPoolFn(torch.autograd.Function):
     if gz is None and gzp is None:
       return (None,) * 12
     return _norm_act_backward(ctx, gz, gzp) + (None,)
+
+
+_CONST = {}
+
+
+def pixel_norm(y, pn_eps=1e-6):
+  """x / sqrt(mean_C(x^2) + eps) alone (nets/pggan_utils.py:330-331; --generator_norm_type none): the fused
+  normalisation kernel with constant unit statistics and parameters; NF_NOSTATS makes its backward treat them so."""
+  n, c = y.shape[0], y.shape[3]
+  key = (n, c, y.device)
+  if key not in _CONST:
+    one = torch.ones(n * c, dtype=torch.float32, device=y.device)
+    _CONST[key] = (one, torch.zeros_like(one))
+  one, zero = _CONST[key]
+  return NormActFn.apply(y, one.view(n, c), zero.view(n, c), None, None, None, NF_PIXNORM | NF_NOSTATS, 0.0, pn_eps,
+                         LRELU_ALPHA, None, (zero, one))
 
 
 def norm_act(y, gamma, beta, lrelu=True, pixel_norm=True, in_eps=1e-6, pn_eps=1e-6, alpha=LRELU_ALPHA, gamma2=None,

@@ -253,11 +253,13 @@ def declare_twingan(store, cfg, model='twingan'):
   pggan_model = model == 'pggan'
   store.phase_of = (lambda name: 0) if pggan_model else (lambda name: grad_phase(name, cfg))
   ms = max_stage_of(hw)
-  NORM_SCOPE = {'instance_norm': 'InstanceNorm', 'batch_norm': 'BatchNorm', 'batch_renorm': 'BatchNorm'}
+  NORM_SCOPE = {'instance_norm': 'InstanceNorm', 'batch_norm': 'BatchNorm', 'batch_renorm': 'BatchNorm', 'none': ''}
   store.renorm = cfg.generator_norm_type == 'batch_renorm'
   if cfg.generator_norm_type not in NORM_SCOPE:
     raise NotImplementedError('generator_norm_type=%s' % cfg.generator_norm_type)
-  nd = ('',) if pggan_model else ('s', 't')
+  # generator_norm_type=none (nets/pggan_utils.py:198-200): no normaliser, so slim's conv2d adds a bias instead
+  g_bias = cfg.generator_norm_type == 'none'
+  nd = () if g_bias else (('',) if pggan_model else ('s', 't'))
   ns = NORM_SCOPE[cfg.generator_norm_type]
   rk = min(7, hw // 2) if cfg.use_larger_filter_at_rgb_layer else 1      # nets/pggan.py:172-175,194-197
   if cfg.equalized_learning_rate:
@@ -312,15 +314,15 @@ def declare_twingan(store, cfg, model='twingan'):
       c = nc
 
   if not pggan_model:
-    enc_skeleton('encoder_content', 'g', False, nd)
+    enc_skeleton('encoder_content', 'g', g_bias, nd)
   gen_kw = {}
   if cfg.use_style_embedding and not pggan_model:      # twingan.py:47-51,201-223: the style encoder (pggan.encoder) and conditional generator norms
     if cfg.generator_norm_type not in ('instance_norm', 'batch_norm'):
       raise NotImplementedError('use_style_embedding with generator_norm_type=%s' % cfg.generator_norm_type)
-    enc_skeleton('encoder_style', 'g', False, nd)
+    enc_skeleton('encoder_style', 'g', g_bias, nd)
     c0 = get_num_channels(0, mc)
-    store.add_conv('encoder_style/before_fc_1x1x%d/Conv' % mc, 3, c0, mc, 'g', False, nd, norm_scope=ns)
-    store.add_conv('encoder_style/before_fc_1x1x%d/Conv_1' % mc, 4, mc, mc, 'g', False, nd, norm_scope=ns)
+    store.add_conv('encoder_style/before_fc_1x1x%d/Conv' % mc, 3, c0, mc, 'g', g_bias, nd, norm_scope=ns)
+    store.add_conv('encoder_style/before_fc_1x1x%d/Conv_1' % mc, 4, mc, mc, 'g', g_bias, nd, norm_scope=ns)
     store.add('encoder_style/prediction/fully_connected/weights', (mc, cfg.style_embed_size), 'g', 'fc_w')
     store.add('encoder_style/prediction/fully_connected/biases', (cfg.style_embed_size,), 'g', 'bias')
     gen_kw = dict(cond_dim=cfg.style_embed_size)
@@ -328,26 +330,26 @@ def declare_twingan(store, cfg, model='twingan'):
   c = get_num_channels(0, mc)
   blk = 'generator/block_4x4x%d' % c
   if pggan_model:      # latent noise [B,1,1,get_num_channels(1)] padded to 7x7, 4x4 VALID (nets/pggan.py:135-153)
-    store.add_conv(blk + '/Conv', 4, get_num_channels(1, mc), c, 'g', False, nd, norm_scope=ns)
+    store.add_conv(blk + '/Conv', 4, get_num_channels(1, mc), c, 'g', g_bias, nd, norm_scope=ns)
   else:
-    store.add_conv(blk + '/Conv', 3, c, c, 'g', False, nd, norm_scope=ns, **gen_kw)
-  store.add_conv(blk + '/Conv_1', 3, c, c, 'g', False, nd, norm_scope=ns, **gen_kw)
-  attention('generator', 4, c, c, 'g', False, nd, **gen_kw)
+    store.add_conv(blk + '/Conv', 3, c, c, 'g', g_bias, nd, norm_scope=ns, **gen_kw)
+  store.add_conv(blk + '/Conv_1', 3, c, c, 'g', g_bias, nd, norm_scope=ns, **gen_kw)
+  attention('generator', 4, c, c, 'g', g_bias, nd, **gen_kw)
   for stage in range(1, ms + 1):
     cur = 2 ** (stage + 2)
     oc = get_num_channels(stage, mc)
     if stage == ms and cfg.is_growing:
-      store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (cur // 2, cur // 2), rk, c, 3, 'g', False, nd, norm_scope=ns, **gen_kw)
+      store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (cur // 2, cur // 2), rk, c, 3, 'g', g_bias, nd, norm_scope=ns, **gen_kw)
     skip = (cfg.use_unet and not pggan_model and
             not (cfg.unet_max_concat_hw and cur > cfg.unet_max_concat_hw))      # pggan_utils.py:287-289
     cin = c + (get_num_channels(stage - 1, mc) if skip else 0)
     blk = 'generator/block_%dx%dx%d' % (cur, cur, oc)
-    store.add_conv(blk + '/Conv', 3, cin, oc, 'g', False, nd, norm_scope=ns, **gen_kw)
-    store.add_conv(blk + '/Conv_1', 3, oc, oc, 'g', False, nd, norm_scope=ns, **gen_kw)
+    store.add_conv(blk + '/Conv', 3, cin, oc, 'g', g_bias, nd, norm_scope=ns, **gen_kw)
+    store.add_conv(blk + '/Conv_1', 3, oc, oc, 'g', g_bias, nd, norm_scope=ns, **gen_kw)
     shortcut(blk, cin, oc, 'g')
-    attention('generator', cur, oc, oc, 'g', False, nd, **gen_kw)
+    attention('generator', cur, oc, oc, 'g', g_bias, nd, **gen_kw)
     c = oc
-  store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (hw, hw), rk, c, 3, 'g', False, nd, norm_scope=ns, **gen_kw)
+  store.add_conv('generator/generator_to_rgb_%dx%d/Conv' % (hw, hw), rk, c, 3, 'g', g_bias, nd, norm_scope=ns, **gen_kw)
   # discriminators
   for top in (('discriminator',) if pggan_model else ('discriminator_s', 'discriminator_t')):
     md = cfg.max_ch_dis or mc      # get_discriminator_max_num_channels (nets/pggan_utils.py:375-380)

@@ -147,6 +147,18 @@ def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pix
   then pixel norm (nets/pggan.py:78-81).  ``domain`` is 's' | 't', or (d0, d1, split): the batch holds
   ``split`` images of domain d0 followed by images of domain d1 (two reference passes as one launch)."""
   w = _sn(P, scope, cfg, False)
+  if cfg.generator_norm_type == 'none':
+    if upcat is not None:
+      x = ops.upsample2x_concat(upcat[0], upcat[1], upcat[2], upcat[3])
+    xe = _equalize(x, cfg, k) if equalize else x
+    b = P[scope + '/biases']
+    if k == 1 and (w.shape[2] <= 4 or w.shape[3] <= 4):
+      y = ops.pointwise_conv(xe, w, b, lrelu=activation)
+    else:
+      y = ops.conv2d(xe, w, b, k, padding, lrelu=activation)
+    if pixel_norm and cfg.do_pixel_norm:
+      y = ops.pixel_norm(y)
+    return (y, ops.avg_pool2(y)) if pool else y
   if upcat is not None:      # x is None: the input is concat(up2(x0), skip), read from the two sources by the conv
     y = ops.upcat_conv(upcat[0], upcat[1], w, upcat[2], upcat[3])
   elif k == 1 and (w.shape[2] <= 4 or w.shape[3] <= 4):
@@ -154,8 +166,12 @@ def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pix
   else:
     y = ops.conv2d(_equalize(x, cfg, k) if equalize else x, w, None, k, padding)
   nt = cfg.generator_norm_type
+  if nt == 'none':
+    # no normaliser (nets/pggan_utils.py:198-200): slim's conv2d then owns a bias; conv + bias + LeakyReLU is the
+    # conv's epilogue, the pixel norm the fused kernel with constant statistics
+    raise AssertionError('unreachable: generator_norm_type none is handled before the conv')
   if nt not in ('instance_norm', 'batch_norm', 'batch_renorm'):
-    raise NotImplementedError('generator_norm_type=%s (instance_norm, batch_norm and batch_renorm are built)' % nt)
+    raise NotImplementedError('generator_norm_type=%s (instance_norm, batch_norm, batch_renorm and none are built)' % nt)
   ns = 'InstanceNorm' if nt == 'instance_norm' else 'BatchNorm'
   if isinstance(domain, tuple):
     d0, d1, split = domain[:3]
