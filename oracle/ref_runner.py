@@ -23,9 +23,11 @@ BASE_FLAGS = dict(generator_network='pggan', is_growing=False, loss_architecture
                   use_gdrop=False, use_conditional_labels=False, do_encoder_distillation=False)
 
 
-def run(flags, sources, targets, global_step=0, seed=0, preset=None, want_grads=True, eager_updates=False):
+def run(flags, sources, targets, global_step=0, seed=0, preset=None, want_grads=True, eager_updates=False, feed=None):
   """flags: reference flag name -> value.  sources / targets: float arrays [B, H, W, 3].  preset: variable values
-  (reference name -> array) to use instead of the reference's initialisers."""
+  (reference name -> array) to use instead of the reference's initialisers.  feed: placeholder name -> array for the
+  inference branch (twingan.py:300-363: 'sources_ph', 'targets_ph', 'style_embed_ph'); its outputs come back under
+  'custom' (custom_generated_{s,t}_style_{rand,source,target,ph}: is_training=False passes)."""
   tf = loader.install()
   import twingan as ref      # the reference module, loaded by oracle.tf_shim.loader
   F = tf.flags.FLAGS
@@ -41,6 +43,7 @@ def run(flags, sources, targets, global_step=0, seed=0, preset=None, want_grads=
   core.STATE.preset = dict(preset or {})
   core.STATE.eager_updates = bool(eager_updates)
   core.STATE.placeholder_batch = int(np.asarray(sources).shape[0])
+  core.STATE.placeholder_feed = dict(feed or {})
   tfapi._ARG_STACK[:] = [{}]
   gs = tfapi.get_or_create_global_step()
   gs.t.fill_(int(global_step))
@@ -80,6 +83,8 @@ def run(flags, sources, targets, global_step=0, seed=0, preset=None, want_grads=
   )
   res['g_loss'] = float(sum(v.t for v in g_terms.values()))
   res['d_loss'] = float(sum(v.t for v in d_terms.values()))
+  res['custom'] = {k: v.t.detach().numpy().copy() for k, v in end_points.items()
+                   if isinstance(v, core.Tensor) and k.startswith('custom_generated')}
   if want_grads:
     names = res['trainable']
     leaves = [core.STATE.variables[k].t for k in names]

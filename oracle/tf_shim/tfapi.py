@@ -335,6 +335,8 @@ def gradients(ys, xs, grad_ys=None, name=None, **unused):
 def placeholder(dtype, shape=None, name=None):
   """Zeros; an unknown (None) dimension takes STATE.placeholder_batch, so that the inference branch of the graph
   (twingan.py:290-363) is built with the same batch as the training tensors it is mixed with."""
+  if name in STATE.placeholder_feed:      # a "feed_dict" for the inference branch
+    return Tensor(torch.tensor(np.asarray(STATE.placeholder_feed[name], np.float64)), dtype, name)
   dims = [STATE.placeholder_batch if (d.value if isinstance(d, Dimension) else d) is None else int(d)
           for d in (shape.dims if isinstance(shape, TensorShape) else shape)]
   return Tensor(torch.zeros(dims, dtype=F64), dtype, name)

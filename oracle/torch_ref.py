@@ -45,6 +45,7 @@ class Config:
   pn_eps: float = 1e-6               # nets/pggan_utils.py:330
   lrelu: float = 0.2                 # util_misc.py:68
   bn_state: object = None            # dict collecting the BatchNorm moving (and renorm) statistics when set
+  is_training: bool = True           # False: the inference branch (twingan.py:300-363): BatchNorm uses the moving statistics
   global_step: int = 0               # batch renorm clipping schedule (nets/pggan_utils.py:207-223)
   spectral_norm: bool = False        # nets/pggan.py:28-30 (discriminator convs; libs/sn.py:38-101)
   sn_non_disc: bool = False          # spectral_norm_in_non_discriminator (nets/pggan.py:31-33): encoder / generator convs too
@@ -294,6 +295,16 @@ def batch_norm_train(x, gamma, beta, eps=BN_EPS):
   return x * inv + (beta - mean * inv), mean.reshape(-1), var.reshape(-1)
 
 
+def batch_norm_inference(x, gamma, beta, state, key, postfix, eps=BN_EPS):
+  """conditional_batch_norm(is_training=False) (libs/batch_norm.py:403-470): tf.nn.batch_normalization with the moving
+  mean / variance (initial values 0 / 1 when the state does not hold them yet)."""
+  c = x.shape[-1]
+  mean = state.get(key + 'moving_mean' + postfix, torch.zeros(c, dtype=x.dtype))
+  var = state.get(key + 'moving_variance' + postfix, torch.ones(c, dtype=x.dtype))
+  inv = torch.rsqrt(var + eps) * gamma
+  return x * inv + (beta - mean * inv)
+
+
 RENORM_MOMENTUM = 0.99                                     # libs/batch_norm.py:62; pggan_utils.py:163 sets decay the same
 RENORM_BOUNDARIES = (10000, 20000, 30000)                  # nets/pggan_utils.py:43-47
 RENORM_RMAX, RENORM_RMIN, RENORM_DMAX = (1.1, 1.5, 2.0, 4.0), (0.9, 0.66, 0.5, 0.25), (0.1, 0.3, 0.5, 1.0)
@@ -489,12 +500,19 @@ def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=Tru
       beta = (cn @ P[pre + 'beta%s/weights' % _pf(domain)] + P[pre + 'beta%s/biases' % _pf(domain)])[:, None, None, :]
     else:
       gamma, beta = P[scope + '/BatchNorm/gamma' + _pf(domain)], P[scope + '/BatchNorm/beta' + _pf(domain)]
-    y, bm, bv = batch_norm_train(y, gamma, beta)
-    if cfg.bn_state is not None:       # moving statistics per domain postfix (libs/batch_norm.py:184-196)
+    if not cfg.is_training:
+      y = batch_norm_inference(y, gamma, beta, cfg.bn_state or {}, scope + '/BatchNorm/', _pf(domain))
+      bm = bv = None
+    else:
+      y, bm, bv = batch_norm_train(y, gamma, beta)
+    if cfg.is_training and cfg.bn_state is not None:       # moving statistics per domain postfix (libs/batch_norm.py:184-196)
       for nm, val, init in (('moving_mean_', bm, 0.0), ('moving_variance_', bv, 1.0)):
         key = scope + '/BatchNorm/' + nm.rstrip('_') + _pf(domain)
         cur = cfg.bn_state.get(key, torch.full_like(val, init))
         cfg.bn_state[key] = moving_average_update(cur, val.detach())
+  elif cfg.norm == 'batch_renorm' and not cfg.is_training:      # inference: the moving statistics, no r / d correction
+    y = batch_norm_inference(y, P[scope + '/BatchNorm/gamma' + _pf(domain)], P[scope + '/BatchNorm/beta' + _pf(domain)],
+                             cfg.bn_state or {}, scope + '/BatchNorm/', _pf(domain))
   elif cfg.norm == 'batch_renorm':     # the configuration of docs/training.md:17
     y = batch_renorm_train(y, P[scope + '/BatchNorm/gamma' + _pf(domain)], P[scope + '/BatchNorm/beta' + _pf(domain)],
                            cfg.bn_state, scope + '/BatchNorm/', _pf(domain), renorm_clipping(cfg.global_step))
@@ -762,6 +780,18 @@ def forward_generators(P, sources, targets, cfg):
 
 
 LOSSES = ('wgan_gp', 'wgan', 'hinge', 'gan', 'dragan')
+
+
+def translate(P, images, cfg, to='t', style=None):
+  """The inference branch of twingan.GanModel._clone_fn (twingan.py:300-363): `custom_generated_<to>_style_*` =
+  G_<to>(E_<from>(images)) with is_training=False, UNet skips from the same encoder pass.  ``style``: the [B, E]
+  conditional embedding (None without --use_style_embedding)."""
+  import dataclasses
+  ci = dataclasses.replace(cfg, is_training=False)
+  frm = 's' if to == 't' else 't'
+  net, ep = encoder(P, images, frm, ci)
+  out, _ = generator(P, net, to, ci, ep if ci.use_unet else None, cond=style)
+  return out
 
 
 def _fool_loss(pred, cfg):

@@ -450,3 +450,52 @@ def test_gpu_pggan_trainer_hits_golden(name):
     tb = t.to(torch.bfloat16)
     losses = [tr2.run(None, tb)[0].item() for _ in range(4)]
     assert all(np.isfinite(losses)), losses
+
+
+# ------------------------------------------------------------------------------------------------
+# the inference branch (twingan.py:300-363; inference/image_translation_infer.py): is_training=False
+# ------------------------------------------------------------------------------------------------
+INFER_NORMS = ('instance_norm', 'batch_norm', 'batch_renorm')
+
+
+def _infer_state(g):
+  P = {k[len('param/'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('param/') and '/moving_' not in k}
+  state = {k[len('param/'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('param/') and '/moving_' in k}
+  return P, state
+
+
+@pytest.mark.parametrize('norm', INFER_NORMS)
+def test_oracle_inference_branch_matches_the_reference(norm):
+  """`sources_ph -> custom_generated_t_style_source` and `targets_ph -> custom_generated_s_style_target` as the
+  reference's graph computed them with fed placeholders and preset moving statistics (tools/make_golden.py --infer)."""
+  g = load('infer_hw16_c8_' + norm)
+  P, state = _infer_state(g)
+  cfg = R.Config(hw=16, max_ch=8, norm=norm, bn_state=state)
+  with torch.no_grad():
+    assert np.abs(R.translate(P, torch.from_numpy(g['in/sources_ph']), cfg, 't').numpy() -
+                  g['out/custom_generated_t_style_source']).max() < 1e-9
+    assert np.abs(R.translate(P, torch.from_numpy(g['in/targets_ph']), cfg, 's').numpy() -
+                  g['out/custom_generated_s_style_target']).max() < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('norm', INFER_NORMS)
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_gpu_inference_branch_hits_golden(norm, precision):
+  """twingan.translate / inference.ImageInferer on the HIP kernels (BatchNorm through the fused kernel's per-image-row
+  mode on the MOVING statistics) against the reference's inference outputs; uint8 input through the TF-1.8 resize."""
+  from twingan_amd import Config
+  from twingan_amd.inference import ImageInferer
+  g = load('infer_hw16_c8_' + norm)
+  sd = {k[len('param/'):]: torch.from_numpy(v).float() for k, v in g.items() if k.startswith('param/')}
+  cfg = Config(hw=16, max_ch=8, precision=precision, generator_norm_type=norm)
+  tol = 2e-5 if precision == 'fp32' else 0.25      # bf16 at 8 channels: see test_gpu_model_hits_golden
+  for name, key in (('custom_generated_t_style_source', 'in/sources_ph'), ('custom_generated_s_style_target', 'in/targets_ph')):
+    inf = ImageInferer(cfg, sd, device='cuda:0', output_tensor_name=name)
+    out = inf.infer(g[key].astype(np.float32))
+    assert out.shape == g['out/' + name].shape
+    assert rel_l2(out / 255.0, g['out/' + name]) < tol, (name, rel_l2(out / 255.0, g['out/' + name]))
+  # uint8 images of another size: convert_image_dtype + resize_images in front of the same graph
+  u8 = (np.random.RandomState(0).rand(1, 24, 20, 3) * 255).astype(np.uint8)
+  out = inf.infer(u8[0])
+  assert out.shape == (1, 16, 16, 3) and np.isfinite(out).all()

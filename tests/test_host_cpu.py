@@ -381,3 +381,28 @@ def test_segmented_backward_equals_plain_backward():
     assert torch.allclose(p.grad, g, rtol=1e-12, atol=1e-14)
   y = torch.ones(2, requires_grad=True)
   assert Cuts.cut(y, 1) is y                    # inactive: the identity
+
+
+def test_tf1_bilinear_resize_restated():
+  """inference.resize_bilinear_tf1 = tf.image.resize_images(BILINEAR, align_corners=False) of TF 1.8
+  (inference/image_translation_infer.py:58): source coordinate = index * in / out, neighbours clamped."""
+  import numpy as np
+  from twingan_amd.inference import resize_bilinear_tf1
+
+  def ref(img, hw):
+    b, h, w, c = img.shape
+    out = np.zeros((b, hw, hw, c))
+    for y in range(hw):
+      sy = y * h / hw
+      y0 = int(np.floor(sy)); y1 = min(y0 + 1, h - 1); fy = sy - y0
+      for x in range(hw):
+        sx = x * w / hw
+        x0 = int(np.floor(sx)); x1 = min(x0 + 1, w - 1); fx = sx - x0
+        top = img[:, y0, x0] * (1 - fx) + img[:, y0, x1] * fx
+        bot = img[:, y1, x0] * (1 - fx) + img[:, y1, x1] * fx
+        out[:, y, x] = top * (1 - fy) + bot * fy
+    return out
+  rng = np.random.RandomState(0)
+  for h, w, hw in ((5, 7, 8), (16, 12, 8), (8, 8, 8), (3, 3, 16)):
+    a = rng.rand(2, h, w, 3).astype(np.float32)
+    assert np.abs(resize_bilinear_tf1(torch.from_numpy(a), hw).numpy() - ref(a, hw)).max() < 1e-6

@@ -138,3 +138,27 @@ def test_pggan_oracle_matches_live_reference(name):
   for k, v in grads.items():
     want = ref['d_grads' if k.startswith('discriminator') else 'g_grads'][k]
     assert np.abs(v.detach().numpy() - want).max() < 1e-9 * scale, k
+
+
+@pytest.mark.parametrize('norm', ['instance_norm', 'batch_norm', 'batch_renorm'])
+def test_inference_branch_matches_live_reference(norm):
+  """twingan.py:300-363 with fed placeholders: is_training=False passes on preset moving statistics -- both translation
+  directions of the oracle's translate() against custom_generated_t_style_source / custom_generated_s_style_target."""
+  from oracle import ref_runner
+  cfg = R.Config(hw=16, max_ch=8, norm=norm)
+  P = R.init_params(cfg, seed=31, dtype=torch.float64, std='he')
+  rng = np.random.RandomState(32)
+  state = {}
+  if norm != 'instance_norm':
+    for k in list(P):
+      if k.endswith(('/gamma_s', '/gamma_t')):
+        base, d, c = k.rsplit('/', 1)[0], k[-2:], P[k].shape[0]
+        state[base + '/moving_mean' + d] = torch.from_numpy(rng.randn(c) * 0.3)
+        state[base + '/moving_variance' + d] = torch.from_numpy(0.5 + rng.rand(c))
+  preset = {k: v.numpy() for k, v in list(P.items()) + list(state.items())}
+  s, t, sp, tp = (rng.rand(2, 16, 16, 3) for _ in range(4))
+  ref = ref_runner.run(ref_runner.flags_of(cfg), s, t, want_grads=False, preset=preset, feed={'sources_ph': sp, 'targets_ph': tp})
+  cfg.bn_state = state
+  with torch.no_grad():
+    assert np.abs(R.translate(P, torch.from_numpy(sp), cfg, 't').numpy() - ref['custom']['custom_generated_t_style_source']).max() < 1e-9
+    assert np.abs(R.translate(P, torch.from_numpy(tp), cfg, 's').numpy() - ref['custom']['custom_generated_s_style_target']).max() < 1e-9

@@ -354,6 +354,36 @@ def pggan_model(batch, seed=0, **kw):
   return d
 
 
+def infer_model(norm, hw=16, max_ch=8, batch=2, seed=5):
+  """The inference branch (twingan.py:300-363: is_training=False, `sources_ph` / `targets_ph` ->
+  custom_generated_t_style_source / custom_generated_s_style_target) computed by the reference's own code with fed
+  placeholders and NON-trivial BatchNorm moving statistics preset into its variables."""
+  from oracle import ref_runner
+  cfg = R.Config(hw=hw, max_ch=max_ch, norm=norm)
+  P = {k: v.float().double() for k, v in R.init_params(cfg, seed=seed, dtype=torch.float64, std='he').items()}
+  rng = np.random.RandomState(seed)
+  state = {}
+  if norm != 'instance_norm':
+    for k in list(P):
+      if k.endswith(('/gamma_s', '/gamma_t')):
+        base, d, c = k.rsplit('/', 1)[0], k[-2:], P[k].shape[0]
+        state[base + '/moving_mean' + d] = torch.from_numpy(np.float32(rng.randn(c) * 0.3)).double()
+        state[base + '/moving_variance' + d] = torch.from_numpy(np.float32(0.5 + rng.rand(c))).double()
+  preset = {k: v.numpy() for k, v in list(P.items()) + list(state.items())}
+  s, t = rng.rand(batch, hw, hw, 3), rng.rand(batch, hw, hw, 3)
+  sp, tp = np.float32(rng.rand(batch, hw, hw, 3)).astype(np.float64), np.float32(rng.rand(batch, hw, hw, 3)).astype(np.float64)
+  ref = ref_runner.run(ref_runner.flags_of(cfg), s, t, want_grads=False, preset=preset, feed={'sources_ph': sp, 'targets_ph': tp})
+  d = {'in/sources_ph': sp, 'in/targets_ph': tp}
+  for k, v in preset.items():
+    d['param/' + k] = v
+  for k in ('custom_generated_t_style_source', 'custom_generated_s_style_target'):
+    d['out/' + k] = ref['custom'][k]
+  cfg.bn_state = state
+  assert np.abs(R.translate(P, torch.from_numpy(sp), cfg, 't').numpy() - d['out/custom_generated_t_style_source']).max() < 1e-9
+  assert np.abs(R.translate(P, torch.from_numpy(tp), cfg, 's').numpy() - d['out/custom_generated_s_style_target']).max() < 1e-9
+  return d
+
+
 def main():
   os.makedirs(OUT, exist_ok=True)
   np.savez_compressed(os.path.join(OUT, 'primitives.npz'), **primitives())
@@ -365,6 +395,8 @@ def main():
   np.savez_compressed(os.path.join(OUT, 'train4_hw16_c8.npz'), **training())
   for name, (batch, kw) in PGGAN_CASES.items():
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **pggan_model(batch, **kw))
+  for norm in ('instance_norm', 'batch_norm', 'batch_renorm'):
+    np.savez_compressed(os.path.join(OUT, 'infer_hw16_c8_%s.npz' % norm), **infer_model(norm))
   # the variables the reference creates at full width, with what its initialisers drew (names, shapes, statistics)
   import json
   from oracle import ref_runner
@@ -394,7 +426,11 @@ def main():
 
 
 if __name__ == '__main__':
-  if '--pggan' in sys.argv:      # only the plain-PGGAN fixtures
+  if '--infer' in sys.argv:      # only the inference-branch fixtures
+    for norm in ('instance_norm', 'batch_norm', 'batch_renorm'):
+      np.savez_compressed(os.path.join(OUT, 'infer_hw16_c8_%s.npz' % norm), **infer_model(norm))
+      print('infer', norm)
+  elif '--pggan' in sys.argv:      # only the plain-PGGAN fixtures
     for name, (batch, kw) in PGGAN_CASES.items():
       np.savez_compressed(os.path.join(OUT, name + '.npz'), **pggan_model(batch, **kw))
       print(name, os.path.getsize(os.path.join(OUT, name + '.npz')))

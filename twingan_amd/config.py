@@ -22,6 +22,7 @@ class Config:
   self_attention_hw: int = 64         # image_generation.py:65-67
   use_style_embedding: bool = False   # twingan.py:47-49: generator norm parameters conditioned on a style embedding
   style_embed_size: int = 16          # twingan.py:50-51
+  is_training: bool = True            # False: the inference branch (twingan.py:300-363) -- BatchNorm reads the moving statistics
   is_growing: bool = False            # image_generation.py:69-72
   alpha_grow: float = 0.0             # twingan.py:833-835
   loss_architecture: str = 'wgan_gp'  # image_generation.py:81-83

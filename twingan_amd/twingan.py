@@ -140,6 +140,27 @@ def forward_generators(P, sources, targets, cfg, style_noise=None):
   return dict(es=es, et=et, s_prime=s_prime, s_cycle=s_cycle, t_prime=t_prime, t_cycle=t_cycle, random_style_embed=rand)
 
 
+def translate(P, images, cfg, to='t', style=None):
+  """The inference branch of GanModel._clone_fn (twingan.py:300-363), i.e. what inference/image_translation_infer.py
+  fetches: `custom_generated_<to>_style_<...>` = G_<to>(E_<from>(images)) with is_training=False (BatchNorm on its
+  moving statistics), the UNet skips from the same encoder pass.  ``style``: [B, E] conditional embedding
+  (--use_style_embedding: the encoded style of the input, a random one, or a supplied one), else None.
+  The serving signature's default (twingan.py:777-805) is sources -> custom_generated_t_style_source."""
+  ci = dataclasses.replace(cfg, is_training=False)
+  frm = 's' if to == 't' else 't'
+  with torch.no_grad():
+    net, ep = pggan.encoder_before_classification(P, images, frm, ci)
+    out, _ = pggan.generator(P, net, to, ci, ep if ci.use_unet else None, cond=style)
+  return out
+
+
+def encode_style(P, images, cfg, domain):
+  """encoder_style_network_fn(images_ph, is_training=False) -> [B, style_embed_size] (twingan.py:330-337)."""
+  ci = dataclasses.replace(cfg, is_training=False)
+  with torch.no_grad():
+    return pggan.encoder(P, images, domain, ci, 'encoder_style')[0]
+
+
 def generator_loss(P, sources, targets, cfg, style_noise=None):
   """GENERATOR_LOSSES (twingan.py:464-505; image_generation.py:331-337).  Returns (total [1], terms)."""
   assert cfg.loss_architecture in LOSSES, cfg.loss_architecture
