@@ -514,8 +514,15 @@ def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=Tru
     y = batch_norm_inference(y, P[scope + '/BatchNorm/gamma' + _pf(domain)], P[scope + '/BatchNorm/beta' + _pf(domain)],
                              cfg.bn_state or {}, scope + '/BatchNorm/', _pf(domain))
   elif cfg.norm == 'batch_renorm':     # the configuration of docs/training.md:17
-    y = batch_renorm_train(y, P[scope + '/BatchNorm/gamma' + _pf(domain)], P[scope + '/BatchNorm/beta' + _pf(domain)],
-                           cfg.bn_state, scope + '/BatchNorm/', _pf(domain), renorm_clipping(cfg.global_step))
+    if cond is not None:      # conditional parameters as for batch norm: l2-normalised embedding, one row per image
+      cn = cond / cond.pow(2).sum(dim=1, keepdim=True).clamp_min(1e-12).sqrt()
+      pre = scope + '/BatchNorm/'
+      gamma = (1.0 + cn @ P[pre + 'gamma%s/weights' % _pf(domain)] + P[pre + 'gamma%s/biases' % _pf(domain)])[:, None, None, :]
+      beta = (cn @ P[pre + 'beta%s/weights' % _pf(domain)] + P[pre + 'beta%s/biases' % _pf(domain)])[:, None, None, :]
+    else:
+      gamma, beta = P[scope + '/BatchNorm/gamma' + _pf(domain)], P[scope + '/BatchNorm/beta' + _pf(domain)]
+    y = batch_renorm_train(y, gamma, beta, cfg.bn_state, scope + '/BatchNorm/', _pf(domain),
+                           renorm_clipping(cfg.global_step))
   elif cfg.norm in ('none', None):      # nets/pggan_utils.py:198-200: normalizer_fn None -> slim's conv2d adds its bias
     y = y + P[scope + '/biases']
   else:

@@ -699,6 +699,42 @@ def test_batch_renorm_generator_matches_oracle(global_step):
     assert np.abs(a - v.numpy()).max() < 2e-5 * max(1.0, np.abs(v.numpy()).max()), k
 
 
+@pytest.mark.parametrize('norm', ['batch_norm', 'batch_renorm'])
+def test_style_embedding_on_batch_norms_matches_oracle(norm):
+  """--use_style_embedding on the batch-norm family (libs/batch_norm.py:82-85,152-159,209-259,403-470): pass statistics
+  from the HIP normaliser, then the per-image rows gamma = 1 + FC(l2n(e)), beta = FC(l2n(e)) -- composed with the
+  renorm r / d of the pass for batch_renorm -- LeakyReLU and pixel norm in the fused kernel's per-image-row mode with
+  constant statistics (ops.affine_act).  Oracle pinned live: test_reference_live style_batch_norm / style_batch_renorm."""
+  from twingan_amd import Config
+  from twingan_amd import twingan as T
+  from twingan_amd.twingan import Trainer
+  cfg = Config(hw=16, max_ch=16, precision='fp32', generator_norm_type=norm, use_style_embedding=True, style_embed_size=6)
+  state = {}
+  rcfg = R.Config(hw=16, max_ch=16, norm=norm, bn_state=state, use_style_embedding=True, style_embed_size=6)
+  Pref = R.init_params(rcfg, seed=18, dtype=torch.float64, std='he')
+  tr = Trainer(cfg, device='cuda:0', seed=18)
+  if norm == 'batch_renorm':
+    tr._set_renorm_clipping()
+  assert set(tr.store.state_dict()) == set(Pref)
+  tr.store.load_state_dict({k: v.float() for k, v in Pref.items()})
+  Pref = {k: v.float().double().requires_grad_(True) for k, v in Pref.items()}
+  g = torch.Generator().manual_seed(88)
+  s, t = torch.rand(3, 16, 16, 3, generator=g), torch.rand(3, 16, 16, 3, generator=g)
+  noise = torch.randn(3, 6, generator=g)
+  rcfg.style_noise = noise.double()
+  dev = lambda x: x.to('cuda:0').contiguous()
+  tr.store.zero_grad('g')
+  tr._set_requires_grad(g=True, d=False)
+  gl, gterms = T.generator_loss(tr.P, dev(s), dev(t), cfg, dev(noise))
+  rgl, rgterms = R.generator_loss(Pref, s.double(), t.double(), rcfg)
+  assert set(gterms) == set(rgterms)
+  for k in rgterms:
+    assert abs(gterms[k].item() - rgterms[k].item()) < 2e-4 * max(1.0, abs(rgterms[k].item())), k
+  gl.backward()
+  rgl.backward()
+  _grads_close(tr, Pref, tr.store.names('g'), FP32_GRAD_TOL, 'generator(style on %s)' % norm, var_tol=FP32_VAR_GRAD_TOL)
+
+
 @pytest.mark.parametrize('loss', ['hinge', 'wgan_gp'])
 def test_spectral_norm_and_self_attention(loss):
   """SURVEY config 4: --spectral_norm on the discriminator convs (libs/sn.py:38-101, gradient through sigma, u assigned

@@ -33,6 +33,7 @@ CASES = {
   'style_embed_6': dict(hw=16, max_ch=16, use_style_embedding=True, style_embed_size=6),
   # conditional BATCH norm is the style configuration the reference can actually build for a batch > 1
   'style_batch_norm': dict(hw=16, max_ch=8, use_style_embedding=True, style_embed_size=4, norm='batch_norm'),
+  'style_batch_renorm': dict(hw=16, max_ch=8, use_style_embedding=True, style_embed_size=4, norm='batch_renorm'),
 }
 
 

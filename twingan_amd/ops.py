@@ -952,6 +952,22 @@ def pixel_norm(y, pn_eps=1e-6):
                          LRELU_ALPHA, None, (zero, one))
 
 
+def affine_act(y_hat, gamma_rows, beta_rows, lrelu=True, pixel_norm=True, pool=False, pn_eps=1e-6, alpha=LRELU_ALPHA):
+  """pixel_norm(lrelu(y_hat * gamma_rows[n] + beta_rows[n])) with one parameter row per image ([n, c], ordinary
+  differentiable tensors): the tail of the CONDITIONAL batch (re)norm layers, whose statistics belong to the whole pass
+  and are applied before (libs/batch_norm.py:403-470) -- the fused kernel with constant unit statistics (NF_NOSTATS)."""
+  n, c = y_hat.shape[0], y_hat.shape[3]
+  key = (n, c, y_hat.device)
+  if key not in _CONST:
+    one = torch.ones(n * c, dtype=torch.float32, device=y_hat.device)
+    _CONST[key] = (one, torch.zeros_like(one))
+  one, zero = _CONST[key]
+  flags = (NF_LRELU if lrelu else 0) | (NF_PIXNORM if pixel_norm else 0) | NF_NOSTATS
+  fn = NormActPoolFn if pool else NormActFn
+  return fn.apply(y_hat, gamma_rows.contiguous(), beta_rows.contiguous(), None, None, None, flags, 0.0, pn_eps, alpha, None,
+                  (zero, one))
+
+
 def norm_act(y, gamma, beta, lrelu=True, pixel_norm=True, in_eps=1e-6, pn_eps=1e-6, alpha=LRELU_ALPHA, gamma2=None,
              beta2=None, split=None, pool=False, ema=None, stats=None):
   """Statistics are per leading index of ``y`` (instance norm: one image; batch norm: the caller passes the view

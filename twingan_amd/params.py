@@ -317,7 +317,7 @@ def declare_twingan(store, cfg, model='twingan'):
     enc_skeleton('encoder_content', 'g', g_bias, nd)
   gen_kw = {}
   if cfg.use_style_embedding and not pggan_model:      # twingan.py:47-51,201-223: the style encoder (pggan.encoder) and conditional generator norms
-    if cfg.generator_norm_type not in ('instance_norm', 'batch_norm'):
+    if cfg.generator_norm_type not in ('instance_norm', 'batch_norm', 'batch_renorm'):
       raise NotImplementedError('use_style_embedding with generator_norm_type=%s' % cfg.generator_norm_type)
     enc_skeleton('encoder_style', 'g', g_bias, nd)
     c0 = get_num_channels(0, mc)

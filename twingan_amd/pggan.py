@@ -187,8 +187,14 @@ def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pix
     if nt == 'instance_norm':
       g_rows, b_rows = _cond_rows(P, scope, ns, cond, segs)
       return ops.norm_act(y, g_rows, b_rows, lrelu=activation, pixel_norm=pn, pool=pool, stats=ops.instance_stats(y, 1e-6))
-    if nt != 'batch_norm':
-      raise NotImplementedError('style embedding with generator_norm_type=%s' % nt)
+    if nt == 'batch_renorm':      # libs/batch_norm.py:209-259 with a conditional layer: r / d per pass, gamma / beta per image
+      cn = cond.float()
+      cn = cn / cn.pow(2).sum(dim=1, keepdim=True).clamp_min(1e-12).sqrt()
+      rows = _cond_rows(P, scope, ns, cn, segs)
+      n, h, w, c = y.shape
+      return _batch_renorm(P, scope, y.view(passes, (n // passes) * h, w, c),
+                           (d0, d1, None if split is None else split * passes // n, passes), activation, pn, pool,
+                           cond_rows=rows, image_shape=(n, h, w, c))
     return _cond_batch_norm(P, scope, y, cond, segs, passes, activation, pn, pool, cfg)
   g0, b0 = P['%s/%s/gamma%s' % (scope, ns, _pf(d0))], P['%s/%s/beta%s' % (scope, ns, _pf(d0))]
   g1 = P['%s/%s/gamma%s' % (scope, ns, _pf(d1))] if d1 else None
@@ -225,7 +231,8 @@ def _cond_batch_norm(P, scope, y, cond, segs, passes, activation, pn, pool, cfg)
   l2-normalised per image, gamma = 1 + FC, beta = FC give one row per image, applied to activations normalised with
   the statistics of the whole reference pass.  An option row, not on the headline path: the batch statistics and
   their backward are the HIP normaliser (per-pass view, unit gamma, zero beta, no activation); the per-image affine,
-  LeakyReLU and pixel norm that follow are a framework composite, like the attention products."""
+  LeakyReLU and pixel norm that follow are the same fused kernel in its per-image-row mode with constant statistics
+  (ops.affine_act)."""
   import torch
   n, h, w, c = y.shape
   cn = cond.float()
@@ -243,42 +250,15 @@ def _cond_batch_norm(P, scope, y, cond, segs, passes, activation, pn, pool, cfg)
   yhat = ops.norm_act(y.view(passes, (n // passes) * h, w, c), one, zero, lrelu=False, pixel_norm=False, in_eps=BN_EPS,
                       gamma2=one if split_v is not None else None, beta2=zero if split_v is not None else None,
                       split=split_v, ema=ema).view(n, h, w, c)
-  z = yhat.float() * g_rows.view(n, 1, 1, c) + b_rows.view(n, 1, 1, c)
-  if activation:
-    z = torch.maximum(z * ops.LRELU_ALPHA, z)
-  if pn:
-    z = z * torch.rsqrt(z.pow(2).mean(dim=3, keepdim=True) + 1e-6)
-  z = z.to(y.dtype).contiguous()
-  return (z, ops.avg_pool2(z)) if pool else z
-
-
-def _batch_norm_inference(P, scope, y, d0, d1, split, cond, activation, pn, pool):
-  """conditional_batch_norm(is_training=False), with or without renorm (libs/batch_norm.py:403-470): normalise with the
-  domain's MOVING mean / variance -- one (mean, rstd, gamma, beta) row per image through the fused kernel's
-  per-image-row mode.  ``cond``: the l2-normalised embedding gives gamma = 1 + FC, beta = FC per image."""
-  import torch
-  n, h, w, c = y.shape
-  segs = [(d0, 0, n)] if d1 is None else [(d0, 0, split), (d1, split, n)]
-  st = P.state
-  pre = scope + '/BatchNorm/'
-  mean = torch.cat([st[pre + 'moving_mean' + _pf(d)].expand(hi - lo, c) for d, lo, hi in segs])
-  rstd = torch.cat([torch.rsqrt(st[pre + 'moving_variance' + _pf(d)] + BN_EPS).expand(hi - lo, c) for d, lo, hi in segs])
-  if cond is not None:
-    cn = cond.float()
-    cn = cn / cn.pow(2).sum(dim=1, keepdim=True).clamp_min(1e-12).sqrt()
-    g_rows, b_rows = _cond_rows(P, scope, 'BatchNorm', cn, segs)
-  else:
-    g_rows = torch.cat([P[pre + 'gamma' + _pf(d)].expand(hi - lo, c) for d, lo, hi in segs])
-    b_rows = torch.cat([P[pre + 'beta' + _pf(d)].expand(hi - lo, c) for d, lo, hi in segs])
-  return ops.norm_act(y, g_rows.contiguous(), b_rows.contiguous(), lrelu=activation, pixel_norm=pn, in_eps=BN_EPS, pool=pool,
-                      stats=(mean.contiguous().reshape(-1), rstd.contiguous().reshape(-1)))
+  # the per-image affine, LeakyReLU, pixel norm (and pool) after it: the fused kernel with constant statistics
+  return ops.affine_act(yhat, g_rows, b_rows, lrelu=activation, pixel_norm=pn, pool=pool)
 
 
 BN_EPS = 1e-3            # libs/batch_norm.py:48
 RENORM_MOMENTUM = 0.99   # libs/batch_norm.py:62; the moving averages use the same decay (nets/pggan_utils.py:163)
 
 
-def _batch_renorm(P, scope, yv, domain, activation, pn, pool):
+def _batch_renorm(P, scope, yv, domain, activation, pn, pool, cond_rows=None, image_shape=None):
   """conditional_batch_norm(renorm=True) in training mode (libs/batch_norm.py:209-246,329-470), for yv =
   [passes, B*H, W, C] where pass i belongs to domain d0 (i < split) or d1.  Per pass, in call order:
     stddev = sqrt(var + eps);  r = clip(stddev / mixed_stddev),  d = clip((mean - mixed_mean) / mixed_stddev)
@@ -287,7 +267,9 @@ def _batch_renorm(P, scope, yv, domain, activation, pn, pool):
     mean / variance (of the unbiased renorm values) are updated with momentum 0.99.
   The reference applies the passes' update ops in unspecified order within one session.run; here (and in the
   oracle) passes update the state sequentially.  The per-channel state arithmetic is a handful of tiny tensor ops;
-  the normalisation itself is the fused kernel with one parameter row per pass."""
+  the normalisation itself is the fused kernel with one parameter row per pass.  ``cond_rows`` = (gamma [n, c], beta
+  [n, c]) of a conditional layer: the passes are normalised with unit rows and the per-image rows r * gamma,
+  d * gamma + beta are applied by ops.affine_act (image_shape = the [n, h, w, c] shape behind the per-pass view)."""
   import torch
   d0, d1, split, passes = domain
   st = P.state
@@ -300,7 +282,11 @@ def _batch_renorm(P, scope, yv, domain, activation, pn, pool):
   for i in range(passes):
     d = d0 if (split is None or i < split) else d1
     pre = '%s/BatchNorm/' % scope
-    gamma, beta = P[pre + 'gamma' + _pf(d)], P[pre + 'beta' + _pf(d)]
+    if cond_rows is None:
+      gamma, beta = P[pre + 'gamma' + _pf(d)], P[pre + 'beta' + _pf(d)]
+    else:      # this pass' images
+      per = image_shape[0] // passes
+      gamma, beta = cond_rows[0][i * per:(i + 1) * per], cond_rows[1][i * per:(i + 1) * per]
     with torch.no_grad():
       bmean, stddev = mean_p[i], 1.0 / rstd_p[i]
       rm, rmw = st[pre + 'renorm_mean' + _pf(d)], st[pre + 'renorm_mean_weight' + _pf(d)]
@@ -318,6 +304,11 @@ def _batch_renorm(P, scope, yv, domain, activation, pn, pool):
       st[pre + 'moving_variance' + _pf(d)].mul_(m).add_(new_std * new_std - BN_EPS, alpha=1.0 - m)
     g_rows.append(r * gamma)
     b_rows.append(dd * gamma + beta)
+  if cond_rows is not None:
+    one = torch.ones(passes, c, dtype=torch.float32, device=yv.device)
+    yhat = ops.norm_act(yv, one, torch.zeros_like(one), lrelu=False, pixel_norm=False, in_eps=BN_EPS, stats=(mean, rstd))
+    return ops.affine_act(yhat.view(image_shape), torch.cat(g_rows), torch.cat(b_rows), lrelu=activation, pixel_norm=pn,
+                          pool=pool)
   return ops.norm_act(yv, torch.stack(g_rows), torch.stack(b_rows), lrelu=activation, pixel_norm=pn, in_eps=BN_EPS,
                       pool=pool, stats=(mean, rstd))
 
