@@ -305,6 +305,16 @@ int tg_adam_step(float* theta, const float* grad, float* m, float* v, void* thet
 int tg_adam_tick(int64_t* step_dev, float* lr_t_dev, float lr, float beta1, float beta2, void* stream);
 
 /* -------------------------------------------------------------------------------------------
+ * Encoder-distillation loss -- replaces tf.nn.l2_normalize x2 + tf.losses.cosine_distance (twingan.py:507-521):
+ *   out[0] = (weight / batch) * sum_b (1 - l2n(expected_b) . l2n(embedding_b)),  fp32 [batch, dim] operands.
+ *   bwd: g_embedding = d out / d embedding * gscale[0]  (expected is dataset input: no gradient).
+ * ------------------------------------------------------------------------------------------- */
+int tg_cosine_distance_fwd(const float* expected, const float* embedding, float* out, int batch, int dim, float weight,
+                           void* stream);
+int tg_cosine_distance_bwd(const float* expected, const float* embedding, const float* gscale, float* g_embedding, int batch,
+                           int dim, float weight, void* stream);
+
+/* -------------------------------------------------------------------------------------------
  * Spectral normalisation of a conv kernel -- replaces libs/sn.py:38-101 (spectral_normed_weight: the tf.matmul /
  * tf.nn.l2_normalize chain behind libs.sn.convolution, nets/pggan_utils.py:316-320, --spectral_norm).
  * w: fp32 [k_rows = kh*kw*cin, cout] (the HWIO kernel flattened), u: fp32 [cout] persistent power-iteration vector.

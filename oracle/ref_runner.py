@@ -23,11 +23,13 @@ BASE_FLAGS = dict(generator_network='pggan', is_growing=False, loss_architecture
                   use_gdrop=False, use_conditional_labels=False, do_encoder_distillation=False)
 
 
-def run(flags, sources, targets, global_step=0, seed=0, preset=None, want_grads=True, eager_updates=False, feed=None):
+def run(flags, sources, targets, global_step=0, seed=0, preset=None, want_grads=True, eager_updates=False, feed=None,
+        embeddings=None):
   """flags: reference flag name -> value.  sources / targets: float arrays [B, H, W, 3].  preset: variable values
   (reference name -> array) to use instead of the reference's initialisers.  feed: placeholder name -> array for the
   inference branch (twingan.py:300-363: 'sources_ph', 'targets_ph', 'style_embed_ph'); its outputs come back under
-  'custom' (custom_generated_{s,t}_style_{rand,source,target,ph}: is_training=False passes)."""
+  'custom' (custom_generated_{s,t}_style_{rand,source,target,ph}: is_training=False passes).  embeddings: (a, b)
+  arrays [B, D] or None -- the dataset's 'a_embedding' / 'b_embedding' fields of --do_encoder_distillation."""
   tf = loader.install()
   import twingan as ref      # the reference module, loaded by oracle.tf_shim.loader
   F = tf.flags.FLAGS
@@ -58,8 +60,11 @@ def run(flags, sources, targets, global_step=0, seed=0, preset=None, want_grads=
     style_fn = networks['encoder_style_network_fn']
     networks['encoder_style_network_fn'] = lambda *a, **k: style_fn(
       *a, **{kk: v for kk, v in k.items() if kk != 'self_attention_hw'})
-  end_points = ref.GanModel._clone_fn(networks, None, None, data_batched={'a_source': S, 'b_source': T},
-                                      is_training=True, global_step=gs)
+  data = {'a_source': S, 'b_source': T}
+  for key, emb in zip(('a_embedding', 'b_embedding'), embeddings or (None, None)):
+    if emb is not None:
+      data[key] = core.Tensor(torch.tensor(np.asarray(emb, np.float64)), core.float32, key)
+  end_points = ref.GanModel._clone_fn(networks, None, None, data_batched=data, is_training=True, global_step=gs)
 
   def losses(coll):
     out = {}      # op names are uniquified the way a tf.Graph does it: the 2nd 'x' becomes 'x_1' (= the t domain)
@@ -117,7 +122,10 @@ def flags_of(cfg):
     equalized_learning_rate=cfg.equalized, use_res_block=cfg.res_block,
     pggan_unet_max_concat_hw=getattr(cfg, 'unet_max_concat_hw', None),
     spectral_norm_in_non_discriminator=getattr(cfg, 'sn_non_disc', False),
-    pggan_max_num_channels_dis=getattr(cfg, 'max_ch_dis', None))
+    pggan_max_num_channels_dis=getattr(cfg, 'max_ch_dis', None),
+    do_encoder_distillation=getattr(cfg, 'do_encoder_distillation', False),
+    distillation_weight=getattr(cfg, 'distillation_weight', 1.0),
+    distillation_start_hw=getattr(cfg, 'distillation_start_hw', 16))
 
 
 def global_step_of(cfg):
@@ -130,6 +138,8 @@ def term_name(ref_name):
   (twingan.py:453), so within one graph 'x' is the s term and the uniquified 'x_1' the t term."""
   fixed = {'l_source_content_before_classification': 'l_content_s', 'l_target_content_before_classification': 'l_content_t',
            'l_source_style_prediction': 'l_style_s', 'l_target_style_prediction': 'l_style_t'}
+  if ref_name.endswith('_distillation'):
+    return ref_name
   if ref_name in fixed:
     return fixed[ref_name]
   if ref_name.startswith('l_cyc_'):

@@ -45,6 +45,12 @@ class Config:
   pn_eps: float = 1e-6               # nets/pggan_utils.py:330
   lrelu: float = 0.2                 # util_misc.py:68
   bn_state: object = None            # dict collecting the BatchNorm moving (and renorm) statistics when set
+  do_encoder_distillation: bool = False   # twingan.py:58-65: content encoder distils dataset-provided embeddings
+  distillation_weight: float = 1.0
+  distillation_start_hw: int = 16
+  distill_embed_dim: int = 0         # width of the 'a_embedding' / 'b_embedding' dataset fields
+  distill_embed_s: object = None     # [B, D] embeddings of the source / target batch (None: that domain has none)
+  distill_embed_t: object = None
   is_training: bool = True           # False: the inference branch (twingan.py:300-363): BatchNorm uses the moving statistics
   global_step: int = 0               # batch renorm clipping schedule (nets/pggan_utils.py:207-223)
   spectral_norm: bool = False        # nets/pggan.py:28-30 (discriminator convs; libs/sn.py:38-101)
@@ -223,6 +229,18 @@ def init_params(cfg, seed=0, dtype=torch.float32, std=0.02):
       lim = math.sqrt(6.0 / (E + c))
       P[k + '/weights'] = ((torch.rand(E, c, generator=g, dtype=torch.float32) * 2 - 1) * lim).to(dtype)
       P[k + '/biases'] = torch.zeros(c, dtype=dtype)
+  if cfg.do_encoder_distillation:      # twingan.py:207-230: two heads under encoder_content, source / target norm postfix
+    for head, d in (('encoder_content/encoder_distillation_source', 's'), ('encoder_content/encoder_distillation_target', 't')):
+      nd1 = (d,) if cfg.norm in NORM_SCOPE else ()
+      blk = '%s/before_fc_1x1x%d' % (head, cfg.max_ch)
+      _conv_p(P, g, blk + '/Conv', 3, get_num_channels(0, cfg.max_ch), cfg.max_ch, nd1, cfg.norm not in NORM_SCOPE, dtype, std,
+              NORM_SCOPE.get(cfg.norm, ''))
+      _conv_p(P, g, blk + '/Conv_1', 4, cfg.max_ch, cfg.max_ch, nd1, cfg.norm not in NORM_SCOPE, dtype, std,
+              NORM_SCOPE.get(cfg.norm, ''))
+      P[head + '/prediction/fully_connected/weights'] = \
+          torch.randn(cfg.max_ch, cfg.distill_embed_dim, generator=g, dtype=torch.float32).to(dtype) * \
+          (math.sqrt(1.0 / cfg.max_ch) if he else std)
+      P[head + '/prediction/fully_connected/biases'] = torch.zeros(cfg.distill_embed_dim, dtype=dtype)
   if cfg.res_block:      # after everything else so the other variables keep their seeded values
     ge = encoder_param_specs('encoder_content', cfg.hw, cfg.max_ch, cfg.is_growing) + \
         generator_param_specs('generator', cfg.hw, cfg.max_ch, cfg.use_unet, cfg.is_growing, cfg.unet_max_concat_hw)
@@ -580,6 +598,23 @@ def encoder(P, x, domain, cfg, top='encoder_content'):
   return net, ep
 
 
+def encoder_classification(P, net, domain, cfg, top):
+  """nets/pggan.py:482-507: conv3x3 SAME, conv4x4 VALID (norm + LeakyReLU, no pixel norm), squeeze, fully connected."""
+  blk = '%s/before_fc_1x1x%d' % (top, cfg.max_ch)
+  net = ge_conv(P, blk + '/Conv', net, domain, cfg, pixnorm=False)
+  net = ge_conv(P, blk + '/Conv_1', net, domain, cfg, k=4, padding='VALID', pixnorm=False)
+  feat = net.reshape(net.shape[0], -1)
+  return equalize(feat, cfg, 1) @ P[top + '/prediction/fully_connected/weights'] + P[top + '/prediction/fully_connected/biases']
+
+
+def cosine_distance(expected, embedding, weight):
+  """twingan.py:515-519: tf.losses.cosine_distance(l2n(expected), l2n(embedding), axis=-1, weights=w) =
+  w * mean_b(1 - sum_c e_c p_c)."""
+  def l2n(x):
+    return x * torch.rsqrt(x.pow(2).sum(dim=-1, keepdim=True).clamp_min(1e-12))
+  return weight * (1.0 - (l2n(expected) * l2n(embedding)).sum(dim=-1)).mean()
+
+
 def encoder_full(P, x, domain, cfg, top='encoder_style'):
   """nets/pggan.py:482-541 (pggan.encoder): encoder_before_classification, conv3x3 SAME, conv4x4 VALID (norm +
   LeakyReLU, no pixel norm), squeeze, fully connected -> [B, output_dim]."""
@@ -843,6 +878,21 @@ def generator_loss(P, sources, targets, cfg):
       if cfg.use_style_embedding:      # twingan.py:495-505: |random_style_embed - E_style(d_prime)|
         st_prime, _ = encoder_full(P, prime, d, cfg)
         terms['l_style_' + d] = (o['random_style_embed'] - st_prime).abs().mean() * cfg.l_content
+  if cfg.do_encoder_distillation:
+    # twingan.py:207-230,290-298: the graph applies both heads to the original and to the re-encoded content whether or
+    # not a dataset carries embeddings (BatchNorm statistics move accordingly); source head first on E(s), then E(s')
+    hs, ht = 'encoder_content/encoder_distillation_source', 'encoder_content/encoder_distillation_target'
+    d_s = encoder_classification(P, o['es'], 's', cfg, hs)
+    d_t = encoder_classification(P, o['et'], 't', cfg, ht)
+    d_sp = encoder_classification(P, e_sp, 's', cfg, hs)
+    d_tp = encoder_classification(P, e_tp, 't', cfg, ht)
+    if cfg.hw >= cfg.distillation_start_hw:      # twingan.py:507-521
+      if cfg.distill_embed_s is not None:      # dataset a: the source image, and t' (generated from its content)
+        terms['l_source_distillation'] = cosine_distance(cfg.distill_embed_s, d_s, cfg.distillation_weight)
+        terms['l_t_prime_distillation'] = cosine_distance(cfg.distill_embed_s, d_tp, cfg.distillation_weight)
+      if cfg.distill_embed_t is not None:
+        terms['l_target_distillation'] = cosine_distance(cfg.distill_embed_t, d_t, cfg.distillation_weight)
+        terms['l_s_prime_distillation'] = cosine_distance(cfg.distill_embed_t, d_sp, cfg.distillation_weight)
   return sum(terms.values()), terms
 
 

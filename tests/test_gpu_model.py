@@ -699,6 +699,50 @@ def test_batch_renorm_generator_matches_oracle(global_step):
     assert np.abs(a - v.numpy()).max() < 2e-5 * max(1.0, np.abs(v.numpy()).max()), k
 
 
+@pytest.mark.parametrize('norm,both', [('instance_norm', True), ('batch_norm', False)])
+def test_encoder_distillation_matches_oracle(norm, both):
+  """--do_encoder_distillation (twingan.py:207-230,290-298,507-521): the two encoder_classification heads under
+  encoder_content on the original and the re-encoded content, cosine distance to the dataset's embeddings
+  (tg_cosine_distance_*); `both` False: only the source dataset carries embeddings (two of the four terms exist, but all
+  four head applications still move the BatchNorm statistics).  Oracle pinned live (test_reference_live distillation*)."""
+  from twingan_amd import Config
+  from twingan_amd import twingan as T
+  from twingan_amd.twingan import Trainer
+  cfg = Config(hw=16, max_ch=16, precision='fp32', generator_norm_type=norm, do_encoder_distillation=True,
+               distill_embed_dim=6, distillation_weight=0.7)
+  state = {}
+  g = torch.Generator().manual_seed(98)
+  emb_s, emb_t = torch.randn(3, 6, generator=g), (torch.randn(3, 6, generator=g) if both else None)
+  rcfg = R.Config(hw=16, max_ch=16, norm=norm, bn_state=state if norm != 'instance_norm' else None,
+                  do_encoder_distillation=True, distill_embed_dim=6, distillation_weight=0.7,
+                  distill_embed_s=emb_s.double(), distill_embed_t=None if emb_t is None else emb_t.double())
+  Pref = R.init_params(rcfg, seed=19, dtype=torch.float64, std='he')
+  tr = Trainer(cfg, device='cuda:0', seed=19)
+  assert set(tr.store.state_dict()) == set(Pref)
+  tr.store.load_state_dict({k: v.float() for k, v in Pref.items()})
+  Pref = {k: v.float().double().requires_grad_(True) for k, v in Pref.items()}
+  s, t = torch.rand(3, 16, 16, 3, generator=g), torch.rand(3, 16, 16, 3, generator=g)
+  dev = lambda x: None if x is None else x.to('cuda:0').contiguous()
+  tr.store.zero_grad('g')
+  tr._set_requires_grad(g=True, d=False)
+  gl, gterms = T.generator_loss(tr.P, dev(s), dev(t), cfg, distill_embed_s=dev(emb_s), distill_embed_t=dev(emb_t))
+  rgl, rgterms = R.generator_loss(Pref, s.double(), t.double(), rcfg)
+  assert set(gterms) == set(rgterms) and ('l_target_distillation' in gterms) == both and 'l_t_prime_distillation' in gterms
+  for k in rgterms:
+    assert abs(gterms[k].item() - rgterms[k].item()) < 2e-4 * max(1.0, abs(rgterms[k].item())), k
+  gl.backward()
+  rgl.backward()
+  _grads_close(tr, Pref, tr.store.names('g'), FP32_GRAD_TOL, 'generator(distillation, %s)' % norm, var_tol=FP32_VAR_GRAD_TOL)
+  if norm == 'batch_norm':
+    for k, v in state.items():
+      a = tr.store.state[k].double().cpu().numpy()
+      assert np.abs(a - v.numpy()).max() < 1e-5 * max(1.0, np.abs(v.numpy()).max()), k
+  # and through Trainer.run (eager: the embeddings are per-batch dataset fields)
+  tr2 = Trainer(cfg, device='cuda:0', seed=19)
+  l0, terms0 = tr2.run(dev(s), dev(t), distill_embed_s=dev(emb_s), distill_embed_t=dev(emb_t))
+  assert 'l_source_distillation' in terms0 and bool(torch.isfinite(l0).all())
+
+
 @pytest.mark.parametrize('norm', ['batch_norm', 'batch_renorm'])
 def test_style_embedding_on_batch_norms_matches_oracle(norm):
   """--use_style_embedding on the batch-norm family (libs/batch_norm.py:82-85,152-159,209-259,403-470): pass statistics

@@ -33,6 +33,8 @@ CASES = {
   'style_embed_6': dict(hw=16, max_ch=16, use_style_embedding=True, style_embed_size=6),
   # conditional BATCH norm is the style configuration the reference can actually build for a batch > 1
   'style_batch_norm': dict(hw=16, max_ch=8, use_style_embedding=True, style_embed_size=4, norm='batch_norm'),
+  'distillation': dict(hw=16, max_ch=8, do_encoder_distillation=True, distill_embed_dim=5, distillation_weight=0.7),
+  'distillation_source_only': dict(hw=16, max_ch=8, do_encoder_distillation=True, distill_embed_dim=4, norm='batch_norm'),
   'style_batch_renorm': dict(hw=16, max_ch=8, use_style_embedding=True, style_embed_size=4, norm='batch_renorm'),
 }
 
@@ -50,8 +52,13 @@ def test_oracle_matches_live_reference(name):
   stateful = cfg.norm in ('batch_norm', 'batch_renorm')
   if stateful:
     cfg.bn_state = {}      # the oracle applies the moving-statistics updates in program order: ask the stand-in for the same
+  emb = None
+  if cfg.do_encoder_distillation:      # the dataset's embedding fields; 'source_only': the target dataset has none
+    emb = (rng.randn(batch, cfg.distill_embed_dim), None if name.endswith('source_only') else rng.randn(batch, cfg.distill_embed_dim))
+    cfg.distill_embed_s = torch.from_numpy(emb[0])
+    cfg.distill_embed_t = None if emb[1] is None else torch.from_numpy(emb[1])
   ref = ref_runner.run(ref_runner.flags_of(cfg), s, t, global_step=ref_runner.global_step_of(cfg), seed=1, preset=preset,
-                       eager_updates=stateful)
+                       eager_updates=stateful, embeddings=emb)
   created = {k for k in ref['variables'] if k != 'global_step' and '/moving_' not in k and '/renorm_' not in k}
   assert created == set(preset)
   draws = {}

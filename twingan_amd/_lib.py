@@ -94,6 +94,8 @@ SIGNATURES = {
     'tg_gp_penalty': (c_int, [_FP, _FP, _FP, c_int, c_float, _P]),
     'tg_adam_step': (c_int, [_FP, _FP, _FP, _FP, _P, c_int64, c_float, _FP, c_float, c_float, c_float, c_float, _P]),
     'tg_adam_tick': (c_int, [_P, _FP, c_float, c_float, c_float, _P]),
+    'tg_cosine_distance_fwd': (c_int, [_FP, _FP, _FP, c_int, c_int, c_float, _P]),
+    'tg_cosine_distance_bwd': (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_float, _P]),
     'tg_spectral_norm_workspace': (c_size_t, [c_int, c_int]),
     'tg_spectral_norm_fwd': (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, _P, c_size_t, _P]),
     'tg_spectral_norm_bwd': (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, _P, c_size_t, _P]),

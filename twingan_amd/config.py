@@ -22,6 +22,10 @@ class Config:
   self_attention_hw: int = 64         # image_generation.py:65-67
   use_style_embedding: bool = False   # twingan.py:47-49: generator norm parameters conditioned on a style embedding
   style_embed_size: int = 16          # twingan.py:50-51
+  do_encoder_distillation: bool = False   # twingan.py:58-65: the content encoder distils dataset-provided embeddings
+  distillation_weight: float = 1.0
+  distillation_start_hw: int = 16
+  distill_embed_dim: int = 0          # width of the dataset's 'a_embedding' / 'b_embedding' fields (twingan.py:164-177)
   is_training: bool = True            # False: the inference branch (twingan.py:300-363) -- BatchNorm reads the moving statistics
   is_growing: bool = False            # image_generation.py:69-72
   alpha_grow: float = 0.0             # twingan.py:833-835

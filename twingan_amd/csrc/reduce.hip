@@ -469,6 +469,54 @@ __global__ void pred_loss_bwd_kernel(const float* __restrict__ x, const float* _
 
 // out[0] = E[x^2] - E[x]^2 from sum = s1[0] and the per-sample sums of squares ss[batch]  (DRAGAN,
 // image_generation.py:445: the VARIANCE over every element of the minibatch)
+// tf.losses.cosine_distance(l2n(expected), l2n(embedding), axis=-1, weights=w) (twingan.py:515-519):
+//   out = (w / B) * sum_b (1 - e_b . p_b / (|e_b| |p_b|)),  norms clamped as tf.nn.l2_normalize does (sum x^2 >= 1e-12).
+// One workgroup walks the rows in order: a handful of [B, D] rows, fixed summation order.
+__global__ __launch_bounds__(256) void cosine_distance_fwd_kernel(const float* __restrict__ e, const float* __restrict__ p,
+                                                                  float* __restrict__ out, int b, int d, float scale) {
+  __shared__ float red[4];
+  float tot = 0.f;
+  for (int r = 0; r < b; ++r) {
+    float dot = 0.f, se = 0.f, sp = 0.f;
+    for (int c = threadIdx.x; c < d; c += 256) {
+      const float x = e[(size_t)r * d + c], y = p[(size_t)r * d + c];
+      dot = fmaf(x, y, dot);
+      se = fmaf(x, x, se);
+      sp = fmaf(y, y, sp);
+    }
+    dot = block_sum(dot, red);
+    se = block_sum(se, red);
+    sp = block_sum(sp, red);
+    tot += 1.f - dot * rsqrtf(fmaxf(se, 1e-12f)) * rsqrtf(fmaxf(sp, 1e-12f));
+  }
+  if (threadIdx.x == 0) out[0] = tot * scale;
+}
+
+// d out / d p[b, c] = -(w / B) * g * (ehat_c - phat_c (ehat . phat)) / |p|   (|p|^2 >= 1e-12; below it phat = p * 1e6)
+__global__ __launch_bounds__(256) void cosine_distance_bwd_kernel(const float* __restrict__ e, const float* __restrict__ p,
+                                                                  const float* __restrict__ gscale, float* __restrict__ gp,
+                                                                  int d, float scale) {
+  __shared__ float red[4];
+  const int r = blockIdx.x;
+  float dot = 0.f, se = 0.f, sp = 0.f;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    const float x = e[(size_t)r * d + c], y = p[(size_t)r * d + c];
+    dot = fmaf(x, y, dot);
+    se = fmaf(x, x, se);
+    sp = fmaf(y, y, sp);
+  }
+  dot = block_sum(dot, red);
+  se = block_sum(se, red);
+  sp = block_sum(sp, red);
+  const float ie = rsqrtf(fmaxf(se, 1e-12f)), ip = rsqrtf(fmaxf(sp, 1e-12f));
+  const float cosv = dot * ie * ip, k = -scale * gscale[0];
+  const bool clamped = sp < 1e-12f;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    const float eh = e[(size_t)r * d + c] * ie, ph = p[(size_t)r * d + c] * ip;
+    gp[(size_t)r * d + c] = k * (clamped ? eh * ip : (eh - ph * cosv) * ip);
+  }
+}
+
 __global__ void var_from_sums_kernel(const float* __restrict__ s1, const float* __restrict__ ss, float* __restrict__ out,
                                      int batch, float inv_numel) {
   __shared__ float red[8];
@@ -666,6 +714,25 @@ int tg_pred_loss_bwd(const float* x, const float* gscale, float* gx, int n, int 
   hipLaunchKernelGGL(pred_loss_bwd_kernel, dim3(tg_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, gscale, gx, n,
                      mode, a, b, scale);
   TG_LAUNCH_CHECK("tg_pred_loss_bwd");
+  return TG_OK;
+}
+
+int tg_cosine_distance_fwd(const float* expected, const float* embedding, float* out, int batch, int dim, float weight,
+                           void* stream) {
+  TG_CHECK(expected && embedding && out && batch > 0 && dim > 0, TG_EINVAL, "tg_cosine_distance_fwd: bad arguments");
+  hipLaunchKernelGGL(cosine_distance_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, expected, embedding, out, batch,
+                     dim, weight / (float)batch);
+  TG_LAUNCH_CHECK("tg_cosine_distance_fwd");
+  return TG_OK;
+}
+
+int tg_cosine_distance_bwd(const float* expected, const float* embedding, const float* gscale, float* g_embedding, int batch,
+                           int dim, float weight, void* stream) {
+  TG_CHECK(expected && embedding && gscale && g_embedding && batch > 0 && dim > 0, TG_EINVAL,
+           "tg_cosine_distance_bwd: bad arguments");
+  hipLaunchKernelGGL(cosine_distance_bwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, expected, embedding, gscale,
+                     g_embedding, dim, weight / (float)batch);
+  TG_LAUNCH_CHECK("tg_cosine_distance_bwd");
   return TG_OK;
 }
 

@@ -1434,6 +1434,35 @@ class PredLossFn(torch.autograd.Function):
     return gx, None, None, None, None
 
 
+class CosineDistanceFn(torch.autograd.Function):
+  """weight * mean_b(1 - l2n(expected_b) . l2n(embedding_b)) -> fp32 [1] (twingan.py:507-521: the encoder-distillation
+  loss; `expected` is the dataset's embedding, no gradient).  First order."""
+
+  @staticmethod
+  def forward(ctx, expected, embedding, weight):
+    _chk(expected, embedding)
+    assert expected.dtype == embedding.dtype == torch.float32 and expected.shape == embedding.shape
+    b, d = embedding.shape
+    out = torch.empty(1, dtype=torch.float32, device=embedding.device)
+    call('tg_cosine_distance_fwd', _p(expected), _p(embedding), _p(out), b, d, weight, _stream())
+    ctx.weight = weight
+    ctx.save_for_backward(expected, embedding)
+    return out
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, g):
+    expected, embedding = ctx.saved_tensors
+    b, d = embedding.shape
+    ge = torch.empty_like(embedding)
+    call('tg_cosine_distance_bwd', _p(expected), _p(embedding), _p(g.contiguous()), _p(ge), b, d, ctx.weight, _stream())
+    return None, ge, None
+
+
+def cosine_distance(expected, embedding, weight=1.0):
+  return CosineDistanceFn.apply(expected.contiguous(), embedding.contiguous(), float(weight))
+
+
 def hinge_mean(x, a, b, weight=1.0):
   """weight * mean(relu(a + b*x))."""
   return PredLossFn.apply(x.contiguous(), 1, float(a), float(b), float(weight))

@@ -315,6 +315,15 @@ def declare_twingan(store, cfg, model='twingan'):
 
   if not pggan_model:
     enc_skeleton('encoder_content', 'g', g_bias, nd)
+    if cfg.do_encoder_distillation:      # twingan.py:207-230: encoder_classification heads under encoder_content, one per domain
+      assert cfg.distill_embed_dim > 0, 'do_encoder_distillation needs distill_embed_dim (the dataset embedding width)'
+      c0 = get_num_channels(0, mc)
+      for head, d in (('encoder_content/encoder_distillation_source', 's'), ('encoder_content/encoder_distillation_target', 't')):
+        hd = () if g_bias else (d,)
+        store.add_conv('%s/before_fc_1x1x%d/Conv' % (head, mc), 3, c0, mc, 'g', g_bias, hd, norm_scope=ns)
+        store.add_conv('%s/before_fc_1x1x%d/Conv_1' % (head, mc), 4, mc, mc, 'g', g_bias, hd, norm_scope=ns)
+        store.add(head + '/prediction/fully_connected/weights', (mc, cfg.distill_embed_dim), 'g', 'fc_w')
+        store.add(head + '/prediction/fully_connected/biases', (cfg.distill_embed_dim,), 'g', 'bias')
   gen_kw = {}
   if cfg.use_style_embedding and not pggan_model:      # twingan.py:47-51,201-223: the style encoder (pggan.encoder) and conditional generator norms
     if cfg.generator_norm_type not in ('instance_norm', 'batch_norm', 'batch_renorm'):

@@ -69,6 +69,21 @@ class _DomainStreams:
 LOSSES = ('wgan_gp', 'wgan', 'hinge', 'gan', 'dragan')      # --loss_architecture, image_generation.py:81-83
 
 
+def select_network(generator_network='pggan'):
+  """GanModel._select_network (twingan.py:122-140): the network-function registry of the hot path -- the same seven
+  entries, bound to the MI355X implementations (signature (P, tensor, domain, cfg, ...) -> (output, end_points))."""
+  if generator_network != 'pggan':
+    raise NotImplementedError('Generator network %s is not implemented.' % generator_network)
+  return {'generator_network_fn': pggan.generator,
+          'discriminator_network_fn': pggan.discriminator,
+          'encoder_network_fn': pggan.encoder_before_classification,
+          'encoder_style_network_fn': pggan.encoder,
+          'encoder_classification_fn': pggan.encoder_classification,
+          # "Intentionally encoder_distillation_fn is the same as classification" (twingan.py:130-131)
+          'encoder_distillation_fn': pggan.encoder_classification,
+          'get_noise_shape': pggan.get_noise_shape}
+
+
 def _fool_loss(pred, cfg):
   """image_generation.py:331-344."""
   pred = pred.contiguous()
@@ -161,8 +176,9 @@ def encode_style(P, images, cfg, domain):
     return pggan.encoder(P, images, domain, ci, 'encoder_style')[0]
 
 
-def generator_loss(P, sources, targets, cfg, style_noise=None):
-  """GENERATOR_LOSSES (twingan.py:464-505; image_generation.py:331-337).  Returns (total [1], terms)."""
+def generator_loss(P, sources, targets, cfg, style_noise=None, distill_embed_s=None, distill_embed_t=None):
+  """GENERATOR_LOSSES (twingan.py:464-521; image_generation.py:331-337).  Returns (total [1], terms).
+  distill_embed_*: the datasets' fp32 [B, D] embeddings of --do_encoder_distillation (None: that dataset has none)."""
   assert cfg.loss_architecture in LOSSES, cfg.loss_architecture
   if cfg.is_growing:
     sources, targets = get_growing_image(sources, cfg.alpha_grow), get_growing_image(targets, cfg.alpha_grow)
@@ -196,6 +212,20 @@ def generator_loss(P, sources, targets, cfg, style_noise=None):
       st_sp, st_tp = st2.chunk(2)
       terms['l_style_s'] = ops.abs_diff_mean(o['random_style_embed'], st_sp.contiguous(), cfg.l_content_weight)
       terms['l_style_t'] = ops.abs_diff_mean(o['random_style_embed'], st_tp.contiguous(), cfg.l_content_weight)
+  if cfg.do_encoder_distillation:
+    # twingan.py:207-230,290-298: both heads on the original and the re-encoded content (each head one batch: original
+    # then prime); the cosine-distance terms only for the datasets that carry embeddings (:507-521)
+    hs, ht = 'encoder_content/encoder_distillation_source', 'encoder_content/encoder_distillation_target'
+    d_s, d_sp = pggan.encoder_classification(P, torch.cat([o['es'], e_sp]), ('s', 's', b, 2), cfg, hs)[0].chunk(2)
+    d_t, d_tp = pggan.encoder_classification(P, torch.cat([o['et'], e_tp]), ('t', 't', b, 2), cfg, ht)[0].chunk(2)
+    if cfg.hw >= cfg.distillation_start_hw:
+      w = cfg.distillation_weight
+      if distill_embed_s is not None:
+        terms['l_source_distillation'] = ops.cosine_distance(distill_embed_s, d_s, w)
+        terms['l_t_prime_distillation'] = ops.cosine_distance(distill_embed_s, d_tp, w)
+      if distill_embed_t is not None:
+        terms['l_target_distillation'] = ops.cosine_distance(distill_embed_t, d_t, w)
+        terms['l_s_prime_distillation'] = ops.cosine_distance(distill_embed_t, d_sp, w)
   streams.join()
   return _sum_terms(terms), terms
 
@@ -315,6 +345,7 @@ class Trainer:
     self.split = bool(want and not (cfg.is_growing or cfg.use_style_embedding or cfg.spectral_norm)
                       and cfg.overlap_cut_hw and cfg.hw > cfg.overlap_cut_hw)
     self._ptr_phase = {self.P[k].data_ptr(): ph for k, ph in self.store.phase.items()}
+    self._extras = None             # per-run dataset fields besides the images (run(..., distill_embed_s=, distill_embed_t=))
     self.use_graph = use_graph
     self.graph_fallback_reason = None
     self._graphs = None
@@ -404,7 +435,9 @@ class Trainer:
     return declare_twingan(store, cfg)
 
   def _generator_loss(self, sources, targets):
-    return generator_loss(self.P, sources, targets, self.cfg)
+    ex = self._extras or {}
+    return generator_loss(self.P, sources, targets, self.cfg, distill_embed_s=ex.get('distill_embed_s'),
+                          distill_embed_t=ex.get('distill_embed_t'))
 
   def _discriminator_loss(self, sources, targets, gp_alpha_s, gp_alpha_t):
     return discriminator_loss(self.P, sources, targets, self.cfg, gp_alpha_s, gp_alpha_t)
@@ -526,10 +559,14 @@ class Trainer:
     self.adam_t += 1
     return self._outs[kind]
 
-  def run(self, sources, targets, gp_alpha_s=None, gp_alpha_t=None):
+  def run(self, sources, targets, gp_alpha_s=None, gp_alpha_t=None, **extras):
     """One ``session.run(train_op)`` of the reference (image_generation.py:640-652):
-    n_critic_counter % n_critic == 0 -> generator/encoder apply, else discriminator apply."""
+    n_critic_counter % n_critic == 0 -> generator/encoder apply, else discriminator apply.
+    ``extras``: further dataset fields of the batch -- distill_embed_s / distill_embed_t ([B, D] fp32, the
+    'a_embedding' / 'b_embedding' of --do_encoder_distillation); eager launches only."""
     is_g = self.n_critic_counter % self.cfg.n_critic == 0
+    assert not (extras and self.use_graph), 'dataset extras are not part of the captured graphs: use_graph=False'
+    self._extras = extras or None
     import contextlib
     # the kernels go to the current device's stream (ops._stream)
     with (torch.cuda.device(self.device) if self.device.type == 'cuda' else contextlib.nullcontext()):
