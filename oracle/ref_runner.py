@@ -276,6 +276,7 @@ def run_training(flags, runs, seed=0, preset=None):
   for i, (s, t) in enumerate(runs):
     tfapi._ARG_STACK[:] = [{}]
     core.STATE.scope_count = {}
+    core.STATE.opt_count = 0                                       # optimizer objects are numbered per graph build
     core.STATE.scope_stack[0].reuse = True if i > 0 else None      # the same graph, built again
     for k in list(core.STATE.collections):                       # per-run collections (losses, update ops ...)
       if k not in ('variables', 'trainable_variables', 'model_variables'):

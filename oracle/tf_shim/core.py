@@ -387,6 +387,7 @@ class State(object):
     self.global_step = None
     self.name_scope = ''
     self.placeholder_batch = 1
+    self.opt_count = 0                  # optimizers built in the current graph (tfapi.AdamOptimizer)
     self.placeholder_feed = {}          # placeholder name -> array fed to it (the inference branch; default zeros)
     self.preset = {}                    # full variable name -> numpy value used instead of the initializer
     self.deferred = []                  # assign ops waiting for run_update_ops()

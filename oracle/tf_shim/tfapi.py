@@ -566,10 +566,15 @@ class AdamOptimizer(Optimizer):
   def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8, use_locking=False, name='Adam'):
     Optimizer.__init__(self, learning_rate)
     self._b1, self._b2, self._eps = float(beta1), float(beta2), float(epsilon)
+    # the non-slot power accumulators belong to the optimizer OBJECT (optimizer.py _non_slot_dict); a graph names the
+    # second optimizer's 'beta1_power_1' ... -- the k-th Adam built in a run (STATE.opt_count, reset per graph build)
+    self._idx = getattr(STATE, 'opt_count', 0)
+    STATE.opt_count = self._idx + 1
 
   def _powers(self):
-    return (self._slot(None, 'beta1_power', torch.tensor(self._b1, dtype=F64)),
-            self._slot(None, 'beta2_power', torch.tensor(self._b2, dtype=F64)))
+    sfx = '' if self._idx == 0 else '_%d' % self._idx
+    return (self._slot(None, 'beta1_power' + sfx, torch.tensor(self._b1, dtype=F64)),
+            self._slot(None, 'beta2_power' + sfx, torch.tensor(self._b2, dtype=F64)))
 
   def _apply(self, grad, var):
     b1p, b2p = self._powers()

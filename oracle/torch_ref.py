@@ -41,6 +41,8 @@ class Config:
   beta1: float = 0.5
   beta2: float = 0.99
   adam_eps: float = 1e-8
+  use_ttur: bool = False             # image_generation.py:554-561: own optimizer (rate, beta powers) for the discriminator
+  d_lr: float = 4e-4                 # discriminator_learning_rate
   in_eps: float = 1e-6               # libs/instance_norm.py:37
   pn_eps: float = 1e-6               # nets/pggan_utils.py:330
   lrelu: float = 0.2                 # util_misc.py:68
@@ -944,10 +946,13 @@ class AdamState:
     self.t = 0
     self.cfg = cfg
 
-  def apply(self, P, grads):
+  def apply(self, P, grads, group='g'):
     c = self.cfg
+    # --use_ttur builds a second optimizer (image_generation.py:554-561) that only COMPUTES the discriminator gradients
+    # (:603-608); both gradient sets are applied by the generator's optimizer (:640-646): one rate, one pair of powers
     self.t += 1
-    lr_t = c.lr * math.sqrt(1.0 - c.beta2 ** self.t) / (1.0 - c.beta1 ** self.t)
+    t, lr = self.t, c.lr
+    lr_t = lr * math.sqrt(1.0 - c.beta2 ** t) / (1.0 - c.beta1 ** t)
     with torch.no_grad():
       for k, g in grads.items():
         self.m[k].mul_(c.beta1).add_(g, alpha=1 - c.beta1)
@@ -980,5 +985,5 @@ def train_step(P, opt, sources, targets, cfg, gp_alpha_s, gp_alpha_t, counter, l
     out['d_loss'] = float(dl.detach())
   for v in P.values():
     v.requires_grad_(False)
-  opt.apply(P, gg if is_g else dg)
+  opt.apply(P, gg if is_g else dg, 'g' if is_g else 'd')
   return out

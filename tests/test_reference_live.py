@@ -170,3 +170,27 @@ def test_inference_branch_matches_live_reference(norm):
   with torch.no_grad():
     assert np.abs(R.translate(P, torch.from_numpy(sp), cfg, 't').numpy() - ref['custom']['custom_generated_t_style_source']).max() < 1e-9
     assert np.abs(R.translate(P, torch.from_numpy(tp), cfg, 's').numpy() - ref['custom']['custom_generated_s_style_target']).max() < 1e-9
+
+
+def test_ttur_training_runs_match_live_reference():
+  """--use_ttur (image_generation.py:554-561) creates a discriminator optimizer with its own rate, but the graph
+  applies the discriminator gradients with the GENERATOR's optimizer (:640-646): running the reference shows the flag
+  changes no update (one shared pair of beta powers advanced by every apply, the generator's learning rate) -- which
+  is what the oracle and the product do."""
+  from oracle import ref_runner
+  cfg = R.Config(hw=16, max_ch=8, lr=1e-3, use_ttur=True, d_lr=3e-3)
+  P = {k: v.float().double() for k, v in R.init_params(cfg, seed=41, dtype=torch.float64, std='he').items()}
+  g = torch.Generator().manual_seed(42)
+  runs = [(torch.rand(2, 16, 16, 3, generator=g).double(), torch.rand(2, 16, 16, 3, generator=g).double()) for _ in range(4)]
+  flags = dict(ref_runner.flags_of(cfg), learning_rate=cfg.lr, learning_rate_decay_type='fixed', optimizer='adam',
+               adam_beta1=cfg.beta1, adam_beta2=cfg.beta2, opt_epsilon=cfg.adam_eps, n_critic=2, use_ttur=True,
+               discriminator_learning_rate=cfg.d_lr)
+  ref = ref_runner.run_training(flags, [(s.numpy(), t.numpy()) for s, t in runs], seed=0,
+                                preset={k: v.numpy() for k, v in P.items()})
+  opt = R.AdamState(P, cfg)
+  for i, ((s, t), h) in enumerate(zip(runs, ref['history'])):
+    a = [v for n, v in h['random'] if n == 'alpha']
+    R.train_step(P, opt, s, t, cfg, torch.from_numpy(a[0]), torch.from_numpy(a[1]), i)
+  assert opt.t == 4 and abs(float(ref['variables']['beta1_power']) - cfg.beta1 ** 5) < 1e-12
+  worst = max(float(np.abs(P[k].detach().numpy() - ref['variables'][k]).max()) for k in P)
+  assert worst < 1e-9, worst

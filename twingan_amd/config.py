@@ -38,6 +38,8 @@ class Config:
   do_l_cyc_gan: bool = True           # twingan.py:77-79
   n_critic: int = 2                   # image_generation.py:87-90
   learning_rate: float = 1e-4         # docs/training.md:24-25
+  use_ttur: bool = False              # image_generation.py:554-561; accepted, changes no update (the reference applies the
+  discriminator_learning_rate: float = 4e-4   # discriminator gradients with the generator's optimizer, :640-646)
   adam_beta1: float = 0.5
   adam_beta2: float = 0.99
   opt_epsilon: float = 1e-8

@@ -337,6 +337,10 @@ class Trainer:
     self.adam_t = 0                 # one shared optimizer: beta powers advance on every apply (:554-561)
     self._adam_step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
     self._lr_t_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
+    # --use_ttur (image_generation.py:554-561) builds a second AdamOptimizer for the discriminator, but the reference
+    # only uses it to COMPUTE the discriminator gradients (:603-608); they are APPLIED by the generator's optimizer
+    # (:640-646 pass `optimizer`, not `d_optimizer`, to maybe_apply_gradients).  So the flag changes no update: one
+    # optimizer, one learning rate, one pair of beta powers -- pinned live (tests/test_reference_live.py, ttur).
     self._group_weights = {g: [self.P[k] for k, s in self.store.specs.items() if s['group'] == g and s['kind'] == 'conv_w']
                            for g in self.store.GROUPS}
     # segmented backward (params.grad_phase): only where no autograd node is shared between segments -- the per-run
@@ -377,13 +381,13 @@ class Trainer:
     """tf.train.AdamOptimizer apply (model/model_inheritor.py:537-542) on the group's flat buffers, then
     refresh the bf16 weight packs of the convs that just moved."""
     c = self.cfg
-    self.adam_t += 1
     s = self.store
     st = torch.cuda.current_stream().cuda_stream
-    call('tg_adam_tick', self._adam_step_dev.data_ptr(), self._lr_t_dev.data_ptr(), c.learning_rate, c.adam_beta1,
-         c.adam_beta2, st)
+    self.adam_t += 1
+    step_dev, lr_dev, lr = self._adam_step_dev, self._lr_t_dev, c.learning_rate
+    call('tg_adam_tick', step_dev.data_ptr(), lr_dev.data_ptr(), lr, c.adam_beta1, c.adam_beta2, st)
     call('tg_adam_step', s.flat[group].data_ptr(), s.grad[group].data_ptr(), s.m[group].data_ptr(),
-         s.v[group].data_ptr(), None, s.flat[group].numel(), 0.0, self._lr_t_dev.data_ptr(), c.adam_beta1,
+         s.v[group].data_ptr(), None, s.flat[group].numel(), 0.0, lr_dev.data_ptr(), c.adam_beta1,
          c.adam_beta2, c.opt_epsilon, 1.0 / c.loss_scale, st,
          work=('adam:numel%d' % s.flat[group].numel(), 0, 28 * s.flat[group].numel()))
     PackCache.refresh(self._group_weights[group])
