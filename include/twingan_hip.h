@@ -305,6 +305,33 @@ int tg_adam_step(float* theta, const float* grad, float* m, float* v, void* thet
 int tg_adam_tick(int64_t* step_dev, float* lr_t_dev, float lr, float beta1, float beta2, void* stream);
 
 /* -------------------------------------------------------------------------------------------
+ * SAGAN self-attention -- replaces tf.matmul (x2), tf.nn.softmax, tf.nn.tanh and gamma * o + layer of
+ * libs/self_attention.py:57-69 (called from nets/pggan_utils.py:301-308 under --do_self_attention).  The layer is
+ * composed on the host from these entry points; each is closed under differentiation (the backward of a product is two
+ * products, the softmax backward has its own gradient kernel), so the layer is differentiable twice on them -- the
+ * discriminators sit under the WGAN-GP penalty (image_generation.py:414-439).
+ *   tg_batched_gemm: C[i] = alpha * op(A[i]) op(B[i]) (+ C[i]), i < batch; op(A) is m x k stored [m][lda] (ta = 0) or
+ *     [k][lda] (ta = 1), op(B) is k x n stored [k][ldb] (tb = 0) or [n][ldb] (tb = 1); strides in elements.
+ *     dtype TG_BF16: MFMA kernel (C bf16, or fp32 with c_is_f32); TG_F32: exact fp32.
+ *   tg_softmax_rows_fwd: p = softmax(s) over the last axis of [rows, cols];  _bwd: ds = p * (dp - sum(dp * p));
+ *     _bwd_bwd: gp = d (sum v * ds) / d p = v * (dp - sum(dp p)) - dp * sum(v p)   (d / d dp is _bwd(p, v)).
+ *   tg_tanh_fwd / _bwd (gx = g (1 - y^2)), tg_mul3 (out = scale a b c; c may be NULL), tg_scale_dev (out = x * s[0],
+ *     s on the device: sa_gamma), tg_dot (out[0] = sum a b; ws >= 1024 floats).
+ * ------------------------------------------------------------------------------------------- */
+int tg_batched_gemm(const void* a, const void* b, void* c, int batch, int m, int n, int k, int ta, int tb, int lda, int ldb,
+                    int ldc, int64_t stride_a, int64_t stride_b, int64_t stride_c, float alpha, int accumulate, int dtype,
+                    int c_is_f32, void* stream);
+int tg_softmax_rows_fwd(const void* s, void* p, int64_t rows, int cols, int dtype, void* stream);
+int tg_softmax_rows_bwd(const void* p, const void* dp, void* ds, int64_t rows, int cols, int dtype, void* stream);
+int tg_softmax_rows_bwd_bwd(const void* p, const void* dp, const void* v, void* gp, int64_t rows, int cols, int dtype,
+                            void* stream);
+int tg_tanh_fwd(const void* x, void* y, int64_t numel, int dtype, void* stream);
+int tg_tanh_bwd(const void* g, const void* y, void* gx, int64_t numel, int dtype, void* stream);
+int tg_mul3(const void* a, const void* b, const void* c, void* out, float scale, int64_t numel, int dtype, void* stream);
+int tg_scale_dev(const void* x, const float* scalar, void* out, int64_t numel, int dtype, void* stream);
+int tg_dot(const void* a, const void* b, float* out, float* ws, int64_t numel, int dtype, void* stream);
+
+/* -------------------------------------------------------------------------------------------
  * Encoder-distillation loss -- replaces tf.nn.l2_normalize x2 + tf.losses.cosine_distance (twingan.py:507-521):
  *   out[0] = (weight / batch) * sum_b (1 - l2n(expected_b) . l2n(embedding_b)),  fp32 [batch, dim] operands.
  *   bwd: g_embedding = d out / d embedding * gscale[0]  (expected is dataset input: no gradient).

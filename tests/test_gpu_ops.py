@@ -769,3 +769,112 @@ def test_spectral_norm_matches_oracle(ops, k, cin, cout):
   assert rel_l2(host(w_bar), ref.detach().numpy()) < F32_TOL
   assert rel_l2(host(u_new), u1.detach().numpy()) < F32_TOL
   assert rel_l2(host(wd.grad), wt.grad.numpy()) < 5 * F32_TOL
+
+
+BGEMM_CASES = [
+    # batch, m, n, k     (attention: s = f g^T is (N, N, c/8); o = beta h is (N, c, N); their gradients transpose them)
+    (2, 64, 64, 2), (2, 64, 16, 64), (3, 256, 256, 8), (2, 256, 64, 256), (1, 130, 70, 36), (2, 33, 9, 5),
+    (2, 1024, 1024, 8), (2, 1024, 64, 1024),
+]
+
+
+@pytest.mark.parametrize('batch,m,n,k', BGEMM_CASES)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_batched_gemm_all_transposes(ops, batch, m, n, k, dtype):
+  """tg_batched_gemm (csrc/attention.hip): all four operand layouts of the MFMA kernel (ds_read_b128 for a K-contiguous
+  operand, the LDS transpose read for the other kind), ragged tiles and unaligned leading dimensions, against float64."""
+  rng = np.random.RandomState(11)
+  for ta in (False, True):
+    for tb in (False, True):
+      a = rng.randn(batch, k, m) if ta else rng.randn(batch, m, k)
+      b = rng.randn(batch, n, k) if tb else rng.randn(batch, k, n)
+      if dtype == torch.bfloat16:
+        a, b = bf16_round(a), bf16_round(b)
+      ref = np.matmul(a.transpose(0, 2, 1) if ta else a, b.transpose(0, 2, 1) if tb else b) * 0.5
+      c = ops.bgemm(to_dev(a, dtype), to_dev(b, dtype), ta, tb, 0.5)
+      assert rel_l2(host(c), ref) < (F32_TOL if dtype == torch.float32 else 4e-3), (ta, tb)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('rows,cols', [(6, 64), (10, 100), (4, 4096)])
+def test_softmax_rows_first_and_second_order(ops, rows, cols, dtype):
+  """Row softmax, its backward and the backward OF that backward (the gradient-penalty pass differentiates the
+  discriminator's attention twice) against float64 autograd."""
+  rng = np.random.RandomState(12)
+  s = rng.randn(rows, cols) * 2.0
+  w1 = rng.randn(rows, cols)
+  w2 = rng.randn(rows, cols)
+  if dtype == torch.bfloat16:
+    s, w1, w2 = bf16_round(s), bf16_round(w1), bf16_round(w2)
+  sd = to_dev(s, dtype).requires_grad_(True)
+  p = ops.softmax_rows(sd)
+  gs, = torch.autograd.grad(p, sd, grad_outputs=to_dev(w1, dtype), create_graph=True)
+  (gs * to_dev(w2, dtype)).sum().backward()
+  st = torch.from_numpy(s).requires_grad_(True)
+  pt = torch.softmax(st, dim=-1)
+  gst, = torch.autograd.grad(pt, st, grad_outputs=torch.from_numpy(w1), create_graph=True)
+  (gst * torch.from_numpy(w2)).sum().backward()
+  tol = F32_TOL if dtype == torch.float32 else 2e-2
+  assert rel_l2(host(p), pt.detach().numpy()) < (F32_TOL if dtype == torch.float32 else 4e-3)
+  assert rel_l2(host(gs), gst.detach().numpy()) < tol
+  assert rel_l2(host(sd.grad), st.grad.numpy()) < (5 * F32_TOL if dtype == torch.float32 else 5e-2)
+
+
+def test_tanh_and_scale_second_order(ops):
+  rng = np.random.RandomState(13)
+  x, w1, w2 = rng.randn(4, 33), rng.randn(4, 33), rng.randn(4, 33)
+  gam = np.array([0.7])
+  xd = to_dev(x).requires_grad_(True)
+  gd = to_dev(gam).requires_grad_(True)
+  y = ops.scale_dev(ops.tanh(xd), gd)
+  gx, = torch.autograd.grad(y, xd, grad_outputs=to_dev(w1), create_graph=True)
+  (gx * to_dev(w2)).sum().backward()
+  xt = torch.from_numpy(x).requires_grad_(True)
+  gt = torch.from_numpy(gam).requires_grad_(True)
+  yt = torch.tanh(xt) * gt
+  gxt, = torch.autograd.grad(yt, xt, grad_outputs=torch.from_numpy(w1), create_graph=True)
+  (gxt * torch.from_numpy(w2)).sum().backward()
+  assert rel_l2(host(y), yt.detach().numpy()) < F32_TOL and rel_l2(host(gx), gxt.detach().numpy()) < F32_TOL
+  assert rel_l2(host(xd.grad), xt.grad.numpy()) < 5 * F32_TOL and rel_l2(host(gd.grad), gt.grad.numpy()) < 5 * F32_TOL
+
+
+@pytest.mark.parametrize('hw,c,n', [(64, 64, 4), (16, 32, 3)])
+def test_self_attention_layer_bf16_at_config4_shape(hw, c, n):
+  """The whole SAGAN layer as the discriminator of BASELINE configs[4] runs it (64x64 map, 64 channels: N = 4096,
+  d = 8) on the MFMA batched GEMM, bf16, forward and first-order backward, against the float64 oracle on the same
+  bf16-rounded inputs and weights."""
+  from oracle import torch_ref as R2
+  from twingan_amd import Config, pggan
+  from twingan_amd.params import ParamStore
+  rng = np.random.RandomState(14)
+  sc = 'discriminator_s/self_attention_%dx%dx%d' % (hw, hw, c)
+  st = ParamStore('cuda:0')
+  for nm, co in (('sa_f', c // 8), ('sa_g', c // 8), ('sa_h', c)):
+    st.add_conv('%s/%s' % (sc, nm), 1, c, co, 'd', True, ())
+  st.add(sc + '/sa_gamma', (1,), 'd', 'beta')
+  st.build(0)
+  vals = {}
+  for k, spec in st.specs.items():
+    v = rng.randn(*spec['shape']) * (0.6 if k.endswith('weights') else 0.1)
+    vals[k] = bf16_round(v) if k.endswith('weights') else np.float32(v).astype(np.float64)
+  vals[sc + '/sa_gamma'] = np.array([0.8])
+  st.load_state_dict({k: torch.from_numpy(v) for k, v in vals.items()})
+  x = bf16_round(rng.randn(n, hw, hw, c) * 0.5)
+  cfg = Config(hw=hw, max_ch=c, precision='bf16', do_self_attention=True, self_attention_hw=hw)
+  for p_ in st.P.values():
+    p_.requires_grad_(True)
+  xd = to_dev(x, torch.bfloat16).requires_grad_(True)
+  y = pggan.self_attention_layer(st.P, sc, xd, None, cfg, True)
+  gy = bf16_round(rng.randn(*x.shape))
+  y.backward(to_dev(gy, torch.bfloat16))
+  Pt = {k: torch.from_numpy(v).requires_grad_(True) for k, v in vals.items()}
+  xt = torch.from_numpy(x).requires_grad_(True)
+  rcfg = R2.Config(hw=hw, max_ch=c, do_self_attention=True, self_attention_hw=hw)
+  yt = R2.self_attention(Pt, sc, xt, None, rcfg, True)
+  yt.backward(torch.from_numpy(gy))
+  assert rel_l2(host(y), yt.detach().numpy()) < 1e-2
+  assert rel_l2(host(xd.grad), xt.grad.numpy()) < 3e-2
+  gd = st.grad_dict()
+  for k in vals:
+    ref = Pt[k].grad.numpy()
+    assert rel_l2(gd[k].double().cpu().numpy(), ref) < 3e-2, k

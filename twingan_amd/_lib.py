@@ -94,6 +94,16 @@ SIGNATURES = {
     'tg_gp_penalty': (c_int, [_FP, _FP, _FP, c_int, c_float, _P]),
     'tg_adam_step': (c_int, [_FP, _FP, _FP, _FP, _P, c_int64, c_float, _FP, c_float, c_float, c_float, c_float, _P]),
     'tg_adam_tick': (c_int, [_P, _FP, c_float, c_float, c_float, _P]),
+    'tg_batched_gemm': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64,
+                                c_int64, c_float, c_int, c_int, c_int, _P]),
+    'tg_softmax_rows_fwd': (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
+    'tg_softmax_rows_bwd': (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P]),
+    'tg_softmax_rows_bwd_bwd': (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
+    'tg_tanh_fwd': (c_int, [_P, _P, c_int64, c_int, _P]),
+    'tg_tanh_bwd': (c_int, [_P, _P, _P, c_int64, c_int, _P]),
+    'tg_mul3': (c_int, [_P, _P, _P, _P, c_float, c_int64, c_int, _P]),
+    'tg_scale_dev': (c_int, [_P, _FP, _P, c_int64, c_int, _P]),
+    'tg_dot': (c_int, [_P, _P, _FP, _FP, c_int64, c_int, _P]),
     'tg_cosine_distance_fwd': (c_int, [_FP, _FP, _FP, c_int, c_int, c_float, _P]),
     'tg_cosine_distance_bwd': (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_float, _P]),
     'tg_spectral_norm_workspace': (c_size_t, [c_int, c_int]),

@@ -1238,6 +1238,190 @@ def minibatch_state_concat(x, cpad, groups=1):
 
 
 # ------------------------------------------------------------------------------------------------
+# SAGAN self-attention pieces (libs/self_attention.py:57-69): every op's backward is made of the same ops
+# ------------------------------------------------------------------------------------------------
+class BGemmFn(torch.autograd.Function):
+  """c[i] = alpha * op(a[i]) @ op(b[i]) for 3-D contiguous a, b (tg_batched_gemm); both gradients are BGemmFn again."""
+
+  @staticmethod
+  def forward(ctx, a, b, ta, tb, alpha):
+    _chk(a, b)
+    assert a.dim() == 3 and b.dim() == 3 and a.shape[0] == b.shape[0] and a.dtype == b.dtype
+    m = a.shape[2] if ta else a.shape[1]
+    k = a.shape[1] if ta else a.shape[2]
+    n = b.shape[1] if tb else b.shape[2]
+    assert (b.shape[2] if tb else b.shape[1]) == k, (a.shape, b.shape, ta, tb)
+    c = torch.empty((a.shape[0], m, n), dtype=a.dtype, device=a.device)
+    call('tg_batched_gemm', _p(a), _p(b), _p(c), a.shape[0], m, n, k, int(ta), int(tb), a.shape[2], b.shape[2], n,
+         a.shape[1] * a.shape[2], b.shape[1] * b.shape[2], m * n, alpha, 0, _dt(a), 0, _stream(),
+         work=('bgemm:%dx%dx%d:b%d' % (m, n, k, a.shape[0]), 2 * a.shape[0] * m * n * k, _nb(a, b, c)))
+    ctx.ta, ctx.tb, ctx.alpha = ta, tb, alpha
+    ctx.save_for_backward(a, b)
+    return c
+
+  @staticmethod
+  def backward(ctx, g):
+    a, b = ctx.saved_tensors
+    g = g.contiguous()
+    ta, tb, al = ctx.ta, ctx.tb, ctx.alpha
+    ga = gb = None
+    if ctx.needs_input_grad[0]:
+      ga = BGemmFn.apply(b, g, tb, True, al) if ta else BGemmFn.apply(g, b, False, not tb, al)
+    if ctx.needs_input_grad[1]:
+      gb = BGemmFn.apply(g, a, True, ta, al) if tb else BGemmFn.apply(a, g, not ta, False, al)
+    return ga, gb, None, None, None
+
+
+def bgemm(a, b, ta=False, tb=False, alpha=1.0):
+  return BGemmFn.apply(a.contiguous(), b.contiguous(), bool(ta), bool(tb), float(alpha))
+
+
+class SoftmaxRowsFn(torch.autograd.Function):
+  """softmax over the last axis (tf.nn.softmax(s, axis=-1), libs/self_attention.py:63)."""
+
+  @staticmethod
+  def forward(ctx, s):
+    _chk(s)
+    p = torch.empty_like(s)
+    cols = s.shape[-1]
+    call('tg_softmax_rows_fwd', _p(s), _p(p), s.numel() // cols, cols, _dt(s), _stream(),
+         work=('softmax_fwd:cols%d:rows%d' % (cols, s.numel() // cols), 0, _nb(s, p)))
+    ctx.save_for_backward(p)
+    return p
+
+  @staticmethod
+  def backward(ctx, dp):
+    p, = ctx.saved_tensors
+    return SoftmaxRowsBwdFn.apply(p, dp.contiguous())
+
+
+class SoftmaxRowsBwdFn(torch.autograd.Function):
+  """ds = p * (dp - sum(dp * p)); its gradient in dp is the same map of v, in p the tg_softmax_rows_bwd_bwd kernel."""
+
+  @staticmethod
+  def forward(ctx, p, dp):
+    _chk(p, dp)
+    ds = torch.empty_like(p)
+    cols = p.shape[-1]
+    call('tg_softmax_rows_bwd', _p(p), _p(dp), _p(ds), p.numel() // cols, cols, _dt(p), _stream(),
+         work=('softmax_bwd:cols%d:rows%d' % (cols, p.numel() // cols), 0, _nb(p, dp, ds)))
+    ctx.save_for_backward(p, dp)
+    return ds
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, v):
+    p, dp = ctx.saved_tensors
+    v = v.contiguous()
+    cols = p.shape[-1]
+    gp = None
+    if ctx.needs_input_grad[0]:
+      gp = torch.empty_like(p)
+      call('tg_softmax_rows_bwd_bwd', _p(p), _p(dp), _p(v), _p(gp), p.numel() // cols, cols, _dt(p), _stream())
+    gdp = None
+    if ctx.needs_input_grad[1]:
+      gdp = torch.empty_like(p)
+      call('tg_softmax_rows_bwd', _p(p), _p(v), _p(gdp), p.numel() // cols, cols, _dt(p), _stream())
+    return gp, gdp
+
+
+def softmax_rows(s):
+  return SoftmaxRowsFn.apply(s.contiguous())
+
+
+class TanhFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x):
+    _chk(x)
+    y = torch.empty_like(x)
+    call('tg_tanh_fwd', _p(x), _p(y), x.numel(), _dt(x), _stream())
+    ctx.save_for_backward(y)
+    return y
+
+  @staticmethod
+  def backward(ctx, g):
+    y, = ctx.saved_tensors
+    return TanhBwdFn.apply(g.contiguous(), y)
+
+
+class TanhBwdFn(torch.autograd.Function):
+  """gx = g * (1 - y^2); d/dg = the same map of v, d/dy = -2 y g v (tg_mul3)."""
+
+  @staticmethod
+  def forward(ctx, g, y):
+    _chk(g, y)
+    gx = torch.empty_like(g)
+    call('tg_tanh_bwd', _p(g), _p(y), _p(gx), g.numel(), _dt(g), _stream())
+    ctx.save_for_backward(g, y)
+    return gx
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, v):
+    g, y = ctx.saved_tensors
+    v = v.contiguous()
+    gg = gy = None
+    if ctx.needs_input_grad[0]:
+      gg = torch.empty_like(g)
+      call('tg_tanh_bwd', _p(v), _p(y), _p(gg), g.numel(), _dt(g), _stream())
+    if ctx.needs_input_grad[1]:
+      gy = torch.empty_like(g)
+      call('tg_mul3', _p(y), _p(g), _p(v), _p(gy), -2.0, g.numel(), _dt(g), _stream())
+    return gg, gy
+
+
+def tanh(x):
+  return TanhFn.apply(x.contiguous())
+
+
+class ScaleDevFn(torch.autograd.Function):
+  """x * s for a device fp32 scalar s [1] (sa_gamma): d/dx = g * s, d/ds = <g, x> (DotFn) -- bilinear, closed."""
+
+  @staticmethod
+  def forward(ctx, x, s):
+    _chk(x, s)
+    assert s.dtype == torch.float32 and s.numel() == 1
+    out = torch.empty_like(x)
+    call('tg_scale_dev', _p(x), _p(s), _p(out), x.numel(), _dt(x), _stream())
+    ctx.save_for_backward(x, s)
+    return out
+
+  @staticmethod
+  def backward(ctx, g):
+    x, s = ctx.saved_tensors
+    g = g.contiguous()
+    gx = ScaleDevFn.apply(g, s) if ctx.needs_input_grad[0] else None
+    gs = DotFn.apply(g, x).reshape(s.shape) if ctx.needs_input_grad[1] else None
+    return gx, gs
+
+
+class DotFn(torch.autograd.Function):
+  """<a, b> over all elements -> fp32 [1] (two-stage sum in a fixed order)."""
+
+  @staticmethod
+  def forward(ctx, a, b):
+    _chk(a, b)
+    assert a.shape == b.shape and a.dtype == b.dtype
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    ws = torch.empty(1024, dtype=torch.float32, device=a.device)
+    call('tg_dot', _p(a), _p(b), _p(out), _p(ws), a.numel(), _dt(a), _stream())
+    ctx.save_for_backward(a, b)
+    return out
+
+  @staticmethod
+  def backward(ctx, v):
+    a, b = ctx.saved_tensors
+    v = v.contiguous().float()
+    ga = ScaleDevFn.apply(b, v) if ctx.needs_input_grad[0] else None
+    gb = ScaleDevFn.apply(a, v) if ctx.needs_input_grad[1] else None
+    return ga, gb
+
+
+def scale_dev(x, s):
+  return ScaleDevFn.apply(x.contiguous(), s)
+
+
+# ------------------------------------------------------------------------------------------------
 # spectral normalisation of a conv kernel (libs/sn.py:38-101)
 # ------------------------------------------------------------------------------------------------
 class SpectralNormFn(torch.autograd.Function):

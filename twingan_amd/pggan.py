@@ -75,10 +75,10 @@ def end_run(P):
 def self_attention_layer(P, sc, layer, domain, cfg, is_discriminator, cond=None):
   """libs/self_attention.py:24-70 (SAGAN): f, g = tanh(conv1x1 -> c/8), h = conv1x1 -> c under the scope's arg-scope
   (bias in D; the generator normaliser, no bias, in G / E -- nets/pggan_utils.py:86-98), s = f g^T over the h*w
-  positions, beta = softmax(s), o = beta h, y = sa_gamma * o + layer.  The two batched matrix products run on the
-  library GEMM and the softmax on the framework kernel (config-5-only path; a fused MFMA attention kernel is the
-  next step for it); everything is differentiable twice (the discriminator sits under the gradient penalty)."""
-  import torch
+  positions, beta = softmax(s), o = beta h, y = sa_gamma * o + layer.  The two batched matrix products are the MFMA
+  batched GEMM of csrc/attention.hip, softmax / tanh / the sa_gamma scale its row and pointwise kernels; every op's
+  backward is made of the same ops, so the layer is differentiable twice on them (the discriminator sits under the
+  gradient penalty)."""
   n, hh, ww, c = layer.shape
   outs = []
   for nm in ('sa_f', 'sa_g', 'sa_h'):
@@ -88,13 +88,13 @@ def self_attention_layer(P, sc, layer, domain, cfg, is_discriminator, cond=None)
       y = ops.conv2d(layer, w, b, 1, 'SAME')      # libs.sn.convolution directly: no equalized-lr input scaling
     else:
       y = _ge_conv(P, scope, layer, domain, cfg, k=1, activation=False, pixel_norm=False, equalize=False, cond=cond)
-    outs.append(torch.tanh(y) if nm != 'sa_h' else y)
+    outs.append(ops.tanh(y) if nm != 'sa_h' else y)
   f, g, h = outs
   npos = hh * ww
-  s = torch.bmm(f.reshape(n, npos, -1), g.reshape(n, npos, -1).transpose(1, 2))
-  beta = torch.softmax(s.float(), dim=-1).to(s.dtype)
-  o = torch.bmm(beta, h.reshape(n, npos, c)).reshape(layer.shape)
-  return P[sc + '/sa_gamma'].to(layer.dtype) * o + layer
+  s = ops.bgemm(f.reshape(n, npos, -1), g.reshape(n, npos, -1), False, True)      # tf.matmul(f, g, transpose_b=True)
+  beta = ops.softmax_rows(s)
+  o = ops.bgemm(beta, h.reshape(n, npos, c), False, False).reshape(layer.shape)
+  return ops.add(ops.scale_dev(o, P[sc + '/sa_gamma']), layer)
 
 
 def maybe_add_self_attention(P, top, hw, name_channels, net, end_points, domain, cfg, is_discriminator=False, cond=None):
