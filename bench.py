@@ -39,8 +39,9 @@ def parse():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=6)
   ap.add_argument('--warmup', type=int, default=2)
-  ap.add_argument('--config', type=int, default=3, choices=[1, 2, 3],
-                  help="BASELINE.json configs[i]: 1 = 64x64 batch 64, 2 = 128x128 batch 32, 3 = 256x256 batch 16 per GPU (the metric's)")
+  ap.add_argument('--config', type=int, default=3, choices=[1, 2, 3, 4],
+                  help="BASELINE.json configs[i]: 1 = 64x64 batch 64, 2 = 128x128 batch 32, 3 = 256x256 batch 16 per GPU (the "
+                       "metric's), 4 = 3 + self-attention at 64x64 + spectral-norm discriminators + loss scale 128")
   ap.add_argument('--batch', type=int, default=None, help='pairs per GPU (default: the config\'s)')
   ap.add_argument('--hw', type=int, default=None)
   ap.add_argument('--max-ch', type=int, default=256)
@@ -57,7 +58,7 @@ def parse():
                   help='no kernels: bring up the N ranks, build the parameter store and time the per-segment gradient '
                        'all-reduce schedule of a step (gloo on CPU when no GPU is visible) -- tests the launcher')
   args = ap.parse_args()
-  hw, batch = {1: (64, 64), 2: (128, 32), 3: (256, 16)}[args.config]
+  hw, batch = {1: (64, 64), 2: (128, 32), 3: (256, 16), 4: (256, 16)}[args.config]
   args.hw = args.hw or hw
   args.batch = args.batch or batch
   return args
@@ -331,13 +332,14 @@ def main():
 
   def base_line(value, ms_per_step, launch):
     return {
-        'metric': METRIC if args.hw == 256 else 'training images/sec (G+D step) at %dx%d' % (args.hw, args.hw),
+        'metric': METRIC if (args.hw == 256 and args.config == 3) else ('training images/sec (G+D step) at 256x256 + self-attention + spectral norm' if args.config == 4 else 'training images/sec (G+D step) at %dx%d' % (args.hw, args.hw)),
         'value': value, 'unit': 'images/sec', 'n_gpus': observed_world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.precision, 'data': 'synthetic',
         'config': {'workload': 'TwinGAN %dx%d stage, batch %d per GPU (configs[%d]): E/G/2xD max_ch %d, UNet + per-domain '
-                               'instance norm + pixel norm, WGAN-GP, Adam; 1 step = G apply + D apply' % (
-                                   args.hw, args.hw, args.batch, args.config, args.max_ch),
+                               'instance norm + pixel norm%s, WGAN-GP, Adam; 1 step = G apply + D apply' % (
+                                   args.hw, args.hw, args.batch, args.config, args.max_ch,
+                                   ' + self-attention at 64x64 + spectral-norm D + loss scale 128' if args.config == 4 else ''),
                    'global_batch': args.batch * observed_world, 'batch_per_gpu': args.batch,
                    'parallelism': 'dp%d' % observed_world, 'launch': launch,
                    'collective': ('%s all-reduce, world %d' % ('RCCL' if backend == 'nccl' else backend, observed_world))
@@ -357,7 +359,13 @@ def main():
 
   from twingan_amd import Config
   from twingan_amd.twingan import Trainer
-  cfg = Config(hw=args.hw, max_ch=args.max_ch, precision=args.precision)
+  extra = {}
+  if args.config == 4:
+    # configs[4]: SAGAN attention (libs/self_attention.py) in E / G / D at 64x64, spectral-norm discriminators
+    # (libs/sn.py), static loss scale 128 (model_inheritor.py:568-570).  Storage is bf16 here, not fp16: the kernels'
+    # half-precision type is bf16 (fp32 accumulation either way); the loss-scale path is exercised as configured.
+    extra = dict(do_self_attention=True, self_attention_hw=64, spectral_norm=True, loss_scale=128.0)
+  cfg = Config(hw=args.hw, max_ch=args.max_ch, precision=args.precision, **extra)
   overlap = None if args.overlap == 'auto' else args.overlap == 'on'
   tr = Trainer(cfg, device=device, seed=0, world_size=world, use_graph=not args.no_graph, overlap=overlap)
   dtype = torch.bfloat16 if args.precision == 'bf16' else torch.float32
