@@ -214,6 +214,11 @@ int main(int argc, char** argv) {
     printf("%-7s %-5s %4d %4d>%-4d | %9.1f %8.0f %8.1f %9.2e\n", c.name, "dgrad", c.hw, c.cin, c.cout, t, bytes / t * 1e-3,
            flops / t * 1e-6, e_d);
     }
+    if (only_op && !strcmp(only_op, "mdgrad")) {      // backward-data with the producer's LeakyReLU mask in the epilogue
+    t = time_us([&] { TC(tg_conv2d_bwd_data_masked(&d0, gy, p1, x, gx, nullptr)); }, iters);
+    printf("%-7s %-5s %4d %4d>%-4d | %9.1f %8.0f %8.1f %9.2e\n", c.name, "mdgrd", c.hw, c.cin, c.cout, t,
+           (bytes + 2.0 * px * c.cin) / t * 1e-3, flops / t * 1e-6, -1.0);
+    }
     if (!only_op || !strcmp(only_op, "wgrad")) {
     t = time_us([&] { TC(tg_conv2d_bwd_weight(&d0, x, gy, gw, 0, ws, wsb, nullptr)); }, iters);
     printf("%-7s %-5s %4d %4d>%-4d | %9.1f %8.0f %8.1f %9.2e\n", c.name, "wgrad", c.hw, c.cin, c.cout, t, bytes / t * 1e-3,

@@ -364,9 +364,18 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
   const size_t img_elems = (size_t)g.h * g.w * g.cin;
   const size_t out_img = (size_t)g.h * g.w * g.cout;
 
-  bf16x8 ra[ASLOTS];
-  // loads chunk `ch` of tile `t` into ra
-  auto load_a = [&](int t, int ch) {
+  static_assert(NCH == 1, "the weight-resident kernel is dispatched for single-chunk layers (cin_pad <= 32)");
+  // One register stage (the halo of tile t+1 is in flight while tile t is reduced).  Measured and not kept: two stages
+  // (t+1 and t+2 in flight) -- 100 instead of 84 VGPRs = 4 instead of 5 workgroups per CU, 70 vs 65 us on 256x256x16
+  // n64 in an A/B on one box.  A pure copy with the same 8x16-tile + halo access pattern and 8 workgroups per CU
+  // reaches 5.2-5.7 TB/s (tools/probes/tile_copy.hip; a flat copy 6.8): resident workgroups, not prefetch depth or the
+  // 2-D pattern, are what this kernel is short of.
+  struct Stage {
+    bf16x8 ra[ASLOTS];
+  };
+  auto load_a = [&](Stage& st, int t) __attribute__((always_inline)) {
+    const unsigned live = t < t_end;
+    if (!live) t = t_begin;
     const int tx = t % g.tiles_x;
     const int r = t / g.tiles_x;
     const int ty = r % g.tiles_y;
@@ -375,9 +384,9 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
 #pragma unroll
     for (int s = 0; s < ASLOTS; ++s) {
       const int iy = ty * TH + a_hy[s] - g.pad, ix = tx * TW + a_hx[s] - g.pad;
-      const bool ok = iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
+      const bool ok = live && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
       const int part8 = ((tid + s * 256) % VPP) * 8;
-      ra[s] = buf_load16(rx, ok ? (unsigned)(((iy * g.w + ix) * g.cin + part8 + ch * KC) * 2) : OOB);
+      st.ra[s] = buf_load16(rx, ok ? (unsigned)(((iy * g.w + ix) * g.cin + part8) * 2) : OOB);
     }
   };
 
@@ -390,50 +399,57 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
       bq[nt][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                  rbias, (unsigned)((n0 + nt * 32 + q * 8 + kgrp * 4) * 4), 0, 0));
 
-  if (t_begin < t_end) load_a(t_begin, 0);
   bool first = true;
-  for (int t = t_begin; t < t_end; ++t) {
+  // one tile: stage -> LDS, refill the stage with tile t + 1, MFMAs, epilogue
+  auto process = [&](Stage& st, int t) __attribute__((always_inline)) {
+    const int tx = t % g.tiles_x;
+    const int r = t / g.tiles_x;
+    const int ty = r % g.tiles_y;
+    const int img = r / g.tiles_y;
+    const int oy = ty * TH + wid * 2 + (l31 >> 4), ox = tx * TW + (l31 & 15);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + (size_t)img * out_img, (unsigned)(out_img * 2));
+    const __amdgpu_buffer_rsrc_t rmask =
+        make_rsrc(g.mask ? g.mask + (size_t)img * out_img : y, g.mask ? (unsigned)(out_img * 2) : 0u);
+    if (!first) __syncthreads();          // everyone finished reading the previous halo
+    first = false;
+#pragma unroll
+    for (int s = 0; s < ASLOTS; ++s)
+      if (s < ASLOTS - 1 || tid + s * 256 < AVEC) *reinterpret_cast<bf16x8*>(sA + a_loff[s]) = st.ra[s];
+    __syncthreads();                      // (the first one also covers the weight staging)
+    load_a(st, t + 1);
+    // the LeakyReLU mask of the epilogue (masked backward-data) is requested NOW, so that it lands during the MFMAs
+    u32x2 zm[NTILE][4];
+    if (g.mask) {      // uniform
+#pragma unroll
+      for (int nt = 0; nt < NTILE; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int chq = n0 + nt * 32 + q * 8 + kgrp * 4;
+          zm[nt][q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
+              rmask, chq + 4 <= g.cout ? (unsigned)(((oy * g.w + ox) * g.cout + chq) * 2) : OOB, 0, 0));
+        }
+    }
     f32x16 acc[NTILE];
 #pragma unroll
     for (int i = 0; i < NTILE; ++i)
 #pragma unroll
       for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-      if (!first) __syncthreads();          // everyone finished reading the previous halo chunk
-      first = false;
+    for (int ky = 0; ky < KH; ++ky) {
 #pragma unroll
-      for (int s = 0; s < ASLOTS; ++s)
-        if (s < ASLOTS - 1 || tid + s * 256 < AVEC) *reinterpret_cast<bf16x8*>(sA + a_loff[s]) = ra[s];
-      __syncthreads();                      // (the first one also covers the weight staging)
-      if (ch + 1 < NCH) load_a(t, ch + 1);
-      else if (t + 1 < t_end) load_a(t + 1, 0);
+      for (int kx = 0; kx < KW; ++kx) {
 #pragma unroll
-      for (int ky = 0; ky < KH; ++ky) {
+        for (int kk = 0; kk < KC / 16; ++kk) {
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sA + a_base + (ky * HWX + kx) * PS_A + kk * 32);
 #pragma unroll
-        for (int kx = 0; kx < KW; ++kx) {
-#pragma unroll
-          for (int kk = 0; kk < KC / 16; ++kk) {
-            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sA + a_base + (ky * HWX + kx) * PS_A + kk * 32);
-#pragma unroll
-            for (int nt = 0; nt < NTILE; ++nt) {
-              const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sB + ch * B_BYTES + b_base + nt * 32 * RS_B +
-                                                                 ((ky * KW + kx) * KC + kk * 16) * 2);
-              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[nt], 0, 0, 0);
-            }
+          for (int nt = 0; nt < NTILE; ++nt) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sB + b_base + nt * 32 * RS_B + ((ky * KW + kx) * KC + kk * 16) * 2);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[nt], 0, 0, 0);
           }
         }
       }
     }
     // ---- epilogue of tile t
-    const int tx = t % g.tiles_x;
-    const int r = t / g.tiles_x;
-    const int ty = r % g.tiles_y;
-    const int img = r / g.tiles_y;
-    const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + (size_t)img * out_img, (unsigned)(out_img * 2));
-    const __amdgpu_buffer_rsrc_t rmask =
-        make_rsrc(g.mask ? g.mask + (size_t)img * out_img : y, g.mask ? (unsigned)(out_img * 2) : 0u);
-    const int oy = ty * TH + wid * 2 + (l31 >> 4), ox = tx * TW + (l31 & 15);
 #pragma unroll
     for (int nt = 0; nt < NTILE; ++nt) {
       unsigned p[4][2];
@@ -446,12 +462,12 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
           if (g.epilogue & TG_EPI_LRELU) a = lrelu_f(a, g.alpha);
           v[j] = a;
         }
-        if (g.mask) {      // uniform
-          const int chq = n0 + nt * 32 + q * 8 + kgrp * 4;
-          float f[4];
-          mask4(rmask, chq + 4 <= g.cout ? (unsigned)(((oy * g.w + ox) * g.cout + chq) * 2) : OOB, g.alpha, f);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] *= f[j];
+        if (g.mask) {      // uniform: a positive bf16 is a positive int16 pattern
+          const u32x2 z = zm[nt][q];
+          v[0] *= (short)(z[0] & 0xffffu) > 0 ? 1.f : g.alpha;
+          v[1] *= (short)(z[0] >> 16) > 0 ? 1.f : g.alpha;
+          v[2] *= (short)(z[1] & 0xffffu) > 0 ? 1.f : g.alpha;
+          v[3] *= (short)(z[1] >> 16) > 0 ? 1.f : g.alpha;
         }
         p[q][0] = pack_bf16x2(v[0], v[1]);
         p[q][1] = pack_bf16x2(v[2], v[3]);
@@ -471,7 +487,11 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
       __builtin_amdgcn_raw_buffer_store_b128(o0, ry, (ch0 + 8 <= g.cout) ? off : OOB, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128(o1, ry, (ch0 + 16 <= g.cout) ? off + 16 : OOB, 0, 0);
     }
-  }
+  };
+
+  Stage sa;
+  load_a(sa, t_begin);
+  for (int t = t_begin; t < t_end; ++t) process(sa, t);
 }
 
 template <int KH, int KC, int BN, int NCH>
