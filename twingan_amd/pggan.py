@@ -254,6 +254,28 @@ def _cond_batch_norm(P, scope, y, cond, segs, passes, activation, pn, pool, cfg)
   return ops.affine_act(yhat, g_rows, b_rows, lrelu=activation, pixel_norm=pn, pool=pool)
 
 
+def _batch_norm_inference(P, scope, y, d0, d1, split, cond, activation, pn, pool):
+  """conditional_batch_norm(is_training=False), with or without renorm (libs/batch_norm.py:403-470): normalise with the
+  domain's MOVING mean / variance -- one (mean, rstd, gamma, beta) row per image through the fused kernel's
+  per-image-row mode.  ``cond``: the l2-normalised embedding gives gamma = 1 + FC, beta = FC per image."""
+  import torch
+  n, h, w, c = y.shape
+  segs = [(d0, 0, n)] if d1 is None else [(d0, 0, split), (d1, split, n)]
+  st = P.state
+  pre = scope + '/BatchNorm/'
+  mean = torch.cat([st[pre + 'moving_mean' + _pf(d)].expand(hi - lo, c) for d, lo, hi in segs])
+  rstd = torch.cat([torch.rsqrt(st[pre + 'moving_variance' + _pf(d)] + BN_EPS).expand(hi - lo, c) for d, lo, hi in segs])
+  if cond is not None:
+    cn = cond.float()
+    cn = cn / cn.pow(2).sum(dim=1, keepdim=True).clamp_min(1e-12).sqrt()
+    g_rows, b_rows = _cond_rows(P, scope, 'BatchNorm', cn, segs)
+  else:
+    g_rows = torch.cat([P[pre + 'gamma' + _pf(d)].expand(hi - lo, c) for d, lo, hi in segs])
+    b_rows = torch.cat([P[pre + 'beta' + _pf(d)].expand(hi - lo, c) for d, lo, hi in segs])
+  return ops.norm_act(y, g_rows.contiguous(), b_rows.contiguous(), lrelu=activation, pixel_norm=pn, in_eps=BN_EPS, pool=pool,
+                      stats=(mean.contiguous().reshape(-1), rstd.contiguous().reshape(-1)))
+
+
 BN_EPS = 1e-3            # libs/batch_norm.py:48
 RENORM_MOMENTUM = 0.99   # libs/batch_norm.py:62; the moving averages use the same decay (nets/pggan_utils.py:163)
 
