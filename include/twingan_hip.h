@@ -117,6 +117,19 @@ int tg_conv2d_bwd_weight2_bias(const TgConvDesc* d, int nb, const void* xa, cons
 int tg_conv2d_upcat_supported(int h, int w, int c0, int c1, int cout);
 int tg_conv2d_upcat_fwd(const void* x0, const void* x1, const void* w_pack, void* y, int n, int h, int w, int c0, int c1,
                         int cout, int gsz, unsigned perm, void* stream);
+/* Conv followed by a normaliser (every encoder / generator conv: layers.conv2d(normalizer_fn=instance_norm),
+ * nets/pggan_utils.py:86-98 -> tf.nn.moments over the conv output, libs/instance_norm.py:131): the forward conv also
+ * writes, per output channel, the sum and the sum of squares of the (bf16-rounded) outputs each workgroup produced --
+ * partials fp32 [n][chunks][2][cout], unshifted, summed in a fixed order -- so that the moments need no second read of
+ * y (tg_norm_act_fwd_conv_stats consumes them).  tg_conv2d_fwd_stats_chunks: chunks per image for this descriptor, or 0
+ * when the kernel it dispatches has no statistics epilogue (the caller then uses tg_instance_norm_partials).  Plain
+ * epilogue only (d->epilogue == 0: normalised convs have no bias), 3x3, MFMA path. */
+int tg_conv2d_fwd_stats_chunks(const TgConvDesc* d);
+int tg_conv2d_fwd_stats(const TgConvDesc* d, const void* x, const void* w_pack, void* y, float* partials, int chunks,
+                        void* stream);
+int tg_conv2d_upcat_fwd_stats_chunks(int n, int h, int w, int c0, int c1, int cout);
+int tg_conv2d_upcat_fwd_stats(const void* x0, const void* x1, const void* w_pack, void* y, float* partials, int chunks,
+                              int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, void* stream);
 size_t tg_conv2d_upcat_bwd_weight_workspace(int n, int h, int w, int c0, int c1, int cout);
 int tg_conv2d_upcat_bwd_weight(const void* x0, const void* x1, const void* gy, float* gw, int accumulate, void* workspace,
                                size_t workspace_bytes, int n, int h, int w, int c0, int c1, int cout, int gsz,
@@ -179,6 +192,12 @@ int tg_norm_act_fwd_partials(const void* y, const float* partials, float* mean, 
                              const float* beta, const float* gamma2, const float* beta2, int split, void* z,
                              void* z_pooled, float* pn_scale, int n, int h, int w, int c, int flags, float lrelu_alpha,
                              float in_eps, float pn_eps, int dtype, void* stream);
+/* tg_norm_act_fwd_partials fed by the partial sums of the producing conv (tg_conv2d_fwd_stats /
+ * tg_conv2d_upcat_fwd_stats: [n][part_chunks][2][c], unshifted). */
+int tg_norm_act_fwd_conv_stats(const void* y, const float* partials, int part_chunks, float* mean, float* rstd,
+                               const float* gamma, const float* beta, const float* gamma2, const float* beta2, int split,
+                               void* z, void* z_pooled, float* pn_scale, int n, int h, int w, int c, int flags,
+                               float lrelu_alpha, float in_eps, float pn_eps, int dtype, void* stream);
 /* Backward of tg_norm_act_fwd.  Inputs: gz [n,h,w,c] and/or gz_pooled [n,h/2,w/2,c] (either may be NULL; the
  * layer-output gradient is gz + 0.25 * upsample(gz_pooled): the tf.nn.avg_pool that follows an encoder block,
  * nets/pggan.py:436,468, is folded in), y (raw conv output), pn_scale, mean, rstd, gamma, beta (+ 2nd domain).

@@ -58,6 +58,17 @@ def _rand_bf16(shape, seed):
   return torch.randn(shape, generator=g, device='cuda', dtype=torch.float32).to(torch.bfloat16).contiguous()
 
 
+def _check_partials(st, y, key):
+  """sum over chunks of the conv's statistics partials == (sum y, sum y^2) per image and channel of the tensor it wrote."""
+  n, h, w, c = y.shape
+  part = st.part.view(n, st.chunks, 2, c).double().sum(dim=1)
+  yd = y.double().view(n, h * w, c)
+  s1, s2 = yd.sum(dim=1), (yd * yd).sum(dim=1)
+  e1 = float(((part[:, 0] - s1).abs() / (s2 * h * w).sqrt().clamp_min(1e-30)).max())
+  e2 = float((part[:, 1] / s2.clamp_min(1e-30) - 1).abs().max())
+  assert e1 < 2e-6 and e2 < 2e-6, ('statistics partials', key, e1, e2)
+
+
 class _Direct:
   """Forces the direct (one thread per output) algorithm inside the block."""
 
@@ -103,6 +114,22 @@ def test_conv_variants_at_bench_shapes(key):
         e = rel_l2(host(y), host(yd))
         assert e < VS_DIRECT_TOL, ('fwd vs direct', key, n, e)
       del y, yd
+
+  # ---- forward with the statistics epilogue (every normalised encoder / generator conv): the same tensor as the plain
+  # forward, bit for bit, and partial sums that add up to the sums of that tensor
+  for n in (int(v) for v in eps.get('tg_conv2d_fwd_stats', [])):
+    y, st = O.conv_fwd_stats_raw(x[:n], w, spec)
+    _note(key, 'tg_conv2d_fwd_stats', str(n))
+    assert st is not None, ('no statistics epilogue', key, n)
+    sel = sorted({0, n - 1})
+    e = rel_l2(host(y[sel]), N.conv2d_gemm(host(x[sel]), wn, pad))
+    assert e < BF16_OUT_TOL, ('fwd_stats', key, n, e)
+    with _Direct():
+      yd = O.conv_fwd_raw(x[:n], w, None, spec, 0)
+    e = rel_l2(host(y), host(yd))
+    assert e < VS_DIRECT_TOL, ('fwd_stats vs direct', key, n, e)
+    _check_partials(st, y, key)
+    del y, yd
 
   # ---- backward-data, plain and with the producer's LeakyReLU mask in the epilogue
   for ep in ('tg_conv2d_bwd_data', 'tg_conv2d_bwd_data_masked'):
@@ -173,8 +200,14 @@ def test_upcat_conv_at_bench_shapes(key):
   assert O.upcat_conv_supported(x0, x1, w)
   x0.requires_grad_(True)
   x1.requires_grad_(True)
-  y = O.upcat_conv(x0, x1, w, gsz, perm)
-  _note(key, 'tg_conv2d_upcat_fwd', str(n))
+  if 'tg_conv2d_upcat_fwd_stats' in LAYERS[key]:
+    y, st = O.upcat_conv_stats(x0, x1, w, gsz, perm)
+    _note(key, 'tg_conv2d_upcat_fwd_stats', str(n))
+    assert st is not None, ('no statistics epilogue', key)
+    _check_partials(st, y.detach(), key)
+  else:
+    y = O.upcat_conv(x0, x1, w, gsz, perm)
+    _note(key, 'tg_conv2d_upcat_fwd', str(n))
   wn = host(w)
 
   def cat_of(i):      # the materialised input of image i

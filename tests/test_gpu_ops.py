@@ -878,3 +878,61 @@ def test_self_attention_layer_bf16_at_config4_shape(hw, c, n):
   for k in vals:
     ref = Pt[k].grad.numpy()
     assert rel_l2(gd[k].double().cpu().numpy(), ref) < 3e-2, k
+
+
+# ------------------------------------------------------------------------- conv with the statistics epilogue
+STATS_CASES = [
+    # n, hw, cin, cout  -> kernel family
+    (4, 256, 16, 16),     # weight-resident thin kernel, several tiles per workgroup
+    (4, 256, 16, 32),
+    (8, 128, 32, 64),     # weight-resident, 64-channel blocks
+    (3, 64, 64, 64),      # tile kernel, two sub-tiles per wave
+    (2, 32, 128, 256),    # tile kernel, channel blocks along grid y
+    (3, 16, 256, 256),    # tile kernel, 2 tiles per image
+    (2, 16, 40, 24),      # ragged channel counts (partial 32-channel blocks; no pixel norm at c = 24)
+]
+
+
+@pytest.mark.parametrize('n,hw,cin,cout', STATS_CASES)
+def test_conv_statistics_epilogue(ops, n, hw, cin, cout):
+  """tg_conv2d_fwd_stats: the tensor is bit-identical to tg_conv2d_fwd's, and the per-workgroup partial sums add up
+  to the sums of THAT tensor (value and square, per image and channel) -- fp32 summation error only.  Then the
+  normaliser fed by those partials (tg_norm_act_fwd_conv_stats) equals the one that reads the tensor itself."""
+  g = torch.Generator().manual_seed(5)
+  x = (torch.randn(n, hw, hw, cin, generator=g) + 0.3).to(dev()).bfloat16()
+  w = (torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev())
+  spec = ops.ConvSpec(3, 'SAME')
+  y_ref = ops.conv_fwd_raw(x, w, None, spec, 0)
+  y, st = ops.conv_fwd_stats_raw(x, w, spec)
+  assert st is not None, 'this shape should dispatch a kernel with the statistics epilogue'
+  assert torch.equal(y, y_ref)
+  part = st.part.view(n, st.chunks, 2, cout).double().sum(dim=1).cpu().numpy()
+  yd = y.double().cpu().numpy().reshape(n, hw * hw, cout)
+  s1, s2 = yd.sum(axis=1), (yd * yd).sum(axis=1)
+  assert np.abs(part[:, 0] - s1).max() <= 2e-6 * np.sqrt(s2 * hw * hw).max()
+  assert np.abs(part[:, 1] / s2 - 1).max() <= 2e-6
+  gamma = (1 + 0.1 * torch.randn(cout, generator=g)).to(dev())
+  beta = (0.1 * torch.randn(cout, generator=g)).to(dev())
+  pn = cout % 8 == 0 and (cout // 8) & (cout // 8 - 1) == 0      # the pixel-norm kernel wants c = 8 * 2^k
+  z_ref = ops.norm_act(y, gamma, beta, pixel_norm=pn)
+  z = ops.norm_act(y, gamma, beta, pixel_norm=pn, conv_stats=st)
+  assert rel_l2(host(z), host(z_ref)) < 2e-3      # one bf16 rounding of the output is 1.1e-3; statistics differ by ~1e-6
+  zp_ref = ops.norm_act(y, gamma, beta, pixel_norm=pn, pool=True)
+  zp = ops.norm_act(y, gamma, beta, pixel_norm=pn, pool=True, conv_stats=st)
+  assert rel_l2(host(zp[1]), host(zp_ref[1])) < 2e-3
+
+
+def test_upcat_conv_statistics_epilogue(ops):
+  g = torch.Generator().manual_seed(6)
+  n, h, c0, c1, cout = 4, 32, 32, 32, 16
+  x0 = torch.randn(n, h, h, c0, generator=g).to(dev()).bfloat16()
+  x1 = torch.randn(2, 2 * h, 2 * h, c1, generator=g).to(dev()).bfloat16()
+  w = (torch.randn(3, 3, c0 + c1, cout, generator=g) * (2.0 / (9 * (c0 + c1))) ** 0.5).to(dev())
+  y_ref = ops.upcat_conv(x0, x1, w, 1, (1, 0, 0, 1))
+  y, st = ops.upcat_conv_stats(x0, x1, w, 1, (1, 0, 0, 1))
+  assert st is not None and torch.equal(y, y_ref)
+  part = st.part.view(n, st.chunks, 2, cout).double().sum(dim=1).cpu().numpy()
+  yd = y.double().cpu().numpy().reshape(n, 4 * h * h, cout)
+  s2 = (yd * yd).sum(axis=1)
+  assert np.abs(part[:, 0] - yd.sum(axis=1)).max() <= 2e-6 * np.sqrt(s2 * 4 * h * h).max()
+  assert np.abs(part[:, 1] / s2 - 1).max() <= 2e-6

@@ -219,6 +219,52 @@ int main(int argc, char** argv) {
     printf("%-7s %-5s %4d %4d>%-4d | %9.1f %8.0f %8.1f %9.2e\n", c.name, "mdgrd", c.hw, c.cin, c.cout, t,
            (bytes + 2.0 * px * c.cin) / t * 1e-3, flops / t * 1e-6, -1.0);
     }
+    if (only_op && !strcmp(only_op, "stats")) {      // conv + statistics pass  vs  conv with the statistics epilogue
+      const int chunks = tg_conv2d_fwd_stats_chunks(&d0);
+      const int nch = tg_norm_chunks(batch, c.hw, c.hw);
+      float* part;
+      HC(hipMalloc(&part, (size_t)batch * (chunks > nch ? chunks : nch) * 2 * c.cout * 4 + 64));
+      const float tp = time_us([&] { TC(tg_conv2d_fwd(&d0, x, p0, nullptr, y, nullptr)); }, iters);
+      const float ts = time_us([&] {
+        TC(tg_conv2d_fwd(&d0, x, p0, nullptr, y, nullptr));
+        TC(tg_instance_norm_partials(y, part, batch, c.hw, c.hw, c.cout, TG_BF16, nullptr));
+      }, iters);
+      float tf = -1.f;
+      double err = -1;
+      if (chunks > 0) {
+        tf = time_us([&] { TC(tg_conv2d_fwd_stats(&d0, x, p0, y2, part, chunks, nullptr)); }, iters);
+        HC(hipDeviceSynchronize());
+        std::vector<uint16_t> hy((size_t)px * c.cout), hy2((size_t)px * c.cout);
+        std::vector<float> hp((size_t)batch * chunks * 2 * c.cout);
+        HC(hipMemcpy(hy.data(), y, hy.size() * 2, hipMemcpyDeviceToHost));
+        HC(hipMemcpy(hy2.data(), y2, hy2.size() * 2, hipMemcpyDeviceToHost));
+        HC(hipMemcpy(hp.data(), part, hp.size() * 4, hipMemcpyDeviceToHost));
+        size_t diff = 0;
+        for (size_t i = 0; i < hy.size(); ++i) diff += hy[i] != hy2[i];
+        err = 0;
+        const size_t hw2 = (size_t)c.hw * c.hw;
+        for (int img = 0; img < batch; ++img)
+          for (int ch = 0; ch < c.cout; ++ch) {
+            double s1 = 0, s2 = 0, q1 = 0, q2 = 0;
+            for (size_t p = 0; p < hw2; ++p) {
+              const double v = bf2f(hy2[((size_t)img * hw2 + p) * c.cout + ch]);
+              s1 += v;
+              s2 += v * v;
+            }
+            for (int k = 0; k < chunks; ++k) {
+              q1 += hp[(((size_t)img * chunks + k) * 2 + 0) * c.cout + ch];
+              q2 += hp[(((size_t)img * chunks + k) * 2 + 1) * c.cout + ch];
+            }
+            const double e1 = fabs(q1 - s1) / (sqrt(s2 * hw2) + 1e-30), e2 = fabs(q2 - s2) / (s2 + 1e-30);
+            if (e1 > err) err = e1;
+            if (e2 > err) err = e2;
+          }
+        if (diff) err = 1e9 + diff;      // the statistics variant must write the very same tensor
+      }
+      printf("%-7s %-5s %4d %4d>%-4d | conv %7.1f  conv+stats-pass %7.1f  conv-with-stats %7.1f us (chunks %d)  err %.2e\n", c.name,
+             "stats", c.hw, c.cin, c.cout, tp, ts, tf, chunks, err);
+      HC(hipFree(part));
+    }
     if (!only_op || !strcmp(only_op, "wgrad")) {
     t = time_us([&] { TC(tg_conv2d_bwd_weight(&d0, x, gy, gw, 0, ws, wsb, nullptr)); }, iters);
     printf("%-7s %-5s %4d %4d>%-4d | %9.1f %8.0f %8.1f %9.2e\n", c.name, "wgrad", c.hw, c.cin, c.cout, t, bytes / t * 1e-3,

@@ -47,6 +47,11 @@ SIGNATURES = {
     'tg_conv2d_bwd_weight2_bias': (c_int, [_D, c_int, _P, _P, _P, _P, _FP, _FP, c_int, c_int, _P, c_size_t, _P]),
     'tg_conv2d_upcat_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'tg_conv2d_upcat_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_uint, _P]),
+    'tg_conv2d_fwd_stats_chunks': (c_int, [_D]),
+    'tg_conv2d_fwd_stats': (c_int, [_D, _P, _P, _P, _FP, c_int, _P]),
+    'tg_conv2d_upcat_fwd_stats_chunks': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    'tg_conv2d_upcat_fwd_stats': (c_int, [_P, _P, _P, _P, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_uint,
+                                          _P]),
     'tg_conv2d_upcat_bwd_weight_workspace': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     'tg_conv2d_upcat_bwd_weight': (c_int, [_P, _P, _P, _FP, c_int, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int,
                                            c_int, c_uint, _P]),
@@ -62,6 +67,8 @@ SIGNATURES = {
     'tg_instance_norm_partials': (c_int, [_P, _FP, c_int, c_int, c_int, c_int, c_int, _P]),
     'tg_norm_act_fwd_partials': (c_int, [_P, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, _P, _P, _FP, c_int, c_int, c_int, c_int,
                                          c_int, c_float, c_float, c_float, c_int, _P]),
+    'tg_norm_act_fwd_conv_stats': (c_int, [_P, _FP, c_int, _FP, _FP, _FP, _FP, _FP, _FP, c_int, _P, _P, _FP, c_int, c_int, c_int,
+                                           c_int, c_int, c_float, c_float, c_float, c_int, _P]),
     'tg_norm_act_fwd': (c_int, [_P, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, _P, _FP, c_int, c_int, c_int, c_int, c_int,
                                 c_float, c_float, c_int, _P]),
     'tg_norm_act_bwd': (c_int, [_P, _P, _P, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, _P, c_int, _FP, _FP, _FP, _FP, _FP,

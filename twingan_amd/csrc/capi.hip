@@ -55,7 +55,11 @@ bool tg_conv2d_bwd_weight_bias_fused_mfma(const TgConvDesc* d);
 
 bool tg_conv_tile_upcat_supported(int h, int w, int c0, int c1, int cout);
 int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, const void* x0,
-                           const void* x1, const void* wp, void* y, hipStream_t s);
+                           const void* x1, const void* wp, void* y, hipStream_t s, float* stats = nullptr,
+                           int stat_chunks = 0, int* chunks_query = nullptr);
+int tg_conv2d_fwd_stats_chunks_mfma(const TgConvDesc* d);
+int tg_conv2d_fwd_stats_mfma(const TgConvDesc* d, const void* x, const void* wp, void* y, float* partials, int chunks,
+                             hipStream_t s);
 size_t tg_wgrad_tile_workspace(int n, int h, int w, int cin, int cout);
 int tg_wgrad_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, const void* x0,
                             const void* x1, const void* gy, float* gw, int accumulate, void* ws, size_t ws_bytes,
@@ -165,6 +169,43 @@ int tg_conv2d_upcat_fwd(const void* x0, const void* x1, const void* w_pack, void
   int rc = check_upcat("tg_conv2d_upcat_fwd", n, h, w, c0, c1, cout, gsz, perm);
   if (rc) return rc;
   return tg_conv_tile_upcat_run(n, h, w, c0, c1, cout, gsz, perm, x0, x1, w_pack, y, (hipStream_t)stream);
+}
+
+int tg_conv2d_fwd_stats_chunks(const TgConvDesc* d) {
+  if (check_desc("tg_conv2d_fwd_stats_chunks", d) || d->algo == TG_ALGO_DIRECT) return 0;
+  return tg_conv2d_fwd_stats_chunks_mfma(d);
+}
+
+int tg_conv2d_fwd_stats(const TgConvDesc* d, const void* x, const void* w_pack, void* y, float* partials, int chunks,
+                        void* stream) {
+  int rc = check_desc("tg_conv2d_fwd_stats", d);
+  if (rc) return rc;
+  TG_CHECK(x && w_pack && y && partials, TG_EINVAL, "tg_conv2d_fwd_stats: null pointer");
+  TG_CHECK(tg_aligned16(x) && tg_aligned16(w_pack) && tg_aligned16(y), TG_EALIGN,
+           "tg_conv2d_fwd_stats: pointers must be 16 B aligned");
+  TG_CHECK(d->algo != TG_ALGO_DIRECT && d->epilogue == 0, TG_ENOSUP,
+           "tg_conv2d_fwd_stats: MFMA path, plain epilogue (query tg_conv2d_fwd_stats_chunks first)");
+  return tg_conv2d_fwd_stats_mfma(d, x, w_pack, y, partials, chunks, (hipStream_t)stream);
+}
+
+int tg_conv2d_upcat_fwd_stats_chunks(int n, int h, int w, int c0, int c1, int cout) {
+  if (n <= 0 || !tg_conv_tile_upcat_supported(h, w, c0, c1, cout)) return 0;
+  int chunks = 0;
+  if (tg_conv_tile_upcat_run(n, h, w, c0, c1, cout, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &chunks) !=
+      TG_OK)
+    return 0;
+  return chunks;
+}
+
+int tg_conv2d_upcat_fwd_stats(const void* x0, const void* x1, const void* w_pack, void* y, float* partials, int chunks, int n,
+                              int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, void* stream) {
+  TG_CHECK(x0 && x1 && w_pack && y && partials, TG_EINVAL, "tg_conv2d_upcat_fwd_stats: null pointer");
+  int rc = check_upcat("tg_conv2d_upcat_fwd_stats", n, h, w, c0, c1, cout, gsz, perm);
+  if (rc) return rc;
+  TG_CHECK(chunks > 0 && chunks == tg_conv2d_upcat_fwd_stats_chunks(n, h, w, c0, c1, cout), TG_EINVAL,
+           "tg_conv2d_upcat_fwd_stats: chunks %d does not match tg_conv2d_upcat_fwd_stats_chunks()", chunks);
+  return tg_conv_tile_upcat_run(n, h, w, c0, c1, cout, gsz, perm, x0, x1, w_pack, y, (hipStream_t)stream, partials, chunks,
+                                nullptr);
 }
 
 size_t tg_conv2d_upcat_bwd_weight_workspace(int n, int h, int w, int c0, int c1, int cout) {

@@ -545,7 +545,32 @@ int tg_conv2d_pack_weights_multi(const void* table_device, int njobs, int total_
 
 bool tg_conv_tile_supported(int h, int w, int hout, int wout, int kh, int kw, int pad_t, int pad_l);
 int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int epilogue, float alpha, const void* x,
-                     const void* wp, const float* bias, void* y, hipStream_t s, const void* mask = nullptr);
+                     const void* wp, const float* bias, void* y, hipStream_t s, const void* mask = nullptr,
+                     float* stats = nullptr, int stat_chunks = 0, int* chunks_query = nullptr);
+
+// Forward conv that also writes the per-workgroup statistics partials of its output (conv_tile.hip STATS kernels).
+// chunks per image of the dispatch this descriptor selects, 0 when that dispatch has no statistics epilogue.
+int tg_conv2d_fwd_stats_chunks_mfma(const TgConvDesc* d0) {
+  TgConvDesc dd;
+  const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
+  if (d->dtype != TG_BF16 || d->algo == TG_ALGO_MFMA_V1 || d->kh != 3 || d->cin % 8 || d->cout % 8 || d->epilogue) return 0;
+  if (!tg_conv_tile_supported(d->hin, d->win, d->hout, d->wout, d->kh, d->kw, d->pad_t, d->pad_l)) return 0;
+  int chunks = 0;
+  if (tg_conv_tile_run(d->n, d->hin, d->win, d->cin, d->cout, d->kh, d->pad_t, 0, 0.f, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, 0, &chunks) != TG_OK)
+    return 0;
+  return chunks;
+}
+
+int tg_conv2d_fwd_stats_mfma(const TgConvDesc* d0, const void* x, const void* wp, void* y, float* partials, int chunks,
+                             hipStream_t s) {
+  TgConvDesc dd;
+  const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
+  TG_CHECK(chunks > 0 && chunks == tg_conv2d_fwd_stats_chunks_mfma(d0), TG_EINVAL,
+           "tg_conv2d_fwd_stats: chunks %d does not match tg_conv2d_fwd_stats_chunks()", chunks);
+  return tg_conv_tile_run(d->n, d->hin, d->win, d->cin, d->cout, d->kh, d->pad_t, 0, d->lrelu_alpha, x, wp, nullptr, y, s,
+                          nullptr, partials, chunks, nullptr);
+}
 
 bool tg_conv_small_supported(int n, int hout, int wout, int kh, int kw);
 int tg_conv_small_run(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l,

@@ -42,6 +42,11 @@ struct TileGeom {
   // out = acc * (mask > 0 ? 1 : alpha), mask = the forward input (= the producer's activation output), same shape as
   // the output (NULL: plain)
   const bf16* mask;
+  // STATS kernels: per-workgroup sums of the (bf16-rounded) outputs and of their squares, per output channel, written
+  // to stats[img][chunk][2][cout] -- what in_stats_partial<PART> (norm.hip) would have read the tensor back for.
+  float* stats;
+  int stat_chunks;         // chunks per image
+  int* chunks_query;       // non-NULL: do not launch, report the chunk count the STATS variant of this dispatch would use
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
@@ -75,10 +80,72 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, v);
 }
 
+// Transposing sum over the 32 lanes of a half-wave, steps [S0, S1) of 5: entering step s a lane holds 32 >> s values;
+// lanes whose bit s differs exchange halves, so after all five steps lane l31 holds the total of original value
+// v[l31] in v[0].  31 exchanges for 32 values (a plain butterfly per value would take 160), fixed summation order.
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float x) {      // quad_perm lane exchange: no LDS, folds into the consumer
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+template <int S>
+__device__ __forceinline__ float lane_xor(float x) {
+  if constexpr (S == 0) return dpp_quad<0xB1>(x);      // quad_perm [1,0,3,2]
+  else if constexpr (S == 1) return dpp_quad<0x4E>(x); // quad_perm [2,3,0,1]
+  else return __shfl_xor(x, 1 << S);
+}
+template <int S>
+__device__ __forceinline__ void transpose_sum_step(float* v, int l31) {
+  const bool hi = (l31 >> S) & 1;
+#pragma unroll
+  for (int i = 0; i < (32 >> (S + 1)); ++i) {
+    const float a = v[2 * i], b = v[2 * i + 1];
+    v[i] = (hi ? b : a) + lane_xor<S>(hi ? a : b);
+  }
+}
+template <int S0, int S1>
+__device__ __forceinline__ void half_wave_transpose_sum(float* v, int l31) {
+  if constexpr (S0 <= 0 && 0 < S1) transpose_sum_step<0>(v, l31);
+  if constexpr (S0 <= 1 && 1 < S1) transpose_sum_step<1>(v, l31);
+  if constexpr (S0 <= 2 && 2 < S1) transpose_sum_step<2>(v, l31);
+  if constexpr (S0 <= 3 && 3 < S1) transpose_sum_step<3>(v, l31);
+  if constexpr (S0 <= 4 && 4 < S1) transpose_sum_step<4>(v, l31);
+}
+// steps 0 and 1 on four values: the lane's share of the quad total (lane bits 0,1 pick which of the four)
+__device__ __forceinline__ float quad_fold4(float a0, float a1, float a2, float a3, int l31) {
+  const bool h0 = l31 & 1, h1 = (l31 >> 1) & 1;
+  const float b0 = (h0 ? a1 : a0) + dpp_quad<0xB1>(h0 ? a0 : a1);
+  const float b1 = (h0 ? a3 : a2) + dpp_quad<0xB1>(h0 ? a2 : a3);
+  return (h1 ? b1 : b0) + dpp_quad<0x4E>(h1 ? b0 : b1);
+}
+
+// the two bf16 values of a packed pair, as floats (exactly what a later reader of the stored tensor sees)
+__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// Workgroup tail of the STATS kernels: every wave's lane l31 holds (for each 32-channel block nt) the half-wave total
+// of statistic r = l31 -- r < 16: sum of channel 8*(r/4) + 4*kgrp + r%4, r >= 16: sum of squares of channel r - 16 --
+// the four waves (different pixels, same channels) are added in wave order through LDS and written out.
+template <int BN>
+__device__ __forceinline__ void stats_flush(const float (&tot)[BN / 32], float* red, int tid, int n0, int cout,
+                                            float* __restrict__ out) {
+  const int lane = tid & 63, wid = tid >> 6, kgrp = lane >> 5, l31 = lane & 31;
+  const int which = l31 >> 4, rr = l31 & 15;
+  __syncthreads();                      // the staging buffers are free now
+#pragma unroll
+  for (int nt = 0; nt < BN / 32; ++nt) red[(wid * 2 + which) * BN + nt * 32 + (rr >> 2) * 8 + kgrp * 4 + (rr & 3)] = tot[nt];
+  __syncthreads();
+  if (tid < 2 * BN) {
+    const int w2 = tid / BN, ch = tid % BN;
+    const float t = (red[(0 * 2 + w2) * BN + ch] + red[(1 * 2 + w2) * BN + ch]) +
+                    (red[(2 * 2 + w2) * BN + ch] + red[(3 * 2 + w2) * BN + ch]);
+    if (n0 + ch < cout) out[(size_t)w2 * cout + n0 + ch] = t;
+  }
+}
+
 // UPCAT: the conv input is concat(nearest_up2(x), x1) on channels (generator_three_layer_block,
 // nets/pggan.py:69-76) read straight from the two sources -- K chunks below c0 come from the half-resolution
 // tensor, the rest from the skip tensor -- instead of from a materialised copy.
-template <int KH, int KC, int BN, int MT, bool UPCAT = false>
+template <int KH, int KC, int BN, int MT, bool UPCAT = false, bool STATS = false>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                         const float* __restrict__ bias, bf16* __restrict__ y,
                                                         const TileGeom g) {
@@ -103,6 +170,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
   // ---- XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous tile range
   int t = blockIdx.x;
   if ((g.nblk & 7) == 0) t = (t & 7) * (g.nblk >> 3) + (t >> 3);
+  const int tile_in_img = t % (g.tiles_x * g.tiles_y);
   const int tx = t % g.tiles_x;
   t /= g.tiles_x;
   const int ty = t % g.tiles_y;
@@ -234,6 +302,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
   const __amdgpu_buffer_rsrc_t rmask =
       make_rsrc(g.mask ? g.mask + (size_t)img * out_img : y, g.mask ? (unsigned)(out_img * 2) : 0u);
   const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, (g.epilogue & TG_EPI_BIAS) ? (unsigned)(g.cout * 4) : 0u);
+  float stot[NTILE];
 #pragma unroll
   for (int nt = 0; nt < NTILE; ++nt) {
     f32x4 bq[4];
@@ -241,6 +310,11 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
     for (int q = 0; q < 4; ++q)      // OOB (channel >= cout, or no bias) reads 0
       bq[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                              rbias, (unsigned)((n0 + nt * 32 + q * 8 + kgrp * 4) * 4), 0, 0));
+    float sv[STATS ? 32 : 1];
+    if constexpr (STATS) {
+#pragma unroll
+      for (int r = 0; r < 32; ++r) sv[r] = 0.f;
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int oy = oy0 + (wid * MT + m) * 2 + (l31 >> 4), ox = ox0 + (l31 & 15);
@@ -263,6 +337,14 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
         }
         p[q][0] = pack_bf16x2(v[0], v[1]);
         p[q][1] = pack_bf16x2(v[2], v[3]);
+        if constexpr (STATS) {
+          const float r4[4] = {bf16_lo(p[q][0]), bf16_hi(p[q][0]), bf16_lo(p[q][1]), bf16_hi(p[q][1])};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            sv[q * 4 + j] += r4[j];
+            sv[16 + q * 4 + j] = fmaf(r4[j], r4[j], sv[16 + q * 4 + j]);
+          }
+        }
       }
       // swap: (p[0], p[2]) and (p[1], p[3]); vdst[hi half] <-> src[lo half]
       u32x4 o0, o1;
@@ -281,7 +363,14 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
       __builtin_amdgcn_raw_buffer_store_b128(o0, ry, (ch0 + 8 <= g.cout) ? off : OOB, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128(o1, ry, (ch0 + 16 <= g.cout) ? off + 16 : OOB, 0, 0);
     }
+    if constexpr (STATS) {
+      half_wave_transpose_sum<0, 5>(sv, l31);
+      stot[nt] = sv[0];
+    }
   }
+  if constexpr (STATS)
+    stats_flush<BN>(stot, reinterpret_cast<float*>(sA), tid, n0, g.cout,
+                    g.stats + ((size_t)img * g.stat_chunks + tile_in_img) * 2 * g.cout);
 }
 
 
@@ -292,7 +381,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
 // workgroup stages its weight slice ONCE and walks `tiles_per_wg` consecutive tiles, so per tile it only moves
 // the input halo; the next tile's halo loads are in flight during the MFMAs of the current one.
 // ------------------------------------------------------------------------------------------------
-template <int KH, int KC, int BN, int NCH>
+template <int KH, int KC, int BN, int NCH, bool STATS = false>
 __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                              const float* __restrict__ bias, bf16* __restrict__ y,
                                                              const TileGeom g) {
@@ -399,6 +488,21 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
       bq[nt][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                  rbias, (unsigned)((n0 + nt * 32 + q * 8 + kgrp * 4) * 4), 0, 0));
 
+  // STATS: a workgroup's tiles belong to ONE image (the launcher picks tiles_per_wg as a divisor of the tiles per image).
+  // Per tile each lane folds its 32 values per channel block (16 channels, value and square) by the first ST steps of
+  // the transposing half-wave sum and accumulates the 32 >> ST that are left; the remaining steps run once at the end.
+  // One 32-channel block: ST = 0 -- everything stays in the lane until the end (16 packed adds / FMAs per tile, 32
+  // accumulators: 4 instead of 5 workgroups per CU).  Two blocks: ST = 2 -- the quad steps run per tile on DPP lane
+  // exchanges and 8 accumulators per block are kept.
+  constexpr int ST = NTILE == 1 ? 0 : 2;
+  float sacc[NTILE][STATS ? (32 >> ST) : 1];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int nt = 0; nt < NTILE; ++nt)
+#pragma unroll
+      for (int i = 0; i < (32 >> ST); ++i) sacc[nt][i] = 0.f;
+  }
+
   bool first = true;
   // one tile: stage -> LDS, refill the stage with tile t + 1, MFMAs, epilogue
   auto process = [&](Stage& st, int t) __attribute__((always_inline)) {
@@ -471,6 +575,19 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
         }
         p[q][0] = pack_bf16x2(v[0], v[1]);
         p[q][1] = pack_bf16x2(v[2], v[3]);
+        if constexpr (STATS) {
+          const float r4[4] = {bf16_lo(p[q][0]), bf16_hi(p[q][0]), bf16_lo(p[q][1]), bf16_hi(p[q][1])};
+          if constexpr (ST == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              sacc[nt][q * 4 + j] += r4[j];
+              sacc[nt][16 + q * 4 + j] = fmaf(r4[j], r4[j], sacc[nt][16 + q * 4 + j]);
+            }
+          } else {
+            sacc[nt][q] += quad_fold4(r4[0], r4[1], r4[2], r4[3], l31);
+            sacc[nt][4 + q] += quad_fold4(r4[0] * r4[0], r4[1] * r4[1], r4[2] * r4[2], r4[3] * r4[3], l31);
+          }
+        }
       }
       u32x4 o0, o1;
 #pragma unroll
@@ -492,6 +609,17 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
   Stage sa;
   load_a(sa, t_begin);
   for (int t = t_begin; t < t_end; ++t) process(sa, t);
+  if constexpr (STATS) {
+    float stot[NTILE];
+#pragma unroll
+    for (int nt = 0; nt < NTILE; ++nt) {
+      half_wave_transpose_sum<ST, 5>(sacc[nt], l31);
+      stot[nt] = sacc[nt][0];
+    }
+    const int tpi = g.tiles_x * g.tiles_y;
+    stats_flush<BN>(stot, reinterpret_cast<float*>(sA), tid, n0, g.cout,
+                    g.stats + ((size_t)(t_begin / tpi) * g.stat_chunks + (t_begin % tpi) / g.tiles_per_wg) * 2 * g.cout);
+  }
 }
 
 template <int KH, int KC, int BN, int NCH>
@@ -505,12 +633,33 @@ int launch_tile_wres(const TileGeom& g0, const bf16* x, const bf16* wp, const fl
   int tpw = g.nblk * ny / (256 * 4);          // aim for ~4 workgroups per CU over the whole grid
   if (tpw < 1) tpw = 1;
   if (tpw > 16) tpw = 16;
+  const bool stats = g.stats || g.chunks_query;
+  if (stats) {      // a workgroup must stay inside one image
+    const int tpi = g.tiles_x * g.tiles_y;
+    while (tpi % tpw) --tpw;
+    if (g.chunks_query) {
+      *g.chunks_query = (KH == 3) ? tpi / tpw : 0;
+      return TG_OK;
+    }
+    TG_CHECK(g.stat_chunks == tpi / tpw, TG_EINVAL, "conv_tile(wres): stat_chunks %d, this dispatch writes %d", g.stat_chunks,
+             tpi / tpw);
+  }
   g.tiles_per_wg = tpw;
   const int nwg = (g.nblk + tpw - 1) / tpw;
   const size_t lds = (size_t)((HH * HWX * (KC * 2 + 16) + 15) & ~15) + (size_t)NCH * BN * (KH * KH * KC * 2 + 16);
   TG_CHECK(lds <= 64 * 1024, TG_ENOSUP, "conv_tile(wres): LDS %zu too large", lds);
-  tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d>", KH, KC, BN, NCH);
-  hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH>), dim3(nwg, ny), dim3(256), lds, s, x, wp, bias, y, g);
+  if (stats) {
+    if constexpr (KH == 3) {
+      TG_CHECK(g.epilogue == 0 && !g.mask, TG_ENOSUP, "conv_tile(wres): statistics come with the plain epilogue only");
+      tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d,stats>", KH, KC, BN, NCH);
+      hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH, true>), dim3(nwg, ny), dim3(256), lds, s, x, wp, bias, y, g);
+    } else {
+      TG_CHECK(false, TG_ENOSUP, "conv_tile(wres): statistics epilogue is built for 3x3 only");
+    }
+  } else {
+    tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d>", KH, KC, BN, NCH);
+    hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH>), dim3(nwg, ny), dim3(256), lds, s, x, wp, bias, y, g);
+  }
   TG_LAUNCH_CHECK("conv_tile_wres");
   return TG_OK;
 }
@@ -524,6 +673,35 @@ int launch_tile(const TileGeom& g0, const bf16* x, const bf16* wp, const float* 
   g.nblk = g.tiles_x * g.tiles_y * g.n;
   const size_t lds = (size_t)((HH * HWX * (KC * 2 + 16) + 15) & ~15) + (size_t)BN * (KH * KH * KC * 2 + 16);
   TG_CHECK(lds <= 160 * 1024, TG_ENOSUP, "conv_tile: LDS %zu too large", lds);
+  if (g.chunks_query) {
+    *g.chunks_query = (KH == 3) ? g.tiles_x * g.tiles_y : 0;
+    return TG_OK;
+  }
+  if (g.stats) {
+    if constexpr (KH == 3) {
+      TG_CHECK(g.epilogue == 0 && !g.mask, TG_ENOSUP, "conv_tile: statistics come with the plain epilogue only");
+      TG_CHECK(g.stat_chunks == g.tiles_x * g.tiles_y, TG_EINVAL, "conv_tile: stat_chunks %d, this dispatch writes %d",
+               g.stat_chunks, g.tiles_x * g.tiles_y);
+      auto kst = conv_tile_kernel<KH, KC, BN, MT, UPCAT, true>;
+      if (lds > 64 * 1024) {
+        static bool raised_st = false;
+        if (!raised_st) {
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(kst), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+              hipSuccess) {
+            tg_set_error("conv_tile: cannot raise dynamic LDS to %zu", lds);
+            return TG_ELAUNCH;
+          }
+          raised_st = true;
+        }
+      }
+      tg_note_kernel(UPCAT ? "conv_tile_kernel<%d,%d,%d,%d,upcat,stats>" : "conv_tile_kernel<%d,%d,%d,%d,stats>", KH, KC, BN, MT);
+      hipLaunchKernelGGL(kst, dim3(g.nblk, (g.cout + BN - 1) / BN), dim3(256), lds, s, x, wp, bias, y, g);
+      TG_LAUNCH_CHECK("conv_tile");
+      return TG_OK;
+    } else {
+      TG_CHECK(false, TG_ENOSUP, "conv_tile: statistics epilogue is built for 3x3 only");
+    }
+  }
   auto kern = conv_tile_kernel<KH, KC, BN, MT, UPCAT>;
   if (lds > 64 * 1024) {
     static bool raised = false;      // per instantiation
@@ -562,7 +740,9 @@ int dispatch_tile(const TileGeom& g, const bf16* x, const bf16* wp, const float*
   // when that still leaves >= 2 workgroups per CU and the map is tall enough
   const bool mt2 = (g.h % 16 == 0) && tiles1 >= 2 * 2 * 256 && g.cin_pad >= 64;
   // thin layers with many tiles: weights resident in LDS, several tiles per workgroup
-  if (tiles1 >= 2048) {
+  static const bool stats_wide_tile = getenv("TG_STATS_WIDE_TILE") != nullptr;      // A/B switch
+  const bool skip_wres = stats_wide_tile && wide && (g.stats || g.chunks_query);
+  if (tiles1 >= 2048 && !skip_wres) {
     if (g.cin_pad == 16) return wide ? launch_tile_wres<KH, 16, 64, 1>(g, x, wp, bias, y, s) : launch_tile_wres<KH, 16, 32, 1>(g, x, wp, bias, y, s);
     if (g.cin_pad == 32) return wide ? launch_tile_wres<KH, 32, 64, 1>(g, x, wp, bias, y, s) : launch_tile_wres<KH, 32, 32, 1>(g, x, wp, bias, y, s);
   }
@@ -585,7 +765,8 @@ bool tg_conv_tile_supported(int h, int w, int hout, int wout, int kh, int kw, in
 }
 
 int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int epilogue, float alpha, const void* x,
-                     const void* wp, const float* bias, void* y, hipStream_t s, const void* mask) {
+                     const void* wp, const float* bias, void* y, hipStream_t s, const void* mask, float* stats,
+                     int stat_chunks, int* chunks_query) {
   TileGeom g;
   g.n = n; g.h = h; g.w = w; g.cin = cin; g.cout = cout;
   g.cin_pad = (cin + 15) / 16 * 16;
@@ -597,6 +778,9 @@ int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int
   g.c0 = g.gsz = 0;
   g.perm = 0;
   g.mask = (const bf16*)mask;
+  g.stats = stats;
+  g.stat_chunks = stat_chunks;
+  g.chunks_query = chunks_query;
   if (k == 1) return dispatch_tile<1>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
   return dispatch_tile<3>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
 }
@@ -607,7 +791,8 @@ bool tg_conv_tile_upcat_supported(int h, int w, int c0, int c1, int cout) {
 }
 
 int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, const void* x0,
-                           const void* x1, const void* wp, void* y, hipStream_t s) {
+                           const void* x1, const void* wp, void* y, hipStream_t s, float* stats, int stat_chunks,
+                           int* chunks_query) {
   TileGeom g;
   g.n = n; g.h = h; g.w = w; g.cin = c0 + c1; g.cout = cout;
   g.cin_pad = g.cin;
@@ -621,5 +806,8 @@ int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gs
   g.gsz = gsz;
   g.perm = perm;
   g.mask = nullptr;
+  g.stats = stats;
+  g.stat_chunks = stat_chunks;
+  g.chunks_query = chunks_query;
   return dispatch_tile_upcat(g, (const bf16*)x0, (const bf16*)wp, nullptr, (bf16*)y, s);
 }

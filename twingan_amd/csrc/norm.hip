@@ -14,6 +14,7 @@ namespace {
 
 #define NF_LRELU 1
 #define NF_PIXNORM 2
+#define NF_ZEROSHIFT 8    // the partial sums were taken without a shift (conv epilogue, tg_conv2d_fwd_stats): K = 0
 #define NF_NOSTATS 4      // mean / rstd are constants (no normaliser: pixel norm only): the backward drops the statistic terms
 
 template <typename T, int V>
@@ -275,7 +276,7 @@ __global__ void norm_act_fwd_part_kernel(const T* __restrict__ y, const float* _
   float m_[8], r_[8];      // c <= 2048: at most 8 channels per thread
   int cnt = 0;
   for (int i = threadIdx.x; i < c; i += blockDim.x, ++cnt) {
-    const float k = ld(y + (int64_t)n * hw * c + i);
+    const float k = (flags & NF_ZEROSHIFT) ? 0.f : ld(y + (int64_t)n * hw * c + i);
     const float m1 = sh[i] * inv, m2 = sh[c + i] * inv;
     float var = m2 - m1 * m1;
     var = var < 0.f ? 0.f : var;
@@ -689,10 +690,10 @@ int tg_instance_norm_partials(const void* y, float* partials, int n, int h, int 
   return TG_OK;
 }
 
-int tg_norm_act_fwd_partials(const void* y, const float* partials, float* mean, float* rstd, const float* gamma,
-                             const float* beta, const float* gamma2, const float* beta2, int split, void* z,
-                             void* z_pooled, float* pn_scale, int n, int h, int w, int c, int flags, float alpha,
-                             float in_eps, float pn_eps, int dtype, void* stream) {
+static int norm_act_fwd_partials_impl(const void* y, const float* partials, int part_chunks, float* mean, float* rstd,
+                                      const float* gamma, const float* beta, const float* gamma2, const float* beta2,
+                                      int split, void* z, void* z_pooled, float* pn_scale, int n, int h, int w, int c,
+                                      int flags, float alpha, float in_eps, float pn_eps, int dtype, void* stream) {
   TG_CHECK(!z_pooled || (h % 2 == 0 && w % 2 == 0), TG_EINVAL, "tg_norm_act_fwd_partials: pooled output needs even h, w");
   TG_CHECK(y && partials && mean && rstd && gamma && beta && z && n > 0 && h > 0 && w > 0 && c > 0, TG_EINVAL,
            "tg_norm_act_fwd_partials: bad arguments");
@@ -702,6 +703,7 @@ int tg_norm_act_fwd_partials(const void* y, const float* partials, float* mean, 
   const int hw = h * w;
   int chunks, ppb_s;
   norm_chunks(n, hw, &chunks, &ppb_s);
+  if (part_chunks > 0) chunks = part_chunks;      // partial sums of a producer with its own chunking
   const int units = z_pooled ? hw / 4 : hw;            // the pooled variant walks 2x2 blocks (4 pixels each)
   int chunks2 = (2048 + n - 1) / n;                    // ~2048 blocks for the streaming pass
   int ppb = (units + chunks2 - 1) / chunks2;
@@ -738,6 +740,25 @@ int tg_norm_act_fwd_partials(const void* y, const float* partials, float* mean, 
   });
   TG_LAUNCH_CHECK("tg_norm_act_fwd_partials");
   return TG_OK;
+}
+
+int tg_norm_act_fwd_partials(const void* y, const float* partials, float* mean, float* rstd, const float* gamma,
+                             const float* beta, const float* gamma2, const float* beta2, int split, void* z,
+                             void* z_pooled, float* pn_scale, int n, int h, int w, int c, int flags, float alpha,
+                             float in_eps, float pn_eps, int dtype, void* stream) {
+  return norm_act_fwd_partials_impl(y, partials, 0, mean, rstd, gamma, beta, gamma2, beta2, split, z, z_pooled, pn_scale, n, h,
+                                    w, c, flags & ~NF_ZEROSHIFT, alpha, in_eps, pn_eps, dtype, stream);
+}
+
+// The same pass fed by the partial sums a conv wrote from its epilogue (tg_conv2d_fwd_stats / tg_conv2d_upcat_fwd_stats:
+// [n][part_chunks][2][c], unshifted): no statistics read of y at all.
+int tg_norm_act_fwd_conv_stats(const void* y, const float* partials, int part_chunks, float* mean, float* rstd,
+                               const float* gamma, const float* beta, const float* gamma2, const float* beta2, int split,
+                               void* z, void* z_pooled, float* pn_scale, int n, int h, int w, int c, int flags, float alpha,
+                               float in_eps, float pn_eps, int dtype, void* stream) {
+  TG_CHECK(part_chunks > 0, TG_EINVAL, "tg_norm_act_fwd_conv_stats: part_chunks must be positive");
+  return norm_act_fwd_partials_impl(y, partials, part_chunks, mean, rstd, gamma, beta, gamma2, beta2, split, z, z_pooled,
+                                    pn_scale, n, h, w, c, flags | NF_ZEROSHIFT, alpha, in_eps, pn_eps, dtype, stream);
 }
 
 int tg_instance_norm_stats(const void* y, float* mean, float* rstd, int n, int h, int w, int c, float eps, int dtype,

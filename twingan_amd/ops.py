@@ -9,6 +9,7 @@ second-order gradients (WGAN-GP, image_generation.py:414-439) flow through the s
 All activations are NHWC contiguous tensors (fp32 or bf16); conv weights are fp32 HWIO masters.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -56,6 +57,9 @@ def _chk(*ts):
 # ------------------------------------------------------------------------------------------------
 # weight-pack cache for the MFMA kernels
 # ------------------------------------------------------------------------------------------------
+# statistics of a normalised conv's output from the conv's own epilogue (TG_CONV_STATS=0: separate statistics pass, for A/Bs)
+USE_CONV_STATS = os.environ.get('TG_CONV_STATS', '1') != '0'
+
 class PackCache:
   """bf16 K-contiguous packs (tg_conv2d_pack_weights) of registered master weights.
 
@@ -348,6 +352,29 @@ def conv_fwd_raw(x, w, bias, spec, epilogue):
   return y
 
 
+class ConvStats:
+  """Per-workgroup statistics partials a conv wrote from its epilogue (tg_conv2d_fwd_stats): fp32
+  [n][chunks][2][cout], consumed by norm_act instead of a statistics pass over the conv output."""
+  __slots__ = ('part', 'chunks')
+
+  def __init__(self, part, chunks):
+    self.part, self.chunks = part, chunks
+
+
+def conv_fwd_stats_raw(x, w, spec):
+  """(y, ConvStats) of a bias-free conv, or (y, None) when the kernel this shape dispatches has no statistics epilogue."""
+  _chk(x, w)
+  d = _desc(x.shape, w.shape[3], spec, x.dtype, 0)
+  chunks = _lib.load().tg_conv2d_fwd_stats_chunks(ctypes.byref(d)) if (USE_CONV_STATS and d.algo == TG_ALGO_MFMA) else 0
+  if chunks <= 0:
+    return conv_fwd_raw(x, w, None, spec, 0), None
+  y = torch.empty((d.n, d.hout, d.wout, d.cout), dtype=x.dtype, device=x.device)
+  part = torch.empty(d.n * chunks * 2 * d.cout, dtype=torch.float32, device=x.device)
+  call('tg_conv2d_fwd_stats', ctypes.byref(d), _p(x), _p(PackCache.get(w, d, 0)), _p(y), _p(part), chunks, _stream(),
+       work=lambda: _conv_work(d, 'fwd', _esize(x)))
+  return y, ConvStats(part, chunks)
+
+
 def conv_bwd_data_raw(gy, w, x_shape, spec):
   _chk(gy, w)
   d = _desc(x_shape, w.shape[3], spec, gy.dtype, 0)
@@ -571,6 +598,24 @@ class Conv2dFn(torch.autograd.Function):
     return _conv_backward(ctx, gz)
 
 
+class Conv2dStatsFn(torch.autograd.Function):
+  """y = conv(x, w) of a normalised layer; the statistics partials the kernel wrote ride along on ``holder`` (a list the
+  caller passes; not a tensor output, so the autograd graph is the plain conv's)."""
+
+  @staticmethod
+  def forward(ctx, x, w, spec, holder):
+    z, st = conv_fwd_stats_raw(x, w, spec)
+    holder.append(st)
+    ctx.spec, ctx.epilogue, ctx.mask_input = spec, 0, False
+    ctx.out_hw = (z.shape[1], z.shape[2])
+    ctx.save_for_backward(x, w, None, None)
+    return z
+
+  @staticmethod
+  def backward(ctx, gz):
+    return _conv_backward(ctx, gz)[:2] + (None, None)
+
+
 class Conv2dPoolFn(torch.autograd.Function):
   """(z, avg_pool2(z)) with z = epilogue(conv(x, w) [+ bias]) -- the last conv of a discriminator block and
   the tf.nn.avg_pool after it (nets/pggan.py:304-306).  Outside create_graph mode the backward folds the
@@ -704,6 +749,13 @@ def _claim_input_lrelu(x, alpha):
   return True
 
 
+def conv2d_stats(x, w, k=3, padding='SAME'):
+  """(y, ConvStats | None): bias-free conv whose output goes to a normaliser (norm_act(..., conv_stats=...))."""
+  holder = []
+  y = Conv2dStatsFn.apply(x, w, ConvSpec(k, padding, 0, LRELU_ALPHA), holder)
+  return y, holder[0]
+
+
 def conv2d(x, w, bias=None, k=3, padding='SAME', lrelu=False, alpha=LRELU_ALPHA, pool=False, fuse_input_lrelu=False):
   """Stride-1 conv, optional fused bias and LeakyReLU (discriminator layers).  ``pool``: also return the
   2x2 average-pooled output -> (z, z_pooled).  ``fuse_input_lrelu``: the caller guarantees that ``x`` is consumed by
@@ -835,7 +887,7 @@ def instance_stats(y, eps):
 
 
 def _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema=None, stats=None,
-                      zp=None):
+                      zp=None, conv_stats=None):
   _chk(y, gamma, beta, gamma2, beta2)
   n, h, w, c = y.shape
   split = n if gamma2 is None else int(split)
@@ -850,13 +902,19 @@ def _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, 
   else:
     mean = torch.empty(n * c, dtype=torch.float32, device=y.device)
     rstd = torch.empty(n * c, dtype=torch.float32, device=y.device)
-    chunks = _lib.load().tg_norm_chunks(n, h, w)
-    part = torch.empty(n * chunks * 2 * c, dtype=torch.float32, device=y.device)
-    call('tg_instance_norm_partials', _p(y), _p(part), n, h, w, c, _dt(y), _stream(),
-         work=('in_stats' + _shape_tag(y), 0, y.numel() * _esize(y)))
-    call('tg_norm_act_fwd_partials', _p(y), _p(part), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(gamma2), _p(beta2), split,
-         _p(z), _p(zp), _p(s), n, h, w, c, flags, alpha, in_eps, pn_eps, _dt(y), _stream(),
-         work=('norm_act_fwd' + _shape_tag(y), 0, int((2 + (0.25 if zp is not None else 0)) * y.numel()) * _esize(y)))
+    fwd_work = ('norm_act_fwd' + _shape_tag(y), 0, int((2 + (0.25 if zp is not None else 0)) * y.numel()) * _esize(y))
+    if conv_stats is not None:      # the producing conv already summed its outputs per workgroup
+      assert conv_stats.part.numel() == n * conv_stats.chunks * 2 * c
+      call('tg_norm_act_fwd_conv_stats', _p(y), _p(conv_stats.part), conv_stats.chunks, _p(mean), _p(rstd), _p(gamma),
+           _p(beta), _p(gamma2), _p(beta2), split, _p(z), _p(zp), _p(s), n, h, w, c, flags, alpha, in_eps, pn_eps, _dt(y),
+           _stream(), work=fwd_work)
+    else:
+      chunks = _lib.load().tg_norm_chunks(n, h, w)
+      part = torch.empty(n * chunks * 2 * c, dtype=torch.float32, device=y.device)
+      call('tg_instance_norm_partials', _p(y), _p(part), n, h, w, c, _dt(y), _stream(),
+           work=('in_stats' + _shape_tag(y), 0, y.numel() * _esize(y)))
+      call('tg_norm_act_fwd_partials', _p(y), _p(part), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(gamma2), _p(beta2), split,
+           _p(z), _p(zp), _p(s), n, h, w, c, flags, alpha, in_eps, pn_eps, _dt(y), _stream(), work=fwd_work)
     if ema is not None:
       _ema_update(mean, rstd, n, c, split, in_eps, ema)
   ctx.flags, ctx.alpha, ctx.split, ctx.per_image = flags, alpha, split, per_image
@@ -901,13 +959,14 @@ class NormActFn(torch.autograd.Function):
   gradient penalty).  With (gamma2, beta2, split) images [split, n) use the second domain's parameters."""
 
   @staticmethod
-  def forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema, stats):
-    return _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema, stats)
+  def forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema, stats, conv_stats=None):
+    return _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema, stats,
+                             conv_stats=conv_stats)
 
   @staticmethod
   @torch.autograd.function.once_differentiable
   def backward(ctx, gz):
-    return _norm_act_backward(ctx, gz) + (None,)
+    return _norm_act_backward(ctx, gz) + (None, None)
 
 
 class NormActPoolFn(torch.autograd.Function):
@@ -916,12 +975,12 @@ class NormActPoolFn(torch.autograd.Function):
   (and the sum of the two) into the normalisation backward kernel."""
 
   @staticmethod
-  def forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema, stats):
+  def forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema, stats, conv_stats=None):
     n, h, w, c = y.shape
     zp = torch.empty((n, h // 2, w // 2, c), dtype=y.dtype, device=y.device)
     fused = gamma.dim() == 1      # the partial-sums forward writes the pooled tensor itself
     z = _norm_act_forward(ctx, y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema, stats,
-                          zp if fused else None)
+                          zp if fused else None, conv_stats=conv_stats if fused else None)
     if not fused:
       call('tg_pool2x2_fwd', _p(z), _p(zp), n, h, w, c, 0.25, _dt(z), _stream(),
            work=('pool_fwd' + _shape_tag(z), 0, int(1.25 * z.numel()) * _esize(z)))
@@ -932,8 +991,8 @@ class NormActPoolFn(torch.autograd.Function):
   @torch.autograd.function.once_differentiable
   def backward(ctx, gz, gzp):
     if gz is None and gzp is None:
-      return (None,) * 12
-    return _norm_act_backward(ctx, gz, gzp) + (None,)
+      return (None,) * 13
+    return _norm_act_backward(ctx, gz, gzp) + (None, None)
 
 
 _CONST = {}
@@ -969,7 +1028,7 @@ def affine_act(y_hat, gamma_rows, beta_rows, lrelu=True, pixel_norm=True, pool=F
 
 
 def norm_act(y, gamma, beta, lrelu=True, pixel_norm=True, in_eps=1e-6, pn_eps=1e-6, alpha=LRELU_ALPHA, gamma2=None,
-             beta2=None, split=None, pool=False, ema=None, stats=None):
+             beta2=None, split=None, pool=False, ema=None, stats=None, conv_stats=None):
   """Statistics are per leading index of ``y`` (instance norm: one image; batch norm: the caller passes the view
   [passes, B*H, W, C] so that each batched pass is one statistic group).  ``pool``: also return the 2x2
   average-pooled output -> (z, z_pooled).  ``ema``: (decay, [(moving_mean, moving_var) per domain]) to update.
@@ -977,7 +1036,9 @@ def norm_act(y, gamma, beta, lrelu=True, pixel_norm=True, in_eps=1e-6, pn_eps=1e
   ordinary differentiable tensors) and ``stats`` = instance_stats(y, eps) computed by the caller."""
   flags = (NF_LRELU if lrelu else 0) | (NF_PIXNORM if pixel_norm else 0)
   fn = NormActPoolFn if pool else NormActFn
-  return fn.apply(y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema, stats)
+  if conv_stats is not None and (gamma.dim() != 1 or stats is not None):
+    conv_stats = None      # per-image parameter rows take their statistics from the caller
+  return fn.apply(y, gamma, beta, gamma2, beta2, split, flags, in_eps, pn_eps, alpha, ema, stats, conv_stats)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1036,7 +1097,7 @@ class UpcatConvFn(torch.autograd.Function):
   layout, split by tg_upsample2x_concat_bwd.  First-order only (the generator never sits under the gradient penalty)."""
 
   @staticmethod
-  def forward(ctx, x0, x1, w, gsz, perm):
+  def forward(ctx, x0, x1, w, gsz, perm, holder=None):
     _chk(x0, x1, w)
     n, h, ww, c0 = x0.shape
     c1, cout = x1.shape[3], w.shape[3]
@@ -1047,9 +1108,19 @@ class UpcatConvFn(torch.autograd.Function):
     d = _desc((n, H, W, c0 + c1), cout, spec, x0.dtype, 0)
     y = torch.empty((n, H, W, cout), dtype=x0.dtype, device=x0.device)
     pk = _pack_perm(perm) if gsz else 0
-    call('tg_conv2d_upcat_fwd', _p(x0), _p(x1), _p(PackCache.get(w, d, 0)), _p(y), n, H, W, c0, c1, cout, gsz, pk, _stream(),
-         work=lambda: ('fwd:upcat:k3:c%d+%d>%d:hw%d:n%d' % (c0, c1, cout, H, n), 2 * n * H * W * cout * 9 * (c0 + c1),
-                       2 * (x0.numel() + x1.numel() + y.numel()) + 2 * w.numel()))
+    work = lambda: ('fwd:upcat:k3:c%d+%d>%d:hw%d:n%d' % (c0, c1, cout, H, n), 2 * n * H * W * cout * 9 * (c0 + c1),    # noqa: E731
+                    2 * (x0.numel() + x1.numel() + y.numel()) + 2 * w.numel())
+    chunks = _lib.load().tg_conv2d_upcat_fwd_stats_chunks(n, H, W, c0, c1, cout) if (holder is not None and USE_CONV_STATS) else 0
+    if chunks > 0:
+      part = torch.empty(n * chunks * 2 * cout, dtype=torch.float32, device=x0.device)
+      call('tg_conv2d_upcat_fwd_stats', _p(x0), _p(x1), _p(PackCache.get(w, d, 0)), _p(y), _p(part), chunks, n, H, W, c0, c1,
+           cout, gsz, pk, _stream(), work=work)
+      holder.append(ConvStats(part, chunks))
+    else:
+      call('tg_conv2d_upcat_fwd', _p(x0), _p(x1), _p(PackCache.get(w, d, 0)), _p(y), n, H, W, c0, c1, cout, gsz, pk,
+           _stream(), work=work)
+      if holder is not None:
+        holder.append(None)
     ctx.dims = (n, H, W, c0, c1, cout, gsz, pk, x1.shape[0])
     ctx.spec = spec
     ctx.save_for_backward(x0, x1, w)
@@ -1080,11 +1151,18 @@ class UpcatConvFn(torch.autograd.Function):
                          2 * (x0.numel() + x1.numel() + gy.numel()) + 4 * w.numel()))
       if sink is not None:
         gw = None
-    return g0, g1, gw, None, None
+    return g0, g1, gw, None, None, None
 
 
 def upcat_conv(x0, x1, w, gsz=0, perm=()):
   return UpcatConvFn.apply(x0, x1, w, gsz, tuple(perm))
+
+
+def upcat_conv_stats(x0, x1, w, gsz=0, perm=()):
+  """(y, ConvStats | None), as conv2d_stats."""
+  holder = []
+  y = UpcatConvFn.apply(x0, x1, w, gsz, tuple(perm), holder)
+  return y, holder[0]
 
 
 def upsample2x_concat(x0, x1=None, gsz=0, perm=()):

@@ -159,10 +159,19 @@ def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pix
     if pixel_norm and cfg.do_pixel_norm:
       y = ops.pixel_norm(y)
     return (y, ops.avg_pool2(y)) if pool else y
+  # instance norm without conditioning: the conv's epilogue sums its outputs per workgroup (ConvStats) and the
+  # normaliser reads those sums instead of the tensor (tg_conv2d_fwd_stats -> tg_norm_act_fwd_conv_stats)
+  want_stats = cfg.generator_norm_type == 'instance_norm' and cond is None
+  cst = None
   if upcat is not None:      # x is None: the input is concat(up2(x0), skip), read from the two sources by the conv
-    y = ops.upcat_conv(upcat[0], upcat[1], w, upcat[2], upcat[3])
+    if want_stats:
+      y, cst = ops.upcat_conv_stats(upcat[0], upcat[1], w, upcat[2], upcat[3])
+    else:
+      y = ops.upcat_conv(upcat[0], upcat[1], w, upcat[2], upcat[3])
   elif k == 1 and (w.shape[2] <= 4 or w.shape[3] <= 4):
     y = ops.pointwise_conv(_equalize(x, cfg, k) if equalize else x, w)
+  elif want_stats:
+    y, cst = ops.conv2d_stats(_equalize(x, cfg, k) if equalize else x, w, k, padding)
   else:
     y = ops.conv2d(_equalize(x, cfg, k) if equalize else x, w, None, k, padding)
   nt = cfg.generator_norm_type
@@ -200,7 +209,8 @@ def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pix
   g1 = P['%s/%s/gamma%s' % (scope, ns, _pf(d1))] if d1 else None
   b1 = P['%s/%s/beta%s' % (scope, ns, _pf(d1))] if d1 else None
   if nt == 'instance_norm':
-    return ops.norm_act(y, g0, b0, lrelu=activation, pixel_norm=pn, gamma2=g1, beta2=b1, split=split, pool=pool)
+    return ops.norm_act(y, g0, b0, lrelu=activation, pixel_norm=pn, gamma2=g1, beta2=b1, split=split, pool=pool,
+                        conv_stats=cst)
   # batch norm (libs/batch_norm.py:42-326, training mode): moments over (N,H,W) of ONE reference pass.  Each of
   # the `passes` batched along N is a statistic group: the [passes, B*H, W, C] view turns the per-image
   # kernels into per-pass ones (pixel norm and pooling are per pixel / per 2x2 block, which the view preserves).
