@@ -386,6 +386,18 @@ __device__ __forceinline__ void norm_act_gu(float (&g)[V], float (&x)[V], float 
   }
 }
 
+// Measured and NOT kept (round 2): the backward as ONE kernel with 3 tensor passes -- an image split over G workgroups
+// that keep their rows of (gz, y) in registers (9 VGPRs per 16-byte row pair, 8 rows per thread at 2 workgroups per
+// CU) between the reduction and the apply and meet on a per-image counter in global memory (no grid barrier,
+// self-resetting counters, bounded wait with a self-sufficient slow path; it passed the parity tests).  With
+// agent-scope fences every workgroup wrote back / invalidated its XCD's whole L2 (20x slower than two kernels); with
+// relaxed agent-scope atomics only (partials, counter, one flag per waiter so that nobody polls a shared line) the
+// rendezvous still costs ~15 us of memory round trips against ~7 us of streaming per workgroup, and two workgroups
+// per CU cannot hide it: 172 vs 158 us at 256x256x16 n64, 43 vs 27 us at 16x16x256 n64.  Keeping an image on one XCD
+// and meeting through its L2 with workgroup-scope atomics timed out (block -> XCD placement and L2-scope visibility
+// are not something a kernel can rely on).  Without a rendezvous (images one workgroup can hold: 4x4 / 8x8) it saves
+// 14 launches and nothing measurable (836 vs 841 images/s).  A kernel boundary IS the cheap barrier on this chip.
+//
 // backward pass 1: partial sums  sums[n][chunk][0..c) = sum gu,  [c..2c) = sum gu * yhat
 template <typename T, int V>
 __global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restrict__ gzp, int wdim,
