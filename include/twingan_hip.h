@@ -125,6 +125,13 @@ int tg_conv2d_upcat_fwd(const void* x0, const void* x1, const void* w_pack, void
  * when the kernel it dispatches has no statistics epilogue (the caller then uses tg_instance_norm_partials).  Plain
  * epilogue only (d->epilogue == 0: normalised convs have no bias), 3x3, MFMA path. */
 int tg_conv2d_fwd_stats_chunks(const TgConvDesc* d);
+/* Last conv of a discriminator block together with the tf.nn.avg_pool that follows it (nets/pggan.py:304-306): y as
+ * tg_conv2d_fwd (bias / LeakyReLU epilogue as d->epilogue says) and y_pooled [n, h/2, w/2, cout] = the 2x2 average of
+ * the bf16-rounded y, written from the same output tile.  tg_conv2d_fwd_pool_supported: 3x3 SAME, h % 8 == 0,
+ * w % 16 == 0, MFMA path. */
+int tg_conv2d_fwd_pool_supported(const TgConvDesc* d);
+int tg_conv2d_fwd_pool(const TgConvDesc* d, const void* x, const void* w_pack, const float* bias, void* y, void* y_pooled,
+                       void* stream);
 int tg_conv2d_fwd_stats(const TgConvDesc* d, const void* x, const void* w_pack, void* y, float* partials, int chunks,
                         void* stream);
 int tg_conv2d_upcat_fwd_stats_chunks(int n, int h, int w, int c0, int c1, int cout);

@@ -936,3 +936,28 @@ def test_upcat_conv_statistics_epilogue(ops):
   s2 = (yd * yd).sum(axis=1)
   assert np.abs(part[:, 0] - yd.sum(axis=1)).max() <= 2e-6 * np.sqrt(s2 * 4 * h * h).max()
   assert np.abs(part[:, 1] / s2 - 1).max() <= 2e-6
+
+
+# ------------------------------------------------------------------------- conv that also writes its 2x2 average pool
+@pytest.mark.parametrize('n,hw,cin,cout', [(4, 256, 16, 32), (5, 128, 32, 64), (3, 64, 64, 128), (2, 32, 128, 256),
+                                           (3, 16, 256, 256), (2, 16, 40, 24)])
+def test_conv_with_pooled_output(ops, monkeypatch, n, hw, cin, cout):
+  """tg_conv2d_fwd_pool (last conv of a discriminator block + the avg_pool after it): z is bit-identical to
+  tg_conv2d_fwd's, the pooled tensor equals tg_pool2x2_fwd of z (the 4 rounded values are added in another order: at
+  most an ulp of bf16 on rare elements)."""
+  from twingan_amd._lib import TG_EPI_BIAS, TG_EPI_LRELU
+  g = torch.Generator().manual_seed(9)
+  x = torch.randn(n, hw, hw, cin, generator=g).to(dev()).bfloat16()
+  w = (torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev())
+  b = (0.1 * torch.randn(cout, generator=g)).to(dev())
+  spec = ops.ConvSpec(3, 'SAME')
+  epi = TG_EPI_BIAS | TG_EPI_LRELU
+  monkeypatch.setattr(ops, 'USE_CONV_POOL', False)
+  z_ref, zp_ref = ops.conv_fwd_pool_raw(x, w, b, spec, epi)
+  monkeypatch.setattr(ops, 'USE_CONV_POOL', True)
+  z, zp = ops.conv_fwd_pool_raw(x, w, b, spec, epi)
+  from twingan_amd import _lib
+  assert 'pool' in _lib.load().tg_last_kernel().decode()
+  assert torch.equal(z, z_ref)
+  assert rel_l2(host(zp), host(zp_ref)) < 1e-4
+  assert float((zp.float() - zp_ref.float()).abs().max()) <= 2.0 ** -7 * float(zp_ref.float().abs().max())

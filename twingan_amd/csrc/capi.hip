@@ -57,6 +57,9 @@ bool tg_conv_tile_upcat_supported(int h, int w, int c0, int c1, int cout);
 int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, const void* x0,
                            const void* x1, const void* wp, void* y, hipStream_t s, float* stats = nullptr,
                            int stat_chunks = 0, int* chunks_query = nullptr);
+bool tg_conv2d_fwd_pool_supported_mfma(const TgConvDesc* d);
+int tg_conv2d_fwd_pool_mfma(const TgConvDesc* d, const void* x, const void* wp, const float* bias, void* y, void* ypool,
+                            hipStream_t s);
 int tg_conv2d_fwd_stats_chunks_mfma(const TgConvDesc* d);
 int tg_conv2d_fwd_stats_mfma(const TgConvDesc* d, const void* x, const void* wp, void* y, float* partials, int chunks,
                              hipStream_t s);
@@ -169,6 +172,22 @@ int tg_conv2d_upcat_fwd(const void* x0, const void* x1, const void* w_pack, void
   int rc = check_upcat("tg_conv2d_upcat_fwd", n, h, w, c0, c1, cout, gsz, perm);
   if (rc) return rc;
   return tg_conv_tile_upcat_run(n, h, w, c0, c1, cout, gsz, perm, x0, x1, w_pack, y, (hipStream_t)stream);
+}
+
+int tg_conv2d_fwd_pool_supported(const TgConvDesc* d) {
+  if (check_desc("tg_conv2d_fwd_pool_supported", d) || d->algo == TG_ALGO_DIRECT) return 0;
+  return tg_conv2d_fwd_pool_supported_mfma(d) ? 1 : 0;
+}
+
+int tg_conv2d_fwd_pool(const TgConvDesc* d, const void* x, const void* w_pack, const float* bias, void* y, void* y_pooled,
+                       void* stream) {
+  int rc = check_desc("tg_conv2d_fwd_pool", d);
+  if (rc) return rc;
+  TG_CHECK(x && w_pack && y && y_pooled, TG_EINVAL, "tg_conv2d_fwd_pool: null pointer");
+  TG_CHECK(tg_aligned16(x) && tg_aligned16(w_pack) && tg_aligned16(y) && tg_aligned16(y_pooled), TG_EALIGN,
+           "tg_conv2d_fwd_pool: pointers must be 16 B aligned");
+  TG_CHECK(d->algo != TG_ALGO_DIRECT, TG_ENOSUP, "tg_conv2d_fwd_pool: MFMA path only (query tg_conv2d_fwd_pool_supported)");
+  return tg_conv2d_fwd_pool_mfma(d, x, w_pack, bias, y, y_pooled, (hipStream_t)stream);
 }
 
 int tg_conv2d_fwd_stats_chunks(const TgConvDesc* d) {

@@ -46,6 +46,9 @@ struct TileGeom {
   // to stats[img][chunk][2][cout] -- what in_stats_partial<PART> (norm.hip) would have read the tensor back for.
   float* stats;
   int stat_chunks;         // chunks per image
+  // POOL kernels: also write avg_pool2x2 of the (bf16-rounded) output, [n, h/2, w/2, cout] (the tf.nn.avg_pool that
+  // ends a discriminator block, nets/pggan.py:304-306) -- the tile already holds every 2x2 block it needs
+  bf16* ypool;
   int* chunks_query;       // non-NULL: do not launch, report the chunk count the STATS variant of this dispatch would use
 };
 
@@ -122,6 +125,26 @@ __device__ __forceinline__ float quad_fold4(float a0, float a1, float a2, float 
 __device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
 
+// 2x2 average over this lane's pixel quad -- lanes l31 ^ 1 (the neighbouring column) and l31 ^ 16 (the sub-tile's other
+// row) -- of the 8 bf16-rounded values in p (four channel quads of one 32-channel block, as packed for the store); all
+// four lanes of a quad receive the result.  Column pairs by a DPP quad exchange, row pairs by v_permlane16_swap.
+__device__ __forceinline__ float add_lane_xor16(float x) {
+  const unsigned u = __builtin_bit_cast(unsigned, x);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // (rows 0,0,2,2 | rows 1,1,3,3) of x
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ void pool_quad(const unsigned (&p)[4][2], unsigned (&pp)[4][2]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      float lo = bf16_lo(p[q][d]), hi = bf16_hi(p[q][d]);
+      lo += dpp_quad<0xB1>(lo);
+      hi += dpp_quad<0xB1>(hi);
+      pp[q][d] = pack_bf16x2(0.25f * add_lane_xor16(lo), 0.25f * add_lane_xor16(hi));
+    }
+}
+
 // Workgroup tail of the STATS kernels: every wave's lane l31 holds (for each 32-channel block nt) the half-wave total
 // of statistic r = l31 -- r < 16: sum of channel 8*(r/4) + 4*kgrp + r%4, r >= 16: sum of squares of channel r - 16 --
 // the four waves (different pixels, same channels) are added in wave order through LDS and written out.
@@ -145,10 +168,12 @@ __device__ __forceinline__ void stats_flush(const float (&tot)[BN / 32], float* 
 // UPCAT: the conv input is concat(nearest_up2(x), x1) on channels (generator_three_layer_block,
 // nets/pggan.py:69-76) read straight from the two sources -- K chunks below c0 come from the half-resolution
 // tensor, the rest from the skip tensor -- instead of from a materialised copy.
-template <int KH, int KC, int BN, int MT, bool UPCAT = false, bool STATS = false>
+// MODE 0: plain; 1: statistics partials of the output (STATS); 2: also the 2x2 average pool of the output (POOL)
+template <int KH, int KC, int BN, int MT, bool UPCAT = false, int MODE = 0>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                         const float* __restrict__ bias, bf16* __restrict__ y,
                                                         const TileGeom g) {
+  constexpr bool STATS = MODE == 1, POOL = MODE == 2;
   constexpr int KW = KH, NT = KH * KW;
   constexpr int TW = 16, TH = 8 * MT;
   constexpr int HWX = TW + KW - 1, HH = TH + KH - 1;
@@ -302,6 +327,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
   const __amdgpu_buffer_rsrc_t rmask =
       make_rsrc(g.mask ? g.mask + (size_t)img * out_img : y, g.mask ? (unsigned)(out_img * 2) : 0u);
   const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, (g.epilogue & TG_EPI_BIAS) ? (unsigned)(g.cout * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t rpool =
+      make_rsrc(POOL ? g.ypool + (size_t)img * (out_img / 4) : y, POOL ? (unsigned)(out_img / 4 * 2) : 0u);
   float stot[NTILE];
 #pragma unroll
   for (int nt = 0; nt < NTILE; ++nt) {
@@ -362,6 +389,24 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
       const unsigned off = (unsigned)(((oy * g.w + ox) * g.cout + ch0) * 2);
       __builtin_amdgcn_raw_buffer_store_b128(o0, ry, (ch0 + 8 <= g.cout) ? off : OOB, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128(o1, ry, (ch0 + 16 <= g.cout) ? off + 16 : OOB, 0, 0);
+      if constexpr (POOL) {
+        unsigned pp[4][2];
+        pool_quad(p, pp);
+        u32x4 q0, q1;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          auto r02 = __builtin_amdgcn_permlane32_swap(pp[0][d], pp[2][d], false, false);
+          auto r13 = __builtin_amdgcn_permlane32_swap(pp[1][d], pp[3][d], false, false);
+          q0[d] = r02[0];
+          q0[2 + d] = r02[1];
+          q1[d] = r13[0];
+          q1[2 + d] = r13[1];
+        }
+        const bool owner = (l31 & 17) == 0;      // even column of the sub-tile's first row
+        const unsigned poff = (unsigned)((((oy >> 1) * (g.w >> 1) + (ox >> 1)) * g.cout + ch0) * 2);
+        __builtin_amdgcn_raw_buffer_store_b128(q0, rpool, (owner && ch0 + 8 <= g.cout) ? poff : OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(q1, rpool, (owner && ch0 + 16 <= g.cout) ? poff + 16 : OOB, 0, 0);
+      }
     }
     if constexpr (STATS) {
       half_wave_transpose_sum<0, 5>(sv, l31);
@@ -381,10 +426,11 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
 // workgroup stages its weight slice ONCE and walks `tiles_per_wg` consecutive tiles, so per tile it only moves
 // the input halo; the next tile's halo loads are in flight during the MFMAs of the current one.
 // ------------------------------------------------------------------------------------------------
-template <int KH, int KC, int BN, int NCH, bool STATS = false>
+template <int KH, int KC, int BN, int NCH, int MODE = 0>
 __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                              const float* __restrict__ bias, bf16* __restrict__ y,
                                                              const TileGeom g) {
+  constexpr bool STATS = MODE == 1, POOL = MODE == 2;
   constexpr int KW = KH, NT = KH * KW;
   constexpr int TW = 16, TH = 8;
   constexpr int HWX = TW + KW - 1, HH = TH + KH - 1;
@@ -603,6 +649,25 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
       const unsigned off = (unsigned)(((oy * g.w + ox) * g.cout + ch0) * 2);
       __builtin_amdgcn_raw_buffer_store_b128(o0, ry, (ch0 + 8 <= g.cout) ? off : OOB, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128(o1, ry, (ch0 + 16 <= g.cout) ? off + 16 : OOB, 0, 0);
+      if constexpr (POOL) {
+        unsigned pp[4][2];
+        pool_quad(p, pp);
+        u32x4 q0, q1;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          auto r02 = __builtin_amdgcn_permlane32_swap(pp[0][d], pp[2][d], false, false);
+          auto r13 = __builtin_amdgcn_permlane32_swap(pp[1][d], pp[3][d], false, false);
+          q0[d] = r02[0];
+          q0[2 + d] = r02[1];
+          q1[d] = r13[0];
+          q1[2 + d] = r13[1];
+        }
+        const __amdgpu_buffer_rsrc_t rpool = make_rsrc(g.ypool + (size_t)img * (out_img / 4), (unsigned)(out_img / 4 * 2));
+        const bool owner = (l31 & 17) == 0;
+        const unsigned poff = (unsigned)((((oy >> 1) * (g.w >> 1) + (ox >> 1)) * g.cout + ch0) * 2);
+        __builtin_amdgcn_raw_buffer_store_b128(q0, rpool, (owner && ch0 + 8 <= g.cout) ? poff : OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(q1, rpool, (owner && ch0 + 16 <= g.cout) ? poff + 16 : OOB, 0, 0);
+      }
     }
   };
 
@@ -650,11 +715,19 @@ int launch_tile_wres(const TileGeom& g0, const bf16* x, const bf16* wp, const fl
   TG_CHECK(lds <= 64 * 1024, TG_ENOSUP, "conv_tile(wres): LDS %zu too large", lds);
   if (stats) {
     if constexpr (KH == 3) {
-      TG_CHECK(g.epilogue == 0 && !g.mask, TG_ENOSUP, "conv_tile(wres): statistics come with the plain epilogue only");
+      TG_CHECK(g.epilogue == 0 && !g.mask && !g.ypool, TG_ENOSUP, "conv_tile(wres): statistics come with the plain epilogue only");
       tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d,stats>", KH, KC, BN, NCH);
-      hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH, true>), dim3(nwg, ny), dim3(256), lds, s, x, wp, bias, y, g);
+      hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH, 1>), dim3(nwg, ny), dim3(256), lds, s, x, wp, bias, y, g);
     } else {
       TG_CHECK(false, TG_ENOSUP, "conv_tile(wres): statistics epilogue is built for 3x3 only");
+    }
+  } else if (g.ypool) {
+    if constexpr (KH == 3) {
+      TG_CHECK(!g.mask, TG_ENOSUP, "conv_tile(wres): the pooled output is a forward feature");
+      tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d,pool>", KH, KC, BN, NCH);
+      hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH, 2>), dim3(nwg, ny), dim3(256), lds, s, x, wp, bias, y, g);
+    } else {
+      TG_CHECK(false, TG_ENOSUP, "conv_tile(wres): pooled output is built for 3x3 only");
     }
   } else {
     tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d>", KH, KC, BN, NCH);
@@ -682,7 +755,7 @@ int launch_tile(const TileGeom& g0, const bf16* x, const bf16* wp, const float* 
       TG_CHECK(g.epilogue == 0 && !g.mask, TG_ENOSUP, "conv_tile: statistics come with the plain epilogue only");
       TG_CHECK(g.stat_chunks == g.tiles_x * g.tiles_y, TG_EINVAL, "conv_tile: stat_chunks %d, this dispatch writes %d",
                g.stat_chunks, g.tiles_x * g.tiles_y);
-      auto kst = conv_tile_kernel<KH, KC, BN, MT, UPCAT, true>;
+      auto kst = conv_tile_kernel<KH, KC, BN, MT, UPCAT, 1>;
       if (lds > 64 * 1024) {
         static bool raised_st = false;
         if (!raised_st) {
@@ -700,6 +773,29 @@ int launch_tile(const TileGeom& g0, const bf16* x, const bf16* wp, const float* 
       return TG_OK;
     } else {
       TG_CHECK(false, TG_ENOSUP, "conv_tile: statistics epilogue is built for 3x3 only");
+    }
+  }
+  if (g.ypool) {
+    if constexpr (KH == 3 && !UPCAT) {
+      TG_CHECK(!g.mask, TG_ENOSUP, "conv_tile: the pooled output is a forward feature");
+      auto kp = conv_tile_kernel<KH, KC, BN, MT, false, 2>;
+      if (lds > 64 * 1024) {
+        static bool raised_p = false;
+        if (!raised_p) {
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+              hipSuccess) {
+            tg_set_error("conv_tile: cannot raise dynamic LDS to %zu", lds);
+            return TG_ELAUNCH;
+          }
+          raised_p = true;
+        }
+      }
+      tg_note_kernel("conv_tile_kernel<%d,%d,%d,%d,pool>", KH, KC, BN, MT);
+      hipLaunchKernelGGL(kp, dim3(g.nblk, (g.cout + BN - 1) / BN), dim3(256), lds, s, x, wp, bias, y, g);
+      TG_LAUNCH_CHECK("conv_tile");
+      return TG_OK;
+    } else {
+      TG_CHECK(false, TG_ENOSUP, "conv_tile: pooled output is built for plain 3x3 convs only");
     }
   }
   auto kern = conv_tile_kernel<KH, KC, BN, MT, UPCAT>;
@@ -766,7 +862,7 @@ bool tg_conv_tile_supported(int h, int w, int hout, int wout, int kh, int kw, in
 
 int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int epilogue, float alpha, const void* x,
                      const void* wp, const float* bias, void* y, hipStream_t s, const void* mask, float* stats,
-                     int stat_chunks, int* chunks_query) {
+                     int stat_chunks, int* chunks_query, void* ypool) {
   TileGeom g;
   g.n = n; g.h = h; g.w = w; g.cin = cin; g.cout = cout;
   g.cin_pad = (cin + 15) / 16 * 16;
@@ -781,6 +877,7 @@ int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int
   g.stats = stats;
   g.stat_chunks = stat_chunks;
   g.chunks_query = chunks_query;
+  g.ypool = (bf16*)ypool;
   if (k == 1) return dispatch_tile<1>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
   return dispatch_tile<3>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
 }
@@ -809,5 +906,6 @@ int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gs
   g.stats = stats;
   g.stat_chunks = stat_chunks;
   g.chunks_query = chunks_query;
+  g.ypool = nullptr;
   return dispatch_tile_upcat(g, (const bf16*)x0, (const bf16*)wp, nullptr, (bf16*)y, s);
 }

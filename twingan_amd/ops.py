@@ -59,6 +59,8 @@ def _chk(*ts):
 # ------------------------------------------------------------------------------------------------
 # statistics of a normalised conv's output from the conv's own epilogue (TG_CONV_STATS=0: separate statistics pass, for A/Bs)
 USE_CONV_STATS = os.environ.get('TG_CONV_STATS', '1') != '0'
+# avg_pool2 of a discriminator block's last conv written by that conv (TG_CONV_POOL=0: separate pool launch)
+USE_CONV_POOL = os.environ.get('TG_CONV_POOL', '1') != '0'
 
 class PackCache:
   """bf16 K-contiguous packs (tg_conv2d_pack_weights) of registered master weights.
@@ -352,6 +354,29 @@ def conv_fwd_raw(x, w, bias, spec, epilogue):
   return y
 
 
+def conv_fwd_pool_raw(x, w, bias, spec, epilogue):
+  """(z, avg_pool2(z)): one launch where the tile kernels take the shape (tg_conv2d_fwd_pool), else conv + pool."""
+  _chk(x, w, bias)
+  d = _desc(x.shape, w.shape[3], spec, x.dtype, epilogue)
+  if USE_CONV_POOL and d.algo == TG_ALGO_MFMA and d.hout % 2 == 0 and d.wout % 2 == 0 and \
+      _lib.load().tg_conv2d_fwd_pool_supported(ctypes.byref(d)):
+    z = torch.empty((d.n, d.hout, d.wout, d.cout), dtype=x.dtype, device=x.device)
+    zp = torch.empty((d.n, d.hout // 2, d.wout // 2, d.cout), dtype=x.dtype, device=x.device)
+
+    def work():
+      tag, fl, by = _conv_work(d, 'fwd', _esize(x))
+      return tag, fl, by + zp.numel() * _esize(x)
+    call('tg_conv2d_fwd_pool', ctypes.byref(d), _p(x), _p(PackCache.get(w, d, 0)), _p(bias), _p(z), _p(zp), _stream(),
+         work=work)
+    return z, zp
+  z = conv_fwd_raw(x, w, bias, spec, epilogue)
+  n, h, ww, c = z.shape
+  zp = torch.empty((n, h // 2, ww // 2, c), dtype=z.dtype, device=z.device)
+  call('tg_pool2x2_fwd', _p(z), _p(zp), n, h, ww, c, 0.25, _dt(z), _stream(),
+       work=('pool_fwd' + _shape_tag(z), 0, int(1.25 * z.numel()) * _esize(z)))
+  return z, zp
+
+
 class ConvStats:
   """Per-workgroup statistics partials a conv wrote from its epilogue (tg_conv2d_fwd_stats): fp32
   [n][chunks][2][cout], consumed by norm_act instead of a statistics pass over the conv output."""
@@ -623,12 +648,9 @@ class Conv2dPoolFn(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, x, w, bias, spec, epilogue, mask_input=False):
-    z = conv_fwd_raw(x, w, bias, spec, epilogue)
+    z, zp = conv_fwd_pool_raw(x, w, bias, spec, epilogue)
     ctx.mask_input = mask_input
     n, h, ww, c = z.shape
-    zp = torch.empty((n, h // 2, ww // 2, c), dtype=z.dtype, device=z.device)
-    call('tg_pool2x2_fwd', _p(z), _p(zp), n, h, ww, c, 0.25, _dt(z), _stream(),
-         work=('pool_fwd' + _shape_tag(z), 0, int(1.25 * z.numel()) * _esize(z)))
     ctx.spec, ctx.epilogue = spec, epilogue
     ctx.out_hw = (h, ww)
     ctx.set_materialize_grads(False)
