@@ -51,7 +51,8 @@ def warm_start(trainer, previous_state):
 
 def run_progressive(base_cfg, batch_fn, start_hw=4, max_hw=256, hw_to_batch_size=None, num_images_per_resolution=300000,
                     device='cuda', seed=0, max_steps_per_stage=None, use_graph=False, on_stage_end=None):
-  """Trains stage after stage.  ``batch_fn(hw, batch_size)`` -> (sources, targets) device tensors.
+  """Trains stage after stage.  ``batch_fn(hw, batch_size)`` -> (sources, targets) device tensors, or
+  (sources, targets, gp_alpha_s, gp_alpha_t) to fix the gradient-penalty interpolation draws (tests).
   One reference "step" (global_step) = one generator apply = ``n_critic`` runs (image_generation.py:640-652).
   Growing stages re-create ``alpha_grow`` every step, so they launch eagerly (a captured graph bakes alpha in)."""
   from .twingan import Trainer
@@ -67,10 +68,10 @@ def run_progressive(base_cfg, batch_fn, start_hw=4, max_hw=256, hw_to_batch_size
       if growing:
         tr.cfg.alpha_grow = alpha_grow(step, steps)
       for _ in range(cfg.n_critic):
-        s, t = batch_fn(hw, bsz)
-        tr.run(s, t)
+        tr.run(*batch_fn(hw, bsz))
     state = tr.store.state_dict(include_state=True)
     history.append(dict(stage=name, hw=hw, is_growing=growing, batch_size=bsz, steps=steps, warm_started=len(loaded)))
     if on_stage_end is not None:
       on_stage_end(name, tr)
+    tr.close()
   return state, history
