@@ -131,6 +131,22 @@ def test_conv_variants_at_bench_shapes(key):
     _check_partials(st, y, key)
     del y, yd
 
+  # ---- forward that also writes its 2x2 average pool (the last conv of a discriminator block): z bit-identical to the
+  # plain forward's, the pooled tensor = the pool of that z
+  for n in (int(v) for v in eps.get('tg_conv2d_fwd_pool', [])):
+    epi = TG_EPI_BIAS | TG_EPI_LRELU
+    z, zp = O.conv_fwd_pool_raw(x[:n], w, bias, spec, epi)
+    _note(key, 'tg_conv2d_fwd_pool', str(n))
+    z_plain = O.conv_fwd_raw(x[:n], w, bias, spec, epi)
+    assert torch.equal(z, z_plain), ('fwd_pool z', key, n)
+    sel = sorted({0, n - 1})
+    e = rel_l2(host(z[sel]), N.leaky_relu(N.conv2d_gemm(host(x[sel]), wn, pad) + bn))
+    assert e < BF16_OUT_TOL, ('fwd_pool', key, n, e)
+    want = z.float().view(n, hw // 2, 2, hw // 2, 2, cout).mean(dim=(2, 4))
+    e = rel_l2(host(zp), host(want))
+    assert e < 2e-3, ('fwd_pool pooled', key, n, e)      # one bf16 rounding of the pooled value
+    del z, zp, z_plain
+
   # ---- backward-data, plain and with the producer's LeakyReLU mask in the epilogue
   for ep in ('tg_conv2d_bwd_data', 'tg_conv2d_bwd_data_masked'):
     for n in (int(v) for v in eps.get(ep, [])):
