@@ -7,6 +7,7 @@ checked directionally (cosine >= 0.9) because the graph is chaotic under bf16 st
 test_losses_and_gradients; per-primitive bf16 bounds are in test_gpu_ops.py.
 """
 import dataclasses
+import os
 
 import numpy as np
 import pytest
@@ -1117,3 +1118,65 @@ def test_progressive_stages_with_warm_start_match_oracle():
     # measured 1.5e-5 / 2.4e-5 / 2.6e-5 / 2.2e-4 / 3.3e-2: Adam's first steps are sign-like (a near-zero gradient may
     # flip one weight's step by 2 lr) and the differences carry over the stages
     assert e < (1e-3 if hw <= 8 else 8e-2), (name, e)
+
+
+def test_progressive_run_through_checkpoint_files_equals_in_memory_and_resumes(tmp_path):
+  """The same stage walk with the reference's directory protocol (TF-format checkpoints, checkpoint.py): equal to the
+  in-memory warm start (to the 1e-9 that two identical runs differ by: bias / loss sums across workgroups are float
+  atomics), a finished run is skipped, and a stage interrupted after its first step resumes from its own checkpoint
+  (optimiser slots, beta powers, global_step) and lands on the same parameters."""
+  from twingan_amd import Config, checkpoint as C
+  from twingan_amd.runner import run_progressive
+  from twingan_amd.twingan import Trainer
+  base = Config(hw=4, max_ch=8, precision='fp32')
+  table = {4: 2, 8: 2}
+
+  def batches():
+    calls = {}
+
+    def fn(hw, bsz):
+      c = calls[hw] = calls.get(hw, -1) + 1
+      g = torch.Generator().manual_seed(77 * hw + c)
+      return tuple(t.to('cuda:0') for t in (torch.rand(bsz, hw, hw, 3, generator=g), torch.rand(bsz, hw, hw, 3, generator=g),
+                                             torch.rand(bsz, generator=g), torch.rand(bsz, generator=g)))
+    return fn
+  kw = dict(start_hw=4, max_hw=8, hw_to_batch_size=table, num_images_per_resolution=4, device='cuda:0', seed=9,
+            max_steps_per_stage=2)
+  mem, _ = run_progressive(base, batches(), **kw)
+  root = str(tmp_path / 'run')
+  disk, hist = run_progressive(base, batches(), train_dir=root, **kw)
+  assert [h['steps'] for h in hist] == [2, 2, 2]
+  def same(a, b):
+    # two identical runs differ by ~1e-9 per step (float atomics in the bias / loss sums), which Adam's sign-like first
+    # steps can turn into a differing step of a weight whose gradient is ~0: compare in aggregate
+    num = sum(float(((a[k] - b[k]).double() ** 2).sum()) for k in a)
+    den = sum(float((a[k].double() ** 2).sum()) for k in a)
+    return set(a) == set(b) and (num / den) ** 0.5 < 1e-4
+  assert same(mem, disk)
+  _, again = run_progressive(base, batches(), train_dir=root, **kw)
+  assert all(h.get('skipped') for h in again)
+
+  # ---- resume inside a stage: stage '4' stopped after its first generator apply
+  tr = Trainer(dataclasses.replace(base, hw=4), device='cuda:0', seed=9)
+  fn = batches()
+  for _ in range(base.n_critic):
+    tr.run(*fn(4, 2))
+  part = str(tmp_path / 'resume')
+  C.save(tr, os.path.join(part, '4'))
+  assert C.latest_checkpoint(os.path.join(part, '4')).endswith('model.ckpt-1')
+  tr.close()
+  calls_done = base.n_critic
+
+  def resumed_batches():
+    inner = batches()
+    skipped = {'n': 0}
+
+    def fn(hw, bsz):
+      while hw == 4 and skipped['n'] < calls_done:      # the data the interrupted run already consumed
+        inner(4, bsz)
+        skipped['n'] += 1
+      return inner(hw, bsz)
+    return fn
+  res, hist = run_progressive(base, resumed_batches(), train_dir=part, **kw)
+  assert hist[0]['steps'] == 2 and not hist[0].get('skipped')
+  assert same(mem, res)

@@ -48,6 +48,25 @@ class ImageInferer:
     self.to = to
     self.dtype = torch.bfloat16 if self.cfg.precision == 'bf16' else torch.float32
 
+  @classmethod
+  def from_checkpoint(cls, cfg, model_path, device='cuda', output_tensor_name='custom_generated_t_style_source'):
+    """``model_path``: a TF-format checkpoint prefix or the train_dir that holds one (image_translation_infer.py:60-74
+    restores tf.train.latest_checkpoint(model_path)): the model's variables are read by name (checkpoint.py)."""
+    import os
+    from . import checkpoint as ckpt
+    cfg = cfg if isinstance(cfg, Config) else Config(**cfg)
+    prefix = ckpt.latest_checkpoint(model_path) if os.path.isdir(model_path) else model_path
+    if prefix is None:
+      raise FileNotFoundError('no checkpoint in %s' % model_path)
+    probe = declare_twingan(ParamStore(torch.device('cpu')), cfg).build(0)
+    names = set(probe.specs) | set(probe.state_specs)
+    probe.close()
+    arrays = ckpt.read_checkpoint(prefix, names=names)
+    missing = sorted(names - set(arrays))
+    if missing:
+      raise KeyError('checkpoint %s lacks %d variable(s) of this configuration, e.g. %s' % (prefix, len(missing), missing[0]))
+    return cls(cfg, {k: torch.from_numpy(v.astype(np.float32)) for k, v in arrays.items()}, device, output_tensor_name)
+
   def preprocess(self, images):
     """uint8 [H,W,3] / [B,H,W,3] (or floats already in [0,1]) -> device tensor [B, hw, hw, 3] of the model's dtype."""
     x = torch.as_tensor(np.asarray(images))

@@ -178,6 +178,25 @@ class ParamStore:
       sd.update({k: v.clone() for k, v in self.state.items() if k in self.state_specs})
     return sd
 
+  def adam_dict(self):
+    """{variable name: (m, v)} -- logical views of the shared Adam optimiser's slot variables (TF: <var>/Adam,
+    <var>/Adam_1)."""
+    out = {}
+    for k, s in self.specs.items():
+      g, off, n = s['group'], self.offsets[k], int(math.prod(s['phys']))
+      out[k] = (self._logical(self.m[g][off:off + n].view(s['phys']), s).clone(),
+                self._logical(self.v[g][off:off + n].view(s['phys']), s).clone())
+    return out
+
+  def load_adam_dict(self, slots):
+    """Inverse of adam_dict for the names given ({name: (m, v)} of logical shape)."""
+    with torch.no_grad():
+      for k, (m, v) in slots.items():
+        s = self.specs[k]
+        g, off, n = s['group'], self.offsets[k], int(math.prod(s['phys']))
+        for dst, src in ((self.m[g], m), (self.v[g], v)):
+          self._logical(dst[off:off + n].view(s['phys']), s).copy_(torch.as_tensor(src, dtype=torch.float32).reshape(s['shape']))
+
   def grad_dict(self):
     GradSink.flush()                             # filter gradients held back for pairing
     if self.device.type == 'cuda':

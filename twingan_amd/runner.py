@@ -50,26 +50,49 @@ def warm_start(trainer, previous_state):
 
 
 def run_progressive(base_cfg, batch_fn, start_hw=4, max_hw=256, hw_to_batch_size=None, num_images_per_resolution=300000,
-                    device='cuda', seed=0, max_steps_per_stage=None, use_graph=False, on_stage_end=None):
+                    device='cuda', seed=0, max_steps_per_stage=None, use_graph=False, on_stage_end=None, train_dir=None):
   """Trains stage after stage.  ``batch_fn(hw, batch_size)`` -> (sources, targets) device tensors, or
   (sources, targets, gp_alpha_s, gp_alpha_t) to fix the gradient-penalty interpolation draws (tests).
   One reference "step" (global_step) = one generator apply = ``n_critic`` runs (image_generation.py:640-652).
-  Growing stages re-create ``alpha_grow`` every step, so they launch eagerly (a captured graph bakes alpha in)."""
+  Growing stages re-create ``alpha_grow`` every step, so they launch eagerly (a captured graph bakes alpha in).
+  ``train_dir``: the reference's directory protocol (pggan_runner.py:100-160) over TF-format checkpoints
+  (checkpoint.py) -- stage ``name`` trains in <train_dir>/<name>, is skipped when that directory already holds a
+  checkpoint of >= its number of steps, resumes from a checkpoint it finds there, otherwise warm-starts from the
+  previous stage's directory with ignore_missing_vars = is_growing, and saves model.ckpt-<global_step> at its end."""
+  import os
+  from . import checkpoint as ckpt
   from .twingan import Trainer
   state = None
   history = []
+  last_dir = None
   for name, hw, growing, bsz, steps in stage_schedule(start_hw, max_hw, hw_to_batch_size, num_images_per_resolution):
     if max_steps_per_stage is not None:
       steps = min(steps, max_steps_per_stage)
+    cur_dir = os.path.join(train_dir, name) if train_dir else None
+    found = ckpt.latest_checkpoint(cur_dir) if cur_dir else None
+    if found is not None and int(found.rsplit('-', 1)[1]) >= steps:      # 'Skipping already trained model'
+      history.append(dict(stage=name, hw=hw, is_growing=growing, batch_size=bsz, steps=0, warm_started=0, skipped=True))
+      last_dir = cur_dir
+      continue
     cfg = replace(base_cfg, hw=hw, is_growing=growing, alpha_grow=0.0)
     tr = Trainer(cfg, device=device, seed=seed, use_graph=use_graph and not growing)
-    loaded = warm_start(tr, state) if state is not None else []
-    for step in range(steps):
+    first = 0
+    if found is not None:
+      first = ckpt.restore(tr, found)
+      loaded = list(tr.store.specs)
+    elif train_dir:
+      loaded = ckpt.init_from_checkpoint(tr, last_dir, ignore_missing_vars=growing, train_dir=cur_dir) if last_dir else []
+    else:
+      loaded = warm_start(tr, state) if state is not None else []
+    for step in range(first, steps):
       if growing:
         tr.cfg.alpha_grow = alpha_grow(step, steps)
       for _ in range(cfg.n_critic):
         tr.run(*batch_fn(hw, bsz))
     state = tr.store.state_dict(include_state=True)
+    if cur_dir:
+      ckpt.save(tr, cur_dir, global_step=steps)
+      last_dir = cur_dir
     history.append(dict(stage=name, hw=hw, is_growing=growing, batch_size=bsz, steps=steps, warm_started=len(loaded)))
     if on_stage_end is not None:
       on_stage_end(name, tr)

@@ -377,6 +377,11 @@ class Trainer:
       lo, hi = self.store.phase_bounds[group][seg]
       self.reducer.start(g[lo:hi], n_buckets=1)
 
+  def set_adam_step(self, t):
+    """The shared optimiser has applied ``t`` times (restoring a checkpoint: beta powers = beta^(t+1))."""
+    self.adam_t = int(t)
+    self._adam_step_dev.fill_(int(t))
+
   def _adam(self, group):
     """tf.train.AdamOptimizer apply (model/model_inheritor.py:537-542) on the group's flat buffers, then
     refresh the bf16 weight packs of the convs that just moved."""
