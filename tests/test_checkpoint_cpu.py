@@ -199,3 +199,41 @@ def test_run_progressive_directory_protocol(tmp_path):
   _, again = run_progressive(base, None, 4, 8, table, num_images_per_resolution=4, device='cpu', seed=8, max_steps_per_stage=0,
                              train_dir=root)
   assert all(h.get('skipped') for h in again)
+
+
+def test_warm_start_restores_model_variables_only(tmp_path):
+  """slim.get_model_variables() (model_inheritor.py:612-614) does not contain what libs/sn.py:56 and
+  libs/self_attention.py:68 create with tf.get_variable: a stage's warm start leaves spectral-norm ``u`` and
+  ``sa_gamma`` at their fresh initialisation (both the in-memory and the file-based warm start); a full restore of a
+  run (checkpoint.restore) loads them."""
+  from twingan_amd import Config
+  from twingan_amd.runner import warm_start
+  from twingan_amd.twingan import Trainer
+  cfg = Config(hw=8, max_ch=8, precision='fp32', spectral_norm=True, do_self_attention=True, self_attention_hw=8)
+  a = Trainer(cfg, device='cpu', seed=1)
+  with torch.no_grad():
+    for k, p in a.store.P.items():
+      if k.endswith('/sa_gamma'):
+        p.fill_(0.7)
+  sd = a.store.state_dict(include_state=True)
+  special = [k for k in sd if k.endswith('/u') or k.endswith('/sa_gamma')]
+  assert any(k.endswith('/u') for k in special) and any(k.endswith('/sa_gamma') for k in special)
+  C.save(a, str(tmp_path / 's'))
+  for how in ('memory', 'files', 'restore'):
+    b = Trainer(cfg, device='cpu', seed=2)
+    fresh = b.store.state_dict(include_state=True)
+    if how == 'memory':
+      loaded = warm_start(b, sd)
+    elif how == 'files':
+      loaded = C.init_from_checkpoint(b, str(tmp_path / 's'))
+    else:
+      C.restore(b, C.latest_checkpoint(str(tmp_path / 's')))
+      loaded = list(sd)
+    after = b.store.state_dict(include_state=True)
+    for k in sd:
+      if k in special and how != 'restore':
+        assert k not in loaded and torch.equal(after[k], fresh[k]), (how, k)
+      else:
+        assert torch.equal(after[k], sd[k]), (how, k)
+    b.close()
+  a.close()

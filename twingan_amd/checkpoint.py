@@ -465,7 +465,9 @@ def save(trainer, train_dir, global_step=None):
 def init_from_checkpoint(trainer, checkpoint_path, checkpoint_exclude_scopes=None, ignore_missing_vars=False,
                          train_dir=None):
   """model/model_inheritor.py:576-644 (_get_init_fn + slim.assign_from_checkpoint_fn): restore the MODEL variables
-  (not the optimiser slots, not global_step) whose names do not start with an excluded scope from ``checkpoint_path``
+  (slim.get_model_variables(): not the optimiser slots, not global_step, and not the two tf.get_variable variables of
+  the path -- spectral-norm ``u`` and ``sa_gamma``, params.is_model_variable) whose names do not start with an excluded
+  scope from ``checkpoint_path``
   (a checkpoint prefix, or a directory -> its latest checkpoint).  Nothing is restored when ``train_dir`` already holds
   a checkpoint (the run resumes from that one instead).  A variable the checkpoint lacks is an error unless
   ``ignore_missing_vars`` (growing stages: the new resolution's layers keep their fresh initialisation,
@@ -478,8 +480,10 @@ def init_from_checkpoint(trainer, checkpoint_path, checkpoint_exclude_scopes=Non
   if prefix is None:
     raise FileNotFoundError('no checkpoint in %s' % checkpoint_path)
   exclusions = [s.strip() for s in (checkpoint_exclude_scopes or '').split(',') if s.strip()]
+  from .params import is_model_variable
   store = trainer.store
-  wanted = [k for k in list(store.specs) + list(store.state_specs) if not any(k.startswith(e) for e in exclusions)]
+  wanted = [k for k in list(store.specs) + list(store.state_specs)
+            if is_model_variable(k) and not any(k.startswith(e) for e in exclusions)]
   available = {name: shape for name, shape, _ in list_variables(prefix)}
   missing = [k for k in wanted if k not in available]
   if missing and not ignore_missing_vars:

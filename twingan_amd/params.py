@@ -237,6 +237,16 @@ class ParamStore:
 _HW_IN_NAME = __import__('re').compile(r'/(?:encoder_block|from_rgb|self_attention|block|generator_to_rgb)_(\d+)x\d+')
 
 
+def is_model_variable(name):
+  """Is ``name`` in slim's MODEL_VARIABLES collection, i.e. among what a stage's warm start restores
+  (slim.get_model_variables() in model/model_inheritor.py:612-614)?  Every variable of the path is created through slim
+  layers / variables.model_variable (libs/instance_norm.py:101,121; libs/batch_norm.py:142-224), except the two that use
+  tf.get_variable directly: the spectral-norm vector ``u`` (libs/sn.py:56) and the attention gate ``sa_gamma``
+  (libs/self_attention.py:68).  Those are re-initialised by every stage of the reference; a full Saver restore
+  (resuming a run, inference) still loads them."""
+  return not (name.endswith('/u') or name.endswith('/sa_gamma'))
+
+
 def grad_phase(name, cfg):
   """Backward segment (twingan.Trainer._grad_segments) at whose end the gradient of variable ``name`` is complete,
   for the cut resolution ``cfg.overlap_cut_hw``:

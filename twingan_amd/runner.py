@@ -41,10 +41,12 @@ def warm_start(trainer, previous_state):
   """Loads every variable of ``previous_state`` (a ParamStore.state_dict()) that this stage also has and whose
   shape matches; the rest keep their fresh initialisation -- slim's assign_from_checkpoint_fn with
   ignore_missing_vars (model/model_inheritor.py:576-644).  Returns the names that were loaded."""
+  from .params import is_model_variable
   specs, state = trainer.store.specs, trainer.store.state
   usable = {k: v for k, v in previous_state.items()
-            if (k in specs and tuple(v.shape) == specs[k]['shape']) or
-            (k in trainer.store.state_specs and tuple(v.shape) == tuple(state[k].shape))}
+            if is_model_variable(k) and      # spectral-norm u and sa_gamma are not model variables: fresh every stage
+            ((k in specs and tuple(v.shape) == specs[k]['shape']) or
+             (k in trainer.store.state_specs and tuple(v.shape) == tuple(state[k].shape)))}
   trainer.store.load_state_dict(usable, strict=False)
   return sorted(usable)
 
