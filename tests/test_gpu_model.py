@@ -1122,9 +1122,8 @@ def test_progressive_stages_with_warm_start_match_oracle():
 
 def test_progressive_run_through_checkpoint_files_equals_in_memory_and_resumes(tmp_path):
   """The same stage walk with the reference's directory protocol (TF-format checkpoints, checkpoint.py): equal to the
-  in-memory warm start (to the 1e-9 that two identical runs differ by: bias / loss sums across workgroups are float
-  atomics), a finished run is skipped, and a stage interrupted after its first step resumes from its own checkpoint
-  (optimiser slots, beta powers, global_step) and lands on the same parameters."""
+  in-memory warm start bit for bit, a finished run is skipped, and a stage interrupted after its first step resumes
+  from its own checkpoint (optimiser slots, beta powers, global_step) and lands on the same parameters."""
   from twingan_amd import Config, checkpoint as C
   from twingan_amd.runner import run_progressive
   from twingan_amd.twingan import Trainer
@@ -1146,12 +1145,8 @@ def test_progressive_run_through_checkpoint_files_equals_in_memory_and_resumes(t
   root = str(tmp_path / 'run')
   disk, hist = run_progressive(base, batches(), train_dir=root, **kw)
   assert [h['steps'] for h in hist] == [2, 2, 2]
-  def same(a, b):
-    # two identical runs differ by ~1e-9 per step (float atomics in the bias / loss sums), which Adam's sign-like first
-    # steps can turn into a differing step of a weight whose gradient is ~0: compare in aggregate
-    num = sum(float(((a[k] - b[k]).double() ** 2).sum()) for k in a)
-    den = sum(float((a[k].double() ** 2).sum()) for k in a)
-    return set(a) == set(b) and (num / den) ** 0.5 < 1e-4
+  def same(a, b):      # the fp32 path is bit-reproducible (test_fp32_path_is_bit_reproducible)
+    return set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
   assert same(mem, disk)
   _, again = run_progressive(base, batches(), train_dir=root, **kw)
   assert all(h.get('skipped') for h in again)
@@ -1180,3 +1175,29 @@ def test_progressive_run_through_checkpoint_files_equals_in_memory_and_resumes(t
   res, hist = run_progressive(base, resumed_batches(), train_dir=part, **kw)
   assert hist[0]['steps'] == 2 and not hist[0].get('skipped')
   assert same(mem, res)
+
+
+@pytest.mark.parametrize('norm', ['instance_norm', 'batch_norm'])
+def test_fp32_path_is_bit_reproducible(norm):
+  """The exact-parity (fp32) path has no order-dependent float atomic left: statistics, filter / bias / gamma / beta
+  gradients, loss sums and per-sample sums are each taken by one workgroup or summed from per-workgroup partials in a
+  fixed order (tg_common.h exact_path).  Two trainers fed the same data follow the same trajectory bit for bit."""
+  from twingan_amd import Config
+  from twingan_amd.twingan import Trainer
+  cfg = Config(hw=32, max_ch=16, precision='fp32', generator_norm_type=norm)
+  g = torch.Generator().manual_seed(3)
+  data = [(torch.rand(3, 32, 32, 3, generator=g), torch.rand(3, 32, 32, 3, generator=g), torch.rand(3, generator=g),
+           torch.rand(3, generator=g)) for _ in range(4)]
+  ends = []
+  for rep in range(2):
+    tr = Trainer(cfg, device='cuda:0', seed=4)
+    for s, t, a_s, a_t in data:
+      tr.run(s.cuda(), t.cuda(), a_s.cuda(), a_t.cuda())
+    torch.cuda.synchronize()
+    ends.append((tr.store.state_dict(include_state=True), {k: (m, v) for k, (m, v) in tr.store.adam_dict().items()}))
+    tr.close()
+  (pa, sa), (pb, sb) = ends
+  bad = [k for k in pa if not torch.equal(pa[k], pb[k])]
+  assert not bad, (len(bad), bad[:5])
+  bad = [k for k in sa if not (torch.equal(sa[k][0], sb[k][0]) and torch.equal(sa[k][1], sb[k][1]))]
+  assert not bad, (len(bad), bad[:5])

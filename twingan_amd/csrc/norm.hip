@@ -791,6 +791,10 @@ int tg_instance_norm_stats(const void* y, float* mean, float* rstd, int n, int h
     const int V = pick_v<T>(c);
     TG_CHECK(c / V <= 256, TG_ENOSUP, "tg_instance_norm_stats: c=%d not supported", c);
     const size_t lds = 2 * (size_t)c * sizeof(float);
+    if (exact_path<T>()) {      // one workgroup per image: its sums do not meet another workgroup's in an atomic
+      chunks = 1;
+      ppb = hw;
+    }
     if (V == 1)
       hipLaunchKernelGGL((in_stats_partial<T, 1>), dim3(chunks, n), dim3(256), lds, s, (const T*)y, mean, rstd, hw, c, ppb);
     else
@@ -899,12 +903,20 @@ static int lrelu_bwd_launch(const char* who, const void* gz, const void* gzp, in
     // few, fat workgroups when a bias gradient is produced: every workgroup ends with c global atomics
     const int blocks = gbias ? tg_grid_for(npix, lanes * 16, 1024) : tg_grid_for(npix, lanes * 4, 2048);
     const size_t lds = (size_t)c * sizeof(float);
+    // exact path: the element-wise part on the full grid, the bias gradient by one workgroup over what it wrote
+    float* gb_here = (exact_path<T>() && blocks > 1) ? nullptr : gbias;
     if (V == 1)
       hipLaunchKernelGGL((lrelu_bwd_bias_kernel<T, 1>), dim3(blocks), dim3(256), lds, s, (const T*)gz, (const T*)gzp, hw,
-                         wdim, (const T*)z, (T*)gy, gbias, npix, c, alpha);
+                         wdim, (const T*)z, (T*)gy, gb_here, npix, c, alpha);
     else
       hipLaunchKernelGGL((lrelu_bwd_bias_kernel<T, Vec16<T>::N>), dim3(blocks), dim3(256), lds, s, (const T*)gz,
-                         (const T*)gzp, hw, wdim, (const T*)z, (T*)gy, gbias, npix, c, alpha);
+                         (const T*)gzp, hw, wdim, (const T*)z, (T*)gy, gb_here, npix, c, alpha);
+    if (gbias && !gb_here) {
+      if (V == 1)
+        hipLaunchKernelGGL((channel_sum_kernel<T, 1>), dim3(1), dim3(256), lds, s, (const T*)gy, gbias, npix, c);
+      else
+        hipLaunchKernelGGL((channel_sum_kernel<T, Vec16<T>::N>), dim3(1), dim3(256), lds, s, (const T*)gy, gbias, npix, c);
+    }
   });
   hipError_t e__ = hipGetLastError();
   if (e__ != hipSuccess) {
@@ -943,7 +955,7 @@ int tg_channel_sum(const void* g, float* out, int64_t npix, int c, int accumulat
     const int V = pick_v<T>(c);
     TG_CHECK(c / V <= 256, TG_ENOSUP, "tg_channel_sum: c=%d not supported", c);
     const int lanes = 256 / (c / V);
-    const int blocks = tg_grid_for(npix, lanes * 8, 1024);
+    const int blocks = exact_path<T>() ? 1 : tg_grid_for(npix, lanes * 8, 1024);
     const size_t lds = (size_t)c * sizeof(float);
     if (V == 1)
       hipLaunchKernelGGL((channel_sum_kernel<T, 1>), dim3(blocks), dim3(256), lds, s, (const T*)g, out, npix, c);

@@ -403,7 +403,7 @@ __global__ void pw_small_out_kernel(const T* __restrict__ x, const float* __rest
 template <typename T, int V>
 __global__ void pw_wgrad_kernel(const T* __restrict__ small, const T* __restrict__ big, float* __restrict__ out,
                                 int64_t npix, int ns, int cb, int os, int oc) {
-  extern __shared__ float sacc[];   // [ns][cb]
+  extern __shared__ float sacc[];   // [ns][cb], then one [ns][cb] slot per wave (pow2 channel-vector counts)
   for (int i = threadIdx.x; i < ns * cb; i += blockDim.x) sacc[i] = 0.f;
   __syncthreads();
   const int cv = cb / V;
@@ -452,10 +452,19 @@ __global__ void pw_wgrad_kernel(const T* __restrict__ small, const T* __restrict
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[s][j] += __shfl_xor(acc[s][j], o, 64);
     }
+    // the waves' sums go to per-wave slots and are added in wave order: no LDS atomics, a fixed summation order
+    float* slot = sacc + (1 + (threadIdx.x >> 6)) * ns * cb;
     if ((int)(threadIdx.x & 63) < cv) {
       for (int s = 0; s < ns; ++s)
 #pragma unroll
-        for (int j = 0; j < V; ++j) atomicAdd(&sacc[s * cb + v * V + j], acc[s][j]);
+        for (int j = 0; j < V; ++j) slot[s * cb + v * V + j] = acc[s][j];
+    }
+    __syncthreads();
+    const int nw = blockDim.x >> 6;
+    for (int i = threadIdx.x; i < ns * cb; i += blockDim.x) {
+      float t = 0.f;
+      for (int wv = 0; wv < nw; ++wv) t += sacc[(1 + wv) * ns * cb + i];
+      sacc[i] = t;
     }
   } else if (pl < lanes) {
     for (int s = 0; s < ns; ++s)
@@ -501,8 +510,8 @@ int launch_pw_wgrad(const T* x, const T* gy, float* gw, int64_t npix, int cin, i
   const T* big = small_in ? gy : x;
   const int ns = small_in ? cin : cout, cb = small_in ? cout : cin;
   const int os = small_in ? cout : 1, oc = small_in ? 1 : cout;   // gw[ci][co] index strides
-  const size_t lds = (size_t)ns * cb * sizeof(float);
-  const int blocks = tg_grid_for(npix, 64, 1024);
+  const size_t lds = (size_t)ns * cb * sizeof(float) * (1 + 256 / 64);
+  const int blocks = exact_path<T>() ? 1 : tg_grid_for(npix, 64, 1024);
   if (cb % V == 0 && cb / V <= 256)
     hipLaunchKernelGGL((pw_wgrad_kernel<T, V>), dim3(blocks), dim3(256), lds, s, small, big, gw, npix, ns, cb, os, oc);
   else

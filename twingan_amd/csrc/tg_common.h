@@ -103,6 +103,11 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 __device__ __forceinline__ float lrelu_f(float x, float a) { return fmaxf(a * x, x); }
 
+// The fp32 storage type is the exact-parity path: every sum that ends in one number per channel / sample / tensor is
+// taken by ONE workgroup there (launchers pass a grid of 1), so no result depends on the order in which workgroups
+// reach a float atomic -- the path is bit-reproducible.  The bf16 path keeps the wide grids and their fp32 atomics.
+template <typename T> constexpr bool exact_path() { return sizeof(T) == 4; }
+
 // launch-heuristic experiments: TG_TUNE_<NAME>=<int> in the environment overrides `dflt` (read at every call, so
 // two hipGraph captures in one process can bake different settings).  For tools/ab_env.py; no call site is left in
 // the tree when an experiment is over
