@@ -384,6 +384,18 @@ int tg_spectral_norm_bwd(const float* g_wbar, const float* w, const float* u, co
                          const float* stats, float* gw, int accumulate, int k_rows, int cout, void* ws, size_t ws_bytes,
                          void* stream);
 
+/* Training-image preprocessing (preprocessing/danbooru_preprocessing.py:115-230 preprocess_image with the TwinGAN
+ * trainer's defaults, model/model_inheritor.py:403-457; resize_image of preprocessing/preprocessing_util.py:97-146): n
+ * decoded uint8 RGB images of arbitrary size -> out [n, hw, hw, 3] (dtype) in [0, 1].  packed: the images' bytes, image i
+ * at packed + offsets[i] as [h][w][3]; rect: int32 [n][6] = image h, w and the source rectangle (y0, x0, sh, sw) in
+ * image coordinates that is resized to hw x hw -- PAD: (-(size-h)/2, -(size-w)/2, size, size) with size = max(h, w) and
+ * zeros outside the image, CROP: ((h-size)/2, (w-size)/2, size, size) with size = min(h, w), RESHAPE: (0, 0, h, w);
+ * bilinear as TF 1.x (align_corners=False, no half-pixel centres).  aug: fp32 [n][4] = flip left-right (0/1), colour
+ * order (0: brightness then saturation, 1: saturation then brightness), brightness delta, saturation factor -- the
+ * random draws of random_flip_left_right / distort_color(fast_mode) are the caller's; (0, 0, 0, 1) = evaluation. */
+int tg_preprocess_images(const void* packed, const int64_t* offsets, const int* rect, const float* aug, void* out, int n,
+                         int hw, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

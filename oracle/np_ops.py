@@ -284,3 +284,92 @@ def adam_step(theta, g, m, v, t, lr=1e-4, beta1=0.5, beta2=0.99, eps=1e-8):
   v = beta2 * v + (1.0 - beta2) * g * g
   theta = theta - lr_t * m / (np.sqrt(v) + eps)
   return theta, m, v
+
+
+# ------------------------------------------------------------------------------------------------ input preprocessing
+def resize_bilinear_tf1(x, out_h, out_w):
+  """tf.image.resize_images(..., BILINEAR), align_corners=False, TF-1.x (no half-pixel centres): in = out * in_size /
+  out_size; top-left = floor, bottom-right = min(+1, size - 1).  x: [h, w, c] float64."""
+  h, w = x.shape[:2]
+  fy = np.arange(out_h) * (np.float32(h) / np.float32(out_h)).astype(np.float64)
+  fx = np.arange(out_w) * (np.float32(w) / np.float32(out_w)).astype(np.float64)
+  top, left = np.floor(fy).astype(int), np.floor(fx).astype(int)
+  bot, right = np.minimum(top + 1, h - 1), np.minimum(left + 1, w - 1)
+  ly, lx = (fy - top)[:, None, None], (fx - left)[None, :, None]
+  t = x[top][:, left] + (x[top][:, right] - x[top][:, left]) * lx
+  b = x[bot][:, left] + (x[bot][:, right] - x[bot][:, left]) * lx
+  return t + (b - t) * ly
+
+
+def rgb_to_hsv(rgb):
+  """tf.image.rgb_to_hsv (core/kernels/colorspace_op.h), element-wise on [..., 3]."""
+  r, g, b = rgb[..., 0], rgb[..., 1], rgb[..., 2]
+  v = rgb.max(axis=-1)
+  rng = v - rgb.min(axis=-1)
+  s = np.where(v > 0, rng / np.where(v > 0, v, 1), 0.0)
+  norm = 1.0 / (6.0 * np.where(rng > 0, rng, 1))
+  h = np.where(r == v, norm * (g - b), np.where(g == v, norm * (b - r) + 2.0 / 6.0, norm * (r - g) + 4.0 / 6.0))
+  h = np.where(rng > 0, h, 0.0)
+  h = np.where(h < 0, h + 1.0, h)
+  return np.stack([h, s, v], axis=-1)
+
+
+def hsv_to_rgb(hsv):
+  """tf.image.hsv_to_rgb (colorspace_op.h)."""
+  h, s, v = hsv[..., 0], hsv[..., 1], hsv[..., 2]
+  c = s * v
+  m = v - c
+  dh = h * 6.0
+  cat = np.floor(dh).astype(int)
+  fm = dh - 2.0 * np.floor(dh / 2.0)
+  x = c * (1 - np.abs(fm - 1))
+  z = np.zeros_like(c)
+  table = [(c, x, z), (x, c, z), (z, c, x), (z, x, c), (x, z, c), (c, z, x)]
+  out = np.zeros(hsv.shape)
+  for k, (rr, gg, bb) in enumerate(table):
+    sel = (cat == k) | ((k == 5) & (cat >= 6)) | ((k == 0) & (cat < 0))
+    out[..., 0] = np.where(sel, rr, out[..., 0])
+    out[..., 1] = np.where(sel, gg, out[..., 1])
+    out[..., 2] = np.where(sel, bb, out[..., 2])
+  return out + m[..., None]
+
+
+def adjust_saturation(rgb, factor):
+  """tf.image.adjust_saturation: HSV round trip with s = clip(s * factor, 0, 1)."""
+  hsv = rgb_to_hsv(rgb)
+  hsv[..., 1] = np.clip(hsv[..., 1] * factor, 0.0, 1.0)
+  return hsv_to_rgb(hsv)
+
+
+def preprocess_image(img_u8, hw, resize_mode='PAD', is_training=True, flip=False, saturation_first=False, delta=0.0,
+                     factor=1.0):
+  """preprocessing/danbooru_preprocessing.py:115-230 with the TwinGAN trainer's defaults (model_inheritor.py:403-457:
+  padding 0, rgb, no mean subtraction, no random cropping, fast_mode): convert_image_dtype to [0, 1]; resize_image
+  (preprocessing_util.py:97-146) -- PAD: zero-pad about the centre to max(h, w); CROP: centre-crop to min(h, w); RESHAPE:
+  as is -- then bilinear to [hw, hw]; when training: random_flip_left_right (flip if the draw < 0.5), distort_color in
+  fast mode (ordering 0: brightness then saturation; orderings 1-3: saturation then brightness), clip to [0, 1].
+  The random draws are arguments."""
+  x = (img_u8.astype(np.float32) * np.float32(1.0 / 255.0)).astype(np.float64)
+  h, w = x.shape[:2]
+  if resize_mode == 'PAD' and h != w:
+    size = max(h, w)
+    oh, ow = (size - h) // 2, (size - w) // 2
+    sq = np.zeros((size, size, x.shape[2]))
+    sq[oh:oh + h, ow:ow + w] = x
+    x = sq
+  elif resize_mode == 'CROP' and h != w:
+    size = min(h, w)
+    oh, ow = (h - size) // 2, (w - size) // 2
+    x = x[oh:oh + size, ow:ow + size]
+  elif resize_mode not in ('PAD', 'CROP', 'RESHAPE'):
+    raise ValueError(resize_mode)
+  x = resize_bilinear_tf1(x, hw, hw)
+  if is_training:
+    if flip:
+      x = x[:, ::-1]
+    if saturation_first:
+      x = adjust_saturation(x, factor) + delta
+    else:
+      x = adjust_saturation(x + delta, factor)
+    x = np.clip(x, 0.0, 1.0)
+  return x

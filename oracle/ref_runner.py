@@ -356,3 +356,25 @@ def run_pggan(flags, targets, global_step=0, seed=0, preset=None, want_grads=Tru
       gr = torch.autograd.grad(total, leaves, allow_unused=True, retain_graph=True)
       res[tag] = {k: g.numpy().copy() for k, g in zip(names, gr) if g is not None}
   return res
+
+
+def run_preprocess(image_u8, hw, resize_mode='PAD', is_training=True, seed=0):
+  """The reference's OWN preprocessing/danbooru_preprocessing.preprocess_image (the TwinGAN trainer's image
+  preprocessing, model/model_inheritor.py:403-457) executed on the TF stand-in for one uint8 image [h, w, 3].
+  Returns (output [hw, hw, 3] float64, draws) with draws = dict(flip_uniform, sel, applied=[(kind, value), ...]) --
+  the random values the code drew for the branch that was live, so that a restatement can be fed the same ones."""
+  import importlib
+  tf = loader.install()
+  from .tf_shim import core
+  importlib.import_module('preprocessing.preprocessing_util')
+  pre = importlib.import_module('preprocessing.danbooru_preprocessing')
+  core.STATE.random_log.clear()
+  core.STATE.aug_log.clear()
+  core.STATE.gen.manual_seed(seed)
+  img = tf.Tensor(torch.tensor(np.asarray(image_u8), dtype=torch.float64), tf.uint8, 'image')
+  out = pre.preprocess_image(img, hw, hw, dtype=tf.float32, resize_mode=resize_mode, is_training=is_training,
+                             add_image_summaries=False)
+  log = [(n, float(v)) for n, v in core.STATE.random_log]
+  draws = dict(flip_uniform=log[0][1] if is_training else None, sel=int(log[1][1]) if is_training else None,
+               applied=list(core.STATE.aug_log))
+  return out.t.detach().numpy().copy(), draws

@@ -53,6 +53,7 @@ class DType(object):
 
 float16, float32, float64 = DType('float16', True), DType('float32', True), DType('float64', True)
 int32, int64, bool_ = DType('int32', False), DType('int64', False), DType('bool', False)
+uint8 = DType('uint8', False)
 
 
 class Dimension(object):
@@ -277,6 +278,9 @@ class Tensor(object):
   def __rtruediv__(self, o):
     return self._bin(o, torch.div, True)
 
+  def __floordiv__(self, o):
+    return self._bin(o, lambda a, b: torch.floor(a / b))
+
   def __pow__(self, o):
     return self._bin(o, torch.pow)
 
@@ -384,6 +388,7 @@ class State(object):
     self.collections = {}
     self.gen = torch.Generator().manual_seed(seed)
     self.random_log = []                # (op name, torch tensor) of every random op, in call order
+    self.aug_log = []                   # (kind, value) of the colour distortions applied to a LIVE image, in order
     self.global_step = None
     self.name_scope = ''
     self.placeholder_batch = 1

@@ -24,7 +24,11 @@ REAL = ('nets', 'nets.pggan', 'nets.pggan_utils', 'libs', 'libs.ops', 'libs.batc
         'libs.sn', 'libs.self_attention', 'libs.gdrop', 'util_misc', 'twingan', 'image_generation', 'model',
         'model.model_inheritor', 'pggan_runner', 'deployment', 'deployment.model_deploy')
 STUBS = ('datasets', 'preprocessing', 'util_io', 'nets.cyclegan', 'nets.cyclegan_dis',
-         'nets.nets_factory', 'PIL', 'scipy.misc')
+         'nets.nets_factory', 'scipy.misc')      # (PIL is installed here: util_misc.py imports the real one)
+# real modules inside a stubbed package (the TwinGAN trainer's own preprocessing; the factory and the classifier
+# zoo's preprocessing stay stubs).  Import preprocessing_util before danbooru_preprocessing: the latter fetches it as an
+# attribute of the (stub) package.
+REAL_IN_STUBS = ('preprocessing.preprocessing_util', 'preprocessing.danbooru_preprocessing')
 
 
 def py2div(a, b):
@@ -76,10 +80,11 @@ class _ReferenceFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
     return None, False
 
   def find_spec(self, name, path=None, target=None):
-    if name in STUBS or name.startswith(tuple(s + '.' for s in STUBS)):
-      return importlib.machinery.ModuleSpec(name, tfapi._StubFinder(()), is_package=True)
-    if name not in REAL:
-      return None
+    if name not in REAL_IN_STUBS:
+      if name in STUBS or name.startswith(tuple(s + '.' for s in STUBS)):
+        return importlib.machinery.ModuleSpec(name, tfapi._StubFinder(()), is_package=True)
+      if name not in REAL:
+        return None
     p, is_pkg = self._path(name)
     if p is None:
       return None

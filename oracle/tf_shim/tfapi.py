@@ -158,6 +158,8 @@ def add_n(inputs, name=None):
 
 
 def clip_by_value(x, lo, hi, name=None):
+  if x is None:      # a dead tensor of a control_flow_ops.switch stays dead
+    return None
   return wrap(torch.minimum(torch.maximum(raw(x), raw(lo)), raw(hi)), x)
 
 
@@ -225,7 +227,11 @@ def random_normal(shape, mean=0.0, stddev=1.0, dtype=float32, seed=None, name=No
 
 def random_uniform(shape, minval=0, maxval=None, dtype=float32, seed=None, name=None):
   maxval = 1.0 if maxval is None else maxval
-  return Tensor(_draw('uniform', shape, name, maxval - minval, minval), dtype, name)
+  t = _draw('uniform', shape, name, maxval - minval, minval)
+  if not dtype.is_floating:      # integer draws: uniform over [minval, maxval)
+    t = torch.floor(t)
+    STATE.random_log[-1] = (STATE.random_log[-1][0], t)
+  return Tensor(t, dtype, name)
 
 
 # ---- control flow / state ------------------------------------------------------------------------------------
@@ -439,7 +445,7 @@ def image_resize_bilinear(images, size, align_corners=False, name=None):
   ih, iw = t.shape[1], t.shape[2]
 
   def taps(o, i):
-    src = torch.arange(o, dtype=F64) * (i / o)
+    src = torch.arange(o, dtype=F64) * float(np.float32(i) / np.float32(o))      # the kernel's scale is a float32
     lo = torch.clamp(torch.floor(src).long(), max=i - 1)
     hi = torch.clamp(lo + 1, max=i - 1)
     return lo, hi, src - lo.to(F64)
@@ -450,6 +456,110 @@ def image_resize_bilinear(images, size, align_corners=False, name=None):
   top = t[:, y0][:, :, x0] * (1 - fx) + t[:, y0][:, :, x1] * fx
   bot = t[:, y1][:, :, x0] * (1 - fx) + t[:, y1][:, :, x1] * fx
   return wrap(top * (1 - fy) + bot * fy, images)
+
+
+# ---- tf.image ops of the input pipeline (preprocessing/*.py): single images [h, w, c] ---------------------------
+class ResizeMethod(object):
+  BILINEAR, NEAREST_NEIGHBOR, BICUBIC, AREA = 0, 1, 2, 3
+
+
+def _int(v):
+  return int(raw(v).item()) if isinstance(v, (Tensor, torch.Tensor)) else int(v)
+
+
+def image_convert_image_dtype(image, dtype, saturate=False, name=None):
+  """uint8 -> float: cast * (1 / 255) in float32 (python/ops/image_ops_impl.py convert_image_dtype)."""
+  if image.dtype == dtype:
+    return image
+  assert image.dtype == core.uint8 and dtype.is_floating, 'only uint8 -> float is modelled'
+  t = (raw(image).to(torch.float32) * torch.tensor(1.0 / 255.0, dtype=torch.float32)).to(F64)
+  return Tensor(t, dtype, name)
+
+
+def image_pad_to_bounding_box(image, offset_height, offset_width, target_height, target_width):
+  t = raw(image)
+  oh, ow, th, tw = _int(offset_height), _int(offset_width), _int(target_height), _int(target_width)
+  out = torch.zeros((th, tw, t.shape[2]), dtype=t.dtype)
+  out[oh:oh + t.shape[0], ow:ow + t.shape[1]] = t
+  return wrap(out, image)
+
+
+def image_crop_to_bounding_box(image, offset_height, offset_width, target_height, target_width):
+  oh, ow, th, tw = _int(offset_height), _int(offset_width), _int(target_height), _int(target_width)
+  return wrap(raw(image)[oh:oh + th, ow:ow + tw], image)
+
+
+def image_resize_images(images, size, method=ResizeMethod.BILINEAR, align_corners=False):
+  assert method == ResizeMethod.BILINEAR and not align_corners, 'only the bilinear kernel is modelled'
+  t = raw(images)
+  if t.dim() == 3:
+    out = raw(image_resize_bilinear(Tensor(t.unsqueeze(0), images.dtype), size))[0]
+    return wrap(out, images)
+  return image_resize_bilinear(images, size)
+
+
+def _rgb_to_hsv(rgb):      # core/kernels/colorspace_op.h
+  r, g, b = rgb[..., 0], rgb[..., 1], rgb[..., 2]
+  v = rgb.max(dim=-1).values
+  rng = v - rgb.min(dim=-1).values
+  s = torch.where(v > 0, rng / torch.where(v > 0, v, torch.ones_like(v)), torch.zeros_like(v))
+  norm = 1.0 / (6.0 * torch.where(rng > 0, rng, torch.ones_like(rng)))
+  h = torch.where(r == v, norm * (g - b), torch.where(g == v, norm * (b - r) + 2.0 / 6.0, norm * (r - g) + 4.0 / 6.0))
+  h = torch.where(rng > 0, h, torch.zeros_like(h))
+  h = torch.where(h < 0, h + 1.0, h)
+  return h, s, v
+
+
+def _hsv_to_rgb(h, s, v):
+  c = s * v
+  m = v - c
+  dh = h * 6.0
+  fm = dh - 2.0 * torch.floor(dh / 2.0)
+  x = c * (1 - (fm - 1).abs())
+  cat = torch.clamp(torch.floor(dh).long(), 0, 5)
+  z = torch.zeros_like(c)
+  table = [(c, x, z), (x, c, z), (z, c, x), (z, x, c), (x, z, c), (c, z, x)]
+  out = torch.stack([sum(torch.where(cat == k, t[i], z) for k, t in enumerate(table)) for i in range(3)], dim=-1)
+  return out + m.unsqueeze(-1)
+
+
+def image_adjust_saturation(image, saturation_factor, name=None):
+  h, s, v = _rgb_to_hsv(raw(image))
+  s = torch.clamp(s * raw(saturation_factor), 0.0, 1.0)
+  return wrap(_hsv_to_rgb(h, s, v), image)
+
+
+def image_random_brightness(image, max_delta, seed=None):
+  """adjust_brightness(image, U[-max_delta, max_delta)); the draw happens whether or not the branch is live."""
+  delta = random_uniform([], -max_delta, max_delta)
+  if image is None:
+    return None
+  STATE.aug_log.append(('brightness', float(raw(delta))))
+  return wrap(raw(image) + raw(delta), image)
+
+
+def image_random_saturation(image, lower, upper, seed=None):
+  factor = random_uniform([], lower, upper)
+  if image is None:
+    return None
+  STATE.aug_log.append(('saturation', float(raw(factor))))
+  return image_adjust_saturation(image, factor)
+
+
+def reverse(tensor, axis, name=None):
+  return wrap(torch.flip(raw(tensor), dims=[int(a) for a in axis]), tensor)
+
+
+def cf_switch(data, pred, dtype=None, name=None):
+  """control_flow_ops.switch: (output_false, output_true); the branch not taken is dead (None here)."""
+  p = bool(raw(pred).item())
+  return (None, data) if p else (data, None)
+
+
+def cf_merge(inputs, name=None):
+  live = [(i, v) for i, v in enumerate(inputs) if v is not None]
+  assert len(live) == 1, 'merge expects exactly one live input'
+  return live[0][1], live[0][0]
 
 
 # ---- tf.losses ---------------------------------------------------------------------------------------------------
@@ -926,7 +1036,13 @@ def build_modules():
                batch_normalization=nn_batch_normalization, l2_normalize=nn_l2_normalize,
                sigmoid_cross_entropy_with_logits=nn_sigmoid_xent)
   image = _module('tensorflow.image', resize_nearest_neighbor=image_resize_nearest,
-                  resize_bilinear=image_resize_bilinear)
+                  resize_bilinear=image_resize_bilinear, ResizeMethod=ResizeMethod,
+                  convert_image_dtype=image_convert_image_dtype, pad_to_bounding_box=image_pad_to_bounding_box,
+                  crop_to_bounding_box=image_crop_to_bounding_box, resize_images=image_resize_images,
+                  adjust_saturation=image_adjust_saturation, random_brightness=image_random_brightness,
+                  random_saturation=image_random_saturation, random_hue=_unsupported('image.random_hue'),
+                  random_contrast=_unsupported('image.random_contrast'))
+  control_flow_ops = _module('tensorflow.python.ops.control_flow_ops', switch=cf_switch, merge=cf_merge)
   losses = _module('tensorflow.losses', compute_weighted_loss=compute_weighted_loss,
                    absolute_difference=absolute_difference, sigmoid_cross_entropy=sigmoid_cross_entropy,
                    cosine_distance=cosine_distance, get_losses=get_losses, Reduction=Reduction,
@@ -997,7 +1113,8 @@ def build_modules():
 
   tf = _module(
     'tensorflow', __version__='1.8.0-shim',
-    float16=float16, float32=float32, float64=float64, int32=int32, int64=int64, bool=bool_, DType=core.DType,
+    float16=float16, float32=float32, float64=float64, int32=int32, int64=int64, bool=bool_, uint8=core.uint8,
+    DType=core.DType, reverse=reverse,
     Tensor=Tensor, Variable=Variable, TensorShape=TensorShape, Dimension=Dimension,
     constant=constant, convert_to_tensor=convert_to_tensor, cast=cast, to_float=to_float, identity=identity,
     stop_gradient=stop_gradient, reshape=reshape, expand_dims=expand_dims, squeeze=squeeze, concat=concat, stack=stack,
@@ -1029,7 +1146,7 @@ def build_modules():
   mods = {m.__name__: m for m in (
     tf, logging, nn, image, losses, train, app, contrib, contrib_layers, py, py_layers, layers_impl, utils,
     initializers, framework, fw_py, fw_ops, fw_variables, slim, py_fw_ops, array_ops, context, convolutional,
-    gen_math_ops, moving_averages)}
+    gen_math_ops, moving_averages, control_flow_ops)}
   return mods
 
 

@@ -1,0 +1,156 @@
+"""twingan_amd/data.py on CPU (host logic; the preprocessing kernel itself is in tests/test_gpu_data.py) and the
+NumPy restatement of the trainer's image preprocessing against the fixture computed by the reference's own
+preprocess_image (tests/golden/preprocess_hw32.npz, tools/make_golden.py --preprocess)."""
+import io
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import np_ops as N
+from twingan_amd import data as D
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'preprocess_hw32.npz')
+
+
+def _cases():
+  g = np.load(GOLD)
+  i = 0
+  while 'img%d' % i in g:
+    yield i, g['img%d' % i], str(g['mode%d' % i]), g['par%d' % i], g['out%d' % i], int(g['hw'])
+    i += 1
+
+
+def test_preprocess_oracle_hits_the_reference_fixture():
+  """oracle.np_ops.preprocess_image == preprocessing/danbooru_preprocessing.preprocess_image as executed when the fixture
+  was made (10 images: PAD / CROP / RESHAPE, portrait / landscape / square, both colour orders, flips, evaluation)."""
+  seen = set()
+  for i, img, mode, par, want, hw in _cases():
+    flip, sat_first, delta, factor, training, sel = par
+    got = N.preprocess_image(img, hw, mode, bool(training), flip=bool(flip), saturation_first=bool(sat_first), delta=delta,
+                             factor=factor)
+    assert np.abs(got - want).max() < 1e-12, i
+    assert got.min() >= 0 and got.max() <= 1
+    seen.add((mode, bool(flip), bool(sat_first), bool(training)))
+  assert {m for m, *_ in seen} == {'PAD', 'CROP', 'RESHAPE'} and len(seen) >= 6
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='the reference tree is only mounted in the build container')
+def test_preprocess_oracle_against_the_live_reference():
+  from oracle import ref_runner
+  rng = np.random.RandomState(5)
+  for k, (h, w, mode) in enumerate([(45, 61, 'PAD'), (80, 33, 'CROP'), (25, 25, 'PAD'), (19, 70, 'RESHAPE')]):
+    img = rng.randint(0, 256, (h, w, 3), dtype=np.uint8)
+    want, dr = ref_runner.run_preprocess(img, 24, mode, True, seed=100 + k)
+    ap = dict(dr['applied'])
+    got = N.preprocess_image(img, 24, mode, True, flip=dr['flip_uniform'] < 0.5,
+                             saturation_first=dr['applied'][0][0] == 'saturation', delta=ap['brightness'],
+                             factor=ap['saturation'])
+    assert np.abs(got - want).max() < 1e-12
+    # apply_with_random_selector: ordering 0 is the only one with brightness first in fast mode
+    assert (dr['sel'] == 0) == (dr['applied'][0][0] == 'brightness')
+
+
+def test_hsv_round_trip_matches_colorsys():
+  import colorsys
+  rgb = np.random.RandomState(0).rand(500, 3)
+  hsv = N.rgb_to_hsv(rgb)
+  ref = np.array([colorsys.rgb_to_hsv(*p) for p in rgb])
+  assert np.abs(hsv - ref).max() < 1e-12
+  assert np.abs(N.hsv_to_rgb(ref) - np.array([colorsys.hsv_to_rgb(*p) for p in ref])).max() < 1e-12
+
+
+def test_tfrecord_round_trip_and_corruption(tmp_path):
+  payloads = [b'', b'a', os.urandom(1000), b'x' * 70000]
+  path = str(tmp_path / 'train-00000-of-00001')
+  D.write_tfrecords(path, payloads)
+  assert list(D.read_tfrecords(path, verify=True)) == payloads
+  raw = open(path, 'rb').read()
+  # layout of the first (empty) record: length 0, crc of the length, crc of the empty payload
+  assert raw[:8] == struct.pack('<Q', 0) and len(raw) == sum(16 + len(p) for p in payloads)
+  bad = bytearray(raw)
+  bad[40] ^= 1
+  open(path, 'wb').write(bad)
+  with pytest.raises(ValueError):
+    list(D.read_tfrecords(path, verify=True))
+
+
+def test_example_codec_matches_protobuf_wire_format():
+  ex = D.encode_example({'image/encoded': b'\x00\x01jpegbytes', 'image/format': 'jpeg', 'image/height': 17,
+                         'labels': [1, 2, -3], 'embedding': [0.5, -2.0]})
+  got = D.decode_example(ex)
+  assert got['image/encoded'] == [b'\x00\x01jpegbytes'] and got['image/format'] == [b'jpeg']
+  assert got['image/height'] == [17] and got['labels'] == [1, 2, -3] and got['embedding'] == [0.5, -2.0]
+  # the same message built with the protobuf runtime from a descriptor spelt out here (independent of the encoder)
+  from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+  fd = descriptor_pb2.FileDescriptorProto(name='ex_test.proto', package='t', syntax='proto3')
+
+  def msg(name, fields):
+    m = fd.message_type.add(name=name)
+    for fname, num, typ, label, tname in fields:
+      f = m.field.add(name=fname, number=num, type=typ, label=label)
+      if tname:
+        f.type_name = tname
+    return m
+  T = descriptor_pb2.FieldDescriptorProto
+  msg('BytesList', [('value', 1, T.TYPE_BYTES, T.LABEL_REPEATED, None)])
+  msg('FloatList', [('value', 1, T.TYPE_FLOAT, T.LABEL_REPEATED, None)])
+  msg('Int64List', [('value', 1, T.TYPE_INT64, T.LABEL_REPEATED, None)])
+  msg('Feature', [('bytes_list', 1, T.TYPE_MESSAGE, T.LABEL_OPTIONAL, '.t.BytesList'),
+                  ('float_list', 2, T.TYPE_MESSAGE, T.LABEL_OPTIONAL, '.t.FloatList'),
+                  ('int64_list', 3, T.TYPE_MESSAGE, T.LABEL_OPTIONAL, '.t.Int64List')])
+  entry = msg('Entry', [('key', 1, T.TYPE_STRING, T.LABEL_OPTIONAL, None), ('value', 2, T.TYPE_MESSAGE, T.LABEL_OPTIONAL, '.t.Feature')])
+  msg('Features', [('feature', 1, T.TYPE_MESSAGE, T.LABEL_REPEATED, '.t.Entry')])
+  msg('Example', [('features', 1, T.TYPE_MESSAGE, T.LABEL_OPTIONAL, '.t.Features')])
+  pool = descriptor_pool.DescriptorPool()
+  pool.Add(fd)
+  Example = message_factory.GetMessageClass(pool.FindMessageTypeByName('t.Example'))
+  m = Example()
+  m.ParseFromString(ex)                        # the runtime accepts the bytes ...
+  by_key = {e.key: e.value for e in m.features.feature}
+  assert list(by_key['labels'].int64_list.value) == [1, 2, -3] and list(by_key['embedding'].float_list.value) == [0.5, -2.0]
+  assert by_key['image/encoded'].bytes_list.value[0] == b'\x00\x01jpegbytes'
+  assert D.decode_example(m.SerializeToString()) == got      # ... and what it writes decodes to the same features
+
+
+def test_image_only_dataset_and_decoder(tmp_path):
+  from PIL import Image
+  rng = np.random.RandomState(3)
+  def smooth(h, w):      # JPEG keeps smooth content within a few grey levels
+    yy, xx = np.mgrid[0:h, 0:w]
+    return np.stack([(4 * yy + 2 * xx) % 256, (3 * xx + 40) % 256, (yy * xx // 4 + 10) % 200], axis=-1).astype(np.uint8)
+  imgs = [rng.randint(0, 256, (20 + 3 * i, 30 - i, 3), dtype=np.uint8) if i % 2 else smooth(20 + 3 * i, 30 - i)
+          for i in range(5)]
+  recs = []
+  for i, a in enumerate(imgs):
+    buf = io.BytesIO()
+    Image.fromarray(a).save(buf, format='PNG' if i % 2 else 'JPEG', quality=95)
+    recs.append(D.image_example(buf.getvalue(), 'png' if i % 2 else 'jpeg', 'f%d' % i))
+  D.write_tfrecords(str(tmp_path / 'train-00000-of-00002'), recs[:3])
+  D.write_tfrecords(str(tmp_path / 'train-00001-of-00002'), recs[3:])
+  D.write_tfrecords(str(tmp_path / 'validation-00000-of-00001'), recs[:1])
+  ds = D.ImageOnlyDataset(str(tmp_path), 'train')
+  assert len(ds.files) == 2
+  got = list(ds)
+  assert [n for _, n in got] == ['f%d' % i for i in range(5)]
+  for i, (a, _) in enumerate(got):
+    assert a.dtype == np.uint8 and a.shape == imgs[i].shape
+    if i % 2:
+      np.testing.assert_array_equal(a, imgs[i])                # PNG is lossless
+    else:
+      assert np.abs(a.astype(int) - imgs[i].astype(int)).mean() < 12      # JPEG, quality 95, smooth content
+  with pytest.raises(FileNotFoundError):
+    D.ImageOnlyDataset(str(tmp_path), 'test')
+
+
+def test_source_rect_and_draws():
+  assert D.source_rect(37, 53, 'PAD') == (-8, 0, 53, 53) and D.source_rect(64, 40, 'PAD') == (0, -12, 64, 64)
+  assert D.source_rect(37, 53, 'CROP') == (0, 8, 37, 37) and D.source_rect(20, 33, 'RESHAPE') == (0, 0, 20, 33)
+  aug = D.draw_augmentation(4000, np.random.default_rng(0))
+  assert set(np.unique(aug[:, 0])) == {0.0, 1.0} and abs(aug[:, 0].mean() - 0.5) < 0.05
+  assert abs(aug[:, 1].mean() - 0.75) < 0.05                   # 3 of the 4 orderings start with saturation
+  assert aug[:, 2].min() >= -32 / 255 and aug[:, 2].max() < 32 / 255 and 0.5 <= aug[:, 3].min() and aug[:, 3].max() < 1.5
+  pre = D.Preprocessor(16, device='cpu')
+  with pytest.raises(RuntimeError):
+    pre([np.zeros((4, 4, 3), np.uint8)])

@@ -1,0 +1,132 @@
+"""The preprocessing kernel (tg_preprocess_images, csrc/preprocess.hip) against the reference's own preprocess_image
+(tests/golden/preprocess_hw32.npz: executed on the TF stand-in when the fixture was made) and the float64 oracle, and the
+loader end to end on a synthetic TFRecord dataset."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import np_ops as N          # noqa: E402  (checker only)
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'preprocess_hw32.npz')
+
+
+def _cases():
+  g = np.load(GOLD)
+  out, i = [], 0
+  while 'img%d' % i in g:
+    out.append((g['img%d' % i], str(g['mode%d' % i]), g['par%d' % i], g['out%d' % i]))
+    i += 1
+  return out, int(g['hw'])
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_preprocess_kernel_hits_the_reference_fixture(precision):
+  """One launch per resize mode over images of different sizes; fp32 output within 2e-6 of the reference's float64
+  result (fp32 arithmetic of ~10 operations on values in [0, 1]), bf16 within one rounding (2^-8)."""
+  from twingan_amd import data as D
+  cases, hw = _cases()
+  for mode in ('PAD', 'CROP', 'RESHAPE'):
+    sel = [c for c in cases if c[1] == mode]
+    pre = D.Preprocessor(hw, device='cuda:0', precision=precision, resize_mode=mode)
+    aug = np.stack([c[2][:4] for c in sel]).astype(np.float32)
+    out = pre([c[0] for c in sel], aug=aug).float().cpu().numpy()
+    for k, c in enumerate(sel):
+      err = np.abs(out[k] - c[3]).max()
+      assert err < (2e-6 if precision == 'fp32' else 2.0 ** -8), (mode, k, err)
+
+
+def test_preprocess_kernel_matches_oracle_on_large_images():
+  """256x256 targets from larger, non-square sources (the bench resolution), random draws from the host helper."""
+  from twingan_amd import data as D
+  rng = np.random.RandomState(11)
+  imgs = [rng.randint(0, 256, (h, w, 3), dtype=np.uint8) for h, w in ((300, 420), (512, 384), (256, 256), (199, 611))]
+  pre = D.Preprocessor(256, device='cuda:0', precision='fp32', resize_mode='PAD', seed=3)
+  aug = D.draw_augmentation(len(imgs), np.random.default_rng(5))
+  out = pre(imgs, aug=aug).cpu().numpy()
+  for k, im in enumerate(imgs):
+    want = N.preprocess_image(im, 256, 'PAD', True, flip=bool(aug[k, 0]), saturation_first=bool(aug[k, 1]),
+                              delta=float(aug[k, 2]), factor=float(aug[k, 3]))
+    assert np.abs(out[k] - want).max() < 2e-6, k
+  ev = D.Preprocessor(256, device='cuda:0', precision='fp32', resize_mode='PAD', is_training=False)(imgs).cpu().numpy()
+  for k, im in enumerate(imgs):
+    assert np.abs(ev[k] - N.preprocess_image(im, 256, 'PAD', False)).max() < 2e-6
+
+
+def test_loader_end_to_end(tmp_path):
+  """TFRecord files of JPEG tf.Examples -> shuffled, decoded, preprocessed device batches; in evaluation mode without
+  shuffling the batch equals the oracle's preprocessing of the decoded images, in order."""
+  from PIL import Image
+  from twingan_amd import data as D
+  rng = np.random.RandomState(2)
+  recs, decoded = [], []
+  for i in range(24):
+    h, w = 40 + 3 * (i % 5), 64 - 2 * (i % 7)
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = np.stack([(3 * yy + i * 9) % 256, (2 * xx + 5 * i) % 256, (yy + xx) % 256], axis=-1).astype(np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(a).save(buf, format='JPEG', quality=90)
+    recs.append(D.image_example(buf.getvalue(), 'jpeg', 'im%02d' % i))
+    decoded.append(D.decode_image(buf.getvalue()))
+  D.write_tfrecords(str(tmp_path / 'train-00000-of-00002'), recs[:12])
+  D.write_tfrecords(str(tmp_path / 'train-00001-of-00002'), recs[12:])
+  ds = D.ImageOnlyDataset(str(tmp_path), 'train')
+  ev = D.Loader(ds, 8, D.Preprocessor(32, device='cuda:0', precision='fp32', is_training=False), num_readers=1,
+                num_workers=1, shuffle=False)
+  try:
+    for b in range(3):
+      batch = ev.next().cpu().numpy()
+      assert batch.shape == (8, 32, 32, 3)
+      for k in range(8):
+        want = N.preprocess_image(decoded[b * 8 + k], 32, 'PAD', False)
+        assert np.abs(batch[k] - want).max() < 2e-6, (b, k)
+  finally:
+    ev.close()
+  tr = D.Loader(ds, 8, D.Preprocessor(32, device='cuda:0', precision='bf16'), num_readers=2, num_workers=3, seed=1)
+  try:
+    seen = []
+    for _ in range(6):
+      batch = tr.next()
+      assert batch.dtype == torch.bfloat16 and batch.shape == (8, 32, 32, 3)
+      assert float(batch.min()) >= 0 and float(batch.max()) <= 1
+      seen.append(batch.float().mean().item())
+    assert len(set(round(v, 4) for v in seen)) > 1      # shuffled, augmented batches differ
+  finally:
+    tr.close()
+
+
+def test_loader_with_decode_processes(tmp_path):
+  """Loader(processes=P): worker processes decode and pack, the consumer uploads and preprocesses; evaluation mode
+  without shuffling, one process: batches equal the oracle's, in order."""
+  from PIL import Image
+  from twingan_amd import data as D
+  recs, decoded = [], []
+  for i in range(16):
+    h, w = 36 + 2 * (i % 3), 48 + i
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = np.stack([(5 * yy + i) % 256, (3 * xx + 2 * i) % 256, (yy * 2 + xx) % 256], axis=-1).astype(np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(a).save(buf, format='PNG')
+    recs.append(D.image_example(buf.getvalue(), 'png', '%d' % i))
+    decoded.append(a)
+  D.write_tfrecords(str(tmp_path / 'train-00000-of-00001'), recs)
+  ds = D.ImageOnlyDataset(str(tmp_path), 'train')
+  ld = D.Loader(ds, 4, D.Preprocessor(24, device='cuda:0', precision='fp32', is_training=False), shuffle=False, processes=1)
+  try:
+    for b in range(4):
+      batch = ld.next().cpu().numpy()
+      for k in range(4):
+        assert np.abs(batch[k] - N.preprocess_image(decoded[b * 4 + k], 24, 'PAD', False)).max() < 2e-6, (b, k)
+  finally:
+    ld.close()
+  tr = D.Loader(ds, 4, D.Preprocessor(24, device='cuda:0', precision='bf16'), processes=2, pool=8, seed=3)
+  try:
+    for _ in range(5):
+      batch = tr.next()
+      assert batch.shape == (4, 24, 24, 3) and float(batch.min()) >= 0 and float(batch.max()) <= 1
+  finally:
+    tr.close()

@@ -425,8 +425,43 @@ def main():
     print(f, os.path.getsize(os.path.join(OUT, f)))
 
 
+PREPROCESS_CASES = [      # (h, w, resize_mode, is_training, seed): the trainer's image preprocessing on one decoded image
+    (37, 53, 'PAD', True, 0), (64, 40, 'PAD', True, 1), (50, 50, 'PAD', True, 2), (37, 53, 'CROP', True, 3),
+    (20, 33, 'RESHAPE', True, 4), (120, 90, 'PAD', True, 5), (31, 17, 'CROP', True, 6), (48, 48, 'PAD', False, 7),
+    (9, 30, 'PAD', True, 8), (70, 64, 'PAD', True, 9)]
+
+
+def preprocess_fixture(hw=32):
+  """preprocessing/danbooru_preprocessing.preprocess_image executed on the TF stand-in (oracle/ref_runner.run_preprocess)
+  for small random images: input, the random draws of the live branch, output."""
+  from oracle import ref_runner
+  rng = np.random.RandomState(17)
+  out = {'hw': np.int64(hw)}
+  for i, (h, w, mode, training, seed) in enumerate(PREPROCESS_CASES):
+    img = rng.randint(0, 256, (h, w, 3), dtype=np.uint8)
+    if i == 2:
+      img[:, :, 1] = img[:, :, 0]      # some grey-ish and saturated pixels
+      img[::3, ::2] = 255
+    res, dr = ref_runner.run_preprocess(img, hw, mode, training, seed)
+    applied = dict(dr['applied'])
+    flip = bool(training and dr['flip_uniform'] < 0.5)
+    sat_first = bool(training and dr['applied'][0][0] == 'saturation')
+    mine = N.preprocess_image(img, hw, mode, training, flip=flip, saturation_first=sat_first,
+                              delta=applied.get('brightness', 0.0), factor=applied.get('saturation', 1.0))
+    assert np.abs(mine - res).max() < 1e-12, (i, np.abs(mine - res).max())
+    out['img%d' % i] = img
+    out['out%d' % i] = res
+    out['par%d' % i] = np.array([float(flip), float(sat_first), applied.get('brightness', 0.0), applied.get('saturation', 1.0),
+                                 float(training), float(dr['sel'] if training else -1)])
+    out['mode%d' % i] = np.array(mode)
+  return out
+
+
 if __name__ == '__main__':
-  if '--infer' in sys.argv:      # only the inference-branch fixtures
+  if '--preprocess' in sys.argv:      # only the input-preprocessing fixture
+    np.savez_compressed(os.path.join(OUT, 'preprocess_hw32.npz'), **preprocess_fixture())
+    print('preprocess_hw32.npz', os.path.getsize(os.path.join(OUT, 'preprocess_hw32.npz')))
+  elif '--infer' in sys.argv:      # only the inference-branch fixtures
     for norm in ('instance_norm', 'batch_norm', 'batch_renorm'):
       np.savez_compressed(os.path.join(OUT, 'infer_hw16_c8_%s.npz' % norm), **infer_model(norm))
       print('infer', norm)

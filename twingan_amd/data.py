@@ -1,0 +1,416 @@
+"""Input pipeline: TFRecord files of tf.Example protos -> decoded images -> the preprocessed [B, hw, hw, 3] batches the
+trainer consumes, with the resize / flip / colour distortion on the GPU (csrc/preprocess.hip).
+
+Reference call sites: datasets/image_only.py:45-106 (`get_split`: files `<dataset_dir>/<split>*`,
+features image/encoded, image/format [default 'jpeg'], image/filename; slim.tfexample_decoder.Image),
+datasets/dataset_utils.py:82-90,495-513 (the converters that write those records), model/model_inheritor.py:786-830
+(DatasetDataProvider: shuffled parallel readers -> preprocessing threads -> tf.train.batch) and
+preprocessing/danbooru_preprocessing.py:115-230 (preprocess_image).  TwinGAN trains on two such datasets, one per domain
+(`--dataset_name` / `--unpaired_target_dataset_name`, twingan.py:146-200).
+
+On-disk formats are restated from TensorFlow's published sources (no TensorFlow here; "parity unpinned" for the file
+formats, like checkpoint.py): a TFRecord file is a sequence of [uint64 length | masked CRC-32C of the length | payload |
+masked CRC-32C of the payload] (core/lib/io/record_writer.cc); tf.Example is the protobuf
+Example{1: Features{1: map<string, Feature{1: BytesList | 2: FloatList | 3: Int64List}>}} (core/example/*.proto).
+The preprocessing itself IS pinned: the reference's own preprocess_image runs on the TF stand-in
+(oracle/ref_runner.run_preprocess) and the HIP kernel is held to it (tests/golden/preprocess_hw32.npz).
+"""
+import glob
+import io
+import os
+import struct
+import threading
+import queue as _queue
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import TG_BF16, TG_F32, call
+from .checkpoint import _field, _get_varint, _parse_message, _put_varint, crc32c, mask_crc
+
+
+# ------------------------------------------------------------------------------------------------ TFRecord
+def write_tfrecords(path, payloads):
+  """Writes byte strings as one TFRecord file."""
+  with open(path, 'wb') as fh:
+    for data in payloads:
+      head = struct.pack('<Q', len(data))
+      fh.write(head + struct.pack('<I', mask_crc(crc32c(head))) + data + struct.pack('<I', mask_crc(crc32c(data))))
+
+
+def read_tfrecords(path, verify=False):
+  """Yields the payloads of a TFRecord file (``verify``: check both checksums of every record)."""
+  with open(path, 'rb') as fh:
+    while True:
+      head = fh.read(12)
+      if not head:
+        return
+      if len(head) < 12:
+        raise ValueError('%s: truncated record header' % path)
+      n, = struct.unpack('<Q', head[:8])
+      if verify and struct.unpack('<I', head[8:])[0] != mask_crc(crc32c(head[:8])):
+        raise ValueError('%s: corrupt record length' % path)
+      body = fh.read(n + 4)
+      if len(body) < n + 4:
+        raise ValueError('%s: truncated record' % path)
+      if verify and struct.unpack('<I', body[n:])[0] != mask_crc(crc32c(body[:n])):
+        raise ValueError('%s: corrupt record payload' % path)
+      yield body[:n]
+
+
+# ------------------------------------------------------------------------------------------------ tf.Example
+def encode_example(features):
+  """{name: bytes | str | [bytes] | int | [int] | float | [float] | ndarray} -> serialized tf.Example."""
+  entries = b''
+  for name in sorted(features):
+    v = features[name]
+    if isinstance(v, (bytes, str)):
+      v = [v]
+    elif isinstance(v, (int, float, np.integer, np.floating)):
+      v = [v]
+    v = list(v)
+    if v and isinstance(v[0], (bytes, str)):
+      items = b''.join(_field(1, 2, _put_varint(len(b)) + b) for b in ((x.encode() if isinstance(x, str) else x) for x in v))
+      feat = _field(1, 2, _put_varint(len(items)) + items)                       # bytes_list
+    elif v and isinstance(v[0], (float, np.floating)):
+      packed = struct.pack('<%df' % len(v), *v)
+      lst = _field(1, 2, _put_varint(len(packed)) + packed)
+      feat = _field(2, 2, _put_varint(len(lst)) + lst)                           # float_list (packed)
+    else:
+      packed = b''.join(_put_varint(int(x)) for x in v)
+      lst = _field(1, 2, _put_varint(len(packed)) + packed)
+      feat = _field(3, 2, _put_varint(len(lst)) + lst)                           # int64_list (packed)
+    key = name.encode()
+    entry = _field(1, 2, _put_varint(len(key)) + key) + _field(2, 2, _put_varint(len(feat)) + feat)
+    entries += _field(1, 2, _put_varint(len(entry)) + entry)
+  return _field(1, 2, _put_varint(len(entries)) + entries)
+
+
+def decode_example(payload):
+  """serialized tf.Example -> {name: [bytes] | [float] | [int]}."""
+  out = {}
+  for feats in _parse_message(payload).get(1, []):
+    for entry in _parse_message(feats).get(1, []):
+      e = _parse_message(entry)
+      name = e[1][0].decode()
+      feat = _parse_message(e.get(2, [b''])[0])
+      if 1 in feat:
+        out[name] = _parse_message(feat[1][0]).get(1, [])
+      elif 2 in feat:
+        vals = []
+        for chunk in _parse_message(feat[2][0]).get(1, []):
+          if isinstance(chunk, bytes):
+            vals.extend(struct.unpack('<%df' % (len(chunk) // 4), chunk))
+          else:                                                                  # unpacked: fixed32 bit pattern
+            vals.append(struct.unpack('<f', struct.pack('<I', chunk))[0])
+        out[name] = vals
+      elif 3 in feat:
+        vals = []
+        for chunk in _parse_message(feat[3][0]).get(1, []):
+          if isinstance(chunk, bytes):
+            pos = 0
+            while pos < len(chunk):
+              v, pos = _get_varint(chunk, pos)
+              vals.append(v - (1 << 64) if v >= (1 << 63) else v)
+          else:
+            vals.append(chunk - (1 << 64) if chunk >= (1 << 63) else chunk)
+        out[name] = vals
+      else:
+        out[name] = []
+  return out
+
+
+def decode_image(encoded, fmt=b'jpeg', channels=3):
+  """slim.tfexample_decoder.Image: 'raw' / 'RAW' -> the bytes are the pixels; otherwise decode_png / decode_jpeg by
+  content.  -> uint8 [h, w, channels]."""
+  if fmt in (b'raw', b'RAW'):
+    raise ValueError('raw images carry no shape in this dataset')
+  from PIL import Image
+  im = Image.open(io.BytesIO(encoded))
+  im = im.convert('RGB' if channels == 3 else 'L')
+  a = np.asarray(im, dtype=np.uint8)
+  return a if a.ndim == 3 else a[:, :, None]
+
+
+def image_example(image_bytes, fmt='jpeg', filename=''):
+  """The record the reference's converters write for an image-only dataset (dataset_utils.py:82-90)."""
+  return encode_example({'image/encoded': image_bytes, 'image/format': fmt, 'image/filename': filename})
+
+
+class ImageOnlyDataset:
+  """datasets/image_only.get_split: the TFRecord files `<dataset_dir>/<split>*`, each record a tf.Example with
+  image/encoded (+ image/format, image/filename)."""
+
+  def __init__(self, dataset_dir, split='train', file_pattern='%s*', key='image/encoded'):
+    self.files = sorted(glob.glob(os.path.join(dataset_dir, file_pattern % split)))
+    if not self.files:
+      raise FileNotFoundError('no files match %s' % os.path.join(dataset_dir, file_pattern % split))
+    self.key = key
+
+  def records(self, files=None):
+    for f in (files or self.files):
+      yield from read_tfrecords(f)
+
+  def decode(self, payload):
+    ex = decode_example(payload)
+    fmt = ex.get('image/format', [b'jpeg'])
+    name = ex.get('image/filename', [b''])
+    return decode_image(ex[self.key][0], fmt[0] if fmt else b'jpeg'), (name[0].decode() if name else '')
+
+  def __iter__(self):
+    for rec in self.records():
+      yield self.decode(rec)
+
+
+# ------------------------------------------------------------------------------------------------ GPU preprocessing
+def source_rect(h, w, resize_mode):
+  """(y0, x0, sh, sw): the rectangle of preprocessing_util.resize_image in image coordinates (see twingan_hip.h)."""
+  if resize_mode == 'PAD':
+    size = max(h, w)
+    return (-((size - h) // 2), -((size - w) // 2), size, size)
+  if resize_mode == 'CROP':
+    size = min(h, w)
+    return ((h - size) // 2, (w - size) // 2, size, size)
+  if resize_mode == 'RESHAPE':
+    return (0, 0, h, w)
+  raise ValueError('resize_mode %s (PAD, CROP and RESHAPE are built)' % resize_mode)
+
+
+def draw_augmentation(n, rng):
+  """The random draws of preprocess_image(is_training=True) for n images -> fp32 [n, 4] (flip, saturation first,
+  brightness delta, saturation factor): random_flip_left_right flips when U[0,1) < 0.5; apply_with_random_selector picks
+  one of 4 orderings, of which only ordering 0 puts brightness first in fast mode; random_brightness(32/255),
+  random_saturation(0.5, 1.5) (danbooru_preprocessing.py:62-113)."""
+  aug = np.empty((n, 4), np.float32)
+  aug[:, 0] = rng.random(n) < 0.5
+  aug[:, 1] = rng.integers(0, 4, n) != 0
+  aug[:, 2] = rng.uniform(-32.0 / 255.0, 32.0 / 255.0, n)
+  aug[:, 3] = rng.uniform(0.5, 1.5, n)
+  return aug
+
+
+class Preprocessor:
+  """preprocess_image for a batch of decoded images on the GPU.  ``aug`` given explicitly (tests) or drawn from
+  ``rng``; evaluation (is_training=False) resizes only."""
+
+  def __init__(self, hw, device='cuda', precision='bf16', resize_mode='PAD', is_training=True, seed=0):
+    self.hw, self.device = int(hw), torch.device(device)
+    self.dtype = torch.bfloat16 if precision == 'bf16' else torch.float32
+    self.resize_mode, self.is_training = resize_mode, is_training
+    self.rng = np.random.default_rng(seed)
+
+  def pack(self, images, aug=None):
+    """Host side: one pinned uint8 buffer + the per-image tables."""
+    n = len(images)
+    sizes = [int(im.shape[0]) * int(im.shape[1]) * 3 for im in images]
+    offsets = np.zeros(n, np.int64)
+    offsets[1:] = np.cumsum(sizes[:-1])
+    buf = torch.empty(int(sum(sizes)), dtype=torch.uint8, pin_memory=self.device.type == 'cuda')
+    flat = buf.numpy()
+    rect = np.empty((n, 6), np.int32)
+    for i, im in enumerate(images):
+      assert im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3, 'decoded RGB uint8 images'
+      flat[offsets[i]:offsets[i] + sizes[i]] = np.ascontiguousarray(im).reshape(-1)
+      rect[i] = (im.shape[0], im.shape[1]) + source_rect(im.shape[0], im.shape[1], self.resize_mode)
+    if aug is None:
+      aug = draw_augmentation(n, self.rng) if self.is_training else np.tile(np.float32([0, 0, 0, 1]), (n, 1))
+    return buf, torch.from_numpy(offsets), torch.from_numpy(rect), torch.from_numpy(np.ascontiguousarray(aug, np.float32))
+
+  def __call__(self, images, aug=None, stream=None):
+    buf, offsets, rect, augt = self.pack(images, aug)
+    return self.run(buf, offsets, rect, augt, stream)
+
+  def run(self, buf, offsets, rect, aug, stream=None):
+    if self.device.type != 'cuda':
+      raise RuntimeError('the preprocessing kernel needs a GPU (there is no CPU fallback)')
+    n = offsets.numel()
+    with torch.cuda.device(self.device):
+      st = stream or torch.cuda.current_stream()
+      with torch.cuda.stream(st):
+        d = [t.to(self.device, non_blocking=True) for t in (buf, offsets, rect, aug)]
+        out = torch.empty((n, self.hw, self.hw, 3), dtype=self.dtype, device=self.device)
+        call('tg_preprocess_images', d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), out.data_ptr(), n,
+             self.hw, TG_BF16 if self.dtype == torch.bfloat16 else TG_F32, st.cuda_stream)
+        for t in d:
+          t.record_stream(st)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ loader
+def _process_main(files, key, batch_size, hw, resize_mode, is_training, shuffle, pool_size, seed, out_q, stop):
+  """A decode worker PROCESS of Loader(processes=P): its own file shard, shuffling pool and random stream; puts packed
+  batches (shared-memory tensors) on ``out_q``."""
+  torch.set_num_threads(1)
+  ds = ImageOnlyDataset.__new__(ImageOnlyDataset)
+  ds.files, ds.key = list(files), key
+  pre = Preprocessor(hw, device='cpu', resize_mode=resize_mode, is_training=is_training)
+  rng = np.random.default_rng(seed)
+  held = []
+  want = max(1, pool_size) if shuffle else 1
+  images = []
+
+  def records():
+    while True:
+      order = list(files)
+      if shuffle:
+        rng.shuffle(order)
+      yield from ds.records(order)
+  for rec in records():
+    if stop.is_set():
+      return
+    held.append(rec)
+    if len(held) < want:
+      continue
+    k = int(rng.integers(len(held))) if shuffle else 0
+    held[k], held[-1] = held[-1], held[k]
+    images.append(ds.decode(held.pop())[0])
+    if len(images) == batch_size:
+      buf, offsets, rect, aug = pre.pack(images, draw_augmentation(batch_size, rng) if is_training else None)
+      images = []
+      item = tuple(t.share_memory_() for t in (buf, offsets, rect, aug))
+      while not stop.is_set():
+        try:
+          out_q.put(item, timeout=0.1)
+          break
+        except _queue.Full:
+          continue
+
+
+class Loader:
+  """DatasetDataProvider + tf.train.batch (model_inheritor.py:786-830, 380-400): ``num_readers`` reader threads walk
+  shuffled file lists forever and push records into a shuffling pool; ``num_workers`` threads decode (PIL releases the
+  GIL inside libjpeg) and assemble packed batches; the consumer uploads and preprocesses on a side stream while the
+  previous batch trains.  next() -> device tensor [batch, hw, hw, 3].
+  ``processes`` = P > 0: decoding in P worker processes instead (threads top out near 3.5 k images/s on the
+  interpreter lock: tf.Example parsing and the array copies hold it), each with its own file shard, shuffling pool
+  (pool / P records) and random stream, handing over packed batches in shared memory."""
+
+  def __init__(self, dataset, batch_size, preprocessor, num_readers=4, num_workers=8, shuffle=True, pool=None, seed=0,
+               prefetch=4, processes=0):
+    self.ds, self.bs, self.pre = dataset, int(batch_size), preprocessor
+    self.shuffle = shuffle
+    self.pool_size = pool if pool is not None else 20 * self.bs      # common_queue_capacity = 20 * batch_size
+    self.stream = torch.cuda.Stream(device=preprocessor.device) if preprocessor.device.type == 'cuda' else None
+    self.threads, self.procs = [], []
+    if processes > 0:
+      import torch.multiprocessing as mp
+      ctx = mp.get_context('spawn')
+      self.stop = ctx.Event()
+      self.batches = ctx.Queue(maxsize=max(prefetch, 2 * processes))
+      files = list(dataset.files)
+      for r in range(processes):
+        mine = files[r::processes] or files
+        pr = ctx.Process(target=_process_main, daemon=True,
+                         args=(mine, dataset.key, self.bs, preprocessor.hw, preprocessor.resize_mode,
+                               preprocessor.is_training, shuffle, max(1, self.pool_size // processes), seed + 1 + r,
+                               self.batches, self.stop))
+        pr.start()
+        self.procs.append(pr)
+      return
+    self.records = _queue.Queue(maxsize=self.pool_size)
+    self.batches = _queue.Queue(maxsize=prefetch)
+    self.stop = threading.Event()
+    self.rng = np.random.default_rng(seed)
+    files = list(dataset.files)
+    for r in range(num_readers):
+      mine = files[r::num_readers] or files
+      self.threads.append(threading.Thread(target=self._read, args=(mine, seed + 1 + r), daemon=True))
+    for w in range(num_workers):
+      self.threads.append(threading.Thread(target=self._work, args=(seed + 1000 + w,), daemon=True))
+    for t in self.threads:
+      t.start()
+
+  def _read(self, files, seed):
+    rng = np.random.default_rng(seed)
+    while not self.stop.is_set():
+      order = list(files)
+      if self.shuffle:
+        rng.shuffle(order)
+      for rec in self.ds.records(order):
+        while not self.stop.is_set():
+          try:
+            self.records.put(rec, timeout=0.1)
+            break
+          except _queue.Full:
+            continue
+        if self.stop.is_set():
+          return
+
+  def _work(self, seed):
+    rng = np.random.default_rng(seed)
+    held = []                                   # a private shuffling pool (RandomShuffleQueue semantics)
+    want = max(1, self.pool_size // 8) if self.shuffle else 1
+    while not self.stop.is_set():
+      images = []
+      while len(images) < self.bs and not self.stop.is_set():
+        try:
+          held.append(self.records.get(timeout=0.1))
+        except _queue.Empty:
+          continue
+        if len(held) < want:
+          continue
+        k = int(rng.integers(len(held))) if self.shuffle else 0
+        held[k], held[-1] = held[-1], held[k]
+        images.append(self.ds.decode(held.pop())[0])
+      if len(images) == self.bs:
+        packed = self.pre.pack(images, draw_augmentation(self.bs, rng) if self.pre.is_training else None)
+        while not self.stop.is_set():
+          try:
+            self.batches.put(packed, timeout=0.1)
+            break
+          except _queue.Full:
+            continue
+
+  def next(self):
+    packed = self.batches.get()
+    out = self.pre.run(*packed, stream=self.stream)
+    if self.stream is not None:
+      cur = torch.cuda.current_stream(self.pre.device)
+      cur.wait_stream(self.stream)
+      out.record_stream(cur)
+    return out
+
+  def close(self):
+    self.stop.set()
+    for t in self.threads:
+      t.join(timeout=2.0)
+    for pr in self.procs:
+      pr.join(timeout=2.0)
+      if pr.is_alive():
+        pr.terminate()
+    if self.procs:      # drop what is left in the queue so that its feeder threads can exit
+      try:
+        while True:
+          self.batches.get_nowait()
+      except Exception:
+        pass
+
+
+class TwoDomainBatches:
+  """The ``batch_fn`` of runner.run_progressive over two image-only datasets -- TwinGAN's unpaired source / target
+  domains (twingan.py:146-200: `--dataset_name` and `--unpaired_target_dataset_name`, one provider each, both through
+  preprocess_image at the stage's resolution).  A loader pair is (re)built whenever the stage's resolution or batch size
+  changes, as the reference rebuilds its graph per stage."""
+
+  def __init__(self, source_dir, target_dir, device='cuda', precision='bf16', split='train', resize_mode='PAD',
+               processes=0, num_workers=8, seed=0):
+    self.dirs = (source_dir, target_dir)
+    self.kw = dict(device=device, precision=precision, resize_mode=resize_mode)
+    self.split, self.processes, self.num_workers, self.seed = split, processes, num_workers, seed
+    self.key, self.loaders = None, ()
+
+  def __call__(self, hw, batch_size):
+    if self.key != (hw, batch_size):
+      self.close()
+      self.loaders = tuple(
+          Loader(ImageOnlyDataset(d, self.split), batch_size, Preprocessor(hw, seed=self.seed + 17 * i, **self.kw),
+                 num_workers=self.num_workers, processes=self.processes, seed=self.seed + 1000 * i)
+          for i, d in enumerate(self.dirs))
+      self.key = (hw, batch_size)
+    return self.loaders[0].next(), self.loaders[1].next()
+
+  def close(self):
+    for ld in self.loaders:
+      ld.close()
+    self.loaders = ()
