@@ -384,6 +384,18 @@ int tg_spectral_norm_bwd(const float* g_wbar, const float* w, const float* u, co
                          const float* stats, float* gw, int accumulate, int k_rows, int cout, void* ws, size_t ws_bytes,
                          void* stream);
 
+/* Gradient all-reduce for callers without torch.distributed (the reference sums its clones' gradients in one process,
+ * deployment/model_deploy.py:473-503; with one process per GPU that sum is a sum all-reduce over xGMI): a thin wrapper
+ * over RCCL, bound lazily (dlopen of $TG_RCCL_PATH, librccl.so.1 or librccl.so at the first call; the library does not
+ * link RCCL).  Rank 0 obtains an id (tg_comm_unique_id_bytes() bytes) and distributes it out of band; every rank calls
+ * tg_comm_init with its current HIP device set; tg_allreduce sums `count` elements of dtype TG_F32 / TG_BF16 IN PLACE,
+ * asynchronously on `stream`. */
+int tg_comm_unique_id_bytes(void);
+int tg_comm_unique_id(void* id);
+int tg_comm_init(const void* id, int nranks, int rank, void** comm);
+int tg_allreduce(void* comm, void* buf, int64_t count, int dtype, void* stream);
+int tg_comm_destroy(void* comm);
+
 /* Training-image preprocessing (preprocessing/danbooru_preprocessing.py:115-230 preprocess_image with the TwinGAN
  * trainer's defaults, model/model_inheritor.py:403-457; resize_image of preprocessing/preprocessing_util.py:97-146): n
  * decoded uint8 RGB images of arbitrary size -> out [n, hw, hw, 3] (dtype) in [0, 1].  packed: the images' bytes, image i

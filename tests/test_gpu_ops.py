@@ -961,3 +961,32 @@ def test_conv_with_pooled_output(ops, monkeypatch, n, hw, cin, cout):
   assert torch.equal(z, z_ref)
   assert rel_l2(host(zp), host(zp_ref)) < 1e-4
   assert float((zp.float() - zp_ref.float()).abs().max()) <= 2.0 ** -7 * float(zp_ref.float().abs().max())
+
+
+def test_rccl_allreduce_wrapper_single_rank():
+  """tg_comm_* / tg_allreduce (the C-ABI RCCL wrapper for callers without torch.distributed): a one-rank communicator on
+  this GPU -- all a 1-GPU box allows -- initialises, sums in place (= identity for one rank) on a side stream, for fp32
+  and bf16, and tears down.  RCCL is bound lazily: the library has no link dependency on it."""
+  import ctypes
+  from twingan_amd import _lib
+  lib = _lib.load()
+  nbytes = lib.tg_comm_unique_id_bytes()
+  assert nbytes == 128
+  uid = ctypes.create_string_buffer(nbytes)
+  rc = lib.tg_comm_unique_id(ctypes.cast(uid, ctypes.c_void_p))
+  assert rc == 0, lib.tg_last_error().decode()
+  comm = ctypes.c_void_p()
+  with torch.cuda.device(0):
+    rc = lib.tg_comm_init(ctypes.cast(uid, ctypes.c_void_p), 1, 0, ctypes.byref(comm))
+    assert rc == 0 and comm.value, lib.tg_last_error().decode()
+    st = torch.cuda.Stream()
+    for dt, code in ((torch.float32, _lib.TG_F32), (torch.bfloat16, _lib.TG_BF16)):
+      x = torch.randn(1 << 20, device='cuda:0').to(dt)
+      want = x.clone()
+      st.wait_stream(torch.cuda.current_stream())
+      rc = lib.tg_allreduce(comm, x.data_ptr(), x.numel(), code, st.cuda_stream)
+      assert rc == 0, lib.tg_last_error().decode()
+      st.synchronize()
+      assert torch.equal(x, want)
+    assert lib.tg_allreduce(comm, 0, 16, _lib.TG_F32, 0) != 0 and b'bad arguments' in lib.tg_last_error()
+    assert lib.tg_comm_destroy(comm) == 0

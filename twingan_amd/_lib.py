@@ -47,6 +47,11 @@ SIGNATURES = {
     'tg_conv2d_bwd_weight2_bias': (c_int, [_D, c_int, _P, _P, _P, _P, _FP, _FP, c_int, c_int, _P, c_size_t, _P]),
     'tg_conv2d_upcat_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'tg_conv2d_upcat_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_uint, _P]),
+    'tg_comm_unique_id_bytes': (c_int, []),
+    'tg_comm_unique_id': (c_int, [_P]),
+    'tg_comm_init': (c_int, [_P, c_int, c_int, POINTER(c_void_p)]),
+    'tg_allreduce': (c_int, [_P, _P, c_int64, c_int, _P]),
+    'tg_comm_destroy': (c_int, [_P]),
     'tg_preprocess_images': (c_int, [_P, _P, _P, _FP, _P, c_int, c_int, c_int, _P]),
     'tg_conv2d_fwd_pool_supported': (c_int, [_D]),
     'tg_conv2d_fwd_pool': (c_int, [_D, _P, _P, _FP, _P, _P, _P]),
