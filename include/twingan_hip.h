@@ -10,7 +10,7 @@
  *
  * Conventions
  *   - all activation tensors are NHWC, C-contiguous, 16-byte aligned base pointers;
- *   - `dtype` selects the activation storage type: TG_F32 or TG_BF16; accumulation is always fp32;
+ *   - `dtype` selects the activation storage type: TG_F32, TG_BF16 or TG_F16; accumulation is always fp32;
  *   - conv weights are TF HWIO [kh][kw][cin][cout] fp32 ("master") unless a parameter says "packed";
  *   - the caller owns all memory; the library never allocates device memory and never synchronises;
  *     kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream);
@@ -29,6 +29,8 @@ extern "C" {
 
 #define TG_F32 0
 #define TG_BF16 1
+#define TG_F16 2            /* IEEE half storage (the reference's --dataset_dtype float16 with loss scale 128,
+                               deployment/model_deploy.py:146-183,308-313); fp32 accumulation and master weights */
 
 #define TG_OK 0
 #define TG_EINVAL (-1)   /* bad shape / dtype / flag combination */

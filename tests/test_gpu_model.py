@@ -44,8 +44,8 @@ def make(cfg_kw, precision, seed=0, batch=3):
   s = torch.rand(batch, cfg.hw, cfg.hw, 3, generator=g)
   t = torch.rand(batch, cfg.hw, cfg.hw, 3, generator=g)
   a_s, a_t = torch.rand(batch, generator=g), torch.rand(batch, generator=g)
-  adt = torch.bfloat16 if precision == 'bf16' else torch.float32
-  if precision == 'bf16':
+  adt = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[precision]
+  if precision != 'fp32':
     s, t = s.to(adt).float(), t.to(adt).float()
   dev = dict(s=s.to('cuda:0').to(adt).contiguous(), t=t.to('cuda:0').to(adt).contiguous(), a_s=a_s.to('cuda:0'),
              a_t=a_t.to('cuda:0'))
@@ -118,7 +118,7 @@ def _grads_close(tr, Pref, names, tol, what, min_cos=None, var_tol=None):
     assert cos > min_cos, '%s grads cosine %.4f' % (what, cos)
 
 
-@pytest.mark.parametrize('precision,hw,max_ch', [('fp32', 16, 16), ('fp32', 64, 8), ('bf16', 32, 32)])
+@pytest.mark.parametrize('precision,hw,max_ch', [('fp32', 16, 16), ('fp32', 64, 8), ('bf16', 32, 32), ('fp16', 32, 32)])
 def test_losses_and_gradients(precision, hw, max_ch):
   from twingan_amd import twingan as T
   cfg, rcfg, tr, Pref, dev, ref = make(dict(hw=hw, max_ch=max_ch), precision, seed=2, batch=2)
@@ -130,7 +130,9 @@ def test_losses_and_gradients(precision, hw, max_ch):
   # with bf16 rounding inserted at the same storage points (tools/bf16_sensitivity.py) moves the G
   # gradients by rel-L2 0.31 on this very case (0.21 from rounding the weights alone, 0.10 in fp16), and
   # the kernels reproduce that figure (0.32); per-primitive bf16 bounds are tight (test_gpu_ops.py).
-  # So the whole-model bf16 check is directional: rel-L2 <= 0.5 and cosine >= 0.9.
+  # So the whole-model bf16 check is directional: rel-L2 <= 0.5 and cosine >= 0.9.  fp16 (TG_F16, 11 significand bits):
+  # the same kernels with the f16 MFMA instructions; the same directional bound, measured tighter (the sensitivity
+  # tool's 0.10).
   ftol, gtol = (1e-4, FP32_GRAD_TOL) if precision == 'fp32' else (3e-2, 0.5)
   vtol = FP32_VAR_GRAD_TOL if precision == 'fp32' else None
   min_cos = None if precision == 'fp32' else 0.9
@@ -863,14 +865,19 @@ def test_spectral_norm_in_encoder_and_generator():
     assert rel_l2(tr.store.state[k], v) < 1e-4, k
 
 
-def test_spectral_norm_attention_bf16_graph_step_runs():
+@pytest.mark.parametrize('precision,loss,scale', [('bf16', 'hinge', 1.0), ('fp16', 'wgan_gp', 128.0)])
+def test_spectral_norm_attention_bf16_graph_step_runs(precision, loss, scale):
+  """configs[4]'s ingredients as captured graphs: spectral norm + self-attention on bf16, and on fp16 storage with the
+  static loss scale 128 under WGAN-GP (the double backward through the discriminator's attention in half precision)."""
   from twingan_amd import Config
   from twingan_amd.twingan import Trainer
-  cfg = Config(hw=32, max_ch=64, spectral_norm=True, do_self_attention=True, self_attention_hw=16, loss_architecture='hinge')
+  cfg = Config(hw=32, max_ch=64, spectral_norm=True, do_self_attention=True, self_attention_hw=16, loss_architecture=loss,
+               precision=precision, loss_scale=scale)
   tr = Trainer(cfg, device='cuda:0', seed=1, use_graph=True)
   g = torch.Generator().manual_seed(3)
-  s = torch.rand(4, 32, 32, 3, generator=g).to('cuda:0').bfloat16()
-  t = torch.rand(4, 32, 32, 3, generator=g).to('cuda:0').bfloat16()
+  dt = torch.bfloat16 if precision == 'bf16' else torch.float16
+  s = torch.rand(4, 32, 32, 3, generator=g).to('cuda:0').to(dt)
+  t = torch.rand(4, 32, 32, 3, generator=g).to('cuda:0').to(dt)
   u0 = tr.store.state['discriminator_s/from_rgb_32x32/Conv/u'].clone()
   for _ in range(6):
     loss, terms = tr.run(s, t)
@@ -1201,3 +1208,41 @@ def test_fp32_path_is_bit_reproducible(norm):
   assert not bad, (len(bad), bad[:5])
   bad = [k for k in sa if not (torch.equal(sa[k][0], sb[k][0]) and torch.equal(sa[k][1], sb[k][1]))]
   assert not bad, (len(bad), bad[:5])
+
+
+def test_fp16_training_steps_with_loss_scale_and_graph():
+  """precision='fp16' (TG_F16 storage, the reference's --dataset_dtype float16) with the static loss scale 128 of
+  model_deploy.py:308-313 / model_inheritor.py:568-570: the scaled backward stays finite in half precision, Adam sees the
+  unscaled gradients (tg_adam_step divides by the scale), eager and hipGraph steps agree with each other, and the
+  parameters move like the fp32 trainer's from the same start."""
+  from twingan_amd import Config
+  from twingan_amd.twingan import Trainer
+  g = torch.Generator().manual_seed(8)
+  s, t = torch.rand(4, 32, 32, 3, generator=g), torch.rand(4, 32, 32, 3, generator=g)
+  ends = {}
+  for prec, scale, graph in (('fp16', 128.0, False), ('fp16', 128.0, True), ('fp32', 1.0, False), ('fp16', 1.0, False)):
+    tr = Trainer(Config(hw=32, max_ch=32, precision=prec, loss_scale=scale), device='cuda:0', seed=3, use_graph=graph)
+    dt = torch.float16 if prec == 'fp16' else torch.float32
+    torch.manual_seed(11)                                   # the device RNG draws the GP alphas
+    for _ in range(4):
+      loss, terms = tr.run(s.cuda().to(dt), t.cuda().to(dt))
+      assert torch.isfinite(loss).all() and all(torch.isfinite(v).all() for v in terms.values())
+    sd = tr.store.state_dict()
+    assert all(torch.isfinite(v).all() for v in sd.values())
+    ends[(prec, scale, graph)] = sd
+    tr.close()
+  start = Trainer(Config(hw=32, max_ch=32, precision='fp16'), device='cuda:0', seed=3)
+  p0 = start.store.state_dict()
+  start.close()
+
+  def update_err(a, b):
+    num = sum(float((((a[k] - p0[k]) - (b[k] - p0[k])).double() ** 2).sum()) for k in a)
+    den = sum(float(((b[k] - p0[k]).double() ** 2).sum()) for k in a)
+    return (num / den) ** 0.5
+  e_graph = update_err(ends[('fp16', 128.0, True)], ends[('fp16', 128.0, False)])
+  e_scale = update_err(ends[('fp16', 128.0, False)], ends[('fp16', 1.0, False)])
+  e_f32 = update_err(ends[('fp16', 128.0, False)], ends[('fp32', 1.0, False)])
+  print('[fp16] update rel-L2: graph vs eager %.3e, scale 128 vs 1 %.3e, fp16 vs fp32 %.3e' % (e_graph, e_scale, e_f32))
+  # graph and eager launch the same kernels with the same device-drawn alphas; Adam's first steps are sign-like, so the
+  # storage rounding (and the rounding pattern a different loss scale gives) moves a fraction of the weights by 2 lr
+  assert e_graph < 1e-6 and e_scale < 0.35 and e_f32 < 0.5

@@ -990,3 +990,94 @@ def test_rccl_allreduce_wrapper_single_rank():
       assert torch.equal(x, want)
     assert lib.tg_allreduce(comm, 0, 16, _lib.TG_F32, 0) != 0 and b'bad arguments' in lib.tg_last_error()
     assert lib.tg_comm_destroy(comm) == 0
+
+
+# ------------------------------------------------------------------------- fp16 storage (TG_F16)
+def f16_round(a):
+  return np.asarray(a, np.float32).astype(np.float16).astype(np.float64)
+
+
+F16_CASES = [
+    # n, hw, cin, cout, k, padding   -> kernel family
+    (4, 128, 16, 32, 3, 'SAME'),      # weight-resident thin kernel; thin (16x16x32 MFMA) filter gradient
+    (4, 64, 32, 64, 3, 'SAME'),       # weight-resident, 64-channel blocks
+    (3, 32, 64, 128, 3, 'SAME'),      # tile kernel
+    (2, 16, 256, 256, 3, 'SAME'),     # tile kernel, two tiles per image
+    (5, 8, 256, 256, 3, 'SAME'),      # small-map kernel
+    (5, 4, 264, 256, 3, 'SAME'),
+    (6, 4, 64, 64, 4, 'VALID'),       # dense rewrite
+    (1, 20, 24, 40, 3, 'SAME'),       # (20 x 12 map) first-generation fallback kernels
+    (2, 12, 32, 48, 1, 'SAME'),
+]
+
+
+@pytest.mark.parametrize('n,hw,cin,cout,k,padding', F16_CASES)
+def test_fp16_conv_kernels_vs_oracle(ops, n, hw, cin, cout, k, padding):
+  """TG_F16 through the same MFMA kernels as bf16 (v_mfma_f32_*_f16 instead of *_bf16): forward with bias + LeakyReLU,
+  backward-data plain and with the producer's mask, filter gradient with and without the bias gradient, against the
+  float64 oracle on fp16-rounded operands.  fp16 keeps 11 significand bits: outputs within 6e-4 (one rounding is
+  2.4e-4), fp32-accumulated filter / bias gradients within 1e-4."""
+  import twingan_amd.ops as O
+  from twingan_amd import _lib
+  from twingan_amd._lib import TG_EPI_BIAS, TG_EPI_LRELU
+  rng = np.random.RandomState(4)
+  h = w = hw
+  if (n, hw, cin) == (1, 20, 24):
+    w = 12
+  x = f16_round(rng.randn(n, h, w, cin))
+  wt = f16_round(rng.randn(k, k, cin, cout) / np.sqrt(k * k * cin))
+  b = rng.randn(cout) * 0.1
+  spec = O.ConvSpec(k, padding)
+  ho, wo = spec.out_hw(h, w)
+  gy = f16_round(rng.randn(n, ho, wo, cout))
+  xd, gyd = to_dev(x, torch.float16), to_dev(gy, torch.float16)
+  wd, bd = to_dev(wt), to_dev(b)
+  assert O._mfma_ok(torch.float16, cin, cout, spec, h, w)
+  y = O.conv_fwd_raw(xd, wd, bd, spec, TG_EPI_BIAS | TG_EPI_LRELU)
+  kern = _lib.load().tg_last_kernel().decode()
+  assert 'f16' in kern, kern
+  assert rel_l2(host(y), N.leaky_relu(N.conv2d(x, wt, padding) + b)) < 6e-4
+  gx = O.conv_bwd_data_raw(gyd, wd, (n, h, w, cin), spec)
+  ref_gx = N.conv2d_bwd_data(gy, wt, (h, w), padding)
+  assert rel_l2(host(gx), ref_gx) < 6e-4
+  if k == 3 and padding == 'SAME':
+    gxm = O.conv_bwd_data_masked_raw(gyd, wd, xd, spec)
+    assert rel_l2(host(gxm), ref_gx * np.where(x > 0, 1.0, 0.2)) < 8e-4
+  gw = O.conv_bwd_weight_raw(xd, gyd, spec)
+  assert rel_l2(host(gw), N.conv2d_bwd_weight(x, gy, (k, k), padding)) < 1e-4
+  if k == 3 and padding == 'SAME' and hw >= 16 and h == w:      # layers whose filter-gradient kernel also sums gy (bias gradient)
+    gb = torch.zeros(cout, device=dev())
+    gw2 = O.conv_bwd_weight_raw(xd, gyd, spec, gbias=gb)
+    assert rel_l2(host(gw2), host(gw)) < 1e-6 and rel_l2(host(gb), gy.sum(axis=(0, 1, 2))) < 1e-4
+  # the bf16 instantiation is untouched by the element format of the previous calls
+  yb = O.conv_fwd_raw(xd.bfloat16(), wd, bd, spec, TG_EPI_BIAS | TG_EPI_LRELU)
+  assert 'f16' not in _lib.load().tg_last_kernel().decode()
+  assert rel_l2(host(yb), host(y)) < 6e-3
+
+
+@pytest.mark.parametrize('n,hw,c', [(3, 16, 32), (2, 64, 16), (4, 4, 256)])
+def test_fp16_norm_pointwise_and_attention_pieces(ops, n, hw, c):
+  rng = np.random.RandomState(6)
+  y = f16_round(rng.randn(n, hw, hw, c) * 1.5 + 0.3)
+  g, b = 1 + 0.1 * rng.randn(c), 0.1 * rng.randn(c)
+  yd = to_dev(y, torch.float16).requires_grad_(True)
+  gd, bd = to_dev(g).requires_grad_(True), to_dev(b).requires_grad_(True)
+  z = ops.norm_act(yd, gd, bd)
+  ref = N.pixel_norm(N.leaky_relu(N.instance_norm(y, g, b)))
+  assert z.dtype == torch.float16 and rel_l2(host(z), ref) < 8e-4
+  gz = f16_round(rng.randn(*y.shape))
+  z.backward(to_dev(gz, torch.float16))
+  yt = torch.tensor(y, dtype=torch.float64, requires_grad=True)
+  gt, bt = torch.tensor(g, requires_grad=True), torch.tensor(b, requires_grad=True)
+  from oracle import torch_ref as R
+  zr = R.pixel_norm(torch.nn.functional.leaky_relu(R.instance_norm(yt, gt, bt), 0.2))
+  zr.backward(torch.tensor(gz))
+  assert rel_l2(host(yd.grad), yt.grad.numpy()) < 2e-3
+  assert rel_l2(host(gd.grad), gt.grad.numpy()) < 1e-3 and rel_l2(host(bd.grad), bt.grad.numpy()) < 1e-3
+  # fromRGB / toRGB and the batched GEMM of the attention layer
+  x3 = to_dev(f16_round(rng.rand(n, hw, hw, 3)), torch.float16)
+  w3 = to_dev(rng.randn(1, 1, 3, c) * 0.5)
+  assert rel_l2(host(ops.pointwise_conv(x3, w3)), N.conv2d(host(x3), host(w3), 'SAME')) < 6e-4
+  a = to_dev(f16_round(rng.randn(n, 40, 24)), torch.float16)
+  bm = to_dev(f16_round(rng.randn(n, 24, 56)), torch.float16)
+  assert rel_l2(host(ops.bgemm(a, bm)), host(a) @ host(bm)) < 6e-4

@@ -7,7 +7,7 @@ import ctypes
 import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint, c_void_p
 
-TG_F32, TG_BF16 = 0, 1
+TG_F32, TG_BF16, TG_F16 = 0, 1, 2
 TG_ALGO_DIRECT, TG_ALGO_MFMA = 0, 1
 TG_EPI_BIAS, TG_EPI_LRELU = 1, 2
 NF_LRELU, NF_PIXNORM, NF_NOSTATS = 1, 2, 4

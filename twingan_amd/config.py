@@ -43,7 +43,8 @@ class Config:
   adam_beta1: float = 0.5
   adam_beta2: float = 0.99
   opt_epsilon: float = 1e-8
-  precision: str = 'bf16'             # 'bf16': bf16 activations + MFMA convs, fp32 master weights; 'fp32': exact path
+  precision: str = 'bf16'             # 'bf16' | 'fp16': 16-bit activations + MFMA convs, fp32 master weights ('fp16' = the
+                                      # reference's --dataset_dtype float16: set loss_scale, 128 there); 'fp32': exact path
   domain_streams: bool = True         # run the two (independent) discriminators on two HIP streams
   overlap_cut_hw: int = 32            # data-parallel runs: the backward is cut where the feature maps grow past this size and
                                       # the all-reduce of the (large) lower-resolution gradients overlaps the rest of it

@@ -55,7 +55,7 @@ constexpr int A_KC_STRIDE = 80, B_KC_STRIDE = 80;        // bytes per row of a K
 constexpr int A_KS_STRIDE = 320, B_KS_STRIDE = 192;      // bytes per k row of a K-strided tile [32 k][128 | 64 cols] (+64 pad)
 
 // AKC / BKC: op(A)'s / op(B)'s reduction axis is contiguous in memory (A stored [m][k] / B stored [n][k])
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, bool F16 = false>
 __global__ __launch_bounds__(256) void bgemm_mfma_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
                                                          void* __restrict__ C, const BgGeom g) {
   __shared__ __attribute__((aligned(16))) unsigned char sA[AKC ? BM * A_KC_STRIDE : BK * A_KS_STRIDE];
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void bgemm_mfma_kernel(const bf16* __restrict_
         bf16x8 bfr;
         if constexpr (BKC) bfr = *reinterpret_cast<const bf16x8*>(sB + b_kc + nb * 32 * B_KC_STRIDE + ks * 32);
         else bfr = lds_tr8(sB + b_ks + nb * 64 + ks * 16 * B_KS_STRIDE, 4 * B_KS_STRIDE);
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[nb], 0, 0, 0);
+        acc[nb] = mfma_32x32x16<F16>(af, bfr, acc[nb]);
       }
     }
   }
@@ -138,8 +138,13 @@ __global__ __launch_bounds__(256) void bgemm_mfma_kernel(const bf16* __restrict_
         float* c = reinterpret_cast<float*>(C) + off;
         *c = g.accumulate ? *c + v : v;
       } else {
-        bf16* c = reinterpret_cast<bf16*>(C) + off;
-        *c = (bf16)(g.accumulate ? (float)*c + v : v);
+        if constexpr (F16) {
+          f16* c = reinterpret_cast<f16*>(C) + off;
+          *c = (f16)(g.accumulate ? (float)*c + v : v);
+        } else {
+          bf16* c = reinterpret_cast<bf16*>(C) + off;
+          *c = (bf16)(g.accumulate ? (float)*c + v : v);
+        }
       }
     }
   }
@@ -278,7 +283,7 @@ int tg_batched_gemm(const void* a, const void* b, void* c, int batch, int m, int
                     int ldc, int64_t stride_a, int64_t stride_b, int64_t stride_c, float alpha, int accumulate, int dtype,
                     int c_is_f32, void* stream) {
   TG_CHECK(a && b && c && batch > 0 && m > 0 && n > 0 && k > 0, TG_EINVAL, "tg_batched_gemm: bad arguments");
-  TG_CHECK(dtype == TG_F32 || dtype == TG_BF16, TG_EINVAL, "tg_batched_gemm: dtype %d", dtype);
+  TG_CHECK(dtype == TG_F32 || dtype == TG_BF16 || dtype == TG_F16, TG_EINVAL, "tg_batched_gemm: dtype %d", dtype);
   BgGeom g;
   g.m = m; g.n = n; g.k = k; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.sa = stride_a; g.sb = stride_b; g.sc = stride_c;
@@ -298,10 +303,18 @@ int tg_batched_gemm(const void* a, const void* b, void* c, int batch, int m, int
   const dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM, batch);
   const bool akc = !ta, bkc = tb != 0;
   tg_note_kernel("bgemm_mfma_kernel<%d,%d>", (int)akc, (int)bkc);
-  if (akc && bkc) hipLaunchKernelGGL((bgemm_mfma_kernel<true, true>), grid, dim3(256), 0, s, (const bf16*)a, (const bf16*)b, c, g);
-  else if (akc) hipLaunchKernelGGL((bgemm_mfma_kernel<true, false>), grid, dim3(256), 0, s, (const bf16*)a, (const bf16*)b, c, g);
-  else if (bkc) hipLaunchKernelGGL((bgemm_mfma_kernel<false, true>), grid, dim3(256), 0, s, (const bf16*)a, (const bf16*)b, c, g);
-  else hipLaunchKernelGGL((bgemm_mfma_kernel<false, false>), grid, dim3(256), 0, s, (const bf16*)a, (const bf16*)b, c, g);
+#define TG_BG_LAUNCH(A_, B_)                                                                                            \
+  do {                                                                                                                \
+    if (dtype == TG_F16)                                                                                              \
+      hipLaunchKernelGGL((bgemm_mfma_kernel<A_, B_, true>), grid, dim3(256), 0, s, (const bf16*)a, (const bf16*)b, c, g); \
+    else                                                                                                              \
+      hipLaunchKernelGGL((bgemm_mfma_kernel<A_, B_>), grid, dim3(256), 0, s, (const bf16*)a, (const bf16*)b, c, g);     \
+  } while (0)
+  if (akc && bkc) TG_BG_LAUNCH(true, true);
+  else if (akc) TG_BG_LAUNCH(true, false);
+  else if (bkc) TG_BG_LAUNCH(false, true);
+  else TG_BG_LAUNCH(false, false);
+#undef TG_BG_LAUNCH
   TG_LAUNCH_CHECK("tg_batched_gemm");
   return TG_OK;
 }

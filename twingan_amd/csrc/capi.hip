@@ -84,11 +84,16 @@ static int check_desc(const char* who, const TgConvDesc* d) {
   const int pb = d->hout + d->kh - 1 - d->hin - d->pad_t, pr = d->wout + d->kw - 1 - d->win - d->pad_l;
   TG_CHECK(pb >= 0 && pb < d->kh && pr >= 0 && pr < d->kw, TG_EINVAL, "%s: output size %dx%d inconsistent with input", who,
            d->hout, d->wout);
-  TG_CHECK(d->dtype == TG_F32 || d->dtype == TG_BF16, TG_EINVAL, "%s: dtype %d", who, d->dtype);
+  TG_CHECK(d->dtype == TG_F32 || d->dtype == TG_BF16 || d->dtype == TG_F16, TG_EINVAL, "%s: dtype %d", who, d->dtype);
+  tg_set_elem_f16(d->dtype == TG_F16);      // read by the MFMA launchers this call reaches
   TG_CHECK(d->algo == TG_ALGO_DIRECT || d->algo == TG_ALGO_MFMA || d->algo == TG_ALGO_MFMA_V1, TG_EINVAL, "%s: algo %d", who,
            d->algo);
   return TG_OK;
 }
+
+static thread_local bool tg_elem_is_f16 = false;
+bool tg_elem_f16() { return tg_elem_is_f16; }
+void tg_set_elem_f16(bool f16) { tg_elem_is_f16 = f16; }
 
 extern "C" {
 
@@ -158,6 +163,7 @@ int tg_conv2d_upcat_supported(int h, int w, int c0, int c1, int cout) {
 }
 
 static int check_upcat(const char* who, int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm) {
+  tg_set_elem_f16(false);      // the two-source kernels take no dtype: bfloat16
   TG_CHECK(n > 0 && tg_conv_tile_upcat_supported(h, w, c0, c1, cout), TG_ENOSUP,
            "%s: needs h %% 8 == 0, w %% 16 == 0, c0 and c1 multiples of 32 (got %dx%d, %d+%d -> %d)", who, h, w, c0, c1, cout);
   TG_CHECK(gsz >= 0 && (gsz == 0 || (n % gsz == 0 && n / gsz <= 4)), TG_EINVAL, "%s: bad skip groups (n %d, gsz %d)", who, n,

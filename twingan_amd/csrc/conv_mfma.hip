@@ -46,7 +46,7 @@ __device__ __forceinline__ bf16x8 zero8() {
 // ------------------------------------------------------------------------------------------------
 // forward (and backward-data) kernel
 // ------------------------------------------------------------------------------------------------
-template <int KH, int KW, int KC, int BN>
+template <int KH, int KW, int KC, int BN, bool F16 = false>
 __global__ __launch_bounds__(256) void conv_fwd_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                      const float* __restrict__ bias, bf16* __restrict__ y,
                                                      const Geom g) {
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma(const bf16* __restrict__ x,
 #pragma unroll
           for (int nt = 0; nt < NTILE; ++nt) {
             const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sB + b_base + nt * 32 * RS_B + (tap * KC + kk * 16) * 2);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[nt], 0, 0, 0);
+            acc[nt] = mfma_32x32x16<F16>(wf, xf, acc[nt]);
           }
         }
       }
@@ -166,15 +166,19 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma(const bf16* __restrict__ x,
       for (int q = 0; q < 4; ++q) {
         const int ch = n0 + nt * 32 + q * 8 + kgrp * 4;
         if (ch < g.cout) {
-          bf16x4 o;
+          float o[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float v = acc[nt][q * 4 + j];
             if (g.epilogue & TG_EPI_BIAS) v += bias[ch + j];
             if (g.epilogue & TG_EPI_LRELU) v = lrelu_f(v, g.alpha);
-            o[j] = (bf16)v;
+            o[j] = v;
           }
-          *reinterpret_cast<bf16x4*>(yp + ch) = o;
+          typedef __attribute__((ext_vector_type(2))) unsigned u2;
+          u2 pk;
+          pk[0] = pack16x2<F16>(o[0], o[1]);
+          pk[1] = pack16x2<F16>(o[2], o[3]);
+          *reinterpret_cast<u2*>(yp + ch) = pk;
         }
       }
     }
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma(const bf16* __restrict__ x,
 // [tap][cin][cout]; conv_wgrad_reduce sums the slabs into the HWIO gradient.
 // D[m = ci][n = co] += sum_pix X[pix + tap][ci] * GY[pix][co]
 // ------------------------------------------------------------------------------------------------
-template <int KH, int KW>
+template <int KH, int KW, bool F16 = false>
 __global__ __launch_bounds__(256) void conv_wgrad_mfma(const bf16* __restrict__ x, const bf16* __restrict__ gy,
                                                        float* __restrict__ slab, const Geom g, int n_co_tiles,
                                                        int tiles_per_block, int total_tiles) {
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma(const bf16* __restrict__ 
           bf16x8 xf;
 #pragma unroll
           for (int j = 0; j < 8; ++j) xf[j] = *reinterpret_cast<const bf16*>(sX + xoff[j] + tapoff);
-          acc[ky * KW + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, gf, acc[ky * KW + kx], 0, 0, 0);
+          acc[ky * KW + kx] = mfma_32x32x16<F16>(xf, gf, acc[ky * KW + kx]);
         }
       }
     }
@@ -323,8 +327,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma(const bf16* __restrict__ 
 // weight packing
 // ------------------------------------------------------------------------------------------------
 // mode 0: out[co][tap][ci] = w[tap][ci][co];  mode 1: out[ci][tap'][co] = w[NT-1-tap'][ci][co]
+// 16-bit store in the pack's element format
+__device__ __forceinline__ void store16(bf16* p, float v, int half_fmt) {
+  if (half_fmt) *reinterpret_cast<f16*>(p) = (f16)v;
+  else *p = (bf16)v;
+}
+
 __global__ void pack_weights(const float* __restrict__ w, bf16* __restrict__ out, int nt, int cin, int cout, int rows,
-                             int rows_pad, int inner, int inner_pad, int mode) {
+                             int rows_pad, int inner, int inner_pad, int mode, int half_fmt) {
   const int64_t total = (int64_t)rows_pad * nt * inner_pad;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int k = (int)(i % inner_pad);
@@ -338,7 +348,7 @@ __global__ void pack_weights(const float* __restrict__ w, bf16* __restrict__ out
       else
         v = w[((int64_t)(nt - 1 - tap) * cin + row) * cout + k];
     }
-    out[i] = (bf16)v;
+    store16(out + i, v, half_fmt);
   }
 }
 
@@ -387,8 +397,11 @@ int launch_fwd(const Geom& g, const bf16* x, const bf16* wp, const float* bias, 
   const size_t lds = ((size_t)(halo_px * (KC * 2 + 16) + 15) & ~(size_t)15) + (size_t)BN * (KH * KW * KC * 2 + 16);
   TG_CHECK(lds <= 64 * 1024, TG_ENOSUP, "conv(mfma): LDS %zu > 64 KiB", lds);
   dim3 grid(g.tiles_x * g.tiles_y * g.tiles_img, (g.cout + BN - 1) / BN);
-  tg_note_kernel("conv_fwd_mfma<%d,%d,%d,%d>", KH, KW, KC, BN);
-  hipLaunchKernelGGL((conv_fwd_mfma<KH, KW, KC, BN>), grid, dim3(256), lds, s, x, wp, bias, y, g);
+  tg_note_kernel(tg_elem_f16() ? "conv_fwd_mfma<%d,%d,%d,%d,f16>" : "conv_fwd_mfma<%d,%d,%d,%d>", KH, KW, KC, BN);
+  if (tg_elem_f16())
+    hipLaunchKernelGGL((conv_fwd_mfma<KH, KW, KC, BN, true>), grid, dim3(256), lds, s, x, wp, bias, y, g);
+  else
+    hipLaunchKernelGGL((conv_fwd_mfma<KH, KW, KC, BN>), grid, dim3(256), lds, s, x, wp, bias, y, g);
   TG_LAUNCH_CHECK("conv_fwd_mfma");
   return TG_OK;
 }
@@ -410,6 +423,8 @@ int dispatch_fwd(const Geom& g, const bf16* x, const bf16* wp, const float* bias
 
 // Rewrites "k x k VALID on a k x k input" (1x1 output) as a 1x1 conv over k*k*cin channels: with NHWC
 // activations and HWIO weights both reshapes are free (nets/pggan.py:330-331,495).
+static inline bool is16(const TgConvDesc* d) { return d->dtype == TG_BF16 || d->dtype == TG_F16; }
+
 static bool as_dense(const TgConvDesc* d, TgConvDesc* o) {
   if (d->hout == 1 && d->wout == 1 && d->hin == d->kh && d->win == d->kw && d->pad_t == 0 && d->pad_l == 0 &&
       (d->kh > 1 || d->kw > 1)) {
@@ -447,7 +462,7 @@ int tg_conv2d_pack_weights(const TgConvDesc* d, const float* w, int mode, void* 
   pack_dims(d, mode, &nt, &cin, &cout, &rows, &rows_pad, &inner, &inner_pad);
   const int64_t total = (int64_t)rows_pad * nt * inner_pad;
   hipLaunchKernelGGL(pack_weights, dim3(tg_grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16*)out, nt,
-                     cin, cout, rows, rows_pad, inner, inner_pad, mode);
+                     cin, cout, rows, rows_pad, inner, inner_pad, mode, d->dtype == TG_F16 ? 1 : 0);
   TG_LAUNCH_CHECK("tg_conv2d_pack_weights");
   return TG_OK;
 }
@@ -458,6 +473,7 @@ struct PackJob {
   const float* w;
   bf16* out;
   int nt, cin, cout, rows, rows_pad, inner, inner_pad, mode;
+  int half_fmt;                    // element format of this pack: 1 = IEEE half (TG_F16 descriptors)
   int block_begin, block_end;      // this job's slice of the grid (PACK_EPB elements per block)
 };
 constexpr int PACK_EPB = 2048;
@@ -492,7 +508,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi(const PackJob* __restr
 #pragma unroll 4
     for (int i = ty; i < 64; i += 4) {
       const int co = r0 + i, ci = k0 + tx;
-      if (ci < j.inner_pad) j.out[((int64_t)co * j.nt + tap) * j.inner_pad + ci] = (bf16)tile[tx][i];
+      if (ci < j.inner_pad) store16(j.out + ((int64_t)co * j.nt + tap) * j.inner_pad + ci, tile[tx][i], j.half_fmt);
     }
     return;
   }
@@ -508,7 +524,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi(const PackJob* __restr
     const int row = (int)(r / j.nt);
     float v = 0.f;
     if (row < j.rows && k < j.inner) v = j.w[((int64_t)(j.nt - 1 - tap) * j.cin + row) * j.cout + k];      // mode 1
-    j.out[i] = (bf16)v;
+    store16(j.out + i, v, j.half_fmt);
   }
 }
 }  // namespace
@@ -523,6 +539,7 @@ int tg_pack_table_fill(const TgConvDesc* d, const float* w, int mode, void* out,
   j.w = w;
   j.out = (bf16*)out;
   j.mode = mode;
+  j.half_fmt = d->dtype == TG_F16;
   pack_dims(d, mode, &j.nt, &j.cin, &j.cout, &j.rows, &j.rows_pad, &j.inner, &j.inner_pad);
   const int64_t total = (int64_t)j.rows_pad * j.nt * j.inner_pad;
   j.block_begin = *total_blocks;
@@ -598,7 +615,7 @@ int tg_conv_small_run(int n, int hin, int win, int cin, int hout, int wout, int 
 int tg_conv2d_fwd_mfma(const TgConvDesc* d0, const void* x, const void* wp, const float* bias, void* y, hipStream_t s) {
   TgConvDesc dd;
   const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
-  TG_CHECK(d->dtype == TG_BF16, TG_ENOSUP, "tg_conv2d_fwd(mfma): bf16 activations only");
+  TG_CHECK(is16(d), TG_ENOSUP, "tg_conv2d_fwd(mfma): 16-bit activations only");
   TG_CHECK(!(d->epilogue & TG_EPI_BIAS) || bias, TG_EINVAL, "tg_conv2d_fwd: bias epilogue without bias pointer");
   if (d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 &&
       tg_conv_tile_supported(d->hin, d->win, d->hout, d->wout, d->kh, d->kw, d->pad_t, d->pad_l))
@@ -623,7 +640,7 @@ int tg_conv2d_fwd_mfma(const TgConvDesc* d0, const void* x, const void* wp, cons
 bool tg_conv2d_bwd_data_mask_fusable_mfma(const TgConvDesc* d0) {
   TgConvDesc dd;
   const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
-  return d->dtype == TG_BF16 && d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 &&
+  return is16(d) && d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 &&
          tg_conv_tile_supported(d->hout, d->wout, d->hin, d->win, d->kh, d->kw, d->pad_t, d->pad_l);
 }
 
@@ -631,7 +648,7 @@ int tg_conv2d_bwd_data_mfma(const TgConvDesc* d0, const void* gy, const void* wp
                             const void* mask) {
   TgConvDesc dd;
   const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
-  TG_CHECK(d->dtype == TG_BF16, TG_ENOSUP, "tg_conv2d_bwd_data(mfma): bf16 activations only");
+  TG_CHECK(is16(d), TG_ENOSUP, "tg_conv2d_bwd_data(mfma): 16-bit activations only");
   TG_CHECK(!mask || tg_conv2d_bwd_data_mask_fusable_mfma(d0), TG_ENOSUP, "tg_conv2d_bwd_data(mfma): mask not fusable here");
   if (d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 &&
       tg_conv_tile_supported(d->hout, d->wout, d->hin, d->win, d->kh, d->kw, d->pad_t, d->pad_l))
@@ -678,7 +695,7 @@ int tg_wgrad_tile_run2(int na, int nb, int h, int w, int cin, int cout, const vo
                        float* gbias = nullptr, int bias_segs = 3);
 
 // two batches (na, nb images) of one layer: supported when the tile kernel takes the layer
-bool tg_conv2d_bwd_weight2_supported_mfma(const TgConvDesc* d) { return d->dtype == TG_BF16 && use_wgrad_tile(d); }
+bool tg_conv2d_bwd_weight2_supported_mfma(const TgConvDesc* d) { return is16(d) && use_wgrad_tile(d); }
 size_t tg_conv2d_bwd_weight2_workspace_mfma(const TgConvDesc* d, int nb) {
   return tg_wgrad_tile_workspace2(d->n, nb, d->hin, d->win, d->cin, d->cout);
 }
@@ -693,7 +710,7 @@ int tg_conv2d_bwd_weight2_mfma(const TgConvDesc* d, int nb, const void* xa, cons
 bool tg_conv2d_bwd_weight_bias_fused_mfma(const TgConvDesc* d0) {
   TgConvDesc dd;
   const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
-  return d->dtype == TG_BF16 && use_wgrad_tile(d);
+  return is16(d) && use_wgrad_tile(d);
 }
 
 size_t tg_conv2d_bwd_weight_workspace_mfma(const TgConvDesc* d0) {
@@ -713,7 +730,7 @@ int tg_conv2d_bwd_weight_mfma(const TgConvDesc* d0, const void* x, const void* g
                               size_t ws_bytes, hipStream_t s, float* gbias) {
   TgConvDesc dd;
   const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
-  TG_CHECK(d->dtype == TG_BF16, TG_ENOSUP, "tg_conv2d_bwd_weight(mfma): bf16 activations only");
+  TG_CHECK(is16(d), TG_ENOSUP, "tg_conv2d_bwd_weight(mfma): 16-bit activations only");
   TG_CHECK(!gbias || use_wgrad_tile(d), TG_ENOSUP, "tg_conv2d_bwd_weight(mfma): bias gradient not fused for this layer");
   if (use_wgrad_tile(d))
     return tg_wgrad_tile_run(d->n, d->hin, d->win, d->cin, d->cout, x, gy, gw, accumulate, ws, ws_bytes, s, gbias);
@@ -734,9 +751,15 @@ int tg_conv2d_bwd_weight_mfma(const TgConvDesc* d0, const void* x, const void* g
   TG_CHECK(lds <= 64 * 1024, TG_ENOSUP, "conv_wgrad(mfma): LDS %zu > 64 KiB", lds);
   dim3 grid(nslices, n_ci * n_co);
   tg_note_kernel("conv_wgrad_mfma<%d,%d>", d->kh, d->kw);
-  if (d->kh == 1)
+  if (d->kh == 1 && tg_elem_f16())
+    hipLaunchKernelGGL((conv_wgrad_mfma<1, 1, true>), grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)gy, (float*)ws,
+                       g, n_co, tpb, total);
+  else if (d->kh == 1)
     hipLaunchKernelGGL((conv_wgrad_mfma<1, 1>), grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g,
                        n_co, tpb, total);
+  else if (tg_elem_f16())
+    hipLaunchKernelGGL((conv_wgrad_mfma<3, 3, true>), grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)gy, (float*)ws,
+                       g, n_co, tpb, total);
   else
     hipLaunchKernelGGL((conv_wgrad_mfma<3, 3>), grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g,
                        n_co, tpb, total);

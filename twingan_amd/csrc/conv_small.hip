@@ -37,14 +37,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t s_rsrc(const void* p, unsigned
 __device__ __forceinline__ bf16x8 s_load16(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
-__device__ __forceinline__ unsigned s_pack2(float lo, float hi) {
-  bf16x2 v;
-  v[0] = (bf16)lo;
-  v[1] = (bf16)hi;
-  return __builtin_bit_cast(unsigned, v);
-}
 
-template <int NT, int MT, int U>      // taps (1 or 9); 32-pixel column blocks per workgroup; chunks per load group
+template <int NT, int MT, int U, bool F16 = false>      // taps (1 or 9); 32-pixel column blocks per workgroup; chunks per load group
 __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                          const float* __restrict__ bias, bf16* __restrict__ y,
                                                          const SmallGeom g) {
@@ -115,7 +109,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict_
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st.w[u][t], st.x[u][m][t], acc[m], 0, 0, 0);
+          acc[m] = mfma_32x32x16<F16>(st.w[u][t], st.x[u][m][t], acc[m]);
   };
   constexpr bool DB = (1 + MT) * NT * U <= 27;      // two stages fit the register file
   if constexpr (DB) {
@@ -169,7 +163,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict_
       v[j] = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane] + bq[j];
       if (g.epilogue & TG_EPI_LRELU) v[j] = lrelu_f(v[j], g.alpha);
     }
-    const unsigned p0 = s_pack2(v[0], v[1]), p1 = s_pack2(v[2], v[3]);
+    const unsigned p0 = pack16x2<F16>(v[0], v[1]), p1 = pack16x2<F16>(v[2], v[3]);
     // low lanes hold channels 8q..8q+3, high lanes 8q+4..8q+7 of the same pixel: give the low lane all 8
     auto s0 = __builtin_amdgcn_permlane32_swap(p0, p0, false, false);   // s0[1] on a low lane = partner's p0
     auto s1 = __builtin_amdgcn_permlane32_swap(p1, p1, false, false);
@@ -213,8 +207,9 @@ int tg_conv_small_run(int n, int hin, int win, int cin, int hout, int wout, int 
   const int mt = (g.npix / 128) * ny >= 256 ? 4 : ((g.npix / 64) * ny >= 256 ? 2 : 1);
   dim3 grid((g.npix + 32 * mt - 1) / (32 * mt), ny);
 #define TG_SMALL_LAUNCH(NT_, MT_)                             \
-  tg_note_kernel("conv_small_kernel<%d,%d>", NT_, MT_); \
-  hipLaunchKernelGGL((conv_small_kernel<NT_, MT_, (NT_ == 1 ? 8 / MT_ : 1)>), grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, g)
+  tg_note_kernel(tg_elem_f16() ? "conv_small_kernel<%d,%d,f16>" : "conv_small_kernel<%d,%d>", NT_, MT_); \
+  if (tg_elem_f16()) hipLaunchKernelGGL((conv_small_kernel<NT_, MT_, (NT_ == 1 ? 8 / MT_ : 1), true>), grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, g); \
+  else hipLaunchKernelGGL((conv_small_kernel<NT_, MT_, (NT_ == 1 ? 8 / MT_ : 1)>), grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, g)
   if (k == 1) {
     if (mt == 4) { TG_SMALL_LAUNCH(1, 4); } else if (mt == 2) { TG_SMALL_LAUNCH(1, 2); } else { TG_SMALL_LAUNCH(1, 1); }
   } else {

@@ -46,6 +46,7 @@ struct TileGeom {
   // to stats[img][chunk][2][cout] -- what in_stats_partial<PART> (norm.hip) would have read the tensor back for.
   float* stats;
   int stat_chunks;         // chunks per image
+  bool f16;                // 16-bit lanes are IEEE half (TG_F16) instead of bfloat16
   // POOL kernels: also write avg_pool2x2 of the (bf16-rounded) output, [n, h/2, w/2, cout] (the tf.nn.avg_pool that
   // ends a discriminator block, nets/pggan.py:304-306) -- the tile already holds every 2x2 block it needs
   bf16* ypool;
@@ -76,12 +77,6 @@ __device__ __forceinline__ void mask4(__amdgpu_buffer_rsrc_t r, unsigned off, fl
   f[3] = (short)(z[1] >> 16) > 0 ? 1.f : alpha;
 }
 
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  bf16x2 v;
-  v[0] = (bf16)lo;
-  v[1] = (bf16)hi;
-  return __builtin_bit_cast(unsigned, v);
-}
 
 // Transposing sum over the 32 lanes of a half-wave, steps [S0, S1) of 5: entering step s a lane holds 32 >> s values;
 // lanes whose bit s differs exchange halves, so after all five steps lane l31 holds the total of original value
@@ -121,9 +116,6 @@ __device__ __forceinline__ float quad_fold4(float a0, float a1, float a2, float 
   return (h1 ? b1 : b0) + dpp_quad<0x4E>(h1 ? b0 : b1);
 }
 
-// the two bf16 values of a packed pair, as floats (exactly what a later reader of the stored tensor sees)
-__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
 
 // 2x2 average over this lane's pixel quad -- lanes l31 ^ 1 (the neighbouring column) and l31 ^ 16 (the sub-tile's other
 // row) -- of the 8 bf16-rounded values in p (four channel quads of one 32-channel block, as packed for the store); all
@@ -133,15 +125,16 @@ __device__ __forceinline__ float add_lane_xor16(float x) {
   auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // (rows 0,0,2,2 | rows 1,1,3,3) of x
   return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
+template <bool F16>
 __device__ __forceinline__ void pool_quad(const unsigned (&p)[4][2], unsigned (&pp)[4][2]) {
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
-      float lo = bf16_lo(p[q][d]), hi = bf16_hi(p[q][d]);
+      float lo = unpack16_lo<F16>(p[q][d]), hi = unpack16_hi<F16>(p[q][d]);
       lo += dpp_quad<0xB1>(lo);
       hi += dpp_quad<0xB1>(hi);
-      pp[q][d] = pack_bf16x2(0.25f * add_lane_xor16(lo), 0.25f * add_lane_xor16(hi));
+      pp[q][d] = pack16x2<F16>(0.25f * add_lane_xor16(lo), 0.25f * add_lane_xor16(hi));
     }
 }
 
@@ -169,7 +162,7 @@ __device__ __forceinline__ void stats_flush(const float (&tot)[BN / 32], float* 
 // nets/pggan.py:69-76) read straight from the two sources -- K chunks below c0 come from the half-resolution
 // tensor, the rest from the skip tensor -- instead of from a materialised copy.
 // MODE 0: plain; 1: statistics partials of the output (STATS); 2: also the 2x2 average pool of the output (POOL)
-template <int KH, int KC, int BN, int MT, bool UPCAT = false, int MODE = 0>
+template <int KH, int KC, int BN, int MT, bool UPCAT = false, int MODE = 0, bool F16 = false>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                         const float* __restrict__ bias, bf16* __restrict__ y,
                                                         const TileGeom g) {
@@ -314,7 +307,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
       for (int nt = 0; nt < NTILE; ++nt)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
-          acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[st & 1][nt], xf[st & 1][m], acc[m][nt], 0, 0, 0);
+          acc[m][nt] = mfma_32x32x16<F16>(wf[st & 1][nt], xf[st & 1][m], acc[m][nt]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -362,10 +355,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] *= f[j];
         }
-        p[q][0] = pack_bf16x2(v[0], v[1]);
-        p[q][1] = pack_bf16x2(v[2], v[3]);
+        p[q][0] = pack16x2<F16>(v[0], v[1]);
+        p[q][1] = pack16x2<F16>(v[2], v[3]);
         if constexpr (STATS) {
-          const float r4[4] = {bf16_lo(p[q][0]), bf16_hi(p[q][0]), bf16_lo(p[q][1]), bf16_hi(p[q][1])};
+          const float r4[4] = {unpack16_lo<F16>(p[q][0]), unpack16_hi<F16>(p[q][0]), unpack16_lo<F16>(p[q][1]), unpack16_hi<F16>(p[q][1])};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             sv[q * 4 + j] += r4[j];
@@ -391,7 +384,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
       __builtin_amdgcn_raw_buffer_store_b128(o1, ry, (ch0 + 16 <= g.cout) ? off + 16 : OOB, 0, 0);
       if constexpr (POOL) {
         unsigned pp[4][2];
-        pool_quad(p, pp);
+        pool_quad<F16>(p, pp);
         u32x4 q0, q1;
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
@@ -426,7 +419,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
 // workgroup stages its weight slice ONCE and walks `tiles_per_wg` consecutive tiles, so per tile it only moves
 // the input halo; the next tile's halo loads are in flight during the MFMAs of the current one.
 // ------------------------------------------------------------------------------------------------
-template <int KH, int KC, int BN, int NCH, int MODE = 0>
+template <int KH, int KC, int BN, int NCH, int MODE = 0, bool F16 = false>
 __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                              const float* __restrict__ bias, bf16* __restrict__ y,
                                                              const TileGeom g) {
@@ -594,7 +587,7 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
 #pragma unroll
           for (int nt = 0; nt < NTILE; ++nt) {
             const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sB + b_base + nt * 32 * RS_B + ((ky * KW + kx) * KC + kk * 16) * 2);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[nt], 0, 0, 0);
+            acc[nt] = mfma_32x32x16<F16>(wf, xf, acc[nt]);
           }
         }
       }
@@ -619,10 +612,10 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
           v[2] *= (short)(z[1] & 0xffffu) > 0 ? 1.f : g.alpha;
           v[3] *= (short)(z[1] >> 16) > 0 ? 1.f : g.alpha;
         }
-        p[q][0] = pack_bf16x2(v[0], v[1]);
-        p[q][1] = pack_bf16x2(v[2], v[3]);
+        p[q][0] = pack16x2<F16>(v[0], v[1]);
+        p[q][1] = pack16x2<F16>(v[2], v[3]);
         if constexpr (STATS) {
-          const float r4[4] = {bf16_lo(p[q][0]), bf16_hi(p[q][0]), bf16_lo(p[q][1]), bf16_hi(p[q][1])};
+          const float r4[4] = {unpack16_lo<F16>(p[q][0]), unpack16_hi<F16>(p[q][0]), unpack16_lo<F16>(p[q][1]), unpack16_hi<F16>(p[q][1])};
           if constexpr (ST == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -651,7 +644,7 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
       __builtin_amdgcn_raw_buffer_store_b128(o1, ry, (ch0 + 16 <= g.cout) ? off + 16 : OOB, 0, 0);
       if constexpr (POOL) {
         unsigned pp[4][2];
-        pool_quad(p, pp);
+        pool_quad<F16>(p, pp);
         u32x4 q0, q1;
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
@@ -699,6 +692,7 @@ int launch_tile_wres(const TileGeom& g0, const bf16* x, const bf16* wp, const fl
   if (tpw < 1) tpw = 1;
   if (tpw > 16) tpw = 16;
   const bool stats = g.stats || g.chunks_query;
+  TG_CHECK(!g.f16 || !(g.stats || g.ypool), TG_ENOSUP, "conv_tile(wres): the statistics / pool epilogues are bf16 only");
   if (stats) {      // a workgroup must stay inside one image
     const int tpi = g.tiles_x * g.tiles_y;
     while (tpi % tpw) --tpw;
@@ -729,6 +723,9 @@ int launch_tile_wres(const TileGeom& g0, const bf16* x, const bf16* wp, const fl
     } else {
       TG_CHECK(false, TG_ENOSUP, "conv_tile(wres): pooled output is built for 3x3 only");
     }
+  } else if (g.f16) {
+    tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d,f16>", KH, KC, BN, NCH);
+    hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH, 0, true>), dim3(nwg, ny), dim3(256), lds, s, x, wp, bias, y, g);
   } else {
     tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d>", KH, KC, BN, NCH);
     hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH>), dim3(nwg, ny), dim3(256), lds, s, x, wp, bias, y, g);
@@ -750,6 +747,7 @@ int launch_tile(const TileGeom& g0, const bf16* x, const bf16* wp, const float* 
     *g.chunks_query = (KH == 3) ? g.tiles_x * g.tiles_y : 0;
     return TG_OK;
   }
+  TG_CHECK(!g.f16 || !(g.stats || g.ypool), TG_ENOSUP, "conv_tile: the statistics / pool epilogues are bf16 only");
   if (g.stats) {
     if constexpr (KH == 3) {
       TG_CHECK(g.epilogue == 0 && !g.mask, TG_ENOSUP, "conv_tile: statistics come with the plain epilogue only");
@@ -796,6 +794,28 @@ int launch_tile(const TileGeom& g0, const bf16* x, const bf16* wp, const float* 
       return TG_OK;
     } else {
       TG_CHECK(false, TG_ENOSUP, "conv_tile: pooled output is built for plain 3x3 convs only");
+    }
+  }
+  if (g.f16) {
+    if constexpr (!UPCAT) {
+      auto kh = conv_tile_kernel<KH, KC, BN, MT, false, 0, true>;
+      if (lds > 64 * 1024) {
+        static bool raised_h = false;
+        if (!raised_h) {
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(kh), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+              hipSuccess) {
+            tg_set_error("conv_tile: cannot raise dynamic LDS to %zu", lds);
+            return TG_ELAUNCH;
+          }
+          raised_h = true;
+        }
+      }
+      tg_note_kernel("conv_tile_kernel<%d,%d,%d,%d,f16>", KH, KC, BN, MT);
+      hipLaunchKernelGGL(kh, dim3(g.nblk, (g.cout + BN - 1) / BN), dim3(256), lds, s, x, wp, bias, y, g);
+      TG_LAUNCH_CHECK("conv_tile");
+      return TG_OK;
+    } else {
+      TG_CHECK(false, TG_ENOSUP, "conv_tile: the two-source (upcat) kernels are bf16 only");
     }
   }
   auto kern = conv_tile_kernel<KH, KC, BN, MT, UPCAT>;
@@ -878,6 +898,7 @@ int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int
   g.stat_chunks = stat_chunks;
   g.chunks_query = chunks_query;
   g.ypool = (bf16*)ypool;
+  g.f16 = tg_elem_f16();      // the descriptor's dtype, noted by the C-ABI entry point
   if (k == 1) return dispatch_tile<1>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
   return dispatch_tile<3>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
 }
@@ -907,5 +928,6 @@ int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gs
   g.stat_chunks = stat_chunks;
   g.chunks_query = chunks_query;
   g.ypool = nullptr;
+  g.f16 = false;
   return dispatch_tile_upcat(g, (const bf16*)x0, (const bf16*)wp, nullptr, (bf16*)y, s);
 }

@@ -20,6 +20,13 @@
 // Reference call site replaced: the Conv2DBackpropFilter gradient of tf.contrib.layers.conv2d
 // (nets/pggan_utils.py:316-320).
 #include "tg_common.h"
+
+// launches conv_wgrad_tile_kernel<TW, BIAS> in the element format of the current call (tg_elem_f16)
+#define TG_WG_LAUNCH(TW_, BIAS_, ...)                                                        \
+  do {                                                                                       \
+    if (tg_elem_f16()) hipLaunchKernelGGL((conv_wgrad_tile_kernel<TW_, BIAS_, true>), __VA_ARGS__); \
+    else hipLaunchKernelGGL((conv_wgrad_tile_kernel<TW_, BIAS_, false>), __VA_ARGS__);         \
+  } while (0)
 #include <cstdlib>
 
 namespace {
@@ -70,7 +77,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
 
 // TW = 16: a tile is 8 rows x 16 cols of one image (maps of 16x16 and up).  TW = 8: the 8x8 maps -- a tile is TWO
 // whole images, K step ks = image ks of the pair, and the two 8-pixel halves of a K step are rows 2w and 2w+1.
-template <int TW, bool BIAS = false>
+template <int TW, bool BIAS = false, bool F16 = false>
 __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gy,
                                                               float* __restrict__ slab, const WgGeom g) {
   constexpr bool ATOMIC = false;
@@ -159,8 +166,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   if constexpr (BIAS) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) accb[j] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+    {      // 1.0 in the element format, eight times
+      typedef __attribute__((ext_vector_type(4))) unsigned u4;
+      u4 o4;
+      o4[0] = o4[1] = o4[2] = o4[3] = ones16x2<F16>();
+      ones = __builtin_bit_cast(bf16x8, o4);
+    }
   }
   const bool do_bias = BIAS && ci_blk == 0;      // uniform
   bool bias_a = false, bias_b = false, bias_0 = false, bias_1 = false;      // per register stage / per LDS buffer
@@ -235,14 +246,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
       const int xpx = TW == 16 ? (wid * 2 + ks) * HWX : ks * (HH * HWX) + wid * 2 * HWX;
       const bf16x8 gf = tr_frag(bG + gpx * PS + frag_off);
       if constexpr (BIAS) {
-        if (bias_on) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, gf, accb, 0, 0, 0);
+        if (bias_on) accb = mfma_32x32x16<F16>(ones, gf, accb);
       }
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           const bf16x8 xf = tr_frag(bX + (xpx + ky * HWX + kx) * PS + frag_off_x);
-          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, gf, acc[ky * 3 + kx], 0, 0, 0);
+          acc[ky * 3 + kx] = mfma_32x32x16<F16>(xf, gf, acc[ky * 3 + kx]);
         }
       }
     }
@@ -316,7 +327,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
 // reads 8 consecutive pixels = 256 contiguous bytes per transpose read (conflict-free), same mapping for both operands.
 // Accumulators: 9 x f32x4 instead of 9 x f32x16 -> 4 workgroups per CU instead of 2.  A 32-channel cout runs as two
 // co blocks (a single workgroup with both, CO = 32, needs 214 VGPRs: 2 workgroups per CU, 112 vs 105 us in kbench).
-template <int CO, bool BIAS>
+template <int CO, bool BIAS, bool F16 = false>
 __global__ __launch_bounds__(256, BIAS ? 3 : 4) void conv_wgrad_thin_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gy,
                                                                  float* __restrict__ slab, const WgGeom g) {
   constexpr int TH = 16, TW = 16, HWX = 18, HH = 18, NT = 9, NB = CO / 16;
@@ -402,8 +413,12 @@ __global__ __launch_bounds__(256, BIAS ? 3 : 4) void conv_wgrad_thin_kernel(cons
     for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int j = 0; j < 4; ++j) accb[b][j] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+    {      // 1.0 in the element format, eight times
+      typedef __attribute__((ext_vector_type(4))) unsigned u4;
+      u4 o4;
+      o4[0] = o4[1] = o4[2] = o4[3] = ones16x2<F16>();
+      ones = __builtin_bit_cast(bf16x8, o4);
+    }
   }
   const bool do_bias = BIAS && ci_blk == 0;      // uniform
   bool bias_a = false, bias_b = false, bias_0 = false, bias_1 = false;
@@ -466,7 +481,7 @@ __global__ __launch_bounds__(256, BIAS ? 3 : 4) void conv_wgrad_thin_kernel(cons
       if constexpr (BIAS) {
         if (bias_on) {
 #pragma unroll
-          for (int b = 0; b < NB; ++b) accb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, gf[b], accb[b], 0, 0, 0);
+          for (int b = 0; b < NB; ++b) accb[b] = mfma_16x16x32<F16>(ones, gf[b], accb[b]);
         }
       }
 #pragma unroll
@@ -476,7 +491,7 @@ __global__ __launch_bounds__(256, BIAS ? 3 : 4) void conv_wgrad_thin_kernel(cons
           const bf16x8 xf = frag(bX + ((r + ky) * HWX + kx) * PSX + fx, HWX * PSX);
 #pragma unroll
           for (int b = 0; b < NB; ++b)
-            acc[ky * 3 + kx][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, gf[b], acc[ky * 3 + kx][b], 0, 0, 0);
+            acc[ky * 3 + kx][b] = mfma_16x16x32<F16>(xf, gf[b], acc[ky * 3 + kx][b]);
         }
       }
     }
@@ -635,7 +650,9 @@ bool wg_launch_thin(const WgGeom& g, const bf16* x, const bf16* gy, float* ws, i
   const bool bias = g.gbias != nullptr;
   const size_t lds = 2 * (18 * 18 * 32 + 256 * 32);
   tg_note_kernel(bias ? "conv_wgrad_thin_kernel<16,bias>" : "conv_wgrad_thin_kernel<16>");
-  if (bias) hipLaunchKernelGGL((conv_wgrad_thin_kernel<16, true>), grid, dim3(256), lds, s, x, gy, ws, g);
+  if (bias && tg_elem_f16()) hipLaunchKernelGGL((conv_wgrad_thin_kernel<16, true, true>), grid, dim3(256), lds, s, x, gy, ws, g);
+  else if (bias) hipLaunchKernelGGL((conv_wgrad_thin_kernel<16, true>), grid, dim3(256), lds, s, x, gy, ws, g);
+  else if (tg_elem_f16()) hipLaunchKernelGGL((conv_wgrad_thin_kernel<16, false, true>), grid, dim3(256), lds, s, x, gy, ws, g);
   else hipLaunchKernelGGL((conv_wgrad_thin_kernel<16, false>), grid, dim3(256), lds, s, x, gy, ws, g);
   return true;
 }
@@ -672,13 +689,13 @@ int tg_wgrad_tile_run(int n, int h, int w, int cin, int cout, const void* x, con
   const size_t lds8 = 2 * (2 * 10 * 10 * 64 + 8 * 16 * 64);
   const dim3 grid(nslices * n_ci * g.n_co_blk);
   if (w == 8 && gbias)
-    hipLaunchKernelGGL((conv_wgrad_tile_kernel<8, true>), grid, dim3(256), lds8, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g);
+    TG_WG_LAUNCH(8, true, grid, dim3(256), lds8, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g);
   else if (w == 8)
-    hipLaunchKernelGGL((conv_wgrad_tile_kernel<8>), grid, dim3(256), lds8, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g);
+    TG_WG_LAUNCH(8, false, grid, dim3(256), lds8, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g);
   else if (gbias)
-    hipLaunchKernelGGL((conv_wgrad_tile_kernel<16, true>), grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g);
+    TG_WG_LAUNCH(16, true, grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g);
   else
-    hipLaunchKernelGGL((conv_wgrad_tile_kernel<16>), grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g);
+    TG_WG_LAUNCH(16, false, grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g);
   TG_LAUNCH_CHECK("conv_wgrad_tile");
   return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
 }
@@ -713,13 +730,13 @@ int tg_wgrad_tile_run2(int na, int nb, int h, int w, int cin, int cout, const vo
   const dim3 grid(nslices * n_ci * g.n_co_blk);
   const size_t l8 = 2 * (2 * 10 * 10 * 64 + 8 * 16 * 64), l16 = 2 * (10 * 18 * 64 + 8 * 16 * 64);
   if (w == 8 && gbias)
-    hipLaunchKernelGGL((conv_wgrad_tile_kernel<8, true>), grid, dim3(256), l8, s, (const bf16*)xa, (const bf16*)gya, (float*)ws, g);
+    TG_WG_LAUNCH(8, true, grid, dim3(256), l8, s, (const bf16*)xa, (const bf16*)gya, (float*)ws, g);
   else if (w == 8)
-    hipLaunchKernelGGL((conv_wgrad_tile_kernel<8>), grid, dim3(256), l8, s, (const bf16*)xa, (const bf16*)gya, (float*)ws, g);
+    TG_WG_LAUNCH(8, false, grid, dim3(256), l8, s, (const bf16*)xa, (const bf16*)gya, (float*)ws, g);
   else if (gbias)
-    hipLaunchKernelGGL((conv_wgrad_tile_kernel<16, true>), grid, dim3(256), l16, s, (const bf16*)xa, (const bf16*)gya, (float*)ws, g);
+    TG_WG_LAUNCH(16, true, grid, dim3(256), l16, s, (const bf16*)xa, (const bf16*)gya, (float*)ws, g);
   else
-    hipLaunchKernelGGL((conv_wgrad_tile_kernel<16>), grid, dim3(256), l16, s, (const bf16*)xa, (const bf16*)gya, (float*)ws, g);
+    TG_WG_LAUNCH(16, false, grid, dim3(256), l16, s, (const bf16*)xa, (const bf16*)gya, (float*)ws, g);
   TG_LAUNCH_CHECK("conv_wgrad_tile(2)");
   return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
 }
@@ -746,7 +763,7 @@ int tg_wgrad_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int g
   const int n_ci = (cin + 31) / 32;
   const size_t lds = 2 * (10 * 18 * 64 + 8 * 16 * 64);
   tg_note_kernel("conv_wgrad_tile_kernel");
-  hipLaunchKernelGGL((conv_wgrad_tile_kernel<16>), dim3(nslices * n_ci * g.n_co_blk), dim3(256), lds, s, (const bf16*)x0,
+  TG_WG_LAUNCH(16, false, dim3(nslices * n_ci * g.n_co_blk), dim3(256), lds, s, (const bf16*)x0,
                      (const bf16*)gy, (float*)ws, g);
   TG_LAUNCH_CHECK("conv_wgrad_tile(upcat)");
   return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);

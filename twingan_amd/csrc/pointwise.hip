@@ -581,6 +581,12 @@ int tg_cast(const void* src, void* dst, int64_t numel, int sd, int dd, void* str
     hipLaunchKernelGGL((cast_kernel<float, float>), grid, blk, 0, s, (const float*)src, (float*)dst, numel);
   else if (sd == TG_BF16 && dd == TG_BF16)
     hipLaunchKernelGGL((cast_kernel<bf16, bf16>), grid, blk, 0, s, (const bf16*)src, (bf16*)dst, numel);
+  else if (sd == TG_F32 && dd == TG_F16)
+    hipLaunchKernelGGL((cast_kernel<float, f16>), grid, blk, 0, s, (const float*)src, (f16*)dst, numel);
+  else if (sd == TG_F16 && dd == TG_F32)
+    hipLaunchKernelGGL((cast_kernel<f16, float>), grid, blk, 0, s, (const f16*)src, (float*)dst, numel);
+  else if (sd == TG_F16 && dd == TG_F16)
+    hipLaunchKernelGGL((cast_kernel<f16, f16>), grid, blk, 0, s, (const f16*)src, (f16*)dst, numel);
   else {
     tg_set_error("tg_cast: unsupported dtypes %d -> %d", sd, dd);
     return TG_EINVAL;

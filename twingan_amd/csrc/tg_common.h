@@ -12,6 +12,9 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -52,14 +55,17 @@ static inline bool tg_aligned16(const void* p) { return (reinterpret_cast<uintpt
 template <typename T> __device__ __forceinline__ float ld(const T* p);
 template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld<bf16>(const bf16* p) { return (float)*p; }
+template <> __device__ __forceinline__ float ld<f16>(const f16* p) { return (float)*p; }
 template <typename T> __device__ __forceinline__ void st(T* p, float v);
 template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st<bf16>(bf16* p, float v) { *p = (bf16)v; }
+template <> __device__ __forceinline__ void st<f16>(f16* p, float v) { *p = (f16)v; }
 
 // round-trip through the storage type (so fp32 math sees what a bf16 store would keep)
 template <typename T> __device__ __forceinline__ float rnd(float v);
 template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
 template <> __device__ __forceinline__ float rnd<bf16>(float v) { return (float)(bf16)v; }
+template <> __device__ __forceinline__ float rnd<f16>(float v) { return (float)(f16)v; }
 
 // ---- 16-byte vectors of the storage type ----------------------------------------------------
 template <typename T> struct Vec16;   // 16 bytes worth of T
@@ -75,12 +81,69 @@ template <> struct Vec16<bf16> {
   __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
   __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16)x; }
 };
+template <> struct Vec16<f16> {
+  static constexpr int N = 8;
+  f16x8 v;
+  __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = (f16)x; }
+};
 template <typename T> __device__ __forceinline__ Vec16<T> ldv(const T* p) {
   return *reinterpret_cast<const Vec16<T>*>(p);
 }
 template <typename T> __device__ __forceinline__ void stv(T* p, const Vec16<T>& v) {
   *reinterpret_cast<Vec16<T>*>(p) = v;
 }
+
+// Which 16-bit format the MFMA kernels of the current C-ABI call see (thread-local; set by the entry point from the
+// descriptor's / the call's dtype, read by the launchers that pick the template variant): false = bfloat16, true = half.
+bool tg_elem_f16();
+void tg_set_elem_f16(bool f16);
+
+// ---- the two 16-bit storage formats of the MFMA kernels ---------------------------------------
+// The kernels move activations and weight packs as opaque 16-byte vectors of eight 16-bit lanes (typed bf16x8 for
+// historical reasons); the element format only matters where a value meets arithmetic: the MFMA instruction, the
+// float -> 16-bit packing of an epilogue, the 16-bit -> float unpacking of the statistics / pool epilogues.
+// F16 = false: bfloat16; true: IEEE half (TG_F16).
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ unsigned pack16x2(float lo, float hi) {
+  if constexpr (F16) {
+    f16x2 v;
+    v[0] = (f16)lo;
+    v[1] = (f16)hi;
+    return __builtin_bit_cast(unsigned, v);
+  } else {
+    bf16x2 v;
+    v[0] = (bf16)lo;
+    v[1] = (bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+  }
+}
+template <bool F16>
+__device__ __forceinline__ float unpack16_lo(unsigned p) {
+  if constexpr (F16) return (float)__builtin_bit_cast(f16x2, p)[0];
+  else return __builtin_bit_cast(float, p << 16);
+}
+template <bool F16>
+__device__ __forceinline__ float unpack16_hi(unsigned p) {
+  if constexpr (F16) return (float)__builtin_bit_cast(f16x2, p)[1];
+  else return __builtin_bit_cast(float, p & 0xffff0000u);
+}
+// 1.0 in either format, twice (the all-ones MFMA operand of the bias-gradient trick)
+template <bool F16> constexpr unsigned ones16x2() { return F16 ? 0x3c003c00u : 0x3f803f80u; }
 
 // ---- reductions -----------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
@@ -131,6 +194,9 @@ static inline int tg_grid_for(int64_t work, int block, int max_blocks = 256 * 16
       __VA_ARGS__                                           \
     } else if ((dtype) == TG_BF16) {                        \
       using T = bf16;                                       \
+      __VA_ARGS__                                           \
+    } else if ((dtype) == TG_F16) {                         \
+      using T = f16;                                        \
       __VA_ARGS__                                           \
     } else {                                                \
       tg_set_error("%s: unsupported dtype %d", NAME, dtype); \

@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import TG_BF16, TG_F32, call
+from ._lib import TG_BF16, TG_F16, TG_F32, call
 from .checkpoint import _field, _get_varint, _parse_message, _put_varint, crc32c, mask_crc
 
 
@@ -196,7 +196,7 @@ class Preprocessor:
 
   def __init__(self, hw, device='cuda', precision='bf16', resize_mode='PAD', is_training=True, seed=0):
     self.hw, self.device = int(hw), torch.device(device)
-    self.dtype = torch.bfloat16 if precision == 'bf16' else torch.float32
+    self.dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[precision]
     self.resize_mode, self.is_training = resize_mode, is_training
     self.rng = np.random.default_rng(seed)
 
@@ -231,7 +231,7 @@ class Preprocessor:
         d = [t.to(self.device, non_blocking=True) for t in (buf, offsets, rect, aug)]
         out = torch.empty((n, self.hw, self.hw, 3), dtype=self.dtype, device=self.device)
         call('tg_preprocess_images', d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), out.data_ptr(), n,
-             self.hw, TG_BF16 if self.dtype == torch.bfloat16 else TG_F32, st.cuda_stream)
+             self.hw, {torch.bfloat16: TG_BF16, torch.float16: TG_F16, torch.float32: TG_F32}[self.dtype], st.cuda_stream)
         for t in d:
           t.record_stream(st)
     return out

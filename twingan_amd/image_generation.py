@@ -60,7 +60,7 @@ class PgganTrainer(Trainer):
   def _noise(self, b):
     shape = get_noise_shape(b, self.cfg.max_ch)
     z = torch.randn(shape, dtype=torch.float32, device=self.device)
-    return z.to(torch.bfloat16) if self.cfg.precision == 'bf16' else z
+    return z.to({'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[self.cfg.precision])
 
   def _generator_loss(self, sources, targets):
     return generator_loss(self.P, targets, self.cfg, self._noise(targets.shape[0]))

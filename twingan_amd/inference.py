@@ -46,7 +46,7 @@ class ImageInferer:
     self.store.load_state_dict(state_dict)
     to, self.style_from = output_tensor_name[len('custom_generated_'):].split('_style_')
     self.to = to
-    self.dtype = torch.bfloat16 if self.cfg.precision == 'bf16' else torch.float32
+    self.dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[self.cfg.precision]
 
   @classmethod
   def from_checkpoint(cls, cfg, model_path, device='cuda', output_tensor_name='custom_generated_t_style_source'):

@@ -15,18 +15,21 @@ import weakref
 import torch
 
 from . import _lib
-from ._lib import (NF_LRELU, NF_NOSTATS, NF_PIXNORM, TG_ALGO_DIRECT, TG_ALGO_MFMA, TG_BF16, TG_EPI_BIAS, TG_EPI_LRELU, TG_F32,
+from ._lib import (NF_LRELU, NF_NOSTATS, NF_PIXNORM, TG_ALGO_DIRECT, TG_ALGO_MFMA, TG_BF16, TG_EPI_BIAS, TG_EPI_LRELU, TG_F16, TG_F32,
                    TgConvDesc, call)
 
 LRELU_ALPHA = 0.2    # util_misc.py:68
 
 
+_DTYPES = {torch.float32: TG_F32, torch.bfloat16: TG_BF16, torch.float16: TG_F16}
+HALF_TYPES = (torch.bfloat16, torch.float16)      # the 16-bit storage formats of the MFMA path
+
+
 def _dt(t):
-  if t.dtype == torch.bfloat16:
-    return TG_BF16
-  if t.dtype == torch.float32:
-    return TG_F32
-  raise _lib.TgError('unsupported tensor dtype %s' % t.dtype)
+  try:
+    return _DTYPES[t.dtype]
+  except KeyError:
+    raise _lib.TgError('unsupported tensor dtype %s' % t.dtype)
 
 
 def _stream():
@@ -110,12 +113,13 @@ class PackCache:
   @classmethod
   def get(cls, w, desc, mode):
     n = _lib.load().tg_conv2d_pack_elems(ctypes.byref(desc), mode)
-    key = (w.data_ptr(), mode, n)
+    key = (w.data_ptr(), mode, n, desc.dtype)
     cached = w.data_ptr() in cls._registered
     ent = cls._packs.get(key) if cached else None
     if ent is not None and ent[0] == cls.version:
       return ent[1]
-    buf = ent[1] if ent is not None else torch.empty(n, dtype=torch.bfloat16, device=w.device)
+    buf = ent[1] if ent is not None else torch.empty(
+        n, dtype=torch.float16 if desc.dtype == TG_F16 else torch.bfloat16, device=w.device)
     cls._pack(w, desc, mode, buf)
     if cached:
       dcopy = TgConvDesc()
@@ -299,7 +303,7 @@ class ConvSpec:
 
 
 def _mfma_ok(dtype, cin, cout, spec, hin, win):
-  if dtype != torch.bfloat16 or cin % 8 or cout % 8:
+  if dtype not in HALF_TYPES or cin % 8 or cout % 8:
     return False
   if spec.kh == 1 or spec.kh == 3:
     return True
@@ -307,7 +311,7 @@ def _mfma_ok(dtype, cin, cout, spec, hin, win):
 
 
 def _esize(t):
-  return 2 if t.dtype == torch.bfloat16 else 4
+  return 2 if t.dtype in HALF_TYPES else 4
 
 
 def _shape_tag(t):
@@ -334,7 +338,7 @@ def _desc(x_shape, cout, spec, dtype, epilogue):
   d.n, d.hin, d.win, d.cin = n, h, w, cin
   d.hout, d.wout, d.cout = ho, wo, cout
   d.kh, d.kw, d.pad_t, d.pad_l = spec.kh, spec.kw, spec.pad_t, spec.pad_l
-  d.dtype = TG_BF16 if dtype == torch.bfloat16 else TG_F32
+  d.dtype = _DTYPES[dtype]
   d.algo = TG_ALGO_MFMA if _mfma_ok(dtype, cin, cout, spec, h, w) else TG_ALGO_DIRECT
   d.epilogue = epilogue
   d.lrelu_alpha = spec.alpha

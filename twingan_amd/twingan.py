@@ -114,7 +114,7 @@ def _sum_terms(terms):
 
 
 def act_dtype(cfg):
-  return torch.bfloat16 if cfg.precision == 'bf16' else torch.float32
+  return {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[cfg.precision]
 
 
 def get_growing_image(img, alpha):
