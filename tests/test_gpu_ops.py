@@ -1081,3 +1081,83 @@ def test_fp16_norm_pointwise_and_attention_pieces(ops, n, hw, c):
   a = to_dev(f16_round(rng.randn(n, 40, 24)), torch.float16)
   bm = to_dev(f16_round(rng.randn(n, 24, 56)), torch.float16)
   assert rel_l2(host(ops.bgemm(a, bm)), host(a) @ host(bm)) < 6e-4
+
+
+# ------------------------------------------------------------------------- flash attention
+def _attention_ref(q, k, v):
+  s = np.einsum('nid,njd->nij', q, k)
+  s = s - s.max(axis=-1, keepdims=True)
+  p = np.exp(s)
+  p /= p.sum(axis=-1, keepdims=True)
+  return np.einsum('nij,njd->nid', p, v)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('n,ln,dk,dv', [(2, 256, 8, 64), (1, 1024, 16, 128), (3, 128, 8, 256)])
+def test_flash_attention_forward(ops, dtype, n, ln, dk, dv):
+  """tg_flash_attention_fwd against softmax(q k^T) v in float64 on the 16-bit-rounded operands: the map is never
+  written, the softmax statistics stay fp32 (the composed path rounds the scores to 16 bit first)."""
+  rng = np.random.RandomState(7)
+  rnd = bf16_round if dtype == torch.bfloat16 else f16_round
+  q, k, v = rnd(np.tanh(rng.randn(n, ln, dk))), rnd(np.tanh(rng.randn(n, ln, dk) * 2)), rnd(rng.randn(n, ln, dv))
+  qd, kd, vd = (to_dev(t, dtype) for t in (q, k, v))
+  assert ops.flash_attention_supported(qd, vd)
+  o, lse = ops.flash_attention_fwd_raw(qd, kd, vd)
+  ref = _attention_ref(q, k, v)
+  tol = 6e-3 if dtype == torch.bfloat16 else 8e-4      # P is rounded to the storage type before the second product
+  assert rel_l2(host(o), ref) < tol
+  s = np.einsum('nid,njd->nij', q, k)
+  want = np.log(np.exp(s - s.max(-1, keepdims=True)).sum(-1)) + s.max(-1)
+  assert np.abs(host(lse) - want).max() < 1e-4
+
+
+def _attention_grads_ref(q, k, v, go):
+  s = np.einsum('nid,njd->nij', q, k)
+  p = np.exp(s - s.max(-1, keepdims=True))
+  p /= p.sum(-1, keepdims=True)
+  gv = np.einsum('nij,nid->njd', p, go)
+  gp = np.einsum('nid,njd->nij', go, v)
+  gs = p * (gp - (gp * p).sum(-1, keepdims=True))
+  return np.einsum('nij,njd->nid', gs, k), np.einsum('nij,nid->njd', gs, q), gv
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('n,ln,dk,dv', [(2, 256, 8, 64), (1, 512, 16, 128), (3, 128, 16, 64)])
+def test_flash_attention_backward(ops, dtype, n, ln, dk, dv):
+  """tg_flash_attention_bwd (dq, dk, dv) against the float64 softmax-attention gradients, and against the composed
+  batched-GEMM / softmax path's own gradients on the same inputs (both 16-bit; the flash path keeps fp32 scores)."""
+  rng = np.random.RandomState(11)
+  rnd = bf16_round if dtype == torch.bfloat16 else f16_round
+  q, k, v = rnd(np.tanh(rng.randn(n, ln, dk))), rnd(np.tanh(rng.randn(n, ln, dk) * 2)), rnd(rng.randn(n, ln, dv))
+  go = rnd(rng.randn(n, ln, dv))
+  qd, kd, vd = (to_dev(t, dtype).requires_grad_(True) for t in (q, k, v))
+  assert ops.flash_attention_trainable(qd, vd)
+  o = ops.flash_attention(qd, kd, vd)
+  gq, gk, gv = torch.autograd.grad(o, (qd, kd, vd), to_dev(go, dtype))
+  rq, rk, rv = _attention_grads_ref(q, k, v, go)
+  tol = 1.2e-2 if dtype == torch.bfloat16 else 2e-3
+  for got, ref, nm in ((gq, rq, 'dq'), (gk, rk, 'dk'), (gv, rv, 'dv')):
+    assert rel_l2(host(got), ref) < tol, nm
+  oc = ops.bgemm(ops.softmax_rows(ops.bgemm(qd, kd, False, True)), vd, False, False)
+  cq, ck, cv = torch.autograd.grad(oc, (qd, kd, vd), to_dev(go, dtype))
+  for got, ref, cmp_, nm in ((gq, rq, cq, 'dq'), (gk, rk, ck, 'dk'), (gv, rv, cv, 'dv')):
+    assert rel_l2(host(got), ref) <= rel_l2(host(cmp_), ref) * 1.5 + 1e-4, nm      # at least as close as the composed path
+
+
+def test_flash_attention_second_order(ops):
+  """Under create_graph the flash node's backward is the differentiable composition: the double backward through it
+  equals the one through the batched-GEMM / softmax path."""
+  rng = np.random.RandomState(5)
+  n, ln, dk, dv = 1, 128, 8, 64
+  q, k, v = (bf16_round(np.tanh(rng.randn(n, ln, d))) for d in (dk, dk, dv))
+  res = []
+  for flash in (True, False):
+    qd, kd, vd = (to_dev(t, torch.bfloat16).requires_grad_(True) for t in (q, k, v))
+    o = ops.flash_attention(qd, kd, vd) if flash else ops.bgemm(ops.softmax_rows(ops.bgemm(qd, kd, False, True)), vd, False, False)
+    gq, = torch.autograd.grad(o, qd, torch.ones_like(o), create_graph=True)
+    loss = (gq.float() ** 2).mean()
+    res.append([host(t) for t in torch.autograd.grad(loss, (kd, vd))])
+    with ops.second_order():
+      assert not ops.flash_attention_trainable(qd, vd)
+  for a, b in zip(*res):
+    assert rel_l2(a, b) < 2e-2

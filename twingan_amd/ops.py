@@ -64,6 +64,9 @@ def _chk(*ts):
 USE_CONV_STATS = os.environ.get('TG_CONV_STATS', '1') != '0'
 # avg_pool2 of a discriminator block's last conv written by that conv (TG_CONV_POOL=0: separate pool launch)
 USE_CONV_POOL = os.environ.get('TG_CONV_POOL', '1') != '0'
+# self-attention's score / softmax / value products as the flash kernels in first-order passes (TG_FLASH_ATTENTION=0: the
+# batched-GEMM + row-softmax composition everywhere)
+USE_FLASH_ATTENTION = os.environ.get('TG_FLASH_ATTENTION', '1') != '0'
 
 class PackCache:
   """bf16 K-contiguous packs (tg_conv2d_pack_weights) of registered master weights.
@@ -1427,6 +1430,91 @@ class SoftmaxRowsBwdFn(torch.autograd.Function):
       gdp = torch.empty_like(p)
       call('tg_softmax_rows_bwd', _p(p), _p(v), _p(gdp), p.numel() // cols, cols, _dt(p), _stream())
     return gp, gdp
+
+
+def transpose16(x):
+  """[n, rows, cols] -> [n, cols, rows] contiguous, 16-bit tensors (tg_transpose16)."""
+  _chk(x)
+  n, r, c = x.shape
+  out = torch.empty((n, c, r), dtype=x.dtype, device=x.device)
+  call('tg_transpose16', _p(x), _p(out), n, r, c, _stream(), work=('transpose16:numel%d' % x.numel(), 0, 2 * _nb(x)))
+  return out
+
+
+def flash_attention_supported(q, v):
+  return q.dtype in HALF_TYPES and bool(_lib.load().tg_flash_attention_supported(q.shape[1], q.shape[2], v.shape[2]))
+
+
+def flash_attention_fwd_raw(q, k, v):
+  """(o, lse): o = softmax(q k^T) v per image without the [len, len] map."""
+  _chk(q, k, v)
+  n, ln, dk = q.shape
+  dv = v.shape[2]
+  vt = transpose16(v)
+  o = torch.empty((n, ln, dv), dtype=q.dtype, device=q.device)
+  lse = torch.empty((n, ln), dtype=torch.float32, device=q.device)
+  call('tg_flash_attention_fwd', _p(q), _p(k), _p(vt), _p(o), _p(lse), n, ln, dk, dv, _dt(q), _stream(),
+       work=('flash_fwd:len%d:dk%d:dv%d:n%d' % (ln, dk, dv, n), 2 * n * ln * ln * (dk + dv), _nb(q, k, v, o)))
+  return o, lse
+
+
+class _SecondOrder(object):
+  depth = 0
+
+
+class second_order(object):
+  """Marks a forward pass whose backward is itself differentiated (the gradient-penalty pass of the discriminator,
+  image_generation.py:414-439): layers with a first-order-only fused kernel build their differentiable composition."""
+
+  def __enter__(self):
+    _SecondOrder.depth += 1
+
+  def __exit__(self, *exc):
+    _SecondOrder.depth -= 1
+
+
+def in_second_order():
+  return _SecondOrder.depth > 0
+
+
+def flash_attention_trainable(q, v):
+  return flash_attention_supported(q, v) and v.shape[2] <= 128 and not in_second_order()
+
+
+class FlashAttnFn(torch.autograd.Function):
+  """softmax(q k^T) v of libs/self_attention.py:56-63 without the [len, len] map in HBM (csrc/flash.hip): forward saves the
+  per-query log-sum-exp; the first-order backward recomputes the probabilities tile by tile.  Under create_graph the
+  backward is built from the differentiable batched-GEMM / softmax ops instead (materialises the map)."""
+
+  @staticmethod
+  def forward(ctx, q, k, v):
+    o, lse = flash_attention_fwd_raw(q, k, v)
+    ctx.save_for_backward(q, k, v, o, lse)
+    return o
+
+  @staticmethod
+  def backward(ctx, go):
+    q, k, v, o, lse = ctx.saved_tensors
+    go = go.contiguous()
+    if torch.is_grad_enabled():
+      p = softmax_rows(bgemm(q, k, False, True))
+      gv = bgemm(p, go, True, False)
+      gs = SoftmaxRowsBwdFn.apply(p, bgemm(go, v, False, True))
+      return bgemm(gs, k, False, False), bgemm(gs, q, True, False), gv
+    _chk(go)
+    n, ln, dk = q.shape
+    dv = v.shape[2]
+    qt, kt, got = transpose16(q), transpose16(k), transpose16(go)
+    gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    dvec = torch.empty_like(lse)
+    call('tg_flash_attention_bwd', _p(q), _p(k), _p(v), _p(qt), _p(kt), _p(go), _p(got), _p(o), _p(lse), _p(dvec), _p(gq),
+         _p(gk), _p(gv), n, ln, dk, dv, _dt(q), _stream(),
+         work=('flash_bwd:len%d:dk%d:dv%d:n%d' % (ln, dk, dv, n), 2 * n * ln * ln * (3 * dk + 3 * dv), _nb(q, k, v, o, go, gq, gk, gv)))
+    return gq, gk, gv
+
+
+def flash_attention(q, k, v):
+  return FlashAttnFn.apply(q.contiguous(), k.contiguous(), v.contiguous())
 
 
 def softmax_rows(s):

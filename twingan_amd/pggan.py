@@ -78,7 +78,8 @@ def self_attention_layer(P, sc, layer, domain, cfg, is_discriminator, cond=None)
   positions, beta = softmax(s), o = beta h, y = sa_gamma * o + layer.  The two batched matrix products are the MFMA
   batched GEMM of csrc/attention.hip, softmax / tanh / the sa_gamma scale its row and pointwise kernels; every op's
   backward is made of the same ops, so the layer is differentiable twice on them (the discriminator sits under the
-  gradient penalty)."""
+  gradient penalty).  First-order passes at supported shapes run the three map ops as the flash kernels of
+  csrc/flash.hip (ops.flash_attention), which never write the [h*w, h*w] map."""
   n, hh, ww, c = layer.shape
   outs = []
   for nm in ('sa_f', 'sa_g', 'sa_h'):
@@ -91,9 +92,13 @@ def self_attention_layer(P, sc, layer, domain, cfg, is_discriminator, cond=None)
     outs.append(ops.tanh(y) if nm != 'sa_h' else y)
   f, g, h = outs
   npos = hh * ww
-  s = ops.bgemm(f.reshape(n, npos, -1), g.reshape(n, npos, -1), False, True)      # tf.matmul(f, g, transpose_b=True)
-  beta = ops.softmax_rows(s)
-  o = ops.bgemm(beta, h.reshape(n, npos, c), False, False).reshape(layer.shape)
+  f, g, h = f.reshape(n, npos, -1), g.reshape(n, npos, -1), h.reshape(n, npos, c)
+  if ops.USE_FLASH_ATTENTION and ops.flash_attention_trainable(f, h):
+    o = ops.flash_attention(f, g, h).reshape(layer.shape)      # the same three ops without the [npos, npos] map in HBM
+  else:
+    s = ops.bgemm(f, g, False, True)                           # tf.matmul(f, g, transpose_b=True)
+    beta = ops.softmax_rows(s)
+    o = ops.bgemm(beta, h, False, False).reshape(layer.shape)
   return ops.add(ops.scale_dev(o, P[sc + '/sa_gamma']), layer)
 
 

@@ -283,7 +283,8 @@ def _d_domain_gp(P, cfg, terms, d, top, real, prime, a, noise=None, name=None):
     interp = ops.dragan_interpolates(real, noise.contiguous(), a).requires_grad_(True)
   else:
     interp = ops.sample_lerp(real, prime, a).requires_grad_(True)             # image_generation.py:420-424
-  pi, _ = pggan.discriminator(P, interp, cfg, top)
+  with ops.second_order():
+    pi, _ = pggan.discriminator(P, interp, cfg, top)
   ones = ops.fill(pi.shape, 1.0, pi.dtype, pi.device)
   with ops.no_param_grads():        # only d pred / d interp is needed here; parameters get theirs via the double backward
     gi, = torch.autograd.grad(pi, interp, grad_outputs=ones, create_graph=True)  # tf.gradients(pred, interp)
