@@ -389,19 +389,22 @@ int tg_spectral_norm_bwd(const float* g_wbar, const float* w, const float* u, co
 /* SAGAN self-attention (libs/self_attention.py:24-70: s = tf.matmul(f, g, transpose_b=True) over the h*w positions,
  * beta = tf.nn.softmax(s), o = tf.matmul(beta, h)) without materialising the [len x len] map: q = f [n, len, dk],
  * k = g [n, len, dk], v = h [n, len, dv], o [n, len, dv]; 16-bit storage, fp32 softmax statistics and accumulation.
- * The kernels read the value-side operands through TRANSPOSED copies ([n, d, len]: tg_transpose16 of the [n, len, d]
- * tensors).  tg_flash_attention_supported: len % 128 == 0, dk in {8, 16}, dv in {64, 128, 256}.
- * fwd: v_t = V^T; writes o and lse [n, len] fp32 (log-sum-exp of every query's scores, saved for the backward).
+ * The kernels fetch their per-tile MFMA operands from fragment-ordered copies of v / d_o (and transposes of q / k) that
+ * the entry points build themselves in `workspace` (tg_flash_attention_workspace_bytes(n, len, dk, dv, backward) bytes of
+ * device memory, 256-byte aligned, contents undefined afterwards; 0 = unsupported shape).
+ * tg_flash_attention_supported: len % 128 == 0, dk in {8, 16}, dv in {64, 128, 256}.
+ * fwd: writes o and lse [n, len] fp32 (log-sum-exp of every query's scores, saved for the backward).
  * bwd (first order; the gradient-penalty double backward keeps the tg_batched_gemm / tg_softmax_rows composition):
- * given d_o, o, lse and the transposed copies q_t, k_t [n, dk, len], d_o_t [n, dv, len] writes dq, dk_out [n, len, dk]
- * and dv_out [n, len, dv]; dvec [n, len] fp32 is scratch (rowsum(d_o * o)); dv in {64, 128}. */
+ * given d_o, o, lse writes dq, dk_out [n, len, dk] and dv_out [n, len, dv]; dv in {64, 128}.
+ * tg_transpose16: [batch, rows, cols] -> [batch, cols, rows] of 16-bit elements. */
 int tg_transpose16(const void* src, void* dst, int batch, int rows, int cols, void* stream);
 int tg_flash_attention_supported(int len, int dk, int dv);
-int tg_flash_attention_fwd(const void* q, const void* k, const void* v_t, void* o, float* lse, int n, int len, int dk, int dv,
-                           int dtype, void* stream);
-int tg_flash_attention_bwd(const void* q, const void* k, const void* v, const void* q_t, const void* k_t, const void* d_o,
-                           const void* d_o_t, const void* o, const float* lse, float* dvec, void* dq, void* dk_out, void* dv_out,
-                           int n, int len, int dk, int dv, int dtype, void* stream);
+int64_t tg_flash_attention_workspace_bytes(int n, int len, int dk, int dv, int backward);
+int tg_flash_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, void* workspace, int n, int len,
+                           int dk, int dv, int dtype, void* stream);
+int tg_flash_attention_bwd(const void* q, const void* k, const void* v, const void* d_o, const void* o, const float* lse,
+                           void* workspace, void* dq, void* dk_out, void* dv_out, int n, int len, int dk, int dv, int dtype,
+                           void* stream);
 
 /* Gradient all-reduce for callers without torch.distributed (the reference sums its clones' gradients in one process,
  * deployment/model_deploy.py:473-503; with one process per GPU that sum is a sum all-reduce over xGMI): a thin wrapper

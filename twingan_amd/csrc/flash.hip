@@ -9,9 +9,15 @@
 //   dK / dV kernel: a wave owns 32 keys, S = Q K^T tile per 32-query block, the per-query quantities (log-sum-exp, D)
 //     are per accumulator ROW there and are read as broadcast loads.
 // P (or dS) goes back into the next MFMA as the B operand after packing to 16 bit and the v_permlane32_swap of the conv
-// epilogues: afterwards a lane of half kgrp holds 8 + 8 consecutive reduction indices (16 kgrp + 0..7 and + 8..15),
-// which is the order the A operands (V^T, K^T, Q^T, dO^T rows from TRANSPOSED copies, 16-byte loads) are fetched in.
-// Operands come straight from L2 (every workgroup of an image re-reads the same K / V: 0.5 MB per image), no LDS.
+// epilogues: afterwards a lane of half kgrp holds 8 + 8 consecutive reduction indices (16 kgrp + 0..7 and + 8..15).
+//
+// Operand layout.  An MFMA A operand puts matrix ROWS on the lanes, so fetching it from a row-major tensor touches 32
+// (or, for a transposed operand, 64) different cache lines per 1-KB wave load and the texture path, not the MFMA pipe,
+// sets the pace (first version: 12 % MFMA utilisation).  The per-tile operands (V / dO as "rows x features" fragments,
+// V^T / dO^T as "features x positions" fragments) are therefore re-packed once per call into FRAGMENT ORDER -- the 64
+// lanes' 16-byte pieces of one fragment contiguous -- by two small kernels into a caller-provided workspace; every
+// in-loop load is then one fully coalesced 1-KB read.  Q / K rows are 16 (32) bytes, already dense.  No LDS: the four
+// waves of a workgroup read the same fragments through L1.
 //
 // MFMA layouts used (as in conv_tile.hip): A lane = row l%32, k = 8 (l/32) + i; B lane = column l%32, k = 8 (l/32) + i;
 // D lane = column l%32, register r = row 8 (r/4) + 4 (l/32) + r%4.
@@ -31,13 +37,19 @@ __device__ __forceinline__ bf16x8 zero_frag() {
   return __builtin_bit_cast(bf16x8, z);
 }
 __device__ __forceinline__ bf16x8 load_frag(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
-
-// rows [row0, row0 + 32) x features [8 kgrp, 8 kgrp + 8) of a [len][dk] matrix: an A (or B) fragment with the feature
-// axis as K; feature slots >= dk are zero (d_qk = 8: the upper half-wave)
-__device__ __forceinline__ bf16x8 feat_frag(const bf16* m, int row, int dk, int kgrp) {
-  return 8 * kgrp < dk ? load_frag(m + (size_t)row * dk + 8 * kgrp) : zero_frag();
+template <bool F16>
+__device__ __forceinline__ bf16x8 ones_frag() {
+  u32x4 z;
+  z[0] = z[1] = z[2] = z[3] = ones16x2<F16>();
+  return __builtin_bit_cast(bf16x8, z);
 }
+// exp(x - m) as ONE fma + v_exp_f32: exp2(x * log2(e) - m * log2(e)); callers keep m pre-multiplied ("m2")
+constexpr float kLog2e = 1.4426950408889634f;
+__device__ __forceinline__ float exp2_sub(float x, float m2) { return __builtin_amdgcn_exp2f(fmaf(x, kLog2e, -m2)); }
 
+// Every in-loop operand is one 16-byte load per lane at (uniform tile base) + (constant lane offset): Q / K rows come
+// from copies zero-padded to 16 features ([len][16]; the tensors themselves when d_qk = 16), Q^T / K^T from "columns"
+// packings zero-padded to 32 feature rows, so the zero slots of the padded MFMA operands are read, not selected.
 // 16 accumulator values of one lane (rows 8q + 4 kgrp + j) -> the two B fragments of the next MFMA's two K steps:
 // step 0 = reduction indices 16 kgrp + 0..7, step 1 = 16 kgrp + 8..15 (see the header)
 template <bool F16>
@@ -72,63 +84,138 @@ __device__ __forceinline__ void store_block(bf16* dst, int kgrp, const float (&v
   *reinterpret_cast<bf16x8*>(dst + 16 * kgrp + 8) = b[1];
 }
 
+
+// fragment-order copies -----------------------------------------------------------------------------------------------
+// "rows" packing of x [rows_total][d]: fragment (rb, t) = rows 32 rb .. + 32 x features 16 t .. + 16 as an A (or B)
+// operand with the FEATURE axis as K: dst[((rb * (d / 16) + t) * 64 + lane) * 8 + i] = x[32 rb + lane % 32][16 t + 8 (lane / 32) + i]
+__global__ __launch_bounds__(256) void pack_rows_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int d,
+                                                        int64_t vecs) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v >= vecs) return;
+  const int lane = (int)(v & 63), per = d >> 4;
+  const int64_t frag = v >> 6, rb = frag / per;
+  const int t = (int)(frag - rb * per);
+  *reinterpret_cast<bf16x8*>(dst + v * 8) = load_frag(src + (rb * 32 + (lane & 31)) * d + 16 * t + 8 * (lane >> 5));
+}
+
+// "columns" packing of x [n][len][d]: fragment (img, db, pb, st) = features 32 db .. + 32 x positions of block pb as an A
+// operand with the POSITION axis as K, in the order acc_to_b emits the matching B operand:
+// dst[((((img * ndb + db) * (len / 32) + pb) * 2 + st) * 64 + lane) * 8 + i] = x[img][32 pb + 16 (lane / 32) + 8 st + i][32 db + lane % 32]
+// with ndb = ceil(d / 32) and zeros for the feature rows >= d
+__global__ __launch_bounds__(256) void pack_cols_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst,
+                                                        int len, int d, int64_t vecs) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v >= vecs) return;
+  const int lane = (int)(v & 63), st = (int)((v >> 6) & 1);
+  int64_t r = v >> 7;
+  const int nb = len >> 5, ndb = (d + 31) >> 5;
+  const int pb = (int)(r % nb);
+  r /= nb;
+  const int db = (int)(r % ndb);
+  const int64_t img = r / ndb;
+  const int col = 32 * db + (lane & 31);
+  typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+  u16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = 0;
+  if (col < d) {
+    const unsigned short* s0 = src + (img * len + 32 * pb + 16 * (lane >> 5) + 8 * st) * d + col;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = s0[(int64_t)i * d];
+  }
+  *reinterpret_cast<u16x8*>(dst + v * 8) = o;
+}
+
+// x [rows][8] -> [rows][16] with zeros in features 8..15 (the K padding of the score MFMAs for d_qk = 8)
+__global__ __launch_bounds__(256) void pad16_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int64_t rows) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one 16-byte half row of dst
+  if (v >= 2 * rows) return;
+  *reinterpret_cast<bf16x8*>(dst + v * 8) = (v & 1) ? zero_frag() : load_frag(src + (v >> 1) * 8);
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward: O[i] = sum_j softmax_j(q_i . k_j) v_j,  lse[i] = log sum_j exp(q_i . k_j)
-// grid = (len / 128, n); 4 waves x 32 queries.  vt = V^T [n][dv][len].
+// grid = (len / 128, n); 4 waves x 32 queries.  vpc = "columns" packing of V.
 // ------------------------------------------------------------------------------------------------
+template <int DVB>
+struct FwdTile {
+  bf16x8 kf, vf[DVB][2];
+};
+
+// The running maximum is allowed to go STALE by up to kStaleMax (natural-log units): the accumulators are rescaled only
+// when a block's maximum exceeds it by more than that (a wave-uniform branch, taken a handful of times per query), so
+// the probabilities are bounded by e^kStaleMax instead of 1 -- harmless in fp32 sums and in 16-bit P.  The row sums come
+// from the MFMA unit too (an all-ones A operand against the same packed P), i.e. they are sums of the ROUNDED
+// probabilities the numerator uses.
+constexpr float kStaleMax = 6.f;
+
 template <int DVB, bool F16>
-__global__ __launch_bounds__(256) void flash_fwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
-                                                        const bf16* __restrict__ vt, bf16* __restrict__ o,
+__global__ __launch_bounds__(256) void flash_fwd_kernel(const bf16* __restrict__ q16, const bf16* __restrict__ k16,
+                                                        const bf16* __restrict__ vpc, bf16* __restrict__ o,
                                                         float* __restrict__ lse, const FlashGeom g) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, kgrp = lane >> 5, l31 = lane & 31;
-  const int img = blockIdx.y;
+  const int img = blockIdx.y, nb = g.len >> 5;
   const int q0 = (blockIdx.x * 4 + wid) * 32;
-  const bf16* qi = q + (size_t)img * g.len * g.dk;
-  const bf16* ki = k + (size_t)img * g.len * g.dk;
-  const bf16* vti = vt + (size_t)img * g.dv * g.len;
-  const bf16x8 qf = feat_frag(qi, q0 + l31, g.dk, kgrp);      // B operand of S^T, constant over the loop
-  f32x16 acc[DVB];
+  const unsigned lfeat = l31 * 16 + 8 * kgrp, lfrag = lane * 8;      // lane offsets: a [32][16] row block, a 1-KB fragment
+  const bf16* ki = k16 + (size_t)img * g.len * 16;                   // uniform bases
+  const bf16* vi = vpc + (size_t)img * g.dv * g.len;
+  const bf16x8 qf = load_frag(q16 + ((size_t)img * g.len + q0) * 16 + lfeat);      // B operand of S^T, constant over the loop
+  const bf16x8 ones = ones_frag<F16>();
+  f32x16 acc[DVB], lacc, zero;
 #pragma unroll
-  for (int d = 0; d < DVB; ++d)
+  for (int r = 0; r < 16; ++r) zero[r] = lacc[r] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-  f32x16 zero;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-  for (int k0 = 0; k0 < g.len; k0 += 32) {
-    const bf16x8 kf = feat_frag(ki, k0 + l31, g.dk, kgrp);
-    bf16x8 vf[DVB][2];
+  for (int d = 0; d < DVB; ++d) acc[d] = zero;
+  float m_run = -INFINITY, m2 = -INFINITY;      // the (stale) maximum and the same times log2(e)
+  // operand schedule: the S^T operand of the NEXT block and this block's V^T fragments (needed only after the
+  // softmax arithmetic) are requested at the top of a block, pinned there by the scheduling barrier
+  // (two blocks per loop trip, the one-ahead registers ping-ponging between kf_a and kf_b: no copies)
+  bf16x8 kf_a = load_frag(ki + lfeat), kf_b;
+  auto tile = [&](int kb, const bf16x8& kf_cur, bf16x8& kf_next) {
+    FwdTile<DVB> t;
+    kf_next = load_frag(ki + (size_t)(kb + 1 < nb ? kb + 1 : kb) * 512 + lfeat);
+    t.kf = kf_cur;
 #pragma unroll
     for (int d = 0; d < DVB; ++d)
 #pragma unroll
-      for (int st = 0; st < 2; ++st) vf[d][st] = load_frag(vti + (size_t)(32 * d + l31) * g.len + k0 + 16 * kgrp + 8 * st);
-    const f32x16 s = mfma_32x32x16<F16>(kf, qf, zero);      // S^T[key][query]
+      for (int st = 0; st < 2; ++st) t.vf[d][st] = load_frag(vi + (((size_t)d * nb + kb) * 2 + st) * 512 + lfrag);
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x16 s = mfma_32x32x16<F16>(t.kf, qf, zero);      // S^T[key][query]
     float mx = s[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float corr = __expf(m_run - m_new);      // exp(-inf) = 0 on the first block
-    float p[16], ps = 0.f;
+    const bool raise = mx > m_run + kStaleMax;      // always on the first block (m_run = -inf)
+    if (__any(raise)) {
+      const float m_new = raise ? mx : m_run;
+      const float corr = m_run == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      p[r] = __expf(s[r] - m_new);
-      ps += p[r];
+      for (int d = 0; d < DVB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[d][r] *= corr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lacc[r] *= corr;
+      m_run = m_new;
+      m2 = m_new * kLog2e;
     }
-    ps += __shfl_xor(ps, 32, 64);
-    l_run = l_run * corr + ps;
-    m_run = m_new;
+    float p[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = exp2_sub(s[r], m2);
     bf16x8 pb[2];
     acc_to_b<F16>(p, pb);
+    lacc = mfma_32x32x16<F16>(ones, pb[0], lacc);      // every row: sum_j P[j][query]
+    lacc = mfma_32x32x16<F16>(ones, pb[1], lacc);
 #pragma unroll
     for (int d = 0; d < DVB; ++d) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[d][r] *= corr;
-      acc[d] = mfma_32x32x16<F16>(vf[d][0], pb[0], acc[d]);
-      acc[d] = mfma_32x32x16<F16>(vf[d][1], pb[1], acc[d]);
+      acc[d] = mfma_32x32x16<F16>(t.vf[d][0], pb[0], acc[d]);
+      acc[d] = mfma_32x32x16<F16>(t.vf[d][1], pb[1], acc[d]);
     }
+  };
+  for (int kb = 0; kb < nb; kb += 2) {      // len % 128 == 0: an even number of blocks
+    tile(kb, kf_a, kf_b);
+    tile(kb + 1, kf_b, kf_a);
   }
+  const float l_run = lacc[0];
   const float inv = 1.f / l_run;
   bf16* orow = o + ((size_t)img * g.len + q0 + l31) * g.dv;
 #pragma unroll
@@ -141,10 +228,11 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const bf16* __restrict__
   if (kgrp == 0) lse[(size_t)img * g.len + q0 + l31] = m_run + __logf(l_run);
 }
 
-// dvec[i] = sum_d dO[i][d] * O[i][d]  (= rowsum(dP o P), the softmax backward's correction term); one thread per row
+// dvec[i] = sum_d dO[i][d] * O[i][d]  (= rowsum(dP o P), the softmax backward's correction term) and lse2[i] = lse[i] *
+// log2(e) (the backward's exp2 form); one thread per row
 template <typename E>
-__global__ void flash_rowdot_kernel(const E* __restrict__ d_o, const E* __restrict__ o, float* __restrict__ dvec,
-                                    int64_t rows, int dv) {
+__global__ void flash_rowdot_kernel(const E* __restrict__ d_o, const E* __restrict__ o, const float* __restrict__ lse,
+                                    float* __restrict__ dvec, float* __restrict__ lse2, int64_t rows, int dv) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows) return;
   float a = 0.f;
@@ -154,6 +242,7 @@ __global__ void flash_rowdot_kernel(const E* __restrict__ d_o, const E* __restri
     for (int j = 0; j < 8; ++j) a = fmaf(x.get(j), y.get(j), a);
   }
   dvec[i] = a;
+  lse2[i] = lse[i] * kLog2e;
 }
 
 // stores rows [0, dk) of a transposed accumulator (row = 8 (r / 4) + 4 kgrp + r % 4, column = the lane's position) as
@@ -174,76 +263,103 @@ __device__ __forceinline__ void store_feat(bf16* dst, int dk, int kgrp, const f3
 
 // ------------------------------------------------------------------------------------------------
 // backward, queries on the lanes: dQ[i] = sum_j dS[i][j] k_j with dS = P o (dO V^T - D), P = exp(S - lse)
-// kt = K^T [n][dk][len]
+// vpr = "rows" packing of V, kt = K^T [n][dk][len]
 // ------------------------------------------------------------------------------------------------
+template <int KT>
+struct BwdQTile {
+  bf16x8 kf, vf[KT], ktf[2];
+};
+
 template <int DVB, bool F16>
-__global__ __launch_bounds__(256) void flash_bwd_q_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
-                                                          const bf16* __restrict__ v, const bf16* __restrict__ kt,
-                                                          const bf16* __restrict__ d_o, const float* __restrict__ lse,
+__global__ __launch_bounds__(256) void flash_bwd_q_kernel(const bf16* __restrict__ q16, const bf16* __restrict__ k16,
+                                                          const bf16* __restrict__ vpr, const bf16* __restrict__ kpc,
+                                                          const bf16* __restrict__ d_o, const float* __restrict__ lse2,
                                                           const float* __restrict__ dvec, bf16* __restrict__ dq,
                                                           const FlashGeom g) {
   constexpr int KT = DVB * 2;      // K steps over d_v
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, kgrp = lane >> 5, l31 = lane & 31;
-  const int img = blockIdx.y;
+  const int img = blockIdx.y, nb = g.len >> 5;
   const int q0 = (blockIdx.x * 4 + wid) * 32;
   const size_t row = (size_t)img * g.len + q0 + l31;
-  const bf16* ki = k + (size_t)img * g.len * g.dk;
-  const bf16* vi = v + (size_t)img * g.len * g.dv;
-  const bf16* kti = kt + (size_t)img * g.dk * g.len;
-  const bf16x8 qf = feat_frag(q + (size_t)img * g.len * g.dk, q0 + l31, g.dk, kgrp);
-  const float lse_q = lse[row], d_q = dvec[row];
+  const unsigned lfeat = l31 * 16 + 8 * kgrp, lfrag = lane * 8;
+  const bf16* ki = k16 + (size_t)img * g.len * 16;
+  const bf16* vi = vpr + (size_t)img * g.len * g.dv;
+  const bf16* kci = kpc + (size_t)img * g.len * 32;      // K^T fragments: [len / 32][2] of 1 KB
+  const bf16x8 qf = load_frag(q16 + ((size_t)img * g.len + q0) * 16 + lfeat);
+  const float lse_q = lse2[row], d_q = dvec[row];
   bf16x8 dof[KT];      // B operand of dP^T = V dO^T: dO[query][16 t + 8 kgrp + i]
 #pragma unroll
   for (int t = 0; t < KT; ++t) dof[t] = load_frag(d_o + row * g.dv + 16 * t + 8 * kgrp);
   f32x16 zero, acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) zero[r] = acc[r] = 0.f;
-  for (int k0 = 0; k0 < g.len; k0 += 32) {
-    const bf16x8 kf = feat_frag(ki, k0 + l31, g.dk, kgrp);
-    bf16x8 vf[KT], ktf[2];
+  // operand schedule as in the forward: S^T / dP^T operands one block ahead, the K^T fragments of this block at its top
+  struct Early {
+    bf16x8 kf, vf[KT];
+  } ea, eb;
+  auto load_early = [&](Early& e, int kb) {
+    e.kf = load_frag(ki + (size_t)kb * 512 + lfeat);
 #pragma unroll
-    for (int t = 0; t < KT; ++t) vf[t] = load_frag(vi + (size_t)(k0 + l31) * g.dv + 16 * t + 8 * kgrp);
+    for (int c = 0; c < KT; ++c) e.vf[c] = load_frag(vi + ((size_t)kb * KT + c) * 512 + lfrag);
+  };
+  load_early(ea, 0);
+  auto tile = [&](int kb, const Early& cur, Early& next) {
+    BwdQTile<KT> t;
+    load_early(next, kb + 1 < nb ? kb + 1 : kb);
+    t.kf = cur.kf;
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
-      ktf[st] = l31 < g.dk ? load_frag(kti + (size_t)l31 * g.len + k0 + 16 * kgrp + 8 * st) : zero_frag();
-    const f32x16 s = mfma_32x32x16<F16>(kf, qf, zero);      // S^T[key][query]
-    f32x16 dp = zero;                                       // dP^T[key][query]
+    for (int c = 0; c < KT; ++c) t.vf[c] = cur.vf[c];
 #pragma unroll
-    for (int t = 0; t < KT; ++t) dp = mfma_32x32x16<F16>(vf[t], dof[t], dp);
+    for (int st = 0; st < 2; ++st) t.ktf[st] = load_frag(kci + ((size_t)kb * 2 + st) * 512 + lfrag);
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x16 s = mfma_32x32x16<F16>(t.kf, qf, zero);      // S^T[key][query]
+    f32x16 dp = zero;                                         // dP^T[key][query]
+#pragma unroll
+    for (int c = 0; c < KT; ++c) dp = mfma_32x32x16<F16>(t.vf[c], dof[c], dp);
     float ds[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ds[r] = __expf(s[r] - lse_q) * (dp[r] - d_q);
+    for (int r = 0; r < 16; ++r) ds[r] = exp2_sub(s[r], lse_q) * (dp[r] - d_q);
     bf16x8 dsb[2];
     acc_to_b<F16>(ds, dsb);
-    acc = mfma_32x32x16<F16>(ktf[0], dsb[0], acc);          // dQ^T[d_qk][query]
-    acc = mfma_32x32x16<F16>(ktf[1], dsb[1], acc);
+    acc = mfma_32x32x16<F16>(t.ktf[0], dsb[0], acc);          // dQ^T[d_qk][query]
+    acc = mfma_32x32x16<F16>(t.ktf[1], dsb[1], acc);
+  };
+  for (int kb = 0; kb < nb; kb += 2) {
+    tile(kb, ea, eb);
+    tile(kb + 1, eb, ea);
   }
   store_feat<F16>(dq + row * g.dk, g.dk, kgrp, acc);
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward, keys on the lanes: dV[j] = sum_i P[i][j] dO_i,  dK[j] = sum_i dS[i][j] q_i
-// qt = Q^T [n][dk][len], dot = dO^T [n][dv][len]
+// qt = Q^T [n][dk][len]; dopr / dopc = "rows" / "columns" packings of dO
 // ------------------------------------------------------------------------------------------------
+template <int DVB>
+struct BwdKvTile {
+  bf16x8 qfa, dofa[2 * DVB], dotf[DVB][2], qtf[2];
+};
+
 template <int DVB, bool F16>
-__global__ __launch_bounds__(256) void flash_bwd_kv_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
-                                                           const bf16* __restrict__ v, const bf16* __restrict__ qt,
-                                                           const bf16* __restrict__ d_o, const bf16* __restrict__ dot,
-                                                           const float* __restrict__ lse, const float* __restrict__ dvec,
+__global__ __launch_bounds__(256) void flash_bwd_kv_kernel(const bf16* __restrict__ q16, const bf16* __restrict__ k16,
+                                                           const bf16* __restrict__ v, const bf16* __restrict__ qpc,
+                                                           const bf16* __restrict__ dopr, const bf16* __restrict__ dopc,
+                                                           const float* __restrict__ lse2, const float* __restrict__ dvec,
                                                            bf16* __restrict__ dk_out, bf16* __restrict__ dv_out,
                                                            const FlashGeom g) {
   constexpr int KT = DVB * 2;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, kgrp = lane >> 5, l31 = lane & 31;
-  const int img = blockIdx.y;
+  const int img = blockIdx.y, nb = g.len >> 5;
   const int key0 = (blockIdx.x * 4 + wid) * 32;
   const size_t krow = (size_t)img * g.len + key0 + l31;
-  const bf16* qi = q + (size_t)img * g.len * g.dk;
-  const bf16* doi = d_o + (size_t)img * g.len * g.dv;
-  const bf16* qti = qt + (size_t)img * g.dk * g.len;
-  const bf16* doti = dot + (size_t)img * g.dv * g.len;
-  const float* lsei = lse + (size_t)img * g.len;
-  const float* dvi = dvec + (size_t)img * g.len;
-  const bf16x8 kfb = feat_frag(k + (size_t)img * g.len * g.dk, key0 + l31, g.dk, kgrp);      // B of S = Q K^T
+  const unsigned lfeat = l31 * 16 + 8 * kgrp, lfrag = lane * 8;
+  const bf16* qi = q16 + (size_t)img * g.len * 16;
+  const bf16* dri = dopr + (size_t)img * g.len * g.dv;
+  const bf16* dci = dopc + (size_t)img * g.len * g.dv;
+  const bf16* qci = qpc + (size_t)img * g.len * 32;      // Q^T fragments
+  const float* lsei = lse2 + (size_t)img * g.len + 4 * kgrp;
+  const float* dvi = dvec + (size_t)img * g.len + 4 * kgrp;
+  const bf16x8 kfb = load_frag(k16 + ((size_t)img * g.len + key0) * 16 + lfeat);      // B of S = Q K^T
   bf16x8 vfb[KT];                                                                           // B of dP = dO V^T
 #pragma unroll
   for (int t = 0; t < KT; ++t) vfb[t] = load_frag(v + krow * g.dv + 16 * t + 8 * kgrp);
@@ -252,45 +368,61 @@ __global__ __launch_bounds__(256) void flash_bwd_kv_kernel(const bf16* __restric
   for (int r = 0; r < 16; ++r) zero[r] = acck[r] = 0.f;
 #pragma unroll
   for (int d = 0; d < DVB; ++d) accv[d] = zero;
-  for (int q0 = 0; q0 < g.len; q0 += 32) {
-    const bf16x8 qfa = feat_frag(qi, q0 + l31, g.dk, kgrp);      // A of S: rows = queries
-    bf16x8 dofa[KT], dotf[DVB][2], qtf[2];
+  // operand schedule: S / dP operands (Q rows, dO "rows" fragments) one block ahead; the dO^T / Q^T fragments, needed
+  // after the exponentials, at the top of their own block
+  struct Early {
+    bf16x8 qfa, dofa[KT];
+  } ea, eb;
+  auto load_early = [&](Early& e, int qb) {
+    e.qfa = load_frag(qi + (size_t)qb * 512 + lfeat);      // A of S: rows = queries
 #pragma unroll
-    for (int t = 0; t < KT; ++t) dofa[t] = load_frag(doi + (size_t)(q0 + l31) * g.dv + 16 * t + 8 * kgrp);
+    for (int c = 0; c < KT; ++c) e.dofa[c] = load_frag(dri + ((size_t)qb * KT + c) * 512 + lfrag);
+  };
+  load_early(ea, 0);
+  auto tile = [&](int qb, const Early& cur, Early& next) {
+    BwdKvTile<DVB> t;
+    load_early(next, qb + 1 < nb ? qb + 1 : qb);
+    t.qfa = cur.qfa;
+#pragma unroll
+    for (int c = 0; c < KT; ++c) t.dofa[c] = cur.dofa[c];
 #pragma unroll
     for (int d = 0; d < DVB; ++d)
 #pragma unroll
-      for (int st = 0; st < 2; ++st) dotf[d][st] = load_frag(doti + (size_t)(32 * d + l31) * g.len + q0 + 16 * kgrp + 8 * st);
+      for (int st = 0; st < 2; ++st) t.dotf[d][st] = load_frag(dci + (((size_t)d * nb + qb) * 2 + st) * 512 + lfrag);
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
-      qtf[st] = l31 < g.dk ? load_frag(qti + (size_t)l31 * g.len + q0 + 16 * kgrp + 8 * st) : zero_frag();
-    float lr[16], dr[16];      // per accumulator ROW = per query of the block: the same for all lanes of a half-wave
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qi_ = q0 + 8 * (r >> 2) + 4 * kgrp + (r & 3);
-      lr[r] = lsei[qi_];
-      dr[r] = dvi[qi_];
-    }
-    const f32x16 s = mfma_32x32x16<F16>(qfa, kfb, zero);      // S[query][key]
+    for (int st = 0; st < 2; ++st) t.qtf[st] = load_frag(qci + ((size_t)qb * 2 + st) * 512 + lfrag);
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x16 s = mfma_32x32x16<F16>(t.qfa, kfb, zero);      // S[query][key]
     f32x16 dp = zero;
 #pragma unroll
-    for (int t = 0; t < KT; ++t) dp = mfma_32x32x16<F16>(dofa[t], vfb[t], dp);      // dP[query][key]
+    for (int c = 0; c < KT; ++c) dp = mfma_32x32x16<F16>(t.dofa[c], vfb[c], dp);      // dP[query][key]
+    // per accumulator ROW = per query of the block: rows 8 j + 4 kgrp + 0..3, the same for all lanes of a half-wave
     float p[16], ds[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      p[r] = __expf(s[r] - lr[r]);
-      ds[r] = p[r] * (dp[r] - dr[r]);
+    for (int j = 0; j < 4; ++j) {
+      const float4 lr = *reinterpret_cast<const float4*>(lsei + 32 * qb + 8 * j);
+      const float4 dr = *reinterpret_cast<const float4*>(dvi + 32 * qb + 8 * j);
+      const float lrv[4] = {lr.x, lr.y, lr.z, lr.w}, drv[4] = {dr.x, dr.y, dr.z, dr.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        p[4 * j + i] = exp2_sub(s[4 * j + i], lrv[i]);
+        ds[4 * j + i] = p[4 * j + i] * (dp[4 * j + i] - drv[i]);
+      }
     }
     bf16x8 pb[2], dsb[2];
     acc_to_b<F16>(p, pb);
     acc_to_b<F16>(ds, dsb);
 #pragma unroll
     for (int d = 0; d < DVB; ++d) {
-      accv[d] = mfma_32x32x16<F16>(dotf[d][0], pb[0], accv[d]);      // dV^T[d_v][key]
-      accv[d] = mfma_32x32x16<F16>(dotf[d][1], pb[1], accv[d]);
+      accv[d] = mfma_32x32x16<F16>(t.dotf[d][0], pb[0], accv[d]);      // dV^T[d_v][key]
+      accv[d] = mfma_32x32x16<F16>(t.dotf[d][1], pb[1], accv[d]);
     }
-    acck = mfma_32x32x16<F16>(qtf[0], dsb[0], acck);                   // dK^T[d_qk][key]
-    acck = mfma_32x32x16<F16>(qtf[1], dsb[1], acck);
+    acck = mfma_32x32x16<F16>(t.qtf[0], dsb[0], acck);                   // dK^T[d_qk][key]
+    acck = mfma_32x32x16<F16>(t.qtf[1], dsb[1], acck);
+  };
+  for (int qb = 0; qb < nb; qb += 2) {
+    tile(qb, ea, eb);
+    tile(qb + 1, eb, ea);
   }
 #pragma unroll
   for (int d = 0; d < DVB; ++d) {
@@ -318,12 +450,71 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const unsigned short* 
 
 }  // namespace
 
+namespace {
+
+inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct FlashWorkspace {      // offsets into the caller's workspace
+  size_t q16, k16, v_pc, v_pr, do_pr, do_pc, q_pc, k_pc, dvec, lse2, total;
+};
+
+FlashWorkspace flash_workspace(int n, int len, int dk, int dv, bool backward) {
+  const size_t big = align256((size_t)n * len * dv * 2), pad = align256((size_t)n * len * 16 * 2);
+  const size_t cols = align256((size_t)n * len * 32 * 2), vec = align256((size_t)n * len * 4);
+  FlashWorkspace w = {};
+  size_t at = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = at;
+    at += bytes;
+    return o;
+  };
+  w.q16 = take(dk == 8 ? pad : 0);      // d_qk = 16: the tensors themselves
+  w.k16 = take(dk == 8 ? pad : 0);
+  if (!backward) {
+    w.v_pc = take(big);
+  } else {
+    w.v_pr = take(big);
+    w.do_pr = take(big);
+    w.do_pc = take(big);
+    w.q_pc = take(cols);
+    w.k_pc = take(cols);
+    w.dvec = take(vec);
+    w.lse2 = take(vec);
+  }
+  w.total = at;
+  return w;
+}
+
+void launch_pack_rows(const void* src, void* dst, int64_t rows, int d, hipStream_t s) {
+  const int64_t vecs = rows * d / 8;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, s, (const bf16*)src, (bf16*)dst, d, vecs);
+}
+
+void launch_pack_cols(const void* src, void* dst, int n, int len, int d, hipStream_t s) {
+  const int64_t vecs = (int64_t)n * len * ((d + 31) / 32 * 32) / 8;
+  hipLaunchKernelGGL(pack_cols_kernel, dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, s, (const unsigned short*)src,
+                     (unsigned short*)dst, len, d, vecs);
+}
+
+// the [rows][16] form of a [rows][dk] tensor: the tensor itself for d_qk = 16, else a zero-padded copy in the workspace
+const bf16* feat16(const void* x, void* pad, int64_t rows, int dk, hipStream_t s) {
+  if (dk == 16) return (const bf16*)x;
+  hipLaunchKernelGGL(pad16_kernel, dim3((unsigned)((2 * rows + 255) / 256)), dim3(256), 0, s, (const bf16*)x, (bf16*)pad, rows);
+  return (const bf16*)pad;
+}
+
+void launch_transpose(const void* src, void* dst, int batch, int rows, int cols, hipStream_t s) {
+  hipLaunchKernelGGL(transpose16_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, batch), dim3(256), 0, s,
+                     (const unsigned short*)src, (unsigned short*)dst, rows, cols);
+}
+
+}  // namespace
+
 extern "C" {
 
 int tg_transpose16(const void* src, void* dst, int batch, int rows, int cols, void* stream) {
   TG_CHECK(src && dst && batch > 0 && rows > 0 && cols > 0, TG_EINVAL, "tg_transpose16: bad arguments");
-  hipLaunchKernelGGL(transpose16_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream,
-                     (const unsigned short*)src, (unsigned short*)dst, rows, cols);
+  launch_transpose(src, dst, batch, rows, cols, (hipStream_t)stream);
   TG_LAUNCH_CHECK("tg_transpose16");
   return TG_OK;
 }
@@ -332,9 +523,14 @@ int tg_flash_attention_supported(int len, int dk, int dv) {
   return (len % 128 == 0 && (dk == 8 || dk == 16) && (dv == 64 || dv == 128 || dv == 256)) ? 1 : 0;
 }
 
-int tg_flash_attention_fwd(const void* q, const void* k, const void* v_t, void* o, float* lse, int n, int len, int dk, int dv,
-                           int dtype, void* stream) {
-  TG_CHECK(q && k && v_t && o && lse && n > 0, TG_EINVAL, "tg_flash_attention_fwd: bad arguments");
+int64_t tg_flash_attention_workspace_bytes(int n, int len, int dk, int dv, int backward) {
+  if (n <= 0 || !tg_flash_attention_supported(len, dk, dv)) return 0;
+  return (int64_t)flash_workspace(n, len, dk, dv, backward != 0).total;
+}
+
+int tg_flash_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, void* workspace, int n, int len,
+                           int dk, int dv, int dtype, void* stream) {
+  TG_CHECK(q && k && v && o && lse && workspace && n > 0, TG_EINVAL, "tg_flash_attention_fwd: bad arguments");
   TG_CHECK(tg_flash_attention_supported(len, dk, dv), TG_ENOSUP,
            "tg_flash_attention_fwd: len %% 128 == 0, d_qk in {8, 16}, d_v in {64, 128, 256} (got %d, %d, %d)", len, dk, dv);
   TG_CHECK(dtype == TG_BF16 || dtype == TG_F16, TG_ENOSUP, "tg_flash_attention_fwd: 16-bit storage only");
@@ -342,27 +538,33 @@ int tg_flash_attention_fwd(const void* q, const void* k, const void* v_t, void* 
   g.n = n; g.len = len; g.dk = dk; g.dv = dv;
   const dim3 grid(len / 128, n);
   hipStream_t s = (hipStream_t)stream;
-#define TG_FL(DVB_)                                                                                                    \
-  do {                                                                                                                 \
-    if (dtype == TG_F16)                                                                                               \
-      hipLaunchKernelGGL((flash_fwd_kernel<DVB_, true>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k,         \
-                         (const bf16*)v_t, (bf16*)o, lse, g);                                                           \
-    else                                                                                                               \
-      hipLaunchKernelGGL((flash_fwd_kernel<DVB_, false>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k,        \
-                         (const bf16*)v_t, (bf16*)o, lse, g);                                                           \
+  const FlashWorkspace w = flash_workspace(n, len, dk, dv, false);
+  char* ws = (char*)workspace;
+  const int64_t rows = (int64_t)n * len;
+  const bf16 *q16 = feat16(q, ws + w.q16, rows, dk, s), *k16 = feat16(k, ws + w.k16, rows, dk, s);
+  launch_pack_cols(v, ws + w.v_pc, n, len, dv, s);
+  const bool f16 = dtype == TG_F16;
+#define TG_FL(DVB_, F16_)                                                                                               \
+  hipLaunchKernelGGL((flash_fwd_kernel<DVB_, F16_>), grid, dim3(256), 0, s, q16, k16, (const bf16*)(ws + w.v_pc), (bf16*)o, \
+                     lse, g)
+#define TG_FL2(DVB_)                                                                                                    \
+  do {                                                                                                                  \
+    if (f16) TG_FL(DVB_, true);                                                                                         \
+    else TG_FL(DVB_, false);                                                                                            \
   } while (0)
-  if (dv == 64) TG_FL(2);
-  else if (dv == 128) TG_FL(4);
-  else TG_FL(8);
+  if (dv == 64) TG_FL2(2);
+  else if (dv == 128) TG_FL2(4);
+  else TG_FL2(8);
+#undef TG_FL2
 #undef TG_FL
   TG_LAUNCH_CHECK("tg_flash_attention_fwd");
   return TG_OK;
 }
 
-int tg_flash_attention_bwd(const void* q, const void* k, const void* v, const void* q_t, const void* k_t, const void* d_o,
-                           const void* d_o_t, const void* o, const float* lse, float* dvec, void* dq, void* dk_out, void* dv_out,
-                           int n, int len, int dk, int dv, int dtype, void* stream) {
-  TG_CHECK(q && k && v && q_t && k_t && d_o && d_o_t && o && lse && dvec && dq && dk_out && dv_out && n > 0, TG_EINVAL,
+int tg_flash_attention_bwd(const void* q, const void* k, const void* v, const void* d_o, const void* o, const float* lse,
+                           void* workspace, void* dq, void* dk_out, void* dv_out, int n, int len, int dk, int dv, int dtype,
+                           void* stream) {
+  TG_CHECK(q && k && v && d_o && o && lse && workspace && dq && dk_out && dv_out && n > 0, TG_EINVAL,
            "tg_flash_attention_bwd: bad arguments");
   TG_CHECK(tg_flash_attention_supported(len, dk, dv) && dv <= 128, TG_ENOSUP,
            "tg_flash_attention_bwd: len %% 128 == 0, d_qk in {8, 16}, d_v in {64, 128} (got %d, %d, %d)", len, dk, dv);
@@ -370,26 +572,41 @@ int tg_flash_attention_bwd(const void* q, const void* k, const void* v, const vo
   FlashGeom g;
   g.n = n; g.len = len; g.dk = dk; g.dv = dv;
   hipStream_t s = (hipStream_t)stream;
+  const FlashWorkspace w = flash_workspace(n, len, dk, dv, true);
+  char* ws = (char*)workspace;
+  const bf16 *v_pr = (const bf16*)(ws + w.v_pr), *do_pr = (const bf16*)(ws + w.do_pr), *do_pc = (const bf16*)(ws + w.do_pc);
+  const bf16 *q_pc = (const bf16*)(ws + w.q_pc), *k_pc = (const bf16*)(ws + w.k_pc);
+  float *dvec = (float*)(ws + w.dvec), *lse2 = (float*)(ws + w.lse2);
   const int64_t rows = (int64_t)n * len;
+  const bf16 *q16 = feat16(q, ws + w.q16, rows, dk, s), *k16 = feat16(k, ws + w.k16, rows, dk, s);
+  launch_pack_rows(v, ws + w.v_pr, rows, dv, s);
+  launch_pack_rows(d_o, ws + w.do_pr, rows, dv, s);
+  launch_pack_cols(d_o, ws + w.do_pc, n, len, dv, s);
+  launch_pack_cols(q, ws + w.q_pc, n, len, dk, s);
+  launch_pack_cols(k, ws + w.k_pc, n, len, dk, s);
   if (dtype == TG_F16)
     hipLaunchKernelGGL(flash_rowdot_kernel<f16>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, (const f16*)d_o,
-                       (const f16*)o, dvec, rows, dv);
+                       (const f16*)o, lse, dvec, lse2, rows, dv);
   else
     hipLaunchKernelGGL(flash_rowdot_kernel<bf16>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, (const bf16*)d_o,
-                       (const bf16*)o, dvec, rows, dv);
+                       (const bf16*)o, lse, dvec, lse2, rows, dv);
   const dim3 grid(len / 128, n);
-#define TG_FLB(DVB_, F16_)                                                                                              \
-  do {                                                                                                                  \
-    hipLaunchKernelGGL((flash_bwd_q_kernel<DVB_, F16_>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k,          \
-                       (const bf16*)v, (const bf16*)k_t, (const bf16*)d_o, lse, dvec, (bf16*)dq, g);                     \
-    hipLaunchKernelGGL((flash_bwd_kv_kernel<DVB_, F16_>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k,         \
-                       (const bf16*)v, (const bf16*)q_t, (const bf16*)d_o, (const bf16*)d_o_t, lse, dvec, (bf16*)dk_out, \
-                       (bf16*)dv_out, g);                                                                                \
+  const bool f16 = dtype == TG_F16;
+#define TG_FLB(DVB_, F16_)                                                                                               \
+  do {                                                                                                                   \
+    hipLaunchKernelGGL((flash_bwd_q_kernel<DVB_, F16_>), grid, dim3(256), 0, s, q16, k16, v_pr, k_pc, (const bf16*)d_o,   \
+                       lse2, dvec, (bf16*)dq, g);                                                                         \
+    hipLaunchKernelGGL((flash_bwd_kv_kernel<DVB_, F16_>), grid, dim3(256), 0, s, q16, k16, (const bf16*)v, q_pc, do_pr,   \
+                       do_pc, lse2, dvec, (bf16*)dk_out, (bf16*)dv_out, g);                                               \
   } while (0)
-  if (dv == 64 && dtype == TG_F16) TG_FLB(2, true);
-  else if (dv == 64) TG_FLB(2, false);
-  else if (dtype == TG_F16) TG_FLB(4, true);
-  else TG_FLB(4, false);
+#define TG_FLB2(DVB_)                                                                                                    \
+  do {                                                                                                                   \
+    if (f16) TG_FLB(DVB_, true);                                                                                         \
+    else TG_FLB(DVB_, false);                                                                                            \
+  } while (0)
+  if (dv == 64) TG_FLB2(2);
+  else TG_FLB2(4);
+#undef TG_FLB2
 #undef TG_FLB
   TG_LAUNCH_CHECK("tg_flash_attention_bwd");
   return TG_OK;

@@ -1445,15 +1445,22 @@ def flash_attention_supported(q, v):
   return q.dtype in HALF_TYPES and bool(_lib.load().tg_flash_attention_supported(q.shape[1], q.shape[2], v.shape[2]))
 
 
+def _flash_workspace(q, v, backward):
+  n, ln, dk = q.shape
+  nbytes = int(_lib.load().tg_flash_attention_workspace_bytes(n, ln, dk, v.shape[2], int(backward)))
+  assert nbytes > 0, 'flash attention: unsupported shape %s / %s' % (tuple(q.shape), tuple(v.shape))
+  return torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+
+
 def flash_attention_fwd_raw(q, k, v):
   """(o, lse): o = softmax(q k^T) v per image without the [len, len] map."""
   _chk(q, k, v)
   n, ln, dk = q.shape
   dv = v.shape[2]
-  vt = transpose16(v)
+  ws = _flash_workspace(q, v, False)
   o = torch.empty((n, ln, dv), dtype=q.dtype, device=q.device)
   lse = torch.empty((n, ln), dtype=torch.float32, device=q.device)
-  call('tg_flash_attention_fwd', _p(q), _p(k), _p(vt), _p(o), _p(lse), n, ln, dk, dv, _dt(q), _stream(),
+  call('tg_flash_attention_fwd', _p(q), _p(k), _p(v), _p(o), _p(lse), _p(ws), n, ln, dk, dv, _dt(q), _stream(),
        work=('flash_fwd:len%d:dk%d:dv%d:n%d' % (ln, dk, dv, n), 2 * n * ln * ln * (dk + dv), _nb(q, k, v, o)))
   return o, lse
 
@@ -1504,11 +1511,10 @@ class FlashAttnFn(torch.autograd.Function):
     _chk(go)
     n, ln, dk = q.shape
     dv = v.shape[2]
-    qt, kt, got = transpose16(q), transpose16(k), transpose16(go)
     gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    dvec = torch.empty_like(lse)
-    call('tg_flash_attention_bwd', _p(q), _p(k), _p(v), _p(qt), _p(kt), _p(go), _p(got), _p(o), _p(lse), _p(dvec), _p(gq),
-         _p(gk), _p(gv), n, ln, dk, dv, _dt(q), _stream(),
+    ws = _flash_workspace(q, v, True)
+    call('tg_flash_attention_bwd', _p(q), _p(k), _p(v), _p(go), _p(o), _p(lse), _p(ws), _p(gq), _p(gk), _p(gv), n, ln, dk,
+         dv, _dt(q), _stream(),
          work=('flash_bwd:len%d:dk%d:dv%d:n%d' % (ln, dk, dv, n), 2 * n * ln * ln * (3 * dk + 3 * dv), _nb(q, k, v, o, go, gq, gk, gv)))
     return gq, gk, gv
 
