@@ -28,6 +28,7 @@
     else hipLaunchKernelGGL((conv_wgrad_tile_kernel<TW_, BIAS_, false>), __VA_ARGS__);         \
   } while (0)
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -192,30 +193,61 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   struct Stage {
     bf16x8 rx[XSLOTS], rg[GSLOTS];
   };
-  auto load_tile = [&](Stage& st, int tile, bool& bias_on) __attribute__((always_inline)) {
-    const unsigned live = tile < tile_end;      // past the end: every lane out of range -> a tile of zeros
-    int t = live ? tile : tile_begin;
-    const bool segb = t >= g.tiles_a;           // second (x, gy) pair
+  // Position of the next tile to request.  Tiles are requested strictly in order, so (tile column, tile row, image) and
+  // the skip source's permuted image advance by compare-and-carry; the divisions run once per workgroup (and once more
+  // where the second segment starts).  The scalar unit issued 250 instructions per loop trip for the divisions before.
+  struct Cursor {
+    int tile, tx, ty, img, grp, rem;      // grp / rem: img = grp * gsz + rem (skip source with a group permutation)
+  };
+  const bool permuted = from_skip && g.gsz != 0;
+  auto cursor_set = [&](Cursor& c, int tile) __attribute__((always_inline)) {
+    c.tile = tile;
+    int t = tile >= g.tiles_a ? tile - g.tiles_a : tile;
+    if constexpr (TW == 16) {
+      c.tx = t % g.tiles_x;
+      t /= g.tiles_x;
+      c.ty = t % g.tiles_y;
+      c.img = t / g.tiles_y;
+    } else {
+      c.tx = c.ty = 0;
+      c.img = t * 2;      // the pair (2t, 2t+1)
+    }
+    c.grp = permuted ? c.img / g.gsz : 0;
+    c.rem = permuted ? c.img - c.grp * g.gsz : 0;
+  };
+  auto cursor_next = [&](Cursor& c) __attribute__((always_inline)) {
+    ++c.tile;
+    if (c.tile == g.tiles_a || (TW != 16 && permuted)) {      // segment switch / 8x8 pairs of a permuted source: recompute
+      cursor_set(c, c.tile);
+      return;
+    }
+    if constexpr (TW == 16) {
+      if (++c.tx == g.tiles_x) {
+        c.tx = 0;
+        if (++c.ty == g.tiles_y) {
+          c.ty = 0;
+          ++c.img;
+          if (permuted && ++c.rem == g.gsz) {
+            c.rem = 0;
+            ++c.grp;
+          }
+        }
+      }
+    } else {
+      c.img += 2;
+    }
+  };
+  auto load_tile = [&](Stage& st, Cursor& c, bool& bias_on) __attribute__((always_inline)) {
+    const unsigned live = c.tile < tile_end;      // past the end: every lane out of range -> a tile of zeros
+    const bool segb = c.tile >= g.tiles_a;        // second (x, gy) pair
     bias_on = do_bias && ((g.bias_segs >> (segb ? 1 : 0)) & 1);
-    if (segb) t -= g.tiles_a;
     const bf16* xs = segb ? g.xb : xsrc;
     const bf16* gs = segb ? g.gyb : gy;
     const int nseg = segb ? g.nb : g.n;
-    int img, ox0, oy0, nimg;
-    if constexpr (TW == 16) {
-      const int tx = t % g.tiles_x;
-      t /= g.tiles_x;
-      const int ty = t % g.tiles_y;
-      img = t / g.tiles_y;
-      ox0 = tx * TW;
-      oy0 = ty * TH;
-      nimg = 1;
-    } else {
-      img = t * 2;                              // the pair (2t, 2t+1); an odd batch ends with a half-empty tile:
-      ox0 = oy0 = 0;                            // the buffer resource then covers one image, the other reads zeros
-      nimg = img + 1 < nseg ? 2 : 1;
-    }
-    const int ximg_i = (from_skip && g.gsz) ? (int)((g.perm >> (8 * (img / g.gsz))) & 0xffu) * g.gsz + img % g.gsz : img;
+    const int img = c.img, ox0 = c.tx * TW, oy0 = c.ty * TH;
+    // TW = 8: an odd batch ends with a half-empty tile: the buffer resource then covers one image, the other reads zeros
+    const int nimg = TW == 16 ? 1 : (img + 1 < nseg ? 2 : 1);
+    const int ximg_i = permuted ? (int)((g.perm >> (8 * c.grp)) & 0xffu) * g.gsz + c.rem : img;
     const __amdgpu_buffer_rsrc_t bx = wg_rsrc(xs + (size_t)ximg_i * ximg, (unsigned)(ximg * 2 * nimg));
     const __amdgpu_buffer_rsrc_t bg = wg_rsrc(gs + (size_t)img * gimg, (unsigned)(gimg * 2 * nimg));
     const int xbase = from_up ? ((oy0 >> 1) * (g.w >> 1) + (ox0 >> 1)) * xc * 2 : (oy0 * g.w + ox0) * xc * 2;
@@ -230,6 +262,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
 #pragma unroll
     for (int s = 0; s < GSLOTS; ++s)      // g_rel = WOOB (bit 31) stays out of range after adding gbase < 2^31
       st.rg[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bg, live ? gbase + g_rel[s] : WOOB, 0, 0));
+    cursor_next(c);
   };
   auto stage_to_lds = [&](const Stage& st, unsigned char* bX, unsigned char* bG) __attribute__((always_inline)) {
 #pragma unroll
@@ -238,24 +271,97 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
 #pragma unroll
     for (int s = 0; s < GSLOTS; ++s) *reinterpret_cast<bf16x8*>(bG + g_loff[s]) = st.rg[s];
   };
-  auto reduce_tile = [&](const unsigned char* bX, const unsigned char* bG, bool bias_on) __attribute__((always_inline)) {
+  // One tile = 2 K steps x 9 taps = 18 (+2 bias) MFMAs.  TW = 16: K step 1 is the next row of the same image, so its
+  // taps (ky, kx) read the halo fragments of K step 0's taps (ky + 1, kx): 4 halo rows x 3 columns = 12 x fragments + 2
+  // gy fragments = 28 transpose reads per tile.  Left to the scheduler the reads came in bursts of 4-8 right before their
+  // MFMAs (an LDS round trip exposed per burst: ~1000 of a tile's ~3400 cycles).  Here they are requested in consumption
+  // order, five fragments ahead of the MFMAs, and the interleaving is pinned with scheduling-group barriers: every read
+  // has >= 3 MFMAs (~100 cycles) to land.
+  // WB (compile time): this workgroup feeds the bias gradient (ci block 0 of a BIAS kernel).
+  auto reduce_tile = [&](const unsigned char* bX, const unsigned char* bG, bool bias_on, auto wb) __attribute__((always_inline)) {
+    constexpr bool WB = decltype(wb)::value;
+    bf16x8 bo;
+    if constexpr (WB) {
+      typedef __attribute__((ext_vector_type(4))) unsigned u4;
+      const u4 o = __builtin_bit_cast(u4, ones);
+      u4 sel;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      // first pixel of this wave's K step in the gy tile / (for tap 0,0) in the halo tile
-      const int gpx = TW == 16 ? (wid * 2 + ks) * 16 : ks * 64 + wid * 16;
-      const int xpx = TW == 16 ? (wid * 2 + ks) * HWX : ks * (HH * HWX) + wid * 2 * HWX;
-      const bf16x8 gf = tr_frag(bG + gpx * PS + frag_off);
-      if constexpr (BIAS) {
-        if (bias_on) accb = mfma_32x32x16<F16>(ones, gf, accb);
+      for (int j = 0; j < 4; ++j) sel[j] = bias_on ? o[j] : 0u;
+      bo = __builtin_bit_cast(bf16x8, sel);
+    }
+    auto gaddr = [&](int ks) { return bG + (TW == 16 ? (wid * 2 + ks) * 16 : ks * 64 + wid * 16) * PS + frag_off; };
+    if constexpr (TW == 16) {
+      // X[row][kx]: halo row 2 wid + row, column offset kx
+      auto xaddr = [&](int row, int kx) { return bX + ((wid * 2 + row) * HWX + kx) * PS + frag_off_x; };
+      bf16x8 g0, g1, X[4][3];
+      g0 = tr_frag(gaddr(0));
+      g1 = tr_frag(gaddr(1));
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) X[0][kx] = tr_frag(xaddr(0, kx));
+      if constexpr (WB) {
+        accb = mfma_32x32x16<F16>(bo, g0, accb);
+        accb = mfma_32x32x16<F16>(bo, g1, accb);
       }
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
+      for (int kx = 0; kx < 3; ++kx) {      // halo row 0: K step 0, ky = 0
+        acc[kx] = mfma_32x32x16<F16>(X[0][kx], g0, acc[kx]);
+        X[1][kx] = tr_frag(xaddr(1, kx));
+      }
+#pragma unroll
+      for (int row = 1; row < 3; ++row)     // halo rows 1, 2: K step 0 tap row `row`, K step 1 tap row `row - 1`
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const bf16x8 xf = tr_frag(bX + (xpx + ky * HWX + kx) * PS + frag_off_x);
-          acc[ky * 3 + kx] = mfma_32x32x16<F16>(xf, gf, acc[ky * 3 + kx]);
+          acc[row * 3 + kx] = mfma_32x32x16<F16>(X[row][kx], g0, acc[row * 3 + kx]);
+          acc[(row - 1) * 3 + kx] = mfma_32x32x16<F16>(X[row][kx], g1, acc[(row - 1) * 3 + kx]);
+          X[row + 1][kx] = tr_frag(xaddr(row + 1, kx));
         }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) acc[6 + kx] = mfma_32x32x16<F16>(X[3][kx], g1, acc[6 + kx]);      // halo row 3
+      __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+      if constexpr (WB) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    } else {
+      // TW = 8: K step ks = image ks of the pair -- nothing shared: 2 x (gy + 9 x) fragments
+      auto xaddr = [&](int ks, int tap) {
+        return bX + (ks * (HH * HWX) + wid * 2 * HWX + (tap / 3) * HWX + tap % 3) * PS + frag_off_x;
+      };
+      bf16x8 gf[2], xf[2][NT];
+      gf[0] = tr_frag(gaddr(0));
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap) xf[0][tap] = tr_frag(xaddr(0, tap));
+#pragma unroll
+      for (int tap = 0; tap < NT; ++tap) {
+        acc[tap] = mfma_32x32x16<F16>(xf[0][tap], gf[0], acc[tap]);
+        if (tap + 3 < NT) xf[0][tap + 3] = tr_frag(xaddr(0, tap + 3));
+        else if (tap + 3 == NT) gf[1] = tr_frag(gaddr(1));
+        else xf[1][tap + 2 - NT] = tr_frag(xaddr(1, tap + 2 - NT));      // taps 7, 8 -> x1[0], x1[1]
+      }
+#pragma unroll
+      for (int tap = 0; tap < NT; ++tap) {
+        acc[tap] = mfma_32x32x16<F16>(xf[1][tap], gf[1], acc[tap]);
+        if (tap + 2 < NT) xf[1][tap + 2] = tr_frag(xaddr(1, tap + 2));
+      }
+      if constexpr (WB) {
+        accb = mfma_32x32x16<F16>(bo, gf[0], accb);
+        accb = mfma_32x32x16<F16>(bo, gf[1], accb);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 + (WB ? 2 : 0), 0);
     }
   };
 
@@ -263,19 +369,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   unsigned char* sG1 = sX1 + X_BYTES;
   // Two tiles per trip, no branches inside: a workgroup with an odd tile count reduces one all-zero tile.
   Stage sa, sb;
-  load_tile(sa, tile_begin, bias_a);
-  load_tile(sb, tile_begin + 1, bias_b);
+  Cursor cur;
+  cursor_set(cur, tile_begin);
+  load_tile(sa, cur, bias_a);
+  load_tile(sb, cur, bias_b);
   for (int tile = tile_begin; tile < tile_end; tile += 2) {
     stage_to_lds(sa, sX, sG);
     bias_0 = bias_a;
     __syncthreads();
-    load_tile(sa, tile + 2, bias_a);
-    reduce_tile(sX, sG, bias_0);
+    load_tile(sa, cur, bias_a);
+    if (do_bias) reduce_tile(sX, sG, bias_0, std::true_type());
+    else reduce_tile(sX, sG, bias_0, std::false_type());
     stage_to_lds(sb, sX1, sG1);
     bias_1 = bias_b;
     __syncthreads();
-    load_tile(sb, tile + 3, bias_b);
-    reduce_tile(sX1, sG1, bias_1);
+    load_tile(sb, cur, bias_b);
+    if (do_bias) reduce_tile(sX1, sG1, bias_1, std::true_type());
+    else reduce_tile(sX1, sG1, bias_1, std::false_type());
   }
 
   // ---- cross-wave reduction through LDS, one tap at a time; write the valid part of the slab.
@@ -435,20 +545,47 @@ __global__ __launch_bounds__(256, BIAS ? 3 : 4) void conv_wgrad_thin_kernel(cons
   struct Stage {
     bf16x8 rx[XSLOTS], rg[GSLOTS];
   };
-  auto load_tile = [&](Stage& st, int tile, bool& bias_on) __attribute__((always_inline)) {
-    const unsigned live = tile < tile_end;
-    int t = live ? tile : tile_begin;
-    const bool segb = t >= g.tiles_a;
+  // tile cursor as in conv_wgrad_tile_kernel (always TW = 16 geometry here)
+  struct Cursor {
+    int tile, tx, ty, img, grp, rem;
+  };
+  const bool permuted = from_skip && g.gsz != 0;
+  auto cursor_set = [&](Cursor& c, int tile) __attribute__((always_inline)) {
+    c.tile = tile;
+    int t = tile >= g.tiles_a ? tile - g.tiles_a : tile;
+    c.tx = t % g.tiles_x;
+    t /= g.tiles_x;
+    c.ty = t % g.tiles_y;
+    c.img = t / g.tiles_y;
+    c.grp = permuted ? c.img / g.gsz : 0;
+    c.rem = permuted ? c.img - c.grp * g.gsz : 0;
+  };
+  auto cursor_next = [&](Cursor& c) __attribute__((always_inline)) {
+    ++c.tile;
+    if (c.tile == g.tiles_a) {
+      cursor_set(c, c.tile);
+      return;
+    }
+    if (++c.tx == g.tiles_x) {
+      c.tx = 0;
+      if (++c.ty == g.tiles_y) {
+        c.ty = 0;
+        ++c.img;
+        if (permuted && ++c.rem == g.gsz) {
+          c.rem = 0;
+          ++c.grp;
+        }
+      }
+    }
+  };
+  auto load_tile = [&](Stage& st, Cursor& c, bool& bias_on) __attribute__((always_inline)) {
+    const unsigned live = c.tile < tile_end;
+    const bool segb = c.tile >= g.tiles_a;
     bias_on = do_bias && ((g.bias_segs >> (segb ? 1 : 0)) & 1);
-    if (segb) t -= g.tiles_a;
     const bf16* xs = segb ? g.xb : xsrc;
     const bf16* gs = segb ? g.gyb : gy;
-    const int tx = t % g.tiles_x;
-    t /= g.tiles_x;
-    const int ty = t % g.tiles_y;
-    const int img = t / g.tiles_y;
-    const int ox0 = tx * TW, oy0 = ty * TH;
-    const int ximg_i = (from_skip && g.gsz) ? (int)((g.perm >> (8 * (img / g.gsz))) & 0xffu) * g.gsz + img % g.gsz : img;
+    const int img = c.img, ox0 = c.tx * TW, oy0 = c.ty * TH;
+    const int ximg_i = permuted ? (int)((g.perm >> (8 * c.grp)) & 0xffu) * g.gsz + c.rem : img;
     const __amdgpu_buffer_rsrc_t bx = wg_rsrc(xs + (size_t)ximg_i * ximg, (unsigned)(ximg * 2));
     const __amdgpu_buffer_rsrc_t bg = wg_rsrc(gs + (size_t)img * gimg, (unsigned)(gimg * 2));
     const int xbase = from_up ? ((oy0 >> 1) * (g.w >> 1) + (ox0 >> 1)) * xc * 2 : (oy0 * g.w + ox0) * xc * 2;
@@ -463,6 +600,7 @@ __global__ __launch_bounds__(256, BIAS ? 3 : 4) void conv_wgrad_thin_kernel(cons
 #pragma unroll
     for (int s = 0; s < GSLOTS; ++s)
       st.rg[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bg, live ? gbase + g_rel[s] : WOOB, 0, 0));
+    cursor_next(c);
   };
   auto stage_to_lds = [&](const Stage& st, unsigned char* bX, unsigned char* bG) __attribute__((always_inline)) {
 #pragma unroll
@@ -502,18 +640,20 @@ __global__ __launch_bounds__(256, BIAS ? 3 : 4) void conv_wgrad_thin_kernel(cons
   unsigned char* sX1 = wg_smem + X_BYTES + G_BYTES;
   unsigned char* sG1 = sX1 + X_BYTES;
   Stage sa, sb;
-  load_tile(sa, tile_begin, bias_a);
-  load_tile(sb, tile_begin + 1, bias_b);
+  Cursor cur;
+  cursor_set(cur, tile_begin);
+  load_tile(sa, cur, bias_a);
+  load_tile(sb, cur, bias_b);
   for (int tile = tile_begin; tile < tile_end; tile += 2) {
     stage_to_lds(sa, sX, sG);
     bias_0 = bias_a;
     __syncthreads();
-    load_tile(sa, tile + 2, bias_a);
+    load_tile(sa, cur, bias_a);
     reduce_tile(sX, sG, bias_0);
     stage_to_lds(sb, sX1, sG1);
     bias_1 = bias_b;
     __syncthreads();
-    load_tile(sb, tile + 3, bias_b);
+    load_tile(sb, cur, bias_b);
     reduce_tile(sX1, sG1, bias_1);
   }
 
