@@ -9,6 +9,8 @@
 // threads of a pixel are adjacent lanes of one wave, so the per-pixel channel reduction of pixel
 // norm is a butterfly shuffle inside the wave.
 #include "tg_common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -60,6 +62,26 @@ __device__ __forceinline__ void load_grad(const T* gz, const T* gzp, int n, int 
     const int64_t pp = ((int64_t)n * hp + (yy >> 1)) * (wdim >> 1) + (xx >> 1);
     float q[V];
     VecIO<T, V>::load(gzp + pp * c + v * V, q);
+#pragma unroll
+    for (int j = 0; j < V; ++j) g[j] = fmaf(pool_scale, q[j], g[j]);
+  }
+}
+
+// the same with the image's base pointers (gz_n = gz + n * hw * c, gzp_n = gzp + n * (hw / 4) * c; either may be NULL)
+// and 32-bit element offsets: the hot loops' form (an image has < 2^31 elements)
+template <typename T, int V>
+__device__ __forceinline__ void load_grad_img(const T* gz_n, const T* gzp_n, unsigned p, int wshift, unsigned wdim,
+                                              unsigned c, unsigned v, float pool_scale, float* g) {
+  if (gz_n) {
+    VecIO<T, V>::load(gz_n + (p * c + v * V), g);
+  } else {
+#pragma unroll
+    for (int j = 0; j < V; ++j) g[j] = 0.f;
+  }
+  if (gzp_n) {
+    const unsigned yy = wshift >= 0 ? (p >> wshift) : p / wdim, xx = p - yy * wdim;
+    float q[V];
+    VecIO<T, V>::load(gzp_n + (((yy >> 1) * (wdim >> 1) + (xx >> 1)) * c + v * V), q);
 #pragma unroll
     for (int j = 0; j < V; ++j) g[j] = fmaf(pool_scale, q[j], g[j]);
   }
@@ -256,15 +278,16 @@ __global__ void norm_act_fwd_kernel(const T* __restrict__ y, const float* __rest
 // POOL: the 4 pixels a thread keeps in flight are one 2x2 block and the thread also writes their average to zp
 // [n, h/2, w/2, c] (the tf.nn.avg_pool after an encoder block, nets/pggan.py:466-468) -- px_per_block then counts
 // 2x2 blocks and wdim is the row length.
-template <typename T, int V, bool POOL = false>
+template <typename T, int V, bool POOL = false, int FL = -1>      // FL: see norm_act_bwd1_kernel
 __global__ void norm_act_fwd_part_kernel(const T* __restrict__ y, const float* __restrict__ part, int chunks,
                                          float* __restrict__ mean, float* __restrict__ rstd,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                          const float* __restrict__ gamma2, const float* __restrict__ beta2, int split,
                                          T* __restrict__ z, T* __restrict__ zp, int wdim, float* __restrict__ pn_scale,
-                                         int hw, int c, int flags, float alpha, float in_eps, float pn_eps,
+                                         int hw, int c, int flags_rt, float alpha, float in_eps, float pn_eps,
                                          int px_per_block) {
   extern __shared__ float sh[];   // [2][c]: sums, then (scale, shift)
+  const int flags = FL < 0 ? flags_rt : ((flags_rt & ~3) | FL);
   const int cv = c / V;
   const int lanes = blockDim.x / cv;
   const int v = threadIdx.x % cv, pl = threadIdx.x / cv;
@@ -306,19 +329,25 @@ __global__ void norm_act_fwd_part_kernel(const T* __restrict__ y, const float* _
   const int p0 = blockIdx.x * px_per_block;
   const int p1 = min(p0 + px_per_block, nunits);
   if (pl >= lanes) return;
-  const int wq = wdim >> 1;
+  const unsigned wq = wdim >> 1;
+  const int wqshift = (wq & (wq - 1)) == 0 ? 31 - __builtin_clz(wq) : -1;      // power-of-two maps: shift, not divide
+  // the image's base pointers; element offsets inside an image fit 32 bits
+  const T* y_n = y + (int64_t)n * hw * c;
+  T* z_n = z + (int64_t)n * hw * c;
+  T* zp_n = POOL ? zp + (int64_t)n * (hw / 4) * c : nullptr;
+  float* pn_n = pn_scale ? pn_scale + (int64_t)n * hw : nullptr;
   for (int pb = p0 + pl; pb < p1; pb += lanes * (POOL ? 1 : U)) {      // pl is uniform within a pixel group: groups stay converged
     float x[U][V];
-    int px[U];
+    unsigned px[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (POOL) {
-        const int qy = pb / wq, qx = pb - qy * wq;
+        const unsigned qy = wqshift >= 0 ? ((unsigned)pb >> wqshift) : (unsigned)pb / wq, qx = pb - qy * wq;
         px[u] = (2 * qy + (u >> 1)) * wdim + 2 * qx + (u & 1);
       } else {
         px[u] = min(pb + u * lanes, p1 - 1);
       }
-      VecIO<T, V>::load(y + ((int64_t)n * hw + px[u]) * c + v * V, x[u]);
+      VecIO<T, V>::load(y_n + (px[u] * c + v * V), x[u]);
     }
     float pooled[V];
 #pragma unroll
@@ -326,7 +355,6 @@ __global__ void norm_act_fwd_part_kernel(const T* __restrict__ y, const float* _
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool live = POOL || pb + u * lanes < p1;
-      const int64_t gp = (int64_t)n * hw + px[u];
       float ss = 0.f;
 #pragma unroll
       for (int j = 0; j < V; ++j) {
@@ -340,9 +368,9 @@ __global__ void norm_act_fwd_part_kernel(const T* __restrict__ y, const float* _
         const float q = rsqrtf(ss / (float)c + pn_eps);
 #pragma unroll
         for (int j = 0; j < V; ++j) x[u][j] *= q;
-        if (pn_scale && v == 0 && live) pn_scale[gp] = q;
+        if (pn_n && v == 0 && live) pn_n[px[u]] = q;
       }
-      if (live) VecIO<T, V>::store(z + gp * c + v * V, x[u]);
+      if (live) VecIO<T, V>::store(z_n + (px[u] * c + v * V), x[u]);
       if (POOL) {
 #pragma unroll
         for (int j = 0; j < V; ++j) pooled[j] += rnd<T>(x[u][j]);      // the pool reads the stored (rounded) z
@@ -351,7 +379,7 @@ __global__ void norm_act_fwd_part_kernel(const T* __restrict__ y, const float* _
     if (POOL) {
 #pragma unroll
       for (int j = 0; j < V; ++j) pooled[j] *= 0.25f;
-      VecIO<T, V>::store(zp + ((int64_t)n * (hw / 4) + pb) * c + v * V, pooled);
+      VecIO<T, V>::store(zp_n + ((unsigned)pb * c + v * V), pooled);
     }
   }
 }
@@ -364,25 +392,25 @@ __global__ void norm_act_fwd_part_kernel(const T* __restrict__ y, const float* _
 template <int V>
 __device__ __forceinline__ void norm_act_gu(float (&g)[V], float (&x)[V], float s, const float (&mu)[V],
                                             const float (&rs)[V], const float (&ga)[V], const float (&be)[V], int flags,
-                                            float alpha, int cv, int c, float (&yh)[V]) {
-  float u[V];
+                                            float alpha, int cv, float inv_c, float (&yh)[V]) {
+  float f[V];      // LeakyReLU slope of the element: lrelu(u) = u * f, d lrelu / du = f
   float dot = 0.f;
 #pragma unroll
   for (int j = 0; j < V; ++j) {
     yh[j] = (x[j] - mu[j]) * rs[j];
-    u[j] = yh[j] * ga[j] + be[j];
-    const float a = (flags & NF_LRELU) ? lrelu_f(u[j], alpha) : u[j];
-    dot = fmaf(g[j], a * s, dot);          // gz . z
-    x[j] = a * s;                          // z
+    const float u = yh[j] * ga[j] + be[j];
+    f[j] = ((flags & NF_LRELU) && !(u > 0.f)) ? alpha : 1.f;
+    x[j] = u * f[j] * s;                   // z
+    dot = fmaf(g[j], x[j], dot);           // gz . z
   }
   if (flags & NF_PIXNORM) {
-    dot = group_sum(dot, cv) / (float)c;
+    dot = group_sum(dot, cv) * inv_c;
 #pragma unroll
     for (int j = 0; j < V; ++j) g[j] = s * (g[j] - x[j] * dot);     // d/da
   }
   if (flags & NF_LRELU) {
 #pragma unroll
-    for (int j = 0; j < V; ++j) g[j] *= (u[j] > 0.f ? 1.f : alpha);
+    for (int j = 0; j < V; ++j) g[j] *= f[j];
   }
 }
 
@@ -399,15 +427,18 @@ __device__ __forceinline__ void norm_act_gu(float (&g)[V], float (&x)[V], float 
 // 14 launches and nothing measurable (836 vs 841 images/s).  A kernel boundary IS the cheap barrier on this chip.
 //
 // backward pass 1: partial sums  sums[n][chunk][0..c) = sum gu,  [c..2c) = sum gu * yhat
-template <typename T, int V>
+// FL >= 0: the LeakyReLU / pixel-norm bits of `flags` as a compile-time constant (the vector paths: no flag tests or
+// branches in the pixel loops); FL < 0: all of `flags` at run time.
+template <typename T, int V, int FL = -1>
 __global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restrict__ gzp, int wdim,
                                      const T* __restrict__ y, const float* __restrict__ pn_scale,
                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                      const float* __restrict__ gamma2, const float* __restrict__ beta2, int split,
-                                     int pstride, float* __restrict__ sums, int hw, int c, int flags, float alpha,
+                                     int pstride, float* __restrict__ sums, int hw, int c, int flags_rt, float alpha,
                                      int px_per_block) {
   extern __shared__ float sh[];   // [2][c]
+  const int flags = FL < 0 ? flags_rt : ((flags_rt & ~3) | FL);
   const int cv = c / V;
   const int lanes = blockDim.x / cv;
   const int v = threadIdx.x % cv, pl = threadIdx.x / cv;
@@ -426,32 +457,44 @@ __global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restri
   }
   const int p0 = blockIdx.x * px_per_block;
   const int p1 = min(p0 + px_per_block, hw);
+  // the image's base pointers; element offsets inside an image fit 32 bits
+  const T* gz_n = gz ? gz + (int64_t)n * hw * c : nullptr;
+  const T* gzp_n = gzp ? gzp + (int64_t)n * (hw >> 2) * c : nullptr;
+  const T* y_n = y + (int64_t)n * hw * c;
+  const float* pn_n = pn_scale ? pn_scale + (int64_t)n * hw : nullptr;
+  const int wshift = (wdim & (wdim - 1)) == 0 ? 31 - __builtin_clz(wdim) : -1;
   // every lane of a pixel group iterates the same number of times (pl is uniform within a group)
+  const float inv_c = 1.f / (float)c;
   if (pl < lanes) {
     constexpr int U = 2;      // pixels in flight per thread (3 loads each)
-    for (int pb = p0 + pl; pb < p1; pb += lanes * U) {
-      float gq[U][V], xq[U][V], sq[U];
+    // TAIL: the block's pixel count is not a multiple of lanes * U -- the last trip clamps and masks its dead pixels
+    auto sweep = [&](auto tail) __attribute__((always_inline)) {
+      constexpr bool TAIL = decltype(tail)::value;
+      for (int pb = p0 + pl; pb < p1; pb += lanes * U) {
+        float gq[U][V], xq[U][V], sq[U];
 #pragma unroll
-      for (int q = 0; q < U; ++q) {
-        const int p = min(pb + q * lanes, p1 - 1);
-        const int64_t gp = (int64_t)n * hw + p;
-        load_grad<T, V>(gz, gzp, n, p, hw, wdim, c, v, 0.25f, gq[q]);
-        VecIO<T, V>::load(y + gp * c + v * V, xq[q]);
-        sq[q] = (flags & NF_PIXNORM) ? pn_scale[gp] : 1.f;
-      }
+        for (int q = 0; q < U; ++q) {
+          const unsigned p = TAIL ? min(pb + q * lanes, p1 - 1) : pb + q * lanes;
+          load_grad_img<T, V>(gz_n, gzp_n, p, wshift, wdim, c, v, 0.25f, gq[q]);
+          VecIO<T, V>::load(y_n + (p * c + v * V), xq[q]);
+          sq[q] = (flags & NF_PIXNORM) ? pn_n[p] : 1.f;
+        }
 #pragma unroll
-      for (int q = 0; q < U; ++q) {
-        const bool live = pb + q * lanes < p1;
-        float yh[V];
-        norm_act_gu<V>(gq[q], xq[q], sq[q], mu, rs, ga, be, flags, alpha, cv, c, yh);
+        for (int q = 0; q < U; ++q) {
+          const bool live = !TAIL || pb + q * lanes < p1;
+          float yh[V];
+          norm_act_gu<V>(gq[q], xq[q], sq[q], mu, rs, ga, be, flags, alpha, cv, inv_c, yh);
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-          const float gr = live ? gq[q][j] : 0.f;
-          a1[j] += gr;
-          a2[j] = fmaf(gr, yh[j], a2[j]);
+          for (int j = 0; j < V; ++j) {
+            const float gr = live ? gq[q][j] : 0.f;
+            a1[j] += gr;
+            a2[j] = fmaf(gr, yh[j], a2[j]);
+          }
         }
       }
-    }
+    };
+    if ((p1 - p0) % (lanes * U) == 0) sweep(std::false_type());
+    else sweep(std::true_type());
   }
   wave_channel_accumulate<V>(a1, sh, 0, cv, v, pl < lanes);
   wave_channel_accumulate<V>(a2, sh, c, cv, v, pl < lanes);
@@ -463,7 +506,7 @@ __global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restri
 
 // backward pass 2: gy = gamma*rstd * (gu - S1/hw - yhat * S2/hw).  grid = (chunks2, n); the prologue sums the
 // image's partial S1 / S2; with `sink` block (0, n) adds them into the parameter gradients.
-template <typename T, int V>
+template <typename T, int V, int FL = -1>
 __global__ void norm_act_bwd2_part_kernel(const T* __restrict__ gz, const T* __restrict__ gzp, int wdim,
                                           const T* __restrict__ y, const float* __restrict__ pn_scale,
                                           const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -472,8 +515,9 @@ __global__ void norm_act_bwd2_part_kernel(const T* __restrict__ gz, const T* __r
                                           int pstride, T* __restrict__ gy, const float* __restrict__ part, int chunks,
                                           float* __restrict__ ggamma, float* __restrict__ gbeta,
                                           float* __restrict__ ggamma2, float* __restrict__ gbeta2, int sink, int hw, int c,
-                                          int flags, float alpha, int px_per_block) {
+                                          int flags_rt, float alpha, int px_per_block) {
   extern __shared__ float sh[];   // [2][c]
+  const int flags = FL < 0 ? flags_rt : ((flags_rt & ~3) | FL);
   const int cv = c / V;
   const int lanes = blockDim.x / cv;
   const int v = threadIdx.x % cv, pl = threadIdx.x / cv;
@@ -522,27 +566,41 @@ __global__ void norm_act_bwd2_part_kernel(const T* __restrict__ gz, const T* __r
   const int p0 = blockIdx.x * px_per_block;
   const int p1 = min(p0 + px_per_block, hw);
   if (pl >= lanes) return;
+  const T* gz_n = gz ? gz + (int64_t)n * hw * c : nullptr;
+  const T* gzp_n = gzp ? gzp + (int64_t)n * (hw >> 2) * c : nullptr;
+  const T* y_n = y + (int64_t)n * hw * c;
+  T* gy_n = gy + (int64_t)n * hw * c;
+  const float* pn_n = pn_scale ? pn_scale + (int64_t)n * hw : nullptr;
+  const int wshift = (wdim & (wdim - 1)) == 0 ? 31 - __builtin_clz(wdim) : -1;
+  float gr[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) gr[j] = ga[j] * rs[j];
+  const float inv_c = 1.f / (float)c;
   constexpr int U = 2;      // pixels in flight per thread (3 loads each)
-  for (int pb = p0 + pl; pb < p1; pb += lanes * U) {
-    float gq[U][V], xq[U][V], sq[U];
+  auto sweep = [&](auto tail) __attribute__((always_inline)) {
+    constexpr bool TAIL = decltype(tail)::value;
+    for (int pb = p0 + pl; pb < p1; pb += lanes * U) {
+      float gq[U][V], xq[U][V], sq[U];
 #pragma unroll
-    for (int q = 0; q < U; ++q) {
-      const int p = min(pb + q * lanes, p1 - 1);
-      const int64_t gp = (int64_t)n * hw + p;
-      load_grad<T, V>(gz, gzp, n, p, hw, wdim, c, v, 0.25f, gq[q]);
-      VecIO<T, V>::load(y + gp * c + v * V, xq[q]);
-      sq[q] = (flags & NF_PIXNORM) ? pn_scale[gp] : 1.f;
+      for (int q = 0; q < U; ++q) {
+        const unsigned p = TAIL ? min(pb + q * lanes, p1 - 1) : pb + q * lanes;
+        load_grad_img<T, V>(gz_n, gzp_n, p, wshift, wdim, c, v, 0.25f, gq[q]);
+        VecIO<T, V>::load(y_n + (p * c + v * V), xq[q]);
+        sq[q] = (flags & NF_PIXNORM) ? pn_n[p] : 1.f;
+      }
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        const unsigned p = pb + q * lanes;
+        float yh[V];
+        norm_act_gu<V>(gq[q], xq[q], sq[q], mu, rs, ga, be, flags, alpha, cv, inv_c, yh);
+#pragma unroll
+        for (int j = 0; j < V; ++j) gq[q][j] = gr[j] * (gq[q][j] - s1[j] - yh[j] * s2[j]);
+        if (!TAIL || p < (unsigned)p1) VecIO<T, V>::store(gy_n + (p * c + v * V), gq[q]);
+      }
     }
-#pragma unroll
-    for (int q = 0; q < U; ++q) {
-      const int p = pb + q * lanes;
-      float yh[V];
-      norm_act_gu<V>(gq[q], xq[q], sq[q], mu, rs, ga, be, flags, alpha, cv, c, yh);
-#pragma unroll
-      for (int j = 0; j < V; ++j) gq[q][j] = ga[j] * rs[j] * (gq[q][j] - s1[j] - yh[j] * s2[j]);
-      if (p < p1) VecIO<T, V>::store(gy + ((int64_t)n * hw + p) * c + v * V, gq[q]);
-    }
-  }
+  };
+  if ((p1 - p0) % (lanes * U) == 0) sweep(std::false_type());
+  else sweep(std::true_type());
 }
 
 // images [i0, i1) -> (ggamma, gbeta); blockIdx.y selects the domain half
@@ -702,6 +760,13 @@ int tg_instance_norm_partials(const void* y, float* partials, int n, int h, int 
   return TG_OK;
 }
 
+// the forward launch of the vector path with the LeakyReLU / pixel-norm bits FL_ fixed at compile time (uses the locals
+// of norm_act_fwd_partials_impl)
+#define TG_NF_LAUNCH(POOL_, FL_)                                                                                         \
+  hipLaunchKernelGGL((norm_act_fwd_part_kernel<T, VN, POOL_, FL_>), dim3(chunks2, n), dim3(256), lds,                    \
+                     (hipStream_t)stream, (const T*)y, partials, chunks, mean, rstd, gamma, beta, gamma2, beta2, split,  \
+                     (T*)z, (T*)z_pooled, w, pn_scale, hw, c, flags, alpha, in_eps, pn_eps, ppb)
+
 static int norm_act_fwd_partials_impl(const void* y, const float* partials, int part_chunks, float* mean, float* rstd,
                                       const float* gamma, const float* beta, const float* gamma2, const float* beta2,
                                       int split, void* z, void* z_pooled, float* pn_scale, int n, int h, int w, int c,
@@ -730,14 +795,17 @@ static int norm_act_fwd_partials_impl(const void* y, const float* partials, int 
       TG_CHECK(vec, TG_ENOSUP, "tg_norm_act_fwd_partials: pixel norm needs c (%d) = %d * 2^k <= %d", c, VN, 64 * VN);
       TG_CHECK(pn_scale, TG_EINVAL, "tg_norm_act_fwd_partials: pixel norm needs pn_scale");
     }
-    if (vec && z_pooled) {
-      hipLaunchKernelGGL((norm_act_fwd_part_kernel<T, VN, true>), dim3(chunks2, n), dim3(256), lds, (hipStream_t)stream,
-                         (const T*)y, partials, chunks, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)z, (T*)z_pooled,
-                         w, pn_scale, hw, c, flags, alpha, in_eps, pn_eps, ppb);
-    } else if (vec) {
-      hipLaunchKernelGGL((norm_act_fwd_part_kernel<T, VN>), dim3(chunks2, n), dim3(256), lds, (hipStream_t)stream,
-                         (const T*)y, partials, chunks, mean, rstd, gamma, beta, gamma2, beta2, split, (T*)z, (T*)nullptr,
-                         w, pn_scale, hw, c, flags, alpha, in_eps, pn_eps, ppb);
+    if (vec) {
+      switch ((flags & 3) | (z_pooled ? 4 : 0)) {
+        case 0: TG_NF_LAUNCH(false, 0); break;
+        case 1: TG_NF_LAUNCH(false, 1); break;
+        case 2: TG_NF_LAUNCH(false, 2); break;
+        case 3: TG_NF_LAUNCH(false, 3); break;
+        case 4: TG_NF_LAUNCH(true, 0); break;
+        case 5: TG_NF_LAUNCH(true, 1); break;
+        case 6: TG_NF_LAUNCH(true, 2); break;
+        default: TG_NF_LAUNCH(true, 3); break;
+      }
     } else {
       TG_CHECK(c <= 256, TG_ENOSUP, "tg_norm_act_fwd_partials: scalar path needs c <= 256 (got %d)", c);
       if (z_pooled)
@@ -838,6 +906,18 @@ int tg_norm_act_fwd(const void* y, const float* mean, const float* rstd, const f
   return TG_OK;
 }
 
+// the two backward launches of the vector path with the LeakyReLU / pixel-norm bits FL_ fixed at compile time (uses the
+// locals of tg_norm_act_bwd)
+#define TG_NB_LAUNCH(FL_)                                                                                                  \
+  do {                                                                                                                     \
+    hipLaunchKernelGGL((norm_act_bwd1_kernel<T, VN, FL_>), dim3(chunks, n), dim3(256), lds, s, (const T*)gz,               \
+                       (const T*)gz_pooled, w, (const T*)y, pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split,       \
+                       pstride, sums, hw, c, flags, alpha, ppb);                                                           \
+    hipLaunchKernelGGL((norm_act_bwd2_part_kernel<T, VN, FL_>), dim3(chunks2, n), dim3(256), lds, s, (const T*)gz,         \
+                       (const T*)gz_pooled, w, (const T*)y, pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split,       \
+                       pstride, (T*)gy, sums, chunks, ggamma, gbeta, ggamma2, gbeta2, sink, hw, c, flags, alpha, ppb2);    \
+  } while (0)
+
 int tg_norm_act_bwd(const void* gz, const void* gz_pooled, const void* y, const float* pn_scale, const float* mean,
                     const float* rstd,
                     const float* gamma, const float* beta, const float* gamma2, const float* beta2, int split, void* gy,
@@ -869,11 +949,12 @@ int tg_norm_act_bwd(const void* gz, const void* gz_pooled, const void* y, const 
       TG_CHECK(vec && pn_scale, TG_ENOSUP, "tg_norm_act_bwd: pixel norm needs c (%d) = %d * 2^k and pn_scale", c, VN);
     }
     if (vec) {
-      hipLaunchKernelGGL((norm_act_bwd1_kernel<T, VN>), dim3(chunks, n), dim3(256), lds, s, (const T*)gz,
-                         (const T*)gz_pooled, w, (const T*)y, pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split, pstride, sums, hw, c, flags, alpha, ppb);
-      hipLaunchKernelGGL((norm_act_bwd2_part_kernel<T, VN>), dim3(chunks2, n), dim3(256), lds, s, (const T*)gz,
-                         (const T*)gz_pooled, w, (const T*)y, pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split,
-                         pstride, (T*)gy, sums, chunks, ggamma, gbeta, ggamma2, gbeta2, sink, hw, c, flags, alpha, ppb2);
+      switch (flags & 3) {
+        case 0: TG_NB_LAUNCH(0); break;
+        case 1: TG_NB_LAUNCH(1); break;
+        case 2: TG_NB_LAUNCH(2); break;
+        default: TG_NB_LAUNCH(3); break;
+      }
     } else {
       TG_CHECK(c <= 256, TG_ENOSUP, "tg_norm_act_bwd: scalar path needs c <= 256 (got %d)", c);
       hipLaunchKernelGGL((norm_act_bwd1_kernel<T, 1>), dim3(chunks, n), dim3(256), lds, s, (const T*)gz,
@@ -900,7 +981,8 @@ static int lrelu_bwd_launch(const char* who, const void* gz, const void* gzp, in
     const int V = pick_v<T>(c);
     TG_CHECK(c / V <= 256, TG_ENOSUP, "%s: c=%d not supported", who, c);
     const int lanes = 256 / (c / V);
-    // few, fat workgroups when a bias gradient is produced: every workgroup ends with c global atomics
+    // few, fat workgroups when a bias gradient is produced: every workgroup ends with c global atomics (measured: a cap
+    // of 512 / 256 workgroups is slower at the 256x256 layers -- 124 / 199 vs 91 us at n48 c32 -- and equal below)
     const int blocks = gbias ? tg_grid_for(npix, lanes * 16, 1024) : tg_grid_for(npix, lanes * 4, 2048);
     const size_t lds = (size_t)c * sizeof(float);
     // exact path: the element-wise part on the full grid, the bias gradient by one workgroup over what it wrote
