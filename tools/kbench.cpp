@@ -270,6 +270,11 @@ int main(int argc, char** argv) {
     printf("%-7s %-5s %4d %4d>%-4d | %9.1f %8.0f %8.1f %9.2e\n", c.name, "wgrad", c.hw, c.cin, c.cout, t, bytes / t * 1e-3,
            flops / t * 1e-6, e_w);
     }
+    if (only_op && !strcmp(only_op, "wgradb")) {      // the filter gradient with the fused bias gradient (timing only)
+      t = time_us([&] { TC(tg_conv2d_bwd_weight_bias(&d0, x, gy, gw, bias, 0, ws, wsb, nullptr)); }, iters);
+      printf("%-7s %-5s %4d %4d>%-4d | %9.1f %8.0f %8.1f\n", c.name, "wgradb", c.hw, c.cin, c.cout, t, bytes / t * 1e-3,
+             flops / t * 1e-6);
+    }
     fflush(stdout);
     HC(hipFree(x)); HC(hipFree(gy)); HC(hipFree(w)); HC(hipFree(bias)); HC(hipFree(y)); HC(hipFree(y2));
     HC(hipFree(gx)); HC(hipFree(gx2)); HC(hipFree(gw)); HC(hipFree(gw2)); HC(hipFree(p0)); HC(hipFree(p1));

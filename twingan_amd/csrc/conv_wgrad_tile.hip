@@ -277,9 +277,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   // MFMAs (an LDS round trip exposed per burst: ~1000 of a tile's ~3400 cycles).  Here they are requested in consumption
   // order, five fragments ahead of the MFMAs, and the interleaving is pinned with scheduling-group barriers: every read
   // has >= 3 MFMAs (~100 cycles) to land.
-  // WB (compile time): this workgroup feeds the bias gradient (ci block 0 of a BIAS kernel).
-  auto reduce_tile = [&](const unsigned char* bX, const unsigned char* bG, bool bias_on, auto wb) __attribute__((always_inline)) {
-    constexpr bool WB = decltype(wb)::value;
+  // BIAS kernels: the bias MFMAs are issued by every workgroup (A operand = ones where this tile feeds the bias gradient,
+  // zeros elsewhere -- a branch would split the scheduling region, and a second copy of the tile code for the
+  // ci-block-0 workgroups doubled the accumulator registers: 256 AGPRs, one wave per SIMD, +45 % time).
+  auto reduce_tile = [&](const unsigned char* bX, const unsigned char* bG, bool bias_on) __attribute__((always_inline)) {
+    constexpr bool WB = BIAS;
     bf16x8 bo;
     if constexpr (WB) {
       typedef __attribute__((ext_vector_type(4))) unsigned u4;
@@ -378,14 +380,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
     bias_0 = bias_a;
     __syncthreads();
     load_tile(sa, cur, bias_a);
-    if (do_bias) reduce_tile(sX, sG, bias_0, std::true_type());
-    else reduce_tile(sX, sG, bias_0, std::false_type());
+    reduce_tile(sX, sG, bias_0);
     stage_to_lds(sb, sX1, sG1);
     bias_1 = bias_b;
     __syncthreads();
     load_tile(sb, cur, bias_b);
-    if (do_bias) reduce_tile(sX1, sG1, bias_1, std::true_type());
-    else reduce_tile(sX1, sG1, bias_1, std::false_type());
+    reduce_tile(sX1, sG1, bias_1);
   }
 
   // ---- cross-wave reduction through LDS, one tap at a time; write the valid part of the slab.
@@ -545,47 +545,22 @@ __global__ __launch_bounds__(256, BIAS ? 3 : 4) void conv_wgrad_thin_kernel(cons
   struct Stage {
     bf16x8 rx[XSLOTS], rg[GSLOTS];
   };
-  // tile cursor as in conv_wgrad_tile_kernel (always TW = 16 geometry here)
-  struct Cursor {
-    int tile, tx, ty, img, grp, rem;
-  };
-  const bool permuted = from_skip && g.gsz != 0;
-  auto cursor_set = [&](Cursor& c, int tile) __attribute__((always_inline)) {
-    c.tile = tile;
-    int t = tile >= g.tiles_a ? tile - g.tiles_a : tile;
-    c.tx = t % g.tiles_x;
-    t /= g.tiles_x;
-    c.ty = t % g.tiles_y;
-    c.img = t / g.tiles_y;
-    c.grp = permuted ? c.img / g.gsz : 0;
-    c.rem = permuted ? c.img - c.grp * g.gsz : 0;
-  };
-  auto cursor_next = [&](Cursor& c) __attribute__((always_inline)) {
-    ++c.tile;
-    if (c.tile == g.tiles_a) {
-      cursor_set(c, c.tile);
-      return;
-    }
-    if (++c.tx == g.tiles_x) {
-      c.tx = 0;
-      if (++c.ty == g.tiles_y) {
-        c.ty = 0;
-        ++c.img;
-        if (permuted && ++c.rem == g.gsz) {
-          c.rem = 0;
-          ++c.grp;
-        }
-      }
-    }
-  };
-  auto load_tile = [&](Stage& st, Cursor& c, bool& bias_on) __attribute__((always_inline)) {
-    const unsigned live = c.tile < tile_end;
-    const bool segb = c.tile >= g.tiles_a;
+  // (per-tile divisions kept here: the tile cursor of conv_wgrad_tile_kernel made this HBM-bound kernel 5 % slower --
+  // 111 vs 106 us at 16 -> 32 channels, 256 x 256, n = 64)
+  auto load_tile = [&](Stage& st, int tile, bool& bias_on) __attribute__((always_inline)) {
+    const unsigned live = tile < tile_end;
+    int t = live ? tile : tile_begin;
+    const bool segb = t >= g.tiles_a;
     bias_on = do_bias && ((g.bias_segs >> (segb ? 1 : 0)) & 1);
+    if (segb) t -= g.tiles_a;
     const bf16* xs = segb ? g.xb : xsrc;
     const bf16* gs = segb ? g.gyb : gy;
-    const int img = c.img, ox0 = c.tx * TW, oy0 = c.ty * TH;
-    const int ximg_i = permuted ? (int)((g.perm >> (8 * c.grp)) & 0xffu) * g.gsz + c.rem : img;
+    const int tx = t % g.tiles_x;
+    t /= g.tiles_x;
+    const int ty = t % g.tiles_y;
+    const int img = t / g.tiles_y;
+    const int ox0 = tx * TW, oy0 = ty * TH;
+    const int ximg_i = (from_skip && g.gsz) ? (int)((g.perm >> (8 * (img / g.gsz))) & 0xffu) * g.gsz + img % g.gsz : img;
     const __amdgpu_buffer_rsrc_t bx = wg_rsrc(xs + (size_t)ximg_i * ximg, (unsigned)(ximg * 2));
     const __amdgpu_buffer_rsrc_t bg = wg_rsrc(gs + (size_t)img * gimg, (unsigned)(gimg * 2));
     const int xbase = from_up ? ((oy0 >> 1) * (g.w >> 1) + (ox0 >> 1)) * xc * 2 : (oy0 * g.w + ox0) * xc * 2;
@@ -600,7 +575,6 @@ __global__ __launch_bounds__(256, BIAS ? 3 : 4) void conv_wgrad_thin_kernel(cons
 #pragma unroll
     for (int s = 0; s < GSLOTS; ++s)
       st.rg[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bg, live ? gbase + g_rel[s] : WOOB, 0, 0));
-    cursor_next(c);
   };
   auto stage_to_lds = [&](const Stage& st, unsigned char* bX, unsigned char* bG) __attribute__((always_inline)) {
 #pragma unroll
@@ -640,20 +614,18 @@ __global__ __launch_bounds__(256, BIAS ? 3 : 4) void conv_wgrad_thin_kernel(cons
   unsigned char* sX1 = wg_smem + X_BYTES + G_BYTES;
   unsigned char* sG1 = sX1 + X_BYTES;
   Stage sa, sb;
-  Cursor cur;
-  cursor_set(cur, tile_begin);
-  load_tile(sa, cur, bias_a);
-  load_tile(sb, cur, bias_b);
+  load_tile(sa, tile_begin, bias_a);
+  load_tile(sb, tile_begin + 1, bias_b);
   for (int tile = tile_begin; tile < tile_end; tile += 2) {
     stage_to_lds(sa, sX, sG);
     bias_0 = bias_a;
     __syncthreads();
-    load_tile(sa, cur, bias_a);
+    load_tile(sa, tile + 2, bias_a);
     reduce_tile(sX, sG, bias_0);
     stage_to_lds(sb, sX1, sG1);
     bias_1 = bias_b;
     __syncthreads();
-    load_tile(sb, cur, bias_b);
+    load_tile(sb, tile + 3, bias_b);
     reduce_tile(sX1, sG1, bias_1);
   }
 
