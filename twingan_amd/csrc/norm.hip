@@ -427,8 +427,10 @@ __device__ __forceinline__ void norm_act_gu(float (&g)[V], float (&x)[V], float 
 // 14 launches and nothing measurable (836 vs 841 images/s).  A kernel boundary IS the cheap barrier on this chip.
 //
 // backward pass 1: partial sums  sums[n][chunk][0..c) = sum gu,  [c..2c) = sum gu * yhat
-// FL >= 0: the LeakyReLU / pixel-norm bits of `flags` as a compile-time constant (the vector paths: no flag tests or
-// branches in the pixel loops); FL < 0: all of `flags` at run time.
+// FL >= 0: the LeakyReLU / pixel-norm bits of `flags` as a compile-time constant (the 16-bit vector paths: no flag tests
+// or branches in the pixel loops); FL < 0: all of `flags` at run time -- the scalar paths and the fp32 exact-parity
+// path, whose arithmetic stays the one the parity tests were pinned on (the specialised code contracts its multiply-adds
+// differently: last-bit changes that Adam's sign-like first steps turn into a 2e-2 difference of the 4x4 stage's update).
 template <typename T, int V, int FL = -1>
 __global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restrict__ gzp, int wdim,
                                      const T* __restrict__ y, const float* __restrict__ pn_scale,
@@ -763,7 +765,7 @@ int tg_instance_norm_partials(const void* y, float* partials, int n, int h, int 
 // the forward launch of the vector path with the LeakyReLU / pixel-norm bits FL_ fixed at compile time (uses the locals
 // of norm_act_fwd_partials_impl)
 #define TG_NF_LAUNCH(POOL_, FL_)                                                                                         \
-  hipLaunchKernelGGL((norm_act_fwd_part_kernel<T, VN, POOL_, FL_>), dim3(chunks2, n), dim3(256), lds,                    \
+  hipLaunchKernelGGL((norm_act_fwd_part_kernel<T, VN, POOL_, exact_path<T>() ? -1 : FL_>), dim3(chunks2, n), dim3(256), lds, \
                      (hipStream_t)stream, (const T*)y, partials, chunks, mean, rstd, gamma, beta, gamma2, beta2, split,  \
                      (T*)z, (T*)z_pooled, w, pn_scale, hw, c, flags, alpha, in_eps, pn_eps, ppb)
 
@@ -910,10 +912,10 @@ int tg_norm_act_fwd(const void* y, const float* mean, const float* rstd, const f
 // locals of tg_norm_act_bwd)
 #define TG_NB_LAUNCH(FL_)                                                                                                  \
   do {                                                                                                                     \
-    hipLaunchKernelGGL((norm_act_bwd1_kernel<T, VN, FL_>), dim3(chunks, n), dim3(256), lds, s, (const T*)gz,               \
+    hipLaunchKernelGGL((norm_act_bwd1_kernel<T, VN, exact_path<T>() ? -1 : FL_>), dim3(chunks, n), dim3(256), lds, s, (const T*)gz, \
                        (const T*)gz_pooled, w, (const T*)y, pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split,       \
                        pstride, sums, hw, c, flags, alpha, ppb);                                                           \
-    hipLaunchKernelGGL((norm_act_bwd2_part_kernel<T, VN, FL_>), dim3(chunks2, n), dim3(256), lds, s, (const T*)gz,         \
+    hipLaunchKernelGGL((norm_act_bwd2_part_kernel<T, VN, exact_path<T>() ? -1 : FL_>), dim3(chunks2, n), dim3(256), lds, s, (const T*)gz, \
                        (const T*)gz_pooled, w, (const T*)y, pn_scale, mean, rstd, gamma, beta, gamma2, beta2, split,       \
                        pstride, (T*)gy, sums, chunks, ggamma, gbeta, ggamma2, gbeta2, sink, hw, c, flags, alpha, ppb2);    \
   } while (0)
