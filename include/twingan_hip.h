@@ -390,12 +390,16 @@ int tg_spectral_norm_bwd(const float* g_wbar, const float* w, const float* u, co
  * beta = tf.nn.softmax(s), o = tf.matmul(beta, h)) without materialising the [len x len] map: q = f [n, len, dk],
  * k = g [n, len, dk], v = h [n, len, dv], o [n, len, dv]; 16-bit storage, fp32 softmax statistics and accumulation.
  * The kernels fetch their per-tile MFMA operands from fragment-ordered copies of v / d_o (and transposes of q / k) that
- * the entry points build themselves in `workspace` (tg_flash_attention_workspace_bytes(n, len, dk, dv, backward) bytes of
+ * the entry points build themselves in `workspace` (tg_flash_attention_workspace_bytes(n, len, dk, dv, pass) bytes -- pass 0: fwd, 1: bwd, 2: bwd_bwd -- of
  * device memory, 256-byte aligned, contents undefined afterwards; 0 = unsupported shape).
  * tg_flash_attention_supported: len % 128 == 0, dk in {8, 16}, dv in {64, 128, 256}.
  * fwd: writes o and lse [n, len] fp32 (log-sum-exp of every query's scores, saved for the backward).
  * bwd (first order; the gradient-penalty double backward keeps the tg_batched_gemm / tg_softmax_rows composition):
  * given d_o, o, lse writes dq, dk_out [n, len, dk] and dv_out [n, len, dv]; dv in {64, 128}.
+ * bwd_bwd (the gradient penalty differentiates the first-order backward, image_generation.py:414-439): given the
+ * cotangents a_q, a_k [n, len, dk], a_v [n, len, dv] of (dq, dk_out, dv_out) writes the gradients of their sum of products
+ * with respect to q, k, v and d_o (adj_q, adj_k [n, len, dk]; adj_v, adj_do [n, len, dv]); dv in {64, 128};
+ * workspace: tg_flash_attention_workspace_bytes(..., 2).
  * tg_transpose16: [batch, rows, cols] -> [batch, cols, rows] of 16-bit elements. */
 int tg_transpose16(const void* src, void* dst, int batch, int rows, int cols, void* stream);
 int tg_flash_attention_supported(int len, int dk, int dv);
@@ -405,6 +409,9 @@ int tg_flash_attention_fwd(const void* q, const void* k, const void* v, void* o,
 int tg_flash_attention_bwd(const void* q, const void* k, const void* v, const void* d_o, const void* o, const float* lse,
                            void* workspace, void* dq, void* dk_out, void* dv_out, int n, int len, int dk, int dv, int dtype,
                            void* stream);
+int tg_flash_attention_bwd_bwd(const void* q, const void* k, const void* v, const void* d_o, const void* o, const float* lse,
+                               const void* a_q, const void* a_k, const void* a_v, void* workspace, void* adj_q, void* adj_k,
+                               void* adj_v, void* adj_do, int n, int len, int dk, int dv, int dtype, void* stream);
 
 /* Gradient all-reduce for callers without torch.distributed (the reference sums its clones' gradients in one process,
  * deployment/model_deploy.py:473-503; with one process per GPU that sum is a sum all-reduce over xGMI): a thin wrapper

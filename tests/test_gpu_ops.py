@@ -1145,20 +1145,44 @@ def test_flash_attention_backward(ops, dtype, n, ln, dk, dv):
     assert rel_l2(host(got), ref) <= rel_l2(host(cmp_), ref) * 1.5 + 1e-4, nm      # at least as close as the composed path
 
 
-def test_flash_attention_second_order(ops):
-  """Under create_graph the flash node's backward is the differentiable composition: the double backward through it
-  equals the one through the batched-GEMM / softmax path."""
+def _attention_second_order_ref(q, k, v, go, aq, ak, av):
+  """Gradients of <dq, aq> + <dk, ak> + <dv, av> (dq, dk, dv = the attention backward) wrt q, k, v, go: torch autograd
+  in float64 on the CPU."""
+  t = [torch.tensor(x, dtype=torch.float64, requires_grad=True) for x in (q, k, v, go)]
+  tq, tk, tv, tg = t
+  o = torch.softmax(tq @ tk.transpose(1, 2), -1) @ tv
+  gq, gk, gv = torch.autograd.grad(o, (tq, tk, tv), tg, create_graph=True)
+  loss = (gq * torch.tensor(aq)).sum() + (gk * torch.tensor(ak)).sum() + (gv * torch.tensor(av)).sum()
+  return [x.numpy() for x in torch.autograd.grad(loss, t)]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('n,ln,dk,dv', [(2, 256, 8, 64), (1, 128, 16, 128)])
+def test_flash_attention_second_order(ops, dtype, n, ln, dk, dv):
+  """The gradient-penalty pattern through a flash node: create_graph backward (FlashAttnBwdFn) and then the backward of
+  that (tg_flash_attention_bwd_bwd), against float64 autograd of the same composition and against the batched-GEMM /
+  softmax path's own double backward."""
   rng = np.random.RandomState(5)
-  n, ln, dk, dv = 1, 128, 8, 64
-  q, k, v = (bf16_round(np.tanh(rng.randn(n, ln, d))) for d in (dk, dk, dv))
-  res = []
+  rnd = bf16_round if dtype == torch.bfloat16 else f16_round
+  q, k = rnd(np.tanh(rng.randn(n, ln, dk))), rnd(np.tanh(rng.randn(n, ln, dk) * 2))
+  v, go = rnd(rng.randn(n, ln, dv)), rnd(rng.randn(n, ln, dv))
+  aq, ak, av = rnd(rng.randn(n, ln, dk)), rnd(rng.randn(n, ln, dk)), rnd(rng.randn(n, ln, dv))
+  ref = _attention_second_order_ref(q, k, v, go, aq, ak, av)
+  res = {}
   for flash in (True, False):
-    qd, kd, vd = (to_dev(t, torch.bfloat16).requires_grad_(True) for t in (q, k, v))
-    o = ops.flash_attention(qd, kd, vd) if flash else ops.bgemm(ops.softmax_rows(ops.bgemm(qd, kd, False, True)), vd, False, False)
-    gq, = torch.autograd.grad(o, qd, torch.ones_like(o), create_graph=True)
-    loss = (gq.float() ** 2).mean()
-    res.append([host(t) for t in torch.autograd.grad(loss, (kd, vd))])
-    with ops.second_order():
-      assert not ops.flash_attention_trainable(qd, vd)
-  for a, b in zip(*res):
-    assert rel_l2(a, b) < 2e-2
+    qd, kd, vd, gd = (to_dev(t, dtype).requires_grad_(True) for t in (q, k, v, go))
+    if flash:
+      with ops.second_order():
+        assert ops.flash_attention_trainable(qd, vd) == ops.USE_FLASH_BWD_BWD
+      o = ops.flash_attention(qd, kd, vd)
+    else:
+      o = ops.bgemm(ops.softmax_rows(ops.bgemm(qd, kd, False, True)), vd, False, False)
+    gq, gk, gv = torch.autograd.grad(o, (qd, kd, vd), gd, create_graph=True)
+    loss = (gq.float() * to_dev(aq, torch.float32)).sum() + (gk.float() * to_dev(ak, torch.float32)).sum() + \
+        (gv.float() * to_dev(av, torch.float32)).sum()
+    res[flash] = [host(t) for t in torch.autograd.grad(loss, (qd, kd, vd, gd))]
+  tol = 2.5e-2 if dtype == torch.bfloat16 else 4e-3
+  for got, cmp_, want, nm in zip(res[True], res[False], ref, ('adj q', 'adj k', 'adj v', 'adj dO')):
+    e, ec = rel_l2(got, want), rel_l2(cmp_, want)
+    print('[flash2] %s %s: flash %.2e composed %.2e' % (dtype, nm, e, ec))
+    assert e < tol and e <= ec * 1.5 + 1e-4, (nm, e, ec)

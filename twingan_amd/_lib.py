@@ -52,6 +52,7 @@ SIGNATURES = {
     'tg_flash_attention_workspace_bytes': (ctypes.c_int64, [c_int, c_int, c_int, c_int, c_int]),
     'tg_flash_attention_fwd': (c_int, [_P, _P, _P, _P, _FP, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'tg_flash_attention_bwd': (c_int, [_P] * 5 + [_FP] + [_P] * 4 + [c_int, c_int, c_int, c_int, c_int, _P]),
+    'tg_flash_attention_bwd_bwd': (c_int, [_P] * 5 + [_FP] + [_P] * 8 + [c_int, c_int, c_int, c_int, c_int, _P]),
     'tg_comm_unique_id_bytes': (c_int, []),
     'tg_comm_unique_id': (c_int, [_P]),
     'tg_comm_init': (c_int, [_P, c_int, c_int, POINTER(c_void_p)]),

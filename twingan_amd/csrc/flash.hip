@@ -434,6 +434,286 @@ __global__ __launch_bounds__(256) void flash_bwd_kv_kernel(const bf16* __restric
   store_feat<F16>(dk_out + krow * g.dk, g.dk, kgrp, acck);
 }
 
+// ------------------------------------------------------------------------------------------------
+// SECOND ORDER: the backward of the first-order backward (the gradient penalty differentiates d pred / d x, i.e. the
+// (dq, dk, dv) above as functions of (q, k, v, dO), image_generation.py:414-439).  Given the cotangents (aQ, aK, aV) of
+// (dQ, dK, dV):
+//   gP = dO V^T,  D = rowsum(P o gP),  gS = P o (gP - D)                       (the first-order quantities)
+//   W = aQ K^T + Q aK^T,  E = rowsum(P o W),  T = P o (W - E)                  (T: adjoint of gP)
+//   Y = dO aV^T,  X = Y + W o (gP - D) - E gP,  F = rowsum(P o X),  U = P o (X - F)   (X, U: adjoints of P, S)
+//   adj Q = gS aK + U K,  adj K = gS^T aQ + U^T Q,  adj V = T^T dO,  adj dO = P aV + T V
+// (checked against autograd in float64).  Three kernels in the first-order kernels' two orientations: a statistics
+// pass (E, F = rowsum(P o Y) + rowsum(P o W o gP) - 2 D E per query), the query-side pass (adj Q, adj dO) and the
+// key-side pass (adj K, adj V); every [N x N] quantity lives in one 32 x 32 MFMA accumulator at a time.
+// ------------------------------------------------------------------------------------------------
+template <int DVB, bool F16>
+__global__ __launch_bounds__(256) void flash_bb_stats_kernel(const bf16* __restrict__ q16, const bf16* __restrict__ k16,
+                                                             const bf16* __restrict__ aq16, const bf16* __restrict__ ak16,
+                                                             const bf16* __restrict__ vpr, const bf16* __restrict__ avpr,
+                                                             const bf16* __restrict__ d_o, const float* __restrict__ lse2,
+                                                             const float* __restrict__ dvec, float* __restrict__ e_out,
+                                                             float* __restrict__ f_out, const FlashGeom g) {
+  constexpr int KT = DVB * 2;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, kgrp = lane >> 5, l31 = lane & 31;
+  const int img = blockIdx.y, nb = g.len >> 5;
+  const int q0 = (blockIdx.x * 4 + wid) * 32;
+  const size_t row = (size_t)img * g.len + q0 + l31;
+  const unsigned lfeat = l31 * 16 + 8 * kgrp, lfrag = lane * 8;
+  const bf16* ki = k16 + (size_t)img * g.len * 16;
+  const bf16* aki = ak16 + (size_t)img * g.len * 16;
+  const bf16* vi = vpr + (size_t)img * g.len * g.dv;
+  const bf16* avi = avpr + (size_t)img * g.len * g.dv;
+  const bf16x8 qf = load_frag(q16 + ((size_t)img * g.len + q0) * 16 + lfeat);
+  const bf16x8 aqf = load_frag(aq16 + ((size_t)img * g.len + q0) * 16 + lfeat);
+  const float lse_q = lse2[row];
+  bf16x8 gof[KT];      // B operand of gP^T = V dO^T and Y^T = aV dO^T
+#pragma unroll
+  for (int t = 0; t < KT; ++t) gof[t] = load_frag(d_o + row * g.dv + 16 * t + 8 * kgrp);
+  f32x16 zero;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+  float e = 0.f, h = 0.f, jj = 0.f;
+  for (int kb = 0; kb < nb; ++kb) {
+    const bf16x8 kf = load_frag(ki + (size_t)kb * 512 + lfeat), akf = load_frag(aki + (size_t)kb * 512 + lfeat);
+    bf16x8 vf[KT], avf[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      vf[c] = load_frag(vi + ((size_t)kb * KT + c) * 512 + lfrag);
+      avf[c] = load_frag(avi + ((size_t)kb * KT + c) * 512 + lfrag);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x16 s = mfma_32x32x16<F16>(kf, qf, zero);                       // S^T[key][query]
+    f32x16 w = mfma_32x32x16<F16>(kf, aqf, zero);                            // W^T = K aQ^T + aK Q^T
+    w = mfma_32x32x16<F16>(akf, qf, w);
+    f32x16 gp = zero, y = zero;
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      gp = mfma_32x32x16<F16>(vf[c], gof[c], gp);                           // gP^T = V dO^T
+      y = mfma_32x32x16<F16>(avf[c], gof[c], y);                            // Y^T = aV dO^T
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = exp2_sub(s[r], lse_q), pw = p * w[r];
+      e += pw;
+      h = fmaf(pw, gp[r], h);
+      jj = fmaf(p, y[r], jj);
+    }
+  }
+  e += __shfl_xor(e, 32, 64);
+  h += __shfl_xor(h, 32, 64);
+  jj += __shfl_xor(jj, 32, 64);
+  if (kgrp == 0) {
+    e_out[row] = e;
+    f_out[row] = jj + h - 2.f * dvec[row] * e;
+  }
+}
+
+// query side: adj Q = gS aK + U K,  adj dO = P aV + T V.  kpc / akpc / vpc / avpc: "columns" packings
+template <int DVB, bool F16>
+__global__ __launch_bounds__(256) void flash_bb_q_kernel(const bf16* __restrict__ q16, const bf16* __restrict__ k16,
+                                                         const bf16* __restrict__ aq16, const bf16* __restrict__ ak16,
+                                                         const bf16* __restrict__ vpr, const bf16* __restrict__ avpr,
+                                                         const bf16* __restrict__ kpc, const bf16* __restrict__ akpc,
+                                                         const bf16* __restrict__ vpc, const bf16* __restrict__ avpc,
+                                                         const bf16* __restrict__ d_o, const float* __restrict__ lse2,
+                                                         const float* __restrict__ dvec, const float* __restrict__ evec,
+                                                         const float* __restrict__ fvec, bf16* __restrict__ adj_q,
+                                                         bf16* __restrict__ adj_do, const FlashGeom g) {
+  constexpr int KT = DVB * 2;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, kgrp = lane >> 5, l31 = lane & 31;
+  const int img = blockIdx.y, nb = g.len >> 5;
+  const int q0 = (blockIdx.x * 4 + wid) * 32;
+  const size_t row = (size_t)img * g.len + q0 + l31;
+  const unsigned lfeat = l31 * 16 + 8 * kgrp, lfrag = lane * 8;
+  const bf16* ki = k16 + (size_t)img * g.len * 16;
+  const bf16* aki = ak16 + (size_t)img * g.len * 16;
+  const bf16* vi = vpr + (size_t)img * g.len * g.dv;
+  const bf16* avi = avpr + (size_t)img * g.len * g.dv;
+  const bf16* kci = kpc + (size_t)img * g.len * 32;
+  const bf16* akci = akpc + (size_t)img * g.len * 32;
+  const bf16* vci = vpc + (size_t)img * g.len * g.dv;
+  const bf16* avci = avpc + (size_t)img * g.len * g.dv;
+  const bf16x8 qf = load_frag(q16 + ((size_t)img * g.len + q0) * 16 + lfeat);
+  const bf16x8 aqf = load_frag(aq16 + ((size_t)img * g.len + q0) * 16 + lfeat);
+  const float lse_q = lse2[row], d_q = dvec[row], e_q = evec[row], f_q = fvec[row];
+  bf16x8 gof[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) gof[t] = load_frag(d_o + row * g.dv + 16 * t + 8 * kgrp);
+  f32x16 zero, accq, accg[DVB];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+  accq = zero;
+#pragma unroll
+  for (int d = 0; d < DVB; ++d) accg[d] = zero;
+  for (int kb = 0; kb < nb; ++kb) {
+    const bf16x8 kf = load_frag(ki + (size_t)kb * 512 + lfeat), akf = load_frag(aki + (size_t)kb * 512 + lfeat);
+    bf16x8 vf[KT], avf[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      vf[c] = load_frag(vi + ((size_t)kb * KT + c) * 512 + lfrag);
+      avf[c] = load_frag(avi + ((size_t)kb * KT + c) * 512 + lfrag);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x16 s = mfma_32x32x16<F16>(kf, qf, zero);
+    f32x16 w = mfma_32x32x16<F16>(kf, aqf, zero);
+    w = mfma_32x32x16<F16>(akf, qf, w);
+    f32x16 gp = zero, y = zero;
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      gp = mfma_32x32x16<F16>(vf[c], gof[c], gp);
+      y = mfma_32x32x16<F16>(avf[c], gof[c], y);
+    }
+    // the post-softmax operands of this block: requested here, needed after the element-wise part
+    bf16x8 kcf[2], akcf[2], vcf[DVB][2], avcf[DVB][2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      kcf[st] = load_frag(kci + ((size_t)kb * 2 + st) * 512 + lfrag);
+      akcf[st] = load_frag(akci + ((size_t)kb * 2 + st) * 512 + lfrag);
+#pragma unroll
+      for (int d = 0; d < DVB; ++d) {
+        vcf[d][st] = load_frag(vci + (((size_t)d * nb + kb) * 2 + st) * 512 + lfrag);
+        avcf[d][st] = load_frag(avci + (((size_t)d * nb + kb) * 2 + st) * 512 + lfrag);
+      }
+    }
+    float pv[16], gs[16], tv[16], uv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = exp2_sub(s[r], lse_q), gpd = gp[r] - d_q;
+      pv[r] = p;
+      gs[r] = p * gpd;
+      tv[r] = p * (w[r] - e_q);
+      const float x = fmaf(w[r], gpd, y[r]) - e_q * gp[r];
+      uv[r] = p * (x - f_q);
+    }
+    bf16x8 pb[2], gsb[2], tb[2], ub[2];
+    acc_to_b<F16>(pv, pb);
+    acc_to_b<F16>(gs, gsb);
+    acc_to_b<F16>(tv, tb);
+    acc_to_b<F16>(uv, ub);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      accq = mfma_32x32x16<F16>(akcf[st], gsb[st], accq);      // adj Q^T += aK^T gS^T
+      accq = mfma_32x32x16<F16>(kcf[st], ub[st], accq);        //          + K^T U^T
+#pragma unroll
+      for (int d = 0; d < DVB; ++d) {
+        accg[d] = mfma_32x32x16<F16>(avcf[d][st], pb[st], accg[d]);      // adj dO^T += aV^T P^T
+        accg[d] = mfma_32x32x16<F16>(vcf[d][st], tb[st], accg[d]);       //           + V^T T^T
+      }
+    }
+  }
+  store_feat<F16>(adj_q + row * g.dk, g.dk, kgrp, accq);
+#pragma unroll
+  for (int d = 0; d < DVB; ++d) {
+    float vals[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vals[r] = accg[d][r];
+    store_block<F16>(adj_do + row * g.dv + 32 * d, kgrp, vals);
+  }
+}
+
+// key side: adj K = gS^T aQ + U^T Q,  adj V = T^T dO.  qpc / aqpc / dopc: "columns" packings, dopr: "rows" packing of dO
+template <int DVB, bool F16>
+__global__ __launch_bounds__(256) void flash_bb_kv_kernel(const bf16* __restrict__ q16, const bf16* __restrict__ k16,
+                                                          const bf16* __restrict__ aq16, const bf16* __restrict__ ak16,
+                                                          const bf16* __restrict__ v, const bf16* __restrict__ av,
+                                                          const bf16* __restrict__ qpc, const bf16* __restrict__ aqpc,
+                                                          const bf16* __restrict__ dopr, const bf16* __restrict__ dopc,
+                                                          const float* __restrict__ lse2, const float* __restrict__ dvec,
+                                                          const float* __restrict__ evec, const float* __restrict__ fvec,
+                                                          bf16* __restrict__ adj_k, bf16* __restrict__ adj_v,
+                                                          const FlashGeom g) {
+  constexpr int KT = DVB * 2;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, kgrp = lane >> 5, l31 = lane & 31;
+  const int img = blockIdx.y, nb = g.len >> 5;
+  const int key0 = (blockIdx.x * 4 + wid) * 32;
+  const size_t krow = (size_t)img * g.len + key0 + l31;
+  const unsigned lfeat = l31 * 16 + 8 * kgrp, lfrag = lane * 8;
+  const bf16* qi = q16 + (size_t)img * g.len * 16;
+  const bf16* aqi = aq16 + (size_t)img * g.len * 16;
+  const bf16* dri = dopr + (size_t)img * g.len * g.dv;
+  const bf16* dci = dopc + (size_t)img * g.len * g.dv;
+  const bf16* qci = qpc + (size_t)img * g.len * 32;
+  const bf16* aqci = aqpc + (size_t)img * g.len * 32;
+  const size_t soff = (size_t)img * g.len + 4 * kgrp;
+  const bf16x8 kfb = load_frag(k16 + ((size_t)img * g.len + key0) * 16 + lfeat);      // B operands: this wave's keys
+  const bf16x8 akfb = load_frag(ak16 + ((size_t)img * g.len + key0) * 16 + lfeat);
+  bf16x8 vfb[KT], avfb[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    vfb[t] = load_frag(v + krow * g.dv + 16 * t + 8 * kgrp);
+    avfb[t] = load_frag(av + krow * g.dv + 16 * t + 8 * kgrp);
+  }
+  f32x16 zero, acck, accv[DVB];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+  acck = zero;
+#pragma unroll
+  for (int d = 0; d < DVB; ++d) accv[d] = zero;
+  for (int qb = 0; qb < nb; ++qb) {
+    const bf16x8 qfa = load_frag(qi + (size_t)qb * 512 + lfeat), aqfa = load_frag(aqi + (size_t)qb * 512 + lfeat);
+    bf16x8 gofa[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) gofa[c] = load_frag(dri + ((size_t)qb * KT + c) * 512 + lfrag);
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x16 s = mfma_32x32x16<F16>(qfa, kfb, zero);             // S[query][key]
+    f32x16 w = mfma_32x32x16<F16>(aqfa, kfb, zero);                  // W = aQ K^T + Q aK^T
+    w = mfma_32x32x16<F16>(qfa, akfb, w);
+    f32x16 gp = zero, y = zero;
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      gp = mfma_32x32x16<F16>(gofa[c], vfb[c], gp);                  // gP = dO V^T
+      y = mfma_32x32x16<F16>(gofa[c], avfb[c], y);                   // Y = dO aV^T
+    }
+    bf16x8 qcf[2], aqcf[2], gocf[DVB][2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      qcf[st] = load_frag(qci + ((size_t)qb * 2 + st) * 512 + lfrag);
+      aqcf[st] = load_frag(aqci + ((size_t)qb * 2 + st) * 512 + lfrag);
+#pragma unroll
+      for (int d = 0; d < DVB; ++d) gocf[d][st] = load_frag(dci + (((size_t)d * nb + qb) * 2 + st) * 512 + lfrag);
+    }
+    // per accumulator ROW = per query of the block: rows 8 j + 4 kgrp + 0..3
+    float gs[16], tv[16], uv[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 lr = *reinterpret_cast<const float4*>(lse2 + soff + 32 * qb + 8 * j);
+      const float4 dr = *reinterpret_cast<const float4*>(dvec + soff + 32 * qb + 8 * j);
+      const float4 er = *reinterpret_cast<const float4*>(evec + soff + 32 * qb + 8 * j);
+      const float4 fr = *reinterpret_cast<const float4*>(fvec + soff + 32 * qb + 8 * j);
+      const float lrv[4] = {lr.x, lr.y, lr.z, lr.w}, drv[4] = {dr.x, dr.y, dr.z, dr.w};
+      const float erv[4] = {er.x, er.y, er.z, er.w}, frv[4] = {fr.x, fr.y, fr.z, fr.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * j + i;
+        const float p = exp2_sub(s[r], lrv[i]), gpd = gp[r] - drv[i];
+        gs[r] = p * gpd;
+        tv[r] = p * (w[r] - erv[i]);
+        const float x = fmaf(w[r], gpd, y[r]) - erv[i] * gp[r];
+        uv[r] = p * (x - frv[i]);
+      }
+    }
+    bf16x8 gsb[2], tb[2], ub[2];
+    acc_to_b<F16>(gs, gsb);
+    acc_to_b<F16>(tv, tb);
+    acc_to_b<F16>(uv, ub);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      acck = mfma_32x32x16<F16>(aqcf[st], gsb[st], acck);      // adj K^T += aQ^T gS
+      acck = mfma_32x32x16<F16>(qcf[st], ub[st], acck);        //          + Q^T U
+#pragma unroll
+      for (int d = 0; d < DVB; ++d) accv[d] = mfma_32x32x16<F16>(gocf[d][st], tb[st], accv[d]);      // adj V^T += dO^T T
+    }
+  }
+  store_feat<F16>(adj_k + krow * g.dk, g.dk, kgrp, acck);
+#pragma unroll
+  for (int d = 0; d < DVB; ++d) {
+    float vals[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vals[r] = accv[d][r];
+    store_block<F16>(adj_v + krow * g.dv + 32 * d, kgrp, vals);
+  }
+}
+
 // [n][rows][cols] -> [n][cols][rows], 16-bit elements, 32 x 32 tiles through LDS
 __global__ __launch_bounds__(256) void transpose16_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst,
                                                           int rows, int cols) {
@@ -455,10 +735,13 @@ namespace {
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 struct FlashWorkspace {      // offsets into the caller's workspace
-  size_t q16, k16, v_pc, v_pr, do_pr, do_pc, q_pc, k_pc, dvec, lse2, total;
+  size_t q16, k16, v_pc, v_pr, do_pr, do_pc, q_pc, k_pc, dvec, lse2;
+  size_t aq16, ak16, av_pr, av_pc, aq_pc, ak_pc, evec, fvec;      // second order only
+  size_t total;
 };
 
-FlashWorkspace flash_workspace(int n, int len, int dk, int dv, bool backward) {
+// pass: 0 = forward, 1 = first-order backward, 2 = second-order backward
+FlashWorkspace flash_workspace(int n, int len, int dk, int dv, int pass) {
   const size_t big = align256((size_t)n * len * dv * 2), pad = align256((size_t)n * len * 16 * 2);
   const size_t cols = align256((size_t)n * len * 32 * 2), vec = align256((size_t)n * len * 4);
   FlashWorkspace w = {};
@@ -470,7 +753,7 @@ FlashWorkspace flash_workspace(int n, int len, int dk, int dv, bool backward) {
   };
   w.q16 = take(dk == 8 ? pad : 0);      // d_qk = 16: the tensors themselves
   w.k16 = take(dk == 8 ? pad : 0);
-  if (!backward) {
+  if (pass == 0) {
     w.v_pc = take(big);
   } else {
     w.v_pr = take(big);
@@ -480,6 +763,17 @@ FlashWorkspace flash_workspace(int n, int len, int dk, int dv, bool backward) {
     w.k_pc = take(cols);
     w.dvec = take(vec);
     w.lse2 = take(vec);
+  }
+  if (pass == 2) {
+    w.aq16 = take(dk == 8 ? pad : 0);
+    w.ak16 = take(dk == 8 ? pad : 0);
+    w.v_pc = take(big);
+    w.av_pr = take(big);
+    w.av_pc = take(big);
+    w.aq_pc = take(cols);
+    w.ak_pc = take(cols);
+    w.evec = take(vec);
+    w.fvec = take(vec);
   }
   w.total = at;
   return w;
@@ -525,7 +819,7 @@ int tg_flash_attention_supported(int len, int dk, int dv) {
 
 int64_t tg_flash_attention_workspace_bytes(int n, int len, int dk, int dv, int backward) {
   if (n <= 0 || !tg_flash_attention_supported(len, dk, dv)) return 0;
-  return (int64_t)flash_workspace(n, len, dk, dv, backward != 0).total;
+  return (int64_t)flash_workspace(n, len, dk, dv, backward < 0 ? 0 : (backward > 2 ? 2 : backward)).total;
 }
 
 int tg_flash_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, void* workspace, int n, int len,
@@ -538,7 +832,7 @@ int tg_flash_attention_fwd(const void* q, const void* k, const void* v, void* o,
   g.n = n; g.len = len; g.dk = dk; g.dv = dv;
   const dim3 grid(len / 128, n);
   hipStream_t s = (hipStream_t)stream;
-  const FlashWorkspace w = flash_workspace(n, len, dk, dv, false);
+  const FlashWorkspace w = flash_workspace(n, len, dk, dv, 0);
   char* ws = (char*)workspace;
   const int64_t rows = (int64_t)n * len;
   const bf16 *q16 = feat16(q, ws + w.q16, rows, dk, s), *k16 = feat16(k, ws + w.k16, rows, dk, s);
@@ -572,7 +866,7 @@ int tg_flash_attention_bwd(const void* q, const void* k, const void* v, const vo
   FlashGeom g;
   g.n = n; g.len = len; g.dk = dk; g.dv = dv;
   hipStream_t s = (hipStream_t)stream;
-  const FlashWorkspace w = flash_workspace(n, len, dk, dv, true);
+  const FlashWorkspace w = flash_workspace(n, len, dk, dv, 1);
   char* ws = (char*)workspace;
   const bf16 *v_pr = (const bf16*)(ws + w.v_pr), *do_pr = (const bf16*)(ws + w.do_pr), *do_pc = (const bf16*)(ws + w.do_pc);
   const bf16 *q_pc = (const bf16*)(ws + w.q_pc), *k_pc = (const bf16*)(ws + w.k_pc);
@@ -609,6 +903,62 @@ int tg_flash_attention_bwd(const void* q, const void* k, const void* v, const vo
 #undef TG_FLB2
 #undef TG_FLB
   TG_LAUNCH_CHECK("tg_flash_attention_bwd");
+  return TG_OK;
+}
+
+int tg_flash_attention_bwd_bwd(const void* q, const void* k, const void* v, const void* d_o, const void* o, const float* lse,
+                               const void* a_q, const void* a_k, const void* a_v, void* workspace, void* adj_q, void* adj_k,
+                               void* adj_v, void* adj_do, int n, int len, int dk, int dv, int dtype, void* stream) {
+  TG_CHECK(q && k && v && d_o && o && lse && a_q && a_k && a_v && workspace && adj_q && adj_k && adj_v && adj_do && n > 0,
+           TG_EINVAL, "tg_flash_attention_bwd_bwd: bad arguments");
+  TG_CHECK(tg_flash_attention_supported(len, dk, dv) && dv <= 128, TG_ENOSUP,
+           "tg_flash_attention_bwd_bwd: len %% 128 == 0, d_qk in {8, 16}, d_v in {64, 128} (got %d, %d, %d)", len, dk, dv);
+  TG_CHECK(dtype == TG_BF16 || dtype == TG_F16, TG_ENOSUP, "tg_flash_attention_bwd_bwd: 16-bit storage only");
+  FlashGeom g;
+  g.n = n; g.len = len; g.dk = dk; g.dv = dv;
+  hipStream_t s = (hipStream_t)stream;
+  const FlashWorkspace w = flash_workspace(n, len, dk, dv, 2);
+  char* ws = (char*)workspace;
+  auto at = [&](size_t off) { return (const bf16*)(ws + off); };
+  float *dvec = (float*)(ws + w.dvec), *lse2 = (float*)(ws + w.lse2), *evec = (float*)(ws + w.evec), *fvec = (float*)(ws + w.fvec);
+  const int64_t rows = (int64_t)n * len;
+  const bf16 *q16 = feat16(q, ws + w.q16, rows, dk, s), *k16 = feat16(k, ws + w.k16, rows, dk, s);
+  const bf16 *aq16 = feat16(a_q, ws + w.aq16, rows, dk, s), *ak16 = feat16(a_k, ws + w.ak16, rows, dk, s);
+  launch_pack_rows(v, ws + w.v_pr, rows, dv, s);
+  launch_pack_rows(a_v, ws + w.av_pr, rows, dv, s);
+  launch_pack_rows(d_o, ws + w.do_pr, rows, dv, s);
+  launch_pack_cols(v, ws + w.v_pc, n, len, dv, s);
+  launch_pack_cols(a_v, ws + w.av_pc, n, len, dv, s);
+  launch_pack_cols(d_o, ws + w.do_pc, n, len, dv, s);
+  launch_pack_cols(q, ws + w.q_pc, n, len, dk, s);
+  launch_pack_cols(k, ws + w.k_pc, n, len, dk, s);
+  launch_pack_cols(a_q, ws + w.aq_pc, n, len, dk, s);
+  launch_pack_cols(a_k, ws + w.ak_pc, n, len, dk, s);
+  if (dtype == TG_F16)
+    hipLaunchKernelGGL(flash_rowdot_kernel<f16>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, (const f16*)d_o,
+                       (const f16*)o, lse, dvec, lse2, rows, dv);
+  else
+    hipLaunchKernelGGL(flash_rowdot_kernel<bf16>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, (const bf16*)d_o,
+                       (const bf16*)o, lse, dvec, lse2, rows, dv);
+  const dim3 grid(len / 128, n);
+#define TG_FBB(DVB_, F16_)                                                                                               \
+  do {                                                                                                                   \
+    hipLaunchKernelGGL((flash_bb_stats_kernel<DVB_, F16_>), grid, dim3(256), 0, s, q16, k16, aq16, ak16, at(w.v_pr),      \
+                       at(w.av_pr), (const bf16*)d_o, lse2, dvec, evec, fvec, g);                                         \
+    hipLaunchKernelGGL((flash_bb_q_kernel<DVB_, F16_>), grid, dim3(256), 0, s, q16, k16, aq16, ak16, at(w.v_pr),          \
+                       at(w.av_pr), at(w.k_pc), at(w.ak_pc), at(w.v_pc), at(w.av_pc), (const bf16*)d_o, lse2, dvec, evec, \
+                       fvec, (bf16*)adj_q, (bf16*)adj_do, g);                                                             \
+    hipLaunchKernelGGL((flash_bb_kv_kernel<DVB_, F16_>), grid, dim3(256), 0, s, q16, k16, aq16, ak16, (const bf16*)v,     \
+                       (const bf16*)a_v, at(w.q_pc), at(w.aq_pc), at(w.do_pr), at(w.do_pc), lse2, dvec, evec, fvec,       \
+                       (bf16*)adj_k, (bf16*)adj_v, g);                                                                    \
+  } while (0)
+  const bool f16 = dtype == TG_F16;
+  if (dv == 64 && f16) TG_FBB(2, true);
+  else if (dv == 64) TG_FBB(2, false);
+  else if (f16) TG_FBB(4, true);
+  else TG_FBB(4, false);
+#undef TG_FBB
+  TG_LAUNCH_CHECK("tg_flash_attention_bwd_bwd");
   return TG_OK;
 }
 

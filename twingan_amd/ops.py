@@ -67,6 +67,9 @@ USE_CONV_POOL = os.environ.get('TG_CONV_POOL', '1') != '0'
 # self-attention's score / softmax / value products as the flash kernels in first-order passes (TG_FLASH_ATTENTION=0: the
 # batched-GEMM + row-softmax composition everywhere)
 USE_FLASH_ATTENTION = os.environ.get('TG_FLASH_ATTENTION', '1') != '0'
+# the gradient-penalty pass through an attention layer on the flash kernels too (forward, differentiable first-order
+# backward, second-order backward); TG_FLASH_BWD_BWD=0: that pass keeps the batched-GEMM / softmax composition
+USE_FLASH_BWD_BWD = os.environ.get('TG_FLASH_BWD_BWD', '1') != '0'
 
 class PackCache:
   """bf16 K-contiguous packs (tg_conv2d_pack_weights) of registered master weights.
@@ -1445,9 +1448,10 @@ def flash_attention_supported(q, v):
   return q.dtype in HALF_TYPES and bool(_lib.load().tg_flash_attention_supported(q.shape[1], q.shape[2], v.shape[2]))
 
 
-def _flash_workspace(q, v, backward):
+def _flash_workspace(q, v, which):
+  """which: 0 forward, 1 first-order backward, 2 second-order backward."""
   n, ln, dk = q.shape
-  nbytes = int(_lib.load().tg_flash_attention_workspace_bytes(n, ln, dk, v.shape[2], int(backward)))
+  nbytes = int(_lib.load().tg_flash_attention_workspace_bytes(n, ln, dk, v.shape[2], int(which)))
   assert nbytes > 0, 'flash attention: unsupported shape %s / %s' % (tuple(q.shape), tuple(v.shape))
   return torch.empty(nbytes, dtype=torch.uint8, device=q.device)
 
@@ -1457,7 +1461,7 @@ def flash_attention_fwd_raw(q, k, v):
   _chk(q, k, v)
   n, ln, dk = q.shape
   dv = v.shape[2]
-  ws = _flash_workspace(q, v, False)
+  ws = _flash_workspace(q, v, 0)
   o = torch.empty((n, ln, dv), dtype=q.dtype, device=q.device)
   lse = torch.empty((n, ln), dtype=torch.float32, device=q.device)
   call('tg_flash_attention_fwd', _p(q), _p(k), _p(v), _p(o), _p(lse), _p(ws), n, ln, dk, dv, _dt(q), _stream(),
@@ -1485,13 +1489,55 @@ def in_second_order():
 
 
 def flash_attention_trainable(q, v):
-  return flash_attention_supported(q, v) and v.shape[2] <= 128 and not in_second_order()
+  """Forward + first-order backward (+ second-order backward, USE_FLASH_BWD_BWD) exist as flash kernels for this shape."""
+  return flash_attention_supported(q, v) and v.shape[2] <= 128 and (USE_FLASH_BWD_BWD or not in_second_order())
+
+
+def _flash_bwd_raw(q, k, v, o, lse, go):
+  n, ln, dk = q.shape
+  dv = v.shape[2]
+  gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+  ws = _flash_workspace(q, v, 1)
+  call('tg_flash_attention_bwd', _p(q), _p(k), _p(v), _p(go), _p(o), _p(lse), _p(ws), _p(gq), _p(gk), _p(gv), n, ln, dk,
+       dv, _dt(q), _stream(),
+       work=('flash_bwd:len%d:dk%d:dv%d:n%d' % (ln, dk, dv, n), 2 * n * ln * ln * (3 * dk + 3 * dv), _nb(q, k, v, o, go, gq, gk, gv)))
+  return gq, gk, gv
+
+
+class FlashAttnBwdFn(torch.autograd.Function):
+  """The first-order backward of FlashAttnFn as a differentiable node (create_graph passes: the gradient penalty,
+  image_generation.py:414-439): (q, k, v, dO) -> (dq, dk, dv) with o / lse as saved constants of the forward; its own
+  backward is tg_flash_attention_bwd_bwd, which accounts for o / lse through q, k, v."""
+
+  @staticmethod
+  def forward(ctx, q, k, v, o, lse, go):
+    ctx.save_for_backward(q, k, v, o, lse, go)
+    return _flash_bwd_raw(q, k, v, o, lse, go)
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, aq, ak, av):
+    q, k, v, o, lse, go = ctx.saved_tensors
+    n, ln, dk = q.shape
+    dv = v.shape[2]
+    aq = torch.zeros_like(q) if aq is None else aq.contiguous()
+    ak = torch.zeros_like(k) if ak is None else ak.contiguous()
+    av = torch.zeros_like(v) if av is None else av.contiguous()
+    _chk(aq, ak, av)
+    adj_q, adj_k, adj_v, adj_go = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), torch.empty_like(go)
+    ws = _flash_workspace(q, v, 2)
+    call('tg_flash_attention_bwd_bwd', _p(q), _p(k), _p(v), _p(go), _p(o), _p(lse), _p(aq), _p(ak), _p(av), _p(ws),
+         _p(adj_q), _p(adj_k), _p(adj_v), _p(adj_go), n, ln, dk, dv, _dt(q), _stream(),
+         work=('flash_bwd_bwd:len%d:dk%d:dv%d:n%d' % (ln, dk, dv, n), 2 * n * ln * ln * (8 * dk + 10 * dv),
+               _nb(q, k, v, o, go, aq, ak, av, adj_q, adj_k, adj_v, adj_go)))
+    return adj_q, adj_k, adj_v, None, None, adj_go
 
 
 class FlashAttnFn(torch.autograd.Function):
   """softmax(q k^T) v of libs/self_attention.py:56-63 without the [len, len] map in HBM (csrc/flash.hip): forward saves the
-  per-query log-sum-exp; the first-order backward recomputes the probabilities tile by tile.  Under create_graph the
-  backward is built from the differentiable batched-GEMM / softmax ops instead (materialises the map)."""
+  per-query log-sum-exp; the backward recomputes the probabilities tile by tile.  Under create_graph the backward is the
+  differentiable FlashAttnBwdFn (or, with TG_FLASH_BWD_BWD=0, the batched-GEMM / softmax composition, which materialises
+  the map)."""
 
   @staticmethod
   def forward(ctx, q, k, v):
@@ -1504,19 +1550,14 @@ class FlashAttnFn(torch.autograd.Function):
     q, k, v, o, lse = ctx.saved_tensors
     go = go.contiguous()
     if torch.is_grad_enabled():
+      if USE_FLASH_BWD_BWD:
+        return FlashAttnBwdFn.apply(q, k, v, o.detach(), lse, go)
       p = softmax_rows(bgemm(q, k, False, True))
       gv = bgemm(p, go, True, False)
       gs = SoftmaxRowsBwdFn.apply(p, bgemm(go, v, False, True))
       return bgemm(gs, k, False, False), bgemm(gs, q, True, False), gv
     _chk(go)
-    n, ln, dk = q.shape
-    dv = v.shape[2]
-    gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    ws = _flash_workspace(q, v, True)
-    call('tg_flash_attention_bwd', _p(q), _p(k), _p(v), _p(go), _p(o), _p(lse), _p(ws), _p(gq), _p(gk), _p(gv), n, ln, dk,
-         dv, _dt(q), _stream(),
-         work=('flash_bwd:len%d:dk%d:dv%d:n%d' % (ln, dk, dv, n), 2 * n * ln * ln * (3 * dk + 3 * dv), _nb(q, k, v, o, go, gq, gk, gv)))
-    return gq, gk, gv
+    return _flash_bwd_raw(q, k, v, o, lse, go)
 
 
 def flash_attention(q, k, v):
