@@ -1,5 +1,6 @@
 // SAGAN self-attention (libs/self_attention.py:24-70: s = f g^T over the h*w positions, beta = softmax(s), o = beta h)
-// without the [N x N] map: flash-style forward and first-order backward on the MFMA units.
+// without the [N x N] map: flash-style forward, first-order backward and second-order backward (the gradient penalty's)
+// on the MFMA units.
 //
 // Shapes of the layer: N = h*w positions (4096 at 64x64), d_qk = c/8 (8 or 16), d_v = c (64..256).  All three kernels
 // put the SOFTMAX ROWS' OWNERS ON THE LANES so that no reduction crosses lanes:
