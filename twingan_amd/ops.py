@@ -1475,7 +1475,8 @@ class _SecondOrder(object):
 
 class second_order(object):
   """Marks a forward pass whose backward is itself differentiated (the gradient-penalty pass of the discriminator,
-  image_generation.py:414-439): layers with a first-order-only fused kernel build their differentiable composition."""
+  image_generation.py:414-439): a layer whose fused kernel has no second-order backward builds its differentiable
+  composition there (flash attention with TG_FLASH_BWD_BWD=0)."""
 
   def __enter__(self):
     _SecondOrder.depth += 1

@@ -78,8 +78,8 @@ def self_attention_layer(P, sc, layer, domain, cfg, is_discriminator, cond=None)
   positions, beta = softmax(s), o = beta h, y = sa_gamma * o + layer.  The two batched matrix products are the MFMA
   batched GEMM of csrc/attention.hip, softmax / tanh / the sa_gamma scale its row and pointwise kernels; every op's
   backward is made of the same ops, so the layer is differentiable twice on them (the discriminator sits under the
-  gradient penalty).  First-order passes at supported shapes run the three map ops as the flash kernels of
-  csrc/flash.hip (ops.flash_attention), which never write the [h*w, h*w] map."""
+  gradient penalty).  At supported shapes the three map ops run as the flash kernels of csrc/flash.hip
+  (ops.flash_attention: forward, backward and the backward of the backward), which never write the [h*w, h*w] map."""
   n, hh, ww, c = layer.shape
   outs = []
   for nm in ('sa_f', 'sa_g', 'sa_h'):
