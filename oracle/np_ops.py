@@ -373,3 +373,46 @@ def preprocess_image(img_u8, hw, resize_mode='PAD', is_training=True, flip=False
       x = adjust_saturation(x + delta, factor)
     x = np.clip(x, 0.0, 1.0)
   return x
+
+
+# ------------------------------------------------------------------------------------------------
+# SAGAN attention core (libs/self_attention.py:56-63: s = matmul(f, g^T), beta = softmax(s), o = matmul(beta, h)) and the
+# closed forms of its first- and second-order backward that csrc/flash.hip evaluates tile by tile.  The reference gets
+# both from tf.gradients (the gradient penalty, image_generation.py:414-439, differentiates the first backward); these
+# restatements are pinned against float64 autograd of the three ops in tests/test_oracle.py.
+# ------------------------------------------------------------------------------------------------
+def attention_forward(q, k, v):
+  """q, k [n, N, dk], v [n, N, dv] -> (o, p): o = softmax(q k^T) v."""
+  s = np.einsum('nid,njd->nij', q, k)
+  p = np.exp(s - s.max(-1, keepdims=True))
+  p /= p.sum(-1, keepdims=True)
+  return np.einsum('nij,njd->nid', p, v), p
+
+
+def attention_backward(q, k, v, go):
+  """(dq, dk, dv) of <o, go>: gP = go v^T, D = rowsum(P o gP), gS = P o (gP - D)."""
+  _, p = attention_forward(q, k, v)
+  gp = np.einsum('nid,njd->nij', go, v)
+  gs = p * (gp - (p * gp).sum(-1, keepdims=True))
+  return np.einsum('nij,njd->nid', gs, k), np.einsum('nij,nid->njd', gs, q), np.einsum('nij,nid->njd', p, go)
+
+
+def attention_backward_backward(q, k, v, go, aq, ak, av):
+  """Gradients of <dq, aq> + <dk, ak> + <dv, av> with (dq, dk, dv) = attention_backward(q, k, v, go), with respect to
+  q, k, v and go:  W = aq k^T + q ak^T, E = rowsum(P o W), T = P o (W - E);  Y = go av^T,
+  X = Y + W o (gP - D) - E gP, F = rowsum(P o X), U = P o (X - F);
+  adj q = gS ak + U k,  adj k = gS^T aq + U^T q,  adj v = T^T go,  adj go = P av + T v."""
+  _, p = attention_forward(q, k, v)
+  gp = np.einsum('nid,njd->nij', go, v)
+  d = (p * gp).sum(-1, keepdims=True)
+  gs = p * (gp - d)
+  w = np.einsum('nid,njd->nij', aq, k) + np.einsum('nid,njd->nij', q, ak)
+  e = (p * w).sum(-1, keepdims=True)
+  t = p * (w - e)
+  x = np.einsum('nid,njd->nij', go, av) + w * (gp - d) - e * gp
+  u = p * (x - (p * x).sum(-1, keepdims=True))
+  adj_q = np.einsum('nij,njd->nid', gs, ak) + np.einsum('nij,njd->nid', u, k)
+  adj_k = np.einsum('nij,nid->njd', gs, aq) + np.einsum('nij,nid->njd', u, q)
+  adj_v = np.einsum('nij,nid->njd', t, go)
+  adj_go = np.einsum('nij,njd->nid', p, av) + np.einsum('nij,njd->nid', t, v)
+  return adj_q, adj_k, adj_v, adj_go

@@ -1147,7 +1147,8 @@ def test_flash_attention_backward(ops, dtype, n, ln, dk, dv):
 
 def _attention_second_order_ref(q, k, v, go, aq, ak, av):
   """Gradients of <dq, aq> + <dk, ak> + <dv, av> (dq, dk, dv = the attention backward) wrt q, k, v, go: torch autograd
-  in float64 on the CPU."""
+  in float64 on the CPU (oracle/np_ops.attention_backward_backward is the closed form of the same, pinned against this
+  in tests/test_oracle.py)."""
   t = [torch.tensor(x, dtype=torch.float64, requires_grad=True) for x in (q, k, v, go)]
   tq, tk, tv, tg = t
   o = torch.softmax(tq @ tk.transpose(1, 2), -1) @ tv

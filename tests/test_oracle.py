@@ -427,3 +427,23 @@ def test_gemm_forms_of_the_conv_oracle_equal_the_einsum_forms():
     gw = N.conv2d_bwd_weight(x, gy, (k, k), pad)
     assert np.allclose(gw, N.conv2d_bwd_weight_gemm(x, gy, (k, k), pad), atol=1e-12)
     assert np.allclose(gw, N.conv2d_bwd_weight_gemm(x, gy, (k, k), pad, per_image=True).sum(0), atol=1e-12)
+
+
+def test_attention_backward_closed_forms_match_autograd():
+  """oracle/N.attention_backward / attention_backward_backward -- the formulas csrc/flash.hip evaluates tile by
+  tile -- against float64 autograd of matmul -> softmax -> matmul (libs/self_attention.py:56-63), the way the reference
+  obtains them (tf.gradients, twice under the gradient penalty: image_generation.py:414-439)."""
+  rng = np.random.RandomState(2)
+  n, ln, dk, dv = 2, 24, 4, 6
+  q, k, v, go = rng.randn(n, ln, dk), rng.randn(n, ln, dk), rng.randn(n, ln, dv), rng.randn(n, ln, dv)
+  aq, ak, av = rng.randn(n, ln, dk), rng.randn(n, ln, dk), rng.randn(n, ln, dv)
+  tq, tk, tv, tg = (torch.tensor(x, dtype=torch.float64, requires_grad=True) for x in (q, k, v, go))
+  o = torch.softmax(tq @ tk.transpose(1, 2), -1) @ tv
+  assert np.abs(N.attention_forward(q, k, v)[0] - o.detach().numpy()).max() < 1e-12
+  g1 = torch.autograd.grad(o, (tq, tk, tv), tg, create_graph=True)
+  for got, want in zip(N.attention_backward(q, k, v, go), g1):
+    assert np.abs(got - want.detach().numpy()).max() < 1e-12
+  loss = sum((g * torch.tensor(a)).sum() for g, a in zip(g1, (aq, ak, av)))
+  g2 = torch.autograd.grad(loss, (tq, tk, tv, tg))
+  for got, want in zip(N.attention_backward_backward(q, k, v, go, aq, ak, av), g2):
+    assert np.abs(got - want.numpy()).max() < 1e-11
