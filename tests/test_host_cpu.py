@@ -420,3 +420,19 @@ def test_network_registry_has_the_reference_entries():
   assert reg['get_noise_shape'](16, 256) == (16, 1, 1, 256) and reg['get_noise_shape'](None, 16) == (None, 1, 1, 16)
   with pytest.raises(NotImplementedError):
     select_network('cyclegan')
+
+
+def test_flash_attention_host_queries():
+  """The host-only entry points of the flash-attention family answer without a GPU: the supported-shape rule of
+  include/twingan_hip.h and workspace sizes that grow with the pass (forward < backward < backward of the backward), are
+  256-byte multiples and scale with the batch."""
+  from twingan_amd import _lib
+  lib = _lib.load()
+  ok = lambda ln, dk, dv: bool(lib.tg_flash_attention_supported(ln, dk, dv))
+  assert ok(4096, 8, 64) and ok(256, 16, 128) and ok(128, 8, 256)
+  assert not ok(64, 8, 64) and not ok(4096, 4, 64) and not ok(4096, 8, 32) and not ok(4000, 8, 64)
+  ws = lambda n, which, dk=8, dv=64: int(lib.tg_flash_attention_workspace_bytes(n, 4096, dk, dv, which))
+  f, b, bb = ws(16, 0), ws(16, 1), ws(16, 2)
+  assert 0 < f < b < bb and all(x % 256 == 0 for x in (f, b, bb))
+  assert f >= 16 * 4096 * 64 * 2 and ws(32, 2) == 2 * bb          # one packed copy of v at least; linear in n
+  assert ws(16, 1, dk=16) < b + 1 and ws(16, 0, dk=4) == 0         # d_qk = 16 needs no padded q / k copies; unsupported: 0
