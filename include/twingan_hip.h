@@ -37,6 +37,7 @@ extern "C" {
 #define TG_EALIGN (-2)   /* pointer or channel count not aligned as required */
 #define TG_ELAUNCH (-3)  /* hipLaunchKernel reported an error */
 #define TG_ENOSUP (-4)   /* combination not implemented by the selected algorithm */
+#define TG_ECOMM (-5)    /* RCCL reported an error (tg_comm_*, tg_allreduce); tg_last_error() carries its text */
 
 /* Conv algorithm selector */
 #define TG_ALGO_DIRECT 0 /* one thread per output, any shape, f32 or bf16 activations */
@@ -52,6 +53,14 @@ const char* tg_last_error(void);
 /* name of the kernel variant the last conv dispatch on this thread selected (e.g. "conv_tile_kernel<3,32,64,1>");
  * lets host-side timing be attributed to the kernel symbols rocprofv3 reports */
 const char* tg_last_kernel(void);
+/* Deterministic mode (process-wide; default = TG_DETERMINISTIC in the environment, 0 if unset).  The fp32 storage type
+ * always sums in a fixed order; with the mode on, the 16-bit storage types do too: every sum that ends in one number per
+ * channel / sample / tensor is taken by one workgroup or from per-workgroup partials in a fixed order instead of fp32
+ * atomics in arrival order, so two runs of a step are bit-identical (TF's graph has no such switch: the reference's
+ * cuDNN / Eigen reductions are whatever the device scheduled, model/model_inheritor.py:537-571 trains without seeds for
+ * them).  Returns the previous setting.  Do not flip it between capturing and replaying a hipGraph. */
+int tg_set_deterministic(int on);
+int tg_get_deterministic(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution: stride 1, kh,kw <= 4, arbitrary zero padding (pad_t/pad_l on the low side; the
@@ -417,8 +426,8 @@ int tg_flash_attention_bwd_bwd(const void* q, const void* k, const void* v, cons
  * deployment/model_deploy.py:473-503; with one process per GPU that sum is a sum all-reduce over xGMI): a thin wrapper
  * over RCCL, bound lazily (dlopen of $TG_RCCL_PATH, librccl.so.1 or librccl.so at the first call; the library does not
  * link RCCL).  Rank 0 obtains an id (tg_comm_unique_id_bytes() bytes) and distributes it out of band; every rank calls
- * tg_comm_init with its current HIP device set; tg_allreduce sums `count` elements of dtype TG_F32 / TG_BF16 IN PLACE,
- * asynchronously on `stream`. */
+ * tg_comm_init with its current HIP device set; tg_allreduce sums `count` elements of dtype TG_F32 / TG_BF16 / TG_F16 IN
+ * PLACE, asynchronously on `stream`.  An RCCL failure returns TG_ECOMM. */
 int tg_comm_unique_id_bytes(void);
 int tg_comm_unique_id(void* id);
 int tg_comm_init(const void* id, int nranks, int rank, void** comm);

@@ -80,6 +80,9 @@ def run(flags, sources, targets, global_step=0, seed=0, preset=None, want_grads=
   res = dict(
     variables={k: v.t.detach().numpy().copy() for k, v in core.STATE.variables.items()},
     trainable=[k for k, v in core.STATE.variables.items() if v.trainable],
+    # slim.get_model_variables(): what a stage's warm start restores (model/model_inheritor.py:612-614)
+    model_variables=[k for k, v in core.STATE.variables.items()
+                     if any(v is m for m in core.get_collection('model_variables'))],
     random=[(n, t.numpy().copy()) for n, t in core.STATE.random_log],
     g_terms={k: float(v.t) for k, v in g_terms.items()},
     d_terms={k: float(v.t) for k, v in d_terms.items()},

@@ -440,6 +440,15 @@ def variable_scope(name_or_scope, default_name=None, values=None, initializer=No
     eff = inherited if inherited else parent.reuse
   STATE.scope_count[full] = STATE.scope_count.get(full, 0) + 1
   sc = VariableScope(full, eff)
+  # custom getters nest: a scope without its own keeps the enclosing one (or, re-entered, the one it was captured with).
+  # Only getters that mark themselves `layer_getter` are honoured (contrib layers._build_variable_getter, libs/sn.py:
+  # 199-204); the dtype getter of deployment/model_deploy.py:146-183 is the identity for float32 variables and ignored.
+  if custom_getter is not None and getattr(custom_getter, 'layer_getter', False):
+    sc.custom_getter = custom_getter
+  elif isinstance(name_or_scope, VariableScope) and name_or_scope.custom_getter is not None:
+    sc.custom_getter = name_or_scope.custom_getter
+  else:
+    sc.custom_getter = parent.custom_getter
   STATE.scope_stack.append(sc)
   try:
     yield sc
@@ -476,6 +485,12 @@ def name_scope(name=None, default_name=None, values=None):
 def get_variable(name, shape=None, dtype=None, initializer=None, regularizer=None, trainable=True, collections=None,
                  **unused):
   sc = current_scope()
+  if sc.custom_getter is not None and not getattr(STATE, 'in_getter', False):
+    STATE.in_getter = True
+    try:
+      return sc.custom_getter(name, shape, dtype, initializer, regularizer, trainable, collections)
+    finally:
+      STATE.in_getter = False
   full = sc.name + '/' + name if sc.name else name
   if full in STATE.variables:
     if not sc.reuse:
@@ -501,7 +516,7 @@ def get_variable(name, shape=None, dtype=None, initializer=None, regularizer=Non
     t.requires_grad_(bool(trainable))
   v = Variable(full, t, dtype, trainable)
   STATE.variables[full] = v
-  if isinstance(collections, str):
+  if isinstance(collections, str):      # tf.Variable itself rejects a bare string; nothing on the path gets here with one
     collections = [collections]
   keys = list(collections) if collections else ['variables']
   if 'variables' not in keys:

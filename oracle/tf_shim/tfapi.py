@@ -891,6 +891,29 @@ def _unsupported(name):
   return add_arg_scope(fn)
 
 
+class _LayerVariableGetter(object):
+  """contrib layers._build_variable_getter(rename) -> _model_variable_getter: every tf.get_variable made under the
+  layer's scope -- the layer's own kernel / bias AND whatever its call() creates, e.g. the spectral-norm ``u`` of
+  libs/sn.py:56 -- is renamed by its last path component and created through slim's model_variable, which does
+  ``list(collections or []) + [GLOBAL_VARIABLES, MODEL_VARIABLES]`` (so the bare string libs/sn.py passes becomes a
+  list of its characters, and the variable lands in MODEL_VARIABLES all the same)."""
+  layer_getter = True
+
+  def __init__(self, rename=None):
+    self.rename = dict(rename or {})
+
+  def __call__(self, name, shape, dtype, initializer, regularizer, trainable, collections):
+    short = name.split('/')[-1]
+    if short in self.rename:
+      name = '/'.join(name.split('/')[:-1] + [self.rename[short]])
+    return model_variable(name, shape=shape, dtype=dtype or float32, initializer=initializer, regularizer=regularizer,
+                          trainable=trainable, collections=collections)
+
+
+def _build_variable_getter(rename=None):
+  return _LayerVariableGetter(rename)
+
+
 # ---- tf.layers base classes (libs/sn.py subclasses them) ----------------------------------------------------------
 _RENAME = {'kernel': 'weights', 'bias': 'biases'}      # what layers._build_variable_getter({...}) does in contrib
 
@@ -1062,7 +1085,7 @@ def build_modules():
     batch_norm=_unsupported('layers.batch_norm'), layer_norm=_unsupported('layers.layer_norm'),
     instance_norm=_unsupported('layers.instance_norm'), l2_regularizer=l2_regularizer,
     xavier_initializer=core.glorot_uniform_initializer, utils=None,
-    _build_variable_getter=lambda rename=None: None, _add_variable_to_collections=lambda *a, **k: None,
+    _build_variable_getter=_build_variable_getter, _add_variable_to_collections=lambda *a, **k: None,
     core_layers=_module('tensorflow.python.layers.core', Dense=Dense),
     six=_module('six', integer_types=(int, np.integer)), nn=None)
   utils = _module('tensorflow.contrib.layers.python.layers.utils', get_variable_collections=get_variable_collections,

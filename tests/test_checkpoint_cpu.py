@@ -202,10 +202,12 @@ def test_run_progressive_directory_protocol(tmp_path):
 
 
 def test_warm_start_restores_model_variables_only(tmp_path):
-  """slim.get_model_variables() (model_inheritor.py:612-614) does not contain what libs/sn.py:56 and
-  libs/self_attention.py:68 create with tf.get_variable: a stage's warm start leaves spectral-norm ``u`` and
-  ``sa_gamma`` at their fresh initialisation (both the in-memory and the file-based warm start); a full restore of a
-  run (checkpoint.restore) loads them."""
+  """slim.get_model_variables() (model_inheritor.py:612-614) holds everything the layers create -- including the
+  spectral-norm ``u`` (libs/sn.py:56 under the layer scope's model-variable getter, pinned live by
+  test_reference_live.py::test_warm_start_set_is_slims_model_variables) -- but not ``sa_gamma``
+  (libs/self_attention.py:68, plain tf.get_variable): a stage's warm start carries ``u`` over and leaves ``sa_gamma`` at
+  its fresh initialisation (both the in-memory and the file-based warm start); a full restore of a run
+  (checkpoint.restore) loads both."""
   from twingan_amd import Config
   from twingan_amd.runner import warm_start
   from twingan_amd.twingan import Trainer
@@ -216,12 +218,14 @@ def test_warm_start_restores_model_variables_only(tmp_path):
       if k.endswith('/sa_gamma'):
         p.fill_(0.7)
   sd = a.store.state_dict(include_state=True)
-  special = [k for k in sd if k.endswith('/u') or k.endswith('/sa_gamma')]
-  assert any(k.endswith('/u') for k in special) and any(k.endswith('/sa_gamma') for k in special)
+  us = [k for k in sd if k.endswith('/u')]
+  gates = [k for k in sd if k.endswith('/sa_gamma')]
+  assert us and gates
   C.save(a, str(tmp_path / 's'))
   for how in ('memory', 'files', 'restore'):
     b = Trainer(cfg, device='cpu', seed=2)
     fresh = b.store.state_dict(include_state=True)
+    assert not any(torch.equal(fresh[k], sd[k]) for k in us)          # a different seed draws a different u
     if how == 'memory':
       loaded = warm_start(b, sd)
     elif how == 'files':
@@ -231,9 +235,50 @@ def test_warm_start_restores_model_variables_only(tmp_path):
       loaded = list(sd)
     after = b.store.state_dict(include_state=True)
     for k in sd:
-      if k in special and how != 'restore':
+      if k in gates and how != 'restore':
         assert k not in loaded and torch.equal(after[k], fresh[k]), (how, k)
       else:
-        assert torch.equal(after[k], sd[k]), (how, k)
+        assert k in loaded and torch.equal(after[k], sd[k]), (how, k)
     b.close()
   a.close()
+
+
+@pytest.mark.parametrize('applies', [3, 148, 149, 200, 5000, 200000])
+def test_restore_recovers_the_adam_step_after_the_beta_powers_underflow(tmp_path, applies):
+  """TF keeps beta^(t+1) in float32: beta1 = 0.5 is exactly 0 from t = 149 (75 G+D steps), beta2 = 0.999 fades near
+  t = 87 000.  restore() inverts whichever power is still a normal number and otherwise reads the n_critic counter the
+  reference saves next to them (image_generation.py:622-623; one Adam apply per increment)."""
+  from twingan_amd import Config
+  from twingan_amd.twingan import Trainer
+  a = Trainer(Config(hw=4, max_ch=8, precision='fp32'), device='cpu', seed=1)
+  a.set_adam_step(applies)
+  a.n_critic_counter, a.global_step = applies, applies // a.cfg.n_critic
+  path = C.save(a, str(tmp_path / 'run'))
+  back = C.read_checkpoint(path)
+  assert int(back['n_critic_counter']) == applies and back['n_critic_counter'].dtype == np.int32
+  if applies >= 149:
+    assert float(back['beta1_power']) == 0.0
+  b = Trainer(Config(hw=4, max_ch=8, precision='fp32'), device='cpu', seed=2)
+  C.restore(b, path)
+  assert (b.adam_t, b.n_critic_counter, b.global_step) == (applies, applies, applies // a.cfg.n_critic)
+  # a checkpoint without the counter (hand-made / older): the powers while they last, then global_step * n_critic
+  arrays = {k: v for k, v in back.items() if k != 'n_critic_counter'}
+  assert C._adam_applies(arrays, a.cfg, (applies // a.cfg.n_critic) * a.cfg.n_critic) in (applies, applies - applies % a.cfg.n_critic)
+  a.close(); b.close()
+
+
+def test_saver_keeps_the_most_recent_checkpoints(tmp_path):
+  """tf.train.Saver(max_to_keep=5) as slim.learning.train builds it: the state file lists the retained checkpoints
+  oldest first, older files are deleted, latest_checkpoint follows ``model_checkpoint_path``."""
+  from twingan_amd import Config
+  from twingan_amd.twingan import Trainer
+  tr = Trainer(Config(hw=4, max_ch=8, precision='fp32'), device='cpu', seed=1)
+  d = str(tmp_path / 'run')
+  for step in (10, 20, 30, 40):
+    C.save(tr, d, global_step=step, max_to_keep=3)
+  assert C._all_checkpoint_paths(d) == ['model.ckpt-20', 'model.ckpt-30', 'model.ckpt-40']
+  assert C.latest_checkpoint(d).endswith('model.ckpt-40')
+  assert not os.path.exists(os.path.join(d, 'model.ckpt-10.index')) and os.path.exists(os.path.join(d, 'model.ckpt-20.index'))
+  C.save(tr, d, global_step=40, max_to_keep=3)                          # re-saving a step does not duplicate its entry
+  assert C._all_checkpoint_paths(d) == ['model.ckpt-20', 'model.ckpt-30', 'model.ckpt-40']
+  tr.close()

@@ -194,3 +194,24 @@ def test_ttur_training_runs_match_live_reference():
   assert opt.t == 4 and abs(float(ref['variables']['beta1_power']) - cfg.beta1 ** 5) < 1e-12
   worst = max(float(np.abs(P[k].detach().numpy() - ref['variables'][k]).max()) for k in P)
   assert worst < 1e-9, worst
+
+
+def test_warm_start_set_is_slims_model_variables():
+  """A stage's warm start restores slim.get_model_variables() (model/model_inheritor.py:612-614).  Built live: the
+  reference's graph for spectral norm everywhere + self-attention, the collection read back from the stand-in.  The
+  spectral-norm vector ``u`` IS in it (libs/sn.py:56 passes collections=MODEL_VARIABLES, and the layer scope's custom
+  getter sends the request through slim's model_variable, libs/sn.py:199-204); the attention gate ``sa_gamma``
+  (libs/self_attention.py:68, plain tf.get_variable) is not.  params.is_model_variable must agree name by name."""
+  from oracle import ref_runner
+  from twingan_amd.params import is_model_variable
+  cfg = R.Config(hw=16, max_ch=8, spectral_norm=True, sn_non_disc=True, do_self_attention=True, self_attention_hw=16)
+  rng = np.random.RandomState(3)
+  ref = ref_runner.run(ref_runner.flags_of(cfg), rng.rand(2, 16, 16, 3), rng.rand(2, 16, 16, 3), seed=1, want_grads=False)
+  in_collection = set(ref['model_variables'])
+  names = [k for k in ref['variables'] if k.split('/')[0] in ('generator', 'encoder_content', 'discriminator_s', 'discriminator_t')]
+  us = [k for k in names if k.endswith('/u')]
+  gates = [k for k in names if k.endswith('/sa_gamma')]
+  assert us and gates
+  assert all(k in in_collection for k in us) and not any(k in in_collection for k in gates)
+  wrong = [k for k in names if is_model_variable(k) != (k in in_collection)]
+  assert not wrong, wrong[:5]

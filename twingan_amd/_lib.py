@@ -36,6 +36,8 @@ SIGNATURES = {
     'tg_version': (c_int, []),
     'tg_last_error': (c_char_p, []),
     'tg_last_kernel': (c_char_p, []),
+    'tg_set_deterministic': (c_int, [c_int]),
+    'tg_get_deterministic': (c_int, []),
     'tg_conv2d_fwd': (c_int, [_D, _P, _P, _FP, _P, _P]),
     'tg_conv2d_bwd_data': (c_int, [_D, _P, _P, _P, _P]),
     'tg_conv2d_bwd_data_masked': (c_int, [_D, _P, _P, _P, _P, _P]),

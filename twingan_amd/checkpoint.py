@@ -441,10 +441,20 @@ def latest_checkpoint(directory):
   return None
 
 
-def save(trainer, train_dir, global_step=None):
+def _all_checkpoint_paths(directory):
+  """the ``all_model_checkpoint_paths`` lines of <directory>/checkpoint, oldest first (names as written)."""
+  state = os.path.join(directory, 'checkpoint')
+  if not os.path.isfile(state):
+    return []
+  with open(state) as fh:
+    return [l.split(':', 1)[1].strip().strip('"') for l in fh if l.startswith('all_model_checkpoint_paths:')]
+
+
+def save(trainer, train_dir, global_step=None, max_to_keep=5):
   """What the reference's Saver leaves for a stage: every model variable (TF names, TF layouts), the non-trainable
   state (moving / renorm statistics, spectral-norm u), ``global_step``, and the shared Adam optimiser's slots
-  (``<var>/Adam``, ``<var>/Adam_1``, ``beta1_power``, ``beta2_power``) -> <train_dir>/model.ckpt-<step> + checkpoint."""
+  (``<var>/Adam``, ``<var>/Adam_1``, ``beta1_power``, ``beta2_power``) -> <train_dir>/model.ckpt-<step> + checkpoint
+  (the ``max_to_keep`` most recent ones are retained)."""
   store = trainer.store
   step = int(trainer.global_step if global_step is None else global_step)
   tensors = {k: v.detach().float().cpu().numpy() for k, v in store.state_dict(include_state=True).items()}
@@ -455,18 +465,34 @@ def save(trainer, train_dir, global_step=None):
   tensors['beta1_power'] = np.float32(trainer.cfg.adam_beta1 ** (t + 1))       # TF keeps beta^(t+1) after t applies
   tensors['beta2_power'] = np.float32(trainer.cfg.adam_beta2 ** (t + 1))
   tensors['global_step'] = np.int64(step)
+  # image_generation.py:622-623: a global (hence saved) int32 variable; every session.run adds 1 to it and applies the
+  # shared Adam once, so it is also the number of Adam applies -- which the beta powers stop encoding once they
+  # underflow (float32 0.5^(t+1) is exactly 0 from t = 149)
+  tensors['n_critic_counter'] = np.int32(trainer.n_critic_counter)
   name = 'model.ckpt-%d' % step
+  kept = [n for n in _all_checkpoint_paths(train_dir) if n != name]
   write_checkpoint(os.path.join(train_dir, name), tensors)
+  kept.append(name)
+  # tf.train.Saver(max_to_keep=5), the default slim.learning.train builds (model_inheritor.py:1119-1130): the state file
+  # lists the retained checkpoints oldest first, older ones are deleted
+  while max_to_keep and len(kept) > max_to_keep:
+    old = kept.pop(0)
+    base = old if os.path.isabs(old) else os.path.join(train_dir, old)
+    for suffix in ('.index', '.data-00000-of-00001'):
+      if os.path.isfile(base + suffix):
+        os.remove(base + suffix)
   with open(os.path.join(train_dir, 'checkpoint'), 'w') as fh:
-    fh.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (name, name))
+    fh.write('model_checkpoint_path: "%s"\n' % name)
+    for n in kept:
+      fh.write('all_model_checkpoint_paths: "%s"\n' % n)
   return os.path.join(train_dir, name)
 
 
 def init_from_checkpoint(trainer, checkpoint_path, checkpoint_exclude_scopes=None, ignore_missing_vars=False,
                          train_dir=None):
   """model/model_inheritor.py:576-644 (_get_init_fn + slim.assign_from_checkpoint_fn): restore the MODEL variables
-  (slim.get_model_variables(): not the optimiser slots, not global_step, and not the two tf.get_variable variables of
-  the path -- spectral-norm ``u`` and ``sa_gamma``, params.is_model_variable) whose names do not start with an excluded
+  (slim.get_model_variables(): not the optimiser slots, not global_step, and not the attention gate ``sa_gamma``, the
+  one plain tf.get_variable of the path -- params.is_model_variable) whose names do not start with an excluded
   scope from ``checkpoint_path``
   (a checkpoint prefix, or a directory -> its latest checkpoint).  Nothing is restored when ``train_dir`` already holds
   a checkpoint (the run resumes from that one instead).  A variable the checkpoint lacks is an error unless
@@ -519,6 +545,21 @@ def restore(trainer, prefix):
   if 'global_step' in arrays:
     trainer.global_step = int(arrays['global_step'])
     trainer.n_critic_counter = trainer.global_step * trainer.cfg.n_critic
-  if 'beta1_power' in arrays:      # beta1^(t+1) after t applies
-    trainer.set_adam_step(max(0, int(round(math.log(float(arrays['beta1_power'])) / math.log(trainer.cfg.adam_beta1))) - 1))
+  if 'n_critic_counter' in arrays:
+    trainer.n_critic_counter = int(arrays['n_critic_counter'])
+  trainer.set_adam_step(_adam_applies(arrays, trainer.cfg, trainer.n_critic_counter))
   return trainer.global_step
+
+
+def _adam_applies(arrays, cfg, counter):
+  """Number of applies t the shared Adam optimiser has made.  TF keeps beta^(t+1) in float32: invert whichever power is
+  still a normal number (beta1 = 0.5 underflows to exactly 0 at t = 149, beta2 = 0.999 near t = 87 000); after that only
+  the n_critic counter knows -- the reference applies the one optimiser exactly once per counter increment
+  (image_generation.py:640-652), so the two agree whenever both are readable."""
+  import math
+  for key, beta in (('beta2_power', cfg.adam_beta2), ('beta1_power', cfg.adam_beta1)):
+    if key in arrays and 0.0 < beta < 1.0:
+      p = float(arrays[key])
+      if 1e-30 < p <= 1.0:
+        return max(0, int(round(math.log(p) / math.log(beta))) - 1)
+  return max(0, int(counter))

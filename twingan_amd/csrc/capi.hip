@@ -95,9 +95,28 @@ static thread_local bool tg_elem_is_f16 = false;
 bool tg_elem_f16() { return tg_elem_is_f16; }
 void tg_set_elem_f16(bool f16) { tg_elem_is_f16 = f16; }
 
+// -1 = not decided yet: the first question reads TG_DETERMINISTIC from the environment; tg_set_deterministic overrides.
+// Process-wide on purpose (not thread-local): a trainer's side-stream threads must see what the main thread set.
+static int tg_det_mode = -1;
+int tg_deterministic_mode() {
+  int m = __atomic_load_n(&tg_det_mode, __ATOMIC_RELAXED);
+  if (m < 0) {
+    const char* v = getenv("TG_DETERMINISTIC");
+    m = (v && *v && atoi(v) != 0) ? 1 : 0;
+    __atomic_store_n(&tg_det_mode, m, __ATOMIC_RELAXED);
+  }
+  return m;
+}
+
 extern "C" {
 
 int tg_version(void) { return 100; }
+int tg_set_deterministic(int on) {
+  const int was = tg_deterministic_mode();
+  __atomic_store_n(&tg_det_mode, on ? 1 : 0, __ATOMIC_RELAXED);
+  return was;
+}
+int tg_get_deterministic(void) { return tg_deterministic_mode(); }
 const char* tg_last_error(void) { return tg_err; }
 const char* tg_last_kernel(void) { return tg_kname; }
 
@@ -258,7 +277,8 @@ int tg_conv2d_bwd_weight_bias(const TgConvDesc* d, const void* x, const void* gy
   int rc = check_desc("tg_conv2d_bwd_weight_bias", d);
   if (rc) return rc;
   TG_CHECK(x && gy && gw && gbias, TG_EINVAL, "tg_conv2d_bwd_weight_bias: null pointer");
-  if (d->algo != TG_ALGO_DIRECT && tg_conv2d_bwd_weight_bias_fused_mfma(d))
+  // the fused form ends in one float atomic per workgroup and channel: not taken in deterministic mode
+  if (d->algo != TG_ALGO_DIRECT && !tg_deterministic_mode() && tg_conv2d_bwd_weight_bias_fused_mfma(d))
     return tg_conv2d_bwd_weight_mfma(d, x, gy, gw, accumulate, ws, ws_bytes, (hipStream_t)stream, gbias);
   rc = tg_conv2d_bwd_weight(d, x, gy, gw, accumulate, ws, ws_bytes, stream);
   if (rc) return rc;
@@ -274,6 +294,13 @@ int tg_conv2d_bwd_weight2_bias(const TgConvDesc* d, int nb, const void* xa, cons
   TG_CHECK(d->algo != TG_ALGO_DIRECT && tg_conv2d_bwd_weight2_supported_mfma(d), TG_ENOSUP,
            "tg_conv2d_bwd_weight2_bias: layer not taken by the tile kernel");
   TG_CHECK(bias_segs >= 1 && bias_segs <= 3, TG_EINVAL, "tg_conv2d_bwd_weight2_bias: bias_segs %d", bias_segs);
+  if (tg_deterministic_mode()) {      // filter gradient without the bias MFMA, bias sums by one workgroup each
+    rc = tg_conv2d_bwd_weight2_mfma(d, nb, xa, gya, xb, gyb, gw, accumulate, ws, ws_bytes, (hipStream_t)stream, nullptr, 3);
+    if (rc) return rc;
+    if (bias_segs & 1) rc = bias_fallback(d, gya, gbias, d->n, stream);
+    if (!rc && (bias_segs & 2)) rc = bias_fallback(d, gyb, gbias, nb, stream);
+    return rc;
+  }
   return tg_conv2d_bwd_weight2_mfma(d, nb, xa, gya, xb, gyb, gw, accumulate, ws, ws_bytes, (hipStream_t)stream, gbias,
                                     bias_segs);
 }

@@ -20,11 +20,7 @@ struct Rccl {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
-Rccl* rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return r.handle ? &r : nullptr;
-  tried = true;
+bool rccl_bind(Rccl& r) {
   const char* env = getenv("TG_RCCL_PATH");
   const char* names[] = {env, "librccl.so.1", "librccl.so"};
   for (const char* n : names) {
@@ -32,7 +28,7 @@ Rccl* rccl() {
     r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     if (r.handle) break;
   }
-  if (!r.handle) return nullptr;
+  if (!r.handle) return false;
   r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
   r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
   r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
@@ -41,14 +37,21 @@ Rccl* rccl() {
   if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy) {
     dlclose(r.handle);
     r.handle = nullptr;
-    return nullptr;
+    return false;
   }
-  return &r;
+  return true;
+}
+
+// bound once, by whichever thread asks first: a function-local static's initialiser is thread-safe in C++11
+Rccl* rccl() {
+  static Rccl r;
+  static const bool ok = rccl_bind(r);
+  return ok ? &r : nullptr;
 }
 
 int fail(const char* who, Rccl* r, ncclResult_t rc) {
   tg_set_error("%s: RCCL error %d (%s)", who, (int)rc, (r && r->GetErrorString) ? r->GetErrorString(rc) : "?");
-  return TG_ELAUNCH;
+  return TG_ECOMM;
 }
 
 }  // namespace
@@ -80,10 +83,11 @@ int tg_comm_init(const void* id, int nranks, int rank, void** comm) {
 
 int tg_allreduce(void* comm, void* buf, int64_t count, int dtype, void* stream) {
   TG_CHECK(comm && buf && count > 0, TG_EINVAL, "tg_allreduce: bad arguments");
-  TG_CHECK(dtype == TG_F32 || dtype == TG_BF16, TG_EINVAL, "tg_allreduce: dtype %d", dtype);
+  TG_CHECK(dtype == TG_F32 || dtype == TG_BF16 || dtype == TG_F16, TG_EINVAL, "tg_allreduce: dtype %d", dtype);
+  const ncclDataType_t nt = dtype == TG_F32 ? ncclFloat32 : (dtype == TG_BF16 ? ncclBfloat16 : ncclFloat16);
   Rccl* r = rccl();
   TG_CHECK(r, TG_ENOSUP, "tg_allreduce: RCCL is not loaded");
-  ncclResult_t rc = r->AllReduce(buf, buf, (size_t)count, dtype == TG_F32 ? ncclFloat32 : ncclBfloat16, ncclSum,
+  ncclResult_t rc = r->AllReduce(buf, buf, (size_t)count, nt, ncclSum,
                                  (ncclComm_t)comm, (hipStream_t)stream);
   return rc == ncclSuccess ? TG_OK : fail("tg_allreduce", r, rc);
 }

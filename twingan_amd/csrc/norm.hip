@@ -533,10 +533,10 @@ __global__ void norm_act_bwd2_part_kernel(const T* __restrict__ gz, const T* __r
   } else if (sink && blockIdx.x == 0) {
     float* gg = n < split ? ggamma : ggamma2;
     float* gb = n < split ? gbeta : gbeta2;
-    if constexpr (sizeof(T) == 4) {
-      // exact-parity (fp32) path: the domain's first image sums the partials of all its images in image order and
-      // issues ONE add per parameter (launches that feed a sink are stream-ordered) -- the result does not depend on
-      // which image's block arrives first
+    if (sink == 2) {
+      // exact-parity (fp32) path and deterministic mode: the domain's first image sums the partials of all its images
+      // in image order and issues ONE add per parameter (launches that feed a sink are stream-ordered) -- the result
+      // does not depend on which image's block arrives first
       const int i0 = n < split ? 0 : split, i1 = n < split ? split : (int)gridDim.y;
       if (n == i0) {
         for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) {
@@ -861,7 +861,7 @@ int tg_instance_norm_stats(const void* y, float* mean, float* rstd, int n, int h
     const int V = pick_v<T>(c);
     TG_CHECK(c / V <= 256, TG_ENOSUP, "tg_instance_norm_stats: c=%d not supported", c);
     const size_t lds = 2 * (size_t)c * sizeof(float);
-    if (exact_path<T>()) {      // one workgroup per image: its sums do not meet another workgroup's in an atomic
+    if (exact_grid<T>()) {      // one workgroup per image: its sums do not meet another workgroup's in an atomic
       chunks = 1;
       ppb = hw;
     }
@@ -942,9 +942,10 @@ int tg_norm_act_bwd(const void* gz, const void* gz_pooled, const void* y, const 
   chunks2 = (hw + ppb2 - 1) / ppb2;
   const bool want_params = ggamma || gbeta || ggamma2 || gbeta2;
   TG_CHECK(!pstride || !accumulate, TG_EINVAL, "tg_norm_act_bwd: per-image parameter gradients are written, not added");
-  const int sink = (want_params && accumulate) ? 1 : 0;      // block (0, n) of pass 2 adds the image's sums
+  int sink = (want_params && accumulate) ? 1 : 0;            // block (0, n) of pass 2 adds the image's sums
   const size_t lds = 2 * (size_t)c * sizeof(float);
   TG_DISPATCH_DTYPE(dtype, "tg_norm_act_bwd", {
+    if (sink && exact_grid<T>()) sink = 2;                   // ... in image order, by the domain's first image
     constexpr int VN = Vec16<T>::N;
     const bool vec = (c % VN == 0) && pow2(c / VN) && c / VN <= 64;
     if (flags & NF_PIXNORM) {
@@ -988,7 +989,7 @@ static int lrelu_bwd_launch(const char* who, const void* gz, const void* gzp, in
     const int blocks = gbias ? tg_grid_for(npix, lanes * 16, 1024) : tg_grid_for(npix, lanes * 4, 2048);
     const size_t lds = (size_t)c * sizeof(float);
     // exact path: the element-wise part on the full grid, the bias gradient by one workgroup over what it wrote
-    float* gb_here = (exact_path<T>() && blocks > 1) ? nullptr : gbias;
+    float* gb_here = (exact_grid<T>() && blocks > 1) ? nullptr : gbias;
     if (V == 1)
       hipLaunchKernelGGL((lrelu_bwd_bias_kernel<T, 1>), dim3(blocks), dim3(256), lds, s, (const T*)gz, (const T*)gzp, hw,
                          wdim, (const T*)z, (T*)gy, gb_here, npix, c, alpha);
@@ -1039,7 +1040,7 @@ int tg_channel_sum(const void* g, float* out, int64_t npix, int c, int accumulat
     const int V = pick_v<T>(c);
     TG_CHECK(c / V <= 256, TG_ENOSUP, "tg_channel_sum: c=%d not supported", c);
     const int lanes = 256 / (c / V);
-    const int blocks = exact_path<T>() ? 1 : tg_grid_for(npix, lanes * 8, 1024);
+    const int blocks = exact_grid<T>() ? 1 : tg_grid_for(npix, lanes * 8, 1024);
     const size_t lds = (size_t)c * sizeof(float);
     if (V == 1)
       hipLaunchKernelGGL((channel_sum_kernel<T, 1>), dim3(blocks), dim3(256), lds, s, (const T*)g, out, npix, c);

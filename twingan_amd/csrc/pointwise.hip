@@ -513,11 +513,11 @@ int launch_pw_wgrad(const T* x, const T* gy, float* gw, int64_t npix, int cin, i
   // Every workgroup ends with ns * cb float atomics on the SAME few addresses, and with only a few trips per thread all
   // workgroups arrive there together: at 1024 workgroups the launch took ~45 us whatever the pixel count (1 M: 49.7 us,
   // 2 M: 43.9 us).  One 1024-thread workgroup per CU keeps the bytes in flight and quarters the atomics per address.
-  const int threads = exact_path<T>() ? 256 : 1024;
+  const int threads = exact_grid<T>() ? 256 : 1024;
   const size_t lds = (size_t)ns * cb * sizeof(float) * (1 + threads / 64);
   // >= 4096 pixels per workgroup: a small map (the 32 x 32 stages of the tests) is one workgroup, i.e. a fixed summation
   // order; with several workgroups the order of their atomics is the run's
-  const int blocks = exact_path<T>() ? 1 : tg_grid_for(npix, 4096, 256);
+  const int blocks = exact_grid<T>() ? 1 : tg_grid_for(npix, 4096, 256);
   if (cb % V == 0 && cb / V <= 256)
     hipLaunchKernelGGL((pw_wgrad_kernel<T, V>), dim3(blocks), dim3(threads), lds, s, small, big, gw, npix, ns, cb, os, oc);
   else

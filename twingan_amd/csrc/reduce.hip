@@ -647,7 +647,7 @@ int tg_sum(const void* x, float* out, int64_t numel, float scale, int accumulate
   int rc = zero_unless(out, sizeof(float), accumulate, s, "tg_sum");
   if (rc) return rc;
   TG_DISPATCH_DTYPE(dtype, "tg_sum", {
-    hipLaunchKernelGGL((sum_kernel<T, 0>), dim3(exact_path<T>() ? 1 : tg_grid_for(numel / Vec16<T>::N + 1, 256, 1024)),
+    hipLaunchKernelGGL((sum_kernel<T, 0>), dim3(exact_grid<T>() ? 1 : tg_grid_for(numel / Vec16<T>::N + 1, 256, 1024)),
                        dim3(256), 0, s, (const T*)x, (const T*)nullptr, out, numel, scale);
   });
   TG_LAUNCH_CHECK("tg_sum");
@@ -661,7 +661,7 @@ int tg_abs_diff_sum(const void* a, const void* b, float* out, int64_t numel, flo
   int rc = zero_unless(out, sizeof(float), accumulate, s, "tg_abs_diff_sum");
   if (rc) return rc;
   TG_DISPATCH_DTYPE(dtype, "tg_abs_diff_sum", {
-    hipLaunchKernelGGL((sum_kernel<T, 1>), dim3(exact_path<T>() ? 1 : tg_grid_for(numel / Vec16<T>::N + 1, 256, 1024)),
+    hipLaunchKernelGGL((sum_kernel<T, 1>), dim3(exact_grid<T>() ? 1 : tg_grid_for(numel / Vec16<T>::N + 1, 256, 1024)),
                        dim3(256), 0, s, (const T*)a, (const T*)b, out, numel, scale);
   });
   TG_LAUNCH_CHECK("tg_abs_diff_sum");
@@ -685,7 +685,7 @@ int tg_sample_sumsq(const void* x, float* out, int batch, int64_t per, int dtype
   int rc = zero_unless(out, (size_t)batch * sizeof(float), 0, s, "tg_sample_sumsq");
   if (rc) return rc;
   TG_DISPATCH_DTYPE(dtype, "tg_sample_sumsq", {
-    const int chunks = exact_path<T>() ? 1 : tg_grid_for(per / Vec16<T>::N + 1, 256, 64);
+    const int chunks = exact_grid<T>() ? 1 : tg_grid_for(per / Vec16<T>::N + 1, 256, 64);
     hipLaunchKernelGGL(sample_sumsq_kernel<T>, dim3(chunks, batch), dim3(256), 0, s, (const T*)x, out, per);
   });
   TG_LAUNCH_CHECK("tg_sample_sumsq");

@@ -171,6 +171,14 @@ __device__ __forceinline__ float lrelu_f(float x, float a) { return fmaxf(a * x,
 // reach a float atomic -- the path is bit-reproducible.  The bf16 path keeps the wide grids and their fp32 atomics.
 template <typename T> constexpr bool exact_path() { return sizeof(T) == 4; }
 
+// TG_DETERMINISTIC=1 in the environment (or tg_set_deterministic(1)) gives the 16-bit storage types the same launch
+// shapes: every launcher that asks exact_grid<T>() instead of exact_path<T>() then sums in a fixed order whatever the
+// storage type, so two runs of a bf16 / fp16 step -- eagerly launched or replayed from a hipGraph -- are bit-identical.
+// (exact_path<T>() stays the compile-time question "is this the fp32 parity path", e.g. for the run-time-flag variants
+// of the normalisation kernels whose contraction pattern must not change.)
+int tg_deterministic_mode();
+template <typename T> inline bool exact_grid() { return sizeof(T) == 4 || tg_deterministic_mode() != 0; }
+
 // launch-heuristic experiments: TG_TUNE_<NAME>=<int> in the environment overrides `dflt` (read at every call, so
 // two hipGraph captures in one process can bake different settings).  For tools/ab_env.py; no call site is left in
 // the tree when an experiment is over

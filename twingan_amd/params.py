@@ -240,11 +240,14 @@ _HW_IN_NAME = __import__('re').compile(r'/(?:encoder_block|from_rgb|self_attenti
 def is_model_variable(name):
   """Is ``name`` in slim's MODEL_VARIABLES collection, i.e. among what a stage's warm start restores
   (slim.get_model_variables() in model/model_inheritor.py:612-614)?  Every variable of the path is created through slim
-  layers / variables.model_variable (libs/instance_norm.py:101,121; libs/batch_norm.py:142-224), except the two that use
-  tf.get_variable directly: the spectral-norm vector ``u`` (libs/sn.py:56) and the attention gate ``sa_gamma``
-  (libs/self_attention.py:68).  Those are re-initialised by every stage of the reference; a full Saver restore
-  (resuming a run, inference) still loads them."""
-  return not (name.endswith('/u') or name.endswith('/sa_gamma'))
+  layers / variables.model_variable (libs/instance_norm.py:101,121; libs/batch_norm.py:142-224), and so is the
+  spectral-norm vector ``u``: libs/sn.py:56 asks tf.get_variable for ``collections=tf.GraphKeys.MODEL_VARIABLES`` from
+  inside the layer's variable scope, whose custom getter (libs/sn.py:199-204, layers._build_variable_getter) routes the
+  request through slim's model_variable, which appends MODEL_VARIABLES itself -- a stage's warm start restores ``u``.
+  The one exception is the attention gate ``sa_gamma`` (libs/self_attention.py:68): plain tf.get_variable outside any
+  layer scope, so every stage of the reference starts it from 0 again; a full Saver restore (resuming a run,
+  inference) still loads it."""
+  return not name.endswith('/sa_gamma')
 
 
 def grad_phase(name, cfg):

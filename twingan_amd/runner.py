@@ -44,7 +44,7 @@ def warm_start(trainer, previous_state):
   from .params import is_model_variable
   specs, state = trainer.store.specs, trainer.store.state
   usable = {k: v for k, v in previous_state.items()
-            if is_model_variable(k) and      # spectral-norm u and sa_gamma are not model variables: fresh every stage
+            if is_model_variable(k) and      # sa_gamma is not a slim model variable: fresh (0) every stage
             ((k in specs and tuple(v.shape) == specs[k]['shape']) or
              (k in trainer.store.state_specs and tuple(v.shape) == tuple(state[k].shape)))}
   trainer.store.load_state_dict(usable, strict=False)
@@ -52,7 +52,8 @@ def warm_start(trainer, previous_state):
 
 
 def run_progressive(base_cfg, batch_fn, start_hw=4, max_hw=256, hw_to_batch_size=None, num_images_per_resolution=300000,
-                    device='cuda', seed=0, max_steps_per_stage=None, use_graph=False, on_stage_end=None, train_dir=None):
+                    device='cuda', seed=0, max_steps_per_stage=None, use_graph=False, on_stage_end=None, train_dir=None,
+                    save_interval_secs=600, save_interval_steps=None, max_to_keep=5):
   """Trains stage after stage.  ``batch_fn(hw, batch_size)`` -> (sources, targets) device tensors, or
   (sources, targets, gp_alpha_s, gp_alpha_t) to fix the gradient-penalty interpolation draws (tests).
   One reference "step" (global_step) = one generator apply = ``n_critic`` runs (image_generation.py:640-652).
@@ -60,8 +61,12 @@ def run_progressive(base_cfg, batch_fn, start_hw=4, max_hw=256, hw_to_batch_size
   ``train_dir``: the reference's directory protocol (pggan_runner.py:100-160) over TF-format checkpoints
   (checkpoint.py) -- stage ``name`` trains in <train_dir>/<name>, is skipped when that directory already holds a
   checkpoint of >= its number of steps, resumes from a checkpoint it finds there, otherwise warm-starts from the
-  previous stage's directory with ignore_missing_vars = is_growing, and saves model.ckpt-<global_step> at its end."""
+  previous stage's directory with ignore_missing_vars = is_growing, and saves model.ckpt-<global_step> at its end and,
+  like slim.learning.train's Saver (--save_interval_secs, model_inheritor.py:75,1126: 600 s), every
+  ``save_interval_secs`` seconds (or every ``save_interval_steps`` steps) inside a stage, keeping ``max_to_keep`` files:
+  the final stage runs for 10 M steps, an interruption must not lose it."""
   import os
+  import time
   from . import checkpoint as ckpt
   from .twingan import Trainer
   state = None
@@ -86,14 +91,20 @@ def run_progressive(base_cfg, batch_fn, start_hw=4, max_hw=256, hw_to_batch_size
       loaded = ckpt.init_from_checkpoint(tr, last_dir, ignore_missing_vars=growing, train_dir=cur_dir) if last_dir else []
     else:
       loaded = warm_start(tr, state) if state is not None else []
+    last_save = time.time()
     for step in range(first, steps):
       if growing:
         tr.cfg.alpha_grow = alpha_grow(step, steps)
       for _ in range(cfg.n_critic):
         tr.run(*batch_fn(hw, bsz))
+      if cur_dir and step + 1 < steps and (
+          (save_interval_steps and (step + 1) % save_interval_steps == 0) or
+          (save_interval_secs and time.time() - last_save >= save_interval_secs)):
+        ckpt.save(tr, cur_dir, global_step=step + 1, max_to_keep=max_to_keep)
+        last_save = time.time()
     state = tr.store.state_dict(include_state=True)
     if cur_dir:
-      ckpt.save(tr, cur_dir, global_step=steps)
+      ckpt.save(tr, cur_dir, global_step=steps, max_to_keep=max_to_keep)
       last_dir = cur_dir
     history.append(dict(stage=name, hw=hw, is_growing=growing, batch_size=bsz, steps=steps, warm_started=len(loaded)))
     if on_stage_end is not None:
