@@ -126,6 +126,7 @@ def flags_of(cfg):
     pggan_unet_max_concat_hw=getattr(cfg, 'unet_max_concat_hw', None),
     spectral_norm_in_non_discriminator=getattr(cfg, 'sn_non_disc', False),
     pggan_max_num_channels_dis=getattr(cfg, 'max_ch_dis', None),
+    use_larger_filter_at_rgb_layer=getattr(cfg, 'larger_rgb', False),
     do_encoder_distillation=getattr(cfg, 'do_encoder_distillation', False),
     distillation_weight=getattr(cfg, 'distillation_weight', 1.0),
     distillation_start_hw=getattr(cfg, 'distillation_start_hw', 16))

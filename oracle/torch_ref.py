@@ -57,6 +57,7 @@ class Config:
   global_step: int = 0               # batch renorm clipping schedule (nets/pggan_utils.py:207-223)
   spectral_norm: bool = False        # nets/pggan.py:28-30 (discriminator convs; libs/sn.py:38-101)
   sn_non_disc: bool = False          # spectral_norm_in_non_discriminator (nets/pggan.py:31-33): encoder / generator convs too
+  larger_rgb: bool = False           # use_larger_filter_at_rgb_layer (nets/pggan.py:47-50,172-175,194-197)
   sn_state: object = None            # dict scope -> u [1, cout] (libs/sn.py:56-57); updated by end_run()
   sn_cache: object = None            # per-run normalised kernels: every use in a run sees the pre-run u
   do_self_attention: bool = False    # image_generation.py:62-64
@@ -121,7 +122,14 @@ def encoder_param_specs(top, hw, max_ch, growing=False):
   return specs
 
 
-def generator_param_specs(top, hw, max_ch, use_unet, growing=False, unet_max_hw=None):
+def rgb_kernel_size(larger_rgb, hw):
+  """nets/pggan.py:172-175,194-197: the to-RGB kernel is min(7, hw / 2) with --use_larger_filter_at_rgb_layer, else 1 --
+  computed from the CURRENT stage's hw for the grown layer and for the previous-resolution layer alike (Python-2 integer
+  division; 8 x 8 gives an EVEN 4 x 4 SAME kernel: TF pads 1 before, 2 after)."""
+  return min(7, hw // 2) if larger_rgb else 1
+
+
+def generator_param_specs(top, hw, max_ch, use_unet, growing=False, unet_max_hw=None, larger_rgb=False):
   """[(scope, k, cin, cout)] for nets/pggan.py:93-211 with a [B,4,4,C] source."""
   ms = max_stage_of(hw)
   specs = []
@@ -133,13 +141,13 @@ def generator_param_specs(top, hw, max_ch, use_unet, growing=False, unet_max_hw=
     cur = 2 ** (stage + 2)
     oc = get_num_channels(stage, max_ch)
     if stage == ms and growing:
-      specs.append(('%s/generator_to_rgb_%dx%d/Conv' % (top, cur // 2, cur // 2), 1, c, 3))
+      specs.append(('%s/generator_to_rgb_%dx%d/Conv' % (top, cur // 2, cur // 2), rgb_kernel_size(larger_rgb, cur), c, 3))
     cin = c + (get_num_channels(stage - 1, max_ch) if (use_unet and not (unet_max_hw and cur > unet_max_hw)) else 0)
     blk = '%s/block_%dx%dx%d' % (top, cur, cur, oc)
     specs.append((blk + '/Conv', 3, cin, oc))
     specs.append((blk + '/Conv_1', 3, oc, oc))
     c = oc
-  specs.append(('%s/generator_to_rgb_%dx%d/Conv' % (top, hw, hw), 1, c, 3))
+  specs.append(('%s/generator_to_rgb_%dx%d/Conv' % (top, hw, hw), rgb_kernel_size(larger_rgb, hw), c, 3))
   return specs
 
 
@@ -179,7 +187,8 @@ def init_params(cfg, seed=0, dtype=torch.float32, std=0.02):
   for s in encoder_param_specs('encoder_content', cfg.hw, cfg.max_ch, cfg.is_growing):
     _conv_p(P, g, s[0], s[1], s[2], s[3], ('s', 't') if cfg.norm in NORM_SCOPE else (), cfg.norm not in NORM_SCOPE, dtype,
             std, NORM_SCOPE.get(cfg.norm, ''))      # no normaliser: slim's conv2d owns a bias instead
-  for s in generator_param_specs('generator', cfg.hw, cfg.max_ch, cfg.use_unet, cfg.is_growing, cfg.unet_max_concat_hw):
+  for s in generator_param_specs('generator', cfg.hw, cfg.max_ch, cfg.use_unet, cfg.is_growing, cfg.unet_max_concat_hw,
+                                    cfg.larger_rgb):
     _conv_p(P, g, s[0], s[1], s[2], s[3], ('s', 't') if cfg.norm in NORM_SCOPE else (), cfg.norm not in NORM_SCOPE, dtype,
             std, NORM_SCOPE.get(cfg.norm, ''))
   md = cfg.max_ch_dis or cfg.max_ch
@@ -245,7 +254,8 @@ def init_params(cfg, seed=0, dtype=torch.float32, std=0.02):
       P[head + '/prediction/fully_connected/biases'] = torch.zeros(cfg.distill_embed_dim, dtype=dtype)
   if cfg.res_block:      # after everything else so the other variables keep their seeded values
     ge = encoder_param_specs('encoder_content', cfg.hw, cfg.max_ch, cfg.is_growing) + \
-        generator_param_specs('generator', cfg.hw, cfg.max_ch, cfg.use_unet, cfg.is_growing, cfg.unet_max_concat_hw)
+        generator_param_specs('generator', cfg.hw, cfg.max_ch, cfg.use_unet, cfg.is_growing, cfg.unet_max_concat_hw,
+                                    cfg.larger_rgb)
     dd = [sp for top in ('discriminator_s', 'discriminator_t')
           for sp in encoder_param_specs(top, cfg.hw, md, cfg.is_growing)]
     for sp in shortcut_specs(ge, cfg.hw, cfg.max_ch) + shortcut_specs(dd, cfg.hw, md):
@@ -669,7 +679,8 @@ def generator(P, source, domain, cfg, unet_ep=None, top='generator', cond=None):
     else:
       if stage == ms and cfg.is_growing:
         rgb = 'generator_to_rgb_%dx%d' % (hw // 2, hw // 2)
-        before_growth = ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=1, act=False, pixnorm=False, cond=cond)
+        before_growth = ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=rgb_kernel_size(cfg.larger_rgb, hw),
+                                act=False, pixnorm=False, cond=cond)
         before_growth = upsample2x(before_growth)
         ep[rgb] = before_growth
       net = upsample2x(net)
@@ -681,7 +692,8 @@ def generator(P, source, domain, cfg, unet_ep=None, top='generator', cond=None):
     ep[name] = net
     net = maybe_self_attention(P, top, hw, oc, net, ep, domain, cfg, cond=cond)      # nets/pggan.py:188-190
   rgb = 'generator_to_rgb_%dx%d' % (hw, hw)
-  to_rgb = ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=1, act=False, pixnorm=False, cond=cond)
+  to_rgb = ge_conv(P, '%s/%s/Conv' % (top, rgb), net, domain, cfg, k=rgb_kernel_size(cfg.larger_rgb, hw), act=False,
+                   pixnorm=False, cond=cond)
   if cfg.is_growing:
     out = to_rgb * cfg.alpha_grow + (1 - cfg.alpha_grow) * before_growth
   else:
@@ -743,7 +755,7 @@ def init_pggan_params(cfg, seed=0, dtype=torch.float32, std=0.02):
   he = std == 'he'
   ns = NORM_SCOPE.get(cfg.norm, '')
   nd = ('',) if cfg.norm in NORM_SCOPE else ()
-  specs = generator_param_specs('generator', cfg.hw, cfg.max_ch, False, cfg.is_growing)
+  specs = generator_param_specs('generator', cfg.hw, cfg.max_ch, False, cfg.is_growing, None, cfg.larger_rgb)
   c0 = get_num_channels(0, cfg.max_ch)
   for sp in specs:
     if sp[0] == 'generator/block_4x4x%d/Conv' % c0:

@@ -53,9 +53,9 @@ def _note(key, ep, n, sym=None):
   RECORDED.setdefault(key, {}).setdefault(ep, {})[n] = sym if sym is not None else last_kernel()
 
 
-def _rand_bf16(shape, seed):
+def _rand_bf16(shape, seed, dtype=torch.bfloat16):
   g = torch.Generator(device='cuda').manual_seed(seed)
-  return torch.randn(shape, generator=g, device='cuda', dtype=torch.float32).to(torch.bfloat16).contiguous()
+  return torch.randn(shape, generator=g, device='cuda', dtype=torch.float32).to(dtype).contiguous()
 
 
 def _check_partials(st, y, key):
@@ -83,17 +83,48 @@ class _Direct:
 
 @pytest.mark.parametrize('key', sorted(k for k in LAYERS if '+' not in k.split('>')[0]))
 def test_conv_variants_at_bench_shapes(key):
+  _conv_variants(key, torch.bfloat16)
+
+
+@pytest.mark.parametrize('key', sorted(k for k in LAYERS if '+' not in k.split('>')[0]))
+def test_fp16_conv_variants_at_config4_shapes(key):
+  """BASELINE configs[4] runs the same layer table in half precision (--dataset_dtype float16,
+  deployment/model_deploy.py:146-183): every (entry point, layer shape, n) of the table again with TG_F16 operands
+  through the f16 MFMA instantiations.  Forward launches that carry a statistics / pool epilogue in bf16 are plain
+  forwards here when the epilogue has no f16 instantiation (the host then takes the unfused route)."""
+  _conv_variants(key, torch.float16)
+
+
+def _conv_variants(key, dtype):
   import twingan_amd.ops as O
   from twingan_amd._lib import TG_EPI_BIAS, TG_EPI_LRELU
+  f16 = dtype == torch.float16
+  # one rounding of the output to the storage type: 2^-9 relative for bf16, 2^-12 for fp16
+  BF16_OUT_TOL, VS_DIRECT_TOL = (6e-4, 4e-4) if f16 else (4e-3, 2e-3)
+  note = (lambda *a, **k: None) if f16 else _note      # the recorded symbol table is config 3's (bf16)
   k, cin, cout, hw = (int(v) for v in re.match(r'k(\d):c(\d+)>(\d+):hw(\d+)', key).groups())
   valid = k == 4
   hin = 4 if valid else hw
   spec = O.ConvSpec(k, 'VALID' if valid else 'SAME')
-  eps = LAYERS[key]
-  x = _rand_bf16((NMAX, hin, hin, cin), 1)
-  gy = _rand_bf16((NMAX, hw, hw, cout), 2)
+  eps = dict(LAYERS[key])
+  if f16:
+    probe = _rand_bf16((1, hin, hin, cin), 1, dtype)
+    wprobe = torch.zeros(k, k, cin, cout, device='cuda')
+    plain = set(eps.get('tg_conv2d_fwd', []))
+    if 'tg_conv2d_fwd_stats' in eps and O.conv_fwd_stats_raw(probe, wprobe, spec)[1] is None:
+      plain |= set(eps.pop('tg_conv2d_fwd_stats'))
+    if 'tg_conv2d_fwd_pool' in eps:
+      import ctypes
+      from twingan_amd import _lib
+      d = O._desc(probe.shape, cout, spec, dtype, TG_EPI_BIAS | TG_EPI_LRELU)
+      if not (d.algo == _lib.TG_ALGO_MFMA and _lib.load().tg_conv2d_fwd_pool_supported(ctypes.byref(d))):
+        plain |= set(eps.pop('tg_conv2d_fwd_pool'))
+    if plain:
+      eps['tg_conv2d_fwd'] = sorted(plain, key=int)
+  x = _rand_bf16((NMAX, hin, hin, cin), 1, dtype)
+  gy = _rand_bf16((NMAX, hw, hw, cout), 2, dtype)
   g = torch.Generator().manual_seed(3)
-  w = (torch.randn(k, k, cin, cout, generator=g) / (k * k * cin) ** 0.5).to(torch.bfloat16).float().cuda().contiguous()
+  w = (torch.randn(k, k, cin, cout, generator=g) / (k * k * cin) ** 0.5).to(dtype).float().cuda().contiguous()
   bias = (torch.randn(cout, generator=g) * 0.1).cuda()
   wn, bn = host(w), host(bias)
   pad = 'VALID' if valid else 'SAME'
@@ -105,7 +136,7 @@ def test_conv_variants_at_bench_shapes(key):
     lin = N.conv2d_gemm(xs, wn, pad)
     for epi, ref in ((0, lin), (TG_EPI_BIAS | TG_EPI_LRELU, N.leaky_relu(lin + bn))):
       y = O.conv_fwd_raw(x[:n], w, bias if epi else None, spec, epi)
-      _note(key, 'tg_conv2d_fwd', str(n))
+      note(key, 'tg_conv2d_fwd', str(n))
       e = rel_l2(host(y[sel]), ref)
       assert e < BF16_OUT_TOL, ('fwd', key, n, epi, e)
       with _Direct():
@@ -119,7 +150,7 @@ def test_conv_variants_at_bench_shapes(key):
   # forward, bit for bit, and partial sums that add up to the sums of that tensor
   for n in (int(v) for v in eps.get('tg_conv2d_fwd_stats', [])):
     y, st = O.conv_fwd_stats_raw(x[:n], w, spec)
-    _note(key, 'tg_conv2d_fwd_stats', str(n))
+    note(key, 'tg_conv2d_fwd_stats', str(n))
     assert st is not None, ('no statistics epilogue', key, n)
     sel = sorted({0, n - 1})
     e = rel_l2(host(y[sel]), N.conv2d_gemm(host(x[sel]), wn, pad))
@@ -136,7 +167,7 @@ def test_conv_variants_at_bench_shapes(key):
   for n in (int(v) for v in eps.get('tg_conv2d_fwd_pool', [])):
     epi = TG_EPI_BIAS | TG_EPI_LRELU
     z, zp = O.conv_fwd_pool_raw(x[:n], w, bias, spec, epi)
-    _note(key, 'tg_conv2d_fwd_pool', str(n))
+    note(key, 'tg_conv2d_fwd_pool', str(n))
     z_plain = O.conv_fwd_raw(x[:n], w, bias, spec, epi)
     assert torch.equal(z, z_plain), ('fwd_pool z', key, n)
     sel = sorted({0, n - 1})
@@ -157,7 +188,7 @@ def test_conv_variants_at_bench_shapes(key):
         ref = ref * np.where(host(x[sel]) > 0, 1.0, 0.2)
       else:
         gx = O.conv_bwd_data_raw(gy[:n], w, (n, hin, hin, cin), spec)
-      _note(key, ep, str(n))
+      note(key, ep, str(n))
       e = rel_l2(host(gx[sel]), ref)
       assert e < BF16_OUT_TOL, (ep, key, n, e)
       with _Direct():
@@ -182,7 +213,7 @@ def test_conv_variants_at_bench_shapes(key):
         gb = torch.zeros(cout, dtype=torch.float32, device='cuda') if want_b else None
         if len(parts) == 1:
           gw = O.conv_bwd_weight_raw(x[:n], gy[:n], spec, gbias=gb)
-          _note(key, ep, nn)
+          note(key, ep, nn)
           bias_ref = bsum[:n].sum(0)
         else:
           a = parts[0]
@@ -190,7 +221,7 @@ def test_conv_variants_at_bench_shapes(key):
           # the trainer's bias segments: only the batched pass (segment a) feeds the bias in a D step
           ok = O.conv_bwd_weight2_raw(x[:a], gy[:a], x[a:n], gy[a:n], spec, gw, gb, 1 if want_b else 3)
           assert ok, ('two-segment filter gradient refused', key, nn)
-          _note(key, ep, nn)
+          note(key, ep, nn)
           bias_ref = bsum[:a].sum(0)
         e = rel_l2(host(gw), per[:n].sum(0))
         assert e < F32_OUT_TOL, (ep, key, nn, e)
@@ -250,6 +281,55 @@ def test_upcat_conv_at_bench_shapes(key):
   tot = sum(N.conv2d_bwd_data_gemm(gyn[i:i + 1], wn, (hw, hw))[..., c0:] for i in (gsz + j, 2 * gsz + j))
   e = rel_l2(host(x1.grad[j:j + 1]), tot)
   assert e < 2 * BF16_OUT_TOL, ('upcat gx1', key, e)
+
+
+@pytest.mark.parametrize('n', [32, 48, 64])
+def test_flash_attention_at_config4_shapes(n):
+  """The attention core BASELINE configs[4] dispatches (`bench.py --config 4`: self-attention at 64 x 64 = 4096 positions,
+  64 channels -> d_qk 8, d_v 64, fp16; n = 32 encoder passes, 48 discriminator passes, 64 generator passes):
+  tg_flash_attention_fwd / _bwd / _bwd_bwd over the whole batch, first and last image against the float64 closed forms of
+  oracle/np_ops.py (libs/self_attention.py:56-63 and its tf.gradients / gradient-penalty derivatives) on the same
+  fp16-rounded operands.  Tolerances: the fp16 bounds of tests/test_gpu_ops.py (forward 8e-4, backward 2e-3, second order
+  4e-3) -- P / dS are rounded to fp16 before the second product, sums over 4096 keys."""
+  import twingan_amd.ops as O
+  ln, dk, dv, dt = 4096, 8, 64, torch.float16
+  rng = np.random.RandomState(100 + n)
+
+  def op(shape, scale=1.0, squash=False):
+    a = rng.randn(*shape) * scale
+    return torch.tensor(np.tanh(a) if squash else a, dtype=torch.float32).to(dt)
+  q, k = op((n, ln, dk), 1.0, True), op((n, ln, dk), 2.0, True)
+  v, go = op((n, ln, dv)), op((n, ln, dv))
+  aq, ak, av = op((n, ln, dk)), op((n, ln, dk)), op((n, ln, dv))
+  sel = [0, n - 1]
+  h64 = lambda t: t[sel].double().numpy()
+  qd, kd, vd, gd = (t.cuda().requires_grad_(True) for t in (q, k, v, go))
+  assert O.flash_attention_supported(qd, vd) and O.flash_attention_trainable(qd, vd)
+  # forward
+  o, lse = O.flash_attention_fwd_raw(qd.detach(), kd.detach(), vd.detach())
+  ref_o, _ = N.attention_forward(h64(q), h64(k), h64(v))
+  e = rel_l2(host(o[sel]), ref_o)
+  assert e < 8e-4, ('flash fwd', n, e)
+  assert bool(torch.isfinite(o.float()).all()) and bool(torch.isfinite(lse).all())
+  # first-order backward (no create_graph: tg_flash_attention_bwd)
+  of = O.flash_attention(qd, kd, vd)
+  gq, gk, gv = torch.autograd.grad(of, (qd, kd, vd), go.cuda())
+  for got, ref, nm in zip((gq, gk, gv), N.attention_backward(h64(q), h64(k), h64(v), h64(go)), ('dq', 'dk', 'dv')):
+    e = rel_l2(host(got[sel]), ref)
+    assert e < 2e-3, ('flash bwd ' + nm, n, e)
+    assert bool(torch.isfinite(got.float()).all())
+  # second order: the gradient-penalty pattern (create_graph backward, then the backward of that)
+  with O.second_order():
+    assert O.flash_attention_trainable(qd, vd) == O.USE_FLASH_BWD_BWD
+  of = O.flash_attention(qd, kd, vd)
+  gq, gk, gv = torch.autograd.grad(of, (qd, kd, vd), gd, create_graph=True)
+  loss = (gq.float() * aq.cuda().float()).sum() + (gk.float() * ak.cuda().float()).sum() + (gv.float() * av.cuda().float()).sum()
+  adj = torch.autograd.grad(loss, (qd, kd, vd, gd))
+  ref = N.attention_backward_backward(h64(q), h64(k), h64(v), h64(go), h64(aq), h64(ak), h64(av))
+  for got, want, nm in zip(adj, ref, ('adj q', 'adj k', 'adj v', 'adj dO')):
+    e = rel_l2(host(got[sel]), want)
+    assert e < 4e-3, ('flash bwd_bwd ' + nm, n, e)
+    assert bool(torch.isfinite(got.float()).all())
 
 
 NORM_SHAPES = [

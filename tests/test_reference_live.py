@@ -36,6 +36,10 @@ CASES = {
   'distillation': dict(hw=16, max_ch=8, do_encoder_distillation=True, distill_embed_dim=5, distillation_weight=0.7),
   'distillation_source_only': dict(hw=16, max_ch=8, do_encoder_distillation=True, distill_embed_dim=4, norm='batch_norm'),
   'style_batch_renorm': dict(hw=16, max_ch=8, use_style_embedding=True, style_embed_size=4, norm='batch_renorm'),
+  # --use_larger_filter_at_rgb_layer (nets/pggan.py:172-175,194-197): 7x7 to-RGB at 16x16; min(7, 8/2) = an EVEN 4x4 SAME
+  # kernel (TF pads 1 low / 2 high) for both to-RGB layers of the growing 8x8 stage
+  'larger_rgb_16': dict(hw=16, max_ch=8, larger_rgb=True),
+  'larger_rgb_growing_8': dict(hw=8, max_ch=8, larger_rgb=True, is_growing=True, alpha_grow=0.4),
 }
 
 
