@@ -1323,6 +1323,10 @@ def test_config4_half_precision_flash_path_matches_composed_path_and_oracle():
   ref_g = {k: Pref[k].grad.numpy().copy() for k in tr.store.names('g') if Pref[k].grad is not None}
   for v in Pref.values():
     v.grad = None
+  if rcfg.sn_cache:                      # drop the run's normalised kernels (their graph is spent) but keep the pre-run u
+    rcfg.sn_cache.clear()
+  for k, v in sn0.items():
+    rcfg.sn_state[k] = v.double()
   rdl, rdterms = R.discriminator_loss(Pref, ref['s'], ref['t'], rcfg, ref['a_s'], ref['a_t'])
   rdl.backward()
   ref_d = {k: Pref[k].grad.numpy().copy() for k in tr.store.names('d') if Pref[k].grad is not None}
@@ -1343,6 +1347,7 @@ def test_config4_half_precision_flash_path_matches_composed_path_and_oracle():
         else:
           loss, terms = T.discriminator_loss(tr.P, dev['s'], dev['t'], cfg, dev['a_s'], dev['a_t'])
         (loss * cfg.loss_scale).backward()
+        pggan.end_run(tr.P)                # drops the run's normalised kernels; u is reset from sn0 above
         torch.cuda.synchronize()
         grads = {k: (v.double().cpu().numpy() / cfg.loss_scale) for k, v in tr.store.grad_dict().items()
                  if k in tr.store.names(grp)}
@@ -1360,7 +1365,6 @@ def test_config4_half_precision_flash_path_matches_composed_path_and_oracle():
     return float(np.sqrt(num / den)), float(dot / np.sqrt(na * den))
 
   # the flash node must actually be on the tape of the first pass and absent from the second
-  from twingan_amd import _lib
   seen = []
   orig_call = ops.call
 
