@@ -39,9 +39,10 @@ def parse():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=6)
   ap.add_argument('--warmup', type=int, default=2)
-  ap.add_argument('--config', type=int, default=3, choices=[1, 2, 3, 4],
-                  help="BASELINE.json configs[i]: 1 = 64x64 batch 64, 2 = 128x128 batch 32, 3 = 256x256 batch 16 per GPU (the "
-                       "metric's), 4 = 3 + self-attention at 64x64 + spectral-norm discriminators + loss scale 128")
+  ap.add_argument('--config', type=int, default=3, choices=[0, 1, 2, 3, 4],
+                  help="BASELINE.json configs[i]: 0 = plain PGGAN trainer, 4x4 stage-0, batch 16 (the reference's CPU-runnable "
+                       "plumbing case, image_generation.py), 1 = 64x64 batch 64, 2 = 128x128 batch 32, 3 = 256x256 batch 16 "
+                       "per GPU (the metric's), 4 = 3 + self-attention at 64x64 + spectral-norm discriminators + loss scale 128")
   ap.add_argument('--batch', type=int, default=None, help='pairs per GPU (default: the config\'s)')
   ap.add_argument('--hw', type=int, default=None)
   ap.add_argument('--max-ch', type=int, default=256)
@@ -55,11 +56,14 @@ def parse():
   ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
   ap.add_argument('--overlap', default='auto', choices=['auto', 'on', 'off'],
                   help='segmented backward + overlapped gradient all-reduce (auto: when N > 1)')
+  ap.add_argument('--reduce-always', action='store_true',
+                  help='one GPU: bring up a one-rank RCCL group and issue the per-segment all-reduces anyway (a one-rank sum '
+                       'is the identity) -- exercises the N > 1 schedule and its diagnostics on a 1-GPU box')
   ap.add_argument('--launch-check', action='store_true',
                   help='no kernels: bring up the N ranks, build the parameter store and time the per-segment gradient '
                        'all-reduce schedule of a step (gloo on CPU when no GPU is visible) -- tests the launcher')
   args = ap.parse_args()
-  hw, batch = {1: (64, 64), 2: (128, 32), 3: (256, 16), 4: (256, 16)}[args.config]
+  hw, batch = {0: (4, 16), 1: (64, 64), 2: (128, 32), 3: (256, 16), 4: (256, 16)}[args.config]
   if args.precision is None:
     args.precision = 'fp16' if args.config == 4 else 'bf16'
   args.hw = args.hw or hw
@@ -111,7 +115,11 @@ def launch_check(args, world, rank, device):
     torch.cuda.synchronize()
   dist.barrier() if world > 1 else None
   dt = time.perf_counter() - t0
-  return dict(ms_per_step=1e3 * dt / max(args.steps, 1),
+  st = red.stats()
+  return dict(ms_per_step=1e3 * dt / max(args.steps, 1), rccl_world=world,
+              allreduce_bytes_per_step=st['allreduce_bytes'] // max(args.steps, 1),
+              collectives_per_step=st['collectives'] // max(args.steps, 1),
+              exposed_allreduce_ms=round(st['exposed_allreduce_ms'], 4),
               grad_bytes={g: 4 * store.grad[g].numel() for g in store.GROUPS},
               segments={g: {str(p): list(b) for p, b in store.phase_bounds[g].items()} for g in store.GROUPS})
 
@@ -197,11 +205,17 @@ def roofline_pass(tr, a, b, steps=2):
                                     'mfma_util', 'mfma_flops_over_algorithmic') if kk in e} for e in rows]
     samples = samples_of(k)
     if samples:
+      # traffic and algorithmic bytes of the SAME launch (the largest sampled layer shape of this kernel), and their ratio;
+      # `algorithmic_bytes_per_launch` above is the family mean over every shape the step dispatches -- do not divide by it
       roof['traffic'] = samples[0].get('hbm_bytes_per_launch')
+      roof['traffic_shape'] = samples[0].get('shape')
+      roof['traffic_shape_algorithmic_bytes'] = samples[0].get('algorithmic_bytes_per_launch')
+      roof['traffic_over_algorithmic'] = samples[0].get('traffic_over_algorithmic')
       roof['traffic_samples'] = samples
-      utils = [e['mfma_util'] for e in samples if 'mfma_util' in e]
-      if utils:
-        roof['mfma_util'] = max(utils)
+      utils = [(e['mfma_util'], e['algorithmic_bytes_per_launch']) for e in samples if 'mfma_util' in e]
+      if utils:      # weighted by the samples' sizes (a proxy for their share of the kernel's time), not the best one
+        roof['mfma_util'] = round(sum(u * wgt for u, wgt in utils) / max(sum(wgt for _, wgt in utils), 1), 4)
+        roof['mfma_util_max'] = max(u for u, _ in utils)
       roof['traffic_source'] = ('%s: rocprofv3 --pmc, one counter set per pass; FETCH_SIZE x2 (gfx950); mfma_util = '
                                 'SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), per launch of the listed layer shape'
                                 % pmc_src)
@@ -213,6 +227,17 @@ def roofline_pass(tr, a, b, steps=2):
             mfma_util=[e['mfma_util'] for e in sm if 'mfma_util' in e],
             traffic_over_algorithmic=[e['traffic_over_algorithmic'] for e in sm if 'traffic_over_algorithmic' in e],
             shapes=[e['shape'] for e in sm])
+  # the north-star quantity: MFMA utilisation of the 3x3 conv kernels, time-weighted over the step.  Per launch the
+  # MFMA pipe is busy flops / 1024 cycles per SIMD (measured identity for the 32x32x16 / 16x16x32 bf16 instructions,
+  # DESIGN.md section 5), so utilisation = algorithmic flops / (launch time x dense peak); padding MFMAs are not counted.
+  conv3 = [(kk, ff) for kk, ff in fam.items() if ff['flops'] and kernel_key(kk)[0].startswith('conv_')]
+  if conv3:
+    t3 = sum(ff['ms'] for _, ff in conv3)
+    f3 = sum(ff['flops'] for _, ff in conv3)
+    roof['conv_mfma_util_time_weighted'] = round(f3 / (t3 * 1e-3) / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4)
+    roof['conv_kernel_time_share'] = round(t3 / t_total, 4)
+    roof['conv_mfma_util_by_kernel'] = {kk: round(ff['flops'] / (ff['ms'] * 1e-3) / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4)
+                                        for kk, ff in sorted(conv3, key=lambda kv: -kv[1]['ms'])[:12]}
   roof['kernel_time_ms_per_step'] = round(t_total / steps, 3)
   roof['kernel_time_note'] = ('sum of per-launch HIP-event durations of an EAGER pass of the same step; it exceeds ms_per_step '
                               'because the two discriminator streams overlap and eager launches add event overhead')
@@ -330,16 +355,27 @@ def main():
       dist.init_process_group(backend, rank=rank, world_size=world)
   elif have_gpu:
     torch.cuda.set_device(0)
+    if args.reduce_always:      # a one-rank RCCL group: the collectives of the N > 1 schedule on one GPU
+      os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+      os.environ.setdefault('MASTER_PORT', str(_free_port()))
+      os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+      dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
   device = torch.device('cuda', local_rank if world > 1 else 0) if have_gpu else torch.device('cpu')
   observed_world = dist.get_world_size() if world > 1 else 1
 
   def base_line(value, ms_per_step, launch):
     return {
-        'metric': METRIC if (args.hw == 256 and args.config == 3) else ('training images/sec (G+D step) at 256x256 + self-attention + spectral norm' if args.config == 4 else 'training images/sec (G+D step) at %dx%d' % (args.hw, args.hw)),
+        'metric': METRIC if (args.hw == 256 and args.config == 3) else (
+            'training images/sec (G+D step) at 256x256 + self-attention + spectral norm' if args.config == 4 else
+            'training images/sec (G+D step), plain PGGAN trainer at 4x4 stage-0' if args.config == 0 else
+            'training images/sec (G+D step) at %dx%d' % (args.hw, args.hw)),
         'value': value, 'unit': 'images/sec', 'n_gpus': observed_world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.precision, 'data': 'synthetic',
-        'config': {'workload': 'TwinGAN %dx%d stage, batch %d per GPU (configs[%d]): E/G/2xD max_ch %d, UNet + per-domain '
+        'config': {'workload': ('plain PGGAN trainer (image_generation.py), 4x4 stage-0, batch %d per GPU (configs[0]): latent-noise '
+                                'generator + one discriminator, max_ch %d, WGAN-GP, Adam; 1 step = G apply + D apply' % (
+                                    args.batch, args.max_ch)) if args.config == 0 else
+                               'TwinGAN %dx%d stage, batch %d per GPU (configs[%d]): E/G/2xD max_ch %d, UNet + per-domain '
                                'instance norm + pixel norm%s, WGAN-GP, Adam; 1 step = G apply + D apply' % (
                                    args.hw, args.hw, args.batch, args.config, args.max_ch,
                                    ' + self-attention at 64x64 + spectral-norm D + loss scale 128' if args.config == 4 else ''),
@@ -370,7 +406,13 @@ def main():
     extra = dict(do_self_attention=True, self_attention_hw=64, spectral_norm=True, loss_scale=128.0)
   cfg = Config(hw=args.hw, max_ch=args.max_ch, precision=args.precision, **extra)
   overlap = None if args.overlap == 'auto' else args.overlap == 'on'
-  tr = Trainer(cfg, device=device, seed=0, world_size=world, use_graph=not args.no_graph, overlap=overlap)
+  if args.config == 0:      # configs[0]: the plain PGGAN trainer (generator from latent noise, one discriminator)
+    from twingan_amd.image_generation import PgganTrainer
+    tr = PgganTrainer(cfg, device=device, seed=0, world_size=world, use_graph=not args.no_graph, overlap=overlap)
+  else:
+    tr = Trainer(cfg, device=device, seed=0, world_size=world, use_graph=not args.no_graph, overlap=overlap)
+  if args.reduce_always:
+    tr.reducer.always = True
   dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.precision]
   a, b = synthetic_batch(args.batch, args.hw, dtype, device, rank)
 
@@ -381,6 +423,7 @@ def main():
     sys.stderr.write('bench.py: hipGraph capture failed on rank %d (%s)\n' % (rank, tr.graph_fallback_reason))
     sys.exit(3)
   torch.cuda.synchronize()
+  tr.reducer.reset_stats()
   if world > 1:
     dist.barrier()
   torch.cuda.synchronize()
@@ -401,20 +444,32 @@ def main():
   value = args.batch * world * args.steps / elapsed
   out = base_line(round(value, 3), round(ms_per_step, 3), 'hipGraph replay' if tr.use_graph else 'eager')
   out['config']['backward_segments'] = {g: tr._nseg(g) for g in ('g', 'd')}
+  if tr.capture_note:
+    out['config']['capture_note'] = tr.capture_note
+  if tr.reducer.active:
+    # what the first run on real xGMI needs to be read: who took part, how the backward was cut, how many bytes went
+    # through the collective per step and how long the compute stream waited for it (the exposed tail of the overlap)
+    st = tr.reducer.stats()
+    out['allreduce'] = dict(rccl_world=observed_world, backend=dist.get_backend() if dist.is_initialized() else None,
+                            overlap='segmented' if tr.split else 'after the whole backward',
+                            allreduce_bytes_per_step=st['allreduce_bytes'] // args.steps,
+                            collectives_per_step=st['collectives'] // args.steps,
+                            exposed_allreduce_ms_per_step=round(st['exposed_allreduce_ms'] * st['finishes'] / args.steps, 4),
+                            exposed_max_ms=round(st['exposed_max_ms'], 4), rank=rank)
   if args.hw == 256:
     tf = value * GFLOP_PER_PAIR_256 / 1e3 / world
     out['step_mfma_frac'] = round(tf / BF16_MFMA_PEAK_TFLOPS, 4)       # whole-step fraction of the conv roofline
   if rank == 0 and world == 1:
     if not args.no_roofline:
       out['roofline'] = roofline_pass(tr, a, b)
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and args.config != 0:
       tr.close()
       del tr
       torch.cuda.empty_cache()
       out['cpu_baseline'] = cpu_baseline(args)
   if rank == 0:
     print(json.dumps(out))
-  if world > 1:
+  if dist.is_initialized():
     dist.destroy_process_group()
 
 

@@ -121,13 +121,14 @@ int tg_conv2d_bwd_weight2_bias(const TgConvDesc* d, int nb, const void* xa, cons
 /* generator_three_layer_block's first conv (nets/pggan.py:69-78) with its input concat(nearest_up2(x0), x1)
  * (resize_twice_as_big + maybe_concat_unet_layer, nets/pggan_utils.py:281-298,349-350) read straight from the two
  * sources instead of from a materialised copy: y[n,h,w,cout] = conv3x3_same(concat(up2(x0 [n,h/2,w/2,c0]),
- * x1 [n1,h,w,c1]), w) and its filter gradient gw[3][3][c0+c1][cout].  bf16 activations; w_pack = mode-0 pack of the
+ * x1 [n1,h,w,c1]), w) and its filter gradient gw[3][3][c0+c1][cout].  16-bit activations (dtype = TG_BF16 / TG_F16, packs
+ * in the same format); w_pack = mode-0 pack of the
  * ordinary [3,3,c0+c1,cout] kernel; (gsz, perm) as in tg_upsample2x_concat_fwd.  The input gradient is the ordinary
  * tg_conv2d_bwd_data followed by tg_upsample2x_concat_bwd.  tg_conv2d_upcat_supported: h % 8 == 0, w % 16 == 0,
  * c0 % 32 == 0, c1 % 32 == 0, cout % 8 == 0. */
 int tg_conv2d_upcat_supported(int h, int w, int c0, int c1, int cout);
 int tg_conv2d_upcat_fwd(const void* x0, const void* x1, const void* w_pack, void* y, int n, int h, int w, int c0, int c1,
-                        int cout, int gsz, unsigned perm, void* stream);
+                        int cout, int gsz, unsigned perm, int dtype, void* stream);
 /* Conv followed by a normaliser (every encoder / generator conv: layers.conv2d(normalizer_fn=instance_norm),
  * nets/pggan_utils.py:86-98 -> tf.nn.moments over the conv output, libs/instance_norm.py:131): the forward conv also
  * writes, per output channel, the sum and the sum of squares of the (bf16-rounded) outputs each workgroup produced --
@@ -147,11 +148,12 @@ int tg_conv2d_fwd_stats(const TgConvDesc* d, const void* x, const void* w_pack, 
                         void* stream);
 int tg_conv2d_upcat_fwd_stats_chunks(int n, int h, int w, int c0, int c1, int cout);
 int tg_conv2d_upcat_fwd_stats(const void* x0, const void* x1, const void* w_pack, void* y, float* partials, int chunks,
-                              int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, void* stream);
+                              int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, int dtype, void* stream);
 size_t tg_conv2d_upcat_bwd_weight_workspace(int n, int h, int w, int c0, int c1, int cout);
 int tg_conv2d_upcat_bwd_weight(const void* x0, const void* x1, const void* gy, float* gw, int accumulate, void* workspace,
                                size_t workspace_bytes, int n, int h, int w, int c0, int c1, int cout, int gsz,
-                               unsigned perm, void* stream);
+                               unsigned perm, int dtype,
+                               void* stream);
 
 /* bf16 K-contiguous weight packs for the MFMA kernels, from the fp32 HWIO master (`d` = forward
  * descriptor; a kxk VALID conv on a kxk input is packed as the equivalent dense 1x1 over k*k*cin).

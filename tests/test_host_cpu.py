@@ -306,8 +306,42 @@ def test_bench_gpus_n_spawns_n_ranks():
   d = json.loads(lines[0])
   assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['config']['global_batch'] == 32
   assert 'world 2' in d['config']['collective'] and d['scaling'] == 'weak'
-  seg = d['launch_check']['segments']
+  lc = d['launch_check']
+  seg = lc['segments']
   assert len(seg['g']) >= 1 and len(seg['d']) >= 1
+  # the diagnostics the first real N > 1 run will be read by: who took part, the bytes through the collective per step
+  # (= both groups' flat gradient buffers, once each), one collective per backward segment, the exposed wait
+  assert lc['rccl_world'] == 2
+  assert lc['allreduce_bytes_per_step'] == lc['grad_bytes']['g'] + lc['grad_bytes']['d']
+  assert lc['collectives_per_step'] == len(seg['g']) + len(seg['d'])
+  assert lc['exposed_allreduce_ms'] >= 0.0
+
+
+def test_grad_reducer_statistics_single_process():
+  """dp.GradReducer.stats(): bytes / collectives / finishes / exposed wait of the per-segment all-reduces, exercised with
+  a one-rank gloo group and always=True (the tools/rccl_smoke.py path: a one-rank sum is the identity)."""
+  import torch.distributed as dist
+  from twingan_amd.dp import GradReducer
+  import socket
+  sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+  dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
+  try:
+    red = GradReducer(1, None, always=True)
+    assert red.active
+    buf = torch.arange(1000, dtype=torch.float32)
+    for _ in range(3):
+      red.start(buf[:600], n_buckets=1)
+      red.start(buf[600:], n_buckets=2)
+      red.finish()
+    st = red.stats()
+    assert st['allreduce_bytes'] == 3 * 4000 and st['collectives'] == 3 * 3 and st['finishes'] == 3
+    assert st['exposed_allreduce_ms'] >= 0.0 and st['exposed_max_ms'] >= st['exposed_allreduce_ms']
+    assert torch.equal(buf, torch.arange(1000, dtype=torch.float32))
+    red.reset_stats()
+    assert red.stats()['allreduce_bytes'] == 0
+    assert GradReducer(1, None).start(buf) == 0      # a single clone without `always`: no collective, no statistics
+  finally:
+    dist.destroy_process_group()
 
 
 def test_gradient_phases_are_contiguous_ranges():

@@ -48,7 +48,7 @@ SIGNATURES = {
     'tg_conv2d_bwd_weight_bias': (c_int, [_D, _P, _P, _FP, _FP, c_int, _P, c_size_t, _P]),
     'tg_conv2d_bwd_weight2_bias': (c_int, [_D, c_int, _P, _P, _P, _P, _FP, _FP, c_int, c_int, _P, c_size_t, _P]),
     'tg_conv2d_upcat_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
-    'tg_conv2d_upcat_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_uint, _P]),
+    'tg_conv2d_upcat_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_uint, c_int, _P]),
     'tg_transpose16': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'tg_flash_attention_supported': (c_int, [c_int, c_int, c_int]),
     'tg_flash_attention_workspace_bytes': (ctypes.c_int64, [c_int, c_int, c_int, c_int, c_int]),
@@ -67,10 +67,10 @@ SIGNATURES = {
     'tg_conv2d_fwd_stats': (c_int, [_D, _P, _P, _P, _FP, c_int, _P]),
     'tg_conv2d_upcat_fwd_stats_chunks': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     'tg_conv2d_upcat_fwd_stats': (c_int, [_P, _P, _P, _P, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_uint,
-                                          _P]),
+                                          c_int, _P]),
     'tg_conv2d_upcat_bwd_weight_workspace': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     'tg_conv2d_upcat_bwd_weight': (c_int, [_P, _P, _P, _FP, c_int, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int,
-                                           c_int, c_uint, _P]),
+                                           c_int, c_uint, c_int, _P]),
     'tg_conv2d_pack_elems': (c_size_t, [_D, c_int]),
     'tg_conv2d_pack_weights': (c_int, [_D, _FP, c_int, _P, _P]),
     'tg_pack_table_bytes': (c_size_t, [c_int]),

@@ -181,8 +181,9 @@ int tg_conv2d_upcat_supported(int h, int w, int c0, int c1, int cout) {
   return tg_conv_tile_upcat_supported(h, w, c0, c1, cout) ? 1 : 0;
 }
 
-static int check_upcat(const char* who, int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm) {
-  tg_set_elem_f16(false);      // the two-source kernels take no dtype: bfloat16
+static int check_upcat(const char* who, int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, int dtype) {
+  TG_CHECK(dtype == TG_BF16 || dtype == TG_F16, TG_EINVAL, "%s: 16-bit storage only (dtype %d)", who, dtype);
+  tg_set_elem_f16(dtype == TG_F16);      // read by the MFMA launchers this call reaches
   TG_CHECK(n > 0 && tg_conv_tile_upcat_supported(h, w, c0, c1, cout), TG_ENOSUP,
            "%s: needs h %% 8 == 0, w %% 16 == 0, c0 and c1 multiples of 32 (got %dx%d, %d+%d -> %d)", who, h, w, c0, c1, cout);
   TG_CHECK(gsz >= 0 && (gsz == 0 || (n % gsz == 0 && n / gsz <= 4)), TG_EINVAL, "%s: bad skip groups (n %d, gsz %d)", who, n,
@@ -192,9 +193,9 @@ static int check_upcat(const char* who, int n, int h, int w, int c0, int c1, int
 }
 
 int tg_conv2d_upcat_fwd(const void* x0, const void* x1, const void* w_pack, void* y, int n, int h, int w, int c0, int c1,
-                        int cout, int gsz, unsigned perm, void* stream) {
+                        int cout, int gsz, unsigned perm, int dtype, void* stream) {
   TG_CHECK(x0 && x1 && w_pack && y, TG_EINVAL, "tg_conv2d_upcat_fwd: null pointer");
-  int rc = check_upcat("tg_conv2d_upcat_fwd", n, h, w, c0, c1, cout, gsz, perm);
+  int rc = check_upcat("tg_conv2d_upcat_fwd", n, h, w, c0, c1, cout, gsz, perm, dtype);
   if (rc) return rc;
   return tg_conv_tile_upcat_run(n, h, w, c0, c1, cout, gsz, perm, x0, x1, w_pack, y, (hipStream_t)stream);
 }
@@ -242,9 +243,9 @@ int tg_conv2d_upcat_fwd_stats_chunks(int n, int h, int w, int c0, int c1, int co
 }
 
 int tg_conv2d_upcat_fwd_stats(const void* x0, const void* x1, const void* w_pack, void* y, float* partials, int chunks, int n,
-                              int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, void* stream) {
+                              int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, int dtype, void* stream) {
   TG_CHECK(x0 && x1 && w_pack && y && partials, TG_EINVAL, "tg_conv2d_upcat_fwd_stats: null pointer");
-  int rc = check_upcat("tg_conv2d_upcat_fwd_stats", n, h, w, c0, c1, cout, gsz, perm);
+  int rc = check_upcat("tg_conv2d_upcat_fwd_stats", n, h, w, c0, c1, cout, gsz, perm, dtype);
   if (rc) return rc;
   TG_CHECK(chunks > 0 && chunks == tg_conv2d_upcat_fwd_stats_chunks(n, h, w, c0, c1, cout), TG_EINVAL,
            "tg_conv2d_upcat_fwd_stats: chunks %d does not match tg_conv2d_upcat_fwd_stats_chunks()", chunks);
@@ -259,9 +260,9 @@ size_t tg_conv2d_upcat_bwd_weight_workspace(int n, int h, int w, int c0, int c1,
 
 int tg_conv2d_upcat_bwd_weight(const void* x0, const void* x1, const void* gy, float* gw, int accumulate, void* ws,
                                size_t ws_bytes, int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm,
-                               void* stream) {
+                               int dtype, void* stream) {
   TG_CHECK(x0 && x1 && gy && gw, TG_EINVAL, "tg_conv2d_upcat_bwd_weight: null pointer");
-  int rc = check_upcat("tg_conv2d_upcat_bwd_weight", n, h, w, c0, c1, cout, gsz, perm);
+  int rc = check_upcat("tg_conv2d_upcat_bwd_weight", n, h, w, c0, c1, cout, gsz, perm, dtype);
   if (rc) return rc;
   return tg_wgrad_tile_upcat_run(n, h, w, c0, c1, cout, gsz, perm, x0, x1, gy, gw, accumulate, ws, ws_bytes,
                                  (hipStream_t)stream);

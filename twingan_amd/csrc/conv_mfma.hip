@@ -570,7 +570,7 @@ int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int
 bool tg_conv2d_fwd_pool_supported_mfma(const TgConvDesc* d0) {
   TgConvDesc dd;
   const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
-  if (d->dtype != TG_BF16 || d->algo == TG_ALGO_MFMA_V1 || d->kh != 3 || d->cin % 8 || d->cout % 8) return false;
+  if (!is16(d) || d->algo == TG_ALGO_MFMA_V1 || d->kh != 3 || d->cin % 8 || d->cout % 8) return false;
   return tg_conv_tile_supported(d->hin, d->win, d->hout, d->wout, d->kh, d->kw, d->pad_t, d->pad_l);
 }
 
@@ -589,7 +589,7 @@ int tg_conv2d_fwd_pool_mfma(const TgConvDesc* d0, const void* x, const void* wp,
 int tg_conv2d_fwd_stats_chunks_mfma(const TgConvDesc* d0) {
   TgConvDesc dd;
   const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
-  if (d->dtype != TG_BF16 || d->algo == TG_ALGO_MFMA_V1 || d->kh != 3 || d->cin % 8 || d->cout % 8 || d->epilogue) return 0;
+  if (!is16(d) || d->algo == TG_ALGO_MFMA_V1 || d->kh != 3 || d->cin % 8 || d->cout % 8 || d->epilogue) return 0;
   if (!tg_conv_tile_supported(d->hin, d->win, d->hout, d->wout, d->kh, d->kw, d->pad_t, d->pad_l)) return 0;
   int chunks = 0;
   if (tg_conv_tile_run(d->n, d->hin, d->win, d->cin, d->cout, d->kh, d->pad_t, 0, 0.f, nullptr, nullptr, nullptr, nullptr,

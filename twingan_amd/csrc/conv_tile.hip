@@ -692,7 +692,6 @@ int launch_tile_wres(const TileGeom& g0, const bf16* x, const bf16* wp, const fl
   if (tpw < 1) tpw = 1;
   if (tpw > 16) tpw = 16;
   const bool stats = g.stats || g.chunks_query;
-  TG_CHECK(!g.f16 || !(g.stats || g.ypool), TG_ENOSUP, "conv_tile(wres): the statistics / pool epilogues are bf16 only");
   if (stats) {      // a workgroup must stay inside one image
     const int tpi = g.tiles_x * g.tiles_y;
     while (tpi % tpw) --tpw;
@@ -707,30 +706,63 @@ int launch_tile_wres(const TileGeom& g0, const bf16* x, const bf16* wp, const fl
   const int nwg = (g.nblk + tpw - 1) / tpw;
   const size_t lds = (size_t)((HH * HWX * (KC * 2 + 16) + 15) & ~15) + (size_t)NCH * BN * (KH * KH * KC * 2 + 16);
   TG_CHECK(lds <= 64 * 1024, TG_ENOSUP, "conv_tile(wres): LDS %zu too large", lds);
+  const char* fmt = g.f16 ? ",f16" : "";
+// the epilogue variant MODE_ in the element format of the call (both formats are instantiated for every epilogue)
+#define TG_WRES_LAUNCH(MODE_)                                                                                              \
+  do {                                                                                                                     \
+    if (g.f16)                                                                                                             \
+      hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH, MODE_, true>), dim3(nwg, ny), dim3(256), lds, s, x, wp,  \
+                         bias, y, g);                                                                                      \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH, MODE_, false>), dim3(nwg, ny), dim3(256), lds, s, x, wp, \
+                         bias, y, g);                                                                                      \
+  } while (0)
   if (stats) {
     if constexpr (KH == 3) {
       TG_CHECK(g.epilogue == 0 && !g.mask && !g.ypool, TG_ENOSUP, "conv_tile(wres): statistics come with the plain epilogue only");
-      tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d,stats>", KH, KC, BN, NCH);
-      hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH, 1>), dim3(nwg, ny), dim3(256), lds, s, x, wp, bias, y, g);
+      tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d,stats%s>", KH, KC, BN, NCH, fmt);
+      TG_WRES_LAUNCH(1);
     } else {
       TG_CHECK(false, TG_ENOSUP, "conv_tile(wres): statistics epilogue is built for 3x3 only");
     }
   } else if (g.ypool) {
     if constexpr (KH == 3) {
       TG_CHECK(!g.mask, TG_ENOSUP, "conv_tile(wres): the pooled output is a forward feature");
-      tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d,pool>", KH, KC, BN, NCH);
-      hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH, 2>), dim3(nwg, ny), dim3(256), lds, s, x, wp, bias, y, g);
+      tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d,pool%s>", KH, KC, BN, NCH, fmt);
+      TG_WRES_LAUNCH(2);
     } else {
       TG_CHECK(false, TG_ENOSUP, "conv_tile(wres): pooled output is built for 3x3 only");
     }
-  } else if (g.f16) {
-    tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d,f16>", KH, KC, BN, NCH);
-    hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH, 0, true>), dim3(nwg, ny), dim3(256), lds, s, x, wp, bias, y, g);
   } else {
-    tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d>", KH, KC, BN, NCH);
-    hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH>), dim3(nwg, ny), dim3(256), lds, s, x, wp, bias, y, g);
+    tg_note_kernel(g.f16 ? "conv_tile_wres_kernel<%d,%d,%d,%d,f16>" : "conv_tile_wres_kernel<%d,%d,%d,%d>", KH, KC, BN, NCH);
+    TG_WRES_LAUNCH(0);
   }
+#undef TG_WRES_LAUNCH
   TG_LAUNCH_CHECK("conv_tile_wres");
+  return TG_OK;
+}
+
+// one instantiation of the tile kernel: raises its dynamic-LDS limit once, notes its name, launches
+template <int KH, int KC, int BN, int MT, bool UPCAT, int MODE, bool F16>
+int launch_tile_variant(const TileGeom& g, size_t lds, const bf16* x, const bf16* wp, const float* bias, bf16* y, hipStream_t s) {
+  auto kern = conv_tile_kernel<KH, KC, BN, MT, UPCAT, MODE, F16>;
+  if (lds > 64 * 1024) {
+    static bool raised = false;      // per instantiation
+    if (!raised) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+          hipSuccess) {
+        tg_set_error("conv_tile: cannot raise dynamic LDS to %zu", lds);
+        return TG_ELAUNCH;
+      }
+      raised = true;
+    }
+  }
+  // names as before for the bf16 kernels (tests/golden/bench_dispatch_kernels.json); ",f16" marks the half instantiation
+  static const char* const mode_tag[3] = {"", ",stats", ",pool"};
+  if (F16 && MODE == 0 && !UPCAT) tg_note_kernel("conv_tile_kernel<%d,%d,%d,%d,f16>", KH, KC, BN, MT);
+  else tg_note_kernel("conv_tile_kernel<%d,%d,%d,%d%s%s%s>", KH, KC, BN, MT, UPCAT ? ",upcat" : "", mode_tag[MODE], F16 ? ",f16" : "");
+  hipLaunchKernelGGL(kern, dim3(g.nblk, (g.cout + BN - 1) / BN), dim3(256), lds, s, x, wp, bias, y, g);
+  TG_LAUNCH_CHECK("conv_tile");
   return TG_OK;
 }
 
@@ -747,28 +779,13 @@ int launch_tile(const TileGeom& g0, const bf16* x, const bf16* wp, const float* 
     *g.chunks_query = (KH == 3) ? g.tiles_x * g.tiles_y : 0;
     return TG_OK;
   }
-  TG_CHECK(!g.f16 || !(g.stats || g.ypool), TG_ENOSUP, "conv_tile: the statistics / pool epilogues are bf16 only");
   if (g.stats) {
     if constexpr (KH == 3) {
       TG_CHECK(g.epilogue == 0 && !g.mask, TG_ENOSUP, "conv_tile: statistics come with the plain epilogue only");
       TG_CHECK(g.stat_chunks == g.tiles_x * g.tiles_y, TG_EINVAL, "conv_tile: stat_chunks %d, this dispatch writes %d",
                g.stat_chunks, g.tiles_x * g.tiles_y);
-      auto kst = conv_tile_kernel<KH, KC, BN, MT, UPCAT, 1>;
-      if (lds > 64 * 1024) {
-        static bool raised_st = false;
-        if (!raised_st) {
-          if (hipFuncSetAttribute(reinterpret_cast<const void*>(kst), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-              hipSuccess) {
-            tg_set_error("conv_tile: cannot raise dynamic LDS to %zu", lds);
-            return TG_ELAUNCH;
-          }
-          raised_st = true;
-        }
-      }
-      tg_note_kernel(UPCAT ? "conv_tile_kernel<%d,%d,%d,%d,upcat,stats>" : "conv_tile_kernel<%d,%d,%d,%d,stats>", KH, KC, BN, MT);
-      hipLaunchKernelGGL(kst, dim3(g.nblk, (g.cout + BN - 1) / BN), dim3(256), lds, s, x, wp, bias, y, g);
-      TG_LAUNCH_CHECK("conv_tile");
-      return TG_OK;
+      return g.f16 ? launch_tile_variant<KH, KC, BN, MT, UPCAT, 1, true>(g, lds, x, wp, bias, y, s)
+                   : launch_tile_variant<KH, KC, BN, MT, UPCAT, 1, false>(g, lds, x, wp, bias, y, s);
     } else {
       TG_CHECK(false, TG_ENOSUP, "conv_tile: statistics epilogue is built for 3x3 only");
     }
@@ -776,65 +793,14 @@ int launch_tile(const TileGeom& g0, const bf16* x, const bf16* wp, const float* 
   if (g.ypool) {
     if constexpr (KH == 3 && !UPCAT) {
       TG_CHECK(!g.mask, TG_ENOSUP, "conv_tile: the pooled output is a forward feature");
-      auto kp = conv_tile_kernel<KH, KC, BN, MT, false, 2>;
-      if (lds > 64 * 1024) {
-        static bool raised_p = false;
-        if (!raised_p) {
-          if (hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-              hipSuccess) {
-            tg_set_error("conv_tile: cannot raise dynamic LDS to %zu", lds);
-            return TG_ELAUNCH;
-          }
-          raised_p = true;
-        }
-      }
-      tg_note_kernel("conv_tile_kernel<%d,%d,%d,%d,pool>", KH, KC, BN, MT);
-      hipLaunchKernelGGL(kp, dim3(g.nblk, (g.cout + BN - 1) / BN), dim3(256), lds, s, x, wp, bias, y, g);
-      TG_LAUNCH_CHECK("conv_tile");
-      return TG_OK;
+      return g.f16 ? launch_tile_variant<KH, KC, BN, MT, false, 2, true>(g, lds, x, wp, bias, y, s)
+                   : launch_tile_variant<KH, KC, BN, MT, false, 2, false>(g, lds, x, wp, bias, y, s);
     } else {
       TG_CHECK(false, TG_ENOSUP, "conv_tile: pooled output is built for plain 3x3 convs only");
     }
   }
-  if (g.f16) {
-    if constexpr (!UPCAT) {
-      auto kh = conv_tile_kernel<KH, KC, BN, MT, false, 0, true>;
-      if (lds > 64 * 1024) {
-        static bool raised_h = false;
-        if (!raised_h) {
-          if (hipFuncSetAttribute(reinterpret_cast<const void*>(kh), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-              hipSuccess) {
-            tg_set_error("conv_tile: cannot raise dynamic LDS to %zu", lds);
-            return TG_ELAUNCH;
-          }
-          raised_h = true;
-        }
-      }
-      tg_note_kernel("conv_tile_kernel<%d,%d,%d,%d,f16>", KH, KC, BN, MT);
-      hipLaunchKernelGGL(kh, dim3(g.nblk, (g.cout + BN - 1) / BN), dim3(256), lds, s, x, wp, bias, y, g);
-      TG_LAUNCH_CHECK("conv_tile");
-      return TG_OK;
-    } else {
-      TG_CHECK(false, TG_ENOSUP, "conv_tile: the two-source (upcat) kernels are bf16 only");
-    }
-  }
-  auto kern = conv_tile_kernel<KH, KC, BN, MT, UPCAT>;
-  if (lds > 64 * 1024) {
-    static bool raised = false;      // per instantiation
-    if (!raised) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-          hipSuccess) {
-        tg_set_error("conv_tile: cannot raise dynamic LDS to %zu", lds);
-        return TG_ELAUNCH;
-      }
-      raised = true;
-    }
-  }
-  dim3 grid(g.nblk, (g.cout + BN - 1) / BN);
-  tg_note_kernel(UPCAT ? "conv_tile_kernel<%d,%d,%d,%d,upcat>" : "conv_tile_kernel<%d,%d,%d,%d>", KH, KC, BN, MT);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, wp, bias, y, g);
-  TG_LAUNCH_CHECK("conv_tile");
-  return TG_OK;
+  return g.f16 ? launch_tile_variant<KH, KC, BN, MT, UPCAT, 0, true>(g, lds, x, wp, bias, y, s)
+               : launch_tile_variant<KH, KC, BN, MT, UPCAT, 0, false>(g, lds, x, wp, bias, y, s);
 }
 
 // forward over concat(nearest_up2(x), x1): 3x3, both channel counts multiples of 32
@@ -910,7 +876,7 @@ bool tg_conv_tile_upcat_supported(int h, int w, int c0, int c1, int cout) {
 
 int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, const void* x0,
                            const void* x1, const void* wp, void* y, hipStream_t s, float* stats, int stat_chunks,
-                           int* chunks_query) {
+                           int* chunks_query) {      // element format: tg_elem_f16(), set by the C-ABI entry point
   TileGeom g;
   g.n = n; g.h = h; g.w = w; g.cin = c0 + c1; g.cout = cout;
   g.cin_pad = g.cin;
@@ -928,6 +894,6 @@ int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gs
   g.stat_chunks = stat_chunks;
   g.chunks_query = chunks_query;
   g.ypool = nullptr;
-  g.f16 = false;
+  g.f16 = tg_elem_f16();
   return dispatch_tile_upcat(g, (const bf16*)x0, (const bf16*)wp, nullptr, (bf16*)y, s);
 }

@@ -36,7 +36,12 @@ def bucket_bounds(numel, n_buckets, align=64):
 
 
 class GradReducer:
-  """Sum all-reduce of one flat gradient buffer across clones, in ``n_buckets`` async pieces."""
+  """Sum all-reduce of one flat gradient buffer across clones, in ``n_buckets`` async pieces.
+
+  Diagnostics for the first run on real xGMI (``stats()``): bytes handed to the collective and, per finish(), the time
+  the compute stream sat waiting for it -- HIP events around the wait on a GPU (resolved lazily, no host sync inside a
+  step), wall clock on the CPU backends.  That wait is the EXPOSED part of the all-reduce: with the segmented backward
+  only the last, small range should show up in it."""
 
   def __init__(self, world_size=1, process_group=None, n_buckets=2, always=False):
     """``always``: issue the collectives for a single clone too (tools/rccl_smoke.py: exercises RCCL and the
@@ -46,6 +51,13 @@ class GradReducer:
     self.n_buckets = n_buckets
     self.always = always
     self._pending = []
+    self.reset_stats()
+
+  def reset_stats(self):
+    self._bytes = 0
+    self._collectives = 0
+    self._finishes = 0
+    self._waits = []        # (start event, end event) on a GPU, seconds (float) on the CPU
 
   @property
   def active(self):
@@ -62,13 +74,46 @@ class GradReducer:
     bounds = bucket_bounds(flat_grad.numel(), n_buckets or self.n_buckets)
     for lo, hi in bounds:
       self._pending.append(dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+    self._bytes += flat_grad.numel() * flat_grad.element_size()
+    self._collectives += len(bounds)
+    self._device = flat_grad.device
     return len(bounds)
 
   def finish(self):
     """Makes the reduced gradients visible to the stream Adam is enqueued on."""
+    if not self._pending:
+      return
+    on_gpu = self._device.type == 'cuda'
+    if on_gpu:
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record()
+    else:
+      import time
+      t0 = time.perf_counter()
     for w in self._pending:
       w.wait()
+    if on_gpu:
+      e1.record()
+      self._waits.append((e0, e1))
+      if len(self._waits) > 4096:      # a long training run: keep the tail
+        del self._waits[:2048]
+    else:
+      self._waits.append(time.perf_counter() - t0)
+    self._finishes += 1
     self._pending = []
+
+  def stats(self):
+    """dict(allreduce_bytes, collectives, finishes, exposed_allreduce_ms = mean per finish(), exposed_max_ms) since the
+    last reset_stats().  Synchronises the device (call it outside the timed region)."""
+    ms = []
+    for w in self._waits:
+      if isinstance(w, tuple):
+        w[1].synchronize()
+        ms.append(w[0].elapsed_time(w[1]))
+      else:
+        ms.append(1e3 * w)
+    return dict(allreduce_bytes=int(self._bytes), collectives=int(self._collectives), finishes=int(self._finishes),
+                exposed_allreduce_ms=(sum(ms) / len(ms)) if ms else 0.0, exposed_max_ms=max(ms) if ms else 0.0)
 
   def allreduce(self, flat_grad):
     self.start(flat_grad)

@@ -24,6 +24,7 @@ def generate(P, noise, cfg):
 def generator_loss(P, targets, cfg, noise):
   """GENERATOR_LOSSES of the plain trainer: generator_fool_loss (image_generation.py:331-344).  Returns (total, terms)."""
   assert cfg.loss_architecture in LOSSES, cfg.loss_architecture
+  pggan.prepare_run(P, cfg)
   fake = generate(P, noise, cfg)
   pred, _ = pggan.discriminator(P, fake, cfg, 'discriminator')
   terms = {'generator_fool_loss': _fool_loss(pred, cfg)}
@@ -33,6 +34,7 @@ def generator_loss(P, targets, cfg, noise):
 def discriminator_loss(P, targets, cfg, noise, gp_alpha, dragan_noise=None):
   """DISCRIMINATOR_LOSSES (image_generation.py:348-476): real / fake terms, drift, gradient penalty."""
   assert cfg.loss_architecture in LOSSES, cfg.loss_architecture
+  pggan.prepare_run(P, cfg)
   with torch.no_grad():
     if cfg.is_growing:
       targets = get_growing_image(targets, cfg.alpha_grow)      # get_growing_source_and_target (:985-1006)

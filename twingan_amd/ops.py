@@ -1117,7 +1117,7 @@ class UpsampleConcatFn(torch.autograd.Function):
 
 def upcat_conv_supported(x0, x1, w):
   """Can conv3x3(concat(up2(x0), x1), w) run from the two sources without materialising the concat?"""
-  if x1 is None or x0.dtype != torch.bfloat16 or w.shape[0] != 3:
+  if x1 is None or x0.dtype not in HALF_TYPES or x1.dtype != x0.dtype or w.shape[0] != 3:
     return False
   return bool(_lib.load().tg_conv2d_upcat_supported(2 * x0.shape[1], 2 * x0.shape[2], x0.shape[3], x1.shape[3], w.shape[3]))
 
@@ -1146,11 +1146,11 @@ class UpcatConvFn(torch.autograd.Function):
     if chunks > 0:
       part = torch.empty(n * chunks * 2 * cout, dtype=torch.float32, device=x0.device)
       call('tg_conv2d_upcat_fwd_stats', _p(x0), _p(x1), _p(PackCache.get(w, d, 0)), _p(y), _p(part), chunks, n, H, W, c0, c1,
-           cout, gsz, pk, _stream(), work=work)
+           cout, gsz, pk, _dt(x0), _stream(), work=work)
       holder.append(ConvStats(part, chunks))
     else:
       call('tg_conv2d_upcat_fwd', _p(x0), _p(x1), _p(PackCache.get(w, d, 0)), _p(y), n, H, W, c0, c1, cout, gsz, pk,
-           _stream(), work=work)
+           _dt(x0), _stream(), work=work)
       if holder is not None:
         holder.append(None)
     ctx.dims = (n, H, W, c0, c1, cout, gsz, pk, x1.shape[0])
@@ -1178,7 +1178,7 @@ class UpcatConvFn(torch.autograd.Function):
       nbytes = lib.tg_conv2d_upcat_bwd_weight_workspace(n, H, W, c0, c1, cout)
       ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=gy.device)
       call('tg_conv2d_upcat_bwd_weight', _p(x0), _p(x1), _p(gy), _p(gw), 1 if sink is not None else 0, _p(ws), nbytes,
-           n, H, W, c0, c1, cout, gsz, pk, _stream(),
+           n, H, W, c0, c1, cout, gsz, pk, _dt(gy), _stream(),
            work=lambda: ('wgrad:upcat:k3:c%d+%d>%d:hw%d:n%d' % (c0, c1, cout, H, n), 2 * n * H * W * cout * 9 * (c0 + c1),
                          2 * (x0.numel() + x1.numel() + gy.numel()) + 4 * w.numel()))
       if sink is not None:
@@ -1670,12 +1670,18 @@ class SpectralNormFn(torch.autograd.Function):
   the gradient flow through sigma, v and u_new like the reference's graph; it is first order -- the gradient-penalty
   double backward reaches the master weight through w_bar, i.e. through ONE application of this node's backward."""
 
+  out_buffer = None      # side channel of spectral_norm(): the persistent fp32 buffer this forward writes w_bar into
+
   @staticmethod
   def forward(ctx, w, u):
     _chk(w, u)
     cout = w.shape[-1]
     k_rows = w.numel() // cout
-    w_bar, u_new = torch.empty_like(w), torch.empty_like(u)
+    buf, SpectralNormFn.out_buffer = SpectralNormFn.out_buffer, None
+    # a fresh tensor object over the persistent storage: the buffer is rewritten by every run, the alias carries this
+    # run's grad_fn
+    w_bar = torch.empty_like(w) if buf is None else buf.view(w.shape)
+    u_new = torch.empty_like(u)
     v = torch.empty(k_rows, dtype=torch.float32, device=w.device)
     stats = torch.empty(2, dtype=torch.float32, device=w.device)
     nbytes = _lib.load().tg_spectral_norm_workspace(k_rows, cout)
@@ -1701,9 +1707,16 @@ class SpectralNormFn(torch.autograd.Function):
     return (None if sink is not None else gw), None
 
 
-def spectral_norm(w, u):
-  """-> (w_bar, u_new); see SpectralNormFn."""
-  return SpectralNormFn.apply(w, u.contiguous())
+def spectral_norm(w, u, out=None):
+  """-> (w_bar, u_new); see SpectralNormFn.  ``out``: a persistent fp32 buffer of w's size that receives w_bar (its
+  MFMA packs then live in PackCache like a master weight's and are rebuilt by PackCache.refresh, one launch for all
+  normalised kernels of a run, instead of once per use)."""
+  assert out is None or (out.dtype == torch.float32 and out.numel() == w.numel() and out.is_contiguous())
+  SpectralNormFn.out_buffer = out
+  try:
+    return SpectralNormFn.apply(w, u.contiguous())
+  finally:
+    SpectralNormFn.out_buffer = None
 
 
 # ------------------------------------------------------------------------------------------------

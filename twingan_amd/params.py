@@ -229,6 +229,8 @@ class ParamStore:
     for p in self.P.values():
       GradSink.unregister(p)
       PackCache.unregister(p)
+    for buf in self.P.__dict__.pop('sn_wbar', {}).values():      # persistent spectrally-normalised kernels (pggan._sn_compute)
+      PackCache.unregister(buf)
 
   def numel(self, group):
     return sum(int(math.prod(s['shape'])) for s in self.specs.values() if s['group'] == group)

@@ -52,11 +52,44 @@ def _sn(P, scope, cfg, is_discriminator):
   cache = P.__dict__.setdefault('sn_cache', {})
   if scope in cache:
     return cache[scope]
-  u = P.state[scope + '/u']
-  w_bar, u1 = ops.spectral_norm(w, u)
-  P.__dict__.setdefault('sn_pending', {})[scope + '/u'] = u1
-  cache[scope] = w_bar
+  w_bar = _sn_compute(P, scope)
+  # not prepared by prepare_run (tests that call a network function directly): the packs made from this buffer in an
+  # earlier run are stale -- rebuild the ones that exist (one launch); new ones are packed from the fresh values
+  ops.PackCache.refresh([P.__dict__['sn_wbar'][scope]])
   return w_bar
+
+
+def _sn_compute(P, scope):
+  """One power iteration for ``scope`` into its persistent w_bar buffer; notes u' for end_run()."""
+  w = P[scope + '/weights']
+  bufs = P.__dict__.setdefault('sn_wbar', {})
+  buf = bufs.get(scope)
+  if buf is None or buf.numel() != w.numel() or buf.device != w.device:
+    import torch
+    buf = bufs[scope] = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+    ops.PackCache.register(buf)
+  w_bar, u1 = ops.spectral_norm(w, P.state[scope + '/u'], out=buf)
+  P.__dict__.setdefault('sn_pending', {})[scope + '/u'] = u1
+  P.__dict__.setdefault('sn_cache', {})[scope] = w_bar
+  return w_bar
+
+
+def prepare_run(P, cfg):
+  """Start of one session.run equivalent under --spectral_norm: the power iteration of EVERY normalised kernel (each is
+  used by the run: a generator step also runs the discriminators forward, a discriminator step the encoder / generator)
+  from the pre-run u, then ONE launch that rebuilds all their MFMA packs (PackCache.refresh) -- instead of one pack
+  launch per kernel, direction and use (1 196 launches in five config-4 steps, profiles/r02_g_bench_c4_kernel_stats.csv)."""
+  if not cfg.spectral_norm:
+    return 0
+  scopes = [k[:-2] for k in P.state if k.endswith('/u')]
+  cache = P.__dict__.setdefault('sn_cache', {})
+  for scope in scopes:
+    if scope not in cache:
+      _sn_compute(P, scope)
+  bufs = P.__dict__.get('sn_wbar', {})
+  if bufs:
+    ops.PackCache.refresh(list(bufs.values()))
+  return len(scopes)
 
 
 def end_run(P):

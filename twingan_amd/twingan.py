@@ -12,6 +12,7 @@ deployment/model_deploy.py:242-315,473-503 -- with two deliberate scheduling dif
     (model_deploy.py:265-268).
 """
 import ctypes
+import os
 
 import dataclasses
 
@@ -180,6 +181,7 @@ def generator_loss(P, sources, targets, cfg, style_noise=None, distill_embed_s=N
   """GENERATOR_LOSSES (twingan.py:464-521; image_generation.py:331-337).  Returns (total [1], terms).
   distill_embed_*: the datasets' fp32 [B, D] embeddings of --do_encoder_distillation (None: that dataset has none)."""
   assert cfg.loss_architecture in LOSSES, cfg.loss_architecture
+  pggan.prepare_run(P, cfg)
   if cfg.is_growing:
     sources, targets = get_growing_image(sources, cfg.alpha_grow), get_growing_image(targets, cfg.alpha_grow)
   b = sources.shape[0]
@@ -236,6 +238,7 @@ def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t, dragan_
   dragan_noise_*: the U(-1,1) draws of get_perturbed_batch (image shaped; drawn on the device when None).
   E/G run without a tape: only discriminator variables are in the var_list (image_generation.py:605-610)."""
   assert cfg.loss_architecture in LOSSES, cfg.loss_architecture
+  pggan.prepare_run(P, cfg)      # with the tape on: the discriminators' kernels are differentiated through sigma
   with torch.no_grad():
     if cfg.is_growing:
       sources, targets = get_growing_image(sources, cfg.alpha_grow), get_growing_image(targets, cfg.alpha_grow)
@@ -316,8 +319,10 @@ class Trainer:
     """``overlap``: cut the backward into segments and start the clone all-reduce of each segment's finished
     gradients while the next one runs (None: whenever there is more than one clone; True forces the segmented
     schedule for a single clone too -- same results, used by the tests)."""
-    if cfg.spectral_norm and cfg.domain_streams:
-      # the per-run normalised kernels (pggan._sn) are shared by every use of a discriminator: keep them on one stream
+    if cfg.spectral_norm and cfg.domain_streams and os.environ.get('TG_SN_DOMAIN_STREAMS', '1') == '0':
+      # The per-run normalised kernels are computed (and their packs rebuilt) on the main stream by pggan.prepare_run
+      # before the discriminators fork onto their streams, so the two discriminators overlap under spectral norm too;
+      # TG_SN_DOMAIN_STREAMS=0 keeps everything on one stream (round-2 behaviour, for A/Bs).
       cfg = dataclasses.replace(cfg, domain_streams=False)
     self.cfg = cfg
     self.device = torch.device(device)
@@ -353,6 +358,7 @@ class Trainer:
     self._extras = None             # per-run dataset fields besides the images (run(..., distill_embed_s=, distill_embed_t=))
     self.use_graph = use_graph
     self.graph_fallback_reason = None
+    self.capture_note = None        # set when the segmented capture had to be replaced by one graph per step kind
     self._graphs = None
     self._static = None
 
@@ -536,24 +542,42 @@ class Trainer:
     self.adam_t = adam_t                          # the captured (not executed) applies
     self._graphs, self._outs = graphs, outs
 
+  def _abandon_capture(self):
+    """Leaves no half-issued step behind after a failed capture: held filter gradients, open cuts, forked side streams."""
+    torch.cuda.synchronize(self.device)
+    ops.GradSink._held.clear()
+    ops.GradSink.pair = False
+    ops.Cuts.end()
+    _DomainStreams.join_all(self.device)
+    self.store.zero_grad('g')
+    self.store.zero_grad('d')
+    self._graphs = None
+    self.adam_t = int(self._adam_step_dev.item())
+
   def _run_graph(self, kind, sources, targets):
     if self._graphs is None:
+      import warnings
       try:
         self._capture(sources, targets)
-      except Exception as e:      # keep training: eager launches are the same kernels, only the host cost differs
-        import warnings
-        self.graph_fallback_reason = '%s: %s' % (type(e).__name__, e)
-        warnings.warn('hipGraph capture failed (%s); falling back to eager launches' % self.graph_fallback_reason)
-        torch.cuda.synchronize(self.device)
-        # leave no half-issued step behind: held filter gradients, open cuts, forked side streams
-        ops.GradSink._held.clear()
-        ops.GradSink.pair = False
-        ops.Cuts.end()
-        _DomainStreams.join_all(self.device)
-        self.store.zero_grad('g')
-        self.store.zero_grad('d')
-        self.use_graph, self._graphs = False, None
-        self.adam_t = int(self._adam_step_dev.item())
+      except Exception as e:
+        reason = '%s: %s' % (type(e).__name__, e)
+        self._abandon_capture()
+        if self.split:
+          # the segmented schedule (one graph per backward segment, captured in thread_local mode beside a live
+          # communicator) could not be recorded: record ONE graph per step kind instead -- the all-reduce then starts
+          # after the whole backward (no overlap) -- and say so (bench.py prints capture_note on its line)
+          self.capture_note = 'segmented capture failed (%s); re-captured unsegmented: the all-reduce is not overlapped' % reason
+          warnings.warn(self.capture_note)
+          self.split = False
+          try:
+            self._capture(sources, targets)
+          except Exception as e2:
+            reason = '%s; unsegmented: %s: %s' % (reason, type(e2).__name__, e2)
+            self._abandon_capture()
+      if self._graphs is None:      # keep training: eager launches are the same kernels, only the host cost differs
+        self.graph_fallback_reason = reason
+        warnings.warn('hipGraph capture failed (%s); falling back to eager launches' % reason)
+        self.use_graph = False
         return self.g_step(sources, targets) if kind == 'g' else self.d_step(sources, targets)
     st = self._static
     if sources is not None and sources.data_ptr() != st['s'].data_ptr():
