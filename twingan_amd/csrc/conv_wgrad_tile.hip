@@ -16,16 +16,20 @@
 //   9 per-tap 32x32 fp32 accumulators; the next tile's global loads are in flight during the MFMAs.
 //   At the end the 4 waves are summed through LDS and the valid [cin x cout] part is written to this
 //   workgroup's fp32 slab; conv_wgrad_slab_reduce sums the slabs into gw.
+//   NW = 8 (round 3): the same wave program with EIGHT waves per workgroup on a 16-row tile (wave w: rows 2w, 2w+1):
+//   one workgroup per CU carries what two did, so the launch writes and re-reads half the slabs (256 x 36 KB instead
+//   of 512 x 36 KB -- the slab round trip was ~10 of a launch's 35-40 us) and a tile's halo overhead drops from
+//   10*18 / (8*16) = 1.41 to 18*18 / (16*16) = 1.27 pixels staged per pixel reduced.
 //
 // Reference call site replaced: the Conv2DBackpropFilter gradient of tf.contrib.layers.conv2d
 // (nets/pggan_utils.py:316-320).
 #include "tg_common.h"
 
-// launches conv_wgrad_tile_kernel<TW, BIAS> in the element format of the current call (tg_elem_f16)
-#define TG_WG_LAUNCH(TW_, BIAS_, ...)                                                        \
-  do {                                                                                       \
-    if (tg_elem_f16()) hipLaunchKernelGGL((conv_wgrad_tile_kernel<TW_, BIAS_, true>), __VA_ARGS__); \
-    else hipLaunchKernelGGL((conv_wgrad_tile_kernel<TW_, BIAS_, false>), __VA_ARGS__);         \
+// launches conv_wgrad_tile_kernel<TW, BIAS, F16, NW> in the element format of the current call (tg_elem_f16)
+#define TG_WG_LAUNCH(TW_, BIAS_, NW_, ...)                                                        \
+  do {                                                                                            \
+    if (tg_elem_f16()) hipLaunchKernelGGL((conv_wgrad_tile_kernel<TW_, BIAS_, true, NW_>), __VA_ARGS__); \
+    else hipLaunchKernelGGL((conv_wgrad_tile_kernel<TW_, BIAS_, false, NW_>), __VA_ARGS__);         \
   } while (0)
 #include <cstdlib>
 #include <type_traits>
@@ -53,6 +57,7 @@ struct WgGeom {
   // workgroups: one more MFMA per K step with an all-ones A operand.
   float* gbias;
   int bias_segs;      // bit 0: segment a contributes to gbias, bit 1: segment b
+  int nw;             // waves per workgroup of the tile kernel: 4 (8-row tiles) or 8 (16-row tiles)
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
@@ -78,18 +83,21 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
 
 // TW = 16: a tile is 8 rows x 16 cols of one image (maps of 16x16 and up).  TW = 8: the 8x8 maps -- a tile is TWO
 // whole images, K step ks = image ks of the pair, and the two 8-pixel halves of a K step are rows 2w and 2w+1.
-template <int TW, bool BIAS = false, bool F16 = false>
-__global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gy,
-                                                              float* __restrict__ slab, const WgGeom g) {
+template <int TW, bool BIAS = false, bool F16 = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void conv_wgrad_tile_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gy,
+                                                                 float* __restrict__ slab, const WgGeom g) {
+  static_assert(NW == 4 || (NW == 8 && TW == 16), "8 waves: 16-row tiles of the 16-column kernel only");
   constexpr bool ATOMIC = false;
-  constexpr int TH = 8, HWX = TW + 2, HH = 10, NT = 9;
+  constexpr int THREADS = 64 * NW;
+  constexpr int TH = 2 * NW, HWX = TW + 2, HH = TH + 2, NT = 9;        // TW = 16: wave w reduces rows 2w, 2w + 1
   constexpr int IPT = 16 / TW;                      // images per tile
   constexpr int PS = 64;                            // LDS bytes per pixel (32 channels, dense)
-  constexpr int XPX = IPT * HH * HWX;               // halo pixels per tile: 180 / 200
-  constexpr int XVEC = XPX * 4, XSLOTS = (XVEC + 255) / 256;           // 720 -> 3, 800 -> 4
-  constexpr int GSLOTS = (128 * 4) / 256;                              // 128 output pixels per tile -> 2
-  constexpr int X_BYTES = XPX * PS;                                    // 11520 / 12800
-  constexpr int G_BYTES = 128 * PS;                                    // 8192
+  constexpr int XPX = IPT * HH * HWX;               // halo pixels per tile: 180 / 200 (NW = 4), 324 (NW = 8)
+  constexpr int XVEC = XPX * 4, XSLOTS = (XVEC + THREADS - 1) / THREADS;   // 720 -> 3, 800 -> 4, 1296 / 512 -> 3
+  constexpr int GPX = TW == 16 ? TH * 16 : 128;                        // output pixels per tile: 128 / 256
+  constexpr int GSLOTS = (GPX * 4) / THREADS;                          // 2
+  constexpr int X_BYTES = XPX * PS;                                    // 11520 / 12800 / 20736
+  constexpr int G_BYTES = GPX * PS;                                    // 8192 / 16384
 
   unsigned char* sX = wg_smem;
   unsigned char* sG = wg_smem + X_BYTES;
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   bool x_use[XSLOTS];
 #pragma unroll
   for (int s = 0; s < XSLOTS; ++s) {
-    const int v = tid + s * 256;
+    const int v = tid + s * THREADS;
     const int px = v >> 2, part = v & 3;
     const int sub = px / (HH * HWX), rem = px - sub * (HH * HWX);          // image of the tile (TW = 8), pixel in its halo
     x_hy1[s] = rem / HWX - 1;
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   unsigned g_rel[GSLOTS];
 #pragma unroll
   for (int s = 0; s < GSLOTS; ++s) {
-    const int v = tid + s * 256;
+    const int v = tid + s * THREADS;
     const int px = v >> 2, part = v & 3;
     const bool use = co0 + part * 8 + 8 <= g.cout;
     // TW = 16: pixel (px >> 4, px & 15) of the tile; TW = 8: pixel px & 63 of image px >> 6 (rows are contiguous)
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
   auto stage_to_lds = [&](const Stage& st, unsigned char* bX, unsigned char* bG) __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < XSLOTS; ++s)
-      if (s < XSLOTS - 1 || tid + s * 256 < XVEC) *reinterpret_cast<bf16x8*>(bX + x_loff[s]) = st.rx[s];
+      if (s < XSLOTS - 1 || tid + s * THREADS < XVEC) *reinterpret_cast<bf16x8*>(bX + x_loff[s]) = st.rx[s];
 #pragma unroll
     for (int s = 0; s < GSLOTS; ++s) *reinterpret_cast<bf16x8*>(bG + g_loff[s]) = st.rg[s];
   };
@@ -390,7 +398,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
 
   // ---- cross-wave reduction through LDS, one tap at a time; write the valid part of the slab.
   // acc[tap][r]: ci = ci0 + (r & 3) + 8*(r >> 2) + 4*(lane >> 5), co = co0 + (lane & 31)
-  float* red = reinterpret_cast<float*>(wg_smem);    // [4 waves][16 regs][64 lanes] = 16 KiB
+  float* red = reinterpret_cast<float*>(wg_smem);    // [NW waves][16 regs][64 lanes] = 16 / 32 KiB
   // ATOMIC: `slab` is the gradient itself and every workgroup adds its partial sums into it (one
   // global_atomic_add_f32 per element, 64 consecutive floats per wave instruction) -- no slab round trip
   // through HBM and no second launch.
@@ -402,11 +410,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
     for (int r = 0; r < 16; ++r) red[(wid * 16 + r) * 64 + lane] = acc[tap][r];
     __syncthreads();
     const int l2 = tid & 63, rq = tid >> 6;
+    constexpr int RPT = 16 / NW;      // accumulator registers summed per thread: 16 regs x 64 lanes over 64 * NW threads
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = rq * 4 + j;
-      const float sum = red[(0 * 16 + r) * 64 + l2] + red[(1 * 16 + r) * 64 + l2] + red[(2 * 16 + r) * 64 + l2] +
-                        red[(3 * 16 + r) * 64 + l2];
+    for (int j = 0; j < RPT; ++j) {
+      const int r = rq * RPT + j;
+      float sum = red[(0 * 16 + r) * 64 + l2] + red[(1 * 16 + r) * 64 + l2] + red[(2 * 16 + r) * 64 + l2] +
+                  red[(3 * 16 + r) * 64 + l2];
+      if constexpr (NW == 8)      // waves in a fixed order
+        sum += red[(4 * 16 + r) * 64 + l2] + red[(5 * 16 + r) * 64 + l2] + red[(6 * 16 + r) * 64 + l2] +
+               red[(7 * 16 + r) * 64 + l2];
       const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * (l2 >> 5);
       const int co = co0 + (l2 & 31);
       if (ci < g.cin && co < g.cout) {
@@ -420,7 +432,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(const bf16* __rest
       __syncthreads();
       if (lane < 32) red[wid * 32 + lane] = accb[0];
       __syncthreads();
-      if (tid < 32 && co0 + tid < g.cout) atomicAdd(g.gbias + co0 + tid, red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid]);
+      if (tid < 32 && co0 + tid < g.cout) {
+        float t = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
+        if constexpr (NW == 8) t += red[128 + tid] + red[160 + tid] + red[192 + tid] + red[224 + tid];
+        atomicAdd(g.gbias + co0 + tid, t);
+      }
     }
   }
 }
@@ -709,8 +725,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_slab_reduce(const float* __res
 
 bool wg_thin(int h, int w, int cin, int cout);
 
+// Waves per workgroup of conv_wgrad_tile_kernel for this layer.  8 (16-row tiles, one workgroup per CU) wherever the
+// map is a multiple of 16 rows: half the slabs for the same waves in flight.  TG_TUNE_WG_NW=4 / 8 forces one (A/B).
+int wg_waves(int h, int w, int cin, int cout) {
+  if (w == 8 || h % 16 != 0 || w % 16 != 0 || wg_thin(h, w, cin, cout)) return 4;
+  const int force = tg_tune("TG_TUNE_WG_NW", 0);
+  return force == 4 ? 4 : 8;
+}
+
 void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices, int nb = 0) {
   const bool thin = wg_thin(h, w, cin, cout);
+  g->nw = wg_waves(h, w, cin, cout);
   g->n = n; g->h = h; g->w = w; g->cin = cin; g->cout = cout;
   g->x1 = nullptr;
   g->c0 = g->gsz = 0;
@@ -725,7 +750,7 @@ void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices, i
     g->total_tiles = g->tiles_a + (nb + 1) / 2;
   } else {
     g->tiles_x = w / 16;
-    g->tiles_y = h / (thin ? 16 : 8);
+    g->tiles_y = h / ((thin || g->nw == 8) ? 16 : 8);
     g->tiles_a = g->tiles_x * g->tiles_y * n;
     g->total_tiles = g->tiles_a + g->tiles_x * g->tiles_y * nb;
   }
@@ -735,9 +760,9 @@ void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices, i
   // costs one slab write + read (9*32*32 floats), which then outweighs its share of the input traffic
   // (kbench, 128x128x32 n16: 24.2 -> 20.6 us; 256x256x16 n48 prefers 512: 70 vs 85 us).
   const int pairs = n_ci * g->n_co_blk;
-  int want = (thin ? 1024 : 512) / pairs;      // thin: 4 workgroups per CU fit
+  int want = (thin ? 1024 : (g->nw == 8 ? 256 : 512)) / pairs;      // thin: 4 workgroups per CU fit; 8 waves: one
   if (want < 1) want = 1;
-  if ((g->total_tiles + want - 1) / want < (thin ? 4 : 8)) want = 256 / pairs;
+  if (g->nw != 8 && (g->total_tiles + want - 1) / want < (thin ? 4 : 8)) want = 256 / pairs;
   if (want < 1) want = 1;
   if (want > g->total_tiles) want = g->total_tiles;
   g->tiles_per_wg = (g->total_tiles + want - 1) / want;
@@ -768,6 +793,45 @@ bool wg_launch_thin(const WgGeom& g, const bf16* x, const bf16* gy, float* ws, i
   else hipLaunchKernelGGL((conv_wgrad_thin_kernel<16, false>), grid, dim3(256), lds, s, x, gy, ws, g);
   return true;
 }
+// launches conv_wgrad_tile_kernel for geometry g (already split, pointers and bias fields set)
+int wg_launch_tile(const WgGeom& g, const bf16* x, const bf16* gy, float* ws, int nslices, hipStream_t s) {
+  const int n_ci = (g.cin + 31) / 32;
+  const dim3 grid(nslices * n_ci * g.n_co_blk);
+  // two tile buffers; the first bytes double as the cross-wave reduction scratch (16 KiB for 4 waves, 32 KiB for 8)
+  const size_t lds8 = 2 * (2 * 10 * 10 * 64 + 8 * 16 * 64);        // 8x8 maps: a pair of images per tile
+  const size_t lds16 = 2 * (10 * 18 * 64 + 8 * 16 * 64);           // 8 x 16 tiles, 4 waves
+  const size_t lds16w8 = 2 * (18 * 18 * 64 + 16 * 16 * 64);        // 16 x 16 tiles, 8 waves: 74 240 B
+  const bool bias = g.gbias != nullptr;
+  if (g.w == 8) {
+    tg_note_kernel("conv_wgrad_tile_kernel");
+    if (bias) TG_WG_LAUNCH(8, true, 4, grid, dim3(256), lds8, s, x, gy, ws, g);
+    else TG_WG_LAUNCH(8, false, 4, grid, dim3(256), lds8, s, x, gy, ws, g);
+  } else if (g.nw == 8) {
+    static bool raised = false;      // > 64 KiB of dynamic LDS: raise the limit of the four instantiations once
+    if (!raised) {
+      const void* ks[4] = {reinterpret_cast<const void*>(conv_wgrad_tile_kernel<16, true, true, 8>),
+                           reinterpret_cast<const void*>(conv_wgrad_tile_kernel<16, true, false, 8>),
+                           reinterpret_cast<const void*>(conv_wgrad_tile_kernel<16, false, true, 8>),
+                           reinterpret_cast<const void*>(conv_wgrad_tile_kernel<16, false, false, 8>)};
+      for (const void* k : ks) {
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16w8) != hipSuccess) {
+          tg_set_error("conv_wgrad_tile: cannot raise dynamic LDS to %zu", lds16w8);
+          return TG_ELAUNCH;
+        }
+      }
+      raised = true;
+    }
+    tg_note_kernel("conv_wgrad_tile_kernel<8 waves>");
+    if (bias) TG_WG_LAUNCH(16, true, 8, grid, dim3(512), lds16w8, s, x, gy, ws, g);
+    else TG_WG_LAUNCH(16, false, 8, grid, dim3(512), lds16w8, s, x, gy, ws, g);
+  } else {
+    tg_note_kernel("conv_wgrad_tile_kernel");
+    if (bias) TG_WG_LAUNCH(16, true, 4, grid, dim3(256), lds16, s, x, gy, ws, g);
+    else TG_WG_LAUNCH(16, false, 4, grid, dim3(256), lds16, s, x, gy, ws, g);
+  }
+  TG_LAUNCH_CHECK("conv_wgrad_tile");
+  return TG_OK;
+}
 }  // namespace
 
 bool tg_wgrad_tile_supported(int h, int w, int hout, int wout, int kh, int kw, int pad_t, int pad_l) {
@@ -795,20 +859,8 @@ int tg_wgrad_tile_run(int n, int h, int w, int cin, int cout, const void* x, con
     TG_LAUNCH_CHECK("conv_wgrad_thin");
     return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
   }
-  const int n_ci = (cin + 31) / 32;
-  const size_t lds = 2 * (10 * 18 * 64 + 8 * 16 * 64);      // two tile buffers of 19712 B; the first doubles as the 16 KiB reduction scratch
-  tg_note_kernel("conv_wgrad_tile_kernel");
-  const size_t lds8 = 2 * (2 * 10 * 10 * 64 + 8 * 16 * 64);
-  const dim3 grid(nslices * n_ci * g.n_co_blk);
-  if (w == 8 && gbias)
-    TG_WG_LAUNCH(8, true, grid, dim3(256), lds8, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g);
-  else if (w == 8)
-    TG_WG_LAUNCH(8, false, grid, dim3(256), lds8, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g);
-  else if (gbias)
-    TG_WG_LAUNCH(16, true, grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g);
-  else
-    TG_WG_LAUNCH(16, false, grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)gy, (float*)ws, g);
-  TG_LAUNCH_CHECK("conv_wgrad_tile");
+  int rc = wg_launch_tile(g, (const bf16*)x, (const bf16*)gy, (float*)ws, nslices, s);
+  if (rc) return rc;
   return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
 }
 
@@ -837,19 +889,8 @@ int tg_wgrad_tile_run2(int na, int nb, int h, int w, int cin, int cout, const vo
     TG_LAUNCH_CHECK("conv_wgrad_thin(2)");
     return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
   }
-  const int n_ci = (cin + 31) / 32;
-  tg_note_kernel("conv_wgrad_tile_kernel");
-  const dim3 grid(nslices * n_ci * g.n_co_blk);
-  const size_t l8 = 2 * (2 * 10 * 10 * 64 + 8 * 16 * 64), l16 = 2 * (10 * 18 * 64 + 8 * 16 * 64);
-  if (w == 8 && gbias)
-    TG_WG_LAUNCH(8, true, grid, dim3(256), l8, s, (const bf16*)xa, (const bf16*)gya, (float*)ws, g);
-  else if (w == 8)
-    TG_WG_LAUNCH(8, false, grid, dim3(256), l8, s, (const bf16*)xa, (const bf16*)gya, (float*)ws, g);
-  else if (gbias)
-    TG_WG_LAUNCH(16, true, grid, dim3(256), l16, s, (const bf16*)xa, (const bf16*)gya, (float*)ws, g);
-  else
-    TG_WG_LAUNCH(16, false, grid, dim3(256), l16, s, (const bf16*)xa, (const bf16*)gya, (float*)ws, g);
-  TG_LAUNCH_CHECK("conv_wgrad_tile(2)");
+  int rc = wg_launch_tile(g, (const bf16*)xa, (const bf16*)gya, (float*)ws, nslices, s);
+  if (rc) return rc;
   return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
 }
 
@@ -872,12 +913,8 @@ int tg_wgrad_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int g
     TG_LAUNCH_CHECK("conv_wgrad_thin(upcat)");
     return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
   }
-  const int n_ci = (cin + 31) / 32;
-  const size_t lds = 2 * (10 * 18 * 64 + 8 * 16 * 64);
-  tg_note_kernel("conv_wgrad_tile_kernel");
-  TG_WG_LAUNCH(16, false, dim3(nslices * n_ci * g.n_co_blk), dim3(256), lds, s, (const bf16*)x0,
-                     (const bf16*)gy, (float*)ws, g);
-  TG_LAUNCH_CHECK("conv_wgrad_tile(upcat)");
+  int rc = wg_launch_tile(g, (const bf16*)x0, (const bf16*)gy, (float*)ws, nslices, s);
+  if (rc) return rc;
   return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
 }
 
