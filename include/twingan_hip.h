@@ -144,6 +144,14 @@ int tg_conv2d_fwd_stats_chunks(const TgConvDesc* d);
 int tg_conv2d_fwd_pool_supported(const TgConvDesc* d);
 int tg_conv2d_fwd_pool(const TgConvDesc* d, const void* x, const void* w_pack, const float* bias, void* y, void* y_pooled,
                        void* stream);
+/* The same conv + pool when the pool is the ONLY consumer of the full-resolution output (the discriminator blocks,
+ * nets/pggan.py:304-306: `net` is overwritten by the pooled tensor): all the backward pass needs of y is the LeakyReLU
+ * derivative, i.e. the sign of each element -- y itself is not written, y_signs [n][h][w][cout/8] bytes is (bit j of
+ * byte q = (y[.., 8q+j] > 0), taken from the storage-rounded value exactly as tg_conv2d_fwd_pool would have stored it):
+ * 1/16 of the tensor's bytes, once, instead of a write and a read of all of it.  cout % 8 == 0; y_signs 4-byte aligned.
+ * Consumed by tg_lrelu_pool_bwd_signs.  Same shapes as tg_conv2d_fwd_pool_supported. */
+int tg_conv2d_fwd_pool_signs(const TgConvDesc* d, const void* x, const void* w_pack, const float* bias, void* y_signs,
+                             void* y_pooled, void* stream);
 int tg_conv2d_fwd_stats(const TgConvDesc* d, const void* x, const void* w_pack, void* y, float* partials, int chunks,
                         void* stream);
 int tg_conv2d_upcat_fwd_stats_chunks(int n, int h, int w, int c0, int c1, int cout);
@@ -246,6 +254,10 @@ int tg_lrelu_bwd_bias(const void* gz, const void* z, void* gy, float* gbias, int
  * gbias may be NULL (no bias gradient wanted). */
 int tg_lrelu_pool_bwd(const void* gz, const void* gz_pooled, const void* z, void* gy, float* gbias, int n, int h, int w,
                       int c, float alpha, int accumulate, int dtype, void* stream);
+/* tg_lrelu_pool_bwd for a layer run by tg_conv2d_fwd_pool_signs: gy = 0.25 * upsample2(gz_pooled) * (sign bit ? 1 : alpha),
+ * gbias += sum over pixels of gy (NULL: no bias gradient).  16-bit storage, c % 8 == 0. */
+int tg_lrelu_pool_bwd_signs(const void* gz_pooled, const void* z_signs, void* gy, float* gbias, int n, int h, int w, int c,
+                            float alpha, int accumulate, int dtype, void* stream);
 /* out[c] (fp32) = sum over pixels of g[pix][c]  (BiasAddGrad) */
 int tg_channel_sum(const void* g, float* out, int64_t npix, int c, int accumulate, int dtype, void* stream);
 

@@ -176,7 +176,22 @@ def _conv_variants(key, dtype):
     want = z.float().view(n, hw // 2, 2, hw // 2, 2, cout).mean(dim=(2, 4))
     e = rel_l2(host(zp), host(want))
     assert e < 2e-3, ('fwd_pool pooled', key, n, e)      # one bf16 rounding of the pooled value
-    del z, zp, z_plain
+    # the sign-bit form of the same launch (tg_conv2d_fwd_pool_signs: what the discriminators' first-order passes run):
+    # the very same pooled tensor, and bit j of byte q = (z[.., 8q+j] > 0) of the z the plain launch stored
+    assert O.conv_fwd_pool_signs_supported(x[:n], w, spec, epi), ('no sign-bit variant', key, n)
+    signs, zp2 = O.conv_fwd_pool_signs_raw(x[:n], w, bias, spec, epi)
+    note(key, 'tg_conv2d_fwd_pool_signs', str(n))
+    assert torch.equal(zp2, zp), ('fwd_pool_signs pooled', key, n)
+    bits = (z > 0).view(n, hw, hw, cout // 8, 8).to(torch.int32)
+    want_bytes = (bits << torch.arange(8, device='cuda', dtype=torch.int32)).sum(dim=-1).to(torch.uint8)
+    assert torch.equal(signs, want_bytes), ('fwd_pool_signs bits', key, n, int((signs != want_bytes).sum()))
+    # ... and the backward that consumes them: the same tensor as the one rebuilt from z
+    gzp = _rand_bf16(tuple(zp.shape), 21, dtype)
+    g_ref, gb_ref = O.lrelu_pool_bwd(None, gzp, z, 0.2, bias, True)
+    g_sig, gb_sig = O.lrelu_pool_bwd_signs(gzp, signs, 0.2, bias, True)
+    assert torch.equal(g_sig, g_ref), ('lrelu_pool_bwd_signs', key, n)
+    assert rel_l2(host(gb_sig), host(gb_ref)) < 1e-5, ('lrelu_pool_bwd_signs bias', key, n)
+    del z, zp, z_plain, signs, zp2, g_ref, g_sig
 
   # ---- backward-data, plain and with the producer's LeakyReLU mask in the epilogue
   for ep in ('tg_conv2d_bwd_data', 'tg_conv2d_bwd_data_masked'):

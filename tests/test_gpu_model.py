@@ -1427,3 +1427,50 @@ def test_larger_filter_at_rgb_layer_matches_oracle(hw, growing, k):
   for n in rgb:      # the gradient of the large kernel itself, tap by tap
     assert rel_l2(tr.store.grad_dict()[n], Pref[n].grad) < 1e-4, n
   tr.close()
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_discriminator_sign_bit_path_equals_the_tensor_path(precision):
+  """The discriminators' block-end convs hand the pool and the LeakyReLU sign bits over instead of their full-resolution
+  output (ops.Conv2dPoolSignsFn, first-order passes; the gradient-penalty pass keeps z).  Same loss terms bit for bit and
+  the same gradients as with TG_POOL_SIGNS=0 (bias sums: fp32 atomics order), generator step and discriminator step."""
+  from twingan_amd import ops
+  from twingan_amd import twingan as T
+  cfg, rcfg, tr, Pref, dev, ref = make(dict(hw=64, max_ch=32), precision, seed=4, batch=2)
+  out = {}
+  seen = []
+  orig_call = ops.call
+
+  def spy(name, *a, **k):
+    seen.append(name)
+    return orig_call(name, *a, **k)
+  for signs in (True, False):
+    saved, ops.USE_POOL_SIGNS = ops.USE_POOL_SIGNS, signs
+    ops.call = spy
+    del seen[:]
+    try:
+      res = {}
+      for grp in ('g', 'd'):
+        tr.store.zero_grad(grp)
+        tr._set_requires_grad(g=grp == 'g', d=grp == 'd')
+        if grp == 'g':
+          loss, terms = T.generator_loss(tr.P, dev['s'], dev['t'], cfg)
+        else:
+          loss, terms = T.discriminator_loss(tr.P, dev['s'], dev['t'], cfg, dev['a_s'], dev['a_t'])
+        loss.backward()
+        res[grp] = ({k: float(v) for k, v in terms.items()}, {k: v.clone() for k, v in tr.store.grad_dict().items()
+                                                               if k in tr.store.names(grp)})
+      out[signs] = res
+      n_sig = seen.count('tg_conv2d_fwd_pool_signs')
+      assert (n_sig > 0) == signs and (seen.count('tg_lrelu_pool_bwd_signs') > 0) == signs, (signs, n_sig)
+      assert seen.count('tg_conv2d_fwd_pool') > 0      # the gradient-penalty pass keeps the tensor either way
+    finally:
+      ops.call = orig_call
+      ops.USE_POOL_SIGNS = saved
+  for grp in ('g', 'd'):
+    ta, tb = out[True][grp][0], out[False][grp][0]
+    assert ta == tb, (grp, ta, tb)
+    num = sum(float(((out[True][grp][1][k] - out[False][grp][1][k]).double() ** 2).sum()) for k in out[True][grp][1])
+    den = sum(float((out[False][grp][1][k].double() ** 2).sum()) for k in out[True][grp][1])
+    assert (num / den) ** 0.5 < 1e-5, (grp, (num / den) ** 0.5)
+  tr.close()

@@ -1187,3 +1187,61 @@ def test_flash_attention_second_order(ops, dtype, n, ln, dk, dv):
     e, ec = rel_l2(got, want), rel_l2(cmp_, want)
     print('[flash2] %s %s: flash %.2e composed %.2e' % (dtype, nm, e, ec))
     assert e < tol and e <= ec * 1.5 + 1e-4, (nm, e, ec)
+
+
+# ------------------------------------------------------------------------- sign bits instead of a pooled layer's output
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('n,hw,cin,cout', [(3, 32, 16, 32), (2, 16, 64, 64), (2, 64, 16, 24), (5, 16, 32, 72), (1, 16, 256, 256)])
+def test_conv_pool_sign_bits(ops, dtype, n, hw, cin, cout):
+  """tg_conv2d_fwd_pool_signs / tg_lrelu_pool_bwd_signs (the discriminator blocks' last conv when the pool is the only
+  consumer of its output, nets/pggan.py:304-306): the pooled tensor equals tg_conv2d_fwd_pool's bit for bit, the sign
+  bytes are (z > 0) of the z that launch stores (incl. a channel count that ends on a lone byte: 24, 72), and the
+  LeakyReLU + unpool backward rebuilt from the bits equals the one rebuilt from z -- both against the float64 oracle
+  too.  Zeros in z (bias-free rows that cancel) count as "not positive", as lrelu'(0) = alpha in util_misc.py:86."""
+  import twingan_amd.ops as O
+  from twingan_amd._lib import TG_EPI_BIAS, TG_EPI_LRELU
+  rng = np.random.RandomState(31)
+  rnd = bf16_round if dtype == torch.bfloat16 else f16_round
+  x = rnd(rng.randn(n, hw, hw, cin))
+  x[0, :4] = 0.0                                   # a patch whose pre-activation is exactly the bias
+  w = rnd(rng.randn(3, 3, cin, cout) / np.sqrt(9 * cin))
+  b = rng.randn(cout) * 0.1
+  b[:3] = 0.0                                      # ... which is zero for three channels: z == 0 there
+  xd, wd, bd = to_dev(x, dtype), to_dev(w), to_dev(b)
+  spec = O.ConvSpec(3, 'SAME')
+  epi = TG_EPI_BIAS | TG_EPI_LRELU
+  assert O.conv_fwd_pool_signs_supported(xd, wd, spec, epi)
+  z, zp = O.conv_fwd_pool_raw(xd, wd, bd, spec, epi)
+  signs, zp2 = O.conv_fwd_pool_signs_raw(xd, wd, bd, spec, epi)
+  assert torch.equal(zp, zp2)
+  assert signs.shape == (n, hw, hw, cout // 8) and signs.dtype == torch.uint8
+  bits = (z > 0).view(n, hw, hw, cout // 8, 8).to(torch.int32)
+  want = (bits << torch.arange(8, device=z.device, dtype=torch.int32)).sum(dim=-1).to(torch.uint8)
+  assert torch.equal(signs, want), int((signs != want).sum())
+  assert int((z[0, :3, :, :3] == 0).sum()) > 0      # the zero case is really in the data
+  ref = N.leaky_relu(N.conv2d(x, w, 'SAME') + b)
+  assert rel_l2(host(z), ref) < (6e-3 if dtype == torch.bfloat16 else 8e-4)
+  gzp = rnd(rng.randn(n, hw // 2, hw // 2, cout))
+  gd = to_dev(gzp, dtype)
+  g_ref, gb_ref = O.lrelu_pool_bwd(None, gd, z, 0.2, bd, True)
+  g_sig, gb_sig = O.lrelu_pool_bwd_signs(gd, signs, 0.2, bd, True)
+  assert torch.equal(g_sig, g_ref)
+  up = np.repeat(np.repeat(gzp, 2, axis=1), 2, axis=2) * 0.25
+  want_g = up * np.where(host(z) > 0, 1.0, 0.2)
+  assert rel_l2(host(g_sig), want_g) < (4e-3 if dtype == torch.bfloat16 else 5e-4)
+  assert rel_l2(host(gb_sig), host(g_sig).sum(axis=(0, 1, 2))) < 1e-5 and rel_l2(host(gb_sig), host(gb_ref)) < 1e-5
+  # through autograd: conv2d(pool_only=True) -> (None, pooled); its gradients equal the z-keeping node's
+  res = {}
+  for only in (True, False):
+    xa = xd.clone().requires_grad_(True)
+    wa, ba = wd.clone().requires_grad_(True), bd.clone().requires_grad_(True)
+    full, pooled = O.conv2d(xa, wa, ba, 3, 'SAME', lrelu=True, pool=True, pool_only=only)
+    assert (full is None) == only
+    pooled.backward(gd)
+    res[only] = (pooled.detach(), xa.grad, wa.grad, ba.grad)
+  assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+  assert rel_l2(host(res[True][2]), host(res[False][2])) < 1e-6 and rel_l2(host(res[True][3]), host(res[False][3])) < 1e-5
+  # a create_graph pass keeps z
+  with O.second_order():
+    full, _ = O.conv2d(xd, wd, bd, 3, 'SAME', lrelu=True, pool=True, pool_only=True)
+  assert full is not None

@@ -63,6 +63,7 @@ SIGNATURES = {
     'tg_preprocess_images': (c_int, [_P, _P, _P, _FP, _P, c_int, c_int, c_int, _P]),
     'tg_conv2d_fwd_pool_supported': (c_int, [_D]),
     'tg_conv2d_fwd_pool': (c_int, [_D, _P, _P, _FP, _P, _P, _P]),
+    'tg_conv2d_fwd_pool_signs': (c_int, [_D, _P, _P, _FP, _P, _P, _P]),
     'tg_conv2d_fwd_stats_chunks': (c_int, [_D]),
     'tg_conv2d_fwd_stats': (c_int, [_D, _P, _P, _P, _FP, c_int, _P]),
     'tg_conv2d_upcat_fwd_stats_chunks': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
@@ -93,6 +94,7 @@ SIGNATURES = {
     'tg_lrelu_bwd': (c_int, [_P, _P, _P, c_int64, c_float, c_int, _P]),
     'tg_lrelu_bwd_bias': (c_int, [_P, _P, _P, _FP, c_int64, c_int, c_float, c_int, c_int, _P]),
     'tg_lrelu_pool_bwd': (c_int, [_P, _P, _P, _P, _FP, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
+    'tg_lrelu_pool_bwd_signs': (c_int, [_P, _P, _P, _FP, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
     'tg_channel_sum': (c_int, [_P, _FP, c_int64, c_int, c_int, c_int, _P]),
     'tg_upsample2x_concat_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint, c_int, _P]),
     'tg_upsample2x_concat_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint, c_int, _P]),

@@ -59,7 +59,7 @@ int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gs
                            int stat_chunks = 0, int* chunks_query = nullptr);
 bool tg_conv2d_fwd_pool_supported_mfma(const TgConvDesc* d);
 int tg_conv2d_fwd_pool_mfma(const TgConvDesc* d, const void* x, const void* wp, const float* bias, void* y, void* ypool,
-                            hipStream_t s);
+                            hipStream_t s, void* ymask = nullptr);
 int tg_conv2d_fwd_stats_chunks_mfma(const TgConvDesc* d);
 int tg_conv2d_fwd_stats_mfma(const TgConvDesc* d, const void* x, const void* wp, void* y, float* partials, int chunks,
                              hipStream_t s);
@@ -214,6 +214,17 @@ int tg_conv2d_fwd_pool(const TgConvDesc* d, const void* x, const void* w_pack, c
            "tg_conv2d_fwd_pool: pointers must be 16 B aligned");
   TG_CHECK(d->algo != TG_ALGO_DIRECT, TG_ENOSUP, "tg_conv2d_fwd_pool: MFMA path only (query tg_conv2d_fwd_pool_supported)");
   return tg_conv2d_fwd_pool_mfma(d, x, w_pack, bias, y, y_pooled, (hipStream_t)stream);
+}
+
+int tg_conv2d_fwd_pool_signs(const TgConvDesc* d, const void* x, const void* w_pack, const float* bias, void* y_signs,
+                             void* y_pooled, void* stream) {
+  int rc = check_desc("tg_conv2d_fwd_pool_signs", d);
+  if (rc) return rc;
+  TG_CHECK(x && w_pack && y_signs && y_pooled, TG_EINVAL, "tg_conv2d_fwd_pool_signs: null pointer");
+  TG_CHECK(tg_aligned16(x) && tg_aligned16(w_pack) && tg_aligned16(y_pooled) && (reinterpret_cast<uintptr_t>(y_signs) & 3u) == 0,
+           TG_EALIGN, "tg_conv2d_fwd_pool_signs: pointers must be 16 B aligned (the sign bits: 4 B)");
+  TG_CHECK(d->algo != TG_ALGO_DIRECT, TG_ENOSUP, "tg_conv2d_fwd_pool_signs: MFMA path only (query tg_conv2d_fwd_pool_supported)");
+  return tg_conv2d_fwd_pool_mfma(d, x, w_pack, bias, nullptr, y_pooled, (hipStream_t)stream, y_signs);
 }
 
 int tg_conv2d_fwd_stats_chunks(const TgConvDesc* d) {

@@ -563,7 +563,8 @@ int tg_conv2d_pack_weights_multi(const void* table_device, int njobs, int total_
 bool tg_conv_tile_supported(int h, int w, int hout, int wout, int kh, int kw, int pad_t, int pad_l);
 int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int epilogue, float alpha, const void* x,
                      const void* wp, const float* bias, void* y, hipStream_t s, const void* mask = nullptr,
-                     float* stats = nullptr, int stat_chunks = 0, int* chunks_query = nullptr, void* ypool = nullptr);
+                     float* stats = nullptr, int stat_chunks = 0, int* chunks_query = nullptr, void* ypool = nullptr,
+                     void* ymask = nullptr);
 
 // Forward conv that also writes the 2x2 average pool of its output (conv_tile.hip POOL kernels): 3x3 SAME, even h / w,
 // shapes the tile kernels take
@@ -575,13 +576,13 @@ bool tg_conv2d_fwd_pool_supported_mfma(const TgConvDesc* d0) {
 }
 
 int tg_conv2d_fwd_pool_mfma(const TgConvDesc* d0, const void* x, const void* wp, const float* bias, void* y, void* ypool,
-                            hipStream_t s) {
+                            hipStream_t s, void* ymask) {
   TgConvDesc dd;
   const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
   TG_CHECK(tg_conv2d_fwd_pool_supported_mfma(d0), TG_ENOSUP, "tg_conv2d_fwd_pool: shape not taken (query tg_conv2d_fwd_pool_supported)");
   TG_CHECK(!(d->epilogue & TG_EPI_BIAS) || bias, TG_EINVAL, "tg_conv2d_fwd_pool: bias epilogue without bias pointer");
   return tg_conv_tile_run(d->n, d->hin, d->win, d->cin, d->cout, d->kh, d->pad_t, d->epilogue, d->lrelu_alpha, x, wp, bias, y,
-                          s, nullptr, nullptr, 0, nullptr, ypool);
+                          s, nullptr, nullptr, 0, nullptr, ypool, ymask);
 }
 
 // Forward conv that also writes the per-workgroup statistics partials of its output (conv_tile.hip STATS kernels).

@@ -50,6 +50,11 @@ struct TileGeom {
   // POOL kernels: also write avg_pool2x2 of the (bf16-rounded) output, [n, h/2, w/2, cout] (the tf.nn.avg_pool that
   // ends a discriminator block, nets/pggan.py:304-306) -- the tile already holds every 2x2 block it needs
   bf16* ypool;
+  // POOL kernels, optionally: instead of y itself write only the SIGN of each output, one bit per element
+  // (ymask[n][h][w][cout/8] bytes, bit j of byte q = (y[.., 8q+j] > 0)) -- what the LeakyReLU backward of a
+  // discriminator block's last conv needs of its full-resolution output when that output's only consumer is the pool
+  // (nets/pggan.py:304-306): the tensor is never written (1/16 of its bytes instead) and never read back
+  unsigned char* ymask;
   int* chunks_query;       // non-NULL: do not launch, report the chunk count the STATS variant of this dispatch would use
 };
 
@@ -77,6 +82,19 @@ __device__ __forceinline__ void mask4(__amdgpu_buffer_rsrc_t r, unsigned off, fl
   f[3] = (short)(z[1] >> 16) > 0 ? 1.f : alpha;
 }
 
+
+// bit j = (element j > 0) of the 16 packed 16-bit values in (a, b) (a positive bf16 / f16 is a positive int16 pattern)
+__device__ __forceinline__ unsigned sign_bits16(u32x4 a, u32x4 b) {
+  unsigned m = 0;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    m |= ((short)(a[d] & 0xffffu) > 0 ? 1u : 0u) << (2 * d);
+    m |= ((short)(a[d] >> 16) > 0 ? 1u : 0u) << (2 * d + 1);
+    m |= ((short)(b[d] & 0xffffu) > 0 ? 1u : 0u) << (8 + 2 * d);
+    m |= ((short)(b[d] >> 16) > 0 ? 1u : 0u) << (8 + 2 * d + 1);
+  }
+  return m;
+}
 
 // Transposing sum over the 32 lanes of a half-wave, steps [S0, S1) of 5: entering step s a lane holds 32 >> s values;
 // lanes whose bit s differs exchange halves, so after all five steps lane l31 holds the total of original value
@@ -316,7 +334,12 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
   // After the half-wave swap the low lane (kgrp 0) owns channels [0,16) of the 32-block, the high lane
   // [16,32), each as two 16-byte vectors.
   const size_t out_img = (size_t)g.h * g.w * g.cout;
-  const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + (size_t)img * out_img, (unsigned)(out_img * 2));
+  // POOL with a sign-mask output: y is not written (a zero-sized resource drops the stores)
+  const bool y_dropped = POOL && g.ymask != nullptr;
+  const __amdgpu_buffer_rsrc_t ry = make_rsrc(y_dropped ? (const bf16*)g.ypool : y + (size_t)img * out_img,
+                                              y_dropped ? 0u : (unsigned)(out_img * 2));
+  const __amdgpu_buffer_rsrc_t rmaskout =
+      make_rsrc(y_dropped ? g.ymask + (size_t)img * (out_img >> 3) : (unsigned char*)g.ypool, y_dropped ? (unsigned)(out_img >> 3) : 0u);
   const __amdgpu_buffer_rsrc_t rmask =
       make_rsrc(g.mask ? g.mask + (size_t)img * out_img : y, g.mask ? (unsigned)(out_img * 2) : 0u);
   const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, (g.epilogue & TG_EPI_BIAS) ? (unsigned)(g.cout * 4) : 0u);
@@ -383,6 +406,12 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
       __builtin_amdgcn_raw_buffer_store_b128(o0, ry, (ch0 + 8 <= g.cout) ? off : OOB, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128(o1, ry, (ch0 + 16 <= g.cout) ? off + 16 : OOB, 0, 0);
       if constexpr (POOL) {
+        if (g.ymask) {      // uniform: the sign bits of this lane's 16 channels (y itself is not stored: ry has size 0)
+          const unsigned bits = sign_bits16(o0, o1);
+          const unsigned moff = (unsigned)((oy * g.w + ox) * (g.cout >> 3) + (ch0 >> 3));
+          if (ch0 + 16 <= g.cout) __builtin_amdgcn_raw_buffer_store_b16((short)bits, rmaskout, moff, 0, 0);
+          else if (ch0 + 8 <= g.cout) __builtin_amdgcn_raw_buffer_store_b8((char)(bits & 0xffu), rmaskout, moff, 0, 0);
+        }
         unsigned pp[4][2];
         pool_quad<F16>(p, pp);
         u32x4 q0, q1;
@@ -550,7 +579,11 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
     const int ty = r % g.tiles_y;
     const int img = r / g.tiles_y;
     const int oy = ty * TH + wid * 2 + (l31 >> 4), ox = tx * TW + (l31 & 15);
-    const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + (size_t)img * out_img, (unsigned)(out_img * 2));
+    const bool y_dropped = POOL && g.ymask != nullptr;      // sign-mask output: y is not written
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(y_dropped ? (const bf16*)g.ypool : y + (size_t)img * out_img,
+                                                y_dropped ? 0u : (unsigned)(out_img * 2));
+    const __amdgpu_buffer_rsrc_t rmaskout =
+        make_rsrc(y_dropped ? g.ymask + (size_t)img * (out_img >> 3) : (unsigned char*)g.ypool, y_dropped ? (unsigned)(out_img >> 3) : 0u);
     const __amdgpu_buffer_rsrc_t rmask =
         make_rsrc(g.mask ? g.mask + (size_t)img * out_img : y, g.mask ? (unsigned)(out_img * 2) : 0u);
     if (!first) __syncthreads();          // everyone finished reading the previous halo
@@ -643,6 +676,12 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
       __builtin_amdgcn_raw_buffer_store_b128(o0, ry, (ch0 + 8 <= g.cout) ? off : OOB, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128(o1, ry, (ch0 + 16 <= g.cout) ? off + 16 : OOB, 0, 0);
       if constexpr (POOL) {
+        if (g.ymask) {      // uniform: the sign bits of this lane's 16 channels (y itself is not stored: ry has size 0)
+          const unsigned bits = sign_bits16(o0, o1);
+          const unsigned moff = (unsigned)((oy * g.w + ox) * (g.cout >> 3) + (ch0 >> 3));
+          if (ch0 + 16 <= g.cout) __builtin_amdgcn_raw_buffer_store_b16((short)bits, rmaskout, moff, 0, 0);
+          else if (ch0 + 8 <= g.cout) __builtin_amdgcn_raw_buffer_store_b8((char)(bits & 0xffu), rmaskout, moff, 0, 0);
+        }
         unsigned pp[4][2];
         pool_quad<F16>(p, pp);
         u32x4 q0, q1;
@@ -848,7 +887,7 @@ bool tg_conv_tile_supported(int h, int w, int hout, int wout, int kh, int kw, in
 
 int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int epilogue, float alpha, const void* x,
                      const void* wp, const float* bias, void* y, hipStream_t s, const void* mask, float* stats,
-                     int stat_chunks, int* chunks_query, void* ypool) {
+                     int stat_chunks, int* chunks_query, void* ypool, void* ymask) {
   TileGeom g;
   g.n = n; g.h = h; g.w = w; g.cin = cin; g.cout = cout;
   g.cin_pad = (cin + 15) / 16 * 16;
@@ -864,6 +903,7 @@ int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int
   g.stat_chunks = stat_chunks;
   g.chunks_query = chunks_query;
   g.ypool = (bf16*)ypool;
+  g.ymask = (unsigned char*)ymask;
   g.f16 = tg_elem_f16();      // the descriptor's dtype, noted by the C-ABI entry point
   if (k == 1) return dispatch_tile<1>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
   return dispatch_tile<3>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
@@ -894,6 +934,7 @@ int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gs
   g.stat_chunks = stat_chunks;
   g.chunks_query = chunks_query;
   g.ypool = nullptr;
+  g.ymask = nullptr;
   g.f16 = tg_elem_f16();
   return dispatch_tile_upcat(g, (const bf16*)x0, (const bf16*)wp, nullptr, (bf16*)y, s);
 }

@@ -725,12 +725,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_slab_reduce(const float* __res
 
 bool wg_thin(int h, int w, int cin, int cout);
 
-// Waves per workgroup of conv_wgrad_tile_kernel for this layer.  8 (16-row tiles, one workgroup per CU) wherever the
-// map is a multiple of 16 rows: half the slabs for the same waves in flight.  TG_TUNE_WG_NW=4 / 8 forces one (A/B).
+// Waves per workgroup of conv_wgrad_tile_kernel for this layer: 8 (16-row tiles, one workgroup per CU, half the slabs
+// for the same waves in flight) or 4.  Measured on one box, n = 64, us with 4 / 8 waves (gpurun_out r3d): the encoder /
+// discriminator layers (cin <= cout) gain where the slice count stays a multiple of 8 (the XCD co-scheduling of the
+// blocks that share a 128-byte line needs that) or the map is one tile -- 128^2 32>32 39.8 / 34.9, 64^2 64>64 34.7 / 33.1,
+// 32^2 128>128 33.3 / 31.9, 16^2 256>256 37.3 / 34.2, with the bias gradient 37.5 / 32.8 ... 35.0 / 29.9; widening ones are
+// even (128^2 32>64 55 / 53, 64^2 64>128 52.0 / 52.2, 32^2 128>256 50.4 / 51.3).  The generator's narrowing layers LOSE:
+// 32^2 512>128 89 / 111 (4 slices: no co-scheduling), 64^2 256>64 90 / 95, 128^2 128>32 101 / 112, 16^2 512>256 53.8 / 55.1.
+// TG_TUNE_WG_NW=4 / 8 forces one (A/B).
 int wg_waves(int h, int w, int cin, int cout) {
   if (w == 8 || h % 16 != 0 || w % 16 != 0 || wg_thin(h, w, cin, cout)) return 4;
   const int force = tg_tune("TG_TUNE_WG_NW", 0);
-  return force == 4 ? 4 : 8;
+  if (force == 4 || force == 8) return force;
+  if (cin > cout) return 4;
+  const int pairs = ((cin + 31) / 32) * ((cout + 31) / 32);
+  const int slices8 = pairs <= 256 ? 256 / pairs : 1;
+  return (slices8 % 8 == 0 || h <= 16) ? 8 : 4;
 }
 
 void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices, int nb = 0) {

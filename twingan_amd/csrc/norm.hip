@@ -655,10 +655,13 @@ __global__ void channel_sum_kernel(const T* __restrict__ g, float* __restrict__ 
 }
 
 // gy = gz * (z > 0 ? 1 : alpha)  and  gbias[c] += sum_p gy[p][c]   (LeakyReLU backward fused with BiasAddGrad)
-template <typename T, int V>
+// BITS (V = 8 only): `z` is not the activation but its sign bits, one byte per 8 channels ([npix][c/8], bit j of byte q =
+// (z[.., 8q+j] > 0)): what tg_conv2d_fwd_pool_signs left of a block-end conv's output
+template <typename T, int V, bool BITS = false>
 __global__ void lrelu_bwd_bias_kernel(const T* __restrict__ gz, const T* __restrict__ gzp, int hw, int wdim,
                                       const T* __restrict__ z, T* __restrict__ gy, float* __restrict__ gbias,
                                       int64_t npix, int c, float alpha) {
+  static_assert(!BITS || V == 8, "sign bits come one byte per 16-byte vector of a 16-bit type");
   extern __shared__ float sh[];   // [c]
   constexpr int U = 4;            // pixels in flight per thread: a streaming pass needs >= 64 KB outstanding per CU
   const int cv = c / V;
@@ -674,6 +677,7 @@ __global__ void lrelu_bwd_bias_kernel(const T* __restrict__ gz, const T* __restr
     const int hw_shift = ((hw & (hw - 1)) == 0) ? 31 - __builtin_clz(hw) : -1;
     for (int64_t pb = (int64_t)blockIdx.x * lanes + pl; pb < npix; pb += stride * U) {
       float g[U][V], zz[U][V];
+      unsigned zb[U];
       // all loads first (addresses clamped instead of predicated: no branches between the loads)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -685,7 +689,14 @@ __global__ void lrelu_bwd_bias_kernel(const T* __restrict__ gz, const T* __restr
         } else {
           VecIO<T, V>::load(gz + p * c + v * V, g[u]);
         }
-        VecIO<T, V>::load(z + p * c + v * V, zz[u]);
+        if constexpr (BITS) zb[u] = reinterpret_cast<const unsigned char*>(z)[p * cv + v];
+        else VecIO<T, V>::load(z + p * c + v * V, zz[u]);
+      }
+      if constexpr (BITS) {      // unfold the bits into the +-1 the arithmetic below tests
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int j = 0; j < V; ++j) zz[u][j] = ((zb[u] >> j) & 1u) ? 1.f : -1.f;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -975,7 +986,8 @@ int tg_norm_act_bwd(const void* gz, const void* gz_pooled, const void* y, const 
 }
 
 static int lrelu_bwd_launch(const char* who, const void* gz, const void* gzp, int hw, int wdim, const void* z, void* gy,
-                            float* gbias, int64_t npix, int c, float alpha, int accumulate, int dtype, hipStream_t s) {
+                            float* gbias, int64_t npix, int c, float alpha, int accumulate, int dtype, hipStream_t s,
+                            bool z_is_sign_bits = false) {
   if (gbias && !accumulate) {
     int rc = tg_zero_async(gbias, (size_t)c * sizeof(float), nullptr, 0, s);
     if (rc) return rc;
@@ -990,7 +1002,15 @@ static int lrelu_bwd_launch(const char* who, const void* gz, const void* gzp, in
     const size_t lds = (size_t)c * sizeof(float);
     // exact path: the element-wise part on the full grid, the bias gradient by one workgroup over what it wrote
     float* gb_here = (exact_grid<T>() && blocks > 1) ? nullptr : gbias;
-    if (V == 1)
+    if (z_is_sign_bits) {
+      if constexpr (sizeof(T) == 2) {
+        TG_CHECK(V == 8, TG_ENOSUP, "%s: sign bits need c %% 8 == 0 (c = %d)", who, c);
+        hipLaunchKernelGGL((lrelu_bwd_bias_kernel<T, 8, true>), dim3(blocks), dim3(256), lds, s, (const T*)gz, (const T*)gzp,
+                           hw, wdim, (const T*)z, (T*)gy, gb_here, npix, c, alpha);
+      } else {
+        TG_CHECK(false, TG_ENOSUP, "%s: sign bits are a feature of the 16-bit storage types", who);
+      }
+    } else if (V == 1)
       hipLaunchKernelGGL((lrelu_bwd_bias_kernel<T, 1>), dim3(blocks), dim3(256), lds, s, (const T*)gz, (const T*)gzp, hw,
                          wdim, (const T*)z, (T*)gy, gb_here, npix, c, alpha);
     else
@@ -1027,6 +1047,15 @@ int tg_lrelu_pool_bwd(const void* gz, const void* gz_pooled, const void* z, void
                             dtype, (hipStream_t)stream);
   return lrelu_bwd_launch("tg_lrelu_pool_bwd", gz, gz_pooled, h * w, w, z, gy, gbias, (int64_t)n * h * w, c, alpha,
                           accumulate, dtype, (hipStream_t)stream);
+}
+
+int tg_lrelu_pool_bwd_signs(const void* gz_pooled, const void* z_signs, void* gy, float* gbias, int n, int h, int w, int c,
+                            float alpha, int accumulate, int dtype, void* stream) {
+  TG_CHECK(gz_pooled && z_signs && gy && n > 0 && h > 0 && w > 0 && c > 0, TG_EINVAL, "tg_lrelu_pool_bwd_signs: bad arguments");
+  TG_CHECK(h % 2 == 0 && w % 2 == 0 && c % 8 == 0, TG_EINVAL, "tg_lrelu_pool_bwd_signs: needs even h, w and c %% 8 == 0");
+  TG_CHECK(dtype == TG_BF16 || dtype == TG_F16, TG_ENOSUP, "tg_lrelu_pool_bwd_signs: 16-bit storage only");
+  return lrelu_bwd_launch("tg_lrelu_pool_bwd_signs", nullptr, gz_pooled, h * w, w, z_signs, gy, gbias, (int64_t)n * h * w, c,
+                          alpha, accumulate, dtype, (hipStream_t)stream, true);
 }
 
 int tg_channel_sum(const void* g, float* out, int64_t npix, int c, int accumulate, int dtype, void* stream) {

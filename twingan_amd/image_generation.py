@@ -26,7 +26,7 @@ def generator_loss(P, targets, cfg, noise):
   assert cfg.loss_architecture in LOSSES, cfg.loss_architecture
   pggan.prepare_run(P, cfg)
   fake = generate(P, noise, cfg)
-  pred, _ = pggan.discriminator(P, fake, cfg, 'discriminator')
+  pred, _ = pggan.discriminator(P, fake, cfg, 'discriminator', block_end_points=False)
   terms = {'generator_fool_loss': _fool_loss(pred, cfg)}
   return _sum_terms(terms), terms
 
@@ -40,7 +40,7 @@ def discriminator_loss(P, targets, cfg, noise, gp_alpha, dragan_noise=None):
       targets = get_growing_image(targets, cfg.alpha_grow)      # get_growing_source_and_target (:985-1006)
     fake = generate(P, noise, cfg)
   b = targets.shape[0]
-  pred, _ = pggan.discriminator(P, torch.cat([targets, fake], dim=0), cfg, 'discriminator', groups=2)
+  pred, _ = pggan.discriminator(P, torch.cat([targets, fake], dim=0), cfg, 'discriminator', groups=2, block_end_points=False)
   pr, pf = (t.contiguous() for t in pred.chunk(2))
   terms = {}
   _real_fake_losses(terms, '', pf, pr, cfg)

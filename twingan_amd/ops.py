@@ -64,6 +64,9 @@ def _chk(*ts):
 USE_CONV_STATS = os.environ.get('TG_CONV_STATS', '1') != '0'
 # avg_pool2 of a discriminator block's last conv written by that conv (TG_CONV_POOL=0: separate pool launch)
 USE_CONV_POOL = os.environ.get('TG_CONV_POOL', '1') != '0'
+# ... and, where the pool is the only consumer of the full-resolution output, only the SIGN bits of that output are
+# kept for the LeakyReLU backward (tg_conv2d_fwd_pool_signs / tg_lrelu_pool_bwd_signs; TG_POOL_SIGNS=0: the tensor itself)
+USE_POOL_SIGNS = os.environ.get('TG_POOL_SIGNS', '1') != '0'
 # self-attention's score / softmax / value products as the flash kernels in first-order passes (TG_FLASH_ATTENTION=0: the
 # batched-GEMM + row-softmax composition everywhere)
 USE_FLASH_ATTENTION = os.environ.get('TG_FLASH_ATTENTION', '1') != '0'
@@ -387,6 +390,46 @@ def conv_fwd_pool_raw(x, w, bias, spec, epilogue):
   return z, zp
 
 
+def conv_fwd_pool_signs_supported(x, w, spec, epilogue):
+  """Can (sign bits of z, avg_pool2(z)) come out of one launch for this layer (tg_conv2d_fwd_pool_signs)?"""
+  if not (USE_CONV_POOL and USE_POOL_SIGNS) or x.dtype not in HALF_TYPES or w.shape[3] % 8 or not (epilogue & TG_EPI_LRELU):
+    return False
+  d = _desc(x.shape, w.shape[3], spec, x.dtype, epilogue)
+  return d.algo == TG_ALGO_MFMA and d.hout % 2 == 0 and d.wout % 2 == 0 and \
+      bool(_lib.load().tg_conv2d_fwd_pool_supported(ctypes.byref(d)))
+
+
+def conv_fwd_pool_signs_raw(x, w, bias, spec, epilogue):
+  """(signs, avg_pool2(z)) of z = epilogue(conv(x, w) + bias): z itself is never written; signs is uint8
+  [n, h, w, cout / 8], bit j of byte q = (z[.., 8q+j] > 0)."""
+  _chk(x, w, bias)
+  d = _desc(x.shape, w.shape[3], spec, x.dtype, epilogue)
+  signs = torch.empty((d.n, d.hout, d.wout, d.cout // 8), dtype=torch.uint8, device=x.device)
+  zp = torch.empty((d.n, d.hout // 2, d.wout // 2, d.cout), dtype=x.dtype, device=x.device)
+
+  def work():      # input + pooled output + one bit per full-resolution output
+    tag, fl, _ = _conv_work(d, 'fwd', _esize(x))
+    return tag, fl, _nb(x, zp, signs) + _esize(x) * d.kh * d.kw * d.cin * d.cout
+  call('tg_conv2d_fwd_pool_signs', ctypes.byref(d), _p(x), _p(PackCache.get(w, d, 0)), _p(bias), _p(signs), _p(zp), _stream(),
+       work=work)
+  return signs, zp
+
+
+def lrelu_pool_bwd_signs(gzp, signs, alpha, bias, want_bias):
+  """g = 0.25 * upsample2(gzp) * (sign ? 1 : alpha) [+ the bias gradient]; see lrelu_pool_bwd."""
+  _chk(gzp, signs)
+  n, h, w, c8 = signs.shape
+  c = c8 * 8
+  g = torch.empty((n, h, w, c), dtype=gzp.dtype, device=gzp.device)
+  sink = GradSink.get(bias) if want_bias else None
+  gb = None
+  if want_bias:
+    gb = sink if sink is not None else torch.empty(c, dtype=torch.float32, device=gzp.device)
+  call('tg_lrelu_pool_bwd_signs', _p(gzp), _p(signs), _p(g), _p(gb), n, h, w, c, alpha, 1 if sink is not None else 0,
+       _dt(gzp), _stream(), work=('lrelu_pool_bwd' + _shape_tag(g), 0, _nb(gzp, signs, g)))
+  return g, (None if sink is not None else gb)
+
+
 class ConvStats:
   """Per-workgroup statistics partials a conv wrote from its epilogue (tg_conv2d_fwd_stats): fp32
   [n][chunks][2][cout], consumed by norm_act instead of a statistics pass over the conv output."""
@@ -597,6 +640,9 @@ def _conv_backward(ctx, gz, gzp=None):
       need_b = False
   elif pooled_lrelu is not None:
     g = pooled_lrelu
+  elif getattr(ctx, 'tg_signs', False):      # z holds the sign bits of the layer's output (Conv2dPoolSignsFn)
+    g, gb = lrelu_pool_bwd_signs(gzp, z, spec.alpha, bias if need_b else None, need_b)
+    need_b = False
   elif ctx.epilogue & TG_EPI_LRELU:
     if fused and (need_b or gzp is not None):
       g, gb = lrelu_pool_bwd(gz, gzp, z, spec.alpha, bias if need_b else None, need_b)
@@ -672,6 +718,27 @@ class Conv2dPoolFn(torch.autograd.Function):
     if gz is None and gzp is None:
       return None, None, None, None, None, None
     return _conv_backward(ctx, gz, gzp)
+
+
+class Conv2dPoolSignsFn(torch.autograd.Function):
+  """avg_pool2(z), z = lrelu(conv(x, w) + bias), when the pool is the only consumer of z (the discriminator blocks,
+  nets/pggan.py:304-306) and the pass is differentiated once: the forward keeps only the sign bits of z
+  (tg_conv2d_fwd_pool_signs: 1/16 of z's bytes written instead of all of them), the backward rebuilds the LeakyReLU
+  derivative from them (tg_lrelu_pool_bwd_signs).  Not for create_graph passes (ops.second_order): those keep z."""
+
+  @staticmethod
+  def forward(ctx, x, w, bias, spec, epilogue, mask_input=False):
+    signs, zp = conv_fwd_pool_signs_raw(x, w, bias, spec, epilogue)
+    ctx.mask_input, ctx.spec, ctx.epilogue, ctx.tg_signs = mask_input, spec, epilogue, True
+    ctx.out_hw = (signs.shape[1], signs.shape[2])
+    ctx.save_for_backward(x, w, signs, bias)
+    return zp
+
+  @staticmethod
+  def backward(ctx, gzp):
+    if torch.is_grad_enabled():
+      raise _lib.TgError('Conv2dPoolSignsFn is first order only: run the forward inside ops.second_order() to keep z')
+    return _conv_backward(ctx, None, gzp)
 
 
 class ConvBwdDataFn(torch.autograd.Function):
@@ -788,14 +855,19 @@ def conv2d_stats(x, w, k=3, padding='SAME'):
   return y, holder[0]
 
 
-def conv2d(x, w, bias=None, k=3, padding='SAME', lrelu=False, alpha=LRELU_ALPHA, pool=False, fuse_input_lrelu=False):
+def conv2d(x, w, bias=None, k=3, padding='SAME', lrelu=False, alpha=LRELU_ALPHA, pool=False, fuse_input_lrelu=False,
+           pool_only=False):
   """Stride-1 conv, optional fused bias and LeakyReLU (discriminator layers).  ``pool``: also return the
   2x2 average-pooled output -> (z, z_pooled).  ``fuse_input_lrelu``: the caller guarantees that ``x`` is consumed by
   this conv only; when x is a conv node's LeakyReLU output, that layer's LeakyReLU backward moves into this conv's
-  backward-data epilogue (raw kernel in first-order passes, the differentiable MaskedDgradFn in create_graph passes)."""
+  backward-data epilogue (raw kernel in first-order passes, the differentiable MaskedDgradFn in create_graph passes).
+  ``pool_only``: the caller uses nothing but the pooled output -> (None, z_pooled) where the layer can run without
+  writing z (Conv2dPoolSignsFn: first-order passes of LeakyReLU layers on the MFMA path), else (z, z_pooled) as usual."""
   spec = ConvSpec(k, padding, 0, alpha)
   epi = (TG_EPI_BIAS if bias is not None else 0) | (TG_EPI_LRELU if lrelu else 0)
   mask_input = bool(fuse_input_lrelu) and _claim_input_lrelu(x, alpha)
+  if pool and pool_only and not in_second_order() and conv_fwd_pool_signs_supported(x, w, spec, epi):
+    return None, Conv2dPoolSignsFn.apply(x, w, bias, spec, epi, mask_input)
   if pool:
     return Conv2dPoolFn.apply(x, w, bias, spec, epi, mask_input)
   z = Conv2dFn.apply(x, w, bias, spec, epi, mask_input)

@@ -383,7 +383,7 @@ def _batch_renorm(P, scope, yv, domain, activation, pn, pool, cond_rows=None, im
                       pool=pool, stats=(mean, rstd))
 
 
-def _d_conv(P, scope, x, cfg, k=3, padding='SAME', pool=False, in_ch=None, sole_consumer=False):
+def _d_conv(P, scope, x, cfg, k=3, padding='SAME', pool=False, in_ch=None, sole_consumer=False, pool_only=False):
   """Discriminator arg-scope (nets/pggan_utils.py:116-127): conv + bias, no norm, LeakyReLU(0.2),
   fused into the conv epilogue."""
   w = _sn(P, scope, cfg, True)
@@ -394,7 +394,7 @@ def _d_conv(P, scope, x, cfg, k=3, padding='SAME', pool=False, in_ch=None, sole_
   # sole_consumer: nothing else reads x, so (when x is the previous conv's LeakyReLU output and no input scaling sits
   # in between) that layer's LeakyReLU backward is folded into this conv's backward-data
   fuse = sole_consumer and not cfg.equalized_learning_rate and not cfg.use_res_block
-  return ops.conv2d(x, w, b, k, padding, lrelu=True, pool=pool, fuse_input_lrelu=fuse)
+  return ops.conv2d(x, w, b, k, padding, lrelu=True, pool=pool, fuse_input_lrelu=fuse, pool_only=pool_only)
 
 
 def resize_twice_as_big(x):
@@ -569,8 +569,11 @@ def generator(P, source, domain, cfg, unet_end_points=None, top='generator', une
 # ------------------------------------------------------------------------------------------------
 # discriminator (nets/pggan.py:217-376)
 # ------------------------------------------------------------------------------------------------
-def discriminator_before_fc(P, source, cfg, top, groups=1, cut_seg=None):
-  """``cut_seg``: segment of a segmented backward (ops.Cuts) in which the blocks above cfg.overlap_cut_hw resume."""
+def discriminator_before_fc(P, source, cfg, top, groups=1, cut_seg=None, block_end_points=True):
+  """``cut_seg``: segment of a segmented backward (ops.Cuts) in which the blocks above cfg.overlap_cut_hw resume.
+  ``block_end_points=False``: the caller wants the prediction only -- the full-resolution output of a block's last conv
+  (end_points['encoder_block_*'], which the reference overwrites with its pooled version as `net`, nets/pggan.py:304-306)
+  is then not materialised where the conv can hand the pool and the LeakyReLU sign bits over directly."""
   hw = source.shape[1]
   max_stage = max_stage_of(hw)
   assert max_stage >= 0
@@ -601,7 +604,10 @@ def discriminator_before_fc(P, source, cfg, top, groups=1, cut_seg=None):
       end_points[name] = maybe_resblock(P, '%s/%s' % (top, name), block_in, num_channels, net, cfg, True)
       net = ops.avg_pool2(end_points[name])
     else:
-      end_points[name], net = _d_conv(P, '%s/%s/Conv_1' % (top, name), net, cfg, pool=True, sole_consumer=True)   # conv + avg_pool (pggan.py:304-306)
+      full, net = _d_conv(P, '%s/%s/Conv_1' % (top, name), net, cfg, pool=True, sole_consumer=True,      # conv + avg_pool (pggan.py:304-306)
+                          pool_only=not block_end_points)
+      if full is not None:
+        end_points[name] = full
     current_hw //= 2
     end_points['downsample_to_%dx%dx%d' % (current_hw, current_hw, num_channels)] = net
     if stage == max_stage and cfg.is_growing:
@@ -616,10 +622,10 @@ def discriminator_before_fc(P, source, cfg, top, groups=1, cut_seg=None):
   return net, end_points
 
 
-def discriminator(P, source, cfg, top, groups=1, cut_seg=None):
+def discriminator(P, source, cfg, top, groups=1, cut_seg=None, block_end_points=True):
   """``groups`` > 1: ``source`` is that many discriminator calls batched along N (each keeps its own
   minibatch-stddev statistic, as separate reference calls would)."""
-  net, end_points = discriminator_before_fc(P, source, cfg, top, groups, cut_seg)
+  net, end_points = discriminator_before_fc(P, source, cfg, top, groups, cut_seg, block_end_points)
   feat = net.reshape(net.shape[0], -1)                                 # tf.squeeze(net, (1, 2))
   pred = ops.fully_connected(_equalize(feat, cfg, 1), P[top + '/prediction/fully_connected/weights'],
                              P[top + '/prediction/fully_connected/biases'])

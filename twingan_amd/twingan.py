@@ -196,11 +196,11 @@ def generator_loss(P, sources, targets, cfg, style_noise=None, distill_embed_s=N
     with streams.domain(i):
       terms['l_cyc_' + d] = ops.abs_diff_mean(orig, cyc, cfg.l_cyc_weight)
       if cyc_gan:      # D(cyc) and D(prime) of one domain share weights: one batch, two minibatch-stddev groups
-        pred, _ = pggan.discriminator(P, torch.cat([cyc, prime], dim=0), cfg, top, groups=2)
+        pred, _ = pggan.discriminator(P, torch.cat([cyc, prime], dim=0), cfg, top, groups=2, block_end_points=False)
         pc, pp = pred.chunk(2)
         terms['generator_fool_loss_cycle_' + d] = _fool_loss(pc, cfg)
       else:
-        pp, _ = pggan.discriminator(P, prime, cfg, top)
+        pp, _ = pggan.discriminator(P, prime, cfg, top, block_end_points=False)
       terms['generator_fool_loss_prime_' + d] = _fool_loss(pp, cfg)
   # re-encode s' in domain s and t' in domain t as one batch (twingan.py:275-288)
   primes = torch.cat([o['s_prime'], o['t_prime']], dim=0)
@@ -263,10 +263,10 @@ def _d_domain_terms(P, cfg, terms, d, top, real, prime, cyc, a, cyc_gan):
   if True:
     # D(real), D(cyc), D(prime) of one domain share weights: one batch, one minibatch-stddev group per call
     if cyc_gan:
-      pred, _ = pggan.discriminator(P, torch.cat([real, cyc, prime], dim=0), cfg, top, groups=3, cut_seg=1)
+      pred, _ = pggan.discriminator(P, torch.cat([real, cyc, prime], dim=0), cfg, top, groups=3, cut_seg=1, block_end_points=False)
       pr, pc, pp = (t.contiguous() for t in pred.chunk(3))
     else:
-      pred, _ = pggan.discriminator(P, torch.cat([real, prime], dim=0), cfg, top, groups=2, cut_seg=1)
+      pred, _ = pggan.discriminator(P, torch.cat([real, prime], dim=0), cfg, top, groups=2, cut_seg=1, block_end_points=False)
       pr, pp = (t.contiguous() for t in pred.chunk(2))
     wgan = cfg.loss_architecture in ('wgan_gp', 'wgan')
     mean_real = ops.mean(pr, cfg.gan_weight) if wgan else None
@@ -287,7 +287,7 @@ def _d_domain_gp(P, cfg, terms, d, top, real, prime, a, noise=None, name=None):
   else:
     interp = ops.sample_lerp(real, prime, a).requires_grad_(True)             # image_generation.py:420-424
   with ops.second_order():
-    pi, _ = pggan.discriminator(P, interp, cfg, top)
+    pi, _ = pggan.discriminator(P, interp, cfg, top, block_end_points=False)
   ones = ops.fill(pi.shape, 1.0, pi.dtype, pi.device)
   with ops.no_param_grads():        # only d pred / d interp is needed here; parameters get theirs via the double backward
     gi, = torch.autograd.grad(pi, interp, grad_outputs=ones, create_graph=True)  # tf.gradients(pred, interp)
