@@ -1469,7 +1469,9 @@ def test_discriminator_sign_bit_path_equals_the_tensor_path(precision):
       ops.USE_POOL_SIGNS = saved
   for grp in ('g', 'd'):
     ta, tb = out[True][grp][0], out[False][grp][0]
-    assert ta == tb, (grp, ta, tb)
+    # the forward values are the same tensors; the gradient-penalty term (which does not use the sign-bit path at all)
+    # ends in fp32 atomics on the 16-bit paths: last-ulp run-to-run noise
+    assert set(ta) == set(tb) and all(abs(ta[k] - tb[k]) <= 2e-6 * max(1.0, abs(tb[k])) for k in tb), (grp, ta, tb)
     num = sum(float(((out[True][grp][1][k] - out[False][grp][1][k]).double() ** 2).sum()) for k in out[True][grp][1])
     den = sum(float((out[False][grp][1][k].double() ** 2).sum()) for k in out[True][grp][1])
     assert (num / den) ** 0.5 < 1e-5, (grp, (num / den) ** 0.5)
