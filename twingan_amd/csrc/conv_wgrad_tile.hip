@@ -58,6 +58,7 @@ struct WgGeom {
   float* gbias;
   int bias_segs;      // bit 0: segment a contributes to gbias, bit 1: segment b
   int nw;             // waves per workgroup of the tile kernel: 4 (8-row tiles) or 8 (16-row tiles)
+  int quad;           // 1: conv_wgrad_quad_kernel (64 x 64 blocks, 8 waves); n_co_blk / n_pairs then count 64-wide blocks
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
@@ -443,6 +444,268 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tile_kernel(const bf16* __
 
 
 // ------------------------------------------------------------------------------------------------------------------
+// Quadrant kernel (round 3): one workgroup owns a 64 ci x 64 co block of the filter gradient -- FOUR 32 x 32 quadrants,
+// each reduced by two waves (the two 4-row halves of an 8 x 16 tile), 8 waves in all.  Why (same per-wave program as
+// conv_wgrad_tile_kernel, different block shape):
+//   * a workgroup stages 64 channels of x and of gy = WHOLE 128-byte lines (a 32-channel block of a 64-channel tensor
+//     reads one half of every line; its neighbour block, on another CU, the other half: each line crossed L2 -> L1 twice);
+//   * 39 KB staged per tile feed 8 x 36 = 288 MFMAs instead of 19.7 KB for 72: half the L2 -> LDS bytes per MFMA, and a
+//     quadrant's operands are shared by two waves instead of being re-fetched by another workgroup;
+//   * 36 MFMAs per wave between two barriers instead of 18.
+// LDS holds the two 32-channel halves of each operand as separate PLANES (64 B per pixel, dense) so that the transpose
+// reads keep the conflict-free pattern of the tile kernel.  cin % 64 == 0 and cout % 64 == 0 (a concat input: c0 % 64 == 0).
+template <bool BIAS = false, bool F16 = false>
+__global__ __launch_bounds__(512) void conv_wgrad_quad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gy,
+                                                              float* __restrict__ slab, const WgGeom g) {
+  constexpr int THREADS = 512, TW = 16, TH = 8, HWX = 18, HH = 10, NT = 9, RPW = 4;
+  constexpr int PS = 64;                                     // LDS bytes per pixel of one plane (32 channels)
+  constexpr int XPX = HH * HWX, GPX = TH * TW;               // 180 halo pixels, 128 output pixels
+  constexpr int XPLANE = XPX * PS, GPLANE = GPX * PS;        // 11520, 8192
+  constexpr int XVEC = XPX * 8, XSLOTS = (XVEC + THREADS - 1) / THREADS;      // 1440 -> 3
+  constexpr int GSLOTS = (GPX * 8) / THREADS;                                 // 2
+  constexpr int X_BYTES = 2 * XPLANE, G_BYTES = 2 * GPLANE;                   // 23040 + 16384 per buffer
+
+  unsigned char* sX = wg_smem;
+  unsigned char* sG = wg_smem + X_BYTES;
+  unsigned char* sX1 = wg_smem + X_BYTES + G_BYTES;
+  unsigned char* sG1 = sX1 + X_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int qi = wid & 1, qo = (wid >> 1) & 1, kh = wid >> 2;      // ci half, co half, 4-row half of the tile
+  int slice, pair;
+  {      // slices of one pair on consecutive XCDs, the pairs of a slice on the same XCD (see conv_wgrad_tile_kernel)
+    const int id = blockIdx.x, npairs = g.n_pairs;
+    if ((g.nslices & 7) == 0) {
+      const int hi = id / (8 * npairs), rem = id - hi * 8 * npairs;
+      pair = rem >> 3;
+      slice = hi * 8 + (rem & 7);
+    } else {
+      pair = id % npairs;
+      slice = id / npairs;
+    }
+  }
+  const int ci_blk = pair / g.n_co_blk, co_blk = pair - ci_blk * g.n_co_blk;
+  const int ci0 = ci_blk * 64, co0 = co_blk * 64;
+
+  // ---- staging slots: 8 lanes fetch the 8 x 16 B of one pixel's 64 channels (one 128-byte line)
+  int x_loff[XSLOTS], x_hy1[XSLOTS], x_hx1[XSLOTS], x_rel[XSLOTS];
+  bool x_use[XSLOTS];
+#pragma unroll
+  for (int s = 0; s < XSLOTS; ++s) {
+    const int v = tid + s * THREADS;
+    const int px = v >> 3, part = v & 7;
+    x_hy1[s] = px / HWX - 1;
+    x_hx1[s] = px % HWX - 1;
+    x_use[s] = v < XVEC && ci0 + part * 8 + 8 <= g.cin;
+    if (g.c0 == 0)
+      x_rel[s] = ((x_hy1[s] * g.w + x_hx1[s]) * g.cin + ci0 + part * 8) * 2;
+    else if (ci0 < g.c0)      // half-resolution source: (iy >> 1, ix >> 1); tile origins are even
+      x_rel[s] = (((x_hy1[s] >> 1) * (g.w >> 1) + (x_hx1[s] >> 1)) * g.c0 + ci0 + part * 8) * 2;
+    else                      // skip source
+      x_rel[s] = ((x_hy1[s] * g.w + x_hx1[s]) * (g.cin - g.c0) + ci0 - g.c0 + part * 8) * 2;
+    x_loff[s] = (part >> 2) * XPLANE + px * PS + (part & 3) * 16;
+  }
+  int g_loff[GSLOTS];
+  unsigned g_rel[GSLOTS];
+#pragma unroll
+  for (int s = 0; s < GSLOTS; ++s) {
+    const int v = tid + s * THREADS;
+    const int px = v >> 3, part = v & 7;
+    const bool use = co0 + part * 8 + 8 <= g.cout;
+    g_rel[s] = use ? (unsigned)((((px >> 4) * g.w + (px & 15)) * g.cout + co0 + part * 8) * 2) : WOOB;
+    g_loff[s] = (part >> 2) * GPLANE + px * PS + (part & 3) * 16;
+  }
+
+  // ---- fragment addresses inside a plane (as conv_wgrad_tile_kernel, TW = 16)
+  const int gq = lane >> 4, t16 = lane & 15;
+  const int frag_off = ((gq >> 1) * 8 + (t16 >> 2)) * PS + ((gq & 1) * 16 + (t16 & 3) * 4) * 2;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  f32x16 accb;
+  bf16x8 ones;
+  if constexpr (BIAS) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) accb[j] = 0.f;
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    u4 o4;
+    o4[0] = o4[1] = o4[2] = o4[3] = ones16x2<F16>();
+    ones = __builtin_bit_cast(bf16x8, o4);
+  }
+  const bool do_bias = BIAS && ci_blk == 0 && qi == 0;      // wave-uniform: the ci-half-0 waves of the ci-block-0 workgroups
+  bool bias_a = false, bias_b = false, bias_0 = false, bias_1 = false;
+
+  const bool from_up = g.c0 != 0 && ci0 < g.c0, from_skip = g.c0 != 0 && ci0 >= g.c0;
+  const int xc = from_up ? g.c0 : (from_skip ? g.cin - g.c0 : g.cin);
+  const size_t ximg = from_up ? (size_t)(g.h >> 1) * (g.w >> 1) * xc : (size_t)g.h * g.w * xc;
+  const size_t gimg = (size_t)g.h * g.w * g.cout;
+  const bf16* xsrc = from_skip ? g.x1 : x;
+  const int tile_begin = slice * g.tiles_per_wg;
+  int tile_end = tile_begin + g.tiles_per_wg;
+  if (tile_end > g.total_tiles) tile_end = g.total_tiles;
+
+  struct Stage {
+    bf16x8 rx[XSLOTS], rg[GSLOTS];
+  };
+  struct Cursor {
+    int tile, tx, ty, img, grp, rem;
+  };
+  const bool permuted = from_skip && g.gsz != 0;
+  auto cursor_set = [&](Cursor& c, int tile) __attribute__((always_inline)) {
+    c.tile = tile;
+    int t = tile >= g.tiles_a ? tile - g.tiles_a : tile;
+    c.tx = t % g.tiles_x;
+    t /= g.tiles_x;
+    c.ty = t % g.tiles_y;
+    c.img = t / g.tiles_y;
+    c.grp = permuted ? c.img / g.gsz : 0;
+    c.rem = permuted ? c.img - c.grp * g.gsz : 0;
+  };
+  auto cursor_next = [&](Cursor& c) __attribute__((always_inline)) {
+    ++c.tile;
+    if (c.tile == g.tiles_a) {      // the second (x, gy) segment starts: recompute
+      cursor_set(c, c.tile);
+      return;
+    }
+    if (++c.tx == g.tiles_x) {
+      c.tx = 0;
+      if (++c.ty == g.tiles_y) {
+        c.ty = 0;
+        ++c.img;
+        if (permuted && ++c.rem == g.gsz) {
+          c.rem = 0;
+          ++c.grp;
+        }
+      }
+    }
+  };
+  auto load_tile = [&](Stage& st, Cursor& c, bool& bias_on) __attribute__((always_inline)) {
+    const unsigned live = c.tile < tile_end;      // past the end: every lane out of range -> a tile of zeros
+    const bool segb = c.tile >= g.tiles_a;
+    bias_on = do_bias && ((g.bias_segs >> (segb ? 1 : 0)) & 1);
+    const bf16* xs = segb ? g.xb : xsrc;
+    const bf16* gs = segb ? g.gyb : gy;
+    const int img = c.img, ox0 = c.tx * TW, oy0 = c.ty * TH;
+    const int ximg_i = permuted ? (int)((g.perm >> (8 * c.grp)) & 0xffu) * g.gsz + c.rem : img;
+    const __amdgpu_buffer_rsrc_t bx = wg_rsrc(xs + (size_t)ximg_i * ximg, (unsigned)(ximg * 2));
+    const __amdgpu_buffer_rsrc_t bg = wg_rsrc(gs + (size_t)img * gimg, (unsigned)(gimg * 2));
+    const int xbase = from_up ? ((oy0 >> 1) * (g.w >> 1) + (ox0 >> 1)) * xc * 2 : (oy0 * g.w + ox0) * xc * 2;
+    const unsigned gbase = (unsigned)((oy0 * g.w + ox0) * g.cout * 2);
+#pragma unroll
+    for (int s = 0; s < XSLOTS; ++s) {
+      const unsigned ok = live & (unsigned)x_use[s] & (unsigned)((unsigned)(oy0 + x_hy1[s]) < (unsigned)g.h) &
+                          (unsigned)((unsigned)(ox0 + x_hx1[s]) < (unsigned)g.w);
+      const unsigned off = ok ? (unsigned)(xbase + x_rel[s]) : WOOB;
+      st.rx[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bx, off, 0, 0));
+    }
+#pragma unroll
+    for (int s = 0; s < GSLOTS; ++s)
+      st.rg[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bg, live ? gbase + g_rel[s] : WOOB, 0, 0));
+    cursor_next(c);
+  };
+  auto stage_to_lds = [&](const Stage& st, unsigned char* bX, unsigned char* bG) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < XSLOTS; ++s)
+      if (s < XSLOTS - 1 || tid + s * THREADS < XVEC) *reinterpret_cast<bf16x8*>(bX + x_loff[s]) = st.rx[s];
+#pragma unroll
+    for (int s = 0; s < GSLOTS; ++s) *reinterpret_cast<bf16x8*>(bG + g_loff[s]) = st.rg[s];
+  };
+  // One tile, one wave: rows r = 0..3 of its half (K steps), halo rows h = 0..5.  Halo row h serves tap row ky of
+  // output row r = h - ky: 3 x fragments per halo row, each used by up to 3 MFMAs per tap column -- 18 x + 4 gy fragments
+  // (44 transpose reads) for 36 MFMAs.  The x fragments of row h + 1 are requested before the MFMAs of row h.
+  auto reduce_tile = [&](const unsigned char* bX, const unsigned char* bG, bool bias_on) __attribute__((always_inline)) {
+    const unsigned char* xb = bX + qi * XPLANE + frag_off;
+    const unsigned char* gb = bG + qo * GPLANE + frag_off;
+    bf16x8 G[RPW], X[3], Xn[3];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) G[r] = tr_frag(gb + ((kh * RPW + r) * TW) * PS);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) X[kx] = tr_frag(xb + ((kh * RPW) * HWX + kx) * PS);
+    if constexpr (BIAS) {
+      typedef __attribute__((ext_vector_type(4))) unsigned u4;
+      const u4 o = __builtin_bit_cast(u4, ones);
+      u4 sel;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sel[j] = bias_on ? o[j] : 0u;
+      const bf16x8 bo = __builtin_bit_cast(bf16x8, sel);
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) accb = mfma_32x32x16<F16>(bo, G[r], accb);
+    }
+#pragma unroll
+    for (int h = 0; h < RPW + 2; ++h) {
+      if (h + 1 < RPW + 2) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) Xn[kx] = tr_frag(xb + ((kh * RPW + h + 1) * HWX + kx) * PS);
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int r = h - ky;
+        if (r >= 0 && r < RPW) {
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = mfma_32x32x16<F16>(X[kx], G[r], acc[ky * 3 + kx]);
+        }
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) X[kx] = Xn[kx];
+    }
+  };
+
+  Stage sa, sb;
+  Cursor cur;
+  cursor_set(cur, tile_begin);
+  load_tile(sa, cur, bias_a);
+  load_tile(sb, cur, bias_b);
+  for (int tile = tile_begin; tile < tile_end; tile += 2) {      // two tiles per trip; an odd count reduces one zero tile
+    stage_to_lds(sa, sX, sG);
+    bias_0 = bias_a;
+    __syncthreads();
+    load_tile(sa, cur, bias_a);
+    reduce_tile(sX, sG, bias_0);
+    stage_to_lds(sb, sX1, sG1);
+    bias_1 = bias_b;
+    __syncthreads();
+    load_tile(sb, cur, bias_b);
+    reduce_tile(sX1, sG1, bias_1);
+  }
+
+  // ---- the two 4-row halves of every quadrant are summed through LDS (kh = 0 first: a fixed order), tap by tap
+  // acc[tap][r]: ci = ci0 + 32 qi + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), co = co0 + 32 qo + (lane & 31)
+  float* red = reinterpret_cast<float*>(wg_smem);      // [8 waves][16 regs][64 lanes] = 32 KiB
+  float* out = slab + (size_t)slice * NT * g.cin * g.cout;
+#pragma unroll
+  for (int tap = 0; tap < NT; ++tap) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wid * 16 + r) * 64 + lane] = acc[tap][r];
+    __syncthreads();
+    const int l2 = tid & 63, q = (tid >> 6) & 3, half = tid >> 8;      // quadrant q = qi + 2 qo, registers 8 half .. 8 half + 7
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = half * 8 + j;
+      const float sum = red[(q * 16 + r) * 64 + l2] + red[((q + 4) * 16 + r) * 64 + l2];
+      const int ci = ci0 + (q & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l2 >> 5);
+      const int co = co0 + (q >> 1) * 32 + (l2 & 31);
+      if (ci < g.cin && co < g.cout) out[((size_t)tap * g.cin + ci) * g.cout + co] = sum;
+    }
+  }
+  if constexpr (BIAS) {
+    if (BIAS && ci_blk == 0) {      // workgroup-uniform; accb[0] on lanes 0..31 = column sum of co0 + 32 qo + lane
+      __syncthreads();
+      if (qi == 0 && lane < 32) red[wid * 32 + lane] = accb[0];
+      __syncthreads();
+      if (tid < 64 && co0 + tid < g.cout) {      // waves (qi 0, qo, kh): wid = 2 qo + 4 kh
+        const int w0 = 2 * (tid >> 5);
+        atomicAdd(g.gbias + co0 + tid, red[w0 * 32 + (tid & 31)] + red[(w0 + 4) * 32 + (tid & 31)]);
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
 // Thin layers (cin or cout = 16: the 256x256 blocks of E / D, the generator's last concat conv).  The 32 x 32
 // accumulator block of the kernel above is 75 % padding there (kbench: 16->16 and 16->32 at 256x256 take the same
 // 100 us -- bound by MFMA issue and per-tile overhead, not by HBM).  Here the block is 16 ci x CO co (CO = 16 | 32)
@@ -743,9 +1006,20 @@ int wg_waves(int h, int w, int cin, int cout) {
   return (slices8 % 8 == 0 || h <= 16) ? 8 : 4;
 }
 
-void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices, int nb = 0) {
+// The quadrant kernel takes 3x3 layers whose channel counts are multiples of 64 (whole 128-byte lines per pixel; a concat
+// input must split on a 64-channel boundary).  TG_TUNE_WG_QUAD=0 / 1 forces it off / on where eligible (A/B).
+bool wg_quad(int h, int w, int cin, int cout, int c0) {
+  if (w % 16 != 0 || h % 8 != 0 || cin % 64 != 0 || cout % 64 != 0 || c0 % 64 != 0) return false;
+  const int force = tg_tune("TG_TUNE_WG_QUAD", -1);
+  if (force == 0) return false;
+  if (force == 1) return true;
+  return true;
+}
+
+void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices, int nb = 0, int c0 = 0, bool allow_quad = true) {
   const bool thin = wg_thin(h, w, cin, cout);
-  g->nw = wg_waves(h, w, cin, cout);
+  g->quad = (allow_quad && wg_quad(h, w, cin, cout, c0)) ? 1 : 0;
+  g->nw = g->quad ? 8 : wg_waves(h, w, cin, cout);
   g->n = n; g->h = h; g->w = w; g->cin = cin; g->cout = cout;
   g->x1 = nullptr;
   g->c0 = g->gsz = 0;
@@ -760,12 +1034,12 @@ void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices, i
     g->total_tiles = g->tiles_a + (nb + 1) / 2;
   } else {
     g->tiles_x = w / 16;
-    g->tiles_y = h / ((thin || g->nw == 8) ? 16 : 8);
+    g->tiles_y = h / ((thin || (g->nw == 8 && !g->quad)) ? 16 : 8);
     g->tiles_a = g->tiles_x * g->tiles_y * n;
     g->total_tiles = g->tiles_a + g->tiles_x * g->tiles_y * nb;
   }
-  const int n_ci = thin ? cin / 16 : (cin + 31) / 32;      // thin: 16-channel ci blocks, one co block (cout <= 32)
-  g->n_co_blk = thin ? (cout + 15) / 16 : (cout + 31) / 32;
+  const int n_ci = g->quad ? cin / 64 : (thin ? cin / 16 : (cin + 31) / 32);      // thin: 16-channel ci blocks, one co block (cout <= 32)
+  g->n_co_blk = g->quad ? cout / 64 : (thin ? (cout + 15) / 16 : (cout + 31) / 32);
   // ~2 workgroups per CU in total; 1 per CU when that leaves a workgroup fewer than 8 tiles: every workgroup
   // costs one slab write + read (9*32*32 floats), which then outweighs its share of the input traffic
   // (kbench, 128x128x32 n16: 24.2 -> 20.6 us; 256x256x16 n48 prefers 512: 70 vs 85 us).
@@ -812,6 +1086,32 @@ int wg_launch_tile(const WgGeom& g, const bf16* x, const bf16* gy, float* ws, in
   const size_t lds16 = 2 * (10 * 18 * 64 + 8 * 16 * 64);           // 8 x 16 tiles, 4 waves
   const size_t lds16w8 = 2 * (18 * 18 * 64 + 16 * 16 * 64);        // 16 x 16 tiles, 8 waves: 74 240 B
   const bool bias = g.gbias != nullptr;
+  if (g.quad) {
+    const size_t ldsq = 2 * (2 * 10 * 18 * 64 + 2 * 8 * 16 * 64);      // two buffers of two x planes + two gy planes: 78 848 B
+    static bool raised_q = false;
+    if (!raised_q) {
+      const void* ks[4] = {reinterpret_cast<const void*>(conv_wgrad_quad_kernel<true, true>),
+                           reinterpret_cast<const void*>(conv_wgrad_quad_kernel<true, false>),
+                           reinterpret_cast<const void*>(conv_wgrad_quad_kernel<false, true>),
+                           reinterpret_cast<const void*>(conv_wgrad_quad_kernel<false, false>)};
+      for (const void* k : ks) {
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq) != hipSuccess) {
+          tg_set_error("conv_wgrad_quad: cannot raise dynamic LDS to %zu", ldsq);
+          return TG_ELAUNCH;
+        }
+      }
+      raised_q = true;
+    }
+    const dim3 gridq(nslices * g.n_pairs);
+    tg_note_kernel("conv_wgrad_quad_kernel");
+    const bool f16 = tg_elem_f16();
+    if (bias && f16) hipLaunchKernelGGL((conv_wgrad_quad_kernel<true, true>), gridq, dim3(512), ldsq, s, x, gy, ws, g);
+    else if (bias) hipLaunchKernelGGL((conv_wgrad_quad_kernel<true, false>), gridq, dim3(512), ldsq, s, x, gy, ws, g);
+    else if (f16) hipLaunchKernelGGL((conv_wgrad_quad_kernel<false, true>), gridq, dim3(512), ldsq, s, x, gy, ws, g);
+    else hipLaunchKernelGGL((conv_wgrad_quad_kernel<false, false>), gridq, dim3(512), ldsq, s, x, gy, ws, g);
+    TG_LAUNCH_CHECK("conv_wgrad_quad");
+    return TG_OK;
+  }
   if (g.w == 8) {
     tg_note_kernel("conv_wgrad_tile_kernel");
     if (bias) TG_WG_LAUNCH(8, true, 4, grid, dim3(256), lds8, s, x, gy, ws, g);
@@ -849,11 +1149,14 @@ bool tg_wgrad_tile_supported(int h, int w, int hout, int wout, int kh, int kw, i
          (((h % 8 == 0) && (w % 16 == 0)) || (h == 8 && w == 8));
 }
 
+// enough for whichever kernel the run picks (a concat input that does not split on a 64-channel boundary falls back
+// from the quadrant kernel to the tile kernel, with another slice count)
 size_t tg_wgrad_tile_workspace(int n, int h, int w, int cin, int cout) {
   WgGeom g;
-  int nslices;
+  int nslices, nslices_t;
   wg_split(n, h, w, cin, cout, &g, &nslices);
-  return (size_t)nslices * 9 * cin * cout * sizeof(float);
+  wg_split(n, h, w, cin, cout, &g, &nslices_t, 0, 0, false);
+  return (size_t)(nslices > nslices_t ? nslices : nslices_t) * 9 * cin * cout * sizeof(float);
 }
 
 int tg_wgrad_tile_run(int n, int h, int w, int cin, int cout, const void* x, const void* gy, float* gw, int accumulate,
@@ -911,7 +1214,7 @@ int tg_wgrad_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int g
   WgGeom g;
   int nslices;
   const int cin = c0 + c1;
-  wg_split(n, h, w, cin, cout, &g, &nslices);
+  wg_split(n, h, w, cin, cout, &g, &nslices, 0, c0);
   g.x1 = (const bf16*)x1;
   g.c0 = c0;
   g.gsz = gsz;
