@@ -1007,18 +1007,29 @@ int wg_waves(int h, int w, int cin, int cout) {
 }
 
 // The quadrant kernel takes 3x3 layers whose channel counts are multiples of 64 (whole 128-byte lines per pixel; a concat
-// input must split on a 64-channel boundary).  TG_TUNE_WG_QUAD=0 / 1 forces it off / on where eligible (A/B).
-bool wg_quad(int h, int w, int cin, int cout, int c0) {
+// input must split on a 64-channel boundary).  Measured against the tile kernel on one box, n = 64, us tile / quadrant
+// (gpurun_out r3g): its loop is ~8 % faster where the slabs do not matter -- 32^2 512>128 90.0 / 82.2 (940 TFLOP/s), 64^2
+// 256>64 87.4 / 81.0, 16^2 512>256 53.9 / 52.2, 32^2 128>256 50.2 / 48.8 -- but a workgroup's slab is four times a tile
+// workgroup's (147 KB), so the layers with few blocks and short loops lose: 64^2 64>64 33.0 / 36.0, 32^2 128>128 32.1 / 34.6,
+// 16^2 256>256 34.1 / 39.3 (n = 16: 21.4 / 32.2), and with the fused bias gradient (254 VGPRs) 29.2 / 38.2.  Taken where it
+// measured faster: narrowing layers (the generator's concat convs), and widening ones with >= 8 blocks and >= 16 tiles per
+// workgroup; never with the bias gradient.  TG_TUNE_WG_QUAD=0 / 1 forces it off / on where eligible (A/B).
+bool wg_quad(int h, int w, int cin, int cout, int c0, int total_tiles8, bool bias) {
   if (w % 16 != 0 || h % 8 != 0 || cin % 64 != 0 || cout % 64 != 0 || c0 % 64 != 0) return false;
   const int force = tg_tune("TG_TUNE_WG_QUAD", -1);
   if (force == 0) return false;
   if (force == 1) return true;
-  return true;
+  if (bias) return false;
+  if (cin > cout) return true;
+  const int pairs = (cin / 64) * (cout / 64);
+  const int slices = pairs <= 256 ? 256 / pairs : 1;
+  return cin < cout && pairs >= 8 && total_tiles8 / slices >= 16;
 }
 
-void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices, int nb = 0, int c0 = 0, bool allow_quad = true) {
+void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices, int nb = 0, int c0 = 0, bool allow_quad = true,
+              bool bias = false) {
   const bool thin = wg_thin(h, w, cin, cout);
-  g->quad = (allow_quad && wg_quad(h, w, cin, cout, c0)) ? 1 : 0;
+  g->quad = (allow_quad && w != 8 && wg_quad(h, w, cin, cout, c0, (w / 16) * (h / 8) * (n + nb), bias)) ? 1 : 0;
   g->nw = g->quad ? 8 : wg_waves(h, w, cin, cout);
   g->n = n; g->h = h; g->w = w; g->cin = cin; g->cout = cout;
   g->x1 = nullptr;
@@ -1163,7 +1174,7 @@ int tg_wgrad_tile_run(int n, int h, int w, int cin, int cout, const void* x, con
                       void* ws, size_t ws_bytes, hipStream_t s, float* gbias) {
   WgGeom g;
   int nslices;
-  wg_split(n, h, w, cin, cout, &g, &nslices);
+  wg_split(n, h, w, cin, cout, &g, &nslices, 0, 0, true, gbias != nullptr);
   g.gbias = gbias;
   const int64_t nw = (int64_t)9 * cin * cout;
   TG_CHECK(ws && ws_bytes >= (size_t)nslices * nw * sizeof(float), TG_EINVAL,
@@ -1179,9 +1190,10 @@ int tg_wgrad_tile_run(int n, int h, int w, int cin, int cout, const void* x, con
 
 size_t tg_wgrad_tile_workspace2(int na, int nb, int h, int w, int cin, int cout) {
   WgGeom g;
-  int nslices;
+  int nslices, nslices_t;
   wg_split(na, h, w, cin, cout, &g, &nslices, nb);
-  return (size_t)nslices * 9 * cin * cout * sizeof(float);
+  wg_split(na, h, w, cin, cout, &g, &nslices_t, nb, 0, false);
+  return (size_t)(nslices > nslices_t ? nslices : nslices_t) * 9 * cin * cout * sizeof(float);
 }
 
 // gw (+)= wgrad(xa, gya) + wgrad(xb, gyb): two batches of the same layer in one launch
@@ -1190,7 +1202,7 @@ int tg_wgrad_tile_run2(int na, int nb, int h, int w, int cin, int cout, const vo
                        int bias_segs) {
   WgGeom g;
   int nslices;
-  wg_split(na, h, w, cin, cout, &g, &nslices, nb);
+  wg_split(na, h, w, cin, cout, &g, &nslices, nb, 0, true, gbias != nullptr);
   g.xb = (const bf16*)xb;
   g.gyb = (const bf16*)gyb;
   g.gbias = gbias;
