@@ -609,6 +609,9 @@ int tg_conv2d_fwd_stats_mfma(const TgConvDesc* d0, const void* x, const void* wp
                           nullptr, partials, chunks, nullptr);
 }
 
+bool tg_conv_img_supported(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l);
+int tg_conv_img_run(int n, int hw, int cin, int cout, int epilogue, float alpha, const void* x, const void* wp,
+                    const float* bias, void* y, hipStream_t s);
 bool tg_conv_small_supported(int n, int hout, int wout, int kh, int kw);
 int tg_conv_small_run(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l,
                       int epilogue, float alpha, const void* x, const void* wp, const float* bias, void* y, hipStream_t s);
@@ -622,6 +625,9 @@ int tg_conv2d_fwd_mfma(const TgConvDesc* d0, const void* x, const void* wp, cons
       tg_conv_tile_supported(d->hin, d->win, d->hout, d->wout, d->kh, d->kw, d->pad_t, d->pad_l))
     return tg_conv_tile_run(d->n, d->hin, d->win, d->cin, d->cout, d->kh, d->pad_t, d->epilogue, d->lrelu_alpha, x, wp,
                             bias, y, s);
+  if (d->algo != TG_ALGO_MFMA_V1 && d->kh == d->kw &&
+      tg_conv_img_supported(d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->pad_t, d->pad_l))
+    return tg_conv_img_run(d->n, d->hin, d->cin, d->cout, d->epilogue, d->lrelu_alpha, x, wp, bias, y, s);
   if (d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 && d->pad_t == d->pad_l &&
       tg_conv_small_supported(d->n, d->hout, d->wout, d->kh, d->kw))
     return tg_conv_small_run(d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->pad_t, d->pad_l,
@@ -655,6 +661,11 @@ int tg_conv2d_bwd_data_mfma(const TgConvDesc* d0, const void* gy, const void* wp
       tg_conv_tile_supported(d->hout, d->wout, d->hin, d->win, d->kh, d->kw, d->pad_t, d->pad_l))
     return tg_conv_tile_run(d->n, d->hout, d->wout, d->cout, d->cin, d->kh, d->kh - 1 - d->pad_t, 0,
                             mask ? d->lrelu_alpha : 1.f, gy, wp, nullptr, gx, s, mask);
+  // backward-data = the same conv over gy with the rotated pack: in = (hout, wout, cout), out = (hin, win, cin), pad' = k-1-pad
+  if (d->algo != TG_ALGO_MFMA_V1 && d->kh == d->kw && !mask &&
+      tg_conv_img_supported(d->n, d->hout, d->wout, d->cout, d->hin, d->win, d->cin, d->kh, d->kh - 1 - d->pad_t,
+                            d->kw - 1 - d->pad_l))
+    return tg_conv_img_run(d->n, d->hout, d->cout, d->cin, 0, 1.f, gy, wp, nullptr, gx, s);
   if (d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 && d->pad_t == d->pad_l &&
       tg_conv_small_supported(d->n, d->hin, d->win, d->kh, d->kw))
     return tg_conv_small_run(d->n, d->hout, d->wout, d->cout, d->hin, d->win, d->cin, d->kh, d->kh - 1 - d->pad_t,
