@@ -203,14 +203,20 @@ int launch_img(const ImgGeom& g, const void* x, const void* wp, const float* bia
 
 }  // namespace
 
-// 3x3 SAME on square 8x8 / 4x4 maps with channel counts the fragment loads take whole (cin % 32: a 16-channel chunk per
-// wave and step; the 264-channel minibatch-stddev layer stays on conv_small).  TG_TUNE_CONV_IMG=0 switches it off (A/B).
+// 3x3 SAME on square 8x8 maps with channel counts the fragment loads take whole (cin % 32: a 16-channel chunk per wave
+// and step).  Measured against conv_small on one box, us conv_small / conv_img (gpurun_out r3j, forward = backward-data):
+// 256 -> 256: n 16 10.5 / 10.2, n 32 15.3 / 10.8, n 64 24.1 / 16.5; 512 -> 256: n 16 18.4 / 16.8 (dgrad 15.3 / 10.9), n 32
+// 26.6 / 18.0, n 64 42.5 / 34.2 (dgrad 46.8 / 30.2); bench step 857.7 -> 870.5 images/s (+1.5 %).  The 4x4 maps (kernel
+// instantiated: four images per workgroup) measured SLOWER, 9.7-10.0 / 10.6-10.9 us at every n -- 16 pixels per image
+// leave the staging nothing to amortise -- and stay on conv_small, like the 264-channel minibatch-stddev layer.
+// TG_TUNE_CONV_IMG=0 switches the kernel off, =2 also takes the 4x4 maps (A/B).
 bool tg_conv_img_supported(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l) {
   if (k != 3 || pad_t != 1 || pad_l != 1 || hin != hout || win != wout || hin != win) return false;
-  if (hin != 8 && hin != 4) return false;
+  const int mode = tg_tune("TG_TUNE_CONV_IMG", 1);
+  if (mode == 0 || (hin != 8 && !(hin == 4 && mode == 2))) return false;
   if (cin % 32 != 0 || cout % 32 != 0 || cin > 1024 || n < 1 || (cin & (cin - 1)) != 0) return false;      // cin / 8 a power of two
   if (hin == 8 && (size_t)100 * (cin * 2 + 16) > 160 * 1024) return false;
-  return tg_tune("TG_TUNE_CONV_IMG", 1) != 0;
+  return true;
 }
 
 int tg_conv_img_run(int n, int hw, int cin, int cout, int epilogue, float alpha, const void* x, const void* wp,
