@@ -324,6 +324,7 @@ def test_flash_attention_at_config4_shapes(n):
   o, lse = O.flash_attention_fwd_raw(qd.detach(), kd.detach(), vd.detach())
   ref_o, _ = N.attention_forward(h64(q), h64(k), h64(v))
   e = rel_l2(host(o[sel]), ref_o)
+  print('[flash c4 n%d] fwd %.2e' % (n, e))
   assert e < 8e-4, ('flash fwd', n, e)
   assert bool(torch.isfinite(o.float()).all()) and bool(torch.isfinite(lse).all())
   # first-order backward (no create_graph: tg_flash_attention_bwd)
@@ -331,6 +332,7 @@ def test_flash_attention_at_config4_shapes(n):
   gq, gk, gv = torch.autograd.grad(of, (qd, kd, vd), go.cuda())
   for got, ref, nm in zip((gq, gk, gv), N.attention_backward(h64(q), h64(k), h64(v), h64(go)), ('dq', 'dk', 'dv')):
     e = rel_l2(host(got[sel]), ref)
+    print('[flash c4 n%d] bwd %s %.2e' % (n, nm, e))
     assert e < 2e-3, ('flash bwd ' + nm, n, e)
     assert bool(torch.isfinite(got.float()).all())
   # second order: the gradient-penalty pattern (create_graph backward, then the backward of that)
@@ -343,6 +345,7 @@ def test_flash_attention_at_config4_shapes(n):
   ref = N.attention_backward_backward(h64(q), h64(k), h64(v), h64(go), h64(aq), h64(ak), h64(av))
   for got, want, nm in zip(adj, ref, ('adj q', 'adj k', 'adj v', 'adj dO')):
     e = rel_l2(host(got[sel]), want)
+    print('[flash c4 n%d] bwd_bwd %s %.2e' % (n, nm, e))
     assert e < 4e-3, ('flash bwd_bwd ' + nm, n, e)
     assert bool(torch.isfinite(got.float()).all())
 
