@@ -1403,10 +1403,12 @@ def test_config4_half_precision_flash_path_matches_composed_path_and_oracle():
         assert abs(terms[k] - want) < 5e-2 * abs(want) + 2e-2, (grp, name, k, terms[k], want)
       e, cos = agg(grads, rgrads)
       print('[config4 fp16] %s %s: gradients vs oracle rel-L2 %.3e cosine %.5f' % (grp, name, e, cos))
-      assert e < 0.2 and cos > 0.98, (grp, name, e, cos)
+      # measured (gpurun_out r3l): g 0.108 / 0.099 (flash / composed), cosine 0.994 / 0.995; d 0.1435 / 0.1433, cosine 0.9897
+      assert e < 0.25 and cos > 0.97, (grp, name, e, cos)
     e, cos = agg(flash[grp][1], composed[grp][1])
     print('[config4 fp16] %s: flash vs composed rel-L2 %.3e cosine %.5f' % (grp, e, cos))
-    assert e < 0.2 and cos > 0.98, (grp, e, cos)
+    # the two HIP paths are closer to each other than either is to the oracle: measured g 0.068, d 0.013
+    assert e < 0.15 and cos > 0.99, (grp, e, cos)
   tr.close()
 
 
