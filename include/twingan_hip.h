@@ -61,6 +61,20 @@ const char* tg_last_kernel(void);
  * them).  Returns the previous setting.  Do not flip it between capturing and replaying a hipGraph. */
 int tg_set_deterministic(int on);
 int tg_get_deterministic(void);
+/* Fixed-order ("ordered") forms of the sums whose plain entry points end in fp32 atomics: every workgroup writes its
+ * partial result to a row of `workspace` (fp32, workspace_floats long: 512 rows are enough for any size; fewer rows mean
+ * fewer workgroups) and one pass adds the rows in workgroup order -- the same bits on every run, at full-grid speed, in
+ * either mode and for every storage type.  twingan_amd/ops.py routes the bias gradients, the fromRGB / toRGB filter
+ * gradients and the loss sums through these when the deterministic mode is on.
+ *   tg_channel_sum_ordered:  out[c] (+)= sum over pixels of g[.., c]                (BiasAddGrad)
+ *   tg_sum_ordered:          out[0] (+)= scale * sum x   (y NULL)  or  scale * sum |x - y|
+ *   tg_pointwise_conv_bwd_weight_ordered: as tg_pointwise_conv_bwd_weight */
+int tg_channel_sum_ordered(const void* g, float* out, int64_t npix, int c, int accumulate, float* workspace,
+                           size_t workspace_floats, int dtype, void* stream);
+int tg_sum_ordered(const void* x, const void* y_or_null, float* out, int64_t numel, float scale, int accumulate,
+                   float* workspace, size_t workspace_floats, int dtype, void* stream);
+int tg_pointwise_conv_bwd_weight_ordered(const void* x, const void* gy, float* gw, int64_t npix, int cin, int cout,
+                                         int accumulate, float* workspace, size_t workspace_floats, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution: stride 1, kh,kw <= 4, arbitrary zero padding (pad_t/pad_l on the low side; the

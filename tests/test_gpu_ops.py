@@ -1245,3 +1245,67 @@ def test_conv_pool_sign_bits(ops, dtype, n, hw, cin, cout):
   with O.second_order():
     full, _ = O.conv2d(xd, wd, bd, 3, 'SAME', lrelu=True, pool=True, pool_only=True)
   assert full is not None
+
+
+# ------------------------------------------------------------------------- ordered (fixed-order) sums
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
+def test_ordered_sums_are_bit_reproducible_and_right(ops, dtype):
+  """tg_channel_sum_ordered / tg_sum_ordered / tg_pointwise_conv_bwd_weight_ordered (what deterministic mode routes the
+  bias gradients, loss sums and fromRGB / toRGB filter gradients through): per-workgroup partials in a workspace added in
+  workgroup order -- the same bits on every call (the atomic forms differ run to run in their last ulp at these sizes),
+  the float64 value to fp32 summation error, also with fewer workspace rows than workgroups wanted."""
+  import twingan_amd.ops as O
+  from twingan_amd import _lib
+  lib = _lib.load()
+  rng = np.random.RandomState(41)
+  n, hw, c = 6, 64, 32
+  g = rng.randn(n, hw, hw, c).astype(np.float32)
+  gd = to_dev(g, dtype)
+  gref = host(gd)
+  st = torch.cuda.current_stream().cuda_stream
+  dt = O._dt(gd)
+  outs = []
+  for rows in (512, 512, 7):
+    ws = torch.empty(rows * c, dtype=torch.float32, device='cuda')
+    out = torch.full((c,), 3.0, dtype=torch.float32, device='cuda')
+    O.call('tg_channel_sum_ordered', gd.data_ptr(), out.data_ptr(), n * hw * hw, c, 1, ws.data_ptr(), ws.numel(), dt, st)
+    outs.append(out.clone())
+    assert rel_l2(host(out) - 3.0, gref.sum(axis=(0, 1, 2))) < 2e-6
+  assert torch.equal(outs[0], outs[1])
+  # loss sums
+  a, b = gd, to_dev(rng.randn(n, hw, hw, c).astype(np.float32), dtype)
+  vals = []
+  for _ in range(2):
+    ws = torch.empty(512, dtype=torch.float32, device='cuda')
+    o1 = torch.empty(1, dtype=torch.float32, device='cuda')
+    o2 = torch.empty(1, dtype=torch.float32, device='cuda')
+    O.call('tg_sum_ordered', a.data_ptr(), None, o1.data_ptr(), a.numel(), 0.5, 0, ws.data_ptr(), ws.numel(), dt, st)
+    O.call('tg_sum_ordered', a.data_ptr(), b.data_ptr(), o2.data_ptr(), a.numel(), 2.0, 0, ws.data_ptr(), ws.numel(), dt, st)
+    vals.append((float(o1), float(o2)))
+  assert vals[0] == vals[1]
+  assert abs(vals[0][0] - 0.5 * host(a).sum()) < 1e-5 * np.abs(host(a)).sum()
+  assert abs(vals[0][1] - 2.0 * np.abs(host(a) - host(b)).sum()) < 1e-5 * 2.0 * np.abs(host(a) - host(b)).sum()
+  # fromRGB filter gradient (cin 3) and toRGB (cout 3)
+  if dtype != torch.float32:
+    x3 = to_dev(rng.rand(n, hw, hw, 3).astype(np.float32), dtype)
+    for xa, xb in ((x3, gd), (gd, x3)):
+      ca, cb = xa.shape[-1], xb.shape[-1]
+      res = []
+      for _ in range(2):
+        ws = torch.empty(256 * ca * cb, dtype=torch.float32, device='cuda')
+        gw = torch.zeros((ca, cb), dtype=torch.float32, device='cuda')
+        O.call('tg_pointwise_conv_bwd_weight_ordered', xa.data_ptr(), xb.data_ptr(), gw.data_ptr(), n * hw * hw, ca, cb, 1,
+               ws.data_ptr(), ws.numel(), dt, st)
+        res.append(gw.clone())
+      assert torch.equal(res[0], res[1])
+      want = host(xa).reshape(-1, ca).T @ host(xb).reshape(-1, cb)
+      assert rel_l2(host(res[0]), want) < 2e-6
+  # the host routes through them exactly when the mode is on
+  was = lib.tg_set_deterministic(1)
+  try:
+    assert O.deterministic()
+    s1, s2 = O.channel_sum_raw(gd), O.channel_sum_raw(gd)
+    assert torch.equal(s1, s2)
+  finally:
+    lib.tg_set_deterministic(was)
+  assert O.deterministic() == bool(was)

@@ -629,8 +629,9 @@ __global__ void norm_param_grads(const float* __restrict__ part, int chunks, flo
   }
 }
 
-// out[c] += sum_p g[p][c]
-template <typename T, int V>
+// out[c] += sum_p g[p][c].  PART: out[blockIdx.x][c] = this workgroup's sum instead (no atomics: tg_channel_sum_ordered adds
+// the workgroups' rows in workgroup order)
+template <typename T, int V, bool PART = false>
 __global__ void channel_sum_kernel(const T* __restrict__ g, float* __restrict__ out, int64_t npix, int c) {
   extern __shared__ float sh[];   // [c]
   const int cv = c / V;
@@ -651,7 +652,27 @@ __global__ void channel_sum_kernel(const T* __restrict__ g, float* __restrict__ 
   }
   wave_channel_accumulate<V>(a, sh, 0, cv, v, pl < lanes);
   __syncthreads();
-  for (int i = threadIdx.x; i < c; i += blockDim.x) atomicAdd(out + i, sh[i]);
+  if constexpr (PART) {
+    for (int i = threadIdx.x; i < c; i += blockDim.x) out[(size_t)blockIdx.x * c + i] = sh[i];
+  } else {
+    for (int i = threadIdx.x; i < c; i += blockDim.x) atomicAdd(out + i, sh[i]);
+  }
+}
+
+// out[i] (+)= scale * sum over rows b = 0 .. nb-1 of part[b][i], in row order (one thread per element: a fixed order)
+__global__ void ordered_rows_sum_kernel(const float* __restrict__ part, int nb, int c, float* __restrict__ out, int accumulate,
+                                        float scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};      // four interleaved chains (loads in flight), combined in a fixed order
+  int b = 0;
+  for (; b + 3 < nb; b += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] += part[(size_t)(b + u) * c + i];
+  }
+  for (; b < nb; ++b) a[0] += part[(size_t)b * c + i];
+  const float t = ((a[0] + a[1]) + (a[2] + a[3])) * scale;
+  out[i] = accumulate ? out[i] + t : t;
 }
 
 // gy = gz * (z > 0 ? 1 : alpha)  and  gbias[c] += sum_p gy[p][c]   (LeakyReLU backward fused with BiasAddGrad)
@@ -1056,6 +1077,29 @@ int tg_lrelu_pool_bwd_signs(const void* gz_pooled, const void* z_signs, void* gy
   TG_CHECK(dtype == TG_BF16 || dtype == TG_F16, TG_ENOSUP, "tg_lrelu_pool_bwd_signs: 16-bit storage only");
   return lrelu_bwd_launch("tg_lrelu_pool_bwd_signs", nullptr, gz_pooled, h * w, w, z_signs, gy, gbias, (int64_t)n * h * w, c,
                           alpha, accumulate, dtype, (hipStream_t)stream, true);
+}
+
+int tg_channel_sum_ordered(const void* g, float* out, int64_t npix, int c, int accumulate, float* ws, size_t ws_floats,
+                           int dtype, void* stream) {
+  TG_CHECK(g && out && ws && npix > 0 && c > 0, TG_EINVAL, "tg_channel_sum_ordered: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  int blocks = 0;
+  TG_DISPATCH_DTYPE(dtype, "tg_channel_sum_ordered", {
+    const int V = pick_v<T>(c);
+    TG_CHECK(c / V <= 256, TG_ENOSUP, "tg_channel_sum_ordered: c=%d not supported", c);
+    const int lanes = 256 / (c / V);
+    blocks = tg_grid_for(npix, lanes * 8, 512);
+    if ((size_t)blocks * c > ws_floats) blocks = (int)(ws_floats / c);
+    TG_CHECK(blocks >= 1, TG_EINVAL, "tg_channel_sum_ordered: workspace of %zu floats cannot hold one row of %d", ws_floats, c);
+    const size_t lds = (size_t)c * sizeof(float);
+    if (V == 1)
+      hipLaunchKernelGGL((channel_sum_kernel<T, 1, true>), dim3(blocks), dim3(256), lds, s, (const T*)g, ws, npix, c);
+    else
+      hipLaunchKernelGGL((channel_sum_kernel<T, Vec16<T>::N, true>), dim3(blocks), dim3(256), lds, s, (const T*)g, ws, npix, c);
+  });
+  hipLaunchKernelGGL(ordered_rows_sum_kernel, dim3((c + 255) / 256), dim3(256), 0, s, ws, blocks, c, out, accumulate, 1.f);
+  TG_LAUNCH_CHECK("tg_channel_sum_ordered");
+  return TG_OK;
 }
 
 int tg_channel_sum(const void* g, float* out, int64_t npix, int c, int accumulate, int dtype, void* stream) {

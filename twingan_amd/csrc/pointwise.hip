@@ -400,7 +400,8 @@ __global__ void pw_small_out_kernel(const T* __restrict__ x, const float* __rest
 }
 
 // out[s*os + c*oc] += sum_p small[p, s] * big[p, c];   thread = (pixel lane, V-vector of big channels)
-template <typename T, int V>
+// PART: out[blockIdx.x][s][c] = this workgroup's sums (dense [ns][cb] rows; pw_wgrad_final adds them in workgroup order)
+template <typename T, int V, bool PART = false>
 __global__ void pw_wgrad_kernel(const T* __restrict__ small, const T* __restrict__ big, float* __restrict__ out,
                                 int64_t npix, int ns, int cb, int os, int oc) {
   extern __shared__ float sacc[];   // [ns][cb], then one [ns][cb] slot per wave (pow2 channel-vector counts)
@@ -474,8 +475,21 @@ __global__ void pw_wgrad_kernel(const T* __restrict__ small, const T* __restrict
   __syncthreads();
   for (int i = threadIdx.x; i < ns * cb; i += blockDim.x) {
     const int s = i / cb, c = i - s * cb;
-    atomicAdd(out + (int64_t)s * os + (int64_t)c * oc, sacc[i]);
+    if constexpr (PART) out[(size_t)blockIdx.x * ns * cb + i] = sacc[i];
+    else atomicAdd(out + (int64_t)s * os + (int64_t)c * oc, sacc[i]);
   }
+}
+
+// gw[s*os + c*oc] (+)= sum over workgroups b of part[b][s][c], in workgroup order
+__global__ void pw_wgrad_final_kernel(const float* __restrict__ part, int nb, int ns, int cb, int os, int oc,
+                                      float* __restrict__ gw, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns * cb) return;
+  float t = 0.f;
+  for (int b = 0; b < nb; ++b) t += part[(size_t)b * ns * cb + i];
+  const int s = i / cb, c = i - s * cb;
+  float* dst = gw + (int64_t)s * os + (int64_t)c * oc;
+  *dst = accumulate ? *dst + t : t;
 }
 
 template <typename T>
@@ -522,6 +536,30 @@ int launch_pw_wgrad(const T* x, const T* gy, float* gw, int64_t npix, int cin, i
     hipLaunchKernelGGL((pw_wgrad_kernel<T, V>), dim3(blocks), dim3(threads), lds, s, small, big, gw, npix, ns, cb, os, oc);
   else
     hipLaunchKernelGGL((pw_wgrad_kernel<T, 1>), dim3(blocks), dim3(threads), lds, s, small, big, gw, npix, ns, cb, os, oc);
+  return TG_OK;
+}
+
+// the same filter gradient from per-workgroup partials in a caller workspace, added in workgroup order
+template <typename T>
+int launch_pw_wgrad_ordered(const T* x, const T* gy, float* gw, int64_t npix, int cin, int cout, int accumulate, float* ws,
+                            size_t ws_floats, hipStream_t s) {
+  constexpr int V = Vec16<T>::N;
+  const bool small_in = cin <= 4;
+  const T* small = small_in ? x : gy;
+  const T* big = small_in ? gy : x;
+  const int ns = small_in ? cin : cout, cb = small_in ? cout : cin;
+  const int os = small_in ? cout : 1, oc = small_in ? 1 : cout;
+  const int threads = 1024;
+  const size_t lds = (size_t)ns * cb * sizeof(float) * (1 + threads / 64);
+  int blocks = tg_grid_for(npix, 4096, 256);
+  if ((size_t)blocks * ns * cb > ws_floats) blocks = (int)(ws_floats / ((size_t)ns * cb));
+  if (blocks < 1) return TG_EINVAL;
+  if (cb % V == 0 && cb / V <= 256)
+    hipLaunchKernelGGL((pw_wgrad_kernel<T, V, true>), dim3(blocks), dim3(threads), lds, s, small, big, ws, npix, ns, cb, os, oc);
+  else
+    hipLaunchKernelGGL((pw_wgrad_kernel<T, 1, true>), dim3(blocks), dim3(threads), lds, s, small, big, ws, npix, ns, cb, os, oc);
+  hipLaunchKernelGGL(pw_wgrad_final_kernel, dim3((ns * cb + 255) / 256), dim3(256), 0, s, ws, blocks, ns, cb, os, oc, gw,
+                     accumulate);
   return TG_OK;
 }
 
@@ -730,6 +768,20 @@ int tg_pointwise_conv_bwd_weight(const void* x, const void* gy, float* gw, int64
     launch_pw_wgrad<T>((const T*)x, (const T*)gy, gw, npix, cin, cout, (hipStream_t)stream);
   });
   TG_LAUNCH_CHECK("tg_pointwise_conv_bwd_weight");
+  return TG_OK;
+}
+
+int tg_pointwise_conv_bwd_weight_ordered(const void* x, const void* gy, float* gw, int64_t npix, int cin, int cout,
+                                         int accumulate, float* ws, size_t ws_floats, int dtype, void* stream) {
+  TG_CHECK(x && gy && gw && ws && npix > 0 && cin > 0 && cout > 0, TG_EINVAL, "tg_pointwise_conv_bwd_weight_ordered: bad arguments");
+  TG_CHECK(cin <= 4 || cout <= 4, TG_ENOSUP, "tg_pointwise_conv_bwd_weight_ordered: one of cin/cout must be <= 4");
+  int rc = TG_OK;
+  TG_DISPATCH_DTYPE(dtype, "tg_pointwise_conv_bwd_weight_ordered", {
+    rc = launch_pw_wgrad_ordered<T>((const T*)x, (const T*)gy, gw, npix, cin, cout, accumulate, ws, ws_floats,
+                                    (hipStream_t)stream);
+  });
+  TG_CHECK(rc == TG_OK, TG_EINVAL, "tg_pointwise_conv_bwd_weight_ordered: workspace of %zu floats is too small", ws_floats);
+  TG_LAUNCH_CHECK("tg_pointwise_conv_bwd_weight_ordered");
   return TG_OK;
 }
 

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(1024) void mbstd_bwd_bwd_kernel(const T* __restrict
 // ------------------------------------------------------------------------------------------------
 // reductions
 // ------------------------------------------------------------------------------------------------
-template <typename T, int MODE>   // MODE 0: sum(x)  1: sum|x-y|
+template <typename T, int MODE, bool PART = false>   // MODE 0: sum(x)  1: sum|x-y|;  PART: out[blockIdx.x] = this workgroup's sum
 __global__ void sum_kernel(const T* __restrict__ x, const T* __restrict__ y, float* __restrict__ out, int64_t numel,
                            float scale) {
   __shared__ float red[8];
@@ -384,7 +384,19 @@ __global__ void sum_kernel(const T* __restrict__ x, const T* __restrict__ y, flo
   for (int64_t i = nvec * V + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride)
     acc += MODE == 0 ? ld(x + i) : fabsf(ld(x + i) - ld(y + i));
   const float tot = block_sum(acc, red);
-  if (threadIdx.x == 0) atomicAdd(out, tot * scale);
+  if (threadIdx.x == 0) {
+    if constexpr (PART) out[blockIdx.x] = tot;
+    else atomicAdd(out, tot * scale);
+  }
+}
+
+// out[0] (+)= scale * (part[0] + part[1] + ... in index order)
+__global__ void ordered_scalar_sum_kernel(const float* __restrict__ part, int n, float* __restrict__ out, float scale,
+                                          int accumulate) {
+  if (blockIdx.x || threadIdx.x) return;
+  float t = 0.f;
+  for (int i = 0; i < n; ++i) t += part[i];
+  out[0] = accumulate ? out[0] + t * scale : t * scale;
 }
 
 template <typename T>
@@ -665,6 +677,26 @@ int tg_abs_diff_sum(const void* a, const void* b, float* out, int64_t numel, flo
                        dim3(256), 0, s, (const T*)a, (const T*)b, out, numel, scale);
   });
   TG_LAUNCH_CHECK("tg_abs_diff_sum");
+  return TG_OK;
+}
+
+// The two sums above with per-workgroup partials in a caller workspace, added in workgroup order: the same value on
+// every run whatever the storage type and whatever the mode (the plain entry points end in one fp32 atomic per workgroup)
+int tg_sum_ordered(const void* x, const void* y_or_null, float* out, int64_t numel, float scale, int accumulate, float* ws,
+                   size_t ws_floats, int dtype, void* stream) {
+  TG_CHECK(x && out && ws && ws_floats >= 1 && numel > 0, TG_EINVAL, "tg_sum_ordered: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  int blocks = 0;
+  TG_DISPATCH_DTYPE(dtype, "tg_sum_ordered", {
+    blocks = tg_grid_for(numel / Vec16<T>::N + 1, 256, 512);
+    if ((size_t)blocks > ws_floats) blocks = (int)ws_floats;
+    if (y_or_null)
+      hipLaunchKernelGGL((sum_kernel<T, 1, true>), dim3(blocks), dim3(256), 0, s, (const T*)x, (const T*)y_or_null, ws, numel, 1.f);
+    else
+      hipLaunchKernelGGL((sum_kernel<T, 0, true>), dim3(blocks), dim3(256), 0, s, (const T*)x, (const T*)nullptr, ws, numel, 1.f);
+  });
+  hipLaunchKernelGGL(ordered_scalar_sum_kernel, dim3(1), dim3(64), 0, s, ws, blocks, out, scale, accumulate);
+  TG_LAUNCH_CHECK("tg_sum_ordered");
   return TG_OK;
 }
 

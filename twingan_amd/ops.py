@@ -425,8 +425,11 @@ def lrelu_pool_bwd_signs(gzp, signs, alpha, bias, want_bias):
   gb = None
   if want_bias:
     gb = sink if sink is not None else torch.empty(c, dtype=torch.float32, device=gzp.device)
-  call('tg_lrelu_pool_bwd_signs', _p(gzp), _p(signs), _p(g), _p(gb), n, h, w, c, alpha, 1 if sink is not None else 0,
-       _dt(gzp), _stream(), work=('lrelu_pool_bwd' + _shape_tag(g), 0, _nb(gzp, signs, g)))
+  fused_bias = want_bias and not deterministic()
+  call('tg_lrelu_pool_bwd_signs', _p(gzp), _p(signs), _p(g), _p(gb if fused_bias else None), n, h, w, c, alpha,
+       1 if sink is not None else 0, _dt(gzp), _stream(), work=('lrelu_pool_bwd' + _shape_tag(g), 0, _nb(gzp, signs, g)))
+  if want_bias and not fused_bias:
+    _channel_sum_into(g, gb, sink is not None)
   return g, (None if sink is not None else gb)
 
 
@@ -537,12 +540,32 @@ def _weight_grad(x, g, spec, w, bias_sink=None):
   return ConvBwdWeightFn.apply(x, g, spec)
 
 
+def deterministic():
+  """Is the library's deterministic mode on (TG_DETERMINISTIC=1 / tg_set_deterministic)?  The host then routes the sums
+  that end in fp32 atomics -- bias gradients, fromRGB / toRGB filter gradients, loss sums -- through their ORDERED forms
+  (per-workgroup partials in a workspace, added in workgroup order: tg_*_ordered) instead of the fused / atomic ones."""
+  return bool(_lib.load().tg_get_deterministic())
+
+
+_ORDERED_ROWS = 512      # workgroups whose partial rows the workspace can hold
+
+
+def _channel_sum_into(g, out, accumulate):
+  """out[c] (+)= sum over pixels of g: ordered two-stage sum in deterministic mode, tg_channel_sum otherwise."""
+  c = g.shape[-1]
+  if deterministic():
+    ws = torch.empty(_ORDERED_ROWS * c, dtype=torch.float32, device=g.device)
+    call('tg_channel_sum_ordered', _p(g), _p(out), g.numel() // c, c, 1 if accumulate else 0, _p(ws), ws.numel(), _dt(g),
+         _stream(), work=('channel_sum' + _shape_tag(g), 0, _nb(g)))
+  else:
+    call('tg_channel_sum', _p(g), _p(out), g.numel() // c, c, 1 if accumulate else 0, _dt(g), _stream(),
+         work=('channel_sum' + _shape_tag(g), 0, _nb(g)))
+
+
 def _bias_grad(g, bias):
   sink = GradSink.get(bias)
   if sink is not None:
-    c = g.shape[-1]
-    call('tg_channel_sum', _p(g), _p(sink), g.numel() // c, c, 1, _dt(g), _stream(),
-         work=('channel_sum' + _shape_tag(g), 0, _nb(g)))
+    _channel_sum_into(g, sink, True)
     return None
   return ChannelSumFn.apply(g)
 
@@ -557,8 +580,12 @@ def lrelu_pool_bwd(gz, gzp, z, alpha, bias, want_bias):
   gb = None
   if want_bias:
     gb = sink if sink is not None else torch.empty(c, dtype=torch.float32, device=z.device)
-  call('tg_lrelu_pool_bwd', _p(gz), _p(gzp), _p(z), _p(g), _p(gb), n, h, w, c, alpha, 1 if sink is not None else 0,
-       _dt(z), _stream(), work=('lrelu_pool_bwd' + _shape_tag(z), 0, int((2 + (gz is not None) + 0.25 * (gzp is not None)) * z.numel()) * _esize(z)))
+  fused_bias = want_bias and not deterministic()      # deterministic mode: the bias sum is its own ordered two-stage pass
+  call('tg_lrelu_pool_bwd', _p(gz), _p(gzp), _p(z), _p(g), _p(gb if fused_bias else None), n, h, w, c, alpha,
+       1 if sink is not None else 0, _dt(z), _stream(),
+       work=('lrelu_pool_bwd' + _shape_tag(z), 0, int((2 + (gz is not None) + 0.25 * (gzp is not None)) * z.numel()) * _esize(z)))
+  if want_bias and not fused_bias:
+    _channel_sum_into(g, gb, sink is not None)
   return g, (None if sink is not None else gb)
 
 
@@ -574,8 +601,7 @@ def channel_sum_raw(g):
   _chk(g)
   c = g.shape[-1]
   out = torch.empty(c, dtype=torch.float32, device=g.device)
-  call('tg_channel_sum', _p(g), _p(out), g.numel() // c, c, 0, _dt(g), _stream(),
-       work=('channel_sum' + _shape_tag(g), 0, _nb(g)))
+  _channel_sum_into(g, out, False)
   return out
 
 
@@ -635,7 +661,7 @@ def _conv_backward(ctx, gz, gzp=None):
     gzp = None
   if premasked:
     g = gz
-    if need_b and need_w and GradSink.get(bias) is not None and GradSink.get(w) is not None:
+    if need_b and need_w and GradSink.get(bias) is not None and GradSink.get(w) is not None and not deterministic():
       bias_sink = GradSink.get(bias)      # the filter-gradient kernel sums g over pixels as well
       need_b = False
   elif pooled_lrelu is not None:
@@ -925,14 +951,25 @@ class PointwiseConvFn(torch.autograd.Function):
       a, b = (g, x) if ctx.wt else (x, g)
       sink = GradSink.get(w)
       if sink is not None:
-        ca, cb = a.shape[-1], b.shape[-1]
-        call('tg_pointwise_conv_bwd_weight', _p(a), _p(b), _p(sink), a.numel() // ca, ca, cb, 1, _dt(a), _stream(),
-             work=('pw_wgrad:c%d>%d:px%d' % (ca, cb, a.numel() // ca), 2 * a.numel() * cb, _nb(a, b)))
+        _pw_wgrad_into(a, b, sink, True)
       else:
         gw = PointwiseWgradFn.apply(a, b)
     if need_b:
       gb = _bias_grad(g, bias)
     return gx, gw, gb, None, None, None
+
+
+def _pw_wgrad_into(a, b, out, accumulate):
+  """out[ca, cb] (+)= a^T b over pixels (one of ca, cb <= 4); the ordered two-stage form in deterministic mode."""
+  ca, cb = a.shape[-1], b.shape[-1]
+  work = ('pw_wgrad:c%d>%d:px%d' % (ca, cb, a.numel() // ca), 2 * a.numel() * cb, _nb(a, b))
+  if deterministic():
+    ws = torch.empty(256 * ca * cb, dtype=torch.float32, device=a.device)
+    call('tg_pointwise_conv_bwd_weight_ordered', _p(a), _p(b), _p(out), a.numel() // ca, ca, cb, 1 if accumulate else 0,
+         _p(ws), ws.numel(), _dt(a), _stream(), work=work)
+  else:
+    call('tg_pointwise_conv_bwd_weight', _p(a), _p(b), _p(out), a.numel() // ca, ca, cb, 1 if accumulate else 0, _dt(a),
+         _stream(), work=work)
 
 
 class PointwiseWgradFn(torch.autograd.Function):
@@ -943,8 +980,7 @@ class PointwiseWgradFn(torch.autograd.Function):
     _chk(a, b)
     ca, cb = a.shape[-1], b.shape[-1]
     out = torch.empty((ca, cb), dtype=torch.float32, device=a.device)
-    call('tg_pointwise_conv_bwd_weight', _p(a), _p(b), _p(out), a.numel() // ca, ca, cb, 0, _dt(a), _stream(),
-         work=('pw_wgrad:c%d>%d:px%d' % (ca, cb, a.numel() // ca), 2 * a.numel() * cb, _nb(a, b)))
+    _pw_wgrad_into(a, b, out, False)
     return out
 
   @staticmethod
@@ -1848,6 +1884,19 @@ def fully_connected(x, w, b):
 # ------------------------------------------------------------------------------------------------
 # losses (twingan.py:464,502; image_generation.py:333,350,431-436)
 # ------------------------------------------------------------------------------------------------
+def _scalar_sum_into(x, y, out, scale):
+  """out[0] = scale * sum(x) (y None) or scale * sum|x - y|; the ordered two-stage form in deterministic mode."""
+  tag = ('abs_diff_sum' if y is not None else 'sum') + ':numel%d' % x.numel()
+  if deterministic():
+    ws = torch.empty(_ORDERED_ROWS, dtype=torch.float32, device=x.device)
+    call('tg_sum_ordered', _p(x), _p(y), _p(out), x.numel(), scale, 0, _p(ws), ws.numel(), _dt(x), _stream(),
+         work=(tag, 0, _nb(x, y)))
+  elif y is not None:
+    call('tg_abs_diff_sum', _p(x), _p(y), _p(out), x.numel(), scale, 0, _dt(x), _stream(), work=(tag, 0, _nb(x, y)))
+  else:
+    call('tg_sum', _p(x), _p(out), x.numel(), scale, 0, _dt(x), _stream(), work=(tag, 0, _nb(x)))
+
+
 class MeanFn(torch.autograd.Function):
   """mean(x) * weight -> fp32 [1]."""
 
@@ -1855,8 +1904,7 @@ class MeanFn(torch.autograd.Function):
   def forward(ctx, x, weight):
     _chk(x)
     out = torch.empty(1, dtype=torch.float32, device=x.device)
-    call('tg_sum', _p(x), _p(out), x.numel(), weight / x.numel(), 0, _dt(x), _stream(),
-         work=('sum:numel%d' % x.numel(), 0, _nb(x)))
+    _scalar_sum_into(x, None, out, weight / x.numel())
     ctx.meta = (x.shape, x.dtype, weight / x.numel())
     return out
 
@@ -1874,8 +1922,7 @@ class AbsDiffMeanFn(torch.autograd.Function):
   def forward(ctx, a, b, weight):
     _chk(a, b)
     out = torch.empty(1, dtype=torch.float32, device=a.device)
-    call('tg_abs_diff_sum', _p(a), _p(b), _p(out), a.numel(), weight / a.numel(), 0, _dt(a), _stream(),
-         work=('abs_diff_sum:numel%d' % a.numel(), 0, _nb(a, b)))
+    _scalar_sum_into(a, b, out, weight / a.numel())
     ctx.k = weight / a.numel()
     ctx.save_for_backward(a, b)
     return out
