@@ -166,6 +166,24 @@ class PackCache:
     return len(keys)
 
 
+# Auxiliary stream of a backward pass (Trainer): the library enqueues the slab reduction of every filter gradient that
+# accumulates into a gradient sink there (tg_set_aux_stream), off the critical path; the workspaces those launches read
+# are kept alive for that stream (_keep_for_aux)
+AUX_STREAM = None
+
+
+def set_aux_stream(stream):
+  """``stream``: a torch.cuda.Stream, or None to switch the auxiliary stream off."""
+  global AUX_STREAM
+  AUX_STREAM = stream
+  call('tg_set_aux_stream', None if stream is None else stream.cuda_stream)
+
+
+def _keep_for_aux(ws, accumulate):
+  if AUX_STREAM is not None and accumulate and ws is not None:
+    ws.record_stream(AUX_STREAM)
+
+
 class GradSink:
   """Fused gradient accumulation: a parameter registered here has its gradient ADDED straight into the
   registered buffer (its slice of the optimiser group's flat fp32 gradient, params.ParamStore) by the
@@ -499,6 +517,7 @@ def conv_bwd_weight_raw(x, gy, spec, out=None, gbias=None):
   else:
     call('tg_conv2d_bwd_weight', ctypes.byref(d), _p(x), _p(gy), _p(gw), 0 if out is None else 1, _p(ws), nbytes, _stream(),
          work=lambda: _conv_work(d, 'wgrad', _esize(x)))
+  _keep_for_aux(ws, out is not None)
   return gw
 
 
@@ -526,6 +545,7 @@ def conv_bwd_weight2_raw(xa, gya, xb, gyb, spec, out, gbias=None, bias_segs=3):
   else:
     call('tg_conv2d_bwd_weight2', ctypes.byref(d), nb, _p(xa), _p(gya), _p(xb), _p(gyb), _p(out), 1, _p(ws), nbytes,
          _stream(), work=work)
+  _keep_for_aux(ws, True)
   return True
 
 
@@ -1289,6 +1309,7 @@ class UpcatConvFn(torch.autograd.Function):
            n, H, W, c0, c1, cout, gsz, pk, _dt(gy), _stream(),
            work=lambda: ('wgrad:upcat:k3:c%d+%d>%d:hw%d:n%d' % (c0, c1, cout, H, n), 2 * n * H * W * cout * 9 * (c0 + c1),
                          2 * (x0.numel() + x1.numel() + gy.numel()) + 4 * w.numel()))
+      _keep_for_aux(ws, sink is not None)
       if sink is not None:
         gw = None
     return g0, g1, gw, None, None, None

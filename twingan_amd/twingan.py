@@ -368,6 +368,15 @@ class Trainer:
     self._graphs = self._static = None
     self.store.close()
 
+  def _aux_stream(self):
+    """The stream the filter gradients' slab reductions run on during a backward pass (TG_WGRAD_AUX=0: none -- they stay
+    on the launch stream, round-2 behaviour, for A/Bs)."""
+    if self.device.type != 'cuda' or os.environ.get('TG_WGRAD_AUX', '1') == '0':
+      return None
+    if getattr(self, '_aux', None) is None:
+      self._aux = torch.cuda.Stream(device=self.device)
+    return self._aux
+
   # ---- optimiser --------------------------------------------------------------------------------
   def _nseg(self, group):
     return len(self.store.phase_bounds[group]) if self.split else 1
@@ -429,6 +438,10 @@ class Trainer:
       out = (loss.detach(), {k: v.detach() for k, v in terms.items()})
       scaled = loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)       # model_deploy.py:265-268,308-313
       ops.GradSink.pair = True
+      aux = self._aux_stream()
+      if aux is not None:      # the slab reductions of the filter gradients leave the backward's critical path
+        aux.wait_stream(torch.cuda.current_stream(self.device))      # ... after the zero fill of the gradient buffers
+        ops.set_aux_stream(aux)
       for seg in range(nseg):
         if seg == 0:
           scaled.backward()
@@ -439,11 +452,15 @@ class Trainer:
         last = seg == nseg - 1
         # filter gradients still waiting for a pair: issue those this segment completes, keep the others
         ops.GradSink.flush(None if last else (lambda ptr, seg=seg: self._ptr_phase.get(ptr, 0) <= seg))
+        if aux is not None:      # the segment's gradients are complete only once their reductions are
+          torch.cuda.current_stream(self.device).wait_stream(aux)
         if last:
           pggan.end_run(self.P)
         yield seg, out
     finally:
       ops.GradSink.pair = False
+      if ops.AUX_STREAM is not None:
+        ops.set_aux_stream(None)
       if nseg > 1:
         ops.Cuts.end()
 
