@@ -826,15 +826,16 @@ def layers_convolution(inputs, num_outputs, kernel_size, stride=1, padding='SAME
     inputs = convert_to_tensor(inputs)
     kh, kw = _two(kernel_size)
     cin = int(inputs.shape[-1])
-    w = core.get_variable('weights', [kh, kw, cin, int(num_outputs)], inputs.dtype.base_dtype,
-                          weights_initializer or core.glorot_uniform_initializer(), trainable=trainable,
-                          collections=get_variable_collections(variables_collections, 'weights'))
+    # contrib's layers create every variable through _build_variable_getter -> slim's model_variable
+    w = model_variable('weights', [kh, kw, cin, int(num_outputs)], inputs.dtype.base_dtype,
+                       weights_initializer or core.glorot_uniform_initializer(), trainable=trainable,
+                       collections=get_variable_collections(variables_collections, 'weights'))
     _apply_regularizer(weights_regularizer, w)
     sh, sw = _two(stride)
     out = nn_conv2d(inputs, w, [1, sh, sw, 1], padding)
     if normalizer_fn is None and biases_initializer is not None:
-      b = core.get_variable('biases', [int(num_outputs)], inputs.dtype.base_dtype, biases_initializer,
-                            trainable=trainable, collections=get_variable_collections(variables_collections, 'biases'))
+      b = model_variable('biases', [int(num_outputs)], inputs.dtype.base_dtype, biases_initializer,
+                         trainable=trainable, collections=get_variable_collections(variables_collections, 'biases'))
       out = nn_bias_add(out, b)
     if normalizer_fn is not None:
       out = normalizer_fn(out, **(normalizer_params or {}))
@@ -855,14 +856,14 @@ def layers_fully_connected(inputs, num_outputs, activation_fn='relu', normalizer
   with core.variable_scope(scope, 'fully_connected', [inputs], reuse=reuse) as sc:
     inputs = convert_to_tensor(inputs)
     cin = int(inputs.shape[-1])
-    w = core.get_variable('weights', [cin, int(num_outputs)], inputs.dtype.base_dtype,
-                          weights_initializer or core.glorot_uniform_initializer(), trainable=trainable,
-                          collections=get_variable_collections(variables_collections, 'weights'))
+    w = model_variable('weights', [cin, int(num_outputs)], inputs.dtype.base_dtype,
+                       weights_initializer or core.glorot_uniform_initializer(), trainable=trainable,
+                       collections=get_variable_collections(variables_collections, 'weights'))
     _apply_regularizer(weights_regularizer, w)
     out = wrap(torch.matmul(raw(inputs), raw(w)), inputs)
     if normalizer_fn is None and biases_initializer is not None:
-      b = core.get_variable('biases', [int(num_outputs)], inputs.dtype.base_dtype, biases_initializer,
-                            trainable=trainable, collections=get_variable_collections(variables_collections, 'biases'))
+      b = model_variable('biases', [int(num_outputs)], inputs.dtype.base_dtype, biases_initializer,
+                         trainable=trainable, collections=get_variable_collections(variables_collections, 'biases'))
       out = nn_bias_add(out, b)
     if normalizer_fn is not None:
       out = normalizer_fn(out, **(normalizer_params or {}))
@@ -871,6 +872,96 @@ def layers_fully_connected(inputs, num_outputs, activation_fn='relu', normalizer
     if activation_fn is not None:
       out = activation_fn(out)
     return out
+
+
+@add_arg_scope
+def layers_layer_norm(inputs, center=True, scale=True, activation_fn=None, reuse=None, variables_collections=None,
+                      outputs_collections=None, trainable=True, begin_norm_axis=1, begin_params_axis=-1, scope=None):
+  """tf.contrib.layers.layer_norm as TF 1.8 ships it (contrib/layers/python/layers/layers.py), restated: `beta` (zeros)
+  and `gamma` (ones) model variables of shape inputs.shape[begin_params_axis:] under variable_scope(scope, 'LayerNorm');
+  moments over axes [begin_norm_axis, rank) kept as dims; tf.nn.batch_normalization with variance_epsilon 1e-12."""
+  with core.variable_scope(scope, 'LayerNorm', [inputs], reuse=reuse):
+    inputs = convert_to_tensor(inputs)
+    rank = raw(inputs).dim()
+    if begin_norm_axis < 0:
+      begin_norm_axis += rank
+    params_shape = [int(d) for d in inputs.shape[begin_params_axis:]]
+    dt = inputs.dtype.base_dtype
+    beta = model_variable('beta', params_shape, dt, core.zeros_initializer(), trainable=trainable) if center else None
+    gamma = model_variable('gamma', params_shape, dt, core.ones_initializer(), trainable=trainable) if scale else None
+    mean, variance = nn_moments(inputs, list(range(begin_norm_axis, rank)), keep_dims=True)
+    out = nn_batch_normalization(inputs, mean, variance, beta, gamma, 1e-12)
+    return activation_fn(out) if activation_fn is not None else out
+
+
+@add_arg_scope
+def layers_batch_norm(inputs, decay=0.999, center=True, scale=False, epsilon=0.001, activation_fn=None,
+                      param_initializers=None, param_regularizers=None, updates_collections='update_ops',
+                      is_training=True, reuse=None, variables_collections=None, outputs_collections=None, trainable=True,
+                      batch_weights=None, fused=None, data_format='NHWC', zero_debias_moving_mean=False, scope=None,
+                      renorm=False, renorm_clipping=None, renorm_decay=0.99, adjustment=None):
+  """tf.contrib.layers.batch_norm on the route TF 1.8 takes with renorm=True (contrib's layers.py hands a call without
+  batch_weights / zero-debias and with the default updates collection to the core tf.layers.BatchNormalization, whose
+  non-fused call() is python/layers/normalization.py), restated.  Variables under variable_scope(scope, 'BatchNorm'):
+  gamma, beta, moving_mean, moving_variance and, with renorm, renorm_mean, renorm_mean_weight (scalar), renorm_stddev,
+  renorm_stddev_weight (scalar), all zero-initialised but gamma / moving_variance.  Training: batch moments; with renorm
+  r = clip(sigma / mixed_sigma), d = clip((mu - mixed_mu) / mixed_sigma) against the pre-update averages 'as if they were
+  initialised with this batch' (mixed_x = renorm_x + (1 - renorm_x_weight) * batch_x), stop-gradient, folded into scale /
+  offset; renorm averages and their weights decay with renorm_decay, the moving mean / variance follow the de-biased
+  renorm values with `decay`.  Inference: the moving statistics, r = 1, d = 0."""
+  assert batch_weights is None and not zero_debias_moving_mean and adjustment is None and data_format == 'NHWC'
+  assert not param_initializers and not param_regularizers and updates_collections == 'update_ops'
+  with core.variable_scope(scope, 'BatchNorm', [inputs], reuse=reuse):
+    x = convert_to_tensor(inputs)
+    c, dt = int(x.shape[-1]), x.dtype.base_dtype
+
+    def var(name, shape, init, train=False):
+      return model_variable(name, shape, dt, init, trainable=train and trainable)
+
+    gamma = var('gamma', [c], core.ones_initializer(), True) if scale else None
+    beta = var('beta', [c], core.zeros_initializer(), True) if center else None
+    moving_mean = var('moving_mean', [c], core.zeros_initializer())
+    moving_variance = var('moving_variance', [c], core.ones_initializer())
+    if renorm:
+      unknown = set(renorm_clipping or {}) - {'rmax', 'rmin', 'dmax'}
+      if unknown:
+        raise ValueError('renorm_clipping contains keys not in rmax / rmin / dmax: %s' % sorted(unknown))
+      r_mean, r_mean_w = var('renorm_mean', [c], core.zeros_initializer()), var('renorm_mean_weight', [], core.zeros_initializer())
+      r_std, r_std_w = var('renorm_stddev', [c], core.zeros_initializer()), var('renorm_stddev_weight', [], core.zeros_initializer())
+    training = constant_value(is_training)
+    training = bool(raw(is_training).item()) if training is None else bool(training)
+    sc_t = raw(gamma) if gamma is not None else None
+    off_t = raw(beta) if beta is not None else None
+    if training:
+      mean, variance = nn_moments(x, [0, 1, 2][:raw(x).dim() - 1])
+      new_mean, new_variance = raw(mean).detach(), raw(variance).detach()
+      if renorm:
+        clip = {k: raw(v) if isinstance(v, Tensor) else v for k, v in (renorm_clipping or {}).items()}
+        with torch.no_grad():
+          mu, sigma = raw(mean).detach(), torch.sqrt(raw(variance).detach() + epsilon)
+          mixed_mu = r_mean.t + (1.0 - r_mean_w.t) * mu
+          mixed_sigma = r_std.t + (1.0 - r_std_w.t) * sigma
+          r, d = sigma / mixed_sigma, (mu - mixed_mu) / mixed_sigma
+          if clip.get('rmin') is not None:
+            r = torch.maximum(r, torch.as_tensor(clip['rmin'], dtype=r.dtype))
+          if clip.get('rmax') is not None:
+            r = torch.minimum(r, torch.as_tensor(clip['rmax'], dtype=r.dtype))
+          if clip.get('dmax') is not None:
+            dm = torch.as_tensor(clip['dmax'], dtype=d.dtype)
+            d = torch.minimum(torch.maximum(d, -dm), dm)
+          one = torch.ones((), dtype=mu.dtype)
+          new_mean = raw(assign_moving_average(r_mean, mu, renorm_decay, False)) / raw(assign_moving_average(r_mean_w, one, renorm_decay, False))
+          new_std = raw(assign_moving_average(r_std, sigma, renorm_decay, False)) / raw(assign_moving_average(r_std_w, one, renorm_decay, False))
+          new_variance = new_std * new_std - epsilon
+        off_t = d * (sc_t if sc_t is not None else 1.0) + (off_t if off_t is not None else 0.0)
+        sc_t = r * (sc_t if sc_t is not None else 1.0)
+      assign_moving_average(moving_mean, new_mean, decay, False)
+      assign_moving_average(moving_variance, new_variance, decay, False)
+    else:
+      mean, variance = moving_mean, moving_variance
+    out = nn_batch_normalization(x, mean, variance, None if off_t is None else wrap(off_t, x),
+                                 None if sc_t is None else wrap(sc_t, x), epsilon)
+    return activation_fn(out) if activation_fn is not None else out
 
 
 def nn_relu(features, name=None):
@@ -1082,7 +1173,7 @@ def build_modules():
   layers_impl = _module(
     'tensorflow.contrib.layers.python.layers.layers', conv2d=conv2d, convolution=conv2d, convolution2d=conv2d,
     fully_connected=fully_connected, conv2d_transpose=_unsupported('layers.conv2d_transpose'),
-    batch_norm=_unsupported('layers.batch_norm'), layer_norm=_unsupported('layers.layer_norm'),
+    batch_norm=layers_batch_norm, layer_norm=layers_layer_norm,
     instance_norm=_unsupported('layers.instance_norm'), l2_regularizer=l2_regularizer,
     xavier_initializer=core.glorot_uniform_initializer, utils=None,
     _build_variable_getter=_build_variable_getter, _add_variable_to_collections=lambda *a, **k: None,

@@ -82,7 +82,10 @@ def max_stage_of(hw):
 # ------------------------------------------------------------------------------------------------
 # parameter construction (names: SURVEY.md Appendix C; init: nets/pggan_utils.py:56,93, pggan.py:364-368)
 # ------------------------------------------------------------------------------------------------
-NORM_SCOPE = {'instance_norm': 'InstanceNorm', 'batch_norm': 'BatchNorm', 'batch_renorm': 'BatchNorm'}      # libs/instance_norm.py:66, batch_norm.py:80
+NATIVE = '@native'  # tf.contrib's own layers, called with scope=<postfix> (nets/pggan_utils.py:175-197): '<conv>/_s/gamma'
+NORM_SCOPE = {'instance_norm': 'InstanceNorm', 'batch_norm': 'BatchNorm', 'batch_renorm': 'BatchNorm',      # libs/instance_norm.py:66, batch_norm.py:80
+              'batch_renorm_native': NATIVE, 'layer_norm_native': NATIVE}
+LN_EPS = 1e-12      # tf.contrib.layers.layer_norm's variance_epsilon (TF 1.8 contrib/layers/python/layers/layers.py)
 BN_EPS = 1e-3       # libs/batch_norm.py:48 (max(epsilon, 1.001e-5), :464-468)
 BN_DECAY = 0.999    # libs/batch_norm.py:45
 
@@ -93,6 +96,19 @@ def _pf(domain):
   return '_' + domain if domain else ''
 
 
+def norm_var(scope, norm_scope, name, domain):
+  """Name of a normaliser variable of the conv at ``scope``.  The reference's own layers (libs/instance_norm.py:66,
+  libs/batch_norm.py:80,130-196) open '<conv>/InstanceNorm' | '<conv>/BatchNorm' and append the domain postfix to the
+  VARIABLE name; tf.contrib's layers, which 'batch_renorm_native' / 'layer_norm_native' call with scope=<postfix>
+  (nets/pggan_utils.py:175-197), have no postfix argument: the postfix IS the scope, the variables keep contrib's plain
+  names ('<conv>/_s/gamma').  The plain PGGAN trainer's postfix '' would make that scope the empty string."""
+  if norm_scope == NATIVE:
+    if not domain:
+      raise NotImplementedError("a native normaliser with an empty postfix opens variable_scope(''): not restated")
+    return '%s/%s/%s' % (scope, _pf(domain), name)
+  return '%s/%s/%s%s' % (scope, norm_scope, name, _pf(domain))
+
+
 def _conv_p(P, g, scope, k, cin, cout, norm_domains, bias, dtype, std=0.02, norm_scope='InstanceNorm'):
   if std == 'he':                    # test-only: O(1) activations so parity errors are visible
     std = math.sqrt(2.0 / (k * k * cin))
@@ -100,8 +116,8 @@ def _conv_p(P, g, scope, k, cin, cout, norm_domains, bias, dtype, std=0.02, norm
   if bias:
     P[scope + '/biases'] = torch.zeros(cout, dtype=dtype)
   for d in norm_domains:
-    P['%s/%s/gamma%s' % (scope, norm_scope, _pf(d))] = torch.ones(cout, dtype=dtype)
-    P['%s/%s/beta%s' % (scope, norm_scope, _pf(d))] = torch.zeros(cout, dtype=dtype)
+    P[norm_var(scope, norm_scope, 'gamma', d)] = torch.ones(cout, dtype=dtype)
+    P[norm_var(scope, norm_scope, 'beta', d)] = torch.zeros(cout, dtype=dtype)
 
 
 def encoder_param_specs(top, hw, max_ch, growing=False):
@@ -553,6 +569,26 @@ def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=Tru
       gamma, beta = P[scope + '/BatchNorm/gamma' + _pf(domain)], P[scope + '/BatchNorm/beta' + _pf(domain)]
     y = batch_renorm_train(y, gamma, beta, cfg.bn_state, scope + '/BatchNorm/', _pf(domain),
                            renorm_clipping(cfg.global_step))
+  elif cfg.norm == 'batch_renorm_native':
+    # tf.contrib.layers.batch_norm(decay=0.99, renorm=True, renorm_clipping=..., scope=<postfix>) (nets/pggan_utils.py:
+    # 175-188) -> tf.layers.BatchNormalization, non-fused: the arithmetic libs/batch_norm.py says it was copied from
+    # (its docstring, :64-66), without the conditional layer; variables '<conv>/_s/{gamma, beta, moving_*, renorm_*}'
+    assert cond is None, 'Tensorflow implementation does not support `conditional_layer`.'      # pggan_utils.py:177
+    pre = '%s/%s/' % (scope, _pf(domain))
+    if not domain:
+      raise NotImplementedError("a native normaliser with an empty postfix opens variable_scope(''): not restated")
+    if cfg.is_training:
+      y = batch_renorm_train(y, P[pre + 'gamma'], P[pre + 'beta'], cfg.bn_state, pre, '', renorm_clipping(cfg.global_step))
+    else:
+      y = batch_norm_inference(y, P[pre + 'gamma'], P[pre + 'beta'], cfg.bn_state or {}, pre, '')
+  elif cfg.norm == 'layer_norm_native':
+    # tf.contrib.layers.layer_norm(center, scale, scope=<postfix>) (nets/pggan_utils.py:189-197), TF 1.8: moments over
+    # axes [1, 2, 3] (begin_norm_axis=1) of each image, gamma / beta over the last axis (begin_params_axis=-1),
+    # tf.nn.batch_normalization with variance_epsilon 1e-12
+    assert cond is None, 'Tensorflow implementation does not support `conditional_layer`.'      # pggan_utils.py:191
+    mean = y.mean(dim=(1, 2, 3), keepdim=True)
+    var = ((y - mean) ** 2).mean(dim=(1, 2, 3), keepdim=True)
+    y = (y - mean) * torch.rsqrt(var + LN_EPS) * P[norm_var(scope, NATIVE, 'gamma', domain)] + P[norm_var(scope, NATIVE, 'beta', domain)]
   elif cfg.norm in ('none', None):      # nets/pggan_utils.py:198-200: normalizer_fn None -> slim's conv2d adds its bias
     y = y + P[scope + '/biases']
   else:

@@ -676,18 +676,21 @@ def test_no_normaliser_generator_matches_oracle(precision):
     _grads_close(tr, Pref, tr.store.names('g'), 0.5, 'generator(no normaliser, bf16)', min_cos=0.9)
 
 
-@pytest.mark.parametrize('global_step', [0, 25000])
-def test_batch_renorm_generator_matches_oracle(global_step):
+@pytest.mark.parametrize('norm,global_step', [('batch_renorm', 0), ('batch_renorm', 25000), ('batch_renorm_native', 0),
+                                              ('batch_renorm_native', 25000)])
+def test_batch_renorm_generator_matches_oracle(norm, global_step):
   """generator_norm_type=batch_renorm -- the configuration the reference's training guide uses (docs/training.md:17;
   libs/batch_norm.py:209-246,329-470): r / d corrections from the renorm statistics (stop-gradient, clipped by the
   global-step schedule), renorm + moving statistics updated per pass in call order.  Two consecutive generator-loss
-  evaluations so the second one sees non-trivial renorm state."""
+  evaluations so the second one sees non-trivial renorm state.  'batch_renorm_native' (nets/pggan_utils.py:175-188:
+  tf.contrib's layers.batch_norm(renorm=True, scope=<postfix>)) is the same arithmetic on variables named
+  '<conv>/_s/{gamma, beta, moving_*, renorm_*}' (pinned live: test_reference_live 'batch_renorm_native_*')."""
   from twingan_amd import Config
   from twingan_amd import twingan as T
   from twingan_amd.twingan import Trainer
-  cfg = Config(hw=16, max_ch=16, precision='fp32', generator_norm_type='batch_renorm')
+  cfg = Config(hw=16, max_ch=16, precision='fp32', generator_norm_type=norm)
   state = {}
-  rcfg = R.Config(hw=16, max_ch=16, norm='batch_renorm', bn_state=state, global_step=global_step)
+  rcfg = R.Config(hw=16, max_ch=16, norm=norm, bn_state=state, global_step=global_step)
   Pref = R.init_params(rcfg, seed=8, dtype=torch.float64, std='he')
   tr = Trainer(cfg, device='cuda:0', seed=8)
   tr.global_step = global_step
@@ -709,12 +712,75 @@ def test_batch_renorm_generator_matches_oracle(global_step):
       assert abs(gterms[k].item() - rgterms[k].item()) < 2e-4 * max(1.0, abs(rgterms[k].item())), (it, k)
     gl.backward()
     rgl.backward()
-    _grads_close(tr, Pref, tr.store.names('g'), FP32_GRAD_TOL, 'generator(batch_renorm, run %d)' % it, var_tol=FP32_VAR_GRAD_TOL)
+    _grads_close(tr, Pref, tr.store.names('g'), FP32_GRAD_TOL, 'generator(%s, run %d)' % (norm, it), var_tol=FP32_VAR_GRAD_TOL)
   renorm_state = {k: v for k, v in tr.store.state.items() if not k.startswith('renorm/')}
   assert set(renorm_state) == set(state)
+  assert any(k.endswith('/_t/renorm_stddev_weight' if norm.endswith('native') else '/BatchNorm/renorm_stddev_weight_t') for k in state)
   for k, v in state.items():
     a = renorm_state[k].double().cpu().numpy()
     assert np.abs(a - v.numpy()).max() < 2e-5 * max(1.0, np.abs(v.numpy()).max()), k
+  if norm.endswith('native'):      # the inference branch on the moving statistics the two runs left (twingan.py:300-363)
+    rcfg.bn_state = {k: v.clone() for k, v in state.items()}
+    x = torch.rand(2, 16, 16, 3, generator=g)
+    with torch.no_grad():
+      want = R.translate({k: v.detach() for k, v in Pref.items()}, x.double(), rcfg, 't')
+    got = T.translate(tr.P, dev(x), cfg, 't')
+    assert rel_l2(got, want) < 2e-5, rel_l2(got, want)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_layer_norm_native_generator_matches_oracle(precision):
+  """generator_norm_type=layer_norm_native (nets/pggan_utils.py:189-197: tf.contrib.layers.layer_norm(center, scale,
+  scope=<postfix>)): every encoder / generator conv is normalised with the statistics of one IMAGE over (H, W, C), gamma /
+  beta per channel and per domain ('<conv>/_s/gamma'), epsilon 1e-12 -- ops.layer_norm_act (the statistics kernel as a
+  differentiable node + the fused per-image-row kernel).  Losses, gradients and the inference branch (the layer keeps no
+  state: the same arithmetic) against the oracle (pinned live: test_reference_live 'layer_norm_native*')."""
+  from twingan_amd import Config
+  from twingan_amd import twingan as T
+  from twingan_amd.twingan import Trainer
+  cfg = Config(hw=16, max_ch=16, precision=precision, generator_norm_type='layer_norm_native')
+  rcfg = R.Config(hw=16, max_ch=16, norm='layer_norm_native')
+  Pref = R.init_params(rcfg, seed=10, dtype=torch.float64, std='he')
+  rng = torch.Generator().manual_seed(80)
+  for k in Pref:      # non-trivial per-channel parameters, different per domain
+    if k.endswith('/gamma'):
+      Pref[k] = (1.0 + 0.3 * torch.randn(Pref[k].shape, generator=rng)).double()
+    elif k.endswith('/beta'):
+      Pref[k] = (0.2 * torch.randn(Pref[k].shape, generator=rng)).double()
+  tr = Trainer(cfg, device='cuda:0', seed=10)
+  assert set(tr.store.state_dict()) == set(Pref) and 'generator/block_8x8x16/Conv/_t/gamma' in Pref
+  assert not [k for k in tr.store.state if not k.startswith('renorm/')]      # no moving statistics
+  tr.store.load_state_dict({k: v.float() for k, v in Pref.items()})
+  Pref = {k: v.float().double().requires_grad_(True) for k, v in Pref.items()}
+  adt = torch.bfloat16 if precision == 'bf16' else torch.float32
+  s, t = (torch.rand(3, 16, 16, 3, generator=rng).to(adt).float() for _ in range(2))
+  dev = lambda x: x.to('cuda:0').to(adt).contiguous()
+  tr.store.zero_grad('g')
+  tr._set_requires_grad(g=True, d=False)
+  gl, gterms = T.generator_loss(tr.P, dev(s), dev(t), cfg)
+  rgl, rgterms = R.generator_loss(Pref, s.double(), t.double(), rcfg)
+  tol = 1e-4 if precision == 'fp32' else 5e-2
+  assert set(gterms) == set(rgterms)
+  for k in rgterms:
+    assert abs(gterms[k].item() - rgterms[k].item()) < tol * max(1.0, abs(rgterms[k].item())), (k, gterms[k].item(), rgterms[k].item())
+  gl.backward()
+  rgl.backward()
+  if precision == 'fp32':
+    _grads_close(tr, Pref, tr.store.names('g'), FP32_GRAD_TOL, 'generator(layer_norm_native)', var_tol=FP32_VAR_GRAD_TOL)
+  else:
+    _grads_close(tr, Pref, tr.store.names('g'), 0.5, 'generator(layer_norm_native, bf16)', min_cos=0.9)
+  x = torch.rand(2, 16, 16, 3, generator=rng).to(adt).float()
+  with torch.no_grad():
+    want = R.translate({k: v.detach() for k, v in Pref.items()}, x.double(), rcfg, 's')
+  got = T.translate(tr.P, dev(x), cfg, 's')
+  assert rel_l2(got, want) < (2e-5 if precision == 'fp32' else 0.1), rel_l2(got, want)
+  # and as a training step through the trainer (eager and as a captured graph: the row arithmetic is capturable)
+  for use_graph in (False, True):
+    tr2 = Trainer(cfg, device='cuda:0', seed=10, use_graph=use_graph)
+    for _ in range(2):
+      loss, _ = tr2.run(dev(s), dev(t))
+    assert np.isfinite(float(loss))
+    tr2.close()
 
 
 @pytest.mark.parametrize('norm,both', [('instance_norm', True), ('batch_norm', False)])

@@ -257,6 +257,56 @@ def test_norm_act(ops, dtype, n, h, w, c, lrelu, pn):
   assert rel_l2(host(bd.grad), bt.grad.numpy()) < tol_for(dtype, True)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('n,h,w,c,lrelu,pn,pool,split', [(2, 8, 8, 16, True, True, False, None), (3, 4, 4, 256, True, True, False, 1),
+                                                        (2, 16, 16, 32, True, False, True, None), (2, 8, 8, 3, False, False, False, None),
+                                                        (4, 32, 32, 64, True, True, True, 2), (2, 5, 7, 8, True, True, False, None)])
+def test_layer_norm_act(ops, dtype, n, h, w, c, lrelu, pn, pool, split):
+  """ops.layer_norm_act = tf.contrib.layers.layer_norm (statistics of one image over (H, W, C), gamma / beta per channel,
+  epsilon 1e-12; nets/pggan_utils.py:189-197) + LeakyReLU + pixel norm (+ the 2x2 pool), with per-domain parameters
+  (images [split, n) use the second pair).  Outputs and all gradients against the same composition in float64."""
+  rng = np.random.RandomState(61)
+  y = rng.randn(n, h, w, c) * 1.5 + 0.7 + 0.5 * rng.randn(1, 1, 1, c)
+  gam = [1.0 + 0.2 * rng.randn(c) for _ in range(2)]
+  bet = [0.1 * rng.randn(c) for _ in range(2)]
+  gz = rng.randn(n, h, w, c)
+  gzp = rng.randn(n, h // 2, w // 2, c)
+  if dtype == torch.bfloat16:
+    y, gz, gzp = bf16_round(y), bf16_round(gz), bf16_round(gzp)
+  yd = to_dev(y, dtype).requires_grad_(True)
+  gd = [to_dev(g).requires_grad_(True) for g in gam]
+  bd = [to_dev(b).requires_grad_(True) for b in bet]
+  two = split is not None
+  out = ops.layer_norm_act(yd, gd[0], bd[0], lrelu=lrelu, pixel_norm=pn, pool=pool, gamma2=gd[1] if two else None,
+                           beta2=bd[1] if two else None, split=split)
+  yt = torch.from_numpy(y).requires_grad_(True)
+  gt = [torch.from_numpy(g).requires_grad_(True) for g in gam]
+  bt = [torch.from_numpy(b).requires_grad_(True) for b in bet]
+  mean = yt.mean(dim=(1, 2, 3), keepdim=True)
+  var = ((yt - mean) ** 2).mean(dim=(1, 2, 3), keepdim=True)
+  sel = (torch.arange(n) >= (split if two else n)).view(n, 1, 1, 1)
+  zt = (yt - mean) * torch.rsqrt(var + 1e-12) * torch.where(sel, gt[1], gt[0]) + torch.where(sel, bt[1], bt[0])
+  if lrelu:
+    zt = R.leaky_relu(zt)
+  if pn:
+    zt = R.pixel_norm(zt)
+  if pool:
+    z, zp = out
+    ztp = R.avg_pool2(zt)
+    torch.autograd.backward([z, zp], [to_dev(gz, dtype), to_dev(gzp, dtype)])
+    torch.autograd.backward([zt, ztp], [torch.from_numpy(gz), torch.from_numpy(gzp)])
+    assert rel_l2(host(zp), ztp.detach().numpy()) < tol_for(dtype)
+  else:
+    z = out
+    z.backward(to_dev(gz, dtype))
+    zt.backward(torch.from_numpy(gz))
+  assert rel_l2(host(z), zt.detach().numpy()) < tol_for(dtype)
+  assert rel_l2(host(yd.grad), yt.grad.numpy()) < tol_for(dtype, True)
+  for i in range(2 if two else 1):
+    assert rel_l2(host(gd[i].grad), gt[i].grad.numpy()) < tol_for(dtype, True), i
+    assert rel_l2(host(bd[i].grad), bt[i].grad.numpy()) < tol_for(dtype, True), i
+
+
 def test_instance_norm_large_mean_is_stable(ops):
   """Shifted-sum statistics: a large common offset must not destroy the variance in fp32."""
   rng = np.random.RandomState(7)

@@ -38,6 +38,13 @@ CASES = {
   'style_batch_renorm': dict(hw=16, max_ch=8, use_style_embedding=True, style_embed_size=4, norm='batch_renorm'),
   # --use_larger_filter_at_rgb_layer (nets/pggan.py:172-175,194-197): 7x7 to-RGB at 16x16; min(7, 8/2) = an EVEN 4x4 SAME
   # kernel (TF pads 1 low / 2 high) for both to-RGB layers of the growing 8x8 stage
+  # tf.contrib's own normalisers behind nets/pggan_utils.py:175-197 (scope=<postfix>: variables '<conv>/_s/gamma'); the
+  # stand-in restates contrib's two layers (oracle/tf_shim/tfapi.py layers_batch_norm / layers_layer_norm) -- this pins the
+  # reference's WIRING (which layer, which arguments, which variable names), the layers' arithmetic is the restatement's
+  'batch_renorm_native_step0': dict(hw=16, max_ch=8, norm='batch_renorm_native'),
+  'batch_renorm_native_step25000': dict(hw=16, max_ch=8, norm='batch_renorm_native', global_step=25000),
+  'layer_norm_native': dict(hw=16, max_ch=8, norm='layer_norm_native'),
+  'layer_norm_native_attention': dict(hw=16, max_ch=16, norm='layer_norm_native', do_self_attention=True, self_attention_hw=8),
   'larger_rgb_16': dict(hw=16, max_ch=8, larger_rgb=True),
   'larger_rgb_growing_8': dict(hw=8, max_ch=8, larger_rgb=True, is_growing=True, alpha_grow=0.4),
 }
@@ -53,7 +60,7 @@ def test_oracle_matches_live_reference(name):
   rng = np.random.RandomState(13)
   s, t = rng.rand(batch, cfg.hw, cfg.hw, 3), rng.rand(batch, cfg.hw, cfg.hw, 3)
   preset = {k: v.numpy() for k, v in list(P.items()) + list(state.items())}
-  stateful = cfg.norm in ('batch_norm', 'batch_renorm')
+  stateful = cfg.norm in ('batch_norm', 'batch_renorm', 'batch_renorm_native')
   if stateful:
     cfg.bn_state = {}      # the oracle applies the moving-statistics updates in program order: ask the stand-in for the same
   emb = None
@@ -152,7 +159,7 @@ def test_pggan_oracle_matches_live_reference(name):
     assert np.abs(v.detach().numpy() - want).max() < 1e-9 * scale, k
 
 
-@pytest.mark.parametrize('norm', ['instance_norm', 'batch_norm', 'batch_renorm'])
+@pytest.mark.parametrize('norm', ['instance_norm', 'batch_norm', 'batch_renorm', 'batch_renorm_native', 'layer_norm_native'])
 def test_inference_branch_matches_live_reference(norm):
   """twingan.py:300-363 with fed placeholders: is_training=False passes on preset moving statistics -- both translation
   directions of the oracle's translate() against custom_generated_t_style_source / custom_generated_s_style_target."""
@@ -161,12 +168,19 @@ def test_inference_branch_matches_live_reference(norm):
   P = R.init_params(cfg, seed=31, dtype=torch.float64, std='he')
   rng = np.random.RandomState(32)
   state = {}
-  if norm != 'instance_norm':
+  if norm in ('batch_norm', 'batch_renorm'):
     for k in list(P):
       if k.endswith(('/gamma_s', '/gamma_t')):
         base, d, c = k.rsplit('/', 1)[0], k[-2:], P[k].shape[0]
         state[base + '/moving_mean' + d] = torch.from_numpy(rng.randn(c) * 0.3)
         state[base + '/moving_variance' + d] = torch.from_numpy(0.5 + rng.rand(c))
+  elif norm == 'batch_renorm_native':      # contrib's names under the postfix scope
+    for k in list(P):
+      if k.endswith(('/_s/gamma', '/_t/gamma')):
+        base, c = k.rsplit('/', 1)[0], P[k].shape[0]
+        state[base + '/moving_mean'] = torch.from_numpy(rng.randn(c) * 0.3)
+        state[base + '/moving_variance'] = torch.from_numpy(0.5 + rng.rand(c))
+    assert state
   preset = {k: v.numpy() for k, v in list(P.items()) + list(state.items())}
   s, t, sp, tp = (rng.rand(2, 16, 16, 3) for _ in range(4))
   ref = ref_runner.run(ref_runner.flags_of(cfg), s, t, want_grads=False, preset=preset, feed={'sources_ph': sp, 'targets_ph': tp})
@@ -218,4 +232,30 @@ def test_warm_start_set_is_slims_model_variables():
   assert us and gates
   assert all(k in in_collection for k in us) and not any(k in in_collection for k in gates)
   wrong = [k for k in names if is_model_variable(k) != (k in in_collection)]
+  assert not wrong, wrong[:5]
+
+
+@pytest.mark.parametrize('norm', ['batch_renorm_native', 'layer_norm_native'])
+def test_native_normaliser_variables_are_what_the_reference_creates(norm):
+  """--generator_norm_type batch_renorm_native / layer_norm_native (nets/pggan_utils.py:175-197) hand the domain postfix to
+  tf.contrib's layers as their SCOPE: the reference's graph, built live, creates '<conv>/_s/gamma' (not 'gamma_s' under
+  'BatchNorm'), and for batch renorm the eight variables of tf.layers.BatchNormalization.  The product's declaration
+  must be the same set, split the same way into trainable / non-trainable, all of them slim model variables."""
+  from oracle import ref_runner
+  from twingan_amd import Config
+  from twingan_amd.params import ParamStore, declare_twingan, is_model_variable
+  rcfg = R.Config(hw=16, max_ch=8, norm=norm)
+  rng = np.random.RandomState(5)
+  ref = ref_runner.run(ref_runner.flags_of(rcfg), rng.rand(2, 16, 16, 3), rng.rand(2, 16, 16, 3), seed=1, want_grads=False)
+  store = declare_twingan(ParamStore('cpu'), Config(hw=16, max_ch=8, generator_norm_type=norm)).build(seed=0)
+  want = {k: v for k, v in ref['variables'].items() if k != 'global_step'}
+  trainable = {k: tuple(store.specs[k]['shape']) for k in store.specs}
+  assert trainable == {k: tuple(want[k].shape) for k in ref['trainable']}
+  state = {k: tuple(v.shape) for k, v in store.state.items() if not k.startswith('renorm/')}      # the clipping scalars
+  assert {k: v if v != (1,) else () for k, v in state.items()} == \
+      {k: tuple(v.shape) for k, v in want.items() if k not in ref['trainable']}
+  assert any('/_s/gamma' in k for k in trainable) and not any('Norm/' in k for k in trainable)
+  if norm == 'batch_renorm_native':
+    assert sum('/_t/renorm_stddev_weight' in k for k in state) == sum('/_t/gamma' in k for k in trainable) > 0
+  wrong = [k for k in want if is_model_variable(k) != (k in ref['model_variables'])]
   assert not wrong, wrong[:5]

@@ -9,7 +9,9 @@ class Config:
   hw: int = 256                       # --train_image_size (pggan_runner.py:136-150)
   max_ch: int = 256                   # --pggan_max_num_channels           nets/pggan.py:51-53
   max_ch_dis: object = None           # --pggan_max_num_channels_dis (nets/pggan.py:54-56): discriminators only; None = max_ch
-  generator_norm_type: str = 'instance_norm'   # nets/pggan.py:24: instance_norm (north star) | batch_norm | batch_renorm
+  # nets/pggan.py:24, nets/pggan_utils.py:35-41: instance_norm (north star) | batch_norm | batch_renorm | none |
+  # batch_renorm_native | layer_norm_native (tf.contrib's own layers; TwinGAN trainer only)
+  generator_norm_type: str = 'instance_norm'
   do_pixel_norm: bool = True          # nets/pggan.py:34-38
   use_unet: bool = True               # twingan.py:53-56
   unet_max_concat_hw: object = None   # --pggan_unet_max_concat_hw (nets/pggan.py:57-59): no UNet skip above this hw

@@ -1187,6 +1187,73 @@ def affine_act(y_hat, gamma_rows, beta_rows, lrelu=True, pixel_norm=True, pool=F
                   (zero, one))
 
 
+_MOMENT_EPS = 1e-12      # only keeps rsqrt finite for a constant channel; removed again from the variance
+
+
+def _unit_rows(n, c, device):
+  key = (n, c, device)
+  if key not in _CONST:
+    one = torch.ones(n * c, dtype=torch.float32, device=device)
+    _CONST[key] = (one, torch.zeros_like(one))
+  return _CONST[key]
+
+
+class ChannelMomentsFn(torch.autograd.Function):
+  """(mean, var), fp32 [n, c], of y[n, h, w, c] over (h, w) (population variance) as a differentiable node: the statistics
+  kernel forward; backward d/dy = gm / hw + gv * 2 (y - mean) / hw = y * a[n, c] + b[n, c], ONE launch of the fused
+  normalisation kernel in its per-image-row mode with constant unit statistics.  First-order only (E / G)."""
+
+  @staticmethod
+  def forward(ctx, y):
+    n, h, w, c = y.shape
+    mean, rstd = instance_stats(y, _MOMENT_EPS)
+    mean = mean.view(n, c)
+    var = (rstd.view(n, c).pow(-2) - _MOMENT_EPS).clamp_min_(0.0)
+    ctx.save_for_backward(y, mean)
+    return mean, var
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, gm, gv):
+    y, mean = ctx.saved_tensors
+    n, h, w, c = y.shape
+    inv = 1.0 / (h * w)
+    a = torch.zeros((n, c), dtype=torch.float32, device=y.device) if gv is None else gv.float() * (2.0 * inv)
+    b = -a * mean
+    if gm is not None:
+      b = b + gm.float() * inv
+    one, zero = _unit_rows(n, c, y.device)
+    gy = torch.empty_like(y)
+    call('tg_norm_act_fwd', _p(y), _p(zero), _p(one), _p(a.contiguous()), _p(b.contiguous()), 0, 0, n, 1, _p(gy), 0, n, h, w, c,
+         NF_NOSTATS, LRELU_ALPHA, 1e-6, _dt(y), _stream(), work=('norm_act_fwd' + _shape_tag(y), 0, 2 * y.numel() * _esize(y)))
+    return gy
+
+
+def layer_norm_act(y, gamma, beta, lrelu=True, pixel_norm=True, ln_eps=1e-12, pn_eps=1e-6, alpha=LRELU_ALPHA, gamma2=None,
+                   beta2=None, split=None, pool=False):
+  """pixel_norm(lrelu(layer_norm(y; gamma, beta))): tf.contrib.layers.layer_norm as 'layer_norm_native' calls it
+  (nets/pggan_utils.py:189-197; TF 1.8: moments of each image over (H, W, C), gamma / beta per channel, epsilon 1e-12).
+  An option row, built from the kernels of the headline path: per-(image, channel) moments (the statistics kernel), the
+  image's mean / variance from them by the law of total variance ([n, c] row arithmetic, no cancellation), and the fused
+  per-image-row kernel with scale = gamma * rstd_n, shift = beta - mean_n * scale (affine + LeakyReLU + pixel norm + pool
+  in one pass, its backward returning the row gradients) -- two tensor passes more than a dedicated kernel would need
+  (the statistics pass and its backward).  Images [split, n) use (gamma2, beta2)."""
+  n, c = y.shape[0], y.shape[3]
+  m_c, v_c = ChannelMomentsFn.apply(y)
+  mu = m_c.mean(dim=1, keepdim=True)
+  var = (v_c + (m_c - mu) ** 2).mean(dim=1, keepdim=True)
+  rstd = torch.rsqrt(var + ln_eps)
+  if gamma2 is None:
+    g_rows, b_rows = gamma.float().expand(n, c), beta.float().expand(n, c)
+  else:
+    sp = int(split)
+    g_rows = torch.cat([gamma.float().expand(sp, c), gamma2.float().expand(n - sp, c)])
+    b_rows = torch.cat([beta.float().expand(sp, c), beta2.float().expand(n - sp, c)])
+  scale_rows = g_rows * rstd
+  return affine_act(y, scale_rows, b_rows - mu * scale_rows, lrelu=lrelu, pixel_norm=pixel_norm, pool=pool, pn_eps=pn_eps,
+                    alpha=alpha)
+
+
 def norm_act(y, gamma, beta, lrelu=True, pixel_norm=True, in_eps=1e-6, pn_eps=1e-6, alpha=LRELU_ALPHA, gamma2=None,
              beta2=None, split=None, pool=False, ema=None, stats=None, conv_stats=None):
   """Statistics are per leading index of ``y`` (instance norm: one image; batch norm: the caller passes the view

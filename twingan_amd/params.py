@@ -68,23 +68,24 @@ class ParamStore:
     self.add(scope + '/weights', (k, k, cin, cout), group, 'conv_w', (k, k, phys_cin or cin, cout))
     if bias:
       self.add(scope + '/biases', (cout,), group, 'bias')
-    pf = lambda d: '_' + d if d else ''      # domain postfix of the normaliser variables ('' in the plain PGGAN trainer)
     for d in norm_domains:
       if cond_dim:      # gamma = 1 + FC(cond), beta = FC(cond)  (libs/instance_norm.py:93-120, batch_norm.py:34-38)
+        assert norm_scope != NATIVE_NORM      # nets/pggan_utils.py:177,191: contrib's layers take no conditional layer
         for nm in ('gamma', 'beta'):
-          self.add('%s/%s/%s%s/weights' % (scope, norm_scope, nm, pf(d)), (cond_dim, cout), group, 'xavier_w')
-          self.add('%s/%s/%s%s/biases' % (scope, norm_scope, nm, pf(d)), (cout,), group, 'bias')
+          self.add(norm_var(scope, norm_scope, nm, d) + '/weights', (cond_dim, cout), group, 'xavier_w')
+          self.add(norm_var(scope, norm_scope, nm, d) + '/biases', (cout,), group, 'bias')
       else:
-        self.add('%s/%s/gamma%s' % (scope, norm_scope, pf(d)), (cout,), group, 'gamma')
-        self.add('%s/%s/beta%s' % (scope, norm_scope, pf(d)), (cout,), group, 'beta')
-      if norm_scope == 'BatchNorm':      # non-trainable moving statistics (libs/batch_norm.py:184-196)
-        self.state_specs['%s/BatchNorm/moving_mean%s' % (scope, pf(d))] = (cout, 0.0)
-        self.state_specs['%s/BatchNorm/moving_variance%s' % (scope, pf(d))] = (cout, 1.0)
+        self.add(norm_var(scope, norm_scope, 'gamma', d), (cout,), group, 'gamma')
+        self.add(norm_var(scope, norm_scope, 'beta', d), (cout,), group, 'beta')
+      if norm_scope == 'BatchNorm' or (norm_scope == NATIVE_NORM and self.renorm):
+        # non-trainable moving statistics (libs/batch_norm.py:184-196; tf.layers.BatchNormalization.build)
+        self.state_specs[norm_var(scope, norm_scope, 'moving_mean', d)] = (cout, 0.0)
+        self.state_specs[norm_var(scope, norm_scope, 'moving_variance', d)] = (cout, 1.0)
         if self.renorm:                  # batch renorm training statistics (libs/batch_norm.py:209-246), zero-initialised
-          self.state_specs['%s/BatchNorm/renorm_mean%s' % (scope, pf(d))] = (cout, 0.0)
-          self.state_specs['%s/BatchNorm/renorm_mean_weight%s' % (scope, pf(d))] = (1, 0.0)
-          self.state_specs['%s/BatchNorm/renorm_stddev%s' % (scope, pf(d))] = (cout, 0.0)
-          self.state_specs['%s/BatchNorm/renorm_stddev_weight%s' % (scope, pf(d))] = (1, 0.0)
+          self.state_specs[norm_var(scope, norm_scope, 'renorm_mean', d)] = (cout, 0.0)
+          self.state_specs[norm_var(scope, norm_scope, 'renorm_mean_weight', d)] = (1, 0.0)
+          self.state_specs[norm_var(scope, norm_scope, 'renorm_stddev', d)] = (cout, 0.0)
+          self.state_specs[norm_var(scope, norm_scope, 'renorm_stddev_weight', d)] = (1, 0.0)
 
   # ---- allocation -----------------------------------------------------------------------------
   def build(self, seed=0):
@@ -274,6 +275,22 @@ def grad_phase(name, cfg):
   return 1 if high else 0
 
 
+NATIVE_NORM = '@native'
+NORM_SCOPE = {'instance_norm': 'InstanceNorm', 'batch_norm': 'BatchNorm', 'batch_renorm': 'BatchNorm', 'none': '',
+              'batch_renorm_native': NATIVE_NORM, 'layer_norm_native': NATIVE_NORM}
+
+
+def norm_var(scope, norm_scope, name, domain):
+  """TF name of a normaliser variable of the conv at ``scope``.  The reference's own layers open '<conv>/InstanceNorm' |
+  '<conv>/BatchNorm' and append the domain postfix to the VARIABLE name (libs/instance_norm.py:66-120,
+  libs/batch_norm.py:80,130-246: 'gamma_s'); tf.contrib's layers behind 'batch_renorm_native' / 'layer_norm_native' get
+  the postfix as their SCOPE (nets/pggan_utils.py:187,196) and keep contrib's plain variable names: '<conv>/_s/gamma'."""
+  pf = '_' + domain if domain else ''
+  if norm_scope == NATIVE_NORM:
+    return '%s/%s/%s' % (scope, pf, name)
+  return '%s/%s/%s%s' % (scope, norm_scope, name, pf)
+
+
 def declare_pggan(store, cfg):
   """The plain PGGAN trainer's variables (image_generation.py:194-316: scopes 'generator' and 'discriminator', latent
   noise input, no encoder, no domain postfix on the normaliser variables) -- BASELINE configs[0]."""
@@ -287,10 +304,13 @@ def declare_twingan(store, cfg, model='twingan'):
   pggan_model = model == 'pggan'
   store.phase_of = (lambda name: 0) if pggan_model else (lambda name: grad_phase(name, cfg))
   ms = max_stage_of(hw)
-  NORM_SCOPE = {'instance_norm': 'InstanceNorm', 'batch_norm': 'BatchNorm', 'batch_renorm': 'BatchNorm', 'none': ''}
-  store.renorm = cfg.generator_norm_type == 'batch_renorm'
+  store.renorm = cfg.generator_norm_type in ('batch_renorm', 'batch_renorm_native')
   if cfg.generator_norm_type not in NORM_SCOPE:
     raise NotImplementedError('generator_norm_type=%s' % cfg.generator_norm_type)
+  if NORM_SCOPE[cfg.generator_norm_type] == NATIVE_NORM and pggan_model:
+    # image_generation.py leaves conditional_layer_var_scope_postfix at '' (nets/pggan_utils.py:102-113), and contrib's
+    # layers would open variable_scope('') -- TF then names the variables '<conv>//gamma'; not restated, not built
+    raise NotImplementedError('generator_norm_type=%s in the plain PGGAN trainer (empty scope postfix)' % cfg.generator_norm_type)
   # generator_norm_type=none (nets/pggan_utils.py:198-200): no normaliser, so slim's conv2d adds a bias instead
   g_bias = cfg.generator_norm_type == 'none'
   nd = () if g_bias else (('',) if pggan_model else ('s', 't'))

@@ -12,7 +12,7 @@ Network functions return ``(output, end_points)`` like the reference.  Tensors a
 import math
 
 from . import ops
-from .params import get_num_channels, max_stage_of, mbstd_cpad
+from .params import NATIVE_NORM, NORM_SCOPE, get_num_channels, max_stage_of, mbstd_cpad, norm_var
 
 
 # ------------------------------------------------------------------------------------------------
@@ -170,9 +170,9 @@ def _cond_rows(P, scope, ns, cond, segments):
   gs, bs = [], []
   for d, lo, hi in segments:
     c = cond[lo:hi].contiguous()
-    pre = '%s/%s/' % (scope, ns)
-    gs.append(ops.fully_connected(c, P[pre + 'gamma_%s/weights' % d], P[pre + 'gamma_%s/biases' % d]) + 1.0)
-    bs.append(ops.fully_connected(c, P[pre + 'beta_%s/weights' % d], P[pre + 'beta_%s/biases' % d]))
+    gn, bn = norm_var(scope, ns, 'gamma', d), norm_var(scope, ns, 'beta', d)
+    gs.append(ops.fully_connected(c, P[gn + '/weights'], P[gn + '/biases']) + 1.0)
+    bs.append(ops.fully_connected(c, P[bn + '/weights'], P[bn + '/biases']))
   if len(gs) == 1:
     return gs[0], bs[0]
   return torch.cat(gs), torch.cat(bs)
@@ -217,17 +217,20 @@ def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pix
     # no normaliser (nets/pggan_utils.py:198-200): slim's conv2d then owns a bias; conv + bias + LeakyReLU is the
     # conv's epilogue, the pixel norm the fused kernel with constant statistics
     raise AssertionError('unreachable: generator_norm_type none is handled before the conv')
-  if nt not in ('instance_norm', 'batch_norm', 'batch_renorm'):
-    raise NotImplementedError('generator_norm_type=%s (instance_norm, batch_norm, batch_renorm and none are built)' % nt)
-  ns = 'InstanceNorm' if nt == 'instance_norm' else 'BatchNorm'
+  if nt not in NORM_SCOPE:
+    raise NotImplementedError('unsupported norm type: %s' % nt)      # nets/pggan_utils.py:201-202
+  ns = NORM_SCOPE[nt]
+  if ns == NATIVE_NORM:      # tf.contrib's own layers (nets/pggan_utils.py:175-197)
+    assert cond is None, 'Tensorflow implementation does not support `conditional_layer`.'      # pggan_utils.py:177,191
+  renorm = nt in ('batch_renorm', 'batch_renorm_native')
   if isinstance(domain, tuple):
     d0, d1, split = domain[:3]
     passes = domain[3] if len(domain) > 3 else 2
   else:
     d0, d1, split, passes = domain, None, None, 1
   pn = pixel_norm and cfg.do_pixel_norm
-  if not cfg.is_training and nt != 'instance_norm':
-    return _batch_norm_inference(P, scope, y, d0, d1, split, cond, activation, pn, pool)
+  if not cfg.is_training and nt not in ('instance_norm', 'layer_norm_native'):      # those two keep no statistics
+    return _batch_norm_inference(P, scope, y, d0, d1, split, cond, activation, pn, pool, ns)
   if cond is not None:      # conditional norm: one parameter row per image (twingan.py:245-267)
     n_ = y.shape[0]
     segs = [(d0, 0, n_)] if d1 is None else [(d0, 0, split), (d1, split, n_)]
@@ -243,12 +246,16 @@ def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pix
                            (d0, d1, None if split is None else split * passes // n, passes), activation, pn, pool,
                            cond_rows=rows, image_shape=(n, h, w, c))
     return _cond_batch_norm(P, scope, y, cond, segs, passes, activation, pn, pool, cfg)
-  g0, b0 = P['%s/%s/gamma%s' % (scope, ns, _pf(d0))], P['%s/%s/beta%s' % (scope, ns, _pf(d0))]
-  g1 = P['%s/%s/gamma%s' % (scope, ns, _pf(d1))] if d1 else None
-  b1 = P['%s/%s/beta%s' % (scope, ns, _pf(d1))] if d1 else None
+  g0, b0 = P[norm_var(scope, ns, 'gamma', d0)], P[norm_var(scope, ns, 'beta', d0)]
+  g1 = P[norm_var(scope, ns, 'gamma', d1)] if d1 else None
+  b1 = P[norm_var(scope, ns, 'beta', d1)] if d1 else None
   if nt == 'instance_norm':
     return ops.norm_act(y, g0, b0, lrelu=activation, pixel_norm=pn, gamma2=g1, beta2=b1, split=split, pool=pool,
                         conv_stats=cst)
+  if nt == 'layer_norm_native':
+    # tf.contrib.layers.layer_norm(center, scale, scope=<postfix>) (nets/pggan_utils.py:189-197): statistics of one IMAGE
+    # over (H, W, C), gamma / beta per channel, variance_epsilon 1e-12
+    return ops.layer_norm_act(y, g0, b0, lrelu=activation, pixel_norm=pn, gamma2=g1, beta2=b1, split=split, pool=pool)
   # batch norm (libs/batch_norm.py:42-326, training mode): moments over (N,H,W) of ONE reference pass.  Each of
   # the `passes` batched along N is a statistic group: the [passes, B*H, W, C] view turns the per-image
   # kernels into per-pass ones (pixel norm and pooling are per pixel / per 2x2 block, which the view preserves).
@@ -256,9 +263,9 @@ def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pix
   assert n % passes == 0 and (split is None or (split * passes) % n == 0)
   yv = y.view(passes, (n // passes) * h, w, c)
   st = P.state if hasattr(P, 'state') else None
-  if nt == 'batch_renorm':
+  if renorm:
     out = _batch_renorm(P, scope, yv, (d0, d1, None if split is None else split * passes // n, passes), activation, pn,
-                        pool)
+                        pool, ns=ns)
     if pool:
       return out[0].view(n, h, w, c), out[1].view(n, h // 2, w // 2, c)
     return out.view(n, h, w, c)
@@ -302,7 +309,7 @@ def _cond_batch_norm(P, scope, y, cond, segs, passes, activation, pn, pool, cfg)
   return ops.affine_act(yhat, g_rows, b_rows, lrelu=activation, pixel_norm=pn, pool=pool)
 
 
-def _batch_norm_inference(P, scope, y, d0, d1, split, cond, activation, pn, pool):
+def _batch_norm_inference(P, scope, y, d0, d1, split, cond, activation, pn, pool, ns='BatchNorm'):
   """conditional_batch_norm(is_training=False), with or without renorm (libs/batch_norm.py:403-470): normalise with the
   domain's MOVING mean / variance -- one (mean, rstd, gamma, beta) row per image through the fused kernel's
   per-image-row mode.  ``cond``: the l2-normalised embedding gives gamma = 1 + FC, beta = FC per image."""
@@ -310,16 +317,16 @@ def _batch_norm_inference(P, scope, y, d0, d1, split, cond, activation, pn, pool
   n, h, w, c = y.shape
   segs = [(d0, 0, n)] if d1 is None else [(d0, 0, split), (d1, split, n)]
   st = P.state
-  pre = scope + '/BatchNorm/'
-  mean = torch.cat([st[pre + 'moving_mean' + _pf(d)].expand(hi - lo, c) for d, lo, hi in segs])
-  rstd = torch.cat([torch.rsqrt(st[pre + 'moving_variance' + _pf(d)] + BN_EPS).expand(hi - lo, c) for d, lo, hi in segs])
+  nm = lambda v, d: norm_var(scope, ns, v, d)
+  mean = torch.cat([st[nm('moving_mean', d)].expand(hi - lo, c) for d, lo, hi in segs])
+  rstd = torch.cat([torch.rsqrt(st[nm('moving_variance', d)] + BN_EPS).expand(hi - lo, c) for d, lo, hi in segs])
   if cond is not None:
     cn = cond.float()
     cn = cn / cn.pow(2).sum(dim=1, keepdim=True).clamp_min(1e-12).sqrt()
-    g_rows, b_rows = _cond_rows(P, scope, 'BatchNorm', cn, segs)
+    g_rows, b_rows = _cond_rows(P, scope, ns, cn, segs)
   else:
-    g_rows = torch.cat([P[pre + 'gamma' + _pf(d)].expand(hi - lo, c) for d, lo, hi in segs])
-    b_rows = torch.cat([P[pre + 'beta' + _pf(d)].expand(hi - lo, c) for d, lo, hi in segs])
+    g_rows = torch.cat([P[nm('gamma', d)].expand(hi - lo, c) for d, lo, hi in segs])
+    b_rows = torch.cat([P[nm('beta', d)].expand(hi - lo, c) for d, lo, hi in segs])
   return ops.norm_act(y, g_rows.contiguous(), b_rows.contiguous(), lrelu=activation, pixel_norm=pn, in_eps=BN_EPS, pool=pool,
                       stats=(mean.contiguous().reshape(-1), rstd.contiguous().reshape(-1)))
 
@@ -328,7 +335,7 @@ BN_EPS = 1e-3            # libs/batch_norm.py:48
 RENORM_MOMENTUM = 0.99   # libs/batch_norm.py:62; the moving averages use the same decay (nets/pggan_utils.py:163)
 
 
-def _batch_renorm(P, scope, yv, domain, activation, pn, pool, cond_rows=None, image_shape=None):
+def _batch_renorm(P, scope, yv, domain, activation, pn, pool, cond_rows=None, image_shape=None, ns='BatchNorm'):
   """conditional_batch_norm(renorm=True) in training mode (libs/batch_norm.py:209-246,329-470), for yv =
   [passes, B*H, W, C] where pass i belongs to domain d0 (i < split) or d1.  Per pass, in call order:
     stddev = sqrt(var + eps);  r = clip(stddev / mixed_stddev),  d = clip((mean - mixed_mean) / mixed_stddev)
@@ -351,16 +358,16 @@ def _batch_renorm(P, scope, yv, domain, activation, pn, pool, cond_rows=None, im
   m = RENORM_MOMENTUM
   for i in range(passes):
     d = d0 if (split is None or i < split) else d1
-    pre = '%s/BatchNorm/' % scope
+    nm = lambda v: norm_var(scope, ns, v, d)
     if cond_rows is None:
-      gamma, beta = P[pre + 'gamma' + _pf(d)], P[pre + 'beta' + _pf(d)]
+      gamma, beta = P[nm('gamma')], P[nm('beta')]
     else:      # this pass' images
       per = image_shape[0] // passes
       gamma, beta = cond_rows[0][i * per:(i + 1) * per], cond_rows[1][i * per:(i + 1) * per]
     with torch.no_grad():
       bmean, stddev = mean_p[i], 1.0 / rstd_p[i]
-      rm, rmw = st[pre + 'renorm_mean' + _pf(d)], st[pre + 'renorm_mean_weight' + _pf(d)]
-      rs, rsw = st[pre + 'renorm_stddev' + _pf(d)], st[pre + 'renorm_stddev_weight' + _pf(d)]
+      rm, rmw = st[nm('renorm_mean')], st[nm('renorm_mean_weight')]
+      rs, rsw = st[nm('renorm_stddev')], st[nm('renorm_stddev_weight')]
       mixed_mean = rm + (1.0 - rmw) * bmean
       mixed_std = rs + (1.0 - rsw) * stddev
       r = torch.minimum(torch.maximum(stddev / mixed_std, rmin), rmax)
@@ -370,8 +377,8 @@ def _batch_renorm(P, scope, yv, domain, activation, pn, pool, cond_rows=None, im
       rs.mul_(m).add_(stddev, alpha=1.0 - m)
       rsw.mul_(m).add_(1.0 - m)
       new_mean, new_std = rm / rmw, rs / rsw
-      st[pre + 'moving_mean' + _pf(d)].mul_(m).add_(new_mean, alpha=1.0 - m)
-      st[pre + 'moving_variance' + _pf(d)].mul_(m).add_(new_std * new_std - BN_EPS, alpha=1.0 - m)
+      st[nm('moving_mean')].mul_(m).add_(new_mean, alpha=1.0 - m)
+      st[nm('moving_variance')].mul_(m).add_(new_std * new_std - BN_EPS, alpha=1.0 - m)
     g_rows.append(r * gamma)
     b_rows.append(dd * gamma + beta)
   if cond_rows is not None:

@@ -626,7 +626,7 @@ class Trainer:
     import contextlib
     # the kernels go to the current device's stream (ops._stream)
     with (torch.cuda.device(self.device) if self.device.type == 'cuda' else contextlib.nullcontext()):
-      if self.cfg.generator_norm_type == 'batch_renorm':
+      if self.cfg.generator_norm_type in ('batch_renorm', 'batch_renorm_native'):
         self._set_renorm_clipping()
       if self.use_graph:
         assert gp_alpha_s is None and gp_alpha_t is None, 'graph mode draws the GP alphas on the device'
