@@ -480,6 +480,16 @@ int tg_comm_destroy(void* comm);
  * random draws of random_flip_left_right / distort_color(fast_mode) are the caller's; (0, 0, 0, 1) = evaluation. */
 int tg_preprocess_images(const void* packed, const int64_t* offsets, const int* rect, const float* aug, void* out, int n,
                          int hw, int dtype, void* stream);
+/* The same with --do_random_cropping (model/model_inheritor.py:225,449-454; docs/training.md:22-23 trains with it;
+ * danbooru_preprocessing.py:187-201, preprocessing_util.random_crop_image :312-331) and --color_space
+ * (model_inheritor.py:240,414; danbooru_preprocessing.py:208-225).  crop (NULL: none): int32 [n][4] = (cy, cx, ch, cw), the
+ * rectangle tf.random_crop cuts out of the INTERMEDIATE image -- the source rectangle resized to mid x mid, mid =
+ * int(hw / random_cropping_ratio) -- which a second bilinear resize brings to hw x hw; 0 <= cy, cy + ch <= mid (same for x);
+ * the draws (ch, cw = int32(mid * U[ratio, 1)), offsets uniform over the valid range) are the caller's.  color_space:
+ * 0 rgb, 1 yiq (preprocessing_util.rgb_to_yiq :154-160, applied after the distortion and clip), 2 bgr (channel reverse),
+ * 3 gray (the colour distortion is skipped; the image keeps its three channels, as in the reference). */
+int tg_preprocess_images_crop(const void* packed, const int64_t* offsets, const int* rect, const int* crop, const float* aug,
+                              void* out, int n, int hw, int mid, int color_space, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

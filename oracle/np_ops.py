@@ -341,14 +341,24 @@ def adjust_saturation(rgb, factor):
   return hsv_to_rgb(hsv)
 
 
+RGB_TO_YIQ = np.array([[0.299, 0.587, 0.114], [0.596, -0.274, -0.322], [0.211, -0.523, 0.312]], np.float32)      # preprocessing_util.py:154-160
+RANDOM_CROP_RATIO = 0.8      # danbooru_preprocessing.py:33
+
+
 def preprocess_image(img_u8, hw, resize_mode='PAD', is_training=True, flip=False, saturation_first=False, delta=0.0,
-                     factor=1.0):
-  """preprocessing/danbooru_preprocessing.py:115-230 with the TwinGAN trainer's defaults (model_inheritor.py:403-457:
-  padding 0, rgb, no mean subtraction, no random cropping, fast_mode): convert_image_dtype to [0, 1]; resize_image
+                     factor=1.0, crop=None, random_cropping_ratio=RANDOM_CROP_RATIO, color_space='rgb', mode_offset=None):
+  """preprocessing/danbooru_preprocessing.py:115-230 as the TwinGAN trainer reaches it (model_inheritor.py:403-457:
+  padding 0, no mean subtraction, fast_mode -- `fast_mode` is not a flag and the partial never sets it, so the hue /
+  contrast orderings are unreachable from the trainer): convert_image_dtype to [0, 1]; resize_image
   (preprocessing_util.py:97-146) -- PAD: zero-pad about the centre to max(h, w); CROP: centre-crop to min(h, w); RESHAPE:
   as is -- then bilinear to [hw, hw]; when training: random_flip_left_right (flip if the draw < 0.5), distort_color in
   fast mode (ordering 0: brightness then saturation; orderings 1-3: saturation then brightness), clip to [0, 1].
-  The random draws are arguments."""
+  ``crop`` = (oy, ox, ch, cw): --do_random_cropping when training (docs/training.md:22-23 trains with it;
+  danbooru_preprocessing.py:187-201, preprocessing_util.random_crop_image :312-331): the first resize goes to
+  int(hw / random_cropping_ratio), tf.random_crop cuts the [ch, cw] rectangle at (oy, ox) out of it (ch, cw =
+  int32(size * U[ratio, 1)), offsets uniform), a second bilinear resize brings that to [hw, hw].  ``color_space``:
+  'gray' skips the colour distortion (:208-212); 'yiq' applies rgb_to_yiq, 'bgr' reverses the channels, after everything
+  else (:221-225).  The random draws are arguments."""
   x = (img_u8.astype(np.float32) * np.float32(1.0 / 255.0)).astype(np.float64)
   h, w = x.shape[:2]
   if resize_mode == 'PAD' and h != w:
@@ -361,17 +371,45 @@ def preprocess_image(img_u8, hw, resize_mode='PAD', is_training=True, flip=False
     size = min(h, w)
     oh, ow = (h - size) // 2, (w - size) // 2
     x = x[oh:oh + size, ow:ow + size]
+  elif resize_mode == 'RANDOM_CROP':
+    # preprocessing_util._random_crop_to_hw (:84-95): an image smaller than the target is first resized to it (the crop
+    # is then the whole image); otherwise tf.random_crop cuts [new_hw, new_hw] at ``mode_offset`` = (oy, ox) and NO
+    # resize follows (:144-146).  new_hw is the first resize's target: int(hw / ratio) with random cropping on.
+    new_hw = int(hw / random_cropping_ratio) if (is_training and crop is not None) else hw
+    if new_hw > min(h, w):
+      x = resize_bilinear_tf1(x, new_hw, new_hw)
+      oy = ox = 0
+    else:
+      oy, ox = (int(v) for v in mode_offset)
+    assert oy + new_hw <= x.shape[0] and ox + new_hw <= x.shape[1]
+    x = x[oy:oy + new_hw, ox:ox + new_hw]
+  elif resize_mode == 'NONE':      # :137-139: the image as it is -- it must already have the size the networks take
+    assert (h, w) == (hw, hw) and crop is None
   elif resize_mode not in ('PAD', 'CROP', 'RESHAPE'):
     raise ValueError(resize_mode)
-  x = resize_bilinear_tf1(x, hw, hw)
+  if is_training and crop is not None:
+    mid = int(hw / random_cropping_ratio)
+    x = resize_bilinear_tf1(x, mid, mid)
+    oy, ox, ch, cw = (int(v) for v in crop)
+    assert 0 <= oy and oy + ch <= mid and 0 <= ox and ox + cw <= mid
+    x = resize_bilinear_tf1(x[oy:oy + ch, ox:ox + cw], hw, hw)
+  else:
+    x = resize_bilinear_tf1(x, hw, hw)
   if is_training:
     if flip:
       x = x[:, ::-1]
-    if saturation_first:
-      x = adjust_saturation(x, factor) + delta
-    else:
-      x = adjust_saturation(x + delta, factor)
-    x = np.clip(x, 0.0, 1.0)
+    if color_space != 'gray':
+      if saturation_first:
+        x = adjust_saturation(x, factor) + delta
+      else:
+        x = adjust_saturation(x + delta, factor)
+      x = np.clip(x, 0.0, 1.0)
+  if color_space == 'yiq':
+    x = x @ RGB_TO_YIQ.astype(np.float64).T
+  elif color_space == 'bgr':
+    x = x[..., ::-1]
+  elif color_space not in ('rgb', 'gray'):
+    raise ValueError(color_space)
   return x
 
 

@@ -362,7 +362,7 @@ def run_pggan(flags, targets, global_step=0, seed=0, preset=None, want_grads=Tru
   return res
 
 
-def run_preprocess(image_u8, hw, resize_mode='PAD', is_training=True, seed=0):
+def run_preprocess(image_u8, hw, resize_mode='PAD', is_training=True, seed=0, do_random_cropping=False, color_space='rgb'):
   """The reference's OWN preprocessing/danbooru_preprocessing.preprocess_image (the TwinGAN trainer's image
   preprocessing, model/model_inheritor.py:403-457) executed on the TF stand-in for one uint8 image [h, w, 3].
   Returns (output [hw, hw, 3] float64, draws) with draws = dict(flip_uniform, sel, applied=[(kind, value), ...]) --
@@ -377,8 +377,17 @@ def run_preprocess(image_u8, hw, resize_mode='PAD', is_training=True, seed=0):
   core.STATE.gen.manual_seed(seed)
   img = tf.Tensor(torch.tensor(np.asarray(image_u8), dtype=torch.float64), tf.uint8, 'image')
   out = pre.preprocess_image(img, hw, hw, dtype=tf.float32, resize_mode=resize_mode, is_training=is_training,
-                             add_image_summaries=False)
-  log = [(n, float(v)) for n, v in core.STATE.random_log]
-  draws = dict(flip_uniform=log[0][1] if is_training else None, sel=int(log[1][1]) if is_training else None,
-               applied=list(core.STATE.aug_log))
+                             add_image_summaries=False, do_random_cropping=do_random_cropping, color_space=color_space)
+  # draw order of a training call: [crop height, crop width, crop offsets] (only with do_random_cropping), the flip
+  # uniform, the ordering selector (not for 'gray'), then the distortions of the live branch
+  log = [(n, v) for n, v in core.STATE.random_log]
+  k = 3 if (is_training and do_random_cropping) else 0
+  applied = [a for a in core.STATE.aug_log if a[0] != 'crop']
+  crops = [a[1] for a in core.STATE.aug_log if a[0] == 'crop']
+  mode_crop = None
+  if resize_mode == 'RANDOM_CROP':      # preprocessing_util._random_crop_to_hw draws its offsets first, in any mode
+    mode_crop, crops, k = crops[0], crops[1:], k + 1
+  draws = dict(flip_uniform=float(log[k][1]) if is_training else None,
+               sel=int(log[k + 1][1]) if (is_training and color_space != 'gray') else None,
+               applied=applied, crop=crops[0] if crops else None, mode_crop=mode_crop)
   return out.t.detach().numpy().copy(), draws

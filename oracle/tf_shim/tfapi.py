@@ -550,6 +550,24 @@ def reverse(tensor, axis, name=None):
   return wrap(torch.flip(raw(tensor), dims=[int(a) for a in axis]), tensor)
 
 
+def matrix_transpose(a, name='matrix_transpose', conjugate=False):
+  return wrap(raw(a).transpose(-1, -2), a)
+
+
+def random_crop(value, size, seed=None, name=None):
+  """tf.random_crop (python/ops/random_ops.py): offset = random_uniform(shape(shape), dtype=size.dtype, maxval=size.dtype.max)
+  % (shape - size + 1), then tf.slice(value, offset, size).  The offsets and the crop size are logged (aug_log 'crop' =
+  (oy, ox, h, w)) so that a restatement can be fed the same rectangle."""
+  t = raw(value)
+  sz = [int(raw(v).item()) if isinstance(v, Tensor) else int(v) for v in size]
+  shape_ = list(t.shape)
+  assert len(sz) == len(shape_) and all(a >= b for a, b in zip(shape_, sz)), 'Need value.shape >= size'
+  draw = random_uniform([len(shape_)], maxval=2 ** 31 - 1, dtype=int32, name=name or 'random_crop')
+  off = [int(d) % (a - b + 1) for d, a, b in zip(raw(draw).tolist(), shape_, sz)]
+  STATE.aug_log.append(('crop', (off[0], off[1], sz[0], sz[1])))
+  return wrap(t[tuple(slice(o, o + n) for o, n in zip(off, sz))], value)
+
+
 def cf_switch(data, pred, dtype=None, name=None):
   """control_flow_ops.switch: (output_false, output_true); the branch not taken is dead (None here)."""
   p = bool(raw(pred).item())
@@ -1228,7 +1246,7 @@ def build_modules():
   tf = _module(
     'tensorflow', __version__='1.8.0-shim',
     float16=float16, float32=float32, float64=float64, int32=int32, int64=int64, bool=bool_, uint8=core.uint8,
-    DType=core.DType, reverse=reverse,
+    DType=core.DType, reverse=reverse, random_crop=random_crop, matrix_transpose=matrix_transpose,
     Tensor=Tensor, Variable=Variable, TensorShape=TensorShape, Dimension=Dimension,
     constant=constant, convert_to_tensor=convert_to_tensor, cast=cast, to_float=to_float, identity=identity,
     stop_gradient=stop_gradient, reshape=reshape, expand_dims=expand_dims, squeeze=squeeze, concat=concat, stack=stack,

@@ -174,3 +174,51 @@ def test_progressive_training_from_tfrecord_datasets(tmp_path):
                                      device='cuda:0')
   out = inf.infer(rng.randint(0, 256, (2, 20, 24, 3), dtype=np.uint8))
   assert out.shape == (2, 8, 8, 3) and np.isfinite(out).all()
+
+
+MODES = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'preprocess_modes_hw32.npz')
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_preprocess_modes_hit_the_reference_fixture(precision):
+  """--do_random_cropping (the reference's training recipe, docs/training.md:22-23), the RANDOM_CROP / NONE resize modes
+  and --color_space yiq / bgr / gray: tg_preprocess_images_crop against what the reference's own preprocess_image computed
+  for the same draws (tests/golden/preprocess_modes_hw32.npz, tools/make_golden.py --preprocess-modes).  The two chained
+  bilinear resizes run inside one launch (16 source taps per output pixel): fp32 within 3e-6, bf16 within one rounding of
+  the value's magnitude (yiq reaches beyond [0, 1])."""
+  from twingan_amd import data as D
+  g = np.load(MODES)
+  hw = int(g['hw'])
+  for i in range(int(g['n'])):
+    img, want, par = g['img%d' % i], g['out%d' % i], g['par%d' % i]
+    mode, cs, training, cropping = str(g['mode%d' % i]), str(g['cs%d' % i]), bool(par[4]), bool(par[5])
+    crop = g['crop%d' % i] if (training and cropping) else None
+    moff = tuple(int(v) for v in g['moff%d' % i]) if g['moff%d' % i][0] >= 0 else None
+    pre = D.Preprocessor(hw, device='cuda:0', precision=precision, resize_mode=mode, is_training=training,
+                         do_random_cropping=cropping, color_space=cs)
+    assert pre.crops == (crop is not None) and (not pre.crops or pre.mid == 40)
+    out = pre([img], aug=par[None, :4].astype(np.float32) if training else None, crop=None if crop is None else crop[None],
+              mode_offsets=[moff]).float().cpu().numpy()[0]
+    err = np.abs(out - want).max()
+    assert err < (3e-6 if precision == 'fp32' else 2.0 ** -8 * max(1.0, np.abs(want).max())), (i, mode, cs, err)
+
+
+def test_random_cropping_at_the_bench_resolution_matches_oracle():
+  """256 x 256 targets with --resize_mode=RESHAPE --do_random_cropping=True from larger sources: the host's own draws
+  (draw_crops on the 320 x 320 intermediate), a batch in one launch, against the float64 oracle; and the loader hands the
+  crop table through its worker threads."""
+  from twingan_amd import data as D
+  rng = np.random.RandomState(12)
+  imgs = [rng.randint(0, 256, (h, w, 3), dtype=np.uint8) for h, w in ((300, 420), (512, 384), (256, 256), (199, 611), (700, 500))]
+  pre = D.Preprocessor(256, device='cuda:0', precision='fp32', resize_mode='RESHAPE', seed=4, do_random_cropping=True)
+  assert pre.mid == 320
+  gen = np.random.default_rng(6)
+  aug, crop = D.draw_augmentation(len(imgs), gen), D.draw_crops(len(imgs), 320, 0.8, gen)
+  assert (crop[:, 2:] >= 256).all() and (crop[:, 2:] < 320).all() and (crop[:, :2] + crop[:, 2:] <= 320).all()
+  out = pre(imgs, aug=aug, crop=crop).cpu().numpy()
+  for k, im in enumerate(imgs):
+    want = N.preprocess_image(im, 256, 'RESHAPE', True, flip=bool(aug[k, 0]), saturation_first=bool(aug[k, 1]),
+                              delta=float(aug[k, 2]), factor=float(aug[k, 3]), crop=tuple(crop[k]))
+    assert np.abs(out[k] - want).max() < 3e-6, k
+  own = pre(imgs)      # every draw from the preprocessor's stream
+  assert own.shape == (5, 256, 256, 3) and float(own.min()) >= 0.0 and float(own.max()) <= 1.0

@@ -457,7 +457,50 @@ def preprocess_fixture(hw=32):
   return out
 
 
+PREPROCESS_MODE_CASES = [      # (h, w, resize_mode, is_training, seed, do_random_cropping, color_space)
+    (37, 53, 'RESHAPE', True, 0, True, 'rgb'),       # the reference's training recipe (docs/training.md:22-23)
+    (64, 40, 'PAD', True, 1, True, 'yiq'), (50, 50, 'CROP', True, 2, True, 'bgr'), (31, 45, 'RESHAPE', True, 3, True, 'gray'),
+    (90, 120, 'PAD', True, 4, True, 'rgb'), (48, 36, 'PAD', False, 5, True, 'rgb'),      # evaluation: the flag is ignored
+    (37, 53, 'RANDOM_CROP', True, 6, False, 'rgb'), (64, 70, 'RANDOM_CROP', True, 7, True, 'rgb'),
+    (20, 45, 'RANDOM_CROP', True, 8, True, 'rgb'), (50, 50, 'RANDOM_CROP', False, 9, False, 'bgr'),
+    (32, 32, 'NONE', True, 10, False, 'rgb'), (33, 47, 'PAD', True, 11, False, 'yiq'), (40, 40, 'RESHAPE', False, 12, False, 'gray')]
+
+
+def preprocess_modes_fixture(hw=32):
+  """The reference's preprocess_image executed on the TF stand-in with --do_random_cropping, the RANDOM_CROP / NONE resize
+  modes and the colour spaces: input, the draws of the live branch (flip, ordering, distortions, both crop rectangles),
+  output; the float64 restatement must reproduce each before it is written."""
+  from oracle import ref_runner
+  rng = np.random.RandomState(23)
+  out = {'hw': np.int64(hw), 'n': np.int64(len(PREPROCESS_MODE_CASES))}
+  for i, (h, w, mode, training, seed, cropping, cs) in enumerate(PREPROCESS_MODE_CASES):
+    img = rng.randint(0, 256, (h, w, 3), dtype=np.uint8)
+    res, dr = ref_runner.run_preprocess(img, hw, mode, training, seed, do_random_cropping=cropping, color_space=cs)
+    applied = dict(dr['applied'])
+    flip = bool(training and dr['flip_uniform'] < 0.5)
+    sat_first = bool(dr['applied'] and dr['applied'][0][0] == 'saturation')
+    moff = None if dr['mode_crop'] is None else dr['mode_crop'][:2]
+    mine = N.preprocess_image(img, hw, mode, training, flip=flip, saturation_first=sat_first,
+                              delta=applied.get('brightness', 0.0), factor=applied.get('saturation', 1.0), crop=dr['crop'],
+                              color_space=cs, mode_offset=moff)
+    assert np.abs(mine - res).max() < 1e-12, (i, np.abs(mine - res).max())
+    assert (dr['crop'] is not None) == (cropping and training)
+    out['img%d' % i] = img
+    out['out%d' % i] = res
+    out['par%d' % i] = np.array([float(flip), float(sat_first), applied.get('brightness', 0.0), applied.get('saturation', 1.0),
+                                 float(training), float(cropping)])
+    out['crop%d' % i] = np.array(dr['crop'] if dr['crop'] is not None else (-1, -1, -1, -1), np.int64)
+    out['moff%d' % i] = np.array(moff if moff is not None else (-1, -1), np.int64)
+    out['mode%d' % i] = np.array(mode)
+    out['cs%d' % i] = np.array(cs)
+  return out
+
+
 if __name__ == '__main__':
+  if '--preprocess-modes' in sys.argv:      # only the fixture of the cropping / resize-mode / colour-space cases
+    np.savez_compressed(os.path.join(OUT, 'preprocess_modes_hw32.npz'), **preprocess_modes_fixture())
+    print('preprocess_modes_hw32.npz', os.path.getsize(os.path.join(OUT, 'preprocess_modes_hw32.npz')))
+    sys.exit(0)
   if '--preprocess' in sys.argv:      # only the input-preprocessing fixture
     np.savez_compressed(os.path.join(OUT, 'preprocess_hw32.npz'), **preprocess_fixture())
     print('preprocess_hw32.npz', os.path.getsize(os.path.join(OUT, 'preprocess_hw32.npz')))

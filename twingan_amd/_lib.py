@@ -65,6 +65,7 @@ SIGNATURES = {
     'tg_allreduce': (c_int, [_P, _P, c_int64, c_int, _P]),
     'tg_comm_destroy': (c_int, [_P]),
     'tg_preprocess_images': (c_int, [_P, _P, _P, _FP, _P, c_int, c_int, c_int, _P]),
+    'tg_preprocess_images_crop': (c_int, [_P, _P, _P, _P, _FP, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'tg_conv2d_fwd_pool_supported': (c_int, [_D]),
     'tg_conv2d_fwd_pool': (c_int, [_D, _P, _P, _FP, _P, _P, _P]),
     'tg_conv2d_fwd_pool_signs': (c_int, [_D, _P, _P, _FP, _P, _P, _P]),

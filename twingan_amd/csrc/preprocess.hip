@@ -9,13 +9,23 @@
 // (preprocessing_util.py:171-205), distort_color in fast mode (danbooru_preprocessing.py:62-113: random_brightness
 // max_delta 32/255 and random_saturation [0.5, 1.5) in one of two orders), tf.clip_by_value(0, 1).  The random draws are
 // inputs (aug[n][4] = flip?, saturation first?, brightness delta, saturation factor): the host draws them.
+//
+// --do_random_cropping (model_inheritor.py:225,449-454; the reference's training recipe sets it, docs/training.md:22-23;
+// danbooru_preprocessing.py:187-201, preprocessing_util.random_crop_image :312-331): the first bilinear resize goes to
+// mid = int(hw / 0.8), tf.random_crop cuts a [ch, cw] rectangle out of that at (cy, cx) (crop[n][4] = cy, cx, ch, cw, drawn
+// by the host), a second bilinear resize brings the rectangle to [hw, hw].  The kernel never materialises the mid x mid
+// image: an output pixel's four taps in the rectangle are each evaluated from their four source taps (16 fetches).
+// --color_space (model_inheritor.py:240,414; danbooru_preprocessing.py:208-225): 'gray' skips the colour distortion,
+// 'yiq' / 'bgr' transform the finished image (preprocessing_util.rgb_to_yiq :154-160, tf.reverse on the channel axis).
 #include "tg_common.h"
 
 namespace {
 
 struct PreGeom {
-  int n, hw;
+  int n, hw, mid, color_space;      // mid: side of the intermediate image (with a crop table); TG_CS_*
 };
+
+enum { TG_CS_RGB = 0, TG_CS_YIQ = 1, TG_CS_BGR = 2, TG_CS_GRAY = 3 };
 
 __device__ __forceinline__ float3 fetch(const uint8_t* img, int h, int w, int y0, int x0, int vy, int vx) {
   // virtual source pixel (vy, vx) -> image pixel (vy + y0, vx + x0); outside the image: the zero padding
@@ -41,55 +51,101 @@ __device__ __forceinline__ float3 saturate(float3 c, float factor) {
   return make_float3(v - (v - c.x) * ratio, v - (v - c.y) * ratio, v - (v - c.z) * ratio);
 }
 
-template <typename T>
+struct Src {      // one decoded image and the rectangle of it (in image coordinates) that the first resize reads
+  const uint8_t* img;
+  int h, w, y0, x0, sh, sw;
+};
+
+// pixel (oy, ox) of ResizeBilinear(source rectangle -> [size, size]), align_corners = False: in = out * (in_size / out_size)
+__device__ __forceinline__ float3 resized(const Src& s, int oy, int ox, float sy, float sx) {
+  const float fy = (float)oy * sy, fx = (float)ox * sx;
+  const int top = (int)floorf(fy), left = (int)floorf(fx);
+  const int bot = min(top + 1, s.sh - 1), right = min(left + 1, s.sw - 1);
+  const float ly = fy - (float)top, lx = fx - (float)left;
+  const float3 t = lerp3(fetch(s.img, s.h, s.w, s.y0, s.x0, top, left), fetch(s.img, s.h, s.w, s.y0, s.x0, top, right), lx);
+  const float3 b = lerp3(fetch(s.img, s.h, s.w, s.y0, s.x0, bot, left), fetch(s.img, s.h, s.w, s.y0, s.x0, bot, right), lx);
+  return lerp3(t, b, ly);
+}
+
+template <typename T, bool CROP>
 __global__ void preprocess_kernel(const uint8_t* __restrict__ packed, const int64_t* __restrict__ offsets,
-                                  const int* __restrict__ rect, const float* __restrict__ aug, T* __restrict__ out,
-                                  PreGeom g) {
+                                  const int* __restrict__ rect, const int* __restrict__ crop,
+                                  const float* __restrict__ aug, T* __restrict__ out, PreGeom g) {
   const int n = blockIdx.y;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= g.hw * g.hw) return;
   int oy = idx / g.hw, ox = idx - oy * g.hw;
   const int* r = rect + n * 6;                         // image h, w; source rectangle y0, x0, sh, sw
-  const int h = r[0], w = r[1], y0 = r[2], x0 = r[3], sh = r[4], sw = r[5];
+  Src s;
+  s.img = packed + offsets[n];
+  s.h = r[0], s.w = r[1], s.y0 = r[2], s.x0 = r[3], s.sh = r[4], s.sw = r[5];
   const float* a = aug + n * 4;
-  const uint8_t* img = packed + offsets[n];
   if (a[0] != 0.f) ox = g.hw - 1 - ox;                 // tf.reverse(image, [1]) of the RESIZED image
-  // ResizeBilinear, align_corners = False: in = out * (in_size / out_size)
-  const float sy = (float)sh / (float)g.hw, sx = (float)sw / (float)g.hw;
-  const float fy = (float)oy * sy, fx = (float)ox * sx;
-  const int top = (int)floorf(fy), left = (int)floorf(fx);
-  const int bot = min(top + 1, sh - 1), right = min(left + 1, sw - 1);
-  const float ly = fy - (float)top, lx = fx - (float)left;
-  const float3 t = lerp3(fetch(img, h, w, y0, x0, top, left), fetch(img, h, w, y0, x0, top, right), lx);
-  const float3 b = lerp3(fetch(img, h, w, y0, x0, bot, left), fetch(img, h, w, y0, x0, bot, right), lx);
-  float3 c = lerp3(t, b, ly);
-  const float delta = a[2], factor = a[3];
-  if (a[1] == 0.f) {                                   // ordering 0: brightness, then saturation
-    c = make_float3(c.x + delta, c.y + delta, c.z + delta);
-    c = saturate(c, factor);
-  } else {                                             // orderings 1-3 (fast mode): saturation, then brightness
-    c = saturate(c, factor);
-    c = make_float3(c.x + delta, c.y + delta, c.z + delta);
+  float3 c;
+  if (CROP) {
+    const int* cr = crop + n * 4;                      // the rectangle tf.random_crop cut out of the mid x mid image
+    const int cy = cr[0], cx = cr[1], ch = cr[2], cw = cr[3];
+    const float sy = (float)s.sh / (float)g.mid, sx = (float)s.sw / (float)g.mid;
+    const float fy = (float)oy * ((float)ch / (float)g.hw), fx = (float)ox * ((float)cw / (float)g.hw);
+    const int top = (int)floorf(fy), left = (int)floorf(fx);
+    const int bot = min(top + 1, ch - 1), right = min(left + 1, cw - 1);
+    const float ly = fy - (float)top, lx = fx - (float)left;
+    const float3 t = lerp3(resized(s, cy + top, cx + left, sy, sx), resized(s, cy + top, cx + right, sy, sx), lx);
+    const float3 b = lerp3(resized(s, cy + bot, cx + left, sy, sx), resized(s, cy + bot, cx + right, sy, sx), lx);
+    c = lerp3(t, b, ly);
+  } else {
+    c = resized(s, oy, ox, (float)s.sh / (float)g.hw, (float)s.sw / (float)g.hw);
+  }
+  if (g.color_space != TG_CS_GRAY) {                   // danbooru_preprocessing.py:208-212: no distort_color for 'gray'
+    const float delta = a[2], factor = a[3];
+    if (a[1] == 0.f) {                                 // ordering 0: brightness, then saturation
+      c = make_float3(c.x + delta, c.y + delta, c.z + delta);
+      c = saturate(c, factor);
+    } else {                                           // orderings 1-3 (fast mode): saturation, then brightness
+      c = saturate(c, factor);
+      c = make_float3(c.x + delta, c.y + delta, c.z + delta);
+    }
+    c = make_float3(fminf(fmaxf(c.x, 0.f), 1.f), fminf(fmaxf(c.y, 0.f), 1.f), fminf(fmaxf(c.z, 0.f), 1.f));
+  }
+  if (g.color_space == TG_CS_YIQ) {                    // preprocessing_util.rgb_to_yiq: tensordot with the fp32 matrix
+    c = make_float3(0.299f * c.x + 0.587f * c.y + 0.114f * c.z, 0.596f * c.x - 0.274f * c.y - 0.322f * c.z,
+                    0.211f * c.x - 0.523f * c.y + 0.312f * c.z);
+  } else if (g.color_space == TG_CS_BGR) {
+    c = make_float3(c.z, c.y, c.x);
   }
   T* o = out + (((int64_t)n * g.hw + oy) * g.hw + (a[0] != 0.f ? g.hw - 1 - ox : ox)) * 3;
-  st(o + 0, fminf(fmaxf(c.x, 0.f), 1.f));
-  st(o + 1, fminf(fmaxf(c.y, 0.f), 1.f));
-  st(o + 2, fminf(fmaxf(c.z, 0.f), 1.f));
+  st(o + 0, c.x);
+  st(o + 1, c.y);
+  st(o + 2, c.z);
 }
 
 }  // namespace
 
-extern "C" int tg_preprocess_images(const void* packed, const int64_t* offsets, const int* rect, const float* aug, void* out,
-                                    int n, int hw, int dtype, void* stream) {
+extern "C" int tg_preprocess_images_crop(const void* packed, const int64_t* offsets, const int* rect, const int* crop,
+                                         const float* aug, void* out, int n, int hw, int mid, int color_space, int dtype,
+                                         void* stream) {
   TG_CHECK(packed && offsets && rect && aug && out && n > 0 && hw > 0, TG_EINVAL, "tg_preprocess_images: bad arguments");
+  TG_CHECK(color_space >= TG_CS_RGB && color_space <= TG_CS_GRAY, TG_EINVAL, "tg_preprocess_images: color_space 0..3");
+  TG_CHECK(!crop || mid >= hw, TG_EINVAL, "tg_preprocess_images: a crop table needs the intermediate size mid >= hw");
   PreGeom g;
   g.n = n;
   g.hw = hw;
+  g.mid = mid;
+  g.color_space = color_space;
   const dim3 grid((hw * hw + 255) / 256, n);
   TG_DISPATCH_DTYPE(dtype, "tg_preprocess_images", {
-    hipLaunchKernelGGL(preprocess_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)packed, offsets, rect,
-                       aug, (T*)out, g);
+    if (crop)
+      hipLaunchKernelGGL((preprocess_kernel<T, true>), grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)packed,
+                         offsets, rect, crop, aug, (T*)out, g);
+    else
+      hipLaunchKernelGGL((preprocess_kernel<T, false>), grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)packed,
+                         offsets, rect, crop, aug, (T*)out, g);
   });
   TG_LAUNCH_CHECK("tg_preprocess_images");
   return TG_OK;
+}
+
+extern "C" int tg_preprocess_images(const void* packed, const int64_t* offsets, const int* rect, const float* aug, void* out,
+                                    int n, int hw, int dtype, void* stream) {
+  return tg_preprocess_images_crop(packed, offsets, rect, nullptr, aug, out, n, hw, 0, TG_CS_RGB, dtype, stream);
 }

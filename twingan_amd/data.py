@@ -164,8 +164,12 @@ class ImageOnlyDataset:
 
 
 # ------------------------------------------------------------------------------------------------ GPU preprocessing
-def source_rect(h, w, resize_mode):
-  """(y0, x0, sh, sw): the rectangle of preprocessing_util.resize_image in image coordinates (see twingan_hip.h)."""
+def source_rect(h, w, resize_mode, new_hw=None, rng=None, offset=None):
+  """(y0, x0, sh, sw): the rectangle of preprocessing_util.resize_image (:97-146) in image coordinates that the first
+  resize reads (see twingan_hip.h).  ``new_hw``: that resize's target (hw, or int(hw / ratio) with random cropping) --
+  RANDOM_CROP (:84-95,126-127,144-146) cuts a [new_hw, new_hw] window at a uniform offset (``rng``) out of an image at
+  least that large, which the resize then copies 1:1, and resizes a smaller image whole; NONE (:137-139) takes the image
+  as it is, so it must already have the target size.  ``offset`` = (oy, ox): the window's position instead of a draw (tests)."""
   if resize_mode == 'PAD':
     size = max(h, w)
     return (-((size - h) // 2), -((size - w) // 2), size, size)
@@ -174,7 +178,18 @@ def source_rect(h, w, resize_mode):
     return ((h - size) // 2, (w - size) // 2, size, size)
   if resize_mode == 'RESHAPE':
     return (0, 0, h, w)
-  raise ValueError('resize_mode %s (PAD, CROP and RESHAPE are built)' % resize_mode)
+  if resize_mode == 'RANDOM_CROP':
+    if new_hw > min(h, w):
+      return (0, 0, h, w)
+    oy, ox = offset if offset is not None else (rng.integers(0, h - new_hw + 1), rng.integers(0, w - new_hw + 1))
+    assert 0 <= oy <= h - new_hw and 0 <= ox <= w - new_hw
+    return (int(oy), int(ox), new_hw, new_hw)
+  if resize_mode == 'NONE':
+    if (h, w) != (new_hw, new_hw):
+      raise ValueError('resize_mode NONE: a %d x %d image where the networks take %d x %d' % (h, w, new_hw, new_hw))
+    return (0, 0, h, w)
+  # RANDOM_CROP_AND_RESHAPE (:128-131) crops to --random_crop_and_reshape_initial_crop_hw and may resize twice: not built
+  raise ValueError('resize_mode %s (PAD, CROP, RESHAPE, RANDOM_CROP and NONE are built)' % resize_mode)
 
 
 def draw_augmentation(n, rng):
@@ -190,18 +205,48 @@ def draw_augmentation(n, rng):
   return aug
 
 
-class Preprocessor:
-  """preprocess_image for a batch of decoded images on the GPU.  ``aug`` given explicitly (tests) or drawn from
-  ``rng``; evaluation (is_training=False) resizes only."""
+RANDOM_CROP_RATIO = 0.8                                        # danbooru_preprocessing.py:33
+COLOR_SPACES = {'rgb': 0, 'yiq': 1, 'bgr': 2, 'gray': 3}       # danbooru_preprocessing.py:31; TG_CS_* of preprocess.hip
 
-  def __init__(self, hw, device='cuda', precision='bf16', resize_mode='PAD', is_training=True, seed=0):
+
+def draw_crops(n, mid, ratio, rng):
+  """The draws of preprocessing_util.random_crop_image (:312-331) on the [mid, mid] image for n images -> int32 [n, 4] =
+  (cy, cx, ch, cw): ch = int32(mid * U[ratio, 1)), cw likewise from its own draw (the products are formed in float32, as
+  the graph does, and truncated), then tf.random_crop's offsets, uniform over [0, mid - size]."""
+  crop = np.empty((n, 4), np.int32)
+  for col in (2, 3):
+    u = np.minimum(rng.uniform(ratio, 1.0, n).astype(np.float32), np.nextafter(np.float32(1.0), np.float32(0.0)))
+    crop[:, col] = (np.float32(mid) * u).astype(np.int32)
+  crop[:, 0] = rng.integers(0, mid - crop[:, 2] + 1)
+  crop[:, 1] = rng.integers(0, mid - crop[:, 3] + 1)
+  return crop
+
+
+class Preprocessor:
+  """preprocess_image for a batch of decoded images on the GPU.  ``aug`` (and ``crop``) given explicitly (tests) or
+  drawn from ``rng``; evaluation (is_training=False) resizes only.  ``do_random_cropping`` / ``color_space``: the flags of
+  model_inheritor.py:225,240 (the reference's training recipe, docs/training.md:22-23, is --resize_mode=RESHAPE
+  --do_random_cropping=True)."""
+
+  def __init__(self, hw, device='cuda', precision='bf16', resize_mode='PAD', is_training=True, seed=0,
+               do_random_cropping=False, random_cropping_ratio=RANDOM_CROP_RATIO, color_space='rgb'):
     self.hw, self.device = int(hw), torch.device(device)
     self.dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[precision]
     self.resize_mode, self.is_training = resize_mode, is_training
+    assert color_space in COLOR_SPACES, 'color_space must be one of %s' % sorted(COLOR_SPACES)      # _check_color_space
+    self.color_space = color_space
+    # danbooru_preprocessing.py:187-190: only a TRAINING call crops; the first resize then goes to int(hw / ratio)
+    self.crops = bool(do_random_cropping and is_training)
+    assert not (self.crops and resize_mode == 'NONE'), 'random cropping of unresized images is not built'
+    self.ratio = float(random_cropping_ratio)
+    self.mid = int(self.hw / self.ratio) if self.crops else 0
     self.rng = np.random.default_rng(seed)
 
-  def pack(self, images, aug=None):
-    """Host side: one pinned uint8 buffer + the per-image tables."""
+  def pack(self, images, aug=None, crop=None, rng=None, mode_offsets=None):
+    """Host side: one pinned uint8 buffer + the per-image tables (+ the crop table when cropping is on).  ``rng``: the
+    caller's random stream (loader workers own one each); default: the preprocessor's.  ``mode_offsets``: per image the
+    RANDOM_CROP window's (oy, ox) or None (tests feed the reference's draws)."""
+    rng = rng or self.rng
     n = len(images)
     sizes = [int(im.shape[0]) * int(im.shape[1]) * 3 for im in images]
     offsets = np.zeros(n, np.int64)
@@ -212,39 +257,53 @@ class Preprocessor:
     for i, im in enumerate(images):
       assert im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3, 'decoded RGB uint8 images'
       flat[offsets[i]:offsets[i] + sizes[i]] = np.ascontiguousarray(im).reshape(-1)
-      rect[i] = (im.shape[0], im.shape[1]) + source_rect(im.shape[0], im.shape[1], self.resize_mode)
+      rect[i] = (im.shape[0], im.shape[1]) + source_rect(im.shape[0], im.shape[1], self.resize_mode,
+                                                         self.mid if self.crops else self.hw, rng,
+                                                         None if mode_offsets is None else mode_offsets[i])
     if aug is None:
-      aug = draw_augmentation(n, self.rng) if self.is_training else np.tile(np.float32([0, 0, 0, 1]), (n, 1))
-    return buf, torch.from_numpy(offsets), torch.from_numpy(rect), torch.from_numpy(np.ascontiguousarray(aug, np.float32))
+      aug = draw_augmentation(n, rng) if self.is_training else np.tile(np.float32([0, 0, 0, 1]), (n, 1))
+    tables = (buf, torch.from_numpy(offsets), torch.from_numpy(rect), torch.from_numpy(np.ascontiguousarray(aug, np.float32)))
+    if not self.crops:
+      assert crop is None, 'a crop table without do_random_cropping (or in evaluation mode)'
+      return tables
+    if crop is None:
+      crop = draw_crops(n, self.mid, self.ratio, rng)
+    crop = np.ascontiguousarray(crop, np.int32).reshape(n, 4)
+    assert (crop[:, :2] >= 0).all() and (crop[:, 2:] >= 1).all() and (crop[:, :2] + crop[:, 2:] <= self.mid).all(), \
+        'crop rectangles must lie inside the %d x %d intermediate image' % (self.mid, self.mid)
+    return tables + (torch.from_numpy(crop),)
 
-  def __call__(self, images, aug=None, stream=None):
-    buf, offsets, rect, augt = self.pack(images, aug)
-    return self.run(buf, offsets, rect, augt, stream)
+  def __call__(self, images, aug=None, stream=None, crop=None, mode_offsets=None):
+    return self.run(*self.pack(images, aug, crop, mode_offsets=mode_offsets), stream=stream)
 
-  def run(self, buf, offsets, rect, aug, stream=None):
+  def run(self, buf, offsets, rect, aug, crop=None, stream=None):
     if self.device.type != 'cuda':
       raise RuntimeError('the preprocessing kernel needs a GPU (there is no CPU fallback)')
     n = offsets.numel()
+    assert (crop is not None) == self.crops
     with torch.cuda.device(self.device):
       st = stream or torch.cuda.current_stream()
       with torch.cuda.stream(st):
-        d = [t.to(self.device, non_blocking=True) for t in (buf, offsets, rect, aug)]
+        d = [t.to(self.device, non_blocking=True) for t in (buf, offsets, rect, aug) + ((crop,) if self.crops else ())]
         out = torch.empty((n, self.hw, self.hw, 3), dtype=self.dtype, device=self.device)
-        call('tg_preprocess_images', d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), out.data_ptr(), n,
-             self.hw, {torch.bfloat16: TG_BF16, torch.float16: TG_F16, torch.float32: TG_F32}[self.dtype], st.cuda_stream)
+        call('tg_preprocess_images_crop', d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(),
+             d[4].data_ptr() if self.crops else 0, d[3].data_ptr(), out.data_ptr(), n, self.hw, self.mid,
+             COLOR_SPACES[self.color_space], {torch.bfloat16: TG_BF16, torch.float16: TG_F16, torch.float32: TG_F32}[self.dtype],
+             st.cuda_stream)
         for t in d:
           t.record_stream(st)
     return out
 
 
 # ------------------------------------------------------------------------------------------------ loader
-def _process_main(files, key, batch_size, hw, resize_mode, is_training, shuffle, pool_size, seed, out_q, stop):
+def _process_main(files, key, batch_size, hw, resize_mode, is_training, shuffle, pool_size, seed, out_q, stop,
+                  crop_kw=None):
   """A decode worker PROCESS of Loader(processes=P): its own file shard, shuffling pool and random stream; puts packed
   batches (shared-memory tensors) on ``out_q``."""
   torch.set_num_threads(1)
   ds = ImageOnlyDataset.__new__(ImageOnlyDataset)
   ds.files, ds.key = list(files), key
-  pre = Preprocessor(hw, device='cpu', resize_mode=resize_mode, is_training=is_training)
+  pre = Preprocessor(hw, device='cpu', resize_mode=resize_mode, is_training=is_training, **(crop_kw or {}))
   rng = np.random.default_rng(seed)
   held = []
   want = max(1, pool_size) if shuffle else 1
@@ -266,9 +325,8 @@ def _process_main(files, key, batch_size, hw, resize_mode, is_training, shuffle,
     held[k], held[-1] = held[-1], held[k]
     images.append(ds.decode(held.pop())[0])
     if len(images) == batch_size:
-      buf, offsets, rect, aug = pre.pack(images, draw_augmentation(batch_size, rng) if is_training else None)
+      item = tuple(t.share_memory_() for t in pre.pack(images, rng=rng))
       images = []
-      item = tuple(t.share_memory_() for t in (buf, offsets, rect, aug))
       while not stop.is_set():
         try:
           out_q.put(item, timeout=0.1)
@@ -304,7 +362,8 @@ class Loader:
         pr = ctx.Process(target=_process_main, daemon=True,
                          args=(mine, dataset.key, self.bs, preprocessor.hw, preprocessor.resize_mode,
                                preprocessor.is_training, shuffle, max(1, self.pool_size // processes), seed + 1 + r,
-                               self.batches, self.stop))
+                               self.batches, self.stop,
+                               dict(do_random_cropping=preprocessor.crops, random_cropping_ratio=preprocessor.ratio)))
         pr.start()
         self.procs.append(pr)
       return
@@ -354,7 +413,7 @@ class Loader:
         held[k], held[-1] = held[-1], held[k]
         images.append(self.ds.decode(held.pop())[0])
       if len(images) == self.bs:
-        packed = self.pre.pack(images, draw_augmentation(self.bs, rng) if self.pre.is_training else None)
+        packed = self.pre.pack(images, rng=rng)
         while not self.stop.is_set():
           try:
             self.batches.put(packed, timeout=0.1)
@@ -394,9 +453,10 @@ class TwoDomainBatches:
   changes, as the reference rebuilds its graph per stage."""
 
   def __init__(self, source_dir, target_dir, device='cuda', precision='bf16', split='train', resize_mode='PAD',
-               processes=0, num_workers=8, seed=0):
+               processes=0, num_workers=8, seed=0, do_random_cropping=False, color_space='rgb'):
     self.dirs = (source_dir, target_dir)
-    self.kw = dict(device=device, precision=precision, resize_mode=resize_mode)
+    self.kw = dict(device=device, precision=precision, resize_mode=resize_mode, do_random_cropping=do_random_cropping,
+                   color_space=color_space)
     self.split, self.processes, self.num_workers, self.seed = split, processes, num_workers, seed
     self.key, self.loaders = None, ()
 
