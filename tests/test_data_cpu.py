@@ -233,3 +233,39 @@ def test_crop_draws_and_resize_modes():
       [5, 10, 20, 40, 80, 160, 320, 640]
   with pytest.raises(AssertionError):
     D.Preprocessor(32, device='cpu', color_space='hsv')
+
+
+def test_embedding_dataset_records_and_fields(tmp_path):
+  """datasets/celeba_facenet.py:86-118: an image + 'image/embedding' FixedLenFeature; decode() hands the vector over as the
+  item 'embedding'; a record of the wrong length is an error; the batch stacker gives [batch, size] fp32; unknown dataset
+  names are refused as dataset_factory.py:77-78 does."""
+  from PIL import Image
+  rng = np.random.RandomState(5)
+  recs, embs, imgs = [], [], []
+  for i in range(6):
+    a = rng.randint(0, 256, (12 + i, 10, 3), dtype=np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(a).save(buf, format='PNG')
+    e = rng.randn(8).astype(np.float32)
+    recs.append(D.embedding_example(buf.getvalue(), e, 'png', 'f%d' % i, **{'image/attribs': [1, 0, 1]}))
+    embs.append(e)
+    imgs.append(a)
+  recs.append(D.embedding_example(buf.getvalue(), rng.randn(7), 'png', 'short'))
+  D.write_tfrecords(str(tmp_path / 'train-00000-of-00001'), recs)
+  ds = D.EmbeddingImageDataset(str(tmp_path), 'train', embedding_size=8)
+  assert D.DATASETS['celeba_facenet'] is D.EmbeddingImageDataset and D.EMBEDDING_SIZE == 512
+  payloads = list(ds.records())
+  decoded = [ds.decode(p) for p in payloads[:6]]
+  for i, (im, name, fields) in enumerate(decoded):
+    np.testing.assert_array_equal(im, imgs[i])
+    assert name == 'f%d' % i and fields['embedding'].dtype == np.float32
+    np.testing.assert_array_equal(fields['embedding'], embs[i])      # float32 survives the tf.Example float list bit-exactly
+  with pytest.raises(ValueError):
+    ds.decode(payloads[6])
+  stacked = D._stack_fields(decoded[:4])
+  assert set(stacked) == {'embedding'} and tuple(stacked['embedding'].shape) == (4, 8) and stacked['embedding'].dtype == torch.float32
+  assert D._stack_fields([(imgs[0], 'x')]) is None                      # an image-only dataset has no further fields
+  two = D.TwoDomainBatches(str(tmp_path), str(tmp_path), device='cpu', dataset_names=('celeba_facenet', 'svhn'))
+  with pytest.raises(ValueError):
+    two._dataset(1, str(tmp_path))
+  assert isinstance(two._dataset(0, str(tmp_path)), D.EmbeddingImageDataset)

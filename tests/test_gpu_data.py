@@ -222,3 +222,58 @@ def test_random_cropping_at_the_bench_resolution_matches_oracle():
     assert np.abs(out[k] - want).max() < 3e-6, k
   own = pre(imgs)      # every draw from the preprocessor's stream
   assert own.shape == (5, 256, 256, 3) and float(own.min()) >= 0.0 and float(own.max()) <= 1.0
+
+
+def test_distillation_trains_from_an_embedding_dataset(tmp_path):
+  """--do_encoder_distillation end to end on files (twingan.py:103,162-177,507-521): the source domain is a
+  celeba_facenet-style dataset (image + 'image/embedding', datasets/celeba_facenet.py:86-99), the target an image-only
+  one; the loader hands the embeddings of exactly the images of the batch to the trainer (evaluation order checked
+  against the file), run_progressive passes them on as distill_embed_s, and the distillation terms of the source side
+  (and only those) appear in the loss."""
+  from PIL import Image
+  from twingan_amd import Config, data as D
+  from twingan_amd.runner import run_progressive
+  from twingan_amd.twingan import Trainer
+  rng = np.random.RandomState(7)
+  embs = rng.randn(12, 6).astype(np.float32)
+  for dom in ('a', 'b'):
+    recs = []
+    for i in range(12):
+      yy, xx = np.mgrid[0:24, 0:20]
+      a = np.clip(np.stack([yy * 7 + i, xx * 9, yy + xx + 11 * i], axis=-1) % 256, 0, 255).astype(np.uint8)
+      buf = io.BytesIO()
+      Image.fromarray(a).save(buf, format='PNG')
+      recs.append(D.embedding_example(buf.getvalue(), embs[i], 'png', 'a%d' % i) if dom == 'a'
+                  else D.image_example(buf.getvalue(), 'png', 'b%d' % i))
+    os.makedirs(tmp_path / dom)
+    D.write_tfrecords(str(tmp_path / dom / 'train-00000-of-00001'), recs)
+  # the loader keeps image and embedding together: evaluation order, no shuffling
+  ds = D.EmbeddingImageDataset(str(tmp_path / 'a'), 'train', embedding_size=6)
+  ev = D.Loader(ds, 4, D.Preprocessor(16, device='cuda:0', precision='fp32', is_training=False), num_readers=1, num_workers=1,
+                shuffle=False)
+  try:
+    for b in range(3):
+      images, fields = ev.next()
+      assert images.shape == (4, 16, 16, 3) and fields['embedding'].is_cuda
+      np.testing.assert_array_equal(fields['embedding'].cpu().numpy(), embs[b * 4:b * 4 + 4])
+  finally:
+    ev.close()
+  batches = D.TwoDomainBatches(str(tmp_path / 'a'), str(tmp_path / 'b'), device='cuda:0', precision='bf16', num_workers=2, seed=1,
+                               dataset_names=('celeba_facenet', 'image_only'), embedding_size=6, resize_mode='RESHAPE',
+                               do_random_cropping=True)
+  cfg = Config(hw=16, max_ch=16, precision='bf16', do_encoder_distillation=True, distill_embed_dim=6, distillation_weight=0.5)
+  try:
+    s, t, extras = batches(16, 4)
+    assert set(extras) == {'distill_embed_s'} and tuple(extras['distill_embed_s'].shape) == (4, 6)
+    rows = {tuple(np.round(r, 5)) for r in embs}
+    assert all(tuple(np.round(r, 5)) in rows for r in extras['distill_embed_s'].cpu().numpy())
+    tr = Trainer(cfg, device='cuda:0', seed=3)
+    loss, terms = tr.run(s, t, **extras)
+    assert {'l_source_distillation', 'l_t_prime_distillation'} <= set(terms) and 'l_target_distillation' not in terms
+    assert 0.0 <= float(terms['l_source_distillation']) <= 2.0 * 0.5      # weight * (1 - cos) per image, averaged
+    tr.close()
+    state, hist = run_progressive(cfg, batches, 16, 16, {16: 4}, num_images_per_resolution=8, device='cuda:0', seed=2,
+                                  max_steps_per_stage=2)
+  finally:
+    batches.close()
+  assert [h['stage'] for h in hist] == ['16'] and all(torch.isfinite(v).all() for v in state.values())

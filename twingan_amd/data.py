@@ -163,6 +163,44 @@ class ImageOnlyDataset:
       yield self.decode(rec)
 
 
+EMBEDDING_SIZE = 512      # datasets/celeba_facenet.py:45 DEFAULT_ENCODING_SIZE
+
+
+def embedding_example(image_bytes, embedding, fmt='jpeg', filename='', **more):
+  """A record of an image + embedding dataset as datasets/celeba_facenet.py:86-99 reads it: image/encoded, image/format,
+  image/filename and the float vector image/embedding (FaceNet's 512 numbers there); ``more``: further features
+  (image/attribs, image/landmarks ... are decoded by the reference but not consumed by the TwinGAN trainer)."""
+  feats = {'image/encoded': image_bytes, 'image/format': fmt, 'image/filename': filename,
+           'image/embedding': [float(v) for v in np.asarray(embedding, np.float32).reshape(-1)]}
+  feats.update(more)
+  return encode_example(feats)
+
+
+class EmbeddingImageDataset(ImageOnlyDataset):
+  """datasets/celeba_facenet.get_split (:50-118; `--dataset_name celeba_facenet`, dataset_factory.py:50-58): images with a
+  precomputed embedding per image -- the item 'embedding' that the trainer reads back as 'a_embedding' / 'b_embedding'
+  for --do_encoder_distillation (twingan.py:103,162-177).  decode() -> (image, filename, {'embedding': fp32 [size]});
+  ``embedding_size`` = the FixedLenFeature's length (a record of another length is an error, as in tf.parse_example)."""
+  fields = ('embedding',)
+
+  def __init__(self, dataset_dir, split='train', file_pattern='%s-*', key='image/encoded', embedding_size=EMBEDDING_SIZE):
+    ImageOnlyDataset.__init__(self, dataset_dir, split, file_pattern, key)
+    self.embedding_size = int(embedding_size)
+
+  def decode(self, payload):
+    ex = decode_example(payload)
+    fmt = ex.get('image/format', [b'jpeg'])
+    name = ex.get('image/filename', [b''])
+    emb = np.asarray(ex.get('image/embedding', ()), np.float32)
+    if emb.shape != (self.embedding_size,):
+      raise ValueError('image/embedding: expected %d floats, the record holds %d' % (self.embedding_size, emb.size))
+    return (decode_image(ex[self.key][0], fmt[0] if fmt else b'jpeg'), (name[0].decode() if name else ''),
+            {'embedding': emb})
+
+
+DATASETS = {'image_only': ImageOnlyDataset, 'celeba_facenet': EmbeddingImageDataset}      # of datasets/dataset_factory.py:50-58
+
+
 # ------------------------------------------------------------------------------------------------ GPU preprocessing
 def source_rect(h, w, resize_mode, new_hw=None, rng=None, offset=None):
   """(y0, x0, sh, sw): the rectangle of preprocessing_util.resize_image (:97-146) in image coordinates that the first
@@ -296,13 +334,23 @@ class Preprocessor:
 
 
 # ------------------------------------------------------------------------------------------------ loader
+def _stack_fields(decoded):
+  """The per-image field dictionaries of a batch (EmbeddingImageDataset.decode()[2]) -> {name: fp32 tensor [batch, size]};
+  None for an image-only dataset."""
+  if len(decoded[0]) < 3:
+    return None
+  return {k: torch.from_numpy(np.stack([d[2][k] for d in decoded])) for k in decoded[0][2]}
+
+
 def _process_main(files, key, batch_size, hw, resize_mode, is_training, shuffle, pool_size, seed, out_q, stop,
-                  crop_kw=None):
+                  crop_kw=None, ds_state=None):
   """A decode worker PROCESS of Loader(processes=P): its own file shard, shuffling pool and random stream; puts packed
   batches (shared-memory tensors) on ``out_q``."""
   torch.set_num_threads(1)
-  ds = ImageOnlyDataset.__new__(ImageOnlyDataset)
+  ds_cls, ds_attrs = ds_state or (ImageOnlyDataset, {})
+  ds = ds_cls.__new__(ds_cls)
   ds.files, ds.key = list(files), key
+  ds.__dict__.update(ds_attrs)
   pre = Preprocessor(hw, device='cpu', resize_mode=resize_mode, is_training=is_training, **(crop_kw or {}))
   rng = np.random.default_rng(seed)
   held = []
@@ -323,9 +371,11 @@ def _process_main(files, key, batch_size, hw, resize_mode, is_training, shuffle,
       continue
     k = int(rng.integers(len(held))) if shuffle else 0
     held[k], held[-1] = held[-1], held[k]
-    images.append(ds.decode(held.pop())[0])
+    images.append(ds.decode(held.pop()))
     if len(images) == batch_size:
-      item = tuple(t.share_memory_() for t in pre.pack(images, rng=rng))
+      fields = _stack_fields(images)
+      item = (tuple(t.share_memory_() for t in pre.pack([d[0] for d in images], rng=rng)),
+              None if fields is None else {k: v.share_memory_() for k, v in fields.items()})
       images = []
       while not stop.is_set():
         try:
@@ -363,7 +413,8 @@ class Loader:
                          args=(mine, dataset.key, self.bs, preprocessor.hw, preprocessor.resize_mode,
                                preprocessor.is_training, shuffle, max(1, self.pool_size // processes), seed + 1 + r,
                                self.batches, self.stop,
-                               dict(do_random_cropping=preprocessor.crops, random_cropping_ratio=preprocessor.ratio)))
+                               dict(do_random_cropping=preprocessor.crops, random_cropping_ratio=preprocessor.ratio),
+                               (type(dataset), {k: v for k, v in dataset.__dict__.items() if k not in ('files', 'key')})))
         pr.start()
         self.procs.append(pr)
       return
@@ -411,9 +462,9 @@ class Loader:
           continue
         k = int(rng.integers(len(held))) if self.shuffle else 0
         held[k], held[-1] = held[-1], held[k]
-        images.append(self.ds.decode(held.pop())[0])
+        images.append(self.ds.decode(held.pop()))
       if len(images) == self.bs:
-        packed = self.pre.pack(images, rng=rng)
+        packed = (self.pre.pack([d[0] for d in images], rng=rng), _stack_fields(images))
         while not self.stop.is_set():
           try:
             self.batches.put(packed, timeout=0.1)
@@ -422,13 +473,20 @@ class Loader:
             continue
 
   def next(self):
-    packed = self.batches.get()
+    """-> images [batch, hw, hw, 3] on the device; for a dataset with further fields (EmbeddingImageDataset):
+    (images, {field: fp32 device tensor [batch, size]})."""
+    packed, fields = self.batches.get()
     out = self.pre.run(*packed, stream=self.stream)
+    if fields is not None:
+      with torch.cuda.stream(self.stream):
+        fields = {k: v.to(self.pre.device, non_blocking=True) for k, v in fields.items()}
     if self.stream is not None:
       cur = torch.cuda.current_stream(self.pre.device)
       cur.wait_stream(self.stream)
       out.record_stream(cur)
-    return out
+      for v in (fields or {}).values():
+        v.record_stream(cur)
+    return out if fields is None else (out, fields)
 
   def close(self):
     self.stop.set()
@@ -453,8 +511,10 @@ class TwoDomainBatches:
   changes, as the reference rebuilds its graph per stage."""
 
   def __init__(self, source_dir, target_dir, device='cuda', precision='bf16', split='train', resize_mode='PAD',
-               processes=0, num_workers=8, seed=0, do_random_cropping=False, color_space='rgb'):
+               processes=0, num_workers=8, seed=0, do_random_cropping=False, color_space='rgb',
+               dataset_names=('image_only', 'image_only'), embedding_size=EMBEDDING_SIZE):
     self.dirs = (source_dir, target_dir)
+    self.dataset_names, self.embedding_size = tuple(dataset_names), embedding_size
     self.kw = dict(device=device, precision=precision, resize_mode=resize_mode, do_random_cropping=do_random_cropping,
                    color_space=color_space)
     self.split, self.processes, self.num_workers, self.seed = split, processes, num_workers, seed
@@ -464,11 +524,26 @@ class TwoDomainBatches:
     if self.key != (hw, batch_size):
       self.close()
       self.loaders = tuple(
-          Loader(ImageOnlyDataset(d, self.split), batch_size, Preprocessor(hw, seed=self.seed + 17 * i, **self.kw),
+          Loader(self._dataset(i, d), batch_size, Preprocessor(hw, seed=self.seed + 17 * i, **self.kw),
                  num_workers=self.num_workers, processes=self.processes, seed=self.seed + 1000 * i)
           for i, d in enumerate(self.dirs))
       self.key = (hw, batch_size)
-    return self.loaders[0].next(), self.loaders[1].next()
+    s, t = self.loaders[0].next(), self.loaders[1].next()
+    extras = {}
+    # the provider's 'a_embedding' / 'b_embedding' (twingan.py:103,162-177): whichever dataset carries embeddings
+    if isinstance(s, tuple):
+      s, extras['distill_embed_s'] = s[0], s[1]['embedding']
+    if isinstance(t, tuple):
+      t, extras['distill_embed_t'] = t[0], t[1]['embedding']
+    return (s, t, extras) if extras else (s, t)
+
+  def _dataset(self, i, d):
+    name = self.dataset_names[i]
+    if name not in DATASETS:
+      raise ValueError('Name of dataset unknown %s' % name)      # dataset_factory.py:77-78
+    if name == 'celeba_facenet':
+      return EmbeddingImageDataset(d, self.split, embedding_size=self.embedding_size)
+    return ImageOnlyDataset(d, self.split)
 
   def close(self):
     for ld in self.loaders:

@@ -55,7 +55,8 @@ def run_progressive(base_cfg, batch_fn, start_hw=4, max_hw=256, hw_to_batch_size
                     device='cuda', seed=0, max_steps_per_stage=None, use_graph=False, on_stage_end=None, train_dir=None,
                     save_interval_secs=600, save_interval_steps=None, max_to_keep=5):
   """Trains stage after stage.  ``batch_fn(hw, batch_size)`` -> (sources, targets) device tensors, or
-  (sources, targets, gp_alpha_s, gp_alpha_t) to fix the gradient-penalty interpolation draws (tests).
+  (sources, targets, gp_alpha_s, gp_alpha_t) to fix the gradient-penalty interpolation draws (tests); a trailing dict
+  holds further dataset fields for Trainer.run (distill_embed_s / distill_embed_t of --do_encoder_distillation).
   One reference "step" (global_step) = one generator apply = ``n_critic`` runs (image_generation.py:640-652).
   Growing stages re-create ``alpha_grow`` every step, so they launch eagerly (a captured graph bakes alpha in).
   ``train_dir``: the reference's directory protocol (pggan_runner.py:100-160) over TF-format checkpoints
@@ -96,7 +97,11 @@ def run_progressive(base_cfg, batch_fn, start_hw=4, max_hw=256, hw_to_batch_size
       if growing:
         tr.cfg.alpha_grow = alpha_grow(step, steps)
       for _ in range(cfg.n_critic):
-        tr.run(*batch_fn(hw, bsz))
+        batch = batch_fn(hw, bsz)
+        if isinstance(batch[-1], dict):      # further dataset fields (data.TwoDomainBatches: distill_embed_s / _t)
+          tr.run(*batch[:-1], **batch[-1])
+        else:
+          tr.run(*batch)
       if cur_dir and step + 1 < steps and (
           (save_interval_steps and (step + 1) % save_interval_steps == 0) or
           (save_interval_secs and time.time() - last_save >= save_interval_secs)):
