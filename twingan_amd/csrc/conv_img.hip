@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_img_kernel(const bf16* __restrict
     const int ch0 = n0 + q * 8;
     const int p = m * 32 + l31;      // pixel inside the workgroup's images (images are contiguous in NHWC)
     const bool ok = kgrp == 0 && ch0 + 8 <= g.cout;      // pixels of images past the batch fall outside `ry`
-    __builtin_amdgcn_raw_buffer_store_b128(o, ry, ok ? (unsigned)((p * g.cout + ch0) * 2) : IOOB, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(o, ry, ok ? (unsigned)((p * g.cout + ch0) * 2) : IOOB, 0, TG_STORE_AUX);
   }
 }
 

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict_
     const int ch0 = n0 + q * 8;
     const int p = pbase + m * 32;
     const bool ok = kgrp == 0 && p < g.npix && ch0 + 8 <= g.cout;
-    __builtin_amdgcn_raw_buffer_store_b128(o, ry, ok ? (unsigned)((p * g.cout + ch0) * 2) : SOOB, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(o, ry, ok ? (unsigned)((p * g.cout + ch0) * 2) : SOOB, 0, TG_STORE_AUX);
   }
 }
 

@@ -403,8 +403,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
       }
       const int ch0 = n0 + nt * 32 + kgrp * 16;
       const unsigned off = (unsigned)(((oy * g.w + ox) * g.cout + ch0) * 2);
-      __builtin_amdgcn_raw_buffer_store_b128(o0, ry, (ch0 + 8 <= g.cout) ? off : OOB, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(o1, ry, (ch0 + 16 <= g.cout) ? off + 16 : OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(o0, ry, (ch0 + 8 <= g.cout) ? off : OOB, 0, TG_STORE_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(o1, ry, (ch0 + 16 <= g.cout) ? off + 16 : OOB, 0, TG_STORE_AUX);
       if constexpr (POOL) {
         if (g.ymask) {      // uniform: the sign bits of this lane's 16 channels (y itself is not stored: ry has size 0)
           const unsigned bits = sign_bits16(o0, o1);
@@ -673,8 +673,8 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
       }
       const int ch0 = n0 + nt * 32 + kgrp * 16;
       const unsigned off = (unsigned)(((oy * g.w + ox) * g.cout + ch0) * 2);
-      __builtin_amdgcn_raw_buffer_store_b128(o0, ry, (ch0 + 8 <= g.cout) ? off : OOB, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(o1, ry, (ch0 + 16 <= g.cout) ? off + 16 : OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(o0, ry, (ch0 + 8 <= g.cout) ? off : OOB, 0, TG_STORE_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(o1, ry, (ch0 + 16 <= g.cout) ? off + 16 : OOB, 0, TG_STORE_AUX);
       if constexpr (POOL) {
         if (g.ymask) {      // uniform: the sign bits of this lane's 16 channels (y itself is not stored: ry has size 0)
           const unsigned bits = sign_bits16(o0, o1);

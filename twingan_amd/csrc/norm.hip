@@ -40,6 +40,17 @@ struct VecIO {
       stv(p, v);
     }
   }
+  // the full-resolution output streams: wave-uniform base + 32-bit element offset (TG_STORE_AUX picks the cache policy)
+  __device__ static __forceinline__ void store_stream(T* base, unsigned off, const float* o) {
+    if constexpr (V == 1) {
+      st(base + off, o[0]);
+    } else {
+      Vec16<T> v;
+#pragma unroll
+      for (int j = 0; j < V; ++j) v.set(j, o[j]);
+      stv_stream(base, off, v);
+    }
+  }
 };
 
 // Incoming layer-output gradient of pixel (n, p) = gz[n,p] (may be NULL) + scale * gzp[n, y/2, x/2] (may be NULL):
@@ -370,7 +381,7 @@ __global__ void norm_act_fwd_part_kernel(const T* __restrict__ y, const float* _
         for (int j = 0; j < V; ++j) x[u][j] *= q;
         if (pn_n && v == 0 && live) pn_n[px[u]] = q;
       }
-      if (live) VecIO<T, V>::store(z_n + (px[u] * c + v * V), x[u]);
+      if (live) VecIO<T, V>::store_stream(z_n, px[u] * c + v * V, x[u]);
       if (POOL) {
 #pragma unroll
         for (int j = 0; j < V; ++j) pooled[j] += rnd<T>(x[u][j]);      // the pool reads the stored (rounded) z
@@ -597,7 +608,7 @@ __global__ void norm_act_bwd2_part_kernel(const T* __restrict__ gz, const T* __r
         norm_act_gu<V>(gq[q], xq[q], sq[q], mu, rs, ga, be, flags, alpha, cv, inv_c, yh);
 #pragma unroll
         for (int j = 0; j < V; ++j) gq[q][j] = gr[j] * (gq[q][j] - s1[j] - yh[j] * s2[j]);
-        if (!TAIL || p < (unsigned)p1) VecIO<T, V>::store(gy_n + (p * c + v * V), gq[q]);
+        if (!TAIL || p < (unsigned)p1) VecIO<T, V>::store_stream(gy_n, p * c + v * V, gq[q]);
       }
     }
   };
@@ -728,6 +739,10 @@ __global__ void lrelu_bwd_bias_kernel(const T* __restrict__ gz, const T* __restr
             g[u][j] = rnd<T>(g[u][j] * (zz[u][j] > 0.f ? 1.f : alpha));
             a[j] += g[u][j];
           }
+#if TG_STORE_AUX
+          if (npix * c < (1ll << 31)) VecIO<T, V>::store_stream(gy, (unsigned)(p * c + v * V), g[u]);
+          else
+#endif
           VecIO<T, V>::store(gy + p * c + v * V, g[u]);
         }
       }

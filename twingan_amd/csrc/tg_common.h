@@ -94,6 +94,21 @@ template <typename T> __device__ __forceinline__ void stv(T* p, const Vec16<T>& 
   *reinterpret_cast<Vec16<T>*>(p) = v;
 }
 
+// Cache policy of the big streaming stores (the `aux` operand of a raw buffer store: 0 plain, 2 nt, 16 sc1, 17 sc0 sc1).
+// A compile-time switch for A/B builds (make CXXFLAGS=... -DTG_STORE_AUX=16): see DESIGN.md section 8c for what it measured.
+#ifndef TG_STORE_AUX
+#define TG_STORE_AUX 0
+#endif
+// 16 bytes to base[elem_off ...] with that policy; `base` must be wave-uniform, the byte offset below 4 GiB
+template <typename T> __device__ __forceinline__ void stv_stream(T* base, unsigned elem_off, const Vec16<T>& v) {
+#if TG_STORE_AUX
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xffffffffu, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bf16x8, v.v), r, elem_off * (unsigned)sizeof(T), 0, TG_STORE_AUX);
+#else
+  stv(base + elem_off, v);
+#endif
+}
+
 // Which 16-bit format the MFMA kernels of the current C-ABI call see (thread-local; set by the entry point from the
 // descriptor's / the call's dtype, read by the launchers that pick the template variant): false = bfloat16, true = half.
 bool tg_elem_f16();
