@@ -291,11 +291,15 @@ def resize_bilinear_tf1(x, out_h, out_w):
   """tf.image.resize_images(..., BILINEAR), align_corners=False, TF-1.x (no half-pixel centres): in = out * in_size /
   out_size; top-left = floor, bottom-right = min(+1, size - 1).  x: [h, w, c] float64."""
   h, w = x.shape[:2]
-  fy = np.arange(out_h) * (np.float32(h) / np.float32(out_h)).astype(np.float64)
-  fx = np.arange(out_w) * (np.float32(w) / np.float32(out_w)).astype(np.float64)
+  # core/kernels/resize_bilinear_op.cc compute_interpolation_weights: scale, `in = i * scale` and `lerp = in - lower` are
+  # float32 (it shows at ~1e-5 on the weights when in / out is not dyadic); the blend itself is evaluated in float64 here
+  fy = np.arange(out_h, dtype=np.float32) * (np.float32(h) / np.float32(out_h))
+  fx = np.arange(out_w, dtype=np.float32) * (np.float32(w) / np.float32(out_w))
+  assert fy.dtype == np.float32 and fx.dtype == np.float32
   top, left = np.floor(fy).astype(int), np.floor(fx).astype(int)
   bot, right = np.minimum(top + 1, h - 1), np.minimum(left + 1, w - 1)
-  ly, lx = (fy - top)[:, None, None], (fx - left)[None, :, None]
+  ly = (fy - top.astype(np.float32)).astype(np.float64)[:, None, None]
+  lx = (fx - left.astype(np.float32)).astype(np.float64)[None, :, None]
   t = x[top][:, left] + (x[top][:, right] - x[top][:, left]) * lx
   b = x[bot][:, left] + (x[bot][:, right] - x[bot][:, left]) * lx
   return t + (b - t) * ly

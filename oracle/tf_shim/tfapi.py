@@ -445,10 +445,13 @@ def image_resize_bilinear(images, size, align_corners=False, name=None):
   ih, iw = t.shape[1], t.shape[2]
 
   def taps(o, i):
-    src = torch.arange(o, dtype=F64) * float(np.float32(i) / np.float32(o))      # the kernel's scale is a float32
+    # core/kernels/resize_bilinear_op.cc compute_interpolation_weights: `const float in = i * scale; lower = (int64)in;
+    # lerp = in - lower` -- scale, product and weight are float32 (visible as ~1e-5 on the weights once in / out is not a
+    # dyadic number, e.g. the 320-pixel intermediate of --do_random_cropping at 256)
+    src = torch.arange(o, dtype=torch.float32) * torch.tensor(np.float32(i) / np.float32(o), dtype=torch.float32)
     lo = torch.clamp(torch.floor(src).long(), max=i - 1)
     hi = torch.clamp(lo + 1, max=i - 1)
-    return lo, hi, src - lo.to(F64)
+    return lo, hi, (src - lo.to(torch.float32)).to(F64)
   y0, y1, fy = taps(oh, ih)
   x0, x1, fx = taps(ow, iw)
   fy = fy.view(1, oh, 1, 1)
