@@ -14,6 +14,9 @@
 
 namespace {
 
+#ifndef TG_NORM_BWD_U
+#define TG_NORM_BWD_U 2      // A/B builds: -DTG_NORM_BWD_U=...
+#endif
 #define NF_LRELU 1
 #define NF_PIXNORM 2
 #define NF_ZEROSHIFT 8    // the partial sums were taken without a shift (conv epilogue, tg_conv2d_fwd_stats): K = 0
@@ -479,7 +482,7 @@ __global__ void norm_act_bwd1_kernel(const T* __restrict__ gz, const T* __restri
   // every lane of a pixel group iterates the same number of times (pl is uniform within a group)
   const float inv_c = 1.f / (float)c;
   if (pl < lanes) {
-    constexpr int U = 2;      // pixels in flight per thread (3 loads each)
+    constexpr int U = TG_NORM_BWD_U;      // pixels in flight per thread (3 loads each)
     // TAIL: the block's pixel count is not a multiple of lanes * U -- the last trip clamps and masks its dead pixels
     auto sweep = [&](auto tail) __attribute__((always_inline)) {
       constexpr bool TAIL = decltype(tail)::value;
@@ -589,7 +592,7 @@ __global__ void norm_act_bwd2_part_kernel(const T* __restrict__ gz, const T* __r
 #pragma unroll
   for (int j = 0; j < V; ++j) gr[j] = ga[j] * rs[j];
   const float inv_c = 1.f / (float)c;
-  constexpr int U = 2;      // pixels in flight per thread (3 loads each)
+  constexpr int U = TG_NORM_BWD_U;      // pixels in flight per thread (3 loads each)
   auto sweep = [&](auto tail) __attribute__((always_inline)) {
     constexpr bool TAIL = decltype(tail)::value;
     for (int pb = p0 + pl; pb < p1; pb += lanes * U) {
