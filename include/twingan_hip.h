@@ -68,6 +68,16 @@ int tg_get_deterministic(void);
  * buffers, (2) make its consumer (the optimiser) wait for the auxiliary stream, (3) keep the workspaces passed to those
  * calls alive until then.  The reference has no counterpart: TF's executor schedules its gradient ops itself. */
 int tg_set_aux_stream(void* stream);
+/* Deferred filter-gradient reductions (process-wide).  Between tg_wgrad_defer(1) and tg_wgrad_defer_flush(stream) the
+ * split-K slab reduction of every filter gradient that ACCUMULATES into a caller buffer (tg_conv2d_bwd_weight*,
+ * tg_conv2d_upcat_bwd_weight with accumulate != 0) is queued instead of launched, and the flush issues all queued
+ * reductions as ONE launch on `stream` (up to 120 per flush; a full queue falls back to the immediate launch; the
+ * deterministic mode never defers).  The caller must keep the workspaces of those calls alive until the flush and flush on
+ * a stream that is ordered after all of them -- and before anything reads the gradients.  tg_wgrad_defer returns the
+ * previous setting; tg_wgrad_defer(0) drops what was not flushed.  tg_wgrad_defer_flush returns the number of reductions
+ * it issued.  The reference has no counterpart (TF schedules its gradient ops itself). */
+int tg_wgrad_defer(int on);
+int tg_wgrad_defer_flush(void* stream);
 /* Fixed-order ("ordered") forms of the sums whose plain entry points end in fp32 atomics: every workgroup writes its
  * partial result to a row of `workspace` (fp32, workspace_floats long: 512 rows are enough for any size; fewer rows mean
  * fewer workgroups) and one pass adds the rows in workgroup order -- the same bits on every run, at full-grid speed, in

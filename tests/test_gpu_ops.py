@@ -1359,3 +1359,53 @@ def test_ordered_sums_are_bit_reproducible_and_right(ops, dtype):
   finally:
     lib.tg_set_deterministic(was)
   assert O.deterministic() == bool(was)
+
+
+def test_deferred_slab_reductions_equal_immediate_ones(ops):
+  """tg_wgrad_defer / tg_wgrad_defer_flush: the split-K slab reductions of filter gradients that accumulate into a sink are
+  queued and issued as ONE launch.  Each job keeps the slice-group shape and summation order of its stand-alone kernel, so
+  a sink that starts at zero receives the same bits; two jobs into one sink add up; a queue of more than 120 jobs falls
+  back to immediate launches for the rest; outside a defer window nothing changes."""
+  spec = ops.ConvSpec(3, 'SAME')
+  g = torch.Generator(device='cpu').manual_seed(5)
+  cases = [(4, 16, 16, 32, 32), (8, 32, 32, 64, 64), (2, 64, 64, 16, 16), (16, 8, 8, 256, 256), (4, 16, 16, 512, 256)]
+  data = []
+  for n, h, w, cin, cout in cases:      # weight sizes on both sides of the 16 384 / 131 072 element thresholds
+    x = torch.randn(n, h, w, cin, generator=g).to(dev()).to(torch.bfloat16)
+    gy = torch.randn(n, h, w, cout, generator=g).to(dev()).to(torch.bfloat16)
+    data.append((x, gy, torch.zeros(3, 3, cin, cout, device=dev()), torch.zeros(3, 3, cin, cout, device=dev())))
+  for x, gy, now, _ in data:
+    ops.conv_bwd_weight_raw(x, gy, spec, out=now)
+  ops.defer_slab_reductions(True)
+  try:
+    for x, gy, _, later in data:
+      ops.conv_bwd_weight_raw(x, gy, spec, out=later)
+    torch.cuda.synchronize()
+    queued = [float(later.abs().max()) for _, _, _, later in data]
+    n_flushed = ops.flush_slab_reductions()
+  finally:
+    ops.defer_slab_reductions(False)
+  torch.cuda.synchronize()
+  assert n_flushed >= 1 and ops.flush_slab_reductions() == 0
+  assert sum(1 for q in queued if q == 0.0) == n_flushed      # the queued sinks were untouched before the flush
+  for (x, gy, now, later), q in zip(data, queued):
+    assert torch.equal(now, later), (tuple(x.shape), float((now - later).abs().max()))
+  # two jobs into one sink, and more jobs than the table holds
+  x, gy, now, later = data[[i for i, q in enumerate(queued) if q == 0.0][0]]      # a layer whose reduction is a slab job
+  ops.conv_bwd_weight_raw(x, gy, spec, out=now)
+  many = [torch.zeros_like(now) for _ in range(130)]
+  ref = torch.zeros_like(now)
+  ops.conv_bwd_weight_raw(x, gy, spec, out=ref)
+  ops.defer_slab_reductions(True)
+  try:
+    ops.conv_bwd_weight_raw(x, gy, spec, out=later)
+    for m in many:
+      ops.conv_bwd_weight_raw(x, gy, spec, out=m)
+    n2 = ops.flush_slab_reductions()
+  finally:
+    ops.defer_slab_reductions(False)
+  torch.cuda.synchronize()
+  assert n2 == 120
+  assert rel_l2(host(later), host(now)) < 1e-6
+  for m in many:
+    assert torch.equal(m, ref)

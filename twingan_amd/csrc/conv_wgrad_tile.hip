@@ -1265,7 +1265,96 @@ static hipStream_t wg_reduce_stream(hipStream_t s, int accumulate) {
   return aux;
 }
 
+// ---- deferred, batched slab reductions -------------------------------------------------------------------------------
+// Between tg_wgrad_defer(1) and tg_wgrad_defer_flush the reductions that ACCUMULATE into a caller buffer (gradient sinks:
+// nobody reads them before the optimiser) are not launched but queued; the flush issues all of them as ONE launch whose
+// job table travels by value in the kernel arguments (so a hipGraph capture records it like any other launch).  86
+// reductions of ~5 us plus a kernel boundary each leave a bench step (config 3; 114 in config 4).  Each job keeps the
+// slice-group shape and the summation order of its stand-alone kernel.  The caller keeps the workspaces (slabs) alive
+// until the flush and flushes on a stream that is ordered after every queued launch.
+namespace {
+
+struct SlabJob {
+  const float* slab;
+  float* gw;
+  int nw, nslices, blk0, sg;      // elements, slices, first block of the job in the batched grid, slice groups (1 / 4 / 16)
+};
+constexpr int MAXJ = 120;         // 120 x 32 B + 8 B < the 4 KB kernel-argument segment
+struct SlabJobTable {
+  SlabJob j[MAXJ];
+  int n, blocks;
+};
+SlabJobTable g_defer;             // host side; the trainer's backward issues launches from one thread at a time
+int g_defer_on = 0;
+
+__global__ __launch_bounds__(256) void conv_wgrad_slab_reduce_multi(const SlabJobTable tab) {
+  __shared__ float part[16 * 17 > 4 * 65 ? 16 * 17 : 4 * 65];
+  int j = 0;
+  while (j + 1 < tab.n && (int)blockIdx.x >= tab.j[j + 1].blk0) ++j;      // block-uniform
+  const float* __restrict__ slab = tab.j[j].slab;
+  float* __restrict__ gw = tab.j[j].gw;
+  const int64_t nw = tab.j[j].nw;
+  const int nslices = tab.j[j].nslices, sgn = tab.j[j].sg, epb = 256 / sgn;
+  const int e = threadIdx.x % epb, sg = threadIdx.x / epb;
+  const int64_t i = (int64_t)((int)blockIdx.x - tab.j[j].blk0) * epb + e;
+  float a[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) a[u] = 0.f;
+  if (i < nw) {
+    int k = sg;
+    for (; k + 7 * sgn < nslices; k += 8 * sgn) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += slab[(size_t)(k + u * sgn) * nw + i];
+    }
+    for (; k < nslices; k += sgn) a[0] += slab[(size_t)k * nw + i];
+  }
+  const float s0 = (a[0] + a[1]) + (a[2] + a[3]), s1 = (a[4] + a[5]) + (a[6] + a[7]);
+  if (sgn == 1) {
+    if (i < nw) atomicAdd(gw + i, s0 + s1);
+    return;
+  }
+  part[sg * (epb + 1) + e] = s0 + s1;
+  __syncthreads();
+  if ((int)threadIdx.x < epb && i < nw) {
+    float t = 0.f;
+    for (int q = 0; q < sgn; ++q) t += part[q * (epb + 1) + e];
+    atomicAdd(gw + i, t);
+  }
+}
+
+}  // namespace
+
+extern "C" int tg_wgrad_defer(int on) {
+  const int prev = g_defer_on;
+  g_defer_on = on ? 1 : 0;
+  if (!on) g_defer.n = g_defer.blocks = 0;      // whatever was not flushed is dropped (an abandoned pass)
+  return prev;
+}
+
+extern "C" int tg_wgrad_defer_flush(void* stream) {
+  const int n = g_defer.n;
+  if (n > 0) {
+    hipLaunchKernelGGL(conv_wgrad_slab_reduce_multi, dim3((unsigned)g_defer.blocks), dim3(256), 0, (hipStream_t)stream,
+                       g_defer);
+    g_defer.n = g_defer.blocks = 0;
+    TG_LAUNCH_CHECK("conv_wgrad_slab_reduce_multi");
+  }
+  return n;
+}
+
 int tg_wgrad_slab_reduce(const float* slab, float* gw, int64_t nw, int nslices, int accumulate, hipStream_t s) {
+  if (g_defer_on && accumulate && g_defer.n < MAXJ && nw < (1ll << 31) && !tg_deterministic_mode()) {
+    SlabJob& jb = g_defer.j[g_defer.n++];
+    jb.slab = slab;
+    jb.gw = gw;
+    jb.nw = (int)nw;
+    jb.nslices = nslices;
+    jb.sg = nw < 16384 ? 16 : (nw < 131072 ? 4 : 1);      // the stand-alone kernels' rule
+    jb.blk0 = g_defer.blocks;
+    const int epb = 256 / jb.sg;
+    g_defer.blocks += (int)((nw + epb - 1) / epb);
+    return TG_OK;
+  }
   s = wg_reduce_stream(s, accumulate);
   if (nw < 16384)
     hipLaunchKernelGGL(conv_wgrad_slab_reduce<16>, dim3((unsigned)((nw + 15) / 16)), dim3(256), 0, s, slab, gw, nw, nslices,

@@ -182,6 +182,35 @@ def set_aux_stream(stream):
 def _keep_for_aux(ws, accumulate):
   if AUX_STREAM is not None and accumulate and ws is not None:
     ws.record_stream(AUX_STREAM)
+  if _DEFERRED is not None and accumulate and ws is not None:
+    _DEFERRED.append(ws)      # its slab reduction is queued in the library: alive until flush_slab_reductions()
+
+
+# Deferred slab reductions of a backward pass (Trainer): between defer_slab_reductions(True) and flush_slab_reductions() the
+# library queues the split-K reduction of every filter gradient that accumulates into a gradient sink and the flush issues
+# them as one launch (tg_wgrad_defer / tg_wgrad_defer_flush); the slabs those launches read are kept alive here
+_DEFERRED = None
+
+
+def defer_slab_reductions(on):
+  global _DEFERRED
+  _lib.load().tg_wgrad_defer(1 if on else 0)
+  _DEFERRED = [] if on else None
+
+
+def flush_slab_reductions():
+  """Issues the queued reductions on the current stream (which must be ordered after every backward launch of the pass:
+  the trainer joins its domain streams first).  -> the number of reductions in the launch."""
+  if _DEFERRED is None:
+    return 0
+  n = _lib.load().tg_wgrad_defer_flush(_stream())
+  if n < 0:
+    raise _lib.TgError('tg_wgrad_defer_flush failed (%d): %s' % (n, _lib.load().tg_last_error().decode()))
+  cur = torch.cuda.current_stream()
+  for ws in _DEFERRED:
+    ws.record_stream(cur)      # may have been allocated on a domain stream
+  del _DEFERRED[:]
+  return n
 
 
 class GradSink:

@@ -442,6 +442,8 @@ class Trainer:
       out = (loss.detach(), {k: v.detach() for k, v in terms.items()})
       scaled = loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)       # model_deploy.py:265-268,308-313
       ops.GradSink.pair = True
+      # the slab reductions of the filter gradients that feed gradient sinks: queued, one launch per backward segment
+      ops.defer_slab_reductions(os.environ.get('TG_WGRAD_DEFER', '1') != '0')
       aux = self._aux_stream()
       if aux is not None:      # the slab reductions of the filter gradients leave the backward's critical path
         aux.wait_stream(torch.cuda.current_stream(self.device))      # ... after the zero fill of the gradient buffers
@@ -456,6 +458,7 @@ class Trainer:
         last = seg == nseg - 1
         # filter gradients still waiting for a pair: issue those this segment completes, keep the others
         ops.GradSink.flush(None if last else (lambda ptr, seg=seg: self._ptr_phase.get(ptr, 0) <= seg))
+        ops.flush_slab_reductions()      # after the join: every queued slab is written, the launch is on the main stream
         if aux is not None:      # the segment's gradients are complete only once their reductions are
           torch.cuda.current_stream(self.device).wait_stream(aux)
         if last:
@@ -463,6 +466,7 @@ class Trainer:
         yield seg, out
     finally:
       ops.GradSink.pair = False
+      ops.defer_slab_reductions(False)
       if ops.AUX_STREAM is not None:
         ops.set_aux_stream(None)
       if nseg > 1:
@@ -569,6 +573,7 @@ class Trainer:
     torch.cuda.synchronize(self.device)
     ops.GradSink._held.clear()
     ops.GradSink.pair = False
+    ops.defer_slab_reductions(False)
     ops.Cuts.end()
     _DomainStreams.join_all(self.device)
     self.store.zero_grad('g')
