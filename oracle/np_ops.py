@@ -350,7 +350,8 @@ RANDOM_CROP_RATIO = 0.8      # danbooru_preprocessing.py:33
 
 
 def preprocess_image(img_u8, hw, resize_mode='PAD', is_training=True, flip=False, saturation_first=False, delta=0.0,
-                     factor=1.0, crop=None, random_cropping_ratio=RANDOM_CROP_RATIO, color_space='rgb', mode_offset=None):
+                     factor=1.0, crop=None, random_cropping_ratio=RANDOM_CROP_RATIO, color_space='rgb', mode_offset=None,
+                     initial_crop_hw=None):
   """preprocessing/danbooru_preprocessing.py:115-230 as the TwinGAN trainer reaches it (model_inheritor.py:403-457:
   padding 0, no mean subtraction, fast_mode -- `fast_mode` is not a flag and the partial never sets it, so the hue /
   contrast orderings are unreachable from the trainer): convert_image_dtype to [0, 1]; resize_image
@@ -387,6 +388,17 @@ def preprocess_image(img_u8, hw, resize_mode='PAD', is_training=True, flip=False
       oy, ox = (int(v) for v in mode_offset)
     assert oy + new_hw <= x.shape[0] and ox + new_hw <= x.shape[1]
     x = x[oy:oy + new_hw, ox:ox + new_hw]
+  elif resize_mode == 'RANDOM_CROP_AND_RESHAPE':
+    # :128-131: _random_crop_to_hw to --random_crop_and_reshape_initial_crop_hw (a smaller image is resized up to it
+    # first), THEN the bilinear resize every mode but RANDOM_CROP ends with (:144-146)
+    c = int(initial_crop_hw)
+    assert c > 0
+    if c > min(h, w):
+      x = resize_bilinear_tf1(x, c, c)
+      oy = ox = 0
+    else:
+      oy, ox = (int(v) for v in mode_offset)
+    x = x[oy:oy + c, ox:ox + c]
   elif resize_mode == 'NONE':      # :137-139: the image as it is -- it must already have the size the networks take
     assert (h, w) == (hw, hw) and crop is None
   elif resize_mode not in ('PAD', 'CROP', 'RESHAPE'):

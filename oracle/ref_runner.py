@@ -362,7 +362,8 @@ def run_pggan(flags, targets, global_step=0, seed=0, preset=None, want_grads=Tru
   return res
 
 
-def run_preprocess(image_u8, hw, resize_mode='PAD', is_training=True, seed=0, do_random_cropping=False, color_space='rgb'):
+def run_preprocess(image_u8, hw, resize_mode='PAD', is_training=True, seed=0, do_random_cropping=False, color_space='rgb',
+                   initial_crop_hw=None):
   """The reference's OWN preprocessing/danbooru_preprocessing.preprocess_image (the TwinGAN trainer's image
   preprocessing, model/model_inheritor.py:403-457) executed on the TF stand-in for one uint8 image [h, w, 3].
   Returns (output [hw, hw, 3] float64, draws) with draws = dict(flip_uniform, sel, applied=[(kind, value), ...]) --
@@ -372,6 +373,7 @@ def run_preprocess(image_u8, hw, resize_mode='PAD', is_training=True, seed=0, do
   from .tf_shim import core
   importlib.import_module('preprocessing.preprocessing_util')
   pre = importlib.import_module('preprocessing.danbooru_preprocessing')
+  tf.flags.FLAGS.random_crop_and_reshape_initial_crop_hw = initial_crop_hw      # preprocessing_util.py:26-27
   core.STATE.random_log.clear()
   core.STATE.aug_log.clear()
   core.STATE.gen.manual_seed(seed)
@@ -385,7 +387,7 @@ def run_preprocess(image_u8, hw, resize_mode='PAD', is_training=True, seed=0, do
   applied = [a for a in core.STATE.aug_log if a[0] != 'crop']
   crops = [a[1] for a in core.STATE.aug_log if a[0] == 'crop']
   mode_crop = None
-  if resize_mode == 'RANDOM_CROP':      # preprocessing_util._random_crop_to_hw draws its offsets first, in any mode
+  if resize_mode in ('RANDOM_CROP', 'RANDOM_CROP_AND_RESHAPE'):      # _random_crop_to_hw draws its offsets first, in any mode
     mode_crop, crops, k = crops[0], crops[1:], k + 1
   draws = dict(flip_uniform=float(log[k][1]) if is_training else None,
                sel=int(log[k + 1][1]) if (is_training and color_space != 'gray') else None,

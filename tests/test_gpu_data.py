@@ -277,3 +277,27 @@ def test_distillation_trains_from_an_embedding_dataset(tmp_path):
   finally:
     batches.close()
   assert [h['stage'] for h in hist] == ['16'] and all(torch.isfinite(v).all() for v in state.values())
+
+
+def test_random_crop_and_reshape_matches_oracle():
+  """--resize_mode=RANDOM_CROP_AND_RESHAPE with --random_crop_and_reshape_initial_crop_hw (preprocessing_util.py:24-27,
+  128-131): a random [c, c] window (a smaller image is first resized up to [c, c]), then the resize to hw -- the kernel's
+  two-stage path with the intermediate size c.  Evaluation and training calls against the float64 oracle (itself held to
+  the reference live: tests/test_data_cpu.py::test_host_tables_reproduce_the_live_reference_for_every_resize_mode)."""
+  from twingan_amd import data as D
+  rng = np.random.RandomState(14)
+  imgs = [rng.randint(0, 256, (h, w, 3), dtype=np.uint8) for h, w in ((60, 70), (30, 45), (48, 48), (100, 49))]
+  offs = [(9, 16), None, (0, 0), (37, 1)]      # None: the image is smaller than the window and resized whole
+  for training in (False, True):
+    pre = D.Preprocessor(32, device='cuda:0', precision='fp32', resize_mode='RANDOM_CROP_AND_RESHAPE', initial_crop_hw=48,
+                         is_training=training, seed=2)
+    aug = D.draw_augmentation(len(imgs), np.random.default_rng(8)) if training else None
+    out = pre(imgs, aug=aug, mode_offsets=offs).cpu().numpy()
+    for k, im in enumerate(imgs):
+      kw = dict(flip=bool(aug[k, 0]), saturation_first=bool(aug[k, 1]), delta=float(aug[k, 2]), factor=float(aug[k, 3])) \
+          if training else {}
+      want = N.preprocess_image(im, 32, 'RANDOM_CROP_AND_RESHAPE', training, mode_offset=offs[k] or (0, 0), initial_crop_hw=48,
+                                **kw)
+      assert np.abs(out[k] - want).max() < 3e-6, (training, k, np.abs(out[k] - want).max())
+  own = D.Preprocessor(32, device='cuda:0', precision='bf16', resize_mode='RANDOM_CROP_AND_RESHAPE', initial_crop_hw=40)(imgs)
+  assert own.shape == (4, 32, 32, 3) and float(own.min()) >= 0.0 and float(own.max()) <= 1.0

@@ -216,7 +216,7 @@ def source_rect(h, w, resize_mode, new_hw=None, rng=None, offset=None):
     return ((h - size) // 2, (w - size) // 2, size, size)
   if resize_mode == 'RESHAPE':
     return (0, 0, h, w)
-  if resize_mode == 'RANDOM_CROP':
+  if resize_mode in ('RANDOM_CROP', 'RANDOM_CROP_AND_RESHAPE'):      # for the latter new_hw is the initial crop size
     if new_hw > min(h, w):
       return (0, 0, h, w)
     oy, ox = offset if offset is not None else (rng.integers(0, h - new_hw + 1), rng.integers(0, w - new_hw + 1))
@@ -226,8 +226,7 @@ def source_rect(h, w, resize_mode, new_hw=None, rng=None, offset=None):
     if (h, w) != (new_hw, new_hw):
       raise ValueError('resize_mode NONE: a %d x %d image where the networks take %d x %d' % (h, w, new_hw, new_hw))
     return (0, 0, h, w)
-  # RANDOM_CROP_AND_RESHAPE (:128-131) crops to --random_crop_and_reshape_initial_crop_hw and may resize twice: not built
-  raise ValueError('resize_mode %s (PAD, CROP, RESHAPE, RANDOM_CROP and NONE are built)' % resize_mode)
+  raise ValueError('resize_mode %s (PAD, CROP, RESHAPE, RANDOM_CROP, RANDOM_CROP_AND_RESHAPE and NONE)' % resize_mode)
 
 
 def draw_augmentation(n, rng):
@@ -267,7 +266,7 @@ class Preprocessor:
   --do_random_cropping=True)."""
 
   def __init__(self, hw, device='cuda', precision='bf16', resize_mode='PAD', is_training=True, seed=0,
-               do_random_cropping=False, random_cropping_ratio=RANDOM_CROP_RATIO, color_space='rgb'):
+               do_random_cropping=False, random_cropping_ratio=RANDOM_CROP_RATIO, color_space='rgb', initial_crop_hw=None):
     self.hw, self.device = int(hw), torch.device(device)
     self.dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[precision]
     self.resize_mode, self.is_training = resize_mode, is_training
@@ -278,6 +277,18 @@ class Preprocessor:
     assert not (self.crops and resize_mode == 'NONE'), 'random cropping of unresized images is not built'
     self.ratio = float(random_cropping_ratio)
     self.mid = int(self.hw / self.ratio) if self.crops else 0
+    # RANDOM_CROP_AND_RESHAPE (preprocessing_util.py:24-27,128-131; --random_crop_and_reshape_initial_crop_hw): a random
+    # [c, c] window of the image (a smaller image is resized up to [c, c] first), then the resize to hw -- the kernel's
+    # two-stage path with the intermediate size c and the whole intermediate image as its "crop", in evaluation as well
+    # (resize_image does not look at is_training).  Together with --do_random_cropping it would be three resizes: not built.
+    self.window = None
+    if resize_mode == 'RANDOM_CROP_AND_RESHAPE':
+      assert initial_crop_hw and int(initial_crop_hw) > 0, 'RANDOM_CROP_AND_RESHAPE needs initial_crop_hw'      # :129
+      assert not self.crops, 'RANDOM_CROP_AND_RESHAPE together with do_random_cropping (three resizes) is not built'
+      self.window = self.mid = int(initial_crop_hw)
+      # tg_preprocess_images_crop takes an intermediate image at least as large as its output (the cropping augmentation
+      # always shrinks); a window SMALLER than the training resolution (an up-sampling crop) is refused here
+      assert self.window >= self.hw, 'initial_crop_hw %d < hw %d: up-sampling windows are not built' % (self.window, self.hw)
     self.rng = np.random.default_rng(seed)
 
   def pack(self, images, aug=None, crop=None, rng=None, mode_offsets=None):
@@ -296,11 +307,14 @@ class Preprocessor:
       assert im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3, 'decoded RGB uint8 images'
       flat[offsets[i]:offsets[i] + sizes[i]] = np.ascontiguousarray(im).reshape(-1)
       rect[i] = (im.shape[0], im.shape[1]) + source_rect(im.shape[0], im.shape[1], self.resize_mode,
-                                                         self.mid if self.crops else self.hw, rng,
+                                                         self.mid if (self.crops or self.window is not None) else self.hw, rng,
                                                          None if mode_offsets is None else mode_offsets[i])
     if aug is None:
       aug = draw_augmentation(n, rng) if self.is_training else np.tile(np.float32([0, 0, 0, 1]), (n, 1))
     tables = (buf, torch.from_numpy(offsets), torch.from_numpy(rect), torch.from_numpy(np.ascontiguousarray(aug, np.float32)))
+    if self.window is not None:      # the second stage reads the whole [c, c] intermediate image
+      assert crop is None
+      return tables + (torch.from_numpy(np.tile(np.int32([0, 0, self.window, self.window]), (n, 1))),)
     if not self.crops:
       assert crop is None, 'a crop table without do_random_cropping (or in evaluation mode)'
       return tables
@@ -318,14 +332,15 @@ class Preprocessor:
     if self.device.type != 'cuda':
       raise RuntimeError('the preprocessing kernel needs a GPU (there is no CPU fallback)')
     n = offsets.numel()
-    assert (crop is not None) == self.crops
+    two_stage = self.crops or self.window is not None
+    assert (crop is not None) == two_stage
     with torch.cuda.device(self.device):
       st = stream or torch.cuda.current_stream()
       with torch.cuda.stream(st):
-        d = [t.to(self.device, non_blocking=True) for t in (buf, offsets, rect, aug) + ((crop,) if self.crops else ())]
+        d = [t.to(self.device, non_blocking=True) for t in (buf, offsets, rect, aug) + ((crop,) if two_stage else ())]
         out = torch.empty((n, self.hw, self.hw, 3), dtype=self.dtype, device=self.device)
         call('tg_preprocess_images_crop', d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(),
-             d[4].data_ptr() if self.crops else 0, d[3].data_ptr(), out.data_ptr(), n, self.hw, self.mid,
+             d[4].data_ptr() if two_stage else 0, d[3].data_ptr(), out.data_ptr(), n, self.hw, self.mid,
              COLOR_SPACES[self.color_space], {torch.bfloat16: TG_BF16, torch.float16: TG_F16, torch.float32: TG_F32}[self.dtype],
              st.cuda_stream)
         for t in d:
