@@ -253,7 +253,7 @@ def test_embedding_dataset_records_and_fields(tmp_path):
   recs.append(D.embedding_example(buf.getvalue(), rng.randn(7), 'png', 'short'))
   D.write_tfrecords(str(tmp_path / 'train-00000-of-00001'), recs)
   ds = D.EmbeddingImageDataset(str(tmp_path), 'train', embedding_size=8)
-  assert D.DATASETS['celeba_facenet'] is D.EmbeddingImageDataset and D.EMBEDDING_SIZE == 512
+  assert 'celeba_facenet' in D.DATASETS and D.EMBEDDING_SIZE == 512
   payloads = list(ds.records())
   decoded = [ds.decode(p) for p in payloads[:6]]
   for i, (im, name, fields) in enumerate(decoded):
@@ -322,3 +322,31 @@ def test_host_tables_reproduce_the_live_reference_for_every_resize_mode():
     D.Preprocessor(32, device='cpu', resize_mode='RANDOM_CROP_AND_RESHAPE', initial_crop_hw=24)    # up-sampling window
   with pytest.raises(AssertionError):
     D.Preprocessor(32, device='cpu', resize_mode='RANDOM_CROP_AND_RESHAPE', initial_crop_hw=48, do_random_cropping=True)
+
+
+def test_labelled_datasets_are_read_for_their_images(tmp_path):
+  """'anime_faces' -- the target domain of the reference's own TwinGAN recipe (docs/training.md:16-17) -- and 'celeba' carry
+  tags / attributes / landmarks next to the image (datasets/anime_faces.py:77-88, celeba.py:82-92); the trainer reads the
+  image only.  get_dataset opens them by their '<split>-*' pattern and skips the other features."""
+  from PIL import Image
+  rng = np.random.RandomState(6)
+  recs, imgs = [], []
+  for i in range(3):
+    a = rng.randint(0, 256, (9, 7 + i, 3), dtype=np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(a).save(buf, format='PNG')
+    recs.append(D.encode_example({'image/encoded': buf.getvalue(), 'image/format': 'png', 'image/filename': 'face%d' % i,
+                                  'image/class/label': [3, 17], 'image/class/text': 'blue hair, smile'}))
+    imgs.append(a)
+  D.write_tfrecords(str(tmp_path / 'train-00000-of-00001'), recs)
+  D.write_tfrecords(str(tmp_path / 'trainextra'), recs[:1])      # matches image_only's '%s*' pattern, not '%s-*'
+  for name in ('anime_faces', 'celeba'):
+    ds = D.get_dataset(name, 'train', str(tmp_path))
+    assert [os.path.basename(f) for f in ds.files] == ['train-00000-of-00001']
+    got = [ds.decode(p) for p in ds.records()]
+    assert [g[1] for g in got] == ['face0', 'face1', 'face2'] and all(len(g) == 2 for g in got)
+    for g, a in zip(got, imgs):
+      np.testing.assert_array_equal(g[0], a)
+  assert len(D.get_dataset('image_only', 'train', str(tmp_path)).files) == 2
+  with pytest.raises(ValueError):
+    D.get_dataset('svhn', 'train', str(tmp_path))

@@ -198,7 +198,23 @@ class EmbeddingImageDataset(ImageOnlyDataset):
             {'embedding': emb})
 
 
-DATASETS = {'image_only': ImageOnlyDataset, 'celeba_facenet': EmbeddingImageDataset}      # of datasets/dataset_factory.py:50-58
+def get_dataset(name, split, dataset_dir, embedding_size=EMBEDDING_SIZE):
+  """datasets/dataset_factory.get_dataset (:61-91) for what the TwinGAN trainer consumes of each dataset: the decoded
+  image ('a_source' / 'b_source', twingan.py:150-152) and, where the dataset has one, the 'embedding' item.  'anime_faces'
+  (the target domain of the reference's own training recipe, docs/training.md:16-17) and 'celeba' carry labels / tags /
+  landmarks as further features: the trainer never reads them ('conditional_labels' only feeds the conditional
+  generators of image_generation.py's other programs), so they are skipped here -- the image key, format key and file
+  pattern ('<split>-*', datasets/anime_faces.py:30, celeba.py:32) are theirs."""
+  if name == 'image_only':
+    return ImageOnlyDataset(dataset_dir, split)                                   # datasets/image_only.py:28 '%s*'
+  if name in ('anime_faces', 'celeba'):
+    return ImageOnlyDataset(dataset_dir, split, file_pattern='%s-*')
+  if name == 'celeba_facenet':
+    return EmbeddingImageDataset(dataset_dir, split, embedding_size=embedding_size)
+  raise ValueError('Name of dataset unknown %s' % name)                           # dataset_factory.py:77-78
+
+
+DATASETS = ('image_only', 'anime_faces', 'celeba', 'celeba_facenet')      # of datasets/dataset_factory.py:50-58
 
 
 # ------------------------------------------------------------------------------------------------ GPU preprocessing
@@ -553,12 +569,7 @@ class TwoDomainBatches:
     return (s, t, extras) if extras else (s, t)
 
   def _dataset(self, i, d):
-    name = self.dataset_names[i]
-    if name not in DATASETS:
-      raise ValueError('Name of dataset unknown %s' % name)      # dataset_factory.py:77-78
-    if name == 'celeba_facenet':
-      return EmbeddingImageDataset(d, self.split, embedding_size=self.embedding_size)
-    return ImageOnlyDataset(d, self.split)
+    return get_dataset(self.dataset_names[i], self.split, d, self.embedding_size)
 
   def close(self):
     for ld in self.loaders:
