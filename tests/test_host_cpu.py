@@ -470,3 +470,26 @@ def test_flash_attention_host_queries():
   assert 0 < f < b < bb and all(x % 256 == 0 for x in (f, b, bb))
   assert f >= 16 * 4096 * 64 * 2 and ws(32, 2) == 2 * bb          # one packed copy of v at least; linear in n
   assert ws(16, 1, dk=16) < b + 1 and ws(16, 0, dk=4) == 0         # d_qk = 16 needs no padded q / k copies; unsupported: 0
+
+
+def test_native_normalisers_refuse_what_the_reference_refuses():
+  """nets/pggan_utils.py:177,191: tf.contrib's layers take no conditional layer ('Tensorflow implementation does not support
+  `conditional_layer`'); and the plain PGGAN trainer's empty postfix would make the layer's scope the empty string --
+  refused rather than guessed."""
+  from twingan_amd import Config
+  from twingan_amd.params import ParamStore, declare_pggan, declare_twingan, norm_var, NATIVE_NORM
+  for norm in ('batch_renorm_native', 'layer_norm_native'):
+    with pytest.raises(NotImplementedError):
+      declare_twingan(ParamStore('cpu'), Config(hw=8, max_ch=8, generator_norm_type=norm, use_style_embedding=True,
+                                                style_embed_size=4))
+    with pytest.raises(NotImplementedError):
+      declare_pggan(ParamStore('cpu'), Config(hw=8, max_ch=8, generator_norm_type=norm))
+    store = declare_twingan(ParamStore('cpu'), Config(hw=8, max_ch=8, generator_norm_type=norm)).build(seed=0)
+    assert 'generator/block_4x4x8/Conv/_s/gamma' in store.specs and 'generator/block_4x4x8/Conv/_t/beta' in store.specs
+    has_state = any('/_s/renorm_mean_weight' in k for k in store.state)
+    assert has_state == (norm == 'batch_renorm_native')
+  assert norm_var('a/Conv', NATIVE_NORM, 'gamma', 's') == 'a/Conv/_s/gamma'
+  assert norm_var('a/Conv', 'BatchNorm', 'gamma', 's') == 'a/Conv/BatchNorm/gamma_s'
+  assert norm_var('a/Conv', 'InstanceNorm', 'beta', '') == 'a/Conv/InstanceNorm/beta'
+  with pytest.raises(NotImplementedError):
+    declare_twingan(ParamStore('cpu'), Config(hw=8, max_ch=8, generator_norm_type='group_norm'))
