@@ -222,6 +222,12 @@ int tg_pointwise_conv_fwd(const void* x, const float* w, const float* bias, void
                           int wt, int epilogue, float lrelu_alpha, int dtype, void* stream);
 int tg_pointwise_conv_bwd_weight(const void* x, const void* gy, float* gw, int64_t npix, int cin, int cout,
                                  int accumulate, int dtype, void* stream);
+/* The fromRGB layer's filter AND bias gradient from one read of gy (Conv2DBackpropFilter + BiasAddGrad of
+ * nets/pggan.py:233-240 in the discriminator arg-scope, nets/pggan_utils.py:116-127): gw as above, gbias[cout] (+)= sum
+ * over pixels of gy.  cin <= 4.  One launch at the shapes the RGB kernel takes (16-bit, cin 3, npix % 4 == 0), else the
+ * filter gradient followed by tg_channel_sum. */
+int tg_pointwise_conv_bwd_weight_bias(const void* x, const void* gy, float* gw, float* gbias, int64_t npix, int cin,
+                                      int cout, int accumulate, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Instance norm (+ LeakyReLU + pixel norm), libs/instance_norm.py:131-135, util_misc.py:68-86,

@@ -225,6 +225,67 @@ def test_pointwise_conv(ops, dtype, cin, cout):
   assert rel_l2(host(bd.grad), gpre.sum(axis=(0, 1, 2))) < tol_for(dtype, True)
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize('n,hw,cs,cb,small_in', [(2, 64, 3, 16, True), (16, 256, 3, 16, True), (3, 32, 3, 256, True),
+                                                   (2, 64, 3, 16, False), (1, 6, 3, 16, True), (2, 8, 4, 16, True)])
+def test_pointwise_rgb_filter_and_bias_gradient(ops, dtype, n, hw, cs, cb, small_in):
+  """tg_pointwise_conv_bwd_weight(_bias) at the fromRGB / toRGB shapes (nets/pggan.py:233-240,176-200): the four-pixel RGB
+  kernel (16-bit, 3 small channels, npix % 4 == 0; incl. the bench shape 16 x 256 x 256 x 3 -> 16) and the generic one,
+  filter gradient with and without the bias gradient riding along, written and accumulated, against float64 sums of the
+  same (rounded) inputs."""
+  from twingan_amd import ops as O
+  g = torch.Generator(device='cpu').manual_seed(7)
+  small = torch.randn(n, hw, hw, cs, generator=g).to(dtype)
+  big = torch.randn(n, hw, hw, cb, generator=g).to(dtype)
+  x, gy = (small, big) if small_in else (big, small)
+  cin, cout = x.shape[-1], gy.shape[-1]
+  ref_w = np.einsum('pc,po->co', host(x).reshape(-1, cin), host(gy).reshape(-1, cout))
+  ref_b = host(gy).reshape(-1, cout).sum(axis=0)
+  xd, gyd = x.to(dev()), gy.to(dev())
+  npix = n * hw * hw
+  tol = 2e-5 if dtype == torch.float32 else 2e-4      # fp32 accumulation of exactly representable products
+  for accumulate in (0, 1):
+    gw = torch.full((cin, cout), 3.0 if accumulate else float('nan'), device=dev())
+    O.call('tg_pointwise_conv_bwd_weight', xd.data_ptr(), gyd.data_ptr(), gw.data_ptr(), npix, cin, cout, accumulate,
+           O._dt(xd), O._stream())
+    assert rel_l2(host(gw) - (3.0 if accumulate else 0.0), ref_w) < tol
+    if small_in:
+      gw = torch.full((cin, cout), 3.0 if accumulate else float('nan'), device=dev())
+      gb = torch.full((cout,), -2.0 if accumulate else float('nan'), device=dev())
+      O.call('tg_pointwise_conv_bwd_weight_bias', xd.data_ptr(), gyd.data_ptr(), gw.data_ptr(), gb.data_ptr(), npix, cin, cout,
+             accumulate, O._dt(xd), O._stream())
+      assert rel_l2(host(gw) - (3.0 if accumulate else 0.0), ref_w) < tol
+      assert rel_l2(host(gb) + (2.0 if accumulate else 0.0), ref_b) < tol
+
+
+def test_pointwise_conv_bias_gradient_rides_in_the_filter_gradient(ops):
+  """The discriminator's fromRGB under a trainer-style gradient sink: one tg_pointwise_conv_bwd_weight_bias launch instead of
+  the filter gradient + a channel-sum pass -- same sums as the unfused autograd path."""
+  from twingan_amd import ops as O
+  g = torch.Generator(device='cpu').manual_seed(8)
+  x = torch.randn(2, 32, 32, 3, generator=g).to(dev()).to(torch.bfloat16)
+  w = (torch.randn(1, 1, 3, 16, generator=g) * 0.5).to(dev()).requires_grad_(True)
+  b = (torch.randn(16, generator=g) * 0.1).to(dev()).requires_grad_(True)
+  gy = torch.randn(2, 32, 32, 16, generator=g).to(dev()).to(torch.bfloat16)
+  y = ops.pointwise_conv(x, w, b, lrelu=True)
+  y.backward(gy)
+  gw_ref, gb_ref = w.grad.clone(), b.grad.clone()
+  sw, sb = torch.zeros_like(w), torch.zeros_like(b)
+  O.GradSink.register(w, sw)
+  O.GradSink.register(b, sb)
+  try:
+    y = ops.pointwise_conv(x, w, b, lrelu=True)
+    y.grad_fn.tg_premasked = True      # as when the consumer conv's backward-data applied the LeakyReLU mask
+    z = y.detach()
+    gpre = (gy.float() * torch.where(z.float() > 0, 1.0, 0.2)).to(torch.bfloat16)
+    torch.autograd.backward(y, gpre)
+  finally:
+    O.GradSink.unregister(w)
+    O.GradSink.unregister(b)
+  assert rel_l2(host(sw), host(gw_ref)) < 2e-3      # gpre is re-rounded to bf16 here, not in the unfused path
+  assert rel_l2(host(sb), host(gb_ref)) < 2e-3
+
+
 # ---------------------------------------------------------------------------------------------- norm_act
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('n,h,w,c,lrelu,pn', [(2, 8, 8, 16, True, True), (3, 4, 4, 256, True, True),

@@ -86,6 +86,7 @@ SIGNATURES = {
     'tg_conv2d_pack_weights_multi': (c_int, [_P, c_int, c_int, _P]),
     'tg_pointwise_conv_fwd': (c_int, [_P, _FP, _FP, _P, c_int64, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     'tg_pointwise_conv_bwd_weight': (c_int, [_P, _P, _FP, c_int64, c_int, c_int, c_int, c_int, _P]),
+    'tg_pointwise_conv_bwd_weight_bias': (c_int, [_P, _P, _FP, _FP, c_int64, c_int, c_int, c_int, c_int, _P]),
     'tg_instance_norm_stats': (c_int, [_P, _FP, _FP, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     'tg_norm_chunks': (c_int, [c_int, c_int, c_int]),
     'tg_instance_norm_partials': (c_int, [_P, _FP, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -1287,38 +1287,47 @@ struct SlabJobTable {
 SlabJobTable g_defer;             // host side; the trainer's backward issues launches from one thread at a time
 int g_defer_on = 0;
 
+// A thread owns FOUR consecutive elements (one 16-byte load per slice, 8 slices in flight: 128 bytes per thread against 32
+// with one element per thread -- the one-element form moved its ~0.6 GB of slabs at 2.7 TB/s, 224 us per launch,
+// profiles/r03_z_bench_c3_kernel_stats.csv); nw = 9 * cin * cout is a multiple of 4 and every slab row starts 16-byte
+// aligned.  Per element the slices are added in the stand-alone kernel's order.
 __global__ __launch_bounds__(256) void conv_wgrad_slab_reduce_multi(const SlabJobTable tab) {
-  __shared__ float part[16 * 17 > 4 * 65 ? 16 * 17 : 4 * 65];
+  __shared__ f32x4 part[16 * 17 > 4 * 65 ? 16 * 17 : 4 * 65];
   int j = 0;
   while (j + 1 < tab.n && (int)blockIdx.x >= tab.j[j + 1].blk0) ++j;      // block-uniform
-  const float* __restrict__ slab = tab.j[j].slab;
+  const f32x4* __restrict__ slab = reinterpret_cast<const f32x4*>(tab.j[j].slab);
   float* __restrict__ gw = tab.j[j].gw;
-  const int64_t nw = tab.j[j].nw;
+  const int64_t nw4 = tab.j[j].nw >> 2;
   const int nslices = tab.j[j].nslices, sgn = tab.j[j].sg, epb = 256 / sgn;
   const int e = threadIdx.x % epb, sg = threadIdx.x / epb;
   const int64_t i = (int64_t)((int)blockIdx.x - tab.j[j].blk0) * epb + e;
-  float a[8];
+  f32x4 a[8];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) a[u] = 0.f;
-  if (i < nw) {
+  for (int u = 0; u < 8; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (i < nw4) {
     int k = sg;
     for (; k + 7 * sgn < nslices; k += 8 * sgn) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] += slab[(size_t)(k + u * sgn) * nw + i];
+      for (int u = 0; u < 8; ++u) a[u] += slab[(size_t)(k + u * sgn) * nw4 + i];
     }
-    for (; k < nslices; k += sgn) a[0] += slab[(size_t)k * nw + i];
+    for (; k < nslices; k += sgn) a[0] += slab[(size_t)k * nw4 + i];
   }
-  const float s0 = (a[0] + a[1]) + (a[2] + a[3]), s1 = (a[4] + a[5]) + (a[6] + a[7]);
+  const f32x4 s0 = (a[0] + a[1]) + (a[2] + a[3]), s1 = (a[4] + a[5]) + (a[6] + a[7]);
   if (sgn == 1) {
-    if (i < nw) atomicAdd(gw + i, s0 + s1);
+    if (i < nw4) {
+      const f32x4 t = s0 + s1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) atomicAdd(gw + 4 * i + q, t[q]);
+    }
     return;
   }
   part[sg * (epb + 1) + e] = s0 + s1;
   __syncthreads();
-  if ((int)threadIdx.x < epb && i < nw) {
-    float t = 0.f;
+  if ((int)threadIdx.x < epb && i < nw4) {
+    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int q = 0; q < sgn; ++q) t += part[q * (epb + 1) + e];
-    atomicAdd(gw + i, t);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) atomicAdd(gw + 4 * i + q, t[q]);
   }
 }
 
@@ -1343,7 +1352,8 @@ extern "C" int tg_wgrad_defer_flush(void* stream) {
 }
 
 int tg_wgrad_slab_reduce(const float* slab, float* gw, int64_t nw, int nslices, int accumulate, hipStream_t s) {
-  if (g_defer_on && accumulate && g_defer.n < MAXJ && nw < (1ll << 31) && !tg_deterministic_mode()) {
+  if (g_defer_on && accumulate && g_defer.n < MAXJ && nw < (1ll << 31) && (nw & 3) == 0 &&
+      (reinterpret_cast<uintptr_t>(slab) & 15u) == 0 && !tg_deterministic_mode()) {
     SlabJob& jb = g_defer.j[g_defer.n++];
     jb.slab = slab;
     jb.gw = gw;
@@ -1351,8 +1361,8 @@ int tg_wgrad_slab_reduce(const float* slab, float* gw, int64_t nw, int nslices, 
     jb.nslices = nslices;
     jb.sg = nw < 16384 ? 16 : (nw < 131072 ? 4 : 1);      // the stand-alone kernels' rule
     jb.blk0 = g_defer.blocks;
-    const int epb = 256 / jb.sg;
-    g_defer.blocks += (int)((nw + epb - 1) / epb);
+    const int epb = 256 / jb.sg;                           // threads per slice group; each owns 4 elements
+    g_defer.blocks += (int)((nw / 4 + epb - 1) / epb);
     return TG_OK;
   }
   s = wg_reduce_stream(s, accumulate);

@@ -480,6 +480,89 @@ __global__ void pw_wgrad_kernel(const T* __restrict__ small, const T* __restrict
   }
 }
 
+// The fromRGB filter gradient at full resolution (nets/pggan.py:233-240,395-399: 3 -> 16 channels at 256 x 256, 1-4 M pixels
+// per launch).  pw_wgrad_kernel fetches a pixel's three RGB values as three 2-byte loads in EVERY channel-vector thread of
+// the pixel -- four memory instructions per 22 bytes: 1.06 TB/s (profiles/r03_z_shapes_eager_step.json).  Here a thread
+// owns one 16-byte channel vector of FOUR consecutive pixels: their 12 RGB values are three aligned 8-byte loads, the big
+// side four 16-byte loads; U quads in flight.  BIAS: the big side is the layer's output gradient and its per-channel
+// pixel sum (the BiasAddGrad of the same layer, a separate tg_channel_sum pass over the same tensor before) rides along
+// as a fourth accumulator row.  16-bit storage types, 3 small channels, cb = 8 * 2^k <= 512 channels, npix % 4 == 0.
+template <typename T> struct Quad16;
+template <> struct Quad16<bf16> { typedef bf16x4 type; };
+template <> struct Quad16<f16> { typedef __attribute__((ext_vector_type(4))) _Float16 type; };
+template <typename T, bool BIAS>
+__global__ __launch_bounds__(1024) void pw_wgrad_rgb4_kernel(const T* __restrict__ small, const T* __restrict__ big,
+                                                             float* __restrict__ out, float* __restrict__ gbias,
+                                                             int64_t nquad, int cb, int os, int oc) {
+  constexpr int V = 8, NS = 3, R = NS + (BIAS ? 1 : 0), U = 2;
+  typedef typename Quad16<T>::type q16;
+  extern __shared__ float sacc[];   // result [R][cb], then one [R][cb] slot per wave
+  const int cv = cb / V;
+  const int lanes = blockDim.x / cv;           // quad lanes per block (cv is a power of two <= 64: lanes * cv = blockDim)
+  const int v = threadIdx.x % cv, pl = threadIdx.x / cv;
+  float acc[R][V];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[r][j] = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * lanes;
+  for (int64_t qb = (int64_t)blockIdx.x * lanes + pl; qb < nquad; qb += stride * U) {
+    Vec16<T> bv[U][4];
+    q16 sw[U][NS];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t q = qb + u * stride;
+      q = q < nquad ? q : nquad - 1;      // clamped, not predicated: no branches between the loads
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bv[u][k] = ldv(big + (4 * q + k) * cb + v * V);
+      const q16* sp = reinterpret_cast<const q16*>(small + 4 * q * NS);      // 24 bytes per quad: 8-byte aligned
+#pragma unroll
+      for (int w = 0; w < NS; ++w) sw[u][w] = sp[w];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (qb + u * stride < nquad) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float sv[NS];
+#pragma unroll
+          for (int c3 = 0; c3 < NS; ++c3) sv[c3] = (float)sw[u][(k * NS + c3) >> 2][(k * NS + c3) & 3];
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            const float b = bv[u][k].get(j);
+#pragma unroll
+            for (int c3 = 0; c3 < NS; ++c3) acc[c3][j] = fmaf(sv[c3], b, acc[c3][j]);
+            if constexpr (BIAS) acc[NS][j] += b;
+          }
+        }
+      }
+    }
+  }
+  // the quad lanes of a wave that own the same channel vector, then the waves in wave order (fixed summation order)
+  for (int o = cv; o < 64; o <<= 1) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[r][j] += __shfl_xor(acc[r][j], o, 64);
+  }
+  float* slot = sacc + (1 + (threadIdx.x >> 6)) * R * cb;
+  if ((int)(threadIdx.x & 63) < cv) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int j = 0; j < V; ++j) slot[r * cb + v * V + j] = acc[r][j];
+  }
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+  for (int i = threadIdx.x; i < R * cb; i += blockDim.x) {
+    float t = 0.f;
+    for (int wv = 0; wv < nw; ++wv) t += sacc[(1 + wv) * R * cb + i];
+    const int r = i / cb, c = i - r * cb;
+    if (r < NS) atomicAdd(out + (int64_t)r * os + (int64_t)c * oc, t);
+    else atomicAdd(gbias + c, t);
+  }
+}
+
 // gw[s*os + c*oc] (+)= sum over workgroups b of part[b][s][c], in workgroup order
 __global__ void pw_wgrad_final_kernel(const float* __restrict__ part, int nb, int ns, int cb, int os, int oc,
                                       float* __restrict__ gw, int accumulate) {
@@ -515,8 +598,9 @@ int launch_pw_fwd(const T* x, const float* w, const float* bias, T* y, int64_t n
   return TG_OK;
 }
 
+// -> 1 when the launch also added the pixel sums of gy into gbias (the RGB kernel), else 0 (gbias untouched)
 template <typename T>
-int launch_pw_wgrad(const T* x, const T* gy, float* gw, int64_t npix, int cin, int cout, hipStream_t s) {
+int launch_pw_wgrad(const T* x, const T* gy, float* gw, int64_t npix, int cin, int cout, hipStream_t s, float* gbias = nullptr) {
   constexpr int V = Vec16<T>::N;
   // small side = the <=4-channel tensor
   const bool small_in = cin <= 4;
@@ -527,6 +611,20 @@ int launch_pw_wgrad(const T* x, const T* gy, float* gw, int64_t npix, int cin, i
   // Every workgroup ends with ns * cb float atomics on the SAME few addresses, and with only a few trips per thread all
   // workgroups arrive there together: at 1024 workgroups the launch took ~45 us whatever the pixel count (1 M: 49.7 us,
   // 2 M: 43.9 us).  One 1024-thread workgroup per CU keeps the bytes in flight and quarters the atomics per address.
+  if constexpr (sizeof(T) == 2) {
+    const int cv8 = cb / 8;
+    if (!exact_grid<T>() && ns == 3 && cb % 8 == 0 && cv8 <= 64 && (cv8 & (cv8 - 1)) == 0 && npix % 4 == 0 &&
+        (gbias == nullptr || small_in) && tg_tune("TG_TUNE_PW_RGB4", 1)) {
+      const int64_t nquad = npix / 4;
+      const int blocks4 = tg_grid_for(nquad, 1024, 256);
+      const size_t lds4 = (size_t)(3 + (gbias ? 1 : 0)) * cb * sizeof(float) * (1 + 1024 / 64);
+      if (gbias)
+        hipLaunchKernelGGL((pw_wgrad_rgb4_kernel<T, true>), dim3(blocks4), dim3(1024), lds4, s, small, big, gw, gbias, nquad, cb, os, oc);
+      else
+        hipLaunchKernelGGL((pw_wgrad_rgb4_kernel<T, false>), dim3(blocks4), dim3(1024), lds4, s, small, big, gw, gbias, nquad, cb, os, oc);
+      return 1;      // the bias sum (if asked for) is done
+    }
+  }
   const int threads = exact_grid<T>() ? 256 : 1024;
   const size_t lds = (size_t)ns * cb * sizeof(float) * (1 + threads / 64);
   // >= 4096 pixels per workgroup: a small map (the 32 x 32 stages of the tests) is one workgroup, i.e. a fixed summation
@@ -768,6 +866,26 @@ int tg_pointwise_conv_bwd_weight(const void* x, const void* gy, float* gw, int64
     launch_pw_wgrad<T>((const T*)x, (const T*)gy, gw, npix, cin, cout, (hipStream_t)stream);
   });
   TG_LAUNCH_CHECK("tg_pointwise_conv_bwd_weight");
+  return TG_OK;
+}
+
+// The same filter gradient and, from the same read of gy, the layer's bias gradient gbias[cout] (+)= sum over pixels of gy
+// (BiasAddGrad of the fromRGB layer, nets/pggan.py:233-240): one launch where the RGB kernel takes the shape, else the
+// filter gradient followed by tg_channel_sum.
+int tg_pointwise_conv_bwd_weight_bias(const void* x, const void* gy, float* gw, float* gbias, int64_t npix, int cin, int cout,
+                                      int accumulate, int dtype, void* stream) {
+  TG_CHECK(x && gy && gw && gbias && npix > 0 && cin > 0 && cout > 0, TG_EINVAL, "tg_pointwise_conv_bwd_weight_bias: bad arguments");
+  TG_CHECK(cin <= 4, TG_ENOSUP, "tg_pointwise_conv_bwd_weight_bias: the small side must be the input (cin <= 4)");
+  if (!accumulate) {
+    int rc = tg_zero_async(gw, (size_t)cin * cout * sizeof(float), gbias, (size_t)cout * sizeof(float), (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  int fused = 0;
+  TG_DISPATCH_DTYPE(dtype, "tg_pointwise_conv_bwd_weight_bias", {
+    fused = launch_pw_wgrad<T>((const T*)x, (const T*)gy, gw, npix, cin, cout, (hipStream_t)stream, gbias);
+  });
+  TG_LAUNCH_CHECK("tg_pointwise_conv_bwd_weight_bias");
+  if (!fused) return tg_channel_sum(gy, gbias, npix, cout, 1, dtype, stream);
   return TG_OK;
 }
 

@@ -14,6 +14,36 @@ __device__ __forceinline__ void mb_load_samples(const T* __restrict__ x, int n, 
 }
 
 
+// out[px][0..c) = src[px][0..c), out[px][c] = val, out[px][c+1..cpad) = 0 over nvec 16-byte vectors of the padded tensor,
+// four vectors per thread in flight (a load -> store loop of one vector per trip is one L2 round trip per trip)
+template <typename T>
+__device__ __forceinline__ void mb_copy_with_stat(const T* __restrict__ src, T* __restrict__ out, int64_t nvec, int c,
+                                                  int cpad, float val) {
+  constexpr int V = Vec16<T>::N;
+  constexpr int U = 4;
+  const int cvp = cpad / V;
+  for (int64_t i0 = threadIdx.x; i0 < nvec; i0 += (int64_t)blockDim.x * U) {
+    Vec16<T> o[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t i = i0 + (int64_t)u * blockDim.x;
+      i = i < nvec ? i : nvec - 1;
+      const int cb = (int)(i % cvp) * V;
+      const int64_t px = i / cvp;
+      if (cb < c) {
+        o[u] = ldv(src + px * c + cb);
+      } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[u].set(j, (cb + j == c) ? val : 0.f);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * blockDim.x;
+      if (i < nvec) stv(out + (i / cvp) * cpad + (int)(i % cvp) * V, o[u]);
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Minibatch stddev, nets/pggan_utils.py:353-366.  x[n][p], p = hw*c.  Single workgroup: the tensor
@@ -96,19 +126,7 @@ __global__ __launch_bounds__(1024) void mbstd_fwd_kernel(const T* __restrict__ x
   if (threadIdx.x == 0 && stat) stat[0] = val;
   const int64_t total = (int64_t)n * hw * cpad;
   if (c % V == 0 && cpad % V == 0) {
-    const int cvp = cpad / V;
-    for (int64_t i = threadIdx.x; i < total / V; i += blockDim.x) {
-      const int cb = (int)(i % cvp) * V;
-      const int64_t px = i / cvp;
-      Vec16<T> o;
-      if (cb < c) {
-        o = ldv(x + px * c + cb);
-      } else {
-#pragma unroll
-        for (int j = 0; j < V; ++j) o.set(j, (cb + j == c) ? val : 0.f);
-      }
-      stv(out + px * cpad + cb, o);
-    }
+    mb_copy_with_stat<T>(x, out, total / V, c, cpad, val);
   } else {
     for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
       const int ch = (int)(i % cpad);
@@ -124,26 +142,43 @@ __global__ __launch_bounds__(1024) void mbstd_fwd_kernel(const T* __restrict__ x
 }
 
 // gx[n][p] = gout[n][hw][ch<c] + G * (x - mu_p) / (N * sigma_p * P),  G = sum over (n,hw) of gout[..., c]
+// 256-thread workgroups, gridDim.y of them per statistic group, one 16-byte position vector per thread and trip (two
+// workgroups cover the [16, 4, 4, 256] bf16 tensor; each sums G for itself): the 2 x 16 sample vectors a thread keeps in
+// flight need more than the 128 VGPRs launch_bounds(1024) left it -- the single 1024-thread workgroup spilled 168-392
+// bytes per thread to scratch and took 24-52 us for 400 KB of traffic (profiles/r03_z_shapes_eager_step.json).
+// The first trip's loads are requested BEFORE the reduction of G, whose barrier they do not depend on.
 template <typename T>
-__global__ __launch_bounds__(1024) void mbstd_bwd_kernel(const T* __restrict__ gout, const T* __restrict__ x,
-                                                         T* __restrict__ gx, int n, int hw, int c, int cpad, float eps) {
+__global__ __launch_bounds__(256) void mbstd_bwd_kernel(const T* __restrict__ gout, const T* __restrict__ x,
+                                                        T* __restrict__ gx, int n, int hw, int c, int cpad, float eps) {
   __shared__ float red[16];
   const int P = hw * c;
   gout += (int64_t)blockIdx.x * n * hw * cpad;
   x += (int64_t)blockIdx.x * n * P;
   gx += (int64_t)blockIdx.x * n * P;
+  constexpr int V = Vec16<T>::N;
+  const bool fast = c % V == 0 && cpad % V == 0 && n <= MB_NMAX;
+  Vec16<T> xs[MB_NMAX], gs[MB_NMAX];
+  const int pstep = gridDim.y * blockDim.x * V;
+  const int pfirst = (blockIdx.y * blockDim.x + threadIdx.x) * V;
+  if (fast) {      // dead threads (pfirst >= P) read position 0: harmless, never used
+    const int p = pfirst < P ? pfirst : 0;
+    const int px = p / c, ch = p - px * c;
+    mb_load_samples<T>(x, n, P, p, xs);
+#pragma unroll
+    for (int i = 0; i < MB_NMAX; ++i) gs[i] = ldv(gout + ((int64_t)(i < n ? i : n - 1) * hw + px) * cpad + ch);
+  }
   float acc = 0.f;
   for (int i = threadIdx.x; i < n * hw; i += blockDim.x) acc += ld(gout + (int64_t)i * cpad + c);
   const float G = block_sum(acc, red);
-  constexpr int V = Vec16<T>::N;
-  if (c % V == 0 && cpad % V == 0 && n <= MB_NMAX) {
-    for (int p = threadIdx.x * V; p < P; p += blockDim.x * V) {
+  if (fast) {
+    for (int p = pfirst; p < P; p += pstep) {
       float mu[V], var[V], k[V];
-      Vec16<T> xs[MB_NMAX], gs[MB_NMAX];
-      const int px = p / c, ch = p - px * c;
-      mb_load_samples<T>(x, n, P, p, xs);
+      if (p != pfirst) {
+        const int px = p / c, ch = p - px * c;
+        mb_load_samples<T>(x, n, P, p, xs);
 #pragma unroll
-      for (int i = 0; i < MB_NMAX; ++i) gs[i] = ldv(gout + ((int64_t)(i < n ? i : n - 1) * hw + px) * cpad + ch);
+        for (int i = 0; i < MB_NMAX; ++i) gs[i] = ldv(gout + ((int64_t)(i < n ? i : n - 1) * hw + px) * cpad + ch);
+      }
 #pragma unroll
       for (int j = 0; j < V; ++j) mu[j] = var[j] = 0.f;
 #pragma unroll
@@ -177,7 +212,7 @@ __global__ __launch_bounds__(1024) void mbstd_bwd_kernel(const T* __restrict__ g
     return;
   }
   if (c % V == 0 && cpad % V == 0 && n <= 32) {
-    for (int p = threadIdx.x * V; p < P; p += blockDim.x * V) {
+    for (int p = pfirst; p < P; p += pstep) {
       float mu[V], var[V], k[V];
 #pragma unroll
       for (int j = 0; j < V; ++j) mu[j] = var[j] = 0.f;
@@ -210,7 +245,7 @@ __global__ __launch_bounds__(1024) void mbstd_bwd_kernel(const T* __restrict__ g
     }
     return;
   }
-  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+  for (int p = blockIdx.y * blockDim.x + threadIdx.x; p < P; p += gridDim.y * blockDim.x) {
     float mu = 0.f;
     for (int i = 0; i < n; ++i) mu += ld(x + (int64_t)i * P + p);
     mu /= (float)n;
@@ -232,11 +267,11 @@ __global__ __launch_bounds__(1024) void mbstd_bwd_kernel(const T* __restrict__ g
 // Double backward.  With c_n = x_n - mu, sigma = sqrt(mean c^2 + eps), gx_n = gpass_n + G c_n /(N sigma P):
 //   d/dG      : T = sum_{n,p} v_np c_np / (N sigma_p P)  -> ggout[..., c] = T for every (n,hw); ggout[..., <c] = v
 //   d/dx_mp   : (G/(N P)) * [ (v_m - mean_n v)/sigma - (sum_n v_n c_n) c_m / (N sigma^3) ]
-template <typename T>
-__global__ __launch_bounds__(1024) void mbstd_bwd_bwd_kernel(const T* __restrict__ v, const T* __restrict__ gout,
-                                                             const T* __restrict__ x, T* __restrict__ ggout,
-                                                             T* __restrict__ gx2, int n, int hw, int c, int cpad,
-                                                             float eps) {
+template <typename T>      // 512 threads, first trip's loads ahead of the reduction of G: see mbstd_bwd_kernel
+__global__ __launch_bounds__(512) void mbstd_bwd_bwd_kernel(const T* __restrict__ v, const T* __restrict__ gout,
+                                                            const T* __restrict__ x, T* __restrict__ ggout,
+                                                            T* __restrict__ gx2, int n, int hw, int c, int cpad,
+                                                            float eps) {
   __shared__ float red[16];
   const int P = hw * c;
   v += (int64_t)blockIdx.x * n * P;
@@ -244,17 +279,24 @@ __global__ __launch_bounds__(1024) void mbstd_bwd_bwd_kernel(const T* __restrict
   x += (int64_t)blockIdx.x * n * P;
   if (ggout) ggout += (int64_t)blockIdx.x * n * hw * cpad;
   if (gx2) gx2 += (int64_t)blockIdx.x * n * P;
+  constexpr int V = Vec16<T>::N;
+  const bool fast = P % V == 0 && n <= MB_NMAX;
+  Vec16<T> xs[MB_NMAX], vs[MB_NMAX];
+  const int pfirst = threadIdx.x * V;
+  if (fast) {      // dead threads (pfirst >= P) read position 0: harmless, never used
+    mb_load_samples<T>(x, n, P, pfirst < P ? pfirst : 0, xs);
+    mb_load_samples<T>(v, n, P, pfirst < P ? pfirst : 0, vs);
+  }
   float acc = 0.f;
   for (int i = threadIdx.x; i < n * hw; i += blockDim.x) acc += ld(gout + (int64_t)i * cpad + c);
   const float G = block_sum(acc, red);
   float tacc = 0.f;
-  constexpr int V = Vec16<T>::N;
-  const bool fast = P % V == 0 && n <= MB_NMAX;
   if (fast) {
-    for (int p = threadIdx.x * V; p < P; p += blockDim.x * V) {
-      Vec16<T> xs[MB_NMAX], vs[MB_NMAX];
-      mb_load_samples<T>(x, n, P, p, xs);
-      mb_load_samples<T>(v, n, P, p, vs);
+    for (int p = pfirst; p < P; p += blockDim.x * V) {
+      if (p != pfirst) {
+        mb_load_samples<T>(x, n, P, p, xs);
+        mb_load_samples<T>(v, n, P, p, vs);
+      }
       float mu[V], vm[V], var[V], vc[V], sigma[V];
 #pragma unroll
       for (int j = 0; j < V; ++j) mu[j] = vm[j] = var[j] = vc[j] = 0.f;
@@ -332,19 +374,7 @@ __global__ __launch_bounds__(1024) void mbstd_bwd_bwd_kernel(const T* __restrict
   if (ggout) {
     const int64_t total = (int64_t)n * hw * cpad;
     if (c % V == 0 && cpad % V == 0) {
-      const int cvp = cpad / V;
-      for (int64_t i = threadIdx.x; i < total / V; i += blockDim.x) {
-        const int cb = (int)(i % cvp) * V;
-        const int64_t px = i / cvp;
-        Vec16<T> o;
-        if (cb < c) {
-          o = ldv(v + px * c + cb);
-        } else {
-#pragma unroll
-          for (int j = 0; j < V; ++j) o.set(j, (cb + j == c) ? Tt : 0.f);
-        }
-        stv(ggout + px * cpad + cb, o);
-      }
+      mb_copy_with_stat<T>(v, ggout, total / V, c, cpad, Tt);
     } else {
       for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
         const int ch = (int)(i % cpad);
@@ -629,7 +659,10 @@ int tg_mbstd_bwd(const void* gout, const void* x, void* gx, int n, int groups, i
   TG_CHECK(gout && x && gx && n > 0 && hw > 0 && c > 0 && cpad > c, TG_EINVAL, "tg_mbstd_bwd: bad arguments");
   TG_CHECK(groups > 0 && n % groups == 0, TG_EINVAL, "tg_mbstd_bwd: n (%d) not divisible by groups (%d)", n, groups);
   TG_DISPATCH_DTYPE(dtype, "tg_mbstd_bwd", {
-    hipLaunchKernelGGL(mbstd_bwd_kernel<T>, dim3(groups), dim3(1024), 0, (hipStream_t)stream, (const T*)gout, (const T*)x,
+    int nsplit = (hw * c / Vec16<T>::N + 255) / 256;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > 8) nsplit = 8;
+    hipLaunchKernelGGL(mbstd_bwd_kernel<T>, dim3(groups, nsplit), dim3(256), 0, (hipStream_t)stream, (const T*)gout, (const T*)x,
                        (T*)gx, n / groups, hw, c, cpad, eps);
   });
   TG_LAUNCH_CHECK("tg_mbstd_bwd");
@@ -641,7 +674,7 @@ int tg_mbstd_bwd_bwd(const void* v, const void* gout, const void* x, void* ggout
   TG_CHECK(v && gout && x && n > 0 && hw > 0 && c > 0 && cpad > c, TG_EINVAL, "tg_mbstd_bwd_bwd: bad arguments");
   TG_CHECK(groups > 0 && n % groups == 0, TG_EINVAL, "tg_mbstd_bwd_bwd: n (%d) not divisible by groups (%d)", n, groups);
   TG_DISPATCH_DTYPE(dtype, "tg_mbstd_bwd_bwd", {
-    hipLaunchKernelGGL(mbstd_bwd_bwd_kernel<T>, dim3(groups), dim3(1024), 0, (hipStream_t)stream, (const T*)v,
+    hipLaunchKernelGGL(mbstd_bwd_bwd_kernel<T>, dim3(groups), dim3(512), 0, (hipStream_t)stream, (const T*)v,
                        (const T*)gout, (const T*)x, (T*)ggout, (T*)gx2, n / groups, hw, c, cpad, eps);
   });
   TG_LAUNCH_CHECK("tg_mbstd_bwd_bwd");

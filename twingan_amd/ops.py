@@ -999,7 +999,14 @@ class PointwiseConvFn(torch.autograd.Function):
       # y = x @ W: dW = x^T g.  With wt the stored tensor is W^T, so dw = g^T x.
       a, b = (g, x) if ctx.wt else (x, g)
       sink = GradSink.get(w)
-      if sink is not None:
+      bsink = GradSink.get(bias) if need_b else None
+      if sink is not None and bsink is not None and not ctx.wt and a.shape[-1] <= 4 and not deterministic():
+        # fromRGB: the bias gradient (pixel sums of g) from the filter gradient's own read of g
+        ca, cb = a.shape[-1], b.shape[-1]
+        call('tg_pointwise_conv_bwd_weight_bias', _p(a), _p(b), _p(sink), _p(bsink), a.numel() // ca, ca, cb, 1, _dt(a), _stream(),
+             work=('pw_wgrad:c%d>%d:px%d' % (ca, cb, a.numel() // ca), 2 * a.numel() * cb, _nb(a, b)))
+        need_b = False
+      elif sink is not None:
         _pw_wgrad_into(a, b, sink, True)
       else:
         gw = PointwiseWgradFn.apply(a, b)
