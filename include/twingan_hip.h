@@ -154,12 +154,20 @@ int tg_conv2d_bwd_weight2_bias(const TgConvDesc* d, int nb, const void* xa, cons
  * sources instead of from a materialised copy: y[n,h,w,cout] = conv3x3_same(concat(up2(x0 [n,h/2,w/2,c0]),
  * x1 [n1,h,w,c1]), w) and its filter gradient gw[3][3][c0+c1][cout].  16-bit activations (dtype = TG_BF16 / TG_F16, packs
  * in the same format); w_pack = mode-0 pack of the
- * ordinary [3,3,c0+c1,cout] kernel; (gsz, perm) as in tg_upsample2x_concat_fwd.  The input gradient is the ordinary
- * tg_conv2d_bwd_data followed by tg_upsample2x_concat_bwd.  tg_conv2d_upcat_supported: h % 8 == 0, w % 16 == 0,
+ * ordinary [3,3,c0+c1,cout] kernel; (gsz, perm) as in tg_upsample2x_concat_fwd.  The input gradient is
+ * tg_conv2d_upcat_bwd_data (or the ordinary tg_conv2d_bwd_data followed by tg_upsample2x_concat_bwd).  tg_conv2d_upcat_supported: h % 8 == 0, w % 16 == 0,
  * c0 % 32 == 0, c1 % 32 == 0, cout % 8 == 0. */
 int tg_conv2d_upcat_supported(int h, int w, int c0, int c1, int cout);
 int tg_conv2d_upcat_fwd(const void* x0, const void* x1, const void* w_pack, void* y, int n, int h, int w, int c0, int c1,
                         int cout, int gsz, unsigned perm, int dtype, void* stream);
+/* The same conv's input gradient written straight into the gradients of the two sources (Conv2DBackpropInput +
+ * ConcatV2 / ResizeNearestNeighbor gradients of nets/pggan_utils.py:281-298,349-350 in one launch): g0 [n,h/2,w/2,c0] =
+ * 2x2 sums of channels [0,c0) of conv3x3^T(gy [n,h,w,cout], w), g1 [n1,h,w,c1] = channels [c0,c0+c1), summed over the groups
+ * that read one skip image ((gsz, perm) as above; n1 = (max perm + 1) * gsz, or n without groups) -- from the fp32
+ * accumulators, one rounding; the concat-layout gradient tensor is never written.  w_pack = mode-1 pack of the kernel for
+ * the descriptor (n,h,w,c0+c1) -> cout.  Either output may be NULL (not wanted).  Shapes: tg_conv2d_upcat_supported. */
+int tg_conv2d_upcat_bwd_data(const void* gy, const void* w_pack, void* g0, void* g1, int n, int h, int w, int c0, int c1,
+                             int cout, int gsz, unsigned perm, int dtype, void* stream);
 /* Conv followed by a normaliser (every encoder / generator conv: layers.conv2d(normalizer_fn=instance_norm),
  * nets/pggan_utils.py:86-98 -> tf.nn.moments over the conv output, libs/instance_norm.py:131): the forward conv also
  * writes, per output channel, the sum and the sum of squares of the (bf16-rounded) outputs each workgroup produced --

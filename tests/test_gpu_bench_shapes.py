@@ -296,6 +296,21 @@ def test_upcat_conv_at_bench_shapes(key):
   tot = sum(N.conv2d_bwd_data_gemm(gyn[i:i + 1], wn, (hw, hw))[..., c0:] for i in (gsz + j, 2 * gsz + j))
   e = rel_l2(host(x1.grad[j:j + 1]), tot)
   assert e < 2 * BF16_OUT_TOL, ('upcat gx1', key, e)
+  # the backward-data kernel that wrote them (concat adjoint in its epilogue), called directly: same bits, and its symbol
+  if O.USE_UPCAT_BWD_FUSED:
+    d = O._desc((n, hw, hw, c0 + c1), cout, O.ConvSpec(3, 'SAME'), gy.dtype, 0)
+    g0, g1 = torch.empty_like(x0), torch.empty_like(x1)
+    O.call('tg_conv2d_upcat_bwd_data', gy.data_ptr(), O.PackCache.get(w.detach(), d, 1).data_ptr(), g0.data_ptr(), g1.data_ptr(),
+           n, hw, hw, c0, c1, cout, gsz, O._pack_perm(perm), O._dt(gy), O._stream())
+    _note(key, 'tg_conv2d_upcat_bwd_data', str(n))
+    assert torch.equal(g0, x0.grad) and torch.equal(g1, x1.grad), ('upcat bwd_data direct call', key)
+    # and against the unfused composition (backward-data into the concat layout, then the split): two roundings there
+    gcat = O.conv_bwd_data_raw(gy, w.detach(), (n, hw, hw, c0 + c1), O.ConvSpec(3, 'SAME'))
+    r0, r1 = torch.empty_like(x0), torch.empty_like(x1)
+    O.call('tg_upsample2x_concat_bwd', gcat.data_ptr(), r0.data_ptr(), r1.data_ptr(), n, hw // 2, hw // 2, c0, c1, gsz,
+           O._pack_perm(perm), O._dt(gcat), O._stream())
+    e0, e1 = rel_l2(host(g0), host(r0)), rel_l2(host(g1), host(r1))
+    assert e0 < BF16_OUT_TOL and e1 < BF16_OUT_TOL, ('fused vs composed concat backward', key, e0, e1)
 
 
 @pytest.mark.parametrize('n', [32, 48, 64])

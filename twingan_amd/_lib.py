@@ -55,6 +55,7 @@ SIGNATURES = {
     'tg_conv2d_bwd_weight2_bias': (c_int, [_D, c_int, _P, _P, _P, _P, _FP, _FP, c_int, c_int, _P, c_size_t, _P]),
     'tg_conv2d_upcat_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'tg_conv2d_upcat_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_uint, c_int, _P]),
+    'tg_conv2d_upcat_bwd_data': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_uint, c_int, _P]),
     'tg_transpose16': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'tg_flash_attention_supported': (c_int, [c_int, c_int, c_int]),
     'tg_flash_attention_workspace_bytes': (ctypes.c_int64, [c_int, c_int, c_int, c_int, c_int]),

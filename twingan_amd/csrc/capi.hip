@@ -54,6 +54,8 @@ int tg_conv2d_bwd_weight2_mfma(const TgConvDesc* d, int nb, const void* xa, cons
 bool tg_conv2d_bwd_weight_bias_fused_mfma(const TgConvDesc* d);
 
 bool tg_conv_tile_upcat_supported(int h, int w, int c0, int c1, int cout);
+int tg_conv_tile_upcat_bwd_run(int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, int n1, const void* gy,
+                               const void* wp, void* g0, void* g1, hipStream_t s);
 int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, const void* x0,
                            const void* x1, const void* wp, void* y, hipStream_t s, float* stats = nullptr,
                            int stat_chunks = 0, int* chunks_query = nullptr);
@@ -249,6 +251,29 @@ int tg_conv2d_fwd_stats(const TgConvDesc* d, const void* x, const void* w_pack, 
   TG_CHECK(d->algo != TG_ALGO_DIRECT && d->epilogue == 0, TG_ENOSUP,
            "tg_conv2d_fwd_stats: MFMA path, plain epilogue (query tg_conv2d_fwd_stats_chunks first)");
   return tg_conv2d_fwd_stats_mfma(d, x, w_pack, y, partials, chunks, (hipStream_t)stream);
+}
+
+// Input gradient of tg_conv2d_upcat_fwd's conv, straight into the two sources' gradients: g0 [n, h/2, w/2, c0] (2x2 sums of
+// the first c0 channels of conv3x3^T(gy, w)) and g1 [n1, h, w, c1] (the other channels, summed over the groups that read one
+// skip image) -- the backward-data kernel's epilogue instead of a concat-layout tensor + tg_upsample2x_concat_bwd.
+int tg_conv2d_upcat_bwd_data(const void* gy, const void* w_pack, void* g0, void* g1, int n, int h, int w, int c0, int c1,
+                             int cout, int gsz, unsigned perm, int dtype, void* stream) {
+  TG_CHECK(gy && w_pack && (g0 || g1), TG_EINVAL, "tg_conv2d_upcat_bwd_data: null pointer");
+  TG_CHECK(tg_aligned16(gy) && tg_aligned16(w_pack) && tg_aligned16(g0) && tg_aligned16(g1), TG_EALIGN,
+           "tg_conv2d_upcat_bwd_data: pointers must be 16 B aligned");
+  int rc = check_upcat("tg_conv2d_upcat_bwd_data", n, h, w, c0, c1, cout, gsz, perm, dtype);
+  if (rc) return rc;
+  int n1 = n;
+  if (gsz) {
+    int mx = 0;
+    for (int k = 0; k < n / gsz; ++k) {
+      const int v = (int)((perm >> (8 * k)) & 0xffu);
+      if (v > mx) mx = v;
+    }
+    TG_CHECK(mx < 4, TG_EINVAL, "tg_conv2d_upcat_bwd_data: permutation entry %d out of range", mx);
+    n1 = (mx + 1) * gsz;
+  }
+  return tg_conv_tile_upcat_bwd_run(n, h, w, c0, c1, cout, gsz, perm, n1, gy, w_pack, g0, g1, (hipStream_t)stream);
 }
 
 int tg_conv2d_upcat_fwd_stats_chunks(int n, int h, int w, int c0, int c1, int cout) {

@@ -56,6 +56,15 @@ struct TileGeom {
   // (nets/pggan.py:304-306): the tensor is never written (1/16 of its bytes instead) and never read back
   unsigned char* ymask;
   int* chunks_query;       // non-NULL: do not launch, report the chunk count the STATS variant of this dispatch would use
+  // UPBWD kernels (MODE 3): backward-data of a conv whose input was concat(nearest_up2(x0), x1) (UPCAT forward), with the
+  // adjoint of the upsample + concat -- tg_upsample2x_concat_bwd: a 2x2 SUM of the first c0 output channels, and the sum
+  // over the generator groups that read one skip image of the others -- done in the epilogue, from the fp32 accumulators:
+  // up_out [n, h/2, w/2, c0], skip_out [n1, h, w, cout - c0].  The concat-layout gradient tensor (537 MB at 256 x 256 x 64,
+  // n 64) is never written.  Output-channel blocks below c0 ("up") run once per image; blocks from c0 on ("skip") run once
+  // per SKIP image and walk the images of the groups og with perm[og] == that image's group (gsz, perm as in UPCAT).
+  bf16* up_out;
+  bf16* skip_out;
+  int n1;
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
@@ -176,6 +185,31 @@ __device__ __forceinline__ void stats_flush(const float (&tot)[BN / 32], float* 
   }
 }
 
+// UPBWD: the gy images whose concat-layout gradient adds up into skip image `img1` -- packed as group indices, 8 bits
+// each (<= 4 groups); without a group permutation the image itself.  -> number of sources (0: nobody read that image)
+__device__ __forceinline__ int upbwd_sources(const TileGeom& g, int img1, unsigned* pk) {
+  if (!g.gsz) {
+    *pk = 0;
+    return 1;
+  }
+  const int sg = img1 / g.gsz;
+  int ns = 0;
+  unsigned v = 0;
+  for (int og = 0; og < g.n / g.gsz; ++og)
+    if ((int)((g.perm >> (8 * og)) & 0xffu) == sg) v |= (unsigned)og << (8 * ns++);
+  *pk = v;
+  return ns;
+}
+__device__ __forceinline__ int upbwd_source_image(const TileGeom& g, int img1, unsigned pk, int s) {
+  return g.gsz ? (int)((pk >> (8 * s)) & 0xffu) * g.gsz + img1 % g.gsz : img1;
+}
+// 2x2 sum over this lane's pixel quad (lanes l31 ^ 1 and l31 ^ 16, see pool_quad) of an fp32 value; every lane of the quad
+// receives it
+__device__ __forceinline__ float sum_quad(float v) {
+  v += dpp_quad<0xB1>(v);
+  return add_lane_xor16(v);
+}
+
 // UPCAT: the conv input is concat(nearest_up2(x), x1) on channels (generator_three_layer_block,
 // nets/pggan.py:69-76) read straight from the two sources -- K chunks below c0 come from the half-resolution
 // tensor, the rest from the skip tensor -- instead of from a materialised copy.
@@ -184,7 +218,8 @@ template <int KH, int KC, int BN, int MT, bool UPCAT = false, int MODE = 0, bool
 __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                         const float* __restrict__ bias, bf16* __restrict__ y,
                                                         const TileGeom g) {
-  constexpr bool STATS = MODE == 1, POOL = MODE == 2;
+  constexpr bool STATS = MODE == 1, POOL = MODE == 2, UPBWD = MODE == 3;
+  static_assert(!(UPBWD && UPCAT), "UPBWD is a backward-data mode: its input is the plain output gradient");
   constexpr int KW = KH, NT = KH * KW;
   constexpr int TW = 16, TH = 8 * MT;
   constexpr int HWX = TW + KW - 1, HH = TH + KH - 1;
@@ -215,6 +250,16 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
   const int n0 = blockIdx.y * BN;
   const int c1 = g.cin - g.c0;
   const size_t img_elems = UPCAT ? (size_t)(g.h / 2) * (g.w / 2) * g.c0 : (size_t)g.h * g.w * g.cin;
+  // UPBWD: a "skip" block (output channels >= c0) belongs to skip image `img` and reads nsrc gy images
+  const bool skip_blk = UPBWD && n0 >= g.c0;
+  unsigned srcpk = 0;
+  int nsrc = 1;
+  if constexpr (UPBWD) {
+    if (skip_blk) {
+      if (img >= g.n1) return;      // block-uniform, before any barrier
+      nsrc = upbwd_sources(g, img, &srcpk);
+    }
+  }
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (size_t)img * img_elems, (unsigned)(img_elems * 2));
   const size_t img1_elems = (size_t)g.h * g.w * c1;
   const int img1 = (UPCAT && g.gsz) ? (int)((g.perm >> (8 * (img / g.gsz))) & 0xffu) * g.gsz + img % g.gsz : img;
@@ -270,8 +315,17 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
   // NOTE: a cin that is not a multiple of 16 (the 264-channel minibatch-stddev tensor) makes the last
   // chunk read 8 channels of the NEXT pixel; the weight pack is zero there, so they contribute 0.
   bf16x8 ra[ASLOTS], rb[BSLOTS];
-  auto load_chunk = [&](int c0) {
-    if constexpr (UPCAT) {
+  // UPBWD skip blocks: iteration `it` of the K loop is chunk it % nch of source it / nch
+  const int nch = g.cin_pad / KC;
+  auto load_chunk = [&](int it) {
+    const int c0 = UPBWD ? (it % nch) * KC : it * KC;
+    if constexpr (UPBWD) {
+      const bool dead = skip_blk && nsrc == 0;      // nobody read this skip image: zeros
+      const int simg = skip_blk ? upbwd_source_image(g, img, srcpk, it / nch) : img;
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(x + (size_t)simg * img_elems, dead ? 0u : (unsigned)(img_elems * 2));
+#pragma unroll
+      for (int s = 0; s < ASLOTS; ++s) ra[s] = buf_load16(rs, a_goff[s] + (unsigned)(c0 * 2));
+    } else if constexpr (UPCAT) {
       if (c0 < g.c0) {      // uniform: a chunk lies entirely in one source (c0 % KC == 0)
 #pragma unroll
         for (int s = 0; s < ASLOTS; ++s) ra[s] = buf_load16(rx, a_goff[s] + (unsigned)(c0 * 2));
@@ -295,12 +349,13 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
       if (s < BSLOTS - 1 || tid + s * 256 < BVEC) *reinterpret_cast<bf16x8*>(sB + b_loff[s]) = rb[s];
   };
 
+  const int nit = (UPBWD && skip_blk) ? (nsrc > 0 ? nsrc : 1) * nch : nch;
   load_chunk(0);
-  for (int c0 = 0; c0 < g.cin_pad; c0 += KC) {
-    if (c0) __syncthreads();             // everyone is done reading the previous chunk
+  for (int it = 0; it < nit; ++it) {
+    if (it) __syncthreads();             // everyone is done reading the previous chunk
     store_chunk();
     __syncthreads();
-    if (c0 + KC < g.cin_pad) load_chunk(c0 + KC);     // in flight during the MFMAs below
+    if (it + 1 < nit) load_chunk(it + 1);     // in flight during the MFMAs below
     // K steps of this chunk: (tap, 16-channel half).  The fragments of step s+1 are read from LDS before the MFMAs of
     // step s are issued (two fragment sets; the scheduling barriers keep the compiler from moving the reads back next
     // to their use), so an MFMA never waits a full LDS round trip for its operands.
@@ -333,6 +388,48 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
   // ---- epilogue.  acc[m][nt][4q + j] = channel n0 + nt*32 + 8q + 4*kgrp + j of this lane's pixel.
   // After the half-wave swap the low lane (kgrp 0) owns channels [0,16) of the 32-block, the high lane
   // [16,32), each as two 16-byte vectors.
+  if constexpr (UPBWD) {
+    // up block: the 2x2 sum of the accumulators -> up_out[img, oy/2, ox/2, n0 ..); skip block: the accumulators (already
+    // summed over the sources) -> skip_out[img, oy, ox, n0 - c0 ..).  One rounding, of the fp32 sums.
+    const int cs = skip_blk ? g.cout - g.c0 : g.c0;      // channels per pixel of the tensor written
+    const int chb = skip_blk ? n0 - g.c0 : n0;
+    const size_t oimg = skip_blk ? (size_t)g.h * g.w * cs : (size_t)(g.h / 2) * (g.w / 2) * cs;
+    bf16* const optr = skip_blk ? g.skip_out : g.up_out;      // NULL: that gradient is not wanted (stores dropped)
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(optr ? optr + (size_t)img * oimg : (bf16*)x, optr ? (unsigned)(oimg * 2) : 0u);
+#pragma unroll
+    for (int nt = 0; nt < NTILE; ++nt) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int oy = oy0 + (wid * MT + m) * 2 + (l31 >> 4), ox = ox0 + (l31 & 15);
+        unsigned p[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = skip_blk ? acc[m][nt][q * 4 + j] : sum_quad(acc[m][nt][q * 4 + j]);
+          p[q][0] = pack16x2<F16>(v[0], v[1]);
+          p[q][1] = pack16x2<F16>(v[2], v[3]);
+        }
+        u32x4 o0, o1;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          auto r02 = __builtin_amdgcn_permlane32_swap(p[0][d], p[2][d], false, false);
+          auto r13 = __builtin_amdgcn_permlane32_swap(p[1][d], p[3][d], false, false);
+          o0[d] = r02[0];
+          o0[2 + d] = r02[1];
+          o1[d] = r13[0];
+          o1[2 + d] = r13[1];
+        }
+        const int ch0 = chb + nt * 32 + kgrp * 16;
+        const bool owner = skip_blk || (l31 & 17) == 0;      // up: the even column of the sub-tile's first row stores
+        const unsigned off = skip_blk ? (unsigned)(((oy * g.w + ox) * cs + ch0) * 2)
+                                      : (unsigned)((((oy >> 1) * (g.w >> 1) + (ox >> 1)) * cs + ch0) * 2);
+        __builtin_amdgcn_raw_buffer_store_b128(o0, ro, (owner && ch0 + 8 <= cs) ? off : OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o1, ro, (owner && ch0 + 16 <= cs) ? off + 16 : OOB, 0, 0);
+      }
+    }
+    return;
+  }
   const size_t out_img = (size_t)g.h * g.w * g.cout;
   // POOL with a sign-mask output: y is not written (a zero-sized resource drops the stores)
   const bool y_dropped = POOL && g.ymask != nullptr;
@@ -452,7 +549,7 @@ template <int KH, int KC, int BN, int NCH, int MODE = 0, bool F16 = false>
 __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                              const float* __restrict__ bias, bf16* __restrict__ y,
                                                              const TileGeom g) {
-  constexpr bool STATS = MODE == 1, POOL = MODE == 2;
+  constexpr bool STATS = MODE == 1, POOL = MODE == 2, UPBWD = MODE == 3;      // UPBWD: see TileGeom::up_out
   constexpr int KW = KH, NT = KH * KW;
   constexpr int TW = 16, TH = 8;
   constexpr int HWX = TW + KW - 1, HH = TH + KH - 1;
@@ -474,6 +571,13 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
   const int n0 = blockIdx.y * BN;
   const int wrow = NT * g.cin_pad;
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(wp + (size_t)n0 * wrow, (unsigned)((size_t)BN * wrow * 2));
+  // UPBWD: "skip" blocks (output channels >= c0) walk the tiles of the n1 SKIP images, each over its source images
+  const bool skip_blk = UPBWD && n0 >= g.c0;
+  if constexpr (UPBWD) {
+    int wg0 = blockIdx.x;
+    if ((gridDim.x & 7) == 0) wg0 = (wg0 & 7) * (gridDim.x >> 3) + (wg0 >> 3);
+    if (skip_blk && wg0 * g.tiles_per_wg >= g.tiles_x * g.tiles_y * g.n1) return;      // block-uniform, before any barrier
+  }
 
   // ---- stage the whole weight slice (all chunks) once
 #pragma unroll
@@ -518,6 +622,9 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
   const int t_begin = wg * g.tiles_per_wg;
   int t_end = t_begin + g.tiles_per_wg;
   if (t_end > g.nblk) t_end = g.nblk;
+  if constexpr (UPBWD) {
+    if (skip_blk && t_end > g.tiles_x * g.tiles_y * g.n1) t_end = g.tiles_x * g.tiles_y * g.n1;
+  }
   const size_t img_elems = (size_t)g.h * g.w * g.cin;
   const size_t out_img = (size_t)g.h * g.w * g.cout;
 
@@ -530,13 +637,22 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
   struct Stage {
     bf16x8 ra[ASLOTS];
   };
-  auto load_a = [&](Stage& st, int t) __attribute__((always_inline)) {
-    const unsigned live = t < t_end;
+  // src (UPBWD skip blocks): which of the tile's source images
+  auto load_a = [&](Stage& st, int t, int src = 0) __attribute__((always_inline)) {
+    unsigned live = t < t_end;
     if (!live) t = t_begin;
     const int tx = t % g.tiles_x;
     const int r = t / g.tiles_x;
     const int ty = r % g.tiles_y;
-    const int img = r / g.tiles_y;
+    int img = r / g.tiles_y;
+    if constexpr (UPBWD) {
+      if (skip_blk) {
+        unsigned pk;
+        const int ns = upbwd_sources(g, img, &pk);
+        if (ns == 0) live = 0;      // nobody read this skip image: the tile is all zeros
+        img = upbwd_source_image(g, img, pk, src);
+      }
+    }
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (size_t)img * img_elems, (unsigned)(img_elems * 2));
 #pragma unroll
     for (int s = 0; s < ASLOTS; ++s) {
@@ -572,8 +688,10 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
   }
 
   bool first = true;
+  f32x16 acc[NTILE];      // outside the per-tile lambda: under UPBWD the accumulators live across the source images of a tile
   // one tile: stage -> LDS, refill the stage with tile t + 1, MFMAs, epilogue
-  auto process = [&](Stage& st, int t) __attribute__((always_inline)) {
+  // UPBWD: (t, src) of n_src is reduced now, (tn, sn) is the next one to stage; the epilogue runs after the last source
+  auto process = [&](Stage& st, int t, int src = 0, int n_src = 1, int tn = 0, int sn = 0) __attribute__((always_inline)) {
     const int tx = t % g.tiles_x;
     const int r = t / g.tiles_x;
     const int ty = r % g.tiles_y;
@@ -592,7 +710,8 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
     for (int s = 0; s < ASLOTS; ++s)
       if (s < ASLOTS - 1 || tid + s * 256 < AVEC) *reinterpret_cast<bf16x8*>(sA + a_loff[s]) = st.ra[s];
     __syncthreads();                      // (the first one also covers the weight staging)
-    load_a(st, t + 1);
+    if constexpr (UPBWD) load_a(st, tn, sn);
+    else load_a(st, t + 1);
     // the LeakyReLU mask of the epilogue (masked backward-data) is requested NOW, so that it lands during the MFMAs
     u32x2 zm[NTILE][4];
     if (g.mask) {      // uniform
@@ -605,11 +724,12 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
               rmask, chq + 4 <= g.cout ? (unsigned)(((oy * g.w + ox) * g.cout + chq) * 2) : OOB, 0, 0));
         }
     }
-    f32x16 acc[NTILE];
+    if (!UPBWD || src == 0) {
 #pragma unroll
-    for (int i = 0; i < NTILE; ++i)
+      for (int i = 0; i < NTILE; ++i)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    }
 #pragma unroll
     for (int ky = 0; ky < KH; ++ky) {
 #pragma unroll
@@ -626,6 +746,43 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
       }
     }
     // ---- epilogue of tile t
+    if constexpr (UPBWD) {      // as in conv_tile_kernel
+      if (src + 1 < n_src) return;
+      const int cs = skip_blk ? g.cout - g.c0 : g.c0;
+      const int chb = skip_blk ? n0 - g.c0 : n0;
+      const size_t oimg = skip_blk ? (size_t)g.h * g.w * cs : (size_t)(g.h / 2) * (g.w / 2) * cs;
+      bf16* const optr = skip_blk ? g.skip_out : g.up_out;      // NULL: that gradient is not wanted (stores dropped)
+      const __amdgpu_buffer_rsrc_t ro = make_rsrc(optr ? optr + (size_t)img * oimg : (bf16*)x, optr ? (unsigned)(oimg * 2) : 0u);
+#pragma unroll
+      for (int nt = 0; nt < NTILE; ++nt) {
+        unsigned p[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = skip_blk ? acc[nt][q * 4 + j] : sum_quad(acc[nt][q * 4 + j]);
+          p[q][0] = pack16x2<F16>(v[0], v[1]);
+          p[q][1] = pack16x2<F16>(v[2], v[3]);
+        }
+        u32x4 o0, o1;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          auto r02 = __builtin_amdgcn_permlane32_swap(p[0][d], p[2][d], false, false);
+          auto r13 = __builtin_amdgcn_permlane32_swap(p[1][d], p[3][d], false, false);
+          o0[d] = r02[0];
+          o0[2 + d] = r02[1];
+          o1[d] = r13[0];
+          o1[2 + d] = r13[1];
+        }
+        const int ch0 = chb + nt * 32 + kgrp * 16;
+        const bool owner = skip_blk || (l31 & 17) == 0;
+        const unsigned off = skip_blk ? (unsigned)(((oy * g.w + ox) * cs + ch0) * 2)
+                                      : (unsigned)((((oy >> 1) * (g.w >> 1) + (ox >> 1)) * cs + ch0) * 2);
+        __builtin_amdgcn_raw_buffer_store_b128(o0, ro, (owner && ch0 + 8 <= cs) ? off : OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o1, ro, (owner && ch0 + 16 <= cs) ? off + 16 : OOB, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NTILE; ++nt) {
       unsigned p[4][2];
@@ -704,6 +861,28 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
   };
 
   Stage sa;
+  if constexpr (UPBWD) {
+    auto n_sources = [&](int t) __attribute__((always_inline)) {
+      if (!skip_blk || t >= t_end) return 1;
+      unsigned pk;
+      const int ns = upbwd_sources(g, t / (g.tiles_x * g.tiles_y), &pk);
+      return ns > 0 ? ns : 1;      // an unread skip image is one all-zero "source"
+    };
+    int t = t_begin, src = 0, ns = n_sources(t);
+    load_a(sa, t, 0);
+    while (t < t_end) {
+      int tn = t, sn = src + 1;
+      if (sn >= ns) {
+        tn = t + 1;
+        sn = 0;
+      }
+      process(sa, t, src, ns, tn, sn);
+      if (tn != t) ns = n_sources(tn);
+      t = tn;
+      src = sn;
+    }
+    return;
+  }
   load_a(sa, t_begin);
   for (int t = t_begin; t < t_end; ++t) process(sa, t);
   if constexpr (STATS) {
@@ -756,7 +935,15 @@ int launch_tile_wres(const TileGeom& g0, const bf16* x, const bf16* wp, const fl
       hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH, MODE_, false>), dim3(nwg, ny), dim3(256), lds, s, x, wp, \
                          bias, y, g);                                                                                      \
   } while (0)
-  if (stats) {
+  if (g.up_out) {
+    if constexpr (KH == 3) {
+      TG_CHECK(g.epilogue == 0 && !g.mask && !g.ypool && !stats, TG_ENOSUP, "conv_tile(wres): the concat backward comes with the plain epilogue only");
+      tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d,upbwd%s>", KH, KC, BN, NCH, fmt);
+      TG_WRES_LAUNCH(3);
+    } else {
+      TG_CHECK(false, TG_ENOSUP, "conv_tile(wres): the concat backward is built for 3x3 only");
+    }
+  } else if (stats) {
     if constexpr (KH == 3) {
       TG_CHECK(g.epilogue == 0 && !g.mask && !g.ypool, TG_ENOSUP, "conv_tile(wres): statistics come with the plain epilogue only");
       tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d,stats%s>", KH, KC, BN, NCH, fmt);
@@ -797,7 +984,7 @@ int launch_tile_variant(const TileGeom& g, size_t lds, const bf16* x, const bf16
     }
   }
   // names as before for the bf16 kernels (tests/golden/bench_dispatch_kernels.json); ",f16" marks the half instantiation
-  static const char* const mode_tag[3] = {"", ",stats", ",pool"};
+  static const char* const mode_tag[4] = {"", ",stats", ",pool", ",upbwd"};
   if (F16 && MODE == 0 && !UPCAT) tg_note_kernel("conv_tile_kernel<%d,%d,%d,%d,f16>", KH, KC, BN, MT);
   else tg_note_kernel("conv_tile_kernel<%d,%d,%d,%d%s%s%s>", KH, KC, BN, MT, UPCAT ? ",upcat" : "", mode_tag[MODE], F16 ? ",f16" : "");
   hipLaunchKernelGGL(kern, dim3(g.nblk, (g.cout + BN - 1) / BN), dim3(256), lds, s, x, wp, bias, y, g);
@@ -817,6 +1004,15 @@ int launch_tile(const TileGeom& g0, const bf16* x, const bf16* wp, const float* 
   if (g.chunks_query) {
     *g.chunks_query = (KH == 3) ? g.tiles_x * g.tiles_y : 0;
     return TG_OK;
+  }
+  if (g.up_out) {
+    if constexpr (KH == 3 && !UPCAT) {
+      TG_CHECK(g.epilogue == 0 && !g.mask && !g.stats && !g.ypool, TG_ENOSUP, "conv_tile: the concat backward comes with the plain epilogue only");
+      return g.f16 ? launch_tile_variant<KH, KC, BN, MT, false, 3, true>(g, lds, x, wp, bias, y, s)
+                   : launch_tile_variant<KH, KC, BN, MT, false, 3, false>(g, lds, x, wp, bias, y, s);
+    } else {
+      TG_CHECK(false, TG_ENOSUP, "conv_tile: the concat backward is built for plain 3x3 backward-data only");
+    }
   }
   if (g.stats) {
     if constexpr (KH == 3) {
@@ -849,6 +1045,26 @@ int dispatch_tile_upcat(const TileGeom& g, const bf16* x, const bf16* wp, const 
   const bool mt2 = (g.h % 16 == 0) && tiles1 >= 2 * 2 * 256;
   if (wide) return mt2 ? launch_tile<3, 32, 64, 2, true>(g, x, wp, bias, y, s) : launch_tile<3, 32, 64, 1, true>(g, x, wp, bias, y, s);
   return mt2 ? launch_tile<3, 32, 32, 2, true>(g, x, wp, bias, y, s) : launch_tile<3, 32, 32, 1, true>(g, x, wp, bias, y, s);
+}
+
+// backward-data of the UPCAT forward with the upsample / concat adjoint in the epilogue (TileGeom::up_out): dispatch_tile's
+// rules, with 64-channel output blocks only where both halves of the concat are multiples of 64 (a block is all "up" or
+// all "skip")
+int dispatch_tile_upbwd(const TileGeom& g, const bf16* gy, const bf16* wp, hipStream_t s) {
+  const int c1 = g.cout - g.c0;
+  const bool wide = g.c0 % 64 == 0 && c1 % 64 == 0 && (g.w / 16) * (g.h / 8) * g.n * ((g.cout + 63) / 64) >= 1024;
+  const int tiles1 = (g.w / 16) * (g.h / 8) * g.n * ((g.cout + (wide ? 63 : 31)) / (wide ? 64 : 32));
+  const bool mt2 = (g.h % 16 == 0) && tiles1 >= 2 * 2 * 256 && g.cin_pad >= 64;
+  if (tiles1 >= 2048) {
+    if (g.cin_pad == 16) return wide ? launch_tile_wres<3, 16, 64, 1>(g, gy, wp, nullptr, nullptr, s) : launch_tile_wres<3, 16, 32, 1>(g, gy, wp, nullptr, nullptr, s);
+    if (g.cin_pad == 32) return wide ? launch_tile_wres<3, 32, 64, 1>(g, gy, wp, nullptr, nullptr, s) : launch_tile_wres<3, 32, 32, 1>(g, gy, wp, nullptr, nullptr, s);
+  }
+  if (g.cin_pad % 32 == 0) {
+    if (wide) return mt2 ? launch_tile<3, 32, 64, 2>(g, gy, wp, nullptr, nullptr, s) : launch_tile<3, 32, 64, 1>(g, gy, wp, nullptr, nullptr, s);
+    return mt2 ? launch_tile<3, 32, 32, 2>(g, gy, wp, nullptr, nullptr, s) : launch_tile<3, 32, 32, 1>(g, gy, wp, nullptr, nullptr, s);
+  }
+  if (wide) return launch_tile<3, 16, 64, 1>(g, gy, wp, nullptr, nullptr, s);
+  return launch_tile<3, 16, 32, 1>(g, gy, wp, nullptr, nullptr, s);
 }
 
 template <int KH>
@@ -904,6 +1120,8 @@ int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int
   g.chunks_query = chunks_query;
   g.ypool = (bf16*)ypool;
   g.ymask = (unsigned char*)ymask;
+  g.up_out = g.skip_out = nullptr;
+  g.n1 = 0;
   g.f16 = tg_elem_f16();      // the descriptor's dtype, noted by the C-ABI entry point
   if (k == 1) return dispatch_tile<1>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
   return dispatch_tile<3>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
@@ -935,6 +1153,37 @@ int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gs
   g.chunks_query = chunks_query;
   g.ypool = nullptr;
   g.ymask = nullptr;
+  g.up_out = g.skip_out = nullptr;
+  g.n1 = 0;
   g.f16 = tg_elem_f16();
   return dispatch_tile_upcat(g, (const bf16*)x0, (const bf16*)wp, nullptr, (bf16*)y, s);
+}
+
+// (g0 [n,h/2,w/2,c0], g1 [n1,h,w,c1]) = the adjoint of concat(nearest_up2(.), skip) applied to conv3x3^T(gy [n,h,w,cout], w):
+// the input gradient of tg_conv_tile_upcat_run's conv.  wp: the backward-data pack (mode 1) of the conv's kernel.
+int tg_conv_tile_upcat_bwd_run(int n, int h, int w, int c0, int c1, int cout, int gsz, unsigned perm, int n1, const void* gy,
+                               const void* wp, void* g0, void* g1, hipStream_t s) {
+  TileGeom g;
+  g.n = n; g.h = h; g.w = w; g.cin = cout; g.cout = c0 + c1;      // a conv over gy: cout -> c0 + c1 channels
+  g.cin_pad = (cout + 15) / 16 * 16;
+  g.pad = 1;
+  g.tiles_x = g.tiles_y = g.nblk = 0;
+  g.tiles_per_wg = 0;
+  g.epilogue = 0;
+  g.alpha = 1.f;
+  g.x1 = nullptr;
+  g.c0 = c0;
+  g.gsz = gsz;
+  g.perm = perm;
+  g.mask = nullptr;
+  g.stats = nullptr;
+  g.stat_chunks = 0;
+  g.chunks_query = nullptr;
+  g.ypool = nullptr;
+  g.ymask = nullptr;
+  g.up_out = (bf16*)g0;
+  g.skip_out = (bf16*)g1;
+  g.n1 = n1;
+  g.f16 = tg_elem_f16();
+  return dispatch_tile_upbwd(g, (const bf16*)gy, (const bf16*)wp, s);
 }

@@ -73,6 +73,10 @@ USE_FLASH_ATTENTION = os.environ.get('TG_FLASH_ATTENTION', '1') != '0'
 # the gradient-penalty pass through an attention layer on the flash kernels too (forward, differentiable first-order
 # backward, second-order backward); TG_FLASH_BWD_BWD=0: that pass keeps the batched-GEMM / softmax composition
 USE_FLASH_BWD_BWD = os.environ.get('TG_FLASH_BWD_BWD', '1') != '0'
+# the input gradient of a generator block's first conv (upsample + UNet concat read in place) written straight into the two
+# sources' gradients by the backward-data kernel (tg_conv2d_upcat_bwd_data; TG_UPCAT_BWD_FUSED=0: backward-data into a
+# concat-layout tensor + tg_upsample2x_concat_bwd, for A/Bs)
+USE_UPCAT_BWD_FUSED = os.environ.get('TG_UPCAT_BWD_FUSED', '1') != '0'
 
 class PackCache:
   """bf16 K-contiguous packs (tg_conv2d_pack_weights) of registered master weights.
@@ -1397,11 +1401,19 @@ class UpcatConvFn(torch.autograd.Function):
     gy = gy.contiguous()
     g0 = g1 = gw = None
     if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-      gcat = conv_bwd_data_raw(gy, w, (n, H, W, c0 + c1), ctx.spec)
       g0 = torch.empty_like(x0) if ctx.needs_input_grad[0] else None
       g1 = torch.empty_like(x1) if ctx.needs_input_grad[1] else None
-      call('tg_upsample2x_concat_bwd', _p(gcat), _p(g0), _p(g1), n, H // 2, W // 2, c0, c1, gsz, pk, _dt(gcat), _stream(),
-           work=('upcat_bwd' + _shape_tag(gcat), 0, (gcat.numel() + x0.numel() + x1.numel()) * _esize(gcat)))
+      if USE_UPCAT_BWD_FUSED and H >= 16:
+        # backward-data with the upsample / concat adjoint in its epilogue: no concat-layout gradient tensor
+        d = _desc((n, H, W, c0 + c1), cout, ctx.spec, gy.dtype, 0)
+        call('tg_conv2d_upcat_bwd_data', _p(gy), _p(PackCache.get(w, d, 1)), _p(g0), _p(g1), n, H, W, c0, c1, cout, gsz, pk,
+             _dt(gy), _stream(),
+             work=lambda: ('dgrad:upcat:k3:c%d>%d+%d:hw%d:n%d' % (cout, c0, c1, H, n), 2 * n * H * W * cout * 9 * (c0 + c1),
+                           2 * (gy.numel() + x0.numel() + x1.numel()) + 2 * w.numel()))
+      else:
+        gcat = conv_bwd_data_raw(gy, w, (n, H, W, c0 + c1), ctx.spec)
+        call('tg_upsample2x_concat_bwd', _p(gcat), _p(g0), _p(g1), n, H // 2, W // 2, c0, c1, gsz, pk, _dt(gcat), _stream(),
+             work=('upcat_bwd' + _shape_tag(gcat), 0, (gcat.numel() + x0.numel() + x1.numel()) * _esize(gcat)))
     if ctx.needs_input_grad[2] and not _State.skip_param_grads:
       sink = GradSink.get(w)
       gw = sink if sink is not None else torch.empty(tuple(w.shape), dtype=torch.float32, device=gy.device)
