@@ -267,6 +267,38 @@ def test_restore_recovers_the_adam_step_after_the_beta_powers_underflow(tmp_path
   a.close(); b.close()
 
 
+def test_renorm_weights_are_scalars_in_checkpoints(tmp_path):
+  """libs/batch_norm.py:237,246 (and tf.layers.BatchNormalization) create renorm_mean_weight / renorm_stddev_weight with
+  shape (): state_dict and the checkpoint files carry them as scalars, restore / init_from_checkpoint take a scalar (what a
+  reference-written file holds) and still accept this repo's older one-element form."""
+  from twingan_amd import Config
+  from twingan_amd.twingan import Trainer
+  for nt in ('batch_renorm', 'batch_renorm_native'):
+    cfg = Config(hw=8, max_ch=8, precision='fp32', generator_norm_type=nt)
+    a = Trainer(cfg, device='cpu', seed=1)
+    ws = [k for k in a.store.state_specs if k.rsplit('/', 1)[-1].startswith(('renorm_mean_weight', 'renorm_stddev_weight'))]
+    assert ws and set(ws) == a.store.scalar_state
+    for i, k in enumerate(ws):
+      a.store.state[k].fill_(0.25 + 0.01 * i)
+    sd = a.store.state_dict(include_state=True)
+    assert all(tuple(sd[k].shape) == () for k in ws)
+    path = C.save(a, str(tmp_path / nt))
+    back = C.read_checkpoint(path)
+    assert all(back[k].shape == () for k in ws)
+    for how in ('restore', 'init', 'legacy'):
+      b = Trainer(cfg, device='cpu', seed=2)
+      if how == 'restore':
+        C.restore(b, path)
+      elif how == 'init':
+        C.init_from_checkpoint(b, str(tmp_path / nt))
+      else:      # the one-element form older files of this repo hold
+        b.store.load_state_dict({k: sd[k].reshape(1) for k in ws}, strict=False)
+      for i, k in enumerate(ws):
+        assert tuple(b.store.state[k].shape) == (1,) and abs(float(b.store.state[k]) - (0.25 + 0.01 * i)) < 1e-7, (how, k)
+      b.close()
+    a.close()
+
+
 def test_saver_keeps_the_most_recent_checkpoints(tmp_path):
   """tf.train.Saver(max_to_keep=5) as slim.learning.train builds it: the state file lists the retained checkpoints
   oldest first, older files are deleted, latest_checkpoint follows ``model_checkpoint_path``."""

@@ -130,6 +130,26 @@ def test_loader_with_decode_processes(tmp_path):
       assert batch.shape == (4, 24, 24, 3) and float(batch.min()) >= 0 and float(batch.max()) <= 1
   finally:
     tr.close()
+  # the worker processes rebuild the preprocessor: the RANDOM_CROP_AND_RESHAPE window must travel with it
+  rc = D.Loader(ds, 4, D.Preprocessor(16, device='cuda:0', precision='bf16', resize_mode='RANDOM_CROP_AND_RESHAPE',
+                                      initial_crop_hw=24), processes=1, pool=4, seed=5)
+  try:
+    batch = rc.next()
+    assert batch.shape == (4, 16, 16, 3) and float(batch.min()) >= 0 and float(batch.max()) <= 1
+  finally:
+    rc.close()
+  # a dead decode worker raises in next() instead of blocking the consumer forever
+  dead = D.Loader(ds, 4, D.Preprocessor(24, device='cuda:0', precision='bf16'), processes=1, pool=4, seed=6)
+  try:
+    dead.next()
+    for pr in dead.procs:
+      pr.terminate()
+      pr.join(timeout=5.0)
+    with pytest.raises(RuntimeError, match='decode worker'):
+      for _ in range(64):      # whatever was already queued is still served
+        dead.next()
+  finally:
+    dead.close()
 
 
 def test_progressive_training_from_tfrecord_datasets(tmp_path):

@@ -13,6 +13,7 @@
 #   ab:<VAR=v,...>    interleaved same-box A/B, ROUNDS (2) rounds: default environment vs the given variables (config 3)
 #   abc:<C>:<VAR=v,...>  the same on config C
 #   lib:<name>        interleaved A/B of the in-tree library vs tools/ab/<name>.so (same ABI)
+#   old:<name>        interleaved A/B of this tree vs the complete older tree tools/ab/<name>_tree (git archive + its built library)
 #   scan              batch scan b = 4 8 16 24 32 (ms per step)
 #   eager             bench --no-graph (3 steps)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -75,6 +76,13 @@ for step in "$@"; do
           timeout 300 python bench.py --no-cpu-baseline --no-roofline --steps ${STEPS:-20} --warmup 3 2> $OUT/lib_${which}_$i.err | line "lib:$which" | tee -a $OUT/ab.log
         done
       done; unset TG_LIB_PATH ;;
+    old)      # interleaved A/B of this tree against a complete older tree under tools/ab/<name>_tree (its own library + python)
+      for i in $(seq 1 $ROUNDS); do
+        for which in cur $arg; do
+          if [ $which = cur ]; then dir=$REPO; else dir=$REPO/tools/ab/${which}_tree; fi
+          (cd $dir && timeout 300 python bench.py --no-cpu-baseline --no-roofline --steps ${STEPS:-20} --warmup 3 2> $REPO/$OUT/old_${which}_$i.err) | line "tree:$which" | tee -a $OUT/ab.log
+        done
+      done ;;
     scan)
       for b in 4 8 16 24 32; do
         timeout 300 python bench.py --batch $b --no-cpu-baseline --no-roofline --steps 20 --warmup 3 2> $OUT/scan_$b.err | line "batch $b" | tee -a $OUT/batch_scan.txt

@@ -519,8 +519,8 @@ def init_from_checkpoint(trainer, checkpoint_path, checkpoint_exclude_scopes=Non
   import torch
   sd = {}
   for k in take:
-    want = tuple(store.specs[k]['shape']) if k in store.specs else tuple(store.state[k].shape)
-    if tuple(arrays[k].shape) != want:
+    want = tuple(store.specs[k]['shape']) if k in store.specs else store.state_shape(k)
+    if tuple(arrays[k].shape) != want and not (k in store.state and tuple(arrays[k].shape) == tuple(store.state[k].shape)):
       raise ValueError('variable %s: checkpoint shape %s, model shape %s' % (k, arrays[k].shape, want))
     sd[k] = torch.from_numpy(arrays[k].astype(np.float32))
   store.load_state_dict(sd, strict=False)
@@ -552,11 +552,14 @@ def restore(trainer, prefix):
 
 
 def _adam_applies(arrays, cfg, counter):
-  """Number of applies t the shared Adam optimiser has made.  TF keeps beta^(t+1) in float32: invert whichever power is
-  still a normal number (beta1 = 0.5 underflows to exactly 0 at t = 149, beta2 = 0.999 near t = 87 000); after that only
-  the n_critic counter knows -- the reference applies the one optimiser exactly once per counter increment
-  (image_generation.py:640-652), so the two agree whenever both are readable."""
+  """Number of applies t the shared Adam optimiser has made.  The reference applies the one optimiser exactly once per
+  n_critic_counter increment (image_generation.py:640-652), so the counter IS t when the checkpoint has it.  Without it:
+  TF keeps beta^(t+1) in float32 (repeated float32 products, off by ~1.3e-8 relative per apply), so invert whichever power
+  is still a normal number (beta1 = 0.5 underflows to exactly 0 at t = 149, beta2 = 0.999 near t = 87 000) -- exact for
+  short runs, within a step or two for long ones; after that the caller's counter (global_step * n_critic)."""
   import math
+  if 'n_critic_counter' in arrays:      # exact; TF's float32 beta powers drift by ~1.3e-5 steps per apply (half a step at 40 k)
+    return max(0, int(arrays['n_critic_counter']))
   for key, beta in (('beta2_power', cfg.adam_beta2), ('beta1_power', cfg.adam_beta1)):
     if key in arrays and 0.0 < beta < 1.0:
       p = float(arrays[key])

@@ -184,14 +184,13 @@ int launch_img(const ImgGeom& g, const void* x, const void* wp, const float* bia
   auto k0 = conv_img_kernel<HW, MT, false>;
   auto k1 = conv_img_kernel<HW, MT, true>;
   if (lds > 64 * 1024) {
-    static bool raised = false;      // per (HW, MT)
-    if (!raised) {
+    static unsigned long long raised = 0;      // per (HW, MT), one bit per device
+    if (tg_first_on_device(&raised)) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
           hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
         tg_set_error("conv_img: cannot raise dynamic LDS to %zu", lds);
         return TG_ELAUNCH;
       }
-      raised = true;
     }
   }
   tg_note_kernel(f16 ? "conv_img_kernel<%d,%d,f16>" : "conv_img_kernel<%d,%d>", HW, MT);

@@ -973,14 +973,13 @@ template <int KH, int KC, int BN, int MT, bool UPCAT, int MODE, bool F16>
 int launch_tile_variant(const TileGeom& g, size_t lds, const bf16* x, const bf16* wp, const float* bias, bf16* y, hipStream_t s) {
   auto kern = conv_tile_kernel<KH, KC, BN, MT, UPCAT, MODE, F16>;
   if (lds > 64 * 1024) {
-    static bool raised = false;      // per instantiation
-    if (!raised) {
+    static unsigned long long raised = 0;      // per instantiation, one bit per device
+    if (tg_first_on_device(&raised)) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
           hipSuccess) {
         tg_set_error("conv_tile: cannot raise dynamic LDS to %zu", lds);
         return TG_ELAUNCH;
       }
-      raised = true;
     }
   }
   // names as before for the bf16 kernels (tests/golden/bench_dispatch_kernels.json); ",f16" marks the half instantiation

@@ -1099,8 +1099,8 @@ int wg_launch_tile(const WgGeom& g, const bf16* x, const bf16* gy, float* ws, in
   const bool bias = g.gbias != nullptr;
   if (g.quad) {
     const size_t ldsq = 2 * (2 * 10 * 18 * 64 + 2 * 8 * 16 * 64);      // two buffers of two x planes + two gy planes: 78 848 B
-    static bool raised_q = false;
-    if (!raised_q) {
+    static unsigned long long raised_q = 0;      // one bit per device
+    if (tg_first_on_device(&raised_q)) {
       const void* ks[4] = {reinterpret_cast<const void*>(conv_wgrad_quad_kernel<true, true>),
                            reinterpret_cast<const void*>(conv_wgrad_quad_kernel<true, false>),
                            reinterpret_cast<const void*>(conv_wgrad_quad_kernel<false, true>),
@@ -1111,7 +1111,6 @@ int wg_launch_tile(const WgGeom& g, const bf16* x, const bf16* gy, float* ws, in
           return TG_ELAUNCH;
         }
       }
-      raised_q = true;
     }
     const dim3 gridq(nslices * g.n_pairs);
     tg_note_kernel("conv_wgrad_quad_kernel");
@@ -1128,8 +1127,8 @@ int wg_launch_tile(const WgGeom& g, const bf16* x, const bf16* gy, float* ws, in
     if (bias) TG_WG_LAUNCH(8, true, 4, grid, dim3(256), lds8, s, x, gy, ws, g);
     else TG_WG_LAUNCH(8, false, 4, grid, dim3(256), lds8, s, x, gy, ws, g);
   } else if (g.nw == 8) {
-    static bool raised = false;      // > 64 KiB of dynamic LDS: raise the limit of the four instantiations once
-    if (!raised) {
+    static unsigned long long raised = 0;      // > 64 KiB of dynamic LDS: raise the limit of the four instantiations once per device
+    if (tg_first_on_device(&raised)) {
       const void* ks[4] = {reinterpret_cast<const void*>(conv_wgrad_tile_kernel<16, true, true, 8>),
                            reinterpret_cast<const void*>(conv_wgrad_tile_kernel<16, true, false, 8>),
                            reinterpret_cast<const void*>(conv_wgrad_tile_kernel<16, false, true, 8>),
@@ -1140,7 +1139,6 @@ int wg_launch_tile(const WgGeom& g, const bf16* x, const bf16* gy, float* ws, in
           return TG_ELAUNCH;
         }
       }
-      raised = true;
     }
     tg_note_kernel("conv_wgrad_tile_kernel<8 waves>");
     if (bias) TG_WG_LAUNCH(16, true, 8, grid, dim3(512), lds16w8, s, x, gy, ws, g);
@@ -1252,15 +1250,19 @@ int tg_wgrad_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int g
 static hipStream_t wg_reduce_stream(hipStream_t s, int accumulate) {
   hipStream_t aux = (hipStream_t)tg_aux_stream();
   if (!aux || aux == s || !accumulate) return s;
-  static hipEvent_t pool[64];
-  static int made = 0, next = 0;      // the trainer's backward is one host thread at a time
-  if (!made) {
+  // one pool per device (events belong to the device they were created on); a backward pass is one host thread per device
+  constexpr int MAXDEV = 16;
+  static hipEvent_t pool[MAXDEV][64];
+  static int made[MAXDEV] = {0}, next[MAXDEV] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return s;
+  if (!made[dev]) {
     for (int i = 0; i < 64; ++i)
-      if (hipEventCreateWithFlags(&pool[i], hipEventDisableTiming) != hipSuccess) return s;
-    made = 1;
+      if (hipEventCreateWithFlags(&pool[dev][i], hipEventDisableTiming) != hipSuccess) return s;
+    made[dev] = 1;
   }
-  hipEvent_t ev = pool[next];
-  next = (next + 1) & 63;
+  hipEvent_t ev = pool[dev][next[dev]];
+  next[dev] = (next[dev] + 1) & 63;
   if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(aux, ev, 0) != hipSuccess) return s;
   return aux;
 }
@@ -1284,8 +1286,10 @@ struct SlabJobTable {
   SlabJob j[MAXJ];
   int n, blocks;
 };
-SlabJobTable g_defer;             // host side; the trainer's backward issues launches from one thread at a time
-int g_defer_on = 0;
+// host side, per thread: a backward pass (defer ... flush) is driven by one host thread; another trainer on another device
+// in the same process has its own queue
+thread_local SlabJobTable g_defer;
+thread_local int g_defer_on = 0;
 
 // A thread owns FOUR consecutive elements (one 16-byte load per slice, 8 slices in flight: 128 bytes per thread against 32
 // with one element per thread -- the one-element form moved its ~0.6 GB of slabs at 2.7 TB/s, 224 us per launch,

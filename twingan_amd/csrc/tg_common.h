@@ -51,6 +51,17 @@ int tg_zero_async(void* a, size_t a_bytes, void* b, size_t b_bytes, hipStream_t 
 
 static inline bool tg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// "Done once per DEVICE" flags for per-device driver state (hipFuncSetAttribute applies to the current device only): `mask`
+// is a static of the call site; returns true when the current device's bit was still clear and sets it.  Devices >= 64 are
+// always "not done" (the attribute call is idempotent).  Launch paths are entered by one host thread per device.
+static inline bool tg_first_on_device(unsigned long long* mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  if (*mask & (1ull << dev)) return false;
+  *mask |= 1ull << dev;
+  return true;
+}
+
 // ---- scalar load/store by storage type ------------------------------------------------------
 template <typename T> __device__ __forceinline__ float ld(const T* p);
 template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }

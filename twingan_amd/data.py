@@ -444,7 +444,8 @@ class Loader:
                          args=(mine, dataset.key, self.bs, preprocessor.hw, preprocessor.resize_mode,
                                preprocessor.is_training, shuffle, max(1, self.pool_size // processes), seed + 1 + r,
                                self.batches, self.stop,
-                               dict(do_random_cropping=preprocessor.crops, random_cropping_ratio=preprocessor.ratio),
+                               dict(do_random_cropping=preprocessor.crops, random_cropping_ratio=preprocessor.ratio,
+                                    initial_crop_hw=preprocessor.window),
                                (type(dataset), {k: v for k, v in dataset.__dict__.items() if k not in ('files', 'key')})))
         pr.start()
         self.procs.append(pr)
@@ -506,7 +507,18 @@ class Loader:
   def next(self):
     """-> images [batch, hw, hw, 3] on the device; for a dataset with further fields (EmbeddingImageDataset):
     (images, {field: fp32 device tensor [batch, size]})."""
-    packed, fields = self.batches.get()
+    if self.procs:      # a worker process that died (bad record, failed assert) must raise here, not hang the consumer
+      while True:
+        try:
+          packed, fields = self.batches.get(timeout=1.0)
+          break
+        except _queue.Empty:
+          dead = [pr for pr in self.procs if not pr.is_alive()]
+          if dead:
+            raise RuntimeError('Loader: %d of %d decode worker process(es) died (exit codes %s)'
+                               % (len(dead), len(self.procs), [pr.exitcode for pr in dead]))
+    else:
+      packed, fields = self.batches.get()
     out = self.pre.run(*packed, stream=self.stream)
     if fields is not None:
       with torch.cuda.stream(self.stream):

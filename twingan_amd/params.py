@@ -52,6 +52,7 @@ class ParamStore:
     self.offsets = {}
     self.state_specs = OrderedDict()   # name -> (numel, init value): non-trainable variables
     self.state = {}
+    self.scalar_state = set()          # names of state variables whose logical (TF) shape is ()
     self.weights_init_stddev = 0.02    # 1.0 under equalized_learning_rate (nets/pggan_utils.py:82-84, pggan.py:364)
     self.renorm = False                # generator_norm_type=batch_renorm: extra non-trainable renorm_* variables
     self.phase_of = None               # name -> backward segment at whose end the gradient is final (grad_phase)
@@ -86,6 +87,10 @@ class ParamStore:
           self.state_specs[norm_var(scope, norm_scope, 'renorm_mean_weight', d)] = (1, 0.0)
           self.state_specs[norm_var(scope, norm_scope, 'renorm_stddev', d)] = (cout, 0.0)
           self.state_specs[norm_var(scope, norm_scope, 'renorm_stddev_weight', d)] = (1, 0.0)
+          # TF creates the two weights as SCALARS (libs/batch_norm.py:237,246; tf.layers.BatchNormalization): the device
+          # buffer keeps one element, state_dict / checkpoints carry shape ()
+          self.scalar_state.add(norm_var(scope, norm_scope, 'renorm_mean_weight', d))
+          self.scalar_state.add(norm_var(scope, norm_scope, 'renorm_stddev_weight', d))
 
   # ---- allocation -----------------------------------------------------------------------------
   def build(self, seed=0):
@@ -176,8 +181,13 @@ class ParamStore:
     variables (BatchNorm moving / renorm statistics, spectral-norm u) -- what a TF checkpoint of the stage holds."""
     sd = {k: self._logical(self.P[k].detach(), s).clone() for k, s in self.specs.items()}
     if include_state:
-      sd.update({k: v.clone() for k, v in self.state.items() if k in self.state_specs})
+      sd.update({k: (v.reshape(()) if k in self.scalar_state else v).clone() for k, v in self.state.items()
+                 if k in self.state_specs})
     return sd
+
+  def state_shape(self, k):
+    """Logical (TF checkpoint) shape of a non-trainable variable."""
+    return () if k in self.scalar_state else tuple(self.state[k].shape)
 
   def adam_dict(self):
     """{variable name: (m, v)} -- logical views of the shared Adam optimiser's slot variables (TF: <var>/Adam,
@@ -217,8 +227,8 @@ class ParamStore:
         self.P[k].zero_() if s['phys'] != s['shape'] else None
         self._logical(self.P[k], s).copy_(src)
       for k in self.state_specs:      # non-trainable variables, when the dict carries them
-        if k in sd and tuple(torch.as_tensor(sd[k]).shape) == tuple(self.state[k].shape):
-          self.state[k].copy_(torch.as_tensor(sd[k]).to(device=self.device, dtype=torch.float32))
+        if k in sd and tuple(torch.as_tensor(sd[k]).shape) in (tuple(self.state[k].shape), self.state_shape(k)):
+          self.state[k].copy_(torch.as_tensor(sd[k]).to(device=self.device, dtype=torch.float32).reshape(self.state[k].shape))
     PackCache.version += 1
 
   def zero_grad(self, group):

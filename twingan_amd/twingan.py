@@ -589,6 +589,7 @@ class Trainer:
       except Exception as e:
         reason = '%s: %s' % (type(e).__name__, e)
         self._abandon_capture()
+        was_split = self.split
         if self.split:
           # the segmented schedule (one graph per backward segment, captured in thread_local mode beside a live
           # communicator) could not be recorded: record ONE graph per step kind instead -- the all-reduce then starts
@@ -602,6 +603,9 @@ class Trainer:
             reason = '%s; unsegmented: %s: %s' % (reason, type(e2).__name__, e2)
             self._abandon_capture()
       if self._graphs is None:      # keep training: eager launches are the same kernels, only the host cost differs
+        # eager steps never needed a graph to run segmented: keep the overlapped all-reduce, and do not claim a re-capture
+        self.split = was_split
+        self.capture_note = None if not was_split else 'segmented capture failed (%s); eager launches, still segmented' % reason
         self.graph_fallback_reason = reason
         warnings.warn('hipGraph capture failed (%s); falling back to eager launches' % reason)
         self.use_graph = False
