@@ -122,6 +122,11 @@ int tg_conv2d_bwd_data(const TgConvDesc* d, const void* gy, const void* w, void*
  * read-read-write pass (tf LeakyReluGrad after Conv2DBackpropInput). */
 int tg_conv2d_bwd_data_masked(const TgConvDesc* d, const void* gy, const void* w, const void* x_act, void* gx,
                               void* stream);
+/* The adjoint of that node, as the gradient penalty's second backward pass needs it (image_generation.py:414-439: the
+ * backward of tf.gradients(pred, interp)): y = conv(x, w) * (mask_src > 0 ? 1 : d->lrelu_alpha) with mask_src [n,hout,
+ * wout,cout] -- the forward conv of the incoming cotangent with the LeakyReLU mask of the NEXT node of that pass in its
+ * epilogue (one launch instead of conv + LeakyReluGrad).  d->epilogue must be 0; w as in tg_conv2d_fwd. */
+int tg_conv2d_fwd_masked(const TgConvDesc* d, const void* x, const void* w, const void* mask_src, void* y, void* stream);
 
 /* gw (fp32 HWIO) = d conv / d w (Conv2DBackpropFilter), `d` is the FORWARD descriptor.
  * workspace: tg_conv2d_bwd_weight_workspace(d) bytes (split-K partial slabs; may be 0/NULL).

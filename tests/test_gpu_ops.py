@@ -940,6 +940,65 @@ def test_lrelu_fold_under_create_graph_matches_unfused(ops, dtype, hw, c1, c2):
     assert rel_l2(a, b) < rtol, rel_l2(a, b)
 
 
+@pytest.mark.parametrize('dtype,hw,c1,c2', [(torch.bfloat16, 16, 32, 64), (torch.float32, 8, 8, 8), (torch.bfloat16, 32, 16, 16),
+                                            (torch.float16, 64, 16, 32)])
+def test_gradient_penalty_second_pass_masks_in_the_conv_epilogue(ops, monkeypatch, dtype, hw, c1, c2):
+  """The trainer's gradient-penalty flow (image_generation.py:414-439): inner gradient under ops.no_param_grads with
+  create_graph, parameters through the double backward.  With USE_GP_PREMASK the LeakyReLU mask every node of the second
+  pass applies to its incoming cotangent sits in the epilogue of the conv that produces it (tg_conv2d_fwd_masked; the
+  producer is flagged and skips its tg_lrelu_bwd launch): fewer launches, same penalty gradients as the unflagged chain and
+  as a float64 torch reference; the launch counts are checked through the profiler hook."""
+  from twingan_amd import _lib
+  g = torch.Generator().manual_seed(34)
+  x = torch.randn(2, hw, hw, 16, generator=g).to(dev()).to(dtype)
+  shapes = [(3, 3, 16, c1), (c1,), (3, 3, c1, c2), (c2,), (3, 3, c2, c2), (c2,), (3, 3, c2, 16), (16,)]
+  ws = [(torch.randn(*s, generator=g) * (0.1 if len(s) == 4 else 0.05)).to(dev()) for s in shapes]
+  res, launches = [], []
+  for premask in (False, True):
+    monkeypatch.setattr(ops, 'USE_GP_PREMASK', premask)
+    ops.GradSink.clear()
+    ps = [t.clone().requires_grad_(True) for t in ws]
+    xin = x.clone().requires_grad_(True)
+    with ops.second_order():
+      z1 = ops.conv2d(xin, ps[0], ps[1], 3, 'SAME', lrelu=True)
+      z2 = ops.conv2d(z1, ps[2], ps[3], 3, 'SAME', lrelu=True, fuse_input_lrelu=True)
+      _, z3 = ops.conv2d(z2, ps[4], ps[5], 3, 'SAME', lrelu=True, fuse_input_lrelu=True, pool=True, pool_only=True)      # block end
+      z4 = ops.conv2d(z3, ps[6], ps[7], 3, 'SAME', lrelu=True, fuse_input_lrelu=True)
+    with ops.no_param_grads():
+      gx, = torch.autograd.grad(z4.float().sum(), xin, create_graph=True)
+    pen = ((gx.float().pow(2).sum(dim=(1, 2, 3)).sqrt() - 1.0) ** 2).mean()
+    _lib.profiler = []
+    try:
+      grads = torch.autograd.grad(pen, [ps[0], ps[2], ps[4], ps[6]])
+      torch.cuda.synchronize()
+      names = [r[0] for r in _lib.profiler]
+    finally:
+      _lib.profiler = None
+    launches.append((names.count('tg_lrelu_bwd'), names.count('tg_conv2d_fwd_masked')))
+    res.append([host(gx.detach()), host(pen.detach().reshape(1))] + [host(t) for t in grads])
+  # three masks move into conv epilogues: z1's (into conv 2's node), z2's (conv 3's node), z3-block-end's (the unpool node)
+  assert launches[1][1] >= 2 and launches[1][0] <= launches[0][0] - launches[1][1], launches
+  tol = 1e-5 if dtype == torch.float32 else 3e-2
+  for a, b in zip(res[1], res[0]):
+    assert rel_l2(a, b) < tol, (rel_l2(a, b))
+  import torch.nn.functional as F
+  xr = x.double().cpu().requires_grad_(True)
+  pr = [t.double().cpu().requires_grad_(True) for t in ws]
+  def layer(a, w, b):
+    y = F.conv2d(a.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), b, padding=1).permute(0, 2, 3, 1)
+    return torch.maximum(y, 0.2 * y)
+  a3 = layer(layer(layer(xr, pr[0], pr[1]), pr[2], pr[3]), pr[4], pr[5])
+  z3r = F.avg_pool2d(a3.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+  z4r = layer(z3r, pr[6], pr[7])
+  gxr, = torch.autograd.grad(z4r.sum(), xr, create_graph=True)
+  penr = ((gxr.pow(2).sum(dim=(1, 2, 3)).sqrt() - 1.0) ** 2).mean()
+  gr = torch.autograd.grad(penr, [pr[0], pr[2], pr[4], pr[6]])
+  want = [gxr.detach().numpy(), penr.detach().reshape(1).numpy()] + [t.numpy() for t in gr]
+  rtol = 1e-4 if dtype == torch.float32 else 6e-2
+  for a, b in zip(res[1], want):
+    assert rel_l2(a, b) < rtol, rel_l2(a, b)
+
+
 @pytest.mark.parametrize('k,cin,cout', [(3, 16, 32), (1, 3, 16), (4, 64, 64), (3, 264, 256), (3, 5, 7)])
 def test_spectral_norm_matches_oracle(ops, k, cin, cout):
   """tg_spectral_norm_fwd / _bwd (libs/sn.py:38-101): w_bar, the next power-iteration vector, and d L / d w with the

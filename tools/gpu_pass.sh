@@ -14,6 +14,7 @@
 #   abc:<C>:<VAR=v,...>  the same on config C
 #   lib:<name>        interleaved A/B of the in-tree library vs tools/ab/<name>.so (same ABI)
 #   old:<name>        interleaved A/B of this tree vs the complete older tree tools/ab/<name>_tree (git archive + its built library)
+#   trace[:C]         rocprofv3 kernel trace of replayed steps: gaps, overlap, per-kernel table of ONE replayed step
 #   scan              batch scan b = 4 8 16 24 32 (ms per step)
 #   eager             bench --no-graph (3 steps)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -83,6 +84,12 @@ for step in "$@"; do
           (cd $dir && timeout 300 python bench.py --no-cpu-baseline --no-roofline --steps ${STEPS:-20} --warmup 3 2> $REPO/$OUT/old_${which}_$i.err) | line "tree:$which" | tee -a $OUT/ab.log
         done
       done ;;
+    trace)    # kernel trace of replayed steps -> gaps / overlap of the last one + its per-kernel table (step_kernels_cC.json)
+      c=${arg:-3}
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $REPO/$OUT/trace_c$c -o bench -- python $REPO/bench.py --config $c --steps 3 --warmup 2 --no-roofline --no-cpu-baseline > $REPO/$OUT/trace_c$c.log 2>&1)
+      f=$(find $OUT/trace_c$c -name "*kernel_trace.csv" | head -1)
+      python tools/trace_gaps.py "$f" $OUT/step_kernels_c$c.json > $OUT/gaps_c$c.txt 2>&1; head -12 $OUT/gaps_c$c.txt
+      rm -rf $OUT/trace_c$c ;;
     scan)
       for b in 4 8 16 24 32; do
         timeout 300 python bench.py --batch $b --no-cpu-baseline --no-roofline --steps 20 --warmup 3 2> $OUT/scan_$b.err | line "batch $b" | tee -a $OUT/batch_scan.txt

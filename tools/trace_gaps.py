@@ -61,6 +61,12 @@ def main(path):
     key = name.split('(')[0][:70]
     fam[key][0] += (e_ - s_) / 1e3
     fam[key][1] += 1
+  if len(sys.argv) > 2:      # per-kernel table of this ONE replayed step (a rocprofv3 --stats file also counts the eager warm-up)
+    import json
+    with open(sys.argv[2], 'w') as fh:
+      json.dump({'kernels': len(seg), 'wall_ms': (t1 - t0) / 1e6, 'busy_ms': busy / 1e6, 'two_in_flight_ms': two / 1e6,
+                 'sum_ms': sum(e - s for s, e, _ in seg) / 1e6,
+                 'by_kernel': sorted(([k, v[1], round(v[0], 1)] for k, v in fam.items()), key=lambda r: -r[2])}, fh, indent=1)
   print('kernels that are not this library\'s (framework ops left in the step):')
   for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0]):
     if 'GLOBAL__N_1' in k or 'anonymous namespace)::conv' in k or 'anonymous namespace)::pack' in k:

@@ -45,6 +45,8 @@ size_t tg_conv2d_bwd_weight_workspace_direct(const TgConvDesc*);
 int tg_conv2d_fwd_mfma(const TgConvDesc*, const void*, const void*, const float*, void*, hipStream_t);
 int tg_conv2d_bwd_data_mfma(const TgConvDesc*, const void*, const void*, void*, hipStream_t, const void* mask = nullptr);
 bool tg_conv2d_bwd_data_mask_fusable_mfma(const TgConvDesc*);
+bool tg_conv2d_fwd_mask_fusable_mfma(const TgConvDesc*);
+int tg_conv2d_fwd_masked_mfma(const TgConvDesc*, const void*, const void*, const void*, void*, hipStream_t);
 size_t tg_conv2d_bwd_weight_workspace_mfma(const TgConvDesc*);
 bool tg_conv2d_bwd_weight2_supported_mfma(const TgConvDesc* d);
 size_t tg_conv2d_bwd_weight2_workspace_mfma(const TgConvDesc* d, int nb);
@@ -136,6 +138,21 @@ int tg_conv2d_fwd(const TgConvDesc* d, const void* x, const void* w, const float
   TG_CHECK(tg_aligned16(x) && tg_aligned16(w) && tg_aligned16(y), TG_EALIGN, "tg_conv2d_fwd: pointers must be 16 B aligned");
   if (d->algo != TG_ALGO_DIRECT) return tg_conv2d_fwd_mfma(d, x, w, bias, y, (hipStream_t)stream);
   return tg_conv2d_fwd_direct(d, x, w, bias, y, (hipStream_t)stream);
+}
+
+int tg_conv2d_fwd_masked(const TgConvDesc* d, const void* x, const void* w, const void* mask_src, void* y, void* stream) {
+  int rc = check_desc("tg_conv2d_fwd_masked", d);
+  if (rc) return rc;
+  TG_CHECK(x && w && y && mask_src, TG_EINVAL, "tg_conv2d_fwd_masked: null pointer");
+  TG_CHECK(d->epilogue == 0, TG_EINVAL, "tg_conv2d_fwd_masked: no bias / activation epilogue next to the mask");
+  TG_CHECK(tg_aligned16(x) && tg_aligned16(w) && tg_aligned16(y) && tg_aligned16(mask_src), TG_EALIGN,
+           "tg_conv2d_fwd_masked: pointers must be 16 B aligned");
+  if (d->algo != TG_ALGO_DIRECT && tg_conv2d_fwd_mask_fusable_mfma(d))
+    return tg_conv2d_fwd_masked_mfma(d, x, w, mask_src, y, (hipStream_t)stream);
+  // not fusable for this shape / algorithm: the plain conv, then the mask in place
+  rc = tg_conv2d_fwd(d, x, w, nullptr, y, stream);
+  if (rc) return rc;
+  return tg_lrelu_bwd(y, mask_src, y, (int64_t)d->n * d->hout * d->wout * d->cout, d->lrelu_alpha, d->dtype, stream);
 }
 
 int tg_conv2d_bwd_data(const TgConvDesc* d, const void* gy, const void* w, void* gx, void* stream) {

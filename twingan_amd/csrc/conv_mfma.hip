@@ -643,6 +643,24 @@ int tg_conv2d_fwd_mfma(const TgConvDesc* d0, const void* x, const void* wp, cons
   return dispatch_fwd<3, 3>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
 }
 
+// Forward conv whose output is multiplied by the LeakyReLU derivative of `mask_src` (same shape as the output): the tile
+// kernels' mask epilogue (built for the masked backward-data) on the forward pack.  Shapes the tile kernels take, no
+// bias / activation epilogue.
+bool tg_conv2d_fwd_mask_fusable_mfma(const TgConvDesc* d0) {
+  TgConvDesc dd;
+  const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
+  return is16(d) && d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 && d->epilogue == 0 &&
+         tg_conv_tile_supported(d->hin, d->win, d->hout, d->wout, d->kh, d->kw, d->pad_t, d->pad_l);
+}
+
+int tg_conv2d_fwd_masked_mfma(const TgConvDesc* d0, const void* x, const void* wp, const void* mask_src, void* y, hipStream_t s) {
+  TgConvDesc dd;
+  const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
+  TG_CHECK(tg_conv2d_fwd_mask_fusable_mfma(d0), TG_ENOSUP, "tg_conv2d_fwd_masked(mfma): mask not fusable here");
+  return tg_conv_tile_run(d->n, d->hin, d->win, d->cin, d->cout, d->kh, d->pad_t, 0, d->lrelu_alpha, x, wp, nullptr, y, s,
+                          mask_src);
+}
+
 // Can the LeakyReLU backward of the producer of x be folded into this backward-data's epilogue?
 bool tg_conv2d_bwd_data_mask_fusable_mfma(const TgConvDesc* d0) {
   TgConvDesc dd;

@@ -32,6 +32,7 @@
     else hipLaunchKernelGGL((conv_wgrad_tile_kernel<TW_, BIAS_, false, NW_>), __VA_ARGS__);         \
   } while (0)
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 namespace {
@@ -1286,58 +1287,67 @@ struct SlabJobTable {
   SlabJob j[MAXJ];
   int n, blocks;
 };
-// host side, per thread: a backward pass (defer ... flush) is driven by one host thread; another trainer on another device
-// in the same process has its own queue
-thread_local SlabJobTable g_defer;
-thread_local int g_defer_on = 0;
+// Host side, ONE queue per process: tg_wgrad_defer / _flush come from the trainer's thread, the queued reductions from the
+// autograd engine's device thread that runs its backward nodes -- so not thread_local; a mutex orders them.  One trainer
+// (one device) per process defers at a time: the one-process-per-GPU layout of DESIGN.md section 6.
+SlabJobTable g_defer;
+int g_defer_on = 0;
+std::mutex g_defer_mu;
 
-// A thread owns FOUR consecutive elements (one 16-byte load per slice, 8 slices in flight: 128 bytes per thread against 32
-// with one element per thread -- the one-element form moved its ~0.6 GB of slabs at 2.7 TB/s, 224 us per launch,
-// profiles/r03_z_bench_c3_kernel_stats.csv); nw = 9 * cin * cout is a multiple of 4 and every slab row starts 16-byte
-// aligned.  Per element the slices are added in the stand-alone kernel's order.
+// VEC = 4: a thread owns FOUR consecutive elements (one 16-byte load per slice, 8 slices in flight: 128 bytes per thread
+// against 32 with one element per thread; nw = 9 * cin * cout is a multiple of 4 and every slab row starts 16-byte aligned);
+// VEC = 1: one element per thread (the stand-alone kernels' shape).  Per element the slices are added in the stand-alone
+// kernel's order either way.  A job whose gw no other job of the table writes (SLAB_UNIQUE: nothing else touches the sink
+// while the flush runs -- the trainer joined its streams before it) adds with a plain read-modify-write instead of one
+// float atomic per element (~14 M atomics per flush at ~0.25 T atomics/s).
+constexpr int SLAB_UNIQUE = 0x100;
+template <int VEC>
 __global__ __launch_bounds__(256) void conv_wgrad_slab_reduce_multi(const SlabJobTable tab) {
-  __shared__ f32x4 part[16 * 17 > 4 * 65 ? 16 * 17 : 4 * 65];
+  typedef typename std::conditional<VEC == 4, f32x4, float>::type vt;
+  __shared__ vt part[16 * 17 > 4 * 65 ? 16 * 17 : 4 * 65];
   int j = 0;
   while (j + 1 < tab.n && (int)blockIdx.x >= tab.j[j + 1].blk0) ++j;      // block-uniform
-  const f32x4* __restrict__ slab = reinterpret_cast<const f32x4*>(tab.j[j].slab);
-  float* __restrict__ gw = tab.j[j].gw;
-  const int64_t nw4 = tab.j[j].nw >> 2;
-  const int nslices = tab.j[j].nslices, sgn = tab.j[j].sg, epb = 256 / sgn;
+  const vt* __restrict__ slab = reinterpret_cast<const vt*>(tab.j[j].slab);
+  vt* __restrict__ gw = reinterpret_cast<vt*>(tab.j[j].gw);
+  const int64_t nwv = tab.j[j].nw / VEC;
+  const int nslices = tab.j[j].nslices, sgn = tab.j[j].sg & 0xff, epb = 256 / sgn;
+  const bool unique = (tab.j[j].sg & SLAB_UNIQUE) != 0;
   const int e = threadIdx.x % epb, sg = threadIdx.x / epb;
   const int64_t i = (int64_t)((int)blockIdx.x - tab.j[j].blk0) * epb + e;
-  f32x4 a[8];
+  vt a[8];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (i < nw4) {
+  for (int u = 0; u < 8; ++u) a[u] = vt{};
+  if (i < nwv) {
     int k = sg;
     for (; k + 7 * sgn < nslices; k += 8 * sgn) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] += slab[(size_t)(k + u * sgn) * nw4 + i];
+      for (int u = 0; u < 8; ++u) a[u] += slab[(size_t)(k + u * sgn) * nwv + i];
     }
-    for (; k < nslices; k += sgn) a[0] += slab[(size_t)k * nw4 + i];
+    for (; k < nslices; k += sgn) a[0] += slab[(size_t)k * nwv + i];
   }
-  const f32x4 s0 = (a[0] + a[1]) + (a[2] + a[3]), s1 = (a[4] + a[5]) + (a[6] + a[7]);
-  if (sgn == 1) {
-    if (i < nw4) {
-      const f32x4 t = s0 + s1;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) atomicAdd(gw + 4 * i + q, t[q]);
-    }
-    return;
-  }
-  part[sg * (epb + 1) + e] = s0 + s1;
-  __syncthreads();
-  if ((int)threadIdx.x < epb && i < nw4) {
-    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+  vt t = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  if (sgn != 1) {
+    part[sg * (epb + 1) + e] = t;
+    __syncthreads();
+    if ((int)threadIdx.x >= epb) return;
+    t = vt{};
     for (int q = 0; q < sgn; ++q) t += part[q * (epb + 1) + e];
+  }
+  if (i >= nwv) return;
+  if (unique) {
+    gw[i] += t;
+  } else if constexpr (VEC == 4) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) atomicAdd(gw + 4 * i + q, t[q]);
+    for (int q = 0; q < 4; ++q) atomicAdd(reinterpret_cast<float*>(gw + i) + q, t[q]);
+  } else {
+    atomicAdd(gw + i, t);
   }
 }
 
 }  // namespace
 
 extern "C" int tg_wgrad_defer(int on) {
+  std::lock_guard<std::mutex> lock(g_defer_mu);
   const int prev = g_defer_on;
   g_defer_on = on ? 1 : 0;
   if (!on) g_defer.n = g_defer.blocks = 0;      // whatever was not flushed is dropped (an abandoned pass)
@@ -1345,10 +1355,29 @@ extern "C" int tg_wgrad_defer(int on) {
 }
 
 extern "C" int tg_wgrad_defer_flush(void* stream) {
+  std::lock_guard<std::mutex> lock(g_defer_mu);
   const int n = g_defer.n;
   if (n > 0) {
-    hipLaunchKernelGGL(conv_wgrad_slab_reduce_multi, dim3((unsigned)g_defer.blocks), dim3(256), 0, (hipStream_t)stream,
-                       g_defer);
+    // grid layout and uniqueness flags for the vector width of this flush (TG_TUNE_SLAB_VEC = 1: one element per thread)
+    const int vec = tg_tune("TG_TUNE_SLAB_VEC", 4) == 1 ? 1 : 4;
+    const bool plain = tg_tune("TG_TUNE_SLAB_PLAIN", 1) != 0;
+    int blocks = 0;
+    for (int a = 0; a < n; ++a) {
+      SlabJob& jb = g_defer.j[a];
+      jb.sg &= 0xff;
+      bool unique = plain;
+      for (int b = 0; b < n && unique; ++b)
+        if (b != a && g_defer.j[b].gw == jb.gw) unique = false;
+      if (unique) jb.sg |= SLAB_UNIQUE;
+      jb.blk0 = blocks;
+      const int epb = 256 / (jb.sg & 0xff);      // threads per slice group; each owns `vec` elements
+      blocks += (int)((jb.nw / vec + epb - 1) / epb);
+    }
+    g_defer.blocks = blocks;
+    if (vec == 4)
+      hipLaunchKernelGGL(conv_wgrad_slab_reduce_multi<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g_defer);
+    else
+      hipLaunchKernelGGL(conv_wgrad_slab_reduce_multi<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g_defer);
     g_defer.n = g_defer.blocks = 0;
     TG_LAUNCH_CHECK("conv_wgrad_slab_reduce_multi");
   }
@@ -1356,19 +1385,19 @@ extern "C" int tg_wgrad_defer_flush(void* stream) {
 }
 
 int tg_wgrad_slab_reduce(const float* slab, float* gw, int64_t nw, int nslices, int accumulate, hipStream_t s) {
+  std::unique_lock<std::mutex> lock(g_defer_mu);
   if (g_defer_on && accumulate && g_defer.n < MAXJ && nw < (1ll << 31) && (nw & 3) == 0 &&
-      (reinterpret_cast<uintptr_t>(slab) & 15u) == 0 && !tg_deterministic_mode()) {
+      (reinterpret_cast<uintptr_t>(slab) & 15u) == 0 && (reinterpret_cast<uintptr_t>(gw) & 15u) == 0 && !tg_deterministic_mode()) {
     SlabJob& jb = g_defer.j[g_defer.n++];
     jb.slab = slab;
     jb.gw = gw;
     jb.nw = (int)nw;
     jb.nslices = nslices;
     jb.sg = nw < 16384 ? 16 : (nw < 131072 ? 4 : 1);      // the stand-alone kernels' rule
-    jb.blk0 = g_defer.blocks;
-    const int epb = 256 / jb.sg;                           // threads per slice group; each owns 4 elements
-    g_defer.blocks += (int)((nw / 4 + epb - 1) / epb);
+    jb.blk0 = 0;                                           // the grid is laid out at the flush
     return TG_OK;
   }
+  lock.unlock();
   s = wg_reduce_stream(s, accumulate);
   if (nw < 16384)
     hipLaunchKernelGGL(conv_wgrad_slab_reduce<16>, dim3((unsigned)((nw + 15) / 16)), dim3(256), 0, s, slab, gw, nw, nslices,

@@ -531,6 +531,21 @@ def conv_bwd_data_masked_raw(gy, w, x_act, spec):
   return gx
 
 
+def conv_fwd_masked_raw(x, w, mask_src, spec):
+  """y = conv(x, w) * (mask_src > 0 ? 1 : alpha): a forward conv with the LeakyReLU derivative of ``mask_src`` (the shape
+  of y) in its epilogue (tg_conv2d_fwd_masked) -- the second backward pass of the gradient penalty."""
+  _chk(x, w, mask_src)
+  d = _desc(x.shape, w.shape[3], spec, x.dtype, 0)
+  y = torch.empty((d.n, d.hout, d.wout, d.cout), dtype=x.dtype, device=x.device)
+  assert tuple(mask_src.shape) == tuple(y.shape), (tuple(mask_src.shape), tuple(y.shape))
+  wk = PackCache.get(w, d, 0) if d.algo == TG_ALGO_MFMA else w
+  def work():      # the mask is one more read of a tensor of the output's size
+    tag, fl, by = _conv_work(d, 'fwd', _esize(x))
+    return tag.replace('fwd:', 'fwd_masked:'), fl, by + _nb(mask_src)
+  call('tg_conv2d_fwd_masked', ctypes.byref(d), _p(x), _p(wk), _p(mask_src), _p(y), _stream(), work=work)
+  return y
+
+
 def conv_bwd_weight_raw(x, gy, spec, out=None, gbias=None):
   """gw = x^T * gy; with ``out`` the result is ADDED into that fp32 HWIO buffer (gradient sink).  ``gbias``: fp32 [cout]
   buffer that also receives += sum over pixels of gy (the layer's bias gradient, from the same read of gy)."""
@@ -707,6 +722,8 @@ def _conv_backward(ctx, gz, gzp=None):
     if gz is None and (ctx.epilogue & TG_EPI_LRELU):
       # create_graph pass over a pooled LeakyReLU layer: unpool + mask in one differentiable node
       pooled_lrelu = LReluPoolBwdFn.apply(gzp, z, spec.alpha)
+      if pooled_lrelu.grad_fn is not None:
+        pooled_lrelu.grad_fn.tg_masks_with = (z.data_ptr(), tuple(z.shape))      # see the mask_input branch below
     else:
       # differentiable composition or no activation: materialise the upsampled pooled gradient
       up = Pool2BwdFn.apply(gzp, 0.25, (z.shape[1], z.shape[2]) if z is not None else ctx.out_hw)
@@ -733,7 +750,20 @@ def _conv_backward(ctx, gz, gzp=None):
   gx = None
   if ctx.needs_input_grad[0]:
     if getattr(ctx, 'mask_input', False):      # x = the producer's LeakyReLU output
-      gx = MaskedDgradFn.apply(g, w, x, spec) if torch.is_grad_enabled() else conv_bwd_data_masked_raw(g, w, x, spec)
+      if torch.is_grad_enabled():
+        # the node that produced g masks the cotangent it gets back from us with THIS layer's LeakyReLU output z: when
+        # we are its only consumer (the gradient penalty's inner gradient: no parameter gradients hang off g) our own
+        # backward applies that mask in its conv's epilogue and tells the producer so
+        node = g.grad_fn
+        premask = (USE_GP_PREMASK and _State.skip_param_grads and z is not None and (ctx.epilogue & TG_EPI_LRELU)
+                   and node is not None and getattr(node, 'tg_masks_with', None) == (z.data_ptr(), tuple(z.shape)))
+        gx = MaskedDgradFn.apply(g, w, x, spec, z if premask else None)
+        if premask:
+          node.tg_v_premasked = True
+        if gx.grad_fn is not None:
+          gx.grad_fn.tg_masks_with = (x.data_ptr(), tuple(x.shape))      # what this node masks an incoming cotangent with
+      else:
+        gx = conv_bwd_data_masked_raw(g, w, x, spec)
     else:
       gx = ConvBwdDataFn.apply(g, w, tuple(x.shape), spec)
   gw = _weight_grad(x, g, spec, w, bias_sink) if need_w else None
@@ -838,25 +868,44 @@ class ConvBwdDataFn(torch.autograd.Function):
     return ggy, gw, None, None
 
 
+# the LeakyReLU mask a node of the gradient penalty's second backward pass applies to its incoming cotangent, moved into
+# the conv that PRODUCES that cotangent (tg_conv2d_fwd_masked; TG_GP_PREMASK=0: every node masks for itself, for A/Bs)
+USE_GP_PREMASK = os.environ.get('TG_GP_PREMASK', '1') != '0'
+
+
 class MaskedDgradFn(torch.autograd.Function):
   """gx = conv^T(gy, w) * mask(x_act), mask = (x_act > 0 ? 1 : alpha): backward-data with the LeakyReLU backward of the
   layer that produced this conv's input folded into its epilogue, for create_graph passes (the gradient-penalty
   first backward).  Linear in gy and in w, so its own backward is  v' = v * mask(x_act);  d/dgy = conv(v', w),
-  d/dw = x'^T-style filter gradient of (v', gy);  the mask is piecewise constant: no gradient to x_act."""
+  d/dw = x'^T-style filter gradient of (v', gy);  the mask is piecewise constant: no gradient to x_act.
+
+  ``out_act`` (optional): the LeakyReLU output of THIS conv's layer.  The node that produced gy -- the masked
+  backward-data of the next layer, or the unpool + mask of a block end -- starts its own backward by masking the
+  cotangent it receives, which is this node's d/dgy, with exactly that tensor: with out_act given this node's backward
+  applies that mask in the epilogue of its conv (tg_conv2d_fwd_masked) and the producer, flagged ``tg_v_premasked`` by
+  the caller, skips its LeakyReluGrad launch."""
 
   @staticmethod
-  def forward(ctx, gy, w, x_act, spec):
+  def forward(ctx, gy, w, x_act, spec, out_act=None):
     ctx.spec = spec
-    ctx.save_for_backward(gy, w, x_act)
+    ctx.save_for_backward(gy, w, x_act, out_act)
     return conv_bwd_data_masked_raw(gy, w, x_act, spec)
 
   @staticmethod
   def backward(ctx, v):
-    gy, w, x_act = ctx.saved_tensors
-    vm = LReluBwdFn.apply(v.contiguous(), x_act, ctx.spec.alpha)
-    ggy = Conv2dFn.apply(vm, w, None, ctx.spec, 0, False) if ctx.needs_input_grad[0] else None
+    gy, w, x_act, out_act = ctx.saved_tensors
+    v = v.contiguous()
+    vm = v if getattr(ctx, 'tg_v_premasked', False) else LReluBwdFn.apply(v, x_act, ctx.spec.alpha)
+    ggy = None
+    if ctx.needs_input_grad[0]:
+      if out_act is not None and not torch.is_grad_enabled():
+        ggy = conv_fwd_masked_raw(vm, w, out_act, ctx.spec)
+      else:
+        ggy = Conv2dFn.apply(vm, w, None, ctx.spec, 0, False)
+        if out_act is not None:      # a third-order pass: keep the premasking contract, differentiably
+          ggy = LReluBwdFn.apply(ggy, out_act, ctx.spec.alpha)
     gw = _weight_grad(vm, gy, ctx.spec, w) if (ctx.needs_input_grad[1] and not _State.skip_param_grads) else None
-    return ggy, gw, None, None
+    return ggy, gw, None, None, None
 
 
 class ConvBwdWeightFn(torch.autograd.Function):
@@ -901,7 +950,10 @@ class LReluPoolBwdFn(torch.autograd.Function):
   @staticmethod
   def backward(ctx, v):
     z, = ctx.saved_tensors
-    return Pool2Fn.apply(LReluBwdFn.apply(v.contiguous(), z, ctx.alpha), 0.25), None, None
+    v = v.contiguous()
+    if not getattr(ctx, 'tg_v_premasked', False):      # else: the conv that produced v masked it (MaskedDgradFn out_act)
+      v = LReluBwdFn.apply(v, z, ctx.alpha)
+    return Pool2Fn.apply(v, 0.25), None, None
 
 
 class ChannelSumFn(torch.autograd.Function):
