@@ -15,6 +15,7 @@
 #   lib:<name>        interleaved A/B of the in-tree library vs tools/ab/<name>.so (same ABI)
 #   old:<name>        interleaved A/B of this tree vs the complete older tree tools/ab/<name>_tree (git archive + its built library)
 #   trace[:C]         rocprofv3 kernel trace of replayed steps: gaps, overlap, per-kernel table of ONE replayed step
+#   py:<VAR=v,..|->:<script+args>  run a python tool (under the given environment) -> py.log
 #   scan              batch scan b = 4 8 16 24 32 (ms per step)
 #   eager             bench --no-graph (3 steps)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -90,6 +91,10 @@ for step in "$@"; do
       f=$(find $OUT/trace_c$c -name "*kernel_trace.csv" | head -1)
       python tools/trace_gaps.py "$f" $OUT/step_kernels_c$c.json > $OUT/gaps_c$c.txt 2>&1; head -12 $OUT/gaps_c$c.txt
       rm -rf $OUT/trace_c$c ;;
+    py)       # py:<VAR=v,...|->:<script and args, '+' for spaces>   -> appended to py.log
+      vars=${arg%%:*}; cmd=${arg#*:}; cmd=${cmd//+/ }
+      envs=""; [ "$vars" != "-" ] && envs=$(echo $vars | tr ',' ' ')
+      env $envs timeout 600 python $cmd 2>> $OUT/py.err | tee -a $OUT/py.log ;;
     scan)
       for b in 4 8 16 24 32; do
         timeout 300 python bench.py --batch $b --no-cpu-baseline --no-roofline --steps 20 --warmup 3 2> $OUT/scan_$b.err | line "batch $b" | tee -a $OUT/batch_scan.txt

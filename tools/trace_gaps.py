@@ -58,7 +58,7 @@ def main(path):
     print('  %.1f  %s' % (gval, name[:100]))
   fam = collections.defaultdict(lambda: [0, 0])
   for s_, e_, name in seg:
-    key = name.split('(')[0][:70]
+    key = (name[5:] if name.startswith('void ') else name).replace('(anonymous namespace)::', '').split('(')[0][:70]
     fam[key][0] += (e_ - s_) / 1e3
     fam[key][1] += 1
   if len(sys.argv) > 2:      # per-kernel table of this ONE replayed step (a rocprofv3 --stats file also counts the eager warm-up)

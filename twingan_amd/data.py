@@ -512,11 +512,13 @@ class Loader:
         try:
           packed, fields = self.batches.get(timeout=1.0)
           break
-        except _queue.Empty:
+        except Exception as e:      # nothing queued -- or a batch whose shared memory went away with its (dead) producer
           dead = [pr for pr in self.procs if not pr.is_alive()]
           if dead:
             raise RuntimeError('Loader: %d of %d decode worker process(es) died (exit codes %s)'
-                               % (len(dead), len(self.procs), [pr.exitcode for pr in dead]))
+                               % (len(dead), len(self.procs), [pr.exitcode for pr in dead])) from e
+          if not isinstance(e, _queue.Empty):
+            raise
     else:
       packed, fields = self.batches.get()
     out = self.pre.run(*packed, stream=self.stream)
