@@ -1353,8 +1353,14 @@ def test_fp16_training_steps_with_loss_scale_and_graph():
   e_f32 = _update_err(eager, f32, p0)
   print('[fp16] update rel-L2: graph vs eager (atomics mode) %.3e, scale 128 vs 1 %.3e, fp16 vs fp32 %.3e' % (e_graph, e_scale, e_f32))
   # Adam's first steps are sign-like, so the storage rounding (and the rounding pattern a different loss scale gives)
-  # moves a fraction of the weights by 2 lr; the atomics-order noise of the default mode measured 3.3e-3 run to run
-  assert e_graph < 2e-2 and e_scale < 0.35 and e_f32 < 0.5, (e_graph, e_scale, e_f32)
+  # moves a fraction of the weights by 2 lr.  The atomics-order noise of the default mode is amplified the same way and
+  # comes in DISCRETE levels -- a last-ulp difference either flips the first update of a weight whose gradient is ~0 or it
+  # does not: round 3 measured 3.3e-3 run to run; round 4 (profiles/r04_c_fp16_noise_by_switch.txt: 3 eager + 3 graph
+  # runs against eager #0, per kernel switch) 7e-9, 7.0e-4 or 3.26e-2, EAGER and GRAPH runs alike, and 1.4e-8 throughout
+  # when the generator's concat backward rounds twice (TG_UPCAT_BWD_FUSED=0) -- which weights sit on the knife edge
+  # depends on the last bit of every kernel's rounding.  The bound is therefore the largest level seen x 3; what pins
+  # the capture is the bit-equality in deterministic mode above.
+  assert e_graph < 1e-1 and e_scale < 0.35 and e_f32 < 0.5, (e_graph, e_scale, e_f32)
 
 
 @pytest.mark.parametrize('prec,kw', [
