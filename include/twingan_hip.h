@@ -122,15 +122,6 @@ int tg_conv2d_bwd_data(const TgConvDesc* d, const void* gy, const void* w, void*
  * read-read-write pass (tf LeakyReluGrad after Conv2DBackpropInput). */
 int tg_conv2d_bwd_data_masked(const TgConvDesc* d, const void* gy, const void* w, const void* x_act, void* gx,
                               void* stream);
-/* Backward-data of the conv that reads a discriminator block's pooled output (nets/pggan.py:304-306: conv -> LeakyReLU ->
- * tf.nn.avg_pool, then the next block's first conv), with the AvgPoolGrad and LeakyReluGrad of the pooled layer in the
- * epilogue: gx_full [n, 2*hin, 2*win, cin] = 0.25 * upsample2(bwd_data(gy)) * (sign ? 1 : d->lrelu_alpha), `signs`
- * [n, 2*hin, 2*win, cin/8] = the bits tg_conv2d_fwd_pool_signs kept of the pooled layer's output.  The same bits
- * tg_conv2d_bwd_data + tg_lrelu_pool_bwd_signs produce, without the quarter-size tensor in between.  16-bit MFMA path;
- * tg_conv2d_bwd_data_unpool_supported(d) != 0: 3x3 SAME layers at 16 x 16 and above. */
-int tg_conv2d_bwd_data_unpool_supported(const TgConvDesc* d);
-int tg_conv2d_bwd_data_unpool(const TgConvDesc* d, const void* gy, const void* w, const void* signs, void* gx_full,
-                              void* stream);
 /* The adjoint of that node, as the gradient penalty's second backward pass needs it (image_generation.py:414-439: the
  * backward of tf.gradients(pred, interp)): y = conv(x, w) * (mask_src > 0 ? 1 : d->lrelu_alpha) with mask_src [n,hout,
  * wout,cout] -- the forward conv of the incoming cotangent with the LeakyReLU mask of the NEXT node of that pass in its

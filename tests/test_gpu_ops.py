@@ -1499,67 +1499,6 @@ def test_conv_pool_sign_bits(ops, dtype, n, hw, cin, cout):
   assert full is not None
 
 
-UNPOOL_CASES = [
-    # n, hw (of the pooled map = the consumer conv's map), cin (pooled layer's channels), cout      kernel of the backward-data
-    (48, 128, 32, 32, 'conv_tile_wres_kernel<3,32,32,1,unpool>'),
-    (48, 64, 64, 64, 'conv_tile_kernel<3,32,64,2,unpool>'),
-    (32, 32, 128, 128, 'conv_tile_kernel<3,32,32,2,unpool>'),
-    (48, 16, 256, 256, 'conv_tile_kernel<3,32,32,1,unpool>'),
-    (3, 48, 24, 40, None),      # ragged: 24 channels end on a lone sign byte per 16-channel lane group, 48 x 48 map
-    (2, 16, 16, 16, 'conv_tile_kernel<3,16,32,1,unpool>'),
-]
-
-
-@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('case', range(len(UNPOOL_CASES)))
-def test_backward_data_with_the_pool_and_leaky_relu_adjoint_in_its_epilogue(ops, dtype, case):
-  """tg_conv2d_bwd_data_unpool: the input gradient of a discriminator block's first conv written as the PRE-activation
-  gradient of the previous block's pooled last layer (nets/pggan.py:304-306: AvgPoolGrad + LeakyReluGrad in the
-  backward-data epilogue) -- bit-identical to tg_conv2d_bwd_data + tg_lrelu_pool_bwd_signs at the discriminators' bench
-  shapes (n 48 / 32) and at ragged ones, per kernel variant; then through autograd: block end -> next conv with and
-  without the claim give the same bits for every gradient."""
-  import twingan_amd.ops as O
-  from twingan_amd import _lib
-  n, hw, cin, cout, want = UNPOOL_CASES[case]
-  g = torch.Generator().manual_seed(200 + case)
-  gy = torch.randn(n, hw, hw, cout, generator=g).to(dtype).to(dev())
-  w = (torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cout)) ** 0.5).to(dtype).float().to(dev())
-  signs = torch.randint(0, 256, (n, 2 * hw, 2 * hw, cin // 8), generator=g, dtype=torch.uint8).to(dev())
-  spec = O.ConvSpec(3, 'SAME')
-  full = O.conv_bwd_data_unpool_raw(gy, w, signs, (n, hw, hw, cin), spec, 0.2)
-  sym = _lib.load().tg_last_kernel().decode()
-  if want is not None:
-    assert sym == (want if dtype == torch.bfloat16 else want.replace('unpool', 'unpool,f16')), sym
-  gzp = O.conv_bwd_data_raw(gy, w, (n, hw, hw, cin), spec)
-  ref, _ = O.lrelu_pool_bwd_signs(gzp, signs, 0.2, None, False)
-  assert torch.equal(full, ref), float((full.float() - ref.float()).abs().max())
-  if case < 4:
-    return
-  # through autograd (small cases): x -> conv+lrelu+pool (sign bits) -> conv+lrelu, sinks for the parameters
-  res = {}
-  for claim in (True, False):
-    O.USE_UNPOOL_DGRAD = claim
-    try:
-      gen = torch.Generator().manual_seed(300 + case)
-      x = torch.randn(n, 2 * hw, 2 * hw, 16, generator=gen).to(dtype).to(dev()).requires_grad_(True)
-      w1 = (torch.randn(3, 3, 16, cin, generator=gen) * 0.1).to(dev()).requires_grad_(True)
-      b1 = (torch.randn(cin, generator=gen) * 0.1).to(dev()).requires_grad_(True)
-      w2 = (torch.randn(3, 3, cin, cout, generator=gen) * 0.1).to(dev()).requires_grad_(True)
-      b2 = (torch.randn(cout, generator=gen) * 0.1).to(dev()).requires_grad_(True)
-      _, zp = O.conv2d(x, w1, b1, 3, 'SAME', lrelu=True, pool=True, pool_only=True)
-      z2 = O.conv2d(zp, w2, b2, 3, 'SAME', lrelu=True, fuse_input_lrelu=True)
-      assert (getattr(z2.grad_fn, 'tg_unpool_node', None) is not None) == claim
-      z2.backward(torch.randn(z2.shape, generator=gen).to(dtype).to(dev()))
-      res[claim] = [t.grad.clone() for t in (x, w1, b1, w2, b2)]
-    finally:
-      O.USE_UNPOOL_DGRAD = True
-  for i, (a, b) in enumerate(zip(res[True], res[False])):
-    if i in (2, 4):      # bias gradients end in float atomics (arrival order) on both paths
-      assert rel_l2(host(a), host(b)) < 1e-5
-    else:
-      assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
-
-
 # ------------------------------------------------------------------------- ordered (fixed-order) sums
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
 def test_ordered_sums_are_bit_reproducible_and_right(ops, dtype):

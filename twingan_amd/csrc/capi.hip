@@ -45,8 +45,6 @@ size_t tg_conv2d_bwd_weight_workspace_direct(const TgConvDesc*);
 int tg_conv2d_fwd_mfma(const TgConvDesc*, const void*, const void*, const float*, void*, hipStream_t);
 int tg_conv2d_bwd_data_mfma(const TgConvDesc*, const void*, const void*, void*, hipStream_t, const void* mask = nullptr);
 bool tg_conv2d_bwd_data_mask_fusable_mfma(const TgConvDesc*);
-bool tg_conv2d_bwd_data_unpool_fusable_mfma(const TgConvDesc*);
-int tg_conv2d_bwd_data_unpool_mfma(const TgConvDesc*, const void*, const void*, const void*, void*, hipStream_t);
 bool tg_conv2d_fwd_mask_fusable_mfma(const TgConvDesc*);
 int tg_conv2d_fwd_masked_mfma(const TgConvDesc*, const void*, const void*, const void*, void*, hipStream_t);
 size_t tg_conv2d_bwd_weight_workspace_mfma(const TgConvDesc*);
@@ -180,23 +178,6 @@ int tg_conv2d_bwd_data_masked(const TgConvDesc* d, const void* gy, const void* w
   rc = tg_conv2d_bwd_data(d, gy, w, gx, stream);
   if (rc) return rc;
   return tg_lrelu_bwd(gx, x_act, gx, (int64_t)d->n * d->hin * d->win * d->cin, d->lrelu_alpha, d->dtype, stream);
-}
-
-int tg_conv2d_bwd_data_unpool_supported(const TgConvDesc* d) {
-  if (!d || check_desc("tg_conv2d_bwd_data_unpool_supported", d) || d->algo == TG_ALGO_DIRECT) return 0;
-  return tg_conv2d_bwd_data_unpool_fusable_mfma(d) ? 1 : 0;
-}
-
-int tg_conv2d_bwd_data_unpool(const TgConvDesc* d, const void* gy, const void* w, const void* signs, void* gx_full,
-                              void* stream) {
-  int rc = check_desc("tg_conv2d_bwd_data_unpool", d);
-  if (rc) return rc;
-  TG_CHECK(gy && w && signs && gx_full, TG_EINVAL, "tg_conv2d_bwd_data_unpool: null pointer");
-  TG_CHECK(tg_aligned16(gy) && tg_aligned16(w) && tg_aligned16(gx_full), TG_EALIGN,
-           "tg_conv2d_bwd_data_unpool: pointers must be 16 B aligned");
-  TG_CHECK(d->algo != TG_ALGO_DIRECT && tg_conv2d_bwd_data_unpool_fusable_mfma(d), TG_ENOSUP,
-           "tg_conv2d_bwd_data_unpool: layer not taken by the tile kernels (query tg_conv2d_bwd_data_unpool_supported first)");
-  return tg_conv2d_bwd_data_unpool_mfma(d, gy, w, signs, gx_full, (hipStream_t)stream);
 }
 
 size_t tg_conv2d_bwd_weight_workspace(const TgConvDesc* d) {

@@ -564,7 +564,7 @@ bool tg_conv_tile_supported(int h, int w, int hout, int wout, int kh, int kw, in
 int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int epilogue, float alpha, const void* x,
                      const void* wp, const float* bias, void* y, hipStream_t s, const void* mask = nullptr,
                      float* stats = nullptr, int stat_chunks = 0, int* chunks_query = nullptr, void* ypool = nullptr,
-                     void* ymask = nullptr, const void* unpool_signs = nullptr, void* unpool_out = nullptr);
+                     void* ymask = nullptr);
 
 // Forward conv that also writes the 2x2 average pool of its output (conv_tile.hip POOL kernels): 3x3 SAME, even h / w,
 // shapes the tile kernels take
@@ -659,24 +659,6 @@ int tg_conv2d_fwd_masked_mfma(const TgConvDesc* d0, const void* x, const void* w
   TG_CHECK(tg_conv2d_fwd_mask_fusable_mfma(d0), TG_ENOSUP, "tg_conv2d_fwd_masked(mfma): mask not fusable here");
   return tg_conv_tile_run(d->n, d->hin, d->win, d->cin, d->cout, d->kh, d->pad_t, 0, d->lrelu_alpha, x, wp, nullptr, y, s,
                           mask_src);
-}
-
-// Backward-data whose epilogue also undoes the 2x2 average pool and the LeakyReLU of the layer that produced this conv's
-// (pooled) input: the tile kernels' UNPOOL epilogue.  3x3 SAME layers the tile kernels take.
-bool tg_conv2d_bwd_data_unpool_fusable_mfma(const TgConvDesc* d0) {
-  TgConvDesc dd;
-  const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
-  return is16(d) && d->algo != TG_ALGO_MFMA_V1 && d->kh == 3 && d->cin % 8 == 0 && d->cout % 8 == 0 &&
-         tg_conv_tile_supported(d->hout, d->wout, d->hin, d->win, d->kh, d->kw, d->pad_t, d->pad_l);
-}
-
-int tg_conv2d_bwd_data_unpool_mfma(const TgConvDesc* d0, const void* gy, const void* wp, const void* signs, void* gx_full,
-                                   hipStream_t s) {
-  TgConvDesc dd;
-  const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
-  TG_CHECK(tg_conv2d_bwd_data_unpool_fusable_mfma(d0), TG_ENOSUP, "tg_conv2d_bwd_data_unpool(mfma): shape not taken");
-  return tg_conv_tile_run(d->n, d->hout, d->wout, d->cout, d->cin, d->kh, d->kh - 1 - d->pad_t, 0, d->lrelu_alpha, gy, wp,
-                          nullptr, nullptr, s, nullptr, nullptr, 0, nullptr, nullptr, nullptr, signs, gx_full);
 }
 
 // Can the LeakyReLU backward of the producer of x be folded into this backward-data's epilogue?

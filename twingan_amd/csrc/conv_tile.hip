@@ -65,14 +65,6 @@ struct TileGeom {
   bf16* up_out;
   bf16* skip_out;
   int n1;
-  // UNPOOL kernels (MODE 4): backward-data of the conv that reads a discriminator block's 2x2-average-pooled output
-  // (nets/pggan.py:304-306) with the adjoint of that pool AND the LeakyReLU backward of the pooled layer in the epilogue:
-  // every output pixel is written to its four source pixels of unpool_out [n, 2h, 2w, cout] as
-  // 0.25 * value * (sign bit ? 1 : alpha), the sign bits being what tg_conv2d_fwd_pool_signs kept of the pooled layer's
-  // output (unpool_signs [n, 2h, 2w, cout / 8]).  Replaces this kernel's quarter-size output + tg_lrelu_pool_bwd_signs
-  // (a read of it and of the bits, a full-size write) by the full-size write alone; bit-identical values.
-  const unsigned char* unpool_signs;
-  bf16* unpool_out;
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
@@ -218,41 +210,6 @@ __device__ __forceinline__ float sum_quad(float v) {
   return add_lane_xor16(v);
 }
 
-// UNPOOL epilogue of one lane: (o0, o1) = its 16 consecutive channels of pooled pixel (oy, ox), already scaled by 0.25 and
-// rounded (exact: a power of two), written to the four pixels (2oy + dy, 2ox + dx) of the [., 2h, 2w, c] tensor behind
-// `ro`, each channel times (its sign bit ? 1 : alpha) with ONE more rounding -- the arithmetic of lrelu_bwd_bias_kernel<BITS>
-template <bool F16>
-__device__ __forceinline__ void unpool_store(u32x4 o0, u32x4 o1, __amdgpu_buffer_rsrc_t ro, __amdgpu_buffer_rsrc_t rsign, int oy,
-                                             int ox, int w2, int c, int ch0, float alpha) {
-  u32x4 a0, a1;      // the same 16 values times alpha, rounded
-#pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    a0[d] = pack16x2<F16>(alpha * unpack16_lo<F16>(o0[d]), alpha * unpack16_hi<F16>(o0[d]));
-    a1[d] = pack16x2<F16>(alpha * unpack16_lo<F16>(o1[d]), alpha * unpack16_hi<F16>(o1[d]));
-  }
-  const bool lo_ok = ch0 + 8 <= c, hi_ok = ch0 + 16 <= c;
-#pragma unroll
-  for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-    for (int dx = 0; dx < 2; ++dx) {
-      const unsigned px = (unsigned)((2 * oy + dy) * w2 + 2 * ox + dx);
-      // 16 sign bits of this pixel's 16 channels: bit j of byte q = (z[.., 8q + j] > 0)
-      const unsigned bits = hi_ok ? (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsign, px * (unsigned)(c >> 3) + (unsigned)(ch0 >> 3), 0, 0)
-                                  : (lo_ok ? (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(rsign, px * (unsigned)(c >> 3) + (unsigned)(ch0 >> 3), 0, 0) : 0u);
-      u32x4 r0, r1;
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const unsigned m0 = ((bits >> (2 * d)) & 1u ? 0xffffu : 0u) | ((bits >> (2 * d + 1)) & 1u ? 0xffff0000u : 0u);
-        const unsigned m1 = ((bits >> (8 + 2 * d)) & 1u ? 0xffffu : 0u) | ((bits >> (8 + 2 * d + 1)) & 1u ? 0xffff0000u : 0u);
-        r0[d] = (o0[d] & m0) | (a0[d] & ~m0);
-        r1[d] = (o1[d] & m1) | (a1[d] & ~m1);
-      }
-      const unsigned off = (px * (unsigned)c + (unsigned)ch0) * 2u;
-      __builtin_amdgcn_raw_buffer_store_b128(r0, ro, lo_ok ? off : OOB, 0, TG_STORE_AUX);
-      __builtin_amdgcn_raw_buffer_store_b128(r1, ro, hi_ok ? off + 16 : OOB, 0, TG_STORE_AUX);
-    }
-}
-
 // UPCAT: the conv input is concat(nearest_up2(x), x1) on channels (generator_three_layer_block,
 // nets/pggan.py:69-76) read straight from the two sources -- K chunks below c0 come from the half-resolution
 // tensor, the rest from the skip tensor -- instead of from a materialised copy.
@@ -261,8 +218,8 @@ template <int KH, int KC, int BN, int MT, bool UPCAT = false, int MODE = 0, bool
 __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                         const float* __restrict__ bias, bf16* __restrict__ y,
                                                         const TileGeom g) {
-  constexpr bool STATS = MODE == 1, POOL = MODE == 2, UPBWD = MODE == 3, UNPOOL = MODE == 4;
-  static_assert(!((UPBWD || UNPOOL) && UPCAT), "UPBWD / UNPOOL are backward-data modes: their input is the plain output gradient");
+  constexpr bool STATS = MODE == 1, POOL = MODE == 2, UPBWD = MODE == 3;
+  static_assert(!(UPBWD && UPCAT), "UPBWD is a backward-data mode: its input is the plain output gradient");
   constexpr int KW = KH, NT = KH * KW;
   constexpr int TW = 16, TH = 8 * MT;
   constexpr int HWX = TW + KW - 1, HH = TH + KH - 1;
@@ -474,35 +431,6 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
     return;
   }
   const size_t out_img = (size_t)g.h * g.w * g.cout;
-  if constexpr (UNPOOL) {
-    const __amdgpu_buffer_rsrc_t ro = make_rsrc(g.unpool_out + (size_t)img * out_img * 4, (unsigned)(out_img * 4 * 2));
-    const __amdgpu_buffer_rsrc_t rsign = make_rsrc(g.unpool_signs + (size_t)img * (out_img >> 1), (unsigned)(out_img >> 1));
-#pragma unroll
-    for (int nt = 0; nt < NTILE; ++nt) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int oy = oy0 + (wid * MT + m) * 2 + (l31 >> 4), ox = ox0 + (l31 & 15);
-        unsigned p[4][2];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          p[q][0] = pack16x2<F16>(0.25f * acc[m][nt][q * 4 + 0], 0.25f * acc[m][nt][q * 4 + 1]);
-          p[q][1] = pack16x2<F16>(0.25f * acc[m][nt][q * 4 + 2], 0.25f * acc[m][nt][q * 4 + 3]);
-        }
-        u32x4 o0, o1;
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          auto r02 = __builtin_amdgcn_permlane32_swap(p[0][d], p[2][d], false, false);
-          auto r13 = __builtin_amdgcn_permlane32_swap(p[1][d], p[3][d], false, false);
-          o0[d] = r02[0];
-          o0[2 + d] = r02[1];
-          o1[d] = r13[0];
-          o1[2 + d] = r13[1];
-        }
-        unpool_store<F16>(o0, o1, ro, rsign, oy, ox, 2 * g.w, g.cout, n0 + nt * 32 + kgrp * 16, g.alpha);
-      }
-    }
-    return;
-  }
   // POOL with a sign-mask output: y is not written (a zero-sized resource drops the stores)
   const bool y_dropped = POOL && g.ymask != nullptr;
   const __amdgpu_buffer_rsrc_t ry = make_rsrc(y_dropped ? (const bf16*)g.ypool : y + (size_t)img * out_img,
@@ -621,7 +549,7 @@ template <int KH, int KC, int BN, int NCH, int MODE = 0, bool F16 = false>
 __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                              const float* __restrict__ bias, bf16* __restrict__ y,
                                                              const TileGeom g) {
-  constexpr bool STATS = MODE == 1, POOL = MODE == 2, UPBWD = MODE == 3, UNPOOL = MODE == 4;      // see TileGeom::up_out / unpool_out
+  constexpr bool STATS = MODE == 1, POOL = MODE == 2, UPBWD = MODE == 3;      // UPBWD: see TileGeom::up_out
   constexpr int KW = KH, NT = KH * KW;
   constexpr int TW = 16, TH = 8;
   constexpr int HWX = TW + KW - 1, HH = TH + KH - 1;
@@ -818,31 +746,6 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
       }
     }
     // ---- epilogue of tile t
-    if constexpr (UNPOOL) {      // as in conv_tile_kernel
-      const __amdgpu_buffer_rsrc_t ro = make_rsrc(g.unpool_out + (size_t)img * out_img * 4, (unsigned)(out_img * 4 * 2));
-      const __amdgpu_buffer_rsrc_t rsign = make_rsrc(g.unpool_signs + (size_t)img * (out_img >> 1), (unsigned)(out_img >> 1));
-#pragma unroll
-      for (int nt = 0; nt < NTILE; ++nt) {
-        unsigned p[4][2];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          p[q][0] = pack16x2<F16>(0.25f * acc[nt][q * 4 + 0], 0.25f * acc[nt][q * 4 + 1]);
-          p[q][1] = pack16x2<F16>(0.25f * acc[nt][q * 4 + 2], 0.25f * acc[nt][q * 4 + 3]);
-        }
-        u32x4 o0, o1;
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          auto r02 = __builtin_amdgcn_permlane32_swap(p[0][d], p[2][d], false, false);
-          auto r13 = __builtin_amdgcn_permlane32_swap(p[1][d], p[3][d], false, false);
-          o0[d] = r02[0];
-          o0[2 + d] = r02[1];
-          o1[d] = r13[0];
-          o1[2 + d] = r13[1];
-        }
-        unpool_store<F16>(o0, o1, ro, rsign, oy, ox, 2 * g.w, g.cout, n0 + nt * 32 + kgrp * 16, g.alpha);
-      }
-      return;
-    }
     if constexpr (UPBWD) {      // as in conv_tile_kernel
       if (src + 1 < n_src) return;
       const int cs = skip_blk ? g.cout - g.c0 : g.c0;
@@ -1032,15 +935,7 @@ int launch_tile_wres(const TileGeom& g0, const bf16* x, const bf16* wp, const fl
       hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH, MODE_, false>), dim3(nwg, ny), dim3(256), lds, s, x, wp, \
                          bias, y, g);                                                                                      \
   } while (0)
-  if (g.unpool_out) {
-    if constexpr (KH == 3) {
-      TG_CHECK(g.epilogue == 0 && !g.mask && !g.ypool && !stats && !g.up_out, TG_ENOSUP, "conv_tile(wres): the unpool epilogue comes alone");
-      tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d,unpool%s>", KH, KC, BN, NCH, fmt);
-      TG_WRES_LAUNCH(4);
-    } else {
-      TG_CHECK(false, TG_ENOSUP, "conv_tile(wres): the unpool epilogue is built for 3x3 only");
-    }
-  } else if (g.up_out) {
+  if (g.up_out) {
     if constexpr (KH == 3) {
       TG_CHECK(g.epilogue == 0 && !g.mask && !g.ypool && !stats, TG_ENOSUP, "conv_tile(wres): the concat backward comes with the plain epilogue only");
       tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d,upbwd%s>", KH, KC, BN, NCH, fmt);
@@ -1088,7 +983,7 @@ int launch_tile_variant(const TileGeom& g, size_t lds, const bf16* x, const bf16
     }
   }
   // names as before for the bf16 kernels (tests/golden/bench_dispatch_kernels.json); ",f16" marks the half instantiation
-  static const char* const mode_tag[5] = {"", ",stats", ",pool", ",upbwd", ",unpool"};
+  static const char* const mode_tag[4] = {"", ",stats", ",pool", ",upbwd"};
   if (F16 && MODE == 0 && !UPCAT) tg_note_kernel("conv_tile_kernel<%d,%d,%d,%d,f16>", KH, KC, BN, MT);
   else tg_note_kernel("conv_tile_kernel<%d,%d,%d,%d%s%s%s>", KH, KC, BN, MT, UPCAT ? ",upcat" : "", mode_tag[MODE], F16 ? ",f16" : "");
   hipLaunchKernelGGL(kern, dim3(g.nblk, (g.cout + BN - 1) / BN), dim3(256), lds, s, x, wp, bias, y, g);
@@ -1108,15 +1003,6 @@ int launch_tile(const TileGeom& g0, const bf16* x, const bf16* wp, const float* 
   if (g.chunks_query) {
     *g.chunks_query = (KH == 3) ? g.tiles_x * g.tiles_y : 0;
     return TG_OK;
-  }
-  if (g.unpool_out) {
-    if constexpr (KH == 3 && !UPCAT) {
-      TG_CHECK(g.epilogue == 0 && !g.mask && !g.stats && !g.ypool && !g.up_out, TG_ENOSUP, "conv_tile: the unpool epilogue comes alone");
-      return g.f16 ? launch_tile_variant<KH, KC, BN, MT, false, 4, true>(g, lds, x, wp, bias, y, s)
-                   : launch_tile_variant<KH, KC, BN, MT, false, 4, false>(g, lds, x, wp, bias, y, s);
-    } else {
-      TG_CHECK(false, TG_ENOSUP, "conv_tile: the unpool epilogue is built for plain 3x3 backward-data only");
-    }
   }
   if (g.up_out) {
     if constexpr (KH == 3 && !UPCAT) {
@@ -1216,7 +1102,7 @@ bool tg_conv_tile_supported(int h, int w, int hout, int wout, int kh, int kw, in
 
 int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int epilogue, float alpha, const void* x,
                      const void* wp, const float* bias, void* y, hipStream_t s, const void* mask, float* stats,
-                     int stat_chunks, int* chunks_query, void* ypool, void* ymask, const void* unpool_signs, void* unpool_out) {
+                     int stat_chunks, int* chunks_query, void* ypool, void* ymask) {
   TileGeom g;
   g.n = n; g.h = h; g.w = w; g.cin = cin; g.cout = cout;
   g.cin_pad = (cin + 15) / 16 * 16;
@@ -1235,8 +1121,6 @@ int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int
   g.ymask = (unsigned char*)ymask;
   g.up_out = g.skip_out = nullptr;
   g.n1 = 0;
-  g.unpool_signs = (const unsigned char*)unpool_signs;
-  g.unpool_out = (bf16*)unpool_out;
   g.f16 = tg_elem_f16();      // the descriptor's dtype, noted by the C-ABI entry point
   if (k == 1) return dispatch_tile<1>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
   return dispatch_tile<3>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
@@ -1270,8 +1154,6 @@ int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gs
   g.ymask = nullptr;
   g.up_out = g.skip_out = nullptr;
   g.n1 = 0;
-  g.unpool_signs = nullptr;
-  g.unpool_out = nullptr;
   g.f16 = tg_elem_f16();
   return dispatch_tile_upcat(g, (const bf16*)x0, (const bf16*)wp, nullptr, (bf16*)y, s);
 }
@@ -1301,8 +1183,6 @@ int tg_conv_tile_upcat_bwd_run(int n, int h, int w, int c0, int c1, int cout, in
   g.up_out = (bf16*)g0;
   g.skip_out = (bf16*)g1;
   g.n1 = n1;
-  g.unpool_signs = nullptr;
-  g.unpool_out = nullptr;
   g.f16 = tg_elem_f16();
   return dispatch_tile_upbwd(g, (const bf16*)gy, (const bf16*)wp, s);
 }

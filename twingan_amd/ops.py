@@ -77,9 +77,6 @@ USE_FLASH_BWD_BWD = os.environ.get('TG_FLASH_BWD_BWD', '1') != '0'
 # sources' gradients by the backward-data kernel (tg_conv2d_upcat_bwd_data; TG_UPCAT_BWD_FUSED=0: backward-data into a
 # concat-layout tensor + tg_upsample2x_concat_bwd, for A/Bs)
 USE_UPCAT_BWD_FUSED = os.environ.get('TG_UPCAT_BWD_FUSED', '1') != '0'
-# the AvgPoolGrad + LeakyReluGrad of a discriminator block's last layer written by the backward-data kernel of the next block's
-# first conv (tg_conv2d_bwd_data_unpool) instead of a quarter-size gradient + tg_lrelu_pool_bwd_signs (TG_UNPOOL_DGRAD=0: A/B)
-USE_UNPOOL_DGRAD = os.environ.get('TG_UNPOOL_DGRAD', '1') != '0'
 
 class PackCache:
   """bf16 K-contiguous packs (tg_conv2d_pack_weights) of registered master weights.
@@ -534,23 +531,6 @@ def conv_bwd_data_masked_raw(gy, w, x_act, spec):
   return gx
 
 
-def conv_bwd_data_unpool_raw(gy, w, signs, x_shape, spec, alpha):
-  """g_full [n, 2h, 2w, cin] = 0.25 * upsample2(conv^T(gy, w)) * (sign ? 1 : alpha): backward-data of the conv that reads a
-  pooled LeakyReLU layer, with that layer's AvgPoolGrad and LeakyReluGrad in its epilogue (tg_conv2d_bwd_data_unpool);
-  ``signs`` as written by tg_conv2d_fwd_pool_signs for the pooled layer, ``x_shape`` the conv's (pooled) input shape."""
-  _chk(gy, w, signs)
-  d = _desc(x_shape, w.shape[3], spec, gy.dtype, 0)
-  d.lrelu_alpha = alpha
-  n, h, ww, cin = x_shape
-  assert tuple(signs.shape) == (n, 2 * h, 2 * ww, cin // 8), (tuple(signs.shape), tuple(x_shape))
-  g = torch.empty((n, 2 * h, 2 * ww, cin), dtype=gy.dtype, device=gy.device)
-  def work():      # the output gradient in, the full-resolution gradient out, one bit per output element
-    tag, fl, _ = _conv_work(d, 'dgrad', _esize(gy))
-    return tag.replace('dgrad:', 'dgrad_unpool:'), fl, _nb(gy, g, signs) + _esize(gy) * d.kh * d.kw * d.cin * d.cout
-  call('tg_conv2d_bwd_data_unpool', ctypes.byref(d), _p(gy), _p(PackCache.get(w, d, 1)), _p(signs), _p(g), _stream(), work=work)
-  return g
-
-
 def conv_fwd_masked_raw(x, w, mask_src, spec):
   """y = conv(x, w) * (mask_src > 0 ? 1 : alpha): a forward conv with the LeakyReLU derivative of ``mask_src`` (the shape
   of y) in its epilogue (tg_conv2d_fwd_masked) -- the second backward pass of the gradient penalty."""
@@ -756,13 +736,6 @@ def _conv_backward(ctx, gz, gzp=None):
       need_b = False
   elif pooled_lrelu is not None:
     g = pooled_lrelu
-  elif getattr(ctx, 'tg_signs', False) and getattr(ctx, 'tg_full_grad', None) is not None:
-    # the only consumer of the pooled output (the next block's first conv) already unpooled and masked its input gradient
-    # in its backward-data epilogue (tg_conv2d_bwd_data_unpool); gzp is its placeholder
-    g, ctx.tg_full_grad = ctx.tg_full_grad, None
-    if need_b and need_w and GradSink.get(bias) is not None and GradSink.get(w) is not None and not deterministic():
-      bias_sink = GradSink.get(bias)      # the filter-gradient kernel sums g over pixels as well
-      need_b = False
   elif getattr(ctx, 'tg_signs', False):      # z holds the sign bits of the layer's output (Conv2dPoolSignsFn)
     g, gb = lrelu_pool_bwd_signs(gzp, z, spec.alpha, bias if need_b else None, need_b)
     need_b = False
@@ -791,12 +764,6 @@ def _conv_backward(ctx, gz, gzp=None):
           gx.grad_fn.tg_masks_with = (x.data_ptr(), tuple(x.shape))      # what this node masks an incoming cotangent with
       else:
         gx = conv_bwd_data_masked_raw(g, w, x, spec)
-    elif getattr(ctx, 'tg_unpool_node', None) is not None and not torch.is_grad_enabled():
-      # x is the pooled output of a Conv2dPoolSignsFn node and this conv is its only consumer: write the gradient of that
-      # node's PRE-activation, full resolution, and hand the node a placeholder of the pooled shape
-      node = ctx.tg_unpool_node
-      node.tg_full_grad = conv_bwd_data_unpool_raw(g, w, node.saved_tensors[2], tuple(x.shape), spec, node.spec.alpha)
-      gx = torch.empty_like(x)
     else:
       gx = ConvBwdDataFn.apply(g, w, tuple(x.shape), spec)
   gw = _weight_grad(x, g, spec, w, bias_sink) if need_w else None
@@ -1012,20 +979,6 @@ def _claim_input_lrelu(x, alpha):
   return True
 
 
-def _claim_input_unpool(x, w, spec):
-  """``x`` is the pooled output of a sign-bit block end (Conv2dPoolSignsFn) and THIS conv is its only consumer: take over
-  that layer's AvgPoolGrad + LeakyReluGrad (our backward-data writes its pre-activation gradient at full resolution).
-  -> the producer node, or None."""
-  node = x.grad_fn
-  if not USE_UNPOOL_DGRAD or node is None or not getattr(node, 'tg_pool_signs', False) or getattr(node, 'tg_unpool_claimed', False):
-    return None
-  d = _desc(x.shape, w.shape[3], spec, x.dtype, 0)
-  if d.algo != TG_ALGO_MFMA or not _lib.load().tg_conv2d_bwd_data_unpool_supported(ctypes.byref(d)):
-    return None
-  node.tg_unpool_claimed = True
-  return node
-
-
 def conv2d_stats(x, w, k=3, padding='SAME'):
   """(y, ConvStats | None): bias-free conv whose output goes to a normaliser (norm_act(..., conv_stats=...))."""
   holder = []
@@ -1045,22 +998,12 @@ def conv2d(x, w, bias=None, k=3, padding='SAME', lrelu=False, alpha=LRELU_ALPHA,
   epi = (TG_EPI_BIAS if bias is not None else 0) | (TG_EPI_LRELU if lrelu else 0)
   mask_input = bool(fuse_input_lrelu) and _claim_input_lrelu(x, alpha)
   if pool and pool_only and not in_second_order() and conv_fwd_pool_signs_supported(x, w, spec, epi):
-    zp = Conv2dPoolSignsFn.apply(x, w, bias, spec, epi, mask_input)
-    if zp.grad_fn is not None:
-      zp.grad_fn.tg_pool_signs = True      # a consumer that is alone may take over the pool / LeakyReLU backward
-    return None, zp
+    return None, Conv2dPoolSignsFn.apply(x, w, bias, spec, epi, mask_input)
   if pool:
     return Conv2dPoolFn.apply(x, w, bias, spec, epi, mask_input)
-  # fuse_input_lrelu = "x has no other consumer": when x is a sign-bit block end's pooled output, claim its backward
-  unpool_node = _claim_input_unpool(x, w, spec) if (fuse_input_lrelu and not mask_input and k == 3) else None
   z = Conv2dFn.apply(x, w, bias, spec, epi, mask_input)
-  if z.grad_fn is not None:
-    if lrelu:
-      z.grad_fn.tg_lrelu_out, z.grad_fn.tg_lrelu_alpha = True, alpha
-    if unpool_node is not None:
-      z.grad_fn.tg_unpool_node = unpool_node
-  elif unpool_node is not None:
-    unpool_node.tg_unpool_claimed = False
+  if lrelu and z.grad_fn is not None:
+    z.grad_fn.tg_lrelu_out, z.grad_fn.tg_lrelu_alpha = True, alpha
   return z
 
 
