@@ -405,7 +405,8 @@ def main():
     # scale 128 (model_inheritor.py:568-570); fp32 accumulation and master weights as on the bf16 path.
     extra = dict(do_self_attention=True, self_attention_hw=64, spectral_norm=True, loss_scale=128.0)
   cfg = Config(hw=args.hw, max_ch=args.max_ch, precision=args.precision, **extra)
-  overlap = None if args.overlap == 'auto' else args.overlap == 'on'
+  # auto: segmented when N > 1 -- and under --reduce-always, which exists to run the N > 1 schedule on one GPU
+  overlap = (True if args.reduce_always else None) if args.overlap == 'auto' else args.overlap == 'on'
   if args.config == 0:      # configs[0]: the plain PGGAN trainer (generator from latent noise, one discriminator)
     from twingan_amd.image_generation import PgganTrainer
     tr = PgganTrainer(cfg, device=device, seed=0, world_size=world, use_graph=not args.no_graph, overlap=overlap)

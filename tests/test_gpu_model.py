@@ -345,6 +345,98 @@ def test_segmented_backward_leaves_the_same_gradients(precision):
       assert lo <= cut.store.offsets[k] < hi
 
 
+SEGMENT_VARIANTS = {
+    'sn': dict(hw=64, max_ch=16, spectral_norm=True, overlap_cut_hw=16),
+    'sn_everywhere_att': dict(hw=64, max_ch=16, spectral_norm=True, spectral_norm_in_non_discriminator=True, do_self_attention=True,
+                              self_attention_hw=32, overlap_cut_hw=16),
+    'growing': dict(hw=64, max_ch=16, is_growing=True, alpha_grow=0.3, overlap_cut_hw=16),
+    'growing_cut_at_half': dict(hw=32, max_ch=16, is_growing=True, alpha_grow=0.6, overlap_cut_hw=16),
+    'style': dict(hw=64, max_ch=16, use_style_embedding=True, style_embed_size=8, overlap_cut_hw=16),
+    'batch_norm_hinge': dict(hw=64, max_ch=16, generator_norm_type='batch_norm', loss_architecture='hinge', overlap_cut_hw=16),
+}
+
+
+@pytest.mark.parametrize('variant', sorted(SEGMENT_VARIANTS))
+def test_segmented_backward_for_every_configuration(variant):
+  """The overlapped clone all-reduce (deployment/model_deploy.py:473-503 sums the clones' gradients of EVERY configuration)
+  needs the segmented backward everywhere: spectral norm (each normalised kernel read through a per-run leaf, sent through
+  the power iteration's backward once, at the end of the segment that completes it), growing stages (the interpolated
+  skip end-point a leaf of the high segment, the shrink path's variables in the high phase), the style encoder (whole in
+  segment 0).  For each: the segmented backward leaves the plain backward's gradients, AND at the end of segment p the
+  flat-buffer range of phase p already holds its final values (what the all-reduce started there would send)."""
+  from twingan_amd import Config
+  from twingan_amd.twingan import Trainer
+  cfg = Config(precision='fp32', **SEGMENT_VARIANTS[variant])
+  g = torch.Generator().manual_seed(23)
+  hw = cfg.hw
+  s = torch.rand(3, hw, hw, 3, generator=g).to('cuda:0')
+  t = torch.rand(3, hw, hw, 3, generator=g).to('cuda:0')
+  al = torch.rand(3, generator=g).to('cuda:0')
+  plain = Trainer(cfg, device='cuda:0', seed=11, overlap=False)
+  cut = Trainer(cfg, device='cuda:0', seed=11, overlap=True)
+  assert cut.split and (cut._nseg('g'), cut._nseg('d')) == (3, 2)
+  for grp in ('g', 'd'):
+    torch.manual_seed(5)      # the style noise / device draws of both trainers
+    for _ in plain._grad_segments(grp, s, t, al, al):
+      pass
+    torch.cuda.synchronize()
+    ga = plain.store.grad_dict()
+    torch.manual_seed(5)
+    at_end = {}
+    for seg, _ in cut._grad_segments(grp, s, t, al, al):
+      torch.cuda.synchronize()
+      lo, hi = cut.store.phase_bounds[grp][seg]
+      at_end[seg] = cut.store.grad[grp][lo:hi].clone()
+    torch.cuda.synchronize()
+    gb = cut.store.grad_dict()
+    top = max(float(ga[k].norm()) for k in plain.store.names(grp))
+    for k in plain.store.names(grp):
+      na = float(ga[k].norm())
+      if na < 1e-4 * top:
+        continue
+      e = float((ga[k] - gb[k]).norm()) / na
+      assert e < 2e-4, (variant, grp, k, e)
+    for seg, snap in at_end.items():      # nothing arrived in a range after its segment ended
+      lo, hi = cut.store.phase_bounds[grp][seg]
+      assert torch.equal(snap, cut.store.grad[grp][lo:hi]), (variant, grp, seg)
+  plain.close()
+  cut.close()
+
+
+def test_distillation_extras_under_graph_replay():
+  """--do_encoder_distillation (twingan.py:162-177,507-521) with hipGraph replay: the datasets' embeddings live in static
+  buffers the captured generator step reads; a graph trajectory with CHANGING embeddings equals the eager one (deterministic
+  mode: bit for bit), and a run that brings other fields than the capture is refused."""
+  from twingan_amd import Config
+  from twingan_amd.twingan import Trainer
+  cfg = Config(hw=16, max_ch=16, precision='bf16', do_encoder_distillation=True, distill_embed_dim=6, distillation_weight=0.5)
+  g = torch.Generator().manual_seed(31)
+  s = torch.rand(4, 16, 16, 3, generator=g).to('cuda:0').bfloat16()
+  t = torch.rand(4, 16, 16, 3, generator=g).to('cuda:0').bfloat16()
+  embs = [torch.randn(4, 6, generator=g).to('cuda:0') for _ in range(6)]
+  out = {}
+  with _Deterministic():
+    for graph in (False, True):
+      tr = Trainer(cfg, device='cuda:0', seed=3, use_graph=graph)
+      torch.manual_seed(9)
+      losses = []
+      for i in range(6):
+        loss, terms = tr.run(s, t, distill_embed_s=embs[i])
+        if i % 2 == 0:
+          assert 'l_source_distillation' in terms
+          losses.append(float(terms['l_source_distillation']))
+      assert not graph or tr.graph_fallback_reason is None, tr.graph_fallback_reason
+      out[graph] = (losses, {k: v.clone() for k, v in tr.store.state_dict().items()})
+      if graph:
+        with pytest.raises(ValueError, match='dataset fields'):
+          tr.run(s, t, distill_embed_t=embs[0])
+      tr.close()
+  assert len(set(out[True][0])) > 1      # the replayed graph saw the new embeddings
+  assert out[True][0] == out[False][0]
+  bad = [k for k in out[True][1] if not torch.equal(out[True][1][k], out[False][1][k])]
+  assert not bad, bad[:5]
+
+
 def test_graph_replay_wgan_gp_bf16_runs():
   """The north-star configuration's shape (bf16, WGAN-GP, device-drawn alphas) under graph replay."""
   from twingan_amd import Config

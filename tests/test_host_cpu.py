@@ -346,8 +346,8 @@ def test_grad_reducer_statistics_single_process():
 
 def test_gradient_phases_are_contiguous_ranges():
   """params.grad_phase: the flat gradient buffer is laid out segment by segment (what one backward segment completes is
-  one contiguous range = one all-reduce), the initial values do not depend on the layout, and growing stages / the
-  style encoder keep a single phase."""
+  one contiguous range = one all-reduce), the initial values do not depend on the layout; growing stages are laid out the
+  same way with the shrink path in the high phase."""
   from twingan_amd import Config
   from twingan_amd.params import ParamStore, declare_twingan, grad_phase
   cfg = Config(hw=128, max_ch=64)
@@ -375,7 +375,16 @@ def test_gradient_phases_are_contiguous_ranges():
   a, b = st.state_dict(), flat.state_dict()
   assert all(torch.equal(a[k], b[k]) for k in a)
   assert flat.offsets != st.offsets
-  one = declare_twingan(ParamStore('cpu'), Config(hw=64, max_ch=16, is_growing=True)).build(seed=0)
+  # growing stages are split too: the shrink path's fromRGB (hw / 2) is blended in above the cut, so it completes with the
+  # full-resolution block whatever its own resolution says
+  gcfg = Config(hw=64, max_ch=16, is_growing=True)      # overlap_cut_hw 32 = hw / 2
+  grow = declare_twingan(ParamStore('cpu'), gcfg).build(seed=0)
+  assert sorted(grow.phase_bounds['g']) == [0, 1, 2] and sorted(grow.phase_bounds['d']) == [0, 1]
+  assert grad_phase('encoder_content/from_rgb_32x32/Conv/weights', gcfg) == 2
+  assert grad_phase('discriminator_s/from_rgb_32x32/Conv/biases', gcfg) == 1
+  assert grad_phase('encoder_content/encoder_block_32x32x16/Conv/weights', gcfg) == 1
+  assert grad_phase('generator/generator_to_rgb_32x32/Conv/weights', gcfg) == 0
+  one = declare_twingan(ParamStore('cpu'), Config(hw=32, max_ch=16, is_growing=True)).build(seed=0)      # hw <= cut: one phase
   assert list(one.phase_bounds['g']) == [0] and list(one.phase_bounds['d']) == [0]
 
 

@@ -272,14 +272,18 @@ def grad_phase(name, cfg):
     discriminator   0: layers at <= cut_hw, the tail and the FC (gradient penalty passes + low-resolution part of the
                        batched pass)                      1: layers above cut_hw
 
-  Growing stages and the style encoder keep everything in phase 0 (the trainer does not split those steps)."""
-  if cfg.is_growing or cfg.use_style_embedding or not cfg.overlap_cut_hw or cfg.hw <= cfg.overlap_cut_hw:
+  Growing stages: the shrink path (from_rgb at hw / 2, nets/pggan.py:233-240,395-399) is blended in ABOVE the cut, so its
+  variables complete with the full-resolution block whatever hw / 2 is.  The style encoder (twingan.py:201-223) is not cut:
+  its gradients are final after segment 0 and travel with the encoder ranges (later than necessary, never too early)."""
+  if not cfg.overlap_cut_hw or cfg.hw <= cfg.overlap_cut_hw:
     return 0
   top = name.split('/', 1)[0]
   if top == 'generator':
     return 0
   m = _HW_IN_NAME.search(name)
   high = bool(m) and int(m.group(1)) > cfg.overlap_cut_hw
+  if cfg.is_growing and ('/from_rgb_%dx%d/' % (cfg.hw // 2, cfg.hw // 2)) in name:
+    high = True
   if top.startswith('encoder'):
     return 2 if high else 1
   return 1 if high else 0

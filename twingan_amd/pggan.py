@@ -70,8 +70,39 @@ def _sn_compute(P, scope):
     ops.PackCache.register(buf)
   w_bar, u1 = ops.spectral_norm(w, P.state[scope + '/u'], out=buf)
   P.__dict__.setdefault('sn_pending', {})[scope + '/u'] = u1
+  if ops.Cuts.active and torch_is_grad_enabled() and w_bar.requires_grad:
+    # Segmented backward (ops.Cuts): one normalised kernel serves uses in several segments (the gradient-penalty pass in
+    # segment 0, the batched pass above the cut in segment 1), so its node must not sit inside any of them -- the uses
+    # read a detached leaf, whose accumulated gradient sn_segment_backward() sends through the power iteration's
+    # backward ONCE, at the end of the segment that completes the kernel's gradient
+    leaf = w_bar.detach().requires_grad_(True)
+    P.__dict__.setdefault('sn_leaves', {})[scope] = (w_bar, leaf)
+    w_bar = leaf
   P.__dict__.setdefault('sn_cache', {})[scope] = w_bar
   return w_bar
+
+
+def torch_is_grad_enabled():
+  import torch
+  return torch.is_grad_enabled()
+
+
+def sn_segment_backward(P, done):
+  """After a backward segment: every spectrally normalised kernel whose uses all lie in finished segments (``done(scope)``)
+  gets its accumulated d loss / d w_bar sent through the normalisation's backward into the master kernel's gradient."""
+  import torch
+  leaves = P.__dict__.get('sn_leaves')
+  if not leaves:
+    return 0
+  roots, grads = [], []
+  for scope in [k for k in leaves if done(k)]:
+    w_bar, leaf = leaves.pop(scope)
+    if leaf.grad is not None:
+      roots.append(w_bar)
+      grads.append(leaf.grad)
+  if roots:
+    torch.autograd.backward(roots, grads)
+  return len(roots)
 
 
 def prepare_run(P, cfg):
@@ -103,6 +134,9 @@ def end_run(P):
   cache = P.__dict__.get('sn_cache')
   if cache:
     cache.clear()
+  leaves = P.__dict__.get('sn_leaves')
+  if leaves:
+    leaves.clear()
 
 
 def self_attention_layer(P, sc, layer, domain, cfg, is_discriminator, cond=None):
@@ -467,7 +501,10 @@ def encoder_before_classification(P, source, domain, cfg, top='encoder_content',
     end_points['downsample_to_%dx%dx%d' % (current_hw, current_hw, num_channels)] = net
     if stage == max_stage and cfg.is_growing:
       net = ops.lerp(net, shrinked, cfg.alpha_grow)
-      end_points['encoder_block_interpolated_%dx%dx%d' % (current_hw, current_hw, num_channels)] = net
+      # the generator reads this end-point as its UNet skip at hw / 2: under a segmented backward it is a leaf of the HIGH
+      # segment whatever its own resolution -- its producers are the full-resolution block and the shrink path
+      end_points['encoder_block_interpolated_%dx%dx%d' % (current_hw, current_hw, num_channels)] = \
+          net if cuts is None else ops.Cuts.cut(net, cuts[1])
   end_points['before_classification'] = net
   return net, end_points
 

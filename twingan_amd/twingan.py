@@ -350,11 +350,11 @@ class Trainer:
     # optimizer, one learning rate, one pair of beta powers -- pinned live (tests/test_reference_live.py, ttur).
     self._group_weights = {g: [self.P[k] for k, s in self.store.specs.items() if s['group'] == g and s['kind'] == 'conv_w']
                            for g in self.store.GROUPS}
-    # segmented backward (params.grad_phase): only where no autograd node is shared between segments -- the per-run
-    # spectrally normalised kernels are such nodes, growing stages / the style encoder add edges the cuts do not cover
+    # segmented backward (params.grad_phase) for every configuration: spectrally normalised kernels are read through
+    # per-run leaves (pggan._sn_compute / sn_segment_backward), a growing stage's interpolated skip end-point is a leaf of
+    # the high segment, the style encoder stays whole in segment 0
     want = (world_size > 1) if overlap is None else bool(overlap)
-    self.split = bool(want and not (cfg.is_growing or cfg.use_style_embedding or cfg.spectral_norm)
-                      and cfg.overlap_cut_hw and cfg.hw > cfg.overlap_cut_hw)
+    self.split = bool(want and cfg.overlap_cut_hw and cfg.hw > cfg.overlap_cut_hw)
     self._ptr_phase = {self.P[k].data_ptr(): ph for k, ph in self.store.phase.items()}
     self._extras = None             # per-run dataset fields besides the images (run(..., distill_embed_s=, distill_embed_t=))
     self.use_graph = use_graph
@@ -456,6 +456,8 @@ class Trainer:
           torch.autograd.backward(roots, grads)
         _DomainStreams.join_all(self.device)
         last = seg == nseg - 1
+        if nseg > 1:      # spectrally normalised kernels whose uses are all behind us: through the normalisation's backward
+          pggan.sn_segment_backward(self.P, lambda scope, seg=seg: last or self.store.phase.get(scope + '/weights', 0) <= seg)
         # filter gradients still waiting for a pair: issue those this segment completes, keep the others
         ops.GradSink.flush(None if last else (lambda ptr, seg=seg: self._ptr_phase.get(ptr, 0) <= seg))
         ops.flush_slab_reductions()      # after the join: every queued slab is written, the launch is on the main stream
@@ -530,6 +532,11 @@ class Trainer:
     run between them, outside any capture.  The eager warm-up (one real step of each kind: allocates every weight pack
     and job table once) is undone afterwards, so graph mode and eager mode follow the same trajectory."""
     self._static = dict(s=None if sources is None else sources.clone(), t=targets.clone())
+    # dataset fields besides the images (the distillation embeddings): static buffers the captured graphs read, refilled
+    # before every replay; the SET of fields is part of the capture
+    if self._extras:
+      self._static['extras'] = {k: v.clone() for k, v in self._extras.items()}
+      self._extras = self._static['extras']
     st = self._static
     snap = self._snapshot()
     side = torch.cuda.Stream(device=self.device)
@@ -615,6 +622,13 @@ class Trainer:
       st['s'].copy_(sources)
     if targets.data_ptr() != st['t'].data_ptr():
       st['t'].copy_(targets)
+    have, want = st.get('extras') or {}, self._extras or {}
+    if set(have) != set(want):
+      raise ValueError('the captured graphs were recorded with the dataset fields %s, this run brings %s'
+                       % (sorted(have), sorted(want)))
+    for k, v in want.items():
+      if v.data_ptr() != have[k].data_ptr():
+        have[k].copy_(v)
     segs, ga = self._graphs[kind]
     for seg, gr in enumerate(segs):
       gr.replay()
@@ -628,9 +642,9 @@ class Trainer:
     """One ``session.run(train_op)`` of the reference (image_generation.py:640-652):
     n_critic_counter % n_critic == 0 -> generator/encoder apply, else discriminator apply.
     ``extras``: further dataset fields of the batch -- distill_embed_s / distill_embed_t ([B, D] fp32, the
-    'a_embedding' / 'b_embedding' of --do_encoder_distillation); eager launches only."""
+    'a_embedding' / 'b_embedding' of --do_encoder_distillation); under graph replay they are copied into static buffers
+    (the same fields on every run)."""
     is_g = self.n_critic_counter % self.cfg.n_critic == 0
-    assert not (extras and self.use_graph), 'dataset extras are not part of the captured graphs: use_graph=False'
     self._extras = extras or None
     import contextlib
     # the kernels go to the current device's stream (ops._stream)
