@@ -155,7 +155,8 @@ def self_attention_layer(P, sc, layer, domain, cfg, is_discriminator, cond=None)
       w, b = P[scope + '/weights'], P[scope + '/biases']
       y = ops.conv2d(layer, w, b, 1, 'SAME')      # libs.sn.convolution directly: no equalized-lr input scaling
     else:
-      y = _ge_conv(P, scope, layer, domain, cfg, k=1, activation=False, pixel_norm=False, equalize=False, cond=cond)
+      y = _ge_conv(P, scope, layer, domain, cfg, k=1, activation=False, pixel_norm=False, equalize=False, cond=cond,
+                   spectral=False)
     outs.append(ops.tanh(y) if nm != 'sa_h' else y)
   f, g, h = outs
   npos = hh * ww
@@ -213,12 +214,14 @@ def _cond_rows(P, scope, ns, cond, segments):
 
 
 def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pixel_norm=True, pool=False, equalize=True,
-             upcat=None, cond=None):
+             upcat=None, cond=None, spectral=True):
   """maybe_pixel_norm(maybe_equalized_conv2d(...)) for the generator / encoder arg-scope
   (nets/pggan_utils.py:86-98,236-245): conv without bias, per-domain instance norm, LeakyReLU(0.2),
   then pixel norm (nets/pggan.py:78-81).  ``domain`` is 's' | 't', or (d0, d1, split): the batch holds
   ``split`` images of domain d0 followed by images of domain d1 (two reference passes as one launch)."""
-  w = _sn(P, scope, cfg, False)
+  # spectral=False: the attention convs go through libs.sn.convolution with do_spec_norm False (libs/self_attention.py:
+  # 30-48): never normalised, whatever --spectral_norm_in_non_discriminator says
+  w = _sn(P, scope, cfg, False) if spectral else P[scope + '/weights']
   if cfg.generator_norm_type == 'none':
     if upcat is not None:
       x = ops.upsample2x_concat(upcat[0], upcat[1], upcat[2], upcat[3])
