@@ -535,7 +535,9 @@ def test_full_size_256_hits_the_reference(precision):
   Measured (tools/full_size_report.py): fp32 path -- worst loss term 2.3e-6, worst probe 2.3e-5, gradient-norm ratios
   0.9988..1.0015; bf16 path -- 7.5e-3, 0.17, ratios 0.75..1.18 with median 0.996.  Bounds: fp32 losses 2e-4 relative
   (to max(1, |x|)), probes 1e-3, gradient norms 1 % (of max(norm, 1e-3 of the group's largest)); bf16 losses 3e-2,
-  probes 0.3, gradient-norm ratios 0.5..1.6 with the median within 3 %."""
+  probes 0.3, gradient-norm ratios 0.5..1.6 with the median within 3 %, and -- the bound that carries the weight -- the
+  aggregate deviation of each group's gradients from the float64 ones <= 1.5 x the deviation bf16 storage rounding alone
+  causes in the float64 oracle on the same weights and inputs (tests/golden/full_hw256_c256_rounding.json)."""
   import json
   import os
   from twingan_amd import Config
@@ -585,6 +587,28 @@ def test_full_size_256_hits_the_reference(precision):
       ratios = [p[1] / p[2] for p in pairs if p[2] > floor]
       bad = [p for p in pairs if p[2] > floor and not 0.5 < p[1] / p[2] < 1.6]
       assert abs(float(np.median(ratios)) - 1.0) < 0.03, float(np.median(ratios))
+      # The statement proper (round 4): the kernels' gradients are no further from the float64 gradients than 1.5 x what
+      # bf16 STORAGE ROUNDING ALONE does to this graph on these weights and inputs.  tests/golden/full_hw256_c256_rounding.json
+      # (tools/make_rounding_sketch.py, float64 oracle at full size) holds that figure per optimiser group -- the oracle
+      # with bf16 rounding at the kernels' storage points moves the generator group by rel-L2 0.417, the discriminator group
+      # by 0.080 -- and K = 16 seeded +-1 projections of every variable's float64 gradient, from which |g_hip - g_64|^2 of a
+      # group is estimated without the 71 MB of gradients (E[(r . d)^2] = |d|^2; the same estimator reads 0.378 / 0.092 on
+      # the rounded oracle itself).
+      with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'full_hw256_c256_rounding.json')) as fh:
+        rs = json.load(fh)
+      num = den = 0.0
+      for k in names:
+        idx = rs['order'].index(k)
+        gen = torch.Generator().manual_seed(rs['sketch_seed'] + idx)
+        r = (torch.randint(0, 2, (rs['K'], gd[k].numel()), generator=gen, dtype=torch.int8).to('cuda:0').double() * 2.0 - 1.0)
+        h = (r @ gd[k].reshape(-1).double().to('cuda:0')).cpu()
+        e = torch.tensor(rs['exact_sketch'][k], dtype=torch.float64)
+        num += float(((h - e) ** 2).sum())
+        den += float((e ** 2).sum())
+      rel = (num / den) ** 0.5
+      print('[full size bf16] %s group: kernels %.3f from the float64 gradients (sketch estimate); storage rounding alone %.3f'
+            % (group, rel, rs['rounded_rel_l2'][group]))
+      assert rel < 1.5 * rs['rounded_rel_l2'][group] + 0.02, (group, rel, rs['rounded_rel_l2'][group])
     assert not bad, bad[:5]
     del loss, terms, gd
 

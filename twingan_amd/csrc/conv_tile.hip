@@ -545,10 +545,15 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
 // workgroup stages its weight slice ONCE and walks `tiles_per_wg` consecutive tiles, so per tile it only moves
 // the input halo; the next tile's halo loads are in flight during the MFMAs of the current one.
 // ------------------------------------------------------------------------------------------------
-template <int KH, int KC, int BN, int NCH, int MODE = 0, bool F16 = false>
+// EPI: which of the per-tile epilogue operands exist -- bit 0 the bias row (16 VGPRs per 32-channel block, held across the
+// workgroup's tiles), bit 1 the LeakyReLU mask of the masked backward-data (8 VGPRs per block).  Compile-time so that a
+// launch without them does not pay their registers: these kernels are short of RESIDENT WORKGROUPS, not of anything else
+// (the single-chunk 16-channel variant: 88 VGPRs = 5 workgroups per CU with both, 8 by LDS).
+template <int KH, int KC, int BN, int NCH, int MODE = 0, bool F16 = false, int EPI = 3>
 __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                              const float* __restrict__ bias, bf16* __restrict__ y,
                                                              const TileGeom g) {
+  constexpr bool HAS_BIAS = (EPI & 1) != 0, HAS_MASK = (EPI & 2) != 0;
   constexpr bool STATS = MODE == 1, POOL = MODE == 2, UPBWD = MODE == 3;      // UPBWD: see TileGeom::up_out
   constexpr int KW = KH, NT = KH * KW;
   constexpr int TW = 16, TH = 8;
@@ -663,14 +668,16 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
     }
   };
 
-  const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, (g.epilogue & TG_EPI_BIAS) ? (unsigned)(g.cout * 4) : 0u);
-  f32x4 bq[NTILE][4];
+  const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, (HAS_BIAS && (g.epilogue & TG_EPI_BIAS)) ? (unsigned)(g.cout * 4) : 0u);
+  f32x4 bq[HAS_BIAS ? NTILE : 1][4];
+  if constexpr (HAS_BIAS) {
 #pragma unroll
-  for (int nt = 0; nt < NTILE; ++nt)
+    for (int nt = 0; nt < NTILE; ++nt)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      bq[nt][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                 rbias, (unsigned)((n0 + nt * 32 + q * 8 + kgrp * 4) * 4), 0, 0));
+      for (int q = 0; q < 4; ++q)
+        bq[nt][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   rbias, (unsigned)((n0 + nt * 32 + q * 8 + kgrp * 4) * 4), 0, 0));
+  }
 
   // STATS: a workgroup's tiles belong to ONE image (the launcher picks tiles_per_wg as a divisor of the tiles per image).
   // Per tile each lane folds its 32 values per channel block (16 channels, value and square) by the first ST steps of
@@ -713,8 +720,8 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
     if constexpr (UPBWD) load_a(st, tn, sn);
     else load_a(st, t + 1);
     // the LeakyReLU mask of the epilogue (masked backward-data) is requested NOW, so that it lands during the MFMAs
-    u32x2 zm[NTILE][4];
-    if (g.mask) {      // uniform
+    u32x2 zm[HAS_MASK ? NTILE : 1][4];
+    if (HAS_MASK && g.mask) {      // uniform
 #pragma unroll
       for (int nt = 0; nt < NTILE; ++nt)
 #pragma unroll
@@ -791,12 +798,13 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float a = acc[nt][q * 4 + j] + bq[nt][q][j];
+          float a = acc[nt][q * 4 + j];
+          if constexpr (HAS_BIAS) a += bq[nt][q][j];
           if (g.epilogue & TG_EPI_LRELU) a = lrelu_f(a, g.alpha);
           v[j] = a;
         }
-        if (g.mask) {      // uniform: a positive bf16 is a positive int16 pattern
-          const u32x2 z = zm[nt][q];
+        if (HAS_MASK && g.mask) {      // uniform: a positive bf16 is a positive int16 pattern
+          const u32x2 z = zm[HAS_MASK ? nt : 0][q];
           v[0] *= (short)(z[0] & 0xffffu) > 0 ? 1.f : g.alpha;
           v[1] *= (short)(z[0] >> 16) > 0 ? 1.f : g.alpha;
           v[2] *= (short)(z[1] & 0xffffu) > 0 ? 1.f : g.alpha;
@@ -924,22 +932,30 @@ int launch_tile_wres(const TileGeom& g0, const bf16* x, const bf16* wp, const fl
   const int nwg = (g.nblk + tpw - 1) / tpw;
   const size_t lds = (size_t)((HH * HWX * (KC * 2 + 16) + 15) & ~15) + (size_t)NCH * BN * (KH * KH * KC * 2 + 16);
   TG_CHECK(lds <= 64 * 1024, TG_ENOSUP, "conv_tile(wres): LDS %zu too large", lds);
+  TG_CHECK(!(g.mask && (g.epilogue & TG_EPI_BIAS)), TG_ENOSUP, "conv_tile(wres): a bias and a mask epilogue do not come together");
   const char* fmt = g.f16 ? ",f16" : "";
 // the epilogue variant MODE_ in the element format of the call (both formats are instantiated for every epilogue)
-#define TG_WRES_LAUNCH(MODE_)                                                                                              \
-  do {                                                                                                                     \
-    if (g.f16)                                                                                                             \
-      hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH, MODE_, true>), dim3(nwg, ny), dim3(256), lds, s, x, wp,  \
-                         bias, y, g);                                                                                      \
-    else                                                                                                                   \
-      hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH, MODE_, false>), dim3(nwg, ny), dim3(256), lds, s, x, wp, \
-                         bias, y, g);                                                                                      \
+#define TG_WRES_LAUNCH_E(MODE_, EPI_)                                                                                           \
+  do {                                                                                                                          \
+    if (g.f16)                                                                                                                  \
+      hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH, MODE_, true, EPI_>), dim3(nwg, ny), dim3(256), lds, s, x, wp, \
+                         bias, y, g);                                                                                           \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((conv_tile_wres_kernel<KH, KC, BN, NCH, MODE_, false, EPI_>), dim3(nwg, ny), dim3(256), lds, s, x,    \
+                         wp, bias, y, g);                                                                                       \
+  } while (0)
+// the variant that carries only the epilogue operands this call has (bias and mask never come together)
+#define TG_WRES_LAUNCH(MODE_)                                     \
+  do {                                                            \
+    if (g.mask) TG_WRES_LAUNCH_E(MODE_, 2);                       \
+    else if (g.epilogue & TG_EPI_BIAS) TG_WRES_LAUNCH_E(MODE_, 1); \
+    else TG_WRES_LAUNCH_E(MODE_, 0);                              \
   } while (0)
   if (g.up_out) {
     if constexpr (KH == 3) {
       TG_CHECK(g.epilogue == 0 && !g.mask && !g.ypool && !stats, TG_ENOSUP, "conv_tile(wres): the concat backward comes with the plain epilogue only");
       tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d,upbwd%s>", KH, KC, BN, NCH, fmt);
-      TG_WRES_LAUNCH(3);
+      TG_WRES_LAUNCH_E(3, 0);
     } else {
       TG_CHECK(false, TG_ENOSUP, "conv_tile(wres): the concat backward is built for 3x3 only");
     }
@@ -947,7 +963,7 @@ int launch_tile_wres(const TileGeom& g0, const bf16* x, const bf16* wp, const fl
     if constexpr (KH == 3) {
       TG_CHECK(g.epilogue == 0 && !g.mask && !g.ypool, TG_ENOSUP, "conv_tile(wres): statistics come with the plain epilogue only");
       tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d,stats%s>", KH, KC, BN, NCH, fmt);
-      TG_WRES_LAUNCH(1);
+      TG_WRES_LAUNCH_E(1, 0);
     } else {
       TG_CHECK(false, TG_ENOSUP, "conv_tile(wres): statistics epilogue is built for 3x3 only");
     }
@@ -955,7 +971,8 @@ int launch_tile_wres(const TileGeom& g0, const bf16* x, const bf16* wp, const fl
     if constexpr (KH == 3) {
       TG_CHECK(!g.mask, TG_ENOSUP, "conv_tile(wres): the pooled output is a forward feature");
       tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d,pool%s>", KH, KC, BN, NCH, fmt);
-      TG_WRES_LAUNCH(2);
+      if (g.epilogue & TG_EPI_BIAS) TG_WRES_LAUNCH_E(2, 1);
+      else TG_WRES_LAUNCH_E(2, 0);
     } else {
       TG_CHECK(false, TG_ENOSUP, "conv_tile(wres): pooled output is built for 3x3 only");
     }
@@ -964,6 +981,7 @@ int launch_tile_wres(const TileGeom& g0, const bf16* x, const bf16* wp, const fl
     TG_WRES_LAUNCH(0);
   }
 #undef TG_WRES_LAUNCH
+#undef TG_WRES_LAUNCH_E
   TG_LAUNCH_CHECK("conv_tile_wres");
   return TG_OK;
 }
