@@ -31,15 +31,18 @@ def storage_rounding(dtype, forward=True, backward=True, weights=True):
 
   def wr(w):      # straight-through: the pack is rounded, the gradient belongs to the fp32 master
     return w + (w.detach().to(wdt).to(w.dtype) - w.detach()) if wdt else w
-  saved = dict(conv2d=R.conv2d, ge_conv=R.ge_conv, d_conv=R.d_conv, avg_pool2=R.avg_pool2)
+  saved = dict(conv2d=R.conv2d, ge_conv=R.ge_conv, d_conv=R.d_conv, avg_pool2=R.avg_pool2, self_attention=R.self_attention)
   conv, inorm, pnorm, lrelu, pool = R.conv2d, R.instance_norm, R.pixel_norm, R.leaky_relu, R.avg_pool2
 
   def conv2d(x, w, padding):
     return rnd(conv(rnd(x), wr(w), padding))
 
-  def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=True, **kw):
-    assert not kw.get('cond') and cfg.norm == 'instance_norm', 'the sensitivity probe covers the headline configuration'
-    y = conv2d(x, P[scope + '/weights'], padding)
+  def ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', act=True, pixnorm=True, equalized=True, cond=None, spectral=True):
+    assert cond is None and cfg.norm == 'instance_norm' and not cfg.equalized, \
+        'the sensitivity probe covers the headline configuration (+ spectral norm / attention)'
+    # a spectrally normalised kernel is computed in fp32 from the master and THEN packed to the storage format
+    w = R.spectral_normed_weight(P, scope, cfg, False) if spectral else P[scope + '/weights']
+    y = conv2d(x, w, padding)
     y = inorm(y, P[scope + '/InstanceNorm/gamma_' + domain], P[scope + '/InstanceNorm/beta_' + domain], cfg.in_eps)
     if act:
       y = lrelu(y, cfg.lrelu)
@@ -48,15 +51,53 @@ def storage_rounding(dtype, forward=True, backward=True, weights=True):
     return rnd(y)
 
   def d_conv(P, scope, x, cfg, k=3, padding='SAME', **kw):
-    y = conv(rnd(x), wr(P[scope + '/weights']), padding) + P[scope + '/biases']
+    assert not cfg.equalized
+    y = conv(rnd(x), wr(R.spectral_normed_weight(P, scope, cfg)), padding) + P[scope + '/biases']
     return rnd(lrelu(y, cfg.lrelu))
-  R.conv2d, R.ge_conv, R.d_conv = conv2d, ge_conv, d_conv
+
+  def self_attention(P, sc, layer, domain, cfg, is_discriminator, cond=None):
+    """libs/self_attention.py:24-70 with the storage points of the HIP path: f, g (after tanh) and h are stored tensors, the
+    softmax map is rounded where the flash kernels pack it for the second product, o and the gated sum are stored."""
+    n, hh, ww, c = layer.shape
+    outs = []
+    for nm in ('sa_f', 'sa_g', 'sa_h'):
+      scope = '%s/%s' % (sc, nm)
+      if is_discriminator:
+        y = rnd(conv2d(layer, P[scope + '/weights'], 'SAME') + P[scope + '/biases'])
+      else:
+        y = ge_conv(P, scope, layer, domain, cfg, k=1, act=False, pixnorm=False, equalized=False, cond=cond, spectral=False)
+      outs.append(rnd(torch.tanh(y)) if nm != 'sa_h' else y)
+    f, g_, h = outs
+    npos = hh * ww
+    s_ = torch.bmm(f.reshape(n, npos, -1), g_.reshape(n, npos, -1).transpose(1, 2))
+    beta = rnd(torch.softmax(s_, dim=-1))
+    o = rnd(torch.bmm(beta, h.reshape(n, npos, c)).reshape(layer.shape))
+    return rnd(P[sc + '/sa_gamma'] * o + layer)
+  R.conv2d, R.ge_conv, R.d_conv, R.self_attention = conv2d, ge_conv, d_conv, self_attention
   R.avg_pool2 = lambda x: rnd(pool(x))
   try:
     yield
   finally:
     for k, v in saved.items():
       setattr(R, k, v)
+
+
+def gradient_sensitivity(P, names, loss_fn, dtype, reset=None, **which):
+  """rel-L2 over the variables ``names`` between the float64 gradients of ``loss_fn(Q)`` (Q: a fresh copy of P that requires
+  grad) and those of the same graph with ``dtype`` storage rounding inserted.  ``reset``: called before each of the two
+  evaluations (spectral norm: put the pre-run u back, drop the run's normalised kernels).
+  -> (rel_l2, rounded gradients, exact gradients)."""
+  def grads():
+    if reset is not None:
+      reset()
+    Q = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    return R.grads_of(loss_fn(Q), Q, names)
+  exact = grads()
+  with storage_rounding(dtype, **which):
+    rounded = grads()
+  num = sum(float(((rounded[k] - exact[k]) ** 2).sum()) for k in exact)
+  den = sum(float((exact[k] ** 2).sum()) for k in exact)
+  return (num / den) ** 0.5, rounded, exact
 
 
 def generator_gradient_sensitivity(P, s, t, cfg, dtype, **which):

@@ -1583,6 +1583,24 @@ def test_config4_half_precision_flash_path_matches_composed_path_and_oracle():
     ops.call = orig_call
   assert all(v > 0 for v in n_flash.values()), n_flash      # forward, first-order and second-order kernels all ran
 
+  # what fp16 STORAGE ROUNDING ALONE does to the float64 gradients of this graph on these inputs (oracle/rounding.py: the
+  # oracle with fp16 rounding at the kernels' storage points, incl. the normalised kernels' packs and the attention's stored
+  # tensors): the bound on the kernels is 1.5 x that figure, per loss group
+  from oracle import rounding
+
+  def sn_reset():
+    if rcfg.sn_cache:
+      rcfg.sn_cache.clear()
+    for k, v in sn0.items():
+      rcfg.sn_state[k] = v.double()
+  P0 = {k: v.detach() for k, v in Pref.items()}
+  pred = {
+      'g': rounding.gradient_sensitivity(P0, [k for k in tr.store.names('g') if k in ref_g],
+                                         lambda Q: R.generator_loss(Q, ref['s'], ref['t'], rcfg)[0], torch.float16, reset=sn_reset)[0],
+      'd': rounding.gradient_sensitivity(P0, [k for k in tr.store.names('d') if k in ref_d],
+                                         lambda Q: R.discriminator_loss(Q, ref['s'], ref['t'], rcfg, ref['a_s'], ref['a_t'])[0],
+                                         torch.float16, reset=sn_reset)[0]}
+  sn_reset()
   for grp, rterms, rgrads in (('g', rgterms, ref_g), ('d', rdterms, ref_d)):
     for name, res in (('flash', flash), ('composed', composed)):
       terms, grads = res[grp]
@@ -1590,9 +1608,11 @@ def test_config4_half_precision_flash_path_matches_composed_path_and_oracle():
         want = float(rterms[k])
         assert abs(terms[k] - want) < 5e-2 * abs(want) + 2e-2, (grp, name, k, terms[k], want)
       e, cos = agg(grads, rgrads)
-      print('[config4 fp16] %s %s: gradients vs oracle rel-L2 %.3e cosine %.5f' % (grp, name, e, cos))
-      # measured (gpurun_out r3l): g 0.108 / 0.099 (flash / composed), cosine 0.994 / 0.995; d 0.1435 / 0.1433, cosine 0.9897
-      assert e < 0.25 and cos > 0.97, (grp, name, e, cos)
+      print('[config4 fp16] %s %s: gradients vs oracle rel-L2 %.3e cosine %.5f; fp16 storage rounding alone %.3e'
+            % (grp, name, e, cos, pred[grp]))
+      # round 3 measured g 0.108 / 0.099 (flash / composed), d 0.1435 / 0.1433 against a fixed 0.25; now against the oracle's
+      # own deviation under the same rounding
+      assert e < 1.5 * pred[grp] + 0.02 and cos > 0.97, (grp, name, e, cos, pred[grp])
     e, cos = agg(flash[grp][1], composed[grp][1])
     print('[config4 fp16] %s: flash vs composed rel-L2 %.3e cosine %.5f' % (grp, e, cos))
     # the two HIP paths are closer to each other than either is to the oracle: measured g 0.068, d 0.013

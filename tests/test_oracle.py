@@ -472,3 +472,36 @@ def test_storage_rounding_sensitivity_of_the_headline_graph():
   la, _ = R.generator_loss(P, s, t, cfg)
   lb, _ = R.generator_loss(P, s, t, cfg)
   assert float(la) == float(lb) and R.conv2d.__module__ == 'oracle.torch_ref'
+
+
+def test_storage_rounding_covers_spectral_norm_and_attention():
+  """oracle/rounding.py on BASELINE configs[4]'s ingredients (spectral norm on the discriminator kernels, self-attention in
+  E / G / D, WGAN-GP): the probe runs both loss groups with the pre-run u put back before each evaluation, fp16 rounding
+  moves the gradients less than bf16, and with no rounding at all (every switch off) the patched graph IS the oracle."""
+  from oracle import rounding
+  from oracle import torch_ref as R
+  cfg = R.Config(hw=16, max_ch=16, spectral_norm=True, do_self_attention=True, self_attention_hw=8)
+  P = {k: v.float().double() for k, v in R.init_params(cfg, seed=5, dtype=torch.float64, std='he').items()}
+  for k in P:
+    if k.endswith('/sa_gamma'):
+      P[k] = torch.full_like(P[k], 0.3)      # the gate starts at 0 (libs/self_attention.py:68): open it so attention matters
+  sn0 = R.init_sn_state(P, seed=3)
+  g = torch.Generator().manual_seed(77)
+  s = torch.rand(2, 16, 16, 3, generator=g).to(torch.float16).double()
+  t = torch.rand(2, 16, 16, 3, generator=g).to(torch.float16).double()
+  a = torch.rand(2, 1, 1, 1, generator=g).double()
+
+  def reset():
+    cfg.sn_cache = None
+    cfg.sn_state = {k: v.clone() for k, v in sn0.items()}
+  losses = {'g': lambda Q: R.generator_loss(Q, s, t, cfg)[0], 'd': lambda Q: R.discriminator_loss(Q, s, t, cfg, a, a)[0]}
+  names = {'g': R.generator_var_names(P), 'd': R.discriminator_var_names(P)}
+  for grp in ('g', 'd'):
+    e16, _, exact = rounding.gradient_sensitivity(P, names[grp], losses[grp], torch.float16, reset=reset)
+    eb16, _, _ = rounding.gradient_sensitivity(P, names[grp], losses[grp], torch.bfloat16, reset=reset)
+    e0, _, _ = rounding.gradient_sensitivity(P, names[grp], losses[grp], torch.float16, reset=reset, forward=False, backward=False,
+                                             weights=False)
+    print('[sensitivity sn+attention] %s: fp16 %.4f bf16 %.4f off %.1e' % (grp, e16, eb16, e0))
+    assert 0.0 < e16 < eb16 < 1.0 and e0 < 1e-12
+    assert any(float(exact[k].abs().max()) > 0 for k in names[grp] if '/self_attention_' in k)
+  assert R.self_attention.__module__ == 'oracle.torch_ref'
