@@ -2127,23 +2127,18 @@ class AbsDiffMeanFn(torch.autograd.Function):
 
 
 class GradPenaltyFn(torch.autograd.Function):
-  """lambda * mean_b (||g_b / scale||_2 - 1)^2 (image_generation.py:431-436) -> fp32 [1].  ``scale``: the factor the caller
-  multiplied the inner gradient's cotangent by (1: none)."""
+  """lambda * mean_b (||g_b||_2 - 1)^2 (image_generation.py:431-436) -> fp32 [1]."""
 
   @staticmethod
-  def forward(ctx, g, lam, scale=1.0):
+  def forward(ctx, g, lam):
     _chk(g)
     b = g.shape[0]
     ss = torch.empty(b, dtype=torch.float32, device=g.device)
     call('tg_sample_sumsq', _p(g), _p(ss), b, g.numel() // b, _dt(g), _stream(),
          work=('sample_sumsq:numel%d' % g.numel(), 0, _nb(g)))
-    if scale != 1.0:
-      ss.mul_(1.0 / (scale * scale))      # ||g / scale||^2 (a power of two: exact)
     loss = torch.empty(1, dtype=torch.float32, device=g.device)
     coef = torch.empty(b, dtype=torch.float32, device=g.device)
     call('tg_gp_penalty', _p(ss), _p(loss), _p(coef), b, lam, _stream())
-    if scale != 1.0:
-      coef.mul_(1.0 / (scale * scale))    # d loss / d g = coef * (g / scale) / scale
     ctx.save_for_backward(g, coef)
     return loss
 
@@ -2155,7 +2150,7 @@ class GradPenaltyFn(torch.autograd.Function):
     b = g.shape[0]
     call('tg_sample_scale', _p(g), _p(coef), _p(gl.contiguous()), _p(out), b, g.numel() // b, _dt(g), _stream(),
          work=('sample_scale:numel%d' % g.numel(), 0, _nb(g, out)))
-    return out, None, None
+    return out, None
 
 
 class PredLossFn(torch.autograd.Function):
@@ -2261,5 +2256,5 @@ def abs_diff_mean(a, b, weight=1.0):
   return AbsDiffMeanFn.apply(a, b, float(weight))
 
 
-def gradient_penalty(g, lam, scale=1.0):
-  return GradPenaltyFn.apply(g, float(lam), float(scale))
+def gradient_penalty(g, lam):
+  return GradPenaltyFn.apply(g, float(lam))

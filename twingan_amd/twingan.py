@@ -288,18 +288,10 @@ def _d_domain_gp(P, cfg, terms, d, top, real, prime, a, noise=None, name=None):
     interp = ops.sample_lerp(real, prime, a).requires_grad_(True)             # image_generation.py:420-424
   with ops.second_order():
     pi, _ = pggan.discriminator(P, interp, cfg, top, block_end_points=False)
-  # fp16 storage: tf.gradients(pred, interp) starts from a cotangent of ONE, outside the loss scale (model_deploy.py:308-313
-  # scales the total loss, i.e. the second pass) -- d pred / d pixel of a fresh discriminator is ~1e-5, fp16's denormal range,
-  # and the discriminator group's gradients then sit 0.14 from the float64 ones where fp16 rounding alone explains 0.02
-  # (tests/test_gpu_model.py config-4 test; flushing fp16 denormals in the oracle's backward gives 0.50).  The inner gradient
-  # is linear in its cotangent, so it runs scaled by the loss scale (a power of two: no rounding changes elsewhere) and the
-  # penalty divides the norm back -- exact in exact arithmetic, bf16 / fp32 paths untouched.
-  inner = float(cfg.loss_scale) if (cfg.precision == 'fp16' and cfg.loss_scale > 1.0) else 1.0
-  ones = ops.fill(pi.shape, inner, pi.dtype, pi.device)
+  ones = ops.fill(pi.shape, 1.0, pi.dtype, pi.device)
   with ops.no_param_grads():        # only d pred / d interp is needed here; parameters get theirs via the double backward
     gi, = torch.autograd.grad(pi, interp, grad_outputs=ones, create_graph=True)  # tf.gradients(pred, interp)
-  terms[name or 'discriminator_gradient_penalty_prime_' + d] = ops.gradient_penalty(gi.contiguous(), cfg.gradient_penalty_lambda,
-                                                                                    scale=inner)
+  terms[name or 'discriminator_gradient_penalty_prime_' + d] = ops.gradient_penalty(gi.contiguous(), cfg.gradient_penalty_lambda)
 
 
 BATCH_RENORM_BOUNDARIES = (10000, 20000, 30000)                      # nets/pggan_utils.py:43-47
