@@ -1296,52 +1296,59 @@ std::mutex g_defer_mu;
 
 // VEC = 4: a thread owns FOUR consecutive elements (one 16-byte load per slice, 8 slices in flight: 128 bytes per thread
 // against 32 with one element per thread; nw = 9 * cin * cout is a multiple of 4 and every slab row starts 16-byte aligned);
-// VEC = 1: one element per thread (the stand-alone kernels' shape).  Per element the slices are added in the stand-alone
-// kernel's order either way.  A job whose gw no other job of the table writes (SLAB_UNIQUE: nothing else touches the sink
-// while the flush runs -- the trainer joined its streams before it) adds with a plain read-modify-write instead of one
-// float atomic per element (~14 M atomics per flush at ~0.25 T atomics/s).
-constexpr int SLAB_UNIQUE = 0x100;
+// VEC = 1: one element per thread (the stand-alone kernels' shape).  Per element the slices of a job are added in the
+// stand-alone kernel's order either way.
+// NO ATOMICS: the jobs that add into one sink (a discriminator kernel gets up to three filter gradients per backward: the
+// batched pass, the gradient penalty's second pass and the pass back through the penalty's forward graph) form a CHAIN --
+// the head owns the blocks, walks the chain and adds the jobs' sums to the sink in queueing order with a plain
+// read-modify-write (nothing else touches a sink while the flush runs: the trainer joined its streams before it).  With one
+// atomic per element and job the ORDER of three float adds depended on block scheduling -- the fp32 path's last bit moved
+// from run to run (test_fp32_path_is_bit_reproducible, round 4) -- and ~14 M atomics per flush cost ~50 us.
+// SlabJob::sg: bits 0-7 the slice groups (1 / 4 / 16), bits 16-31 the index of the next job of the chain (0: none; entry 0
+// is always a head).  The table holds the `n` heads first (blk0 ascending), the chained jobs behind them.
 template <int VEC>
 __global__ __launch_bounds__(256) void conv_wgrad_slab_reduce_multi(const SlabJobTable tab) {
   typedef typename std::conditional<VEC == 4, f32x4, float>::type vt;
   __shared__ vt part[16 * 17 > 4 * 65 ? 16 * 17 : 4 * 65];
   int j = 0;
   while (j + 1 < tab.n && (int)blockIdx.x >= tab.j[j + 1].blk0) ++j;      // block-uniform
-  const vt* __restrict__ slab = reinterpret_cast<const vt*>(tab.j[j].slab);
   vt* __restrict__ gw = reinterpret_cast<vt*>(tab.j[j].gw);
   const int64_t nwv = tab.j[j].nw / VEC;
-  const int nslices = tab.j[j].nslices, sgn = tab.j[j].sg & 0xff, epb = 256 / sgn;
-  const bool unique = (tab.j[j].sg & SLAB_UNIQUE) != 0;
+  const int sgn = tab.j[j].sg & 0xff, epb = 256 / sgn;      // the same for every job of a chain (a function of nw)
   const int e = threadIdx.x % epb, sg = threadIdx.x / epb;
   const int64_t i = (int64_t)((int)blockIdx.x - tab.j[j].blk0) * epb + e;
-  vt a[8];
+  const bool owner = (int)threadIdx.x < epb && i < nwv;
+  vt total = vt{};
+  if (owner) total = gw[i];
+  for (int job = j;;) {      // block-uniform chain walk
+    const vt* __restrict__ slab = reinterpret_cast<const vt*>(tab.j[job].slab);
+    const int nslices = tab.j[job].nslices;
+    vt a[8];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) a[u] = vt{};
-  if (i < nwv) {
-    int k = sg;
-    for (; k + 7 * sgn < nslices; k += 8 * sgn) {
+    for (int u = 0; u < 8; ++u) a[u] = vt{};
+    if (i < nwv) {
+      int k = sg;
+      for (; k + 7 * sgn < nslices; k += 8 * sgn) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] += slab[(size_t)(k + u * sgn) * nwv + i];
+        for (int u = 0; u < 8; ++u) a[u] += slab[(size_t)(k + u * sgn) * nwv + i];
+      }
+      for (; k < nslices; k += sgn) a[0] += slab[(size_t)k * nwv + i];
     }
-    for (; k < nslices; k += sgn) a[0] += slab[(size_t)k * nwv + i];
+    vt t = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    if (sgn != 1) {
+      part[sg * (epb + 1) + e] = t;
+      __syncthreads();
+      if (owner) {
+        t = vt{};
+        for (int q = 0; q < sgn; ++q) t += part[q * (epb + 1) + e];
+      }
+      __syncthreads();      // the next job of the chain reuses the scratch
+    }
+    total += t;
+    job = (int)((unsigned)tab.j[job].sg >> 16);
+    if (!job) break;
   }
-  vt t = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-  if (sgn != 1) {
-    part[sg * (epb + 1) + e] = t;
-    __syncthreads();
-    if ((int)threadIdx.x >= epb) return;
-    t = vt{};
-    for (int q = 0; q < sgn; ++q) t += part[q * (epb + 1) + e];
-  }
-  if (i >= nwv) return;
-  if (unique) {
-    gw[i] += t;
-  } else if constexpr (VEC == 4) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) atomicAdd(reinterpret_cast<float*>(gw + i) + q, t[q]);
-  } else {
-    atomicAdd(gw + i, t);
-  }
+  if (owner) gw[i] = total;
 }
 
 }  // namespace
@@ -1358,26 +1365,47 @@ extern "C" int tg_wgrad_defer_flush(void* stream) {
   std::lock_guard<std::mutex> lock(g_defer_mu);
   const int n = g_defer.n;
   if (n > 0) {
-    // grid layout and uniqueness flags for the vector width of this flush (TG_TUNE_SLAB_VEC = 1: one element per thread)
+    // heads (the first job of every sink, in queueing order) in front, the other jobs of their chains behind them; grid laid
+    // out over the heads for the vector width of this flush (TG_TUNE_SLAB_VEC = 1: one element per thread)
     const int vec = tg_tune("TG_TUNE_SLAB_VEC", 4) == 1 ? 1 : 4;
-    const bool plain = tg_tune("TG_TUNE_SLAB_PLAIN", 1) != 0;
+    SlabJobTable tab;
+    int order[MAXJ], head_of[MAXJ], nheads = 0;
+    for (int a = 0; a < n; ++a) {
+      head_of[a] = a;
+      for (int b = 0; b < a; ++b)
+        if (g_defer.j[b].gw == g_defer.j[a].gw) {
+          head_of[a] = head_of[b];
+          break;
+        }
+      if (head_of[a] == a) order[nheads++] = a;
+    }
+    int pos[MAXJ], m = nheads;
+    for (int h = 0; h < nheads; ++h) pos[order[h]] = h;
+    for (int a = 0; a < n; ++a)
+      if (head_of[a] != a) pos[a] = m++;
     int blocks = 0;
     for (int a = 0; a < n; ++a) {
-      SlabJob& jb = g_defer.j[a];
+      SlabJob jb = g_defer.j[a];
       jb.sg &= 0xff;
-      bool unique = plain;
-      for (int b = 0; b < n && unique; ++b)
-        if (b != a && g_defer.j[b].gw == jb.gw) unique = false;
-      if (unique) jb.sg |= SLAB_UNIQUE;
+      int nxt = 0;      // the next job queued for the same sink
+      for (int b = a + 1; b < n && !nxt; ++b)
+        if (head_of[b] == head_of[a]) nxt = pos[b];
+      jb.sg |= nxt << 16;
+      jb.blk0 = 0;
+      tab.j[pos[a]] = jb;
+    }
+    for (int h = 0; h < nheads; ++h) {
+      SlabJob& jb = tab.j[h];
       jb.blk0 = blocks;
       const int epb = 256 / (jb.sg & 0xff);      // threads per slice group; each owns `vec` elements
       blocks += (int)((jb.nw / vec + epb - 1) / epb);
     }
-    g_defer.blocks = blocks;
+    tab.n = nheads;
+    tab.blocks = blocks;
     if (vec == 4)
-      hipLaunchKernelGGL(conv_wgrad_slab_reduce_multi<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g_defer);
+      hipLaunchKernelGGL(conv_wgrad_slab_reduce_multi<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tab);
     else
-      hipLaunchKernelGGL(conv_wgrad_slab_reduce_multi<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g_defer);
+      hipLaunchKernelGGL(conv_wgrad_slab_reduce_multi<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tab);
     g_defer.n = g_defer.blocks = 0;
     TG_LAUNCH_CHECK("conv_wgrad_slab_reduce_multi");
   }
