@@ -212,17 +212,33 @@ __global__ void in_stats_partial(const T* __restrict__ y, float* __restrict__ s1
 }
 
 // sh[0..2c) = sum over the chunks of part[n][chunk][0..2c)  (every thread of the block; ends with a barrier)
+// Every workgroup of the streaming passes starts with this: `chunks` (16-64) rows per value, and written as a two-term loop
+// the compiler issued two loads per trip and waited for them -- 8-32 dependent L2 round trips (~10 us) in front of a kernel
+// that streams for 10-30 us on the mid-size maps (the 64 x 64 ... 16 x 16 layers sat 1.5-1.8 x above their byte time,
+// profiles/r03_z_shapes_eager_step.json).  Eight rows in flight per trip, eight accumulators combined in a fixed order.
 __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int n, int chunks, int c, float* sh) {
+  const int64_t row = 2 * (int64_t)c;
   for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) {
-    const float* p = part + (int64_t)n * chunks * 2 * c + i;
-    float a = 0.f, b = 0.f;
+    const float* p = part + (int64_t)n * chunks * row + i;
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = 0.f;
     int k = 0;
-    for (; k + 1 < chunks; k += 2) {
-      a += p[(int64_t)k * 2 * c];
-      b += p[(int64_t)(k + 1) * 2 * c];
+    for (; k + 8 <= chunks; k += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(k + u) * row];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += v[u];
     }
-    if (k < chunks) a += p[(int64_t)k * 2 * c];
-    sh[i] = a + b;
+    if (k < chunks) {      // the tail: clamped addresses, masked adds -- still all requested together
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(k + u < chunks ? k + u : chunks - 1) * row];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += (k + u < chunks) ? v[u] : 0.f;
+    }
+    sh[i] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
   __syncthreads();
 }
@@ -555,7 +571,16 @@ __global__ void norm_act_bwd2_part_kernel(const T* __restrict__ gz, const T* __r
       if (n == i0) {
         for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) {
           float t = 0.f;
-          for (int64_t k = (int64_t)i0 * chunks; k < (int64_t)i1 * chunks; ++k) t += part[k * 2 * c + i];
+          const int64_t k1 = (int64_t)i1 * chunks;
+          int64_t k = (int64_t)i0 * chunks;
+          for (; k + 8 <= k1; k += 8) {      // the same order of adds, eight loads in flight
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(k + u) * 2 * c + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+          }
+          for (; k < k1; ++k) t += part[k * 2 * c + i];
           float* dst = i < c ? gb : gg;
           if (dst) atomicAdd(dst + (i < c ? i : i - c), t);
         }
