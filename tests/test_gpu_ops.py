@@ -1142,6 +1142,8 @@ STATS_CASES = [
     (2, 32, 128, 256),    # tile kernel, channel blocks along grid y
     (3, 16, 256, 256),    # tile kernel, 2 tiles per image
     (2, 16, 40, 24),      # ragged channel counts (partial 32-channel blocks; no pixel norm at c = 24)
+    (5, 8, 256, 256),     # conv_img: a whole 8x8 image per workgroup, ONE chunk per image
+    (3, 8, 512, 256),
 ]
 
 

@@ -22,6 +22,10 @@ struct ImgGeom {
   int epilogue;
   float alpha;
   unsigned w_bytes;
+  // STATS kernels: sums of the (16-bit-rounded) outputs and of their squares per image and output channel, written as the
+  // ONE statistics chunk of the image -- stats[img][0][2][cout], the layout of conv_tile's STATS epilogue with
+  // stat_chunks = 1 -- so the instance norm after an 8x8 conv needs no pass over the tensor (in_stats_partial, norm.hip)
+  float* stats;
 };
 
 constexpr unsigned IOOB = 0x80000000u;
@@ -33,7 +37,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t i_rsrc(const void* p, unsigned
 }
 
 // HW: map size (8 or 4).  MT: 32-pixel column blocks per workgroup (images per workgroup = 32 * MT / HW^2).
-template <int HW, int MT, bool F16 = false>
+template <int HW, int MT, bool F16 = false, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void conv_img_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                        const float* __restrict__ bias, bf16* __restrict__ y,
                                                        const ImgGeom g) {
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void conv_img_kernel(const bf16* __restrict
     const __amdgpu_buffer_rsrc_t rx = i_rsrc(x + (size_t)img0 * img_elems, (unsigned)(nimg * img_elems * 2));
     const int total = IMGS * HD * HD * vpp;
     const int vshift = 31 - __builtin_clz(vpp);      // vpp = cin / 8 is a power of two for the layers taken (checked by the host)
-    constexpr int UL = 8;                             // loads in flight per thread: all requested before the first LDS write
+    constexpr int UL = 13;                            // loads in flight per thread: an 8x8 image at 256 channels is ONE trip (12.5 vectors per thread), at 512 two
     for (int base = tid; base < total; base += 256 * UL) {
       iu32x4 val[UL];
 #pragma unroll
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(256, 2) void conv_img_kernel(const bf16* __restrict
   const int q = wid;      // wave w finishes register quads q = w: channels 8w + 4 kgrp .. + 3 of the 32-block
   const f32x4 bq = __builtin_bit_cast(
       f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, (unsigned)((n0 + q * 8 + kgrp * 4) * 4), 0, 0));
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};      // STATS: this lane's pixels, channels 8q + 4 kgrp + j
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     if (m) __syncthreads();
@@ -161,6 +166,14 @@ __global__ __launch_bounds__(256, 2) void conv_img_kernel(const bf16* __restrict
       if (g.epilogue & TG_EPI_LRELU) v[j] = lrelu_f(v[j], g.alpha);
     }
     const unsigned p0 = pack16x2<F16>(v[0], v[1]), p1 = pack16x2<F16>(v[2], v[3]);
+    if constexpr (STATS) {      // of the values as stored
+      const float r4[4] = {unpack16_lo<F16>(p0), unpack16_hi<F16>(p0), unpack16_lo<F16>(p1), unpack16_hi<F16>(p1)};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ssum[j] += r4[j];
+        ssq[j] = fmaf(r4[j], r4[j], ssq[j]);
+      }
+    }
     // low lanes hold channels 8q..8q+3, high lanes 8q+4..8q+7 of the same pixel: give the low lane all 8
     auto s0 = __builtin_amdgcn_permlane32_swap(p0, p0, false, false);
     auto s1 = __builtin_amdgcn_permlane32_swap(p1, p1, false, false);
@@ -171,9 +184,30 @@ __global__ __launch_bounds__(256, 2) void conv_img_kernel(const bf16* __restrict
     const bool ok = kgrp == 0 && ch0 + 8 <= g.cout;      // pixels of images past the batch fall outside `ry`
     __builtin_amdgcn_raw_buffer_store_b128(o, ry, ok ? (unsigned)((p * g.cout + ch0) * 2) : IOOB, 0, TG_STORE_AUX);
   }
+  if constexpr (STATS) {
+    // the workgroup holds ONE whole image: a butterfly over the 32 pixel lanes of each half-wave (fixed order) leaves the
+    // image's sums of 4 channels in every lane; lane 0 of each half writes them
+    static_assert(IMGS == 1, "statistics epilogue: one image per workgroup");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        ssum[j] += __shfl_xor(ssum[j], o, 64);
+        ssq[j] += __shfl_xor(ssq[j], o, 64);
+      }
+    }
+    if (l31 == 0 && img0 < g.n) {
+      float* out = g.stats + (size_t)img0 * 2 * g.cout + n0 + q * 8 + kgrp * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        out[j] = ssum[j];
+        out[g.cout + j] = ssq[j];
+      }
+    }
+  }
 }
 
-template <int HW, int MT>
+template <int HW, int MT, bool STATS = false>
 int launch_img(const ImgGeom& g, const void* x, const void* wp, const float* bias, void* y, hipStream_t s) {
   constexpr int IMGS = 32 * MT / (HW * HW), HD = HW + 2;
   const size_t lds_img = (size_t)IMGS * HD * HD * (g.cin * 2 + 16);
@@ -181,10 +215,10 @@ int launch_img(const ImgGeom& g, const void* x, const void* wp, const float* bia
   TG_CHECK(lds <= 160 * 1024, TG_ENOSUP, "conv_img: LDS %zu too large", lds);
   const dim3 grid((g.n + IMGS - 1) / IMGS, g.cout / 32);
   const bool f16 = tg_elem_f16();
-  auto k0 = conv_img_kernel<HW, MT, false>;
-  auto k1 = conv_img_kernel<HW, MT, true>;
+  auto k0 = conv_img_kernel<HW, MT, false, STATS>;
+  auto k1 = conv_img_kernel<HW, MT, true, STATS>;
   if (lds > 64 * 1024) {
-    static unsigned long long raised = 0;      // per (HW, MT), one bit per device
+    static unsigned long long raised = 0;      // per (HW, MT, STATS), one bit per device
     if (tg_first_on_device(&raised)) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
           hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -193,7 +227,8 @@ int launch_img(const ImgGeom& g, const void* x, const void* wp, const float* bia
       }
     }
   }
-  tg_note_kernel(f16 ? "conv_img_kernel<%d,%d,f16>" : "conv_img_kernel<%d,%d>", HW, MT);
+  if (STATS) tg_note_kernel(f16 ? "conv_img_kernel<%d,%d,f16,stats>" : "conv_img_kernel<%d,%d,stats>", HW, MT);
+  else tg_note_kernel(f16 ? "conv_img_kernel<%d,%d,f16>" : "conv_img_kernel<%d,%d>", HW, MT);
   if (f16) hipLaunchKernelGGL(k1, grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, g);
   else hipLaunchKernelGGL(k0, grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, g);
   TG_LAUNCH_CHECK("conv_img");
@@ -218,9 +253,16 @@ bool tg_conv_img_supported(int n, int hin, int win, int cin, int hout, int wout,
   return true;
 }
 
+// the statistics epilogue exists for the 8x8 maps (one image per workgroup), plain epilogue; TG_TUNE_IMG_STATS=0: A/B
+bool tg_conv_img_stats_supported(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l) {
+  return hin == 8 && tg_tune("TG_TUNE_IMG_STATS", 1) != 0 &&
+         tg_conv_img_supported(n, hin, win, cin, hout, wout, cout, k, pad_t, pad_l);
+}
+
 int tg_conv_img_run(int n, int hw, int cin, int cout, int epilogue, float alpha, const void* x, const void* wp,
-                    const float* bias, void* y, hipStream_t s) {
+                    const float* bias, void* y, hipStream_t s, float* stats) {
   ImgGeom g;
+  g.stats = stats;
   g.n = n; g.cin = cin; g.cout = cout;
   g.cin_pad = (cin + 15) / 16 * 16;
   g.epilogue = epilogue;
@@ -230,6 +272,10 @@ int tg_conv_img_run(int n, int hw, int cin, int cout, int epilogue, float alpha,
   TG_CHECK(wb < 0x7fffffffull && (size_t)n * hw * hw * (cin > cout ? cin : cout) * 2 < 0x7fffffffull, TG_ENOSUP,
            "conv_img: tensor too large");
   g.w_bytes = (unsigned)wb;
+  if (stats) {
+    TG_CHECK(hw == 8 && epilogue == 0, TG_ENOSUP, "conv_img: the statistics epilogue takes 8x8 maps and the plain epilogue");
+    return launch_img<8, 2, true>(g, x, wp, bias, y, s);
+  }
   if (hw == 8) return launch_img<8, 2>(g, x, wp, bias, y, s);
   return launch_img<4, 2>(g, x, wp, bias, y, s);
 }

@@ -216,8 +216,46 @@ __global__ void in_stats_partial(const T* __restrict__ y, float* __restrict__ s1
 // the compiler issued two loads per trip and waited for them -- 8-32 dependent L2 round trips (~10 us) in front of a kernel
 // that streams for 10-30 us on the mid-size maps (the 64 x 64 ... 16 x 16 layers sat 1.5-1.8 x above their byte time,
 // profiles/r03_z_shapes_eager_step.json).  Eight rows in flight per trip, eight accumulators combined in a fixed order.
+// Thin layers (2c <= 128 columns, a power of two) with >= 16 rows: the 256 threads split into 256 / 2c ROW GROUPS -- thread
+// (group r, column) sums rows r, r + R, ... (eight in flight), the groups' results meet in LDS and are added in group
+// order -- so that 32 rows x 32 columns (256 x 256 x 16, n 32) are ONE round of loads instead of four, and the 256 rows a
+// 256 x 256 concat conv leaves per image four instead of 32.  Fixed order: bit-reproducible.
 __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int n, int chunks, int c, float* sh) {
   const int64_t row = 2 * (int64_t)c;
+  const int ncol = 2 * c;
+  if (ncol <= 128 && (ncol & (ncol - 1)) == 0 && chunks >= 16 && blockDim.x == 256) {      // block-uniform
+    __shared__ float grp[256];
+    const int R = 256 / ncol;
+    const int col = threadIdx.x & (ncol - 1), r = threadIdx.x / ncol;
+    const float* p = part + (int64_t)n * chunks * row + col;
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = 0.f;
+    int k = r;
+    for (; k + 7 * R < chunks; k += 8 * R) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(k + u * R) * row];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += v[u];
+    }
+    if (k < chunks) {      // the tail: clamped addresses, masked adds
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(k + u * R < chunks ? k + u * R : k) * row];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += (k + u * R < chunks) ? v[u] : 0.f;
+    }
+    grp[threadIdx.x] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if ((int)threadIdx.x < ncol) {
+      float t = 0.f;
+      for (int q = 0; q < R; ++q) t += grp[q * ncol + threadIdx.x];
+      sh[threadIdx.x] = t;
+    }
+    __syncthreads();
+    return;
+  }
   for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) {
     const float* p = part + (int64_t)n * chunks * row + i;
     float a[8];
@@ -322,30 +360,45 @@ __global__ void norm_act_fwd_part_kernel(const T* __restrict__ y, const float* _
   const int lanes = blockDim.x / cv;
   const int v = threadIdx.x % cv, pl = threadIdx.x / cv;
   const int n = blockIdx.y;
-  reduce_partials(part, n, chunks, c, sh);
   const float* ga = n < split ? gamma : gamma2;
   const float* be = n < split ? beta : beta2;
+  // this thread's gamma / beta values are requested BEFORE the partial sums: behind the prologue's barriers they were a
+  // second dependent round trip of every workgroup (the loads do not depend on the statistics)
+  float ga_[8], be_[8], k_[8];      // c <= 2048: at most 8 channels per thread; k: the shift of the shifted sums
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int i = threadIdx.x + q * blockDim.x;
+    ga_[q] = i < c ? ga[i] : 0.f;
+    be_[q] = i < c ? be[i] : 0.f;
+    k_[q] = (i < c && !(flags & NF_ZEROSHIFT)) ? ld(y + (int64_t)n * hw * c + i) : 0.f;
+  }
+  reduce_partials(part, n, chunks, c, sh);
   const float inv = 1.f / (float)hw;
-  float m_[8], r_[8];      // c <= 2048: at most 8 channels per thread
-  int cnt = 0;
-  for (int i = threadIdx.x; i < c; i += blockDim.x, ++cnt) {
-    const float k = (flags & NF_ZEROSHIFT) ? 0.f : ld(y + (int64_t)n * hw * c + i);
-    const float m1 = sh[i] * inv, m2 = sh[c + i] * inv;
-    float var = m2 - m1 * m1;
-    var = var < 0.f ? 0.f : var;
-    m_[cnt] = k + m1;
-    r_[cnt] = rsqrtf(var + in_eps);
+  float m_[8], r_[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {      // compile-time indices: the per-thread rows stay in registers
+    const int i = threadIdx.x + q * blockDim.x;
+    if (i < c) {
+      const float m1 = sh[i] * inv, m2 = sh[c + i] * inv;
+      float var = m2 - m1 * m1;
+      var = var < 0.f ? 0.f : var;
+      m_[q] = k_[q] + m1;
+      r_[q] = rsqrtf(var + in_eps);
+    }
   }
   __syncthreads();
-  cnt = 0;
-  for (int i = threadIdx.x; i < c; i += blockDim.x, ++cnt) {
-    if (blockIdx.x == 0) {
-      mean[n * c + i] = m_[cnt];
-      rstd[n * c + i] = r_[cnt];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int i = threadIdx.x + q * blockDim.x;
+    if (i < c) {
+      if (blockIdx.x == 0) {
+        mean[n * c + i] = m_[q];
+        rstd[n * c + i] = r_[q];
+      }
+      const float r = r_[q] * ga_[q];
+      sh[i] = r;                                  // u = y * scale + shift (tf.nn.batch_normalization form)
+      sh[c + i] = be_[q] - m_[q] * r;
     }
-    const float r = r_[cnt] * ga[i];
-    sh[i] = r;                                  // u = y * scale + shift (tf.nn.batch_normalization form)
-    sh[c + i] = be[i] - m_[cnt] * r;
   }
   __syncthreads();
   float sc[V], sf[V];
@@ -554,6 +607,16 @@ __global__ void norm_act_bwd2_part_kernel(const T* __restrict__ gz, const T* __r
   const int lanes = blockDim.x / cv;
   const int v = threadIdx.x % cv, pl = threadIdx.x / cv;
   const int n = blockIdx.y;
+  // the per-channel constants do not depend on the partial sums: requested before them (one dependent round trip less)
+  float mu[V], rs[V], ga[V], be[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int ch = v * V + j;
+    mu[j] = mean[n * c + ch];
+    rs[j] = rstd[n * c + ch];
+    ga[j] = pstride ? gamma[(int64_t)n * pstride + ch] : (n < split ? gamma : gamma2)[ch];
+    be[j] = pstride ? beta[(int64_t)n * pstride + ch] : (n < split ? beta : beta2)[ch];
+  }
   reduce_partials(part, n, chunks, c, sh);
   if (pstride && blockIdx.x == 0) {      // one parameter row per image: its gradient row is this image's sums
     for (int i = threadIdx.x; i < c; i += blockDim.x) {
@@ -593,14 +656,10 @@ __global__ void norm_act_bwd2_part_kernel(const T* __restrict__ gz, const T* __r
     }
   }
   const float inv = 1.f / (float)hw;
-  float mu[V], rs[V], ga[V], be[V], s1[V], s2[V];
+  float s1[V], s2[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) {
     const int ch = v * V + j;
-    mu[j] = mean[n * c + ch];
-    rs[j] = rstd[n * c + ch];
-    ga[j] = pstride ? gamma[(int64_t)n * pstride + ch] : (n < split ? gamma : gamma2)[ch];
-    be[j] = pstride ? beta[(int64_t)n * pstride + ch] : (n < split ? beta : beta2)[ch];
     s1[j] = (flags & NF_NOSTATS) ? 0.f : sh[ch] * inv;
     s2[j] = (flags & NF_NOSTATS) ? 0.f : sh[c + ch] * inv;
   }

@@ -7,20 +7,37 @@ namespace {
 // The n (<= 16) samples of V consecutive positions, all requested before any is used: a runtime-length load/use
 // loop is one L2 round trip per sample (3 such loops made these single-workgroup kernels 20-90 us).
 constexpr int MB_NMAX = 16;
-template <typename T>
-__device__ __forceinline__ void mb_load_samples(const T* __restrict__ x, int n, int P, int p, Vec16<T> (&xv)[MB_NMAX]) {
+// A thread's POSITION vector is 8 bytes (4 positions of a 16-bit type, 2 of fp32), not 16: the [16, 4, 4, 256] tensor then
+// spreads over 1024 threads instead of 512 -- these kernels' time is the per-thread chain (16 samples x V conversions,
+// sums, a division or two per position), not bytes; with 16-byte vectors half of the forward's 1024 threads idled and the
+// backward kernels needed 226-256 VGPRs.
+template <typename T, int V>
+struct alignas(sizeof(T) * V) MbVec {
+  T e[V];
+  __device__ __forceinline__ float get(int i) const { return (float)e[i]; }
+  __device__ __forceinline__ void set(int i, float x) { e[i] = (T)x; }
+};
+template <typename T> constexpr int mb_v() { return 8 / (int)sizeof(T); }
+template <typename T, int V> __device__ __forceinline__ MbVec<T, V> mb_ld(const T* p) {
+  return *reinterpret_cast<const MbVec<T, V>*>(p);
+}
+template <typename T, int V> __device__ __forceinline__ void mb_st(T* p, const MbVec<T, V>& v) {
+  *reinterpret_cast<MbVec<T, V>*>(p) = v;
+}
+template <typename T, int V>
+__device__ __forceinline__ void mb_load_samples(const T* __restrict__ x, int n, int P, int p, MbVec<T, V> (&xv)[MB_NMAX]) {
 #pragma unroll
-  for (int i = 0; i < MB_NMAX; ++i) xv[i] = ldv(x + (int64_t)(i < n ? i : n - 1) * P + p);
+  for (int i = 0; i < MB_NMAX; ++i) xv[i] = mb_ld<T, V>(x + (int64_t)(i < n ? i : n - 1) * P + p);
 }
 
 
 // out[px][0..c) = src[px][0..c), out[px][c] = val, out[px][c+1..cpad) = 0 over nvec 16-byte vectors of the padded tensor,
-// four vectors per thread in flight (a load -> store loop of one vector per trip is one L2 round trip per trip)
-template <typename T>
+// U vectors per thread in flight (a load -> store loop of one vector per trip is one L2 round trip per trip; U = 9 with
+// 1024 threads takes the [16, 4, 4, 264] tensor in ONE trip)
+template <typename T, int U = 4>
 __device__ __forceinline__ void mb_copy_with_stat(const T* __restrict__ src, T* __restrict__ out, int64_t nvec, int c,
                                                   int cpad, float val) {
   constexpr int V = Vec16<T>::N;
-  constexpr int U = 4;
   const int cvp = cpad / V;
   for (int64_t i0 = threadIdx.x; i0 < nvec; i0 += (int64_t)blockDim.x * U) {
     Vec16<T> o[U];
@@ -62,16 +79,16 @@ __global__ __launch_bounds__(1024) void mbstd_fwd_kernel(const T* __restrict__ x
   out += (int64_t)blockIdx.x * n * hw * cpad;
   if (stat) stat += blockIdx.x;
   float acc = 0.f;
-  constexpr int V = Vec16<T>::N;
+  constexpr int V = mb_v<T>();
   if (P % V == 0 && n <= 32) {
-    // 16-byte loads: a thread owns V consecutive positions and keeps the n samples' vectors in flight together
+    // a thread owns V consecutive positions and keeps the n samples' vectors in flight together
     for (int p = threadIdx.x * V; p < P; p += blockDim.x * V) {
       float mu[V], var[V];
 #pragma unroll
       for (int j = 0; j < V; ++j) mu[j] = var[j] = 0.f;
       if (n <= MB_NMAX) {
-        Vec16<T> xs[MB_NMAX];
-        mb_load_samples<T>(x, n, P, p, xs);
+        MbVec<T, V> xs[MB_NMAX];
+        mb_load_samples<T, V>(x, n, P, p, xs);
 #pragma unroll
         for (int i = 0; i < MB_NMAX; ++i)
           if (i < n) {
@@ -91,14 +108,14 @@ __global__ __launch_bounds__(1024) void mbstd_fwd_kernel(const T* __restrict__ x
           }
       } else {
         for (int i = 0; i < n; ++i) {
-          const Vec16<T> xv = ldv(x + (int64_t)i * P + p);
+          const MbVec<T, V> xv = mb_ld<T, V>(x + (int64_t)i * P + p);
 #pragma unroll
           for (int j = 0; j < V; ++j) mu[j] += xv.get(j);
         }
 #pragma unroll
         for (int j = 0; j < V; ++j) mu[j] /= (float)n;
         for (int i = 0; i < n; ++i) {
-          const Vec16<T> xv = ldv(x + (int64_t)i * P + p);
+          const MbVec<T, V> xv = mb_ld<T, V>(x + (int64_t)i * P + p);
 #pragma unroll
           for (int j = 0; j < V; ++j) {
             const float d = xv.get(j) - mu[j];
@@ -125,8 +142,9 @@ __global__ __launch_bounds__(1024) void mbstd_fwd_kernel(const T* __restrict__ x
   const float val = block_sum(acc, red) / (float)P;
   if (threadIdx.x == 0 && stat) stat[0] = val;
   const int64_t total = (int64_t)n * hw * cpad;
-  if (c % V == 0 && cpad % V == 0) {
-    mb_copy_with_stat<T>(x, out, total / V, c, cpad, val);
+  constexpr int V16 = Vec16<T>::N;
+  if (c % V16 == 0 && cpad % V16 == 0) {
+    mb_copy_with_stat<T, 9>(x, out, total / V16, c, cpad, val);
   } else {
     for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
       const int ch = (int)(i % cpad);
@@ -142,10 +160,10 @@ __global__ __launch_bounds__(1024) void mbstd_fwd_kernel(const T* __restrict__ x
 }
 
 // gx[n][p] = gout[n][hw][ch<c] + G * (x - mu_p) / (N * sigma_p * P),  G = sum over (n,hw) of gout[..., c]
-// 256-thread workgroups, gridDim.y of them per statistic group, one 16-byte position vector per thread and trip (two
-// workgroups cover the [16, 4, 4, 256] bf16 tensor; each sums G for itself): the 2 x 16 sample vectors a thread keeps in
-// flight need more than the 128 VGPRs launch_bounds(1024) left it -- the single 1024-thread workgroup spilled 168-392
-// bytes per thread to scratch and took 24-52 us for 400 KB of traffic (profiles/r03_z_shapes_eager_step.json).
+// 256-thread workgroups, gridDim.y of them per statistic group, one 8-byte position vector per thread and trip (four
+// workgroups cover the [16, 4, 4, 256] bf16 tensor; each sums G for itself).  History: the single 1024-thread workgroup
+// with 16-byte vectors spilled 168-392 bytes per thread to scratch and took 24-52 us for 400 KB of traffic
+// (profiles/r03_z_shapes_eager_step.json); two 256-thread workgroups with 16-byte vectors 256 VGPRs and 15 us.
 // The first trip's loads are requested BEFORE the reduction of G, whose barrier they do not depend on.
 template <typename T>
 __global__ __launch_bounds__(256) void mbstd_bwd_kernel(const T* __restrict__ gout, const T* __restrict__ x,
@@ -155,17 +173,17 @@ __global__ __launch_bounds__(256) void mbstd_bwd_kernel(const T* __restrict__ go
   gout += (int64_t)blockIdx.x * n * hw * cpad;
   x += (int64_t)blockIdx.x * n * P;
   gx += (int64_t)blockIdx.x * n * P;
-  constexpr int V = Vec16<T>::N;
+  constexpr int V = mb_v<T>();
   const bool fast = c % V == 0 && cpad % V == 0 && n <= MB_NMAX;
-  Vec16<T> xs[MB_NMAX], gs[MB_NMAX];
+  MbVec<T, V> xs[MB_NMAX], gs[MB_NMAX];
   const int pstep = gridDim.y * blockDim.x * V;
   const int pfirst = (blockIdx.y * blockDim.x + threadIdx.x) * V;
   if (fast) {      // dead threads (pfirst >= P) read position 0: harmless, never used
     const int p = pfirst < P ? pfirst : 0;
     const int px = p / c, ch = p - px * c;
-    mb_load_samples<T>(x, n, P, p, xs);
+    mb_load_samples<T, V>(x, n, P, p, xs);
 #pragma unroll
-    for (int i = 0; i < MB_NMAX; ++i) gs[i] = ldv(gout + ((int64_t)(i < n ? i : n - 1) * hw + px) * cpad + ch);
+    for (int i = 0; i < MB_NMAX; ++i) gs[i] = mb_ld<T, V>(gout + ((int64_t)(i < n ? i : n - 1) * hw + px) * cpad + ch);
   }
   float acc = 0.f;
   for (int i = threadIdx.x; i < n * hw; i += blockDim.x) acc += ld(gout + (int64_t)i * cpad + c);
@@ -175,9 +193,9 @@ __global__ __launch_bounds__(256) void mbstd_bwd_kernel(const T* __restrict__ go
       float mu[V], var[V], k[V];
       if (p != pfirst) {
         const int px = p / c, ch = p - px * c;
-        mb_load_samples<T>(x, n, P, p, xs);
+        mb_load_samples<T, V>(x, n, P, p, xs);
 #pragma unroll
-        for (int i = 0; i < MB_NMAX; ++i) gs[i] = ldv(gout + ((int64_t)(i < n ? i : n - 1) * hw + px) * cpad + ch);
+        for (int i = 0; i < MB_NMAX; ++i) gs[i] = mb_ld<T, V>(gout + ((int64_t)(i < n ? i : n - 1) * hw + px) * cpad + ch);
       }
 #pragma unroll
       for (int j = 0; j < V; ++j) mu[j] = var[j] = 0.f;
@@ -203,10 +221,10 @@ __global__ __launch_bounds__(256) void mbstd_bwd_kernel(const T* __restrict__ go
 #pragma unroll
       for (int i = 0; i < MB_NMAX; ++i)
         if (i < n) {
-          Vec16<T> o;
+          MbVec<T, V> o;
 #pragma unroll
           for (int j = 0; j < V; ++j) o.set(j, gs[i].get(j) + k[j] * (xs[i].get(j) - mu[j]));
-          stv(gx + (int64_t)i * P + p, o);
+          mb_st<T, V>(gx + (int64_t)i * P + p, o);
         }
     }
     return;
@@ -217,14 +235,14 @@ __global__ __launch_bounds__(256) void mbstd_bwd_kernel(const T* __restrict__ go
 #pragma unroll
       for (int j = 0; j < V; ++j) mu[j] = var[j] = 0.f;
       for (int i = 0; i < n; ++i) {
-        const Vec16<T> xv = ldv(x + (int64_t)i * P + p);
+        const MbVec<T, V> xv = mb_ld<T, V>(x + (int64_t)i * P + p);
 #pragma unroll
         for (int j = 0; j < V; ++j) mu[j] += xv.get(j);
       }
 #pragma unroll
       for (int j = 0; j < V; ++j) mu[j] /= (float)n;
       for (int i = 0; i < n; ++i) {
-        const Vec16<T> xv = ldv(x + (int64_t)i * P + p);
+        const MbVec<T, V> xv = mb_ld<T, V>(x + (int64_t)i * P + p);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
           const float d = xv.get(j) - mu[j];
@@ -235,12 +253,12 @@ __global__ __launch_bounds__(256) void mbstd_bwd_kernel(const T* __restrict__ go
       for (int j = 0; j < V; ++j) k[j] = G / ((float)n * sqrtf(var[j] / (float)n + eps) * (float)P);
       const int px = p / c, ch = p - px * c;
       for (int i = 0; i < n; ++i) {
-        const Vec16<T> xv = ldv(x + (int64_t)i * P + p);
-        const Vec16<T> gv = ldv(gout + ((int64_t)i * hw + px) * cpad + ch);
-        Vec16<T> o;
+        const MbVec<T, V> xv = mb_ld<T, V>(x + (int64_t)i * P + p);
+        const MbVec<T, V> gv = mb_ld<T, V>(gout + ((int64_t)i * hw + px) * cpad + ch);
+        MbVec<T, V> o;
 #pragma unroll
         for (int j = 0; j < V; ++j) o.set(j, gv.get(j) + k[j] * (xv.get(j) - mu[j]));
-        stv(gx + (int64_t)i * P + p, o);
+        mb_st<T, V>(gx + (int64_t)i * P + p, o);
       }
     }
     return;
@@ -267,8 +285,11 @@ __global__ __launch_bounds__(256) void mbstd_bwd_kernel(const T* __restrict__ go
 // Double backward.  With c_n = x_n - mu, sigma = sqrt(mean c^2 + eps), gx_n = gpass_n + G c_n /(N sigma P):
 //   d/dG      : T = sum_{n,p} v_np c_np / (N sigma_p P)  -> ggout[..., c] = T for every (n,hw); ggout[..., <c] = v
 //   d/dx_mp   : (G/(N P)) * [ (v_m - mean_n v)/sigma - (sum_n v_n c_n) c_m / (N sigma^3) ]
-template <typename T>      // 512 threads, first trip's loads ahead of the reduction of G: see mbstd_bwd_kernel
-__global__ __launch_bounds__(512) void mbstd_bwd_bwd_kernel(const T* __restrict__ v, const T* __restrict__ gout,
+// 1024 threads, 8-byte position vectors (one trip at [16, 4, 4, 256]), first trip's loads ahead of the reduction of G (see
+// mbstd_bwd_kernel); the per-element divisions by sigma / sigma^3 are multiplications by per-POSITION reciprocals (two
+// fp32 divisions per element were most of this kernel's instructions: 35 us for 400 KB)
+template <typename T, int NTHR>      // NTHR: 1024 for the 16-bit types, 512 for fp32 (its 128-VGPR budget at 1024 spilled)
+__global__ __launch_bounds__(NTHR) void mbstd_bwd_bwd_kernel(const T* __restrict__ v, const T* __restrict__ gout,
                                                             const T* __restrict__ x, T* __restrict__ ggout,
                                                             T* __restrict__ gx2, int n, int hw, int c, int cpad,
                                                             float eps) {
@@ -279,13 +300,13 @@ __global__ __launch_bounds__(512) void mbstd_bwd_bwd_kernel(const T* __restrict_
   x += (int64_t)blockIdx.x * n * P;
   if (ggout) ggout += (int64_t)blockIdx.x * n * hw * cpad;
   if (gx2) gx2 += (int64_t)blockIdx.x * n * P;
-  constexpr int V = Vec16<T>::N;
+  constexpr int V = mb_v<T>();
   const bool fast = P % V == 0 && n <= MB_NMAX;
-  Vec16<T> xs[MB_NMAX], vs[MB_NMAX];
+  MbVec<T, V> xs[MB_NMAX], vs[MB_NMAX];
   const int pfirst = threadIdx.x * V;
   if (fast) {      // dead threads (pfirst >= P) read position 0: harmless, never used
-    mb_load_samples<T>(x, n, P, pfirst < P ? pfirst : 0, xs);
-    mb_load_samples<T>(v, n, P, pfirst < P ? pfirst : 0, vs);
+    mb_load_samples<T, V>(x, n, P, pfirst < P ? pfirst : 0, xs);
+    mb_load_samples<T, V>(v, n, P, pfirst < P ? pfirst : 0, vs);
   }
   float acc = 0.f;
   for (int i = threadIdx.x; i < n * hw; i += blockDim.x) acc += ld(gout + (int64_t)i * cpad + c);
@@ -294,8 +315,8 @@ __global__ __launch_bounds__(512) void mbstd_bwd_bwd_kernel(const T* __restrict_
   if (fast) {
     for (int p = pfirst; p < P; p += blockDim.x * V) {
       if (p != pfirst) {
-        mb_load_samples<T>(x, n, P, p, xs);
-        mb_load_samples<T>(v, n, P, p, vs);
+        mb_load_samples<T, V>(x, n, P, p, xs);
+        mb_load_samples<T, V>(v, n, P, p, vs);
       }
       float mu[V], vm[V], var[V], vc[V], sigma[V];
 #pragma unroll
@@ -331,16 +352,22 @@ __global__ __launch_bounds__(512) void mbstd_bwd_bwd_kernel(const T* __restrict_
       }
       if (gx2) {
         const float k = G / ((float)n * (float)P);
+        float is[V], cf[V];      // 1 / sigma,  sum_n(v c) / (N sigma^3)
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          is[j] = 1.f / sigma[j];
+          cf[j] = vc[j] * is[j] * is[j] * is[j] / (float)n;
+        }
 #pragma unroll
         for (int i = 0; i < MB_NMAX; ++i)
           if (i < n) {
-            Vec16<T> o;
+            MbVec<T, V> o;
 #pragma unroll
             for (int j = 0; j < V; ++j) {
               const float d = xs[i].get(j) - mu[j];
-              o.set(j, k * ((vs[i].get(j) - vm[j]) / sigma[j] - vc[j] * d / ((float)n * sigma[j] * sigma[j] * sigma[j])));
+              o.set(j, k * ((vs[i].get(j) - vm[j]) * is[j] - cf[j] * d));
             }
-            stv(gx2 + (int64_t)i * P + p, o);
+            mb_st<T, V>(gx2 + (int64_t)i * P + p, o);
           }
       }
     }
@@ -373,8 +400,9 @@ __global__ __launch_bounds__(512) void mbstd_bwd_bwd_kernel(const T* __restrict_
   const float Tt = block_sum(tacc, red);
   if (ggout) {
     const int64_t total = (int64_t)n * hw * cpad;
-    if (c % V == 0 && cpad % V == 0) {
-      mb_copy_with_stat<T>(v, ggout, total / V, c, cpad, Tt);
+    constexpr int V16 = Vec16<T>::N;
+    if (c % V16 == 0 && cpad % V16 == 0) {
+      mb_copy_with_stat<T, 9>(v, ggout, total / V16, c, cpad, Tt);
     } else {
       for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
         const int ch = (int)(i % cpad);
@@ -659,7 +687,7 @@ int tg_mbstd_bwd(const void* gout, const void* x, void* gx, int n, int groups, i
   TG_CHECK(gout && x && gx && n > 0 && hw > 0 && c > 0 && cpad > c, TG_EINVAL, "tg_mbstd_bwd: bad arguments");
   TG_CHECK(groups > 0 && n % groups == 0, TG_EINVAL, "tg_mbstd_bwd: n (%d) not divisible by groups (%d)", n, groups);
   TG_DISPATCH_DTYPE(dtype, "tg_mbstd_bwd", {
-    int nsplit = (hw * c / Vec16<T>::N + 255) / 256;
+    int nsplit = (hw * c / mb_v<T>() + 255) / 256;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > 8) nsplit = 8;
     hipLaunchKernelGGL(mbstd_bwd_kernel<T>, dim3(groups, nsplit), dim3(256), 0, (hipStream_t)stream, (const T*)gout, (const T*)x,
@@ -674,7 +702,8 @@ int tg_mbstd_bwd_bwd(const void* v, const void* gout, const void* x, void* ggout
   TG_CHECK(v && gout && x && n > 0 && hw > 0 && c > 0 && cpad > c, TG_EINVAL, "tg_mbstd_bwd_bwd: bad arguments");
   TG_CHECK(groups > 0 && n % groups == 0, TG_EINVAL, "tg_mbstd_bwd_bwd: n (%d) not divisible by groups (%d)", n, groups);
   TG_DISPATCH_DTYPE(dtype, "tg_mbstd_bwd_bwd", {
-    hipLaunchKernelGGL(mbstd_bwd_bwd_kernel<T>, dim3(groups), dim3(512), 0, (hipStream_t)stream, (const T*)v,
+    constexpr int NTHR = sizeof(T) == 4 ? 512 : 1024;
+    hipLaunchKernelGGL((mbstd_bwd_bwd_kernel<T, NTHR>), dim3(groups), dim3(NTHR), 0, (hipStream_t)stream, (const T*)v,
                        (const T*)gout, (const T*)x, (T*)ggout, (T*)gx2, n / groups, hw, c, cpad, eps);
   });
   TG_LAUNCH_CHECK("tg_mbstd_bwd_bwd");
