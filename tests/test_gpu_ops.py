@@ -770,7 +770,7 @@ def test_upcat_conv_matches_materialised_path(ops, n, h, c0, c1, cout, gsz, perm
 
 UPBWD_CASES = [
     # n, hw, c0, c1, cout, gsz, perm                      kernel the shape dispatches
-    (4, 256, 32, 32, 16, 1, (1, 0, 0, 1)),              # conv_tile_wres_kernel<3,16,32,1,upbwd>
+    (4, 256, 32, 32, 16, 1, (1, 0, 0, 1)),              # conv_tile_wres_kernel<3,16,64,1,upboth>: a 32 + 32 concat in one block
     (8, 128, 64, 64, 32, 2, (1, 0, 0, 1)),              # conv_tile_wres_kernel<3,32,64,1,upbwd>
     (8, 128, 32, 32, 32, 2, (0, 1, 1, 0)),              # conv_tile_wres_kernel<3,32,32,1,upbwd>
     (8, 128, 64, 64, 16, 0, ()),                        # conv_tile_wres_kernel<3,16,64,1,upbwd>, no groups
@@ -781,11 +781,17 @@ UPBWD_CASES = [
     (2, 16, 32, 32, 32, 1, (1, 1)),                     # conv_tile_kernel<3,32,32,1,upbwd>, skip group 0 unread (zeros)
     (2, 32, 32, 32, 16, 0, ()),                         # conv_tile_kernel<3,16,32,1,upbwd>
     (3, 48, 32, 64, 40, 0, ()),                         # ragged: 48 x 48 map, cout 40 (cin_pad 48), c1 = 64
+    (4, 256, 32, 64, 16, 1, (1, 0, 0, 1)),              # conv_tile_wres_kernel<3,16,32,1,upbwd> (c1 = 64: two-block form)
+    (4, 256, 32, 32, 16, 1, (0, 0, 0, 1)),              # upboth: three sources / one source
+    (4, 256, 32, 32, 16, 1, (1, 1, 1, 1)),              # upboth: skip image 0 unread (zeros), image 1 read four times
+    (6, 256, 32, 32, 16, 0, ()),                        # upboth without groups
 ]
-UPBWD_KERNELS = ['conv_tile_wres_kernel<3,16,32,1,upbwd>', 'conv_tile_wres_kernel<3,32,64,1,upbwd>', 'conv_tile_wres_kernel<3,32,32,1,upbwd>',
+UPBWD_KERNELS = ['conv_tile_wres_kernel<3,16,64,1,upboth>', 'conv_tile_wres_kernel<3,32,64,1,upbwd>', 'conv_tile_wres_kernel<3,32,32,1,upbwd>',
                  'conv_tile_wres_kernel<3,16,64,1,upbwd>', 'conv_tile_kernel<3,16,64,1,upbwd>', 'conv_tile_kernel<3,32,64,2,upbwd>',
                  'conv_tile_kernel<3,32,64,1,upbwd>', 'conv_tile_kernel<3,32,32,2,upbwd>', 'conv_tile_kernel<3,32,32,1,upbwd>',
-                 'conv_tile_kernel<3,16,32,1,upbwd>', None]
+                 'conv_tile_kernel<3,16,32,1,upbwd>', None, 'conv_tile_wres_kernel<3,16,32,1,upbwd>',
+                 'conv_tile_wres_kernel<3,16,64,1,upboth>', 'conv_tile_wres_kernel<3,16,64,1,upboth>',
+                 'conv_tile_wres_kernel<3,16,64,1,upboth>']
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
@@ -812,7 +818,7 @@ def test_upcat_backward_data_epilogue(ops, dtype, case):
   sym = _lib.load().tg_last_kernel().decode()
   want = UPBWD_KERNELS[case]
   if want is not None:
-    assert sym == (want if dtype == torch.bfloat16 else want.replace('upbwd', 'upbwd,f16')), sym
+    assert sym == (want if dtype == torch.bfloat16 else want.replace('upbwd', 'upbwd,f16').replace('upboth', 'upboth,f16')), sym
   assert bool(torch.isfinite(g0.float()).all()) and bool(torch.isfinite(g1.float()).all())
   # composed path on the device: same values up to the extra rounding of the concat-layout tensor
   gcat = O.conv_bwd_data_raw(gyd, wd, (n, hw, hw, c0 + c1), spec)

@@ -554,7 +554,12 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
                                                              const float* __restrict__ bias, bf16* __restrict__ y,
                                                              const TileGeom g) {
   constexpr bool HAS_BIAS = (EPI & 1) != 0, HAS_MASK = (EPI & 2) != 0;
-  constexpr bool STATS = MODE == 1, POOL = MODE == 2, UPBWD = MODE == 3;      // UPBWD: see TileGeom::up_out
+  // UPBWD: see TileGeom::up_out.  MODE 4 (UPBOTH) is UPBWD with ONE 64-channel block that holds both halves of a 32 + 32
+  // concat: channel block 0 = "up" (flushed per source image), block 1 = "skip" (summed over the sources of a skip image)
+  // -- the workgroup walks (skip image, source) pairs, so every gy tile is staged ONCE (the two-block form reads gy twice
+  // and runs twice the tile iterations, which is what these thin kernels are bound by)
+  constexpr bool STATS = MODE == 1, POOL = MODE == 2, UPBOTH = MODE == 4, UPBWD = MODE == 3 || UPBOTH;
+  static_assert(!UPBOTH || BN == 64, "UPBOTH: one up block + one skip block");
   constexpr int KW = KH, NT = KH * KW;
   constexpr int TW = 16, TH = 8;
   constexpr int HWX = TW + KW - 1, HH = TH + KH - 1;
@@ -577,7 +582,7 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
   const int wrow = NT * g.cin_pad;
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(wp + (size_t)n0 * wrow, (unsigned)((size_t)BN * wrow * 2));
   // UPBWD: "skip" blocks (output channels >= c0) walk the tiles of the n1 SKIP images, each over its source images
-  const bool skip_blk = UPBWD && n0 >= g.c0;
+  const bool skip_blk = UPBOTH || (UPBWD && n0 >= g.c0);      // UPBOTH: the walk of a skip block
   if constexpr (UPBWD) {
     int wg0 = blockIdx.x;
     if ((gridDim.x & 7) == 0) wg0 = (wg0 & 7) * (gridDim.x >> 3) + (wg0 >> 3);
@@ -736,6 +741,9 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
       for (int i = 0; i < NTILE; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    } else if (UPBOTH) {      // the up block restarts with every source image
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[0][j] = 0.f;
     }
 #pragma unroll
     for (int ky = 0; ky < KH; ++ky) {
@@ -753,7 +761,49 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
       }
     }
     // ---- epilogue of tile t
-    if constexpr (UPBWD) {      // as in conv_tile_kernel
+    if constexpr (UPBOTH) {
+      // block 0 -> the 2x2 sums of THIS source image's up gradient; block 1 -> the skip gradient after the last source
+      unsigned pk;
+      const int ns_here = upbwd_sources(g, img, &pk);
+      const int simg = upbwd_source_image(g, img, pk, src);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const bool up = nt == 0;
+        if (!up && src + 1 < n_src) continue;
+        const int cs = up ? g.c0 : g.cout - g.c0;
+        const size_t oimg = up ? (size_t)(g.h / 2) * (g.w / 2) * cs : (size_t)g.h * g.w * cs;
+        bf16* const optr = up ? g.up_out : g.skip_out;
+        const bool wanted = optr != nullptr && !(up && ns_here == 0);      // an unread skip image has no source image
+        const __amdgpu_buffer_rsrc_t ro =
+            make_rsrc(wanted ? optr + (size_t)(up ? simg : img) * oimg : (bf16*)x, wanted ? (unsigned)(oimg * 2) : 0u);
+        unsigned p[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = up ? sum_quad(acc[nt][q * 4 + j]) : acc[nt][q * 4 + j];
+          p[q][0] = pack16x2<F16>(v[0], v[1]);
+          p[q][1] = pack16x2<F16>(v[2], v[3]);
+        }
+        u32x4 o0, o1;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          auto r02 = __builtin_amdgcn_permlane32_swap(p[0][d], p[2][d], false, false);
+          auto r13 = __builtin_amdgcn_permlane32_swap(p[1][d], p[3][d], false, false);
+          o0[d] = r02[0];
+          o0[2 + d] = r02[1];
+          o1[d] = r13[0];
+          o1[2 + d] = r13[1];
+        }
+        const int ch0 = kgrp * 16;
+        const bool owner = !up || (l31 & 17) == 0;
+        const unsigned off = up ? (unsigned)((((oy >> 1) * (g.w >> 1) + (ox >> 1)) * cs + ch0) * 2)
+                                : (unsigned)(((oy * g.w + ox) * cs + ch0) * 2);
+        __builtin_amdgcn_raw_buffer_store_b128(o0, ro, (owner && ch0 + 8 <= cs) ? off : OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o1, ro, (owner && ch0 + 16 <= cs) ? off + 16 : OOB, 0, 0);
+      }
+      return;
+    } else if constexpr (UPBWD) {      // as in conv_tile_kernel
       if (src + 1 < n_src) return;
       const int cs = skip_blk ? g.cout - g.c0 : g.c0;
       const int chb = skip_blk ? n0 - g.c0 : n0;
@@ -913,6 +963,9 @@ int launch_tile_wres(const TileGeom& g0, const bf16* x, const bf16* wp, const fl
   g.tiles_x = g.w / 16;
   g.tiles_y = g.h / 8;
   g.nblk = g.tiles_x * g.tiles_y * g.n;
+  // UPBOTH (kernel MODE 4): a 32 + 32 concat in ONE 64-channel block that walks the tiles of the n1 skip images
+  const bool upboth = BN == 64 && KH == 3 && (g.up_out || g.skip_out) && g.c0 == 32 && g.cout == 64 && g.n1 > 0;
+  if (upboth) g.nblk = g.tiles_x * g.tiles_y * g.n1;
   const int ny = (g.cout + BN - 1) / BN;
   int tpw = g.nblk * ny / (256 * 4);          // aim for ~4 workgroups per CU over the whole grid
   if (tpw < 1) tpw = 1;
@@ -951,9 +1004,17 @@ int launch_tile_wres(const TileGeom& g0, const bf16* x, const bf16* wp, const fl
     else if (g.epilogue & TG_EPI_BIAS) TG_WRES_LAUNCH_E(MODE_, 1); \
     else TG_WRES_LAUNCH_E(MODE_, 0);                              \
   } while (0)
-  if (g.up_out) {
+  if (g.up_out || g.skip_out) {
     if constexpr (KH == 3) {
       TG_CHECK(g.epilogue == 0 && !g.mask && !g.ypool && !stats, TG_ENOSUP, "conv_tile(wres): the concat backward comes with the plain epilogue only");
+      if constexpr (BN == 64) {
+        if (upboth) {
+          tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d,upboth%s>", KH, KC, BN, NCH, fmt);
+          TG_WRES_LAUNCH_E(4, 0);
+          TG_LAUNCH_CHECK("conv_tile_wres");
+          return TG_OK;
+        }
+      }
       tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d,upbwd%s>", KH, KC, BN, NCH, fmt);
       TG_WRES_LAUNCH_E(3, 0);
     } else {
@@ -1022,7 +1083,7 @@ int launch_tile(const TileGeom& g0, const bf16* x, const bf16* wp, const float* 
     *g.chunks_query = (KH == 3) ? g.tiles_x * g.tiles_y : 0;
     return TG_OK;
   }
-  if (g.up_out) {
+  if (g.up_out || g.skip_out) {
     if constexpr (KH == 3 && !UPCAT) {
       TG_CHECK(g.epilogue == 0 && !g.mask && !g.stats && !g.ypool, TG_ENOSUP, "conv_tile: the concat backward comes with the plain epilogue only");
       return g.f16 ? launch_tile_variant<KH, KC, BN, MT, false, 3, true>(g, lds, x, wp, bias, y, s)
@@ -1073,6 +1134,9 @@ int dispatch_tile_upbwd(const TileGeom& g, const bf16* gy, const bf16* wp, hipSt
   const int tiles1 = (g.w / 16) * (g.h / 8) * g.n * ((g.cout + (wide ? 63 : 31)) / (wide ? 64 : 32));
   const bool mt2 = (g.h % 16 == 0) && tiles1 >= 2 * 2 * 256 && g.cin_pad >= 64;
   if (tiles1 >= 2048) {
+    // a 32 + 32 concat: both halves in one 64-channel block, every gy tile staged once (launch_tile_wres picks MODE 4)
+    const bool both = g.c0 == 32 && c1 == 32 && g.n1 > 0 && tg_tune("TG_TUNE_UPBOTH", 1) != 0;
+    if (g.cin_pad == 16 && both) return launch_tile_wres<3, 16, 64, 1>(g, gy, wp, nullptr, nullptr, s);
     if (g.cin_pad == 16) return wide ? launch_tile_wres<3, 16, 64, 1>(g, gy, wp, nullptr, nullptr, s) : launch_tile_wres<3, 16, 32, 1>(g, gy, wp, nullptr, nullptr, s);
     if (g.cin_pad == 32) return wide ? launch_tile_wres<3, 32, 64, 1>(g, gy, wp, nullptr, nullptr, s) : launch_tile_wres<3, 32, 32, 1>(g, gy, wp, nullptr, nullptr, s);
   }
