@@ -1150,6 +1150,9 @@ STATS_CASES = [
     (2, 16, 40, 24),      # ragged channel counts (partial 32-channel blocks; no pixel norm at c = 24)
     (5, 8, 256, 256),     # conv_img: a whole 8x8 image per workgroup, ONE chunk per image
     (3, 8, 512, 256),
+    (6, 4, 256, 256),     # conv_small: a 4x4 image is 16 lanes of a column block, ONE chunk per image
+    (64, 4, 256, 64),     # ... two column blocks per workgroup
+    (200, 4, 64, 32),     # ... four
 ]
 
 

@@ -587,6 +587,11 @@ int tg_conv2d_fwd_pool_mfma(const TgConvDesc* d0, const void* x, const void* wp,
 
 // Forward conv that also writes the per-workgroup statistics partials of its output (conv_tile.hip STATS kernels).
 // chunks per image of the dispatch this descriptor selects, 0 when that dispatch has no statistics epilogue.
+bool tg_conv_small_supported(int n, int hout, int wout, int kh, int kw);
+bool tg_conv_small_stats_supported(int n, int hin, int win, int hout, int wout, int cout, int k, int pad_t, int pad_l);
+int tg_conv_small_run(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l,
+                      int epilogue, float alpha, const void* x, const void* wp, const float* bias, void* y, hipStream_t s,
+                      float* stats = nullptr);
 bool tg_conv_img_supported(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l);
 bool tg_conv_img_stats_supported(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l);
 int tg_conv_img_run(int n, int hw, int cin, int cout, int epilogue, float alpha, const void* x, const void* wp,
@@ -597,9 +602,13 @@ int tg_conv2d_fwd_stats_chunks_mfma(const TgConvDesc* d0) {
   const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
   if (!is16(d) || d->algo == TG_ALGO_MFMA_V1 || d->kh != 3 || d->cin % 8 || d->cout % 8 || d->epilogue) return 0;
   if (!tg_conv_tile_supported(d->hin, d->win, d->hout, d->wout, d->kh, d->kw, d->pad_t, d->pad_l)) {
-    // 8x8 maps: conv_img holds a whole image per workgroup -- ONE chunk per image
-    return (d->kh == d->kw && tg_conv_img_stats_supported(d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh,
-                                                          d->pad_t, d->pad_l)) ? 1 : 0;
+    // 8x8 maps: conv_img holds a whole image per workgroup; 4x4 maps: an image is 16 lanes of conv_small's column block
+    // -- ONE chunk per image (the order of the tests mirrors tg_conv2d_fwd_mfma's dispatch)
+    if (d->kh == d->kw && tg_conv_img_supported(d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->pad_t, d->pad_l))
+      return tg_conv_img_stats_supported(d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->pad_t, d->pad_l) ? 1 : 0;
+    if (d->pad_t == d->pad_l && tg_conv_small_supported(d->n, d->hout, d->wout, d->kh, d->kw))
+      return tg_conv_small_stats_supported(d->n, d->hin, d->win, d->hout, d->wout, d->cout, d->kh, d->pad_t, d->pad_l) ? 1 : 0;
+    return 0;
   }
   int chunks = 0;
   if (tg_conv_tile_run(d->n, d->hin, d->win, d->cin, d->cout, d->kh, d->pad_t, 0, 0.f, nullptr, nullptr, nullptr, nullptr,
@@ -614,16 +623,17 @@ int tg_conv2d_fwd_stats_mfma(const TgConvDesc* d0, const void* x, const void* wp
   const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
   TG_CHECK(chunks > 0 && chunks == tg_conv2d_fwd_stats_chunks_mfma(d0), TG_EINVAL,
            "tg_conv2d_fwd_stats: chunks %d does not match tg_conv2d_fwd_stats_chunks()", chunks);
-  if (!tg_conv_tile_supported(d->hin, d->win, d->hout, d->wout, d->kh, d->kw, d->pad_t, d->pad_l))
-    return tg_conv_img_run(d->n, d->hin, d->cin, d->cout, 0, d->lrelu_alpha, x, wp, nullptr, y, s, partials);
+  if (!tg_conv_tile_supported(d->hin, d->win, d->hout, d->wout, d->kh, d->kw, d->pad_t, d->pad_l)) {
+    if (tg_conv_img_supported(d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->pad_t, d->pad_l))
+      return tg_conv_img_run(d->n, d->hin, d->cin, d->cout, 0, d->lrelu_alpha, x, wp, nullptr, y, s, partials);
+    return tg_conv_small_run(d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->pad_t, d->pad_l, 0,
+                             d->lrelu_alpha, x, wp, nullptr, y, s, partials);
+  }
   return tg_conv_tile_run(d->n, d->hin, d->win, d->cin, d->cout, d->kh, d->pad_t, 0, d->lrelu_alpha, x, wp, nullptr, y, s,
                           nullptr, partials, chunks, nullptr);
 }
 
 
-bool tg_conv_small_supported(int n, int hout, int wout, int kh, int kw);
-int tg_conv_small_run(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l,
-                      int epilogue, float alpha, const void* x, const void* wp, const float* bias, void* y, hipStream_t s);
 
 int tg_conv2d_fwd_mfma(const TgConvDesc* d0, const void* x, const void* wp, const float* bias, void* y, hipStream_t s) {
   TgConvDesc dd;

@@ -26,6 +26,9 @@ struct SmallGeom {
   int epilogue;
   float alpha;
   unsigned x_bytes, w_bytes, y_bytes;
+  // STATS kernels (4x4 maps): sums of the (16-bit-rounded) outputs and of their squares per image and output channel as
+  // the image's ONE statistics chunk, stats[img][0][2][cout] (the layout of conv_tile's STATS epilogue, stat_chunks = 1)
+  float* stats;
 };
 
 constexpr unsigned SOOB = 0x80000000u;
@@ -38,7 +41,7 @@ __device__ __forceinline__ bf16x8 s_load16(__amdgpu_buffer_rsrc_t r, unsigned of
   return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
 
-template <int NT, int MT, int U, bool F16 = false>      // taps (1 or 9); 32-pixel column blocks per workgroup; chunks per load group
+template <int NT, int MT, int U, bool F16 = false, bool STATS = false>      // taps (1 or 9); 32-pixel column blocks per workgroup; chunks per load group
 __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                          const float* __restrict__ bias, bf16* __restrict__ y,
                                                          const SmallGeom g) {
@@ -164,6 +167,31 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict_
       if (g.epilogue & TG_EPI_LRELU) v[j] = lrelu_f(v[j], g.alpha);
     }
     const unsigned p0 = pack16x2<F16>(v[0], v[1]), p1 = pack16x2<F16>(v[2], v[3]);
+    if constexpr (STATS) {
+      // a 4x4 image is 16 consecutive pixel lanes of a column block: a butterfly over them (fixed order) leaves the
+      // image's sums of this lane's 4 channels in every lane; the first lane of each image writes them
+      float r4[4] = {unpack16_lo<F16>(p0), unpack16_hi<F16>(p0), unpack16_lo<F16>(p1), unpack16_hi<F16>(p1)};
+      float sq[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sq[j] = r4[j] * r4[j];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          r4[j] += __shfl_xor(r4[j], o, 64);
+          sq[j] += __shfl_xor(sq[j], o, 64);
+        }
+      }
+      const int pp = pbase + m * 32;
+      if ((l31 & 15) == 0 && pp < g.npix) {
+        float* out = g.stats + (size_t)(pp >> 4) * 2 * g.cout + n0 + q * 8 + kgrp * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          out[j] = r4[j];
+          out[g.cout + j] = sq[j];
+        }
+      }
+    }
     // low lanes hold channels 8q..8q+3, high lanes 8q+4..8q+7 of the same pixel: give the low lane all 8
     auto s0 = __builtin_amdgcn_permlane32_swap(p0, p0, false, false);   // s0[1] on a low lane = partner's p0
     auto s1 = __builtin_amdgcn_permlane32_swap(p1, p1, false, false);
@@ -184,10 +212,18 @@ bool tg_conv_small_supported(int n, int hout, int wout, int kh, int kw) {
   return (int64_t)n * hout * wout <= 4096;
 }
 
+// the statistics epilogue exists for 3x3 SAME convs over 4x4 maps (an image = 16 lanes of a column block), whole 32-channel
+// output blocks, plain epilogue; TG_TUNE_SMALL_STATS=0: A/B
+bool tg_conv_small_stats_supported(int n, int hin, int win, int hout, int wout, int cout, int k, int pad_t, int pad_l) {
+  return k == 3 && pad_t == 1 && pad_l == 1 && hin == 4 && win == 4 && hout == 4 && wout == 4 && cout % 32 == 0 &&
+         tg_conv_small_supported(n, hout, wout, k, k) && tg_tune("TG_TUNE_SMALL_STATS", 1) != 0;
+}
+
 int tg_conv_small_run(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l,
                       int epilogue, float alpha, const void* x, const void* wp, const float* bias, void* y,
-                      hipStream_t s) {
+                      hipStream_t s, float* stats) {
   SmallGeom g;
+  g.stats = stats;
   g.n = n; g.hin = hin; g.win = win; g.cin = cin; g.hout = hout; g.wout = wout; g.cout = cout;
   g.cin_pad = (cin + 15) / 16 * 16;
   g.kh = g.kw = k;
@@ -210,12 +246,21 @@ int tg_conv_small_run(int n, int hin, int win, int cin, int hout, int wout, int 
   tg_note_kernel(tg_elem_f16() ? "conv_small_kernel<%d,%d,f16>" : "conv_small_kernel<%d,%d>", NT_, MT_); \
   if (tg_elem_f16()) hipLaunchKernelGGL((conv_small_kernel<NT_, MT_, (NT_ == 1 ? 8 / MT_ : 1), true>), grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, g); \
   else hipLaunchKernelGGL((conv_small_kernel<NT_, MT_, (NT_ == 1 ? 8 / MT_ : 1)>), grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, g)
-  if (k == 1) {
+#define TG_SMALL_LAUNCH_STATS(MT_)                             \
+  tg_note_kernel(tg_elem_f16() ? "conv_small_kernel<9,%d,f16,stats>" : "conv_small_kernel<9,%d,stats>", MT_); \
+  if (tg_elem_f16()) hipLaunchKernelGGL((conv_small_kernel<9, MT_, 1, true, true>), grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, g); \
+  else hipLaunchKernelGGL((conv_small_kernel<9, MT_, 1, false, true>), grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, g)
+  if (stats) {
+    TG_CHECK(tg_conv_small_stats_supported(n, hin, win, hout, wout, cout, k, pad_t, pad_l) && epilogue == 0, TG_ENOSUP,
+             "conv_small: the statistics epilogue takes 3x3 SAME convs over 4x4 maps with the plain epilogue");
+    if (mt == 4) { TG_SMALL_LAUNCH_STATS(4); } else if (mt == 2) { TG_SMALL_LAUNCH_STATS(2); } else { TG_SMALL_LAUNCH_STATS(1); }
+  } else if (k == 1) {
     if (mt == 4) { TG_SMALL_LAUNCH(1, 4); } else if (mt == 2) { TG_SMALL_LAUNCH(1, 2); } else { TG_SMALL_LAUNCH(1, 1); }
   } else {
     if (mt == 4) { TG_SMALL_LAUNCH(9, 4); } else if (mt == 2) { TG_SMALL_LAUNCH(9, 2); } else { TG_SMALL_LAUNCH(9, 1); }
   }
 #undef TG_SMALL_LAUNCH
+#undef TG_SMALL_LAUNCH_STATS
   TG_LAUNCH_CHECK("conv_small");
   return TG_OK;
 }
