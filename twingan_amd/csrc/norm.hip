@@ -216,46 +216,12 @@ __global__ void in_stats_partial(const T* __restrict__ y, float* __restrict__ s1
 // the compiler issued two loads per trip and waited for them -- 8-32 dependent L2 round trips (~10 us) in front of a kernel
 // that streams for 10-30 us on the mid-size maps (the 64 x 64 ... 16 x 16 layers sat 1.5-1.8 x above their byte time,
 // profiles/r03_z_shapes_eager_step.json).  Eight rows in flight per trip, eight accumulators combined in a fixed order.
-// Thin layers (2c <= 128 columns, a power of two) with >= 16 rows: the 256 threads split into 256 / 2c ROW GROUPS -- thread
-// (group r, column) sums rows r, r + R, ... (eight in flight), the groups' results meet in LDS and are added in group
-// order -- so that 32 rows x 32 columns (256 x 256 x 16, n 32) are ONE round of loads instead of four, and the 256 rows a
-// 256 x 256 concat conv leaves per image four instead of 32.  Fixed order: bit-reproducible.
+// Measured and not kept (round 4): thin layers (2c <= 128 columns) summing their rows in 256 / 2c row groups that meet in
+// LDS -- one round of loads instead of four at 32 rows x 32 columns.  +0.1 % on the step (those prologues sit in front of
+// kernels that stream for 60-190 us), and the changed summation order moved the fp32 parity path of an ill-conditioned
+// configuration (equalized learning rate: var = m2 - m1^2 under cancellation) from inside to outside its tolerance.
 __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int n, int chunks, int c, float* sh) {
   const int64_t row = 2 * (int64_t)c;
-  const int ncol = 2 * c;
-  if (ncol <= 128 && (ncol & (ncol - 1)) == 0 && chunks >= 16 && blockDim.x == 256) {      // block-uniform
-    __shared__ float grp[256];
-    const int R = 256 / ncol;
-    const int col = threadIdx.x & (ncol - 1), r = threadIdx.x / ncol;
-    const float* p = part + (int64_t)n * chunks * row + col;
-    float a[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] = 0.f;
-    int k = r;
-    for (; k + 7 * R < chunks; k += 8 * R) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(k + u * R) * row];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] += v[u];
-    }
-    if (k < chunks) {      // the tail: clamped addresses, masked adds
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(k + u * R < chunks ? k + u * R : k) * row];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] += (k + u * R < chunks) ? v[u] : 0.f;
-    }
-    grp[threadIdx.x] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    __syncthreads();
-    if ((int)threadIdx.x < ncol) {
-      float t = 0.f;
-      for (int q = 0; q < R; ++q) t += grp[q * ncol + threadIdx.x];
-      sh[threadIdx.x] = t;
-    }
-    __syncthreads();
-    return;
-  }
   for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) {
     const float* p = part + (int64_t)n * chunks * row + i;
     float a[8];
