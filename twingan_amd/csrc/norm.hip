@@ -220,8 +220,28 @@ __global__ void in_stats_partial(const T* __restrict__ y, float* __restrict__ s1
 // LDS -- one round of loads instead of four at 32 rows x 32 columns.  +0.1 % on the step (those prologues sit in front of
 // kernels that stream for 60-190 us), and the changed summation order moved the fp32 parity path of an ill-conditioned
 // configuration (equalized learning rate: var = m2 - m1^2 under cancellation) from inside to outside its tolerance.
+// EXACT (the fp32 parity path): the two-accumulator order (even rows + odd rows) that path has had since round 1.  Its
+// model-level fixtures are sensitive to this order where a configuration is ill-conditioned (batch statistics as
+// E[y^2] - E[y]^2 of a nearly constant channel: 1e-4 -> 5e-3 on the conditional batch norm's gradients with another,
+// equally valid order), so the order that was validated stays; speed is not that path's concern.
+template <bool EXACT>
 __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int n, int chunks, int c, float* sh) {
   const int64_t row = 2 * (int64_t)c;
+  if constexpr (EXACT) {
+    for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) {
+      const float* p = part + (int64_t)n * chunks * row + i;
+      float a = 0.f, b = 0.f;
+      int k = 0;
+      for (; k + 1 < chunks; k += 2) {
+        a += p[(int64_t)k * row];
+        b += p[(int64_t)(k + 1) * row];
+      }
+      if (k < chunks) a += p[(int64_t)k * row];
+      sh[i] = a + b;
+    }
+    __syncthreads();
+    return;
+  }
   for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) {
     const float* p = part + (int64_t)n * chunks * row + i;
     float a[8];
@@ -338,7 +358,7 @@ __global__ void norm_act_fwd_part_kernel(const T* __restrict__ y, const float* _
     be_[q] = i < c ? be[i] : 0.f;
     k_[q] = (i < c && !(flags & NF_ZEROSHIFT)) ? ld(y + (int64_t)n * hw * c + i) : 0.f;
   }
-  reduce_partials(part, n, chunks, c, sh);
+  reduce_partials<exact_path<T>()>(part, n, chunks, c, sh);
   const float inv = 1.f / (float)hw;
   float m_[8], r_[8];
 #pragma unroll
@@ -583,7 +603,7 @@ __global__ void norm_act_bwd2_part_kernel(const T* __restrict__ gz, const T* __r
     ga[j] = pstride ? gamma[(int64_t)n * pstride + ch] : (n < split ? gamma : gamma2)[ch];
     be[j] = pstride ? beta[(int64_t)n * pstride + ch] : (n < split ? beta : beta2)[ch];
   }
-  reduce_partials(part, n, chunks, c, sh);
+  reduce_partials<exact_path<T>()>(part, n, chunks, c, sh);
   if (pstride && blockIdx.x == 0) {      // one parameter row per image: its gradient row is this image's sums
     for (int i = threadIdx.x; i < c; i += blockDim.x) {
       if (gbeta) gbeta[(int64_t)n * pstride + i] = sh[i];
