@@ -300,7 +300,8 @@ def test_upcat_conv_at_bench_shapes(key):
   if O.USE_UPCAT_BWD_FUSED:
     d = O._desc((n, hw, hw, c0 + c1), cout, O.ConvSpec(3, 'SAME'), gy.dtype, 0)
     g0, g1 = torch.empty_like(x0), torch.empty_like(x1)
-    O.call('tg_conv2d_upcat_bwd_data', gy.data_ptr(), O.PackCache.get(w.detach(), d, 1).data_ptr(), g0.data_ptr(), g1.data_ptr(),
+    wpack = O.PackCache.get(w.detach(), d, 1)      # held in a local: an uncached pack must outlive the launch
+    O.call('tg_conv2d_upcat_bwd_data', gy.data_ptr(), wpack.data_ptr(), g0.data_ptr(), g1.data_ptr(),
            n, hw, hw, c0, c1, cout, gsz, O._pack_perm(perm), O._dt(gy), O._stream())
     _note(key, 'tg_conv2d_upcat_bwd_data', str(n))
     assert torch.equal(g0, x0.grad) and torch.equal(g1, x1.grad), ('upcat bwd_data direct call', key)

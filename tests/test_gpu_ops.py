@@ -813,7 +813,8 @@ def test_upcat_backward_data_epilogue(ops, dtype, case):
   d = O._desc((n, hw, hw, c0 + c1), cout, spec, dtype, 0)
   g0 = torch.full((n, hw // 2, hw // 2, c0), float('nan'), dtype=dtype, device=dev())
   g1 = torch.full((n1, hw, hw, c1), float('nan'), dtype=dtype, device=dev())
-  O.call('tg_conv2d_upcat_bwd_data', gyd.data_ptr(), O.PackCache.get(wd, d, 1).data_ptr(), g0.data_ptr(), g1.data_ptr(), n, hw, hw,
+  wpack = O.PackCache.get(wd, d, 1)      # held in a local: an uncached pack must outlive the launch
+  O.call('tg_conv2d_upcat_bwd_data', gyd.data_ptr(), wpack.data_ptr(), g0.data_ptr(), g1.data_ptr(), n, hw, hw,
          c0, c1, cout, gsz, O._pack_perm(perm), O._dt(gyd), O._stream())
   sym = _lib.load().tg_last_kernel().decode()
   want = UPBWD_KERNELS[case]
@@ -848,7 +849,8 @@ def test_upcat_backward_data_epilogue(ops, dtype, case):
   assert e < tol, ('g1 vs float64', e, srcs)
   # one output not wanted: the other is unchanged
   g0b = torch.empty_like(g0)
-  O.call('tg_conv2d_upcat_bwd_data', gyd.data_ptr(), O.PackCache.get(wd, d, 1).data_ptr(), g0b.data_ptr(), None, n, hw, hw,
+  wpack = O.PackCache.get(wd, d, 1)      # held in a local: an uncached pack must outlive the launch
+  O.call('tg_conv2d_upcat_bwd_data', gyd.data_ptr(), wpack.data_ptr(), g0b.data_ptr(), None, n, hw, hw,
          c0, c1, cout, gsz, O._pack_perm(perm), O._dt(gyd), O._stream())
   assert torch.equal(g0b, g0)
 

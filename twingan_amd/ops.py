@@ -217,6 +217,71 @@ def flush_slab_reductions():
   return n
 
 
+class WgradFork:
+  """Filter gradients of the low-resolution layers off the backward's critical path (Trainer, TG_WGRAD_FORK=1).
+
+  A filter gradient feeds nothing but the optimiser, while the backward-data chain it sits in is a dependent chain of
+  launches; at <= 32 x 32 both are latency-bound and fill a fraction of the chip.  While ``active``, the filter-gradient
+  launches of layers at or below ``max_hw`` are QUEUED per stream; the first one above ``max_hw`` that follows on that
+  stream forks ONE side stream (a single stream-wait edge: cross-stream edges are expensive in a replayed hipGraph) on which
+  the queued launches then run next to the high-resolution part of the chain; ``join()`` (Trainer, at the end of a backward
+  segment, after the domain streams were joined) runs what never met a fork inline and makes the current stream wait for
+  the side streams.  Same kernels, same per-sink order of additions per stream as the inline path."""
+  active = False
+  max_hw = 32
+  _queues = {}       # stream handle -> [(launch closure, tensors it reads)]
+  _sides = {}        # stream handle -> its side stream
+  _pending = []      # side streams with work since the last join
+
+  @classmethod
+  def run(cls, hw, fn, keep):
+    if not cls.active:
+      fn()
+      return
+    cur = torch.cuda.current_stream()
+    q = cls._queues.setdefault(cur.cuda_stream, [])
+    if hw <= cls.max_hw:
+      q.append((fn, keep))
+      return
+    if q:
+      side = cls._sides.get(cur.cuda_stream)
+      if side is None:
+        side = cls._sides[cur.cuda_stream] = torch.cuda.Stream(device=keep[0].device)
+      side.wait_stream(cur)
+      with torch.cuda.stream(side):
+        for f, ts in q:
+          f()
+          for t in ts:
+            t.record_stream(side)
+      del q[:]
+      if side not in cls._pending:
+        cls._pending.append(side)
+    fn()
+
+  @classmethod
+  def join(cls):
+    """Called on the stream that consumes the gradients, ordered after every stream a backward node ran on."""
+    cur = None
+    for q in cls._queues.values():
+      for f, ts in q:
+        f()
+        cur = cur or torch.cuda.current_stream()
+        for t in ts:
+          t.record_stream(cur)
+      del q[:]
+    if cls._pending:
+      cur = cur or torch.cuda.current_stream()
+      for side in cls._pending:
+        cur.wait_stream(side)
+      del cls._pending[:]
+
+  @classmethod
+  def reset(cls):
+    for q in cls._queues.values():
+      del q[:]
+    del cls._pending[:]
+
+
 class GradSink:
   """Fused gradient accumulation: a parameter registered here has its gradient ADDED straight into the
   registered buffer (its slice of the optimiser group's flat fp32 gradient, params.ParamStore) by the
@@ -266,7 +331,7 @@ class GradSink:
   def submit(cls, w, x, gy, spec, sink, bias_sink=None):
     """``bias_sink``: the layer's bias gradient buffer when it is to be produced from this read of gy."""
     if not cls.pair:
-      conv_bwd_weight_raw(x, gy, spec, out=sink, gbias=bias_sink)
+      WgradFork.run(x.shape[1], lambda: conv_bwd_weight_raw(x, gy, spec, out=sink, gbias=bias_sink), (x, gy))
       return
     key = w.data_ptr()
     first = cls._held.pop(key, None)
@@ -275,9 +340,12 @@ class GradSink:
       return
     gb = first[4] if first[4] is not None else bias_sink
     segs = (1 if first[4] is not None else 0) | (2 if bias_sink is not None else 0)
-    if not conv_bwd_weight2_raw(first[0], first[1], x, gy, spec, sink, gb, segs):
-      conv_bwd_weight_raw(first[0], first[1], first[2], out=sink, gbias=first[4])
-      conv_bwd_weight_raw(x, gy, spec, out=sink, gbias=bias_sink)
+
+    def both():
+      if not conv_bwd_weight2_raw(first[0], first[1], x, gy, spec, sink, gb, segs):
+        conv_bwd_weight_raw(first[0], first[1], first[2], out=sink, gbias=first[4])
+        conv_bwd_weight_raw(x, gy, spec, out=sink, gbias=bias_sink)
+    WgradFork.run(x.shape[1], both, (first[0], first[1], x, gy))
 
   @classmethod
   def flush(cls, only=None):
@@ -430,7 +498,8 @@ def conv_fwd_pool_raw(x, w, bias, spec, epilogue):
     def work():
       tag, fl, by = _conv_work(d, 'fwd', _esize(x))
       return tag, fl, by + zp.numel() * _esize(x)
-    call('tg_conv2d_fwd_pool', ctypes.byref(d), _p(x), _p(PackCache.get(w, d, 0)), _p(bias), _p(z), _p(zp), _stream(),
+    wk = PackCache.get(w, d, 0)      # a local keeps an uncached pack alive across the launch
+    call('tg_conv2d_fwd_pool', ctypes.byref(d), _p(x), _p(wk), _p(bias), _p(z), _p(zp), _stream(),
          work=work)
     return z, zp
   z = conv_fwd_raw(x, w, bias, spec, epilogue)
@@ -461,7 +530,8 @@ def conv_fwd_pool_signs_raw(x, w, bias, spec, epilogue):
   def work():      # input + pooled output + one bit per full-resolution output
     tag, fl, _ = _conv_work(d, 'fwd', _esize(x))
     return tag, fl, _nb(x, zp, signs) + _esize(x) * d.kh * d.kw * d.cin * d.cout
-  call('tg_conv2d_fwd_pool_signs', ctypes.byref(d), _p(x), _p(PackCache.get(w, d, 0)), _p(bias), _p(signs), _p(zp), _stream(),
+  wk = PackCache.get(w, d, 0)      # a local keeps an uncached pack alive across the launch
+  call('tg_conv2d_fwd_pool_signs', ctypes.byref(d), _p(x), _p(wk), _p(bias), _p(signs), _p(zp), _stream(),
        work=work)
   return signs, zp
 
@@ -502,7 +572,8 @@ def conv_fwd_stats_raw(x, w, spec):
     return conv_fwd_raw(x, w, None, spec, 0), None
   y = torch.empty((d.n, d.hout, d.wout, d.cout), dtype=x.dtype, device=x.device)
   part = torch.empty(d.n * chunks * 2 * d.cout, dtype=torch.float32, device=x.device)
-  call('tg_conv2d_fwd_stats', ctypes.byref(d), _p(x), _p(PackCache.get(w, d, 0)), _p(y), _p(part), chunks, _stream(),
+  wk = PackCache.get(w, d, 0)      # a local keeps an uncached pack alive across the launch
+  call('tg_conv2d_fwd_stats', ctypes.byref(d), _p(x), _p(wk), _p(y), _p(part), chunks, _stream(),
        work=lambda: _conv_work(d, 'fwd', _esize(x)))
   return y, ConvStats(part, chunks)
 
@@ -1432,11 +1503,13 @@ class UpcatConvFn(torch.autograd.Function):
     chunks = _lib.load().tg_conv2d_upcat_fwd_stats_chunks(n, H, W, c0, c1, cout) if (holder is not None and USE_CONV_STATS) else 0
     if chunks > 0:
       part = torch.empty(n * chunks * 2 * cout, dtype=torch.float32, device=x0.device)
-      call('tg_conv2d_upcat_fwd_stats', _p(x0), _p(x1), _p(PackCache.get(w, d, 0)), _p(y), _p(part), chunks, n, H, W, c0, c1,
+      wk = PackCache.get(w, d, 0)      # a local keeps an uncached pack alive across the launch
+      call('tg_conv2d_upcat_fwd_stats', _p(x0), _p(x1), _p(wk), _p(y), _p(part), chunks, n, H, W, c0, c1,
            cout, gsz, pk, _dt(x0), _stream(), work=work)
       holder.append(ConvStats(part, chunks))
     else:
-      call('tg_conv2d_upcat_fwd', _p(x0), _p(x1), _p(PackCache.get(w, d, 0)), _p(y), n, H, W, c0, c1, cout, gsz, pk,
+      wk = PackCache.get(w, d, 0)      # a local keeps an uncached pack alive across the launch
+      call('tg_conv2d_upcat_fwd', _p(x0), _p(x1), _p(wk), _p(y), n, H, W, c0, c1, cout, gsz, pk,
            _dt(x0), _stream(), work=work)
       if holder is not None:
         holder.append(None)
@@ -1458,7 +1531,8 @@ class UpcatConvFn(torch.autograd.Function):
       if USE_UPCAT_BWD_FUSED and H >= 16:
         # backward-data with the upsample / concat adjoint in its epilogue: no concat-layout gradient tensor
         d = _desc((n, H, W, c0 + c1), cout, ctx.spec, gy.dtype, 0)
-        call('tg_conv2d_upcat_bwd_data', _p(gy), _p(PackCache.get(w, d, 1)), _p(g0), _p(g1), n, H, W, c0, c1, cout, gsz, pk,
+        wk = PackCache.get(w, d, 1)      # a local keeps an uncached pack alive across the launch
+        call('tg_conv2d_upcat_bwd_data', _p(gy), _p(wk), _p(g0), _p(g1), n, H, W, c0, c1, cout, gsz, pk,
              _dt(gy), _stream(),
              work=lambda: ('dgrad:upcat:k3:c%d>%d+%d:hw%d:n%d' % (cout, c0, c1, H, n), 2 * n * H * W * cout * 9 * (c0 + c1),
                            2 * (gy.numel() + x0.numel() + x1.numel()) + 2 * w.numel()))
@@ -1469,16 +1543,21 @@ class UpcatConvFn(torch.autograd.Function):
     if ctx.needs_input_grad[2] and not _State.skip_param_grads:
       sink = GradSink.get(w)
       gw = sink if sink is not None else torch.empty(tuple(w.shape), dtype=torch.float32, device=gy.device)
-      lib = _lib.load()
-      nbytes = lib.tg_conv2d_upcat_bwd_weight_workspace(n, H, W, c0, c1, cout)
-      ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=gy.device)
-      call('tg_conv2d_upcat_bwd_weight', _p(x0), _p(x1), _p(gy), _p(gw), 1 if sink is not None else 0, _p(ws), nbytes,
-           n, H, W, c0, c1, cout, gsz, pk, _dt(gy), _stream(),
-           work=lambda: ('wgrad:upcat:k3:c%d+%d>%d:hw%d:n%d' % (c0, c1, cout, H, n), 2 * n * H * W * cout * 9 * (c0 + c1),
-                         2 * (x0.numel() + x1.numel() + gy.numel()) + 4 * w.numel()))
-      _keep_for_aux(ws, sink is not None)
-      if sink is not None:
+
+      def wgrad(gw=gw):
+        lib = _lib.load()
+        nbytes = lib.tg_conv2d_upcat_bwd_weight_workspace(n, H, W, c0, c1, cout)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=gy.device)
+        call('tg_conv2d_upcat_bwd_weight', _p(x0), _p(x1), _p(gy), _p(gw), 1 if sink is not None else 0, _p(ws), nbytes,
+             n, H, W, c0, c1, cout, gsz, pk, _dt(gy), _stream(),
+             work=lambda: ('wgrad:upcat:k3:c%d+%d>%d:hw%d:n%d' % (c0, c1, cout, H, n), 2 * n * H * W * cout * 9 * (c0 + c1),
+                           2 * (x0.numel() + x1.numel() + gy.numel()) + 4 * w.numel()))
+        _keep_for_aux(ws, sink is not None)
+      if sink is not None:      # nothing reads a sink before the optimiser: may leave the critical path (WgradFork)
+        WgradFork.run(H, wgrad, (x0, x1, gy))
         gw = None
+      else:
+        wgrad()
     return g0, g1, gw, None, None, None
 
 

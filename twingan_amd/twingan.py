@@ -442,6 +442,9 @@ class Trainer:
       out = (loss.detach(), {k: v.detach() for k, v in terms.items()})
       scaled = loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)       # model_deploy.py:265-268,308-313
       ops.GradSink.pair = True
+      # low-resolution filter gradients on a forked stream next to the high-resolution part of the backward (A/B switch)
+      ops.WgradFork.reset()
+      ops.WgradFork.active = os.environ.get('TG_WGRAD_FORK', '0') == '1'
       # the slab reductions of the filter gradients that feed gradient sinks: queued, one launch per backward segment
       ops.defer_slab_reductions(os.environ.get('TG_WGRAD_DEFER', '1') != '0')
       aux = self._aux_stream()
@@ -455,6 +458,7 @@ class Trainer:
           roots, grads = ops.Cuts.roots(seg)
           torch.autograd.backward(roots, grads)
         _DomainStreams.join_all(self.device)
+        ops.WgradFork.join()
         last = seg == nseg - 1
         if nseg > 1:      # spectrally normalised kernels whose uses are all behind us: through the normalisation's backward
           pggan.sn_segment_backward(self.P, lambda scope, seg=seg: last or self.store.phase.get(scope + '/weights', 0) <= seg)
@@ -468,6 +472,8 @@ class Trainer:
         yield seg, out
     finally:
       ops.GradSink.pair = False
+      ops.WgradFork.active = False
+      ops.WgradFork.reset()
       ops.defer_slab_reductions(False)
       if ops.AUX_STREAM is not None:
         ops.set_aux_stream(None)
