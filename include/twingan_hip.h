@@ -122,6 +122,18 @@ int tg_conv2d_bwd_data(const TgConvDesc* d, const void* gy, const void* w, void*
  * read-read-write pass (tf LeakyReluGrad after Conv2DBackpropInput). */
 int tg_conv2d_bwd_data_masked(const TgConvDesc* d, const void* gy, const void* w, const void* x_act, void* gx,
                               void* stream);
+/* Backward-data of the LAST conv of a discriminator block (nets/pggan.py:304-306: conv -> LeakyReLU -> tf.nn.avg_pool) taken
+ * straight from the gradient of the POOLED output: the conv's incoming gradient
+ *   gy[n,y,x,c] = rnd(0.25 * gy_pooled[n,y/2,x/2,c] * (bit c of y_signs[n,y,x] ? 1 : d->lrelu_alpha))
+ * (AvgPoolGrad + LeakyReluGrad, what tg_lrelu_pool_bwd_signs writes) is formed while the kernel stages its input tiles and
+ * is never in memory.  gy_pooled [n,hout/2,wout/2,cout]; y_signs [n,hout,wout,cout/8] bytes from tg_conv2d_fwd_pool_signs;
+ * x_act (may be NULL): as in tg_conv2d_bwd_data_masked; w: pack of mode 1.  gx is bit-identical to the two-launch path.
+ * tg_conv2d_bwd_data_unpool_supported(d) != 0: the layer is one the kernels take (3x3 SAME on the tile kernels' maps,
+ * cout % 32 == 0, 16-bit storage); callers keep the two-launch path otherwise, and whenever the layer's filter gradient
+ * needs gy itself. */
+int tg_conv2d_bwd_data_unpool_supported(const TgConvDesc* d);
+int tg_conv2d_bwd_data_unpool(const TgConvDesc* d, const void* gy_pooled, const void* y_signs, const void* w, const void* x_act,
+                              void* gx, void* stream);
 /* The adjoint of that node, as the gradient penalty's second backward pass needs it (image_generation.py:414-439: the
  * backward of tf.gradients(pred, interp)): y = conv(x, w) * (mask_src > 0 ? 1 : d->lrelu_alpha) with mask_src [n,hout,
  * wout,cout] -- the forward conv of the incoming cotangent with the LeakyReLU mask of the NEXT node of that pass in its

@@ -104,6 +104,10 @@ inline u32x2_t buffer_load_b64(const Rsrc& r, unsigned voff, unsigned soff, int)
   for (int i = 0; i < 2; ++i) v[i] = buf_dword(r, (uint64_t)voff + soff + 4 * i);
   return v;
 }
+inline unsigned char buffer_load_b8(const Rsrc& r, unsigned voff, unsigned soff, int) {
+  const uint64_t off = (uint64_t)voff + soff;
+  return off + 1 <= r.bytes ? r.base[off] : (unsigned char)0;
+}
 template <typename V> inline void buffer_store_b128(V val, const Rsrc& r, unsigned voff, unsigned soff, int) {
   static_assert(sizeof(V) == 16, "b128 store");
   unsigned char b[16];
@@ -250,6 +254,7 @@ typedef hipemu::Rsrc __amdgpu_buffer_rsrc_t;
 #define __builtin_amdgcn_make_buffer_rsrc hipemu::make_buffer_rsrc
 #define __builtin_amdgcn_raw_buffer_load_b128 hipemu::buffer_load_b128
 #define __builtin_amdgcn_raw_buffer_load_b64 hipemu::buffer_load_b64
+#define __builtin_amdgcn_raw_buffer_load_b8 hipemu::buffer_load_b8
 #define __builtin_amdgcn_raw_buffer_store_b128 hipemu::buffer_store_b128
 #define __builtin_amdgcn_raw_buffer_store_b16 hipemu::buffer_store_b16
 #define __builtin_amdgcn_raw_buffer_store_b8 hipemu::buffer_store_b8

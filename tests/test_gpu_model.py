@@ -345,6 +345,54 @@ def test_segmented_backward_leaves_the_same_gradients(precision):
       assert lo <= cut.store.offsets[k] < hi
 
 
+def test_unpool_backward_data_and_forked_filter_gradients_leave_the_same_gradients(monkeypatch):
+  """Two schedule changes of the backward that must not change a gradient: (a) in a generator step the backward-data of
+  every discriminator block end reads the pooled gradient + sign bytes itself (tg_conv2d_bwd_data_unpool) instead of a
+  full-resolution gradient tensor written by tg_lrelu_pool_bwd_signs; (b) TG_WGRAD_FORK=1 queues the filter gradients of
+  the <= 32 x 32 layers and runs them on ONE forked stream next to the high-resolution part of the backward.  Same
+  kernels on the same tensors (a) bit for bit per launch, (b) in another order per gradient sink."""
+  from twingan_amd import Config, ops
+  from twingan_amd.twingan import Trainer
+  cfg = Config(hw=64, max_ch=64, precision='bf16')
+  g = torch.Generator().manual_seed(29)
+  s = torch.rand(2, 64, 64, 3, generator=g).to('cuda:0').bfloat16()
+  t = torch.rand(2, 64, 64, 3, generator=g).to('cuda:0').bfloat16()
+  al = torch.rand(2, generator=g).to('cuda:0')
+  calls = []
+  real = ops.conv_bwd_data_unpool_raw
+
+  def counted(*a, **k):
+    out = real(*a, **k)
+    calls.append(out is not None)
+    return out
+  monkeypatch.setattr(ops, 'conv_bwd_data_unpool_raw', counted)
+  grads = {}
+  for name, unpool, fork in (('base', False, '0'), ('new', True, '1')):
+    monkeypatch.setattr(ops, 'USE_DGRAD_UNPOOL', unpool)
+    monkeypatch.setenv('TG_WGRAD_FORK', fork)
+    tr = Trainer(cfg, device='cuda:0', seed=13, overlap=False)
+    grads[name] = {}
+    for grp in ('g', 'd'):
+      for _ in tr._grad_segments(grp, s, t, al, al):
+        pass
+      torch.cuda.synchronize()
+      gd = tr.store.grad_dict()
+      grads[name][grp] = {k: gd[k].clone() for k in tr.store.names(grp)}
+    assert not ops.WgradFork.active and not any(ops.WgradFork._queues.values())
+    if unpool:      # the 64 x 64, 32 x 32 and 16 x 16 block ends of both discriminators, in the generator step only
+      assert sum(calls) >= 6, calls
+    else:
+      assert not calls
+  for grp in ('g', 'd'):
+    top = max(float(v.norm()) for v in grads['base'][grp].values())
+    for k, a in grads['base'][grp].items():
+      na = float(a.norm())
+      if na < 1e-4 * top:
+        continue
+      e = float((a - grads['new'][grp][k]).norm()) / na
+      assert e < 2e-3, (grp, k, e)
+
+
 SEGMENT_VARIANTS = {
     'sn': dict(hw=64, max_ch=16, spectral_norm=True, overlap_cut_hw=16),
     'sn_everywhere_att': dict(hw=64, max_ch=16, spectral_norm=True, spectral_norm_in_non_discriminator=True, do_self_attention=True,

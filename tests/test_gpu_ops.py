@@ -1454,6 +1454,81 @@ def test_flash_attention_second_order(ops, dtype, n, ln, dk, dv):
     assert e < tol and e <= ec * 1.5 + 1e-4, (nm, e, ec)
 
 
+# ------------------------------------------------ backward-data of a block's last conv from the pooled gradient + sign bytes
+UNPOOL_CASES = [
+    # n, hw, cin, cout, masked, kernel the dispatch picks (bf16 name)
+    (2, 16, 16, 32, True, 'conv_tile_kernel<3,32,32,1,unpool>'),
+    (1, 32, 32, 64, False, 'conv_tile_kernel<3,32,32,1,unpool>'),
+    (2, 16, 128, 256, True, 'conv_tile_kernel<3,32,32,1,unpool>'),
+    (16, 64, 64, 128, True, 'conv_tile_kernel<3,32,32,2,unpool>'),     # two sub-tiles per wave (>= 1024 tiles, cin_pad >= 64)
+    (32, 64, 64, 32, True, 'conv_tile_kernel<3,32,64,1,unpool>'),      # 64-channel output blocks
+    (32, 64, 64, 128, False, 'conv_tile_kernel<3,32,64,2,unpool>'),
+    (16, 128, 16, 32, True, 'conv_tile_wres_kernel<3,32,32,1,unpool>'),      # weight-resident thin kernel (the 256 x 256 block end)
+    (1, 48, 16, 32, True, 'conv_tile_kernel<3,32,32,1,unpool>'),       # 48 rows / columns: three column tiles
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', range(len(UNPOOL_CASES)))
+def test_unpool_backward_data_equals_the_two_launch_path(ops, dtype, case):
+  """tg_conv2d_bwd_data_unpool: the backward-data of a discriminator block's last conv (nets/pggan.py:304-306) with
+  AvgPoolGrad + LeakyReluGrad applied while its tiles are staged -- bit-identical to tg_lrelu_pool_bwd_signs followed by
+  tg_conv2d_bwd_data(_masked) for every kernel variant the dispatch picks, and within the rounding bound of the float64
+  oracle evaluated on the same rounded operands."""
+  import twingan_amd.ops as O
+  from twingan_amd import _lib
+  n, hw, cin, cout, masked, want = UNPOOL_CASES[case]
+  g = torch.Generator().manual_seed(300 + case)
+  spec = O.ConvSpec(3, 'SAME')
+  x = torch.randn(n, hw, hw, cin, generator=g).to(dtype).to(dev())               # the conv's forward input: the mask source
+  w = (torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev())
+  gzp = torch.randn(n, hw // 2, hw // 2, cout, generator=g).to(dtype).to(dev())
+  gzp[0, 0, 0, :8] = 0.0                                                         # zeros stay zeros whatever their sign bit
+  signs = torch.randint(0, 256, (n, hw, hw, cout // 8), generator=g, dtype=torch.uint8).to(dev())
+  g2, _ = O.lrelu_pool_bwd_signs(gzp, signs, spec.alpha, None, False)
+  ref = O.conv_bwd_data_masked_raw(g2, w, x, spec) if masked else O.conv_bwd_data_raw(g2, w, (n, hw, hw, cin), spec)
+  got = O.conv_bwd_data_unpool_raw(gzp, signs, w, x if masked else None, (n, hw, hw, cin), spec)
+  assert got is not None, 'the tile kernels take this layer'
+  sym = _lib.load().tg_last_kernel().decode()
+  assert sym == (want if dtype == torch.bfloat16 else want.replace('unpool', 'unpool,f16')), sym
+  assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
+  if n * hw * hw * cout <= 1 << 21:      # the float64 oracle on the small cases
+    bits = ((signs.to(torch.int32).unsqueeze(-1) >> torch.arange(8, dtype=torch.int32, device=signs.device)) & 1).reshape(n, hw, hw, cout)
+    up = host(gzp).repeat(2, axis=1).repeat(2, axis=2) * 0.25 * np.where(host(bits) > 0, 1.0, 0.2)
+    rnd = bf16_round if dtype == torch.bfloat16 else f16_round
+    wr = rnd(host(w))
+    want_gx = N.conv2d_bwd_data(rnd(up), wr, (hw, hw), 'SAME')
+    if masked:
+      want_gx = want_gx * np.where(host(x) > 0, 1.0, 0.2)
+    assert rel_l2(host(got), want_gx) < (4e-3 if dtype == torch.bfloat16 else 5e-4)
+
+
+def test_generator_step_backward_through_a_block_end_uses_the_unpool_kernel(ops):
+  """A discriminator block end differentiated for its INPUT only (a generator step: the discriminator's parameters are
+  frozen): conv2d(pool_only=True) then backpropagates through tg_conv2d_bwd_data_unpool and the gradient equals the
+  two-launch path's (TG_DGRAD_UNPOOL=0) bit for bit."""
+  import twingan_amd.ops as O
+  g = torch.Generator().manual_seed(41)
+  n, hw, cin, cout = 2, 32, 32, 64
+  x0 = torch.randn(n, hw, hw, cin, generator=g).bfloat16().to(dev())
+  w = (torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev())
+  b = (torch.randn(cout, generator=g) * 0.1).to(dev())
+  gz = torch.randn(n, hw // 2, hw // 2, cout, generator=g).bfloat16().to(dev())
+  res = {}
+  saved = O.USE_DGRAD_UNPOOL
+  try:
+    for on in (True, False):
+      O.USE_DGRAD_UNPOOL = on
+      x = x0.clone().requires_grad_(True)
+      out = O.conv2d(x, w, b, 3, 'SAME', lrelu=True, pool=True, pool_only=True)
+      zp = out[1] if isinstance(out, tuple) else out
+      zp.backward(gz)
+      res[on] = x.grad
+  finally:
+    O.USE_DGRAD_UNPOOL = saved
+  assert torch.equal(res[True], res[False])
+
+
 # ------------------------------------------------------------------------- sign bits instead of a pooled layer's output
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('n,hw,cin,cout', [(3, 32, 16, 32), (2, 16, 64, 64), (2, 64, 16, 24), (5, 16, 32, 72), (1, 16, 256, 256)])

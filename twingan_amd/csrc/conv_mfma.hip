@@ -564,7 +564,7 @@ bool tg_conv_tile_supported(int h, int w, int hout, int wout, int kh, int kw, in
 int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int epilogue, float alpha, const void* x,
                      const void* wp, const float* bias, void* y, hipStream_t s, const void* mask = nullptr,
                      float* stats = nullptr, int stat_chunks = 0, int* chunks_query = nullptr, void* ypool = nullptr,
-                     void* ymask = nullptr);
+                     void* ymask = nullptr, const void* up_src = nullptr, const void* up_signs = nullptr, float up_alpha = 0.f);
 
 // Forward conv that also writes the 2x2 average pool of its output (conv_tile.hip POOL kernels): 3x3 SAME, even h / w,
 // shapes the tile kernels take
@@ -713,6 +713,25 @@ int tg_conv2d_bwd_data_mfma(const TgConvDesc* d0, const void* gy, const void* wp
   if (rc) return rc;
   if (d->kh == 1) return dispatch_fwd<1, 1>(g, (const bf16*)gy, (const bf16*)wp, nullptr, (bf16*)gx, s);
   return dispatch_fwd<3, 3>(g, (const bf16*)gy, (const bf16*)wp, nullptr, (bf16*)gx, s);
+}
+
+// Backward-data of a discriminator block's last conv straight from the gradient of the POOLED output and the layer's sign
+// bytes (conv_tile.hip UNPOOL kernels): the tile kernels' shapes with 32-channel chunks of the incoming gradient
+bool tg_conv2d_bwd_data_unpool_supported_mfma(const TgConvDesc* d0) {
+  TgConvDesc dd;
+  const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
+  return d == d0 && is16(d) && d->algo != TG_ALGO_MFMA_V1 && d->kh == 3 && d->kw == 3 && d->cin % 8 == 0 && d->cout % 32 == 0 &&
+         d->hout % 2 == 0 && d->wout % 2 == 0 &&
+         tg_conv_tile_supported(d->hout, d->wout, d->hin, d->win, d->kh, d->kw, d->pad_t, d->pad_l);
+}
+
+int tg_conv2d_bwd_data_unpool_mfma(const TgConvDesc* d, const void* gy_pooled, const void* y_signs, const void* wp, void* gx,
+                                   hipStream_t s, const void* mask) {
+  TG_CHECK(tg_conv2d_bwd_data_unpool_supported_mfma(d), TG_ENOSUP, "tg_conv2d_bwd_data_unpool: not built for this layer");
+  TG_CHECK(!mask || tg_conv2d_bwd_data_mask_fusable_mfma(d), TG_ENOSUP, "tg_conv2d_bwd_data_unpool: mask not fusable here");
+  return tg_conv_tile_run(d->n, d->hout, d->wout, d->cout, d->cin, d->kh, d->kh - 1 - d->pad_t, 0, mask ? d->lrelu_alpha : 1.f,
+                          nullptr, wp, nullptr, gx, s, mask, nullptr, 0, nullptr, nullptr, nullptr, gy_pooled, y_signs,
+                          d->lrelu_alpha);
 }
 
 static void wgrad_split(const Geom& g, int* n_ci, int* n_co, int* nslices, int* tiles_per_block, int* total_tiles) {

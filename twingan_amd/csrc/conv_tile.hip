@@ -65,6 +65,14 @@ struct TileGeom {
   bf16* up_out;
   bf16* skip_out;
   int n1;
+  // UNPOOL kernels: the conv input is never in memory -- it is the gradient of a discriminator block's last LeakyReLU layer,
+  // x[n,y,x,c] = rnd(0.25 * up_src[n,y/2,x/2,c] * (sign bit of (n,y,x,c) ? 1 : up_alpha)), i.e. AvgPoolGrad + LeakyReluGrad
+  // (tg_lrelu_pool_bwd_signs) applied while the halo tile is staged: up_src [n,h/2,w/2,cin] is the gradient of the pooled
+  // output, up_signs [n,h,w,cin/8] the sign bytes tg_conv2d_fwd_pool_signs left.  Backward-data of that layer then reads
+  // 1/4 + 1/16 of the tensor's bytes and the tensor itself is neither written nor read (nets/pggan.py:304-306).
+  const bf16* up_src;
+  const unsigned char* up_signs;
+  float up_alpha;
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
@@ -91,6 +99,25 @@ __device__ __forceinline__ void mask4(__amdgpu_buffer_rsrc_t r, unsigned off, fl
   f[3] = (short)(z[1] >> 16) > 0 ? 1.f : alpha;
 }
 
+
+// UNPOOL staging: eight pooled-gradient values q and their eight sign bits -> rnd(0.25 * q * (bit ? 1 : alpha)), the
+// arithmetic (and rounding) of lrelu_bwd_bias_kernel<.., BITS> in norm.hip, so the staged tile is bit-identical to the tensor
+// tg_lrelu_pool_bwd_signs would have written
+__device__ __forceinline__ unsigned buf_load_u8(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r, off, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ bf16x8 unpool8(bf16x8 q, unsigned bits, float alpha) {
+  const u32x4 u = __builtin_bit_cast(u32x4, q);
+  u32x4 o;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const float lo = fmaf(0.25f, unpack16_lo<F16>(u[d]), 0.f) * (((bits >> (2 * d)) & 1u) ? 1.f : alpha);
+    const float hi = fmaf(0.25f, unpack16_hi<F16>(u[d]), 0.f) * (((bits >> (2 * d + 1)) & 1u) ? 1.f : alpha);
+    o[d] = pack16x2<F16>(lo, hi);
+  }
+  return __builtin_bit_cast(bf16x8, o);
+}
 
 // bit j = (element j > 0) of the 16 packed 16-bit values in (a, b) (a positive bf16 / f16 is a positive int16 pattern)
 __device__ __forceinline__ unsigned sign_bits16(u32x4 a, u32x4 b) {
@@ -218,8 +245,9 @@ template <int KH, int KC, int BN, int MT, bool UPCAT = false, int MODE = 0, bool
 __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                         const float* __restrict__ bias, bf16* __restrict__ y,
                                                         const TileGeom g) {
-  constexpr bool STATS = MODE == 1, POOL = MODE == 2, UPBWD = MODE == 3;
+  constexpr bool STATS = MODE == 1, POOL = MODE == 2, UPBWD = MODE == 3, UNPOOL = MODE == 4;
   static_assert(!(UPBWD && UPCAT), "UPBWD is a backward-data mode: its input is the plain output gradient");
+  static_assert(!(UNPOOL && UPCAT), "UNPOOL is a backward-data mode: its input is the pooled gradient + sign bytes");
   constexpr int KW = KH, NT = KH * KW;
   constexpr int TW = 16, TH = 8 * MT;
   constexpr int HWX = TW + KW - 1, HH = TH + KH - 1;
@@ -249,7 +277,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
   const int ox0 = tx * TW, oy0 = ty * TH;
   const int n0 = blockIdx.y * BN;
   const int c1 = g.cin - g.c0;
-  const size_t img_elems = UPCAT ? (size_t)(g.h / 2) * (g.w / 2) * g.c0 : (size_t)g.h * g.w * g.cin;
+  const size_t img_elems = UPCAT ? (size_t)(g.h / 2) * (g.w / 2) * g.c0
+                                 : UNPOOL ? (size_t)(g.h / 2) * (g.w / 2) * g.cin : (size_t)g.h * g.w * g.cin;
   // UPBWD: a "skip" block (output channels >= c0) belongs to skip image `img` and reads nsrc gy images
   const bool skip_blk = UPBWD && n0 >= g.c0;
   unsigned srcpk = 0;
@@ -260,7 +289,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
       nsrc = upbwd_sources(g, img, &srcpk);
     }
   }
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (size_t)img * img_elems, (unsigned)(img_elems * 2));
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc((UNPOOL ? g.up_src : x) + (size_t)img * img_elems, (unsigned)(img_elems * 2));
+  const size_t sign_bytes = (size_t)g.h * g.w * (g.cin >> 3);      // UNPOOL: one byte per 8 channels
+  const __amdgpu_buffer_rsrc_t rsg = make_rsrc(UNPOOL ? g.up_signs + (size_t)img * sign_bytes : (const unsigned char*)x,
+                                               UNPOOL ? (unsigned)sign_bytes : 0u);
   const size_t img1_elems = (size_t)g.h * g.w * c1;
   const int img1 = (UPCAT && g.gsz) ? (int)((g.perm >> (8 * (img / g.gsz))) & 0xffu) * g.gsz + img % g.gsz : img;
   const __amdgpu_buffer_rsrc_t rx1 =
@@ -270,7 +302,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
 
   // ---- per-thread staging slots (compile-time trip counts, constant divisors); byte offsets
   unsigned a_goff[ASLOTS];     // inside the image at chunk 0, or OOB (zero fill: border / unused slot)
-  unsigned a_goff1[UPCAT ? ASLOTS : 1];      // UPCAT: the same pixel in the skip tensor
+  unsigned a_goff1[(UPCAT || UNPOOL) ? ASLOTS : 1];      // UPCAT: the same pixel in the skip tensor; UNPOOL: its sign byte
   int a_loff[ASLOTS];
 #pragma unroll
   for (int s = 0; s < ASLOTS; ++s) {
@@ -283,6 +315,9 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
     if constexpr (UPCAT) {
       a_goff[s] = ok ? (unsigned)((((iy >> 1) * (g.w >> 1) + (ix >> 1)) * g.c0 + part * 8) * 2) : OOB;
       a_goff1[s] = ok ? (unsigned)(((iy * g.w + ix) * c1 + part * 8) * 2) : OOB;
+    } else if constexpr (UNPOOL) {
+      a_goff[s] = ok ? (unsigned)((((iy >> 1) * (g.w >> 1) + (ix >> 1)) * g.cin + part * 8) * 2) : OOB;
+      a_goff1[s] = ok ? (unsigned)((iy * g.w + ix) * (g.cin >> 3) + part) : OOB;
     } else {
       a_goff[s] = ok ? (unsigned)(((iy * g.w + ix) * g.cin + part * 8) * 2) : OOB;
     }
@@ -315,6 +350,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
   // NOTE: a cin that is not a multiple of 16 (the 264-channel minibatch-stddev tensor) makes the last
   // chunk read 8 channels of the NEXT pixel; the weight pack is zero there, so they contribute 0.
   bf16x8 ra[ASLOTS], rb[BSLOTS];
+  unsigned rs[UNPOOL ? ASLOTS : 1];      // UNPOOL: the sign byte of each staged vector
   // UPBWD skip blocks: iteration `it` of the K loop is chunk it % nch of source it / nch
   const int nch = g.cin_pad / KC;
   auto load_chunk = [&](int it) {
@@ -333,6 +369,12 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
 #pragma unroll
         for (int s = 0; s < ASLOTS; ++s) ra[s] = buf_load16(rx1, a_goff1[s] + (unsigned)((c0 - g.c0) * 2));
       }
+    } else if constexpr (UNPOOL) {
+#pragma unroll
+      for (int s = 0; s < ASLOTS; ++s) {
+        ra[s] = buf_load16(rx, a_goff[s] + (unsigned)(c0 * 2));
+        rs[s] = buf_load_u8(rsg, a_goff1[s] + (unsigned)(c0 >> 3));
+      }
     } else {
 #pragma unroll
       for (int s = 0; s < ASLOTS; ++s) ra[s] = buf_load16(rx, a_goff[s] + (unsigned)(c0 * 2));
@@ -341,6 +383,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
     for (int s = 0; s < BSLOTS; ++s) rb[s] = buf_load16(rw, b_goff[s] + (unsigned)(c0 * 2));
   };
   auto store_chunk = [&]() {
+    if constexpr (UNPOOL) {      // AvgPoolGrad + LeakyReluGrad on the way into LDS (border slots: 0 stays 0)
+#pragma unroll
+      for (int s = 0; s < ASLOTS; ++s) ra[s] = unpool8<F16>(ra[s], rs[s], g.up_alpha);
+    }
 #pragma unroll
     for (int s = 0; s < ASLOTS; ++s)
       if (s < ASLOTS - 1 || tid + s * 256 < AVEC) *reinterpret_cast<bf16x8*>(sA + a_loff[s]) = ra[s];
@@ -559,6 +605,7 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
   // -- the workgroup walks (skip image, source) pairs, so every gy tile is staged ONCE (the two-block form reads gy twice
   // and runs twice the tile iterations, which is what these thin kernels are bound by)
   constexpr bool STATS = MODE == 1, POOL = MODE == 2, UPBOTH = MODE == 4, UPBWD = MODE == 3 || UPBOTH;
+  constexpr bool UNPOOL = MODE == 5;      // the input tile is built from the pooled gradient + sign bytes (TileGeom::up_src)
   static_assert(!UPBOTH || BN == 64, "UPBOTH: one up block + one skip block");
   constexpr int KW = KH, NT = KH * KW;
   constexpr int TW = 16, TH = 8;
@@ -646,6 +693,7 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
   // 2-D pattern, are what this kernel is short of.
   struct Stage {
     bf16x8 ra[ASLOTS];
+    unsigned rs[UNPOOL ? ASLOTS : 1];      // UNPOOL: the sign byte of each staged vector
   };
   // src (UPBWD skip blocks): which of the tile's source images
   auto load_a = [&](Stage& st, int t, int src = 0) __attribute__((always_inline)) {
@@ -662,6 +710,20 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
         if (ns == 0) live = 0;      // nobody read this skip image: the tile is all zeros
         img = upbwd_source_image(g, img, pk, src);
       }
+    }
+    if constexpr (UNPOOL) {
+      const size_t pool_elems = (size_t)(g.h / 2) * (g.w / 2) * g.cin, sign_bytes = (size_t)g.h * g.w * (g.cin >> 3);
+      const __amdgpu_buffer_rsrc_t rp = make_rsrc(g.up_src + (size_t)img * pool_elems, (unsigned)(pool_elems * 2));
+      const __amdgpu_buffer_rsrc_t rsg = make_rsrc(g.up_signs + (size_t)img * sign_bytes, (unsigned)sign_bytes);
+#pragma unroll
+      for (int s = 0; s < ASLOTS; ++s) {
+        const int iy = ty * TH + a_hy[s] - g.pad, ix = tx * TW + a_hx[s] - g.pad;
+        const bool ok = live && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
+        const int part = (tid + s * 256) % VPP;
+        st.ra[s] = buf_load16(rp, ok ? (unsigned)((((iy >> 1) * (g.w >> 1) + (ix >> 1)) * g.cin + part * 8) * 2) : OOB);
+        st.rs[s] = buf_load_u8(rsg, ok ? (unsigned)((iy * g.w + ix) * (g.cin >> 3) + part) : OOB);
+      }
+      return;
     }
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (size_t)img * img_elems, (unsigned)(img_elems * 2));
 #pragma unroll
@@ -716,6 +778,10 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
         make_rsrc(y_dropped ? g.ymask + (size_t)img * (out_img >> 3) : (unsigned char*)g.ypool, y_dropped ? (unsigned)(out_img >> 3) : 0u);
     const __amdgpu_buffer_rsrc_t rmask =
         make_rsrc(g.mask ? g.mask + (size_t)img * out_img : y, g.mask ? (unsigned)(out_img * 2) : 0u);
+    if constexpr (UNPOOL) {      // AvgPoolGrad + LeakyReluGrad on the way into LDS (border / dead slots: 0 stays 0)
+#pragma unroll
+      for (int s = 0; s < ASLOTS; ++s) st.ra[s] = unpool8<F16>(st.ra[s], st.rs[s], g.up_alpha);
+    }
     if (!first) __syncthreads();          // everyone finished reading the previous halo
     first = false;
 #pragma unroll
@@ -1004,7 +1070,17 @@ int launch_tile_wres(const TileGeom& g0, const bf16* x, const bf16* wp, const fl
     else if (g.epilogue & TG_EPI_BIAS) TG_WRES_LAUNCH_E(MODE_, 1); \
     else TG_WRES_LAUNCH_E(MODE_, 0);                              \
   } while (0)
-  if (g.up_out || g.skip_out) {
+  if (g.up_src) {
+    if constexpr (KH == 3 && KC == 32 && NCH == 1) {
+      TG_CHECK(g.epilogue == 0 && !g.ypool && !stats && !g.up_out && !g.skip_out && g.cin % 32 == 0, TG_ENOSUP,
+               "conv_tile(wres): the unpooling input comes with the plain / masked epilogue and 32-channel chunks only");
+      tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d,unpool%s>", KH, KC, BN, NCH, fmt);
+      if (g.mask) TG_WRES_LAUNCH_E(5, 2);
+      else TG_WRES_LAUNCH_E(5, 0);
+    } else {
+      TG_CHECK(false, TG_ENOSUP, "conv_tile(wres): the unpooling input is built for 3x3, 32-channel chunks only");
+    }
+  } else if (g.up_out || g.skip_out) {
     if constexpr (KH == 3) {
       TG_CHECK(g.epilogue == 0 && !g.mask && !g.ypool && !stats, TG_ENOSUP, "conv_tile(wres): the concat backward comes with the plain epilogue only");
       if constexpr (BN == 64) {
@@ -1062,7 +1138,7 @@ int launch_tile_variant(const TileGeom& g, size_t lds, const bf16* x, const bf16
     }
   }
   // names as before for the bf16 kernels (tests/golden/bench_dispatch_kernels.json); ",f16" marks the half instantiation
-  static const char* const mode_tag[4] = {"", ",stats", ",pool", ",upbwd"};
+  static const char* const mode_tag[5] = {"", ",stats", ",pool", ",upbwd", ",unpool"};
   if (F16 && MODE == 0 && !UPCAT) tg_note_kernel("conv_tile_kernel<%d,%d,%d,%d,f16>", KH, KC, BN, MT);
   else tg_note_kernel("conv_tile_kernel<%d,%d,%d,%d%s%s%s>", KH, KC, BN, MT, UPCAT ? ",upcat" : "", mode_tag[MODE], F16 ? ",f16" : "");
   hipLaunchKernelGGL(kern, dim3(g.nblk, (g.cout + BN - 1) / BN), dim3(256), lds, s, x, wp, bias, y, g);
@@ -1082,6 +1158,16 @@ int launch_tile(const TileGeom& g0, const bf16* x, const bf16* wp, const float* 
   if (g.chunks_query) {
     *g.chunks_query = (KH == 3) ? g.tiles_x * g.tiles_y : 0;
     return TG_OK;
+  }
+  if (g.up_src) {
+    if constexpr (KH == 3 && !UPCAT && KC == 32) {
+      TG_CHECK(g.epilogue == 0 && !g.stats && !g.ypool && !g.up_out && !g.skip_out && g.cin % 32 == 0, TG_ENOSUP,
+               "conv_tile: the unpooling input comes with the plain / masked epilogue and 32-channel chunks only");
+      return g.f16 ? launch_tile_variant<KH, KC, BN, MT, false, 4, true>(g, lds, x, wp, bias, y, s)
+                   : launch_tile_variant<KH, KC, BN, MT, false, 4, false>(g, lds, x, wp, bias, y, s);
+    } else {
+      TG_CHECK(false, TG_ENOSUP, "conv_tile: the unpooling input is built for plain 3x3 backward-data with 32-channel chunks only");
+    }
   }
   if (g.up_out || g.skip_out) {
     if constexpr (KH == 3 && !UPCAT) {
@@ -1160,7 +1246,7 @@ int dispatch_tile(const TileGeom& g, const bf16* x, const bf16* wp, const float*
   // thin layers with many tiles: weights resident in LDS, several tiles per workgroup
   static const bool stats_wide_tile = getenv("TG_STATS_WIDE_TILE") != nullptr;      // A/B switch
   const bool skip_wres = stats_wide_tile && wide && (g.stats || g.chunks_query);
-  if (tiles1 >= 2048 && !skip_wres) {
+  if (tiles1 >= 2048 && !skip_wres && !(g.up_src && g.cin_pad != 32)) {
     if (g.cin_pad == 16) return wide ? launch_tile_wres<KH, 16, 64, 1>(g, x, wp, bias, y, s) : launch_tile_wres<KH, 16, 32, 1>(g, x, wp, bias, y, s);
     if (g.cin_pad == 32) return wide ? launch_tile_wres<KH, 32, 64, 1>(g, x, wp, bias, y, s) : launch_tile_wres<KH, 32, 32, 1>(g, x, wp, bias, y, s);
   }
@@ -1184,7 +1270,8 @@ bool tg_conv_tile_supported(int h, int w, int hout, int wout, int kh, int kw, in
 
 int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int epilogue, float alpha, const void* x,
                      const void* wp, const float* bias, void* y, hipStream_t s, const void* mask, float* stats,
-                     int stat_chunks, int* chunks_query, void* ypool, void* ymask) {
+                     int stat_chunks, int* chunks_query, void* ypool, void* ymask, const void* up_src, const void* up_signs,
+                     float up_alpha) {
   TileGeom g;
   g.n = n; g.h = h; g.w = w; g.cin = cin; g.cout = cout;
   g.cin_pad = (cin + 15) / 16 * 16;
@@ -1203,6 +1290,9 @@ int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int
   g.ymask = (unsigned char*)ymask;
   g.up_out = g.skip_out = nullptr;
   g.n1 = 0;
+  g.up_src = (const bf16*)up_src;
+  g.up_signs = (const unsigned char*)up_signs;
+  g.up_alpha = up_alpha;
   g.f16 = tg_elem_f16();      // the descriptor's dtype, noted by the C-ABI entry point
   if (k == 1) return dispatch_tile<1>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
   return dispatch_tile<3>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
@@ -1236,6 +1326,9 @@ int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gs
   g.ymask = nullptr;
   g.up_out = g.skip_out = nullptr;
   g.n1 = 0;
+  g.up_src = nullptr;
+  g.up_signs = nullptr;
+  g.up_alpha = 0.f;
   g.f16 = tg_elem_f16();
   return dispatch_tile_upcat(g, (const bf16*)x0, (const bf16*)wp, nullptr, (bf16*)y, s);
 }
@@ -1265,6 +1358,9 @@ int tg_conv_tile_upcat_bwd_run(int n, int h, int w, int c0, int c1, int cout, in
   g.up_out = (bf16*)g0;
   g.skip_out = (bf16*)g1;
   g.n1 = n1;
+  g.up_src = nullptr;
+  g.up_signs = nullptr;
+  g.up_alpha = 0.f;
   g.f16 = tg_elem_f16();
   return dispatch_tile_upbwd(g, (const bf16*)gy, (const bf16*)wp, s);
 }

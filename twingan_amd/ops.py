@@ -602,6 +602,32 @@ def conv_bwd_data_masked_raw(gy, w, x_act, spec):
   return gx
 
 
+# backward-data of a discriminator block's last conv straight from the pooled gradient + the layer's sign bytes
+# (tg_conv2d_bwd_data_unpool) wherever the layer's filter gradient is not needed (TG_DGRAD_UNPOOL=0: the two-launch path)
+USE_DGRAD_UNPOOL = os.environ.get('TG_DGRAD_UNPOOL', '1') != '0'
+
+
+def conv_bwd_data_unpool_raw(gzp, signs, w, x_act, x_shape, spec):
+  """gx = conv^T(unpool_lrelu(gzp, signs), w) [* mask(x_act)] without the full-resolution gradient in memory, or None when
+  the kernels do not take the layer.  ``gzp`` [n, h/2, w/2, cout]: gradient of the pooled output; ``signs`` [n, h, w, cout/8]
+  uint8 (conv_fwd_pool_signs_raw); ``x_act``: the conv's forward input when the producer's LeakyReLU backward is folded in
+  (as conv_bwd_data_masked_raw), else None."""
+  _chk(gzp, signs, w, x_act)
+  d = _desc(x_shape, w.shape[3], spec, gzp.dtype, 0)
+  if d.algo != TG_ALGO_MFMA or not _lib.load().tg_conv2d_bwd_data_unpool_supported(ctypes.byref(d)):
+    return None
+  gx = torch.empty(tuple(x_shape), dtype=gzp.dtype, device=gzp.device)
+  wk = PackCache.get(w, d, 1)
+
+  def work():      # reads: a quarter of the gradient tensor + its sign bytes (+ the mask); the tensor itself is never moved
+    tag, fl, by = _conv_work(d, 'dgrad', _esize(gzp))
+    full = d.n * d.hout * d.wout * d.cout * _esize(gzp)
+    return (tag.replace('dgrad:', 'dgrad_unpool:'), fl,
+            by - full + _nb(gzp) + signs.numel() + (_nb(x_act) if x_act is not None else 0))
+  call('tg_conv2d_bwd_data_unpool', ctypes.byref(d), _p(gzp), _p(signs), _p(wk), _p(x_act), _p(gx), _stream(), work=work)
+  return gx
+
+
 def conv_fwd_masked_raw(x, w, mask_src, spec):
   """y = conv(x, w) * (mask_src > 0 ? 1 : alpha): a forward conv with the LeakyReLU derivative of ``mask_src`` (the shape
   of y) in its epilogue (tg_conv2d_fwd_masked) -- the second backward pass of the gradient penalty."""
@@ -808,6 +834,12 @@ def _conv_backward(ctx, gz, gzp=None):
   elif pooled_lrelu is not None:
     g = pooled_lrelu
   elif getattr(ctx, 'tg_signs', False):      # z holds the sign bits of the layer's output (Conv2dPoolSignsFn)
+    if (USE_DGRAD_UNPOOL and not need_w and not need_b and ctx.needs_input_grad[0] and not torch.is_grad_enabled()):
+      # nothing but the backward-data reads this layer's gradient (a generator step: the discriminator's parameters are
+      # not trained): it is formed from the pooled gradient and the sign bytes inside that kernel
+      gx = conv_bwd_data_unpool_raw(gzp, z, w, x if getattr(ctx, 'mask_input', False) else None, tuple(x.shape), spec)
+      if gx is not None:
+        return gx, None, None, None, None, None
     g, gb = lrelu_pool_bwd_signs(gzp, z, spec.alpha, bias if need_b else None, need_b)
     need_b = False
   elif ctx.epilogue & TG_EPI_LRELU:
