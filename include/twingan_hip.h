@@ -128,12 +128,13 @@ int tg_conv2d_bwd_data_masked(const TgConvDesc* d, const void* gy, const void* w
  * (AvgPoolGrad + LeakyReluGrad, what tg_lrelu_pool_bwd_signs writes) is formed while the kernel stages its input tiles and
  * is never in memory.  gy_pooled [n,hout/2,wout/2,cout]; y_signs [n,hout,wout,cout/8] bytes from tg_conv2d_fwd_pool_signs;
  * x_act (may be NULL): as in tg_conv2d_bwd_data_masked; w: pack of mode 1.  gx is bit-identical to the two-launch path.
- * tg_conv2d_bwd_data_unpool_supported(d) != 0: the layer is one the kernels take (3x3 SAME on the tile kernels' maps,
- * cout % 32 == 0, 16-bit storage); callers keep the two-launch path otherwise, and whenever the layer's filter gradient
- * needs gy itself. */
+ * gy_out (may be NULL): [n,hout,wout,cout] -- the kernel also WRITES gy (each element once, from the tile that owns the pixel),
+ * for the layer's filter / bias gradient in a discriminator step: the tg_lrelu_pool_bwd_signs launch and this kernel's read of
+ * its output are still gone.  tg_conv2d_bwd_data_unpool_supported(d) != 0: the layer is one the kernels take (3x3 SAME on the
+ * tile kernels' maps, cout % 32 == 0, 16-bit storage); callers keep the two-launch path otherwise. */
 int tg_conv2d_bwd_data_unpool_supported(const TgConvDesc* d);
 int tg_conv2d_bwd_data_unpool(const TgConvDesc* d, const void* gy_pooled, const void* y_signs, const void* w, const void* x_act,
-                              void* gx, void* stream);
+                              void* gx, void* gy_out, void* stream);
 /* The adjoint of that node, as the gradient penalty's second backward pass needs it (image_generation.py:414-439: the
  * backward of tf.gradients(pred, interp)): y = conv(x, w) * (mask_src > 0 ? 1 : d->lrelu_alpha) with mask_src [n,hout,
  * wout,cout] -- the forward conv of the incoming cotangent with the LeakyReLU mask of the NEXT node of that pass in its

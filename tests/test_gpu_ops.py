@@ -1492,6 +1492,10 @@ def test_unpool_backward_data_equals_the_two_launch_path(ops, dtype, case):
   sym = _lib.load().tg_last_kernel().decode()
   assert sym == (want if dtype == torch.bfloat16 else want.replace('unpool', 'unpool,f16')), sym
   assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
+  # keep mode (a discriminator step): the same kernel also writes the gradient tensor itself, each element exactly once
+  got2, g2w = O.conv_bwd_data_unpool_raw(gzp, signs, w, x if masked else None, (n, hw, hw, cin), spec, True)
+  assert _lib.load().tg_last_kernel().decode() == sym
+  assert torch.equal(got2, ref) and torch.equal(g2w, g2), float((g2w.float() - g2.float()).abs().max())
   if n * hw * hw * cout <= 1 << 21:      # the float64 oracle on the small cases
     bits = ((signs.to(torch.int32).unsqueeze(-1) >> torch.arange(8, dtype=torch.int32, device=signs.device)) & 1).reshape(n, hw, hw, cout)
     up = host(gzp).repeat(2, axis=1).repeat(2, axis=2) * 0.25 * np.where(host(bits) > 0, 1.0, 0.2)
@@ -1503,30 +1507,45 @@ def test_unpool_backward_data_equals_the_two_launch_path(ops, dtype, case):
     assert rel_l2(host(got), want_gx) < (4e-3 if dtype == torch.bfloat16 else 5e-4)
 
 
-def test_generator_step_backward_through_a_block_end_uses_the_unpool_kernel(ops):
-  """A discriminator block end differentiated for its INPUT only (a generator step: the discriminator's parameters are
-  frozen): conv2d(pool_only=True) then backpropagates through tg_conv2d_bwd_data_unpool and the gradient equals the
-  two-launch path's (TG_DGRAD_UNPOOL=0) bit for bit."""
+@pytest.mark.parametrize('train_d', [False, True])
+def test_backward_through_a_block_end_uses_the_unpool_kernel(ops, train_d):
+  """A discriminator block end: conv2d(pool_only=True) backpropagates through tg_conv2d_bwd_data_unpool -- differentiated for
+  its INPUT only (a generator step: the discriminator's parameters are frozen) the layer's gradient is never in memory;
+  with the filter and bias gradients wanted too (a discriminator step) the same kernel writes it for them.  Every gradient
+  equals the two-launch path's (TG_DGRAD_UNPOOL=0): the input gradient bit for bit, the parameter gradients to fp32
+  summation order."""
   import twingan_amd.ops as O
   g = torch.Generator().manual_seed(41)
   n, hw, cin, cout = 2, 32, 32, 64
   x0 = torch.randn(n, hw, hw, cin, generator=g).bfloat16().to(dev())
-  w = (torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev())
-  b = (torch.randn(cout, generator=g) * 0.1).to(dev())
+  w0 = (torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev())
+  b0 = (torch.randn(cout, generator=g) * 0.1).to(dev())
   gz = torch.randn(n, hw // 2, hw // 2, cout, generator=g).bfloat16().to(dev())
-  res = {}
+  res, used = {}, []
+  real = O.conv_bwd_data_unpool_raw
+
+  def counted(*a, **k):
+    out = real(*a, **k)
+    used.append(out is not None)
+    return out
   saved = O.USE_DGRAD_UNPOOL
+  O.conv_bwd_data_unpool_raw = counted
   try:
     for on in (True, False):
       O.USE_DGRAD_UNPOOL = on
       x = x0.clone().requires_grad_(True)
+      w, b = w0.clone().requires_grad_(train_d), b0.clone().requires_grad_(train_d)
       out = O.conv2d(x, w, b, 3, 'SAME', lrelu=True, pool=True, pool_only=True)
       zp = out[1] if isinstance(out, tuple) else out
       zp.backward(gz)
-      res[on] = x.grad
+      res[on] = (x.grad, w.grad, b.grad)
   finally:
     O.USE_DGRAD_UNPOOL = saved
-  assert torch.equal(res[True], res[False])
+    O.conv_bwd_data_unpool_raw = real
+  assert used == [True]
+  assert torch.equal(res[True][0], res[False][0])
+  if train_d:
+    assert rel_l2(host(res[True][1]), host(res[False][1])) < 1e-5 and rel_l2(host(res[True][2]), host(res[False][2])) < 1e-5
 
 
 # ------------------------------------------------------------------------- sign bits instead of a pooled layer's output

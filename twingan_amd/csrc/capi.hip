@@ -45,7 +45,8 @@ size_t tg_conv2d_bwd_weight_workspace_direct(const TgConvDesc*);
 int tg_conv2d_fwd_mfma(const TgConvDesc*, const void*, const void*, const float*, void*, hipStream_t);
 int tg_conv2d_bwd_data_mfma(const TgConvDesc*, const void*, const void*, void*, hipStream_t, const void* mask = nullptr);
 bool tg_conv2d_bwd_data_unpool_supported_mfma(const TgConvDesc*);
-int tg_conv2d_bwd_data_unpool_mfma(const TgConvDesc*, const void*, const void*, const void*, void*, hipStream_t, const void* mask);
+int tg_conv2d_bwd_data_unpool_mfma(const TgConvDesc*, const void*, const void*, const void*, void*, hipStream_t, const void* mask,
+                                   void* gy_out);
 bool tg_conv2d_bwd_data_mask_fusable_mfma(const TgConvDesc*);
 bool tg_conv2d_fwd_mask_fusable_mfma(const TgConvDesc*);
 int tg_conv2d_fwd_masked_mfma(const TgConvDesc*, const void*, const void*, const void*, void*, hipStream_t);
@@ -190,14 +191,15 @@ int tg_conv2d_bwd_data_unpool_supported(const TgConvDesc* d) {
 }
 
 int tg_conv2d_bwd_data_unpool(const TgConvDesc* d, const void* gy_pooled, const void* y_signs, const void* w, const void* x_act,
-                              void* gx, void* stream) {
+                              void* gx, void* gy_out, void* stream) {
   int rc = check_desc("tg_conv2d_bwd_data_unpool", d);
   if (rc) return rc;
   TG_CHECK(gy_pooled && y_signs && w && gx, TG_EINVAL, "tg_conv2d_bwd_data_unpool: null pointer");
-  TG_CHECK(tg_aligned16(gy_pooled) && tg_aligned16(w) && tg_aligned16(gx) && (!x_act || tg_aligned16(x_act)), TG_EALIGN,
-           "tg_conv2d_bwd_data_unpool: pointers must be 16 B aligned");
+  TG_CHECK(tg_aligned16(gy_pooled) && tg_aligned16(w) && tg_aligned16(gx) && (!x_act || tg_aligned16(x_act)) &&
+               (!gy_out || tg_aligned16(gy_out)),
+           TG_EALIGN, "tg_conv2d_bwd_data_unpool: pointers must be 16 B aligned");
   TG_CHECK(d->algo != TG_ALGO_DIRECT, TG_ENOSUP, "tg_conv2d_bwd_data_unpool: MFMA path only (tg_conv2d_bwd_data_unpool_supported)");
-  return tg_conv2d_bwd_data_unpool_mfma(d, gy_pooled, y_signs, w, gx, (hipStream_t)stream, x_act);
+  return tg_conv2d_bwd_data_unpool_mfma(d, gy_pooled, y_signs, w, gx, (hipStream_t)stream, x_act, gy_out);
 }
 
 size_t tg_conv2d_bwd_weight_workspace(const TgConvDesc* d) {

@@ -73,6 +73,11 @@ struct TileGeom {
   const bf16* up_src;
   const unsigned char* up_signs;
   float up_alpha;
+  // ... and, when the layer's filter gradient needs that gradient tensor after all (a discriminator step), the kernel also
+  // WRITES it: up_store [n,h,w,cin] receives every staged vector that is an interior pixel of its tile, from the workgroups
+  // of output-channel block 0 (tiles partition the image, so each element is written exactly once) -- the separate
+  // tg_lrelu_pool_bwd_signs launch and this kernel's read of its output are gone.  NULL: not written.
+  bf16* up_store;
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
@@ -303,6 +308,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
   // ---- per-thread staging slots (compile-time trip counts, constant divisors); byte offsets
   unsigned a_goff[ASLOTS];     // inside the image at chunk 0, or OOB (zero fill: border / unused slot)
   unsigned a_goff1[(UPCAT || UNPOOL) ? ASLOTS : 1];      // UPCAT: the same pixel in the skip tensor; UNPOOL: its sign byte
+  unsigned a_soff[UNPOOL ? ASLOTS : 1];                  // UNPOOL: where the staged vector goes in up_store (OOB: nowhere)
   int a_loff[ASLOTS];
 #pragma unroll
   for (int s = 0; s < ASLOTS; ++s) {
@@ -318,6 +324,9 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
     } else if constexpr (UNPOOL) {
       a_goff[s] = ok ? (unsigned)((((iy >> 1) * (g.w >> 1) + (ix >> 1)) * g.cin + part * 8) * 2) : OOB;
       a_goff1[s] = ok ? (unsigned)((iy * g.w + ix) * (g.cin >> 3) + part) : OOB;
+      // interior pixels of the tile (the halo ring belongs to the neighbours): where the staged vector is also written
+      const bool own = ok && hy >= g.pad && hy < g.pad + TH && hx >= g.pad && hx < g.pad + TW;
+      a_soff[s] = own ? (unsigned)(((iy * g.w + ix) * g.cin + part * 8) * 2) : OOB;
     } else {
       a_goff[s] = ok ? (unsigned)(((iy * g.w + ix) * g.cin + part * 8) * 2) : OOB;
     }
@@ -382,10 +391,20 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
 #pragma unroll
     for (int s = 0; s < BSLOTS; ++s) rb[s] = buf_load16(rw, b_goff[s] + (unsigned)(c0 * 2));
   };
-  auto store_chunk = [&]() {
+  const size_t full_img = (size_t)g.h * g.w * g.cin;      // UNPOOL: the (never read) full-resolution gradient image
+  const bool wr_through = UNPOOL && g.up_store != nullptr && n0 == 0;
+  const __amdgpu_buffer_rsrc_t rst = make_rsrc(wr_through ? g.up_store + (size_t)img * full_img : (bf16*)x,
+                                               wr_through ? (unsigned)(full_img * 2) : 0u);
+  auto store_chunk = [&](int it_st) {
+    const int cst = it_st * KC;      // first channel of the chunk being stored
     if constexpr (UNPOOL) {      // AvgPoolGrad + LeakyReluGrad on the way into LDS (border slots: 0 stays 0)
 #pragma unroll
       for (int s = 0; s < ASLOTS; ++s) ra[s] = unpool8<F16>(ra[s], rs[s], g.up_alpha);
+      if (wr_through) {      // uniform
+#pragma unroll
+        for (int s = 0; s < ASLOTS; ++s)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ra[s]), rst, a_soff[s] + (unsigned)(cst * 2), 0, TG_STORE_AUX);
+      }
     }
 #pragma unroll
     for (int s = 0; s < ASLOTS; ++s)
@@ -399,7 +418,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
   load_chunk(0);
   for (int it = 0; it < nit; ++it) {
     if (it) __syncthreads();             // everyone is done reading the previous chunk
-    store_chunk();
+    store_chunk(it);
     __syncthreads();
     if (it + 1 < nit) load_chunk(it + 1);     // in flight during the MFMAs below
     // K steps of this chunk: (tap, 16-channel half).  The fragments of step s+1 are read from LDS before the MFMAs of
@@ -781,6 +800,17 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
     if constexpr (UNPOOL) {      // AvgPoolGrad + LeakyReluGrad on the way into LDS (border / dead slots: 0 stays 0)
 #pragma unroll
       for (int s = 0; s < ASLOTS; ++s) st.ra[s] = unpool8<F16>(st.ra[s], st.rs[s], g.up_alpha);
+      if (g.up_store && n0 == 0) {      // uniform: the interior pixels of this tile also go to the gradient tensor itself
+        const __amdgpu_buffer_rsrc_t rst = make_rsrc(g.up_store + (size_t)img * img_elems, (unsigned)(img_elems * 2));
+#pragma unroll
+        for (int s = 0; s < ASLOTS; ++s) {
+          const int iy = ty * TH + a_hy[s] - g.pad, ix = tx * TW + a_hx[s] - g.pad;
+          const bool own = a_hy[s] >= g.pad && a_hy[s] < g.pad + TH && a_hx[s] >= g.pad && a_hx[s] < g.pad + TW;
+          const int part8 = ((tid + s * 256) % VPP) * 8;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, st.ra[s]), rst,
+                                                 own ? (unsigned)(((iy * g.w + ix) * g.cin + part8) * 2) : OOB, 0, TG_STORE_AUX);
+        }
+      }
     }
     if (!first) __syncthreads();          // everyone finished reading the previous halo
     first = false;
@@ -1271,7 +1301,7 @@ bool tg_conv_tile_supported(int h, int w, int hout, int wout, int kh, int kw, in
 int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int epilogue, float alpha, const void* x,
                      const void* wp, const float* bias, void* y, hipStream_t s, const void* mask, float* stats,
                      int stat_chunks, int* chunks_query, void* ypool, void* ymask, const void* up_src, const void* up_signs,
-                     float up_alpha) {
+                     float up_alpha, void* up_store) {
   TileGeom g;
   g.n = n; g.h = h; g.w = w; g.cin = cin; g.cout = cout;
   g.cin_pad = (cin + 15) / 16 * 16;
@@ -1293,6 +1323,7 @@ int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int
   g.up_src = (const bf16*)up_src;
   g.up_signs = (const unsigned char*)up_signs;
   g.up_alpha = up_alpha;
+  g.up_store = (bf16*)up_store;
   g.f16 = tg_elem_f16();      // the descriptor's dtype, noted by the C-ABI entry point
   if (k == 1) return dispatch_tile<1>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
   return dispatch_tile<3>(g, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, s);
@@ -1329,6 +1360,7 @@ int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gs
   g.up_src = nullptr;
   g.up_signs = nullptr;
   g.up_alpha = 0.f;
+  g.up_store = nullptr;
   g.f16 = tg_elem_f16();
   return dispatch_tile_upcat(g, (const bf16*)x0, (const bf16*)wp, nullptr, (bf16*)y, s);
 }
@@ -1361,6 +1393,7 @@ int tg_conv_tile_upcat_bwd_run(int n, int h, int w, int c0, int c1, int cout, in
   g.up_src = nullptr;
   g.up_signs = nullptr;
   g.up_alpha = 0.f;
+  g.up_store = nullptr;
   g.f16 = tg_elem_f16();
   return dispatch_tile_upbwd(g, (const bf16*)gy, (const bf16*)wp, s);
 }

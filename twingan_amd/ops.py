@@ -605,27 +605,32 @@ def conv_bwd_data_masked_raw(gy, w, x_act, spec):
 # backward-data of a discriminator block's last conv straight from the pooled gradient + the layer's sign bytes
 # (tg_conv2d_bwd_data_unpool) wherever the layer's filter gradient is not needed (TG_DGRAD_UNPOOL=0: the two-launch path)
 USE_DGRAD_UNPOOL = os.environ.get('TG_DGRAD_UNPOOL', '1') != '0'
+# ... and where the filter / bias gradient does need that tensor (a discriminator step), the same kernel writes it
+# (TG_DGRAD_UNPOOL_KEEP=0: tg_lrelu_pool_bwd_signs + the plain backward-data there)
+USE_DGRAD_UNPOOL_KEEP = os.environ.get('TG_DGRAD_UNPOOL_KEEP', '1') != '0'
 
 
-def conv_bwd_data_unpool_raw(gzp, signs, w, x_act, x_shape, spec):
-  """gx = conv^T(unpool_lrelu(gzp, signs), w) [* mask(x_act)] without the full-resolution gradient in memory, or None when
-  the kernels do not take the layer.  ``gzp`` [n, h/2, w/2, cout]: gradient of the pooled output; ``signs`` [n, h, w, cout/8]
-  uint8 (conv_fwd_pool_signs_raw); ``x_act``: the conv's forward input when the producer's LeakyReLU backward is folded in
-  (as conv_bwd_data_masked_raw), else None."""
+def conv_bwd_data_unpool_raw(gzp, signs, w, x_act, x_shape, spec, keep=False):
+  """gx = conv^T(unpool_lrelu(gzp, signs), w) [* mask(x_act)] without reading the full-resolution gradient from memory, or
+  None when the kernels do not take the layer.  ``gzp`` [n, h/2, w/2, cout]: gradient of the pooled output; ``signs``
+  [n, h, w, cout/8] uint8 (conv_fwd_pool_signs_raw); ``x_act``: the conv's forward input when the producer's LeakyReLU
+  backward is folded in (as conv_bwd_data_masked_raw), else None.  ``keep``: -> (gx, g) with g = unpool_lrelu(gzp, signs)
+  [n, h, w, cout] written by the same kernel (for the layer's filter / bias gradient)."""
   _chk(gzp, signs, w, x_act)
   d = _desc(x_shape, w.shape[3], spec, gzp.dtype, 0)
   if d.algo != TG_ALGO_MFMA or not _lib.load().tg_conv2d_bwd_data_unpool_supported(ctypes.byref(d)):
     return None
   gx = torch.empty(tuple(x_shape), dtype=gzp.dtype, device=gzp.device)
+  g = torch.empty((d.n, d.hout, d.wout, d.cout), dtype=gzp.dtype, device=gzp.device) if keep else None
   wk = PackCache.get(w, d, 1)
 
-  def work():      # reads: a quarter of the gradient tensor + its sign bytes (+ the mask); the tensor itself is never moved
+  def work():      # reads: a quarter of the gradient tensor + its sign bytes (+ the mask); the tensor itself is at most written
     tag, fl, by = _conv_work(d, 'dgrad', _esize(gzp))
     full = d.n * d.hout * d.wout * d.cout * _esize(gzp)
-    return (tag.replace('dgrad:', 'dgrad_unpool:'), fl,
-            by - full + _nb(gzp) + signs.numel() + (_nb(x_act) if x_act is not None else 0))
-  call('tg_conv2d_bwd_data_unpool', ctypes.byref(d), _p(gzp), _p(signs), _p(wk), _p(x_act), _p(gx), _stream(), work=work)
-  return gx
+    return (tag.replace('dgrad:', 'dgrad_unpool_keep:' if keep else 'dgrad_unpool:'), fl,
+            by - (0 if keep else full) + _nb(gzp) + signs.numel() + (_nb(x_act) if x_act is not None else 0))
+  call('tg_conv2d_bwd_data_unpool', ctypes.byref(d), _p(gzp), _p(signs), _p(wk), _p(x_act), _p(gx), _p(g), _stream(), work=work)
+  return (gx, g) if keep else gx
 
 
 def conv_fwd_masked_raw(x, w, mask_src, spec):
@@ -815,6 +820,7 @@ def _conv_backward(ctx, gz, gzp=None):
   premasked = bool(ctx.epilogue & TG_EPI_LRELU) and gzp is None and getattr(ctx, 'tg_premasked', False)
   bias_sink = None
   pooled_lrelu = None
+  gx_done = None      # the input gradient when the branch below already ran the backward-data (the unpooling kernel)
   if gzp is not None and not fused:
     if gz is None and (ctx.epilogue & TG_EPI_LRELU):
       # create_graph pass over a pooled LeakyReLU layer: unpool + mask in one differentiable node
@@ -834,14 +840,23 @@ def _conv_backward(ctx, gz, gzp=None):
   elif pooled_lrelu is not None:
     g = pooled_lrelu
   elif getattr(ctx, 'tg_signs', False):      # z holds the sign bits of the layer's output (Conv2dPoolSignsFn)
-    if (USE_DGRAD_UNPOOL and not need_w and not need_b and ctx.needs_input_grad[0] and not torch.is_grad_enabled()):
-      # nothing but the backward-data reads this layer's gradient (a generator step: the discriminator's parameters are
-      # not trained): it is formed from the pooled gradient and the sign bytes inside that kernel
-      gx = conv_bwd_data_unpool_raw(gzp, z, w, x if getattr(ctx, 'mask_input', False) else None, tuple(x.shape), spec)
-      if gx is not None:
-        return gx, None, None, None, None, None
-    g, gb = lrelu_pool_bwd_signs(gzp, z, spec.alpha, bias if need_b else None, need_b)
-    need_b = False
+    if USE_DGRAD_UNPOOL and ctx.needs_input_grad[0] and not torch.is_grad_enabled():
+      # this layer's gradient is formed from the pooled gradient and the sign bytes inside the backward-data kernel.  A
+      # generator step (the discriminator's parameters are not trained): nothing else reads it and it is never in memory;
+      # a discriminator step: the same kernel writes it for the filter / bias gradient
+      keep = need_w or need_b
+      if not keep or USE_DGRAD_UNPOOL_KEEP:
+        out = conv_bwd_data_unpool_raw(gzp, z, w, x if getattr(ctx, 'mask_input', False) else None, tuple(x.shape), spec, keep)
+        if out is not None and not keep:
+          return out, None, None, None, None, None
+        if out is not None:
+          gx_done, g = out
+    if gx_done is None:
+      g, gb = lrelu_pool_bwd_signs(gzp, z, spec.alpha, bias if need_b else None, need_b)
+      need_b = False
+    elif need_b and need_w and GradSink.get(bias) is not None and GradSink.get(w) is not None and not deterministic():
+      bias_sink = GradSink.get(bias)      # the filter-gradient kernel sums g over pixels as well
+      need_b = False
   elif ctx.epilogue & TG_EPI_LRELU:
     if fused and (need_b or gzp is not None):
       g, gb = lrelu_pool_bwd(gz, gzp, z, spec.alpha, bias if need_b else None, need_b)
@@ -850,8 +865,10 @@ def _conv_backward(ctx, gz, gzp=None):
       g = LReluBwdFn.apply(gz, z, spec.alpha)
   else:
     g = gz
-  gx = None
-  if ctx.needs_input_grad[0]:
+  gx = gx_done
+  if gx is not None:
+    pass
+  elif ctx.needs_input_grad[0]:
     if getattr(ctx, 'mask_input', False):      # x = the producer's LeakyReLU output
       if torch.is_grad_enabled():
         # the node that produced g masks the cotangent it gets back from us with THIS layer's LeakyReLU output z: when
