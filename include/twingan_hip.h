@@ -135,6 +135,11 @@ int tg_conv2d_bwd_data_masked(const TgConvDesc* d, const void* gy, const void* w
 int tg_conv2d_bwd_data_unpool_supported(const TgConvDesc* d);
 int tg_conv2d_bwd_data_unpool(const TgConvDesc* d, const void* gy_pooled, const void* y_signs, const void* w, const void* x_act,
                               void* gx, void* gy_out, void* stream);
+/* The same for a pass that kept the layer's activation output y_act [n,hout,wout,cout] instead of its sign bytes (the
+ * gradient-penalty pass, image_generation.py:414-439, whose second differentiation reads y_act): bit j = (y_act > 0),
+ * i.e. gy = what tg_lrelu_pool_bwd writes from (gy_pooled, y_act). */
+int tg_conv2d_bwd_data_unpool_act(const TgConvDesc* d, const void* gy_pooled, const void* y_act, const void* w, const void* x_act,
+                                  void* gx, void* gy_out, void* stream);
 /* The adjoint of that node, as the gradient penalty's second backward pass needs it (image_generation.py:414-439: the
  * backward of tf.gradients(pred, interp)): y = conv(x, w) * (mask_src > 0 ? 1 : d->lrelu_alpha) with mask_src [n,hout,
  * wout,cout] -- the forward conv of the incoming cotangent with the LeakyReLU mask of the NEXT node of that pass in its

@@ -1496,6 +1496,14 @@ def test_unpool_backward_data_equals_the_two_launch_path(ops, dtype, case):
   got2, g2w = O.conv_bwd_data_unpool_raw(gzp, signs, w, x if masked else None, (n, hw, hw, cin), spec, True)
   assert _lib.load().tg_last_kernel().decode() == sym
   assert torch.equal(got2, ref) and torch.equal(g2w, g2), float((g2w.float() - g2.float()).abs().max())
+  # the signs taken from the activation tensor itself (a pass that kept it): same kernels, 'unpoolz'
+  zact = torch.randn(n, hw, hw, cout, generator=g).to(dtype).to(dev())
+  zact[0, 0, :, :4] = 0.0                                                        # exact zeros count as "not positive"
+  g3, _ = O.lrelu_pool_bwd(None, gzp, zact, spec.alpha, None, False)
+  ref3 = O.conv_bwd_data_masked_raw(g3, w, x, spec) if masked else O.conv_bwd_data_raw(g3, w, (n, hw, hw, cin), spec)
+  got3, g3w = O.conv_bwd_data_unpool_raw(gzp, zact, w, x if masked else None, (n, hw, hw, cin), spec, True)
+  assert _lib.load().tg_last_kernel().decode() == sym.replace('unpool', 'unpoolz')
+  assert torch.equal(got3, ref3) and torch.equal(g3w, g3)
   if n * hw * hw * cout <= 1 << 21:      # the float64 oracle on the small cases
     bits = ((signs.to(torch.int32).unsqueeze(-1) >> torch.arange(8, dtype=torch.int32, device=signs.device)) & 1).reshape(n, hw, hw, cout)
     up = host(gzp).repeat(2, axis=1).repeat(2, axis=2) * 0.25 * np.where(host(bits) > 0, 1.0, 0.2)

@@ -50,6 +50,7 @@ SIGNATURES = {
     'tg_conv2d_fwd_masked': (c_int, [_D, _P, _P, _P, _P, _P]),
     'tg_conv2d_bwd_data_unpool_supported': (c_int, [_D]),
     'tg_conv2d_bwd_data_unpool': (c_int, [_D, _P, _P, _P, _P, _P, _P, _P]),
+    'tg_conv2d_bwd_data_unpool_act': (c_int, [_D, _P, _P, _P, _P, _P, _P, _P]),
     'tg_conv2d_bwd_weight_workspace': (c_size_t, [_D]),
     'tg_conv2d_bwd_weight': (c_int, [_D, _P, _P, _FP, c_int, _P, c_size_t, _P]),
     'tg_conv2d_bwd_weight2_workspace': (c_size_t, [_D, c_int]),

@@ -46,7 +46,7 @@ int tg_conv2d_fwd_mfma(const TgConvDesc*, const void*, const void*, const float*
 int tg_conv2d_bwd_data_mfma(const TgConvDesc*, const void*, const void*, void*, hipStream_t, const void* mask = nullptr);
 bool tg_conv2d_bwd_data_unpool_supported_mfma(const TgConvDesc*);
 int tg_conv2d_bwd_data_unpool_mfma(const TgConvDesc*, const void*, const void*, const void*, void*, hipStream_t, const void* mask,
-                                   void* gy_out);
+                                   void* gy_out, const void* y_act);
 bool tg_conv2d_bwd_data_mask_fusable_mfma(const TgConvDesc*);
 bool tg_conv2d_fwd_mask_fusable_mfma(const TgConvDesc*);
 int tg_conv2d_fwd_masked_mfma(const TgConvDesc*, const void*, const void*, const void*, void*, hipStream_t);
@@ -199,7 +199,19 @@ int tg_conv2d_bwd_data_unpool(const TgConvDesc* d, const void* gy_pooled, const 
                (!gy_out || tg_aligned16(gy_out)),
            TG_EALIGN, "tg_conv2d_bwd_data_unpool: pointers must be 16 B aligned");
   TG_CHECK(d->algo != TG_ALGO_DIRECT, TG_ENOSUP, "tg_conv2d_bwd_data_unpool: MFMA path only (tg_conv2d_bwd_data_unpool_supported)");
-  return tg_conv2d_bwd_data_unpool_mfma(d, gy_pooled, y_signs, w, gx, (hipStream_t)stream, x_act, gy_out);
+  return tg_conv2d_bwd_data_unpool_mfma(d, gy_pooled, y_signs, w, gx, (hipStream_t)stream, x_act, gy_out, nullptr);
+}
+
+int tg_conv2d_bwd_data_unpool_act(const TgConvDesc* d, const void* gy_pooled, const void* y_act, const void* w, const void* x_act,
+                                  void* gx, void* gy_out, void* stream) {
+  int rc = check_desc("tg_conv2d_bwd_data_unpool_act", d);
+  if (rc) return rc;
+  TG_CHECK(gy_pooled && y_act && w && gx, TG_EINVAL, "tg_conv2d_bwd_data_unpool_act: null pointer");
+  TG_CHECK(tg_aligned16(gy_pooled) && tg_aligned16(y_act) && tg_aligned16(w) && tg_aligned16(gx) && (!x_act || tg_aligned16(x_act)) &&
+               (!gy_out || tg_aligned16(gy_out)),
+           TG_EALIGN, "tg_conv2d_bwd_data_unpool_act: pointers must be 16 B aligned");
+  TG_CHECK(d->algo != TG_ALGO_DIRECT, TG_ENOSUP, "tg_conv2d_bwd_data_unpool_act: MFMA path only (tg_conv2d_bwd_data_unpool_supported)");
+  return tg_conv2d_bwd_data_unpool_mfma(d, gy_pooled, nullptr, w, gx, (hipStream_t)stream, x_act, gy_out, y_act);
 }
 
 size_t tg_conv2d_bwd_weight_workspace(const TgConvDesc* d) {

@@ -565,7 +565,7 @@ int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int
                      const void* wp, const float* bias, void* y, hipStream_t s, const void* mask = nullptr,
                      float* stats = nullptr, int stat_chunks = 0, int* chunks_query = nullptr, void* ypool = nullptr,
                      void* ymask = nullptr, const void* up_src = nullptr, const void* up_signs = nullptr, float up_alpha = 0.f,
-                     void* up_store = nullptr);
+                     void* up_store = nullptr, const void* up_z = nullptr);
 
 // Forward conv that also writes the 2x2 average pool of its output (conv_tile.hip POOL kernels): 3x3 SAME, even h / w,
 // shapes the tile kernels take
@@ -727,12 +727,12 @@ bool tg_conv2d_bwd_data_unpool_supported_mfma(const TgConvDesc* d0) {
 }
 
 int tg_conv2d_bwd_data_unpool_mfma(const TgConvDesc* d, const void* gy_pooled, const void* y_signs, const void* wp, void* gx,
-                                   hipStream_t s, const void* mask, void* gy_out) {
+                                   hipStream_t s, const void* mask, void* gy_out, const void* y_act) {
   TG_CHECK(tg_conv2d_bwd_data_unpool_supported_mfma(d), TG_ENOSUP, "tg_conv2d_bwd_data_unpool: not built for this layer");
   TG_CHECK(!mask || tg_conv2d_bwd_data_mask_fusable_mfma(d), TG_ENOSUP, "tg_conv2d_bwd_data_unpool: mask not fusable here");
   return tg_conv_tile_run(d->n, d->hout, d->wout, d->cout, d->cin, d->kh, d->kh - 1 - d->pad_t, 0, mask ? d->lrelu_alpha : 1.f,
                           nullptr, wp, nullptr, gx, s, mask, nullptr, 0, nullptr, nullptr, nullptr, gy_pooled, y_signs,
-                          d->lrelu_alpha, gy_out);
+                          d->lrelu_alpha, gy_out, y_act);
 }
 
 static void wgrad_split(const Geom& g, int* n_ci, int* n_co, int* nslices, int* tiles_per_block, int* total_tiles) {

@@ -72,6 +72,8 @@ struct TileGeom {
   // 1/4 + 1/16 of the tensor's bytes and the tensor itself is neither written nor read (nets/pggan.py:304-306).
   const bf16* up_src;
   const unsigned char* up_signs;
+  const bf16* up_z;      // UNPOOL-Z kernels: the layer's activation output itself [n,h,w,cin] instead of its sign bytes (passes that
+                         // kept it: the gradient penalty's, nets/pggan.py:304-306 under image_generation.py:414-439)
   float up_alpha;
   // ... and, when the layer's filter gradient needs that gradient tensor after all (a discriminator step), the kernel also
   // WRITES it: up_store [n,h,w,cin] receives every staged vector that is an interior pixel of its tile, from the workgroups
@@ -110,6 +112,17 @@ __device__ __forceinline__ void mask4(__amdgpu_buffer_rsrc_t r, unsigned off, fl
 // tg_lrelu_pool_bwd_signs would have written
 __device__ __forceinline__ unsigned buf_load_u8(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r, off, 0, 0);
+}
+// bit j = (element j > 0) of eight 16-bit activations (a positive bf16 / f16 is a positive int16 pattern)
+__device__ __forceinline__ unsigned sign_bits8(bf16x8 z) {
+  const u32x4 u = __builtin_bit_cast(u32x4, z);
+  unsigned m = 0;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    m |= ((short)(u[d] & 0xffffu) > 0 ? 1u : 0u) << (2 * d);
+    m |= ((short)(u[d] >> 16) > 0 ? 1u : 0u) << (2 * d + 1);
+  }
+  return m;
 }
 template <bool F16>
 __device__ __forceinline__ bf16x8 unpool8(bf16x8 q, unsigned bits, float alpha) {
@@ -250,7 +263,7 @@ template <int KH, int KC, int BN, int MT, bool UPCAT = false, int MODE = 0, bool
 __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                         const float* __restrict__ bias, bf16* __restrict__ y,
                                                         const TileGeom g) {
-  constexpr bool STATS = MODE == 1, POOL = MODE == 2, UPBWD = MODE == 3, UNPOOL = MODE == 4;
+  constexpr bool STATS = MODE == 1, POOL = MODE == 2, UPBWD = MODE == 3, UNPOOL = MODE == 4 || MODE == 5, UPZ = MODE == 5;
   static_assert(!(UPBWD && UPCAT), "UPBWD is a backward-data mode: its input is the plain output gradient");
   static_assert(!(UNPOOL && UPCAT), "UNPOOL is a backward-data mode: its input is the pooled gradient + sign bytes");
   constexpr int KW = KH, NT = KH * KW;
@@ -295,9 +308,12 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
     }
   }
   const __amdgpu_buffer_rsrc_t rx = make_rsrc((UNPOOL ? g.up_src : x) + (size_t)img * img_elems, (unsigned)(img_elems * 2));
-  const size_t sign_bytes = (size_t)g.h * g.w * (g.cin >> 3);      // UNPOOL: one byte per 8 channels
-  const __amdgpu_buffer_rsrc_t rsg = make_rsrc(UNPOOL ? g.up_signs + (size_t)img * sign_bytes : (const unsigned char*)x,
-                                               UNPOOL ? (unsigned)sign_bytes : 0u);
+  // UNPOOL: one sign byte per 8 channels; UPZ: the activation tensor itself (16 bytes per 8 channels)
+  const size_t sign_bytes = UPZ ? (size_t)g.h * g.w * g.cin * 2 : (size_t)g.h * g.w * (g.cin >> 3);
+  const __amdgpu_buffer_rsrc_t rsg =
+      make_rsrc(UPZ ? (const unsigned char*)g.up_z + (size_t)img * sign_bytes
+                    : UNPOOL ? g.up_signs + (size_t)img * sign_bytes : (const unsigned char*)x,
+                UNPOOL ? (unsigned)sign_bytes : 0u);
   const size_t img1_elems = (size_t)g.h * g.w * c1;
   const int img1 = (UPCAT && g.gsz) ? (int)((g.perm >> (8 * (img / g.gsz))) & 0xffu) * g.gsz + img % g.gsz : img;
   const __amdgpu_buffer_rsrc_t rx1 =
@@ -323,7 +339,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
       a_goff1[s] = ok ? (unsigned)(((iy * g.w + ix) * c1 + part * 8) * 2) : OOB;
     } else if constexpr (UNPOOL) {
       a_goff[s] = ok ? (unsigned)((((iy >> 1) * (g.w >> 1) + (ix >> 1)) * g.cin + part * 8) * 2) : OOB;
-      a_goff1[s] = ok ? (unsigned)((iy * g.w + ix) * (g.cin >> 3) + part) : OOB;
+      a_goff1[s] = !ok ? OOB : UPZ ? (unsigned)(((iy * g.w + ix) * g.cin + part * 8) * 2) : (unsigned)((iy * g.w + ix) * (g.cin >> 3) + part);
       // interior pixels of the tile (the halo ring belongs to the neighbours): where the staged vector is also written
       const bool own = ok && hy >= g.pad && hy < g.pad + TH && hx >= g.pad && hx < g.pad + TW;
       a_soff[s] = own ? (unsigned)(((iy * g.w + ix) * g.cin + part * 8) * 2) : OOB;
@@ -360,6 +376,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
   // chunk read 8 channels of the NEXT pixel; the weight pack is zero there, so they contribute 0.
   bf16x8 ra[ASLOTS], rb[BSLOTS];
   unsigned rs[UNPOOL ? ASLOTS : 1];      // UNPOOL: the sign byte of each staged vector
+  bf16x8 rz[UPZ ? ASLOTS : 1];           // UPZ: ... or the eight activations it is taken from
   // UPBWD skip blocks: iteration `it` of the K loop is chunk it % nch of source it / nch
   const int nch = g.cin_pad / KC;
   auto load_chunk = [&](int it) {
@@ -382,7 +399,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
 #pragma unroll
       for (int s = 0; s < ASLOTS; ++s) {
         ra[s] = buf_load16(rx, a_goff[s] + (unsigned)(c0 * 2));
-        rs[s] = buf_load_u8(rsg, a_goff1[s] + (unsigned)(c0 >> 3));
+        if constexpr (UPZ) rz[s] = buf_load16(rsg, a_goff1[s] + (unsigned)(c0 * 2));
+        else rs[s] = buf_load_u8(rsg, a_goff1[s] + (unsigned)(c0 >> 3));
       }
     } else {
 #pragma unroll
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
     const int cst = it_st * KC;      // first channel of the chunk being stored
     if constexpr (UNPOOL) {      // AvgPoolGrad + LeakyReluGrad on the way into LDS (border slots: 0 stays 0)
 #pragma unroll
-      for (int s = 0; s < ASLOTS; ++s) ra[s] = unpool8<F16>(ra[s], rs[s], g.up_alpha);
+      for (int s = 0; s < ASLOTS; ++s) ra[s] = unpool8<F16>(ra[s], UPZ ? sign_bits8(rz[s]) : rs[s], g.up_alpha);
       if (wr_through) {      // uniform
 #pragma unroll
         for (int s = 0; s < ASLOTS; ++s)
@@ -624,7 +642,8 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
   // -- the workgroup walks (skip image, source) pairs, so every gy tile is staged ONCE (the two-block form reads gy twice
   // and runs twice the tile iterations, which is what these thin kernels are bound by)
   constexpr bool STATS = MODE == 1, POOL = MODE == 2, UPBOTH = MODE == 4, UPBWD = MODE == 3 || UPBOTH;
-  constexpr bool UNPOOL = MODE == 5;      // the input tile is built from the pooled gradient + sign bytes (TileGeom::up_src)
+  constexpr bool UNPOOL = MODE == 5 || MODE == 6;      // the input tile is built from the pooled gradient + sign bytes (TileGeom::up_src)
+  constexpr bool UPZ = MODE == 6;                      // ... the signs taken from the activation tensor itself (TileGeom::up_z)
   static_assert(!UPBOTH || BN == 64, "UPBOTH: one up block + one skip block");
   constexpr int KW = KH, NT = KH * KW;
   constexpr int TW = 16, TH = 8;
@@ -713,6 +732,7 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
   struct Stage {
     bf16x8 ra[ASLOTS];
     unsigned rs[UNPOOL ? ASLOTS : 1];      // UNPOOL: the sign byte of each staged vector
+    bf16x8 rz[UPZ ? ASLOTS : 1];           // UPZ: ... or the eight activations it is taken from
   };
   // src (UPBWD skip blocks): which of the tile's source images
   auto load_a = [&](Stage& st, int t, int src = 0) __attribute__((always_inline)) {
@@ -733,14 +753,17 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
     if constexpr (UNPOOL) {
       const size_t pool_elems = (size_t)(g.h / 2) * (g.w / 2) * g.cin, sign_bytes = (size_t)g.h * g.w * (g.cin >> 3);
       const __amdgpu_buffer_rsrc_t rp = make_rsrc(g.up_src + (size_t)img * pool_elems, (unsigned)(pool_elems * 2));
-      const __amdgpu_buffer_rsrc_t rsg = make_rsrc(g.up_signs + (size_t)img * sign_bytes, (unsigned)sign_bytes);
+      const __amdgpu_buffer_rsrc_t rsg =
+          UPZ ? make_rsrc(g.up_z + (size_t)img * img_elems, (unsigned)(img_elems * 2))
+              : make_rsrc(g.up_signs + (size_t)img * sign_bytes, (unsigned)sign_bytes);
 #pragma unroll
       for (int s = 0; s < ASLOTS; ++s) {
         const int iy = ty * TH + a_hy[s] - g.pad, ix = tx * TW + a_hx[s] - g.pad;
         const bool ok = live && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
         const int part = (tid + s * 256) % VPP;
         st.ra[s] = buf_load16(rp, ok ? (unsigned)((((iy >> 1) * (g.w >> 1) + (ix >> 1)) * g.cin + part * 8) * 2) : OOB);
-        st.rs[s] = buf_load_u8(rsg, ok ? (unsigned)((iy * g.w + ix) * (g.cin >> 3) + part) : OOB);
+        if constexpr (UPZ) st.rz[s] = buf_load16(rsg, ok ? (unsigned)(((iy * g.w + ix) * g.cin + part * 8) * 2) : OOB);
+        else st.rs[s] = buf_load_u8(rsg, ok ? (unsigned)((iy * g.w + ix) * (g.cin >> 3) + part) : OOB);
       }
       return;
     }
@@ -799,7 +822,7 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
         make_rsrc(g.mask ? g.mask + (size_t)img * out_img : y, g.mask ? (unsigned)(out_img * 2) : 0u);
     if constexpr (UNPOOL) {      // AvgPoolGrad + LeakyReluGrad on the way into LDS (border / dead slots: 0 stays 0)
 #pragma unroll
-      for (int s = 0; s < ASLOTS; ++s) st.ra[s] = unpool8<F16>(st.ra[s], st.rs[s], g.up_alpha);
+      for (int s = 0; s < ASLOTS; ++s) st.ra[s] = unpool8<F16>(st.ra[s], UPZ ? sign_bits8(st.rz[s]) : st.rs[s], g.up_alpha);
       if (g.up_store && n0 == 0) {      // uniform: the interior pixels of this tile also go to the gradient tensor itself
         const __amdgpu_buffer_rsrc_t rst = make_rsrc(g.up_store + (size_t)img * img_elems, (unsigned)(img_elems * 2));
 #pragma unroll
@@ -1104,8 +1127,12 @@ int launch_tile_wres(const TileGeom& g0, const bf16* x, const bf16* wp, const fl
     if constexpr (KH == 3 && KC == 32 && NCH == 1) {
       TG_CHECK(g.epilogue == 0 && !g.ypool && !stats && !g.up_out && !g.skip_out && g.cin % 32 == 0, TG_ENOSUP,
                "conv_tile(wres): the unpooling input comes with the plain / masked epilogue and 32-channel chunks only");
-      tg_note_kernel("conv_tile_wres_kernel<%d,%d,%d,%d,unpool%s>", KH, KC, BN, NCH, fmt);
-      if (g.mask) TG_WRES_LAUNCH_E(5, 2);
+      tg_note_kernel(g.up_z ? "conv_tile_wres_kernel<%d,%d,%d,%d,unpoolz%s>" : "conv_tile_wres_kernel<%d,%d,%d,%d,unpool%s>", KH, KC, BN,
+                     NCH, fmt);
+      if (g.up_z) {
+        if (g.mask) TG_WRES_LAUNCH_E(6, 2);
+        else TG_WRES_LAUNCH_E(6, 0);
+      } else if (g.mask) TG_WRES_LAUNCH_E(5, 2);
       else TG_WRES_LAUNCH_E(5, 0);
     } else {
       TG_CHECK(false, TG_ENOSUP, "conv_tile(wres): the unpooling input is built for 3x3, 32-channel chunks only");
@@ -1168,7 +1195,7 @@ int launch_tile_variant(const TileGeom& g, size_t lds, const bf16* x, const bf16
     }
   }
   // names as before for the bf16 kernels (tests/golden/bench_dispatch_kernels.json); ",f16" marks the half instantiation
-  static const char* const mode_tag[5] = {"", ",stats", ",pool", ",upbwd", ",unpool"};
+  static const char* const mode_tag[6] = {"", ",stats", ",pool", ",upbwd", ",unpool", ",unpoolz"};
   if (F16 && MODE == 0 && !UPCAT) tg_note_kernel("conv_tile_kernel<%d,%d,%d,%d,f16>", KH, KC, BN, MT);
   else tg_note_kernel("conv_tile_kernel<%d,%d,%d,%d%s%s%s>", KH, KC, BN, MT, UPCAT ? ",upcat" : "", mode_tag[MODE], F16 ? ",f16" : "");
   hipLaunchKernelGGL(kern, dim3(g.nblk, (g.cout + BN - 1) / BN), dim3(256), lds, s, x, wp, bias, y, g);
@@ -1193,6 +1220,9 @@ int launch_tile(const TileGeom& g0, const bf16* x, const bf16* wp, const float* 
     if constexpr (KH == 3 && !UPCAT && KC == 32) {
       TG_CHECK(g.epilogue == 0 && !g.stats && !g.ypool && !g.up_out && !g.skip_out && g.cin % 32 == 0, TG_ENOSUP,
                "conv_tile: the unpooling input comes with the plain / masked epilogue and 32-channel chunks only");
+      if (g.up_z)
+        return g.f16 ? launch_tile_variant<KH, KC, BN, MT, false, 5, true>(g, lds, x, wp, bias, y, s)
+                     : launch_tile_variant<KH, KC, BN, MT, false, 5, false>(g, lds, x, wp, bias, y, s);
       return g.f16 ? launch_tile_variant<KH, KC, BN, MT, false, 4, true>(g, lds, x, wp, bias, y, s)
                    : launch_tile_variant<KH, KC, BN, MT, false, 4, false>(g, lds, x, wp, bias, y, s);
     } else {
@@ -1301,7 +1331,7 @@ bool tg_conv_tile_supported(int h, int w, int hout, int wout, int kh, int kw, in
 int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int epilogue, float alpha, const void* x,
                      const void* wp, const float* bias, void* y, hipStream_t s, const void* mask, float* stats,
                      int stat_chunks, int* chunks_query, void* ypool, void* ymask, const void* up_src, const void* up_signs,
-                     float up_alpha, void* up_store) {
+                     float up_alpha, void* up_store, const void* up_z) {
   TileGeom g;
   g.n = n; g.h = h; g.w = w; g.cin = cin; g.cout = cout;
   g.cin_pad = (cin + 15) / 16 * 16;
@@ -1322,6 +1352,7 @@ int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int
   g.n1 = 0;
   g.up_src = (const bf16*)up_src;
   g.up_signs = (const unsigned char*)up_signs;
+  g.up_z = (const bf16*)up_z;
   g.up_alpha = up_alpha;
   g.up_store = (bf16*)up_store;
   g.f16 = tg_elem_f16();      // the descriptor's dtype, noted by the C-ABI entry point
@@ -1359,6 +1390,7 @@ int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gs
   g.n1 = 0;
   g.up_src = nullptr;
   g.up_signs = nullptr;
+  g.up_z = nullptr;
   g.up_alpha = 0.f;
   g.up_store = nullptr;
   g.f16 = tg_elem_f16();
@@ -1392,6 +1424,7 @@ int tg_conv_tile_upcat_bwd_run(int n, int h, int w, int c0, int c1, int cout, in
   g.n1 = n1;
   g.up_src = nullptr;
   g.up_signs = nullptr;
+  g.up_z = nullptr;
   g.up_alpha = 0.f;
   g.up_store = nullptr;
   g.f16 = tg_elem_f16();

@@ -608,6 +608,9 @@ USE_DGRAD_UNPOOL = os.environ.get('TG_DGRAD_UNPOOL', '1') != '0'
 # ... and where the filter / bias gradient does need that tensor (a discriminator step), the same kernel writes it
 # (TG_DGRAD_UNPOOL_KEEP=0: tg_lrelu_pool_bwd_signs + the plain backward-data there)
 USE_DGRAD_UNPOOL_KEEP = os.environ.get('TG_DGRAD_UNPOOL_KEEP', '1') != '0'
+# ... and for block ends that kept their activation output instead of sign bytes (the gradient-penalty pass' nodes in the
+# second differentiation): the signs read from that tensor (TG_DGRAD_UNPOOL_ACT=0: tg_lrelu_pool_bwd + backward-data)
+USE_DGRAD_UNPOOL_ACT = os.environ.get('TG_DGRAD_UNPOOL_ACT', '1') != '0'
 
 
 def conv_bwd_data_unpool_raw(gzp, signs, w, x_act, x_shape, spec, keep=False):
@@ -629,7 +632,9 @@ def conv_bwd_data_unpool_raw(gzp, signs, w, x_act, x_shape, spec, keep=False):
     full = d.n * d.hout * d.wout * d.cout * _esize(gzp)
     return (tag.replace('dgrad:', 'dgrad_unpool_keep:' if keep else 'dgrad_unpool:'), fl,
             by - (0 if keep else full) + _nb(gzp) + signs.numel() + (_nb(x_act) if x_act is not None else 0))
-  call('tg_conv2d_bwd_data_unpool', ctypes.byref(d), _p(gzp), _p(signs), _p(wk), _p(x_act), _p(gx), _p(g), _stream(), work=work)
+  # ``signs`` uint8: the sign bytes; a 16-bit tensor: the layer's activation output itself (a pass that kept it)
+  entry = 'tg_conv2d_bwd_data_unpool' if signs.dtype == torch.uint8 else 'tg_conv2d_bwd_data_unpool_act'
+  call(entry, ctypes.byref(d), _p(gzp), _p(signs), _p(wk), _p(x_act), _p(gx), _p(g), _stream(), work=work)
   return (gx, g) if keep else gx
 
 
@@ -858,7 +863,22 @@ def _conv_backward(ctx, gz, gzp=None):
       bias_sink = GradSink.get(bias)      # the filter-gradient kernel sums g over pixels as well
       need_b = False
   elif ctx.epilogue & TG_EPI_LRELU:
-    if fused and (need_b or gzp is not None):
+    if (fused and gz is None and gzp is not None and USE_DGRAD_UNPOOL and USE_DGRAD_UNPOOL_ACT and ctx.needs_input_grad[0]
+        and z.dtype in HALF_TYPES):
+      # a block end whose activation output was kept (the gradient-penalty pass), differentiated once more: as above, the
+      # signs taken from z itself
+      keep = need_w or need_b
+      out = conv_bwd_data_unpool_raw(gzp, z, w, x if getattr(ctx, 'mask_input', False) else None, tuple(x.shape), spec, keep)
+      if out is not None and not keep:
+        return out, None, None, None, None, None
+      if out is not None:
+        gx_done, g = out
+        if need_b and need_w and GradSink.get(bias) is not None and GradSink.get(w) is not None and not deterministic():
+          bias_sink = GradSink.get(bias)
+          need_b = False
+    if gx_done is not None:
+      pass
+    elif fused and (need_b or gzp is not None):
       g, gb = lrelu_pool_bwd(gz, gzp, z, spec.alpha, bias if need_b else None, need_b)
       need_b = False
     else:
