@@ -944,8 +944,9 @@ def test_lrelu_fold_under_create_graph_matches_unfused(ops, dtype, hw, c1, c2):
   gr = torch.autograd.grad(penr, [pr[0], pr[2], pr[4]])
   want = [gxr.detach().numpy(), penr.detach().reshape(1).numpy()] + [t.numpy() for t in gr]
   rtol = 1e-4 if dtype == torch.float32 else 6e-2
-  for a, b in zip(res[1], want):
-    assert rel_l2(a, b) < rtol, rel_l2(a, b)
+  for r in (res[1], res[2]):
+    for a, b in zip(r, want):
+      assert rel_l2(a, b) < rtol, rel_l2(a, b)
 
 
 @pytest.mark.parametrize('dtype,hw,c1,c2', [(torch.bfloat16, 16, 32, 64), (torch.float32, 8, 8, 8), (torch.bfloat16, 32, 16, 16),
@@ -962,8 +963,10 @@ def test_gradient_penalty_second_pass_masks_in_the_conv_epilogue(ops, monkeypatc
   shapes = [(3, 3, 16, c1), (c1,), (3, 3, c1, c2), (c2,), (3, 3, c2, c2), (c2,), (3, 3, c2, 16), (16,)]
   ws = [(torch.randn(*s, generator=g) * (0.1 if len(s) == 4 else 0.05)).to(dev()) for s in shapes]
   res, launches = [], []
-  for premask in (False, True):
+  # third run: the block end's unpool + mask + masked backward-data as ONE differentiable node (UnpoolMaskedDgradFn)
+  for premask, one_node in ((False, False), (True, False), (True, True)):
     monkeypatch.setattr(ops, 'USE_GP_PREMASK', premask)
+    monkeypatch.setattr(ops, 'USE_DGRAD_UNPOOL_GP', one_node)
     ops.GradSink.clear()
     ps = [t.clone().requires_grad_(True) for t in ws]
     xin = x.clone().requires_grad_(True)
@@ -984,10 +987,23 @@ def test_gradient_penalty_second_pass_masks_in_the_conv_epilogue(ops, monkeypatc
       _lib.profiler = None
     launches.append((names.count('tg_lrelu_bwd'), names.count('tg_conv2d_fwd_masked')))
     res.append([host(gx.detach()), host(pen.detach().reshape(1))] + [host(t) for t in grads])
+    node = gx.grad_fn
+    seen = set()
+    stack = [node]
+    while stack:      # is the one-node form in the graph of the inner gradient exactly when it should be?
+      nd = stack.pop()
+      if nd is None or nd in seen:
+        continue
+      seen.add(nd)
+      stack.extend(f for f, _ in nd.next_functions)
+    has = any('UnpoolMaskedDgradFn' in type(nd).__name__ for nd in seen)
+    assert has == (one_node and dtype != torch.float32 and c2 % 32 == 0), (has, one_node)
   # three masks move into conv epilogues: z1's (into conv 2's node), z2's (conv 3's node), z3-block-end's (the unpool node)
   assert launches[1][1] >= 2 and launches[1][0] <= launches[0][0] - launches[1][1], launches
   tol = 1e-5 if dtype == torch.float32 else 3e-2
   for a, b in zip(res[1], res[0]):
+    assert rel_l2(a, b) < tol, (rel_l2(a, b))
+  for a, b in zip(res[2], res[0]):
     assert rel_l2(a, b) < tol, (rel_l2(a, b))
   import torch.nn.functional as F
   xr = x.double().cpu().requires_grad_(True)

@@ -124,14 +124,17 @@ __device__ __forceinline__ unsigned sign_bits8(bf16x8 z) {
   }
   return m;
 }
+// (0.25 * q) * slope == q * (0.25 * slope): a scaling by a power of two commutes with the rounding of the product (the one
+// difference: q = -0 stays -0 here and became +0 there -- equal as numbers, and as MFMA operands)
 template <bool F16>
 __device__ __forceinline__ bf16x8 unpool8(bf16x8 q, unsigned bits, float alpha) {
   const u32x4 u = __builtin_bit_cast(u32x4, q);
+  const float s1 = 0.25f, sa = 0.25f * alpha;
   u32x4 o;
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
-    const float lo = fmaf(0.25f, unpack16_lo<F16>(u[d]), 0.f) * (((bits >> (2 * d)) & 1u) ? 1.f : alpha);
-    const float hi = fmaf(0.25f, unpack16_hi<F16>(u[d]), 0.f) * (((bits >> (2 * d + 1)) & 1u) ? 1.f : alpha);
+    const float lo = unpack16_lo<F16>(u[d]) * (((bits >> (2 * d)) & 1u) ? s1 : sa);
+    const float hi = unpack16_hi<F16>(u[d]) * (((bits >> (2 * d + 1)) & 1u) ? s1 : sa);
     o[d] = pack16x2<F16>(lo, hi);
   }
   return __builtin_bit_cast(bf16x8, o);

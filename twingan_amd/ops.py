@@ -611,6 +611,9 @@ USE_DGRAD_UNPOOL_KEEP = os.environ.get('TG_DGRAD_UNPOOL_KEEP', '1') != '0'
 # ... and for block ends that kept their activation output instead of sign bytes (the gradient-penalty pass' nodes in the
 # second differentiation): the signs read from that tensor (TG_DGRAD_UNPOOL_ACT=0: tg_lrelu_pool_bwd + backward-data)
 USE_DGRAD_UNPOOL_ACT = os.environ.get('TG_DGRAD_UNPOOL_ACT', '1') != '0'
+# ... and in the gradient penalty's first (create_graph) backward pass: LReluPoolBwdFn + MaskedDgradFn as the one
+# differentiable UnpoolMaskedDgradFn (TG_DGRAD_UNPOOL_GP=0: the two nodes)
+USE_DGRAD_UNPOOL_GP = os.environ.get('TG_DGRAD_UNPOOL_GP', '1') != '0'
 
 
 def conv_bwd_data_unpool_raw(gzp, signs, w, x_act, x_shape, spec, keep=False):
@@ -827,6 +830,15 @@ def _conv_backward(ctx, gz, gzp=None):
   pooled_lrelu = None
   gx_done = None      # the input gradient when the branch below already ran the backward-data (the unpooling kernel)
   if gzp is not None and not fused:
+    if (gz is None and (ctx.epilogue & TG_EPI_LRELU) and USE_DGRAD_UNPOOL and USE_DGRAD_UNPOOL_GP and getattr(ctx, 'mask_input', False)
+        and ctx.needs_input_grad[0] and not need_w and not need_b and z.dtype in HALF_TYPES
+        and _unpool_act_supported(tuple(x.shape), w, spec, z.dtype)):
+      # create_graph pass over a pooled LeakyReLU layer whose input gradient is all that is wanted (the gradient penalty's
+      # inner gradient): unpool + mask + masked backward-data as ONE differentiable node
+      gx = UnpoolMaskedDgradFn.apply(gzp, w, x, z, spec)
+      if gx.grad_fn is not None:
+        gx.grad_fn.tg_masks_with = (x.data_ptr(), tuple(x.shape))      # what this node masks an incoming cotangent with
+      return gx, None, None, None, None, None
     if gz is None and (ctx.epilogue & TG_EPI_LRELU):
       # create_graph pass over a pooled LeakyReLU layer: unpool + mask in one differentiable node
       pooled_lrelu = LReluPoolBwdFn.apply(gzp, z, spec.alpha)
@@ -1046,6 +1058,42 @@ class MaskedDgradFn(torch.autograd.Function):
           ggy = LReluBwdFn.apply(ggy, out_act, ctx.spec.alpha)
     gw = _weight_grad(vm, gy, ctx.spec, w) if (ctx.needs_input_grad[1] and not _State.skip_param_grads) else None
     return ggy, gw, None, None, None
+
+
+class UnpoolMaskedDgradFn(torch.autograd.Function):
+  """gx = conv^T(g, w) * mask(x_act) with g = 0.25 * upsample2(gzp) * mask(z) -- LReluPoolBwdFn followed by MaskedDgradFn as
+  ONE launch (tg_conv2d_bwd_data_unpool_act: g is formed while the backward-data kernel stages its tiles, and written once
+  for the second differentiation), for the gradient penalty's first backward pass through a discriminator block end
+  (image_generation.py:414-439 over nets/pggan.py:304-306).  Linear in gzp and w; its backward is the two nodes' backwards
+  in sequence: v' = v * mask(x_act); d/dgzp = avg_pool2(conv(v', w) * mask(z)) (the mask in the conv's epilogue);
+  d/dw = filter gradient of (v', g)."""
+
+  @staticmethod
+  def forward(ctx, gzp, w, x_act, z, spec):
+    gx, g = conv_bwd_data_unpool_raw(gzp.contiguous(), z, w, x_act, tuple(x_act.shape), spec, True)
+    ctx.spec = spec
+    ctx.save_for_backward(g, w, x_act, z)
+    return gx
+
+  @staticmethod
+  def backward(ctx, v):
+    g, w, x_act, z = ctx.saved_tensors
+    v = v.contiguous()
+    vm = v if getattr(ctx, 'tg_v_premasked', False) else LReluBwdFn.apply(v, x_act, ctx.spec.alpha)
+    ggzp = None
+    if ctx.needs_input_grad[0]:
+      if not torch.is_grad_enabled():
+        t = conv_fwd_masked_raw(vm, w, z, ctx.spec)
+      else:      # a third-order pass: differentiably
+        t = LReluBwdFn.apply(Conv2dFn.apply(vm, w, None, ctx.spec, 0, False), z, ctx.spec.alpha)
+      ggzp = Pool2Fn.apply(t, 0.25)
+    gw = _weight_grad(vm, g, ctx.spec, w) if (ctx.needs_input_grad[1] and not _State.skip_param_grads) else None
+    return ggzp, gw, None, None, None
+
+
+def _unpool_act_supported(x_shape, w, spec, dtype):
+  d = _desc(x_shape, w.shape[3], spec, dtype, 0)
+  return d.algo == TG_ALGO_MFMA and bool(_lib.load().tg_conv2d_bwd_data_unpool_supported(ctypes.byref(d)))
 
 
 class ConvBwdWeightFn(torch.autograd.Function):
