@@ -944,9 +944,8 @@ def test_lrelu_fold_under_create_graph_matches_unfused(ops, dtype, hw, c1, c2):
   gr = torch.autograd.grad(penr, [pr[0], pr[2], pr[4]])
   want = [gxr.detach().numpy(), penr.detach().reshape(1).numpy()] + [t.numpy() for t in gr]
   rtol = 1e-4 if dtype == torch.float32 else 6e-2
-  for r in (res[1], res[2]):
-    for a, b in zip(r, want):
-      assert rel_l2(a, b) < rtol, rel_l2(a, b)
+  for a, b in zip(res[1], want):
+    assert rel_l2(a, b) < rtol, rel_l2(a, b)
 
 
 @pytest.mark.parametrize('dtype,hw,c1,c2', [(torch.bfloat16, 16, 32, 64), (torch.float32, 8, 8, 8), (torch.bfloat16, 32, 16, 16),
@@ -1019,8 +1018,9 @@ def test_gradient_penalty_second_pass_masks_in_the_conv_epilogue(ops, monkeypatc
   gr = torch.autograd.grad(penr, [pr[0], pr[2], pr[4], pr[6]])
   want = [gxr.detach().numpy(), penr.detach().reshape(1).numpy()] + [t.numpy() for t in gr]
   rtol = 1e-4 if dtype == torch.float32 else 1e-1      # four 16-bit layers (the three-layer test above: 6e-2; measured 7.4e-2)
-  for a, b in zip(res[1], want):
-    assert rel_l2(a, b) < rtol, rel_l2(a, b)
+  for r in (res[1], res[2]):
+    for a, b in zip(r, want):
+      assert rel_l2(a, b) < rtol, rel_l2(a, b)
 
 
 @pytest.mark.parametrize('k,cin,cout', [(3, 16, 32), (1, 3, 16), (4, 64, 64), (3, 264, 256), (3, 5, 7)])
