@@ -1767,7 +1767,9 @@ def test_discriminator_sign_bit_path_equals_the_tensor_path(precision):
                                                                if k in tr.store.names(grp)})
       out[signs] = res
       n_sig = seen.count('tg_conv2d_fwd_pool_signs')
-      assert (n_sig > 0) == signs and (seen.count('tg_lrelu_pool_bwd_signs') > 0) == signs, (signs, n_sig)
+      # the backward reads the sign bytes in the block end's own backward-data kernel (round 4) or in tg_lrelu_pool_bwd_signs
+      n_bwd = seen.count('tg_lrelu_pool_bwd_signs') + seen.count('tg_conv2d_bwd_data_unpool')
+      assert (n_sig > 0) == signs and (n_bwd > 0) == signs, (signs, n_sig, n_bwd)
       assert seen.count('tg_conv2d_fwd_pool') > 0      # the gradient-penalty pass keeps the tensor either way
     finally:
       ops.call = orig_call
