@@ -60,7 +60,9 @@ def build(force=False):
   with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
     changed = list(ex.map(compile_one, jobs))
   if any(changed) or not os.path.exists(LIB):
-    subprocess.check_call([CXX, '-shared', '-fPIC'] + [j[1] for j in jobs] + ['-o', LIB])
+    tmp = LIB + '.tmp%d' % os.getpid()      # linked aside, then renamed: processes that have the old file mapped keep it
+    subprocess.check_call([CXX, '-shared', '-fPIC'] + [j[1] for j in jobs] + ['-o', tmp])
+    os.replace(tmp, LIB)
   return LIB
 
 

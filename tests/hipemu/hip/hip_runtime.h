@@ -117,6 +117,15 @@ template <typename V> inline void buffer_store_b128(V val, const Rsrc& r, unsign
     if (off + 4 <= r.bytes) memcpy(r.base + off, b + 4 * i, 4);
   }
 }
+template <typename V> inline void buffer_store_b64(V val, const Rsrc& r, unsigned voff, unsigned soff, int) {
+  static_assert(sizeof(V) == 8, "b64 store");
+  unsigned char b[8];
+  memcpy(b, &val, 8);
+  for (int i = 0; i < 2; ++i) {
+    const uint64_t off = (uint64_t)voff + soff + 4 * i;
+    if (off + 4 <= r.bytes) memcpy(r.base + off, b + 4 * i, 4);
+  }
+}
 inline void buffer_store_b16(short val, const Rsrc& r, unsigned voff, unsigned soff, int) {
   const uint64_t off = (uint64_t)voff + soff;
   if (off + 2 <= r.bytes) memcpy(r.base + off, &val, 2);
@@ -256,6 +265,7 @@ typedef hipemu::Rsrc __amdgpu_buffer_rsrc_t;
 #define __builtin_amdgcn_raw_buffer_load_b64 hipemu::buffer_load_b64
 #define __builtin_amdgcn_raw_buffer_load_b8 hipemu::buffer_load_b8
 #define __builtin_amdgcn_raw_buffer_store_b128 hipemu::buffer_store_b128
+#define __builtin_amdgcn_raw_buffer_store_b64 hipemu::buffer_store_b64
 #define __builtin_amdgcn_raw_buffer_store_b16 hipemu::buffer_store_b16
 #define __builtin_amdgcn_raw_buffer_store_b8 hipemu::buffer_store_b8
 #define __builtin_amdgcn_update_dpp hipemu::update_dpp

@@ -1470,6 +1470,57 @@ def test_flash_attention_second_order(ops, dtype, n, ln, dk, dv):
     assert e < tol and e <= ec * 1.5 + 1e-4, (nm, e, ec)
 
 
+# --------------------------------------------------------------- thin-output kernel (<= 16 output channels, TG_THIN16=1)
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('cin,cout', [(16, 16), (32, 16), (16, 8)])
+def test_thin_output_kernel_matches_the_wide_block_kernels(ops, monkeypatch, dtype, cin, cout):
+  """conv_thin16_kernel (v_mfma_f32_16x16x32, weights in registers; an A/B switch, off by default): forward with bias +
+  LeakyReLU, forward with the statistics epilogue, backward-data with and without the LeakyReLU mask -- against the
+  32-wide-block kernels the dispatch uses otherwise (same products, another summation order inside the MFMA: <= 2e-3) and
+  against the float64 oracle on the same rounded operands."""
+  import twingan_amd.ops as O
+  from twingan_amd import _lib
+  from twingan_amd._lib import TG_EPI_BIAS, TG_EPI_LRELU
+  n, hw = 16, 128      # 2048 tiles: where the dispatch goes to the thin kernels
+  g = torch.Generator().manual_seed(17)
+  x = torch.randn(n, hw, hw, cin, generator=g).to(dtype).to(dev())
+  w = (torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev())
+  b = (torch.randn(cout, generator=g) * 0.1).to(dev())
+  spec = O.ConvSpec(3, 'SAME')
+  f16 = ',f16' if dtype == torch.float16 else ''
+
+  def both(fn):
+    out = []
+    for on in ('0', '1'):
+      monkeypatch.setenv('TG_THIN16', on)
+      out.append((fn(), _lib.load().tg_last_kernel().decode()))
+    monkeypatch.setenv('TG_THIN16', '0')
+    return out
+  (ya, ka), (yb, kb) = both(lambda: O.conv_fwd_raw(x, w, b, spec, TG_EPI_BIAS | TG_EPI_LRELU))
+  assert 'thin16' not in ka and kb == 'conv_thin16_kernel<%d%s>' % (cin, f16), (ka, kb)
+  assert rel_l2(host(yb), host(ya)) < 2e-3
+  rnd = bf16_round if dtype == torch.bfloat16 else f16_round
+  sub = slice(0, 2)      # the oracle on two images
+  ref = N.leaky_relu(N.conv2d(host(x[sub]), rnd(host(w)), 'SAME') + host(b))
+  assert rel_l2(host(yb[sub]), ref) < (6e-3 if dtype == torch.bfloat16 else 8e-4)
+  if cout % 8 == 0:
+    ((y1, s1), k1), ((y2, s2), k2) = both(lambda: O.conv_fwd_stats_raw(x, w, spec))
+    assert k2 == 'conv_thin16_kernel<%d,stats%s>' % (cin, f16), k2
+    assert rel_l2(host(y2), host(y1)) < 2e-3
+    part = s2.part.view(n, s2.chunks, 2, cout).double().sum(dim=1).cpu().numpy()
+    yd = y2.double()
+    want = torch.stack([yd.sum(dim=(1, 2)), (yd * yd).sum(dim=(1, 2))], dim=1).cpu().numpy()
+    assert rel_l2(part, want) < 1e-5      # the partials are sums of THIS tensor
+  if cin <= 16:      # backward-data of this layer writes cin <= 16 channels: thin as well
+    gy = torch.randn(n, hw, hw, cout, generator=g).to(dtype).to(dev())
+    if cout == 16:
+      (ga, _), (gb, k3) = both(lambda: O.conv_bwd_data_masked_raw(gy, w, x, spec))
+      assert k3 == 'conv_thin16_kernel<16%s>' % f16, k3
+      assert rel_l2(host(gb), host(ga)) < 2e-3
+      want_g = N.conv2d_bwd_data(host(gy[sub]), rnd(host(w)), (hw, hw), 'SAME') * np.where(host(x[sub]) > 0, 1.0, 0.2)
+      assert rel_l2(host(gb[sub]), want_g) < (6e-3 if dtype == torch.bfloat16 else 8e-4)
+
+
 # ------------------------------------------------ backward-data of a block's last conv from the pooled gradient + sign bytes
 UNPOOL_CASES = [
     # n, hw, cin, cout, masked, kernel the dispatch picks (bf16 name)

@@ -1078,6 +1078,246 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Thin-OUTPUT variant: 3x3 layers with <= 16 output channels (the 256x256 stage: 16 -> 16 forward with or without the
+// statistics epilogue, the discriminators' first conv, their masked backward-data).  In the 32-wide blocks above half of
+// every MFMA, of every fragment read and of the epilogue is padding there.  Here M = the 16 output channels of
+// v_mfma_f32_16x16x32:
+//   workgroup = 4 waves, tile = 8 rows x 16 cols as above; wave w owns rows 2w, 2w + 1 = two 16-pixel blocks (N = 16);
+//   K = 32 is a PAIR of taps of a 16-channel layer (lane group q = lane / 16: taps (t0, t0, t1, t1), channel halves
+//   (0, 1, 0, 1); the ninth tap pairs with zero weights) or ONE tap of a 32-channel layer (q = its 8-channel quarter);
+//   the weights -- 5 or 9 A fragments, <= 36 VGPRs -- are loaded from the pack ONCE per workgroup and stay in registers: LDS
+//   holds the pixel halo only and is read 10 (18) times 1 KB per wave and tile instead of 18 (36);
+//   accumulators: 4 channels (4q .. 4q+3) of the lane's pixel per block -> 8-byte NHWC stores, four lane groups = the
+//   pixel's 32 bytes.
+// MODE 0: plain (bias / LeakyReLU / mask epilogue), 1: + statistics partials of the rounded outputs (layout of stats_flush).
+// ------------------------------------------------------------------------------------------------
+template <int KC, int MODE, bool F16, int EPI>
+__global__ __launch_bounds__(256) void conv_thin16_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
+                                                          const float* __restrict__ bias, bf16* __restrict__ y,
+                                                          const TileGeom g) {
+  static_assert(KC == 16 || KC == 32, "one 16- or 32-channel chunk");
+  constexpr bool STATS = MODE == 1, HAS_BIAS = (EPI & 1) != 0, HAS_MASK = (EPI & 2) != 0;
+  constexpr int NT = 9, TW = 16, TH = 8, HWX = TW + 2, HH = TH + 2;
+  constexpr int VPP = KC / 8, PS_A = KC * 2 + 16;
+  constexpr int AVEC = HH * HWX * VPP, ASLOTS = (AVEC + 255) / 256;
+  constexpr int NP = KC == 16 ? 5 : 9;      // MFMAs (K = 32) per pixel block: tap pairs / taps
+  unsigned char* sA = tile_smem;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int q = lane >> 4, c16 = lane & 15;
+
+  // ---- the weights: A fragments, row = output channel c16, k = this lane group's 8 channels of its tap
+  const int wrow = NT * g.cin_pad;
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(wp, (unsigned)((size_t)g.cout * wrow * 2));
+  bf16x8 wf[NP];
+  int a_off[NP];      // LDS byte offset of this lane's pixel fragment of MFMA p, relative to its pixel block's origin
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int tap = KC == 16 ? 2 * p + (q >> 1) : p;
+    const int part = KC == 16 ? (q & 1) : q;
+    const bool real = tap < NT && c16 < g.cout;
+    wf[p] = buf_load16(rw, real ? (unsigned)((c16 * wrow + tap * g.cin_pad + part * 8) * 2) : OOB);
+    const int tp = tap < NT ? tap : NT - 1;      // the zero-weight half reads a valid address
+    a_off[p] = ((tp / 3) * HWX + (tp % 3)) * PS_A + part * 16;
+  }
+  const int a_base = ((wid * 2) * HWX + c16) * PS_A;      // + pb * HWX * PS_A + a_off[p]
+
+  // ---- tile-independent staging geometry (as conv_tile_wres_kernel)
+  int a_hy[ASLOTS], a_hx[ASLOTS], a_loff[ASLOTS];
+#pragma unroll
+  for (int s = 0; s < ASLOTS; ++s) {
+    const int v = tid + s * 256;
+    const int px = v / VPP, part = v % VPP;
+    a_hy[s] = (v < AVEC) ? px / HWX : -100000;
+    a_hx[s] = px % HWX;
+    a_loff[s] = px * PS_A + part * 16;
+  }
+  int wg = blockIdx.x;
+  const int nwg = gridDim.x;
+  if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
+  const int t_begin = wg * g.tiles_per_wg;
+  int t_end = t_begin + g.tiles_per_wg;
+  if (t_end > g.nblk) t_end = g.nblk;
+  const size_t img_elems = (size_t)g.h * g.w * g.cin;
+  const size_t out_img = (size_t)g.h * g.w * g.cout;
+
+  struct Stage {
+    bf16x8 ra[ASLOTS];
+  };
+  auto load_a = [&](Stage& st, int t) __attribute__((always_inline)) {
+    const bool live = t < t_end;
+    if (!live) t = t_begin;
+    const int tx = t % g.tiles_x;
+    const int r = t / g.tiles_x;
+    const int ty = r % g.tiles_y;
+    const int img = r / g.tiles_y;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (size_t)img * img_elems, (unsigned)(img_elems * 2));
+#pragma unroll
+    for (int s = 0; s < ASLOTS; ++s) {
+      const int iy = ty * TH + a_hy[s] - g.pad, ix = tx * TW + a_hx[s] - g.pad;
+      const bool ok = live && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
+      const int part8 = ((tid + s * 256) % VPP) * 8;
+      st.ra[s] = buf_load16(rx, ok ? (unsigned)(((iy * g.w + ix) * g.cin + part8) * 2) : OOB);
+    }
+  };
+
+  const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, (HAS_BIAS && (g.epilogue & TG_EPI_BIAS)) ? (unsigned)(g.cout * 4) : 0u);
+  f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (HAS_BIAS) bq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, (unsigned)(q * 16), 0, 0));
+
+  float sacc[STATS ? 8 : 1];      // per lane: sums (0..3) and sums of squares (4..7) of its 4 channels over its pixels
+  if constexpr (STATS) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sacc[i] = 0.f;
+  }
+
+  bool first = true;
+  Stage sa;
+  load_a(sa, t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    const int tx = t % g.tiles_x;
+    const int r = t / g.tiles_x;
+    const int ty = r % g.tiles_y;
+    const int img = r / g.tiles_y;
+    if (!first) __syncthreads();
+    first = false;
+#pragma unroll
+    for (int s = 0; s < ASLOTS; ++s)
+      if (s < ASLOTS - 1 || tid + s * 256 < AVEC) *reinterpret_cast<bf16x8*>(sA + a_loff[s]) = sa.ra[s];
+    __syncthreads();
+    load_a(sa, t + 1);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + (size_t)img * out_img, (unsigned)(out_img * 2));
+    const __amdgpu_buffer_rsrc_t rmask =
+        make_rsrc(g.mask ? g.mask + (size_t)img * out_img : y, g.mask ? (unsigned)(out_img * 2) : 0u);
+    const int ox = tx * TW + c16;
+    u32x2 zm[2];
+    if (HAS_MASK && g.mask) {      // uniform; requested now, lands during the MFMAs
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        const int oy = ty * TH + wid * 2 + pb;
+        zm[pb] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
+            rmask, 4 * q + 4 <= g.cout ? (unsigned)(((oy * g.w + ox) * g.cout + 4 * q) * 2) : OOB, 0, 0));
+      }
+    }
+    f32x4 acc[2];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) acc[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sA + a_base + pb * HWX * PS_A + a_off[p]);
+        acc[pb] = mfma_16x16x32<F16>(wf[p], xf, acc[pb]);
+      }
+    }
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+      const int oy = ty * TH + wid * 2 + pb;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = acc[pb][j];
+        if constexpr (HAS_BIAS) a += bq[j];
+        if (g.epilogue & TG_EPI_LRELU) a = lrelu_f(a, g.alpha);
+        v[j] = a;
+      }
+      if (HAS_MASK && g.mask) {      // uniform: a positive bf16 / f16 is a positive int16 pattern
+        const u32x2 z = zm[pb];
+        v[0] *= (short)(z[0] & 0xffffu) > 0 ? 1.f : g.alpha;
+        v[1] *= (short)(z[0] >> 16) > 0 ? 1.f : g.alpha;
+        v[2] *= (short)(z[1] & 0xffffu) > 0 ? 1.f : g.alpha;
+        v[3] *= (short)(z[1] >> 16) > 0 ? 1.f : g.alpha;
+      }
+      u32x2 o;
+      o[0] = pack16x2<F16>(v[0], v[1]);
+      o[1] = pack16x2<F16>(v[2], v[3]);
+      if constexpr (STATS) {
+        const float r4[4] = {unpack16_lo<F16>(o[0]), unpack16_hi<F16>(o[0]), unpack16_lo<F16>(o[1]), unpack16_hi<F16>(o[1])};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sacc[j] += r4[j];
+          sacc[4 + j] = fmaf(r4[j], r4[j], sacc[4 + j]);
+        }
+      }
+      __builtin_amdgcn_raw_buffer_store_b64(o, ry, 4 * q + 4 <= g.cout ? (unsigned)(((oy * g.w + ox) * g.cout + 4 * q) * 2) : OOB, 0,
+                                            TG_STORE_AUX);
+    }
+  }
+  if constexpr (STATS) {
+    // the 16 lanes of a group hold different pixels of the same 4 channels: butterfly over the pixel bits, then the four
+    // waves through LDS in wave order; out[which][ch] as stats_flush writes it
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) sacc[i] += __shfl_xor(sacc[i], o, 64);
+    }
+    float* red = reinterpret_cast<float*>(sA);      // [wave][which][16]
+    __syncthreads();
+    if (c16 == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        red[(wid * 2 + 0) * 16 + 4 * q + j] = sacc[j];
+        red[(wid * 2 + 1) * 16 + 4 * q + j] = sacc[4 + j];
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int which = tid >> 4, ch = tid & 15;
+      const float tsum = (red[(0 * 2 + which) * 16 + ch] + red[(1 * 2 + which) * 16 + ch]) +
+                         (red[(2 * 2 + which) * 16 + ch] + red[(3 * 2 + which) * 16 + ch]);
+      const int tpi = g.tiles_x * g.tiles_y;
+      float* out = g.stats + ((size_t)(t_begin / tpi) * g.stat_chunks + (t_begin % tpi) / g.tiles_per_wg) * 2 * g.cout;
+      if (ch < g.cout) out[(size_t)which * g.cout + ch] = tsum;
+    }
+  }
+}
+
+// TG_THIN16=1 (A/B switch, off): 3x3 layers with <= 16 output channels and one 16- / 32-channel chunk on conv_thin16_kernel
+inline bool thin16_on() { return tg_tune("TG_THIN16", 0) != 0; }      // read at every call: two captures in one process can differ
+inline bool thin16_takes(const TileGeom& g) {
+  return thin16_on() && g.cout <= 16 && g.cout % 4 == 0 && (g.cin_pad == 16 || g.cin_pad == 32) && g.cin == g.cin_pad && !g.ypool &&
+         !g.up_src && !g.up_out && !g.skip_out && !(g.mask && (g.epilogue & TG_EPI_BIAS));
+}
+
+template <int KC>
+int launch_thin16(const TileGeom& g0, const bf16* x, const bf16* wp, const float* bias, bf16* y, hipStream_t s) {
+  TileGeom g = g0;
+  g.tiles_x = g.w / 16;
+  g.tiles_y = g.h / 8;
+  g.nblk = g.tiles_x * g.tiles_y * g.n;
+  int tpw = g.nblk / (256 * 4);
+  if (tpw < 1) tpw = 1;
+  if (tpw > 16) tpw = 16;
+  const bool stats = g.stats || g.chunks_query;
+  if (stats) {
+    const int tpi = g.tiles_x * g.tiles_y;
+    while (tpi % tpw) --tpw;
+    if (g.chunks_query) {
+      *g.chunks_query = tpi / tpw;
+      return TG_OK;
+    }
+    TG_CHECK(g.stat_chunks == tpi / tpw, TG_EINVAL, "conv_thin16: stat_chunks %d, this dispatch writes %d", g.stat_chunks, tpi / tpw);
+    TG_CHECK(g.epilogue == 0 && !g.mask, TG_ENOSUP, "conv_thin16: statistics come with the plain epilogue only");
+  }
+  g.tiles_per_wg = tpw;
+  const int nwg = (g.nblk + tpw - 1) / tpw;
+  const size_t lds = (size_t)((10 * 18 * (KC * 2 + 16) + 15) & ~15);
+  tg_note_kernel(g.f16 ? "conv_thin16_kernel<%d%s,f16>" : "conv_thin16_kernel<%d%s>", KC, stats ? ",stats" : "");
+#define TG_THIN_LAUNCH(MODE_, EPI_)                                                                                              \
+  do {                                                                                                                           \
+    if (g.f16) hipLaunchKernelGGL((conv_thin16_kernel<KC, MODE_, true, EPI_>), dim3(nwg), dim3(256), lds, s, x, wp, bias, y, g); \
+    else hipLaunchKernelGGL((conv_thin16_kernel<KC, MODE_, false, EPI_>), dim3(nwg), dim3(256), lds, s, x, wp, bias, y, g);     \
+  } while (0)
+  if (stats) TG_THIN_LAUNCH(1, 0);
+  else if (g.mask) TG_THIN_LAUNCH(0, 2);
+  else if (g.epilogue & TG_EPI_BIAS) TG_THIN_LAUNCH(0, 1);
+  else TG_THIN_LAUNCH(0, 0);
+#undef TG_THIN_LAUNCH
+  TG_LAUNCH_CHECK("conv_thin16");
+  return TG_OK;
+}
+
 template <int KH, int KC, int BN, int NCH>
 int launch_tile_wres(const TileGeom& g0, const bf16* x, const bf16* wp, const float* bias, bf16* y, hipStream_t s) {
   TileGeom g = g0;
@@ -1309,6 +1549,9 @@ int dispatch_tile(const TileGeom& g, const bf16* x, const bf16* wp, const float*
   // thin layers with many tiles: weights resident in LDS, several tiles per workgroup
   static const bool stats_wide_tile = getenv("TG_STATS_WIDE_TILE") != nullptr;      // A/B switch
   const bool skip_wres = stats_wide_tile && wide && (g.stats || g.chunks_query);
+  if constexpr (KH == 3) {
+    if (tiles1 >= 2048 && thin16_takes(g)) return g.cin_pad == 16 ? launch_thin16<16>(g, x, wp, bias, y, s) : launch_thin16<32>(g, x, wp, bias, y, s);
+  }
   if (tiles1 >= 2048 && !skip_wres && !(g.up_src && g.cin_pad != 32)) {
     if (g.cin_pad == 16) return wide ? launch_tile_wres<KH, 16, 64, 1>(g, x, wp, bias, y, s) : launch_tile_wres<KH, 16, 32, 1>(g, x, wp, bias, y, s);
     if (g.cin_pad == 32) return wide ? launch_tile_wres<KH, 32, 64, 1>(g, x, wp, bias, y, s) : launch_tile_wres<KH, 32, 32, 1>(g, x, wp, bias, y, s);
