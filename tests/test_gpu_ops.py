@@ -1521,6 +1521,44 @@ def test_thin_output_kernel_matches_the_wide_block_kernels(ops, monkeypatch, dty
       assert rel_l2(host(gb[sub]), want_g) < (6e-3 if dtype == torch.bfloat16 else 8e-4)
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_thin_output_kernel_over_the_concat_input(ops, monkeypatch, dtype):
+  """conv_thin16_upcat_kernel (TG_THIN16=1): the generator's concat conv with 16 outputs -- concat(nearest_up2(x0), skip),
+  32 + 32 channels read in place, groups permuted as the trainer does -- forward with and without the statistics epilogue
+  against the 32-wide-block UPCAT kernels (<= 2e-3: another summation order inside the MFMA)."""
+  from twingan_amd import _lib
+  g = torch.Generator().manual_seed(19)
+  b, h, c0, c1, cout = 4, 64, 32, 32, 16      # 4 groups of 4 images at 128 x 128: 2048 tiles
+  n = 4 * b
+  x0 = torch.randn(n, h, h, c0, generator=g).to(dtype).to(dev())
+  x1 = torch.randn(2 * b, 2 * h, 2 * h, c1, generator=g).to(dtype).to(dev())
+  w = (torch.randn(3, 3, c0 + c1, cout, generator=g) * (2.0 / (9 * (c0 + c1))) ** 0.5).to(dev())
+  f16 = ',f16' if dtype == torch.float16 else ''
+  res = {}
+  for on in ('0', '1'):
+    monkeypatch.setenv('TG_THIN16', on)
+    y_plain = ops.upcat_conv(x0, x1, w, b, (1, 0, 0, 1))
+    k_plain = _lib.load().tg_last_kernel().decode()
+    y, st = ops.upcat_conv_stats(x0, x1, w, b, (1, 0, 0, 1))
+    res[on] = (y_plain, k_plain, y, st, _lib.load().tg_last_kernel().decode())
+  monkeypatch.setenv('TG_THIN16', '0')
+  assert 'thin16' not in res['0'][1] and res['1'][1] == 'conv_thin16_upcat_kernel<plain%s>' % f16, (res['0'][1], res['1'][1])
+  assert res['1'][4] == 'conv_thin16_upcat_kernel<stats%s>' % f16
+  y_plain, _, y, st, _ = res['1']
+  assert st is not None and torch.equal(y, y_plain)
+  assert rel_l2(host(y), host(res['0'][2])) < 2e-3
+  part = st.part.view(n, st.chunks, 2, cout).double().sum(dim=1).cpu().numpy()
+  yd = y.double()
+  want = torch.stack([yd.sum(dim=(1, 2)), (yd * yd).sum(dim=(1, 2))], dim=1).cpu().numpy()
+  assert rel_l2(part, want) < 1e-5
+  # the float64 oracle on the first image of the last group (skip group 1)
+  up = host(x0[3 * b:3 * b + 1]).repeat(2, axis=1).repeat(2, axis=2)
+  cat = np.concatenate([up, host(x1[b:b + 1])], axis=-1)
+  rnd = bf16_round if dtype == torch.bfloat16 else f16_round
+  ref = N.conv2d(cat, rnd(host(w)), 'SAME')
+  assert rel_l2(host(y[3 * b:3 * b + 1]), ref) < (6e-3 if dtype == torch.bfloat16 else 8e-4)
+
+
 # ------------------------------------------------ backward-data of a block's last conv from the pooled gradient + sign bytes
 UNPOOL_CASES = [
     # n, hw, cin, cout, masked, kernel the dispatch picks (bf16 name)

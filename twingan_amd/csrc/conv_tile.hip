@@ -1273,6 +1273,157 @@ __global__ __launch_bounds__(256) void conv_thin16_kernel(const bf16* __restrict
   }
 }
 
+// The same wave program over concat(nearest_up2(x0), x1) with 32 + 32 channels (the generator's 256 x 256 concat conv,
+// nets/pggan.py:69-76): both sources' halos are staged side by side (two LDS images, one barrier per tile), 18 A fragments
+// (9 taps x 2 sources, 72 VGPRs) stay in registers; the sources are read in place as in the UPCAT tile kernels.
+template <bool STATS, bool F16>
+__global__ __launch_bounds__(256) void conv_thin16_upcat_kernel(const bf16* __restrict__ x0, const bf16* __restrict__ wp,
+                                                                bf16* __restrict__ y, const TileGeom g) {
+  constexpr int NT = 9, TW = 16, TH = 8, HWX = TW + 2, HH = TH + 2, KC = 32;
+  constexpr int VPP = KC / 8, PS_A = KC * 2 + 16;
+  constexpr int AVEC = HH * HWX * VPP, ASLOTS = (AVEC + 255) / 256;
+  constexpr int A_BYTES = (HH * HWX * PS_A + 15) & ~15;
+  unsigned char* sA = tile_smem;      // [2 sources][A_BYTES]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int q = lane >> 4, c16 = lane & 15;
+  const int c1 = g.cin - g.c0;      // 32 + 32 (checked by the launcher)
+
+  const int wrow = NT * g.cin_pad;
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(wp, (unsigned)((size_t)g.cout * wrow * 2));
+  bf16x8 wf[2][NT];
+  int a_off[NT];
+#pragma unroll
+  for (int p = 0; p < NT; ++p) {
+#pragma unroll
+    for (int src = 0; src < 2; ++src)
+      wf[src][p] = buf_load16(rw, c16 < g.cout ? (unsigned)((c16 * wrow + p * g.cin_pad + src * KC + q * 8) * 2) : OOB);
+    a_off[p] = ((p / 3) * HWX + (p % 3)) * PS_A + q * 16;
+  }
+  const int a_base = ((wid * 2) * HWX + c16) * PS_A;
+
+  int a_hy[ASLOTS], a_hx[ASLOTS], a_loff[ASLOTS];
+#pragma unroll
+  for (int s = 0; s < ASLOTS; ++s) {
+    const int v = tid + s * 256;
+    const int px = v / VPP, part = v % VPP;
+    a_hy[s] = (v < AVEC) ? px / HWX : -100000;
+    a_hx[s] = px % HWX;
+    a_loff[s] = px * PS_A + part * 16;
+  }
+  int wg = blockIdx.x;
+  const int nwg = gridDim.x;
+  if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
+  const int t_begin = wg * g.tiles_per_wg;
+  int t_end = t_begin + g.tiles_per_wg;
+  if (t_end > g.nblk) t_end = g.nblk;
+  const size_t img0_elems = (size_t)(g.h / 2) * (g.w / 2) * g.c0, img1_elems = (size_t)g.h * g.w * c1;
+  const size_t out_img = (size_t)g.h * g.w * g.cout;
+
+  struct Stage {
+    bf16x8 ra[2][ASLOTS];
+  };
+  auto load_a = [&](Stage& st, int t) __attribute__((always_inline)) {
+    const bool live = t < t_end;
+    if (!live) t = t_begin;
+    const int tx = t % g.tiles_x;
+    const int r = t / g.tiles_x;
+    const int ty = r % g.tiles_y;
+    const int img = r / g.tiles_y;
+    const int img1 = g.gsz ? (int)((g.perm >> (8 * (img / g.gsz))) & 0xffu) * g.gsz + img % g.gsz : img;
+    const __amdgpu_buffer_rsrc_t r0 = make_rsrc(x0 + (size_t)img * img0_elems, (unsigned)(img0_elems * 2));
+    const __amdgpu_buffer_rsrc_t r1 = make_rsrc(g.x1 + (size_t)img1 * img1_elems, (unsigned)(img1_elems * 2));
+#pragma unroll
+    for (int s = 0; s < ASLOTS; ++s) {
+      const int iy = ty * TH + a_hy[s] - g.pad, ix = tx * TW + a_hx[s] - g.pad;
+      const bool ok = live && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
+      const int part8 = ((tid + s * 256) % VPP) * 8;
+      st.ra[0][s] = buf_load16(r0, ok ? (unsigned)((((iy >> 1) * (g.w >> 1) + (ix >> 1)) * g.c0 + part8) * 2) : OOB);
+      st.ra[1][s] = buf_load16(r1, ok ? (unsigned)(((iy * g.w + ix) * c1 + part8) * 2) : OOB);
+    }
+  };
+
+  float sacc[STATS ? 8 : 1];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sacc[i] = 0.f;
+  }
+  bool first = true;
+  Stage sa;
+  load_a(sa, t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    const int tx = t % g.tiles_x;
+    const int r = t / g.tiles_x;
+    const int ty = r % g.tiles_y;
+    const int img = r / g.tiles_y;
+    if (!first) __syncthreads();
+    first = false;
+#pragma unroll
+    for (int src = 0; src < 2; ++src)
+#pragma unroll
+      for (int s = 0; s < ASLOTS; ++s)
+        if (s < ASLOTS - 1 || tid + s * 256 < AVEC) *reinterpret_cast<bf16x8*>(sA + src * A_BYTES + a_loff[s]) = sa.ra[src][s];
+    __syncthreads();
+    load_a(sa, t + 1);
+    f32x4 acc[2];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) acc[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int src = 0; src < 2; ++src)
+#pragma unroll
+      for (int p = 0; p < NT; ++p)
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sA + src * A_BYTES + a_base + pb * HWX * PS_A + a_off[p]);
+          acc[pb] = mfma_16x16x32<F16>(wf[src][p], xf, acc[pb]);
+        }
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + (size_t)img * out_img, (unsigned)(out_img * 2));
+    const int ox = tx * TW + c16;
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+      const int oy = ty * TH + wid * 2 + pb;
+      u32x2 o;
+      o[0] = pack16x2<F16>(acc[pb][0], acc[pb][1]);
+      o[1] = pack16x2<F16>(acc[pb][2], acc[pb][3]);
+      if constexpr (STATS) {
+        const float r4[4] = {unpack16_lo<F16>(o[0]), unpack16_hi<F16>(o[0]), unpack16_lo<F16>(o[1]), unpack16_hi<F16>(o[1])};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sacc[j] += r4[j];
+          sacc[4 + j] = fmaf(r4[j], r4[j], sacc[4 + j]);
+        }
+      }
+      __builtin_amdgcn_raw_buffer_store_b64(o, ry, 4 * q + 4 <= g.cout ? (unsigned)(((oy * g.w + ox) * g.cout + 4 * q) * 2) : OOB, 0,
+                                            TG_STORE_AUX);
+    }
+  }
+  if constexpr (STATS) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) sacc[i] += __shfl_xor(sacc[i], o, 64);
+    }
+    float* red = reinterpret_cast<float*>(sA);
+    __syncthreads();
+    if (c16 == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        red[(wid * 2 + 0) * 16 + 4 * q + j] = sacc[j];
+        red[(wid * 2 + 1) * 16 + 4 * q + j] = sacc[4 + j];
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int which = tid >> 4, ch = tid & 15;
+      const float tsum = (red[(0 * 2 + which) * 16 + ch] + red[(1 * 2 + which) * 16 + ch]) +
+                         (red[(2 * 2 + which) * 16 + ch] + red[(3 * 2 + which) * 16 + ch]);
+      const int tpi = g.tiles_x * g.tiles_y;
+      float* out = g.stats + ((size_t)(t_begin / tpi) * g.stat_chunks + (t_begin % tpi) / g.tiles_per_wg) * 2 * g.cout;
+      if (ch < g.cout) out[(size_t)which * g.cout + ch] = tsum;
+    }
+  }
+}
+
 // TG_THIN16=1 (A/B switch, off): 3x3 layers with <= 16 output channels and one 16- / 32-channel chunk on conv_thin16_kernel
 inline bool thin16_on() { return tg_tune("TG_THIN16", 0) != 0; }      // read at every call: two captures in one process can differ
 inline bool thin16_takes(const TileGeom& g) {
@@ -1315,6 +1466,40 @@ int launch_thin16(const TileGeom& g0, const bf16* x, const bf16* wp, const float
   else TG_THIN_LAUNCH(0, 0);
 #undef TG_THIN_LAUNCH
   TG_LAUNCH_CHECK("conv_thin16");
+  return TG_OK;
+}
+
+int launch_thin16_upcat(const TileGeom& g0, const bf16* x0, const bf16* wp, bf16* y, hipStream_t s) {
+  TileGeom g = g0;
+  g.tiles_x = g.w / 16;
+  g.tiles_y = g.h / 8;
+  g.nblk = g.tiles_x * g.tiles_y * g.n;
+  int tpw = g.nblk / (256 * 4);
+  if (tpw < 1) tpw = 1;
+  if (tpw > 16) tpw = 16;
+  const bool stats = g.stats || g.chunks_query;
+  if (stats) {
+    const int tpi = g.tiles_x * g.tiles_y;
+    while (tpi % tpw) --tpw;
+    if (g.chunks_query) {
+      *g.chunks_query = tpi / tpw;
+      return TG_OK;
+    }
+    TG_CHECK(g.stat_chunks == tpi / tpw, TG_EINVAL, "conv_thin16(upcat): stat_chunks %d, this dispatch writes %d", g.stat_chunks,
+             tpi / tpw);
+  }
+  g.tiles_per_wg = tpw;
+  const int nwg = (g.nblk + tpw - 1) / tpw;
+  const size_t lds = 2 * (size_t)((10 * 18 * (32 * 2 + 16) + 15) & ~15);
+  tg_note_kernel(g.f16 ? "conv_thin16_upcat_kernel<%s,f16>" : "conv_thin16_upcat_kernel<%s>", stats ? "stats" : "plain");
+  if (stats) {
+    if (g.f16) hipLaunchKernelGGL((conv_thin16_upcat_kernel<true, true>), dim3(nwg), dim3(256), lds, s, x0, wp, y, g);
+    else hipLaunchKernelGGL((conv_thin16_upcat_kernel<true, false>), dim3(nwg), dim3(256), lds, s, x0, wp, y, g);
+  } else {
+    if (g.f16) hipLaunchKernelGGL((conv_thin16_upcat_kernel<false, true>), dim3(nwg), dim3(256), lds, s, x0, wp, y, g);
+    else hipLaunchKernelGGL((conv_thin16_upcat_kernel<false, false>), dim3(nwg), dim3(256), lds, s, x0, wp, y, g);
+  }
+  TG_LAUNCH_CHECK("conv_thin16(upcat)");
   return TG_OK;
 }
 
@@ -1507,6 +1692,9 @@ int launch_tile(const TileGeom& g0, const bf16* x, const bf16* wp, const float* 
 
 // forward over concat(nearest_up2(x), x1): 3x3, both channel counts multiples of 32
 int dispatch_tile_upcat(const TileGeom& g, const bf16* x, const bf16* wp, const float* bias, bf16* y, hipStream_t s) {
+  if (thin16_on() && !bias && g.cout <= 16 && g.cout % 4 == 0 && g.c0 == 32 && g.cin - g.c0 == 32 && g.cin_pad == 64 &&
+      (g.w / 16) * (g.h / 8) * g.n >= 2048)
+    return launch_thin16_upcat(g, x, wp, y, s);
   const bool wide = g.cout > 32;
   const int tiles1 = (g.w / 16) * (g.h / 8) * g.n * ((g.cout + (wide ? 63 : 31)) / (wide ? 64 : 32));
   const bool mt2 = (g.h % 16 == 0) && tiles1 >= 2 * 2 * 256;
