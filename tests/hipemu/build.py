@@ -19,7 +19,7 @@ CXX = os.environ.get('HIPEMU_CXX', '/opt/rocm/lib/llvm/bin/clang++')
 # comm.hip (RCCL) is replaced by stubs in emu.cpp
 SOURCES = ['capi', 'conv_direct', 'conv_mfma', 'conv_tile', 'conv_wgrad_tile', 'conv_small', 'conv_img', 'pointwise', 'norm', 'reduce',
            'sn', 'attention', 'preprocess', 'flash']
-FLAGS = ['-std=c++17', '-O1', '-fPIC', '-fno-strict-aliasing', '-w', '-I', HERE, '-I', CSRC, '-DHIPEMU=1']
+FLAGS = ['-std=c++17', '-O1', '-fPIC', '-fno-strict-aliasing', '-fmax-type-align=4', '-w', '-I', HERE, '-I', CSRC, '-DHIPEMU=1']
 
 _DYN = re.compile(r'extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_][A-Za-z0-9_ ]*?)\s+([A-Za-z_][A-Za-z0-9_]*)\[\];')
 

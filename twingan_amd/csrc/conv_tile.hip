@@ -1424,8 +1424,9 @@ __global__ __launch_bounds__(256) void conv_thin16_upcat_kernel(const bf16* __re
   }
 }
 
-// TG_THIN16=1 (A/B switch, off): 3x3 layers with <= 16 output channels and one 16- / 32-channel chunk on conv_thin16_kernel
-inline bool thin16_on() { return tg_tune("TG_THIN16", 0) != 0; }      // read at every call: two captures in one process can differ
+// 3x3 layers with <= 16 output channels and one 16- / 32-channel chunk (or the 32 + 32 concat) go to the thin-output kernels;
+// TG_THIN16=0: the 32-wide-block kernels instead (A/B switch, read at every call: two captures in one process can differ)
+inline bool thin16_on() { return tg_tune("TG_THIN16", 1) != 0; }
 inline bool thin16_takes(const TileGeom& g) {
   return thin16_on() && g.cout <= 16 && g.cout % 4 == 0 && (g.cin_pad == 16 || g.cin_pad == 32) && g.cin == g.cin_pad && !g.ypool &&
          !g.up_src && !g.up_out && !g.skip_out && !(g.mask && (g.epilogue & TG_EPI_BIAS));
