@@ -16,8 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HERE = os.path.join(ROOT, 'tests', 'hipemu')
 
 
-def _run(args, timeout):
-  env = dict(os.environ, TG_EMU='1')
+def _run(args, timeout, **extra):
+  env = dict(os.environ, TG_EMU='1', **extra)
   env.pop('TG_LIB_PATH', None)
   return subprocess.run([sys.executable, '-m', 'pytest', '-m', 'gpu', '-q', '-x', '-p', 'no:cacheprovider', '--tb=short'] + args,
                         cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
@@ -51,3 +51,13 @@ def test_unpooling_backward_data_over_the_emulated_kernels():
   """This round's kernel path, developed against the emulation first: the cases small enough for it."""
   r = _run(['tests/test_gpu_ops.py', '-k', 'unpool and (0-dtype or 1-dtype or 7-dtype or block_end)'], timeout=1500)
   assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_thin_output_kernels_over_the_emulated_kernels():
+  """conv_thin16_kernel (on by default) at the smallest shapes that dispatch it, and the OFF switch TG_THIN16_UNPOOL, whose
+  GPU test is skipped until it has run on hardware."""
+  r = _run(['tests/test_gpu_ops.py', '-n', '2', '-k',
+            '(thin_output_kernel_matches and 16-16-dtype0) or (thin_output_kernel_with_the_unpooling and True-dtype0)'],
+           timeout=2400, TG_TEST_THIN16_UNPOOL='1')
+  assert r.returncode == 0, r.stdout[-3000:]
+  assert ' passed' in r.stdout[-3000:]

@@ -1559,6 +1559,38 @@ def test_thin_output_kernel_over_the_concat_input(ops, monkeypatch, dtype):
   assert rel_l2(host(y[3 * b:3 * b + 1]), ref) < (6e-3 if dtype == torch.bfloat16 else 8e-4)
 
 
+@pytest.mark.skipif(__import__('os').environ.get('TG_TEST_THIN16_UNPOOL') != '1',
+                    reason='TG_THIN16_UNPOOL is an OFF switch built on the emulated kernels after the last GPU minute of round 4: its '
+                           'test has never run on hardware (TG_TEST_THIN16_UNPOOL=1 runs it; the CPU suite does, over the emulation)')
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('masked', [True, False])
+def test_thin_output_kernel_with_the_unpooling_input(ops, monkeypatch, dtype, masked):
+  """TG_THIN16_UNPOOL=1 (an A/B switch, off by default): the 256 x 256 block end's backward-data (32 -> 16 channels) on the
+  thin-output wave program with the unpooling loader -- sign bytes, kept activation, and the write-through of the gradient
+  tensor -- against the 32-wide-block unpooling kernels (the tensor written: the same bits; the input gradient: <= 2e-3)."""
+  import twingan_amd.ops as O
+  from twingan_amd import _lib
+  n, hw, cin, cout = 16, 128, 16, 32
+  g = torch.Generator().manual_seed(23)
+  spec = O.ConvSpec(3, 'SAME')
+  x = torch.randn(n, hw, hw, cin, generator=g).to(dtype).to(dev())
+  w = (torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev())
+  gzp = torch.randn(n, hw // 2, hw // 2, cout, generator=g).to(dtype).to(dev())
+  signs = torch.randint(0, 256, (n, hw, hw, cout // 8), generator=g, dtype=torch.uint8).to(dev())
+  zact = torch.randn(n, hw, hw, cout, generator=g).to(dtype).to(dev())
+  f16 = ',f16' if dtype == torch.float16 else ''
+  for src, tag in ((signs, 'unpool'), (zact, 'unpoolz')):
+    out = {}
+    for on in ('0', '1'):
+      monkeypatch.setenv('TG_THIN16_UNPOOL', on)
+      out[on] = O.conv_bwd_data_unpool_raw(gzp, src, w, x if masked else None, (n, hw, hw, cin), spec, True) + \
+          (_lib.load().tg_last_kernel().decode(),)
+    monkeypatch.setenv('TG_THIN16_UNPOOL', '0')
+    assert 'thin16' not in out['0'][2] and out['1'][2] == 'conv_thin16_kernel<32,%s%s>' % (tag, f16), (out['0'][2], out['1'][2])
+    assert torch.equal(out['1'][1], out['0'][1])      # the gradient tensor written through
+    assert rel_l2(host(out['1'][0]), host(out['0'][0])) < 2e-3
+
+
 # ------------------------------------------------ backward-data of a block's last conv from the pooled gradient + sign bytes
 UNPOOL_CASES = [
     # n, hw, cin, cout, masked, kernel the dispatch picks (bf16 name)

@@ -1092,12 +1092,15 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
 //   pixel's 32 bytes.
 // MODE 0: plain (bias / LeakyReLU / mask epilogue), 1: + statistics partials of the rounded outputs (layout of stats_flush).
 // ------------------------------------------------------------------------------------------------
-template <int KC, int MODE, bool F16, int EPI>
+// UP: the input tile is the unpooled gradient of a block end (TileGeom::up_src, as the UNPOOL tile kernels): 1 = signs from
+// the sign bytes, 2 = from the kept activation tensor; with up_store the interior pixels are written through.
+template <int KC, int MODE, bool F16, int EPI, int UP = 0>
 __global__ __launch_bounds__(256) void conv_thin16_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                           const float* __restrict__ bias, bf16* __restrict__ y,
                                                           const TileGeom g) {
   static_assert(KC == 16 || KC == 32, "one 16- or 32-channel chunk");
-  constexpr bool STATS = MODE == 1, HAS_BIAS = (EPI & 1) != 0, HAS_MASK = (EPI & 2) != 0;
+  static_assert(UP == 0 || KC == 32, "the unpooling input comes in 32-channel chunks");
+  constexpr bool STATS = MODE == 1, HAS_BIAS = (EPI & 1) != 0, HAS_MASK = (EPI & 2) != 0, UPZ = UP == 2;
   constexpr int NT = 9, TW = 16, TH = 8, HWX = TW + 2, HH = TH + 2;
   constexpr int VPP = KC / 8, PS_A = KC * 2 + 16;
   constexpr int AVEC = HH * HWX * VPP, ASLOTS = (AVEC + 255) / 256;
@@ -1144,6 +1147,8 @@ __global__ __launch_bounds__(256) void conv_thin16_kernel(const bf16* __restrict
 
   struct Stage {
     bf16x8 ra[ASLOTS];
+    unsigned rs[UP == 1 ? ASLOTS : 1];
+    bf16x8 rz[UPZ ? ASLOTS : 1];
   };
   auto load_a = [&](Stage& st, int t) __attribute__((always_inline)) {
     const bool live = t < t_end;
@@ -1152,6 +1157,22 @@ __global__ __launch_bounds__(256) void conv_thin16_kernel(const bf16* __restrict
     const int r = t / g.tiles_x;
     const int ty = r % g.tiles_y;
     const int img = r / g.tiles_y;
+    if constexpr (UP != 0) {
+      const size_t pool_elems = (size_t)(g.h / 2) * (g.w / 2) * g.cin, sign_bytes = (size_t)g.h * g.w * (g.cin >> 3);
+      const __amdgpu_buffer_rsrc_t rp = make_rsrc(g.up_src + (size_t)img * pool_elems, (unsigned)(pool_elems * 2));
+      const __amdgpu_buffer_rsrc_t rsg = UPZ ? make_rsrc(g.up_z + (size_t)img * img_elems, (unsigned)(img_elems * 2))
+                                             : make_rsrc(g.up_signs + (size_t)img * sign_bytes, (unsigned)sign_bytes);
+#pragma unroll
+      for (int s = 0; s < ASLOTS; ++s) {
+        const int iy = ty * TH + a_hy[s] - g.pad, ix = tx * TW + a_hx[s] - g.pad;
+        const bool ok = live && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
+        const int part = (tid + s * 256) % VPP;
+        st.ra[s] = buf_load16(rp, ok ? (unsigned)((((iy >> 1) * (g.w >> 1) + (ix >> 1)) * g.cin + part * 8) * 2) : OOB);
+        if constexpr (UPZ) st.rz[s] = buf_load16(rsg, ok ? (unsigned)(((iy * g.w + ix) * g.cin + part * 8) * 2) : OOB);
+        else st.rs[s] = buf_load_u8(rsg, ok ? (unsigned)((iy * g.w + ix) * (g.cin >> 3) + part) : OOB);
+      }
+      return;
+    }
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (size_t)img * img_elems, (unsigned)(img_elems * 2));
 #pragma unroll
     for (int s = 0; s < ASLOTS; ++s) {
@@ -1180,6 +1201,21 @@ __global__ __launch_bounds__(256) void conv_thin16_kernel(const bf16* __restrict
     const int r = t / g.tiles_x;
     const int ty = r % g.tiles_y;
     const int img = r / g.tiles_y;
+    if constexpr (UP != 0) {      // AvgPoolGrad + LeakyReluGrad on the way into LDS; interior pixels written through
+#pragma unroll
+      for (int s = 0; s < ASLOTS; ++s) sa.ra[s] = unpool8<F16>(sa.ra[s], UPZ ? sign_bits8(sa.rz[s]) : sa.rs[s], g.up_alpha);
+      if (g.up_store) {      // uniform
+        const __amdgpu_buffer_rsrc_t rst = make_rsrc(g.up_store + (size_t)img * img_elems, (unsigned)(img_elems * 2));
+#pragma unroll
+        for (int s = 0; s < ASLOTS; ++s) {
+          const int iy = ty * TH + a_hy[s] - g.pad, ix = tx * TW + a_hx[s] - g.pad;
+          const bool own = a_hy[s] >= g.pad && a_hy[s] < g.pad + TH && a_hx[s] >= g.pad && a_hx[s] < g.pad + TW;
+          const int part8 = ((tid + s * 256) % VPP) * 8;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sa.ra[s]), rst,
+                                                 own ? (unsigned)(((iy * g.w + ix) * g.cin + part8) * 2) : OOB, 0, TG_STORE_AUX);
+        }
+      }
+    }
     if (!first) __syncthreads();
     first = false;
 #pragma unroll
@@ -1427,9 +1463,13 @@ __global__ __launch_bounds__(256) void conv_thin16_upcat_kernel(const bf16* __re
 // 3x3 layers with <= 16 output channels and one 16- / 32-channel chunk (or the 32 + 32 concat) go to the thin-output kernels;
 // TG_THIN16=0: the 32-wide-block kernels instead (A/B switch, read at every call: two captures in one process can differ)
 inline bool thin16_on() { return tg_tune("TG_THIN16", 1) != 0; }
+// ... with the unpooling input too (the 256 x 256 block end's backward-data, 32 -> 16 channels): TG_THIN16_UNPOOL=1, an A/B
+// switch that is OFF -- built on the emulated kernels after the round's last GPU minute, never timed
+inline bool thin16_unpool_on() { return tg_tune("TG_THIN16_UNPOOL", 0) != 0; }
 inline bool thin16_takes(const TileGeom& g) {
+  if (g.up_src && !(thin16_unpool_on() && g.cin_pad == 32 && g.epilogue == 0)) return false;
   return thin16_on() && g.cout <= 16 && g.cout % 4 == 0 && (g.cin_pad == 16 || g.cin_pad == 32) && g.cin == g.cin_pad && !g.ypool &&
-         !g.up_src && !g.up_out && !g.skip_out && !(g.mask && (g.epilogue & TG_EPI_BIAS));
+         !g.up_out && !g.skip_out && !(g.mask && (g.epilogue & TG_EPI_BIAS));
 }
 
 template <int KC>
@@ -1455,6 +1495,27 @@ int launch_thin16(const TileGeom& g0, const bf16* x, const bf16* wp, const float
   g.tiles_per_wg = tpw;
   const int nwg = (g.nblk + tpw - 1) / tpw;
   const size_t lds = (size_t)((10 * 18 * (KC * 2 + 16) + 15) & ~15);
+  if (g.up_src) {
+    if constexpr (KC == 32) {
+      TG_CHECK(!stats && !(g.epilogue & TG_EPI_BIAS), TG_ENOSUP, "conv_thin16: the unpooling input comes with the plain / masked epilogue");
+      tg_note_kernel(g.f16 ? "conv_thin16_kernel<32,%s,f16>" : "conv_thin16_kernel<32,%s>", g.up_z ? "unpoolz" : "unpool");
+#define TG_THIN_UP(EPI_, UP_)                                                                                                        \
+  do {                                                                                                                               \
+    if (g.f16) hipLaunchKernelGGL((conv_thin16_kernel<32, 0, true, EPI_, UP_>), dim3(nwg), dim3(256), lds, s, x, wp, bias, y, g);    \
+    else hipLaunchKernelGGL((conv_thin16_kernel<32, 0, false, EPI_, UP_>), dim3(nwg), dim3(256), lds, s, x, wp, bias, y, g);         \
+  } while (0)
+      if (g.up_z) {
+        if (g.mask) TG_THIN_UP(2, 2);
+        else TG_THIN_UP(0, 2);
+      } else if (g.mask) TG_THIN_UP(2, 1);
+      else TG_THIN_UP(0, 1);
+#undef TG_THIN_UP
+      TG_LAUNCH_CHECK("conv_thin16(unpool)");
+      return TG_OK;
+    } else {
+      TG_CHECK(false, TG_ENOSUP, "conv_thin16: the unpooling input comes in 32-channel chunks");
+    }
+  }
   tg_note_kernel(g.f16 ? "conv_thin16_kernel<%d%s,f16>" : "conv_thin16_kernel<%d%s>", KC, stats ? ",stats" : "");
 #define TG_THIN_LAUNCH(MODE_, EPI_)                                                                                              \
   do {                                                                                                                           \
