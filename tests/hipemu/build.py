@@ -19,7 +19,16 @@ CXX = os.environ.get('HIPEMU_CXX', '/opt/rocm/lib/llvm/bin/clang++')
 # comm.hip (RCCL) is replaced by stubs in emu.cpp
 SOURCES = ['capi', 'conv_direct', 'conv_mfma', 'conv_tile', 'conv_wgrad_tile', 'conv_small', 'conv_img', 'pointwise', 'norm', 'reduce',
            'sn', 'attention', 'preprocess', 'flash']
-FLAGS = ['-std=c++17', '-O1', '-fPIC', '-fno-strict-aliasing', '-fmax-type-align=4', '-w', '-I', HERE, '-I', CSRC, '-DHIPEMU=1']
+# -fmax-type-align=4: a 16-byte vector access at a 4-byte-aligned address is legal on the GPU (x86 would fault on movaps);
+# -ffp-contract=fast (+ -mfma where the host has it): hipcc contracts a * b + c into fma by default, and the fp32 parity
+# path's model-level tests sit on LeakyReLU units that one last-bit difference flips
+FLAGS = ['-std=c++17', '-O1', '-fPIC', '-fno-strict-aliasing', '-fmax-type-align=4', '-ffp-contract=fast', '-w', '-I', HERE, '-I', CSRC,
+         '-DHIPEMU=1']
+try:
+  if ' fma ' in open('/proc/cpuinfo').read():
+    FLAGS.insert(6, '-mfma')
+except OSError:
+  pass
 
 _DYN = re.compile(r'extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_][A-Za-z0-9_ ]*?)\s+([A-Za-z_][A-Za-z0-9_]*)\[\];')
 
