@@ -38,7 +38,8 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
       if item.name.split('[')[0] in ('test_adam_kernel_tf_semantics', 'test_adam_device_tick_matches_host_schedule',
                                      'test_errors_are_loud', 'test_rccl_allreduce_wrapper_single_rank') or \
-          os.path.basename(str(item.fspath)) == 'test_gpu_data.py' or 'graph' in item.name or \
+          os.path.basename(str(item.fspath)) == 'test_gpu_data.py' or 'graph_replay' in item.name or \
+          item.name.split('[')[0].endswith('_and_graph') or \
           item.name.startswith(('test_data_parallel_two_clones', 'test_deterministic_mode_makes_16_bit')):
         # the input pipeline asks torch for a GPU itself; hipGraph capture (also inside the determinism test); RCCL
         item.add_marker(no)
