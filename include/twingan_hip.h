@@ -476,6 +476,15 @@ int tg_spectral_norm_fwd(const float* w, const float* u, float* w_bar, float* u_
 int tg_spectral_norm_bwd(const float* g_wbar, const float* w, const float* u, const float* u_new, const float* v,
                          const float* stats, float* gw, int accumulate, int k_rows, int cout, void* ws, size_t ws_bytes,
                          void* stream);
+/* The power iteration of MANY kernels in three launches (the trainer's start-of-run pass under --spectral_norm: 60 matrices
+ * in BASELINE configs[4]).  A job table in device memory: tg_sn_table_bytes(njobs) bytes, filled on the host job by job with
+ * tg_sn_table_fill (arguments as tg_spectral_norm_fwd; `totals` = three running block counts, zeroed before job 0) and copied
+ * to the device by the caller; tg_spectral_norm_fwd_multi(table, njobs, totals[0], totals[1], totals[2]) then computes every
+ * job's w_bar / u_new / v / stats exactly as tg_spectral_norm_fwd would (same kernels' bodies, same summation order). */
+size_t tg_sn_table_bytes(int njobs);
+int tg_sn_table_fill(int j, const float* w, const float* u, float* w_bar, float* u_new, float* v, float* stats, void* ws,
+                     size_t ws_bytes, int k_rows, int cout, void* host_table, int32_t* totals);
+int tg_spectral_norm_fwd_multi(const void* table, int njobs, int row_blocks, int col_blocks, int fin_blocks, void* stream);
 
 /* SAGAN self-attention (libs/self_attention.py:24-70: s = tf.matmul(f, g, transpose_b=True) over the h*w positions,
  * beta = tf.nn.softmax(s), o = tf.matmul(beta, h)) without materialising the [len x len] map: q = f [n, len, dk],

@@ -1047,6 +1047,46 @@ def test_spectral_norm_matches_oracle(ops, k, cin, cout):
   assert rel_l2(host(wd.grad), wt.grad.numpy()) < 5 * F32_TOL
 
 
+@pytest.mark.skipif(__import__('os').environ.get('TG_TEST_SN_MULTI') != '1',
+                    reason='TG_SN_MULTI is an OFF switch built on the emulated kernels after the last GPU minute of round 4: its test '
+                           'has never run on hardware (TG_TEST_SN_MULTI=1 runs it; the CPU suite does, over the emulation)')
+def test_spectral_norm_of_many_kernels_in_three_launches(ops):
+  """tg_spectral_norm_fwd_multi (ops.spectral_norm_multi, TG_SN_MULTI=1): the power iterations of several kernels of
+  different shapes from one job table -- w_bar, u', and the gradients through the per-kernel nodes equal the one-kernel
+  entry point's bit for bit (the same kernel bodies in the same order), also when the table is reused for a second run."""
+  g = torch.Generator().manual_seed(37)
+  shapes = [(3, 3, 16, 32), (1, 1, 3, 16), (4, 4, 64, 64), (3, 3, 264, 256), (3, 3, 5, 7), (3, 3, 128, 40)]
+  ws = [(torch.randn(*sh, generator=g) * 0.1).to(dev()) for sh in shapes]
+  us = [torch.randn(1, sh[3], generator=g).to(dev()) for sh in shapes]
+  gq = [torch.randn(*sh, generator=g).to(dev()) for sh in shapes]
+  outs = [torch.empty(w.numel(), dtype=torch.float32, device=w.device) for w in ws]
+  table = None
+  for run in range(2):
+    single = []
+    for w, u, q in zip(ws, us, gq):
+      wd = w.clone().requires_grad_(True)
+      wb, un = ops.spectral_norm(wd, u)
+      (wb * q).sum().backward()
+      single.append((wb.detach().clone(), un.detach().clone(), wd.grad.clone()))
+    wds = [w.clone().requires_grad_(True) for w in ws]
+    if run == 1:      # the same addresses: the table of run 0 is reused
+      for wd, keep in zip(wds, kept):
+        keep.data.copy_(wd.data)
+      wds = kept
+      for wd in wds:
+        wd.grad = None
+    res, table2 = ops.spectral_norm_multi(list(zip(wds, us, outs)), table)
+    assert run == 0 or table2 is table
+    table, kept = table2, wds
+    loss = sum((wb * q).sum() for (wb, _), q in zip(res, gq))
+    loss.backward()
+    for (wb, un), wd, (wb1, un1, g1) in zip(res, wds, single):
+      assert torch.equal(wb.detach(), wb1) and torch.equal(un.detach().reshape(-1), un1.reshape(-1))
+      assert torch.equal(wd.grad, g1)
+    for u, (_, un) in zip(us, res):      # the next run starts from u', assigned in place as pggan.end_run does
+      u.copy_(un.detach().reshape(1, -1))
+
+
 BGEMM_CASES = [
     # batch, m, n, k     (attention: s = f g^T is (N, N, c/8); o = beta h is (N, c, N); their gradients transpose them)
     (2, 64, 64, 2), (2, 64, 16, 64), (3, 256, 256, 8), (2, 256, 64, 256), (1, 130, 70, 36), (2, 33, 9, 5),

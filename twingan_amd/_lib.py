@@ -147,6 +147,9 @@ SIGNATURES = {
     'tg_spectral_norm_workspace': (c_size_t, [c_int, c_int]),
     'tg_spectral_norm_fwd': (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, _P, c_size_t, _P]),
     'tg_spectral_norm_bwd': (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, _P, c_size_t, _P]),
+    'tg_sn_table_bytes': (c_size_t, [c_int]),
+    'tg_sn_table_fill': (c_int, [c_int, _FP, _FP, _FP, _FP, _FP, _FP, _P, c_size_t, c_int, c_int, _P, POINTER(c_int32)]),
+    'tg_spectral_norm_fwd_multi': (c_int, [_P, c_int, c_int, c_int, c_int, _P]),
 }
 
 _lib = None

@@ -148,6 +148,152 @@ __global__ __launch_bounds__(256) void sn_bwd_apply(const float* __restrict__ g,
 
 inline int nb_rows(int k_rows) { return (k_rows + ROWS - 1) / ROWS; }
 
+// ---- the three forward kernels' bodies once more, with the block index as an argument, for the *_multi kernels below
+// (copies rather than a refactoring of the kernels above: those stay byte-identical to the build the GPU suite ran on)
+template <bool WITH_G>
+__device__ __forceinline__ void sn_rowdot_body(const int bx, const float* __restrict__ w, const float* __restrict__ vec,
+                                               float* __restrict__ out, float* __restrict__ part_ss,
+                                               const float* __restrict__ g, const float* __restrict__ v,
+                                               float* __restrict__ part_s, float* __restrict__ part_va, int k_rows, int cout) {
+  __shared__ float red[3][4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float ss = 0.f, s = 0.f, va = 0.f;
+  for (int j = 0; j < ROWS / 4; ++j) {
+    const int r = bx * ROWS + wid * (ROWS / 4) + j;
+    if (r >= k_rows) break;      // wave-uniform
+    float d = 0.f, gs = 0.f;
+    for (int c = lane; c < cout; c += 64) {
+      const float x = w[(size_t)r * cout + c];
+      d = fmaf(x, vec[c], d);
+      if (WITH_G) gs = fmaf(x, g[(size_t)r * cout + c], gs);
+    }
+    d = wave_sum(d);
+    if (WITH_G) gs = wave_sum(gs);
+    if (lane == 0) out[r] = d;
+    ss = fmaf(d, d, ss);
+    if (WITH_G) {
+      s += gs;
+      va = fmaf(v[r], d, va);
+    }
+  }
+  if (lane == 0) {
+    red[0][wid] = ss;
+    red[1][wid] = s;
+    red[2][wid] = va;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (!WITH_G) part_ss[bx] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    if (WITH_G) {
+      part_s[bx] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+      part_va[bx] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    }
+  }
+}
+
+__device__ __forceinline__ void sn_coldot_body(const int bx, const int by, const float* __restrict__ w,
+                                               const float* __restrict__ v_raw, const float* __restrict__ part_ss, int nb1,
+                                               float* __restrict__ upart, int k_rows, int cout) {
+  __shared__ float red[4];
+  __shared__ float acc[4][64];
+  const float ssv = sum_parts(part_ss, nb1, red);
+  const float inv = rsqrtf(fmaxf(ssv, 1e-12f));      // tf.nn.l2_normalize: x * rsqrt(max(sum x^2, 1e-12))
+  const int c = bx * 64 + (threadIdx.x & 63), rs = threadIdx.x >> 6;
+  const int per = (k_rows + KS - 1) / KS;
+  const int k0 = by * per, k1 = min(k0 + per, k_rows);
+  float a = 0.f;
+  if (c < cout)
+    for (int k = k0 + rs; k < k1; k += 4) a = fmaf(v_raw[k], w[(size_t)k * cout + c], a);
+  acc[rs][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (rs == 0 && c < cout) {
+    const int l = threadIdx.x;
+    upart[(size_t)by * cout + c] = ((acc[0][l] + acc[1][l]) + (acc[2][l] + acc[3][l])) * inv;
+  }
+}
+
+__device__ __forceinline__ void sn_finish_body(const int bx, const float* __restrict__ w, const float* __restrict__ upart,
+                                               const float* __restrict__ v_raw, const float* __restrict__ part_ss, int nb1,
+                                               float* __restrict__ w_bar, float* __restrict__ u_new, float* __restrict__ v,
+                                               float* __restrict__ stats, int k_rows, int cout) {
+  __shared__ float red[4];
+  float ur[4], ssu = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = threadIdx.x + j * 256;
+    float t = 0.f;
+    if (c < cout)
+      for (int ks = 0; ks < KS; ++ks) t += upart[(size_t)ks * cout + c];
+    ur[j] = t;
+    ssu = fmaf(t, t, ssu);
+  }
+  ssu = block_sum(ssu, red);
+  const float inv_u = rsqrtf(fmaxf(ssu, 1e-12f));
+  const float sigma = ssu * inv_u;                     // v W u'^T = u_raw . u' = |u_raw|^2 / max(|u_raw|, 1e-6)
+  const float inv_sigma = 1.f / sigma;
+  const size_t total = (size_t)k_rows * cout;
+  for (size_t i = (size_t)bx * 1024 + threadIdx.x; i < min(total, (size_t)(bx + 1) * 1024); i += 256)
+    w_bar[i] = w[i] * inv_sigma;
+  if (bx == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = threadIdx.x + j * 256;
+      if (c < cout) u_new[c] = ur[j] * inv_u;
+    }
+    const float ssv = sum_parts(part_ss, nb1, red);
+    const float inv_v = rsqrtf(fmaxf(ssv, 1e-12f));
+    for (int k = threadIdx.x; k < k_rows; k += 256) v[k] = v_raw[k] * inv_v;
+    if (threadIdx.x == 0) {
+      stats[0] = sigma;
+      stats[1] = 1.f / inv_v;
+    }
+  }
+}
+
+// One power iteration of MANY kernels in three launches (tg_spectral_norm_fwd_multi): a job table in device memory, the
+// blocks of each of the three passes laid end to end (row0 / col0 / fin0 = a job's first block in that pass).
+struct SnJob {
+  const float* w;
+  const float* u;
+  float* w_bar;
+  float* u_new;
+  float* v;
+  float* stats;
+  float* ws;      // tg_spectral_norm_workspace(k_rows, cout) bytes
+  int k_rows, cout, nb;
+  int row0, col0, fin0;
+};
+template <int WHICH>
+__device__ __forceinline__ int sn_job_of(const SnJob* __restrict__ t, int njobs, int blk) {
+  int j = 0;
+  for (int i = 1; i < njobs; ++i) {
+    const int first = WHICH == 0 ? t[i].row0 : WHICH == 1 ? t[i].col0 : t[i].fin0;
+    if (first <= blk) j = i;
+  }
+  return j;
+}
+__global__ __launch_bounds__(256) void sn_rowdot_multi(const SnJob* __restrict__ t, int njobs) {
+  const SnJob J = t[sn_job_of<0>(t, njobs, blockIdx.x)];
+  float* v_raw = J.ws;
+  sn_rowdot_body<false>(blockIdx.x - J.row0, J.w, J.u, v_raw, v_raw + J.k_rows, nullptr, nullptr, nullptr, nullptr, J.k_rows,
+                        J.cout);
+}
+__global__ __launch_bounds__(256) void sn_coldot_multi(const SnJob* __restrict__ t, int njobs) {
+  const SnJob J = t[sn_job_of<1>(t, njobs, blockIdx.x)];
+  float* v_raw = J.ws;
+  float* part_ss = v_raw + J.k_rows;
+  const int local = blockIdx.x - J.col0, ncb = (J.cout + 63) / 64;
+  sn_coldot_body(local % ncb, local / ncb, J.w, v_raw, part_ss, J.nb, part_ss + 3 * J.nb, J.k_rows, J.cout);
+}
+__global__ __launch_bounds__(256) void sn_finish_multi(const SnJob* __restrict__ t, int njobs) {
+  const SnJob J = t[sn_job_of<2>(t, njobs, blockIdx.x)];
+  float* v_raw = J.ws;
+  float* part_ss = v_raw + J.k_rows;
+  sn_finish_body(blockIdx.x - J.fin0, J.w, part_ss + 3 * J.nb, v_raw, part_ss, J.nb, J.w_bar, J.u_new, J.v, J.stats, J.k_rows,
+                 J.cout);
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -195,6 +341,36 @@ int tg_spectral_norm_bwd(const float* g_wbar, const float* w, const float* u, co
   hipLaunchKernelGGL(sn_bwd_apply, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, s, g_wbar, u, u_new, v, a, part_s,
                      part_va, nb, stats, gw, accumulate, k_rows, cout);
   TG_LAUNCH_CHECK("tg_spectral_norm_bwd");
+  return TG_OK;
+}
+
+// ---- many kernels, three launches (the trainer's prepare_run under --spectral_norm: 60 matrices in config 4) ----------
+size_t tg_sn_table_bytes(int njobs) { return njobs > 0 ? (size_t)njobs * sizeof(SnJob) : 0; }
+
+// Fills job j of a HOST table (copied to the device by the caller) and advances the three running block totals.
+int tg_sn_table_fill(int j, const float* w, const float* u, float* w_bar, float* u_new, float* v, float* stats, void* ws,
+                     size_t ws_bytes, int k_rows, int cout, void* host_table, int32_t* totals) {
+  TG_CHECK(j >= 0 && w && u && w_bar && u_new && v && stats && ws && host_table && totals && k_rows > 0 && cout > 0 && cout <= 1024,
+           TG_EINVAL, "tg_sn_table_fill: bad arguments (K %d, cout %d)", k_rows, cout);
+  TG_CHECK(ws_bytes >= tg_spectral_norm_workspace(k_rows, cout), TG_EINVAL, "tg_sn_table_fill: workspace too small");
+  SnJob& J = ((SnJob*)host_table)[j];
+  J.w = w; J.u = u; J.w_bar = w_bar; J.u_new = u_new; J.v = v; J.stats = stats; J.ws = (float*)ws;
+  J.k_rows = k_rows; J.cout = cout; J.nb = nb_rows(k_rows);
+  J.row0 = totals[0]; J.col0 = totals[1]; J.fin0 = totals[2];
+  totals[0] += J.nb;
+  totals[1] += ((cout + 63) / 64) * KS;
+  totals[2] += (int)(((size_t)k_rows * cout + 1023) / 1024);
+  return TG_OK;
+}
+
+int tg_spectral_norm_fwd_multi(const void* table, int njobs, int row_blocks, int col_blocks, int fin_blocks, void* stream) {
+  TG_CHECK(table && njobs > 0 && row_blocks > 0 && col_blocks > 0 && fin_blocks > 0, TG_EINVAL,
+           "tg_spectral_norm_fwd_multi: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sn_rowdot_multi, dim3(row_blocks), dim3(256), 0, s, (const SnJob*)table, njobs);
+  hipLaunchKernelGGL(sn_coldot_multi, dim3(col_blocks), dim3(256), 0, s, (const SnJob*)table, njobs);
+  hipLaunchKernelGGL(sn_finish_multi, dim3(fin_blocks), dim3(256), 0, s, (const SnJob*)table, njobs);
+  TG_LAUNCH_CHECK("tg_spectral_norm_fwd_multi");
   return TG_OK;
 }
 

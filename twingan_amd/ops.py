@@ -2199,6 +2199,87 @@ class SpectralNormFn(torch.autograd.Function):
     return (None if sink is not None else gw), None
 
 
+class SpectralNormPreFn(torch.autograd.Function):
+  """The node of SpectralNormFn around a power iteration that has ALREADY run (spectral_norm_multi: every kernel of a run
+  in three launches): forward hands out the precomputed w_bar / u_new, backward is SpectralNormFn's."""
+
+  pre = None      # side channel of spectral_norm_multi(): (w_bar buffer, u_new, v, stats) of the node being made.  NOT
+                  # inputs: an output that is a view of an INPUT rebases that input's history onto this node, and the
+                  # persistent buffers would then drag the previous run's graph into the next one
+
+  @staticmethod
+  def forward(ctx, w, u):
+    (w_bar, u_new, v, stats), SpectralNormPreFn.pre = SpectralNormPreFn.pre, None
+    cout = w.shape[-1]
+    k_rows = w.numel() // cout
+    ctx.dims = (k_rows, cout, _lib.load().tg_spectral_norm_workspace(k_rows, cout))
+    u1 = u_new.view_as(u)
+    ctx.save_for_backward(w, u, u1, v, stats)
+    ctx.mark_non_differentiable(u1)
+    return w_bar.view(w.shape), u1
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, g, _gu):
+    return SpectralNormFn.backward(ctx, g, _gu)
+
+
+# TG_SN_MULTI=1 (an A/B switch, OFF: built on the emulated kernels after round 4's last GPU minute, never timed): the power
+# iterations of a run as tg_spectral_norm_fwd_multi instead of one tg_spectral_norm_fwd per kernel
+USE_SN_MULTI = os.environ.get('TG_SN_MULTI', '0') == '1'
+
+
+class SnTable:
+  """Persistent per-kernel buffers (u_new, v, stats, workspace) and the device job table of spectral_norm_multi for one
+  fixed list of (w, u, w_bar buffer) triples -- fixed addresses, so a captured hipGraph replays the three launches."""
+
+  def __init__(self, items):
+    lib = _lib.load()
+    dev = items[0][0].device
+    self.n = len(items)
+    self.key = tuple((w.data_ptr(), u.data_ptr(), out.data_ptr()) for w, u, out in items)
+    host = ctypes.create_string_buffer(lib.tg_sn_table_bytes(self.n))
+    totals = (ctypes.c_int32 * 3)(0, 0, 0)
+    self.bufs = []
+    for j, (w, u, out) in enumerate(items):
+      _chk(w, u, out)
+      cout = w.shape[-1]
+      k_rows = w.numel() // cout
+      nbytes = lib.tg_spectral_norm_workspace(k_rows, cout)
+      u_new = torch.empty(cout, dtype=torch.float32, device=dev)
+      v = torch.empty(k_rows, dtype=torch.float32, device=dev)
+      stats = torch.empty(2, dtype=torch.float32, device=dev)
+      ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+      call('tg_sn_table_fill', j, _p(w), _p(u), _p(out), _p(u_new), _p(v), _p(stats), _p(ws), nbytes, k_rows, cout,
+           ctypes.addressof(host), totals)
+      self.bufs.append((u_new, v, stats, ws))
+    self.totals = tuple(int(t) for t in totals)
+    self.table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev)
+    self.nbytes = sum(4 * _nb(w) for w, _, _ in items)
+
+  def run(self):
+    call('tg_spectral_norm_fwd_multi', _p(self.table), self.n, self.totals[0], self.totals[1], self.totals[2], _stream(),
+         work=('sn_fwd_multi:%d' % self.n, 0, self.nbytes))
+
+
+def spectral_norm_multi(items, table=None):
+  """items: [(w, u [1, cout] contiguous, out)] with persistent fp32 ``out`` buffers (as spectral_norm's) -> ([(w_bar, u_new)],
+  table).  ``table``: the SnTable of a previous call with the same tensors (rebuilt when an address changed)."""
+  items = [(w, u.contiguous(), out) for w, u, out in items]
+  key = tuple((w.data_ptr(), u.data_ptr(), out.data_ptr()) for w, u, out in items)
+  if table is None or table.key != key:
+    table = SnTable(items)
+  table.run()
+  outs = []
+  for (w, u, out), (u_new, v, stats, _) in zip(items, table.bufs):
+    SpectralNormPreFn.pre = (out, u_new, v, stats)
+    try:
+      outs.append(SpectralNormPreFn.apply(w, u))
+    finally:
+      SpectralNormPreFn.pre = None
+  return outs, table
+
+
 def spectral_norm(w, u, out=None):
   """-> (w_bar, u_new); see SpectralNormFn.  ``out``: a persistent fp32 buffer of w's size that receives w_bar (its
   MFMA packs then live in PackCache like a master weight's and are rebuilt by PackCache.refresh, one launch for all

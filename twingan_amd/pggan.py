@@ -82,6 +82,30 @@ def _sn_compute(P, scope):
   return w_bar
 
 
+def _sn_compute_multi(P, scopes):
+  """_sn_compute for every scope of ``scopes`` with ONE batched power iteration (ops.spectral_norm_multi: three launches
+  for all kernels instead of three per kernel); the per-kernel autograd nodes, the pending u' and the Cuts leaves as there."""
+  import torch
+  bufs = P.__dict__.setdefault('sn_wbar', {})
+  items = []
+  for scope in scopes:
+    w = P[scope + '/weights']
+    buf = bufs.get(scope)
+    if buf is None or buf.numel() != w.numel() or buf.device != w.device:
+      buf = bufs[scope] = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+      ops.PackCache.register(buf)
+    items.append((w, P.state[scope + '/u'], buf))
+  outs, table = ops.spectral_norm_multi(items, P.__dict__.get('sn_table'))
+  P.__dict__['sn_table'] = table
+  for scope, (w_bar, u1) in zip(scopes, outs):
+    P.__dict__.setdefault('sn_pending', {})[scope + '/u'] = u1
+    if ops.Cuts.active and torch_is_grad_enabled() and w_bar.requires_grad:
+      leaf = w_bar.detach().requires_grad_(True)
+      P.__dict__.setdefault('sn_leaves', {})[scope] = (w_bar, leaf)
+      w_bar = leaf
+    P.__dict__.setdefault('sn_cache', {})[scope] = w_bar
+
+
 def torch_is_grad_enabled():
   import torch
   return torch.is_grad_enabled()
@@ -114,9 +138,12 @@ def prepare_run(P, cfg):
     return 0
   scopes = [k[:-2] for k in P.state if k.endswith('/u')]
   cache = P.__dict__.setdefault('sn_cache', {})
-  for scope in scopes:
-    if scope not in cache:
-      _sn_compute(P, scope)
+  todo = [scope for scope in scopes if scope not in cache]
+  if ops.USE_SN_MULTI and len(todo) > 1:
+    _sn_compute_multi(P, todo)
+    todo = []
+  for scope in todo:
+    _sn_compute(P, scope)
   bufs = P.__dict__.get('sn_wbar', {})
   if bufs:
     ops.PackCache.refresh(list(bufs.values()))
