@@ -61,13 +61,6 @@ const char* tg_last_kernel(void);
  * them).  Returns the previous setting.  Do not flip it between capturing and replaying a hipGraph. */
 int tg_set_deterministic(int on);
 int tg_get_deterministic(void);
-/* Auxiliary stream (process-wide; NULL = none, the default).  While one is set, work that nothing waits for inside a
- * backward pass -- today: the slab reduction of every filter gradient that ACCUMULATES into a caller buffer
- * (tg_conv2d_bwd_weight* with accumulate != 0) -- is enqueued on it behind an event of the launch stream instead of on the
- * launch stream itself.  The caller must (1) make the auxiliary stream wait for whatever zeroed / last touched those
- * buffers, (2) make its consumer (the optimiser) wait for the auxiliary stream, (3) keep the workspaces passed to those
- * calls alive until then.  The reference has no counterpart: TF's executor schedules its gradient ops itself. */
-int tg_set_aux_stream(void* stream);
 /* Deferred filter-gradient reductions (process-wide).  Between tg_wgrad_defer(1) and tg_wgrad_defer_flush(stream) the
  * split-K slab reduction of every filter gradient that ACCUMULATES into a caller buffer (tg_conv2d_bwd_weight*,
  * tg_conv2d_upcat_bwd_weight with accumulate != 0) is queued instead of launched, and the flush issues all queued

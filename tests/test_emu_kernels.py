@@ -54,11 +54,8 @@ def test_unpooling_backward_data_over_the_emulated_kernels():
 
 
 def test_thin_output_kernels_over_the_emulated_kernels():
-  """conv_thin16_kernel (on by default) at the smallest shapes that dispatch it, and the OFF switches TG_THIN16_UNPOOL /
-  TG_THIN32 / TG_SN_MULTI, whose GPU tests are skipped until they have run on hardware."""
+  """conv_thin16_kernel at the smallest shapes that dispatch it, and the multi-kernel spectral-norm launch."""
   r = _run(['tests/test_gpu_ops.py', '-n', '3', '-k',
-            '(thin_output_kernel_matches and 16-16-dtype0) or (thin_output_kernel_with_the_unpooling and True-dtype0) or '
-            '(two_block_thin and 16-32-dtype0) or spectral_norm_of_many'],
-           timeout=2400, TG_TEST_THIN16_UNPOOL='1', TG_TEST_THIN32='1', TG_TEST_SN_MULTI='1')
+            '(thin_output_kernel_matches and 16-16-dtype0) or spectral_norm_of_many'], timeout=2400)
   assert r.returncode == 0, r.stdout[-3000:]
   assert ' passed' in r.stdout[-3000:]

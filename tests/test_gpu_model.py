@@ -345,12 +345,10 @@ def test_segmented_backward_leaves_the_same_gradients(precision):
       assert lo <= cut.store.offsets[k] < hi
 
 
-def test_unpool_backward_data_and_forked_filter_gradients_leave_the_same_gradients(monkeypatch):
-  """Two schedule changes of the backward that must not change a gradient: (a) in a generator step the backward-data of
-  every discriminator block end reads the pooled gradient + sign bytes itself (tg_conv2d_bwd_data_unpool) instead of a
-  full-resolution gradient tensor written by tg_lrelu_pool_bwd_signs; (b) TG_WGRAD_FORK=1 queues the filter gradients of
-  the <= 32 x 32 layers and runs them on ONE forked stream next to the high-resolution part of the backward.  Same
-  kernels on the same tensors (a) bit for bit per launch, (b) in another order per gradient sink."""
+def test_unpool_backward_data_leaves_the_same_gradients(monkeypatch):
+  """A schedule change of the backward that must not change a gradient: in a generator step the backward-data of every
+  discriminator block end reads the pooled gradient + sign bytes itself (tg_conv2d_bwd_data_unpool) instead of a
+  full-resolution gradient tensor written by tg_lrelu_pool_bwd_signs -- bit for bit per launch."""
   from twingan_amd import Config, ops
   from twingan_amd.twingan import Trainer
   cfg = Config(hw=64, max_ch=64, precision='bf16')
@@ -367,9 +365,8 @@ def test_unpool_backward_data_and_forked_filter_gradients_leave_the_same_gradien
     return out
   monkeypatch.setattr(ops, 'conv_bwd_data_unpool_raw', counted)
   grads = {}
-  for name, unpool, fork in (('base', False, '0'), ('new', True, '1')):
+  for name, unpool in (('base', False), ('new', True)):
     monkeypatch.setattr(ops, 'USE_DGRAD_UNPOOL', unpool)
-    monkeypatch.setenv('TG_WGRAD_FORK', fork)
     tr = Trainer(cfg, device='cuda:0', seed=13, overlap=False)
     grads[name] = {}
     for grp in ('g', 'd'):
@@ -378,7 +375,6 @@ def test_unpool_backward_data_and_forked_filter_gradients_leave_the_same_gradien
       torch.cuda.synchronize()
       gd = tr.store.grad_dict()
       grads[name][grp] = {k: gd[k].clone() for k in tr.store.names(grp)}
-    assert not ops.WgradFork.active and not any(ops.WgradFork._queues.values())
     if unpool:      # the 64 x 64, 32 x 32 and 16 x 16 block ends of both discriminators, in the generator step only
       assert sum(calls) >= 6, calls
     else:

@@ -1047,11 +1047,8 @@ def test_spectral_norm_matches_oracle(ops, k, cin, cout):
   assert rel_l2(host(wd.grad), wt.grad.numpy()) < 5 * F32_TOL
 
 
-@pytest.mark.skipif(__import__('os').environ.get('TG_TEST_SN_MULTI') != '1',
-                    reason='TG_SN_MULTI is an OFF switch built on the emulated kernels after the last GPU minute of round 4: its test '
-                           'has never run on hardware (TG_TEST_SN_MULTI=1 runs it; the CPU suite does, over the emulation)')
 def test_spectral_norm_of_many_kernels_in_three_launches(ops):
-  """tg_spectral_norm_fwd_multi (ops.spectral_norm_multi, TG_SN_MULTI=1): the power iterations of several kernels of
+  """tg_spectral_norm_fwd_multi (ops.spectral_norm_multi, what pggan.prepare_run uses): the power iterations of several kernels of
   different shapes from one job table -- w_bar, u', and the gradients through the per-kernel nodes equal the one-kernel
   entry point's bit for bit (the same kernel bodies in the same order), also when the table is reused for a second run."""
   g = torch.Generator().manual_seed(37)
@@ -1085,6 +1082,14 @@ def test_spectral_norm_of_many_kernels_in_three_launches(ops):
       assert torch.equal(wd.grad, g1)
     for u, (_, un) in zip(us, res):      # the next run starts from u', assigned in place as pggan.end_run does
       u.copy_(un.detach().reshape(1, -1))
+  # the nodes save the table's PERSISTENT buffers: a backward after the table has run again must refuse, not use them
+  for wd in wds:
+    wd.grad = None
+  res, _ = ops.spectral_norm_multi(list(zip(wds, us, outs)), table)
+  stale = sum((wb * q).sum() for (wb, _), q in zip(res, gq))
+  ops.spectral_norm_multi(list(zip(wds, us, outs)), table)
+  with pytest.raises(RuntimeError, match='one outstanding graph'):
+    stale.backward()
 
 
 BGEMM_CASES = [
@@ -1597,102 +1602,6 @@ def test_thin_output_kernel_over_the_concat_input(ops, monkeypatch, dtype):
   rnd = bf16_round if dtype == torch.bfloat16 else f16_round
   ref = N.conv2d(cat, rnd(host(w)), 'SAME')
   assert rel_l2(host(y[3 * b:3 * b + 1]), ref) < (6e-3 if dtype == torch.bfloat16 else 8e-4)
-
-
-@pytest.mark.skipif(__import__('os').environ.get('TG_TEST_THIN16_UNPOOL') != '1',
-                    reason='TG_THIN16_UNPOOL is an OFF switch built on the emulated kernels after the last GPU minute of round 4: its '
-                           'test has never run on hardware (TG_TEST_THIN16_UNPOOL=1 runs it; the CPU suite does, over the emulation)')
-@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('masked', [True, False])
-def test_thin_output_kernel_with_the_unpooling_input(ops, monkeypatch, dtype, masked):
-  """TG_THIN16_UNPOOL=1 (an A/B switch, off by default): the 256 x 256 block end's backward-data (32 -> 16 channels) on the
-  thin-output wave program with the unpooling loader -- sign bytes, kept activation, and the write-through of the gradient
-  tensor -- against the 32-wide-block unpooling kernels (the tensor written: the same bits; the input gradient: <= 2e-3)."""
-  import twingan_amd.ops as O
-  from twingan_amd import _lib
-  n, hw, cin, cout = 16, 128, 16, 32
-  g = torch.Generator().manual_seed(23)
-  spec = O.ConvSpec(3, 'SAME')
-  x = torch.randn(n, hw, hw, cin, generator=g).to(dtype).to(dev())
-  w = (torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev())
-  gzp = torch.randn(n, hw // 2, hw // 2, cout, generator=g).to(dtype).to(dev())
-  signs = torch.randint(0, 256, (n, hw, hw, cout // 8), generator=g, dtype=torch.uint8).to(dev())
-  zact = torch.randn(n, hw, hw, cout, generator=g).to(dtype).to(dev())
-  f16 = ',f16' if dtype == torch.float16 else ''
-  for src, tag in ((signs, 'unpool'), (zact, 'unpoolz')):
-    out = {}
-    for on in ('0', '1'):
-      monkeypatch.setenv('TG_THIN16_UNPOOL', on)
-      out[on] = O.conv_bwd_data_unpool_raw(gzp, src, w, x if masked else None, (n, hw, hw, cin), spec, True) + \
-          (_lib.load().tg_last_kernel().decode(),)
-    monkeypatch.setenv('TG_THIN16_UNPOOL', '0')
-    assert 'thin16' not in out['0'][2] and out['1'][2] == 'conv_thin16_kernel<32,%s%s>' % (tag, f16), (out['0'][2], out['1'][2])
-    assert torch.equal(out['1'][1], out['0'][1])      # the gradient tensor written through
-    assert rel_l2(host(out['1'][0]), host(out['0'][0])) < 2e-3
-
-
-@pytest.mark.skipif(__import__('os').environ.get('TG_TEST_THIN32') != '1',
-                    reason='TG_THIN32 is an OFF switch built on the emulated kernels after the last GPU minute of round 4: its test '
-                           'has never run on hardware (TG_TEST_THIN32=1 runs it; the CPU suite does, over the emulation)')
-@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('cin,cout', [(16, 32), (32, 32), (32, 24)])
-def test_two_block_thin_kernel_matches_the_wide_block_kernels(ops, monkeypatch, dtype, cin, cout):
-  """conv_thin32_kernel (TG_THIN32=1, off by default): 17..32 output channels as two 16-channel MFMA blocks that share every
-  pixel fragment -- forward with bias + LeakyReLU, with the statistics epilogue, with the pooled output and with pooled
-  output + sign bytes (the discriminators' block ends), masked backward-data -- against the 32-wide-block kernels."""
-  import twingan_amd.ops as O
-  from twingan_amd import _lib
-  from twingan_amd._lib import TG_EPI_BIAS, TG_EPI_LRELU
-  n, hw = 16, 128
-  g = torch.Generator().manual_seed(29)
-  x = torch.randn(n, hw, hw, cin, generator=g).to(dtype).to(dev())
-  w = (torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev())
-  b = (torch.randn(cout, generator=g) * 0.1).to(dev())
-  spec = O.ConvSpec(3, 'SAME')
-  epi = TG_EPI_BIAS | TG_EPI_LRELU
-  f16 = ',f16' if dtype == torch.float16 else ''
-
-  def both(fn):
-    out = []
-    for on in ('0', '1'):
-      monkeypatch.setenv('TG_THIN32', on)
-      out.append((fn(), _lib.load().tg_last_kernel().decode()))
-    monkeypatch.setenv('TG_THIN32', '0')
-    return out
-  (ya, ka), (yb, kb) = both(lambda: O.conv_fwd_raw(x, w, b, spec, epi))
-  assert 'thin32' not in ka and kb == 'conv_thin32_kernel<%d%s>' % (cin, f16), (ka, kb)
-  assert rel_l2(host(yb), host(ya)) < 2e-3
-  rnd = bf16_round if dtype == torch.bfloat16 else f16_round
-  ref = N.leaky_relu(N.conv2d(host(x[:1]), rnd(host(w)), 'SAME') + host(b))
-  assert rel_l2(host(yb[:1]), ref) < (6e-3 if dtype == torch.bfloat16 else 8e-4)
-  ((y1, s1), _), ((y2, s2), k2) = both(lambda: O.conv_fwd_stats_raw(x, w, spec))
-  assert k2 == 'conv_thin32_kernel<%d,stats%s>' % (cin, f16), k2
-  assert rel_l2(host(y2), host(y1)) < 2e-3
-  part = s2.part.view(n, s2.chunks, 2, cout).double().sum(dim=1).cpu().numpy()
-  yd = y2.double()
-  want = torch.stack([yd.sum(dim=(1, 2)), (yd * yd).sum(dim=(1, 2))], dim=1).cpu().numpy()
-  assert rel_l2(part, want) < 1e-5
-  # block end: y + pooled, and pooled + sign bytes
-  ((za, zpa), _), ((zb, zpb), k3) = both(lambda: O.conv_fwd_pool_raw(x, w, b, spec, epi))
-  assert k3 == 'conv_thin32_kernel<%d,pool%s>' % (cin, f16), k3
-  assert torch.equal(zb, yb)      # the same kernel body as the plain forward
-  pooled = zb.float().view(n, hw // 2, 2, hw // 2, 2, cout)
-  want_p = 0.25 * ((pooled[:, :, 0, :, 0] + pooled[:, :, 0, :, 1]) + (pooled[:, :, 1, :, 0] + pooled[:, :, 1, :, 1]))
-  assert torch.equal(zpb, want_p.to(dtype))      # the 2x2 average of the ROUNDED outputs, in pool_quad's order
-  assert rel_l2(host(zpb), host(zpa)) < 2e-3
-  ((sa_, spa), _), ((sb_, spb), k4) = both(lambda: O.conv_fwd_pool_signs_raw(x, w, b, spec, epi))
-  assert k4 == 'conv_thin32_kernel<%d,pool,signs%s>' % (cin, f16), k4
-  assert torch.equal(spb, zpb)
-  bits = (zb > 0).view(n, hw, hw, cout // 8, 8).to(torch.int32)
-  want_s = (bits << torch.arange(8, device=zb.device, dtype=torch.int32)).sum(dim=-1).to(torch.uint8)
-  assert torch.equal(sb_, want_s), int((sb_ != want_s).sum())
-  if cout == 32:      # masked backward-data of a layer with 32 INPUT channels writes 32 channels
-    w2 = (torch.randn(3, 3, cout, cin, generator=g) * (2.0 / (9 * cout)) ** 0.5).to(dev())      # forward: cout(=32) -> cin
-    gy = torch.randn(n, hw, hw, cin, generator=g).to(dtype).to(dev())
-    xa = torch.randn(n, hw, hw, cout, generator=g).to(dtype).to(dev())
-    (ga, _), (gb, k5) = both(lambda: O.conv_bwd_data_masked_raw(gy, w2, xa, spec))
-    assert k5 == 'conv_thin32_kernel<%d%s>' % (cin, f16), k5
-    assert rel_l2(host(gb), host(ga)) < 2e-3
 
 
 # ------------------------------------------------ backward-data of a block's last conv from the pooled gradient + sign bytes

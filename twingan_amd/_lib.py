@@ -38,7 +38,6 @@ SIGNATURES = {
     'tg_last_kernel': (c_char_p, []),
     'tg_set_deterministic': (c_int, [c_int]),
     'tg_get_deterministic': (c_int, []),
-    'tg_set_aux_stream': (c_int, [_P]),
     'tg_wgrad_defer': (c_int, [c_int]),
     'tg_wgrad_defer_flush': (c_int, [_P]),
     'tg_channel_sum_ordered': (c_int, [_P, _FP, c_int64, c_int, c_int, _FP, c_size_t, c_int, _P]),

@@ -115,16 +115,9 @@ int tg_deterministic_mode() {
   return m;
 }
 
-static void* tg_aux_stream_ptr = nullptr;      // process-wide: autograd runs the backward kernels' host calls on its own thread
-void* tg_aux_stream() { return __atomic_load_n(&tg_aux_stream_ptr, __ATOMIC_RELAXED); }
-
 extern "C" {
 
 int tg_version(void) { return 100; }
-int tg_set_aux_stream(void* stream) {
-  __atomic_store_n(&tg_aux_stream_ptr, stream, __ATOMIC_RELAXED);
-  return TG_OK;
-}
 int tg_set_deterministic(int on) {
   const int was = tg_deterministic_mode();
   __atomic_store_n(&tg_det_mode, on ? 1 : 0, __ATOMIC_RELAXED);

@@ -1092,15 +1092,12 @@ __global__ __launch_bounds__(256) void conv_tile_wres_kernel(const bf16* __restr
 //   pixel's 32 bytes.
 // MODE 0: plain (bias / LeakyReLU / mask epilogue), 1: + statistics partials of the rounded outputs (layout of stats_flush).
 // ------------------------------------------------------------------------------------------------
-// UP: the input tile is the unpooled gradient of a block end (TileGeom::up_src, as the UNPOOL tile kernels): 1 = signs from
-// the sign bytes, 2 = from the kept activation tensor; with up_store the interior pixels are written through.
-template <int KC, int MODE, bool F16, int EPI, int UP = 0>
+template <int KC, int MODE, bool F16, int EPI>
 __global__ __launch_bounds__(256) void conv_thin16_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                           const float* __restrict__ bias, bf16* __restrict__ y,
                                                           const TileGeom g) {
   static_assert(KC == 16 || KC == 32, "one 16- or 32-channel chunk");
-  static_assert(UP == 0 || KC == 32, "the unpooling input comes in 32-channel chunks");
-  constexpr bool STATS = MODE == 1, HAS_BIAS = (EPI & 1) != 0, HAS_MASK = (EPI & 2) != 0, UPZ = UP == 2;
+  constexpr bool STATS = MODE == 1, HAS_BIAS = (EPI & 1) != 0, HAS_MASK = (EPI & 2) != 0;
   constexpr int NT = 9, TW = 16, TH = 8, HWX = TW + 2, HH = TH + 2;
   constexpr int VPP = KC / 8, PS_A = KC * 2 + 16;
   constexpr int AVEC = HH * HWX * VPP, ASLOTS = (AVEC + 255) / 256;
@@ -1147,8 +1144,6 @@ __global__ __launch_bounds__(256) void conv_thin16_kernel(const bf16* __restrict
 
   struct Stage {
     bf16x8 ra[ASLOTS];
-    unsigned rs[UP == 1 ? ASLOTS : 1];
-    bf16x8 rz[UPZ ? ASLOTS : 1];
   };
   auto load_a = [&](Stage& st, int t) __attribute__((always_inline)) {
     const bool live = t < t_end;
@@ -1157,22 +1152,6 @@ __global__ __launch_bounds__(256) void conv_thin16_kernel(const bf16* __restrict
     const int r = t / g.tiles_x;
     const int ty = r % g.tiles_y;
     const int img = r / g.tiles_y;
-    if constexpr (UP != 0) {
-      const size_t pool_elems = (size_t)(g.h / 2) * (g.w / 2) * g.cin, sign_bytes = (size_t)g.h * g.w * (g.cin >> 3);
-      const __amdgpu_buffer_rsrc_t rp = make_rsrc(g.up_src + (size_t)img * pool_elems, (unsigned)(pool_elems * 2));
-      const __amdgpu_buffer_rsrc_t rsg = UPZ ? make_rsrc(g.up_z + (size_t)img * img_elems, (unsigned)(img_elems * 2))
-                                             : make_rsrc(g.up_signs + (size_t)img * sign_bytes, (unsigned)sign_bytes);
-#pragma unroll
-      for (int s = 0; s < ASLOTS; ++s) {
-        const int iy = ty * TH + a_hy[s] - g.pad, ix = tx * TW + a_hx[s] - g.pad;
-        const bool ok = live && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
-        const int part = (tid + s * 256) % VPP;
-        st.ra[s] = buf_load16(rp, ok ? (unsigned)((((iy >> 1) * (g.w >> 1) + (ix >> 1)) * g.cin + part * 8) * 2) : OOB);
-        if constexpr (UPZ) st.rz[s] = buf_load16(rsg, ok ? (unsigned)(((iy * g.w + ix) * g.cin + part * 8) * 2) : OOB);
-        else st.rs[s] = buf_load_u8(rsg, ok ? (unsigned)((iy * g.w + ix) * (g.cin >> 3) + part) : OOB);
-      }
-      return;
-    }
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (size_t)img * img_elems, (unsigned)(img_elems * 2));
 #pragma unroll
     for (int s = 0; s < ASLOTS; ++s) {
@@ -1201,21 +1180,6 @@ __global__ __launch_bounds__(256) void conv_thin16_kernel(const bf16* __restrict
     const int r = t / g.tiles_x;
     const int ty = r % g.tiles_y;
     const int img = r / g.tiles_y;
-    if constexpr (UP != 0) {      // AvgPoolGrad + LeakyReluGrad on the way into LDS; interior pixels written through
-#pragma unroll
-      for (int s = 0; s < ASLOTS; ++s) sa.ra[s] = unpool8<F16>(sa.ra[s], UPZ ? sign_bits8(sa.rz[s]) : sa.rs[s], g.up_alpha);
-      if (g.up_store) {      // uniform
-        const __amdgpu_buffer_rsrc_t rst = make_rsrc(g.up_store + (size_t)img * img_elems, (unsigned)(img_elems * 2));
-#pragma unroll
-        for (int s = 0; s < ASLOTS; ++s) {
-          const int iy = ty * TH + a_hy[s] - g.pad, ix = tx * TW + a_hx[s] - g.pad;
-          const bool own = a_hy[s] >= g.pad && a_hy[s] < g.pad + TH && a_hx[s] >= g.pad && a_hx[s] < g.pad + TW;
-          const int part8 = ((tid + s * 256) % VPP) * 8;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sa.ra[s]), rst,
-                                                 own ? (unsigned)(((iy * g.w + ix) * g.cin + part8) * 2) : OOB, 0, TG_STORE_AUX);
-        }
-      }
-    }
     if (!first) __syncthreads();
     first = false;
 #pragma unroll
@@ -1302,246 +1266,6 @@ __global__ __launch_bounds__(256) void conv_thin16_kernel(const bf16* __restrict
       const int which = tid >> 4, ch = tid & 15;
       const float tsum = (red[(0 * 2 + which) * 16 + ch] + red[(1 * 2 + which) * 16 + ch]) +
                          (red[(2 * 2 + which) * 16 + ch] + red[(3 * 2 + which) * 16 + ch]);
-      const int tpi = g.tiles_x * g.tiles_y;
-      float* out = g.stats + ((size_t)(t_begin / tpi) * g.stat_chunks + (t_begin % tpi) / g.tiles_per_wg) * 2 * g.cout;
-      if (ch < g.cout) out[(size_t)which * g.cout + ch] = tsum;
-    }
-  }
-}
-
-// Two 16-channel M blocks on the same wave program (TG_THIN32=1, an A/B switch that is OFF: written on the emulated kernels
-// after round 4's last GPU minute, never timed): the layers with 17..32 output channels and one 16- / 32-channel chunk -- the
-// 256 x 256 / 128 x 128 stages' 16 -> 32 and 32 -> 32 convs, incl. the discriminators' block-end forward with its pooled
-// output and sign bytes.  A pixel fragment read from LDS feeds both blocks' MFMAs; 10 / 18 A fragments (40 / 72 VGPRs) stay
-// in registers.  The 2x2 average pool is lane-local here: a lane's two pixel blocks are the two rows of its pool window, the
-// column neighbour is lane ^ 1.
-// MODE 0: plain, 1: statistics partials, 2: + pooled output, 3: pooled output + sign bytes instead of y.
-template <int KC, int MODE, bool F16, int EPI>
-__global__ __launch_bounds__(256) void conv_thin32_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
-                                                          const float* __restrict__ bias, bf16* __restrict__ y,
-                                                          const TileGeom g) {
-  static_assert(KC == 16 || KC == 32, "one 16- or 32-channel chunk");
-  constexpr bool STATS = MODE == 1, POOL = MODE == 2 || MODE == 3, SIGNS = MODE == 3;
-  constexpr bool HAS_BIAS = (EPI & 1) != 0, HAS_MASK = (EPI & 2) != 0;
-  constexpr int NB = 2, NT = 9, TW = 16, TH = 8, HWX = TW + 2, HH = TH + 2;
-  constexpr int VPP = KC / 8, PS_A = KC * 2 + 16;
-  constexpr int AVEC = HH * HWX * VPP, ASLOTS = (AVEC + 255) / 256;
-  constexpr int NP = KC == 16 ? 5 : 9;
-  unsigned char* sA = tile_smem;
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int q = lane >> 4, c16 = lane & 15;
-
-  const int wrow = NT * g.cin_pad;
-  const __amdgpu_buffer_rsrc_t rw = make_rsrc(wp, (unsigned)((size_t)g.cout * wrow * 2));
-  bf16x8 wf[NB][NP];
-  int a_off[NP];
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    const int tap = KC == 16 ? 2 * p + (q >> 1) : p;
-    const int part = KC == 16 ? (q & 1) : q;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int row = nb * 16 + c16;
-      wf[nb][p] = buf_load16(rw, (tap < NT && row < g.cout) ? (unsigned)((row * wrow + tap * g.cin_pad + part * 8) * 2) : OOB);
-    }
-    const int tp = tap < NT ? tap : NT - 1;
-    a_off[p] = ((tp / 3) * HWX + (tp % 3)) * PS_A + part * 16;
-  }
-  const int a_base = ((wid * 2) * HWX + c16) * PS_A;
-
-  int a_hy[ASLOTS], a_hx[ASLOTS], a_loff[ASLOTS];
-#pragma unroll
-  for (int s = 0; s < ASLOTS; ++s) {
-    const int v = tid + s * 256;
-    const int px = v / VPP, part = v % VPP;
-    a_hy[s] = (v < AVEC) ? px / HWX : -100000;
-    a_hx[s] = px % HWX;
-    a_loff[s] = px * PS_A + part * 16;
-  }
-  int wg = blockIdx.x;
-  const int nwg = gridDim.x;
-  if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
-  const int t_begin = wg * g.tiles_per_wg;
-  int t_end = t_begin + g.tiles_per_wg;
-  if (t_end > g.nblk) t_end = g.nblk;
-  const size_t img_elems = (size_t)g.h * g.w * g.cin;
-  const size_t out_img = (size_t)g.h * g.w * g.cout;
-
-  struct Stage {
-    bf16x8 ra[ASLOTS];
-  };
-  auto load_a = [&](Stage& st, int t) __attribute__((always_inline)) {
-    const bool live = t < t_end;
-    if (!live) t = t_begin;
-    const int tx = t % g.tiles_x;
-    const int r = t / g.tiles_x;
-    const int ty = r % g.tiles_y;
-    const int img = r / g.tiles_y;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (size_t)img * img_elems, (unsigned)(img_elems * 2));
-#pragma unroll
-    for (int s = 0; s < ASLOTS; ++s) {
-      const int iy = ty * TH + a_hy[s] - g.pad, ix = tx * TW + a_hx[s] - g.pad;
-      const bool ok = live && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
-      const int part8 = ((tid + s * 256) % VPP) * 8;
-      st.ra[s] = buf_load16(rx, ok ? (unsigned)(((iy * g.w + ix) * g.cin + part8) * 2) : OOB);
-    }
-  };
-
-  const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, (HAS_BIAS && (g.epilogue & TG_EPI_BIAS)) ? (unsigned)(g.cout * 4) : 0u);
-  f32x4 bq[NB];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    bq[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (HAS_BIAS)
-      bq[nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, (unsigned)((nb * 16 + q * 4) * 4), 0, 0));
-  }
-
-  float sacc[STATS ? NB * 8 : 1];
-  if constexpr (STATS) {
-#pragma unroll
-    for (int i = 0; i < NB * 8; ++i) sacc[i] = 0.f;
-  }
-
-  bool first = true;
-  Stage sa;
-  load_a(sa, t_begin);
-  for (int t = t_begin; t < t_end; ++t) {
-    const int tx = t % g.tiles_x;
-    const int r = t / g.tiles_x;
-    const int ty = r % g.tiles_y;
-    const int img = r / g.tiles_y;
-    if (!first) __syncthreads();
-    first = false;
-#pragma unroll
-    for (int s = 0; s < ASLOTS; ++s)
-      if (s < ASLOTS - 1 || tid + s * 256 < AVEC) *reinterpret_cast<bf16x8*>(sA + a_loff[s]) = sa.ra[s];
-    __syncthreads();
-    load_a(sa, t + 1);
-    const bool y_dropped = SIGNS;      // sign-byte output: y is not written
-    const __amdgpu_buffer_rsrc_t ry = make_rsrc(y_dropped ? (const bf16*)g.ypool : y + (size_t)img * out_img,
-                                                y_dropped ? 0u : (unsigned)(out_img * 2));
-    const __amdgpu_buffer_rsrc_t rmask =
-        make_rsrc(g.mask ? g.mask + (size_t)img * out_img : y, g.mask ? (unsigned)(out_img * 2) : 0u);
-    const int ox = tx * TW + c16;
-    u32x2 zm[NB][2];
-    if (HAS_MASK && g.mask) {      // uniform
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
-          const int oy = ty * TH + wid * 2 + pb, ch = nb * 16 + 4 * q;
-          zm[nb][pb] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
-              rmask, ch + 4 <= g.cout ? (unsigned)(((oy * g.w + ox) * g.cout + ch) * 2) : OOB, 0, 0));
-        }
-    }
-    f32x4 acc[NB][2];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int pb = 0; pb < 2; ++pb) acc[nb][pb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-#pragma unroll
-      for (int pb = 0; pb < 2; ++pb) {
-        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sA + a_base + pb * HWX * PS_A + a_off[p]);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb][pb] = mfma_16x16x32<F16>(wf[nb][p], xf, acc[nb][pb]);
-      }
-    }
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int ch = nb * 16 + 4 * q;
-      u32x2 o[2];
-#pragma unroll
-      for (int pb = 0; pb < 2; ++pb) {
-        const int oy = ty * TH + wid * 2 + pb;
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float a = acc[nb][pb][j];
-          if constexpr (HAS_BIAS) a += bq[nb][j];
-          if (g.epilogue & TG_EPI_LRELU) a = lrelu_f(a, g.alpha);
-          v[j] = a;
-        }
-        if (HAS_MASK && g.mask) {      // uniform
-          const u32x2 z = zm[nb][pb];
-          v[0] *= (short)(z[0] & 0xffffu) > 0 ? 1.f : g.alpha;
-          v[1] *= (short)(z[0] >> 16) > 0 ? 1.f : g.alpha;
-          v[2] *= (short)(z[1] & 0xffffu) > 0 ? 1.f : g.alpha;
-          v[3] *= (short)(z[1] >> 16) > 0 ? 1.f : g.alpha;
-        }
-        o[pb][0] = pack16x2<F16>(v[0], v[1]);
-        o[pb][1] = pack16x2<F16>(v[2], v[3]);
-        if constexpr (STATS) {
-          const float r4[4] = {unpack16_lo<F16>(o[pb][0]), unpack16_hi<F16>(o[pb][0]), unpack16_lo<F16>(o[pb][1]),
-                               unpack16_hi<F16>(o[pb][1])};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            sacc[nb * 8 + j] += r4[j];
-            sacc[nb * 8 + 4 + j] = fmaf(r4[j], r4[j], sacc[nb * 8 + 4 + j]);
-          }
-        }
-        __builtin_amdgcn_raw_buffer_store_b64(o[pb], ry, ch + 4 <= g.cout ? (unsigned)(((oy * g.w + ox) * g.cout + ch) * 2) : OOB, 0,
-                                              TG_STORE_AUX);
-      }
-      if constexpr (POOL) {
-        const int oy0 = ty * TH + wid * 2;      // the pool window's first row (even)
-        if constexpr (SIGNS) {      // one byte per 8 channels and pixel: this lane's nibble + its neighbour group's (lane ^ 16)
-          const __amdgpu_buffer_rsrc_t rsig =
-              make_rsrc(g.ymask + (size_t)img * (out_img >> 3), (unsigned)(out_img >> 3));
-#pragma unroll
-          for (int pb = 0; pb < 2; ++pb) {
-            unsigned nib = ((short)(o[pb][0] & 0xffffu) > 0 ? 1u : 0u) | ((short)(o[pb][0] >> 16) > 0 ? 2u : 0u) |
-                           ((short)(o[pb][1] & 0xffffu) > 0 ? 4u : 0u) | ((short)(o[pb][1] >> 16) > 0 ? 8u : 0u);
-            const unsigned other = (unsigned)__shfl_xor((int)nib, 16, 64);
-            const unsigned byte = (q & 1) ? 0u : (nib | (other << 4));
-            const unsigned moff = (unsigned)(((oy0 + pb) * g.w + ox) * (g.cout >> 3) + nb * 2 + (q >> 1));
-            __builtin_amdgcn_raw_buffer_store_b8((char)byte, rsig, (!(q & 1) && ch + 8 <= g.cout) ? moff : OOB, 0, 0);
-          }
-        }
-        // 2x2 average of the ROUNDED outputs, added as pool_quad does: column pairs first, then the even row + the odd row
-        float pv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float r0 = (j & 1) ? unpack16_hi<F16>(o[0][j >> 1]) : unpack16_lo<F16>(o[0][j >> 1]);
-          float r1 = (j & 1) ? unpack16_hi<F16>(o[1][j >> 1]) : unpack16_lo<F16>(o[1][j >> 1]);
-          r0 += __shfl_xor(r0, 1, 64);
-          r1 += __shfl_xor(r1, 1, 64);
-          pv[j] = 0.25f * (r0 + r1);
-        }
-        u32x2 po;
-        po[0] = pack16x2<F16>(pv[0], pv[1]);
-        po[1] = pack16x2<F16>(pv[2], pv[3]);
-        const __amdgpu_buffer_rsrc_t rpool = make_rsrc(g.ypool + (size_t)img * (out_img / 4), (unsigned)(out_img / 4 * 2));
-        const bool owner = (c16 & 1) == 0;
-        __builtin_amdgcn_raw_buffer_store_b64(
-            po, rpool, (owner && ch + 4 <= g.cout) ? (unsigned)((((oy0 >> 1) * (g.w >> 1) + (ox >> 1)) * g.cout + ch) * 2) : OOB, 0, 0);
-      }
-    }
-  }
-  if constexpr (STATS) {
-#pragma unroll
-    for (int i = 0; i < NB * 8; ++i) {
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) sacc[i] += __shfl_xor(sacc[i], o, 64);
-    }
-    float* red = reinterpret_cast<float*>(sA);      // [wave][which][32]
-    __syncthreads();
-    if (c16 == 0) {
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          red[(wid * 2 + 0) * 32 + nb * 16 + 4 * q + j] = sacc[nb * 8 + j];
-          red[(wid * 2 + 1) * 32 + nb * 16 + 4 * q + j] = sacc[nb * 8 + 4 + j];
-        }
-    }
-    __syncthreads();
-    if (tid < 64) {
-      const int which = tid >> 5, ch = tid & 31;
-      const float tsum = (red[(0 * 2 + which) * 32 + ch] + red[(1 * 2 + which) * 32 + ch]) +
-                         (red[(2 * 2 + which) * 32 + ch] + red[(3 * 2 + which) * 32 + ch]);
       const int tpi = g.tiles_x * g.tiles_y;
       float* out = g.stats + ((size_t)(t_begin / tpi) * g.stat_chunks + (t_begin % tpi) / g.tiles_per_wg) * 2 * g.cout;
       if (ch < g.cout) out[(size_t)which * g.cout + ch] = tsum;
@@ -1703,13 +1427,9 @@ __global__ __launch_bounds__(256) void conv_thin16_upcat_kernel(const bf16* __re
 // 3x3 layers with <= 16 output channels and one 16- / 32-channel chunk (or the 32 + 32 concat) go to the thin-output kernels;
 // TG_THIN16=0: the 32-wide-block kernels instead (A/B switch, read at every call: two captures in one process can differ)
 inline bool thin16_on() { return tg_tune("TG_THIN16", 1) != 0; }
-// ... with the unpooling input too (the 256 x 256 block end's backward-data, 32 -> 16 channels): TG_THIN16_UNPOOL=1, an A/B
-// switch that is OFF -- built on the emulated kernels after the round's last GPU minute, never timed
-inline bool thin16_unpool_on() { return tg_tune("TG_THIN16_UNPOOL", 0) != 0; }
 inline bool thin16_takes(const TileGeom& g) {
-  if (g.up_src && !(thin16_unpool_on() && g.cin_pad == 32 && g.epilogue == 0)) return false;
   return thin16_on() && g.cout <= 16 && g.cout % 4 == 0 && (g.cin_pad == 16 || g.cin_pad == 32) && g.cin == g.cin_pad && !g.ypool &&
-         !g.up_out && !g.skip_out && !(g.mask && (g.epilogue & TG_EPI_BIAS));
+         !g.up_src && !g.up_out && !g.skip_out && !(g.mask && (g.epilogue & TG_EPI_BIAS));
 }
 
 template <int KC>
@@ -1735,27 +1455,6 @@ int launch_thin16(const TileGeom& g0, const bf16* x, const bf16* wp, const float
   g.tiles_per_wg = tpw;
   const int nwg = (g.nblk + tpw - 1) / tpw;
   const size_t lds = (size_t)((10 * 18 * (KC * 2 + 16) + 15) & ~15);
-  if (g.up_src) {
-    if constexpr (KC == 32) {
-      TG_CHECK(!stats && !(g.epilogue & TG_EPI_BIAS), TG_ENOSUP, "conv_thin16: the unpooling input comes with the plain / masked epilogue");
-      tg_note_kernel(g.f16 ? "conv_thin16_kernel<32,%s,f16>" : "conv_thin16_kernel<32,%s>", g.up_z ? "unpoolz" : "unpool");
-#define TG_THIN_UP(EPI_, UP_)                                                                                                        \
-  do {                                                                                                                               \
-    if (g.f16) hipLaunchKernelGGL((conv_thin16_kernel<32, 0, true, EPI_, UP_>), dim3(nwg), dim3(256), lds, s, x, wp, bias, y, g);    \
-    else hipLaunchKernelGGL((conv_thin16_kernel<32, 0, false, EPI_, UP_>), dim3(nwg), dim3(256), lds, s, x, wp, bias, y, g);         \
-  } while (0)
-      if (g.up_z) {
-        if (g.mask) TG_THIN_UP(2, 2);
-        else TG_THIN_UP(0, 2);
-      } else if (g.mask) TG_THIN_UP(2, 1);
-      else TG_THIN_UP(0, 1);
-#undef TG_THIN_UP
-      TG_LAUNCH_CHECK("conv_thin16(unpool)");
-      return TG_OK;
-    } else {
-      TG_CHECK(false, TG_ENOSUP, "conv_thin16: the unpooling input comes in 32-channel chunks");
-    }
-  }
   tg_note_kernel(g.f16 ? "conv_thin16_kernel<%d%s,f16>" : "conv_thin16_kernel<%d%s>", KC, stats ? ",stats" : "");
 #define TG_THIN_LAUNCH(MODE_, EPI_)                                                                                              \
   do {                                                                                                                           \
@@ -1768,58 +1467,6 @@ int launch_thin16(const TileGeom& g0, const bf16* x, const bf16* wp, const float
   else TG_THIN_LAUNCH(0, 0);
 #undef TG_THIN_LAUNCH
   TG_LAUNCH_CHECK("conv_thin16");
-  return TG_OK;
-}
-
-inline bool thin32_takes(const TileGeom& g) {
-  return tg_tune("TG_THIN32", 0) != 0 && g.cout > 16 && g.cout <= 32 && g.cout % 8 == 0 && (g.cin_pad == 16 || g.cin_pad == 32) &&
-         g.cin == g.cin_pad && !g.up_src && !g.up_out && !g.skip_out && !(g.mask && (g.epilogue & TG_EPI_BIAS)) &&
-         !(g.ypool && (g.mask || g.stats || g.chunks_query)) && !(g.ymask && !g.ypool);
-}
-
-template <int KC>
-int launch_thin32(const TileGeom& g0, const bf16* x, const bf16* wp, const float* bias, bf16* y, hipStream_t s) {
-  TileGeom g = g0;
-  g.tiles_x = g.w / 16;
-  g.tiles_y = g.h / 8;
-  g.nblk = g.tiles_x * g.tiles_y * g.n;
-  int tpw = g.nblk / (256 * 4);
-  if (tpw < 1) tpw = 1;
-  if (tpw > 16) tpw = 16;
-  const bool stats = g.stats || g.chunks_query;
-  if (stats) {
-    const int tpi = g.tiles_x * g.tiles_y;
-    while (tpi % tpw) --tpw;
-    if (g.chunks_query) {
-      *g.chunks_query = tpi / tpw;
-      return TG_OK;
-    }
-    TG_CHECK(g.stat_chunks == tpi / tpw, TG_EINVAL, "conv_thin32: stat_chunks %d, this dispatch writes %d", g.stat_chunks, tpi / tpw);
-    TG_CHECK(g.epilogue == 0 && !g.mask, TG_ENOSUP, "conv_thin32: statistics come with the plain epilogue only");
-  }
-  g.tiles_per_wg = tpw;
-  const int nwg = (g.nblk + tpw - 1) / tpw;
-  const size_t lds = (size_t)((10 * 18 * (KC * 2 + 16) + 15) & ~15);
-  const char* tag = stats ? ",stats" : g.ypool ? (g.ymask ? ",pool,signs" : ",pool") : "";
-  tg_note_kernel(g.f16 ? "conv_thin32_kernel<%d%s,f16>" : "conv_thin32_kernel<%d%s>", KC, tag);
-#define TG_THIN32_LAUNCH(MODE_, EPI_)                                                                                            \
-  do {                                                                                                                           \
-    if (g.f16) hipLaunchKernelGGL((conv_thin32_kernel<KC, MODE_, true, EPI_>), dim3(nwg), dim3(256), lds, s, x, wp, bias, y, g); \
-    else hipLaunchKernelGGL((conv_thin32_kernel<KC, MODE_, false, EPI_>), dim3(nwg), dim3(256), lds, s, x, wp, bias, y, g);     \
-  } while (0)
-  const bool has_bias = (g.epilogue & TG_EPI_BIAS) != 0;
-  if (stats) TG_THIN32_LAUNCH(1, 0);
-  else if (g.ypool && g.ymask) {
-    if (has_bias) TG_THIN32_LAUNCH(3, 1);
-    else TG_THIN32_LAUNCH(3, 0);
-  } else if (g.ypool) {
-    if (has_bias) TG_THIN32_LAUNCH(2, 1);
-    else TG_THIN32_LAUNCH(2, 0);
-  } else if (g.mask) TG_THIN32_LAUNCH(0, 2);
-  else if (has_bias) TG_THIN32_LAUNCH(0, 1);
-  else TG_THIN32_LAUNCH(0, 0);
-#undef TG_THIN32_LAUNCH
-  TG_LAUNCH_CHECK("conv_thin32");
   return TG_OK;
 }
 
@@ -2093,8 +1740,6 @@ int dispatch_tile(const TileGeom& g, const bf16* x, const bf16* wp, const float*
   const bool skip_wres = stats_wide_tile && wide && (g.stats || g.chunks_query);
   if constexpr (KH == 3) {
     if (tiles1 >= 2048 && thin16_takes(g)) return g.cin_pad == 16 ? launch_thin16<16>(g, x, wp, bias, y, s) : launch_thin16<32>(g, x, wp, bias, y, s);
-    if (tiles1 >= 2048 && !wide && thin32_takes(g) && (!g.ypool || (g.h % 2 == 0 && g.w % 2 == 0)))
-      return g.cin_pad == 16 ? launch_thin32<16>(g, x, wp, bias, y, s) : launch_thin32<32>(g, x, wp, bias, y, s);
   }
   if (tiles1 >= 2048 && !skip_wres && !(g.up_src && g.cin_pad != 32)) {
     if (g.cin_pad == 16) return wide ? launch_tile_wres<KH, 16, 64, 1>(g, x, wp, bias, y, s) : launch_tile_wres<KH, 16, 32, 1>(g, x, wp, bias, y, s);

@@ -1242,32 +1242,6 @@ int tg_wgrad_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int g
   return tg_wgrad_slab_reduce((const float*)ws, gw, nw, nslices, accumulate, s);
 }
 
-// The slab reduction of a filter gradient that ACCUMULATES into a gradient sink is needed by nobody before the optimiser
-// runs: with an auxiliary stream set (tg_set_aux_stream; the trainer, around a backward pass) it is enqueued there behind
-// an event of the launch stream, off the critical path of the backward-data chain (a ~5 us launch plus a kernel boundary
-// per filter gradient: 86 per bench step).  The caller joins the auxiliary stream before it consumes the sinks and keeps
-// the workspace alive for that stream.  A gradient that is WRITTEN (accumulate == 0: the caller reads it next) stays on
-// the launch stream.
-static hipStream_t wg_reduce_stream(hipStream_t s, int accumulate) {
-  hipStream_t aux = (hipStream_t)tg_aux_stream();
-  if (!aux || aux == s || !accumulate) return s;
-  // one pool per device (events belong to the device they were created on); a backward pass is one host thread per device
-  constexpr int MAXDEV = 16;
-  static hipEvent_t pool[MAXDEV][64];
-  static int made[MAXDEV] = {0}, next[MAXDEV] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return s;
-  if (!made[dev]) {
-    for (int i = 0; i < 64; ++i)
-      if (hipEventCreateWithFlags(&pool[dev][i], hipEventDisableTiming) != hipSuccess) return s;
-    made[dev] = 1;
-  }
-  hipEvent_t ev = pool[dev][next[dev]];
-  next[dev] = (next[dev] + 1) & 63;
-  if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(aux, ev, 0) != hipSuccess) return s;
-  return aux;
-}
-
 // ---- deferred, batched slab reductions -------------------------------------------------------------------------------
 // Between tg_wgrad_defer(1) and tg_wgrad_defer_flush the reductions that ACCUMULATE into a caller buffer (gradient sinks:
 // nobody reads them before the optimiser) are not launched but queued; the flush issues all of them as ONE launch whose
@@ -1426,7 +1400,6 @@ int tg_wgrad_slab_reduce(const float* slab, float* gw, int64_t nw, int nslices, 
     return TG_OK;
   }
   lock.unlock();
-  s = wg_reduce_stream(s, accumulate);
   if (nw < 16384)
     hipLaunchKernelGGL(conv_wgrad_slab_reduce<16>, dim3((unsigned)((nw + 15) / 16)), dim3(256), 0, s, slab, gw, nw, nslices,
                        accumulate);

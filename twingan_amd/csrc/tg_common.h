@@ -203,8 +203,6 @@ template <typename T> constexpr bool exact_path() { return sizeof(T) == 4; }
 // (exact_path<T>() stays the compile-time question "is this the fp32 parity path", e.g. for the run-time-flag variants
 // of the normalisation kernels whose contraction pattern must not change.)
 int tg_deterministic_mode();
-// auxiliary stream for work nobody waits for inside a backward pass (tg_set_aux_stream; NULL: none)
-void* tg_aux_stream();
 template <typename T> inline bool exact_grid() { return sizeof(T) == 4 || tg_deterministic_mode() != 0; }
 
 // launch-heuristic experiments: TG_TUNE_<NAME>=<int> in the environment overrides `dflt` (read at every call, so

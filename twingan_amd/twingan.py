@@ -368,19 +368,6 @@ class Trainer:
     self._graphs = self._static = None
     self.store.close()
 
-  def _aux_stream(self):
-    """The stream the filter gradients' slab reductions run on during a backward pass -- OFF unless TG_WGRAD_AUX=1:
-    measured on one box, interleaved (gpurun_out r3o), 887.6 / 887.4 images/s without and 811.0 / 810.8 with it.  The 86
-    reductions of a step are off the backward-data chain then, but each costs an event record + a cross-stream wait, and in
-    a replayed hipGraph a cross-stream edge is dearer than the same-stream boundary it replaces (the same lesson as the
-    filter gradients on companion streams).  Kept as a switch; correct either way (golden / model
-    suites pass with it on)."""
-    if self.device.type != 'cuda' or os.environ.get('TG_WGRAD_AUX', '0') != '1':
-      return None
-    if getattr(self, '_aux', None) is None:
-      self._aux = torch.cuda.Stream(device=self.device)
-    return self._aux
-
   # ---- optimiser --------------------------------------------------------------------------------
   def _nseg(self, group):
     return len(self.store.phase_bounds[group]) if self.split else 1
@@ -442,15 +429,8 @@ class Trainer:
       out = (loss.detach(), {k: v.detach() for k, v in terms.items()})
       scaled = loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)       # model_deploy.py:265-268,308-313
       ops.GradSink.pair = True
-      # low-resolution filter gradients on a forked stream next to the high-resolution part of the backward (A/B switch)
-      ops.WgradFork.reset()
-      ops.WgradFork.active = os.environ.get('TG_WGRAD_FORK', '0') == '1'
       # the slab reductions of the filter gradients that feed gradient sinks: queued, one launch per backward segment
       ops.defer_slab_reductions(os.environ.get('TG_WGRAD_DEFER', '1') != '0')
-      aux = self._aux_stream()
-      if aux is not None:      # the slab reductions of the filter gradients leave the backward's critical path
-        aux.wait_stream(torch.cuda.current_stream(self.device))      # ... after the zero fill of the gradient buffers
-        ops.set_aux_stream(aux)
       for seg in range(nseg):
         if seg == 0:
           scaled.backward()
@@ -458,25 +438,18 @@ class Trainer:
           roots, grads = ops.Cuts.roots(seg)
           torch.autograd.backward(roots, grads)
         _DomainStreams.join_all(self.device)
-        ops.WgradFork.join()
         last = seg == nseg - 1
         if nseg > 1:      # spectrally normalised kernels whose uses are all behind us: through the normalisation's backward
           pggan.sn_segment_backward(self.P, lambda scope, seg=seg: last or self.store.phase.get(scope + '/weights', 0) <= seg)
         # filter gradients still waiting for a pair: issue those this segment completes, keep the others
         ops.GradSink.flush(None if last else (lambda ptr, seg=seg: self._ptr_phase.get(ptr, 0) <= seg))
         ops.flush_slab_reductions()      # after the join: every queued slab is written, the launch is on the main stream
-        if aux is not None:      # the segment's gradients are complete only once their reductions are
-          torch.cuda.current_stream(self.device).wait_stream(aux)
         if last:
           pggan.end_run(self.P)
         yield seg, out
     finally:
       ops.GradSink.pair = False
-      ops.WgradFork.active = False
-      ops.WgradFork.reset()
       ops.defer_slab_reductions(False)
-      if ops.AUX_STREAM is not None:
-        ops.set_aux_stream(None)
       if nseg > 1:
         ops.Cuts.end()
 
@@ -588,6 +561,12 @@ class Trainer:
     ops.GradSink.pair = False
     ops.defer_slab_reductions(False)
     ops.Cuts.end()
+    # the per-run spectrally normalised kernels of the aborted capture (detached leaves, u' tensors from the capture pool
+    # that never executed): dropped WITHOUT assigning u', so the next prepare_run() runs the power iteration again
+    for name in ('sn_cache', 'sn_pending', 'sn_leaves'):
+      d = self.P.__dict__.get(name)
+      if d:
+        d.clear()
     _DomainStreams.join_all(self.device)
     self.store.zero_grad('g')
     self.store.zero_grad('d')
