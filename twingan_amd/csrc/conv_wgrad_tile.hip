@@ -60,6 +60,7 @@ struct WgGeom {
   int bias_segs;      // bit 0: segment a contributes to gbias, bit 1: segment b
   int nw;             // waves per workgroup of the tile kernel: 4 (8-row tiles) or 8 (16-row tiles)
   int quad;           // 1: conv_wgrad_quad_kernel (64 x 64 blocks, 8 waves); n_co_blk / n_pairs then count 64-wide blocks
+  int vec_ok;         // 16-byte slab stores: cout % 4 == 0 and the slab 16-byte aligned (set by the launchers)
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
@@ -89,7 +90,6 @@ template <int TW, bool BIAS = false, bool F16 = false, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void conv_wgrad_tile_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gy,
                                                                  float* __restrict__ slab, const WgGeom g) {
   static_assert(NW == 4 || (NW == 8 && TW == 16), "8 waves: 16-row tiles of the 16-column kernel only");
-  constexpr bool ATOMIC = false;
   constexpr int THREADS = 64 * NW;
   constexpr int TH = 2 * NW, HWX = TW + 2, HH = TH + 2, NT = 9;        // TW = 16: wave w reduces rows 2w, 2w + 1
   constexpr int IPT = 16 / TW;                      // images per tile
@@ -398,34 +398,45 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tile_kernel(const bf16* __
     reduce_tile(sX1, sG1, bias_1);
   }
 
-  // ---- cross-wave reduction through LDS, one tap at a time; write the valid part of the slab.
+  // ---- cross-wave reduction through LDS and the slab write.
   // acc[tap][r]: ci = ci0 + (r & 3) + 8*(r >> 2) + 4*(lane >> 5), co = co0 + (lane & 31)
-  float* red = reinterpret_cast<float*>(wg_smem);    // [NW waves][16 regs][64 lanes] = 16 / 32 KiB
-  // ATOMIC: `slab` is the gradient itself and every workgroup adds its partial sums into it (one
-  // global_atomic_add_f32 per element, 64 consecutive floats per wave instruction) -- no slab round trip
-  // through HBM and no second launch.
-  float* out = ATOMIC ? slab : slab + (size_t)slice * NT * g.cin * g.cout;
+  // A thread owns FOUR consecutive co of one ci: 16-byte LDS reads of each wave's partial sums, one 16-byte slab store.
+  // TPP taps per phase (two with 8 waves, so that all 512 threads hold a float4): 18 barriers -> 10.  The
+  // one-element-per-thread form (4-byte stores of 128-byte runs, two barriers per tap) cost 8 us of a 15-19 us launch at
+  // n = 16 -- 5 us of it the stores (profiles/r05_c_wgrad_epilogue_probes.txt); the sums are taken in the same order.
+  constexpr int TPP = NW / 4;
+  float* red = reinterpret_cast<float*>(wg_smem);    // [TPP][NW waves][16 regs][64 lanes] floats = 16 / 64 KiB
+  float* out = slab + (size_t)slice * NT * g.cin * g.cout;
+  {
+    const int tp = tid >> 8, q = tid & 255;
+    const int r = q >> 4, l4 = (q & 15) * 4;
+    const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * (l4 >> 5);
+    const int co = co0 + (l4 & 31);
 #pragma unroll
-  for (int tap = 0; tap < NT; ++tap) {
-    __syncthreads();
+    for (int p = 0; p < (NT + TPP - 1) / TPP; ++p) {
+      __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wid * 16 + r) * 64 + lane] = acc[tap][r];
-    __syncthreads();
-    const int l2 = tid & 63, rq = tid >> 6;
-    constexpr int RPT = 16 / NW;      // accumulator registers summed per thread: 16 regs x 64 lanes over 64 * NW threads
+      for (int t = 0; t < TPP; ++t) {
+        if (p * TPP + t < NT) {
 #pragma unroll
-    for (int j = 0; j < RPT; ++j) {
-      const int r = rq * RPT + j;
-      float sum = red[(0 * 16 + r) * 64 + l2] + red[(1 * 16 + r) * 64 + l2] + red[(2 * 16 + r) * 64 + l2] +
-                  red[(3 * 16 + r) * 64 + l2];
-      if constexpr (NW == 8)      // waves in a fixed order
-        sum += red[(4 * 16 + r) * 64 + l2] + red[(5 * 16 + r) * 64 + l2] + red[(6 * 16 + r) * 64 + l2] +
-               red[(7 * 16 + r) * 64 + l2];
-      const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * (l2 >> 5);
-      const int co = co0 + (l2 & 31);
-      if (ci < g.cin && co < g.cout) {
-        if (ATOMIC) atomicAdd(out + ((size_t)tap * g.cin + ci) * g.cout + co, sum);
-        else out[((size_t)tap * g.cin + ci) * g.cout + co] = sum;
+          for (int rr = 0; rr < 16; ++rr) red[((t * NW + wid) * 16 + rr) * 64 + lane] = acc[p * TPP + t][rr];
+        }
+      }
+      __syncthreads();
+      const int tap = p * TPP + tp;
+      if (tap < NT && ci < g.cin && co < g.cout) {
+        const float* src = red + ((tp * NW) * 16 + r) * 64 + l4;
+        auto part = [&](int w) { return *reinterpret_cast<const f32x4*>(src + w * 16 * 64); };
+        f32x4 sum = part(0) + part(1) + part(2) + part(3);      // waves in a fixed order
+        if constexpr (NW == 8) sum += part(4) + part(5) + part(6) + part(7);
+        float* dst = out + ((size_t)tap * g.cin + ci) * g.cout + co;
+        if (g.vec_ok) {      // cout % 4 == 0 and a 16-byte aligned slab
+          *reinterpret_cast<f32x4*>(dst) = sum;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (co + j < g.cout) dst[j] = sum[j];
+        }
       }
     }
   }
@@ -672,24 +683,42 @@ __global__ __launch_bounds__(512) void conv_wgrad_quad_kernel(const bf16* __rest
     reduce_tile(sX1, sG1, bias_1);
   }
 
-  // ---- the two 4-row halves of every quadrant are summed through LDS (kh = 0 first: a fixed order), tap by tap
+  // ---- the two 4-row halves of every quadrant are summed through LDS (kh = 0 first: a fixed order), two taps per phase;
+  // a thread owns four consecutive co of one ci (16-byte LDS reads, 16-byte slab stores: see conv_wgrad_tile_kernel)
   // acc[tap][r]: ci = ci0 + 32 qi + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), co = co0 + 32 qo + (lane & 31)
-  float* red = reinterpret_cast<float*>(wg_smem);      // [8 waves][16 regs][64 lanes] = 32 KiB
+  float* red = reinterpret_cast<float*>(wg_smem);      // [2 taps][8 waves][16 regs][64 lanes] floats = 64 KiB
   float* out = slab + (size_t)slice * NT * g.cin * g.cout;
 #pragma unroll
-  for (int tap = 0; tap < NT; ++tap) {
+  for (int p = 0; p < (NT + 1) / 2; ++p) {
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wid * 16 + r) * 64 + lane] = acc[tap][r];
-    __syncthreads();
-    const int l2 = tid & 63, q = (tid >> 6) & 3, half = tid >> 8;      // quadrant q = qi + 2 qo, registers 8 half .. 8 half + 7
+    for (int t = 0; t < 2; ++t) {
+      if (p * 2 + t < NT) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int r = half * 8 + j;
-      const float sum = red[(q * 16 + r) * 64 + l2] + red[((q + 4) * 16 + r) * 64 + l2];
-      const int ci = ci0 + (q & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l2 >> 5);
-      const int co = co0 + (q >> 1) * 32 + (l2 & 31);
-      if (ci < g.cin && co < g.cout) out[((size_t)tap * g.cin + ci) * g.cout + co] = sum;
+        for (int r = 0; r < 16; ++r) red[((t * 8 + wid) * 16 + r) * 64 + lane] = acc[p * 2 + t][r];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 512 * i;
+      const int tp = idx >> 10, q = (idx >> 8) & 3, rem = idx & 255;      // quadrant q = qi + 2 qo
+      const int r = rem >> 4, l4 = (rem & 15) * 4;
+      const int tap = p * 2 + tp;
+      const int ci = ci0 + (q & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l4 >> 5);
+      const int co = co0 + (q >> 1) * 32 + (l4 & 31);
+      if (tap < NT && ci < g.cin && co < g.cout) {
+        const f32x4 sum = *reinterpret_cast<const f32x4*>(red + ((tp * 8 + q) * 16 + r) * 64 + l4) +
+                          *reinterpret_cast<const f32x4*>(red + ((tp * 8 + q + 4) * 16 + r) * 64 + l4);
+        float* dst = out + ((size_t)tap * g.cin + ci) * g.cout + co;
+        if (g.vec_ok) {
+          *reinterpret_cast<f32x4*>(dst) = sum;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (co + j < g.cout) dst[j] = sum[j];
+        }
+      }
     }
   }
   if constexpr (BIAS) {
@@ -1031,6 +1060,7 @@ void wg_split(int n, int h, int w, int cin, int cout, WgGeom* g, int* nslices, i
               bool bias = false) {
   const bool thin = wg_thin(h, w, cin, cout);
   g->quad = (allow_quad && w != 8 && wg_quad(h, w, cin, cout, c0, (w / 16) * (h / 8) * (n + nb), bias)) ? 1 : 0;
+  g->vec_ok = 0;
   g->nw = g->quad ? 8 : wg_waves(h, w, cin, cout);
   g->n = n; g->h = h; g->w = w; g->cin = cin; g->cout = cout;
   g->x1 = nullptr;
@@ -1090,7 +1120,9 @@ bool wg_launch_thin(const WgGeom& g, const bf16* x, const bf16* gy, float* ws, i
   return true;
 }
 // launches conv_wgrad_tile_kernel for geometry g (already split, pointers and bias fields set)
-int wg_launch_tile(const WgGeom& g, const bf16* x, const bf16* gy, float* ws, int nslices, hipStream_t s) {
+int wg_launch_tile(const WgGeom& g0, const bf16* x, const bf16* gy, float* ws, int nslices, hipStream_t s) {
+  WgGeom g = g0;
+  g.vec_ok = (g.cout % 4 == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) ? 1 : 0;
   const int n_ci = (g.cin + 31) / 32;
   const dim3 grid(nslices * n_ci * g.n_co_blk);
   // two tile buffers; the first bytes double as the cross-wave reduction scratch (16 KiB for 4 waves, 32 KiB for 8)
