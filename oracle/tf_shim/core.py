@@ -506,6 +506,10 @@ def get_variable(name, shape=None, dtype=None, initializer=None, regularizer=Non
   else:
     if initializer is None:
       initializer = glorot_uniform_initializer()
+    if getattr(initializer, '_tf_initializer_class', False):
+      # the CLASS passed uninstantiated (initializer=tf.zeros_initializer, image_generation.py:1035-1038): TensorFlow
+      # instantiates it with the variable's dtype (variable_scope._get_single_variable)
+      initializer = initializer(dtype=dtype)
     if callable(initializer):
       t = raw(initializer(shape_list(shape), dtype=dtype))
     else:
@@ -570,6 +574,10 @@ def zeros_initializer(dtype=None):
 
 def ones_initializer(dtype=None):
   return lambda shape, dtype=None, partition_info=None: Tensor(torch.ones(shape_list(shape), dtype=F64))
+
+
+zeros_initializer._tf_initializer_class = True      # classes in TensorFlow: get_variable accepts them uninstantiated
+ones_initializer._tf_initializer_class = True
 
 
 def constant_initializer(value=0.0, dtype=None):

@@ -571,9 +571,11 @@ def test_full_size_properties_256_bf16():
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
-def test_full_size_256_hits_the_reference(precision):
-  """BASELINE.json's headline configuration at FULL size (256x256, 256 channels, batch 2) against what the
-  reference's own code computed for it (tests/golden/full_hw256_c256.json, tools/make_golden.py --full: the graph of
+@pytest.mark.parametrize('hw', [64, 128, 256])
+def test_full_width_stage_hits_the_reference(hw, precision):
+  """BASELINE.json's configurations at FULL width -- configs[1] (64x64), configs[2] (128x128) and the headline configs[3]
+  (256x256), 256 channels, batch 2 -- against what the
+  reference's own code computed for each (tests/golden/full_hw<hw>_c256.json, tools/make_golden.py --full [--hw N]: the graph of
   twingan.GanModel._clone_fn executed on the TF stand-in): every loss term, probes of every generated image, and --
   fp32 path -- the norm of every variable's gradient.  Weights and inputs are re-created from the fixture's seeds.
   Measured (tools/full_size_report.py): fp32 path -- worst loss term 2.3e-6, worst probe 2.3e-5, gradient-norm ratios
@@ -581,14 +583,16 @@ def test_full_size_256_hits_the_reference(precision):
   (to max(1, |x|)), probes 1e-3, gradient norms 1 % (of max(norm, 1e-3 of the group's largest)); bf16 losses 3e-2,
   probes 0.3, gradient-norm ratios 0.5..1.6 with the median within 3 %, and -- the bound that carries the weight -- the
   aggregate deviation of each group's gradients from the float64 ones <= 1.5 x the deviation bf16 storage rounding alone
-  causes in the float64 oracle on the same weights and inputs (tests/golden/full_hw256_c256_rounding.json)."""
+  causes in the float64 oracle on the same weights and inputs (tests/golden/full_hw<hw>_c256_rounding.json,
+  tools/make_rounding_sketch.py [--hw N]).  The figures quoted above are the 256 x 256 ones."""
   import json
   import os
   from twingan_amd import Config
   from twingan_amd import twingan as T
-  with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'full_hw256_c256.json')) as fh:
+  with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'full_hw%d_c256.json' % hw)) as fh:
     fix = json.load(fh)
-  hw, batch = fix['config']['hw'], fix['batch']
+  assert fix['config']['hw'] == hw
+  batch = fix['batch']
   rcfg = R.Config(**fix['config'])
   P = R.init_params(rcfg, seed=fix['param_seed'], dtype=torch.float64, std='he')
   cfg = Config(precision=precision, **fix['config'])
@@ -638,7 +642,7 @@ def test_full_size_256_hits_the_reference(precision):
       # by 0.080 -- and K = 16 seeded +-1 projections of every variable's float64 gradient, from which |g_hip - g_64|^2 of a
       # group is estimated without the 71 MB of gradients (E[(r . d)^2] = |d|^2; the same estimator reads 0.378 / 0.092 on
       # the rounded oracle itself).
-      with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'full_hw256_c256_rounding.json')) as fh:
+      with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'full_hw%d_c256_rounding.json' % hw)) as fh:
         rs = json.load(fh)
       num = den = 0.0
       for k in names:
@@ -650,8 +654,8 @@ def test_full_size_256_hits_the_reference(precision):
         num += float(((h - e) ** 2).sum())
         den += float((e ** 2).sum())
       rel = (num / den) ** 0.5
-      print('[full size bf16] %s group: kernels %.3f from the float64 gradients (sketch estimate); storage rounding alone %.3f'
-            % (group, rel, rs['rounded_rel_l2'][group]))
+      print('[full width %d bf16] %s group: kernels %.3f from the float64 gradients (sketch estimate); storage rounding alone %.3f'
+            % (hw, group, rel, rs['rounded_rel_l2'][group]))
       assert rel < 1.5 * rs['rounded_rel_l2'][group] + 0.02, (group, rel, rs['rounded_rel_l2'][group])
     assert not bad, bad[:5]
     del loss, terms, gd

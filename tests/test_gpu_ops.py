@@ -905,6 +905,56 @@ def test_lrelu_backward_folded_into_next_backward_data(ops, dtype, hw, c1, c2):
       assert rel_l2(a, b) < tol
 
 
+SMALL_MASK_CASES = [
+    # n, hw, cin, cout, k, padding, kernel family of the backward-data
+    (5, 8, 256, 256, 3, 'SAME', 'conv_img'),
+    (3, 8, 512, 256, 3, 'SAME', 'conv_img'),
+    (5, 4, 256, 256, 3, 'SAME', 'conv_small'),
+    (6, 4, 264, 256, 3, 'SAME', 'conv_small'),      # the minibatch-stddev layer: 264 input channels (a partial last block)
+    (6, 4, 64, 64, 4, 'VALID', 'conv_small'),       # the dense rewrite of the discriminator's 4x4 VALID conv
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('n,hw,cin,cout,k,padding,family', SMALL_MASK_CASES)
+def test_masked_backward_data_on_the_small_maps(ops, dtype, n, hw, cin, cout, k, padding, family):
+  """tg_conv2d_bwd_data_masked at the 8x8 / 4x4 maps and the dense 4x4-VALID layer: the LeakyReLU backward of the layer
+  below rides in the epilogue of conv_img / conv_small (as it does in conv_tile's from 16x16 up) -- ONE launch, no
+  tg_lrelu_bwd pass over the result -- against the float64 oracle on rounded operands (one rounding of the product)."""
+  from twingan_amd import _lib
+  rng = np.random.RandomState(31)
+  rnd = bf16_round if dtype == torch.bfloat16 else f16_round
+  x = rnd(rng.randn(n, hw, hw, cin))
+  wt = rnd(rng.randn(k, k, cin, cout) / np.sqrt(k * k * cin))
+  spec = ops.ConvSpec(k, padding)
+  ho, wo = spec.out_hw(hw, hw)
+  gy = rnd(rng.randn(n, ho, wo, cout))
+  xd, gyd, wd = to_dev(x, dtype), to_dev(gy, dtype), to_dev(wt)
+  names = []
+  import twingan_amd.ops as O
+  real = O.call
+
+  def spy(name, *a, **kw):
+    names.append(name)
+    return real(name, *a, **kw)
+  O.call = spy
+  try:
+    gxm = ops.conv_bwd_data_masked_raw(gyd, wd, xd, spec)
+  finally:
+    O.call = real
+  kern = _lib.load().tg_last_kernel().decode()
+  assert names[-1] == 'tg_conv2d_bwd_data_masked' and 'tg_lrelu_bwd' not in names and family in kern, (names, kern)      # the conv kernel ran LAST: no mask pass after it
+  ref = N.conv2d_bwd_data(gy, wt, (hw, hw), padding) * np.where(x > 0, 1.0, 0.2)
+  assert rel_l2(host(gxm), ref) < (8e-4 if dtype == torch.float16 else 5e-3)
+  plain = ops.conv_bwd_data_raw(gyd, wd, (n, hw, hw, cin), spec)      # the same kernel without the mask: untouched
+  assert rel_l2(host(plain), N.conv2d_bwd_data(gy, wt, (hw, hw), padding)) < (8e-4 if dtype == torch.float16 else 5e-3)
+  # ... and the forward conv with the mask of its OUTPUT's shape (tg_conv2d_fwd_masked: the gradient penalty's second pass)
+  msrc = rnd(rng.randn(n, ho, wo, cout))
+  ym = ops.conv_fwd_masked_raw(xd, wd, to_dev(msrc, dtype), spec)
+  assert family in _lib.load().tg_last_kernel().decode()
+  assert rel_l2(host(ym), N.conv2d(x, wt, padding) * np.where(msrc > 0, 1.0, 0.2)) < (8e-4 if dtype == torch.float16 else 5e-3)
+
+
 @pytest.mark.parametrize('dtype,hw,c1,c2', [(torch.bfloat16, 16, 32, 64), (torch.float32, 8, 8, 8), (torch.bfloat16, 32, 16, 16)])
 def test_lrelu_fold_under_create_graph_matches_unfused(ops, dtype, hw, c1, c2):
   """Gradient-penalty shaped double backward through conv+bias+lrelu -> conv+bias+lrelu -> conv: with fuse_input_lrelu

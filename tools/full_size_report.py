@@ -1,6 +1,6 @@
 """Prints how far the HIP path is from the reference-computed full-size fixture (tests/golden/full_hw256_c256.json):
 worst loss-term deviation, worst image-probe deviation, and the distribution of per-variable gradient-norm ratios,
-for the fp32 and the bf16 path.  Same comparison as tests/test_gpu_model.py::test_full_size_256_hits_the_reference."""
+for the fp32 and the bf16 path.  Same comparison as tests/test_gpu_model.py::test_full_width_stage_hits_the_reference."""
 import json
 import os
 import sys

@@ -512,10 +512,13 @@ if __name__ == '__main__':
     for name, (batch, kw) in PGGAN_CASES.items():
       np.savez_compressed(os.path.join(OUT, name + '.npz'), **pggan_model(batch, **kw))
       print(name, os.path.getsize(os.path.join(OUT, name + '.npz')))
-  elif '--full' in sys.argv:      # only the full-size fixture (slow); the default run leaves it untouched
+  elif '--full' in sys.argv:      # only a full-width fixture (slow); the default run leaves them untouched
+    # --full [--hw 64|128|256]: BASELINE.json configs[1] / configs[2] / configs[3] at 256 channels, batch 2
     import json
-    with open(os.path.join(OUT, 'full_hw256_c256.json'), 'w') as fh:
-      json.dump(full_size(), fh, indent=0, sort_keys=True)
-    print('full_hw256_c256.json', os.path.getsize(os.path.join(OUT, 'full_hw256_c256.json')))
+    hw = int(sys.argv[sys.argv.index('--hw') + 1]) if '--hw' in sys.argv else 256
+    name = 'full_hw%d_c256.json' % hw
+    with open(os.path.join(OUT, name), 'w') as fh:
+      json.dump(full_size(hw=hw), fh, indent=0, sort_keys=True)
+    print(name, os.path.getsize(os.path.join(OUT, name)))
   else:
     main()

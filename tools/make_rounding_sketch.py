@@ -13,7 +13,7 @@ fixture's own weights and inputs, and stores what the GPU test needs to turn tha
     E[(r . d)^2] = |d|^2, so the test estimates |g_hip - g_float64|^2 of a whole group from K x (number of variables)
     projections of the kernels' gradients without the 71 MB.
 
-tests/test_gpu_model.py::test_full_size_256_hits_the_reference[bf16] then asserts, per group,
+tests/test_gpu_model.py::test_full_width_stage_hits_the_reference[bf16] then asserts, per group,
   rel-L2(kernels vs float64) <= 1.5 x rounded_rel_l2 + 0.02.
 
 Oracle only (oracle/torch_ref.py, pinned to the reference's code at 1e-13 on this configuration); ~30 min and ~25 GB on 8
@@ -41,7 +41,9 @@ def sketch_vectors(index, numel, device='cpu'):
 
 
 def main():
-  with open(os.path.join(ROOT, 'tests', 'golden', 'full_hw256_c256.json')) as fh:
+  hw_arg = int(sys.argv[sys.argv.index('--hw') + 1]) if '--hw' in sys.argv else 256      # --hw 64 | 128: configs[1] / configs[2]
+  base = 'full_hw%d_c256' % hw_arg
+  with open(os.path.join(ROOT, 'tests', 'golden', base + '.json')) as fh:
     fix = json.load(fh)
   hw, batch = fix['config']['hw'], fix['batch']
   cfg = R.Config(**fix['config'])
@@ -90,7 +92,7 @@ def main():
     print('  %s: storage rounding moves the gradients by rel-L2 %.4f (sketch estimate %.4f)'
           % (group, out['rounded_rel_l2'][group], out['rounded_rel_l2_from_sketch'][group]), flush=True)
     del exact, rnd
-  with open(os.path.join(ROOT, 'tests', 'golden', 'full_hw256_c256_rounding.json'), 'w') as fh:
+  with open(os.path.join(ROOT, 'tests', 'golden', base + '_rounding.json'), 'w') as fh:
     json.dump(out, fh)
   print('written')
 

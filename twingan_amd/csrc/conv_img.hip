@@ -26,6 +26,11 @@ struct ImgGeom {
   // ONE statistics chunk of the image -- stats[img][0][2][cout], the layout of conv_tile's STATS epilogue with
   // stat_chunks = 1 -- so the instance norm after an 8x8 conv needs no pass over the tensor (in_stats_partial, norm.hip)
   float* stats;
+  // masked backward-data: the output is multiplied by the LeakyReLU derivative of `mask` (the forward input of the layer
+  // this backward-data belongs to = the producer's activation output, same shape as y): mask > 0 ? 1 : alpha.  NULL: plain.
+  // (conv_tile's mask epilogue for the 8x8 / 4x4 maps: their tg_lrelu_bwd launches -- one per block of every discriminator
+  // pass -- are gone)
+  const bf16* mask;
 };
 
 constexpr unsigned IOOB = 0x80000000u;
@@ -147,6 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv_img_kernel(const bf16* __restrict
   const int nimg = min(IMGS, g.n - img0);
   const __amdgpu_buffer_rsrc_t rbias = i_rsrc(bias, (g.epilogue & TG_EPI_BIAS) ? (unsigned)(g.cout * 4) : 0u);
   const __amdgpu_buffer_rsrc_t ry = i_rsrc(y + (size_t)img0 * out_elems, (unsigned)(nimg * out_elems * 2));
+  const __amdgpu_buffer_rsrc_t rmask = i_rsrc(g.mask ? g.mask + (size_t)img0 * out_elems : y, g.mask ? (unsigned)(nimg * out_elems * 2) : 0u);
   const int q = wid;      // wave w finishes register quads q = w: channels 8w + 4 kgrp .. + 3 of the 32-block
   const f32x4 bq = __builtin_bit_cast(
       f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, (unsigned)((n0 + q * 8 + kgrp * 4) * 4), 0, 0));
@@ -164,6 +170,15 @@ __global__ __launch_bounds__(256, 2) void conv_img_kernel(const bf16* __restrict
       v[j] = red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane] + red[(2 * 16 + r) * 64 + lane] +
              red[(3 * 16 + r) * 64 + lane] + bq[j];
       if (g.epilogue & TG_EPI_LRELU) v[j] = lrelu_f(v[j], g.alpha);
+    }
+    if (g.mask) {      // uniform: a positive bf16 / f16 is a positive int16 pattern
+      typedef __attribute__((ext_vector_type(2))) unsigned iu32x2;
+      const iu32x2 z = __builtin_bit_cast(iu32x2, __builtin_amdgcn_raw_buffer_load_b64(
+          rmask, (unsigned)(((m * 32 + l31) * g.cout + n0 + q * 8 + kgrp * 4) * 2), 0, 0));
+      v[0] *= (short)(z[0] & 0xffffu) > 0 ? 1.f : g.alpha;
+      v[1] *= (short)(z[0] >> 16) > 0 ? 1.f : g.alpha;
+      v[2] *= (short)(z[1] & 0xffffu) > 0 ? 1.f : g.alpha;
+      v[3] *= (short)(z[1] >> 16) > 0 ? 1.f : g.alpha;
     }
     const unsigned p0 = pack16x2<F16>(v[0], v[1]), p1 = pack16x2<F16>(v[2], v[3]);
     if constexpr (STATS) {      // of the values as stored
@@ -260,9 +275,11 @@ bool tg_conv_img_stats_supported(int n, int hin, int win, int cin, int hout, int
 }
 
 int tg_conv_img_run(int n, int hw, int cin, int cout, int epilogue, float alpha, const void* x, const void* wp,
-                    const float* bias, void* y, hipStream_t s, float* stats) {
+                    const float* bias, void* y, hipStream_t s, float* stats, const void* mask) {
   ImgGeom g;
   g.stats = stats;
+  g.mask = (const bf16*)mask;
+  TG_CHECK(!(mask && (stats || epilogue)), TG_ENOSUP, "conv_img: the mask epilogue comes with the plain epilogue only");
   g.n = n; g.cin = cin; g.cout = cout;
   g.cin_pad = (cin + 15) / 16 * 16;
   g.epilogue = epilogue;

@@ -592,11 +592,11 @@ bool tg_conv_small_supported(int n, int hout, int wout, int kh, int kw);
 bool tg_conv_small_stats_supported(int n, int hin, int win, int hout, int wout, int cout, int k, int pad_t, int pad_l);
 int tg_conv_small_run(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l,
                       int epilogue, float alpha, const void* x, const void* wp, const float* bias, void* y, hipStream_t s,
-                      float* stats = nullptr);
+                      float* stats = nullptr, const void* mask = nullptr);
 bool tg_conv_img_supported(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l);
 bool tg_conv_img_stats_supported(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l);
 int tg_conv_img_run(int n, int hw, int cin, int cout, int epilogue, float alpha, const void* x, const void* wp,
-                    const float* bias, void* y, hipStream_t s, float* stats = nullptr);
+                    const float* bias, void* y, hipStream_t s, float* stats = nullptr, const void* mask = nullptr);
 
 int tg_conv2d_fwd_stats_chunks_mfma(const TgConvDesc* d0) {
   TgConvDesc dd;
@@ -669,24 +669,38 @@ int tg_conv2d_fwd_mfma(const TgConvDesc* d0, const void* x, const void* wp, cons
 bool tg_conv2d_fwd_mask_fusable_mfma(const TgConvDesc* d0) {
   TgConvDesc dd;
   const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
-  return is16(d) && d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 && d->epilogue == 0 &&
-         tg_conv_tile_supported(d->hin, d->win, d->hout, d->wout, d->kh, d->kw, d->pad_t, d->pad_l);
+  if (!is16(d) || d->algo == TG_ALGO_MFMA_V1 || d->cin % 8 != 0 || d->cout % 8 != 0 || d->epilogue != 0) return false;
+  if (tg_conv_tile_supported(d->hin, d->win, d->hout, d->wout, d->kh, d->kw, d->pad_t, d->pad_l)) return true;
+  // 8x8 / 4x4 maps and the dense rewrite: conv_img / conv_small carry the same mask epilogue (tests as tg_conv2d_fwd_mfma's)
+  if (d->kh == d->kw && tg_conv_img_supported(d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->pad_t, d->pad_l))
+    return true;
+  return d->pad_t == d->pad_l && tg_conv_small_supported(d->n, d->hout, d->wout, d->kh, d->kw);
 }
 
 int tg_conv2d_fwd_masked_mfma(const TgConvDesc* d0, const void* x, const void* wp, const void* mask_src, void* y, hipStream_t s) {
   TgConvDesc dd;
   const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
   TG_CHECK(tg_conv2d_fwd_mask_fusable_mfma(d0), TG_ENOSUP, "tg_conv2d_fwd_masked(mfma): mask not fusable here");
-  return tg_conv_tile_run(d->n, d->hin, d->win, d->cin, d->cout, d->kh, d->pad_t, 0, d->lrelu_alpha, x, wp, nullptr, y, s,
-                          mask_src);
+  if (tg_conv_tile_supported(d->hin, d->win, d->hout, d->wout, d->kh, d->kw, d->pad_t, d->pad_l))
+    return tg_conv_tile_run(d->n, d->hin, d->win, d->cin, d->cout, d->kh, d->pad_t, 0, d->lrelu_alpha, x, wp, nullptr, y, s,
+                            mask_src);
+  if (d->kh == d->kw && tg_conv_img_supported(d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->pad_t, d->pad_l))
+    return tg_conv_img_run(d->n, d->hin, d->cin, d->cout, 0, d->lrelu_alpha, x, wp, nullptr, y, s, nullptr, mask_src);
+  return tg_conv_small_run(d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->pad_t, d->pad_l, 0,
+                           d->lrelu_alpha, x, wp, nullptr, y, s, nullptr, mask_src);
 }
 
 // Can the LeakyReLU backward of the producer of x be folded into this backward-data's epilogue?
 bool tg_conv2d_bwd_data_mask_fusable_mfma(const TgConvDesc* d0) {
   TgConvDesc dd;
   const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
-  return is16(d) && d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 &&
-         tg_conv_tile_supported(d->hout, d->wout, d->hin, d->win, d->kh, d->kw, d->pad_t, d->pad_l);
+  if (!is16(d) || d->algo == TG_ALGO_MFMA_V1 || d->cin % 8 != 0 || d->cout % 8 != 0) return false;
+  if (tg_conv_tile_supported(d->hout, d->wout, d->hin, d->win, d->kh, d->kw, d->pad_t, d->pad_l)) return true;
+  // the 8x8 / 4x4 maps and the dense k x k VALID layers (conv_img / conv_small: the same tests as tg_conv2d_bwd_data_mfma)
+  if (d->kh == d->kw && tg_conv_img_supported(d->n, d->hout, d->wout, d->cout, d->hin, d->win, d->cin, d->kh, d->kh - 1 - d->pad_t,
+                                              d->kw - 1 - d->pad_l))
+    return true;
+  return d->pad_t == d->pad_l && tg_conv_small_supported(d->n, d->hin, d->win, d->kh, d->kw);
 }
 
 int tg_conv2d_bwd_data_mfma(const TgConvDesc* d0, const void* gy, const void* wp, void* gx, hipStream_t s,
@@ -700,14 +714,14 @@ int tg_conv2d_bwd_data_mfma(const TgConvDesc* d0, const void* gy, const void* wp
     return tg_conv_tile_run(d->n, d->hout, d->wout, d->cout, d->cin, d->kh, d->kh - 1 - d->pad_t, 0,
                             mask ? d->lrelu_alpha : 1.f, gy, wp, nullptr, gx, s, mask);
   // backward-data = the same conv over gy with the rotated pack: in = (hout, wout, cout), out = (hin, win, cin), pad' = k-1-pad
-  if (d->algo != TG_ALGO_MFMA_V1 && d->kh == d->kw && !mask &&
+  if (d->algo != TG_ALGO_MFMA_V1 && d->kh == d->kw &&
       tg_conv_img_supported(d->n, d->hout, d->wout, d->cout, d->hin, d->win, d->cin, d->kh, d->kh - 1 - d->pad_t,
                             d->kw - 1 - d->pad_l))
-    return tg_conv_img_run(d->n, d->hout, d->cout, d->cin, 0, 1.f, gy, wp, nullptr, gx, s);
+    return tg_conv_img_run(d->n, d->hout, d->cout, d->cin, 0, mask ? d->lrelu_alpha : 1.f, gy, wp, nullptr, gx, s, nullptr, mask);
   if (d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 && d->pad_t == d->pad_l &&
       tg_conv_small_supported(d->n, d->hin, d->win, d->kh, d->kw))
     return tg_conv_small_run(d->n, d->hout, d->wout, d->cout, d->hin, d->win, d->cin, d->kh, d->kh - 1 - d->pad_t,
-                             d->kw - 1 - d->pad_l, 0, 1.f, gy, wp, nullptr, gx, s);
+                             d->kw - 1 - d->pad_l, 0, mask ? d->lrelu_alpha : 1.f, gy, wp, nullptr, gx, s, nullptr, mask);
   Geom g;   // a forward conv over gy: in = (hout,wout,cout), out = (hin,win,cin), pad' = k-1-pad
   int rc = fill_geom("tg_conv2d_bwd_data", d->n, d->hout, d->wout, d->cout, d->hin, d->win, d->cin, d->kh, d->kw,
                      d->kh - 1 - d->pad_t, d->kw - 1 - d->pad_l, &g);

@@ -29,6 +29,8 @@ struct SmallGeom {
   // STATS kernels (4x4 maps): sums of the (16-bit-rounded) outputs and of their squares per image and output channel as
   // the image's ONE statistics chunk, stats[img][0][2][cout] (the layout of conv_tile's STATS epilogue, stat_chunks = 1)
   float* stats;
+  // masked backward-data: y *= (mask > 0 ? 1 : alpha), mask = the forward input of the layer (same shape as y); NULL: plain
+  const bf16* mask;
 };
 
 constexpr unsigned SOOB = 0x80000000u;
@@ -148,6 +150,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict_
   // ---- sum the 4 K-slices, one column block at a time
   const __amdgpu_buffer_rsrc_t rbias = s_rsrc(bias, (g.epilogue & TG_EPI_BIAS) ? (unsigned)(g.cout * 4) : 0u);
   const __amdgpu_buffer_rsrc_t ry = s_rsrc(y, g.y_bytes);
+  const __amdgpu_buffer_rsrc_t rmask = s_rsrc(g.mask ? (const void*)g.mask : (const void*)y, g.mask ? g.y_bytes : 0u);
   // wave w finishes register quads q = w (channels 8w + 4*kgrp .. +3 of the 32-block) for every pixel
   // -> after the half-wave swap each lane stores 8 consecutive channels (16 bytes)
   const int q = wid;
@@ -165,6 +168,16 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict_
       const int r = q * 4 + j;
       v[j] = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane] + bq[j];
       if (g.epilogue & TG_EPI_LRELU) v[j] = lrelu_f(v[j], g.alpha);
+    }
+    if (g.mask) {      // uniform: a positive bf16 / f16 is a positive int16 pattern
+      typedef __attribute__((ext_vector_type(2))) unsigned su32x2;
+      const int pm = pbase + m * 32, chq = n0 + q * 8 + kgrp * 4;
+      const su32x2 z = __builtin_bit_cast(su32x2, __builtin_amdgcn_raw_buffer_load_b64(
+          rmask, (pm < g.npix && chq + 4 <= g.cout) ? (unsigned)((pm * g.cout + chq) * 2) : SOOB, 0, 0));
+      v[0] *= (short)(z[0] & 0xffffu) > 0 ? 1.f : g.alpha;
+      v[1] *= (short)(z[0] >> 16) > 0 ? 1.f : g.alpha;
+      v[2] *= (short)(z[1] & 0xffffu) > 0 ? 1.f : g.alpha;
+      v[3] *= (short)(z[1] >> 16) > 0 ? 1.f : g.alpha;
     }
     const unsigned p0 = pack16x2<F16>(v[0], v[1]), p1 = pack16x2<F16>(v[2], v[3]);
     if constexpr (STATS) {
@@ -221,9 +234,11 @@ bool tg_conv_small_stats_supported(int n, int hin, int win, int hout, int wout, 
 
 int tg_conv_small_run(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l,
                       int epilogue, float alpha, const void* x, const void* wp, const float* bias, void* y,
-                      hipStream_t s, float* stats) {
+                      hipStream_t s, float* stats, const void* mask) {
   SmallGeom g;
   g.stats = stats;
+  g.mask = (const bf16*)mask;
+  TG_CHECK(!(mask && (stats || epilogue)), TG_ENOSUP, "conv_small: the mask epilogue comes with the plain epilogue only");
   g.n = n; g.hin = hin; g.win = win; g.cin = cin; g.hout = hout; g.wout = wout; g.cout = cout;
   g.cin_pad = (cin + 15) / 16 * 16;
   g.kh = g.kw = k;

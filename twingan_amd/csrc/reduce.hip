@@ -421,9 +421,11 @@ __global__ __launch_bounds__(NTHR) void mbstd_bwd_bwd_kernel(const T* __restrict
 // ------------------------------------------------------------------------------------------------
 // reductions
 // ------------------------------------------------------------------------------------------------
-template <typename T, int MODE, bool PART = false>   // MODE 0: sum(x)  1: sum|x-y|;  PART: out[blockIdx.x] = this workgroup's sum
+// MODE 0: sum(x)  1: sum|x-y|;  PART: out[blockIdx.x] = this workgroup's sum;  direct (a ONE-workgroup launch that does not
+// accumulate): out[0] is written, not added to -- the launch needs no zero fill before it
+template <typename T, int MODE, bool PART = false>
 __global__ void sum_kernel(const T* __restrict__ x, const T* __restrict__ y, float* __restrict__ out, int64_t numel,
-                           float scale) {
+                           float scale, int direct = 0) {
   __shared__ float red[8];
   constexpr int V = Vec16<T>::N;
   const int64_t nvec = numel / V, stride = (int64_t)gridDim.x * blockDim.x;
@@ -444,6 +446,7 @@ __global__ void sum_kernel(const T* __restrict__ x, const T* __restrict__ y, flo
   const float tot = block_sum(acc, red);
   if (threadIdx.x == 0) {
     if constexpr (PART) out[blockIdx.x] = tot;
+    else if (direct) out[0] = tot * scale;
     else atomicAdd(out, tot * scale);
   }
 }
@@ -718,11 +721,14 @@ static int zero_unless(float* p, size_t bytes, int accumulate, hipStream_t s, co
 int tg_sum(const void* x, float* out, int64_t numel, float scale, int accumulate, int dtype, void* stream) {
   TG_CHECK(x && out && numel > 0, TG_EINVAL, "tg_sum: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  int rc = zero_unless(out, sizeof(float), accumulate, s, "tg_sum");
-  if (rc) return rc;
   TG_DISPATCH_DTYPE(dtype, "tg_sum", {
-    hipLaunchKernelGGL((sum_kernel<T, 0>), dim3(exact_grid<T>() ? 1 : tg_grid_for(numel / Vec16<T>::N + 1, 256, 1024)),
-                       dim3(256), 0, s, (const T*)x, (const T*)nullptr, out, numel, scale);
+    const int blocks = exact_grid<T>() ? 1 : tg_grid_for(numel / Vec16<T>::N + 1, 256, 1024);
+    const int direct = (blocks == 1 && !accumulate) ? 1 : 0;      // the [B, 1] predictions of the loss tails: one launch, not two
+    if (!direct) {
+      int rc = zero_unless(out, sizeof(float), accumulate, s, "tg_sum");
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL((sum_kernel<T, 0>), dim3(blocks), dim3(256), 0, s, (const T*)x, (const T*)nullptr, out, numel, scale, direct);
   });
   TG_LAUNCH_CHECK("tg_sum");
   return TG_OK;
@@ -732,11 +738,14 @@ int tg_abs_diff_sum(const void* a, const void* b, float* out, int64_t numel, flo
                     void* stream) {
   TG_CHECK(a && b && out && numel > 0, TG_EINVAL, "tg_abs_diff_sum: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  int rc = zero_unless(out, sizeof(float), accumulate, s, "tg_abs_diff_sum");
-  if (rc) return rc;
   TG_DISPATCH_DTYPE(dtype, "tg_abs_diff_sum", {
-    hipLaunchKernelGGL((sum_kernel<T, 1>), dim3(exact_grid<T>() ? 1 : tg_grid_for(numel / Vec16<T>::N + 1, 256, 1024)),
-                       dim3(256), 0, s, (const T*)a, (const T*)b, out, numel, scale);
+    const int blocks = exact_grid<T>() ? 1 : tg_grid_for(numel / Vec16<T>::N + 1, 256, 1024);
+    const int direct = (blocks == 1 && !accumulate) ? 1 : 0;
+    if (!direct) {
+      int rc = zero_unless(out, sizeof(float), accumulate, s, "tg_abs_diff_sum");
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL((sum_kernel<T, 1>), dim3(blocks), dim3(256), 0, s, (const T*)a, (const T*)b, out, numel, scale, direct);
   });
   TG_LAUNCH_CHECK("tg_abs_diff_sum");
   return TG_OK;

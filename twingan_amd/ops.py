@@ -1683,6 +1683,71 @@ def lerp(new, old, alpha):
   return AxpbyFn.apply(new, old, float(alpha), float(1.0 - alpha))
 
 
+class RowViewsFn(torch.autograd.Function):
+  """Overlapping row ranges of one batch as VIEWS: x [N, ...] -> x[lo:hi] for every (lo, hi) of ``ranges``.
+
+  The generator's batch [s_cyc; s'; t'; t_cyc] feeds the two discriminators ([s_cyc; s'] and [t'; t_cyc]), the re-encoding
+  pass ([s'; t']) and the cycle losses (s_cyc, t_cyc) (twingan.py:198-288): as torch.cat inputs that was three 12.5 MB
+  copies forward and, backward, a chain of framework adds plus the 25 MB cat of the chunks' gradients.  Here the consumers
+  read the batch in place, and the backward writes every row block of the gradient ONCE: the sum of the (at most two)
+  incoming gradients that cover it, by tg_axpby straight into its rows."""
+
+  @staticmethod
+  def forward(ctx, x, ranges):
+    assert x.is_contiguous()
+    ctx.ranges, ctx.shape = tuple(ranges), tuple(x.shape)
+    d = x.detach()      # the outputs are views of the storage, not autograd views of the input (nothing is modified in place)
+    return tuple(d.narrow(0, lo, hi - lo) for lo, hi in ranges)
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, *grads):
+    n = ctx.shape[0]
+    live = [(lo, hi, g.contiguous()) for (lo, hi), g in zip(ctx.ranges, grads) if g is not None]
+    cuts = sorted({0, n} | {lo for lo, _, _ in live} | {hi for _, hi, _ in live})
+    gx = torch.empty(ctx.shape, dtype=live[0][2].dtype, device=live[0][2].device)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+      src = [g.narrow(0, a - lo, b - a) for lo, hi, g in live if lo <= a and b <= hi]
+      dst = gx.narrow(0, a, b - a)
+      if not src:
+        dst.zero_()
+      elif len(src) == 1:
+        dst.copy_(src[0])
+      else:
+        acc = src[0]
+        for k, g in enumerate(src[1:]):
+          if dst.is_cuda:
+            call('tg_axpby', _p(acc), _p(g), _p(dst), dst.numel(), 1.0, 1.0, _dt(dst), _stream(),
+                 work=('axpby:numel%d' % dst.numel(), 0, _nb(acc, g, dst)))
+          else:
+            torch.add(acc, g, out=dst)
+          acc = dst
+    return gx, None
+
+
+def row_views(x, ranges):
+  """-> a tuple of views x[lo:hi]; see RowViewsFn.  Without a tape they are plain narrows."""
+  if not (torch.is_grad_enabled() and x.requires_grad):
+    return tuple(x.narrow(0, lo, hi - lo) for lo, hi in ranges)
+  return RowViewsFn.apply(x, tuple(ranges))
+
+
+def cat_rows(tensors):
+  """torch.cat(tensors, 0) -- or, when the tensors already sit one after the other in one allocation (the trainer's static
+  input buffers under graph replay) and no tape is involved, a view of those rows: no copy."""
+  t0 = tensors[0]
+  if all(t.is_contiguous() and not t.requires_grad and t.dtype == t0.dtype and t.shape[1:] == t0.shape[1:]
+         and t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr() for t in tensors):
+    end = t0.data_ptr() + t0.numel() * t0.element_size()
+    for t in tensors[1:]:
+      if t.data_ptr() != end:
+        break
+      end += t.numel() * t.element_size()
+    else:
+      return torch.as_strided(t0, (sum(t.shape[0] for t in tensors),) + tuple(t0.shape[1:]), t0.stride())
+  return torch.cat(tensors, dim=0)
+
+
 class CastFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, x, dtype):

@@ -129,17 +129,23 @@ def forward_generators(P, sources, targets, cfg, style_noise=None):
   parameters, UNet skips from the encoder whose content is decoded).
 
   The reference builds six separate towers; here passes that share conv weights run as ONE batch along N --
-  E([s; t]) with domains (s, t), and G([E(t); E(s); E(s); E(t)]) with domains (s, s, t, t) = s', s_cyc, t', t_cyc --
+  E([s; t]) with domains (s, t), and G([E(s); E(t); E(s); E(t)]) with domains (s, s, t, t) = s_cyc, s', t', t_cyc --
   because the low-resolution layers cannot fill 256 CUs with 16 images (instance-norm statistics are per image
-  and the norm kernels pick gamma/beta per image, so the results are those of the separate passes)."""
+  and the norm kernels pick gamma/beta per image, so the results are those of the separate passes).  The batch order
+  makes every later consumer a ROW RANGE of the generator's output (ops.row_views: no copies): discriminator_s reads
+  [s_cyc; s'], the re-encoding pass [s'; t'], discriminator_t [t'; t_cyc]."""
   b = sources.shape[0]
-  x = torch.cat([sources, targets], dim=0)
+  x = ops.cat_rows([sources, targets])
   # cuts (segmented backward of a data-parallel generator step, no-ops otherwise): every tensor this encoder pass
   # hands to the generator / the losses becomes a leaf; its low-resolution half resumes in segment 1, the rest in 2
   e, ep = pggan.encoder_before_classification(P, x, ('s', 't', b, 2), cfg, cuts=(1, 2))
   e = ops.Cuts.cut(e, 1)
   es, et = e.chunk(2)
-  content = torch.cat([et, es, es, et], dim=0)
+  # Batch order of the generator pass.  With a stateless normaliser (instance / layer norm) the four passes commute and run
+  # as [s_cyc; s'; t'; t_cyc], which makes the re-encoding batch [s'; t'] a row range too.  Batch norm / renorm update their
+  # moving statistics pass by pass, so there the reference's tower order stays ([s'; s_cyc; t'; t_cyc], twingan.py:233-269)
+  # and [s'; t'] is the one copy left.
+  cyc_first = 'batch' not in cfg.generator_norm_type
   cond = rand = None
   if cfg.use_style_embedding:
     # twingan.py:201-267: style encoder on s / t (one batch, domains s|t); s' and t' are generated with ONE random
@@ -148,12 +154,20 @@ def forward_generators(P, sources, targets, cfg, style_noise=None):
     style_s, style_t = st.chunk(2)
     rand = style_noise if style_noise is not None else torch.randn(b, cfg.style_embed_size, dtype=torch.float32,
                                                                   device=x.device)
-    cond = torch.cat([rand, style_s, rand, style_t], dim=0)
-  # UNet skips: generator group k reads encoder group (t, s, s, t)[k] of the [s; t] encoder batch -- no copies
+    cond = torch.cat([style_s, rand, rand, style_t] if cyc_first else [rand, style_s, rand, style_t], dim=0)
+  # UNet skips: generator group k reads encoder group (s, t, s, t)[k] / (t, s, s, t)[k] of the [s; t] encoder batch -- no copies
+  content = torch.cat([e, e] if cyc_first else [et, es, es, et], dim=0)
   out, _ = pggan.generator(P, content, ('s', 't', 2 * b, 4), cfg, ep if cfg.use_unet else None,
-                           unet_groups=(b, (1, 0, 0, 1)), cond=cond)
-  s_prime, s_cycle, t_prime, t_cycle = out.chunk(4)
-  return dict(es=es, et=et, s_prime=s_prime, s_cycle=s_cycle, t_prime=t_prime, t_cycle=t_cycle, random_style_embed=rand)
+                           unet_groups=(b, (0, 1, 0, 1) if cyc_first else (1, 0, 0, 1)), cond=cond)
+  out = out.contiguous()
+  rows = [(0, b), (b, 2 * b), (2 * b, 3 * b), (3 * b, 4 * b), (0, 2 * b), (2 * b, 4 * b)] + ([(b, 3 * b)] if cyc_first else [])
+  v = ops.row_views(out, rows)
+  s_cycle, s_prime = (v[0], v[1]) if cyc_first else (v[1], v[0])
+  t_prime, t_cycle = v[2], v[3]
+  primes = v[6] if cyc_first else torch.cat([s_prime, t_prime], dim=0)
+  # both_s / both_t: (the cycle and the prime image of a domain as one tensor, "the cycle image comes first")
+  return dict(es=es, et=et, s_prime=s_prime, s_cycle=s_cycle, t_prime=t_prime, t_cycle=t_cycle, random_style_embed=rand,
+              both_s=(v[4], cyc_first), primes=primes, both_t=(v[5], False))
 
 
 def translate(P, images, cfg, to='t', style=None):
@@ -190,20 +204,23 @@ def generator_loss(P, sources, targets, cfg, style_noise=None, distill_embed_s=N
   terms = {}
   # fork: the two discriminators run on their own streams while the main stream re-encodes s' / t'
   streams = _DomainStreams(sources.device, cfg.domain_streams)
-  for i, (d, orig, prime, cyc) in enumerate((('s', sources, o['s_prime'], o['s_cycle']),
-                                             ('t', targets, o['t_prime'], o['t_cycle']))):
+  # D(cyc) and D(prime) of one domain share weights: one batch, two minibatch-stddev groups -- rows of the generator's batch
+  # (``cyc_first``: which chunk of the prediction is the cycle image's)
+  for i, (d, orig, prime, cyc, (both, cyc_first)) in enumerate((
+      ('s', sources, o['s_prime'], o['s_cycle'], o['both_s']),
+      ('t', targets, o['t_prime'], o['t_cycle'], o['both_t']))):
     top = 'discriminator_' + d
     with streams.domain(i):
       terms['l_cyc_' + d] = ops.abs_diff_mean(orig, cyc, cfg.l_cyc_weight)
-      if cyc_gan:      # D(cyc) and D(prime) of one domain share weights: one batch, two minibatch-stddev groups
-        pred, _ = pggan.discriminator(P, torch.cat([cyc, prime], dim=0), cfg, top, groups=2, block_end_points=False)
-        pc, pp = pred.chunk(2)
+      if cyc_gan:
+        pred, _ = pggan.discriminator(P, both, cfg, top, groups=2, block_end_points=False)
+        pc, pp = pred.chunk(2) if cyc_first else reversed(pred.chunk(2))
         terms['generator_fool_loss_cycle_' + d] = _fool_loss(pc, cfg)
       else:
         pp, _ = pggan.discriminator(P, prime, cfg, top, block_end_points=False)
       terms['generator_fool_loss_prime_' + d] = _fool_loss(pp, cfg)
-  # re-encode s' in domain s and t' in domain t as one batch (twingan.py:275-288)
-  primes = torch.cat([o['s_prime'], o['t_prime']], dim=0)
+  # re-encode s' in domain s and t' in domain t as one batch (twingan.py:275-288): rows [s'; t'] of the generator's batch
+  primes = o['primes']
   e2, _ = pggan.encoder_before_classification(P, primes, ('s', 't', b, 2), cfg)
   e_sp, e_tp = e2.chunk(2)
   if cfg.l_content_weight:
@@ -246,25 +263,30 @@ def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t, dragan_
   cyc_gan = cfg.hw >= 64 and cfg.do_l_cyc_gan
   terms = {}
   streams = _DomainStreams(sources.device, cfg.domain_streams)
-  for i, (d, real, prime, cyc, a, noise) in enumerate((
-      ('s', sources, o['s_prime'], o['s_cycle'], gp_alpha_s, dragan_noise_s),
-      ('t', targets, o['t_prime'], o['t_cycle'], gp_alpha_t, dragan_noise_t))):
+  for i, (d, real, prime, cyc, a, noise, (both, cyc_first)) in enumerate((
+      ('s', sources, o['s_prime'], o['s_cycle'], gp_alpha_s, dragan_noise_s, o['both_s']),
+      ('t', targets, o['t_prime'], o['t_cycle'], gp_alpha_t, dragan_noise_t, o['both_t']))):
     top = 'discriminator_' + d
     with streams.domain(i):
-      _d_domain_terms(P, cfg, terms, d, top, real, prime, cyc, a, cyc_gan)
+      _d_domain_terms(P, cfg, terms, d, top, real, prime, cyc, a, cyc_gan, both, cyc_first)
       if cfg.loss_architecture in ('wgan_gp', 'dragan'):
         _d_domain_gp(P, cfg, terms, d, top, real, prime, a, noise)
   streams.join()
   return _sum_terms(terms), terms
 
 
-def _d_domain_terms(P, cfg, terms, d, top, real, prime, cyc, a, cyc_gan):
-  """One domain's DISCRIMINATOR_LOSSES (the body of the loop in image_generation.py:348-379,414-439)."""
+def _d_domain_terms(P, cfg, terms, d, top, real, prime, cyc, a, cyc_gan, both=None, cyc_first=True):
+  """One domain's DISCRIMINATOR_LOSSES (the body of the loop in image_generation.py:348-379,414-439).  ``both``: the cycle
+  and the prime image as ONE tensor (rows of the generator's batch), the cycle image first or last (``cyc_first``)."""
   if True:
     # D(real), D(cyc), D(prime) of one domain share weights: one batch, one minibatch-stddev group per call
     if cyc_gan:
-      pred, _ = pggan.discriminator(P, torch.cat([real, cyc, prime], dim=0), cfg, top, groups=3, cut_seg=1, block_end_points=False)
+      if both is None:
+        both, cyc_first = torch.cat([cyc, prime], dim=0), True
+      pred, _ = pggan.discriminator(P, torch.cat([real, both], dim=0), cfg, top, groups=3, cut_seg=1, block_end_points=False)
       pr, pc, pp = (t.contiguous() for t in pred.chunk(3))
+      if not cyc_first:
+        pc, pp = pp, pc
     else:
       pred, _ = pggan.discriminator(P, torch.cat([real, prime], dim=0), cfg, top, groups=2, cut_seg=1, block_end_points=False)
       pr, pp = (t.contiguous() for t in pred.chunk(2))
@@ -510,7 +532,11 @@ class Trainer:
     """Captures, per step kind, one graph per backward segment and one for the apply: the clone all-reduces (RCCL)
     run between them, outside any capture.  The eager warm-up (one real step of each kind: allocates every weight pack
     and job table once) is undone afterwards, so graph mode and eager mode follow the same trajectory."""
-    self._static = dict(s=None if sources is None else sources.clone(), t=targets.clone())
+    if sources is None:
+      self._static = dict(s=None, t=targets.clone())
+    else:      # one allocation, [s; t]: the encoder's batch is then a view of it (ops.cat_rows), not a copy per run
+      both = torch.cat([sources, targets], dim=0)
+      self._static = dict(s=both[:sources.shape[0]], t=both[sources.shape[0]:], st=both)
     # dataset fields besides the images (the distillation embeddings): static buffers the captured graphs read, refilled
     # before every replay; the SET of fields is part of the capture
     if self._extras:
@@ -553,6 +579,14 @@ class Trainer:
       graphs[kind] = (segs, ga)
     self.adam_t = adam_t                          # the captured (not executed) applies
     self._graphs, self._outs = graphs, outs
+
+  def static_inputs(self):
+    """-> (sources, targets) static input buffers of the captured graphs (None before the capture / in eager mode).  A
+    loader that writes its batch INTO them and passes them to run() saves the per-run copy (run() copies only tensors
+    at other addresses)."""
+    if not self.use_graph or self._graphs is None:
+      return None
+    return self._static['s'], self._static['t']
 
   def _abandon_capture(self):
     """Leaves no half-issued step behind after a failed capture: held filter gradients, open cuts, forked side streams."""
