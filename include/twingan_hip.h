@@ -349,6 +349,13 @@ int tg_sample_lerp(const void* x, const void* y, const float* alpha, void* out, 
 /* out[b,...] = coef[b] * x[b,...] * scalar[0]   (coef fp32 [batch], scalar fp32 device pointer or NULL) */
 int tg_sample_scale(const void* x, const float* coef, const float* scalar, void* out, int batch, int64_t per_sample,
                     int dtype, void* stream);
+/* gdrop, mode 'prop' (libs/gdrop.py:20-36, the maybe_gdrop hook of nets/pggan.py:221-231,328-331,351-355):
+ * out[n,p,c] = x[n,p,c] * (noise[n,c] * strength * sqrt(c_logical) + 1), noise fp32 [n, c] ~ N(0,1) drawn by the caller
+ * (tf.random_normal there), x / out [n, hw, c] in `dtype`.  strength_dev: fp32 device scalar (the `gdrop_strength` variable
+ * of image_generation.py:563-585) or NULL for the host value `strength`.  c_logical <= c: channels that count for the
+ * sqrt (c is padded for the minibatch-stddev tensor).  Linear in x: the same call is its backward (and that one's). */
+int tg_gdrop(const void* x, const float* noise, const float* strength_dev, float strength, int c_logical, void* out, int n,
+             int64_t hw, int c, int dtype, void* stream);
 /* out[i] = value * (scalar ? scalar[0] : 1)   (broadcast of a device scalar, e.g. d mean / d x) */
 int tg_fill_scaled(void* out, const float* scalar, float value, int64_t numel, int dtype, void* stream);
 int tg_cast(const void* src, void* dst, int64_t numel, int src_dtype, int dst_dtype, void* stream);

@@ -251,7 +251,7 @@ def run_clones(flags, batches, global_step=0, seed=0, preset=None):
   return res
 
 
-def run_training(flags, runs, seed=0, preset=None):
+def run_training(flags, runs, seed=0, preset=None, global_step=0):
   """`len(runs)` consecutive session.run(train_op) calls of the reference's training graph: clones
   (model_deploy.create_clones around GanModel._clone_fn), learning rate and optimizer (model_inheritor.py:471-542),
   and GanModel._add_optimization (image_generation.py:587-662: generator / discriminator gradients through
@@ -273,6 +273,7 @@ def run_training(flags, runs, seed=0, preset=None):
   core.STATE.preset = dict(preset or {})
   core.STATE.eager_updates = True
   gs = tfapi.get_or_create_global_step()
+  gs.t.fill_(int(global_step))
   model = ref.GanModel.__new__(ref.GanModel)
   networks = ref.GanModel._select_network(None)
   config = model_deploy.DeploymentConfig(num_clones=1)
@@ -360,6 +361,32 @@ def run_pggan(flags, targets, global_step=0, seed=0, preset=None, want_grads=Tru
       gr = torch.autograd.grad(total, leaves, allow_unused=True, retain_graph=True)
       res[tag] = {k: g.numpy().copy() for k, g in zip(names, gr) if g is not None}
   return res
+
+
+def run_discriminator(flags, images, scope='discriminator_s', seed=0, preset=None, **kwargs):
+  """One call of the reference's pggan.discriminator (/root/reference/nets/pggan.py:337-376) under variable_scope(scope),
+  with the keyword arguments the caller gives (do_dgrop, gdrop_strength, is_training ...: what no flag of the trainers
+  reaches).  Returns the prediction, the random draws in call order (the gdrop noises) and the variables."""
+  tf = loader.install()
+  import twingan as ref      # defines the flags the network reads
+  from nets import pggan
+  F = tf.flags.FLAGS
+  if not hasattr(run, '_defaults'):
+    run._defaults = F.flag_values_dict()
+  for k, v in run._defaults.items():
+    setattr(F, k, v)
+  for k, v in dict(BASE_FLAGS, **flags).items():
+    setattr(F, k, v)
+  core.STATE.reset(seed)
+  core.STATE.preset = dict(preset or {})
+  core.STATE.eager_updates = False
+  tfapi._ARG_STACK[:] = [{}]
+  x = core.Tensor(torch.tensor(np.asarray(images, np.float64), requires_grad=True), core.float32, 'images')
+  with tf.variable_scope(scope):
+    pred, end_points = pggan.discriminator(x, **kwargs)
+  return dict(prediction=pred.t.detach().numpy().copy(),
+              random=[(n, t.numpy().copy()) for n, t in core.STATE.random_log],
+              variables={k: v.t.detach().numpy().copy() for k, v in core.STATE.variables.items()})
 
 
 def run_preprocess(image_u8, hw, resize_mode='PAD', is_training=True, seed=0, do_random_cropping=False, color_space='rgb',

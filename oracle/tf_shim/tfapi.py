@@ -788,6 +788,15 @@ def model_variable(name, shape=None, dtype=float32, initializer=None, regularize
   return core.get_variable(name, shape, dtype, initializer, regularizer, trainable, collections)
 
 
+def get_unique_variable(var_op_name):
+  """slim.get_unique_variable (contrib/framework/python/ops/variables.py): the one variable whose op name is exactly
+  `var_op_name`; ValueError when there is none (image_generation.py:566-570 relies on both)."""
+  for name, var in STATE.variables.items():
+    if name == var_op_name:
+      return var
+  raise ValueError('Couldn\'t find variable %s' % var_op_name)
+
+
 @add_arg_scope
 def contrib_variable(name, shape=None, dtype=float32, initializer=None, regularizer=None, trainable=True,
                      collections=None, **unused):
@@ -1229,7 +1238,8 @@ def build_modules():
   slim = _module('tensorflow.contrib.slim', arg_scope=arg_scope, add_arg_scope=add_arg_scope, conv2d=conv2d,
                  fully_connected=fully_connected, model_variable=model_variable,
                  get_or_create_global_step=get_or_create_global_step, l2_regularizer=l2_regularizer,
-                 variable=contrib_variable, get_variables=framework.get_variables, get_model_variables=framework.get_model_variables)
+                 variable=contrib_variable, get_variables=framework.get_variables, get_model_variables=framework.get_model_variables,
+                 get_unique_variable=get_unique_variable)
   contrib = _module('tensorflow.contrib', layers=contrib_layers, framework=framework, slim=slim)
 
   py_fw_ops = _module('tensorflow.python.framework.ops', convert_to_tensor=convert_to_tensor,

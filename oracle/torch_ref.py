@@ -12,6 +12,8 @@ image_generation.py:318-439,543-662,1001-1006, model/model_inheritor.py:537-542,
 deployment/model_deploy.py:242-315.
 """
 import math
+
+import numpy as np
 from dataclasses import dataclass
 
 import torch
@@ -64,6 +66,10 @@ class Config:
   self_attention_hw: int = 64        # image_generation.py:65-67
   use_style_embedding: bool = False  # twingan.py:47-49
   style_embed_size: int = 16         # twingan.py:50-51
+  # gdrop (libs/gdrop.py:20-36; nets/pggan.py:340-355): the layer runs only under do_dgrop (no reference trainer sets it)
+  do_dgrop: bool = False
+  gdrop_strength: float = 0.0
+  gdrop_noise: object = None         # list of [N, C] N(0,1) draws consumed in call order (drawn when None / exhausted)
   style_noise: object = None         # the N(0,1) random_style_embed [B, E] of twingan.py:232-235 (drawn when None)
   equalized: bool = False            # equalized_learning_rate           (nets/pggan.py:40; pggan_utils.py:236-254)
   res_block: bool = False            # use_res_block                     (nets/pggan.py:44; pggan_utils.py:257-264,334-342)
@@ -738,6 +744,24 @@ def generator(P, source, domain, cfg, unet_ep=None, top='generator', cond=None):
   return out, ep
 
 
+def gdrop(layer, strength, noise):
+  """libs/gdrop.py:20-36, mode 'prop', NHWC: layer * (noise[N,1,1,C] * strength * sqrt(C) + 1)."""
+  n, c = layer.shape[0], layer.shape[-1]
+  coef = strength * float(np.sqrt(np.float32(c)))      # np.sqrt(np.float32(int(layer.shape[-1]))): a float32 square root
+  return layer * (noise.reshape(n, 1, 1, c).to(layer.dtype) * coef + 1.0)
+
+
+def maybe_gdrop(layer, cfg):
+  """nets/pggan.py:351-355."""
+  if cfg.do_dgrop and cfg.is_training and cfg.gdrop_strength:
+    if cfg.gdrop_noise:
+      noise = cfg.gdrop_noise.pop(0)
+    else:
+      noise = torch.randn(layer.shape[0], layer.shape[-1], dtype=layer.dtype)
+    return gdrop(layer, cfg.gdrop_strength, noise)
+  return layer
+
+
 def discriminator(P, x, cfg, top):
   """nets/pggan.py:242-376.  Returns (prediction [B,1], end_points)."""
   hw = x.shape[1]
@@ -761,8 +785,8 @@ def discriminator(P, x, cfg, top):
     net = maybe_self_attention(P, top, cur, nc, net, ep, None, cfg, True)   # nets/pggan.py:294-296
     name = 'encoder_block_%dx%dx%d' % (cur, cur, nc)
     blk_in = net
-    net = d_conv(P, '%s/%s/Conv' % (top, name), net, cfg)
-    net = d_conv(P, '%s/%s/Conv_1' % (top, name), net, cfg)
+    net = d_conv(P, '%s/%s/Conv' % (top, name), maybe_gdrop(net, cfg), cfg)      # nets/pggan.py:221-231
+    net = d_conv(P, '%s/%s/Conv_1' % (top, name), maybe_gdrop(net, cfg), cfg)
     net = resblock(P, '%s/%s' % (top, name), blk_in, nc, net, cfg)
     ep[name] = net
     net = avg_pool2(net)
@@ -770,8 +794,8 @@ def discriminator(P, x, cfg, top):
       net = net * cfg.alpha_grow + (1 - cfg.alpha_grow) * shr
   blk = '%s/before_fc_1x1x%d' % (top, cfg.max_ch_dis or cfg.max_ch)
   net = minibatch_state_concat(net)
-  net = d_conv(P, blk + '/Conv', net, cfg, k=3, padding='SAME')
-  net = d_conv(P, blk + '/Conv_1', net, cfg, k=4, padding='VALID')
+  net = d_conv(P, blk + '/Conv', maybe_gdrop(net, cfg), cfg, k=3, padding='SAME')      # nets/pggan.py:328-331
+  net = d_conv(P, blk + '/Conv_1', maybe_gdrop(net, cfg), cfg, k=4, padding='VALID')
   ep['before_fc'] = net
   feat = net.reshape(net.shape[0], -1)
   pred = equalize(feat, cfg, 1) @ P[top + '/prediction/fully_connected/weights'] + \

@@ -181,6 +181,71 @@ def test_losses_and_gradients(precision, hw, max_ch):
   _grads_close(tr, Pref, tr.store.names('d'), gtol, 'discriminator', min_cos, vtol)
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_gdrop_layer_in_the_discriminator_matches_oracle(precision, monkeypatch):
+  """libs/gdrop.py:20-36 behind nets/pggan.py's do_dgrop argument (which no trainer of the reference sets: off by default
+  here as there): with the SAME noise draws the discriminator's prediction and its input gradient land on the oracle's,
+  whose gdrop is pinned to the reference's (tests/test_reference_live.py::test_gdrop_layer_matches_live_reference); the
+  node's second derivative (the gradient penalty differentiates it twice): tests/test_gpu_ops.py::test_gdrop_op."""
+  from twingan_amd import ops, pggan
+  kw = dict(hw=16, max_ch=8, do_dgrop=True, gdrop_strength=0.3)
+  cfg, rcfg, tr, Pref, dev, ref = make(kw, precision, seed=9, batch=3)
+  rcfg.do_dgrop, rcfg.gdrop_strength = True, 0.3
+  g = torch.Generator().manual_seed(77)
+  noises = [torch.randn(3, c, generator=g) for c in (8, 8, 8, 8, 9, 8)]      # one discriminator call: 2 + 2 block convs, 2 tail convs
+  feed = {'i': 0}
+  real = ops.gdrop
+
+  def fed(x, strength, noise=None, c_logical=None):
+    nz = noises[feed['i']]
+    feed['i'] += 1
+    assert nz.shape[1] == (c_logical or x.shape[-1]), (nz.shape, x.shape, c_logical)
+    pad = torch.zeros(nz.shape[0], x.shape[-1])      # the minibatch-stddev tensor is channel-padded: 9 -> 16
+    pad[:, :nz.shape[1]] = nz
+    return real(x, strength, noise=pad.to(x.device), c_logical=c_logical)
+  monkeypatch.setattr(ops, 'gdrop', fed)
+  tol = 2e-5 if precision == 'fp32' else 3e-2
+  xin = dev['s'].clone().requires_grad_(True)
+  pred, _ = pggan.discriminator(tr.P, xin, cfg, 'discriminator_s')
+  assert feed['i'] == 6
+  rcfg.gdrop_noise = [n.double() for n in noises[:6]]
+  rx = ref['s'].clone().requires_grad_(True)
+  rpred, _ = R.discriminator(Pref, rx, rcfg, 'discriminator_s')
+  assert rel_l2(pred, rpred) < tol
+  pred.sum().backward()
+  rpred.sum().backward()
+  assert rel_l2(xin.grad, rx.grad) < (5e-5 if precision == 'fp32' else 0.12)      # bf16: one rounding per layer through 8 convs and 6 gdrop layers, both ways
+
+
+def test_use_gdrop_controller_and_identity(monkeypatch):
+  """--use_gdrop: the `gdrop_strength` variable exists (checkpoint schema), training is unchanged (do_dgrop is never set by
+  the trainers: twingan.py:861-867), and after a generator run past global step 100 the variable holds
+  gdrop_coef * max(clip(generator_loss, 0, 1) - gdrop_lim, 0) ** gdrop_exp (image_generation.py:563-585; pinned to the
+  reference by tests/test_reference_live.py)."""
+  from twingan_amd import Config
+  from twingan_amd.twingan import Trainer
+  g = torch.Generator().manual_seed(3)
+  s = torch.rand(2, 16, 16, 3, generator=g).to('cuda:0')
+  t = torch.rand(2, 16, 16, 3, generator=g).to('cuda:0')
+  al = torch.rand(2, generator=g).to('cuda:0')
+  flats = {}
+  for flag in (False, True):
+    cfg = Config(hw=16, max_ch=8, precision='fp32', use_gdrop=flag, gdrop_lim=0.25)
+    tr = Trainer(cfg, device='cuda:0', seed=4)
+    tr.global_step = 150
+    assert ('gdrop_strength' in tr.store.state_dict(include_state=True)) == flag
+    out = tr.run(s, t, al, al)      # generator run
+    if flag:
+      want = 0.2 * max(min(max(float(out[0]), 0.0), 1.0) - 0.25, 0.0) ** 2.0
+      got = float(tr.store.state['gdrop_strength'])
+      assert want > 0 and abs(got - want) < 1e-6 * max(1.0, want), (got, want)
+      assert tuple(tr.store.state_dict(include_state=True)['gdrop_strength'].shape) == ()
+    tr.run(s, t, al, al)            # discriminator run
+    torch.cuda.synchronize()
+    flats[flag] = (tr.store.flat['g'].clone(), tr.store.flat['d'].clone())
+  assert torch.equal(flats[True][0], flats[False][0]) and torch.equal(flats[True][1], flats[False][1])
+
+
 @pytest.mark.parametrize('equalized,res_block,growing', [(True, False, False), (False, True, False), (True, True, True)])
 def test_equalized_lr_and_res_block(equalized, res_block, growing):
   """--equalized_learning_rate (input scaling, N(0,1) weights; nets/pggan_utils.py:82-84,236-254) and --use_res_block

@@ -905,6 +905,36 @@ def test_lrelu_backward_folded_into_next_backward_data(ops, dtype, hw, c1, c2):
       assert rel_l2(a, b) < tol
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_gdrop_op(ops, dtype):
+  """tg_gdrop (libs/gdrop.py:20-36, mode 'prop'): x * (noise[N,1,1,C] * strength * sqrt(C) + 1) with a host or a device
+  strength, a channel-padded tensor (c_logical < C), and the node differentiated twice (it is linear: its backward is
+  itself)."""
+  rng = np.random.RandomState(8)
+  n, hw, c, cl = 3, 4, 16, 9
+  x = rng.randn(n, hw, hw, c)
+  x[..., cl:] = 0.0
+  if dtype == torch.bfloat16:
+    x = bf16_round(x)
+  noise = rng.randn(n, c).astype(np.float32)
+  strength = 0.37
+  f = noise.astype(np.float64) * (strength * float(np.sqrt(np.float32(cl)))) + 1.0
+  ref = x * f[:, None, None, :]
+  xd = to_dev(x, dtype).requires_grad_(True)
+  nd = torch.from_numpy(noise).to(dev())
+  y = ops.gdrop(xd, strength, noise=nd, c_logical=cl)
+  assert rel_l2(host(y), ref) < tol_for(dtype)
+  sdev = torch.tensor([strength], dtype=torch.float32, device=dev())      # the gdrop_strength variable
+  assert torch.equal(ops.gdrop(xd.detach(), sdev, noise=nd, c_logical=cl), y.detach())
+  gy = rng.randn(n, hw, hw, c)
+  gyd = to_dev(gy, dtype).requires_grad_(True)
+  gx, = torch.autograd.grad(y, xd, gyd, create_graph=True)
+  assert rel_l2(host(gx), gy * f[:, None, None, :]) < tol_for(dtype, True)
+  v = rng.randn(n, hw, hw, c)
+  ggy, = torch.autograd.grad(gx, gyd, to_dev(v, dtype))      # d/d gy of gy * f, contracted with v
+  assert rel_l2(host(ggy), v * f[:, None, None, :]) < tol_for(dtype, True)
+
+
 SMALL_MASK_CASES = [
     # n, hw, cin, cout, k, padding, kernel family of the backward-data
     (5, 8, 256, 256, 3, 'SAME', 'conv_img'),

@@ -259,3 +259,59 @@ def test_native_normaliser_variables_are_what_the_reference_creates(norm):
     assert sum('/_t/renorm_stddev_weight' in k for k in state) == sum('/_t/gamma' in k for k in trainable) > 0
   wrong = [k for k in want if is_model_variable(k) != (k in ref['model_variables'])]
   assert not wrong, wrong[:5]
+
+
+def test_gdrop_layer_matches_live_reference():
+  """libs/gdrop.py:20-36 through nets/pggan.py's discriminator with do_dgrop=True (the argument no trainer of the reference
+  sets): the oracle with the reference's own noise draws lands on the reference's prediction; without the layer it does not."""
+  from oracle import ref_runner
+  cfg = R.Config(hw=16, max_ch=8, do_dgrop=True, gdrop_strength=0.3)
+  P = {k: v.float().double() for k, v in R.init_params(cfg, seed=5, dtype=torch.float64, std='he').items()}
+  x = torch.rand(3, 16, 16, 3, generator=torch.Generator().manual_seed(6)).double()
+  ref = ref_runner.run_discriminator(ref_runner.flags_of(cfg), x.numpy(), 'discriminator_s',
+                                     preset={k: v.numpy() for k, v in P.items()}, do_dgrop=True, gdrop_strength=0.3,
+                                     is_training=True)
+  draws = [v for n, v in ref['random'] if n == 'gdrop']
+  assert [v.shape[-1] for v in draws] == [8, 8, 8, 8, 9, 8]      # two per block (16x16, 8x8), two after the minibatch stddev
+  cfg.gdrop_noise = [torch.from_numpy(v).reshape(v.shape[0], v.shape[-1]) for v in draws]
+  pred, _ = R.discriminator(P, x, cfg, 'discriminator_s')
+  assert np.abs(pred.detach().numpy() - ref['prediction']).max() < 1e-12
+  plain, _ = R.discriminator(P, x, R.Config(hw=16, max_ch=8), 'discriminator_s')
+  assert np.abs(plain.detach().numpy() - ref['prediction']).max() > 1e-2
+  # is_training=False: the identity (nets/pggan.py:352)
+  ref_eval = ref_runner.run_discriminator(ref_runner.flags_of(cfg), x.numpy(), 'discriminator_s',
+                                          preset={k: v.numpy() for k, v in P.items()}, do_dgrop=True, gdrop_strength=0.3,
+                                          is_training=False)
+  assert not ref_eval['random'] and np.abs(plain.detach().numpy() - ref_eval['prediction']).max() < 1e-12
+
+
+def test_use_gdrop_changes_no_update_and_its_controller_matches_live_reference():
+  """--use_gdrop (image_generation.py:563-585, twingan.py:861-867): the trainers create the `gdrop_strength` variable and
+  update it from the generator loss, but never pass do_dgrop=True -- the layer is the identity, every parameter update
+  equals the run without the flag -- and the controller's value after a generator run is
+  gdrop_coef * max(clip(generator_loss, 0, 1) - gdrop_lim, 0) ** gdrop_exp once global_step > 100."""
+  from oracle import ref_runner
+  cfg = R.Config(hw=16, max_ch=8, lr=1e-3)
+  P0 = {k: v.float().double() for k, v in R.init_params(cfg, seed=41, dtype=torch.float64, std='he').items()}
+  g = torch.Generator().manual_seed(42)
+  runs = [(torch.rand(2, 16, 16, 3, generator=g).double(), torch.rand(2, 16, 16, 3, generator=g).double()) for _ in range(3)]
+  base = dict(ref_runner.flags_of(cfg), learning_rate=cfg.lr, learning_rate_decay_type='fixed', optimizer='adam',
+              adam_beta1=cfg.beta1, adam_beta2=cfg.beta2, opt_epsilon=cfg.adam_eps, n_critic=2)
+  out = {}
+  for flag in (False, True):
+    out[flag] = ref_runner.run_training(dict(base, use_gdrop=flag, gdrop_lim=0.25), [(s.numpy(), t.numpy()) for s, t in runs],
+                                        seed=0, preset={k: v.numpy() for k, v in P0.items()}, global_step=150)
+  assert 'gdrop_strength' in out[True]['variables'] and 'gdrop_strength' not in out[False]['variables']
+  for k in P0:      # the flag changes no parameter
+    assert np.array_equal(out[True]['variables'][k], out[False]['variables'][k]), k
+  # the controller: the last run (index 2) is a generator run; its generator loss comes from the oracle on the parameters
+  # that run started from
+  P = {k: v.clone() for k, v in P0.items()}
+  opt = R.AdamState(P, cfg)
+  for i, ((s, t), h) in enumerate(zip(runs, out[True]['history'])):
+    a = [v for n, v in h['random'] if n == 'alpha']
+    if i == 2:
+      gl, _ = R.generator_loss(P, s, t, cfg)
+      want = 0.2 * max(min(max(float(gl), 0.0), 1.0) - 0.25, 0.0) ** 2.0
+    R.train_step(P, opt, s, t, cfg, torch.from_numpy(a[0]), torch.from_numpy(a[1]), i)
+  assert want > 0 and abs(float(out[True]['variables']['gdrop_strength']) - want) < 1e-12, (want, out[True]['variables']['gdrop_strength'])

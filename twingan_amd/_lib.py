@@ -115,6 +115,7 @@ SIGNATURES = {
     'tg_axpby': (c_int, [_P, _P, _P, c_int64, c_float, c_float, c_int, _P]),
     'tg_sample_lerp': (c_int, [_P, _P, _FP, _P, c_int, c_int64, c_int, _P]),
     'tg_sample_scale': (c_int, [_P, _FP, _FP, _P, c_int, c_int64, c_int, _P]),
+    'tg_gdrop': (c_int, [_P, _FP, _FP, c_float, c_int, _P, c_int, c_int64, c_int, c_int, _P]),
     'tg_fill_scaled': (c_int, [_P, _FP, c_float, c_int64, c_int, _P]),
     'tg_cast': (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
     'tg_mbstd_fwd': (c_int, [_P, _P, _FP, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P]),

@@ -28,6 +28,15 @@ class Config:
   distillation_weight: float = 1.0
   distillation_start_hw: int = 16
   distill_embed_dim: int = 0          # width of the dataset's 'a_embedding' / 'b_embedding' fields (twingan.py:164-177)
+  # gdrop (libs/gdrop.py:20-36).  As in the reference: --use_gdrop creates the `gdrop_strength` variable and its controller
+  # (image_generation.py:563-585, 1034-1040) and hands the variable to the discriminators, but the layer itself runs only
+  # under nets/pggan.py's `do_dgrop` argument, which no trainer of the reference sets (default False, :340,352)
+  use_gdrop: bool = False
+  gdrop_coef: float = 0.2
+  gdrop_lim: float = 0.5
+  gdrop_exp: float = 2.0
+  do_dgrop: bool = False              # nets/pggan.py:340 (the reference's spelling)
+  gdrop_strength: float = 0.0         # nets/pggan.py:341: the strength when no `gdrop_strength` variable exists
   is_training: bool = True            # False: the inference branch (twingan.py:300-363) -- BatchNorm reads the moving statistics
   is_growing: bool = False            # image_generation.py:69-72
   alpha_grow: float = 0.0             # twingan.py:833-835

@@ -98,6 +98,23 @@ __global__ void sample_scale_kernel(const T* __restrict__ x, const float* __rest
     st(out + i, ld(x + i) * coef[i / per] * sc);
 }
 
+// gdrop, mode 'prop' (libs/gdrop.py:20-36): out[n, p, c] = x[n, p, c] * (noise[n, c] * coef + 1) with
+// coef = strength * sqrt(c_logical); the strength is a DEVICE scalar (the `gdrop_strength` variable of the controller,
+// image_generation.py:563-585) or a constant.  c may be channel-padded (the minibatch-stddev tensor): noise has c entries
+// per image, the pad channels of x are zero.  One thread per element: this is an off-by-default layer of the plain PGGAN
+// discriminator, a single pass at the tensor's byte rate.
+template <typename T>
+__global__ void gdrop_kernel(const T* __restrict__ x, const float* __restrict__ noise, const float* __restrict__ strength_dev,
+                             float strength, float sqrt_c, T* __restrict__ out, int64_t per_image, int c, int64_t numel) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float coef = (strength_dev ? strength_dev[0] : strength) * sqrt_c;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) {
+    const int64_t img = i / per_image;
+    const int ch = (int)(i % c);
+    st(out + i, ld(x + i) * fmaf(noise[img * c + ch], coef, 1.f));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 2x nearest upsample (+ channel concat), its backward; 2x2 pool and its backward.
 // One thread per 16-byte channel vector of one OUTPUT pixel (scalar path when c % V != 0).
@@ -756,6 +773,18 @@ int tg_sample_scale(const void* x, const float* coef, const float* scalar, void*
                        (const T*)x, coef, scalar, (T*)out, per, batch * per);
   });
   TG_LAUNCH_CHECK("tg_sample_scale");
+  return TG_OK;
+}
+
+int tg_gdrop(const void* x, const float* noise, const float* strength_dev, float strength, int c_logical, void* out, int n,
+             int64_t hw, int c, int dtype, void* stream) {
+  TG_CHECK(x && noise && out && n > 0 && hw > 0 && c > 0 && c_logical > 0 && c_logical <= c, TG_EINVAL, "tg_gdrop: bad arguments");
+  const int64_t per = hw * c;
+  TG_DISPATCH_DTYPE(dtype, "tg_gdrop", {
+    hipLaunchKernelGGL(gdrop_kernel<T>, dim3(tg_grid_for(n * per, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, noise,
+                       strength_dev, strength, sqrtf((float)c_logical), (T*)out, per, c, n * per);
+  });
+  TG_LAUNCH_CHECK("tg_gdrop");
   return TG_OK;
 }
 

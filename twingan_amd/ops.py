@@ -1683,6 +1683,37 @@ def lerp(new, old, alpha):
   return AxpbyFn.apply(new, old, float(alpha), float(1.0 - alpha))
 
 
+class GDropFn(torch.autograd.Function):
+  """libs/gdrop.py:20-36 (mode 'prop'): x * (noise * strength * sqrt(C) + 1), noise [N, C] fp32 ~ N(0, 1) per image and
+  channel (rnd_shape [N, 1, 1, C]).  ``strength``: a python float or a fp32 device scalar (the `gdrop_strength` variable).
+  Linear in x with a constant factor, so the backward -- and the backward of that, under the gradient penalty -- is the
+  same node applied to the incoming gradient."""
+
+  @staticmethod
+  def forward(ctx, x, noise, strength, c_logical):
+    _chk(x, noise)
+    n, c = x.shape[0], x.shape[-1]
+    assert noise.dtype == torch.float32 and tuple(noise.shape) == (n, c), (tuple(noise.shape), n, c)
+    out = torch.empty_like(x)
+    dev = strength if isinstance(strength, torch.Tensor) else None
+    call('tg_gdrop', _p(x), _p(noise), _p(dev), 0.0 if dev is not None else float(strength), int(c_logical), _p(out), n,
+         x.numel() // (n * c), c, _dt(x), _stream(), work=('gdrop' + _shape_tag(x), 0, _nb(x, out)))
+    ctx.noise, ctx.strength, ctx.c_logical = noise, strength, c_logical
+    return out
+
+  @staticmethod
+  def backward(ctx, g):
+    return GDropFn.apply(g.contiguous(), ctx.noise, ctx.strength, ctx.c_logical), None, None, None
+
+
+def gdrop(x, strength, noise=None, c_logical=None):
+  """ops.gdrop of the reference (libs/ops.py:31) on an NHWC tensor; ``noise`` [N, C] (drawn on the device when None)."""
+  n, c = x.shape[0], x.shape[-1]
+  if noise is None:
+    noise = torch.randn(n, c, dtype=torch.float32, device=x.device)
+  return GDropFn.apply(x.contiguous(), noise.contiguous(), strength, c_logical or c)
+
+
 class RowViewsFn(torch.autograd.Function):
   """Overlapping row ranges of one batch as VIEWS: x [N, ...] -> x[lo:hi] for every (lo, hi) of ``ranges``.
 

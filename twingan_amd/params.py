@@ -140,6 +140,8 @@ class ParamStore:
     if self.renorm:      # clipping bounds of the current global step (nets/pggan_utils.py:207-223), set by the trainer
       for k, v in (('renorm/rmax', 1.1), ('renorm/rmin', 0.9), ('renorm/dmax', 0.1)):
         self.state[k] = torch.full((1,), v, dtype=torch.float32, device=self.device)
+    if 'gdrop_strength' in self.state_specs:      # the controller's coefficient of the current global step (Trainer._set_gdrop_coef)
+      self.state['gdrop/coef'] = torch.zeros(1, dtype=torch.float32, device=self.device)
     self.P.state = self.state
     PackCache.version += 1
     return self
@@ -332,6 +334,10 @@ def declare_twingan(store, cfg, model='twingan'):
   rk = min(7, hw // 2) if cfg.use_larger_filter_at_rgb_layer else 1      # nets/pggan.py:172-175,194-197
   if cfg.equalized_learning_rate:
     store.weights_init_stddev = 1.0
+
+  if cfg.use_gdrop:      # twingan.py:861-865 / image_generation.py:1034-1038: slim.model_variable('gdrop_strength', shape=[], zeros)
+    store.state_specs['gdrop_strength'] = (1, 0.0)
+    store.scalar_state.add('gdrop_strength')
 
   def sn_state(scope, cout, is_disc):
     """--spectral_norm: the power-iteration vector 'u' [1, cout] of a conv (libs/sn.py:56-57, truncated normal)."""

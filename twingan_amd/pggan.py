@@ -454,9 +454,26 @@ def _batch_renorm(P, scope, yv, domain, activation, pn, pool, cond_rows=None, im
                       pool=pool, stats=(mean, rstd))
 
 
-def _d_conv(P, scope, x, cfg, k=3, padding='SAME', pool=False, in_ch=None, sole_consumer=False, pool_only=False):
+def maybe_gdrop(P, x, cfg, in_ch=None):
+  """nets/pggan.py:351-355: ``ops.gdrop(layer, mode='prop', strength=gdrop_strength)`` when do_dgrop and is_training and
+  the strength is set -- the `gdrop_strength` variable under --use_gdrop (twingan.py:861-865), else the constant of the
+  signature (nets/pggan.py:341).  No trainer of the reference passes do_dgrop=True, so by default this is the identity
+  there and here; -> (tensor, whether the layer ran)."""
+  if not (cfg.do_dgrop and cfg.is_training):
+    return x, False
+  strength = P.state['gdrop_strength'] if cfg.use_gdrop else cfg.gdrop_strength
+  if not isinstance(strength, float) or strength:
+    return ops.gdrop(x, strength, c_logical=in_ch), True
+  return x, False
+
+
+def _d_conv(P, scope, x, cfg, k=3, padding='SAME', pool=False, in_ch=None, sole_consumer=False, pool_only=False, gdrop=False):
   """Discriminator arg-scope (nets/pggan_utils.py:116-127): conv + bias, no norm, LeakyReLU(0.2),
-  fused into the conv epilogue."""
+  fused into the conv epilogue.  ``gdrop``: the conv's input goes through maybe_gdrop first (the two convs of a block,
+  nets/pggan.py:221-231, and the two after the minibatch stddev, :328-331)."""
+  if gdrop:
+    x, ran = maybe_gdrop(P, x, cfg, in_ch)
+    sole_consumer = sole_consumer and not ran      # the producer's LeakyReLU output is then not this conv's input
   w = _sn(P, scope, cfg, True)
   b = P[scope + '/biases']
   x = _equalize(x, cfg, k, in_ch)      # in_ch: logical channel count when x is channel-padded (minibatch stddev)
@@ -672,14 +689,14 @@ def discriminator_before_fc(P, source, cfg, top, groups=1, cut_seg=None, block_e
     net = maybe_add_self_attention(P, top, current_hw, num_channels, net, end_points, None, cfg, True)   # pggan.py:294-296
     name = 'encoder_block_%dx%dx%d' % (current_hw, current_hw, num_channels)
     block_in = net
-    net = _d_conv(P, '%s/%s/Conv' % (top, name), net, cfg, sole_consumer=True)
+    net = _d_conv(P, '%s/%s/Conv' % (top, name), net, cfg, sole_consumer=True, gdrop=True)
     if cfg.use_res_block:
-      net = _d_conv(P, '%s/%s/Conv_1' % (top, name), net, cfg)
+      net = _d_conv(P, '%s/%s/Conv_1' % (top, name), net, cfg, gdrop=True)
       end_points[name] = maybe_resblock(P, '%s/%s' % (top, name), block_in, num_channels, net, cfg, True)
       net = ops.avg_pool2(end_points[name])
     else:
       full, net = _d_conv(P, '%s/%s/Conv_1' % (top, name), net, cfg, pool=True, sole_consumer=True,      # conv + avg_pool (pggan.py:304-306)
-                          pool_only=not block_end_points)
+                          pool_only=not block_end_points, gdrop=True)
       if full is not None:
         end_points[name] = full
     current_hw //= 2
@@ -689,8 +706,8 @@ def discriminator_before_fc(P, source, cfg, top, groups=1, cut_seg=None, block_e
       end_points['encoder_block_interpolated_%dx%dx%d' % (current_hw, current_hw, num_channels)] = net
   blk = 'before_fc_1x1x%d' % max_ch
   net = ops.minibatch_state_concat(net, mbstd_cpad(net.shape[3]), groups)      # pggan_utils.py:353-366
-  net = _d_conv(P, '%s/%s/Conv' % (top, blk), net, cfg, k=3, padding='SAME', in_ch=max_ch + 1)
-  net = _d_conv(P, '%s/%s/Conv_1' % (top, blk), net, cfg, k=4, padding='VALID', sole_consumer=True)
+  net = _d_conv(P, '%s/%s/Conv' % (top, blk), net, cfg, k=3, padding='SAME', in_ch=max_ch + 1, gdrop=True)
+  net = _d_conv(P, '%s/%s/Conv_1' % (top, blk), net, cfg, k=4, padding='VALID', sole_consumer=True, gdrop=True)
   end_points[blk] = net
   end_points['before_fc'] = net
   return net, end_points

@@ -449,6 +449,8 @@ class Trainer:
           gp_alpha_t = torch.rand(b, dtype=torch.float32, device=self.device)
         loss, terms = self._discriminator_loss(sources, targets, gp_alpha_s, gp_alpha_t)
       out = (loss.detach(), {k: v.detach() for k, v in terms.items()})
+      if group == 'g' and self.cfg.use_gdrop:
+        self._update_gdrop(out[0])
       scaled = loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)       # model_deploy.py:265-268,308-313
       ops.GradSink.pair = True
       # the slab reductions of the filter gradients that feed gradient sinks: queued, one launch per backward segment
@@ -670,6 +672,8 @@ class Trainer:
     with (torch.cuda.device(self.device) if self.device.type == 'cuda' else contextlib.nullcontext()):
       if self.cfg.generator_norm_type in ('batch_renorm', 'batch_renorm_native'):
         self._set_renorm_clipping()
+      if self.cfg.use_gdrop:
+        self._set_gdrop_coef()
       if self.use_graph:
         assert gp_alpha_s is None and gp_alpha_t is None, 'graph mode draws the GP alphas on the device'
         out = self._run_graph('g' if is_g else 'd', sources, targets)
@@ -689,6 +693,22 @@ class Trainer:
     self.n_critic_counter += 1
     if self.n_critic_counter % self.cfg.n_critic == 0:
       self.global_step += 1
+
+  def _update_gdrop(self, generator_loss):
+    """GanModel._maybe_add_gdrop_update_op (image_generation.py:563-585): gdrop_strength = coef * max(clip(mean(generator
+    loss), 0, 1) - gdrop_lim, 0) ** gdrop_exp, coef = gdrop_coef once global_step > 100 (the ExponentialMovingAverage the
+    reference also applies feeds nothing).  On the device, so a captured step replays it.  The reference's graph evaluates
+    the generator loss in EVERY run and so also refreshes the variable in discriminator runs; here it is refreshed where
+    the generator loss exists -- the generator runs.  Nothing reads the variable unless cfg.do_dgrop is set."""
+    c, st = self.cfg, self.store.state
+    cur = generator_loss.detach().float().mean().clamp(0.0, 1.0)
+    st['gdrop_strength'].copy_((st['gdrop/coef'] * (cur - c.gdrop_lim).clamp_min(0.0) ** c.gdrop_exp).reshape(1))
+
+  def _set_gdrop_coef(self):
+    coef = self.cfg.gdrop_coef if self.global_step > 100 else 0.0      # tf.cond(tf.greater(global_step, 100), ...)
+    if getattr(self, '_gdrop_coef', None) != coef:
+      self._gdrop_coef = coef
+      self.store.state['gdrop/coef'].fill_(coef)
 
   def _set_renorm_clipping(self):
     """get_renorm_clipping_params (nets/pggan_utils.py:40-50,207-223): rmax / rmin / dmax are piecewise constant in the
