@@ -485,6 +485,9 @@ size_t tg_sn_table_bytes(int njobs);
 int tg_sn_table_fill(int j, const float* w, const float* u, float* w_bar, float* u_new, float* v, float* stats, void* ws,
                      size_t ws_bytes, int k_rows, int cout, void* host_table, int32_t* totals);
 int tg_spectral_norm_fwd_multi(const void* table, int njobs, int row_blocks, int col_blocks, int fin_blocks, void* stream);
+/* u <- u_new of every job of the table, one launch: the assign of libs/sn.py:84-86 at the end of a run (the caller's u
+ * buffers are the table's `u` entries, read by tg_spectral_norm_fwd_multi of the NEXT run). */
+int tg_sn_assign_u(const void* table, int njobs, void* stream);
 
 /* SAGAN self-attention (libs/self_attention.py:24-70: s = tf.matmul(f, g, transpose_b=True) over the h*w positions,
  * beta = tf.nn.softmax(s), o = tf.matmul(beta, h)) without materialising the [len x len] map: q = f [n, len, dk],

@@ -13,7 +13,7 @@
 #   ab:<VAR=v,...>    interleaved same-box A/B, ROUNDS (2) rounds: default environment vs the given variables (config 3)
 #   abc:<C>:<VAR=v,...>  the same on config C
 #   lib:<name>        interleaved A/B of the in-tree library vs tools/ab/<name>.so (same ABI)
-#   old:<name>        interleaved A/B of this tree vs the complete older tree tools/ab/<name>_tree (git archive + its built library)
+#   old:<name>        interleaved A/B of this tree vs the complete older tree tools/ab/<name>_tree (git archive + its built library); OLD_ARGS='--config 4' for another configuration
 #   trace[:C]         rocprofv3 kernel trace of replayed steps: gaps, overlap, per-kernel table of ONE replayed step
 #   py:<VAR=v,..|->:<script+args>  run a python tool (under the given environment) -> py.log
 #   scan              batch scan b = 4 8 16 24 32 (ms per step)
@@ -82,7 +82,7 @@ for step in "$@"; do
       for i in $(seq 1 $ROUNDS); do
         for which in cur $arg; do
           if [ $which = cur ]; then dir=$REPO; else dir=$REPO/tools/ab/${which}_tree; fi
-          (cd $dir && timeout 300 python bench.py --no-cpu-baseline --no-roofline --steps ${STEPS:-20} --warmup 3 2> $REPO/$OUT/old_${which}_$i.err) | line "tree:$which" | tee -a $OUT/ab.log
+          (cd $dir && timeout 300 python bench.py --no-cpu-baseline --no-roofline --steps ${STEPS:-20} --warmup 3 ${OLD_ARGS} 2> $REPO/$OUT/old_${which}_$i.err) | line "tree:$which ${OLD_ARGS}" | tee -a $OUT/ab.log
         done
       done ;;
     trace)    # kernel trace of replayed steps -> gaps / overlap of the last one + its per-kernel table (step_kernels_cC.json)

@@ -150,6 +150,7 @@ SIGNATURES = {
     'tg_sn_table_bytes': (c_size_t, [c_int]),
     'tg_sn_table_fill': (c_int, [c_int, _FP, _FP, _FP, _FP, _FP, _FP, _P, c_size_t, c_int, c_int, _P, POINTER(c_int32)]),
     'tg_spectral_norm_fwd_multi': (c_int, [_P, c_int, c_int, c_int, c_int, _P]),
+    'tg_sn_assign_u': (c_int, [_P, c_int, _P]),
 }
 
 _lib = None

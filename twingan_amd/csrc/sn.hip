@@ -272,6 +272,13 @@ __device__ __forceinline__ int sn_job_of(const SnJob* __restrict__ t, int njobs,
   }
   return j;
 }
+// u <- u_new for every job (libs/sn.py:84-86: the assign of the power-iteration vector at the end of a run), one workgroup
+// per job: 30 device-to-device copies of a few hundred bytes in BASELINE configs[4] otherwise
+__global__ __launch_bounds__(256) void sn_assign_u_multi(const SnJob* __restrict__ t) {
+  const SnJob J = t[blockIdx.x];
+  float* u = const_cast<float*>(J.u);
+  for (int i = threadIdx.x; i < J.cout; i += 256) u[i] = J.u_new[i];
+}
 __global__ __launch_bounds__(256) void sn_rowdot_multi(const SnJob* __restrict__ t, int njobs) {
   const SnJob J = t[sn_job_of<0>(t, njobs, blockIdx.x)];
   float* v_raw = J.ws;
@@ -371,6 +378,13 @@ int tg_spectral_norm_fwd_multi(const void* table, int njobs, int row_blocks, int
   hipLaunchKernelGGL(sn_coldot_multi, dim3(col_blocks), dim3(256), 0, s, (const SnJob*)table, njobs);
   hipLaunchKernelGGL(sn_finish_multi, dim3(fin_blocks), dim3(256), 0, s, (const SnJob*)table, njobs);
   TG_LAUNCH_CHECK("tg_spectral_norm_fwd_multi");
+  return TG_OK;
+}
+
+int tg_sn_assign_u(const void* table, int njobs, void* stream) {
+  TG_CHECK(table && njobs > 0, TG_EINVAL, "tg_sn_assign_u: bad arguments");
+  hipLaunchKernelGGL(sn_assign_u_multi, dim3(njobs), dim3(256), 0, (hipStream_t)stream, (const SnJob*)table);
+  TG_LAUNCH_CHECK("tg_sn_assign_u");
   return TG_OK;
 }
 

@@ -624,6 +624,15 @@ def conv_bwd_weight2_raw(xa, gya, xb, gyb, spec, out, gbias=None, bias_segs=3):
   return True
 
 
+def _bias_rides_with_filter_gradient(need_b, need_w, bias, w):
+  """Can the filter-gradient kernel sum g over pixels as well (the layer's bias gradient from the same read of g,
+  tg_conv2d_bwd_weight*_bias)?  When the bias has a gradient sink and the weight has one too (the paired launches of
+  GradSink) -- or has none in a first-order pass: a spectrally normalised kernel, whose ``w`` is the per-run w_bar and
+  whose gradient is a plain tensor (config 4: 38 tg_channel_sum launches of 15 us per step otherwise)."""
+  return (need_b and need_w and GradSink.get(bias) is not None and not deterministic()
+          and (GradSink.get(w) is not None or not torch.is_grad_enabled()))
+
+
 def _weight_grad(x, g, spec, w, bias_sink=None):
   """Parameter gradient of a conv: into the sink when ``w`` has one (returns None), else a differentiable node.
   ``bias_sink``: also add the bias gradient (pixel sums of g) into that buffer from the same kernel."""
@@ -631,7 +640,9 @@ def _weight_grad(x, g, spec, w, bias_sink=None):
   if sink is not None:
     GradSink.submit(w, x, g, spec, sink, bias_sink)
     return None
-  assert bias_sink is None
+  if bias_sink is not None:      # first-order pass, no sink for w: the gradient tensor, the bias gradient riding along
+    assert not torch.is_grad_enabled()
+    return conv_bwd_weight_raw(x, g, spec, gbias=bias_sink)
   return ConvBwdWeightFn.apply(x, g, spec)
 
 
@@ -768,7 +779,7 @@ def _conv_backward(ctx, gz, gzp=None):
     gzp = None
   if premasked:
     g = gz
-    if need_b and need_w and GradSink.get(bias) is not None and GradSink.get(w) is not None and not deterministic():
+    if _bias_rides_with_filter_gradient(need_b, need_w, bias, w):
       bias_sink = GradSink.get(bias)      # the filter-gradient kernel sums g over pixels as well
       need_b = False
   elif pooled_lrelu is not None:
@@ -788,7 +799,7 @@ def _conv_backward(ctx, gz, gzp=None):
     if gx_done is None:
       g, gb = lrelu_pool_bwd_signs(gzp, z, spec.alpha, bias if need_b else None, need_b)
       need_b = False
-    elif need_b and need_w and GradSink.get(bias) is not None and GradSink.get(w) is not None and not deterministic():
+    elif _bias_rides_with_filter_gradient(need_b, need_w, bias, w):
       bias_sink = GradSink.get(bias)      # the filter-gradient kernel sums g over pixels as well
       need_b = False
   elif ctx.epilogue & TG_EPI_LRELU:
@@ -802,7 +813,7 @@ def _conv_backward(ctx, gz, gzp=None):
         return out, None, None, None, None, None
       if out is not None:
         gx_done, g = out
-        if need_b and need_w and GradSink.get(bias) is not None and GradSink.get(w) is not None and not deterministic():
+        if _bias_rides_with_filter_gradient(need_b, need_w, bias, w):
           bias_sink = GradSink.get(bias)
           need_b = False
     if gx_done is not None:
@@ -2271,6 +2282,10 @@ class SnTable:
     self.totals = tuple(int(t) for t in totals)
     self.table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev)
     self.nbytes = sum(4 * _nb(w) for w, _, _ in items)
+
+  def assign_u(self):
+    """u <- u' for every kernel of the table (pggan.end_run), one launch."""
+    call('tg_sn_assign_u', _p(self.table), self.n, _stream())
 
   def run(self):
     self.generation += 1

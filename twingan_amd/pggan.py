@@ -97,6 +97,7 @@ def _sn_compute_multi(P, scopes):
     items.append((w, P.state[scope + '/u'], buf))
   outs, table = ops.spectral_norm_multi(items, P.__dict__.get('sn_table'))
   P.__dict__['sn_table'] = table
+  P.__dict__['sn_table_scopes'] = list(scopes)
   for scope, (w_bar, u1) in zip(scopes, outs):
     P.__dict__.setdefault('sn_pending', {})[scope + '/u'] = u1
     if ops.Cuts.active and torch_is_grad_enabled() and w_bar.requires_grad:
@@ -155,8 +156,18 @@ def end_run(P):
   per-run normalised kernels."""
   pending = P.__dict__.get('sn_pending')
   if pending:
+    table = P.__dict__.get('sn_table')
+    done = set()
+    if table is not None and P.__dict__.get('sn_table_scopes'):
+      # the kernels whose power iteration ran through the job table: ONE launch assigns all their u (the table reads
+      # P.state's u buffers in place, so their addresses are the table's)
+      scopes = P.__dict__['sn_table_scopes']
+      if all(s + '/u' in pending and P.state[s + '/u'].data_ptr() == key[1] for s, key in zip(scopes, table.key)):
+        table.assign_u()
+        done = {s + '/u' for s in scopes}
     for k, v in pending.items():
-      P.state[k].copy_(v)
+      if k not in done:
+        P.state[k].copy_(v)
     pending.clear()
   cache = P.__dict__.get('sn_cache')
   if cache:
