@@ -394,6 +394,22 @@ int tg_abs_diff_sum(const void* a, const void* b, float* out, int64_t numel, flo
 /* ga = gscale[0]*scale*sign(a-b), gb = -ga  (either may be NULL) */
 int tg_abs_diff_bwd(const void* a, const void* b, const float* gscale, void* ga, void* gb, int64_t numel, float scale,
                     int dtype, void* stream);
+/* The loss tail of ONE batched discriminator call in one launch each way.  pred: fp32 [groups * group_size] (the
+ * predictions of [real; cycle; prime] ..., image_generation.py:348-400); job j adds coef * mean_i f_mode(x_i; a, b) over
+ * group `group` to terms[term] (modes as tg_pred_loss_fwd; at most 12 jobs, 8 terms; the jobs are read on the HOST and
+ * travel in the kernel arguments).  bwd: gpred_i = sum over the jobs of i's group of gterms[term][0] * coef / group_size *
+ * f'(x_i); gterms: HOST array of nterms device pointers to fp32 scalars (NULL: no gradient for that term). */
+typedef struct TgPredJob {
+  int32_t group, term, mode;
+  float a, b, coef;
+} TgPredJob;
+int tg_pred_losses_fwd(const float* pred, int group_size, int groups, const TgPredJob* jobs, int njobs, float* terms, int nterms,
+                       void* stream);
+int tg_pred_losses_bwd(const float* pred, int group_size, int groups, const TgPredJob* jobs, int njobs, const float* const* gterms,
+                       int nterms, float* gpred, void* stream);
+/* out[0] = sum of n (<= 24) device fp32 scalars, in argument order (tf.add_n over the loss collection,
+ * model/model_inheritor.py); scalars: HOST array of device pointers. */
+int tg_sum_scalars(const float* const* scalars, int n, float* out, void* stream);
 /* Prediction losses on the fp32 [B,1] discriminator outputs (image_generation.py:331-400):
  * out[0] (+)= scale * sum_i f(x_i) with mode 0: x (WGAN means), 1: relu(a + b*x) (hinge), 2: sigmoid cross
  * entropy against label a (tf.losses.sigmoid_cross_entropy: max(x,0) - x*a + log(1+exp(-|x|))), 3: x^2 (drift

@@ -21,7 +21,8 @@ CASES = {'E256a': (256, 16, 16), 'E256b': (256, 16, 32), 'E128a': (128, 32, 32),
          'E16': (16, 256, 256), 'E8': (8, 256, 256), 'D4': (4, 264, 256), 'G4': (4, 256, 256), 'G8a': (8, 512, 256),
          'G16a': (16, 512, 256), 'G32a': (32, 512, 128), 'G32b': (32, 128, 128), 'G64a': (64, 256, 64),
          'G128a': (128, 128, 32), 'G256a': (256, 64, 16)}
-CONV = ('conv_tile', 'conv_wgrad_tile', 'conv_wgrad_quad', 'conv_wgrad_thin', 'conv_small', 'conv_fwd_mfma', 'conv_wgrad_mfma')
+CONV = ('conv_tile', 'conv_thin16', 'conv_img', 'conv_wgrad_tile', 'conv_wgrad_quad', 'conv_wgrad_thin', 'conv_small', 'conv_fwd_mfma',
+        'conv_wgrad_mfma')
 N_SIMD = 256 * 4
 N_XCD = 8
 

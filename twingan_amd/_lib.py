@@ -125,6 +125,9 @@ SIGNATURES = {
     'tg_sum': (c_int, [_P, _FP, c_int64, c_float, c_int, c_int, _P]),
     'tg_abs_diff_sum': (c_int, [_P, _P, _FP, c_int64, c_float, c_int, c_int, _P]),
     'tg_abs_diff_bwd': (c_int, [_P, _P, _FP, _P, _P, c_int64, c_float, c_int, _P]),
+    'tg_pred_losses_fwd': (c_int, [_FP, c_int, c_int, _P, c_int, _FP, c_int, _P]),
+    'tg_pred_losses_bwd': (c_int, [_FP, c_int, c_int, _P, c_int, _P, c_int, _FP, _P]),
+    'tg_sum_scalars': (c_int, [_P, c_int, _FP, _P]),
     'tg_pred_loss_fwd': (c_int, [_FP, _FP, c_int, c_int, c_float, c_float, c_float, c_int, _P]),
     'tg_pred_loss_bwd': (c_int, [_FP, _FP, _FP, c_int, c_int, c_float, c_float, c_float, _P]),
     'tg_var_from_sums': (c_int, [_FP, _FP, _FP, c_int, c_int64, _P]),

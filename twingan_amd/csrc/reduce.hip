@@ -540,6 +540,59 @@ __global__ void pred_loss_bwd_kernel(const float* __restrict__ x, const float* _
     gx[i] = g * pred_loss_df(x[i], mode, a, b);
 }
 
+// ---- the loss tail of one batched discriminator call in ONE launch each way (image_generation.py:331-400).  pred holds
+// `groups` predictions of group_size rows ([real; cyc; prime] ...); job j adds coef * mean_i f_mode(x_i; a, b) over group
+// `group` to term `term`.  Jobs and gradient pointers travel by value in the kernel arguments (a hipGraph records them).
+constexpr int PRED_MAX_JOBS = 12, PRED_MAX_TERMS = 8;
+struct PredJobs {
+  TgPredJob j[PRED_MAX_JOBS];
+  int n;
+};
+struct PredGrads {
+  const float* g[PRED_MAX_TERMS];      // d loss / d term t: a device fp32 scalar each (NULL: that term has no gradient)
+};
+__global__ __launch_bounds__(256) void pred_losses_fwd_kernel(const float* __restrict__ x, int gs, PredJobs jobs, float* __restrict__ terms,
+                                                              int nterms) {
+  __shared__ float red[8];
+  __shared__ float acc_t[PRED_MAX_TERMS];
+  if (threadIdx.x < PRED_MAX_TERMS) acc_t[threadIdx.x] = 0.f;
+  __syncthreads();
+  for (int j = 0; j < jobs.n; ++j) {      // in job order: a fixed summation order
+    const TgPredJob J = jobs.j[j];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < gs; i += blockDim.x) acc += pred_loss_f(x[J.group * gs + i], J.mode, J.a, J.b);
+    const float tot = block_sum(acc, red);
+    if (threadIdx.x == 0) acc_t[J.term] += J.coef * tot / (float)gs;
+    __syncthreads();
+  }
+  if (threadIdx.x < nterms) terms[threadIdx.x] = acc_t[threadIdx.x];
+}
+__global__ void pred_losses_bwd_kernel(const float* __restrict__ x, int gs, int groups, PredJobs jobs, PredGrads gr,
+                                       float* __restrict__ gx) {
+  const int n = gs * groups;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int grp = i / gs;
+    const float xi = x[i];
+    float g = 0.f;
+    for (int j = 0; j < jobs.n; ++j) {
+      const TgPredJob J = jobs.j[j];
+      if (J.group == grp && gr.g[J.term]) g += gr.g[J.term][0] * (J.coef / (float)gs) * pred_loss_df(xi, J.mode, J.a, J.b);
+    }
+    gx[i] = g;
+  }
+}
+// out[0] = sum_i x_i[0] over up to 24 device fp32 scalars (tf.add_n over the loss collection), in argument order
+struct ScalarPtrs {
+  const float* p[24];
+  int n;
+};
+__global__ void sum_scalars_kernel(ScalarPtrs a, float* __restrict__ out) {
+  if (blockIdx.x || threadIdx.x) return;
+  float t = 0.f;
+  for (int i = 0; i < a.n; ++i) t += a.p[i][0];
+  out[0] = t;
+}
+
 // out[0] = E[x^2] - E[x]^2 from sum = s1[0] and the per-sample sums of squares ss[batch]  (DRAGAN,
 // image_generation.py:445: the VARIANCE over every element of the minibatch)
 // tf.losses.cosine_distance(l2n(expected), l2n(embedding), axis=-1, weights=w) (twingan.py:515-519):
@@ -817,6 +870,55 @@ int tg_pred_loss_bwd(const float* x, const float* gscale, float* gx, int n, int 
   hipLaunchKernelGGL(pred_loss_bwd_kernel, dim3(tg_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, gscale, gx, n,
                      mode, a, b, scale);
   TG_LAUNCH_CHECK("tg_pred_loss_bwd");
+  return TG_OK;
+}
+
+int tg_pred_losses_fwd(const float* pred, int group_size, int groups, const TgPredJob* jobs, int njobs, float* terms, int nterms,
+                       void* stream) {
+  TG_CHECK(pred && jobs && terms && group_size > 0 && groups > 0 && njobs > 0 && njobs <= PRED_MAX_JOBS && nterms > 0 &&
+               nterms <= PRED_MAX_TERMS, TG_EINVAL, "tg_pred_losses_fwd: bad arguments (at most %d jobs, %d terms)", PRED_MAX_JOBS,
+           PRED_MAX_TERMS);
+  PredJobs pj;
+  pj.n = njobs;
+  for (int j = 0; j < njobs; ++j) {
+    TG_CHECK(jobs[j].group >= 0 && jobs[j].group < groups && jobs[j].term >= 0 && jobs[j].term < nterms && jobs[j].mode >= 0 &&
+                 jobs[j].mode <= 3, TG_EINVAL, "tg_pred_losses_fwd: job %d out of range", j);
+    pj.j[j] = jobs[j];
+  }
+  hipLaunchKernelGGL(pred_losses_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, group_size, pj, terms, nterms);
+  TG_LAUNCH_CHECK("tg_pred_losses_fwd");
+  return TG_OK;
+}
+
+int tg_pred_losses_bwd(const float* pred, int group_size, int groups, const TgPredJob* jobs, int njobs, const float* const* gterms,
+                       int nterms, float* gpred, void* stream) {
+  TG_CHECK(pred && jobs && gterms && gpred && group_size > 0 && groups > 0 && njobs > 0 && njobs <= PRED_MAX_JOBS && nterms > 0 &&
+               nterms <= PRED_MAX_TERMS, TG_EINVAL, "tg_pred_losses_bwd: bad arguments");
+  PredJobs pj;
+  pj.n = njobs;
+  for (int j = 0; j < njobs; ++j) {
+    TG_CHECK(jobs[j].group >= 0 && jobs[j].group < groups && jobs[j].term >= 0 && jobs[j].term < nterms, TG_EINVAL,
+             "tg_pred_losses_bwd: job %d out of range", j);
+    pj.j[j] = jobs[j];
+  }
+  PredGrads pg;
+  for (int t = 0; t < PRED_MAX_TERMS; ++t) pg.g[t] = t < nterms ? gterms[t] : nullptr;
+  hipLaunchKernelGGL(pred_losses_bwd_kernel, dim3(tg_grid_for((int64_t)group_size * groups, 256, 64)), dim3(256), 0,
+                     (hipStream_t)stream, pred, group_size, groups, pj, pg, gpred);
+  TG_LAUNCH_CHECK("tg_pred_losses_bwd");
+  return TG_OK;
+}
+
+int tg_sum_scalars(const float* const* scalars, int n, float* out, void* stream) {
+  TG_CHECK(scalars && out && n > 0 && n <= 24, TG_EINVAL, "tg_sum_scalars: 1..24 scalars");
+  ScalarPtrs a;
+  a.n = n;
+  for (int i = 0; i < n; ++i) {
+    TG_CHECK(scalars[i], TG_EINVAL, "tg_sum_scalars: null scalar %d", i);
+    a.p[i] = scalars[i];
+  }
+  hipLaunchKernelGGL(sum_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, out);
+  TG_LAUNCH_CHECK("tg_sum_scalars");
   return TG_OK;
 }
 

@@ -2486,6 +2486,79 @@ class PredLossFn(torch.autograd.Function):
     return gx, None, None, None, None
 
 
+class _PredJob(ctypes.Structure):
+  _fields_ = [('group', ctypes.c_int32), ('term', ctypes.c_int32), ('mode', ctypes.c_int32), ('a', ctypes.c_float),
+              ('b', ctypes.c_float), ('coef', ctypes.c_float)]
+
+
+def _pred_jobs(jobs):
+  arr = (_PredJob * len(jobs))()
+  for k, (group, term, mode, a, b, coef) in enumerate(jobs):
+    arr[k] = _PredJob(group, term, mode, a, b, coef)
+  return arr
+
+
+class PredLossesFn(torch.autograd.Function):
+  """Every prediction loss of ONE batched discriminator call: pred fp32 [groups * group_size, 1] (e.g. [real; cycle; prime]);
+  ``jobs``: tuples (group, term, mode, a, b, coef) -- term += coef * mean_i f_mode(pred[group]_i; a, b), f as PredLossFn's --
+  -> ``nterms`` fp32 [1] tensors.  One launch forward (all means, all terms) and one backward (the gradient of the whole
+  prediction) instead of a sum / fill launch per term and group plus the framework's sub / neg / add / cat glue
+  (image_generation.py:331-400).  First order."""
+
+  @staticmethod
+  def forward(ctx, pred, group_size, jobs, nterms):
+    _chk(pred)
+    assert pred.dtype == torch.float32 and pred.numel() % group_size == 0
+    groups = pred.numel() // group_size
+    out = torch.empty(nterms, dtype=torch.float32, device=pred.device)
+    arr = _pred_jobs(jobs)      # kept alive across the call
+    call('tg_pred_losses_fwd', _p(pred), group_size, groups, ctypes.addressof(arr), len(jobs), _p(out), nterms, _stream())
+    ctx.meta = (group_size, groups, jobs, nterms)
+    ctx.save_for_backward(pred)
+    return tuple(out[t:t + 1] for t in range(nterms))
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, *gterms):
+    pred, = ctx.saved_tensors
+    group_size, groups, jobs, nterms = ctx.meta
+    keep = [g.contiguous() if g is not None else None for g in gterms]
+    ptrs = (ctypes.c_void_p * nterms)(*[(_p(g) if g is not None else None) for g in keep])
+    gpred = torch.empty_like(pred)
+    arr = _pred_jobs(jobs)
+    call('tg_pred_losses_bwd', _p(pred), group_size, groups, ctypes.addressof(arr), len(jobs), ctypes.addressof(ptrs), nterms,
+         _p(gpred), _stream())
+    return gpred, None, None, None
+
+
+def pred_losses(pred, group_size, jobs, nterms):
+  return PredLossesFn.apply(pred.contiguous(), int(group_size), tuple(jobs), int(nterms))
+
+
+class SumScalarsFn(torch.autograd.Function):
+  """tf.add_n over fp32 [1] loss terms (model/model_inheritor.py): one launch; every term's gradient IS the incoming one."""
+
+  @staticmethod
+  def forward(ctx, *terms):
+    _chk(*terms)
+    assert all(t.dtype == torch.float32 and t.numel() == 1 for t in terms) and len(terms) <= 24
+    out = torch.empty(1, dtype=torch.float32, device=terms[0].device)
+    keep = [t.contiguous() for t in terms]
+    ptrs = (ctypes.c_void_p * len(keep))(*[_p(t) for t in keep])
+    call('tg_sum_scalars', ctypes.addressof(ptrs), len(keep), _p(out), _stream())
+    ctx.n = len(terms)
+    return out
+
+  @staticmethod
+  def backward(ctx, g):
+    return (g,) * ctx.n
+
+
+def sum_scalars(terms):
+  terms = list(terms)
+  return terms[0] if len(terms) == 1 else SumScalarsFn.apply(*terms)
+
+
 class CosineDistanceFn(torch.autograd.Function):
   """weight * mean_b(1 - l2n(expected_b) . l2n(embedding_b)) -> fp32 [1] (twingan.py:507-521: the encoder-distillation
   loss; `expected` is the dataset's embedding, no gradient).  First order."""

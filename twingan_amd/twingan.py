@@ -93,6 +93,13 @@ def _fool_loss(pred, cfg):
   return ops.sigmoid_xent_mean(pred, 1.0, cfg.gan_weight)
 
 
+def _fool_jobs(group, term, cfg):
+  """_fool_loss as a job of ops.pred_losses (group, term, mode, a, b, coef)."""
+  if cfg.loss_architecture in ('wgan_gp', 'wgan', 'hinge'):
+    return [(group, term, 0, 0.0, 0.0, -cfg.gan_weight)]
+  return [(group, term, 2, 1.0, 0.0, cfg.gan_weight)]
+
+
 def _real_fake_losses(terms, name, pf, pr, cfg, mean_real=None):
   """image_generation.py:348-357 (wgan), :370-379 (hinge), :380-394 (gan / dragan)."""
   la = cfg.loss_architecture
@@ -107,10 +114,30 @@ def _real_fake_losses(terms, name, pf, pr, cfg, mean_real=None):
     terms['discriminator_real_loss' + name] = ops.sigmoid_xent_mean(pr, 1.0, cfg.gan_weight)
 
 
+def _real_fake_jobs(names, jobs, name, gf, gr, cfg):
+  """_real_fake_losses as jobs of ops.pred_losses over the groups gf (fake) / gr (real) of one batched prediction; appends
+  the term names to ``names`` (term index = position)."""
+  la, w = cfg.loss_architecture, cfg.gan_weight
+  if la in ('wgan_gp', 'wgan'):
+    t = len(names)
+    names.append('discriminator_loss' + name)
+    jobs += [(gf, t, 0, 0.0, 0.0, w), (gr, t, 0, 0.0, 0.0, -w)]
+  elif la == 'hinge':
+    t = len(names)
+    names.append('discriminator_loss' + name)
+    jobs += [(gf, t, 1, 1.0, 1.0, w), (gr, t, 1, 1.0, -1.0, w)]
+  else:
+    t = len(names)
+    names += ['discriminator_fake_loss' + name, 'discriminator_real_loss' + name]
+    jobs += [(gf, t, 2, 0.0, 0.0, w), (gr, t + 1, 2, 1.0, 0.0, w)]
+
+
 def _sum_terms(terms):
-  """tf.add_n over the loss collection (model/model_inheritor.py): one stack + sum instead of a chain of adds (each
-  add is a launch forward and another one backward)."""
+  """tf.add_n over the loss collection (model/model_inheritor.py): ONE launch over the scalar terms (ops.sum_scalars;
+  backward: every term receives the incoming gradient itself)."""
   vals = list(terms.values())
+  if vals[0].is_cuda:
+    return ops.sum_scalars(v.reshape(1) for v in vals)
   return torch.stack([v.reshape(1) for v in vals]).sum(dim=0) if len(vals) > 1 else vals[0]
 
 
@@ -212,13 +239,15 @@ def generator_loss(P, sources, targets, cfg, style_noise=None, distill_embed_s=N
     top = 'discriminator_' + d
     with streams.domain(i):
       terms['l_cyc_' + d] = ops.abs_diff_mean(orig, cyc, cfg.l_cyc_weight)
-      if cyc_gan:
+      if cyc_gan:      # both fool losses of the domain from the one batched prediction: one launch each way
         pred, _ = pggan.discriminator(P, both, cfg, top, groups=2, block_end_points=False)
-        pc, pp = pred.chunk(2) if cyc_first else reversed(pred.chunk(2))
-        terms['generator_fool_loss_cycle_' + d] = _fool_loss(pc, cfg)
+        gc, gp = (0, 1) if cyc_first else (1, 0)
+        tc, tp = ops.pred_losses(pred, pred.shape[0] // 2, _fool_jobs(gc, 0, cfg) + _fool_jobs(gp, 1, cfg), 2)
+        terms['generator_fool_loss_cycle_' + d] = tc
+        terms['generator_fool_loss_prime_' + d] = tp
       else:
         pp, _ = pggan.discriminator(P, prime, cfg, top, block_end_points=False)
-      terms['generator_fool_loss_prime_' + d] = _fool_loss(pp, cfg)
+        terms['generator_fool_loss_prime_' + d] = _fool_loss(pp, cfg)
   # re-encode s' in domain s and t' in domain t as one batch (twingan.py:275-288): rows [s'; t'] of the generator's batch
   primes = o['primes']
   e2, _ = pggan.encoder_before_classification(P, primes, ('s', 't', b, 2), cfg)
@@ -284,19 +313,21 @@ def _d_domain_terms(P, cfg, terms, d, top, real, prime, cyc, a, cyc_gan, both=No
       if both is None:
         both, cyc_first = torch.cat([cyc, prime], dim=0), True
       pred, _ = pggan.discriminator(P, torch.cat([real, both], dim=0), cfg, top, groups=3, cut_seg=1, block_end_points=False)
-      pr, pc, pp = (t.contiguous() for t in pred.chunk(3))
-      if not cyc_first:
-        pc, pp = pp, pc
+      gc, gp = (1, 2) if cyc_first else (2, 1)      # groups of the batched prediction: 0 = real
+      names, jobs = [], []
+      _real_fake_jobs(names, jobs, '_cycle_' + d, gc, 0, cfg)      # only_real_fake_loss=True (twingan.py:466-474)
+      _real_fake_jobs(names, jobs, '_prime_' + d, gp, 0, cfg)
     else:
       pred, _ = pggan.discriminator(P, torch.cat([real, prime], dim=0), cfg, top, groups=2, cut_seg=1, block_end_points=False)
-      pr, pp = (t.contiguous() for t in pred.chunk(2))
-    wgan = cfg.loss_architecture in ('wgan_gp', 'wgan')
-    mean_real = ops.mean(pr, cfg.gan_weight) if wgan else None
-    if cyc_gan:                                             # only_real_fake_loss=True (twingan.py:466-474)
-      _real_fake_losses(terms, '_cycle_' + d, pc, pr, cfg, mean_real)
-    _real_fake_losses(terms, '_prime_' + d, pp, pr, cfg, mean_real)
-    if cfg.wgan_drift_loss_weight and wgan:                 # image_generation.py:360-367
-      terms['discriminator_drift_loss_prime_' + d] = ops.square_mean(pr, cfg.wgan_drift_loss_weight)
+      names, jobs = [], []
+      _real_fake_jobs(names, jobs, '_prime_' + d, 1, 0, cfg)
+    if cfg.wgan_drift_loss_weight and cfg.loss_architecture in ('wgan_gp', 'wgan'):      # image_generation.py:360-367
+      jobs.append((0, len(names), 3, 0.0, 0.0, cfg.wgan_drift_loss_weight))
+      names.append('discriminator_drift_loss_prime_' + d)
+    # every prediction loss of the domain from the one batched prediction: one launch each way (ops.PredLossesFn)
+    groups = 3 if cyc_gan else 2
+    for k, v in zip(names, ops.pred_losses(pred, pred.shape[0] // groups, jobs, len(names))):
+      terms[k] = v
 
 
 def _d_domain_gp(P, cfg, terms, d, top, real, prime, a, noise=None, name=None):
@@ -451,7 +482,8 @@ class Trainer:
       out = (loss.detach(), {k: v.detach() for k, v in terms.items()})
       if group == 'g' and self.cfg.use_gdrop:
         self._update_gdrop(out[0])
-      scaled = loss * loss_scale_for_clones(self.cfg.loss_scale, self.world)       # model_deploy.py:265-268,308-313
+      k = loss_scale_for_clones(self.cfg.loss_scale, self.world)       # model_deploy.py:265-268,308-313
+      scaled = loss if k == 1.0 else loss * k
       ops.GradSink.pair = True
       # the slab reductions of the filter gradients that feed gradient sinks: queued, one launch per backward segment
       ops.defer_slab_reductions(os.environ.get('TG_WGRAD_DEFER', '1') != '0')
