@@ -376,6 +376,13 @@ int tg_mbstd_bwd(const void* gout, const void* x, void* gx, int n, int groups, i
 int tg_mbstd_bwd_bwd(const void* v, const void* gout, const void* x, void* ggout, void* gx2, int n, int groups, int hw,
                      int c, int cpad, float eps, int dtype, void* stream);
 
+/* layers.fully_connected (nets/pggan_utils.py:323-327) on a network tail's [B, K] features in ONE launch each way.
+ * fwd: y[m,n] fp32 = x[m,k] (`dtype`) @ w[k,n] fp32 + bias[n] (NULL: none).  bwd (first order): gx[m,k] (`dtype`) = g @ w^T,
+ * gw[k,n] (+)= x^T @ g, gb[n] (+)= column sums of g; any of gx / gw / gb may be NULL; acc_w / acc_b: add into the
+ * caller's buffers (gradient sinks) instead of writing.  n <= k. */
+int tg_fc_fwd(const void* x, const float* w, const float* bias, float* y, int m, int n, int k, int dtype, void* stream);
+int tg_fc_bwd(const void* x, const float* w, const float* g, void* gx, float* gw, float* gb, int m, int n, int k, int acc_w,
+              int acc_b, int dtype, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * Small dense layers (layers.fully_connected, nets/pggan_utils.py:323-327; pggan.py:365-370):
  * C[m,n] = op(A)[m,k] @ op(B)[k,n] (+ bias[n]); A,B,C fp32 row-major; ta/tb transpose flags.

@@ -483,10 +483,14 @@ def test_mbstd_fwd_bwd_bwdbwd(ops, dtype, n, c):
 
 # ---------------------------------------------------------------------------------------------- dense, losses
 def test_fully_connected_and_grads(ops):
+  """layers.fully_connected: (a) inside ops.second_order() -- the gradient-penalty pass -- the twice-differentiable
+  composition (cast, GEMM, bias add); (b) in first-order passes ONE launch each way (tg_fc_fwd / tg_fc_bwd: FcFn), with
+  the parameter gradients written or, under gradient sinks, added in place; fp32 and 16-bit features."""
   rng = np.random.RandomState(12)
   x, w, b = rng.randn(6, 40), rng.randn(40, 3), rng.randn(3)
   xd, wd, bd = to_dev(x).requires_grad_(True), to_dev(w).requires_grad_(True), to_dev(b).requires_grad_(True)
-  y = ops.fully_connected(xd, wd, bd)
+  with ops.second_order():
+    y = ops.fully_connected(xd, wd, bd)
   assert rel_l2(host(y), N.fully_connected(x, w, b)) < F32_TOL
   g = rng.randn(6, 3)
   gx, = torch.autograd.grad(y, xd, grad_outputs=to_dev(g), create_graph=True)
@@ -494,6 +498,28 @@ def test_fully_connected_and_grads(ops):
   v = rng.randn(6, 40)
   (gx * to_dev(v)).sum().backward()            # d/dw of <v, g w^T> = v^T g
   assert rel_l2(host(wd.grad), v.T @ g) < F32_TOL
+  # (b) first order
+  for dtype in (torch.float32, torch.bfloat16):
+    xr = bf16_round(x) if dtype == torch.bfloat16 else x
+    xd = to_dev(xr, dtype).requires_grad_(True)
+    wd, bd = to_dev(w).requires_grad_(True), to_dev(b).requires_grad_(True)
+    y = ops.fully_connected(xd, wd, bd)
+    assert type(y.grad_fn).__name__ == 'FcFnBackward' and y.dtype == torch.float32
+    assert rel_l2(host(y), N.fully_connected(xr, w, b)) < F32_TOL
+    y.backward(to_dev(g))
+    assert rel_l2(host(xd.grad), g @ w.T) < tol_for(dtype, True)
+    assert rel_l2(host(wd.grad), xr.T @ g) < F32_TOL and rel_l2(host(bd.grad), g.sum(0)) < F32_TOL
+    # gradient sinks: added into the caller's buffers, twice
+    ops.GradSink.clear()
+    ws, bs = torch.ones_like(wd), torch.ones_like(bd)
+    ops.GradSink.register(wd, ws)
+    ops.GradSink.register(bd, bs)
+    wd.grad = bd.grad = None
+    for _ in range(2):
+      ops.fully_connected(xd, wd, bd).backward(to_dev(g))
+    ops.GradSink.clear()
+    assert wd.grad is None and bd.grad is None
+    assert rel_l2(host(ws), 1.0 + 2.0 * (xr.T @ g)) < F32_TOL and rel_l2(host(bs), 1.0 + 2.0 * g.sum(0)) < F32_TOL
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])

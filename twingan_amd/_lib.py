@@ -125,6 +125,8 @@ SIGNATURES = {
     'tg_sum': (c_int, [_P, _FP, c_int64, c_float, c_int, c_int, _P]),
     'tg_abs_diff_sum': (c_int, [_P, _P, _FP, c_int64, c_float, c_int, c_int, _P]),
     'tg_abs_diff_bwd': (c_int, [_P, _P, _FP, _P, _P, c_int64, c_float, c_int, _P]),
+    'tg_fc_fwd': (c_int, [_P, _FP, _FP, _FP, c_int, c_int, c_int, c_int, _P]),
+    'tg_fc_bwd': (c_int, [_P, _FP, _FP, _P, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'tg_pred_losses_fwd': (c_int, [_FP, c_int, c_int, _P, c_int, _FP, c_int, _P]),
     'tg_pred_losses_bwd': (c_int, [_FP, c_int, c_int, _P, c_int, _P, c_int, _FP, _P]),
     'tg_sum_scalars': (c_int, [_P, c_int, _FP, _P]),

@@ -655,6 +655,50 @@ __global__ void var_from_sums_kernel(const float* __restrict__ s1, const float* 
   }
 }
 
+// ---- the fully connected layer of a network's tail (layers.fully_connected, nets/pggan_utils.py:323-327) as ONE launch each
+// way: y[B,N] = x[B,K] @ w[K,N] + b[N] with x in the activations' storage type (the cast, the GEMM and the bias add were
+// three launches), and gx = g @ w^T (in x's type), gw (+)= x^T @ g, gb (+)= sum_b g (four launches).  B <= 64-ish rows,
+// K = 256, N = 1 (the discriminators' prediction) .. 16: one WAVE per output element forward (lanes split K), one THREAD
+// per k backward (it owns row k of gw and column k of gx).
+template <typename T>
+__global__ void fc_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                              float* __restrict__ y, int m, int n, int k) {
+  const int64_t total = (int64_t)m * n;
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i = w0; i < total; i += nw) {
+    const int col = (int)(i % n), row = (int)(i / n);
+    float acc = 0.f;
+    for (int kk = lane; kk < k; kk += 64) acc = fmaf(ld(x + (int64_t)row * k + kk), w[(int64_t)kk * n + col], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) y[i] = acc + (b ? b[col] : 0.f);
+  }
+}
+template <typename T>
+__global__ void fc_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ g,
+                              T* __restrict__ gx, float* __restrict__ gw, float* __restrict__ gb, int m, int n, int k,
+                              int acc_w, int acc_b) {
+  const int kk = blockIdx.x * blockDim.x + threadIdx.x;
+  if (kk < k) {
+    for (int row = 0; gx && row < m; ++row) {      // gx[row, kk] = sum_col g[row, col] * w[kk, col]
+      float a = 0.f;
+      for (int col = 0; col < n; ++col) a = fmaf(g[(int64_t)row * n + col], w[(int64_t)kk * n + col], a);
+      st(gx + (int64_t)row * k + kk, a);
+    }
+    for (int col = 0; gw && col < n; ++col) {      // gw[kk, col] (+)= sum_row x[row, kk] * g[row, col], rows in order
+      float a = 0.f;
+      for (int row = 0; row < m; ++row) a = fmaf(ld(x + (int64_t)row * k + kk), g[(int64_t)row * n + col], a);
+      gw[(int64_t)kk * n + col] = (acc_w ? gw[(int64_t)kk * n + col] : 0.f) + a;
+    }
+  }
+  if (gb && kk < n) {                              // gb[col] (+)= sum_row g[row, col]
+    float a = 0.f;
+    for (int row = 0; row < m; ++row) a += g[(int64_t)row * n + kk];
+    gb[kk] = (acc_b ? gb[kk] : 0.f) + a;
+  }
+}
+
 // C[m,n] (+)= op(A)[m,k] @ op(B)[k,n] + bias[n]; one thread per output element
 __global__ void small_gemm_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias,
                                   float* __restrict__ c, int m, int n, int k, int ta, int tb, int accumulate) {
@@ -959,6 +1003,27 @@ int tg_small_gemm(const float* a, const float* b, const float* bias, float* c, i
     hipLaunchKernelGGL(small_gemm_kernel, dim3(tg_grid_for((int64_t)m * n, 256)), dim3(256), 0, (hipStream_t)stream, a, b,
                        bias, c, m, n, k, ta, tb, accumulate);
   TG_LAUNCH_CHECK("tg_small_gemm");
+  return TG_OK;
+}
+
+int tg_fc_fwd(const void* x, const float* w, const float* bias, float* y, int m, int n, int k, int dtype, void* stream) {
+  TG_CHECK(x && w && y && m > 0 && n > 0 && k > 0, TG_EINVAL, "tg_fc_fwd: bad arguments");
+  TG_DISPATCH_DTYPE(dtype, "tg_fc_fwd", {
+    hipLaunchKernelGGL(fc_fwd_kernel<T>, dim3(tg_grid_for((int64_t)m * n * 64, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)x, w, bias, y, m, n, k);
+  });
+  TG_LAUNCH_CHECK("tg_fc_fwd");
+  return TG_OK;
+}
+
+int tg_fc_bwd(const void* x, const float* w, const float* g, void* gx, float* gw, float* gb, int m, int n, int k, int acc_w,
+              int acc_b, int dtype, void* stream) {
+  TG_CHECK(x && w && g && (gx || gw || gb) && m > 0 && n > 0 && k > 0 && n <= k, TG_EINVAL, "tg_fc_bwd: bad arguments");
+  TG_DISPATCH_DTYPE(dtype, "tg_fc_bwd", {
+    hipLaunchKernelGGL(fc_bwd_kernel<T>, dim3(tg_grid_for(k, 64)), dim3(64), 0, (hipStream_t)stream, (const T*)x, w, g, (T*)gx,
+                       gw, gb, m, n, k, acc_w, acc_b);
+  });
+  TG_LAUNCH_CHECK("tg_fc_bwd");
   return TG_OK;
 }
 

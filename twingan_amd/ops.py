@@ -1758,11 +1758,8 @@ class RowViewsFn(torch.autograd.Function):
       else:
         acc = src[0]
         for k, g in enumerate(src[1:]):
-          if dst.is_cuda:
-            call('tg_axpby', _p(acc), _p(g), _p(dst), dst.numel(), 1.0, 1.0, _dt(dst), _stream(),
-                 work=('axpby:numel%d' % dst.numel(), 0, _nb(acc, g, dst)))
-          else:
-            torch.add(acc, g, out=dst)
+          call('tg_axpby', _p(acc), _p(g), _p(dst), dst.numel(), 1.0, 1.0, _dt(dst), _stream(),
+               work=('axpby:numel%d' % dst.numel(), 0, _nb(acc, g, dst)))
           acc = dst
     return gx, None
 
@@ -2371,8 +2368,45 @@ class AddRowBiasFn(torch.autograd.Function):
     return g, (ChannelSumFn.apply(g) if ctx.needs_input_grad[1] else None)
 
 
+class FcFn(torch.autograd.Function):
+  """x [B,K] (the activations' type) @ w [K,N] + b -> fp32 [B,N] as ONE launch (tg_fc_fwd; the composition below is a cast,
+  a GEMM and a bias add) and, backward, ONE launch for gx / gw / gb (tg_fc_bwd; four there), the parameter gradients
+  straight into their sinks.  First-order passes only: the gradient penalty differentiates the composition."""
+
+  @staticmethod
+  def forward(ctx, x, w, b):
+    _chk(x, w, b)
+    m, k = x.shape
+    n = w.shape[1]
+    y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    call('tg_fc_fwd', _p(x), _p(w), _p(b), _p(y), m, n, k, _dt(x), _stream())
+    ctx.save_for_backward(x, w, b)
+    return y
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, g):
+    x, w, b = ctx.saved_tensors
+    m, k = x.shape
+    n = w.shape[1]
+    g = g.contiguous()
+    params = not _State.skip_param_grads
+    gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+    sw = GradSink.get(w) if (ctx.needs_input_grad[1] and params) else None
+    gw = sw if sw is not None else (torch.empty_like(w) if (ctx.needs_input_grad[1] and params) else None)
+    sb = GradSink.get(b) if (b is not None and ctx.needs_input_grad[2] and params) else None
+    gb = sb if sb is not None else (torch.empty_like(b) if (b is not None and ctx.needs_input_grad[2] and params) else None)
+    if gx is not None or gw is not None or gb is not None:
+      call('tg_fc_bwd', _p(x), _p(w), _p(g), _p(gx), _p(gw), _p(gb), m, n, k, 1 if sw is not None else 0,
+           1 if sb is not None else 0, _dt(x), _stream())
+    return gx, (None if sw is not None else gw), (None if sb is not None else gb)
+
+
 def fully_connected(x, w, b):
   """x [B,K] (any dtype) @ w [K,N] + b -> fp32 [B,N]."""
+  if (not in_second_order() and not deterministic() and x.dim() == 2 and x.is_contiguous()
+      and w.dtype == torch.float32 and w.is_contiguous() and w.shape[1] <= w.shape[0]):
+    return FcFn.apply(x, w, b)
   y = GemmFn.apply(cast(x, torch.float32), w, False, False)
   return AddRowBiasFn.apply(y, b) if b is not None else y
 

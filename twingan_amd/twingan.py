@@ -135,10 +135,7 @@ def _real_fake_jobs(names, jobs, name, gf, gr, cfg):
 def _sum_terms(terms):
   """tf.add_n over the loss collection (model/model_inheritor.py): ONE launch over the scalar terms (ops.sum_scalars;
   backward: every term receives the incoming gradient itself)."""
-  vals = list(terms.values())
-  if vals[0].is_cuda:
-    return ops.sum_scalars(v.reshape(1) for v in vals)
-  return torch.stack([v.reshape(1) for v in vals]).sum(dim=0) if len(vals) > 1 else vals[0]
+  return ops.sum_scalars(v.reshape(1) for v in terms.values())
 
 
 def act_dtype(cfg):
