@@ -258,19 +258,17 @@ int launch_img(const ImgGeom& g, const void* x, const void* wp, const float* bia
 // 26.6 / 18.0, n 64 42.5 / 34.2 (dgrad 46.8 / 30.2); bench step 857.7 -> 870.5 images/s (+1.5 %).  The 4x4 maps (kernel
 // instantiated: four images per workgroup) measured SLOWER, 9.7-10.0 / 10.6-10.9 us at every n -- 16 pixels per image
 // leave the staging nothing to amortise -- and stay on conv_small, like the 264-channel minibatch-stddev layer.
-// TG_TUNE_CONV_IMG=0 switches the kernel off, =2 also takes the 4x4 maps (A/B).
 bool tg_conv_img_supported(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l) {
   if (k != 3 || pad_t != 1 || pad_l != 1 || hin != hout || win != wout || hin != win) return false;
-  const int mode = tg_tune("TG_TUNE_CONV_IMG", 1);
-  if (mode == 0 || (hin != 8 && !(hin == 4 && mode == 2))) return false;
+  if (hin != 8) return false;      // the 4x4 maps measured slower than conv_small (see above)
   if (cin % 32 != 0 || cout % 32 != 0 || cin > 1024 || n < 1 || (cin & (cin - 1)) != 0) return false;      // cin / 8 a power of two
   if (hin == 8 && (size_t)100 * (cin * 2 + 16) > 160 * 1024) return false;
   return true;
 }
 
-// the statistics epilogue exists for the 8x8 maps (one image per workgroup), plain epilogue; TG_TUNE_IMG_STATS=0: A/B
+// the statistics epilogue exists for the 8x8 maps (one image per workgroup), plain epilogue
 bool tg_conv_img_stats_supported(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l) {
-  return hin == 8 && tg_tune("TG_TUNE_IMG_STATS", 1) != 0 &&
+  return hin == 8 &&
          tg_conv_img_supported(n, hin, win, cin, hout, wout, cout, k, pad_t, pad_l);
 }
 

@@ -226,10 +226,10 @@ bool tg_conv_small_supported(int n, int hout, int wout, int kh, int kw) {
 }
 
 // the statistics epilogue exists for 3x3 SAME convs over 4x4 maps (an image = 16 lanes of a column block), whole 32-channel
-// output blocks, plain epilogue; TG_TUNE_SMALL_STATS=0: A/B
+// output blocks, plain epilogue
 bool tg_conv_small_stats_supported(int n, int hin, int win, int hout, int wout, int cout, int k, int pad_t, int pad_l) {
   return k == 3 && pad_t == 1 && pad_l == 1 && hin == 4 && win == 4 && hout == 4 && wout == 4 && cout % 32 == 0 &&
-         tg_conv_small_supported(n, hout, wout, k, k) && tg_tune("TG_TUNE_SMALL_STATS", 1) != 0;
+         tg_conv_small_supported(n, hout, wout, k, k);
 }
 
 int tg_conv_small_run(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l,

@@ -1732,7 +1732,7 @@ int dispatch_tile_upbwd(const TileGeom& g, const bf16* gy, const bf16* wp, hipSt
   const bool mt2 = (g.h % 16 == 0) && tiles1 >= 2 * 2 * 256 && g.cin_pad >= 64;
   if (tiles1 >= 2048) {
     // a 32 + 32 concat: both halves in one 64-channel block, every gy tile staged once (launch_tile_wres picks MODE 4)
-    const bool both = g.c0 == 32 && c1 == 32 && g.n1 > 0 && tg_tune("TG_TUNE_UPBOTH", 1) != 0;
+    const bool both = g.c0 == 32 && c1 == 32 && g.n1 > 0;
     if (g.cin_pad == 16 && both) return launch_tile_wres<3, 16, 64, 1>(g, gy, wp, nullptr, nullptr, s);
     if (g.cin_pad == 16) return wide ? launch_tile_wres<3, 16, 64, 1>(g, gy, wp, nullptr, nullptr, s) : launch_tile_wres<3, 16, 32, 1>(g, gy, wp, nullptr, nullptr, s);
     if (g.cin_pad == 32) return wide ? launch_tile_wres<3, 32, 64, 1>(g, gy, wp, nullptr, nullptr, s) : launch_tile_wres<3, 32, 32, 1>(g, gy, wp, nullptr, nullptr, s);
@@ -1755,12 +1755,10 @@ int dispatch_tile(const TileGeom& g, const bf16* x, const bf16* wp, const float*
   // when that still leaves >= 2 workgroups per CU and the map is tall enough
   const bool mt2 = (g.h % 16 == 0) && tiles1 >= 2 * 2 * 256 && g.cin_pad >= 64;
   // thin layers with many tiles: weights resident in LDS, several tiles per workgroup
-  static const bool stats_wide_tile = getenv("TG_STATS_WIDE_TILE") != nullptr;      // A/B switch
-  const bool skip_wres = stats_wide_tile && wide && (g.stats || g.chunks_query);
   if constexpr (KH == 3) {
     if (tiles1 >= 2048 && thin16_takes(g)) return g.cin_pad == 16 ? launch_thin16<16>(g, x, wp, bias, y, s) : launch_thin16<32>(g, x, wp, bias, y, s);
   }
-  if (tiles1 >= 2048 && !skip_wres && !(g.up_src && g.cin_pad != 32)) {
+  if (tiles1 >= 2048 && !(g.up_src && g.cin_pad != 32)) {
     if (g.cin_pad == 16) return wide ? launch_tile_wres<KH, 16, 64, 1>(g, x, wp, bias, y, s) : launch_tile_wres<KH, 16, 32, 1>(g, x, wp, bias, y, s);
     if (g.cin_pad == 32) return wide ? launch_tile_wres<KH, 32, 64, 1>(g, x, wp, bias, y, s) : launch_tile_wres<KH, 32, 32, 1>(g, x, wp, bias, y, s);
   }

@@ -1025,11 +1025,8 @@ bool wg_thin(int h, int w, int cin, int cout);
 // 32^2 128>128 33.3 / 31.9, 16^2 256>256 37.3 / 34.2, with the bias gradient 37.5 / 32.8 ... 35.0 / 29.9; widening ones are
 // even (128^2 32>64 55 / 53, 64^2 64>128 52.0 / 52.2, 32^2 128>256 50.4 / 51.3).  The generator's narrowing layers LOSE:
 // 32^2 512>128 89 / 111 (4 slices: no co-scheduling), 64^2 256>64 90 / 95, 128^2 128>32 101 / 112, 16^2 512>256 53.8 / 55.1.
-// TG_TUNE_WG_NW=4 / 8 forces one (A/B).
 int wg_waves(int h, int w, int cin, int cout) {
   if (w == 8 || h % 16 != 0 || w % 16 != 0 || wg_thin(h, w, cin, cout)) return 4;
-  const int force = tg_tune("TG_TUNE_WG_NW", 0);
-  if (force == 4 || force == 8) return force;
   if (cin > cout) return 4;
   const int pairs = ((cin + 31) / 32) * ((cout + 31) / 32);
   const int slices8 = pairs <= 256 ? 256 / pairs : 1;
@@ -1043,12 +1040,9 @@ int wg_waves(int h, int w, int cin, int cout) {
 // workgroup's (147 KB), so the layers with few blocks and short loops lose: 64^2 64>64 33.0 / 36.0, 32^2 128>128 32.1 / 34.6,
 // 16^2 256>256 34.1 / 39.3 (n = 16: 21.4 / 32.2), and with the fused bias gradient (254 VGPRs) 29.2 / 38.2.  Taken where it
 // measured faster: narrowing layers (the generator's concat convs), and widening ones with >= 8 blocks and >= 16 tiles per
-// workgroup; never with the bias gradient.  TG_TUNE_WG_QUAD=0 / 1 forces it off / on where eligible (A/B).
+// workgroup; never with the bias gradient.
 bool wg_quad(int h, int w, int cin, int cout, int c0, int total_tiles8, bool bias) {
   if (w % 16 != 0 || h % 8 != 0 || cin % 64 != 0 || cout % 64 != 0 || c0 % 64 != 0) return false;
-  const int force = tg_tune("TG_TUNE_WG_QUAD", -1);
-  if (force == 0) return false;
-  if (force == 1) return true;
   if (bias) return false;
   if (cin > cout) return true;
   const int pairs = (cin / 64) * (cout / 64);
@@ -1372,8 +1366,8 @@ extern "C" int tg_wgrad_defer_flush(void* stream) {
   const int n = g_defer.n;
   if (n > 0) {
     // heads (the first job of every sink, in queueing order) in front, the other jobs of their chains behind them; grid laid
-    // out over the heads for the vector width of this flush (TG_TUNE_SLAB_VEC = 1: one element per thread)
-    const int vec = tg_tune("TG_TUNE_SLAB_VEC", 4) == 1 ? 1 : 4;
+    // out over the heads for the vector width of this flush
+    constexpr int vec = 4;
     SlabJobTable tab;
     int order[MAXJ], head_of[MAXJ], nheads = 0;
     for (int a = 0; a < n; ++a) {

@@ -631,7 +631,7 @@ int launch_pw_wgrad(const T* x, const T* gy, float* gw, int64_t npix, int cin, i
   if constexpr (sizeof(T) == 2) {
     const int cv8 = cb / 8;
     if (!exact_grid<T>() && ns == 3 && cb % 8 == 0 && cv8 <= 64 && (cv8 & (cv8 - 1)) == 0 && npix % 4 == 0 &&
-        (gbias == nullptr || small_in) && tg_tune("TG_TUNE_PW_RGB4", 1)) {
+        (gbias == nullptr || small_in)) {
       const int64_t nquad = npix / 4;
       const int blocks4 = tg_grid_for(nquad, 1024, 256);
       const size_t lds4 = (size_t)(3 + (gbias ? 1 : 0)) * cb * sizeof(float) * (1 + 1024 / 64);

@@ -205,9 +205,8 @@ template <typename T> constexpr bool exact_path() { return sizeof(T) == 4; }
 int tg_deterministic_mode();
 template <typename T> inline bool exact_grid() { return sizeof(T) == 4 || tg_deterministic_mode() != 0; }
 
-// launch-heuristic experiments: TG_TUNE_<NAME>=<int> in the environment overrides `dflt` (read at every call, so
-// two hipGraph captures in one process can bake different settings).  For tools/ab_env.py; no call site is left in
-// the tree when an experiment is over
+// The one kernel A/B left in the tree: TG_THIN16=0 sends the <= 16-output-channel 3x3 layers back to the 32-wide-block
+// kernels (tests/test_gpu_ops.py compares the two families through it).  Read at every call.
 static inline int tg_tune(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;

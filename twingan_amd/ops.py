@@ -60,23 +60,23 @@ def _chk(*ts):
 # ------------------------------------------------------------------------------------------------
 # weight-pack cache for the MFMA kernels
 # ------------------------------------------------------------------------------------------------
-# statistics of a normalised conv's output from the conv's own epilogue (TG_CONV_STATS=0: separate statistics pass, for A/Bs)
-USE_CONV_STATS = os.environ.get('TG_CONV_STATS', '1') != '0'
-# avg_pool2 of a discriminator block's last conv written by that conv (TG_CONV_POOL=0: separate pool launch)
-USE_CONV_POOL = os.environ.get('TG_CONV_POOL', '1') != '0'
+# statistics of a normalised conv's output from the conv's own epilogue (USE_CONV_STATS = False (tests): separate statistics pass, for A/Bs)
+USE_CONV_STATS = True
+# avg_pool2 of a discriminator block's last conv written by that conv (USE_CONV_POOL = False (tests): separate pool launch)
+USE_CONV_POOL = True
 # ... and, where the pool is the only consumer of the full-resolution output, only the SIGN bits of that output are
-# kept for the LeakyReLU backward (tg_conv2d_fwd_pool_signs / tg_lrelu_pool_bwd_signs; TG_POOL_SIGNS=0: the tensor itself)
-USE_POOL_SIGNS = os.environ.get('TG_POOL_SIGNS', '1') != '0'
-# self-attention's score / softmax / value products as the flash kernels in first-order passes (TG_FLASH_ATTENTION=0: the
+# kept for the LeakyReLU backward (tg_conv2d_fwd_pool_signs / tg_lrelu_pool_bwd_signs; USE_POOL_SIGNS = False (tests): the tensor itself)
+USE_POOL_SIGNS = True
+# self-attention's score / softmax / value products as the flash kernels in first-order passes (USE_FLASH_ATTENTION = False (tests): the
 # batched-GEMM + row-softmax composition everywhere)
-USE_FLASH_ATTENTION = os.environ.get('TG_FLASH_ATTENTION', '1') != '0'
+USE_FLASH_ATTENTION = True
 # the gradient-penalty pass through an attention layer on the flash kernels too (forward, differentiable first-order
-# backward, second-order backward); TG_FLASH_BWD_BWD=0: that pass keeps the batched-GEMM / softmax composition
-USE_FLASH_BWD_BWD = os.environ.get('TG_FLASH_BWD_BWD', '1') != '0'
+# backward, second-order backward); USE_FLASH_BWD_BWD = False (tests): that pass keeps the batched-GEMM / softmax composition
+USE_FLASH_BWD_BWD = True
 # the input gradient of a generator block's first conv (upsample + UNet concat read in place) written straight into the two
-# sources' gradients by the backward-data kernel (tg_conv2d_upcat_bwd_data; TG_UPCAT_BWD_FUSED=0: backward-data into a
+# sources' gradients by the backward-data kernel (tg_conv2d_upcat_bwd_data; USE_UPCAT_BWD_FUSED = False (tests): backward-data into a
 # concat-layout tensor + tg_upsample2x_concat_bwd, for A/Bs)
-USE_UPCAT_BWD_FUSED = os.environ.get('TG_UPCAT_BWD_FUSED', '1') != '0'
+USE_UPCAT_BWD_FUSED = True
 
 class PackCache:
   """bf16 K-contiguous packs (tg_conv2d_pack_weights) of registered master weights.
@@ -520,17 +520,17 @@ def conv_bwd_data_masked_raw(gy, w, x_act, spec):
 
 
 # backward-data of a discriminator block's last conv straight from the pooled gradient + the layer's sign bytes
-# (tg_conv2d_bwd_data_unpool) wherever the layer's filter gradient is not needed (TG_DGRAD_UNPOOL=0: the two-launch path)
-USE_DGRAD_UNPOOL = os.environ.get('TG_DGRAD_UNPOOL', '1') != '0'
+# (tg_conv2d_bwd_data_unpool) wherever the layer's filter gradient is not needed (USE_DGRAD_UNPOOL = False (tests): the two-launch path)
+USE_DGRAD_UNPOOL = True
 # ... and where the filter / bias gradient does need that tensor (a discriminator step), the same kernel writes it
-# (TG_DGRAD_UNPOOL_KEEP=0: tg_lrelu_pool_bwd_signs + the plain backward-data there)
-USE_DGRAD_UNPOOL_KEEP = os.environ.get('TG_DGRAD_UNPOOL_KEEP', '1') != '0'
+# (USE_DGRAD_UNPOOL_KEEP = False (tests): tg_lrelu_pool_bwd_signs + the plain backward-data there)
+USE_DGRAD_UNPOOL_KEEP = True
 # ... and for block ends that kept their activation output instead of sign bytes (the gradient-penalty pass' nodes in the
-# second differentiation): the signs read from that tensor (TG_DGRAD_UNPOOL_ACT=0: tg_lrelu_pool_bwd + backward-data)
-USE_DGRAD_UNPOOL_ACT = os.environ.get('TG_DGRAD_UNPOOL_ACT', '1') != '0'
+# second differentiation): the signs read from that tensor (USE_DGRAD_UNPOOL_ACT = False (tests): tg_lrelu_pool_bwd + backward-data)
+USE_DGRAD_UNPOOL_ACT = True
 # ... and in the gradient penalty's first (create_graph) backward pass: LReluPoolBwdFn + MaskedDgradFn as the one
-# differentiable UnpoolMaskedDgradFn (TG_DGRAD_UNPOOL_GP=0: the two nodes)
-USE_DGRAD_UNPOOL_GP = os.environ.get('TG_DGRAD_UNPOOL_GP', '1') != '0'
+# differentiable UnpoolMaskedDgradFn (USE_DGRAD_UNPOOL_GP = False (tests): the two nodes)
+USE_DGRAD_UNPOOL_GP = True
 
 
 def conv_bwd_data_unpool_raw(gzp, signs, w, x_act, x_shape, spec, keep=False):
@@ -949,8 +949,8 @@ class ConvBwdDataFn(torch.autograd.Function):
 
 
 # the LeakyReLU mask a node of the gradient penalty's second backward pass applies to its incoming cotangent, moved into
-# the conv that PRODUCES that cotangent (tg_conv2d_fwd_masked; TG_GP_PREMASK=0: every node masks for itself, for A/Bs)
-USE_GP_PREMASK = os.environ.get('TG_GP_PREMASK', '1') != '0'
+# the conv that PRODUCES that cotangent (tg_conv2d_fwd_masked; USE_GP_PREMASK = False (tests): every node masks for itself, for A/Bs)
+USE_GP_PREMASK = True
 
 
 class MaskedDgradFn(torch.autograd.Function):
@@ -1987,7 +1987,7 @@ class _SecondOrder(object):
 class second_order(object):
   """Marks a forward pass whose backward is itself differentiated (the gradient-penalty pass of the discriminator,
   image_generation.py:414-439): a layer whose fused kernel has no second-order backward builds its differentiable
-  composition there (flash attention with TG_FLASH_BWD_BWD=0)."""
+  composition there (flash attention with USE_FLASH_BWD_BWD = False (tests))."""
 
   def __enter__(self):
     _SecondOrder.depth += 1
@@ -2048,7 +2048,7 @@ class FlashAttnBwdFn(torch.autograd.Function):
 class FlashAttnFn(torch.autograd.Function):
   """softmax(q k^T) v of libs/self_attention.py:56-63 without the [len, len] map in HBM (csrc/flash.hip): forward saves the
   per-query log-sum-exp; the backward recomputes the probabilities tile by tile.  Under create_graph the backward is the
-  differentiable FlashAttnBwdFn (or, with TG_FLASH_BWD_BWD=0, the batched-GEMM / softmax composition, which materialises
+  differentiable FlashAttnBwdFn (or, with USE_FLASH_BWD_BWD = False (tests), the batched-GEMM / softmax composition, which materialises
   the map)."""
 
   @staticmethod

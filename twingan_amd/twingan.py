@@ -369,10 +369,10 @@ class Trainer:
     """``overlap``: cut the backward into segments and start the clone all-reduce of each segment's finished
     gradients while the next one runs (None: whenever there is more than one clone; True forces the segmented
     schedule for a single clone too -- same results, used by the tests)."""
-    if cfg.spectral_norm and cfg.domain_streams and os.environ.get('TG_SN_DOMAIN_STREAMS', '0') != '1':
+    if cfg.spectral_norm and cfg.domain_streams:
       # Spectral norm keeps the discriminators on one stream.  The per-run normalised kernels are computed (and their
       # packs rebuilt) on the main stream by pggan.prepare_run before anything forks, so two streams are SAFE
-      # (TG_SN_DOMAIN_STREAMS=1: the full GPU suite passes with it) -- but on config 4 they measured 450.0 vs 453.9
+      # (the full GPU suite passed with them) -- but on config 4 they measured 450.0 vs 453.9
       # images/s on one stream (gpurun_out r3c): the attention kernels fill the chip on their own.
       cfg = dataclasses.replace(cfg, domain_streams=False)
     self.cfg = cfg
@@ -483,7 +483,7 @@ class Trainer:
       scaled = loss if k == 1.0 else loss * k
       ops.GradSink.pair = True
       # the slab reductions of the filter gradients that feed gradient sinks: queued, one launch per backward segment
-      ops.defer_slab_reductions(os.environ.get('TG_WGRAD_DEFER', '1') != '0')
+      ops.defer_slab_reductions(True)
       for seg in range(nseg):
         if seg == 0:
           scaled.backward()
