@@ -70,16 +70,47 @@ def _sn_compute(P, scope):
     ops.PackCache.register(buf)
   w_bar, u1 = ops.spectral_norm(w, P.state[scope + '/u'], out=buf)
   P.__dict__.setdefault('sn_pending', {})[scope + '/u'] = u1
-  if ops.Cuts.active and torch_is_grad_enabled() and w_bar.requires_grad:
-    # Segmented backward (ops.Cuts): one normalised kernel serves uses in several segments (the gradient-penalty pass in
-    # segment 0, the batched pass above the cut in segment 1), so its node must not sit inside any of them -- the uses
-    # read a detached leaf, whose accumulated gradient sn_segment_backward() sends through the power iteration's
-    # backward ONCE, at the end of the segment that completes the kernel's gradient
-    leaf = w_bar.detach().requires_grad_(True)
-    P.__dict__.setdefault('sn_leaves', {})[scope] = (w_bar, leaf)
-    w_bar = leaf
+  w_bar = _sn_leaf(P, scope, w_bar)
   P.__dict__.setdefault('sn_cache', {})[scope] = w_bar
   return w_bar
+
+
+def _sn_leaf(P, scope, w_bar):
+  """The tensor the uses of a normalised kernel read.  Under the trainer (P.sn_sink_mode) or a segmented backward (ops.Cuts)
+  it is a detached LEAF: one kernel serves several passes (the batched pass and the gradient-penalty pass of a discriminator
+  step, in different backward segments when the step is cut), so its node must not sit inside any of them, and
+  sn_segment_backward() sends the accumulated d loss / d w_bar through the power iteration's backward ONCE.
+  Trainer mode also gives the leaf a GRADIENT SINK (a persistent fp32 buffer, zeroed by prepare_run): the filter-gradient
+  kernels then add into it themselves -- paired launches, deferred slab reductions, the bias gradient riding along, as for
+  an unnormalised kernel -- instead of one gradient tensor per use summed by the framework (config 4: ~80 framework adds
+  and ~30 stand-alone slab reductions per step)."""
+  sink_mode = bool(P.__dict__.get('sn_sink_mode'))
+  if not ((ops.Cuts.active or sink_mode) and torch_is_grad_enabled() and w_bar.requires_grad):
+    return w_bar
+  leaf = w_bar.detach().requires_grad_(True)
+  gbuf = None
+  if sink_mode:
+    gbuf = _sn_grad_buffer(P, scope, leaf)
+    ops.GradSink.register(leaf, gbuf)
+  P.__dict__.setdefault('sn_leaves', {})[scope] = (w_bar, leaf, gbuf)
+  return leaf
+
+
+def _sn_grad_buffer(P, scope, leaf):
+  """The gradient sink of ``scope``'s w_bar: a slice of ONE flat fp32 buffer (so that prepare_run zeroes all of them in one
+  launch), laid out on first use in the order the kernels are prepared."""
+  import torch
+  lay = P.__dict__.setdefault('sn_glayout', {})
+  if scope not in lay:
+    off = P.__dict__.get('sn_gsize', 0)
+    lay[scope] = (off, leaf.numel())
+    P.__dict__['sn_gsize'] = off + leaf.numel()
+    P.__dict__['sn_gflat'] = None      # grown: re-allocated below
+  flat = P.__dict__.get('sn_gflat')
+  if flat is None or flat.numel() < P.__dict__['sn_gsize'] or flat.device != leaf.device:
+    flat = P.__dict__['sn_gflat'] = torch.zeros(P.__dict__['sn_gsize'], dtype=torch.float32, device=leaf.device)
+  off, n = lay[scope]
+  return flat[off:off + n].view(leaf.shape)
 
 
 def _sn_compute_multi(P, scopes):
@@ -100,11 +131,7 @@ def _sn_compute_multi(P, scopes):
   P.__dict__['sn_table_scopes'] = list(scopes)
   for scope, (w_bar, u1) in zip(scopes, outs):
     P.__dict__.setdefault('sn_pending', {})[scope + '/u'] = u1
-    if ops.Cuts.active and torch_is_grad_enabled() and w_bar.requires_grad:
-      leaf = w_bar.detach().requires_grad_(True)
-      P.__dict__.setdefault('sn_leaves', {})[scope] = (w_bar, leaf)
-      w_bar = leaf
-    P.__dict__.setdefault('sn_cache', {})[scope] = w_bar
+    P.__dict__.setdefault('sn_cache', {})[scope] = _sn_leaf(P, scope, w_bar)
 
 
 def torch_is_grad_enabled():
@@ -121,8 +148,12 @@ def sn_segment_backward(P, done):
     return 0
   roots, grads = [], []
   for scope in [k for k in leaves if done(k)]:
-    w_bar, leaf = leaves.pop(scope)
-    if leaf.grad is not None:
+    w_bar, leaf, gbuf = leaves.pop(scope)
+    if gbuf is not None:      # trainer mode: the filter-gradient kernels added into the sink (flushed by the caller before this)
+      ops.GradSink.unregister(leaf)
+      roots.append(w_bar)
+      grads.append(gbuf)
+    elif leaf.grad is not None:
       roots.append(w_bar)
       grads.append(leaf.grad)
   if roots:
@@ -138,6 +169,9 @@ def prepare_run(P, cfg):
   if not cfg.spectral_norm:
     return 0
   scopes = [k[:-2] for k in P.state if k.endswith('/u')]
+  flat = P.__dict__.get('sn_gflat')
+  if flat is not None and P.__dict__.get('sn_sink_mode'):
+    flat.zero_()      # the w_bar gradient sinks of this run (one launch for all of them)
   cache = P.__dict__.setdefault('sn_cache', {})
   todo = [scope for scope in scopes if scope not in cache]
   if len(todo) > 1:      # one tg_spectral_norm_fwd_multi for every kernel of the run (config 4: 60 launches -> 3, +2.5 %)

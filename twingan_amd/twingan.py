@@ -464,6 +464,7 @@ class Trainer:
     nseg = self._nseg(group)
     self.store.zero_grad(group)
     self._set_requires_grad(g=group == 'g', d=group == 'd')
+    self.P.__dict__['sn_sink_mode'] = bool(self.cfg.spectral_norm)      # w_bar leaves with gradient sinks (pggan._sn_leaf)
     if nseg > 1:
       ops.Cuts.begin()
     try:
@@ -492,15 +493,18 @@ class Trainer:
           torch.autograd.backward(roots, grads)
         _DomainStreams.join_all(self.device)
         last = seg == nseg - 1
-        if nseg > 1:      # spectrally normalised kernels whose uses are all behind us: through the normalisation's backward
-          pggan.sn_segment_backward(self.P, lambda scope, seg=seg: last or self.store.phase.get(scope + '/weights', 0) <= seg)
         # filter gradients still waiting for a pair: issue those this segment completes, keep the others
         ops.GradSink.flush(None if last else (lambda ptr, seg=seg: self._ptr_phase.get(ptr, 0) <= seg))
         ops.flush_slab_reductions()      # after the join: every queued slab is written, the launch is on the main stream
+        if nseg > 1 or self.cfg.spectral_norm:
+          # spectrally normalised kernels whose uses are all behind us: their accumulated d loss / d w_bar (the sinks the
+          # flushes above completed) through the normalisation's backward, into the master kernels' gradients
+          pggan.sn_segment_backward(self.P, lambda scope, seg=seg: last or self.store.phase.get(scope + '/weights', 0) <= seg)
         if last:
           pggan.end_run(self.P)
         yield seg, out
     finally:
+      self.P.__dict__['sn_sink_mode'] = False
       ops.GradSink.pair = False
       ops.defer_slab_reductions(False)
       if nseg > 1:
