@@ -721,6 +721,13 @@ def sample_lerp(x, y, alpha):
   return out
 
 
+def zero_(t):
+  """t[...] = 0 for a contiguous device tensor, through the library (tg_fill_scaled) rather than the framework's fill."""
+  assert t.is_contiguous()
+  call('tg_fill_scaled', _p(t), None, 0.0, t.numel(), _dt(t), _stream(), work=('fill:numel%d' % t.numel(), 0, _nb(t)))
+  return t
+
+
 def fill(shape, value, dtype, device, scalar=None):
   out = torch.empty(shape, dtype=dtype, device=device)
   call('tg_fill_scaled', _p(out), _p(scalar), float(value), out.numel(), _dt(out), _stream(),

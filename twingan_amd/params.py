@@ -234,7 +234,11 @@ class ParamStore:
     PackCache.version += 1
 
   def zero_grad(self, group):
-    self.grad[group].zero_()
+    if self.grad[group].is_cuda:
+      from . import ops
+      ops.zero_(self.grad[group])
+    else:
+      self.grad[group].zero_()
 
   def close(self):
     """Drops this store's entries from the process-wide pack / gradient-sink registries (they hold strong references

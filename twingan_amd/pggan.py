@@ -171,7 +171,7 @@ def prepare_run(P, cfg):
   scopes = [k[:-2] for k in P.state if k.endswith('/u')]
   flat = P.__dict__.get('sn_gflat')
   if flat is not None and P.__dict__.get('sn_sink_mode'):
-    flat.zero_()      # the w_bar gradient sinks of this run (one launch for all of them)
+    ops.zero_(flat)      # the w_bar gradient sinks of this run (one launch for all of them)
   cache = P.__dict__.setdefault('sn_cache', {})
   todo = [scope for scope in scopes if scope not in cache]
   if len(todo) > 1:      # one tg_spectral_norm_fwd_multi for every kernel of the run (config 4: 60 launches -> 3, +2.5 %)

@@ -487,7 +487,9 @@ class Trainer:
       ops.defer_slab_reductions(True)
       for seg in range(nseg):
         if seg == 0:
-          scaled.backward()
+          if getattr(self, '_seed', None) is None or self._seed.device != scaled.device:
+            self._seed = torch.ones(1, dtype=torch.float32, device=scaled.device)      # d loss / d loss, made once
+          scaled.backward(self._seed)
         else:
           roots, grads = ops.Cuts.roots(seg)
           torch.autograd.backward(roots, grads)
