@@ -244,6 +244,10 @@ int tg_conv2d_pack_weights_multi(const void* table_device, int njobs, int total_
  * ------------------------------------------------------------------------------------------- */
 int tg_pointwise_conv_fwd(const void* x, const float* w, const float* bias, void* y, int64_t npix, int cin, int cout,
                           int wt, int epilogue, float lrelu_alpha, int dtype, void* stream);
+/* y = rnd(x @ w) * (mask > 0 ? 1 : alpha), mask of y's shape, cin <= 4: the transposed toRGB-side conv of the gradient
+ * penalty's second backward with the LeakyReluGrad of fromRGB's output in its epilogue (image_generation.py:414-439). */
+int tg_pointwise_conv_fwd_masked(const void* x, const float* w, const void* mask, void* y, int64_t npix, int cin, int cout,
+                                 int transpose_w, float alpha, int dtype, void* stream);
 int tg_pointwise_conv_bwd_weight(const void* x, const void* gy, float* gw, int64_t npix, int cin, int cout,
                                  int accumulate, int dtype, void* stream);
 /* The fromRGB layer's filter AND bias gradient from one read of gy (Conv2DBackpropFilter + BiasAddGrad of
@@ -414,6 +418,22 @@ int tg_pred_losses_fwd(const float* pred, int group_size, int groups, const TgPr
                        void* stream);
 int tg_pred_losses_bwd(const float* pred, int group_size, int groups, const TgPredJob* jobs, int njobs, const float* const* gterms,
                        int nterms, float* gpred, void* stream);
+/* Row blocks of a batch put together in ONE launch: for every job, dst[dst_off + i] = sum_k src[k][i], i < numel (elements of
+ * `dtype`; fp32 sum rounded once; sources packed to the front of src[], a job without sources writes zeros).  The copies of
+ * a concatenation along N (tf.concat(..., 0) of the reference's batched towers, twingan.py:233-288), the repeat of a batch,
+ * and the backward of a tensor that is read through several row ranges.  jobs: HOST array (it travels in the kernel
+ * arguments). */
+#define TG_ROWS_MAX_JOBS 8
+typedef struct TgRowsJob {
+  const void* src[4];
+  int64_t dst_off, numel;
+} TgRowsJob;
+int tg_rows_assemble(const TgRowsJob* jobs, int njobs, void* dst, int dtype, void* stream);
+/* out[i] = lo + (hi - lo) * U[0,1), i < n (tf.random_uniform of the gradient-penalty interpolation weights and the DRAGAN
+ * perturbation, image_generation.py:420-424,441-450): Philox4x32-10 keyed by (seed, state[0]).  state: TWO device words,
+ * zero-initialised by the caller; the kernel advances state[0] by one per launch (so a launch captured in a hipGraph draws
+ * new numbers on every replay) and uses state[1] as its rendezvous ticket. */
+int tg_uniform(float* out, int64_t n, uint64_t seed, uint32_t* state, float lo, float hi, void* stream);
 /* out[0] = sum of n (<= 24) device fp32 scalars, in argument order (tf.add_n over the loss collection,
  * model/model_inheritor.py); scalars: HOST array of device pointers. */
 int tg_sum_scalars(const float* const* scalars, int n, float* out, void* stream);

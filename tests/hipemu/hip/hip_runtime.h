@@ -251,6 +251,10 @@ static HIPEMU_PRIM int __any(int p) { return hipemu::any_lane(p); }
 static inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
+static inline void __threadfence() {}
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 #define __expf expf
 #define __logf logf

@@ -55,6 +55,20 @@ def ops():
   return _ops
 
 
+@pytest.fixture
+def record_calls():
+  """-> the list of (entry point, args) of every library call made while the test runs."""
+  import twingan_amd.ops as O
+  real, seen = O.call, []
+
+  def spy(name, *a, **kw):
+    seen.append((name, a))
+    return real(name, *a, **kw)
+  O.call = spy
+  yield seen
+  O.call = real
+
+
 # ---------------------------------------------------------------------------------------------- conv
 CONV_CASES = [
     # n, h, w, cin, cout, k, padding
@@ -959,6 +973,136 @@ def test_gdrop_op(ops, dtype):
   v = rng.randn(n, hw, hw, c)
   ggy, = torch.autograd.grad(gx, gyd, to_dev(v, dtype))      # d/d gy of gy * f, contracted with v
   assert rel_l2(host(ggy), v * f[:, None, None, :]) < tol_for(dtype, True)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('inner', [(4, 4, 8), (5,), (3, 3)])      # 16-byte rows, and rows only the scalar path can take
+def test_rows_and_cat_rows(ops, record_calls, dtype, inner):
+  """ops.rows / ops.cat_rows (tg_rows_assemble): the batched towers' tf.concat / split glue (twingan.py:233-288).  Views
+  forward; repeats and concatenations one launch; the backward ONE launch that writes each row block once -- the fp32 sum
+  of every gradient covering it, zeros where none does -- against the framework's chunk / cat / add arithmetic in fp64."""
+  rng = np.random.RandomState(5)
+  b = 3
+  x = to_dev(rng.randn(*((2 * b,) + inner)), dtype).double().cpu().numpy()      # values the dtype holds exactly
+  xd = to_dev(x, dtype).requires_grad_(True)
+  s_rows, t_rows = (0, b), (b, 2 * b)
+  record_calls.clear()
+  es, et, rep, unused, mid = ops.rows(xd, [s_rows, t_rows, (t_rows, s_rows, s_rows, t_rows), (1, 4), (2, 5)])
+  assert [c[0] for c in record_calls] == ['tg_rows_assemble']
+  assert es.data_ptr() == xd.data_ptr() and et.data_ptr() == xd.data_ptr() + b * xd[0].numel() * xd.element_size()
+  np.testing.assert_array_equal(host(rep), np.concatenate([x[b:], x[:b], x[:b], x[b:]]))
+  np.testing.assert_array_equal(host(mid), x[2:5])
+  g_es, g_rep, g_mid = rng.randn(*es.shape), rng.randn(*rep.shape), rng.randn(*mid.shape)
+  g_es, g_rep, g_mid = (to_dev(g, dtype).double().cpu().numpy() for g in (g_es, g_rep, g_mid))
+  want = np.zeros_like(x)
+  want[:b] += g_es
+  want[b:] += g_rep[:b] + g_rep[3 * b:]
+  want[:b] += g_rep[b:2 * b] + g_rep[2 * b:3 * b]
+  want[2:5] += g_mid
+  record_calls.clear()
+  gx, = torch.autograd.grad([es, rep, mid], xd, [to_dev(g_es, dtype), to_dev(g_rep, dtype), to_dev(g_mid, dtype)])
+  assert [c[0] for c in record_calls] == ['tg_rows_assemble']      # et and `unused` bring no gradient and no zero tensor
+  assert rel_l2(host(gx), want) < (1e-6 if dtype == torch.float32 else 4e-3)
+  # a lone gradient over all rows is passed through; no gradient at all is None
+  whole, = ops.rows(xd, [(0, 2 * b)])
+  record_calls.clear()
+  g1, = torch.autograd.grad(whole, xd, to_dev(x, dtype))
+  assert record_calls == [] and torch.equal(g1, to_dev(x, dtype))
+  # concatenation: a copy with a tape (the gradients are views), a view of adjacent rows without one
+  a, c = to_dev(x[:2], dtype).requires_grad_(True), to_dev(x[2:], dtype)
+  both = ops.cat_rows([a, c, a])
+  np.testing.assert_array_equal(host(both), np.concatenate([x[:2], x[2:], x[:2]]))
+  ga, = torch.autograd.grad(both, a, both.detach())
+  assert rel_l2(host(ga), 2 * x[:2]) < (1e-6 if dtype == torch.float32 else 4e-3)
+  base = to_dev(x, dtype)
+  record_calls.clear()
+  view = ops.cat_rows([base[:2], base[2:]])
+  assert record_calls == [] and view.data_ptr() == base.data_ptr() and torch.equal(view, base)
+  apart = ops.cat_rows([base[:2], base[3:]])
+  np.testing.assert_array_equal(host(apart), np.concatenate([x[:2], x[3:]]))
+  # more blocks than one launch takes, more sources than one job takes
+  many = ops.cat_rows([base[k:k + 1] for k in (0, 1, 2, 3, 4, 5, 0, 1, 2, 3)])
+  np.testing.assert_array_equal(host(many), x[[0, 1, 2, 3, 4, 5, 0, 1, 2, 3]])
+  dst = torch.empty_like(base[:1])
+  ops.assemble_rows(dst, [(0, 1, [base[k:k + 1] for k in range(6)])])
+  assert rel_l2(host(dst), x.sum(0, keepdims=True)) < (1e-6 if dtype == torch.float32 else 8e-3)
+
+
+def test_uniform_draws(ops):
+  """tg_uniform: Philox4x32-10 keyed by (seed, draw counter) -- U[0,1) values, a new draw per launch (the counter is
+  advanced on the device, ticket word back at 0), the same stream for the same seed, ragged lengths, and sane moments."""
+  state = torch.zeros(2, dtype=torch.int32, device=dev())
+  a = ops.uniform(32, 7, state)
+  b = ops.uniform(32, 7, state)
+  assert state.tolist() == [2, 0]
+  assert float(a.min()) >= 0.0 and float(a.max()) < 1.0 and not torch.equal(a, b)
+  again = torch.zeros(2, dtype=torch.int32, device=dev())
+  assert torch.equal(ops.uniform(32, 7, again), a) and torch.equal(ops.uniform(32, 7, again), b)
+  assert not torch.equal(ops.uniform(32, 8, torch.zeros(2, dtype=torch.int32, device=dev())), a)
+  # a prefix of a longer draw is the shorter draw (counter = block index), whatever the grid
+  long = ops.uniform(300001, 7, torch.zeros(2, dtype=torch.int32, device=dev()))
+  assert torch.equal(long[:32], a)
+  x = host(long)
+  assert abs(x.mean() - 0.5) < 3e-3 and abs(x.var() - 1.0 / 12.0) < 2e-3 and x.min() >= 0.0 and x.max() < 1.0
+  assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 1e-2
+  r = host(ops.uniform(1000, 3, torch.zeros(2, dtype=torch.int32, device=dev()), lo=-1.0, hi=1.0))
+  assert r.min() >= -1.0 and r.max() < 1.0 and abs(r.mean()) < 0.1
+  # the known-answer vector of Philox4x32-10 (Random123 kat_vectors: counter 0, key 0)
+  z = ops.uniform(4, 0, torch.zeros(2, dtype=torch.int32, device=dev()))
+  words = [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+  assert host(z).tolist() == [float(np.float32(w >> 8) * np.float32(1.0 / 16777216.0)) for w in words]
+
+
+def test_no_backward_work_without_a_gradient(ops, record_calls):
+  """A conv / minibatch-stddev node the backward reaches WITHOUT a gradient (the gradient penalty's second backward
+  reaches the layers after the minibatch stddev only through LeakyReLU masks) launches nothing and passes None on --
+  the default would materialise a tensor of zeros and run backward-data, filter-gradient and mbstd kernels on it."""
+  class Drop(torch.autograd.Function):      # a consumer whose backward has nothing to say about its input
+    @staticmethod
+    def forward(ctx, t):
+      return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+      return None
+
+  rng = np.random.RandomState(2)
+  x = to_dev(rng.randn(4, 4, 4, 16), torch.bfloat16).requires_grad_(True)
+  w1, w2 = (to_dev(rng.randn(3, 3, c, 16) * 0.1).requires_grad_(True) for c in (16, 24))
+  b = to_dev(rng.randn(16) * 0.1).requires_grad_(True)
+  h = ops.conv2d(x, w1, b, 3, 'SAME', lrelu=True)
+  y = ops.conv2d(ops.minibatch_state_concat(h, 24, 2), w2, None, 3, 'SAME', lrelu=False)
+  record_calls.clear()
+  (Drop.apply(y).float().sum() + x.float().sum()).backward()
+  assert [c[0] for c in record_calls if c[0].startswith(('tg_conv2d', 'tg_mbstd', 'tg_lrelu'))] == []
+  assert w1.grad is None and w2.grad is None and b.grad is None
+  assert torch.equal(x.grad, torch.ones_like(x))
+
+
+def test_first_order_only_input(ops, record_calls):
+  """ops.first_order_only: the gradient penalty differentiates D with respect to the interpolates under create_graph;
+  the FINAL backward then wants parameter gradients only -- the first layer skips its input gradient (a full-resolution
+  backward-data launch and a copy into .grad), the parameter gradients are those of the unmarked run."""
+  rng = np.random.RandomState(3)
+  xv = to_dev(rng.randn(2, 8, 8, 3), torch.bfloat16)
+  wv, bv = to_dev(rng.randn(1, 1, 3, 16) * 0.5), to_dev(rng.randn(16) * 0.1)
+  res = []
+  for mark in (False, True):
+    x = xv.clone().requires_grad_(True)
+    if mark:
+      ops.first_order_only(x)
+    w, b = wv.clone().requires_grad_(True), bv.clone().requires_grad_(True)
+    with ops.second_order():
+      y = ops.pointwise_conv(ops.scale(x, 0.7), w, b, lrelu=True)
+    gx, = torch.autograd.grad(y, x, torch.ones_like(y), create_graph=True)      # first order: wanted either way
+    record_calls.clear()
+    (gx.float().pow(2).sum() + y.float().sum()).backward()
+    res.append((gx.detach(), w.grad, b.grad, x.grad, [c[0] for c in record_calls]))
+  (gx0, w0, b0, x0, calls0), (gx1, w1, b1, x1, calls1) = res
+  assert torch.equal(gx0, gx1) and torch.equal(w0, w1) and torch.equal(b0, b1)
+  assert x0 is not None and x1 is None
+  assert calls0.count('tg_pointwise_conv_fwd') == calls1.count('tg_pointwise_conv_fwd') + 1, (calls0, calls1)
+  assert calls0.count('tg_axpby') == calls1.count('tg_axpby') + 1, (calls0, calls1)
 
 
 SMALL_MASK_CASES = [

@@ -67,11 +67,13 @@ def main(path):
       json.dump({'kernels': len(seg), 'wall_ms': (t1 - t0) / 1e6, 'busy_ms': busy / 1e6, 'two_in_flight_ms': two / 1e6,
                  'sum_ms': sum(e - s for s, e, _ in seg) / 1e6,
                  'by_kernel': sorted(([k, v[1], round(v[0], 1)] for k, v in fam.items()), key=lambda r: -r[2])}, fh, indent=1)
-  print('kernels that are not this library\'s (framework ops left in the step):')
-  for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0]):
-    if 'GLOBAL__N_1' in k or 'anonymous namespace)::conv' in k or 'anonymous namespace)::pack' in k:
-      continue
+  # the library's kernels all live in anonymous namespaces (mangled: _GLOBAL__N_1; demangled: the prefix `key` dropped);
+  # what the framework or the runtime launches carries its own namespace (at::native::, __amd_rocclr_, rccl)
+  print('kernels that are not this library\'s (framework / runtime launches left in the step):')
+  foreign = [(k, v) for k, v in fam.items() if k.startswith(('at::', '__amd_', 'rccl', 'nccl', 'hip'))]
+  for k, v in sorted(foreign, key=lambda kv: -kv[1][0]):
     print('  %8.1f us %4d  %s' % (v[0], v[1], k))
+  print('  total: %d launches, %.1f us' % (sum(v[1] for _, v in foreign), sum(v[0] for _, v in foreign)))
 
 
 if __name__ == '__main__':

@@ -89,6 +89,7 @@ SIGNATURES = {
     'tg_pack_table_fill': (c_int, [_D, _FP, c_int, _P, c_int, _P, POINTER(c_int32)]),
     'tg_conv2d_pack_weights_multi': (c_int, [_P, c_int, c_int, _P]),
     'tg_pointwise_conv_fwd': (c_int, [_P, _FP, _FP, _P, c_int64, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    'tg_pointwise_conv_fwd_masked': (c_int, [_P, _FP, _P, _P, c_int64, c_int, c_int, c_int, c_float, c_int, _P]),
     'tg_pointwise_conv_bwd_weight': (c_int, [_P, _P, _FP, c_int64, c_int, c_int, c_int, c_int, _P]),
     'tg_pointwise_conv_bwd_weight_bias': (c_int, [_P, _P, _FP, _FP, c_int64, c_int, c_int, c_int, c_int, _P]),
     'tg_instance_norm_stats': (c_int, [_P, _FP, _FP, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
@@ -130,6 +131,8 @@ SIGNATURES = {
     'tg_pred_losses_fwd': (c_int, [_FP, c_int, c_int, _P, c_int, _FP, c_int, _P]),
     'tg_pred_losses_bwd': (c_int, [_FP, c_int, c_int, _P, c_int, _P, c_int, _FP, _P]),
     'tg_sum_scalars': (c_int, [_P, c_int, _FP, _P]),
+    'tg_rows_assemble': (c_int, [_P, c_int, _P, c_int, _P]),
+    'tg_uniform': (c_int, [_FP, c_int64, ctypes.c_uint64, _P, c_float, c_float, _P]),
     'tg_pred_loss_fwd': (c_int, [_FP, _FP, c_int, c_int, c_float, c_float, c_float, c_int, _P]),
     'tg_pred_loss_bwd': (c_int, [_FP, _FP, _FP, c_int, c_int, c_float, c_float, c_float, _P]),
     'tg_var_from_sums': (c_int, [_FP, _FP, _FP, c_int, c_int64, _P]),

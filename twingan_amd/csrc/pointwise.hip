@@ -29,6 +29,103 @@ __global__ void axpby_kernel(const T* __restrict__ x, const T* __restrict__ y, T
     st(out + i, a * ld(x + i) + (y ? b * ld(y + i) : 0.f));
 }
 
+// ---- row blocks of a batch put together: dst[dst_off + i] = sum_k src[k][i] (fp32 sum, rounded once), zeros without a source.
+// One launch for every block of a destination: the copies of a concatenation along N, the repeat of a batch, and -- the
+// backward of tensors read through several row ranges -- the sum of the gradients that cover each block.
+struct RowsJobs {
+  TgRowsJob j[TG_ROWS_MAX_JOBS];
+};
+template <typename T, bool VEC>
+__global__ void rows_assemble_kernel(RowsJobs jobs, T* __restrict__ dst) {
+  const TgRowsJob& jb = jobs.j[blockIdx.y];
+  const T* s0 = (const T*)jb.src[0];
+  const T* s1 = (const T*)jb.src[1];
+  const T* s2 = (const T*)jb.src[2];
+  const T* s3 = (const T*)jb.src[3];
+  T* d = dst + jb.dst_off;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if constexpr (VEC) {
+    constexpr int V = Vec16<T>::N;
+    const int64_t nvec = jb.numel / V;
+    for (int64_t i = t0; i < nvec; i += stride) {
+      Vec16<T> vo;
+      if (!s0) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) vo.set(j, 0.f);
+      } else if (!s1) {
+        vo = ldv(s0 + i * V);
+      } else {
+        float acc[V];
+        Vec16<T> a = ldv(s0 + i * V), b = ldv(s1 + i * V);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = a.get(j) + b.get(j);
+        if (s2) {
+          a = ldv(s2 + i * V);
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc[j] += a.get(j);
+        }
+        if (s3) {
+          a = ldv(s3 + i * V);
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc[j] += a.get(j);
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) vo.set(j, acc[j]);
+      }
+      stv(d + i * V, vo);
+    }
+  } else {
+    for (int64_t i = t0; i < jb.numel; i += stride) {
+      float acc = 0.f;
+      if (s0) acc = ld(s0 + i);
+      if (s1) acc += ld(s1 + i);
+      if (s2) acc += ld(s2 + i);
+      if (s3) acc += ld(s3 + i);
+      st(d + i, acc);
+    }
+  }
+}
+
+// ---- U[0, 1) draws: Philox4x32-10 keyed by (seed, draw counter), one 4-word block per four outputs.  The draw counter is
+// a DEVICE word the kernel itself advances (the last workgroup to finish), so a captured launch draws new numbers on every
+// replay; state[1] is that rendezvous' ticket and is left at 0.
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+  const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+  const unsigned h0 = (unsigned)(p0 >> 32), l0 = (unsigned)p0, h1 = (unsigned)(p1 >> 32), l1 = (unsigned)p1;
+  c[0] = h1 ^ c[1] ^ k0;
+  c[1] = l1;
+  c[2] = h0 ^ c[3] ^ k1;
+  c[3] = l0;
+}
+__global__ void uniform_kernel(float* __restrict__ out, int64_t n, unsigned seed_lo, unsigned seed_hi,
+                               unsigned* __restrict__ state, float lo, float scale) {
+  const unsigned draw = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += stride) {
+    unsigned c[4] = {(unsigned)q, (unsigned)(q >> 32), draw, 0u};
+    unsigned k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (q * 4 + j < n) out[q * 4 + j] = lo + scale * ((float)(c[j] >> 8) * (1.f / 16777216.f));      // 24 bits: [0, 1)
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned ticket = atomicAdd(state + 1, 1u);
+    if (ticket == gridDim.x - 1) {      // every workgroup has read the counter: advance it, reset the ticket
+      __hip_atomic_store(state + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(state, draw + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 template <typename T>
 __global__ void lrelu_bwd_kernel(const T* __restrict__ gz, const T* __restrict__ z, T* __restrict__ gy, int64_t numel,
                                  float alpha) {
@@ -307,7 +404,10 @@ __global__ void pool_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, in
 // small-in: y[p, co] = sum_{ci<cin} x[p,ci] * w[ci,co]; thread = (pixel, V-vector of co)
 template <typename T, int V>
 __global__ void pw_small_in_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                   T* __restrict__ y, int64_t npix, int cin, int cout, int wt, int epi, float alpha) {
+                                   T* __restrict__ y, int64_t npix, int cin, int cout, int wt, int epi, float alpha,
+                                   const T* __restrict__ mask) {
+  // mask (optional, y's shape): the ROUNDED output times (mask > 0 ? 1 : alpha) -- the LeakyReluGrad the gradient penalty's
+  // second backward applies to what fromRGB's transposed conv hands the first block (tg_pointwise_conv_fwd_masked)
   extern __shared__ float sw[];   // [cin][cout] (+ bias[cout])
   for (int i = threadIdx.x; i < cin * cout; i += blockDim.x) {
     const int ci = i / cout, co = i - ci * cout;
@@ -344,11 +444,16 @@ __global__ void pw_small_in_kernel(const T* __restrict__ x, const float* __restr
       }
       T* dst = y + p * cout + v * V;
       if (V == 1) {
-        st(dst, acc[0]);
+        st(dst, mask ? rnd<T>(acc[0]) * (ld(mask + p * cout + v) > 0.f ? 1.f : alpha) : acc[0]);
       } else {
         Vec16<T> o;
 #pragma unroll
         for (int j = 0; j < V; ++j) o.set(j, acc[j]);
+        if (mask) {
+          const Vec16<T> m = ldv(mask + p * cout + v * V);
+#pragma unroll
+          for (int j = 0; j < V; ++j) o.set(j, o.get(j) * (m.get(j) > 0.f ? 1.f : alpha));
+        }
         stv(dst, o);
       }
     }
@@ -371,11 +476,16 @@ __global__ void pw_small_in_kernel(const T* __restrict__ x, const float* __restr
     }
     T* dst = y + p * cout + v * V;
     if (V == 1) {
-      st(dst, acc[0]);
+      st(dst, mask ? rnd<T>(acc[0]) * (ld(mask + p * cout + v) > 0.f ? 1.f : alpha) : acc[0]);
     } else {
       Vec16<T> o;
 #pragma unroll
       for (int j = 0; j < V; ++j) o.set(j, acc[j]);
+      if (mask) {
+        const Vec16<T> m = ldv(mask + p * cout + v * V);
+#pragma unroll
+        for (int j = 0; j < V; ++j) o.set(j, o.get(j) * (m.get(j) > 0.f ? 1.f : alpha));
+      }
       stv(dst, o);
     }
   }
@@ -594,16 +704,16 @@ __global__ void pw_wgrad_final_kernel(const float* __restrict__ part, int nb, in
 
 template <typename T>
 int launch_pw_fwd(const T* x, const float* w, const float* bias, T* y, int64_t npix, int cin, int cout, int wt, int epi,
-                  float alpha, hipStream_t s) {
+                  float alpha, hipStream_t s, const T* mask = nullptr) {
   constexpr int V = Vec16<T>::N;
   const size_t lds = (size_t)(cin * cout + cout) * sizeof(float);
   if (cin <= 4) {
     if (cout % V == 0)
       hipLaunchKernelGGL((pw_small_in_kernel<T, V>), dim3(tg_grid_for(npix * (cout / V), 256)), dim3(256), lds, s, x, w,
-                         bias, y, npix, cin, cout, wt, epi, alpha);
+                         bias, y, npix, cin, cout, wt, epi, alpha, mask);
     else
       hipLaunchKernelGGL((pw_small_in_kernel<T, 1>), dim3(tg_grid_for(npix * cout, 256)), dim3(256), lds, s, x, w, bias, y,
-                         npix, cin, cout, wt, epi, alpha);
+                         npix, cin, cout, wt, epi, alpha, mask);
   } else {
     if (cin % V == 0)
       hipLaunchKernelGGL((pw_small_out_kernel<T, V>), dim3(tg_grid_for(npix, 256)), dim3(256), lds, s, x, w, bias, y, npix,
@@ -690,6 +800,46 @@ int tg_axpby(const void* x, const void* y, void* out, int64_t numel, float a, fl
                        (const T*)x, (const T*)y, (T*)out, numel, a, b);
   });
   TG_LAUNCH_CHECK("tg_axpby");
+  return TG_OK;
+}
+
+int tg_rows_assemble(const TgRowsJob* jobs, int njobs, void* dst, int dtype, void* stream) {
+  TG_CHECK(jobs && dst && njobs > 0 && njobs <= TG_ROWS_MAX_JOBS, TG_EINVAL, "tg_rows_assemble: 1..%d jobs", TG_ROWS_MAX_JOBS);
+  RowsJobs a;
+  int64_t longest = 0;
+  const size_t esz = dtype == TG_F32 ? 4 : 2;
+  bool vec = ((uintptr_t)dst & 15) == 0;
+  for (int i = 0; i < njobs; ++i) {
+    a.j[i] = jobs[i];
+    const TgRowsJob& jb = jobs[i];
+    TG_CHECK(jb.numel >= 0 && jb.dst_off >= 0, TG_EINVAL, "tg_rows_assemble: job %d: bad extent", i);
+    bool open = true;      // sources are packed to the front
+    for (int k = 0; k < 4; ++k) {
+      TG_CHECK(open || !jb.src[k], TG_EINVAL, "tg_rows_assemble: job %d: source %d after an empty slot", i, k);
+      open = open && jb.src[k];
+      vec = vec && ((uintptr_t)jb.src[k] & 15) == 0;
+    }
+    vec = vec && (jb.dst_off * esz) % 16 == 0 && (jb.numel * esz) % 16 == 0;
+    if (jb.numel > longest) longest = jb.numel;
+  }
+  if (longest == 0) return TG_OK;
+  TG_DISPATCH_DTYPE(dtype, "tg_rows_assemble", {
+    const int per = vec ? Vec16<T>::N * 2 : 2;      // two trips of the stride loop per thread on the longest block
+    const dim3 grid(tg_grid_for((longest + per - 1) / per, 256, 2048), njobs);
+    if (vec)
+      hipLaunchKernelGGL((rows_assemble_kernel<T, true>), grid, dim3(256), 0, (hipStream_t)stream, a, (T*)dst);
+    else
+      hipLaunchKernelGGL((rows_assemble_kernel<T, false>), grid, dim3(256), 0, (hipStream_t)stream, a, (T*)dst);
+  });
+  TG_LAUNCH_CHECK("tg_rows_assemble");
+  return TG_OK;
+}
+
+int tg_uniform(float* out, int64_t n, uint64_t seed, uint32_t* state, float lo, float hi, void* stream) {
+  TG_CHECK(out && state && n > 0, TG_EINVAL, "tg_uniform: bad arguments");
+  hipLaunchKernelGGL(uniform_kernel, dim3(tg_grid_for((n + 3) / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream, out, n,
+                     (unsigned)seed, (unsigned)(seed >> 32), state, lo, hi - lo);
+  TG_LAUNCH_CHECK("tg_uniform");
   return TG_OK;
 }
 
@@ -880,6 +1030,18 @@ int tg_pointwise_conv_fwd(const void* x, const float* w, const float* bias, void
     launch_pw_fwd<T>((const T*)x, w, bias, (T*)y, npix, cin, cout, wt, epilogue, alpha, (hipStream_t)stream);
   });
   TG_LAUNCH_CHECK("tg_pointwise_conv_fwd");
+  return TG_OK;
+}
+
+int tg_pointwise_conv_fwd_masked(const void* x, const float* w, const void* mask, void* y, int64_t npix, int cin, int cout,
+                                 int wt, float alpha, int dtype, void* stream) {
+  TG_CHECK(x && w && mask && y && npix > 0 && cin > 0 && cout > 0, TG_EINVAL, "tg_pointwise_conv_fwd_masked: bad arguments");
+  TG_CHECK(cin <= 4, TG_ENOSUP, "tg_pointwise_conv_fwd_masked: the small side must be the input (cin = %d)", cin);
+  TG_CHECK((size_t)(cin * cout + cout) * sizeof(float) <= 48 * 1024, TG_ENOSUP, "tg_pointwise_conv_fwd_masked: weights too large");
+  TG_DISPATCH_DTYPE(dtype, "tg_pointwise_conv_fwd_masked", {
+    launch_pw_fwd<T>((const T*)x, w, nullptr, (T*)y, npix, cin, cout, wt, 0, alpha, (hipStream_t)stream, (const T*)mask);
+  });
+  TG_LAUNCH_CHECK("tg_pointwise_conv_fwd_masked");
   return TG_OK;
 }
 

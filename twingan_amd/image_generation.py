@@ -40,8 +40,8 @@ def discriminator_loss(P, targets, cfg, noise, gp_alpha, dragan_noise=None):
       targets = get_growing_image(targets, cfg.alpha_grow)      # get_growing_source_and_target (:985-1006)
     fake = generate(P, noise, cfg)
   b = targets.shape[0]
-  pred, _ = pggan.discriminator(P, torch.cat([targets, fake], dim=0), cfg, 'discriminator', groups=2, block_end_points=False)
-  pr, pf = (t.contiguous() for t in pred.chunk(2))
+  pred, _ = pggan.discriminator(P, ops.cat_rows([targets, fake]), cfg, 'discriminator', groups=2, block_end_points=False)
+  pr, pf = ops.rows(pred, [(0, b), (b, 2 * b)])
   terms = {}
   _real_fake_losses(terms, '', pf, pr, cfg)
   if cfg.wgan_drift_loss_weight and cfg.loss_architecture in ('wgan_gp', 'wgan'):

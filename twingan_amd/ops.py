@@ -747,11 +747,26 @@ def cast_raw(x, dtype):
 # ------------------------------------------------------------------------------------------------
 # convolution  (layers.conv2d, nets/pggan_utils.py:316-320)
 # ------------------------------------------------------------------------------------------------
+def first_order_only(t):
+  """Marks ``t`` -- an input a pass is differentiated with respect to under create_graph (the gradient penalty's interpolates,
+  image_generation.py:414-439) -- as wanting no gradient from the FINAL backward: d penalty / d interpolates is not a
+  parameter gradient, yet the second backward would compute it (the first layer's backward-data at full resolution, the
+  input scaling's backward, a copy into .grad).  The nodes that read ``t`` skip their input gradient when they run without
+  a graph being recorded.  Returns ``t``."""
+  t._tg_first_order_only = True
+  return t
+
+
+def _input_grad_wanted(ctx, x):
+  return ctx.needs_input_grad[0] and not (getattr(x, '_tg_first_order_only', False) and not torch.is_grad_enabled())
+
+
 def _conv_backward(ctx, gz, gzp=None):
   """Shared backward of Conv2dFn / Conv2dPoolFn.  ``gzp``: gradient of the 2x2-average-pooled output."""
   x, w, z, bias = ctx.saved_tensors
   spec = ctx.spec
   params = not _State.skip_param_grads
+  need_x = _input_grad_wanted(ctx, x)
   need_w = ctx.needs_input_grad[1] and params
   need_b = bool(ctx.epilogue & TG_EPI_BIAS) and ctx.needs_input_grad[2] and params
   gb = None
@@ -766,7 +781,7 @@ def _conv_backward(ctx, gz, gzp=None):
   gx_done = None      # the input gradient when the branch below already ran the backward-data (the unpooling kernel)
   if gzp is not None and not fused:
     if (gz is None and (ctx.epilogue & TG_EPI_LRELU) and USE_DGRAD_UNPOOL and USE_DGRAD_UNPOOL_GP and getattr(ctx, 'mask_input', False)
-        and ctx.needs_input_grad[0] and not need_w and not need_b and z.dtype in HALF_TYPES
+        and need_x and not need_w and not need_b and z.dtype in HALF_TYPES
         and _unpool_act_supported(tuple(x.shape), w, spec, z.dtype)):
       # create_graph pass over a pooled LeakyReLU layer whose input gradient is all that is wanted (the gradient penalty's
       # inner gradient): unpool + mask + masked backward-data as ONE differentiable node
@@ -792,7 +807,7 @@ def _conv_backward(ctx, gz, gzp=None):
   elif pooled_lrelu is not None:
     g = pooled_lrelu
   elif getattr(ctx, 'tg_signs', False):      # z holds the sign bits of the layer's output (Conv2dPoolSignsFn)
-    if USE_DGRAD_UNPOOL and ctx.needs_input_grad[0] and not torch.is_grad_enabled():
+    if USE_DGRAD_UNPOOL and need_x and not torch.is_grad_enabled():
       # this layer's gradient is formed from the pooled gradient and the sign bytes inside the backward-data kernel.  A
       # generator step (the discriminator's parameters are not trained): nothing else reads it and it is never in memory;
       # a discriminator step: the same kernel writes it for the filter / bias gradient
@@ -810,7 +825,7 @@ def _conv_backward(ctx, gz, gzp=None):
       bias_sink = GradSink.get(bias)      # the filter-gradient kernel sums g over pixels as well
       need_b = False
   elif ctx.epilogue & TG_EPI_LRELU:
-    if (fused and gz is None and gzp is not None and USE_DGRAD_UNPOOL and USE_DGRAD_UNPOOL_ACT and ctx.needs_input_grad[0]
+    if (fused and gz is None and gzp is not None and USE_DGRAD_UNPOOL and USE_DGRAD_UNPOOL_ACT and need_x
         and z.dtype in HALF_TYPES):
       # a block end whose activation output was kept (the gradient-penalty pass), differentiated once more: as above, the
       # signs taken from z itself
@@ -835,7 +850,7 @@ def _conv_backward(ctx, gz, gzp=None):
   gx = gx_done
   if gx is not None:
     pass
-  elif ctx.needs_input_grad[0]:
+  elif need_x:
     if getattr(ctx, 'mask_input', False):      # x = the producer's LeakyReLU output
       if torch.is_grad_enabled():
         # the node that produced g masks the cotangent it gets back from us with THIS layer's LeakyReLU output z: when
@@ -852,7 +867,17 @@ def _conv_backward(ctx, gz, gzp=None):
       else:
         gx = conv_bwd_data_masked_raw(g, w, x, spec)
     else:
-      gx = ConvBwdDataFn.apply(g, w, tuple(x.shape), spec)
+      # the first conv of a discriminator block (its input is a pooled tensor: nothing to mask on the way in).  As in the
+      # mask_input branch: when the node that produced g masks the cotangent it gets back from us with THIS layer's
+      # LeakyReLU output and we are its only consumer, our backward applies that mask in its conv's epilogue
+      node = g.grad_fn
+      premask = (torch.is_grad_enabled() and USE_GP_PREMASK and _State.skip_param_grads and z is not None
+                 and bool(ctx.epilogue & TG_EPI_LRELU) and node is not None
+                 and getattr(node, 'tg_masks_with', None) == (z.data_ptr(), tuple(z.shape))
+                 and not getattr(node, 'tg_v_premasked', False))
+      gx = ConvBwdDataFn.apply(g, w, tuple(x.shape), spec, z if premask else None)
+      if premask:
+        node.tg_v_premasked = True
   gw = _weight_grad(x, g, spec, w, bias_sink) if need_w else None
   if need_b:
     gb = _bias_grad(g, bias)
@@ -867,11 +892,17 @@ class Conv2dFn(torch.autograd.Function):
     z = conv_fwd_raw(x, w, bias, spec, epilogue)
     ctx.spec, ctx.epilogue, ctx.mask_input = spec, epilogue, mask_input
     ctx.out_hw = (z.shape[1], z.shape[2])
+    # No gradient for z means no work here.  The gradient penalty's pass reads the activations after the minibatch
+    # stddev only through LeakyReLU masks: the second backward reaches those convs with an undefined gradient, which the
+    # default would turn into a tensor of zeros -- backward-data, filter-gradient and mbstd launches that compute zeros.
+    ctx.set_materialize_grads(False)
     ctx.save_for_backward(x, w, z if (epilogue & TG_EPI_LRELU) else None, bias)
     return z
 
   @staticmethod
   def backward(ctx, gz):
+    if gz is None:
+      return None, None, None, None, None, None
     return _conv_backward(ctx, gz)
 
 
@@ -885,11 +916,14 @@ class Conv2dStatsFn(torch.autograd.Function):
     holder.append(st)
     ctx.spec, ctx.epilogue, ctx.mask_input = spec, 0, False
     ctx.out_hw = (z.shape[1], z.shape[2])
+    ctx.set_materialize_grads(False)
     ctx.save_for_backward(x, w, None, None)
     return z
 
   @staticmethod
   def backward(ctx, gz):
+    if gz is None:
+      return None, None, None, None
     return _conv_backward(ctx, gz)[:2] + (None, None)
 
 
@@ -938,21 +972,32 @@ class Conv2dPoolSignsFn(torch.autograd.Function):
 
 
 class ConvBwdDataFn(torch.autograd.Function):
-  """gx = conv^T(gy, w)  (Conv2DBackpropInput); differentiable in gy and w."""
+  """gx = conv^T(gy, w)  (Conv2DBackpropInput); differentiable in gy and w.
+
+  ``out_act`` (optional): the LeakyReLU output of this conv's layer, with which the node that produced gy masks the
+  cotangent this node's backward hands it (see MaskedDgradFn): given, the backward applies that mask in the epilogue of
+  its conv (tg_conv2d_fwd_masked) and the producer, flagged ``tg_v_premasked`` by the caller, skips its launch."""
 
   @staticmethod
-  def forward(ctx, gy, w, x_shape, spec):
+  def forward(ctx, gy, w, x_shape, spec, out_act=None):
     ctx.spec, ctx.x_shape = spec, x_shape
-    ctx.save_for_backward(gy, w)
+    ctx.save_for_backward(gy, w, out_act)
     return conv_bwd_data_raw(gy, w, x_shape, spec)
 
   @staticmethod
   def backward(ctx, v):
-    gy, w = ctx.saved_tensors
+    gy, w, out_act = ctx.saved_tensors
     v = v.contiguous()
-    ggy = Conv2dFn.apply(v, w, None, ctx.spec, 0, False) if ctx.needs_input_grad[0] else None
+    ggy = None
+    if ctx.needs_input_grad[0]:
+      if out_act is not None and not torch.is_grad_enabled():
+        ggy = conv_fwd_masked_raw(v, w, out_act, ctx.spec)
+      else:
+        ggy = Conv2dFn.apply(v, w, None, ctx.spec, 0, False)
+        if out_act is not None:      # a third-order pass: keep the premasking contract, differentiably
+          ggy = LReluBwdFn.apply(ggy, out_act, ctx.spec.alpha)
     gw = _weight_grad(v, gy, ctx.spec, w) if (ctx.needs_input_grad[1] and not _State.skip_param_grads) else None
-    return ggy, gw, None, None
+    return ggy, gw, None, None, None
 
 
 # the LeakyReLU mask a node of the gradient penalty's second backward pass applies to its incoming cotangent, moved into
@@ -1144,19 +1189,34 @@ def _pw_fwd_raw(x, w, bias, wt, epilogue, alpha):
   return y
 
 
+def _pw_fwd_masked_raw(x, w, wt, mask_src, alpha):
+  """rnd(x @ W) * (mask_src > 0 ? 1 : alpha), x with <= 4 channels (tg_pointwise_conv_fwd_masked)."""
+  _chk(x, w, mask_src)
+  cin = x.shape[-1]
+  cout = w.shape[0] if wt else w.shape[1]
+  assert (w.shape[1] if wt else w.shape[0]) == cin and tuple(mask_src.shape) == tuple(x.shape[:-1]) + (cout,), (w.shape, cin, wt)
+  y = torch.empty(x.shape[:-1] + (cout,), dtype=x.dtype, device=x.device)
+  call('tg_pointwise_conv_fwd_masked', _p(x), _p(w), _p(mask_src), _p(y), x.numel() // cin, cin, cout, int(wt), alpha, _dt(x),
+       _stream(), work=('pw_fwd_masked:c%d>%d:px%d' % (cin, cout, x.numel() // cin), 2 * x.numel() * cout, _nb(x, y, mask_src)))
+  return y
+
+
 class PointwiseConvFn(torch.autograd.Function):
   """z = epilogue(x @ W [+ b]) with W = w (wt=False) or w^T (wt=True); w is fp32 [a, b]."""
 
   @staticmethod
-  def forward(ctx, x, w, bias, wt, epilogue, alpha):
+  def forward(ctx, x, w, bias, wt, epilogue, alpha, out_act=None):
+    """``out_act`` (optional, x's shape; see MaskedDgradFn): the LeakyReLU output with which the node that produced x masks
+    the cotangent this node's backward hands it -- given, the backward applies that mask itself
+    (tg_pointwise_conv_fwd_masked) and the producer, flagged ``tg_v_premasked`` by the caller, skips its launch."""
     z = _pw_fwd_raw(x, w, bias, wt, epilogue, alpha)
     ctx.wt, ctx.epilogue, ctx.alpha = wt, epilogue, alpha
-    ctx.save_for_backward(x, w, z if (epilogue & TG_EPI_LRELU) else None, bias)
+    ctx.save_for_backward(x, w, z if (epilogue & TG_EPI_LRELU) else None, bias, out_act)
     return z
 
   @staticmethod
   def backward(ctx, gz):
-    x, w, z, bias = ctx.saved_tensors
+    x, w, z, bias, out_act = ctx.saved_tensors
     gz = gz.contiguous()
     params = not _State.skip_param_grads
     need_b = bool(ctx.epilogue & TG_EPI_BIAS) and ctx.needs_input_grad[2] and params
@@ -1172,7 +1232,24 @@ class PointwiseConvFn(torch.autograd.Function):
         g = LReluBwdFn.apply(gz, z, ctx.alpha)
     else:
       g = gz
-    gx = PointwiseConvFn.apply(g, w, None, not ctx.wt, 0, ctx.alpha) if ctx.needs_input_grad[0] else None
+    gx = None
+    if _input_grad_wanted(ctx, x):
+      if out_act is not None and not torch.is_grad_enabled() and g.shape[-1] <= 4:
+        gx = _pw_fwd_masked_raw(g, w, not ctx.wt, out_act, ctx.alpha)
+      else:
+        # the node that produced g (the first block's masked backward-data in the gradient penalty's first backward) masks
+        # the cotangent it gets back from us with THIS layer's LeakyReLU output: when we are its only consumer our own
+        # backward applies that mask in its epilogue and tells the producer so (as _conv_backward does for the convs)
+        node = g.grad_fn
+        premask = (torch.is_grad_enabled() and USE_GP_PREMASK and _State.skip_param_grads and z is not None
+                   and out_act is None and node is not None
+                   and getattr(node, 'tg_masks_with', None) == (z.data_ptr(), tuple(z.shape))
+                   and not getattr(node, 'tg_v_premasked', False))
+        gx = PointwiseConvFn.apply(g, w, None, not ctx.wt, 0, ctx.alpha, z if premask else None)
+        if premask:
+          node.tg_v_premasked = True
+        if out_act is not None:      # a pass this node cannot fuse (third order, or the wide side in): mask differentiably
+          gx = LReluBwdFn.apply(gx, out_act, ctx.alpha)
     gw = None
     if ctx.needs_input_grad[1] and params:
       # y = x @ W: dW = x^T g.  With wt the stored tensor is W^T, so dw = g^T x.
@@ -1191,7 +1268,7 @@ class PointwiseConvFn(torch.autograd.Function):
         gw = PointwiseWgradFn.apply(a, b)
     if need_b:
       gb = _bias_grad(g, bias)
-    return gx, gw, gb, None, None, None
+    return gx, gw, gb, None, None, None, None
 
 
 def _pw_wgrad_into(a, b, out, accumulate):
@@ -1676,10 +1753,13 @@ class AxpbyFn(torch.autograd.Function):
     call('tg_axpby', _p(x), _p(y), _p(out), x.numel(), a, b, _dt(x), _stream(),
          work=('axpby:numel%d' % x.numel(), 0, _nb(x, y, out)))
     ctx.a, ctx.b, ctx.has_y = a, b, y is not None
+    ctx.set_materialize_grads(False)      # no gradient, no work (see first_order_only)
     return out
 
   @staticmethod
   def backward(ctx, g):
+    if g is None:
+      return None, None, None, None
     g = g.contiguous()
     gx = AxpbyFn.apply(g, None, ctx.a, 0.0) if ctx.needs_input_grad[0] else None
     gy = AxpbyFn.apply(g, None, ctx.b, 0.0) if (ctx.has_y and ctx.needs_input_grad[1]) else None
@@ -1688,7 +1768,8 @@ class AxpbyFn(torch.autograd.Function):
 
 def scale(x, a):
   """a * x (the input scaling of maybe_equalized_conv2d / maybe_equalized_fc, nets/pggan_utils.py:236-254)."""
-  return AxpbyFn.apply(x, None, float(a), 0.0)
+  y = AxpbyFn.apply(x, None, float(a), 0.0)
+  return first_order_only(y) if getattr(x, '_tg_first_order_only', False) else y
 
 
 def add(x, y):
@@ -1732,58 +1813,168 @@ def gdrop(x, strength, noise=None, c_logical=None):
   return GDropFn.apply(x.contiguous(), noise.contiguous(), strength, c_logical or c)
 
 
-class RowViewsFn(torch.autograd.Function):
-  """Overlapping row ranges of one batch as VIEWS: x [N, ...] -> x[lo:hi] for every (lo, hi) of ``ranges``.
+def uniform(n, seed, state, lo=0.0, hi=1.0):
+  """-> fp32 [n], lo + (hi - lo) * U[0, 1): Philox4x32-10 keyed by (``seed``, state[0]).  ``state``: int32 [2] device tensor,
+  zero at the start; the kernel advances state[0] (tg_uniform)."""
+  assert state.dtype == torch.int32 and state.numel() == 2
+  out = torch.empty(int(n), dtype=torch.float32, device=state.device)
+  call('tg_uniform', _p(out), int(n), int(seed) & 0xffffffffffffffff, _p(state), float(lo), float(hi), _stream())
+  return out
+
+
+class _RowsJob(ctypes.Structure):
+  _fields_ = [('src', ctypes.c_void_p * 4), ('dst_off', ctypes.c_int64), ('numel', ctypes.c_int64)]
+
+
+_ROWS_MAX_JOBS = 8      # TG_ROWS_MAX_JOBS
+
+
+def assemble_rows(dst, blocks):
+  """dst[lo : lo + rows] = the sum of ``sources`` (contiguous [rows, ...] tensors of dst's dtype; none: zeros) for every
+  (lo, rows, sources) of ``blocks`` -- tg_rows_assemble: one launch per eight blocks, whatever the mix of copies, sums and
+  zero fills.  More than four sources of a block chain through dst."""
+  assert dst.is_contiguous()
+  per = dst[0].numel() if dst.shape[0] else 0
+  waves, keep = [[]], []      # a block with more than four sources continues in a LATER launch: its jobs read what the first wrote
+  for lo, rows, sources in blocks:
+    if rows == 0:
+      continue
+    src = []
+    for t in sources:
+      assert t.dtype == dst.dtype and t.numel() == rows * per, (t.shape, t.dtype, dst.shape, dst.dtype, rows)
+      t = t if t.is_contiguous() else t.contiguous()
+      keep.append(t)
+      src.append(t)
+    wave = 0
+    while wave == 0 or src:
+      head, src = src[:3 if wave else 4], src[3 if wave else 4:]
+      ptrs = ([dst.data_ptr() + lo * per * dst.element_size()] if wave else []) + [_p(t) for t in head]
+      if wave == len(waves):
+        waves.append([])
+      waves[wave].append((ptrs, lo * per, rows * per))
+      wave += 1
+  for jobs in waves:
+    for k in range(0, len(jobs), _ROWS_MAX_JOBS):
+      part = jobs[k:k + _ROWS_MAX_JOBS]
+      arr = (_RowsJob * len(part))()      # kept alive across the call
+      moved = 0
+      for j, (ptrs, off, numel) in enumerate(part):
+        for q, ptr in enumerate(ptrs):
+          arr[j].src[q] = ptr
+        arr[j].dst_off, arr[j].numel = off, numel
+        moved += (len(ptrs) + 1) * numel * dst.element_size()
+      call('tg_rows_assemble', ctypes.addressof(arr), len(part), _p(dst), _dt(dst), _stream(),
+           work=('rows_assemble:jobs%d:numel%d' % (len(part), sum(j[2] for j in part)), 0, moved))
+  return dst
+
+
+def _rows_out(d, spec):
+  """One output of ``rows``: a view for a (lo, hi) range, a new tensor for a tuple of ranges."""
+  if isinstance(spec[0], int):
+    return d.narrow(0, spec[0], spec[1] - spec[0])
+  out = torch.empty((sum(hi - lo for lo, hi in spec),) + tuple(d.shape[1:]), dtype=d.dtype, device=d.device)
+  blocks, off = [], 0
+  for lo, hi in spec:
+    blocks.append((off, hi - lo, [d.narrow(0, lo, hi - lo)]))
+    off += hi - lo
+  return assemble_rows(out, blocks)
+
+
+class RowsFn(torch.autograd.Function):
+  """Row ranges of one batch x [N, ...], each output either a VIEW x[lo:hi] (spec (lo, hi)) or a new tensor made of several
+  ranges one after the other (spec ((lo, hi), ...): a repeat, a reordering).
 
   The generator's batch [s_cyc; s'; t'; t_cyc] feeds the two discriminators ([s_cyc; s'] and [t'; t_cyc]), the re-encoding
-  pass ([s'; t']) and the cycle losses (s_cyc, t_cyc) (twingan.py:198-288): as torch.cat inputs that was three 12.5 MB
-  copies forward and, backward, a chain of framework adds plus the 25 MB cat of the chunks' gradients.  Here the consumers
-  read the batch in place, and the backward writes every row block of the gradient ONCE: the sum of the (at most two)
-  incoming gradients that cover it, by tg_axpby straight into its rows."""
+  pass ([s'; t']) and the cycle losses (s_cyc, t_cyc); the encoder's batch [E(s); E(t)] feeds the content losses (each half)
+  and, repeated, the four generator passes (twingan.py:198-288).  As framework chunks / cats that was a copy per consumer
+  forward and, backward, a chain of framework adds, zero fills and the cat of the chunks' gradients.  Here the range
+  consumers read the batch in place, the repeats are one launch, and the backward writes every row block of the gradient
+  ONCE -- the sum of all the incoming gradients that cover it -- in one launch (assemble_rows)."""
 
   @staticmethod
-  def forward(ctx, x, ranges):
+  def forward(ctx, x, specs):
     assert x.is_contiguous()
-    ctx.ranges, ctx.shape = tuple(ranges), tuple(x.shape)
-    d = x.detach()      # the outputs are views of the storage, not autograd views of the input (nothing is modified in place)
-    return tuple(d.narrow(0, lo, hi - lo) for lo, hi in ranges)
+    ctx.specs, ctx.shape = specs, tuple(x.shape)
+    ctx.set_materialize_grads(False)      # an unused output contributes nothing: no zero tensor is made for it
+    d = x.detach()      # the views are views of the storage, not autograd views of the input (nothing is modified in place)
+    return tuple(_rows_out(d, spec) for spec in specs)
 
   @staticmethod
   @torch.autograd.function.once_differentiable
   def backward(ctx, *grads):
     n = ctx.shape[0]
-    live = [(lo, hi, g.contiguous()) for (lo, hi), g in zip(ctx.ranges, grads) if g is not None]
-    cuts = sorted({0, n} | {lo for lo, _, _ in live} | {hi for _, hi, _ in live})
-    gx = torch.empty(ctx.shape, dtype=live[0][2].dtype, device=live[0][2].device)
-    for a, b in zip(cuts[:-1], cuts[1:]):
-      src = [g.narrow(0, a - lo, b - a) for lo, hi, g in live if lo <= a and b <= hi]
-      dst = gx.narrow(0, a, b - a)
-      if not src:
-        dst.zero_()
-      elif len(src) == 1:
-        dst.copy_(src[0])
+    pieces = []      # (lo, hi, gradient rows)
+    for spec, g in zip(ctx.specs, grads):
+      if g is None:
+        continue
+      g = g.contiguous()
+      if isinstance(spec[0], int):
+        pieces.append((spec[0], spec[1], g))
       else:
-        acc = src[0]
-        for k, g in enumerate(src[1:]):
-          call('tg_axpby', _p(acc), _p(g), _p(dst), dst.numel(), 1.0, 1.0, _dt(dst), _stream(),
-               work=('axpby:numel%d' % dst.numel(), 0, _nb(acc, g, dst)))
-          acc = dst
+        off = 0
+        for lo, hi in spec:
+          pieces.append((lo, hi, g.narrow(0, off, hi - lo)))
+          off += hi - lo
+    if not pieces:
+      return None, None
+    if len(pieces) == 1 and pieces[0][:2] == (0, n):
+      return pieces[0][2], None
+    cuts = sorted({0, n} | {lo for lo, _, _ in pieces} | {hi for _, hi, _ in pieces})
+    gx = torch.empty(ctx.shape, dtype=pieces[0][2].dtype, device=pieces[0][2].device)
+    assemble_rows(gx, [(a, b - a, [g.narrow(0, a - lo, b - a) for lo, hi, g in pieces if lo <= a and b <= hi])
+                       for a, b in zip(cuts[:-1], cuts[1:])])
     return gx, None
 
 
-def row_views(x, ranges):
-  """-> a tuple of views x[lo:hi]; see RowViewsFn.  Without a tape they are plain narrows."""
+def rows(x, specs):
+  """-> a tuple, one tensor per spec: x[lo:hi] as a view for (lo, hi), the listed ranges one after the other as a new tensor
+  for ((lo, hi), ...); see RowsFn."""
+  specs = tuple(tuple(sp) if isinstance(sp[0], int) else tuple(tuple(r) for r in sp) for sp in specs)
+  x = x.contiguous()
   if not (torch.is_grad_enabled() and x.requires_grad):
-    return tuple(x.narrow(0, lo, hi - lo) for lo, hi in ranges)
-  return RowViewsFn.apply(x, tuple(ranges))
+    return tuple(_rows_out(x, spec) for spec in specs)
+  return RowsFn.apply(x, specs)
+
+
+def row_views(x, ranges):
+  """-> a tuple of views x[lo:hi]."""
+  return rows(x, ranges)
+
+
+class CatRowsFn(torch.autograd.Function):
+  """tf.concat(tensors, 0): one launch forward; every input's gradient is a row range of the incoming one (a view)."""
+
+  @staticmethod
+  def forward(ctx, *tensors):
+    ctx.rows = [t.shape[0] for t in tensors]
+    return _cat_rows_copy(tensors)
+
+  @staticmethod
+  def backward(ctx, g):
+    out, off = [], 0
+    for k, r in enumerate(ctx.rows):
+      out.append(g.narrow(0, off, r) if ctx.needs_input_grad[k] else None)
+      off += r
+    return tuple(out)
+
+
+def _cat_rows_copy(tensors):
+  t0 = tensors[0]
+  out = torch.empty((sum(t.shape[0] for t in tensors),) + tuple(t0.shape[1:]), dtype=t0.dtype, device=t0.device)
+  blocks, off = [], 0
+  for t in tensors:
+    blocks.append((off, t.shape[0], [t.detach()]))
+    off += t.shape[0]
+  return assemble_rows(out, blocks)
 
 
 def cat_rows(tensors):
-  """torch.cat(tensors, 0) -- or, when the tensors already sit one after the other in one allocation (the trainer's static
-  input buffers under graph replay) and no tape is involved, a view of those rows: no copy."""
+  """torch.cat(tensors, 0) -- a view of the rows when the tensors already sit one after the other in one allocation (the
+  trainer's static input buffers under graph replay) and no tape is involved, else one tg_rows_assemble launch."""
   t0 = tensors[0]
-  if all(t.is_contiguous() and not t.requires_grad and t.dtype == t0.dtype and t.shape[1:] == t0.shape[1:]
-         and t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr() for t in tensors):
+  assert all(t.dtype == t0.dtype and t.shape[1:] == t0.shape[1:] for t in tensors), [(t.shape, t.dtype) for t in tensors]
+  taped = torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
+  if not taped and all(t.is_contiguous() and t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr() for t in tensors):
     end = t0.data_ptr() + t0.numel() * t0.element_size()
     for t in tensors[1:]:
       if t.data_ptr() != end:
@@ -1791,7 +1982,7 @@ def cat_rows(tensors):
       end += t.numel() * t.element_size()
     else:
       return torch.as_strided(t0, (sum(t.shape[0] for t in tensors),) + tuple(t0.shape[1:]), t0.stride())
-  return torch.cat(tensors, dim=0)
+  return CatRowsFn.apply(*tensors) if taped else _cat_rows_copy(tensors)
 
 
 class CastFn(torch.autograd.Function):
@@ -1828,11 +2019,14 @@ class MbstdFn(torch.autograd.Function):
     call('tg_mbstd_fwd', _p(x), _p(out), None, n, groups, h * w, c, cpad, _mbstd_eps(x.dtype), _dt(x), _stream(),
          work=('mbstd_fwd' + _shape_tag(x), 0, _nb(x, out)))
     ctx.cpad, ctx.groups = cpad, groups
+    ctx.set_materialize_grads(False)      # see Conv2dFn: the gradient penalty's second backward brings none
     ctx.save_for_backward(x)
     return out
 
   @staticmethod
   def backward(ctx, gout):
+    if gout is None:
+      return None, None, None
     x, = ctx.saved_tensors
     return MbstdBwdFn.apply(gout.contiguous(), x, ctx.cpad, ctx.groups), None, None
 

@@ -164,23 +164,25 @@ def forward_generators(P, sources, targets, cfg, style_noise=None):
   # hands to the generator / the losses becomes a leaf; its low-resolution half resumes in segment 1, the rest in 2
   e, ep = pggan.encoder_before_classification(P, x, ('s', 't', b, 2), cfg, cuts=(1, 2))
   e = ops.Cuts.cut(e, 1)
-  es, et = e.chunk(2)
   # Batch order of the generator pass.  With a stateless normaliser (instance / layer norm) the four passes commute and run
   # as [s_cyc; s'; t'; t_cyc], which makes the re-encoding batch [s'; t'] a row range too.  Batch norm / renorm update their
   # moving statistics pass by pass, so there the reference's tower order stays ([s'; s_cyc; t'; t_cyc], twingan.py:233-269)
   # and [s'; t'] is the one copy left.
   cyc_first = 'batch' not in cfg.generator_norm_type
+  # E(s), E(t) for the content losses (views) and the generator's batch of contents (one launch; its gradient and the two
+  # halves' meet in ONE launch of the backward, ops.RowsFn)
+  s_rows, t_rows = (0, b), (b, 2 * b)
+  es, et, content = ops.rows(e, [s_rows, t_rows, (s_rows, t_rows, s_rows, t_rows) if cyc_first else (t_rows, s_rows, s_rows, t_rows)])
   cond = rand = None
   if cfg.use_style_embedding:
     # twingan.py:201-267: style encoder on s / t (one batch, domains s|t); s' and t' are generated with ONE random
     # N(0,1) embedding, the cycle images with the encoded style of their own input
     st, _ = pggan.encoder(P, x, ('s', 't', b, 2), cfg, 'encoder_style')
-    style_s, style_t = st.chunk(2)
+    style_s, style_t = ops.rows(st, [s_rows, t_rows])
     rand = style_noise if style_noise is not None else torch.randn(b, cfg.style_embed_size, dtype=torch.float32,
                                                                   device=x.device)
-    cond = torch.cat([style_s, rand, rand, style_t] if cyc_first else [rand, style_s, rand, style_t], dim=0)
+    cond = ops.cat_rows([style_s, rand, rand, style_t] if cyc_first else [rand, style_s, rand, style_t])
   # UNet skips: generator group k reads encoder group (s, t, s, t)[k] / (t, s, s, t)[k] of the [s; t] encoder batch -- no copies
-  content = torch.cat([e, e] if cyc_first else [et, es, es, et], dim=0)
   out, _ = pggan.generator(P, content, ('s', 't', 2 * b, 4), cfg, ep if cfg.use_unet else None,
                            unet_groups=(b, (0, 1, 0, 1) if cyc_first else (1, 0, 0, 1)), cond=cond)
   out = out.contiguous()
@@ -188,7 +190,7 @@ def forward_generators(P, sources, targets, cfg, style_noise=None):
   v = ops.row_views(out, rows)
   s_cycle, s_prime = (v[0], v[1]) if cyc_first else (v[1], v[0])
   t_prime, t_cycle = v[2], v[3]
-  primes = v[6] if cyc_first else torch.cat([s_prime, t_prime], dim=0)
+  primes = v[6] if cyc_first else ops.cat_rows([s_prime, t_prime])
   # both_s / both_t: (the cycle and the prime image of a domain as one tensor, "the cycle image comes first")
   return dict(es=es, et=et, s_prime=s_prime, s_cycle=s_cycle, t_prime=t_prime, t_cycle=t_cycle, random_style_embed=rand,
               both_s=(v[4], cyc_first), primes=primes, both_t=(v[5], False))
@@ -248,21 +250,21 @@ def generator_loss(P, sources, targets, cfg, style_noise=None, distill_embed_s=N
   # re-encode s' in domain s and t' in domain t as one batch (twingan.py:275-288): rows [s'; t'] of the generator's batch
   primes = o['primes']
   e2, _ = pggan.encoder_before_classification(P, primes, ('s', 't', b, 2), cfg)
-  e_sp, e_tp = e2.chunk(2)
+  e_sp, e_tp = ops.rows(e2, [(0, b), (b, 2 * b)])
   if cfg.l_content_weight:
     terms['l_content_s'] = ops.abs_diff_mean(o['es'], e_tp, cfg.l_content_weight)
     terms['l_content_t'] = ops.abs_diff_mean(o['et'], e_sp, cfg.l_content_weight)
     if cfg.use_style_embedding:      # twingan.py:495-505: the style read back from s' / t' must be the random one
       st2, _ = pggan.encoder(P, primes, ('s', 't', b, 2), cfg, 'encoder_style')
-      st_sp, st_tp = st2.chunk(2)
+      st_sp, st_tp = ops.rows(st2, [(0, b), (b, 2 * b)])
       terms['l_style_s'] = ops.abs_diff_mean(o['random_style_embed'], st_sp.contiguous(), cfg.l_content_weight)
       terms['l_style_t'] = ops.abs_diff_mean(o['random_style_embed'], st_tp.contiguous(), cfg.l_content_weight)
   if cfg.do_encoder_distillation:
     # twingan.py:207-230,290-298: both heads on the original and the re-encoded content (each head one batch: original
     # then prime); the cosine-distance terms only for the datasets that carry embeddings (:507-521)
     hs, ht = 'encoder_content/encoder_distillation_source', 'encoder_content/encoder_distillation_target'
-    d_s, d_sp = pggan.encoder_classification(P, torch.cat([o['es'], e_sp]), ('s', 's', b, 2), cfg, hs)[0].chunk(2)
-    d_t, d_tp = pggan.encoder_classification(P, torch.cat([o['et'], e_tp]), ('t', 't', b, 2), cfg, ht)[0].chunk(2)
+    d_s, d_sp = ops.rows(pggan.encoder_classification(P, ops.cat_rows([o['es'], e_sp]), ('s', 's', b, 2), cfg, hs)[0], [(0, b), (b, 2 * b)])
+    d_t, d_tp = ops.rows(pggan.encoder_classification(P, ops.cat_rows([o['et'], e_tp]), ('t', 't', b, 2), cfg, ht)[0], [(0, b), (b, 2 * b)])
     if cfg.hw >= cfg.distillation_start_hw:
       w = cfg.distillation_weight
       if distill_embed_s is not None:
@@ -308,14 +310,14 @@ def _d_domain_terms(P, cfg, terms, d, top, real, prime, cyc, a, cyc_gan, both=No
     # D(real), D(cyc), D(prime) of one domain share weights: one batch, one minibatch-stddev group per call
     if cyc_gan:
       if both is None:
-        both, cyc_first = torch.cat([cyc, prime], dim=0), True
-      pred, _ = pggan.discriminator(P, torch.cat([real, both], dim=0), cfg, top, groups=3, cut_seg=1, block_end_points=False)
+        both, cyc_first = ops.cat_rows([cyc, prime]), True
+      pred, _ = pggan.discriminator(P, ops.cat_rows([real, both]), cfg, top, groups=3, cut_seg=1, block_end_points=False)
       gc, gp = (1, 2) if cyc_first else (2, 1)      # groups of the batched prediction: 0 = real
       names, jobs = [], []
       _real_fake_jobs(names, jobs, '_cycle_' + d, gc, 0, cfg)      # only_real_fake_loss=True (twingan.py:466-474)
       _real_fake_jobs(names, jobs, '_prime_' + d, gp, 0, cfg)
     else:
-      pred, _ = pggan.discriminator(P, torch.cat([real, prime], dim=0), cfg, top, groups=2, cut_seg=1, block_end_points=False)
+      pred, _ = pggan.discriminator(P, ops.cat_rows([real, prime]), cfg, top, groups=2, cut_seg=1, block_end_points=False)
       names, jobs = [], []
       _real_fake_jobs(names, jobs, '_prime_' + d, 1, 0, cfg)
     if cfg.wgan_drift_loss_weight and cfg.loss_architecture in ('wgan_gp', 'wgan'):      # image_generation.py:360-367
@@ -333,9 +335,9 @@ def _d_domain_gp(P, cfg, terms, d, top, real, prime, a, noise=None, name=None):
   if cfg.loss_architecture == 'dragan':
     if noise is None:
       noise = (torch.rand(real.shape, dtype=torch.float32, device=real.device) * 2.0 - 1.0).to(real.dtype)
-    interp = ops.dragan_interpolates(real, noise.contiguous(), a).requires_grad_(True)
+    interp = ops.first_order_only(ops.dragan_interpolates(real, noise.contiguous(), a).requires_grad_(True))
   else:
-    interp = ops.sample_lerp(real, prime, a).requires_grad_(True)             # image_generation.py:420-424
+    interp = ops.first_order_only(ops.sample_lerp(real, prime, a).requires_grad_(True))             # image_generation.py:420-424
   with ops.second_order():
     pi, _ = pggan.discriminator(P, interp, cfg, top, block_end_points=False)
   ones = ops.fill(pi.shape, 1.0, pi.dtype, pi.device)
@@ -386,6 +388,10 @@ class Trainer:
       rank = torch.distributed.get_rank(process_group) if torch.distributed.is_initialized() else 0
       with torch.cuda.device(self.device):
         torch.cuda.manual_seed(1000003 * (seed + 1) + rank)
+    # the device draws of this clone (GP alphas): Philox keyed by (seed, clone), counter on the device
+    rank = torch.distributed.get_rank(process_group) if (world_size > 1 and torch.distributed.is_initialized()) else 0
+    self._rng_seed = 1000003 * (seed + 1) + rank
+    self._rng_state = torch.zeros(2, dtype=torch.int32, device=self.device)
     self.reducer = GradReducer(world_size, process_group)
     self.store = self._declare(ParamStore(self.device), cfg).build(seed)
     self.P = self.store.P
@@ -440,6 +446,11 @@ class Trainer:
     self.adam_t = int(t)
     self._adam_step_dev.fill_(int(t))
 
+  def _uniform(self, n):
+    """n fp32 U[0, 1) draws on the device (ops.uniform: the draw counter lives on the device, so a captured step draws
+    new numbers on every replay)."""
+    return ops.uniform(n, self._rng_seed, self._rng_state)
+
   def _adam(self, group):
     """tf.train.AdamOptimizer apply (model/model_inheritor.py:537-542) on the group's flat buffers, then
     refresh the bf16 weight packs of the convs that just moved."""
@@ -472,10 +483,11 @@ class Trainer:
         loss, terms = self._generator_loss(sources, targets)
       else:
         b = targets.shape[0]
-        if gp_alpha_s is None:
-          gp_alpha_s = torch.rand(b, dtype=torch.float32, device=self.device)
-        if gp_alpha_t is None:
-          gp_alpha_t = torch.rand(b, dtype=torch.float32, device=self.device)
+        if gp_alpha_s is None and gp_alpha_t is None:      # tf.random_uniform([batch]) per domain (image_generation.py:420-424)
+          gp_alpha_s, gp_alpha_t = self._uniform(2 * b).split(b)
+        elif gp_alpha_s is None or gp_alpha_t is None:
+          draw = self._uniform(b)
+          gp_alpha_s, gp_alpha_t = (draw if gp_alpha_s is None else gp_alpha_s), (draw if gp_alpha_t is None else gp_alpha_t)
         loss, terms = self._discriminator_loss(sources, targets, gp_alpha_s, gp_alpha_t)
       out = (loss.detach(), {k: v.detach() for k, v in terms.items()})
       if group == 'g' and self.cfg.use_gdrop:
@@ -545,7 +557,7 @@ class Trainer:
     s = self.store
     return dict(flat={g: s.flat[g].clone() for g in s.GROUPS}, m={g: s.m[g].clone() for g in s.GROUPS},
                 v={g: s.v[g].clone() for g in s.GROUPS}, state={k: v.clone() for k, v in s.state.items()},
-                step=self._adam_step_dev.clone(), lr=self._lr_t_dev.clone(),
+                step=self._adam_step_dev.clone(), lr=self._lr_t_dev.clone(), draws=self._rng_state.clone(),
                 host=(self.n_critic_counter, self.global_step, self.adam_t), rng=torch.cuda.get_rng_state(self.device))
 
   def _restore(self, snap):
@@ -560,6 +572,7 @@ class Trainer:
         s.state[k].copy_(v)
       self._adam_step_dev.copy_(snap['step'])
       self._lr_t_dev.copy_(snap['lr'])
+      self._rng_state.copy_(snap['draws'])
     self.n_critic_counter, self.global_step, self.adam_t = snap['host']
     torch.cuda.set_rng_state(snap['rng'], self.device)
     for g in s.GROUPS:                      # the packs follow the restored masters
