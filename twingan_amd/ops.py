@@ -2546,9 +2546,12 @@ class GemmFn(torch.autograd.Function):
     g = g.contiguous()
     ta, tb = ctx.ta, ctx.tb
     ga = gb = None
-    if ctx.needs_input_grad[0]:
+    # ops.no_param_grads (the gradient penalty's inner gradient): a leaf operand is a parameter -- its gradient arrives
+    # through the double backward, this pass would compute it only to drop it
+    skip = _State.skip_param_grads
+    if ctx.needs_input_grad[0] and not (skip and a.is_leaf):
       ga = GemmFn.apply(b, g, tb, True) if ta else GemmFn.apply(g, b, False, not tb)
-    if ctx.needs_input_grad[1]:
+    if ctx.needs_input_grad[1] and not (skip and b.is_leaf):
       gb = GemmFn.apply(g, a, True, ta) if tb else GemmFn.apply(a, g, not ta, False)
     return ga, gb, None, None
 
@@ -2566,7 +2569,7 @@ class AddRowBiasFn(torch.autograd.Function):
   @staticmethod
   def backward(ctx, g):
     g = g.contiguous()
-    return g, (ChannelSumFn.apply(g) if ctx.needs_input_grad[1] else None)
+    return g, (ChannelSumFn.apply(g) if (ctx.needs_input_grad[1] and not _State.skip_param_grads) else None)
 
 
 class FcFn(torch.autograd.Function):
