@@ -289,6 +289,59 @@ def test_bench_line_contract():
     assert "'%s'" % flag in src
 
 
+def test_bench_line_stays_small_and_names_the_dominant_family():
+  """Round 5's line was 20.6 KB and the driver recorded `parsed: null`.  The launch records of a roofline pass are rebuilt
+  from the committed per-shape table of that round (profiles/r05_z_shapes_eager_step.json: launches, mean duration, rates
+  per (entry point, layer shape, n)) with the kernel symbols the dispatch test pins (tests/golden/bench_dispatch_kernels.json);
+  bench.summarize_launches must give a compact object -- scalars + six family rows, every template instantiation of a kernel in
+  ONE family -- and the whole line must stay below bench.MAX_LINE_BYTES with the tables in a side file."""
+  import json
+  import re
+  import sys
+  import tempfile
+  sys.path.insert(0, ROOT)
+  import bench
+  rows = json.load(open(os.path.join(ROOT, 'profiles', 'r05_z_shapes_eager_step.json')))
+  pins = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'bench_dispatch_kernels.json')))
+  rec = []
+  for r in rows:
+    m = re.match(r'(\w+)\[(.*)\]$', r['kernel'])
+    name, tag = (m.group(1), m.group(2)) if m else (r['kernel'], '')
+    ms = r['avg_us'] * 1e-3
+    kname = ''
+    if name.startswith('tg_conv2d'):
+      parts = tag.split(':')
+      shape = ':'.join(p for p in parts if re.match(r'(k\d|c\d|hw\d)', p))
+      n = next((p[1:] for p in parts if re.match(r'n[\d+]+$', p)), '')
+      kname = pins.get(shape, {}).get(name, {}).get(n, 'conv_tile_kernel<3,32,32,1>')
+    for _ in range(2 * r['launches']):      # two instrumented steps
+      rec.append((name, tag, r['tflops'] * 1e12 * ms * 1e-3, r['gbs'] * 1e9 * ms * 1e-3, ms, kname))
+  pmc = bench.load_pmc()
+  roof, tables = bench.summarize_launches(rec, 2, pmc=pmc)
+  assert roof['bound'] in ('hbm', 'mfma') and abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
+  assert len(roof['families']) <= 6 and all('<' not in f['kernel'] for f in roof['families'])
+  assert roof['kernel'] == roof['families'][0]['kernel']
+  # the forward / backward-data tile kernel is what the step spends most time in once its instantiations are one family
+  assert roof['kernel'] == 'conv_tile_kernel', roof['kernel']
+  assert 0.0 < roof['conv_mfma_util_time_weighted'] < 1.0 and 0.0 < roof['step_roofline_frac'] < 1.0
+  assert not any(isinstance(v, (list, dict)) for k, v in roof.items() if k != 'families')
+  assert len(rows) - 4 <= len(tables['shapes']) <= len(rows) and len(tables['symbols']) >= len(tables['families'])
+  line = dict(metric=bench.METRIC, value=1032.2, unit='images/sec', n_gpus=1, steps=20, warmup=5, ms_per_step=15.5,
+              higher_is_better=True, scaling='weak', vs_baseline=None, dtype='bf16', data='synthetic',
+              config={'workload': 'x' * 300, 'global_batch': 16}, roofline=roof,
+              cpu_baseline=dict(value=0.9, unit='images/sec', cores=32, kind='port', sample='y' * 200,
+                                literal_schedule=dict(value=0.4, unit='images/sec', sample='z' * 150)),
+              timed_regions=dict(repeats=3, steps_each=20, reported='median', value_max=1.0, value_min=1.0))
+  assert len(json.dumps(line)) < bench.MAX_LINE_BYTES < 8192, len(json.dumps(line))
+  with tempfile.TemporaryDirectory() as td:
+    os.environ['TG_BENCH_TABLES'] = os.path.join(td, 't.json')
+    try:
+      path = bench.write_tables(tables, 3)
+    finally:
+      del os.environ['TG_BENCH_TABLES']
+    assert json.load(open(path))['shapes'][0]['kernel'] == tables['shapes'][0]['kernel']
+
+
 def test_bench_gpus_n_spawns_n_ranks():
   """`python bench.py --gpus 2` with no launcher in the environment starts 2 ranks itself (the reference's
   one-process --num_clones=N, deployment/model_deploy.py:186-239, as one process per GPU).  --launch-check runs the
