@@ -100,7 +100,15 @@ typedef struct {
   int32_t algo;               /* TG_ALGO_*                                                   */
   int32_t epilogue;           /* TG_EPI_* bits (forward only)                                */
   float lrelu_alpha;          /* util_misc.py:68 (0.2)                                       */
+  int32_t groups;             /* 0 / 1: one weight set.  G > 1 (<= TG_MAX_GROUPS, n % G == 0): the batch is G equal image
+                                 ranges and range g is convolved with weight set g -- `w` (master [G][kh][kw][cin][cout] or
+                                 G packs back to back: tg_conv2d_pack_elems counts all of them), `bias` [G][cout], `gw`, `gbias`
+                                 hold G sets; every other operand is the plain [n, ...] tensor.  The reference builds
+                                 discriminator_s and discriminator_t as two towers of identical layers (twingan.py:105-110,
+                                 image_generation.py:348-439 per domain): G = 2 runs a layer of both as one launch.  Entry
+                                 points whose kernel cannot select the set per image launch once per group. */
 } TgConvDesc;
+#define TG_MAX_GROUPS 4
 
 /* y = epilogue(conv(x, w)).  DIRECT: w = fp32 HWIO master (rounded to bf16 on read when dtype is
  * bf16).  MFMA: w = bf16 pack from tg_conv2d_pack_weights(mode 0).  bias: fp32 [cout] or NULL. */

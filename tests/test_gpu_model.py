@@ -1856,3 +1856,55 @@ def test_discriminator_sign_bit_path_equals_the_tensor_path(precision):
     den = sum(float((out[False][grp][1][k].double() ** 2).sum()) for k in out[True][grp][1])
     assert (num / den) ** 0.5 < 1e-5, (grp, (num / den) ** 0.5)
   tr.close()
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'fp16'])
+def test_discriminator_pair_equals_the_two_separate_discriminators(precision):
+  """From 32 x 32 down the two discriminators run as ONE batch through grouped convs (pggan.discriminator_pair: the stacked
+  twin variables of ParamStore.pairs, TgConvDesc.groups = 2 -- half the launches of the two towers the reference builds,
+  twingan.py:105-110, image_generation.py:348-439).  Every loss term and every gradient -- generator step (through the
+  frozen discriminators) and discriminator step (batched pass + the gradient penalty's double backward) -- equals the
+  per-domain path's: the forward values bit for bit (per-image arithmetic), gradients to fp32 summation order."""
+  from twingan_amd import ops, pggan
+  from twingan_amd import twingan as T
+  cfg, rcfg, tr, Pref, dev, ref = make(dict(hw=64, max_ch=32), precision, seed=5, batch=2)
+  assert pggan.discriminator_pair_supported(tr.P, cfg, cfg.hw)
+  assert tr.P.pairs['discriminator_*/encoder_block_32x32x32/Conv/weights'].shape == (2, 3, 3, 32, 32)
+  out, seen = {}, []
+  orig_call = ops.call
+
+  def spy(name, *a, **k):
+    seen.append(name)
+    return orig_call(name, *a, **k)
+  for pair in (True, False):
+    saved, pggan.USE_DISCRIMINATOR_PAIR = pggan.USE_DISCRIMINATOR_PAIR, pair
+    ops.call = spy
+    del seen[:]
+    try:
+      res = {}
+      for grp in ('g', 'd'):
+        tr.store.zero_grad(grp)
+        tr._set_requires_grad(g=grp == 'g', d=grp == 'd')
+        if grp == 'g':
+          loss, terms = T.generator_loss(tr.P, dev['s'], dev['t'], cfg)
+        else:
+          loss, terms = T.discriminator_loss(tr.P, dev['s'], dev['t'], cfg, dev['a_s'], dev['a_t'])
+        loss.backward()
+        res[grp] = ({k: float(v) for k, v in terms.items()}, {k: v.clone() for k, v in tr.store.grad_dict().items()
+                                                               if k in tr.store.names(grp)})
+      out[pair] = (res, seen.count('tg_conv2d_fwd') + seen.count('tg_conv2d_fwd_pool') + seen.count('tg_conv2d_fwd_pool_signs'))
+    finally:
+      ops.call = orig_call
+      pggan.USE_DISCRIMINATOR_PAIR = saved
+  assert out[True][1] < out[False][1], (out[True][1], out[False][1])      # fewer conv calls with the pair
+  for grp in ('g', 'd'):
+    ta, tb = out[True][0][grp][0], out[False][0][grp][0]
+    # losses: same forward tensors; the sums end in fp32 atomics on the 16-bit paths (last-ulp run-to-run noise)
+    assert set(ta) == set(tb) and all(abs(ta[k] - tb[k]) <= 2e-6 * max(1.0, abs(tb[k])) for k in tb), (grp, ta, tb)
+    ga, gb = out[True][0][grp][1], out[False][0][grp][1]
+    num = sum(float(((ga[k] - gb[k]).double() ** 2).sum()) for k in ga)
+    den = sum(float((gb[k].double() ** 2).sum()) for k in ga)
+    assert (num / den) ** 0.5 < 1e-5, (grp, (num / den) ** 0.5)
+    worst = max(rel_l2(ga[k], gb[k]) for k in ga if float(gb[k].abs().max()) > 0)
+    assert worst < 1e-3, (grp, worst)
+  tr.close()

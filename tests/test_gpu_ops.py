@@ -2126,3 +2126,83 @@ def test_deferred_slab_reductions_equal_immediate_ones(ops):
   assert rel_l2(host(later), host(now)) < 1e-6
   for m in many:
     assert torch.equal(m, ref)
+
+
+# ---------------------------------------------------------------------------------------------- grouped convs
+GROUPED_CASES = [
+    # n (both groups), hw, cin, cout, k, padding        -- what the two discriminators run from 32 x 32 down
+    (4, 32, 16, 32, 3, 'SAME'),      # conv_tile
+    (4, 16, 32, 32, 3, 'SAME'),      # conv_tile
+    (4, 8, 32, 32, 3, 'SAME'),       # conv_img
+    (6, 4, 24, 32, 3, 'SAME'),       # conv_small (the minibatch-stddev layer's padded channel count is no multiple of 16)
+    (4, 4, 32, 32, 4, 'VALID'),      # the dense layer
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', range(len(GROUPED_CASES)))
+def test_grouped_conv_equals_one_call_per_weight_set(ops, dtype, case):
+  """TgConvDesc.groups = 2 (a stacked [2, kh, kw, cin, cout] kernel: the layers of discriminator_s and discriminator_t,
+  twingan.py:105-110, as ONE call over the batch [D_s rows; D_t rows]): every conv entry point the discriminators' layers
+  reach gives each image range exactly what the single-set call with its own weights gives it -- bit for bit in the
+  forward and backward-data forms (per-image arithmetic), to fp32 summation order in the filter / bias gradients."""
+  import twingan_amd.ops as O
+  n, hw, cin, cout, k, padding = GROUPED_CASES[case]
+  g = torch.Generator().manual_seed(500 + case)
+  spec = O.ConvSpec(k, padding)
+  ho = hw if padding == 'SAME' else hw - k + 1
+  h = n // 2
+  x = torch.randn(n, hw, hw, cin, generator=g).to(dtype).to(dev())
+  w2 = (torch.randn(2, k, k, cin, cout, generator=g) * (2.0 / (k * k * cin)) ** 0.5).to(dev())
+  b2 = (torch.randn(2, cout, generator=g) * 0.1).to(dev())
+  gy = torch.randn(n, ho, ho, cout, generator=g).to(dtype).to(dev())
+  epi = O.TG_EPI_BIAS | O.TG_EPI_LRELU
+
+  def per_set(fn):
+    return [fn(i, slice(i * h, (i + 1) * h)) for i in range(2)]
+
+  def same(got, parts):
+    want = torch.cat(parts)
+    assert got.shape == want.shape and torch.equal(got, want), float((got.float() - want.float()).abs().max())
+
+  # forward, bias + LeakyReLU epilogue
+  y = O.conv_fwd_raw(x, w2, b2, spec, epi)
+  same(y, per_set(lambda i, r: O.conv_fwd_raw(x[r].contiguous(), w2[i], b2[i], spec, epi)))
+  # backward-data, plain and with the producer's LeakyReLU mask
+  same(O.conv_bwd_data_raw(gy, w2, tuple(x.shape), spec),
+       per_set(lambda i, r: O.conv_bwd_data_raw(gy[r].contiguous(), w2[i], (h,) + tuple(x.shape[1:]), spec)))
+  same(O.conv_bwd_data_masked_raw(gy, w2, x, spec),
+       per_set(lambda i, r: O.conv_bwd_data_masked_raw(gy[r].contiguous(), w2[i], x[r].contiguous(), spec)))
+  # forward with the mask epilogue (the gradient penalty's second backward)
+  same(O.conv_fwd_masked_raw(x, w2, y, spec),
+       per_set(lambda i, r: O.conv_fwd_masked_raw(x[r].contiguous(), w2[i], y[r].contiguous(), spec)))
+  if padding == 'SAME' and dtype != torch.float32 and hw >= 16:
+    # block ends: pooled output (+ sign bytes), and the backward-data that unpools
+    z, zp = O.conv_fwd_pool_raw(x, w2, b2, spec, epi)
+    ref = per_set(lambda i, r: O.conv_fwd_pool_raw(x[r].contiguous(), w2[i], b2[i], spec, epi))
+    same(z, [p[0] for p in ref])
+    same(zp, [p[1] for p in ref])
+    assert O.conv_fwd_pool_signs_supported(x, w2, spec, epi)
+    sg, zp2 = O.conv_fwd_pool_signs_raw(x, w2, b2, spec, epi)
+    ref = per_set(lambda i, r: O.conv_fwd_pool_signs_raw(x[r].contiguous(), w2[i], b2[i], spec, epi))
+    same(sg, [p[0] for p in ref])
+    same(zp2, [p[1] for p in ref])
+    gzp = torch.randn(n, ho // 2, ho // 2, cout, generator=g).to(dtype).to(dev())
+    out = O.conv_bwd_data_unpool_raw(gzp, sg, w2, x, tuple(x.shape), spec, True)
+    assert out is not None
+    ref = per_set(lambda i, r: O.conv_bwd_data_unpool_raw(gzp[r].contiguous(), sg[r].contiguous(), w2[i], x[r].contiguous(),
+                                                          (h,) + tuple(x.shape[1:]), spec, True))
+    same(out[0], [p[0] for p in ref])
+    same(out[1], [p[1] for p in ref])
+  # filter (+ bias) gradients: into zeroed stacked sinks
+  tol = 1e-6 if dtype == torch.float32 else 2e-5
+  gw = O.conv_bwd_weight_raw(x, gy, spec, groups=2)
+  ref = torch.stack(per_set(lambda i, r: O.conv_bwd_weight_raw(x[r].contiguous(), gy[r].contiguous(), spec)))
+  assert gw.shape == ref.shape and rel_l2(host(gw), host(ref)) < tol
+  if dtype != torch.float32:
+    sink, bsink = torch.zeros_like(w2), torch.zeros_like(b2)
+    O.conv_bwd_weight_raw(x, gy, spec, out=sink, gbias=bsink)
+    assert rel_l2(host(sink), host(ref)) < tol
+    assert rel_l2(host(bsink), host(gy.float().reshape(2, -1, cout).sum(1))) < 1e-3
+    if O.conv_bwd_weight2_raw(x, gy, x[:n].contiguous(), gy[:n].contiguous(), spec, sink, bsink, 3):      # two segments, both grouped
+      assert rel_l2(host(sink), 3.0 * host(ref)) < tol

@@ -39,7 +39,7 @@ def test_ctypes_signatures_cover_header():
 def test_conv_desc_layout_matches_header():
   import ctypes
   from twingan_amd._lib import TgConvDesc
-  assert ctypes.sizeof(TgConvDesc) == 15 * 4      # 14 int32 + 1 float, no padding
+  assert ctypes.sizeof(TgConvDesc) == 16 * 4      # 14 int32 + 1 float + groups, no padding
 
 
 def test_invalid_descriptor_is_rejected_without_gpu():

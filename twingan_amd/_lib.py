@@ -24,7 +24,7 @@ class TgError(RuntimeError):
 
 class TgConvDesc(Structure):
   _fields_ = [(k, c_int32) for k in ('n', 'hin', 'win', 'cin', 'hout', 'wout', 'cout', 'kh', 'kw', 'pad_t', 'pad_l',
-                                     'dtype', 'algo', 'epilogue')] + [('lrelu_alpha', c_float)]
+                                     'dtype', 'algo', 'epilogue')] + [('lrelu_alpha', c_float), ('groups', c_int32)]
 
 
 _P = c_void_p

@@ -95,8 +95,44 @@ static int check_desc(const char* who, const TgConvDesc* d) {
   tg_set_elem_f16(d->dtype == TG_F16);      // read by the MFMA launchers this call reaches
   TG_CHECK(d->algo == TG_ALGO_DIRECT || d->algo == TG_ALGO_MFMA || d->algo == TG_ALGO_MFMA_V1, TG_EINVAL, "%s: algo %d", who,
            d->algo);
+  TG_CHECK(d->groups >= 0 && d->groups <= TG_MAX_GROUPS && (d->groups <= 1 || d->n % d->groups == 0), TG_EINVAL,
+           "%s: groups %d does not divide the batch of %d (at most %d weight sets)", who, d->groups, d->n, TG_MAX_GROUPS);
   return TG_OK;
 }
+
+// ---- weight-set groups (TgConvDesc::groups) ---------------------------------------------------------------------------
+// The batch of a grouped call is G equal image ranges, range g convolved with weight set g (the two discriminators of a
+// TwinGAN step as ONE launch per layer).  Kernels that select the weight set per image take the call whole (*_grouped_native_
+// mfma); every other kernel is launched once per group on that group's rows, so a grouped call is always valid.
+namespace {
+struct Groups {
+  int G;
+  TgConvDesc d1;              // one group's descriptor (n / G images, groups = 1)
+  size_t xin, yout;           // bytes of one group's input / output activations
+  size_t wset[2];             // bytes of one weight set as the forward (mode 0) / backward-data (mode 1) operand
+  size_t wmaster, bias;       // bytes of one fp32 HWIO master / bias row
+  Groups(const TgConvDesc* d) {
+    G = d->groups > 1 ? d->groups : 1;
+    d1 = *d;
+    d1.n = d->n / G;
+    d1.groups = 1;
+    const size_t es = d->dtype == TG_F32 ? 4 : 2;
+    xin = (size_t)d1.n * d->hin * d->win * d->cin * es;
+    yout = (size_t)d1.n * d->hout * d->wout * d->cout * es;
+    wmaster = (size_t)d->kh * d->kw * d->cin * d->cout * sizeof(float);
+    bias = (size_t)d->cout * sizeof(float);
+    for (int m = 0; m < 2; ++m) wset[m] = d->algo == TG_ALGO_DIRECT ? wmaster : tg_conv2d_pack_elems(&d1, m) * 2;
+  }
+};
+template <typename P>
+inline P* at(P* p, size_t bytes) {
+  return p ? reinterpret_cast<P*>(reinterpret_cast<uintptr_t>(p) + bytes) : nullptr;
+}
+inline bool grouped(const TgConvDesc* d) { return d->groups > 1; }
+}  // namespace
+// which grouped calls the MFMA dispatch takes as one launch (conv_mfma.hip); TG_GRP_*: the operation
+enum { TG_GRP_FWD = 0, TG_GRP_DGRAD = 1, TG_GRP_WGRAD = 2 };
+bool tg_conv2d_grouped_native_mfma(const TgConvDesc* d, int op);
 
 static thread_local bool tg_elem_is_f16 = false;
 bool tg_elem_f16() { return tg_elem_is_f16; }
@@ -132,6 +168,12 @@ int tg_conv2d_fwd(const TgConvDesc* d, const void* x, const void* w, const float
   if (rc) return rc;
   TG_CHECK(x && w && y, TG_EINVAL, "tg_conv2d_fwd: null pointer");
   TG_CHECK(tg_aligned16(x) && tg_aligned16(w) && tg_aligned16(y), TG_EALIGN, "tg_conv2d_fwd: pointers must be 16 B aligned");
+  if (grouped(d) && !(d->algo != TG_ALGO_DIRECT && tg_conv2d_grouped_native_mfma(d, TG_GRP_FWD))) {
+    const Groups gr(d);
+    for (int g = 0; g < gr.G && !rc; ++g)
+      rc = tg_conv2d_fwd(&gr.d1, at(x, g * gr.xin), at(w, g * gr.wset[0]), at(bias, g * gr.bias), at(y, g * gr.yout), stream);
+    return rc;
+  }
   if (d->algo != TG_ALGO_DIRECT) return tg_conv2d_fwd_mfma(d, x, w, bias, y, (hipStream_t)stream);
   return tg_conv2d_fwd_direct(d, x, w, bias, y, (hipStream_t)stream);
 }
@@ -143,6 +185,12 @@ int tg_conv2d_fwd_masked(const TgConvDesc* d, const void* x, const void* w, cons
   TG_CHECK(d->epilogue == 0, TG_EINVAL, "tg_conv2d_fwd_masked: no bias / activation epilogue next to the mask");
   TG_CHECK(tg_aligned16(x) && tg_aligned16(w) && tg_aligned16(y) && tg_aligned16(mask_src), TG_EALIGN,
            "tg_conv2d_fwd_masked: pointers must be 16 B aligned");
+  if (grouped(d) && !(d->algo != TG_ALGO_DIRECT && tg_conv2d_fwd_mask_fusable_mfma(d) && tg_conv2d_grouped_native_mfma(d, TG_GRP_FWD))) {
+    const Groups gr(d);
+    for (int g = 0; g < gr.G && !rc; ++g)
+      rc = tg_conv2d_fwd_masked(&gr.d1, at(x, g * gr.xin), at(w, g * gr.wset[0]), at(mask_src, g * gr.yout), at(y, g * gr.yout), stream);
+    return rc;
+  }
   if (d->algo != TG_ALGO_DIRECT && tg_conv2d_fwd_mask_fusable_mfma(d))
     return tg_conv2d_fwd_masked_mfma(d, x, w, mask_src, y, (hipStream_t)stream);
   // not fusable for this shape / algorithm: the plain conv, then the mask in place
@@ -157,6 +205,12 @@ int tg_conv2d_bwd_data(const TgConvDesc* d, const void* gy, const void* w, void*
   TG_CHECK(gy && w && gx, TG_EINVAL, "tg_conv2d_bwd_data: null pointer");
   TG_CHECK(tg_aligned16(gy) && tg_aligned16(w) && tg_aligned16(gx), TG_EALIGN,
            "tg_conv2d_bwd_data: pointers must be 16 B aligned");
+  if (grouped(d) && !(d->algo != TG_ALGO_DIRECT && tg_conv2d_grouped_native_mfma(d, TG_GRP_DGRAD))) {
+    const Groups gr(d);
+    for (int g = 0; g < gr.G && !rc; ++g)
+      rc = tg_conv2d_bwd_data(&gr.d1, at(gy, g * gr.yout), at(w, g * gr.wset[1]), at(gx, g * gr.xin), stream);
+    return rc;
+  }
   if (d->algo != TG_ALGO_DIRECT) return tg_conv2d_bwd_data_mfma(d, gy, w, gx, (hipStream_t)stream);
   return tg_conv2d_bwd_data_direct(d, gy, w, gx, (hipStream_t)stream);
 }
@@ -168,6 +222,12 @@ int tg_conv2d_bwd_data_masked(const TgConvDesc* d, const void* gy, const void* w
   TG_CHECK(gy && w && gx && x_act, TG_EINVAL, "tg_conv2d_bwd_data_masked: null pointer");
   TG_CHECK(tg_aligned16(gy) && tg_aligned16(w) && tg_aligned16(gx) && tg_aligned16(x_act), TG_EALIGN,
            "tg_conv2d_bwd_data_masked: pointers must be 16 B aligned");
+  if (grouped(d) && !(d->algo != TG_ALGO_DIRECT && tg_conv2d_bwd_data_mask_fusable_mfma(d) && tg_conv2d_grouped_native_mfma(d, TG_GRP_DGRAD))) {
+    const Groups gr(d);
+    for (int g = 0; g < gr.G && !rc; ++g)
+      rc = tg_conv2d_bwd_data_masked(&gr.d1, at(gy, g * gr.yout), at(w, g * gr.wset[1]), at(x_act, g * gr.xin), at(gx, g * gr.xin), stream);
+    return rc;
+  }
   if (d->algo != TG_ALGO_DIRECT && tg_conv2d_bwd_data_mask_fusable_mfma(d))
     return tg_conv2d_bwd_data_mfma(d, gy, w, gx, (hipStream_t)stream, x_act);
   // not fusable for this shape / algorithm: plain backward-data, then the mask in place
@@ -177,10 +237,9 @@ int tg_conv2d_bwd_data_masked(const TgConvDesc* d, const void* gy, const void* w
 }
 
 int tg_conv2d_bwd_data_unpool_supported(const TgConvDesc* d) {
-  return d && !check_desc("tg_conv2d_bwd_data_unpool_supported", d) && d->algo != TG_ALGO_DIRECT &&
-                 tg_conv2d_bwd_data_unpool_supported_mfma(d)
-             ? 1
-             : 0;
+  if (!d || check_desc("tg_conv2d_bwd_data_unpool_supported", d) || d->algo == TG_ALGO_DIRECT) return 0;
+  const Groups gr(d);
+  return tg_conv2d_bwd_data_unpool_supported_mfma(&gr.d1) ? 1 : 0;
 }
 
 int tg_conv2d_bwd_data_unpool(const TgConvDesc* d, const void* gy_pooled, const void* y_signs, const void* w, const void* x_act,
@@ -192,6 +251,14 @@ int tg_conv2d_bwd_data_unpool(const TgConvDesc* d, const void* gy_pooled, const 
                (!gy_out || tg_aligned16(gy_out)),
            TG_EALIGN, "tg_conv2d_bwd_data_unpool: pointers must be 16 B aligned");
   TG_CHECK(d->algo != TG_ALGO_DIRECT, TG_ENOSUP, "tg_conv2d_bwd_data_unpool: MFMA path only (tg_conv2d_bwd_data_unpool_supported)");
+  if (grouped(d) && !tg_conv2d_grouped_native_mfma(d, TG_GRP_DGRAD)) {
+    const Groups gr(d);      // one group's pooled gradient is a quarter of its gradient, its sign bytes a sixteenth
+    const size_t es = d->dtype == TG_F32 ? 4 : 2;
+    for (int g = 0; g < gr.G && !rc; ++g)
+      rc = tg_conv2d_bwd_data_unpool(&gr.d1, at(gy_pooled, g * (gr.yout / 4)), at(y_signs, g * (gr.yout / es / 8)), at(w, g * gr.wset[1]),
+                                     at(x_act, g * gr.xin), at(gx, g * gr.xin), at(gy_out, g * gr.yout), stream);
+    return rc;
+  }
   return tg_conv2d_bwd_data_unpool_mfma(d, gy_pooled, y_signs, w, gx, (hipStream_t)stream, x_act, gy_out, nullptr);
 }
 
@@ -204,11 +271,23 @@ int tg_conv2d_bwd_data_unpool_act(const TgConvDesc* d, const void* gy_pooled, co
                (!gy_out || tg_aligned16(gy_out)),
            TG_EALIGN, "tg_conv2d_bwd_data_unpool_act: pointers must be 16 B aligned");
   TG_CHECK(d->algo != TG_ALGO_DIRECT, TG_ENOSUP, "tg_conv2d_bwd_data_unpool_act: MFMA path only (tg_conv2d_bwd_data_unpool_supported)");
+  if (grouped(d) && !tg_conv2d_grouped_native_mfma(d, TG_GRP_DGRAD)) {
+    const Groups gr(d);
+    for (int g = 0; g < gr.G && !rc; ++g)
+      rc = tg_conv2d_bwd_data_unpool_act(&gr.d1, at(gy_pooled, g * (gr.yout / 4)), at(y_act, g * gr.yout), at(w, g * gr.wset[1]),
+                                         at(x_act, g * gr.xin), at(gx, g * gr.xin), at(gy_out, g * gr.yout), stream);
+    return rc;
+  }
   return tg_conv2d_bwd_data_unpool_mfma(d, gy_pooled, nullptr, w, gx, (hipStream_t)stream, x_act, gy_out, y_act);
 }
 
 size_t tg_conv2d_bwd_weight_workspace(const TgConvDesc* d) {
   if (!d) return 0;
+  if (grouped(d)) {      // G disjoint parts: a queued slab reduction (tg_wgrad_defer) reads its part after the call returned
+    if (d->n % d->groups) return 0;
+    const Groups gr(d);
+    return gr.G * ((tg_conv2d_bwd_weight_workspace(&gr.d1) + 255) & ~(size_t)255);
+  }
   if (d->algo == TG_ALGO_DIRECT) return tg_conv2d_bwd_weight_workspace_direct(d);
   return tg_conv2d_bwd_weight_workspace_mfma(d);
 }
@@ -217,6 +296,11 @@ size_t tg_conv2d_bwd_weight2_workspace(const TgConvDesc* d, int nb) {
   if (!d || nb <= 0 || check_desc("tg_conv2d_bwd_weight2_workspace", d) || d->algo == TG_ALGO_DIRECT ||
       !tg_conv2d_bwd_weight2_supported_mfma(d))
     return 0;
+  if (grouped(d)) {
+    if (nb % d->groups) return 0;
+    const Groups gr(d);
+    return gr.G * ((tg_conv2d_bwd_weight2_workspace(&gr.d1, nb / gr.G) + 255) & ~(size_t)255);
+  }
   return tg_conv2d_bwd_weight2_workspace_mfma(d, nb);
 }
 
@@ -227,6 +311,15 @@ int tg_conv2d_bwd_weight2(const TgConvDesc* d, int nb, const void* xa, const voi
   TG_CHECK(xa && gya && xb && gyb && gw && nb > 0, TG_EINVAL, "tg_conv2d_bwd_weight2: bad arguments");
   TG_CHECK(d->algo != TG_ALGO_DIRECT && tg_conv2d_bwd_weight2_supported_mfma(d), TG_ENOSUP,
            "tg_conv2d_bwd_weight2: layer not taken by the tile kernel (query tg_conv2d_bwd_weight2_workspace first)");
+  if (grouped(d) && !tg_conv2d_grouped_native_mfma(d, TG_GRP_WGRAD)) {
+    TG_CHECK(nb % d->groups == 0, TG_EINVAL, "tg_conv2d_bwd_weight2: groups %d does not divide the second batch of %d", d->groups, nb);
+    const Groups gr(d);
+    const size_t part = ws_bytes / gr.G & ~(size_t)255, xb1 = gr.xin / gr.d1.n * (nb / gr.G), yb1 = gr.yout / gr.d1.n * (nb / gr.G);
+    for (int g = 0; g < gr.G && !rc; ++g)
+      rc = tg_conv2d_bwd_weight2(&gr.d1, nb / gr.G, at(xa, g * gr.xin), at(gya, g * gr.yout), at(xb, g * xb1), at(gyb, g * yb1),
+                                 at(gw, g * gr.wmaster), accumulate, at(ws, g * part), part, stream);
+    return rc;
+  }
   return tg_conv2d_bwd_weight2_mfma(d, nb, xa, gya, xb, gyb, gw, accumulate, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -255,7 +348,8 @@ int tg_conv2d_upcat_fwd(const void* x0, const void* x1, const void* w_pack, void
 
 int tg_conv2d_fwd_pool_supported(const TgConvDesc* d) {
   if (check_desc("tg_conv2d_fwd_pool_supported", d) || d->algo == TG_ALGO_DIRECT) return 0;
-  return tg_conv2d_fwd_pool_supported_mfma(d) ? 1 : 0;
+  const Groups gr(d);
+  return tg_conv2d_fwd_pool_supported_mfma(&gr.d1) ? 1 : 0;
 }
 
 int tg_conv2d_fwd_pool(const TgConvDesc* d, const void* x, const void* w_pack, const float* bias, void* y, void* y_pooled,
@@ -266,6 +360,13 @@ int tg_conv2d_fwd_pool(const TgConvDesc* d, const void* x, const void* w_pack, c
   TG_CHECK(tg_aligned16(x) && tg_aligned16(w_pack) && tg_aligned16(y) && tg_aligned16(y_pooled), TG_EALIGN,
            "tg_conv2d_fwd_pool: pointers must be 16 B aligned");
   TG_CHECK(d->algo != TG_ALGO_DIRECT, TG_ENOSUP, "tg_conv2d_fwd_pool: MFMA path only (query tg_conv2d_fwd_pool_supported)");
+  if (grouped(d) && !tg_conv2d_grouped_native_mfma(d, TG_GRP_FWD)) {
+    const Groups gr(d);
+    for (int g = 0; g < gr.G && !rc; ++g)
+      rc = tg_conv2d_fwd_pool(&gr.d1, at(x, g * gr.xin), at(w_pack, g * gr.wset[0]), at(bias, g * gr.bias), at(y, g * gr.yout),
+                              at(y_pooled, g * (gr.yout / 4)), stream);
+    return rc;
+  }
   return tg_conv2d_fwd_pool_mfma(d, x, w_pack, bias, y, y_pooled, (hipStream_t)stream);
 }
 
@@ -277,11 +378,19 @@ int tg_conv2d_fwd_pool_signs(const TgConvDesc* d, const void* x, const void* w_p
   TG_CHECK(tg_aligned16(x) && tg_aligned16(w_pack) && tg_aligned16(y_pooled) && (reinterpret_cast<uintptr_t>(y_signs) & 3u) == 0,
            TG_EALIGN, "tg_conv2d_fwd_pool_signs: pointers must be 16 B aligned (the sign bits: 4 B)");
   TG_CHECK(d->algo != TG_ALGO_DIRECT, TG_ENOSUP, "tg_conv2d_fwd_pool_signs: MFMA path only (query tg_conv2d_fwd_pool_supported)");
+  if (grouped(d) && !tg_conv2d_grouped_native_mfma(d, TG_GRP_FWD)) {
+    const Groups gr(d);
+    const size_t es = d->dtype == TG_F32 ? 4 : 2;
+    for (int g = 0; g < gr.G && !rc; ++g)
+      rc = tg_conv2d_fwd_pool_signs(&gr.d1, at(x, g * gr.xin), at(w_pack, g * gr.wset[0]), at(bias, g * gr.bias),
+                                    at(y_signs, g * (gr.yout / es / 8)), at(y_pooled, g * (gr.yout / 4)), stream);
+    return rc;
+  }
   return tg_conv2d_fwd_pool_mfma(d, x, w_pack, bias, nullptr, y_pooled, (hipStream_t)stream, y_signs);
 }
 
 int tg_conv2d_fwd_stats_chunks(const TgConvDesc* d) {
-  if (check_desc("tg_conv2d_fwd_stats_chunks", d) || d->algo == TG_ALGO_DIRECT) return 0;
+  if (check_desc("tg_conv2d_fwd_stats_chunks", d) || d->algo == TG_ALGO_DIRECT || grouped(d)) return 0;
   return tg_conv2d_fwd_stats_chunks_mfma(d);
 }
 
@@ -292,8 +401,8 @@ int tg_conv2d_fwd_stats(const TgConvDesc* d, const void* x, const void* w_pack, 
   TG_CHECK(x && w_pack && y && partials, TG_EINVAL, "tg_conv2d_fwd_stats: null pointer");
   TG_CHECK(tg_aligned16(x) && tg_aligned16(w_pack) && tg_aligned16(y), TG_EALIGN,
            "tg_conv2d_fwd_stats: pointers must be 16 B aligned");
-  TG_CHECK(d->algo != TG_ALGO_DIRECT && d->epilogue == 0, TG_ENOSUP,
-           "tg_conv2d_fwd_stats: MFMA path, plain epilogue (query tg_conv2d_fwd_stats_chunks first)");
+  TG_CHECK(d->algo != TG_ALGO_DIRECT && d->epilogue == 0 && !grouped(d), TG_ENOSUP,
+           "tg_conv2d_fwd_stats: MFMA path, plain epilogue, one weight set (query tg_conv2d_fwd_stats_chunks first)");
   return tg_conv2d_fwd_stats_mfma(d, x, w_pack, y, partials, chunks, (hipStream_t)stream);
 }
 
@@ -365,6 +474,14 @@ int tg_conv2d_bwd_weight_bias(const TgConvDesc* d, const void* x, const void* gy
   int rc = check_desc("tg_conv2d_bwd_weight_bias", d);
   if (rc) return rc;
   TG_CHECK(x && gy && gw && gbias, TG_EINVAL, "tg_conv2d_bwd_weight_bias: null pointer");
+  if (grouped(d) && !(d->algo != TG_ALGO_DIRECT && tg_conv2d_grouped_native_mfma(d, TG_GRP_WGRAD))) {
+    const Groups gr(d);
+    const size_t part = ws_bytes / gr.G & ~(size_t)255;
+    for (int g = 0; g < gr.G && !rc; ++g)
+      rc = tg_conv2d_bwd_weight_bias(&gr.d1, at(x, g * gr.xin), at(gy, g * gr.yout), at(gw, g * gr.wmaster), at(gbias, g * gr.bias),
+                                     accumulate, at(ws, g * part), part, stream);
+    return rc;
+  }
   // the fused form ends in one float atomic per workgroup and channel: not taken in deterministic mode
   if (d->algo != TG_ALGO_DIRECT && !tg_deterministic_mode() && tg_conv2d_bwd_weight_bias_fused_mfma(d))
     return tg_conv2d_bwd_weight_mfma(d, x, gy, gw, accumulate, ws, ws_bytes, (hipStream_t)stream, gbias);
@@ -382,6 +499,15 @@ int tg_conv2d_bwd_weight2_bias(const TgConvDesc* d, int nb, const void* xa, cons
   TG_CHECK(d->algo != TG_ALGO_DIRECT && tg_conv2d_bwd_weight2_supported_mfma(d), TG_ENOSUP,
            "tg_conv2d_bwd_weight2_bias: layer not taken by the tile kernel");
   TG_CHECK(bias_segs >= 1 && bias_segs <= 3, TG_EINVAL, "tg_conv2d_bwd_weight2_bias: bias_segs %d", bias_segs);
+  if (grouped(d) && !tg_conv2d_grouped_native_mfma(d, TG_GRP_WGRAD)) {
+    TG_CHECK(nb % d->groups == 0, TG_EINVAL, "tg_conv2d_bwd_weight2_bias: groups %d does not divide the second batch of %d", d->groups, nb);
+    const Groups gr(d);
+    const size_t part = ws_bytes / gr.G & ~(size_t)255, xb1 = gr.xin / gr.d1.n * (nb / gr.G), yb1 = gr.yout / gr.d1.n * (nb / gr.G);
+    for (int g = 0; g < gr.G && !rc; ++g)
+      rc = tg_conv2d_bwd_weight2_bias(&gr.d1, nb / gr.G, at(xa, g * gr.xin), at(gya, g * gr.yout), at(xb, g * xb1), at(gyb, g * yb1),
+                                      at(gw, g * gr.wmaster), at(gbias, g * gr.bias), bias_segs, accumulate, at(ws, g * part), part, stream);
+    return rc;
+  }
   if (tg_deterministic_mode()) {      // filter gradient without the bias MFMA, bias sums by one workgroup each
     rc = tg_conv2d_bwd_weight2_mfma(d, nb, xa, gya, xb, gyb, gw, accumulate, ws, ws_bytes, (hipStream_t)stream, nullptr, 3);
     if (rc) return rc;
@@ -399,6 +525,14 @@ int tg_conv2d_bwd_weight(const TgConvDesc* d, const void* x, const void* gy, flo
   if (rc) return rc;
   TG_CHECK(x && gy && gw, TG_EINVAL, "tg_conv2d_bwd_weight: null pointer");
   TG_CHECK(tg_aligned16(x) && tg_aligned16(gy), TG_EALIGN, "tg_conv2d_bwd_weight: pointers must be 16 B aligned");
+  if (grouped(d) && !(d->algo != TG_ALGO_DIRECT && tg_conv2d_grouped_native_mfma(d, TG_GRP_WGRAD))) {
+    const Groups gr(d);
+    const size_t part = ws_bytes / gr.G & ~(size_t)255;
+    for (int g = 0; g < gr.G && !rc; ++g)
+      rc = tg_conv2d_bwd_weight(&gr.d1, at(x, g * gr.xin), at(gy, g * gr.yout), at(gw, g * gr.wmaster), accumulate, at(ws, g * part), part,
+                                stream);
+    return rc;
+  }
   if (d->algo != TG_ALGO_DIRECT) return tg_conv2d_bwd_weight_mfma(d, x, gy, gw, accumulate, ws, ws_bytes, (hipStream_t)stream);
   return tg_conv2d_bwd_weight_direct(d, x, gy, gw, accumulate, (hipStream_t)stream, ws, ws_bytes);
 }

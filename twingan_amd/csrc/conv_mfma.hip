@@ -453,7 +453,7 @@ static void pack_dims(const TgConvDesc* d0, int mode, int* nt, int* cin, int* co
 size_t tg_conv2d_pack_elems(const TgConvDesc* d, int mode) {
   int nt, cin, cout, rows, rows_pad, inner, inner_pad;
   pack_dims(d, mode, &nt, &cin, &cout, &rows, &rows_pad, &inner, &inner_pad);
-  return (size_t)rows_pad * nt * inner_pad;
+  return (size_t)rows_pad * nt * inner_pad * (d->groups > 1 ? d->groups : 1);      // one pack per weight set, back to back
 }
 
 int tg_conv2d_pack_weights(const TgConvDesc* d, const float* w, int mode, void* out, void* stream) {
@@ -461,9 +461,12 @@ int tg_conv2d_pack_weights(const TgConvDesc* d, const float* w, int mode, void* 
   int nt, cin, cout, rows, rows_pad, inner, inner_pad;
   pack_dims(d, mode, &nt, &cin, &cout, &rows, &rows_pad, &inner, &inner_pad);
   const int64_t total = (int64_t)rows_pad * nt * inner_pad;
-  hipLaunchKernelGGL(pack_weights, dim3(tg_grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16*)out, nt,
-                     cin, cout, rows, rows_pad, inner, inner_pad, mode, d->dtype == TG_F16 ? 1 : 0);
-  TG_LAUNCH_CHECK("tg_conv2d_pack_weights");
+  for (int g = 0; g < (d->groups > 1 ? d->groups : 1); ++g) {      // weight set g: master w[g] -> pack g
+    hipLaunchKernelGGL(pack_weights, dim3(tg_grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w + (size_t)g * nt * cin * cout, (bf16*)out + (size_t)g * total, nt, cin, cout, rows, rows_pad, inner,
+                       inner_pad, mode, d->dtype == TG_F16 ? 1 : 0);
+    TG_LAUNCH_CHECK("tg_conv2d_pack_weights");
+  }
   return TG_OK;
 }
 
@@ -535,6 +538,7 @@ int tg_pack_table_fill(const TgConvDesc* d, const float* w, int mode, void* out,
                        int32_t* total_blocks) {
   TG_CHECK(d && w && out && table_host && total_blocks && job >= 0, TG_EINVAL, "tg_pack_table_fill: bad arguments");
   TG_CHECK(mode == 0 || mode == 1, TG_EINVAL, "tg_pack_table_fill: mode %d", mode);
+  TG_CHECK(d->groups <= 1, TG_EINVAL, "tg_pack_table_fill: one job per weight set (fill each set of a grouped descriptor as its own job)");
   PackJob j;
   j.w = w;
   j.out = (bf16*)out;
@@ -566,6 +570,15 @@ int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int
                      float* stats = nullptr, int stat_chunks = 0, int* chunks_query = nullptr, void* ypool = nullptr,
                      void* ymask = nullptr, const void* up_src = nullptr, const void* up_signs = nullptr, float up_alpha = 0.f,
                      void* up_store = nullptr, const void* up_z = nullptr);
+
+// Grouped calls (TgConvDesc::groups > 1) the dispatch below takes as ONE launch: the kernel picks the weight set from the
+// image index.  op: 0 forward-shaped (forward, masked, pool), 1 backward-data-shaped, 2 filter gradient.  Everything else
+// is launched once per group by the entry point (capi.hip).
+bool tg_conv2d_grouped_native_mfma(const TgConvDesc* d, int op) {
+  (void)d;
+  (void)op;
+  return false;
+}
 
 // Forward conv that also writes the 2x2 average pool of its output (conv_tile.hip POOL kernels): 3x3 SAME, even h / w,
 // shapes the tile kernels take

@@ -155,15 +155,26 @@ class PackCache:
     tab = cls._tables.get(tkey)
     if tab is None:
       lib = _lib.load()
-      host = ctypes.create_string_buffer(lib.tg_pack_table_bytes(len(keys)))
+      njobs = sum(max(int(cls._packs[k][2].groups), 1) for k in keys)
+      host = ctypes.create_string_buffer(lib.tg_pack_table_bytes(njobs))
       blocks = ctypes.c_int32(0)
-      for j, k in enumerate(keys):
+      j = nbytes = 0
+      for k in keys:
         ent = cls._packs[k]
-        call('tg_pack_table_fill', ctypes.byref(ent[2]), _p(cls._registered[k[0]]), k[1], _p(ent[1]), j,
-             ctypes.addressof(host), ctypes.byref(blocks))
+        g = max(int(ent[2].groups), 1)
+        d1 = TgConvDesc()
+        ctypes.pointer(d1)[0] = ent[2]
+        d1.groups = 1
+        # weight set i of a stacked kernel (params.ParamStore.pairs): its master starts i sets after the first, its pack i
+        # packs after the first; one job per set
+        wset, per = 4 * d1.kh * d1.kw * d1.cin * d1.cout, k[2] // g
+        for i in range(g):
+          call('tg_pack_table_fill', ctypes.byref(d1), k[0] + i * wset, k[1], ent[1].data_ptr() + i * per * ent[1].element_size(), j,
+               ctypes.addressof(host), ctypes.byref(blocks))
+          j += 1
+        nbytes += g * wset + _nb(ent[1])
       dev = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(cls._packs[keys[0]][1].device)
-      nbytes = sum(_nb(cls._registered[k[0]]) for k in keys) + sum(_nb(cls._packs[k][1]) for k in keys)
-      tab = cls._tables[tkey] = (dev, len(keys), blocks.value, nbytes)
+      tab = cls._tables[tkey] = (dev, njobs, blocks.value, nbytes)
     call('tg_conv2d_pack_weights_multi', _p(tab[0]), tab[1], tab[2], _stream(), work=('pack_multi:%d' % tab[1], 0, tab[3]))
     for k in keys:
       cls._packs[k][0] = cls.version
@@ -208,12 +219,17 @@ class GradSink:
   backward kernels themselves, and the autograd Function returns None for it -- no temporary gradient
   tensor, no zero-fill of it, no AccumulateGrad add kernel.  Only used outside create_graph mode (nothing
   differentiates a parameter gradient)."""
-  _sinks = {}
+  _sinks = {}      # (data_ptr, numel) -> (weakref of the parameter, gradient buffer).  numel is part of the key: the stacked
+                   # [2, ...] view of two adjacent discriminator variables (params.ParamStore.pairs) starts where the first does
+
+  @staticmethod
+  def _key(p):
+    return (p.data_ptr(), p.numel())
 
   @classmethod
   def register(cls, p, grad):
-    cls._sinks[p.data_ptr()] = (weakref.ref(p), grad)
-    cls._held.pop(p.data_ptr(), None)
+    cls._sinks[cls._key(p)] = (weakref.ref(p), grad)
+    cls._held.pop(cls._key(p), None)
 
   @classmethod
   def clear(cls):
@@ -222,22 +238,22 @@ class GradSink:
 
   @classmethod
   def unregister(cls, p):
-    ent = cls._sinks.get(p.data_ptr())
+    ent = cls._sinks.get(cls._key(p))
     if ent is not None and ent[0]() is p:
-      del cls._sinks[p.data_ptr()]
-      cls._held.pop(p.data_ptr(), None)
+      del cls._sinks[cls._key(p)]
+      cls._held.pop(cls._key(p), None)
 
   @classmethod
   def get(cls, p):
     if p is None or torch.is_grad_enabled():
       return None
-    ent = cls._sinks.get(p.data_ptr())
+    ent = cls._sinks.get(cls._key(p))
     if ent is None:
       return None
     if ent[0]() is None:       # the registered parameter is gone and the allocator handed its address out again
-      del cls._sinks[p.data_ptr()]
+      del cls._sinks[cls._key(p)]
       return None
-    return ent[1]              # p is the parameter or a view of it (its memory cannot be anything else while it lives)
+    return ent[1]              # p is the parameter or a reshaped view of it (its memory cannot be anything else while it lives)
 
   # Pairing of filter gradients: with ``pair`` on (the trainer), the first filter-gradient request of a weight in a
   # backward pass is held back; when a second one for the same weight arrives (the batched real/fake/interpolate pass
@@ -245,7 +261,7 @@ class GradSink:
   # both run as ONE tg_conv2d_bwd_weight2 launch.  flush() issues the ones that stayed alone; it runs where gradients
   # are consumed (Trainer before the all-reduce / Adam, ParamStore.grad_dict()).
   pair = False
-  _held = {}      # weight data_ptr -> (x, gy, spec, sink, bias_sink)
+  _held = {}      # (weight data_ptr, numel) -> (x, gy, spec, sink, bias_sink)
 
   @classmethod
   def submit(cls, w, x, gy, spec, sink, bias_sink=None):
@@ -253,7 +269,7 @@ class GradSink:
     if not cls.pair:
       conv_bwd_weight_raw(x, gy, spec, out=sink, gbias=bias_sink)
       return
-    key = w.data_ptr()
+    key = cls._key(w)
     first = cls._held.pop(key, None)
     if first is None:
       cls._held[key] = (x, gy, spec, sink, bias_sink)
@@ -272,7 +288,7 @@ class GradSink:
     if only is None:
       held, cls._held = cls._held, {}
     else:
-      held = {k: v for k, v in cls._held.items() if only(k)}
+      held = {k: v for k, v in cls._held.items() if only(k[0])}
       for k in held:
         del cls._held[k]
     cur = torch.cuda.current_stream() if held else None
@@ -376,7 +392,13 @@ def _conv_work(d, tag, es):
   return ('%s:%s:k%d:c%d>%d:hw%d:n%d' % (tag, algo, d.kh, d.cin, d.cout, d.hout, d.n), flops, by)
 
 
-def _desc(x_shape, cout, spec, dtype, epilogue):
+def _wg(w):
+  """Weight sets of a conv kernel tensor: a 5-d [G, kh, kw, cin, cout] tensor holds G sets (TgConvDesc.groups: the batch is
+  G equal image ranges, range g convolved with set g -- the two discriminators' layers as one call), else 1."""
+  return int(w.shape[0]) if w.dim() == 5 else 1
+
+
+def _desc(x_shape, cout, spec, dtype, epilogue, groups=1):
   n, h, w, cin = x_shape
   ho, wo = spec.out_hw(h, w)
   d = TgConvDesc()
@@ -387,6 +409,8 @@ def _desc(x_shape, cout, spec, dtype, epilogue):
   d.algo = TG_ALGO_MFMA if _mfma_ok(dtype, cin, cout, spec, h, w) else TG_ALGO_DIRECT
   d.epilogue = epilogue
   d.lrelu_alpha = spec.alpha
+  d.groups = groups
+  assert groups == 1 or n % groups == 0, (n, groups)
   return d
 
 
@@ -395,7 +419,7 @@ def _desc(x_shape, cout, spec, dtype, epilogue):
 # ------------------------------------------------------------------------------------------------
 def conv_fwd_raw(x, w, bias, spec, epilogue):
   _chk(x, w, bias)
-  d = _desc(x.shape, w.shape[3], spec, x.dtype, epilogue)
+  d = _desc(x.shape, w.shape[-1], spec, x.dtype, epilogue, _wg(w))
   y = torch.empty((d.n, d.hout, d.wout, d.cout), dtype=x.dtype, device=x.device)
   wk = PackCache.get(w, d, 0) if d.algo == TG_ALGO_MFMA else w
   call('tg_conv2d_fwd', ctypes.byref(d), _p(x), _p(wk), _p(bias), _p(y), _stream(),
@@ -406,7 +430,7 @@ def conv_fwd_raw(x, w, bias, spec, epilogue):
 def conv_fwd_pool_raw(x, w, bias, spec, epilogue):
   """(z, avg_pool2(z)): one launch where the tile kernels take the shape (tg_conv2d_fwd_pool), else conv + pool."""
   _chk(x, w, bias)
-  d = _desc(x.shape, w.shape[3], spec, x.dtype, epilogue)
+  d = _desc(x.shape, w.shape[-1], spec, x.dtype, epilogue, _wg(w))
   if USE_CONV_POOL and d.algo == TG_ALGO_MFMA and d.hout % 2 == 0 and d.wout % 2 == 0 and \
       _lib.load().tg_conv2d_fwd_pool_supported(ctypes.byref(d)):
     z = torch.empty((d.n, d.hout, d.wout, d.cout), dtype=x.dtype, device=x.device)
@@ -429,9 +453,9 @@ def conv_fwd_pool_raw(x, w, bias, spec, epilogue):
 
 def conv_fwd_pool_signs_supported(x, w, spec, epilogue):
   """Can (sign bits of z, avg_pool2(z)) come out of one launch for this layer (tg_conv2d_fwd_pool_signs)?"""
-  if not (USE_CONV_POOL and USE_POOL_SIGNS) or x.dtype not in HALF_TYPES or w.shape[3] % 8 or not (epilogue & TG_EPI_LRELU):
+  if not (USE_CONV_POOL and USE_POOL_SIGNS) or x.dtype not in HALF_TYPES or w.shape[-1] % 8 or not (epilogue & TG_EPI_LRELU):
     return False
-  d = _desc(x.shape, w.shape[3], spec, x.dtype, epilogue)
+  d = _desc(x.shape, w.shape[-1], spec, x.dtype, epilogue, _wg(w))
   return d.algo == TG_ALGO_MFMA and d.hout % 2 == 0 and d.wout % 2 == 0 and \
       bool(_lib.load().tg_conv2d_fwd_pool_supported(ctypes.byref(d)))
 
@@ -440,7 +464,7 @@ def conv_fwd_pool_signs_raw(x, w, bias, spec, epilogue):
   """(signs, avg_pool2(z)) of z = epilogue(conv(x, w) + bias): z itself is never written; signs is uint8
   [n, h, w, cout / 8], bit j of byte q = (z[.., 8q+j] > 0)."""
   _chk(x, w, bias)
-  d = _desc(x.shape, w.shape[3], spec, x.dtype, epilogue)
+  d = _desc(x.shape, w.shape[-1], spec, x.dtype, epilogue, _wg(w))
   signs = torch.empty((d.n, d.hout, d.wout, d.cout // 8), dtype=torch.uint8, device=x.device)
   zp = torch.empty((d.n, d.hout // 2, d.wout // 2, d.cout), dtype=x.dtype, device=x.device)
 
@@ -462,8 +486,8 @@ def lrelu_pool_bwd_signs(gzp, signs, alpha, bias, want_bias):
   sink = GradSink.get(bias) if want_bias else None
   gb = None
   if want_bias:
-    gb = sink if sink is not None else torch.empty(c, dtype=torch.float32, device=gzp.device)
-  fused_bias = want_bias and not deterministic()
+    gb = sink if sink is not None else torch.empty(tuple(bias.shape), dtype=torch.float32, device=gzp.device)
+  fused_bias = want_bias and not deterministic() and bias.dim() == 1      # stacked biases (grouped conv): per-group sums below
   call('tg_lrelu_pool_bwd_signs', _p(gzp), _p(signs), _p(g), _p(gb if fused_bias else None), n, h, w, c, alpha,
        1 if sink is not None else 0, _dt(gzp), _stream(), work=('lrelu_pool_bwd' + _shape_tag(g), 0, _nb(gzp, signs, g)))
   if want_bias and not fused_bias:
@@ -483,7 +507,7 @@ class ConvStats:
 def conv_fwd_stats_raw(x, w, spec):
   """(y, ConvStats) of a bias-free conv, or (y, None) when the kernel this shape dispatches has no statistics epilogue."""
   _chk(x, w)
-  d = _desc(x.shape, w.shape[3], spec, x.dtype, 0)
+  d = _desc(x.shape, w.shape[-1], spec, x.dtype, 0, _wg(w))
   chunks = _lib.load().tg_conv2d_fwd_stats_chunks(ctypes.byref(d)) if (USE_CONV_STATS and d.algo == TG_ALGO_MFMA) else 0
   if chunks <= 0:
     return conv_fwd_raw(x, w, None, spec, 0), None
@@ -497,7 +521,7 @@ def conv_fwd_stats_raw(x, w, spec):
 
 def conv_bwd_data_raw(gy, w, x_shape, spec):
   _chk(gy, w)
-  d = _desc(x_shape, w.shape[3], spec, gy.dtype, 0)
+  d = _desc(x_shape, w.shape[-1], spec, gy.dtype, 0, _wg(w))
   gx = torch.empty(tuple(x_shape), dtype=gy.dtype, device=gy.device)
   wk = PackCache.get(w, d, 1) if d.algo == TG_ALGO_MFMA else w
   call('tg_conv2d_bwd_data', ctypes.byref(d), _p(gy), _p(wk), _p(gx), _stream(),
@@ -509,7 +533,7 @@ def conv_bwd_data_masked_raw(gy, w, x_act, spec):
   """gx = conv^T(gy, w) * (x_act > 0 ? 1 : alpha): backward-data with the LeakyReLU backward of the layer that produced
   this conv's input ``x_act`` folded into the epilogue (tg_conv2d_bwd_data_masked)."""
   _chk(gy, w, x_act)
-  d = _desc(x_act.shape, w.shape[3], spec, gy.dtype, 0)
+  d = _desc(x_act.shape, w.shape[-1], spec, gy.dtype, 0, _wg(w))
   gx = torch.empty_like(x_act)
   wk = PackCache.get(w, d, 1) if d.algo == TG_ALGO_MFMA else w
   def work():      # the mask is one more read of a tensor of the input's size
@@ -540,7 +564,7 @@ def conv_bwd_data_unpool_raw(gzp, signs, w, x_act, x_shape, spec, keep=False):
   backward is folded in (as conv_bwd_data_masked_raw), else None.  ``keep``: -> (gx, g) with g = unpool_lrelu(gzp, signs)
   [n, h, w, cout] written by the same kernel (for the layer's filter / bias gradient)."""
   _chk(gzp, signs, w, x_act)
-  d = _desc(x_shape, w.shape[3], spec, gzp.dtype, 0)
+  d = _desc(x_shape, w.shape[-1], spec, gzp.dtype, 0, _wg(w))
   if d.algo != TG_ALGO_MFMA or not _lib.load().tg_conv2d_bwd_data_unpool_supported(ctypes.byref(d)):
     return None
   gx = torch.empty(tuple(x_shape), dtype=gzp.dtype, device=gzp.device)
@@ -562,7 +586,7 @@ def conv_fwd_masked_raw(x, w, mask_src, spec):
   """y = conv(x, w) * (mask_src > 0 ? 1 : alpha): a forward conv with the LeakyReLU derivative of ``mask_src`` (the shape
   of y) in its epilogue (tg_conv2d_fwd_masked) -- the second backward pass of the gradient penalty."""
   _chk(x, w, mask_src)
-  d = _desc(x.shape, w.shape[3], spec, x.dtype, 0)
+  d = _desc(x.shape, w.shape[-1], spec, x.dtype, 0, _wg(w))
   y = torch.empty((d.n, d.hout, d.wout, d.cout), dtype=x.dtype, device=x.device)
   assert tuple(mask_src.shape) == tuple(y.shape), (tuple(mask_src.shape), tuple(y.shape))
   wk = PackCache.get(w, d, 0) if d.algo == TG_ALGO_MFMA else w
@@ -573,12 +597,17 @@ def conv_fwd_masked_raw(x, w, mask_src, spec):
   return y
 
 
-def conv_bwd_weight_raw(x, gy, spec, out=None, gbias=None):
+def conv_bwd_weight_raw(x, gy, spec, out=None, gbias=None, groups=1):
   """gw = x^T * gy; with ``out`` the result is ADDED into that fp32 HWIO buffer (gradient sink).  ``gbias``: fp32 [cout]
-  buffer that also receives += sum over pixels of gy (the layer's bias gradient, from the same read of gy)."""
+  buffer that also receives += sum over pixels of gy (the layer's bias gradient, from the same read of gy).  ``groups`` (or
+  a 5-d ``out``): G weight sets, image range g of the batch feeds gw[g] (and gbias[g])."""
   _chk(x, gy)
-  d = _desc(x.shape, gy.shape[3], spec, x.dtype, 0)
+  if out is not None and out.dim() == 5:
+    groups = int(out.shape[0])
+  d = _desc(x.shape, gy.shape[3], spec, x.dtype, 0, groups)
   shape = (spec.kh, spec.kw, x.shape[3], gy.shape[3])
+  if groups > 1:
+    shape = (groups,) + shape
   if out is None:
     gw = torch.empty(shape, dtype=torch.float32, device=x.device)
   else:
@@ -602,7 +631,10 @@ def conv_bwd_weight2_raw(xa, gya, xb, gyb, spec, out, gbias=None, bias_segs=3):
   _chk(xa, gya, xb, gyb)
   if xa.shape[1:] != xb.shape[1:] or gya.shape[1:] != gyb.shape[1:] or xa.dtype != xb.dtype:
     return False
-  d = _desc(xa.shape, gya.shape[3], spec, xa.dtype, 0)
+  groups = int(out.shape[0]) if out.dim() == 5 else 1
+  if xb.shape[0] % groups:
+    return False
+  d = _desc(xa.shape, gya.shape[3], spec, xa.dtype, 0, groups)
   nb = xb.shape[0]
   nbytes = _lib.load().tg_conv2d_bwd_weight2_workspace(ctypes.byref(d), nb)
   if not nbytes:
@@ -642,8 +674,8 @@ def _weight_grad(x, g, spec, w, bias_sink=None):
     return None
   if bias_sink is not None:      # first-order pass, no sink for w: the gradient tensor, the bias gradient riding along
     assert not torch.is_grad_enabled()
-    return conv_bwd_weight_raw(x, g, spec, gbias=bias_sink)
-  return ConvBwdWeightFn.apply(x, g, spec)
+    return conv_bwd_weight_raw(x, g, spec, gbias=bias_sink, groups=_wg(w))
+  return ConvBwdWeightFn.apply(x, g, spec, _wg(w))
 
 
 def deterministic():
@@ -657,8 +689,14 @@ _ORDERED_ROWS = 512      # workgroups whose partial rows the workspace can hold
 
 
 def _channel_sum_into(g, out, accumulate):
-  """out[c] (+)= sum over pixels of g: ordered two-stage sum in deterministic mode, tg_channel_sum otherwise."""
+  """out[c] (+)= sum over pixels of g: ordered two-stage sum in deterministic mode, tg_channel_sum otherwise.  A 2-d
+  ``out`` [G, c] (the stacked biases of a grouped conv): image range i of g feeds row i."""
   c = g.shape[-1]
+  if out.dim() == 2:
+    n1 = g.shape[0] // out.shape[0]
+    for i in range(out.shape[0]):
+      _channel_sum_into(g[i * n1:(i + 1) * n1], out[i], accumulate)
+    return
   if deterministic():
     ws = torch.empty(_ORDERED_ROWS * c, dtype=torch.float32, device=g.device)
     call('tg_channel_sum_ordered', _p(g), _p(out), g.numel() // c, c, 1 if accumulate else 0, _p(ws), ws.numel(), _dt(g),
@@ -673,7 +711,7 @@ def _bias_grad(g, bias):
   if sink is not None:
     _channel_sum_into(g, sink, True)
     return None
-  return ChannelSumFn.apply(g)
+  return ChannelSumFn.apply(g, int(bias.shape[0]) if bias.dim() == 2 else 1)
 
 
 def lrelu_pool_bwd(gz, gzp, z, alpha, bias, want_bias):
@@ -685,8 +723,9 @@ def lrelu_pool_bwd(gz, gzp, z, alpha, bias, want_bias):
   sink = GradSink.get(bias) if want_bias else None
   gb = None
   if want_bias:
-    gb = sink if sink is not None else torch.empty(c, dtype=torch.float32, device=z.device)
-  fused_bias = want_bias and not deterministic()      # deterministic mode: the bias sum is its own ordered two-stage pass
+    gb = sink if sink is not None else torch.empty(tuple(bias.shape), dtype=torch.float32, device=z.device)
+  # deterministic mode: the bias sum is its own ordered two-stage pass; stacked biases (grouped conv): per-group sums
+  fused_bias = want_bias and not deterministic() and bias.dim() == 1
   call('tg_lrelu_pool_bwd', _p(gz), _p(gzp), _p(z), _p(g), _p(gb if fused_bias else None), n, h, w, c, alpha,
        1 if sink is not None else 0, _dt(z), _stream(),
        work=('lrelu_pool_bwd' + _shape_tag(z), 0, int((2 + (gz is not None) + 0.25 * (gzp is not None)) * z.numel()) * _esize(z)))
@@ -703,10 +742,10 @@ def lrelu_bwd_raw(g, z, alpha):
   return out
 
 
-def channel_sum_raw(g):
+def channel_sum_raw(g, groups=1):
   _chk(g)
   c = g.shape[-1]
-  out = torch.empty(c, dtype=torch.float32, device=g.device)
+  out = torch.empty((groups, c) if groups > 1 else (c,), dtype=torch.float32, device=g.device)
   _channel_sum_into(g, out, False)
   return out
 
@@ -1072,7 +1111,7 @@ class UnpoolMaskedDgradFn(torch.autograd.Function):
 
 
 def _unpool_act_supported(x_shape, w, spec, dtype):
-  d = _desc(x_shape, w.shape[3], spec, dtype, 0)
+  d = _desc(x_shape, w.shape[-1], spec, dtype, 0, _wg(w))
   return d.algo == TG_ALGO_MFMA and bool(_lib.load().tg_conv2d_bwd_data_unpool_supported(ctypes.byref(d)))
 
 
@@ -1081,8 +1120,8 @@ class ConvBwdWeightFn(torch.autograd.Function):
   TwinGAN loss, so this node is a leaf of the double-backward graph."""
 
   @staticmethod
-  def forward(ctx, x, gy, spec):
-    return conv_bwd_weight_raw(x, gy, spec)
+  def forward(ctx, x, gy, spec, groups=1):
+    return conv_bwd_weight_raw(x, gy, spec, groups=groups)
 
   @staticmethod
   @torch.autograd.function.once_differentiable
@@ -1128,8 +1167,8 @@ class ChannelSumFn(torch.autograd.Function):
   """BiasAddGrad: sum over pixels -> fp32 [C]."""
 
   @staticmethod
-  def forward(ctx, g):
-    return channel_sum_raw(g)
+  def forward(ctx, g, groups=1):
+    return channel_sum_raw(g, groups)
 
   @staticmethod
   @torch.autograd.function.once_differentiable
@@ -1900,9 +1939,15 @@ class RowsFn(torch.autograd.Function):
     return tuple(_rows_out(d, spec) for spec in specs)
 
   @staticmethod
-  @torch.autograd.function.once_differentiable
   def backward(ctx, *grads):
     n = ctx.shape[0]
+    if torch.is_grad_enabled() and any(g is not None and g.requires_grad for g in grads):
+      # a create_graph pass (the gradient penalty through the split of the two discriminators' features): differentiable when
+      # the ranges tile the batch in order -- the gradient is then their concatenation (CatRowsFn)
+      if all(isinstance(sp[0], int) for sp in ctx.specs) and all(g is not None for g in grads) and \
+          [sp[0] for sp in ctx.specs] + [n] == [0] + [sp[1] for sp in ctx.specs]:
+        return cat_rows([g.contiguous() for g in grads]), None
+      raise NotImplementedError('second-order gradient through ops.rows with overlapping / repeated ranges')
     pieces = []      # (lo, hi, gradient rows)
     for spec, g in zip(ctx.specs, grads):
       if g is None:

@@ -34,8 +34,10 @@ def mbstd_cpad(c):
 
 
 class _ParamDict(dict):
-  """name -> parameter tensor; ``state`` holds the non-trainable variables (BatchNorm moving statistics)."""
+  """name -> parameter tensor; ``state`` holds the non-trainable variables (BatchNorm moving statistics); ``pairs`` the
+  stacked [2, ...] views of the two discriminators' twin variables (ParamStore.build)."""
   state = None
+  pairs = None
 
 
 class ParamStore:
@@ -58,6 +60,7 @@ class ParamStore:
     self.phase_of = None               # name -> backward segment at whose end the gradient is final (grad_phase)
     self.phase_bounds = {}             # group -> {phase: (lo, hi)} element range of each phase in the flat buffers
     self.phase = {}                    # name -> phase
+    self.pairs = {}                    # 'discriminator_*/<rest>' -> [2, *phys] view over the two domains' adjacent variables
 
   # ---- declaration ----------------------------------------------------------------------------
   def add(self, name, shape, group, kind, phys=None):
@@ -100,13 +103,30 @@ class ParamStore:
     sizes = {g: 0 for g in self.GROUPS}
     phase = {name: (int(self.phase_of(name)) if self.phase_of else 0) for name in self.specs}
     order = sorted(self.specs, key=lambda k: phase[k])      # stable: declaration order inside a phase
+    # The two discriminators are towers of identical layers (twingan.py:105-110): a variable of discriminator_t goes right
+    # behind its discriminator_s twin, so that the pair is ONE dense [2, ...] tensor (self.pairs) -- what the grouped convs
+    # (TgConvDesc.groups: both discriminators' layer as one launch) read their two weight sets from.  Values are drawn in
+    # declaration order whatever the layout, names / shapes / checkpoints are untouched.
+    twins = {}
+    for name in order:
+      if name.startswith('discriminator_s/'):
+        t = 'discriminator_t/' + name[len('discriminator_s/'):]
+        n = int(math.prod(self.specs[name]['phys']))
+        if t in self.specs and self.specs[t]['phys'] == self.specs[name]['phys'] and phase[t] == phase[name] and n % 4 == 0:
+          twins[name] = t
+    moved = set(twins.values())
+    order = [k for name in order if name not in moved for k in ((name, twins[name]) if name in twins else (name,))]
     marks = {g: {} for g in self.GROUPS}
+    second = set(twins.values())
     for name in order:
       s = self.specs[name]
       n = int(math.prod(s['phys']))
       self.offsets[name] = sizes[s['group']]
       marks[s['group']].setdefault(phase[name], sizes[s['group']])
-      sizes[s['group']] += (n + ALIGN - 1) // ALIGN * ALIGN
+      # a first twin is followed by its second without padding (16-byte aligned: n % 4 == 0); the pair is padded as a whole
+      sizes[s['group']] += n if name in twins else (n + ALIGN - 1) // ALIGN * ALIGN
+      if name in second:
+        sizes[s['group']] = (sizes[s['group']] + ALIGN - 1) // ALIGN * ALIGN
     for g in self.GROUPS:
       ids = sorted(marks[g]) or [0]
       starts = [marks[g].get(p, 0) for p in ids]
@@ -129,6 +149,17 @@ class ParamStore:
       self.P[name] = p
       if s['kind'] == 'conv_w':
         PackCache.register(p)
+    for name, t in twins.items():
+      s = self.specs[name]
+      g, off, n = s['group'], self.offsets[name], int(math.prod(s['phys']))
+      assert self.offsets[t] == off + n, (name, t)
+      pr = self.flat[g][off:off + 2 * n].view((2,) + s['phys'])
+      pr.requires_grad_(True)
+      pr.grad = self.grad[g][off:off + 2 * n].view((2,) + s['phys'])
+      GradSink.register(pr, pr.grad)      # keyed by (address, numel): distinct from the first twin's own sink
+      # no PackCache.register: the pair starts at the first twin's address, whose registration covers its packs too
+      self.pairs['discriminator_*/' + name[len('discriminator_s/'):]] = pr
+    self.P.pairs = self.pairs
     for name, (n, init) in self.state_specs.items():
       if init == 'trunc_normal':      # tf.truncated_normal_initializer(): N(0,1) redrawn outside 2 sigma
         t = torch.empty(n, dtype=torch.float32)
@@ -246,6 +277,8 @@ class ParamStore:
     for p in self.P.values():
       GradSink.unregister(p)
       PackCache.unregister(p)
+    for p in self.pairs.values():
+      GradSink.unregister(p)
     for buf in self.P.__dict__.pop('sn_wbar', {}).values():      # persistent spectrally-normalised kernels (pggan._sn_compute)
       PackCache.unregister(buf)
 

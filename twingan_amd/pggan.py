@@ -519,8 +519,11 @@ def _d_conv(P, scope, x, cfg, k=3, padding='SAME', pool=False, in_ch=None, sole_
   if gdrop:
     x, ran = maybe_gdrop(P, x, cfg, in_ch)
     sole_consumer = sole_consumer and not ran      # the producer's LeakyReLU output is then not this conv's input
-  w = _sn(P, scope, cfg, True)
-  b = P[scope + '/biases']
+  if scope.startswith(PAIR_TOP + '/'):      # both discriminators' layer: the stacked [2, ...] kernel and bias (ParamStore.pairs)
+    w, b = P.pairs[scope + '/weights'], P.pairs[scope + '/biases']
+  else:
+    w = _sn(P, scope, cfg, True)
+    b = P[scope + '/biases']
   x = _equalize(x, cfg, k, in_ch)      # in_ch: logical channel count when x is channel-padded (minibatch stddev)
   if k == 1 and (w.shape[2] <= 4 or w.shape[3] <= 4):
     return ops.pointwise_conv(x, w, b, lrelu=True)
@@ -705,30 +708,45 @@ def generator(P, source, domain, cfg, unet_end_points=None, top='generator', une
 # ------------------------------------------------------------------------------------------------
 # discriminator (nets/pggan.py:217-376)
 # ------------------------------------------------------------------------------------------------
-def discriminator_before_fc(P, source, cfg, top, groups=1, cut_seg=None, block_end_points=True):
+PAIR_TOP = 'discriminator_*'      # scope of the stacked twin variables of discriminator_s / discriminator_t (ParamStore.pairs)
+PAIR_HW = 32                      # the two discriminators run as ONE grouped launch per layer from this resolution down
+
+
+def discriminator_before_fc(P, source, cfg, top, groups=1, cut_seg=None, block_end_points=True, until_hw=None, from_hw=None,
+                            full_hw=None):
   """``cut_seg``: segment of a segmented backward (ops.Cuts) in which the blocks above cfg.overlap_cut_hw resume.
   ``block_end_points=False``: the caller wants the prediction only -- the full-resolution output of a block's last conv
   (end_points['encoder_block_*'], which the reference overwrites with its pooled version as `net`, nets/pggan.py:304-306)
-  is then not materialised where the conv can hand the pool and the LeakyReLU sign bits over directly."""
-  hw = source.shape[1]
+  is then not materialised where the conv can hand the pool and the LeakyReLU sign bits over directly.
+  ``until_hw``: only the HEAD of the network -- from_rgb and the blocks above that resolution; returns the tensor that
+  enters the block at ``until_hw``.  ``from_hw`` (+ ``full_hw``, the network's input resolution): only the TAIL -- ``source``
+  is such a tensor, the blocks from ``from_hw`` down, the minibatch stddev and the two last convs follow (discriminator_pair
+  runs the heads per domain and the tail of both discriminators as one batch with ``top`` = PAIR_TOP)."""
+  hw = full_hw or source.shape[1]
   max_stage = max_stage_of(hw)
   assert max_stage >= 0
   max_ch = cfg.max_ch_dis or cfg.max_ch      # get_discriminator_max_num_channels (nets/pggan_utils.py:375-380)
   end_points = {}
   shrinked = None
-  if cfg.is_growing:
-    pooled = ops.avg_pool2(source)
-    name = 'from_rgb_%dx%d' % (hw // 2, hw // 2)
-    shrinked = _d_conv(P, '%s/%s/Conv' % (top, name), pooled, cfg, k=1)
-    shrinked = maybe_resblock(P, '%s/%s' % (top, name), pooled, shrinked.shape[-1], shrinked, cfg, True)
-    end_points[name] = shrinked
-  name = 'from_rgb_%dx%d' % (hw, hw)
-  net = _d_conv(P, '%s/%s/Conv' % (top, name), source, cfg, k=1)
-  net = maybe_resblock(P, '%s/%s' % (top, name), source, net.shape[-1], net, cfg, True)
-  end_points[name] = net
+  net = source
+  if from_hw is None:
+    if cfg.is_growing:
+      pooled = ops.avg_pool2(source)
+      name = 'from_rgb_%dx%d' % (hw // 2, hw // 2)
+      shrinked = _d_conv(P, '%s/%s/Conv' % (top, name), pooled, cfg, k=1)
+      shrinked = maybe_resblock(P, '%s/%s' % (top, name), pooled, shrinked.shape[-1], shrinked, cfg, True)
+      end_points[name] = shrinked
+    name = 'from_rgb_%dx%d' % (hw, hw)
+    net = _d_conv(P, '%s/%s/Conv' % (top, name), source, cfg, k=1)
+    net = maybe_resblock(P, '%s/%s' % (top, name), source, net.shape[-1], net, cfg, True)
+    end_points[name] = net
   for stage in range(max_stage, 0, -1):
     num_channels = get_num_channels(stage - 1, max_ch)
     current_hw = hw // (2 ** (max_stage - stage))
+    if from_hw is not None and current_hw > from_hw:
+      continue
+    if until_hw is not None and current_hw <= until_hw:
+      return net, end_points
     if cut_seg is not None and current_hw == cfg.overlap_cut_hw and current_hw < hw:
       net = ops.Cuts.cut(net, cut_seg)
     net = maybe_add_self_attention(P, top, current_hw, num_channels, net, end_points, None, cfg, True)   # pggan.py:294-296
@@ -749,6 +767,8 @@ def discriminator_before_fc(P, source, cfg, top, groups=1, cut_seg=None, block_e
     if stage == max_stage and cfg.is_growing:
       net = ops.lerp(net, shrinked, cfg.alpha_grow)
       end_points['encoder_block_interpolated_%dx%dx%d' % (current_hw, current_hw, num_channels)] = net
+  if until_hw is not None:
+    return net, end_points
   blk = 'before_fc_1x1x%d' % max_ch
   net = ops.minibatch_state_concat(net, mbstd_cpad(net.shape[3]), groups)      # pggan_utils.py:353-366
   net = _d_conv(P, '%s/%s/Conv' % (top, blk), net, cfg, k=3, padding='SAME', in_ch=max_ch + 1, gdrop=True)
@@ -767,3 +787,57 @@ def discriminator(P, source, cfg, top, groups=1, cut_seg=None, block_end_points=
                              P[top + '/prediction/fully_connected/biases'])
   end_points['prediction'] = pred
   return pred, end_points
+
+
+USE_DISCRIMINATOR_PAIR = True      # False (tests, A/Bs): the two discriminators as separate networks on two streams
+
+
+def discriminator_pair_supported(P, cfg, hw):
+  """Can discriminator_s and discriminator_t run their layers at <= PAIR_HW as grouped launches?  The plain tower only:
+  every option that reads more than (kernel, bias) per layer keeps the per-domain path."""
+  return bool(USE_DISCRIMINATOR_PAIR and getattr(P, 'pairs', None) and hw > PAIR_HW and not cfg.spectral_norm
+              and not cfg.equalized_learning_rate and not cfg.use_res_block and not (cfg.do_dgrop and cfg.is_training)
+              and not (cfg.do_self_attention and cfg.self_attention_hw <= PAIR_HW)
+              and not (cfg.is_growing and hw // 2 <= PAIR_HW))
+
+
+def discriminator_pair(P, source_s, source_t, cfg, groups=1, cut_seg=None, streams=None):
+  """discriminator(source_s; 'discriminator_s') and discriminator(source_t; 'discriminator_t') -> (pred_s, pred_t).
+
+  The reference builds the two discriminators as two towers of identical layers over different variables
+  (twingan.py:105-110; image_generation.py:348-439 once per domain).  Above PAIR_HW each runs on its own stream (kernels
+  that fill the chip); from PAIR_HW down -- launches of a few workgroups each, where the step is bound by the length of
+  the dependent launch chain -- both run as ONE batch [D_s rows; D_t rows] through grouped convs (TgConvDesc.groups = 2:
+  the kernel picks the weight set from the image index), i.e. half the launches.  Every image sees exactly the arithmetic
+  of its own tower: the minibatch-stddev groups stay per call (2 x ``groups``), the convs are per image."""
+  hw = source_s.shape[1]
+  if not discriminator_pair_supported(P, cfg, hw):
+    preds = []
+    for i, (d, src) in enumerate((('s', source_s), ('t', source_t))):
+      with (streams.domain(i) if streams is not None else _null()):
+        preds.append(discriminator(P, src, cfg, 'discriminator_' + d, groups, cut_seg, False)[0])
+    return preds[0], preds[1]
+  heads = []
+  for i, (d, src) in enumerate((('s', source_s), ('t', source_t))):
+    with (streams.domain(i) if streams is not None else _null()):
+      heads.append(discriminator_before_fc(P, src, cfg, 'discriminator_' + d, groups, cut_seg, False, until_hw=PAIR_HW)[0])
+  with (streams.gather(0) if streams is not None else _null()):      # stream 0, ordered after stream 1's head
+    if heads[1].is_cuda:
+      import torch
+      heads[1].record_stream(torch.cuda.current_stream(heads[1].device))      # allocated on stream 1, read here
+    return discriminator_pair_tail(P, heads[0], heads[1], cfg, hw, groups, cut_seg)
+
+
+def discriminator_pair_tail(P, net_s, net_t, cfg, hw, groups=1, cut_seg=None):
+  n = net_s.shape[0]
+  net = ops.cat_rows([net_s, net_t])
+  net, _ = discriminator_before_fc(P, net, cfg, PAIR_TOP, 2 * groups, cut_seg, False, from_hw=PAIR_HW, full_hw=hw)
+  feat = net.reshape(net.shape[0], -1)                                 # tf.squeeze(net, (1, 2))
+  fs, ft = ops.rows(feat, [(0, n), (n, 2 * n)])
+  return tuple(ops.fully_connected(_equalize(f, cfg, 1), P['discriminator_%s/prediction/fully_connected/weights' % d],
+                                   P['discriminator_%s/prediction/fully_connected/biases' % d]) for d, f in (('s', fs), ('t', ft)))
+
+
+def _null():
+  import contextlib
+  return contextlib.nullcontext()

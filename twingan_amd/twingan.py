@@ -50,6 +50,17 @@ class _DomainStreams:
     import contextlib
     return torch.cuda.stream(self.side[i]) if self.enabled else contextlib.nullcontext()
 
+  def gather(self, i):
+    """Context: domain stream i, ordered after everything enqueued on the other domain streams so far (the grouped tail of
+    the two discriminators, pggan.discriminator_pair, reads both heads)."""
+    import contextlib
+    if not self.enabled:
+      return contextlib.nullcontext()
+    for j, st in enumerate(self.side):
+      if j != i:
+        self.side[i].wait_stream(st)
+    return torch.cuda.stream(self.side[i])
+
   def join(self):
     if self.enabled:
       for st in self.side:
@@ -232,9 +243,29 @@ def generator_loss(P, sources, targets, cfg, style_noise=None, distill_embed_s=N
   streams = _DomainStreams(sources.device, cfg.domain_streams)
   # D(cyc) and D(prime) of one domain share weights: one batch, two minibatch-stddev groups -- rows of the generator's batch
   # (``cyc_first``: which chunk of the prediction is the cycle image's)
-  for i, (d, orig, prime, cyc, (both, cyc_first)) in enumerate((
-      ('s', sources, o['s_prime'], o['s_cycle'], o['both_s']),
-      ('t', targets, o['t_prime'], o['t_cycle'], o['both_t']))):
+  if pggan.discriminator_pair_supported(P, cfg, cfg.hw):
+    # both discriminators: heads per domain on two streams, everything from pggan.PAIR_HW down as grouped launches
+    doms = (('s', sources, o['s_prime'], o['s_cycle'], o['both_s']), ('t', targets, o['t_prime'], o['t_cycle'], o['both_t']))
+    for i, (d, orig, prime, cyc, _) in enumerate(doms):
+      with streams.domain(i):
+        terms['l_cyc_' + d] = ops.abs_diff_mean(orig, cyc, cfg.l_cyc_weight)
+    if cyc_gan:
+      preds = pggan.discriminator_pair(P, doms[0][4][0], doms[1][4][0], cfg, groups=2, streams=streams)
+    else:
+      preds = pggan.discriminator_pair(P, doms[0][2], doms[1][2], cfg, streams=streams)
+    for i, ((d, _, _, _, (_, cyc_first)), pred) in enumerate(zip(doms, preds)):
+      with streams.domain(0):      # the grouped tail ran on stream 0
+        if cyc_gan:
+          gc, gp = (0, 1) if cyc_first else (1, 0)
+          tc, tp = ops.pred_losses(pred, pred.shape[0] // 2, _fool_jobs(gc, 0, cfg) + _fool_jobs(gp, 1, cfg), 2)
+          terms['generator_fool_loss_cycle_' + d] = tc
+          terms['generator_fool_loss_prime_' + d] = tp
+        else:
+          terms['generator_fool_loss_prime_' + d] = _fool_loss(pred, cfg)
+    doms = ()
+  else:
+    doms = (('s', sources, o['s_prime'], o['s_cycle'], o['both_s']), ('t', targets, o['t_prime'], o['t_cycle'], o['both_t']))
+  for i, (d, orig, prime, cyc, (both, cyc_first)) in enumerate(doms):
     top = 'discriminator_' + d
     with streams.domain(i):
       terms['l_cyc_' + d] = ops.abs_diff_mean(orig, cyc, cfg.l_cyc_weight)
@@ -291,9 +322,14 @@ def discriminator_loss(P, sources, targets, cfg, gp_alpha_s, gp_alpha_t, dragan_
   cyc_gan = cfg.hw >= 64 and cfg.do_l_cyc_gan
   terms = {}
   streams = _DomainStreams(sources.device, cfg.domain_streams)
-  for i, (d, real, prime, cyc, a, noise, (both, cyc_first)) in enumerate((
-      ('s', sources, o['s_prime'], o['s_cycle'], gp_alpha_s, dragan_noise_s, o['both_s']),
-      ('t', targets, o['t_prime'], o['t_cycle'], gp_alpha_t, dragan_noise_t, o['both_t']))):
+  doms = (('s', sources, o['s_prime'], o['s_cycle'], gp_alpha_s, dragan_noise_s, o['both_s']),
+          ('t', targets, o['t_prime'], o['t_cycle'], gp_alpha_t, dragan_noise_t, o['both_t']))
+  if pggan.discriminator_pair_supported(P, cfg, cfg.hw):
+    _d_pair_terms(P, cfg, terms, doms, cyc_gan, streams)
+    if cfg.loss_architecture in ('wgan_gp', 'dragan'):
+      _d_pair_gp(P, cfg, terms, doms, streams)
+    doms = ()
+  for i, (d, real, prime, cyc, a, noise, (both, cyc_first)) in enumerate(doms):
     top = 'discriminator_' + d
     with streams.domain(i):
       _d_domain_terms(P, cfg, terms, d, top, real, prime, cyc, a, cyc_gan, both, cyc_first)
@@ -327,6 +363,60 @@ def _d_domain_terms(P, cfg, terms, d, top, real, prime, cyc, a, cyc_gan, both=No
     groups = 3 if cyc_gan else 2
     for k, v in zip(names, ops.pred_losses(pred, pred.shape[0] // groups, jobs, len(names))):
       terms[k] = v
+
+
+def _d_pair_terms(P, cfg, terms, doms, cyc_gan, streams):
+  """_d_domain_terms for both domains with the discriminators' low-resolution layers as grouped launches
+  (pggan.discriminator_pair): the per-domain batches [real; cyc; prime] go through their own heads, one tail."""
+  srcs, metas = [], []
+  for i, (d, real, prime, cyc, a, noise, (both, cyc_first)) in enumerate(doms):
+    with streams.domain(i):
+      if cyc_gan:
+        if both is None:
+          both, cyc_first = ops.cat_rows([cyc, prime]), True
+        srcs.append(ops.cat_rows([real, both]))
+      else:
+        srcs.append(ops.cat_rows([real, prime]))
+    metas.append((d, cyc_first))
+  groups = 3 if cyc_gan else 2
+  preds = pggan.discriminator_pair(P, srcs[0], srcs[1], cfg, groups=groups, cut_seg=1, streams=streams)
+  for (d, cyc_first), pred in zip(metas, preds):
+    names, jobs = [], []
+    if cyc_gan:
+      gc, gp = (1, 2) if cyc_first else (2, 1)      # groups of the batched prediction: 0 = real
+      _real_fake_jobs(names, jobs, '_cycle_' + d, gc, 0, cfg)      # only_real_fake_loss=True (twingan.py:466-474)
+      _real_fake_jobs(names, jobs, '_prime_' + d, gp, 0, cfg)
+    else:
+      _real_fake_jobs(names, jobs, '_prime_' + d, 1, 0, cfg)
+    if cfg.wgan_drift_loss_weight and cfg.loss_architecture in ('wgan_gp', 'wgan'):      # image_generation.py:360-367
+      jobs.append((0, len(names), 3, 0.0, 0.0, cfg.wgan_drift_loss_weight))
+      names.append('discriminator_drift_loss_prime_' + d)
+    with streams.domain(0):      # the grouped tail ran on stream 0
+      for k, v in zip(names, ops.pred_losses(pred, pred.shape[0] // groups, jobs, len(names))):
+        terms[k] = v
+
+
+def _d_pair_gp(P, cfg, terms, doms, streams):
+  """_d_domain_gp for both domains: one grouped pass of the two discriminators over the two domains' interpolates, ONE
+  inner tf.gradients call for both (image_generation.py:414-439 per domain)."""
+  interps = []
+  for i, (d, real, prime, cyc, a, noise, _) in enumerate(doms):
+    with streams.domain(i):
+      if cfg.loss_architecture == 'dragan':
+        if noise is None:
+          noise = (torch.rand(real.shape, dtype=torch.float32, device=real.device) * 2.0 - 1.0).to(real.dtype)
+        interps.append(ops.first_order_only(ops.dragan_interpolates(real, noise.contiguous(), a).requires_grad_(True)))
+      else:
+        interps.append(ops.first_order_only(ops.sample_lerp(real, prime, a).requires_grad_(True)))             # image_generation.py:420-424
+  with ops.second_order():
+    pis = pggan.discriminator_pair(P, interps[0], interps[1], cfg, streams=streams)
+  with streams.domain(0):
+    ones = [ops.fill(pi.shape, 1.0, pi.dtype, pi.device) for pi in pis]
+    with ops.no_param_grads():        # only d pred / d interp is needed here; parameters get theirs via the double backward
+      gis = torch.autograd.grad(list(pis), interps, grad_outputs=ones, create_graph=True)  # tf.gradients(pred, interp)
+  for i, ((d, *_), gi) in enumerate(zip(doms, gis)):
+    with streams.domain(i):
+      terms['discriminator_gradient_penalty_prime_' + d] = ops.gradient_penalty(gi.contiguous(), cfg.gradient_penalty_lambda)
 
 
 def _d_domain_gp(P, cfg, terms, d, top, real, prime, a, noise=None, name=None):
@@ -772,3 +862,5 @@ class Trainer:
   def _set_requires_grad(self, g, d):
     for name, s in self.store.specs.items():
       self.P[name].requires_grad_(g if s['group'] == 'g' else d)
+    for pr in self.store.pairs.values():      # the stacked views of the discriminators' twin variables
+      pr.requires_grad_(d)
