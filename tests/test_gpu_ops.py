@@ -2167,6 +2167,11 @@ def test_grouped_conv_equals_one_call_per_weight_set(ops, dtype, case):
 
   # forward, bias + LeakyReLU epilogue
   y = O.conv_fwd_raw(x, w2, b2, spec, epi)
+  if dtype != torch.float32:      # the MFMA kernels of these shapes pick the weight set per image: ONE launch
+    from twingan_amd import _lib
+    sym = _lib.load().tg_last_kernel().decode()
+    assert sym.startswith(('conv_tile_kernel', 'conv_img_kernel', 'conv_small_kernel')[min(case, 3) - (1 if case > 0 else 0)]) and \
+        sym.endswith(',sets>'), sym
   same(y, per_set(lambda i, r: O.conv_fwd_raw(x[r].contiguous(), w2[i], b2[i], spec, epi)))
   # backward-data, plain and with the producer's LeakyReLU mask
   same(O.conv_bwd_data_raw(gy, w2, tuple(x.shape), spec),

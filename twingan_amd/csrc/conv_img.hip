@@ -31,6 +31,10 @@ struct ImgGeom {
   // (conv_tile's mask epilogue for the 8x8 / 4x4 maps: their tg_lrelu_bwd launches -- one per block of every discriminator
   // pass -- are gone)
   const bf16* mask;
+  // weight-set groups (TgConvDesc::groups): npg > 0 = images per group; image i uses weight set i / npg, whose pack starts
+  // wgs_bytes after the previous one (bias row: cout floats).  8x8 maps only (one image per workgroup).
+  int npg;
+  unsigned wgs_bytes;
 };
 
 constexpr unsigned IOOB = 0x80000000u;
@@ -44,7 +48,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t i_rsrc(const void* p, unsigned
 // HW: map size (8 or 4).  MT: 32-pixel column blocks per workgroup (images per workgroup = 32 * MT / HW^2).
 template <int HW, int MT, bool F16 = false, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void conv_img_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
-                                                       const float* __restrict__ bias, bf16* __restrict__ y,
+                                                       const float* __restrict__ bias0, bf16* __restrict__ y,
                                                        const ImgGeom g) {
   constexpr int PPI = HW * HW, HD = HW + 2, IMGS = 32 * MT / PPI, NT = 9;
   static_assert(IMGS >= 1 && IMGS * PPI == 32 * MT, "a workgroup holds whole images");
@@ -56,7 +60,9 @@ __global__ __launch_bounds__(256, 2) void conv_img_kernel(const bf16* __restrict
   const int vpp = g.cin >> 3;                       // 16-byte vectors per pixel
 
   // ---- weight fragments of the first stages go out before anything else: they do not depend on the image
-  const __amdgpu_buffer_rsrc_t rw = i_rsrc(wp, g.w_bytes);
+  const int wset = g.npg ? (img0 >= g.npg) + (img0 >= 2 * g.npg) + (img0 >= 3 * g.npg) : 0;      // uniform: IMGS == 1 when grouped
+  const float* bias = bias0 + wset * g.cout;      // only read under TG_EPI_BIAS
+  const __amdgpu_buffer_rsrc_t rw = i_rsrc(reinterpret_cast<const unsigned char*>(wp) + (size_t)wset * g.wgs_bytes, g.w_bytes);
   const unsigned wrow = (unsigned)(NT * g.cin_pad);
   const unsigned woff = (unsigned)(((n0 + l31) * wrow + kgrp * 8) * 2);      // + (tap * cin_pad + channel) * 2
   const int nchunks = g.cin >> 4;                   // 16-channel K chunks; wave w takes w, w + 4, ...
@@ -243,6 +249,7 @@ int launch_img(const ImgGeom& g, const void* x, const void* wp, const float* bia
     }
   }
   if (STATS) tg_note_kernel(f16 ? "conv_img_kernel<%d,%d,f16,stats>" : "conv_img_kernel<%d,%d,stats>", HW, MT);
+  else if (g.npg) tg_note_kernel(f16 ? "conv_img_kernel<%d,%d,f16,sets>" : "conv_img_kernel<%d,%d,sets>", HW, MT);
   else tg_note_kernel(f16 ? "conv_img_kernel<%d,%d,f16>" : "conv_img_kernel<%d,%d>", HW, MT);
   if (f16) hipLaunchKernelGGL(k1, grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, g);
   else hipLaunchKernelGGL(k0, grid, dim3(256), lds, s, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, g);
@@ -273,8 +280,11 @@ bool tg_conv_img_stats_supported(int n, int hin, int win, int cin, int hout, int
 }
 
 int tg_conv_img_run(int n, int hw, int cin, int cout, int epilogue, float alpha, const void* x, const void* wp,
-                    const float* bias, void* y, hipStream_t s, float* stats, const void* mask) {
+                    const float* bias, void* y, hipStream_t s, float* stats, const void* mask, int groups, size_t wset_elems) {
   ImgGeom g;
+  TG_CHECK(groups <= 1 || (hw == 8 && !stats), TG_ENOSUP, "conv_img: weight-set groups take the 8x8 maps (one image per workgroup)");
+  g.npg = groups > 1 ? n / groups : 0;
+  g.wgs_bytes = groups > 1 ? (unsigned)(wset_elems * 2) : 0u;
   g.stats = stats;
   g.mask = (const bf16*)mask;
   TG_CHECK(!(mask && (stats || epilogue)), TG_ENOSUP, "conv_img: the mask epilogue comes with the plain epilogue only");

@@ -569,15 +569,35 @@ int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int
                      const void* wp, const float* bias, void* y, hipStream_t s, const void* mask = nullptr,
                      float* stats = nullptr, int stat_chunks = 0, int* chunks_query = nullptr, void* ypool = nullptr,
                      void* ymask = nullptr, const void* up_src = nullptr, const void* up_signs = nullptr, float up_alpha = 0.f,
-                     void* up_store = nullptr, const void* up_z = nullptr);
+                     void* up_store = nullptr, const void* up_z = nullptr, int groups = 1, size_t wset_elems = 0);
+bool tg_conv_tile_grouped_native(int n, int h, int w, int cin, int cout);
 
 // Grouped calls (TgConvDesc::groups > 1) the dispatch below takes as ONE launch: the kernel picks the weight set from the
 // image index.  op: 0 forward-shaped (forward, masked, pool), 1 backward-data-shaped, 2 filter gradient.  Everything else
 // is launched once per group by the entry point (capi.hip).
-bool tg_conv2d_grouped_native_mfma(const TgConvDesc* d, int op) {
-  (void)d;
-  (void)op;
-  return false;
+bool tg_conv_img_supported(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l);
+bool tg_conv_small_supported(int n, int hout, int wout, int kh, int kw);
+bool tg_conv2d_grouped_native_mfma(const TgConvDesc* d0, int op) {
+  TgConvDesc dd;
+  const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
+  if (!is16(d) || d->algo == TG_ALGO_MFMA_V1 || d->cin % 8 || d->cout % 8 || d->groups < 2) return false;
+  if (op == 2) return false;      // filter gradients: one launch per group
+  // the conv the kernels see: forward (x -> y) or the same conv over gy with the rotated pack (gy -> gx)
+  const bool fw = op == 0;
+  const int hi = fw ? d->hin : d->hout, wi = fw ? d->win : d->wout, ci = fw ? d->cin : d->cout;
+  const int ho = fw ? d->hout : d->hin, wo = fw ? d->wout : d->win, co = fw ? d->cout : d->cin;
+  const int pt = fw ? d->pad_t : d->kh - 1 - d->pad_t, pl = fw ? d->pad_l : d->kw - 1 - d->pad_l;
+  if (tg_conv_tile_supported(hi, wi, ho, wo, d->kh, d->kw, d->pad_t, d->pad_l)) return tg_conv_tile_grouped_native(d->n, hi, wi, ci, co);
+  if (d->kh == d->kw && tg_conv_img_supported(d->n, hi, wi, ci, ho, wo, co, d->kh, pt, pl)) return true;
+  return d->pad_t == d->pad_l && tg_conv_small_supported(d->n, ho, wo, d->kh, d->kw);
+}
+// weight sets of a descriptor and the elements of one set's pack (mode 0 forward / 1 backward-data operand)
+static int ngroups(const TgConvDesc* d) { return d->groups > 1 ? d->groups : 1; }
+static size_t wset_elems(const TgConvDesc* d, int mode) {
+  if (d->groups <= 1) return 0;
+  TgConvDesc d1 = *d;
+  d1.groups = 1;
+  return tg_conv2d_pack_elems(&d1, mode);
 }
 
 // Forward conv that also writes the 2x2 average pool of its output (conv_tile.hip POOL kernels): 3x3 SAME, even h / w,
@@ -596,7 +616,8 @@ int tg_conv2d_fwd_pool_mfma(const TgConvDesc* d0, const void* x, const void* wp,
   TG_CHECK(tg_conv2d_fwd_pool_supported_mfma(d0), TG_ENOSUP, "tg_conv2d_fwd_pool: shape not taken (query tg_conv2d_fwd_pool_supported)");
   TG_CHECK(!(d->epilogue & TG_EPI_BIAS) || bias, TG_EINVAL, "tg_conv2d_fwd_pool: bias epilogue without bias pointer");
   return tg_conv_tile_run(d->n, d->hin, d->win, d->cin, d->cout, d->kh, d->pad_t, d->epilogue, d->lrelu_alpha, x, wp, bias, y,
-                          s, nullptr, nullptr, 0, nullptr, ypool, ymask);
+                          s, nullptr, nullptr, 0, nullptr, ypool, ymask, nullptr, nullptr, 0.f, nullptr, nullptr, ngroups(d0),
+                          wset_elems(d0, 0));
 }
 
 // Forward conv that also writes the per-workgroup statistics partials of its output (conv_tile.hip STATS kernels).
@@ -605,11 +626,12 @@ bool tg_conv_small_supported(int n, int hout, int wout, int kh, int kw);
 bool tg_conv_small_stats_supported(int n, int hin, int win, int hout, int wout, int cout, int k, int pad_t, int pad_l);
 int tg_conv_small_run(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l,
                       int epilogue, float alpha, const void* x, const void* wp, const float* bias, void* y, hipStream_t s,
-                      float* stats = nullptr, const void* mask = nullptr);
+                      float* stats = nullptr, const void* mask = nullptr, int groups = 1, size_t wset_elems = 0);
 bool tg_conv_img_supported(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l);
 bool tg_conv_img_stats_supported(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l);
 int tg_conv_img_run(int n, int hw, int cin, int cout, int epilogue, float alpha, const void* x, const void* wp,
-                    const float* bias, void* y, hipStream_t s, float* stats = nullptr, const void* mask = nullptr);
+                    const float* bias, void* y, hipStream_t s, float* stats = nullptr, const void* mask = nullptr, int groups = 1,
+                    size_t wset_elems = 0);
 
 int tg_conv2d_fwd_stats_chunks_mfma(const TgConvDesc* d0) {
   TgConvDesc dd;
@@ -657,14 +679,17 @@ int tg_conv2d_fwd_mfma(const TgConvDesc* d0, const void* x, const void* wp, cons
   if (d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 &&
       tg_conv_tile_supported(d->hin, d->win, d->hout, d->wout, d->kh, d->kw, d->pad_t, d->pad_l))
     return tg_conv_tile_run(d->n, d->hin, d->win, d->cin, d->cout, d->kh, d->pad_t, d->epilogue, d->lrelu_alpha, x, wp,
-                            bias, y, s);
+                            bias, y, s, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr,
+                            ngroups(d0), wset_elems(d0, 0));
   if (d->algo != TG_ALGO_MFMA_V1 && d->kh == d->kw &&
       tg_conv_img_supported(d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->pad_t, d->pad_l))
-    return tg_conv_img_run(d->n, d->hin, d->cin, d->cout, d->epilogue, d->lrelu_alpha, x, wp, bias, y, s);
+    return tg_conv_img_run(d->n, d->hin, d->cin, d->cout, d->epilogue, d->lrelu_alpha, x, wp, bias, y, s, nullptr, nullptr,
+                           ngroups(d0), wset_elems(d0, 0));
   if (d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 && d->pad_t == d->pad_l &&
       tg_conv_small_supported(d->n, d->hout, d->wout, d->kh, d->kw))
     return tg_conv_small_run(d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->pad_t, d->pad_l,
-                             d->epilogue, d->lrelu_alpha, x, wp, bias, y, s);
+                             d->epilogue, d->lrelu_alpha, x, wp, bias, y, s, nullptr, nullptr, ngroups(d0), wset_elems(d0, 0));
+  TG_CHECK(d0->groups <= 1, TG_ENOSUP, "tg_conv2d_fwd(mfma): weight-set groups on a first-generation kernel");
   Geom g;
   int rc = fill_geom("tg_conv2d_fwd", d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->kw, d->pad_t,
                      d->pad_l, &g);
@@ -696,11 +721,13 @@ int tg_conv2d_fwd_masked_mfma(const TgConvDesc* d0, const void* x, const void* w
   TG_CHECK(tg_conv2d_fwd_mask_fusable_mfma(d0), TG_ENOSUP, "tg_conv2d_fwd_masked(mfma): mask not fusable here");
   if (tg_conv_tile_supported(d->hin, d->win, d->hout, d->wout, d->kh, d->kw, d->pad_t, d->pad_l))
     return tg_conv_tile_run(d->n, d->hin, d->win, d->cin, d->cout, d->kh, d->pad_t, 0, d->lrelu_alpha, x, wp, nullptr, y, s,
-                            mask_src);
+                            mask_src, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, ngroups(d0),
+                            wset_elems(d0, 0));
   if (d->kh == d->kw && tg_conv_img_supported(d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->pad_t, d->pad_l))
-    return tg_conv_img_run(d->n, d->hin, d->cin, d->cout, 0, d->lrelu_alpha, x, wp, nullptr, y, s, nullptr, mask_src);
+    return tg_conv_img_run(d->n, d->hin, d->cin, d->cout, 0, d->lrelu_alpha, x, wp, nullptr, y, s, nullptr, mask_src, ngroups(d0),
+                           wset_elems(d0, 0));
   return tg_conv_small_run(d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->pad_t, d->pad_l, 0,
-                           d->lrelu_alpha, x, wp, nullptr, y, s, nullptr, mask_src);
+                           d->lrelu_alpha, x, wp, nullptr, y, s, nullptr, mask_src, ngroups(d0), wset_elems(d0, 0));
 }
 
 // Can the LeakyReLU backward of the producer of x be folded into this backward-data's epilogue?
@@ -725,16 +752,20 @@ int tg_conv2d_bwd_data_mfma(const TgConvDesc* d0, const void* gy, const void* wp
   if (d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 &&
       tg_conv_tile_supported(d->hout, d->wout, d->hin, d->win, d->kh, d->kw, d->pad_t, d->pad_l))
     return tg_conv_tile_run(d->n, d->hout, d->wout, d->cout, d->cin, d->kh, d->kh - 1 - d->pad_t, 0,
-                            mask ? d->lrelu_alpha : 1.f, gy, wp, nullptr, gx, s, mask);
+                            mask ? d->lrelu_alpha : 1.f, gy, wp, nullptr, gx, s, mask, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
+                            nullptr, 0.f, nullptr, nullptr, ngroups(d0), wset_elems(d0, 1));
   // backward-data = the same conv over gy with the rotated pack: in = (hout, wout, cout), out = (hin, win, cin), pad' = k-1-pad
   if (d->algo != TG_ALGO_MFMA_V1 && d->kh == d->kw &&
       tg_conv_img_supported(d->n, d->hout, d->wout, d->cout, d->hin, d->win, d->cin, d->kh, d->kh - 1 - d->pad_t,
                             d->kw - 1 - d->pad_l))
-    return tg_conv_img_run(d->n, d->hout, d->cout, d->cin, 0, mask ? d->lrelu_alpha : 1.f, gy, wp, nullptr, gx, s, nullptr, mask);
+    return tg_conv_img_run(d->n, d->hout, d->cout, d->cin, 0, mask ? d->lrelu_alpha : 1.f, gy, wp, nullptr, gx, s, nullptr, mask,
+                           ngroups(d0), wset_elems(d0, 1));
   if (d->algo != TG_ALGO_MFMA_V1 && d->cin % 8 == 0 && d->cout % 8 == 0 && d->pad_t == d->pad_l &&
       tg_conv_small_supported(d->n, d->hin, d->win, d->kh, d->kw))
     return tg_conv_small_run(d->n, d->hout, d->wout, d->cout, d->hin, d->win, d->cin, d->kh, d->kh - 1 - d->pad_t,
-                             d->kw - 1 - d->pad_l, 0, mask ? d->lrelu_alpha : 1.f, gy, wp, nullptr, gx, s, nullptr, mask);
+                             d->kw - 1 - d->pad_l, 0, mask ? d->lrelu_alpha : 1.f, gy, wp, nullptr, gx, s, nullptr, mask, ngroups(d0),
+                             wset_elems(d0, 1));
+  TG_CHECK(d0->groups <= 1, TG_ENOSUP, "tg_conv2d_bwd_data(mfma): weight-set groups on a first-generation kernel");
   Geom g;   // a forward conv over gy: in = (hout,wout,cout), out = (hin,win,cin), pad' = k-1-pad
   int rc = fill_geom("tg_conv2d_bwd_data", d->n, d->hout, d->wout, d->cout, d->hin, d->win, d->cin, d->kh, d->kw,
                      d->kh - 1 - d->pad_t, d->kw - 1 - d->pad_l, &g);
@@ -759,7 +790,7 @@ int tg_conv2d_bwd_data_unpool_mfma(const TgConvDesc* d, const void* gy_pooled, c
   TG_CHECK(!mask || tg_conv2d_bwd_data_mask_fusable_mfma(d), TG_ENOSUP, "tg_conv2d_bwd_data_unpool: mask not fusable here");
   return tg_conv_tile_run(d->n, d->hout, d->wout, d->cout, d->cin, d->kh, d->kh - 1 - d->pad_t, 0, mask ? d->lrelu_alpha : 1.f,
                           nullptr, wp, nullptr, gx, s, mask, nullptr, 0, nullptr, nullptr, nullptr, gy_pooled, y_signs,
-                          d->lrelu_alpha, gy_out, y_act);
+                          d->lrelu_alpha, gy_out, y_act, ngroups(d), wset_elems(d, 1));
 }
 
 static void wgrad_split(const Geom& g, int* n_ci, int* n_co, int* nslices, int* tiles_per_block, int* total_tiles) {

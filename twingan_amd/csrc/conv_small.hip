@@ -31,6 +31,11 @@ struct SmallGeom {
   float* stats;
   // masked backward-data: y *= (mask > 0 ? 1 : alpha), mask = the forward input of the layer (same shape as y); NULL: plain
   const bf16* mask;
+  // weight-set groups (TgConvDesc::groups): bpg > 0 = workgroups (along x) per group; group i owns the pixels
+  // [i * gpix, (i + 1) * gpix) and uses weight set i, whose pack starts wgs_bytes after the previous one (bias row: cout
+  // floats).  A workgroup never straddles two groups (the MFMA's weight operand is shared by its pixel columns).
+  int bpg, gpix;
+  unsigned wgs_bytes;
 };
 
 constexpr unsigned SOOB = 0x80000000u;
@@ -45,16 +50,23 @@ __device__ __forceinline__ bf16x8 s_load16(__amdgpu_buffer_rsrc_t r, unsigned of
 
 template <int NT, int MT, int U, bool F16 = false, bool STATS = false>      // taps (1 or 9); 32-pixel column blocks per workgroup; chunks per load group
 __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
-                                                         const float* __restrict__ bias, bf16* __restrict__ y,
+                                                         const float* __restrict__ bias0, bf16* __restrict__ y,
                                                          const SmallGeom g) {
   __shared__ float red[4][16][64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, kgrp = lane >> 5;
-  const int pbase = blockIdx.x * 32 * MT + l31;     // this lane's output pixel of column block 0 (B operand column)
+  int bx = blockIdx.x, wset = 0;
+  if (g.bpg) {      // uniform
+    wset = bx / g.bpg;
+    bx -= wset * g.bpg;
+  }
+  const int npix = g.bpg ? (wset + 1) * g.gpix : g.npix;      // end of this workgroup's pixel range
+  const int pbase = wset * g.gpix + bx * 32 * MT + l31;      // this lane's output pixel of column block 0 (B operand column)
   const int n0 = blockIdx.y * 32;                   // first output channel of the tile
+  const float* bias = bias0 + wset * g.cout;        // only read under TG_EPI_BIAS
 
   const __amdgpu_buffer_rsrc_t rx = s_rsrc(x, g.x_bytes);
-  const __amdgpu_buffer_rsrc_t rw = s_rsrc(wp, g.w_bytes);
+  const __amdgpu_buffer_rsrc_t rw = s_rsrc(reinterpret_cast<const unsigned char*>(wp) + (size_t)wset * g.wgs_bytes, g.w_bytes);
 
   // per-tap byte offset of this lane's source pixel (channel 0 + kgrp*8), SOOB outside the image / tile
   unsigned xoff[MT][NT];
@@ -68,7 +80,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict_
     for (int t = 0; t < NT; ++t) {
       const int ky = t / (NT == 1 ? 1 : 3), kx = t - ky * (NT == 1 ? 1 : 3);
       const int iy = oy + ky - g.pad_t, ix = ox + kx - g.pad_l;
-      const bool ok = p < g.npix && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
+      const bool ok = p < npix && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
       xoff[m][t] = ok ? (unsigned)((((img * g.hin + iy) * g.win + ix) * g.cin + kgrp * 8) * 2) : SOOB;
     }
   }
@@ -173,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict_
       typedef __attribute__((ext_vector_type(2))) unsigned su32x2;
       const int pm = pbase + m * 32, chq = n0 + q * 8 + kgrp * 4;
       const su32x2 z = __builtin_bit_cast(su32x2, __builtin_amdgcn_raw_buffer_load_b64(
-          rmask, (pm < g.npix && chq + 4 <= g.cout) ? (unsigned)((pm * g.cout + chq) * 2) : SOOB, 0, 0));
+          rmask, (pm < npix && chq + 4 <= g.cout) ? (unsigned)((pm * g.cout + chq) * 2) : SOOB, 0, 0));
       v[0] *= (short)(z[0] & 0xffffu) > 0 ? 1.f : g.alpha;
       v[1] *= (short)(z[0] >> 16) > 0 ? 1.f : g.alpha;
       v[2] *= (short)(z[1] & 0xffffu) > 0 ? 1.f : g.alpha;
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict_
         }
       }
       const int pp = pbase + m * 32;
-      if ((l31 & 15) == 0 && pp < g.npix) {
+      if ((l31 & 15) == 0 && pp < npix) {
         float* out = g.stats + (size_t)(pp >> 4) * 2 * g.cout + n0 + q * 8 + kgrp * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict_
     o[0] = p0; o[1] = p1; o[2] = s0[1]; o[3] = s1[1];
     const int ch0 = n0 + q * 8;
     const int p = pbase + m * 32;
-    const bool ok = kgrp == 0 && p < g.npix && ch0 + 8 <= g.cout;
+    const bool ok = kgrp == 0 && p < npix && ch0 + 8 <= g.cout;
     __builtin_amdgcn_raw_buffer_store_b128(o, ry, ok ? (unsigned)((p * g.cout + ch0) * 2) : SOOB, 0, TG_STORE_AUX);
   }
 }
@@ -234,8 +246,9 @@ bool tg_conv_small_stats_supported(int n, int hin, int win, int hout, int wout, 
 
 int tg_conv_small_run(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l,
                       int epilogue, float alpha, const void* x, const void* wp, const float* bias, void* y,
-                      hipStream_t s, float* stats, const void* mask) {
+                      hipStream_t s, float* stats, const void* mask, int groups, size_t wset_elems) {
   SmallGeom g;
+  TG_CHECK(groups <= 1 || !stats, TG_ENOSUP, "conv_small: no statistics epilogue with weight-set groups");
   g.stats = stats;
   g.mask = (const bf16*)mask;
   TG_CHECK(!(mask && (stats || epilogue)), TG_ENOSUP, "conv_small: the mask epilogue comes with the plain epilogue only");
@@ -257,8 +270,16 @@ int tg_conv_small_run(int n, int hin, int win, int cin, int hout, int wout, int 
   const int ny = (cout + 31) / 32;
   const int mt = (g.npix / 128) * ny >= 256 ? 4 : ((g.npix / 64) * ny >= 256 ? 2 : 1);
   dim3 grid((g.npix + 32 * mt - 1) / (32 * mt), ny);
+  g.bpg = g.gpix = 0;
+  g.wgs_bytes = 0;
+  if (groups > 1) {      // every group its own workgroups: ceil(pixels of a group / pixels of a workgroup) each
+    g.gpix = g.npix / groups;
+    g.bpg = (g.gpix + 32 * mt - 1) / (32 * mt);
+    g.wgs_bytes = (unsigned)(wset_elems * 2);
+    grid.x = groups * g.bpg;
+  }
 #define TG_SMALL_LAUNCH(NT_, MT_)                             \
-  tg_note_kernel(tg_elem_f16() ? "conv_small_kernel<%d,%d,f16>" : "conv_small_kernel<%d,%d>", NT_, MT_); \
+  tg_note_kernel(tg_elem_f16() ? "conv_small_kernel<%d,%d,f16%s>" : "conv_small_kernel<%d,%d%s>", NT_, MT_, g.bpg ? ",sets" : ""); \
   if (tg_elem_f16()) hipLaunchKernelGGL((conv_small_kernel<NT_, MT_, (NT_ == 1 ? 8 / MT_ : 1), true>), grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, g); \
   else hipLaunchKernelGGL((conv_small_kernel<NT_, MT_, (NT_ == 1 ? 8 / MT_ : 1)>), grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, g)
 #define TG_SMALL_LAUNCH_STATS(MT_)                             \

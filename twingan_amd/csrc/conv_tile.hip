@@ -80,6 +80,11 @@ struct TileGeom {
   // of output-channel block 0 (tiles partition the image, so each element is written exactly once) -- the separate
   // tg_lrelu_pool_bwd_signs launch and this kernel's read of its output are gone.  NULL: not written.
   bf16* up_store;
+  // Weight-set groups (TgConvDesc::groups): npg > 0 = images per group -- image i is convolved with weight set i / npg, whose
+  // pack starts wgs elements after the previous one (bias row: cout floats).  The two discriminators' layer as ONE launch
+  // over [D_s rows; D_t rows].  conv_tile_kernel only: a workgroup works on one image.
+  int npg;
+  unsigned wgs;
 };
 
 // LDS layout of a staged halo tile: PS bytes per pixel, ROW bytes per halo row, such that the 16-byte fragment reads of a
@@ -281,8 +286,8 @@ __device__ __forceinline__ float sum_quad(float v) {
 // tensor, the rest from the skip tensor -- instead of from a materialised copy.
 // MODE 0: plain; 1: statistics partials of the output (STATS); 2: also the 2x2 average pool of the output (POOL)
 template <int KH, int KC, int BN, int MT, bool UPCAT = false, int MODE = 0, bool F16 = false>
-__global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
-                                                        const float* __restrict__ bias, bf16* __restrict__ y,
+__global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp0,
+                                                        const float* __restrict__ bias0, bf16* __restrict__ y,
                                                         const TileGeom g) {
   constexpr bool STATS = MODE == 1, POOL = MODE == 2, UPBWD = MODE == 3, UNPOOL = MODE == 4 || MODE == 5, UPZ = MODE == 5;
   static_assert(!(UPBWD && UPCAT), "UPBWD is a backward-data mode: its input is the plain output gradient");
@@ -317,6 +322,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const bf16* __restrict__
   const int ox0 = tx * TW, oy0 = ty * TH;
   const int n0 = blockIdx.y * BN;
   const int c1 = g.cin - g.c0;
+  // weight set of this image (uniform: a workgroup works on one image); npg == 0: one set
+  const int wset = g.npg ? (img >= g.npg) + (img >= 2 * g.npg) + (img >= 3 * g.npg) : 0;
+  const bf16* __restrict__ wp = wp0 + (size_t)wset * g.wgs;
+  const float* __restrict__ bias = bias0 + wset * g.cout;      // only read under TG_EPI_BIAS (a zero-sized resource otherwise)
   const size_t img_elems = UPCAT ? (size_t)(g.h / 2) * (g.w / 2) * g.c0
                                  : UNPOOL ? (size_t)(g.h / 2) * (g.w / 2) * g.cin : (size_t)g.h * g.w * g.cin;
   // UPBWD: a "skip" block (output channels >= c0) belongs to skip image `img` and reads nsrc gy images
@@ -1644,8 +1653,10 @@ int launch_tile_variant(const TileGeom& g, size_t lds, const bf16* x, const bf16
   }
   // names as before for the bf16 kernels (tests/golden/bench_dispatch_kernels.json); ",f16" marks the half instantiation
   static const char* const mode_tag[6] = {"", ",stats", ",pool", ",upbwd", ",unpool", ",unpoolz"};
-  if (F16 && MODE == 0 && !UPCAT) tg_note_kernel("conv_tile_kernel<%d,%d,%d,%d,f16>", KH, KC, BN, MT);
-  else tg_note_kernel("conv_tile_kernel<%d,%d,%d,%d%s%s%s>", KH, KC, BN, MT, UPCAT ? ",upcat" : "", mode_tag[MODE], F16 ? ",f16" : "");
+  // ",sets": one launch over several weight sets (TileGeom::npg)
+  if (F16 && MODE == 0 && !UPCAT) tg_note_kernel("conv_tile_kernel<%d,%d,%d,%d,f16%s>", KH, KC, BN, MT, g.npg ? ",sets" : "");
+  else tg_note_kernel("conv_tile_kernel<%d,%d,%d,%d%s%s%s%s>", KH, KC, BN, MT, UPCAT ? ",upcat" : "", mode_tag[MODE], F16 ? ",f16" : "",
+                      g.npg ? ",sets" : "");
   hipLaunchKernelGGL(kern, dim3(g.nblk, (g.cout + BN - 1) / BN), dim3(256), lds, s, x, wp, bias, y, g);
   TG_LAUNCH_CHECK("conv_tile");
   return TG_OK;
@@ -1745,6 +1756,14 @@ int dispatch_tile_upbwd(const TileGeom& g, const bf16* gy, const bf16* wp, hipSt
   return launch_tile<3, 16, 32, 1>(g, gy, wp, nullptr, nullptr, s);
 }
 
+// does dispatch_tile send this geometry to a kernel whose workgroups hold ONE weight slice over several tiles / images
+// (conv_tile_wres, conv_thin16)?  Those do not select a weight set per image.
+static bool tile_leaves_plain_kernel(const TileGeom& g) {
+  const bool wide = g.cout > 32 && (g.w / 16) * (g.h / 8) * g.n * ((g.cout + 63) / 64) >= 1024;
+  const int tiles1 = (g.w / 16) * (g.h / 8) * g.n * ((g.cout + (wide ? 63 : 31)) / (wide ? 64 : 32));
+  return tiles1 >= 2048 && (g.cin_pad == 16 || g.cin_pad == 32);
+}
+
 template <int KH>
 int dispatch_tile(const TileGeom& g, const bf16* x, const bf16* wp, const float* bias, bf16* y, hipStream_t s) {
   // 64-channel blocks halve the pixel staging per output, but a grid under ~4 workgroups per CU wants 32-channel
@@ -1755,6 +1774,8 @@ int dispatch_tile(const TileGeom& g, const bf16* x, const bf16* wp, const float*
   // when that still leaves >= 2 workgroups per CU and the map is tall enough
   const bool mt2 = (g.h % 16 == 0) && tiles1 >= 2 * 2 * 256 && g.cin_pad >= 64;
   // thin layers with many tiles: weights resident in LDS, several tiles per workgroup
+  // weight-set groups: the plain tile kernel only (tg_conv_tile_grouped_native answers for this dispatch)
+  TG_CHECK(!g.npg || !tile_leaves_plain_kernel(g), TG_ENOSUP, "conv_tile: weight-set groups on a weight-resident / thin-output dispatch");
   if constexpr (KH == 3) {
     if (tiles1 >= 2048 && thin16_takes(g)) return g.cin_pad == 16 ? launch_thin16<16>(g, x, wp, bias, y, s) : launch_thin16<32>(g, x, wp, bias, y, s);
   }
@@ -1780,14 +1801,24 @@ bool tg_conv_tile_supported(int h, int w, int hout, int wout, int kh, int kw, in
   return (h % 8 == 0) && (w % 16 == 0);
 }
 
+// Does a grouped call of this shape (n = the whole batch) stay on conv_tile_kernel, which picks the weight set per image?
+bool tg_conv_tile_grouped_native(int n, int h, int w, int cin, int cout) {
+  TileGeom g;
+  g.n = n; g.h = h; g.w = w; g.cin = cin; g.cout = cout;
+  g.cin_pad = (cin + 15) / 16 * 16;
+  return !tile_leaves_plain_kernel(g);
+}
+
 int tg_conv_tile_run(int n, int h, int w, int cin, int cout, int k, int pad, int epilogue, float alpha, const void* x,
                      const void* wp, const float* bias, void* y, hipStream_t s, const void* mask, float* stats,
                      int stat_chunks, int* chunks_query, void* ypool, void* ymask, const void* up_src, const void* up_signs,
-                     float up_alpha, void* up_store, const void* up_z) {
+                     float up_alpha, void* up_store, const void* up_z, int groups, size_t wset_elems) {
   TileGeom g;
   g.n = n; g.h = h; g.w = w; g.cin = cin; g.cout = cout;
   g.cin_pad = (cin + 15) / 16 * 16;
   g.pad = pad;
+  g.npg = groups > 1 ? n / groups : 0;
+  g.wgs = groups > 1 ? (unsigned)wset_elems : 0u;
   g.tiles_x = g.tiles_y = g.nblk = 0;
   g.epilogue = epilogue;
   g.alpha = alpha;
@@ -1824,6 +1855,8 @@ int tg_conv_tile_upcat_run(int n, int h, int w, int c0, int c1, int cout, int gs
   g.n = n; g.h = h; g.w = w; g.cin = c0 + c1; g.cout = cout;
   g.cin_pad = g.cin;
   g.pad = 1;
+  g.npg = 0;
+  g.wgs = 0;
   g.tiles_x = g.tiles_y = g.nblk = 0;
   g.tiles_per_wg = 0;
   g.epilogue = 0;
@@ -1857,6 +1890,8 @@ int tg_conv_tile_upcat_bwd_run(int n, int h, int w, int c0, int c1, int cout, in
   g.n = n; g.h = h; g.w = w; g.cin = cout; g.cout = c0 + c1;      // a conv over gy: cout -> c0 + c1 channels
   g.cin_pad = (cout + 15) / 16 * 16;
   g.pad = 1;
+  g.npg = 0;
+  g.wgs = 0;
   g.tiles_x = g.tiles_y = g.nblk = 0;
   g.tiles_per_wg = 0;
   g.epilogue = 0;

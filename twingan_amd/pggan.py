@@ -789,7 +789,8 @@ def discriminator(P, source, cfg, top, groups=1, cut_seg=None, block_end_points=
   return pred, end_points
 
 
-USE_DISCRIMINATOR_PAIR = True      # False (tests, A/Bs): the two discriminators as separate networks on two streams
+# False (tests; TG_D_PAIR=0 for same-box A/Bs of the bench): the two discriminators as separate networks on two streams
+USE_DISCRIMINATOR_PAIR = __import__('os').environ.get('TG_D_PAIR', '1') != '0'
 
 
 def discriminator_pair_supported(P, cfg, hw):
