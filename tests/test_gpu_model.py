@@ -1904,7 +1904,8 @@ def test_discriminator_pair_equals_the_two_separate_discriminators(precision):
     ga, gb = out[True][0][grp][1], out[False][0][grp][1]
     num = sum(float(((ga[k] - gb[k]).double() ** 2).sum()) for k in ga)
     den = sum(float((gb[k].double() ** 2).sum()) for k in ga)
-    assert (num / den) ** 0.5 < 1e-5, (grp, (num / den) ** 0.5)
+    # fp32: fixed summation orders; 16-bit: the filter / bias gradients end in fp32 atomics (measured 1.9e-5 in fp16)
+    assert (num / den) ** 0.5 < (1e-5 if precision == 'fp32' else 5e-5), (grp, (num / den) ** 0.5)
     worst = max(rel_l2(ga[k], gb[k]) for k in ga if float(gb[k].abs().max()) > 0)
     assert worst < 1e-3, (grp, worst)
   tr.close()

@@ -709,7 +709,7 @@ def generator(P, source, domain, cfg, unet_end_points=None, top='generator', une
 # discriminator (nets/pggan.py:217-376)
 # ------------------------------------------------------------------------------------------------
 PAIR_TOP = 'discriminator_*'      # scope of the stacked twin variables of discriminator_s / discriminator_t (ParamStore.pairs)
-PAIR_HW = 32                      # the two discriminators run as ONE grouped launch per layer from this resolution down
+PAIR_HW = int(__import__('os').environ.get('TG_PAIR_HW', '32'))      # the two discriminators run as ONE grouped launch per layer from this resolution down
 
 
 def discriminator_before_fc(P, source, cfg, top, groups=1, cut_seg=None, block_end_points=True, until_hw=None, from_hw=None,
@@ -789,8 +789,12 @@ def discriminator(P, source, cfg, top, groups=1, cut_seg=None, block_end_points=
   return pred, end_points
 
 
-# False (tests; TG_D_PAIR=0 for same-box A/Bs of the bench): the two discriminators as separate networks on two streams
-USE_DISCRIMINATOR_PAIR = __import__('os').environ.get('TG_D_PAIR', '1') != '0'
+# The two discriminators as ONE batch through grouped convs from PAIR_HW down.  OFF by default -- measured on MI355X
+# (profiles/r06_b_ab_discriminator_pair.txt, config 3, ms per step): two independent streams, no pair 15.67; pair from 32 / 16 /
+# 8 / 4 down 16.59 / 16.47 / 16.43 / 16.47; pair without streams 16.60; neither 17.29.  Grouping does shorten the serial
+# chain (17.29 -> 16.6), but two streams that never meet hide more (-> 15.67), and the pair needs a join per pass, which a
+# replayed hipGraph pays for dearly.  TG_D_PAIR=1 (or the tests) turns it on; the grouped kernels are exact either way.
+USE_DISCRIMINATOR_PAIR = __import__('os').environ.get('TG_D_PAIR', '0') == '1'
 
 
 def discriminator_pair_supported(P, cfg, hw):
@@ -802,7 +806,7 @@ def discriminator_pair_supported(P, cfg, hw):
               and not (cfg.is_growing and hw // 2 <= PAIR_HW))
 
 
-def discriminator_pair(P, source_s, source_t, cfg, groups=1, cut_seg=None, streams=None):
+def discriminator_pair(P, source_s, source_t, cfg, groups=1, cut_seg=None, streams=None, meanwhile=None):
   """discriminator(source_s; 'discriminator_s') and discriminator(source_t; 'discriminator_t') -> (pred_s, pred_t).
 
   The reference builds the two discriminators as two towers of identical layers over different variables
@@ -810,23 +814,32 @@ def discriminator_pair(P, source_s, source_t, cfg, groups=1, cut_seg=None, strea
   that fill the chip); from PAIR_HW down -- launches of a few workgroups each, where the step is bound by the length of
   the dependent launch chain -- both run as ONE batch [D_s rows; D_t rows] through grouped convs (TgConvDesc.groups = 2:
   the kernel picks the weight set from the image index), i.e. half the launches.  Every image sees exactly the arithmetic
-  of its own tower: the minibatch-stddev groups stay per call (2 x ``groups``), the convs are per image."""
+  of its own tower: the minibatch-stddev groups stay per call (2 x ``groups``), the convs are per image.
+  ``meanwhile``: work for the MAIN stream that is independent of the discriminators (the generator step's re-encoding pass),
+  enqueued after the heads were forked onto the domain streams and before the main stream joins them for the tail.  (The
+  tail runs on the main stream: a wait edge between the two domain streams made hipStreamEndCapture fault, ROCm 7.2.)"""
   hw = source_s.shape[1]
   if not discriminator_pair_supported(P, cfg, hw):
     preds = []
     for i, (d, src) in enumerate((('s', source_s), ('t', source_t))):
       with (streams.domain(i) if streams is not None else _null()):
         preds.append(discriminator(P, src, cfg, 'discriminator_' + d, groups, cut_seg, False)[0])
+    if meanwhile is not None:
+      meanwhile()
     return preds[0], preds[1]
   heads = []
   for i, (d, src) in enumerate((('s', source_s), ('t', source_t))):
     with (streams.domain(i) if streams is not None else _null()):
       heads.append(discriminator_before_fc(P, src, cfg, 'discriminator_' + d, groups, cut_seg, False, until_hw=PAIR_HW)[0])
-  with (streams.gather(0) if streams is not None else _null()):      # stream 0, ordered after stream 1's head
-    if heads[1].is_cuda:
+  if meanwhile is not None:
+    meanwhile()
+  if streams is not None:
+    streams.join()
+    if heads[0].is_cuda:
       import torch
-      heads[1].record_stream(torch.cuda.current_stream(heads[1].device))      # allocated on stream 1, read here
-    return discriminator_pair_tail(P, heads[0], heads[1], cfg, hw, groups, cut_seg)
+      for h in heads:
+        h.record_stream(torch.cuda.current_stream(h.device))      # allocated on a domain stream, read on the main one
+  return discriminator_pair_tail(P, heads[0], heads[1], cfg, hw, groups, cut_seg)
 
 
 def discriminator_pair_tail(P, net_s, net_t, cfg, hw, groups=1, cut_seg=None):

@@ -36,7 +36,7 @@ class _DomainStreams:
   NSTREAMS = 2      # measured: 2 streams 676 img/s, 4 streams (GP passes on their own) 615-623
 
   def __init__(self, device, enabled):
-    self.enabled = enabled and torch.cuda.is_available()
+    self.enabled = enabled and torch.cuda.is_available() and os.environ.get('TG_DOMAIN_STREAMS', '1') != '0'
     if self.enabled:
       key = torch.device(device).index
       if key not in self._pool:
@@ -49,17 +49,6 @@ class _DomainStreams:
   def domain(self, i):
     import contextlib
     return torch.cuda.stream(self.side[i]) if self.enabled else contextlib.nullcontext()
-
-  def gather(self, i):
-    """Context: domain stream i, ordered after everything enqueued on the other domain streams so far (the grouped tail of
-    the two discriminators, pggan.discriminator_pair, reads both heads)."""
-    import contextlib
-    if not self.enabled:
-      return contextlib.nullcontext()
-    for j, st in enumerate(self.side):
-      if j != i:
-        self.side[i].wait_stream(st)
-    return torch.cuda.stream(self.side[i])
 
   def join(self):
     if self.enabled:
@@ -243,25 +232,30 @@ def generator_loss(P, sources, targets, cfg, style_noise=None, distill_embed_s=N
   streams = _DomainStreams(sources.device, cfg.domain_streams)
   # D(cyc) and D(prime) of one domain share weights: one batch, two minibatch-stddev groups -- rows of the generator's batch
   # (``cyc_first``: which chunk of the prediction is the cycle image's)
+  reenc = {}
+
+  def reencode():
+    # re-encode s' in domain s and t' in domain t as one batch (twingan.py:275-288): rows [s'; t'] of the generator's batch
+    reenc['e2'] = pggan.encoder_before_classification(P, o['primes'], ('s', 't', b, 2), cfg)[0]
   if pggan.discriminator_pair_supported(P, cfg, cfg.hw):
-    # both discriminators: heads per domain on two streams, everything from pggan.PAIR_HW down as grouped launches
+    # both discriminators: heads per domain on two streams (the main stream re-encodes meanwhile), everything from
+    # pggan.PAIR_HW down as grouped launches on the main stream
     doms = (('s', sources, o['s_prime'], o['s_cycle'], o['both_s']), ('t', targets, o['t_prime'], o['t_cycle'], o['both_t']))
     for i, (d, orig, prime, cyc, _) in enumerate(doms):
       with streams.domain(i):
         terms['l_cyc_' + d] = ops.abs_diff_mean(orig, cyc, cfg.l_cyc_weight)
     if cyc_gan:
-      preds = pggan.discriminator_pair(P, doms[0][4][0], doms[1][4][0], cfg, groups=2, streams=streams)
+      preds = pggan.discriminator_pair(P, doms[0][4][0], doms[1][4][0], cfg, groups=2, streams=streams, meanwhile=reencode)
     else:
-      preds = pggan.discriminator_pair(P, doms[0][2], doms[1][2], cfg, streams=streams)
-    for i, ((d, _, _, _, (_, cyc_first)), pred) in enumerate(zip(doms, preds)):
-      with streams.domain(0):      # the grouped tail ran on stream 0
-        if cyc_gan:
-          gc, gp = (0, 1) if cyc_first else (1, 0)
-          tc, tp = ops.pred_losses(pred, pred.shape[0] // 2, _fool_jobs(gc, 0, cfg) + _fool_jobs(gp, 1, cfg), 2)
-          terms['generator_fool_loss_cycle_' + d] = tc
-          terms['generator_fool_loss_prime_' + d] = tp
-        else:
-          terms['generator_fool_loss_prime_' + d] = _fool_loss(pred, cfg)
+      preds = pggan.discriminator_pair(P, doms[0][2], doms[1][2], cfg, streams=streams, meanwhile=reencode)
+    for (d, _, _, _, (_, cyc_first)), pred in zip(doms, preds):
+      if cyc_gan:
+        gc, gp = (0, 1) if cyc_first else (1, 0)
+        tc, tp = ops.pred_losses(pred, pred.shape[0] // 2, _fool_jobs(gc, 0, cfg) + _fool_jobs(gp, 1, cfg), 2)
+        terms['generator_fool_loss_cycle_' + d] = tc
+        terms['generator_fool_loss_prime_' + d] = tp
+      else:
+        terms['generator_fool_loss_prime_' + d] = _fool_loss(pred, cfg)
     doms = ()
   else:
     doms = (('s', sources, o['s_prime'], o['s_cycle'], o['both_s']), ('t', targets, o['t_prime'], o['t_cycle'], o['both_t']))
@@ -278,9 +272,9 @@ def generator_loss(P, sources, targets, cfg, style_noise=None, distill_embed_s=N
       else:
         pp, _ = pggan.discriminator(P, prime, cfg, top, block_end_points=False)
         terms['generator_fool_loss_prime_' + d] = _fool_loss(pp, cfg)
-  # re-encode s' in domain s and t' in domain t as one batch (twingan.py:275-288): rows [s'; t'] of the generator's batch
-  primes = o['primes']
-  e2, _ = pggan.encoder_before_classification(P, primes, ('s', 't', b, 2), cfg)
+  if 'e2' not in reenc:
+    reencode()
+  primes, e2 = o['primes'], reenc['e2']
   e_sp, e_tp = ops.rows(e2, [(0, b), (b, 2 * b)])
   if cfg.l_content_weight:
     terms['l_content_s'] = ops.abs_diff_mean(o['es'], e_tp, cfg.l_content_weight)
@@ -391,9 +385,8 @@ def _d_pair_terms(P, cfg, terms, doms, cyc_gan, streams):
     if cfg.wgan_drift_loss_weight and cfg.loss_architecture in ('wgan_gp', 'wgan'):      # image_generation.py:360-367
       jobs.append((0, len(names), 3, 0.0, 0.0, cfg.wgan_drift_loss_weight))
       names.append('discriminator_drift_loss_prime_' + d)
-    with streams.domain(0):      # the grouped tail ran on stream 0
-      for k, v in zip(names, ops.pred_losses(pred, pred.shape[0] // groups, jobs, len(names))):
-        terms[k] = v
+    for k, v in zip(names, ops.pred_losses(pred, pred.shape[0] // groups, jobs, len(names))):      # main stream, as the tail
+      terms[k] = v
 
 
 def _d_pair_gp(P, cfg, terms, doms, streams):
@@ -410,10 +403,9 @@ def _d_pair_gp(P, cfg, terms, doms, streams):
         interps.append(ops.first_order_only(ops.sample_lerp(real, prime, a).requires_grad_(True)))             # image_generation.py:420-424
   with ops.second_order():
     pis = pggan.discriminator_pair(P, interps[0], interps[1], cfg, streams=streams)
-  with streams.domain(0):
-    ones = [ops.fill(pi.shape, 1.0, pi.dtype, pi.device) for pi in pis]
-    with ops.no_param_grads():        # only d pred / d interp is needed here; parameters get theirs via the double backward
-      gis = torch.autograd.grad(list(pis), interps, grad_outputs=ones, create_graph=True)  # tf.gradients(pred, interp)
+  ones = [ops.fill(pi.shape, 1.0, pi.dtype, pi.device) for pi in pis]
+  with ops.no_param_grads():        # only d pred / d interp is needed here; parameters get theirs via the double backward
+    gis = torch.autograd.grad(list(pis), interps, grad_outputs=ones, create_graph=True)  # tf.gradients(pred, interp)
   for i, ((d, *_), gi) in enumerate(zip(doms, gis)):
     with streams.domain(i):
       terms['discriminator_gradient_penalty_prime_' + d] = ops.gradient_penalty(gi.contiguous(), cfg.gradient_penalty_lambda)
