@@ -429,6 +429,8 @@ def main():
       dist.destroy_process_group()
     return
 
+  # a 16-bit conv that the MFMA kernels do not take must fail here, not run 100 x slower under an MFMA label (ops._slow_dispatch)
+  os.environ.setdefault('TG_STRICT_DISPATCH', '1')
   from twingan_amd import Config
   from twingan_amd.twingan import Trainer
   extra = {}

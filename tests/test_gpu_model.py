@@ -1909,3 +1909,32 @@ def test_discriminator_pair_equals_the_two_separate_discriminators(precision):
     worst = max(rel_l2(ga[k], gb[k]) for k in ga if float(gb[k].abs().max()) > 0)
     assert worst < 1e-3, (grp, worst)
   tr.close()
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_rccl_segmented_capture_one_rank(precision):
+  """The path the first real 8-GPU run takes (deployment/model_deploy.py:265-268,473-503 replaced by it): a torch.distributed
+  "nccl" (= RCCL) process group alive in the process, the backward cut into segments (ops.Cuts) and captured as one hipGraph
+  per segment in thread_local mode, an asynchronous all-reduce of each segment's range of the flat gradient buffer between
+  the replays, the wait before the apply graph.  With ONE rank (all a 1-GPU box allows; a one-rank sum is the identity) the
+  parameters after three G+D steps must equal the unsegmented single-graph trainer's -- bit for bit in fp32 -- with
+  collectives actually issued and no fallback to an unsegmented capture.  tools/rccl_smoke.py in a child process: the process
+  group must not leak into the other tests."""
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+  env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+  r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'rccl_smoke.py'), '--precision', precision, '--steps', '3'],
+                     capture_output=True, text=True, timeout=900, env=env)
+  assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+  d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+  assert d['backend'] == 'nccl' and d['world'] == 1 and d['segments'] == {'g': 3, 'd': 2}
+  assert d['use_graph'] and d['capture_note'] is None, d
+  # six runs: 3 generator applies x 3 ranges + 3 discriminator applies x 2 ranges, every byte of both gradient buffers once per apply
+  assert d['collectives'] == 3 * 3 + 3 * 2 and d['finishes'] == 6 and d['allreduce_bytes'] > 0, d
+  if precision == 'fp32':
+    assert d['tensors_not_bit_equal'] == 0 and d['params_rel_l2'] == 0.0, d
+  else:
+    assert d['params_rel_l2'] < 2e-2, d      # 16-bit run-to-run noise under Adam's sign-like first steps (DESIGN.md section 2)

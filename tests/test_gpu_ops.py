@@ -2211,3 +2211,48 @@ def test_grouped_conv_equals_one_call_per_weight_set(ops, dtype, case):
     assert rel_l2(host(bsink), host(gy.float().reshape(2, -1, cout).sum(1))) < 1e-3
     if O.conv_bwd_weight2_raw(x, gy, x[:n].contiguous(), gy[:n].contiguous(), spec, sink, bsink, 3):      # two segments, both grouped
       assert rel_l2(host(sink), 3.0 * host(ref)) < tol
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_latent_layer_as_a_gemm_equals_the_padded_valid_conv(ops, dtype, monkeypatch):
+  """ops.latent_conv: the plain PGGAN generator's first layer (nets/pggan.py:135-153, a 4x4 VALID conv over the latent noise
+  zero-padded to 7x7) as [B, C] @ [C, 16 C'] of the flipped kernel -- output, kernel gradient and noise gradient against the
+  float64 oracle's conv over the padded tensor, and against the conv kernel it replaces (which the 16-bit MFMA dispatch does
+  not take: under TG_STRICT_DISPATCH=1 that fallback is an error, not a 100x slower launch)."""
+  import twingan_amd.ops as O
+  from twingan_amd import _lib
+  g = torch.Generator().manual_seed(77)
+  b, c, co, k = 6, 32, 24, 4
+  rnd = bf16_round if dtype == torch.bfloat16 else f16_round
+  noise = torch.randn(b, 1, 1, c, generator=g)
+  w = torch.randn(k, k, c, co, generator=g) * (2.0 / (k * k * c)) ** 0.5
+  gy = torch.randn(b, k, k, co, generator=g)
+  nd = noise.to(dtype).to(dev()).requires_grad_(True)
+  wd = w.to(dev()).requires_grad_(True)
+  y = O.latent_conv(nd, wd)
+  assert y.shape == (b, k, k, co) and y.dtype == dtype
+  y.backward(gy.to(dtype).to(dev()))
+  # oracle: the VALID conv over the zero-padded noise, operands as stored
+  xpad = np.zeros((b, 2 * k - 1, 2 * k - 1, c))
+  xpad[:, k - 1, k - 1, :] = rnd(host(noise))[:, 0, 0, :]
+  want = N.conv2d(xpad, host(w), 'VALID')
+  assert rel_l2(host(y), want) < (1e-2 if dtype == torch.bfloat16 else 2e-3)
+  gyr = rnd(host(gy))
+  want_gw = N.conv2d_bwd_weight(xpad, gyr, (k, k), 'VALID')
+  assert rel_l2(host(wd.grad), want_gw) < 1e-5      # fp32 products of the stored operands, fp32 sums
+  want_gx = N.conv2d_bwd_data(gyr, host(w), (2 * k - 1, 2 * k - 1), 'VALID')[:, k - 1, k - 1, :]
+  assert rel_l2(host(nd.grad).reshape(b, c), want_gx) < (1e-2 if dtype == torch.bfloat16 else 2e-3)
+  # the conv it replaces: same numbers from the direct kernel -- with a warning, and an error in strict mode
+  xp = torch.nn.functional.pad(noise.to(dtype).to(dev()), (0, 0, k - 1, k - 1, k - 1, k - 1)).contiguous()
+  O._SLOW_SEEN.clear()
+  c2, co2 = 64, 64      # above the 1 MFLOP threshold
+  xp2 = torch.zeros(b, 7, 7, c2, dtype=dtype, device=dev())
+  w2 = torch.zeros(4, 4, c2, co2, device=dev())
+  with pytest.warns(UserWarning, match='conv_\\*_direct'):
+    O.conv2d(xp2, w2, None, 4, 'VALID')
+  monkeypatch.setenv('TG_STRICT_DISPATCH', '1')
+  with pytest.raises(_lib.TgError, match='TG_STRICT_DISPATCH'):
+    O.conv2d(xp2, w2, None, 4, 'VALID')
+  monkeypatch.delenv('TG_STRICT_DISPATCH')
+  ref = O.conv2d(xp, wd.detach(), None, 4, 'VALID')
+  assert rel_l2(host(y), host(ref)) < (1e-2 if dtype == torch.bfloat16 else 2e-3)

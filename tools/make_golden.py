@@ -254,23 +254,26 @@ def training(hw=16, max_ch=8, batch=2, n_runs=4, seed=0):
   return d
 
 
-def full_size(hw=256, max_ch=256, batch=2, seed=0):
+def full_size(hw=256, max_ch=256, batch=2, seed=0, **extra):
   """BASELINE.json's headline configuration (256x256, 256 channels) through the reference's own code, at full size.
   The weights (71 MB) are not stored: they are `R.init_params(cfg, seed, float64, 'he')` rounded to fp32 and the inputs
   come from a seeded generator, both re-created by the test; what is stored is what the reference computed -- every
   loss term, the L2 norm of every variable's gradient, a probe of every generated image.  (Takes a few minutes and
   ~20 GB: `python tools/make_golden.py --full`.)"""
   from oracle import ref_runner
-  cfg = R.Config(hw=hw, max_ch=max_ch)
+  cfg = R.Config(hw=hw, max_ch=max_ch, **extra)
   P = {k: v.float().double() for k, v in R.init_params(cfg, seed=seed, dtype=torch.float64, std='he').items()}
+  # ``extra`` (BASELINE configs[4]: spectral_norm, do_self_attention, self_attention_hw): the power-iteration vectors u are
+  # R.init_sn_state(P, seed + 1) rounded to fp32, re-created by the test like the weights
+  state = {k: v.float().double() for k, v in R.init_sn_state(P, seed=seed + 1).items()} if cfg.spectral_norm else {}
   g = torch.Generator().manual_seed(1234)
   s = torch.rand(batch, hw, hw, 3, generator=g).double()
   t = torch.rand(batch, hw, hw, 3, generator=g).double()
   ref = ref_runner.run(ref_runner.flags_of(cfg), s.numpy(), t.numpy(), seed=seed,
-                       preset={k: v.numpy() for k, v in P.items()})
-  assert set(ref['variables']) - {'global_step'} == set(P)
+                       preset={k: v.numpy() for k, v in list(P.items()) + list(state.items())})
+  assert set(ref['variables']) - {'global_step'} == set(P) | set(state)
   alphas = [v.reshape(-1).tolist() for n, v in ref['random'] if n == 'alpha']
-  out = dict(config=dict(hw=hw, max_ch=max_ch), batch=batch, param_seed=seed, input_seed=1234,
+  out = dict(config=dict(hw=hw, max_ch=max_ch, **extra), batch=batch, param_seed=seed, input_seed=1234,
              gp_alpha_s=alphas[0], gp_alpha_t=alphas[1], g_total=ref['g_loss'], d_total=ref['d_loss'],
              g_terms={ref_runner.term_name(k): v for k, v in ref['g_terms'].items()},
              d_terms={ref_runner.term_name(k): v for k, v in ref['d_terms'].items()})
@@ -516,9 +519,16 @@ if __name__ == '__main__':
     # --full [--hw 64|128|256]: BASELINE.json configs[1] / configs[2] / configs[3] at 256 channels, batch 2
     import json
     hw = int(sys.argv[sys.argv.index('--hw') + 1]) if '--hw' in sys.argv else 256
-    name = 'full_hw%d_c256.json' % hw
+    # --sn --attention [--batch N]: BASELINE configs[4] (256 x 256 + self-attention at 64 x 64 + spectral-norm discriminators)
+    extra = {}
+    if '--sn' in sys.argv:
+      extra['spectral_norm'] = True
+    if '--attention' in sys.argv:
+      extra.update(do_self_attention=True, self_attention_hw=64)
+    batch = int(sys.argv[sys.argv.index('--batch') + 1]) if '--batch' in sys.argv else 2
+    name = 'full_hw%d_c256%s%s.json' % (hw, '_sn' if '--sn' in sys.argv else '', '_att' if '--attention' in sys.argv else '')
     with open(os.path.join(OUT, name), 'w') as fh:
-      json.dump(full_size(hw=hw), fh, indent=0, sort_keys=True)
+      json.dump(full_size(hw=hw, batch=batch, **extra), fh, indent=0, sort_keys=True)
     print(name, os.path.getsize(os.path.join(OUT, name)))
   else:
     main()

@@ -371,6 +371,28 @@ def _mfma_ok(dtype, cin, cout, spec, hin, win):
   return spec.valid and hin == spec.kh and win == spec.kw     # k x k VALID on k x k input -> dense
 
 
+_SLOW_SEEN = set()
+
+
+def _slow_dispatch(n, ho, wo, cin, cout, spec):
+  """A 16-bit conv the MFMA kernels do not take runs on the one-thread-per-output kernels (conv_direct.hip: the exact
+  fp32 path's kernels) -- two orders of magnitude slower.  Never silently: above 1 MFLOP a warning once per shape, an error
+  under TG_STRICT_DISPATCH=1 (bench.py sets it: a bench line must not time such a fallback under an MFMA label)."""
+  flops = 2 * n * ho * wo * cout * spec.kh * spec.kw * cin
+  if flops < 1e6:
+    return
+  key = (ho, wo, cin, cout, spec.kh, spec.valid)
+  msg = ('16-bit conv k%d %s c%d>%d at %dx%d (n %d, %.1f MFLOP) is not taken by the MFMA kernels (cin %% 8, cout %% 8, k in {1, 3} '
+         'or the dense k x k VALID case) and runs on conv_*_direct' % (spec.kh, 'VALID' if spec.valid else 'SAME', cin, cout, ho, wo,
+                                                                        n, flops / 1e6))
+  if os.environ.get('TG_STRICT_DISPATCH') == '1':
+    raise _lib.TgError(msg + ' (TG_STRICT_DISPATCH=1)')
+  if key not in _SLOW_SEEN:
+    _SLOW_SEEN.add(key)
+    import warnings
+    warnings.warn(msg)
+
+
 def _esize(t):
   return 2 if t.dtype in HALF_TYPES else 4
 
@@ -407,6 +429,8 @@ def _desc(x_shape, cout, spec, dtype, epilogue, groups=1):
   d.kh, d.kw, d.pad_t, d.pad_l = spec.kh, spec.kw, spec.pad_t, spec.pad_l
   d.dtype = _DTYPES[dtype]
   d.algo = TG_ALGO_MFMA if _mfma_ok(dtype, cin, cout, spec, h, w) else TG_ALGO_DIRECT
+  if d.algo == TG_ALGO_DIRECT and dtype in HALF_TYPES:
+    _slow_dispatch(n, ho, wo, cin, cout, spec)
   d.epilogue = epilogue
   d.lrelu_alpha = spec.alpha
   d.groups = groups
@@ -2658,6 +2682,21 @@ def fully_connected(x, w, b):
     return FcFn.apply(x, w, b)
   y = GemmFn.apply(cast(x, torch.float32), w, False, False)
   return AddRowBiasFn.apply(y, b) if b is not None else y
+
+
+def latent_conv(noise, w):
+  """The plain PGGAN generator's first layer (nets/pggan.py:135-153): a k x k VALID conv over the [B, 1, 1, C] latent noise
+  zero-padded to (2k - 1) x (2k - 1), whose only non-zero pixel meets tap (k-1-oy, k-1-ox) at output pixel (oy, ox):
+      y[b, oy, ox, :] = noise[b, :] @ w[k-1-oy, k-1-ox]        i.e.  [B, C] @ [C, k*k*C'] of the flipped kernel,
+  a GEMM with 1 / (2k-1)^2 of the padded conv's multiplies, every one of them on a non-zero (the conv kernels have no
+  k = 4 VALID form off the dense k x k-input case: the layer fell to the one-thread-per-output kernel, 62 % of BASELINE
+  configs[0]'s step).  fp32 accumulation over the fp32 master kernel; the flip / regrouping of the kernel and its adjoint
+  (into the kernel's gradient) are framework view ops of a 4 MB tensor.  -> [B, k, k, C'] of noise's dtype."""
+  b = noise.shape[0]
+  k, _, c, co = w.shape
+  wm = w.flip(0, 1).permute(2, 0, 1, 3).reshape(c, k * k * co)
+  y = GemmFn.apply(cast(noise.reshape(b, c), torch.float32), wm.contiguous(), False, False)
+  return cast(y, noise.dtype).view(b, k, k, co)
 
 
 # ------------------------------------------------------------------------------------------------

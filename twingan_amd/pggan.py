@@ -286,7 +286,7 @@ def _cond_rows(P, scope, ns, cond, segments):
 
 
 def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pixel_norm=True, pool=False, equalize=True,
-             upcat=None, cond=None, spectral=True):
+             upcat=None, cond=None, spectral=True, latent=None):
   """maybe_pixel_norm(maybe_equalized_conv2d(...)) for the generator / encoder arg-scope
   (nets/pggan_utils.py:86-98,236-245): conv without bias, per-domain instance norm, LeakyReLU(0.2),
   then pixel norm (nets/pggan.py:78-81).  ``domain`` is 's' | 't', or (d0, d1, split): the batch holds
@@ -315,6 +315,9 @@ def _ge_conv(P, scope, x, domain, cfg, k=3, padding='SAME', activation=True, pix
       y, cst = ops.upcat_conv_stats(upcat[0], upcat[1], w, upcat[2], upcat[3])
     else:
       y = ops.upcat_conv(upcat[0], upcat[1], w, upcat[2], upcat[3])
+  elif latent is not None and latent.dtype in ops.HALF_TYPES:
+    # x is the [B, 1, 1, C] noise ``latent`` zero-padded for a k x k VALID conv (nets/pggan.py:135-153): the GEMM form
+    y = ops.latent_conv(_equalize(latent, cfg, k, in_ch=latent.shape[-1]) if equalize else latent, w)
   elif k == 1 and (w.shape[2] <= 4 or w.shape[3] <= 4):
     y = ops.pointwise_conv(_equalize(x, cfg, k) if equalize else x, w)
   elif want_stats:
@@ -650,6 +653,7 @@ def generator(P, source, domain, cfg, unet_end_points=None, top='generator', une
   if source.dim() == 2:
     source = source.reshape(source.shape[0], 1, 1, source.shape[1])
   noise_mode = source.shape[1] == 1 and source.shape[2] == 1
+  noise = source if noise_mode else None
   if noise_mode:
     source = torch.nn.functional.pad(source, (0, 0, 3, 3, 3, 3)).contiguous()
   else:
@@ -664,7 +668,7 @@ def generator(P, source, domain, cfg, unet_end_points=None, top='generator', une
     name = 'block_%dx%dx%d' % (hw, hw, output_channels)
     if hw == 4:
       if noise_mode:
-        net = _ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg, k=4, padding='VALID', cond=cond)
+        net = _ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg, k=4, padding='VALID', cond=cond, latent=noise)
       else:
         net = _ge_conv(P, '%s/%s/Conv' % (top, name), net, domain, cfg, cond=cond)
       net = _ge_conv(P, '%s/%s/Conv_1' % (top, name), net, domain, cfg, cond=cond)
