@@ -43,6 +43,10 @@ def sketch_vectors(index, numel, device='cpu'):
 def main():
   hw_arg = int(sys.argv[sys.argv.index('--hw') + 1]) if '--hw' in sys.argv else 256      # --hw 64 | 128: configs[1] / configs[2]
   base = 'full_hw%d_c256' % hw_arg
+  if '--fixture' in sys.argv:      # --fixture full_hw256_c256_sn_att --dtype fp16: BASELINE configs[4] (its storage type is fp16)
+    base = sys.argv[sys.argv.index('--fixture') + 1]
+  sdt_name = sys.argv[sys.argv.index('--dtype') + 1] if '--dtype' in sys.argv else 'bf16'
+  sdt = {'bf16': torch.bfloat16, 'fp16': torch.float16}[sdt_name]
   with open(os.path.join(ROOT, 'tests', 'golden', base + '.json')) as fh:
     fix = json.load(fh)
   hw, batch = fix['config']['hw'], fix['batch']
@@ -53,14 +57,17 @@ def main():
   t = torch.rand(batch, hw, hw, 3, generator=g).double()
   a_s = torch.tensor(fix['gp_alpha_s'], dtype=torch.float64).reshape(-1, 1, 1, 1)
   a_t = torch.tensor(fix['gp_alpha_t'], dtype=torch.float64).reshape(-1, 1, 1, 1)
-  sr, tr_ = s.to(torch.bfloat16).double(), t.to(torch.bfloat16).double()      # what the bf16 test feeds the kernels
+  sr, tr_ = s.to(sdt).double(), t.to(sdt).double()      # what the 16-bit test feeds the kernels
+  sn_state = {k: v.float().double() for k, v in R.init_sn_state(P, seed=fix['param_seed'] + 1).items()} if cfg.spectral_norm else None
   groups = {'g': R.generator_var_names(P), 'd': R.discriminator_var_names(P)}
   order = sorted(P)
-  out = dict(K=K, sketch_seed=SKETCH_SEED, dtype='bf16', order=order, exact_sketch={}, rounded_rel_l2={}, exact_norm_check={})
+  out = dict(K=K, sketch_seed=SKETCH_SEED, dtype=sdt_name, order=order, exact_sketch={}, rounded_rel_l2={}, exact_norm_check={})
 
   def grads(group, rounded):
     Q = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
     x, y = (sr, tr_) if rounded else (s, t)
+    if sn_state is not None:      # every run starts from the fixture's u (the runs do not assign it: no end_run)
+      cfg.sn_state, cfg.sn_cache = {k: v.clone() for k, v in sn_state.items()}, {}
     t0 = time.time()
     if group == 'g':
       loss, _ = R.generator_loss(Q, x, y, cfg)
@@ -79,7 +86,7 @@ def main():
     assert worst < 1e-6, worst
     for k, v in exact.items():
       out['exact_sketch'][k] = (sketch_vectors(order.index(k), v.numel()).double() @ v.reshape(-1)).tolist()
-    with rounding.storage_rounding(torch.bfloat16):
+    with rounding.storage_rounding(sdt):
       rnd = grads(group, True)
     num = sum(float(((rnd[k] - exact[k]) ** 2).sum()) for k in exact)
     den = sum(float((exact[k] ** 2).sum()) for k in exact)

@@ -429,32 +429,48 @@ __global__ void pw_small_in_kernel(const T* __restrict__ x, const float* __restr
 #pragma unroll
       for (int ci = 0; ci < 4; ++ci) wr[ci][j] = ci < cin ? sw[ci * cout + v * V + j] : 0.f;
     }
+    // U pixels in flight per thread (a grid stride apart, so every store instruction of a wave stays one contiguous run):
+    // the loads of a pixel are three 2-byte scalars -- with one pixel per trip a CU had a few KB of reads outstanding and
+    // the layer ran at 2.5 TB/s of its (write-dominated) bytes.  Loads clamped, not predicated: no branches between them.
+    constexpr int U = 4;
     const int64_t pstride = nthreads / cv;
-    for (int64_t p = gtid / cv; p < npix; p += pstride) {
-      float xin[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int ci = 0; ci < cin; ++ci) xin[ci] = ld(x + p * cin + ci);
-      float acc[V];
+    const int cl = cin - 1;
+    for (int64_t p0 = gtid / cv; p0 < npix; p0 += pstride * U) {
+      float xin[U][4];
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        float a = br[j];
+      for (int u = 0; u < U; ++u) {
+        int64_t p = p0 + u * pstride;
+        p = p < npix ? p : npix - 1;
 #pragma unroll
-        for (int ci = 0; ci < 4; ++ci) a = fmaf(xin[ci], wr[ci][j], a);
-        if (epi & TG_EPI_LRELU) a = lrelu_f(a, alpha);
-        acc[j] = a;
+        for (int ci = 0; ci < 4; ++ci) xin[u][ci] = ld(x + p * cin + (ci < cl ? ci : cl));      // ci >= cin: weight 0
       }
-      T* dst = y + p * cout + v * V;
-      if (V == 1) {
-        st(dst, mask ? rnd<T>(acc[0]) * (ld(mask + p * cout + v) > 0.f ? 1.f : alpha) : acc[0]);
-      } else {
-        Vec16<T> o;
 #pragma unroll
-        for (int j = 0; j < V; ++j) o.set(j, acc[j]);
-        if (mask) {
-          const Vec16<T> m = ldv(mask + p * cout + v * V);
+      for (int u = 0; u < U; ++u) {
+        const int64_t p = p0 + u * pstride;
+        if (p >= npix) break;
+        float acc[V];
 #pragma unroll
-          for (int j = 0; j < V; ++j) o.set(j, o.get(j) * (m.get(j) > 0.f ? 1.f : alpha));
+        for (int j = 0; j < V; ++j) {
+          float a = br[j];
+#pragma unroll
+          for (int ci = 0; ci < 4; ++ci) a = fmaf(xin[u][ci], wr[ci][j], a);
+          if (epi & TG_EPI_LRELU) a = lrelu_f(a, alpha);
+          acc[j] = a;
         }
-        stv(dst, o);
+        T* dst = y + p * cout + v * V;
+        if (V == 1) {
+          st(dst, mask ? rnd<T>(acc[0]) * (ld(mask + p * cout + v) > 0.f ? 1.f : alpha) : acc[0]);
+        } else {
+          Vec16<T> o;
+#pragma unroll
+          for (int j = 0; j < V; ++j) o.set(j, acc[j]);
+          if (mask) {
+            const Vec16<T> m = ldv(mask + p * cout + v * V);
+#pragma unroll
+            for (int j = 0; j < V; ++j) o.set(j, o.get(j) * (m.get(j) > 0.f ? 1.f : alpha));
+          }
+          stv(dst, o);
+        }
       }
     }
     return;
@@ -503,6 +519,38 @@ __global__ void pw_small_out_kernel(const T* __restrict__ x, const float* __rest
   for (int i = threadIdx.x; i < cout; i += blockDim.x) sw[cin * cout + i] = (epi & TG_EPI_BIAS) ? bias[i] : 0.f;
   __syncthreads();
   const int civ = cin / V;
+  if (V > 1 && civ == 2) {
+    // toRGB at full resolution (16 -> 3 channels, 1-4 M pixels): U pixels in flight per thread, a grid stride apart
+    constexpr int U = 4;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < npix; p0 += nthreads * U) {
+      Vec16<T> xv[U][2];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int64_t p = p0 + u * nthreads;
+        p = p < npix ? p : npix - 1;
+        xv[u][0] = ldv(x + p * cin);
+        xv[u][1] = ldv(x + p * cin + V);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t p = p0 + u * nthreads;
+        if (p >= npix) break;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+          for (int co = 0; co < cout; ++co)
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[co] = fmaf(xv[u][v].get(j), sw[co * cin + v * V + j], acc[co]);
+        for (int co = 0; co < cout; ++co) {
+          float a = acc[co] + sw[cin * cout + co];
+          if (epi & TG_EPI_LRELU) a = lrelu_f(a, alpha);
+          st(y + p * cout + co, a);
+        }
+      }
+    }
+    return;
+  }
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int v = 0; v < civ; ++v) {
