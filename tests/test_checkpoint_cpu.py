@@ -314,3 +314,31 @@ def test_saver_keeps_the_most_recent_checkpoints(tmp_path):
   C.save(tr, d, global_step=40, max_to_keep=3)                          # re-saving a step does not duplicate its entry
   assert C._all_checkpoint_paths(d) == ['model.ckpt-20', 'model.ckpt-30', 'model.ckpt-40']
   tr.close()
+
+
+def test_resume_continues_the_gradient_penalty_draws(tmp_path):
+  """The gradient penalty's interpolation weights come from the clone's device generator (Philox keyed by (seed, draw counter),
+  ops.uniform); the counter travels in the checkpoint (the one tensor there that is no variable of the reference: its
+  tf.random_uniform state lives in the session), so a resumed run continues the sequence instead of replaying it from the
+  first draw; a checkpoint without it (one TensorFlow wrote) leaves the counter alone."""
+  from twingan_amd import Config
+  from twingan_amd.twingan import Trainer
+  a = Trainer(Config(hw=4, max_ch=8, precision='fp32'), device='cpu', seed=1)
+  a._rng_state[0] = 12345
+  d = str(tmp_path / 'run')
+  path = C.save(a, d, global_step=7)
+  arrays = C.read_checkpoint(path)
+  assert int(arrays[C.RNG_DRAWS_KEY]) == 12345
+  b = Trainer(Config(hw=4, max_ch=8, precision='fp32'), device='cpu', seed=2)
+  assert int(b._rng_state[0]) == 0
+  C.restore(b, path)
+  assert int(b._rng_state[0]) == 12345 and b.global_step == 7
+  # a bundle without the key: written from the same tensors minus it
+  del arrays[C.RNG_DRAWS_KEY]
+  C.write_checkpoint(os.path.join(d, 'plain.ckpt-7'), arrays)
+  c = Trainer(Config(hw=4, max_ch=8, precision='fp32'), device='cpu', seed=3)
+  c._rng_state[0] = 5
+  C.restore(c, os.path.join(d, 'plain.ckpt-7'))
+  assert int(c._rng_state[0]) == 5
+  for t in (a, b, c):
+    t.close()

@@ -450,6 +450,9 @@ def _all_checkpoint_paths(directory):
     return [l.split(':', 1)[1].strip().strip('"') for l in fh if l.startswith('all_model_checkpoint_paths:')]
 
 
+RNG_DRAWS_KEY = 'twingan_amd/gp_alpha_draws'      # the one tensor of a checkpoint that is not a variable of the reference
+
+
 def save(trainer, train_dir, global_step=None, max_to_keep=5):
   """What the reference's Saver leaves for a stage: every model variable (TF names, TF layouts), the non-trainable
   state (moving / renorm statistics, spectral-norm u), ``global_step``, and the shared Adam optimiser's slots
@@ -469,6 +472,11 @@ def save(trainer, train_dir, global_step=None, max_to_keep=5):
   # shared Adam once, so it is also the number of Adam applies -- which the beta powers stop encoding once they
   # underflow (float32 0.5^(t+1) is exactly 0 from t = 149)
   tensors['n_critic_counter'] = np.int32(trainer.n_critic_counter)
+  # not a variable of the reference (its tf.random_uniform draws are stateful in the session, never saved): the draw counter
+  # of this clone's device generator (the gradient penalty's interpolation weights, ops.uniform), so that a resumed run
+  # continues the sequence instead of replaying it from the first draw.  A TensorFlow-written checkpoint simply lacks it.
+  if getattr(trainer, '_rng_state', None) is not None:
+    tensors[RNG_DRAWS_KEY] = np.int64(int(trainer._rng_state[0].item()))
   name = 'model.ckpt-%d' % step
   kept = [n for n in _all_checkpoint_paths(train_dir) if n != name]
   write_checkpoint(os.path.join(train_dir, name), tensors)
@@ -548,6 +556,8 @@ def restore(trainer, prefix):
   if 'n_critic_counter' in arrays:
     trainer.n_critic_counter = int(arrays['n_critic_counter'])
   trainer.set_adam_step(_adam_applies(arrays, trainer.cfg, trainer.n_critic_counter))
+  if RNG_DRAWS_KEY in arrays and getattr(trainer, '_rng_state', None) is not None:
+    trainer._rng_state[0] = int(arrays[RNG_DRAWS_KEY])      # continue the device generator's sequence (see save)
   return trainer.global_step
 
 

@@ -2593,6 +2593,14 @@ def spectral_norm(w, u, out=None):
 # ------------------------------------------------------------------------------------------------
 # small dense layer (layers.fully_connected, nets/pggan_utils.py:323-327)
 # ------------------------------------------------------------------------------------------------
+def _is_parameter(t):
+  """Is ``t`` a trainable variable (ParamStore registers every one, and the per-run spectrally normalised kernels, with a
+  gradient sink)?  Not "is it a leaf": the gradient penalty's interpolates and the leaves of a segmented backward (Cuts.cut)
+  are leaves too, and their gradient is exactly what no_param_grads passes are run for."""
+  ent = GradSink._sinks.get(GradSink._key(t))
+  return ent is not None and ent[0]() is t
+
+
 class GemmFn(torch.autograd.Function):
   """c = op(a) @ op(b), fp32 row-major; fully differentiable (every gradient is another GemmFn)."""
 
@@ -2618,9 +2626,9 @@ class GemmFn(torch.autograd.Function):
     # ops.no_param_grads (the gradient penalty's inner gradient): a leaf operand is a parameter -- its gradient arrives
     # through the double backward, this pass would compute it only to drop it
     skip = _State.skip_param_grads
-    if ctx.needs_input_grad[0] and not (skip and a.is_leaf):
+    if ctx.needs_input_grad[0] and not (skip and _is_parameter(a)):
       ga = GemmFn.apply(b, g, tb, True) if ta else GemmFn.apply(g, b, False, not tb)
-    if ctx.needs_input_grad[1] and not (skip and b.is_leaf):
+    if ctx.needs_input_grad[1] and not (skip and _is_parameter(b)):
       gb = GemmFn.apply(g, a, True, ta) if tb else GemmFn.apply(a, g, not ta, False)
     return ga, gb, None, None
 

@@ -150,6 +150,9 @@ def sn_segment_backward(P, done):
   for scope in [k for k in leaves if done(k)]:
     w_bar, leaf, gbuf = leaves.pop(scope)
     if gbuf is not None:      # trainer mode: the filter-gradient kernels added into the sink (flushed by the caller before this)
+      # every consumer of the leaf adds into the sink itself; one that handed autograd a gradient tensor instead (an op
+      # without sink support, a backward run with grad mode on) would be dropped here -- loudly, not silently
+      assert leaf.grad is None, 'a consumer of the normalised kernel %s returned a gradient tensor next to its sink' % scope
       ops.GradSink.unregister(leaf)
       roots.append(w_bar)
       grads.append(gbuf)
