@@ -234,6 +234,12 @@ int tg_conv2d_upcat_bwd_weight(const void* x0, const void* x1, const void* gy, f
  * zero filled.  tg_conv2d_pack_elems returns the element count of the pack. */
 size_t tg_conv2d_pack_elems(const TgConvDesc* d, int mode);
 int tg_conv2d_pack_weights(const TgConvDesc* d, const float* w_hwio, int mode, void* out_bf16, void* stream);
+/* A pack is OPAQUE: made for (d, mode), read by the conv entry point called with the same d.  For the layers whose
+ * dispatch ends in the whole-image kernel (3x3 over 8x8 maps) the elements are stored in MFMA-fragment order instead
+ * ([row / 32][k / 16][tap][row % 32][k % 16]: one contiguous KB per wave load).  tg_conv2d_pack_layout tells which
+ * (0 = the [row][tap][k] order above, 1 = fragment order): a host that caches packs by (weight, mode) must not share one
+ * between descriptors whose layouts differ (twingan_amd/ops.py PackCache keys on it). */
+int tg_conv2d_pack_layout(const TgConvDesc* d, int mode);
 
 /* All packs of an optimiser group in ONE launch (the step re-packs ~60 weights after every Adam apply; one
  * launch per pack is launch-latency bound).  The caller builds a job table in HOST memory with

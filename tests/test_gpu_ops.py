@@ -758,12 +758,21 @@ def test_multi_tensor_pack_matches_single_packs(ops):
   g = torch.Generator().manual_seed(5)
   ws = [torch.randn(3, 3, ci, co, generator=g).to(dev()) for ci, co in ((16, 32), (40, 16), (64, 64))]
   ws.append(torch.randn(4, 4, 32, 32, generator=g).to(dev()))
+  # 8x8 maps (conv_img): fragment-ordered packs, tg_conv2d_pack_layout = 1 -- a 32-channel kernel (two K chunks) and wider
+  on8 = [torch.randn(3, 3, ci, co, generator=g).to(dev()) for ci, co in ((32, 64), (128, 32))]
+  ws += on8
   for w in ws:
     PackCache.register(w)
   packs = []
   for w in ws:
     k = w.shape[0]
-    x = torch.randn(2, 16 if k == 3 else 4, 16 if k == 3 else 4, w.shape[2], generator=g).to(dev()).bfloat16()
+    hw = 8 if any(w is v for v in on8) else (16 if k == 3 else 4)
+    x = torch.randn(2, hw, hw, w.shape[2], generator=g).to(dev()).bfloat16()
+    if hw == 8:
+      from twingan_amd import _lib
+      d8 = ops._desc(x.shape, w.shape[3], ops.ConvSpec(3, 'SAME'), x.dtype, 0)
+      import ctypes
+      assert _lib.load().tg_conv2d_pack_layout(ctypes.byref(d8), 0) == 1 and _lib.load().tg_conv2d_pack_layout(ctypes.byref(d8), 1) == 1
     spec = ops.ConvSpec(k, 'SAME' if k == 3 else 'VALID')
     d = ops._desc(x.shape, w.shape[3], spec, x.dtype, 0)
     for mode in (0, 1):

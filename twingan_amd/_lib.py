@@ -84,6 +84,7 @@ SIGNATURES = {
     'tg_conv2d_upcat_bwd_weight': (c_int, [_P, _P, _P, _FP, c_int, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int,
                                            c_int, c_uint, c_int, _P]),
     'tg_conv2d_pack_elems': (c_size_t, [_D, c_int]),
+    'tg_conv2d_pack_layout': (c_int, [_D, c_int]),
     'tg_conv2d_pack_weights': (c_int, [_D, _FP, c_int, _P, _P]),
     'tg_pack_table_bytes': (c_size_t, [c_int]),
     'tg_pack_table_fill': (c_int, [_D, _FP, c_int, _P, c_int, _P, POINTER(c_int32)]),

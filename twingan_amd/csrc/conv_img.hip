@@ -63,9 +63,11 @@ __global__ __launch_bounds__(256, 2) void conv_img_kernel(const bf16* __restrict
   const int wset = g.npg ? (img0 >= g.npg) + (img0 >= 2 * g.npg) + (img0 >= 3 * g.npg) : 0;      // uniform: IMGS == 1 when grouped
   const float* bias = bias0 + wset * g.cout;      // only read under TG_EPI_BIAS
   const __amdgpu_buffer_rsrc_t rw = i_rsrc(reinterpret_cast<const unsigned char*>(wp) + (size_t)wset * g.wgs_bytes, g.w_bytes);
-  const unsigned wrow = (unsigned)(NT * g.cin_pad);
-  const unsigned woff = (unsigned)(((n0 + l31) * wrow + kgrp * 8) * 2);      // + (tap * cin_pad + channel) * 2
+  // fragment-ordered pack (conv_mfma.hip pack_coords): [row block][K chunk][tap][32 rows][16 channels] -- the wave's fragment
+  // of (tap, chunk) is one contiguous KB in lane order, a chunk's nine taps nine consecutive KB
   const int nchunks = g.cin >> 4;                   // 16-channel K chunks; wave w takes w, w + 4, ...
+  const unsigned wblk = (unsigned)((n0 >> 5) * (g.cin_pad >> 4)) * (NT * 1024u);      // this workgroup's row block
+  const unsigned woff = wblk + (unsigned)((l31 * 16 + kgrp * 8) * 2);                   // + (chunk * 9 + tap) * 1024
   struct WStage {
     bf16x8 w[NT];
   };
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void conv_img_kernel(const bf16* __restrict
 #pragma unroll
     for (int t = 0; t < NT; ++t)
       st.w[t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                                               rw, in ? woff + (unsigned)((t * g.cin_pad + ck * 16) * 2) : IOOB, 0, 0));
+                                               rw, in ? woff + (unsigned)((ck * NT + t) * 1024) : IOOB, 0, 0));
   };
   WStage wa, wb, wc;
   load_w(wa, wid);

@@ -333,14 +333,34 @@ __device__ __forceinline__ void store16(bf16* p, float v, int half_fmt) {
   else *p = (bf16)v;
 }
 
+// Fragment-ordered packs (`frag`, the layers conv_img takes: 3x3 over the 8x8 maps): the same elements in the order the
+// MFMA weight fragments are fetched -- out[row / 32][k / 16][tap][row % 32][k % 16] -- so that the 32 rows x 16 channels a
+// wave loads for one (tap, K chunk) are ONE contiguous KB (64 lanes x 16 bytes in lane order) and a wave's nine taps of a
+// chunk nine consecutive KB; in the [row][tap][k] order that load touched 32 separate 32-byte segments 4.6 KB apart
+// (profiles/r05_g: 3.5 of conv_img's 10.6 us).  (row, tap, k) of pack element i:
+__device__ __forceinline__ void pack_coords(int64_t i, int nt, int inner_pad, int frag, int* row, int* tap, int* k) {
+  if (frag) {
+    const int within = (int)(i & 511);
+    int64_t r = i >> 9;
+    *tap = (int)(r % nt);
+    r /= nt;
+    const int nch = inner_pad >> 4;
+    *k = (int)(r % nch) * 16 + (within & 15);
+    *row = (int)(r / nch) * 32 + (within >> 4);
+  } else {
+    *k = (int)(i % inner_pad);
+    const int64_t r = i / inner_pad;
+    *tap = (int)(r % nt);
+    *row = (int)(r / nt);
+  }
+}
+
 __global__ void pack_weights(const float* __restrict__ w, bf16* __restrict__ out, int nt, int cin, int cout, int rows,
-                             int rows_pad, int inner, int inner_pad, int mode, int half_fmt) {
+                             int rows_pad, int inner, int inner_pad, int mode, int half_fmt, int frag) {
   const int64_t total = (int64_t)rows_pad * nt * inner_pad;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int k = (int)(i % inner_pad);
-    int64_t r = i / inner_pad;
-    const int tap = (int)(r % nt);
-    const int row = (int)(r / nt);
+    int k, tap, row;
+    pack_coords(i, nt, inner_pad, frag, &row, &tap, &k);
     float v = 0.f;
     if (row < rows && k < inner) {
       if (mode == 0)
@@ -437,6 +457,26 @@ static bool as_dense(const TgConvDesc* d, TgConvDesc* o) {
   return false;
 }
 
+bool tg_conv_tile_supported(int h, int w, int hout, int wout, int kh, int kw, int pad_t, int pad_l);
+bool tg_conv_img_supported(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l);
+
+// Is the pack of (descriptor, mode) fragment-ordered?  Exactly when the dispatch of that direction ends in conv_img
+// (tg_conv2d_fwd_mfma / tg_conv2d_bwd_data_mfma: the tile kernels first, then conv_img): the layout is a property of
+// the pack that its kernel knows; callers treat packs as opaque.
+static bool pack_frag(const TgConvDesc* d0, int mode) {
+  TgConvDesc dd;
+  if (as_dense(d0, &dd)) return false;
+  const TgConvDesc* d = d0;
+  if (!is16(d) || d->algo != TG_ALGO_MFMA || d->kh != 3 || d->kw != 3 || d->cin % 8 || d->cout % 8) return false;
+  if (mode == 0)
+    return !tg_conv_tile_supported(d->hin, d->win, d->hout, d->wout, d->kh, d->kw, d->pad_t, d->pad_l) &&
+           tg_conv_img_supported(d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->pad_t, d->pad_l);
+  return !tg_conv_tile_supported(d->hout, d->wout, d->hin, d->win, d->kh, d->kw, d->pad_t, d->pad_l) &&
+         tg_conv_img_supported(d->n, d->hout, d->wout, d->cout, d->hin, d->win, d->cin, d->kh, d->kh - 1 - d->pad_t,
+                               d->kw - 1 - d->pad_l);
+}
+extern "C" int tg_conv2d_pack_layout(const TgConvDesc* d, int mode) { return d && pack_frag(d, mode) ? 1 : 0; }
+
 static void pack_dims(const TgConvDesc* d0, int mode, int* nt, int* cin, int* cout, int* rows, int* rows_pad,
                       int* inner, int* inner_pad) {
   TgConvDesc dd;
@@ -464,7 +504,7 @@ int tg_conv2d_pack_weights(const TgConvDesc* d, const float* w, int mode, void* 
   for (int g = 0; g < (d->groups > 1 ? d->groups : 1); ++g) {      // weight set g: master w[g] -> pack g
     hipLaunchKernelGGL(pack_weights, dim3(tg_grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        w + (size_t)g * nt * cin * cout, (bf16*)out + (size_t)g * total, nt, cin, cout, rows, rows_pad, inner,
-                       inner_pad, mode, d->dtype == TG_F16 ? 1 : 0);
+                       inner_pad, mode, d->dtype == TG_F16 ? 1 : 0, pack_frag(d, mode) ? 1 : 0);
     TG_LAUNCH_CHECK("tg_conv2d_pack_weights");
   }
   return TG_OK;
@@ -477,6 +517,7 @@ struct PackJob {
   bf16* out;
   int nt, cin, cout, rows, rows_pad, inner, inner_pad, mode;
   int half_fmt;                    // element format of this pack: 1 = IEEE half (TG_F16 descriptors)
+  int frag;                        // fragment-ordered pack (pack_coords)
   int block_begin, block_end;      // this job's slice of the grid (PACK_EPB elements per block)
 };
 constexpr int PACK_EPB = 2048;
@@ -508,6 +549,19 @@ __global__ __launch_bounds__(256) void pack_weights_multi(const PackJob* __restr
       tile[i][tx] = (ci < j.cin && co < j.cout) ? j.w[((int64_t)tap * j.cin + ci) * j.cout + co] : 0.f;
     }
     __syncthreads();
+    if (j.frag) {
+      // the 64 (ci) x 64 (co) tile = 2 row blocks x 4 K chunks of this tap: eight contiguous 512-element runs of the pack
+      // (rows_pad % 64 == 0 always; cin a multiple of 32: chunks past the kernel's last one are skipped)
+      const int nch = j.inner_pad >> 4;
+#pragma unroll 4
+      for (int e = threadIdx.x; e < 4096; e += 256) {
+        const int run = e >> 9, within = e & 511;
+        const int co_l = (run >> 2) * 32 + (within >> 4), ci_l = (run & 3) * 16 + (within & 15);
+        const int64_t o = ((((int64_t)(r0 >> 5) + (run >> 2)) * nch + (k0 >> 4) + (run & 3)) * j.nt + tap) * 512 + within;
+        if ((k0 >> 4) + (run & 3) < nch) store16(j.out + o, tile[ci_l][co_l], j.half_fmt);      // a 32-channel kernel: two chunks
+      }
+      return;
+    }
 #pragma unroll 4
     for (int i = ty; i < 64; i += 4) {
       const int co = r0 + i, ci = k0 + tx;
@@ -521,10 +575,8 @@ __global__ __launch_bounds__(256) void pack_weights_multi(const PackJob* __restr
   for (int e = threadIdx.x; e < PACK_EPB; e += 256) {
     const int64_t i = i0 + e;
     if (i >= total) break;
-    const int k = (int)(i % j.inner_pad);
-    const int64_t r = i / j.inner_pad;
-    const int tap = (int)(r % j.nt);
-    const int row = (int)(r / j.nt);
+    int k, tap, row;
+    pack_coords(i, j.nt, j.inner_pad, j.frag, &row, &tap, &k);
     float v = 0.f;
     if (row < j.rows && k < j.inner) v = j.w[((int64_t)(j.nt - 1 - tap) * j.cin + row) * j.cout + k];      // mode 1
     store16(j.out + i, v, j.half_fmt);
@@ -544,7 +596,9 @@ int tg_pack_table_fill(const TgConvDesc* d, const float* w, int mode, void* out,
   j.out = (bf16*)out;
   j.mode = mode;
   j.half_fmt = d->dtype == TG_F16;
+  j.frag = pack_frag(d, mode) ? 1 : 0;
   pack_dims(d, mode, &j.nt, &j.cin, &j.cout, &j.rows, &j.rows_pad, &j.inner, &j.inner_pad);
+  TG_CHECK(!j.frag || (j.inner_pad % 16 == 0 && j.rows_pad % 64 == 0), TG_ENOSUP, "tg_pack_table_fill: fragment-ordered pack of a %d x %d kernel", j.rows_pad, j.inner_pad);
   const int64_t total = (int64_t)j.rows_pad * j.nt * j.inner_pad;
   j.block_begin = *total_blocks;
   if (mode == 0)      // one block per (tap, 64 rows, 64 inner) tile

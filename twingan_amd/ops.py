@@ -125,8 +125,10 @@ class PackCache:
 
   @classmethod
   def get(cls, w, desc, mode):
-    n = _lib.load().tg_conv2d_pack_elems(ctypes.byref(desc), mode)
-    key = (w.data_ptr(), mode, n, desc.dtype)
+    lib = _lib.load()
+    n = lib.tg_conv2d_pack_elems(ctypes.byref(desc), mode)
+    # a pack is made FOR a descriptor: its element order is the one the kernel that descriptor dispatches reads
+    key = (w.data_ptr(), mode, n, desc.dtype, lib.tg_conv2d_pack_layout(ctypes.byref(desc), mode))
     cached = w.data_ptr() in cls._registered
     ent = cls._packs.get(key) if cached else None
     if ent is not None and ent[0] == cls.version:
