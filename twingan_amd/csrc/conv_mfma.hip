@@ -459,21 +459,24 @@ static bool as_dense(const TgConvDesc* d, TgConvDesc* o) {
 
 bool tg_conv_tile_supported(int h, int w, int hout, int wout, int kh, int kw, int pad_t, int pad_l);
 bool tg_conv_img_supported(int n, int hin, int win, int cin, int hout, int wout, int cout, int k, int pad_t, int pad_l);
+bool tg_conv_small_supported(int n, int hout, int wout, int kh, int kw);
 
-// Is the pack of (descriptor, mode) fragment-ordered?  Exactly when the dispatch of that direction ends in conv_img
-// (tg_conv2d_fwd_mfma / tg_conv2d_bwd_data_mfma: the tile kernels first, then conv_img): the layout is a property of
-// the pack that its kernel knows; callers treat packs as opaque.
+// Is the pack of (descriptor, mode) fragment-ordered?  Exactly when the dispatch of that direction ends in conv_img or
+// conv_small (tg_conv2d_fwd_mfma / tg_conv2d_bwd_data_mfma: the tile kernels first, then conv_img, then conv_small) --
+// the two kernels that fetch their weight fragments straight from L2: the layout is a property of the pack that its
+// kernel knows; callers treat packs as opaque.  (conv_small's test involves the batch: n * hout * wout <= 4096.)
 static bool pack_frag(const TgConvDesc* d0, int mode) {
   TgConvDesc dd;
-  if (as_dense(d0, &dd)) return false;
-  const TgConvDesc* d = d0;
-  if (!is16(d) || d->algo != TG_ALGO_MFMA || d->kh != 3 || d->kw != 3 || d->cin % 8 || d->cout % 8) return false;
-  if (mode == 0)
-    return !tg_conv_tile_supported(d->hin, d->win, d->hout, d->wout, d->kh, d->kw, d->pad_t, d->pad_l) &&
-           tg_conv_img_supported(d->n, d->hin, d->win, d->cin, d->hout, d->wout, d->cout, d->kh, d->pad_t, d->pad_l);
-  return !tg_conv_tile_supported(d->hout, d->wout, d->hin, d->win, d->kh, d->kw, d->pad_t, d->pad_l) &&
-         tg_conv_img_supported(d->n, d->hout, d->wout, d->cout, d->hin, d->win, d->cin, d->kh, d->kh - 1 - d->pad_t,
-                               d->kw - 1 - d->pad_l);
+  const TgConvDesc* d = as_dense(d0, &dd) ? &dd : d0;
+  if (!is16(d) || d->algo != TG_ALGO_MFMA || d->kh != d->kw || (d->kh != 3 && d->kh != 1) || d->cin % 8 || d->cout % 8) return false;
+  // the conv the kernels see: forward, or the same conv over gy with the rotated pack (mode 1)
+  const bool fw = mode == 0;
+  const int hi = fw ? d->hin : d->hout, wi = fw ? d->win : d->wout, ci = fw ? d->cin : d->cout;
+  const int ho = fw ? d->hout : d->hin, wo = fw ? d->wout : d->win, co = fw ? d->cout : d->cin;
+  const int pt = fw ? d->pad_t : d->kh - 1 - d->pad_t, pl = fw ? d->pad_l : d->kw - 1 - d->pad_l;
+  if (tg_conv_tile_supported(hi, wi, ho, wo, d->kh, d->kw, d->pad_t, d->pad_l)) return false;
+  if (tg_conv_img_supported(d->n, hi, wi, ci, ho, wo, co, d->kh, pt, pl)) return true;
+  return d->pad_t == d->pad_l && tg_conv_small_supported(d->n, ho, wo, d->kh, d->kw);      // conv_small (4x4 maps, dense layers)
 }
 extern "C" int tg_conv2d_pack_layout(const TgConvDesc* d, int mode) { return d && pack_frag(d, mode) ? 1 : 0; }
 

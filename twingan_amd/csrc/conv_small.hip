@@ -84,8 +84,9 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict_
       xoff[m][t] = ok ? (unsigned)((((img * g.hin + iy) * g.win + ix) * g.cin + kgrp * 8) * 2) : SOOB;
     }
   }
-  const unsigned wrow = (unsigned)(NT * g.cin_pad);
-  const unsigned woff = (unsigned)(((n0 + l31) * wrow + kgrp * 8) * 2);      // + (tap*cin_pad + c)*2
+  // fragment-ordered pack (conv_mfma.hip pack_coords): [row block][K chunk][tap][32 rows][16 channels] -- a wave's fragment of
+  // (tap, chunk) is one contiguous KB in lane order
+  const unsigned woff = (unsigned)((n0 >> 5) * g.nchunks) * (NT * 1024u) + (unsigned)((l31 * 16 + kgrp * 8) * 2);      // + (chunk * NT + tap) * 1024
 
   f32x16 acc[MT];
 #pragma unroll
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const bf16* __restrict_
       const bool in = ck < g.nchunks;                 // chunks past the end read zeros
       const unsigned c2 = (unsigned)(ck * 32);        // byte offset of the chunk's first channel
 #pragma unroll
-      for (int t = 0; t < NT; ++t) st.w[u][t] = s_load16(rw, in ? woff + (unsigned)(t * g.cin_pad * 2) + c2 : SOOB);
+      for (int t = 0; t < NT; ++t) st.w[u][t] = s_load16(rw, in ? woff + (unsigned)((ck * NT + t) * 1024) : SOOB);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
