@@ -7,7 +7,7 @@
 #   4. rocprofv3 --kernel-trace --stats of the headline bench, kernel trace of replayed steps (gaps, per-step table), batch scan
 # Everything lands under gpurun_out/<rNN>z/ (copy what is to be judged into profiles/).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-R=${1:-r05}; OUT=gpurun_out/${R}z; mkdir -p $OUT; export TMPDIR=/tmp
+R=${1:-r06}; OUT=gpurun_out/${R}z; mkdir -p $OUT; export TMPDIR=/tmp
 make -C twingan_amd/csrc kbench > /dev/null 2>&1
 SPECS="E256a fwd 64;E256a dgrad 64;E256a wgrad 64;E256b fwd 48;E256b dgrad 48;E256b wgrad 64;E128a fwd 64;E128a wgrad 64;E128b fwd 48;E128b wgrad 64;E64a fwd 64;E64a wgrad 64;E64b fwd 48;E64b wgrad 64;E32a fwd 64;E32a wgrad 64;E32b fwd 48;E16 fwd 64;E16 dgrad 64;E16 wgrad 64;E8 fwd 64;E8 wgrad 64;G64a fwd 64;G64a wgrad 64;G32a fwd 64;G32a wgrad 64;G16a fwd 64;G256a fwd 64;G128a fwd 64"
 bash tools/pmc_kernels.sh "$SPECS" > $OUT/pmc_kernels.txt 2>&1
