@@ -270,6 +270,38 @@ int main(int argc, char** argv) {
     printf("%-7s %-5s %4d %4d>%-4d | %9.1f %8.0f %8.1f %9.2e\n", c.name, "wgrad", c.hw, c.cin, c.cout, t, bytes / t * 1e-3,
            flops / t * 1e-6, e_w);
     }
+    if (only_op && !strcmp(only_op, "wgradpar")) {
+      // K independent filter gradients (own outputs, own workspaces) of this layer: one after the other on ONE stream vs spread
+      // over K streams -- the second is what a merged multi-job launch could at best approach (ramps and tails overlap)
+      const int K = 8;
+      std::vector<float*> gws(K);
+      std::vector<void*> wss(K);
+      std::vector<hipStream_t> st(K);
+      for (int i = 0; i < K; ++i) {
+        HC(hipMalloc(&gws[i], nw * 4));
+        wss[i] = nullptr;
+        if (wsb) HC(hipMalloc(&wss[i], wsb));
+        HC(hipStreamCreate(&st[i]));
+      }
+      const float t1 = time_us([&] { for (int i = 0; i < K; ++i) TC(tg_conv2d_bwd_weight(&d0, x, gy, gws[i], 0, wss[i], wsb, nullptr)); }, iters);
+      hipEvent_t e0, e1;
+      HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
+      float tot = 0.f;
+      for (int it = 0; it < iters + 2; ++it) {
+        HC(hipDeviceSynchronize());
+        HC(hipEventRecord(e0, st[0]));
+        for (int i = 1; i < K; ++i) HC(hipStreamWaitEvent(st[i], e0, 0));
+        for (int i = 0; i < K; ++i) TC(tg_conv2d_bwd_weight(&d0, x, gy, gws[i], 0, wss[i], wsb, (void*)st[i]));
+        for (int i = 1; i < K; ++i) { hipEvent_t ej; HC(hipEventCreate(&ej)); HC(hipEventRecord(ej, st[i])); HC(hipStreamWaitEvent(st[0], ej, 0)); HC(hipEventDestroy(ej)); }
+        HC(hipEventRecord(e1, st[0]));
+        HC(hipEventSynchronize(e1));
+        float ms; HC(hipEventElapsedTime(&ms, e0, e1));
+        if (it >= 2) tot += ms;
+      }
+      printf("%-7s %-8s %4d %4d>%-4d n%-3d | %d launches on one stream %8.1f us, on %d streams %8.1f us\n", c.name, "wgradpar", c.hw, c.cin,
+             c.cout, batch, K, t1, K, tot / iters * 1e3);
+      for (int i = 0; i < K; ++i) { HC(hipFree(gws[i])); if (wss[i]) HC(hipFree(wss[i])); HC(hipStreamDestroy(st[i])); }
+    }
     if (only_op && !strcmp(only_op, "wgradb")) {      // the filter gradient with the fused bias gradient (timing only)
       t = time_us([&] { TC(tg_conv2d_bwd_weight_bias(&d0, x, gy, gw, bias, 0, ws, wsb, nullptr)); }, iters);
       printf("%-7s %-5s %4d %4d>%-4d | %9.1f %8.0f %8.1f\n", c.name, "wgradb", c.hw, c.cin, c.cout, t, bytes / t * 1e-3,
