@@ -1959,6 +1959,6 @@ def test_rccl_segmented_capture_one_rank(precision):
   if precision == 'fp32':
     # same kernels on the same tensors; the order in which contributions reach a gradient sink differs with the cut
     # (test_segmented_backward_leaves_the_same_gradients: <= 1e-4 per gradient), then Adam's sign-like first steps
-    assert d['params_rel_l2'] < 1e-4, d
+    assert d['params_rel_l2'] < 1e-5, d      # measured 6.5e-8 (40 of 148 tensors not bit-equal)
   else:
-    assert d['params_rel_l2'] < 2e-2, d      # 16-bit run-to-run noise under Adam's sign-like first steps
+    assert d['params_rel_l2'] < 1e-3, d      # measured 2.6e-6: 16-bit run-to-run noise (fp32 atomics order)
